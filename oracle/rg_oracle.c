@@ -1,0 +1,1363 @@
+/*
+ * rg_oracle.c — CPU restatement (double precision, scalar, one env) of the arithmetic on
+ * robogym's env.step hot path: MuJoCo-2.0 mj_step / mj_forward as driven by
+ * SimulationInterface.step (/root/reference/robogym/mujoco/simulation_interface.py:176-189)
+ * plus mujoco-py's PID actuator callbacks (cymj.set_pid_control, simulation_interface.py:86-88).
+ *
+ * THIS IS TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it; the product path (robogym_amd/) never does.
+ *
+ * PARITY UNPINNED vs MuJoCo: the algorithm lives in third-party, un-vendored
+ * dependencies of the reference (setup.py:14,16: mujoco-py==2.0.2.13 -> MuJoCo 2.0 binary,
+ * mjpid.pyx) that are absent from /root/reference and from this machine, and the
+ * reference ships no golden trajectories.  Each stage below restates
+ * the published MuJoCo computation pipeline ("Computation" chapter of the MuJoCo
+ * documentation; engine_* function names given per stage) and is pinned only by
+ * (i) the in-tree pure-numpy pieces of the reference that do run (hand forward
+ * kinematics, rotation utilities, hand control tables: tests/golden/), and
+ * (ii) physical invariants (energy, momentum, M symmetry/CRB-vs-Jacobian agreement,
+ * constraint KKT conditions) checked in tests/.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MINVAL 1e-15
+#define MAXCON 128
+#define MAXEFC 600
+#define MAXCONPAIR 8
+#define PI 3.14159265358979323846
+
+enum { JNT_FREE = 0, JNT_BALL, JNT_SLIDE, JNT_HINGE };
+enum { GEOM_PLANE = 0, GEOM_HFIELD, GEOM_SPHERE, GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_CYLINDER, GEOM_BOX, GEOM_MESH };
+enum { WRAP_JOINT = 1, WRAP_PULLEY, WRAP_SITE, WRAP_SPHERE, WRAP_CYLINDER };
+enum { TRN_JOINT = 0, TRN_TENDON = 3 };
+enum { EFC_FRICTION_DOF = 1, EFC_FRICTION_TENDON, EFC_LIMIT_JOINT, EFC_LIMIT_TENDON, EFC_CONTACT_PYRAMIDAL };
+
+typedef struct {
+  int nq, nv, nu, nbody, njnt, ngeom, nsite, ntendon, nwrap, nmesh, nmeshvert, nexclude, nsensor;
+  double timestep, gravity[3], tolerance, impratio, ls_tolerance, mpr_tolerance, meaninertia;
+  int iterations, cone, ls_iterations, mpr_iterations;
+  int nconmax, njmax;
+  const int *body_parentid, *body_rootid, *body_weldid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum,
+      *body_geomadr, *body_geomnum;
+  const double *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_subtreemass,
+      *body_invweight0;
+  const int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid, *jnt_limited;
+  const double *jnt_pos, *jnt_axis, *jnt_stiffness, *jnt_range, *jnt_margin, *jnt_solref, *jnt_solimp;
+  const int *dof_bodyid, *dof_jntid, *dof_parentid;
+  const double *dof_armature, *dof_damping, *dof_frictionloss, *dof_solref, *dof_solimp, *dof_invweight0;
+  const double *qpos0, *qpos_spring;
+  const int *geom_type, *geom_bodyid, *geom_dataid, *geom_contype, *geom_conaffinity, *geom_condim;
+  const double *geom_size, *geom_rbound, *geom_pos, *geom_quat, *geom_friction, *geom_margin, *geom_gap, *geom_solmix,
+      *geom_solref, *geom_solimp;
+  const int *site_bodyid;
+  const double *site_pos, *site_quat;
+  const int *mesh_vertadr, *mesh_vertnum;
+  const float *mesh_vert;
+  const int *exclude_signature;
+  const int *tendon_adr, *tendon_num, *tendon_limited;
+  const double *tendon_range, *tendon_margin, *tendon_stiffness, *tendon_damping, *tendon_frictionloss,
+      *tendon_lengthspring, *tendon_solref_lim, *tendon_solimp_lim, *tendon_solref_fri, *tendon_solimp_fri,
+      *tendon_invweight0;
+  const int *wrap_type, *wrap_objid;
+  const double *wrap_prm;
+  const int *actuator_trntype, *actuator_trnid, *actuator_ctrllimited, *actuator_forcelimited, *actuator_gaintype,
+      *actuator_biastype;
+  const double *actuator_gear, *actuator_ctrlrange, *actuator_forcerange, *actuator_gainprm, *actuator_biasprm,
+      *actuator_user;
+  void* blob;
+} ro_model;
+
+typedef struct {
+  double dist, pos[3], frame[9], includemargin, friction[5], solref[2], solimp[5], mu;
+  int dim, geom1, geom2, efc_address;
+} ro_contact;
+
+typedef struct {
+  /* state */
+  double *qpos, *qvel, *ctrl, *pid, *qacc_warmstart, time;
+  /* position stage */
+  double *xpos, *xquat, *xmat, *xipos, *ximat, *xanchor, *xaxis, *geom_xpos, *geom_xmat, *site_xpos, *site_xmat;
+  double *subtree_com, *cinert, *cdof, *crb;
+  double *ten_length, *ten_J, *actuator_length, *actuator_moment;
+  double *qM, *qL; /* dense nv*nv inertia and its Cholesky factor (lower) */
+  int ncon, nefc, nf, nl;
+  ro_contact contact[MAXCON];
+  double *efc_J, *efc_pos, *efc_margin, *efc_frictionloss, *efc_diagApprox, *efc_R, *efc_D, *efc_KBIP, *efc_vel,
+      *efc_aref, *efc_force;
+  int *efc_type, *efc_id;
+  /* velocity / force stage */
+  double *ten_velocity, *actuator_velocity, *cvel, *cdof_dot, *qfrc_passive, *qfrc_bias, *actuator_force,
+      *qfrc_actuator, *qfrc_smooth, *qacc_smooth, *qfrc_constraint, *qacc;
+  /* diagnostics */
+  int solver_iter, warn_contact_full, warn_efc_full, warn_bad;
+  long stat_ncon, stat_nefc, stat_iter, stat_steps, stat_mpr_calls, stat_mpr_iter;
+} ro_data;
+
+/* ------------------------------------------------------------------------------------------ small math */
+static inline double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline void cross3(double* r, const double* a, const double* b) {
+  double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static inline void copy3(double* r, const double* a) { r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; }
+static inline void zero3(double* r) { r[0] = r[1] = r[2] = 0; }
+static inline void sub3(double* r, const double* a, const double* b) { r[0] = a[0] - b[0]; r[1] = a[1] - b[1]; r[2] = a[2] - b[2]; }
+static inline void add3(double* r, const double* a, const double* b) { r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2]; }
+static inline void addscl3(double* r, const double* a, double s) { r[0] += a[0] * s; r[1] += a[1] * s; r[2] += a[2] * s; }
+static inline void scl3(double* r, const double* a, double s) { r[0] = a[0] * s; r[1] = a[1] * s; r[2] = a[2] * s; }
+static inline double norm3(const double* a) { return sqrt(dot3(a, a)); }
+static inline double normalize3(double* a) {
+  double n = norm3(a);
+  if (n < MINVAL) { a[0] = 1; a[1] = a[2] = 0; return n; }
+  a[0] /= n; a[1] /= n; a[2] /= n;
+  return n;
+}
+/* r = M v, M row-major 3x3 */
+static inline void mulmat3(double* r, const double* M, const double* v) {
+  double x = M[0] * v[0] + M[1] * v[1] + M[2] * v[2], y = M[3] * v[0] + M[4] * v[1] + M[5] * v[2],
+         z = M[6] * v[0] + M[7] * v[1] + M[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static inline void mulmatT3(double* r, const double* M, const double* v) {
+  double x = M[0] * v[0] + M[3] * v[1] + M[6] * v[2], y = M[1] * v[0] + M[4] * v[1] + M[7] * v[2],
+         z = M[2] * v[0] + M[5] * v[1] + M[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static void mulquat(double* r, const double* a, const double* b) {
+  double w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  double x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  double y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  double z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
+}
+static void normalize4(double* q) {
+  double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < MINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
+  q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+static void quat2mat(double* m, const double* q) {
+  double w = q[0], x = q[1], y = q[2], z = q[3];
+  m[0] = w * w + x * x - y * y - z * z; m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y);
+  m[3] = 2 * (x * y + w * z); m[4] = w * w - x * x + y * y - z * z; m[5] = 2 * (y * z - w * x);
+  m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = w * w - x * x - y * y + z * z;
+}
+static void axisangle2quat(double* q, const double* axis, double angle) {
+  double s = sin(angle * 0.5);
+  q[0] = cos(angle * 0.5); q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
+}
+/* C = A(3x3) * B(3x3) */
+static void mulmat33(double* C, const double* A, const double* B) {
+  double t[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) t[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+  memcpy(C, t, sizeof t);
+}
+static inline double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+/* ------------------------------------------------------------------------------------------ model blob */
+typedef struct { char name[40]; uint32_t dtype, count; uint64_t offset; } blob_entry;
+
+static const void* blob_find(const void* blob, const char* name, uint32_t* count, int required) {
+  const char* b = (const char*)blob;
+  uint32_t n = *(const uint32_t*)(b + 8);
+  const blob_entry* e = (const blob_entry*)(b + 16);
+  for (uint32_t i = 0; i < n; i++)
+    if (strncmp(e[i].name, name, 40) == 0) {
+      if (count) *count = e[i].count;
+      return b + e[i].offset;
+    }
+  if (required) { fprintf(stderr, "rg_oracle: model blob lacks '%s'\n", name); abort(); }
+  return NULL;
+}
+#define F64(field) m->field = (const double*)blob_find(m->blob, #field, NULL, 1)
+#define I32(field) m->field = (const int*)blob_find(m->blob, #field, NULL, 1)
+
+ro_model* ro_model_load(const void* blob_in, size_t nbytes) {
+  if (nbytes < 16 || memcmp(blob_in, "RGMODEL1", 8) != 0) return NULL;
+  ro_model* m = (ro_model*)calloc(1, sizeof(ro_model));
+  m->blob = malloc(nbytes);
+  memcpy(m->blob, blob_in, nbytes);
+  const int* dims = (const int*)blob_find(m->blob, "dims", NULL, 1);
+  m->nq = dims[0]; m->nv = dims[1]; m->nu = dims[2]; m->nbody = dims[3]; m->njnt = dims[4]; m->ngeom = dims[5];
+  m->nsite = dims[6]; m->ntendon = dims[7]; m->nwrap = dims[8]; m->nmesh = dims[9]; m->nmeshvert = dims[10];
+  m->nexclude = dims[11]; m->nsensor = dims[12];
+  m->timestep = *(const double*)blob_find(m->blob, "opt_timestep", NULL, 1);
+  memcpy(m->gravity, blob_find(m->blob, "opt_gravity", NULL, 1), 3 * sizeof(double));
+  m->tolerance = *(const double*)blob_find(m->blob, "opt_tolerance", NULL, 1);
+  m->impratio = *(const double*)blob_find(m->blob, "opt_impratio", NULL, 1);
+  m->ls_tolerance = *(const double*)blob_find(m->blob, "opt_ls_tolerance", NULL, 1);
+  m->mpr_tolerance = *(const double*)blob_find(m->blob, "opt_mpr_tolerance", NULL, 1);
+  m->meaninertia = *(const double*)blob_find(m->blob, "stat_meaninertia", NULL, 1);
+  const int* oi = (const int*)blob_find(m->blob, "opt_int", NULL, 1);
+  m->iterations = oi[0]; m->cone = oi[1]; m->ls_iterations = oi[2]; m->mpr_iterations = oi[3];
+  const int* si = (const int*)blob_find(m->blob, "size_int", NULL, 1);
+  m->njmax = si[0] > 0 && si[0] < MAXEFC ? si[0] : MAXEFC;
+  m->nconmax = si[1] > 0 && si[1] < MAXCON ? si[1] : MAXCON;
+  I32(body_parentid); I32(body_rootid); I32(body_weldid); I32(body_jntadr); I32(body_jntnum); I32(body_dofadr);
+  I32(body_dofnum); I32(body_geomadr); I32(body_geomnum);
+  F64(body_pos); F64(body_quat); F64(body_ipos); F64(body_iquat); F64(body_mass); F64(body_inertia);
+  F64(body_subtreemass); F64(body_invweight0);
+  I32(jnt_type); I32(jnt_qposadr); I32(jnt_dofadr); I32(jnt_bodyid); I32(jnt_limited);
+  F64(jnt_pos); F64(jnt_axis); F64(jnt_stiffness); F64(jnt_range); F64(jnt_margin); F64(jnt_solref); F64(jnt_solimp);
+  I32(dof_bodyid); I32(dof_jntid); I32(dof_parentid);
+  F64(dof_armature); F64(dof_damping); F64(dof_frictionloss); F64(dof_solref); F64(dof_solimp); F64(dof_invweight0);
+  F64(qpos0); F64(qpos_spring);
+  I32(geom_type); I32(geom_bodyid); I32(geom_dataid); I32(geom_contype); I32(geom_conaffinity); I32(geom_condim);
+  F64(geom_size); F64(geom_rbound); F64(geom_pos); F64(geom_quat); F64(geom_friction); F64(geom_margin); F64(geom_gap);
+  F64(geom_solmix); F64(geom_solref); F64(geom_solimp);
+  I32(site_bodyid); F64(site_pos); F64(site_quat);
+  I32(mesh_vertadr); I32(mesh_vertnum);
+  m->mesh_vert = (const float*)blob_find(m->blob, "mesh_vert", NULL, 1);
+  I32(exclude_signature);
+  I32(tendon_adr); I32(tendon_num); I32(tendon_limited);
+  F64(tendon_range); F64(tendon_margin); F64(tendon_stiffness); F64(tendon_damping); F64(tendon_frictionloss);
+  F64(tendon_lengthspring); F64(tendon_solref_lim); F64(tendon_solimp_lim); F64(tendon_solref_fri);
+  F64(tendon_solimp_fri); F64(tendon_invweight0);
+  I32(wrap_type); I32(wrap_objid); F64(wrap_prm);
+  I32(actuator_trntype); I32(actuator_trnid); I32(actuator_ctrllimited); I32(actuator_forcelimited);
+  I32(actuator_gaintype); I32(actuator_biastype);
+  F64(actuator_gear); F64(actuator_ctrlrange); F64(actuator_forcerange); F64(actuator_gainprm); F64(actuator_biasprm);
+  F64(actuator_user);
+  return m;
+}
+void ro_model_free(ro_model* m) { if (m) { free(m->blob); free(m); } }
+
+static double* dalloc(size_t n) { return (double*)calloc(n ? n : 1, sizeof(double)); }
+
+ro_data* ro_data_new(const ro_model* m) {
+  ro_data* d = (ro_data*)calloc(1, sizeof(ro_data));
+  int nv = m->nv, nb = m->nbody;
+  d->qpos = dalloc(m->nq); d->qvel = dalloc(nv); d->ctrl = dalloc(m->nu); d->pid = dalloc(3 * m->nu);
+  d->qacc_warmstart = dalloc(nv);
+  d->xpos = dalloc(3 * nb); d->xquat = dalloc(4 * nb); d->xmat = dalloc(9 * nb); d->xipos = dalloc(3 * nb);
+  d->ximat = dalloc(9 * nb); d->xanchor = dalloc(3 * m->njnt); d->xaxis = dalloc(3 * m->njnt);
+  d->geom_xpos = dalloc(3 * m->ngeom); d->geom_xmat = dalloc(9 * m->ngeom);
+  d->site_xpos = dalloc(3 * m->nsite); d->site_xmat = dalloc(9 * m->nsite);
+  d->subtree_com = dalloc(3 * nb); d->cinert = dalloc(10 * nb); d->cdof = dalloc(6 * nv); d->crb = dalloc(10 * nb);
+  d->ten_length = dalloc(m->ntendon); d->ten_J = dalloc((size_t)m->ntendon * nv);
+  d->actuator_length = dalloc(m->nu); d->actuator_moment = dalloc((size_t)m->nu * nv);
+  d->qM = dalloc((size_t)nv * nv); d->qL = dalloc((size_t)nv * nv);
+  d->efc_J = dalloc((size_t)MAXEFC * nv); d->efc_pos = dalloc(MAXEFC); d->efc_margin = dalloc(MAXEFC);
+  d->efc_frictionloss = dalloc(MAXEFC); d->efc_diagApprox = dalloc(MAXEFC); d->efc_R = dalloc(MAXEFC);
+  d->efc_D = dalloc(MAXEFC); d->efc_KBIP = dalloc(4 * MAXEFC); d->efc_vel = dalloc(MAXEFC);
+  d->efc_aref = dalloc(MAXEFC); d->efc_force = dalloc(MAXEFC);
+  d->efc_type = (int*)calloc(MAXEFC, sizeof(int)); d->efc_id = (int*)calloc(MAXEFC, sizeof(int));
+  d->ten_velocity = dalloc(m->ntendon); d->actuator_velocity = dalloc(m->nu); d->cvel = dalloc(6 * nb);
+  d->cdof_dot = dalloc(6 * nv); d->qfrc_passive = dalloc(nv); d->qfrc_bias = dalloc(nv);
+  d->actuator_force = dalloc(m->nu); d->qfrc_actuator = dalloc(nv); d->qfrc_smooth = dalloc(nv);
+  d->qacc_smooth = dalloc(nv); d->qfrc_constraint = dalloc(nv); d->qacc = dalloc(nv);
+  memcpy(d->qpos, m->qpos0, m->nq * sizeof(double));
+  return d;
+}
+void ro_data_free(ro_data* d) {
+  if (!d) return;
+  double** p[] = {&d->qpos, &d->qvel, &d->ctrl, &d->pid, &d->qacc_warmstart, &d->xpos, &d->xquat, &d->xmat, &d->xipos,
+                  &d->ximat, &d->xanchor, &d->xaxis, &d->geom_xpos, &d->geom_xmat, &d->site_xpos, &d->site_xmat,
+                  &d->subtree_com, &d->cinert, &d->cdof, &d->crb, &d->ten_length, &d->ten_J, &d->actuator_length,
+                  &d->actuator_moment, &d->qM, &d->qL, &d->efc_J, &d->efc_pos, &d->efc_margin, &d->efc_frictionloss,
+                  &d->efc_diagApprox, &d->efc_R, &d->efc_D, &d->efc_KBIP, &d->efc_vel, &d->efc_aref, &d->efc_force,
+                  &d->ten_velocity, &d->actuator_velocity, &d->cvel, &d->cdof_dot, &d->qfrc_passive, &d->qfrc_bias,
+                  &d->actuator_force, &d->qfrc_actuator, &d->qfrc_smooth, &d->qacc_smooth, &d->qfrc_constraint, &d->qacc};
+  for (size_t i = 0; i < sizeof(p) / sizeof(p[0]); i++) free(*p[i]);
+  free(d->efc_type); free(d->efc_id); free(d);
+}
+
+/* mj_resetData: qpos <- qpos0, everything else zero (mujoco-py MjSim.reset) */
+void ro_reset(const ro_model* m, ro_data* d) {
+  memcpy(d->qpos, m->qpos0, m->nq * sizeof(double));
+  memset(d->qvel, 0, m->nv * sizeof(double)); memset(d->ctrl, 0, m->nu * sizeof(double));
+  memset(d->pid, 0, 3 * m->nu * sizeof(double)); memset(d->qacc_warmstart, 0, m->nv * sizeof(double));
+  d->time = 0; d->warn_bad = d->warn_contact_full = d->warn_efc_full = 0;
+}
+
+/* ------------------------------------------------------------------------------------------ kinematics
+ * engine_core_smooth.c: mj_kinematics */
+static void ro_kinematics(const ro_model* m, ro_data* d) {
+  zero3(d->xpos); d->xquat[0] = 1; d->xquat[1] = d->xquat[2] = d->xquat[3] = 0;
+  quat2mat(d->xmat, d->xquat); zero3(d->xipos); quat2mat(d->ximat, d->xquat);
+  for (int b = 1; b < m->nbody; b++) {
+    int p = m->body_parentid[b];
+    double pos[3], quat[4], tmp[3], mat[9];
+    mulmat3(tmp, d->xmat + 9 * p, m->body_pos + 3 * b);
+    add3(pos, d->xpos + 3 * p, tmp);
+    mulquat(quat, d->xquat + 4 * p, m->body_quat + 4 * b);
+    for (int k = 0; k < m->body_jntnum[b]; k++) {
+      int j = m->body_jntadr[b] + k, qa = m->jnt_qposadr[j], t = m->jnt_type[j];
+      if (t == JNT_FREE) {
+        copy3(pos, d->qpos + qa);
+        memcpy(quat, d->qpos + qa + 3, 4 * sizeof(double)); normalize4(quat);
+        copy3(d->xanchor + 3 * j, pos); d->xaxis[3 * j] = 0; d->xaxis[3 * j + 1] = 0; d->xaxis[3 * j + 2] = 1;
+        continue;
+      }
+      quat2mat(mat, quat);
+      mulmat3(tmp, mat, m->jnt_pos + 3 * j); add3(d->xanchor + 3 * j, pos, tmp);
+      mulmat3(d->xaxis + 3 * j, mat, m->jnt_axis + 3 * j);
+      if (t == JNT_SLIDE) {
+        addscl3(pos, d->xaxis + 3 * j, d->qpos[qa] - m->qpos0[qa]);
+      } else {
+        double ql[4], qn[4];
+        if (t == JNT_BALL) { memcpy(ql, d->qpos + qa, 4 * sizeof(double)); normalize4(ql); }
+        else axisangle2quat(ql, m->jnt_axis + 3 * j, d->qpos[qa] - m->qpos0[qa]);
+        mulquat(qn, quat, ql); memcpy(quat, qn, sizeof qn);
+        /* keep the anchor fixed: xpos = xanchor - R_new * jnt_pos */
+        quat2mat(mat, quat); mulmat3(tmp, mat, m->jnt_pos + 3 * j); sub3(pos, d->xanchor + 3 * j, tmp);
+      }
+    }
+    normalize4(quat);
+    copy3(d->xpos + 3 * b, pos); memcpy(d->xquat + 4 * b, quat, 4 * sizeof(double));
+    quat2mat(d->xmat + 9 * b, quat);
+    mulmat3(tmp, d->xmat + 9 * b, m->body_ipos + 3 * b); add3(d->xipos + 3 * b, pos, tmp);
+    double iq[4]; mulquat(iq, quat, m->body_iquat + 4 * b); quat2mat(d->ximat + 9 * b, iq);
+  }
+  for (int g = 0; g < m->ngeom; g++) {
+    int b = m->geom_bodyid[g];
+    double tmp[3], q[4];
+    mulmat3(tmp, d->xmat + 9 * b, m->geom_pos + 3 * g); add3(d->geom_xpos + 3 * g, d->xpos + 3 * b, tmp);
+    mulquat(q, d->xquat + 4 * b, m->geom_quat + 4 * g); quat2mat(d->geom_xmat + 9 * g, q);
+  }
+  for (int s = 0; s < m->nsite; s++) {
+    int b = m->site_bodyid[s];
+    double tmp[3], q[4];
+    mulmat3(tmp, d->xmat + 9 * b, m->site_pos + 3 * s); add3(d->site_xpos + 3 * s, d->xpos + 3 * b, tmp);
+    mulquat(q, d->xquat + 4 * b, m->site_quat + 4 * s); quat2mat(d->site_xmat + 9 * s, q);
+  }
+}
+
+/* engine_core_smooth.c: mj_comPos — subtree COMs, body inertias and motion axes in the com-based frame */
+static void ro_com_pos(const ro_model* m, ro_data* d) {
+  int nb = m->nbody;
+  for (int b = 0; b < nb; b++) scl3(d->subtree_com + 3 * b, d->xipos + 3 * b, m->body_mass[b]);
+  for (int b = nb - 1; b > 0; b--) add3(d->subtree_com + 3 * m->body_parentid[b], d->subtree_com + 3 * m->body_parentid[b], d->subtree_com + 3 * b);
+  for (int b = 0; b < nb; b++) {
+    if (m->body_subtreemass[b] < MINVAL) copy3(d->subtree_com + 3 * b, d->xipos + 3 * b);
+    else scl3(d->subtree_com + 3 * b, d->subtree_com + 3 * b, 1.0 / m->body_subtreemass[b]);
+  }
+  memset(d->cinert, 0, 10 * sizeof(double));
+  for (int b = 1; b < nb; b++) {
+    double dif[3], *ci = d->cinert + 10 * b, tmp[9], I[9];
+    const double *R = d->ximat + 9 * b, *in = m->body_inertia + 3 * b;
+    double mass = m->body_mass[b];
+    sub3(dif, d->xipos + 3 * b, d->subtree_com + 3 * m->body_rootid[b]);
+    /* I = R diag(in) R^T */
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) tmp[3 * i + j] = R[3 * i + j] * in[j];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) I[3 * i + j] = tmp[3 * i] * R[3 * j] + tmp[3 * i + 1] * R[3 * j + 1] + tmp[3 * i + 2] * R[3 * j + 2];
+    double d2 = dot3(dif, dif);
+    ci[0] = I[0] + mass * (d2 - dif[0] * dif[0]); ci[1] = I[4] + mass * (d2 - dif[1] * dif[1]); ci[2] = I[8] + mass * (d2 - dif[2] * dif[2]);
+    ci[3] = I[1] - mass * dif[0] * dif[1]; ci[4] = I[2] - mass * dif[0] * dif[2]; ci[5] = I[5] - mass * dif[1] * dif[2];
+    ci[6] = mass * dif[0]; ci[7] = mass * dif[1]; ci[8] = mass * dif[2]; ci[9] = mass;
+  }
+  for (int j = 0; j < m->njnt; j++) {
+    int b = m->jnt_bodyid[j], da = m->jnt_dofadr[j], t = m->jnt_type[j];
+    double off[3];
+    sub3(off, d->subtree_com + 3 * m->body_rootid[b], d->xanchor + 3 * j);
+    const double* R = d->xmat + 9 * b;
+    if (t == JNT_FREE || t == JNT_BALL) {
+      if (t == JNT_FREE) {
+        for (int k = 0; k < 3; k++) { double* c = d->cdof + 6 * (da + k); memset(c, 0, 6 * sizeof(double)); c[3 + k] = 1; }
+        da += 3;
+      }
+      for (int k = 0; k < 3; k++) {
+        double ax[3] = {R[k], R[3 + k], R[6 + k]}, *c = d->cdof + 6 * (da + k);
+        copy3(c, ax); cross3(c + 3, ax, off);
+      }
+    } else if (t == JNT_SLIDE) {
+      double* c = d->cdof + 6 * da; zero3(c); copy3(c + 3, d->xaxis + 3 * j);
+    } else {
+      double* c = d->cdof + 6 * da; copy3(c, d->xaxis + 3 * j); cross3(c + 3, d->xaxis + 3 * j, off);
+    }
+  }
+}
+
+/* y = cinert * v  (mju_mulInertVec) */
+static void mul_inert_vec(double* r, const double* i, const double* v) {
+  r[0] = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
+  r[1] = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
+  r[2] = i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4];
+  r[3] = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
+  r[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
+  r[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
+}
+static void cross_motion(double* r, const double* vel, const double* v) {
+  double a[3], b[3];
+  cross3(r, vel, v); cross3(a, vel, v + 3); cross3(b, vel + 3, v); add3(r + 3, a, b);
+}
+static void cross_force(double* r, const double* vel, const double* f) {
+  double a[3], b[3];
+  cross3(a, vel, f); cross3(b, vel + 3, f + 3); add3(r, a, b); cross3(r + 3, vel, f + 3);
+}
+
+/* translational/rotational Jacobian of a world point attached to `body` (mj_jac); jp, jr: 3 x nv or NULL */
+static void ro_jac(const ro_model* m, const ro_data* d, double* jp, double* jr, const double* point, int body) {
+  int nv = m->nv;
+  if (jp) memset(jp, 0, 3 * nv * sizeof(double));
+  if (jr) memset(jr, 0, 3 * nv * sizeof(double));
+  if (body <= 0) return;
+  double off[3];
+  sub3(off, point, d->subtree_com + 3 * m->body_rootid[body]);
+  /* last dof of the nearest body (self or ancestor) that has dofs */
+  int b = body;
+  while (b > 0 && m->body_dofnum[b] == 0) b = m->body_parentid[b];
+  if (b <= 0) return;
+  for (int i = m->body_dofadr[b] + m->body_dofnum[b] - 1; i >= 0; i = m->dof_parentid[i]) {
+    const double* c = d->cdof + 6 * i;
+    if (jr) { jr[i] = c[0]; jr[nv + i] = c[1]; jr[2 * nv + i] = c[2]; }
+    if (jp) {
+      double t[3]; cross3(t, c, off);
+      jp[i] = c[3] + t[0]; jp[nv + i] = c[4] + t[1]; jp[2 * nv + i] = c[5] + t[2];
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ tendons
+ * engine_util_misc.c: mju_wrap / wrap_circle / is_intersect; engine_core_smooth.c: mj_tendon */
+static int is_intersect(const double* p1, const double* p2, const double* p3, const double* p4) {
+  double det = (p4[1] - p3[1]) * (p2[0] - p1[0]) - (p4[0] - p3[0]) * (p2[1] - p1[1]);
+  if (fabs(det) < MINVAL) return 0;
+  double a = ((p4[0] - p3[0]) * (p1[1] - p3[1]) - (p4[1] - p3[1]) * (p1[0] - p3[0])) / det;
+  double b = ((p2[0] - p1[0]) * (p1[1] - p3[1]) - (p2[1] - p1[1]) * (p1[0] - p3[0])) / det;
+  return a >= 0 && a <= 1 && b >= 0 && b <= 1;
+}
+static double wrap_circle(double* pnt, const double* d, const double* sd, double rad) {
+  double sq0 = d[0] * d[0] + d[1] * d[1], sq1 = d[2] * d[2] + d[3] * d[3], sqr = rad * rad;
+  double dif[2] = {d[2] - d[0], d[3] - d[1]}, dd = dif[0] * dif[0] + dif[1] * dif[1];
+  if (sq0 < sqr || sq1 < sqr || rad < MINVAL || dd < MINVAL) return -1;
+  double a = clampd(-(dif[0] * d[0] + dif[1] * d[1]) / dd, 0, 1);
+  double nr[2] = {a * dif[0] + d[0], a * dif[1] + d[1]};
+  if (nr[0] * nr[0] + nr[1] * nr[1] > sqr && (!sd || sd[0] * nr[0] + sd[1] * nr[1] >= 0)) return -1;
+  double sol[2][4], good[2];
+  for (int i = 0; i < 2; i++) {
+    double sgn = i == 0 ? 1 : -1, r0 = sqrt(sq0 - sqr), r1 = sqrt(sq1 - sqr);
+    sol[i][0] = (d[0] * sqr + sgn * rad * d[1] * r0) / sq0; sol[i][1] = (d[1] * sqr - sgn * rad * d[0] * r0) / sq0;
+    sol[i][2] = (d[2] * sqr - sgn * rad * d[3] * r1) / sq1; sol[i][3] = (d[3] * sqr + sgn * rad * d[2] * r1) / sq1;
+    if (sd) {
+      double mx = sol[i][0] + sol[i][2], my = sol[i][1] + sol[i][3], n = sqrt(mx * mx + my * my);
+      if (n < MINVAL) n = MINVAL;
+      good[i] = (mx * sd[0] + my * sd[1]) / n;
+    } else {
+      double tx = sol[i][0] - sol[i][2], ty = sol[i][1] - sol[i][3];
+      good[i] = -(tx * tx + ty * ty);
+    }
+    if (is_intersect(d, sol[i], d + 2, sol[i] + 2)) good[i] = -10000;
+  }
+  int k = good[0] > good[1] ? 0 : 1;
+  memcpy(pnt, sol[k], 4 * sizeof(double));
+  if (is_intersect(d, pnt, d + 2, pnt + 2)) return -1;
+  return rad * acos(clampd((pnt[0] * pnt[2] + pnt[1] * pnt[3]) / sqr, -1, 1));
+}
+/* returns wrap length (<0: straight) and the two tangent points wpnt[6] in world frame */
+static double ro_wrap(double* wpnt, const double* x0, const double* x1, const double* gpos, const double* gmat,
+                      double radius, int type, const double* side) {
+  double p0[3], p1[3], t[3];
+  sub3(t, x0, gpos); mulmatT3(p0, gmat, t); sub3(t, x1, gpos); mulmatT3(p1, gmat, t);
+  if (norm3(p0) < MINVAL || norm3(p1) < MINVAL) return -1;
+  double ax0[3], ax1[3];
+  if (type == WRAP_SPHERE) {
+    double nrm[3];
+    copy3(ax0, p0); normalize3(ax0); cross3(nrm, p0, p1);
+    if (norm3(nrm) < MINVAL) { double e[3] = {fabs(ax0[0]) < 0.9, fabs(ax0[0]) >= 0.9, 0}; cross3(nrm, ax0, e); }
+    normalize3(nrm); cross3(ax1, nrm, ax0); normalize3(ax1);
+  } else { ax0[0] = 1; ax0[1] = ax0[2] = 0; ax1[0] = ax1[2] = 0; ax1[1] = 1; }
+  double dd[4] = {dot3(p0, ax0), dot3(p0, ax1), dot3(p1, ax0), dot3(p1, ax1)}, sd[2], *psd = NULL;
+  if (side) {
+    double s[3]; sub3(t, side, gpos); mulmatT3(s, gmat, t);
+    sd[0] = dot3(s, ax0); sd[1] = dot3(s, ax1);
+    double n = sqrt(sd[0] * sd[0] + sd[1] * sd[1]);
+    if (n < radius) { fprintf(stderr, "rg_oracle: inside tendon wrap not supported\n"); abort(); }
+    sd[0] *= radius / n; sd[1] *= radius / n; psd = sd;
+  }
+  double pnt[4], wlen = wrap_circle(pnt, dd, psd, radius);
+  if (wlen < 0) return -1;
+  double r0[3], r1[3];
+  for (int k = 0; k < 3; k++) { r0[k] = ax0[k] * pnt[0] + ax1[k] * pnt[1]; r1[k] = ax0[k] * pnt[2] + ax1[k] * pnt[3]; }
+  if (type == WRAP_CYLINDER) {
+    double L0 = hypot(dd[0] - pnt[0], dd[1] - pnt[1]), L1 = hypot(dd[2] - pnt[2], dd[3] - pnt[3]);
+    r0[2] = p0[2] + (p1[2] - p0[2]) * L0 / (L0 + wlen + L1);
+    r1[2] = p0[2] + (p1[2] - p0[2]) * (L0 + wlen) / (L0 + wlen + L1);
+    wlen = hypot(wlen, r1[2] - r0[2]);
+  }
+  mulmat3(t, gmat, r0); add3(wpnt, t, gpos); mulmat3(t, gmat, r1); add3(wpnt + 3, t, gpos);
+  return wlen;
+}
+
+static void ro_tendon(const ro_model* m, ro_data* d) {
+  int nv = m->nv;
+  double* ja = (double*)malloc(6 * nv * sizeof(double));
+  double* jb = ja + 3 * nv;
+  memset(d->ten_J, 0, (size_t)m->ntendon * nv * sizeof(double));
+  for (int t = 0; t < m->ntendon; t++) {
+    int adr = m->tendon_adr[t], num = m->tendon_num[t];
+    double L = 0, *J = d->ten_J + (size_t)t * nv;
+    if (m->wrap_type[adr] == WRAP_JOINT) {
+      for (int w = adr; w < adr + num; w++) {
+        int j = m->wrap_objid[w];
+        L += m->wrap_prm[w] * d->qpos[m->jnt_qposadr[j]];
+        J[m->jnt_dofadr[j]] = m->wrap_prm[w];
+      }
+      d->ten_length[t] = L;
+      continue;
+    }
+    double divisor = 1;
+    int w = adr;
+    while (w < adr + num - 1) {
+      int t0 = m->wrap_type[w], t1 = m->wrap_type[w + 1];
+      if (t0 == WRAP_PULLEY || t1 == WRAP_PULLEY) { if (t0 == WRAP_PULLEY) divisor = m->wrap_prm[w]; w++; continue; }
+      double pnt[12]; int body[4], cnt;
+      int s0 = m->wrap_objid[w];
+      copy3(pnt, d->site_xpos + 3 * s0); body[0] = m->site_bodyid[s0];
+      double wlen = -1;
+      if (t1 == WRAP_SPHERE || t1 == WRAP_CYLINDER) {
+        int g = m->wrap_objid[w + 1], s1 = m->wrap_objid[w + 2], sid = (int)lround(m->wrap_prm[w + 1]);
+        wlen = ro_wrap(pnt + 3, pnt, d->site_xpos + 3 * s1, d->geom_xpos + 3 * g, d->geom_xmat + 9 * g,
+                       m->geom_size[3 * g], t1, sid >= 0 ? d->site_xpos + 3 * sid : NULL);
+        if (wlen < 0) { copy3(pnt + 3, d->site_xpos + 3 * s1); body[1] = m->site_bodyid[s1]; cnt = 2; }
+        else { copy3(pnt + 9, d->site_xpos + 3 * s1); body[1] = body[2] = m->geom_bodyid[g]; body[3] = m->site_bodyid[s1]; cnt = 4; }
+        w += 2;
+      } else {
+        int s1 = m->wrap_objid[w + 1];
+        copy3(pnt + 3, d->site_xpos + 3 * s1); body[1] = m->site_bodyid[s1]; cnt = 2;
+        w += 1;
+      }
+      if (wlen >= 0) L += wlen / divisor;
+      for (int k = 0; k < cnt - 1; k++) {
+        if (cnt == 4 && k == 1) continue; /* the arc lies on the wrapping geom */
+        double dif[3]; sub3(dif, pnt + 3 * (k + 1), pnt + 3 * k);
+        double dist = norm3(dif);
+        L += dist / divisor;
+        if (body[k] != body[k + 1] && dist > MINVAL) {
+          scl3(dif, dif, 1 / dist);
+          ro_jac(m, d, ja, NULL, pnt + 3 * k, body[k]); ro_jac(m, d, jb, NULL, pnt + 3 * (k + 1), body[k + 1]);
+          for (int i = 0; i < nv; i++)
+            J[i] += (dif[0] * (jb[i] - ja[i]) + dif[1] * (jb[nv + i] - ja[nv + i]) + dif[2] * (jb[2 * nv + i] - ja[2 * nv + i])) / divisor;
+        }
+      }
+    }
+    d->ten_length[t] = L;
+  }
+  free(ja);
+}
+
+/* engine_core_smooth.c: mj_transmission (joint and tendon transmissions, scalar gear) */
+static void ro_transmission(const ro_model* m, ro_data* d) {
+  int nv = m->nv;
+  memset(d->actuator_moment, 0, (size_t)m->nu * nv * sizeof(double));
+  for (int i = 0; i < m->nu; i++) {
+    double g = m->actuator_gear[i];
+    int id = m->actuator_trnid[i];
+    if (m->actuator_trntype[i] == TRN_JOINT) {
+      d->actuator_length[i] = g * d->qpos[m->jnt_qposadr[id]];
+      d->actuator_moment[(size_t)i * nv + m->jnt_dofadr[id]] = g;
+    } else {
+      d->actuator_length[i] = g * d->ten_length[id];
+      for (int k = 0; k < nv; k++) d->actuator_moment[(size_t)i * nv + k] = g * d->ten_J[(size_t)id * nv + k];
+    }
+  }
+}
+
+/* engine_core_smooth.c: mj_crb + mj_factorM (dense Cholesky here; MuJoCo uses sparse L'DL — same solution) */
+static int cholesky(double* L, const double* A, int n) {
+  memcpy(L, A, (size_t)n * n * sizeof(double));
+  for (int j = 0; j < n; j++) {
+    double s = L[j * n + j];
+    for (int k = 0; k < j; k++) s -= L[j * n + k] * L[j * n + k];
+    if (s < MINVAL) return -1;
+    s = sqrt(s); L[j * n + j] = s;
+    for (int i = j + 1; i < n; i++) {
+      double t = L[i * n + j];
+      for (int k = 0; k < j; k++) t -= L[i * n + k] * L[j * n + k];
+      L[i * n + j] = t / s;
+    }
+  }
+  return 0;
+}
+static void chol_solve(const double* L, double* x, int n) { /* in place: x <- A^-1 x */
+  for (int i = 0; i < n; i++) { double s = x[i]; for (int k = 0; k < i; k++) s -= L[i * n + k] * x[k]; x[i] = s / L[i * n + i]; }
+  for (int i = n - 1; i >= 0; i--) { double s = x[i]; for (int k = i + 1; k < n; k++) s -= L[k * n + i] * x[k]; x[i] = s / L[i * n + i]; }
+}
+static void ro_crb(const ro_model* m, ro_data* d) {
+  int nv = m->nv, nb = m->nbody;
+  memcpy(d->crb, d->cinert, 10 * nb * sizeof(double));
+  for (int b = nb - 1; b > 0; b--) {
+    int p = m->body_parentid[b];
+    if (p > 0) for (int k = 0; k < 10; k++) d->crb[10 * p + k] += d->crb[10 * b + k];
+  }
+  memset(d->qM, 0, (size_t)nv * nv * sizeof(double));
+  for (int i = 0; i < nv; i++) {
+    double buf[6];
+    mul_inert_vec(buf, d->crb + 10 * m->dof_bodyid[i], d->cdof + 6 * i);
+    for (int j = i; j >= 0; j = m->dof_parentid[j]) {
+      const double* c = d->cdof + 6 * j;
+      double v = c[0] * buf[0] + c[1] * buf[1] + c[2] * buf[2] + c[3] * buf[3] + c[4] * buf[4] + c[5] * buf[5];
+      d->qM[i * nv + j] = d->qM[j * nv + i] = v;
+    }
+    d->qM[i * nv + i] += m->dof_armature[i];
+  }
+  if (cholesky(d->qL, d->qM, nv) != 0) d->warn_bad |= 1;
+}
+
+/* ------------------------------------------------------------------------------------------ collision
+ * engine_collision_driver.c (filters), engine_collision_convex.c (mjc_Convex on libccd's MPR),
+ * engine_collision_primitive.c (plane cases).  libccd: ccd/mpr.c ccdMPRPenetration. */
+typedef struct { const ro_model* m; const ro_data* d; int geom; double margin; } ccd_obj;
+typedef struct { double v[3], v1[3], v2[3]; } ccd_support;
+
+static void geom_support(const ccd_obj* o, const double* dir, double* res) {
+  const ro_model* m = o->m; int g = o->geom;
+  const double* mat = o->d->geom_xmat + 9 * g; const double* pos = o->d->geom_xpos + 3 * g;
+  double ld[3], lr[3] = {0, 0, 0};
+  mulmatT3(ld, mat, dir);
+  const double* sz = m->geom_size + 3 * g;
+  switch (m->geom_type[g]) {
+    case GEOM_SPHERE: scl3(lr, ld, sz[0]); break;
+    case GEOM_CAPSULE: scl3(lr, ld, sz[0]); lr[2] += (ld[2] >= 0 ? 1 : -1) * sz[1]; break;
+    case GEOM_ELLIPSOID: {
+      double t[3] = {ld[0] * sz[0], ld[1] * sz[1], ld[2] * sz[2]}; double n = norm3(t); if (n < MINVAL) n = MINVAL;
+      lr[0] = t[0] * sz[0] / n; lr[1] = t[1] * sz[1] / n; lr[2] = t[2] * sz[2] / n; break; }
+    case GEOM_CYLINDER: {
+      double n = sqrt(ld[0] * ld[0] + ld[1] * ld[1]);
+      if (n > MINVAL) { lr[0] = ld[0] / n * sz[0]; lr[1] = ld[1] / n * sz[0]; }
+      lr[2] = (ld[2] >= 0 ? 1 : -1) * sz[1]; break; }
+    case GEOM_BOX: for (int k = 0; k < 3; k++) lr[k] = (ld[k] >= 0 ? 1 : -1) * sz[k]; break;
+    case GEOM_MESH: {
+      int id = m->geom_dataid[g], adr = m->mesh_vertadr[id], n = m->mesh_vertnum[id], best = 0;
+      double bv = -1e300;
+      for (int i = 0; i < n; i++) {
+        const float* v = m->mesh_vert + 3 * (adr + i);
+        double s = ld[0] * v[0] + ld[1] * v[1] + ld[2] * v[2];
+        if (s > bv) { bv = s; best = i; }
+      }
+      const float* v = m->mesh_vert + 3 * (adr + best);
+      lr[0] = v[0]; lr[1] = v[1]; lr[2] = v[2]; break; }
+    default: break;
+  }
+  addscl3(lr, ld, o->margin);
+  mulmat3(res, mat, lr); add3(res, res, pos);
+}
+static void mpr_support(const ccd_obj* o1, const ccd_obj* o2, const double* dir, ccd_support* s) {
+  double nd[3] = {-dir[0], -dir[1], -dir[2]};
+  geom_support(o1, dir, s->v1); geom_support(o2, nd, s->v2); sub3(s->v, s->v1, s->v2);
+}
+#define CCD_EPS 2.220446049250313e-16
+static inline int ccd_zero(double x) { return fabs(x) < CCD_EPS; }
+static inline int ccd_eq(double a, double b) {
+  double ab = fabs(a - b);
+  if (ab < CCD_EPS) return 1;
+  double aa = fabs(a), bb = fabs(b);
+  return ab < CCD_EPS * (bb > aa ? bb : aa);
+}
+static void portal_dir(const ccd_support* p, double* dir) {
+  double a[3], b[3];
+  sub3(a, p[2].v, p[1].v); sub3(b, p[3].v, p[1].v); cross3(dir, a, b); normalize3(dir);
+}
+static int portal_reach_tol(const ccd_support* p, const ccd_support* v4, const double* dir, double tol) {
+  double dv1 = dot3(p[1].v, dir), dv2 = dot3(p[2].v, dir), dv3 = dot3(p[3].v, dir), dv4 = dot3(v4->v, dir);
+  double d1 = dv4 - dv1, d2 = dv4 - dv2, d3 = dv4 - dv3;
+  double mn = d1 < d2 ? d1 : d2; mn = mn < d3 ? mn : d3;
+  return ccd_eq(mn, tol) || mn < tol;
+}
+static void expand_portal(ccd_support* p, const ccd_support* v4) {
+  double v4v0[3]; cross3(v4v0, v4->v, p[0].v);
+  if (dot3(p[1].v, v4v0) > 0) { if (dot3(p[2].v, v4v0) > 0) p[1] = *v4; else p[3] = *v4; }
+  else { if (dot3(p[3].v, v4v0) > 0) p[2] = *v4; else p[1] = *v4; }
+}
+/* squared distance from the origin to triangle (a,b,c); closest point in `w` */
+static double origin_tri_dist2(const double* a, const double* b, const double* c, double* w) {
+  double ab[3], ac[3], ap[3] = {-a[0], -a[1], -a[2]};
+  sub3(ab, b, a); sub3(ac, c, a);
+  double d1 = dot3(ab, ap), d2 = dot3(ac, ap);
+  if (d1 <= 0 && d2 <= 0) { copy3(w, a); return dot3(w, w); }
+  double bp[3] = {-b[0], -b[1], -b[2]}, d3 = dot3(ab, bp), d4 = dot3(ac, bp);
+  if (d3 >= 0 && d4 <= d3) { copy3(w, b); return dot3(w, w); }
+  double vc = d1 * d4 - d3 * d2;
+  if (vc <= 0 && d1 >= 0 && d3 <= 0) { double v = d1 / (d1 - d3); copy3(w, a); addscl3(w, ab, v); return dot3(w, w); }
+  double cp[3] = {-c[0], -c[1], -c[2]}, d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+  if (d6 >= 0 && d5 <= d6) { copy3(w, c); return dot3(w, w); }
+  double vb = d5 * d2 - d1 * d6;
+  if (vb <= 0 && d2 >= 0 && d6 <= 0) { double v = d2 / (d2 - d6); copy3(w, a); addscl3(w, ac, v); return dot3(w, w); }
+  double va = d3 * d6 - d5 * d4;
+  if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) {
+    double v = (d4 - d3) / ((d4 - d3) + (d5 - d6)), bc[3]; sub3(bc, c, b); copy3(w, b); addscl3(w, bc, v); return dot3(w, w);
+  }
+  double den = 1.0 / (va + vb + vc), v = vb * den, u = vc * den;
+  copy3(w, a); addscl3(w, ab, v); addscl3(w, ac, u);
+  return dot3(w, w);
+}
+static void find_pos(const ccd_support* p, double* pos) {
+  double dir[3], b[4], t[3];
+  portal_dir(p, dir);
+  cross3(t, p[1].v, p[2].v); b[0] = dot3(t, p[3].v);
+  cross3(t, p[3].v, p[2].v); b[1] = dot3(t, p[0].v);
+  cross3(t, p[0].v, p[1].v); b[2] = dot3(t, p[3].v);
+  cross3(t, p[2].v, p[1].v); b[3] = dot3(t, p[0].v);
+  double sum = b[0] + b[1] + b[2] + b[3];
+  if (ccd_zero(sum) || sum < 0) {
+    b[0] = 0;
+    cross3(t, p[2].v, p[3].v); b[1] = dot3(t, dir);
+    cross3(t, p[3].v, p[1].v); b[2] = dot3(t, dir);
+    cross3(t, p[1].v, p[2].v); b[3] = dot3(t, dir);
+    sum = b[1] + b[2] + b[3];
+  }
+  double inv = 1.0 / sum, p1[3] = {0, 0, 0}, p2[3] = {0, 0, 0};
+  for (int i = 0; i < 4; i++) { addscl3(p1, p[i].v1, b[i]); addscl3(p2, p[i].v2, b[i]); }
+  for (int k = 0; k < 3; k++) pos[k] = 0.5 * inv * (p1[k] + p2[k]);
+}
+/* returns 0 and fills depth/dir/pos on penetration, -1 otherwise */
+static int mpr_penetration(const ccd_obj* o1, const ccd_obj* o2, int max_iter, double tol, double* depth, double* dir_out,
+                           double* pos, long* iters) {
+  ccd_support p[4], v4;
+  double dir[3], va[3], vb[3], dt;
+  /* discoverPortal */
+  copy3(p[0].v1, o1->d->geom_xpos + 3 * o1->geom); copy3(p[0].v2, o2->d->geom_xpos + 3 * o2->geom);
+  sub3(p[0].v, p[0].v1, p[0].v2);
+  if (ccd_zero(p[0].v[0]) && ccd_zero(p[0].v[1]) && ccd_zero(p[0].v[2])) p[0].v[0] += CCD_EPS * 10;
+  scl3(dir, p[0].v, -1); normalize3(dir);
+  mpr_support(o1, o2, dir, &p[1]);
+  dt = dot3(p[1].v, dir);
+  if (ccd_zero(dt) || dt < 0) return -1;
+  cross3(dir, p[0].v, p[1].v);
+  if (ccd_zero(dot3(dir, dir))) {
+    if (ccd_zero(p[1].v[0]) && ccd_zero(p[1].v[1]) && ccd_zero(p[1].v[2])) {
+      /* touching contact at v1 (findPenetrTouch) */
+      *depth = 0; zero3(dir_out); for (int k = 0; k < 3; k++) pos[k] = 0.5 * (p[1].v1[k] + p[1].v2[k]);
+      return 0;
+    }
+    /* origin on the v0-v1 segment (findPenetrSegment) */
+    for (int k = 0; k < 3; k++) pos[k] = 0.5 * (p[1].v1[k] + p[1].v2[k]);
+    copy3(dir_out, p[1].v); *depth = normalize3(dir_out);
+    return 0;
+  }
+  normalize3(dir);
+  mpr_support(o1, o2, dir, &p[2]);
+  dt = dot3(p[2].v, dir);
+  if (ccd_zero(dt) || dt < 0) return -1;
+  sub3(va, p[1].v, p[0].v); sub3(vb, p[2].v, p[0].v); cross3(dir, va, vb); normalize3(dir);
+  if (dot3(dir, p[0].v) > 0) { ccd_support t = p[1]; p[1] = p[2]; p[2] = t; scl3(dir, dir, -1); }
+  for (int guard = 0;; guard++) {
+    if (guard > 100) return -1;
+    mpr_support(o1, o2, dir, &p[3]);
+    dt = dot3(p[3].v, dir);
+    if (ccd_zero(dt) || dt < 0) return -1;
+    int cont = 0;
+    cross3(va, p[1].v, p[3].v); dt = dot3(va, p[0].v);
+    if (dt < 0 && !ccd_zero(dt)) { p[2] = p[3]; cont = 1; }
+    if (!cont) {
+      cross3(va, p[3].v, p[2].v); dt = dot3(va, p[0].v);
+      if (dt < 0 && !ccd_zero(dt)) { p[1] = p[3]; cont = 1; }
+    }
+    if (!cont) break;
+    sub3(va, p[1].v, p[0].v); sub3(vb, p[2].v, p[0].v); cross3(dir, va, vb); normalize3(dir);
+  }
+  /* refinePortal */
+  for (int guard = 0;; guard++) {
+    if (guard > 1000) return -1;
+    portal_dir(p, dir);
+    dt = dot3(dir, p[1].v);
+    if (ccd_zero(dt) || dt > 0) break; /* portal encapsulates the origin */
+    mpr_support(o1, o2, dir, &v4);
+    dt = dot3(v4.v, dir);
+    if (!(ccd_zero(dt) || dt > 0) || portal_reach_tol(p, &v4, dir, tol)) return -1;
+    expand_portal(p, &v4);
+  }
+  /* findPenetr */
+  for (int it = 0;; it++) {
+    portal_dir(p, dir);
+    mpr_support(o1, o2, dir, &v4);
+    if (iters) (*iters)++;
+    if (portal_reach_tol(p, &v4, dir, tol) || it > max_iter) {
+      double w[3];
+      *depth = sqrt(origin_tri_dist2(p[1].v, p[2].v, p[3].v, w));
+      if (ccd_zero(*depth)) zero3(dir_out);
+      else { copy3(dir_out, w); normalize3(dir_out); }
+      find_pos(p, pos);
+      return 0;
+    }
+    expand_portal(p, &v4);
+  }
+}
+
+static void make_frame(double* f) {
+  normalize3(f);
+  if (norm3(f + 3) < 0.5) { zero3(f + 3); if (f[1] < 0.5 && f[1] > -0.5) f[4] = 1; else f[5] = 1; }
+  double t = dot3(f, f + 3); addscl3(f + 3, f, -t); normalize3(f + 3);
+  cross3(f + 6, f, f + 3);
+}
+
+static int add_contact(const ro_model* m, ro_data* d, int g1, int g2, double dist, const double* pos, const double* normal,
+                       double margin, double gap) {
+  if (d->ncon >= m->nconmax) { d->warn_contact_full = 1; return 0; }
+  ro_contact* c = &d->contact[d->ncon++];
+  memset(c, 0, sizeof *c);
+  c->dist = dist; copy3(c->pos, pos); copy3(c->frame, normal); make_frame(c->frame);
+  c->includemargin = margin - gap; c->geom1 = g1; c->geom2 = g2;
+  c->dim = m->geom_condim[g1] > m->geom_condim[g2] ? m->geom_condim[g1] : m->geom_condim[g2];
+  double f[3];
+  for (int k = 0; k < 3; k++) f[k] = fmax(m->geom_friction[3 * g1 + k], m->geom_friction[3 * g2 + k]);
+  c->friction[0] = c->friction[1] = f[0]; c->friction[2] = f[1]; c->friction[3] = c->friction[4] = f[2];
+  double mix1 = m->geom_solmix[g1], mix2 = m->geom_solmix[g2], mix;
+  if (mix1 >= MINVAL && mix2 >= MINVAL) mix = mix1 / (mix1 + mix2);
+  else if (mix1 < MINVAL && mix2 < MINVAL) mix = 0.5;
+  else mix = mix1 < MINVAL ? 0.0 : 1.0;
+  const double *r1 = m->geom_solref + 2 * g1, *r2 = m->geom_solref + 2 * g2;
+  if (r1[0] > 0 && r2[0] > 0) for (int k = 0; k < 2; k++) c->solref[k] = mix * r1[k] + (1 - mix) * r2[k];
+  else for (int k = 0; k < 2; k++) c->solref[k] = fmin(r1[k], r2[k]);
+  for (int k = 0; k < 5; k++) c->solimp[k] = mix * m->geom_solimp[5 * g1 + k] + (1 - mix) * m->geom_solimp[5 * g2 + k];
+  return 1;
+}
+
+static void collide_pair(const ro_model* m, ro_data* d, int g1, int g2) {
+  if (m->geom_type[g1] > m->geom_type[g2]) { int t = g1; g1 = g2; g2 = t; }
+  int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
+  if (!((m->geom_contype[g1] & m->geom_conaffinity[g2]) || (m->geom_contype[g2] & m->geom_conaffinity[g1]))) return;
+  double margin = fmax(m->geom_margin[g1], m->geom_margin[g2]), gap = fmax(m->geom_gap[g1], m->geom_gap[g2]);
+  const double *p1 = d->geom_xpos + 3 * g1, *p2 = d->geom_xpos + 3 * g2;
+  const double *R1 = d->geom_xmat + 9 * g1;
+  if (t1 == GEOM_PLANE) {
+    double n[3] = {R1[2], R1[5], R1[8]}, dif[3];
+    sub3(dif, p2, p1);
+    if (t2 == GEOM_PLANE) return;
+    if (dot3(dif, n) > m->geom_rbound[g2] + margin) return;
+    if (t2 == GEOM_BOX) { /* mjc_PlaneBox: corners below plane+margin, at most 4 */
+      const double *R2 = d->geom_xmat + 9 * g2, *sz = m->geom_size + 3 * g2;
+      int cnt = 0;
+      for (int i = 0; i < 8 && cnt < 4; i++) {
+        double lc[3] = {(i & 1 ? 1 : -1) * sz[0], (i & 2 ? 1 : -1) * sz[1], (i & 4 ? 1 : -1) * sz[2]}, c[3];
+        mulmat3(c, R2, lc); add3(c, c, p2);
+        double t[3]; sub3(t, c, p1);
+        double dist = dot3(t, n);
+        if (dist > margin) continue;
+        double pos[3]; copy3(pos, c); addscl3(pos, n, -0.5 * dist);
+        cnt += add_contact(m, d, g1, g2, dist, pos, n, margin, gap);
+      }
+    } else { /* mjc_PlaneConvex (deepest support point) / plane-sphere etc. through the support map */
+      ccd_obj o = {m, d, g2, 0};
+      double nd[3] = {-n[0], -n[1], -n[2]}, s[3], t[3];
+      geom_support(&o, nd, s); sub3(t, s, p1);
+      double dist = dot3(t, n);
+      if (dist > margin) return;
+      double pos[3]; copy3(pos, s); addscl3(pos, n, -0.5 * dist);
+      add_contact(m, d, g1, g2, dist, pos, n, margin, gap);
+    }
+    return;
+  }
+  double dif[3]; sub3(dif, p2, p1);
+  double bound = m->geom_rbound[g1] + m->geom_rbound[g2] + margin;
+  if (dot3(dif, dif) > bound * bound) return;
+  /* mjc_Convex: MPR on shapes inflated by margin/2 each; dist = margin - depth */
+  ccd_obj o1 = {m, d, g1, 0.5 * margin}, o2 = {m, d, g2, 0.5 * margin};
+  double depth, dir[3], pos[3];
+  d->stat_mpr_calls++;
+  if (mpr_penetration(&o1, &o2, m->mpr_iterations, m->mpr_tolerance, &depth, dir, pos, &d->stat_mpr_iter) != 0) return;
+  if (norm3(dir) < 0.5) return; /* contact found but normal undefined */
+  /* libccd reports the direction that separates obj2 from obj1 when applied to obj2's negative;
+     MuJoCo's frame normal points from geom1 to geom2 */
+  add_contact(m, d, g1, g2, margin - depth, pos, dir, margin, gap);
+}
+
+static int body_pair_excluded(const ro_model* m, int b1, int b2) {
+  int sig = (b1 < b2 ? (b1 << 16) + b2 : (b2 << 16) + b1);
+  for (int i = 0; i < m->nexclude; i++) if (m->exclude_signature[i] == sig) return 1;
+  return 0;
+}
+static void ro_collision(const ro_model* m, ro_data* d) {
+  d->ncon = 0;
+  for (int b1 = 0; b1 < m->nbody; b1++) {
+    if (!m->body_geomnum[b1]) continue;
+    for (int b2 = b1 + 1; b2 < m->nbody; b2++) {
+      if (!m->body_geomnum[b2]) continue;
+      int w1 = m->body_weldid[b1], w2 = m->body_weldid[b2];
+      if (w1 == w2) continue;
+      int pw1 = m->body_weldid[m->body_parentid[w1]], pw2 = m->body_weldid[m->body_parentid[w2]];
+      if (w1 != 0 && w2 != 0 && (w1 == pw2 || w2 == pw1)) continue;
+      if (body_pair_excluded(m, b1, b2)) continue;
+      for (int i = 0; i < m->body_geomnum[b1]; i++)
+        for (int j = 0; j < m->body_geomnum[b2]; j++) collide_pair(m, d, m->body_geomadr[b1] + i, m->body_geomadr[b2] + j);
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ constraints
+ * engine_core_constraint.c: mj_makeConstraint (friction, limit, contact rows), mj_makeImpedance */
+static double get_impedance(const double* si, double pos, double margin) {
+  double dmin = clampd(si[0], 1e-4, 0.9999), dmax = clampd(si[1], 1e-4, 0.9999), width = fmax(si[2], MINVAL);
+  double mid = clampd(si[3], 1e-4, 0.9999), power = fmax(si[4], 1.0);
+  if (dmin == dmax || width <= MINVAL) return 0.5 * (dmin + dmax);
+  double x = fabs((pos - margin) / width);
+  if (x >= 1) return dmax;
+  if (x <= 0) return dmin;
+  double y;
+  if (power == 1) y = x;
+  else if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
+  else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
+  return dmin + y * (dmax - dmin);
+}
+static int add_row(const ro_model* m, ro_data* d, int type, int id, double pos, double margin, double floss, double diag) {
+  if (d->nefc >= m->njmax) { d->warn_efc_full = 1; return -1; }
+  int r = d->nefc++;
+  memset(d->efc_J + (size_t)r * m->nv, 0, m->nv * sizeof(double));
+  d->efc_type[r] = type; d->efc_id[r] = id; d->efc_pos[r] = pos; d->efc_margin[r] = margin;
+  d->efc_frictionloss[r] = floss; d->efc_diagApprox[r] = diag;
+  return r;
+}
+static void ro_make_constraint(const ro_model* m, ro_data* d) {
+  int nv = m->nv;
+  d->nefc = d->nf = d->nl = 0;
+  /* friction loss: dofs, then tendons */
+  for (int i = 0; i < nv; i++)
+    if (m->dof_frictionloss[i] > 0) {
+      int r = add_row(m, d, EFC_FRICTION_DOF, i, 0, 0, m->dof_frictionloss[i], m->dof_invweight0[i]);
+      if (r >= 0) d->efc_J[(size_t)r * nv + i] = 1;
+    }
+  for (int t = 0; t < m->ntendon; t++)
+    if (m->tendon_frictionloss[t] > 0) {
+      int r = add_row(m, d, EFC_FRICTION_TENDON, t, 0, 0, m->tendon_frictionloss[t], m->tendon_invweight0[t]);
+      if (r >= 0) memcpy(d->efc_J + (size_t)r * nv, d->ten_J + (size_t)t * nv, nv * sizeof(double));
+    }
+  d->nf = d->nefc;
+  /* limits: joints (hinge/slide), then tendons */
+  for (int j = 0; j < m->njnt; j++) {
+    if (!m->jnt_limited[j]) continue;
+    int t = m->jnt_type[j];
+    if (t != JNT_HINGE && t != JNT_SLIDE) continue; /* ball limits are not used by the robogym models */
+    double q = d->qpos[m->jnt_qposadr[j]];
+    for (int side = -1; side <= 1; side += 2) {
+      double dist = side * (m->jnt_range[2 * j + (side + 1) / 2] - q);
+      if (dist < m->jnt_margin[j]) {
+        int r = add_row(m, d, EFC_LIMIT_JOINT, j, dist, m->jnt_margin[j], 0, m->dof_invweight0[m->jnt_dofadr[j]]);
+        if (r >= 0) d->efc_J[(size_t)r * nv + m->jnt_dofadr[j]] = -side;
+      }
+    }
+  }
+  for (int t = 0; t < m->ntendon; t++) {
+    if (!m->tendon_limited[t]) continue;
+    for (int side = -1; side <= 1; side += 2) {
+      double dist = side * (m->tendon_range[2 * t + (side + 1) / 2] - d->ten_length[t]);
+      if (dist < m->tendon_margin[t]) {
+        int r = add_row(m, d, EFC_LIMIT_TENDON, t, dist, m->tendon_margin[t], 0, m->tendon_invweight0[t]);
+        if (r >= 0) for (int k = 0; k < nv; k++) d->efc_J[(size_t)r * nv + k] = -side * d->ten_J[(size_t)t * nv + k];
+      }
+    }
+  }
+  d->nl = d->nefc - d->nf;
+  /* contacts (pyramidal cones) */
+  double* jbuf = (double*)malloc(12 * nv * sizeof(double));
+  double *jp1 = jbuf, *jr1 = jbuf + 3 * nv, *jp2 = jbuf + 6 * nv, *jr2 = jbuf + 9 * nv;
+  for (int ci = 0; ci < d->ncon; ci++) {
+    ro_contact* c = &d->contact[ci];
+    c->efc_address = -1;
+    if (m->cone != 0) { fprintf(stderr, "rg_oracle: elliptic cones not implemented\n"); abort(); }
+    int b1 = m->geom_bodyid[c->geom1], b2 = m->geom_bodyid[c->geom2];
+    ro_jac(m, d, jp1, jr1, c->pos, b1); ro_jac(m, d, jp2, jr2, c->pos, b2);
+    /* contact-frame Jacobian rows: 3 translational then 3 rotational, difference body2 - body1 */
+    double* Jc = (double*)malloc(6 * nv * sizeof(double));
+    for (int r = 0; r < 3; r++)
+      for (int k = 0; k < nv; k++) {
+        Jc[r * nv + k] = c->frame[3 * r] * (jp2[k] - jp1[k]) + c->frame[3 * r + 1] * (jp2[nv + k] - jp1[nv + k]) + c->frame[3 * r + 2] * (jp2[2 * nv + k] - jp1[2 * nv + k]);
+        Jc[(3 + r) * nv + k] = c->frame[3 * r] * (jr2[k] - jr1[k]) + c->frame[3 * r + 1] * (jr2[nv + k] - jr1[nv + k]) + c->frame[3 * r + 2] * (jr2[2 * nv + k] - jr1[2 * nv + k]);
+      }
+    double tran = m->body_invweight0[2 * b1] + m->body_invweight0[2 * b2];
+    double rot = m->body_invweight0[2 * b1 + 1] + m->body_invweight0[2 * b2 + 1];
+    if (c->dim == 1) {
+      int r = add_row(m, d, EFC_CONTACT_PYRAMIDAL, ci, c->dist, c->includemargin, 0, tran);
+      if (r >= 0) { memcpy(d->efc_J + (size_t)r * nv, Jc, nv * sizeof(double)); c->efc_address = r; }
+    } else {
+      for (int k = 0; k < c->dim - 1; k++) {
+        double fri = c->friction[k], diag = tran + fri * fri * (k < 2 ? tran : rot);
+        for (int s = 1; s >= -1; s -= 2) {
+          int r = add_row(m, d, EFC_CONTACT_PYRAMIDAL, ci, c->dist, c->includemargin, 0, diag);
+          if (r < 0) continue;
+          if (c->efc_address < 0) c->efc_address = r;
+          for (int i = 0; i < nv; i++) d->efc_J[(size_t)r * nv + i] = Jc[i] + s * fri * Jc[(k + 1) * nv + i];
+        }
+      }
+    }
+    free(Jc);
+  }
+  free(jbuf);
+}
+
+static void ro_make_impedance(const ro_model* m, ro_data* d) {
+  int nv = m->nv;
+  for (int r = 0; r < d->nefc; r++) {
+    const double *solref, *solimp;
+    int id = d->efc_id[r], type = d->efc_type[r];
+    switch (type) {
+      case EFC_FRICTION_DOF: solref = m->dof_solref + 2 * id; solimp = m->dof_solimp + 5 * id; break;
+      case EFC_FRICTION_TENDON: solref = m->tendon_solref_fri + 2 * id; solimp = m->tendon_solimp_fri + 5 * id; break;
+      case EFC_LIMIT_JOINT: solref = m->jnt_solref + 2 * id; solimp = m->jnt_solimp + 5 * id; break;
+      case EFC_LIMIT_TENDON: solref = m->tendon_solref_lim + 2 * id; solimp = m->tendon_solimp_lim + 5 * id; break;
+      default: solref = d->contact[id].solref; solimp = d->contact[id].solimp; break;
+    }
+    double imp = get_impedance(solimp, d->efc_pos[r], d->efc_margin[r]);
+    d->efc_R[r] = fmax(MINVAL, (1 - imp) * d->efc_diagApprox[r] / imp);
+    double dmax = clampd(solimp[1], 1e-4, 0.9999), K, B;
+    if (solref[0] > 0) {
+      double tc = fmax(solref[0], 2 * m->timestep), dr = solref[1];
+      K = 1 / fmax(MINVAL, dmax * dmax * tc * tc * dr * dr); B = 2 / fmax(MINVAL, dmax * tc);
+    } else { K = -solref[0] / fmax(MINVAL, dmax * dmax); B = -solref[1] / fmax(MINVAL, dmax); }
+    if (type == EFC_FRICTION_DOF || type == EFC_FRICTION_TENDON) K = 0;
+    d->efc_KBIP[4 * r] = K; d->efc_KBIP[4 * r + 1] = B; d->efc_KBIP[4 * r + 2] = imp; d->efc_KBIP[4 * r + 3] = 0;
+  }
+  /* pyramidal contacts: all rows share R = 2 mu^2 R_first */
+  for (int ci = 0; ci < d->ncon; ci++) {
+    ro_contact* c = &d->contact[ci];
+    if (c->efc_address < 0 || c->dim == 1) continue;
+    c->mu = c->friction[0] * sqrt(1 / m->impratio);
+    double Rpy = 2 * c->mu * c->mu * d->efc_R[c->efc_address];
+    for (int k = 0; k < 2 * (c->dim - 1) && c->efc_address + k < d->nefc; k++) d->efc_R[c->efc_address + k] = Rpy;
+  }
+  for (int r = 0; r < d->nefc; r++) {
+    d->efc_D[r] = 1 / d->efc_R[r];
+    double v = 0; const double* J = d->efc_J + (size_t)r * nv;
+    for (int k = 0; k < nv; k++) v += J[k] * d->qvel[k];
+    d->efc_vel[r] = v;
+    d->efc_aref[r] = -d->efc_KBIP[4 * r + 1] * v - d->efc_KBIP[4 * r] * d->efc_KBIP[4 * r + 2] * (d->efc_pos[r] - d->efc_margin[r]);
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ velocity stage
+ * engine_core_smooth.c: mj_comVel, mj_passive, mj_rne */
+static void ro_fwd_velocity(const ro_model* m, ro_data* d) {
+  int nv = m->nv, nb = m->nbody;
+  for (int t = 0; t < m->ntendon; t++) {
+    double v = 0; for (int k = 0; k < nv; k++) v += d->ten_J[(size_t)t * nv + k] * d->qvel[k];
+    d->ten_velocity[t] = v;
+  }
+  for (int i = 0; i < m->nu; i++) {
+    double v = 0; for (int k = 0; k < nv; k++) v += d->actuator_moment[(size_t)i * nv + k] * d->qvel[k];
+    d->actuator_velocity[i] = v;
+  }
+  memset(d->cvel, 0, 6 * sizeof(double));
+  for (int b = 1; b < nb; b++) {
+    double cv[6]; memcpy(cv, d->cvel + 6 * m->body_parentid[b], sizeof cv);
+    for (int k = 0; k < m->body_jntnum[b]; k++) {
+      int j = m->body_jntadr[b] + k, da = m->jnt_dofadr[j], t = m->jnt_type[j];
+      if (t == JNT_FREE) {
+        for (int i = 0; i < 3; i++) { memset(d->cdof_dot + 6 * (da + i), 0, 6 * sizeof(double)); for (int c = 0; c < 6; c++) cv[c] += d->cdof[6 * (da + i) + c] * d->qvel[da + i]; }
+        da += 3;
+      }
+      if (t == JNT_FREE || t == JNT_BALL) {
+        for (int i = 0; i < 3; i++) cross_motion(d->cdof_dot + 6 * (da + i), cv, d->cdof + 6 * (da + i));
+        for (int i = 0; i < 3; i++) for (int c = 0; c < 6; c++) cv[c] += d->cdof[6 * (da + i) + c] * d->qvel[da + i];
+      } else {
+        cross_motion(d->cdof_dot + 6 * da, cv, d->cdof + 6 * da);
+        for (int c = 0; c < 6; c++) cv[c] += d->cdof[6 * da + c] * d->qvel[da];
+      }
+    }
+    memcpy(d->cvel + 6 * b, cv, sizeof cv);
+  }
+  /* passive: joint springs, dof damping, tendon spring-dampers */
+  memset(d->qfrc_passive, 0, nv * sizeof(double));
+  for (int j = 0; j < m->njnt; j++) {
+    double k = m->jnt_stiffness[j];
+    if (k == 0) continue;
+    int t = m->jnt_type[j], qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+    if (t == JNT_HINGE || t == JNT_SLIDE) d->qfrc_passive[da] -= k * (d->qpos[qa] - m->qpos_spring[qa]);
+    else { fprintf(stderr, "rg_oracle: ball/free joint springs not implemented\n"); abort(); }
+  }
+  for (int i = 0; i < nv; i++) d->qfrc_passive[i] -= m->dof_damping[i] * d->qvel[i];
+  for (int t = 0; t < m->ntendon; t++) {
+    double f = m->tendon_stiffness[t] * (m->tendon_lengthspring[t] - d->ten_length[t]) - m->tendon_damping[t] * d->ten_velocity[t];
+    if (f != 0) for (int k = 0; k < nv; k++) d->qfrc_passive[k] += d->ten_J[(size_t)t * nv + k] * f;
+  }
+  /* RNE with zero acceleration: Coriolis, centrifugal and gravity */
+  double* cacc = (double*)calloc(6 * nb, sizeof(double));
+  double* cfrc = (double*)calloc(6 * nb, sizeof(double));
+  cacc[3] = -m->gravity[0]; cacc[4] = -m->gravity[1]; cacc[5] = -m->gravity[2];
+  for (int b = 1; b < nb; b++) {
+    double* a = cacc + 6 * b; memcpy(a, cacc + 6 * m->body_parentid[b], 6 * sizeof(double));
+    for (int k = 0; k < m->body_dofnum[b]; k++) { int i = m->body_dofadr[b] + k; for (int c = 0; c < 6; c++) a[c] += d->cdof_dot[6 * i + c] * d->qvel[i]; }
+    double t1[6], t2[6], t3[6];
+    mul_inert_vec(t1, d->cinert + 10 * b, a);
+    mul_inert_vec(t2, d->cinert + 10 * b, d->cvel + 6 * b);
+    cross_force(t3, d->cvel + 6 * b, t2);
+    for (int c = 0; c < 6; c++) cfrc[6 * b + c] = t1[c] + t3[c];
+  }
+  for (int b = nb - 1; b > 0; b--) { int p = m->body_parentid[b]; if (p > 0) for (int c = 0; c < 6; c++) cfrc[6 * p + c] += cfrc[6 * b + c]; }
+  for (int i = 0; i < nv; i++) {
+    const double *c = d->cdof + 6 * i, *f = cfrc + 6 * m->dof_bodyid[i];
+    d->qfrc_bias[i] = c[0] * f[0] + c[1] * f[1] + c[2] * f[2] + c[3] * f[3] + c[4] * f[4] + c[5] * f[5];
+  }
+  free(cacc); free(cfrc);
+}
+
+/* ------------------------------------------------------------------------------------------ actuation
+ * engine_forward.c: mj_fwdActuation with mujoco-py's mjpid.pyx callbacks (gain = 0, bias = PID force).
+ * gainprm = [kp, ti, iclamp, td, dsmooth, deadband] (/root/reference/robogym/mujoco/constants.py:35-52,
+ * robot/shadow_hand/mujoco/parameter_manager.py:23-47).  Controller state per actuator:
+ * {integral error, last error, last smoothed derivative}.  The callback runs in EVERY mj_forward,
+ * including the three state-less forward() calls the reference makes per env step. */
+static void ro_fwd_actuation(const ro_model* m, ro_data* d) {
+  int nv = m->nv;
+  double dt = m->timestep;
+  memset(d->qfrc_actuator, 0, nv * sizeof(double));
+  for (int i = 0; i < m->nu; i++) {
+    const double* gp = m->actuator_gainprm + 10 * i;
+    double force;
+    if (m->actuator_biastype[i] == 2) {
+      double kp = gp[0], ti = gp[1], iclamp = gp[2], td = gp[3], smooth = gp[4], deadband = gp[5];
+      double err = d->ctrl[i] - d->actuator_length[i];
+      if (fabs(err) < deadband) err = 0;
+      double* st = d->pid + 3 * i;
+      double integ = clampd(st[0] + err * dt, -iclamp, iclamp);
+      double deriv = (1 - smooth) * st[2] + smooth * (err - st[1]) / dt;
+      force = kp * (err + (ti != 0 ? integ / ti : 0) + td * deriv);
+      st[0] = integ; st[1] = err; st[2] = deriv;
+      double lo = m->actuator_forcerange[2 * i], hi = m->actuator_forcerange[2 * i + 1];
+      if (lo != 0 || hi != 0) force = clampd(force, lo, hi);
+    } else {
+      double ctrl = d->ctrl[i];
+      if (m->actuator_ctrllimited[i]) ctrl = clampd(ctrl, m->actuator_ctrlrange[2 * i], m->actuator_ctrlrange[2 * i + 1]);
+      const double* bp = m->actuator_biasprm + 10 * i;
+      force = gp[0] * ctrl + (m->actuator_biastype[i] == 1 ? bp[0] + bp[1] * d->actuator_length[i] + bp[2] * d->actuator_velocity[i] : 0);
+    }
+    if (m->actuator_forcelimited[i]) force = clampd(force, m->actuator_forcerange[2 * i], m->actuator_forcerange[2 * i + 1]);
+    d->actuator_force[i] = force;
+    for (int k = 0; k < nv; k++) d->qfrc_actuator[k] += d->actuator_moment[(size_t)i * nv + k] * force;
+  }
+}
+
+/* engine_forward.c: mj_fwdAcceleration */
+static void ro_fwd_acceleration(const ro_model* m, ro_data* d) {
+  int nv = m->nv;
+  for (int i = 0; i < nv; i++) d->qfrc_smooth[i] = d->qfrc_passive[i] - d->qfrc_bias[i] + d->qfrc_actuator[i];
+  memcpy(d->qacc_smooth, d->qfrc_smooth, nv * sizeof(double));
+  chol_solve(d->qL, d->qacc_smooth, nv);
+}
+
+/* ------------------------------------------------------------------------------------------ solver
+ * engine_solver.c: mj_solNewton — primal Newton on
+ *     cost(a) = 1/2 (a - a_s)' M (a - a_s) + sum_i s_i(J_i a - aref_i)
+ * with exact line search.  (MuJoCo updates the Cholesky factor incrementally; refactoring each
+ * iteration gives the same iterates.) */
+typedef struct { double cost, grad, hess; } ls_pt;
+
+static void constraint_update(const ro_model* m, const ro_data* d, const double* jar, double* force, int* active, double* cost) {
+  double c = 0;
+  for (int r = 0; r < d->nefc; r++) {
+    double D = d->efc_D[r], R = d->efc_R[r], x = jar[r];
+    int type = d->efc_type[r];
+    if (type == EFC_FRICTION_DOF || type == EFC_FRICTION_TENDON) {
+      double f = d->efc_frictionloss[r];
+      if (x <= -R * f) { force[r] = f; active[r] = 0; c += f * (-0.5 * R * f - x); }
+      else if (x >= R * f) { force[r] = -f; active[r] = 0; c += f * (-0.5 * R * f + x); }
+      else { force[r] = -D * x; active[r] = 1; c += 0.5 * D * x * x; }
+    } else {
+      if (x >= 0) { force[r] = 0; active[r] = 0; }
+      else { force[r] = -D * x; active[r] = 1; c += 0.5 * D * x * x; }
+    }
+  }
+  *cost = c;
+}
+static ls_pt ls_eval(const ro_data* d, double alpha, const double* jar, const double* jv, const double* quadGauss) {
+  ls_pt p = {alpha * alpha * quadGauss[2] + alpha * quadGauss[1] + quadGauss[0], 2 * alpha * quadGauss[2] + quadGauss[1], 2 * quadGauss[2]};
+  for (int r = 0; r < d->nefc; r++) {
+    double D = d->efc_D[r], R = d->efc_R[r], x = jar[r] + alpha * jv[r];
+    int type = d->efc_type[r];
+    if (type == EFC_FRICTION_DOF || type == EFC_FRICTION_TENDON) {
+      double f = d->efc_frictionloss[r];
+      if (x <= -R * f) { p.cost += f * (-0.5 * R * f - x); p.grad += -f * jv[r]; }
+      else if (x >= R * f) { p.cost += f * (-0.5 * R * f + x); p.grad += f * jv[r]; }
+      else { p.cost += 0.5 * D * x * x; p.grad += D * x * jv[r]; p.hess += D * jv[r] * jv[r]; }
+    } else if (x < 0) { p.cost += 0.5 * D * x * x; p.grad += D * x * jv[r]; p.hess += D * jv[r] * jv[r]; }
+  }
+  return p;
+}
+/* exact minimiser of the convex piecewise-quadratic 1-D restriction: safeguarded Newton on its derivative */
+static double line_search(const ro_data* d, const double* jar, const double* jv, const double* quadGauss, double gtol, int maxit) {
+  ls_pt p0 = ls_eval(d, 0, jar, jv, quadGauss);
+  if (p0.grad >= 0 || p0.hess <= 0) return 0;
+  double lo = 0, hi = -1, glo = p0.grad, hlo = p0.hess, ghi = 0, hhi = 0;
+  double a = -p0.grad / p0.hess;
+  for (int it = 0; it < maxit; it++) {
+    ls_pt p = ls_eval(d, a, jar, jv, quadGauss);
+    if (fabs(p.grad) < gtol) return a;
+    if (p.grad < 0) { lo = a; glo = p.grad; hlo = p.hess; } else { hi = a; ghi = p.grad; hhi = p.hess; }
+    double cand = lo - glo / hlo;               /* Newton step from the left end (derivative is convex-monotone) */
+    if (hi >= 0 && !(cand > lo && cand < hi)) { /* fall back: Newton from the right end, then bisection */
+      cand = hi - ghi / hhi;
+      if (!(cand > lo && cand < hi)) cand = 0.5 * (lo + hi);
+    }
+    if (cand == a) return a;
+    a = cand;
+  }
+  return a;
+}
+
+static void ro_solve(const ro_model* m, ro_data* d) {
+  int nv = m->nv, ne = d->nefc;
+  memset(d->qfrc_constraint, 0, nv * sizeof(double));
+  d->solver_iter = 0;
+  if (ne == 0) { memcpy(d->qacc, d->qacc_smooth, nv * sizeof(double)); return; }
+  double *jar = dalloc(ne), *jv = dalloc(ne), *force = dalloc(ne), *Ma = dalloc(nv), *grad = dalloc(nv), *search = dalloc(nv),
+         *Mv = dalloc(nv), *H = dalloc((size_t)nv * nv), *Lh = dalloc((size_t)nv * nv), *qa = dalloc(nv);
+  int* active = (int*)calloc(ne, sizeof(int));
+  double scale = 1.0 / (m->meaninertia * (nv > 1 ? nv : 1));
+  /* warm start: pick the better of qacc_warmstart and qacc_smooth */
+  double cost_ws, cost_sm;
+  for (int pass = 0; pass < 2; pass++) {
+    const double* a = pass == 0 ? d->qacc_warmstart : d->qacc_smooth;
+    double g = 0;
+    for (int i = 0; i < nv; i++) { double s = 0; for (int k = 0; k < nv; k++) s += d->qM[i * nv + k] * a[k]; Ma[i] = s; }
+    for (int i = 0; i < nv; i++) g += 0.5 * (Ma[i] - d->qfrc_smooth[i]) * (a[i] - d->qacc_smooth[i]);
+    for (int r = 0; r < ne; r++) { double s = 0; for (int k = 0; k < nv; k++) s += d->efc_J[(size_t)r * nv + k] * a[k]; jar[r] = s - d->efc_aref[r]; }
+    double c; constraint_update(m, d, jar, force, active, &c);
+    if (pass == 0) cost_ws = g + c; else cost_sm = g + c;
+  }
+  memcpy(qa, cost_ws < cost_sm ? d->qacc_warmstart : d->qacc_smooth, nv * sizeof(double));
+  double cost = 0, oldcost;
+  for (int iter = 0;; iter++) {
+    /* Ma, jar, cost, gradient */
+    for (int i = 0; i < nv; i++) { double s = 0; for (int k = 0; k < nv; k++) s += d->qM[i * nv + k] * qa[k]; Ma[i] = s; }
+    for (int r = 0; r < ne; r++) { double s = 0; for (int k = 0; k < nv; k++) s += d->efc_J[(size_t)r * nv + k] * qa[k]; jar[r] = s - d->efc_aref[r]; }
+    double cc; constraint_update(m, d, jar, force, active, &cc);
+    double gauss = 0;
+    for (int i = 0; i < nv; i++) gauss += 0.5 * (Ma[i] - d->qfrc_smooth[i]) * (qa[i] - d->qacc_smooth[i]);
+    oldcost = cost; cost = gauss + cc;
+    for (int i = 0; i < nv; i++) { double s = Ma[i] - d->qfrc_smooth[i]; for (int r = 0; r < ne; r++) s -= d->efc_J[(size_t)r * nv + i] * force[r]; grad[i] = s; }
+    double gn = 0; for (int i = 0; i < nv; i++) gn += grad[i] * grad[i];
+    gn = sqrt(gn) * scale;
+    if (iter > 0) { double improvement = scale * (oldcost - cost); if (improvement < m->tolerance) break; }
+    if (gn < m->tolerance || iter >= m->iterations) break;
+    d->solver_iter = iter + 1;
+    /* Hessian H = M + J' diag(D_active) J */
+    memcpy(H, d->qM, (size_t)nv * nv * sizeof(double));
+    for (int r = 0; r < ne; r++) {
+      if (!active[r]) continue;
+      const double* J = d->efc_J + (size_t)r * nv; double D = d->efc_D[r];
+      for (int i = 0; i < nv; i++) { if (J[i] == 0) continue; double di = D * J[i]; for (int k = 0; k < nv; k++) H[i * nv + k] += di * J[k]; }
+    }
+    if (cholesky(Lh, H, nv) != 0) { d->warn_bad |= 2; break; }
+    for (int i = 0; i < nv; i++) search[i] = -grad[i];
+    chol_solve(Lh, search, nv);
+    /* line search */
+    for (int i = 0; i < nv; i++) { double s = 0; for (int k = 0; k < nv; k++) s += d->qM[i * nv + k] * search[k]; Mv[i] = s; }
+    for (int r = 0; r < ne; r++) { double s = 0; for (int k = 0; k < nv; k++) s += d->efc_J[(size_t)r * nv + k] * search[k]; jv[r] = s; }
+    double quadGauss[3] = {gauss, 0, 0};
+    for (int i = 0; i < nv; i++) { quadGauss[1] += search[i] * (Ma[i] - d->qfrc_smooth[i]); quadGauss[2] += 0.5 * search[i] * Mv[i]; }
+    double snorm = 0; for (int i = 0; i < nv; i++) snorm += search[i] * search[i];
+    snorm = sqrt(snorm);
+    if (snorm < MINVAL) break;
+    double gtol = m->tolerance * m->ls_tolerance * snorm / scale * 1e-3; /* much tighter than MuJoCo's: "exact" */
+    double alpha = line_search(d, jar, jv, quadGauss, gtol, 60);
+    if (alpha == 0) break;
+    for (int i = 0; i < nv; i++) qa[i] += alpha * search[i];
+  }
+  /* final forces at the solution */
+  for (int r = 0; r < ne; r++) { double s = 0; for (int k = 0; k < nv; k++) s += d->efc_J[(size_t)r * nv + k] * qa[k]; jar[r] = s - d->efc_aref[r]; }
+  double cc; constraint_update(m, d, jar, force, active, &cc);
+  memcpy(d->efc_force, force, ne * sizeof(double));
+  memcpy(d->qacc, qa, nv * sizeof(double));
+  for (int r = 0; r < ne; r++) for (int k = 0; k < nv; k++) d->qfrc_constraint[k] += d->efc_J[(size_t)r * nv + k] * force[r];
+  free(jar); free(jv); free(force); free(Ma); free(grad); free(search); free(Mv); free(H); free(Lh); free(qa); free(active);
+}
+
+/* ------------------------------------------------------------------------------------------ forward / step */
+void ro_fwd_position(const ro_model* m, ro_data* d) {
+  ro_kinematics(m, d); ro_com_pos(m, d); ro_tendon(m, d); ro_transmission(m, d); ro_crb(m, d);
+  ro_collision(m, d); ro_make_constraint(m, d);
+}
+void ro_forward(const ro_model* m, ro_data* d) {
+  ro_fwd_position(m, d);
+  ro_fwd_velocity(m, d);
+  ro_make_impedance(m, d); /* needs efc_vel: reference acceleration */
+  ro_fwd_actuation(m, d);
+  ro_fwd_acceleration(m, d);
+  ro_solve(m, d);
+}
+static int bad(const double* x, int n) { for (int i = 0; i < n; i++) if (!(fabs(x[i]) < 1e10)) return 1; return 0; }
+
+/* engine_forward.c: mj_step with the Euler integrator (implicit in joint damping), mj_Euler / mj_advance */
+void ro_step(const ro_model* m, ro_data* d) {
+  int nv = m->nv;
+  if (bad(d->qpos, m->nq) || bad(d->qvel, nv)) { d->warn_bad |= 4; return; }
+  ro_forward(m, d);
+  if (bad(d->qacc, nv)) { d->warn_bad |= 8; return; }
+  d->stat_ncon += d->ncon; d->stat_nefc += d->nefc; d->stat_iter += d->solver_iter; d->stat_steps++;
+  double* qacc = dalloc(nv);
+  int damped = 0;
+  for (int i = 0; i < nv; i++) if (m->dof_damping[i] > 0) damped = 1;
+  if (!damped) memcpy(qacc, d->qacc, nv * sizeof(double));
+  else {
+    double *H = dalloc((size_t)nv * nv), *L = dalloc((size_t)nv * nv);
+    memcpy(H, d->qM, (size_t)nv * nv * sizeof(double));
+    for (int i = 0; i < nv; i++) { H[i * nv + i] += m->timestep * m->dof_damping[i]; qacc[i] = d->qfrc_smooth[i] + d->qfrc_constraint[i]; }
+    cholesky(L, H, nv); chol_solve(L, qacc, nv);
+    free(H); free(L);
+  }
+  double h = m->timestep;
+  for (int i = 0; i < nv; i++) d->qvel[i] += h * qacc[i];
+  for (int j = 0; j < m->njnt; j++) {
+    int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j], t = m->jnt_type[j];
+    if (t == JNT_FREE) { for (int k = 0; k < 3; k++) d->qpos[qa + k] += h * d->qvel[da + k]; qa += 3; da += 3; }
+    if (t == JNT_FREE || t == JNT_BALL) {
+      double w[3] = {d->qvel[da], d->qvel[da + 1], d->qvel[da + 2]}, ang = norm3(w) * h;
+      if (ang > 0) {
+        double q[4], qn[4]; normalize3(w); axisangle2quat(q, w, ang);
+        mulquat(qn, d->qpos + qa, q); normalize4(qn); memcpy(d->qpos + qa, qn, sizeof qn);
+      }
+    } else d->qpos[qa] += h * d->qvel[da];
+  }
+  d->time += h;
+  memcpy(d->qacc_warmstart, d->qacc, nv * sizeof(double));
+  free(qacc);
+}
+
+/* SimulationInterface.step (simulation_interface.py:176-189): nsubsteps x mj_step, then mj_forward */
+void ro_sim_step(const ro_model* m, ro_data* d, int nsubsteps) {
+  for (int i = 0; i < nsubsteps; i++) ro_step(m, d);
+  ro_forward(m, d);
+}
+
+/* ------------------------------------------------------------------------------------------ accessors */
+#define FIELD(name, cnt) if (strcmp(field, #name) == 0) { *n = (cnt); return d->name; }
+double* ro_field(const ro_model* m, ro_data* d, const char* field, int* n) {
+  int nv = m->nv, nb = m->nbody;
+  FIELD(qpos, m->nq) FIELD(qvel, nv) FIELD(ctrl, m->nu) FIELD(pid, 3 * m->nu) FIELD(qacc_warmstart, nv)
+  FIELD(xpos, 3 * nb) FIELD(xquat, 4 * nb) FIELD(xmat, 9 * nb) FIELD(xipos, 3 * nb) FIELD(ximat, 9 * nb)
+  FIELD(xanchor, 3 * m->njnt) FIELD(xaxis, 3 * m->njnt) FIELD(geom_xpos, 3 * m->ngeom) FIELD(geom_xmat, 9 * m->ngeom)
+  FIELD(site_xpos, 3 * m->nsite) FIELD(site_xmat, 9 * m->nsite) FIELD(subtree_com, 3 * nb) FIELD(cinert, 10 * nb)
+  FIELD(cdof, 6 * nv) FIELD(ten_length, m->ntendon) FIELD(ten_J, m->ntendon * nv) FIELD(actuator_length, m->nu)
+  FIELD(actuator_moment, m->nu * nv) FIELD(qM, nv * nv) FIELD(efc_J, d->nefc * nv) FIELD(efc_pos, d->nefc)
+  FIELD(efc_margin, d->nefc) FIELD(efc_R, d->nefc) FIELD(efc_D, d->nefc) FIELD(efc_aref, d->nefc) FIELD(efc_force, d->nefc)
+  FIELD(efc_vel, d->nefc) FIELD(efc_frictionloss, d->nefc) FIELD(efc_diagApprox, d->nefc)
+  FIELD(ten_velocity, m->ntendon) FIELD(actuator_velocity, m->nu) FIELD(cvel, 6 * nb) FIELD(cdof_dot, 6 * nv)
+  FIELD(qfrc_passive, nv) FIELD(qfrc_bias, nv) FIELD(actuator_force, m->nu) FIELD(qfrc_actuator, nv) FIELD(qfrc_smooth, nv)
+  FIELD(qacc_smooth, nv) FIELD(qfrc_constraint, nv) FIELD(qacc, nv)
+  *n = 0;
+  return NULL;
+}
+int ro_int(const ro_model* m, const ro_data* d, const char* field) {
+  (void)m;
+  if (!strcmp(field, "ncon")) return d->ncon;
+  if (!strcmp(field, "nefc")) return d->nefc;
+  if (!strcmp(field, "nf")) return d->nf;
+  if (!strcmp(field, "nl")) return d->nl;
+  if (!strcmp(field, "solver_iter")) return d->solver_iter;
+  if (!strcmp(field, "warn_bad")) return d->warn_bad;
+  if (!strcmp(field, "warn_contact_full")) return d->warn_contact_full;
+  if (!strcmp(field, "warn_efc_full")) return d->warn_efc_full;
+  return -1;
+}
+int* ro_efc_type(ro_data* d) { return d->efc_type; }
+double ro_time(const ro_data* d) { return d->time; }
+void ro_set_time(ro_data* d, double t) { d->time = t; }
+/* contact i -> out[0..]: dist, pos3, frame9, includemargin, friction5, dim, geom1, geom2, efc_address  (23 doubles) */
+void ro_contact_get(const ro_data* d, int i, double* out) {
+  const ro_contact* c = &d->contact[i];
+  out[0] = c->dist; memcpy(out + 1, c->pos, 24); memcpy(out + 4, c->frame, 72); out[13] = c->includemargin;
+  memcpy(out + 14, c->friction, 40); out[19] = c->dim; out[20] = c->geom1; out[21] = c->geom2; out[22] = c->efc_address;
+}
+void ro_stats(const ro_data* d, double* out) {
+  double n = d->stat_steps > 0 ? (double)d->stat_steps : 1;
+  out[0] = d->stat_ncon / n; out[1] = d->stat_nefc / n; out[2] = d->stat_iter / n; out[3] = (double)d->stat_steps;
+  out[4] = d->stat_mpr_calls / n; out[5] = d->stat_mpr_iter / n;
+}
+void ro_stats_reset(ro_data* d) { d->stat_ncon = d->stat_nefc = d->stat_iter = d->stat_steps = d->stat_mpr_calls = d->stat_mpr_iter = 0; }
+/* standalone MPR call between two geoms of the current configuration (for collision unit tests) */
+int ro_mpr_pair(const ro_model* m, ro_data* d, int g1, int g2, double margin, double* out /* depth, dir3, pos3 */) {
+  ccd_obj o1 = {m, d, g1, 0.5 * margin}, o2 = {m, d, g2, 0.5 * margin};
+  return mpr_penetration(&o1, &o2, m->mpr_iterations, m->mpr_tolerance, out, out + 1, out + 4, NULL);
+}
