@@ -1,0 +1,100 @@
+/*
+ * rgstep.h — C ABI of the MI355X-native batched physics stepper ("librgstep").
+ *
+ * The reference (openai/robogym) has no FFI of its own: its seam to native code is class
+ * substitution around a mujoco_py.MjSim (robogym/mujoco/mujoco_xml.py:249-260 builds it,
+ * robogym/mujoco/simulation_interface.py:25-250 wraps it).  Each entry point below names the
+ * reference interface it replaces.  All pointers are plain C pointers; `*_dev` arguments are
+ * device (HBM) addresses, e.g. torch.Tensor.data_ptr().  No torch types cross this boundary.
+ *
+ * Ownership: the library owns models and batches (state rows live in HBM inside the batch);
+ * callers own the I/O buffers they pass in.  Errors: negative return codes + rg_last_error().
+ * Per-env problems (NaN state, contact/row overflow) are sticky status bits (rg_batch_copy with
+ * RG_F_STATUS), replacing MuJoCo's process-global warning callback
+ * (robogym/mujoco/warning_buffer.py:27-83).  Threading: a batch may be used from one thread at a
+ * time; work is asynchronous on the HIP stream passed to rg_batch_step.
+ */
+#ifndef RGSTEP_H
+#define RGSTEP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rg_model rg_model;
+typedef struct rg_batch rg_batch;
+
+/* state / diagnostic fields addressable through rg_batch_copy */
+enum {
+  RG_F_QPOS = 0,      /* float [B][nq]     sim.data.qpos  (simulation_interface.py:128-150 get/set_qpos)   */
+  RG_F_QVEL = 1,      /* float [B][nv]     sim.data.qvel                                                   */
+  RG_F_CTRL = 2,      /* float [B][nu]     sim.data.ctrl  (mujoco_shadow_hand.py:120-137)                  */
+  RG_F_PID = 3,       /* float [B][3*nu]   sim.data.userdata slice used by mjpid (integral, last error, last derivative) */
+  RG_F_WARMSTART = 4, /* float [B][nv]     sim.data.qacc_warmstart                                         */
+  RG_F_TIME = 5,      /* float [B]         sim.data.time                                                   */
+  RG_F_STATUS = 6,    /* uint32 [B]        sticky per-env status bits (RG_STATUS_*)                        */
+  RG_F_STATS = 7,     /* float [B][4]      accumulated ncon, nefc, Newton iterations, substeps             */
+  RG_F_DEBUG = 8      /* float [B][rg_debug_size()] stage dump of the first substep (flags & 1)            */
+};
+
+#define RG_STATUS_BAD_STATE 1u
+#define RG_STATUS_CON_FULL 2u
+#define RG_STATUS_CAND_FULL 4u
+#define RG_STATUS_ROW_FULL 8u
+#define RG_STATUS_BAD_FACTOR 16u
+
+/* Replaces mujoco_py.load_model_from_xml (mujoco_xml.py:259): `blob` is the "RGMODEL1" flat model
+ * produced by the host-side MJCF compiler (robogym_amd/mujoco/model_blob.py). Returns NULL on error. */
+rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen);
+void rg_model_free(rg_model* m);
+/* sizes: out[0..4] = nq, nv, nu, nbody, nsite */
+int rg_model_dims(const rg_model* m, int* out);
+
+/* Replaces constructing B independent MjSim objects (robot_env.py:328-350: one env <-> one sim).
+ * State is initialised as MjSim.reset() would (qpos0, zeros). `device` is the HIP device ordinal. */
+rg_batch* rg_batch_create(const rg_model* m, int B, int device);
+void rg_batch_free(rg_batch* b);
+
+/* Task description for the dactyl cube-in-hand family: which qpos slices / sites feed the action
+ * map and the observation row (robot_env.py:497-504, robot_interface.py:247-278,
+ * hand_interface.py:245-266 and 399-405, envs/dactyl/observation/ *.py).
+ * ints[16]: hand_qposadr, n_hand_jnt, cube_pos_qposadr, cube_quat_qposadr, target_qposadr, target_nq,
+ *           target_dofadr, target_nv, cube_body, ref_site[3], tip_site[5] (=19 ints), relative_action
+ * pos_to_ctrl: host float [nu][n_hand_jnt]. */
+int rg_batch_set_env(rg_batch* b, const int* ints, int nints, const float* pos_to_ctrl_host, float success_threshold);
+
+/* MjSim.reset / set_state / get_state (simulation_interface.py:154-172,191-197).
+ * to_batch != 0 copies ptr -> batch field, else batch field -> ptr; ptr_is_device selects HBM vs host. */
+int rg_batch_copy(rg_batch* b, int field, void* ptr, int to_batch, int ptr_is_device);
+int rg_batch_reset(rg_batch* b);
+
+/* One env.step of the whole batch (robot_env.py:804-844 + simulation_interface.py:176-189):
+ *   action_dev   float [B][nu] in [-1,1] or NULL (then the stored ctrl row is used unchanged)
+ *   goal_quat_dev float [B][4] or NULL
+ *   obs_dev      float [B][rg_obs_dim] or NULL:  cube_pos3 cube_quat4 qpos[nq] qvel[nv] hand_angle[nh] fingertip_pos15
+ *   goal_dist_dev float [B] or NULL
+ *   active_dev   int [B] or NULL: envs whose entry is 0 are left untouched by this call (masked
+ *                resets, per-env goal resets; the reference simply does not call step on those envs)
+ *   nsubsteps    mj_step calls (MjSim.nsubsteps, mujoco_xml.py:249-260 / robot_env.py:132)
+ *   nforward_ticks number of state-less mj_forward calls the reference makes afterwards (3 per env.step)
+ *   flags        bit0: write the RG_F_DEBUG stage dump of the first substep
+ *   stream       hipStream_t (NULL = default stream).  Asynchronous. */
+int rg_batch_step(rg_batch* b, const float* action_dev, const float* goal_quat_dev, float* obs_dev, float* goal_dist_dev,
+                  const int* active_dev, int nsubsteps, int nforward_ticks, int flags, void* stream);
+/* Collision unit-test hook (no reference counterpart; mjc_Convex is internal to MuJoCo): runs the
+ * kinematics of every env's stored qpos and one MPR penetration query between geoms g1, g2 inflated
+ * by margin/2 each.  out_dev float [B][8] = hit, depth, direction3 (g1 -> g2), position3. */
+int rg_batch_mpr_pair(rg_batch* b, int g1, int g2, float margin, float* out_dev, void* stream);
+int rg_obs_dim(const rg_batch* b);
+int rg_debug_size(void);
+/* bytes of LDS one env occupies (diagnostic) */
+int rg_lds_bytes(void);
+int rg_sync(void* stream);
+const char* rg_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

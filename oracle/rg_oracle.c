@@ -685,6 +685,8 @@ static double origin_tri_dist2(const double* a, const double* b, const double* c
   copy3(w, a); addscl3(w, ab, v); addscl3(w, ac, u);
   return dot3(w, w);
 }
+static int ro_mpr_libccd_tridist = 0;
+void ro_set_mpr_libccd_tridist(int on) { ro_mpr_libccd_tridist = on; }
 static void find_pos(const ccd_support* p, double* pos) {
   double dir[3], b[4], t[3];
   portal_dir(p, dir);
@@ -767,10 +769,22 @@ static int mpr_penetration(const ccd_obj* o1, const ccd_obj* o2, int max_iter, d
     mpr_support(o1, o2, dir, &v4);
     if (iters) (*iters)++;
     if (portal_reach_tol(p, &v4, dir, tol) || it > max_iter) {
-      double w[3];
-      *depth = sqrt(origin_tri_dist2(p[1].v, p[2].v, p[3].v, w));
-      if (ccd_zero(*depth)) zero3(dir_out);
-      else { copy3(dir_out, w); normalize3(dir_out); }
+      if (ro_mpr_libccd_tridist) {
+        /* libccd verbatim: distance/direction to the closest point of the final portal TRIANGLE.  On flat
+           (face-face) contacts the final triangle depends on rounding-level tie breaks among equal support
+           points, and the answer jumps whenever the origin's projection leaves the triangle. */
+        double w[3];
+        *depth = sqrt(origin_tri_dist2(p[1].v, p[2].v, p[3].v, w));
+        if (ccd_zero(*depth)) zero3(dir_out);
+        else { copy3(dir_out, w); normalize3(dir_out); }
+      } else {
+        /* default: the portal PLANE (its normal and distance).  Identical to the above whenever the
+           projection lies inside the triangle, independent of which triangle of the supporting plane
+           the refinement ended on, and a tighter bound on the penetration depth.  (DESIGN.md "MPR".) */
+        *depth = (dot3(p[1].v, dir) + dot3(p[2].v, dir) + dot3(p[3].v, dir)) / 3.0;
+        if (*depth < 0) *depth = 0;
+        copy3(dir_out, dir);
+      }
       find_pos(p, pos);
       return 0;
     }

@@ -1,0 +1,67 @@
+"""ctypes binding of librgstep.so (the gfx950 HIP stepper behind the C ABI of include/rgstep.h).
+
+There is no CPU fallback: if the library is missing or no MI355X is visible the product raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librgstep.so")
+
+RG_F_QPOS, RG_F_QVEL, RG_F_CTRL, RG_F_PID, RG_F_WARMSTART, RG_F_TIME, RG_F_STATUS, RG_F_STATS, RG_F_DEBUG = range(9)
+
+EXPORTS = [
+    "rg_model_create", "rg_model_free", "rg_model_dims", "rg_batch_create", "rg_batch_free", "rg_batch_set_env",
+    "rg_batch_copy", "rg_batch_reset", "rg_batch_step", "rg_obs_dim", "rg_debug_size", "rg_lds_bytes", "rg_sync",
+    "rg_last_error", "rg_batch_mpr_pair",
+]
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def bind(path):
+    """Load a build of the C ABI and declare its signatures."""
+    if not os.path.exists(path):
+        raise NativeError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path
+        )
+    L = ctypes.CDLL(path)
+    vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+    L.rg_model_create.restype = vp
+    L.rg_model_create.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ci]
+    L.rg_model_free.argtypes = [vp]
+    L.rg_model_dims.argtypes = [vp, ctypes.POINTER(ci)]
+    L.rg_batch_create.restype = vp
+    L.rg_batch_create.argtypes = [vp, ci, ci]
+    L.rg_batch_free.argtypes = [vp]
+    L.rg_batch_set_env.argtypes = [vp, ctypes.POINTER(ci), ci, ctypes.POINTER(cf), cf]
+    L.rg_batch_copy.argtypes = [vp, ci, vp, ci, ci]
+    L.rg_batch_reset.argtypes = [vp]
+    L.rg_batch_step.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]
+    L.rg_batch_mpr_pair.argtypes = [vp, ci, ci, cf, vp, vp]
+    L.rg_obs_dim.argtypes = [vp]
+    L.rg_debug_size.restype = ci
+    L.rg_lds_bytes.restype = ci
+    L.rg_sync.argtypes = [vp]
+    L.rg_last_error.restype = ctypes.c_char_p
+    return L
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = bind(LIB_PATH)
+    return _LIB
+
+
+def check(L, rc, what):
+    if rc != 0:
+        raise NativeError("%s failed: %s" % (what, L.rg_last_error().decode()))

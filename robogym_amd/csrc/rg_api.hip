@@ -1,0 +1,317 @@
+// rg_api.hip — host side of librgstep: the C ABI declared in include/rgstep.h.
+// Parses the RGMODEL1 blob, keeps fp32/int32 copies of every model table in HBM, owns the
+// per-batch state rows and launches the env-step kernel (one 64-lane workgroup per env).
+#include "../../include/rgstep.h"
+#include "rg_kernel.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#ifdef RG_EMUL
+// CPU emulation harness (tests/emul): "device memory" is host memory
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+static hipError_t hipMalloc(void** p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? 0 : 1; }
+static hipError_t hipFree(void* p) { free(p); return 0; }
+enum { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+static hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return 0; }
+static hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return 0; }
+static hipError_t hipSetDevice(int) { return 0; }
+static hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+static const char* hipGetErrorString(hipError_t) { return "emul"; }
+#endif
+
+static thread_local std::string g_err;
+static int fail(const std::string& msg) { g_err = msg; return -1; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+struct blob_entry { char name[40]; uint32_t dtype, count; uint64_t offset; };
+
+struct rg_model {
+  RgModelDev dev;
+  RgAux aux;
+  std::vector<void*> allocs;
+  std::vector<float> qpos0;
+  int ok = 0;
+};
+struct rg_batch {
+  const rg_model* model;
+  RgBatchDev dev;
+  RgEnvDev env;
+  int device;
+  int has_env = 0;
+  std::vector<void*> allocs;
+};
+
+namespace {
+struct Blob {
+  const char* base; size_t nbytes;
+  const blob_entry* find(const char* name) const {
+    uint32_t n = *(const uint32_t*)(base + 8);
+    const blob_entry* e = (const blob_entry*)(base + 16);
+    for (uint32_t i = 0; i < n; i++) if (strncmp(e[i].name, name, 40) == 0) return &e[i];
+    return nullptr;
+  }
+};
+
+template <class T> bool upload(rg_model* m, const std::vector<T>& host, const T** dst) {
+  void* p = nullptr;
+  if (hipMalloc(&p, (host.size() ? host.size() : 1) * sizeof(T)) != hipSuccess) return false;
+  if (host.size() && hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return false;
+  m->allocs.push_back(p);
+  *dst = (const T*)p;
+  return true;
+}
+bool get_f(const Blob& b, const char* name, std::vector<float>& out, std::string& err) {
+  const blob_entry* e = b.find(name);
+  if (!e) { err = std::string("model blob lacks '") + name + "'"; return false; }
+  out.resize(e->count);
+  if (e->dtype == 0) { const double* p = (const double*)(b.base + e->offset); for (uint32_t i = 0; i < e->count; i++) out[i] = (float)p[i]; }
+  else if (e->dtype == 2) { const float* p = (const float*)(b.base + e->offset); for (uint32_t i = 0; i < e->count; i++) out[i] = p[i]; }
+  else { const int* p = (const int*)(b.base + e->offset); for (uint32_t i = 0; i < e->count; i++) out[i] = (float)p[i]; }
+  return true;
+}
+bool get_i(const Blob& b, const char* name, std::vector<int>& out, std::string& err) {
+  const blob_entry* e = b.find(name);
+  if (!e) { err = std::string("model blob lacks '") + name + "'"; return false; }
+  if (e->dtype != 1) { err = std::string("'") + name + "' is not int32"; return false; }
+  out.assign((const int*)(b.base + e->offset), (const int*)(b.base + e->offset) + e->count);
+  return true;
+}
+}  // namespace
+
+extern "C" {
+
+const char* rg_last_error(void) { return g_err.c_str(); }
+int rg_debug_size(void) { return RG_DBG_SIZE; }
+int rg_lds_bytes(void) { return (int)sizeof(RgLds); }
+
+rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen) {
+  auto bail = [&](const std::string& msg, rg_model* m) -> rg_model* {
+    g_err = msg;
+    if (err && errlen > 0) { strncpy(err, msg.c_str(), errlen - 1); err[errlen - 1] = 0; }
+    if (m) rg_model_free(m);
+    return nullptr;
+  };
+  if (!blob || nbytes < 16 || memcmp(blob, "RGMODEL1", 8) != 0) return bail("not an RGMODEL1 blob", nullptr);
+  Blob B{(const char*)blob, nbytes};
+  rg_model* m = new rg_model();
+  RgModelDev& d = m->dev;
+  memset(&d, 0, sizeof d);
+  std::string e;
+  std::vector<int> iv; std::vector<float> fv;
+#define GI(name) if (!get_i(B, name, iv, e)) return bail(e, m)
+#define GF(name) if (!get_f(B, name, fv, e)) return bail(e, m)
+#define UPI(field, name) do { GI(name); if (!upload<int>(m, iv, &d.field)) return bail("hipMalloc failed", m); } while (0)
+#define UPF(field, name) do { GF(name); if (!upload<float>(m, fv, &d.field)) return bail("hipMalloc failed", m); } while (0)
+  GI("dims");
+  d.nq = iv[0]; d.nv = iv[1]; d.nu = iv[2]; d.nbody = iv[3]; d.njnt = iv[4]; d.ngeom = iv[5]; d.nsite = iv[6]; d.ntendon = iv[7]; d.nwrap = iv[8]; d.nmesh = iv[9];
+  GI("k_dims");
+  d.nlevel = iv[0]; d.ndoflevel = iv[1]; d.nM = iv[2]; d.npair = iv[3]; d.nstatic = iv[4];
+  if (iv[5] > RG_W) return bail("constraint row wider than RG_W", m);
+  if (d.nq > RG_MAXNQ || d.nv > RG_MAXNV || d.nbody > RG_MAXBODY || d.njnt > RG_MAXJNT || d.ngeom > RG_MAXGEOM || d.nsite > RG_MAXSITE ||
+      d.ntendon > RG_MAXTEN || d.nu > RG_MAXU)
+    return bail("model exceeds the compiled kernel capacities (rg_types.h)", m);
+  GI("opt_int"); d.iterations = iv[0]; d.cone = iv[1]; d.mpr_iterations = iv[3];
+  if (d.cone != 0) return bail("elliptic friction cones are not implemented in this kernel configuration", m);
+  GF("opt_timestep"); d.timestep = fv[0];
+  GF("opt_gravity"); d.gravity[0] = fv[0]; d.gravity[1] = fv[1]; d.gravity[2] = fv[2];
+  GF("opt_tolerance"); d.tolerance = fv[0];
+  GF("opt_impratio"); d.impratio = fv[0];
+  GF("opt_mpr_tolerance"); d.mpr_tolerance = fv[0];
+  GF("stat_meaninertia"); d.meaninertia = fv[0];
+  UPI(body_parentid, "body_parentid"); UPI(body_rootid, "body_rootid"); UPI(body_jntadr, "body_jntadr"); UPI(body_jntnum, "body_jntnum");
+  UPI(body_dofadr, "body_dofadr"); UPI(body_dofnum, "body_dofnum"); UPI(body_lastdof, "k_body_lastdof");
+  UPF(body_pos, "body_pos"); UPF(body_quat, "body_quat"); UPF(body_ipos, "body_ipos"); UPF(body_iquat, "body_iquat");
+  UPF(body_mass, "body_mass"); UPF(body_inertia, "body_inertia"); UPF(body_invweight0, "body_invweight0");
+  UPI(lvl_body, "k_lvl_body"); UPI(lvl_body_adr, "k_lvl_body_adr"); UPI(static_body, "k_static_body");
+  UPF(static_xpos, "k_static_xpos"); UPF(static_xquat, "k_static_xquat");
+  UPI(root_origin_body, "k_root_origin_body"); UPF(root_origin_const, "k_root_origin_const");
+  { GI("k_body_dofmask"); std::vector<uint32_t> u(iv.begin(), iv.end()); for (size_t i = 0; i < iv.size(); i++) u[i] = (uint32_t)iv[i]; if (!upload<uint32_t>(m, u, &d.body_dofmask)) return bail("hipMalloc failed", m); }
+  UPI(jnt_type, "jnt_type"); UPI(jnt_qposadr, "jnt_qposadr"); UPI(jnt_dofadr, "jnt_dofadr"); UPI(jnt_bodyid, "jnt_bodyid");
+  UPF(jnt_pos, "jnt_pos"); UPF(jnt_axis, "jnt_axis"); UPF(jnt_stiffness, "jnt_stiffness"); UPF(jnt_range, "jnt_range");
+  UPF(jnt_margin, "jnt_margin"); UPF(jnt_solref, "jnt_solref"); UPF(jnt_solimp, "jnt_solimp");
+  UPI(dof_bodyid, "dof_bodyid"); UPI(dof_jntid, "dof_jntid"); UPI(dof_parentid, "dof_parentid");
+  UPF(dof_armature, "dof_armature"); UPF(dof_damping, "dof_damping"); UPF(dof_frictionloss, "dof_frictionloss");
+  UPF(dof_solref, "dof_solref"); UPF(dof_solimp, "dof_solimp"); UPF(dof_invweight0, "dof_invweight0");
+  UPF(qpos0, "qpos0"); m->qpos0 = fv; UPF(qpos_spring, "qpos_spring");
+  UPI(lvl_dof, "k_lvl_dof"); UPI(lvl_dof_adr, "k_lvl_dof_adr"); UPI(M_i, "k_M_i"); UPI(M_j, "k_M_j"); UPI(M_lvl_adr, "k_M_lvl_adr");
+  UPI(desc_adr, "k_desc_adr"); UPI(desc, "k_desc");
+  UPI(geom_type, "geom_type"); UPI(geom_bodyid, "geom_bodyid"); UPI(geom_dataid, "geom_dataid");
+  UPF(geom_size, "geom_size"); UPF(geom_rbound, "geom_rbound"); UPF(geom_pos, "geom_pos"); UPF(geom_quat, "geom_quat"); UPF(geom_aabb, "k_geom_aabb");
+  UPI(site_bodyid, "site_bodyid"); UPF(site_pos, "site_pos");
+  UPI(mesh_vertadr, "mesh_vertadr"); UPI(mesh_vertnum, "mesh_vertnum"); UPF(mesh_vert, "mesh_vert");
+  UPI(pair_geom, "k_pair_geom"); UPF(pair_prm, "k_pair_prm");
+  UPI(tendon_adr, "tendon_adr"); UPI(tendon_num, "tendon_num"); UPI(wrap_type, "wrap_type"); UPI(wrap_objid, "wrap_objid"); UPI(ten_dofs, "k_ten_dofs");
+  UPF(wrap_prm, "wrap_prm"); UPF(tendon_range, "tendon_range"); UPF(tendon_margin, "tendon_margin"); UPF(tendon_stiffness, "tendon_stiffness");
+  UPF(tendon_damping, "tendon_damping"); UPF(tendon_frictionloss, "tendon_frictionloss"); UPF(tendon_lengthspring, "tendon_lengthspring");
+  UPF(tendon_solref_lim, "tendon_solref_lim"); UPF(tendon_solimp_lim, "tendon_solimp_lim"); UPF(tendon_solref_fri, "tendon_solref_fri");
+  UPF(tendon_solimp_fri, "tendon_solimp_fri"); UPF(tendon_invweight0, "tendon_invweight0");
+  UPI(dof_ten_adr, "k_dof_ten_adr"); UPI(dof_ten, "k_dof_ten"); UPI(dof_act_adr, "k_dof_act_adr"); UPI(dof_act, "k_dof_act");
+  UPI(actuator_trntype, "actuator_trntype"); UPI(actuator_trnid, "actuator_trnid"); UPI(actuator_ctrllimited, "actuator_ctrllimited");
+  UPI(actuator_forcelimited, "actuator_forcelimited"); UPI(actuator_biastype, "actuator_biastype");
+  UPF(actuator_gear, "actuator_gear"); UPF(actuator_ctrlrange, "actuator_ctrlrange"); UPF(actuator_forcerange, "actuator_forcerange");
+  UPF(actuator_gainprm, "actuator_gainprm"); UPF(actuator_biasprm, "actuator_biasprm");
+  GI("k_fric_dof"); d.nfric_dof = (int)iv.size(); if (!upload<int>(m, iv, &d.fric_dof)) return bail("hipMalloc failed", m);
+  GI("k_fric_ten"); d.nfric_ten = (int)iv.size(); if (!upload<int>(m, iv, &d.fric_ten)) return bail("hipMalloc failed", m);
+  GI("k_lim_jnt"); d.nlim_jnt = (int)iv.size(); if (!upload<int>(m, iv, &d.lim_jnt)) return bail("hipMalloc failed", m);
+  GI("k_lim_ten"); d.nlim_ten = (int)iv.size(); if (!upload<int>(m, iv, &d.lim_ten)) return bail("hipMalloc failed", m);
+  if (d.nfric_dof + d.nfric_ten + 2 * d.nlim_jnt + 2 * d.nlim_ten > RG_MAXSROW) return bail("too many friction/limit rows for RG_MAXSROW", m);
+  GI("k_subtree_adr"); if (!upload<int>(m, iv, &m->aux.subtree_adr)) return bail("hipMalloc failed", m);
+  GI("k_subtree"); if (!upload<int>(m, iv, &m->aux.subtree)) return bail("hipMalloc failed", m);
+  { GI("k_dof_velmask"); std::vector<uint32_t> u(iv.size()); for (size_t i = 0; i < iv.size(); i++) u[i] = (uint32_t)iv[i]; if (!upload<uint32_t>(m, u, &m->aux.dof_velmask)) return bail("hipMalloc failed", m); }
+  m->ok = 1;
+  return m;
+}
+
+void rg_model_free(rg_model* m) {
+  if (!m) return;
+  for (void* p : m->allocs) hipFree(p);
+  delete m;
+}
+int rg_model_dims(const rg_model* m, int* out) {
+  if (!m) return fail("null model");
+  out[0] = m->dev.nq; out[1] = m->dev.nv; out[2] = m->dev.nu; out[3] = m->dev.nbody; out[4] = m->dev.nsite;
+  return 0;
+}
+
+static void* balloc(rg_batch* b, size_t n) {
+  void* p = nullptr;
+  if (hipMalloc(&p, n ? n : 1) != hipSuccess) return nullptr;
+  hipMemset(p, 0, n ? n : 1);
+  b->allocs.push_back(p);
+  return p;
+}
+
+rg_batch* rg_batch_create(const rg_model* m, int B, int device) {
+  if (!m || !m->ok || B <= 0) { fail("bad arguments to rg_batch_create"); return nullptr; }
+  if (hipSetDevice(device) != hipSuccess) { fail("hipSetDevice failed"); return nullptr; }
+  rg_batch* b = new rg_batch();
+  b->model = m; b->device = device;
+  memset(&b->dev, 0, sizeof b->dev); memset(&b->env, 0, sizeof b->env);
+  const RgModelDev& d = m->dev;
+  RgBatchDev& s = b->dev;
+  s.B = B;
+  s.qpos = (float*)balloc(b, (size_t)B * d.nq * 4); s.qvel = (float*)balloc(b, (size_t)B * d.nv * 4);
+  s.ctrl = (float*)balloc(b, (size_t)B * d.nu * 4); s.pid = (float*)balloc(b, (size_t)B * 3 * d.nu * 4);
+  s.qacc_warmstart = (float*)balloc(b, (size_t)B * d.nv * 4); s.time = (float*)balloc(b, (size_t)B * 4);
+  s.status = (uint32_t*)balloc(b, (size_t)B * 4); s.stats = (float*)balloc(b, (size_t)B * 16);
+  s.dbg = (float*)balloc(b, (size_t)B * RG_DBG_SIZE * 4);
+  if (!s.qpos || !s.qvel || !s.ctrl || !s.pid || !s.qacc_warmstart || !s.time || !s.status || !s.stats || !s.dbg) { fail("hipMalloc failed"); rg_batch_free(b); return nullptr; }
+  if (rg_batch_reset(b) != 0) { rg_batch_free(b); return nullptr; }
+  return b;
+}
+void rg_batch_free(rg_batch* b) {
+  if (!b) return;
+  for (void* p : b->allocs) hipFree(p);
+  delete b;
+}
+int rg_batch_reset(rg_batch* b) {
+  if (!b) return fail("null batch");
+  const RgModelDev& d = b->model->dev;
+  RgBatchDev& s = b->dev;
+  std::vector<float> q((size_t)s.B * d.nq);
+  for (int e = 0; e < s.B; e++) memcpy(q.data() + (size_t)e * d.nq, b->model->qpos0.data(), d.nq * 4);
+  HIPCHK(hipMemcpy(s.qpos, q.data(), q.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(s.qvel, 0, (size_t)s.B * d.nv * 4)); HIPCHK(hipMemset(s.ctrl, 0, (size_t)s.B * d.nu * 4));
+  HIPCHK(hipMemset(s.pid, 0, (size_t)s.B * 3 * d.nu * 4)); HIPCHK(hipMemset(s.qacc_warmstart, 0, (size_t)s.B * d.nv * 4));
+  HIPCHK(hipMemset(s.time, 0, (size_t)s.B * 4)); HIPCHK(hipMemset(s.status, 0, (size_t)s.B * 4)); HIPCHK(hipMemset(s.stats, 0, (size_t)s.B * 16));
+  return 0;
+}
+
+int rg_batch_set_env(rg_batch* b, const int* ints, int nints, const float* p2c, float thr) {
+  if (!b || !ints || nints < 20) return fail("rg_batch_set_env: need 20 ints");
+  RgEnvDev& e = b->env;
+  e.hand_qposadr = ints[0]; e.n_hand_jnt = ints[1]; e.cube_pos_qposadr = ints[2]; e.cube_quat_qposadr = ints[3];
+  e.target_qposadr = ints[4]; e.target_nq = ints[5]; e.target_dofadr = ints[6]; e.target_nv = ints[7]; e.cube_body = ints[8];
+  for (int i = 0; i < 3; i++) e.ref_site[i] = ints[9 + i];
+  for (int i = 0; i < 5; i++) e.tip_site[i] = ints[12 + i];
+  e.relative_action = ints[17];
+  e.success_threshold = thr;
+  size_t n = (size_t)b->model->dev.nu * e.n_hand_jnt;
+  float* dp = (float*)balloc(b, n * 4);
+  if (!dp) return fail("hipMalloc failed");
+  HIPCHK(hipMemcpy(dp, p2c, n * 4, hipMemcpyHostToDevice));
+  e.pos_to_ctrl = dp;
+  b->has_env = 1;
+  return 0;
+}
+int rg_obs_dim(const rg_batch* b) {
+  if (!b || !b->has_env) return -1;
+  return 7 + b->model->dev.nq + b->model->dev.nv + b->env.n_hand_jnt + 15;
+}
+
+int rg_batch_copy(rg_batch* b, int field, void* ptr, int to_batch, int ptr_is_device) {
+  if (!b || !ptr) return fail("rg_batch_copy: null argument");
+  const RgModelDev& d = b->model->dev;
+  RgBatchDev& s = b->dev;
+  void* p; size_t n;
+  switch (field) {
+    case RG_F_QPOS: p = s.qpos; n = (size_t)d.nq; break;
+    case RG_F_QVEL: p = s.qvel; n = (size_t)d.nv; break;
+    case RG_F_CTRL: p = s.ctrl; n = (size_t)d.nu; break;
+    case RG_F_PID: p = s.pid; n = (size_t)3 * d.nu; break;
+    case RG_F_WARMSTART: p = s.qacc_warmstart; n = (size_t)d.nv; break;
+    case RG_F_TIME: p = s.time; n = 1; break;
+    case RG_F_STATUS: p = s.status; n = 1; break;
+    case RG_F_STATS: p = s.stats; n = 4; break;
+    case RG_F_DEBUG: p = s.dbg; n = RG_DBG_SIZE; break;
+    default: return fail("rg_batch_copy: unknown field");
+  }
+  size_t bytes = n * 4 * (size_t)s.B;
+  if (to_batch) HIPCHK(hipMemcpy(p, ptr, bytes, ptr_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  else HIPCHK(hipMemcpy(ptr, p, bytes, ptr_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+  return 0;
+}
+
+#ifdef RG_EMUL
+struct EmulArgs { RgModelDev m; RgAux x; RgEnvDev env; RgBatchDev bt; int nsub, nticks, flags; };
+static void emul_entry(void* a) { EmulArgs* p = (EmulArgs*)a; rg_step_kernel(p->m, p->x, p->env, p->bt, p->nsub, p->nticks, p->flags); }
+#endif
+
+int rg_batch_step(rg_batch* b, const float* action_dev, const float* goal_quat_dev, float* obs_dev, float* goal_dist_dev,
+                  const int* active_dev, int nsubsteps, int nforward_ticks, int flags, void* stream) {
+  if (!b) return fail("null batch");
+  if ((action_dev || obs_dev) && !b->has_env) return fail("rg_batch_set_env must be called before stepping with actions/observations");
+  RgBatchDev bt = b->dev;
+  bt.action = action_dev; bt.goal_quat = goal_quat_dev; bt.obs = obs_dev; bt.goal_dist = goal_dist_dev; bt.active = active_dev;
+#ifdef RG_EMUL
+  EmulArgs args{b->model->dev, b->model->aux, b->env, bt, nsubsteps, nforward_ticks, flags};
+  emul_launch(bt.B, sizeof(RgLds), emul_entry, &args);
+#else
+  hipLaunchKernelGGL(rg_step_kernel, dim3(bt.B), dim3(RG_WAVE), sizeof(RgLds), (hipStream_t)stream, b->model->dev, b->model->aux, b->env, bt,
+                     nsubsteps, nforward_ticks, flags);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+
+#ifdef RG_EMUL
+struct EmulMprArgs { RgModelDev m; RgBatchDev bt; int g1, g2; float margin; float* out; };
+static void emul_mpr_entry(void* a) { EmulMprArgs* p = (EmulMprArgs*)a; rg_mpr_pair_kernel(p->m, p->bt, p->g1, p->g2, p->margin, p->out); }
+#endif
+int rg_batch_mpr_pair(rg_batch* b, int g1, int g2, float margin, float* out_dev, void* stream) {
+  if (!b || !out_dev) return fail("null argument");
+  const RgModelDev& d = b->model->dev;
+  if (g1 < 0 || g2 < 0 || g1 >= d.ngeom || g2 >= d.ngeom) return fail("geom id out of range");
+#ifdef RG_EMUL
+  EmulMprArgs args{d, b->dev, g1, g2, margin, out_dev};
+  emul_launch(b->dev.B, sizeof(RgLds), emul_mpr_entry, &args);
+#else
+  hipLaunchKernelGGL(rg_mpr_pair_kernel, dim3(b->dev.B), dim3(RG_WAVE), sizeof(RgLds), (hipStream_t)stream, d, b->dev, g1, g2, margin, out_dev);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+
+int rg_sync(void* stream) {
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,1319 @@
+// rg_kernel.h — the batched env.step kernel for gfx950 (MI355X).
+//
+// Execution plan: ONE 64-lane wavefront (= one workgroup) per environment.  The whole env step —
+// action -> ctrl, nsubsteps x mj_step (kinematics, tendons, CRB + tree-sparse L'DL, convex collision
+// by MPR, constraint rows, PID actuation, Newton solve, implicit-damping Euler), the three PID
+// ticks of the reference's state-less forward() calls, observation readout and goal distance —
+// runs inside one launch with all per-env state resident in LDS.  HBM traffic per env step is the
+// state row in, state row + observation row out (row-major [B][n] buffers, contiguous per env so
+// a wave's loads are coalesced).  Tree recursions are level sweeps over precomputed level lists,
+// reductions are wave butterflies, sparse scatters are LDS atomics issued by a single wave
+// (in-order, hence deterministic).  No MFMA: this is sparse articulated dynamics.
+//
+// Replaces, for the hot path, mujoco_py.MjSim.step + mjpid (reference call sites:
+// /root/reference/robogym/mujoco/simulation_interface.py:176-189, :86-88) and the readout done by
+// /root/reference/robogym/robot_env.py:804-844.  Semantics follow the CPU oracle stage by stage.
+#pragma once
+#include "rg_types.h"
+
+#ifdef RG_EMUL
+#include "hip_emul.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+
+#define NVP (RG_MAXNV + 1)  // padded row stride of dense nv x nv matrices in LDS (bank-conflict free)
+#define RG_MAXSROW (RG_MAXROW + 64)  // static row slots: friction dofs/tendons + 2 per limited joint/tendon
+#define RG_MAXPYR (RG_MAXCON * 6)
+
+struct RgLds {
+  // state
+  float qpos[RG_MAXNQ], qvel[RG_MAXNV], ctrl[RG_MAXU], pid[3 * RG_MAXU], warm[RG_MAXNV];
+  // position stage
+  float xpos[RG_MAXBODY * 3], xquat[RG_MAXBODY * 4], xmat[RG_MAXBODY * 9], xipos[RG_MAXBODY * 3], org[RG_MAXBODY * 3];
+  float xanchor[RG_MAXJNT * 3], xaxis[RG_MAXJNT * 3];
+  float gpos[RG_MAXGEOM * 3], gmat[RG_MAXGEOM * 9], spos[RG_MAXSITE * 3];
+  float cinert[RG_MAXBODY * 10], crb[RG_MAXBODY * 10], cdof[RG_MAXNV * 6], cdofdot[RG_MAXNV * 6];
+  float cacc[RG_MAXBODY * 6], cfrc[RG_MAXBODY * 6];
+  float M[RG_MAXNV * NVP], LD[RG_MAXNV * NVP], H[RG_MAXNV * NVP];
+  float tenlen[RG_MAXTEN], tenvel[RG_MAXTEN], tenJ[RG_MAXTEN * 4], tenfrc[RG_MAXTEN];
+  float actlen[RG_MAXU], actfrc[RG_MAXU];
+  float qfrc_passive[RG_MAXNV], qfrc_bias[RG_MAXNV], qfrc_act[RG_MAXNV], qfrc_smooth[RG_MAXNV], qacc_smooth[RG_MAXNV];
+  float qfrc_con[RG_MAXNV], qacc[RG_MAXNV];
+  // solver work vectors
+  float Ma[RG_MAXNV], grad[RG_MAXNV], search[RG_MAXNV], Mv[RG_MAXNV], tmpv[RG_MAXNV];
+  // static row slots (friction loss, limits)
+  float r_D[RG_MAXSROW], r_R[RG_MAXSROW], r_aref[RG_MAXSROW], r_floss[RG_MAXSROW], r_jar[RG_MAXSROW], r_jv[RG_MAXSROW], r_force[RG_MAXSROW];
+  int r_active[RG_MAXSROW], r_quad[RG_MAXSROW];
+  // contacts
+  int ncand, ncon;
+  int cand[RG_MAXCAND];
+  float c_dist[RG_MAXCON], c_pos[RG_MAXCON * 3], c_frame[RG_MAXCON * 9], c_D[RG_MAXCON], c_mu[RG_MAXCON * 4];
+  int c_pair[RG_MAXCON], c_dim[RG_MAXCON], c_nnz[RG_MAXCON];
+  unsigned char c_idx[RG_MAXCON * RG_W];
+  float c_B[RG_MAXCON * 4 * RG_W];  // basis Jacobian rows (normal, tangent1, tangent2, spin) on the merged dof slots
+  float c_bdot[RG_MAXCON * 4], c_bfrc[RG_MAXCON * 4];
+  float p_aref[RG_MAXPYR], p_jar[RG_MAXPYR], p_jv[RG_MAXPYR], p_force[RG_MAXPYR];
+  int p_quad[RG_MAXPYR];
+  unsigned int status;
+};
+
+// ------------------------------------------------------------------------------------------------- small math
+struct v3 { float x, y, z; };
+__device__ __forceinline__ v3 mk3(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ v3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+__device__ __forceinline__ void st3(float* p, v3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+__device__ __forceinline__ v3 operator+(v3 a, v3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ v3 operator-(v3 a, v3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ v3 operator*(v3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ v3 cross(v3 a, v3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ float norm(v3 a) { return sqrtf(dot(a, a)); }
+__device__ __forceinline__ v3 normalized(v3 a) { float n = norm(a); return n < 1e-30f ? mk3(1, 0, 0) : a * (1.0f / n); }
+// M row-major 3x3
+__device__ __forceinline__ v3 mulm(const float* M, v3 v) { return mk3(M[0] * v.x + M[1] * v.y + M[2] * v.z, M[3] * v.x + M[4] * v.y + M[5] * v.z, M[6] * v.x + M[7] * v.y + M[8] * v.z); }
+__device__ __forceinline__ v3 mulmT(const float* M, v3 v) { return mk3(M[0] * v.x + M[3] * v.y + M[6] * v.z, M[1] * v.x + M[4] * v.y + M[7] * v.z, M[2] * v.x + M[5] * v.y + M[8] * v.z); }
+struct q4 { float w, x, y, z; };
+__device__ __forceinline__ q4 ldq(const float* p) { q4 q; q.w = p[0]; q.x = p[1]; q.y = p[2]; q.z = p[3]; return q; }
+__device__ __forceinline__ void stq(float* p, q4 q) { p[0] = q.w; p[1] = q.x; p[2] = q.y; p[3] = q.z; }
+__device__ __forceinline__ q4 qmul(q4 a, q4 b) {
+  q4 r;
+  r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+  r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+  r.y = a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x;
+  r.z = a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w;
+  return r;
+}
+__device__ __forceinline__ q4 qnormalize(q4 q) {
+  float n = sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+  if (n < 1e-30f) { q.w = 1; q.x = q.y = q.z = 0; return q; }
+  float s = 1.0f / n; q.w *= s; q.x *= s; q.y *= s; q.z *= s; return q;
+}
+__device__ __forceinline__ void q2mat(float* m, q4 q) {
+  float w = q.w, x = q.x, y = q.y, z = q.z;
+  m[0] = w * w + x * x - y * y - z * z; m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y);
+  m[3] = 2 * (x * y + w * z); m[4] = w * w - x * x + y * y - z * z; m[5] = 2 * (y * z - w * x);
+  m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = w * w - x * x - y * y + z * z;
+}
+__device__ __forceinline__ q4 axisangle(v3 ax, float ang) {
+  float s, c; sincosf(0.5f * ang, &s, &c);
+  q4 q; q.w = c; q.x = ax.x * s; q.y = ax.y * s; q.z = ax.z * s; return q;
+}
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+// ------------------------------------------------------------------------------------------------- wave collectives
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// arg-max with smallest-index tie break (matches a first-max serial scan)
+__device__ __forceinline__ void wave_argmax(float& v, int& i) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(v, o); int oi = __shfl_xor(i, o);
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+}
+#define LANE ((int)threadIdx.x)
+#define SYNC() __syncthreads()
+#define PFOR(i, n) for (int i = LANE; i < (n); i += RG_WAVE)
+
+// spatial algebra in the com-based frame: 6-vectors are [rotational(3); translational(3)]
+__device__ __forceinline__ void mul_inert_vec(float* r, const float* i, const float* v) {
+  r[0] = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
+  r[1] = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
+  r[2] = i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4];
+  r[3] = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
+  r[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
+  r[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
+}
+__device__ __forceinline__ void cross_motion(float* r, const float* vel, const float* v) {
+  v3 w = ld3(vel), vt = ld3(vel + 3), a = ld3(v), b = ld3(v + 3);
+  st3(r, cross(w, a)); st3(r + 3, cross(w, b) + cross(vt, a));
+}
+__device__ __forceinline__ void cross_force(float* r, const float* vel, const float* f) {
+  v3 w = ld3(vel), vt = ld3(vel + 3), a = ld3(f), b = ld3(f + 3);
+  st3(r, cross(w, a) + cross(vt, b)); st3(r + 3, cross(w, b));
+}
+
+// ------------------------------------------------------------------------------------------------- position stage
+__device__ void rg_kinematics(const RgModelDev& m, RgLds& s) {
+  PFOR(i, m.nstatic) {
+    int b = m.static_body[i];
+    st3(s.xpos + 3 * b, ld3(m.static_xpos + 3 * b));
+    q4 q = ldq(m.static_xquat + 4 * b); stq(s.xquat + 4 * b, q); q2mat(s.xmat + 9 * b, q);
+    st3(s.xipos + 3 * b, ld3(s.xpos + 3 * b) + mulm(s.xmat + 9 * b, ld3(m.body_ipos + 3 * b)));
+  }
+  SYNC();
+  for (int L = 0; L < m.nlevel; L++) {
+    int a0 = m.lvl_body_adr[L], a1 = m.lvl_body_adr[L + 1];
+    for (int k = a0 + LANE; k < a1; k += RG_WAVE) {
+      int b = m.lvl_body[k], p = m.body_parentid[b];
+      v3 pos = ld3(s.xpos + 3 * p) + mulm(s.xmat + 9 * p, ld3(m.body_pos + 3 * b));
+      q4 quat = qmul(ldq(s.xquat + 4 * p), ldq(m.body_quat + 4 * b));
+      int jn = m.body_jntnum[b], ja = m.body_jntadr[b];
+      for (int jj = 0; jj < jn; jj++) {
+        int j = ja + jj, t = m.jnt_type[j], qa = m.jnt_qposadr[j];
+        if (t == RG_JNT_FREE) {
+          pos = ld3(s.qpos + qa); quat = qnormalize(ldq(s.qpos + qa + 3));
+          st3(s.xanchor + 3 * j, pos); st3(s.xaxis + 3 * j, mk3(0, 0, 1));
+          continue;
+        }
+        float mat[9]; q2mat(mat, quat);
+        v3 anchor = pos + mulm(mat, ld3(m.jnt_pos + 3 * j));
+        v3 axis = mulm(mat, ld3(m.jnt_axis + 3 * j));
+        st3(s.xanchor + 3 * j, anchor); st3(s.xaxis + 3 * j, axis);
+        if (t == RG_JNT_SLIDE) pos = pos + axis * (s.qpos[qa] - m.qpos0[qa]);
+        else {
+          q4 ql = (t == RG_JNT_BALL) ? qnormalize(ldq(s.qpos + qa)) : axisangle(ld3(m.jnt_axis + 3 * j), s.qpos[qa] - m.qpos0[qa]);
+          quat = qmul(quat, ql);
+          q2mat(mat, quat);
+          pos = anchor - mulm(mat, ld3(m.jnt_pos + 3 * j));
+        }
+      }
+      quat = qnormalize(quat);
+      st3(s.xpos + 3 * b, pos); stq(s.xquat + 4 * b, quat); q2mat(s.xmat + 9 * b, quat);
+      st3(s.xipos + 3 * b, pos + mulm(s.xmat + 9 * b, ld3(m.body_ipos + 3 * b)));
+    }
+    SYNC();
+  }
+  PFOR(g, m.ngeom) {
+    int b = m.geom_bodyid[g];
+    st3(s.gpos + 3 * g, ld3(s.xpos + 3 * b) + mulm(s.xmat + 9 * b, ld3(m.geom_pos + 3 * g)));
+    q2mat(s.gmat + 9 * g, qmul(ldq(s.xquat + 4 * b), ldq(m.geom_quat + 4 * g)));
+  }
+  PFOR(i, m.nsite) {
+    int b = m.site_bodyid[i];
+    st3(s.spos + 3 * i, ld3(s.xpos + 3 * b) + mulm(s.xmat + 9 * b, ld3(m.site_pos + 3 * i)));
+  }
+  PFOR(b, m.nbody) {
+    int r = m.body_rootid[b], ob = m.root_origin_body[r];
+    st3(s.org + 3 * b, ob >= 0 ? ld3(s.xipos + 3 * ob) : ld3(m.root_origin_const + 3 * r));
+  }
+  SYNC();
+}
+
+__device__ void rg_com_pos(const RgModelDev& m, RgLds& s) {
+  for (int b = 1 + LANE; b < m.nbody; b += RG_WAVE) {
+    float R[9], I[9], qm[9];
+    q2mat(qm, ldq(m.body_iquat + 4 * b));
+    const float* X = s.xmat + 9 * b;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[3 * i + j] = X[3 * i] * qm[j] + X[3 * i + 1] * qm[3 + j] + X[3 * i + 2] * qm[6 + j];
+    const float* in = m.body_inertia + 3 * b;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) I[3 * i + j] = R[3 * i] * in[0] * R[3 * j] + R[3 * i + 1] * in[1] * R[3 * j + 1] + R[3 * i + 2] * in[2] * R[3 * j + 2];
+    v3 d = ld3(s.xipos + 3 * b) - ld3(s.org + 3 * b);
+    float mass = m.body_mass[b], d2 = dot(d, d);
+    float* ci = s.cinert + 10 * b;
+    ci[0] = I[0] + mass * (d2 - d.x * d.x); ci[1] = I[4] + mass * (d2 - d.y * d.y); ci[2] = I[8] + mass * (d2 - d.z * d.z);
+    ci[3] = I[1] - mass * d.x * d.y; ci[4] = I[2] - mass * d.x * d.z; ci[5] = I[5] - mass * d.y * d.z;
+    ci[6] = mass * d.x; ci[7] = mass * d.y; ci[8] = mass * d.z; ci[9] = mass;
+  }
+  PFOR(j, m.njnt) {
+    int b = m.jnt_bodyid[j], da = m.jnt_dofadr[j], t = m.jnt_type[j];
+    v3 off = ld3(s.org + 3 * b) - ld3(s.xanchor + 3 * j);
+    const float* R = s.xmat + 9 * b;
+    if (t == RG_JNT_FREE || t == RG_JNT_BALL) {
+      if (t == RG_JNT_FREE) {
+        for (int k = 0; k < 3; k++) { float* c = s.cdof + 6 * (da + k); for (int e = 0; e < 6; e++) c[e] = 0; c[3 + k] = 1; }
+        da += 3;
+      }
+      for (int k = 0; k < 3; k++) { v3 ax = mk3(R[k], R[3 + k], R[6 + k]); st3(s.cdof + 6 * (da + k), ax); st3(s.cdof + 6 * (da + k) + 3, cross(ax, off)); }
+    } else if (t == RG_JNT_SLIDE) {
+      st3(s.cdof + 6 * da, mk3(0, 0, 0)); st3(s.cdof + 6 * da + 3, ld3(s.xaxis + 3 * j));
+    } else {
+      v3 ax = ld3(s.xaxis + 3 * j); st3(s.cdof + 6 * da, ax); st3(s.cdof + 6 * da + 3, cross(ax, off));
+    }
+  }
+  SYNC();
+}
+
+// translational Jacobian column of dof d for a point with offset `off` from the com-frame origin
+__device__ __forceinline__ v3 jac_col(const RgLds& s, int d, v3 off) { return ld3(s.cdof + 6 * d + 3) + cross(ld3(s.cdof + 6 * d), off); }
+__device__ __forceinline__ bool in_chain(const RgModelDev& m, int body, int d) { return (m.body_dofmask[2 * body + (d >> 5)] >> (d & 31)) & 1u; }
+
+// ---- tendon wrapping (see oracle: wrap_circle / ro_wrap)
+__device__ inline bool seg_intersect(float p1x, float p1y, float p2x, float p2y, float p3x, float p3y, float p4x, float p4y) {
+  float det = (p4y - p3y) * (p2x - p1x) - (p4x - p3x) * (p2y - p1y);
+  if (fabsf(det) < 1e-15f) return false;
+  float a = ((p4x - p3x) * (p1y - p3y) - (p4y - p3y) * (p1x - p3x)) / det;
+  float b = ((p2x - p1x) * (p1y - p3y) - (p2y - p1y) * (p1x - p3x)) / det;
+  return a >= 0 && a <= 1 && b >= 0 && b <= 1;
+}
+__device__ inline float wrap_circle(float* pnt, const float* d, const float* sd, float rad) {
+  float sq0 = d[0] * d[0] + d[1] * d[1], sq1 = d[2] * d[2] + d[3] * d[3], sqr = rad * rad;
+  float dx = d[2] - d[0], dy = d[3] - d[1], dd = dx * dx + dy * dy;
+  if (sq0 < sqr || sq1 < sqr || rad < 1e-15f || dd < 1e-15f) return -1;
+  float a = clampf(-(dx * d[0] + dy * d[1]) / dd, 0.f, 1.f);
+  float nx = a * dx + d[0], ny = a * dy + d[1];
+  if (nx * nx + ny * ny > sqr && (!sd || sd[0] * nx + sd[1] * ny >= 0)) return -1;
+  float sol[2][4], good[2];
+  float r0 = sqrtf(sq0 - sqr), r1 = sqrtf(sq1 - sqr);
+  for (int i = 0; i < 2; i++) {
+    float sgn = i == 0 ? 1.f : -1.f;
+    sol[i][0] = (d[0] * sqr + sgn * rad * d[1] * r0) / sq0; sol[i][1] = (d[1] * sqr - sgn * rad * d[0] * r0) / sq0;
+    sol[i][2] = (d[2] * sqr - sgn * rad * d[3] * r1) / sq1; sol[i][3] = (d[3] * sqr + sgn * rad * d[2] * r1) / sq1;
+    if (sd) {
+      float mx = sol[i][0] + sol[i][2], my = sol[i][1] + sol[i][3], n = fmaxf(sqrtf(mx * mx + my * my), 1e-15f);
+      good[i] = (mx * sd[0] + my * sd[1]) / n;
+    } else {
+      float tx = sol[i][0] - sol[i][2], ty = sol[i][1] - sol[i][3];
+      good[i] = -(tx * tx + ty * ty);
+    }
+    if (seg_intersect(d[0], d[1], sol[i][0], sol[i][1], d[2], d[3], sol[i][2], sol[i][3])) good[i] = -10000.f;
+  }
+  int k = good[0] > good[1] ? 0 : 1;
+  for (int e = 0; e < 4; e++) pnt[e] = sol[k][e];
+  if (seg_intersect(d[0], d[1], pnt[0], pnt[1], d[2], d[3], pnt[2], pnt[3])) return -1;
+  return rad * acosf(clampf((pnt[0] * pnt[2] + pnt[1] * pnt[3]) / sqr, -1.f, 1.f));
+}
+__device__ inline float rg_wrap(v3& w0, v3& w1, v3 x0, v3 x1, v3 gpos, const float* gmat, float radius, int type, bool has_side, v3 side) {
+  v3 p0 = mulmT(gmat, x0 - gpos), p1 = mulmT(gmat, x1 - gpos);
+  if (norm(p0) < 1e-15f || norm(p1) < 1e-15f) return -1;
+  v3 ax0, ax1;
+  if (type == RG_WRAP_SPHERE) {
+    ax0 = normalized(p0);
+    v3 nrm = cross(p0, p1);
+    if (norm(nrm) < 1e-15f) nrm = cross(ax0, fabsf(ax0.x) < 0.9f ? mk3(1, 0, 0) : mk3(0, 1, 0));
+    nrm = normalized(nrm); ax1 = normalized(cross(nrm, ax0));
+  } else { ax0 = mk3(1, 0, 0); ax1 = mk3(0, 1, 0); }
+  float dd[4] = {dot(p0, ax0), dot(p0, ax1), dot(p1, ax0), dot(p1, ax1)}, sd[2];
+  if (has_side) {
+    v3 sl = mulmT(gmat, side - gpos);
+    sd[0] = dot(sl, ax0); sd[1] = dot(sl, ax1);
+    float n = fmaxf(sqrtf(sd[0] * sd[0] + sd[1] * sd[1]), 1e-15f);
+    sd[0] *= radius / n; sd[1] *= radius / n;
+  }
+  float pnt[4], wlen = wrap_circle(pnt, dd, has_side ? sd : (const float*)0, radius);
+  if (wlen < 0) return -1;
+  v3 r0 = ax0 * pnt[0] + ax1 * pnt[1], r1 = ax0 * pnt[2] + ax1 * pnt[3];
+  if (type == RG_WRAP_CYLINDER) {
+    float L0 = sqrtf((dd[0] - pnt[0]) * (dd[0] - pnt[0]) + (dd[1] - pnt[1]) * (dd[1] - pnt[1]));
+    float L1 = sqrtf((dd[2] - pnt[2]) * (dd[2] - pnt[2]) + (dd[3] - pnt[3]) * (dd[3] - pnt[3]));
+    r0.z = p0.z + (p1.z - p0.z) * L0 / (L0 + wlen + L1);
+    r1.z = p0.z + (p1.z - p0.z) * (L0 + wlen) / (L0 + wlen + L1);
+    wlen = sqrtf(wlen * wlen + (r1.z - r0.z) * (r1.z - r0.z));
+  }
+  w0 = mulm(gmat, r0) + gpos; w1 = mulm(gmat, r1) + gpos;
+  return wlen;
+}
+
+// tendon lengths and Jacobians on their static dof supports; actuator lengths
+__device__ void rg_tendon(const RgModelDev& m, RgLds& s) {
+  PFOR(t, m.ntendon) {
+    int adr = m.tendon_adr[t], num = m.tendon_num[t];
+    const int* td = m.ten_dofs + 4 * t;
+    float J[4] = {0, 0, 0, 0}, L = 0;
+    if (m.wrap_type[adr] == RG_WRAP_JOINT) {
+      for (int w = adr; w < adr + num; w++) {
+        int j = m.wrap_objid[w], d = m.jnt_dofadr[j];
+        L += m.wrap_prm[w] * s.qpos[m.jnt_qposadr[j]];
+        for (int e = 0; e < 4; e++) if (td[e] == d) J[e] += m.wrap_prm[w];
+      }
+    } else {
+      float divisor = 1;
+      int w = adr;
+      while (w < adr + num - 1) {
+        int t0 = m.wrap_type[w], t1 = m.wrap_type[w + 1];
+        if (t0 == RG_WRAP_PULLEY || t1 == RG_WRAP_PULLEY) { if (t0 == RG_WRAP_PULLEY) divisor = m.wrap_prm[w]; w++; continue; }
+        v3 pnt[4]; int body[4], cnt;
+        int s0 = m.wrap_objid[w];
+        pnt[0] = ld3(s.spos + 3 * s0); body[0] = m.site_bodyid[s0];
+        float wlen = -1;
+        if (t1 == RG_WRAP_SPHERE || t1 == RG_WRAP_CYLINDER) {
+          int g = m.wrap_objid[w + 1], s1 = m.wrap_objid[w + 2], sid = (int)m.wrap_prm[w + 1];
+          v3 x1 = ld3(s.spos + 3 * s1);
+          wlen = rg_wrap(pnt[1], pnt[2], pnt[0], x1, ld3(s.gpos + 3 * g), s.gmat + 9 * g, m.geom_size[3 * g], t1, sid >= 0, sid >= 0 ? ld3(s.spos + 3 * sid) : mk3(0, 0, 0));
+          if (wlen < 0) { pnt[1] = x1; body[1] = m.site_bodyid[s1]; cnt = 2; }
+          else { pnt[3] = x1; body[1] = body[2] = m.geom_bodyid[g]; body[3] = m.site_bodyid[s1]; cnt = 4; }
+          w += 2;
+        } else {
+          int s1 = m.wrap_objid[w + 1];
+          pnt[1] = ld3(s.spos + 3 * s1); body[1] = m.site_bodyid[s1]; cnt = 2;
+          w += 1;
+        }
+        if (wlen >= 0) L += wlen / divisor;
+        for (int k = 0; k < cnt - 1; k++) {
+          if (cnt == 4 && k == 1) continue;
+          v3 dif = pnt[k + 1] - pnt[k];
+          float dist = norm(dif);
+          L += dist / divisor;
+          if (body[k] != body[k + 1] && dist > 1e-15f) {
+            dif = dif * (1.0f / dist);
+            for (int e = 0; e < 4; e++) {
+              int d = td[e];
+              if (d < 0) continue;
+              float v = 0;
+              if (in_chain(m, body[k + 1], d)) v += dot(dif, jac_col(s, d, pnt[k + 1] - ld3(s.org + 3 * body[k + 1])));
+              if (in_chain(m, body[k], d)) v -= dot(dif, jac_col(s, d, pnt[k] - ld3(s.org + 3 * body[k])));
+              J[e] += v / divisor;
+            }
+          }
+        }
+      }
+    }
+    s.tenlen[t] = L;
+    for (int e = 0; e < 4; e++) s.tenJ[4 * t + e] = J[e];
+  }
+  SYNC();
+  PFOR(u, m.nu) {
+    int id = m.actuator_trnid[u];
+    s.actlen[u] = m.actuator_gear[u] * (m.actuator_trntype[u] == 0 ? s.qpos[m.jnt_qposadr[id]] : s.tenlen[id]);
+  }
+  SYNC();
+}
+
+// composite inertias (subtree gathers), sparse M, tree-sparse L'DL factorisation
+__device__ void rg_crb(const RgModelDev& m, RgLds& s, const int* subtree_adr, const int* subtree) {
+  for (int w = LANE; w < m.nbody * 10; w += RG_WAVE) {
+    int b = w / 10, k = w - 10 * b;
+    float acc = 0;
+    for (int e = subtree_adr[b]; e < subtree_adr[b + 1]; e++) acc += s.cinert[10 * subtree[e] + k];
+    s.crb[w] = acc;
+  }
+  for (int w = LANE; w < m.nv * NVP; w += RG_WAVE) s.M[w] = 0;
+  SYNC();
+  PFOR(e, m.nM) {
+    int i = m.M_i[e], j = m.M_j[e];
+    float buf[6];
+    mul_inert_vec(buf, s.crb + 10 * m.dof_bodyid[i], s.cdof + 6 * i);
+    const float* c = s.cdof + 6 * j;
+    float v = c[0] * buf[0] + c[1] * buf[1] + c[2] * buf[2] + c[3] * buf[3] + c[4] * buf[4] + c[5] * buf[5];
+    if (i == j) v += m.dof_armature[i];
+    s.M[i * NVP + j] = v; s.M[j * NVP + i] = v;
+  }
+  SYNC();
+}
+
+// LD <- tree-sparse factor of (M + diag(extra)); entries (i,j), j ancestor-or-self of i
+__device__ void rg_factor_tree(const RgModelDev& m, RgLds& s, const float* extra_diag, float extra_scale) {
+  for (int L = m.ndoflevel - 1; L >= 0; L--) {
+    int e0 = m.M_lvl_adr[L], e1 = m.M_lvl_adr[L + 1];
+    for (int e = e0 + LANE; e < e1; e += RG_WAVE) {
+      int i = m.M_i[e], j = m.M_j[e];
+      float v = s.M[i * NVP + j];
+      if (i == j && extra_diag) v += extra_scale * extra_diag[i];
+      for (int q = m.desc_adr[i]; q < m.desc_adr[i + 1]; q++) { int k = m.desc[q]; v -= s.LD[k * NVP + i] * s.LD[k * NVP + j] * s.LD[k * NVP + k]; }
+      s.LD[i * NVP + j] = v;
+    }
+    SYNC();
+    for (int e = e0 + LANE; e < e1; e += RG_WAVE) {
+      int i = m.M_i[e], j = m.M_j[e];
+      if (i != j) {
+        float dgl = s.LD[i * NVP + i];
+        s.LD[i * NVP + j] = s.LD[i * NVP + j] / dgl;
+      } else if (!(s.LD[i * NVP + i] > 1e-30f)) s.status |= RG_STATUS_BAD_FACTOR;
+    }
+    SYNC();
+  }
+}
+// x <- (M + diag)^-1 x using LD
+__device__ void rg_solve_tree(const RgModelDev& m, RgLds& s, float* x) {
+  for (int L = m.ndoflevel - 1; L >= 0; L--) {
+    for (int k = m.lvl_dof_adr[L] + LANE; k < m.lvl_dof_adr[L + 1]; k += RG_WAVE) {
+      int i = m.lvl_dof[k];
+      float v = x[i];
+      for (int q = m.desc_adr[i]; q < m.desc_adr[i + 1]; q++) { int d = m.desc[q]; v -= s.LD[d * NVP + i] * x[d]; }
+      x[i] = v;
+    }
+    SYNC();
+  }
+  for (int L = 0; L < m.ndoflevel; L++) {
+    for (int k = m.lvl_dof_adr[L] + LANE; k < m.lvl_dof_adr[L + 1]; k += RG_WAVE) {
+      int i = m.lvl_dof[k];
+      float v = x[i] / s.LD[i * NVP + i];
+      for (int a = m.dof_parentid[i]; a >= 0; a = m.dof_parentid[a]) v -= s.LD[i * NVP + a] * x[a];
+      x[i] = v;
+    }
+    SYNC();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- collision
+struct SupPt { v3 v, v1, v2; };
+struct MprGeom { int type; const float* mat; v3 pos; v3 size; const float* vert; int nvert; float margin; };
+
+// support point of one geom (relative to the MPR reference origin), wave-cooperative for meshes
+__device__ inline v3 rg_support(const MprGeom& g, v3 dir) {
+  v3 ld = mulmT(g.mat, dir), lr;
+  if (g.type == RG_GEOM_MESH) {
+    float bv = -3.0e38f; int bi = 0x7fffffff;
+    for (int i = LANE; i < g.nvert; i += RG_WAVE) {
+      float d = ld.x * g.vert[3 * i] + ld.y * g.vert[3 * i + 1] + ld.z * g.vert[3 * i + 2];
+      if (d > bv) { bv = d; bi = i; }
+    }
+    wave_argmax(bv, bi);
+    lr = mk3(g.vert[3 * bi], g.vert[3 * bi + 1], g.vert[3 * bi + 2]);
+  } else if (g.type == RG_GEOM_BOX) {
+    lr = mk3(ld.x >= 0 ? g.size.x : -g.size.x, ld.y >= 0 ? g.size.y : -g.size.y, ld.z >= 0 ? g.size.z : -g.size.z);
+  } else if (g.type == RG_GEOM_SPHERE) {
+    lr = ld * g.size.x;
+  } else if (g.type == RG_GEOM_CAPSULE) {
+    lr = ld * g.size.x; lr.z += ld.z >= 0 ? g.size.y : -g.size.y;
+  } else if (g.type == RG_GEOM_CYLINDER) {
+    float n = sqrtf(ld.x * ld.x + ld.y * ld.y);
+    lr = n > 1e-15f ? mk3(ld.x / n * g.size.x, ld.y / n * g.size.x, 0) : mk3(0, 0, 0);
+    lr.z = ld.z >= 0 ? g.size.y : -g.size.y;
+  } else {  // ellipsoid
+    v3 t = mk3(ld.x * g.size.x, ld.y * g.size.y, ld.z * g.size.z);
+    float n = fmaxf(norm(t), 1e-15f);
+    lr = mk3(t.x * g.size.x / n, t.y * g.size.y / n, t.z * g.size.z / n);
+  }
+  lr = lr + ld * g.margin;
+  return mulm(g.mat, lr) + g.pos;
+}
+__device__ inline void mpr_support(const MprGeom& a, const MprGeom& b, v3 dir, SupPt& p) {
+  p.v1 = rg_support(a, dir); p.v2 = rg_support(b, dir * -1.0f); p.v = p.v1 - p.v2;
+}
+#define MPR_EPS 1.0e-7f  /* plays the role of libccd's CCD_EPS at fp32 (coordinates are pair-local, |x| ~ 0.1) */
+__device__ __forceinline__ bool mz(float x) { return fabsf(x) < MPR_EPS * 1e-3f; }
+__device__ __forceinline__ v3 portal_dir(const SupPt* p) { return normalized(cross(p[2].v - p[1].v, p[3].v - p[1].v)); }
+__device__ __forceinline__ bool portal_reach_tol(const SupPt* p, const SupPt& v4, v3 dir, float tol) {
+  float dv4 = dot(v4.v, dir);
+  float mn = fminf(fminf(dv4 - dot(p[1].v, dir), dv4 - dot(p[2].v, dir)), dv4 - dot(p[3].v, dir));
+  return mn <= tol;
+}
+__device__ __forceinline__ void expand_portal(SupPt* p, const SupPt& v4) {
+  v3 c = cross(v4.v, p[0].v);
+  if (dot(p[1].v, c) > 0) { if (dot(p[2].v, c) > 0) p[1] = v4; else p[3] = v4; }
+  else { if (dot(p[3].v, c) > 0) p[2] = v4; else p[1] = v4; }
+}
+__device__ inline float origin_tri_dist2(v3 a, v3 b, v3 c, v3& w) {
+  v3 ab = b - a, ac = c - a, ap = a * -1.0f;
+  float d1 = dot(ab, ap), d2 = dot(ac, ap);
+  if (d1 <= 0 && d2 <= 0) { w = a; return dot(w, w); }
+  v3 bp = b * -1.0f; float d3 = dot(ab, bp), d4 = dot(ac, bp);
+  if (d3 >= 0 && d4 <= d3) { w = b; return dot(w, w); }
+  float vc = d1 * d4 - d3 * d2;
+  if (vc <= 0 && d1 >= 0 && d3 <= 0) { w = a + ab * (d1 / (d1 - d3)); return dot(w, w); }
+  v3 cp = c * -1.0f; float d5 = dot(ab, cp), d6 = dot(ac, cp);
+  if (d6 >= 0 && d5 <= d6) { w = c; return dot(w, w); }
+  float vb = d5 * d2 - d1 * d6;
+  if (vb <= 0 && d2 >= 0 && d6 <= 0) { w = a + ac * (d2 / (d2 - d6)); return dot(w, w); }
+  float va = d3 * d6 - d5 * d4;
+  if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { w = b + (c - b) * ((d4 - d3) / ((d4 - d3) + (d5 - d6))); return dot(w, w); }
+  float den = 1.0f / (va + vb + vc);
+  w = a + ab * (vb * den) + ac * (vc * den);
+  return dot(w, w);
+}
+// MPR penetration query (libccd ccdMPRPenetration); wave-uniform control flow.  Returns true on contact.
+__device__ bool rg_mpr(const MprGeom& A, const MprGeom& B, int max_iter, float tol, float& depth, v3& dir_out, v3& pos) {
+  SupPt p[4], v4;
+  p[0].v1 = A.pos; p[0].v2 = B.pos; p[0].v = A.pos - B.pos;
+  if (mz(p[0].v.x) && mz(p[0].v.y) && mz(p[0].v.z)) p[0].v.x += 1e-6f;
+  v3 dir = normalized(p[0].v * -1.0f);
+  mpr_support(A, B, dir, p[1]);
+  float dt = dot(p[1].v, dir);
+  if (dt <= 0) return false;
+  dir = cross(p[0].v, p[1].v);
+  if (dot(dir, dir) < 1e-30f) {
+    pos = (p[1].v1 + p[1].v2) * 0.5f;
+    if (dot(p[1].v, p[1].v) < 1e-30f) { depth = 0; dir_out = mk3(0, 0, 0); return true; }
+    depth = norm(p[1].v); dir_out = p[1].v * (1.0f / depth);
+    return true;
+  }
+  dir = normalized(dir);
+  mpr_support(A, B, dir, p[2]);
+  if (dot(p[2].v, dir) <= 0) return false;
+  dir = normalized(cross(p[1].v - p[0].v, p[2].v - p[0].v));
+  if (dot(dir, p[0].v) > 0) { SupPt t = p[1]; p[1] = p[2]; p[2] = t; dir = dir * -1.0f; }
+  for (int guard = 0;; guard++) {
+    if (guard > 64) return false;
+    mpr_support(A, B, dir, p[3]);
+    if (dot(p[3].v, dir) <= 0) return false;
+    bool cont = false;
+    if (dot(cross(p[1].v, p[3].v), p[0].v) < 0) { p[2] = p[3]; cont = true; }
+    if (!cont && dot(cross(p[3].v, p[2].v), p[0].v) < 0) { p[1] = p[3]; cont = true; }
+    if (!cont) break;
+    dir = normalized(cross(p[1].v - p[0].v, p[2].v - p[0].v));
+  }
+  for (int guard = 0;; guard++) {  // refinePortal
+    if (guard > 128) return false;
+    dir = portal_dir(p);
+    if (dot(dir, p[1].v) >= 0) break;
+    mpr_support(A, B, dir, v4);
+    if (dot(v4.v, dir) < 0 || portal_reach_tol(p, v4, dir, tol)) return false;
+    expand_portal(p, v4);
+  }
+  for (int it = 0;; it++) {  // findPenetr
+    dir = portal_dir(p);
+    mpr_support(A, B, dir, v4);
+    if (portal_reach_tol(p, v4, dir, tol) || it > max_iter) {
+      // depth / direction from the portal PLANE (not libccd's closest point on the final portal triangle,
+      // whose choice among the triangles of a flat supporting plane is rounding noise; see DESIGN.md "MPR")
+      depth = fmaxf((dot(p[1].v, dir) + dot(p[2].v, dir) + dot(p[3].v, dir)) * (1.0f / 3.0f), 0.f);
+      dir_out = dir;
+      // contact position from the barycentric coordinates of the origin in the portal tetrahedron
+      float b0 = dot(cross(p[1].v, p[2].v), p[3].v), b1 = dot(cross(p[3].v, p[2].v), p[0].v);
+      float b2 = dot(cross(p[0].v, p[1].v), p[3].v), b3 = dot(cross(p[2].v, p[1].v), p[0].v);
+      float sum = b0 + b1 + b2 + b3;
+      if (sum <= 0) {
+        v3 dd = portal_dir(p);
+        b0 = 0; b1 = dot(cross(p[2].v, p[3].v), dd); b2 = dot(cross(p[3].v, p[1].v), dd); b3 = dot(cross(p[1].v, p[2].v), dd);
+        sum = b1 + b2 + b3;
+      }
+      float inv = 0.5f / sum;
+      pos = (p[0].v1 + p[0].v2) * (b0 * inv) + (p[1].v1 + p[1].v2) * (b1 * inv) + (p[2].v1 + p[2].v2) * (b2 * inv) + (p[3].v1 + p[3].v2) * (b3 * inv);
+      return true;
+    }
+    expand_portal(p, v4);
+  }
+}
+
+// separating-axis test of two oriented boxes (half extents ea, eb; rotations Ra, Rb; centre offset t in world)
+__device__ inline bool obb_overlap(const float* Ra, v3 ea, const float* Rb, v3 eb, v3 tw) {
+  float R[9], AR[9];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    R[3 * i + j] = Ra[i] * Rb[j] + Ra[3 + i] * Rb[3 + j] + Ra[6 + i] * Rb[6 + j];
+    AR[3 * i + j] = fabsf(R[3 * i + j]) + 1e-6f;
+  }
+  v3 t = mulmT(Ra, tw);
+  float ta[3] = {t.x, t.y, t.z}, a[3] = {ea.x, ea.y, ea.z}, b[3] = {eb.x, eb.y, eb.z};
+  for (int i = 0; i < 3; i++) if (fabsf(ta[i]) > a[i] + b[0] * AR[3 * i] + b[1] * AR[3 * i + 1] + b[2] * AR[3 * i + 2]) return false;
+  for (int j = 0; j < 3; j++) if (fabsf(ta[0] * R[j] + ta[1] * R[3 + j] + ta[2] * R[6 + j]) > a[0] * AR[j] + a[1] * AR[3 + j] + a[2] * AR[6 + j] + b[j]) return false;
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    float ra = a[i1] * AR[3 * i2 + j] + a[i2] * AR[3 * i1 + j];
+    float rb = b[j1] * AR[3 * i + j2] + b[j2] * AR[3 * i + j1];
+    if (fabsf(ta[i2] * R[3 * i1 + j] - ta[i1] * R[3 * i2 + j]) > ra + rb) return false;
+  }
+  return true;
+}
+
+__device__ __forceinline__ void make_frame(float* f) {
+  v3 n = normalized(ld3(f));
+  v3 y = (n.y < 0.5f && n.y > -0.5f) ? mk3(0, 1, 0) : mk3(0, 0, 1);
+  y = normalized(y - n * dot(n, y));
+  st3(f, n); st3(f + 3, y); st3(f + 6, cross(n, y));
+}
+__device__ inline void add_contact(RgLds& s, int pair, float dist, v3 pos, v3 normal, int dim) {
+  // called with wave-uniform arguments; lane 0 writes
+  int c = s.ncon;
+  if (c >= RG_MAXCON) { if (LANE == 0) s.status |= RG_STATUS_CON_FULL; return; }
+  if (LANE == 0) {
+    s.c_dist[c] = dist; st3(s.c_pos + 3 * c, pos); st3(s.c_frame + 9 * c, normal); make_frame(s.c_frame + 9 * c);
+    s.c_pair[c] = pair; s.c_dim[c] = dim; s.ncon = c + 1;
+  }
+  SYNC();
+}
+
+__device__ void rg_collision(const RgModelDev& m, RgLds& s) {
+  if (LANE == 0) { s.ncand = 0; s.ncon = 0; }
+  SYNC();
+  // broadphase over the static pair list: bounding spheres, then oriented boxes (both conservative,
+  // so the surviving set only prunes MPR calls that would report "no contact")
+  int nround = (m.npair + RG_WAVE - 1) / RG_WAVE;
+  for (int r = 0; r < nround; r++) {
+    int p = r * RG_WAVE + LANE;
+    bool hit = false;
+    if (p < m.npair) {
+      int g1 = m.pair_geom[3 * p], g2 = m.pair_geom[3 * p + 1];
+      float margin = m.pair_prm[12 * p];
+      v3 p1 = ld3(s.gpos + 3 * g1), p2 = ld3(s.gpos + 3 * g2), dif = p2 - p1;
+      if (m.geom_type[g1] == RG_GEOM_PLANE) {
+        const float* R1 = s.gmat + 9 * g1;
+        hit = dot(dif, mk3(R1[2], R1[5], R1[8])) <= m.geom_rbound[g2] + margin;
+      } else {
+        float bound = m.geom_rbound[g1] + m.geom_rbound[g2] + margin;
+        if (dot(dif, dif) <= bound * bound) {
+          float hm = 0.5f * margin + 1e-6f;
+          v3 ea = ld3(m.geom_aabb + 3 * g1) + mk3(hm, hm, hm), eb = ld3(m.geom_aabb + 3 * g2) + mk3(hm, hm, hm);
+          hit = obb_overlap(s.gmat + 9 * g1, ea, s.gmat + 9 * g2, eb, dif);
+        }
+      }
+    }
+    unsigned long long bal = __ballot(hit);
+    int base = s.ncand;
+    SYNC();
+    if (hit) {
+      int slot = base + __popcll(bal & ((1ull << LANE) - 1ull));
+      if (slot < RG_MAXCAND) s.cand[slot] = p; else s.status |= RG_STATUS_CAND_FULL;
+    }
+    if (LANE == 0) { int n = base + __popcll(bal); s.ncand = n < RG_MAXCAND ? n : RG_MAXCAND; }
+    SYNC();
+  }
+  // narrowphase, one candidate at a time, whole wave cooperating
+  int ncand = s.ncand;
+  for (int ci = 0; ci < ncand; ci++) {
+    int p = s.cand[ci];
+    int g1 = m.pair_geom[3 * p], g2 = m.pair_geom[3 * p + 1], dim = m.pair_geom[3 * p + 2];
+    float margin = m.pair_prm[12 * p];
+    int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
+    v3 p1 = ld3(s.gpos + 3 * g1), p2 = ld3(s.gpos + 3 * g2);
+    MprGeom B;
+    B.type = t2; B.mat = s.gmat + 9 * g2; B.size = ld3(m.geom_size + 3 * g2); B.margin = 0;
+    if (t2 == RG_GEOM_MESH) { int id = m.geom_dataid[g2]; B.vert = m.mesh_vert + 3 * m.mesh_vertadr[id]; B.nvert = m.mesh_vertnum[id]; } else { B.vert = 0; B.nvert = 0; }
+    if (t1 == RG_GEOM_PLANE) {
+      const float* R1 = s.gmat + 9 * g1;
+      v3 n = mk3(R1[2], R1[5], R1[8]);
+      if (t2 == RG_GEOM_BOX) {
+        int cnt = 0;
+        for (int i = 0; i < 8 && cnt < 4; i++) {
+          v3 lc = mk3((i & 1) ? B.size.x : -B.size.x, (i & 2) ? B.size.y : -B.size.y, (i & 4) ? B.size.z : -B.size.z);
+          v3 c = mulm(B.mat, lc) + p2;
+          float dist = dot(c - p1, n);
+          if (dist > margin) continue;
+          add_contact(s, p, dist, c - n * (0.5f * dist), n, dim); cnt++;
+        }
+      } else {
+        B.pos = p2 - p1;
+        v3 sp = rg_support(B, n * -1.0f);
+        float dist = dot(sp, n);
+        if (dist <= margin) add_contact(s, p, dist, sp + p1 - n * (0.5f * dist), n, dim);
+      }
+      continue;
+    }
+    MprGeom A;
+    A.type = t1; A.mat = s.gmat + 9 * g1; A.size = ld3(m.geom_size + 3 * g1); A.margin = 0.5f * margin; B.margin = 0.5f * margin;
+    if (t1 == RG_GEOM_MESH) { int id = m.geom_dataid[g1]; A.vert = m.mesh_vert + 3 * m.mesh_vertadr[id]; A.nvert = m.mesh_vertnum[id]; } else { A.vert = 0; A.nvert = 0; }
+    A.pos = mk3(0, 0, 0); B.pos = p2 - p1;  // pair-local coordinates keep fp32 resolution ~1e-9 m
+    float depth; v3 dir, pos;
+    if (rg_mpr(A, B, m.mpr_iterations, m.mpr_tolerance, depth, dir, pos)) {
+      if (dot(dir, dir) > 0.25f) add_contact(s, p, margin - depth, pos + p1, dir, dim);
+    }
+  }
+  SYNC();
+}
+
+// ------------------------------------------------------------------------------------------------- velocity stage
+__device__ void rg_velocity(const RgModelDev& m, RgLds& s, const uint32_t* dof_velmask, const int* subtree_adr, const int* subtree) {
+  // cdof_dot: spatial velocity accumulated over the dofs "before" d on its chain, crossed with cdof
+  PFOR(d, m.nv) {
+    float cv[6] = {0, 0, 0, 0, 0, 0};
+    for (int h = 0; h < 2; h++) {
+      uint32_t bits = dof_velmask[2 * d + h];
+      while (bits) { int a = __builtin_ctz(bits) + 32 * h; bits &= bits - 1; float q = s.qvel[a]; for (int e = 0; e < 6; e++) cv[e] += s.cdof[6 * a + e] * q; }
+    }
+    int j = m.dof_jntid[d];
+    if (m.jnt_type[j] == RG_JNT_FREE && d - m.jnt_dofadr[j] < 3) { for (int e = 0; e < 6; e++) s.cdofdot[6 * d + e] = 0; }
+    else cross_motion(s.cdofdot + 6 * d, cv, s.cdof + 6 * d);
+  }
+  PFOR(t, m.ntendon) {
+    float v = 0;
+    for (int e = 0; e < 4; e++) { int d = m.ten_dofs[4 * t + e]; if (d >= 0) v += s.tenJ[4 * t + e] * s.qvel[d]; }
+    s.tenvel[t] = v;
+    s.tenfrc[t] = m.tendon_stiffness[t] * (m.tendon_lengthspring[t] - s.tenlen[t]) - m.tendon_damping[t] * v;
+  }
+  SYNC();
+  // body velocities / bias accelerations by chain gathers, then body forces
+  for (int b = 1 + LANE; b < m.nbody; b += RG_WAVE) {
+    float cv[6] = {0, 0, 0, 0, 0, 0}, ca[6] = {0, 0, 0, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
+    for (int h = 0; h < 2; h++) {
+      uint32_t bits = m.body_dofmask[2 * b + h];
+      while (bits) {
+        int a = __builtin_ctz(bits) + 32 * h; bits &= bits - 1; float q = s.qvel[a];
+        for (int e = 0; e < 6; e++) { cv[e] += s.cdof[6 * a + e] * q; ca[e] += s.cdofdot[6 * a + e] * q; }
+      }
+    }
+    float t1[6], t2[6], t3[6];
+    mul_inert_vec(t1, s.cinert + 10 * b, ca);
+    mul_inert_vec(t2, s.cinert + 10 * b, cv);
+    cross_force(t3, cv, t2);
+    for (int e = 0; e < 6; e++) s.cacc[6 * b + e] = t1[e] + t3[e];  // per-body force before subtree accumulation
+  }
+  SYNC();
+  for (int w = LANE; w < m.nbody * 6; w += RG_WAVE) {
+    int b = w / 6, k = w - 6 * b;
+    float acc = 0;
+    if (b > 0) for (int e = subtree_adr[b]; e < subtree_adr[b + 1]; e++) acc += s.cacc[6 * subtree[e] + k];
+    s.cfrc[w] = acc;
+  }
+  SYNC();
+  PFOR(d, m.nv) {
+    const float *c = s.cdof + 6 * d, *f = s.cfrc + 6 * m.dof_bodyid[d];
+    s.qfrc_bias[d] = c[0] * f[0] + c[1] * f[1] + c[2] * f[2] + c[3] * f[3] + c[4] * f[4] + c[5] * f[5];
+    int j = m.dof_jntid[d], t = m.jnt_type[j];
+    float pas = -m.dof_damping[d] * s.qvel[d];
+    if ((t == RG_JNT_HINGE || t == RG_JNT_SLIDE) && m.jnt_stiffness[j] != 0) { int qa = m.jnt_qposadr[j]; pas -= m.jnt_stiffness[j] * (s.qpos[qa] - m.qpos_spring[qa]); }
+    for (int q = m.dof_ten_adr[d]; q < m.dof_ten_adr[d + 1]; q++) { int tt = m.dof_ten[2 * q], sl = m.dof_ten[2 * q + 1]; pas += s.tenJ[4 * tt + sl] * s.tenfrc[tt]; }
+    s.qfrc_passive[d] = pas;
+  }
+  SYNC();
+}
+
+// PID actuators (mjpid.pyx semantics, see oracle ro_fwd_actuation); updates controller state
+__device__ void rg_pid(const RgModelDev& m, RgLds& s) {
+  float dt = m.timestep;
+  PFOR(u, m.nu) {
+    const float* gp = m.actuator_gainprm + 10 * u;
+    float force;
+    float lo = m.actuator_forcerange[2 * u], hi = m.actuator_forcerange[2 * u + 1];
+    if (m.actuator_biastype[u] == 2) {
+      float err = s.ctrl[u] - s.actlen[u];
+      if (fabsf(err) < gp[5]) err = 0;
+      float* st = s.pid + 3 * u;
+      float integ = clampf(st[0] + err * dt, -gp[2], gp[2]);
+      float deriv = (1 - gp[4]) * st[2] + gp[4] * (err - st[1]) / dt;
+      force = gp[0] * (err + (gp[1] != 0 ? integ / gp[1] : 0.f) + gp[3] * deriv);
+      st[0] = integ; st[1] = err; st[2] = deriv;
+      if (lo != 0 || hi != 0) force = clampf(force, lo, hi);
+    } else {
+      float c = s.ctrl[u];
+      if (m.actuator_ctrllimited[u]) c = clampf(c, m.actuator_ctrlrange[2 * u], m.actuator_ctrlrange[2 * u + 1]);
+      force = gp[0] * c;
+    }
+    if (m.actuator_forcelimited[u]) force = clampf(force, lo, hi);
+    s.actfrc[u] = force;
+  }
+  SYNC();
+}
+__device__ void rg_smooth(const RgModelDev& m, RgLds& s) {
+  PFOR(d, m.nv) {
+    float f = 0;
+    for (int q = m.dof_act_adr[d]; q < m.dof_act_adr[d + 1]; q++) {
+      int u = m.dof_act[2 * q], sl = m.dof_act[2 * q + 1];
+      f += m.actuator_gear[u] * (sl < 0 ? 1.0f : s.tenJ[4 * m.actuator_trnid[u] + sl]) * s.actfrc[u];
+    }
+    s.qfrc_act[d] = f;
+    float v = s.qfrc_passive[d] - s.qfrc_bias[d] + f;
+    s.qfrc_smooth[d] = v; s.qacc_smooth[d] = v;
+  }
+  SYNC();
+  rg_solve_tree(m, s, s.qacc_smooth);
+}
+
+// ------------------------------------------------------------------------------------------------- constraints
+__device__ __forceinline__ float impedance(const float* si, float pos, float margin) {
+  float dmin = clampf(si[0], 1e-4f, 0.9999f), dmax = clampf(si[1], 1e-4f, 0.9999f), width = fmaxf(si[2], 1e-15f);
+  float mid = clampf(si[3], 1e-4f, 0.9999f), power = fmaxf(si[4], 1.0f);
+  if (dmin == dmax || width <= 1e-15f) return 0.5f * (dmin + dmax);
+  float x = fabsf((pos - margin) / width);
+  if (x >= 1) return dmax;
+  if (x <= 0) return dmin;
+  float y;
+  if (power == 1) y = x;
+  else if (x <= mid) y = powf(x, power) / powf(mid, power - 1);
+  else y = 1 - powf(1 - x, power) / powf(1 - mid, power - 1);
+  return dmin + y * (dmax - dmin);
+}
+__device__ __forceinline__ void kb(const RgModelDev& m, const float* solref, const float* solimp, float& K, float& B) {
+  float dmax = clampf(solimp[1], 1e-4f, 0.9999f);
+  if (solref[0] > 0) {
+    float tc = fmaxf(solref[0], 2 * m.timestep), dr = solref[1];
+    K = 1.0f / fmaxf(1e-15f, dmax * dmax * tc * tc * dr * dr); B = 2.0f / fmaxf(1e-15f, dmax * tc);
+  } else { K = -solref[0] / fmaxf(1e-15f, dmax * dmax); B = -solref[1] / fmaxf(1e-15f, dmax); }
+}
+// static row slot layout: [friction dofs][friction tendons][joint limits x2][tendon limits x2]
+__device__ __forceinline__ int nsrow(const RgModelDev& m) { return m.nfric_dof + m.nfric_ten + 2 * m.nlim_jnt + 2 * m.nlim_ten; }
+// J_r . x for a static row
+__device__ __forceinline__ float srow_dot(const RgModelDev& m, const RgLds& s, int r, const float* x) {
+  if (r < m.nfric_dof) return x[m.fric_dof[r]];
+  r -= m.nfric_dof;
+  if (r < m.nfric_ten) { int t = m.fric_ten[r]; float v = 0; for (int e = 0; e < 4; e++) { int d = m.ten_dofs[4 * t + e]; if (d >= 0) v += s.tenJ[4 * t + e] * x[d]; } return v; }
+  r -= m.nfric_ten;
+  if (r < 2 * m.nlim_jnt) { int j = m.lim_jnt[r >> 1]; float sg = (r & 1) ? -1.f : 1.f; return sg * x[m.jnt_dofadr[j]]; }  // side -1 (lower): J=+1; side +1 (upper): J=-1
+  r -= 2 * m.nlim_jnt;
+  int t = m.lim_ten[r >> 1]; float sg = (r & 1) ? -1.f : 1.f, v = 0;
+  for (int e = 0; e < 4; e++) { int d = m.ten_dofs[4 * t + e]; if (d >= 0) v += s.tenJ[4 * t + e] * x[d]; }
+  return sg * v;
+}
+// dst[dofs] += coef * J_r  (LDS atomics: several rows may touch one dof)
+__device__ __forceinline__ void srow_scatter(const RgModelDev& m, RgLds& s, int r, float coef, float* dst) {
+  if (r < m.nfric_dof) { atomicAdd(dst + m.fric_dof[r], coef); return; }
+  r -= m.nfric_dof;
+  int t; float sg = 1.f;
+  if (r < m.nfric_ten) t = m.fric_ten[r];
+  else {
+    r -= m.nfric_ten;
+    if (r < 2 * m.nlim_jnt) { int j = m.lim_jnt[r >> 1]; atomicAdd(dst + m.jnt_dofadr[j], (r & 1) ? -coef : coef); return; }
+    r -= 2 * m.nlim_jnt; t = m.lim_ten[r >> 1]; sg = (r & 1) ? -1.f : 1.f;
+  }
+  for (int e = 0; e < 4; e++) { int d = m.ten_dofs[4 * t + e]; if (d >= 0) atomicAdd(dst + d, sg * coef * s.tenJ[4 * t + e]); }
+}
+// H += D * J_r^T J_r
+__device__ __forceinline__ void srow_hess(const RgModelDev& m, RgLds& s, int r, float D) {
+  if (r < m.nfric_dof) { int d = m.fric_dof[r]; atomicAdd(s.H + d * NVP + d, D); return; }
+  r -= m.nfric_dof;
+  int t;
+  if (r < m.nfric_ten) t = m.fric_ten[r];
+  else {
+    r -= m.nfric_ten;
+    if (r < 2 * m.nlim_jnt) { int d = m.jnt_dofadr[m.lim_jnt[r >> 1]]; atomicAdd(s.H + d * NVP + d, D); return; }
+    r -= 2 * m.nlim_jnt; t = m.lim_ten[r >> 1];
+  }
+  for (int a = 0; a < 4; a++) { int da = m.ten_dofs[4 * t + a]; if (da < 0) continue;
+    for (int b = 0; b < 4; b++) { int db = m.ten_dofs[4 * t + b]; if (db < 0) continue; atomicAdd(s.H + da * NVP + db, D * s.tenJ[4 * t + a] * s.tenJ[4 * t + b]); } }
+}
+
+__device__ void rg_make_constraint(const RgModelDev& m, RgLds& s) {
+  int ns = nsrow(m);
+  PFOR(r, ns) {
+    int rr = r; float pos = 0, margin = 0, diag, floss = 0; const float *solref, *solimp; bool active = true, fric = false;
+    if (rr < m.nfric_dof) { int d = m.fric_dof[rr]; floss = m.dof_frictionloss[d]; diag = m.dof_invweight0[d]; solref = m.dof_solref + 2 * d; solimp = m.dof_solimp + 5 * d; fric = true; }
+    else if ((rr -= m.nfric_dof) < m.nfric_ten) { int t = m.fric_ten[rr]; floss = m.tendon_frictionloss[t]; diag = m.tendon_invweight0[t]; solref = m.tendon_solref_fri + 2 * t; solimp = m.tendon_solimp_fri + 5 * t; fric = true; }
+    else if ((rr -= m.nfric_ten) < 2 * m.nlim_jnt) {
+      int j = m.lim_jnt[rr >> 1]; float q = s.qpos[m.jnt_qposadr[j]];
+      pos = (rr & 1) ? (m.jnt_range[2 * j + 1] - q) : (q - m.jnt_range[2 * j]);
+      margin = m.jnt_margin[j]; active = pos < margin; diag = m.dof_invweight0[m.jnt_dofadr[j]]; solref = m.jnt_solref + 2 * j; solimp = m.jnt_solimp + 5 * j;
+    } else {
+      rr -= 2 * m.nlim_jnt; int t = m.lim_ten[rr >> 1]; float L = s.tenlen[t];
+      pos = (rr & 1) ? (m.tendon_range[2 * t + 1] - L) : (L - m.tendon_range[2 * t]);
+      margin = m.tendon_margin[t]; active = pos < margin; diag = m.tendon_invweight0[t]; solref = m.tendon_solref_lim + 2 * t; solimp = m.tendon_solimp_lim + 5 * t;
+    }
+    s.r_active[r] = active;
+    if (active) {
+      float imp = impedance(solimp, pos, margin), K, B;
+      float R = fmaxf(1e-15f, (1 - imp) * diag / imp);
+      kb(m, solref, solimp, K, B);
+      if (fric) K = 0;
+      float vel = srow_dot(m, s, r, s.qvel);
+      s.r_R[r] = R; s.r_D[r] = 1.0f / R; s.r_floss[r] = floss;
+      s.r_aref[r] = -B * vel - K * imp * (pos - margin);
+    }
+  }
+  // contact basis Jacobians on merged dof chains
+  int ncon = s.ncon;
+  for (int w = LANE; w < ncon * RG_W; w += RG_WAVE) {
+    int c = w / RG_W, sl = w - c * RG_W, p = s.c_pair[c];
+    int b1 = m.geom_bodyid[m.pair_geom[3 * p]], b2 = m.geom_bodyid[m.pair_geom[3 * p + 1]];
+    uint32_t lo = m.body_dofmask[2 * b1] | m.body_dofmask[2 * b2], hi = m.body_dofmask[2 * b1 + 1] | m.body_dofmask[2 * b2 + 1];
+    int nnz = __popc(lo) + __popc(hi);
+    if (sl == 0) s.c_nnz[c] = nnz;
+    float vn = 0, v1 = 0, v2 = 0, vs = 0; int d = 0;
+    if (sl < nnz) {
+      // sl-th set bit of (hi:lo)
+      int k = sl; uint32_t bits = lo; int base = 0;
+      if (k >= __popc(lo)) { k -= __popc(lo); bits = hi; base = 32; }
+      for (int q = 0; q < k; q++) bits &= bits - 1;
+      d = base + __builtin_ctz(bits);
+      v3 pos = ld3(s.c_pos + 3 * c);
+      v3 jp = mk3(0, 0, 0), jr = mk3(0, 0, 0);
+      if (in_chain(m, b2, d)) { jp = jp + jac_col(s, d, pos - ld3(s.org + 3 * b2)); jr = jr + ld3(s.cdof + 6 * d); }
+      if (in_chain(m, b1, d)) { jp = jp - jac_col(s, d, pos - ld3(s.org + 3 * b1)); jr = jr - ld3(s.cdof + 6 * d); }
+      const float* f = s.c_frame + 9 * c;
+      vn = dot(ld3(f), jp); v1 = dot(ld3(f + 3), jp); v2 = dot(ld3(f + 6), jp); vs = dot(ld3(f), jr);
+    }
+    s.c_idx[c * RG_W + sl] = (unsigned char)d;
+    float* Bc = s.c_B + c * 4 * RG_W;
+    Bc[sl] = vn; Bc[RG_W + sl] = v1; Bc[2 * RG_W + sl] = v2; Bc[3 * RG_W + sl] = vs;
+  }
+  SYNC();
+  // contact parameters: D (shared by the pyramid), friction coefficients, reference accelerations
+  PFOR(c, ncon) {
+    int p = s.c_pair[c], dim = s.c_dim[c];
+    const float* prm = m.pair_prm + 12 * p;
+    int b1 = m.geom_bodyid[m.pair_geom[3 * p]], b2 = m.geom_bodyid[m.pair_geom[3 * p + 1]];
+    float tran = m.body_invweight0[2 * b1] + m.body_invweight0[2 * b2];
+    float includemargin = prm[0] - prm[1], dist = s.c_dist[c];
+    float imp = impedance(prm + 7, dist, includemargin), K, B;
+    kb(m, prm + 5, prm + 7, K, B);
+    float mu0 = prm[2];  // friction[0]
+    // first pyramid row: diagApprox = tran + mu0^2 * tran ; all rows get R = 2 mu^2 R_first, mu = friction[0]/sqrt(impratio)
+    float R;
+    if (dim == 1) R = fmaxf(1e-15f, (1 - imp) * tran / imp);
+    else { float Rf = fmaxf(1e-15f, (1 - imp) * (tran + mu0 * mu0 * tran) / imp); float mu = mu0 * sqrtf(1.0f / m.impratio); R = 2 * mu * mu * Rf; }
+    s.c_D[c] = 1.0f / R;
+    // friction coefficient of tangent direction k (k = 0,1 sliding; 2 spin)
+    s.c_mu[4 * c] = prm[2]; s.c_mu[4 * c + 1] = prm[2]; s.c_mu[4 * c + 2] = prm[3]; s.c_mu[4 * c + 3] = 0;
+    const float* Bc = s.c_B + c * 4 * RG_W; int nnz = s.c_nnz[c];
+    float vb[4] = {0, 0, 0, 0};
+    for (int sl = 0; sl < nnz; sl++) { float q = s.qvel[s.c_idx[c * RG_W + sl]]; for (int k = 0; k < 4; k++) vb[k] += Bc[k * RG_W + sl] * q; }
+    float base = -K * imp * (dist - includemargin);
+    if (dim == 1) s.p_aref[6 * c] = base - B * vb[0];
+    else for (int k = 0; k < dim - 1; k++) { float mu = s.c_mu[4 * c + k]; s.p_aref[6 * c + 2 * k] = base - B * (vb[0] + mu * vb[k + 1]); s.p_aref[6 * c + 2 * k + 1] = base - B * (vb[0] - mu * vb[k + 1]); }
+  }
+  SYNC();
+}
+__device__ __forceinline__ int npyr(int dim) { return dim == 1 ? 1 : 2 * (dim - 1); }
+
+// jar = J x - aref (or J x when `homog`) for every active row; result in r_jar/p_jar (or r_jv/p_jv)
+__device__ void rg_J_mul(const RgModelDev& m, RgLds& s, const float* x, bool to_jv) {
+  int ns = nsrow(m), ncon = s.ncon;
+  PFOR(r, ns) if (s.r_active[r]) { float v = srow_dot(m, s, r, x); if (to_jv) s.r_jv[r] = v; else s.r_jar[r] = v - s.r_aref[r]; }
+  for (int w = LANE; w < ncon * 4; w += RG_WAVE) {
+    int c = w >> 2, k = w & 3; const float* Bc = s.c_B + c * 4 * RG_W + k * RG_W; int nnz = s.c_nnz[c]; float v = 0;
+    for (int sl = 0; sl < nnz; sl++) v += Bc[sl] * x[s.c_idx[c * RG_W + sl]];
+    s.c_bdot[w] = v;
+  }
+  SYNC();
+  for (int w = LANE; w < ncon * 6; w += RG_WAVE) {
+    int c = w / 6, q = w - 6 * c, dim = s.c_dim[c];
+    if (q >= npyr(dim)) continue;
+    float v;
+    if (dim == 1) v = s.c_bdot[4 * c];
+    else { int k = q >> 1; float mu = s.c_mu[4 * c + k]; v = s.c_bdot[4 * c] + ((q & 1) ? -mu : mu) * s.c_bdot[4 * c + k + 1]; }
+    if (to_jv) s.p_jv[w] = v; else s.p_jar[w] = v - s.p_aref[w];
+  }
+  SYNC();
+}
+// forces / quadratic flags from jar; returns the wave-summed constraint cost
+__device__ float rg_constraint_update(const RgModelDev& m, RgLds& s) {
+  int ns = nsrow(m), ncon = s.ncon; float cost = 0;
+  PFOR(r, ns) {
+    if (!s.r_active[r]) { s.r_quad[r] = 0; s.r_force[r] = 0; continue; }
+    float x = s.r_jar[r], D = s.r_D[r], R = s.r_R[r], f = s.r_floss[r];
+    if (f > 0) {
+      if (x <= -R * f) { s.r_force[r] = f; s.r_quad[r] = 0; cost += f * (-0.5f * R * f - x); }
+      else if (x >= R * f) { s.r_force[r] = -f; s.r_quad[r] = 0; cost += f * (-0.5f * R * f + x); }
+      else { s.r_force[r] = -D * x; s.r_quad[r] = 1; cost += 0.5f * D * x * x; }
+    } else if (x >= 0) { s.r_force[r] = 0; s.r_quad[r] = 0; }
+    else { s.r_force[r] = -D * x; s.r_quad[r] = 1; cost += 0.5f * D * x * x; }
+  }
+  for (int w = LANE; w < ncon * 6; w += RG_WAVE) {
+    int c = w / 6, q = w - 6 * c;
+    if (q >= npyr(s.c_dim[c])) { s.p_quad[w] = 0; s.p_force[w] = 0; continue; }
+    float x = s.p_jar[w], D = s.c_D[c];
+    if (x >= 0) { s.p_force[w] = 0; s.p_quad[w] = 0; } else { s.p_force[w] = -D * x; s.p_quad[w] = 1; cost += 0.5f * D * x * x; }
+  }
+  SYNC();
+  return wave_sum(cost);
+}
+// dst = J^T force (dst zeroed here)
+__device__ void rg_JT_force(const RgModelDev& m, RgLds& s, float* dst) {
+  int ns = nsrow(m), ncon = s.ncon;
+  PFOR(d, m.nv) dst[d] = 0;
+  for (int w = LANE; w < ncon * 4; w += RG_WAVE) {
+    int c = w >> 2, k = w & 3, dim = s.c_dim[c]; float v = 0; const float* pf = s.p_force + 6 * c;
+    if (dim == 1) v = k == 0 ? pf[0] : 0.f;
+    else if (k == 0) { for (int q = 0; q < npyr(dim); q++) v += pf[q]; }
+    else if (k < dim) v = s.c_mu[4 * c + k - 1] * (pf[2 * (k - 1)] - pf[2 * (k - 1) + 1]);
+    s.c_bfrc[w] = v;
+  }
+  SYNC();
+  PFOR(r, ns) if (s.r_active[r] && s.r_force[r] != 0) srow_scatter(m, s, r, s.r_force[r], dst);
+  for (int w = LANE; w < ncon * RG_W; w += RG_WAVE) {
+    int c = w / RG_W, sl = w - c * RG_W;
+    if (sl >= s.c_nnz[c]) continue;
+    const float* Bc = s.c_B + c * 4 * RG_W; const float* bf = s.c_bfrc + 4 * c;
+    float v = Bc[sl] * bf[0] + Bc[RG_W + sl] * bf[1] + Bc[2 * RG_W + sl] * bf[2] + Bc[3 * RG_W + sl] * bf[3];
+    atomicAdd(dst + s.c_idx[c * RG_W + sl], v);
+  }
+  SYNC();
+}
+// y = M x (dense rows; x, y in LDS)
+__device__ void rg_M_mul(const RgModelDev& m, RgLds& s, const float* x, float* y) {
+  PFOR(i, m.nv) { float v = 0; const float* row = s.M + i * NVP; for (int k = 0; k < m.nv; k++) v += row[k] * x[k]; y[i] = v; }
+  SYNC();
+}
+// dense Cholesky of H (lower, in place) and solve H x = b
+__device__ void rg_chol(const RgModelDev& m, RgLds& s) {
+  int n = m.nv;
+  for (int j = 0; j < n; j++) {
+    float djj = s.H[j * NVP + j];
+    if (!(djj > 1e-30f)) { s.status |= RG_STATUS_BAD_FACTOR; djj = 1e-30f; }
+    float r = 1.0f / sqrtf(djj);
+    SYNC();
+    for (int i = j + LANE; i < n; i += RG_WAVE) { if (i == j) s.H[j * NVP + j] = sqrtf(djj); else s.H[i * NVP + j] *= r; }
+    SYNC();
+    int rem = n - j - 1, cnt = rem * (rem + 1) / 2;
+    for (int w = LANE; w < cnt; w += RG_WAVE) {
+      // w -> (a >= b) in the trailing lower triangle
+      int a = (int)((sqrtf(8.0f * w + 1.0f) - 1.0f) * 0.5f);
+      while (a * (a + 1) / 2 > w) a--;
+      while ((a + 1) * (a + 2) / 2 <= w) a++;
+      int b = w - a * (a + 1) / 2;
+      int i = j + 1 + a, k = j + 1 + b;
+      s.H[i * NVP + k] -= s.H[i * NVP + j] * s.H[k * NVP + j];
+    }
+    SYNC();
+  }
+}
+__device__ void rg_chol_solve(const RgModelDev& m, RgLds& s, float* x) {
+  int n = m.nv;
+  // forward: L y = b, lane i owns x[i]
+  float xi = LANE < n ? x[LANE] : 0.f;
+  for (int j = 0; j < n; j++) {
+    float xj = __shfl(xi, j) / s.H[j * NVP + j];
+    if (LANE == j) xi = xj;
+    else if (LANE > j && LANE < n) xi -= s.H[LANE * NVP + j] * xj;
+  }
+  for (int j = n - 1; j >= 0; j--) {
+    float xj = __shfl(xi, j) / s.H[j * NVP + j];
+    if (LANE == j) xi = xj;
+    else if (LANE < j) xi -= s.H[j * NVP + LANE] * xj;
+  }
+  if (LANE < n) x[LANE] = xi;
+  SYNC();
+}
+
+struct LsPt { float cost, grad, hess; };
+__device__ LsPt rg_ls_eval(const RgModelDev& m, RgLds& s, float alpha, float q0, float q1, float q2) {
+  int ns = nsrow(m), ncon = s.ncon; float c = 0, g = 0, h = 0;
+  PFOR(r, ns) {
+    if (!s.r_active[r]) continue;
+    float jv = s.r_jv[r], x = s.r_jar[r] + alpha * jv, D = s.r_D[r], R = s.r_R[r], f = s.r_floss[r];
+    if (f > 0) {
+      if (x <= -R * f) { c += f * (-0.5f * R * f - x); g += -f * jv; }
+      else if (x >= R * f) { c += f * (-0.5f * R * f + x); g += f * jv; }
+      else { c += 0.5f * D * x * x; g += D * x * jv; h += D * jv * jv; }
+    } else if (x < 0) { c += 0.5f * D * x * x; g += D * x * jv; h += D * jv * jv; }
+  }
+  for (int w = LANE; w < ncon * 6; w += RG_WAVE) {
+    int cc = w / 6, q = w - 6 * cc;
+    if (q >= npyr(s.c_dim[cc])) continue;
+    float jv = s.p_jv[w], x = s.p_jar[w] + alpha * jv, D = s.c_D[cc];
+    if (x < 0) { c += 0.5f * D * x * x; g += D * x * jv; h += D * jv * jv; }
+  }
+  LsPt p;
+  p.cost = wave_sum(c) + alpha * alpha * q2 + alpha * q1 + q0;
+  p.grad = wave_sum(g) + 2 * alpha * q2 + q1;
+  p.hess = wave_sum(h) + 2 * q2;
+  return p;
+}
+
+// Newton solver on the primal problem (see oracle ro_solve); result: s.qacc, s.qfrc_con.  Returns iterations.
+__device__ int rg_solve(const RgModelDev& m, RgLds& s, int& nefc_out) {
+  int nv = m.nv, ns = nsrow(m), ncon = s.ncon;
+  // count active rows (diagnostic only)
+  { float cnt = 0; PFOR(r, ns) cnt += s.r_active[r] ? 1.f : 0.f; PFOR(c, ncon) cnt += (float)npyr(s.c_dim[c]); nefc_out = (int)(wave_sum(cnt) + 0.5f); }
+  float scale = 1.0f / (m.meaninertia * (nv > 1 ? nv : 1));
+  float tol = fmaxf(m.tolerance, 1e-7f);
+  // warm start: the better of qacc_warmstart and qacc_smooth
+  float cost_pick[2];
+  for (int pass = 0; pass < 2; pass++) {
+    const float* a = pass == 0 ? s.warm : s.qacc_smooth;
+    rg_M_mul(m, s, a, s.Ma);
+    rg_J_mul(m, s, a, false);
+    float g = 0; PFOR(i, nv) g += 0.5f * (s.Ma[i] - s.qfrc_smooth[i]) * (a[i] - s.qacc_smooth[i]);
+    g = wave_sum(g);
+    cost_pick[pass] = g + rg_constraint_update(m, s);
+  }
+  { const float* a = cost_pick[0] < cost_pick[1] ? s.warm : s.qacc_smooth; PFOR(i, nv) s.qacc[i] = a[i]; }
+  SYNC();
+  float cost = 0, oldcost = 0; int iters = 0;
+  for (int iter = 0;; iter++) {
+    rg_M_mul(m, s, s.qacc, s.Ma);
+    rg_J_mul(m, s, s.qacc, false);
+    float gauss = 0; PFOR(i, nv) gauss += 0.5f * (s.Ma[i] - s.qfrc_smooth[i]) * (s.qacc[i] - s.qacc_smooth[i]);
+    gauss = wave_sum(gauss);
+    float cc = rg_constraint_update(m, s);
+    oldcost = cost; cost = gauss + cc;
+    rg_JT_force(m, s, s.qfrc_con);
+    float gn = 0; PFOR(i, nv) { float gi = s.Ma[i] - s.qfrc_smooth[i] - s.qfrc_con[i]; s.grad[i] = gi; gn += gi * gi; }
+    gn = sqrtf(wave_sum(gn)) * scale;
+    SYNC();
+#ifdef RG_EMUL_TRACE
+    if (LANE == 0) printf("  newton it %d cost %.9e gn %.3e improvement %.3e\n", iter, cost, gn, scale * (oldcost - cost));
+#endif
+    if (iter > 0 && scale * (oldcost - cost) < tol) break;
+    if (gn < tol || iter >= m.iterations) break;
+    iters = iter + 1;
+    // H = M + J' D J over the quadratic rows
+    for (int w = LANE; w < nv * NVP; w += RG_WAVE) s.H[w] = s.M[w];
+    SYNC();
+    PFOR(r, ns) if (s.r_active[r] && s.r_quad[r]) srow_hess(m, s, r, s.r_D[r]);
+    for (int c = 0; c < ncon; c++) {
+      int dim = s.c_dim[c], nnz = s.c_nnz[c]; float D = s.c_D[c];
+      // C = P' D_act P in the basis (normal, t1, t2, spin): only first row/col and the diagonal are non-zero
+      float cn = 0, ck[3] = {0, 0, 0}, cd[3] = {0, 0, 0};
+      if (dim == 1) cn = s.p_quad[6 * c] ? D : 0.f;
+      else for (int k = 0; k < dim - 1; k++) {
+        float mu = s.c_mu[4 * c + k]; int qp = s.p_quad[6 * c + 2 * k], qm = s.p_quad[6 * c + 2 * k + 1];
+        cn += D * (qp + qm); ck[k] = D * mu * (qp - qm); cd[k] = D * mu * mu * (qp + qm);
+      }
+      if (cn == 0) continue;
+      const float* Bc = s.c_B + c * 4 * RG_W;
+      for (int w = LANE; w < nnz * nnz; w += RG_WAVE) {
+        int a = w / nnz, b = w - a * nnz;
+        float na = Bc[a], nb = Bc[b], v = cn * na * nb;
+        for (int k = 0; k < 3; k++) { float ta = Bc[(k + 1) * RG_W + a], tb = Bc[(k + 1) * RG_W + b]; v += ck[k] * (na * tb + ta * nb) + cd[k] * ta * tb; }
+        s.H[s.c_idx[c * RG_W + a] * NVP + s.c_idx[c * RG_W + b]] += v;
+      }
+      SYNC();
+    }
+    SYNC();
+    rg_chol(m, s);
+    PFOR(i, nv) s.search[i] = -s.grad[i];
+    SYNC();
+    rg_chol_solve(m, s, s.search);
+    // exact line search along `search`
+    rg_M_mul(m, s, s.search, s.Mv);
+    rg_J_mul(m, s, s.search, true);
+    float q1 = 0, q2 = 0, sn = 0;
+    PFOR(i, nv) { q1 += s.search[i] * (s.Ma[i] - s.qfrc_smooth[i]); q2 += 0.5f * s.search[i] * s.Mv[i]; sn += s.search[i] * s.search[i]; }
+    q1 = wave_sum(q1); q2 = wave_sum(q2); sn = sqrtf(wave_sum(sn));
+    if (sn < 1e-15f) break;
+    float gtol = tol * 0.01f * sn / scale;
+    LsPt p0 = rg_ls_eval(m, s, 0.f, gauss, q1, q2);
+    float alpha = 0;
+    if (p0.grad < 0 && p0.hess > 0) {
+      float lo = 0, hi = -1, glo = p0.grad, hlo = p0.hess, ghi = 0, hhi = 1;
+      alpha = -p0.grad / p0.hess;
+      for (int it = 0; it < 12; it++) {
+        LsPt p = rg_ls_eval(m, s, alpha, gauss, q1, q2);
+        if (fabsf(p.grad) < gtol) break;
+        if (p.grad < 0) { lo = alpha; glo = p.grad; hlo = p.hess; } else { hi = alpha; ghi = p.grad; hhi = p.hess; }
+        float cand = lo - glo / hlo;
+        if (hi >= 0 && !(cand > lo && cand < hi)) { cand = hi - ghi / hhi; if (!(cand > lo && cand < hi)) cand = 0.5f * (lo + hi); }
+        if (cand == alpha) break;
+        alpha = cand;
+      }
+    }
+#ifdef RG_EMUL_TRACE
+    if (LANE == 0) printf("     alpha %.6e p0.grad %.3e p0.hess %.3e gtol %.3e\n", alpha, p0.grad, p0.hess, gtol);
+#endif
+    if (alpha == 0) break;
+    PFOR(i, nv) s.qacc[i] += alpha * s.search[i];
+    SYNC();
+  }
+  // forces at the solution
+  rg_J_mul(m, s, s.qacc, false);
+  rg_constraint_update(m, s);
+  rg_JT_force(m, s, s.qfrc_con);
+  return iters;
+}
+
+// ------------------------------------------------------------------------------------------------- integration
+__device__ void rg_euler(const RgModelDev& m, RgLds& s) {
+  float h = m.timestep;
+  rg_factor_tree(m, s, m.dof_damping, h);
+  PFOR(i, m.nv) s.tmpv[i] = s.qfrc_smooth[i] + s.qfrc_con[i];
+  SYNC();
+  rg_solve_tree(m, s, s.tmpv);
+  PFOR(i, m.nv) { s.qvel[i] += h * s.tmpv[i]; s.warm[i] = s.qacc[i]; }
+  SYNC();
+  PFOR(j, m.njnt) {
+    int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j], t = m.jnt_type[j];
+    if (t == RG_JNT_FREE) { for (int k = 0; k < 3; k++) s.qpos[qa + k] += h * s.qvel[da + k]; qa += 3; da += 3; }
+    if (t == RG_JNT_FREE || t == RG_JNT_BALL) {
+      v3 w = ld3(s.qvel + da); float ang = norm(w) * h;
+      if (ang > 0) { q4 q = qnormalize(qmul(ldq(s.qpos + qa), axisangle(normalized(w), ang))); stq(s.qpos + qa, q); }
+    } else s.qpos[qa] += h * s.qvel[da];
+  }
+  SYNC();
+}
+
+// ------------------------------------------------------------------------------------------------- the env-step kernel
+struct RgAux {  // extra static tables (kept out of RgModelDev to keep the kernarg small)
+  const int *subtree_adr, *subtree;
+  const uint32_t* dof_velmask;
+};
+
+__device__ void rg_dump(const RgModelDev& m, RgLds& s, float* dbg, int nefc, int iters) {
+  PFOR(i, m.nbody * 3) dbg[RG_DBG_XPOS + i] = s.xpos[i];
+  PFOR(i, m.nbody * 4) dbg[RG_DBG_XQUAT + i] = s.xquat[i];
+  PFOR(i, m.nsite * 3) dbg[RG_DBG_SITE + i] = s.spos[i];
+  for (int w = LANE; w < m.nv * m.nv; w += RG_WAVE) dbg[RG_DBG_M + w] = s.M[(w / m.nv) * NVP + (w % m.nv)];
+  PFOR(i, m.ntendon) dbg[RG_DBG_TENLEN + i] = s.tenlen[i];
+  PFOR(i, m.ntendon * 4) dbg[RG_DBG_TENJ + i] = s.tenJ[i];
+  PFOR(i, m.nv) { dbg[RG_DBG_BIAS + i] = s.qfrc_bias[i]; dbg[RG_DBG_PASSIVE + i] = s.qfrc_passive[i]; dbg[RG_DBG_ACTFRC + i] = s.qfrc_act[i]; dbg[RG_DBG_QACCS + i] = s.qacc_smooth[i]; dbg[RG_DBG_QACC + i] = s.qacc[i]; }
+  if (LANE == 0) { dbg[RG_DBG_NCON] = (float)s.ncon; dbg[RG_DBG_NCON + 1] = (float)nefc; dbg[RG_DBG_NCON + 2] = (float)iters; dbg[RG_DBG_NCON + 3] = (float)s.ncand; }
+  PFOR(c, s.ncon) { float* o = dbg + RG_DBG_CON + 8 * c; o[0] = s.c_dist[c]; o[1] = s.c_pos[3 * c]; o[2] = s.c_pos[3 * c + 1]; o[3] = s.c_pos[3 * c + 2]; o[4] = s.c_frame[9 * c]; o[5] = s.c_frame[9 * c + 1]; o[6] = s.c_frame[9 * c + 2]; o[7] = (float)s.c_pair[c]; }
+}
+
+__device__ void rg_position_stage(const RgModelDev& m, const RgAux& x, RgLds& s) {
+  rg_kinematics(m, s);
+  rg_com_pos(m, s);
+  rg_tendon(m, s);
+}
+
+__global__ void __launch_bounds__(RG_WAVE) rg_step_kernel(RgModelDev m, RgAux x, RgEnvDev env, RgBatchDev bt, int nsubsteps, int nforward_ticks, int flags) {
+#ifdef RG_EMUL
+  RgLds& s = *(RgLds*)emul_lds();
+#else
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  RgLds& s = *(RgLds*)lds_raw;
+#endif
+  int e = blockIdx.x;
+  if (e >= bt.B) return;
+  if (bt.active && !bt.active[e]) return;
+  // ---- load the env's state row
+  PFOR(i, m.nq) s.qpos[i] = bt.qpos[(size_t)e * m.nq + i];
+  PFOR(i, m.nv) { s.qvel[i] = bt.qvel[(size_t)e * m.nv + i]; s.warm[i] = bt.qacc_warmstart[(size_t)e * m.nv + i]; }
+  PFOR(i, 3 * m.nu) s.pid[i] = bt.pid[(size_t)e * 3 * m.nu + i];
+  if (LANE == 0) s.status = bt.status[e];
+  SYNC();
+  // ---- action -> ctrl (robot_interface.py:247-278 with the hand's position->control matrix)
+  if (bt.action) {
+    PFOR(u, m.nu) {
+      float lo = m.actuator_ctrlrange[2 * u], hi = m.actuator_ctrlrange[2 * u + 1], centre;
+      if (env.relative_action) { centre = 0; for (int j = 0; j < env.n_hand_jnt; j++) centre += env.pos_to_ctrl[u * env.n_hand_jnt + j] * s.qpos[env.hand_qposadr + j]; }
+      else centre = 0.5f * (hi + lo);
+      float a = clampf(bt.action[(size_t)e * m.nu + u], -1.f, 1.f);
+      s.ctrl[u] = clampf(centre + a * 0.5f * (hi - lo), lo, hi);
+    }
+  } else { PFOR(u, m.nu) s.ctrl[u] = bt.ctrl[(size_t)e * m.nu + u]; }
+  SYNC();
+  float st_ncon = 0, st_nefc = 0, st_iter = 0;
+  bool bad = false;
+  for (int sub = 0; sub < nsubsteps; sub++) {
+    // mj_checkPos / mj_checkVel
+    float bd = 0; PFOR(i, m.nq) bd += (fabsf(s.qpos[i]) < 1e10f) ? 0.f : 1.f; PFOR(i, m.nv) bd += (fabsf(s.qvel[i]) < 1e10f) ? 0.f : 1.f;
+    if (wave_sum(bd) > 0) { bad = true; break; }
+    rg_position_stage(m, x, s);
+    rg_crb(m, s, x.subtree_adr, x.subtree);
+    rg_factor_tree(m, s, (const float*)0, 0.f);
+    rg_collision(m, s);
+    rg_velocity(m, s, x.dof_velmask, x.subtree_adr, x.subtree);
+    rg_make_constraint(m, s);
+    rg_pid(m, s);
+    rg_smooth(m, s);
+    int nefc = 0;
+    int iters = rg_solve(m, s, nefc);
+    st_ncon += s.ncon; st_nefc += nefc; st_iter += iters;
+    if (sub == 0 && (flags & 1) && bt.dbg) rg_dump(m, s, bt.dbg + (size_t)e * RG_DBG_SIZE, nefc, iters);
+    bd = 0; PFOR(i, m.nv) bd += (fabsf(s.qacc[i]) < 1e10f) ? 0.f : 1.f;
+    if (wave_sum(bd) > 0) { bad = true; break; }
+    rg_euler(m, s);
+  }
+  if (bad && LANE == 0) s.status |= RG_STATUS_BAD_STATE;
+  // ---- state-less forward() calls of the reference (simulation_interface.py:185, robot_env.py:677,
+  //      observation/mujoco.py:22-27): only their PID-controller side effect touches the state
+  if (nforward_ticks > 0 || bt.obs) {
+    rg_position_stage(m, x, s);
+    for (int k = 0; k < nforward_ticks; k++) rg_pid(m, s);
+  }
+  // ---- write back
+  PFOR(i, m.nq) bt.qpos[(size_t)e * m.nq + i] = s.qpos[i];
+  PFOR(i, m.nv) { bt.qvel[(size_t)e * m.nv + i] = s.qvel[i]; bt.qacc_warmstart[(size_t)e * m.nv + i] = s.warm[i]; }
+  PFOR(i, 3 * m.nu) bt.pid[(size_t)e * 3 * m.nu + i] = s.pid[i];
+  PFOR(u, m.nu) bt.ctrl[(size_t)e * m.nu + u] = s.ctrl[u];
+  if (LANE == 0) {
+    bt.status[e] = s.status; bt.time[e] += nsubsteps * m.timestep;
+    if (bt.stats) { float* st = bt.stats + 4 * (size_t)e; st[0] += st_ncon; st[1] += st_nefc; st[2] += st_iter; st[3] += nsubsteps; }
+  }
+  // ---- observation row (robot_env.py:714-743; keys/order: DESIGN.md "observation layout")
+  if (bt.obs) {
+    int od = 3 + 4 + m.nq + m.nv + env.n_hand_jnt + 15;
+    float* o = bt.obs + (size_t)e * od;
+    // cube_pos = the three slide-joint coordinates, cube_quat sign-normalised to w >= 0
+    // (envs/dactyl/observation/cube.py:8-29)
+    PFOR(i, 3) o[i] = s.qpos[env.cube_pos_qposadr + i];
+    { float sg = s.qpos[env.cube_quat_qposadr] < 0 ? -1.f : 1.f; PFOR(i, 4) o[3 + i] = sg * s.qpos[env.cube_quat_qposadr + i]; }
+    PFOR(i, m.nq) o[7 + i] = (i >= env.target_qposadr && i < env.target_qposadr + env.target_nq) ? 0.f : s.qpos[i];
+    PFOR(i, m.nv) o[7 + m.nq + i] = (i >= env.target_dofadr && i < env.target_dofadr + env.target_nv) ? 0.f : s.qvel[i];
+    PFOR(i, env.n_hand_jnt) o[7 + m.nq + m.nv + i] = s.qpos[env.hand_qposadr + i];
+    // fingertips relative to the three reference sites (hand_forward_kinematics.py:39-50)
+    PFOR(i, 5) {
+      v3 r0 = ld3(s.spos + 3 * env.ref_site[0]), r1 = ld3(s.spos + 3 * env.ref_site[1]), r2 = ld3(s.spos + 3 * env.ref_site[2]);
+      v3 a = normalized(r0 - r1), c = normalized(r2 - r1), b = cross(a, c);
+      v3 t = ld3(s.spos + 3 * env.tip_site[i]) - r1;
+      float* ot = o + 7 + m.nq + m.nv + env.n_hand_jnt + 3 * i;
+      ot[0] = dot(t, a); ot[1] = dot(t, b); ot[2] = dot(t, c);
+    }
+    // goal distance: 2 acos(|w|) of q_goal * conj(q_cube)  (locked_parallel.py:54-76, rotation.py:271-286)
+    if (bt.goal_quat && bt.goal_dist && LANE == 0) {
+      q4 g = ldq(bt.goal_quat + 4 * (size_t)e), c = ldq(s.qpos + env.cube_quat_qposadr);
+      c.x = -c.x; c.y = -c.y; c.z = -c.z;
+      q4 dq = qmul(g, c);
+      bt.goal_dist[e] = 2.0f * acosf(clampf(fabsf(dq.w), -1.f, 1.f));
+    }
+  }
+}
+
+// Collision unit-test hook: kinematics of each env's stored qpos, then one MPR query between two geoms.
+// out[e][8] = hit, depth, dir3, pos3 (world)
+__global__ void __launch_bounds__(RG_WAVE) rg_mpr_pair_kernel(RgModelDev m, RgBatchDev bt, int g1, int g2, float margin, float* out) {
+#ifdef RG_EMUL
+  RgLds& s = *(RgLds*)emul_lds();
+#else
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  RgLds& s = *(RgLds*)lds_raw;
+#endif
+  int e = blockIdx.x;
+  PFOR(i, m.nq) s.qpos[i] = bt.qpos[(size_t)e * m.nq + i];
+  SYNC();
+  rg_kinematics(m, s);
+  MprGeom A, B;
+  v3 p1 = ld3(s.gpos + 3 * g1), p2 = ld3(s.gpos + 3 * g2);
+  A.type = m.geom_type[g1]; A.mat = s.gmat + 9 * g1; A.size = ld3(m.geom_size + 3 * g1); A.margin = 0.5f * margin; A.pos = mk3(0, 0, 0);
+  B.type = m.geom_type[g2]; B.mat = s.gmat + 9 * g2; B.size = ld3(m.geom_size + 3 * g2); B.margin = 0.5f * margin; B.pos = p2 - p1;
+  if (A.type == RG_GEOM_MESH) { int id = m.geom_dataid[g1]; A.vert = m.mesh_vert + 3 * m.mesh_vertadr[id]; A.nvert = m.mesh_vertnum[id]; } else { A.vert = 0; A.nvert = 0; }
+  if (B.type == RG_GEOM_MESH) { int id = m.geom_dataid[g2]; B.vert = m.mesh_vert + 3 * m.mesh_vertadr[id]; B.nvert = m.mesh_vertnum[id]; } else { B.vert = 0; B.nvert = 0; }
+  float depth = 0; v3 dir = mk3(0, 0, 0), pos = mk3(0, 0, 0);
+  bool hit = rg_mpr(A, B, m.mpr_iterations, m.mpr_tolerance, depth, dir, pos);
+  if (LANE == 0) {
+    float* o = out + 8 * (size_t)e;
+    o[0] = hit ? 1.f : 0.f; o[1] = depth; o[2] = dir.x; o[3] = dir.y; o[4] = dir.z; o[5] = pos.x + p1.x; o[6] = pos.y + p1.y; o[7] = pos.z + p1.z;
+  }
+}

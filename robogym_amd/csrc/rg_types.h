@@ -1,0 +1,117 @@
+// rg_types.h — device-side model / batch descriptors shared by the C-ABI host code (rg_api.hip)
+// and the stepper kernel (rg_kernel.h).  All device arrays are fp32 / int32.
+#pragma once
+#include <stdint.h>
+
+// compile-time capacities of the "hand" kernel configuration (dactyl/locked, dactyl/reach)
+#define RG_MAXNQ 40
+#define RG_MAXNV 40
+#define RG_MAXBODY 32
+#define RG_MAXJNT 32
+#define RG_MAXGEOM 72
+#define RG_MAXSITE 40
+#define RG_MAXTEN 12
+#define RG_MAXU 20
+#define RG_MAXCON 32    // contacts kept per env (overflow -> RG_STATUS_CON_FULL)
+#define RG_MAXCAND 64   // candidate geom pairs surviving the broadphase per substep
+#define RG_MAXROW 64    // friction-loss + limit rows
+#define RG_W 16         // max nonzeros of a sparse constraint row
+#define RG_WAVE 64
+
+// per-env sticky status bits (replace MuJoCo's warning callback, warning_buffer.py:27-83)
+#define RG_STATUS_BAD_STATE 1u   // NaN/inf or |x|>1e10 in qpos/qvel/qacc
+#define RG_STATUS_CON_FULL 2u    // more contacts than RG_MAXCON
+#define RG_STATUS_CAND_FULL 4u   // more broadphase candidates than RG_MAXCAND
+#define RG_STATUS_ROW_FULL 8u    // more friction/limit rows than RG_MAXROW
+#define RG_STATUS_BAD_FACTOR 16u // Cholesky pivot <= 0
+
+enum { RG_JNT_FREE = 0, RG_JNT_BALL = 1, RG_JNT_SLIDE = 2, RG_JNT_HINGE = 3 };
+enum { RG_GEOM_PLANE = 0, RG_GEOM_SPHERE = 2, RG_GEOM_CAPSULE = 3, RG_GEOM_ELLIPSOID = 4, RG_GEOM_CYLINDER = 5, RG_GEOM_BOX = 6, RG_GEOM_MESH = 7 };
+enum { RG_WRAP_JOINT = 1, RG_WRAP_PULLEY = 2, RG_WRAP_SITE = 3, RG_WRAP_SPHERE = 4, RG_WRAP_CYLINDER = 5 };
+
+struct RgModelDev {
+  int nq, nv, nu, nbody, njnt, ngeom, nsite, ntendon, nwrap, nmesh;
+  int nlevel, ndoflevel, nM, npair, nstatic, nfric_dof, nfric_ten, nlim_jnt, nlim_ten;
+  int iterations, mpr_iterations, cone;
+  float timestep, gravity[3], tolerance, impratio, mpr_tolerance, meaninertia;
+  // bodies
+  const int *body_parentid, *body_rootid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum, *body_lastdof;
+  const float *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_invweight0;
+  const int *lvl_body, *lvl_body_adr, *static_body;
+  const float *static_xpos, *static_xquat;
+  const int* root_origin_body;
+  const float* root_origin_const;
+  const uint32_t* body_dofmask;  // [nbody][2]
+  // joints / dofs
+  const int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid;
+  const float *jnt_pos, *jnt_axis, *jnt_stiffness, *jnt_range, *jnt_margin, *jnt_solref, *jnt_solimp;
+  const int *dof_bodyid, *dof_jntid, *dof_parentid;
+  const float *dof_armature, *dof_damping, *dof_frictionloss, *dof_solref, *dof_solimp, *dof_invweight0;
+  const float *qpos0, *qpos_spring;
+  const int *lvl_dof, *lvl_dof_adr, *M_i, *M_j, *M_lvl_adr, *desc_adr, *desc;
+  // geoms / sites / meshes
+  const int *geom_type, *geom_bodyid, *geom_dataid;
+  const float *geom_size, *geom_rbound, *geom_pos, *geom_quat, *geom_aabb;
+  const int* site_bodyid;
+  const float *site_pos;
+  const int *mesh_vertadr, *mesh_vertnum;
+  const float* mesh_vert;
+  const int* pair_geom;   // [npair][3] g1, g2, condim
+  const float* pair_prm;  // [npair][12] margin, gap, friction3, solref2, solimp5
+  // tendons
+  const int *tendon_adr, *tendon_num, *wrap_type, *wrap_objid, *ten_dofs;
+  const float *wrap_prm, *tendon_range, *tendon_margin, *tendon_stiffness, *tendon_damping, *tendon_frictionloss,
+      *tendon_lengthspring, *tendon_solref_lim, *tendon_solimp_lim, *tendon_solref_fri, *tendon_solimp_fri, *tendon_invweight0;
+  const int *dof_ten_adr, *dof_ten, *dof_act_adr, *dof_act;
+  // actuators
+  const int *actuator_trntype, *actuator_trnid, *actuator_ctrllimited, *actuator_forcelimited, *actuator_biastype;
+  const float *actuator_gear, *actuator_ctrlrange, *actuator_forcerange, *actuator_gainprm, *actuator_biasprm;
+  // constraint row sources
+  const int *fric_dof, *fric_ten, *lim_jnt, *lim_ten;
+};
+
+// env-level description of the dactyl "cube in hand" task family (obs readout, goal, reward)
+struct RgEnvDev {
+  int hand_qposadr;      // first of the 24 hand joint angles in qpos
+  int n_hand_jnt;        // 24
+  int cube_pos_qposadr;  // 3 slides
+  int cube_quat_qposadr; // ball
+  int target_qposadr, target_nq, target_dofadr, target_nv;  // zeroed in the qpos/qvel observations
+  int cube_body;         // body whose xpos is the cube_pos observation
+  int ref_site[3];       // phasespace reference sites
+  int tip_site[5];       // fingertip sites
+  int relative_action;   // 1: action centred on current joint positions
+  const float* pos_to_ctrl;  // [nu][n_hand_jnt] joint positions -> control (device)
+  float success_threshold;   // cube_quat < 0.4 rad
+};
+
+// per-batch device buffers, row-major [B][n]
+struct RgBatchDev {
+  int B;
+  float *qpos, *qvel, *ctrl, *pid, *qacc_warmstart, *time;
+  uint32_t* status;
+  // env-step I/O
+  const float* action;  // [B][nu] in [-1,1]   (may be null: ctrl used as is)
+  const float* goal_quat;  // [B][4]
+  const int* active;    // [B] or null: envs with 0 are skipped by this launch
+  float* obs;           // [B][obs_dim]
+  float* goal_dist;     // [B]
+  float* stats;         // [B][4]: sum ncon, sum nefc, sum newton iters, substeps
+  float* dbg;           // optional [B][RG_DBG_SIZE] stage dump of the first forward pass
+};
+
+// debug-dump layout (floats)
+#define RG_DBG_XPOS 0                                   // nbody*3
+#define RG_DBG_XQUAT (RG_DBG_XPOS + RG_MAXBODY * 3)     // nbody*4
+#define RG_DBG_SITE (RG_DBG_XQUAT + RG_MAXBODY * 4)     // nsite*3
+#define RG_DBG_M (RG_DBG_SITE + RG_MAXSITE * 3)         // nv*nv dense
+#define RG_DBG_TENLEN (RG_DBG_M + RG_MAXNV * RG_MAXNV)  // ntendon
+#define RG_DBG_TENJ (RG_DBG_TENLEN + RG_MAXTEN)         // ntendon*4
+#define RG_DBG_BIAS (RG_DBG_TENJ + RG_MAXTEN * 4)       // nv
+#define RG_DBG_PASSIVE (RG_DBG_BIAS + RG_MAXNV)         // nv
+#define RG_DBG_ACTFRC (RG_DBG_PASSIVE + RG_MAXNV)       // nv  qfrc_actuator
+#define RG_DBG_QACCS (RG_DBG_ACTFRC + RG_MAXNV)         // nv  qacc_smooth
+#define RG_DBG_QACC (RG_DBG_QACCS + RG_MAXNV)           // nv
+#define RG_DBG_NCON (RG_DBG_QACC + RG_MAXNV)            // 1: ncon, +1: nefc, +2: iters, +3: ncand
+#define RG_DBG_CON (RG_DBG_NCON + 4)                    // MAXCON * 8: dist, pos3, normal3, pair index
+#define RG_DBG_SIZE (RG_DBG_CON + RG_MAXCON * 8)

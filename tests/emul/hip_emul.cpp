@@ -1,0 +1,57 @@
+// hip_emul.cpp — fiber scheduler of the CPU emulation harness (see hip_emul.h).  TEST HARNESS ONLY.
+#include "hip_emul.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <ucontext.h>
+
+emul_dim3 threadIdx, blockIdx, blockDim = {64, 1, 1}, gridDim;
+uint64_t emul_xchg[64];
+
+static const size_t kStack = 512 * 1024;
+static ucontext_t g_sched, g_fiber[64];
+static char* g_stacks = nullptr;
+static int g_done[64];
+static int g_cur = 0;
+static void* g_lds = nullptr;
+static emul_kernel_fn g_fn;
+static void* g_arg;
+
+void* emul_lds() { return g_lds; }
+
+void emul_yield() { swapcontext(&g_fiber[g_cur], &g_sched); }
+
+static void fiber_main() {
+  g_fn(g_arg);
+  g_done[g_cur] = 1;
+  swapcontext(&g_fiber[g_cur], &g_sched);
+}
+
+void emul_launch(int nblocks, size_t lds_bytes, emul_kernel_fn fn, void* arg) {
+  if (!g_stacks) g_stacks = (char*)malloc(64 * kStack);
+  g_fn = fn; g_arg = arg;
+  gridDim.x = nblocks; gridDim.y = gridDim.z = 1;
+  for (int b = 0; b < nblocks; b++) {
+    g_lds = calloc(1, lds_bytes);
+    blockIdx.x = b; blockIdx.y = blockIdx.z = 0;
+    for (int l = 0; l < 64; l++) {
+      getcontext(&g_fiber[l]);
+      g_fiber[l].uc_stack.ss_sp = g_stacks + l * kStack;
+      g_fiber[l].uc_stack.ss_size = kStack;
+      g_fiber[l].uc_link = &g_sched;
+      makecontext(&g_fiber[l], fiber_main, 0);
+      g_done[l] = 0;
+    }
+    int alive = 64;
+    while (alive > 0) {
+      alive = 0;
+      for (int l = 0; l < 64; l++) {
+        if (g_done[l]) continue;
+        g_cur = l; threadIdx.x = l; threadIdx.y = threadIdx.z = 0;
+        swapcontext(&g_sched, &g_fiber[l]);
+        if (!g_done[l]) alive++;
+      }
+    }
+    free(g_lds);
+  }
+}

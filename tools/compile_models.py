@@ -1,0 +1,29 @@
+"""Compile the robogym MJCF + STL assets of the hot-path envs into the flat model files shipped
+under robogym_amd/models/ (the asset tree itself is not redistributed in this repository).
+
+    ROBOGYM_ASSETS_DIR=/path/to/robogym/assets python tools/compile_models.py
+
+Reads the assets (default: the read-only reference checkout), writes *.npz.  Derived data only:
+body trees, inertias, joint/actuator/tendon tables and the convex-hull vertices of the collision
+meshes in their inertial frames.
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+from robogym_amd.envs.dactyl.locked import MODEL_DIR, build_locked_xml  # noqa: E402
+
+
+def main():
+    os.makedirs(MODEL_DIR, exist_ok=True)
+    model = build_locked_xml().build()
+    path = os.path.join(MODEL_DIR, "dactyl_locked.npz")
+    model.save(path)
+    d = model.dims
+    print("dactyl_locked: nq=%d nv=%d nu=%d nbody=%d ngeom=%d nsite=%d ntendon=%d nmeshvert=%d -> %s (%d bytes)"
+          % (d[0], d[1], d[2], d[3], d[5], d[6], d[7], d[10], path, os.path.getsize(path)))
+
+
+if __name__ == "__main__":
+    main()
