@@ -133,7 +133,7 @@ def main():
     kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
     stats = sim.get_field(7).sum(0).cpu().numpy()
     nsub_total = max(stats[3], 1.0)
-    ncon, nefc, iters = stats[0] / nsub_total, stats[1] / nsub_total, stats[2] / nsub_total
+    ncon, nefc, iters = float(stats[0] / nsub_total), float(stats[1] / nsub_total), float(stats[2] / nsub_total)
     status = int(sim.status.max().item())
 
     if rank == 0:
@@ -154,7 +154,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+        print(json.dumps(out, default=float))
     if distributed:
         dist.destroy_process_group()
 

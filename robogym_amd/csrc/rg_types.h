@@ -13,7 +13,7 @@
 #define RG_MAXTEN 12
 #define RG_MAXU 20
 #define RG_MAXCON 32    // contacts kept per env (overflow -> RG_STATUS_CON_FULL)
-#define RG_MAXCAND 64   // candidate geom pairs surviving the broadphase per substep
+#define RG_MAXCAND 128  // candidate geom pairs surviving the broadphase per substep
 #define RG_MAXROW 64    // friction-loss + limit rows
 #define RG_W 16         // max nonzeros of a sparse constraint row
 #define RG_WAVE 64
