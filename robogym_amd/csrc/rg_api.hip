@@ -145,7 +145,10 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
   UPI(geom_type, "geom_type"); UPI(geom_bodyid, "geom_bodyid"); UPI(geom_dataid, "geom_dataid");
   UPF(geom_size, "geom_size"); UPF(geom_rbound, "geom_rbound"); UPF(geom_pos, "geom_pos"); UPF(geom_quat, "geom_quat"); UPF(geom_aabb, "k_geom_aabb");
   UPI(site_bodyid, "site_bodyid"); UPF(site_pos, "site_pos");
-  UPI(mesh_vertadr, "mesh_vertadr"); UPI(mesh_vertnum, "mesh_vertnum"); UPF(mesh_vert, "mesh_vert");
+  UPI(mesh_vertadr, "mesh_vertadr"); UPI(mesh_vertnum, "mesh_vertnum");
+  { GF("mesh_vert"); std::vector<float> v4(fv.size() / 3 * 4, 0.f);  // 16-byte vertex records: one dwordx4 load per vertex
+    for (size_t i = 0; i < fv.size() / 3; i++) { v4[4 * i] = fv[3 * i]; v4[4 * i + 1] = fv[3 * i + 1]; v4[4 * i + 2] = fv[3 * i + 2]; }
+    if (!upload<float>(m, v4, &d.mesh_vert)) return bail("hipMalloc failed", m); }
   UPI(pair_geom, "k_pair_geom"); UPF(pair_prm, "k_pair_prm");
   UPI(tendon_adr, "tendon_adr"); UPI(tendon_num, "tendon_num"); UPI(wrap_type, "wrap_type"); UPI(wrap_objid, "wrap_objid"); UPI(ten_dofs, "k_ten_dofs");
   UPF(wrap_prm, "wrap_prm"); UPF(tendon_range, "tendon_range"); UPF(tendon_margin, "tendon_margin"); UPF(tendon_stiffness, "tendon_stiffness");

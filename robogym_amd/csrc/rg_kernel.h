@@ -22,26 +22,28 @@
 #include <hip/hip_runtime.h>
 #endif
 
-#define NVP (RG_MAXNV + 1)  // padded row stride of dense nv x nv matrices in LDS (bank-conflict free)
+#define NVP (RG_MAXNV + 4)  // row stride of dense nv x nv matrices in LDS: 16-byte aligned rows, 44 words -> conflict-free ds_read_b128 across lanes
 #define RG_MAXSROW (RG_MAXROW + 64)  // static row slots: friction dofs/tendons + 2 per limited joint/tendon
 #define RG_MAXPYR (RG_MAXCON * 6)
+#define RG_NPROF 16
 
 struct RgLds {
   // state
-  float qpos[RG_MAXNQ], qvel[RG_MAXNV], ctrl[RG_MAXU], pid[3 * RG_MAXU], warm[RG_MAXNV];
+  alignas(16) float qpos[RG_MAXNQ], qvel[RG_MAXNV], ctrl[RG_MAXU], pid[3 * RG_MAXU], warm[RG_MAXNV];
   // position stage
   float xpos[RG_MAXBODY * 3], xquat[RG_MAXBODY * 4], xmat[RG_MAXBODY * 9], xipos[RG_MAXBODY * 3], org[RG_MAXBODY * 3];
   float xanchor[RG_MAXJNT * 3], xaxis[RG_MAXJNT * 3];
   float gpos[RG_MAXGEOM * 3], gmat[RG_MAXGEOM * 9], spos[RG_MAXSITE * 3];
   float cinert[RG_MAXBODY * 10], crb[RG_MAXBODY * 10], cdof[RG_MAXNV * 6], cdofdot[RG_MAXNV * 6];
   float cacc[RG_MAXBODY * 6], cfrc[RG_MAXBODY * 6];
-  float M[RG_MAXNV * NVP], LD[RG_MAXNV * NVP], H[RG_MAXNV * NVP];
+  alignas(16) float M[RG_MAXNV * NVP];
+  alignas(16) float H[RG_MAXNV * NVP];  // H: work matrix (factor of M, Newton Hessian, factor of M + h B)
   float tenlen[RG_MAXTEN], tenvel[RG_MAXTEN], tenJ[RG_MAXTEN * 4], tenfrc[RG_MAXTEN];
   float actlen[RG_MAXU], actfrc[RG_MAXU];
-  float qfrc_passive[RG_MAXNV], qfrc_bias[RG_MAXNV], qfrc_act[RG_MAXNV], qfrc_smooth[RG_MAXNV], qacc_smooth[RG_MAXNV];
-  float qfrc_con[RG_MAXNV], qacc[RG_MAXNV];
+  alignas(16) float qfrc_passive[RG_MAXNV], qfrc_bias[RG_MAXNV], qfrc_act[RG_MAXNV], qfrc_smooth[RG_MAXNV], qacc_smooth[RG_MAXNV];
+  alignas(16) float qfrc_con[RG_MAXNV], qacc[RG_MAXNV];
   // solver work vectors
-  float Ma[RG_MAXNV], grad[RG_MAXNV], search[RG_MAXNV], Mv[RG_MAXNV], tmpv[RG_MAXNV];
+  alignas(16) float Ma[RG_MAXNV], grad[RG_MAXNV], search[RG_MAXNV], Mv[RG_MAXNV], tmpv[RG_MAXNV];
   // static row slots (friction loss, limits)
   float r_D[RG_MAXSROW], r_R[RG_MAXSROW], r_aref[RG_MAXSROW], r_floss[RG_MAXSROW], r_jar[RG_MAXSROW], r_jv[RG_MAXSROW], r_force[RG_MAXSROW];
   int r_active[RG_MAXSROW], r_quad[RG_MAXSROW];
@@ -56,9 +58,11 @@ struct RgLds {
   float p_aref[RG_MAXPYR], p_jar[RG_MAXPYR], p_jv[RG_MAXPYR], p_force[RG_MAXPYR];
   int p_quad[RG_MAXPYR];
   unsigned int status;
+  float prof[RG_NPROF];
 };
 
 // ------------------------------------------------------------------------------------------------- small math
+struct alignas(16) rgf4 { float x, y, z, w; };
 struct v3 { float x, y, z; };
 __device__ __forceinline__ v3 mk3(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
 __device__ __forceinline__ v3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
@@ -102,19 +106,64 @@ __device__ __forceinline__ q4 axisangle(v3 ax, float ang) {
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
 // ------------------------------------------------------------------------------------------------- wave collectives
+// gfx950: reductions run on the VALU with DPP row shifts / row broadcasts (no LDS crossbar round trips);
+// the result is read back from lane 63 with v_readlane, i.e. it is wave-uniform (an SGPR).
+#ifdef RG_EMUL
+__device__ __forceinline__ float wave_sum(float v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
+__device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ int wave_min_i(int v) { for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o); v = t < v ? t : v; } return v; }
+__device__ __forceinline__ float lane_bcast(float v, int src) { return __shfl(v, src); }
+#else
+template <int CTRL, int RMASK> __device__ __forceinline__ float dpp_f(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, RMASK, 0xf, false));
+}
+template <int CTRL, int RMASK> __device__ __forceinline__ int dpp_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, RMASK, 0xf, false); }
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  v += dpp_f<0x111, 0xf>(0.f, v); v += dpp_f<0x112, 0xf>(0.f, v); v += dpp_f<0x114, 0xf>(0.f, v); v += dpp_f<0x118, 0xf>(0.f, v);
+  v += dpp_f<0x142, 0xa>(0.f, v); v += dpp_f<0x143, 0xc>(0.f, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_max(float v) {
+  const float ninf = -3.0e38f;
+  v = fmaxf(v, dpp_f<0x111, 0xf>(ninf, v)); v = fmaxf(v, dpp_f<0x112, 0xf>(ninf, v)); v = fmaxf(v, dpp_f<0x114, 0xf>(ninf, v)); v = fmaxf(v, dpp_f<0x118, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_f<0x142, 0xa>(ninf, v)); v = fmaxf(v, dpp_f<0x143, 0xc>(ninf, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int wave_min_i(int v) {
+  const int big = 0x7fffffff;
+  v = imin(v, dpp_i<0x111, 0xf>(big, v)); v = imin(v, dpp_i<0x112, 0xf>(big, v)); v = imin(v, dpp_i<0x114, 0xf>(big, v)); v = imin(v, dpp_i<0x118, 0xf>(big, v));
+  v = imin(v, dpp_i<0x142, 0xa>(big, v)); v = imin(v, dpp_i<0x143, 0xc>(big, v));
+  return __builtin_amdgcn_readlane(v, 63);
+}
+// value of lane `src` (wave-uniform index) in every lane
+__device__ __forceinline__ float lane_bcast(float v, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); }
+#endif
+// all-reduce inside a 16-lane DPP row (every lane of the row ends up with the result): row rotations
+#ifdef RG_EMUL
+__device__ __forceinline__ float row_max(float v) { for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ int row_min_i(int v) { for (int o = 8; o > 0; o >>= 1) { int t = __shfl_xor(v, o); v = t < v ? t : v; } return v; }
+#else
+__device__ __forceinline__ float row_max(float v) {
+  v = fmaxf(v, dpp_f<0x128, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x124, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x122, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x121, 0xf>(v, v));
   return v;
 }
+__device__ __forceinline__ int row_min_i(int v) {
+  v = imin(v, dpp_i<0x128, 0xf>(v, v)); v = imin(v, dpp_i<0x124, 0xf>(v, v)); v = imin(v, dpp_i<0x122, 0xf>(v, v)); v = imin(v, dpp_i<0x121, 0xf>(v, v));
+  return v;
+}
+#endif
 // arg-max with smallest-index tie break (matches a first-max serial scan)
 __device__ __forceinline__ void wave_argmax(float& v, int& i) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    float ov = __shfl_xor(v, o); int oi = __shfl_xor(i, o);
-    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
-  }
+  float vm = wave_max(v);
+  i = wave_min_i(v == vm ? i : 0x7fffffff);
+  v = vm;
 }
+#ifdef RG_EMUL
+static inline long long rg_clock() { return 0; }
+#else
+__device__ __forceinline__ long long rg_clock() { return (long long)__builtin_readcyclecounter(); }
+#endif
 #define LANE ((int)threadIdx.x)
 #define SYNC() __syncthreads()
 #define PFOR(i, n) for (int i = LANE; i < (n); i += RG_WAVE)
@@ -138,7 +187,7 @@ __device__ __forceinline__ void cross_force(float* r, const float* vel, const fl
 }
 
 // ------------------------------------------------------------------------------------------------- position stage
-__device__ void rg_kinematics(const RgModelDev& m, RgLds& s) {
+__device__ __forceinline__ void rg_kinematics(const RgModelDev& m, RgLds& s) {
   PFOR(i, m.nstatic) {
     int b = m.static_body[i];
     st3(s.xpos + 3 * b, ld3(m.static_xpos + 3 * b));
@@ -194,7 +243,7 @@ __device__ void rg_kinematics(const RgModelDev& m, RgLds& s) {
   SYNC();
 }
 
-__device__ void rg_com_pos(const RgModelDev& m, RgLds& s) {
+__device__ __forceinline__ void rg_com_pos(const RgModelDev& m, RgLds& s) {
   for (int b = 1 + LANE; b < m.nbody; b += RG_WAVE) {
     float R[9], I[9], qm[9];
     q2mat(qm, ldq(m.body_iquat + 4 * b));
@@ -233,14 +282,14 @@ __device__ __forceinline__ v3 jac_col(const RgLds& s, int d, v3 off) { return ld
 __device__ __forceinline__ bool in_chain(const RgModelDev& m, int body, int d) { return (m.body_dofmask[2 * body + (d >> 5)] >> (d & 31)) & 1u; }
 
 // ---- tendon wrapping (see oracle: wrap_circle / ro_wrap)
-__device__ inline bool seg_intersect(float p1x, float p1y, float p2x, float p2y, float p3x, float p3y, float p4x, float p4y) {
+__device__ __forceinline__ bool seg_intersect(float p1x, float p1y, float p2x, float p2y, float p3x, float p3y, float p4x, float p4y) {
   float det = (p4y - p3y) * (p2x - p1x) - (p4x - p3x) * (p2y - p1y);
   if (fabsf(det) < 1e-15f) return false;
   float a = ((p4x - p3x) * (p1y - p3y) - (p4y - p3y) * (p1x - p3x)) / det;
   float b = ((p2x - p1x) * (p1y - p3y) - (p2y - p1y) * (p1x - p3x)) / det;
   return a >= 0 && a <= 1 && b >= 0 && b <= 1;
 }
-__device__ inline float wrap_circle(float* pnt, const float* d, const float* sd, float rad) {
+__device__ __forceinline__ float wrap_circle(float* pnt, const float* d, const float* sd, float rad) {
   float sq0 = d[0] * d[0] + d[1] * d[1], sq1 = d[2] * d[2] + d[3] * d[3], sqr = rad * rad;
   float dx = d[2] - d[0], dy = d[3] - d[1], dd = dx * dx + dy * dy;
   if (sq0 < sqr || sq1 < sqr || rad < 1e-15f || dd < 1e-15f) return -1;
@@ -267,7 +316,7 @@ __device__ inline float wrap_circle(float* pnt, const float* d, const float* sd,
   if (seg_intersect(d[0], d[1], pnt[0], pnt[1], d[2], d[3], pnt[2], pnt[3])) return -1;
   return rad * acosf(clampf((pnt[0] * pnt[2] + pnt[1] * pnt[3]) / sqr, -1.f, 1.f));
 }
-__device__ inline float rg_wrap(v3& w0, v3& w1, v3 x0, v3 x1, v3 gpos, const float* gmat, float radius, int type, bool has_side, v3 side) {
+__device__ __forceinline__ float rg_wrap(v3& w0, v3& w1, v3 x0, v3 x1, v3 gpos, const float* gmat, float radius, int type, bool has_side, v3 side) {
   v3 p0 = mulmT(gmat, x0 - gpos), p1 = mulmT(gmat, x1 - gpos);
   if (norm(p0) < 1e-15f || norm(p1) < 1e-15f) return -1;
   v3 ax0, ax1;
@@ -299,7 +348,7 @@ __device__ inline float rg_wrap(v3& w0, v3& w1, v3 x0, v3 x1, v3 gpos, const flo
 }
 
 // tendon lengths and Jacobians on their static dof supports; actuator lengths
-__device__ void rg_tendon(const RgModelDev& m, RgLds& s) {
+__device__ __forceinline__ void rg_tendon(const RgModelDev& m, RgLds& s) {
   PFOR(t, m.ntendon) {
     int adr = m.tendon_adr[t], num = m.tendon_num[t];
     const int* td = m.ten_dofs + 4 * t;
@@ -364,7 +413,7 @@ __device__ void rg_tendon(const RgModelDev& m, RgLds& s) {
 }
 
 // composite inertias (subtree gathers), sparse M, tree-sparse L'DL factorisation
-__device__ void rg_crb(const RgModelDev& m, RgLds& s, const int* subtree_adr, const int* subtree) {
+__device__ __forceinline__ void rg_crb(const RgModelDev& m, RgLds& s, const int* subtree_adr, const int* subtree) {
   for (int w = LANE; w < m.nbody * 10; w += RG_WAVE) {
     int b = w / 10, k = w - 10 * b;
     float acc = 0;
@@ -385,72 +434,48 @@ __device__ void rg_crb(const RgModelDev& m, RgLds& s, const int* subtree_adr, co
   SYNC();
 }
 
-// LD <- tree-sparse factor of (M + diag(extra)); entries (i,j), j ancestor-or-self of i
-__device__ void rg_factor_tree(const RgModelDev& m, RgLds& s, const float* extra_diag, float extra_scale) {
-  for (int L = m.ndoflevel - 1; L >= 0; L--) {
-    int e0 = m.M_lvl_adr[L], e1 = m.M_lvl_adr[L + 1];
-    for (int e = e0 + LANE; e < e1; e += RG_WAVE) {
-      int i = m.M_i[e], j = m.M_j[e];
-      float v = s.M[i * NVP + j];
-      if (i == j && extra_diag) v += extra_scale * extra_diag[i];
-      for (int q = m.desc_adr[i]; q < m.desc_adr[i + 1]; q++) { int k = m.desc[q]; v -= s.LD[k * NVP + i] * s.LD[k * NVP + j] * s.LD[k * NVP + k]; }
-      s.LD[i * NVP + j] = v;
-    }
-    SYNC();
-    for (int e = e0 + LANE; e < e1; e += RG_WAVE) {
-      int i = m.M_i[e], j = m.M_j[e];
-      if (i != j) {
-        float dgl = s.LD[i * NVP + i];
-        s.LD[i * NVP + j] = s.LD[i * NVP + j] / dgl;
-      } else if (!(s.LD[i * NVP + i] > 1e-30f)) s.status |= RG_STATUS_BAD_FACTOR;
-    }
-    SYNC();
-  }
-}
-// x <- (M + diag)^-1 x using LD
-__device__ void rg_solve_tree(const RgModelDev& m, RgLds& s, float* x) {
-  for (int L = m.ndoflevel - 1; L >= 0; L--) {
-    for (int k = m.lvl_dof_adr[L] + LANE; k < m.lvl_dof_adr[L + 1]; k += RG_WAVE) {
-      int i = m.lvl_dof[k];
-      float v = x[i];
-      for (int q = m.desc_adr[i]; q < m.desc_adr[i + 1]; q++) { int d = m.desc[q]; v -= s.LD[d * NVP + i] * x[d]; }
-      x[i] = v;
-    }
-    SYNC();
-  }
-  for (int L = 0; L < m.ndoflevel; L++) {
-    for (int k = m.lvl_dof_adr[L] + LANE; k < m.lvl_dof_adr[L + 1]; k += RG_WAVE) {
-      int i = m.lvl_dof[k];
-      float v = x[i] / s.LD[i * NVP + i];
-      for (int a = m.dof_parentid[i]; a >= 0; a = m.dof_parentid[a]) v -= s.LD[i * NVP + a] * x[a];
-      x[i] = v;
-    }
-    SYNC();
-  }
-}
-
 // ------------------------------------------------------------------------------------------------- collision
 struct SupPt { v3 v, v1, v2; };
 struct MprGeom { int type; const float* mat; v3 pos; v3 size; const float* vert; int nvert; float margin; };
 
-// support point of one geom (relative to the MPR reference origin), wave-cooperative for meshes
-__device__ inline v3 rg_support(const MprGeom& g, v3 dir) {
-  v3 ld = mulmT(g.mat, dir), lr;
-  if (g.type == RG_GEOM_MESH) {
-    float bv = -3.0e38f; int bi = 0x7fffffff;
-    for (int i = LANE; i < g.nvert; i += RG_WAVE) {
-      float d = ld.x * g.vert[3 * i] + ld.y * g.vert[3 * i + 1] + ld.z * g.vert[3 * i + 2];
-      if (d > bv) { bv = d; bi = i; }
-    }
-    wave_argmax(bv, bi);
-    lr = mk3(g.vert[3 * bi], g.vert[3 * bi + 1], g.vert[3 * bi + 2]);
-  } else if (g.type == RG_GEOM_BOX) {
-    lr = mk3(ld.x >= 0 ? g.size.x : -g.size.x, ld.y >= 0 ? g.size.y : -g.size.y, ld.z >= 0 ? g.size.z : -g.size.z);
-  } else if (g.type == RG_GEOM_SPHERE) {
-    lr = ld * g.size.x;
-  } else if (g.type == RG_GEOM_CAPSULE) {
-    lr = ld * g.size.x; lr.z += ld.z >= 0 ? g.size.y : -g.size.y;
-  } else if (g.type == RG_GEOM_CYLINDER) {
+// per-lane scan of a hull's vertices: 16-byte records (one dwordx4 load per vertex), four independent
+// loads in flight per lane; out-of-range slots re-read the last vertex (harmless for a max).
+// G lanes cooperate on one hull (G = 64: the wave, G = 16: one DPP row, four MPR queries per wave).
+template <int G> __device__ __forceinline__ void scan_batch(const rgf4* vert, int nvert, int base, v3 ld, float& bv, int& bi, v3& bp) {
+  int i0 = base + (LANE & (G - 1)), last = nvert - 1;
+  int j0 = i0 < last ? i0 : last, j1 = i0 + G < last ? i0 + G : last, j2 = i0 + 2 * G < last ? i0 + 2 * G : last, j3 = i0 + 3 * G < last ? i0 + 3 * G : last;
+  rgf4 a = vert[j0], b = vert[j1], c = vert[j2], d = vert[j3];
+  float da = ld.x * a.x + ld.y * a.y + ld.z * a.z, db = ld.x * b.x + ld.y * b.y + ld.z * b.z;
+  float dc = ld.x * c.x + ld.y * c.y + ld.z * c.z, dd = ld.x * d.x + ld.y * d.y + ld.z * d.z;
+  if (da > bv) { bv = da; bi = j0; bp = mk3(a.x, a.y, a.z); }
+  if (db > bv) { bv = db; bi = j1; bp = mk3(b.x, b.y, b.z); }
+  if (dc > bv) { bv = dc; bi = j2; bp = mk3(c.x, c.y, c.z); }
+  if (dd > bv) { bv = dd; bi = j3; bp = mk3(d.x, d.y, d.z); }
+}
+template <int G> __device__ __forceinline__ void scan_verts(const rgf4* vert, int nvert, v3 ld, float& bv, int& bi, v3& bp) {
+  for (int base = 0; base < nvert; base += 4 * G) scan_batch<G>(vert, nvert, base, ld, bv, bi, bp);
+}
+// arg-max over the G cooperating lanes (lowest vertex index on ties, as a serial first-max scan); the
+// winner's coordinates come from the registers of a lane that scanned it
+template <int G> __device__ __forceinline__ v3 pick_vert(float bv, int bi, v3 bp) {
+  if (G == 64) {
+    float vm = wave_max(bv);
+    int wi = wave_min_i(bv == vm ? bi : 0x7fffffff);
+    int wl = wave_min_i((bv == vm && bi == wi) ? LANE : 0x7fffffff);
+    return mk3(lane_bcast(bp.x, wl), lane_bcast(bp.y, wl), lane_bcast(bp.z, wl));
+  } else {
+    float vm = row_max(bv);
+    int wi = row_min_i(bv == vm ? bi : 0x7fffffff);
+    bool win = bv == vm && bi == wi;  // several lanes may hold the same (clamped) vertex: identical coordinates
+    return mk3(row_max(win ? bp.x : -3.0e38f), row_max(win ? bp.y : -3.0e38f), row_max(win ? bp.z : -3.0e38f));
+  }
+}
+__device__ __forceinline__ v3 support_primitive(const MprGeom& g, v3 ld) {
+  v3 lr;
+  if (g.type == RG_GEOM_BOX) lr = mk3(ld.x >= 0 ? g.size.x : -g.size.x, ld.y >= 0 ? g.size.y : -g.size.y, ld.z >= 0 ? g.size.z : -g.size.z);
+  else if (g.type == RG_GEOM_SPHERE) lr = ld * g.size.x;
+  else if (g.type == RG_GEOM_CAPSULE) { lr = ld * g.size.x; lr.z += ld.z >= 0 ? g.size.y : -g.size.y; }
+  else if (g.type == RG_GEOM_CYLINDER) {
     float n = sqrtf(ld.x * ld.x + ld.y * ld.y);
     lr = n > 1e-15f ? mk3(ld.x / n * g.size.x, ld.y / n * g.size.x, 0) : mk3(0, 0, 0);
     lr.z = ld.z >= 0 ? g.size.y : -g.size.y;
@@ -459,11 +484,40 @@ __device__ inline v3 rg_support(const MprGeom& g, v3 dir) {
     float n = fmaxf(norm(t), 1e-15f);
     lr = mk3(t.x * g.size.x / n, t.y * g.size.y / n, t.z * g.size.z / n);
   }
+  return lr;
+}
+// support point of one geom (relative to the MPR reference origin), cooperative for meshes
+template <int G> __device__ __forceinline__ v3 rg_support(const MprGeom& g, v3 dir) {
+  v3 ld = mulmT(g.mat, dir), lr;
+  if (g.type == RG_GEOM_MESH) {
+    float bv = -3.0e38f; int bi = 0x7fffffff; v3 bp = mk3(0, 0, 0);
+    scan_verts<G>((const rgf4*)g.vert, g.nvert, ld, bv, bi, bp);
+    lr = pick_vert<G>(bv, bi, bp);
+  } else lr = support_primitive(g, ld);
   lr = lr + ld * g.margin;
   return mulm(g.mat, lr) + g.pos;
 }
-__device__ inline void mpr_support(const MprGeom& a, const MprGeom& b, v3 dir, SupPt& p) {
-  p.v1 = rg_support(a, dir); p.v2 = rg_support(b, dir * -1.0f); p.v = p.v1 - p.v2;
+// Minkowski-difference support A(dir) - B(-dir); the two hull scans are issued back to back so their
+// vertex loads overlap
+template <int G> __device__ __forceinline__ void mpr_support(const MprGeom& a, const MprGeom& b, v3 dir, SupPt& p) {
+  v3 la = mulmT(a.mat, dir), lb = mulmT(b.mat, dir * -1.0f), ra, rb;
+  float av = -3.0e38f, bvv = -3.0e38f; int ai = 0x7fffffff, bi = 0x7fffffff; v3 ap = mk3(0, 0, 0), bp = mk3(0, 0, 0);
+  bool am = a.type == RG_GEOM_MESH, bm = b.type == RG_GEOM_MESH;
+  if (am && bm) {
+    int nmax = a.nvert > b.nvert ? a.nvert : b.nvert;
+    for (int base = 0; base < nmax; base += 4 * G) {  // both hulls' loads are issued before either compare chain
+      if (base < a.nvert) scan_batch<G>((const rgf4*)a.vert, a.nvert, base, la, av, ai, ap);
+      if (base < b.nvert) scan_batch<G>((const rgf4*)b.vert, b.nvert, base, lb, bvv, bi, bp);
+    }
+  } else {
+    if (am) scan_verts<G>((const rgf4*)a.vert, a.nvert, la, av, ai, ap);
+    if (bm) scan_verts<G>((const rgf4*)b.vert, b.nvert, lb, bvv, bi, bp);
+  }
+  ra = am ? pick_vert<G>(av, ai, ap) : support_primitive(a, la);
+  rb = bm ? pick_vert<G>(bvv, bi, bp) : support_primitive(b, lb);
+  p.v1 = mulm(a.mat, ra + la * a.margin) + a.pos;
+  p.v2 = mulm(b.mat, rb + lb * b.margin) + b.pos;
+  p.v = p.v1 - p.v2;
 }
 #define MPR_EPS 1.0e-7f  /* plays the role of libccd's CCD_EPS at fp32 (coordinates are pair-local, |x| ~ 0.1) */
 __device__ __forceinline__ bool mz(float x) { return fabsf(x) < MPR_EPS * 1e-3f; }
@@ -478,7 +532,7 @@ __device__ __forceinline__ void expand_portal(SupPt* p, const SupPt& v4) {
   if (dot(p[1].v, c) > 0) { if (dot(p[2].v, c) > 0) p[1] = v4; else p[3] = v4; }
   else { if (dot(p[3].v, c) > 0) p[2] = v4; else p[1] = v4; }
 }
-__device__ inline float origin_tri_dist2(v3 a, v3 b, v3 c, v3& w) {
+__device__ __forceinline__ float origin_tri_dist2(v3 a, v3 b, v3 c, v3& w) {
   v3 ab = b - a, ac = c - a, ap = a * -1.0f;
   float d1 = dot(ab, ap), d2 = dot(ac, ap);
   if (d1 <= 0 && d2 <= 0) { w = a; return dot(w, w); }
@@ -497,12 +551,12 @@ __device__ inline float origin_tri_dist2(v3 a, v3 b, v3 c, v3& w) {
   return dot(w, w);
 }
 // MPR penetration query (libccd ccdMPRPenetration); wave-uniform control flow.  Returns true on contact.
-__device__ bool rg_mpr(const MprGeom& A, const MprGeom& B, int max_iter, float tol, float& depth, v3& dir_out, v3& pos) {
+template <int G> __device__ __forceinline__ bool rg_mpr(const MprGeom& A, const MprGeom& B, int max_iter, float tol, float& depth, v3& dir_out, v3& pos) {
   SupPt p[4], v4;
   p[0].v1 = A.pos; p[0].v2 = B.pos; p[0].v = A.pos - B.pos;
   if (mz(p[0].v.x) && mz(p[0].v.y) && mz(p[0].v.z)) p[0].v.x += 1e-6f;
   v3 dir = normalized(p[0].v * -1.0f);
-  mpr_support(A, B, dir, p[1]);
+  mpr_support<G>(A, B, dir, p[1]);
   float dt = dot(p[1].v, dir);
   if (dt <= 0) return false;
   dir = cross(p[0].v, p[1].v);
@@ -513,13 +567,13 @@ __device__ bool rg_mpr(const MprGeom& A, const MprGeom& B, int max_iter, float t
     return true;
   }
   dir = normalized(dir);
-  mpr_support(A, B, dir, p[2]);
+  mpr_support<G>(A, B, dir, p[2]);
   if (dot(p[2].v, dir) <= 0) return false;
   dir = normalized(cross(p[1].v - p[0].v, p[2].v - p[0].v));
   if (dot(dir, p[0].v) > 0) { SupPt t = p[1]; p[1] = p[2]; p[2] = t; dir = dir * -1.0f; }
   for (int guard = 0;; guard++) {
     if (guard > 64) return false;
-    mpr_support(A, B, dir, p[3]);
+    mpr_support<G>(A, B, dir, p[3]);
     if (dot(p[3].v, dir) <= 0) return false;
     bool cont = false;
     if (dot(cross(p[1].v, p[3].v), p[0].v) < 0) { p[2] = p[3]; cont = true; }
@@ -531,13 +585,13 @@ __device__ bool rg_mpr(const MprGeom& A, const MprGeom& B, int max_iter, float t
     if (guard > 128) return false;
     dir = portal_dir(p);
     if (dot(dir, p[1].v) >= 0) break;
-    mpr_support(A, B, dir, v4);
+    mpr_support<G>(A, B, dir, v4);
     if (dot(v4.v, dir) < 0 || portal_reach_tol(p, v4, dir, tol)) return false;
     expand_portal(p, v4);
   }
   for (int it = 0;; it++) {  // findPenetr
     dir = portal_dir(p);
-    mpr_support(A, B, dir, v4);
+    mpr_support<G>(A, B, dir, v4);
     if (portal_reach_tol(p, v4, dir, tol) || it > max_iter) {
       // depth / direction from the portal PLANE (not libccd's closest point on the final portal triangle,
       // whose choice among the triangles of a flat supporting plane is rounding noise; see DESIGN.md "MPR")
@@ -561,7 +615,7 @@ __device__ bool rg_mpr(const MprGeom& A, const MprGeom& B, int max_iter, float t
 }
 
 // separating-axis test of two oriented boxes (half extents ea, eb; rotations Ra, Rb; centre offset t in world)
-__device__ inline bool obb_overlap(const float* Ra, v3 ea, const float* Rb, v3 eb, v3 tw) {
+__device__ __forceinline__ bool obb_overlap(const float* Ra, v3 ea, const float* Rb, v3 eb, v3 tw) {
   float R[9], AR[9];
   for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
     R[3 * i + j] = Ra[i] * Rb[j] + Ra[3 + i] * Rb[3 + j] + Ra[6 + i] * Rb[6 + j];
@@ -586,7 +640,7 @@ __device__ __forceinline__ void make_frame(float* f) {
   y = normalized(y - n * dot(n, y));
   st3(f, n); st3(f + 3, y); st3(f + 6, cross(n, y));
 }
-__device__ inline void add_contact(RgLds& s, int pair, float dist, v3 pos, v3 normal, int dim) {
+__device__ __forceinline__ void add_contact(RgLds& s, int pair, float dist, v3 pos, v3 normal, int dim) {
   // called with wave-uniform arguments; lane 0 writes
   int c = s.ncon;
   if (c >= RG_MAXCON) { if (LANE == 0) s.status |= RG_STATUS_CON_FULL; return; }
@@ -597,7 +651,8 @@ __device__ inline void add_contact(RgLds& s, int pair, float dist, v3 pos, v3 no
   SYNC();
 }
 
-__device__ void rg_collision(const RgModelDev& m, RgLds& s) {
+__device__ __forceinline__ void rg_collision(const RgModelDev& m, RgLds& s, float* prof) {
+  long long tb0 = rg_clock();
   if (LANE == 0) { s.ncand = 0; s.ncon = 0; }
   SYNC();
   // broadphase over the static pair list: bounding spheres, then oriented boxes (both conservative,
@@ -632,51 +687,80 @@ __device__ void rg_collision(const RgModelDev& m, RgLds& s) {
     if (LANE == 0) { int n = base + __popcll(bal); s.ncand = n < RG_MAXCAND ? n : RG_MAXCAND; }
     SYNC();
   }
-  // narrowphase, one candidate at a time, whole wave cooperating
+  if (prof && LANE == 0) prof[5] += (float)(rg_clock() - tb0);
+  // narrowphase.  Convex pairs: four candidates at a time, one 16-lane DPP row per MPR query (the portal
+  // algebra is scalar per query, so a whole wave per query would execute it 64-fold redundantly).
   int ncand = s.ncand;
+  for (int base = 0; base < ncand; base += 4) {
+    int ci = base + (LANE >> 4);
+    bool valid = ci < ncand, hit = false;
+    float depth = 0, margin = 0; v3 dir = mk3(0, 0, 0), pos = mk3(0, 0, 0); int p = 0, dim = 3;
+    if (valid) {
+      p = s.cand[ci];
+      int g1 = m.pair_geom[3 * p], g2 = m.pair_geom[3 * p + 1]; dim = m.pair_geom[3 * p + 2];
+      margin = m.pair_prm[12 * p];
+      int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
+      if (t1 != RG_GEOM_PLANE) {
+        v3 p1 = ld3(s.gpos + 3 * g1), p2 = ld3(s.gpos + 3 * g2);
+        MprGeom A, B;
+        A.type = t1; A.mat = s.gmat + 9 * g1; A.size = ld3(m.geom_size + 3 * g1); A.margin = 0.5f * margin; A.pos = mk3(0, 0, 0);
+        B.type = t2; B.mat = s.gmat + 9 * g2; B.size = ld3(m.geom_size + 3 * g2); B.margin = 0.5f * margin; B.pos = p2 - p1;  // pair-local coordinates
+        if (t1 == RG_GEOM_MESH) { int id = m.geom_dataid[g1]; A.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; A.nvert = m.mesh_vertnum[id]; } else { A.vert = 0; A.nvert = 0; }
+        if (t2 == RG_GEOM_MESH) { int id = m.geom_dataid[g2]; B.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; B.nvert = m.mesh_vertnum[id]; } else { B.vert = 0; B.nvert = 0; }
+        hit = rg_mpr<16>(A, B, m.mpr_iterations, m.mpr_tolerance, depth, dir, pos);
+        hit = hit && dot(dir, dir) > 0.25f;
+        pos = pos + p1;
+      }
+    }
+    // append the rows' contacts in candidate order (row leaders hold the result)
+    bool lead = hit && (LANE & 15) == 0;
+    unsigned long long bal = __ballot(lead);
+    int cbase = s.ncon;
+    SYNC();
+    if (lead) {
+      int c = cbase + __popcll(bal & ((1ull << LANE) - 1ull));
+      if (c < RG_MAXCON) {
+        s.c_dist[c] = margin - depth; st3(s.c_pos + 3 * c, pos); st3(s.c_frame + 9 * c, dir); make_frame(s.c_frame + 9 * c);
+        s.c_pair[c] = p; s.c_dim[c] = dim;
+      } else s.status |= RG_STATUS_CON_FULL;
+    }
+    if (LANE == 0) { int n = cbase + __popcll(bal); s.ncon = n < RG_MAXCON ? n : RG_MAXCON; }
+    SYNC();
+  }
+  // plane pairs (rare: something near the floor), whole wave cooperating, one candidate at a time
   for (int ci = 0; ci < ncand; ci++) {
     int p = s.cand[ci];
     int g1 = m.pair_geom[3 * p], g2 = m.pair_geom[3 * p + 1], dim = m.pair_geom[3 * p + 2];
+    if (m.geom_type[g1] != RG_GEOM_PLANE) continue;
     float margin = m.pair_prm[12 * p];
-    int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
+    int t2 = m.geom_type[g2];
     v3 p1 = ld3(s.gpos + 3 * g1), p2 = ld3(s.gpos + 3 * g2);
     MprGeom B;
     B.type = t2; B.mat = s.gmat + 9 * g2; B.size = ld3(m.geom_size + 3 * g2); B.margin = 0;
-    if (t2 == RG_GEOM_MESH) { int id = m.geom_dataid[g2]; B.vert = m.mesh_vert + 3 * m.mesh_vertadr[id]; B.nvert = m.mesh_vertnum[id]; } else { B.vert = 0; B.nvert = 0; }
-    if (t1 == RG_GEOM_PLANE) {
-      const float* R1 = s.gmat + 9 * g1;
-      v3 n = mk3(R1[2], R1[5], R1[8]);
-      if (t2 == RG_GEOM_BOX) {
-        int cnt = 0;
-        for (int i = 0; i < 8 && cnt < 4; i++) {
-          v3 lc = mk3((i & 1) ? B.size.x : -B.size.x, (i & 2) ? B.size.y : -B.size.y, (i & 4) ? B.size.z : -B.size.z);
-          v3 c = mulm(B.mat, lc) + p2;
-          float dist = dot(c - p1, n);
-          if (dist > margin) continue;
-          add_contact(s, p, dist, c - n * (0.5f * dist), n, dim); cnt++;
-        }
-      } else {
-        B.pos = p2 - p1;
-        v3 sp = rg_support(B, n * -1.0f);
-        float dist = dot(sp, n);
-        if (dist <= margin) add_contact(s, p, dist, sp + p1 - n * (0.5f * dist), n, dim);
+    if (t2 == RG_GEOM_MESH) { int id = m.geom_dataid[g2]; B.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; B.nvert = m.mesh_vertnum[id]; } else { B.vert = 0; B.nvert = 0; }
+    const float* R1 = s.gmat + 9 * g1;
+    v3 n = mk3(R1[2], R1[5], R1[8]);
+    if (t2 == RG_GEOM_BOX) {
+      int cnt = 0;
+      for (int i = 0; i < 8 && cnt < 4; i++) {
+        v3 lc = mk3((i & 1) ? B.size.x : -B.size.x, (i & 2) ? B.size.y : -B.size.y, (i & 4) ? B.size.z : -B.size.z);
+        v3 c = mulm(B.mat, lc) + p2;
+        float dist = dot(c - p1, n);
+        if (dist > margin) continue;
+        add_contact(s, p, dist, c - n * (0.5f * dist), n, dim); cnt++;
       }
-      continue;
-    }
-    MprGeom A;
-    A.type = t1; A.mat = s.gmat + 9 * g1; A.size = ld3(m.geom_size + 3 * g1); A.margin = 0.5f * margin; B.margin = 0.5f * margin;
-    if (t1 == RG_GEOM_MESH) { int id = m.geom_dataid[g1]; A.vert = m.mesh_vert + 3 * m.mesh_vertadr[id]; A.nvert = m.mesh_vertnum[id]; } else { A.vert = 0; A.nvert = 0; }
-    A.pos = mk3(0, 0, 0); B.pos = p2 - p1;  // pair-local coordinates keep fp32 resolution ~1e-9 m
-    float depth; v3 dir, pos;
-    if (rg_mpr(A, B, m.mpr_iterations, m.mpr_tolerance, depth, dir, pos)) {
-      if (dot(dir, dir) > 0.25f) add_contact(s, p, margin - depth, pos + p1, dir, dim);
+    } else {
+      B.pos = p2 - p1;
+      v3 sp = rg_support<64>(B, n * -1.0f);
+      float dist = dot(sp, n);
+      if (dist <= margin) add_contact(s, p, dist, sp + p1 - n * (0.5f * dist), n, dim);
     }
   }
   SYNC();
 }
 
 // ------------------------------------------------------------------------------------------------- velocity stage
-__device__ void rg_velocity(const RgModelDev& m, RgLds& s, const uint32_t* dof_velmask, const int* subtree_adr, const int* subtree) {
+__device__ __forceinline__ void rg_velocity(const RgModelDev& m, RgLds& s, const uint32_t* dof_velmask, const int* subtree_adr, const int* subtree) {
   // cdof_dot: spatial velocity accumulated over the dofs "before" d on its chain, crossed with cdof
   PFOR(d, m.nv) {
     float cv[6] = {0, 0, 0, 0, 0, 0};
@@ -732,7 +816,7 @@ __device__ void rg_velocity(const RgModelDev& m, RgLds& s, const uint32_t* dof_v
 }
 
 // PID actuators (mjpid.pyx semantics, see oracle ro_fwd_actuation); updates controller state
-__device__ void rg_pid(const RgModelDev& m, RgLds& s) {
+__device__ __forceinline__ void rg_pid(const RgModelDev& m, RgLds& s) {
   float dt = m.timestep;
   PFOR(u, m.nu) {
     const float* gp = m.actuator_gainprm + 10 * u;
@@ -757,7 +841,7 @@ __device__ void rg_pid(const RgModelDev& m, RgLds& s) {
   }
   SYNC();
 }
-__device__ void rg_smooth(const RgModelDev& m, RgLds& s) {
+__device__ __forceinline__ void rg_smooth(const RgModelDev& m, RgLds& s) {
   PFOR(d, m.nv) {
     float f = 0;
     for (int q = m.dof_act_adr[d]; q < m.dof_act_adr[d + 1]; q++) {
@@ -769,7 +853,6 @@ __device__ void rg_smooth(const RgModelDev& m, RgLds& s) {
     s.qfrc_smooth[d] = v; s.qacc_smooth[d] = v;
   }
   SYNC();
-  rg_solve_tree(m, s, s.qacc_smooth);
 }
 
 // ------------------------------------------------------------------------------------------------- constraints
@@ -835,7 +918,7 @@ __device__ __forceinline__ void srow_hess(const RgModelDev& m, RgLds& s, int r, 
     for (int b = 0; b < 4; b++) { int db = m.ten_dofs[4 * t + b]; if (db < 0) continue; atomicAdd(s.H + da * NVP + db, D * s.tenJ[4 * t + a] * s.tenJ[4 * t + b]); } }
 }
 
-__device__ void rg_make_constraint(const RgModelDev& m, RgLds& s) {
+__device__ __forceinline__ void rg_make_constraint(const RgModelDev& m, RgLds& s) {
   int ns = nsrow(m);
   PFOR(r, ns) {
     int rr = r; float pos = 0, margin = 0, diag, floss = 0; const float *solref, *solimp; bool active = true, fric = false;
@@ -917,7 +1000,7 @@ __device__ void rg_make_constraint(const RgModelDev& m, RgLds& s) {
 __device__ __forceinline__ int npyr(int dim) { return dim == 1 ? 1 : 2 * (dim - 1); }
 
 // jar = J x - aref (or J x when `homog`) for every active row; result in r_jar/p_jar (or r_jv/p_jv)
-__device__ void rg_J_mul(const RgModelDev& m, RgLds& s, const float* x, bool to_jv) {
+__device__ __forceinline__ void rg_J_mul(const RgModelDev& m, RgLds& s, const float* x, bool to_jv) {
   int ns = nsrow(m), ncon = s.ncon;
   PFOR(r, ns) if (s.r_active[r]) { float v = srow_dot(m, s, r, x); if (to_jv) s.r_jv[r] = v; else s.r_jar[r] = v - s.r_aref[r]; }
   for (int w = LANE; w < ncon * 4; w += RG_WAVE) {
@@ -937,7 +1020,7 @@ __device__ void rg_J_mul(const RgModelDev& m, RgLds& s, const float* x, bool to_
   SYNC();
 }
 // forces / quadratic flags from jar; returns the wave-summed constraint cost
-__device__ float rg_constraint_update(const RgModelDev& m, RgLds& s) {
+__device__ __forceinline__ float rg_constraint_update(const RgModelDev& m, RgLds& s) {
   int ns = nsrow(m), ncon = s.ncon; float cost = 0;
   PFOR(r, ns) {
     if (!s.r_active[r]) { s.r_quad[r] = 0; s.r_force[r] = 0; continue; }
@@ -959,7 +1042,7 @@ __device__ float rg_constraint_update(const RgModelDev& m, RgLds& s) {
   return wave_sum(cost);
 }
 // dst = J^T force (dst zeroed here)
-__device__ void rg_JT_force(const RgModelDev& m, RgLds& s, float* dst) {
+__device__ __forceinline__ void rg_JT_force(const RgModelDev& m, RgLds& s, float* dst) {
   int ns = nsrow(m), ncon = s.ncon;
   PFOR(d, m.nv) dst[d] = 0;
   for (int w = LANE; w < ncon * 4; w += RG_WAVE) {
@@ -981,53 +1064,70 @@ __device__ void rg_JT_force(const RgModelDev& m, RgLds& s, float* dst) {
   SYNC();
 }
 // y = M x (dense rows; x, y in LDS)
-__device__ void rg_M_mul(const RgModelDev& m, RgLds& s, const float* x, float* y) {
-  PFOR(i, m.nv) { float v = 0; const float* row = s.M + i * NVP; for (int k = 0; k < m.nv; k++) v += row[k] * x[k]; y[i] = v; }
+__device__ __forceinline__ void rg_M_mul(const RgModelDev& m, RgLds& s, const float* x, float* y) {
+  PFOR(i, m.nv) {
+    float v = 0; const rgf4* row = (const rgf4*)(s.M + i * NVP); const rgf4* x4 = (const rgf4*)x;
+    int nc = (m.nv + 3) >> 2;  // rows and vectors are zero-padded to a multiple of 4
+#pragma unroll 3
+    for (int c = 0; c < nc; c++) { rgf4 a = row[c], b = x4[c]; v += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+    y[i] = v;
+  }
   SYNC();
 }
-// dense Cholesky of H (lower, in place) and solve H x = b
-__device__ void rg_chol(const RgModelDev& m, RgLds& s) {
-  int n = m.nv;
+// Dense Cholesky of the n x n matrix in s.H (lower triangle, in place), left-looking with lane i owning
+// row i: column j costs j multiply-adds per lane on independent LDS reads (row j is a broadcast read,
+// own-row reads are conflict-free with the padded stride), one pivot broadcast by v_readlane, one barrier.
+__device__ __forceinline__ void rg_chol(const RgModelDev& m, RgLds& s) {
+  int n = m.nv, i = LANE;
+  float* H = s.H;
   for (int j = 0; j < n; j++) {
-    float djj = s.H[j * NVP + j];
-    if (!(djj > 1e-30f)) { s.status |= RG_STATUS_BAD_FACTOR; djj = 1e-30f; }
-    float r = 1.0f / sqrtf(djj);
-    SYNC();
-    for (int i = j + LANE; i < n; i += RG_WAVE) { if (i == j) s.H[j * NVP + j] = sqrtf(djj); else s.H[i * NVP + j] *= r; }
-    SYNC();
-    int rem = n - j - 1, cnt = rem * (rem + 1) / 2;
-    for (int w = LANE; w < cnt; w += RG_WAVE) {
-      // w -> (a >= b) in the trailing lower triangle
-      int a = (int)((sqrtf(8.0f * w + 1.0f) - 1.0f) * 0.5f);
-      while (a * (a + 1) / 2 > w) a--;
-      while ((a + 1) * (a + 2) / 2 <= w) a++;
-      int b = w - a * (a + 1) / 2;
-      int i = j + 1 + a, k = j + 1 + b;
-      s.H[i * NVP + k] -= s.H[i * NVP + j] * s.H[k * NVP + j];
+    float acc = 0.f;
+    if (i >= j && i < n) {
+      acc = H[i * NVP + j];
+      const rgf4 *ri = (const rgf4*)(H + i * NVP), *rj = (const rgf4*)(H + j * NVP);
+      int nc = (j + 3) >> 2;
+#pragma unroll 3
+      for (int c = 0; c < nc; c++) {
+        rgf4 a = ri[c], b = rj[c];
+        int k = 4 * c;
+        acc -= a.x * (k < j ? b.x : 0.f) + a.y * (k + 1 < j ? b.y : 0.f) + a.z * (k + 2 < j ? b.z : 0.f) + a.w * (k + 3 < j ? b.w : 0.f);
+      }
     }
+    float d = lane_bcast(acc, j);
+    if (!(d > 1e-30f)) { if (i == 0) s.status |= RG_STATUS_BAD_FACTOR; d = 1e-30f; }
+    float r = 1.0f / sqrtf(d);
+    if (i >= j && i < n) H[i * NVP + j] = (i == j) ? d * r : acc * r;
     SYNC();
   }
 }
-__device__ void rg_chol_solve(const RgModelDev& m, RgLds& s, float* x) {
-  int n = m.nv;
-  // forward: L y = b, lane i owns x[i]
-  float xi = LANE < n ? x[LANE] : 0.f;
+// x <- H^-1 x with the factor above; lane i owns x[i]; the pivot reciprocal lives in the owning lane
+__device__ __forceinline__ void rg_chol_solve(const RgModelDev& m, RgLds& s, float* x) {
+  int n = m.nv, i = LANE;
+  const float* H = s.H;
+  float xi = i < n ? x[i] : 0.f;
+  float inv = i < n ? 1.0f / H[i * NVP + i] : 0.f;
   for (int j = 0; j < n; j++) {
-    float xj = __shfl(xi, j) / s.H[j * NVP + j];
-    if (LANE == j) xi = xj;
-    else if (LANE > j && LANE < n) xi -= s.H[LANE * NVP + j] * xj;
+    float xj = lane_bcast(xi * inv, j);
+    if (i == j) xi = xj;
+    else if (i > j && i < n) xi -= H[i * NVP + j] * xj;
   }
   for (int j = n - 1; j >= 0; j--) {
-    float xj = __shfl(xi, j) / s.H[j * NVP + j];
-    if (LANE == j) xi = xj;
-    else if (LANE < j) xi -= s.H[j * NVP + LANE] * xj;
+    float xj = lane_bcast(xi * inv, j);
+    if (i == j) xi = xj;
+    else if (i < j) xi -= H[j * NVP + i] * xj;
   }
-  if (LANE < n) x[LANE] = xi;
+  if (i < n) x[i] = xi;
   SYNC();
+}
+// s.H <- M + scale * diag(extra)
+__device__ __forceinline__ void rg_load_H(const RgModelDev& m, RgLds& s, const float* extra_diag, float scale) {
+  for (int w = LANE; w < m.nv * NVP; w += RG_WAVE) s.H[w] = s.M[w];
+  SYNC();
+  if (extra_diag) { PFOR(d, m.nv) s.H[d * NVP + d] += scale * extra_diag[d]; SYNC(); }
 }
 
 struct LsPt { float cost, grad, hess; };
-__device__ LsPt rg_ls_eval(const RgModelDev& m, RgLds& s, float alpha, float q0, float q1, float q2) {
+__device__ __forceinline__ LsPt rg_ls_eval(const RgModelDev& m, RgLds& s, float alpha, float q0, float q1, float q2) {
   int ns = nsrow(m), ncon = s.ncon; float c = 0, g = 0, h = 0;
   PFOR(r, ns) {
     if (!s.r_active[r]) continue;
@@ -1052,7 +1152,9 @@ __device__ LsPt rg_ls_eval(const RgModelDev& m, RgLds& s, float alpha, float q0,
 }
 
 // Newton solver on the primal problem (see oracle ro_solve); result: s.qacc, s.qfrc_con.  Returns iterations.
-__device__ int rg_solve(const RgModelDev& m, RgLds& s, int& nefc_out) {
+__device__ __forceinline__ int rg_solve(const RgModelDev& m, RgLds& s, int& nefc_out, int flags) {
+  long long t0 = rg_clock(), t1;
+#define PROFS(k) do { if (flags & 2) { t1 = rg_clock(); if (LANE == 0) s.prof[k] += (float)(t1 - t0); t0 = t1; } } while (0)
   int nv = m.nv, ns = nsrow(m), ncon = s.ncon;
   // count active rows (diagnostic only)
   { float cnt = 0; PFOR(r, ns) cnt += s.r_active[r] ? 1.f : 0.f; PFOR(c, ncon) cnt += (float)npyr(s.c_dim[c]); nefc_out = (int)(wave_sum(cnt) + 0.5f); }
@@ -1088,6 +1190,7 @@ __device__ int rg_solve(const RgModelDev& m, RgLds& s, int& nefc_out) {
     if (iter > 0 && scale * (oldcost - cost) < tol) break;
     if (gn < tol || iter >= m.iterations) break;
     iters = iter + 1;
+    PROFS(12);
     // H = M + J' D J over the quadratic rows
     for (int w = LANE; w < nv * NVP; w += RG_WAVE) s.H[w] = s.M[w];
     SYNC();
@@ -1112,10 +1215,13 @@ __device__ int rg_solve(const RgModelDev& m, RgLds& s, int& nefc_out) {
       SYNC();
     }
     SYNC();
+    PROFS(13);
     rg_chol(m, s);
+    PROFS(14);
     PFOR(i, nv) s.search[i] = -s.grad[i];
     SYNC();
     rg_chol_solve(m, s, s.search);
+    PROFS(15);
     // exact line search along `search`
     rg_M_mul(m, s, s.search, s.Mv);
     rg_J_mul(m, s, s.search, true);
@@ -1145,6 +1251,7 @@ __device__ int rg_solve(const RgModelDev& m, RgLds& s, int& nefc_out) {
     if (alpha == 0) break;
     PFOR(i, nv) s.qacc[i] += alpha * s.search[i];
     SYNC();
+    PROFS(10);
   }
   // forces at the solution
   rg_J_mul(m, s, s.qacc, false);
@@ -1154,12 +1261,13 @@ __device__ int rg_solve(const RgModelDev& m, RgLds& s, int& nefc_out) {
 }
 
 // ------------------------------------------------------------------------------------------------- integration
-__device__ void rg_euler(const RgModelDev& m, RgLds& s) {
+__device__ __forceinline__ void rg_euler(const RgModelDev& m, RgLds& s) {
   float h = m.timestep;
-  rg_factor_tree(m, s, m.dof_damping, h);
+  rg_load_H(m, s, m.dof_damping, h);
+  rg_chol(m, s);
   PFOR(i, m.nv) s.tmpv[i] = s.qfrc_smooth[i] + s.qfrc_con[i];
   SYNC();
-  rg_solve_tree(m, s, s.tmpv);
+  rg_chol_solve(m, s, s.tmpv);
   PFOR(i, m.nv) { s.qvel[i] += h * s.tmpv[i]; s.warm[i] = s.qacc[i]; }
   SYNC();
   PFOR(j, m.njnt) {
@@ -1179,7 +1287,7 @@ struct RgAux {  // extra static tables (kept out of RgModelDev to keep the kerna
   const uint32_t* dof_velmask;
 };
 
-__device__ void rg_dump(const RgModelDev& m, RgLds& s, float* dbg, int nefc, int iters) {
+__device__ __forceinline__ void rg_dump(const RgModelDev& m, RgLds& s, float* dbg, int nefc, int iters) {
   PFOR(i, m.nbody * 3) dbg[RG_DBG_XPOS + i] = s.xpos[i];
   PFOR(i, m.nbody * 4) dbg[RG_DBG_XQUAT + i] = s.xquat[i];
   PFOR(i, m.nsite * 3) dbg[RG_DBG_SITE + i] = s.spos[i];
@@ -1191,7 +1299,7 @@ __device__ void rg_dump(const RgModelDev& m, RgLds& s, float* dbg, int nefc, int
   PFOR(c, s.ncon) { float* o = dbg + RG_DBG_CON + 8 * c; o[0] = s.c_dist[c]; o[1] = s.c_pos[3 * c]; o[2] = s.c_pos[3 * c + 1]; o[3] = s.c_pos[3 * c + 2]; o[4] = s.c_frame[9 * c]; o[5] = s.c_frame[9 * c + 1]; o[6] = s.c_frame[9 * c + 2]; o[7] = (float)s.c_pair[c]; }
 }
 
-__device__ void rg_position_stage(const RgModelDev& m, const RgAux& x, RgLds& s) {
+__device__ __forceinline__ void rg_position_stage(const RgModelDev& m, const RgAux& x, RgLds& s) {
   rg_kinematics(m, s);
   rg_com_pos(m, s);
   rg_tendon(m, s);
@@ -1212,6 +1320,7 @@ __global__ void __launch_bounds__(RG_WAVE) rg_step_kernel(RgModelDev m, RgAux x,
   PFOR(i, m.nv) { s.qvel[i] = bt.qvel[(size_t)e * m.nv + i]; s.warm[i] = bt.qacc_warmstart[(size_t)e * m.nv + i]; }
   PFOR(i, 3 * m.nu) s.pid[i] = bt.pid[(size_t)e * 3 * m.nu + i];
   if (LANE == 0) s.status = bt.status[e];
+  if (LANE < RG_NPROF) s.prof[LANE] = 0;
   SYNC();
   // ---- action -> ctrl (robot_interface.py:247-278 with the hand's position->control matrix)
   if (bt.action) {
@@ -1230,21 +1339,25 @@ __global__ void __launch_bounds__(RG_WAVE) rg_step_kernel(RgModelDev m, RgAux x,
     // mj_checkPos / mj_checkVel
     float bd = 0; PFOR(i, m.nq) bd += (fabsf(s.qpos[i]) < 1e10f) ? 0.f : 1.f; PFOR(i, m.nv) bd += (fabsf(s.qvel[i]) < 1e10f) ? 0.f : 1.f;
     if (wave_sum(bd) > 0) { bad = true; break; }
-    rg_position_stage(m, x, s);
-    rg_crb(m, s, x.subtree_adr, x.subtree);
-    rg_factor_tree(m, s, (const float*)0, 0.f);
-    rg_collision(m, s);
-    rg_velocity(m, s, x.dof_velmask, x.subtree_adr, x.subtree);
-    rg_make_constraint(m, s);
+    long long t0 = rg_clock(), t1;
+#define PROF(k) do { if (flags & 2) { t1 = rg_clock(); if (LANE == 0) s.prof[k] += (float)(t1 - t0); t0 = t1; } } while (0)
+    rg_kinematics(m, s); PROF(0);
+    rg_com_pos(m, s); PROF(1);
+    rg_tendon(m, s); PROF(2);
+    rg_crb(m, s, x.subtree_adr, x.subtree); PROF(3);
+    rg_load_H(m, s, (const float*)0, 0.f); rg_chol(m, s); PROF(4);
+    rg_collision(m, s, (flags & 2) ? s.prof : (float*)0); PROF(6);
+    rg_velocity(m, s, x.dof_velmask, x.subtree_adr, x.subtree); PROF(7);
+    rg_make_constraint(m, s); PROF(8);
     rg_pid(m, s);
-    rg_smooth(m, s);
+    rg_smooth(m, s); rg_chol_solve(m, s, s.qacc_smooth); PROF(9);
     int nefc = 0;
-    int iters = rg_solve(m, s, nefc);
+    int iters = rg_solve(m, s, nefc, flags); t0 = rg_clock();
     st_ncon += s.ncon; st_nefc += nefc; st_iter += iters;
     if (sub == 0 && (flags & 1) && bt.dbg) rg_dump(m, s, bt.dbg + (size_t)e * RG_DBG_SIZE, nefc, iters);
     bd = 0; PFOR(i, m.nv) bd += (fabsf(s.qacc[i]) < 1e10f) ? 0.f : 1.f;
     if (wave_sum(bd) > 0) { bad = true; break; }
-    rg_euler(m, s);
+    rg_euler(m, s); PROF(11);
   }
   if (bad && LANE == 0) s.status |= RG_STATUS_BAD_STATE;
   // ---- state-less forward() calls of the reference (simulation_interface.py:185, robot_env.py:677,
@@ -1262,6 +1375,7 @@ __global__ void __launch_bounds__(RG_WAVE) rg_step_kernel(RgModelDev m, RgAux x,
     bt.status[e] = s.status; bt.time[e] += nsubsteps * m.timestep;
     if (bt.stats) { float* st = bt.stats + 4 * (size_t)e; st[0] += st_ncon; st[1] += st_nefc; st[2] += st_iter; st[3] += nsubsteps; }
   }
+  if ((flags & 2) && bt.dbg && LANE < RG_NPROF) bt.dbg[(size_t)e * RG_DBG_SIZE + RG_DBG_CON + LANE] = s.prof[LANE];  // stage cycle counters (overlays the contact dump)
   // ---- observation row (robot_env.py:714-743; keys/order: DESIGN.md "observation layout")
   if (bt.obs) {
     int od = 3 + 4 + m.nq + m.nv + env.n_hand_jnt + 15;
@@ -1308,10 +1422,10 @@ __global__ void __launch_bounds__(RG_WAVE) rg_mpr_pair_kernel(RgModelDev m, RgBa
   v3 p1 = ld3(s.gpos + 3 * g1), p2 = ld3(s.gpos + 3 * g2);
   A.type = m.geom_type[g1]; A.mat = s.gmat + 9 * g1; A.size = ld3(m.geom_size + 3 * g1); A.margin = 0.5f * margin; A.pos = mk3(0, 0, 0);
   B.type = m.geom_type[g2]; B.mat = s.gmat + 9 * g2; B.size = ld3(m.geom_size + 3 * g2); B.margin = 0.5f * margin; B.pos = p2 - p1;
-  if (A.type == RG_GEOM_MESH) { int id = m.geom_dataid[g1]; A.vert = m.mesh_vert + 3 * m.mesh_vertadr[id]; A.nvert = m.mesh_vertnum[id]; } else { A.vert = 0; A.nvert = 0; }
-  if (B.type == RG_GEOM_MESH) { int id = m.geom_dataid[g2]; B.vert = m.mesh_vert + 3 * m.mesh_vertadr[id]; B.nvert = m.mesh_vertnum[id]; } else { B.vert = 0; B.nvert = 0; }
+  if (A.type == RG_GEOM_MESH) { int id = m.geom_dataid[g1]; A.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; A.nvert = m.mesh_vertnum[id]; } else { A.vert = 0; A.nvert = 0; }
+  if (B.type == RG_GEOM_MESH) { int id = m.geom_dataid[g2]; B.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; B.nvert = m.mesh_vertnum[id]; } else { B.vert = 0; B.nvert = 0; }
   float depth = 0; v3 dir = mk3(0, 0, 0), pos = mk3(0, 0, 0);
-  bool hit = rg_mpr(A, B, m.mpr_iterations, m.mpr_tolerance, depth, dir, pos);
+  bool hit = rg_mpr<64>(A, B, m.mpr_iterations, m.mpr_tolerance, depth, dir, pos);
   if (LANE == 0) {
     float* o = out + 8 * (size_t)e;
     o[0] = hit ? 1.f : 0.f; o[1] = depth; o[2] = dir.x; o[3] = dir.y; o[4] = dir.z; o[5] = pos.x + p1.x; o[6] = pos.y + p1.y; o[7] = pos.z + p1.z;

@@ -21,6 +21,21 @@ void* emul_lds() { return g_lds; }
 
 void emul_yield() { swapcontext(&g_fiber[g_cur], &g_sched); }
 
+// barrier state per group size (16-lane rows: 4 groups, wave: 1 group)
+static int g_arrived[2][4], g_gen[2][4];
+static int live_in_group(int gsize, int grp) { int n = 0; for (int l = grp * gsize; l < (grp + 1) * gsize; l++) n += !g_done[l]; return n; }
+void emul_barrier(int gsize) {
+  int k = gsize == 64 ? 1 : 0, grp = gsize == 64 ? 0 : g_cur / 16, gs = gsize == 64 ? 64 : 16;
+  int gen = g_gen[k][grp];
+  g_arrived[k][grp]++;
+  if (g_arrived[k][grp] >= live_in_group(gs, grp)) { g_arrived[k][grp] = 0; g_gen[k][grp]++; emul_yield(); return; }
+  while (g_gen[k][grp] == gen) {
+    // a lane of the group may have exited the kernel while we wait
+    if (g_arrived[k][grp] >= live_in_group(gs, grp)) { g_arrived[k][grp] = 0; g_gen[k][grp]++; break; }
+    emul_yield();
+  }
+}
+
 static void fiber_main() {
   g_fn(g_arg);
   g_done[g_cur] = 1;
@@ -42,6 +57,7 @@ void emul_launch(int nblocks, size_t lds_bytes, emul_kernel_fn fn, void* arg) {
       makecontext(&g_fiber[l], fiber_main, 0);
       g_done[l] = 0;
     }
+    for (int k = 0; k < 2; k++) for (int g = 0; g < 4; g++) g_arrived[k][g] = 0;
     int alive = 64;
     while (alive > 0) {
       alive = 0;

@@ -22,27 +22,30 @@ extern emul_dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 void emul_yield();
 void* emul_lds();
+// arrival-counting barrier over the `gsize`-lane group that contains the calling lane (64 = the wave)
+void emul_barrier(int gsize);
 extern uint64_t emul_xchg[64];
 
-static inline void __syncthreads() { emul_yield(); }
+static inline void __syncthreads() { emul_barrier(64); }
 
-template <class T> static inline T emul_exchange(T v, int src) {
+template <class T> static inline T emul_exchange(T v, int src, int gsize) {
   static_assert(sizeof(T) <= 8, "shuffle payload");
   uint64_t raw = 0; memcpy(&raw, &v, sizeof(T));
   emul_xchg[threadIdx.x] = raw;
-  emul_yield();
+  emul_barrier(gsize);
   T r; memcpy(&r, &emul_xchg[src & 63], sizeof(T));
-  emul_yield();
+  emul_barrier(gsize);
   return r;
 }
-template <class T> static inline T __shfl_xor(T v, int mask) { return emul_exchange(v, (int)threadIdx.x ^ mask); }
-template <class T> static inline T __shfl(T v, int src) { return emul_exchange(v, src); }
+// xor shuffles with a mask below 16 stay inside a 16-lane row: only that row has to be convergent
+template <class T> static inline T __shfl_xor(T v, int mask) { return emul_exchange(v, (int)threadIdx.x ^ mask, mask < 16 ? 16 : 64); }
+template <class T> static inline T __shfl(T v, int src) { return emul_exchange(v, src, 64); }
 static inline unsigned long long __ballot(int pred) {
   emul_xchg[threadIdx.x] = pred ? 1 : 0;
-  emul_yield();
+  emul_barrier(64);
   unsigned long long r = 0;
   for (int i = 0; i < 64; i++) if (emul_xchg[i]) r |= 1ull << i;
-  emul_yield();
+  emul_barrier(64);
   return r;
 }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }

@@ -1,0 +1,26 @@
+"""Per-stage cycle counters of the env-step kernel (flags bit 1): mean cycles per substep per wavefront."""
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from robogym_amd.envs.dactyl.locked import make_simple_env
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+env = make_simple_env(batch_size=B, device="cuda:0", starting_seed=1)
+env.reset()
+sim = env.mujoco_simulation
+gen = torch.Generator(device="cuda:0"); gen.manual_seed(0)
+for _ in range(5):
+    env.step(torch.rand((B, 20), generator=gen, device="cuda:0") * 2 - 1)
+a = (torch.rand((B, 20), generator=gen, device="cuda:0") * 2 - 1).contiguous()
+torch.cuda.synchronize()
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record(); sim.env_step(action=a, nforward_ticks=3, flags=2); e.record(); torch.cuda.synchronize()
+dbg = sim.get_field(8)
+off = dbg.shape[1] - 32 * 8
+prof = dbg[:, off:off + 16].double().mean(0).cpu().numpy() / 10.0
+names = ["kinematics", "com_pos", "tendon", "crb+M", "factor M", "broadphase", "narrowphase(+broad)", "velocity/RNE", "constraint rows", "pid+smooth", "newton linesearch+update", "euler", "newton grad/cost eval", "newton H assembly", "newton cholesky", "newton tri-solve"]
+tot = sum(prof[i] for i in range(16) if i != 5)
+print("kernel ms %.2f for B=%d ; cycles per substep per wave (mean over envs):" % (s.elapsed_time(e), B))
+for i, n in enumerate(names):
+    print("  %-22s %10.0f  %5.1f%%" % (n, prof[i], 100 * prof[i] / tot))
+print("  total %.0f cycles/substep" % tot)
