@@ -89,13 +89,14 @@ def main():
     sim = env.mujoco_simulation
     gen = torch.Generator(device=dev)
     gen.manual_seed(20200901 + 1 + 1000 * rank)
-    obs_all = torch.empty((world * B, sim.obs_dim), dtype=torch.float32, device=dev) if distributed else None
+    from robogym_amd.distributed import ShardedObservationGather
+
+    gather = ShardedObservationGather(B, sim.obs_dim, dev)
 
     def one_step():
         a = torch.rand((B, 20), generator=gen, device=dev) * 2 - 1
         obs, reward, done, info = env.step(a)
-        if distributed:
-            dist.all_gather_into_tensor(obs_all, env._obs_buf)
+        gather(env._obs_buf)  # RCCL all-gather of the observation rows when N > 1
         return done
 
     for _ in range(args.warmup):

@@ -25,7 +25,7 @@
 #define NVP (RG_MAXNV + 4)  // row stride of dense nv x nv matrices in LDS: 16-byte aligned rows, 44 words -> conflict-free ds_read_b128 across lanes
 #define RG_MAXSROW (RG_MAXROW + 64)  // static row slots: friction dofs/tendons + 2 per limited joint/tendon
 #define RG_MAXPYR (RG_MAXCON * 6)
-#define RG_NPROF 16
+#define RG_NPROF 32
 
 struct RgLds {
   // state
@@ -48,8 +48,8 @@ struct RgLds {
   float r_D[RG_MAXSROW], r_R[RG_MAXSROW], r_aref[RG_MAXSROW], r_floss[RG_MAXSROW], r_jar[RG_MAXSROW], r_jv[RG_MAXSROW], r_force[RG_MAXSROW];
   int r_active[RG_MAXSROW], r_quad[RG_MAXSROW];
   // contacts
-  int ncand, ncon;
-  int cand[RG_MAXCAND];
+  int ncand, ncand2, ncon;
+  int cand[RG_MAXCAND], cand2[RG_MAXCAND];
   float c_dist[RG_MAXCON], c_pos[RG_MAXCON * 3], c_frame[RG_MAXCON * 9], c_D[RG_MAXCON], c_mu[RG_MAXCON * 4];
   int c_pair[RG_MAXCON], c_dim[RG_MAXCON], c_nnz[RG_MAXCON];
   unsigned char c_idx[RG_MAXCON * RG_W];
@@ -436,7 +436,7 @@ __device__ __forceinline__ void rg_crb(const RgModelDev& m, RgLds& s, const int*
 
 // ------------------------------------------------------------------------------------------------- collision
 struct SupPt { v3 v, v1, v2; };
-struct MprGeom { int type; const float* mat; v3 pos; v3 size; const float* vert; int nvert; float margin; };
+struct MprGeom { int type; const float* mat; v3 pos; v3 size; const float* vert; int nvert; float margin; float* prof; };
 
 // per-lane scan of a hull's vertices: 16-byte records (one dwordx4 load per vertex), four independent
 // loads in flight per lane; out-of-range slots re-read the last vertex (harmless for a max).
@@ -500,6 +500,7 @@ template <int G> __device__ __forceinline__ v3 rg_support(const MprGeom& g, v3 d
 // Minkowski-difference support A(dir) - B(-dir); the two hull scans are issued back to back so their
 // vertex loads overlap
 template <int G> __device__ __forceinline__ void mpr_support(const MprGeom& a, const MprGeom& b, v3 dir, SupPt& p) {
+  long long tt0 = a.prof ? rg_clock() : 0;
   v3 la = mulmT(a.mat, dir), lb = mulmT(b.mat, dir * -1.0f), ra, rb;
   float av = -3.0e38f, bvv = -3.0e38f; int ai = 0x7fffffff, bi = 0x7fffffff; v3 ap = mk3(0, 0, 0), bp = mk3(0, 0, 0);
   bool am = a.type == RG_GEOM_MESH, bm = b.type == RG_GEOM_MESH;
@@ -513,11 +514,13 @@ template <int G> __device__ __forceinline__ void mpr_support(const MprGeom& a, c
     if (am) scan_verts<G>((const rgf4*)a.vert, a.nvert, la, av, ai, ap);
     if (bm) scan_verts<G>((const rgf4*)b.vert, b.nvert, lb, bvv, bi, bp);
   }
+  long long tt1 = a.prof ? rg_clock() : 0;
   ra = am ? pick_vert<G>(av, ai, ap) : support_primitive(a, la);
   rb = bm ? pick_vert<G>(bvv, bi, bp) : support_primitive(b, lb);
   p.v1 = mulm(a.mat, ra + la * a.margin) + a.pos;
   p.v2 = mulm(b.mat, rb + lb * b.margin) + b.pos;
   p.v = p.v1 - p.v2;
+  if (a.prof && LANE == 0) { long long tt2 = rg_clock(); a.prof[20] += 1.f; a.prof[21] += (float)(tt1 - tt0); a.prof[22] += (float)(tt2 - tt1); }
 }
 #define MPR_EPS 1.0e-7f  /* plays the role of libccd's CCD_EPS at fp32 (coordinates are pair-local, |x| ~ 0.1) */
 __device__ __forceinline__ bool mz(float x) { return fabsf(x) < MPR_EPS * 1e-3f; }
@@ -651,6 +654,18 @@ __device__ __forceinline__ void add_contact(RgLds& s, int pair, float dist, v3 p
   SYNC();
 }
 
+// the two geoms of candidate pair p in pair-local coordinates (origin at geom1's centre: fp32 resolution ~1e-9 m),
+// each inflated by margin/2
+__device__ __forceinline__ void rg_mpr_geoms(const RgModelDev& m, const RgLds& s, int p, MprGeom& A, MprGeom& B) {
+  int g1 = m.pair_geom[3 * p], g2 = m.pair_geom[3 * p + 1];
+  float margin = m.pair_prm[12 * p];
+  int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
+  A.type = t1; A.mat = s.gmat + 9 * g1; A.size = ld3(m.geom_size + 3 * g1); A.margin = 0.5f * margin; A.pos = mk3(0, 0, 0);
+  B.type = t2; B.mat = s.gmat + 9 * g2; B.size = ld3(m.geom_size + 3 * g2); B.margin = 0.5f * margin; B.pos = ld3(s.gpos + 3 * g2) - ld3(s.gpos + 3 * g1);
+  if (t1 == RG_GEOM_MESH) { int id = m.geom_dataid[g1]; A.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; A.nvert = m.mesh_vertnum[id]; } else { A.vert = 0; A.nvert = 0; }
+  if (t2 == RG_GEOM_MESH) { int id = m.geom_dataid[g2]; B.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; B.nvert = m.mesh_vertnum[id]; } else { B.vert = 0; B.nvert = 0; }
+  A.prof = 0; B.prof = 0;
+}
 __device__ __forceinline__ void rg_collision(const RgModelDev& m, RgLds& s, float* prof) {
   long long tb0 = rg_clock();
   if (LANE == 0) { s.ncand = 0; s.ncon = 0; }
@@ -688,29 +703,53 @@ __device__ __forceinline__ void rg_collision(const RgModelDev& m, RgLds& s, floa
     SYNC();
   }
   if (prof && LANE == 0) prof[5] += (float)(rg_clock() - tb0);
-  // narrowphase.  Convex pairs: four candidates at a time, one 16-lane DPP row per MPR query (the portal
-  // algebra is scalar per query, so a whole wave per query would execute it 64-fold redundantly).
+  // narrowphase.  Convex pairs run in 16-lane DPP rows, four queries per wave (the portal algebra is
+  // scalar per query; a whole wave per query would execute it 64-fold redundantly).
+  // Phase 1 (uniform cost): MPR's first support test along the centre line for every candidate —
+  // "separated along the centre direction" rejects most OBB-overlapping neighbours.  Survivors are
+  // compacted in order so that phase 2 (full MPR) only runs rows of genuinely close pairs.
   int ncand = s.ncand;
+  if (LANE == 0) s.ncand2 = 0;
+  SYNC();
   for (int base = 0; base < ncand; base += 4) {
     int ci = base + (LANE >> 4);
-    bool valid = ci < ncand, hit = false;
-    float depth = 0, margin = 0; v3 dir = mk3(0, 0, 0), pos = mk3(0, 0, 0); int p = 0, dim = 3;
-    if (valid) {
+    bool keep = false; int p = 0;
+    if (ci < ncand) {
       p = s.cand[ci];
-      int g1 = m.pair_geom[3 * p], g2 = m.pair_geom[3 * p + 1]; dim = m.pair_geom[3 * p + 2];
-      margin = m.pair_prm[12 * p];
-      int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
-      if (t1 != RG_GEOM_PLANE) {
-        v3 p1 = ld3(s.gpos + 3 * g1), p2 = ld3(s.gpos + 3 * g2);
+      int g1 = m.pair_geom[3 * p], g2 = m.pair_geom[3 * p + 1];
+      if (m.geom_type[g1] != RG_GEOM_PLANE) {
         MprGeom A, B;
-        A.type = t1; A.mat = s.gmat + 9 * g1; A.size = ld3(m.geom_size + 3 * g1); A.margin = 0.5f * margin; A.pos = mk3(0, 0, 0);
-        B.type = t2; B.mat = s.gmat + 9 * g2; B.size = ld3(m.geom_size + 3 * g2); B.margin = 0.5f * margin; B.pos = p2 - p1;  // pair-local coordinates
-        if (t1 == RG_GEOM_MESH) { int id = m.geom_dataid[g1]; A.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; A.nvert = m.mesh_vertnum[id]; } else { A.vert = 0; A.nvert = 0; }
-        if (t2 == RG_GEOM_MESH) { int id = m.geom_dataid[g2]; B.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; B.nvert = m.mesh_vertnum[id]; } else { B.vert = 0; B.nvert = 0; }
-        hit = rg_mpr<16>(A, B, m.mpr_iterations, m.mpr_tolerance, depth, dir, pos);
-        hit = hit && dot(dir, dir) > 0.25f;
-        pos = pos + p1;
+        rg_mpr_geoms(m, s, p, A, B);
+        v3 c0 = A.pos - B.pos;
+        if (mz(c0.x) && mz(c0.y) && mz(c0.z)) c0.x += 1e-6f;
+        v3 dir = normalized(c0 * -1.0f);
+        SupPt p1; mpr_support<16>(A, B, dir, p1);
+        keep = dot(p1.v, dir) > 0;
       }
+    }
+    bool lead = keep && (LANE & 15) == 0;
+    unsigned long long bal = __ballot(lead);
+    int cbase = s.ncand2;
+    SYNC();
+    if (lead) s.cand2[cbase + __popcll(bal & ((1ull << LANE) - 1ull))] = p;
+    if (LANE == 0) s.ncand2 = cbase + __popcll(bal);
+    SYNC();
+  }
+  int ncand2 = s.ncand2;
+  if (prof && LANE == 0) { prof[16] += (float)(rg_clock() - tb0); prof[17] += ncand; prof[18] += ncand2; }
+  for (int base = 0; base < ncand2; base += 4) {
+    int ci = base + (LANE >> 4);
+    bool hit = false;
+    float depth = 0, margin = 0; v3 dir = mk3(0, 0, 0), pos = mk3(0, 0, 0); int p = 0, dim = 3;
+    if (ci < ncand2) {
+      p = s.cand2[ci];
+      dim = m.pair_geom[3 * p + 2]; margin = m.pair_prm[12 * p];
+      MprGeom A, B;
+      rg_mpr_geoms(m, s, p, A, B);
+      A.prof = prof;
+      hit = rg_mpr<16>(A, B, m.mpr_iterations, m.mpr_tolerance, depth, dir, pos);
+      hit = hit && dot(dir, dir) > 0.25f;
+      pos = pos + ld3(s.gpos + 3 * m.pair_geom[3 * p]);
     }
     // append the rows' contacts in candidate order (row leaders hold the result)
     bool lead = hit && (LANE & 15) == 0;
@@ -727,6 +766,7 @@ __device__ __forceinline__ void rg_collision(const RgModelDev& m, RgLds& s, floa
     if (LANE == 0) { int n = cbase + __popcll(bal); s.ncon = n < RG_MAXCON ? n : RG_MAXCON; }
     SYNC();
   }
+  if (prof && LANE == 0) prof[19] += (float)(rg_clock() - tb0);
   // plane pairs (rare: something near the floor), whole wave cooperating, one candidate at a time
   for (int ci = 0; ci < ncand; ci++) {
     int p = s.cand[ci];
@@ -736,7 +776,7 @@ __device__ __forceinline__ void rg_collision(const RgModelDev& m, RgLds& s, floa
     int t2 = m.geom_type[g2];
     v3 p1 = ld3(s.gpos + 3 * g1), p2 = ld3(s.gpos + 3 * g2);
     MprGeom B;
-    B.type = t2; B.mat = s.gmat + 9 * g2; B.size = ld3(m.geom_size + 3 * g2); B.margin = 0;
+    B.type = t2; B.mat = s.gmat + 9 * g2; B.size = ld3(m.geom_size + 3 * g2); B.margin = 0; B.prof = 0;
     if (t2 == RG_GEOM_MESH) { int id = m.geom_dataid[g2]; B.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; B.nvert = m.mesh_vertnum[id]; } else { B.vert = 0; B.nvert = 0; }
     const float* R1 = s.gmat + 9 * g1;
     v3 n = mk3(R1[2], R1[5], R1[8]);
@@ -1420,8 +1460,8 @@ __global__ void __launch_bounds__(RG_WAVE) rg_mpr_pair_kernel(RgModelDev m, RgBa
   rg_kinematics(m, s);
   MprGeom A, B;
   v3 p1 = ld3(s.gpos + 3 * g1), p2 = ld3(s.gpos + 3 * g2);
-  A.type = m.geom_type[g1]; A.mat = s.gmat + 9 * g1; A.size = ld3(m.geom_size + 3 * g1); A.margin = 0.5f * margin; A.pos = mk3(0, 0, 0);
-  B.type = m.geom_type[g2]; B.mat = s.gmat + 9 * g2; B.size = ld3(m.geom_size + 3 * g2); B.margin = 0.5f * margin; B.pos = p2 - p1;
+  A.type = m.geom_type[g1]; A.mat = s.gmat + 9 * g1; A.size = ld3(m.geom_size + 3 * g1); A.margin = 0.5f * margin; A.pos = mk3(0, 0, 0); A.prof = 0;
+  B.type = m.geom_type[g2]; B.mat = s.gmat + 9 * g2; B.size = ld3(m.geom_size + 3 * g2); B.margin = 0.5f * margin; B.pos = p2 - p1; B.prof = 0;
   if (A.type == RG_GEOM_MESH) { int id = m.geom_dataid[g1]; A.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; A.nvert = m.mesh_vertnum[id]; } else { A.vert = 0; A.nvert = 0; }
   if (B.type == RG_GEOM_MESH) { int id = m.geom_dataid[g2]; B.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; B.nvert = m.mesh_vertnum[id]; } else { B.vert = 0; B.nvert = 0; }
   float depth = 0; v3 dir = mk3(0, 0, 0), pos = mk3(0, 0, 0);

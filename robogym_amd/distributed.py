@@ -1,0 +1,31 @@
+"""Data-parallel sharding of the env batch over the GPUs of one node.
+
+Envs never interact, so rank r simply owns envs [r*B, (r+1)*B); model tables are replicated.  The only
+exchange the path has is the end-of-step all-gather of the observation rows (RCCL over xGMI via
+torch.distributed's "nccl" backend; "gloo" on CPU for tests) for a learner that consumes the full
+batch on every rank."""
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+class ShardedObservationGather:
+    def __init__(self, local_batch: int, obs_dim: int, device, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.local_batch = local_batch
+        self.buffer: Optional[torch.Tensor] = None
+        if self.world > 1:
+            self.buffer = torch.empty((self.world * local_batch, obs_dim), dtype=torch.float32, device=device)
+
+    def __call__(self, local_obs_rows: torch.Tensor) -> torch.Tensor:
+        """[B, obs_dim] on this rank -> [world*B, obs_dim] on every rank (rank-major order)."""
+        if self.world == 1:
+            return local_obs_rows
+        dist.all_gather_into_tensor(self.buffer, local_obs_rows.contiguous(), group=self.group)
+        return self.buffer
+
+    def global_env_ids(self) -> torch.Tensor:
+        return torch.arange(self.rank * self.local_batch, (self.rank + 1) * self.local_batch)

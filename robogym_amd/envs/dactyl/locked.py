@@ -22,6 +22,7 @@ from robogym_amd.mujoco.mjcf_compiler import CompiledModel
 from robogym_amd.mujoco.mujoco_xml import MujocoXML
 from robogym_amd.mujoco.simulation_interface import BatchedSimulationInterface
 from robogym_amd.utils import rotation
+from robogym_amd.utils.multi_goal_tracker import BatchedMultiGoalTracker
 
 MODEL_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "models")
 
@@ -190,10 +191,8 @@ class BatchedLockedEnv:
         self._prev_dist = torch.zeros(B, dtype=torch.float32, device=dev)
         self._prev_valid = torch.zeros(B, dtype=torch.bool, device=dev)
         self._is_successful = torch.zeros(B, dtype=torch.bool, device=dev)
-        # MultiGoalTracker state (multi_goal_tracker.py:88-113)
+        self.multi_goal_tracker = BatchedMultiGoalTracker(B, dev, c.max_timesteps_per_goal, c.success_reward, c.successes_needed, c.use_goal_distance_reward)
         z = lambda: torch.zeros(B, dtype=torch.int32, device=dev)
-        self._steps, self._steps_since_last_goal, self._successes_so_far, self._goals_so_far = z(), z(), z(), z()
-        self._consecutive_success = z()
         self.t = z()
         self._needs_reset = True
 
@@ -224,8 +223,7 @@ class BatchedLockedEnv:
         self.t = torch.where(mask, torch.zeros_like(self.t), self.t)
         self._randomize_cube_pose(mask)
         # tracker.reset + reset_goal_generation -> reset_goal (robot_env.py:787-792, 893-909)
-        for buf in (self._steps, self._steps_since_last_goal, self._successes_so_far, self._goals_so_far, self._consecutive_success):
-            buf[mask] = 0
+        self.multi_goal_tracker.reset(mask)
         self._new_goal(mask)
         self._needs_reset = False
         return self.observe()
@@ -280,9 +278,7 @@ class BatchedLockedEnv:
         m1 = mask[:, None]
         self._goal_quat = torch.where(m1, g["cube_quat"], self._goal_quat).contiguous()
         self._qpos_goal = torch.where(m1, g["qpos_goal"], self._qpos_goal)
-        self._goals_so_far += mask.to(torch.int32)
-        self._steps_since_last_goal = torch.where(mask, torch.zeros_like(self._steps_since_last_goal), self._steps_since_last_goal)
-        self._consecutive_success = torch.where(mask, torch.zeros_like(self._consecutive_success), self._consecutive_success)
+        self.multi_goal_tracker.reset_goal_steps(mask)
         sim.env_step(goal_quat=self._goal_quat, obs=self._obs_buf, goal_dist=self._goal_dist, active=mask.to(torch.int32).contiguous(),
                      nsubsteps=0, nforward_ticks=2)
         # _previous_goal_distance = None, then update_goal_info sets it to the current distance
@@ -325,35 +321,9 @@ class BatchedLockedEnv:
         is_successful = dist < c.success_threshold["cube_quat"]
         self._is_successful = is_successful
         goal_dist_before = dist.clone()
-        # MultiGoalTracker.process (multi_goal_tracker.py:157-241) with success_steps_required = 1,
-        # min_timesteps_per_goal = 0, check_goal_reachable = False
-        self._steps += 1
-        self._steps_since_last_goal += 1
-        self._consecutive_success = torch.where(is_successful, self._consecutive_success + 1, torch.zeros_like(self._consecutive_success))
-        got = self._consecutive_success >= 1
-        success_reward = got.to(torch.float32) * c.success_reward
-        self._successes_so_far += got.to(torch.int32)
-        timeout = (~got) & (self._steps_since_last_goal >= c.max_timesteps_per_goal)
-        trial_success = got & (self._successes_so_far >= c.successes_needed)
-        done = timeout | trial_success
-        steps_since_for_info = self._steps_since_last_goal.clone()
-        self._steps_since_last_goal = torch.where(trial_success, torch.zeros_like(self._steps_since_last_goal), self._steps_since_last_goal)
-        new_goal = got & ~trial_success
+        reward, done, new_goal, info = self.multi_goal_tracker.process(is_successful, goal_distance_reward)
         self._new_goal(new_goal)
-        goal_reward = goal_distance_reward if c.use_goal_distance_reward else torch.zeros_like(dist)
-        reward = torch.stack([torch.zeros_like(dist), goal_reward, success_reward], dim=-1)
-        info = {
-            "goal_dist": {"cube_quat": goal_dist_before},
-            "goal_achieved": is_successful,
-            "sub_goal_is_successful": got,
-            "trial_success": trial_success,
-            "goal_reset": new_goal,
-            "successes_so_far": self._successes_so_far.clone(),
-            "goals_so_far": self._goals_so_far.clone(),
-            "steps_since_last_goal": torch.where(new_goal, torch.zeros_like(steps_since_for_info), self._steps_since_last_goal),
-            "env_crash": torch.zeros_like(done),
-            "sim_status": None,
-        }
+        info.update({"goal_dist": {"cube_quat": goal_dist_before}, "goal_achieved": is_successful, "goals_so_far": self.multi_goal_tracker.goals_so_far.clone()})
         return self.observe(), reward, done, info
 
     # ------------------------------------------------------------------ diagnostics
