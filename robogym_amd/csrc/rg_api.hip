@@ -117,6 +117,11 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
   if (d.nq > RG_MAXNQ || d.nv > RG_MAXNV || d.nbody > RG_MAXBODY || d.njnt > RG_MAXJNT || d.ngeom > RG_MAXGEOM || d.nsite > RG_MAXSITE ||
       d.ntendon > RG_MAXTEN || d.nu > RG_MAXU)
     return bail("model exceeds the compiled kernel capacities (rg_types.h)", m);
+  GI("k_blk_dims");
+  d.nvc = iv[0]; d.hs = iv[1]; d.blkwords = iv[2]; d.ntree = iv[3]; d.maxtree = iv[4];
+  if (d.nvc > RG_MAXNVC || d.blkwords > RG_MAXBLK || d.nvc * d.hs > RG_HWORDS || d.blkwords > RG_HWORDS || d.npair >= 32768)
+    return bail("model exceeds the compiled solver capacities (rg_types.h)", m);
+  UPI(dof_blk, "k_dof_blk"); UPI(dof_blk2, "k_dof_blk2"); UPI(c_blk, "k_c_blk"); UPI(d2c, "k_d2c"); UPI(c2d, "k_c2d");
   GI("opt_int"); d.iterations = iv[0]; d.cone = iv[1]; d.mpr_iterations = iv[3];
   if (d.cone != 0) return bail("elliptic friction cones are not implemented in this kernel configuration", m);
   GF("opt_timestep"); d.timestep = fv[0];
@@ -131,7 +136,7 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
   UPF(body_mass, "body_mass"); UPF(body_inertia, "body_inertia"); UPF(body_invweight0, "body_invweight0");
   UPI(lvl_body, "k_lvl_body"); UPI(lvl_body_adr, "k_lvl_body_adr"); UPI(static_body, "k_static_body");
   UPF(static_xpos, "k_static_xpos"); UPF(static_xquat, "k_static_xquat");
-  UPI(root_origin_body, "k_root_origin_body"); UPF(root_origin_const, "k_root_origin_const");
+  UPI(root_origin_body, "k_root_origin_body"); UPI(body_orgslot, "k_body_orgslot"); UPF(root_origin_const, "k_root_origin_const");
   { GI("k_body_dofmask"); std::vector<uint32_t> u(iv.begin(), iv.end()); for (size_t i = 0; i < iv.size(); i++) u[i] = (uint32_t)iv[i]; if (!upload<uint32_t>(m, u, &d.body_dofmask)) return bail("hipMalloc failed", m); }
   UPI(jnt_type, "jnt_type"); UPI(jnt_qposadr, "jnt_qposadr"); UPI(jnt_dofadr, "jnt_dofadr"); UPI(jnt_bodyid, "jnt_bodyid");
   UPF(jnt_pos, "jnt_pos"); UPF(jnt_axis, "jnt_axis"); UPF(jnt_stiffness, "jnt_stiffness"); UPF(jnt_range, "jnt_range");
@@ -164,7 +169,8 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
   GI("k_fric_ten"); d.nfric_ten = (int)iv.size(); if (!upload<int>(m, iv, &d.fric_ten)) return bail("hipMalloc failed", m);
   GI("k_lim_jnt"); d.nlim_jnt = (int)iv.size(); if (!upload<int>(m, iv, &d.lim_jnt)) return bail("hipMalloc failed", m);
   GI("k_lim_ten"); d.nlim_ten = (int)iv.size(); if (!upload<int>(m, iv, &d.lim_ten)) return bail("hipMalloc failed", m);
-  if (d.nfric_dof + d.nfric_ten + 2 * d.nlim_jnt + 2 * d.nlim_ten > RG_MAXSROW) return bail("too many friction/limit rows for RG_MAXSROW", m);
+  if (d.nfric_dof + d.nfric_ten + 2 * d.nlim_jnt + 2 * d.nlim_ten > RG_MAXSROW || d.nfric_dof + d.nfric_ten > RG_MAXFRIC) return bail("too many friction/limit rows for RG_MAXSROW / RG_MAXFRIC", m);
+  { GI("k_pair_geom"); for (size_t i = 2; i < iv.size(); i += 3) if (iv[i] > 4) return bail("condim 6 (rolling friction) contacts are not implemented", m); }
   GI("k_subtree_adr"); if (!upload<int>(m, iv, &m->aux.subtree_adr)) return bail("hipMalloc failed", m);
   GI("k_subtree"); if (!upload<int>(m, iv, &m->aux.subtree)) return bail("hipMalloc failed", m);
   { GI("k_dof_velmask"); std::vector<uint32_t> u(iv.size()); for (size_t i = 0; i < iv.size(); i++) u[i] = (uint32_t)iv[i]; if (!upload<uint32_t>(m, u, &m->aux.dof_velmask)) return bail("hipMalloc failed", m); }

@@ -22,43 +22,59 @@
 #include <hip/hip_runtime.h>
 #endif
 
-#define NVP (RG_MAXNV + 4)  // row stride of dense nv x nv matrices in LDS: 16-byte aligned rows, 44 words -> conflict-free ds_read_b128 across lanes
-#define RG_MAXSROW (RG_MAXROW + 64)  // static row slots: friction dofs/tendons + 2 per limited joint/tendon
 #define RG_MAXPYR (RG_MAXCON * 6)
-#define RG_NPROF 32
+#define RG_NPROF 24
+#define RG_HWORDS 1088  // work matrix: max(inertia blocks, nvc x hs)
 
+// Per-env LDS image (~23 kB: LDS capacity is what bounds the number of envs in flight per CU).
+// Arrays whose lifetimes inside a substep do not overlap share storage:
+//   pos:  position/velocity/collision scratch, itself overlaid by phase
+//           slot A: kinematics frames (T1-T3) | composite inertias (T4) | velocity-stage vectors (T6-T8)
+//           slot B: geom frames (until the narrowphase), slot C: cinert, slot D: candidates + raw contacts
+//   slv:  solver scratch — H holds, in turn, chol(M) (block layout), the Newton Hessian (compact nvc x hs)
+//         and chol(M + hB); all needed only after `pos` died.
 struct RgLds {
   // state
   alignas(16) float qpos[RG_MAXNQ], qvel[RG_MAXNV], ctrl[RG_MAXU], pid[3 * RG_MAXU], warm[RG_MAXNV];
-  // position stage
-  float xpos[RG_MAXBODY * 3], xquat[RG_MAXBODY * 4], xmat[RG_MAXBODY * 9], xipos[RG_MAXBODY * 3], org[RG_MAXBODY * 3];
-  float xanchor[RG_MAXJNT * 3], xaxis[RG_MAXJNT * 3];
-  float gpos[RG_MAXGEOM * 3], gmat[RG_MAXGEOM * 9], spos[RG_MAXSITE * 3];
-  float cinert[RG_MAXBODY * 10], crb[RG_MAXBODY * 10], cdof[RG_MAXNV * 6], cdofdot[RG_MAXNV * 6];
-  float cacc[RG_MAXBODY * 6], cfrc[RG_MAXBODY * 6];
-  alignas(16) float M[RG_MAXNV * NVP];
-  alignas(16) float H[RG_MAXNV * NVP];  // H: work matrix (factor of M, Newton Hessian, factor of M + h B)
-  float tenlen[RG_MAXTEN], tenvel[RG_MAXTEN], tenJ[RG_MAXTEN * 4], tenfrc[RG_MAXTEN];
+  // persistent through the substep
+  float org[4 * 3];   // com-frame origin per kinematic tree (slot via b2org)
+  alignas(16) float M[RG_MAXBLK];  // joint-space inertia as dense per-tree blocks
+  float tenlen[RG_MAXTEN], tenJ[RG_MAXTEN * 4];
   float actlen[RG_MAXU], actfrc[RG_MAXU];
-  alignas(16) float qfrc_passive[RG_MAXNV], qfrc_bias[RG_MAXNV], qfrc_act[RG_MAXNV], qfrc_smooth[RG_MAXNV], qacc_smooth[RG_MAXNV];
-  alignas(16) float qfrc_con[RG_MAXNV], qacc[RG_MAXNV];
-  // solver work vectors
-  alignas(16) float Ma[RG_MAXNV], grad[RG_MAXNV], search[RG_MAXNV], Mv[RG_MAXNV], tmpv[RG_MAXNV];
-  // static row slots (friction loss, limits)
-  float r_D[RG_MAXSROW], r_R[RG_MAXSROW], r_aref[RG_MAXSROW], r_floss[RG_MAXSROW], r_jar[RG_MAXSROW], r_jv[RG_MAXSROW], r_force[RG_MAXSROW];
-  int r_active[RG_MAXSROW], r_quad[RG_MAXSROW];
-  // contacts
+  float qfrc_smooth[RG_MAXNV], qacc_smooth[RG_MAXNV];
+  float r_D[RG_MAXSROW], r_aref[RG_MAXSROW], r_floss[RG_MAXFRIC];
+  unsigned short r_desc[RG_MAXSROW];   // compact dof (6 bits) | tendon id (5 bits, 31 = none) << 6 | negative sign << 11
+  unsigned char ten_cdof[RG_MAXTEN * 4], c2d[RG_MAXNVC], b2org[RG_MAXBODY];
   int ncand, ncand2, ncon;
-  int cand[RG_MAXCAND], cand2[RG_MAXCAND];
-  float c_dist[RG_MAXCON], c_pos[RG_MAXCON * 3], c_frame[RG_MAXCON * 9], c_D[RG_MAXCON], c_mu[RG_MAXCON * 4];
-  int c_pair[RG_MAXCON], c_dim[RG_MAXCON], c_nnz[RG_MAXCON];
+  float c_D[RG_MAXCON], c_mu[RG_MAXCON * 3];
+  short c_pair[RG_MAXCON], c_off[RG_MAXCON];
+  unsigned char c_dim[RG_MAXCON], c_nnz[RG_MAXCON];
   unsigned char c_idx[RG_MAXCON * RG_W];
-  float c_B[RG_MAXCON * 4 * RG_W];  // basis Jacobian rows (normal, tangent1, tangent2, spin) on the merged dof slots
-  float c_bdot[RG_MAXCON * 4], c_bfrc[RG_MAXCON * 4];
-  float p_aref[RG_MAXPYR], p_jar[RG_MAXPYR], p_jv[RG_MAXPYR], p_force[RG_MAXPYR];
-  int p_quad[RG_MAXPYR];
+  float c_pool[RG_CPOOL];  // basis Jacobian rows (normal, tangent1, tangent2, spin) x nnz, packed per contact
+  float p_aref[RG_MAXPYR];
   unsigned int status;
   float prof[RG_NPROF];
+  union {
+    struct {  // ---- pos
+      union {  // slot A
+        struct { float xpos[RG_MAXBODY * 3], xquat[RG_MAXBODY * 4], xmat[RG_MAXBODY * 9], xipos[RG_MAXBODY * 3], xanchor[RG_MAXJNT * 3], xaxis[RG_MAXJNT * 3], spos[RG_MAXSITE * 3]; };
+        struct { float crb[RG_MAXBODY * 10]; };
+        struct { float cdofdot[RG_MAXNV * 6], cacc[RG_MAXBODY * 6], cfrc[RG_MAXBODY * 6], tenfrc[RG_MAXTEN], tenvel[RG_MAXTEN], qfrc_passive[RG_MAXNV], qfrc_bias[RG_MAXNV], qfrc_act[RG_MAXNV]; };
+      };
+      float gpos[RG_MAXGEOM * 3], gmat[RG_MAXGEOM * 9];  // slot B
+      float cinert[RG_MAXBODY * 10], cdof[RG_MAXNV * 6];  // slot C (alive from com_pos to the constraint rows)
+      short cand[RG_MAXCAND], cand2[RG_MAXCAND];          // slot D
+      float c_dist[RG_MAXCON], c_pos[RG_MAXCON * 3], c_normal[RG_MAXCON * 3];
+    };
+    struct {  // ---- slv
+      alignas(16) float H[RG_HWORDS];
+      float a[RG_MAXNVC], as[RG_MAXNVC], fs[RG_MAXNVC], jtf[RG_MAXNVC], Ma[RG_MAXNVC], grad[RG_MAXNVC], search[RG_MAXNVC], Mv[RG_MAXNVC], tmpv[RG_MAXNV], qfrc_con[RG_MAXNV], qacc[RG_MAXNV];
+      float r_jar[RG_MAXSROW], r_jv[RG_MAXSROW], r_force[RG_MAXSROW];
+      unsigned char r_quad[RG_MAXSROW], p_quad[RG_MAXPYR];
+      float c_bdot[RG_MAXCON * 4], c_bfrc[RG_MAXCON * 4];
+      float p_jar[RG_MAXPYR], p_jv[RG_MAXPYR], p_force[RG_MAXPYR];
+    };
+  };
 };
 
 // ------------------------------------------------------------------------------------------------- small math
@@ -238,7 +254,7 @@ __device__ __forceinline__ void rg_kinematics(const RgModelDev& m, RgLds& s) {
   }
   PFOR(b, m.nbody) {
     int r = m.body_rootid[b], ob = m.root_origin_body[r];
-    st3(s.org + 3 * b, ob >= 0 ? ld3(s.xipos + 3 * ob) : ld3(m.root_origin_const + 3 * r));
+    st3(s.org + 3 * s.b2org[b], ob >= 0 ? ld3(s.xipos + 3 * ob) : ld3(m.root_origin_const + 3 * r));
   }
   SYNC();
 }
@@ -251,7 +267,7 @@ __device__ __forceinline__ void rg_com_pos(const RgModelDev& m, RgLds& s) {
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[3 * i + j] = X[3 * i] * qm[j] + X[3 * i + 1] * qm[3 + j] + X[3 * i + 2] * qm[6 + j];
     const float* in = m.body_inertia + 3 * b;
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) I[3 * i + j] = R[3 * i] * in[0] * R[3 * j] + R[3 * i + 1] * in[1] * R[3 * j + 1] + R[3 * i + 2] * in[2] * R[3 * j + 2];
-    v3 d = ld3(s.xipos + 3 * b) - ld3(s.org + 3 * b);
+    v3 d = ld3(s.xipos + 3 * b) - ld3(s.org + 3 * s.b2org[b]);
     float mass = m.body_mass[b], d2 = dot(d, d);
     float* ci = s.cinert + 10 * b;
     ci[0] = I[0] + mass * (d2 - d.x * d.x); ci[1] = I[4] + mass * (d2 - d.y * d.y); ci[2] = I[8] + mass * (d2 - d.z * d.z);
@@ -260,7 +276,7 @@ __device__ __forceinline__ void rg_com_pos(const RgModelDev& m, RgLds& s) {
   }
   PFOR(j, m.njnt) {
     int b = m.jnt_bodyid[j], da = m.jnt_dofadr[j], t = m.jnt_type[j];
-    v3 off = ld3(s.org + 3 * b) - ld3(s.xanchor + 3 * j);
+    v3 off = ld3(s.org + 3 * s.b2org[b]) - ld3(s.xanchor + 3 * j);
     const float* R = s.xmat + 9 * b;
     if (t == RG_JNT_FREE || t == RG_JNT_BALL) {
       if (t == RG_JNT_FREE) {
@@ -393,8 +409,8 @@ __device__ __forceinline__ void rg_tendon(const RgModelDev& m, RgLds& s) {
               int d = td[e];
               if (d < 0) continue;
               float v = 0;
-              if (in_chain(m, body[k + 1], d)) v += dot(dif, jac_col(s, d, pnt[k + 1] - ld3(s.org + 3 * body[k + 1])));
-              if (in_chain(m, body[k], d)) v -= dot(dif, jac_col(s, d, pnt[k] - ld3(s.org + 3 * body[k])));
+              if (in_chain(m, body[k + 1], d)) v += dot(dif, jac_col(s, d, pnt[k + 1] - ld3(s.org + 3 * s.b2org[body[k + 1]])));
+              if (in_chain(m, body[k], d)) v -= dot(dif, jac_col(s, d, pnt[k] - ld3(s.org + 3 * s.b2org[body[k]])));
               J[e] += v / divisor;
             }
           }
@@ -420,7 +436,7 @@ __device__ __forceinline__ void rg_crb(const RgModelDev& m, RgLds& s, const int*
     for (int e = subtree_adr[b]; e < subtree_adr[b + 1]; e++) acc += s.cinert[10 * subtree[e] + k];
     s.crb[w] = acc;
   }
-  for (int w = LANE; w < m.nv * NVP; w += RG_WAVE) s.M[w] = 0;
+  for (int w = LANE; w < m.blkwords; w += RG_WAVE) s.M[w] = 0;
   SYNC();
   PFOR(e, m.nM) {
     int i = m.M_i[e], j = m.M_j[e];
@@ -429,7 +445,8 @@ __device__ __forceinline__ void rg_crb(const RgModelDev& m, RgLds& s, const int*
     const float* c = s.cdof + 6 * j;
     float v = c[0] * buf[0] + c[1] * buf[1] + c[2] * buf[2] + c[3] * buf[3] + c[4] * buf[4] + c[5] * buf[5];
     if (i == j) v += m.dof_armature[i];
-    s.M[i * NVP + j] = v; s.M[j * NVP + i] = v;
+    int bi = m.dof_blk[i], bj = m.dof_blk[j], s0 = (bi >> 16) & 255;   // i and j belong to one tree
+    s.M[(bi & 0xFFFF) + (j - s0)] = v; s.M[(bj & 0xFFFF) + (i - s0)] = v;
   }
   SYNC();
 }
@@ -648,7 +665,7 @@ __device__ __forceinline__ void add_contact(RgLds& s, int pair, float dist, v3 p
   int c = s.ncon;
   if (c >= RG_MAXCON) { if (LANE == 0) s.status |= RG_STATUS_CON_FULL; return; }
   if (LANE == 0) {
-    s.c_dist[c] = dist; st3(s.c_pos + 3 * c, pos); st3(s.c_frame + 9 * c, normal); make_frame(s.c_frame + 9 * c);
+    s.c_dist[c] = dist; st3(s.c_pos + 3 * c, pos); st3(s.c_normal + 3 * c, normalized(normal));
     s.c_pair[c] = pair; s.c_dim[c] = dim; s.ncon = c + 1;
   }
   SYNC();
@@ -759,7 +776,7 @@ __device__ __forceinline__ void rg_collision(const RgModelDev& m, RgLds& s, floa
     if (lead) {
       int c = cbase + __popcll(bal & ((1ull << LANE) - 1ull));
       if (c < RG_MAXCON) {
-        s.c_dist[c] = margin - depth; st3(s.c_pos + 3 * c, pos); st3(s.c_frame + 9 * c, dir); make_frame(s.c_frame + 9 * c);
+        s.c_dist[c] = margin - depth; st3(s.c_pos + 3 * c, pos); st3(s.c_normal + 3 * c, normalized(dir));
         s.c_pair[c] = p; s.c_dim[c] = dim;
       } else s.status |= RG_STATUS_CON_FULL;
     }
@@ -916,47 +933,49 @@ __device__ __forceinline__ void kb(const RgModelDev& m, const float* solref, con
     K = 1.0f / fmaxf(1e-15f, dmax * dmax * tc * tc * dr * dr); B = 2.0f / fmaxf(1e-15f, dmax * tc);
   } else { K = -solref[0] / fmaxf(1e-15f, dmax * dmax); B = -solref[1] / fmaxf(1e-15f, dmax); }
 }
-// static row slot layout: [friction dofs][friction tendons][joint limits x2][tendon limits x2]
+// static row slot layout: [friction dofs][friction tendons][joint limits x2][tendon limits x2].
+// Each slot has a packed descriptor in LDS (built once per launch): bits 0-7 compact dof (single-dof rows),
+// bits 8-15 tendon id (255: none), bit 16: negative sign.  Tendon rows take their (<=4) compact dofs from
+// s.ten_cdof and their coefficients from s.tenJ.
 __device__ __forceinline__ int nsrow(const RgModelDev& m) { return m.nfric_dof + m.nfric_ten + 2 * m.nlim_jnt + 2 * m.nlim_ten; }
-// J_r . x for a static row
-__device__ __forceinline__ float srow_dot(const RgModelDev& m, const RgLds& s, int r, const float* x) {
-  if (r < m.nfric_dof) return x[m.fric_dof[r]];
-  r -= m.nfric_dof;
-  if (r < m.nfric_ten) { int t = m.fric_ten[r]; float v = 0; for (int e = 0; e < 4; e++) { int d = m.ten_dofs[4 * t + e]; if (d >= 0) v += s.tenJ[4 * t + e] * x[d]; } return v; }
-  r -= m.nfric_ten;
-  if (r < 2 * m.nlim_jnt) { int j = m.lim_jnt[r >> 1]; float sg = (r & 1) ? -1.f : 1.f; return sg * x[m.jnt_dofadr[j]]; }  // side -1 (lower): J=+1; side +1 (upper): J=-1
-  r -= 2 * m.nlim_jnt;
-  int t = m.lim_ten[r >> 1]; float sg = (r & 1) ? -1.f : 1.f, v = 0;
-  for (int e = 0; e < 4; e++) { int d = m.ten_dofs[4 * t + e]; if (d >= 0) v += s.tenJ[4 * t + e] * x[d]; }
-  return sg * v;
-}
-// dst[dofs] += coef * J_r  (LDS atomics: several rows may touch one dof)
-__device__ __forceinline__ void srow_scatter(const RgModelDev& m, RgLds& s, int r, float coef, float* dst) {
-  if (r < m.nfric_dof) { atomicAdd(dst + m.fric_dof[r], coef); return; }
-  r -= m.nfric_dof;
-  int t; float sg = 1.f;
-  if (r < m.nfric_ten) t = m.fric_ten[r];
-  else {
-    r -= m.nfric_ten;
-    if (r < 2 * m.nlim_jnt) { int j = m.lim_jnt[r >> 1]; atomicAdd(dst + m.jnt_dofadr[j], (r & 1) ? -coef : coef); return; }
-    r -= 2 * m.nlim_jnt; t = m.lim_ten[r >> 1]; sg = (r & 1) ? -1.f : 1.f;
+__device__ __forceinline__ void rg_build_row_desc(const RgModelDev& m, RgLds& s) {
+  int ns = nsrow(m);
+  PFOR(r, ns) {
+    int rr = r, dof = 0, ten = 31, neg = 0;
+    if (rr < m.nfric_dof) dof = m.d2c[m.fric_dof[rr]];
+    else if ((rr -= m.nfric_dof) < m.nfric_ten) ten = m.fric_ten[rr];
+    else if ((rr -= m.nfric_ten) < 2 * m.nlim_jnt) { dof = m.d2c[m.jnt_dofadr[m.lim_jnt[rr >> 1]]]; neg = rr & 1; }  // lower: J = +1, upper: J = -1
+    else { rr -= 2 * m.nlim_jnt; ten = m.lim_ten[rr >> 1]; neg = rr & 1; }
+    s.r_desc[r] = (unsigned short)((dof & 63) | (ten << 6) | (neg << 11));
   }
-  for (int e = 0; e < 4; e++) { int d = m.ten_dofs[4 * t + e]; if (d >= 0) atomicAdd(dst + d, sg * coef * s.tenJ[4 * t + e]); }
+  PFOR(w, m.ntendon * 4) { int d = m.ten_dofs[w]; s.ten_cdof[w] = (unsigned char)(d >= 0 ? m.d2c[d] : 255); }
+  PFOR(i, m.nvc) s.c2d[i] = (unsigned char)m.c2d[i];
+  PFOR(b, m.nbody) s.b2org[b] = (unsigned char)m.body_orgslot[b];
+  SYNC();
+}
+// J_r . x for a static row; x is indexed by compact dof unless `full` (then through c2d)
+template <bool FULL> __device__ __forceinline__ float srow_dot(const RgLds& s, int r, const float* x) {
+  int desc = s.r_desc[r], t = (desc >> 6) & 31; float v;
+  if (t == 31) { int d = desc & 63; v = x[FULL ? s.c2d[d] : d]; }
+  else { v = 0; for (int e = 0; e < 4; e++) { int d = s.ten_cdof[4 * t + e]; if (d != 255) v += s.tenJ[4 * t + e] * x[FULL ? s.c2d[d] : d]; } }
+  return (desc >> 11) & 1 ? -v : v;
+}
+// dst[compact dofs] += coef * J_r  (LDS atomics: several rows may touch one dof)
+__device__ __forceinline__ void srow_scatter(RgLds& s, int r, float coef, float* dst) {
+  int desc = s.r_desc[r], t = (desc >> 6) & 31;
+  if ((desc >> 11) & 1) coef = -coef;
+  if (t == 31) { atomicAdd(dst + (desc & 63), coef); return; }
+  for (int e = 0; e < 4; e++) { int d = s.ten_cdof[4 * t + e]; if (d != 255) atomicAdd(dst + d, coef * s.tenJ[4 * t + e]); }
 }
 // H += D * J_r^T J_r
 __device__ __forceinline__ void srow_hess(const RgModelDev& m, RgLds& s, int r, float D) {
-  if (r < m.nfric_dof) { int d = m.fric_dof[r]; atomicAdd(s.H + d * NVP + d, D); return; }
-  r -= m.nfric_dof;
-  int t;
-  if (r < m.nfric_ten) t = m.fric_ten[r];
-  else {
-    r -= m.nfric_ten;
-    if (r < 2 * m.nlim_jnt) { int d = m.jnt_dofadr[m.lim_jnt[r >> 1]]; atomicAdd(s.H + d * NVP + d, D); return; }
-    r -= 2 * m.nlim_jnt; t = m.lim_ten[r >> 1];
-  }
-  for (int a = 0; a < 4; a++) { int da = m.ten_dofs[4 * t + a]; if (da < 0) continue;
-    for (int b = 0; b < 4; b++) { int db = m.ten_dofs[4 * t + b]; if (db < 0) continue; atomicAdd(s.H + da * NVP + db, D * s.tenJ[4 * t + a] * s.tenJ[4 * t + b]); } }
+  int desc = s.r_desc[r], t = (desc >> 6) & 31;
+  if (t == 31) { int d = desc & 63; atomicAdd(s.H + d * m.hs + d, D); return; }
+  for (int a = 0; a < 4; a++) { int da = s.ten_cdof[4 * t + a]; if (da == 255) continue;
+    for (int b = 0; b < 4; b++) { int db = s.ten_cdof[4 * t + b]; if (db == 255) continue; atomicAdd(s.H + da * m.hs + db, D * s.tenJ[4 * t + a] * s.tenJ[4 * t + b]); } }
 }
+__device__ __forceinline__ int npyr(int dim) { return dim == 1 ? 1 : 2 * (dim - 1); }
+__device__ __forceinline__ int nbasis(int dim) { return dim >= 4 ? 4 : (dim == 1 ? 1 : 3); }
 
 __device__ __forceinline__ void rg_make_constraint(const RgModelDev& m, RgLds& s) {
   int ns = nsrow(m);
@@ -973,42 +992,53 @@ __device__ __forceinline__ void rg_make_constraint(const RgModelDev& m, RgLds& s
       pos = (rr & 1) ? (m.tendon_range[2 * t + 1] - L) : (L - m.tendon_range[2 * t]);
       margin = m.tendon_margin[t]; active = pos < margin; diag = m.tendon_invweight0[t]; solref = m.tendon_solref_lim + 2 * t; solimp = m.tendon_solimp_lim + 5 * t;
     }
-    s.r_active[r] = active;
+    float D = 0, aref = 0;
     if (active) {
       float imp = impedance(solimp, pos, margin), K, B;
       float R = fmaxf(1e-15f, (1 - imp) * diag / imp);
       kb(m, solref, solimp, K, B);
       if (fric) K = 0;
-      float vel = srow_dot(m, s, r, s.qvel);
-      s.r_R[r] = R; s.r_D[r] = 1.0f / R; s.r_floss[r] = floss;
-      s.r_aref[r] = -B * vel - K * imp * (pos - margin);
+      float vel = srow_dot<true>(s, r, s.qvel);
+      D = 1.0f / R; aref = -B * vel - K * imp * (pos - margin);
     }
+    s.r_D[r] = D; s.r_aref[r] = aref;   // D == 0 marks an inactive slot
+    if (r < RG_MAXFRIC) s.r_floss[r] = fric ? floss : 0.f;
   }
-  // contact basis Jacobians on merged dof chains
+  // contact basis Jacobians on the merged dof chains, packed into a shared pool (rows x nnz per contact)
   int ncon = s.ncon;
+  PFOR(c, ncon) {
+    int p = s.c_pair[c];
+    int b1 = m.geom_bodyid[m.pair_geom[3 * p]], b2 = m.geom_bodyid[m.pair_geom[3 * p + 1]];
+    int nnz = __popc(m.body_dofmask[2 * b1] | m.body_dofmask[2 * b2]) + __popc(m.body_dofmask[2 * b1 + 1] | m.body_dofmask[2 * b2 + 1]);
+    s.c_nnz[c] = nnz;
+  }
+  SYNC();
+  {
+    int c = LANE, off = 0, sz = 0;
+    if (c < ncon) { for (int q = 0; q < c; q++) off += nbasis(s.c_dim[q]) * s.c_nnz[q]; sz = nbasis(s.c_dim[c]) * s.c_nnz[c]; s.c_off[c] = off; }
+    int firstbad = wave_min_i((c < ncon && off + sz > RG_CPOOL) ? c : 0x7fffffff);
+    if (firstbad < ncon) { ncon = firstbad; if (LANE == 0) { s.ncon = ncon; s.status |= RG_STATUS_CON_FULL; } }
+  }
+  SYNC();
   for (int w = LANE; w < ncon * RG_W; w += RG_WAVE) {
-    int c = w / RG_W, sl = w - c * RG_W, p = s.c_pair[c];
+    int c = w / RG_W, sl = w - c * RG_W, p = s.c_pair[c], nnz = s.c_nnz[c];
+    if (sl >= nnz) continue;
     int b1 = m.geom_bodyid[m.pair_geom[3 * p]], b2 = m.geom_bodyid[m.pair_geom[3 * p + 1]];
     uint32_t lo = m.body_dofmask[2 * b1] | m.body_dofmask[2 * b2], hi = m.body_dofmask[2 * b1 + 1] | m.body_dofmask[2 * b2 + 1];
-    int nnz = __popc(lo) + __popc(hi);
-    if (sl == 0) s.c_nnz[c] = nnz;
-    float vn = 0, v1 = 0, v2 = 0, vs = 0; int d = 0;
-    if (sl < nnz) {
-      // sl-th set bit of (hi:lo)
-      int k = sl; uint32_t bits = lo; int base = 0;
-      if (k >= __popc(lo)) { k -= __popc(lo); bits = hi; base = 32; }
-      for (int q = 0; q < k; q++) bits &= bits - 1;
-      d = base + __builtin_ctz(bits);
-      v3 pos = ld3(s.c_pos + 3 * c);
-      v3 jp = mk3(0, 0, 0), jr = mk3(0, 0, 0);
-      if (in_chain(m, b2, d)) { jp = jp + jac_col(s, d, pos - ld3(s.org + 3 * b2)); jr = jr + ld3(s.cdof + 6 * d); }
-      if (in_chain(m, b1, d)) { jp = jp - jac_col(s, d, pos - ld3(s.org + 3 * b1)); jr = jr - ld3(s.cdof + 6 * d); }
-      const float* f = s.c_frame + 9 * c;
-      vn = dot(ld3(f), jp); v1 = dot(ld3(f + 3), jp); v2 = dot(ld3(f + 6), jp); vs = dot(ld3(f), jr);
-    }
-    s.c_idx[c * RG_W + sl] = (unsigned char)d;
-    float* Bc = s.c_B + c * 4 * RG_W;
-    Bc[sl] = vn; Bc[RG_W + sl] = v1; Bc[2 * RG_W + sl] = v2; Bc[3 * RG_W + sl] = vs;
+    int k = sl; uint32_t bits = lo; int base = 0;   // sl-th set bit of (hi:lo)
+    if (k >= __popc(lo)) { k -= __popc(lo); bits = hi; base = 32; }
+    for (int q = 0; q < k; q++) bits &= bits - 1;
+    int d = base + __builtin_ctz(bits);
+    v3 pos = ld3(s.c_pos + 3 * c);
+    v3 jp = mk3(0, 0, 0), jr = mk3(0, 0, 0);
+    if (in_chain(m, b2, d)) { jp = jp + jac_col(s, d, pos - ld3(s.org + 3 * s.b2org[b2])); jr = jr + ld3(s.cdof + 6 * d); }
+    if (in_chain(m, b1, d)) { jp = jp - jac_col(s, d, pos - ld3(s.org + 3 * s.b2org[b1])); jr = jr - ld3(s.cdof + 6 * d); }
+    float f[9]; st3(f, ld3(s.c_normal + 3 * c)); make_frame(f);   // contact frame: normal, two tangents (mju_makeFrame)
+    s.c_idx[c * RG_W + sl] = (unsigned char)m.d2c[d];
+    float* Bc = s.c_pool + s.c_off[c]; int nb = nbasis(s.c_dim[c]);
+    Bc[sl] = dot(ld3(f), jp);
+    if (nb >= 3) { Bc[nnz + sl] = dot(ld3(f + 3), jp); Bc[2 * nnz + sl] = dot(ld3(f + 6), jp); }
+    if (nb >= 4) Bc[3 * nnz + sl] = dot(ld3(f), jr);
   }
   SYNC();
   // contact parameters: D (shared by the pyramid), friction coefficients, reference accelerations
@@ -1027,25 +1057,24 @@ __device__ __forceinline__ void rg_make_constraint(const RgModelDev& m, RgLds& s
     else { float Rf = fmaxf(1e-15f, (1 - imp) * (tran + mu0 * mu0 * tran) / imp); float mu = mu0 * sqrtf(1.0f / m.impratio); R = 2 * mu * mu * Rf; }
     s.c_D[c] = 1.0f / R;
     // friction coefficient of tangent direction k (k = 0,1 sliding; 2 spin)
-    s.c_mu[4 * c] = prm[2]; s.c_mu[4 * c + 1] = prm[2]; s.c_mu[4 * c + 2] = prm[3]; s.c_mu[4 * c + 3] = 0;
-    const float* Bc = s.c_B + c * 4 * RG_W; int nnz = s.c_nnz[c];
+    s.c_mu[3 * c] = prm[2]; s.c_mu[3 * c + 1] = prm[2]; s.c_mu[3 * c + 2] = prm[3];
+    const float* Bc = s.c_pool + s.c_off[c]; int nnz = s.c_nnz[c], nb = nbasis(dim);
     float vb[4] = {0, 0, 0, 0};
-    for (int sl = 0; sl < nnz; sl++) { float q = s.qvel[s.c_idx[c * RG_W + sl]]; for (int k = 0; k < 4; k++) vb[k] += Bc[k * RG_W + sl] * q; }
+    for (int sl = 0; sl < nnz; sl++) { float q = s.qvel[s.c2d[s.c_idx[c * RG_W + sl]]]; for (int k = 0; k < nb; k++) vb[k] += Bc[k * nnz + sl] * q; }
     float base = -K * imp * (dist - includemargin);
     if (dim == 1) s.p_aref[6 * c] = base - B * vb[0];
-    else for (int k = 0; k < dim - 1; k++) { float mu = s.c_mu[4 * c + k]; s.p_aref[6 * c + 2 * k] = base - B * (vb[0] + mu * vb[k + 1]); s.p_aref[6 * c + 2 * k + 1] = base - B * (vb[0] - mu * vb[k + 1]); }
+    else for (int k = 0; k < dim - 1; k++) { float mu = s.c_mu[3 * c + k]; s.p_aref[6 * c + 2 * k] = base - B * (vb[0] + mu * vb[k + 1]); s.p_aref[6 * c + 2 * k + 1] = base - B * (vb[0] - mu * vb[k + 1]); }
   }
   SYNC();
 }
-__device__ __forceinline__ int npyr(int dim) { return dim == 1 ? 1 : 2 * (dim - 1); }
 
-// jar = J x - aref (or J x when `homog`) for every active row; result in r_jar/p_jar (or r_jv/p_jv)
+// jar = J x - aref (or jv = J x) for every active row; x lives in the compact dof space
 __device__ __forceinline__ void rg_J_mul(const RgModelDev& m, RgLds& s, const float* x, bool to_jv) {
   int ns = nsrow(m), ncon = s.ncon;
-  PFOR(r, ns) if (s.r_active[r]) { float v = srow_dot(m, s, r, x); if (to_jv) s.r_jv[r] = v; else s.r_jar[r] = v - s.r_aref[r]; }
+  PFOR(r, ns) if (s.r_D[r] > 0) { float v = srow_dot<false>(s, r, x); if (to_jv) s.r_jv[r] = v; else s.r_jar[r] = v - s.r_aref[r]; }
   for (int w = LANE; w < ncon * 4; w += RG_WAVE) {
-    int c = w >> 2, k = w & 3; const float* Bc = s.c_B + c * 4 * RG_W + k * RG_W; int nnz = s.c_nnz[c]; float v = 0;
-    for (int sl = 0; sl < nnz; sl++) v += Bc[sl] * x[s.c_idx[c * RG_W + sl]];
+    int c = w >> 2, k = w & 3, nnz = s.c_nnz[c]; float v = 0;
+    if (k < nbasis(s.c_dim[c])) { const float* Bc = s.c_pool + s.c_off[c] + k * nnz; for (int sl = 0; sl < nnz; sl++) v += Bc[sl] * x[s.c_idx[c * RG_W + sl]]; }
     s.c_bdot[w] = v;
   }
   SYNC();
@@ -1054,7 +1083,7 @@ __device__ __forceinline__ void rg_J_mul(const RgModelDev& m, RgLds& s, const fl
     if (q >= npyr(dim)) continue;
     float v;
     if (dim == 1) v = s.c_bdot[4 * c];
-    else { int k = q >> 1; float mu = s.c_mu[4 * c + k]; v = s.c_bdot[4 * c] + ((q & 1) ? -mu : mu) * s.c_bdot[4 * c + k + 1]; }
+    else { int k = q >> 1; float mu = s.c_mu[3 * c + k]; v = s.c_bdot[4 * c] + ((q & 1) ? -mu : mu) * s.c_bdot[4 * c + k + 1]; }
     if (to_jv) s.p_jv[w] = v; else s.p_jar[w] = v - s.p_aref[w];
   }
   SYNC();
@@ -1063,9 +1092,11 @@ __device__ __forceinline__ void rg_J_mul(const RgModelDev& m, RgLds& s, const fl
 __device__ __forceinline__ float rg_constraint_update(const RgModelDev& m, RgLds& s) {
   int ns = nsrow(m), ncon = s.ncon; float cost = 0;
   PFOR(r, ns) {
-    if (!s.r_active[r]) { s.r_quad[r] = 0; s.r_force[r] = 0; continue; }
-    float x = s.r_jar[r], D = s.r_D[r], R = s.r_R[r], f = s.r_floss[r];
+    float D = s.r_D[r];
+    if (!(D > 0)) { s.r_quad[r] = 0; s.r_force[r] = 0; continue; }
+    float x = s.r_jar[r], f = r < RG_MAXFRIC ? s.r_floss[r] : 0.f;
     if (f > 0) {
+      float R = 1.0f / D;
       if (x <= -R * f) { s.r_force[r] = f; s.r_quad[r] = 0; cost += f * (-0.5f * R * f - x); }
       else if (x >= R * f) { s.r_force[r] = -f; s.r_quad[r] = 0; cost += f * (-0.5f * R * f + x); }
       else { s.r_force[r] = -D * x; s.r_quad[r] = 1; cost += 0.5f * D * x * x; }
@@ -1081,50 +1112,52 @@ __device__ __forceinline__ float rg_constraint_update(const RgModelDev& m, RgLds
   SYNC();
   return wave_sum(cost);
 }
-// dst = J^T force (dst zeroed here)
+// dst = J^T force in the compact dof space (dst zeroed here)
 __device__ __forceinline__ void rg_JT_force(const RgModelDev& m, RgLds& s, float* dst) {
   int ns = nsrow(m), ncon = s.ncon;
-  PFOR(d, m.nv) dst[d] = 0;
+  PFOR(d, m.nvc) dst[d] = 0;
   for (int w = LANE; w < ncon * 4; w += RG_WAVE) {
     int c = w >> 2, k = w & 3, dim = s.c_dim[c]; float v = 0; const float* pf = s.p_force + 6 * c;
     if (dim == 1) v = k == 0 ? pf[0] : 0.f;
     else if (k == 0) { for (int q = 0; q < npyr(dim); q++) v += pf[q]; }
-    else if (k < dim) v = s.c_mu[4 * c + k - 1] * (pf[2 * (k - 1)] - pf[2 * (k - 1) + 1]);
+    else if (k < dim) v = s.c_mu[3 * c + k - 1] * (pf[2 * (k - 1)] - pf[2 * (k - 1) + 1]);
     s.c_bfrc[w] = v;
   }
   SYNC();
-  PFOR(r, ns) if (s.r_active[r] && s.r_force[r] != 0) srow_scatter(m, s, r, s.r_force[r], dst);
+  PFOR(r, ns) if (s.r_D[r] > 0 && s.r_force[r] != 0) srow_scatter(s, r, s.r_force[r], dst);
   for (int w = LANE; w < ncon * RG_W; w += RG_WAVE) {
-    int c = w / RG_W, sl = w - c * RG_W;
-    if (sl >= s.c_nnz[c]) continue;
-    const float* Bc = s.c_B + c * 4 * RG_W; const float* bf = s.c_bfrc + 4 * c;
-    float v = Bc[sl] * bf[0] + Bc[RG_W + sl] * bf[1] + Bc[2 * RG_W + sl] * bf[2] + Bc[3 * RG_W + sl] * bf[3];
+    int c = w / RG_W, sl = w - c * RG_W, nnz = s.c_nnz[c];
+    if (sl >= nnz) continue;
+    const float* Bc = s.c_pool + s.c_off[c]; const float* bf = s.c_bfrc + 4 * c; int nb = nbasis(s.c_dim[c]);
+    float v = Bc[sl] * bf[0];
+    if (nb >= 3) v += Bc[nnz + sl] * bf[1] + Bc[2 * nnz + sl] * bf[2];
+    if (nb >= 4) v += Bc[3 * nnz + sl] * bf[3];
     atomicAdd(dst + s.c_idx[c * RG_W + sl], v);
   }
   SYNC();
 }
-// y = M x (dense rows; x, y in LDS)
+// y = M x in the compact dof space: row i of the tree block of dof c2d[i] against that tree's slice of x
 __device__ __forceinline__ void rg_M_mul(const RgModelDev& m, RgLds& s, const float* x, float* y) {
-  PFOR(i, m.nv) {
-    float v = 0; const rgf4* row = (const rgf4*)(s.M + i * NVP); const rgf4* x4 = (const rgf4*)x;
-    int nc = (m.nv + 3) >> 2;  // rows and vectors are zero-padded to a multiple of 4
-#pragma unroll 3
-    for (int c = 0; c < nc; c++) { rgf4 a = row[c], b = x4[c]; v += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+  PFOR(i, m.nvc) {
+    int blk = m.c_blk[i], n = (blk >> 24) & 255; const float* row = s.M + (blk & 0xFFFF); const float* xs = x + ((blk >> 16) & 255);
+    float v = 0;
+#pragma unroll 4
+    for (int k = 0; k < n; k++) v += row[k] * xs[k];
     y[i] = v;
   }
   SYNC();
 }
-// Dense Cholesky of the n x n matrix in s.H (lower triangle, in place), left-looking with lane i owning
-// row i: column j costs j multiply-adds per lane on independent LDS reads (row j is a broadcast read,
-// own-row reads are conflict-free with the padded stride), one pivot broadcast by v_readlane, one barrier.
+// Dense Cholesky of the n x n matrix in s.H (row stride hs, lower triangle, in place), left-looking with
+// lane i owning row i: column j costs j multiply-adds per lane on independent LDS reads (row j is a
+// broadcast read, own-row reads are conflict-free with the padded stride), pivot by v_readlane, one barrier.
 __device__ __forceinline__ void rg_chol(const RgModelDev& m, RgLds& s) {
-  int n = m.nv, i = LANE;
+  int n = m.nvc, hs = m.hs, i = LANE;
   float* H = s.H;
   for (int j = 0; j < n; j++) {
     float acc = 0.f;
     if (i >= j && i < n) {
-      acc = H[i * NVP + j];
-      const rgf4 *ri = (const rgf4*)(H + i * NVP), *rj = (const rgf4*)(H + j * NVP);
+      acc = H[i * hs + j];
+      const rgf4 *ri = (const rgf4*)(H + i * hs), *rj = (const rgf4*)(H + j * hs);
       int nc = (j + 3) >> 2;
 #pragma unroll 3
       for (int c = 0; c < nc; c++) {
@@ -1136,43 +1169,87 @@ __device__ __forceinline__ void rg_chol(const RgModelDev& m, RgLds& s) {
     float d = lane_bcast(acc, j);
     if (!(d > 1e-30f)) { if (i == 0) s.status |= RG_STATUS_BAD_FACTOR; d = 1e-30f; }
     float r = 1.0f / sqrtf(d);
-    if (i >= j && i < n) H[i * NVP + j] = (i == j) ? d * r : acc * r;
+    if (i >= j && i < n) H[i * hs + j] = (i == j) ? d * r : acc * r;
     SYNC();
   }
 }
 // x <- H^-1 x with the factor above; lane i owns x[i]; the pivot reciprocal lives in the owning lane
 __device__ __forceinline__ void rg_chol_solve(const RgModelDev& m, RgLds& s, float* x) {
-  int n = m.nv, i = LANE;
+  int n = m.nvc, hs = m.hs, i = LANE;
   const float* H = s.H;
   float xi = i < n ? x[i] : 0.f;
-  float inv = i < n ? 1.0f / H[i * NVP + i] : 0.f;
+  float inv = i < n ? 1.0f / H[i * hs + i] : 0.f;
   for (int j = 0; j < n; j++) {
     float xj = lane_bcast(xi * inv, j);
     if (i == j) xi = xj;
-    else if (i > j && i < n) xi -= H[i * NVP + j] * xj;
+    else if (i > j && i < n) xi -= H[i * hs + j] * xj;
   }
   for (int j = n - 1; j >= 0; j--) {
     float xj = lane_bcast(xi * inv, j);
     if (i == j) xi = xj;
-    else if (i < j) xi -= H[j * NVP + i] * xj;
+    else if (i < j) xi -= H[j * hs + i] * xj;
   }
   if (i < n) x[i] = xi;
   SYNC();
 }
-// s.H <- M + scale * diag(extra)
-__device__ __forceinline__ void rg_load_H(const RgModelDev& m, RgLds& s, const float* extra_diag, float scale) {
-  for (int w = LANE; w < m.nv * NVP; w += RG_WAVE) s.H[w] = s.M[w];
+// Block-diagonal factorisation over ALL dofs: s.H (same block layout as s.M) <- chol(M + scale*diag(extra)),
+// every kinematic tree's block factored concurrently (lane d owns row d of its tree), then x <- solve.
+// Used for qacc_smooth = M^-1 qfrc_smooth and for the implicit-damping Euler solve.
+__device__ __forceinline__ void rg_block_factor_solve(const RgModelDev& m, RgLds& s, const float* extra_diag, float scale, float* x) {
+  for (int w = LANE; w < m.blkwords; w += RG_WAVE) s.H[w] = s.M[w];
   SYNC();
-  if (extra_diag) { PFOR(d, m.nv) s.H[d * NVP + d] += scale * extra_diag[d]; SYNC(); }
+  int d = LANE; bool on = d < m.nv;
+  int blk = on ? m.dof_blk[d] : 0, s0 = (blk >> 16) & 255, n = on ? (blk >> 24) & 255 : 0, jj_me = d - s0;
+  float* row = s.H + (blk & 0xFFFF);
+  int blk2 = on ? m.dof_blk2[d] : 0, stride = blk2 & 255;
+  if (on && extra_diag) row[jj_me] += scale * extra_diag[d];
+  SYNC();
+  float* blk0 = s.H + (blk2 >> 8);
+  for (int jj = 0; jj < m.maxtree; jj++) {
+    float acc = 0.f;
+    bool act = on && jj < n && jj_me >= jj;
+    if (act) {
+      acc = row[jj];
+      const rgf4 *ri = (const rgf4*)row, *rj = (const rgf4*)(blk0 + jj * stride);
+      int nc = (jj + 3) >> 2;
+#pragma unroll 3
+      for (int c = 0; c < nc; c++) {
+        rgf4 a = ri[c], b = rj[c];
+        int k = 4 * c;
+        acc -= a.x * (k < jj ? b.x : 0.f) + a.y * (k + 1 < jj ? b.y : 0.f) + a.z * (k + 2 < jj ? b.z : 0.f) + a.w * (k + 3 < jj ? b.w : 0.f);
+      }
+    }
+    float dv = __shfl(acc, (on && jj < n) ? s0 + jj : 0);   // pivot of this lane's own tree
+    if (act) {
+      if (!(dv > 1e-30f)) { s.status |= RG_STATUS_BAD_FACTOR; dv = 1e-30f; }
+      float r = 1.0f / sqrtf(dv);
+      row[jj] = (jj_me == jj) ? dv * r : acc * r;
+    }
+    SYNC();
+  }
+  float xi = on ? x[d] : 0.f;
+  float inv = on ? 1.0f / row[jj_me] : 0.f;
+  for (int jj = 0; jj < m.maxtree; jj++) {
+    float xj = __shfl(xi * inv, (on && jj < n) ? s0 + jj : 0);
+    if (on && jj < n) { if (jj_me == jj) xi = xj; else if (jj_me > jj) xi -= row[jj] * xj; }
+  }
+  for (int jj = m.maxtree - 1; jj >= 0; jj--) {
+    float xj = __shfl(xi * inv, (on && jj < n) ? s0 + jj : 0);
+    if (on && jj < n) { if (jj_me == jj) xi = xj; else if (jj_me < jj) xi -= blk0[jj * stride + jj_me] * xj; }
+  }
+  if (on) x[d] = xi;
+  SYNC();
 }
 
 struct LsPt { float cost, grad, hess; };
 __device__ __forceinline__ LsPt rg_ls_eval(const RgModelDev& m, RgLds& s, float alpha, float q0, float q1, float q2) {
   int ns = nsrow(m), ncon = s.ncon; float c = 0, g = 0, h = 0;
   PFOR(r, ns) {
-    if (!s.r_active[r]) continue;
-    float jv = s.r_jv[r], x = s.r_jar[r] + alpha * jv, D = s.r_D[r], R = s.r_R[r], f = s.r_floss[r];
+    float D = s.r_D[r];
+    if (!(D > 0)) continue;
+    float jv = s.r_jv[r], x = s.r_jar[r] + alpha * jv, f = r < RG_MAXFRIC ? s.r_floss[r] : 0.f;
     if (f > 0) {
+      float R = 1.0f / D;
       if (x <= -R * f) { c += f * (-0.5f * R * f - x); g += -f * jv; }
       else if (x >= R * f) { c += f * (-0.5f * R * f + x); g += f * jv; }
       else { c += 0.5f * D * x * x; g += D * x * jv; h += D * jv * jv; }
@@ -1191,37 +1268,40 @@ __device__ __forceinline__ LsPt rg_ls_eval(const RgModelDev& m, RgLds& s, float 
   return p;
 }
 
-// Newton solver on the primal problem (see oracle ro_solve); result: s.qacc, s.qfrc_con.  Returns iterations.
+// Newton solver on the primal problem (see oracle ro_solve), in the compact space of constrained dofs
+// (trees no constraint row can touch keep qacc = qacc_smooth).  Result: s.qacc, s.qfrc_con (full space).
 __device__ __forceinline__ int rg_solve(const RgModelDev& m, RgLds& s, int& nefc_out, int flags) {
   long long t0 = rg_clock(), t1;
 #define PROFS(k) do { if (flags & 2) { t1 = rg_clock(); if (LANE == 0) s.prof[k] += (float)(t1 - t0); t0 = t1; } } while (0)
-  int nv = m.nv, ns = nsrow(m), ncon = s.ncon;
+  int nv = m.nv, nvc = m.nvc, hs = m.hs, ns = nsrow(m), ncon = s.ncon;
   // count active rows (diagnostic only)
-  { float cnt = 0; PFOR(r, ns) cnt += s.r_active[r] ? 1.f : 0.f; PFOR(c, ncon) cnt += (float)npyr(s.c_dim[c]); nefc_out = (int)(wave_sum(cnt) + 0.5f); }
+  { float cnt = 0; PFOR(r, ns) cnt += s.r_D[r] > 0 ? 1.f : 0.f; PFOR(c, ncon) cnt += (float)npyr(s.c_dim[c]); nefc_out = (int)(wave_sum(cnt) + 0.5f); }
   float scale = 1.0f / (m.meaninertia * (nv > 1 ? nv : 1));
   float tol = fmaxf(m.tolerance, 1e-7f);
+  PFOR(i, nvc) { int d = s.c2d[i]; s.as[i] = s.qacc_smooth[d]; s.fs[i] = s.qfrc_smooth[d]; s.a[i] = s.warm[d]; }
+  SYNC();
   // warm start: the better of qacc_warmstart and qacc_smooth
   float cost_pick[2];
   for (int pass = 0; pass < 2; pass++) {
-    const float* a = pass == 0 ? s.warm : s.qacc_smooth;
+    const float* a = pass == 0 ? s.a : s.as;
     rg_M_mul(m, s, a, s.Ma);
     rg_J_mul(m, s, a, false);
-    float g = 0; PFOR(i, nv) g += 0.5f * (s.Ma[i] - s.qfrc_smooth[i]) * (a[i] - s.qacc_smooth[i]);
+    float g = 0; PFOR(i, nvc) g += 0.5f * (s.Ma[i] - s.fs[i]) * (a[i] - s.as[i]);
     g = wave_sum(g);
     cost_pick[pass] = g + rg_constraint_update(m, s);
   }
-  { const float* a = cost_pick[0] < cost_pick[1] ? s.warm : s.qacc_smooth; PFOR(i, nv) s.qacc[i] = a[i]; }
+  if (!(cost_pick[0] < cost_pick[1])) { PFOR(i, nvc) s.a[i] = s.as[i]; }
   SYNC();
   float cost = 0, oldcost = 0; int iters = 0;
   for (int iter = 0;; iter++) {
-    rg_M_mul(m, s, s.qacc, s.Ma);
-    rg_J_mul(m, s, s.qacc, false);
-    float gauss = 0; PFOR(i, nv) gauss += 0.5f * (s.Ma[i] - s.qfrc_smooth[i]) * (s.qacc[i] - s.qacc_smooth[i]);
+    rg_M_mul(m, s, s.a, s.Ma);
+    rg_J_mul(m, s, s.a, false);
+    float gauss = 0; PFOR(i, nvc) gauss += 0.5f * (s.Ma[i] - s.fs[i]) * (s.a[i] - s.as[i]);
     gauss = wave_sum(gauss);
     float cc = rg_constraint_update(m, s);
     oldcost = cost; cost = gauss + cc;
-    rg_JT_force(m, s, s.qfrc_con);
-    float gn = 0; PFOR(i, nv) { float gi = s.Ma[i] - s.qfrc_smooth[i] - s.qfrc_con[i]; s.grad[i] = gi; gn += gi * gi; }
+    rg_JT_force(m, s, s.jtf);
+    float gn = 0; PFOR(i, nvc) { float gi = s.Ma[i] - s.fs[i] - s.jtf[i]; s.grad[i] = gi; gn += gi * gi; }
     gn = sqrtf(wave_sum(gn)) * scale;
     SYNC();
 #ifdef RG_EMUL_TRACE
@@ -1232,25 +1312,30 @@ __device__ __forceinline__ int rg_solve(const RgModelDev& m, RgLds& s, int& nefc
     iters = iter + 1;
     PROFS(12);
     // H = M + J' D J over the quadratic rows
-    for (int w = LANE; w < nv * NVP; w += RG_WAVE) s.H[w] = s.M[w];
+    for (int w = LANE; w < nvc * hs; w += RG_WAVE) s.H[w] = 0.f;
     SYNC();
-    PFOR(r, ns) if (s.r_active[r] && s.r_quad[r]) srow_hess(m, s, r, s.r_D[r]);
+    PFOR(i, nvc) {
+      int blk = m.c_blk[i], n = (blk >> 24) & 255; const float* row = s.M + (blk & 0xFFFF); float* hrow = s.H + i * hs + ((blk >> 16) & 255);
+      for (int k = 0; k < n; k++) hrow[k] = row[k];
+    }
+    SYNC();
+    PFOR(r, ns) if (s.r_D[r] > 0 && s.r_quad[r]) srow_hess(m, s, r, s.r_D[r]);
     for (int c = 0; c < ncon; c++) {
-      int dim = s.c_dim[c], nnz = s.c_nnz[c]; float D = s.c_D[c];
+      int dim = s.c_dim[c], nnz = s.c_nnz[c], nb = nbasis(dim); float D = s.c_D[c];
       // C = P' D_act P in the basis (normal, t1, t2, spin): only first row/col and the diagonal are non-zero
       float cn = 0, ck[3] = {0, 0, 0}, cd[3] = {0, 0, 0};
       if (dim == 1) cn = s.p_quad[6 * c] ? D : 0.f;
       else for (int k = 0; k < dim - 1; k++) {
-        float mu = s.c_mu[4 * c + k]; int qp = s.p_quad[6 * c + 2 * k], qm = s.p_quad[6 * c + 2 * k + 1];
+        float mu = s.c_mu[3 * c + k]; int qp = s.p_quad[6 * c + 2 * k], qm = s.p_quad[6 * c + 2 * k + 1];
         cn += D * (qp + qm); ck[k] = D * mu * (qp - qm); cd[k] = D * mu * mu * (qp + qm);
       }
       if (cn == 0) continue;
-      const float* Bc = s.c_B + c * 4 * RG_W;
+      const float* Bc = s.c_pool + s.c_off[c];
       for (int w = LANE; w < nnz * nnz; w += RG_WAVE) {
         int a = w / nnz, b = w - a * nnz;
-        float na = Bc[a], nb = Bc[b], v = cn * na * nb;
-        for (int k = 0; k < 3; k++) { float ta = Bc[(k + 1) * RG_W + a], tb = Bc[(k + 1) * RG_W + b]; v += ck[k] * (na * tb + ta * nb) + cd[k] * ta * tb; }
-        s.H[s.c_idx[c * RG_W + a] * NVP + s.c_idx[c * RG_W + b]] += v;
+        float na = Bc[a], nbv = Bc[b], v = cn * na * nbv;
+        for (int k = 0; k + 1 < nb; k++) { float ta = Bc[(k + 1) * nnz + a], tb = Bc[(k + 1) * nnz + b]; v += ck[k] * (na * tb + ta * nbv) + cd[k] * ta * tb; }
+        s.H[s.c_idx[c * RG_W + a] * hs + s.c_idx[c * RG_W + b]] += v;
       }
       SYNC();
     }
@@ -1258,7 +1343,7 @@ __device__ __forceinline__ int rg_solve(const RgModelDev& m, RgLds& s, int& nefc
     PROFS(13);
     rg_chol(m, s);
     PROFS(14);
-    PFOR(i, nv) s.search[i] = -s.grad[i];
+    PFOR(i, nvc) s.search[i] = -s.grad[i];
     SYNC();
     rg_chol_solve(m, s, s.search);
     PROFS(15);
@@ -1266,7 +1351,7 @@ __device__ __forceinline__ int rg_solve(const RgModelDev& m, RgLds& s, int& nefc
     rg_M_mul(m, s, s.search, s.Mv);
     rg_J_mul(m, s, s.search, true);
     float q1 = 0, q2 = 0, sn = 0;
-    PFOR(i, nv) { q1 += s.search[i] * (s.Ma[i] - s.qfrc_smooth[i]); q2 += 0.5f * s.search[i] * s.Mv[i]; sn += s.search[i] * s.search[i]; }
+    PFOR(i, nvc) { q1 += s.search[i] * (s.Ma[i] - s.fs[i]); q2 += 0.5f * s.search[i] * s.Mv[i]; sn += s.search[i] * s.search[i]; }
     q1 = wave_sum(q1); q2 = wave_sum(q2); sn = sqrtf(wave_sum(sn));
     if (sn < 1e-15f) break;
     float gtol = tol * 0.01f * sn / scale;
@@ -1289,25 +1374,25 @@ __device__ __forceinline__ int rg_solve(const RgModelDev& m, RgLds& s, int& nefc
     if (LANE == 0) printf("     alpha %.6e p0.grad %.3e p0.hess %.3e gtol %.3e\n", alpha, p0.grad, p0.hess, gtol);
 #endif
     if (alpha == 0) break;
-    PFOR(i, nv) s.qacc[i] += alpha * s.search[i];
+    PFOR(i, nvc) s.a[i] += alpha * s.search[i];
     SYNC();
     PROFS(10);
   }
-  // forces at the solution
-  rg_J_mul(m, s, s.qacc, false);
+  // forces at the solution; expand to the full dof space
+  rg_J_mul(m, s, s.a, false);
   rg_constraint_update(m, s);
-  rg_JT_force(m, s, s.qfrc_con);
+  rg_JT_force(m, s, s.jtf);
+  PFOR(d, nv) { int i = m.d2c[d]; s.qacc[d] = i >= 0 ? s.a[i] : s.qacc_smooth[d]; s.qfrc_con[d] = i >= 0 ? s.jtf[i] : 0.f; }
+  SYNC();
   return iters;
 }
 
 // ------------------------------------------------------------------------------------------------- integration
 __device__ __forceinline__ void rg_euler(const RgModelDev& m, RgLds& s) {
   float h = m.timestep;
-  rg_load_H(m, s, m.dof_damping, h);
-  rg_chol(m, s);
   PFOR(i, m.nv) s.tmpv[i] = s.qfrc_smooth[i] + s.qfrc_con[i];
   SYNC();
-  rg_chol_solve(m, s, s.tmpv);
+  rg_block_factor_solve(m, s, m.dof_damping, h, s.tmpv);
   PFOR(i, m.nv) { s.qvel[i] += h * s.tmpv[i]; s.warm[i] = s.qacc[i]; }
   SYNC();
   PFOR(j, m.njnt) {
@@ -1327,16 +1412,28 @@ struct RgAux {  // extra static tables (kept out of RgModelDev to keep the kerna
   const uint32_t* dof_velmask;
 };
 
-__device__ __forceinline__ void rg_dump(const RgModelDev& m, RgLds& s, float* dbg, int nefc, int iters) {
+// stage dump in three parts, each taken while the arrays it reads are alive
+__device__ __forceinline__ void rg_dump_kin(const RgModelDev& m, RgLds& s, float* dbg) {
   PFOR(i, m.nbody * 3) dbg[RG_DBG_XPOS + i] = s.xpos[i];
   PFOR(i, m.nbody * 4) dbg[RG_DBG_XQUAT + i] = s.xquat[i];
   PFOR(i, m.nsite * 3) dbg[RG_DBG_SITE + i] = s.spos[i];
-  for (int w = LANE; w < m.nv * m.nv; w += RG_WAVE) dbg[RG_DBG_M + w] = s.M[(w / m.nv) * NVP + (w % m.nv)];
   PFOR(i, m.ntendon) dbg[RG_DBG_TENLEN + i] = s.tenlen[i];
   PFOR(i, m.ntendon * 4) dbg[RG_DBG_TENJ + i] = s.tenJ[i];
-  PFOR(i, m.nv) { dbg[RG_DBG_BIAS + i] = s.qfrc_bias[i]; dbg[RG_DBG_PASSIVE + i] = s.qfrc_passive[i]; dbg[RG_DBG_ACTFRC + i] = s.qfrc_act[i]; dbg[RG_DBG_QACCS + i] = s.qacc_smooth[i]; dbg[RG_DBG_QACC + i] = s.qacc[i]; }
-  if (LANE == 0) { dbg[RG_DBG_NCON] = (float)s.ncon; dbg[RG_DBG_NCON + 1] = (float)nefc; dbg[RG_DBG_NCON + 2] = (float)iters; dbg[RG_DBG_NCON + 3] = (float)s.ncand; }
-  PFOR(c, s.ncon) { float* o = dbg + RG_DBG_CON + 8 * c; o[0] = s.c_dist[c]; o[1] = s.c_pos[3 * c]; o[2] = s.c_pos[3 * c + 1]; o[3] = s.c_pos[3 * c + 2]; o[4] = s.c_frame[9 * c]; o[5] = s.c_frame[9 * c + 1]; o[6] = s.c_frame[9 * c + 2]; o[7] = (float)s.c_pair[c]; }
+  SYNC();
+}
+__device__ __forceinline__ void rg_dump_pos(const RgModelDev& m, RgLds& s, float* dbg) {
+  for (int w = LANE; w < m.nv * m.nv; w += RG_WAVE) {
+    int i = w / m.nv, j = w - i * m.nv, bi = m.dof_blk[i], s0 = (bi >> 16) & 255, n = (bi >> 24) & 255;
+    dbg[RG_DBG_M + w] = (j >= s0 && j < s0 + n) ? s.M[(bi & 0xFFFF) + (j - s0)] : 0.f;
+  }
+  PFOR(i, m.nv) { dbg[RG_DBG_BIAS + i] = s.qfrc_bias[i]; dbg[RG_DBG_PASSIVE + i] = s.qfrc_passive[i]; dbg[RG_DBG_ACTFRC + i] = s.qfrc_act[i]; }
+  if (LANE == 0) { dbg[RG_DBG_NCON] = (float)s.ncon; dbg[RG_DBG_NCON + 3] = (float)s.ncand; }
+  PFOR(c, s.ncon) { float* o = dbg + RG_DBG_CON + 8 * c; o[0] = s.c_dist[c]; o[1] = s.c_pos[3 * c]; o[2] = s.c_pos[3 * c + 1]; o[3] = s.c_pos[3 * c + 2]; o[4] = s.c_normal[3 * c]; o[5] = s.c_normal[3 * c + 1]; o[6] = s.c_normal[3 * c + 2]; o[7] = (float)s.c_pair[c]; }
+  SYNC();
+}
+__device__ __forceinline__ void rg_dump_slv(const RgModelDev& m, RgLds& s, float* dbg, int nefc, int iters) {
+  PFOR(i, m.nv) { dbg[RG_DBG_QACCS + i] = s.qacc_smooth[i]; dbg[RG_DBG_QACC + i] = s.qacc[i]; }
+  if (LANE == 0) { dbg[RG_DBG_NCON + 1] = (float)nefc; dbg[RG_DBG_NCON + 2] = (float)iters; }
 }
 
 __device__ __forceinline__ void rg_position_stage(const RgModelDev& m, const RgAux& x, RgLds& s) {
@@ -1345,7 +1442,7 @@ __device__ __forceinline__ void rg_position_stage(const RgModelDev& m, const RgA
   rg_tendon(m, s);
 }
 
-__global__ void __launch_bounds__(RG_WAVE) rg_step_kernel(RgModelDev m, RgAux x, RgEnvDev env, RgBatchDev bt, int nsubsteps, int nforward_ticks, int flags) {
+__global__ void __launch_bounds__(RG_WAVE, 2) rg_step_kernel(RgModelDev m, RgAux x, RgEnvDev env, RgBatchDev bt, int nsubsteps, int nforward_ticks, int flags) {
 #ifdef RG_EMUL
   RgLds& s = *(RgLds*)emul_lds();
 #else
@@ -1361,7 +1458,7 @@ __global__ void __launch_bounds__(RG_WAVE) rg_step_kernel(RgModelDev m, RgAux x,
   PFOR(i, 3 * m.nu) s.pid[i] = bt.pid[(size_t)e * 3 * m.nu + i];
   if (LANE == 0) s.status = bt.status[e];
   if (LANE < RG_NPROF) s.prof[LANE] = 0;
-  SYNC();
+  rg_build_row_desc(m, s);
   // ---- action -> ctrl (robot_interface.py:247-278 with the hand's position->control matrix)
   if (bt.action) {
     PFOR(u, m.nu) {
@@ -1384,17 +1481,21 @@ __global__ void __launch_bounds__(RG_WAVE) rg_step_kernel(RgModelDev m, RgAux x,
     rg_kinematics(m, s); PROF(0);
     rg_com_pos(m, s); PROF(1);
     rg_tendon(m, s); PROF(2);
+    if (sub == 0 && (flags & 1) && bt.dbg) rg_dump_kin(m, s, bt.dbg + (size_t)e * RG_DBG_SIZE);
     rg_crb(m, s, x.subtree_adr, x.subtree); PROF(3);
-    rg_load_H(m, s, (const float*)0, 0.f); rg_chol(m, s); PROF(4);
     rg_collision(m, s, (flags & 2) ? s.prof : (float*)0); PROF(6);
+    if ((flags & 2) && LANE == 0 && (float)s.ncon > s.prof[23]) s.prof[23] = (float)s.ncon;
     rg_velocity(m, s, x.dof_velmask, x.subtree_adr, x.subtree); PROF(7);
     rg_make_constraint(m, s); PROF(8);
     rg_pid(m, s);
-    rg_smooth(m, s); rg_chol_solve(m, s, s.qacc_smooth); PROF(9);
+    rg_smooth(m, s); PROF(9);
+    if (sub == 0 && (flags & 1) && bt.dbg) rg_dump_pos(m, s, bt.dbg + (size_t)e * RG_DBG_SIZE);
+    // ---- the position-stage scratch is dead from here on; the solver scratch takes its place
+    rg_block_factor_solve(m, s, (const float*)0, 0.f, s.qacc_smooth); PROF(4);
     int nefc = 0;
     int iters = rg_solve(m, s, nefc, flags); t0 = rg_clock();
     st_ncon += s.ncon; st_nefc += nefc; st_iter += iters;
-    if (sub == 0 && (flags & 1) && bt.dbg) rg_dump(m, s, bt.dbg + (size_t)e * RG_DBG_SIZE, nefc, iters);
+    if (sub == 0 && (flags & 1) && bt.dbg) rg_dump_slv(m, s, bt.dbg + (size_t)e * RG_DBG_SIZE, nefc, iters);
     bd = 0; PFOR(i, m.nv) bd += (fabsf(s.qacc[i]) < 1e10f) ? 0.f : 1.f;
     if (wave_sum(bd) > 0) { bad = true; break; }
     rg_euler(m, s); PROF(11);

@@ -5,17 +5,22 @@
 
 // compile-time capacities of the "hand" kernel configuration (dactyl/locked, dactyl/reach)
 #define RG_MAXNQ 40
-#define RG_MAXNV 40
+#define RG_MAXNV 36
 #define RG_MAXBODY 32
 #define RG_MAXJNT 32
-#define RG_MAXGEOM 72
-#define RG_MAXSITE 40
+#define RG_MAXGEOM 66
+#define RG_MAXSITE 36
 #define RG_MAXTEN 12
 #define RG_MAXU 20
-#define RG_MAXCON 32    // contacts kept per env (overflow -> RG_STATUS_CON_FULL)
+#define RG_MAXCON 32    // contacts kept per env (overflow -> RG_STATUS_CON_FULL); rollouts: P(ncon > 16) = 9e-6, max 21 in 6.5e5 substeps; the reset recipe (cube dropped into a closing hand) reaches 24+
+#define RG_CPOOL 1160   // words of pooled contact basis Jacobians (rows x nnz per contact; 22 full-size cube contacts, ~30 mixed)
+#define RG_MAXFRIC 32   // friction-loss rows (dofs + tendons)
+#define RG_MAXSROW 96   // static row slots: friction rows + 2 per limited joint / tendon
+#define RG_MAXNVC 32    // dofs in constrained kinematic trees (the Newton space)
+#define RG_MAXBLK 816   // words of the per-tree dense inertia blocks
 #define RG_MAXCAND 128  // candidate geom pairs surviving the broadphase per substep
 #define RG_MAXROW 64    // friction-loss + limit rows
-#define RG_W 16         // max nonzeros of a sparse constraint row
+#define RG_W 14         // max nonzeros of a sparse constraint row
 #define RG_WAVE 64
 
 // per-env sticky status bits (replace MuJoCo's warning callback, warning_buffer.py:27-83)
@@ -32,6 +37,8 @@ enum { RG_WRAP_JOINT = 1, RG_WRAP_PULLEY = 2, RG_WRAP_SITE = 3, RG_WRAP_SPHERE =
 struct RgModelDev {
   int nq, nv, nu, nbody, njnt, ngeom, nsite, ntendon, nwrap, nmesh;
   int nlevel, ndoflevel, nM, npair, nstatic, nfric_dof, nfric_ten, nlim_jnt, nlim_ten;
+  int nvc, hs, blkwords, ntree, maxtree;  // Newton space size, its row stride, inertia block words, trees, largest tree
+  const int *dof_blk, *dof_blk2, *c_blk, *d2c, *c2d;
   int iterations, mpr_iterations, cone;
   float timestep, gravity[3], tolerance, impratio, mpr_tolerance, meaninertia;
   // bodies
@@ -39,7 +46,7 @@ struct RgModelDev {
   const float *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_invweight0;
   const int *lvl_body, *lvl_body_adr, *static_body;
   const float *static_xpos, *static_xquat;
-  const int* root_origin_body;
+  const int *root_origin_body, *body_orgslot;
   const float* root_origin_const;
   const uint32_t* body_dofmask;  // [nbody][2]
   // joints / dofs
@@ -102,16 +109,16 @@ struct RgBatchDev {
 
 // debug-dump layout (floats)
 #define RG_DBG_XPOS 0                                   // nbody*3
-#define RG_DBG_XQUAT (RG_DBG_XPOS + RG_MAXBODY * 3)     // nbody*4
-#define RG_DBG_SITE (RG_DBG_XQUAT + RG_MAXBODY * 4)     // nsite*3
-#define RG_DBG_M (RG_DBG_SITE + RG_MAXSITE * 3)         // nv*nv dense
-#define RG_DBG_TENLEN (RG_DBG_M + RG_MAXNV * RG_MAXNV)  // ntendon
+#define RG_DBG_XQUAT (RG_DBG_XPOS + 32 * 3)     // nbody*4
+#define RG_DBG_SITE (RG_DBG_XQUAT + 32 * 4)     // nsite*3
+#define RG_DBG_M (RG_DBG_SITE + 40 * 3)         // nv*nv dense
+#define RG_DBG_TENLEN (RG_DBG_M + 40 * 40)  // ntendon
 #define RG_DBG_TENJ (RG_DBG_TENLEN + RG_MAXTEN)         // ntendon*4
 #define RG_DBG_BIAS (RG_DBG_TENJ + RG_MAXTEN * 4)       // nv
-#define RG_DBG_PASSIVE (RG_DBG_BIAS + RG_MAXNV)         // nv
-#define RG_DBG_ACTFRC (RG_DBG_PASSIVE + RG_MAXNV)       // nv  qfrc_actuator
-#define RG_DBG_QACCS (RG_DBG_ACTFRC + RG_MAXNV)         // nv  qacc_smooth
-#define RG_DBG_QACC (RG_DBG_QACCS + RG_MAXNV)           // nv
-#define RG_DBG_NCON (RG_DBG_QACC + RG_MAXNV)            // 1: ncon, +1: nefc, +2: iters, +3: ncand
+#define RG_DBG_PASSIVE (RG_DBG_BIAS + 40)         // nv
+#define RG_DBG_ACTFRC (RG_DBG_PASSIVE + 40)       // nv  qfrc_actuator
+#define RG_DBG_QACCS (RG_DBG_ACTFRC + 40)         // nv  qacc_smooth
+#define RG_DBG_QACC (RG_DBG_QACCS + 40)           // nv
+#define RG_DBG_NCON (RG_DBG_QACC + 40)            // 1: ncon, +1: nefc, +2: iters, +3: ncand
 #define RG_DBG_CON (RG_DBG_NCON + 4)                    // MAXCON * 8: dist, pos3, normal3, pair index
-#define RG_DBG_SIZE (RG_DBG_CON + RG_MAXCON * 8)
+#define RG_DBG_SIZE (RG_DBG_CON + 32 * 8)

@@ -68,6 +68,11 @@ def derive_kernel_tables(model, max_row_nnz=16):
             if not is_static[r]:
                 # moving multi-body tree: fall back to the root body's com as origin
                 origin_body[r] = r
+    # origin slots: one per kinematic tree that owns dofs; dof-less trees (floor, world) share slot 0
+    roots_with_dofs = sorted(set(int(root[A["dof_bodyid"][d]]) for d in range(nv)))
+    if len(roots_with_dofs) > 3:
+        raise NotImplementedError("more than 3 kinematic trees with dofs (origin slots)")
+    A["k_body_orgslot"] = _i32([1 + roots_with_dofs.index(int(root[b])) if int(root[b]) in roots_with_dofs else 0 for b in range(nbody)])
     A["k_root_origin_body"] = origin_body
     A["k_root_origin_const"] = origin_const
 
@@ -270,5 +275,68 @@ def derive_kernel_tables(model, max_row_nnz=16):
     A["k_fric_ten"] = _i32([t for t in range(nt) if A["tendon_frictionloss"][t] > 0])
     A["k_lim_jnt"] = _i32([j for j in range(len(A["jnt_type"])) if A["jnt_limited"][j] and A["jnt_type"][j] in (C.JNT_SLIDE, C.JNT_HINGE)])
     A["k_lim_ten"] = _i32([t for t in range(nt) if A["tendon_limited"][t]])
+    # ---------------------------------------------------------------- kinematic trees as dense inertia blocks
+    # dofs of one tree are contiguous; M (and M + hB) is block diagonal over trees.  A tree is "constrained"
+    # when any constraint row can ever touch it (friction loss, limits, tendons, collidable geoms); the
+    # Newton solve runs in the compact space of constrained dofs, the others keep qacc = qacc_smooth.
+    dof_root = [int(root[A["dof_bodyid"][d]]) for d in range(nv)]
+    trees = []
+    for d in range(nv):
+        if not trees or trees[-1][0] != dof_root[d]:
+            trees.append([dof_root[d], d, 0])
+        trees[-1][2] += 1
+    assert len(set(t[0] for t in trees)) == len(trees), "dofs of a kinematic tree must be contiguous"
+    col_bodies = set()
+    for a, b, _ in pairs:
+        col_bodies.add(int(gbody[a])); col_bodies.add(int(gbody[b]))
+    constrained_dof = np.zeros(nv, dtype=bool)
+    constrained_dof[A["dof_frictionloss"] > 0] = True
+    for j in A["k_lim_jnt"] if "k_lim_jnt" in A else []:
+        constrained_dof[A["jnt_dofadr"][j]] = True
+    for j in range(len(A["jnt_type"])):
+        if A["jnt_limited"][j] and A["jnt_type"][j] in (C.JNT_SLIDE, C.JNT_HINGE):
+            constrained_dof[A["jnt_dofadr"][j]] = True
+    for t in range(nt):
+        for e in range(4):
+            if tdofs[t, e] >= 0:
+                constrained_dof[tdofs[t, e]] = True
+    for b in col_bodies:
+        for d in range(nv):
+            if (int(mask[b]) >> d) & 1:
+                constrained_dof[d] = True
+    madr, blk_words = [], 0
+    dof_blk = np.zeros(nv, dtype=np.int32)
+    dof_blk2 = np.zeros(nv, dtype=np.int32)   # row stride | block start word << 8
+    tree_tab = []
+    d2c = np.full(nv, -1, dtype=np.int32)
+    c2d = []
+    for (r, s0, n) in trees:
+        stride = (n + 3) // 4 * 4
+        if stride % 8 == 0:
+            stride += 4          # conflict-free 16-byte row reads across lanes
+        cons = bool(constrained_dof[s0:s0 + n].any())
+        cbase = len(c2d) if cons else 255
+        if cons:
+            for d in range(s0, s0 + n):
+                d2c[d] = len(c2d); c2d.append(d)
+        for d in range(s0, s0 + n):
+            mrow = blk_words + (d - s0) * stride
+            assert mrow < 65536 and s0 < 256 and n < 256
+            dof_blk[d] = mrow | (s0 << 16) | (n << 24)
+            dof_blk2[d] = stride | (blk_words << 8)
+        tree_tab.append([s0, n, blk_words, stride, cbase])
+        blk_words += n * stride
+    nvc = len(c2d)
+    hs = (nvc + 3) // 4 * 4
+    if hs % 8 == 0:
+        hs += 4
+    c_blk = np.zeros(max(nvc, 1), dtype=np.int32)
+    for i, d in enumerate(c2d):
+        s0, n = (dof_blk[d] >> 16) & 255, (dof_blk[d] >> 24) & 255
+        c_blk[i] = (dof_blk[d] & 0xFFFF) | (int(d2c[s0]) << 16) | (n << 24)
+    A["k_dof_blk"] = dof_blk; A["k_dof_blk2"] = dof_blk2; A["k_c_blk"] = c_blk
+    A["k_d2c"] = d2c; A["k_c2d"] = _i32(c2d)
+    A["k_tree"] = _i32(tree_tab).reshape(-1, 5)
+    A["k_blk_dims"] = _i32([nvc, hs, blk_words, len(trees), max(t[2] for t in trees)])
     A["k_dims"] = _i32([nlevel, ndl, len(Mi), len(pairs), len(A["k_static_body"]), max_nnz])
     return model

@@ -17,7 +17,7 @@ s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True
 s.record(); sim.env_step(action=a, nforward_ticks=3, flags=2); e.record(); torch.cuda.synchronize()
 dbg = sim.get_field(8)
 off = dbg.shape[1] - 32 * 8
-prof = dbg[:, off:off + 32].double().mean(0).cpu().numpy() / 10.0
+prof = dbg[:, off:off + 24].double().mean(0).cpu().numpy() / 10.0
 names = ["kinematics", "com_pos", "tendon", "crb+M", "factor M", "broadphase", "narrowphase(+broad)", "velocity/RNE", "constraint rows", "pid+smooth", "newton linesearch+update", "euler", "newton grad/cost eval", "newton H assembly", "newton cholesky", "newton tri-solve"]
 tot = sum(prof[i] for i in range(16) if i != 5)
 print("kernel ms %.2f for B=%d ; cycles per substep per wave (mean over envs):" % (s.elapsed_time(e), B))
