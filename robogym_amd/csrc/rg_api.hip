@@ -211,7 +211,8 @@ rg_batch* rg_batch_create(const rg_model* m, int B, int device) {
   s.qacc_warmstart = (float*)balloc(b, (size_t)B * d.nv * 4); s.time = (float*)balloc(b, (size_t)B * 4);
   s.status = (uint32_t*)balloc(b, (size_t)B * 4); s.stats = (float*)balloc(b, (size_t)B * 16);
   s.dbg = (float*)balloc(b, (size_t)B * RG_DBG_SIZE * 4);
-  if (!s.qpos || !s.qvel || !s.ctrl || !s.pid || !s.qacc_warmstart || !s.time || !s.status || !s.stats || !s.dbg) { fail("hipMalloc failed"); rg_batch_free(b); return nullptr; }
+  s.sepdir = (float*)balloc(b, (size_t)B * (d.npair > 0 ? d.npair : 1) * 16);
+  if (!s.qpos || !s.qvel || !s.ctrl || !s.pid || !s.qacc_warmstart || !s.time || !s.status || !s.stats || !s.dbg || !s.sepdir) { fail("hipMalloc failed"); rg_batch_free(b); return nullptr; }
   if (rg_batch_reset(b) != 0) { rg_batch_free(b); return nullptr; }
   return b;
 }

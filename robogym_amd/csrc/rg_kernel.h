@@ -571,14 +571,17 @@ __device__ __forceinline__ float origin_tri_dist2(v3 a, v3 b, v3 c, v3& w) {
   return dot(w, w);
 }
 // MPR penetration query (libccd ccdMPRPenetration); wave-uniform control flow.  Returns true on contact.
-template <int G> __device__ __forceinline__ bool rg_mpr(const MprGeom& A, const MprGeom& B, int max_iter, float tol, float& depth, v3& dir_out, v3& pos) {
+// `sep`: on a "no contact" exit that PROVES separation (support of the Minkowski difference along `sep` is <= 0)
+// the unit direction that proves it, else zero — cached per pair and tried first on the next substep.
+template <int G> __device__ __forceinline__ bool rg_mpr(const MprGeom& A, const MprGeom& B, int max_iter, float tol, float& depth, v3& dir_out, v3& pos, v3& sep) {
   SupPt p[4], v4;
+  sep = mk3(0, 0, 0);
   p[0].v1 = A.pos; p[0].v2 = B.pos; p[0].v = A.pos - B.pos;
   if (mz(p[0].v.x) && mz(p[0].v.y) && mz(p[0].v.z)) p[0].v.x += 1e-6f;
   v3 dir = normalized(p[0].v * -1.0f);
   mpr_support<G>(A, B, dir, p[1]);
   float dt = dot(p[1].v, dir);
-  if (dt <= 0) return false;
+  if (dt <= 0) { sep = dir; return false; }
   dir = cross(p[0].v, p[1].v);
   if (dot(dir, dir) < 1e-30f) {
     pos = (p[1].v1 + p[1].v2) * 0.5f;
@@ -588,13 +591,13 @@ template <int G> __device__ __forceinline__ bool rg_mpr(const MprGeom& A, const 
   }
   dir = normalized(dir);
   mpr_support<G>(A, B, dir, p[2]);
-  if (dot(p[2].v, dir) <= 0) return false;
+  if (dot(p[2].v, dir) <= 0) { sep = dir; return false; }
   dir = normalized(cross(p[1].v - p[0].v, p[2].v - p[0].v));
   if (dot(dir, p[0].v) > 0) { SupPt t = p[1]; p[1] = p[2]; p[2] = t; dir = dir * -1.0f; }
   for (int guard = 0;; guard++) {
     if (guard > 64) return false;
     mpr_support<G>(A, B, dir, p[3]);
-    if (dot(p[3].v, dir) <= 0) return false;
+    if (dot(p[3].v, dir) <= 0) { sep = dir; return false; }
     bool cont = false;
     if (dot(cross(p[1].v, p[3].v), p[0].v) < 0) { p[2] = p[3]; cont = true; }
     if (!cont && dot(cross(p[3].v, p[2].v), p[0].v) < 0) { p[1] = p[3]; cont = true; }
@@ -606,7 +609,8 @@ template <int G> __device__ __forceinline__ bool rg_mpr(const MprGeom& A, const 
     dir = portal_dir(p);
     if (dot(dir, p[1].v) >= 0) break;
     mpr_support<G>(A, B, dir, v4);
-    if (dot(v4.v, dir) < 0 || portal_reach_tol(p, v4, dir, tol)) return false;
+    if (dot(v4.v, dir) < 0) { sep = dir; return false; }
+    if (portal_reach_tol(p, v4, dir, tol)) return false;
     expand_portal(p, v4);
   }
   for (int it = 0;; it++) {  // findPenetr
@@ -683,7 +687,7 @@ __device__ __forceinline__ void rg_mpr_geoms(const RgModelDev& m, const RgLds& s
   if (t2 == RG_GEOM_MESH) { int id = m.geom_dataid[g2]; B.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; B.nvert = m.mesh_vertnum[id]; } else { B.vert = 0; B.nvert = 0; }
   A.prof = 0; B.prof = 0;
 }
-__device__ __forceinline__ void rg_collision(const RgModelDev& m, RgLds& s, float* prof) {
+__device__ __forceinline__ void rg_collision(const RgModelDev& m, RgLds& s, float* prof, rgf4* sepdir) {
   long long tb0 = rg_clock();
   if (LANE == 0) { s.ncand = 0; s.ncon = 0; }
   SYNC();
@@ -740,6 +744,7 @@ __device__ __forceinline__ void rg_collision(const RgModelDev& m, RgLds& s, floa
         v3 c0 = A.pos - B.pos;
         if (mz(c0.x) && mz(c0.y) && mz(c0.z)) c0.x += 1e-6f;
         v3 dir = normalized(c0 * -1.0f);
+        if (sepdir) { rgf4 cd = sepdir[p]; if (cd.x * cd.x + cd.y * cd.y + cd.z * cd.z > 0.5f) dir = mk3(cd.x, cd.y, cd.z); }  // last substep's separating direction first
         SupPt p1; mpr_support<16>(A, B, dir, p1);
         keep = dot(p1.v, dir) > 0;
       }
@@ -764,7 +769,9 @@ __device__ __forceinline__ void rg_collision(const RgModelDev& m, RgLds& s, floa
       MprGeom A, B;
       rg_mpr_geoms(m, s, p, A, B);
       A.prof = prof;
-      hit = rg_mpr<16>(A, B, m.mpr_iterations, m.mpr_tolerance, depth, dir, pos);
+      v3 sep;
+      hit = rg_mpr<16>(A, B, m.mpr_iterations, m.mpr_tolerance, depth, dir, pos, sep);
+      if (sepdir && (LANE & 15) == 0) { rgf4 cd; cd.x = hit ? 0.f : sep.x; cd.y = hit ? 0.f : sep.y; cd.z = hit ? 0.f : sep.z; cd.w = 0.f; sepdir[p] = cd; }
       hit = hit && dot(dir, dir) > 0.25f;
       pos = pos + ld3(s.gpos + 3 * m.pair_geom[3 * p]);
     }
@@ -1483,7 +1490,7 @@ __global__ void __launch_bounds__(RG_WAVE, 2) rg_step_kernel(RgModelDev m, RgAux
     rg_tendon(m, s); PROF(2);
     if (sub == 0 && (flags & 1) && bt.dbg) rg_dump_kin(m, s, bt.dbg + (size_t)e * RG_DBG_SIZE);
     rg_crb(m, s, x.subtree_adr, x.subtree); PROF(3);
-    rg_collision(m, s, (flags & 2) ? s.prof : (float*)0); PROF(6);
+    rg_collision(m, s, (flags & 2) ? s.prof : (float*)0, bt.sepdir ? (rgf4*)bt.sepdir + (size_t)e * m.npair : (rgf4*)0); PROF(6);
     if ((flags & 2) && LANE == 0 && (float)s.ncon > s.prof[23]) s.prof[23] = (float)s.ncon;
     rg_velocity(m, s, x.dof_velmask, x.subtree_adr, x.subtree); PROF(7);
     rg_make_constraint(m, s); PROF(8);
@@ -1566,7 +1573,7 @@ __global__ void __launch_bounds__(RG_WAVE) rg_mpr_pair_kernel(RgModelDev m, RgBa
   if (A.type == RG_GEOM_MESH) { int id = m.geom_dataid[g1]; A.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; A.nvert = m.mesh_vertnum[id]; } else { A.vert = 0; A.nvert = 0; }
   if (B.type == RG_GEOM_MESH) { int id = m.geom_dataid[g2]; B.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; B.nvert = m.mesh_vertnum[id]; } else { B.vert = 0; B.nvert = 0; }
   float depth = 0; v3 dir = mk3(0, 0, 0), pos = mk3(0, 0, 0);
-  bool hit = rg_mpr<64>(A, B, m.mpr_iterations, m.mpr_tolerance, depth, dir, pos);
+  v3 sep; bool hit = rg_mpr<64>(A, B, m.mpr_iterations, m.mpr_tolerance, depth, dir, pos, sep);
   if (LANE == 0) {
     float* o = out + 8 * (size_t)e;
     o[0] = hit ? 1.f : 0.f; o[1] = depth; o[2] = dir.x; o[3] = dir.y; o[4] = dir.z; o[5] = pos.x + p1.x; o[6] = pos.y + p1.y; o[7] = pos.z + p1.z;

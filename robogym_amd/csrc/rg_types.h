@@ -97,6 +97,7 @@ struct RgBatchDev {
   int B;
   float *qpos, *qvel, *ctrl, *pid, *qacc_warmstart, *time;
   uint32_t* status;
+  float* sepdir;        // [B][npair][4] cached separating direction per candidate pair (pure cache, not state)
   // env-step I/O
   const float* action;  // [B][nu] in [-1,1]   (may be null: ctrl used as is)
   const float* goal_quat;  // [B][4]
