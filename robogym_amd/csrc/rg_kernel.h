@@ -45,6 +45,7 @@ struct RgLds {
   float r_D[RG_MAXSROW], r_aref[RG_MAXSROW], r_floss[RG_MAXFRIC];
   unsigned short r_desc[RG_MAXSROW];   // compact dof (6 bits) | tendon id (5 bits, 31 = none) << 6 | negative sign << 11
   unsigned char ten_cdof[RG_MAXTEN * 4], c2d[RG_MAXNVC], b2org[RG_MAXBODY];
+  int cblk[RG_MAXNVC];   // per compact dof: inertia-block row word | compact index of its tree start << 16 | tree size << 24
   int ncand, ncand2, ncon;
   float c_D[RG_MAXCON], c_mu[RG_MAXCON * 3];
   short c_pair[RG_MAXCON], c_off[RG_MAXCON];
@@ -68,7 +69,7 @@ struct RgLds {
     };
     struct {  // ---- slv
       alignas(16) float H[RG_HWORDS];
-      float a[RG_MAXNVC], as[RG_MAXNVC], fs[RG_MAXNVC], jtf[RG_MAXNVC], Ma[RG_MAXNVC], grad[RG_MAXNVC], search[RG_MAXNVC], Mv[RG_MAXNVC], tmpv[RG_MAXNV], qfrc_con[RG_MAXNV], qacc[RG_MAXNV];
+      float a[RG_MAXNVC], as[RG_MAXNVC], fs[RG_MAXNVC], jtf[RG_MAXNVC], Ma[RG_MAXNVC], search[RG_MAXNVC], Mv[RG_MAXNVC], dinv[RG_MAXNV], tmpv[RG_MAXNV], qfrc_con[RG_MAXNV], qacc[RG_MAXNV];
       float r_jar[RG_MAXSROW], r_jv[RG_MAXSROW], r_force[RG_MAXSROW];
       unsigned char r_quad[RG_MAXSROW], p_quad[RG_MAXPYR];
       float c_bdot[RG_MAXCON * 4], c_bfrc[RG_MAXCON * 4];
@@ -956,7 +957,7 @@ __device__ __forceinline__ void rg_build_row_desc(const RgModelDev& m, RgLds& s)
     s.r_desc[r] = (unsigned short)((dof & 63) | (ten << 6) | (neg << 11));
   }
   PFOR(w, m.ntendon * 4) { int d = m.ten_dofs[w]; s.ten_cdof[w] = (unsigned char)(d >= 0 ? m.d2c[d] : 255); }
-  PFOR(i, m.nvc) s.c2d[i] = (unsigned char)m.c2d[i];
+  PFOR(i, m.nvc) { s.c2d[i] = (unsigned char)m.c2d[i]; s.cblk[i] = m.c_blk[i]; }
   PFOR(b, m.nbody) s.b2org[b] = (unsigned char)m.body_orgslot[b];
   SYNC();
 }
@@ -1146,7 +1147,7 @@ __device__ __forceinline__ void rg_JT_force(const RgModelDev& m, RgLds& s, float
 // y = M x in the compact dof space: row i of the tree block of dof c2d[i] against that tree's slice of x
 __device__ __forceinline__ void rg_M_mul(const RgModelDev& m, RgLds& s, const float* x, float* y) {
   PFOR(i, m.nvc) {
-    int blk = m.c_blk[i], n = (blk >> 24) & 255; const float* row = s.M + (blk & 0xFFFF); const float* xs = x + ((blk >> 16) & 255);
+    int blk = s.cblk[i], n = (blk >> 24) & 255; const float* row = s.M + (blk & 0xFFFF); const float* xs = x + ((blk >> 16) & 255);
     float v = 0;
 #pragma unroll 4
     for (int k = 0; k < n; k++) v += row[k] * xs[k];
@@ -1154,97 +1155,189 @@ __device__ __forceinline__ void rg_M_mul(const RgModelDev& m, RgLds& s, const fl
   }
   SYNC();
 }
-// Dense Cholesky of the n x n matrix in s.H (row stride hs, lower triangle, in place), left-looking with
-// lane i owning row i: column j costs j multiply-adds per lane on independent LDS reads (row j is a
-// broadcast read, own-row reads are conflict-free with the padded stride), pivot by v_readlane, one barrier.
+// Dense Cholesky of the n x n matrix in s.H (row stride hs, lower triangle, in place), left-looking, lane i
+// owns row i, FOUR columns per step: one pass over the lane's own row chunks serves four dot products
+// (pivot rows are broadcast reads), the 4x4 diagonal block is factored redundantly in every lane from ten
+// v_readlane values, and each lane solves its four new entries against it.  n/4 LDS round trips, not n.
+__device__ __forceinline__ float dot4(rgf4 a, rgf4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 __device__ __forceinline__ void rg_chol(const RgModelDev& m, RgLds& s) {
-  int n = m.nvc, hs = m.hs, i = LANE;
-  float* H = s.H;
-  for (int j = 0; j < n; j++) {
-    float acc = 0.f;
-    if (i >= j && i < n) {
-      acc = H[i * hs + j];
-      const rgf4 *ri = (const rgf4*)(H + i * hs), *rj = (const rgf4*)(H + j * hs);
-      int nc = (j + 3) >> 2;
-#pragma unroll 3
-      for (int c = 0; c < nc; c++) {
-        rgf4 a = ri[c], b = rj[c];
-        int k = 4 * c;
-        acc -= a.x * (k < j ? b.x : 0.f) + a.y * (k + 1 < j ? b.y : 0.f) + a.z * (k + 2 < j ? b.z : 0.f) + a.w * (k + 3 < j ? b.w : 0.f);
-      }
+  int n = m.nvc, hs4 = m.hs >> 2, i = LANE;
+  rgf4* H4 = (rgf4*)s.H;
+  bool bad = false;
+  for (int j0 = 0; j0 < n; j0 += 4) {
+    int jb = j0 >> 2, nb = n - j0;  // nb >= 4: full block
+    int r1 = j0 + 1 < n ? j0 + 1 : n - 1, r2 = j0 + 2 < n ? j0 + 2 : n - 1, r3 = j0 + 3 < n ? j0 + 3 : n - 1;
+    float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    bool mine = i >= j0 && i < n;
+    if (mine) {
+      rgf4 own = H4[i * hs4 + jb];
+      a0 = own.x; a1 = own.y; a2 = own.z; a3 = own.w;
+      const rgf4 *ri = H4 + i * hs4, *p0 = H4 + j0 * hs4, *p1 = H4 + r1 * hs4, *p2 = H4 + r2 * hs4, *p3 = H4 + r3 * hs4;
+#pragma unroll 2
+      for (int c = 0; c < jb; c++) { rgf4 a = ri[c]; a0 -= dot4(a, p0[c]); a1 -= dot4(a, p1[c]); a2 -= dot4(a, p2[c]); a3 -= dot4(a, p3[c]); }
     }
-    float d = lane_bcast(acc, j);
-    if (!(d > 1e-30f)) { if (i == 0) s.status |= RG_STATUS_BAD_FACTOR; d = 1e-30f; }
-    float r = 1.0f / sqrtf(d);
-    if (i >= j && i < n) H[i * hs + j] = (i == j) ? d * r : acc * r;
+    // diagonal block (lower triangle) from the four pivot lanes
+    float t00 = lane_bcast(a0, j0);
+    float t10 = lane_bcast(a0, j0 + 1), t11 = lane_bcast(a1, j0 + 1);
+    float t20 = lane_bcast(a0, j0 + 2), t21 = lane_bcast(a1, j0 + 2), t22 = lane_bcast(a2, j0 + 2);
+    float t30 = lane_bcast(a0, j0 + 3), t31 = lane_bcast(a1, j0 + 3), t32 = lane_bcast(a2, j0 + 3), t33 = lane_bcast(a3, j0 + 3);
+    bool v1 = nb > 1, v2 = nb > 2, v3 = nb > 3;
+    if (!(t00 > 1e-30f)) { bad = true; t00 = 1e-30f; }
+    float l00 = sqrtf(t00), i00 = 1.0f / l00;
+    float l10 = v1 ? t10 * i00 : 0.f, d11 = v1 ? t11 - l10 * l10 : 1.f;
+    if (!(d11 > 1e-30f)) { bad = true; d11 = 1e-30f; }
+    float l11 = sqrtf(d11), i11 = v1 ? 1.0f / l11 : 0.f;
+    float l20 = v2 ? t20 * i00 : 0.f, l21 = v2 ? (t21 - l20 * l10) * i11 : 0.f, d22 = v2 ? t22 - l20 * l20 - l21 * l21 : 1.f;
+    if (!(d22 > 1e-30f)) { bad = true; d22 = 1e-30f; }
+    float l22 = sqrtf(d22), i22 = v2 ? 1.0f / l22 : 0.f;
+    float l30 = v3 ? t30 * i00 : 0.f, l31 = v3 ? (t31 - l30 * l10) * i11 : 0.f, l32 = v3 ? (t32 - l30 * l20 - l31 * l21) * i22 : 0.f;
+    float d33 = v3 ? t33 - l30 * l30 - l31 * l31 - l32 * l32 : 1.f;
+    if (!(d33 > 1e-30f)) { bad = true; d33 = 1e-30f; }
+    float l33 = sqrtf(d33), i33 = v3 ? 1.0f / l33 : 0.f;
+    if (mine) {
+      int r = i - j0;
+      float x0 = a0 * i00, x1 = (a1 - x0 * l10) * i11, x2 = (a2 - x0 * l20 - x1 * l21) * i22, x3 = (a3 - x0 * l30 - x1 * l31 - x2 * l32) * i33;
+      if (r == 0) { x0 = l00; x1 = 0; x2 = 0; x3 = 0; }
+      else if (r == 1) { x1 = l11; x2 = 0; x3 = 0; }
+      else if (r == 2) { x2 = l22; x3 = 0; }
+      else if (r == 3) x3 = l33;
+      rgf4 o; o.x = x0; o.y = x1; o.z = x2; o.w = x3;
+      H4[i * hs4 + jb] = o;
+    }
+    if (i == 0) { s.dinv[j0] = i00; if (v1) s.dinv[j0 + 1] = i11; if (v2) s.dinv[j0 + 2] = i22; if (v3) s.dinv[j0 + 3] = i33; }
     SYNC();
   }
+  if (bad && i == 0) s.status |= RG_STATUS_BAD_FACTOR;
 }
-// x <- H^-1 x with the factor above; lane i owns x[i]; the pivot reciprocal lives in the owning lane
+// x <- H^-1 x with the factor above, four pivots per step; lane i owns x[i]
 __device__ __forceinline__ void rg_chol_solve(const RgModelDev& m, RgLds& s, float* x) {
-  int n = m.nvc, hs = m.hs, i = LANE;
-  const float* H = s.H;
+  int n = m.nvc, hs = m.hs, hs4 = hs >> 2, i = LANE;
+  const float* H = s.H; const rgf4* H4 = (const rgf4*)s.H;
   float xi = i < n ? x[i] : 0.f;
-  float inv = i < n ? 1.0f / H[i * hs + i] : 0.f;
-  for (int j = 0; j < n; j++) {
-    float xj = lane_bcast(xi * inv, j);
-    if (i == j) xi = xj;
-    else if (i > j && i < n) xi -= H[i * hs + j] * xj;
+  for (int j0 = 0; j0 < n; j0 += 4) {  // forward: L y = b
+    int jb = j0 >> 2, nb = n - j0;
+    int r1 = j0 + 1 < n ? j0 + 1 : n - 1, r2 = j0 + 2 < n ? j0 + 2 : n - 1, r3 = j0 + 3 < n ? j0 + 3 : n - 1;
+    rgf4 q1 = H4[r1 * hs4 + jb], q2 = H4[r2 * hs4 + jb], q3 = H4[r3 * hs4 + jb];
+    float i00 = s.dinv[j0], i11 = nb > 1 ? s.dinv[r1] : 0.f, i22 = nb > 2 ? s.dinv[r2] : 0.f, i33 = nb > 3 ? s.dinv[r3] : 0.f;
+    float x0 = lane_bcast(xi, j0) * i00;
+    float x1 = (lane_bcast(xi, j0 + 1) - q1.x * x0) * i11;
+    float x2 = (lane_bcast(xi, j0 + 2) - q2.x * x0 - q2.y * x1) * i22;
+    float x3 = (lane_bcast(xi, j0 + 3) - q3.x * x0 - q3.y * x1 - q3.z * x2) * i33;
+    int r = i - j0;
+    if (r >= 4 && i < n) { rgf4 own = H4[i * hs4 + jb]; xi -= own.x * x0 + own.y * x1 + own.z * x2 + own.w * x3; }
+    else if (r == 0) xi = x0; else if (r == 1) xi = x1; else if (r == 2) xi = x2; else if (r == 3) xi = x3;
   }
-  for (int j = n - 1; j >= 0; j--) {
-    float xj = lane_bcast(xi * inv, j);
-    if (i == j) xi = xj;
-    else if (i < j) xi -= H[j * hs + i] * xj;
+  for (int j0 = ((n - 1) >> 2) << 2; j0 >= 0; j0 -= 4) {  // backward: L' x = y
+    int jb = j0 >> 2, nb = n - j0;
+    int r1 = j0 + 1 < n ? j0 + 1 : n - 1, r2 = j0 + 2 < n ? j0 + 2 : n - 1, r3 = j0 + 3 < n ? j0 + 3 : n - 1;
+    rgf4 q1 = H4[r1 * hs4 + jb], q2 = H4[r2 * hs4 + jb], q3 = H4[r3 * hs4 + jb];
+    float i00 = s.dinv[j0], i11 = nb > 1 ? s.dinv[r1] : 0.f, i22 = nb > 2 ? s.dinv[r2] : 0.f, i33 = nb > 3 ? s.dinv[r3] : 0.f;
+    float l10 = nb > 1 ? q1.x : 0.f, l20 = nb > 2 ? q2.x : 0.f, l21 = nb > 2 ? q2.y : 0.f, l30 = nb > 3 ? q3.x : 0.f, l31 = nb > 3 ? q3.y : 0.f, l32 = nb > 3 ? q3.z : 0.f;
+    float x3 = lane_bcast(xi, j0 + 3) * i33;
+    float x2 = (lane_bcast(xi, j0 + 2) - l32 * x3) * i22;
+    float x1 = (lane_bcast(xi, j0 + 1) - l21 * x2 - l31 * x3) * i11;
+    float x0 = (lane_bcast(xi, j0) - l10 * x1 - l20 * x2 - l30 * x3) * i00;
+    int r = i - j0;
+    if (i < j0) xi -= H[j0 * hs + i] * x0 + (nb > 1 ? H[r1 * hs + i] * x1 : 0.f) + (nb > 2 ? H[r2 * hs + i] * x2 : 0.f) + (nb > 3 ? H[r3 * hs + i] * x3 : 0.f);
+    else if (r == 0) xi = x0; else if (r == 1) xi = x1; else if (r == 2) xi = x2; else if (r == 3) xi = x3;
   }
   if (i < n) x[i] = xi;
   SYNC();
 }
 // Block-diagonal factorisation over ALL dofs: s.H (same block layout as s.M) <- chol(M + scale*diag(extra)),
-// every kinematic tree's block factored concurrently (lane d owns row d of its tree), then x <- solve.
-// Used for qacc_smooth = M^-1 qfrc_smooth and for the implicit-damping Euler solve.
+// every kinematic tree's block factored concurrently (lane d owns row d of its tree), four columns per
+// step as in rg_chol; the pivot lanes differ per tree, so pivot values travel by ds_bpermute (__shfl).
+// Then x <- solve.  Used for qacc_smooth = M^-1 qfrc_smooth and for the implicit-damping Euler solve.
 __device__ __forceinline__ void rg_block_factor_solve(const RgModelDev& m, RgLds& s, const float* extra_diag, float scale, float* x) {
   for (int w = LANE; w < m.blkwords; w += RG_WAVE) s.H[w] = s.M[w];
   SYNC();
   int d = LANE; bool on = d < m.nv;
-  int blk = on ? m.dof_blk[d] : 0, s0 = (blk >> 16) & 255, n = on ? (blk >> 24) & 255 : 0, jj_me = d - s0;
-  float* row = s.H + (blk & 0xFFFF);
-  int blk2 = on ? m.dof_blk2[d] : 0, stride = blk2 & 255;
-  if (on && extra_diag) row[jj_me] += scale * extra_diag[d];
+  int blk = on ? m.dof_blk[d] : 0, blk2 = on ? m.dof_blk2[d] : 0;
+  int s0 = (blk >> 16) & 255, n = on ? (blk >> 24) & 255 : 0, r = d - s0, st4 = (blk2 & 255) >> 2;
+  rgf4* B4 = (rgf4*)(s.H + (blk2 >> 8));   // this lane's tree block, rows of st4 16-byte chunks
+  if (on && extra_diag) s.H[(blk & 0xFFFF) + r] += scale * extra_diag[d];
   SYNC();
-  float* blk0 = s.H + (blk2 >> 8);
-  for (int jj = 0; jj < m.maxtree; jj++) {
-    float acc = 0.f;
-    bool act = on && jj < n && jj_me >= jj;
-    if (act) {
-      acc = row[jj];
-      const rgf4 *ri = (const rgf4*)row, *rj = (const rgf4*)(blk0 + jj * stride);
-      int nc = (jj + 3) >> 2;
-#pragma unroll 3
-      for (int c = 0; c < nc; c++) {
-        rgf4 a = ri[c], b = rj[c];
-        int k = 4 * c;
-        acc -= a.x * (k < jj ? b.x : 0.f) + a.y * (k + 1 < jj ? b.y : 0.f) + a.z * (k + 2 < jj ? b.z : 0.f) + a.w * (k + 3 < jj ? b.w : 0.f);
-      }
+  bool bad = false;
+  int nsteps = (m.maxtree + 3) >> 2;
+  for (int sb = 0; sb < nsteps; sb++) {
+    int j0 = sb << 2, nb = n - j0;  // columns j0..j0+3 of the lane's own block
+    bool blk_on = on && nb > 0, mine = blk_on && r >= j0;
+    int q1 = j0 + 1 < n ? j0 + 1 : n - 1, q2 = j0 + 2 < n ? j0 + 2 : n - 1, q3 = j0 + 3 < n ? j0 + 3 : n - 1;
+    float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    if (mine) {
+      rgf4 own = B4[r * st4 + sb];
+      a0 = own.x; a1 = own.y; a2 = own.z; a3 = own.w;
+      const rgf4 *ri = B4 + r * st4, *p0 = B4 + j0 * st4, *p1 = B4 + q1 * st4, *p2 = B4 + q2 * st4, *p3 = B4 + q3 * st4;
+#pragma unroll 2
+      for (int c = 0; c < sb; c++) { rgf4 a = ri[c]; a0 -= dot4(a, p0[c]); a1 -= dot4(a, p1[c]); a2 -= dot4(a, p2[c]); a3 -= dot4(a, p3[c]); }
     }
-    float dv = __shfl(acc, (on && jj < n) ? s0 + jj : 0);   // pivot of this lane's own tree
-    if (act) {
-      if (!(dv > 1e-30f)) { s.status |= RG_STATUS_BAD_FACTOR; dv = 1e-30f; }
-      float r = 1.0f / sqrtf(dv);
-      row[jj] = (jj_me == jj) ? dv * r : acc * r;
+    int l0 = blk_on ? s0 + j0 : 0, l1 = blk_on ? s0 + q1 : 0, l2 = blk_on ? s0 + q2 : 0, l3 = blk_on ? s0 + q3 : 0;
+    float t00 = __shfl(a0, l0);
+    float t10 = __shfl(a0, l1), t11 = __shfl(a1, l1);
+    float t20 = __shfl(a0, l2), t21 = __shfl(a1, l2), t22 = __shfl(a2, l2);
+    float t30 = __shfl(a0, l3), t31 = __shfl(a1, l3), t32 = __shfl(a2, l3), t33 = __shfl(a3, l3);
+    if (blk_on) {
+      bool v1 = nb > 1, v2 = nb > 2, v3 = nb > 3;
+      if (!(t00 > 1e-30f)) { bad = true; t00 = 1e-30f; }
+      float l00 = sqrtf(t00), i00 = 1.0f / l00;
+      float l10 = v1 ? t10 * i00 : 0.f, d11 = v1 ? t11 - l10 * l10 : 1.f;
+      if (!(d11 > 1e-30f)) { bad = true; d11 = 1e-30f; }
+      float l11 = sqrtf(d11), i11 = v1 ? 1.0f / l11 : 0.f;
+      float l20 = v2 ? t20 * i00 : 0.f, l21 = v2 ? (t21 - l20 * l10) * i11 : 0.f, d22 = v2 ? t22 - l20 * l20 - l21 * l21 : 1.f;
+      if (!(d22 > 1e-30f)) { bad = true; d22 = 1e-30f; }
+      float l22 = sqrtf(d22), i22 = v2 ? 1.0f / l22 : 0.f;
+      float l30 = v3 ? t30 * i00 : 0.f, l31 = v3 ? (t31 - l30 * l10) * i11 : 0.f, l32 = v3 ? (t32 - l30 * l20 - l31 * l21) * i22 : 0.f;
+      float d33 = v3 ? t33 - l30 * l30 - l31 * l31 - l32 * l32 : 1.f;
+      if (!(d33 > 1e-30f)) { bad = true; d33 = 1e-30f; }
+      float l33 = sqrtf(d33), i33 = v3 ? 1.0f / l33 : 0.f;
+      if (mine) {
+        int rr = r - j0;
+        float x0 = a0 * i00, x1 = (a1 - x0 * l10) * i11, x2 = (a2 - x0 * l20 - x1 * l21) * i22, x3 = (a3 - x0 * l30 - x1 * l31 - x2 * l32) * i33;
+        if (rr == 0) { x0 = l00; x1 = 0; x2 = 0; x3 = 0; }
+        else if (rr == 1) { x1 = l11; x2 = 0; x3 = 0; }
+        else if (rr == 2) { x2 = l22; x3 = 0; }
+        else if (rr == 3) x3 = l33;
+        rgf4 o; o.x = x0; o.y = x1; o.z = x2; o.w = x3;
+        B4[r * st4 + sb] = o;
+        if (rr < 4) s.dinv[d] = rr == 0 ? i00 : (rr == 1 ? i11 : (rr == 2 ? i22 : i33));   // reciprocal pivot of dof d
+      }
     }
     SYNC();
   }
+  // substitution sweeps, four pivots per step
+  const float* Bf = s.H + (blk2 >> 8); int st = blk2 & 255;
   float xi = on ? x[d] : 0.f;
-  float inv = on ? 1.0f / row[jj_me] : 0.f;
-  for (int jj = 0; jj < m.maxtree; jj++) {
-    float xj = __shfl(xi * inv, (on && jj < n) ? s0 + jj : 0);
-    if (on && jj < n) { if (jj_me == jj) xi = xj; else if (jj_me > jj) xi -= row[jj] * xj; }
+  for (int sb = 0; sb < nsteps; sb++) {
+    int j0 = sb << 2, nb = n - j0; bool blk_on = on && nb > 0;
+    int q1 = j0 + 1 < n ? j0 + 1 : n - 1, q2 = j0 + 2 < n ? j0 + 2 : n - 1, q3 = j0 + 3 < n ? j0 + 3 : n - 1;
+    int l0 = blk_on ? s0 + j0 : 0, l1 = blk_on ? s0 + q1 : 0, l2 = blk_on ? s0 + q2 : 0, l3 = blk_on ? s0 + q3 : 0;
+    float y0 = __shfl(xi, l0), y1 = __shfl(xi, l1), y2 = __shfl(xi, l2), y3 = __shfl(xi, l3);
+    if (blk_on) {
+      rgf4 e1 = B4[q1 * st4 + sb], e2 = B4[q2 * st4 + sb], e3 = B4[q3 * st4 + sb];
+      float i00 = s.dinv[s0 + j0], i11 = nb > 1 ? s.dinv[s0 + q1] : 0.f, i22 = nb > 2 ? s.dinv[s0 + q2] : 0.f, i33 = nb > 3 ? s.dinv[s0 + q3] : 0.f;
+      float x0 = y0 * i00, x1 = (y1 - e1.x * x0) * i11, x2 = (y2 - e2.x * x0 - e2.y * x1) * i22, x3 = (y3 - e3.x * x0 - e3.y * x1 - e3.z * x2) * i33;
+      int rr = r - j0;
+      if (rr >= 4) { rgf4 own = B4[r * st4 + sb]; xi -= own.x * x0 + own.y * x1 + own.z * x2 + own.w * x3; }
+      else if (rr == 0) xi = x0; else if (rr == 1) xi = x1; else if (rr == 2) xi = x2; else if (rr == 3) xi = x3;
+    }
   }
-  for (int jj = m.maxtree - 1; jj >= 0; jj--) {
-    float xj = __shfl(xi * inv, (on && jj < n) ? s0 + jj : 0);
-    if (on && jj < n) { if (jj_me == jj) xi = xj; else if (jj_me < jj) xi -= blk0[jj * stride + jj_me] * xj; }
+  for (int sb = nsteps - 1; sb >= 0; sb--) {
+    int j0 = sb << 2, nb = n - j0; bool blk_on = on && nb > 0;
+    int q1 = j0 + 1 < n ? j0 + 1 : n - 1, q2 = j0 + 2 < n ? j0 + 2 : n - 1, q3 = j0 + 3 < n ? j0 + 3 : n - 1;
+    int l0 = blk_on ? s0 + j0 : 0, l1 = blk_on ? s0 + q1 : 0, l2 = blk_on ? s0 + q2 : 0, l3 = blk_on ? s0 + q3 : 0;
+    float y0 = __shfl(xi, l0), y1 = __shfl(xi, l1), y2 = __shfl(xi, l2), y3 = __shfl(xi, l3);
+    if (blk_on) {
+      rgf4 e1 = B4[q1 * st4 + sb], e2 = B4[q2 * st4 + sb], e3 = B4[q3 * st4 + sb];
+      float i00 = s.dinv[s0 + j0], i11 = nb > 1 ? s.dinv[s0 + q1] : 0.f, i22 = nb > 2 ? s.dinv[s0 + q2] : 0.f, i33 = nb > 3 ? s.dinv[s0 + q3] : 0.f;
+      float l10 = nb > 1 ? e1.x : 0.f, l20 = nb > 2 ? e2.x : 0.f, l21 = nb > 2 ? e2.y : 0.f, l30 = nb > 3 ? e3.x : 0.f, l31 = nb > 3 ? e3.y : 0.f, l32 = nb > 3 ? e3.z : 0.f;
+      float x3 = y3 * i33, x2 = (y2 - l32 * x3) * i22, x1 = (y1 - l21 * x2 - l31 * x3) * i11, x0 = (y0 - l10 * x1 - l20 * x2 - l30 * x3) * i00;
+      int rr = r - j0;
+      if (rr < 0) xi -= Bf[j0 * st + r] * x0 + (nb > 1 ? Bf[q1 * st + r] * x1 : 0.f) + (nb > 2 ? Bf[q2 * st + r] * x2 : 0.f) + (nb > 3 ? Bf[q3 * st + r] * x3 : 0.f);
+      else if (rr == 0) xi = x0; else if (rr == 1) xi = x1; else if (rr == 2) xi = x2; else if (rr == 3) xi = x3;
+    }
   }
   if (on) x[d] = xi;
+  if (bad) s.status |= RG_STATUS_BAD_FACTOR;
   SYNC();
 }
 
@@ -1287,30 +1380,33 @@ __device__ __forceinline__ int rg_solve(const RgModelDev& m, RgLds& s, int& nefc
   float tol = fmaxf(m.tolerance, 1e-7f);
   PFOR(i, nvc) { int d = s.c2d[i]; s.as[i] = s.qacc_smooth[d]; s.fs[i] = s.qfrc_smooth[d]; s.a[i] = s.warm[d]; }
   SYNC();
-  // warm start: the better of qacc_warmstart and qacc_smooth
+  // warm start: the better of qacc_smooth and qacc_warmstart (evaluated last, so Ma / jar are left valid for it)
   float cost_pick[2];
   for (int pass = 0; pass < 2; pass++) {
-    const float* a = pass == 0 ? s.a : s.as;
+    const float* a = pass == 0 ? s.as : s.a;
     rg_M_mul(m, s, a, s.Ma);
     rg_J_mul(m, s, a, false);
     float g = 0; PFOR(i, nvc) g += 0.5f * (s.Ma[i] - s.fs[i]) * (a[i] - s.as[i]);
     g = wave_sum(g);
     cost_pick[pass] = g + rg_constraint_update(m, s);
   }
-  if (!(cost_pick[0] < cost_pick[1])) { PFOR(i, nvc) s.a[i] = s.as[i]; }
-  SYNC();
-  float cost = 0, oldcost = 0; int iters = 0;
-  for (int iter = 0;; iter++) {
+  if (!(cost_pick[1] < cost_pick[0])) {
+    PFOR(i, nvc) s.a[i] = s.as[i];
+    SYNC();
     rg_M_mul(m, s, s.a, s.Ma);
     rg_J_mul(m, s, s.a, false);
+  }
+  // Invariant at the top of every iteration: Ma = M a and jar = J a - aref (both linear in a, so they are
+  // advanced by alpha * (M s, J s) after the line search instead of being recomputed).
+  float cost = 0, oldcost = 0; int iters = 0;
+  for (int iter = 0;; iter++) {
     float gauss = 0; PFOR(i, nvc) gauss += 0.5f * (s.Ma[i] - s.fs[i]) * (s.a[i] - s.as[i]);
     gauss = wave_sum(gauss);
     float cc = rg_constraint_update(m, s);
     oldcost = cost; cost = gauss + cc;
     rg_JT_force(m, s, s.jtf);
-    float gn = 0; PFOR(i, nvc) { float gi = s.Ma[i] - s.fs[i] - s.jtf[i]; s.grad[i] = gi; gn += gi * gi; }
+    float gn = 0; PFOR(i, nvc) { float gi = s.Ma[i] - s.fs[i] - s.jtf[i]; s.search[i] = -gi; gn += gi * gi; }
     gn = sqrtf(wave_sum(gn)) * scale;
-    SYNC();
 #ifdef RG_EMUL_TRACE
     if (LANE == 0) printf("  newton it %d cost %.9e gn %.3e improvement %.3e\n", iter, cost, gn, scale * (oldcost - cost));
 #endif
@@ -1318,12 +1414,12 @@ __device__ __forceinline__ int rg_solve(const RgModelDev& m, RgLds& s, int& nefc
     if (gn < tol || iter >= m.iterations) break;
     iters = iter + 1;
     PROFS(12);
-    // H = M + J' D J over the quadratic rows
+    // H = M + J' D J over the quadratic rows (LDS atomics from one wave: in-order, deterministic)
     for (int w = LANE; w < nvc * hs; w += RG_WAVE) s.H[w] = 0.f;
     SYNC();
-    PFOR(i, nvc) {
-      int blk = m.c_blk[i], n = (blk >> 24) & 255; const float* row = s.M + (blk & 0xFFFF); float* hrow = s.H + i * hs + ((blk >> 16) & 255);
-      for (int k = 0; k < n; k++) hrow[k] = row[k];
+    for (int w = LANE; w < nvc * 32; w += RG_WAVE) {
+      int i = w >> 5, k = w & 31, blk = s.cblk[i];
+      if (k < ((blk >> 24) & 255)) s.H[i * hs + ((blk >> 16) & 255) + k] = s.M[(blk & 0xFFFF) + k];
     }
     SYNC();
     PFOR(r, ns) if (s.r_D[r] > 0 && s.r_quad[r]) srow_hess(m, s, r, s.r_D[r]);
@@ -1338,20 +1434,17 @@ __device__ __forceinline__ int rg_solve(const RgModelDev& m, RgLds& s, int& nefc
       }
       if (cn == 0) continue;
       const float* Bc = s.c_pool + s.c_off[c];
-      for (int w = LANE; w < nnz * nnz; w += RG_WAVE) {
-        int a = w / nnz, b = w - a * nnz;
+      for (int a = LANE >> 4, b = LANE & 15; a < nnz; a += 4) {   // nnz <= RG_W < 16: 4 rows of the block per pass
+        if (b >= nnz) continue;
         float na = Bc[a], nbv = Bc[b], v = cn * na * nbv;
         for (int k = 0; k + 1 < nb; k++) { float ta = Bc[(k + 1) * nnz + a], tb = Bc[(k + 1) * nnz + b]; v += ck[k] * (na * tb + ta * nbv) + cd[k] * ta * tb; }
-        s.H[s.c_idx[c * RG_W + a] * hs + s.c_idx[c * RG_W + b]] += v;
+        atomicAdd(s.H + s.c_idx[c * RG_W + a] * hs + s.c_idx[c * RG_W + b], v);
       }
-      SYNC();
     }
     SYNC();
     PROFS(13);
     rg_chol(m, s);
     PROFS(14);
-    PFOR(i, nvc) s.search[i] = -s.grad[i];
-    SYNC();
     rg_chol_solve(m, s, s.search);
     PROFS(15);
     // exact line search along `search`
@@ -1381,7 +1474,9 @@ __device__ __forceinline__ int rg_solve(const RgModelDev& m, RgLds& s, int& nefc
     if (LANE == 0) printf("     alpha %.6e p0.grad %.3e p0.hess %.3e gtol %.3e\n", alpha, p0.grad, p0.hess, gtol);
 #endif
     if (alpha == 0) break;
-    PFOR(i, nvc) s.a[i] += alpha * s.search[i];
+    PFOR(i, nvc) { s.a[i] += alpha * s.search[i]; s.Ma[i] += alpha * s.Mv[i]; }
+    PFOR(r, ns) if (s.r_D[r] > 0) s.r_jar[r] += alpha * s.r_jv[r];
+    for (int w = LANE; w < ncon * 6; w += RG_WAVE) s.p_jar[w] += alpha * s.p_jv[w];
     SYNC();
     PROFS(10);
   }
