@@ -80,6 +80,11 @@ int rg_batch_reset(rg_batch* b);
  *   nsubsteps    mj_step calls (MjSim.nsubsteps, mujoco_xml.py:249-260 / robot_env.py:132)
  *   nforward_ticks number of state-less mj_forward calls the reference makes afterwards (3 per env.step)
  *   flags        bit0: write the RG_F_DEBUG stage dump of the first substep
+ *                bit1: accumulate per-stage cycle counters into the RG_F_DEBUG contact region (profiling)
+ *                bit2: ignore the cached pair distance bounds (every pair goes through the sphere/box tests
+ *                      each substep; results are bit-identical either way — test hook for that claim)
+ *                bit3: hull support points by scanning every vertex instead of the per-direction-cell
+ *                      candidate lists (bit-identical as well; test hook)
  *   stream       hipStream_t (NULL = default stream).  Asynchronous. */
 int rg_batch_step(rg_batch* b, const float* action_dev, const float* goal_quat_dev, float* obs_dev, float* goal_dist_dev,
                   const int* active_dev, int nsubsteps, int nforward_ticks, int flags, void* stream);

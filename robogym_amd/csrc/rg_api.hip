@@ -147,13 +147,29 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
   UPF(qpos0, "qpos0"); m->qpos0 = fv; UPF(qpos_spring, "qpos_spring");
   UPI(lvl_dof, "k_lvl_dof"); UPI(lvl_dof_adr, "k_lvl_dof_adr"); UPI(M_i, "k_M_i"); UPI(M_j, "k_M_j"); UPI(M_lvl_adr, "k_M_lvl_adr");
   UPI(desc_adr, "k_desc_adr"); UPI(desc, "k_desc");
-  UPI(geom_type, "geom_type"); UPI(geom_bodyid, "geom_bodyid"); UPI(geom_dataid, "geom_dataid");
+  UPI(geom_type, "geom_type"); UPI(geom_bodyid, "geom_bodyid"); UPI(geom_dataid, "geom_dataid"); UPI(body_geomadr, "body_geomadr"); UPI(body_geomnum, "body_geomnum");
   UPF(geom_size, "geom_size"); UPF(geom_rbound, "geom_rbound"); UPF(geom_pos, "geom_pos"); UPF(geom_quat, "geom_quat"); UPF(geom_aabb, "k_geom_aabb");
   UPI(site_bodyid, "site_bodyid"); UPF(site_pos, "site_pos");
   UPI(mesh_vertadr, "mesh_vertadr"); UPI(mesh_vertnum, "mesh_vertnum");
   { GF("mesh_vert"); std::vector<float> v4(fv.size() / 3 * 4, 0.f);  // 16-byte vertex records: one dwordx4 load per vertex
     for (size_t i = 0; i < fv.size() / 3; i++) { v4[4 * i] = fv[3 * i]; v4[4 * i + 1] = fv[3 * i + 1]; v4[4 * i + 2] = fv[3 * i + 2]; }
-    if (!upload<float>(m, v4, &d.mesh_vert)) return bail("hipMalloc failed", m); }
+    if (!upload<float>(m, v4, &d.mesh_vert)) return bail("hipMalloc failed", m);
+    // support-cell records: the cell lists' vertices copied out so that one cell is one contiguous run
+    std::vector<int> vadr, cadr, vidx;
+    if (!get_i(B, "mesh_vertadr", vadr, e) || !get_i(B, "k_mesh_cell_adr", cadr, e) || !get_i(B, "k_mesh_cell_vidx", vidx, e)) return bail(e, m);
+    if (cadr.size() != (size_t)d.nmesh * RG_NCELL) return bail("k_mesh_cell_adr has the wrong size (RG_CELLN mismatch?)", m);
+    std::vector<float> rec(vidx.size() * 4 + 4, 0.f);
+    for (int mi = 0; mi < d.nmesh; mi++) for (int c = 0; c < RG_NCELL; c++) {
+      int e = cadr[(size_t)mi * RG_NCELL + c], start = e >> 8, cnt = e & 255;
+      if (cnt < 1 || (size_t)(start + cnt) > vidx.size()) return bail("bad support cell", m);
+      for (int k = 0; k < cnt; k++) {
+        int vi = vidx[start + k]; size_t src = (size_t)(vadr[mi] + vi);
+        if (vi < 0 || src * 3 + 2 >= fv.size()) return bail("bad support cell vertex", m);
+        float* o = rec.data() + 4 * (size_t)(start + k);
+        o[0] = fv[3 * src]; o[1] = fv[3 * src + 1]; o[2] = fv[3 * src + 2]; memcpy(o + 3, &vi, 4);
+      }
+    }
+    if (!upload<int>(m, cadr, &d.mesh_cell_adr) || !upload<float>(m, rec, &d.mesh_cell_vert)) return bail("hipMalloc failed", m); }
   UPI(pair_geom, "k_pair_geom"); UPF(pair_prm, "k_pair_prm");
   UPI(tendon_adr, "tendon_adr"); UPI(tendon_num, "tendon_num"); UPI(wrap_type, "wrap_type"); UPI(wrap_objid, "wrap_objid"); UPI(ten_dofs, "k_ten_dofs");
   UPF(wrap_prm, "wrap_prm"); UPF(tendon_range, "tendon_range"); UPF(tendon_margin, "tendon_margin"); UPF(tendon_stiffness, "tendon_stiffness");
@@ -212,7 +228,8 @@ rg_batch* rg_batch_create(const rg_model* m, int B, int device) {
   s.status = (uint32_t*)balloc(b, (size_t)B * 4); s.stats = (float*)balloc(b, (size_t)B * 16);
   s.dbg = (float*)balloc(b, (size_t)B * RG_DBG_SIZE * 4);
   s.sepdir = (float*)balloc(b, (size_t)B * (d.npair > 0 ? d.npair : 1) * 16);
-  if (!s.qpos || !s.qvel || !s.ctrl || !s.pid || !s.qacc_warmstart || !s.time || !s.status || !s.stats || !s.dbg || !s.sepdir) { fail("hipMalloc failed"); rg_batch_free(b); return nullptr; }
+  s.pairlb = (float*)balloc(b, (size_t)B * (d.npair > 0 ? d.npair : 1) * 4);
+  if (!s.qpos || !s.qvel || !s.ctrl || !s.pid || !s.qacc_warmstart || !s.time || !s.status || !s.stats || !s.dbg || !s.sepdir || !s.pairlb) { fail("hipMalloc failed"); rg_batch_free(b); return nullptr; }
   if (rg_batch_reset(b) != 0) { rg_batch_free(b); return nullptr; }
   return b;
 }
@@ -231,6 +248,7 @@ int rg_batch_reset(rg_batch* b) {
   HIPCHK(hipMemset(s.qvel, 0, (size_t)s.B * d.nv * 4)); HIPCHK(hipMemset(s.ctrl, 0, (size_t)s.B * d.nu * 4));
   HIPCHK(hipMemset(s.pid, 0, (size_t)s.B * 3 * d.nu * 4)); HIPCHK(hipMemset(s.qacc_warmstart, 0, (size_t)s.B * d.nv * 4));
   HIPCHK(hipMemset(s.time, 0, (size_t)s.B * 4)); HIPCHK(hipMemset(s.status, 0, (size_t)s.B * 4)); HIPCHK(hipMemset(s.stats, 0, (size_t)s.B * 16));
+  HIPCHK(hipMemset(s.pairlb, 0, (size_t)s.B * (d.npair > 0 ? d.npair : 1) * 4));
   return 0;
 }
 
@@ -274,7 +292,11 @@ int rg_batch_copy(rg_batch* b, int field, void* ptr, int to_batch, int ptr_is_de
     default: return fail("rg_batch_copy: unknown field");
   }
   size_t bytes = n * 4 * (size_t)s.B;
-  if (to_batch) HIPCHK(hipMemcpy(p, ptr, bytes, ptr_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  if (to_batch) {
+    HIPCHK(hipMemcpy(p, ptr, bytes, ptr_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    // positions changed behind the kernel's back: the cached pair distance bounds are void
+    if (field == RG_F_QPOS) HIPCHK(hipMemset(s.pairlb, 0, (size_t)s.B * (d.npair > 0 ? d.npair : 1) * 4));
+  }
   else HIPCHK(hipMemcpy(ptr, p, bytes, ptr_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
   return 0;
 }

@@ -60,11 +60,12 @@ struct RgLds {
       union {  // slot A
         struct { float xpos[RG_MAXBODY * 3], xquat[RG_MAXBODY * 4], xmat[RG_MAXBODY * 9], xipos[RG_MAXBODY * 3], xanchor[RG_MAXJNT * 3], xaxis[RG_MAXJNT * 3], spos[RG_MAXSITE * 3]; };
         struct { float crb[RG_MAXBODY * 10]; };
-        struct { float cdofdot[RG_MAXNV * 6], cacc[RG_MAXBODY * 6], cfrc[RG_MAXBODY * 6], tenfrc[RG_MAXTEN], tenvel[RG_MAXTEN], qfrc_passive[RG_MAXNV], qfrc_bias[RG_MAXNV], qfrc_act[RG_MAXNV]; };
+        struct { float cdofdot[RG_MAXNV * 6], cacc[RG_MAXBODY * 6], cfrc[RG_MAXBODY * 6], tenfrc[RG_MAXTEN], tenvel[RG_MAXTEN], qfrc_passive[RG_MAXNV], qfrc_bias[RG_MAXNV], qfrc_act[RG_MAXNV]; short tlist[RG_TLIST]; };
       };
       float gpos[RG_MAXGEOM * 3], gmat[RG_MAXGEOM * 9];  // slot B
       float cinert[RG_MAXBODY * 10], cdof[RG_MAXNV * 6];  // slot C (alive from com_pos to the constraint rows)
-      short cand[RG_MAXCAND], cand2[RG_MAXCAND];          // slot D
+      short cand[RG_MAXCAND], cand2[RG_MAXCAND2];         // slot D
+      float gspeed[RG_MAXGEOM];  // bound on the speed of any point of the geom (velocity stage -> broadphase)
       float c_dist[RG_MAXCON], c_pos[RG_MAXCON * 3], c_normal[RG_MAXCON * 3];
     };
     struct {  // ---- slv
@@ -156,17 +157,21 @@ __device__ __forceinline__ int wave_min_i(int v) {
 // value of lane `src` (wave-uniform index) in every lane
 __device__ __forceinline__ float lane_bcast(float v, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); }
 #endif
-// all-reduce inside a 16-lane DPP row (every lane of the row ends up with the result): row rotations
+// all-reduce inside a group of G = 16 lanes (one DPP row: row rotations) or G = 8 lanes (half a row: two
+// quad permutes and the half-row mirror); every lane of the group ends up with the result.  Only the
+// group has to be convergent.
 #ifdef RG_EMUL
-__device__ __forceinline__ float row_max(float v) { for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
-__device__ __forceinline__ int row_min_i(int v) { for (int o = 8; o > 0; o >>= 1) { int t = __shfl_xor(v, o); v = t < v ? t : v; } return v; }
+template <int G> __device__ __forceinline__ float grp_max(float v) { for (int o = G / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
+template <int G> __device__ __forceinline__ int grp_min_i(int v) { for (int o = G / 2; o > 0; o >>= 1) { int t = __shfl_xor(v, o); v = t < v ? t : v; } return v; }
 #else
-__device__ __forceinline__ float row_max(float v) {
-  v = fmaxf(v, dpp_f<0x128, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x124, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x122, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x121, 0xf>(v, v));
+template <int G> __device__ __forceinline__ float grp_max(float v) {
+  if (G == 16) { v = fmaxf(v, dpp_f<0x128, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x124, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x122, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x121, 0xf>(v, v)); }
+  else { v = fmaxf(v, dpp_f<0xB1, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x4E, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x141, 0xf>(v, v)); }
   return v;
 }
-__device__ __forceinline__ int row_min_i(int v) {
-  v = imin(v, dpp_i<0x128, 0xf>(v, v)); v = imin(v, dpp_i<0x124, 0xf>(v, v)); v = imin(v, dpp_i<0x122, 0xf>(v, v)); v = imin(v, dpp_i<0x121, 0xf>(v, v));
+template <int G> __device__ __forceinline__ int grp_min_i(int v) {
+  if (G == 16) { v = imin(v, dpp_i<0x128, 0xf>(v, v)); v = imin(v, dpp_i<0x124, 0xf>(v, v)); v = imin(v, dpp_i<0x122, 0xf>(v, v)); v = imin(v, dpp_i<0x121, 0xf>(v, v)); }
+  else { v = imin(v, dpp_i<0xB1, 0xf>(v, v)); v = imin(v, dpp_i<0x4E, 0xf>(v, v)); v = imin(v, dpp_i<0x141, 0xf>(v, v)); }
   return v;
 }
 #endif
@@ -453,18 +458,19 @@ __device__ __forceinline__ void rg_crb(const RgModelDev& m, RgLds& s, const int*
 }
 
 // ------------------------------------------------------------------------------------------------- collision
-struct SupPt { v3 v, v1, v2; };
-struct MprGeom { int type; const float* mat; v3 pos; v3 size; const float* vert; int nvert; float margin; float* prof; };
+struct SupPt { v3 v, s; };  // v = v1 - v2 (Minkowski difference), s = v1 + v2 (all the contact position needs)
+struct MprGeom { int type; const float* mat; v3 pos; v3 size; const float* vert; int nvert; float margin; float* prof; const int* celladr; const rgf4* cellvert; };
 
 // per-lane scan of a hull's vertices: 16-byte records (one dwordx4 load per vertex), four independent
 // loads in flight per lane; out-of-range slots re-read the last vertex (harmless for a max).
-// G lanes cooperate on one hull (G = 64: the wave, G = 16: one DPP row, four MPR queries per wave).
+// G lanes cooperate on one hull (G = 64: the wave; G = 16 / 8: a DPP row / half row, 4 / 8 MPR queries per wave).
+// one fixed fused sequence, so that every scan variant ranks the vertices identically
+__device__ __forceinline__ float vdot(v3 d, const rgf4& a) { return __builtin_fmaf(d.z, a.z, __builtin_fmaf(d.y, a.y, d.x * a.x)); }
 template <int G> __device__ __forceinline__ void scan_batch(const rgf4* vert, int nvert, int base, v3 ld, float& bv, int& bi, v3& bp) {
   int i0 = base + (LANE & (G - 1)), last = nvert - 1;
   int j0 = i0 < last ? i0 : last, j1 = i0 + G < last ? i0 + G : last, j2 = i0 + 2 * G < last ? i0 + 2 * G : last, j3 = i0 + 3 * G < last ? i0 + 3 * G : last;
   rgf4 a = vert[j0], b = vert[j1], c = vert[j2], d = vert[j3];
-  float da = ld.x * a.x + ld.y * a.y + ld.z * a.z, db = ld.x * b.x + ld.y * b.y + ld.z * b.z;
-  float dc = ld.x * c.x + ld.y * c.y + ld.z * c.z, dd = ld.x * d.x + ld.y * d.y + ld.z * d.z;
+  float da = vdot(ld, a), db = vdot(ld, b), dc = vdot(ld, c), dd = vdot(ld, d);
   if (da > bv) { bv = da; bi = j0; bp = mk3(a.x, a.y, a.z); }
   if (db > bv) { bv = db; bi = j1; bp = mk3(b.x, b.y, b.z); }
   if (dc > bv) { bv = dc; bi = j2; bp = mk3(c.x, c.y, c.z); }
@@ -472,6 +478,35 @@ template <int G> __device__ __forceinline__ void scan_batch(const rgf4* vert, in
 }
 template <int G> __device__ __forceinline__ void scan_verts(const rgf4* vert, int nvert, v3 ld, float& bv, int& bi, v3& bp) {
   for (int base = 0; base < nvert; base += 4 * G) scan_batch<G>(vert, nvert, base, ld, bv, bi, bp);
+}
+// direction cell of a (hull-local) direction: cube-map face and RG_CELLN x RG_CELLN grid on it
+// (kernel_tables.py _direction_cells is the host-side statement of the same arithmetic)
+__device__ __forceinline__ int dir_cell(v3 ld) {
+  float ax = fabsf(ld.x), ay = fabsf(ld.y), az = fabsf(ld.z);
+  int axis = ax >= ay ? (ax >= az ? 0 : 2) : (ay >= az ? 1 : 2);
+  float mj = axis == 0 ? ld.x : (axis == 1 ? ld.y : ld.z), a = axis == 0 ? ld.y : (axis == 1 ? ld.z : ld.x), b = axis == 0 ? ld.z : (axis == 1 ? ld.x : ld.y);
+  float inv = (0.5f * RG_CELLN) / fmaxf(fabsf(mj), 1e-30f);
+  int iu = (int)(a * inv + 0.5f * RG_CELLN), iv = (int)(b * inv + 0.5f * RG_CELLN);
+  iu = iu < 0 ? 0 : (iu > RG_CELLN - 1 ? RG_CELLN - 1 : iu); iv = iv < 0 ? 0 : (iv > RG_CELLN - 1 ? RG_CELLN - 1 : iv);
+  return ((2 * axis + (mj < 0 ? 1 : 0)) * RG_CELLN + iu) * RG_CELLN + iv;
+}
+// the same arg-max restricted to the cell's candidate list (typically 3-6 records instead of 60-300
+// vertices; the list provably contains every vertex that can win, so the result is bit-identical)
+template <int G> __device__ __forceinline__ void scan_cell(const int* celladr, const rgf4* cellvert, v3 ld, float& bv, int& bi, v3& bp) {
+  int e = celladr[dir_cell(ld)], cnt = e & 255, last = cnt - 1;
+  const rgf4* rec = cellvert + (e >> 8);
+  for (int base = 0; base < cnt; base += 2 * G) {
+    int i0 = base + (LANE & (G - 1)), j0 = i0 < last ? i0 : last, j1 = i0 + G < last ? i0 + G : last;
+    rgf4 a = rec[j0], b = rec[j1];
+    float da = vdot(ld, a), db = vdot(ld, b);
+    int ia = __builtin_bit_cast(int, a.w), ib = __builtin_bit_cast(int, b.w);
+    if (da > bv) { bv = da; bi = ia; bp = mk3(a.x, a.y, a.z); }   // records ascend in vertex index: first max = lowest index
+    if (db > bv) { bv = db; bi = ib; bp = mk3(b.x, b.y, b.z); }
+  }
+}
+template <int G> __device__ __forceinline__ void scan_hull(const MprGeom& g, v3 ld, float& bv, int& bi, v3& bp) {
+  if (g.celladr) scan_cell<G>(g.celladr, g.cellvert, ld, bv, bi, bp);
+  else scan_verts<G>((const rgf4*)g.vert, g.nvert, ld, bv, bi, bp);
 }
 // arg-max over the G cooperating lanes (lowest vertex index on ties, as a serial first-max scan); the
 // winner's coordinates come from the registers of a lane that scanned it
@@ -482,10 +517,10 @@ template <int G> __device__ __forceinline__ v3 pick_vert(float bv, int bi, v3 bp
     int wl = wave_min_i((bv == vm && bi == wi) ? LANE : 0x7fffffff);
     return mk3(lane_bcast(bp.x, wl), lane_bcast(bp.y, wl), lane_bcast(bp.z, wl));
   } else {
-    float vm = row_max(bv);
-    int wi = row_min_i(bv == vm ? bi : 0x7fffffff);
+    float vm = grp_max<G>(bv);
+    int wi = grp_min_i<G>(bv == vm ? bi : 0x7fffffff);
     bool win = bv == vm && bi == wi;  // several lanes may hold the same (clamped) vertex: identical coordinates
-    return mk3(row_max(win ? bp.x : -3.0e38f), row_max(win ? bp.y : -3.0e38f), row_max(win ? bp.z : -3.0e38f));
+    return mk3(grp_max<G>(win ? bp.x : -3.0e38f), grp_max<G>(win ? bp.y : -3.0e38f), grp_max<G>(win ? bp.z : -3.0e38f));
   }
 }
 __device__ __forceinline__ v3 support_primitive(const MprGeom& g, v3 ld) {
@@ -509,7 +544,7 @@ template <int G> __device__ __forceinline__ v3 rg_support(const MprGeom& g, v3 d
   v3 ld = mulmT(g.mat, dir), lr;
   if (g.type == RG_GEOM_MESH) {
     float bv = -3.0e38f; int bi = 0x7fffffff; v3 bp = mk3(0, 0, 0);
-    scan_verts<G>((const rgf4*)g.vert, g.nvert, ld, bv, bi, bp);
+    scan_hull<G>(g, ld, bv, bi, bp);
     lr = pick_vert<G>(bv, bi, bp);
   } else lr = support_primitive(g, ld);
   lr = lr + ld * g.margin;
@@ -522,22 +557,22 @@ template <int G> __device__ __forceinline__ void mpr_support(const MprGeom& a, c
   v3 la = mulmT(a.mat, dir), lb = mulmT(b.mat, dir * -1.0f), ra, rb;
   float av = -3.0e38f, bvv = -3.0e38f; int ai = 0x7fffffff, bi = 0x7fffffff; v3 ap = mk3(0, 0, 0), bp = mk3(0, 0, 0);
   bool am = a.type == RG_GEOM_MESH, bm = b.type == RG_GEOM_MESH;
-  if (am && bm) {
+  if (am && bm && !a.celladr) {
     int nmax = a.nvert > b.nvert ? a.nvert : b.nvert;
     for (int base = 0; base < nmax; base += 4 * G) {  // both hulls' loads are issued before either compare chain
       if (base < a.nvert) scan_batch<G>((const rgf4*)a.vert, a.nvert, base, la, av, ai, ap);
       if (base < b.nvert) scan_batch<G>((const rgf4*)b.vert, b.nvert, base, lb, bvv, bi, bp);
     }
   } else {
-    if (am) scan_verts<G>((const rgf4*)a.vert, a.nvert, la, av, ai, ap);
-    if (bm) scan_verts<G>((const rgf4*)b.vert, b.nvert, lb, bvv, bi, bp);
+    if (am) scan_hull<G>(a, la, av, ai, ap);
+    if (bm) scan_hull<G>(b, lb, bvv, bi, bp);
   }
   long long tt1 = a.prof ? rg_clock() : 0;
   ra = am ? pick_vert<G>(av, ai, ap) : support_primitive(a, la);
   rb = bm ? pick_vert<G>(bvv, bi, bp) : support_primitive(b, lb);
-  p.v1 = mulm(a.mat, ra + la * a.margin) + a.pos;
-  p.v2 = mulm(b.mat, rb + lb * b.margin) + b.pos;
-  p.v = p.v1 - p.v2;
+  v3 w1 = mulm(a.mat, ra + la * a.margin) + a.pos;
+  v3 w2 = mulm(b.mat, rb + lb * b.margin) + b.pos;
+  p.v = w1 - w2; p.s = w1 + w2;
   if (a.prof && LANE == 0) { long long tt2 = rg_clock(); a.prof[20] += 1.f; a.prof[21] += (float)(tt1 - tt0); a.prof[22] += (float)(tt2 - tt1); }
 }
 #define MPR_EPS 1.0e-7f  /* plays the role of libccd's CCD_EPS at fp32 (coordinates are pair-local, |x| ~ 0.1) */
@@ -577,7 +612,7 @@ __device__ __forceinline__ float origin_tri_dist2(v3 a, v3 b, v3 c, v3& w) {
 template <int G> __device__ __forceinline__ bool rg_mpr(const MprGeom& A, const MprGeom& B, int max_iter, float tol, float& depth, v3& dir_out, v3& pos, v3& sep) {
   SupPt p[4], v4;
   sep = mk3(0, 0, 0);
-  p[0].v1 = A.pos; p[0].v2 = B.pos; p[0].v = A.pos - B.pos;
+  p[0].s = A.pos + B.pos; p[0].v = A.pos - B.pos;
   if (mz(p[0].v.x) && mz(p[0].v.y) && mz(p[0].v.z)) p[0].v.x += 1e-6f;
   v3 dir = normalized(p[0].v * -1.0f);
   mpr_support<G>(A, B, dir, p[1]);
@@ -585,7 +620,7 @@ template <int G> __device__ __forceinline__ bool rg_mpr(const MprGeom& A, const 
   if (dt <= 0) { sep = dir; return false; }
   dir = cross(p[0].v, p[1].v);
   if (dot(dir, dir) < 1e-30f) {
-    pos = (p[1].v1 + p[1].v2) * 0.5f;
+    pos = p[1].s * 0.5f;
     if (dot(p[1].v, p[1].v) < 1e-30f) { depth = 0; dir_out = mk3(0, 0, 0); return true; }
     depth = norm(p[1].v); dir_out = p[1].v * (1.0f / depth);
     return true;
@@ -632,15 +667,17 @@ template <int G> __device__ __forceinline__ bool rg_mpr(const MprGeom& A, const 
         sum = b1 + b2 + b3;
       }
       float inv = 0.5f / sum;
-      pos = (p[0].v1 + p[0].v2) * (b0 * inv) + (p[1].v1 + p[1].v2) * (b1 * inv) + (p[2].v1 + p[2].v2) * (b2 * inv) + (p[3].v1 + p[3].v2) * (b3 * inv);
+      pos = p[0].s * (b0 * inv) + p[1].s * (b1 * inv) + p[2].s * (b2 * inv) + p[3].s * (b3 * inv);
       return true;
     }
     expand_portal(p, v4);
   }
 }
 
-// separating-axis test of two oriented boxes (half extents ea, eb; rotations Ra, Rb; centre offset t in world)
-__device__ __forceinline__ bool obb_overlap(const float* Ra, v3 ea, const float* Rb, v3 eb, v3 tw) {
+// separating-axis test of two oriented boxes (half extents ea, eb; rotations Ra, Rb; centre offset t in world).
+// Returns -1 when no axis separates them, otherwise a lower bound (>= 0) on their distance: the gap along
+// the separating face normal (unit axes), 0 when only an edge-edge axis separates.
+__device__ __forceinline__ float obb_gap(const float* Ra, v3 ea, const float* Rb, v3 eb, v3 tw) {
   float R[9], AR[9];
   for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
     R[3 * i + j] = Ra[i] * Rb[j] + Ra[3 + i] * Rb[3 + j] + Ra[6 + i] * Rb[6 + j];
@@ -648,15 +685,17 @@ __device__ __forceinline__ bool obb_overlap(const float* Ra, v3 ea, const float*
   }
   v3 t = mulmT(Ra, tw);
   float ta[3] = {t.x, t.y, t.z}, a[3] = {ea.x, ea.y, ea.z}, b[3] = {eb.x, eb.y, eb.z};
-  for (int i = 0; i < 3; i++) if (fabsf(ta[i]) > a[i] + b[0] * AR[3 * i] + b[1] * AR[3 * i + 1] + b[2] * AR[3 * i + 2]) return false;
-  for (int j = 0; j < 3; j++) if (fabsf(ta[0] * R[j] + ta[1] * R[3 + j] + ta[2] * R[6 + j]) > a[0] * AR[j] + a[1] * AR[3 + j] + a[2] * AR[6 + j] + b[j]) return false;
+  float gap = -1.f;
+  for (int i = 0; i < 3; i++) gap = fmaxf(gap, fabsf(ta[i]) - (a[i] + b[0] * AR[3 * i] + b[1] * AR[3 * i + 1] + b[2] * AR[3 * i + 2]));
+  for (int j = 0; j < 3; j++) gap = fmaxf(gap, fabsf(ta[0] * R[j] + ta[1] * R[3 + j] + ta[2] * R[6 + j]) - (a[0] * AR[j] + a[1] * AR[3 + j] + a[2] * AR[6 + j] + b[j]));
+  if (gap > 0) return gap;
   for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
     int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
     float ra = a[i1] * AR[3 * i2 + j] + a[i2] * AR[3 * i1 + j];
     float rb = b[j1] * AR[3 * i + j2] + b[j2] * AR[3 * i + j1];
-    if (fabsf(ta[i2] * R[3 * i1 + j] - ta[i1] * R[3 * i2 + j]) > ra + rb) return false;
+    if (fabsf(ta[i2] * R[3 * i1 + j] - ta[i1] * R[3 * i2 + j]) > ra + rb) return 0.f;
   }
-  return true;
+  return -1.f;
 }
 
 __device__ __forceinline__ void make_frame(float* f) {
@@ -678,106 +717,69 @@ __device__ __forceinline__ void add_contact(RgLds& s, int pair, float dist, v3 p
 
 // the two geoms of candidate pair p in pair-local coordinates (origin at geom1's centre: fp32 resolution ~1e-9 m),
 // each inflated by margin/2
-__device__ __forceinline__ void rg_mpr_geoms(const RgModelDev& m, const RgLds& s, int p, MprGeom& A, MprGeom& B) {
+__device__ __forceinline__ void rg_mpr_geoms(const RgModelDev& m, const RgLds& s, int p, MprGeom& A, MprGeom& B, bool cells) {
   int g1 = m.pair_geom[3 * p], g2 = m.pair_geom[3 * p + 1];
   float margin = m.pair_prm[12 * p];
   int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
   A.type = t1; A.mat = s.gmat + 9 * g1; A.size = ld3(m.geom_size + 3 * g1); A.margin = 0.5f * margin; A.pos = mk3(0, 0, 0);
   B.type = t2; B.mat = s.gmat + 9 * g2; B.size = ld3(m.geom_size + 3 * g2); B.margin = 0.5f * margin; B.pos = ld3(s.gpos + 3 * g2) - ld3(s.gpos + 3 * g1);
-  if (t1 == RG_GEOM_MESH) { int id = m.geom_dataid[g1]; A.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; A.nvert = m.mesh_vertnum[id]; } else { A.vert = 0; A.nvert = 0; }
-  if (t2 == RG_GEOM_MESH) { int id = m.geom_dataid[g2]; B.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; B.nvert = m.mesh_vertnum[id]; } else { B.vert = 0; B.nvert = 0; }
+  A.celladr = 0; B.celladr = 0; A.cellvert = B.cellvert = (const rgf4*)m.mesh_cell_vert;
+  if (t1 == RG_GEOM_MESH) { int id = m.geom_dataid[g1]; A.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; A.nvert = m.mesh_vertnum[id]; if (cells) A.celladr = m.mesh_cell_adr + id * RG_NCELL; } else { A.vert = 0; A.nvert = 0; }
+  if (t2 == RG_GEOM_MESH) { int id = m.geom_dataid[g2]; B.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; B.nvert = m.mesh_vertnum[id]; if (cells) B.celladr = m.mesh_cell_adr + id * RG_NCELL; } else { B.vert = 0; B.nvert = 0; }
   A.prof = 0; B.prof = 0;
 }
-__device__ __forceinline__ void rg_collision(const RgModelDev& m, RgLds& s, float* prof, rgf4* sepdir) {
-  long long tb0 = rg_clock();
-  if (LANE == 0) { s.ncand = 0; s.ncon = 0; }
-  SYNC();
-  // broadphase over the static pair list: bounding spheres, then oriented boxes (both conservative,
-  // so the surviving set only prunes MPR calls that would report "no contact")
-  int nround = (m.npair + RG_WAVE - 1) / RG_WAVE;
-  for (int r = 0; r < nround; r++) {
-    int p = r * RG_WAVE + LANE;
-    bool hit = false;
-    if (p < m.npair) {
-      int g1 = m.pair_geom[3 * p], g2 = m.pair_geom[3 * p + 1];
-      float margin = m.pair_prm[12 * p];
-      v3 p1 = ld3(s.gpos + 3 * g1), p2 = ld3(s.gpos + 3 * g2), dif = p2 - p1;
-      if (m.geom_type[g1] == RG_GEOM_PLANE) {
-        const float* R1 = s.gmat + 9 * g1;
-        hit = dot(dif, mk3(R1[2], R1[5], R1[8])) <= m.geom_rbound[g2] + margin;
-      } else {
-        float bound = m.geom_rbound[g1] + m.geom_rbound[g2] + margin;
-        if (dot(dif, dif) <= bound * bound) {
-          float hm = 0.5f * margin + 1e-6f;
-          v3 ea = ld3(m.geom_aabb + 3 * g1) + mk3(hm, hm, hm), eb = ld3(m.geom_aabb + 3 * g2) + mk3(hm, hm, hm);
-          hit = obb_overlap(s.gmat + 9 * g1, ea, s.gmat + 9 * g2, eb, dif);
-        }
-      }
-    }
-    unsigned long long bal = __ballot(hit);
-    int base = s.ncand;
-    SYNC();
-    if (hit) {
-      int slot = base + __popcll(bal & ((1ull << LANE) - 1ull));
-      if (slot < RG_MAXCAND) s.cand[slot] = p; else s.status |= RG_STATUS_CAND_FULL;
-    }
-    if (LANE == 0) { int n = base + __popcll(bal); s.ncand = n < RG_MAXCAND ? n : RG_MAXCAND; }
-    SYNC();
-  }
-  if (prof && LANE == 0) prof[5] += (float)(rg_clock() - tb0);
-  // narrowphase.  Convex pairs run in 16-lane DPP rows, four queries per wave (the portal algebra is
-  // scalar per query; a whole wave per query would execute it 64-fold redundantly).
-  // Phase 1 (uniform cost): MPR's first support test along the centre line for every candidate —
-  // "separated along the centre direction" rejects most OBB-overlapping neighbours.  Survivors are
-  // compacted in order so that phase 2 (full MPR) only runs rows of genuinely close pairs.
-  int ncand = s.ncand;
-  if (LANE == 0) s.ncand2 = 0;
-  SYNC();
-  for (int base = 0; base < ncand; base += 4) {
-    int ci = base + (LANE >> 4);
+template <int G> __device__ __forceinline__ void rg_narrow_phase1(const RgModelDev& m, RgLds& s, rgf4* sepdir, float* pairlb, int ncand, bool cells) {
+  for (int base = 0; base < ncand; base += RG_WAVE / G) {
+    int ci = base + LANE / G;
     bool keep = false; int p = 0;
     if (ci < ncand) {
       p = s.cand[ci];
       int g1 = m.pair_geom[3 * p], g2 = m.pair_geom[3 * p + 1];
       if (m.geom_type[g1] != RG_GEOM_PLANE) {
         MprGeom A, B;
-        rg_mpr_geoms(m, s, p, A, B);
+        rg_mpr_geoms(m, s, p, A, B, cells);
         v3 c0 = A.pos - B.pos;
         if (mz(c0.x) && mz(c0.y) && mz(c0.z)) c0.x += 1e-6f;
         v3 dir = normalized(c0 * -1.0f);
         if (sepdir) { rgf4 cd = sepdir[p]; if (cd.x * cd.x + cd.y * cd.y + cd.z * cd.z > 0.5f) dir = mk3(cd.x, cd.y, cd.z); }  // last substep's separating direction first
-        SupPt p1; mpr_support<16>(A, B, dir, p1);
-        keep = dot(p1.v, dir) > 0;
+        SupPt p1; mpr_support<G>(A, B, dir, p1);
+        float d = dot(p1.v, dir);
+        keep = d > 0;
+        // separated by -d along dir: a lower bound on the distance of the inflated shapes
+        if (!keep && pairlb && (LANE & (G - 1)) == 0) pairlb[p] = fmaxf(-d - 1e-6f, 0.f);
       }
     }
-    bool lead = keep && (LANE & 15) == 0;
+    bool lead = keep && (LANE & (G - 1)) == 0;
     unsigned long long bal = __ballot(lead);
     int cbase = s.ncand2;
     SYNC();
-    if (lead) s.cand2[cbase + __popcll(bal & ((1ull << LANE) - 1ull))] = p;
-    if (LANE == 0) s.ncand2 = cbase + __popcll(bal);
+    if (lead) {
+      int slot = cbase + __popcll(bal & ((1ull << LANE) - 1ull));
+      if (slot < RG_MAXCAND2) s.cand2[slot] = p; else s.status |= RG_STATUS_CAND_FULL;
+    }
+    if (LANE == 0) { int n = cbase + __popcll(bal); s.ncand2 = n < RG_MAXCAND2 ? n : RG_MAXCAND2; }
     SYNC();
   }
-  int ncand2 = s.ncand2;
-  if (prof && LANE == 0) { prof[16] += (float)(rg_clock() - tb0); prof[17] += ncand; prof[18] += ncand2; }
-  for (int base = 0; base < ncand2; base += 4) {
-    int ci = base + (LANE >> 4);
+}
+template <int G> __device__ __forceinline__ void rg_narrow_phase2(const RgModelDev& m, RgLds& s, float* prof, rgf4* sepdir, int ncand2, bool cells) {
+  for (int base = 0; base < ncand2; base += RG_WAVE / G) {
+    int ci = base + LANE / G;
     bool hit = false;
     float depth = 0, margin = 0; v3 dir = mk3(0, 0, 0), pos = mk3(0, 0, 0); int p = 0, dim = 3;
     if (ci < ncand2) {
       p = s.cand2[ci];
       dim = m.pair_geom[3 * p + 2]; margin = m.pair_prm[12 * p];
       MprGeom A, B;
-      rg_mpr_geoms(m, s, p, A, B);
+      rg_mpr_geoms(m, s, p, A, B, cells);
       A.prof = prof;
       v3 sep;
-      hit = rg_mpr<16>(A, B, m.mpr_iterations, m.mpr_tolerance, depth, dir, pos, sep);
-      if (sepdir && (LANE & 15) == 0) { rgf4 cd; cd.x = hit ? 0.f : sep.x; cd.y = hit ? 0.f : sep.y; cd.z = hit ? 0.f : sep.z; cd.w = 0.f; sepdir[p] = cd; }
+      hit = rg_mpr<G>(A, B, m.mpr_iterations, m.mpr_tolerance, depth, dir, pos, sep);
+      if (sepdir && (LANE & (G - 1)) == 0) { rgf4 cd; cd.x = hit ? 0.f : sep.x; cd.y = hit ? 0.f : sep.y; cd.z = hit ? 0.f : sep.z; cd.w = 0.f; sepdir[p] = cd; }
       hit = hit && dot(dir, dir) > 0.25f;
       pos = pos + ld3(s.gpos + 3 * m.pair_geom[3 * p]);
     }
-    // append the rows' contacts in candidate order (row leaders hold the result)
-    bool lead = hit && (LANE & 15) == 0;
+    // append the groups' contacts in candidate order (group leaders hold the result)
+    bool lead = hit && (LANE & (G - 1)) == 0;
     unsigned long long bal = __ballot(lead);
     int cbase = s.ncon;
     SYNC();
@@ -791,6 +793,83 @@ __device__ __forceinline__ void rg_collision(const RgModelDev& m, RgLds& s, floa
     if (LANE == 0) { int n = cbase + __popcll(bal); s.ncon = n < RG_MAXCON ? n : RG_MAXCON; }
     SYNC();
   }
+}
+__device__ __forceinline__ void rg_collision(const RgModelDev& m, RgLds& s, float* prof, rgf4* sepdir, float* pairlb, bool cells) {
+  long long tb0 = rg_clock();
+  if (LANE == 0) { s.ncand = 0; s.ncon = 0; }
+  SYNC();
+  // Broadphase over the static pair list.
+  // Pass 1 (every pair, a few instructions): the cached lower bound on the pair's distance minus this
+  // substep's motion bound (velocity stage: gspeed) — pairs that are still certainly apart stop here.
+  // Pass 2 (pairs whose bound ran out, compacted so that only full rows pay for it): bounding spheres,
+  // then oriented boxes; both conservative, both refresh the bound when they separate the pair.
+  int nround = (m.npair + RG_WAVE - 1) / RG_WAVE;
+  float hb = 1.5f * m.timestep;
+  int nt = 0;
+  for (int r = 0; r < nround; r++) {
+    int p = r * RG_WAVE + LANE;
+    bool need = false;
+    if (p < m.npair) {
+      int g1 = m.pair_geom[3 * p], g2 = m.pair_geom[3 * p + 1];
+      float lb = (pairlb ? pairlb[p] : 0.f) - (hb * (s.gspeed[g1] + s.gspeed[g2]) + 1e-7f);
+      need = !(lb > 0.f);
+      if (!need) pairlb[p] = lb;
+    }
+    unsigned long long nb = __ballot(need);
+    if (need) s.tlist[nt + __popcll(nb & ((1ull << LANE) - 1ull))] = (short)p;
+    nt += __popcll(nb);
+    if (nt <= RG_TLIST - RG_WAVE && r != nround - 1) continue;
+    SYNC();
+    for (int i0 = 0; i0 < nt; i0 += RG_WAVE) {
+      int i = i0 + LANE, q = 0;
+      bool hit = false;
+      if (i < nt) {
+        q = s.tlist[i];
+        int g1 = m.pair_geom[3 * q], g2 = m.pair_geom[3 * q + 1];
+        float margin = m.pair_prm[12 * q], newlb = 0.f;
+        v3 p1 = ld3(s.gpos + 3 * g1), p2 = ld3(s.gpos + 3 * g2), dif = p2 - p1;
+        if (m.geom_type[g1] == RG_GEOM_PLANE) {
+          const float* R1 = s.gmat + 9 * g1;
+          float d = dot(dif, mk3(R1[2], R1[5], R1[8])) - (m.geom_rbound[g2] + margin);
+          hit = d <= 0; newlb = fmaxf(d, 0.f);
+        } else {
+          float d = sqrtf(dot(dif, dif)) - (m.geom_rbound[g1] + m.geom_rbound[g2] + margin);
+          if (d <= 0) {
+            float hm = 0.5f * margin + 1e-6f;
+            v3 ea = ld3(m.geom_aabb + 3 * g1) + mk3(hm, hm, hm), eb = ld3(m.geom_aabb + 3 * g2) + mk3(hm, hm, hm);
+            float og = obb_gap(s.gmat + 9 * g1, ea, s.gmat + 9 * g2, eb, dif);
+            hit = og < 0; newlb = fmaxf(og, 0.f);
+          } else newlb = d;
+        }
+        if (pairlb) pairlb[q] = fmaxf(newlb - 1e-6f, 0.f);
+      }
+      unsigned long long bal = __ballot(hit);
+      int base = s.ncand;
+      SYNC();
+      if (hit) {
+        int slot = base + __popcll(bal & ((1ull << LANE) - 1ull));
+        if (slot < RG_MAXCAND) s.cand[slot] = q; else s.status |= RG_STATUS_CAND_FULL;
+      }
+      if (LANE == 0) { int n = base + __popcll(bal); s.ncand = n < RG_MAXCAND ? n : RG_MAXCAND; }
+      SYNC();
+    }
+    nt = 0;
+  }
+  if (prof && LANE == 0) prof[5] += (float)(rg_clock() - tb0);
+  // narrowphase.  Convex pairs run in groups of G lanes, 64/G queries per wave (the portal algebra is scalar
+  // per query; a whole wave per query would execute it 64-fold redundantly).  G = 16 (a DPP row) scans a
+  // hull twice as fast as G = 8 (half a row) but runs half as many queries at once: picked by queue length.
+  // Phase 1 (uniform cost): one support test per candidate, along the cached separating direction of the
+  // pair or else the centre line — "separated along that direction" rejects most box-overlapping
+  // neighbours.  Survivors are compacted in order so that phase 2 (full MPR) only runs groups of
+  // genuinely close pairs.
+  int ncand = s.ncand;
+  if (LANE == 0) s.ncand2 = 0;
+  SYNC();
+  if (ncand > 4) rg_narrow_phase1<8>(m, s, sepdir, pairlb, ncand, cells); else rg_narrow_phase1<16>(m, s, sepdir, pairlb, ncand, cells);
+  int ncand2 = s.ncand2;
+  if (prof && LANE == 0) { prof[16] += (float)(rg_clock() - tb0); prof[17] += ncand; prof[18] += ncand2; }
+  if (ncand2 > 4) rg_narrow_phase2<8>(m, s, prof, sepdir, ncand2, cells); else rg_narrow_phase2<16>(m, s, prof, sepdir, ncand2, cells);
   if (prof && LANE == 0) prof[19] += (float)(rg_clock() - tb0);
   // plane pairs (rare: something near the floor), whole wave cooperating, one candidate at a time
   for (int ci = 0; ci < ncand; ci++) {
@@ -801,7 +880,7 @@ __device__ __forceinline__ void rg_collision(const RgModelDev& m, RgLds& s, floa
     int t2 = m.geom_type[g2];
     v3 p1 = ld3(s.gpos + 3 * g1), p2 = ld3(s.gpos + 3 * g2);
     MprGeom B;
-    B.type = t2; B.mat = s.gmat + 9 * g2; B.size = ld3(m.geom_size + 3 * g2); B.margin = 0; B.prof = 0;
+    B.type = t2; B.mat = s.gmat + 9 * g2; B.size = ld3(m.geom_size + 3 * g2); B.margin = 0; B.prof = 0; B.celladr = 0; B.cellvert = 0;
     if (t2 == RG_GEOM_MESH) { int id = m.geom_dataid[g2]; B.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; B.nvert = m.mesh_vertnum[id]; } else { B.vert = 0; B.nvert = 0; }
     const float* R1 = s.gmat + 9 * g1;
     v3 n = mk3(R1[2], R1[5], R1[8]);
@@ -845,6 +924,7 @@ __device__ __forceinline__ void rg_velocity(const RgModelDev& m, RgLds& s, const
   }
   SYNC();
   // body velocities / bias accelerations by chain gathers, then body forces
+  PFOR(k, m.body_geomnum[0]) s.gspeed[m.body_geomadr[0] + k] = 0;
   for (int b = 1 + LANE; b < m.nbody; b += RG_WAVE) {
     float cv[6] = {0, 0, 0, 0, 0, 0}, ca[6] = {0, 0, 0, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
     for (int h = 0; h < 2; h++) {
@@ -853,6 +933,12 @@ __device__ __forceinline__ void rg_velocity(const RgModelDev& m, RgLds& s, const
         int a = __builtin_ctz(bits) + 32 * h; bits &= bits - 1; float q = s.qvel[a];
         for (int e = 0; e < 6; e++) { cv[e] += s.cdof[6 * a + e] * q; ca[e] += s.cdofdot[6 * a + e] * q; }
       }
+    }
+    {  // speed bound of the body's geoms: |v(geom centre)| + |omega| * bounding radius
+      v3 w = mk3(cv[0], cv[1], cv[2]), vo = mk3(cv[3], cv[4], cv[5]), og = ld3(s.org + 3 * s.b2org[b]);
+      float wn = norm(w);
+      int ga = m.body_geomadr[b], gn = m.body_geomnum[b];
+      for (int k = 0; k < gn; k++) s.gspeed[ga + k] = norm(vo + cross(w, ld3(s.gpos + 3 * (ga + k)) - og)) + wn * m.geom_rbound[ga + k];
     }
     float t1[6], t2[6], t3[6];
     mul_inert_vec(t1, s.cinert + 10 * b, ca);
@@ -1580,19 +1666,26 @@ __global__ void __launch_bounds__(RG_WAVE, 2) rg_step_kernel(RgModelDev m, RgAux
     if (wave_sum(bd) > 0) { bad = true; break; }
     long long t0 = rg_clock(), t1;
 #define PROF(k) do { if (flags & 2) { t1 = rg_clock(); if (LANE == 0) s.prof[k] += (float)(t1 - t0); t0 = t1; } } while (0)
+#ifdef RG_EMUL_POISON
+    { unsigned int* u = (unsigned int*)s.H; int nw = (int)((sizeof(RgLds) - ((char*)s.H - (char*)&s)) / 4); for (int w = LANE; w < nw; w += RG_WAVE) u[w] = 0x7fc00000u; SYNC(); }
+#endif
     rg_kinematics(m, s); PROF(0);
     rg_com_pos(m, s); PROF(1);
     rg_tendon(m, s); PROF(2);
     if (sub == 0 && (flags & 1) && bt.dbg) rg_dump_kin(m, s, bt.dbg + (size_t)e * RG_DBG_SIZE);
     rg_crb(m, s, x.subtree_adr, x.subtree); PROF(3);
-    rg_collision(m, s, (flags & 2) ? s.prof : (float*)0, bt.sepdir ? (rgf4*)bt.sepdir + (size_t)e * m.npair : (rgf4*)0); PROF(6);
-    if ((flags & 2) && LANE == 0 && (float)s.ncon > s.prof[23]) s.prof[23] = (float)s.ncon;
     rg_velocity(m, s, x.dof_velmask, x.subtree_adr, x.subtree); PROF(7);
+    rg_collision(m, s, (flags & 2) ? s.prof : (float*)0, bt.sepdir ? (rgf4*)bt.sepdir + (size_t)e * m.npair : (rgf4*)0,
+                 (bt.pairlb && !(flags & 4)) ? bt.pairlb + (size_t)e * m.npair : (float*)0, !(flags & 8)); PROF(6);
+    if ((flags & 2) && LANE == 0 && (float)s.ncon > s.prof[23]) s.prof[23] = (float)s.ncon;
     rg_make_constraint(m, s); PROF(8);
     rg_pid(m, s);
     rg_smooth(m, s); PROF(9);
     if (sub == 0 && (flags & 1) && bt.dbg) rg_dump_pos(m, s, bt.dbg + (size_t)e * RG_DBG_SIZE);
     // ---- the position-stage scratch is dead from here on; the solver scratch takes its place
+#ifdef RG_EMUL_POISON
+    { unsigned int* u = (unsigned int*)s.H; int nw = (int)((sizeof(RgLds) - ((char*)s.H - (char*)&s)) / 4); for (int w = LANE; w < nw; w += RG_WAVE) u[w] = 0x7fc00000u; SYNC(); }
+#endif
     rg_block_factor_solve(m, s, (const float*)0, 0.f, s.qacc_smooth); PROF(4);
     int nefc = 0;
     int iters = rg_solve(m, s, nefc, flags); t0 = rg_clock();
@@ -1665,8 +1758,9 @@ __global__ void __launch_bounds__(RG_WAVE) rg_mpr_pair_kernel(RgModelDev m, RgBa
   v3 p1 = ld3(s.gpos + 3 * g1), p2 = ld3(s.gpos + 3 * g2);
   A.type = m.geom_type[g1]; A.mat = s.gmat + 9 * g1; A.size = ld3(m.geom_size + 3 * g1); A.margin = 0.5f * margin; A.pos = mk3(0, 0, 0); A.prof = 0;
   B.type = m.geom_type[g2]; B.mat = s.gmat + 9 * g2; B.size = ld3(m.geom_size + 3 * g2); B.margin = 0.5f * margin; B.pos = p2 - p1; B.prof = 0;
-  if (A.type == RG_GEOM_MESH) { int id = m.geom_dataid[g1]; A.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; A.nvert = m.mesh_vertnum[id]; } else { A.vert = 0; A.nvert = 0; }
-  if (B.type == RG_GEOM_MESH) { int id = m.geom_dataid[g2]; B.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; B.nvert = m.mesh_vertnum[id]; } else { B.vert = 0; B.nvert = 0; }
+  A.celladr = 0; B.celladr = 0; A.cellvert = B.cellvert = (const rgf4*)m.mesh_cell_vert;   // the hook exercises the cell-list supports
+  if (A.type == RG_GEOM_MESH) { int id = m.geom_dataid[g1]; A.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; A.nvert = m.mesh_vertnum[id]; A.celladr = m.mesh_cell_adr + id * RG_NCELL; } else { A.vert = 0; A.nvert = 0; }
+  if (B.type == RG_GEOM_MESH) { int id = m.geom_dataid[g2]; B.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; B.nvert = m.mesh_vertnum[id]; B.celladr = m.mesh_cell_adr + id * RG_NCELL; } else { B.vert = 0; B.nvert = 0; }
   float depth = 0; v3 dir = mk3(0, 0, 0), pos = mk3(0, 0, 0);
   v3 sep; bool hit = rg_mpr<64>(A, B, m.mpr_iterations, m.mpr_tolerance, depth, dir, pos, sep);
   if (LANE == 0) {

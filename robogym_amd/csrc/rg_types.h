@@ -19,6 +19,10 @@
 #define RG_MAXNVC 32    // dofs in constrained kinematic trees (the Newton space)
 #define RG_MAXBLK 816   // words of the per-tree dense inertia blocks
 #define RG_MAXCAND 128  // candidate geom pairs surviving the broadphase per substep
+#define RG_MAXCAND2 64  // candidates surviving the first support test (full MPR queries) per substep
+#define RG_CELLN 8      // direction cells: cube map, RG_CELLN x RG_CELLN per face (kernel_tables.py CELL_N)
+#define RG_NCELL (6 * RG_CELLN * RG_CELLN)
+#define RG_TLIST 320    // pairs whose distance bound ran out, queued for the sphere/box tests (drained in chunks)
 #define RG_MAXROW 64    // friction-loss + limit rows
 #define RG_W 14         // max nonzeros of a sparse constraint row
 #define RG_WAVE 64
@@ -57,12 +61,14 @@ struct RgModelDev {
   const float *qpos0, *qpos_spring;
   const int *lvl_dof, *lvl_dof_adr, *M_i, *M_j, *M_lvl_adr, *desc_adr, *desc;
   // geoms / sites / meshes
-  const int *geom_type, *geom_bodyid, *geom_dataid;
+  const int *geom_type, *geom_bodyid, *geom_dataid, *body_geomadr, *body_geomnum;
   const float *geom_size, *geom_rbound, *geom_pos, *geom_quat, *geom_aabb;
   const int* site_bodyid;
   const float *site_pos;
   const int *mesh_vertadr, *mesh_vertnum;
   const float* mesh_vert;
+  const int* mesh_cell_adr;     // [nmesh][RG_NCELL] first record << 8 | count: hull vertices that can be the support point for a direction in the cell
+  const float* mesh_cell_vert;  // 16-byte records x, y, z, vertex index (int bits), ascending index inside a cell
   const int* pair_geom;   // [npair][3] g1, g2, condim
   const float* pair_prm;  // [npair][12] margin, gap, friction3, solref2, solimp5
   // tendons
@@ -98,6 +104,9 @@ struct RgBatchDev {
   float *qpos, *qvel, *ctrl, *pid, *qacc_warmstart, *time;
   uint32_t* status;
   float* sepdir;        // [B][npair][4] cached separating direction per candidate pair (pure cache, not state)
+  float* pairlb;        // [B][npair] lower bound on the distance of the pair's (margin-inflated) geoms, decremented by
+                        // a motion bound every substep; pairs with a positive bound skip all collision tests.
+                        // Zeroed (= unknown) whenever qpos is written from outside.
   // env-step I/O
   const float* action;  // [B][nu] in [-1,1]   (may be null: ctrl used as is)
   const float* goal_quat;  // [B][4]

@@ -219,6 +219,9 @@ def derive_kernel_tables(model, max_row_nnz=16):
             aabb[g] = [s[0], s[0], s[1]]
     A["k_geom_aabb"] = aabb
 
+    # ---------------------------------------------------------------- hull support tables per direction cell
+    A["k_mesh_cell_adr"], A["k_mesh_cell_vidx"] = mesh_support_cells(A["mesh_vertadr"], A["mesh_vertnum"], A["mesh_vert"])
+
     # ---------------------------------------------------------------- tendon static dof supports
     nt = len(A["tendon_adr"])
     tdofs = np.full((nt, 4), -1, dtype=np.int32)
@@ -340,3 +343,60 @@ def derive_kernel_tables(model, max_row_nnz=16):
     A["k_blk_dims"] = _i32([nvc, hs, blk_words, len(trees), max(t[2] for t in trees)])
     A["k_dims"] = _i32([nlevel, ndl, len(Mi), len(pairs), len(A["k_static_body"]), max_nnz])
     return model
+
+
+# ------------------------------------------------------------------------------------ convex-hull support cells
+CELL_N = 8                      # RG_CELLN in rg_types.h: cube-map grid per face, 6 * 8 * 8 = 384 direction cells
+_cell_cache = {}
+
+
+def _direction_cells(n=CELL_N):
+    """(centre, angular radius) of every direction cell.  Cell id = (face * n + iu) * n + iv with
+    face = 2 * axis + (direction[axis] < 0), u / v the (axis+1)%3 / (axis+2)%3 components divided by |major|
+    — the same arithmetic as dir_cell() in rg_kernel.h."""
+    out = []
+    for f in range(6):
+        ax, sg = f // 2, (1.0 if f % 2 == 0 else -1.0)
+        for iu in range(n):
+            for iv in range(n):
+                corners = []
+                for du in (0, 1):
+                    for dv in (0, 1):
+                        x = np.zeros(3)
+                        x[ax], x[(ax + 1) % 3], x[(ax + 2) % 3] = sg, -1 + 2 * (iu + du) / n, -1 + 2 * (iv + dv) / n
+                        corners.append(x / np.linalg.norm(x))
+                corners = np.array(corners)
+                c = corners.mean(0)
+                c /= np.linalg.norm(c)
+                rho = np.arccos(np.clip(corners @ c, -1, 1)).max() + 2e-3  # slack: fp32 cell assignment at the borders
+                out.append((c, rho))
+    return out
+
+
+def mesh_support_cells(vertadr, vertnum, vert):
+    """For every mesh and direction cell: the hull vertices that can be the support point for SOME direction
+    of the cell (ascending vertex index).  A vertex v is dropped only when a single other vertex u beats it
+    over the whole cap of the cell by a clear margin ((u - v).d > 1e-5 * hull size for every d in the cap), so
+    the arg-max over the list equals the arg-max over the full hull bit for bit, ties included.
+    Returns (adr [nmesh * ncell] = first record << 8 | count, vidx [nrec] = vertex index inside the mesh)."""
+    vert = np.asarray(vert, dtype=np.float64).reshape(-1, 3)
+    key = (vert.tobytes(), np.asarray(vertadr).tobytes(), np.asarray(vertnum).tobytes())
+    if key in _cell_cache:
+        return _cell_cache[key]
+    cells = _direction_cells()
+    adr, vidx = [], []
+    for mi in range(len(vertnum)):
+        P = vert[int(vertadr[mi]): int(vertadr[mi]) + int(vertnum[mi])]
+        dn = np.linalg.norm(P[None, :, :] - P[:, None, :], axis=2)   # dn[v, u] = |u - v|
+        tol = 1e-5 * np.abs(P).max()
+        for c, rho in cells:
+            pc = P @ c
+            dominated = ((pc[None, :] - pc[:, None]) - dn * np.sin(rho) > tol).any(axis=1)
+            keep = np.nonzero(~dominated)[0]
+            if len(keep) > 255:
+                raise NotImplementedError("support cell with %d candidate vertices" % len(keep))
+            adr.append((len(vidx) << 8) | len(keep))
+            vidx.extend(int(k) for k in keep)
+    out = (_i32(adr), _i32(vidx))
+    _cell_cache[key] = out
+    return out

@@ -21,17 +21,18 @@ void* emul_lds() { return g_lds; }
 
 void emul_yield() { swapcontext(&g_fiber[g_cur], &g_sched); }
 
-// barrier state per group size (16-lane rows: 4 groups, wave: 1 group)
-static int g_arrived[2][4], g_gen[2][4];
+// barrier state per group size (8-lane half rows: 8 groups, 16-lane rows: 4 groups, wave: 1 group)
+static int g_arrived[3][8], g_gen[3][8];
+static bool g_restart;  // a wave barrier was released: resume the sweep at lane 0 (hardware executes a wave's lanes in lane order)
 static int live_in_group(int gsize, int grp) { int n = 0; for (int l = grp * gsize; l < (grp + 1) * gsize; l++) n += !g_done[l]; return n; }
 void emul_barrier(int gsize) {
-  int k = gsize == 64 ? 1 : 0, grp = gsize == 64 ? 0 : g_cur / 16, gs = gsize == 64 ? 64 : 16;
+  int k = gsize == 64 ? 2 : (gsize == 16 ? 1 : 0), gs = gsize == 64 ? 64 : (gsize == 16 ? 16 : 8), grp = g_cur / gs;
   int gen = g_gen[k][grp];
   g_arrived[k][grp]++;
-  if (g_arrived[k][grp] >= live_in_group(gs, grp)) { g_arrived[k][grp] = 0; g_gen[k][grp]++; emul_yield(); return; }
+  if (g_arrived[k][grp] >= live_in_group(gs, grp)) { g_arrived[k][grp] = 0; g_gen[k][grp]++; g_restart = true; emul_yield(); return; }
   while (g_gen[k][grp] == gen) {
     // a lane of the group may have exited the kernel while we wait
-    if (g_arrived[k][grp] >= live_in_group(gs, grp)) { g_arrived[k][grp] = 0; g_gen[k][grp]++; break; }
+    if (g_arrived[k][grp] >= live_in_group(gs, grp)) { g_arrived[k][grp] = 0; g_gen[k][grp]++; g_restart = true; emul_yield(); break; }
     emul_yield();
   }
 }
@@ -57,7 +58,7 @@ void emul_launch(int nblocks, size_t lds_bytes, emul_kernel_fn fn, void* arg) {
       makecontext(&g_fiber[l], fiber_main, 0);
       g_done[l] = 0;
     }
-    for (int k = 0; k < 2; k++) for (int g = 0; g < 4; g++) g_arrived[k][g] = 0;
+    for (int k = 0; k < 3; k++) for (int g = 0; g < 8; g++) g_arrived[k][g] = 0;
     int alive = 64;
     while (alive > 0) {
       alive = 0;
@@ -66,6 +67,7 @@ void emul_launch(int nblocks, size_t lds_bytes, emul_kernel_fn fn, void* arg) {
         g_cur = l; threadIdx.x = l; threadIdx.y = threadIdx.z = 0;
         swapcontext(&g_sched, &g_fiber[l]);
         if (!g_done[l]) alive++;
+        if (g_restart) { g_restart = false; alive = 64; l = -1; }
       }
     }
     free(g_lds);

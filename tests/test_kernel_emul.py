@@ -85,3 +85,18 @@ def test_mpr_hook_matches_oracle(pair, locked_model):
             np.testing.assert_allclose(out[0, 2:5].numpy(), d, atol=5e-4)
             np.testing.assert_allclose(out[0, 5:8].numpy(), p, atol=2e-6)
     assert hits >= 2
+
+
+def test_pair_distance_cache_is_exact(locked_model, emul_lib):
+    """The broadphase skips pairs whose cached distance lower bound (minus a per-substep motion bound)
+    is still positive, and hull support points come from per-direction-cell candidate lists.  Neither may
+    change a single bit: free-running rollouts with both (flags 0) and with every pair tested by full
+    vertex scans (flags 4|8) are identical."""
+    sims = [LockedSimulation(locked_model, 2, lib=emul_lib) for _ in range(2)]
+    rng = np.random.RandomState(11)
+    for k in range(14):
+        a = torch.tensor(rng.uniform(-1, 1, (2, 20)) if k >= 6 else np.zeros((2, 20)), dtype=torch.float32)
+        for sim, fl in zip(sims, (0, 4 | 8)):
+            sim.env_step(action=a, nforward_ticks=3, flags=fl)
+    assert torch.equal(sims[0].qpos, sims[1].qpos) and torch.equal(sims[0].qvel, sims[1].qvel)
+    assert int(sims[0].status.max()) == 0
