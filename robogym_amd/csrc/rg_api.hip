@@ -158,19 +158,46 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
     std::vector<int> vadr, cadr, vidx;
     if (!get_i(B, "mesh_vertadr", vadr, e) || !get_i(B, "k_mesh_cell_adr", cadr, e) || !get_i(B, "k_mesh_cell_vidx", vidx, e)) return bail(e, m);
     if (cadr.size() != (size_t)d.nmesh * RG_NCELL) return bail("k_mesh_cell_adr has the wrong size (RG_CELLN mismatch?)", m);
-    std::vector<float> rec(vidx.size() * 4 + 4, 0.f);
+    std::vector<float> blk((size_t)d.nmesh * RG_NCELL * 16, 0.f), ovf(4, 0.f);
     for (int mi = 0; mi < d.nmesh; mi++) for (int c = 0; c < RG_NCELL; c++) {
-      int e = cadr[(size_t)mi * RG_NCELL + c], start = e >> 8, cnt = e & 255;
+      size_t ce = (size_t)mi * RG_NCELL + c;
+      int e = cadr[ce], start = e >> 8, cnt = e & 255;
       if (cnt < 1 || (size_t)(start + cnt) > vidx.size()) return bail("bad support cell", m);
-      for (int k = 0; k < cnt; k++) {
-        int vi = vidx[start + k]; size_t src = (size_t)(vadr[mi] + vi);
+      cadr[ce] = (int)((ovf.size() / 4) << 8) | cnt;
+      for (int k = 0; k < (cnt > 4 ? cnt : 4); k++) {
+        int vi = vidx[start + (k < cnt ? k : cnt - 1)]; size_t src = (size_t)(vadr[mi] + vi);
         if (vi < 0 || src * 3 + 2 >= fv.size()) return bail("bad support cell vertex", m);
-        float* o = rec.data() + 4 * (size_t)(start + k);
-        o[0] = fv[3 * src]; o[1] = fv[3 * src + 1]; o[2] = fv[3 * src + 2]; memcpy(o + 3, &vi, 4);
+        float o[4] = {fv[3 * src], fv[3 * src + 1], fv[3 * src + 2], 0.f}; memcpy(o + 3, &vi, 4);
+        if (k < 4) memcpy(blk.data() + ce * 16 + 4 * k, o, 16); else ovf.insert(ovf.end(), o, o + 4);
       }
     }
-    if (!upload<int>(m, cadr, &d.mesh_cell_adr) || !upload<float>(m, rec, &d.mesh_cell_vert)) return bail("hipMalloc failed", m); }
+    if (!upload<int>(m, cadr, &d.mesh_cell_adr) || !upload<float>(m, blk, &d.mesh_cell_blk) || !upload<float>(m, ovf, &d.mesh_cell_ovf)) return bail("hipMalloc failed", m); }
   UPI(pair_geom, "k_pair_geom"); UPF(pair_prm, "k_pair_prm");
+  {  // pair records: w0 g1 | g2<<8 | condim<<16 | type1<<20 | type2<<24, w1 margin, w2/w3 mesh ids (-1: none),
+     // w4-6 size1, w7 nvert1, w8-10 size2, w11 nvert2, w12/w13 first vertex of the meshes, w14/w15 bounding radii,
+     // w16-18 / w20-22 box half extents of the geoms (geom frame)
+    std::vector<int> pg, gt, gd, va, vn; std::vector<float> pp, gs, gr, ga;
+    if (!get_i(B, "k_pair_geom", pg, e) || !get_i(B, "geom_type", gt, e) || !get_i(B, "geom_dataid", gd, e) || !get_i(B, "mesh_vertadr", va, e) || !get_i(B, "mesh_vertnum", vn, e) ||
+        !get_f(B, "k_pair_prm", pp, e) || !get_f(B, "geom_size", gs, e) || !get_f(B, "geom_rbound", gr, e) || !get_f(B, "k_geom_aabb", ga, e)) return bail(e, m);
+    size_t np = pg.size() / 3;
+    std::vector<int> gg(np ? np : 1, 0); std::vector<float> rec((np ? np : 1) * RG_PAIRREC, 0.f);
+    for (size_t p = 0; p < np; p++) {
+      int g[2] = {pg[3 * p], pg[3 * p + 1]};
+      if (g[0] < 0 || g[1] < 0 || g[0] > 255 || g[1] > 255 || g[0] >= d.ngeom || g[1] >= d.ngeom) return bail("pair geom id out of range", m);
+      gg[p] = g[0] | (g[1] << 8);
+      float* r = rec.data() + p * RG_PAIRREC;
+      int hdr = g[0] | (g[1] << 8) | (pg[3 * p + 2] << 16) | (gt[g[0]] << 20) | (gt[g[1]] << 24);
+      memcpy(r, &hdr, 4); r[1] = pp[12 * p];
+      for (int k = 0; k < 2; k++) {
+        int id = gt[g[k]] == RG_GEOM_MESH ? gd[g[k]] : -1, nvert = id >= 0 ? vn[id] : 0, vadr0 = id >= 0 ? va[id] : 0;
+        memcpy(r + 2 + k, &id, 4);
+        for (int c = 0; c < 3; c++) { r[4 + 4 * k + c] = gs[3 * g[k] + c]; r[16 + 4 * k + c] = ga[3 * g[k] + c]; }
+        memcpy(r + 7 + 4 * k, &nvert, 4); memcpy(r + 12 + k, &vadr0, 4);
+        r[14 + k] = gr[g[k]];
+      }
+    }
+    if (!upload<int>(m, gg, &d.pair_gg) || !upload<float>(m, rec, &d.pair_rec)) return bail("hipMalloc failed", m);
+  }
   UPI(tendon_adr, "tendon_adr"); UPI(tendon_num, "tendon_num"); UPI(wrap_type, "wrap_type"); UPI(wrap_objid, "wrap_objid"); UPI(ten_dofs, "k_ten_dofs");
   UPF(wrap_prm, "wrap_prm"); UPF(tendon_range, "tendon_range"); UPF(tendon_margin, "tendon_margin"); UPF(tendon_stiffness, "tendon_stiffness");
   UPF(tendon_damping, "tendon_damping"); UPF(tendon_frictionloss, "tendon_frictionloss"); UPF(tendon_lengthspring, "tendon_lengthspring");

@@ -459,7 +459,7 @@ __device__ __forceinline__ void rg_crb(const RgModelDev& m, RgLds& s, const int*
 
 // ------------------------------------------------------------------------------------------------- collision
 struct SupPt { v3 v, s; };  // v = v1 - v2 (Minkowski difference), s = v1 + v2 (all the contact position needs)
-struct MprGeom { int type; const float* mat; v3 pos; v3 size; const float* vert; int nvert; float margin; float* prof; const int* celladr; const rgf4* cellvert; };
+struct MprGeom { int type; const float* mat; v3 pos; v3 size; const float* vert; int nvert; float margin; float* prof; const int* celladr; const rgf4 *cellblk, *cellovf; };
 
 // per-lane scan of a hull's vertices: 16-byte records (one dwordx4 load per vertex), four independent
 // loads in flight per lane; out-of-range slots re-read the last vertex (harmless for a max).
@@ -492,20 +492,27 @@ __device__ __forceinline__ int dir_cell(v3 ld) {
 }
 // the same arg-max restricted to the cell's candidate list (typically 3-6 records instead of 60-300
 // vertices; the list provably contains every vertex that can win, so the result is bit-identical)
-template <int G> __device__ __forceinline__ void scan_cell(const int* celladr, const rgf4* cellvert, v3 ld, float& bv, int& bi, v3& bp) {
-  int e = celladr[dir_cell(ld)], cnt = e & 255, last = cnt - 1;
-  const rgf4* rec = cellvert + (e >> 8);
-  for (int base = 0; base < cnt; base += 2 * G) {
-    int i0 = base + (LANE & (G - 1)), j0 = i0 < last ? i0 : last, j1 = i0 + G < last ? i0 + G : last;
-    rgf4 a = rec[j0], b = rec[j1];
-    float da = vdot(ld, a), db = vdot(ld, b);
-    int ia = __builtin_bit_cast(int, a.w), ib = __builtin_bit_cast(int, b.w);
-    if (da > bv) { bv = da; bi = ia; bp = mk3(a.x, a.y, a.z); }   // records ascend in vertex index: first max = lowest index
-    if (db > bv) { bv = db; bi = ib; bp = mk3(b.x, b.y, b.z); }
+template <int G> __device__ __forceinline__ void scan_cell(const int* celladr, const rgf4* cellblk, const rgf4* cellovf, v3 ld, float& bv, int& bi, v3& bp) {
+  int cell = dir_cell(ld), l = LANE & (G - 1);
+  int e = celladr[cell];
+  rgf4 a = cellblk[4 * cell + (l & 3)];   // the cell's first four candidates sit at a computable address: one load latency
+  float da = vdot(ld, a);
+  if (da > bv) { bv = da; bi = __builtin_bit_cast(int, a.w); bp = mk3(a.x, a.y, a.z); }
+  int cnt = (e & 255) - 4, last = cnt - 1;
+  if (cnt > 0) {
+    const rgf4* rec = cellovf + (e >> 8);
+    for (int base = 0; base < cnt; base += 2 * G) {
+      int i0 = base + l, j0 = i0 < last ? i0 : last, j1 = i0 + G < last ? i0 + G : last;
+      rgf4 b = rec[j0], c = rec[j1];
+      float db = vdot(ld, b), dc = vdot(ld, c);
+      int ib = __builtin_bit_cast(int, b.w), ic = __builtin_bit_cast(int, c.w);
+      if (db > bv || (db == bv && ib < bi)) { bv = db; bi = ib; bp = mk3(b.x, b.y, b.z); }
+      if (dc > bv || (dc == bv && ic < bi)) { bv = dc; bi = ic; bp = mk3(c.x, c.y, c.z); }
+    }
   }
 }
 template <int G> __device__ __forceinline__ void scan_hull(const MprGeom& g, v3 ld, float& bv, int& bi, v3& bp) {
-  if (g.celladr) scan_cell<G>(g.celladr, g.cellvert, ld, bv, bi, bp);
+  if (g.celladr) scan_cell<G>(g.celladr, g.cellblk, g.cellovf, ld, bv, bi, bp);
   else scan_verts<G>((const rgf4*)g.vert, g.nvert, ld, bv, bi, bp);
 }
 // arg-max over the G cooperating lanes (lowest vertex index on ties, as a serial first-max scan); the
@@ -606,72 +613,93 @@ __device__ __forceinline__ float origin_tri_dist2(v3 a, v3 b, v3 c, v3& w) {
   w = a + ab * (vb * den) + ac * (vc * den);
   return dot(w, w);
 }
-// MPR penetration query (libccd ccdMPRPenetration); wave-uniform control flow.  Returns true on contact.
+// MPR penetration query (libccd ccdMPRPenetration) of one pair per group of G lanes.  Returns true on contact.
 // `sep`: on a "no contact" exit that PROVES separation (support of the Minkowski difference along `sep` is <= 0)
 // the unit direction that proves it, else zero — cached per pair and tried first on the next substep.
-template <int G> __device__ __forceinline__ bool rg_mpr(const MprGeom& A, const MprGeom& B, int max_iter, float tol, float& depth, v3& dir_out, v3& pos, v3& sep) {
-  SupPt p[4], v4;
+//
+// All groups of the wave run ONE loop whose body is "support point along dir, then the state's bookkeeping":
+// every step of the algorithm (the two initial supports, portal discovery, portal refinement, penetration
+// search) is "pick a direction, take a support point, test / update the portal", so the expensive common
+// part — the support — executes convergently for all groups and only the few dozen scalar instructions
+// of bookkeeping diverge.  (With one nested loop per phase the groups drift apart and the wave
+// serialises their different phases.)  `active` false: the group idles; call from convergent code.
+enum { MPR_DONE = 0, MPR_FIRST, MPR_SECOND, MPR_DISCOVER, MPR_REFINE, MPR_PENETR };
+template <int G> __device__ __forceinline__ bool rg_mpr(const MprGeom& A, const MprGeom& B, int max_iter, float tol, float& depth, v3& dir_out, v3& pos, v3& sep, bool active) {
+  SupPt p[4];
+  int state = active ? MPR_FIRST : MPR_DONE, guard = 0;
+  bool result = false;
+  v3 dir = mk3(1, 0, 0);
   sep = mk3(0, 0, 0);
-  p[0].s = A.pos + B.pos; p[0].v = A.pos - B.pos;
-  if (mz(p[0].v.x) && mz(p[0].v.y) && mz(p[0].v.z)) p[0].v.x += 1e-6f;
-  v3 dir = normalized(p[0].v * -1.0f);
-  mpr_support<G>(A, B, dir, p[1]);
-  float dt = dot(p[1].v, dir);
-  if (dt <= 0) { sep = dir; return false; }
-  dir = cross(p[0].v, p[1].v);
-  if (dot(dir, dir) < 1e-30f) {
-    pos = p[1].s * 0.5f;
-    if (dot(p[1].v, p[1].v) < 1e-30f) { depth = 0; dir_out = mk3(0, 0, 0); return true; }
-    depth = norm(p[1].v); dir_out = p[1].v * (1.0f / depth);
-    return true;
+  if (active) {
+    p[0].s = A.pos + B.pos; p[0].v = A.pos - B.pos;
+    if (mz(p[0].v.x) && mz(p[0].v.y) && mz(p[0].v.z)) p[0].v.x += 1e-6f;
+    dir = normalized(p[0].v * -1.0f);
   }
-  dir = normalized(dir);
-  mpr_support<G>(A, B, dir, p[2]);
-  if (dot(p[2].v, dir) <= 0) { sep = dir; return false; }
-  dir = normalized(cross(p[1].v - p[0].v, p[2].v - p[0].v));
-  if (dot(dir, p[0].v) > 0) { SupPt t = p[1]; p[1] = p[2]; p[2] = t; dir = dir * -1.0f; }
-  for (int guard = 0;; guard++) {
-    if (guard > 64) return false;
-    mpr_support<G>(A, B, dir, p[3]);
-    if (dot(p[3].v, dir) <= 0) { sep = dir; return false; }
-    bool cont = false;
-    if (dot(cross(p[1].v, p[3].v), p[0].v) < 0) { p[2] = p[3]; cont = true; }
-    if (!cont && dot(cross(p[3].v, p[2].v), p[0].v) < 0) { p[1] = p[3]; cont = true; }
-    if (!cont) break;
-    dir = normalized(cross(p[1].v - p[0].v, p[2].v - p[0].v));
-  }
-  for (int guard = 0;; guard++) {  // refinePortal
-    if (guard > 128) return false;
-    dir = portal_dir(p);
-    if (dot(dir, p[1].v) >= 0) break;
-    mpr_support<G>(A, B, dir, v4);
-    if (dot(v4.v, dir) < 0) { sep = dir; return false; }
-    if (portal_reach_tol(p, v4, dir, tol)) return false;
-    expand_portal(p, v4);
-  }
-  for (int it = 0;; it++) {  // findPenetr
-    dir = portal_dir(p);
-    mpr_support<G>(A, B, dir, v4);
-    if (portal_reach_tol(p, v4, dir, tol) || it > max_iter) {
-      // depth / direction from the portal PLANE (not libccd's closest point on the final portal triangle,
-      // whose choice among the triangles of a flat supporting plane is rounding noise; see DESIGN.md "MPR")
-      depth = fmaxf((dot(p[1].v, dir) + dot(p[2].v, dir) + dot(p[3].v, dir)) * (1.0f / 3.0f), 0.f);
-      dir_out = dir;
-      // contact position from the barycentric coordinates of the origin in the portal tetrahedron
-      float b0 = dot(cross(p[1].v, p[2].v), p[3].v), b1 = dot(cross(p[3].v, p[2].v), p[0].v);
-      float b2 = dot(cross(p[0].v, p[1].v), p[3].v), b3 = dot(cross(p[2].v, p[1].v), p[0].v);
-      float sum = b0 + b1 + b2 + b3;
-      if (sum <= 0) {
-        v3 dd = portal_dir(p);
-        b0 = 0; b1 = dot(cross(p[2].v, p[3].v), dd); b2 = dot(cross(p[3].v, p[1].v), dd); b3 = dot(cross(p[1].v, p[2].v), dd);
-        sum = b1 + b2 + b3;
+  while (__ballot(state != MPR_DONE)) {
+    if (state == MPR_DONE) continue;
+    SupPt q;
+    mpr_support<G>(A, B, dir, q);
+    float dq = dot(q.v, dir);
+    bool to_refine = false;   // portal complete or expanded: decide between refinement and the penetration search
+    if (state == MPR_FIRST) {
+      p[1] = q;
+      if (dq <= 0) { sep = dir; state = MPR_DONE; }
+      else {
+        dir = cross(p[0].v, p[1].v);
+        if (dot(dir, dir) < 1e-30f) {   // centre, origin and support point on one line
+          pos = p[1].s * 0.5f; result = true; state = MPR_DONE;
+          if (dot(p[1].v, p[1].v) < 1e-30f) { depth = 0; dir_out = mk3(0, 0, 0); }
+          else { depth = norm(p[1].v); dir_out = p[1].v * (1.0f / depth); }
+        } else { dir = normalized(dir); state = MPR_SECOND; }
       }
-      float inv = 0.5f / sum;
-      pos = p[0].s * (b0 * inv) + p[1].s * (b1 * inv) + p[2].s * (b2 * inv) + p[3].s * (b3 * inv);
-      return true;
+    } else if (state == MPR_SECOND) {
+      p[2] = q;
+      if (dq <= 0) { sep = dir; state = MPR_DONE; }
+      else {
+        dir = normalized(cross(p[1].v - p[0].v, p[2].v - p[0].v));
+        if (dot(dir, p[0].v) > 0) { SupPt t = p[1]; p[1] = p[2]; p[2] = t; dir = dir * -1.0f; }
+        state = MPR_DISCOVER; guard = 0;
+      }
+    } else if (state == MPR_DISCOVER) {
+      p[3] = q;
+      if (dq <= 0) { sep = dir; state = MPR_DONE; }
+      else {
+        bool cont = false;
+        if (dot(cross(p[1].v, p[3].v), p[0].v) < 0) { p[2] = p[3]; cont = true; }
+        if (!cont && dot(cross(p[3].v, p[2].v), p[0].v) < 0) { p[1] = p[3]; cont = true; }
+        if (cont) { dir = normalized(cross(p[1].v - p[0].v, p[2].v - p[0].v)); if (++guard > 64) state = MPR_DONE; }
+        else { to_refine = true; guard = 0; }
+      }
+    } else if (state == MPR_REFINE) {
+      if (dq < 0) { sep = dir; state = MPR_DONE; }
+      else if (portal_reach_tol(p, q, dir, tol)) state = MPR_DONE;
+      else { expand_portal(p, q); to_refine = true; if (++guard > 128) { state = MPR_DONE; to_refine = false; } }
+    } else {  // MPR_PENETR
+      if (portal_reach_tol(p, q, dir, tol) || guard > max_iter) {
+        // depth / direction from the portal PLANE (not libccd's closest point on the final portal triangle,
+        // whose choice among the triangles of a flat supporting plane is rounding noise; see DESIGN.md "MPR")
+        depth = fmaxf((dot(p[1].v, dir) + dot(p[2].v, dir) + dot(p[3].v, dir)) * (1.0f / 3.0f), 0.f);
+        dir_out = dir;
+        // contact position from the barycentric coordinates of the origin in the portal tetrahedron
+        float b0 = dot(cross(p[1].v, p[2].v), p[3].v), b1 = dot(cross(p[3].v, p[2].v), p[0].v);
+        float b2 = dot(cross(p[0].v, p[1].v), p[3].v), b3 = dot(cross(p[2].v, p[1].v), p[0].v);
+        float sum = b0 + b1 + b2 + b3;
+        if (sum <= 0) {
+          v3 dd = portal_dir(p);
+          b0 = 0; b1 = dot(cross(p[2].v, p[3].v), dd); b2 = dot(cross(p[3].v, p[1].v), dd); b3 = dot(cross(p[1].v, p[2].v), dd);
+          sum = b1 + b2 + b3;
+        }
+        float inv = 0.5f / sum;
+        pos = p[0].s * (b0 * inv) + p[1].s * (b1 * inv) + p[2].s * (b2 * inv) + p[3].s * (b3 * inv);
+        result = true; state = MPR_DONE;
+      } else { expand_portal(p, q); dir = portal_dir(p); guard++; }
     }
-    expand_portal(p, v4);
+    if (to_refine) {   // refinePortal's loop head: the origin side of the portal decides
+      dir = portal_dir(p);
+      if (dot(dir, p[1].v) >= 0) { state = MPR_PENETR; guard = 0; } else state = MPR_REFINE;
+    }
   }
+  return result;
 }
 
 // separating-axis test of two oriented boxes (half extents ea, eb; rotations Ra, Rb; centre offset t in world).
@@ -717,15 +745,18 @@ __device__ __forceinline__ void add_contact(RgLds& s, int pair, float dist, v3 p
 
 // the two geoms of candidate pair p in pair-local coordinates (origin at geom1's centre: fp32 resolution ~1e-9 m),
 // each inflated by margin/2
-__device__ __forceinline__ void rg_mpr_geoms(const RgModelDev& m, const RgLds& s, int p, MprGeom& A, MprGeom& B, bool cells) {
-  int g1 = m.pair_geom[3 * p], g2 = m.pair_geom[3 * p + 1];
-  float margin = m.pair_prm[12 * p];
-  int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
-  A.type = t1; A.mat = s.gmat + 9 * g1; A.size = ld3(m.geom_size + 3 * g1); A.margin = 0.5f * margin; A.pos = mk3(0, 0, 0);
-  B.type = t2; B.mat = s.gmat + 9 * g2; B.size = ld3(m.geom_size + 3 * g2); B.margin = 0.5f * margin; B.pos = ld3(s.gpos + 3 * g2) - ld3(s.gpos + 3 * g1);
-  A.celladr = 0; B.celladr = 0; A.cellvert = B.cellvert = (const rgf4*)m.mesh_cell_vert;
-  if (t1 == RG_GEOM_MESH) { int id = m.geom_dataid[g1]; A.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; A.nvert = m.mesh_vertnum[id]; if (cells) A.celladr = m.mesh_cell_adr + id * RG_NCELL; } else { A.vert = 0; A.nvert = 0; }
-  if (t2 == RG_GEOM_MESH) { int id = m.geom_dataid[g2]; B.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; B.nvert = m.mesh_vertnum[id]; if (cells) B.celladr = m.mesh_cell_adr + id * RG_NCELL; } else { B.vert = 0; B.nvert = 0; }
+__device__ __forceinline__ void rg_mpr_geoms(const RgModelDev& m, const RgLds& s, int p, MprGeom& A, MprGeom& B, bool cells, int& dim, float& margin) {
+  const rgf4* R = (const rgf4*)m.pair_rec + (RG_PAIRREC / 4) * p;
+  rgf4 r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3];
+  int hdr = __builtin_bit_cast(int, r0.x), g1 = hdr & 255, g2 = (hdr >> 8) & 255, id1 = __builtin_bit_cast(int, r0.z), id2 = __builtin_bit_cast(int, r0.w);
+  dim = (hdr >> 16) & 15; margin = r0.y;
+  A.type = (hdr >> 20) & 15; A.mat = s.gmat + 9 * g1; A.size = mk3(r1.x, r1.y, r1.z); A.margin = 0.5f * margin; A.pos = mk3(0, 0, 0);
+  B.type = (hdr >> 24) & 15; B.mat = s.gmat + 9 * g2; B.size = mk3(r2.x, r2.y, r2.z); B.margin = 0.5f * margin; B.pos = ld3(s.gpos + 3 * g2) - ld3(s.gpos + 3 * g1);
+  A.vert = m.mesh_vert + 4 * __builtin_bit_cast(int, r3.x); A.nvert = __builtin_bit_cast(int, r1.w);
+  B.vert = m.mesh_vert + 4 * __builtin_bit_cast(int, r3.y); B.nvert = __builtin_bit_cast(int, r2.w);
+  A.cellovf = B.cellovf = (const rgf4*)m.mesh_cell_ovf;
+  A.celladr = (cells && id1 >= 0) ? m.mesh_cell_adr + id1 * RG_NCELL : (const int*)0; A.cellblk = (const rgf4*)m.mesh_cell_blk + (size_t)(id1 >= 0 ? id1 : 0) * (RG_NCELL * 4);
+  B.celladr = (cells && id2 >= 0) ? m.mesh_cell_adr + id2 * RG_NCELL : (const int*)0; B.cellblk = (const rgf4*)m.mesh_cell_blk + (size_t)(id2 >= 0 ? id2 : 0) * (RG_NCELL * 4);
   A.prof = 0; B.prof = 0;
 }
 template <int G> __device__ __forceinline__ void rg_narrow_phase1(const RgModelDev& m, RgLds& s, rgf4* sepdir, float* pairlb, int ncand, bool cells) {
@@ -734,10 +765,9 @@ template <int G> __device__ __forceinline__ void rg_narrow_phase1(const RgModelD
     bool keep = false; int p = 0;
     if (ci < ncand) {
       p = s.cand[ci];
-      int g1 = m.pair_geom[3 * p], g2 = m.pair_geom[3 * p + 1];
-      if (m.geom_type[g1] != RG_GEOM_PLANE) {
-        MprGeom A, B;
-        rg_mpr_geoms(m, s, p, A, B, cells);
+      MprGeom A, B; int dim; float margin;
+      rg_mpr_geoms(m, s, p, A, B, cells, dim, margin);
+      if (A.type != RG_GEOM_PLANE) {
         v3 c0 = A.pos - B.pos;
         if (mz(c0.x) && mz(c0.y) && mz(c0.z)) c0.x += 1e-6f;
         v3 dir = normalized(c0 * -1.0f);
@@ -766,17 +796,19 @@ template <int G> __device__ __forceinline__ void rg_narrow_phase2(const RgModelD
     int ci = base + LANE / G;
     bool hit = false;
     float depth = 0, margin = 0; v3 dir = mk3(0, 0, 0), pos = mk3(0, 0, 0); int p = 0, dim = 3;
-    if (ci < ncand2) {
+    bool active = ci < ncand2;
+    MprGeom A, B;
+    if (active) {
       p = s.cand2[ci];
-      dim = m.pair_geom[3 * p + 2]; margin = m.pair_prm[12 * p];
-      MprGeom A, B;
-      rg_mpr_geoms(m, s, p, A, B, cells);
+      rg_mpr_geoms(m, s, p, A, B, cells, dim, margin);
       A.prof = prof;
-      v3 sep;
-      hit = rg_mpr<G>(A, B, m.mpr_iterations, m.mpr_tolerance, depth, dir, pos, sep);
+    }
+    v3 sep;
+    hit = rg_mpr<G>(A, B, m.mpr_iterations, m.mpr_tolerance, depth, dir, pos, sep, active);
+    if (active) {
       if (sepdir && (LANE & (G - 1)) == 0) { rgf4 cd; cd.x = hit ? 0.f : sep.x; cd.y = hit ? 0.f : sep.y; cd.z = hit ? 0.f : sep.z; cd.w = 0.f; sepdir[p] = cd; }
       hit = hit && dot(dir, dir) > 0.25f;
-      pos = pos + ld3(s.gpos + 3 * m.pair_geom[3 * p]);
+      pos = pos + ld3(s.gpos + 3 * (m.pair_gg[p] & 255));
     }
     // append the groups' contacts in candidate order (group leaders hold the result)
     bool lead = hit && (LANE & (G - 1)) == 0;
@@ -810,7 +842,7 @@ __device__ __forceinline__ void rg_collision(const RgModelDev& m, RgLds& s, floa
     int p = r * RG_WAVE + LANE;
     bool need = false;
     if (p < m.npair) {
-      int g1 = m.pair_geom[3 * p], g2 = m.pair_geom[3 * p + 1];
+      int gg = m.pair_gg[p], g1 = gg & 255, g2 = gg >> 8;
       float lb = (pairlb ? pairlb[p] : 0.f) - (hb * (s.gspeed[g1] + s.gspeed[g2]) + 1e-7f);
       need = !(lb > 0.f);
       if (!need) pairlb[p] = lb;
@@ -825,18 +857,20 @@ __device__ __forceinline__ void rg_collision(const RgModelDev& m, RgLds& s, floa
       bool hit = false;
       if (i < nt) {
         q = s.tlist[i];
-        int g1 = m.pair_geom[3 * q], g2 = m.pair_geom[3 * q + 1];
-        float margin = m.pair_prm[12 * q], newlb = 0.f;
+        const rgf4* R = (const rgf4*)m.pair_rec + (RG_PAIRREC / 4) * q;
+        rgf4 r0 = R[0], r3 = R[3], r4 = R[4], r5 = R[5];
+        int hdr = __builtin_bit_cast(int, r0.x), g1 = hdr & 255, g2 = (hdr >> 8) & 255;
+        float margin = r0.y, newlb = 0.f;
         v3 p1 = ld3(s.gpos + 3 * g1), p2 = ld3(s.gpos + 3 * g2), dif = p2 - p1;
-        if (m.geom_type[g1] == RG_GEOM_PLANE) {
+        if (((hdr >> 20) & 15) == RG_GEOM_PLANE) {
           const float* R1 = s.gmat + 9 * g1;
-          float d = dot(dif, mk3(R1[2], R1[5], R1[8])) - (m.geom_rbound[g2] + margin);
+          float d = dot(dif, mk3(R1[2], R1[5], R1[8])) - (r3.w + margin);
           hit = d <= 0; newlb = fmaxf(d, 0.f);
         } else {
-          float d = sqrtf(dot(dif, dif)) - (m.geom_rbound[g1] + m.geom_rbound[g2] + margin);
+          float d = sqrtf(dot(dif, dif)) - (r3.z + r3.w + margin);
           if (d <= 0) {
             float hm = 0.5f * margin + 1e-6f;
-            v3 ea = ld3(m.geom_aabb + 3 * g1) + mk3(hm, hm, hm), eb = ld3(m.geom_aabb + 3 * g2) + mk3(hm, hm, hm);
+            v3 ea = mk3(r4.x + hm, r4.y + hm, r4.z + hm), eb = mk3(r5.x + hm, r5.y + hm, r5.z + hm);
             float og = obb_gap(s.gmat + 9 * g1, ea, s.gmat + 9 * g2, eb, dif);
             hit = og < 0; newlb = fmaxf(og, 0.f);
           } else newlb = d;
@@ -880,7 +914,7 @@ __device__ __forceinline__ void rg_collision(const RgModelDev& m, RgLds& s, floa
     int t2 = m.geom_type[g2];
     v3 p1 = ld3(s.gpos + 3 * g1), p2 = ld3(s.gpos + 3 * g2);
     MprGeom B;
-    B.type = t2; B.mat = s.gmat + 9 * g2; B.size = ld3(m.geom_size + 3 * g2); B.margin = 0; B.prof = 0; B.celladr = 0; B.cellvert = 0;
+    B.type = t2; B.mat = s.gmat + 9 * g2; B.size = ld3(m.geom_size + 3 * g2); B.margin = 0; B.prof = 0; B.celladr = 0; B.cellblk = 0; B.cellovf = 0;
     if (t2 == RG_GEOM_MESH) { int id = m.geom_dataid[g2]; B.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; B.nvert = m.mesh_vertnum[id]; } else { B.vert = 0; B.nvert = 0; }
     const float* R1 = s.gmat + 9 * g1;
     v3 n = mk3(R1[2], R1[5], R1[8]);
@@ -1183,26 +1217,32 @@ __device__ __forceinline__ void rg_J_mul(const RgModelDev& m, RgLds& s, const fl
   SYNC();
 }
 // forces / quadratic flags from jar; returns the wave-summed constraint cost
-__device__ __forceinline__ float rg_constraint_update(const RgModelDev& m, RgLds& s) {
-  int ns = nsrow(m), ncon = s.ncon; float cost = 0;
+// `changed`: whether any row's quadratic flag differs from what the arrays held before (the Hessian
+// M + J' D J depends on the state only through these flags)
+__device__ __forceinline__ float rg_constraint_update(const RgModelDev& m, RgLds& s, bool& changed) {
+  int ns = nsrow(m), ncon = s.ncon; float cost = 0; bool chg = false;
   PFOR(r, ns) {
-    float D = s.r_D[r];
-    if (!(D > 0)) { s.r_quad[r] = 0; s.r_force[r] = 0; continue; }
-    float x = s.r_jar[r], f = r < RG_MAXFRIC ? s.r_floss[r] : 0.f;
-    if (f > 0) {
-      float R = 1.0f / D;
-      if (x <= -R * f) { s.r_force[r] = f; s.r_quad[r] = 0; cost += f * (-0.5f * R * f - x); }
-      else if (x >= R * f) { s.r_force[r] = -f; s.r_quad[r] = 0; cost += f * (-0.5f * R * f + x); }
-      else { s.r_force[r] = -D * x; s.r_quad[r] = 1; cost += 0.5f * D * x * x; }
-    } else if (x >= 0) { s.r_force[r] = 0; s.r_quad[r] = 0; }
-    else { s.r_force[r] = -D * x; s.r_quad[r] = 1; cost += 0.5f * D * x * x; }
+    float D = s.r_D[r]; int old = s.r_quad[r], q = 0; float frc = 0;
+    if (D > 0) {
+      float x = s.r_jar[r], f = r < RG_MAXFRIC ? s.r_floss[r] : 0.f;
+      if (f > 0) {
+        float R = 1.0f / D;
+        if (x <= -R * f) { frc = f; cost += f * (-0.5f * R * f - x); }
+        else if (x >= R * f) { frc = -f; cost += f * (-0.5f * R * f + x); }
+        else { frc = -D * x; q = 1; cost += 0.5f * D * x * x; }
+      } else if (x < 0) { frc = -D * x; q = 1; cost += 0.5f * D * x * x; }
+    }
+    s.r_force[r] = frc; s.r_quad[r] = q; chg |= q != old;
   }
   for (int w = LANE; w < ncon * 6; w += RG_WAVE) {
-    int c = w / 6, q = w - 6 * c;
-    if (q >= npyr(s.c_dim[c])) { s.p_quad[w] = 0; s.p_force[w] = 0; continue; }
-    float x = s.p_jar[w], D = s.c_D[c];
-    if (x >= 0) { s.p_force[w] = 0; s.p_quad[w] = 0; } else { s.p_force[w] = -D * x; s.p_quad[w] = 1; cost += 0.5f * D * x * x; }
+    int c = w / 6, k = w - 6 * c, old = s.p_quad[w], q = 0; float frc = 0;
+    if (k < npyr(s.c_dim[c])) {
+      float x = s.p_jar[w], D = s.c_D[c];
+      if (x < 0) { frc = -D * x; q = 1; cost += 0.5f * D * x * x; }
+    }
+    s.p_force[w] = frc; s.p_quad[w] = q; chg |= q != old;
   }
+  changed = __ballot(chg) != 0;
   SYNC();
   return wave_sum(cost);
 }
@@ -1474,7 +1514,7 @@ __device__ __forceinline__ int rg_solve(const RgModelDev& m, RgLds& s, int& nefc
     rg_J_mul(m, s, a, false);
     float g = 0; PFOR(i, nvc) g += 0.5f * (s.Ma[i] - s.fs[i]) * (a[i] - s.as[i]);
     g = wave_sum(g);
-    cost_pick[pass] = g + rg_constraint_update(m, s);
+    bool chg; cost_pick[pass] = g + rg_constraint_update(m, s, chg);
   }
   if (!(cost_pick[1] < cost_pick[0])) {
     PFOR(i, nvc) s.a[i] = s.as[i];
@@ -1484,11 +1524,12 @@ __device__ __forceinline__ int rg_solve(const RgModelDev& m, RgLds& s, int& nefc
   }
   // Invariant at the top of every iteration: Ma = M a and jar = J a - aref (both linear in a, so they are
   // advanced by alpha * (M s, J s) after the line search instead of being recomputed).
-  float cost = 0, oldcost = 0; int iters = 0;
+  // The factor of H is kept while the set of quadratic rows stays the same (H depends on nothing else).
+  float cost = 0, oldcost = 0; int iters = 0; bool have_factor = false;
   for (int iter = 0;; iter++) {
     float gauss = 0; PFOR(i, nvc) gauss += 0.5f * (s.Ma[i] - s.fs[i]) * (s.a[i] - s.as[i]);
     gauss = wave_sum(gauss);
-    float cc = rg_constraint_update(m, s);
+    bool flags_changed; float cc = rg_constraint_update(m, s, flags_changed);
     oldcost = cost; cost = gauss + cc;
     rg_JT_force(m, s, s.jtf);
     float gn = 0; PFOR(i, nvc) { float gi = s.Ma[i] - s.fs[i] - s.jtf[i]; s.search[i] = -gi; gn += gi * gi; }
@@ -1500,6 +1541,8 @@ __device__ __forceinline__ int rg_solve(const RgModelDev& m, RgLds& s, int& nefc
     if (gn < tol || iter >= m.iterations) break;
     iters = iter + 1;
     PROFS(12);
+    if (!have_factor || flags_changed) {
+    have_factor = true;
     // H = M + J' D J over the quadratic rows (LDS atomics from one wave: in-order, deterministic)
     for (int w = LANE; w < nvc * hs; w += RG_WAVE) s.H[w] = 0.f;
     SYNC();
@@ -1530,6 +1573,7 @@ __device__ __forceinline__ int rg_solve(const RgModelDev& m, RgLds& s, int& nefc
     SYNC();
     PROFS(13);
     rg_chol(m, s);
+    }
     PROFS(14);
     rg_chol_solve(m, s, s.search);
     PROFS(15);
@@ -1568,7 +1612,7 @@ __device__ __forceinline__ int rg_solve(const RgModelDev& m, RgLds& s, int& nefc
   }
   // forces at the solution; expand to the full dof space
   rg_J_mul(m, s, s.a, false);
-  rg_constraint_update(m, s);
+  { bool chg; rg_constraint_update(m, s, chg); }
   rg_JT_force(m, s, s.jtf);
   PFOR(d, nv) { int i = m.d2c[d]; s.qacc[d] = i >= 0 ? s.a[i] : s.qacc_smooth[d]; s.qfrc_con[d] = i >= 0 ? s.jtf[i] : 0.f; }
   SYNC();
@@ -1758,11 +1802,11 @@ __global__ void __launch_bounds__(RG_WAVE) rg_mpr_pair_kernel(RgModelDev m, RgBa
   v3 p1 = ld3(s.gpos + 3 * g1), p2 = ld3(s.gpos + 3 * g2);
   A.type = m.geom_type[g1]; A.mat = s.gmat + 9 * g1; A.size = ld3(m.geom_size + 3 * g1); A.margin = 0.5f * margin; A.pos = mk3(0, 0, 0); A.prof = 0;
   B.type = m.geom_type[g2]; B.mat = s.gmat + 9 * g2; B.size = ld3(m.geom_size + 3 * g2); B.margin = 0.5f * margin; B.pos = p2 - p1; B.prof = 0;
-  A.celladr = 0; B.celladr = 0; A.cellvert = B.cellvert = (const rgf4*)m.mesh_cell_vert;   // the hook exercises the cell-list supports
-  if (A.type == RG_GEOM_MESH) { int id = m.geom_dataid[g1]; A.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; A.nvert = m.mesh_vertnum[id]; A.celladr = m.mesh_cell_adr + id * RG_NCELL; } else { A.vert = 0; A.nvert = 0; }
-  if (B.type == RG_GEOM_MESH) { int id = m.geom_dataid[g2]; B.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; B.nvert = m.mesh_vertnum[id]; B.celladr = m.mesh_cell_adr + id * RG_NCELL; } else { B.vert = 0; B.nvert = 0; }
+  A.celladr = 0; B.celladr = 0; A.cellovf = B.cellovf = (const rgf4*)m.mesh_cell_ovf; A.cellblk = B.cellblk = (const rgf4*)m.mesh_cell_blk;   // the hook exercises the cell-list supports
+  if (A.type == RG_GEOM_MESH) { int id = m.geom_dataid[g1]; A.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; A.nvert = m.mesh_vertnum[id]; A.celladr = m.mesh_cell_adr + id * RG_NCELL; A.cellblk += (size_t)id * (RG_NCELL * 4); } else { A.vert = 0; A.nvert = 0; }
+  if (B.type == RG_GEOM_MESH) { int id = m.geom_dataid[g2]; B.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; B.nvert = m.mesh_vertnum[id]; B.celladr = m.mesh_cell_adr + id * RG_NCELL; B.cellblk += (size_t)id * (RG_NCELL * 4); } else { B.vert = 0; B.nvert = 0; }
   float depth = 0; v3 dir = mk3(0, 0, 0), pos = mk3(0, 0, 0);
-  v3 sep; bool hit = rg_mpr<64>(A, B, m.mpr_iterations, m.mpr_tolerance, depth, dir, pos, sep);
+  v3 sep; bool hit = rg_mpr<64>(A, B, m.mpr_iterations, m.mpr_tolerance, depth, dir, pos, sep, true);
   if (LANE == 0) {
     float* o = out + 8 * (size_t)e;
     o[0] = hit ? 1.f : 0.f; o[1] = depth; o[2] = dir.x; o[3] = dir.y; o[4] = dir.z; o[5] = pos.x + p1.x; o[6] = pos.y + p1.y; o[7] = pos.z + p1.z;

@@ -22,6 +22,7 @@
 #define RG_MAXCAND2 64  // candidates surviving the first support test (full MPR queries) per substep
 #define RG_CELLN 8      // direction cells: cube map, RG_CELLN x RG_CELLN per face (kernel_tables.py CELL_N)
 #define RG_NCELL (6 * RG_CELLN * RG_CELLN)
+#define RG_PAIRREC 24   // words per pair record
 #define RG_TLIST 320    // pairs whose distance bound ran out, queued for the sphere/box tests (drained in chunks)
 #define RG_MAXROW 64    // friction-loss + limit rows
 #define RG_W 14         // max nonzeros of a sparse constraint row
@@ -67,8 +68,13 @@ struct RgModelDev {
   const float *site_pos;
   const int *mesh_vertadr, *mesh_vertnum;
   const float* mesh_vert;
-  const int* mesh_cell_adr;     // [nmesh][RG_NCELL] first record << 8 | count: hull vertices that can be the support point for a direction in the cell
-  const float* mesh_cell_vert;  // 16-byte records x, y, z, vertex index (int bits), ascending index inside a cell
+  // hull vertices that can be the support point for a direction in the cell (ascending vertex index):
+  const int* mesh_cell_adr;     // [nmesh][RG_NCELL] first overflow record << 8 | count
+  const float* mesh_cell_blk;   // [nmesh][RG_NCELL][4] 16-byte records x, y, z, vertex index (int bits): the first four (padded with the last)
+  const float* mesh_cell_ovf;   // records 5.. of the cells that have more than four
+  // everything the collision stages need about a pair in one place (one load latency instead of a chain)
+  const int* pair_gg;           // [npair] g1 | g2 << 8
+  const float* pair_rec;        // [npair][RG_PAIRREC] see rg_api.hip build_pair_records
   const int* pair_geom;   // [npair][3] g1, g2, condim
   const float* pair_prm;  // [npair][12] margin, gap, friction3, solref2, solimp5
   // tendons
