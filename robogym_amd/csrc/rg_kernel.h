@@ -1503,7 +1503,10 @@ __device__ __forceinline__ int rg_solve(const RgModelDev& m, RgLds& s, int& nefc
   // count active rows (diagnostic only)
   { float cnt = 0; PFOR(r, ns) cnt += s.r_D[r] > 0 ? 1.f : 0.f; PFOR(c, ncon) cnt += (float)npyr(s.c_dim[c]); nefc_out = (int)(wave_sum(cnt) + 0.5f); }
   float scale = 1.0f / (m.meaninertia * (nv > 1 ? nv : 1));
-  float tol = fmaxf(m.tolerance, 1e-7f);
+#ifndef RG_TOL_FLOOR
+#define RG_TOL_FLOOR 1e-7f   /* fp32 cannot resolve cost improvements below this (scaled by meaninertia * nv) */
+#endif
+  float tol = fmaxf(m.tolerance, RG_TOL_FLOOR);
   PFOR(i, nvc) { int d = s.c2d[i]; s.as[i] = s.qacc_smooth[d]; s.fs[i] = s.qfrc_smooth[d]; s.a[i] = s.warm[d]; }
   SYNC();
   // warm start: the better of qacc_smooth and qacc_warmstart (evaluated last, so Ma / jar are left valid for it)
