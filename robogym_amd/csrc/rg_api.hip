@@ -145,6 +145,24 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
   UPF(dof_armature, "dof_armature"); UPF(dof_damping, "dof_damping"); UPF(dof_frictionloss, "dof_frictionloss");
   UPF(dof_solref, "dof_solref"); UPF(dof_solimp, "dof_solimp"); UPF(dof_invweight0, "dof_invweight0");
   UPF(qpos0, "qpos0"); m->qpos0 = fv; UPF(qpos_spring, "qpos_spring");
+  {  // kinematics records, one per level slot: w0 body | parent<<8 | njnt<<16 | type(first joint)<<20, w1 first joint | its qposadr<<16,
+     // w2-4 body_pos, w5-8 body_quat, w9-11 body_ipos, w12-14 jnt_pos, w15-17 jnt_axis, w18 qpos0 of the joint
+    std::vector<int> lb, par, jn, ja, jt, jq; std::vector<float> bp, bq, bi, jp, jx, q0;
+    if (!get_i(B, "k_lvl_body", lb, e) || !get_i(B, "body_parentid", par, e) || !get_i(B, "body_jntnum", jn, e) || !get_i(B, "body_jntadr", ja, e) ||
+        !get_i(B, "jnt_type", jt, e) || !get_i(B, "jnt_qposadr", jq, e) || !get_f(B, "body_pos", bp, e) || !get_f(B, "body_quat", bq, e) ||
+        !get_f(B, "body_ipos", bi, e) || !get_f(B, "jnt_pos", jp, e) || !get_f(B, "jnt_axis", jx, e) || !get_f(B, "qpos0", q0, e)) return bail(e, m);
+    std::vector<float> rec((lb.size() ? lb.size() : 1) * RG_KINREC, 0.f);
+    for (size_t k = 0; k < lb.size(); k++) {
+      int b = lb[k], j = jn[b] > 0 ? ja[b] : 0, t = jn[b] > 0 ? jt[j] : 0, qa = jn[b] > 0 ? jq[j] : 0;
+      float* r = rec.data() + k * RG_KINREC;
+      int w0 = b | (par[b] << 8) | (jn[b] << 16) | (t << 20), w1 = j | (qa << 16);
+      memcpy(r, &w0, 4); memcpy(r + 1, &w1, 4);
+      for (int c = 0; c < 3; c++) { r[2 + c] = bp[3 * b + c]; r[9 + c] = bi[3 * b + c]; r[12 + c] = jn[b] > 0 ? jp[3 * j + c] : 0.f; r[15 + c] = jn[b] > 0 ? jx[3 * j + c] : 0.f; }
+      for (int c = 0; c < 4; c++) r[5 + c] = bq[4 * b + c];
+      r[18] = jn[b] > 0 ? q0[qa] : 0.f;
+    }
+    if (!upload<float>(m, rec, &d.kin_rec)) return bail("hipMalloc failed", m);
+  }
   UPI(lvl_dof, "k_lvl_dof"); UPI(lvl_dof_adr, "k_lvl_dof_adr"); UPI(M_i, "k_M_i"); UPI(M_j, "k_M_j"); UPI(M_lvl_adr, "k_M_lvl_adr");
   UPI(desc_adr, "k_desc_adr"); UPI(desc, "k_desc");
   UPI(geom_type, "geom_type"); UPI(geom_bodyid, "geom_bodyid"); UPI(geom_dataid, "geom_dataid"); UPI(body_geomadr, "body_geomadr"); UPI(body_geomnum, "body_geomnum");

@@ -220,32 +220,39 @@ __device__ __forceinline__ void rg_kinematics(const RgModelDev& m, RgLds& s) {
   for (int L = 0; L < m.nlevel; L++) {
     int a0 = m.lvl_body_adr[L], a1 = m.lvl_body_adr[L + 1];
     for (int k = a0 + LANE; k < a1; k += RG_WAVE) {
-      int b = m.lvl_body[k], p = m.body_parentid[b];
-      v3 pos = ld3(s.xpos + 3 * p) + mulm(s.xmat + 9 * p, ld3(m.body_pos + 3 * b));
-      q4 quat = qmul(ldq(s.xquat + 4 * p), ldq(m.body_quat + 4 * b));
-      int jn = m.body_jntnum[b], ja = m.body_jntadr[b];
+      // everything static about this level slot in one 80-byte record (one load latency, not a chain of four)
+      const rgf4* R = (const rgf4*)m.kin_rec + (RG_KINREC / 4) * k;
+      rgf4 r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3], r4 = R[4];
+      int w0 = __builtin_bit_cast(int, r0.x), w1 = __builtin_bit_cast(int, r0.y);
+      int b = w0 & 255, p = (w0 >> 8) & 255, jn = (w0 >> 16) & 15, ja = w1 & 0xFFFF;
+      v3 bipos = mk3(r2.y, r2.z, r2.w);
+      v3 pos = ld3(s.xpos + 3 * p) + mulm(s.xmat + 9 * p, mk3(r0.z, r0.w, r1.x));
+      q4 bq; bq.w = r1.y; bq.x = r1.z; bq.y = r1.w; bq.z = r2.x;
+      q4 quat = qmul(ldq(s.xquat + 4 * p), bq);
       for (int jj = 0; jj < jn; jj++) {
-        int j = ja + jj, t = m.jnt_type[j], qa = m.jnt_qposadr[j];
+        int j = ja + jj, t, qa; v3 jpos, jaxis; float q0;
+        if (jj == 0) { t = (w0 >> 20) & 15; qa = (w1 >> 16) & 0xFFFF; jpos = mk3(r3.x, r3.y, r3.z); jaxis = mk3(r3.w, r4.x, r4.y); q0 = r4.z; }
+        else { t = m.jnt_type[j]; qa = m.jnt_qposadr[j]; jpos = ld3(m.jnt_pos + 3 * j); jaxis = ld3(m.jnt_axis + 3 * j); q0 = m.qpos0[qa]; }
         if (t == RG_JNT_FREE) {
           pos = ld3(s.qpos + qa); quat = qnormalize(ldq(s.qpos + qa + 3));
           st3(s.xanchor + 3 * j, pos); st3(s.xaxis + 3 * j, mk3(0, 0, 1));
           continue;
         }
         float mat[9]; q2mat(mat, quat);
-        v3 anchor = pos + mulm(mat, ld3(m.jnt_pos + 3 * j));
-        v3 axis = mulm(mat, ld3(m.jnt_axis + 3 * j));
+        v3 anchor = pos + mulm(mat, jpos);
+        v3 axis = mulm(mat, jaxis);
         st3(s.xanchor + 3 * j, anchor); st3(s.xaxis + 3 * j, axis);
-        if (t == RG_JNT_SLIDE) pos = pos + axis * (s.qpos[qa] - m.qpos0[qa]);
+        if (t == RG_JNT_SLIDE) pos = pos + axis * (s.qpos[qa] - q0);
         else {
-          q4 ql = (t == RG_JNT_BALL) ? qnormalize(ldq(s.qpos + qa)) : axisangle(ld3(m.jnt_axis + 3 * j), s.qpos[qa] - m.qpos0[qa]);
+          q4 ql = (t == RG_JNT_BALL) ? qnormalize(ldq(s.qpos + qa)) : axisangle(jaxis, s.qpos[qa] - q0);
           quat = qmul(quat, ql);
           q2mat(mat, quat);
-          pos = anchor - mulm(mat, ld3(m.jnt_pos + 3 * j));
+          pos = anchor - mulm(mat, jpos);
         }
       }
       quat = qnormalize(quat);
       st3(s.xpos + 3 * b, pos); stq(s.xquat + 4 * b, quat); q2mat(s.xmat + 9 * b, quat);
-      st3(s.xipos + 3 * b, pos + mulm(s.xmat + 9 * b, ld3(m.body_ipos + 3 * b)));
+      st3(s.xipos + 3 * b, pos + mulm(s.xmat + 9 * b, bipos));
     }
     SYNC();
   }
@@ -838,19 +845,28 @@ __device__ __forceinline__ void rg_collision(const RgModelDev& m, RgLds& s, floa
   int nround = (m.npair + RG_WAVE - 1) / RG_WAVE;
   float hb = 1.5f * m.timestep;
   int nt = 0;
-  for (int r = 0; r < nround; r++) {
-    int p = r * RG_WAVE + LANE;
-    bool need = false;
-    if (p < m.npair) {
-      int gg = m.pair_gg[p], g1 = gg & 255, g2 = gg >> 8;
-      float lb = (pairlb ? pairlb[p] : 0.f) - (hb * (s.gspeed[g1] + s.gspeed[g2]) + 1e-7f);
-      need = !(lb > 0.f);
-      if (!need) pairlb[p] = lb;
+  for (int r0 = 0; r0 < nround; r0 += 4) {   // four rounds per trip: eight independent loads in flight per lane
+    int gg[4]; float lbv[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      int p = (r0 + k) * RG_WAVE + LANE, pc = p < m.npair ? p : m.npair - 1;
+      gg[k] = m.pair_gg[pc]; lbv[k] = pairlb ? pairlb[pc] : 0.f;
     }
-    unsigned long long nb = __ballot(need);
-    if (need) s.tlist[nt + __popcll(nb & ((1ull << LANE) - 1ull))] = (short)p;
-    nt += __popcll(nb);
-    if (nt <= RG_TLIST - RG_WAVE && r != nround - 1) continue;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      int p = (r0 + k) * RG_WAVE + LANE;
+      bool need = false;
+      if (p < m.npair) {
+        int g1 = gg[k] & 255, g2 = gg[k] >> 8;
+        float lb = lbv[k] - (hb * (s.gspeed[g1] + s.gspeed[g2]) + 1e-7f);
+        need = !(lb > 0.f);
+        if (!need) pairlb[p] = lb;
+      }
+      unsigned long long nb = __ballot(need);
+      if (need) s.tlist[nt + __popcll(nb & ((1ull << LANE) - 1ull))] = (short)p;
+      nt += __popcll(nb);
+    }
+    if (nt <= RG_TLIST - 4 * RG_WAVE && r0 + 4 < nround) continue;
     SYNC();
     for (int i0 = 0; i0 < nt; i0 += RG_WAVE) {
       int i = i0 + LANE, q = 0;
