@@ -1351,37 +1351,53 @@ __device__ __forceinline__ void rg_chol(const RgModelDev& m, RgLds& s) {
   }
   if (bad && i == 0) s.status |= RG_STATUS_BAD_FACTOR;
 }
-// x <- H^-1 x with the factor above, four pivots per step; lane i owns x[i]
-__device__ __forceinline__ void rg_chol_solve(const RgModelDev& m, RgLds& s, float* x) {
-  int n = m.nvc, hs = m.hs, hs4 = hs >> 2, i = LANE;
+// x <- H^-1 x with the factor above, four pivots per step; lane i owns x[i].  The operands of step k+1 (pivot
+// rows, reciprocal pivots, the lane's own chunk) do not depend on step k's result, so they are fetched one
+// step ahead and the LDS latency hides behind the substitution arithmetic.
+struct TriOps { rgf4 q1, q2, q3, own; float i00, i11, i22, i33; float c0, c1, c2, c3; };
+__device__ __forceinline__ void tri_fetch(const RgLds& s, int n, int hs, int j0, int i, bool backward, TriOps& t) {
   const float* H = s.H; const rgf4* H4 = (const rgf4*)s.H;
+  int hs4 = hs >> 2, jb = j0 >> 2, nb = n - j0;
+  int r1 = j0 + 1 < n ? j0 + 1 : n - 1, r2 = j0 + 2 < n ? j0 + 2 : n - 1, r3 = j0 + 3 < n ? j0 + 3 : n - 1;
+  t.q1 = H4[r1 * hs4 + jb]; t.q2 = H4[r2 * hs4 + jb]; t.q3 = H4[r3 * hs4 + jb];
+  t.i00 = s.dinv[j0]; t.i11 = s.dinv[r1]; t.i22 = s.dinv[r2]; t.i33 = s.dinv[r3];
+  if (nb <= 1) t.i11 = 0.f;
+  if (nb <= 2) t.i22 = 0.f;
+  if (nb <= 3) t.i33 = 0.f;
+  int ic = i < n ? i : n - 1;
+  if (!backward) t.own = H4[ic * hs4 + jb];
+  else { t.c0 = H[j0 * hs + ic]; t.c1 = H[r1 * hs + ic]; t.c2 = H[r2 * hs + ic]; t.c3 = H[r3 * hs + ic]; }
+}
+__device__ __forceinline__ void rg_chol_solve(const RgModelDev& m, RgLds& s, float* x) {
+  int n = m.nvc, hs = m.hs, i = LANE;
   float xi = i < n ? x[i] : 0.f;
+  TriOps cur, nxt;
+  tri_fetch(s, n, hs, 0, i, false, cur);
   for (int j0 = 0; j0 < n; j0 += 4) {  // forward: L y = b
-    int jb = j0 >> 2, nb = n - j0;
-    int r1 = j0 + 1 < n ? j0 + 1 : n - 1, r2 = j0 + 2 < n ? j0 + 2 : n - 1, r3 = j0 + 3 < n ? j0 + 3 : n - 1;
-    rgf4 q1 = H4[r1 * hs4 + jb], q2 = H4[r2 * hs4 + jb], q3 = H4[r3 * hs4 + jb];
-    float i00 = s.dinv[j0], i11 = nb > 1 ? s.dinv[r1] : 0.f, i22 = nb > 2 ? s.dinv[r2] : 0.f, i33 = nb > 3 ? s.dinv[r3] : 0.f;
-    float x0 = lane_bcast(xi, j0) * i00;
-    float x1 = (lane_bcast(xi, j0 + 1) - q1.x * x0) * i11;
-    float x2 = (lane_bcast(xi, j0 + 2) - q2.x * x0 - q2.y * x1) * i22;
-    float x3 = (lane_bcast(xi, j0 + 3) - q3.x * x0 - q3.y * x1 - q3.z * x2) * i33;
+    if (j0 + 4 < n) tri_fetch(s, n, hs, j0 + 4, i, false, nxt);
+    float x0 = lane_bcast(xi, j0) * cur.i00;
+    float x1 = (lane_bcast(xi, j0 + 1) - cur.q1.x * x0) * cur.i11;
+    float x2 = (lane_bcast(xi, j0 + 2) - cur.q2.x * x0 - cur.q2.y * x1) * cur.i22;
+    float x3 = (lane_bcast(xi, j0 + 3) - cur.q3.x * x0 - cur.q3.y * x1 - cur.q3.z * x2) * cur.i33;
     int r = i - j0;
-    if (r >= 4 && i < n) { rgf4 own = H4[i * hs4 + jb]; xi -= own.x * x0 + own.y * x1 + own.z * x2 + own.w * x3; }
+    if (r >= 4 && i < n) xi -= cur.own.x * x0 + cur.own.y * x1 + cur.own.z * x2 + cur.own.w * x3;
     else if (r == 0) xi = x0; else if (r == 1) xi = x1; else if (r == 2) xi = x2; else if (r == 3) xi = x3;
+    cur = nxt;
   }
-  for (int j0 = ((n - 1) >> 2) << 2; j0 >= 0; j0 -= 4) {  // backward: L' x = y
-    int jb = j0 >> 2, nb = n - j0;
-    int r1 = j0 + 1 < n ? j0 + 1 : n - 1, r2 = j0 + 2 < n ? j0 + 2 : n - 1, r3 = j0 + 3 < n ? j0 + 3 : n - 1;
-    rgf4 q1 = H4[r1 * hs4 + jb], q2 = H4[r2 * hs4 + jb], q3 = H4[r3 * hs4 + jb];
-    float i00 = s.dinv[j0], i11 = nb > 1 ? s.dinv[r1] : 0.f, i22 = nb > 2 ? s.dinv[r2] : 0.f, i33 = nb > 3 ? s.dinv[r3] : 0.f;
-    float l10 = nb > 1 ? q1.x : 0.f, l20 = nb > 2 ? q2.x : 0.f, l21 = nb > 2 ? q2.y : 0.f, l30 = nb > 3 ? q3.x : 0.f, l31 = nb > 3 ? q3.y : 0.f, l32 = nb > 3 ? q3.z : 0.f;
-    float x3 = lane_bcast(xi, j0 + 3) * i33;
-    float x2 = (lane_bcast(xi, j0 + 2) - l32 * x3) * i22;
-    float x1 = (lane_bcast(xi, j0 + 1) - l21 * x2 - l31 * x3) * i11;
-    float x0 = (lane_bcast(xi, j0) - l10 * x1 - l20 * x2 - l30 * x3) * i00;
+  int jl = ((n - 1) >> 2) << 2;
+  tri_fetch(s, n, hs, jl, i, true, cur);
+  for (int j0 = jl; j0 >= 0; j0 -= 4) {  // backward: L' x = y
+    if (j0 >= 4) tri_fetch(s, n, hs, j0 - 4, i, true, nxt);
+    int nb = n - j0;
+    float l10 = nb > 1 ? cur.q1.x : 0.f, l20 = nb > 2 ? cur.q2.x : 0.f, l21 = nb > 2 ? cur.q2.y : 0.f, l30 = nb > 3 ? cur.q3.x : 0.f, l31 = nb > 3 ? cur.q3.y : 0.f, l32 = nb > 3 ? cur.q3.z : 0.f;
+    float x3 = lane_bcast(xi, j0 + 3) * cur.i33;
+    float x2 = (lane_bcast(xi, j0 + 2) - l32 * x3) * cur.i22;
+    float x1 = (lane_bcast(xi, j0 + 1) - l21 * x2 - l31 * x3) * cur.i11;
+    float x0 = (lane_bcast(xi, j0) - l10 * x1 - l20 * x2 - l30 * x3) * cur.i00;
     int r = i - j0;
-    if (i < j0) xi -= H[j0 * hs + i] * x0 + (nb > 1 ? H[r1 * hs + i] * x1 : 0.f) + (nb > 2 ? H[r2 * hs + i] * x2 : 0.f) + (nb > 3 ? H[r3 * hs + i] * x3 : 0.f);
+    if (i < j0) xi -= cur.c0 * x0 + (nb > 1 ? cur.c1 * x1 : 0.f) + (nb > 2 ? cur.c2 * x2 : 0.f) + (nb > 3 ? cur.c3 * x3 : 0.f);
     else if (r == 0) xi = x0; else if (r == 1) xi = x1; else if (r == 2) xi = x2; else if (r == 3) xi = x3;
+    cur = nxt;
   }
   if (i < n) x[i] = xi;
   SYNC();
@@ -1563,11 +1579,16 @@ __device__ __forceinline__ int rg_solve(const RgModelDev& m, RgLds& s, int& nefc
     if (!have_factor || flags_changed) {
     have_factor = true;
     // H = M + J' D J over the quadratic rows (LDS atomics from one wave: in-order, deterministic)
-    for (int w = LANE; w < nvc * hs; w += RG_WAVE) s.H[w] = 0.f;
-    SYNC();
-    for (int w = LANE; w < nvc * 32; w += RG_WAVE) {
-      int i = w >> 5, k = w & 31, blk = s.cblk[i];
-      if (k < ((blk >> 24) & 255)) s.H[i * hs + ((blk >> 16) & 255) + k] = s.M[(blk & 0xFFFF) + k];
+    {  // H <- M expanded from the per-tree blocks: one 16-byte store per (row, 4-column chunk), zeros outside the tree
+      int hs4 = hs >> 2; rgf4* H4 = (rgf4*)s.H;
+      for (int w = LANE; w < nvc * hs4; w += RG_WAVE) {
+        int i = w / hs4, c = w - i * hs4, blk = s.cblk[i], k0 = 4 * c - ((blk >> 16) & 255), n = (blk >> 24) & 255;
+        const float* Mr = s.M + (blk & 0xFFFF);
+        rgf4 o;
+        o.x = (k0 >= 0 && k0 < n) ? Mr[k0] : 0.f; o.y = (k0 + 1 >= 0 && k0 + 1 < n) ? Mr[k0 + 1] : 0.f;
+        o.z = (k0 + 2 >= 0 && k0 + 2 < n) ? Mr[k0 + 2] : 0.f; o.w = (k0 + 3 >= 0 && k0 + 3 < n) ? Mr[k0 + 3] : 0.f;
+        H4[w] = o;
+      }
     }
     SYNC();
     PFOR(r, ns) if (s.r_D[r] > 0 && s.r_quad[r]) srow_hess(m, s, r, s.r_D[r]);
