@@ -69,9 +69,16 @@ int rg_batch_set_env(rg_batch* b, const int* ints, int nints, const float* pos_t
  * to_batch != 0 copies ptr -> batch field, else batch field -> ptr; ptr_is_device selects HBM vs host. */
 int rg_batch_copy(rg_batch* b, int field, void* ptr, int to_batch, int ptr_is_device);
 int rg_batch_reset(rg_batch* b);
+/* Masked row copy, device to device and asynchronous on `stream`: for every env e with mask_dev[e] != 0 the
+ * columns [col0, col0 + ncols) of its `field` row are replaced by row e of src_dev ([B][ncols]; ncols <= 0: the
+ * whole row, src_dev laid out as for rg_batch_copy).  Writing RG_F_QPOS voids the collision caches of those
+ * envs only.  This is what a per-env `MjSim.set_state` / `mj_resetData` is for
+ * a batch (simulation_interface.py:128-172, cube_env.py:330-355) without stalling the other envs. */
+int rg_batch_copy_rows(rg_batch* b, int field, const void* src_dev, const int* mask_dev, int col0, int ncols, void* stream);
 
 /* One env.step of the whole batch (robot_env.py:804-844 + simulation_interface.py:176-189):
- *   action_dev   float [B][nu] in [-1,1] or NULL (then the stored ctrl row is used unchanged)
+ *   action_dev   float [B][nu] in [-1,1] or NULL (then the stored ctrl row is used unchanged); a row whose first
+ *                entry is NaN keeps that env's stored ctrl row (envs that are being reset follow a scripted ctrl)
  *   goal_quat_dev float [B][4] or NULL
  *   obs_dev      float [B][rg_obs_dim] or NULL:  cube_pos3 cube_quat4 qpos[nq] qvel[nv] hand_angle[nh] fingertip_pos15
  *   goal_dist_dev float [B] or NULL

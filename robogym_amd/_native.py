@@ -15,7 +15,7 @@ RG_F_QPOS, RG_F_QVEL, RG_F_CTRL, RG_F_PID, RG_F_WARMSTART, RG_F_TIME, RG_F_STATU
 EXPORTS = [
     "rg_model_create", "rg_model_free", "rg_model_dims", "rg_batch_create", "rg_batch_free", "rg_batch_set_env",
     "rg_batch_copy", "rg_batch_reset", "rg_batch_step", "rg_obs_dim", "rg_debug_size", "rg_lds_bytes", "rg_sync",
-    "rg_last_error", "rg_batch_mpr_pair",
+    "rg_last_error", "rg_batch_mpr_pair", "rg_batch_copy_rows",
 ]
 
 
@@ -42,6 +42,7 @@ def bind(path):
     L.rg_batch_set_env.argtypes = [vp, ctypes.POINTER(ci), ci, ctypes.POINTER(cf), cf]
     L.rg_batch_copy.argtypes = [vp, ci, vp, ci, ci]
     L.rg_batch_reset.argtypes = [vp]
+    L.rg_batch_copy_rows.argtypes = [vp, ci, vp, vp, ci, ci, vp]
     L.rg_batch_step.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]
     L.rg_batch_mpr_pair.argtypes = [vp, ci, ci, cf, vp, vp]
     L.rg_obs_dim.argtypes = [vp]

@@ -347,6 +347,38 @@ int rg_batch_copy(rg_batch* b, int field, void* ptr, int to_batch, int ptr_is_de
 }
 
 #ifdef RG_EMUL
+struct EmulCopyArgs { float* dst; const float* src; const int* mask; int n, col0, ncols; float* lb; int npair; };
+static void emul_copy_entry(void* a) { EmulCopyArgs* p = (EmulCopyArgs*)a; rg_copy_rows_kernel(p->dst, p->src, p->mask, p->n, p->col0, p->ncols, p->lb, p->npair); }
+#endif
+int rg_batch_copy_rows(rg_batch* b, int field, const void* src_dev, const int* mask_dev, int col0, int ncols, void* stream) {
+  if (!b || !src_dev || !mask_dev) return fail("rg_batch_copy_rows: null argument");
+  const RgModelDev& d = b->model->dev;
+  RgBatchDev& s = b->dev;
+  void* p; int n;
+  switch (field) {
+    case RG_F_QPOS: p = s.qpos; n = d.nq; break;
+    case RG_F_QVEL: p = s.qvel; n = d.nv; break;
+    case RG_F_CTRL: p = s.ctrl; n = d.nu; break;
+    case RG_F_PID: p = s.pid; n = 3 * d.nu; break;
+    case RG_F_WARMSTART: p = s.qacc_warmstart; n = d.nv; break;
+    case RG_F_TIME: p = s.time; n = 1; break;
+    case RG_F_STATUS: p = s.status; n = 1; break;
+    default: return fail("rg_batch_copy_rows: field cannot be written row-wise");
+  }
+  if (ncols <= 0) { col0 = 0; ncols = n; }
+  if (col0 < 0 || col0 + ncols > n) return fail("rg_batch_copy_rows: column range outside the row");
+  float* lb = field == RG_F_QPOS ? s.pairlb : nullptr;
+#ifdef RG_EMUL
+  EmulCopyArgs args{(float*)p, (const float*)src_dev, mask_dev, n, col0, ncols, lb, d.npair};
+  emul_launch(s.B, 16, emul_copy_entry, &args);
+#else
+  hipLaunchKernelGGL(rg_copy_rows_kernel, dim3(s.B), dim3(RG_WAVE), 0, (hipStream_t)stream, (float*)p, (const float*)src_dev, mask_dev, n, col0, ncols, lb, d.npair);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+
+#ifdef RG_EMUL
 struct EmulArgs { RgModelDev m; RgAux x; RgEnvDev env; RgBatchDev bt; int nsub, nticks, flags; };
 static void emul_entry(void* a) { EmulArgs* p = (EmulArgs*)a; rg_step_kernel(p->m, p->x, p->env, p->bt, p->nsub, p->nticks, p->flags); }
 #endif

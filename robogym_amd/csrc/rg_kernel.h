@@ -1732,7 +1732,8 @@ __global__ void __launch_bounds__(RG_WAVE, 2) rg_step_kernel(RgModelDev m, RgAux
   if (LANE < RG_NPROF) s.prof[LANE] = 0;
   rg_build_row_desc(m, s);
   // ---- action -> ctrl (robot_interface.py:247-278 with the hand's position->control matrix)
-  if (bt.action) {
+  float a0 = bt.action ? bt.action[(size_t)e * m.nu] : 0.f;
+  if (bt.action && a0 == a0) {   // a NaN first entry: this env keeps its stored ctrl row
     PFOR(u, m.nu) {
       float lo = m.actuator_ctrlrange[2 * u], hi = m.actuator_ctrlrange[2 * u + 1], centre;
       if (env.relative_action) { centre = 0; for (int j = 0; j < env.n_hand_jnt; j++) centre += env.pos_to_ctrl[u * env.n_hand_jnt + j] * s.qpos[env.hand_qposadr + j]; }
@@ -1851,4 +1852,12 @@ __global__ void __launch_bounds__(RG_WAVE) rg_mpr_pair_kernel(RgModelDev m, RgBa
     float* o = out + 8 * (size_t)e;
     o[0] = hit ? 1.f : 0.f; o[1] = depth; o[2] = dir.x; o[3] = dir.y; o[4] = dir.z; o[5] = pos.x + p1.x; o[6] = pos.y + p1.y; o[7] = pos.z + p1.z;
   }
+}
+
+// masked row copy (rg_batch_copy_rows): one workgroup per env
+__global__ void rg_copy_rows_kernel(float* dst, const float* src, const int* mask, int n, int col0, int ncols, float* pairlb, int npair) {
+  int e = blockIdx.x;
+  if (!mask[e]) return;
+  for (int i = LANE; i < ncols; i += RG_WAVE) dst[(size_t)e * n + col0 + i] = src[(size_t)e * ncols + i];
+  if (pairlb) for (int i = LANE; i < npair; i += RG_WAVE) pairlb[(size_t)e * npair + i] = 0.f;
 }

@@ -82,6 +82,16 @@ class BatchedSimulationInterface:
         self.sync()
         _native.check(self._L, self._L.rg_batch_copy(self._bh, field, value.data_ptr(), 1, 0 if self._emul else 1), "rg_batch_copy")
 
+    def copy_rows(self, field, value: torch.Tensor, mask: torch.Tensor, col0: int = 0):
+        """Asynchronous masked write (rg_batch_copy_rows): rows of the envs with mask != 0, columns
+        [col0, col0 + value.shape[1]) <- value.  Stream-ordered with the step launches; no host sync."""
+        dtype = torch.int32 if field == _native.RG_F_STATUS else torch.float32
+        value = torch.as_tensor(value, dtype=dtype, device=self.device).reshape(self.batch_size, -1).contiguous()
+        mask = mask.to(device=self.device, dtype=torch.int32).contiguous()
+        stream = None if self._emul else ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _native.check(self._L, self._L.rg_batch_copy_rows(self._bh, field, value.data_ptr(), mask.data_ptr(), int(col0), int(value.shape[1]), stream), "rg_batch_copy_rows")
+        self._keepalive = (value, mask)   # the launch is asynchronous: keep the operands alive until the next call
+
     @property
     def qpos(self) -> torch.Tensor:
         return self.get_field(_native.RG_F_QPOS)

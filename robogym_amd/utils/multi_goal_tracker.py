@@ -30,21 +30,27 @@ class BatchedMultiGoalTracker:
         self.steps_since_last_goal = torch.where(mask, zero, self.steps_since_last_goal)
         self.consecutive_success = torch.where(mask, zero, self.consecutive_success)
 
-    def process(self, is_successful: torch.Tensor, goal_distance_reward: torch.Tensor):
+    def process(self, is_successful: torch.Tensor, goal_distance_reward: torch.Tensor, live: torch.Tensor = None):
         """:157-241.  Returns (reward [B,3], done [B], new_goal [B], info).  The caller samples the new
-        goals for `new_goal` (the reference calls `reset_goal_fn` from inside `process`)."""
-        self.steps += 1
-        self.steps_since_last_goal += 1
-        self.consecutive_success = torch.where(is_successful, self.consecutive_success + 1, torch.zeros_like(self.consecutive_success))
-        got = self.consecutive_success >= 1
+        goals for `new_goal` (the reference calls `reset_goal_fn` from inside `process`).
+        `live` (optional bool [B]): envs outside it are not stepped by the tracker this call (they are in the
+        middle of a pipelined reset): counters untouched, zero reward, not done."""
+        if live is None:
+            live = torch.ones_like(is_successful)
+        one = live.to(torch.int32)
+        is_successful = is_successful & live
+        self.steps += one
+        self.steps_since_last_goal += one
+        self.consecutive_success = torch.where(live, torch.where(is_successful, self.consecutive_success + 1, torch.zeros_like(self.consecutive_success)), self.consecutive_success)
+        got = (self.consecutive_success >= 1) & live
         success_reward = got.to(torch.float32) * self.success_reward
         self.successes_so_far += got.to(torch.int32)
-        timeout = (~got) & (self.steps_since_last_goal >= self.max_timesteps_per_goal)
+        timeout = (~got) & live & (self.steps_since_last_goal >= self.max_timesteps_per_goal)
         trial_success = got & (self.successes_so_far >= self.successes_needed)
         done = timeout | trial_success
         self.steps_since_last_goal = torch.where(trial_success, torch.zeros_like(self.steps_since_last_goal), self.steps_since_last_goal)
         new_goal = got & ~trial_success
-        goal_reward = goal_distance_reward if self.use_goal_distance_reward else torch.zeros_like(goal_distance_reward)
+        goal_reward = goal_distance_reward * live.to(goal_distance_reward.dtype) if self.use_goal_distance_reward else torch.zeros_like(goal_distance_reward)
         reward = torch.stack([torch.zeros_like(goal_reward), goal_reward, success_reward], dim=-1)
         info: Dict[str, torch.Tensor] = {
             "sub_goal_is_successful": got,

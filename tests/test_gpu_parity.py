@@ -206,3 +206,29 @@ def test_pair_distance_cache_is_exact_gpu():
                 q = sim.qpos.clone(); q[::2, 2] += 0.02; sim.set_field(0, q)
     assert torch.equal(sims[0].qpos, sims[1].qpos) and torch.equal(sims[0].qvel, sims[1].qvel)
     assert int(sims[0].status.max().item()) == 0
+
+
+def test_pipelined_reset_gpu():
+    """Pipelined resets on the MI355X: goals time out every 5 steps, so every env goes through the reset recipe
+    (20 zero-action steps, cube perturbation, 10 random-action steps, on-palm retry) inside the regular step
+    launches.  Property from the reference's reset test (test_locked.py:10-67): >= 80 % of the freshly started
+    episodes have the cube on the palm at their first try budget; states finite; no status bit but CON_FULL."""
+    from robogym_amd.envs.dactyl.locked import BatchedLockedEnv, LockedEnvConstants
+
+    B = 512
+    env = BatchedLockedEnv(B, device="cuda:0", constants=LockedEnvConstants(max_timesteps_per_goal=5), starting_seed=11, pipelined_reset=True)
+    env.reset()
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(2)
+    started, on_palm_at_start, ndone = 0, 0, 0
+    for k in range(90):
+        a = torch.rand((B, 20), generator=gen, device="cuda:0") * 2 - 1
+        obs, reward, done, info = env.step(a)
+        s = info["episode_started"]
+        started += int(s.sum()); ndone += int(done.sum())
+        on_palm_at_start += int((s & (0.2 + obs["cube_pos"][:, 2] > 0.04)).sum())
+        assert (reward[info["resetting"] & ~done] == 0).all()      # (the step that ends an episode still pays its reward)
+    assert ndone >= B and started >= B                      # every env finished and restarted at least once
+    assert on_palm_at_start >= 0.8 * started, (on_palm_at_start, started)
+    for k_, v in obs.items():
+        assert torch.isfinite(v.float()).all(), k_
+    assert int(env.sim_status().max().item()) & ~2 == 0

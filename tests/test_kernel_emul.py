@@ -100,3 +100,29 @@ def test_pair_distance_cache_is_exact(locked_model, emul_lib):
             sim.env_step(action=a, nforward_ticks=3, flags=fl)
     assert torch.equal(sims[0].qpos, sims[1].qpos) and torch.equal(sims[0].qvel, sims[1].qvel)
     assert int(sims[0].status.max()) == 0
+
+
+def test_pipelined_reset_state_machine(locked_model, emul_lib):
+    """finished episodes are re-initialised inside the following step launches.  Short
+    recipe (2 zero-action steps, perturbation, 1 random-action step), goals time out after 3 steps:
+    step 3 reports done; steps 4-6 run the recipe (`resetting`, zero reward, action ignored); the step that
+    completes it starts the new episode (tracker and clock at zero, goal resampled, state finite)."""
+    from robogym_amd.envs.dactyl.locked import BatchedLockedEnv, LockedEnvConstants
+
+    c = LockedEnvConstants(max_timesteps_per_goal=3, reset_initial_steps=2, n_random_initial_steps=1)
+    env = BatchedLockedEnv(2, constants=c, model=locked_model, lib=emul_lib, starting_seed=3, pipelined_reset=True)
+    env.reset()
+    a = torch.zeros((2, 20))
+    log = []
+    for k in range(8):
+        obs, reward, done, info = env.step(a)
+        log.append((done.clone(), info["resetting"].clone(), info["episode_started"].clone(), reward.clone(), env.t.clone(), env.multi_goal_tracker.steps.clone()))
+    assert not log[0][0].any() and not log[1][0].any() and log[2][0].all()          # timeout on the third step
+    assert all(log[k][1].all() for k in (2, 3, 4)) and not log[5][1].any()             # three recipe steps follow
+    assert log[5][2].all() and not any(log[k][2].any() for k in (0, 1, 2, 3, 4, 6))     # the episode starts once
+    assert all((log[k][3] == 0).all() for k in (3, 4, 5))                              # no reward while resetting
+    assert (log[5][4] == 0).all() and (log[6][4] == 1).all() and (log[5][5] == 0).all() and (log[6][5] == 1).all()
+    assert not log[6][0].any() and not log[7][0].any()
+    q = env.mujoco_simulation.qpos
+    assert torch.isfinite(q).all() and int(env.sim_status().max()) == 0
+    assert (0.2 + obs["cube_pos"][:, 2] > 0.04).all()                                  # the cube rests in the hand
