@@ -1,13 +1,14 @@
 // rg_kernel.h — the batched env.step kernel for gfx950 (MI355X).
 //
 // Execution plan: ONE 64-lane wavefront (= one workgroup) per environment.  The whole env step —
-// action -> ctrl, nsubsteps x mj_step (kinematics, tendons, CRB + tree-sparse L'DL, convex collision
-// by MPR, constraint rows, PID actuation, Newton solve, implicit-damping Euler), the three PID
+// action -> ctrl, nsubsteps x mj_step (kinematics, tendons, CRB into per-tree dense blocks, velocities,
+// collision = cached distance bounds + boxes + MPR, constraint rows, PID actuation, blocked Cholesky,
+// Newton solve, implicit-damping Euler), the three PID
 // ticks of the reference's state-less forward() calls, observation readout and goal distance —
 // runs inside one launch with all per-env state resident in LDS.  HBM traffic per env step is the
 // state row in, state row + observation row out (row-major [B][n] buffers, contiguous per env so
-// a wave's loads are coalesced).  Tree recursions are level sweeps over precomputed level lists,
-// reductions are wave butterflies, sparse scatters are LDS atomics issued by a single wave
+// a wave's loads are coalesced) plus the stream of per-pair collision caches (pairlb, sepdir).  Tree recursions are level sweeps over precomputed level lists,
+// reductions are DPP row shifts/broadcasts, sparse scatters are LDS atomics issued by a single wave
 // (in-order, hence deterministic).  No MFMA: this is sparse articulated dynamics.
 //
 // Replaces, for the hot path, mujoco_py.MjSim.step + mjpid (reference call sites:
