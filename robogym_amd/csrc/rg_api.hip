@@ -51,10 +51,16 @@ struct rg_batch {
 namespace {
 struct Blob {
   const char* base; size_t nbytes;
+  // directory entries are validated against the blob size here, so the readers below cannot run past the buffer
   const blob_entry* find(const char* name) const {
     uint32_t n = *(const uint32_t*)(base + 8);
+    if (16 + (uint64_t)n * sizeof(blob_entry) > nbytes) return nullptr;
     const blob_entry* e = (const blob_entry*)(base + 16);
-    for (uint32_t i = 0; i < n; i++) if (strncmp(e[i].name, name, 40) == 0) return &e[i];
+    for (uint32_t i = 0; i < n; i++) if (strncmp(e[i].name, name, 40) == 0) {
+      uint64_t esz = e[i].dtype == 0 ? 8 : 4;
+      if (e[i].dtype > 2 || e[i].offset > nbytes || (uint64_t)e[i].count * esz > nbytes - e[i].offset) return nullptr;
+      return &e[i];
+    }
     return nullptr;
   }
 };
@@ -62,14 +68,14 @@ struct Blob {
 template <class T> bool upload(rg_model* m, const std::vector<T>& host, const T** dst) {
   void* p = nullptr;
   if (hipMalloc(&p, (host.size() ? host.size() : 1) * sizeof(T)) != hipSuccess) return false;
+  m->allocs.push_back(p);   // owned by the model from here on (freed by rg_model_free also on a failed create)
   if (host.size() && hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return false;
-  m->allocs.push_back(p);
   *dst = (const T*)p;
   return true;
 }
 bool get_f(const Blob& b, const char* name, std::vector<float>& out, std::string& err) {
   const blob_entry* e = b.find(name);
-  if (!e) { err = std::string("model blob lacks '") + name + "'"; return false; }
+  if (!e) { err = std::string("model blob lacks '") + name + "' (or its directory entry is out of bounds)"; return false; }
   out.resize(e->count);
   if (e->dtype == 0) { const double* p = (const double*)(b.base + e->offset); for (uint32_t i = 0; i < e->count; i++) out[i] = (float)p[i]; }
   else if (e->dtype == 2) { const float* p = (const float*)(b.base + e->offset); for (uint32_t i = 0; i < e->count; i++) out[i] = p[i]; }
@@ -78,7 +84,7 @@ bool get_f(const Blob& b, const char* name, std::vector<float>& out, std::string
 }
 bool get_i(const Blob& b, const char* name, std::vector<int>& out, std::string& err) {
   const blob_entry* e = b.find(name);
-  if (!e) { err = std::string("model blob lacks '") + name + "'"; return false; }
+  if (!e) { err = std::string("model blob lacks '") + name + "' (or its directory entry is out of bounds)"; return false; }
   if (e->dtype != 1) { err = std::string("'") + name + "' is not int32"; return false; }
   out.assign((const int*)(b.base + e->offset), (const int*)(b.base + e->offset) + e->count);
   return true;

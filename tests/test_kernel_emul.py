@@ -126,3 +126,18 @@ def test_pipelined_reset_state_machine(locked_model, emul_lib):
     q = env.mujoco_simulation.qpos
     assert torch.isfinite(q).all() and int(env.sim_status().max()) == 0
     assert (0.2 + obs["cube_pos"][:, 2] > 0.04).all()                                  # the cube rests in the hand
+
+
+def test_model_blob_is_validated(emul_lib, locked_model):
+    """The C ABI refuses blobs whose directory points outside the buffer (and says why) instead of reading past it."""
+    import ctypes
+
+    from robogym_amd.mujoco.model_blob import pack_model
+
+    blob = pack_model(locked_model)
+    err = ctypes.create_string_buffer(256)
+    assert not emul_lib.rg_model_create(b"garbage!" + blob[8:], len(blob), err, 256) and b"RGMODEL1" in err.value
+    assert not emul_lib.rg_model_create(blob, len(blob) // 2, err, 256) and b"out of bounds" in err.value   # truncated payload
+    h = emul_lib.rg_model_create(blob, len(blob), err, 256)
+    assert h, err.value
+    emul_lib.rg_model_free(h)
