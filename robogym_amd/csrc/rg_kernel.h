@@ -1501,12 +1501,32 @@ __device__ __forceinline__ void rg_block_factor_solve(const RgModelDev& m, RgLds
 }
 
 struct LsPt { float cost, grad, hess; };
-__device__ __forceinline__ LsPt rg_ls_eval(const RgModelDev& m, RgLds& s, float alpha, float q0, float q1, float q2) {
-  int ns = nsrow(m), ncon = s.ncon; float c = 0, g = 0, h = 0;
-  PFOR(r, ns) {
-    float D = s.r_D[r];
+// The rows a lane owns (static slots LANE, LANE+64; pyramid rows LANE+64k) do not change during a line search:
+// their (D, floss, jar, jv) are read from LDS once and every trial step length is evaluated from registers.
+struct LsRows { float rD[2], rf[2], rjar[2], rjv[2], pD[3], pjar[3], pjv[3]; };
+__device__ __forceinline__ void rg_ls_load(const RgModelDev& m, const RgLds& s, LsRows& L) {
+  int ns = nsrow(m), ncon = s.ncon;
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    int r = LANE + RG_WAVE * k; bool on = r < ns;
+    float D = on ? s.r_D[r] : 0.f;
+    L.rD[k] = D > 0 ? D : 0.f; L.rf[k] = (on && r < RG_MAXFRIC) ? s.r_floss[r] : 0.f;
+    L.rjar[k] = on ? s.r_jar[r] : 0.f; L.rjv[k] = on ? s.r_jv[r] : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    int w = LANE + RG_WAVE * k; bool on = w < ncon * 6;
+    int cc = on ? w / 6 : 0; on = on && (w - 6 * cc) < npyr(s.c_dim[cc]);
+    L.pD[k] = on ? s.c_D[cc] : 0.f; L.pjar[k] = on ? s.p_jar[w] : 0.f; L.pjv[k] = on ? s.p_jv[w] : 0.f;
+  }
+}
+__device__ __forceinline__ LsPt rg_ls_eval(const LsRows& L, float alpha, float q0, float q1, float q2) {
+  float c = 0, g = 0, h = 0;
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    float D = L.rD[k];
     if (!(D > 0)) continue;
-    float jv = s.r_jv[r], x = s.r_jar[r] + alpha * jv, f = r < RG_MAXFRIC ? s.r_floss[r] : 0.f;
+    float jv = L.rjv[k], x = L.rjar[k] + alpha * jv, f = L.rf[k];
     if (f > 0) {
       float R = 1.0f / D;
       if (x <= -R * f) { c += f * (-0.5f * R * f - x); g += -f * jv; }
@@ -1514,11 +1534,10 @@ __device__ __forceinline__ LsPt rg_ls_eval(const RgModelDev& m, RgLds& s, float 
       else { c += 0.5f * D * x * x; g += D * x * jv; h += D * jv * jv; }
     } else if (x < 0) { c += 0.5f * D * x * x; g += D * x * jv; h += D * jv * jv; }
   }
-  for (int w = LANE; w < ncon * 6; w += RG_WAVE) {
-    int cc = w / 6, q = w - 6 * cc;
-    if (q >= npyr(s.c_dim[cc])) continue;
-    float jv = s.p_jv[w], x = s.p_jar[w] + alpha * jv, D = s.c_D[cc];
-    if (x < 0) { c += 0.5f * D * x * x; g += D * x * jv; h += D * jv * jv; }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    float D = L.pD[k], jv = L.pjv[k], x = L.pjar[k] + alpha * jv;
+    if (D > 0 && x < 0) { c += 0.5f * D * x * x; g += D * x * jv; h += D * jv * jv; }
   }
   LsPt p;
   p.cost = wave_sum(c) + alpha * alpha * q2 + alpha * q1 + q0;
@@ -1626,13 +1645,14 @@ __device__ __forceinline__ int rg_solve(const RgModelDev& m, RgLds& s, int& nefc
     q1 = wave_sum(q1); q2 = wave_sum(q2); sn = sqrtf(wave_sum(sn));
     if (sn < 1e-15f) break;
     float gtol = tol * 0.01f * sn / scale;
-    LsPt p0 = rg_ls_eval(m, s, 0.f, gauss, q1, q2);
+    LsRows rows; rg_ls_load(m, s, rows);
+    LsPt p0 = rg_ls_eval(rows, 0.f, gauss, q1, q2);
     float alpha = 0;
     if (p0.grad < 0 && p0.hess > 0) {
       float lo = 0, hi = -1, glo = p0.grad, hlo = p0.hess, ghi = 0, hhi = 1;
       alpha = -p0.grad / p0.hess;
       for (int it = 0; it < 12; it++) {
-        LsPt p = rg_ls_eval(m, s, alpha, gauss, q1, q2);
+        LsPt p = rg_ls_eval(rows, alpha, gauss, q1, q2);
         if (fabsf(p.grad) < gtol) break;
         if (p.grad < 0) { lo = alpha; glo = p.grad; hlo = p.hess; } else { hi = alpha; ghi = p.grad; hhi = p.hess; }
         float cand = lo - glo / hlo;
