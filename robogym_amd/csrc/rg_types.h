@@ -9,7 +9,7 @@
 #define RG_MAXBODY 32
 #define RG_MAXJNT 32
 #define RG_MAXGEOM 66
-#define RG_MAXSITE 36
+#define RG_MAXSITE 40
 #define RG_MAXTEN 12
 #define RG_MAXU 20
 #define RG_MAXCON 32    // contacts kept per env (overflow -> RG_STATUS_CON_FULL); rollouts: P(ncon > 16) = 9e-6, max 21 in 6.5e5 substeps; the reset recipe (cube dropped into a closing hand) reaches 24+

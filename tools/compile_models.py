@@ -13,16 +13,18 @@ import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 from robogym_amd.envs.dactyl.locked import MODEL_DIR, build_locked_xml  # noqa: E402
+from robogym_amd.envs.dactyl.reach import build_reach_xml  # noqa: E402
 
 
 def main():
     os.makedirs(MODEL_DIR, exist_ok=True)
-    model = build_locked_xml().build()
-    path = os.path.join(MODEL_DIR, "dactyl_locked.npz")
-    model.save(path)
-    d = model.dims
-    print("dactyl_locked: nq=%d nv=%d nu=%d nbody=%d ngeom=%d nsite=%d ntendon=%d nmeshvert=%d -> %s (%d bytes)"
-          % (d[0], d[1], d[2], d[3], d[5], d[6], d[7], d[10], path, os.path.getsize(path)))
+    for name, build in (("dactyl_locked", build_locked_xml), ("dactyl_reach", build_reach_xml)):
+        model = build().build()
+        path = os.path.join(MODEL_DIR, name + ".npz")
+        model.save(path)
+        d = model.dims
+        print("%s: nq=%d nv=%d nu=%d nbody=%d ngeom=%d nsite=%d ntendon=%d nmeshvert=%d -> %s (%d bytes)"
+              % (name, d[0], d[1], d[2], d[3], d[5], d[6], d[7], d[10], path, os.path.getsize(path)))
 
 
 if __name__ == "__main__":
