@@ -102,6 +102,8 @@ def main():
     for _ in range(args.warmup):
         one_step()
     sim.set_field(7, torch.zeros((B, 4), device=dev))  # reset kernel statistics
+    status_before = int(sim.status.max().item())       # capacity flags raised by the reset recipe / warm-up (sticky bits)
+    sim.set_field(6, torch.zeros((B, 1), dtype=torch.int32, device=dev))
     # physics-kernel timing with events on the launch stream
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     orig_env_step = sim.env_step
@@ -157,7 +159,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "dactyl/locked (Shadow hand + locked cube, nv=36), batch %d per GPU, iid U(-1,1) relative actions, 10 substeps x 0.008 s" % B,
                        "batch_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d (envs sharded, RCCL all-gather of obs rows)" % world,
-                       "mean_ncon": float(ncon), "mean_nefc": float(nefc), "mean_newton_iters": float(iters), "status_bits": status},
+                       "mean_ncon": float(ncon), "mean_nefc": float(nefc), "mean_newton_iters": float(iters), "status_bits": status, "status_bits_before_timed_region": status_before},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
                          "kernel": "rg_step_kernel", "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": b_step, "algorithmic_bytes_per_substep": b_sub,
                          "note": "algorithmic bytes = SURVEY 8(d) stage-boundary model with measured ncon/nefc/iters; the fused kernel keeps stage arrays in LDS, so real HBM traffic is far below the algorithmic figure" + tnote},
