@@ -34,6 +34,7 @@ struct blob_entry { char name[40]; uint32_t dtype, count; uint64_t offset; };
 
 struct rg_model {
   RgModelDev dev;
+  const RgModelDev* dev_copy = nullptr;   // the same descriptor in device memory (kernels read it through the constant address space)
   RgAux aux;
   std::vector<void*> allocs;
   std::vector<float> qpos0;
@@ -241,6 +242,7 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
   GI("k_subtree_adr"); if (!upload<int>(m, iv, &m->aux.subtree_adr)) return bail("hipMalloc failed", m);
   GI("k_subtree"); if (!upload<int>(m, iv, &m->aux.subtree)) return bail("hipMalloc failed", m);
   { GI("k_dof_velmask"); std::vector<uint32_t> u(iv.size()); for (size_t i = 0; i < iv.size(); i++) u[i] = (uint32_t)iv[i]; if (!upload<uint32_t>(m, u, &m->aux.dof_velmask)) return bail("hipMalloc failed", m); }
+  { std::vector<RgModelDev> one(1, d); if (!upload<RgModelDev>(m, one, &m->dev_copy)) return bail("hipMalloc failed", m); }
   m->ok = 1;
   return m;
 }
@@ -385,7 +387,7 @@ int rg_batch_copy_rows(rg_batch* b, int field, const void* src_dev, const int* m
 }
 
 #ifdef RG_EMUL
-struct EmulArgs { RgModelDev m; RgAux x; RgEnvDev env; RgBatchDev bt; int nsub, nticks, flags; };
+struct EmulArgs { const RgModelDev* m; RgAux x; RgEnvDev env; RgBatchDev bt; int nsub, nticks, flags; };
 static void emul_entry(void* a) { EmulArgs* p = (EmulArgs*)a; rg_step_kernel(p->m, p->x, p->env, p->bt, p->nsub, p->nticks, p->flags); }
 #endif
 
@@ -396,10 +398,10 @@ int rg_batch_step(rg_batch* b, const float* action_dev, const float* goal_quat_d
   RgBatchDev bt = b->dev;
   bt.action = action_dev; bt.goal_quat = goal_quat_dev; bt.obs = obs_dev; bt.goal_dist = goal_dist_dev; bt.active = active_dev;
 #ifdef RG_EMUL
-  EmulArgs args{b->model->dev, b->model->aux, b->env, bt, nsubsteps, nforward_ticks, flags};
+  EmulArgs args{b->model->dev_copy, b->model->aux, b->env, bt, nsubsteps, nforward_ticks, flags};
   emul_launch(bt.B, sizeof(RgLds), emul_entry, &args);
 #else
-  hipLaunchKernelGGL(rg_step_kernel, dim3(bt.B), dim3(RG_WAVE), sizeof(RgLds), (hipStream_t)stream, b->model->dev, b->model->aux, b->env, bt,
+  hipLaunchKernelGGL(rg_step_kernel, dim3(bt.B), dim3(RG_WAVE), sizeof(RgLds), (hipStream_t)stream, b->model->dev_copy, b->model->aux, b->env, bt,
                      nsubsteps, nforward_ticks, flags);
   HIPCHK(hipGetLastError());
 #endif
@@ -407,7 +409,7 @@ int rg_batch_step(rg_batch* b, const float* action_dev, const float* goal_quat_d
 }
 
 #ifdef RG_EMUL
-struct EmulMprArgs { RgModelDev m; RgBatchDev bt; int g1, g2; float margin; float* out; };
+struct EmulMprArgs { const RgModelDev* m; RgBatchDev bt; int g1, g2; float margin; float* out; };
 static void emul_mpr_entry(void* a) { EmulMprArgs* p = (EmulMprArgs*)a; rg_mpr_pair_kernel(p->m, p->bt, p->g1, p->g2, p->margin, p->out); }
 #endif
 int rg_batch_mpr_pair(rg_batch* b, int g1, int g2, float margin, float* out_dev, void* stream) {
@@ -415,10 +417,10 @@ int rg_batch_mpr_pair(rg_batch* b, int g1, int g2, float margin, float* out_dev,
   const RgModelDev& d = b->model->dev;
   if (g1 < 0 || g2 < 0 || g1 >= d.ngeom || g2 >= d.ngeom) return fail("geom id out of range");
 #ifdef RG_EMUL
-  EmulMprArgs args{d, b->dev, g1, g2, margin, out_dev};
+  EmulMprArgs args{b->model->dev_copy, b->dev, g1, g2, margin, out_dev};
   emul_launch(b->dev.B, sizeof(RgLds), emul_mpr_entry, &args);
 #else
-  hipLaunchKernelGGL(rg_mpr_pair_kernel, dim3(b->dev.B), dim3(RG_WAVE), sizeof(RgLds), (hipStream_t)stream, d, b->dev, g1, g2, margin, out_dev);
+  hipLaunchKernelGGL(rg_mpr_pair_kernel, dim3(b->dev.B), dim3(RG_WAVE), sizeof(RgLds), (hipStream_t)stream, b->model->dev_copy, b->dev, g1, g2, margin, out_dev);
   HIPCHK(hipGetLastError());
 #endif
   return 0;

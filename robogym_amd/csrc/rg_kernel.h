@@ -23,6 +23,13 @@
 #include <hip/hip_runtime.h>
 #endif
 
+#ifdef RG_EMUL
+typedef const RgModelDev& RgM;
+#else
+// the model descriptor lives in constant address space: every field read is a scalar load that the
+// compiler may re-issue next to its use instead of keeping ~240 SGPRs of pointers alive
+typedef const __attribute__((address_space(4))) RgModelDev& RgM;
+#endif
 #define RG_MAXPYR (RG_MAXCON * 6)
 #define RG_NPROF 24
 #define RG_HWORDS 1088  // work matrix: max(inertia blocks, nvc x hs)
@@ -210,7 +217,7 @@ __device__ __forceinline__ void cross_force(float* r, const float* vel, const fl
 }
 
 // ------------------------------------------------------------------------------------------------- position stage
-__device__ __forceinline__ void rg_kinematics(const RgModelDev& m, RgLds& s) {
+__device__ __forceinline__ void rg_kinematics(RgM m, RgLds& s) {
   PFOR(i, m.nstatic) {
     int b = m.static_body[i];
     st3(s.xpos + 3 * b, ld3(m.static_xpos + 3 * b));
@@ -273,7 +280,7 @@ __device__ __forceinline__ void rg_kinematics(const RgModelDev& m, RgLds& s) {
   SYNC();
 }
 
-__device__ __forceinline__ void rg_com_pos(const RgModelDev& m, RgLds& s) {
+__device__ __forceinline__ void rg_com_pos(RgM m, RgLds& s) {
   for (int b = 1 + LANE; b < m.nbody; b += RG_WAVE) {
     float R[9], I[9], qm[9];
     q2mat(qm, ldq(m.body_iquat + 4 * b));
@@ -309,7 +316,7 @@ __device__ __forceinline__ void rg_com_pos(const RgModelDev& m, RgLds& s) {
 
 // translational Jacobian column of dof d for a point with offset `off` from the com-frame origin
 __device__ __forceinline__ v3 jac_col(const RgLds& s, int d, v3 off) { return ld3(s.cdof + 6 * d + 3) + cross(ld3(s.cdof + 6 * d), off); }
-__device__ __forceinline__ bool in_chain(const RgModelDev& m, int body, int d) { return (m.body_dofmask[2 * body + (d >> 5)] >> (d & 31)) & 1u; }
+__device__ __forceinline__ bool in_chain(RgM m, int body, int d) { return (m.body_dofmask[2 * body + (d >> 5)] >> (d & 31)) & 1u; }
 
 // ---- tendon wrapping (see oracle: wrap_circle / ro_wrap)
 __device__ __forceinline__ bool seg_intersect(float p1x, float p1y, float p2x, float p2y, float p3x, float p3y, float p4x, float p4y) {
@@ -378,7 +385,7 @@ __device__ __forceinline__ float rg_wrap(v3& w0, v3& w1, v3 x0, v3 x1, v3 gpos, 
 }
 
 // tendon lengths and Jacobians on their static dof supports; actuator lengths
-__device__ __forceinline__ void rg_tendon(const RgModelDev& m, RgLds& s) {
+__device__ __forceinline__ void rg_tendon(RgM m, RgLds& s) {
   PFOR(t, m.ntendon) {
     int adr = m.tendon_adr[t], num = m.tendon_num[t];
     const int* td = m.ten_dofs + 4 * t;
@@ -443,7 +450,7 @@ __device__ __forceinline__ void rg_tendon(const RgModelDev& m, RgLds& s) {
 }
 
 // composite inertias (subtree gathers), sparse M, tree-sparse L'DL factorisation
-__device__ __forceinline__ void rg_crb(const RgModelDev& m, RgLds& s, const int* subtree_adr, const int* subtree) {
+__device__ __forceinline__ void rg_crb(RgM m, RgLds& s, const int* subtree_adr, const int* subtree) {
   for (int w = LANE; w < m.nbody * 10; w += RG_WAVE) {
     int b = w / 10, k = w - 10 * b;
     float acc = 0;
@@ -753,7 +760,7 @@ __device__ __forceinline__ void add_contact(RgLds& s, int pair, float dist, v3 p
 
 // the two geoms of candidate pair p in pair-local coordinates (origin at geom1's centre: fp32 resolution ~1e-9 m),
 // each inflated by margin/2
-__device__ __forceinline__ void rg_mpr_geoms(const RgModelDev& m, const RgLds& s, int p, MprGeom& A, MprGeom& B, bool cells, int& dim, float& margin) {
+__device__ __forceinline__ void rg_mpr_geoms(RgM m, const RgLds& s, int p, MprGeom& A, MprGeom& B, bool cells, int& dim, float& margin) {
   const rgf4* R = (const rgf4*)m.pair_rec + (RG_PAIRREC / 4) * p;
   rgf4 r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3];
   int hdr = __builtin_bit_cast(int, r0.x), g1 = hdr & 255, g2 = (hdr >> 8) & 255, id1 = __builtin_bit_cast(int, r0.z), id2 = __builtin_bit_cast(int, r0.w);
@@ -767,7 +774,7 @@ __device__ __forceinline__ void rg_mpr_geoms(const RgModelDev& m, const RgLds& s
   B.celladr = (cells && id2 >= 0) ? m.mesh_cell_adr + id2 * RG_NCELL : (const int*)0; B.cellblk = (const rgf4*)m.mesh_cell_blk + (size_t)(id2 >= 0 ? id2 : 0) * (RG_NCELL * 4);
   A.prof = 0; B.prof = 0;
 }
-template <int G> __device__ __forceinline__ void rg_narrow_phase1(const RgModelDev& m, RgLds& s, rgf4* sepdir, float* pairlb, int ncand, bool cells) {
+template <int G> __device__ __forceinline__ void rg_narrow_phase1(RgM m, RgLds& s, rgf4* sepdir, float* pairlb, int ncand, bool cells) {
   for (int base = 0; base < ncand; base += RG_WAVE / G) {
     int ci = base + LANE / G;
     bool keep = false; int p = 0;
@@ -799,7 +806,7 @@ template <int G> __device__ __forceinline__ void rg_narrow_phase1(const RgModelD
     SYNC();
   }
 }
-template <int G> __device__ __forceinline__ void rg_narrow_phase2(const RgModelDev& m, RgLds& s, float* prof, rgf4* sepdir, int ncand2, bool cells) {
+template <int G> __device__ __forceinline__ void rg_narrow_phase2(RgM m, RgLds& s, float* prof, rgf4* sepdir, int ncand2, bool cells) {
   for (int base = 0; base < ncand2; base += RG_WAVE / G) {
     int ci = base + LANE / G;
     bool hit = false;
@@ -834,7 +841,7 @@ template <int G> __device__ __forceinline__ void rg_narrow_phase2(const RgModelD
     SYNC();
   }
 }
-__device__ __forceinline__ void rg_collision(const RgModelDev& m, RgLds& s, float* prof, rgf4* sepdir, float* pairlb, bool cells) {
+__device__ __forceinline__ void rg_collision(RgM m, RgLds& s, float* prof, rgf4* sepdir, float* pairlb, bool cells) {
   long long tb0 = rg_clock();
   if (LANE == 0) { s.ncand = 0; s.ncon = 0; }
   SYNC();
@@ -955,7 +962,7 @@ __device__ __forceinline__ void rg_collision(const RgModelDev& m, RgLds& s, floa
 }
 
 // ------------------------------------------------------------------------------------------------- velocity stage
-__device__ __forceinline__ void rg_velocity(const RgModelDev& m, RgLds& s, const uint32_t* dof_velmask, const int* subtree_adr, const int* subtree) {
+__device__ __forceinline__ void rg_velocity(RgM m, RgLds& s, const uint32_t* dof_velmask, const int* subtree_adr, const int* subtree) {
   // cdof_dot: spatial velocity accumulated over the dofs "before" d on its chain, crossed with cdof
   PFOR(d, m.nv) {
     float cv[6] = {0, 0, 0, 0, 0, 0};
@@ -1018,7 +1025,7 @@ __device__ __forceinline__ void rg_velocity(const RgModelDev& m, RgLds& s, const
 }
 
 // PID actuators (mjpid.pyx semantics, see oracle ro_fwd_actuation); updates controller state
-__device__ __forceinline__ void rg_pid(const RgModelDev& m, RgLds& s) {
+__device__ __forceinline__ void rg_pid(RgM m, RgLds& s) {
   float dt = m.timestep;
   PFOR(u, m.nu) {
     const float* gp = m.actuator_gainprm + 10 * u;
@@ -1043,7 +1050,7 @@ __device__ __forceinline__ void rg_pid(const RgModelDev& m, RgLds& s) {
   }
   SYNC();
 }
-__device__ __forceinline__ void rg_smooth(const RgModelDev& m, RgLds& s) {
+__device__ __forceinline__ void rg_smooth(RgM m, RgLds& s) {
   PFOR(d, m.nv) {
     float f = 0;
     for (int q = m.dof_act_adr[d]; q < m.dof_act_adr[d + 1]; q++) {
@@ -1071,7 +1078,7 @@ __device__ __forceinline__ float impedance(const float* si, float pos, float mar
   else y = 1 - powf(1 - x, power) / powf(1 - mid, power - 1);
   return dmin + y * (dmax - dmin);
 }
-__device__ __forceinline__ void kb(const RgModelDev& m, const float* solref, const float* solimp, float& K, float& B) {
+__device__ __forceinline__ void kb(RgM m, const float* solref, const float* solimp, float& K, float& B) {
   float dmax = clampf(solimp[1], 1e-4f, 0.9999f);
   if (solref[0] > 0) {
     float tc = fmaxf(solref[0], 2 * m.timestep), dr = solref[1];
@@ -1082,8 +1089,8 @@ __device__ __forceinline__ void kb(const RgModelDev& m, const float* solref, con
 // Each slot has a packed descriptor in LDS (built once per launch): bits 0-7 compact dof (single-dof rows),
 // bits 8-15 tendon id (255: none), bit 16: negative sign.  Tendon rows take their (<=4) compact dofs from
 // s.ten_cdof and their coefficients from s.tenJ.
-__device__ __forceinline__ int nsrow(const RgModelDev& m) { return m.nfric_dof + m.nfric_ten + 2 * m.nlim_jnt + 2 * m.nlim_ten; }
-__device__ __forceinline__ void rg_build_row_desc(const RgModelDev& m, RgLds& s) {
+__device__ __forceinline__ int nsrow(RgM m) { return m.nfric_dof + m.nfric_ten + 2 * m.nlim_jnt + 2 * m.nlim_ten; }
+__device__ __forceinline__ void rg_build_row_desc(RgM m, RgLds& s) {
   int ns = nsrow(m);
   PFOR(r, ns) {
     int rr = r, dof = 0, ten = 31, neg = 0;
@@ -1113,7 +1120,7 @@ __device__ __forceinline__ void srow_scatter(RgLds& s, int r, float coef, float*
   for (int e = 0; e < 4; e++) { int d = s.ten_cdof[4 * t + e]; if (d != 255) atomicAdd(dst + d, coef * s.tenJ[4 * t + e]); }
 }
 // H += D * J_r^T J_r
-__device__ __forceinline__ void srow_hess(const RgModelDev& m, RgLds& s, int r, float D) {
+__device__ __forceinline__ void srow_hess(RgM m, RgLds& s, int r, float D) {
   int desc = s.r_desc[r], t = (desc >> 6) & 31;
   if (t == 31) { int d = desc & 63; atomicAdd(s.H + d * m.hs + d, D); return; }
   for (int a = 0; a < 4; a++) { int da = s.ten_cdof[4 * t + a]; if (da == 255) continue;
@@ -1122,7 +1129,7 @@ __device__ __forceinline__ void srow_hess(const RgModelDev& m, RgLds& s, int r, 
 __device__ __forceinline__ int npyr(int dim) { return dim == 1 ? 1 : 2 * (dim - 1); }
 __device__ __forceinline__ int nbasis(int dim) { return dim >= 4 ? 4 : (dim == 1 ? 1 : 3); }
 
-__device__ __forceinline__ void rg_make_constraint(const RgModelDev& m, RgLds& s) {
+__device__ __forceinline__ void rg_make_constraint(RgM m, RgLds& s) {
   int ns = nsrow(m);
   PFOR(r, ns) {
     int rr = r; float pos = 0, margin = 0, diag, floss = 0; const float *solref, *solimp; bool active = true, fric = false;
@@ -1214,7 +1221,7 @@ __device__ __forceinline__ void rg_make_constraint(const RgModelDev& m, RgLds& s
 }
 
 // jar = J x - aref (or jv = J x) for every active row; x lives in the compact dof space
-__device__ __forceinline__ void rg_J_mul(const RgModelDev& m, RgLds& s, const float* x, bool to_jv) {
+__device__ __forceinline__ void rg_J_mul(RgM m, RgLds& s, const float* x, bool to_jv) {
   int ns = nsrow(m), ncon = s.ncon;
   PFOR(r, ns) if (s.r_D[r] > 0) { float v = srow_dot<false>(s, r, x); if (to_jv) s.r_jv[r] = v; else s.r_jar[r] = v - s.r_aref[r]; }
   for (int w = LANE; w < ncon * 4; w += RG_WAVE) {
@@ -1236,7 +1243,7 @@ __device__ __forceinline__ void rg_J_mul(const RgModelDev& m, RgLds& s, const fl
 // forces / quadratic flags from jar; returns the wave-summed constraint cost
 // `changed`: whether any row's quadratic flag differs from what the arrays held before (the Hessian
 // M + J' D J depends on the state only through these flags)
-__device__ __forceinline__ float rg_constraint_update(const RgModelDev& m, RgLds& s, bool& changed) {
+__device__ __forceinline__ float rg_constraint_update(RgM m, RgLds& s, bool& changed) {
   int ns = nsrow(m), ncon = s.ncon; float cost = 0; bool chg = false;
   PFOR(r, ns) {
     float D = s.r_D[r]; int old = s.r_quad[r], q = 0; float frc = 0;
@@ -1264,7 +1271,7 @@ __device__ __forceinline__ float rg_constraint_update(const RgModelDev& m, RgLds
   return wave_sum(cost);
 }
 // dst = J^T force in the compact dof space (dst zeroed here)
-__device__ __forceinline__ void rg_JT_force(const RgModelDev& m, RgLds& s, float* dst) {
+__device__ __forceinline__ void rg_JT_force(RgM m, RgLds& s, float* dst) {
   int ns = nsrow(m), ncon = s.ncon;
   PFOR(d, m.nvc) dst[d] = 0;
   for (int w = LANE; w < ncon * 4; w += RG_WAVE) {
@@ -1288,7 +1295,7 @@ __device__ __forceinline__ void rg_JT_force(const RgModelDev& m, RgLds& s, float
   SYNC();
 }
 // y = M x in the compact dof space: row i of the tree block of dof c2d[i] against that tree's slice of x
-__device__ __forceinline__ void rg_M_mul(const RgModelDev& m, RgLds& s, const float* x, float* y) {
+__device__ __forceinline__ void rg_M_mul(RgM m, RgLds& s, const float* x, float* y) {
   PFOR(i, m.nvc) {
     int blk = s.cblk[i], n = (blk >> 24) & 255; const float* row = s.M + (blk & 0xFFFF); const float* xs = x + ((blk >> 16) & 255);
     float v = 0;
@@ -1303,7 +1310,7 @@ __device__ __forceinline__ void rg_M_mul(const RgModelDev& m, RgLds& s, const fl
 // (pivot rows are broadcast reads), the 4x4 diagonal block is factored redundantly in every lane from ten
 // v_readlane values, and each lane solves its four new entries against it.  n/4 LDS round trips, not n.
 __device__ __forceinline__ float dot4(rgf4 a, rgf4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
-__device__ __forceinline__ void rg_chol(const RgModelDev& m, RgLds& s) {
+__device__ __forceinline__ void rg_chol(RgM m, RgLds& s) {
   int n = m.nvc, hs4 = m.hs >> 2, i = LANE;
   rgf4* H4 = (rgf4*)s.H;
   bool bad = false;
@@ -1369,7 +1376,7 @@ __device__ __forceinline__ void tri_fetch(const RgLds& s, int n, int hs, int j0,
   if (!backward) t.own = H4[ic * hs4 + jb];
   else { t.c0 = H[j0 * hs + ic]; t.c1 = H[r1 * hs + ic]; t.c2 = H[r2 * hs + ic]; t.c3 = H[r3 * hs + ic]; }
 }
-__device__ __forceinline__ void rg_chol_solve(const RgModelDev& m, RgLds& s, float* x) {
+__device__ __forceinline__ void rg_chol_solve(RgM m, RgLds& s, float* x) {
   int n = m.nvc, hs = m.hs, i = LANE;
   float xi = i < n ? x[i] : 0.f;
   TriOps cur, nxt;
@@ -1407,7 +1414,7 @@ __device__ __forceinline__ void rg_chol_solve(const RgModelDev& m, RgLds& s, flo
 // every kinematic tree's block factored concurrently (lane d owns row d of its tree), four columns per
 // step as in rg_chol; the pivot lanes differ per tree, so pivot values travel by ds_bpermute (__shfl).
 // Then x <- solve.  Used for qacc_smooth = M^-1 qfrc_smooth and for the implicit-damping Euler solve.
-__device__ __forceinline__ void rg_block_factor_solve(const RgModelDev& m, RgLds& s, const float* extra_diag, float scale, float* x) {
+__device__ __forceinline__ void rg_block_factor_solve(RgM m, RgLds& s, const float* extra_diag, float scale, float* x) {
   for (int w = LANE; w < m.blkwords; w += RG_WAVE) s.H[w] = s.M[w];
   SYNC();
   int d = LANE; bool on = d < m.nv;
@@ -1504,7 +1511,7 @@ struct LsPt { float cost, grad, hess; };
 // The rows a lane owns (static slots LANE, LANE+64; pyramid rows LANE+64k) do not change during a line search:
 // their (D, floss, jar, jv) are read from LDS once and every trial step length is evaluated from registers.
 struct LsRows { float rD[2], rf[2], rjar[2], rjv[2], pD[3], pjar[3], pjv[3]; };
-__device__ __forceinline__ void rg_ls_load(const RgModelDev& m, const RgLds& s, LsRows& L) {
+__device__ __forceinline__ void rg_ls_load(RgM m, const RgLds& s, LsRows& L) {
   int ns = nsrow(m), ncon = s.ncon;
 #pragma unroll
   for (int k = 0; k < 2; k++) {
@@ -1548,7 +1555,7 @@ __device__ __forceinline__ LsPt rg_ls_eval(const LsRows& L, float alpha, float q
 
 // Newton solver on the primal problem (see oracle ro_solve), in the compact space of constrained dofs
 // (trees no constraint row can touch keep qacc = qacc_smooth).  Result: s.qacc, s.qfrc_con (full space).
-__device__ __forceinline__ int rg_solve(const RgModelDev& m, RgLds& s, int& nefc_out, int flags) {
+__device__ __forceinline__ int rg_solve(RgM m, RgLds& s, int& nefc_out, int flags) {
   long long t0 = rg_clock(), t1;
 #define PROFS(k) do { if (flags & 2) { t1 = rg_clock(); if (LANE == 0) s.prof[k] += (float)(t1 - t0); t0 = t1; } } while (0)
   int nv = m.nv, nvc = m.nvc, hs = m.hs, ns = nsrow(m), ncon = s.ncon;
@@ -1681,7 +1688,7 @@ __device__ __forceinline__ int rg_solve(const RgModelDev& m, RgLds& s, int& nefc
 }
 
 // ------------------------------------------------------------------------------------------------- integration
-__device__ __forceinline__ void rg_euler(const RgModelDev& m, RgLds& s) {
+__device__ __forceinline__ void rg_euler(RgM m, RgLds& s) {
   float h = m.timestep;
   PFOR(i, m.nv) s.tmpv[i] = s.qfrc_smooth[i] + s.qfrc_con[i];
   SYNC();
@@ -1706,7 +1713,7 @@ struct RgAux {  // extra static tables (kept out of RgModelDev to keep the kerna
 };
 
 // stage dump in three parts, each taken while the arrays it reads are alive
-__device__ __forceinline__ void rg_dump_kin(const RgModelDev& m, RgLds& s, float* dbg) {
+__device__ __forceinline__ void rg_dump_kin(RgM m, RgLds& s, float* dbg) {
   PFOR(i, m.nbody * 3) dbg[RG_DBG_XPOS + i] = s.xpos[i];
   PFOR(i, m.nbody * 4) dbg[RG_DBG_XQUAT + i] = s.xquat[i];
   PFOR(i, m.nsite * 3) dbg[RG_DBG_SITE + i] = s.spos[i];
@@ -1714,7 +1721,7 @@ __device__ __forceinline__ void rg_dump_kin(const RgModelDev& m, RgLds& s, float
   PFOR(i, m.ntendon * 4) dbg[RG_DBG_TENJ + i] = s.tenJ[i];
   SYNC();
 }
-__device__ __forceinline__ void rg_dump_pos(const RgModelDev& m, RgLds& s, float* dbg) {
+__device__ __forceinline__ void rg_dump_pos(RgM m, RgLds& s, float* dbg) {
   for (int w = LANE; w < m.nv * m.nv; w += RG_WAVE) {
     int i = w / m.nv, j = w - i * m.nv, bi = m.dof_blk[i], s0 = (bi >> 16) & 255, n = (bi >> 24) & 255;
     dbg[RG_DBG_M + w] = (j >= s0 && j < s0 + n) ? s.M[(bi & 0xFFFF) + (j - s0)] : 0.f;
@@ -1724,18 +1731,23 @@ __device__ __forceinline__ void rg_dump_pos(const RgModelDev& m, RgLds& s, float
   PFOR(c, s.ncon) { float* o = dbg + RG_DBG_CON + 8 * c; o[0] = s.c_dist[c]; o[1] = s.c_pos[3 * c]; o[2] = s.c_pos[3 * c + 1]; o[3] = s.c_pos[3 * c + 2]; o[4] = s.c_normal[3 * c]; o[5] = s.c_normal[3 * c + 1]; o[6] = s.c_normal[3 * c + 2]; o[7] = (float)s.c_pair[c]; }
   SYNC();
 }
-__device__ __forceinline__ void rg_dump_slv(const RgModelDev& m, RgLds& s, float* dbg, int nefc, int iters) {
+__device__ __forceinline__ void rg_dump_slv(RgM m, RgLds& s, float* dbg, int nefc, int iters) {
   PFOR(i, m.nv) { dbg[RG_DBG_QACCS + i] = s.qacc_smooth[i]; dbg[RG_DBG_QACC + i] = s.qacc[i]; }
   if (LANE == 0) { dbg[RG_DBG_NCON + 1] = (float)nefc; dbg[RG_DBG_NCON + 2] = (float)iters; }
 }
 
-__device__ __forceinline__ void rg_position_stage(const RgModelDev& m, const RgAux& x, RgLds& s) {
+__device__ __forceinline__ void rg_position_stage(RgM m, const RgAux& x, RgLds& s) {
   rg_kinematics(m, s);
   rg_com_pos(m, s);
   rg_tendon(m, s);
 }
 
-__global__ void __launch_bounds__(RG_WAVE, 2) rg_step_kernel(RgModelDev m, RgAux x, RgEnvDev env, RgBatchDev bt, int nsubsteps, int nforward_ticks, int flags) {
+__global__ void __launch_bounds__(RG_WAVE, 2) rg_step_kernel(const RgModelDev* mp, RgAux x, RgEnvDev env, RgBatchDev bt, int nsubsteps, int nforward_ticks, int flags) {
+#ifdef RG_EMUL
+  RgM m = *mp;
+#else
+  RgM m = *(const __attribute__((address_space(4))) RgModelDev*)mp;
+#endif
 #ifdef RG_EMUL
   RgLds& s = *(RgLds*)emul_lds();
 #else
@@ -1849,7 +1861,12 @@ __global__ void __launch_bounds__(RG_WAVE, 2) rg_step_kernel(RgModelDev m, RgAux
 
 // Collision unit-test hook: kinematics of each env's stored qpos, then one MPR query between two geoms.
 // out[e][8] = hit, depth, dir3, pos3 (world)
-__global__ void __launch_bounds__(RG_WAVE) rg_mpr_pair_kernel(RgModelDev m, RgBatchDev bt, int g1, int g2, float margin, float* out) {
+__global__ void __launch_bounds__(RG_WAVE) rg_mpr_pair_kernel(const RgModelDev* mp, RgBatchDev bt, int g1, int g2, float margin, float* out) {
+#ifdef RG_EMUL
+  RgM m = *mp;
+#else
+  RgM m = *(const __attribute__((address_space(4))) RgModelDev*)mp;
+#endif
 #ifdef RG_EMUL
   RgLds& s = *(RgLds*)emul_lds();
 #else
