@@ -387,8 +387,8 @@ int rg_batch_copy_rows(rg_batch* b, int field, const void* src_dev, const int* m
 }
 
 #ifdef RG_EMUL
-struct EmulArgs { const RgModelDev* m; RgAux x; RgEnvDev env; RgBatchDev bt; int nsub, nticks, flags; };
-static void emul_entry(void* a) { EmulArgs* p = (EmulArgs*)a; rg_step_kernel(p->m, p->x, p->env, p->bt, p->nsub, p->nticks, p->flags); }
+struct EmulArgs { const RgModelDev* m; RgLaunch launch; };
+static void emul_entry(void* a) { EmulArgs* p = (EmulArgs*)a; rg_step_kernel(p->m, p->launch); }
 #endif
 
 int rg_batch_step(rg_batch* b, const float* action_dev, const float* goal_quat_dev, float* obs_dev, float* goal_dist_dev,
@@ -397,12 +397,12 @@ int rg_batch_step(rg_batch* b, const float* action_dev, const float* goal_quat_d
   if ((action_dev || obs_dev) && !b->has_env) return fail("rg_batch_set_env must be called before stepping with actions/observations");
   RgBatchDev bt = b->dev;
   bt.action = action_dev; bt.goal_quat = goal_quat_dev; bt.obs = obs_dev; bt.goal_dist = goal_dist_dev; bt.active = active_dev;
+  RgLaunch launch{b->model->aux, b->env, bt, nsubsteps, nforward_ticks, flags};
 #ifdef RG_EMUL
-  EmulArgs args{b->model->dev_copy, b->model->aux, b->env, bt, nsubsteps, nforward_ticks, flags};
+  EmulArgs args{b->model->dev_copy, launch};
   emul_launch(bt.B, sizeof(RgLds), emul_entry, &args);
 #else
-  hipLaunchKernelGGL(rg_step_kernel, dim3(bt.B), dim3(RG_WAVE), sizeof(RgLds), (hipStream_t)stream, b->model->dev_copy, b->model->aux, b->env, bt,
-                     nsubsteps, nforward_ticks, flags);
+  hipLaunchKernelGGL(rg_step_kernel, dim3(bt.B), dim3(RG_WAVE), sizeof(RgLds), (hipStream_t)stream, b->model->dev_copy, launch);
   HIPCHK(hipGetLastError());
 #endif
   return 0;

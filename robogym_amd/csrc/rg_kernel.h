@@ -1736,18 +1736,27 @@ __device__ __forceinline__ void rg_dump_slv(RgM m, RgLds& s, float* dbg, int nef
   if (LANE == 0) { dbg[RG_DBG_NCON + 1] = (float)nefc; dbg[RG_DBG_NCON + 2] = (float)iters; }
 }
 
-__device__ __forceinline__ void rg_position_stage(RgM m, const RgAux& x, RgLds& s) {
+__device__ __forceinline__ void rg_position_stage(RgM m, RgLds& s) {
   rg_kinematics(m, s);
   rg_com_pos(m, s);
   rg_tendon(m, s);
 }
 
-__global__ void __launch_bounds__(RG_WAVE, 2) rg_step_kernel(const RgModelDev* mp, RgAux x, RgEnvDev env, RgBatchDev bt, int nsubsteps, int nforward_ticks, int flags) {
+// Everything a launch passes besides the model, as ONE by-value kernel argument that the body reads through the
+// constant address space (the kernarg segment), so that its ~100 scalars are loaded where they are used
+// instead of living in (or being spilled from) SGPRs for the whole kernel.
+struct RgLaunch { RgAux x; RgEnvDev env; RgBatchDev bt; int nsubsteps, nforward_ticks, flags; };
+__global__ void __launch_bounds__(RG_WAVE, 2) rg_step_kernel(const RgModelDev* mp, RgLaunch launch) {
 #ifdef RG_EMUL
   RgM m = *mp;
+  const RgLaunch& L = launch;
 #else
   RgM m = *(const __attribute__((address_space(4))) RgModelDev*)mp;
+  // second kernel argument: 8-byte aligned, right after the model pointer
+  const __attribute__((address_space(4))) RgLaunch& L =
+      *(const __attribute__((address_space(4))) RgLaunch*)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + 8);
 #endif
+  const int nsubsteps = L.nsubsteps, nforward_ticks = L.nforward_ticks, flags = L.flags;
 #ifdef RG_EMUL
   RgLds& s = *(RgLds*)emul_lds();
 #else
@@ -1755,26 +1764,26 @@ __global__ void __launch_bounds__(RG_WAVE, 2) rg_step_kernel(const RgModelDev* m
   RgLds& s = *(RgLds*)lds_raw;
 #endif
   int e = blockIdx.x;
-  if (e >= bt.B) return;
-  if (bt.active && !bt.active[e]) return;
+  if (e >= L.bt.B) return;
+  if (L.bt.active && !L.bt.active[e]) return;
   // ---- load the env's state row
-  PFOR(i, m.nq) s.qpos[i] = bt.qpos[(size_t)e * m.nq + i];
-  PFOR(i, m.nv) { s.qvel[i] = bt.qvel[(size_t)e * m.nv + i]; s.warm[i] = bt.qacc_warmstart[(size_t)e * m.nv + i]; }
-  PFOR(i, 3 * m.nu) s.pid[i] = bt.pid[(size_t)e * 3 * m.nu + i];
-  if (LANE == 0) s.status = bt.status[e];
+  PFOR(i, m.nq) s.qpos[i] = L.bt.qpos[(size_t)e * m.nq + i];
+  PFOR(i, m.nv) { s.qvel[i] = L.bt.qvel[(size_t)e * m.nv + i]; s.warm[i] = L.bt.qacc_warmstart[(size_t)e * m.nv + i]; }
+  PFOR(i, 3 * m.nu) s.pid[i] = L.bt.pid[(size_t)e * 3 * m.nu + i];
+  if (LANE == 0) s.status = L.bt.status[e];
   if (LANE < RG_NPROF) s.prof[LANE] = 0;
   rg_build_row_desc(m, s);
   // ---- action -> ctrl (robot_interface.py:247-278 with the hand's position->control matrix)
-  float a0 = bt.action ? bt.action[(size_t)e * m.nu] : 0.f;
-  if (bt.action && a0 == a0) {   // a NaN first entry: this env keeps its stored ctrl row
+  float a0 = L.bt.action ? L.bt.action[(size_t)e * m.nu] : 0.f;
+  if (L.bt.action && a0 == a0) {   // a NaN first entry: this env keeps its stored ctrl row
     PFOR(u, m.nu) {
       float lo = m.actuator_ctrlrange[2 * u], hi = m.actuator_ctrlrange[2 * u + 1], centre;
-      if (env.relative_action) { centre = 0; for (int j = 0; j < env.n_hand_jnt; j++) centre += env.pos_to_ctrl[u * env.n_hand_jnt + j] * s.qpos[env.hand_qposadr + j]; }
+      if (L.env.relative_action) { centre = 0; for (int j = 0; j < L.env.n_hand_jnt; j++) centre += L.env.pos_to_ctrl[u * L.env.n_hand_jnt + j] * s.qpos[L.env.hand_qposadr + j]; }
       else centre = 0.5f * (hi + lo);
-      float a = clampf(bt.action[(size_t)e * m.nu + u], -1.f, 1.f);
+      float a = clampf(L.bt.action[(size_t)e * m.nu + u], -1.f, 1.f);
       s.ctrl[u] = clampf(centre + a * 0.5f * (hi - lo), lo, hi);
     }
-  } else { PFOR(u, m.nu) s.ctrl[u] = bt.ctrl[(size_t)e * m.nu + u]; }
+  } else { PFOR(u, m.nu) s.ctrl[u] = L.bt.ctrl[(size_t)e * m.nu + u]; }
   SYNC();
   float st_ncon = 0, st_nefc = 0, st_iter = 0;
   bool bad = false;
@@ -1790,16 +1799,16 @@ __global__ void __launch_bounds__(RG_WAVE, 2) rg_step_kernel(const RgModelDev* m
     rg_kinematics(m, s); PROF(0);
     rg_com_pos(m, s); PROF(1);
     rg_tendon(m, s); PROF(2);
-    if (sub == 0 && (flags & 1) && bt.dbg) rg_dump_kin(m, s, bt.dbg + (size_t)e * RG_DBG_SIZE);
-    rg_crb(m, s, x.subtree_adr, x.subtree); PROF(3);
-    rg_velocity(m, s, x.dof_velmask, x.subtree_adr, x.subtree); PROF(7);
-    rg_collision(m, s, (flags & 2) ? s.prof : (float*)0, bt.sepdir ? (rgf4*)bt.sepdir + (size_t)e * m.npair : (rgf4*)0,
-                 (bt.pairlb && !(flags & 4)) ? bt.pairlb + (size_t)e * m.npair : (float*)0, !(flags & 8)); PROF(6);
+    if (sub == 0 && (flags & 1) && L.bt.dbg) rg_dump_kin(m, s, L.bt.dbg + (size_t)e * RG_DBG_SIZE);
+    rg_crb(m, s, L.x.subtree_adr, L.x.subtree); PROF(3);
+    rg_velocity(m, s, L.x.dof_velmask, L.x.subtree_adr, L.x.subtree); PROF(7);
+    rg_collision(m, s, (flags & 2) ? s.prof : (float*)0, L.bt.sepdir ? (rgf4*)L.bt.sepdir + (size_t)e * m.npair : (rgf4*)0,
+                 (L.bt.pairlb && !(flags & 4)) ? L.bt.pairlb + (size_t)e * m.npair : (float*)0, !(flags & 8)); PROF(6);
     if ((flags & 2) && LANE == 0 && (float)s.ncon > s.prof[23]) s.prof[23] = (float)s.ncon;
     rg_make_constraint(m, s); PROF(8);
     rg_pid(m, s);
     rg_smooth(m, s); PROF(9);
-    if (sub == 0 && (flags & 1) && bt.dbg) rg_dump_pos(m, s, bt.dbg + (size_t)e * RG_DBG_SIZE);
+    if (sub == 0 && (flags & 1) && L.bt.dbg) rg_dump_pos(m, s, L.bt.dbg + (size_t)e * RG_DBG_SIZE);
     // ---- the position-stage scratch is dead from here on; the solver scratch takes its place
 #ifdef RG_EMUL_POISON
     { unsigned int* u = (unsigned int*)s.H; int nw = (int)((sizeof(RgLds) - ((char*)s.H - (char*)&s)) / 4); for (int w = LANE; w < nw; w += RG_WAVE) u[w] = 0x7fc00000u; SYNC(); }
@@ -1808,7 +1817,7 @@ __global__ void __launch_bounds__(RG_WAVE, 2) rg_step_kernel(const RgModelDev* m
     int nefc = 0;
     int iters = rg_solve(m, s, nefc, flags); t0 = rg_clock();
     st_ncon += s.ncon; st_nefc += nefc; st_iter += iters;
-    if (sub == 0 && (flags & 1) && bt.dbg) rg_dump_slv(m, s, bt.dbg + (size_t)e * RG_DBG_SIZE, nefc, iters);
+    if (sub == 0 && (flags & 1) && L.bt.dbg) rg_dump_slv(m, s, L.bt.dbg + (size_t)e * RG_DBG_SIZE, nefc, iters);
     bd = 0; PFOR(i, m.nv) bd += (fabsf(s.qacc[i]) < 1e10f) ? 0.f : 1.f;
     if (wave_sum(bd) > 0) { bad = true; break; }
     rg_euler(m, s); PROF(11);
@@ -1816,45 +1825,45 @@ __global__ void __launch_bounds__(RG_WAVE, 2) rg_step_kernel(const RgModelDev* m
   if (bad && LANE == 0) s.status |= RG_STATUS_BAD_STATE;
   // ---- state-less forward() calls of the reference (simulation_interface.py:185, robot_env.py:677,
   //      observation/mujoco.py:22-27): only their PID-controller side effect touches the state
-  if (nforward_ticks > 0 || bt.obs) {
-    rg_position_stage(m, x, s);
+  if (nforward_ticks > 0 || L.bt.obs) {
+    rg_position_stage(m, s);
     for (int k = 0; k < nforward_ticks; k++) rg_pid(m, s);
   }
   // ---- write back
-  PFOR(i, m.nq) bt.qpos[(size_t)e * m.nq + i] = s.qpos[i];
-  PFOR(i, m.nv) { bt.qvel[(size_t)e * m.nv + i] = s.qvel[i]; bt.qacc_warmstart[(size_t)e * m.nv + i] = s.warm[i]; }
-  PFOR(i, 3 * m.nu) bt.pid[(size_t)e * 3 * m.nu + i] = s.pid[i];
-  PFOR(u, m.nu) bt.ctrl[(size_t)e * m.nu + u] = s.ctrl[u];
+  PFOR(i, m.nq) L.bt.qpos[(size_t)e * m.nq + i] = s.qpos[i];
+  PFOR(i, m.nv) { L.bt.qvel[(size_t)e * m.nv + i] = s.qvel[i]; L.bt.qacc_warmstart[(size_t)e * m.nv + i] = s.warm[i]; }
+  PFOR(i, 3 * m.nu) L.bt.pid[(size_t)e * 3 * m.nu + i] = s.pid[i];
+  PFOR(u, m.nu) L.bt.ctrl[(size_t)e * m.nu + u] = s.ctrl[u];
   if (LANE == 0) {
-    bt.status[e] = s.status; bt.time[e] += nsubsteps * m.timestep;
-    if (bt.stats) { float* st = bt.stats + 4 * (size_t)e; st[0] += st_ncon; st[1] += st_nefc; st[2] += st_iter; st[3] += nsubsteps; }
+    L.bt.status[e] = s.status; L.bt.time[e] += nsubsteps * m.timestep;
+    if (L.bt.stats) { float* st = L.bt.stats + 4 * (size_t)e; st[0] += st_ncon; st[1] += st_nefc; st[2] += st_iter; st[3] += nsubsteps; }
   }
-  if ((flags & 2) && bt.dbg && LANE < RG_NPROF) bt.dbg[(size_t)e * RG_DBG_SIZE + RG_DBG_CON + LANE] = s.prof[LANE];  // stage cycle counters (overlays the contact dump)
+  if ((flags & 2) && L.bt.dbg && LANE < RG_NPROF) L.bt.dbg[(size_t)e * RG_DBG_SIZE + RG_DBG_CON + LANE] = s.prof[LANE];  // stage cycle counters (overlays the contact dump)
   // ---- observation row (robot_env.py:714-743; keys/order: DESIGN.md "observation layout")
-  if (bt.obs) {
-    int od = 3 + 4 + m.nq + m.nv + env.n_hand_jnt + 15;
-    float* o = bt.obs + (size_t)e * od;
+  if (L.bt.obs) {
+    int od = 3 + 4 + m.nq + m.nv + L.env.n_hand_jnt + 15;
+    float* o = L.bt.obs + (size_t)e * od;
     // cube_pos = the three slide-joint coordinates, cube_quat sign-normalised to w >= 0
     // (envs/dactyl/observation/cube.py:8-29)
-    PFOR(i, 3) o[i] = s.qpos[env.cube_pos_qposadr + i];
-    { float sg = s.qpos[env.cube_quat_qposadr] < 0 ? -1.f : 1.f; PFOR(i, 4) o[3 + i] = sg * s.qpos[env.cube_quat_qposadr + i]; }
-    PFOR(i, m.nq) o[7 + i] = (i >= env.target_qposadr && i < env.target_qposadr + env.target_nq) ? 0.f : s.qpos[i];
-    PFOR(i, m.nv) o[7 + m.nq + i] = (i >= env.target_dofadr && i < env.target_dofadr + env.target_nv) ? 0.f : s.qvel[i];
-    PFOR(i, env.n_hand_jnt) o[7 + m.nq + m.nv + i] = s.qpos[env.hand_qposadr + i];
+    PFOR(i, 3) o[i] = s.qpos[L.env.cube_pos_qposadr + i];
+    { float sg = s.qpos[L.env.cube_quat_qposadr] < 0 ? -1.f : 1.f; PFOR(i, 4) o[3 + i] = sg * s.qpos[L.env.cube_quat_qposadr + i]; }
+    PFOR(i, m.nq) o[7 + i] = (i >= L.env.target_qposadr && i < L.env.target_qposadr + L.env.target_nq) ? 0.f : s.qpos[i];
+    PFOR(i, m.nv) o[7 + m.nq + i] = (i >= L.env.target_dofadr && i < L.env.target_dofadr + L.env.target_nv) ? 0.f : s.qvel[i];
+    PFOR(i, L.env.n_hand_jnt) o[7 + m.nq + m.nv + i] = s.qpos[L.env.hand_qposadr + i];
     // fingertips relative to the three reference sites (hand_forward_kinematics.py:39-50)
     PFOR(i, 5) {
-      v3 r0 = ld3(s.spos + 3 * env.ref_site[0]), r1 = ld3(s.spos + 3 * env.ref_site[1]), r2 = ld3(s.spos + 3 * env.ref_site[2]);
+      v3 r0 = ld3(s.spos + 3 * L.env.ref_site[0]), r1 = ld3(s.spos + 3 * L.env.ref_site[1]), r2 = ld3(s.spos + 3 * L.env.ref_site[2]);
       v3 a = normalized(r0 - r1), c = normalized(r2 - r1), b = cross(a, c);
-      v3 t = ld3(s.spos + 3 * env.tip_site[i]) - r1;
-      float* ot = o + 7 + m.nq + m.nv + env.n_hand_jnt + 3 * i;
+      v3 t = ld3(s.spos + 3 * L.env.tip_site[i]) - r1;
+      float* ot = o + 7 + m.nq + m.nv + L.env.n_hand_jnt + 3 * i;
       ot[0] = dot(t, a); ot[1] = dot(t, b); ot[2] = dot(t, c);
     }
     // goal distance: 2 acos(|w|) of q_goal * conj(q_cube)  (locked_parallel.py:54-76, rotation.py:271-286)
-    if (bt.goal_quat && bt.goal_dist && LANE == 0) {
-      q4 g = ldq(bt.goal_quat + 4 * (size_t)e), c = ldq(s.qpos + env.cube_quat_qposadr);
+    if (L.bt.goal_quat && L.bt.goal_dist && LANE == 0) {
+      q4 g = ldq(L.bt.goal_quat + 4 * (size_t)e), c = ldq(s.qpos + L.env.cube_quat_qposadr);
       c.x = -c.x; c.y = -c.y; c.z = -c.z;
       q4 dq = qmul(g, c);
-      bt.goal_dist[e] = 2.0f * acosf(clampf(fabsf(dq.w), -1.f, 1.f));
+      L.bt.goal_dist[e] = 2.0f * acosf(clampf(fabsf(dq.w), -1.f, 1.f));
     }
   }
 }
