@@ -409,18 +409,19 @@ int rg_batch_step(rg_batch* b, const float* action_dev, const float* goal_quat_d
 }
 
 #ifdef RG_EMUL
-struct EmulMprArgs { const RgModelDev* m; RgBatchDev bt; int g1, g2; float margin; float* out; };
-static void emul_mpr_entry(void* a) { EmulMprArgs* p = (EmulMprArgs*)a; rg_mpr_pair_kernel(p->m, p->bt, p->g1, p->g2, p->margin, p->out); }
+struct EmulMprArgs { const RgModelDev* m; RgLaunch launch; int g1, g2; float margin; float* out; };
+static void emul_mpr_entry(void* a) { EmulMprArgs* p = (EmulMprArgs*)a; rg_mpr_pair_kernel(p->m, p->launch, p->g1, p->g2, p->margin, p->out); }
 #endif
 int rg_batch_mpr_pair(rg_batch* b, int g1, int g2, float margin, float* out_dev, void* stream) {
   if (!b || !out_dev) return fail("null argument");
   const RgModelDev& d = b->model->dev;
   if (g1 < 0 || g2 < 0 || g1 >= d.ngeom || g2 >= d.ngeom) return fail("geom id out of range");
+  RgLaunch launch{b->model->aux, b->env, b->dev, 0, 0, 0};
 #ifdef RG_EMUL
-  EmulMprArgs args{b->model->dev_copy, b->dev, g1, g2, margin, out_dev};
+  EmulMprArgs args{b->model->dev_copy, launch, g1, g2, margin, out_dev};
   emul_launch(b->dev.B, sizeof(RgLds), emul_mpr_entry, &args);
 #else
-  hipLaunchKernelGGL(rg_mpr_pair_kernel, dim3(b->dev.B), dim3(RG_WAVE), sizeof(RgLds), (hipStream_t)stream, b->model->dev_copy, b->dev, g1, g2, margin, out_dev);
+  hipLaunchKernelGGL(rg_mpr_pair_kernel, dim3(b->dev.B), dim3(RG_WAVE), sizeof(RgLds), (hipStream_t)stream, b->model->dev_copy, launch, g1, g2, margin, out_dev);
   HIPCHK(hipGetLastError());
 #endif
   return 0;

@@ -1742,27 +1742,81 @@ __device__ __forceinline__ void rg_position_stage(RgM m, RgLds& s) {
   rg_tendon(m, s);
 }
 
-// Everything a launch passes besides the model, as ONE by-value kernel argument that the body reads through the
+// ------------------------------------------------------------------------------------------------- stage calls
+// Everything a launch passes besides the model, as ONE by-value kernel argument that is read through the
 // constant address space (the kernarg segment), so that its ~100 scalars are loaded where they are used
 // instead of living in (or being spilled from) SGPRs for the whole kernel.
 struct RgLaunch { RgAux x; RgEnvDev env; RgBatchDev bt; int nsubsteps, nforward_ticks, flags; };
+
+// The substep is a sequence of REAL function calls (not inlined): each stage gets its own register
+// allocation, so loop invariants of one stage are not kept alive (or spilled) through all the others.
+// A stage finds the model, the launch descriptor and the env's LDS image by itself: the kernarg segment
+// pointer is an implicit argument of every device function, and the LDS image is the workgroup's only
+// dynamic shared allocation.
+struct RgCtx { const void* km; const void* kl; };   // device address of the model descriptor, address of the launch descriptor
+#ifdef RG_EMUL
+#define RG_M(c) (*(const RgModelDev*)(c).km)
+#define RG_L(c) (*(const RgLaunch*)(c).kl)
+#define RG_S() (*(RgLds*)emul_lds())
+#define RG_STAGE static inline
+typedef const RgLaunch& RgLRef;
+#else
+extern __shared__ __attribute__((aligned(16))) unsigned char rg_lds_raw[];
+#define RG_AS4 __attribute__((address_space(4)))
+// function arguments arrive in VGPRs: read the (wave-uniform) addresses back into SGPRs so that everything
+// loaded through them is a scalar load again
+__device__ __forceinline__ unsigned long long rg_uniform(const void* p) {
+  unsigned long long v = (unsigned long long)p;
+  unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v), hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+#define RG_M(c) (*(const RG_AS4 RgModelDev*)rg_uniform((c).km))
+#define RG_L(c) (*(const RG_AS4 RgLaunch*)rg_uniform((c).kl))
+#define RG_S() (*(RgLds*)rg_lds_raw)
+#ifdef RG_INLINE_STAGES
+#define RG_STAGE __device__ __forceinline__
+#else
+#define RG_STAGE __device__ __attribute__((noinline))
+#endif
+typedef const RG_AS4 RgLaunch& RgLRef;
+#endif
+RG_STAGE void st_kinematics(RgCtx c) { rg_kinematics(RG_M(c), RG_S()); }
+RG_STAGE void st_com_pos(RgCtx c) { rg_com_pos(RG_M(c), RG_S()); }
+RG_STAGE void st_tendon(RgCtx c) { rg_tendon(RG_M(c), RG_S()); }
+RG_STAGE void st_crb(RgCtx c) { RgLRef L = RG_L(c); rg_crb(RG_M(c), RG_S(), L.x.subtree_adr, L.x.subtree); }
+RG_STAGE void st_velocity(RgCtx c) { RgLRef L = RG_L(c); rg_velocity(RG_M(c), RG_S(), L.x.dof_velmask, L.x.subtree_adr, L.x.subtree); }
+RG_STAGE void st_collision(RgCtx c) {
+  RgM m = RG_M(c); RgLRef L = RG_L(c); RgLds& s = RG_S();
+  int e = blockIdx.x, flags = L.flags;
+  rg_collision(m, s, (flags & 2) ? s.prof : (float*)0, L.bt.sepdir ? (rgf4*)L.bt.sepdir + (size_t)e * m.npair : (rgf4*)0,
+               (L.bt.pairlb && !(flags & 4)) ? L.bt.pairlb + (size_t)e * m.npair : (float*)0, !(flags & 8));
+}
+RG_STAGE void st_make_constraint(RgCtx c) { rg_make_constraint(RG_M(c), RG_S()); }
+RG_STAGE void st_pid(RgCtx c) { rg_pid(RG_M(c), RG_S()); }
+RG_STAGE void st_smooth(RgCtx c) { rg_smooth(RG_M(c), RG_S()); }
+RG_STAGE void st_factor_smooth(RgCtx c) { RgLds& s = RG_S(); rg_block_factor_solve(RG_M(c), s, (const float*)0, 0.f, s.qacc_smooth); }
+RG_STAGE int st_solve(RgCtx c) { int nefc = 0; int it = rg_solve(RG_M(c), RG_S(), nefc, RG_L(c).flags); return it | (nefc << 8); }
+RG_STAGE void st_euler(RgCtx c) { rg_euler(RG_M(c), RG_S()); }
+RG_STAGE void st_build_row_desc(RgCtx c) { rg_build_row_desc(RG_M(c), RG_S()); }
+RG_STAGE void st_dump(RgCtx c, int which, int nefc, int iters) {
+  RgM m = RG_M(c); RgLRef L = RG_L(c); RgLds& s = RG_S();
+  float* dbg = L.bt.dbg + (size_t)blockIdx.x * RG_DBG_SIZE;
+  if (which == 0) rg_dump_kin(m, s, dbg); else if (which == 1) rg_dump_pos(m, s, dbg); else rg_dump_slv(m, s, dbg, nefc, iters);
+}
+
+// kernel arguments: the model descriptor's device address at kernarg offset 0, the launch descriptor (8-byte
+// aligned) at offset 8 of the kernarg segment
+#ifdef RG_EMUL
+#define RG_MAKE_CTX() RgCtx c{mp, &launch}
+#else
+#define RG_MAKE_CTX() RgCtx c{mp, (const void*)((const RG_AS4 char*)__builtin_amdgcn_kernarg_segment_ptr() + 8)}
+#endif
 __global__ void __launch_bounds__(RG_WAVE, 2) rg_step_kernel(const RgModelDev* mp, RgLaunch launch) {
-#ifdef RG_EMUL
-  RgM m = *mp;
-  const RgLaunch& L = launch;
-#else
-  RgM m = *(const __attribute__((address_space(4))) RgModelDev*)mp;
-  // second kernel argument: 8-byte aligned, right after the model pointer
-  const __attribute__((address_space(4))) RgLaunch& L =
-      *(const __attribute__((address_space(4))) RgLaunch*)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + 8);
-#endif
+  RG_MAKE_CTX();
+  RgM m = RG_M(c);
+  RgLRef L = RG_L(c);
+  RgLds& s = RG_S();
   const int nsubsteps = L.nsubsteps, nforward_ticks = L.nforward_ticks, flags = L.flags;
-#ifdef RG_EMUL
-  RgLds& s = *(RgLds*)emul_lds();
-#else
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  RgLds& s = *(RgLds*)lds_raw;
-#endif
   int e = blockIdx.x;
   if (e >= L.bt.B) return;
   if (L.bt.active && !L.bt.active[e]) return;
@@ -1772,7 +1826,7 @@ __global__ void __launch_bounds__(RG_WAVE, 2) rg_step_kernel(const RgModelDev* m
   PFOR(i, 3 * m.nu) s.pid[i] = L.bt.pid[(size_t)e * 3 * m.nu + i];
   if (LANE == 0) s.status = L.bt.status[e];
   if (LANE < RG_NPROF) s.prof[LANE] = 0;
-  rg_build_row_desc(m, s);
+  st_build_row_desc(c);
   // ---- action -> ctrl (robot_interface.py:247-278 with the hand's position->control matrix)
   float a0 = L.bt.action ? L.bt.action[(size_t)e * m.nu] : 0.f;
   if (L.bt.action && a0 == a0) {   // a NaN first entry: this env keeps its stored ctrl row
@@ -1796,38 +1850,36 @@ __global__ void __launch_bounds__(RG_WAVE, 2) rg_step_kernel(const RgModelDev* m
 #ifdef RG_EMUL_POISON
     { unsigned int* u = (unsigned int*)s.H; int nw = (int)((sizeof(RgLds) - ((char*)s.H - (char*)&s)) / 4); for (int w = LANE; w < nw; w += RG_WAVE) u[w] = 0x7fc00000u; SYNC(); }
 #endif
-    rg_kinematics(m, s); PROF(0);
-    rg_com_pos(m, s); PROF(1);
-    rg_tendon(m, s); PROF(2);
-    if (sub == 0 && (flags & 1) && L.bt.dbg) rg_dump_kin(m, s, L.bt.dbg + (size_t)e * RG_DBG_SIZE);
-    rg_crb(m, s, L.x.subtree_adr, L.x.subtree); PROF(3);
-    rg_velocity(m, s, L.x.dof_velmask, L.x.subtree_adr, L.x.subtree); PROF(7);
-    rg_collision(m, s, (flags & 2) ? s.prof : (float*)0, L.bt.sepdir ? (rgf4*)L.bt.sepdir + (size_t)e * m.npair : (rgf4*)0,
-                 (L.bt.pairlb && !(flags & 4)) ? L.bt.pairlb + (size_t)e * m.npair : (float*)0, !(flags & 8)); PROF(6);
+    st_kinematics(c); PROF(0);
+    st_com_pos(c); PROF(1);
+    st_tendon(c); PROF(2);
+    if (sub == 0 && (flags & 1) && L.bt.dbg) st_dump(c, 0, 0, 0);
+    st_crb(c); PROF(3);
+    st_velocity(c); PROF(7);
+    st_collision(c); PROF(6);
     if ((flags & 2) && LANE == 0 && (float)s.ncon > s.prof[23]) s.prof[23] = (float)s.ncon;
-    rg_make_constraint(m, s); PROF(8);
-    rg_pid(m, s);
-    rg_smooth(m, s); PROF(9);
-    if (sub == 0 && (flags & 1) && L.bt.dbg) rg_dump_pos(m, s, L.bt.dbg + (size_t)e * RG_DBG_SIZE);
+    st_make_constraint(c); PROF(8);
+    st_pid(c);
+    st_smooth(c); PROF(9);
+    if (sub == 0 && (flags & 1) && L.bt.dbg) st_dump(c, 1, 0, 0);
     // ---- the position-stage scratch is dead from here on; the solver scratch takes its place
 #ifdef RG_EMUL_POISON
     { unsigned int* u = (unsigned int*)s.H; int nw = (int)((sizeof(RgLds) - ((char*)s.H - (char*)&s)) / 4); for (int w = LANE; w < nw; w += RG_WAVE) u[w] = 0x7fc00000u; SYNC(); }
 #endif
-    rg_block_factor_solve(m, s, (const float*)0, 0.f, s.qacc_smooth); PROF(4);
-    int nefc = 0;
-    int iters = rg_solve(m, s, nefc, flags); t0 = rg_clock();
+    st_factor_smooth(c); PROF(4);
+    int packed = st_solve(c), iters = packed & 255, nefc = packed >> 8; t0 = rg_clock();
     st_ncon += s.ncon; st_nefc += nefc; st_iter += iters;
-    if (sub == 0 && (flags & 1) && L.bt.dbg) rg_dump_slv(m, s, L.bt.dbg + (size_t)e * RG_DBG_SIZE, nefc, iters);
+    if (sub == 0 && (flags & 1) && L.bt.dbg) st_dump(c, 2, nefc, iters);
     bd = 0; PFOR(i, m.nv) bd += (fabsf(s.qacc[i]) < 1e10f) ? 0.f : 1.f;
     if (wave_sum(bd) > 0) { bad = true; break; }
-    rg_euler(m, s); PROF(11);
+    st_euler(c); PROF(11);
   }
   if (bad && LANE == 0) s.status |= RG_STATUS_BAD_STATE;
   // ---- state-less forward() calls of the reference (simulation_interface.py:185, robot_env.py:677,
   //      observation/mujoco.py:22-27): only their PID-controller side effect touches the state
   if (nforward_ticks > 0 || L.bt.obs) {
-    rg_position_stage(m, s);
-    for (int k = 0; k < nforward_ticks; k++) rg_pid(m, s);
+    st_kinematics(c); st_com_pos(c); st_tendon(c);
+    for (int k = 0; k < nforward_ticks; k++) st_pid(c);
   }
   // ---- write back
   PFOR(i, m.nq) L.bt.qpos[(size_t)e * m.nq + i] = s.qpos[i];
@@ -1870,22 +1922,15 @@ __global__ void __launch_bounds__(RG_WAVE, 2) rg_step_kernel(const RgModelDev* m
 
 // Collision unit-test hook: kinematics of each env's stored qpos, then one MPR query between two geoms.
 // out[e][8] = hit, depth, dir3, pos3 (world)
-__global__ void __launch_bounds__(RG_WAVE) rg_mpr_pair_kernel(const RgModelDev* mp, RgBatchDev bt, int g1, int g2, float margin, float* out) {
-#ifdef RG_EMUL
-  RgM m = *mp;
-#else
-  RgM m = *(const __attribute__((address_space(4))) RgModelDev*)mp;
-#endif
-#ifdef RG_EMUL
-  RgLds& s = *(RgLds*)emul_lds();
-#else
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  RgLds& s = *(RgLds*)lds_raw;
-#endif
+__global__ void __launch_bounds__(RG_WAVE) rg_mpr_pair_kernel(const RgModelDev* mp, RgLaunch launch, int g1, int g2, float margin, float* out) {
+  RG_MAKE_CTX();
+  RgM m = RG_M(c);
+  RgLRef L = RG_L(c);
+  RgLds& s = RG_S();
   int e = blockIdx.x;
-  PFOR(i, m.nq) s.qpos[i] = bt.qpos[(size_t)e * m.nq + i];
+  PFOR(i, m.nq) s.qpos[i] = L.bt.qpos[(size_t)e * m.nq + i];
   SYNC();
-  rg_kinematics(m, s);
+  st_kinematics(c);
   MprGeom A, B;
   v3 p1 = ld3(s.gpos + 3 * g1), p2 = ld3(s.gpos + 3 * g2);
   A.type = m.geom_type[g1]; A.mat = s.gmat + 9 * g1; A.size = ld3(m.geom_size + 3 * g1); A.margin = 0.5f * margin; A.pos = mk3(0, 0, 0); A.prof = 0;
