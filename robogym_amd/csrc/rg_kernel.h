@@ -87,6 +87,49 @@ struct RgLds {
   };
 };
 
+struct RgAux {  // extra static tables (kept out of RgModelDev to keep the kernarg small)
+  const int *subtree_adr, *subtree;
+  const uint32_t* dof_velmask;
+};
+
+// ------------------------------------------------------------------------------------------------- launch context
+// Everything a launch passes besides the model, as ONE by-value kernel argument that is read through the
+// constant address space (the kernarg segment), so that its ~100 scalars are loaded where they are used
+// instead of living in (or being spilled from) SGPRs for the whole kernel.
+struct RgLaunch { RgAux x; RgEnvDev env; RgBatchDev bt; int nsubsteps, nforward_ticks, flags; };
+
+// The substep is a sequence of REAL function calls (not inlined): each stage gets its own register
+// allocation, so loop invariants of one stage are not kept alive (or spilled) through all the others.
+// A stage finds the model, the launch descriptor and the env's LDS image by itself: the kernarg segment
+// pointer is an implicit argument of every device function, and the LDS image is the workgroup's only
+// dynamic shared allocation.
+struct RgCtx { const void* km; const void* kl; };   // device address of the model descriptor, address of the launch descriptor
+#ifdef RG_EMUL
+#define RG_M(c) (*(const RgModelDev*)(c).km)
+#define RG_L(c) (*(const RgLaunch*)(c).kl)
+#define RG_S() (*(RgLds*)emul_lds())
+#define RG_STAGE static inline
+typedef const RgLaunch& RgLRef;
+#else
+extern __shared__ __attribute__((aligned(16))) unsigned char rg_lds_raw[];
+#define RG_AS4 __attribute__((address_space(4)))
+// function arguments arrive in VGPRs: read the (wave-uniform) addresses back into SGPRs so that everything
+// loaded through them is a scalar load again
+__device__ __forceinline__ unsigned long long rg_uniform(const void* p) {
+  unsigned long long v = (unsigned long long)p;
+  unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v), hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+#define RG_M(c) (*(const RG_AS4 RgModelDev*)rg_uniform((c).km))
+#define RG_L(c) (*(const RG_AS4 RgLaunch*)rg_uniform((c).kl))
+#define RG_S() (*(RgLds*)rg_lds_raw)
+#ifdef RG_INLINE_STAGES
+#define RG_STAGE __device__ __forceinline__
+#else
+#define RG_STAGE __device__ __attribute__((noinline))
+#endif
+typedef const RG_AS4 RgLaunch& RgLRef;
+#endif
 // ------------------------------------------------------------------------------------------------- small math
 struct alignas(16) rgf4 { float x, y, z, w; };
 struct v3 { float x, y, z; };
@@ -474,7 +517,10 @@ __device__ __forceinline__ void rg_crb(RgM m, RgLds& s, const int* subtree_adr, 
 
 // ------------------------------------------------------------------------------------------------- collision
 struct SupPt { v3 v, s; };  // v = v1 - v2 (Minkowski difference), s = v1 + v2 (all the contact position needs)
-struct MprGeom { int type; const float* mat; v3 pos; v3 size; const float* vert; int nvert; float margin; float* prof; const int* celladr; const rgf4 *cellblk, *cellovf; };
+// per-query (lane-varying) description of one geom, and the wave-uniform tables every query shares: keeping the
+// 64-bit table pointers out of MprGeom keeps them in SGPRs (the narrowphase is the register-hungriest stage)
+struct MprGeom { int type; const float* mat; v3 pos; v3 size; int vertadr, nvert, mesh; float margin; };   // mesh: id, -1 for primitives
+struct MprEnv { const float* mesh_vert; const int* cell_adr; const rgf4 *cell_blk, *cell_ovf; float* prof; bool cells; };
 
 // per-lane scan of a hull's vertices: 16-byte records (one dwordx4 load per vertex), four independent
 // loads in flight per lane; out-of-range slots re-read the last vertex (harmless for a max).
@@ -491,6 +537,7 @@ template <int G> __device__ __forceinline__ void scan_batch(const rgf4* vert, in
   if (dc > bv) { bv = dc; bi = j2; bp = mk3(c.x, c.y, c.z); }
   if (dd > bv) { bv = dd; bi = j3; bp = mk3(d.x, d.y, d.z); }
 }
+// full scan of a hull: the reference path behind the cell lists (flags bit 3, the plane-convex pairs)
 template <int G> __device__ __forceinline__ void scan_verts(const rgf4* vert, int nvert, v3 ld, float& bv, int& bi, v3& bp) {
   for (int base = 0; base < nvert; base += 4 * G) scan_batch<G>(vert, nvert, base, ld, bv, bi, bp);
 }
@@ -526,9 +573,9 @@ template <int G> __device__ __forceinline__ void scan_cell(const int* celladr, c
     }
   }
 }
-template <int G> __device__ __forceinline__ void scan_hull(const MprGeom& g, v3 ld, float& bv, int& bi, v3& bp) {
-  if (g.celladr) scan_cell<G>(g.celladr, g.cellblk, g.cellovf, ld, bv, bi, bp);
-  else scan_verts<G>((const rgf4*)g.vert, g.nvert, ld, bv, bi, bp);
+template <int G> __device__ __forceinline__ void scan_hull(const MprEnv& E, const MprGeom& g, v3 ld, float& bv, int& bi, v3& bp) {
+  if (E.cells) scan_cell<G>(E.cell_adr + g.mesh * RG_NCELL, E.cell_blk + (size_t)g.mesh * (RG_NCELL * 4), E.cell_ovf, ld, bv, bi, bp);
+  else scan_verts<G>((const rgf4*)E.mesh_vert + g.vertadr, g.nvert, ld, bv, bi, bp);
 }
 // arg-max over the G cooperating lanes (lowest vertex index on ties, as a serial first-max scan); the
 // winner's coordinates come from the registers of a lane that scanned it
@@ -562,11 +609,11 @@ __device__ __forceinline__ v3 support_primitive(const MprGeom& g, v3 ld) {
   return lr;
 }
 // support point of one geom (relative to the MPR reference origin), cooperative for meshes
-template <int G> __device__ __forceinline__ v3 rg_support(const MprGeom& g, v3 dir) {
+template <int G> __device__ __forceinline__ v3 rg_support(const MprEnv& E, const MprGeom& g, v3 dir) {
   v3 ld = mulmT(g.mat, dir), lr;
   if (g.type == RG_GEOM_MESH) {
     float bv = -3.0e38f; int bi = 0x7fffffff; v3 bp = mk3(0, 0, 0);
-    scan_hull<G>(g, ld, bv, bi, bp);
+    scan_hull<G>(E, g, ld, bv, bi, bp);
     lr = pick_vert<G>(bv, bi, bp);
   } else lr = support_primitive(g, ld);
   lr = lr + ld * g.margin;
@@ -574,41 +621,34 @@ template <int G> __device__ __forceinline__ v3 rg_support(const MprGeom& g, v3 d
 }
 // Minkowski-difference support A(dir) - B(-dir); the two hull scans are issued back to back so their
 // vertex loads overlap
-template <int G> __device__ __forceinline__ void mpr_support(const MprGeom& a, const MprGeom& b, v3 dir, SupPt& p) {
-  long long tt0 = a.prof ? rg_clock() : 0;
+template <int G> __device__ __forceinline__ void mpr_support(const MprEnv& E, const MprGeom& a, const MprGeom& b, v3 dir, SupPt& p) {
+  long long tt0 = E.prof ? rg_clock() : 0;
   v3 la = mulmT(a.mat, dir), lb = mulmT(b.mat, dir * -1.0f), ra, rb;
   float av = -3.0e38f, bvv = -3.0e38f; int ai = 0x7fffffff, bi = 0x7fffffff; v3 ap = mk3(0, 0, 0), bp = mk3(0, 0, 0);
   bool am = a.type == RG_GEOM_MESH, bm = b.type == RG_GEOM_MESH;
-  if (am && bm && !a.celladr) {
-    int nmax = a.nvert > b.nvert ? a.nvert : b.nvert;
-    for (int base = 0; base < nmax; base += 4 * G) {  // both hulls' loads are issued before either compare chain
-      if (base < a.nvert) scan_batch<G>((const rgf4*)a.vert, a.nvert, base, la, av, ai, ap);
-      if (base < b.nvert) scan_batch<G>((const rgf4*)b.vert, b.nvert, base, lb, bvv, bi, bp);
-    }
-  } else {
-    if (am) scan_hull<G>(a, la, av, ai, ap);
-    if (bm) scan_hull<G>(b, lb, bvv, bi, bp);
-  }
-  long long tt1 = a.prof ? rg_clock() : 0;
+  if (am) scan_hull<G>(E, a, la, av, ai, ap);
+  if (bm) scan_hull<G>(E, b, lb, bvv, bi, bp);
+  long long tt1 = E.prof ? rg_clock() : 0;
   ra = am ? pick_vert<G>(av, ai, ap) : support_primitive(a, la);
   rb = bm ? pick_vert<G>(bvv, bi, bp) : support_primitive(b, lb);
   v3 w1 = mulm(a.mat, ra + la * a.margin) + a.pos;
   v3 w2 = mulm(b.mat, rb + lb * b.margin) + b.pos;
   p.v = w1 - w2; p.s = w1 + w2;
-  if (a.prof && LANE == 0) { long long tt2 = rg_clock(); a.prof[20] += 1.f; a.prof[21] += (float)(tt1 - tt0); a.prof[22] += (float)(tt2 - tt1); }
+  if (E.prof && LANE == 0) { long long tt2 = rg_clock(); E.prof[20] += 1.f; E.prof[21] += (float)(tt1 - tt0); E.prof[22] += (float)(tt2 - tt1); }
 }
 #define MPR_EPS 1.0e-7f  /* plays the role of libccd's CCD_EPS at fp32 (coordinates are pair-local, |x| ~ 0.1) */
 __device__ __forceinline__ bool mz(float x) { return fabsf(x) < MPR_EPS * 1e-3f; }
-__device__ __forceinline__ v3 portal_dir(const SupPt* p) { return normalized(cross(p[2].v - p[1].v, p[3].v - p[1].v)); }
-__device__ __forceinline__ bool portal_reach_tol(const SupPt* p, const SupPt& v4, v3 dir, float tol) {
+// (the portal is four named points, not an array: an indexed private array ends up in scratch memory)
+__device__ __forceinline__ v3 portal_dir(const SupPt& p1, const SupPt& p2, const SupPt& p3) { return normalized(cross(p2.v - p1.v, p3.v - p1.v)); }
+__device__ __forceinline__ bool portal_reach_tol(const SupPt& p1, const SupPt& p2, const SupPt& p3, const SupPt& v4, v3 dir, float tol) {
   float dv4 = dot(v4.v, dir);
-  float mn = fminf(fminf(dv4 - dot(p[1].v, dir), dv4 - dot(p[2].v, dir)), dv4 - dot(p[3].v, dir));
+  float mn = fminf(fminf(dv4 - dot(p1.v, dir), dv4 - dot(p2.v, dir)), dv4 - dot(p3.v, dir));
   return mn <= tol;
 }
-__device__ __forceinline__ void expand_portal(SupPt* p, const SupPt& v4) {
-  v3 c = cross(v4.v, p[0].v);
-  if (dot(p[1].v, c) > 0) { if (dot(p[2].v, c) > 0) p[1] = v4; else p[3] = v4; }
-  else { if (dot(p[3].v, c) > 0) p[2] = v4; else p[1] = v4; }
+__device__ __forceinline__ void expand_portal(const SupPt& p0, SupPt& p1, SupPt& p2, SupPt& p3, const SupPt& v4) {
+  v3 c = cross(v4.v, p0.v);
+  if (dot(p1.v, c) > 0) { if (dot(p2.v, c) > 0) p1 = v4; else p3 = v4; }
+  else { if (dot(p3.v, c) > 0) p2 = v4; else p1 = v4; }
 }
 __device__ __forceinline__ float origin_tri_dist2(v3 a, v3 b, v3 c, v3& w) {
   v3 ab = b - a, ac = c - a, ap = a * -1.0f;
@@ -639,79 +679,80 @@ __device__ __forceinline__ float origin_tri_dist2(v3 a, v3 b, v3 c, v3& w) {
 // of bookkeeping diverge.  (With one nested loop per phase the groups drift apart and the wave
 // serialises their different phases.)  `active` false: the group idles; call from convergent code.
 enum { MPR_DONE = 0, MPR_FIRST, MPR_SECOND, MPR_DISCOVER, MPR_REFINE, MPR_PENETR };
-template <int G> __device__ __forceinline__ bool rg_mpr(const MprGeom& A, const MprGeom& B, int max_iter, float tol, float& depth, v3& dir_out, v3& pos, v3& sep, bool active) {
-  SupPt p[4];
+template <int G> __device__ __forceinline__ bool rg_mpr(const MprEnv& E, const MprGeom& A, const MprGeom& B, int max_iter, float tol, float& depth, v3& dir_out, v3& pos, v3& sep, bool active) {
+  SupPt p0, p1, p2, p3;
+  p0.v = p0.s = p1.v = p1.s = p2.v = p2.s = p3.v = p3.s = mk3(0, 0, 0);
   int state = active ? MPR_FIRST : MPR_DONE, guard = 0;
   bool result = false;
   v3 dir = mk3(1, 0, 0);
   sep = mk3(0, 0, 0);
   if (active) {
-    p[0].s = A.pos + B.pos; p[0].v = A.pos - B.pos;
-    if (mz(p[0].v.x) && mz(p[0].v.y) && mz(p[0].v.z)) p[0].v.x += 1e-6f;
-    dir = normalized(p[0].v * -1.0f);
+    p0.s = A.pos + B.pos; p0.v = A.pos - B.pos;
+    if (mz(p0.v.x) && mz(p0.v.y) && mz(p0.v.z)) p0.v.x += 1e-6f;
+    dir = normalized(p0.v * -1.0f);
   }
   while (__ballot(state != MPR_DONE)) {
     if (state == MPR_DONE) continue;
     SupPt q;
-    mpr_support<G>(A, B, dir, q);
+    mpr_support<G>(E, A, B, dir, q);
     float dq = dot(q.v, dir);
     bool to_refine = false;   // portal complete or expanded: decide between refinement and the penetration search
     if (state == MPR_FIRST) {
-      p[1] = q;
+      p1 = q;
       if (dq <= 0) { sep = dir; state = MPR_DONE; }
       else {
-        dir = cross(p[0].v, p[1].v);
+        dir = cross(p0.v, p1.v);
         if (dot(dir, dir) < 1e-30f) {   // centre, origin and support point on one line
-          pos = p[1].s * 0.5f; result = true; state = MPR_DONE;
-          if (dot(p[1].v, p[1].v) < 1e-30f) { depth = 0; dir_out = mk3(0, 0, 0); }
-          else { depth = norm(p[1].v); dir_out = p[1].v * (1.0f / depth); }
+          pos = p1.s * 0.5f; result = true; state = MPR_DONE;
+          if (dot(p1.v, p1.v) < 1e-30f) { depth = 0; dir_out = mk3(0, 0, 0); }
+          else { depth = norm(p1.v); dir_out = p1.v * (1.0f / depth); }
         } else { dir = normalized(dir); state = MPR_SECOND; }
       }
     } else if (state == MPR_SECOND) {
-      p[2] = q;
+      p2 = q;
       if (dq <= 0) { sep = dir; state = MPR_DONE; }
       else {
-        dir = normalized(cross(p[1].v - p[0].v, p[2].v - p[0].v));
-        if (dot(dir, p[0].v) > 0) { SupPt t = p[1]; p[1] = p[2]; p[2] = t; dir = dir * -1.0f; }
+        dir = normalized(cross(p1.v - p0.v, p2.v - p0.v));
+        if (dot(dir, p0.v) > 0) { SupPt t = p1; p1 = p2; p2 = t; dir = dir * -1.0f; }
         state = MPR_DISCOVER; guard = 0;
       }
     } else if (state == MPR_DISCOVER) {
-      p[3] = q;
+      p3 = q;
       if (dq <= 0) { sep = dir; state = MPR_DONE; }
       else {
         bool cont = false;
-        if (dot(cross(p[1].v, p[3].v), p[0].v) < 0) { p[2] = p[3]; cont = true; }
-        if (!cont && dot(cross(p[3].v, p[2].v), p[0].v) < 0) { p[1] = p[3]; cont = true; }
-        if (cont) { dir = normalized(cross(p[1].v - p[0].v, p[2].v - p[0].v)); if (++guard > 64) state = MPR_DONE; }
+        if (dot(cross(p1.v, p3.v), p0.v) < 0) { p2 = p3; cont = true; }
+        if (!cont && dot(cross(p3.v, p2.v), p0.v) < 0) { p1 = p3; cont = true; }
+        if (cont) { dir = normalized(cross(p1.v - p0.v, p2.v - p0.v)); if (++guard > 64) state = MPR_DONE; }
         else { to_refine = true; guard = 0; }
       }
     } else if (state == MPR_REFINE) {
       if (dq < 0) { sep = dir; state = MPR_DONE; }
-      else if (portal_reach_tol(p, q, dir, tol)) state = MPR_DONE;
-      else { expand_portal(p, q); to_refine = true; if (++guard > 128) { state = MPR_DONE; to_refine = false; } }
+      else if (portal_reach_tol(p1, p2, p3, q, dir, tol)) state = MPR_DONE;
+      else { expand_portal(p0, p1, p2, p3, q); to_refine = true; if (++guard > 128) { state = MPR_DONE; to_refine = false; } }
     } else {  // MPR_PENETR
-      if (portal_reach_tol(p, q, dir, tol) || guard > max_iter) {
+      if (portal_reach_tol(p1, p2, p3, q, dir, tol) || guard > max_iter) {
         // depth / direction from the portal PLANE (not libccd's closest point on the final portal triangle,
         // whose choice among the triangles of a flat supporting plane is rounding noise; see DESIGN.md "MPR")
-        depth = fmaxf((dot(p[1].v, dir) + dot(p[2].v, dir) + dot(p[3].v, dir)) * (1.0f / 3.0f), 0.f);
+        depth = fmaxf((dot(p1.v, dir) + dot(p2.v, dir) + dot(p3.v, dir)) * (1.0f / 3.0f), 0.f);
         dir_out = dir;
         // contact position from the barycentric coordinates of the origin in the portal tetrahedron
-        float b0 = dot(cross(p[1].v, p[2].v), p[3].v), b1 = dot(cross(p[3].v, p[2].v), p[0].v);
-        float b2 = dot(cross(p[0].v, p[1].v), p[3].v), b3 = dot(cross(p[2].v, p[1].v), p[0].v);
+        float b0 = dot(cross(p1.v, p2.v), p3.v), b1 = dot(cross(p3.v, p2.v), p0.v);
+        float b2 = dot(cross(p0.v, p1.v), p3.v), b3 = dot(cross(p2.v, p1.v), p0.v);
         float sum = b0 + b1 + b2 + b3;
         if (sum <= 0) {
-          v3 dd = portal_dir(p);
-          b0 = 0; b1 = dot(cross(p[2].v, p[3].v), dd); b2 = dot(cross(p[3].v, p[1].v), dd); b3 = dot(cross(p[1].v, p[2].v), dd);
+          v3 dd = portal_dir(p1, p2, p3);
+          b0 = 0; b1 = dot(cross(p2.v, p3.v), dd); b2 = dot(cross(p3.v, p1.v), dd); b3 = dot(cross(p1.v, p2.v), dd);
           sum = b1 + b2 + b3;
         }
         float inv = 0.5f / sum;
-        pos = p[0].s * (b0 * inv) + p[1].s * (b1 * inv) + p[2].s * (b2 * inv) + p[3].s * (b3 * inv);
+        pos = p0.s * (b0 * inv) + p1.s * (b1 * inv) + p2.s * (b2 * inv) + p3.s * (b3 * inv);
         result = true; state = MPR_DONE;
-      } else { expand_portal(p, q); dir = portal_dir(p); guard++; }
+      } else { expand_portal(p0, p1, p2, p3, q); dir = portal_dir(p1, p2, p3); guard++; }
     }
     if (to_refine) {   // refinePortal's loop head: the origin side of the portal decides
-      dir = portal_dir(p);
-      if (dot(dir, p[1].v) >= 0) { state = MPR_PENETR; guard = 0; } else state = MPR_REFINE;
+      dir = portal_dir(p1, p2, p3);
+      if (dot(dir, p1.v) >= 0) { state = MPR_PENETR; guard = 0; } else state = MPR_REFINE;
     }
   }
   return result;
@@ -760,34 +801,41 @@ __device__ __forceinline__ void add_contact(RgLds& s, int pair, float dist, v3 p
 
 // the two geoms of candidate pair p in pair-local coordinates (origin at geom1's centre: fp32 resolution ~1e-9 m),
 // each inflated by margin/2
-__device__ __forceinline__ void rg_mpr_geoms(RgM m, const RgLds& s, int p, MprGeom& A, MprGeom& B, bool cells, int& dim, float& margin) {
+__device__ __forceinline__ MprEnv rg_mpr_env(RgM m, float* prof, bool cells) {
+  MprEnv E;
+  E.mesh_vert = m.mesh_vert; E.cell_adr = m.mesh_cell_adr; E.cell_blk = (const rgf4*)m.mesh_cell_blk; E.cell_ovf = (const rgf4*)m.mesh_cell_ovf;
+  E.prof = prof; E.cells = cells;
+  return E;
+}
+__device__ __forceinline__ void rg_mpr_geoms(RgM m, const RgLds& s, int p, MprGeom& A, MprGeom& B, int& dim, float& margin) {
   const rgf4* R = (const rgf4*)m.pair_rec + (RG_PAIRREC / 4) * p;
   rgf4 r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3];
-  int hdr = __builtin_bit_cast(int, r0.x), g1 = hdr & 255, g2 = (hdr >> 8) & 255, id1 = __builtin_bit_cast(int, r0.z), id2 = __builtin_bit_cast(int, r0.w);
+  int hdr = __builtin_bit_cast(int, r0.x), g1 = hdr & 255, g2 = (hdr >> 8) & 255;
   dim = (hdr >> 16) & 15; margin = r0.y;
   A.type = (hdr >> 20) & 15; A.mat = s.gmat + 9 * g1; A.size = mk3(r1.x, r1.y, r1.z); A.margin = 0.5f * margin; A.pos = mk3(0, 0, 0);
   B.type = (hdr >> 24) & 15; B.mat = s.gmat + 9 * g2; B.size = mk3(r2.x, r2.y, r2.z); B.margin = 0.5f * margin; B.pos = ld3(s.gpos + 3 * g2) - ld3(s.gpos + 3 * g1);
-  A.vert = m.mesh_vert + 4 * __builtin_bit_cast(int, r3.x); A.nvert = __builtin_bit_cast(int, r1.w);
-  B.vert = m.mesh_vert + 4 * __builtin_bit_cast(int, r3.y); B.nvert = __builtin_bit_cast(int, r2.w);
-  A.cellovf = B.cellovf = (const rgf4*)m.mesh_cell_ovf;
-  A.celladr = (cells && id1 >= 0) ? m.mesh_cell_adr + id1 * RG_NCELL : (const int*)0; A.cellblk = (const rgf4*)m.mesh_cell_blk + (size_t)(id1 >= 0 ? id1 : 0) * (RG_NCELL * 4);
-  B.celladr = (cells && id2 >= 0) ? m.mesh_cell_adr + id2 * RG_NCELL : (const int*)0; B.cellblk = (const rgf4*)m.mesh_cell_blk + (size_t)(id2 >= 0 ? id2 : 0) * (RG_NCELL * 4);
-  A.prof = 0; B.prof = 0;
+  A.mesh = __builtin_bit_cast(int, r0.z); A.vertadr = __builtin_bit_cast(int, r3.x); A.nvert = __builtin_bit_cast(int, r1.w);
+  B.mesh = __builtin_bit_cast(int, r0.w); B.vertadr = __builtin_bit_cast(int, r3.y); B.nvert = __builtin_bit_cast(int, r2.w);
 }
-template <int G> __device__ __forceinline__ void rg_narrow_phase1(RgM m, RgLds& s, rgf4* sepdir, float* pairlb, int ncand, bool cells) {
+template <int G> RG_STAGE void rg_narrow_phase1(RgCtx c, int ncand) {
+  RgM m = RG_M(c); RgLRef L = RG_L(c); RgLds& s = RG_S();
+  bool cells = !(L.flags & 8);
+  rgf4* sepdir = L.bt.sepdir ? (rgf4*)L.bt.sepdir + (size_t)blockIdx.x * m.npair : (rgf4*)0;
+  float* pairlb = (L.bt.pairlb && !(L.flags & 4)) ? L.bt.pairlb + (size_t)blockIdx.x * m.npair : (float*)0;
+  MprEnv E = rg_mpr_env(m, (float*)0, cells);
   for (int base = 0; base < ncand; base += RG_WAVE / G) {
     int ci = base + LANE / G;
     bool keep = false; int p = 0;
     if (ci < ncand) {
       p = s.cand[ci];
       MprGeom A, B; int dim; float margin;
-      rg_mpr_geoms(m, s, p, A, B, cells, dim, margin);
+      rg_mpr_geoms(m, s, p, A, B, dim, margin);
       if (A.type != RG_GEOM_PLANE) {
         v3 c0 = A.pos - B.pos;
         if (mz(c0.x) && mz(c0.y) && mz(c0.z)) c0.x += 1e-6f;
         v3 dir = normalized(c0 * -1.0f);
         if (sepdir) { rgf4 cd = sepdir[p]; if (cd.x * cd.x + cd.y * cd.y + cd.z * cd.z > 0.5f) dir = mk3(cd.x, cd.y, cd.z); }  // last substep's separating direction first
-        SupPt p1; mpr_support<G>(A, B, dir, p1);
+        SupPt p1; mpr_support<G>(E, A, B, dir, p1);
         float d = dot(p1.v, dir);
         keep = d > 0;
         // separated by -d along dir: a lower bound on the distance of the inflated shapes
@@ -806,7 +854,12 @@ template <int G> __device__ __forceinline__ void rg_narrow_phase1(RgM m, RgLds& 
     SYNC();
   }
 }
-template <int G> __device__ __forceinline__ void rg_narrow_phase2(RgM m, RgLds& s, float* prof, rgf4* sepdir, int ncand2, bool cells) {
+template <int G> RG_STAGE void rg_narrow_phase2(RgCtx c, int ncand2) {
+  RgM m = RG_M(c); RgLRef L = RG_L(c); RgLds& s = RG_S();
+  bool cells = !(L.flags & 8);
+  float* prof = (L.flags & 2) ? s.prof : (float*)0;
+  rgf4* sepdir = L.bt.sepdir ? (rgf4*)L.bt.sepdir + (size_t)blockIdx.x * m.npair : (rgf4*)0;
+  MprEnv E = rg_mpr_env(m, prof, cells);
   for (int base = 0; base < ncand2; base += RG_WAVE / G) {
     int ci = base + LANE / G;
     bool hit = false;
@@ -815,11 +868,10 @@ template <int G> __device__ __forceinline__ void rg_narrow_phase2(RgM m, RgLds& 
     MprGeom A, B;
     if (active) {
       p = s.cand2[ci];
-      rg_mpr_geoms(m, s, p, A, B, cells, dim, margin);
-      A.prof = prof;
+      rg_mpr_geoms(m, s, p, A, B, dim, margin);
     }
     v3 sep;
-    hit = rg_mpr<G>(A, B, m.mpr_iterations, m.mpr_tolerance, depth, dir, pos, sep, active);
+    hit = rg_mpr<G>(E, A, B, m.mpr_iterations, m.mpr_tolerance, depth, dir, pos, sep, active);
     if (active) {
       if (sepdir && (LANE & (G - 1)) == 0) { rgf4 cd; cd.x = hit ? 0.f : sep.x; cd.y = hit ? 0.f : sep.y; cd.z = hit ? 0.f : sep.z; cd.w = 0.f; sepdir[p] = cd; }
       hit = hit && dot(dir, dir) > 0.25f;
@@ -841,7 +893,7 @@ template <int G> __device__ __forceinline__ void rg_narrow_phase2(RgM m, RgLds& 
     SYNC();
   }
 }
-__device__ __forceinline__ void rg_collision(RgM m, RgLds& s, float* prof, rgf4* sepdir, float* pairlb, bool cells) {
+__device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, float* prof, rgf4* sepdir, float* pairlb, bool cells) {
   long long tb0 = rg_clock();
   if (LANE == 0) { s.ncand = 0; s.ncon = 0; }
   SYNC();
@@ -924,10 +976,10 @@ __device__ __forceinline__ void rg_collision(RgM m, RgLds& s, float* prof, rgf4*
   int ncand = s.ncand;
   if (LANE == 0) s.ncand2 = 0;
   SYNC();
-  if (ncand > 4) rg_narrow_phase1<8>(m, s, sepdir, pairlb, ncand, cells); else rg_narrow_phase1<16>(m, s, sepdir, pairlb, ncand, cells);
+  if (ncand > 4) rg_narrow_phase1<8>(c, ncand); else rg_narrow_phase1<16>(c, ncand);
   int ncand2 = s.ncand2;
   if (prof && LANE == 0) { prof[16] += (float)(rg_clock() - tb0); prof[17] += ncand; prof[18] += ncand2; }
-  if (ncand2 > 4) rg_narrow_phase2<8>(m, s, prof, sepdir, ncand2, cells); else rg_narrow_phase2<16>(m, s, prof, sepdir, ncand2, cells);
+  if (ncand2 > 4) rg_narrow_phase2<8>(c, ncand2); else rg_narrow_phase2<16>(c, ncand2);
   if (prof && LANE == 0) prof[19] += (float)(rg_clock() - tb0);
   // plane pairs (rare: something near the floor), whole wave cooperating, one candidate at a time
   for (int ci = 0; ci < ncand; ci++) {
@@ -938,8 +990,8 @@ __device__ __forceinline__ void rg_collision(RgM m, RgLds& s, float* prof, rgf4*
     int t2 = m.geom_type[g2];
     v3 p1 = ld3(s.gpos + 3 * g1), p2 = ld3(s.gpos + 3 * g2);
     MprGeom B;
-    B.type = t2; B.mat = s.gmat + 9 * g2; B.size = ld3(m.geom_size + 3 * g2); B.margin = 0; B.prof = 0; B.celladr = 0; B.cellblk = 0; B.cellovf = 0;
-    if (t2 == RG_GEOM_MESH) { int id = m.geom_dataid[g2]; B.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; B.nvert = m.mesh_vertnum[id]; } else { B.vert = 0; B.nvert = 0; }
+    B.type = t2; B.mat = s.gmat + 9 * g2; B.size = ld3(m.geom_size + 3 * g2); B.margin = 0; B.mesh = -1; B.vertadr = 0; B.nvert = 0;
+    if (t2 == RG_GEOM_MESH) { B.mesh = m.geom_dataid[g2]; B.vertadr = m.mesh_vertadr[B.mesh]; B.nvert = m.mesh_vertnum[B.mesh]; }
     const float* R1 = s.gmat + 9 * g1;
     v3 n = mk3(R1[2], R1[5], R1[8]);
     if (t2 == RG_GEOM_BOX) {
@@ -953,7 +1005,7 @@ __device__ __forceinline__ void rg_collision(RgM m, RgLds& s, float* prof, rgf4*
       }
     } else {
       B.pos = p2 - p1;
-      v3 sp = rg_support<64>(B, n * -1.0f);
+      v3 sp = rg_support<64>(rg_mpr_env(m, (float*)0, false), B, n * -1.0f);   // whole wave on one hull: full scan
       float dist = dot(sp, n);
       if (dist <= margin) add_contact(s, p, dist, sp + p1 - n * (0.5f * dist), n, dim);
     }
@@ -1707,10 +1759,6 @@ __device__ __forceinline__ void rg_euler(RgM m, RgLds& s) {
 }
 
 // ------------------------------------------------------------------------------------------------- the env-step kernel
-struct RgAux {  // extra static tables (kept out of RgModelDev to keep the kernarg small)
-  const int *subtree_adr, *subtree;
-  const uint32_t* dof_velmask;
-};
 
 // stage dump in three parts, each taken while the arrays it reads are alive
 __device__ __forceinline__ void rg_dump_kin(RgM m, RgLds& s, float* dbg) {
@@ -1742,44 +1790,7 @@ __device__ __forceinline__ void rg_position_stage(RgM m, RgLds& s) {
   rg_tendon(m, s);
 }
 
-// ------------------------------------------------------------------------------------------------- stage calls
-// Everything a launch passes besides the model, as ONE by-value kernel argument that is read through the
-// constant address space (the kernarg segment), so that its ~100 scalars are loaded where they are used
-// instead of living in (or being spilled from) SGPRs for the whole kernel.
-struct RgLaunch { RgAux x; RgEnvDev env; RgBatchDev bt; int nsubsteps, nforward_ticks, flags; };
-
-// The substep is a sequence of REAL function calls (not inlined): each stage gets its own register
-// allocation, so loop invariants of one stage are not kept alive (or spilled) through all the others.
-// A stage finds the model, the launch descriptor and the env's LDS image by itself: the kernarg segment
-// pointer is an implicit argument of every device function, and the LDS image is the workgroup's only
-// dynamic shared allocation.
-struct RgCtx { const void* km; const void* kl; };   // device address of the model descriptor, address of the launch descriptor
-#ifdef RG_EMUL
-#define RG_M(c) (*(const RgModelDev*)(c).km)
-#define RG_L(c) (*(const RgLaunch*)(c).kl)
-#define RG_S() (*(RgLds*)emul_lds())
-#define RG_STAGE static inline
-typedef const RgLaunch& RgLRef;
-#else
-extern __shared__ __attribute__((aligned(16))) unsigned char rg_lds_raw[];
-#define RG_AS4 __attribute__((address_space(4)))
-// function arguments arrive in VGPRs: read the (wave-uniform) addresses back into SGPRs so that everything
-// loaded through them is a scalar load again
-__device__ __forceinline__ unsigned long long rg_uniform(const void* p) {
-  unsigned long long v = (unsigned long long)p;
-  unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v), hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
-  return ((unsigned long long)hi << 32) | lo;
-}
-#define RG_M(c) (*(const RG_AS4 RgModelDev*)rg_uniform((c).km))
-#define RG_L(c) (*(const RG_AS4 RgLaunch*)rg_uniform((c).kl))
-#define RG_S() (*(RgLds*)rg_lds_raw)
-#ifdef RG_INLINE_STAGES
-#define RG_STAGE __device__ __forceinline__
-#else
-#define RG_STAGE __device__ __attribute__((noinline))
-#endif
-typedef const RG_AS4 RgLaunch& RgLRef;
-#endif
+// ------------------------------------------------------------------------------------------------- stage calls (definitions of RgLaunch / RgCtx / RG_STAGE: top of the file)
 RG_STAGE void st_kinematics(RgCtx c) { rg_kinematics(RG_M(c), RG_S()); }
 RG_STAGE void st_com_pos(RgCtx c) { rg_com_pos(RG_M(c), RG_S()); }
 RG_STAGE void st_tendon(RgCtx c) { rg_tendon(RG_M(c), RG_S()); }
@@ -1788,7 +1799,7 @@ RG_STAGE void st_velocity(RgCtx c) { RgLRef L = RG_L(c); rg_velocity(RG_M(c), RG
 RG_STAGE void st_collision(RgCtx c) {
   RgM m = RG_M(c); RgLRef L = RG_L(c); RgLds& s = RG_S();
   int e = blockIdx.x, flags = L.flags;
-  rg_collision(m, s, (flags & 2) ? s.prof : (float*)0, L.bt.sepdir ? (rgf4*)L.bt.sepdir + (size_t)e * m.npair : (rgf4*)0,
+  rg_collision(c, m, s, (flags & 2) ? s.prof : (float*)0, L.bt.sepdir ? (rgf4*)L.bt.sepdir + (size_t)e * m.npair : (rgf4*)0,
                (L.bt.pairlb && !(flags & 4)) ? L.bt.pairlb + (size_t)e * m.npair : (float*)0, !(flags & 8));
 }
 RG_STAGE void st_make_constraint(RgCtx c) { rg_make_constraint(RG_M(c), RG_S()); }
@@ -1933,13 +1944,14 @@ __global__ void __launch_bounds__(RG_WAVE) rg_mpr_pair_kernel(const RgModelDev* 
   st_kinematics(c);
   MprGeom A, B;
   v3 p1 = ld3(s.gpos + 3 * g1), p2 = ld3(s.gpos + 3 * g2);
-  A.type = m.geom_type[g1]; A.mat = s.gmat + 9 * g1; A.size = ld3(m.geom_size + 3 * g1); A.margin = 0.5f * margin; A.pos = mk3(0, 0, 0); A.prof = 0;
-  B.type = m.geom_type[g2]; B.mat = s.gmat + 9 * g2; B.size = ld3(m.geom_size + 3 * g2); B.margin = 0.5f * margin; B.pos = p2 - p1; B.prof = 0;
-  A.celladr = 0; B.celladr = 0; A.cellovf = B.cellovf = (const rgf4*)m.mesh_cell_ovf; A.cellblk = B.cellblk = (const rgf4*)m.mesh_cell_blk;   // the hook exercises the cell-list supports
-  if (A.type == RG_GEOM_MESH) { int id = m.geom_dataid[g1]; A.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; A.nvert = m.mesh_vertnum[id]; A.celladr = m.mesh_cell_adr + id * RG_NCELL; A.cellblk += (size_t)id * (RG_NCELL * 4); } else { A.vert = 0; A.nvert = 0; }
-  if (B.type == RG_GEOM_MESH) { int id = m.geom_dataid[g2]; B.vert = m.mesh_vert + 4 * m.mesh_vertadr[id]; B.nvert = m.mesh_vertnum[id]; B.celladr = m.mesh_cell_adr + id * RG_NCELL; B.cellblk += (size_t)id * (RG_NCELL * 4); } else { B.vert = 0; B.nvert = 0; }
+  A.type = m.geom_type[g1]; A.mat = s.gmat + 9 * g1; A.size = ld3(m.geom_size + 3 * g1); A.margin = 0.5f * margin; A.pos = mk3(0, 0, 0);
+  B.type = m.geom_type[g2]; B.mat = s.gmat + 9 * g2; B.size = ld3(m.geom_size + 3 * g2); B.margin = 0.5f * margin; B.pos = p2 - p1;
+  A.mesh = B.mesh = -1; A.vertadr = B.vertadr = 0; A.nvert = B.nvert = 0;
+  if (A.type == RG_GEOM_MESH) { A.mesh = m.geom_dataid[g1]; A.vertadr = m.mesh_vertadr[A.mesh]; A.nvert = m.mesh_vertnum[A.mesh]; }
+  if (B.type == RG_GEOM_MESH) { B.mesh = m.geom_dataid[g2]; B.vertadr = m.mesh_vertadr[B.mesh]; B.nvert = m.mesh_vertnum[B.mesh]; }
+  MprEnv E = rg_mpr_env(m, (float*)0, true);   // the hook exercises the cell-list supports
   float depth = 0; v3 dir = mk3(0, 0, 0), pos = mk3(0, 0, 0);
-  v3 sep; bool hit = rg_mpr<64>(A, B, m.mpr_iterations, m.mpr_tolerance, depth, dir, pos, sep, true);
+  v3 sep; bool hit = rg_mpr<64>(E, A, B, m.mpr_iterations, m.mpr_tolerance, depth, dir, pos, sep, true);
   if (LANE == 0) {
     float* o = out + 8 * (size_t)e;
     o[0] = hit ? 1.f : 0.f; o[1] = depth; o[2] = dir.x; o[3] = dir.y; o[4] = dir.z; o[5] = pos.x + p1.x; o[6] = pos.y + p1.y; o[7] = pos.z + p1.z;
