@@ -141,8 +141,17 @@ __device__ __forceinline__ v3 operator-(v3 a, v3 b) { return mk3(a.x - b.x, a.y 
 __device__ __forceinline__ v3 operator*(v3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
 __device__ __forceinline__ float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ v3 cross(v3 a, v3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+// hardware reciprocal / reciprocal square root (v_rcp_f32 / v_rsq_f32, 1 ulp): the IEEE-exact sqrtf and '/' expand to
+// ~10 dependent instructions each, which is what the pivot chains of the factorisations would otherwise spend their time on
+#ifdef RG_EMUL
+static inline float rg_rsqrt(float x) { return 1.0f / sqrtf(x); }
+static inline float rg_rcp(float x) { return 1.0f / x; }
+#else
+__device__ __forceinline__ float rg_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float rg_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#endif
 __device__ __forceinline__ float norm(v3 a) { return sqrtf(dot(a, a)); }
-__device__ __forceinline__ v3 normalized(v3 a) { float n = norm(a); return n < 1e-30f ? mk3(1, 0, 0) : a * (1.0f / n); }
+__device__ __forceinline__ v3 normalized(v3 a) { float n2 = dot(a, a); return n2 < 1e-37f ? mk3(1, 0, 0) : a * rg_rsqrt(n2); }
 // M row-major 3x3
 __device__ __forceinline__ v3 mulm(const float* M, v3 v) { return mk3(M[0] * v.x + M[1] * v.y + M[2] * v.z, M[3] * v.x + M[4] * v.y + M[5] * v.z, M[6] * v.x + M[7] * v.y + M[8] * v.z); }
 __device__ __forceinline__ v3 mulmT(const float* M, v3 v) { return mk3(M[0] * v.x + M[3] * v.y + M[6] * v.z, M[1] * v.x + M[4] * v.y + M[7] * v.z, M[2] * v.x + M[5] * v.y + M[8] * v.z); }
@@ -160,7 +169,7 @@ __device__ __forceinline__ q4 qmul(q4 a, q4 b) {
 __device__ __forceinline__ q4 qnormalize(q4 q) {
   float n = sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
   if (n < 1e-30f) { q.w = 1; q.x = q.y = q.z = 0; return q; }
-  float s = 1.0f / n; q.w *= s; q.x *= s; q.y *= s; q.z *= s; return q;
+  float s = rg_rcp(n); q.w *= s; q.x *= s; q.y *= s; q.z *= s; return q;
 }
 __device__ __forceinline__ void q2mat(float* m, q4 q) {
   float w = q.w, x = q.x, y = q.y, z = q.z;
@@ -547,7 +556,7 @@ __device__ __forceinline__ int dir_cell(v3 ld) {
   float ax = fabsf(ld.x), ay = fabsf(ld.y), az = fabsf(ld.z);
   int axis = ax >= ay ? (ax >= az ? 0 : 2) : (ay >= az ? 1 : 2);
   float mj = axis == 0 ? ld.x : (axis == 1 ? ld.y : ld.z), a = axis == 0 ? ld.y : (axis == 1 ? ld.z : ld.x), b = axis == 0 ? ld.z : (axis == 1 ? ld.x : ld.y);
-  float inv = (0.5f * RG_CELLN) / fmaxf(fabsf(mj), 1e-30f);
+  float inv = (0.5f * RG_CELLN) * rg_rcp(fmaxf(fabsf(mj), 1e-30f));
   int iu = (int)(a * inv + 0.5f * RG_CELLN), iv = (int)(b * inv + 0.5f * RG_CELLN);
   iu = iu < 0 ? 0 : (iu > RG_CELLN - 1 ? RG_CELLN - 1 : iu); iv = iv < 0 ? 0 : (iv > RG_CELLN - 1 ? RG_CELLN - 1 : iv);
   return ((2 * axis + (mj < 0 ? 1 : 0)) * RG_CELLN + iu) * RG_CELLN + iv;
@@ -745,7 +754,7 @@ template <int G> __device__ __forceinline__ bool rg_mpr(const MprEnv& E, const M
           b0 = 0; b1 = dot(cross(p2.v, p3.v), dd); b2 = dot(cross(p3.v, p1.v), dd); b3 = dot(cross(p1.v, p2.v), dd);
           sum = b1 + b2 + b3;
         }
-        float inv = 0.5f / sum;
+        float inv = 0.5f * rg_rcp(sum);
         pos = p0.s * (b0 * inv) + p1.s * (b1 * inv) + p2.s * (b2 * inv) + p3.s * (b3 * inv);
         result = true; state = MPR_DONE;
       } else { expand_portal(p0, p1, p2, p3, q); dir = portal_dir(p1, p2, p3); guard++; }
@@ -1302,7 +1311,7 @@ __device__ __forceinline__ float rg_constraint_update(RgM m, RgLds& s, bool& cha
     if (D > 0) {
       float x = s.r_jar[r], f = r < RG_MAXFRIC ? s.r_floss[r] : 0.f;
       if (f > 0) {
-        float R = 1.0f / D;
+        float R = rg_rcp(D);
         if (x <= -R * f) { frc = f; cost += f * (-0.5f * R * f - x); }
         else if (x >= R * f) { frc = -f; cost += f * (-0.5f * R * f + x); }
         else { frc = -D * x; q = 1; cost += 0.5f * D * x * x; }
@@ -1385,17 +1394,17 @@ __device__ __forceinline__ void rg_chol(RgM m, RgLds& s) {
     float t30 = lane_bcast(a0, j0 + 3), t31 = lane_bcast(a1, j0 + 3), t32 = lane_bcast(a2, j0 + 3), t33 = lane_bcast(a3, j0 + 3);
     bool v1 = nb > 1, v2 = nb > 2, v3 = nb > 3;
     if (!(t00 > 1e-30f)) { bad = true; t00 = 1e-30f; }
-    float l00 = sqrtf(t00), i00 = 1.0f / l00;
+    float i00 = rg_rsqrt(t00), l00 = t00 * i00;
     float l10 = v1 ? t10 * i00 : 0.f, d11 = v1 ? t11 - l10 * l10 : 1.f;
     if (!(d11 > 1e-30f)) { bad = true; d11 = 1e-30f; }
-    float l11 = sqrtf(d11), i11 = v1 ? 1.0f / l11 : 0.f;
+    float r11 = rg_rsqrt(d11), l11 = d11 * r11, i11 = v1 ? r11 : 0.f;
     float l20 = v2 ? t20 * i00 : 0.f, l21 = v2 ? (t21 - l20 * l10) * i11 : 0.f, d22 = v2 ? t22 - l20 * l20 - l21 * l21 : 1.f;
     if (!(d22 > 1e-30f)) { bad = true; d22 = 1e-30f; }
-    float l22 = sqrtf(d22), i22 = v2 ? 1.0f / l22 : 0.f;
+    float r22 = rg_rsqrt(d22), l22 = d22 * r22, i22 = v2 ? r22 : 0.f;
     float l30 = v3 ? t30 * i00 : 0.f, l31 = v3 ? (t31 - l30 * l10) * i11 : 0.f, l32 = v3 ? (t32 - l30 * l20 - l31 * l21) * i22 : 0.f;
     float d33 = v3 ? t33 - l30 * l30 - l31 * l31 - l32 * l32 : 1.f;
     if (!(d33 > 1e-30f)) { bad = true; d33 = 1e-30f; }
-    float l33 = sqrtf(d33), i33 = v3 ? 1.0f / l33 : 0.f;
+    float r33 = rg_rsqrt(d33), l33 = d33 * r33, i33 = v3 ? r33 : 0.f;
     if (mine) {
       int r = i - j0;
       float x0 = a0 * i00, x1 = (a1 - x0 * l10) * i11, x2 = (a2 - x0 * l20 - x1 * l21) * i22, x3 = (a3 - x0 * l30 - x1 * l31 - x2 * l32) * i33;
@@ -1497,17 +1506,17 @@ __device__ __forceinline__ void rg_block_factor_solve(RgM m, RgLds& s, const flo
     if (blk_on) {
       bool v1 = nb > 1, v2 = nb > 2, v3 = nb > 3;
       if (!(t00 > 1e-30f)) { bad = true; t00 = 1e-30f; }
-      float l00 = sqrtf(t00), i00 = 1.0f / l00;
+      float i00 = rg_rsqrt(t00), l00 = t00 * i00;
       float l10 = v1 ? t10 * i00 : 0.f, d11 = v1 ? t11 - l10 * l10 : 1.f;
       if (!(d11 > 1e-30f)) { bad = true; d11 = 1e-30f; }
-      float l11 = sqrtf(d11), i11 = v1 ? 1.0f / l11 : 0.f;
+      float r11 = rg_rsqrt(d11), l11 = d11 * r11, i11 = v1 ? r11 : 0.f;
       float l20 = v2 ? t20 * i00 : 0.f, l21 = v2 ? (t21 - l20 * l10) * i11 : 0.f, d22 = v2 ? t22 - l20 * l20 - l21 * l21 : 1.f;
       if (!(d22 > 1e-30f)) { bad = true; d22 = 1e-30f; }
-      float l22 = sqrtf(d22), i22 = v2 ? 1.0f / l22 : 0.f;
+      float r22 = rg_rsqrt(d22), l22 = d22 * r22, i22 = v2 ? r22 : 0.f;
       float l30 = v3 ? t30 * i00 : 0.f, l31 = v3 ? (t31 - l30 * l10) * i11 : 0.f, l32 = v3 ? (t32 - l30 * l20 - l31 * l21) * i22 : 0.f;
       float d33 = v3 ? t33 - l30 * l30 - l31 * l31 - l32 * l32 : 1.f;
       if (!(d33 > 1e-30f)) { bad = true; d33 = 1e-30f; }
-      float l33 = sqrtf(d33), i33 = v3 ? 1.0f / l33 : 0.f;
+      float r33 = rg_rsqrt(d33), l33 = d33 * r33, i33 = v3 ? r33 : 0.f;
       if (mine) {
         int rr = r - j0;
         float x0 = a0 * i00, x1 = (a1 - x0 * l10) * i11, x2 = (a2 - x0 * l20 - x1 * l21) * i22, x3 = (a3 - x0 * l30 - x1 * l31 - x2 * l32) * i33;
@@ -1587,7 +1596,7 @@ __device__ __forceinline__ LsPt rg_ls_eval(const LsRows& L, float alpha, float q
     if (!(D > 0)) continue;
     float jv = L.rjv[k], x = L.rjar[k] + alpha * jv, f = L.rf[k];
     if (f > 0) {
-      float R = 1.0f / D;
+      float R = rg_rcp(D);
       if (x <= -R * f) { c += f * (-0.5f * R * f - x); g += -f * jv; }
       else if (x >= R * f) { c += f * (-0.5f * R * f + x); g += f * jv; }
       else { c += 0.5f * D * x * x; g += D * x * jv; h += D * jv * jv; }
