@@ -177,8 +177,17 @@ __device__ __forceinline__ void q2mat(float* m, q4 q) {
   m[3] = 2 * (x * y + w * z); m[4] = w * w - x * x + y * y - z * z; m[5] = 2 * (y * z - w * x);
   m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = w * w - x * x - y * y + z * z;
 }
+// sin / cos of a hinge half-angle: |x| <= 1.5 covers every joint range with margin; there the Taylor
+// polynomials below are exact to fp32 rounding (remainders x^13/13! < 3e-8 relative, x^14/14! < 4e-9) and cost
+// a dozen FMAs instead of libm's range-reduced sincosf
+__device__ __forceinline__ void rg_sincos(float x, float& sn, float& cs) {
+  if (fabsf(x) > 1.5f) { sincosf(x, &sn, &cs); return; }
+  float x2 = x * x;
+  sn = x * (1.f + x2 * (-1.6666667e-1f + x2 * (8.3333333e-3f + x2 * (-1.9841270e-4f + x2 * (2.7557319e-6f + x2 * (-2.5052108e-8f))))));
+  cs = 1.f + x2 * (-0.5f + x2 * (4.1666667e-2f + x2 * (-1.3888889e-3f + x2 * (2.4801587e-5f + x2 * (-2.7557319e-7f + x2 * 2.0876757e-9f)))));
+}
 __device__ __forceinline__ q4 axisangle(v3 ax, float ang) {
-  float s, c; sincosf(0.5f * ang, &s, &c);
+  float s, c; rg_sincos(0.5f * ang, s, c);
   q4 q; q.w = c; q.x = ax.x * s; q.y = ax.y * s; q.z = ax.z * s; return q;
 }
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
@@ -1130,11 +1139,12 @@ __device__ __forceinline__ float impedance(const float* si, float pos, float mar
   float dmin = clampf(si[0], 1e-4f, 0.9999f), dmax = clampf(si[1], 1e-4f, 0.9999f), width = fmaxf(si[2], 1e-15f);
   float mid = clampf(si[3], 1e-4f, 0.9999f), power = fmaxf(si[4], 1.0f);
   if (dmin == dmax || width <= 1e-15f) return 0.5f * (dmin + dmax);
-  float x = fabsf((pos - margin) / width);
+  float x = fabsf((pos - margin) * rg_rcp(width));
   if (x >= 1) return dmax;
   if (x <= 0) return dmin;
   float y;
   if (power == 1) y = x;
+  else if (power == 2) y = x <= mid ? x * x * rg_rcp(mid) : 1 - (1 - x) * (1 - x) * rg_rcp(1 - mid);   // MuJoCo's default solimp: no powf
   else if (x <= mid) y = powf(x, power) / powf(mid, power - 1);
   else y = 1 - powf(1 - x, power) / powf(1 - mid, power - 1);
   return dmin + y * (dmax - dmin);
@@ -1143,7 +1153,7 @@ __device__ __forceinline__ void kb(RgM m, const float* solref, const float* soli
   float dmax = clampf(solimp[1], 1e-4f, 0.9999f);
   if (solref[0] > 0) {
     float tc = fmaxf(solref[0], 2 * m.timestep), dr = solref[1];
-    K = 1.0f / fmaxf(1e-15f, dmax * dmax * tc * tc * dr * dr); B = 2.0f / fmaxf(1e-15f, dmax * tc);
+    K = rg_rcp(fmaxf(1e-15f, dmax * dmax * tc * tc * dr * dr)); B = 2.0f * rg_rcp(fmaxf(1e-15f, dmax * tc));
   } else { K = -solref[0] / fmaxf(1e-15f, dmax * dmax); B = -solref[1] / fmaxf(1e-15f, dmax); }
 }
 // static row slot layout: [friction dofs][friction tendons][joint limits x2][tendon limits x2].
@@ -1212,7 +1222,7 @@ __device__ __forceinline__ void rg_make_constraint(RgM m, RgLds& s) {
       kb(m, solref, solimp, K, B);
       if (fric) K = 0;
       float vel = srow_dot<true>(s, r, s.qvel);
-      D = 1.0f / R; aref = -B * vel - K * imp * (pos - margin);
+      D = rg_rcp(R); aref = -B * vel - K * imp * (pos - margin);
     }
     s.r_D[r] = D; s.r_aref[r] = aref;   // D == 0 marks an inactive slot
     if (r < RG_MAXFRIC) s.r_floss[r] = fric ? floss : 0.f;
@@ -1268,7 +1278,7 @@ __device__ __forceinline__ void rg_make_constraint(RgM m, RgLds& s) {
     float R;
     if (dim == 1) R = fmaxf(1e-15f, (1 - imp) * tran / imp);
     else { float Rf = fmaxf(1e-15f, (1 - imp) * (tran + mu0 * mu0 * tran) / imp); float mu = mu0 * sqrtf(1.0f / m.impratio); R = 2 * mu * mu * Rf; }
-    s.c_D[c] = 1.0f / R;
+    s.c_D[c] = rg_rcp(R);
     // friction coefficient of tangent direction k (k = 0,1 sliding; 2 spin)
     s.c_mu[3 * c] = prm[2]; s.c_mu[3 * c + 1] = prm[2]; s.c_mu[3 * c + 2] = prm[3];
     const float* Bc = s.c_pool + s.c_off[c]; int nnz = s.c_nnz[c], nb = nbasis(dim);
