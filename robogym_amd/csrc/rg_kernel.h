@@ -1447,36 +1447,46 @@ __device__ __forceinline__ void tri_fetch(const RgLds& s, int n, int hs, int j0,
   if (!backward) t.own = H4[ic * hs4 + jb];
   else { t.c0 = H[j0 * hs + ic]; t.c1 = H[r1 * hs + ic]; t.c2 = H[r2 * hs + ic]; t.c3 = H[r3 * hs + ic]; }
 }
+__device__ __forceinline__ void tri_fwd(const TriOps& t, int n, int j0, int i, float& xi) {
+  float x0 = lane_bcast(xi, j0) * t.i00;
+  float x1 = (lane_bcast(xi, j0 + 1) - t.q1.x * x0) * t.i11;
+  float x2 = (lane_bcast(xi, j0 + 2) - t.q2.x * x0 - t.q2.y * x1) * t.i22;
+  float x3 = (lane_bcast(xi, j0 + 3) - t.q3.x * x0 - t.q3.y * x1 - t.q3.z * x2) * t.i33;
+  int r = i - j0;
+  if (r >= 4 && i < n) xi -= t.own.x * x0 + t.own.y * x1 + t.own.z * x2 + t.own.w * x3;
+  else if (r == 0) xi = x0; else if (r == 1) xi = x1; else if (r == 2) xi = x2; else if (r == 3) xi = x3;
+}
+__device__ __forceinline__ void tri_bwd(const TriOps& t, int n, int j0, int i, float& xi) {
+  int nb = n - j0;
+  float l10 = nb > 1 ? t.q1.x : 0.f, l20 = nb > 2 ? t.q2.x : 0.f, l21 = nb > 2 ? t.q2.y : 0.f, l30 = nb > 3 ? t.q3.x : 0.f, l31 = nb > 3 ? t.q3.y : 0.f, l32 = nb > 3 ? t.q3.z : 0.f;
+  float x3 = lane_bcast(xi, j0 + 3) * t.i33;
+  float x2 = (lane_bcast(xi, j0 + 2) - l32 * x3) * t.i22;
+  float x1 = (lane_bcast(xi, j0 + 1) - l21 * x2 - l31 * x3) * t.i11;
+  float x0 = (lane_bcast(xi, j0) - l10 * x1 - l20 * x2 - l30 * x3) * t.i00;
+  int r = i - j0;
+  if (i < j0) xi -= t.c0 * x0 + (nb > 1 ? t.c1 * x1 : 0.f) + (nb > 2 ? t.c2 * x2 : 0.f) + (nb > 3 ? t.c3 * x3 : 0.f);
+  else if (r == 0) xi = x0; else if (r == 1) xi = x1; else if (r == 2) xi = x2; else if (r == 3) xi = x3;
+}
 __device__ __forceinline__ void rg_chol_solve(RgM m, RgLds& s, float* x) {
   int n = m.nvc, hs = m.hs, i = LANE;
   float xi = i < n ? x[i] : 0.f;
-  TriOps cur, nxt;
-  tri_fetch(s, n, hs, 0, i, false, cur);
-  for (int j0 = 0; j0 < n; j0 += 4) {  // forward: L y = b
-    if (j0 + 4 < n) tri_fetch(s, n, hs, j0 + 4, i, false, nxt);
-    float x0 = lane_bcast(xi, j0) * cur.i00;
-    float x1 = (lane_bcast(xi, j0 + 1) - cur.q1.x * x0) * cur.i11;
-    float x2 = (lane_bcast(xi, j0 + 2) - cur.q2.x * x0 - cur.q2.y * x1) * cur.i22;
-    float x3 = (lane_bcast(xi, j0 + 3) - cur.q3.x * x0 - cur.q3.y * x1 - cur.q3.z * x2) * cur.i33;
-    int r = i - j0;
-    if (r >= 4 && i < n) xi -= cur.own.x * x0 + cur.own.y * x1 + cur.own.z * x2 + cur.own.w * x3;
-    else if (r == 0) xi = x0; else if (r == 1) xi = x1; else if (r == 2) xi = x2; else if (r == 3) xi = x3;
-    cur = nxt;
+  TriOps A, B;   // two operand sets used alternately: the fetch of one overlaps the arithmetic on the other, no copies
+  tri_fetch(s, n, hs, 0, i, false, A);
+  for (int j0 = 0; j0 < n; j0 += 8) {  // forward: L y = b
+    if (j0 + 4 < n) tri_fetch(s, n, hs, j0 + 4, i, false, B);
+    tri_fwd(A, n, j0, i, xi);
+    if (j0 + 4 >= n) break;
+    if (j0 + 8 < n) tri_fetch(s, n, hs, j0 + 8, i, false, A);
+    tri_fwd(B, n, j0 + 4, i, xi);
   }
   int jl = ((n - 1) >> 2) << 2;
-  tri_fetch(s, n, hs, jl, i, true, cur);
-  for (int j0 = jl; j0 >= 0; j0 -= 4) {  // backward: L' x = y
-    if (j0 >= 4) tri_fetch(s, n, hs, j0 - 4, i, true, nxt);
-    int nb = n - j0;
-    float l10 = nb > 1 ? cur.q1.x : 0.f, l20 = nb > 2 ? cur.q2.x : 0.f, l21 = nb > 2 ? cur.q2.y : 0.f, l30 = nb > 3 ? cur.q3.x : 0.f, l31 = nb > 3 ? cur.q3.y : 0.f, l32 = nb > 3 ? cur.q3.z : 0.f;
-    float x3 = lane_bcast(xi, j0 + 3) * cur.i33;
-    float x2 = (lane_bcast(xi, j0 + 2) - l32 * x3) * cur.i22;
-    float x1 = (lane_bcast(xi, j0 + 1) - l21 * x2 - l31 * x3) * cur.i11;
-    float x0 = (lane_bcast(xi, j0) - l10 * x1 - l20 * x2 - l30 * x3) * cur.i00;
-    int r = i - j0;
-    if (i < j0) xi -= cur.c0 * x0 + (nb > 1 ? cur.c1 * x1 : 0.f) + (nb > 2 ? cur.c2 * x2 : 0.f) + (nb > 3 ? cur.c3 * x3 : 0.f);
-    else if (r == 0) xi = x0; else if (r == 1) xi = x1; else if (r == 2) xi = x2; else if (r == 3) xi = x3;
-    cur = nxt;
+  tri_fetch(s, n, hs, jl, i, true, A);
+  for (int j0 = jl; j0 >= 0; j0 -= 8) {  // backward: L' x = y
+    if (j0 >= 4) tri_fetch(s, n, hs, j0 - 4, i, true, B);
+    tri_bwd(A, n, j0, i, xi);
+    if (j0 < 4) break;
+    if (j0 >= 8) tri_fetch(s, n, hs, j0 - 8, i, true, A);
+    tri_bwd(B, n, j0 - 4, i, xi);
   }
   if (i < n) x[i] = xi;
   SYNC();
