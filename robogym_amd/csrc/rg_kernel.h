@@ -146,9 +146,11 @@ __device__ __forceinline__ v3 cross(v3 a, v3 b) { return mk3(a.y * b.z - a.z * b
 #ifdef RG_EMUL
 static inline float rg_rsqrt(float x) { return 1.0f / sqrtf(x); }
 static inline float rg_rcp(float x) { return 1.0f / x; }
+static inline float rg_sqrt(float x) { return sqrtf(x); }
 #else
 __device__ __forceinline__ float rg_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float rg_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float rg_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 #endif
 __device__ __forceinline__ float norm(v3 a) { return sqrtf(dot(a, a)); }
 __device__ __forceinline__ v3 normalized(v3 a) { float n2 = dot(a, a); return n2 < 1e-37f ? mk3(1, 0, 0) : a * rg_rsqrt(n2); }
@@ -391,18 +393,18 @@ __device__ __forceinline__ float wrap_circle(float* pnt, const float* d, const f
   float sq0 = d[0] * d[0] + d[1] * d[1], sq1 = d[2] * d[2] + d[3] * d[3], sqr = rad * rad;
   float dx = d[2] - d[0], dy = d[3] - d[1], dd = dx * dx + dy * dy;
   if (sq0 < sqr || sq1 < sqr || rad < 1e-15f || dd < 1e-15f) return -1;
-  float a = clampf(-(dx * d[0] + dy * d[1]) / dd, 0.f, 1.f);
+  float a = clampf(-(dx * d[0] + dy * d[1]) * rg_rcp(dd), 0.f, 1.f);
   float nx = a * dx + d[0], ny = a * dy + d[1];
   if (nx * nx + ny * ny > sqr && (!sd || sd[0] * nx + sd[1] * ny >= 0)) return -1;
   float sol[2][4], good[2];
-  float r0 = sqrtf(sq0 - sqr), r1 = sqrtf(sq1 - sqr);
+  float r0 = rg_sqrt(sq0 - sqr), r1 = rg_sqrt(sq1 - sqr), isq0 = rg_rcp(sq0), isq1 = rg_rcp(sq1);
   for (int i = 0; i < 2; i++) {
     float sgn = i == 0 ? 1.f : -1.f;
-    sol[i][0] = (d[0] * sqr + sgn * rad * d[1] * r0) / sq0; sol[i][1] = (d[1] * sqr - sgn * rad * d[0] * r0) / sq0;
-    sol[i][2] = (d[2] * sqr - sgn * rad * d[3] * r1) / sq1; sol[i][3] = (d[3] * sqr + sgn * rad * d[2] * r1) / sq1;
+    sol[i][0] = (d[0] * sqr + sgn * rad * d[1] * r0) * isq0; sol[i][1] = (d[1] * sqr - sgn * rad * d[0] * r0) * isq0;
+    sol[i][2] = (d[2] * sqr - sgn * rad * d[3] * r1) * isq1; sol[i][3] = (d[3] * sqr + sgn * rad * d[2] * r1) * isq1;
     if (sd) {
-      float mx = sol[i][0] + sol[i][2], my = sol[i][1] + sol[i][3], n = fmaxf(sqrtf(mx * mx + my * my), 1e-15f);
-      good[i] = (mx * sd[0] + my * sd[1]) / n;
+      float mx = sol[i][0] + sol[i][2], my = sol[i][1] + sol[i][3], n = fmaxf(rg_sqrt(mx * mx + my * my), 1e-15f);
+      good[i] = (mx * sd[0] + my * sd[1]) * rg_rcp(n);
     } else {
       float tx = sol[i][0] - sol[i][2], ty = sol[i][1] - sol[i][3];
       good[i] = -(tx * tx + ty * ty);
@@ -412,7 +414,7 @@ __device__ __forceinline__ float wrap_circle(float* pnt, const float* d, const f
   int k = good[0] > good[1] ? 0 : 1;
   for (int e = 0; e < 4; e++) pnt[e] = sol[k][e];
   if (seg_intersect(d[0], d[1], pnt[0], pnt[1], d[2], d[3], pnt[2], pnt[3])) return -1;
-  return rad * acosf(clampf((pnt[0] * pnt[2] + pnt[1] * pnt[3]) / sqr, -1.f, 1.f));
+  return rad * acosf(clampf((pnt[0] * pnt[2] + pnt[1] * pnt[3]) * rg_rcp(sqr), -1.f, 1.f));
 }
 __device__ __forceinline__ float rg_wrap(v3& w0, v3& w1, v3 x0, v3 x1, v3 gpos, const float* gmat, float radius, int type, bool has_side, v3 side) {
   v3 p0 = mulmT(gmat, x0 - gpos), p1 = mulmT(gmat, x1 - gpos);
@@ -428,18 +430,19 @@ __device__ __forceinline__ float rg_wrap(v3& w0, v3& w1, v3 x0, v3 x1, v3 gpos, 
   if (has_side) {
     v3 sl = mulmT(gmat, side - gpos);
     sd[0] = dot(sl, ax0); sd[1] = dot(sl, ax1);
-    float n = fmaxf(sqrtf(sd[0] * sd[0] + sd[1] * sd[1]), 1e-15f);
-    sd[0] *= radius / n; sd[1] *= radius / n;
+    float n = fmaxf(rg_sqrt(sd[0] * sd[0] + sd[1] * sd[1]), 1e-15f), rn = radius * rg_rcp(n);
+    sd[0] *= rn; sd[1] *= rn;
   }
   float pnt[4], wlen = wrap_circle(pnt, dd, has_side ? sd : (const float*)0, radius);
   if (wlen < 0) return -1;
   v3 r0 = ax0 * pnt[0] + ax1 * pnt[1], r1 = ax0 * pnt[2] + ax1 * pnt[3];
   if (type == RG_WRAP_CYLINDER) {
-    float L0 = sqrtf((dd[0] - pnt[0]) * (dd[0] - pnt[0]) + (dd[1] - pnt[1]) * (dd[1] - pnt[1]));
-    float L1 = sqrtf((dd[2] - pnt[2]) * (dd[2] - pnt[2]) + (dd[3] - pnt[3]) * (dd[3] - pnt[3]));
-    r0.z = p0.z + (p1.z - p0.z) * L0 / (L0 + wlen + L1);
-    r1.z = p0.z + (p1.z - p0.z) * (L0 + wlen) / (L0 + wlen + L1);
-    wlen = sqrtf(wlen * wlen + (r1.z - r0.z) * (r1.z - r0.z));
+    float L0 = rg_sqrt((dd[0] - pnt[0]) * (dd[0] - pnt[0]) + (dd[1] - pnt[1]) * (dd[1] - pnt[1]));
+    float L1 = rg_sqrt((dd[2] - pnt[2]) * (dd[2] - pnt[2]) + (dd[3] - pnt[3]) * (dd[3] - pnt[3]));
+    float iL = rg_rcp(L0 + wlen + L1);
+    r0.z = p0.z + (p1.z - p0.z) * L0 * iL;
+    r1.z = p0.z + (p1.z - p0.z) * (L0 + wlen) * iL;
+    wlen = rg_sqrt(wlen * wlen + (r1.z - r0.z) * (r1.z - r0.z));
   }
   w0 = mulm(gmat, r0) + gpos; w1 = mulm(gmat, r1) + gpos;
   return wlen;
@@ -458,11 +461,11 @@ __device__ __forceinline__ void rg_tendon(RgM m, RgLds& s) {
         for (int e = 0; e < 4; e++) if (td[e] == d) J[e] += m.wrap_prm[w];
       }
     } else {
-      float divisor = 1;
+      float divisor = 1, idiv = 1;
       int w = adr;
       while (w < adr + num - 1) {
         int t0 = m.wrap_type[w], t1 = m.wrap_type[w + 1];
-        if (t0 == RG_WRAP_PULLEY || t1 == RG_WRAP_PULLEY) { if (t0 == RG_WRAP_PULLEY) divisor = m.wrap_prm[w]; w++; continue; }
+        if (t0 == RG_WRAP_PULLEY || t1 == RG_WRAP_PULLEY) { if (t0 == RG_WRAP_PULLEY) { divisor = m.wrap_prm[w]; idiv = rg_rcp(divisor); } w++; continue; }
         v3 pnt[4]; int body[4], cnt;
         int s0 = m.wrap_objid[w];
         pnt[0] = ld3(s.spos + 3 * s0); body[0] = m.site_bodyid[s0];
@@ -479,21 +482,21 @@ __device__ __forceinline__ void rg_tendon(RgM m, RgLds& s) {
           pnt[1] = ld3(s.spos + 3 * s1); body[1] = m.site_bodyid[s1]; cnt = 2;
           w += 1;
         }
-        if (wlen >= 0) L += wlen / divisor;
+        if (wlen >= 0) L += wlen * idiv;
         for (int k = 0; k < cnt - 1; k++) {
           if (cnt == 4 && k == 1) continue;
           v3 dif = pnt[k + 1] - pnt[k];
-          float dist = norm(dif);
-          L += dist / divisor;
+          float dist = rg_sqrt(dot(dif, dif));
+          L += dist * idiv;
           if (body[k] != body[k + 1] && dist > 1e-15f) {
-            dif = dif * (1.0f / dist);
+            dif = dif * rg_rcp(dist);
             for (int e = 0; e < 4; e++) {
               int d = td[e];
               if (d < 0) continue;
               float v = 0;
               if (in_chain(m, body[k + 1], d)) v += dot(dif, jac_col(s, d, pnt[k + 1] - ld3(s.org + 3 * s.b2org[body[k + 1]])));
               if (in_chain(m, body[k], d)) v -= dot(dif, jac_col(s, d, pnt[k] - ld3(s.org + 3 * s.b2org[body[k]])));
-              J[e] += v / divisor;
+              J[e] += v * idiv;
             }
           }
         }
