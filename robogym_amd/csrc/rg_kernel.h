@@ -747,12 +747,17 @@ template <int G> __device__ __forceinline__ bool rg_mpr(const MprEnv& E, const M
         if (cont) { dir = normalized(cross(p1.v - p0.v, p2.v - p0.v)); if (++guard > 64) state = MPR_DONE; }
         else { to_refine = true; guard = 0; }
       }
-    } else if (state == MPR_REFINE) {
-      if (dq < 0) { sep = dir; state = MPR_DONE; }
-      else if (portal_reach_tol(p1, p2, p3, q, dir, tol)) state = MPR_DONE;
-      else { expand_portal(p0, p1, p2, p3, q); to_refine = true; if (++guard > 128) { state = MPR_DONE; to_refine = false; } }
-    } else {  // MPR_PENETR
-      if (portal_reach_tol(p1, p2, p3, q, dir, tol) || guard > max_iter) {
+    } else {
+      // refinement and penetration search share "did the portal reach the surface / expand it / new direction":
+      // one copy of that code for the groups in either state
+      bool penetr = state == MPR_PENETR;
+      bool reach = portal_reach_tol(p1, p2, p3, q, dir, tol);
+      bool expand = false;
+      if (!penetr) {
+        if (dq < 0) { sep = dir; state = MPR_DONE; }
+        else if (reach) state = MPR_DONE;
+        else expand = true;
+      } else if (reach || guard > max_iter) {
         // depth / direction from the portal PLANE (not libccd's closest point on the final portal triangle,
         // whose choice among the triangles of a flat supporting plane is rounding noise; see DESIGN.md "MPR")
         depth = fmaxf((dot(p1.v, dir) + dot(p2.v, dir) + dot(p3.v, dir)) * (1.0f / 3.0f), 0.f);
@@ -769,11 +774,17 @@ template <int G> __device__ __forceinline__ bool rg_mpr(const MprEnv& E, const M
         float inv = 0.5f * rg_rcp(sum);
         pos = p0.s * (b0 * inv) + p1.s * (b1 * inv) + p2.s * (b2 * inv) + p3.s * (b3 * inv);
         result = true; state = MPR_DONE;
-      } else { expand_portal(p0, p1, p2, p3, q); dir = portal_dir(p1, p2, p3); guard++; }
+      } else expand = true;
+      if (expand) {
+        expand_portal(p0, p1, p2, p3, q);
+        guard++;
+        if (!penetr && guard > 128) state = MPR_DONE;
+        else to_refine = true;
+      }
     }
-    if (to_refine) {   // refinePortal's loop head: the origin side of the portal decides
+    if (to_refine) {   // new portal: its normal is the next direction; during refinement the origin side decides the state
       dir = portal_dir(p1, p2, p3);
-      if (dot(dir, p1.v) >= 0) { state = MPR_PENETR; guard = 0; } else state = MPR_REFINE;
+      if (state != MPR_PENETR) { if (dot(dir, p1.v) >= 0) { state = MPR_PENETR; guard = 0; } else state = MPR_REFINE; }
     }
   }
   return result;
