@@ -518,7 +518,7 @@ __device__ __forceinline__ void rg_crb(RgM m, RgLds& s, const int* subtree_adr, 
   for (int w = LANE; w < m.nbody * 10; w += RG_WAVE) {
     int b = w / 10, k = w - 10 * b;
     float acc = 0;
-    for (int e = subtree_adr[b]; e < subtree_adr[b + 1]; e++) acc += s.cinert[10 * subtree[e] + k];
+    for (uint32_t bits = (uint32_t)m.subtree_mask[b]; bits; bits &= bits - 1) acc += s.cinert[10 * __builtin_ctz(bits) + k];
     s.crb[w] = acc;
   }
   for (int w = LANE; w < m.blkwords; w += RG_WAVE) s.M[w] = 0;
@@ -1092,7 +1092,7 @@ __device__ __forceinline__ void rg_velocity(RgM m, RgLds& s, const uint32_t* dof
   for (int w = LANE; w < m.nbody * 6; w += RG_WAVE) {
     int b = w / 6, k = w - 6 * b;
     float acc = 0;
-    if (b > 0) for (int e = subtree_adr[b]; e < subtree_adr[b + 1]; e++) acc += s.cacc[6 * subtree[e] + k];
+    if (b > 0) for (uint32_t bits = (uint32_t)m.subtree_mask[b]; bits; bits &= bits - 1) acc += s.cacc[6 * __builtin_ctz(bits) + k];
     s.cfrc[w] = acc;
   }
   SYNC();

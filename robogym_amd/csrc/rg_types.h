@@ -51,6 +51,7 @@ struct RgModelDev {
   const int *body_parentid, *body_rootid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum, *body_lastdof;
   const float *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_invweight0;
   const int *lvl_body, *lvl_body_adr, *static_body;
+  const int* subtree_mask;      // [nbody] bit c: body c belongs to the subtree rooted at the body (self included)
   const float* kin_rec;         // [len(lvl_body)][RG_KINREC] per level slot: body, parent, first joint and their constants (rg_api.hip)
   const float *static_xpos, *static_xquat;
   const int *root_origin_body, *body_orgslot;

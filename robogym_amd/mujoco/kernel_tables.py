@@ -138,6 +138,11 @@ def derive_kernel_tables(model, max_row_nnz=16):
         sflat += members
         sadr.append(len(sflat))
     A["k_subtree_adr"] = _i32(sadr); A["k_subtree"] = _i32(sflat)
+    if nbody > 32:
+        raise NotImplementedError("subtree masks are 32-bit: nbody=%d" % nbody)
+    # the same membership as one bit mask per body (bit c = body c is in the subtree of b): the gathers iterate set bits
+    # in ascending order instead of chasing the index list through global memory
+    A["k_subtree_mask"] = np.array([sum(1 << int(c) for c in sflat[sadr[b]:sadr[b + 1]]) for b in range(nbody)], dtype=np.uint32).view(np.int32)
     # dofs whose motion precedes dof d on its chain (velocity "before" the joint, mj_comVel):
     # strict ancestors, minus the sibling rotational dofs of the same ball / free joint
     velmask = np.zeros(nv, dtype=np.uint64)
