@@ -228,8 +228,9 @@ __device__ __forceinline__ int wave_min_i(int v) {
 // value of lane `src` (wave-uniform index) in every lane
 __device__ __forceinline__ float lane_bcast(float v, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); }
 #endif
-// all-reduce inside a group of G = 16 lanes (one DPP row: row rotations) or G = 8 lanes (half a row: two
-// quad permutes and the half-row mirror); every lane of the group ends up with the result.  Only the
+// all-reduce inside a group of G = 16 lanes (one DPP row: row rotations), G = 8 lanes (half a row: two quad
+// permutes and the half-row mirror) or G = 4 lanes (a quad: two quad permutes); every lane of the group ends up
+// with the result.  Only the
 // group has to be convergent.
 #ifdef RG_EMUL
 template <int G> __device__ __forceinline__ float grp_max(float v) { for (int o = G / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
@@ -237,12 +238,12 @@ template <int G> __device__ __forceinline__ int grp_min_i(int v) { for (int o = 
 #else
 template <int G> __device__ __forceinline__ float grp_max(float v) {
   if (G == 16) { v = fmaxf(v, dpp_f<0x128, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x124, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x122, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x121, 0xf>(v, v)); }
-  else { v = fmaxf(v, dpp_f<0xB1, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x4E, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x141, 0xf>(v, v)); }
+  else { v = fmaxf(v, dpp_f<0xB1, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x4E, 0xf>(v, v)); if (G == 8) v = fmaxf(v, dpp_f<0x141, 0xf>(v, v)); }
   return v;
 }
 template <int G> __device__ __forceinline__ int grp_min_i(int v) {
   if (G == 16) { v = imin(v, dpp_i<0x128, 0xf>(v, v)); v = imin(v, dpp_i<0x124, 0xf>(v, v)); v = imin(v, dpp_i<0x122, 0xf>(v, v)); v = imin(v, dpp_i<0x121, 0xf>(v, v)); }
-  else { v = imin(v, dpp_i<0xB1, 0xf>(v, v)); v = imin(v, dpp_i<0x4E, 0xf>(v, v)); v = imin(v, dpp_i<0x141, 0xf>(v, v)); }
+  else { v = imin(v, dpp_i<0xB1, 0xf>(v, v)); v = imin(v, dpp_i<0x4E, 0xf>(v, v)); if (G == 8) v = imin(v, dpp_i<0x141, 0xf>(v, v)); }
   return v;
 }
 #endif
@@ -999,8 +1000,9 @@ __device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, float* pr
   }
   if (prof && LANE == 0) prof[5] += (float)(rg_clock() - tb0);
   // narrowphase.  Convex pairs run in groups of G lanes, 64/G queries per wave (the portal algebra is scalar
-  // per query; a whole wave per query would execute it 64-fold redundantly).  G = 16 (a DPP row) scans a
-  // hull twice as fast as G = 8 (half a row) but runs half as many queries at once: picked by queue length.
+  // per query; a whole wave per query would execute it 64-fold redundantly).  Wider groups scan a hull
+  // faster, narrower groups run more queries at once (G = 16 / 8 / 4: 4 / 8 / 16 per wave): picked by queue length;
+  // with the cell lists a support is ~4 records, so the one-support phase 1 runs in quads once the queue is long.
   // Phase 1 (uniform cost): one support test per candidate, along the cached separating direction of the
   // pair or else the centre line — "separated along that direction" rejects most box-overlapping
   // neighbours.  Survivors are compacted in order so that phase 2 (full MPR) only runs groups of
@@ -1008,7 +1010,7 @@ __device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, float* pr
   int ncand = s.ncand;
   if (LANE == 0) s.ncand2 = 0;
   SYNC();
-  if (ncand > 4) rg_narrow_phase1<8>(c, ncand); else rg_narrow_phase1<16>(c, ncand);
+  if (ncand > 8) rg_narrow_phase1<4>(c, ncand); else if (ncand > 4) rg_narrow_phase1<8>(c, ncand); else rg_narrow_phase1<16>(c, ncand);
   int ncand2 = s.ncand2;
   if (prof && LANE == 0) { prof[16] += (float)(rg_clock() - tb0); prof[17] += ncand; prof[18] += ncand2; }
   if (ncand2 > 4) rg_narrow_phase2<8>(c, ncand2); else rg_narrow_phase2<16>(c, ncand2);

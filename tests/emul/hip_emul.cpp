@@ -21,12 +21,12 @@ void* emul_lds() { return g_lds; }
 
 void emul_yield() { swapcontext(&g_fiber[g_cur], &g_sched); }
 
-// barrier state per group size (8-lane half rows: 8 groups, 16-lane rows: 4 groups, wave: 1 group)
-static int g_arrived[3][8], g_gen[3][8];
+// barrier state per group size (quads: 16 groups, 8-lane half rows: 8, 16-lane rows: 4, wave: 1)
+static int g_arrived[4][16], g_gen[4][16];
 static bool g_restart;  // a wave barrier was released: resume the sweep at lane 0 (hardware executes a wave's lanes in lane order)
 static int live_in_group(int gsize, int grp) { int n = 0; for (int l = grp * gsize; l < (grp + 1) * gsize; l++) n += !g_done[l]; return n; }
 void emul_barrier(int gsize) {
-  int k = gsize == 64 ? 2 : (gsize == 16 ? 1 : 0), gs = gsize == 64 ? 64 : (gsize == 16 ? 16 : 8), grp = g_cur / gs;
+  int k = gsize == 64 ? 3 : (gsize == 16 ? 2 : (gsize == 8 ? 1 : 0)), gs = gsize == 64 ? 64 : (gsize == 16 ? 16 : (gsize == 8 ? 8 : 4)), grp = g_cur / gs;
   int gen = g_gen[k][grp];
   g_arrived[k][grp]++;
   if (g_arrived[k][grp] >= live_in_group(gs, grp)) { g_arrived[k][grp] = 0; g_gen[k][grp]++; g_restart = true; emul_yield(); return; }
@@ -58,7 +58,7 @@ void emul_launch(int nblocks, size_t lds_bytes, emul_kernel_fn fn, void* arg) {
       makecontext(&g_fiber[l], fiber_main, 0);
       g_done[l] = 0;
     }
-    for (int k = 0; k < 3; k++) for (int g = 0; g < 8; g++) g_arrived[k][g] = 0;
+    for (int k = 0; k < 4; k++) for (int g = 0; g < 16; g++) g_arrived[k][g] = 0;
     int alive = 64;
     while (alive > 0) {
       alive = 0;
