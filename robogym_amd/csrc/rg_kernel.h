@@ -667,10 +667,15 @@ __device__ __forceinline__ bool portal_reach_tol(const SupPt& p1, const SupPt& p
   float mn = fminf(fminf(dv4 - dot(p1.v, dir), dv4 - dot(p2.v, dir)), dv4 - dot(p3.v, dir));
   return mn <= tol;
 }
+__device__ __forceinline__ v3 sel3(bool c, v3 a, v3 b) { return mk3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
+// (value selects per component, not "store through a selected pointer": the latter keeps the points in scratch memory)
 __device__ __forceinline__ void expand_portal(const SupPt& p0, SupPt& p1, SupPt& p2, SupPt& p3, const SupPt& v4) {
   v3 c = cross(v4.v, p0.v);
-  if (dot(p1.v, c) > 0) { if (dot(p2.v, c) > 0) p1 = v4; else p3 = v4; }
-  else { if (dot(p3.v, c) > 0) p2 = v4; else p1 = v4; }
+  bool a = dot(p1.v, c) > 0, b = dot(p2.v, c) > 0, d = dot(p3.v, c) > 0;
+  bool to1 = a ? b : !d, to3 = a && !b, to2 = !a && d;
+  p1.v = sel3(to1, v4.v, p1.v); p1.s = sel3(to1, v4.s, p1.s);
+  p2.v = sel3(to2, v4.v, p2.v); p2.s = sel3(to2, v4.s, p2.s);
+  p3.v = sel3(to3, v4.v, p3.v); p3.s = sel3(to3, v4.s, p3.s);
 }
 __device__ __forceinline__ float origin_tri_dist2(v3 a, v3 b, v3 c, v3& w) {
   v3 ab = b - a, ac = c - a, ap = a * -1.0f;
