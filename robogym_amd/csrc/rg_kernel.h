@@ -390,22 +390,22 @@ __device__ __forceinline__ bool seg_intersect(float p1x, float p1y, float p2x, f
   float b = ((p2x - p1x) * (p1y - p3y) - (p2y - p1y) * (p1x - p3x)) / det;
   return a >= 0 && a <= 1 && b >= 0 && b <= 1;
 }
-__device__ __forceinline__ float wrap_circle(float* pnt, const float* d, const float* sd, float rad) {
+__device__ __forceinline__ float wrap_circle(float* pnt, const float* d, bool has_sd, float sd0, float sd1, float rad) {
   float sq0 = d[0] * d[0] + d[1] * d[1], sq1 = d[2] * d[2] + d[3] * d[3], sqr = rad * rad;
   float dx = d[2] - d[0], dy = d[3] - d[1], dd = dx * dx + dy * dy;
   if (sq0 < sqr || sq1 < sqr || rad < 1e-15f || dd < 1e-15f) return -1;
   float a = clampf(-(dx * d[0] + dy * d[1]) * rg_rcp(dd), 0.f, 1.f);
   float nx = a * dx + d[0], ny = a * dy + d[1];
-  if (nx * nx + ny * ny > sqr && (!sd || sd[0] * nx + sd[1] * ny >= 0)) return -1;
+  if (nx * nx + ny * ny > sqr && (!has_sd || sd0 * nx + sd1 * ny >= 0)) return -1;
   float sol[2][4], good[2];
   float r0 = rg_sqrt(sq0 - sqr), r1 = rg_sqrt(sq1 - sqr), isq0 = rg_rcp(sq0), isq1 = rg_rcp(sq1);
   for (int i = 0; i < 2; i++) {
     float sgn = i == 0 ? 1.f : -1.f;
     sol[i][0] = (d[0] * sqr + sgn * rad * d[1] * r0) * isq0; sol[i][1] = (d[1] * sqr - sgn * rad * d[0] * r0) * isq0;
     sol[i][2] = (d[2] * sqr - sgn * rad * d[3] * r1) * isq1; sol[i][3] = (d[3] * sqr + sgn * rad * d[2] * r1) * isq1;
-    if (sd) {
+    if (has_sd) {
       float mx = sol[i][0] + sol[i][2], my = sol[i][1] + sol[i][3], n = fmaxf(rg_sqrt(mx * mx + my * my), 1e-15f);
-      good[i] = (mx * sd[0] + my * sd[1]) * rg_rcp(n);
+      good[i] = (mx * sd0 + my * sd1) * rg_rcp(n);
     } else {
       float tx = sol[i][0] - sol[i][2], ty = sol[i][1] - sol[i][3];
       good[i] = -(tx * tx + ty * ty);
@@ -427,14 +427,14 @@ __device__ __forceinline__ float rg_wrap(v3& w0, v3& w1, v3 x0, v3 x1, v3 gpos, 
     if (norm(nrm) < 1e-15f) nrm = cross(ax0, fabsf(ax0.x) < 0.9f ? mk3(1, 0, 0) : mk3(0, 1, 0));
     nrm = normalized(nrm); ax1 = normalized(cross(nrm, ax0));
   } else { ax0 = mk3(1, 0, 0); ax1 = mk3(0, 1, 0); }
-  float dd[4] = {dot(p0, ax0), dot(p0, ax1), dot(p1, ax0), dot(p1, ax1)}, sd[2];
+  float dd[4] = {dot(p0, ax0), dot(p0, ax1), dot(p1, ax0), dot(p1, ax1)}, sd0 = 0, sd1 = 0;
   if (has_side) {
     v3 sl = mulmT(gmat, side - gpos);
-    sd[0] = dot(sl, ax0); sd[1] = dot(sl, ax1);
-    float n = fmaxf(rg_sqrt(sd[0] * sd[0] + sd[1] * sd[1]), 1e-15f), rn = radius * rg_rcp(n);
-    sd[0] *= rn; sd[1] *= rn;
+    sd0 = dot(sl, ax0); sd1 = dot(sl, ax1);
+    float n = fmaxf(rg_sqrt(sd0 * sd0 + sd1 * sd1), 1e-15f), rn = radius * rg_rcp(n);
+    sd0 *= rn; sd1 *= rn;
   }
-  float pnt[4], wlen = wrap_circle(pnt, dd, has_side ? sd : (const float*)0, radius);
+  float pnt[4], wlen = wrap_circle(pnt, dd, has_side, sd0, sd1, radius);
   if (wlen < 0) return -1;
   v3 r0 = ax0 * pnt[0] + ax1 * pnt[1], r1 = ax0 * pnt[2] + ax1 * pnt[3];
   if (type == RG_WRAP_CYLINDER) {
@@ -467,36 +467,38 @@ __device__ __forceinline__ void rg_tendon(RgM m, RgLds& s) {
       while (w < adr + num - 1) {
         int t0 = m.wrap_type[w], t1 = m.wrap_type[w + 1];
         if (t0 == RG_WRAP_PULLEY || t1 == RG_WRAP_PULLEY) { if (t0 == RG_WRAP_PULLEY) { divisor = m.wrap_prm[w]; idiv = rg_rcp(divisor); } w++; continue; }
-        v3 pnt[4]; int body[4], cnt;
+        // straight segments of this stretch: site -> site, or site -> wrap entry and wrap exit -> site
+        // (named points, no indexed private arrays: those live in scratch memory)
         int s0 = m.wrap_objid[w];
-        pnt[0] = ld3(s.spos + 3 * s0); body[0] = m.site_bodyid[s0];
+        v3 pa = ld3(s.spos + 3 * s0), pb, pc = mk3(0, 0, 0), pd = mk3(0, 0, 0); int ba = m.site_bodyid[s0], bb, bc = 0, bd = 0;
+        bool two = false;
         float wlen = -1;
         if (t1 == RG_WRAP_SPHERE || t1 == RG_WRAP_CYLINDER) {
           int g = m.wrap_objid[w + 1], s1 = m.wrap_objid[w + 2], sid = (int)m.wrap_prm[w + 1];
-          v3 x1 = ld3(s.spos + 3 * s1);
-          wlen = rg_wrap(pnt[1], pnt[2], pnt[0], x1, ld3(s.gpos + 3 * g), s.gmat + 9 * g, m.geom_size[3 * g], t1, sid >= 0, sid >= 0 ? ld3(s.spos + 3 * sid) : mk3(0, 0, 0));
-          if (wlen < 0) { pnt[1] = x1; body[1] = m.site_bodyid[s1]; cnt = 2; }
-          else { pnt[3] = x1; body[1] = body[2] = m.geom_bodyid[g]; body[3] = m.site_bodyid[s1]; cnt = 4; }
+          v3 x1 = ld3(s.spos + 3 * s1), w0 = mk3(0, 0, 0), w1 = mk3(0, 0, 0);
+          wlen = rg_wrap(w0, w1, pa, x1, ld3(s.gpos + 3 * g), s.gmat + 9 * g, m.geom_size[3 * g], t1, sid >= 0, sid >= 0 ? ld3(s.spos + 3 * sid) : mk3(0, 0, 0));
+          if (wlen < 0) { pb = x1; bb = m.site_bodyid[s1]; }
+          else { pb = w0; pc = w1; pd = x1; bb = bc = m.geom_bodyid[g]; bd = m.site_bodyid[s1]; two = true; }
           w += 2;
         } else {
           int s1 = m.wrap_objid[w + 1];
-          pnt[1] = ld3(s.spos + 3 * s1); body[1] = m.site_bodyid[s1]; cnt = 2;
+          pb = ld3(s.spos + 3 * s1); bb = m.site_bodyid[s1];
           w += 1;
         }
         if (wlen >= 0) L += wlen * idiv;
-        for (int k = 0; k < cnt - 1; k++) {
-          if (cnt == 4 && k == 1) continue;
-          v3 dif = pnt[k + 1] - pnt[k];
+        for (int seg = 0; seg < (two ? 2 : 1); seg++) {
+          v3 q0 = seg ? pc : pa, q1 = seg ? pd : pb; int b0 = seg ? bc : ba, b1 = seg ? bd : bb;
+          v3 dif = q1 - q0;
           float dist = rg_sqrt(dot(dif, dif));
           L += dist * idiv;
-          if (body[k] != body[k + 1] && dist > 1e-15f) {
+          if (b0 != b1 && dist > 1e-15f) {
             dif = dif * rg_rcp(dist);
             for (int e = 0; e < 4; e++) {
               int d = td[e];
               if (d < 0) continue;
               float v = 0;
-              if (in_chain(m, body[k + 1], d)) v += dot(dif, jac_col(s, d, pnt[k + 1] - ld3(s.org + 3 * s.b2org[body[k + 1]])));
-              if (in_chain(m, body[k], d)) v -= dot(dif, jac_col(s, d, pnt[k] - ld3(s.org + 3 * s.b2org[body[k]])));
+              if (in_chain(m, b1, d)) v += dot(dif, jac_col(s, d, q1 - ld3(s.org + 3 * s.b2org[b1])));
+              if (in_chain(m, b0, d)) v -= dot(dif, jac_col(s, d, q0 - ld3(s.org + 3 * s.b2org[b0])));
               J[e] += v * idiv;
             }
           }
