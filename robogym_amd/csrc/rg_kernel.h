@@ -130,6 +130,11 @@ __device__ __forceinline__ unsigned long long rg_uniform(const void* p) {
 #endif
 typedef const RG_AS4 RgLaunch& RgLRef;
 #endif
+#ifdef RG_EMUL
+#define RG_STAGE_BIG static inline
+#else
+#define RG_STAGE_BIG __device__ __forceinline__   /* the register-hungriest stages stay in the kernel body: a call would save/restore ~30 callee-saved VGPRs through scratch */
+#endif
 // ------------------------------------------------------------------------------------------------- small math
 struct alignas(16) rgf4 { float x, y, z, w; };
 struct v3 { float x, y, z; };
@@ -894,7 +899,7 @@ template <int G> RG_STAGE void rg_narrow_phase1(RgCtx c, int ncand) {
     SYNC();
   }
 }
-template <int G> RG_STAGE void rg_narrow_phase2(RgCtx c, int ncand2) {
+template <int G> RG_STAGE_BIG void rg_narrow_phase2(RgCtx c, int ncand2) {
   RgM m = RG_M(c); RgLRef L = RG_L(c); RgLds& s = RG_S();
   bool cells = !(L.flags & 8);
   float* prof = (L.flags & 2) ? s.prof : (float*)0;
@@ -1848,7 +1853,7 @@ RG_STAGE void st_com_pos(RgCtx c) { rg_com_pos(RG_M(c), RG_S()); }
 RG_STAGE void st_tendon(RgCtx c) { rg_tendon(RG_M(c), RG_S()); }
 RG_STAGE void st_crb(RgCtx c) { RgLRef L = RG_L(c); rg_crb(RG_M(c), RG_S(), L.x.subtree_adr, L.x.subtree); }
 RG_STAGE void st_velocity(RgCtx c) { RgLRef L = RG_L(c); rg_velocity(RG_M(c), RG_S(), L.x.dof_velmask, L.x.subtree_adr, L.x.subtree); }
-RG_STAGE void st_collision(RgCtx c) {
+RG_STAGE_BIG void st_collision(RgCtx c) {
   RgM m = RG_M(c); RgLRef L = RG_L(c); RgLds& s = RG_S();
   int e = blockIdx.x, flags = L.flags;
   rg_collision(c, m, s, (flags & 2) ? s.prof : (float*)0, L.bt.sepdir ? (rgf4*)L.bt.sepdir + (size_t)e * m.npair : (rgf4*)0,
@@ -1858,7 +1863,7 @@ RG_STAGE void st_make_constraint(RgCtx c) { rg_make_constraint(RG_M(c), RG_S());
 RG_STAGE void st_pid(RgCtx c) { rg_pid(RG_M(c), RG_S()); }
 RG_STAGE void st_smooth(RgCtx c) { rg_smooth(RG_M(c), RG_S()); }
 RG_STAGE void st_factor_smooth(RgCtx c) { RgLds& s = RG_S(); rg_block_factor_solve(RG_M(c), s, (const float*)0, 0.f, s.qacc_smooth); }
-RG_STAGE int st_solve(RgCtx c) { int nefc = 0; int it = rg_solve(RG_M(c), RG_S(), nefc, RG_L(c).flags); return it | (nefc << 8); }
+RG_STAGE_BIG int st_solve(RgCtx c) { int nefc = 0; int it = rg_solve(RG_M(c), RG_S(), nefc, RG_L(c).flags); return it | (nefc << 8); }
 RG_STAGE void st_euler(RgCtx c) { rg_euler(RG_M(c), RG_S()); }
 RG_STAGE void st_build_row_desc(RgCtx c) { rg_build_row_desc(RG_M(c), RG_S()); }
 RG_STAGE void st_dump(RgCtx c, int which, int nefc, int iters) {
