@@ -1766,13 +1766,13 @@ __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, int& nefc_out, int flag
     float alpha = 0;
     if (p0.grad < 0 && p0.hess > 0) {
       float lo = 0, hi = -1, glo = p0.grad, hlo = p0.hess, ghi = 0, hhi = 1;
-      alpha = -p0.grad / p0.hess;
+      alpha = -p0.grad * rg_rcp(p0.hess);
       for (int it = 0; it < 12; it++) {
         LsPt p = rg_ls_eval(rows, alpha, gauss, q1, q2);
         if (fabsf(p.grad) < gtol) break;
         if (p.grad < 0) { lo = alpha; glo = p.grad; hlo = p.hess; } else { hi = alpha; ghi = p.grad; hhi = p.hess; }
-        float cand = lo - glo / hlo;
-        if (hi >= 0 && !(cand > lo && cand < hi)) { cand = hi - ghi / hhi; if (!(cand > lo && cand < hi)) cand = 0.5f * (lo + hi); }
+        float cand = lo - glo * rg_rcp(hlo);
+        if (hi >= 0 && !(cand > lo && cand < hi)) { cand = hi - ghi * rg_rcp(hhi); if (!(cand > lo && cand < hi)) cand = 0.5f * (lo + hi); }
         if (cand == alpha) break;
         alpha = cand;
       }
