@@ -391,8 +391,9 @@ __device__ __forceinline__ bool in_chain(RgM m, int body, int d) { return (m.bod
 __device__ __forceinline__ bool seg_intersect(float p1x, float p1y, float p2x, float p2y, float p3x, float p3y, float p4x, float p4y) {
   float det = (p4y - p3y) * (p2x - p1x) - (p4x - p3x) * (p2y - p1y);
   if (fabsf(det) < 1e-15f) return false;
-  float a = ((p4x - p3x) * (p1y - p3y) - (p4y - p3y) * (p1x - p3x)) / det;
-  float b = ((p2x - p1x) * (p1y - p3y) - (p2y - p1y) * (p1x - p3x)) / det;
+  float idet = rg_rcp(det);
+  float a = ((p4x - p3x) * (p1y - p3y) - (p4y - p3y) * (p1x - p3x)) * idet;
+  float b = ((p2x - p1x) * (p1y - p3y) - (p2y - p1y) * (p1x - p3x)) * idet;
   return a >= 0 && a <= 1 && b >= 0 && b <= 1;
 }
 __device__ __forceinline__ float wrap_circle(float* pnt, const float* d, bool has_sd, float sd0, float sd1, float rad) {
@@ -1134,8 +1135,8 @@ __device__ __forceinline__ void rg_pid(RgM m, RgLds& s) {
       if (fabsf(err) < gp[5]) err = 0;
       float* st = s.pid + 3 * u;
       float integ = clampf(st[0] + err * dt, -gp[2], gp[2]);
-      float deriv = (1 - gp[4]) * st[2] + gp[4] * (err - st[1]) / dt;
-      force = gp[0] * (err + (gp[1] != 0 ? integ / gp[1] : 0.f) + gp[3] * deriv);
+      float deriv = (1 - gp[4]) * st[2] + gp[4] * (err - st[1]) * rg_rcp(dt);
+      force = gp[0] * (err + (gp[1] != 0 ? integ * rg_rcp(gp[1]) : 0.f) + gp[3] * deriv);
       st[0] = integ; st[1] = err; st[2] = deriv;
       if (lo != 0 || hi != 0) force = clampf(force, lo, hi);
     } else {
@@ -1246,7 +1247,7 @@ __device__ __forceinline__ void rg_make_constraint(RgM m, RgLds& s) {
     float D = 0, aref = 0;
     if (active) {
       float imp = impedance(solimp, pos, margin), K, B;
-      float R = fmaxf(1e-15f, (1 - imp) * diag / imp);
+      float R = fmaxf(1e-15f, (1 - imp) * diag * rg_rcp(imp));
       kb(m, solref, solimp, K, B);
       if (fric) K = 0;
       float vel = srow_dot<true>(s, r, s.qvel);
@@ -1304,8 +1305,8 @@ __device__ __forceinline__ void rg_make_constraint(RgM m, RgLds& s) {
     float mu0 = prm[2];  // friction[0]
     // first pyramid row: diagApprox = tran + mu0^2 * tran ; all rows get R = 2 mu^2 R_first, mu = friction[0]/sqrt(impratio)
     float R;
-    if (dim == 1) R = fmaxf(1e-15f, (1 - imp) * tran / imp);
-    else { float Rf = fmaxf(1e-15f, (1 - imp) * (tran + mu0 * mu0 * tran) / imp); float mu = mu0 * sqrtf(1.0f / m.impratio); R = 2 * mu * mu * Rf; }
+    if (dim == 1) R = fmaxf(1e-15f, (1 - imp) * tran * rg_rcp(imp));
+    else { float Rf = fmaxf(1e-15f, (1 - imp) * (tran + mu0 * mu0 * tran) * rg_rcp(imp)); float mu = mu0 * rg_rsqrt(m.impratio); R = 2 * mu * mu * Rf; }
     s.c_D[c] = rg_rcp(R);
     // friction coefficient of tangent direction k (k = 0,1 sliding; 2 spin)
     s.c_mu[3 * c] = prm[2]; s.c_mu[3 * c + 1] = prm[2]; s.c_mu[3 * c + 2] = prm[3];
@@ -1717,8 +1718,9 @@ __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, int& nefc_out, int flag
     // H = M + J' D J over the quadratic rows (LDS atomics from one wave: in-order, deterministic)
     {  // H <- M expanded from the per-tree blocks: one 16-byte store per (row, 4-column chunk), zeros outside the tree
       int hs4 = hs >> 2; rgf4* H4 = (rgf4*)s.H;
+      float ihs4 = 1.0f / (float)hs4;   // row of a chunk index without an integer division (exact: w < 2^10)
       for (int w = LANE; w < nvc * hs4; w += RG_WAVE) {
-        int i = w / hs4, c = w - i * hs4, blk = s.cblk[i], k0 = 4 * c - ((blk >> 16) & 255), n = (blk >> 24) & 255;
+        int i = (int)(((float)w + 0.5f) * ihs4), c = w - i * hs4, blk = s.cblk[i], k0 = 4 * c - ((blk >> 16) & 255), n = (blk >> 24) & 255;
         const float* Mr = s.M + (blk & 0xFFFF);
         rgf4 o;
         o.x = (k0 >= 0 && k0 < n) ? Mr[k0] : 0.f; o.y = (k0 + 1 >= 0 && k0 + 1 < n) ? Mr[k0 + 1] : 0.f;
