@@ -141,7 +141,10 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
   UPI(body_dofadr, "body_dofadr"); UPI(body_dofnum, "body_dofnum"); UPI(body_lastdof, "k_body_lastdof");
   UPF(body_pos, "body_pos"); UPF(body_quat, "body_quat"); UPF(body_ipos, "body_ipos"); UPF(body_iquat, "body_iquat");
   UPF(body_mass, "body_mass"); UPF(body_inertia, "body_inertia"); UPF(body_invweight0, "body_invweight0");
-  UPI(subtree_mask, "k_subtree_mask"); UPI(lvl_body, "k_lvl_body"); UPI(lvl_body_adr, "k_lvl_body_adr"); UPI(static_body, "k_static_body");
+  UPI(subtree_mask, "k_subtree_mask");
+  GI("k_ltdl_tri"); d.n_tri_rounds = (int)(iv.size() / 128); if (!upload<int>(m, iv, &d.ltdl_tri)) return bail("hipMalloc failed", m);
+  GI("k_ltdl_pair"); d.n_pair_rounds = (int)(iv.size() / 64); if (!upload<int>(m, iv, &d.ltdl_pair)) return bail("hipMalloc failed", m);
+  if (d.n_tri_rounds > RG_LTDL_TRI_ROUNDS || d.n_pair_rounds > RG_LTDL_PAIR_ROUNDS) return bail("dof tree too large for the L'DL descriptor caps", m); UPI(lvl_body, "k_lvl_body"); UPI(lvl_body_adr, "k_lvl_body_adr"); UPI(static_body, "k_static_body");
   UPF(static_xpos, "k_static_xpos"); UPF(static_xquat, "k_static_xquat");
   UPI(root_origin_body, "k_root_origin_body"); UPI(body_orgslot, "k_body_orgslot"); UPF(root_origin_const, "k_root_origin_const");
   { GI("k_body_dofmask"); std::vector<uint32_t> u(iv.begin(), iv.end()); for (size_t i = 0; i < iv.size(); i++) u[i] = (uint32_t)iv[i]; if (!upload<uint32_t>(m, u, &d.body_dofmask)) return bail("hipMalloc failed", m); }

@@ -1520,101 +1520,67 @@ __device__ __forceinline__ void rg_chol_solve(RgM m, RgLds& s, float* x) {
   if (i < n) x[i] = xi;
   SYNC();
 }
-// Block-diagonal factorisation over ALL dofs: s.H (same block layout as s.M) <- chol(M + scale*diag(extra)),
-// every kinematic tree's block factored concurrently (lane d owns row d of its tree), four columns per
-// step as in rg_chol; the pivot lanes differ per tree, so pivot values travel by ds_bpermute (__shfl).
-// Then x <- solve.  Used for qacc_smooth = M^-1 qfrc_smooth and for the implicit-damping Euler solve.
-__device__ __forceinline__ void rg_block_factor_solve(RgM m, RgLds& s, const float* extra_diag, float scale, float* x) {
+// Tree-sparse factorisation M + scale*diag(extra) = L' D L over ALL dofs (mj_factorM) and x <- solve (mj_solveM), in the
+// per-tree block storage of s.M (work copy in s.H).  Only (dof, ancestor) entries exist and dofs of equal depth
+// are independent, so the factorisation is one lane-parallel pass per depth (deepest first), every lane taking
+// one (k, i, j) update M[i][j] -= M[k][i] M[k][j] / M[k][k] and adding it with an LDS atomic (several dofs share
+// ancestors; one wave issues them in lane order: deterministic).  The substitutions are the same passes over the
+// (k, i) pairs.  A lane loads all of its descriptors up front (one load latency), the passes themselves only
+// touch LDS.  Used for qacc_smooth = M^-1 qfrc_smooth and for the implicit-damping Euler solve.
+__device__ __forceinline__ void rg_ltdl_factor_solve(RgM m, RgLds& s, const float* extra_diag, float scale, float* x) {
+  int ntr = m.n_tri_rounds, npr = m.n_pair_rounds;
+  int t0[RG_LTDL_TRI_ROUNDS], t1[RG_LTDL_TRI_ROUNDS], pr[RG_LTDL_PAIR_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < RG_LTDL_TRI_ROUNDS; r++) { bool on = r < ntr; t0[r] = on ? m.ltdl_tri[2 * (r * RG_WAVE + LANE)] : 0; t1[r] = on ? m.ltdl_tri[2 * (r * RG_WAVE + LANE) + 1] : 0; }
+#pragma unroll
+  for (int r = 0; r < RG_LTDL_PAIR_ROUNDS; r++) pr[r] = r < npr ? m.ltdl_pair[r * RG_WAVE + LANE] : -1;
   for (int w = LANE; w < m.blkwords; w += RG_WAVE) s.H[w] = s.M[w];
   SYNC();
   int d = LANE; bool on = d < m.nv;
-  int blk = on ? m.dof_blk[d] : 0, blk2 = on ? m.dof_blk2[d] : 0;
-  int s0 = (blk >> 16) & 255, n = on ? (blk >> 24) & 255 : 0, r = d - s0, st4 = (blk2 & 255) >> 2;
-  rgf4* B4 = (rgf4*)(s.H + (blk2 >> 8));   // this lane's tree block, rows of st4 16-byte chunks
-  if (on && extra_diag) s.H[(blk & 0xFFFF) + r] += scale * extra_diag[d];
+  int blk = on ? m.dof_blk[d] : 0, akk = (blk & 0xFFFF) + d - ((blk >> 16) & 255);
+  if (on && extra_diag) s.H[akk] += scale * extra_diag[d];
   SYNC();
-  bool bad = false;
-  int nsteps = (m.maxtree + 3) >> 2;
-  for (int sb = 0; sb < nsteps; sb++) {
-    int j0 = sb << 2, nb = n - j0;  // columns j0..j0+3 of the lane's own block
-    bool blk_on = on && nb > 0, mine = blk_on && r >= j0;
-    int q1 = j0 + 1 < n ? j0 + 1 : n - 1, q2 = j0 + 2 < n ? j0 + 2 : n - 1, q3 = j0 + 3 < n ? j0 + 3 : n - 1;
-    float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    if (mine) {
-      rgf4 own = B4[r * st4 + sb];
-      a0 = own.x; a1 = own.y; a2 = own.z; a3 = own.w;
-      const rgf4 *ri = B4 + r * st4, *p0 = B4 + j0 * st4, *p1 = B4 + q1 * st4, *p2 = B4 + q2 * st4, *p3 = B4 + q3 * st4;
-#pragma unroll 2
-      for (int c = 0; c < sb; c++) { rgf4 a = ri[c]; a0 -= dot4(a, p0[c]); a1 -= dot4(a, p1[c]); a2 -= dot4(a, p2[c]); a3 -= dot4(a, p3[c]); }
-    }
-    int l0 = blk_on ? s0 + j0 : 0, l1 = blk_on ? s0 + q1 : 0, l2 = blk_on ? s0 + q2 : 0, l3 = blk_on ? s0 + q3 : 0;
-    float t00 = __shfl(a0, l0);
-    float t10 = __shfl(a0, l1), t11 = __shfl(a1, l1);
-    float t20 = __shfl(a0, l2), t21 = __shfl(a1, l2), t22 = __shfl(a2, l2);
-    float t30 = __shfl(a0, l3), t31 = __shfl(a1, l3), t32 = __shfl(a2, l3), t33 = __shfl(a3, l3);
-    if (blk_on) {
-      bool v1 = nb > 1, v2 = nb > 2, v3 = nb > 3;
-      if (!(t00 > 1e-30f)) { bad = true; t00 = 1e-30f; }
-      float i00 = rg_rsqrt(t00), l00 = t00 * i00;
-      float l10 = v1 ? t10 * i00 : 0.f, d11 = v1 ? t11 - l10 * l10 : 1.f;
-      if (!(d11 > 1e-30f)) { bad = true; d11 = 1e-30f; }
-      float r11 = rg_rsqrt(d11), l11 = d11 * r11, i11 = v1 ? r11 : 0.f;
-      float l20 = v2 ? t20 * i00 : 0.f, l21 = v2 ? (t21 - l20 * l10) * i11 : 0.f, d22 = v2 ? t22 - l20 * l20 - l21 * l21 : 1.f;
-      if (!(d22 > 1e-30f)) { bad = true; d22 = 1e-30f; }
-      float r22 = rg_rsqrt(d22), l22 = d22 * r22, i22 = v2 ? r22 : 0.f;
-      float l30 = v3 ? t30 * i00 : 0.f, l31 = v3 ? (t31 - l30 * l10) * i11 : 0.f, l32 = v3 ? (t32 - l30 * l20 - l31 * l21) * i22 : 0.f;
-      float d33 = v3 ? t33 - l30 * l30 - l31 * l31 - l32 * l32 : 1.f;
-      if (!(d33 > 1e-30f)) { bad = true; d33 = 1e-30f; }
-      float r33 = rg_rsqrt(d33), l33 = d33 * r33, i33 = v3 ? r33 : 0.f;
-      if (mine) {
-        int rr = r - j0;
-        float x0 = a0 * i00, x1 = (a1 - x0 * l10) * i11, x2 = (a2 - x0 * l20 - x1 * l21) * i22, x3 = (a3 - x0 * l30 - x1 * l31 - x2 * l32) * i33;
-        if (rr == 0) { x0 = l00; x1 = 0; x2 = 0; x3 = 0; }
-        else if (rr == 1) { x1 = l11; x2 = 0; x3 = 0; }
-        else if (rr == 2) { x2 = l22; x3 = 0; }
-        else if (rr == 3) x3 = l33;
-        rgf4 o; o.x = x0; o.y = x1; o.z = x2; o.w = x3;
-        B4[r * st4 + sb] = o;
-        if (rr < 4) s.dinv[d] = rr == 0 ? i00 : (rr == 1 ? i11 : (rr == 2 ? i22 : i33));   // reciprocal pivot of dof d
+  // factor: M[i][j] -= M[k][i] M[k][j] / M[k][k], deepest dofs first
+#pragma unroll
+  for (int r = 0; r < RG_LTDL_TRI_ROUNDS; r++) {   // (no break / continue: the loops must unroll fully, or the descriptor arrays end up in scratch)
+    if (r < ntr) {
+      if (t1[r] < 0) {
+        float v = s.H[t0[r] & 1023] * s.H[(t0[r] >> 10) & 1023] * rg_rcp(s.H[(t0[r] >> 20) & 1023]);
+        atomicAdd(s.H + (t1[r] & 1023), -v);
       }
-    }
-    SYNC();
-  }
-  // substitution sweeps, four pivots per step
-  const float* Bf = s.H + (blk2 >> 8); int st = blk2 & 255;
-  float xi = on ? x[d] : 0.f;
-  for (int sb = 0; sb < nsteps; sb++) {
-    int j0 = sb << 2, nb = n - j0; bool blk_on = on && nb > 0;
-    int q1 = j0 + 1 < n ? j0 + 1 : n - 1, q2 = j0 + 2 < n ? j0 + 2 : n - 1, q3 = j0 + 3 < n ? j0 + 3 : n - 1;
-    int l0 = blk_on ? s0 + j0 : 0, l1 = blk_on ? s0 + q1 : 0, l2 = blk_on ? s0 + q2 : 0, l3 = blk_on ? s0 + q3 : 0;
-    float y0 = __shfl(xi, l0), y1 = __shfl(xi, l1), y2 = __shfl(xi, l2), y3 = __shfl(xi, l3);
-    if (blk_on) {
-      rgf4 e1 = B4[q1 * st4 + sb], e2 = B4[q2 * st4 + sb], e3 = B4[q3 * st4 + sb];
-      float i00 = s.dinv[s0 + j0], i11 = nb > 1 ? s.dinv[s0 + q1] : 0.f, i22 = nb > 2 ? s.dinv[s0 + q2] : 0.f, i33 = nb > 3 ? s.dinv[s0 + q3] : 0.f;
-      float x0 = y0 * i00, x1 = (y1 - e1.x * x0) * i11, x2 = (y2 - e2.x * x0 - e2.y * x1) * i22, x3 = (y3 - e3.x * x0 - e3.y * x1 - e3.z * x2) * i33;
-      int rr = r - j0;
-      if (rr >= 4) { rgf4 own = B4[r * st4 + sb]; xi -= own.x * x0 + own.y * x1 + own.z * x2 + own.w * x3; }
-      else if (rr == 0) xi = x0; else if (rr == 1) xi = x1; else if (rr == 2) xi = x2; else if (rr == 3) xi = x3;
+      SYNC();
     }
   }
-  for (int sb = nsteps - 1; sb >= 0; sb--) {
-    int j0 = sb << 2, nb = n - j0; bool blk_on = on && nb > 0;
-    int q1 = j0 + 1 < n ? j0 + 1 : n - 1, q2 = j0 + 2 < n ? j0 + 2 : n - 1, q3 = j0 + 3 < n ? j0 + 3 : n - 1;
-    int l0 = blk_on ? s0 + j0 : 0, l1 = blk_on ? s0 + q1 : 0, l2 = blk_on ? s0 + q2 : 0, l3 = blk_on ? s0 + q3 : 0;
-    float y0 = __shfl(xi, l0), y1 = __shfl(xi, l1), y2 = __shfl(xi, l2), y3 = __shfl(xi, l3);
-    if (blk_on) {
-      rgf4 e1 = B4[q1 * st4 + sb], e2 = B4[q2 * st4 + sb], e3 = B4[q3 * st4 + sb];
-      float i00 = s.dinv[s0 + j0], i11 = nb > 1 ? s.dinv[s0 + q1] : 0.f, i22 = nb > 2 ? s.dinv[s0 + q2] : 0.f, i33 = nb > 3 ? s.dinv[s0 + q3] : 0.f;
-      float l10 = nb > 1 ? e1.x : 0.f, l20 = nb > 2 ? e2.x : 0.f, l21 = nb > 2 ? e2.y : 0.f, l30 = nb > 3 ? e3.x : 0.f, l31 = nb > 3 ? e3.y : 0.f, l32 = nb > 3 ? e3.z : 0.f;
-      float x3 = y3 * i33, x2 = (y2 - l32 * x3) * i22, x1 = (y1 - l21 * x2 - l31 * x3) * i11, x0 = (y0 - l10 * x1 - l20 * x2 - l30 * x3) * i00;
-      int rr = r - j0;
-      if (rr < 0) xi -= Bf[j0 * st + r] * x0 + (nb > 1 ? Bf[q1 * st + r] * x1 : 0.f) + (nb > 2 ? Bf[q2 * st + r] * x2 : 0.f) + (nb > 3 ? Bf[q3 * st + r] * x3 : 0.f);
-      else if (rr == 0) xi = x0; else if (rr == 1) xi = x1; else if (rr == 2) xi = x2; else if (rr == 3) xi = x3;
-    }
-  }
-  if (on) x[d] = xi;
-  if (bad) s.status |= RG_STATUS_BAD_FACTOR;
+  // L[k][i] = M[k][i] / D[k]; reciprocal pivots; a non-positive pivot flags the factorisation
+  bool bad = false;
+  float dk = on ? s.H[akk] : 1.f;
+  if (!(dk > 1e-30f)) { bad = on; dk = 1e-30f; }
+  float idk = rg_rcp(dk);
+#pragma unroll
+  for (int r = 0; r < RG_LTDL_PAIR_ROUNDS; r++)
+    if (r < npr && pr[r] != -1) { int a = (pr[r] >> 12) & 1023; s.H[a] *= rg_rcp(fmaxf(s.H[(pr[r] >> 22) & 1023], 1e-30f)); }
   SYNC();
+  // x <- inv(L') x : x[i] -= L[k][i] x[k], deepest first
+#pragma unroll
+  for (int r = 0; r < RG_LTDL_PAIR_ROUNDS; r++) {
+    if (r < npr) {
+      if (pr[r] != -1) atomicAdd(x + ((pr[r] >> 6) & 63), -s.H[(pr[r] >> 12) & 1023] * x[pr[r] & 63]);
+      SYNC();
+    }
+  }
+  // x <- inv(D) x
+  if (on) x[d] *= idk;
+  SYNC();
+  // x <- inv(L) x : x[k] -= L[k][i] x[i], shallowest first
+#pragma unroll
+  for (int q = 0; q < RG_LTDL_PAIR_ROUNDS; q++) {
+    const int r = RG_LTDL_PAIR_ROUNDS - 1 - q;
+    if (r < npr) {
+      if (pr[r] != -1) atomicAdd(x + (pr[r] & 63), -s.H[(pr[r] >> 12) & 1023] * x[(pr[r] >> 6) & 63]);
+      SYNC();
+    }
+  }
+  if (bad) s.status |= RG_STATUS_BAD_FACTOR;
 }
 
 struct LsPt { float cost, grad, hess; };
@@ -1803,7 +1769,7 @@ __device__ __forceinline__ void rg_euler(RgM m, RgLds& s) {
   float h = m.timestep;
   PFOR(i, m.nv) s.tmpv[i] = s.qfrc_smooth[i] + s.qfrc_con[i];
   SYNC();
-  rg_block_factor_solve(m, s, m.dof_damping, h, s.tmpv);
+  rg_ltdl_factor_solve(m, s, m.dof_damping, h, s.tmpv);
   PFOR(i, m.nv) { s.qvel[i] += h * s.tmpv[i]; s.warm[i] = s.qacc[i]; }
   SYNC();
   PFOR(j, m.njnt) {
@@ -1864,7 +1830,7 @@ RG_STAGE_BIG void st_collision(RgCtx c) {
 RG_STAGE void st_make_constraint(RgCtx c) { rg_make_constraint(RG_M(c), RG_S()); }
 RG_STAGE void st_pid(RgCtx c) { rg_pid(RG_M(c), RG_S()); }
 RG_STAGE void st_smooth(RgCtx c) { rg_smooth(RG_M(c), RG_S()); }
-RG_STAGE void st_factor_smooth(RgCtx c) { RgLds& s = RG_S(); rg_block_factor_solve(RG_M(c), s, (const float*)0, 0.f, s.qacc_smooth); }
+RG_STAGE void st_factor_smooth(RgCtx c) { RgLds& s = RG_S(); rg_ltdl_factor_solve(RG_M(c), s, (const float*)0, 0.f, s.qacc_smooth); }
 RG_STAGE_BIG int st_solve(RgCtx c) { int nefc = 0; int it = rg_solve(RG_M(c), RG_S(), nefc, RG_L(c).flags); return it | (nefc << 8); }
 RG_STAGE void st_euler(RgCtx c) { rg_euler(RG_M(c), RG_S()); }
 RG_STAGE void st_build_row_desc(RgCtx c) { rg_build_row_desc(RG_M(c), RG_S()); }

@@ -22,6 +22,8 @@
 #define RG_MAXCAND2 64  // candidates surviving the first support test (full MPR queries) per substep
 #define RG_CELLN 8      // direction cells: cube map, RG_CELLN x RG_CELLN per face (kernel_tables.py CELL_N)
 #define RG_NCELL (6 * RG_CELLN * RG_CELLN)
+#define RG_LTDL_TRI_ROUNDS 12   // caps on the descriptor rounds of the L'DL passes (registers per lane)
+#define RG_LTDL_PAIR_ROUNDS 8
 #define RG_KINREC 20    // words per kinematics record
 #define RG_PAIRREC 24   // words per pair record
 #define RG_TLIST 320    // pairs whose distance bound ran out, queued for the sphere/box tests (drained in chunks)
@@ -51,6 +53,8 @@ struct RgModelDev {
   const int *body_parentid, *body_rootid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum, *body_lastdof;
   const float *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_invweight0;
   const int *lvl_body, *lvl_body_adr, *static_body;
+  const int *ltdl_tri, *ltdl_pair;   // tree-sparse L'DL passes of M: rounds of 64 descriptors (kernel_tables.py)
+  int n_tri_rounds, n_pair_rounds;
   const int* subtree_mask;      // [nbody] bit c: body c belongs to the subtree rooted at the body (self included)
   const float* kin_rec;         // [len(lvl_body)][RG_KINREC] per level slot: body, parent, first joint and their constants (rg_api.hip)
   const float *static_xpos, *static_xquat;

@@ -346,6 +346,45 @@ def derive_kernel_tables(model, max_row_nnz=16):
     A["k_d2c"] = d2c; A["k_c2d"] = _i32(c2d)
     A["k_tree"] = _i32(tree_tab).reshape(-1, 5)
     A["k_blk_dims"] = _i32([nvc, hs, blk_words, len(trees), max(t[2] for t in trees)])
+
+    # ---------------------------------------------------------------- tree-sparse L'DL of M (mj_factorM / mj_solveM)
+    # M = L' D L over the dof tree touches only (dof, ancestor) entries.  Dofs of equal depth are independent, so the
+    # factorisation is one lane-parallel pass per depth, deepest first: for a dof k and ancestors j <= i < k,
+    # M[i][j] -= M[k][i] M[k][j] / M[k][k].  The passes are stored as rounds of 64 descriptors (padded with zeros) so
+    # that a lane prefetches all of its descriptors with one batch of loads.
+    #   triple: w0 = addr(k,i) | addr(k,j) << 10 | addr(k,k) << 20, w1 = addr(i,j) | valid << 31
+    #   pair  : k | i << 6 | addr(k,i) << 12 | addr(k,k) << 22 (all-ones: padding)
+    # addr = word inside the per-tree block storage (lower triangle: row >= column).
+    dpar = A["dof_parentid"]
+    depth = np.zeros(nv, dtype=int)
+    for k in range(nv):
+        depth[k] = 0 if dpar[k] < 0 else depth[dpar[k]] + 1
+
+    def addr(a, b):
+        assert a >= b
+        return int(dof_blk[a] & 0xFFFF) + (b - int((dof_blk[a] >> 16) & 255))
+
+    assert blk_words < 1024
+    tri_rounds, pair_rounds = [], []
+    for lev in range(int(depth.max()), 0, -1):
+        tri, pr = [], []
+        for k in range(nv):
+            if depth[k] != lev:
+                continue
+            anc, i = [], dpar[k]
+            while i >= 0:
+                anc.append(int(i)); i = dpar[i]
+            for i in anc:
+                pr.append(k | (i << 6) | (addr(k, i) << 12) | (addr(k, k) << 22))
+                for j in anc:
+                    if j <= i:
+                        tri.append((addr(k, i) | (addr(k, j) << 10) | (addr(k, k) << 20), addr(i, j) | (1 << 31)))
+        for lst, rounds, pad in ((tri, tri_rounds, (0, 0)), (pr, pair_rounds, -1)):
+            for r0 in range(0, len(lst), 64):
+                chunk = lst[r0:r0 + 64]
+                rounds.append(chunk + [pad] * (64 - len(chunk)))
+    A["k_ltdl_tri"] = np.array(tri_rounds, dtype=np.int64).astype(np.uint32).view(np.int32).reshape(-1, 2) if tri_rounds else np.zeros((0, 2), np.int32)
+    A["k_ltdl_pair"] = np.array(pair_rounds, dtype=np.int64).astype(np.uint32).view(np.int32).reshape(-1) if pair_rounds else np.zeros(0, np.int32)
     A["k_dims"] = _i32([nlevel, ndl, len(Mi), len(pairs), len(A["k_static_body"]), max_nnz])
     return model
 
