@@ -144,6 +144,10 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
   UPI(subtree_mask, "k_subtree_mask");
   GI("k_ltdl_tri"); d.n_tri_rounds = (int)(iv.size() / 128); if (!upload<int>(m, iv, &d.ltdl_tri)) return bail("hipMalloc failed", m);
   GI("k_ltdl_pair"); d.n_pair_rounds = (int)(iv.size() / 64); if (!upload<int>(m, iv, &d.ltdl_pair)) return bail("hipMalloc failed", m);
+  GI("k_ltdl_tri_c"); d.n_tri_rounds_c = (int)(iv.size() / 128); if (!upload<int>(m, iv, &d.ltdl_tri_c)) return bail("hipMalloc failed", m);
+  GI("k_ltdl_pair_c"); d.n_pair_rounds_c = (int)(iv.size() / 64); if (!upload<int>(m, iv, &d.ltdl_pair_c)) return bail("hipMalloc failed", m);
+  GI("k_tree_newton_ok"); d.tree_newton_ok = iv.empty() ? 0 : iv[0];
+  if (d.n_tri_rounds_c > RG_LTDL_TRI_ROUNDS || d.n_pair_rounds_c > RG_LTDL_PAIR_ROUNDS) d.tree_newton_ok = 0;
   if (d.n_tri_rounds > RG_LTDL_TRI_ROUNDS || d.n_pair_rounds > RG_LTDL_PAIR_ROUNDS) return bail("dof tree too large for the L'DL descriptor caps", m); UPI(lvl_body, "k_lvl_body"); UPI(lvl_body_adr, "k_lvl_body_adr"); UPI(static_body, "k_static_body");
   UPF(static_xpos, "k_static_xpos"); UPF(static_xquat, "k_static_xquat");
   UPI(root_origin_body, "k_root_origin_body"); UPI(body_orgslot, "k_body_orgslot"); UPF(root_origin_const, "k_root_origin_const");

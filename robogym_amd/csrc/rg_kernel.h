@@ -1226,6 +1226,14 @@ __device__ __forceinline__ void srow_hess(RgM m, RgLds& s, int r, float D) {
   for (int a = 0; a < 4; a++) { int da = s.ten_cdof[4 * t + a]; if (da == 255) continue;
     for (int b = 0; b < 4; b++) { int db = s.ten_cdof[4 * t + b]; if (db == 255) continue; atomicAdd(s.H + da * m.hs + db, D * s.tenJ[4 * t + a] * s.tenJ[4 * t + b]); } }
 }
+// the same in the per-tree block layout, lower triangle only (Hessian with the pattern of M)
+__device__ __forceinline__ void srow_hess_tree(RgLds& s, int r, float D) {
+  int desc = s.r_desc[r], t = (desc >> 6) & 31;
+  if (t == 31) { int d = desc & 63, blk = s.cblk[d]; atomicAdd(s.H + (blk & 0xFFFF) + d - ((blk >> 16) & 255), D); return; }
+  for (int a = 0; a < 4; a++) { int da = s.ten_cdof[4 * t + a]; if (da == 255) continue;
+    int blk = s.cblk[da];
+    for (int b = 0; b < 4; b++) { int db = s.ten_cdof[4 * t + b]; if (db == 255 || db > da) continue; atomicAdd(s.H + (blk & 0xFFFF) + db - ((blk >> 16) & 255), D * s.tenJ[4 * t + a] * s.tenJ[4 * t + b]); } }
+}
 __device__ __forceinline__ int npyr(int dim) { return dim == 1 ? 1 : 2 * (dim - 1); }
 __device__ __forceinline__ int nbasis(int dim) { return dim >= 4 ? 4 : (dim == 1 ? 1 : 3); }
 
@@ -1520,67 +1528,73 @@ __device__ __forceinline__ void rg_chol_solve(RgM m, RgLds& s, float* x) {
   if (i < n) x[i] = xi;
   SYNC();
 }
-// Tree-sparse factorisation M + scale*diag(extra) = L' D L over ALL dofs (mj_factorM) and x <- solve (mj_solveM), in the
-// per-tree block storage of s.M (work copy in s.H).  Only (dof, ancestor) entries exist and dofs of equal depth
-// are independent, so the factorisation is one lane-parallel pass per depth (deepest first), every lane taking
-// one (k, i, j) update M[i][j] -= M[k][i] M[k][j] / M[k][k] and adding it with an LDS atomic (several dofs share
-// ancestors; one wave issues them in lane order: deterministic).  The substitutions are the same passes over the
-// (k, i) pairs.  A lane loads all of its descriptors up front (one load latency), the passes themselves only
-// touch LDS.  Used for qacc_smooth = M^-1 qfrc_smooth and for the implicit-damping Euler solve.
+// Tree-sparse factorisation A = L' D L in the per-tree block storage (work copy in s.H) and its substitutions
+// (mj_factorM / mj_solveM).  Only (dof, ancestor) entries exist and dofs of equal depth are independent, so the
+// factorisation is one lane-parallel pass per depth (deepest first), every lane taking one (k, i, j) update
+// A[i][j] -= A[k][i] A[k][j] / A[k][k] and adding it with an LDS atomic (several dofs share ancestors; one wave
+// issues them in lane order: deterministic).  The substitutions are the same passes over the (k, i) pairs.  A lane
+// loads all of its descriptors up front (one load latency); the passes themselves only touch LDS.
+struct LtdlDesc { int t0[RG_LTDL_TRI_ROUNDS], t1[RG_LTDL_TRI_ROUNDS], pr[RG_LTDL_PAIR_ROUNDS], ntr, npr; };
+__device__ __forceinline__ void rg_ltdl_load(const int* tri, const int* pair, int ntr, int npr, LtdlDesc& L) {
+  L.ntr = ntr; L.npr = npr;
+#pragma unroll
+  for (int r = 0; r < RG_LTDL_TRI_ROUNDS; r++) { bool on = r < ntr; L.t0[r] = on ? tri[2 * (r * RG_WAVE + LANE)] : 0; L.t1[r] = on ? tri[2 * (r * RG_WAVE + LANE) + 1] : 0; }
+#pragma unroll
+  for (int r = 0; r < RG_LTDL_PAIR_ROUNDS; r++) L.pr[r] = r < npr ? pair[r * RG_WAVE + LANE] : -1;
+}
+// s.H (already holding A, lower triangle) <- its factor: D on the diagonal, L below it
+__device__ __forceinline__ void rg_ltdl_factor(RgLds& s, const LtdlDesc& L) {
+#pragma unroll
+  for (int r = 0; r < RG_LTDL_TRI_ROUNDS; r++) {   // (no break / continue: the loops must unroll fully, or the descriptor arrays end up in scratch)
+    if (r < L.ntr) {
+      if (L.t1[r] < 0) {
+        float v = s.H[L.t0[r] & 1023] * s.H[(L.t0[r] >> 10) & 1023] * rg_rcp(s.H[(L.t0[r] >> 20) & 1023]);
+        atomicAdd(s.H + (L.t1[r] & 1023), -v);
+      }
+      SYNC();
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RG_LTDL_PAIR_ROUNDS; r++)
+    if (r < L.npr && L.pr[r] != -1) { int a = (L.pr[r] >> 12) & 1023; s.H[a] *= rg_rcp(fmaxf(s.H[(L.pr[r] >> 22) & 1023], 1e-30f)); }
+  SYNC();
+}
+// x <- A^-1 x with the factor in s.H; lane i owns x[i], akk = address of its pivot (on: lane has a dof)
+__device__ __forceinline__ void rg_ltdl_solve(RgLds& s, const LtdlDesc& L, float* x, int i, bool on, int akk) {
+  float dk = on ? s.H[akk] : 1.f;
+  bool bad = on && !(dk > 1e-30f);
+  float idk = rg_rcp(fmaxf(dk, 1e-30f));
+#pragma unroll
+  for (int r = 0; r < RG_LTDL_PAIR_ROUNDS; r++) {   // x <- inv(L') x : x[i] -= L[k][i] x[k], deepest first
+    if (r < L.npr) {
+      if (L.pr[r] != -1) atomicAdd(x + ((L.pr[r] >> 6) & 63), -s.H[(L.pr[r] >> 12) & 1023] * x[L.pr[r] & 63]);
+      SYNC();
+    }
+  }
+  if (on) x[i] *= idk;                              // x <- inv(D) x
+  SYNC();
+#pragma unroll
+  for (int q = 0; q < RG_LTDL_PAIR_ROUNDS; q++) {   // x <- inv(L) x : x[k] -= L[k][i] x[i], shallowest first
+    const int r = RG_LTDL_PAIR_ROUNDS - 1 - q;
+    if (r < L.npr) {
+      if (L.pr[r] != -1) atomicAdd(x + (L.pr[r] & 63), -s.H[(L.pr[r] >> 12) & 1023] * x[(L.pr[r] >> 6) & 63]);
+      SYNC();
+    }
+  }
+  if (bad) s.status |= RG_STATUS_BAD_FACTOR;
+}
+// M + scale*diag(extra) over ALL dofs, then x <- solve: qacc_smooth = M^-1 qfrc_smooth and the implicit-damping Euler solve
 __device__ __forceinline__ void rg_ltdl_factor_solve(RgM m, RgLds& s, const float* extra_diag, float scale, float* x) {
-  int ntr = m.n_tri_rounds, npr = m.n_pair_rounds;
-  int t0[RG_LTDL_TRI_ROUNDS], t1[RG_LTDL_TRI_ROUNDS], pr[RG_LTDL_PAIR_ROUNDS];
-#pragma unroll
-  for (int r = 0; r < RG_LTDL_TRI_ROUNDS; r++) { bool on = r < ntr; t0[r] = on ? m.ltdl_tri[2 * (r * RG_WAVE + LANE)] : 0; t1[r] = on ? m.ltdl_tri[2 * (r * RG_WAVE + LANE) + 1] : 0; }
-#pragma unroll
-  for (int r = 0; r < RG_LTDL_PAIR_ROUNDS; r++) pr[r] = r < npr ? m.ltdl_pair[r * RG_WAVE + LANE] : -1;
+  LtdlDesc L;
+  rg_ltdl_load(m.ltdl_tri, m.ltdl_pair, m.n_tri_rounds, m.n_pair_rounds, L);
   for (int w = LANE; w < m.blkwords; w += RG_WAVE) s.H[w] = s.M[w];
   SYNC();
   int d = LANE; bool on = d < m.nv;
   int blk = on ? m.dof_blk[d] : 0, akk = (blk & 0xFFFF) + d - ((blk >> 16) & 255);
   if (on && extra_diag) s.H[akk] += scale * extra_diag[d];
   SYNC();
-  // factor: M[i][j] -= M[k][i] M[k][j] / M[k][k], deepest dofs first
-#pragma unroll
-  for (int r = 0; r < RG_LTDL_TRI_ROUNDS; r++) {   // (no break / continue: the loops must unroll fully, or the descriptor arrays end up in scratch)
-    if (r < ntr) {
-      if (t1[r] < 0) {
-        float v = s.H[t0[r] & 1023] * s.H[(t0[r] >> 10) & 1023] * rg_rcp(s.H[(t0[r] >> 20) & 1023]);
-        atomicAdd(s.H + (t1[r] & 1023), -v);
-      }
-      SYNC();
-    }
-  }
-  // L[k][i] = M[k][i] / D[k]; reciprocal pivots; a non-positive pivot flags the factorisation
-  bool bad = false;
-  float dk = on ? s.H[akk] : 1.f;
-  if (!(dk > 1e-30f)) { bad = on; dk = 1e-30f; }
-  float idk = rg_rcp(dk);
-#pragma unroll
-  for (int r = 0; r < RG_LTDL_PAIR_ROUNDS; r++)
-    if (r < npr && pr[r] != -1) { int a = (pr[r] >> 12) & 1023; s.H[a] *= rg_rcp(fmaxf(s.H[(pr[r] >> 22) & 1023], 1e-30f)); }
-  SYNC();
-  // x <- inv(L') x : x[i] -= L[k][i] x[k], deepest first
-#pragma unroll
-  for (int r = 0; r < RG_LTDL_PAIR_ROUNDS; r++) {
-    if (r < npr) {
-      if (pr[r] != -1) atomicAdd(x + ((pr[r] >> 6) & 63), -s.H[(pr[r] >> 12) & 1023] * x[pr[r] & 63]);
-      SYNC();
-    }
-  }
-  // x <- inv(D) x
-  if (on) x[d] *= idk;
-  SYNC();
-  // x <- inv(L) x : x[k] -= L[k][i] x[i], shallowest first
-#pragma unroll
-  for (int q = 0; q < RG_LTDL_PAIR_ROUNDS; q++) {
-    const int r = RG_LTDL_PAIR_ROUNDS - 1 - q;
-    if (r < npr) {
-      if (pr[r] != -1) atomicAdd(x + (pr[r] & 63), -s.H[(pr[r] >> 12) & 1023] * x[(pr[r] >> 6) & 63]);
-      SYNC();
-    }
-  }
-  if (bad) s.status |= RG_STATUS_BAD_FACTOR;
+  rg_ltdl_factor(s, L);
+  rg_ltdl_solve(s, L, x, d, on, akk);
 }
 
 struct LsPt { float cost, grad, hess; };
@@ -1644,6 +1658,25 @@ __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, int& nefc_out, int flag
   float tol = fmaxf(m.tolerance, RG_TOL_FLOOR);
   PFOR(i, nvc) { int d = s.c2d[i]; s.as[i] = s.qacc_smooth[d]; s.fs[i] = s.qfrc_smooth[d]; s.a[i] = s.warm[d]; }
   SYNC();
+  // When every contact couples the dofs of ONE chain only (a body against a static geom, or against one of its own
+  // ancestors), J'DJ has the pattern of M and the Hessian is factorised tree-sparsely like M instead of densely.
+#ifdef RG_NO_TREE_NEWTON
+  bool tree = false;
+#else
+  bool tree = m.tree_newton_ok != 0;
+#endif
+  if (tree) {
+    bool cross = false;
+    PFOR(c, ncon) {
+      int gg = m.pair_gg[s.c_pair[c]], b1 = m.geom_bodyid[gg & 255], b2 = m.geom_bodyid[gg >> 8];
+      uint32_t a0 = m.body_dofmask[2 * b1], a1 = m.body_dofmask[2 * b1 + 1], c0 = m.body_dofmask[2 * b2], c1 = m.body_dofmask[2 * b2 + 1];
+      cross = cross || (((a0 & ~c0) | (a1 & ~c1)) != 0 && ((c0 & ~a0) | (c1 & ~a1)) != 0);
+    }
+    tree = __ballot(cross) == 0;
+  }
+  LtdlDesc LT;
+  if (tree) rg_ltdl_load(m.ltdl_tri_c, m.ltdl_pair_c, m.n_tri_rounds_c, m.n_pair_rounds_c, LT); else { LT.ntr = 0; LT.npr = 0; }
+  int cblk_own = LANE < nvc ? s.cblk[LANE] : 0, akk_own = (cblk_own & 0xFFFF) + LANE - ((cblk_own >> 16) & 255);
   // warm start: the better of qacc_smooth and qacc_warmstart (evaluated last, so Ma / jar are left valid for it)
   float cost_pick[2];
   for (int pass = 0; pass < 2; pass++) {
@@ -1681,6 +1714,12 @@ __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, int& nefc_out, int flag
     PROFS(12);
     if (!have_factor || flags_changed) {
     have_factor = true;
+    if (tree) {
+      // H <- M in the block layout (the factor only uses the lower triangle), then + J' D J on the same addresses
+      { const rgf4* M4 = (const rgf4*)s.M; rgf4* H4 = (rgf4*)s.H; for (int w = LANE; w < (m.blkwords >> 2); w += RG_WAVE) H4[w] = M4[w]; }
+      SYNC();
+      PFOR(r, ns) if (s.r_D[r] > 0 && s.r_quad[r]) srow_hess_tree(s, r, s.r_D[r]);
+    } else {
     // H = M + J' D J over the quadratic rows (LDS atomics from one wave: in-order, deterministic)
     {  // H <- M expanded from the per-tree blocks: one 16-byte store per (row, 4-column chunk), zeros outside the tree
       int hs4 = hs >> 2; rgf4* H4 = (rgf4*)s.H;
@@ -1696,6 +1735,7 @@ __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, int& nefc_out, int flag
     }
     SYNC();
     PFOR(r, ns) if (s.r_D[r] > 0 && s.r_quad[r]) srow_hess(m, s, r, s.r_D[r]);
+    }
     for (int c = 0; c < ncon; c++) {
       int dim = s.c_dim[c], nnz = s.c_nnz[c], nb = nbasis(dim); float D = s.c_D[c];
       // C = P' D_act P in the basis (normal, t1, t2, spin): only first row/col and the diagonal are non-zero
@@ -1711,15 +1751,17 @@ __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, int& nefc_out, int flag
         if (b >= nnz) continue;
         float na = Bc[a], nbv = Bc[b], v = cn * na * nbv;
         for (int k = 0; k + 1 < nb; k++) { float ta = Bc[(k + 1) * nnz + a], tb = Bc[(k + 1) * nnz + b]; v += ck[k] * (na * tb + ta * nbv) + cd[k] * ta * tb; }
-        atomicAdd(s.H + s.c_idx[c * RG_W + a] * hs + s.c_idx[c * RG_W + b], v);
+        int ia = s.c_idx[c * RG_W + a], ib = s.c_idx[c * RG_W + b];
+        if (!tree) atomicAdd(s.H + ia * hs + ib, v);
+        else if (ia >= ib) { int blk = s.cblk[ia]; atomicAdd(s.H + (blk & 0xFFFF) + ib - ((blk >> 16) & 255), v); }
       }
     }
     SYNC();
     PROFS(13);
-    rg_chol(m, s);
+    if (tree) rg_ltdl_factor(s, LT); else rg_chol(m, s);
     }
     PROFS(14);
-    rg_chol_solve(m, s, s.search);
+    if (tree) rg_ltdl_solve(s, LT, s.search, LANE, LANE < nvc, akk_own); else rg_chol_solve(m, s, s.search);
     PROFS(15);
     // exact line search along `search`
     rg_M_mul(m, s, s.search, s.Mv);

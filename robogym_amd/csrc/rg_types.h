@@ -55,6 +55,8 @@ struct RgModelDev {
   const int *lvl_body, *lvl_body_adr, *static_body;
   const int *ltdl_tri, *ltdl_pair;   // tree-sparse L'DL passes of M: rounds of 64 descriptors (kernel_tables.py)
   int n_tri_rounds, n_pair_rounds;
+  const int *ltdl_tri_c, *ltdl_pair_c;   // the same for the constrained trees, vectors indexed by compact dof (Newton Hessian with tree pattern)
+  int n_tri_rounds_c, n_pair_rounds_c, tree_newton_ok;
   const int* subtree_mask;      // [nbody] bit c: body c belongs to the subtree rooted at the body (self included)
   const float* kin_rec;         // [len(lvl_body)][RG_KINREC] per level slot: body, parent, first joint and their constants (rg_api.hip)
   const float *static_xpos, *static_xquat;

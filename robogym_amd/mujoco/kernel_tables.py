@@ -365,26 +365,47 @@ def derive_kernel_tables(model, max_row_nnz=16):
         return int(dof_blk[a] & 0xFFFF) + (b - int((dof_blk[a] >> 16) & 255))
 
     assert blk_words < 1024
-    tri_rounds, pair_rounds = [], []
-    for lev in range(int(depth.max()), 0, -1):
-        tri, pr = [], []
-        for k in range(nv):
-            if depth[k] != lev:
-                continue
-            anc, i = [], dpar[k]
-            while i >= 0:
-                anc.append(int(i)); i = dpar[i]
-            for i in anc:
-                pr.append(k | (i << 6) | (addr(k, i) << 12) | (addr(k, k) << 22))
-                for j in anc:
-                    if j <= i:
-                        tri.append((addr(k, i) | (addr(k, j) << 10) | (addr(k, k) << 20), addr(i, j) | (1 << 31)))
-        for lst, rounds, pad in ((tri, tri_rounds, (0, 0)), (pr, pair_rounds, -1)):
-            for r0 in range(0, len(lst), 64):
-                chunk = lst[r0:r0 + 64]
-                rounds.append(chunk + [pad] * (64 - len(chunk)))
-    A["k_ltdl_tri"] = np.array(tri_rounds, dtype=np.int64).astype(np.uint32).view(np.int32).reshape(-1, 2) if tri_rounds else np.zeros((0, 2), np.int32)
-    A["k_ltdl_pair"] = np.array(pair_rounds, dtype=np.int64).astype(np.uint32).view(np.int32).reshape(-1) if pair_rounds else np.zeros(0, np.int32)
+    def ltdl_rounds(dofs, index_of):
+        """descriptor rounds for the trees spanned by `dofs`; pair fields k, i are written as index_of[dof]"""
+        tri_rounds, pair_rounds = [], []
+        for lev in range(int(depth.max()), 0, -1):
+            tri, pr = [], []
+            for k in dofs:
+                if depth[k] != lev:
+                    continue
+                anc, i = [], dpar[k]
+                while i >= 0:
+                    anc.append(int(i)); i = dpar[i]
+                for i in anc:
+                    pr.append(int(index_of[k]) | (int(index_of[i]) << 6) | (addr(k, i) << 12) | (addr(k, k) << 22))
+                    for j in anc:
+                        if j <= i:
+                            tri.append((addr(k, i) | (addr(k, j) << 10) | (addr(k, k) << 20), addr(i, j) | (1 << 31)))
+            for lst, rounds, pad in ((tri, tri_rounds, (0, 0)), (pr, pair_rounds, -1)):
+                for r0 in range(0, len(lst), 64):
+                    chunk = lst[r0:r0 + 64]
+                    rounds.append(chunk + [pad] * (64 - len(chunk)))
+        t = np.array(tri_rounds, dtype=np.int64).astype(np.uint32).view(np.int32).reshape(-1, 2) if tri_rounds else np.zeros((0, 2), np.int32)
+        q = np.array(pair_rounds, dtype=np.int64).astype(np.uint32).view(np.int32).reshape(-1) if pair_rounds else np.zeros(0, np.int32)
+        return t, q
+
+    A["k_ltdl_tri"], A["k_ltdl_pair"] = ltdl_rounds(list(range(nv)), list(range(nv)))
+    # the same passes for the Newton Hessian when it has the tree pattern (every contact couples one dof chain only):
+    # constrained trees only, vectors indexed by compact dof
+    A["k_ltdl_tri_c"], A["k_ltdl_pair_c"] = ltdl_rounds([d for d in range(nv) if d2c[d] >= 0], d2c)
+    # static precondition: every tendon's dof support lies on one chain (its J'DJ block then fits the tree pattern)
+    chain_ok = 1
+    for t in range(len(A["k_ten_dofs"])):
+        ds = sorted(int(d) for d in A["k_ten_dofs"][t] if d >= 0)
+        for a_ in ds:
+            for b_ in ds:
+                if a_ > b_:
+                    i = a_
+                    while i >= 0 and i != b_:
+                        i = dpar[i]
+                    if i != b_:
+                        chain_ok = 0
+    A["k_tree_newton_ok"] = _i32([chain_ok])
     A["k_dims"] = _i32([nlevel, ndl, len(Mi), len(pairs), len(A["k_static_body"]), max_nnz])
     return model
 
