@@ -5,7 +5,7 @@ R=${1:-r01}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python bench.py --steps 50 --warmup 5 > gpurun_out/bench_$R.json 2> gpurun_out/bench_$R.err
+python bench.py > gpurun_out/bench_$R.json 2> gpurun_out/bench_$R.err
 tail -1 gpurun_out/bench_$R.json
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$R -o $R --output-format csv -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_prof_$R.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_fetch_$R -o fetch --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/pmc_fetch_$R.log 2>&1
