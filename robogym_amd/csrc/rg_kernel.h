@@ -1405,10 +1405,13 @@ __device__ __forceinline__ void rg_JT_force(RgM m, RgLds& s, float* dst) {
 // y = M x in the compact dof space: row i of the tree block of dof c2d[i] against that tree's slice of x
 __device__ __forceinline__ void rg_M_mul(RgM m, RgLds& s, const float* x, float* y) {
   PFOR(i, m.nvc) {
-    int blk = s.cblk[i], n = (blk >> 24) & 255; const float* row = s.M + (blk & 0xFFFF); const float* xs = x + ((blk >> 16) & 255);
+    int blk = s.cblk[i], n = (blk >> 24) & 255; const rgf4* row = (const rgf4*)(s.M + (blk & 0xFFFF)); const float* xs = x + ((blk >> 16) & 255);
     float v = 0;
-#pragma unroll 4
-    for (int k = 0; k < n; k++) v += row[k] * xs[k];
+    int n4 = n >> 2;   // block rows are 16-byte aligned and padded to a multiple of four columns
+#pragma unroll 2
+    for (int c = 0; c < n4; c++) { rgf4 r = row[c]; v += r.x * xs[4 * c] + r.y * xs[4 * c + 1] + r.z * xs[4 * c + 2] + r.w * xs[4 * c + 3]; }
+    const float* rs = (const float*)row;
+    for (int k = 4 * n4; k < n; k++) v += rs[k] * xs[k];
     y[i] = v;
   }
   SYNC();
