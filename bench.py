@@ -7,8 +7,9 @@ Workload: BASELINE.json configs[1] — dactyl/locked (Shadow hand + locked cube,
 GPU (weak scaling), synthetic iid U(-1,1)^20 relative actions, 1 env-step = action map + 10 mj_step
 substeps (dt 0.008) + the 3 state-less forward ticks + observation row + goal distance + reward /
 tracker logic.  State is resident in HBM when the timed region starts (after `env.reset()`).
-One JSON line on stdout (rank 0).  With N>1 every step ends with the RCCL all-gather of the
-observation rows over xGMI (the only exchange the path has).
+One JSON line on stdout (rank 0).  With N>1 every step starts the RCCL all-gather of its observation
+rows over xGMI (the only exchange the path has); it overlaps with the next step and is awaited before the
+following one is started, the last one inside the timed region.
 """
 import argparse
 import json
@@ -96,7 +97,7 @@ def main():
     def one_step():
         a = torch.rand((B, 20), generator=gen, device=dev) * 2 - 1
         obs, reward, done, info = env.step(a)
-        gather(env._obs_buf)  # RCCL all-gather of the observation rows when N > 1
+        gather.start(env._obs_buf)  # RCCL all-gather of the observation rows when N > 1, overlapped with the next step
         return done
 
     for _ in range(args.warmup):
@@ -124,6 +125,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
+    gather.finish()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize(dev)

@@ -17,6 +17,9 @@ class ShardedObservationGather:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.local_batch = local_batch
         self.buffer: Optional[torch.Tensor] = None
+        self._staging: Optional[torch.Tensor] = None
+        self._work = None
+        self._last: Optional[torch.Tensor] = None
         if self.world > 1:
             self.buffer = torch.empty((self.world * local_batch, obs_dim), dtype=torch.float32, device=device)
 
@@ -25,6 +28,27 @@ class ShardedObservationGather:
         if self.world == 1:
             return local_obs_rows
         dist.all_gather_into_tensor(self.buffer, local_obs_rows.contiguous(), group=self.group)
+        return self.buffer
+
+    def start(self, local_obs_rows: torch.Tensor):
+        """Overlapped variant: snapshot the rows into a staging buffer (so the next env.step may overwrite the
+        live buffer) and start the all-gather without making the compute stream wait for it; `finish()` returns
+        the gathered tensor of the PREVIOUS `start()`.  At most one gather is in flight."""
+        if self.world == 1:
+            self._last = local_obs_rows
+            return
+        self.finish()
+        if self._staging is None:
+            self._staging = torch.empty_like(local_obs_rows)
+        self._staging.copy_(local_obs_rows)
+        self._work = dist.all_gather_into_tensor(self.buffer, self._staging, group=self.group, async_op=True)
+
+    def finish(self) -> Optional[torch.Tensor]:
+        if self.world == 1:
+            return self._last
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
         return self.buffer
 
     def global_env_ids(self) -> torch.Tensor:

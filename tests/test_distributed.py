@@ -29,6 +29,8 @@ def _worker(rank, world, port, out_dir):
     gen = torch.Generator(); gen.manual_seed(rank)
     obs, reward, done, info = env.step(torch.rand((2, 20), generator=gen) * 2 - 1)
     full = gather(env._obs_buf)
+    gather.start(env._obs_buf)                       # overlapped variant: same result, one gather in flight
+    assert torch.equal(gather.finish(), full)
     assert full.shape == (world * 2, env.mujoco_simulation.obs_dim)
     assert torch.equal(full[2 * rank:2 * rank + 2], env._obs_buf)
     np.save(os.path.join(out_dir, "full_%d.npy" % rank), full.numpy())
