@@ -1739,15 +1739,23 @@ __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, int& nefc_out, int flag
     SYNC();
     PFOR(r, ns) if (s.r_D[r] > 0 && s.r_quad[r]) srow_hess(m, s, r, s.r_D[r]);
     }
-    for (int c = 0; c < ncon; c++) {
-      int dim = s.c_dim[c], nnz = s.c_nnz[c], nb = nbasis(dim); float D = s.c_D[c];
-      // C = P' D_act P in the basis (normal, t1, t2, spin): only first row/col and the diagonal are non-zero
-      float cn = 0, ck[3] = {0, 0, 0}, cd[3] = {0, 0, 0};
+    // per contact, C = P' D_act P in the basis (normal, t1, t2, spin) has only its first row/column and its diagonal
+    // non-zero: cn, ck[3], cd[3].  One lane per contact computes them (c_bdot/c_bfrc are free between J products).
+    float* cf = s.c_bdot;
+    PFOR(c, ncon) {
+      int dim = s.c_dim[c]; float D = s.c_D[c], cn = 0, ck[3] = {0, 0, 0}, cd[3] = {0, 0, 0};
       if (dim == 1) cn = s.p_quad[6 * c] ? D : 0.f;
       else for (int k = 0; k < dim - 1; k++) {
         float mu = s.c_mu[3 * c + k]; int qp = s.p_quad[6 * c + 2 * k], qm = s.p_quad[6 * c + 2 * k + 1];
         cn += D * (qp + qm); ck[k] = D * mu * (qp - qm); cd[k] = D * mu * mu * (qp + qm);
       }
+      float* o = cf + 8 * c; o[0] = cn; o[1] = ck[0]; o[2] = ck[1]; o[3] = ck[2]; o[4] = cd[0]; o[5] = cd[1]; o[6] = cd[2];
+    }
+    SYNC();
+    for (int c = 0; c < ncon; c++) {
+      int nnz = s.c_nnz[c], nb = nbasis(s.c_dim[c]);
+      const float* o = cf + 8 * c;
+      float cn = o[0], ck[3] = {o[1], o[2], o[3]}, cd[3] = {o[4], o[5], o[6]};
       if (cn == 0) continue;
       const float* Bc = s.c_pool + s.c_off[c];
       for (int a = LANE >> 4, b = LANE & 15; a < nnz; a += 4) {   // nnz <= RG_W < 16: 4 rows of the block per pass
