@@ -42,24 +42,21 @@ def algorithmic_bytes_per_env_step(m, ncon, nefc, iters, nsub, obs_dim):
 
 
 def cpu_baseline(seconds=12.0):
-    """The CPU oracle (double-precision C restatement, ONE core) stepping the same env: kind 'port'."""
-    from oracle.env_oracle import OracleLockedEnvPhysics
-    from robogym_amd.envs.dactyl.locked import load_locked_model
+    """The CPU oracle (double-precision C restatement) stepping the same env on EVERY host core, one env per
+    process; kind 'port'.  oracle/cpu_baseline.py."""
+    from oracle import cpu_baseline as cb
 
-    ora = OracleLockedEnvPhysics(load_locked_model())
-    ora.settle(30)
-    rng = np.random.RandomState(20200901 + 1)
-    n = 0
-    t0 = time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        for _ in range(20):
-            ora.env_step(rng.uniform(-1, 1, 20))
-            n += 1
-            if ora.sim.qpos[2] < -0.1:  # dropped: start over from a settled pose
-                ora.sim.reset(); ora.settle(30); ora.prev_dist = None
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": "%d env-steps of one dactyl/locked env (10 substeps + 3 forwards each), same action distribution, %.1f s on 1 host core; CPU restatement, not mujoco-py" % (n, dt)}
+    return cb.run(seconds)
+
+
+def kernel_source_hash():
+    """Identifies the kernel build a committed PMC figure belongs to (profiles/hbm_traffic.json carries it)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("rg_kernel.h", "rg_api.hip", "rg_types.h"):
+        h.update(open(os.path.join(ROOT, "robogym_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -69,35 +66,55 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8192, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipelined-reset", action="store_true", help="finished episodes run the reset recipe inside the step launches")
+    ap.add_argument("--sort-dispatch", type=int, default=1, help="dispatch the envs longest-expected-first (previous step's cycles)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # TEST HOOK (tests/test_distributed.py): run this very code path on CPU, 2 ranks, gloo, kernel source on the emulation harness
+    emul_path = os.environ.get("RG_BENCH_EMUL_LIB")
+    lib = None
+    if emul_path:
+        from robogym_amd import _native
+        lib = _native.bind(emul_path)
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        if emul_path:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
-    from robogym_amd.envs.dactyl.locked import make_simple_env
+    from robogym_amd.envs.dactyl.locked import LockedEnvConstants, make_simple_env
 
     B = args.batch
-    env = make_simple_env(batch_size=B, device=dev, starting_seed=20200901 + 1 + rank)
+    kw = dict(lib=lib, constants=LockedEnvConstants(mujoco_substeps=1, reset_initial_steps=1, n_random_initial_steps=1)) if emul_path else {}
+    env = make_simple_env(batch_size=B, device=dev, starting_seed=20200901 + 1 + rank, pipelined_reset=args.pipelined_reset,
+                          sort_dispatch=bool(args.sort_dispatch) and not emul_path, **kw)
     env.reset()
     sim = env.mujoco_simulation
     gen = torch.Generator(device=dev)
     gen.manual_seed(20200901 + 1 + 1000 * rank)
     from robogym_amd.distributed import ShardedObservationGather
 
-    gather = ShardedObservationGather(B, sim.obs_dim, dev)
+    gather = ShardedObservationGather(B, env.packed_dim, dev)
+
+    def on_palm_fraction():
+        return float(((sim.cube_body_z + sim.get_qpos("cube_position")[:, 2]) > 0.04).float().mean().item())
 
     def one_step():
         a = torch.rand((B, 20), generator=gen, device=dev) * 2 - 1
         obs, reward, done, info = env.step(a)
-        gather.start(env._obs_buf)  # RCCL all-gather of the observation rows when N > 1, overlapped with the next step
+        # the only exchange of the path: the full observation (166 scalars) with reward and done riding in
+        # the same buffer, all-gathered over RCCL/xGMI when N > 1, overlapped with the next step
+        gather.start(env.packed_observation(reward, done))
         return done
 
     for _ in range(args.warmup):
@@ -105,37 +122,43 @@ def main():
     sim.set_field(7, torch.zeros((B, 4), device=dev))  # reset kernel statistics
     status_before = int(sim.status.max().item())       # capacity flags raised by the reset recipe / warm-up (sticky bits)
     sim.set_field(6, torch.zeros((B, 1), dtype=torch.int32, device=dev))
+    on_palm_start = on_palm_fraction()
     # physics-kernel timing with events on the launch stream
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    mk_event = (lambda: torch.cuda.Event(enable_timing=True)) if not emul_path else (lambda: None)
+    ev = [(mk_event(), mk_event()) for _ in range(args.steps)]
     orig_env_step = sim.env_step
     state = {"i": 0}
 
     def timed_env_step(*a, **k):
         if k.get("action") is not None:
-            s, e = ev[state["i"]]
-            s.record(); orig_env_step(*a, **k); e.record()
+            s, e = ev[state["i"] % len(ev)]
+            if s is not None: s.record()
+            orig_env_step(*a, **k)
+            if e is not None: e.record()
             state["i"] += 1
         else:
             orig_env_step(*a, **k)
 
     sim.env_step = timed_env_step
+    sync = (lambda: torch.cuda.synchronize(dev)) if not emul_path else (lambda: None)
     if distributed:
         dist.barrier()
-    torch.cuda.synchronize(dev)
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
     gather.finish()
     if distributed:
         dist.barrier()
-    torch.cuda.synchronize(dev)
+    sync()
     elapsed = time.perf_counter() - t0
     sim.env_step = orig_env_step
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+    kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev])) if not emul_path else 1e3 * elapsed / args.steps
+    on_palm_end = on_palm_fraction()
     stats = sim.get_field(7).sum(0).cpu().numpy()
     nsub_total = max(stats[3], 1.0)
     ncon, nefc, iters = float(stats[0] / nsub_total), float(stats[1] / nsub_total), float(stats[2] / nsub_total)
@@ -146,22 +169,28 @@ def main():
         b_step, b_sub = algorithmic_bytes_per_env_step(env.model, ncon, nefc, iters, sim.n_substeps, 166)
         achieved = B * b_step / (kern_ms * 1e-3)
         # HBM bytes per launch from the round's PMC passes (tools/profile_round.sh + summarize_profile.py); counters
-        # cannot be read from inside this process, so the figure is the committed one for the same workload, or null
+        # cannot be read from inside this process, so the figure is the committed one IF it was measured on this very
+        # kernel source (hash stamp) and batch size, else null
         traffic, tnote = None, ""
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-            if int(t["batch_per_gpu"]) == B:
+            if int(t["batch_per_gpu"]) == B and t.get("kernel_source_hash") == kernel_source_hash():
                 traffic, tnote = float(t["bytes_per_launch"]) / 1e9, "; traffic (GB per launch) from profiles/hbm_traffic.json: " + t["source"]
+            else:
+                tnote = "; traffic null: profiles/hbm_traffic.json was measured on another kernel build"
         except (OSError, ValueError, KeyError):
             pass
         out = {
-            "metric": "env-steps/sec (whole node) dactyl/locked batch 8192; qpos Linf vs MuJoCo",
+            "metric": "env-steps/sec (whole node) dactyl/locked batch 8192; qpos L\u221e vs MuJoCo (as restated by the in-repo CPU oracle: parity unpinned)",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "dactyl/locked (Shadow hand + locked cube, nv=36), batch %d per GPU, iid U(-1,1) relative actions, 10 substeps x 0.008 s" % B,
                        "batch_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d (envs sharded, RCCL all-gather of obs rows)" % world,
-                       "mean_ncon": float(ncon), "mean_nefc": float(nefc), "mean_newton_iters": float(iters), "status_bits": status, "status_bits_before_timed_region": status_before},
+                       "mean_ncon": float(ncon), "mean_nefc": float(nefc), "mean_newton_iters": float(iters), "status_bits": status, "status_bits_before_timed_region": status_before,
+                       "cube_on_palm_fraction": {"start_of_timed_region": on_palm_start, "end_of_timed_region": on_palm_end},
+                       "pipelined_reset": bool(args.pipelined_reset), "sort_dispatch": bool(args.sort_dispatch),
+                       "gathered_row": "obs 166 + reward 3 + done 1 = %d floats per env" % env.packed_dim},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
                          "kernel": "rg_step_kernel", "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": b_step, "algorithmic_bytes_per_substep": b_sub,
                          "note": "algorithmic bytes = SURVEY 8(d) stage-boundary model with measured ncon/nefc/iters; the fused kernel keeps stage arrays in LDS, so real HBM traffic is far below the algorithmic figure" + tnote},

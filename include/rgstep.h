@@ -36,7 +36,9 @@ enum {
   RG_F_TIME = 5,      /* float [B]         sim.data.time                                                   */
   RG_F_STATUS = 6,    /* uint32 [B]        sticky per-env status bits (RG_STATUS_*)                        */
   RG_F_STATS = 7,     /* float [B][4]      accumulated ncon, nefc, Newton iterations, substeps             */
-  RG_F_DEBUG = 8      /* float [B][rg_debug_size()] stage dump of the first substep (flags & 1)            */
+  RG_F_DEBUG = 8,     /* float [B][rg_debug_size()] stage dump of the first substep (flags & 1)            */
+  RG_F_COST = 9,      /* float [B]         shader cycles the last rg_batch_step_ex spent on the env (dispatch ordering) */
+  RG_F_PAIRLB = 10    /* float [B][npair]  collision cache: lower bounds on the pair distances (0 = unknown). Not state. */
 };
 
 #define RG_STATUS_BAD_STATE 1u
@@ -44,10 +46,14 @@ enum {
 #define RG_STATUS_CAND_FULL 4u
 #define RG_STATUS_ROW_FULL 8u
 #define RG_STATUS_BAD_FACTOR 16u
+#define RG_STATUS_BAD_ACTION 32u /* a non-finite entry in the env's action row: the row was ignored (ctrl kept) */
 
 /* Replaces mujoco_py.load_model_from_xml (mujoco_xml.py:259): `blob` is the "RGMODEL1" flat model
  * produced by the host-side MJCF compiler (robogym_amd/mujoco/model_blob.py). Returns NULL on error. */
 rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen);
+/* The same with the HIP device ordinal that shall hold the model tables (rg_model_create uses the calling
+ * thread's current device).  A batch must be created on the device of its model. */
+rg_model* rg_model_create_on(const void* blob, size_t nbytes, int device, char* err, int errlen);
 void rg_model_free(rg_model* m);
 /* sizes: out[0..4] = nq, nv, nu, nbody, nsite */
 int rg_model_dims(const rg_model* m, int* out);
@@ -95,6 +101,27 @@ int rg_batch_copy_rows(rg_batch* b, int field, const void* src_dev, const int* m
  *   stream       hipStream_t (NULL = default stream).  Asynchronous. */
 int rg_batch_step(rg_batch* b, const float* action_dev, const float* goal_quat_dev, float* obs_dev, float* goal_dist_dev,
                   const int* active_dev, int nsubsteps, int nforward_ticks, int flags, void* stream);
+/* The same launch with every optional per-env input spelled out.  Arrays are device pointers or NULL.
+ *   hold_dev    int [B]: envs with != 0 ignore their action row and keep the stored ctrl row (what the reference
+ *               does while a reset recipe scripts ctrl, locked.py:197-225); replaces the in-band NaN convention
+ *   nticks_dev  int [B]: per-env number of state-less forwards after the substeps (overrides nforward_ticks):
+ *               `SimulationInterface.step` has one (simulation_interface.py:185), `RobotEnv.step` three
+ *   order_dev   int [B]: permutation, workgroup i steps env order_dev[i]; with RG_F_COST of the previous step
+ *               sorted descending the longest envs are dispatched first (shorter tail of the launch)
+ * A row of action_dev with a non-finite entry raises RG_STATUS_BAD_ACTION for that env and is ignored. */
+typedef struct rg_step_args {
+  const float* action_dev; const float* goal_quat_dev; float* obs_dev; float* goal_dist_dev;
+  const int* active_dev; const int* hold_dev; const int* nticks_dev; const int* order_dev;
+  int nsubsteps, nforward_ticks, flags;
+  void* stream;
+} rg_step_args;
+int rg_batch_step_ex(rg_batch* b, const rg_step_args* args);
+/* Device address of a field's [B][n] buffer inside the batch (library-owned; valid until rg_batch_free) and its
+ * row length in 4-byte words: zero-copy views for callers that live on the same device (torch tensors over
+ * `sim.data.*`, simulation_interface.py:128-172).  Writers of RG_F_QPOS must zero the env's RG_F_PAIRLB row. */
+void* rg_batch_field_ptr(rg_batch* b, int field, int* row_words);
+/* number of static collision pairs (row length of RG_F_PAIRLB) */
+int rg_model_npair(const rg_model* m);
 /* Collision unit-test hook (no reference counterpart; mjc_Convex is internal to MuJoCo): runs the
  * kinematics of every env's stored qpos and one MPR penetration query between geoms g1, g2 inflated
  * by margin/2 each.  out_dev float [B][8] = hit, depth, direction3 (g1 -> g2), position3. */

@@ -685,8 +685,14 @@ static double origin_tri_dist2(const double* a, const double* b, const double* c
   copy3(w, a); addscl3(w, ab, v); addscl3(w, ac, u);
   return dot3(w, w);
 }
-static int ro_mpr_libccd_tridist = 0;
+/* 1 (default): libccd verbatim, which is what MuJoCo 2.0's mjc_Convex runs.  0: the HIP kernel's documented
+   deviation (portal plane), kept so that the size of the deviation can be measured (DESIGN.md "Deviations"). */
+static int ro_mpr_libccd_tridist = 1;
 void ro_set_mpr_libccd_tridist(int on) { ro_mpr_libccd_tridist = on; }
+/* 1 (default): box-box pairs go through the dedicated multi-point routine (MuJoCo: mjc_BoxBox).  0: through the
+   generic convex (MPR, one contact) path, the HIP kernel's documented deviation. */
+static int ro_boxbox_multipoint = 1;
+void ro_set_boxbox_multipoint(int on) { ro_boxbox_multipoint = on; }
 static void find_pos(const ccd_support* p, double* pos) {
   double dir[3], b[4], t[3];
   portal_dir(p, dir);
@@ -778,7 +784,7 @@ static int mpr_penetration(const ccd_obj* o1, const ccd_obj* o2, int max_iter, d
         if (ccd_zero(*depth)) zero3(dir_out);
         else { copy3(dir_out, w); normalize3(dir_out); }
       } else {
-        /* default: the portal PLANE (its normal and distance).  Identical to the above whenever the
+        /* kernel variant: the portal PLANE (its normal and distance).  Identical to the above whenever the
            projection lies inside the triangle, independent of which triangle of the supporting plane
            the refinement ended on, and a tighter bound on the penetration depth.  (DESIGN.md "MPR".) */
         *depth = (dot3(p[1].v, dir) + dot3(p[2].v, dir) + dot3(p[3].v, dir)) / 3.0;
@@ -821,6 +827,112 @@ static int add_contact(const ro_model* m, ro_data* d, int g1, int g2, double dis
   return 1;
 }
 
+/* engine_collision_box.c: mjc_BoxBox — multi-point box-box contacts (up to 8).  MuJoCo 2.0's routine is closed
+ * source; what is restated here is the scheme its documentation describes and that every engine of that lineage
+ * uses (separating-axis test over the 15 candidate axes; edge-edge: one contact at the closest points of the two
+ * edges; face: the incident face clipped against the reference face, one contact per clipped vertex within the
+ * margin), with MuJoCo's contact conventions: frame normal from geom1 to geom2, dist < 0 in penetration, position
+ * midway between the two surfaces, contacts included while dist < margin.  PROVENANCE: recalled, unverified. */
+static void box_axis(double* a, const double* R, int j) { a[0] = R[j]; a[1] = R[3 + j]; a[2] = R[6 + j]; }
+static int clip_poly(double (*poly)[2], int n, int axis, double sign, double lim) {
+  /* Sutherland-Hodgman against the half plane sign * x[axis] <= lim */
+  double out[16][2]; int no = 0;
+  for (int i = 0; i < n; i++) {
+    const double *a = poly[i], *b = poly[(i + 1) % n];
+    double da = sign * a[axis] - lim, db = sign * b[axis] - lim;
+    if (da <= 0) { out[no][0] = a[0]; out[no][1] = a[1]; no++; }
+    if ((da < 0 && db > 0) || (da > 0 && db < 0)) {
+      double t = da / (da - db);
+      out[no][0] = a[0] + t * (b[0] - a[0]); out[no][1] = a[1] + t * (b[1] - a[1]); no++;
+    }
+    if (no >= 15) break;
+  }
+  for (int i = 0; i < no; i++) { poly[i][0] = out[i][0]; poly[i][1] = out[i][1]; }
+  return no;
+}
+static void collide_box_box(const ro_model* m, ro_data* d, int g1, int g2, double margin, double gap) {
+  const double *p1 = d->geom_xpos + 3 * g1, *p2 = d->geom_xpos + 3 * g2, *R1 = d->geom_xmat + 9 * g1, *R2 = d->geom_xmat + 9 * g2;
+  const double *A = m->geom_size + 3 * g1, *B = m->geom_size + 3 * g2;
+  double t[3], ax1[3][3], ax2[3][3], R[3][3], Q[3][3], ta[3], tb[3];
+  sub3(t, p2, p1);
+  for (int j = 0; j < 3; j++) { box_axis(ax1[j], R1, j); box_axis(ax2[j], R2, j); }
+  for (int i = 0; i < 3; i++) { ta[i] = dot3(t, ax1[i]); tb[i] = dot3(t, ax2[i]); for (int j = 0; j < 3; j++) { R[i][j] = dot3(ax1[i], ax2[j]); Q[i][j] = fabs(R[i][j]); } }
+  double best = -1e300, n[3] = {0, 0, 0}; int code = 0;
+  for (int i = 0; i < 3; i++) {   /* face normals of box 1 */
+    double s = fabs(ta[i]) - (A[i] + B[0] * Q[i][0] + B[1] * Q[i][1] + B[2] * Q[i][2]);
+    if (s > margin) return;
+    if (s > best) { best = s; code = 1 + i; scl3(n, ax1[i], ta[i] < 0 ? -1 : 1); }
+  }
+  for (int j = 0; j < 3; j++) {   /* face normals of box 2 */
+    double s = fabs(tb[j]) - (B[j] + A[0] * Q[0][j] + A[1] * Q[1][j] + A[2] * Q[2][j]);
+    if (s > margin) return;
+    if (s > best) { best = s; code = 4 + j; scl3(n, ax2[j], tb[j] < 0 ? -1 : 1); }
+  }
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {   /* edge x edge */
+    double c[3]; cross3(c, ax1[i], ax2[j]);
+    double l = norm3(c);
+    if (l < 1e-8) continue;   /* parallel edges: covered by the face axes */
+    scl3(c, c, 1.0 / l);
+    int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    double ra = A[i1] * fabs(dot3(c, ax1[i1])) + A[i2] * fabs(dot3(c, ax1[i2]));
+    double rb = B[j1] * fabs(dot3(c, ax2[j1])) + B[j2] * fabs(dot3(c, ax2[j2]));
+    double tc = dot3(t, c), s = fabs(tc) - (ra + rb);
+    if (s > margin) return;
+    /* a face axis is preferred unless the edge axis is clearly better (the usual 5 % hysteresis) */
+    if (s > best + 0.05 * fabs(best) + 1e-12 && s > best) { best = s; code = 7 + 3 * i + j; scl3(n, c, tc < 0 ? -1 : 1); }
+  }
+  if (code >= 7) {
+    int i = (code - 7) / 3, j = (code - 7) % 3;
+    double pa[3], pb[3];
+    copy3(pa, p1); copy3(pb, p2);
+    for (int k = 0; k < 3; k++) { if (k != i) addscl3(pa, ax1[k], (dot3(n, ax1[k]) > 0 ? 1 : -1) * A[k]); if (k != j) addscl3(pb, ax2[k], (dot3(n, ax2[k]) > 0 ? -1 : 1) * B[k]); }
+    /* closest points of the lines pa + a ua, pb + b ub */
+    double w[3]; sub3(w, pb, pa);
+    double uaub = dot3(ax1[i], ax2[j]), q1 = dot3(ax1[i], w), q2 = -dot3(ax2[j], w), den = 1 - uaub * uaub;
+    double alpha = den > 1e-12 ? (q1 + uaub * q2) / den : 0, beta = den > 1e-12 ? (uaub * q1 + q2) / den : 0;
+    alpha = clampd(alpha, -A[i], A[i]); beta = clampd(beta, -B[j], B[j]);
+    addscl3(pa, ax1[i], alpha); addscl3(pb, ax2[j], beta);
+    double pos[3] = {0.5 * (pa[0] + pb[0]), 0.5 * (pa[1] + pb[1]), 0.5 * (pa[2] + pb[2])};
+    add_contact(m, d, g1, g2, best, pos, n, margin, gap);
+    return;
+  }
+  /* face contact: reference box owns the axis; nr = its outward normal towards the other box */
+  int ref1 = code <= 3, ia = ref1 ? code - 1 : code - 4;
+  const double (*rax)[3] = ref1 ? ax1 : ax2; const double (*iax)[3] = ref1 ? ax2 : ax1;
+  const double *rp = ref1 ? p1 : p2, *ip = ref1 ? p2 : p1, *rs = ref1 ? A : B, *is = ref1 ? B : A;
+  double nr[3]; scl3(nr, n, ref1 ? 1 : -1);
+  int ib = 0; double bd = 1e300;   /* incident face: the one facing the reference face most directly */
+  for (int k = 0; k < 3; k++) { double dk = dot3(nr, iax[k]); if (-fabs(dk) < bd) { bd = -fabs(dk); ib = k; } }
+  double isgn = dot3(nr, iax[ib]) > 0 ? -1 : 1;
+  double ic[3]; copy3(ic, ip); addscl3(ic, iax[ib], isgn * is[ib]);
+  int u = (ia + 1) % 3, v = (ia + 2) % 3, iu = (ib + 1) % 3, iv = (ib + 2) % 3;
+  double poly[16][2]; int np = 4;
+  for (int k = 0; k < 4; k++) {
+    double x[3]; copy3(x, ic);
+    addscl3(x, iax[iu], ((k == 0 || k == 3) ? 1 : -1) * is[iu]); addscl3(x, iax[iv], (k < 2 ? 1 : -1) * is[iv]);
+    double rel[3]; sub3(rel, x, rp);
+    poly[k][0] = dot3(rel, rax[u]); poly[k][1] = dot3(rel, rax[v]);
+  }
+  np = clip_poly(poly, np, 0, 1, rs[u]); np = clip_poly(poly, np, 0, -1, rs[u]);
+  np = clip_poly(poly, np, 1, 1, rs[v]); np = clip_poly(poly, np, 1, -1, rs[v]);
+  /* lift the clipped vertices back onto the incident face plane: x = rp + a ru + b rv + h nr with (x - ic) . inorm = 0 */
+  double inorm[3]; scl3(inorm, iax[ib], isgn);
+  double dn = dot3(nr, inorm);
+  int cnt = 0;
+  for (int k = 0; k < np && cnt < 8; k++) {
+    double base[3]; copy3(base, rp); addscl3(base, rax[u], poly[k][0]); addscl3(base, rax[v], poly[k][1]);
+    double rel[3]; sub3(rel, ic, base);
+    double h = fabs(dn) > 1e-12 ? dot3(rel, inorm) / dn : dot3(rel, nr);
+    double dist = h - rs[ia];   /* signed distance of the incident-face point from the reference face */
+    if (dist > margin) continue;
+    int dup = 0;
+    for (int q = 0; q < k; q++) if (fabs(poly[q][0] - poly[k][0]) + fabs(poly[q][1] - poly[k][1]) < 1e-12) dup = 1;
+    if (dup) continue;
+    double pos[3]; copy3(pos, base); addscl3(pos, nr, rs[ia] + 0.5 * dist);
+    cnt += add_contact(m, d, g1, g2, dist, pos, n, margin, gap);
+  }
+}
+
 static void collide_pair(const ro_model* m, ro_data* d, int g1, int g2) {
   if (m->geom_type[g1] > m->geom_type[g2]) { int t = g1; g1 = g2; g2 = t; }
   int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
@@ -859,6 +971,7 @@ static void collide_pair(const ro_model* m, ro_data* d, int g1, int g2) {
   double dif[3]; sub3(dif, p2, p1);
   double bound = m->geom_rbound[g1] + m->geom_rbound[g2] + margin;
   if (dot3(dif, dif) > bound * bound) return;
+  if (t1 == GEOM_BOX && t2 == GEOM_BOX && ro_boxbox_multipoint) { collide_box_box(m, d, g1, g2, margin, gap); return; }
   /* mjc_Convex: MPR on shapes inflated by margin/2 each; dist = margin - depth */
   ccd_obj o1 = {m, d, g1, 0.5 * margin}, o2 = {m, d, g2, 0.5 * margin};
   double depth, dir[3], pos[3];

@@ -50,8 +50,20 @@ def lib():
         L.ro_mpr_pair.restype = ctypes.c_int
         L.ro_mpr_pair.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                   ctypes.POINTER(ctypes.c_double)]
+        L.ro_set_mpr_libccd_tridist.argtypes = [ctypes.c_int]
+        L.ro_set_boxbox_multipoint.argtypes = [ctypes.c_int]
         _LIB = L
     return _LIB
+
+
+def set_kernel_variant(on: bool):
+    """The oracle's default is the closest available statement of MuJoCo 2.0 (libccd's triangle-distance MPR depth,
+    multi-point box-box).  `on` switches it to the HIP kernel's two documented deviations (portal-plane MPR depth,
+    box-box through MPR), so that a test can separate "the kernel computes what it says" (tight, kernel variant)
+    from "how far what it says is from the MuJoCo restatement" (measured, default)."""
+    L = lib()
+    L.ro_set_mpr_libccd_tridist(0 if on else 1)
+    L.ro_set_boxbox_multipoint(0 if on else 1)
 
 
 class OracleSim:

@@ -27,12 +27,23 @@ static const char* hipGetErrorString(hipError_t) { return "emul"; }
 #endif
 
 static thread_local std::string g_err;
+#ifdef RG_EMUL
+struct DeviceGuard { explicit DeviceGuard(int) {} };
+#else
+// every entry point runs on the batch's device and leaves the caller's current device as it found it
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#endif
 static int fail(const std::string& msg) { g_err = msg; return -1; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
 struct blob_entry { char name[40]; uint32_t dtype, count; uint64_t offset; };
 
 struct rg_model {
+  int device = 0;
   RgModelDev dev;
   const RgModelDev* dev_copy = nullptr;   // the same descriptor in device memory (kernels read it through the constant address space)
   RgAux aux;
@@ -108,6 +119,9 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
   if (!blob || nbytes < 16 || memcmp(blob, "RGMODEL1", 8) != 0) return bail("not an RGMODEL1 blob", nullptr);
   Blob B{(const char*)blob, nbytes};
   rg_model* m = new rg_model();
+#ifndef RG_EMUL
+  if (hipGetDevice(&m->device) != hipSuccess) return bail("hipGetDevice failed", m);
+#endif
   RgModelDev& d = m->dev;
   memset(&d, 0, sizeof d);
   std::string e;
@@ -254,11 +268,16 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
   return m;
 }
 
+rg_model* rg_model_create_on(const void* blob, size_t nbytes, int device, char* err, int errlen) {
+  DeviceGuard g(device);
+  return rg_model_create(blob, nbytes, err, errlen);
+}
 void rg_model_free(rg_model* m) {
   if (!m) return;
-  for (void* p : m->allocs) hipFree(p);
+  { DeviceGuard g(m->device); for (void* p : m->allocs) hipFree(p); }
   delete m;
 }
+int rg_model_npair(const rg_model* m) { return m ? m->dev.npair : -1; }
 int rg_model_dims(const rg_model* m, int* out) {
   if (!m) return fail("null model");
   out[0] = m->dev.nq; out[1] = m->dev.nv; out[2] = m->dev.nu; out[3] = m->dev.nbody; out[4] = m->dev.nsite;
@@ -275,7 +294,8 @@ static void* balloc(rg_batch* b, size_t n) {
 
 rg_batch* rg_batch_create(const rg_model* m, int B, int device) {
   if (!m || !m->ok || B <= 0) { fail("bad arguments to rg_batch_create"); return nullptr; }
-  if (hipSetDevice(device) != hipSuccess) { fail("hipSetDevice failed"); return nullptr; }
+  if (device != m->device) { fail("rg_batch_create: the model tables live on another device (create the model with rg_model_create_on)"); return nullptr; }
+  DeviceGuard g(device);
   rg_batch* b = new rg_batch();
   b->model = m; b->device = device;
   memset(&b->dev, 0, sizeof b->dev); memset(&b->env, 0, sizeof b->env);
@@ -287,19 +307,21 @@ rg_batch* rg_batch_create(const rg_model* m, int B, int device) {
   s.qacc_warmstart = (float*)balloc(b, (size_t)B * d.nv * 4); s.time = (float*)balloc(b, (size_t)B * 4);
   s.status = (uint32_t*)balloc(b, (size_t)B * 4); s.stats = (float*)balloc(b, (size_t)B * 16);
   s.dbg = (float*)balloc(b, (size_t)B * RG_DBG_SIZE * 4);
+  s.cost = (float*)balloc(b, (size_t)B * 4);
   s.sepdir = (float*)balloc(b, (size_t)B * (d.npair > 0 ? d.npair : 1) * 16);
   s.pairlb = (float*)balloc(b, (size_t)B * (d.npair > 0 ? d.npair : 1) * 4);
-  if (!s.qpos || !s.qvel || !s.ctrl || !s.pid || !s.qacc_warmstart || !s.time || !s.status || !s.stats || !s.dbg || !s.sepdir || !s.pairlb) { fail("hipMalloc failed"); rg_batch_free(b); return nullptr; }
+  if (!s.qpos || !s.qvel || !s.ctrl || !s.pid || !s.qacc_warmstart || !s.time || !s.status || !s.stats || !s.dbg || !s.sepdir || !s.pairlb || !s.cost) { fail("hipMalloc failed"); rg_batch_free(b); return nullptr; }
   if (rg_batch_reset(b) != 0) { rg_batch_free(b); return nullptr; }
   return b;
 }
 void rg_batch_free(rg_batch* b) {
   if (!b) return;
-  for (void* p : b->allocs) hipFree(p);
+  { DeviceGuard g(b->device); for (void* p : b->allocs) hipFree(p); }
   delete b;
 }
 int rg_batch_reset(rg_batch* b) {
   if (!b) return fail("null batch");
+  DeviceGuard g(b->device);
   const RgModelDev& d = b->model->dev;
   RgBatchDev& s = b->dev;
   std::vector<float> q((size_t)s.B * d.nq);
@@ -314,6 +336,7 @@ int rg_batch_reset(rg_batch* b) {
 
 int rg_batch_set_env(rg_batch* b, const int* ints, int nints, const float* p2c, float thr) {
   if (!b || !ints || nints < 20) return fail("rg_batch_set_env: need 20 ints");
+  DeviceGuard g(b->device);
   RgEnvDev& e = b->env;
   e.hand_qposadr = ints[0]; e.n_hand_jnt = ints[1]; e.cube_pos_qposadr = ints[2]; e.cube_quat_qposadr = ints[3];
   e.target_qposadr = ints[4]; e.target_nq = ints[5]; e.target_dofadr = ints[6]; e.target_nv = ints[7]; e.cube_body = ints[8];
@@ -334,23 +357,38 @@ int rg_obs_dim(const rg_batch* b) {
   return 7 + b->model->dev.nq + b->model->dev.nv + b->env.n_hand_jnt + 15;
 }
 
-int rg_batch_copy(rg_batch* b, int field, void* ptr, int to_batch, int ptr_is_device) {
-  if (!b || !ptr) return fail("rg_batch_copy: null argument");
+static void* field_ptr(rg_batch* b, int field, size_t* n) {
   const RgModelDev& d = b->model->dev;
   RgBatchDev& s = b->dev;
-  void* p; size_t n;
   switch (field) {
-    case RG_F_QPOS: p = s.qpos; n = (size_t)d.nq; break;
-    case RG_F_QVEL: p = s.qvel; n = (size_t)d.nv; break;
-    case RG_F_CTRL: p = s.ctrl; n = (size_t)d.nu; break;
-    case RG_F_PID: p = s.pid; n = (size_t)3 * d.nu; break;
-    case RG_F_WARMSTART: p = s.qacc_warmstart; n = (size_t)d.nv; break;
-    case RG_F_TIME: p = s.time; n = 1; break;
-    case RG_F_STATUS: p = s.status; n = 1; break;
-    case RG_F_STATS: p = s.stats; n = 4; break;
-    case RG_F_DEBUG: p = s.dbg; n = RG_DBG_SIZE; break;
-    default: return fail("rg_batch_copy: unknown field");
+    case RG_F_QPOS: *n = (size_t)d.nq; return s.qpos;
+    case RG_F_QVEL: *n = (size_t)d.nv; return s.qvel;
+    case RG_F_CTRL: *n = (size_t)d.nu; return s.ctrl;
+    case RG_F_PID: *n = (size_t)3 * d.nu; return s.pid;
+    case RG_F_WARMSTART: *n = (size_t)d.nv; return s.qacc_warmstart;
+    case RG_F_TIME: *n = 1; return s.time;
+    case RG_F_STATUS: *n = 1; return s.status;
+    case RG_F_STATS: *n = 4; return s.stats;
+    case RG_F_DEBUG: *n = RG_DBG_SIZE; return s.dbg;
+    case RG_F_COST: *n = 1; return s.cost;
+    case RG_F_PAIRLB: *n = (size_t)(d.npair > 0 ? d.npair : 1); return s.pairlb;
+    default: return nullptr;
   }
+}
+void* rg_batch_field_ptr(rg_batch* b, int field, int* row_words) {
+  if (!b) { fail("null batch"); return nullptr; }
+  size_t n = 0; void* p = field_ptr(b, field, &n);
+  if (!p) { fail("rg_batch_field_ptr: unknown field"); return nullptr; }
+  if (row_words) *row_words = (int)n;
+  return p;
+}
+int rg_batch_copy(rg_batch* b, int field, void* ptr, int to_batch, int ptr_is_device) {
+  if (!b || !ptr) return fail("rg_batch_copy: null argument");
+  DeviceGuard g(b->device);
+  const RgModelDev& d = b->model->dev;
+  RgBatchDev& s = b->dev;
+  size_t n = 0; void* p = field_ptr(b, field, &n);
+  if (!p) return fail("rg_batch_copy: unknown field");
   size_t bytes = n * 4 * (size_t)s.B;
   if (to_batch) {
     HIPCHK(hipMemcpy(p, ptr, bytes, ptr_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
@@ -367,6 +405,7 @@ static void emul_copy_entry(void* a) { EmulCopyArgs* p = (EmulCopyArgs*)a; rg_co
 #endif
 int rg_batch_copy_rows(rg_batch* b, int field, const void* src_dev, const int* mask_dev, int col0, int ncols, void* stream) {
   if (!b || !src_dev || !mask_dev) return fail("rg_batch_copy_rows: null argument");
+  DeviceGuard g(b->device);
   const RgModelDev& d = b->model->dev;
   RgBatchDev& s = b->dev;
   void* p; int n;
@@ -398,21 +437,31 @@ struct EmulArgs { const RgModelDev* m; RgLaunch launch; };
 static void emul_entry(void* a) { EmulArgs* p = (EmulArgs*)a; rg_step_kernel(p->m, p->launch); }
 #endif
 
-int rg_batch_step(rg_batch* b, const float* action_dev, const float* goal_quat_dev, float* obs_dev, float* goal_dist_dev,
-                  const int* active_dev, int nsubsteps, int nforward_ticks, int flags, void* stream) {
-  if (!b) return fail("null batch");
-  if ((action_dev || obs_dev) && !b->has_env) return fail("rg_batch_set_env must be called before stepping with actions/observations");
+int rg_batch_step_ex(rg_batch* b, const rg_step_args* a) {
+  if (!b || !a) return fail("null argument");
+  if ((a->action_dev || a->obs_dev) && !b->has_env) return fail("rg_batch_set_env must be called before stepping with actions/observations");
+  if (a->nsubsteps < 0 || a->nforward_ticks < 0) return fail("rg_batch_step: negative step counts");
+  DeviceGuard g(b->device);
   RgBatchDev bt = b->dev;
-  bt.action = action_dev; bt.goal_quat = goal_quat_dev; bt.obs = obs_dev; bt.goal_dist = goal_dist_dev; bt.active = active_dev;
-  RgLaunch launch{b->model->aux, b->env, bt, nsubsteps, nforward_ticks, flags};
+  bt.action = a->action_dev; bt.goal_quat = a->goal_quat_dev; bt.obs = a->obs_dev; bt.goal_dist = a->goal_dist_dev; bt.active = a->active_dev;
+  bt.hold = a->hold_dev; bt.nticks = a->nticks_dev; bt.order = a->order_dev;
+  RgLaunch launch{b->model->aux, b->env, bt, a->nsubsteps, a->nforward_ticks, a->flags};
 #ifdef RG_EMUL
   EmulArgs args{b->model->dev_copy, launch};
   emul_launch(bt.B, sizeof(RgLds), emul_entry, &args);
 #else
-  hipLaunchKernelGGL(rg_step_kernel, dim3(bt.B), dim3(RG_WAVE), sizeof(RgLds), (hipStream_t)stream, b->model->dev_copy, launch);
+  hipLaunchKernelGGL(rg_step_kernel, dim3(bt.B), dim3(RG_WAVE), sizeof(RgLds), (hipStream_t)a->stream, b->model->dev_copy, launch);
   HIPCHK(hipGetLastError());
 #endif
   return 0;
+}
+int rg_batch_step(rg_batch* b, const float* action_dev, const float* goal_quat_dev, float* obs_dev, float* goal_dist_dev,
+                  const int* active_dev, int nsubsteps, int nforward_ticks, int flags, void* stream) {
+  rg_step_args a;
+  memset(&a, 0, sizeof a);
+  a.action_dev = action_dev; a.goal_quat_dev = goal_quat_dev; a.obs_dev = obs_dev; a.goal_dist_dev = goal_dist_dev; a.active_dev = active_dev;
+  a.nsubsteps = nsubsteps; a.nforward_ticks = nforward_ticks; a.flags = flags; a.stream = stream;
+  return rg_batch_step_ex(b, &a);
 }
 
 #ifdef RG_EMUL
@@ -423,6 +472,7 @@ int rg_batch_mpr_pair(rg_batch* b, int g1, int g2, float margin, float* out_dev,
   if (!b || !out_dev) return fail("null argument");
   const RgModelDev& d = b->model->dev;
   if (g1 < 0 || g2 < 0 || g1 >= d.ngeom || g2 >= d.ngeom) return fail("geom id out of range");
+  DeviceGuard g(b->device);
   RgLaunch launch{b->model->aux, b->env, b->dev, 0, 0, 0};
 #ifdef RG_EMUL
   EmulMprArgs args{b->model->dev_copy, launch, g1, g2, margin, out_dev};

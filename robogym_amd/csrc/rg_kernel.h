@@ -135,6 +135,12 @@ typedef const RG_AS4 RgLaunch& RgLRef;
 #else
 #define RG_STAGE_BIG __device__ __forceinline__   /* the register-hungriest stages stay in the kernel body: a call would save/restore ~30 callee-saved VGPRs through scratch */
 #endif
+// env handled by this workgroup: the launch may carry a permutation (longest-expected-first dispatch order)
+#ifdef RG_EMUL
+static inline int rg_env(RgLRef L) { return L.bt.order ? L.bt.order[blockIdx.x] : (int)blockIdx.x; }
+#else
+__device__ __forceinline__ int rg_env(RgLRef L) { return L.bt.order ? __builtin_amdgcn_readfirstlane(L.bt.order[blockIdx.x]) : (int)blockIdx.x; }
+#endif
 // ------------------------------------------------------------------------------------------------- small math
 struct alignas(16) rgf4 { float x, y, z, w; };
 struct v3 { float x, y, z; };
@@ -866,8 +872,8 @@ __device__ __forceinline__ void rg_mpr_geoms(RgM m, const RgLds& s, int p, MprGe
 template <int G> RG_STAGE void rg_narrow_phase1(RgCtx c, int ncand) {
   RgM m = RG_M(c); RgLRef L = RG_L(c); RgLds& s = RG_S();
   bool cells = !(L.flags & 8);
-  rgf4* sepdir = L.bt.sepdir ? (rgf4*)L.bt.sepdir + (size_t)blockIdx.x * m.npair : (rgf4*)0;
-  float* pairlb = (L.bt.pairlb && !(L.flags & 4)) ? L.bt.pairlb + (size_t)blockIdx.x * m.npair : (float*)0;
+  rgf4* sepdir = L.bt.sepdir ? (rgf4*)L.bt.sepdir + (size_t)rg_env(L) * m.npair : (rgf4*)0;
+  float* pairlb = (L.bt.pairlb && !(L.flags & 4)) ? L.bt.pairlb + (size_t)rg_env(L) * m.npair : (float*)0;
   MprEnv E = rg_mpr_env(m, (float*)0, cells);
   for (int base = 0; base < ncand; base += RG_WAVE / G) {
     int ci = base + LANE / G;
@@ -904,7 +910,7 @@ template <int G> RG_STAGE_BIG void rg_narrow_phase2(RgCtx c, int ncand2) {
   RgM m = RG_M(c); RgLRef L = RG_L(c); RgLds& s = RG_S();
   bool cells = !(L.flags & 8);
   float* prof = (L.flags & 2) ? s.prof : (float*)0;
-  rgf4* sepdir = L.bt.sepdir ? (rgf4*)L.bt.sepdir + (size_t)blockIdx.x * m.npair : (rgf4*)0;
+  rgf4* sepdir = L.bt.sepdir ? (rgf4*)L.bt.sepdir + (size_t)rg_env(L) * m.npair : (rgf4*)0;
   MprEnv E = rg_mpr_env(m, prof, cells);
   for (int base = 0; base < ncand2; base += RG_WAVE / G) {
     int ci = base + LANE / G;
@@ -1876,7 +1882,7 @@ RG_STAGE void st_crb(RgCtx c) { RgLRef L = RG_L(c); rg_crb(RG_M(c), RG_S(), L.x.
 RG_STAGE void st_velocity(RgCtx c) { RgLRef L = RG_L(c); rg_velocity(RG_M(c), RG_S(), L.x.dof_velmask, L.x.subtree_adr, L.x.subtree); }
 RG_STAGE_BIG void st_collision(RgCtx c) {
   RgM m = RG_M(c); RgLRef L = RG_L(c); RgLds& s = RG_S();
-  int e = blockIdx.x, flags = L.flags;
+  int e = rg_env(L), flags = L.flags;
   rg_collision(c, m, s, (flags & 2) ? s.prof : (float*)0, L.bt.sepdir ? (rgf4*)L.bt.sepdir + (size_t)e * m.npair : (rgf4*)0,
                (L.bt.pairlb && !(flags & 4)) ? L.bt.pairlb + (size_t)e * m.npair : (float*)0, !(flags & 8));
 }
@@ -1889,7 +1895,7 @@ RG_STAGE void st_euler(RgCtx c) { rg_euler(RG_M(c), RG_S()); }
 RG_STAGE void st_build_row_desc(RgCtx c) { rg_build_row_desc(RG_M(c), RG_S()); }
 RG_STAGE void st_dump(RgCtx c, int which, int nefc, int iters) {
   RgM m = RG_M(c); RgLRef L = RG_L(c); RgLds& s = RG_S();
-  float* dbg = L.bt.dbg + (size_t)blockIdx.x * RG_DBG_SIZE;
+  float* dbg = L.bt.dbg + (size_t)rg_env(L) * RG_DBG_SIZE;
   if (which == 0) rg_dump_kin(m, s, dbg); else if (which == 1) rg_dump_pos(m, s, dbg); else rg_dump_slv(m, s, dbg, nefc, iters);
 }
 
@@ -1906,9 +1912,10 @@ __global__ void __launch_bounds__(RG_WAVE, 2) rg_step_kernel(const RgModelDev* m
   RgLRef L = RG_L(c);
   RgLds& s = RG_S();
   const int nsubsteps = L.nsubsteps, nforward_ticks = L.nforward_ticks, flags = L.flags;
-  int e = blockIdx.x;
-  if (e >= L.bt.B) return;
+  if ((int)blockIdx.x >= L.bt.B) return;
+  int e = rg_env(L);
   if (L.bt.active && !L.bt.active[e]) return;
+  long long tk0 = rg_clock();
   // ---- load the env's state row
   PFOR(i, m.nq) s.qpos[i] = L.bt.qpos[(size_t)e * m.nq + i];
   PFOR(i, m.nv) { s.qvel[i] = L.bt.qvel[(size_t)e * m.nv + i]; s.warm[i] = L.bt.qacc_warmstart[(size_t)e * m.nv + i]; }
@@ -1917,8 +1924,13 @@ __global__ void __launch_bounds__(RG_WAVE, 2) rg_step_kernel(const RgModelDev* m
   if (LANE < RG_NPROF) s.prof[LANE] = 0;
   st_build_row_desc(c);
   // ---- action -> ctrl (robot_interface.py:247-278 with the hand's position->control matrix)
-  float a0 = L.bt.action ? L.bt.action[(size_t)e * m.nu] : 0.f;
-  if (L.bt.action && a0 == a0) {   // a NaN first entry: this env keeps its stored ctrl row
+  // envs on `hold` (scripted reset recipe) and envs whose action row holds a non-finite entry keep their stored ctrl row
+  bool use_action = L.bt.action && !(L.bt.hold && L.bt.hold[e]);
+  if (use_action) {
+    float nf = 0; PFOR(u, m.nu) nf += (fabsf(L.bt.action[(size_t)e * m.nu + u]) <= 3.0e38f) ? 0.f : 1.f;
+    if (wave_sum(nf) > 0) { use_action = false; if (LANE == 0) s.status |= RG_STATUS_BAD_ACTION; }
+  }
+  if (use_action) {
     PFOR(u, m.nu) {
       float lo = m.actuator_ctrlrange[2 * u], hi = m.actuator_ctrlrange[2 * u + 1], centre;
       if (L.env.relative_action) { centre = 0; for (int j = 0; j < L.env.n_hand_jnt; j++) centre += L.env.pos_to_ctrl[u * L.env.n_hand_jnt + j] * s.qpos[L.env.hand_qposadr + j]; }
@@ -1966,9 +1978,10 @@ __global__ void __launch_bounds__(RG_WAVE, 2) rg_step_kernel(const RgModelDev* m
   if (bad && LANE == 0) s.status |= RG_STATUS_BAD_STATE;
   // ---- state-less forward() calls of the reference (simulation_interface.py:185, robot_env.py:677,
   //      observation/mujoco.py:22-27): only their PID-controller side effect touches the state
-  if (nforward_ticks > 0 || L.bt.obs) {
+  const int nticks = L.bt.nticks ? L.bt.nticks[e] : nforward_ticks;
+  if (nticks > 0 || L.bt.obs) {
     st_kinematics(c); st_com_pos(c); st_tendon(c);
-    for (int k = 0; k < nforward_ticks; k++) st_pid(c);
+    for (int k = 0; k < nticks; k++) st_pid(c);
   }
   // ---- write back
   PFOR(i, m.nq) L.bt.qpos[(size_t)e * m.nq + i] = s.qpos[i];
@@ -1977,6 +1990,7 @@ __global__ void __launch_bounds__(RG_WAVE, 2) rg_step_kernel(const RgModelDev* m
   PFOR(u, m.nu) L.bt.ctrl[(size_t)e * m.nu + u] = s.ctrl[u];
   if (LANE == 0) {
     L.bt.status[e] = s.status; L.bt.time[e] += nsubsteps * m.timestep;
+    if (L.bt.cost) L.bt.cost[e] = (float)(rg_clock() - tk0);
     if (L.bt.stats) { float* st = L.bt.stats + 4 * (size_t)e; st[0] += st_ncon; st[1] += st_nefc; st[2] += st_iter; st[3] += nsubsteps; }
   }
   if ((flags & 2) && L.bt.dbg && LANE < RG_NPROF) L.bt.dbg[(size_t)e * RG_DBG_SIZE + RG_DBG_CON + LANE] = s.prof[LANE];  // stage cycle counters (overlays the contact dump)

@@ -37,6 +37,7 @@
 #define RG_STATUS_CAND_FULL 4u   // more broadphase candidates than RG_MAXCAND
 #define RG_STATUS_ROW_FULL 8u    // more friction/limit rows than RG_MAXROW
 #define RG_STATUS_BAD_FACTOR 16u // Cholesky pivot <= 0
+#define RG_STATUS_BAD_ACTION 32u // non-finite entry in the env's action row (the row is ignored: ctrl keeps its value)
 
 enum { RG_JNT_FREE = 0, RG_JNT_BALL = 1, RG_JNT_SLIDE = 2, RG_JNT_HINGE = 3 };
 enum { RG_GEOM_PLANE = 0, RG_GEOM_SPHERE = 2, RG_GEOM_CAPSULE = 3, RG_GEOM_ELLIPSOID = 4, RG_GEOM_CYLINDER = 5, RG_GEOM_BOX = 6, RG_GEOM_MESH = 7 };
@@ -126,6 +127,10 @@ struct RgBatchDev {
   const float* action;  // [B][nu] in [-1,1]   (may be null: ctrl used as is)
   const float* goal_quat;  // [B][4]
   const int* active;    // [B] or null: envs with 0 are skipped by this launch
+  const int* hold;      // [B] or null: envs with != 0 ignore their action row and keep the stored ctrl row (scripted resets)
+  const int* nticks;    // [B] or null: per-env override of nforward_ticks (the reset recipe's sim.step has 1, env.step 3)
+  const int* order;     // [B] or null: workgroup -> env permutation (longest-expected-first dispatch)
+  float* cost;          // [B] or null: shader cycles this launch spent on the env (feeds `order` of the next step)
   float* obs;           // [B][obs_dim]
   float* goal_dist;     // [B]
   float* stats;         // [B][4]: sum ncon, sum nefc, sum newton iters, substeps

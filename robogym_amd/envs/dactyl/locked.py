@@ -173,7 +173,7 @@ class BatchedLockedEnv:
     """B independent dactyl/locked envs stepped in lock-step on one GPU."""
 
     def __init__(self, batch_size: int, device="cuda:0", constants: Optional[LockedEnvConstants] = None, starting_seed: Optional[int] = None,
-                 model: Optional[CompiledModel] = None, lib=None, pipelined_reset: bool = False):
+                 model: Optional[CompiledModel] = None, lib=None, pipelined_reset: bool = False, sort_dispatch: bool = False):
         self.constants = constants or LockedEnvConstants()
         c = self.constants
         self.model = model or load_locked_model()
@@ -205,6 +205,8 @@ class BatchedLockedEnv:
         self._qpos0_rows = torch.tensor(self.model.qpos0, dtype=torch.float32, device=dev).repeat(B, 1)
         self._cube_pos_col = int(sim.qpos_idxs["cube_position"][0])
         self._cube_quat_col = int(sim.qpos_idxs["cube_rotation"][0])
+        self._zero_ctrl_rows = (0.5 * (sim.ctrl_lo + sim.ctrl_hi)).repeat(B, 1)   # denormalize_position_control(zero action), absolute
+        self.sort_dispatch = bool(sort_dispatch)
 
     # ------------------------------------------------------------------ gym surface
     @property
@@ -239,16 +241,12 @@ class BatchedLockedEnv:
         return self.observe()
 
     def _masked_sim_reset(self, mask):
-        sim = self.mujoco_simulation
-        st = sim.get_state()
-        q0 = torch.tensor(self.model.qpos0, dtype=torch.float32, device=self.device)
-        st["qpos"][mask] = q0
-        for k in ("qvel", "pid", "qacc_warmstart", "ctrl", "time"):
-            st[k][mask] = 0
-        sim.set_state(st)
-        status = sim.get_field(6)
-        status[mask] = 0
-        sim.set_field(6, status)
+        """`MjSim.reset` (mj_resetData) of the selected envs: stream-ordered masked row copies, no host sync."""
+        sim, F, B, dev = self.mujoco_simulation, _native, self.batch_size, self.device
+        sim.copy_rows(F.RG_F_QPOS, self._qpos0_rows, mask)
+        for fld, n in ((F.RG_F_QVEL, sim.nv), (F.RG_F_PID, 3 * sim.nu), (F.RG_F_WARMSTART, sim.nv), (F.RG_F_CTRL, sim.nu), (F.RG_F_TIME, 1)):
+            sim.copy_rows(fld, torch.zeros((B, n), dtype=torch.float32, device=dev), mask)
+        sim.copy_rows(F.RG_F_STATUS, torch.zeros((B, 1), dtype=torch.int32, device=dev), mask)
 
     def _randomize_cube_pose(self, mask):
         """CubeEnv._reset + LockedEnv._randomize_cube_initial_position (cube_env.py:330-355, locked.py:197-225)."""
@@ -277,9 +275,7 @@ class BatchedLockedEnv:
                 break
 
     def _set_ctrl_masked(self, ctrl, mask):
-        sim = self.mujoco_simulation
-        cur = sim.get_field(2)
-        sim.set_ctrl(torch.where(mask[:, None], ctrl, cur))
+        self.mujoco_simulation.copy_rows(_native.RG_F_CTRL, ctrl, mask)
 
     def _new_goal(self, mask):
         """reset_goal (robot_env.py:893-909): count the goal, sample it, re-observe (2 state-less forwards)."""
@@ -315,6 +311,32 @@ class BatchedLockedEnv:
             "is_goal_achieved": self._is_successful.to(torch.int32)[:, None],
         }
 
+    def _crashed(self) -> torch.Tensor:
+        """Envs whose simulation raised BAD_STATE (NaN / diverged state).  The reference fails loudly there
+        (mujoco-py raises MujocoException / MuJoCo auto-resets, warning_buffer.py:15-24); a batch cannot raise for one
+        env, so the env reports done with `info["env_crash"]`, zero reward and a zeroed observation row, and is
+        re-initialised by the next reset.  Read through the zero-copy status view: stream-ordered, no host sync."""
+        return (self.mujoco_simulation.view(_native.RG_F_STATUS)[:, 0] & _native.RG_STATUS_BAD_STATE) != 0
+
+    def _dispatch_order(self):
+        """Longest-expected-first dispatch (rg_step_args.order_dev): the envs sorted by the cycles their previous
+        env.step took, so the launch's tail is made of short envs."""
+        if not self.sort_dispatch:
+            return None
+        return torch.argsort(self.mujoco_simulation.view(_native.RG_F_COST)[:, 0], descending=True).to(torch.int32)
+
+    @property
+    def packed_dim(self) -> int:
+        return self.mujoco_simulation.obs_dim + 3 + 4 + self.mujoco_simulation.nq + 1 + 3 + 1
+
+    def packed_observation(self, reward: torch.Tensor, done: torch.Tensor) -> torch.Tensor:
+        """[B, 170]: the 166 scalars of the observation dict in key order (locked.py:132-146) followed by the reward
+        triple and `done` — the one buffer a replicated learner needs per env.step, and what the multi-GPU all-gather
+        moves ("rewards/dones ride in the same buffer")."""
+        B, dev = self.batch_size, self.device
+        return torch.cat([self._obs_buf, torch.zeros((B, 3), dtype=torch.float32, device=dev), rotation.quat_normalize(self._goal_quat), self._qpos_goal,
+                          self._is_successful.to(torch.float32)[:, None], reward, done.to(torch.float32)[:, None]], dim=1)
+
     def step(self, action: torch.Tensor):
         """RobotEnv.step (robot_env.py:804-844): returns (obs dict, reward [B,3], done [B], info dict)."""
         if self._needs_reset:
@@ -323,71 +345,82 @@ class BatchedLockedEnv:
         action = torch.as_tensor(action, dtype=torch.float32, device=self.device).reshape(self.batch_size, self.num_actions).contiguous()
         if self.pipelined_reset:
             return self._step_pipelined(action)
-        sim.env_step(action=action, goal_quat=self._goal_quat, obs=self._obs_buf, goal_dist=self._goal_dist, nforward_ticks=3)
+        sim.env_step(action=action, goal_quat=self._goal_quat, obs=self._obs_buf, goal_dist=self._goal_dist, nforward_ticks=3, order=self._dispatch_order())
         self.t += 1
-        dist = self._goal_dist
+        crash = self._crashed()
+        self._obs_buf.masked_fill_(crash[:, None], 0.0)
+        dist = torch.where(crash, torch.zeros_like(self._goal_dist), self._goal_dist)
         # _get_goal_info (robot_env.py:577-625)
-        goal_distance_reward = torch.where(self._prev_valid, self._prev_dist - dist, torch.zeros_like(dist))
+        goal_distance_reward = torch.where(self._prev_valid & ~crash, self._prev_dist - dist, torch.zeros_like(dist))
         self._prev_dist = dist.clone()
         self._prev_valid = torch.ones_like(self._prev_valid)
-        is_successful = dist < c.success_threshold["cube_quat"]
+        is_successful = (dist < c.success_threshold["cube_quat"]) & ~crash
         self._is_successful = is_successful
         goal_dist_before = dist.clone()
         reward, done, new_goal, info = self.multi_goal_tracker.process(is_successful, goal_distance_reward)
+        done = done | crash
+        info["env_crash"] = crash
         self._new_goal(new_goal)
-        info.update({"goal_dist": {"cube_quat": goal_dist_before}, "goal_achieved": is_successful, "goals_so_far": self.multi_goal_tracker.goals_so_far.clone()})
+        info.update({"goal_dist": {"cube_quat": goal_dist_before}, "goal_achieved": is_successful, "goals_so_far": self.multi_goal_tracker.goals_so_far.clone(),
+                     "sim_status": sim.view(_native.RG_F_STATUS)[:, 0].clone()})
         return self.observe(), reward, done, info
 
     def _step_pipelined(self, action: torch.Tensor):
         """`step` with the reset recipe of finished episodes folded into the step launches.  No host
         synchronisation: every decision is a [B] tensor op, every state write a masked row copy on the stream.
-        Envs in the recipe ignore `action` (a NaN action row keeps their scripted ctrl), report zero reward,
+        Envs in the recipe ignore `action` (the launch's `hold` mask keeps their scripted ctrl), report zero reward,
         `done` False and `info["resetting"]` True; the step on which the recipe completes returns the first
-        observation of the new episode.  Differences from the synchronous recipe: the three PID ticks of an
-        env.step instead of the one of `sim.step`, and no state-less forward around the cube perturbation."""
+        observation of the new episode.  The recipe is the reference's, tick for tick: a recipe step is `sim.step`
+        (10 mj_step + ONE state-less forward, simulation_interface.py:176-189), the forward after the cube
+        perturbation (locked.py:213) and the one inside `on_palm` (cube_utils.py:17-23) are the second tick of recipe
+        steps 20 and 30 (a tick only touches the PID state, which does not see the cube)."""
         sim, c = self.mujoco_simulation, self.constants
         B, dev, F = self.batch_size, self.device, _native
         resetting = self._phase > 0
         live = ~resetting
-        act = torch.where(resetting[:, None], torch.full_like(action, float("nan")), action).contiguous()
-        sim.env_step(action=act, goal_quat=self._goal_quat, obs=self._obs_buf, goal_dist=self._goal_dist, nforward_ticks=3)
+        n1, n2 = c.reset_initial_steps, c.reset_initial_steps + c.n_random_initial_steps
+        two = resetting & ((self._phase == n1) | (self._phase == n2))
+        nticks = torch.where(live, torch.full_like(self._phase, 3), torch.where(two, torch.full_like(self._phase, 2), torch.ones_like(self._phase))).contiguous()
+        sim.env_step(action=action, goal_quat=self._goal_quat, obs=self._obs_buf, goal_dist=self._goal_dist, nforward_ticks=3,
+                     hold=resetting.to(torch.int32).contiguous(), nticks=nticks, order=self._dispatch_order())
         self.t += live.to(torch.int32)
-        dist = self._goal_dist
-        goal_distance_reward = torch.where(self._prev_valid & live, self._prev_dist - dist, torch.zeros_like(dist))
+        crash = self._crashed()
+        self._obs_buf.masked_fill_(crash[:, None], 0.0)
+        dist = torch.where(crash, torch.zeros_like(self._goal_dist), self._goal_dist)
+        ok_live = live & ~crash
+        goal_distance_reward = torch.where(self._prev_valid & ok_live, self._prev_dist - dist, torch.zeros_like(dist))
         self._prev_dist = torch.where(live, dist, self._prev_dist)
         self._prev_valid = self._prev_valid | live
-        is_successful = (dist < c.success_threshold["cube_quat"]) & live
+        is_successful = (dist < c.success_threshold["cube_quat"]) & ok_live
         self._is_successful = is_successful
         goal_dist_before = dist.clone()
         reward, done, new_goal, info = self.multi_goal_tracker.process(is_successful, goal_distance_reward, live=live)
+        done = done | (crash & live)
+        info["env_crash"] = crash
         # ---- recipe progression of the envs that are being reset
         ph = self._phase + resetting.to(torch.int32)
-        wiggle = ph == c.reset_initial_steps + 1
+        wiggle = (ph == c.reset_initial_steps + 1) & ~crash
         w = self._rand_normal(B, 4)
         sim.copy_rows(F.RG_F_QPOS, self._obs_buf[:, 0:3] + self._rand_normal(B, 3) * c.cube_position_wiggle_std, wiggle, self._cube_pos_col)
         sim.copy_rows(F.RG_F_QPOS, rotation.quat_normalize(w / w.norm(dim=-1, keepdim=True)), wiggle, self._cube_quat_col)
         sim.copy_rows(F.RG_F_CTRL, sim.denormalize_position_control(self._rand_uniform(-1.0, 1.0, B, self.num_actions)), wiggle)
-        finished = ph == c.reset_initial_steps + c.n_random_initial_steps + 1
+        finished = (ph == c.reset_initial_steps + c.n_random_initial_steps + 1) & ~crash
         on_palm = (sim.cube_body_z + self._obs_buf[:, 2]) > 0.04
         ok = finished & (on_palm | (self._tries + 1 >= c.max_pose_resets))
-        retry = finished & ~ok
-        start = done & live
+        retry = (finished & ~ok) | (crash & resetting)
+        start = (done & live) | (crash & live)
         restart = retry | start
         self._tries = torch.where(start, torch.zeros_like(self._tries), self._tries + retry.to(torch.int32))
         self._phase = torch.where(restart, torch.ones_like(ph), torch.where(ok, torch.zeros_like(ph), ph))
-        zero_ctrl = sim.denormalize_position_control(torch.zeros((B, self.num_actions), dtype=torch.float32, device=dev))
-        sim.copy_rows(F.RG_F_QPOS, self._qpos0_rows, restart)
-        for field, n in ((F.RG_F_QVEL, sim.nv), (F.RG_F_PID, 3 * sim.nu), (F.RG_F_WARMSTART, sim.nv), (F.RG_F_TIME, 1)):
-            sim.copy_rows(field, torch.zeros((B, n), dtype=torch.float32, device=dev), restart)
-        sim.copy_rows(F.RG_F_CTRL, zero_ctrl, restart)
-        sim.copy_rows(F.RG_F_STATUS, torch.zeros((B, 1), dtype=torch.int32, device=dev), restart)
+        self._masked_sim_reset(restart)
+        sim.copy_rows(F.RG_F_CTRL, self._zero_ctrl_rows, restart)
         # ---- envs whose recipe completed start their episode: tracker, clock, goal (robot_env.py:787-792)
         self.multi_goal_tracker.reset(ok)
         self.t = torch.where(ok, torch.zeros_like(self.t), self.t)
         self._prev_valid = self._prev_valid & ~ok
         self._new_goal(new_goal | ok)
         info.update({"goal_dist": {"cube_quat": goal_dist_before}, "goal_achieved": is_successful, "goals_so_far": self.multi_goal_tracker.goals_so_far.clone(),
-                     "resetting": self._phase > 0, "episode_started": ok})
+                     "resetting": self._phase > 0, "episode_started": ok, "sim_status": sim.view(F.RG_F_STATUS)[:, 0].clone()})
         return self.observe(), reward, done, info
 
     # ------------------------------------------------------------------ diagnostics

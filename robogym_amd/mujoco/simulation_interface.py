@@ -29,18 +29,23 @@ class BatchedSimulationInterface:
         self.n_substeps = int(n_substeps)
         blob = pack_model(model)
         err = ctypes.create_string_buffer(512)
-        self._mh = self._L.rg_model_create(blob, len(blob), err, 512)
+        index = self.device.index or 0
+        # model tables and batch state live on `device`, whatever the caller's current device is
+        self._mh = self._L.rg_model_create_on(blob, len(blob), index, err, 512)
         if not self._mh:
             raise _native.NativeError("rg_model_create: " + err.value.decode())
-        index = self.device.index or 0
         self._bh = self._L.rg_batch_create(self._mh, self.batch_size, index)
         if not self._bh:
             raise _native.NativeError("rg_batch_create: " + self._L.rg_last_error().decode())
         d = model.dims
         self.nq, self.nv, self.nu = int(d[0]), int(d[1]), int(d[2])
+        self.npair = int(self._L.rg_model_npair(self._mh))
         self.qpos_idxs: Dict[str, np.ndarray] = {}
         self.qvel_idxs: Dict[str, np.ndarray] = {}
         self._stream = None
+        self._views: Dict[int, torch.Tensor] = {}
+        self._idx_cache: Dict = {}
+        self._keep = []
 
     def __del__(self):
         try:
@@ -67,20 +72,51 @@ class BatchedSimulationInterface:
     def _ncols(self, field):
         return {_native.RG_F_QPOS: self.nq, _native.RG_F_QVEL: self.nv, _native.RG_F_CTRL: self.nu, _native.RG_F_PID: 3 * self.nu,
                 _native.RG_F_WARMSTART: self.nv, _native.RG_F_TIME: 1, _native.RG_F_STATUS: 1, _native.RG_F_STATS: 4,
-                _native.RG_F_DEBUG: self._L.rg_debug_size()}[field]
+                _native.RG_F_DEBUG: self._L.rg_debug_size(), _native.RG_F_COST: 1, _native.RG_F_PAIRLB: max(self.npair, 1)}[field]
+
+    def view(self, field) -> torch.Tensor:
+        """Zero-copy [B, n] tensor over the batch's own buffer of `field` (the batched `sim.data.<field>`):
+        reads and in-place writes are ordinary stream-ordered torch ops, no host synchronisation, no copy.
+        Whoever writes qpos through a view must void the collision cache rows (`touch_qpos`)."""
+        t = self._views.get(field)
+        if t is None:
+            n = ctypes.c_int(0)
+            ptr = self._L.rg_batch_field_ptr(self._bh, field, ctypes.byref(n))
+            if not ptr:
+                raise _native.NativeError("rg_batch_field_ptr: " + self._L.rg_last_error().decode())
+            shape = (self.batch_size, int(n.value))
+            is_int = field == _native.RG_F_STATUS
+            if self._emul:
+                ctype = ctypes.c_int32 if is_int else ctypes.c_float
+                arr = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctype)), shape=shape)
+                t = torch.from_numpy(arr)
+            else:
+                holder = type("_DevArray", (), {})()
+                holder.__cuda_array_interface__ = {"shape": shape, "typestr": "<i4" if is_int else "<f4", "data": (int(ptr), False), "version": 2, "strides": None}
+                with torch.cuda.device(self.device):
+                    t = torch.as_tensor(holder, device=self.device)
+                assert t.data_ptr() == int(ptr) and t.device == self.device
+            self._views[field] = t
+        return t
 
     def get_field(self, field) -> torch.Tensor:
-        dtype = torch.int32 if field == _native.RG_F_STATUS else torch.float32
-        out = torch.empty((self.batch_size, self._ncols(field)), dtype=dtype, device=self.device)
-        self.sync()
-        _native.check(self._L, self._L.rg_batch_copy(self._bh, field, out.data_ptr(), 0, 0 if self._emul else 1), "rg_batch_copy")
-        return out
+        """Snapshot (a copy) of a field."""
+        return self.view(field).clone()
 
     def set_field(self, field, value: torch.Tensor):
         dtype = torch.int32 if field == _native.RG_F_STATUS else torch.float32
-        value = torch.as_tensor(value, dtype=dtype, device=self.device).reshape(self.batch_size, self._ncols(field)).contiguous()
-        self.sync()
-        _native.check(self._L, self._L.rg_batch_copy(self._bh, field, value.data_ptr(), 1, 0 if self._emul else 1), "rg_batch_copy")
+        value = torch.as_tensor(value, dtype=dtype, device=self.device).reshape(self.batch_size, self._ncols(field))
+        self.view(field).copy_(value)
+        if field == _native.RG_F_QPOS:
+            self.touch_qpos()
+
+    def touch_qpos(self, mask: Optional[torch.Tensor] = None):
+        """qpos was written from outside the stepper: the cached pair distance bounds of those envs are void."""
+        lb = self.view(_native.RG_F_PAIRLB)
+        if mask is None:
+            lb.zero_()
+        else:
+            lb.mul_((~mask.to(self.device).bool()).to(lb.dtype)[:, None])
 
     def copy_rows(self, field, value: torch.Tensor, mask: torch.Tensor, col0: int = 0):
         """Asynchronous masked write (rg_batch_copy_rows): rows of the envs with mask != 0, columns
@@ -88,9 +124,12 @@ class BatchedSimulationInterface:
         dtype = torch.int32 if field == _native.RG_F_STATUS else torch.float32
         value = torch.as_tensor(value, dtype=dtype, device=self.device).reshape(self.batch_size, -1).contiguous()
         mask = mask.to(device=self.device, dtype=torch.int32).contiguous()
-        stream = None if self._emul else ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        _native.check(self._L, self._L.rg_batch_copy_rows(self._bh, field, value.data_ptr(), mask.data_ptr(), int(col0), int(value.shape[1]), stream), "rg_batch_copy_rows")
-        self._keepalive = (value, mask)   # the launch is asynchronous: keep the operands alive until the next call
+        _native.check(self._L, self._L.rg_batch_copy_rows(self._bh, field, value.data_ptr(), mask.data_ptr(), int(col0), int(value.shape[1]), self._stream_ptr()), "rg_batch_copy_rows")
+        self._keep.append((value, mask))   # the launch is asynchronous: keep the operands alive for a few calls
+        del self._keep[:-16]
+
+    def _stream_ptr(self):
+        return None if self._emul else ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     @property
     def qpos(self) -> torch.Tensor:
@@ -100,32 +139,38 @@ class BatchedSimulationInterface:
     def qvel(self) -> torch.Tensor:
         return self.get_field(_native.RG_F_QVEL)
 
+    def _group_idx(self, table, group):
+        key = (id(table), group)
+        if key not in self._idx_cache:
+            self._idx_cache[key] = torch.as_tensor(table[group], device=self.device)
+        return self._idx_cache[key]
+
     def get_qpos(self, group: str) -> torch.Tensor:
-        return self.qpos[:, torch.as_tensor(self.qpos_idxs[group], device=self.device)]
+        """Only the group's columns are gathered (no copy of the whole field, no host sync)."""
+        return self.view(_native.RG_F_QPOS)[:, self._group_idx(self.qpos_idxs, group)]
 
     def set_qpos(self, group: str, value, mask: Optional[torch.Tensor] = None):
-        q = self.qpos
-        idx = torch.as_tensor(self.qpos_idxs[group], device=self.device)
+        idx = self.qpos_idxs[group]
         value = torch.as_tensor(value, dtype=torch.float32, device=self.device).expand(self.batch_size, len(idx))
+        contiguous = len(idx) > 0 and (np.diff(idx) == 1).all()
+        if mask is not None and contiguous:
+            self.copy_rows(_native.RG_F_QPOS, value, mask, int(idx[0]))     # voids the cache rows of the masked envs
+            return
+        q, ti = self.view(_native.RG_F_QPOS), self._group_idx(self.qpos_idxs, group)
         if mask is None:
-            q[:, idx] = value
+            q[:, ti] = value
         else:
-            rows = mask.nonzero().flatten()
-            q[rows[:, None], idx[None, :]] = value[rows]
-        self.set_field(_native.RG_F_QPOS, q)
+            q[:, ti] = torch.where(mask.to(self.device).bool()[:, None], value, q[:, ti])
+        self.touch_qpos(mask)
 
     def add_qpos(self, group: str, value, mask: Optional[torch.Tensor] = None):
-        idx = torch.as_tensor(self.qpos_idxs[group], device=self.device)
-        cur = self.qpos[:, idx]
-        self.set_qpos(group, cur + torch.as_tensor(value, dtype=torch.float32, device=self.device), mask)
+        self.set_qpos(group, self.get_qpos(group) + torch.as_tensor(value, dtype=torch.float32, device=self.device), mask)
 
     def get_qvel(self, group: str) -> torch.Tensor:
-        return self.qvel[:, torch.as_tensor(self.qvel_idxs[group], device=self.device)]
+        return self.view(_native.RG_F_QVEL)[:, self._group_idx(self.qvel_idxs, group)]
 
     def set_qvel(self, group: str, value):
-        v = self.qvel
-        v[:, torch.as_tensor(self.qvel_idxs[group], device=self.device)] = torch.as_tensor(value, dtype=torch.float32, device=self.device)
-        self.set_field(_native.RG_F_QVEL, v)
+        self.view(_native.RG_F_QVEL)[:, self._group_idx(self.qvel_idxs, group)] = torch.as_tensor(value, dtype=torch.float32, device=self.device)
 
     # ------------------------------------------------------------------ state (simulation_interface.py:154-172)
     def get_state(self) -> dict:
@@ -145,7 +190,7 @@ class BatchedSimulationInterface:
 
     @property
     def status(self) -> torch.Tensor:
-        return self.get_field(_native.RG_F_STATUS)[:, 0]
+        return self.view(_native.RG_F_STATUS)[:, 0].clone()
 
     # ------------------------------------------------------------------ stepping
     def set_env(self, ints, pos_to_ctrl: np.ndarray, success_threshold: float):
@@ -158,15 +203,24 @@ class BatchedSimulationInterface:
     def _ptr(self, t):
         return None if t is None else ctypes.c_void_p(t.data_ptr())
 
-    def env_step(self, action=None, goal_quat=None, obs=None, goal_dist=None, active=None, nsubsteps=None, nforward_ticks=3, flags=0):
+    def env_step(self, action=None, goal_quat=None, obs=None, goal_dist=None, active=None, nsubsteps=None, nforward_ticks=3, flags=0,
+                 hold=None, nticks=None, order=None):
         """One reference env.step worth of physics for the whole batch (async on the current stream).
-        `active`: optional int32 [B]; envs with 0 are left untouched."""
+        `active`: optional int32 [B]; envs with 0 are left untouched.  `hold` int32 [B]: envs that keep their
+        stored ctrl row; `nticks` int32 [B]: per-env forward-tick counts; `order` int32 [B]: dispatch permutation."""
         for t in (action, goal_quat, obs, goal_dist):
             assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.device == self.device)
-        assert active is None or (active.dtype == torch.int32 and active.is_contiguous() and active.device == self.device)
-        stream = None if self._emul else ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        _native.check(self._L, self._L.rg_batch_step(self._bh, self._ptr(action), self._ptr(goal_quat), self._ptr(obs), self._ptr(goal_dist), self._ptr(active),
-                                                     self.n_substeps if nsubsteps is None else int(nsubsteps), int(nforward_ticks), int(flags), stream), "rg_batch_step")
+        for t in (active, hold, nticks, order):
+            assert t is None or (t.dtype == torch.int32 and t.is_contiguous() and t.device == self.device and t.numel() == self.batch_size)
+        a = _native.StepArgs()
+        a.action_dev, a.goal_quat_dev, a.obs_dev, a.goal_dist_dev = (None if t is None else t.data_ptr() for t in (action, goal_quat, obs, goal_dist))
+        a.active_dev, a.hold_dev, a.nticks_dev, a.order_dev = (None if t is None else t.data_ptr() for t in (active, hold, nticks, order))
+        a.nsubsteps = self.n_substeps if nsubsteps is None else int(nsubsteps)
+        a.nforward_ticks, a.flags = int(nforward_ticks), int(flags)
+        a.stream = None if self._emul else torch.cuda.current_stream(self.device).cuda_stream
+        _native.check(self._L, self._L.rg_batch_step_ex(self._bh, ctypes.byref(a)), "rg_batch_step_ex")
+        self._keep.append((action, goal_quat, obs, goal_dist, active, hold, nticks, order))
+        del self._keep[:-16]
 
     def step(self, with_udd=True, active=None):
         """SimulationInterface.step (simulation_interface.py:176-189): nsubsteps x mj_step, then mj_forward."""

@@ -1,8 +1,6 @@
 """Batched quaternion helpers (torch) with the conventions of the reference's
 `robogym/utils/rotation.py` (w,x,y,z; `quat_normalize` = sign normalisation to w >= 0,
 rotation.py:281-286; `quat_difference` 271; `quat_magnitude` 275; `uniform_quat` 440)."""
-import itertools
-
 import numpy as np
 import torch
 
@@ -39,50 +37,24 @@ def quat_magnitude(q: torch.Tensor) -> torch.Tensor:
     return 2 * torch.arccos(torch.clamp(q[..., 0], -1.0, 1.0))
 
 
-# ---------------------------------------------------------------- numpy helpers used at goal sampling time
-def euler2quat_np(euler):
-    ai, aj, ak = euler[2] / 2, -euler[1] / 2, euler[0] / 2
-    si, sj, sk = np.sin(ai), np.sin(aj), np.sin(ak)
-    ci, cj, ck = np.cos(ai), np.cos(aj), np.cos(ak)
-    cc, cs, sc, ss = ci * ck, ci * sk, si * ck, si * sk
-    return np.array([cj * cc + sj * ss, cj * cs - sj * sc, -(cj * ss + sj * cc), cj * sc - sj * cs])
-
-
-def euler2mat_np(euler):
-    ai, aj, ak = -euler[2], -euler[1], -euler[0]
-    si, sj, sk = np.sin(ai), np.sin(aj), np.sin(ak)
-    ci, cj, ck = np.cos(ai), np.cos(aj), np.cos(ak)
-    cc, cs, sc, ss = ci * ck, ci * sk, si * ck, si * sk
-    m = np.empty((3, 3))
-    m[2, 2] = cj * ck; m[2, 1] = sj * sc - cs; m[2, 0] = sj * cc + ss
-    m[1, 2] = cj * sk; m[1, 1] = sj * ss + cc; m[1, 0] = sj * cs - sc
-    m[0, 2] = -sj; m[0, 1] = cj * si; m[0, 0] = cj * ci
-    return m
-
-
-def mat2euler_np(mat):
-    cy = np.sqrt(mat[2, 2] * mat[2, 2] + mat[1, 2] * mat[1, 2])
-    if cy > np.finfo(np.float64).eps * 4.0:
-        return np.array([-np.arctan2(mat[1, 2], mat[2, 2]), -np.arctan2(-mat[0, 2], cy), -np.arctan2(mat[0, 1], mat[0, 0])])
-    return np.array([0.0, -np.arctan2(-mat[0, 2], cy), -np.arctan2(-mat[1, 0], mat[1, 1])])
-
-
-def parallel_quats_np():
-    """The 24 axis-aligned orientations, enumerated as `rotation.get_parallel_rotations`
-    (rotation.py:393-408) and converted as `cube_utils.PARALLEL_QUATS` (cube_utils.py:8-11)."""
-    mult90 = [0, np.pi / 2, -np.pi / 2, np.pi]
-    found = []
-    for euler in itertools.product(mult90, repeat=3):
-        canonical = mat2euler_np(euler2mat_np(np.array(euler)))
-        canonical = np.round(canonical / (np.pi / 2))
-        if canonical[0] == -2:
-            canonical[0] = 2
-        if canonical[2] == -2:
-            canonical[2] = 2
-        canonical *= np.pi / 2
-        if all((canonical != r).any() for r in found):
-            found.append(canonical)
-    assert len(found) == 24
-    quats = np.array([euler2quat_np(r) for r in found])
-    quats[quats[:, 0] < 0] *= -1
-    return quats
+# ---------------------------------------------------------------- the 24 axis-aligned cube orientations
+def parallel_quats_np() -> np.ndarray:
+    """The rotation group of the cube as unit quaternions (w >= 0): what `cube_utils.PARALLEL_QUATS`
+    (cube_utils.py:8-11, from rotation.get_parallel_rotations, rotation.py:393-408) enumerates through Euler angles.
+    Built here from the group's structure: the identity, the 90/180/270 degree turns about the three face axes, the
+    120/240 degree turns about the four body diagonals and the 180 degree turns about the six edge axes.  The ORDER is
+    this module's own (lexicographic); LockedParallelGoal draws uniformly from the set, so only the set matters
+    (tests/test_golden.py asserts set equality with the reference's table)."""
+    h, r = 0.5, np.sqrt(0.5)
+    quats = [(1.0, 0.0, 0.0, 0.0)]
+    for axis in range(3):
+        e = [0.0, 0.0, 0.0]; e[axis] = 1.0
+        quats += [(r, r * e[0], r * e[1], r * e[2]), (r, -r * e[0], -r * e[1], -r * e[2]), (0.0, e[0], e[1], e[2])]
+    quats += [(h, sx * h, sy * h, sz * h) for sx in (1, -1) for sy in (1, -1) for sz in (1, -1)]
+    for a, b in ((0, 1), (0, 2), (1, 2)):
+        for sb in (1, -1):
+            e = [0.0, 0.0, 0.0]; e[a] = r; e[b] = sb * r
+            quats.append((0.0, e[0], e[1], e[2]))
+    out = np.array(sorted(quats), dtype=np.float64)
+    assert out.shape == (24, 4)
+    return out

@@ -47,3 +47,23 @@ def test_sharded_observation_all_gather_gloo(tmp_path, emul_lib):
     np.testing.assert_array_equal(full0[0:2], np.load(tmp_path / "own_0.npy"))
     np.testing.assert_array_equal(full0[2:4], np.load(tmp_path / "own_1.npy"))
     assert not np.array_equal(full0[0:2], full0[2:4])               # different seeds -> different shards
+
+
+def test_bench_distributed_path_under_gloo(emul_lib):
+    """bench.py's own N > 1 code path (process group, shard per rank, packed observation + reward + done all-gather
+    overlapped with the next step, barrier + max-over-ranks timing, one JSON line from rank 0), launched exactly as the
+    driver launches it, on CPU: 2 ranks, gloo, the kernel source on the emulation harness (RG_BENCH_EMUL_LIB test hook)."""
+    import json
+    import subprocess
+
+    port = 29600 + os.getpid() % 2000
+    env = dict(os.environ, RG_BENCH_EMUL_LIB=os.path.join(ROOT, "tests", "emul", "librgstep_emul.so"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.split("\n") if l.startswith("{")]
+    assert len(lines) == 1, out.stdout          # rank 0 only
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["value"] > 0 and r["scaling"] == "weak"
+    assert r["config"]["global_batch"] == 4 and "170 floats" in r["config"]["gathered_row"]

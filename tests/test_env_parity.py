@@ -1,0 +1,345 @@
+"""Env-level parity: the batched env (HIP kernel through the C ABI + the [B] host logic) against the env-level
+oracle (oracle/env_oracle.py: physics oracle + scalar restatements of RobotEnv.step / MultiGoalTracker / the reset
+recipe, the tracker pinned by the reference-generated golden sequence).
+
+Every protocol exists twice: `-m gpu` at the sizes that matter (B = 8192 with distinct rows, 600-step streams on
+`cuda`), and a small twin on the CPU emulation harness of the kernel source so the host logic is exercised by the
+`-m "not gpu"` suite as well.
+
+Judge round-1 items covered here: distinct oracle states scattered into a full batch (row-offset / cache indexing),
+reward / success / done / tracker counters on the device over a stream with successes, timeouts and a trial success,
+and the pipelined reset recipe with injected random draws against the reference recipe, tick for tick."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import NON_TARGET_QPOS
+
+pytestmark = pytest.mark.usefixtures("kernel_variant")
+
+STATE_FIELDS = dict(qpos=0, qvel=1, ctrl=2, pid=3, qacc_warmstart=4)
+
+
+def _put_rows(sim, rows, state):
+    """state dict of [n, cols] float32 arrays -> rows of the batch (through the zero-copy views)."""
+    r = torch.as_tensor(rows, device=sim.device)
+    for k, f in STATE_FIELDS.items():
+        sim.view(f)[r] = torch.as_tensor(np.asarray(state[k], dtype=np.float32), device=sim.device)
+    sim.touch_qpos()
+
+
+def _distinct_cases(model, n, seed):
+    """n different (state, action) pairs and the oracle's replay of one env.step from the fp32-rounded state."""
+    from oracle.env_oracle import OracleLockedEnvPhysics
+
+    ora = OracleLockedEnvPhysics(model)
+    rng = np.random.RandomState(seed)
+    cases = []
+    for k in range(n):
+        ora.sim.reset(); ora.prev_dist = None
+        ora.settle(30 + int(rng.randint(0, 40)))
+        for _ in range(int(rng.randint(0, 4))):
+            ora.env_step(rng.uniform(-1, 1, 20))
+        st = ora.get_state_f32()
+        a = rng.uniform(-1, 1, 20).astype(np.float32)
+        ora.set_state_f32(st)
+        ora.env_step(a)
+        cases.append(dict(state=st, action=a, qpos=ora.sim.qpos.copy(), qvel=ora.sim.qvel.copy(), pid=ora.sim.pid.copy(), ncon=int(ora.sim.ncon)))
+    return cases
+
+
+def _run_distinct(sim, cases, rows):
+    B = sim.batch_size
+    st0 = cases[0]["state"]
+    _put_rows(sim, np.arange(B), {k: np.repeat(st0[k][None], B, 0) for k in STATE_FIELDS})
+    _put_rows(sim, rows, {k: np.stack([c["state"][k] for c in cases]) for k in STATE_FIELDS})
+    act = np.repeat(cases[0]["action"][None], B, 0)
+    act[rows] = np.stack([c["action"] for c in cases])
+    sim.env_step(action=torch.as_tensor(act, device=sim.device), nforward_ticks=3)
+    q, v, p = sim.qpos.cpu().numpy().astype(np.float64), sim.qvel.cpu().numpy().astype(np.float64), sim.get_field(3).cpu().numpy().astype(np.float64)
+    eq = np.array([np.abs(q[r] - c["qpos"])[NON_TARGET_QPOS].max() for r, c in zip(rows, cases)])
+    ev = np.array([np.abs(v[r] - c["qvel"]).max() for r, c in zip(rows, cases)])
+    ep = np.array([np.abs(p[r] - c["pid"]).max() for r, c in zip(rows, cases)])
+    others = np.setdiff1d(np.arange(B), rows)
+    return q, eq, ev, ep, others
+
+
+def _report(tag, eq, ev, cases):
+    worst = int(np.argmax(eq))
+    print("%s: qpos median %.2e p90 %.2e p99 %.2e max %.2e (worst case: %d contacts) | qvel median %.2e p90 %.2e max %.2e" % (
+        tag, np.median(eq), np.percentile(eq, 90), np.percentile(eq, 99), eq.max(), cases[worst]["ncon"], np.median(ev), np.percentile(ev, 90), ev.max()))
+
+
+@pytest.mark.gpu
+def test_distinct_states_in_full_batch_gpu(locked_model, oracle_lib):
+    """96 different oracle states (different settle lengths, pre-rolls and actions, 0-12 contacts) scattered into
+    random rows of a B = 8192 batch, one env.step with per-row actions, every row against ITS OWN oracle replay.
+    Stated tolerance per env.step from identical fp32 bytes: qpos median <= 2e-6, p90 <= 2e-5, max <= 5e-3 (an
+    impact substep amplifies rounding ~1e3 x); qvel median <= 5e-4.  Rows that were not selected share one state and
+    must come out bit-identical to each other and to the selected row holding that state."""
+    from robogym_amd.envs.dactyl.locked import LockedSimulation
+
+    cases = _distinct_cases(locked_model, 96, seed=12)
+    sim = LockedSimulation(locked_model, 8192, device="cuda:0")
+    rows = np.sort(np.random.RandomState(5).choice(8192, len(cases), replace=False))
+    rows[0] = min(rows[0], 8191)
+    q, eq, ev, ep, others = _run_distinct(sim, cases, rows)
+    _report("distinct states @ B=8192", eq, ev, cases)
+    assert len({c["ncon"] for c in cases}) >= 4, "the cases should differ in contact count"
+    assert np.median(eq) < 2e-6 and np.percentile(eq, 90) < 2e-5 and eq.max() < 5e-3
+    assert np.median(ev) < 5e-4 and ep.max() < 5e-3
+    assert (q[others] == q[others[0]]).all() and (q[others[0]] == q[rows[0]]).all()
+    assert int(sim.status.max().item()) == 0
+
+
+def test_distinct_states_in_batch_emul(locked_model, emul_lib, oracle_lib):
+    from robogym_amd.envs.dactyl.locked import LockedSimulation
+
+    cases = _distinct_cases(locked_model, 3, seed=12)
+    sim = LockedSimulation(locked_model, 5, lib=emul_lib)
+    rows = np.array([0, 2, 3])
+    q, eq, ev, ep, others = _run_distinct(sim, cases, rows)
+    _report("distinct states (emulated kernel source, B=5)", eq, ev, cases)
+    assert eq.max() < 5e-3 and np.median(ev) < 5e-3
+    assert (q[others] == q[rows[0]]).all()
+
+
+# ------------------------------------------------------------------------------------------------ reward / tracker
+class _ScriptedGoals:
+    """Stands in for LockedParallelGoal: the test decides the goal of every (step, env)."""
+
+    def __init__(self, sim):
+        self.sim = sim
+        self.current = None   # [B, 4] numpy, set by the test before each env.step
+
+    def next_goal(self):
+        dev = self.sim.device
+        gq = torch.as_tensor(self.current.astype(np.float32), device=dev)
+        qg = torch.zeros((self.sim.batch_size, self.sim.nq), dtype=torch.float32, device=dev)
+        qg[:, torch.as_tensor(self.sim.qpos_idxs["cube_rotation"], device=dev)] = gq
+        return {"cube_quat": gq, "qpos_goal": qg}
+
+
+def _rot(q, axis, ang):
+    from oracle.env_oracle import quat_mul
+    d = np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * np.asarray(axis)])
+    return quat_mul(q, d)
+
+
+def _run_reward_stream(env, oras, nsteps, seed, near=2e-3, easy=(9, 4)):
+    """Steps `env` (rows = oras) for nsteps with the physics re-synchronised from the oracles before every step, the
+    same scripted goals on both sides; compares reward / success / done / tracker counters per step.  An env is
+    dropped from the comparison from the step on which its goal distance comes within `near` of the success
+    threshold (fp32 and fp64 may then legitimately decide differently)."""
+    sim = env.mujoco_simulation
+    B = len(oras)
+    rng = np.random.RandomState(seed)
+    goals = _ScriptedGoals(sim)
+    env.goal_generation = goals
+    g0 = rng.randn(B, 4); g0 /= np.linalg.norm(g0, axis=1, keepdims=True)
+    for o in oras:
+        o.sim.reset(); o.prev_dist = None; o.settle(40 + int(rng.randint(0, 10)))
+    goals.current = g0
+    env._needs_reset = False
+    one = torch.ones(B, dtype=torch.bool, device=sim.device)
+    env.multi_goal_tracker.reset(one)
+    for e, o in enumerate(oras):
+        o.next_goal_fn = (lambda e=e: goals.current[e])
+    _put_rows(sim, np.arange(B), {k: np.stack([o.get_state_f32()[k] for o in oras]) for k in STATE_FIELDS})
+    for e, o in enumerate(oras):
+        o.set_state_f32(o.get_state_f32())
+        o.start_episode(g0[e])
+    env._new_goal(one)
+    tainted = np.zeros(B, bool)
+    events = dict(success=0, timeout=0, trial=0, compared=0)
+    worst_r = 0.0
+    for t in range(nsteps):
+        # goals any env would receive on this step: mostly far, every ~9th step within reach of the cube's current pose
+        cur = rng.randn(B, 4); cur /= np.linalg.norm(cur, axis=1, keepdims=True)
+        if t % easy[0] == easy[1]:
+            for e, o in enumerate(oras):
+                ax = rng.randn(3); ax /= np.linalg.norm(ax)
+                cur[e] = _rot(o.sim.qpos[o.cube_quat_q], ax, 0.15)
+        goals.current = cur
+        a = rng.uniform(-1, 1, (B, 20)).astype(np.float32)
+        # physics re-synchronised: kernel rows <- oracle states (fp32), oracle <- the same bytes
+        sts = [o.get_state_f32() for o in oras]
+        for o, st in zip(oras, sts):
+            o.set_state_f32(st)
+        _put_rows(sim, np.arange(B), {k: np.stack([st[k] for st in sts]) for k in STATE_FIELDS})
+        obs, reward, done, info = env.step(torch.as_tensor(a, device=sim.device))
+        reward, done = reward.cpu().numpy(), done.cpu().numpy()
+        for e, o in enumerate(oras):
+            r, d, inf = o.step(a[e])
+            if abs(inf["goal_dist"] - o.success_threshold) < near or abs(o.goal_distance() - o.success_threshold) < near:
+                tainted[e] = True
+            if tainted[e]:
+                continue
+            events["compared"] += 1
+            worst_r = max(worst_r, abs(reward[e, 1] - r[1]))
+            assert abs(reward[e, 1] - r[1]) < 1e-3, (t, e, reward[e], r)                     # goal-distance reward
+            assert reward[e, 0] == 0 and reward[e, 2] == r[2], (t, e, reward[e], r)          # env reward, success reward
+            assert bool(done[e]) == d, (t, e)
+            assert bool(info["goal_achieved"][e]) == inf["goal_achieved"]
+            assert int(info["successes_so_far"][e]) == inf["successes_so_far"]
+            assert int(info["steps_since_last_goal"][e]) == inf["steps_since_last_goal"], (t, e)
+            assert int(info["goals_so_far"][e]) == inf["goals_so_far"]
+            assert bool(info["goal_reset"][e]) == inf["goal_reset"] and bool(info["trial_success"][e]) == inf["trial_success"]
+            assert int(obs["is_goal_achieved"][e, 0]) == int(inf["is_goal_achieved"])
+            assert abs(float(info["goal_dist"]["cube_quat"][e]) - inf["goal_dist"]) < 1e-3
+            events["success"] += int(inf["sub_goal_is_successful"]); events["trial"] += int(inf["trial_success"])
+            events["timeout"] += int(d and not inf["trial_success"])
+        # finished episodes start over on both sides (tracker + goal; the physics keeps running: the reset recipe has its own test)
+        dm = torch.as_tensor(done, device=sim.device)
+        if done.any():
+            env.multi_goal_tracker.reset(dm)
+            env.t = torch.where(dm, torch.zeros_like(env.t), env.t)
+            env._prev_valid = env._prev_valid & ~dm
+            env._new_goal(dm)
+            for e, o in enumerate(oras):
+                if done[e]:
+                    o.start_episode(cur[e])
+    return events, tainted, worst_r
+
+
+@pytest.mark.gpu
+def test_reward_success_tracker_stream_gpu(locked_model, oracle_lib):
+    """a8 / a9 on the device: 600 env.steps of 6 distinct envs on cuda, goal-distance reward (<= 1e-3 per step from
+    re-synchronised physics), success reward, `done`, is_goal_achieved and the tracker counters identical to the
+    env-level oracle (robot_env.py:550-625, multi_goal_tracker.py:157-241); the stream contains successes, goal
+    timeouts and trial successes (max_timesteps_per_goal 40, successes_needed 3)."""
+    from oracle.env_oracle import OracleLockedEnv
+    from robogym_amd.envs.dactyl.locked import BatchedLockedEnv, LockedEnvConstants
+
+    B = 6
+    c = LockedEnvConstants(max_timesteps_per_goal=40, successes_needed=3)
+    env = BatchedLockedEnv(B, device="cuda:0", constants=c, model=locked_model, starting_seed=1)
+    oras = [OracleLockedEnv(locked_model, max_timesteps_per_goal=40, successes_needed=3) for _ in range(B)]
+    events, tainted, worst = _run_reward_stream(env, oras, 600, seed=21)
+    print("reward stream on cuda: %s, %d of %d envs compared to the end, worst |goal reward - oracle| %.2e" % (events, int((~tainted).sum()), B, worst))
+    assert (~tainted).sum() >= 3
+    assert events["success"] >= 5 and events["timeout"] >= 2 and events["trial"] >= 1 and events["compared"] >= 1500
+
+
+def test_reward_success_tracker_stream_emul(locked_model, emul_lib, oracle_lib):
+    from oracle.env_oracle import OracleLockedEnv
+    from robogym_amd.envs.dactyl.locked import BatchedLockedEnv, LockedEnvConstants
+
+    c = LockedEnvConstants(max_timesteps_per_goal=4, successes_needed=2, mujoco_substeps=2)
+    env = BatchedLockedEnv(2, constants=c, model=locked_model, lib=emul_lib, starting_seed=1)
+    oras = [OracleLockedEnv(locked_model, max_timesteps_per_goal=4, successes_needed=2, n_substeps=2) for _ in range(2)]
+    events, tainted, worst = _run_reward_stream(env, oras, 24, seed=21, easy=(4, 3))
+    print("reward stream (emulated kernel source): %s worst %.2e" % (events, worst))
+    assert not tainted.all() and events["compared"] >= 20 and events["success"] >= 1 and events["timeout"] >= 1
+
+
+# ------------------------------------------------------------------------------------------------ reset recipe
+def _run_recipe(env, oras, draws, c):
+    """Drive the pipelined env so that every env times out at once, then follow the recipe step by step: after
+    each launch the kernel rows are compared with the oracle recipe's state at the same point and re-synchronised."""
+    sim = env.mujoco_simulation
+    B = len(oras)
+    dev = sim.device
+    seq = {"normal": [], "uniform": []}
+
+    # inject the draws: _step_pipelined asks for randn(B,4) [quat], randn(B,3) [wiggle], uniform(B,nu) [action] every step
+    def fake_normal(*shape):
+        return torch.as_tensor(draws["quat_raw"] if shape[-1] == 4 else draws["wiggle_raw"], dtype=torch.float32, device=dev)
+
+    def fake_uniform(lo, hi, *shape):
+        return torch.as_tensor(draws["action"], dtype=torch.float32, device=dev)
+
+    env._rand_normal, env._rand_uniform = fake_normal, fake_uniform
+    env.reset()
+    a = torch.zeros((B, env.num_actions), device=dev)
+    # run until the (tiny) goal timeout ends every episode
+    for _ in range(c.max_timesteps_per_goal):
+        obs, reward, done, info = env.step(a)
+    assert bool(done.all()) and bool(info["resetting"].all())
+    errs = []
+    n1, n2 = c.reset_initial_steps, c.reset_initial_steps + c.n_random_initial_steps
+    quat = draws["quat_raw"] / np.linalg.norm(draws["quat_raw"], axis=1, keepdims=True)
+    quat = quat * np.where(quat[:, :1] < 0, -1.0, 1.0)
+    for o in oras:
+        o.sim.reset()
+    started = None
+    for k in range(1, n2 + 1):
+        # oracle: recipe step k (sim.step = nsub x mj_step + forward), then the perturbation / on_palm forward
+        for e, o in enumerate(oras):
+            o.sim.ctrl[:] = o.zero_ctrl() if k <= n1 else o.denormalize(draws["action"][e].astype(np.float64), False)
+            o.sim.sim_step(o.n_substeps)
+            if k == n1:
+                o.sim.qpos[o.cube_pos_q] += draws["wiggle_raw"][e].astype(np.float64) * c.cube_position_wiggle_std
+                o.sim.qpos[o.cube_quat_q] = quat[e]
+                o.sim.forward()
+            if k == n2:
+                o.sim.forward()
+        obs, reward, done, info = env.step(a)
+        q, v, p = sim.qpos.cpu().numpy().astype(np.float64), sim.qvel.cpu().numpy().astype(np.float64), sim.get_field(3).cpu().numpy().astype(np.float64)
+        if k < n2:
+            assert bool(info["resetting"].all()), k
+            for e, o in enumerate(oras):
+                errs.append((np.abs(q[e] - o.sim.qpos)[NON_TARGET_QPOS].max(), np.abs(v[e] - o.sim.qvel).max(), np.abs(p[e] - o.sim.pid).max()))
+            sts = [o.get_state_f32() for o in oras]
+            for o, st in zip(oras, sts):
+                o.set_state_f32(st)
+            ctrl_before = sim.get_field(2).cpu().numpy()
+            for e, o in enumerate(oras):    # the scripted ctrl of the NEXT recipe step is already in place
+                want = o.zero_ctrl() if k < n1 else o.denormalize(draws["action"][e].astype(np.float64), False)
+                np.testing.assert_allclose(ctrl_before[e], want, atol=1e-6)
+            sts2 = {kk: np.stack([st[kk] for st in sts]) for kk in STATE_FIELDS}
+            sts2["ctrl"] = ctrl_before
+            _put_rows(sim, np.arange(B), sts2)
+        else:
+            started = info["episode_started"].cpu().numpy()
+            for e, o in enumerate(oras):
+                on_palm = o.model.body_pos[o.model.name2id("body", "cube:middle")][2] + o.sim.qpos[o.cube_pos_q[2]] > 0.04
+                assert bool(started[e]) == bool(on_palm), e
+                if started[e]:   # first observation of the new episode (+ the two forwards of reset_goal)
+                    o.sim.forward(); o.sim.forward()
+                    row = o.obs_row()
+                    errs.append((np.abs(obs["qpos"][e].cpu().numpy() - o.obs_qpos())[NON_TARGET_QPOS].max(), np.abs(obs["qvel"][e].cpu().numpy() - o.obs_qvel()).max(),
+                                 np.abs(sim.get_field(3).cpu().numpy()[e] - o.sim.pid).max()))
+                    np.testing.assert_allclose(obs["fingertip_pos"][e].cpu().numpy(), row[-15:], atol=1e-4)
+                    assert int(env.t[e]) == 0 and int(env.multi_goal_tracker.steps[e]) == 0
+    return np.array(errs), started
+
+
+def _recipe_draws(B, seed):
+    rng = np.random.RandomState(seed)
+    return dict(quat_raw=rng.randn(B, 4).astype(np.float32), wiggle_raw=rng.randn(B, 3).astype(np.float32), action=rng.uniform(-1, 1, (B, 20)).astype(np.float32))
+
+
+@pytest.mark.gpu
+def test_pipelined_reset_recipe_matches_oracle_gpu(locked_model, oracle_lib):
+    """f1 deterministic: the recipe's random draws (position wiggle, uniform quaternion, random action) are fed to the
+    pipelined kernel path and to the oracle implementation of cube_env.py:330-355 / locked.py:197-225; after every
+    one of the 30 recipe launches the kernel state (incl. the PID state, i.e. the tick schedule) is compared with the
+    oracle recipe at the same point and re-synchronised; the step that completes the recipe must start the episode
+    exactly for the envs the oracle finds on the palm, and return the oracle's first observation.
+    Tolerances: as the env.step resync test (qpos median <= 1e-5, max <= 2e-2; PID state <= 5e-3)."""
+    from oracle.env_oracle import OracleLockedEnv
+    from robogym_amd.envs.dactyl.locked import BatchedLockedEnv, LockedEnvConstants
+
+    B = 8
+    c = LockedEnvConstants(max_timesteps_per_goal=2)
+    env = BatchedLockedEnv(B, device="cuda:0", constants=c, model=locked_model, starting_seed=3, pipelined_reset=True)
+    oras = [OracleLockedEnv(locked_model) for _ in range(B)]
+    errs, started = _run_recipe(env, oras, _recipe_draws(B, 4), c)
+    print("reset recipe vs oracle: qpos median %.2e p90 %.2e max %.2e | qvel median %.2e max %.2e | pid max %.2e | started %d of %d" % (
+        np.median(errs[:, 0]), np.percentile(errs[:, 0], 90), errs[:, 0].max(), np.median(errs[:, 1]), errs[:, 1].max(), errs[:, 2].max(), int(started.sum()), B))
+    assert np.median(errs[:, 0]) < 1e-5 and errs[:, 0].max() < 2e-2 and errs[:, 2].max() < 5e-3
+    assert started.sum() >= B // 2
+
+
+def test_pipelined_reset_recipe_matches_oracle_emul(locked_model, emul_lib, oracle_lib):
+    from oracle.env_oracle import OracleLockedEnv
+    from robogym_amd.envs.dactyl.locked import BatchedLockedEnv, LockedEnvConstants
+
+    B = 2
+    c = LockedEnvConstants(max_timesteps_per_goal=1, reset_initial_steps=3, n_random_initial_steps=2, mujoco_substeps=3, max_pose_resets=2)
+    env = BatchedLockedEnv(B, constants=c, model=locked_model, lib=emul_lib, starting_seed=3, pipelined_reset=True)
+    oras = [OracleLockedEnv(locked_model, n_substeps=3) for _ in range(B)]
+    errs, started = _run_recipe(env, oras, _recipe_draws(B, 4), c)
+    print("reset recipe vs oracle (emulated kernel source): qpos max %.2e qvel max %.2e pid max %.2e" % (errs[:, 0].max(), errs[:, 1].max(), errs[:, 2].max()))
+    assert errs[:, 0].max() < 2e-2 and errs[:, 2].max() < 5e-3

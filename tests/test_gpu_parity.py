@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("kernel_variant")]
 
 
 @pytest.fixture(scope="module")
@@ -74,21 +74,25 @@ def test_resync_substep_errors_gpu(gpu_pair):
     errs = resync_errors(sim, ora, rng.uniform(-1, 1, (6, 20)), substep_level=True)
     print("substep resync errors: qpos max %.2e | qvel median %.2e p90 %.2e max %.2e" % (errs[:, 0].max(), np.median(errs[:, 1]), np.percentile(errs[:, 1], 90), errs[:, 1].max()))
     assert errs[:, 0].max() < 2e-6 + 0.008 * 5e-2
-    assert np.median(errs[:, 1]) < 2e-4 and errs[:, 1].max() < 5e-2
+    assert np.median(errs[:, 1]) < 2e-4 and np.percentile(errs[:, 1], 90) < 2e-3 and errs[:, 1].max() < 5e-2
     assert int(sim.status.max()) == 0
 
 
 def test_resync_env_step_errors_gpu(gpu_pair):
-    """One full env.step (action map, 10 substeps, 3 forward ticks) from identical bytes: the error that
-    accumulates over 10 substeps of contact-rich motion.  Stated tolerance: median qpos <= 1e-5, max <= 2e-2."""
+    """One full env.step (action map, 10 substeps, 3 forward ticks) from identical bytes, 100 random-action steps of a
+    free-running oracle trajectory (0-12 contacts): the error that accumulates over 10 substeps of contact-rich
+    motion.  Stated tolerance: qpos median <= 1e-6, p90 <= 1e-5, p99 <= 2e-3, max <= 5e-3; qvel median <= 2e-4, p90 <= 5e-3."""
     from tests.helpers import resync_errors
 
     sim, ora = gpu_pair
     ora.sim.reset(); ora.settle(40)
     rng = np.random.RandomState(5)
-    errs = resync_errors(sim, ora, rng.uniform(-1, 1, (12, 20)))
-    print("env-step resync errors: qpos median %.2e max %.2e | pid max %.2e" % (np.median(errs[:, 0]), errs[:, 0].max(), errs[:, 2].max()))
-    assert np.median(errs[:, 0]) < 1e-5 and errs[:, 0].max() < 2e-2
+    errs = resync_errors(sim, ora, rng.uniform(-1, 1, (100, 20)))
+    print("env-step resync errors: qpos median %.2e p90 %.2e p99 %.2e max %.2e | qvel median %.2e p90 %.2e max %.2e | pid max %.2e" % (
+        np.median(errs[:, 0]), np.percentile(errs[:, 0], 90), np.percentile(errs[:, 0], 99), errs[:, 0].max(),
+        np.median(errs[:, 1]), np.percentile(errs[:, 1], 90), errs[:, 1].max(), errs[:, 2].max()))
+    assert np.median(errs[:, 0]) < 1e-6 and np.percentile(errs[:, 0], 90) < 1e-5 and np.percentile(errs[:, 0], 99) < 2e-3 and errs[:, 0].max() < 5e-3
+    assert np.median(errs[:, 1]) < 2e-4 and np.percentile(errs[:, 1], 90) < 5e-3
 
 
 def test_observation_row_matches_oracle_gpu(gpu_pair):
@@ -232,3 +236,21 @@ def test_pipelined_reset_gpu():
     for k_, v in obs.items():
         assert torch.isfinite(v.float()).all(), k_
     assert int(env.sim_status().max().item()) & ~2 == 0
+
+
+def test_deviation_from_mujoco_restatement_gpu(gpu_pair, oracle_lib):
+    """The kernel against the oracle's DEFAULT configuration (libccd triangle-distance MPR depth and multi-point
+    box-box: the closest available statement of MuJoCo 2.0).  The kernel deliberately computes the MPR depth /
+    direction from the portal plane (DESIGN.md "Deviations"), so on flat contacts this is a measured, stated
+    deviation and not fp32 noise: per env.step from identical bytes, qpos median <= 2e-6 (most steps are identical),
+    max <= 5e-3; tools/parity_report.py writes the distribution and the contact-level deltas to profiles/."""
+    from tests.helpers import resync_errors
+
+    sim, ora = gpu_pair
+    oracle_lib.set_kernel_variant(False)
+    ora.sim.reset(); ora.settle(40)
+    rng = np.random.RandomState(5)
+    errs = resync_errors(sim, ora, rng.uniform(-1, 1, (40, 20)))
+    print("deviation vs MuJoCo restatement (libccd MPR depth): qpos median %.2e p90 %.2e p99 %.2e max %.2e | qvel median %.2e max %.2e" % (
+        np.median(errs[:, 0]), np.percentile(errs[:, 0], 90), np.percentile(errs[:, 0], 99), errs[:, 0].max(), np.median(errs[:, 1]), errs[:, 1].max()))
+    assert np.median(errs[:, 0]) < 2e-6 and errs[:, 0].max() < 5e-3 and errs[:, 1].max() < 0.3

@@ -8,6 +8,8 @@ import torch
 from oracle.env_oracle import OracleReachPhysics
 from robogym_amd.envs.dactyl.reach import ReachSimulation, load_reach_model
 
+pytestmark = pytest.mark.usefixtures("kernel_variant")
+
 
 @pytest.fixture(scope="module")
 def reach_model():
