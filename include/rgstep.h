@@ -114,7 +114,15 @@ typedef struct rg_step_args {
   const int* active_dev; const int* hold_dev; const int* nticks_dev; const int* order_dev;
   int nsubsteps, nforward_ticks, flags;
   void* stream;
+  /* Kernel configuration: RG_CFG_ROLLOUT holds 24 contacts / 896 Jacobian words per env in LDS (rollouts: mean 3.5
+   * contacts, P(> 21) < 2e-6 per mj_step; 9 envs in flight per CU), RG_CFG_LARGE 64 / 3072 (the reset recipe, where the
+   * hand closes around a freshly dropped cube; MuJoCo's nconmax for these models is 100).
+   * redo_dev int [B] (RG_CFG_ROLLOUT only, may be NULL): an env that exceeds the rollout capacities is left untouched
+   * and gets redo_dev[e] = 1 instead of dropping contacts; pass the array as active_dev of an RG_CFG_LARGE launch. */
+  int config;
+  int* redo_dev;
 } rg_step_args;
+enum { RG_CFG_ROLLOUT = 0, RG_CFG_LARGE = 1 };
 int rg_batch_step_ex(rg_batch* b, const rg_step_args* args);
 /* Device address of a field's [B][n] buffer inside the batch (library-owned; valid until rg_batch_free) and its
  * row length in 4-byte words: zero-copy views for callers that live on the same device (torch tensors over
@@ -128,8 +136,9 @@ int rg_model_npair(const rg_model* m);
 int rg_batch_mpr_pair(rg_batch* b, int g1, int g2, float margin, float* out_dev, void* stream);
 int rg_obs_dim(const rg_batch* b);
 int rg_debug_size(void);
-/* bytes of LDS one env occupies (diagnostic) */
+/* bytes of LDS one env occupies in the rollout configuration (diagnostic); rg_lds_bytes_cfg: any configuration */
 int rg_lds_bytes(void);
+int rg_lds_bytes_cfg(int config);
 int rg_sync(void* stream);
 const char* rg_last_error(void);
 

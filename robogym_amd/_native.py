@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librgstep.so")
+LIB_PATH = os.environ.get("RGSTEP_LIB") or os.path.join(_HERE, "csrc", "librgstep.so")   # (RGSTEP_LIB: A/B builds of the same ABI, tools/ only)
 
 RG_F_QPOS, RG_F_QVEL, RG_F_CTRL, RG_F_PID, RG_F_WARMSTART, RG_F_TIME, RG_F_STATUS, RG_F_STATS, RG_F_DEBUG, RG_F_COST, RG_F_PAIRLB = range(11)
 RG_STATUS_BAD_STATE, RG_STATUS_CON_FULL, RG_STATUS_CAND_FULL, RG_STATUS_ROW_FULL, RG_STATUS_BAD_FACTOR, RG_STATUS_BAD_ACTION = 1, 2, 4, 8, 16, 32
@@ -19,13 +19,17 @@ class StepArgs(ctypes.Structure):
 
     _fields_ = [("action_dev", ctypes.c_void_p), ("goal_quat_dev", ctypes.c_void_p), ("obs_dev", ctypes.c_void_p), ("goal_dist_dev", ctypes.c_void_p),
                 ("active_dev", ctypes.c_void_p), ("hold_dev", ctypes.c_void_p), ("nticks_dev", ctypes.c_void_p), ("order_dev", ctypes.c_void_p),
-                ("nsubsteps", ctypes.c_int), ("nforward_ticks", ctypes.c_int), ("flags", ctypes.c_int), ("stream", ctypes.c_void_p)]
+                ("nsubsteps", ctypes.c_int), ("nforward_ticks", ctypes.c_int), ("flags", ctypes.c_int), ("stream", ctypes.c_void_p),
+                ("config", ctypes.c_int), ("redo_dev", ctypes.c_void_p)]
+
+
+RG_CFG_ROLLOUT, RG_CFG_LARGE = 0, 1
 
 
 EXPORTS = [
     "rg_model_create", "rg_model_free", "rg_model_dims", "rg_batch_create", "rg_batch_free", "rg_batch_set_env",
     "rg_batch_copy", "rg_batch_reset", "rg_batch_step", "rg_obs_dim", "rg_debug_size", "rg_lds_bytes", "rg_sync",
-    "rg_last_error", "rg_batch_mpr_pair", "rg_batch_copy_rows", "rg_batch_step_ex", "rg_batch_field_ptr", "rg_model_create_on", "rg_model_npair",
+    "rg_last_error", "rg_batch_mpr_pair", "rg_batch_copy_rows", "rg_batch_step_ex", "rg_batch_field_ptr", "rg_model_create_on", "rg_model_npair", "rg_lds_bytes_cfg",
 ]
 
 
@@ -64,6 +68,8 @@ def bind(path):
     L.rg_obs_dim.argtypes = [vp]
     L.rg_debug_size.restype = ci
     L.rg_lds_bytes.restype = ci
+    L.rg_lds_bytes_cfg.restype = ci
+    L.rg_lds_bytes_cfg.argtypes = [ci]
     L.rg_sync.argtypes = [vp]
     L.rg_last_error.restype = ctypes.c_char_p
     return L

@@ -2,7 +2,31 @@
 // Parses the RGMODEL1 blob, keeps fp32/int32 copies of every model table in HBM, owns the
 // per-batch state rows and launches the env-step kernel (one 64-lane workgroup per env).
 #include "../../include/rgstep.h"
+// two kernel configurations of the same source (rg_kernel.h, "Everything below depends on ..."): LDS per env is what
+// bounds the envs in flight per CU, so the hot path runs with capacities sized for rollouts and the reset recipe
+// (2-3 x more contacts) with larger ones
+#define RG_NS rgs
+#define RG_MAXCON 24
+#define RG_CPOOL 896
+#define RG_MAXCAND 128
+#define RG_MAXCAND2 64
 #include "rg_kernel.h"
+#undef RG_NS
+#undef RG_MAXCON
+#undef RG_CPOOL
+#undef RG_MAXCAND
+#undef RG_MAXCAND2
+#define RG_NS rgl
+#define RG_MAXCON 64
+#define RG_CPOOL 3072
+#define RG_MAXCAND 256
+#define RG_MAXCAND2 128
+#include "rg_kernel.h"
+#undef RG_NS
+#undef RG_MAXCON
+#undef RG_CPOOL
+#undef RG_MAXCAND
+#undef RG_MAXCAND2
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -107,7 +131,8 @@ extern "C" {
 
 const char* rg_last_error(void) { return g_err.c_str(); }
 int rg_debug_size(void) { return RG_DBG_SIZE; }
-int rg_lds_bytes(void) { return (int)sizeof(RgLds); }
+int rg_lds_bytes(void) { return (int)rgs::rg_lds_launch_bytes(false); }
+int rg_lds_bytes_cfg(int config) { return (int)(config == RG_CFG_LARGE ? rgl::rg_lds_launch_bytes(false) : rgs::rg_lds_launch_bytes(false)); }
 
 rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen) {
   auto bail = [&](const std::string& msg, rg_model* m) -> rg_model* {
@@ -140,7 +165,7 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
     return bail("model exceeds the compiled kernel capacities (rg_types.h)", m);
   GI("k_blk_dims");
   d.nvc = iv[0]; d.hs = iv[1]; d.blkwords = iv[2]; d.ntree = iv[3]; d.maxtree = iv[4];
-  if (d.nvc > RG_MAXNVC || d.blkwords > RG_MAXBLK || d.nvc * d.hs > RG_HWORDS || d.blkwords > RG_HWORDS || d.npair >= 32768)
+  if (d.nvc > RG_MAXNVC || d.nvc * d.hs > RG_HWORDS || d.blkwords > RG_HWORDS || d.npair >= 32768)
     return bail("model exceeds the compiled solver capacities (rg_types.h)", m);
   UPI(dof_blk, "k_dof_blk"); UPI(dof_blk2, "k_dof_blk2"); UPI(c_blk, "k_c_blk"); UPI(d2c, "k_d2c"); UPI(c2d, "k_c2d");
   GI("opt_int"); d.iterations = iv[0]; d.cone = iv[1]; d.mpr_iterations = iv[3];
@@ -193,6 +218,20 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
   }
   UPI(lvl_dof, "k_lvl_dof"); UPI(lvl_dof_adr, "k_lvl_dof_adr"); UPI(M_i, "k_M_i"); UPI(M_j, "k_M_j"); UPI(M_lvl_adr, "k_M_lvl_adr");
   UPI(desc_adr, "k_desc_adr"); UPI(desc, "k_desc");
+  {  // per tree-sparse entry of M: its two words in the per-tree block layout and its place in the compact Newton space
+    std::vector<int> mi, mj, blk, d2c;
+    if (!get_i(B, "k_M_i", mi, e) || !get_i(B, "k_M_j", mj, e) || !get_i(B, "k_dof_blk", blk, e) || !get_i(B, "k_d2c", d2c, e)) return bail(e, m);
+    if ((int)mi.size() > RG_MAXNM || mi.size() != mj.size()) return bail("inertia matrix has more non-zeros than RG_MAXNM", m);
+    std::vector<int> ent(2 * (mi.size() ? mi.size() : 1), 0);
+    for (size_t k = 0; k < mi.size(); k++) {
+      int i = mi[k], j = mj[k], s0 = (blk[i] >> 16) & 255;
+      int aij = (blk[i] & 0xFFFF) + (j - s0), aji = (blk[j] & 0xFFFF) + (i - s0);
+      if (aij >= RG_HWORDS || aji >= RG_HWORDS || aij < 0 || aji < 0) return bail("inertia block layout exceeds RG_HWORDS", m);
+      ent[2 * k] = aij | (aji << 16);
+      ent[2 * k + 1] = (d2c[i] >= 0 && d2c[j] >= 0) ? (d2c[i] | (d2c[j] << 8) | (1 << 16)) : 0;
+    }
+    if (!upload<int>(m, ent, &d.M_ent)) return bail("hipMalloc failed", m);
+  }
   UPI(geom_type, "geom_type"); UPI(geom_bodyid, "geom_bodyid"); UPI(geom_dataid, "geom_dataid"); UPI(body_geomadr, "body_geomadr"); UPI(body_geomnum, "body_geomnum");
   UPF(geom_size, "geom_size"); UPF(geom_rbound, "geom_rbound"); UPF(geom_pos, "geom_pos"); UPF(geom_quat, "geom_quat"); UPF(geom_aabb, "k_geom_aabb");
   UPI(site_bodyid, "site_bodyid"); UPF(site_pos, "site_pos");
@@ -401,7 +440,7 @@ int rg_batch_copy(rg_batch* b, int field, void* ptr, int to_batch, int ptr_is_de
 
 #ifdef RG_EMUL
 struct EmulCopyArgs { float* dst; const float* src; const int* mask; int n, col0, ncols; float* lb; int npair; };
-static void emul_copy_entry(void* a) { EmulCopyArgs* p = (EmulCopyArgs*)a; rg_copy_rows_kernel(p->dst, p->src, p->mask, p->n, p->col0, p->ncols, p->lb, p->npair); }
+static void emul_copy_entry(void* a) { EmulCopyArgs* p = (EmulCopyArgs*)a; rgs::rg_copy_rows_kernel(p->dst, p->src, p->mask, p->n, p->col0, p->ncols, p->lb, p->npair); }
 #endif
 int rg_batch_copy_rows(rg_batch* b, int field, const void* src_dev, const int* mask_dev, int col0, int ncols, void* stream) {
   if (!b || !src_dev || !mask_dev) return fail("rg_batch_copy_rows: null argument");
@@ -426,7 +465,7 @@ int rg_batch_copy_rows(rg_batch* b, int field, const void* src_dev, const int* m
   EmulCopyArgs args{(float*)p, (const float*)src_dev, mask_dev, n, col0, ncols, lb, d.npair};
   emul_launch(s.B, 16, emul_copy_entry, &args);
 #else
-  hipLaunchKernelGGL(rg_copy_rows_kernel, dim3(s.B), dim3(RG_WAVE), 0, (hipStream_t)stream, (float*)p, (const float*)src_dev, mask_dev, n, col0, ncols, lb, d.npair);
+  hipLaunchKernelGGL(rgs::rg_copy_rows_kernel, dim3(s.B), dim3(RG_WAVE), 0, (hipStream_t)stream, (float*)p, (const float*)src_dev, mask_dev, n, col0, ncols, lb, d.npair);
   HIPCHK(hipGetLastError());
 #endif
   return 0;
@@ -434,7 +473,8 @@ int rg_batch_copy_rows(rg_batch* b, int field, const void* src_dev, const int* m
 
 #ifdef RG_EMUL
 struct EmulArgs { const RgModelDev* m; RgLaunch launch; };
-static void emul_entry(void* a) { EmulArgs* p = (EmulArgs*)a; rg_step_kernel(p->m, p->launch); }
+static void emul_entry(void* a) { EmulArgs* p = (EmulArgs*)a; rgs::rg_step_kernel(p->m, p->launch); }
+static void emul_entry_large(void* a) { EmulArgs* p = (EmulArgs*)a; rgl::rg_step_kernel(p->m, p->launch); }
 #endif
 
 int rg_batch_step_ex(rg_batch* b, const rg_step_args* a) {
@@ -445,12 +485,17 @@ int rg_batch_step_ex(rg_batch* b, const rg_step_args* a) {
   RgBatchDev bt = b->dev;
   bt.action = a->action_dev; bt.goal_quat = a->goal_quat_dev; bt.obs = a->obs_dev; bt.goal_dist = a->goal_dist_dev; bt.active = a->active_dev;
   bt.hold = a->hold_dev; bt.nticks = a->nticks_dev; bt.order = a->order_dev;
+  const bool large = a->config == RG_CFG_LARGE, prof = (a->flags & 2) != 0;
+  if (a->config != RG_CFG_LARGE && a->config != RG_CFG_ROLLOUT) return fail("rg_batch_step: unknown kernel configuration");
+  bt.redo = large ? nullptr : a->redo_dev;
   RgLaunch launch{b->model->aux, b->env, bt, a->nsubsteps, a->nforward_ticks, a->flags};
+  const size_t lds = large ? rgl::rg_lds_launch_bytes(prof) : rgs::rg_lds_launch_bytes(prof);
 #ifdef RG_EMUL
   EmulArgs args{b->model->dev_copy, launch};
-  emul_launch(bt.B, sizeof(RgLds), emul_entry, &args);
+  emul_launch(bt.B, lds, large ? emul_entry_large : emul_entry, &args);
 #else
-  hipLaunchKernelGGL(rg_step_kernel, dim3(bt.B), dim3(RG_WAVE), sizeof(RgLds), (hipStream_t)a->stream, b->model->dev_copy, launch);
+  if (large) hipLaunchKernelGGL(rgl::rg_step_kernel, dim3(bt.B), dim3(RG_WAVE), lds, (hipStream_t)a->stream, b->model->dev_copy, launch);
+  else hipLaunchKernelGGL(rgs::rg_step_kernel, dim3(bt.B), dim3(RG_WAVE), lds, (hipStream_t)a->stream, b->model->dev_copy, launch);
   HIPCHK(hipGetLastError());
 #endif
   return 0;
@@ -466,7 +511,7 @@ int rg_batch_step(rg_batch* b, const float* action_dev, const float* goal_quat_d
 
 #ifdef RG_EMUL
 struct EmulMprArgs { const RgModelDev* m; RgLaunch launch; int g1, g2; float margin; float* out; };
-static void emul_mpr_entry(void* a) { EmulMprArgs* p = (EmulMprArgs*)a; rg_mpr_pair_kernel(p->m, p->launch, p->g1, p->g2, p->margin, p->out); }
+static void emul_mpr_entry(void* a) { EmulMprArgs* p = (EmulMprArgs*)a; rgs::rg_mpr_pair_kernel(p->m, p->launch, p->g1, p->g2, p->margin, p->out); }
 #endif
 int rg_batch_mpr_pair(rg_batch* b, int g1, int g2, float margin, float* out_dev, void* stream) {
   if (!b || !out_dev) return fail("null argument");
@@ -476,9 +521,9 @@ int rg_batch_mpr_pair(rg_batch* b, int g1, int g2, float margin, float* out_dev,
   RgLaunch launch{b->model->aux, b->env, b->dev, 0, 0, 0};
 #ifdef RG_EMUL
   EmulMprArgs args{b->model->dev_copy, launch, g1, g2, margin, out_dev};
-  emul_launch(b->dev.B, sizeof(RgLds), emul_mpr_entry, &args);
+  emul_launch(b->dev.B, sizeof(rgs::RgLds), emul_mpr_entry, &args);
 #else
-  hipLaunchKernelGGL(rg_mpr_pair_kernel, dim3(b->dev.B), dim3(RG_WAVE), sizeof(RgLds), (hipStream_t)stream, b->model->dev_copy, launch, g1, g2, margin, out_dev);
+  hipLaunchKernelGGL(rgs::rg_mpr_pair_kernel, dim3(b->dev.B), dim3(RG_WAVE), sizeof(rgs::RgLds), (hipStream_t)stream, b->model->dev_copy, launch, g1, g2, margin, out_dev);
   HIPCHK(hipGetLastError());
 #endif
   return 0;

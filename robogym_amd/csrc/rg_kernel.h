@@ -14,7 +14,8 @@
 // Replaces, for the hot path, mujoco_py.MjSim.step + mjpid (reference call sites:
 // /root/reference/robogym/mujoco/simulation_interface.py:176-189, :86-88) and the readout done by
 // /root/reference/robogym/robot_env.py:804-844.  Semantics follow the CPU oracle stage by stage.
-#pragma once
+#ifndef RG_KERNEL_COMMON_H
+#define RG_KERNEL_COMMON_H
 #include "rg_types.h"
 
 #ifdef RG_EMUL
@@ -30,63 +31,7 @@ typedef const RgModelDev& RgM;
 // compiler may re-issue next to its use instead of keeping ~240 SGPRs of pointers alive
 typedef const __attribute__((address_space(4))) RgModelDev& RgM;
 #endif
-#define RG_MAXPYR (RG_MAXCON * 6)
 #define RG_NPROF 24
-#define RG_HWORDS 1088  // work matrix: max(inertia blocks, nvc x hs)
-
-// Per-env LDS image (~23 kB: LDS capacity is what bounds the number of envs in flight per CU).
-// Arrays whose lifetimes inside a substep do not overlap share storage:
-//   pos:  position/velocity/collision scratch, itself overlaid by phase
-//           slot A: kinematics frames (T1-T3) | composite inertias (T4) | velocity-stage vectors (T6-T8)
-//           slot B: geom frames (until the narrowphase), slot C: cinert, slot D: candidates + raw contacts
-//   slv:  solver scratch — H holds, in turn, chol(M) (block layout), the Newton Hessian (compact nvc x hs)
-//         and chol(M + hB); all needed only after `pos` died.
-struct RgLds {
-  // state
-  alignas(16) float qpos[RG_MAXNQ], qvel[RG_MAXNV], ctrl[RG_MAXU], pid[3 * RG_MAXU], warm[RG_MAXNV];
-  // persistent through the substep
-  float org[4 * 3];   // com-frame origin per kinematic tree (slot via b2org)
-  alignas(16) float M[RG_MAXBLK];  // joint-space inertia as dense per-tree blocks
-  float tenlen[RG_MAXTEN], tenJ[RG_MAXTEN * 4];
-  float actlen[RG_MAXU], actfrc[RG_MAXU];
-  float qfrc_smooth[RG_MAXNV], qacc_smooth[RG_MAXNV];
-  float r_D[RG_MAXSROW], r_aref[RG_MAXSROW], r_floss[RG_MAXFRIC];
-  unsigned short r_desc[RG_MAXSROW];   // compact dof (6 bits) | tendon id (5 bits, 31 = none) << 6 | negative sign << 11
-  unsigned char ten_cdof[RG_MAXTEN * 4], c2d[RG_MAXNVC], b2org[RG_MAXBODY];
-  int cblk[RG_MAXNVC];   // per compact dof: inertia-block row word | compact index of its tree start << 16 | tree size << 24
-  int ncand, ncand2, ncon;
-  float c_D[RG_MAXCON], c_mu[RG_MAXCON * 3];
-  short c_pair[RG_MAXCON], c_off[RG_MAXCON];
-  unsigned char c_dim[RG_MAXCON], c_nnz[RG_MAXCON];
-  unsigned char c_idx[RG_MAXCON * RG_W];
-  float c_pool[RG_CPOOL];  // basis Jacobian rows (normal, tangent1, tangent2, spin) x nnz, packed per contact
-  float p_aref[RG_MAXPYR];
-  unsigned int status;
-  float prof[RG_NPROF];
-  union {
-    struct {  // ---- pos
-      union {  // slot A
-        struct { float xpos[RG_MAXBODY * 3], xquat[RG_MAXBODY * 4], xmat[RG_MAXBODY * 9], xipos[RG_MAXBODY * 3], xanchor[RG_MAXJNT * 3], xaxis[RG_MAXJNT * 3], spos[RG_MAXSITE * 3]; };
-        struct { float crb[RG_MAXBODY * 10]; };
-        struct { float cdofdot[RG_MAXNV * 6], cacc[RG_MAXBODY * 6], cfrc[RG_MAXBODY * 6], tenfrc[RG_MAXTEN], tenvel[RG_MAXTEN], qfrc_passive[RG_MAXNV], qfrc_bias[RG_MAXNV], qfrc_act[RG_MAXNV]; short tlist[RG_TLIST]; };
-      };
-      float gpos[RG_MAXGEOM * 3], gmat[RG_MAXGEOM * 9];  // slot B
-      float cinert[RG_MAXBODY * 10], cdof[RG_MAXNV * 6];  // slot C (alive from com_pos to the constraint rows)
-      short cand[RG_MAXCAND], cand2[RG_MAXCAND2];         // slot D
-      float gspeed[RG_MAXGEOM];  // bound on the speed of any point of the geom (velocity stage -> broadphase)
-      float c_dist[RG_MAXCON], c_pos[RG_MAXCON * 3], c_normal[RG_MAXCON * 3];
-    };
-    struct {  // ---- slv
-      alignas(16) float H[RG_HWORDS];
-      float a[RG_MAXNVC], as[RG_MAXNVC], fs[RG_MAXNVC], jtf[RG_MAXNVC], Ma[RG_MAXNVC], search[RG_MAXNVC], Mv[RG_MAXNVC], dinv[RG_MAXNV], tmpv[RG_MAXNV], qfrc_con[RG_MAXNV], qacc[RG_MAXNV];
-      float r_jar[RG_MAXSROW], r_jv[RG_MAXSROW], r_force[RG_MAXSROW];
-      unsigned char r_quad[RG_MAXSROW], p_quad[RG_MAXPYR];
-      float c_bdot[RG_MAXCON * 4], c_bfrc[RG_MAXCON * 4];
-      float p_jar[RG_MAXPYR], p_jv[RG_MAXPYR], p_force[RG_MAXPYR];
-    };
-  };
-};
-
 struct RgAux {  // extra static tables (kept out of RgModelDev to keep the kernarg small)
   const int *subtree_adr, *subtree;
   const uint32_t* dof_velmask;
@@ -290,6 +235,81 @@ __device__ __forceinline__ void cross_force(float* r, const float* vel, const fl
   v3 w = ld3(vel), vt = ld3(vel + 3), a = ld3(f), b = ld3(f + 3);
   st3(r, cross(w, a) + cross(vt, b)); st3(r + 3, cross(w, b));
 }
+
+#endif  // RG_KERNEL_COMMON_H
+
+// =================================================================================================================
+// Everything below depends on the compiled contact / candidate capacities and is instantiated once per kernel
+// CONFIGURATION: the includer defines RG_NS (namespace), RG_MAXCON, RG_CPOOL, RG_MAXCAND, RG_MAXCAND2 and includes this
+// file again (rg_api.hip: "rollout" capacities sized for the hot path, "large" ones for the reset recipe, where a hand
+// closing around a freshly dropped cube makes 2-3 x more contacts).  LDS per env, hence envs in flight per CU, is what
+// the capacities buy.
+// =================================================================================================================
+#if !defined(RG_NS) || !defined(RG_MAXCON) || !defined(RG_CPOOL) || !defined(RG_MAXCAND) || !defined(RG_MAXCAND2)
+#error "define RG_NS, RG_MAXCON, RG_CPOOL, RG_MAXCAND, RG_MAXCAND2 before including rg_kernel.h"
+#endif
+namespace RG_NS {
+#define RG_MAXPYR (RG_MAXCON * 6)
+#define RG_PSLOTS ((RG_MAXPYR + RG_WAVE - 1) / RG_WAVE)   // pyramid rows a lane owns during a line search
+
+// Per-env LDS image (LDS capacity is what bounds the number of envs in flight per CU).
+// Arrays whose lifetimes inside a substep do not overlap share storage:
+//   pos:  position/velocity/collision scratch, itself overlaid by phase
+//           slot A: kinematics frames (T1-T3) | composite inertias (T4) | velocity-stage vectors (T6-T8)
+//           slot B: geom frames (until the narrowphase)
+//           slot C: cinert (com_pos .. velocity) | candidate lists + raw contacts (collision .. constraint rows)
+//   slv:  solver scratch — H holds, in turn, the per-tree block expansion of M and its L'DL factor, the Newton
+//         Hessian (compact nvc x hs) and M + hB; all needed only after `pos` died.
+// The joint-space inertia M persists in MuJoCo's tree-sparse form (one word per (dof, ancestor) pair, 149 for the hand
+// models) and is expanded into H's block layout where a factorisation needs it.
+struct RgLds {
+  // state
+  alignas(16) float qpos[RG_MAXNQ], qvel[RG_MAXNV], ctrl[RG_MAXU], pid[3 * RG_MAXU], warm[RG_MAXNV];
+  // persistent through the substep
+  float org[4 * 3];   // com-frame origin per kinematic tree (slot via b2org)
+  float Msp[RG_MAXNM];  // M[i][j] for the model's (i, j = i or an ancestor of i) list (M_i, M_j)
+  float tenlen[RG_MAXTEN], tenJ[RG_MAXTEN * 4];
+  float actlen[RG_MAXU], actfrc[RG_MAXU];
+  float qfrc_smooth[RG_MAXNV], qacc_smooth[RG_MAXNV];
+  float r_D[RG_MAXSROW], r_aref[RG_MAXSROW], r_floss[RG_MAXFRIC];
+  unsigned short r_desc[RG_MAXSROW];   // compact dof (6 bits) | tendon id (5 bits, 31 = none) << 6 | negative sign << 11
+  unsigned char ten_cdof[RG_MAXTEN * 4], c2d[RG_MAXNVC], b2org[RG_MAXBODY];
+  int cblk[RG_MAXNVC];   // per compact dof: inertia-block row word | compact index of its tree start << 16 | tree size << 24
+  int ncand, ncand2, ncon;
+  float c_D[RG_MAXCON], c_mu[RG_MAXCON * 3];
+  short c_pair[RG_MAXCON], c_off[RG_MAXCON];
+  unsigned char c_dim[RG_MAXCON], c_nnz[RG_MAXCON];
+  unsigned char c_idx[RG_MAXCON * RG_W];
+  float c_pool[RG_CPOOL];  // basis Jacobian rows (normal, tangent1, tangent2, spin) x nnz, packed per contact
+  float p_aref[RG_MAXPYR];
+  unsigned int status;
+  union {
+    struct {  // ---- pos
+      union {  // slot A
+        struct { float xpos[RG_MAXBODY * 3], xquat[RG_MAXBODY * 4], xmat[RG_MAXBODY * 9], xipos[RG_MAXBODY * 3], xanchor[RG_MAXJNT * 3], xaxis[RG_MAXJNT * 3], spos[RG_MAXSITE * 3]; };
+        struct { float crb[RG_MAXBODY * 10]; };
+        struct { float cdofdot[RG_MAXNV * 6], cacc[RG_MAXBODY * 6], cfrc[RG_MAXBODY * 6], tenfrc[RG_MAXTEN], tenvel[RG_MAXTEN], qfrc_passive[RG_MAXNV], qfrc_bias[RG_MAXNV], qfrc_act[RG_MAXNV]; short tlist[RG_TLIST]; };
+      };
+      float gpos[RG_MAXGEOM * 3], gmat[RG_MAXGEOM * 9];  // slot B
+      float cdof[RG_MAXNV * 6];   // alive from com_pos to the constraint rows
+      float gspeed[RG_MAXGEOM];  // bound on the speed of any point of the geom (velocity stage -> broadphase)
+      union {  // slot C
+        float cinert[RG_MAXBODY * 10];   // com_pos .. velocity stage
+        struct { short cand[RG_MAXCAND], cand2[RG_MAXCAND2]; float c_dist[RG_MAXCON], c_pos[RG_MAXCON * 3], c_normal[RG_MAXCON * 3]; };   // collision .. constraint rows
+      };
+    };
+    struct {  // ---- slv
+      alignas(16) float H[RG_HWORDS];
+      float a[RG_MAXNVC], as[RG_MAXNVC], fs[RG_MAXNVC], jtf[RG_MAXNVC], Ma[RG_MAXNVC], search[RG_MAXNVC], Mv[RG_MAXNVC], dinv[RG_MAXNV], tmpv[RG_MAXNV], qfrc_con[RG_MAXNV], qacc[RG_MAXNV];
+      unsigned char p_quad[RG_MAXPYR];
+      float c_bdot[RG_MAXCON * 4], c_bfrc[RG_MAXCON * 4];
+      float p_jar[RG_MAXPYR], p_jv[RG_MAXPYR], p_force[RG_MAXPYR];
+    };
+  };
+  float prof[RG_NPROF];   // LAST: launches without the profiling flag do not allocate it (rg_lds_launch_bytes)
+};
+// dynamic LDS bytes of a launch
+static inline size_t rg_lds_launch_bytes(bool profiling) { return profiling ? sizeof(RgLds) : offsetof(RgLds, prof); }
 
 // ------------------------------------------------------------------------------------------------- position stage
 __device__ __forceinline__ void rg_kinematics(RgM m, RgLds& s) {
@@ -536,7 +556,6 @@ __device__ __forceinline__ void rg_crb(RgM m, RgLds& s, const int* subtree_adr, 
     for (uint32_t bits = (uint32_t)m.subtree_mask[b]; bits; bits &= bits - 1) acc += s.cinert[10 * __builtin_ctz(bits) + k];
     s.crb[w] = acc;
   }
-  for (int w = LANE; w < m.blkwords; w += RG_WAVE) s.M[w] = 0;
   SYNC();
   PFOR(e, m.nM) {
     int i = m.M_i[e], j = m.M_j[e];
@@ -545,9 +564,15 @@ __device__ __forceinline__ void rg_crb(RgM m, RgLds& s, const int* subtree_adr, 
     const float* c = s.cdof + 6 * j;
     float v = c[0] * buf[0] + c[1] * buf[1] + c[2] * buf[2] + c[3] * buf[3] + c[4] * buf[4] + c[5] * buf[5];
     if (i == j) v += m.dof_armature[i];
-    int bi = m.dof_blk[i], bj = m.dof_blk[j], s0 = (bi >> 16) & 255;   // i and j belong to one tree
-    s.M[(bi & 0xFFFF) + (j - s0)] = v; s.M[(bj & 0xFFFF) + (i - s0)] = v;
+    s.Msp[e] = v;
   }
+  SYNC();
+}
+// s.H <- M in the per-tree block layout (both triangles; M_ent[2e] = word of (i,j) | word of (j,i) << 16)
+__device__ __forceinline__ void rg_M_to_blocks(RgM m, RgLds& s) {
+  { rgf4 z; z.x = z.y = z.z = z.w = 0.f; rgf4* H4 = (rgf4*)s.H; for (int w = LANE; w < ((m.blkwords + 3) >> 2); w += RG_WAVE) H4[w] = z; }
+  SYNC();
+  PFOR(e, m.nM) { int a = m.M_ent[2 * e]; float v = s.Msp[e]; s.H[a & 0xFFFF] = v; s.H[(a >> 16) & 0xFFFF] = v; }
   SYNC();
 }
 
@@ -1334,10 +1359,18 @@ __device__ __forceinline__ void rg_make_constraint(RgM m, RgLds& s) {
   SYNC();
 }
 
+// Residuals of the static rows (friction loss, limits) live in the registers of the lane that owns the row (row
+// LANE + 64 k): only that lane ever touches them, so they need no LDS (1.2 kB per env that the occupancy wants back).
+#define RG_RSLOTS ((RG_MAXSROW + RG_WAVE - 1) / RG_WAVE)
+struct RowRegs { float jar[RG_RSLOTS], jv[RG_RSLOTS], force[RG_RSLOTS]; int quad[RG_RSLOTS]; };
 // jar = J x - aref (or jv = J x) for every active row; x lives in the compact dof space
-__device__ __forceinline__ void rg_J_mul(RgM m, RgLds& s, const float* x, bool to_jv) {
+__device__ __forceinline__ void rg_J_mul(RgM m, RgLds& s, RowRegs& R, const float* x, bool to_jv) {
   int ns = nsrow(m), ncon = s.ncon;
-  PFOR(r, ns) if (s.r_D[r] > 0) { float v = srow_dot<false>(s, r, x); if (to_jv) s.r_jv[r] = v; else s.r_jar[r] = v - s.r_aref[r]; }
+#pragma unroll
+  for (int k = 0; k < RG_RSLOTS; k++) {
+    int r = LANE + RG_WAVE * k;
+    if (r < ns && s.r_D[r] > 0) { float v = srow_dot<false>(s, r, x); if (to_jv) R.jv[k] = v; else R.jar[k] = v - s.r_aref[r]; }
+  }
   for (int w = LANE; w < ncon * 4; w += RG_WAVE) {
     int c = w >> 2, k = w & 3, nnz = s.c_nnz[c]; float v = 0;
     if (k < nbasis(s.c_dim[c])) { const float* Bc = s.c_pool + s.c_off[c] + k * nnz; for (int sl = 0; sl < nnz; sl++) v += Bc[sl] * x[s.c_idx[c * RG_W + sl]]; }
@@ -1357,12 +1390,15 @@ __device__ __forceinline__ void rg_J_mul(RgM m, RgLds& s, const float* x, bool t
 // forces / quadratic flags from jar; returns the wave-summed constraint cost
 // `changed`: whether any row's quadratic flag differs from what the arrays held before (the Hessian
 // M + J' D J depends on the state only through these flags)
-__device__ __forceinline__ float rg_constraint_update(RgM m, RgLds& s, bool& changed) {
+__device__ __forceinline__ float rg_constraint_update(RgM m, RgLds& s, RowRegs& R, bool& changed) {
   int ns = nsrow(m), ncon = s.ncon; float cost = 0; bool chg = false;
-  PFOR(r, ns) {
-    float D = s.r_D[r]; int old = s.r_quad[r], q = 0; float frc = 0;
+#pragma unroll
+  for (int k = 0; k < RG_RSLOTS; k++) {
+    int r = LANE + RG_WAVE * k;
+    if (r >= ns) continue;
+    float D = s.r_D[r]; int old = R.quad[k], q = 0; float frc = 0;
     if (D > 0) {
-      float x = s.r_jar[r], f = r < RG_MAXFRIC ? s.r_floss[r] : 0.f;
+      float x = R.jar[k], f = r < RG_MAXFRIC ? s.r_floss[r] : 0.f;
       if (f > 0) {
         float R = rg_rcp(D);
         if (x <= -R * f) { frc = f; cost += f * (-0.5f * R * f - x); }
@@ -1370,7 +1406,7 @@ __device__ __forceinline__ float rg_constraint_update(RgM m, RgLds& s, bool& cha
         else { frc = -D * x; q = 1; cost += 0.5f * D * x * x; }
       } else if (x < 0) { frc = -D * x; q = 1; cost += 0.5f * D * x * x; }
     }
-    s.r_force[r] = frc; s.r_quad[r] = q; chg |= q != old;
+    R.force[k] = frc; R.quad[k] = q; chg |= q != old;
   }
   for (int w = LANE; w < ncon * 6; w += RG_WAVE) {
     int c = w / 6, k = w - 6 * c, old = s.p_quad[w], q = 0; float frc = 0;
@@ -1385,7 +1421,7 @@ __device__ __forceinline__ float rg_constraint_update(RgM m, RgLds& s, bool& cha
   return wave_sum(cost);
 }
 // dst = J^T force in the compact dof space (dst zeroed here)
-__device__ __forceinline__ void rg_JT_force(RgM m, RgLds& s, float* dst) {
+__device__ __forceinline__ void rg_JT_force(RgM m, RgLds& s, const RowRegs& R, float* dst) {
   int ns = nsrow(m), ncon = s.ncon;
   PFOR(d, m.nvc) dst[d] = 0;
   for (int w = LANE; w < ncon * 4; w += RG_WAVE) {
@@ -1396,7 +1432,8 @@ __device__ __forceinline__ void rg_JT_force(RgM m, RgLds& s, float* dst) {
     s.c_bfrc[w] = v;
   }
   SYNC();
-  PFOR(r, ns) if (s.r_D[r] > 0 && s.r_force[r] != 0) srow_scatter(s, r, s.r_force[r], dst);
+#pragma unroll
+  for (int k = 0; k < RG_RSLOTS; k++) { int r = LANE + RG_WAVE * k; if (r < ns && s.r_D[r] > 0 && R.force[k] != 0) srow_scatter(s, r, R.force[k], dst); }
   for (int w = LANE; w < ncon * RG_W; w += RG_WAVE) {
     int c = w / RG_W, sl = w - c * RG_W, nnz = s.c_nnz[c];
     if (sl >= nnz) continue;
@@ -1408,17 +1445,26 @@ __device__ __forceinline__ void rg_JT_force(RgM m, RgLds& s, float* dst) {
   }
   SYNC();
 }
-// y = M x in the compact dof space: row i of the tree block of dof c2d[i] against that tree's slice of x
-__device__ __forceinline__ void rg_M_mul(RgM m, RgLds& s, const float* x, float* y) {
-  PFOR(i, m.nvc) {
-    int blk = s.cblk[i], n = (blk >> 24) & 255; const rgf4* row = (const rgf4*)(s.M + (blk & 0xFFFF)); const float* xs = x + ((blk >> 16) & 255);
-    float v = 0;
-    int n4 = n >> 2;   // block rows are 16-byte aligned and padded to a multiple of four columns
-#pragma unroll 2
-    for (int c = 0; c < n4; c++) { rgf4 r = row[c]; v += r.x * xs[4 * c] + r.y * xs[4 * c + 1] + r.z * xs[4 * c + 2] + r.w * xs[4 * c + 3]; }
-    const float* rs = (const float*)row;
-    for (int k = 4 * n4; k < n; k++) v += rs[k] * xs[k];
-    y[i] = v;
+// y = M x in the compact dof space from the tree-sparse entries (mj_mulM): a lane takes entries LANE, LANE + 64, ...
+// (their compact row / column, prefetched once per solve: RgMEnt) and adds M_ij x_j to y_i and M_ij x_i to y_j with
+// LDS atomics (issued by one wave in lane order: deterministic)
+#define RG_MSLOTS ((RG_MAXNM + RG_WAVE - 1) / RG_WAVE)
+struct RgMEnt { int w[RG_MSLOTS]; };   // ci | cj << 8 | valid << 16
+__device__ __forceinline__ void rg_M_ent_load(RgM m, RgMEnt& E) {
+#pragma unroll
+  for (int k = 0; k < RG_MSLOTS; k++) { int e = LANE + RG_WAVE * k; E.w[k] = e < m.nM ? m.M_ent[2 * e + 1] : 0; }
+}
+__device__ __forceinline__ void rg_M_mul(RgM m, RgLds& s, const RgMEnt& E, const float* x, float* y) {
+  PFOR(i, m.nvc) y[i] = 0;
+  SYNC();
+#pragma unroll
+  for (int k = 0; k < RG_MSLOTS; k++) {
+    int w = E.w[k];
+    if (w >> 16) {
+      int ci = w & 255, cj = (w >> 8) & 255; float mv = s.Msp[LANE + RG_WAVE * k];
+      atomicAdd(y + ci, mv * x[cj]);
+      if (ci != cj) atomicAdd(y + cj, mv * x[ci]);
+    }
   }
   SYNC();
 }
@@ -1596,8 +1642,7 @@ __device__ __forceinline__ void rg_ltdl_solve(RgLds& s, const LtdlDesc& L, float
 __device__ __forceinline__ void rg_ltdl_factor_solve(RgM m, RgLds& s, const float* extra_diag, float scale, float* x) {
   LtdlDesc L;
   rg_ltdl_load(m.ltdl_tri, m.ltdl_pair, m.n_tri_rounds, m.n_pair_rounds, L);
-  for (int w = LANE; w < m.blkwords; w += RG_WAVE) s.H[w] = s.M[w];
-  SYNC();
+  rg_M_to_blocks(m, s);
   int d = LANE; bool on = d < m.nv;
   int blk = on ? m.dof_blk[d] : 0, akk = (blk & 0xFFFF) + d - ((blk >> 16) & 255);
   if (on && extra_diag) s.H[akk] += scale * extra_diag[d];
@@ -1609,18 +1654,18 @@ __device__ __forceinline__ void rg_ltdl_factor_solve(RgM m, RgLds& s, const floa
 struct LsPt { float cost, grad, hess; };
 // The rows a lane owns (static slots LANE, LANE+64; pyramid rows LANE+64k) do not change during a line search:
 // their (D, floss, jar, jv) are read from LDS once and every trial step length is evaluated from registers.
-struct LsRows { float rD[2], rf[2], rjar[2], rjv[2], pD[3], pjar[3], pjv[3]; };
-__device__ __forceinline__ void rg_ls_load(RgM m, const RgLds& s, LsRows& L) {
+struct LsRows { float rD[2], rf[2], rjar[2], rjv[2], pD[RG_PSLOTS], pjar[RG_PSLOTS], pjv[RG_PSLOTS]; };
+__device__ __forceinline__ void rg_ls_load(RgM m, const RgLds& s, const RowRegs& R, LsRows& L) {
   int ns = nsrow(m), ncon = s.ncon;
 #pragma unroll
   for (int k = 0; k < 2; k++) {
     int r = LANE + RG_WAVE * k; bool on = r < ns;
     float D = on ? s.r_D[r] : 0.f;
     L.rD[k] = D > 0 ? D : 0.f; L.rf[k] = (on && r < RG_MAXFRIC) ? s.r_floss[r] : 0.f;
-    L.rjar[k] = on ? s.r_jar[r] : 0.f; L.rjv[k] = on ? s.r_jv[r] : 0.f;
+    L.rjar[k] = on ? R.jar[k] : 0.f; L.rjv[k] = on ? R.jv[k] : 0.f;
   }
 #pragma unroll
-  for (int k = 0; k < 3; k++) {
+  for (int k = 0; k < RG_PSLOTS; k++) {
     int w = LANE + RG_WAVE * k; bool on = w < ncon * 6;
     int cc = on ? w / 6 : 0; on = on && (w - 6 * cc) < npyr(s.c_dim[cc]);
     L.pD[k] = on ? s.c_D[cc] : 0.f; L.pjar[k] = on ? s.p_jar[w] : 0.f; L.pjv[k] = on ? s.p_jv[w] : 0.f;
@@ -1641,7 +1686,7 @@ __device__ __forceinline__ LsPt rg_ls_eval(const LsRows& L, float alpha, float q
     } else if (x < 0) { c += 0.5f * D * x * x; g += D * x * jv; h += D * jv * jv; }
   }
 #pragma unroll
-  for (int k = 0; k < 3; k++) {
+  for (int k = 0; k < RG_PSLOTS; k++) {
     float D = L.pD[k], jv = L.pjv[k], x = L.pjar[k] + alpha * jv;
     if (D > 0 && x < 0) { c += 0.5f * D * x * x; g += D * x * jv; h += D * jv * jv; }
   }
@@ -1683,6 +1728,10 @@ __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, int& nefc_out, int flag
     }
     tree = __ballot(cross) == 0;
   }
+  RgMEnt ME; rg_M_ent_load(m, ME);
+  RowRegs RR;
+#pragma unroll
+  for (int k = 0; k < RG_RSLOTS; k++) { RR.jar[k] = RR.jv[k] = RR.force[k] = 0.f; RR.quad[k] = 0; }
   LtdlDesc LT;
   if (tree) rg_ltdl_load(m.ltdl_tri_c, m.ltdl_pair_c, m.n_tri_rounds_c, m.n_pair_rounds_c, LT); else { LT.ntr = 0; LT.npr = 0; }
   int cblk_own = LANE < nvc ? s.cblk[LANE] : 0, akk_own = (cblk_own & 0xFFFF) + LANE - ((cblk_own >> 16) & 255);
@@ -1690,17 +1739,17 @@ __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, int& nefc_out, int flag
   float cost_pick[2];
   for (int pass = 0; pass < 2; pass++) {
     const float* a = pass == 0 ? s.as : s.a;
-    rg_M_mul(m, s, a, s.Ma);
-    rg_J_mul(m, s, a, false);
+    rg_M_mul(m, s, ME, a, s.Ma);
+    rg_J_mul(m, s, RR, a, false);
     float g = 0; PFOR(i, nvc) g += 0.5f * (s.Ma[i] - s.fs[i]) * (a[i] - s.as[i]);
     g = wave_sum(g);
-    bool chg; cost_pick[pass] = g + rg_constraint_update(m, s, chg);
+    bool chg; cost_pick[pass] = g + rg_constraint_update(m, s, RR, chg);
   }
   if (!(cost_pick[1] < cost_pick[0])) {
     PFOR(i, nvc) s.a[i] = s.as[i];
     SYNC();
-    rg_M_mul(m, s, s.a, s.Ma);
-    rg_J_mul(m, s, s.a, false);
+    rg_M_mul(m, s, ME, s.a, s.Ma);
+    rg_J_mul(m, s, RR, s.a, false);
   }
   // Invariant at the top of every iteration: Ma = M a and jar = J a - aref (both linear in a, so they are
   // advanced by alpha * (M s, J s) after the line search instead of being recomputed).
@@ -1709,9 +1758,9 @@ __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, int& nefc_out, int flag
   for (int iter = 0;; iter++) {
     float gauss = 0; PFOR(i, nvc) gauss += 0.5f * (s.Ma[i] - s.fs[i]) * (s.a[i] - s.as[i]);
     gauss = wave_sum(gauss);
-    bool flags_changed; float cc = rg_constraint_update(m, s, flags_changed);
+    bool flags_changed; float cc = rg_constraint_update(m, s, RR, flags_changed);
     oldcost = cost; cost = gauss + cc;
-    rg_JT_force(m, s, s.jtf);
+    rg_JT_force(m, s, RR, s.jtf);
     float gn = 0; PFOR(i, nvc) { float gi = s.Ma[i] - s.fs[i] - s.jtf[i]; s.search[i] = -gi; gn += gi * gi; }
     gn = sqrtf(wave_sum(gn)) * scale;
 #ifdef RG_EMUL_TRACE
@@ -1725,25 +1774,24 @@ __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, int& nefc_out, int flag
     have_factor = true;
     if (tree) {
       // H <- M in the block layout (the factor only uses the lower triangle), then + J' D J on the same addresses
-      { const rgf4* M4 = (const rgf4*)s.M; rgf4* H4 = (rgf4*)s.H; for (int w = LANE; w < (m.blkwords >> 2); w += RG_WAVE) H4[w] = M4[w]; }
-      SYNC();
-      PFOR(r, ns) if (s.r_D[r] > 0 && s.r_quad[r]) srow_hess_tree(s, r, s.r_D[r]);
+      rg_M_to_blocks(m, s);
+#pragma unroll
+      for (int k = 0; k < RG_RSLOTS; k++) { int r = LANE + RG_WAVE * k; if (r < ns && s.r_D[r] > 0 && RR.quad[k]) srow_hess_tree(s, r, s.r_D[r]); }
     } else {
     // H = M + J' D J over the quadratic rows (LDS atomics from one wave: in-order, deterministic)
-    {  // H <- M expanded from the per-tree blocks: one 16-byte store per (row, 4-column chunk), zeros outside the tree
-      int hs4 = hs >> 2; rgf4* H4 = (rgf4*)s.H;
-      float ihs4 = 1.0f / (float)hs4;   // row of a chunk index without an integer division (exact: w < 2^10)
-      for (int w = LANE; w < nvc * hs4; w += RG_WAVE) {
-        int i = (int)(((float)w + 0.5f) * ihs4), c = w - i * hs4, blk = s.cblk[i], k0 = 4 * c - ((blk >> 16) & 255), n = (blk >> 24) & 255;
-        const float* Mr = s.M + (blk & 0xFFFF);
-        rgf4 o;
-        o.x = (k0 >= 0 && k0 < n) ? Mr[k0] : 0.f; o.y = (k0 + 1 >= 0 && k0 + 1 < n) ? Mr[k0 + 1] : 0.f;
-        o.z = (k0 + 2 >= 0 && k0 + 2 < n) ? Mr[k0 + 2] : 0.f; o.w = (k0 + 3 >= 0 && k0 + 3 < n) ? Mr[k0 + 3] : 0.f;
-        H4[w] = o;
+    {  // H <- M: zero the compact nvc x hs matrix, then scatter the tree-sparse entries (both triangles)
+      rgf4 z; z.x = z.y = z.z = z.w = 0.f; rgf4* H4 = (rgf4*)s.H;
+      for (int w = LANE; w < nvc * (hs >> 2); w += RG_WAVE) H4[w] = z;
+      SYNC();
+#pragma unroll
+      for (int k = 0; k < RG_MSLOTS; k++) {
+        int w = ME.w[k];
+        if (w >> 16) { int ci = w & 255, cj = (w >> 8) & 255; float mv = s.Msp[LANE + RG_WAVE * k]; s.H[ci * hs + cj] = mv; s.H[cj * hs + ci] = mv; }
       }
     }
     SYNC();
-    PFOR(r, ns) if (s.r_D[r] > 0 && s.r_quad[r]) srow_hess(m, s, r, s.r_D[r]);
+#pragma unroll
+    for (int k = 0; k < RG_RSLOTS; k++) { int r = LANE + RG_WAVE * k; if (r < ns && s.r_D[r] > 0 && RR.quad[k]) srow_hess(m, s, r, s.r_D[r]); }
     }
     // per contact, C = P' D_act P in the basis (normal, t1, t2, spin) has only its first row/column and its diagonal
     // non-zero: cn, ck[3], cd[3].  One lane per contact computes them (c_bdot/c_bfrc are free between J products).
@@ -1781,14 +1829,14 @@ __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, int& nefc_out, int flag
     if (tree) rg_ltdl_solve(s, LT, s.search, LANE, LANE < nvc, akk_own); else rg_chol_solve(m, s, s.search);
     PROFS(15);
     // exact line search along `search`
-    rg_M_mul(m, s, s.search, s.Mv);
-    rg_J_mul(m, s, s.search, true);
+    rg_M_mul(m, s, ME, s.search, s.Mv);
+    rg_J_mul(m, s, RR, s.search, true);
     float q1 = 0, q2 = 0, sn = 0;
     PFOR(i, nvc) { q1 += s.search[i] * (s.Ma[i] - s.fs[i]); q2 += 0.5f * s.search[i] * s.Mv[i]; sn += s.search[i] * s.search[i]; }
     q1 = wave_sum(q1); q2 = wave_sum(q2); sn = sqrtf(wave_sum(sn));
     if (sn < 1e-15f) break;
     float gtol = tol * 0.01f * sn / scale;
-    LsRows rows; rg_ls_load(m, s, rows);
+    LsRows rows; rg_ls_load(m, s, RR, rows);
     LsPt p0 = rg_ls_eval(rows, 0.f, gauss, q1, q2);
     float alpha = 0;
     if (p0.grad < 0 && p0.hess > 0) {
@@ -1809,15 +1857,16 @@ __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, int& nefc_out, int flag
 #endif
     if (alpha == 0) break;
     PFOR(i, nvc) { s.a[i] += alpha * s.search[i]; s.Ma[i] += alpha * s.Mv[i]; }
-    PFOR(r, ns) if (s.r_D[r] > 0) s.r_jar[r] += alpha * s.r_jv[r];
+#pragma unroll
+    for (int k = 0; k < RG_RSLOTS; k++) RR.jar[k] += alpha * RR.jv[k];
     for (int w = LANE; w < ncon * 6; w += RG_WAVE) s.p_jar[w] += alpha * s.p_jv[w];
     SYNC();
     PROFS(10);
   }
   // forces at the solution; expand to the full dof space
-  rg_J_mul(m, s, s.a, false);
-  { bool chg; rg_constraint_update(m, s, chg); }
-  rg_JT_force(m, s, s.jtf);
+  rg_J_mul(m, s, RR, s.a, false);
+  { bool chg; rg_constraint_update(m, s, RR, chg); }
+  rg_JT_force(m, s, RR, s.jtf);
   PFOR(d, nv) { int i = m.d2c[d]; s.qacc[d] = i >= 0 ? s.a[i] : s.qacc_smooth[d]; s.qfrc_con[d] = i >= 0 ? s.jtf[i] : 0.f; }
   SYNC();
   return iters;
@@ -1854,13 +1903,12 @@ __device__ __forceinline__ void rg_dump_kin(RgM m, RgLds& s, float* dbg) {
   SYNC();
 }
 __device__ __forceinline__ void rg_dump_pos(RgM m, RgLds& s, float* dbg) {
-  for (int w = LANE; w < m.nv * m.nv; w += RG_WAVE) {
-    int i = w / m.nv, j = w - i * m.nv, bi = m.dof_blk[i], s0 = (bi >> 16) & 255, n = (bi >> 24) & 255;
-    dbg[RG_DBG_M + w] = (j >= s0 && j < s0 + n) ? s.M[(bi & 0xFFFF) + (j - s0)] : 0.f;
-  }
+  for (int w = LANE; w < m.nv * m.nv; w += RG_WAVE) dbg[RG_DBG_M + w] = 0.f;
+  SYNC();
+  PFOR(e, m.nM) { int i = m.M_i[e], j = m.M_j[e]; dbg[RG_DBG_M + i * m.nv + j] = s.Msp[e]; dbg[RG_DBG_M + j * m.nv + i] = s.Msp[e]; }
   PFOR(i, m.nv) { dbg[RG_DBG_BIAS + i] = s.qfrc_bias[i]; dbg[RG_DBG_PASSIVE + i] = s.qfrc_passive[i]; dbg[RG_DBG_ACTFRC + i] = s.qfrc_act[i]; }
   if (LANE == 0) { dbg[RG_DBG_NCON] = (float)s.ncon; dbg[RG_DBG_NCON + 3] = (float)s.ncand; }
-  PFOR(c, s.ncon) { float* o = dbg + RG_DBG_CON + 8 * c; o[0] = s.c_dist[c]; o[1] = s.c_pos[3 * c]; o[2] = s.c_pos[3 * c + 1]; o[3] = s.c_pos[3 * c + 2]; o[4] = s.c_normal[3 * c]; o[5] = s.c_normal[3 * c + 1]; o[6] = s.c_normal[3 * c + 2]; o[7] = (float)s.c_pair[c]; }
+  PFOR(c, (s.ncon < RG_DBG_MAXCON ? s.ncon : RG_DBG_MAXCON)) { float* o = dbg + RG_DBG_CON + 8 * c; o[0] = s.c_dist[c]; o[1] = s.c_pos[3 * c]; o[2] = s.c_pos[3 * c + 1]; o[3] = s.c_pos[3 * c + 2]; o[4] = s.c_normal[3 * c]; o[5] = s.c_normal[3 * c + 1]; o[6] = s.c_normal[3 * c + 2]; o[7] = (float)s.c_pair[c]; }
   SYNC();
 }
 __device__ __forceinline__ void rg_dump_slv(RgM m, RgLds& s, float* dbg, int nefc, int iters) {
@@ -1920,8 +1968,9 @@ __global__ void __launch_bounds__(RG_WAVE, 2) rg_step_kernel(const RgModelDev* m
   PFOR(i, m.nq) s.qpos[i] = L.bt.qpos[(size_t)e * m.nq + i];
   PFOR(i, m.nv) { s.qvel[i] = L.bt.qvel[(size_t)e * m.nv + i]; s.warm[i] = L.bt.qacc_warmstart[(size_t)e * m.nv + i]; }
   PFOR(i, 3 * m.nu) s.pid[i] = L.bt.pid[(size_t)e * 3 * m.nu + i];
-  if (LANE == 0) s.status = L.bt.status[e];
-  if (LANE < RG_NPROF) s.prof[LANE] = 0;
+  const unsigned status0 = L.bt.status[e];
+  if (LANE == 0) s.status = status0;
+  if ((L.flags & 2) && LANE < RG_NPROF) s.prof[LANE] = 0;
   st_build_row_desc(c);
   // ---- action -> ctrl (robot_interface.py:247-278 with the hand's position->control matrix)
   // envs on `hold` (scripted reset recipe) and envs whose action row holds a non-finite entry keep their stored ctrl row
@@ -1960,6 +2009,14 @@ __global__ void __launch_bounds__(RG_WAVE, 2) rg_step_kernel(const RgModelDev* m
     st_collision(c); PROF(6);
     if ((flags & 2) && LANE == 0 && (float)s.ncon > s.prof[23]) s.prof[23] = (float)s.ncon;
     st_make_constraint(c); PROF(8);
+    if (L.bt.redo && (s.status & ~status0 & (RG_STATUS_CON_FULL | RG_STATUS_CAND_FULL))) {
+      // more contacts / candidates than this configuration holds: leave the env exactly as it was (state rows are
+      // written at the end; the distance-bound cache was advanced by the substeps done so far, so it is voided) and
+      // hand it to the large configuration
+      if (L.bt.pairlb) { float* lb = L.bt.pairlb + (size_t)e * m.npair; PFOR(i, m.npair) lb[i] = 0.f; }
+      if (LANE == 0) L.bt.redo[e] = 1;
+      return;
+    }
     st_pid(c);
     st_smooth(c); PROF(9);
     if (sub == 0 && (flags & 1) && L.bt.dbg) st_dump(c, 1, 0, 0);
@@ -2057,3 +2114,10 @@ __global__ void rg_copy_rows_kernel(float* dst, const float* src, const int* mas
   for (int i = LANE; i < ncols; i += RG_WAVE) dst[(size_t)e * n + col0 + i] = src[(size_t)e * ncols + i];
   if (pairlb) for (int i = LANE; i < npair; i += RG_WAVE) pairlb[(size_t)e * npair + i] = 0.f;
 }
+}  // namespace RG_NS
+#undef RG_MAXPYR
+#undef RG_PSLOTS
+#undef RG_RSLOTS
+#undef RG_MSLOTS
+#undef PROF
+#undef PROFS

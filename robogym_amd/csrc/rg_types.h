@@ -3,7 +3,8 @@
 #pragma once
 #include <stdint.h>
 
-// compile-time capacities of the "hand" kernel configuration (dactyl/locked, dactyl/reach)
+// compile-time capacities of the "hand" kernel configuration (dactyl/locked, dactyl/reach); the contact and
+// candidate capacities (RG_MAXCON, RG_CPOOL, RG_MAXCAND, RG_MAXCAND2) belong to the kernel configurations of rg_api.hip
 #define RG_MAXNQ 40
 #define RG_MAXNV 36
 #define RG_MAXBODY 32
@@ -12,14 +13,11 @@
 #define RG_MAXSITE 40
 #define RG_MAXTEN 12
 #define RG_MAXU 20
-#define RG_MAXCON 32    // contacts kept per env (overflow -> RG_STATUS_CON_FULL); rollouts: P(ncon > 16) = 9e-6, max 21 in 6.5e5 substeps; the reset recipe (cube dropped into a closing hand) reaches 24+
-#define RG_CPOOL 1160   // words of pooled contact basis Jacobians (rows x nnz per contact; 22 full-size cube contacts, ~30 mixed)
 #define RG_MAXFRIC 32   // friction-loss rows (dofs + tendons)
 #define RG_MAXSROW 96   // static row slots: friction rows + 2 per limited joint / tendon
 #define RG_MAXNVC 32    // dofs in constrained kinematic trees (the Newton space)
-#define RG_MAXBLK 816   // words of the per-tree dense inertia blocks
-#define RG_MAXCAND 128  // candidate geom pairs surviving the broadphase per substep
-#define RG_MAXCAND2 64  // candidates surviving the first support test (full MPR queries) per substep
+#define RG_HWORDS 1088  // solver work matrix: max(per-tree inertia blocks, nvc x hs)
+#define RG_MAXNM 160    // non-zeros of the tree-sparse inertia matrix: (dof, ancestor) pairs
 #define RG_CELLN 8      // direction cells: cube map, RG_CELLN x RG_CELLN per face (kernel_tables.py CELL_N)
 #define RG_NCELL (6 * RG_CELLN * RG_CELLN)
 #define RG_LTDL_TRI_ROUNDS 12   // caps on the descriptor rounds of the L'DL passes (registers per lane)
@@ -71,6 +69,7 @@ struct RgModelDev {
   const float *dof_armature, *dof_damping, *dof_frictionloss, *dof_solref, *dof_solimp, *dof_invweight0;
   const float *qpos0, *qpos_spring;
   const int *lvl_dof, *lvl_dof_adr, *M_i, *M_j, *M_lvl_adr, *desc_adr, *desc;
+  const int* M_ent;   // [nM][2]: block-layout word of (i,j) | word of (j,i) << 16 ; compact i | compact j << 8 | constrained-tree << 16
   // geoms / sites / meshes
   const int *geom_type, *geom_bodyid, *geom_dataid, *body_geomadr, *body_geomnum;
   const float *geom_size, *geom_rbound, *geom_pos, *geom_quat, *geom_aabb;
@@ -131,6 +130,8 @@ struct RgBatchDev {
   const int* nticks;    // [B] or null: per-env override of nforward_ticks (the reset recipe's sim.step has 1, env.step 3)
   const int* order;     // [B] or null: workgroup -> env permutation (longest-expected-first dispatch)
   float* cost;          // [B] or null: shader cycles this launch spent on the env (feeds `order` of the next step)
+  int* redo;            // [B] or null: an env that exceeds this configuration's contact / candidate capacities is left
+                        // untouched and flagged here, to be stepped again by a launch of the large configuration
   float* obs;           // [B][obs_dim]
   float* goal_dist;     // [B]
   float* stats;         // [B][4]: sum ncon, sum nefc, sum newton iters, substeps
@@ -151,4 +152,5 @@ struct RgBatchDev {
 #define RG_DBG_QACC (RG_DBG_QACCS + 40)           // nv
 #define RG_DBG_NCON (RG_DBG_QACC + 40)            // 1: ncon, +1: nefc, +2: iters, +3: ncand
 #define RG_DBG_CON (RG_DBG_NCON + 4)                    // MAXCON * 8: dist, pos3, normal3, pair index
-#define RG_DBG_SIZE (RG_DBG_CON + 32 * 8)
+#define RG_DBG_MAXCON 32                               // contacts in the dump (a configuration may keep more)
+#define RG_DBG_SIZE (RG_DBG_CON + RG_DBG_MAXCON * 8)

@@ -259,7 +259,7 @@ class BatchedLockedEnv:
             zero = torch.zeros((B, self.num_actions), dtype=torch.float32, device=self.device)
             self._set_ctrl_masked(sim.denormalize_position_control(zero), need)
             for _ in range(c.reset_initial_steps):
-                sim.step(active=active)
+                sim.step(active=active, capacity="large")
             sim.add_qpos("cube_position", self._rand_normal(B, 3) * c.cube_position_wiggle_std, need)
             w = self._rand_normal(B, 4)
             sim.set_qpos("cube_rotation", rotation.quat_normalize(w / w.norm(dim=-1, keepdim=True)), need)
@@ -267,7 +267,7 @@ class BatchedLockedEnv:
             action = self._rand_uniform(-1.0, 1.0, B, self.num_actions)
             self._set_ctrl_masked(sim.denormalize_position_control(action), need)
             for _ in range(c.n_random_initial_steps):
-                sim.step(active=active)
+                sim.step(active=active, capacity="large")
             sim.forward(active=active)  # the forward() inside cube_utils.on_palm
             z = sim.cube_body_z + sim.get_qpos("cube_position")[:, 2]
             need = need & ~(z > 0.04)
@@ -381,8 +381,9 @@ class BatchedLockedEnv:
         n1, n2 = c.reset_initial_steps, c.reset_initial_steps + c.n_random_initial_steps
         two = resetting & ((self._phase == n1) | (self._phase == n2))
         nticks = torch.where(live, torch.full_like(self._phase, 3), torch.where(two, torch.full_like(self._phase, 2), torch.ones_like(self._phase))).contiguous()
+        hold = resetting.to(torch.int32).contiguous()
         sim.env_step(action=action, goal_quat=self._goal_quat, obs=self._obs_buf, goal_dist=self._goal_dist, nforward_ticks=3,
-                     hold=resetting.to(torch.int32).contiguous(), nticks=nticks, order=self._dispatch_order())
+                     hold=hold, nticks=nticks, order=self._dispatch_order(), large_mask=hold)   # the recipe runs in the large kernel configuration
         self.t += live.to(torch.int32)
         crash = self._crashed()
         self._obs_buf.masked_fill_(crash[:, None], 0.0)

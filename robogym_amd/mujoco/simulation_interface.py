@@ -46,6 +46,8 @@ class BatchedSimulationInterface:
         self._views: Dict[int, torch.Tensor] = {}
         self._idx_cache: Dict = {}
         self._keep = []
+        self._redo = None
+        self._side = None
 
     def __del__(self):
         try:
@@ -204,27 +206,62 @@ class BatchedSimulationInterface:
         return None if t is None else ctypes.c_void_p(t.data_ptr())
 
     def env_step(self, action=None, goal_quat=None, obs=None, goal_dist=None, active=None, nsubsteps=None, nforward_ticks=3, flags=0,
-                 hold=None, nticks=None, order=None):
+                 hold=None, nticks=None, order=None, capacity="auto", large_mask=None):
         """One reference env.step worth of physics for the whole batch (async on the current stream).
         `active`: optional int32 [B]; envs with 0 are left untouched.  `hold` int32 [B]: envs that keep their
-        stored ctrl row; `nticks` int32 [B]: per-env forward-tick counts; `order` int32 [B]: dispatch permutation."""
+        stored ctrl row; `nticks` int32 [B]: per-env forward-tick counts; `order` int32 [B]: dispatch permutation.
+        `capacity`: "rollout" / "large" = one launch of that kernel configuration (rg_step_args.config);
+        "auto" = the rollout configuration, then the large one for exactly the envs that exceeded the rollout
+        capacities (flagged on the device, no host sync; almost always an empty launch).  `large_mask` (int32 [B], with
+        "auto"): envs known to need the large configuration (the reset recipe): they skip the rollout launch and run on a
+        side stream concurrently with it."""
         for t in (action, goal_quat, obs, goal_dist):
             assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.device == self.device)
-        for t in (active, hold, nticks, order):
+        for t in (active, hold, nticks, order, large_mask):
             assert t is None or (t.dtype == torch.int32 and t.is_contiguous() and t.device == self.device and t.numel() == self.batch_size)
         a = _native.StepArgs()
         a.action_dev, a.goal_quat_dev, a.obs_dev, a.goal_dist_dev = (None if t is None else t.data_ptr() for t in (action, goal_quat, obs, goal_dist))
-        a.active_dev, a.hold_dev, a.nticks_dev, a.order_dev = (None if t is None else t.data_ptr() for t in (active, hold, nticks, order))
+        a.hold_dev, a.nticks_dev, a.order_dev = (None if t is None else t.data_ptr() for t in (hold, nticks, order))
         a.nsubsteps = self.n_substeps if nsubsteps is None else int(nsubsteps)
         a.nforward_ticks, a.flags = int(nforward_ticks), int(flags)
-        a.stream = None if self._emul else torch.cuda.current_stream(self.device).cuda_stream
-        _native.check(self._L, self._L.rg_batch_step_ex(self._bh, ctypes.byref(a)), "rg_batch_step_ex")
-        self._keep.append((action, goal_quat, obs, goal_dist, active, hold, nticks, order))
+        self._keep.append((action, goal_quat, obs, goal_dist, active, hold, nticks, order, large_mask))
         del self._keep[:-16]
 
-    def step(self, with_udd=True, active=None):
+        def launch(config, active_t, redo_t, stream):
+            a.config = config
+            a.active_dev = None if active_t is None else active_t.data_ptr()
+            a.redo_dev = None if redo_t is None else redo_t.data_ptr()
+            a.stream = None if self._emul else stream.cuda_stream
+            _native.check(self._L, self._L.rg_batch_step_ex(self._bh, ctypes.byref(a)), "rg_batch_step_ex")
+
+        cur = None if self._emul else torch.cuda.current_stream(self.device)
+        if capacity != "auto" or a.nsubsteps == 0:   # (no substeps: no collision stage, nothing can overflow)
+            launch(_native.RG_CFG_LARGE if capacity == "large" else _native.RG_CFG_ROLLOUT, active, None, cur)
+            return
+        if self._redo is None:
+            self._redo = torch.zeros(self.batch_size, dtype=torch.int32, device=self.device)
+        self._redo.zero_()
+        act0 = active
+        if large_mask is not None:
+            small = 1 - large_mask if active is None else active * (1 - large_mask)
+            big = large_mask if active is None else active * large_mask
+            act0 = small.contiguous()
+            self._keep.append((act0, big))
+            if self._emul:
+                launch(_native.RG_CFG_LARGE, big.contiguous(), None, None)
+            else:
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=self.device)
+                self._side.wait_stream(cur)
+                launch(_native.RG_CFG_LARGE, big.contiguous(), None, self._side)
+        launch(_native.RG_CFG_ROLLOUT, act0, self._redo, cur)
+        launch(_native.RG_CFG_LARGE, self._redo, None, cur)
+        if large_mask is not None and not self._emul:
+            cur.wait_stream(self._side)
+
+    def step(self, with_udd=True, active=None, capacity="auto"):
         """SimulationInterface.step (simulation_interface.py:176-189): nsubsteps x mj_step, then mj_forward."""
-        self.env_step(nforward_ticks=1, active=active)
+        self.env_step(nforward_ticks=1, active=active, capacity=capacity)
 
     def forward(self, active=None, ticks=1):
         """SimulationInterface.forward (:203-207): state-less, except that the PID callback ticks."""

@@ -49,6 +49,8 @@ void emul_launch(int nblocks, size_t lds_bytes, emul_kernel_fn fn, void* arg) {
   gridDim.x = nblocks; gridDim.y = gridDim.z = 1;
   for (int b = 0; b < nblocks; b++) {
     g_lds = calloc(1, lds_bytes);
+    // RG_EMUL_LDS_GARBAGE=1: LDS starts as on the hardware — whatever the previous workgroup left (here: NaN / huge-int patterns)
+    { static const char* garb = getenv("RG_EMUL_LDS_GARBAGE"); if (garb && garb[0] == '1') { unsigned* u = (unsigned*)g_lds; for (size_t w = 0; w < lds_bytes / 4; w++) u[w] = (w & 1) ? 0x7fc00000u : 0xcdcdcdcdu; } }
     blockIdx.x = b; blockIdx.y = blockIdx.z = 0;
     for (int l = 0; l < 64; l++) {
       getcontext(&g_fiber[l]);
