@@ -1732,8 +1732,8 @@ __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, int& nefc_out, int flag
   RowRegs RR;
 #pragma unroll
   for (int k = 0; k < RG_RSLOTS; k++) { RR.jar[k] = RR.jv[k] = RR.force[k] = 0.f; RR.quad[k] = 0; }
-  LtdlDesc LT;
-  if (tree) rg_ltdl_load(m.ltdl_tri_c, m.ltdl_pair_c, m.n_tri_rounds_c, m.n_pair_rounds_c, LT); else { LT.ntr = 0; LT.npr = 0; }
+  // (the tree-pattern descriptors are fetched where they are used — 32 registers that would otherwise stay live, or be
+  //  spilled, through the whole dense path as well)
   int cblk_own = LANE < nvc ? s.cblk[LANE] : 0, akk_own = (cblk_own & 0xFFFF) + LANE - ((cblk_own >> 16) & 255);
   // warm start: the better of qacc_smooth and qacc_warmstart (evaluated last, so Ma / jar are left valid for it)
   float cost_pick[2];
@@ -1823,10 +1823,10 @@ __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, int& nefc_out, int flag
     }
     SYNC();
     PROFS(13);
-    if (tree) rg_ltdl_factor(s, LT); else rg_chol(m, s);
+    if (tree) { LtdlDesc LT; rg_ltdl_load(m.ltdl_tri_c, m.ltdl_pair_c, m.n_tri_rounds_c, m.n_pair_rounds_c, LT); rg_ltdl_factor(s, LT); } else rg_chol(m, s);
     }
     PROFS(14);
-    if (tree) rg_ltdl_solve(s, LT, s.search, LANE, LANE < nvc, akk_own); else rg_chol_solve(m, s, s.search);
+    if (tree) { LtdlDesc LT; rg_ltdl_load((const int*)0, m.ltdl_pair_c, 0, m.n_pair_rounds_c, LT); rg_ltdl_solve(s, LT, s.search, LANE, LANE < nvc, akk_own); } else rg_chol_solve(m, s, s.search);
     PROFS(15);
     // exact line search along `search`
     rg_M_mul(m, s, ME, s.search, s.Mv);
@@ -1954,7 +1954,12 @@ RG_STAGE void st_dump(RgCtx c, int which, int nefc, int iters) {
 #else
 #define RG_MAKE_CTX() RgCtx c{mp, (const void*)((const RG_AS4 char*)__builtin_amdgcn_kernarg_segment_ptr() + 8)}
 #endif
-__global__ void __launch_bounds__(RG_WAVE, 2) rg_step_kernel(const RgModelDev* mp, RgLaunch launch) {
+// (RG_WAVES_PER_SIMD 3: <= 168 VGPRs, so that the LDS-permitted 9 envs per CU are also register-permitted; measured
+//  +3 % over the 256-VGPR build at 8 per CU in spite of ~80 spilled registers, profiles/r02_ab.txt)
+#ifndef RG_WAVES_PER_SIMD
+#define RG_WAVES_PER_SIMD 3
+#endif
+__global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_kernel(const RgModelDev* mp, RgLaunch launch) {
   RG_MAKE_CTX();
   RgM m = RG_M(c);
   RgLRef L = RG_L(c);
