@@ -121,6 +121,9 @@ typedef struct rg_step_args {
    * and gets redo_dev[e] = 1 instead of dropping contacts; pass the array as active_dev of an RG_CFG_LARGE launch. */
   int config;
   int* redo_dev;
+  /* int [B] or NULL: state-less forwards owed to the env from the goal reset of its previous step (rg_env_post_step);
+   * executed before the action is applied, then zeroed. */
+  int* preticks_dev;
 } rg_step_args;
 enum { RG_CFG_ROLLOUT = 0, RG_CFG_LARGE = 1 };
 int rg_batch_step_ex(rg_batch* b, const rg_step_args* args);
@@ -130,6 +133,53 @@ int rg_batch_step_ex(rg_batch* b, const rg_step_args* args);
 void* rg_batch_field_ptr(rg_batch* b, int field, int* row_words);
 /* number of static collision pairs (row length of RG_F_PAIRLB) */
 int rg_model_npair(const rg_model* m);
+
+/* ---- the env-level half of RobotEnv.step, one launch for the whole batch -------------------------------------------
+ * After rg_batch_step(_ex) wrote the observation rows and goal distances: goal-distance reward and success flag
+ * (robot_env.py:550-625), MultiGoalTracker.process / reset / reset_goal_steps (utils/multi_goal_tracker.py:83-241, dactyl
+ * settings: one successful step counts, min_timesteps_per_goal 0, no reachability check), goal resampling
+ * (envs/dactyl/goals/locked_parallel.py:32-46), reset_goal's bookkeeping (robot_env.py:893-909; its two state-less
+ * forwards are booked in `preticks` and executed by the env's next step launch, RG args preticks_dev) and, with
+ * `pipelined`, the per-env phase machine of the reset recipe (cube_env.py:330-355, locked.py:197-225) including its
+ * masked state writes (MjSim.reset, cube pose perturbation, scripted ctrl).  All arrays are device pointers owned by the
+ * caller, int32 / float32, [B] unless noted.  Randomness: `draws` ([B][RG_POST_NDRAW]: u_angle, u_choice in [0,1),
+ * 4 + 3 standard normals, nu actions in [-1,1]) or, when NULL, a counter-based generator keyed by (seed, step, env). */
+#define RG_POST_NDRAW (2 + 4 + 3 + 20)
+typedef struct rg_post_args {
+  // ---- physics outputs of this step (read)
+  const float* goal_dist;      // [B] distance to the goal the env had during the step
+  float* obs;                  // [B][obs_dim] observation row (zeroed for crashed envs)
+  int obs_dim;
+  // ---- env state (read / write), all [B] unless noted
+  int *t, *phase, *tries;                      // env clock; reset-recipe phase (0 = live) and retry counter
+  int *steps, *steps_since_last_goal, *successes_so_far, *goals_so_far, *consecutive;   // MultiGoalTracker
+  float* prev_dist; int* prev_valid; int* is_successful;
+  float* goal_quat;            // [B][4]
+  float* qpos_goal;            // [B][nq]
+  int* preticks;               // [B] state-less forwards owed to the env (consumed by its next step launch)
+  // ---- outputs
+  float* reward;               // [B][3]
+  unsigned char *done, *goal_reset, *trial_success, *sub_goal_ok, *env_crash, *resetting, *episode_started;   /* 0 / 1 bytes (torch.bool storage) */
+  int* info_ssl;               /* [B] steps_since_last_goal as the reference's info reports it */
+  int *nticks_next, *reset_mask, *live_mask;   /* [B] inputs of the NEXT step launch: per-env forward ticks (3 live, 1 / 2 in the recipe), envs in the recipe (hold + large configuration), the others */
+  float* goal_dist_before;     // [B]
+  float* packed;               // [B][obs_dim + 3 + 4 + nq + 1 + 3 + 1] or null: obs | goal_pos | goal_quat | qpos_goal | achieved | reward | done
+  // ---- randomness: either the caller's draws or a counter-based generator (seed, step, env)
+  const float* draws;          // [B][RG_POST_NDRAW] or null: u_angle, u_choice, n_quat[4], n_wiggle[3], u_action[nu]
+  const float* goal_override;  // [B][4] or null: the goal an env receives if it needs a new one (scripted goals; default: LockedParallelGoal sampling)
+  unsigned seed, step;
+  // ---- constants
+  const float* parallel_quats; // [24][4]
+  const float* qpos0;          // [nq]
+  const float* zero_ctrl;      // [nu] ctrl of the zero action (absolute)
+  const float* ctrl_lo, *ctrl_hi;   // [nu]
+  float success_threshold, success_reward, wiggle_std, cube_body_z;
+  int max_timesteps_per_goal, successes_needed, use_goal_distance_reward;
+  int pipelined, reset_initial_steps, n_random_initial_steps, max_pose_resets;
+  int cube_pos_col, cube_quat_col;
+} rg_post_args;
+int rg_env_post_step(rg_batch* b, const rg_post_args* args, void* stream);
+int rg_post_args_size(void);   /* sizeof(rg_post_args) as compiled: a binding checks its own struct against it */
 /* Collision unit-test hook (no reference counterpart; mjc_Convex is internal to MuJoCo): runs the
  * kinematics of every env's stored qpos and one MPR penetration query between geoms g1, g2 inflated
  * by margin/2 each.  out_dev float [B][8] = hit, depth, direction3 (g1 -> g2), position3. */

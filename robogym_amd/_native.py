@@ -20,16 +20,37 @@ class StepArgs(ctypes.Structure):
     _fields_ = [("action_dev", ctypes.c_void_p), ("goal_quat_dev", ctypes.c_void_p), ("obs_dev", ctypes.c_void_p), ("goal_dist_dev", ctypes.c_void_p),
                 ("active_dev", ctypes.c_void_p), ("hold_dev", ctypes.c_void_p), ("nticks_dev", ctypes.c_void_p), ("order_dev", ctypes.c_void_p),
                 ("nsubsteps", ctypes.c_int), ("nforward_ticks", ctypes.c_int), ("flags", ctypes.c_int), ("stream", ctypes.c_void_p),
-                ("config", ctypes.c_int), ("redo_dev", ctypes.c_void_p)]
+                ("config", ctypes.c_int), ("redo_dev", ctypes.c_void_p), ("preticks_dev", ctypes.c_void_p)]
 
 
 RG_CFG_ROLLOUT, RG_CFG_LARGE = 0, 1
+RG_POST_NDRAW = 2 + 4 + 3 + 20
+
+
+def _post_fields():
+    p_, i_, f_, u_ = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_uint
+    ptrs1 = ("t", "phase", "tries", "steps", "steps_since_last_goal", "successes_so_far", "goals_so_far", "consecutive",
+             "prev_dist", "prev_valid", "is_successful", "goal_quat", "qpos_goal", "preticks", "reward",
+             "done", "goal_reset", "trial_success", "sub_goal_ok", "env_crash", "resetting", "episode_started",
+             "info_ssl", "nticks_next", "reset_mask", "live_mask", "goal_dist_before", "packed", "draws", "goal_override")
+    return ([("goal_dist", p_), ("obs", p_), ("obs_dim", i_)] + [(n, p_) for n in ptrs1] + [("seed", u_), ("step", u_)]
+            + [(n, p_) for n in ("parallel_quats", "qpos0", "zero_ctrl", "ctrl_lo", "ctrl_hi")]
+            + [(n, f_) for n in ("success_threshold", "success_reward", "wiggle_std", "cube_body_z")]
+            + [(n, i_) for n in ("max_timesteps_per_goal", "successes_needed", "use_goal_distance_reward", "pipelined", "reset_initial_steps",
+                                 "n_random_initial_steps", "max_pose_resets", "cube_pos_col", "cube_quat_col")])
+
+
+class PostArgs(ctypes.Structure):
+    """`rg_post_args` of include/rgstep.h (field order and types must match; bind() checks the size)."""
+
+    _fields_ = _post_fields()
 
 
 EXPORTS = [
     "rg_model_create", "rg_model_free", "rg_model_dims", "rg_batch_create", "rg_batch_free", "rg_batch_set_env",
     "rg_batch_copy", "rg_batch_reset", "rg_batch_step", "rg_obs_dim", "rg_debug_size", "rg_lds_bytes", "rg_sync",
-    "rg_last_error", "rg_batch_mpr_pair", "rg_batch_copy_rows", "rg_batch_step_ex", "rg_batch_field_ptr", "rg_model_create_on", "rg_model_npair", "rg_lds_bytes_cfg",
+    "rg_last_error", "rg_batch_mpr_pair", "rg_batch_copy_rows", "rg_batch_step_ex", "rg_batch_field_ptr", "rg_model_create_on", "rg_model_npair",
+    "rg_lds_bytes_cfg", "rg_env_post_step", "rg_post_args_size",
 ]
 
 
@@ -70,6 +91,10 @@ def bind(path):
     L.rg_lds_bytes.restype = ci
     L.rg_lds_bytes_cfg.restype = ci
     L.rg_lds_bytes_cfg.argtypes = [ci]
+    L.rg_env_post_step.argtypes = [vp, ctypes.POINTER(PostArgs), vp]
+    L.rg_post_args_size.restype = ci
+    if L.rg_post_args_size() != ctypes.sizeof(PostArgs):
+        raise NativeError("rg_post_args layout mismatch between include/rgstep.h and robogym_amd/_native.py")
     L.rg_sync.argtypes = [vp]
     L.rg_last_error.restype = ctypes.c_char_p
     return L

@@ -5,6 +5,7 @@
 // two kernel configurations of the same source (rg_kernel.h, "Everything below depends on ..."): LDS per env is what
 // bounds the envs in flight per CU, so the hot path runs with capacities sized for rollouts and the reset recipe
 // (2-3 x more contacts) with larger ones
+typedef rg_post_args RgPostArgs;
 #define RG_NS rgs
 #define RG_MAXCON 24
 #define RG_CPOOL 896
@@ -49,6 +50,8 @@ static hipError_t hipSetDevice(int) { return 0; }
 static hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 static const char* hipGetErrorString(hipError_t) { return "emul"; }
 #endif
+
+#include "rg_env_kernel.h"
 
 static thread_local std::string g_err;
 #ifdef RG_EMUL
@@ -488,6 +491,7 @@ int rg_batch_step_ex(rg_batch* b, const rg_step_args* a) {
   const bool large = a->config == RG_CFG_LARGE, prof = (a->flags & 2) != 0;
   if (a->config != RG_CFG_LARGE && a->config != RG_CFG_ROLLOUT) return fail("rg_batch_step: unknown kernel configuration");
   bt.redo = large ? nullptr : a->redo_dev;
+  bt.preticks = a->preticks_dev;
   RgLaunch launch{b->model->aux, b->env, bt, a->nsubsteps, a->nforward_ticks, a->flags};
   const size_t lds = large ? rgl::rg_lds_launch_bytes(prof) : rgs::rg_lds_launch_bytes(prof);
 #ifdef RG_EMUL
@@ -524,6 +528,32 @@ int rg_batch_mpr_pair(rg_batch* b, int g1, int g2, float margin, float* out_dev,
   emul_launch(b->dev.B, sizeof(rgs::RgLds), emul_mpr_entry, &args);
 #else
   hipLaunchKernelGGL(rgs::rg_mpr_pair_kernel, dim3(b->dev.B), dim3(RG_WAVE), sizeof(rgs::RgLds), (hipStream_t)stream, b->model->dev_copy, launch, g1, g2, margin, out_dev);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+
+#ifdef RG_EMUL
+struct EmulPostArgs { RgBatchDev bt; RgPostArgs a; int nq, nv, nu, npair; };
+static void emul_post_entry(void* p_) { EmulPostArgs* p = (EmulPostArgs*)p_; rg_post_step_kernel(p->bt, p->a, p->nq, p->nv, p->nu, p->npair); }
+#endif
+int rg_post_args_size(void) { return (int)sizeof(rg_post_args); }
+int rg_env_post_step(rg_batch* b, const rg_post_args* args, void* stream) {
+  if (!b || !args) return fail("null argument");
+  if (!b->has_env) return fail("rg_batch_set_env must be called first");
+  const rg_post_args& a = *args;
+  if (!a.goal_dist || !a.obs || !a.t || !a.phase || !a.tries || !a.steps || !a.steps_since_last_goal || !a.successes_so_far || !a.goals_so_far || !a.consecutive ||
+      !a.prev_dist || !a.prev_valid || !a.is_successful || !a.goal_quat || !a.qpos_goal || !a.preticks || !a.reward || !a.done || !a.goal_reset || !a.trial_success ||
+      !a.sub_goal_ok || !a.env_crash || !a.resetting || !a.episode_started || !a.info_ssl || !a.nticks_next || !a.reset_mask || !a.live_mask || !a.goal_dist_before || !a.parallel_quats || !a.qpos0 || !a.zero_ctrl ||
+      !a.ctrl_lo || !a.ctrl_hi) return fail("rg_env_post_step: a required array is NULL");
+  const RgModelDev& d = b->model->dev;
+  if (d.nu > 20) return fail("rg_env_post_step: nu exceeds RG_POST_NDRAW's action slots");
+  DeviceGuard g(b->device);
+#ifdef RG_EMUL
+  EmulPostArgs ea{b->dev, a, d.nq, d.nv, d.nu, d.npair};
+  emul_launch(b->dev.B, 256, emul_post_entry, &ea);
+#else
+  hipLaunchKernelGGL(rg_post_step_kernel, dim3(b->dev.B), dim3(RG_WAVE), 0, (hipStream_t)stream, b->dev, a, d.nq, d.nv, d.nu, d.npair);
   HIPCHK(hipGetLastError());
 #endif
   return 0;

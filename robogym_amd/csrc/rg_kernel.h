@@ -1978,6 +1978,18 @@ __global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_kernel(con
   if ((L.flags & 2) && LANE < RG_NPROF) s.prof[LANE] = 0;
   st_build_row_desc(c);
   // ---- action -> ctrl (robot_interface.py:247-278 with the hand's position->control matrix)
+  if (L.bt.preticks) {
+    // reset_goal's two state-less forwards (robot_env.py:893-909 -> _observe_sync), booked by rg_env_post_step: same state,
+    // same stored ctrl as when they were owed, so running them here is the same arithmetic
+    const int pre = L.bt.preticks[e];
+    if (pre > 0) {
+      PFOR(u, m.nu) s.ctrl[u] = L.bt.ctrl[(size_t)e * m.nu + u];
+      SYNC();
+      st_kinematics(c); st_com_pos(c); st_tendon(c);
+      for (int k = 0; k < pre; k++) st_pid(c);
+      if (LANE == 0) L.bt.preticks[e] = 0;
+    }
+  }
   // envs on `hold` (scripted reset recipe) and envs whose action row holds a non-finite entry keep their stored ctrl row
   bool use_action = L.bt.action && !(L.bt.hold && L.bt.hold[e]);
   if (use_action) {

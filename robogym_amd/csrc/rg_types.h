@@ -130,6 +130,7 @@ struct RgBatchDev {
   const int* nticks;    // [B] or null: per-env override of nforward_ticks (the reset recipe's sim.step has 1, env.step 3)
   const int* order;     // [B] or null: workgroup -> env permutation (longest-expected-first dispatch)
   float* cost;          // [B] or null: shader cycles this launch spent on the env (feeds `order` of the next step)
+  int* preticks;        // [B] or null: state-less forwards owed from the previous step's goal reset (run before the action is applied, then zeroed)
   int* redo;            // [B] or null: an env that exceeds this configuration's contact / candidate capacities is left
                         // untouched and flagged here, to be stepped again by a launch of the large configuration
   float* obs;           // [B][obs_dim]

@@ -206,7 +206,7 @@ class BatchedSimulationInterface:
         return None if t is None else ctypes.c_void_p(t.data_ptr())
 
     def env_step(self, action=None, goal_quat=None, obs=None, goal_dist=None, active=None, nsubsteps=None, nforward_ticks=3, flags=0,
-                 hold=None, nticks=None, order=None, capacity="auto", large_mask=None):
+                 hold=None, nticks=None, order=None, capacity="auto", large_mask=None, small_mask=None, preticks=None):
         """One reference env.step worth of physics for the whole batch (async on the current stream).
         `active`: optional int32 [B]; envs with 0 are left untouched.  `hold` int32 [B]: envs that keep their
         stored ctrl row; `nticks` int32 [B]: per-env forward-tick counts; `order` int32 [B]: dispatch permutation.
@@ -214,14 +214,15 @@ class BatchedSimulationInterface:
         "auto" = the rollout configuration, then the large one for exactly the envs that exceeded the rollout
         capacities (flagged on the device, no host sync; almost always an empty launch).  `large_mask` (int32 [B], with
         "auto"): envs known to need the large configuration (the reset recipe): they skip the rollout launch and run on a
-        side stream concurrently with it."""
+        side stream concurrently with it (`small_mask`: its complement, if the caller already has it).  `preticks` int32 [B]:
+        state-less forwards owed from the previous step's goal reset (rg_step_args.preticks_dev)."""
         for t in (action, goal_quat, obs, goal_dist):
             assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.device == self.device)
-        for t in (active, hold, nticks, order, large_mask):
+        for t in (active, hold, nticks, order, large_mask, small_mask, preticks):
             assert t is None or (t.dtype == torch.int32 and t.is_contiguous() and t.device == self.device and t.numel() == self.batch_size)
         a = _native.StepArgs()
         a.action_dev, a.goal_quat_dev, a.obs_dev, a.goal_dist_dev = (None if t is None else t.data_ptr() for t in (action, goal_quat, obs, goal_dist))
-        a.hold_dev, a.nticks_dev, a.order_dev = (None if t is None else t.data_ptr() for t in (hold, nticks, order))
+        a.hold_dev, a.nticks_dev, a.order_dev, a.preticks_dev = (None if t is None else t.data_ptr() for t in (hold, nticks, order, preticks))
         a.nsubsteps = self.n_substeps if nsubsteps is None else int(nsubsteps)
         a.nforward_ticks, a.flags = int(nforward_ticks), int(flags)
         self._keep.append((action, goal_quat, obs, goal_dist, active, hold, nticks, order, large_mask))
@@ -243,8 +244,11 @@ class BatchedSimulationInterface:
         self._redo.zero_()
         act0 = active
         if large_mask is not None:
-            small = 1 - large_mask if active is None else active * (1 - large_mask)
-            big = large_mask if active is None else active * large_mask
+            if small_mask is not None and active is None:
+                small, big = small_mask, large_mask
+            else:
+                small = 1 - large_mask if active is None else active * (1 - large_mask)
+                big = large_mask if active is None else active * large_mask
             act0 = small.contiguous()
             self._keep.append((act0, big))
             if self._emul:

@@ -108,21 +108,6 @@ def test_distinct_states_in_batch_emul(locked_model, emul_lib, oracle_lib):
 
 
 # ------------------------------------------------------------------------------------------------ reward / tracker
-class _ScriptedGoals:
-    """Stands in for LockedParallelGoal: the test decides the goal of every (step, env)."""
-
-    def __init__(self, sim):
-        self.sim = sim
-        self.current = None   # [B, 4] numpy, set by the test before each env.step
-
-    def next_goal(self):
-        dev = self.sim.device
-        gq = torch.as_tensor(self.current.astype(np.float32), device=dev)
-        qg = torch.zeros((self.sim.batch_size, self.sim.nq), dtype=torch.float32, device=dev)
-        qg[:, torch.as_tensor(self.sim.qpos_idxs["cube_rotation"], device=dev)] = gq
-        return {"cube_quat": gq, "qpos_goal": qg}
-
-
 def _rot(q, axis, ang):
     from oracle.env_oracle import quat_mul
     d = np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * np.asarray(axis)])
@@ -137,12 +122,13 @@ def _run_reward_stream(env, oras, nsteps, seed, near=2e-3, easy=0.4):
     sim = env.mujoco_simulation
     B = len(oras)
     rng = np.random.RandomState(seed)
-    goals = _ScriptedGoals(sim)
-    env.goal_generation = goals
+    class goals:   # the goal every (step, env) would receive; fed to the env kernel (set_goal_override) and to the oracles
+        current = None
     g0 = rng.randn(B, 4); g0 /= np.linalg.norm(g0, axis=1, keepdims=True)
     for o in oras:
         o.sim.reset(); o.prev_dist = None; o.settle(40 + int(rng.randint(0, 10)))
     goals.current = g0
+    env.set_goal_override(torch.as_tensor(g0, dtype=torch.float32))
     env._needs_reset = False
     one = torch.ones(B, dtype=torch.bool, device=sim.device)
     env.multi_goal_tracker.reset(one)
@@ -165,6 +151,7 @@ def _run_reward_stream(env, oras, nsteps, seed, near=2e-3, easy=0.4):
             if pick[e]:
                 cur[e] = _rot(o.sim.qpos[o.cube_quat_q], ax, 0.15)
         goals.current = cur
+        env.set_goal_override(torch.as_tensor(cur, dtype=torch.float32))
         a = rng.uniform(-1, 1, (B, 20)).astype(np.float32)
         # physics re-synchronised: kernel rows <- oracle states (fp32), oracle <- the same bytes
         sts = [o.get_state_f32() for o in oras]
@@ -197,8 +184,8 @@ def _run_reward_stream(env, oras, nsteps, seed, near=2e-3, easy=0.4):
         dm = torch.as_tensor(done, device=sim.device)
         if done.any():
             env.multi_goal_tracker.reset(dm)
-            env.t = torch.where(dm, torch.zeros_like(env.t), env.t)
-            env._prev_valid = env._prev_valid & ~dm
+            env.t.masked_fill_(dm, 0)
+            env._prev_valid.masked_fill_(dm, 0)
             env._new_goal(dm)
             for e, o in enumerate(oras):
                 if done[e]:
@@ -246,7 +233,7 @@ def _run_recipe(env, oras, draws, c):
     dev = sim.device
     seq = {"normal": [], "uniform": []}
 
-    # inject the draws: _step_pipelined asks for randn(B,4) [quat], randn(B,3) [wiggle], uniform(B,nu) [action] every step
+    # the synchronous env.reset() draws through torch; the pipelined recipe takes its draws from set_draws
     def fake_normal(*shape):
         return torch.as_tensor(draws["quat_raw"] if shape[-1] == 4 else draws["wiggle_raw"], dtype=torch.float32, device=dev)
 
@@ -254,6 +241,7 @@ def _run_recipe(env, oras, draws, c):
         return torch.as_tensor(draws["action"], dtype=torch.float32, device=dev)
 
     env._rand_normal, env._rand_uniform = fake_normal, fake_uniform
+    env.set_draws(torch.as_tensor(np.concatenate([np.full((B, 1), 0.3), np.full((B, 1), 0.5), draws["quat_raw"], draws["wiggle_raw"], draws["action"]], axis=1), dtype=torch.float32))
     env.reset()
     a = torch.zeros((B, env.num_actions), device=dev)
     # run until the (tiny) goal timeout ends every episode
@@ -299,7 +287,9 @@ def _run_recipe(env, oras, draws, c):
             for e, o in enumerate(oras):
                 on_palm = o.model.body_pos[o.model.name2id("body", "cube:middle")][2] + o.sim.qpos[o.cube_pos_q[2]] > 0.04
                 assert bool(started[e]) == bool(on_palm), e
-                if started[e]:   # first observation of the new episode (+ the two forwards of reset_goal)
+                if started[e]:   # first observation of the new episode (+ the two forwards of reset_goal, which the kernel owes until its next launch)
+                    if e == int(np.argmax(started)):
+                        sim.env_step(nsubsteps=0, nforward_ticks=0, preticks=env._preticks)
                     o.sim.forward(); o.sim.forward()
                     row = o.obs_row()
                     errs.append((np.abs(obs["qpos"][e].cpu().numpy() - o.obs_qpos())[NON_TARGET_QPOS].max(), np.abs(obs["qvel"][e].cpu().numpy() - o.obs_qvel()).max(),
