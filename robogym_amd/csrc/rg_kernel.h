@@ -135,6 +135,10 @@ __device__ __forceinline__ void q2mat(float* m, q4 q) {
   m[3] = 2 * (x * y + w * z); m[4] = w * w - x * x + y * y - z * z; m[5] = 2 * (y * z - w * x);
   m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = w * w - x * x - y * y + z * z;
 }
+// v rotated by the unit quaternion q (and by its inverse): v + w t + u x t with t = 2 u x v.  Frames are kept as
+// quaternions in LDS (4 words instead of the 9 of a rotation matrix: LDS per env is what bounds the envs in flight)
+__device__ __forceinline__ v3 qrot(q4 q, v3 v) { v3 u = mk3(q.x, q.y, q.z), t = cross(u, v) * 2.0f; return v + t * q.w + cross(u, t); }
+__device__ __forceinline__ v3 qrotT(q4 q, v3 v) { v3 u = mk3(q.x, q.y, q.z), t = cross(u, v) * 2.0f; return v - t * q.w + cross(u, t); }
 // sin / cos of a hinge half-angle: |x| <= 1.5 covers every joint range with margin; there the Taylor
 // polynomials below are exact to fp32 rounding (remainders x^13/13! < 3e-8 relative, x^14/14! < 4e-9) and cost
 // a dozen FMAs instead of libm's range-reduced sincosf
@@ -271,7 +275,6 @@ struct RgLds {
   float tenlen[RG_MAXTEN], tenJ[RG_MAXTEN * 4];
   float actlen[RG_MAXU], actfrc[RG_MAXU];
   float qfrc_smooth[RG_MAXNV], qacc_smooth[RG_MAXNV];
-  float r_D[RG_MAXSROW], r_aref[RG_MAXSROW], r_floss[RG_MAXFRIC];
   unsigned short r_desc[RG_MAXSROW];   // compact dof (6 bits) | tendon id (5 bits, 31 = none) << 6 | negative sign << 11
   unsigned char ten_cdof[RG_MAXTEN * 4], c2d[RG_MAXNVC], b2org[RG_MAXBODY];
   int cblk[RG_MAXNVC];   // per compact dof: inertia-block row word | compact index of its tree start << 16 | tree size << 24
@@ -286,16 +289,16 @@ struct RgLds {
   union {
     struct {  // ---- pos
       union {  // slot A
-        struct { float xpos[RG_MAXBODY * 3], xquat[RG_MAXBODY * 4], xmat[RG_MAXBODY * 9], xipos[RG_MAXBODY * 3], xanchor[RG_MAXJNT * 3], xaxis[RG_MAXJNT * 3], spos[RG_MAXSITE * 3]; };
+        struct { alignas(16) float xquat[RG_MAXBODY * 4]; float xpos[RG_MAXBODY * 3], xipos[RG_MAXBODY * 3], xanchor[RG_MAXJNT * 3], xaxis[RG_MAXJNT * 3], spos[RG_MAXSITE * 3]; };
         struct { float crb[RG_MAXBODY * 10]; };
-        struct { float cdofdot[RG_MAXNV * 6], cacc[RG_MAXBODY * 6], cfrc[RG_MAXBODY * 6], tenfrc[RG_MAXTEN], tenvel[RG_MAXTEN], qfrc_passive[RG_MAXNV], qfrc_bias[RG_MAXNV], qfrc_act[RG_MAXNV]; short tlist[RG_TLIST]; };
+        struct { float cdofdot[RG_MAXNV * 6], cacc[RG_MAXBODY * 6], tenfrc[RG_MAXTEN], tenvel[RG_MAXTEN], qfrc_passive[RG_MAXNV], qfrc_bias[RG_MAXNV], qfrc_act[RG_MAXNV]; };   // (cacc: per-body forces, then their subtree sums in place)
       };
-      float gpos[RG_MAXGEOM * 3], gmat[RG_MAXGEOM * 9];  // slot B
+      alignas(16) float gquat[RG_MAXGEOM * 4]; float gpos[RG_MAXGEOM * 3];  // slot B: geom frames (orientation as a quaternion)
       float cdof[RG_MAXNV * 6];   // alive from com_pos to the constraint rows
       float gspeed[RG_MAXGEOM];  // bound on the speed of any point of the geom (velocity stage -> broadphase)
       union {  // slot C
         float cinert[RG_MAXBODY * 10];   // com_pos .. velocity stage
-        struct { short cand[RG_MAXCAND], cand2[RG_MAXCAND2]; float c_dist[RG_MAXCON], c_pos[RG_MAXCON * 3], c_normal[RG_MAXCON * 3]; };   // collision .. constraint rows
+        struct { short cand[RG_MAXCAND], cand2[RG_MAXCAND2], tlist[RG_TLIST]; float c_dist[RG_MAXCON], c_pos[RG_MAXCON * 3], c_normal[RG_MAXCON * 3]; };   // collision .. constraint rows
       };
     };
     struct {  // ---- slv
@@ -303,7 +306,6 @@ struct RgLds {
       float a[RG_MAXNVC], as[RG_MAXNVC], fs[RG_MAXNVC], jtf[RG_MAXNVC], Ma[RG_MAXNVC], search[RG_MAXNVC], Mv[RG_MAXNVC], dinv[RG_MAXNV], tmpv[RG_MAXNV], qfrc_con[RG_MAXNV], qacc[RG_MAXNV];
       unsigned char p_quad[RG_MAXPYR];
       float c_bdot[RG_MAXCON * 4], c_bfrc[RG_MAXCON * 4];
-      float p_jar[RG_MAXPYR], p_jv[RG_MAXPYR], p_force[RG_MAXPYR];
     };
   };
   float prof[RG_NPROF];   // LAST: launches without the profiling flag do not allocate it (rg_lds_launch_bytes)
@@ -316,8 +318,8 @@ __device__ __forceinline__ void rg_kinematics(RgM m, RgLds& s) {
   PFOR(i, m.nstatic) {
     int b = m.static_body[i];
     st3(s.xpos + 3 * b, ld3(m.static_xpos + 3 * b));
-    q4 q = ldq(m.static_xquat + 4 * b); stq(s.xquat + 4 * b, q); q2mat(s.xmat + 9 * b, q);
-    st3(s.xipos + 3 * b, ld3(s.xpos + 3 * b) + mulm(s.xmat + 9 * b, ld3(m.body_ipos + 3 * b)));
+    q4 q = ldq(m.static_xquat + 4 * b); stq(s.xquat + 4 * b, q);
+    st3(s.xipos + 3 * b, ld3(m.static_xpos + 3 * b) + qrot(q, ld3(m.body_ipos + 3 * b)));
   }
   SYNC();
   for (int L = 0; L < m.nlevel; L++) {
@@ -329,9 +331,10 @@ __device__ __forceinline__ void rg_kinematics(RgM m, RgLds& s) {
       int w0 = __builtin_bit_cast(int, r0.x), w1 = __builtin_bit_cast(int, r0.y);
       int b = w0 & 255, p = (w0 >> 8) & 255, jn = (w0 >> 16) & 15, ja = w1 & 0xFFFF;
       v3 bipos = mk3(r2.y, r2.z, r2.w);
-      v3 pos = ld3(s.xpos + 3 * p) + mulm(s.xmat + 9 * p, mk3(r0.z, r0.w, r1.x));
+      q4 pq = ldq(s.xquat + 4 * p);
+      v3 pos = ld3(s.xpos + 3 * p) + qrot(pq, mk3(r0.z, r0.w, r1.x));
       q4 bq; bq.w = r1.y; bq.x = r1.z; bq.y = r1.w; bq.z = r2.x;
-      q4 quat = qmul(ldq(s.xquat + 4 * p), bq);
+      q4 quat = qmul(pq, bq);
       for (int jj = 0; jj < jn; jj++) {
         int j = ja + jj, t, qa; v3 jpos, jaxis; float q0;
         if (jj == 0) { t = (w0 >> 20) & 15; qa = (w1 >> 16) & 0xFFFF; jpos = mk3(r3.x, r3.y, r3.z); jaxis = mk3(r3.w, r4.x, r4.y); q0 = r4.z; }
@@ -341,32 +344,31 @@ __device__ __forceinline__ void rg_kinematics(RgM m, RgLds& s) {
           st3(s.xanchor + 3 * j, pos); st3(s.xaxis + 3 * j, mk3(0, 0, 1));
           continue;
         }
-        float mat[9]; q2mat(mat, quat);
-        v3 anchor = pos + mulm(mat, jpos);
-        v3 axis = mulm(mat, jaxis);
+        v3 anchor = pos + qrot(quat, jpos);
+        v3 axis = qrot(quat, jaxis);
         st3(s.xanchor + 3 * j, anchor); st3(s.xaxis + 3 * j, axis);
         if (t == RG_JNT_SLIDE) pos = pos + axis * (s.qpos[qa] - q0);
         else {
           q4 ql = (t == RG_JNT_BALL) ? qnormalize(ldq(s.qpos + qa)) : axisangle(jaxis, s.qpos[qa] - q0);
           quat = qmul(quat, ql);
-          q2mat(mat, quat);
-          pos = anchor - mulm(mat, jpos);
+          pos = anchor - qrot(quat, jpos);
         }
       }
       quat = qnormalize(quat);
-      st3(s.xpos + 3 * b, pos); stq(s.xquat + 4 * b, quat); q2mat(s.xmat + 9 * b, quat);
-      st3(s.xipos + 3 * b, pos + mulm(s.xmat + 9 * b, bipos));
+      st3(s.xpos + 3 * b, pos); stq(s.xquat + 4 * b, quat);
+      st3(s.xipos + 3 * b, pos + qrot(quat, bipos));
     }
     SYNC();
   }
   PFOR(g, m.ngeom) {
     int b = m.geom_bodyid[g];
-    st3(s.gpos + 3 * g, ld3(s.xpos + 3 * b) + mulm(s.xmat + 9 * b, ld3(m.geom_pos + 3 * g)));
-    q2mat(s.gmat + 9 * g, qmul(ldq(s.xquat + 4 * b), ldq(m.geom_quat + 4 * g)));
+    q4 xq = ldq(s.xquat + 4 * b);
+    st3(s.gpos + 3 * g, ld3(s.xpos + 3 * b) + qrot(xq, ld3(m.geom_pos + 3 * g)));
+    stq(s.gquat + 4 * g, qmul(xq, ldq(m.geom_quat + 4 * g)));
   }
   PFOR(i, m.nsite) {
     int b = m.site_bodyid[i];
-    st3(s.spos + 3 * i, ld3(s.xpos + 3 * b) + mulm(s.xmat + 9 * b, ld3(m.site_pos + 3 * i)));
+    st3(s.spos + 3 * i, ld3(s.xpos + 3 * b) + qrot(ldq(s.xquat + 4 * b), ld3(m.site_pos + 3 * i)));
   }
   PFOR(b, m.nbody) {
     int r = m.body_rootid[b], ob = m.root_origin_body[r];
@@ -377,10 +379,8 @@ __device__ __forceinline__ void rg_kinematics(RgM m, RgLds& s) {
 
 __device__ __forceinline__ void rg_com_pos(RgM m, RgLds& s) {
   for (int b = 1 + LANE; b < m.nbody; b += RG_WAVE) {
-    float R[9], I[9], qm[9];
-    q2mat(qm, ldq(m.body_iquat + 4 * b));
-    const float* X = s.xmat + 9 * b;
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[3 * i + j] = X[3 * i] * qm[j] + X[3 * i + 1] * qm[3 + j] + X[3 * i + 2] * qm[6 + j];
+    float R[9], I[9];
+    q2mat(R, qmul(ldq(s.xquat + 4 * b), ldq(m.body_iquat + 4 * b)));   // orientation of the inertial frame: body frame x iquat
     const float* in = m.body_inertia + 3 * b;
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) I[3 * i + j] = R[3 * i] * in[0] * R[3 * j] + R[3 * i + 1] * in[1] * R[3 * j + 1] + R[3 * i + 2] * in[2] * R[3 * j + 2];
     v3 d = ld3(s.xipos + 3 * b) - ld3(s.org + 3 * s.b2org[b]);
@@ -393,7 +393,7 @@ __device__ __forceinline__ void rg_com_pos(RgM m, RgLds& s) {
   PFOR(j, m.njnt) {
     int b = m.jnt_bodyid[j], da = m.jnt_dofadr[j], t = m.jnt_type[j];
     v3 off = ld3(s.org + 3 * s.b2org[b]) - ld3(s.xanchor + 3 * j);
-    const float* R = s.xmat + 9 * b;
+    float R[9]; q2mat(R, ldq(s.xquat + 4 * b));
     if (t == RG_JNT_FREE || t == RG_JNT_BALL) {
       if (t == RG_JNT_FREE) {
         for (int k = 0; k < 3; k++) { float* c = s.cdof + 6 * (da + k); for (int e = 0; e < 6; e++) c[e] = 0; c[3 + k] = 1; }
@@ -508,7 +508,8 @@ __device__ __forceinline__ void rg_tendon(RgM m, RgLds& s) {
         if (t1 == RG_WRAP_SPHERE || t1 == RG_WRAP_CYLINDER) {
           int g = m.wrap_objid[w + 1], s1 = m.wrap_objid[w + 2], sid = (int)m.wrap_prm[w + 1];
           v3 x1 = ld3(s.spos + 3 * s1), w0 = mk3(0, 0, 0), w1 = mk3(0, 0, 0);
-          wlen = rg_wrap(w0, w1, pa, x1, ld3(s.gpos + 3 * g), s.gmat + 9 * g, m.geom_size[3 * g], t1, sid >= 0, sid >= 0 ? ld3(s.spos + 3 * sid) : mk3(0, 0, 0));
+          float gm[9]; q2mat(gm, ldq(s.gquat + 4 * g));
+          wlen = rg_wrap(w0, w1, pa, x1, ld3(s.gpos + 3 * g), gm, m.geom_size[3 * g], t1, sid >= 0, sid >= 0 ? ld3(s.spos + 3 * sid) : mk3(0, 0, 0));
           if (wlen < 0) { pb = x1; bb = m.site_bodyid[s1]; }
           else { pb = w0; pc = w1; pd = x1; bb = bc = m.geom_bodyid[g]; bd = m.site_bodyid[s1]; two = true; }
           w += 2;
@@ -580,7 +581,7 @@ __device__ __forceinline__ void rg_M_to_blocks(RgM m, RgLds& s) {
 struct SupPt { v3 v, s; };  // v = v1 - v2 (Minkowski difference), s = v1 + v2 (all the contact position needs)
 // per-query (lane-varying) description of one geom, and the wave-uniform tables every query shares: keeping the
 // 64-bit table pointers out of MprGeom keeps them in SGPRs (the narrowphase is the register-hungriest stage)
-struct MprGeom { int type; const float* mat; v3 pos; v3 size; int vertadr, nvert, mesh; float margin; };   // mesh: id, -1 for primitives
+struct MprGeom { int type; const float* quat; v3 pos; v3 size; int vertadr, nvert, mesh; float margin; };   // quat: the geom's orientation in LDS (16-byte aligned)   // mesh: id, -1 for primitives
 struct MprEnv { const float* mesh_vert; const int* cell_adr; const rgf4 *cell_blk, *cell_ovf; float* prof; bool cells; };
 
 // per-lane scan of a hull's vertices: 16-byte records (one dwordx4 load per vertex), four independent
@@ -671,20 +672,22 @@ __device__ __forceinline__ v3 support_primitive(const MprGeom& g, v3 ld) {
 }
 // support point of one geom (relative to the MPR reference origin), cooperative for meshes
 template <int G> __device__ __forceinline__ v3 rg_support(const MprEnv& E, const MprGeom& g, v3 dir) {
-  v3 ld = mulmT(g.mat, dir), lr;
+  q4 gq = ldq(g.quat);
+  v3 ld = qrotT(gq, dir), lr;
   if (g.type == RG_GEOM_MESH) {
     float bv = -3.0e38f; int bi = 0x7fffffff; v3 bp = mk3(0, 0, 0);
     scan_hull<G>(E, g, ld, bv, bi, bp);
     lr = pick_vert<G>(bv, bi, bp);
   } else lr = support_primitive(g, ld);
   lr = lr + ld * g.margin;
-  return mulm(g.mat, lr) + g.pos;
+  return qrot(gq, lr) + g.pos;
 }
 // Minkowski-difference support A(dir) - B(-dir); the two hull scans are issued back to back so their
 // vertex loads overlap
 template <int G> __device__ __forceinline__ void mpr_support(const MprEnv& E, const MprGeom& a, const MprGeom& b, v3 dir, SupPt& p) {
   long long tt0 = E.prof ? rg_clock() : 0;
-  v3 la = mulmT(a.mat, dir), lb = mulmT(b.mat, dir * -1.0f), ra, rb;
+  q4 qa = ldq(a.quat), qb = ldq(b.quat);
+  v3 la = qrotT(qa, dir), lb = qrotT(qb, dir * -1.0f), ra, rb;
   float av = -3.0e38f, bvv = -3.0e38f; int ai = 0x7fffffff, bi = 0x7fffffff; v3 ap = mk3(0, 0, 0), bp = mk3(0, 0, 0);
   bool am = a.type == RG_GEOM_MESH, bm = b.type == RG_GEOM_MESH;
   if (am) scan_hull<G>(E, a, la, av, ai, ap);
@@ -692,8 +695,8 @@ template <int G> __device__ __forceinline__ void mpr_support(const MprEnv& E, co
   long long tt1 = E.prof ? rg_clock() : 0;
   ra = am ? pick_vert<G>(av, ai, ap) : support_primitive(a, la);
   rb = bm ? pick_vert<G>(bvv, bi, bp) : support_primitive(b, lb);
-  v3 w1 = mulm(a.mat, ra + la * a.margin) + a.pos;
-  v3 w2 = mulm(b.mat, rb + lb * b.margin) + b.pos;
+  v3 w1 = qrot(qa, ra + la * a.margin) + a.pos;
+  v3 w2 = qrot(qb, rb + lb * b.margin) + b.pos;
   p.v = w1 - w2; p.s = w1 + w2;
   if (E.prof && LANE == 0) { long long tt2 = rg_clock(); E.prof[20] += 1.f; E.prof[21] += (float)(tt1 - tt0); E.prof[22] += (float)(tt2 - tt1); }
 }
@@ -889,8 +892,8 @@ __device__ __forceinline__ void rg_mpr_geoms(RgM m, const RgLds& s, int p, MprGe
   rgf4 r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3];
   int hdr = __builtin_bit_cast(int, r0.x), g1 = hdr & 255, g2 = (hdr >> 8) & 255;
   dim = (hdr >> 16) & 15; margin = r0.y;
-  A.type = (hdr >> 20) & 15; A.mat = s.gmat + 9 * g1; A.size = mk3(r1.x, r1.y, r1.z); A.margin = 0.5f * margin; A.pos = mk3(0, 0, 0);
-  B.type = (hdr >> 24) & 15; B.mat = s.gmat + 9 * g2; B.size = mk3(r2.x, r2.y, r2.z); B.margin = 0.5f * margin; B.pos = ld3(s.gpos + 3 * g2) - ld3(s.gpos + 3 * g1);
+  A.type = (hdr >> 20) & 15; A.quat = s.gquat + 4 * g1; A.size = mk3(r1.x, r1.y, r1.z); A.margin = 0.5f * margin; A.pos = mk3(0, 0, 0);
+  B.type = (hdr >> 24) & 15; B.quat = s.gquat + 4 * g2; B.size = mk3(r2.x, r2.y, r2.z); B.margin = 0.5f * margin; B.pos = ld3(s.gpos + 3 * g2) - ld3(s.gpos + 3 * g1);
   A.mesh = __builtin_bit_cast(int, r0.z); A.vertadr = __builtin_bit_cast(int, r3.x); A.nvert = __builtin_bit_cast(int, r1.w);
   B.mesh = __builtin_bit_cast(int, r0.w); B.vertadr = __builtin_bit_cast(int, r3.y); B.nvert = __builtin_bit_cast(int, r2.w);
 }
@@ -1016,15 +1019,15 @@ __device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, float* pr
         float margin = r0.y, newlb = 0.f;
         v3 p1 = ld3(s.gpos + 3 * g1), p2 = ld3(s.gpos + 3 * g2), dif = p2 - p1;
         if (((hdr >> 20) & 15) == RG_GEOM_PLANE) {
-          const float* R1 = s.gmat + 9 * g1;
-          float d = dot(dif, mk3(R1[2], R1[5], R1[8])) - (r3.w + margin);
+          float d = dot(dif, qrot(ldq(s.gquat + 4 * g1), mk3(0, 0, 1))) - (r3.w + margin);
           hit = d <= 0; newlb = fmaxf(d, 0.f);
         } else {
           float d = sqrtf(dot(dif, dif)) - (r3.z + r3.w + margin);
           if (d <= 0) {
             float hm = 0.5f * margin + 1e-6f;
             v3 ea = mk3(r4.x + hm, r4.y + hm, r4.z + hm), eb = mk3(r5.x + hm, r5.y + hm, r5.z + hm);
-            float og = obb_gap(s.gmat + 9 * g1, ea, s.gmat + 9 * g2, eb, dif);
+            float Ra[9], Rb[9]; q2mat(Ra, ldq(s.gquat + 4 * g1)); q2mat(Rb, ldq(s.gquat + 4 * g2));
+            float og = obb_gap(Ra, ea, Rb, eb, dif);
             hit = og < 0; newlb = fmaxf(og, 0.f);
           } else newlb = d;
         }
@@ -1068,15 +1071,14 @@ __device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, float* pr
     int t2 = m.geom_type[g2];
     v3 p1 = ld3(s.gpos + 3 * g1), p2 = ld3(s.gpos + 3 * g2);
     MprGeom B;
-    B.type = t2; B.mat = s.gmat + 9 * g2; B.size = ld3(m.geom_size + 3 * g2); B.margin = 0; B.mesh = -1; B.vertadr = 0; B.nvert = 0;
+    B.type = t2; B.quat = s.gquat + 4 * g2; B.size = ld3(m.geom_size + 3 * g2); B.margin = 0; B.mesh = -1; B.vertadr = 0; B.nvert = 0;
     if (t2 == RG_GEOM_MESH) { B.mesh = m.geom_dataid[g2]; B.vertadr = m.mesh_vertadr[B.mesh]; B.nvert = m.mesh_vertnum[B.mesh]; }
-    const float* R1 = s.gmat + 9 * g1;
-    v3 n = mk3(R1[2], R1[5], R1[8]);
+    v3 n = qrot(ldq(s.gquat + 4 * g1), mk3(0, 0, 1));
     if (t2 == RG_GEOM_BOX) {
       int cnt = 0;
       for (int i = 0; i < 8 && cnt < 4; i++) {
         v3 lc = mk3((i & 1) ? B.size.x : -B.size.x, (i & 2) ? B.size.y : -B.size.y, (i & 4) ? B.size.z : -B.size.z);
-        v3 c = mulm(B.mat, lc) + p2;
+        v3 c = qrot(ldq(B.quat), lc) + p2;
         float dist = dot(c - p1, n);
         if (dist > margin) continue;
         add_contact(s, p, dist, c - n * (0.5f * dist), n, dim); cnt++;
@@ -1135,15 +1137,21 @@ __device__ __forceinline__ void rg_velocity(RgM m, RgLds& s, const uint32_t* dof
     for (int e = 0; e < 6; e++) s.cacc[6 * b + e] = t1[e] + t3[e];  // per-body force before subtree accumulation
   }
   SYNC();
-  for (int w = LANE; w < m.nbody * 6; w += RG_WAVE) {
-    int b = w / 6, k = w - 6 * b;
-    float acc = 0;
-    if (b > 0) for (uint32_t bits = (uint32_t)m.subtree_mask[b]; bits; bits &= bits - 1) acc += s.cacc[6 * __builtin_ctz(bits) + k];
-    s.cfrc[w] = acc;
+  {  // subtree sums in place: every lane gathers its (<= RG_MAXBODY * 6 / 64 = 3) sums first, then the wave overwrites
+    float acc[(RG_MAXBODY * 6 + RG_WAVE - 1) / RG_WAVE];
+#pragma unroll
+    for (int k0 = 0; k0 < (RG_MAXBODY * 6 + RG_WAVE - 1) / RG_WAVE; k0++) {
+      int w = LANE + RG_WAVE * k0, b = w / 6, k = w - 6 * b; float a = 0;
+      if (w < m.nbody * 6 && b > 0) for (uint32_t bits = (uint32_t)m.subtree_mask[b]; bits; bits &= bits - 1) a += s.cacc[6 * __builtin_ctz(bits) + k];
+      acc[k0] = a;
+    }
+    SYNC();
+#pragma unroll
+    for (int k0 = 0; k0 < (RG_MAXBODY * 6 + RG_WAVE - 1) / RG_WAVE; k0++) { int w = LANE + RG_WAVE * k0; if (w < m.nbody * 6) s.cacc[w] = acc[k0]; }
   }
   SYNC();
   PFOR(d, m.nv) {
-    const float *c = s.cdof + 6 * d, *f = s.cfrc + 6 * m.dof_bodyid[d];
+    const float *c = s.cdof + 6 * d, *f = s.cacc + 6 * m.dof_bodyid[d];
     s.qfrc_bias[d] = c[0] * f[0] + c[1] * f[1] + c[2] * f[2] + c[3] * f[3] + c[4] * f[4] + c[5] * f[5];
     int j = m.dof_jntid[d], t = m.jnt_type[j];
     float pas = -m.dof_damping[d] * s.qvel[d];
@@ -1269,32 +1277,6 @@ __device__ __forceinline__ int npyr(int dim) { return dim == 1 ? 1 : 2 * (dim - 
 __device__ __forceinline__ int nbasis(int dim) { return dim >= 4 ? 4 : (dim == 1 ? 1 : 3); }
 
 __device__ __forceinline__ void rg_make_constraint(RgM m, RgLds& s) {
-  int ns = nsrow(m);
-  PFOR(r, ns) {
-    int rr = r; float pos = 0, margin = 0, diag, floss = 0; const float *solref, *solimp; bool active = true, fric = false;
-    if (rr < m.nfric_dof) { int d = m.fric_dof[rr]; floss = m.dof_frictionloss[d]; diag = m.dof_invweight0[d]; solref = m.dof_solref + 2 * d; solimp = m.dof_solimp + 5 * d; fric = true; }
-    else if ((rr -= m.nfric_dof) < m.nfric_ten) { int t = m.fric_ten[rr]; floss = m.tendon_frictionloss[t]; diag = m.tendon_invweight0[t]; solref = m.tendon_solref_fri + 2 * t; solimp = m.tendon_solimp_fri + 5 * t; fric = true; }
-    else if ((rr -= m.nfric_ten) < 2 * m.nlim_jnt) {
-      int j = m.lim_jnt[rr >> 1]; float q = s.qpos[m.jnt_qposadr[j]];
-      pos = (rr & 1) ? (m.jnt_range[2 * j + 1] - q) : (q - m.jnt_range[2 * j]);
-      margin = m.jnt_margin[j]; active = pos < margin; diag = m.dof_invweight0[m.jnt_dofadr[j]]; solref = m.jnt_solref + 2 * j; solimp = m.jnt_solimp + 5 * j;
-    } else {
-      rr -= 2 * m.nlim_jnt; int t = m.lim_ten[rr >> 1]; float L = s.tenlen[t];
-      pos = (rr & 1) ? (m.tendon_range[2 * t + 1] - L) : (L - m.tendon_range[2 * t]);
-      margin = m.tendon_margin[t]; active = pos < margin; diag = m.tendon_invweight0[t]; solref = m.tendon_solref_lim + 2 * t; solimp = m.tendon_solimp_lim + 5 * t;
-    }
-    float D = 0, aref = 0;
-    if (active) {
-      float imp = impedance(solimp, pos, margin), K, B;
-      float R = fmaxf(1e-15f, (1 - imp) * diag * rg_rcp(imp));
-      kb(m, solref, solimp, K, B);
-      if (fric) K = 0;
-      float vel = srow_dot<true>(s, r, s.qvel);
-      D = rg_rcp(R); aref = -B * vel - K * imp * (pos - margin);
-    }
-    s.r_D[r] = D; s.r_aref[r] = aref;   // D == 0 marks an inactive slot
-    if (r < RG_MAXFRIC) s.r_floss[r] = fric ? floss : 0.f;
-  }
   // contact basis Jacobians on the merged dof chains, packed into a shared pool (rows x nnz per contact)
   int ncon = s.ncon;
   PFOR(c, ncon) {
@@ -1362,14 +1344,46 @@ __device__ __forceinline__ void rg_make_constraint(RgM m, RgLds& s) {
 // Residuals of the static rows (friction loss, limits) live in the registers of the lane that owns the row (row
 // LANE + 64 k): only that lane ever touches them, so they need no LDS (1.2 kB per env that the occupancy wants back).
 #define RG_RSLOTS ((RG_MAXSROW + RG_WAVE - 1) / RG_WAVE)
-struct RowRegs { float jar[RG_RSLOTS], jv[RG_RSLOTS], force[RG_RSLOTS]; int quad[RG_RSLOTS]; };
+struct RowRegs { float D[RG_RSLOTS], aref[RG_RSLOTS], floss[RG_RSLOTS], jar[RG_RSLOTS], jv[RG_RSLOTS], force[RG_RSLOTS]; int quad[RG_RSLOTS]; float pjar[RG_PSLOTS], pjv[RG_PSLOTS], pforce[RG_PSLOTS]; };   // p*: pyramid row LANE + 64 k (= 6 c + q)
+// friction-loss and limit rows (mj_makeConstraint's first two blocks + mj_makeImpedance for them): impedance, regulariser,
+// reference acceleration — straight into the registers of the lanes that own the rows (RowRegs), at the start of the solve
+__device__ __forceinline__ void rg_static_rows(RgM m, const RgLds& s, RowRegs& R) {
+  int ns = nsrow(m);
+#pragma unroll
+  for (int k = 0; k < RG_RSLOTS; k++) {
+    int r = LANE + RG_WAVE * k;
+    if (r >= ns) { R.D[k] = 0.f; R.aref[k] = 0.f; R.floss[k] = 0.f; continue; }
+    int rr = r; float pos = 0, margin = 0, diag, floss = 0; const float *solref, *solimp; bool active = true, fric = false;
+    if (rr < m.nfric_dof) { int d = m.fric_dof[rr]; floss = m.dof_frictionloss[d]; diag = m.dof_invweight0[d]; solref = m.dof_solref + 2 * d; solimp = m.dof_solimp + 5 * d; fric = true; }
+    else if ((rr -= m.nfric_dof) < m.nfric_ten) { int t = m.fric_ten[rr]; floss = m.tendon_frictionloss[t]; diag = m.tendon_invweight0[t]; solref = m.tendon_solref_fri + 2 * t; solimp = m.tendon_solimp_fri + 5 * t; fric = true; }
+    else if ((rr -= m.nfric_ten) < 2 * m.nlim_jnt) {
+      int j = m.lim_jnt[rr >> 1]; float q = s.qpos[m.jnt_qposadr[j]];
+      pos = (rr & 1) ? (m.jnt_range[2 * j + 1] - q) : (q - m.jnt_range[2 * j]);
+      margin = m.jnt_margin[j]; active = pos < margin; diag = m.dof_invweight0[m.jnt_dofadr[j]]; solref = m.jnt_solref + 2 * j; solimp = m.jnt_solimp + 5 * j;
+    } else {
+      rr -= 2 * m.nlim_jnt; int t = m.lim_ten[rr >> 1]; float L = s.tenlen[t];
+      pos = (rr & 1) ? (m.tendon_range[2 * t + 1] - L) : (L - m.tendon_range[2 * t]);
+      margin = m.tendon_margin[t]; active = pos < margin; diag = m.tendon_invweight0[t]; solref = m.tendon_solref_lim + 2 * t; solimp = m.tendon_solimp_lim + 5 * t;
+    }
+    float D = 0, aref = 0;
+    if (active) {
+      float imp = impedance(solimp, pos, margin), K, B;
+      float R = fmaxf(1e-15f, (1 - imp) * diag * rg_rcp(imp));
+      kb(m, solref, solimp, K, B);
+      if (fric) K = 0;
+      float vel = srow_dot<true>(s, r, s.qvel);
+      D = rg_rcp(R); aref = -B * vel - K * imp * (pos - margin);
+    }
+    R.D[k] = D; R.aref[k] = aref; R.floss[k] = fric ? floss : 0.f;   // D == 0 marks an inactive slot
+  }
+}
 // jar = J x - aref (or jv = J x) for every active row; x lives in the compact dof space
 __device__ __forceinline__ void rg_J_mul(RgM m, RgLds& s, RowRegs& R, const float* x, bool to_jv) {
   int ns = nsrow(m), ncon = s.ncon;
 #pragma unroll
   for (int k = 0; k < RG_RSLOTS; k++) {
     int r = LANE + RG_WAVE * k;
-    if (r < ns && s.r_D[r] > 0) { float v = srow_dot<false>(s, r, x); if (to_jv) R.jv[k] = v; else R.jar[k] = v - s.r_aref[r]; }
+    if (r < ns && R.D[k] > 0) { float v = srow_dot<false>(s, r, x); if (to_jv) R.jv[k] = v; else R.jar[k] = v - R.aref[k]; }
   }
   for (int w = LANE; w < ncon * 4; w += RG_WAVE) {
     int c = w >> 2, k = w & 3, nnz = s.c_nnz[c]; float v = 0;
@@ -1377,13 +1391,16 @@ __device__ __forceinline__ void rg_J_mul(RgM m, RgLds& s, RowRegs& R, const floa
     s.c_bdot[w] = v;
   }
   SYNC();
-  for (int w = LANE; w < ncon * 6; w += RG_WAVE) {
+#pragma unroll
+  for (int kk = 0; kk < RG_PSLOTS; kk++) {
+    int w = LANE + RG_WAVE * kk;
+    if (w >= ncon * 6) continue;
     int c = w / 6, q = w - 6 * c, dim = s.c_dim[c];
     if (q >= npyr(dim)) continue;
     float v;
     if (dim == 1) v = s.c_bdot[4 * c];
     else { int k = q >> 1; float mu = s.c_mu[3 * c + k]; v = s.c_bdot[4 * c] + ((q & 1) ? -mu : mu) * s.c_bdot[4 * c + k + 1]; }
-    if (to_jv) s.p_jv[w] = v; else s.p_jar[w] = v - s.p_aref[w];
+    if (to_jv) R.pjv[kk] = v; else R.pjar[kk] = v - s.p_aref[w];
   }
   SYNC();
 }
@@ -1396,9 +1413,9 @@ __device__ __forceinline__ float rg_constraint_update(RgM m, RgLds& s, RowRegs& 
   for (int k = 0; k < RG_RSLOTS; k++) {
     int r = LANE + RG_WAVE * k;
     if (r >= ns) continue;
-    float D = s.r_D[r]; int old = R.quad[k], q = 0; float frc = 0;
+    float D = R.D[k]; int old = R.quad[k], q = 0; float frc = 0;
     if (D > 0) {
-      float x = R.jar[k], f = r < RG_MAXFRIC ? s.r_floss[r] : 0.f;
+      float x = R.jar[k], f = R.floss[k];
       if (f > 0) {
         float R = rg_rcp(D);
         if (x <= -R * f) { frc = f; cost += f * (-0.5f * R * f - x); }
@@ -1408,13 +1425,18 @@ __device__ __forceinline__ float rg_constraint_update(RgM m, RgLds& s, RowRegs& 
     }
     R.force[k] = frc; R.quad[k] = q; chg |= q != old;
   }
-  for (int w = LANE; w < ncon * 6; w += RG_WAVE) {
-    int c = w / 6, k = w - 6 * c, old = s.p_quad[w], q = 0; float frc = 0;
-    if (k < npyr(s.c_dim[c])) {
-      float x = s.p_jar[w], D = s.c_D[c];
-      if (x < 0) { frc = -D * x; q = 1; cost += 0.5f * D * x * x; }
+#pragma unroll
+  for (int kk = 0; kk < RG_PSLOTS; kk++) {
+    int w = LANE + RG_WAVE * kk; float frc = 0;
+    if (w < ncon * 6) {
+      int c = w / 6, k = w - 6 * c, old = s.p_quad[w], q = 0;
+      if (k < npyr(s.c_dim[c])) {
+        float x = R.pjar[kk], D = s.c_D[c];
+        if (x < 0) { frc = -D * x; q = 1; cost += 0.5f * D * x * x; }
+      }
+      s.p_quad[w] = q; chg |= q != old;
     }
-    s.p_force[w] = frc; s.p_quad[w] = q; chg |= q != old;
+    R.pforce[kk] = frc;
   }
   changed = __ballot(chg) != 0;
   SYNC();
@@ -1424,16 +1446,21 @@ __device__ __forceinline__ float rg_constraint_update(RgM m, RgLds& s, RowRegs& 
 __device__ __forceinline__ void rg_JT_force(RgM m, RgLds& s, const RowRegs& R, float* dst) {
   int ns = nsrow(m), ncon = s.ncon;
   PFOR(d, m.nvc) dst[d] = 0;
-  for (int w = LANE; w < ncon * 4; w += RG_WAVE) {
-    int c = w >> 2, k = w & 3, dim = s.c_dim[c]; float v = 0; const float* pf = s.p_force + 6 * c;
-    if (dim == 1) v = k == 0 ? pf[0] : 0.f;
-    else if (k == 0) { for (int q = 0; q < npyr(dim); q++) v += pf[q]; }
-    else if (k < dim) v = s.c_mu[3 * c + k - 1] * (pf[2 * (k - 1)] - pf[2 * (k - 1) + 1]);
-    s.c_bfrc[w] = v;
+  // basis forces (normal, tangent 1, tangent 2, spin) of every contact: P' f, accumulated from the pyramid rows' owner lanes
+  for (int w = LANE; w < ncon * 4; w += RG_WAVE) s.c_bfrc[w] = 0.f;
+  SYNC();
+#pragma unroll
+  for (int kk = 0; kk < RG_PSLOTS; kk++) {
+    float f = R.pforce[kk]; int w = LANE + RG_WAVE * kk;
+    if (f != 0.f && w < ncon * 6) {
+      int c = w / 6, q = w - 6 * c;
+      atomicAdd(s.c_bfrc + 4 * c, f);
+      if (s.c_dim[c] > 1) { int k = q >> 1; float mu = s.c_mu[3 * c + k]; atomicAdd(s.c_bfrc + 4 * c + 1 + k, (q & 1) ? -mu * f : mu * f); }
+    }
   }
   SYNC();
 #pragma unroll
-  for (int k = 0; k < RG_RSLOTS; k++) { int r = LANE + RG_WAVE * k; if (r < ns && s.r_D[r] > 0 && R.force[k] != 0) srow_scatter(s, r, R.force[k], dst); }
+  for (int k = 0; k < RG_RSLOTS; k++) { int r = LANE + RG_WAVE * k; if (r < ns && R.D[k] > 0 && R.force[k] != 0) srow_scatter(s, r, R.force[k], dst); }
   for (int w = LANE; w < ncon * RG_W; w += RG_WAVE) {
     int c = w / RG_W, sl = w - c * RG_W, nnz = s.c_nnz[c];
     if (sl >= nnz) continue;
@@ -1654,21 +1681,21 @@ __device__ __forceinline__ void rg_ltdl_factor_solve(RgM m, RgLds& s, const floa
 struct LsPt { float cost, grad, hess; };
 // The rows a lane owns (static slots LANE, LANE+64; pyramid rows LANE+64k) do not change during a line search:
 // their (D, floss, jar, jv) are read from LDS once and every trial step length is evaluated from registers.
-struct LsRows { float rD[2], rf[2], rjar[2], rjv[2], pD[RG_PSLOTS], pjar[RG_PSLOTS], pjv[RG_PSLOTS]; };
+struct LsRows { float rD[2], rf[2], rjar[2], rjv[2], pD[RG_PSLOTS], pjar[RG_PSLOTS], pjv[RG_PSLOTS]; };   // (copies of register-resident values: no storage of their own after inlining)
 __device__ __forceinline__ void rg_ls_load(RgM m, const RgLds& s, const RowRegs& R, LsRows& L) {
   int ns = nsrow(m), ncon = s.ncon;
 #pragma unroll
   for (int k = 0; k < 2; k++) {
     int r = LANE + RG_WAVE * k; bool on = r < ns;
-    float D = on ? s.r_D[r] : 0.f;
-    L.rD[k] = D > 0 ? D : 0.f; L.rf[k] = (on && r < RG_MAXFRIC) ? s.r_floss[r] : 0.f;
+    float D = on ? R.D[k] : 0.f;
+    L.rD[k] = D > 0 ? D : 0.f; L.rf[k] = on ? R.floss[k] : 0.f;
     L.rjar[k] = on ? R.jar[k] : 0.f; L.rjv[k] = on ? R.jv[k] : 0.f;
   }
 #pragma unroll
   for (int k = 0; k < RG_PSLOTS; k++) {
     int w = LANE + RG_WAVE * k; bool on = w < ncon * 6;
     int cc = on ? w / 6 : 0; on = on && (w - 6 * cc) < npyr(s.c_dim[cc]);
-    L.pD[k] = on ? s.c_D[cc] : 0.f; L.pjar[k] = on ? s.p_jar[w] : 0.f; L.pjv[k] = on ? s.p_jv[w] : 0.f;
+    L.pD[k] = on ? s.c_D[cc] : 0.f; L.pjar[k] = on ? R.pjar[k] : 0.f; L.pjv[k] = on ? R.pjv[k] : 0.f;
   }
 }
 __device__ __forceinline__ LsPt rg_ls_eval(const LsRows& L, float alpha, float q0, float q1, float q2) {
@@ -1704,7 +1731,13 @@ __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, int& nefc_out, int flag
 #define PROFS(k) do { if (flags & 2) { t1 = rg_clock(); if (LANE == 0) s.prof[k] += (float)(t1 - t0); t0 = t1; } } while (0)
   int nv = m.nv, nvc = m.nvc, hs = m.hs, ns = nsrow(m), ncon = s.ncon;
   // count active rows (diagnostic only)
-  { float cnt = 0; PFOR(r, ns) cnt += s.r_D[r] > 0 ? 1.f : 0.f; PFOR(c, ncon) cnt += (float)npyr(s.c_dim[c]); nefc_out = (int)(wave_sum(cnt) + 0.5f); }
+  RgMEnt ME; rg_M_ent_load(m, ME);
+  RowRegs RR;
+  rg_static_rows(m, s, RR);
+  { float cnt = 0;
+#pragma unroll
+    for (int k = 0; k < RG_RSLOTS; k++) cnt += RR.D[k] > 0 ? 1.f : 0.f;
+    PFOR(c, ncon) cnt += (float)npyr(s.c_dim[c]); nefc_out = (int)(wave_sum(cnt) + 0.5f); }
   float scale = 1.0f / (m.meaninertia * (nv > 1 ? nv : 1));
 #ifndef RG_TOL_FLOOR
 #define RG_TOL_FLOOR 1e-7f   /* fp32 cannot resolve cost improvements below this (scaled by meaninertia * nv) */
@@ -1728,10 +1761,10 @@ __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, int& nefc_out, int flag
     }
     tree = __ballot(cross) == 0;
   }
-  RgMEnt ME; rg_M_ent_load(m, ME);
-  RowRegs RR;
 #pragma unroll
   for (int k = 0; k < RG_RSLOTS; k++) { RR.jar[k] = RR.jv[k] = RR.force[k] = 0.f; RR.quad[k] = 0; }
+#pragma unroll
+  for (int k = 0; k < RG_PSLOTS; k++) RR.pjar[k] = RR.pjv[k] = RR.pforce[k] = 0.f;
   // (the tree-pattern descriptors are fetched where they are used — 32 registers that would otherwise stay live, or be
   //  spilled, through the whole dense path as well)
   int cblk_own = LANE < nvc ? s.cblk[LANE] : 0, akk_own = (cblk_own & 0xFFFF) + LANE - ((cblk_own >> 16) & 255);
@@ -1776,7 +1809,7 @@ __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, int& nefc_out, int flag
       // H <- M in the block layout (the factor only uses the lower triangle), then + J' D J on the same addresses
       rg_M_to_blocks(m, s);
 #pragma unroll
-      for (int k = 0; k < RG_RSLOTS; k++) { int r = LANE + RG_WAVE * k; if (r < ns && s.r_D[r] > 0 && RR.quad[k]) srow_hess_tree(s, r, s.r_D[r]); }
+      for (int k = 0; k < RG_RSLOTS; k++) { int r = LANE + RG_WAVE * k; if (r < ns && RR.D[k] > 0 && RR.quad[k]) srow_hess_tree(s, r, RR.D[k]); }
     } else {
     // H = M + J' D J over the quadratic rows (LDS atomics from one wave: in-order, deterministic)
     {  // H <- M: zero the compact nvc x hs matrix, then scatter the tree-sparse entries (both triangles)
@@ -1791,7 +1824,7 @@ __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, int& nefc_out, int flag
     }
     SYNC();
 #pragma unroll
-    for (int k = 0; k < RG_RSLOTS; k++) { int r = LANE + RG_WAVE * k; if (r < ns && s.r_D[r] > 0 && RR.quad[k]) srow_hess(m, s, r, s.r_D[r]); }
+    for (int k = 0; k < RG_RSLOTS; k++) { int r = LANE + RG_WAVE * k; if (r < ns && RR.D[k] > 0 && RR.quad[k]) srow_hess(m, s, r, RR.D[k]); }
     }
     // per contact, C = P' D_act P in the basis (normal, t1, t2, spin) has only its first row/column and its diagonal
     // non-zero: cn, ck[3], cd[3].  One lane per contact computes them (c_bdot/c_bfrc are free between J products).
@@ -1859,7 +1892,8 @@ __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, int& nefc_out, int flag
     PFOR(i, nvc) { s.a[i] += alpha * s.search[i]; s.Ma[i] += alpha * s.Mv[i]; }
 #pragma unroll
     for (int k = 0; k < RG_RSLOTS; k++) RR.jar[k] += alpha * RR.jv[k];
-    for (int w = LANE; w < ncon * 6; w += RG_WAVE) s.p_jar[w] += alpha * s.p_jv[w];
+#pragma unroll
+    for (int k = 0; k < RG_PSLOTS; k++) RR.pjar[k] += alpha * RR.pjv[k];
     SYNC();
     PROFS(10);
   }
@@ -2110,8 +2144,8 @@ __global__ void __launch_bounds__(RG_WAVE) rg_mpr_pair_kernel(const RgModelDev* 
   st_kinematics(c);
   MprGeom A, B;
   v3 p1 = ld3(s.gpos + 3 * g1), p2 = ld3(s.gpos + 3 * g2);
-  A.type = m.geom_type[g1]; A.mat = s.gmat + 9 * g1; A.size = ld3(m.geom_size + 3 * g1); A.margin = 0.5f * margin; A.pos = mk3(0, 0, 0);
-  B.type = m.geom_type[g2]; B.mat = s.gmat + 9 * g2; B.size = ld3(m.geom_size + 3 * g2); B.margin = 0.5f * margin; B.pos = p2 - p1;
+  A.type = m.geom_type[g1]; A.quat = s.gquat + 4 * g1; A.size = ld3(m.geom_size + 3 * g1); A.margin = 0.5f * margin; A.pos = mk3(0, 0, 0);
+  B.type = m.geom_type[g2]; B.quat = s.gquat + 4 * g2; B.size = ld3(m.geom_size + 3 * g2); B.margin = 0.5f * margin; B.pos = p2 - p1;
   A.mesh = B.mesh = -1; A.vertadr = B.vertadr = 0; A.nvert = B.nvert = 0;
   if (A.type == RG_GEOM_MESH) { A.mesh = m.geom_dataid[g1]; A.vertadr = m.mesh_vertadr[A.mesh]; A.nvert = m.mesh_vertnum[A.mesh]; }
   if (B.type == RG_GEOM_MESH) { B.mesh = m.geom_dataid[g2]; B.vertadr = m.mesh_vertadr[B.mesh]; B.nvert = m.mesh_vertnum[B.mesh]; }
