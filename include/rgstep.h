@@ -114,7 +114,7 @@ typedef struct rg_step_args {
   const int* active_dev; const int* hold_dev; const int* nticks_dev; const int* order_dev;
   int nsubsteps, nforward_ticks, flags;
   void* stream;
-  /* Kernel configuration: RG_CFG_ROLLOUT holds 24 contacts / 896 Jacobian words per env in LDS (rollouts: mean 3.5
+  /* Kernel configuration: RG_CFG_ROLLOUT holds 24 contacts / 768 Jacobian words per env in LDS (rollouts: mean 3.5
    * contacts, P(> 21) < 2e-6 per mj_step; 9 envs in flight per CU), RG_CFG_LARGE 64 / 3072 (the reset recipe, where the
    * hand closes around a freshly dropped cube; MuJoCo's nconmax for these models is 100).
    * redo_dev int [B] (RG_CFG_ROLLOUT only, may be NULL): an env that exceeds the rollout capacities is left untouched

@@ -8,7 +8,7 @@
 typedef rg_post_args RgPostArgs;
 #define RG_NS rgs
 #define RG_MAXCON 24
-#define RG_CPOOL 896
+#define RG_CPOOL 768
 #define RG_MAXCAND 128
 #define RG_MAXCAND2 64
 #include "rg_kernel.h"

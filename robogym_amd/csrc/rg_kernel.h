@@ -275,11 +275,10 @@ struct RgLds {
   float tenlen[RG_MAXTEN], tenJ[RG_MAXTEN * 4];
   float actlen[RG_MAXU], actfrc[RG_MAXU];
   float qfrc_smooth[RG_MAXNV], qacc_smooth[RG_MAXNV];
-  unsigned short r_desc[RG_MAXSROW];   // compact dof (6 bits) | tendon id (5 bits, 31 = none) << 6 | negative sign << 11
   unsigned char ten_cdof[RG_MAXTEN * 4], c2d[RG_MAXNVC], b2org[RG_MAXBODY];
   int cblk[RG_MAXNVC];   // per compact dof: inertia-block row word | compact index of its tree start << 16 | tree size << 24
   int ncand, ncand2, ncon;
-  float c_D[RG_MAXCON], c_mu[RG_MAXCON * 3];
+  float c_D[RG_MAXCON], c_mu[RG_MAXCON * 2];   // friction coefficient of the two sliding directions | of the spin direction
   short c_pair[RG_MAXCON], c_off[RG_MAXCON];
   unsigned char c_dim[RG_MAXCON], c_nnz[RG_MAXCON];
   unsigned char c_idx[RG_MAXCON * RG_W];
@@ -1225,49 +1224,42 @@ __device__ __forceinline__ void kb(RgM m, const float* solref, const float* soli
   } else { K = -solref[0] / fmaxf(1e-15f, dmax * dmax); B = -solref[1] / fmaxf(1e-15f, dmax); }
 }
 // static row slot layout: [friction dofs][friction tendons][joint limits x2][tendon limits x2].
-// Each slot has a packed descriptor in LDS (built once per launch): bits 0-7 compact dof (single-dof rows),
-// bits 8-15 tendon id (255: none), bit 16: negative sign.  Tendon rows take their (<=4) compact dofs from
+// Each slot has a packed descriptor (RowRegs.desc, derived by the owner lane at the start of a solve): bits 0-5 compact dof
+// (single-dof rows), bits 6-10 tendon id (31: none), bit 11: negative sign.  Tendon rows take their (<=4) compact dofs from
 // s.ten_cdof and their coefficients from s.tenJ.
 __device__ __forceinline__ int nsrow(RgM m) { return m.nfric_dof + m.nfric_ten + 2 * m.nlim_jnt + 2 * m.nlim_ten; }
 __device__ __forceinline__ void rg_build_row_desc(RgM m, RgLds& s) {
   int ns = nsrow(m);
-  PFOR(r, ns) {
-    int rr = r, dof = 0, ten = 31, neg = 0;
-    if (rr < m.nfric_dof) dof = m.d2c[m.fric_dof[rr]];
-    else if ((rr -= m.nfric_dof) < m.nfric_ten) ten = m.fric_ten[rr];
-    else if ((rr -= m.nfric_ten) < 2 * m.nlim_jnt) { dof = m.d2c[m.jnt_dofadr[m.lim_jnt[rr >> 1]]]; neg = rr & 1; }  // lower: J = +1, upper: J = -1
-    else { rr -= 2 * m.nlim_jnt; ten = m.lim_ten[rr >> 1]; neg = rr & 1; }
-    s.r_desc[r] = (unsigned short)((dof & 63) | (ten << 6) | (neg << 11));
-  }
+  (void)ns;
   PFOR(w, m.ntendon * 4) { int d = m.ten_dofs[w]; s.ten_cdof[w] = (unsigned char)(d >= 0 ? m.d2c[d] : 255); }
   PFOR(i, m.nvc) { s.c2d[i] = (unsigned char)m.c2d[i]; s.cblk[i] = m.c_blk[i]; }
   PFOR(b, m.nbody) s.b2org[b] = (unsigned char)m.body_orgslot[b];
   SYNC();
 }
 // J_r . x for a static row; x is indexed by compact dof unless `full` (then through c2d)
-template <bool FULL> __device__ __forceinline__ float srow_dot(const RgLds& s, int r, const float* x) {
-  int desc = s.r_desc[r], t = (desc >> 6) & 31; float v;
+template <bool FULL> __device__ __forceinline__ float srow_dot(const RgLds& s, int desc, const float* x) {
+  int t = (desc >> 6) & 31; float v;
   if (t == 31) { int d = desc & 63; v = x[FULL ? s.c2d[d] : d]; }
   else { v = 0; for (int e = 0; e < 4; e++) { int d = s.ten_cdof[4 * t + e]; if (d != 255) v += s.tenJ[4 * t + e] * x[FULL ? s.c2d[d] : d]; } }
   return (desc >> 11) & 1 ? -v : v;
 }
 // dst[compact dofs] += coef * J_r  (LDS atomics: several rows may touch one dof)
-__device__ __forceinline__ void srow_scatter(RgLds& s, int r, float coef, float* dst) {
-  int desc = s.r_desc[r], t = (desc >> 6) & 31;
+__device__ __forceinline__ void srow_scatter(RgLds& s, int desc, float coef, float* dst) {
+  int t = (desc >> 6) & 31;
   if ((desc >> 11) & 1) coef = -coef;
   if (t == 31) { atomicAdd(dst + (desc & 63), coef); return; }
   for (int e = 0; e < 4; e++) { int d = s.ten_cdof[4 * t + e]; if (d != 255) atomicAdd(dst + d, coef * s.tenJ[4 * t + e]); }
 }
 // H += D * J_r^T J_r
-__device__ __forceinline__ void srow_hess(RgM m, RgLds& s, int r, float D) {
-  int desc = s.r_desc[r], t = (desc >> 6) & 31;
+__device__ __forceinline__ void srow_hess(RgM m, RgLds& s, int desc, float D) {
+  int t = (desc >> 6) & 31;
   if (t == 31) { int d = desc & 63; atomicAdd(s.H + d * m.hs + d, D); return; }
   for (int a = 0; a < 4; a++) { int da = s.ten_cdof[4 * t + a]; if (da == 255) continue;
     for (int b = 0; b < 4; b++) { int db = s.ten_cdof[4 * t + b]; if (db == 255) continue; atomicAdd(s.H + da * m.hs + db, D * s.tenJ[4 * t + a] * s.tenJ[4 * t + b]); } }
 }
 // the same in the per-tree block layout, lower triangle only (Hessian with the pattern of M)
-__device__ __forceinline__ void srow_hess_tree(RgLds& s, int r, float D) {
-  int desc = s.r_desc[r], t = (desc >> 6) & 31;
+__device__ __forceinline__ void srow_hess_tree(RgLds& s, int desc, float D) {
+  int t = (desc >> 6) & 31;
   if (t == 31) { int d = desc & 63, blk = s.cblk[d]; atomicAdd(s.H + (blk & 0xFFFF) + d - ((blk >> 16) & 255), D); return; }
   for (int a = 0; a < 4; a++) { int da = s.ten_cdof[4 * t + a]; if (da == 255) continue;
     int blk = s.cblk[da];
@@ -1330,13 +1322,13 @@ __device__ __forceinline__ void rg_make_constraint(RgM m, RgLds& s) {
     else { float Rf = fmaxf(1e-15f, (1 - imp) * (tran + mu0 * mu0 * tran) * rg_rcp(imp)); float mu = mu0 * rg_rsqrt(m.impratio); R = 2 * mu * mu * Rf; }
     s.c_D[c] = rg_rcp(R);
     // friction coefficient of tangent direction k (k = 0,1 sliding; 2 spin)
-    s.c_mu[3 * c] = prm[2]; s.c_mu[3 * c + 1] = prm[2]; s.c_mu[3 * c + 2] = prm[3];
+    s.c_mu[2 * c] = prm[2]; s.c_mu[2 * c + 1] = prm[3];
     const float* Bc = s.c_pool + s.c_off[c]; int nnz = s.c_nnz[c], nb = nbasis(dim);
     float vb[4] = {0, 0, 0, 0};
     for (int sl = 0; sl < nnz; sl++) { float q = s.qvel[s.c2d[s.c_idx[c * RG_W + sl]]]; for (int k = 0; k < nb; k++) vb[k] += Bc[k * nnz + sl] * q; }
     float base = -K * imp * (dist - includemargin);
     if (dim == 1) s.p_aref[6 * c] = base - B * vb[0];
-    else for (int k = 0; k < dim - 1; k++) { float mu = s.c_mu[3 * c + k]; s.p_aref[6 * c + 2 * k] = base - B * (vb[0] + mu * vb[k + 1]); s.p_aref[6 * c + 2 * k + 1] = base - B * (vb[0] - mu * vb[k + 1]); }
+    else for (int k = 0; k < dim - 1; k++) { float mu = s.c_mu[2 * c + (k >> 1)]; s.p_aref[6 * c + 2 * k] = base - B * (vb[0] + mu * vb[k + 1]); s.p_aref[6 * c + 2 * k + 1] = base - B * (vb[0] - mu * vb[k + 1]); }
   }
   SYNC();
 }
@@ -1344,7 +1336,7 @@ __device__ __forceinline__ void rg_make_constraint(RgM m, RgLds& s) {
 // Residuals of the static rows (friction loss, limits) live in the registers of the lane that owns the row (row
 // LANE + 64 k): only that lane ever touches them, so they need no LDS (1.2 kB per env that the occupancy wants back).
 #define RG_RSLOTS ((RG_MAXSROW + RG_WAVE - 1) / RG_WAVE)
-struct RowRegs { float D[RG_RSLOTS], aref[RG_RSLOTS], floss[RG_RSLOTS], jar[RG_RSLOTS], jv[RG_RSLOTS], force[RG_RSLOTS]; int quad[RG_RSLOTS]; float pjar[RG_PSLOTS], pjv[RG_PSLOTS], pforce[RG_PSLOTS]; };   // p*: pyramid row LANE + 64 k (= 6 c + q)
+struct RowRegs { int desc[RG_RSLOTS]; float D[RG_RSLOTS], aref[RG_RSLOTS], floss[RG_RSLOTS], jar[RG_RSLOTS], jv[RG_RSLOTS], force[RG_RSLOTS]; int quad[RG_RSLOTS]; float pjar[RG_PSLOTS], pjv[RG_PSLOTS], pforce[RG_PSLOTS]; };   // p*: pyramid row LANE + 64 k (= 6 c + q)
 // friction-loss and limit rows (mj_makeConstraint's first two blocks + mj_makeImpedance for them): impedance, regulariser,
 // reference acceleration — straight into the registers of the lanes that own the rows (RowRegs), at the start of the solve
 __device__ __forceinline__ void rg_static_rows(RgM m, const RgLds& s, RowRegs& R) {
@@ -1352,26 +1344,31 @@ __device__ __forceinline__ void rg_static_rows(RgM m, const RgLds& s, RowRegs& R
 #pragma unroll
   for (int k = 0; k < RG_RSLOTS; k++) {
     int r = LANE + RG_WAVE * k;
-    if (r >= ns) { R.D[k] = 0.f; R.aref[k] = 0.f; R.floss[k] = 0.f; continue; }
+    if (r >= ns) { R.D[k] = 0.f; R.aref[k] = 0.f; R.floss[k] = 0.f; R.desc[k] = 0; continue; }
     int rr = r; float pos = 0, margin = 0, diag, floss = 0; const float *solref, *solimp; bool active = true, fric = false;
-    if (rr < m.nfric_dof) { int d = m.fric_dof[rr]; floss = m.dof_frictionloss[d]; diag = m.dof_invweight0[d]; solref = m.dof_solref + 2 * d; solimp = m.dof_solimp + 5 * d; fric = true; }
-    else if ((rr -= m.nfric_dof) < m.nfric_ten) { int t = m.fric_ten[rr]; floss = m.tendon_frictionloss[t]; diag = m.tendon_invweight0[t]; solref = m.tendon_solref_fri + 2 * t; solimp = m.tendon_solimp_fri + 5 * t; fric = true; }
+    int dsc_dof = 0, dsc_ten = 31, dsc_neg = 0;
+    if (rr < m.nfric_dof) { int d = m.fric_dof[rr]; dsc_dof = m.d2c[d]; floss = m.dof_frictionloss[d]; diag = m.dof_invweight0[d]; solref = m.dof_solref + 2 * d; solimp = m.dof_solimp + 5 * d; fric = true; }
+    else if ((rr -= m.nfric_dof) < m.nfric_ten) { int t = m.fric_ten[rr]; dsc_ten = t; floss = m.tendon_frictionloss[t]; diag = m.tendon_invweight0[t]; solref = m.tendon_solref_fri + 2 * t; solimp = m.tendon_solimp_fri + 5 * t; fric = true; }
     else if ((rr -= m.nfric_ten) < 2 * m.nlim_jnt) {
       int j = m.lim_jnt[rr >> 1]; float q = s.qpos[m.jnt_qposadr[j]];
+      dsc_dof = m.d2c[m.jnt_dofadr[j]]; dsc_neg = rr & 1;   // lower: J = +1, upper: J = -1
       pos = (rr & 1) ? (m.jnt_range[2 * j + 1] - q) : (q - m.jnt_range[2 * j]);
       margin = m.jnt_margin[j]; active = pos < margin; diag = m.dof_invweight0[m.jnt_dofadr[j]]; solref = m.jnt_solref + 2 * j; solimp = m.jnt_solimp + 5 * j;
     } else {
       rr -= 2 * m.nlim_jnt; int t = m.lim_ten[rr >> 1]; float L = s.tenlen[t];
+      dsc_ten = t; dsc_neg = rr & 1;
       pos = (rr & 1) ? (m.tendon_range[2 * t + 1] - L) : (L - m.tendon_range[2 * t]);
       margin = m.tendon_margin[t]; active = pos < margin; diag = m.tendon_invweight0[t]; solref = m.tendon_solref_lim + 2 * t; solimp = m.tendon_solimp_lim + 5 * t;
     }
+    const int desc = (dsc_dof & 63) | (dsc_ten << 6) | (dsc_neg << 11);
+    R.desc[k] = desc;
     float D = 0, aref = 0;
     if (active) {
       float imp = impedance(solimp, pos, margin), K, B;
       float R = fmaxf(1e-15f, (1 - imp) * diag * rg_rcp(imp));
       kb(m, solref, solimp, K, B);
       if (fric) K = 0;
-      float vel = srow_dot<true>(s, r, s.qvel);
+      float vel = srow_dot<true>(s, desc, s.qvel);
       D = rg_rcp(R); aref = -B * vel - K * imp * (pos - margin);
     }
     R.D[k] = D; R.aref[k] = aref; R.floss[k] = fric ? floss : 0.f;   // D == 0 marks an inactive slot
@@ -1383,7 +1380,7 @@ __device__ __forceinline__ void rg_J_mul(RgM m, RgLds& s, RowRegs& R, const floa
 #pragma unroll
   for (int k = 0; k < RG_RSLOTS; k++) {
     int r = LANE + RG_WAVE * k;
-    if (r < ns && R.D[k] > 0) { float v = srow_dot<false>(s, r, x); if (to_jv) R.jv[k] = v; else R.jar[k] = v - R.aref[k]; }
+    if (r < ns && R.D[k] > 0) { float v = srow_dot<false>(s, R.desc[k], x); if (to_jv) R.jv[k] = v; else R.jar[k] = v - R.aref[k]; }
   }
   for (int w = LANE; w < ncon * 4; w += RG_WAVE) {
     int c = w >> 2, k = w & 3, nnz = s.c_nnz[c]; float v = 0;
@@ -1399,7 +1396,7 @@ __device__ __forceinline__ void rg_J_mul(RgM m, RgLds& s, RowRegs& R, const floa
     if (q >= npyr(dim)) continue;
     float v;
     if (dim == 1) v = s.c_bdot[4 * c];
-    else { int k = q >> 1; float mu = s.c_mu[3 * c + k]; v = s.c_bdot[4 * c] + ((q & 1) ? -mu : mu) * s.c_bdot[4 * c + k + 1]; }
+    else { int k = q >> 1; float mu = s.c_mu[2 * c + (k >> 1)]; v = s.c_bdot[4 * c] + ((q & 1) ? -mu : mu) * s.c_bdot[4 * c + k + 1]; }
     if (to_jv) R.pjv[kk] = v; else R.pjar[kk] = v - s.p_aref[w];
   }
   SYNC();
@@ -1455,12 +1452,12 @@ __device__ __forceinline__ void rg_JT_force(RgM m, RgLds& s, const RowRegs& R, f
     if (f != 0.f && w < ncon * 6) {
       int c = w / 6, q = w - 6 * c;
       atomicAdd(s.c_bfrc + 4 * c, f);
-      if (s.c_dim[c] > 1) { int k = q >> 1; float mu = s.c_mu[3 * c + k]; atomicAdd(s.c_bfrc + 4 * c + 1 + k, (q & 1) ? -mu * f : mu * f); }
+      if (s.c_dim[c] > 1) { int k = q >> 1; float mu = s.c_mu[2 * c + (k >> 1)]; atomicAdd(s.c_bfrc + 4 * c + 1 + k, (q & 1) ? -mu * f : mu * f); }
     }
   }
   SYNC();
 #pragma unroll
-  for (int k = 0; k < RG_RSLOTS; k++) { int r = LANE + RG_WAVE * k; if (r < ns && R.D[k] > 0 && R.force[k] != 0) srow_scatter(s, r, R.force[k], dst); }
+  for (int k = 0; k < RG_RSLOTS; k++) { int r = LANE + RG_WAVE * k; if (r < ns && R.D[k] > 0 && R.force[k] != 0) srow_scatter(s, R.desc[k], R.force[k], dst); }
   for (int w = LANE; w < ncon * RG_W; w += RG_WAVE) {
     int c = w / RG_W, sl = w - c * RG_W, nnz = s.c_nnz[c];
     if (sl >= nnz) continue;
@@ -1809,7 +1806,7 @@ __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, int& nefc_out, int flag
       // H <- M in the block layout (the factor only uses the lower triangle), then + J' D J on the same addresses
       rg_M_to_blocks(m, s);
 #pragma unroll
-      for (int k = 0; k < RG_RSLOTS; k++) { int r = LANE + RG_WAVE * k; if (r < ns && RR.D[k] > 0 && RR.quad[k]) srow_hess_tree(s, r, RR.D[k]); }
+      for (int k = 0; k < RG_RSLOTS; k++) { int r = LANE + RG_WAVE * k; if (r < ns && RR.D[k] > 0 && RR.quad[k]) srow_hess_tree(s, RR.desc[k], RR.D[k]); }
     } else {
     // H = M + J' D J over the quadratic rows (LDS atomics from one wave: in-order, deterministic)
     {  // H <- M: zero the compact nvc x hs matrix, then scatter the tree-sparse entries (both triangles)
@@ -1824,7 +1821,7 @@ __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, int& nefc_out, int flag
     }
     SYNC();
 #pragma unroll
-    for (int k = 0; k < RG_RSLOTS; k++) { int r = LANE + RG_WAVE * k; if (r < ns && RR.D[k] > 0 && RR.quad[k]) srow_hess(m, s, r, RR.D[k]); }
+    for (int k = 0; k < RG_RSLOTS; k++) { int r = LANE + RG_WAVE * k; if (r < ns && RR.D[k] > 0 && RR.quad[k]) srow_hess(m, s, RR.desc[k], RR.D[k]); }
     }
     // per contact, C = P' D_act P in the basis (normal, t1, t2, spin) has only its first row/column and its diagonal
     // non-zero: cn, ck[3], cd[3].  One lane per contact computes them (c_bdot/c_bfrc are free between J products).
@@ -1833,7 +1830,7 @@ __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, int& nefc_out, int flag
       int dim = s.c_dim[c]; float D = s.c_D[c], cn = 0, ck[3] = {0, 0, 0}, cd[3] = {0, 0, 0};
       if (dim == 1) cn = s.p_quad[6 * c] ? D : 0.f;
       else for (int k = 0; k < dim - 1; k++) {
-        float mu = s.c_mu[3 * c + k]; int qp = s.p_quad[6 * c + 2 * k], qm = s.p_quad[6 * c + 2 * k + 1];
+        float mu = s.c_mu[2 * c + (k >> 1)]; int qp = s.p_quad[6 * c + 2 * k], qm = s.p_quad[6 * c + 2 * k + 1];
         cn += D * (qp + qm); ck[k] = D * mu * (qp - qm); cd[k] = D * mu * mu * (qp + qm);
       }
       float* o = cf + 8 * c; o[0] = cn; o[1] = ck[0]; o[2] = ck[1]; o[3] = ck[2]; o[4] = cd[0]; o[5] = cd[1]; o[6] = cd[2];
