@@ -1336,7 +1336,13 @@ __device__ __forceinline__ void rg_make_constraint(RgM m, RgLds& s) {
 // Residuals of the static rows (friction loss, limits) live in the registers of the lane that owns the row (row
 // LANE + 64 k): only that lane ever touches them, so they need no LDS (1.2 kB per env that the occupancy wants back).
 #define RG_RSLOTS ((RG_MAXSROW + RG_WAVE - 1) / RG_WAVE)
-struct RowRegs { int desc[RG_RSLOTS]; float D[RG_RSLOTS], aref[RG_RSLOTS], floss[RG_RSLOTS], jar[RG_RSLOTS], jv[RG_RSLOTS], force[RG_RSLOTS]; int quad[RG_RSLOTS]; float pjar[RG_PSLOTS], pjv[RG_PSLOTS], pforce[RG_PSLOTS]; };   // p*: pyramid row LANE + 64 k (= 6 c + q)
+struct RowRegs { int desc[RG_RSLOTS]; float D[RG_RSLOTS], aref[RG_RSLOTS], floss[RG_RSLOTS], jar[RG_RSLOTS], jv[RG_RSLOTS]; int quad[RG_RSLOTS]; float pjar[RG_PSLOTS], pjv[RG_PSLOTS]; };   // (row forces are functions of jar: recomputed where needed, not kept)
+// force of a friction-loss / limit row from its residual (mj_constraintUpdate's three cases)
+__device__ __forceinline__ float srow_force(float D, float f, float x) {
+  if (!(D > 0)) return 0.f;
+  if (f > 0) { float R = rg_rcp(D); return x <= -R * f ? f : (x >= R * f ? -f : -D * x); }
+  return x < 0 ? -D * x : 0.f;
+}   // p*: pyramid row LANE + 64 k (= 6 c + q)
 // friction-loss and limit rows (mj_makeConstraint's first two blocks + mj_makeImpedance for them): impedance, regulariser,
 // reference acceleration — straight into the registers of the lanes that own the rows (RowRegs), at the start of the solve
 __device__ __forceinline__ void rg_static_rows(RgM m, const RgLds& s, RowRegs& R) {
@@ -1410,30 +1416,29 @@ __device__ __forceinline__ float rg_constraint_update(RgM m, RgLds& s, RowRegs& 
   for (int k = 0; k < RG_RSLOTS; k++) {
     int r = LANE + RG_WAVE * k;
     if (r >= ns) continue;
-    float D = R.D[k]; int old = R.quad[k], q = 0; float frc = 0;
+    float D = R.D[k]; int old = R.quad[k], q = 0;
     if (D > 0) {
       float x = R.jar[k], f = R.floss[k];
       if (f > 0) {
         float R = rg_rcp(D);
-        if (x <= -R * f) { frc = f; cost += f * (-0.5f * R * f - x); }
-        else if (x >= R * f) { frc = -f; cost += f * (-0.5f * R * f + x); }
-        else { frc = -D * x; q = 1; cost += 0.5f * D * x * x; }
-      } else if (x < 0) { frc = -D * x; q = 1; cost += 0.5f * D * x * x; }
+        if (x <= -R * f) cost += f * (-0.5f * R * f - x);
+        else if (x >= R * f) cost += f * (-0.5f * R * f + x);
+        else { q = 1; cost += 0.5f * D * x * x; }
+      } else if (x < 0) { q = 1; cost += 0.5f * D * x * x; }
     }
-    R.force[k] = frc; R.quad[k] = q; chg |= q != old;
+    R.quad[k] = q; chg |= q != old;
   }
 #pragma unroll
   for (int kk = 0; kk < RG_PSLOTS; kk++) {
-    int w = LANE + RG_WAVE * kk; float frc = 0;
+    int w = LANE + RG_WAVE * kk;
     if (w < ncon * 6) {
       int c = w / 6, k = w - 6 * c, old = s.p_quad[w], q = 0;
       if (k < npyr(s.c_dim[c])) {
         float x = R.pjar[kk], D = s.c_D[c];
-        if (x < 0) { frc = -D * x; q = 1; cost += 0.5f * D * x * x; }
+        if (x < 0) { q = 1; cost += 0.5f * D * x * x; }
       }
       s.p_quad[w] = q; chg |= q != old;
     }
-    R.pforce[kk] = frc;
   }
   changed = __ballot(chg) != 0;
   SYNC();
@@ -1448,16 +1453,16 @@ __device__ __forceinline__ void rg_JT_force(RgM m, RgLds& s, const RowRegs& R, f
   SYNC();
 #pragma unroll
   for (int kk = 0; kk < RG_PSLOTS; kk++) {
-    float f = R.pforce[kk]; int w = LANE + RG_WAVE * kk;
-    if (f != 0.f && w < ncon * 6) {
-      int c = w / 6, q = w - 6 * c;
+    int w = LANE + RG_WAVE * kk;
+    if (w < ncon * 6 && s.p_quad[w]) {   // (a pyramid row carries force exactly when it is quadratic: x < 0)
+      int c = w / 6, q = w - 6 * c; float f = -s.c_D[c] * R.pjar[kk];
       atomicAdd(s.c_bfrc + 4 * c, f);
       if (s.c_dim[c] > 1) { int k = q >> 1; float mu = s.c_mu[2 * c + (k >> 1)]; atomicAdd(s.c_bfrc + 4 * c + 1 + k, (q & 1) ? -mu * f : mu * f); }
     }
   }
   SYNC();
 #pragma unroll
-  for (int k = 0; k < RG_RSLOTS; k++) { int r = LANE + RG_WAVE * k; if (r < ns && R.D[k] > 0 && R.force[k] != 0) srow_scatter(s, R.desc[k], R.force[k], dst); }
+  for (int k = 0; k < RG_RSLOTS; k++) { int r = LANE + RG_WAVE * k; float f = r < ns ? srow_force(R.D[k], R.floss[k], R.jar[k]) : 0.f; if (f != 0) srow_scatter(s, R.desc[k], f, dst); }
   for (int w = LANE; w < ncon * RG_W; w += RG_WAVE) {
     int c = w / RG_W, sl = w - c * RG_W, nnz = s.c_nnz[c];
     if (sl >= nnz) continue;
@@ -1760,9 +1765,9 @@ __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, int& nefc_out, int flag
     tree = __ballot(cross) == 0;
   }
 #pragma unroll
-  for (int k = 0; k < RG_RSLOTS; k++) { RR.jar[k] = RR.jv[k] = RR.force[k] = 0.f; RR.quad[k] = 0; }
+  for (int k = 0; k < RG_RSLOTS; k++) { RR.jar[k] = RR.jv[k] = 0.f; RR.quad[k] = 0; }
 #pragma unroll
-  for (int k = 0; k < RG_PSLOTS; k++) RR.pjar[k] = RR.pjv[k] = RR.pforce[k] = 0.f;
+  for (int k = 0; k < RG_PSLOTS; k++) RR.pjar[k] = RR.pjv[k] = 0.f;
   // (the tree-pattern descriptors are fetched where they are used — 32 registers that would otherwise stay live, or be
   //  spilled, through the whole dense path as well)
   int cblk_own = LANE < nvc ? s.cblk[LANE] : 0, akk_own = (cblk_own & 0xFFFF) + LANE - ((cblk_own >> 16) & 255);
@@ -1895,10 +1900,15 @@ __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, int& nefc_out, int flag
     SYNC();
     PROFS(10);
   }
-  // forces at the solution; expand to the full dof space
+  // Every exit of the loop leaves s.jtf = J' f(a) for the final a (the gradient evaluation at the top of the pass that
+  // broke out, or the pass whose step length came out zero), so the forces at the solution are already there; only the
+  // expansion to the full dof space remains.  (RG_SOLVE_RECOMPUTE: evaluate them once more from J a - aref computed from
+  // scratch instead of the incrementally advanced residuals: identical to ~1e-7 relative, and 3.5 % of the step.)
+#ifdef RG_SOLVE_RECOMPUTE
   rg_J_mul(m, s, RR, s.a, false);
   { bool chg; rg_constraint_update(m, s, RR, chg); }
   rg_JT_force(m, s, RR, s.jtf);
+#endif
   PFOR(d, nv) { int i = m.d2c[d]; s.qacc[d] = i >= 0 ? s.a[i] : s.qacc_smooth[d]; s.qfrc_con[d] = i >= 0 ? s.jtf[i] : 0.f; }
   SYNC();
   return iters;
