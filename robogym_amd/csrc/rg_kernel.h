@@ -1775,10 +1775,10 @@ __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, int& nefc_out, int flag
   float cost_pick[2];
   for (int pass = 0; pass < 2; pass++) {
     const float* a = pass == 0 ? s.as : s.a;
-    rg_M_mul(m, s, ME, a, s.Ma);
+    float g = 0;
+    if (pass == 1) rg_M_mul(m, s, ME, a, s.Ma);    // (at a = qacc_smooth the Gauss term is exactly zero: no M a needed to price it)
     rg_J_mul(m, s, RR, a, false);
-    float g = 0; PFOR(i, nvc) g += 0.5f * (s.Ma[i] - s.fs[i]) * (a[i] - s.as[i]);
-    g = wave_sum(g);
+    if (pass == 1) { PFOR(i, nvc) g += 0.5f * (s.Ma[i] - s.fs[i]) * (a[i] - s.as[i]); g = wave_sum(g); }
     bool chg; cost_pick[pass] = g + rg_constraint_update(m, s, RR, chg);
   }
   if (!(cost_pick[1] < cost_pick[0])) {

@@ -14,6 +14,7 @@ env.mujoco_simulation.set_field(6, torch.zeros((B, 1), dtype=torch.int32, device
 gen = torch.Generator(device=dev); gen.manual_seed(9)
 started = torch.zeros((), device=dev); onpalm = torch.zeros((), device=dev); ended = torch.zeros((), device=dev); bad = torch.zeros((), device=dev)
 seen = torch.zeros(B, dtype=torch.int32, device=dev)
+redo = torch.zeros((), dtype=torch.int64, device=dev)
 t0 = time.time()
 for t in range(T):
     obs, reward, done, info = env.step(torch.rand((B, 20), generator=gen, device=dev) * 2 - 1)
@@ -22,8 +23,11 @@ for t in range(T):
     onpalm += (s & (0.2 + obs["cube_pos"][:, 2] > 0.04)).sum()
     bad += (~torch.isfinite(obs["qpos"]).all(1)).sum()
     seen |= env.sim_status()
+    if env.mujoco_simulation._redo is not None:
+        redo += env.mujoco_simulation._redo.sum()
 torch.cuda.synchronize(); el = time.time() - t0
 st = seen
 print("%d envs x %d steps in %.1f s = %.0f env-steps/s (recipe steps included)" % (B, T, el, B * T / el))
 print("episodes ended %d, started %d, cube on palm at start %.4f" % (int(ended), int(started), float(onpalm / started.clamp(min=1))))
-print("status bits ever seen (envs):", {int(b): int((st & b != 0).sum()) for b in (1, 2, 4, 8, 16)}, " non-finite qpos rows summed over steps:", int(bad))
+print("status bits ever seen (envs):", {int(b): int((st & b != 0).sum()) for b in (1, 2, 4, 8, 16, 32)}, " non-finite qpos rows summed over steps:", int(bad))
+print("env.steps handed from the rollout to the large kernel configuration (contact / candidate capacity exceeded): %d of %d" % (int(redo), B * T))
