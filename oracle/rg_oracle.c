@@ -79,6 +79,7 @@ typedef struct {
 typedef struct {
   /* state */
   double *qpos, *qvel, *ctrl, *pid, *qacc_warmstart, time;
+  double* xfrc_applied; /* [nbody][6] force, torque in world coordinates, applied at the body's com (mjData.xfrc_applied) */
   /* position stage */
   double *xpos, *xquat, *xmat, *xipos, *ximat, *xanchor, *xaxis, *geom_xpos, *geom_xmat, *site_xpos, *site_xmat;
   double *subtree_com, *cinert, *cdof, *crb;
@@ -232,7 +233,7 @@ ro_data* ro_data_new(const ro_model* m) {
   ro_data* d = (ro_data*)calloc(1, sizeof(ro_data));
   int nv = m->nv, nb = m->nbody;
   d->qpos = dalloc(m->nq); d->qvel = dalloc(nv); d->ctrl = dalloc(m->nu); d->pid = dalloc(3 * m->nu);
-  d->qacc_warmstart = dalloc(nv);
+  d->qacc_warmstart = dalloc(nv); d->xfrc_applied = dalloc(6 * m->nbody);
   d->xpos = dalloc(3 * nb); d->xquat = dalloc(4 * nb); d->xmat = dalloc(9 * nb); d->xipos = dalloc(3 * nb);
   d->ximat = dalloc(9 * nb); d->xanchor = dalloc(3 * m->njnt); d->xaxis = dalloc(3 * m->njnt);
   d->geom_xpos = dalloc(3 * m->ngeom); d->geom_xmat = dalloc(9 * m->ngeom);
@@ -255,7 +256,7 @@ ro_data* ro_data_new(const ro_model* m) {
 }
 void ro_data_free(ro_data* d) {
   if (!d) return;
-  double** p[] = {&d->qpos, &d->qvel, &d->ctrl, &d->pid, &d->qacc_warmstart, &d->xpos, &d->xquat, &d->xmat, &d->xipos,
+  double** p[] = {&d->qpos, &d->qvel, &d->ctrl, &d->pid, &d->qacc_warmstart, &d->xfrc_applied, &d->xpos, &d->xquat, &d->xmat, &d->xipos,
                   &d->ximat, &d->xanchor, &d->xaxis, &d->geom_xpos, &d->geom_xmat, &d->site_xpos, &d->site_xmat,
                   &d->subtree_com, &d->cinert, &d->cdof, &d->crb, &d->ten_length, &d->ten_J, &d->actuator_length,
                   &d->actuator_moment, &d->qM, &d->qL, &d->efc_J, &d->efc_pos, &d->efc_margin, &d->efc_frictionloss,
@@ -271,6 +272,7 @@ void ro_reset(const ro_model* m, ro_data* d) {
   memcpy(d->qpos, m->qpos0, m->nq * sizeof(double));
   memset(d->qvel, 0, m->nv * sizeof(double)); memset(d->ctrl, 0, m->nu * sizeof(double));
   memset(d->pid, 0, 3 * m->nu * sizeof(double)); memset(d->qacc_warmstart, 0, m->nv * sizeof(double));
+  memset(d->xfrc_applied, 0, 6 * m->nbody * sizeof(double));
   d->time = 0; d->warn_bad = d->warn_contact_full = d->warn_efc_full = 0;
 }
 
@@ -1250,6 +1252,16 @@ static void ro_fwd_actuation(const ro_model* m, ro_data* d) {
 static void ro_fwd_acceleration(const ro_model* m, ro_data* d) {
   int nv = m->nv;
   for (int i = 0; i < nv; i++) d->qfrc_smooth[i] = d->qfrc_passive[i] - d->qfrc_bias[i] + d->qfrc_actuator[i];
+  /* engine_forward.c: mj_xfrcAccumulate — qfrc += J(com of body)' force + J_rot' torque for every body with xfrc_applied */
+  for (int b = 1; b < m->nbody; b++) {
+    const double* w = d->xfrc_applied + 6 * b;
+    if (w[0] == 0 && w[1] == 0 && w[2] == 0 && w[3] == 0 && w[4] == 0 && w[5] == 0) continue;
+    double* jp = dalloc(3 * nv); double* jr = dalloc(3 * nv);
+    ro_jac(m, d, jp, jr, d->xipos + 3 * b, b);
+    for (int i = 0; i < nv; i++)
+      for (int k = 0; k < 3; k++) d->qfrc_smooth[i] += jp[k * nv + i] * w[k] + jr[k * nv + i] * w[3 + k];
+    free(jp); free(jr);
+  }
   memcpy(d->qacc_smooth, d->qfrc_smooth, nv * sizeof(double));
   chol_solve(d->qL, d->qacc_smooth, nv);
 }
@@ -1442,7 +1454,7 @@ void ro_sim_step(const ro_model* m, ro_data* d, int nsubsteps) {
 #define FIELD(name, cnt) if (strcmp(field, #name) == 0) { *n = (cnt); return d->name; }
 double* ro_field(const ro_model* m, ro_data* d, const char* field, int* n) {
   int nv = m->nv, nb = m->nbody;
-  FIELD(qpos, m->nq) FIELD(qvel, nv) FIELD(ctrl, m->nu) FIELD(pid, 3 * m->nu) FIELD(qacc_warmstart, nv)
+  FIELD(qpos, m->nq) FIELD(qvel, nv) FIELD(ctrl, m->nu) FIELD(pid, 3 * m->nu) FIELD(qacc_warmstart, nv) FIELD(xfrc_applied, 6 * nb)
   FIELD(xpos, 3 * nb) FIELD(xquat, 4 * nb) FIELD(xmat, 9 * nb) FIELD(xipos, 3 * nb) FIELD(ximat, 9 * nb)
   FIELD(xanchor, 3 * m->njnt) FIELD(xaxis, 3 * m->njnt) FIELD(geom_xpos, 3 * m->ngeom) FIELD(geom_xmat, 9 * m->ngeom)
   FIELD(site_xpos, 3 * m->nsite) FIELD(site_xmat, 9 * m->nsite) FIELD(subtree_com, 3 * nb) FIELD(cinert, 10 * nb)

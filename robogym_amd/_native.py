@@ -10,7 +10,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RGSTEP_LIB") or os.path.join(_HERE, "csrc", "librgstep.so")   # (RGSTEP_LIB: A/B builds of the same ABI, tools/ only)
 
-RG_F_QPOS, RG_F_QVEL, RG_F_CTRL, RG_F_PID, RG_F_WARMSTART, RG_F_TIME, RG_F_STATUS, RG_F_STATS, RG_F_DEBUG, RG_F_COST, RG_F_PAIRLB = range(11)
+RG_F_QPOS, RG_F_QVEL, RG_F_CTRL, RG_F_PID, RG_F_WARMSTART, RG_F_TIME, RG_F_STATUS, RG_F_STATS, RG_F_DEBUG, RG_F_COST, RG_F_PAIRLB, RG_F_ENVPRM = range(12)
 RG_STATUS_BAD_STATE, RG_STATUS_CON_FULL, RG_STATUS_CAND_FULL, RG_STATUS_ROW_FULL, RG_STATUS_BAD_FACTOR, RG_STATUS_BAD_ACTION = 1, 2, 4, 8, 16, 32
 
 
@@ -50,7 +50,7 @@ EXPORTS = [
     "rg_model_create", "rg_model_free", "rg_model_dims", "rg_batch_create", "rg_batch_free", "rg_batch_set_env",
     "rg_batch_copy", "rg_batch_reset", "rg_batch_step", "rg_obs_dim", "rg_debug_size", "rg_lds_bytes", "rg_sync",
     "rg_last_error", "rg_batch_mpr_pair", "rg_batch_copy_rows", "rg_batch_step_ex", "rg_batch_field_ptr", "rg_model_create_on", "rg_model_npair",
-    "rg_lds_bytes_cfg", "rg_env_post_step", "rg_post_args_size",
+    "rg_lds_bytes_cfg", "rg_env_post_step", "rg_post_args_size", "rg_batch_enable_env_params", "rg_prm_layout",
 ]
 
 
@@ -91,6 +91,8 @@ def bind(path):
     L.rg_lds_bytes.restype = ci
     L.rg_lds_bytes_cfg.restype = ci
     L.rg_lds_bytes_cfg.argtypes = [ci]
+    L.rg_batch_enable_env_params.argtypes = [vp]
+    L.rg_prm_layout.argtypes = [ctypes.POINTER(ci), ci]
     L.rg_env_post_step.argtypes = [vp, ctypes.POINTER(PostArgs), vp]
     L.rg_post_args_size.restype = ci
     if L.rg_post_args_size() != ctypes.sizeof(PostArgs):
@@ -113,3 +115,15 @@ def lib():
 def check(L, rc, what):
     if rc != 0:
         raise NativeError("%s failed: %s" % (what, L.rg_last_error().decode()))
+
+
+PRM_NAMES = ["row", "gravity", "timestep", "dof_damping", "dof_armature", "dof_frictionloss", "dof_invweight0", "body_mass", "body_inertia", "body_invweight0",
+             "jnt_range", "tendon_range", "tendon_invweight0", "actuator_gainprm", "actuator_ctrlrange", "actuator_forcerange", "geom_friction", "xfrc_applied"]
+
+
+def prm_layout(L):
+    """rg_prm_layout as a dict: 'row' -> floats per env, then field -> offset."""
+    buf = (ctypes.c_int * 32)()
+    n = L.rg_prm_layout(buf, 32)
+    assert n == len(PRM_NAMES), "rg_prm_layout and robogym_amd/_native.py disagree"
+    return {k: int(buf[i]) for i, k in enumerate(PRM_NAMES)}

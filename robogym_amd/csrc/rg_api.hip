@@ -75,7 +75,7 @@ struct rg_model {
   const RgModelDev* dev_copy = nullptr;   // the same descriptor in device memory (kernels read it through the constant address space)
   RgAux aux;
   std::vector<void*> allocs;
-  std::vector<float> qpos0;
+  std::vector<float> qpos0, prm_default;
   int ok = 0;
 };
 struct rg_batch {
@@ -305,6 +305,23 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
   GI("k_subtree_adr"); if (!upload<int>(m, iv, &m->aux.subtree_adr)) return bail("hipMalloc failed", m);
   GI("k_subtree"); if (!upload<int>(m, iv, &m->aux.subtree)) return bail("hipMalloc failed", m);
   { GI("k_dof_velmask"); std::vector<uint32_t> u(iv.size()); for (size_t i = 0; i < iv.size(); i++) u[i] = (uint32_t)iv[i]; if (!upload<uint32_t>(m, u, &m->aux.dof_velmask)) return bail("hipMalloc failed", m); }
+  {  // the model's own values in the per-env parameter layout (RG_PRM_*): the row every env reads unless the batch overrides it
+    std::vector<float> prm(RG_NPRM, 0.f), v;
+    auto put = [&](const char* name, int off, size_t cap) -> bool {
+      if (!get_f(B, name, v, e)) return false;
+      if (v.size() > cap) { e = std::string(name) + " exceeds the per-env parameter layout"; return false; }
+      for (size_t i = 0; i < v.size(); i++) prm[off + i] = v[i];
+      return true;
+    };
+    if (!put("opt_gravity", RG_PRM_GRAVITY, 3) || !put("opt_timestep", RG_PRM_TIMESTEP, 1) || !put("dof_damping", RG_PRM_DOF_DAMPING, RG_MAXNV) ||
+        !put("dof_armature", RG_PRM_DOF_ARMATURE, RG_MAXNV) || !put("dof_frictionloss", RG_PRM_DOF_FRICTIONLOSS, RG_MAXNV) || !put("dof_invweight0", RG_PRM_DOF_INVWEIGHT0, RG_MAXNV) ||
+        !put("body_mass", RG_PRM_BODY_MASS, RG_MAXBODY) || !put("body_inertia", RG_PRM_BODY_INERTIA, 3 * RG_MAXBODY) || !put("body_invweight0", RG_PRM_BODY_INVWEIGHT0, 2 * RG_MAXBODY) ||
+        !put("jnt_range", RG_PRM_JNT_RANGE, 2 * RG_MAXJNT) || !put("tendon_range", RG_PRM_TENDON_RANGE, 2 * RG_MAXTEN) || !put("tendon_invweight0", RG_PRM_TENDON_INVWEIGHT0, RG_MAXTEN) ||
+        !put("actuator_gainprm", RG_PRM_ACT_GAINPRM, 10 * RG_MAXU) || !put("actuator_ctrlrange", RG_PRM_ACT_CTRLRANGE, 2 * RG_MAXU) ||
+        !put("actuator_forcerange", RG_PRM_ACT_FORCERANGE, 2 * RG_MAXU) || !put("geom_friction", RG_PRM_GEOM_FRICTION, 3 * RG_MAXGEOM)) return bail(e, m);
+    m->prm_default = prm;
+    if (!upload<float>(m, prm, &d.prm_default)) return bail("hipMalloc failed", m);
+  }
   { std::vector<RgModelDev> one(1, d); if (!upload<RgModelDev>(m, one, &m->dev_copy)) return bail("hipMalloc failed", m); }
   m->ok = 1;
   return m;
@@ -376,6 +393,27 @@ int rg_batch_reset(rg_batch* b) {
   return 0;
 }
 
+int rg_batch_enable_env_params(rg_batch* b) {
+  if (!b) return fail("null batch");
+  if (b->dev.envprm) return 0;
+  DeviceGuard g(b->device);
+  const size_t n = (size_t)b->dev.B * RG_NPRM;
+  float* p = (float*)balloc(b, n * 4);
+  if (!p) return fail("hipMalloc failed");
+  std::vector<float> rows(n);
+  for (int e = 0; e < b->dev.B; e++) memcpy(rows.data() + (size_t)e * RG_NPRM, b->model->prm_default.data(), RG_NPRM * 4);
+  HIPCHK(hipMemcpy(p, rows.data(), n * 4, hipMemcpyHostToDevice));
+  b->dev.envprm = p;
+  return 0;
+}
+int rg_prm_layout(int* out, int n) {
+  const int lay[] = {RG_NPRM, RG_PRM_GRAVITY, RG_PRM_TIMESTEP, RG_PRM_DOF_DAMPING, RG_PRM_DOF_ARMATURE, RG_PRM_DOF_FRICTIONLOSS, RG_PRM_DOF_INVWEIGHT0, RG_PRM_BODY_MASS,
+                     RG_PRM_BODY_INERTIA, RG_PRM_BODY_INVWEIGHT0, RG_PRM_JNT_RANGE, RG_PRM_TENDON_RANGE, RG_PRM_TENDON_INVWEIGHT0, RG_PRM_ACT_GAINPRM, RG_PRM_ACT_CTRLRANGE,
+                     RG_PRM_ACT_FORCERANGE, RG_PRM_GEOM_FRICTION, RG_PRM_XFRC};
+  const int k = (int)(sizeof lay / sizeof lay[0]);
+  for (int i = 0; i < k && i < n; i++) out[i] = lay[i];
+  return k;
+}
 int rg_batch_set_env(rg_batch* b, const int* ints, int nints, const float* p2c, float thr) {
   if (!b || !ints || nints < 20) return fail("rg_batch_set_env: need 20 ints");
   DeviceGuard g(b->device);
@@ -414,6 +452,7 @@ static void* field_ptr(rg_batch* b, int field, size_t* n) {
     case RG_F_DEBUG: *n = RG_DBG_SIZE; return s.dbg;
     case RG_F_COST: *n = 1; return s.cost;
     case RG_F_PAIRLB: *n = (size_t)(d.npair > 0 ? d.npair : 1); return s.pairlb;
+    case RG_F_ENVPRM: *n = RG_NPRM; return (void*)s.envprm;   // (null until rg_batch_enable_env_params)
     default: return nullptr;
   }
 }

@@ -150,6 +150,7 @@ __global__ void __launch_bounds__(RG_WAVE) rg_post_step_kernel(RgBatchDev bt, Rg
     }
     for (int u = lane; u < nu; u += RG_WAVE) {
       float lo = a.ctrl_lo[u], hi = a.ctrl_hi[u], act = 2.f * U(9 + u) - 1.f;
+      if (bt.envprm) { lo = bt.envprm[(size_t)e * RG_NPRM + RG_PRM_ACT_CTRLRANGE + 2 * u]; hi = bt.envprm[(size_t)e * RG_NPRM + RG_PRM_ACT_CTRLRANGE + 2 * u + 1]; }   // the env's own actuator_ctrlrange
       if (a.draws) act = a.draws[(size_t)e * RG_POST_NDRAW + 9 + u];   // supplied draws are the actions themselves (in [-1, 1])
       bt.ctrl[(size_t)e * nu + u] = fminf(fmaxf(0.5f * (hi + lo) + act * 0.5f * (hi - lo), lo), hi);
     }
@@ -159,8 +160,10 @@ __global__ void __launch_bounds__(RG_WAVE) rg_post_step_kernel(RgBatchDev bt, Rg
     for (int i = lane; i < nq; i += RG_WAVE) qrow[i] = a.qpos0[i];
     for (int i = lane; i < nv; i += RG_WAVE) { bt.qvel[(size_t)e * nv + i] = 0.f; bt.qacc_warmstart[(size_t)e * nv + i] = 0.f; }
     for (int i = lane; i < 3 * nu; i += RG_WAVE) bt.pid[(size_t)e * 3 * nu + i] = 0.f;
-    for (int u = lane; u < nu; u += RG_WAVE) bt.ctrl[(size_t)e * nu + u] = a.zero_ctrl[u];
+    for (int u = lane; u < nu; u += RG_WAVE)
+      bt.ctrl[(size_t)e * nu + u] = bt.envprm ? 0.5f * (bt.envprm[(size_t)e * RG_NPRM + RG_PRM_ACT_CTRLRANGE + 2 * u] + bt.envprm[(size_t)e * RG_NPRM + RG_PRM_ACT_CTRLRANGE + 2 * u + 1]) : a.zero_ctrl[u];
     if (lane == 0) { bt.time[e] = 0.f; bt.status[e] = 0; a.preticks[e] = 0; }
+    if (bt.envprm) for (int i = lane; i < 6 * RG_MAXBODY; i += RG_WAVE) ((float*)bt.envprm)[(size_t)e * RG_NPRM + RG_PRM_XFRC + i] = 0.f;   // mj_resetData zeroes data.xfrc_applied
     touched = true;
   }
   if (touched && bt.pairlb) for (int i = lane; i < npair; i += RG_WAVE) bt.pairlb[(size_t)e * npair + i] = 0.f;   // qpos written from outside: cache void

@@ -86,6 +86,12 @@ static inline int rg_env(RgLRef L) { return L.bt.order ? L.bt.order[blockIdx.x] 
 #else
 __device__ __forceinline__ int rg_env(RgLRef L) { return L.bt.order ? __builtin_amdgcn_readfirstlane(L.bt.order[blockIdx.x]) : (int)blockIdx.x; }
 #endif
+// the env's row of model parameters (RG_PRM_* layout): its own if the batch carries per-env overrides, else the model's
+#ifdef RG_EMUL
+static inline const float* rg_prm(const RgModelDev& m, RgLRef L) { return L.bt.envprm ? L.bt.envprm + (size_t)rg_env(L) * RG_NPRM : m.prm_default; }
+#else
+__device__ __forceinline__ const float* rg_prm(const RG_AS4 RgModelDev& m, RgLRef L) { return L.bt.envprm ? L.bt.envprm + (size_t)rg_env(L) * RG_NPRM : m.prm_default; }
+#endif
 // ------------------------------------------------------------------------------------------------- small math
 struct alignas(16) rgf4 { float x, y, z, w; };
 struct v3 { float x, y, z; };
@@ -285,6 +291,7 @@ struct RgLds {
   float c_pool[RG_CPOOL];  // basis Jacobian rows (normal, tangent1, tangent2, spin) x nnz, packed per contact
   float p_aref[RG_MAXPYR];
   unsigned int status;
+  int has_xfrc;   // any non-zero entry in the env's xfrc_applied row (checked once per launch)
   union {
     struct {  // ---- pos
       union {  // slot A
@@ -376,14 +383,18 @@ __device__ __forceinline__ void rg_kinematics(RgM m, RgLds& s) {
   SYNC();
 }
 
-__device__ __forceinline__ void rg_com_pos(RgM m, RgLds& s) {
+// translational Jacobian column of dof d for a point with offset `off` from the com-frame origin
+__device__ __forceinline__ v3 jac_col(const RgLds& s, int d, v3 off) { return ld3(s.cdof + 6 * d + 3) + cross(ld3(s.cdof + 6 * d), off); }
+__device__ __forceinline__ bool in_chain(RgM m, int body, int d) { return (m.body_dofmask[2 * body + (d >> 5)] >> (d & 31)) & 1u; }
+
+__device__ __forceinline__ void rg_com_pos(RgM m, RgLds& s, const float* P) {
   for (int b = 1 + LANE; b < m.nbody; b += RG_WAVE) {
     float R[9], I[9];
     q2mat(R, qmul(ldq(s.xquat + 4 * b), ldq(m.body_iquat + 4 * b)));   // orientation of the inertial frame: body frame x iquat
-    const float* in = m.body_inertia + 3 * b;
+    const float* in = P + RG_PRM_BODY_INERTIA + 3 * b;
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) I[3 * i + j] = R[3 * i] * in[0] * R[3 * j] + R[3 * i + 1] * in[1] * R[3 * j + 1] + R[3 * i + 2] * in[2] * R[3 * j + 2];
     v3 d = ld3(s.xipos + 3 * b) - ld3(s.org + 3 * s.b2org[b]);
-    float mass = m.body_mass[b], d2 = dot(d, d);
+    float mass = P[RG_PRM_BODY_MASS + b], d2 = dot(d, d);
     float* ci = s.cinert + 10 * b;
     ci[0] = I[0] + mass * (d2 - d.x * d.x); ci[1] = I[4] + mass * (d2 - d.y * d.y); ci[2] = I[8] + mass * (d2 - d.z * d.z);
     ci[3] = I[1] - mass * d.x * d.y; ci[4] = I[2] - mass * d.x * d.z; ci[5] = I[5] - mass * d.y * d.z;
@@ -406,11 +417,24 @@ __device__ __forceinline__ void rg_com_pos(RgM m, RgLds& s) {
     }
   }
   SYNC();
+  if (s.has_xfrc) {
+    // data.xfrc_applied (mj_xfrcAccumulate): force and torque at the com of every body whose chain holds the dof.  cdof is
+    // expressed in the com-based frame of the body's tree: J_point(d) = cdof_lin + cdof_ang x (point - origin).  The result
+    // waits in qfrc_smooth for rg_smooth (the body frames are gone by then).
+    PFOR(d, m.nv) {
+      float xf = 0;
+      for (int b = 1; b < m.nbody; b++) {
+        if (!in_chain(m, b, d)) continue;
+        const float* w = P + RG_PRM_XFRC + 6 * b;
+        v3 off = ld3(s.xipos + 3 * b) - ld3(s.org + 3 * s.b2org[b]);
+        xf += dot(ld3(w), jac_col(s, d, off)) + dot(ld3(w + 3), ld3(s.cdof + 6 * d));
+      }
+      s.qfrc_smooth[d] = xf;
+    }
+    SYNC();
+  }
 }
 
-// translational Jacobian column of dof d for a point with offset `off` from the com-frame origin
-__device__ __forceinline__ v3 jac_col(const RgLds& s, int d, v3 off) { return ld3(s.cdof + 6 * d + 3) + cross(ld3(s.cdof + 6 * d), off); }
-__device__ __forceinline__ bool in_chain(RgM m, int body, int d) { return (m.body_dofmask[2 * body + (d >> 5)] >> (d & 31)) & 1u; }
 
 // ---- tendon wrapping (see oracle: wrap_circle / ro_wrap)
 __device__ __forceinline__ bool seg_intersect(float p1x, float p1y, float p2x, float p2y, float p3x, float p3y, float p4x, float p4y) {
@@ -549,7 +573,7 @@ __device__ __forceinline__ void rg_tendon(RgM m, RgLds& s) {
 }
 
 // composite inertias (subtree gathers), sparse M, tree-sparse L'DL factorisation
-__device__ __forceinline__ void rg_crb(RgM m, RgLds& s, const int* subtree_adr, const int* subtree) {
+__device__ __forceinline__ void rg_crb(RgM m, RgLds& s, const float* P, const int* subtree_adr, const int* subtree) {
   for (int w = LANE; w < m.nbody * 10; w += RG_WAVE) {
     int b = w / 10, k = w - 10 * b;
     float acc = 0;
@@ -563,7 +587,7 @@ __device__ __forceinline__ void rg_crb(RgM m, RgLds& s, const int* subtree_adr, 
     mul_inert_vec(buf, s.crb + 10 * m.dof_bodyid[i], s.cdof + 6 * i);
     const float* c = s.cdof + 6 * j;
     float v = c[0] * buf[0] + c[1] * buf[1] + c[2] * buf[2] + c[3] * buf[3] + c[4] * buf[4] + c[5] * buf[5];
-    if (i == j) v += m.dof_armature[i];
+    if (i == j) v += P[RG_PRM_DOF_ARMATURE + i];
     s.Msp[e] = v;
   }
   SYNC();
@@ -972,7 +996,7 @@ template <int G> RG_STAGE_BIG void rg_narrow_phase2(RgCtx c, int ncand2) {
     SYNC();
   }
 }
-__device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, float* prof, rgf4* sepdir, float* pairlb, bool cells) {
+__device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, const float* P, float* prof, rgf4* sepdir, float* pairlb, bool cells) {
   long long tb0 = rg_clock();
   if (LANE == 0) { s.ncand = 0; s.ncon = 0; }
   SYNC();
@@ -982,7 +1006,7 @@ __device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, float* pr
   // Pass 2 (pairs whose bound ran out, compacted so that only full rows pay for it): bounding spheres,
   // then oriented boxes; both conservative, both refresh the bound when they separate the pair.
   int nround = (m.npair + RG_WAVE - 1) / RG_WAVE;
-  float hb = 1.5f * m.timestep;
+  float hb = 1.5f * P[RG_PRM_TIMESTEP];
   int nt = 0;
   for (int r0 = 0; r0 < nround; r0 += 4) {   // four rounds per trip: eight independent loads in flight per lane
     int gg[4]; float lbv[4];
@@ -1093,7 +1117,7 @@ __device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, float* pr
 }
 
 // ------------------------------------------------------------------------------------------------- velocity stage
-__device__ __forceinline__ void rg_velocity(RgM m, RgLds& s, const uint32_t* dof_velmask, const int* subtree_adr, const int* subtree) {
+__device__ __forceinline__ void rg_velocity(RgM m, RgLds& s, const float* P, const uint32_t* dof_velmask, const int* subtree_adr, const int* subtree) {
   // cdof_dot: spatial velocity accumulated over the dofs "before" d on its chain, crossed with cdof
   PFOR(d, m.nv) {
     float cv[6] = {0, 0, 0, 0, 0, 0};
@@ -1115,7 +1139,7 @@ __device__ __forceinline__ void rg_velocity(RgM m, RgLds& s, const uint32_t* dof
   // body velocities / bias accelerations by chain gathers, then body forces
   PFOR(k, m.body_geomnum[0]) s.gspeed[m.body_geomadr[0] + k] = 0;
   for (int b = 1 + LANE; b < m.nbody; b += RG_WAVE) {
-    float cv[6] = {0, 0, 0, 0, 0, 0}, ca[6] = {0, 0, 0, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
+    float cv[6] = {0, 0, 0, 0, 0, 0}, ca[6] = {0, 0, 0, -P[RG_PRM_GRAVITY], -P[RG_PRM_GRAVITY + 1], -P[RG_PRM_GRAVITY + 2]};
     for (int h = 0; h < 2; h++) {
       uint32_t bits = m.body_dofmask[2 * b + h];
       while (bits) {
@@ -1153,7 +1177,7 @@ __device__ __forceinline__ void rg_velocity(RgM m, RgLds& s, const uint32_t* dof
     const float *c = s.cdof + 6 * d, *f = s.cacc + 6 * m.dof_bodyid[d];
     s.qfrc_bias[d] = c[0] * f[0] + c[1] * f[1] + c[2] * f[2] + c[3] * f[3] + c[4] * f[4] + c[5] * f[5];
     int j = m.dof_jntid[d], t = m.jnt_type[j];
-    float pas = -m.dof_damping[d] * s.qvel[d];
+    float pas = -P[RG_PRM_DOF_DAMPING + d] * s.qvel[d];
     if ((t == RG_JNT_HINGE || t == RG_JNT_SLIDE) && m.jnt_stiffness[j] != 0) { int qa = m.jnt_qposadr[j]; pas -= m.jnt_stiffness[j] * (s.qpos[qa] - m.qpos_spring[qa]); }
     for (int q = m.dof_ten_adr[d]; q < m.dof_ten_adr[d + 1]; q++) { int tt = m.dof_ten[2 * q], sl = m.dof_ten[2 * q + 1]; pas += s.tenJ[4 * tt + sl] * s.tenfrc[tt]; }
     s.qfrc_passive[d] = pas;
@@ -1162,12 +1186,12 @@ __device__ __forceinline__ void rg_velocity(RgM m, RgLds& s, const uint32_t* dof
 }
 
 // PID actuators (mjpid.pyx semantics, see oracle ro_fwd_actuation); updates controller state
-__device__ __forceinline__ void rg_pid(RgM m, RgLds& s) {
-  float dt = m.timestep;
+__device__ __forceinline__ void rg_pid(RgM m, RgLds& s, const float* P) {
+  float dt = P[RG_PRM_TIMESTEP];
   PFOR(u, m.nu) {
-    const float* gp = m.actuator_gainprm + 10 * u;
+    const float* gp = P + RG_PRM_ACT_GAINPRM + 10 * u;
     float force;
-    float lo = m.actuator_forcerange[2 * u], hi = m.actuator_forcerange[2 * u + 1];
+    float lo = P[RG_PRM_ACT_FORCERANGE + 2 * u], hi = P[RG_PRM_ACT_FORCERANGE + 2 * u + 1];
     if (m.actuator_biastype[u] == 2) {
       float err = s.ctrl[u] - s.actlen[u];
       if (fabsf(err) < gp[5]) err = 0;
@@ -1179,7 +1203,7 @@ __device__ __forceinline__ void rg_pid(RgM m, RgLds& s) {
       if (lo != 0 || hi != 0) force = clampf(force, lo, hi);
     } else {
       float c = s.ctrl[u];
-      if (m.actuator_ctrllimited[u]) c = clampf(c, m.actuator_ctrlrange[2 * u], m.actuator_ctrlrange[2 * u + 1]);
+      if (m.actuator_ctrllimited[u]) c = clampf(c, P[RG_PRM_ACT_CTRLRANGE + 2 * u], P[RG_PRM_ACT_CTRLRANGE + 2 * u + 1]);
       force = gp[0] * c;
     }
     if (m.actuator_forcelimited[u]) force = clampf(force, lo, hi);
@@ -1187,7 +1211,7 @@ __device__ __forceinline__ void rg_pid(RgM m, RgLds& s) {
   }
   SYNC();
 }
-__device__ __forceinline__ void rg_smooth(RgM m, RgLds& s) {
+__device__ __forceinline__ void rg_smooth(RgM m, RgLds& s, const float* P) {
   PFOR(d, m.nv) {
     float f = 0;
     for (int q = m.dof_act_adr[d]; q < m.dof_act_adr[d + 1]; q++) {
@@ -1195,7 +1219,7 @@ __device__ __forceinline__ void rg_smooth(RgM m, RgLds& s) {
       f += m.actuator_gear[u] * (sl < 0 ? 1.0f : s.tenJ[4 * m.actuator_trnid[u] + sl]) * s.actfrc[u];
     }
     s.qfrc_act[d] = f;
-    float v = s.qfrc_passive[d] - s.qfrc_bias[d] + f;
+    float v = s.qfrc_passive[d] - s.qfrc_bias[d] + f + (s.has_xfrc ? s.qfrc_smooth[d] : 0.f);   // (+ J' xfrc_applied, left there by rg_com_pos)
     s.qfrc_smooth[d] = v; s.qacc_smooth[d] = v;
   }
   SYNC();
@@ -1216,10 +1240,10 @@ __device__ __forceinline__ float impedance(const float* si, float pos, float mar
   else y = 1 - powf(1 - x, power) / powf(1 - mid, power - 1);
   return dmin + y * (dmax - dmin);
 }
-__device__ __forceinline__ void kb(RgM m, const float* solref, const float* solimp, float& K, float& B) {
+__device__ __forceinline__ void kb(float timestep, const float* solref, const float* solimp, float& K, float& B) {
   float dmax = clampf(solimp[1], 1e-4f, 0.9999f);
   if (solref[0] > 0) {
-    float tc = fmaxf(solref[0], 2 * m.timestep), dr = solref[1];
+    float tc = fmaxf(solref[0], 2 * timestep), dr = solref[1];
     K = rg_rcp(fmaxf(1e-15f, dmax * dmax * tc * tc * dr * dr)); B = 2.0f * rg_rcp(fmaxf(1e-15f, dmax * tc));
   } else { K = -solref[0] / fmaxf(1e-15f, dmax * dmax); B = -solref[1] / fmaxf(1e-15f, dmax); }
 }
@@ -1268,7 +1292,7 @@ __device__ __forceinline__ void srow_hess_tree(RgLds& s, int desc, float D) {
 __device__ __forceinline__ int npyr(int dim) { return dim == 1 ? 1 : 2 * (dim - 1); }
 __device__ __forceinline__ int nbasis(int dim) { return dim >= 4 ? 4 : (dim == 1 ? 1 : 3); }
 
-__device__ __forceinline__ void rg_make_constraint(RgM m, RgLds& s) {
+__device__ __forceinline__ void rg_make_constraint(RgM m, RgLds& s, const float* P) {
   // contact basis Jacobians on the merged dof chains, packed into a shared pool (rows x nnz per contact)
   int ncon = s.ncon;
   PFOR(c, ncon) {
@@ -1311,18 +1335,21 @@ __device__ __forceinline__ void rg_make_constraint(RgM m, RgLds& s) {
     int p = s.c_pair[c], dim = s.c_dim[c];
     const float* prm = m.pair_prm + 12 * p;
     int b1 = m.geom_bodyid[m.pair_geom[3 * p]], b2 = m.geom_bodyid[m.pair_geom[3 * p + 1]];
-    float tran = m.body_invweight0[2 * b1] + m.body_invweight0[2 * b2];
+    float tran = P[RG_PRM_BODY_INVWEIGHT0 + 2 * b1] + P[RG_PRM_BODY_INVWEIGHT0 + 2 * b2];
     float includemargin = prm[0] - prm[1], dist = s.c_dist[c];
     float imp = impedance(prm + 7, dist, includemargin), K, B;
-    kb(m, prm + 5, prm + 7, K, B);
-    float mu0 = prm[2];  // friction[0]
+    kb(P[RG_PRM_TIMESTEP], prm + 5, prm + 7, K, B);
+    // friction of the pair: element-wise max of its geoms' (engine_collision_driver: mj_contactParam)
+    const int pg1 = m.pair_geom[3 * p], pg2 = m.pair_geom[3 * p + 1];
+    const float fr_slide = fmaxf(P[RG_PRM_GEOM_FRICTION + 3 * pg1], P[RG_PRM_GEOM_FRICTION + 3 * pg2]), fr_spin = fmaxf(P[RG_PRM_GEOM_FRICTION + 3 * pg1 + 1], P[RG_PRM_GEOM_FRICTION + 3 * pg2 + 1]);
+    float mu0 = fr_slide;  // friction[0]
     // first pyramid row: diagApprox = tran + mu0^2 * tran ; all rows get R = 2 mu^2 R_first, mu = friction[0]/sqrt(impratio)
     float R;
     if (dim == 1) R = fmaxf(1e-15f, (1 - imp) * tran * rg_rcp(imp));
     else { float Rf = fmaxf(1e-15f, (1 - imp) * (tran + mu0 * mu0 * tran) * rg_rcp(imp)); float mu = mu0 * rg_rsqrt(m.impratio); R = 2 * mu * mu * Rf; }
     s.c_D[c] = rg_rcp(R);
     // friction coefficient of tangent direction k (k = 0,1 sliding; 2 spin)
-    s.c_mu[2 * c] = prm[2]; s.c_mu[2 * c + 1] = prm[3];
+    s.c_mu[2 * c] = fr_slide; s.c_mu[2 * c + 1] = fr_spin;
     const float* Bc = s.c_pool + s.c_off[c]; int nnz = s.c_nnz[c], nb = nbasis(dim);
     float vb[4] = {0, 0, 0, 0};
     for (int sl = 0; sl < nnz; sl++) { float q = s.qvel[s.c2d[s.c_idx[c * RG_W + sl]]]; for (int k = 0; k < nb; k++) vb[k] += Bc[k * nnz + sl] * q; }
@@ -1345,7 +1372,7 @@ __device__ __forceinline__ float srow_force(float D, float f, float x) {
 }   // p*: pyramid row LANE + 64 k (= 6 c + q)
 // friction-loss and limit rows (mj_makeConstraint's first two blocks + mj_makeImpedance for them): impedance, regulariser,
 // reference acceleration — straight into the registers of the lanes that own the rows (RowRegs), at the start of the solve
-__device__ __forceinline__ void rg_static_rows(RgM m, const RgLds& s, RowRegs& R) {
+__device__ __forceinline__ void rg_static_rows(RgM m, const RgLds& s, const float* P, RowRegs& R) {
   int ns = nsrow(m);
 #pragma unroll
   for (int k = 0; k < RG_RSLOTS; k++) {
@@ -1353,18 +1380,18 @@ __device__ __forceinline__ void rg_static_rows(RgM m, const RgLds& s, RowRegs& R
     if (r >= ns) { R.D[k] = 0.f; R.aref[k] = 0.f; R.floss[k] = 0.f; R.desc[k] = 0; continue; }
     int rr = r; float pos = 0, margin = 0, diag, floss = 0; const float *solref, *solimp; bool active = true, fric = false;
     int dsc_dof = 0, dsc_ten = 31, dsc_neg = 0;
-    if (rr < m.nfric_dof) { int d = m.fric_dof[rr]; dsc_dof = m.d2c[d]; floss = m.dof_frictionloss[d]; diag = m.dof_invweight0[d]; solref = m.dof_solref + 2 * d; solimp = m.dof_solimp + 5 * d; fric = true; }
-    else if ((rr -= m.nfric_dof) < m.nfric_ten) { int t = m.fric_ten[rr]; dsc_ten = t; floss = m.tendon_frictionloss[t]; diag = m.tendon_invweight0[t]; solref = m.tendon_solref_fri + 2 * t; solimp = m.tendon_solimp_fri + 5 * t; fric = true; }
+    if (rr < m.nfric_dof) { int d = m.fric_dof[rr]; dsc_dof = m.d2c[d]; floss = P[RG_PRM_DOF_FRICTIONLOSS + d]; diag = P[RG_PRM_DOF_INVWEIGHT0 + d]; solref = m.dof_solref + 2 * d; solimp = m.dof_solimp + 5 * d; fric = true; }
+    else if ((rr -= m.nfric_dof) < m.nfric_ten) { int t = m.fric_ten[rr]; dsc_ten = t; floss = m.tendon_frictionloss[t]; diag = P[RG_PRM_TENDON_INVWEIGHT0 + t]; solref = m.tendon_solref_fri + 2 * t; solimp = m.tendon_solimp_fri + 5 * t; fric = true; }
     else if ((rr -= m.nfric_ten) < 2 * m.nlim_jnt) {
       int j = m.lim_jnt[rr >> 1]; float q = s.qpos[m.jnt_qposadr[j]];
       dsc_dof = m.d2c[m.jnt_dofadr[j]]; dsc_neg = rr & 1;   // lower: J = +1, upper: J = -1
-      pos = (rr & 1) ? (m.jnt_range[2 * j + 1] - q) : (q - m.jnt_range[2 * j]);
-      margin = m.jnt_margin[j]; active = pos < margin; diag = m.dof_invweight0[m.jnt_dofadr[j]]; solref = m.jnt_solref + 2 * j; solimp = m.jnt_solimp + 5 * j;
+      pos = (rr & 1) ? (P[RG_PRM_JNT_RANGE + 2 * j + 1] - q) : (q - P[RG_PRM_JNT_RANGE + 2 * j]);
+      margin = m.jnt_margin[j]; active = pos < margin; diag = P[RG_PRM_DOF_INVWEIGHT0 + m.jnt_dofadr[j]]; solref = m.jnt_solref + 2 * j; solimp = m.jnt_solimp + 5 * j;
     } else {
       rr -= 2 * m.nlim_jnt; int t = m.lim_ten[rr >> 1]; float L = s.tenlen[t];
       dsc_ten = t; dsc_neg = rr & 1;
-      pos = (rr & 1) ? (m.tendon_range[2 * t + 1] - L) : (L - m.tendon_range[2 * t]);
-      margin = m.tendon_margin[t]; active = pos < margin; diag = m.tendon_invweight0[t]; solref = m.tendon_solref_lim + 2 * t; solimp = m.tendon_solimp_lim + 5 * t;
+      pos = (rr & 1) ? (P[RG_PRM_TENDON_RANGE + 2 * t + 1] - L) : (L - P[RG_PRM_TENDON_RANGE + 2 * t]);
+      margin = m.tendon_margin[t]; active = pos < margin; diag = P[RG_PRM_TENDON_INVWEIGHT0 + t]; solref = m.tendon_solref_lim + 2 * t; solimp = m.tendon_solimp_lim + 5 * t;
     }
     const int desc = (dsc_dof & 63) | (dsc_ten << 6) | (dsc_neg << 11);
     R.desc[k] = desc;
@@ -1372,7 +1399,7 @@ __device__ __forceinline__ void rg_static_rows(RgM m, const RgLds& s, RowRegs& R
     if (active) {
       float imp = impedance(solimp, pos, margin), K, B;
       float R = fmaxf(1e-15f, (1 - imp) * diag * rg_rcp(imp));
-      kb(m, solref, solimp, K, B);
+      kb(P[RG_PRM_TIMESTEP], solref, solimp, K, B);
       if (fric) K = 0;
       float vel = srow_dot<true>(s, desc, s.qvel);
       D = rg_rcp(R); aref = -B * vel - K * imp * (pos - margin);
@@ -1728,14 +1755,14 @@ __device__ __forceinline__ LsPt rg_ls_eval(const LsRows& L, float alpha, float q
 
 // Newton solver on the primal problem (see oracle ro_solve), in the compact space of constrained dofs
 // (trees no constraint row can touch keep qacc = qacc_smooth).  Result: s.qacc, s.qfrc_con (full space).
-__device__ __forceinline__ int rg_solve(RgM m, RgLds& s, int& nefc_out, int flags) {
+__device__ __forceinline__ int rg_solve(RgM m, RgLds& s, const float* P, int& nefc_out, int flags) {
   long long t0 = rg_clock(), t1;
 #define PROFS(k) do { if (flags & 2) { t1 = rg_clock(); if (LANE == 0) s.prof[k] += (float)(t1 - t0); t0 = t1; } } while (0)
   int nv = m.nv, nvc = m.nvc, hs = m.hs, ns = nsrow(m), ncon = s.ncon;
   // count active rows (diagnostic only)
   RgMEnt ME; rg_M_ent_load(m, ME);
   RowRegs RR;
-  rg_static_rows(m, s, RR);
+  rg_static_rows(m, s, P, RR);
   { float cnt = 0;
 #pragma unroll
     for (int k = 0; k < RG_RSLOTS; k++) cnt += RR.D[k] > 0 ? 1.f : 0.f;
@@ -1915,11 +1942,11 @@ __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, int& nefc_out, int flag
 }
 
 // ------------------------------------------------------------------------------------------------- integration
-__device__ __forceinline__ void rg_euler(RgM m, RgLds& s) {
-  float h = m.timestep;
+__device__ __forceinline__ void rg_euler(RgM m, RgLds& s, const float* P) {
+  float h = P[RG_PRM_TIMESTEP];
   PFOR(i, m.nv) s.tmpv[i] = s.qfrc_smooth[i] + s.qfrc_con[i];
   SYNC();
-  rg_ltdl_factor_solve(m, s, m.dof_damping, h, s.tmpv);
+  rg_ltdl_factor_solve(m, s, P + RG_PRM_DOF_DAMPING, h, s.tmpv);
   PFOR(i, m.nv) { s.qvel[i] += h * s.tmpv[i]; s.warm[i] = s.qacc[i]; }
   SYNC();
   PFOR(j, m.njnt) {
@@ -1958,30 +1985,24 @@ __device__ __forceinline__ void rg_dump_slv(RgM m, RgLds& s, float* dbg, int nef
   if (LANE == 0) { dbg[RG_DBG_NCON + 1] = (float)nefc; dbg[RG_DBG_NCON + 2] = (float)iters; }
 }
 
-__device__ __forceinline__ void rg_position_stage(RgM m, RgLds& s) {
-  rg_kinematics(m, s);
-  rg_com_pos(m, s);
-  rg_tendon(m, s);
-}
-
 // ------------------------------------------------------------------------------------------------- stage calls (definitions of RgLaunch / RgCtx / RG_STAGE: top of the file)
 RG_STAGE void st_kinematics(RgCtx c) { rg_kinematics(RG_M(c), RG_S()); }
-RG_STAGE void st_com_pos(RgCtx c) { rg_com_pos(RG_M(c), RG_S()); }
+RG_STAGE void st_com_pos(RgCtx c) { RgM m = RG_M(c); rg_com_pos(m, RG_S(), rg_prm(m, RG_L(c))); }
 RG_STAGE void st_tendon(RgCtx c) { rg_tendon(RG_M(c), RG_S()); }
-RG_STAGE void st_crb(RgCtx c) { RgLRef L = RG_L(c); rg_crb(RG_M(c), RG_S(), L.x.subtree_adr, L.x.subtree); }
-RG_STAGE void st_velocity(RgCtx c) { RgLRef L = RG_L(c); rg_velocity(RG_M(c), RG_S(), L.x.dof_velmask, L.x.subtree_adr, L.x.subtree); }
+RG_STAGE void st_crb(RgCtx c) { RgM m = RG_M(c); RgLRef L = RG_L(c); rg_crb(m, RG_S(), rg_prm(m, L), L.x.subtree_adr, L.x.subtree); }
+RG_STAGE void st_velocity(RgCtx c) { RgM m = RG_M(c); RgLRef L = RG_L(c); rg_velocity(m, RG_S(), rg_prm(m, L), L.x.dof_velmask, L.x.subtree_adr, L.x.subtree); }
 RG_STAGE_BIG void st_collision(RgCtx c) {
   RgM m = RG_M(c); RgLRef L = RG_L(c); RgLds& s = RG_S();
   int e = rg_env(L), flags = L.flags;
-  rg_collision(c, m, s, (flags & 2) ? s.prof : (float*)0, L.bt.sepdir ? (rgf4*)L.bt.sepdir + (size_t)e * m.npair : (rgf4*)0,
+  rg_collision(c, m, s, rg_prm(m, L), (flags & 2) ? s.prof : (float*)0, L.bt.sepdir ? (rgf4*)L.bt.sepdir + (size_t)e * m.npair : (rgf4*)0,
                (L.bt.pairlb && !(flags & 4)) ? L.bt.pairlb + (size_t)e * m.npair : (float*)0, !(flags & 8));
 }
-RG_STAGE void st_make_constraint(RgCtx c) { rg_make_constraint(RG_M(c), RG_S()); }
-RG_STAGE void st_pid(RgCtx c) { rg_pid(RG_M(c), RG_S()); }
-RG_STAGE void st_smooth(RgCtx c) { rg_smooth(RG_M(c), RG_S()); }
+RG_STAGE void st_make_constraint(RgCtx c) { RgM m = RG_M(c); rg_make_constraint(m, RG_S(), rg_prm(m, RG_L(c))); }
+RG_STAGE void st_pid(RgCtx c) { RgM m = RG_M(c); rg_pid(m, RG_S(), rg_prm(m, RG_L(c))); }
+RG_STAGE void st_smooth(RgCtx c) { RgM m = RG_M(c); rg_smooth(m, RG_S(), rg_prm(m, RG_L(c))); }
 RG_STAGE void st_factor_smooth(RgCtx c) { RgLds& s = RG_S(); rg_ltdl_factor_solve(RG_M(c), s, (const float*)0, 0.f, s.qacc_smooth); }
-RG_STAGE_BIG int st_solve(RgCtx c) { int nefc = 0; int it = rg_solve(RG_M(c), RG_S(), nefc, RG_L(c).flags); return it | (nefc << 8); }
-RG_STAGE void st_euler(RgCtx c) { rg_euler(RG_M(c), RG_S()); }
+RG_STAGE_BIG int st_solve(RgCtx c) { RgM m = RG_M(c); int nefc = 0; int it = rg_solve(m, RG_S(), rg_prm(m, RG_L(c)), nefc, RG_L(c).flags); return it | (nefc << 8); }
+RG_STAGE void st_euler(RgCtx c) { RgM m = RG_M(c); rg_euler(m, RG_S(), rg_prm(m, RG_L(c))); }
 RG_STAGE void st_build_row_desc(RgCtx c) { rg_build_row_desc(RG_M(c), RG_S()); }
 RG_STAGE void st_dump(RgCtx c, int which, int nefc, int iters) {
   RgM m = RG_M(c); RgLRef L = RG_L(c); RgLds& s = RG_S();
@@ -2015,6 +2036,8 @@ __global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_kernel(con
   PFOR(i, m.nq) s.qpos[i] = L.bt.qpos[(size_t)e * m.nq + i];
   PFOR(i, m.nv) { s.qvel[i] = L.bt.qvel[(size_t)e * m.nv + i]; s.warm[i] = L.bt.qacc_warmstart[(size_t)e * m.nv + i]; }
   PFOR(i, 3 * m.nu) s.pid[i] = L.bt.pid[(size_t)e * 3 * m.nu + i];
+  const float* P = rg_prm(m, L);
+  { float nz = 0; PFOR(i, 6 * m.nbody) nz += P[RG_PRM_XFRC + i] != 0.f ? 1.f : 0.f; nz = wave_sum(nz); if (LANE == 0) s.has_xfrc = nz > 0; }
   const unsigned status0 = L.bt.status[e];
   if (LANE == 0) s.status = status0;
   if ((L.flags & 2) && LANE < RG_NPROF) s.prof[LANE] = 0;
@@ -2040,7 +2063,7 @@ __global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_kernel(con
   }
   if (use_action) {
     PFOR(u, m.nu) {
-      float lo = m.actuator_ctrlrange[2 * u], hi = m.actuator_ctrlrange[2 * u + 1], centre;
+      float lo = P[RG_PRM_ACT_CTRLRANGE + 2 * u], hi = P[RG_PRM_ACT_CTRLRANGE + 2 * u + 1], centre;
       if (L.env.relative_action) { centre = 0; for (int j = 0; j < L.env.n_hand_jnt; j++) centre += L.env.pos_to_ctrl[u * L.env.n_hand_jnt + j] * s.qpos[L.env.hand_qposadr + j]; }
       else centre = 0.5f * (hi + lo);
       float a = clampf(L.bt.action[(size_t)e * m.nu + u], -1.f, 1.f);
@@ -2105,7 +2128,7 @@ __global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_kernel(con
   PFOR(i, 3 * m.nu) L.bt.pid[(size_t)e * 3 * m.nu + i] = s.pid[i];
   PFOR(u, m.nu) L.bt.ctrl[(size_t)e * m.nu + u] = s.ctrl[u];
   if (LANE == 0) {
-    L.bt.status[e] = s.status; L.bt.time[e] += nsubsteps * m.timestep;
+    L.bt.status[e] = s.status; L.bt.time[e] += nsubsteps * P[RG_PRM_TIMESTEP];
     if (L.bt.cost) L.bt.cost[e] = (float)(rg_clock() - tk0);
     if (L.bt.stats) { float* st = L.bt.stats + 4 * (size_t)e; st[0] += st_ncon; st[1] += st_nefc; st[2] += st_iter; st[3] += nsubsteps; }
   }

@@ -29,6 +29,30 @@
 #define RG_W 14         // max nonzeros of a sparse constraint row
 #define RG_WAVE 64
 
+// Per-env model parameters (what the reference's simulation randomizers write into `sim.model` per
+// episode, randomization/sim.py:115-589, wrappers/randomizations.py:72-310,562-746): one row of RG_NPRM floats per env,
+// laid out by the compile-time capacities; the model carries a default row (its own values) for batches without overrides.
+enum {
+  RG_PRM_GRAVITY = 0,                                      // 3   opt.gravity
+  RG_PRM_TIMESTEP = 3,                                     // 1   opt.timestep
+  RG_PRM_DOF_DAMPING = 4,                                  // nv
+  RG_PRM_DOF_ARMATURE = RG_PRM_DOF_DAMPING + RG_MAXNV,
+  RG_PRM_DOF_FRICTIONLOSS = RG_PRM_DOF_ARMATURE + RG_MAXNV,
+  RG_PRM_DOF_INVWEIGHT0 = RG_PRM_DOF_FRICTIONLOSS + RG_MAXNV,   // (mj_setConst output: follows mass / inertia / armature)
+  RG_PRM_BODY_MASS = RG_PRM_DOF_INVWEIGHT0 + RG_MAXNV,     // nbody
+  RG_PRM_BODY_INERTIA = RG_PRM_BODY_MASS + RG_MAXBODY,     // 3 nbody
+  RG_PRM_BODY_INVWEIGHT0 = RG_PRM_BODY_INERTIA + 3 * RG_MAXBODY,   // 2 nbody (mj_setConst output)
+  RG_PRM_JNT_RANGE = RG_PRM_BODY_INVWEIGHT0 + 2 * RG_MAXBODY,      // 2 njnt
+  RG_PRM_TENDON_RANGE = RG_PRM_JNT_RANGE + 2 * RG_MAXJNT,  // 2 ntendon
+  RG_PRM_TENDON_INVWEIGHT0 = RG_PRM_TENDON_RANGE + 2 * RG_MAXTEN,  // ntendon (mj_setConst output)
+  RG_PRM_ACT_GAINPRM = RG_PRM_TENDON_INVWEIGHT0 + RG_MAXTEN,       // 10 nu: kp, ti, imax_clamp, td, dsmooth, error_deadband, ...
+  RG_PRM_ACT_CTRLRANGE = RG_PRM_ACT_GAINPRM + 10 * RG_MAXU,        // 2 nu
+  RG_PRM_ACT_FORCERANGE = RG_PRM_ACT_CTRLRANGE + 2 * RG_MAXU,      // 2 nu
+  RG_PRM_GEOM_FRICTION = RG_PRM_ACT_FORCERANGE + 2 * RG_MAXU,      // 3 ngeom: sliding, torsional, rolling (a contact takes the element-wise max of its geoms)
+  RG_PRM_XFRC = RG_PRM_GEOM_FRICTION + 3 * RG_MAXGEOM,     // 6 nbody: data.xfrc_applied (force, torque in world coordinates at the body's com)
+  RG_NPRM = RG_PRM_XFRC + 6 * RG_MAXBODY
+};
+
 // per-env sticky status bits (replace MuJoCo's warning callback, warning_buffer.py:27-83)
 #define RG_STATUS_BAD_STATE 1u   // NaN/inf or |x|>1e10 in qpos/qvel/qacc
 #define RG_STATUS_CON_FULL 2u    // more contacts than RG_MAXCON
@@ -69,6 +93,7 @@ struct RgModelDev {
   const float *dof_armature, *dof_damping, *dof_frictionloss, *dof_solref, *dof_solimp, *dof_invweight0;
   const float *qpos0, *qpos_spring;
   const int *lvl_dof, *lvl_dof_adr, *M_i, *M_j, *M_lvl_adr, *desc_adr, *desc;
+  const float* prm_default;   // [RG_NPRM] the model's own values in the per-env parameter layout (RG_PRM_*)
   const int* M_ent;   // [nM][2]: block-layout word of (i,j) | word of (j,i) << 16 ; compact i | compact j << 8 | constrained-tree << 16
   // geoms / sites / meshes
   const int *geom_type, *geom_bodyid, *geom_dataid, *body_geomadr, *body_geomnum;
@@ -130,6 +155,7 @@ struct RgBatchDev {
   const int* nticks;    // [B] or null: per-env override of nforward_ticks (the reset recipe's sim.step has 1, env.step 3)
   const int* order;     // [B] or null: workgroup -> env permutation (longest-expected-first dispatch)
   float* cost;          // [B] or null: shader cycles this launch spent on the env (feeds `order` of the next step)
+  const float* envprm;  // [B][RG_NPRM] or null: per-env model parameters (null: every env uses the model's)
   int* preticks;        // [B] or null: state-less forwards owed from the previous step's goal reset (run before the action is applied, then zeroed)
   int* redo;            // [B] or null: an env that exceeds this configuration's contact / candidate capacities is left
                         // untouched and flagged here, to be stepped again by a launch of the large configuration

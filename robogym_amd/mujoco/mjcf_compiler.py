@@ -252,6 +252,16 @@ class CompiledModel:
     def name2id(self, kind, name):
         return self.names[kind].index(name)
 
+    def copy_with(self, **overrides):
+        """A copy of the model with some arrays replaced (per-env model variants: the oracle side of the per-env parameter
+        tests, `refresh_constants`).  Shapes are taken from the original arrays."""
+        m = CompiledModel()
+        m.names = self.names
+        m.arrays = {k: v.copy() for k, v in self.arrays.items()}
+        for k, v in overrides.items():
+            m.arrays[k] = np.asarray(v, dtype=self.arrays[k].dtype).reshape(self.arrays[k].shape).copy()
+        return m
+
     def save(self, path):
         payload = dict(self.arrays)
         for kind, lst in self.names.items():

@@ -48,6 +48,7 @@ class BatchedSimulationInterface:
         self._keep = []
         self._redo = None
         self._side = None
+        self._params = None
 
     def __del__(self):
         try:
@@ -74,7 +75,8 @@ class BatchedSimulationInterface:
     def _ncols(self, field):
         return {_native.RG_F_QPOS: self.nq, _native.RG_F_QVEL: self.nv, _native.RG_F_CTRL: self.nu, _native.RG_F_PID: 3 * self.nu,
                 _native.RG_F_WARMSTART: self.nv, _native.RG_F_TIME: 1, _native.RG_F_STATUS: 1, _native.RG_F_STATS: 4,
-                _native.RG_F_DEBUG: self._L.rg_debug_size(), _native.RG_F_COST: 1, _native.RG_F_PAIRLB: max(self.npair, 1)}[field]
+                _native.RG_F_DEBUG: self._L.rg_debug_size(), _native.RG_F_COST: 1, _native.RG_F_PAIRLB: max(self.npair, 1),
+                _native.RG_F_ENVPRM: _native.prm_layout(self._L)["row"]}[field]
 
     def view(self, field) -> torch.Tensor:
         """Zero-copy [B, n] tensor over the batch's own buffer of `field` (the batched `sim.data.<field>`):
@@ -173,6 +175,17 @@ class BatchedSimulationInterface:
 
     def set_qvel(self, group: str, value):
         self.view(_native.RG_F_QVEL)[:, self._group_idx(self.qvel_idxs, group)] = torch.as_tensor(value, dtype=torch.float32, device=self.device)
+
+    # ------------------------------------------------------------------ per-env model parameters
+    @property
+    def params(self) -> "EnvParams":
+        """`sim.model.<field>` of the reference for a batch: `[B, ...]` tensor views into the per-env parameter rows the
+        kernel reads (gravity, timestep, dof_damping, dof_armature, dof_frictionloss, body_mass, body_inertia, jnt_range,
+        tendon_range, actuator_gainprm / ctrlrange / forcerange, geom_friction, xfrc_applied, and the mj_setConst outputs
+        dof / body / tendon _invweight0).  First access allocates the rows (initialised with the model's own values)."""
+        if self._params is None:
+            self._params = EnvParams(self)
+        return self._params
 
     # ------------------------------------------------------------------ state (simulation_interface.py:154-172)
     def get_state(self) -> dict:
@@ -277,3 +290,28 @@ class BatchedSimulationInterface:
     def sync(self):
         if not self._emul:
             torch.cuda.synchronize(self.device)
+
+
+class EnvParams:
+    """Named `[B, ...]` views into the per-env model parameter rows (include/rgstep.h RG_F_ENVPRM, rg_prm_layout)."""
+
+    def __init__(self, sim: BatchedSimulationInterface):
+        _native.check(sim._L, sim._L.rg_batch_enable_env_params(sim._bh), "rg_batch_enable_env_params")
+        lay = _native.prm_layout(sim._L)
+        self.rows = sim.view(_native.RG_F_ENVPRM)
+        d = sim.model.dims
+        nv, nu, nb, nj, ng, nt = int(d[1]), int(d[2]), int(d[3]), int(d[4]), int(d[5]), int(d[7])
+        shapes = dict(gravity=(3,), timestep=(1,), dof_damping=(nv,), dof_armature=(nv,), dof_frictionloss=(nv,), dof_invweight0=(nv,), body_mass=(nb,),
+                      body_inertia=(nb, 3), body_invweight0=(nb, 2), jnt_range=(nj, 2), tendon_range=(nt, 2), tendon_invweight0=(nt,),
+                      actuator_gainprm=(nu, 10), actuator_ctrlrange=(nu, 2), actuator_forcerange=(nu, 2), geom_friction=(ng, 3), xfrc_applied=(nb, 6))
+        self._views: Dict[str, torch.Tensor] = {}
+        B = sim.batch_size
+        for name, shape in shapes.items():
+            n = int(np.prod(shape))
+            self._views[name] = self.rows[:, lay[name]:lay[name] + n].view((B,) + shape)
+
+    def __getitem__(self, name: str) -> torch.Tensor:
+        return self._views[name]
+
+    def keys(self):
+        return self._views.keys()

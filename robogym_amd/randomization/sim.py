@@ -1,0 +1,159 @@
+"""Batched simulation randomizers: the reference's `robogym/randomization/sim.py` (GravityRandomizer :115-133,
+PidRandomizer :136-160, GenericSimRandomizer :317-589) and the dactyl physics wrappers
+(`wrappers/randomizations.py`: RandomizedBodyInertiaWrapper :72-92, RandomizedFrictionBaseWrapper :95-173,
+RandomizedGravityWrapper :176-191, RandomizedDampingWrapper :562-590, RandomizedKpWrapper :720-746) acting on the
+per-env model parameter rows of the HIP stepper instead of on one `sim.model`.
+
+The reference writes `sim.model.<field>` of ONE env before `reset()`; here `sim.params[<field>]` is a `[B, ...]` tensor view
+into the rows the kernel reads (include/rgstep.h RG_F_ENVPRM), a randomizer draws for the envs selected by `mask` (the envs
+being reset) and writes them with ordinary tensor ops: no host loop, no synchronisation.  The per-episode formulas are the
+reference's; what is folded in is the ADR parameter plumbing (`_randomizer_param_values` is a constructor argument here).
+Mass / inertia / armature changes need the mj_setConst outputs recomputed (`*_invweight0`: regulariser scales of the
+constraint rows); `refresh_constants` does that on the host with robogym_amd/mujoco/setconst.py for the distinct rows.
+"""
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+PID_GAIN_PARAMS = ["pid_kp", "pid_ti", "pid_imax_clamp", "pid_td", "pid_dsmooth", "pid_error_deadband"]   # mujoco/constants.py:35-52
+
+
+class SimulationRandomizer:
+    def __init__(self, name: str):
+        self.name = name
+        self._initial = None
+
+    def _field(self, sim) -> torch.Tensor:
+        raise NotImplementedError
+
+    def _sample(self, init: torch.Tensor, gen: torch.Generator) -> torch.Tensor:
+        raise NotImplementedError
+
+    def randomize(self, sim, gen: torch.Generator, mask: Optional[torch.Tensor] = None):
+        """Draw new values for the envs in `mask` (default: all) from the model's initial values."""
+        f = self._field(sim)
+        if self._initial is None:
+            self._initial = f[0].clone()          # every row starts as the model's own values
+        new = self._sample(self._initial.expand_as(f), gen)
+        if mask is None:
+            f.copy_(new)
+        else:
+            f.copy_(torch.where(mask.reshape((-1,) + (1,) * (f.dim() - 1)), new, f))
+
+
+class GravityRandomizer(SimulationRandomizer):
+    """sim.py:115-133: gravity + (exp(p) - 1) * random unit vector."""
+
+    def __init__(self, param: float = 0.0):
+        super().__init__("gravity")
+        self.param = param
+
+    def _field(self, sim):
+        return sim.params["gravity"]
+
+    def _sample(self, init, gen):
+        d = torch.randn(init.shape, generator=gen, device=init.device)
+        d = d / d.norm(dim=-1, keepdim=True)
+        return init + d * float(np.exp(self.param) - 1.0)
+
+
+class PidRandomizer(SimulationRandomizer):
+    """sim.py:136-160: actuator_gainprm[:, idx] * exp(N(mean, |std|)) per actuator."""
+
+    def __init__(self, field_name: str, mean: float = 0.0, std: float = 0.0):
+        super().__init__(field_name)
+        self.idx, self.mean, self.std = PID_GAIN_PARAMS.index(field_name), mean, abs(std)
+
+    def _field(self, sim):
+        return sim.params["actuator_gainprm"][:, :, self.idx]
+
+    def _sample(self, init, gen):
+        return init * torch.exp(self.mean + self.std * torch.randn(init.shape, generator=gen, device=init.device))
+
+
+class GenericSimRandomizer(SimulationRandomizer):
+    """sim.py:317-589 for the modes the dactyl / rearrange randomizer lists use (base.py:1008-1092).  `ids` restricts the
+    randomizer to a subset of rows (the reference's geom_ / body_ / dof_jnt_ / jnt_ prefixes, resolved by the caller with
+    the model's name lists)."""
+
+    def __init__(self, name: str, field_name: str, apply_mode: str = "uncoupled_mean_variance", param=(0.0, 0.0), coef: float = 1.0,
+                 ids: Optional[Sequence[int]] = None, positive_only: bool = False):
+        super().__init__(name)
+        self.field_name, self.mode, self.coef, self.ids, self.positive_only = field_name, apply_mode, coef, ids, positive_only
+        self.param = np.atleast_1d(np.asarray(param, dtype=np.float64)) * coef
+
+    def _field(self, sim):
+        f = sim.params[self.field_name]
+        return f if self.ids is None else _RowSubset(f, self.ids)
+
+    def randomize(self, sim, gen, mask=None):
+        f = sim.params[self.field_name]
+        if self._initial is None:
+            self._initial = f[0].clone()
+        init = self._initial.expand_as(f)
+        new = self._sample(init, gen)
+        if self.positive_only:
+            new = new.clamp(min=0.0)
+        if self.ids is not None:
+            sel = torch.zeros(f.shape[1], dtype=torch.bool, device=f.device)
+            sel[torch.as_tensor(list(self.ids), device=f.device)] = True
+            new = torch.where(sel.reshape((1, -1) + (1,) * (f.dim() - 2)), new, f)
+        if mask is not None:
+            new = torch.where(mask.reshape((-1,) + (1,) * (f.dim() - 1)), new, f)
+        f.copy_(new)
+
+    def _sample(self, init, gen):
+        p, dev = self.param, init.device
+        n = lambda: torch.randn(init.shape, generator=gen, device=dev)
+        u = lambda: torch.rand(init.shape, generator=gen, device=dev)
+        m = self.mode
+        if m == "coupled":
+            return init * float(np.exp(p[0]))
+        if m == "uncoupled":
+            return init * torch.exp((p[0] + n()) * abs(p[0]))
+        if m == "ranges":
+            lo, hi = min(0.0, -p[0]), max(0.0, p[1])
+            return init * torch.exp(lo + (hi - lo) * u())
+        if m == "variance":
+            return init * torch.exp(n() * abs(p[0]))
+        if m == "variance_additive":
+            return init + n() * float(np.exp(abs(p[0])) - 1.0)
+        if m == "variance_mean_additive":
+            return init + (float(np.exp(p[0]) - 1.0) + n() * float(np.exp(abs(p[1])) - 1.0)).abs()
+        if m == "coupled_mean_variance":
+            return init * torch.exp(p[0] + abs(p[0]) * n())
+        if m == "uncoupled_mean_variance":
+            return init * torch.exp(p[0] + abs(p[1]) * n())
+        if m == "max_additive":
+            return init + u() * float(np.exp(abs(p[0])) - 1.0)
+        raise ValueError("Invalid mode: {}".format(m))
+
+
+class _RowSubset:   # (placeholder type for _field(); GenericSimRandomizer.randomize handles subsets itself)
+    def __init__(self, f, ids):
+        self.f, self.ids = f, ids
+
+
+def refresh_constants(sim, rows: Optional[Sequence[int]] = None):
+    """mj_setConst for the envs whose mass / inertia / armature rows were changed (the reference calls
+    `mujoco_simulation.set_constants()` in `_reset`, cube_env.py:349): recompute dof / body / tendon `_invweight0` on the
+    host from each row's values (robogym_amd/mujoco/setconst.py, double precision) and write them back.  Host cost is per
+    distinct env row; identical rows are computed once."""
+    from robogym_amd.mujoco import setconst
+
+    P = sim.params
+    mass, inertia, arm = P["body_mass"].cpu().numpy(), P["body_inertia"].cpu().numpy(), P["dof_armature"].cpu().numpy()
+    rows = range(sim.batch_size) if rows is None else rows
+    cache = {}
+    out_d, out_b, out_t = P["dof_invweight0"], P["body_invweight0"], P["tendon_invweight0"]
+    for e in rows:
+        key = (mass[e].tobytes(), inertia[e].tobytes(), arm[e].tobytes())
+        if key not in cache:
+            m = sim.model.copy_with(body_mass=mass[e].astype(np.float64), body_inertia=inertia[e].astype(np.float64), dof_armature=arm[e].astype(np.float64))
+            setconst.set_constants(m)
+            cache[key] = (m.arrays["dof_invweight0"], m.arrays["body_invweight0"], m.arrays["tendon_invweight0"])
+        d, b, t = cache[key]
+        out_d[e] = torch.as_tensor(d, dtype=torch.float32, device=out_d.device)
+        out_b[e] = torch.as_tensor(b.reshape(-1, 2), dtype=torch.float32, device=out_b.device)
+        out_t[e] = torch.as_tensor(t, dtype=torch.float32, device=out_t.device)
