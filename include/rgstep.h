@@ -138,7 +138,14 @@ typedef struct rg_step_args {
   /* int [B] or NULL: state-less forwards owed to the env from the goal reset of its previous step (rg_env_post_step);
    * executed before the action is applied, then zeroed. */
   int* preticks_dev;
+  /* float [B][rg_xdata_layout()[0]] or NULL: the mjData fields in-tree code reads after a step — body xpos / xquat and
+   * site_xpos of the final state (mujoco_shadow_hand.py:18-61, observation providers), actuator_force of the last
+   * state-less forward, ncon and contact[i].{geom1, geom2, dist} of the last mj_step (simulation/base.py:562-635,
+   * utils/sensor_utils.py:18-38).  rg_xdata_layout: out = row length, offsets of xpos, xquat, site_xpos, actuator_force,
+   * ncon, contact triples, number of contact slots. */
+  float* xdata_dev;
 } rg_step_args;
+int rg_xdata_layout(int* out, int n);
 enum { RG_CFG_ROLLOUT = 0, RG_CFG_LARGE = 1 };
 int rg_batch_step_ex(rg_batch* b, const rg_step_args* args);
 /* Device address of a field's [B][n] buffer inside the batch (library-owned; valid until rg_batch_free) and its

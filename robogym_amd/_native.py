@@ -20,7 +20,7 @@ class StepArgs(ctypes.Structure):
     _fields_ = [("action_dev", ctypes.c_void_p), ("goal_quat_dev", ctypes.c_void_p), ("obs_dev", ctypes.c_void_p), ("goal_dist_dev", ctypes.c_void_p),
                 ("active_dev", ctypes.c_void_p), ("hold_dev", ctypes.c_void_p), ("nticks_dev", ctypes.c_void_p), ("order_dev", ctypes.c_void_p),
                 ("nsubsteps", ctypes.c_int), ("nforward_ticks", ctypes.c_int), ("flags", ctypes.c_int), ("stream", ctypes.c_void_p),
-                ("config", ctypes.c_int), ("redo_dev", ctypes.c_void_p), ("preticks_dev", ctypes.c_void_p)]
+                ("config", ctypes.c_int), ("redo_dev", ctypes.c_void_p), ("preticks_dev", ctypes.c_void_p), ("xdata_dev", ctypes.c_void_p)]
 
 
 RG_CFG_ROLLOUT, RG_CFG_LARGE = 0, 1
@@ -50,7 +50,7 @@ EXPORTS = [
     "rg_model_create", "rg_model_free", "rg_model_dims", "rg_batch_create", "rg_batch_free", "rg_batch_set_env",
     "rg_batch_copy", "rg_batch_reset", "rg_batch_step", "rg_obs_dim", "rg_debug_size", "rg_lds_bytes", "rg_sync",
     "rg_last_error", "rg_batch_mpr_pair", "rg_batch_copy_rows", "rg_batch_step_ex", "rg_batch_field_ptr", "rg_model_create_on", "rg_model_npair",
-    "rg_lds_bytes_cfg", "rg_env_post_step", "rg_post_args_size", "rg_batch_enable_env_params", "rg_prm_layout",
+    "rg_lds_bytes_cfg", "rg_env_post_step", "rg_post_args_size", "rg_batch_enable_env_params", "rg_prm_layout", "rg_xdata_layout",
 ]
 
 
@@ -93,6 +93,7 @@ def bind(path):
     L.rg_lds_bytes_cfg.argtypes = [ci]
     L.rg_batch_enable_env_params.argtypes = [vp]
     L.rg_prm_layout.argtypes = [ctypes.POINTER(ci), ci]
+    L.rg_xdata_layout.argtypes = [ctypes.POINTER(ci), ci]
     L.rg_env_post_step.argtypes = [vp, ctypes.POINTER(PostArgs), vp]
     L.rg_post_args_size.restype = ci
     if L.rg_post_args_size() != ctypes.sizeof(PostArgs):

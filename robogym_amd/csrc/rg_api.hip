@@ -406,6 +406,12 @@ int rg_batch_enable_env_params(rg_batch* b) {
   b->dev.envprm = p;
   return 0;
 }
+int rg_xdata_layout(int* out, int n) {
+  const int lay[] = {RG_XDATA, RG_XD_XPOS, RG_XD_XQUAT, RG_XD_SITE_XPOS, RG_XD_ACT_FORCE, RG_XD_NCON, RG_XD_CONTACT, RG_DBG_MAXCON};
+  const int k = (int)(sizeof lay / sizeof lay[0]);
+  for (int i = 0; i < k && i < n; i++) out[i] = lay[i];
+  return k;
+}
 int rg_prm_layout(int* out, int n) {
   const int lay[] = {RG_NPRM, RG_PRM_GRAVITY, RG_PRM_TIMESTEP, RG_PRM_DOF_DAMPING, RG_PRM_DOF_ARMATURE, RG_PRM_DOF_FRICTIONLOSS, RG_PRM_DOF_INVWEIGHT0, RG_PRM_BODY_MASS,
                      RG_PRM_BODY_INERTIA, RG_PRM_BODY_INVWEIGHT0, RG_PRM_JNT_RANGE, RG_PRM_TENDON_RANGE, RG_PRM_TENDON_INVWEIGHT0, RG_PRM_ACT_GAINPRM, RG_PRM_ACT_CTRLRANGE,
@@ -531,6 +537,7 @@ int rg_batch_step_ex(rg_batch* b, const rg_step_args* a) {
   if (a->config != RG_CFG_LARGE && a->config != RG_CFG_ROLLOUT) return fail("rg_batch_step: unknown kernel configuration");
   bt.redo = large ? nullptr : a->redo_dev;
   bt.preticks = a->preticks_dev;
+  bt.xdata = a->xdata_dev;
   RgLaunch launch{b->model->aux, b->env, bt, a->nsubsteps, a->nforward_ticks, a->flags};
   const size_t lds = large ? rgl::rg_lds_launch_bytes(prof) : rgs::rg_lds_launch_bytes(prof);
 #ifdef RG_EMUL

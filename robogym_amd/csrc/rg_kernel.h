@@ -2091,6 +2091,12 @@ __global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_kernel(con
     st_collision(c); PROF(6);
     if ((flags & 2) && LANE == 0 && (float)s.ncon > s.prof[23]) s.prof[23] = (float)s.ncon;
     st_make_constraint(c); PROF(8);
+    if (L.bt.xdata && sub == nsubsteps - 1) {   // data.ncon / data.contact[i].{geom1, geom2, dist} of the last mj_step
+      float* xd = L.bt.xdata + (size_t)e * RG_XDATA;
+      const int nc = s.ncon < RG_DBG_MAXCON ? s.ncon : RG_DBG_MAXCON;
+      if (LANE == 0) xd[RG_XD_NCON] = (float)s.ncon;
+      PFOR(ci, nc) { int gg = m.pair_gg[s.c_pair[ci]]; float* o = xd + RG_XD_CONTACT + 3 * ci; o[0] = (float)(gg & 255); o[1] = (float)(gg >> 8); o[2] = s.c_dist[ci]; }
+    }
     if (L.bt.redo && (s.status & ~status0 & (RG_STATUS_CON_FULL | RG_STATUS_CAND_FULL))) {
       // more contacts / candidates than this configuration holds: leave the env exactly as it was (state rows are
       // written at the end; the distance-bound cache was advanced by the substeps done so far, so it is voided) and
@@ -2118,9 +2124,18 @@ __global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_kernel(con
   // ---- state-less forward() calls of the reference (simulation_interface.py:185, robot_env.py:677,
   //      observation/mujoco.py:22-27): only their PID-controller side effect touches the state
   const int nticks = L.bt.nticks ? L.bt.nticks[e] : nforward_ticks;
-  if (nticks > 0 || L.bt.obs) {
-    st_kinematics(c); st_com_pos(c); st_tendon(c);
+  if (nticks > 0 || L.bt.obs || L.bt.xdata) {
+    st_kinematics(c);
+    if (L.bt.xdata) {   // body / site frames of the final state, before the later stages reuse their LDS
+      float* xd = L.bt.xdata + (size_t)e * RG_XDATA;
+      PFOR(i, 3 * m.nbody) xd[RG_XD_XPOS + i] = s.xpos[i];
+      PFOR(i, 4 * m.nbody) xd[RG_XD_XQUAT + i] = s.xquat[i];
+      PFOR(i, 3 * m.nsite) xd[RG_XD_SITE_XPOS + i] = s.spos[i];
+      if (nsubsteps == 0 && LANE == 0) xd[RG_XD_NCON] = 0.f;
+    }
+    st_com_pos(c); st_tendon(c);
     for (int k = 0; k < nticks; k++) st_pid(c);
+    if (L.bt.xdata) PFOR(u, m.nu) L.bt.xdata[(size_t)e * RG_XDATA + RG_XD_ACT_FORCE + u] = s.actfrc[u];
   }
   // ---- write back
   PFOR(i, m.nq) L.bt.qpos[(size_t)e * m.nq + i] = s.qpos[i];

@@ -53,6 +53,18 @@ enum {
   RG_NPRM = RG_PRM_XFRC + 6 * RG_MAXBODY
 };
 
+// `sim.data` readout row (mujoco_shadow_hand.py:18-61 reads site_xpos / actuator_force, simulation/base.py and
+// sensor_utils.py read contacts, robot_env.py observation providers read body poses): per env, compile-time layout
+enum {
+  RG_XD_XPOS = 0,                                   // 3 nbody   data.xpos (body_xpos)
+  RG_XD_XQUAT = RG_XD_XPOS + 3 * RG_MAXBODY,        // 4 nbody   data.xquat
+  RG_XD_SITE_XPOS = RG_XD_XQUAT + 4 * RG_MAXBODY,   // 3 nsite   data.site_xpos
+  RG_XD_ACT_FORCE = RG_XD_SITE_XPOS + 3 * RG_MAXSITE,   // nu    data.actuator_force (of the last state-less forward)
+  RG_XD_NCON = RG_XD_ACT_FORCE + RG_MAXU,           // 1         data.ncon of the last mj_step
+  RG_XD_CONTACT = RG_XD_NCON + 1,                   // RG_DBG_MAXCON x (geom1, geom2, dist)
+  RG_XDATA = RG_XD_CONTACT + 3 * 32
+};
+
 // per-env sticky status bits (replace MuJoCo's warning callback, warning_buffer.py:27-83)
 #define RG_STATUS_BAD_STATE 1u   // NaN/inf or |x|>1e10 in qpos/qvel/qacc
 #define RG_STATUS_CON_FULL 2u    // more contacts than RG_MAXCON
@@ -155,6 +167,7 @@ struct RgBatchDev {
   const int* nticks;    // [B] or null: per-env override of nforward_ticks (the reset recipe's sim.step has 1, env.step 3)
   const int* order;     // [B] or null: workgroup -> env permutation (longest-expected-first dispatch)
   float* cost;          // [B] or null: shader cycles this launch spent on the env (feeds `order` of the next step)
+  float* xdata;         // [B][RG_XDATA] or null: the mjData fields in-tree callers read after a step (RG_XD_*)
   const float* envprm;  // [B][RG_NPRM] or null: per-env model parameters (null: every env uses the model's)
   int* preticks;        // [B] or null: state-less forwards owed from the previous step's goal reset (run before the action is applied, then zeroed)
   int* redo;            // [B] or null: an env that exceeds this configuration's contact / candidate capacities is left

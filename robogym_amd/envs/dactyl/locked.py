@@ -442,16 +442,89 @@ class BatchedLockedEnv:
         return self.mujoco_simulation.status
 
 
-def make_env(batch_size: int = 1, device="cuda:0", constants=None, parameters=None, starting_seed=None, apply_wrappers=True, **kwargs):
-    """`LockedEnv.build` (locked.py:305, robot_env.py:1081-1139) for a batch of envs.
-
-    The wrapper stack of the reference (`apply_wrappers=True`) is not part of the hot path built
-    here; the returned env is the unwrapped one in both cases."""
-    if isinstance(constants, dict):
-        constants = LockedEnvConstants(**constants)
-    return BatchedLockedEnv(batch_size, device=device, constants=constants, starting_seed=starting_seed, **kwargs)
+#: constants / parameters of the reference's LockedEnv (locked.py:42-67, cube_env.py:61-124, robot_env.py:104-195) this env honours
+_PARAMETER_FIELDS = {"n_random_initial_steps", "cube_position_wiggle_std"}
+_IGNORED_CONSTANTS = {"randomize": False, "vision_observations": False, "vision_goal": False, "goal_generation": "state", "render_mode": None,
+                      "max_steps_goal_unreachable": None, "mujoco_timestep": 0.008}   # accepted when they hold the value the built path implements
 
 
-def make_simple_env(batch_size: int = 1, device="cuda:0", constants=None, parameters=None, starting_seed=None, **kwargs):
+def _constants_from(constants, parameters) -> LockedEnvConstants:
+    kw = {}
+    if isinstance(constants, LockedEnvConstants):
+        return constants
+    for src, kind in ((constants or {}), "constants"), ((parameters or {}), "parameters"):
+        src = dict(src) if isinstance(src, dict) else {k: getattr(src, k) for k in dir(src) if not k.startswith("_")}
+        for k, v in src.items():
+            if k in LockedEnvConstants.__dataclass_fields__:
+                kw[k] = v
+            elif k in _IGNORED_CONSTANTS and (_IGNORED_CONSTANTS[k] is None or v == _IGNORED_CONSTANTS[k]):
+                continue
+            elif k == "simulation_params" and isinstance(v, dict) and not v:
+                continue
+            else:
+                raise NotImplementedError("make_env(%s={%r: %r}) is not supported by the MI355X-native dactyl/locked path "
+                                          "(supported: %s)" % (kind, k, v, sorted(LockedEnvConstants.__dataclass_fields__)))
+    return LockedEnvConstants(**kw)
+
+
+def make_env(parameters=None, constants=None, wrapper_params=None, starting_seed=None, apply_wrappers=True, batch_size: int = 1, device="cuda:0", **kwargs):
+    """`LockedEnv.build` (locked.py:305, robot_env.py:1081-1139) for a batch of envs: the reference's signature
+    `make_env(parameters=None, constants=None, wrapper_params=None, starting_seed=None, apply_wrappers=True)` plus
+    `batch_size` / `device`.  `constants` / `parameters` accept the reference's names for everything the built path
+    implements and raise for the rest (no silent narrowing).  The reference's default wrapper stack
+    (dactyl_cube_wrappers.py:8-91) is not built: with `apply_wrappers=True` the unwrapped env is
+    returned WITH A WARNING (a caller porting reference code gets the raw [-1, 1]^20 action space and un-noised
+    observations); `make_simple_env` is the reference's own name for that configuration."""
+    if apply_wrappers:
+        import warnings
+
+        warnings.warn("robogym_amd dactyl/locked: the default wrapper stack (discretised actions, observation noise, drop penalty) is not built; "
+                      "returning the unwrapped env (what the reference's make_simple_env returns)" + (" — wrapper_params ignored" if wrapper_params else ""), stacklevel=2)
+    return BatchedLockedEnv(batch_size, device=device, constants=_constants_from(constants, parameters), starting_seed=starting_seed, parameters=parameters, **kwargs)
+
+
+def make_simple_env(parameters=None, constants=None, starting_seed=None, batch_size: int = 1, device="cuda:0", **kwargs):
     """`make_simple_env` (locked.py:304): no wrappers."""
-    return make_env(batch_size, device, constants, parameters, starting_seed, apply_wrappers=False, **kwargs)
+    return make_env(parameters=parameters, constants=constants, starting_seed=starting_seed, apply_wrappers=False, batch_size=batch_size, device=device, **kwargs)
+
+
+class SingleEnvView:
+    """B = 1 view of the batched env with the reference's types: numpy arrays without the batch dimension, a reward LIST of
+    three floats, a Python bool `done`, an info dict of Python scalars — what a reference caller of `RobotEnv` sees
+    (robot_env.py:757-844).  For porting single-env code and the reference's own tests; not the fast path."""
+
+    def __init__(self, env: "BatchedLockedEnv"):
+        assert env.batch_size == 1
+        self.env = env
+        self.unwrapped = self
+        self.mujoco_simulation = env.mujoco_simulation
+        self.sim = env.mujoco_simulation
+        self.action_space = env.action_space
+
+    @staticmethod
+    def _np(t):
+        a = t[0].detach().cpu().numpy()
+        return a.astype(np.float32) if a.dtype.kind == "f" else a
+
+    def _obs(self, obs):
+        return {k: self._np(v) for k, v in obs.items()}
+
+    def seed(self, seed=None):
+        return self.env.seed(seed)
+
+    def reset(self):
+        return self._obs(self.env.reset())
+
+    def observe(self):
+        return self._obs(self.env.observe())
+
+    def step(self, action):
+        obs, reward, done, info = self.env.step(torch.as_tensor(np.asarray(action, dtype=np.float32)[None], device=self.env.device))
+        out = {}
+        for k, v in info.items():
+            out[k] = {kk: float(vv[0]) for kk, vv in v.items()} if isinstance(v, dict) else v[0].item()
+        return self._obs(obs), [float(x) for x in reward[0]], bool(done[0]), out
+
+    def goal_info(self):
+        r, s_, info = self.env.goal_info()
+        return float(r[0]), bool(s_[0]), {"goal_dist": {k: float(v[0]) for k, v in info["goal_dist"].items()}, "goal": {k: self._np(v) for k, v in info["goal"].items()}}

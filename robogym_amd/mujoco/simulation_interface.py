@@ -49,6 +49,8 @@ class BatchedSimulationInterface:
         self._redo = None
         self._side = None
         self._params = None
+        self._xdata = None
+        self._data = None
 
     def __del__(self):
         try:
@@ -176,6 +178,20 @@ class BatchedSimulationInterface:
     def set_qvel(self, group: str, value):
         self.view(_native.RG_F_QVEL)[:, self._group_idx(self.qvel_idxs, group)] = torch.as_tensor(value, dtype=torch.float32, device=self.device)
 
+    # ------------------------------------------------------------------ sim.data fields in-tree callers read
+    @property
+    def data(self) -> "BatchedData":
+        """`sim.data.<field>` of the reference for a batch: qpos / qvel / ctrl / time (zero-copy views of the state) and,
+        refreshed by every step / forward launch from now on, body_xpos, body_xquat, site_xpos, actuator_force, ncon and the
+        contact list (geom1, geom2, dist).  First access switches the readout on (one more row written per env per launch)."""
+        if self._data is None:
+            lay = (ctypes.c_int * 8)()
+            self._L.rg_xdata_layout(lay, 8)
+            self._xdata = torch.zeros((self.batch_size, int(lay[0])), dtype=torch.float32, device=self.device)
+            self._data = BatchedData(self, [int(v) for v in lay])
+            self.forward(ticks=0)   # fill it for the current state
+        return self._data
+
     # ------------------------------------------------------------------ per-env model parameters (SURVEY 8f rank 2)
     @property
     def params(self) -> "EnvParams":
@@ -236,6 +252,7 @@ class BatchedSimulationInterface:
         a = _native.StepArgs()
         a.action_dev, a.goal_quat_dev, a.obs_dev, a.goal_dist_dev = (None if t is None else t.data_ptr() for t in (action, goal_quat, obs, goal_dist))
         a.hold_dev, a.nticks_dev, a.order_dev, a.preticks_dev = (None if t is None else t.data_ptr() for t in (hold, nticks, order, preticks))
+        a.xdata_dev = None if self._xdata is None else self._xdata.data_ptr()
         a.nsubsteps = self.n_substeps if nsubsteps is None else int(nsubsteps)
         a.nforward_ticks, a.flags = int(nforward_ticks), int(flags)
         self._keep.append((action, goal_quat, obs, goal_dist, active, hold, nticks, order, large_mask))
@@ -315,3 +332,45 @@ class EnvParams:
 
     def keys(self):
         return self._views.keys()
+
+
+class BatchedData:
+    """The `mjData` fields the reference's in-tree code reads, batched: every attribute is a `[B, ...]` tensor.
+    State fields are views of the stepper's own buffers; the derived ones are views of the readout row each launch writes."""
+
+    def __init__(self, sim: BatchedSimulationInterface, lay):
+        self._sim = sim
+        row, o_xpos, o_xquat, o_site, o_act, o_ncon, o_con, ncon_slots = lay
+        d = sim.model.dims
+        nb, ns, nu = int(d[3]), int(d[6]), int(d[2])
+        x, B = sim._xdata, sim.batch_size
+        self.body_xpos = x[:, o_xpos:o_xpos + 3 * nb].view(B, nb, 3)
+        self.xpos = self.body_xpos
+        self.body_xquat = x[:, o_xquat:o_xquat + 4 * nb].view(B, nb, 4)
+        self.xquat = self.body_xquat
+        self.site_xpos = x[:, o_site:o_site + 3 * ns].view(B, ns, 3)
+        self.actuator_force = x[:, o_act:o_act + nu]
+        self._ncon = x[:, o_ncon]
+        self._contact = x[:, o_con:o_con + 3 * ncon_slots].view(B, ncon_slots, 3)
+
+    qpos = property(lambda self: self._sim.view(_native.RG_F_QPOS))
+    qvel = property(lambda self: self._sim.view(_native.RG_F_QVEL))
+    ctrl = property(lambda self: self._sim.view(_native.RG_F_CTRL))
+    time = property(lambda self: self._sim.view(_native.RG_F_TIME)[:, 0])
+    ncon = property(lambda self: self._ncon.to(torch.int32))
+
+    @property
+    def contact(self):
+        """(geom1 [B,K] int32, geom2 [B,K] int32, dist [B,K]); entries beyond ncon[e] are stale.  The list is that of the
+        last mj_step of the launch (the state-less forward after it does not run the collision stage)."""
+        c = self._contact
+        return c[:, :, 0].to(torch.int32), c[:, :, 1].to(torch.int32), c[:, :, 2]
+
+    def get_site_xpos(self, name: str) -> torch.Tensor:
+        return self.site_xpos[:, self._sim.model.name2id("site", name)]
+
+    def get_body_xpos(self, name: str) -> torch.Tensor:
+        return self.body_xpos[:, self._sim.model.name2id("body", name)]
+
+    def get_body_xquat(self, name: str) -> torch.Tensor:
+        return self.body_xquat[:, self._sim.model.name2id("body", name)]

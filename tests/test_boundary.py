@@ -1,0 +1,128 @@
+"""The drop-in boundary: the reference's `make_env` / `make_simple_env` signature, the B = 1 numpy view with the
+reference's keys / shapes / dtypes, a port of the reference's `test_observe` (envs/dactyl/tests/test_locked.py:70-97:
+observation == simulation state), `goal_info()`, `action_space`, and the `sim.data` fields in-tree callers read
+(site_xpos, body xpos / xquat, actuator_force, ncon + contact geoms / dist) against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from tests.test_env_parity import STATE_FIELDS, _put_rows
+
+pytestmark = pytest.mark.usefixtures("kernel_variant")
+
+OBS_SHAPES = {"cube_pos": (3,), "cube_quat": (4,), "qpos": (38,), "qvel": (36,), "hand_angle": (24,), "fingertip_pos": (15,), "goal_pos": (3,), "goal_quat": (4,),
+              "qpos_goal": (38,), "is_goal_achieved": (1,)}
+
+
+def _check_single_env_view(env):
+    from oracle.env_oracle import relative_fingertips
+    from robogym_amd.envs.dactyl.locked import FINGERTIP_SITE_NAMES, REFERENCE_SITE_NAMES, SingleEnvView
+
+    view = SingleEnvView(env)
+    obs = view.reset()
+    # keys, order, shapes and dtypes of LockedEnv._default_observation_map (locked.py:132-146; Box(-inf, inf, shape, float32) per key)
+    assert list(obs.keys()) == list(OBS_SHAPES.keys())
+    for k, shape in OBS_SHAPES.items():
+        assert obs[k].shape == shape, k
+        assert obs[k].dtype == (np.int32 if k == "is_goal_achieved" else np.float32), k
+    assert view.action_space["shape"] == (20,) and view.action_space["low"] == -1.0 and view.action_space["high"] == 1.0
+    # ---- port of the reference's test_observe: the observation matches the simulation state
+    simulation = view.mujoco_simulation
+    obs = view.observe()
+    qpos = simulation.qpos[0].cpu().numpy(); qpos[simulation.qpos_idxs["target_all_joints"]] = 0.0
+    qvel = simulation.qvel[0].cpu().numpy(); qvel[simulation.qvel_idxs["target_all_joints"]] = 0.0
+    cube_quat = simulation.get_qpos("cube_rotation")[0].cpu().numpy()
+    sx = simulation.data.site_xpos[0].cpu().numpy().astype(np.float64)
+    tips = [simulation.model.name2id("site", "robot0:" + n) for n in FINGERTIP_SITE_NAMES]
+    refs = [simulation.model.name2id("site", "robot0:" + n) for n in REFERENCE_SITE_NAMES]
+    true_obs = {
+        "cube_pos": simulation.get_qpos("cube_position")[0].cpu().numpy(),
+        "cube_quat": cube_quat * (-1.0 if cube_quat[0] < 0 else 1.0),
+        "hand_angle": simulation.get_qpos("hand_angle")[0].cpu().numpy(),
+        "fingertip_pos": relative_fingertips(sx[tips], sx[refs]).ravel(),   # MuJoCoObservation.fingertip_positions() (mujoco_shadow_hand.py:18-46)
+        "qpos": qpos, "qvel": qvel,
+    }
+    for key, true_val in true_obs.items():
+        assert np.allclose(obs[key], true_val, atol=2e-6), "Value for obs %s %s doesn't match true value %s." % (key, obs[key], true_val)
+    # ---- step: reference return types
+    o2, reward, done, info = view.step(np.zeros(20))
+    assert isinstance(reward, list) and len(reward) == 3 and all(isinstance(r, float) for r in reward) and isinstance(done, bool)
+    assert set(["goal_dist", "goal_achieved", "successes_so_far", "steps_since_last_goal", "goals_so_far", "trial_success", "env_crash"]) <= set(info)
+    assert isinstance(info["goal_dist"]["cube_quat"], float) and info["goals_so_far"] == 1 and info["steps_since_last_goal"] == 1
+    gd_reward, is_successful, ginfo = view.goal_info()
+    assert gd_reward == reward[1] and isinstance(is_successful, bool) and abs(ginfo["goal_dist"]["cube_quat"] - info["goal_dist"]["cube_quat"]) < 1e-7
+    np.testing.assert_allclose(ginfo["goal"]["cube_quat"], o2["goal_quat"])
+
+
+def test_single_env_view_and_observe_emul(locked_model, emul_lib):
+    from robogym_amd.envs.dactyl.locked import make_simple_env
+
+    env = make_simple_env(constants={"reset_initial_steps": 2, "n_random_initial_steps": 1, "mujoco_substeps": 3}, starting_seed=0, batch_size=1, model=locked_model, lib=emul_lib)
+    _check_single_env_view(env)
+
+
+@pytest.mark.gpu
+def test_single_env_view_and_observe_gpu(locked_model):
+    from robogym_amd.envs.dactyl.locked import make_simple_env
+
+    _check_single_env_view(make_simple_env(starting_seed=0, batch_size=1, model=locked_model))
+
+
+def test_make_env_signature_and_constants(locked_model, emul_lib):
+    from robogym_amd.envs.dactyl.locked import make_env, make_simple_env
+
+    env = make_simple_env(parameters={"n_random_initial_steps": 3}, constants={"max_timesteps_per_goal": 77, "successes_needed": 5, "randomize": False},
+                          starting_seed=4, batch_size=2, model=locked_model, lib=emul_lib)
+    assert env.constants.n_random_initial_steps == 3 and env.constants.max_timesteps_per_goal == 77 and env.constants.successes_needed == 5
+    with pytest.raises(NotImplementedError):
+        make_simple_env(constants={"vision_observations": True}, batch_size=1, model=locked_model, lib=emul_lib)
+    with pytest.raises(NotImplementedError):
+        make_simple_env(constants={"randomize": True}, batch_size=1, model=locked_model, lib=emul_lib)
+    with pytest.warns(UserWarning, match="wrapper stack"):   # the reference's default (apply_wrappers=True) is not silently narrowed
+        make_env(batch_size=1, model=locked_model, lib=emul_lib)
+
+
+def _check_data_fields(sim, ora):
+    d = sim.data
+    ora.sim.reset(); ora.settle(50)
+    st = ora.get_state_f32(); ora.set_state_f32(st)
+    _put_rows(sim, np.arange(sim.batch_size), {k: np.repeat(st[k][None], sim.batch_size, 0) for k in STATE_FIELDS})
+    rng = np.random.RandomState(3)
+    a = rng.uniform(-1, 1, 20).astype(np.float32)
+    sim.env_step(action=torch.as_tensor(np.repeat(a[None], sim.batch_size, 0), device=sim.device), nforward_ticks=1)
+    ctrl = ora.denormalize(np.clip(a.astype(np.float64), -1, 1), True)
+    ora.sim.ctrl[:] = ctrl
+    # the oracle's contact list of the LAST mj_step (the state-less forward afterwards recomputes it at the final state)
+    for _ in range(ora.n_substeps - 1):
+        ora.sim.step()
+    ora.sim.fwd_position()
+    want_con = sorted((c["geom1"], c["geom2"], round(c["dist"], 5)) for c in ora.sim.contacts())
+    ora.sim.step(); ora.sim.forward()
+    nb, ns = 31, 36
+    np.testing.assert_allclose(d.body_xpos[0].cpu().numpy(), ora.sim.xpos.reshape(nb, 3), atol=2e-6)
+    np.testing.assert_allclose(d.body_xquat[0].cpu().numpy(), ora.sim.xquat.reshape(nb, 4), atol=2e-6)
+    np.testing.assert_allclose(d.site_xpos[0].cpu().numpy(), ora.sim.site_xpos.reshape(ns, 3), atol=2e-6)
+    np.testing.assert_allclose(d.actuator_force[0].cpu().numpy(), ora.sim.actuator_force, atol=2e-3)
+    g1, g2, dist = d.contact
+    n = int(d.ncon[0])
+    got = sorted((int(g1[0, i]), int(g2[0, i]), round(float(dist[0, i]), 5)) for i in range(n))
+    assert n == len(want_con) and [g[:2] for g in got] == [w[:2] for w in want_con]
+    np.testing.assert_allclose([g[2] for g in got], [w[2] for w in want_con], atol=2e-5)
+    assert n >= 1
+    np.testing.assert_allclose(d.get_site_xpos("robot0:S_fftip")[0].cpu().numpy(), ora.sim.site_xpos.reshape(ns, 3)[sim.model.name2id("site", "robot0:S_fftip")], atol=2e-6)
+    assert torch.equal(d.qpos, sim.view(0)) and d.time.shape == (sim.batch_size,)
+
+
+def test_data_fields_match_oracle_emul(locked_model, emul_lib, oracle_lib):
+    from oracle.env_oracle import OracleLockedEnvPhysics
+    from robogym_amd.envs.dactyl.locked import LockedSimulation
+
+    _check_data_fields(LockedSimulation(locked_model, 1, lib=emul_lib, n_substeps=3), OracleLockedEnvPhysics(locked_model, n_substeps=3))
+
+
+@pytest.mark.gpu
+def test_data_fields_match_oracle_gpu(locked_model, oracle_lib):
+    from oracle.env_oracle import OracleLockedEnvPhysics
+    from robogym_amd.envs.dactyl.locked import LockedSimulation
+
+    _check_data_fields(LockedSimulation(locked_model, 3, device="cuda:0"), OracleLockedEnvPhysics(locked_model))
