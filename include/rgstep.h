@@ -198,6 +198,7 @@ typedef struct rg_post_args {
   int max_timesteps_per_goal, successes_needed, use_goal_distance_reward;
   int pipelined, reset_initial_steps, n_random_initial_steps, max_pose_resets;
   int cube_pos_col, cube_quat_col;
+  int stop_on_fall;            /* StopOnFallWrapper (wrappers/cube.py:106-156) folded in: a live env whose cube centre is below z = 0.04 reports done (and, pipelined, restarts) */
 } rg_post_args;
 int rg_env_post_step(rg_batch* b, const rg_post_args* args, void* stream);
 int rg_post_args_size(void);   /* sizeof(rg_post_args) as compiled: a binding checks its own struct against it */

@@ -37,7 +37,7 @@ def _post_fields():
             + [(n, p_) for n in ("parallel_quats", "qpos0", "zero_ctrl", "ctrl_lo", "ctrl_hi")]
             + [(n, f_) for n in ("success_threshold", "success_reward", "wiggle_std", "cube_body_z")]
             + [(n, i_) for n in ("max_timesteps_per_goal", "successes_needed", "use_goal_distance_reward", "pipelined", "reset_initial_steps",
-                                 "n_random_initial_steps", "max_pose_resets", "cube_pos_col", "cube_quat_col")])
+                                 "n_random_initial_steps", "max_pose_resets", "cube_pos_col", "cube_quat_col", "stop_on_fall")])
 
 
 class PostArgs(ctypes.Structure):

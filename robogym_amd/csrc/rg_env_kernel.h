@@ -67,7 +67,8 @@ __global__ void __launch_bounds__(RG_WAVE) rg_post_step_kernel(RgBatchDev bt, Rg
       newgoal = got && !trial;
       a.steps_since_last_goal[e] = ssl; a.consecutive[e] = cons;
     }
-    int done = timeout || trial || (crash && live);
+    const int fallen = a.stop_on_fall && live && !crash && (a.cube_body_z + obs[2]) < 0.04f;   // cube:center z = body z offset + cube_tz
+    int done = timeout || trial || (crash && live) || fallen;
     float* rw = a.reward + 3 * (size_t)e;
     rw[0] = 0.f; rw[1] = (a.use_goal_distance_reward && live) ? gdr : 0.f; rw[2] = got ? a.success_reward : 0.f;
     a.goal_dist_before[e] = dist;

@@ -218,6 +218,7 @@ class BatchedLockedEnv:
         self._cube_quat_col = int(sim.qpos_idxs["cube_rotation"][0])
         self._zero_ctrl_rows = (0.5 * (sim.ctrl_lo + sim.ctrl_hi)).repeat(B, 1)   # denormalize_position_control(zero action), absolute
         self.sort_dispatch = bool(sort_dispatch)
+        self.stop_on_fall = False    # set by the wrapper stack (StopOnFallWrapper): a dropped cube ends the episode
         self._order, self._order_age = None, 0
         self._draws = None           # test hook: [B, RG_POST_NDRAW] draws instead of the counter-based generator
         self._goal_override = None   # test hook / scripted goals: [B, 4]
@@ -404,6 +405,7 @@ class BatchedLockedEnv:
         a.max_timesteps_per_goal, a.successes_needed, a.use_goal_distance_reward = int(c.max_timesteps_per_goal), int(c.successes_needed), int(c.use_goal_distance_reward)
         a.pipelined, a.reset_initial_steps, a.n_random_initial_steps, a.max_pose_resets = int(self.pipelined_reset), int(c.reset_initial_steps), int(c.n_random_initial_steps), int(c.max_pose_resets)
         a.cube_pos_col, a.cube_quat_col = self._cube_pos_col, self._cube_quat_col
+        a.stop_on_fall = int(self.stop_on_fall)
         return a
 
     def step(self, action: torch.Tensor):
@@ -471,16 +473,29 @@ def make_env(parameters=None, constants=None, wrapper_params=None, starting_seed
     """`LockedEnv.build` (locked.py:305, robot_env.py:1081-1139) for a batch of envs: the reference's signature
     `make_env(parameters=None, constants=None, wrapper_params=None, starting_seed=None, apply_wrappers=True)` plus
     `batch_size` / `device`.  `constants` / `parameters` accept the reference's names for everything the built path
-    implements and raise for the rest (no silent narrowing).  The reference's default wrapper stack
-    (dactyl_cube_wrappers.py:8-91) is not built: with `apply_wrappers=True` the unwrapped env is
-    returned WITH A WARNING (a caller porting reference code gets the raw [-1, 1]^20 action space and un-noised
-    observations); `make_simple_env` is the reference's own name for that configuration."""
-    if apply_wrappers:
-        import warnings
+    implements and raise for the rest (no silent narrowing).  `apply_wrappers=True` wraps the env in the reference's
+    default wrapper stack, vectorised (robogym_amd/wrappers/dactyl_cube.py; dactyl_cube_wrappers.py:8-91): MultiDiscrete
+    actions of 11 bins, drop penalty / done on fall, noisy_* / relative_goal / unified goal observations, sin / cos
+    angles, clipping, previous action and reward observations.  `constants["randomize"]` defaults to False here (the
+    reference's default is True; its randomizations are implemented in part, see the wrapper module's NOT_BUILT list)."""
+    wc = {}
+    if isinstance(constants, dict):   # wrapper-level constants of DactylCubeEnvConstants (cube_env.py:61-124)
+        constants = dict(constants)
+        for k in ("randomize", "n_action_bins", "relative_goal_wrapper", "drop_reward", "min_episode_length", "fixed_wrist"):
+            if k in constants and (apply_wrappers or k != "randomize"):
+                wc[k] = constants.pop(k)
+    env = BatchedLockedEnv(batch_size, device=device, constants=_constants_from(constants, parameters), starting_seed=starting_seed, parameters=parameters, **kwargs)
+    if not apply_wrappers:
+        return env
+    from robogym_amd.wrappers.dactyl_cube import BatchedDactylCubeWrappers
 
-        warnings.warn("robogym_amd dactyl/locked: the default wrapper stack (discretised actions, observation noise, drop penalty) is not built; "
-                      "returning the unwrapped env (what the reference's make_simple_env returns)" + (" — wrapper_params ignored" if wrapper_params else ""), stacklevel=2)
-    return BatchedLockedEnv(batch_size, device=device, constants=_constants_from(constants, parameters), starting_seed=starting_seed, parameters=parameters, **kwargs)
+    wp = dict(wrapper_params or {})
+    for k in ("insert_above", "insert_below", "replace", "delete", "wrappers", "adr_wrapper"):
+        if wp.get(k):
+            raise NotImplementedError("wrapper_params[%r]: editing the wrapper list is not supported (the stack is one vectorised object)" % k)
+        wp.pop(k, None)
+    env.stop_on_fall = True
+    return BatchedDactylCubeWrappers(env, **{"randomize": False, **wc, **wp})
 
 
 def make_simple_env(parameters=None, constants=None, starting_seed=None, batch_size: int = 1, device="cuda:0", **kwargs):

@@ -78,8 +78,10 @@ def test_make_env_signature_and_constants(locked_model, emul_lib):
         make_simple_env(constants={"vision_observations": True}, batch_size=1, model=locked_model, lib=emul_lib)
     with pytest.raises(NotImplementedError):
         make_simple_env(constants={"randomize": True}, batch_size=1, model=locked_model, lib=emul_lib)
-    with pytest.warns(UserWarning, match="wrapper stack"):   # the reference's default (apply_wrappers=True) is not silently narrowed
-        make_env(batch_size=1, model=locked_model, lib=emul_lib)
+    wrapped = make_env(batch_size=2, model=locked_model, lib=emul_lib)          # the reference's default: apply_wrappers=True
+    assert wrapped.action_space["nvec"] == [11] * 20 and wrapped.unwrapped.stop_on_fall
+    with pytest.raises(NotImplementedError):
+        make_env(wrapper_params={"delete": ["StopOnFallWrapper"]}, batch_size=1, model=locked_model, lib=emul_lib)
 
 
 def _check_data_fields(sim, ora):
