@@ -894,6 +894,7 @@ __device__ __forceinline__ void make_frame(float* f) {
 __device__ __forceinline__ void add_contact(RgLds& s, int pair, float dist, v3 pos, v3 normal, int dim) {
   // called with wave-uniform arguments; lane 0 writes
   int c = s.ncon;
+  SYNC();   // every lane holds the count before lane 0 advances it (the cap test below must stay wave-uniform)
   if (c >= RG_MAXCON) { if (LANE == 0) s.status |= RG_STATUS_CON_FULL; return; }
   if (LANE == 0) {
     s.c_dist[c] = dist; st3(s.c_pos + 3 * c, pos); st3(s.c_normal + 3 * c, normalized(normal));

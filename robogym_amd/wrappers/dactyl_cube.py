@@ -56,6 +56,7 @@ class BatchedDactylCubeWrappers:
         self.unwrapped = env
         self.randomize = bool(randomize)
         self.B, self.device, self.nu = env.batch_size, env.device, env.num_actions
+        self.batch_size = self.B
         nb = 11 if n_action_bins is None else int(n_action_bins)          # DiscretizeActionWrapper.DEFAULT_BINS
         self.n_action_bins = nb
         self._bins = torch.linspace(-1.0, 1.0, nb, device=self.device)     # BinSpacing.LINEAR over Box(-1, 1)

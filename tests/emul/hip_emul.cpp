@@ -3,6 +3,7 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#include <dlfcn.h>
 #include <ucontext.h>
 
 emul_dim3 threadIdx, blockIdx, blockDim = {64, 1, 1}, gridDim;
@@ -23,11 +24,16 @@ void emul_yield() { swapcontext(&g_fiber[g_cur], &g_sched); }
 
 // barrier state per group size (quads: 16 groups, 8-lane half rows: 8, 16-lane rows: 4, wave: 1)
 static int g_arrived[4][16], g_gen[4][16];
+static int g_wsize[64];
+static void* g_hist[64][16]; static long g_nwave[64];   // last wave-wide collectives of each lane + how many it has executed
+static void* g_where[64];  // call site of the collective each lane waits in (deadlock report)
 static bool g_restart;  // a wave barrier was released: resume the sweep at lane 0 (hardware executes a wave's lanes in lane order)
 static int live_in_group(int gsize, int grp) { int n = 0; for (int l = grp * gsize; l < (grp + 1) * gsize; l++) n += !g_done[l]; return n; }
 void emul_barrier(int gsize) {
   int k = gsize == 64 ? 3 : (gsize == 16 ? 2 : (gsize == 8 ? 1 : 0)), gs = gsize == 64 ? 64 : (gsize == 16 ? 16 : (gsize == 8 ? 8 : 4)), grp = g_cur / gs;
   int gen = g_gen[k][grp];
+  g_where[g_cur] = __builtin_return_address(0); g_wsize[g_cur] = gs;
+  if (gs == 64) { g_hist[g_cur][g_nwave[g_cur] & 15] = g_where[g_cur]; g_nwave[g_cur]++; }
   g_arrived[k][grp]++;
   if (g_arrived[k][grp] >= live_in_group(gs, grp)) { g_arrived[k][grp] = 0; g_gen[k][grp]++; g_restart = true; emul_yield(); return; }
   while (g_gen[k][grp] == gen) {
@@ -61,15 +67,34 @@ void emul_launch(int nblocks, size_t lds_bytes, emul_kernel_fn fn, void* arg) {
       g_done[l] = 0;
     }
     for (int k = 0; k < 4; k++) for (int g = 0; g < 16; g++) g_arrived[k][g] = 0;
+    for (int l = 0; l < 64; l++) g_nwave[l] = 0;
     int alive = 64;
+    long idle_sweeps = 0;
     while (alive > 0) {
       alive = 0;
+      // a sweep over all lanes that releases no barrier makes no progress: lanes wait in DIFFERENT collectives (control flow
+      // around a wave collective that is not uniform).  Report where instead of spinning.
+      if (++idle_sweeps > 100000) {
+        fprintf(stderr, "hip_emul: deadlock in block %d; lanes wait at (addr2line -e librgstep_emul.so <offset>):\n", b);
+        for (int l = 0; l < 64; l++) {
+          Dl_info info; size_t off = (size_t)g_where[l];
+          if (dladdr(g_where[l], &info)) off -= (size_t)info.dli_fbase;
+          fprintf(stderr, "  lane %2d %s 0x%zx (group of %d)\n", l, g_done[l] ? "exited " : "waiting", off, g_wsize[l]);
+        }
+        for (int l = 0; l < 64; l++) {
+          if (l && g_nwave[l] == g_nwave[l - 1]) continue;
+          fprintf(stderr, "  lane %d has executed %ld wave-wide collectives, the last at:", l, g_nwave[l]);
+          for (long q = g_nwave[l] - 1; q >= 0 && q >= g_nwave[l] - 12; q--) { Dl_info info; size_t off = (size_t)g_hist[l][q & 15]; if (dladdr(g_hist[l][q & 15], &info)) off -= (size_t)info.dli_fbase; fprintf(stderr, " 0x%zx", off); }
+          fprintf(stderr, "\n");
+        }
+        abort();
+      }
       for (int l = 0; l < 64; l++) {
         if (g_done[l]) continue;
         g_cur = l; threadIdx.x = l; threadIdx.y = threadIdx.z = 0;
         swapcontext(&g_sched, &g_fiber[l]);
         if (!g_done[l]) alive++;
-        if (g_restart) { g_restart = false; alive = 64; l = -1; }
+        if (g_restart) { g_restart = false; alive = 64; l = -1; idle_sweeps = 0; }
       }
     }
     free(g_lds);

@@ -154,3 +154,19 @@ def test_deviation_from_mujoco_restatement(pair, oracle_lib):
     rng = np.random.RandomState(5)
     errs = resync_errors(sim, ora, rng.uniform(-1, 1, (4, 20)))
     assert np.median(errs[:, 0]) < 1e-4 and errs[:, 0].max() < 5e-3, errs
+
+
+def test_contact_cap_in_plane_pairs_stays_convergent(locked_model, emul_lib):
+    """A cube under the floor plane (4 box-plane contacts) plus a hand posture with many finger-finger contacts reaches the
+    rollout configuration's contact cap inside `add_contact`; the cap test must be wave-uniform (the harness reports a
+    deadlock otherwise) and the step is redone in the large configuration: status 0."""
+    from robogym_amd import _native
+    from robogym_amd.envs.dactyl.locked import LockedSimulation
+
+    sim = LockedSimulation(locked_model, 1, n_substeps=1, lib=emul_lib)
+    q = np.random.RandomState(5).randn(38) * 0.1
+    q[:14] = 0; q[3] = 1; q[10] = 1; q[0:3] = -2; q[7:10] = -2
+    sim.view(_native.RG_F_QPOS)[:] = torch.as_tensor(q[None].astype(np.float32))
+    sim.touch_qpos()
+    sim.env_step(action=torch.zeros(1, 20), nforward_ticks=1)
+    assert int(sim.status[0]) == 0 and torch.isfinite(sim.qpos).all()
