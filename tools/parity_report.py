@@ -18,36 +18,43 @@ from tests.helpers import NON_TARGET_QPOS, resync_errors, sync_state_from_oracle
 
 n_streams = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 n_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+from oracle import rg_oracle  # noqa: E402
+
 model = load_locked_model()
-marks = [1, 10, 100, 1000]
-print("free-running drift, kernel (fp32, MI355X) vs oracle (fp64, CPU), dactyl/locked, iid U(-1,1) relative actions, same bytes at step 0")
-print("stream  " + "  ".join("Linf@%-5d" % m for m in marks) + "  first step with Linf > 1e-4   contacts/substep")
-for sidx in range(n_streams):
-    rng = np.random.RandomState(20200901 + 1 + sidx)
+for kernel_variant in (True, False):
+    rg_oracle.set_kernel_variant(kernel_variant)
+    print("=" * 110)
+    print("ORACLE = %s" % ("KERNEL VARIANT (portal-plane MPR depth, box-box through MPR): does the kernel compute what it says"
+                           if kernel_variant else "DEFAULT (libccd triangle-distance MPR depth, multi-point box-box): distance to the MuJoCo restatement, documented deviations included"))
+    marks = [1, 10, 100, 1000]
+    print("free-running drift, kernel (fp32, MI355X) vs oracle (fp64, CPU), dactyl/locked, iid U(-1,1) relative actions, same bytes at step 0")
+    print("stream  " + "  ".join("Linf@%-5d" % m for m in marks) + "  first step with Linf > 1e-4   contacts/substep")
+    for sidx in range(n_streams):
+        rng = np.random.RandomState(20200901 + 1 + sidx)
+        ora = OracleLockedEnvPhysics(model)
+        ora.sim.reset(); ora.settle(30)
+        sim = LockedSimulation(model, 1, device="cuda:0")
+        sync_state_from_oracle(sim, ora)
+        first, at = None, {}
+        for t in range(1, n_steps + 1):
+            a = rng.uniform(-1, 1, 20)
+            sim.env_step(action=torch.tensor(a[None].astype(np.float32), device="cuda:0"), nforward_ticks=3)
+            ora.env_step(a)
+            e = np.abs(sim.qpos.cpu().numpy()[0].astype(np.float64) - ora.sim.qpos)[NON_TARGET_QPOS].max()
+            if first is None and e > 1e-4:
+                first = t
+            if t in marks:
+                at[t] = e
+        st = sim.get_field(7).cpu().numpy()[0]
+        print("%-7d " % sidx + "  ".join("%-10.2e" % at.get(m, float("nan")) for m in marks) + "  %-28s %.2f" % (first, st[0] / max(st[3], 1)))
+
+    print()
+    print("re-synchronised one-env-step errors (kernel restarted from the oracle's fp32-rounded state before every env.step)")
     ora = OracleLockedEnvPhysics(model)
     ora.sim.reset(); ora.settle(30)
     sim = LockedSimulation(model, 1, device="cuda:0")
-    sync_state_from_oracle(sim, ora)
-    first, at = None, {}
-    for t in range(1, n_steps + 1):
-        a = rng.uniform(-1, 1, 20)
-        sim.env_step(action=torch.tensor(a[None].astype(np.float32), device="cuda:0"), nforward_ticks=3)
-        ora.env_step(a)
-        e = np.abs(sim.qpos.cpu().numpy()[0].astype(np.float64) - ora.sim.qpos)[NON_TARGET_QPOS].max()
-        if first is None and e > 1e-4:
-            first = t
-        if t in marks:
-            at[t] = e
-    st = sim.get_field(7).cpu().numpy()[0]
-    print("%-7d " % sidx + "  ".join("%-10.2e" % at.get(m, float("nan")) for m in marks) + "  %-28s %.2f" % (first, st[0] / max(st[3], 1)))
-
-print()
-print("re-synchronised one-env-step errors (kernel restarted from the oracle's fp32-rounded state before every env.step)")
-ora = OracleLockedEnvPhysics(model)
-ora.sim.reset(); ora.settle(30)
-sim = LockedSimulation(model, 1, device="cuda:0")
-rng = np.random.RandomState(20200901 + 1)
-errs = resync_errors(sim, ora, rng.uniform(-1, 1, (200, 20)))
-for name, col in (("qpos", 0), ("qvel", 1), ("pid state", 2)):
-    v = errs[:, col]
-    print("  %-9s median %.2e   p90 %.2e   max %.2e   (200 env-steps)" % (name, np.median(v), np.percentile(v, 90), v.max()))
+    rng = np.random.RandomState(20200901 + 1)
+    errs = resync_errors(sim, ora, rng.uniform(-1, 1, (200, 20)))
+    for name, col in (("qpos", 0), ("qvel", 1), ("pid state", 2)):
+        v = errs[:, col]
+        print("  %-9s median %.2e   p90 %.2e   max %.2e   (200 env-steps)" % (name, np.median(v), np.percentile(v, 90), v.max()))

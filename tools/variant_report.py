@@ -1,0 +1,100 @@
+"""How far the HIP kernel's two documented collision deviations (portal-plane MPR depth instead of libccd's closest point
+on the final portal triangle; box-box through MPR instead of MuJoCo's multi-point mjc_BoxBox) move the physics, measured
+inside the oracle alone: the DEFAULT oracle (closest available statement of MuJoCo 2.0) against the oracle in kernel-variant
+mode, from identical fp64 states along random-action rollouts.  Per state: the contact lists of both variants (matched by
+geom pair), their depth and normal deltas, and the non-target qpos / qvel delta after ONE mj_step and after one env.step.
+CPU only (oracle = test infrastructure).
+
+    python tools/variant_report.py [n_streams] [n_steps]  >> profiles/rNN_parity.txt
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import rg_oracle  # noqa: E402
+from oracle.env_oracle import OracleLockedEnvPhysics  # noqa: E402
+from robogym_amd.envs.dactyl.locked import load_locked_model  # noqa: E402
+from tests.helpers import NON_TARGET_QPOS  # noqa: E402
+
+n_streams = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+n_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+rg_oracle.build()
+model = load_locked_model()
+FIELDS = ("qpos", "qvel", "pid", "qacc_warmstart", "ctrl")
+
+
+def snapshot(o):
+    return {k: getattr(o.sim, k).copy() for k in FIELDS}
+
+
+def restore(o, st):
+    for k in FIELDS:
+        getattr(o.sim, k)[:] = st[k]
+
+
+def pct(v, q):
+    return float(np.percentile(v, q)) if len(v) else float("nan")
+
+
+a_main, b_var = OracleLockedEnvPhysics(model), OracleLockedEnvPhysics(model)
+depth, angle, extra, sub_q, sub_v, env_q, env_v, ncons = [], [], [], [], [], [], [], []
+boxbox_states = 0
+for sidx in range(n_streams):
+    rng = np.random.RandomState(777 + sidx)
+    rg_oracle.set_kernel_variant(False)
+    a_main.sim.reset(); a_main.prev_dist = None; a_main.settle(30)
+    for t in range(n_steps):
+        act = rng.uniform(-1, 1, 20)
+        st = snapshot(a_main)
+        # --- contact lists at this state
+        lists = []
+        for variant, o in ((False, a_main), (True, b_var)):
+            rg_oracle.set_kernel_variant(variant)
+            restore(o, st); o.sim.fwd_position()
+            lists.append(o.sim.contacts())
+        d, k = lists
+        ncons.append(len(d))
+        kd = {}
+        for c in k:
+            kd.setdefault((c["geom1"], c["geom2"]), []).append(c)
+        seen = {}
+        for c in d:
+            key = (c["geom1"], c["geom2"])
+            seen[key] = seen.get(key, 0) + 1
+            if key in kd and seen[key] == 1:
+                c2 = kd[key][0]
+                depth.append(abs(c["dist"] - c2["dist"]))
+                angle.append(np.degrees(np.arccos(np.clip(np.dot(c["frame"][0], c2["frame"][0]), -1, 1))))
+        GT = model.arrays["geom_type"]
+        boxbox_states += any(GT[c["geom1"]] == 6 and GT[c["geom2"]] == 6 for c in d)
+        extra.append(abs(len(d) - len(k)))
+        # --- one mj_step from the same state
+        out = []
+        for variant, o in ((False, a_main), (True, b_var)):
+            rg_oracle.set_kernel_variant(variant)
+            restore(o, st); o.sim.step()
+            out.append((o.sim.qpos.copy(), o.sim.qvel.copy()))
+        sub_q.append(np.abs(out[0][0] - out[1][0])[NON_TARGET_QPOS].max()); sub_v.append(np.abs(out[0][1] - out[1][1]).max())
+        # --- one env.step from the same state (the main oracle's result continues the rollout)
+        rg_oracle.set_kernel_variant(True)
+        restore(b_var, st); b_var.env_step(act)
+        rg_oracle.set_kernel_variant(False)
+        restore(a_main, st); a_main.env_step(act)
+        env_q.append(np.abs(a_main.sim.qpos - b_var.sim.qpos)[NON_TARGET_QPOS].max()); env_v.append(np.abs(a_main.sim.qvel - b_var.sim.qvel).max())
+
+depth, angle, sub_q, sub_v, env_q, env_v = map(np.asarray, (depth, angle, sub_q, sub_v, env_q, env_v))
+print()
+print("documented collision deviations, measured inside the oracle: DEFAULT (libccd triangle-distance MPR depth + multi-point box-box)")
+print("vs KERNEL VARIANT (portal-plane depth, box-box through MPR); %d states along %d random-action rollouts of dactyl/locked, fp64" % (len(sub_q), n_streams))
+print("  contacts per state (default oracle): mean %.2f, max %d; states where the contact COUNT differs: %d (a box-box pair in contact in %d)" % (np.mean(ncons), max(ncons), int(np.sum(np.asarray(extra) > 0)), boxbox_states))
+print("  matched contacts: %d" % len(depth))
+print("    |depth delta|  [m]   median %.2e  p90 %.2e  p99 %.2e  max %.2e" % (np.median(depth), pct(depth, 90), pct(depth, 99), depth.max()))
+print("    normal angle   [deg] median %.2e  p90 %.2e  p99 %.2e  max %.2e" % (np.median(angle), pct(angle, 90), pct(angle, 99), angle.max()))
+print("  one mj_step from the same state:  qpos Linf median %.2e  p90 %.2e  p99 %.2e  max %.2e | qvel Linf median %.2e  p99 %.2e  max %.2e" % (
+    np.median(sub_q), pct(sub_q, 90), pct(sub_q, 99), sub_q.max(), np.median(sub_v), pct(sub_v, 99), sub_v.max()))
+print("  one env.step from the same state: qpos Linf median %.2e  p90 %.2e  p99 %.2e  max %.2e | qvel Linf median %.2e  p99 %.2e  max %.2e" % (
+    np.median(env_q), pct(env_q, 90), pct(env_q, 99), env_q.max(), np.median(env_v), pct(env_v, 99), env_v.max()))
+print("  states whose env.step is bit-identical under both variants: %d of %d" % (int(np.sum(env_q == 0)), len(env_q)))
