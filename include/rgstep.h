@@ -67,14 +67,16 @@ void rg_batch_free(rg_batch* b);
 /* Per-env model parameters: the batched form of what the reference's simulation randomizers and physics wrappers write
  * into `sim.model` / `sim.data` of ONE env per episode (randomization/sim.py:115-589, wrappers/randomizations.py:72-310 and
  * 562-746, wrappers/cube.py:12-85): opt.gravity, opt.timestep, dof_damping / armature / frictionloss, body_mass / inertia,
- * jnt_range, tendon_range, actuator_gainprm / ctrlrange / forcerange, geom_friction, data.xfrc_applied, plus the
+ * jnt_range, tendon_range, actuator_gainprm / ctrlrange / forcerange, geom_friction, data.xfrc_applied, site_pos
+ * (marker placement, wrappers/dactyl.py:14-50), one size factor for the geoms the model flags in `k_geom_scaled` (the cube,
+ * wrappers/cube.py:12-53; boxes only), plus the
  * mj_setConst outputs that follow mass changes (dof / body / tendon _invweight0, supplied by the caller:
  * robogym_amd/mujoco/setconst.py).  rg_batch_enable_env_params allocates one row per env, initialised with the model's own
  * values; rows are read and written through rg_batch_field_ptr(RG_F_ENVPRM) (device pointer).  rg_prm_layout fills
  * out[0] = row length, then the offsets of gravity, timestep, dof_damping, dof_armature, dof_frictionloss, dof_invweight0,
  * body_mass, body_inertia, body_invweight0, jnt_range, tendon_range, tendon_invweight0, actuator_gainprm (10 per
- * actuator), actuator_ctrlrange, actuator_forcerange, geom_friction (3 per geom), xfrc_applied (6 per body: force, torque)
- * and returns the number of entries.  Arrays are dense by the model's own counts (e.g. dof_damping[d] at offset + d). */
+ * actuator), actuator_ctrlrange, actuator_forcerange, geom_friction (3 per geom), xfrc_applied (6 per body: force, torque),
+ * site_pos (3 per site), geom_scale (1) and returns the number of entries.  Arrays are dense by the model's own counts (e.g. dof_damping[d] at offset + d). */
 int rg_batch_enable_env_params(rg_batch* b);
 int rg_prm_layout(int* out, int n);
 /* Task description for the dactyl cube-in-hand family: which qpos slices / sites feed the action

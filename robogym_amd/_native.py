@@ -119,7 +119,7 @@ def check(L, rc, what):
 
 
 PRM_NAMES = ["row", "gravity", "timestep", "dof_damping", "dof_armature", "dof_frictionloss", "dof_invweight0", "body_mass", "body_inertia", "body_invweight0",
-             "jnt_range", "tendon_range", "tendon_invweight0", "actuator_gainprm", "actuator_ctrlrange", "actuator_forcerange", "geom_friction", "xfrc_applied"]
+             "jnt_range", "tendon_range", "tendon_invweight0", "actuator_gainprm", "actuator_ctrlrange", "actuator_forcerange", "geom_friction", "xfrc_applied", "site_pos", "geom_scale"]
 
 
 def prm_layout(L):

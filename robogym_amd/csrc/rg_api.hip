@@ -267,6 +267,9 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
     std::vector<int> pg, gt, gd, va, vn; std::vector<float> pp, gs, gr, ga;
     if (!get_i(B, "k_pair_geom", pg, e) || !get_i(B, "geom_type", gt, e) || !get_i(B, "geom_dataid", gd, e) || !get_i(B, "mesh_vertadr", va, e) || !get_i(B, "mesh_vertnum", vn, e) ||
         !get_f(B, "k_pair_prm", pp, e) || !get_f(B, "geom_size", gs, e) || !get_f(B, "geom_rbound", gr, e) || !get_f(B, "k_geom_aabb", ga, e)) return bail(e, m);
+    std::vector<int> gsc;   // optional: geoms whose size follows the env's RG_PRM_GEOM_SCALE (boxes only: the bounds scale exactly)
+    if (B.find("k_geom_scaled") && !get_i(B, "k_geom_scaled", gsc, e)) return bail(e, m);
+    for (size_t g = 0; g < gsc.size(); g++) if (gsc[g] && (g >= gt.size() || gt[g] != RG_GEOM_BOX)) return bail("k_geom_scaled flags a geom that is not a box", m);
     size_t np = pg.size() / 3;
     std::vector<int> gg(np ? np : 1, 0); std::vector<float> rec((np ? np : 1) * RG_PAIRREC, 0.f);
     for (size_t p = 0; p < np; p++) {
@@ -275,6 +278,8 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
       gg[p] = g[0] | (g[1] << 8);
       float* r = rec.data() + p * RG_PAIRREC;
       int hdr = g[0] | (g[1] << 8) | (pg[3 * p + 2] << 16) | (gt[g[0]] << 20) | (gt[g[1]] << 24);
+      if ((size_t)g[0] < gsc.size() && gsc[g[0]]) hdr |= RG_PAIR_SCALED1;
+      if ((size_t)g[1] < gsc.size() && gsc[g[1]]) hdr |= RG_PAIR_SCALED2;
       memcpy(r, &hdr, 4); r[1] = pp[12 * p];
       for (int k = 0; k < 2; k++) {
         int id = gt[g[k]] == RG_GEOM_MESH ? gd[g[k]] : -1, nvert = id >= 0 ? vn[id] : 0, vadr0 = id >= 0 ? va[id] : 0;
@@ -318,7 +323,9 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
         !put("body_mass", RG_PRM_BODY_MASS, RG_MAXBODY) || !put("body_inertia", RG_PRM_BODY_INERTIA, 3 * RG_MAXBODY) || !put("body_invweight0", RG_PRM_BODY_INVWEIGHT0, 2 * RG_MAXBODY) ||
         !put("jnt_range", RG_PRM_JNT_RANGE, 2 * RG_MAXJNT) || !put("tendon_range", RG_PRM_TENDON_RANGE, 2 * RG_MAXTEN) || !put("tendon_invweight0", RG_PRM_TENDON_INVWEIGHT0, RG_MAXTEN) ||
         !put("actuator_gainprm", RG_PRM_ACT_GAINPRM, 10 * RG_MAXU) || !put("actuator_ctrlrange", RG_PRM_ACT_CTRLRANGE, 2 * RG_MAXU) ||
-        !put("actuator_forcerange", RG_PRM_ACT_FORCERANGE, 2 * RG_MAXU) || !put("geom_friction", RG_PRM_GEOM_FRICTION, 3 * RG_MAXGEOM)) return bail(e, m);
+        !put("actuator_forcerange", RG_PRM_ACT_FORCERANGE, 2 * RG_MAXU) || !put("geom_friction", RG_PRM_GEOM_FRICTION, 3 * RG_MAXGEOM) ||
+        !put("site_pos", RG_PRM_SITE_POS, 3 * RG_MAXSITE)) return bail(e, m);
+    prm[RG_PRM_GEOM_SCALE] = 1.f;
     m->prm_default = prm;
     if (!upload<float>(m, prm, &d.prm_default)) return bail("hipMalloc failed", m);
   }
@@ -415,7 +422,7 @@ int rg_xdata_layout(int* out, int n) {
 int rg_prm_layout(int* out, int n) {
   const int lay[] = {RG_NPRM, RG_PRM_GRAVITY, RG_PRM_TIMESTEP, RG_PRM_DOF_DAMPING, RG_PRM_DOF_ARMATURE, RG_PRM_DOF_FRICTIONLOSS, RG_PRM_DOF_INVWEIGHT0, RG_PRM_BODY_MASS,
                      RG_PRM_BODY_INERTIA, RG_PRM_BODY_INVWEIGHT0, RG_PRM_JNT_RANGE, RG_PRM_TENDON_RANGE, RG_PRM_TENDON_INVWEIGHT0, RG_PRM_ACT_GAINPRM, RG_PRM_ACT_CTRLRANGE,
-                     RG_PRM_ACT_FORCERANGE, RG_PRM_GEOM_FRICTION, RG_PRM_XFRC};
+                     RG_PRM_ACT_FORCERANGE, RG_PRM_GEOM_FRICTION, RG_PRM_XFRC, RG_PRM_SITE_POS, RG_PRM_GEOM_SCALE};
   const int k = (int)(sizeof lay / sizeof lay[0]);
   for (int i = 0; i < k && i < n; i++) out[i] = lay[i];
   return k;

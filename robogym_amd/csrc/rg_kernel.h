@@ -320,7 +320,7 @@ struct RgLds {
 static inline size_t rg_lds_launch_bytes(bool profiling) { return profiling ? sizeof(RgLds) : offsetof(RgLds, prof); }
 
 // ------------------------------------------------------------------------------------------------- position stage
-__device__ __forceinline__ void rg_kinematics(RgM m, RgLds& s) {
+__device__ __forceinline__ void rg_kinematics(RgM m, RgLds& s, const float* P) {
   PFOR(i, m.nstatic) {
     int b = m.static_body[i];
     st3(s.xpos + 3 * b, ld3(m.static_xpos + 3 * b));
@@ -374,7 +374,7 @@ __device__ __forceinline__ void rg_kinematics(RgM m, RgLds& s) {
   }
   PFOR(i, m.nsite) {
     int b = m.site_bodyid[i];
-    st3(s.spos + 3 * i, ld3(s.xpos + 3 * b) + qrot(ldq(s.xquat + 4 * b), ld3(m.site_pos + 3 * i)));
+    st3(s.spos + 3 * i, ld3(s.xpos + 3 * b) + qrot(ldq(s.xquat + 4 * b), ld3(P + RG_PRM_SITE_POS + 3 * i)));
   }
   PFOR(b, m.nbody) {
     int r = m.body_rootid[b], ob = m.root_origin_body[r];
@@ -911,13 +911,15 @@ __device__ __forceinline__ MprEnv rg_mpr_env(RgM m, float* prof, bool cells) {
   E.prof = prof; E.cells = cells;
   return E;
 }
-__device__ __forceinline__ void rg_mpr_geoms(RgM m, const RgLds& s, int p, MprGeom& A, MprGeom& B, int& dim, float& margin) {
+__device__ __forceinline__ void rg_mpr_geoms(RgM m, const RgLds& s, int p, float gscale, MprGeom& A, MprGeom& B, int& dim, float& margin) {
   const rgf4* R = (const rgf4*)m.pair_rec + (RG_PAIRREC / 4) * p;
   rgf4 r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3];
   int hdr = __builtin_bit_cast(int, r0.x), g1 = hdr & 255, g2 = (hdr >> 8) & 255;
   dim = (hdr >> 16) & 15; margin = r0.y;
   A.type = (hdr >> 20) & 15; A.quat = s.gquat + 4 * g1; A.size = mk3(r1.x, r1.y, r1.z); A.margin = 0.5f * margin; A.pos = mk3(0, 0, 0);
   B.type = (hdr >> 24) & 15; B.quat = s.gquat + 4 * g2; B.size = mk3(r2.x, r2.y, r2.z); B.margin = 0.5f * margin; B.pos = ld3(s.gpos + 3 * g2) - ld3(s.gpos + 3 * g1);
+  if (hdr & RG_PAIR_SCALED1) A.size = A.size * gscale;   // per-env size factor of the flagged geoms (RG_PRM_GEOM_SCALE)
+  if (hdr & RG_PAIR_SCALED2) B.size = B.size * gscale;
   A.mesh = __builtin_bit_cast(int, r0.z); A.vertadr = __builtin_bit_cast(int, r3.x); A.nvert = __builtin_bit_cast(int, r1.w);
   B.mesh = __builtin_bit_cast(int, r0.w); B.vertadr = __builtin_bit_cast(int, r3.y); B.nvert = __builtin_bit_cast(int, r2.w);
 }
@@ -926,6 +928,7 @@ template <int G> RG_STAGE void rg_narrow_phase1(RgCtx c, int ncand) {
   bool cells = !(L.flags & 8);
   rgf4* sepdir = L.bt.sepdir ? (rgf4*)L.bt.sepdir + (size_t)rg_env(L) * m.npair : (rgf4*)0;
   float* pairlb = (L.bt.pairlb && !(L.flags & 4)) ? L.bt.pairlb + (size_t)rg_env(L) * m.npair : (float*)0;
+  const float gscale = rg_prm(m, L)[RG_PRM_GEOM_SCALE];
   MprEnv E = rg_mpr_env(m, (float*)0, cells);
   for (int base = 0; base < ncand; base += RG_WAVE / G) {
     int ci = base + LANE / G;
@@ -933,7 +936,7 @@ template <int G> RG_STAGE void rg_narrow_phase1(RgCtx c, int ncand) {
     if (ci < ncand) {
       p = s.cand[ci];
       MprGeom A, B; int dim; float margin;
-      rg_mpr_geoms(m, s, p, A, B, dim, margin);
+      rg_mpr_geoms(m, s, p, gscale, A, B, dim, margin);
       if (A.type != RG_GEOM_PLANE) {
         v3 c0 = A.pos - B.pos;
         if (mz(c0.x) && mz(c0.y) && mz(c0.z)) c0.x += 1e-6f;
@@ -963,6 +966,7 @@ template <int G> RG_STAGE_BIG void rg_narrow_phase2(RgCtx c, int ncand2) {
   bool cells = !(L.flags & 8);
   float* prof = (L.flags & 2) ? s.prof : (float*)0;
   rgf4* sepdir = L.bt.sepdir ? (rgf4*)L.bt.sepdir + (size_t)rg_env(L) * m.npair : (rgf4*)0;
+  const float gscale = rg_prm(m, L)[RG_PRM_GEOM_SCALE];
   MprEnv E = rg_mpr_env(m, prof, cells);
   for (int base = 0; base < ncand2; base += RG_WAVE / G) {
     int ci = base + LANE / G;
@@ -972,7 +976,7 @@ template <int G> RG_STAGE_BIG void rg_narrow_phase2(RgCtx c, int ncand2) {
     MprGeom A, B;
     if (active) {
       p = s.cand2[ci];
-      rg_mpr_geoms(m, s, p, A, B, dim, margin);
+      rg_mpr_geoms(m, s, p, gscale, A, B, dim, margin);
     }
     v3 sep;
     hit = rg_mpr<G>(E, A, B, m.mpr_iterations, m.mpr_tolerance, depth, dir, pos, sep, active);
@@ -999,6 +1003,7 @@ template <int G> RG_STAGE_BIG void rg_narrow_phase2(RgCtx c, int ncand2) {
 }
 __device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, const float* P, float* prof, rgf4* sepdir, float* pairlb, bool cells) {
   long long tb0 = rg_clock();
+  const float gscale = P[RG_PRM_GEOM_SCALE];
   if (LANE == 0) { s.ncand = 0; s.ncon = 0; }
   SYNC();
   // Broadphase over the static pair list.
@@ -1041,6 +1046,8 @@ __device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, const flo
         rgf4 r0 = R[0], r3 = R[3], r4 = R[4], r5 = R[5];
         int hdr = __builtin_bit_cast(int, r0.x), g1 = hdr & 255, g2 = (hdr >> 8) & 255;
         float margin = r0.y, newlb = 0.f;
+        const float sc1 = (hdr & RG_PAIR_SCALED1) ? gscale : 1.f, sc2 = (hdr & RG_PAIR_SCALED2) ? gscale : 1.f;
+        r3.z *= sc1; r3.w *= sc2;
         v3 p1 = ld3(s.gpos + 3 * g1), p2 = ld3(s.gpos + 3 * g2), dif = p2 - p1;
         if (((hdr >> 20) & 15) == RG_GEOM_PLANE) {
           float d = dot(dif, qrot(ldq(s.gquat + 4 * g1), mk3(0, 0, 1))) - (r3.w + margin);
@@ -1049,7 +1056,7 @@ __device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, const flo
           float d = sqrtf(dot(dif, dif)) - (r3.z + r3.w + margin);
           if (d <= 0) {
             float hm = 0.5f * margin + 1e-6f;
-            v3 ea = mk3(r4.x + hm, r4.y + hm, r4.z + hm), eb = mk3(r5.x + hm, r5.y + hm, r5.z + hm);
+            v3 ea = mk3(r4.x * sc1 + hm, r4.y * sc1 + hm, r4.z * sc1 + hm), eb = mk3(r5.x * sc2 + hm, r5.y * sc2 + hm, r5.z * sc2 + hm);
             float Ra[9], Rb[9]; q2mat(Ra, ldq(s.gquat + 4 * g1)); q2mat(Rb, ldq(s.gquat + 4 * g2));
             float og = obb_gap(Ra, ea, Rb, eb, dif);
             hit = og < 0; newlb = fmaxf(og, 0.f);
@@ -1096,6 +1103,7 @@ __device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, const flo
     v3 p1 = ld3(s.gpos + 3 * g1), p2 = ld3(s.gpos + 3 * g2);
     MprGeom B;
     B.type = t2; B.quat = s.gquat + 4 * g2; B.size = ld3(m.geom_size + 3 * g2); B.margin = 0; B.mesh = -1; B.vertadr = 0; B.nvert = 0;
+    if (__builtin_bit_cast(int, m.pair_rec[RG_PAIRREC * p]) & RG_PAIR_SCALED2) B.size = B.size * gscale;
     if (t2 == RG_GEOM_MESH) { B.mesh = m.geom_dataid[g2]; B.vertadr = m.mesh_vertadr[B.mesh]; B.nvert = m.mesh_vertnum[B.mesh]; }
     v3 n = qrot(ldq(s.gquat + 4 * g1), mk3(0, 0, 1));
     if (t2 == RG_GEOM_BOX) {
@@ -1148,11 +1156,12 @@ __device__ __forceinline__ void rg_velocity(RgM m, RgLds& s, const float* P, con
         for (int e = 0; e < 6; e++) { cv[e] += s.cdof[6 * a + e] * q; ca[e] += s.cdofdot[6 * a + e] * q; }
       }
     }
-    {  // speed bound of the body's geoms: |v(geom centre)| + |omega| * bounding radius
+    {  // speed bound of the body's geoms: |v(geom centre)| + |omega| * bounding radius (radius of a size-scaled geom: conservative factor for all)
+      const float gsmax = fmaxf(P[RG_PRM_GEOM_SCALE], 1.f);
       v3 w = mk3(cv[0], cv[1], cv[2]), vo = mk3(cv[3], cv[4], cv[5]), og = ld3(s.org + 3 * s.b2org[b]);
       float wn = norm(w);
       int ga = m.body_geomadr[b], gn = m.body_geomnum[b];
-      for (int k = 0; k < gn; k++) s.gspeed[ga + k] = norm(vo + cross(w, ld3(s.gpos + 3 * (ga + k)) - og)) + wn * m.geom_rbound[ga + k];
+      for (int k = 0; k < gn; k++) s.gspeed[ga + k] = norm(vo + cross(w, ld3(s.gpos + 3 * (ga + k)) - og)) + wn * (m.geom_rbound[ga + k] * gsmax);
     }
     float t1[6], t2[6], t3[6];
     mul_inert_vec(t1, s.cinert + 10 * b, ca);
@@ -1987,7 +1996,7 @@ __device__ __forceinline__ void rg_dump_slv(RgM m, RgLds& s, float* dbg, int nef
 }
 
 // ------------------------------------------------------------------------------------------------- stage calls (definitions of RgLaunch / RgCtx / RG_STAGE: top of the file)
-RG_STAGE void st_kinematics(RgCtx c) { rg_kinematics(RG_M(c), RG_S()); }
+RG_STAGE void st_kinematics(RgCtx c) { RgM m = RG_M(c); RgLRef L = RG_L(c); rg_kinematics(m, RG_S(), rg_prm(m, L)); }
 RG_STAGE void st_com_pos(RgCtx c) { RgM m = RG_M(c); rg_com_pos(m, RG_S(), rg_prm(m, RG_L(c))); }
 RG_STAGE void st_tendon(RgCtx c) { rg_tendon(RG_M(c), RG_S()); }
 RG_STAGE void st_crb(RgCtx c) { RgM m = RG_M(c); RgLRef L = RG_L(c); rg_crb(m, RG_S(), rg_prm(m, L), L.x.subtree_adr, L.x.subtree); }

@@ -24,6 +24,8 @@
 #define RG_LTDL_PAIR_ROUNDS 8
 #define RG_KINREC 20    // words per kinematics record
 #define RG_PAIRREC 24   // words per pair record
+#define RG_PAIR_SCALED1 (1 << 28)   // pair record header: geom 1 / geom 2 takes the env's RG_PRM_GEOM_SCALE
+#define RG_PAIR_SCALED2 (1 << 29)
 #define RG_TLIST 320    // pairs whose distance bound ran out, queued for the sphere/box tests (drained in chunks)
 #define RG_MAXROW 64    // friction-loss + limit rows
 #define RG_W 14         // max nonzeros of a sparse constraint row
@@ -50,7 +52,9 @@ enum {
   RG_PRM_ACT_FORCERANGE = RG_PRM_ACT_CTRLRANGE + 2 * RG_MAXU,      // 2 nu
   RG_PRM_GEOM_FRICTION = RG_PRM_ACT_FORCERANGE + 2 * RG_MAXU,      // 3 ngeom: sliding, torsional, rolling (a contact takes the element-wise max of its geoms)
   RG_PRM_XFRC = RG_PRM_GEOM_FRICTION + 3 * RG_MAXGEOM,     // 6 nbody: data.xfrc_applied (force, torque in world coordinates at the body's com)
-  RG_NPRM = RG_PRM_XFRC + 6 * RG_MAXBODY
+  RG_PRM_SITE_POS = RG_PRM_XFRC + 6 * RG_MAXBODY,          // 3 nsite: model.site_pos (marker placement, wrappers/dactyl.py:14-50)
+  RG_PRM_GEOM_SCALE = RG_PRM_SITE_POS + 3 * RG_MAXSITE,    // 1   size factor of the geoms flagged in k_geom_scaled (the cube: wrappers/cube.py:12-53)
+  RG_NPRM = RG_PRM_GEOM_SCALE + 1
 };
 
 // `sim.data` readout row (mujoco_shadow_hand.py:18-61 reads site_xpos / actuator_force, simulation/base.py and

@@ -209,6 +209,9 @@ def derive_kernel_tables(model, max_row_nnz=16):
     if max_nnz > max_row_nnz:
         raise NotImplementedError("contact row needs %d nonzeros > %d" % (max_nnz, max_row_nnz))
     A["k_pair_geom"] = _i32(pairs).reshape(-1, 3)
+    # geoms whose size follows the env's `geom_scale` parameter: what RandomizedCubeSizeWrapper rescales (wrappers/cube.py:12-53)
+    gnames = model.names["geom"]
+    A["k_geom_scaled"] = _i32([1 if (n in ("cube:middle", "cube:top", "cube:bottom") and int(A["geom_type"][g]) == 6) else 0 for g, n in enumerate(gnames)])
     A["k_pair_prm"] = np.asarray(prm, dtype=np.float64).reshape(-1, 12)
     # oriented bounding boxes in the geom frame (conservative pre-filter before MPR)
     aabb = np.zeros((ngeom, 3))

@@ -76,10 +76,11 @@ def test_make_env_signature_and_constants(locked_model, emul_lib):
     assert env.constants.n_random_initial_steps == 3 and env.constants.max_timesteps_per_goal == 77 and env.constants.successes_needed == 5
     with pytest.raises(NotImplementedError):
         make_simple_env(constants={"vision_observations": True}, batch_size=1, model=locked_model, lib=emul_lib)
+    wrapped = make_env(batch_size=2, model=locked_model, lib=emul_lib)          # the reference's defaults: apply_wrappers=True, randomize=True
+    assert wrapped.action_space["nvec"] == [11] * 20 and wrapped.unwrapped.stop_on_fall and wrapped.randomize
+    assert not make_env(constants={"randomize": False}, batch_size=1, model=locked_model, lib=emul_lib).randomize
     with pytest.raises(NotImplementedError):
-        make_simple_env(constants={"randomize": True}, batch_size=1, model=locked_model, lib=emul_lib)
-    wrapped = make_env(batch_size=2, model=locked_model, lib=emul_lib)          # the reference's default: apply_wrappers=True
-    assert wrapped.action_space["nvec"] == [11] * 20 and wrapped.unwrapped.stop_on_fall
+        make_env(constants={"fixed_wrist": True}, batch_size=1, model=locked_model, lib=emul_lib)
     with pytest.raises(NotImplementedError):
         make_env(wrapper_params={"delete": ["StopOnFallWrapper"]}, batch_size=1, model=locked_model, lib=emul_lib)
 

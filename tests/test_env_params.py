@@ -25,11 +25,20 @@ def _variants(model):
     v[1]["opt_gravity"] = np.array([0.7, -0.4, -9.3]); v[1]["opt_timestep"] = np.array([0.006])
     d = A["dof_damping"].copy(); d[hand_dofs] *= 1.5; v[1]["dof_damping"] = d
     g = A["actuator_gainprm"].copy(); g[:, 0] *= 1.3; g[:, 3] *= 0.8; v[1]["actuator_gainprm"] = g
+    # ... and a 5 % larger cube (RandomizedCubeSizeWrapper, wrappers/cube.py:12-53: geom_size only, inertia unchanged)
+    cube_geom = model.name2id("geom", "cube:middle")
+    gs = A["geom_size"].copy(); gs[cube_geom] *= 1.05; v[1]["geom_size"] = gs
+    gr = A["geom_rbound"].copy(); gr[cube_geom] *= 1.05; v[1]["geom_rbound"] = gr
     # env 2: heavier cube, more armature, less friction loss, slippery cube / grippy hand
     m_ = A["body_mass"].copy(); m_[cube_body] *= 1.4; v[2]["body_mass"] = m_
     i_ = A["body_inertia"].copy(); i_[cube_body] *= 1.4; v[2]["body_inertia"] = i_
     a_ = A["dof_armature"].copy(); a_[hand_dofs] *= 2.0; v[2]["dof_armature"] = a_
     f_ = A["dof_frictionloss"].copy(); f_ *= 0.5; v[2]["dof_frictionloss"] = f_
+    sp = A["site_pos"].copy(); sp += np.random.RandomState(0).uniform(-0.003, 0.003, sp.shape)   # RandomizedPhasespaceFingersWrapper (wrappers/dactyl.py:14-50)
+    tendon_sites = set(int(i) for i, t in zip(A["wrap_objid"], A["wrap_type"]) if int(t) == 3)   # mjWRAP_SITE: keep the tendon geometry
+    for i in tendon_sites:
+        sp[i] = A["site_pos"][i]
+    v[2]["site_pos"] = sp
     gf = A["geom_friction"].copy(); gf[:, 0] *= 1.2; gf[cube_geoms, 0] = 0.5 * A["geom_friction"][cube_geoms, 0]; gf[cube_geoms, 1] *= 2.0; v[2]["geom_friction"] = gf
     # env 3: narrower joint / tendon / control / force ranges, external wrench on the cube
     jr = A["jnt_range"].copy(); jr[10:20, 1] = jr[10:20, 0] + 0.6 * (jr[10:20, 1] - jr[10:20, 0]); v[3]["jnt_range"] = jr
@@ -42,7 +51,7 @@ def _variants(model):
 
 PARAM_OF = dict(opt_gravity="gravity", opt_timestep="timestep", dof_damping="dof_damping", dof_armature="dof_armature", dof_frictionloss="dof_frictionloss",
                 body_mass="body_mass", body_inertia="body_inertia", geom_friction="geom_friction", jnt_range="jnt_range", tendon_range="tendon_range",
-                actuator_gainprm="actuator_gainprm", actuator_forcerange="actuator_forcerange", actuator_ctrlrange="actuator_ctrlrange")
+                actuator_gainprm="actuator_gainprm", actuator_forcerange="actuator_forcerange", actuator_ctrlrange="actuator_ctrlrange", site_pos="site_pos")
 
 
 def _run(sim, model, nsteps, seed):
@@ -63,6 +72,11 @@ def _run(sim, model, nsteps, seed):
             o.sim.xfrc_applied[:] = xf.ravel()
         oras.append(o)
         for k, val in ov.items():
+            if k == "geom_rbound":
+                continue
+            if k == "geom_size":   # one size factor for the flagged geoms
+                P["geom_scale"][e] = float(val[model.name2id("geom", "cube:middle"), 0] / model.arrays["geom_size"][model.name2id("geom", "cube:middle"), 0])
+                continue
             t = torch.as_tensor(np.asarray(val, dtype=np.float32), device=sim.device)
             P[PARAM_OF[k]][e] = t.reshape(P[PARAM_OF[k]][e].shape)
     P["xfrc_applied"][3] = torch.as_tensor(xf.astype(np.float32), device=sim.device)
@@ -88,6 +102,12 @@ def _run(sim, model, nsteps, seed):
             o.env_step(a[e])
             row.append((np.abs(q[e] - o.sim.qpos)[NON_TARGET_QPOS].max(), np.abs(v[e] - o.sim.qvel).max()))
         errs.append(row)
+    # marker placement: the readout row's site positions follow the env's own site_pos
+    sx = sim.data.site_xpos.cpu().numpy().astype(np.float64)
+    for e, o in enumerate(oras):
+        o.sim.forward()
+        np.testing.assert_allclose(sx[e], o.sim.site_xpos.reshape(-1, 3), atol=5e-4 if nsteps > 4 else 5e-5)
+    assert np.abs(sx[2] - sx[0]).max() > 1e-3
     # the parameter sets really differ in their effect: the envs end up in different states from the same action
     return np.array(errs), oras
 
