@@ -6,15 +6,19 @@ What is built for this config is the physics path: model assembly exactly as `Re
 removed, 20 settling steps under the zero control), the batched simulation with the hand's action map, and the
 observation quantities of `ReachEnv._default_observation_map` (:163-174) that the physics produces (hand joint
 positions / velocities, absolute fingertip positions).  It serves as the second model through the same
-compiler -> oracle -> kernel stack and as a parity case (tests/test_reach.py).  The reach goal generator
-(a second physics simulation that samples collision-free hand poses, `FingertipPosGoal`) and the env
-bookkeeping around it are not part of this round.
+compiler -> oracle -> kernel stack and as a parity case (tests/test_reach.py).  `BatchedReachEnv` is the env proper:
+`FingertipPosGoal` (goals/shadow_hand_reach_fingertip_pos.py:10-102: a SECOND simulation with 2 mm more geom margin that
+is moved to a sampled joint pose and stepped twice so that contacts push the fingers to a reachable pose; the goal is its
+fingertip positions), `RobotEnv.step` / `reset` bookkeeping (robot_env.py:757-844) with the golden-pinned tracker, and the
+observation keys of `ReachEnv._default_observation_map`.  This config is the reference's plumbing case (B = 1, 1000 steps);
+its bookkeeping runs as `[B]` tensor ops around the physics launch, not in the fused env kernel of dactyl/locked.
 """
 import os
 
 import numpy as np
 import torch
 
+from robogym_amd import _native
 from robogym_amd.envs.dactyl.locked import FINGERTIP_SITE_NAMES, MODEL_DIR, position_to_control_matrix
 from robogym_amd.mujoco.mjcf_compiler import CompiledModel
 from robogym_amd.mujoco.mujoco_xml import MujocoXML
@@ -72,3 +76,140 @@ class ReachSimulation(BatchedSimulationInterface):
         self.set_ctrl((0.5 * (self.ctrl_lo + self.ctrl_hi)).expand(self.batch_size, -1).contiguous())
         for _ in range(nsteps):
             self.step()
+
+
+def actuated_joint_range(model: CompiledModel) -> np.ndarray:
+    """utils/dactyl_utils.py:4-14: the joint range of every joint, intersected with the control range of its actuator."""
+    A, N = model.arrays, model.names
+    lim = np.array(A["jnt_range"], dtype=np.float64).copy()
+    for u, name in enumerate(N["actuator"]):
+        j = N["joint"].index(name.replace("A_", ""))
+        lo, hi = A["actuator_ctrlrange"][u]
+        lim[j, 0] = max(lim[j, 0], lo); lim[j, 1] = min(lim[j, 1], hi); lim[j, 1] = max(lim[j, 0], lim[j, 1])
+    return lim
+
+
+def goal_simulation_model(model: CompiledModel) -> CompiledModel:
+    """ReachEnv.build_goal_generation (reach.py:176-190): the goal simulation's geoms get 2 mm more margin, "to make sure
+    fingers are separated"."""
+    from robogym_amd.mujoco.kernel_tables import derive_kernel_tables
+
+    gm = model.copy_with(geom_margin=np.asarray(model.arrays["geom_margin"]) + 0.002)
+    derive_kernel_tables(gm)
+    return gm
+
+
+class BatchedReachEnv:
+    """`ReachEnv` (reach.py:146-214) for a batch of envs; unwrapped (`make_simple_env`)."""
+
+    SUCCESS_THRESHOLD = 0.025          # ReachEnvConstants.success_threshold["fingertip_pos"] (reach.py:47)
+
+    def __init__(self, batch_size: int, device="cuda:0", model: CompiledModel = None, lib=None, mujoco_substeps: int = 10, max_timesteps_per_goal: int = 150,
+                 successes_needed: int = 50, success_reward: float = 5.0, starting_seed: int = 0, relative_action: bool = True):
+        from robogym_amd.mujoco.kernel_tables import derive_kernel_tables
+        from robogym_amd.utils.multi_goal_tracker import BatchedMultiGoalTracker
+
+        model = model if model is not None else load_reach_model()
+        if "k_dims" not in model.arrays:
+            derive_kernel_tables(model)
+        kw = dict(lib=lib) if lib is not None else dict(device=device)
+        self.mujoco_simulation = ReachSimulation(model, batch_size, n_substeps=mujoco_substeps, relative_action=relative_action, **kw)
+        self.goal_simulation = ReachSimulation(goal_simulation_model(model), batch_size, n_substeps=mujoco_substeps, relative_action=True, **kw)
+        for s_ in (self.mujoco_simulation, self.goal_simulation):
+            s_.data                                                    # switches the readout row (site positions) on for every launch
+            s_.settle(20)                                              # ReachSimulation.build: "move fingers out of the way"
+        self.sim = self.mujoco_simulation
+        self.batch_size, self.device, self.num_actions = batch_size, self.sim.device, 20
+        self.relative_action = relative_action
+        hand_j = [j for j, n in enumerate(model.names["joint"]) if n.startswith("robot0:")]
+        lim = actuated_joint_range(model)[hand_j]
+        self._jl_lo = torch.tensor(lim[:, 0], dtype=torch.float32, device=self.device)
+        self._jl_hi = torch.tensor(lim[:, 1], dtype=torch.float32, device=self.device)
+        self._p2c = torch.tensor(self.sim.pos_to_ctrl, dtype=torch.float32, device=self.device)
+        self._tips = torch.tensor(self.sim.tip_sites, dtype=torch.long, device=self.device)
+        self.goal_joint_pos = self.sim.get_qpos("hand_angle").clone()  # FingertipPosGoal.__init__: the hand's pose after the build
+        self.tracker = BatchedMultiGoalTracker(batch_size, self.device, max_timesteps_per_goal, success_reward, successes_needed)
+        self._gen = torch.Generator(device=self.device); self._gen.manual_seed(int(starting_seed))
+        self._goal = torch.zeros((batch_size, 15), device=self.device)
+        self._prev_dist = torch.zeros(batch_size, device=self.device)
+        self._draws = None
+        self.action_space = {"low": -1.0, "high": 1.0, "shape": (20,), "dtype": "float32"}
+
+    # ------------------------------------------------------------------ goal generation
+    def set_draws(self, normal: torch.Tensor):
+        """Test hook: the `[B, 24]` standard-normal draws the NEXT goal sampling uses instead of the generator's."""
+        self._draws = normal.to(self.device, torch.float32)
+
+    def fingertip_pos(self, sim=None) -> torch.Tensor:
+        """FingertipPosGoal._get_fingertip_position: absolute site positions of the five tips, flattened."""
+        sim = sim or self.sim
+        return sim.data.site_xpos[:, self._tips].reshape(self.batch_size, 15)
+
+    def _next_goal(self, mask: torch.Tensor):
+        """FingertipPosGoal.next_goal (shadow_hand_reach_fingertip_pos.py:27-73) for the envs in `mask`."""
+        B, g = self.batch_size, self.goal_simulation
+        n = self._draws if self._draws is not None else torch.randn((B, 24), generator=self._gen, device=self.device)
+        self._draws = None
+        rng = self._jl_hi - self._jl_lo
+        pose = torch.minimum(torch.maximum(self.goal_joint_pos + n * (0.1 * rng), self._jl_lo), self._jl_hi)
+        act = mask.to(torch.int32).contiguous()
+        g.set_qpos("hand_angle", pose, mask)
+        g.forward(active=act)
+        for _ in range(2):                                            # "take a few steps to avoid goals that are impossible due to contacts"
+            centre = g.get_qpos("hand_angle") @ self._p2c.T          # denormalize_position_control(zero_control(), relative_action=True)
+            ctrl = torch.minimum(torch.maximum(centre, g.ctrl_lo), g.ctrl_hi)
+            g.set_ctrl(torch.where(mask[:, None], ctrl, g.view(_native.RG_F_CTRL)))
+            g.step(active=act)
+        self.goal_joint_pos = torch.where(mask[:, None], g.get_qpos("hand_angle"), self.goal_joint_pos)
+        self._goal = torch.where(mask[:, None], self.fingertip_pos(g), self._goal)
+
+    def _reset_goal(self, mask: torch.Tensor):
+        """RobotEnv.reset_goal (robot_env.py:893-903): tracker goal counters, next goal, `_previous_goal_distance = None`,
+        `_observe_sync` (two state-less forwards, after which the goal info is recomputed: previous = current distance)."""
+        self.tracker.reset_goal_steps(mask)
+        self._next_goal(mask)
+        self.sim.forward(active=mask.to(torch.int32).contiguous(), ticks=2)
+        self._prev_dist = torch.where(mask, self.goal_distance(), self._prev_dist)
+
+    def goal_distance(self) -> torch.Tensor:
+        return (self._goal - self.fingertip_pos()).norm(dim=1)        # FingertipPosGoal.goal_distance: one L2 norm over the 15 coordinates
+
+    # ------------------------------------------------------------------ gym surface
+    def observe(self):
+        s = self.sim
+        d = self.goal_distance()
+        return {"qpos": s.get_qpos("hand_angle").clone(), "qvel": s.get_qvel("hand_angle").clone(), "fingertip_pos": self.fingertip_pos().clone(),
+                "goal_fingertip_pos": self._goal.clone(), "is_goal_achieved": (d < self.SUCCESS_THRESHOLD).to(torch.int32)[:, None]}
+
+    def reset(self, mask: torch.Tensor = None):
+        """RobotEnv.reset (robot_env.py:757-792).  ReachEnv._reset does not touch the simulation: a new episode continues from
+        the hand's current state with fresh counters and a fresh goal."""
+        mask = torch.ones(self.batch_size, dtype=torch.bool, device=self.device) if mask is None else mask.to(self.device).bool()
+        self.tracker.reset(mask)
+        self._reset_goal(mask)
+        return self.observe()
+
+    def step(self, action: torch.Tensor):
+        a = torch.as_tensor(action, dtype=torch.float32, device=self.device)
+        self.sim.env_step(action=a, nforward_ticks=3)                 # _set_action + SimulationInterface.step + the two observer forwards
+        dist = self.goal_distance()
+        goal_reward = self._prev_dist - dist
+        self._prev_dist = dist
+        success = dist < self.SUCCESS_THRESHOLD
+        reward, done, new_goal, info = self.tracker.process(success, goal_reward)
+        info["goal_dist"] = {"fingertip_pos": dist}
+        info["goal_achieved"] = success
+        if bool(new_goal.any()):
+            self._reset_goal(new_goal)
+        info["goals_so_far"] = self.tracker.goals_so_far.clone()
+        return self.observe(), reward, done, info
+
+
+def make_simple_env(batch_size: int = 1, device="cuda:0", constants=None, starting_seed=0, **kwargs):
+    """`make_simple_env` of envs/dactyl/reach.py:289 (no wrappers)."""
+    c = dict(constants or {})
+    allowed = {"mujoco_substeps", "max_timesteps_per_goal", "successes_needed", "success_reward", "relative_action"}
+    bad = set(c) - allowed
+    if bad:
+        raise NotImplementedError("reach make_simple_env(constants=%r): not supported (supported: %s)" % (sorted(bad), sorted(allowed)))
+    return BatchedReachEnv(batch_size, device=device, starting_seed=starting_seed, **c, **kwargs)
