@@ -1093,11 +1093,16 @@ __device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, const flo
   if (prof && LANE == 0) { prof[16] += (float)(rg_clock() - tb0); prof[17] += ncand; prof[18] += ncand2; }
   if (ncand2 > 4) rg_narrow_phase2<8>(c, ncand2); else rg_narrow_phase2<16>(c, ncand2);
   if (prof && LANE == 0) prof[19] += (float)(rg_clock() - tb0);
-  // plane pairs (rare: something near the floor), whole wave cooperating, one candidate at a time
-  for (int ci = 0; ci < ncand; ci++) {
+  // plane pairs (rare: something near the floor), whole wave cooperating, one pair at a time.  Which candidates are plane
+  // pairs is found lane-parallel from the pair headers (a serial scan of ~25 candidates cost two dependent loads each).
+  for (int cbase = 0; cbase < ncand; cbase += RG_WAVE) {
+  bool is_plane = false;
+  if (cbase + LANE < ncand) is_plane = ((__builtin_bit_cast(int, m.pair_rec[RG_PAIRREC * s.cand[cbase + LANE]]) >> 20) & 15) == RG_GEOM_PLANE;
+  unsigned long long plane_bits = __ballot(is_plane);
+  while (plane_bits) {
+    int ci = cbase + __builtin_ctzll(plane_bits); plane_bits &= plane_bits - 1;
     int p = s.cand[ci];
     int g1 = m.pair_geom[3 * p], g2 = m.pair_geom[3 * p + 1], dim = m.pair_geom[3 * p + 2];
-    if (m.geom_type[g1] != RG_GEOM_PLANE) continue;
     float margin = m.pair_prm[12 * p];
     int t2 = m.geom_type[g2];
     v3 p1 = ld3(s.gpos + 3 * g1), p2 = ld3(s.gpos + 3 * g2);
@@ -1121,6 +1126,7 @@ __device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, const flo
       float dist = dot(sp, n);
       if (dist <= margin) add_contact(s, p, dist, sp + p1 - n * (0.5f * dist), n, dim);
     }
+  }
   }
   SYNC();
 }
