@@ -292,6 +292,7 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
     if (!upload<int>(m, gg, &d.pair_gg) || !upload<float>(m, rec, &d.pair_rec)) return bail("hipMalloc failed", m);
   }
   UPI(tendon_adr, "tendon_adr"); UPI(tendon_num, "tendon_num"); UPI(wrap_type, "wrap_type"); UPI(wrap_objid, "wrap_objid"); UPI(ten_dofs, "k_ten_dofs");
+  UPI(ten_path, "k_ten_path"); UPI(ten_path_adr, "k_ten_path_adr");
   UPF(wrap_prm, "wrap_prm"); UPF(tendon_range, "tendon_range"); UPF(tendon_margin, "tendon_margin"); UPF(tendon_stiffness, "tendon_stiffness");
   UPF(tendon_damping, "tendon_damping"); UPF(tendon_frictionloss, "tendon_frictionloss"); UPF(tendon_lengthspring, "tendon_lengthspring");
   UPF(tendon_solref_lim, "tendon_solref_lim"); UPF(tendon_solimp_lim, "tendon_solimp_lim"); UPF(tendon_solref_fri, "tendon_solref_fri");

@@ -507,56 +507,52 @@ __device__ __forceinline__ float rg_wrap(v3& w0, v3& w1, v3 x0, v3 x1, v3 gpos, 
 // tendon lengths and Jacobians on their static dof supports; actuator lengths
 __device__ __forceinline__ void rg_tendon(RgM m, RgLds& s) {
   PFOR(t, m.ntendon) {
-    int adr = m.tendon_adr[t], num = m.tendon_num[t];
+    // the tendon's path as static 8-word records (kernel_tables.py k_ten_path): one load per stretch, no index chains
+    int r0 = m.ten_path_adr[t], r1 = m.ten_path_adr[t + 1];
     const int* td = m.ten_dofs + 4 * t;
+    int d0 = td[0], d1 = td[1], d2 = td[2], d3 = td[3];
     float J[4] = {0, 0, 0, 0}, L = 0;
-    if (m.wrap_type[adr] == RG_WRAP_JOINT) {
-      for (int w = adr; w < adr + num; w++) {
-        int j = m.wrap_objid[w], d = m.jnt_dofadr[j];
-        L += m.wrap_prm[w] * s.qpos[m.jnt_qposadr[j]];
-        for (int e = 0; e < 4; e++) if (td[e] == d) J[e] += m.wrap_prm[w];
+    for (int r = r0; r < r1; r++) {
+      const rgf4* R = (const rgf4*)m.ten_path + 2 * r;
+      rgf4 ra = R[0], rb = R[1];
+      int kind = __builtin_bit_cast(int, ra.x), w1 = __builtin_bit_cast(int, ra.y), w2 = __builtin_bit_cast(int, ra.z);
+      if ((kind & 15) == 0) {   // fixed tendon: coef * joint position
+        float coef = ra.w;
+        L += coef * s.qpos[w1];
+        for (int e = 0; e < 4; e++) if (e == w2) J[e] += coef;
+        continue;
       }
-    } else {
-      float divisor = 1, idiv = 1;
-      int w = adr;
-      while (w < adr + num - 1) {
-        int t0 = m.wrap_type[w], t1 = m.wrap_type[w + 1];
-        if (t0 == RG_WRAP_PULLEY || t1 == RG_WRAP_PULLEY) { if (t0 == RG_WRAP_PULLEY) { divisor = m.wrap_prm[w]; idiv = rg_rcp(divisor); } w++; continue; }
-        // straight segments of this stretch: site -> site, or site -> wrap entry and wrap exit -> site
-        // (named points, no indexed private arrays: those live in scratch memory)
-        int s0 = m.wrap_objid[w];
-        v3 pa = ld3(s.spos + 3 * s0), pb, pc = mk3(0, 0, 0), pd = mk3(0, 0, 0); int ba = m.site_bodyid[s0], bb, bc = 0, bd = 0;
-        bool two = false;
-        float wlen = -1;
-        if (t1 == RG_WRAP_SPHERE || t1 == RG_WRAP_CYLINDER) {
-          int g = m.wrap_objid[w + 1], s1 = m.wrap_objid[w + 2], sid = (int)m.wrap_prm[w + 1];
-          v3 x1 = ld3(s.spos + 3 * s1), w0 = mk3(0, 0, 0), w1 = mk3(0, 0, 0);
-          float gm[9]; q2mat(gm, ldq(s.gquat + 4 * g));
-          wlen = rg_wrap(w0, w1, pa, x1, ld3(s.gpos + 3 * g), gm, m.geom_size[3 * g], t1, sid >= 0, sid >= 0 ? ld3(s.spos + 3 * sid) : mk3(0, 0, 0));
-          if (wlen < 0) { pb = x1; bb = m.site_bodyid[s1]; }
-          else { pb = w0; pc = w1; pd = x1; bb = bc = m.geom_bodyid[g]; bd = m.site_bodyid[s1]; two = true; }
-          w += 2;
-        } else {
-          int s1 = m.wrap_objid[w + 1];
-          pb = ld3(s.spos + 3 * s1); bb = m.site_bodyid[s1];
-          w += 1;
-        }
-        if (wlen >= 0) L += wlen * idiv;
-        for (int seg = 0; seg < (two ? 2 : 1); seg++) {
-          v3 q0 = seg ? pc : pa, q1 = seg ? pd : pb; int b0 = seg ? bc : ba, b1 = seg ? bd : bb;
-          v3 dif = q1 - q0;
-          float dist = rg_sqrt(dot(dif, dif));
-          L += dist * idiv;
-          if (b0 != b1 && dist > 1e-15f) {
-            dif = dif * rg_rcp(dist);
-            for (int e = 0; e < 4; e++) {
-              int d = td[e];
-              if (d < 0) continue;
-              float v = 0;
-              if (in_chain(m, b1, d)) v += dot(dif, jac_col(s, d, q1 - ld3(s.org + 3 * s.b2org[b1])));
-              if (in_chain(m, b0, d)) v -= dot(dif, jac_col(s, d, q0 - ld3(s.org + 3 * s.b2org[b0])));
-              J[e] += v * idiv;
-            }
+      float idiv = ra.w, radius = rb.x; int bits = __builtin_bit_cast(int, rb.y);
+      // straight segments of this stretch: site -> site, or site -> wrap entry and wrap exit -> site
+      // (named points, no indexed private arrays: those live in scratch memory)
+      int s0 = w1 & 255, s1 = (w1 >> 8) & 255, g = (w1 >> 16) & 255, sid = (w1 >> 24) & 255;
+      int ba = w2 & 255, bs = (w2 >> 8) & 255, bg = (w2 >> 16) & 255;
+      v3 pa = ld3(s.spos + 3 * s0), x1 = ld3(s.spos + 3 * s1), pb = x1, pc = mk3(0, 0, 0), pd = mk3(0, 0, 0);
+      bool two = false;
+      float wlen = -1;
+      if ((kind & 15) == 2) {
+        v3 w0 = mk3(0, 0, 0), w1p = mk3(0, 0, 0);
+        float gm[9]; q2mat(gm, ldq(s.gquat + 4 * g));
+        wlen = rg_wrap(w0, w1p, pa, x1, ld3(s.gpos + 3 * g), gm, radius, kind >> 4, sid != 255, sid != 255 ? ld3(s.spos + 3 * sid) : mk3(0, 0, 0));
+        if (wlen >= 0) { pb = w0; pc = w1p; pd = x1; two = true; L += wlen * idiv; }
+      }
+      for (int seg = 0; seg < (two ? 2 : 1); seg++) {
+        v3 q0 = seg ? pc : pa, q1 = seg ? pd : pb;
+        int k0 = seg ? 2 : 0, k1 = two ? (seg ? 1 : 2) : 1;      // which of (ba, bs, bg) the segment's end points ride on
+        int b0 = seg ? bg : ba, b1 = two ? (seg ? bs : bg) : bs;
+        v3 dif = q1 - q0;
+        float dist = rg_sqrt(dot(dif, dif));
+        L += dist * idiv;
+        if (b0 != b1 && dist > 1e-15f) {
+          dif = dif * rg_rcp(dist);
+          v3 o0 = q0 - ld3(s.org + 3 * s.b2org[b0]), o1 = q1 - ld3(s.org + 3 * s.b2org[b1]);
+          for (int e = 0; e < 4; e++) {
+            int d = e == 0 ? d0 : (e == 1 ? d1 : (e == 2 ? d2 : d3));
+            if (d < 0) continue;
+            float v = 0;
+            if ((bits >> (3 * e + k1)) & 1) v += dot(dif, jac_col(s, d, o1));
+            if ((bits >> (3 * e + k0)) & 1) v -= dot(dif, jac_col(s, d, o0));
+            J[e] += v * idiv;
           }
         }
       }

@@ -129,6 +129,7 @@ struct RgModelDev {
   const float* pair_prm;  // [npair][12] margin, gap, friction3, solref2, solimp5
   // tendons
   const int *tendon_adr, *tendon_num, *wrap_type, *wrap_objid, *ten_dofs;
+  const int *ten_path, *ten_path_adr;   // per tendon: 8-word path records (kernel_tables.py k_ten_path), [ntendon + 1] offsets
   const float *wrap_prm, *tendon_range, *tendon_margin, *tendon_stiffness, *tendon_damping, *tendon_frictionloss,
       *tendon_lengthspring, *tendon_solref_lim, *tendon_solimp_lim, *tendon_solref_fri, *tendon_solimp_fri, *tendon_invweight0;
   const int *dof_ten_adr, *dof_ten, *dof_act_adr, *dof_act;

@@ -257,6 +257,51 @@ def derive_kernel_tables(model, max_row_nnz=16):
             raise NotImplementedError("tendon %d touches %d dofs (>4)" % (t, len(support)))
         tdofs[t, : len(support)] = support
     A["k_ten_dofs"] = tdofs
+    # per tendon: its path as a list of 8-word records, so that the tendon stage reads ONE record per stretch instead of walking
+    # wrap_type -> wrap_objid -> site_bodyid -> body_dofmask chains of dependent loads:
+    #   joint term      : [0, qposadr, slot of the dof in k_ten_dofs, coef]
+    #   site -> site    : [1, s0 | s1 << 8 | 255 << 16 | 255 << 24, ba | bb << 8, 1 / divisor, 0, chain bits]
+    #   site -> (wrap geom) -> site : [2 | geom wrap type << 4, s0 | s1 << 8 | g << 16 | sidesite << 24, ba | bb << 8 | bg << 16, 1 / divisor, radius, chain bits]
+    # chain bits: bit 3 e + k = "dof k_ten_dofs[t][e] moves body k" (k = 0: ba, 1: bb, 2: bg).  Floats are stored by bit pattern.
+    f2i = lambda x: int(np.float32(x).view(np.int32))
+    recs, radr = [], [0]
+    for t in range(nt):
+        adr, num = int(A["tendon_adr"][t]), int(A["tendon_num"][t])
+        td = [int(d) for d in tdofs[t]]
+        if A["wrap_type"][adr] == C.WRAP_JOINT:
+            for w in range(adr, adr + num):
+                j = int(A["wrap_objid"][w]); d = int(A["jnt_dofadr"][j])
+                recs.append([0, int(A["jnt_qposadr"][j]), td.index(d), f2i(A["wrap_prm"][w]), 0, 0, 0, 0])
+        else:
+            divisor, w = 1.0, adr
+            while w < adr + num - 1:
+                t0, t1 = int(A["wrap_type"][w]), int(A["wrap_type"][w + 1])
+                if t0 == C.WRAP_PULLEY or t1 == C.WRAP_PULLEY:
+                    if t0 == C.WRAP_PULLEY:
+                        divisor = float(A["wrap_prm"][w])
+                    w += 1
+                    continue
+                s0 = int(A["wrap_objid"][w]); ba = int(A["site_bodyid"][s0])
+                if t1 in (C.WRAP_SPHERE, C.WRAP_CYLINDER):
+                    g, s1, sid = int(A["wrap_objid"][w + 1]), int(A["wrap_objid"][w + 2]), int(A["wrap_prm"][w + 1])
+                    kind, bg, radius = 2 | (t1 << 4), int(A["geom_bodyid"][g]), float(A["geom_size"][g][0])
+                    w += 2
+                else:
+                    g, s1, sid, kind, bg, radius = 255, int(A["wrap_objid"][w + 1]), -1, 1, 0, 0.0
+                    w += 1
+                bb = int(A["site_bodyid"][s1])
+                bits = 0
+                for e, d in enumerate(td):
+                    if d >= 0:
+                        for k, b in enumerate((ba, bb, bg)):
+                            if (int(mask[b]) >> d) & 1:
+                                bits |= 1 << (3 * e + k)
+                if max(s0, s1, g if g != 255 else 0, max(sid, 0)) > 254 or max(ba, bb, bg) > 255:
+                    raise NotImplementedError("tendon path record: index beyond 8 bits")
+                recs.append([kind, s0 | (s1 << 8) | (g << 16) | ((sid if sid >= 0 else 255) << 24), ba | (bb << 8) | (bg << 16), f2i(1.0 / divisor), f2i(radius), bits, 0, 0])
+        radr.append(len(recs))
+    A["k_ten_path"] = np.array(recs, dtype=np.int64).astype(np.uint32).view(np.int32).reshape(-1, 8) if recs else np.zeros((0, 8), np.int32)
+    A["k_ten_path_adr"] = _i32(radr)
     # per-dof gather lists: (tendon, slot)
     adr, flat = [0], []
     for i in range(nv):
