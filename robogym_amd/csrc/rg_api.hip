@@ -263,8 +263,9 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
   UPI(pair_geom, "k_pair_geom"); UPF(pair_prm, "k_pair_prm");
   {  // pair records: w0 g1 | g2<<8 | condim<<16 | type1<<20 | type2<<24, w1 margin, w2/w3 mesh ids (-1: none),
      // w4-6 size1, w7 nvert1, w8-10 size2, w11 nvert2, w12/w13 first vertex of the meshes, w14/w15 bounding radii,
-     // w16-18 / w20-22 box half extents of the geoms (geom frame)
-    std::vector<int> pg, gt, gd, va, vn; std::vector<float> pp, gs, gr, ga;
+     // w16-18 / w20-22 box half extents of the geoms (geom frame), w19 body1 | body2 << 8, w23 / w24 union of the two bodies' dof masks
+    std::vector<int> pg, gt, gd, va, vn, gb, bdm; std::vector<float> pp, gs, gr, ga;
+    if (!get_i(B, "geom_bodyid", gb, e) || !get_i(B, "k_body_dofmask", bdm, e)) return bail(e, m);
     if (!get_i(B, "k_pair_geom", pg, e) || !get_i(B, "geom_type", gt, e) || !get_i(B, "geom_dataid", gd, e) || !get_i(B, "mesh_vertadr", va, e) || !get_i(B, "mesh_vertnum", vn, e) ||
         !get_f(B, "k_pair_prm", pp, e) || !get_f(B, "geom_size", gs, e) || !get_f(B, "geom_rbound", gr, e) || !get_f(B, "k_geom_aabb", ga, e)) return bail(e, m);
     std::vector<int> gsc;   // optional: geoms whose size follows the env's RG_PRM_GEOM_SCALE (boxes only: the bounds scale exactly)
@@ -288,6 +289,9 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
         memcpy(r + 7 + 4 * k, &nvert, 4); memcpy(r + 12 + k, &vadr0, 4);
         r[14 + k] = gr[g[k]];
       }
+      int b1 = gb[g[0]], b2 = gb[g[1]], bb = b1 | (b2 << 8), lo = bdm[2 * b1] | bdm[2 * b2], hi = bdm[2 * b1 + 1] | bdm[2 * b2 + 1];
+      if (b1 > 255 || b2 > 255) return bail("pair body id out of range", m);
+      memcpy(r + 19, &bb, 4); memcpy(r + 23, &lo, 4); memcpy(r + 24, &hi, 4);
     }
     if (!upload<int>(m, gg, &d.pair_gg) || !upload<float>(m, rec, &d.pair_rec)) return bail("hipMalloc failed", m);
   }

@@ -1307,11 +1307,10 @@ __device__ __forceinline__ int nbasis(int dim) { return dim >= 4 ? 4 : (dim == 1
 __device__ __forceinline__ void rg_make_constraint(RgM m, RgLds& s, const float* P) {
   // contact basis Jacobians on the merged dof chains, packed into a shared pool (rows x nnz per contact)
   int ncon = s.ncon;
+  // (bodies and the union of their dof masks come from the pair record: one load latency instead of pair -> geom -> body -> mask)
   PFOR(c, ncon) {
-    int p = s.c_pair[c];
-    int b1 = m.geom_bodyid[m.pair_geom[3 * p]], b2 = m.geom_bodyid[m.pair_geom[3 * p + 1]];
-    int nnz = __popc(m.body_dofmask[2 * b1] | m.body_dofmask[2 * b2]) + __popc(m.body_dofmask[2 * b1 + 1] | m.body_dofmask[2 * b2 + 1]);
-    s.c_nnz[c] = nnz;
+    const float* R = m.pair_rec + RG_PAIRREC * s.c_pair[c];
+    s.c_nnz[c] = __popc(__builtin_bit_cast(uint32_t, R[23])) + __popc(__builtin_bit_cast(uint32_t, R[24]));
   }
   SYNC();
   {
@@ -1324,8 +1323,9 @@ __device__ __forceinline__ void rg_make_constraint(RgM m, RgLds& s, const float*
   for (int w = LANE; w < ncon * RG_W; w += RG_WAVE) {
     int c = w / RG_W, sl = w - c * RG_W, p = s.c_pair[c], nnz = s.c_nnz[c];
     if (sl >= nnz) continue;
-    int b1 = m.geom_bodyid[m.pair_geom[3 * p]], b2 = m.geom_bodyid[m.pair_geom[3 * p + 1]];
-    uint32_t lo = m.body_dofmask[2 * b1] | m.body_dofmask[2 * b2], hi = m.body_dofmask[2 * b1 + 1] | m.body_dofmask[2 * b2 + 1];
+    const float* R = m.pair_rec + RG_PAIRREC * p;
+    int bb = __builtin_bit_cast(int, R[19]), b1 = bb & 255, b2 = bb >> 8;
+    uint32_t lo = __builtin_bit_cast(uint32_t, R[23]), hi = __builtin_bit_cast(uint32_t, R[24]);
     int k = sl; uint32_t bits = lo; int base = 0;   // sl-th set bit of (hi:lo)
     if (k >= __popc(lo)) { k -= __popc(lo); bits = hi; base = 32; }
     for (int q = 0; q < k; q++) bits &= bits - 1;
@@ -1346,13 +1346,13 @@ __device__ __forceinline__ void rg_make_constraint(RgM m, RgLds& s, const float*
   PFOR(c, ncon) {
     int p = s.c_pair[c], dim = s.c_dim[c];
     const float* prm = m.pair_prm + 12 * p;
-    int b1 = m.geom_bodyid[m.pair_geom[3 * p]], b2 = m.geom_bodyid[m.pair_geom[3 * p + 1]];
+    const int hdr = __builtin_bit_cast(int, m.pair_rec[RG_PAIRREC * p]), bb = __builtin_bit_cast(int, m.pair_rec[RG_PAIRREC * p + 19]), b1 = bb & 255, b2 = bb >> 8;
     float tran = P[RG_PRM_BODY_INVWEIGHT0 + 2 * b1] + P[RG_PRM_BODY_INVWEIGHT0 + 2 * b2];
     float includemargin = prm[0] - prm[1], dist = s.c_dist[c];
     float imp = impedance(prm + 7, dist, includemargin), K, B;
     kb(P[RG_PRM_TIMESTEP], prm + 5, prm + 7, K, B);
     // friction of the pair: element-wise max of its geoms' (engine_collision_driver: mj_contactParam)
-    const int pg1 = m.pair_geom[3 * p], pg2 = m.pair_geom[3 * p + 1];
+    const int pg1 = hdr & 255, pg2 = (hdr >> 8) & 255;
     const float fr_slide = fmaxf(P[RG_PRM_GEOM_FRICTION + 3 * pg1], P[RG_PRM_GEOM_FRICTION + 3 * pg2]), fr_spin = fmaxf(P[RG_PRM_GEOM_FRICTION + 3 * pg1 + 1], P[RG_PRM_GEOM_FRICTION + 3 * pg2 + 1]);
     float mu0 = fr_slide;  // friction[0]
     // first pyramid row: diagApprox = tran + mu0^2 * tran ; all rows get R = 2 mu^2 R_first, mu = friction[0]/sqrt(impratio)

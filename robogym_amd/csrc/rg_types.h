@@ -23,7 +23,7 @@
 #define RG_LTDL_TRI_ROUNDS 12   // caps on the descriptor rounds of the L'DL passes (registers per lane)
 #define RG_LTDL_PAIR_ROUNDS 8
 #define RG_KINREC 20    // words per kinematics record
-#define RG_PAIRREC 24   // words per pair record
+#define RG_PAIRREC 28   // words per pair record
 #define RG_PAIR_SCALED1 (1 << 28)   // pair record header: geom 1 / geom 2 takes the env's RG_PRM_GEOM_SCALE
 #define RG_PAIR_SCALED2 (1 << 29)
 #define RG_TLIST 320    // pairs whose distance bound ran out, queued for the sphere/box tests (drained in chunks)
