@@ -88,7 +88,10 @@ int rg_prm_layout(int* out, int n);
 int rg_batch_set_env(rg_batch* b, const int* ints, int nints, const float* pos_to_ctrl_host, float success_threshold);
 
 /* MjSim.reset / set_state / get_state (simulation_interface.py:154-172,191-197).
- * to_batch != 0 copies ptr -> batch field, else batch field -> ptr; ptr_is_device selects HBM vs host. */
+ * to_batch != 0 copies ptr -> batch field, else batch field -> ptr; ptr_is_device selects HBM vs host.
+ * Both are slow-path, synchronous calls: they wait for all work queued on the device (whatever the stream) and return when
+ * the copy is complete, so they are ordered with step launches on any stream.  The hot path writes rows through
+ * rg_batch_field_ptr views / rg_batch_copy_rows (stream-ordered, asynchronous). */
 int rg_batch_copy(rg_batch* b, int field, void* ptr, int to_batch, int ptr_is_device);
 int rg_batch_reset(rg_batch* b);
 /* Masked row copy, device to device and asynchronous on `stream`: for every env e with mask_dev[e] != 0 the

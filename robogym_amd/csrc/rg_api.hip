@@ -48,6 +48,7 @@ static hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s
 static hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return 0; }
 static hipError_t hipSetDevice(int) { return 0; }
 static hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+static hipError_t hipDeviceSynchronize() { return 0; }
 static const char* hipGetErrorString(hipError_t) { return "emul"; }
 #endif
 
@@ -395,6 +396,7 @@ int rg_batch_reset(rg_batch* b) {
   DeviceGuard g(b->device);
   const RgModelDev& d = b->model->dev;
   RgBatchDev& s = b->dev;
+  HIPCHK(hipDeviceSynchronize());   // slow-path call: ordered after everything queued on any stream (step launches run on the caller's streams)
   std::vector<float> q((size_t)s.B * d.nq);
   for (int e = 0; e < s.B; e++) memcpy(q.data() + (size_t)e * d.nq, b->model->qpos0.data(), d.nq * 4);
   HIPCHK(hipMemcpy(s.qpos, q.data(), q.size() * 4, hipMemcpyHostToDevice));
@@ -489,6 +491,7 @@ int rg_batch_copy(rg_batch* b, int field, void* ptr, int to_batch, int ptr_is_de
   size_t n = 0; void* p = field_ptr(b, field, &n);
   if (!p) return fail("rg_batch_copy: unknown field");
   size_t bytes = n * 4 * (size_t)s.B;
+  HIPCHK(hipDeviceSynchronize());   // slow-path call: ordered after everything queued on any stream (the blocking copies below then complete before it returns)
   if (to_batch) {
     HIPCHK(hipMemcpy(p, ptr, bytes, ptr_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
     // positions changed behind the kernel's back: the cached pair distance bounds are void
