@@ -54,7 +54,7 @@ def kernel_source_hash():
     import hashlib
 
     h = hashlib.sha256()
-    for f in ("rg_kernel.h", "rg_api.hip", "rg_types.h"):
+    for f in ("rg_kernel.h", "rg_env_kernel.h", "rg_api.hip", "rg_types.h", "Makefile"):
         h.update(open(os.path.join(ROOT, "robogym_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
