@@ -73,7 +73,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
+    # RG_BENCH_FORCE_DIST=1: take the distributed branch (process group, barriers, all-gather, max-reduce) even with one rank, so the
+    # RCCL code path can be executed on a 1-GPU box: torchrun --nproc-per-node 1 bench.py --gpus 1
+    distributed = world > 1 or os.environ.get("RG_BENCH_FORCE_DIST") == "1"
     # TEST HOOK (tests/test_distributed.py): run this very code path on CPU, 2 ranks, gloo, kernel source on the emulation harness
     emul_path = os.environ.get("RG_BENCH_EMUL_LIB")
     lib = None

@@ -6,6 +6,8 @@ torch.distributed's "nccl" backend; "gloo" on CPU for tests) for a learner that 
 batch on every rank."""
 from typing import Optional
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -20,12 +22,15 @@ class ShardedObservationGather:
         self._staging: Optional[torch.Tensor] = None
         self._work = None
         self._last: Optional[torch.Tensor] = None
-        if self.world > 1:
+        # RG_BENCH_FORCE_DIST=1 (with an initialised process group): run the collective even with one rank, so the RCCL path can be
+        # executed on a single-GPU box
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("RG_BENCH_FORCE_DIST") == "1")
+        if self.active:
             self.buffer = torch.empty((self.world * local_batch, obs_dim), dtype=torch.float32, device=device)
 
     def __call__(self, local_obs_rows: torch.Tensor) -> torch.Tensor:
         """[B, obs_dim] on this rank -> [world*B, obs_dim] on every rank (rank-major order)."""
-        if self.world == 1:
+        if not self.active:
             return local_obs_rows
         dist.all_gather_into_tensor(self.buffer, local_obs_rows.contiguous(), group=self.group)
         return self.buffer
@@ -34,7 +39,7 @@ class ShardedObservationGather:
         """Overlapped variant: snapshot the rows into a staging buffer (so the next env.step may overwrite the
         live buffer) and start the all-gather without making the compute stream wait for it; `finish()` returns
         the gathered tensor of the PREVIOUS `start()`.  At most one gather is in flight."""
-        if self.world == 1:
+        if not self.active:
             self._last = local_obs_rows
             return
         self.finish()
@@ -44,7 +49,7 @@ class ShardedObservationGather:
         self._work = dist.all_gather_into_tensor(self.buffer, self._staging, group=self.group, async_op=True)
 
     def finish(self) -> Optional[torch.Tensor]:
-        if self.world == 1:
+        if not self.active:
             return self._last
         if self._work is not None:
             self._work.wait()
