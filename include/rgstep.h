@@ -117,6 +117,10 @@ int rg_batch_copy_rows(rg_batch* b, int field, const void* src_dev, const int* m
  *                      each substep; results are bit-identical either way — test hook for that claim)
  *                bit3: hull support points by scanning every vertex instead of the per-direction-cell
  *                      candidate lists (bit-identical as well; test hook)
+ *                bit4: contact depth / normal of convex pairs from the final MPR portal's PLANE instead of libccd's closest
+ *                      point on the final portal TRIANGLE (the default, = MuJoCo 2.0's mjc_Convex).  The two agree whenever
+ *                      the origin projects inside the triangle; the plane variant does not depend on the rounding-level
+ *                      tie breaks that pick the triangle on flat contacts.
  *   stream       hipStream_t (NULL = default stream).  Asynchronous. */
 int rg_batch_step(rg_batch* b, const float* action_dev, const float* goal_quat_dev, float* obs_dev, float* goal_dist_dev,
                   const int* active_dev, int nsubsteps, int nforward_ticks, int flags, void* stream);

@@ -601,7 +601,7 @@ struct SupPt { v3 v, s; };  // v = v1 - v2 (Minkowski difference), s = v1 + v2 (
 // per-query (lane-varying) description of one geom, and the wave-uniform tables every query shares: keeping the
 // 64-bit table pointers out of MprGeom keeps them in SGPRs (the narrowphase is the register-hungriest stage)
 struct MprGeom { int type; const float* quat; v3 pos; v3 size; int vertadr, nvert, mesh; float margin; };   // quat: the geom's orientation in LDS (16-byte aligned)   // mesh: id, -1 for primitives
-struct MprEnv { const float* mesh_vert; const int* cell_adr; const rgf4 *cell_blk, *cell_ovf; float* prof; bool cells; };
+struct MprEnv { const float* mesh_vert; const int* cell_adr; const rgf4 *cell_blk, *cell_ovf; float* prof; bool cells; bool plane_depth; };
 
 // per-lane scan of a hull's vertices: 16-byte records (one dwordx4 load per vertex), four independent
 // loads in flight per lane; out-of-range slots re-read the last vertex (harmless for a max).
@@ -827,8 +827,13 @@ template <int G> __device__ __forceinline__ bool rg_mpr(const MprEnv& E, const M
       } else if (reach || guard > max_iter) {
         // depth / direction from the portal PLANE (not libccd's closest point on the final portal triangle,
         // whose choice among the triangles of a flat supporting plane is rounding noise; see DESIGN.md "MPR")
-        depth = fmaxf((dot(p1.v, dir) + dot(p2.v, dir) + dot(p3.v, dir)) * (1.0f / 3.0f), 0.f);
-        dir_out = dir;
+        if (E.plane_depth) {
+          depth = fmaxf((dot(p1.v, dir) + dot(p2.v, dir) + dot(p3.v, dir)) * (1.0f / 3.0f), 0.f);
+          dir_out = dir;
+        } else {   // libccd verbatim (what MuJoCo 2.0's mjc_Convex runs): the closest point of the final portal triangle to the origin
+          v3 w; depth = sqrtf(origin_tri_dist2(p1.v, p2.v, p3.v, w));
+          dir_out = mz(depth) ? mk3(0, 0, 0) : w * (1.0f / depth);
+        }
         // contact position from the barycentric coordinates of the origin in the portal tetrahedron
         float b0 = dot(cross(p1.v, p2.v), p3.v), b1 = dot(cross(p3.v, p2.v), p0.v);
         float b2 = dot(cross(p0.v, p1.v), p3.v), b3 = dot(cross(p2.v, p1.v), p0.v);
@@ -904,7 +909,7 @@ __device__ __forceinline__ void add_contact(RgLds& s, int pair, float dist, v3 p
 __device__ __forceinline__ MprEnv rg_mpr_env(RgM m, float* prof, bool cells) {
   MprEnv E;
   E.mesh_vert = m.mesh_vert; E.cell_adr = m.mesh_cell_adr; E.cell_blk = (const rgf4*)m.mesh_cell_blk; E.cell_ovf = (const rgf4*)m.mesh_cell_ovf;
-  E.prof = prof; E.cells = cells;
+  E.prof = prof; E.cells = cells; E.plane_depth = false;
   return E;
 }
 __device__ __forceinline__ void rg_mpr_geoms(RgM m, const RgLds& s, int p, float gscale, MprGeom& A, MprGeom& B, int& dim, float& margin) {
@@ -964,6 +969,7 @@ template <int G> RG_STAGE_BIG void rg_narrow_phase2(RgCtx c, int ncand2) {
   rgf4* sepdir = L.bt.sepdir ? (rgf4*)L.bt.sepdir + (size_t)rg_env(L) * m.npair : (rgf4*)0;
   const float gscale = rg_prm(m, L)[RG_PRM_GEOM_SCALE];
   MprEnv E = rg_mpr_env(m, prof, cells);
+  E.plane_depth = (L.flags & 16) != 0;
   for (int base = 0; base < ncand2; base += RG_WAVE / G) {
     int ci = base + LANE / G;
     bool hit = false;
@@ -2208,6 +2214,7 @@ __global__ void __launch_bounds__(RG_WAVE) rg_mpr_pair_kernel(const RgModelDev* 
   if (A.type == RG_GEOM_MESH) { A.mesh = m.geom_dataid[g1]; A.vertadr = m.mesh_vertadr[A.mesh]; A.nvert = m.mesh_vertnum[A.mesh]; }
   if (B.type == RG_GEOM_MESH) { B.mesh = m.geom_dataid[g2]; B.vertadr = m.mesh_vertadr[B.mesh]; B.nvert = m.mesh_vertnum[B.mesh]; }
   MprEnv E = rg_mpr_env(m, (float*)0, true);   // the hook exercises the cell-list supports
+  E.plane_depth = true;
   float depth = 0; v3 dir = mk3(0, 0, 0), pos = mk3(0, 0, 0);
   v3 sep; bool hit = rg_mpr<64>(E, A, B, m.mpr_iterations, m.mpr_tolerance, depth, dir, pos, sep, true);
   if (LANE == 0) {

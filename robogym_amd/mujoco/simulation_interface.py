@@ -4,6 +4,7 @@ leading env-batch dimension on every array and state living in HBM inside the HI
 (C ABI: include/rgstep.h).  One `BatchedSimulationInterface` stands for B independent
 (model, MjSim) pairs of the reference (robot_env.py:328-350)."""
 import ctypes
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -12,6 +13,11 @@ import torch
 from robogym_amd import _native
 from robogym_amd.mujoco.kernel_tables import derive_kernel_tables
 from robogym_amd.mujoco.model_blob import pack_model
+
+#: Contact depth / normal of convex pairs.  False (default): libccd's formula, which is what MuJoCo 2.0 runs (closest point of the final
+#: MPR portal triangle).  True: the portal-plane variant (rg_step_args.flags bit 4) — identical whenever the origin projects inside the
+#: final triangle, and free of libccd's rounding-level tie breaks on flat contacts; the tight-tolerance parity tests use it on both sides.
+MPR_PLANE_DEPTH = os.environ.get("RG_MPR_PLANE", "0") == "1"
 
 
 class BatchedSimulationInterface:
@@ -254,7 +260,7 @@ class BatchedSimulationInterface:
         a.hold_dev, a.nticks_dev, a.order_dev, a.preticks_dev = (None if t is None else t.data_ptr() for t in (hold, nticks, order, preticks))
         a.xdata_dev = None if self._xdata is None else self._xdata.data_ptr()
         a.nsubsteps = self.n_substeps if nsubsteps is None else int(nsubsteps)
-        a.nforward_ticks, a.flags = int(nforward_ticks), int(flags)
+        a.nforward_ticks, a.flags = int(nforward_ticks), int(flags) | (_native.RG_FLAG_MPR_PLANE_DEPTH if MPR_PLANE_DEPTH else 0)
         self._keep.append((action, goal_quat, obs, goal_dist, active, hold, nticks, order, large_mask))
         del self._keep[:-16]
 

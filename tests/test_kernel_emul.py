@@ -145,11 +145,14 @@ def test_model_blob_is_validated(emul_lib, locked_model):
     emul_lib.rg_model_free(h)
 
 
-def test_deviation_from_mujoco_restatement(pair, oracle_lib):
-    """CPU twin of test_deviation_from_mujoco_restatement_gpu: the kernel source against the oracle's default
-    (libccd MPR depth) configuration; the deviation on flat contacts is the kernel's documented one."""
+def test_distance_to_mujoco_restatement(pair, oracle_lib):
+    """CPU twin of test_distance_to_mujoco_restatement_gpu: the kernel source in its default configuration (libccd contact
+    depth) against the oracle's default configuration."""
+    from robogym_amd.mujoco import simulation_interface
+
     sim, ora = pair
     oracle_lib.set_kernel_variant(False)
+    simulation_interface.MPR_PLANE_DEPTH = False
     ora.sim.reset(); ora.settle(40)
     rng = np.random.RandomState(5)
     errs = resync_errors(sim, ora, rng.uniform(-1, 1, (4, 20)))

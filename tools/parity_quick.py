@@ -9,6 +9,8 @@ from oracle.env_oracle import OracleLockedEnvPhysics
 from robogym_amd.envs.dactyl.locked import LockedSimulation, load_locked_model
 from tests.helpers import resync_errors
 rg_oracle.set_kernel_variant(True)
+from robogym_amd.mujoco import simulation_interface  # noqa: E402
+simulation_interface.MPR_PLANE_DEPTH = True
 model = load_locked_model()
 ora = OracleLockedEnvPhysics(model); ora.sim.reset(); ora.settle(30)
 sim = LockedSimulation(model, 1, device="cuda:0")

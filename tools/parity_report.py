@@ -19,13 +19,15 @@ from tests.helpers import NON_TARGET_QPOS, resync_errors, sync_state_from_oracle
 n_streams = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 n_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 from oracle import rg_oracle  # noqa: E402
+from robogym_amd.mujoco import simulation_interface  # noqa: E402
 
 model = load_locked_model()
 for kernel_variant in (True, False):
     rg_oracle.set_kernel_variant(kernel_variant)
+    simulation_interface.MPR_PLANE_DEPTH = kernel_variant
     print("=" * 110)
-    print("ORACLE = %s" % ("KERNEL VARIANT (portal-plane MPR depth, box-box through MPR): does the kernel compute what it says"
-                           if kernel_variant else "DEFAULT (libccd triangle-distance MPR depth, multi-point box-box): distance to the MuJoCo restatement, documented deviations included"))
+    print("ORACLE = %s" % ("PORTAL-PLANE contact depth on both sides (kernel flags bit 4; oracle: set_kernel_variant, box-box through MPR): does the kernel compute what it says, at fp32 tolerance"
+                           if kernel_variant else "DEFAULT on both sides (product: libccd contact depth, box-box through MPR; oracle: libccd depth, multi-point box-box): distance of the product to the MuJoCo restatement"))
     marks = [1, 10, 100, 1000]
     print("free-running drift, kernel (fp32, MI355X) vs oracle (fp64, CPU), dactyl/locked, iid U(-1,1) relative actions, same bytes at step 0")
     print("stream  " + "  ".join("Linf@%-5d" % m for m in marks) + "  first step with Linf > 1e-4   contacts/substep")
