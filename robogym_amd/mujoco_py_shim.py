@@ -1,0 +1,225 @@
+"""A `mujoco_py`-shaped view of ONE env of the batched stepper (seam B1): what robogym's in-tree code touches of
+`mujoco_py` — `load_model_from_xml`, `MjSim{step, forward, reset, set_constants, get_state, set_state, nsubsteps, model, data}`,
+`MjSimState`, `cymj.set_pid_control`, `const` (mujoco/mujoco_xml.py:5,38,259; mujoco/simulation_interface.py:5,80-88,
+176-207; robot/shadow_hand/mujoco/mujoco_shadow_hand.py:18-156) — so that single-env reference code and tests can be ported
+line by line.  Not the fast path: `MjSim.data` / `MjSim.model` hold host numpy arrays with mujoco_py's names and shapes;
+`step()` / `forward()` upload what the caller may have written (state, ctrl, xfrc_applied, the model fields below), run the
+HIP kernel for a batch of one, and download the results IN PLACE (references to the arrays stay valid, as with mujoco_py's
+views of mjData).
+
+Model fields the kernel reads per env, hence writable here (`sim.model.<name>[...] = ...` takes effect at the next step):
+opt.gravity, opt.timestep, dof_damping, dof_armature, dof_frictionloss, body_mass, body_inertia, jnt_range, tendon_range,
+actuator_gainprm, actuator_ctrlrange, actuator_forcerange, geom_friction, site_pos.  Every other model array is READ-ONLY
+(numpy raises on assignment) rather than silently ignored.  After mass / inertia / armature writes call
+`sim.set_constants()` as the reference does (cube_env.py:349).
+"""
+import collections
+import types
+from typing import Optional
+
+import numpy as np
+import torch
+
+from robogym_amd import _native
+from robogym_amd.mujoco.kernel_tables import derive_kernel_tables
+from robogym_amd.mujoco.mjcf_compiler import CompiledModel
+from robogym_amd.mujoco.mujoco_xml import MujocoXML
+from robogym_amd.mujoco.simulation_interface import BatchedSimulationInterface
+
+MjSimState = collections.namedtuple("MjSimState", "time qpos qvel act udd_state")   # mujoco_py.MjSimState
+
+#: mujoco_py.const / mujoco_py.generated.const: the enum values in-tree code names (mjtGain, mjtBias, mjtJoint, mjtGeom, mjtObj)
+const = types.SimpleNamespace(GAIN_FIXED=0, GAIN_USER=2, BIAS_NONE=0, BIAS_AFFINE=1, BIAS_USER=2, JNT_FREE=0, JNT_BALL=1, JNT_SLIDE=2, JNT_HINGE=3,
+                              GEOM_PLANE=0, GEOM_SPHERE=2, GEOM_CAPSULE=3, GEOM_ELLIPSOID=4, GEOM_CYLINDER=5, GEOM_BOX=6, GEOM_MESH=7,
+                              OBJ_BODY=1, OBJ_JOINT=3, OBJ_GEOM=5, OBJ_SITE=6)
+#: mujoco_py.cymj: the PID controller is part of the stepper; installing it is a no-op (simulation_interface.py:86-88)
+cymj = types.SimpleNamespace(set_pid_control=lambda model, data: None)
+
+_WRITABLE = {"dof_damping": "dof_damping", "dof_armature": "dof_armature", "dof_frictionloss": "dof_frictionloss", "body_mass": "body_mass",
+             "body_inertia": "body_inertia", "jnt_range": "jnt_range", "tendon_range": "tendon_range", "actuator_gainprm": "actuator_gainprm",
+             "actuator_ctrlrange": "actuator_ctrlrange", "actuator_forcerange": "actuator_forcerange", "geom_friction": "geom_friction", "site_pos": "site_pos"}
+_KINDS = ("body", "joint", "geom", "site", "actuator", "tendon", "sensor")
+
+
+class _Opt:
+    def __init__(self, arrays):
+        self.gravity = np.array(arrays["opt_gravity"], dtype=np.float64)
+        self.timestep = float(arrays["opt_timestep"][0])
+
+
+class PyMjModel:
+    """The fields of mujoco_py's PyMjModel that exist in the compiled model, under mujoco_py's names."""
+
+    def __init__(self, compiled: CompiledModel):
+        if "k_dims" not in compiled.arrays:
+            derive_kernel_tables(compiled)
+        self._compiled = compiled
+        A, d = compiled.arrays, compiled.arrays["dims"]
+        self.nq, self.nv, self.nu, self.nbody, self.njnt, self.ngeom, self.nsite, self.ntendon = (int(d[i]) for i in range(8))
+        self.opt = _Opt(A)
+        for name, arr in A.items():
+            if name.startswith(("k_", "opt_", "dims", "mesh_", "names_")):
+                continue
+            a = np.array(arr)
+            if name == "actuator_gainprm":
+                a = a[:, :10].copy()
+            if name not in _WRITABLE:
+                a.flags.writeable = False
+            setattr(self, name, a)
+        for kind in _KINDS:
+            names = list(compiled.names.get(kind, []))
+            setattr(self, kind + "_names", tuple(names))
+            setattr(self, kind + "_name2id", (lambda names, kind: (lambda n: self._lookup(names, kind, n)))(names, kind))
+            setattr(self, kind + "_id2name", (lambda names: (lambda i: names[i]))(names))
+
+    @staticmethod
+    def _lookup(names, kind, name):
+        if name not in names:
+            raise ValueError('No "%s" with name %s exists. Available "%s" names = %s.' % (kind, name, kind, tuple(names)))
+        return names.index(name)
+
+    def get_joint_qpos_addr(self, name):
+        """mujoco_py: an int for hinge / slide joints, a (start, end) tuple for free / ball joints."""
+        j = self.joint_name2id(name)
+        adr, t = int(self.jnt_qposadr[j]), int(self.jnt_type[j])
+        return adr if t in (const.JNT_SLIDE, const.JNT_HINGE) else (adr, adr + (7 if t == const.JNT_FREE else 4))
+
+    def get_joint_qvel_addr(self, name):
+        j = self.joint_name2id(name)
+        adr, t = int(self.jnt_dofadr[j]), int(self.jnt_type[j])
+        return adr if t in (const.JNT_SLIDE, const.JNT_HINGE) else (adr, adr + (6 if t == const.JNT_FREE else 3))
+
+
+def load_model_from_xml(xml: str, meshdir: Optional[str] = None) -> PyMjModel:
+    """mujoco_py.load_model_from_xml (mujoco_xml.py:259): MJCF text -> model, through the in-repo MJCF compiler."""
+    return PyMjModel(MujocoXML.from_string(xml).build(meshdir=meshdir))
+
+
+class _Contact:
+    __slots__ = ("geom1", "geom2", "dist")
+
+    def __init__(self, g1, g2, dist):
+        self.geom1, self.geom2, self.dist = int(g1), int(g2), float(dist)
+
+
+class PyMjData:
+    def __init__(self, model: PyMjModel):
+        m = model
+        self._model = m
+        self.qpos, self.qvel, self.ctrl = np.zeros(m.nq), np.zeros(m.nv), np.zeros(m.nu)
+        self.qacc_warmstart, self.actuator_force = np.zeros(m.nv), np.zeros(m.nu)
+        self.userdata = np.zeros(3 * m.nu)            # the PID controllers' state (integral, previous error, filtered derivative per actuator)
+        self.xfrc_applied = np.zeros((m.nbody, 6))
+        self.site_xpos, self.body_xpos, self.body_xquat = np.zeros((m.nsite, 3)), np.zeros((m.nbody, 3)), np.zeros((m.nbody, 4))
+        self.xpos, self.xquat = self.body_xpos, self.body_xquat
+        self.time, self.ncon, self.contact = 0.0, 0, []
+
+    def get_site_xpos(self, name):
+        return self.site_xpos[self._model.site_name2id(name)]
+
+    def get_body_xpos(self, name):
+        return self.body_xpos[self._model.body_name2id(name)]
+
+    def get_body_xquat(self, name):
+        return self.body_xquat[self._model.body_name2id(name)]
+
+    def _slice(self, addr):
+        return slice(addr, addr + 1) if isinstance(addr, int) else slice(*addr)
+
+    def get_joint_qpos(self, name):
+        a = self._model.get_joint_qpos_addr(name)
+        return self.qpos[a] if isinstance(a, int) else self.qpos[a[0]:a[1]]
+
+    def set_joint_qpos(self, name, value):
+        self.qpos[self._slice(self._model.get_joint_qpos_addr(name))] = value
+
+    def get_joint_qvel(self, name):
+        a = self._model.get_joint_qvel_addr(name)
+        return self.qvel[a] if isinstance(a, int) else self.qvel[a[0]:a[1]]
+
+    def set_joint_qvel(self, name, value):
+        self.qvel[self._slice(self._model.get_joint_qvel_addr(name))] = value
+
+
+class MjSim:
+    """mujoco_py.MjSim over a batch of one (mujoco_xml.py:260, simulation_interface.py:25-90,176-207)."""
+
+    def __init__(self, model: PyMjModel, nsubsteps: int = 1, device="cuda:0", lib=None):
+        self.model, self.nsubsteps = model, int(nsubsteps)
+        kw = dict(lib=lib) if lib is not None else dict(device=device)
+        self._sim = BatchedSimulationInterface(model._compiled, 1, n_substeps=self.nsubsteps, **kw)
+        self._sim.data           # readout row on
+        self._P = self._sim.params
+        self.data = PyMjData(model)
+        self.reset()
+
+    # ------------------------------------------------------------------ host <-> device
+    def _t(self, a, shape=None):
+        t = torch.as_tensor(np.asarray(a, dtype=np.float32), device=self._sim.device)
+        return t.reshape(shape) if shape is not None else t
+
+    def _upload(self):
+        s, d, m, P = self._sim, self.data, self.model, self._P
+        s.view(_native.RG_F_QPOS)[0] = self._t(d.qpos); s.touch_qpos()
+        s.view(_native.RG_F_QVEL)[0] = self._t(d.qvel)
+        s.view(_native.RG_F_CTRL)[0] = self._t(d.ctrl)
+        s.view(_native.RG_F_PID)[0] = self._t(d.userdata)
+        s.view(_native.RG_F_WARMSTART)[0] = self._t(d.qacc_warmstart)
+        s.view(_native.RG_F_TIME)[0, 0] = float(d.time)
+        P["xfrc_applied"][0] = self._t(d.xfrc_applied)
+        P["gravity"][0] = self._t(m.opt.gravity); P["timestep"][0, 0] = float(m.opt.timestep)
+        for name, key in _WRITABLE.items():
+            P[key][0] = self._t(getattr(m, name), P[key][0].shape)
+
+    def _download(self):
+        s, d = self._sim, self.data
+        s.sync()
+        x = s.data
+        d.qpos[:] = s.view(_native.RG_F_QPOS)[0].cpu().numpy(); d.qvel[:] = s.view(_native.RG_F_QVEL)[0].cpu().numpy()
+        d.userdata[:] = s.view(_native.RG_F_PID)[0].cpu().numpy(); d.qacc_warmstart[:] = s.view(_native.RG_F_WARMSTART)[0].cpu().numpy()
+        d.time = float(s.view(_native.RG_F_TIME)[0, 0])
+        d.site_xpos[:] = x.site_xpos[0].cpu().numpy(); d.body_xpos[:] = x.body_xpos[0].cpu().numpy(); d.body_xquat[:] = x.body_xquat[0].cpu().numpy()
+        d.actuator_force[:] = x.actuator_force[0].cpu().numpy()
+        g1, g2, dist = x.contact
+        d.ncon = int(x.ncon[0])
+        d.contact = [_Contact(g1[0, i], g2[0, i], dist[0, i]) for i in range(d.ncon)]
+        status = int(s.status[0])
+        if status & ~2:      # mujoco_py raises MujocoException from the warning callback (mujoco/warning_buffer.py:27-83)
+            raise RuntimeError("simulation status bits 0x%x (bad state / factorisation / non-finite action)" % status)
+
+    # ------------------------------------------------------------------ mujoco_py surface
+    def step(self, with_udd: bool = True):
+        """nsubsteps x mj_step (mujoco_py's MjSim.step does not add a forward; SimulationInterface.step does, :176-189)."""
+        self._upload()
+        self._sim.env_step(nsubsteps=self.nsubsteps, nforward_ticks=0)
+        self._download()
+
+    def forward(self):
+        self._upload()
+        self._sim.env_step(nsubsteps=0, nforward_ticks=1)
+        self._download()
+
+    def reset(self):
+        """mj_resetData: qpos0, zero velocity / control / controller state / time / applied forces."""
+        d = self.data
+        d.qpos[:] = self.model.qpos0; d.qvel[:] = 0; d.ctrl[:] = 0; d.userdata[:] = 0; d.qacc_warmstart[:] = 0; d.xfrc_applied[:] = 0; d.time = 0.0
+        self._upload()
+        self._sim.env_step(nsubsteps=0, nforward_ticks=0)     # positions / readout for the new state, no controller tick
+        self._download()
+
+    def set_constants(self):
+        """mj_setConst: the `_invweight0` quantities that follow mass / inertia / armature."""
+        from robogym_amd.randomization.sim import refresh_constants
+
+        self._upload()
+        refresh_constants(self._sim)
+
+    def get_state(self) -> MjSimState:
+        d = self.data
+        return MjSimState(d.time, d.qpos.copy(), d.qvel.copy(), None, {"pid": d.userdata.copy()})
+
+    def set_state(self, state: MjSimState):
+        d = self.data
+        d.time = float(state.time); d.qpos[:] = state.qpos; d.qvel[:] = state.qvel
+        if state.udd_state and "pid" in state.udd_state:
+            d.userdata[:] = state.udd_state["pid"]
