@@ -478,7 +478,9 @@ def make_env(parameters=None, constants=None, wrapper_params=None, starting_seed
     actions of 11 bins, drop penalty / done on fall, noisy_* / relative_goal / unified goal observations, sin / cos
     angles, clipping, previous action and reward observations, and — `constants["randomize"]`, default True as in the
     reference (robot_env.py:155) — backlash, the thirteen physics / latency randomizations of LockedEnv, observation and action
-    noise, occluded / freezing markers.  Without wrappers `randomize` has no effect, as in the reference (cube_env.py:369)."""
+    noise, occluded / freezing markers.  Without wrappers `randomize` has no effect, as in the reference (cube_env.py:369).
+    With `pipelined_reset=True` the wrapped env restarts finished episodes by itself (wrapper `auto_reset`): the randomizations of an
+    env are redrawn on the step its episode ends, the reset recipe then runs with them inside the following steps."""
     wc = {}
     if isinstance(constants, dict):   # wrapper-level constants of DactylCubeEnvConstants (cube_env.py:61-124)
         constants = dict(constants)
@@ -496,7 +498,7 @@ def make_env(parameters=None, constants=None, wrapper_params=None, starting_seed
             raise NotImplementedError("wrapper_params[%r]: editing the wrapper list is not supported (the stack is one vectorised object)" % k)
         wp.pop(k, None)
     env.stop_on_fall = True
-    return BatchedDactylCubeWrappers(env, **{"randomize": True, **wc, **wp})
+    return BatchedDactylCubeWrappers(env, **{"randomize": True, "auto_reset": bool(kwargs.get("pipelined_reset", False)), **wc, **wp})
 
 
 def make_simple_env(parameters=None, constants=None, starting_seed=None, batch_size: int = 1, device="cuda:0", **kwargs):

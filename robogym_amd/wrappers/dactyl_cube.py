@@ -90,12 +90,19 @@ def _bmask(mask, t):
 class BatchedDactylCubeWrappers:
     def __init__(self, env, randomize: bool = False, n_action_bins: Optional[int] = None, relative_goal_wrapper: bool = True, drop_reward: float = -20.0,
                  min_episode_length: int = -1, noise_levels: Optional[dict] = None, smooth_alpha: float = 0.0, clip: float = 100.0, fixed_wrist: bool = False,
-                 draws=None):
+                 draws=None, auto_reset: bool = False):
         if fixed_wrist:
             raise NotImplementedError("FixedWristWrapper is not built (wrappers/dactyl.py:173-189)")
         self.env = env
         self.unwrapped = env
         self.randomize = bool(randomize)
+        # auto_reset: around an env with `pipelined_reset=True` — a finished episode restarts by itself inside the following steps, and
+        # the wrappers redraw that env's randomizations when its episode ends and reset their per-episode state when the new one starts
+        self.auto_reset = bool(auto_reset)
+        self._next_delta: Dict[str, torch.Tensor] = {}
+        self._in_recipe = torch.zeros(env.batch_size, dtype=torch.bool, device=env.device)
+        if self.auto_reset and not getattr(env, "pipelined_reset", False):
+            raise ValueError("auto_reset needs an env built with pipelined_reset=True")
         self.B, self.device, self.nu = env.batch_size, env.device, env.num_actions
         self.batch_size = self.B
         nb = 11 if n_action_bins is None else int(n_action_bins)          # DiscretizeActionWrapper.DEFAULT_BINS
@@ -262,7 +269,7 @@ class BatchedDactylCubeWrappers:
                                ("randomized_phasespace_fingers", sp), ("joint_damping", damp), ("actuator_kp", kp), ("joint_limit", joint_delta),
                                ("tendon_range", tendon_delta)]
 
-    def _randomize_after_reset(self, mask):
+    def _randomize_after_reset(self, mask, deltas=None):
         D, dev = self.draws, self.device
         t = lambda a: torch.as_tensor(a, dtype=torch.float32, device=dev)
         # BacklashWrapper.reset (randomizations.py:856-874)
@@ -281,7 +288,7 @@ class BatchedDactylCubeWrappers:
         hp = torch.exp(D.uniform(torch.log(0.01 * step_s / 0.8), torch.log(step_s / 0.8)))
         self._wind_hit_prob = torch.where(mask, hp.to(self._wind_hit_prob.dtype), self._wind_hit_prob)
         # the observation entries of the RandomizedBodyWrapper family (ActionLatency's are live: see _randomization_obs)
-        for key, val in self._pending_delta:
+        for key, val in (deltas if deltas is not None else self._pending_delta):
             self._delta(key, mask, val)
 
     def _randomization_obs(self, o):
@@ -329,19 +336,23 @@ class BatchedDactylCubeWrappers:
         force = D.randn_where(hit, (3,)) * P["body_mass"][:, self._cube_body, None] * 1.0
         P["xfrc_applied"][:, self._cube_body, :3] = torch.where(hit[:, None], force.to(x.dtype), x)
 
-    def _post_noise_obs(self, o, at_reset):
+    def _post_noise_obs(self, o, at_reset, mixed=False):
         """FingersOccludedPhasespaceMarkers -> FingersFreezingPhasespaceMarkers -> CubeFreezingPhasespaceBody (dactyl.py:53-107,
         randomizations.py:400-513, cube.py:88-103): stale marker / cube readings."""
         D, key = self.draws, "noisy_fingertip_pos"
         cube_keys = [k for k in CUBE_FREEZE_KEYS if k in o]
-        if at_reset is not None:        # reset(): the buffers take the first observation, nothing is drawn
-            m = at_reset
+        fresh = {k: o[k] for k in [key] + cube_keys}
+
+        def restart(m):                 # reset(): the buffers take the first observation, nothing is drawn
             keep = lambda old, new: new.clone() if old is None else torch.where(_bmask(m, new), new, old.to(new.dtype))
-            self._occl_buf = keep(self._occl_buf, o[key]); self._ff_buf = keep(self._ff_buf, o[key])
+            self._occl_buf = keep(self._occl_buf, fresh[key]); self._ff_buf = keep(self._ff_buf, fresh[key])
             self._ff_left = torch.where(m[:, None], torch.zeros_like(self._ff_left), self._ff_left)
             self._cf_left = torch.where(m, torch.zeros_like(self._cf_left), self._cf_left)
             for k in cube_keys:
-                self._cf_buf[k] = keep(self._cf_buf.get(k), o[k])
+                self._cf_buf[k] = keep(self._cf_buf.get(k), fresh[k])
+
+        if at_reset is not None and not mixed:
+            restart(at_reset)
             return
         if self._idx["occlusion"] is not None:      # check_occlusion (utils/sensor_utils.py:25-44): a penetrating contact on the finger's occlusion geom
             data = self.env.mujoco_simulation.data
@@ -368,6 +379,10 @@ class BatchedDactylCubeWrappers:
         self._cf_left = torch.where(does, new_len.to(self._cf_left.dtype), self._cf_left)
         for k in cube_keys:
             o[k] = self._cf_buf[k].clone()
+        if at_reset is not None:        # auto-reset: the envs whose episode starts on this step see their first observation unfrozen
+            restart(at_reset)
+            for k in fresh:
+                o[k] = torch.where(_bmask(at_reset, fresh[k]), fresh[k], o[k])
 
     # ================================================================== observation pipeline
     def _is_fallen(self, obs):     # StopOnFallWrapper._is_fallen (cube.py:153-156): site cube:center z < 0.04
@@ -399,7 +414,7 @@ class BatchedDactylCubeWrappers:
             out["noisy_" + key] = v
         return out
 
-    def _observation(self, obs, action_ema, reward, at_reset=None):
+    def _observation(self, obs, action_ema, reward, at_reset=None, mixed=False):
         o = OrderedDict(obs)
         o["fell_down"] = self._is_fallen(obs)[:, None]                                  # StopOnFallWrapper
         if self.randomize:
@@ -416,7 +431,7 @@ class BatchedDactylCubeWrappers:
                 o["noisy_achieved_goal_" + name] = o["noisy_cube_" + name].clone()
                 o["noisy_relative_goal_" + name] = rel[name](o["noisy_cube_" + name])
         if self.randomize:
-            self._post_noise_obs(o, at_reset)
+            self._post_noise_obs(o, at_reset, mixed)
         for key in list(o.keys()):                                                       # AngleObservationWrapper
             if key.endswith("_angle"):
                 o[key] = torch.cat([torch.cos(o[key]), torch.sin(o[key])], dim=-1)
@@ -441,19 +456,26 @@ class BatchedDactylCubeWrappers:
         if self.randomize:
             self._randomize_before_reset(mask)   # RandomizedBodyWrapper.reset: parameters first, THEN the env's reset recipe runs with them
         obs = self.env.reset(mask)
+        self._episode_start(mask)
+        out = self._observation(obs, torch.zeros((B, self.nu), device=dev), torch.zeros((B, 2), device=dev), at_reset=mask)
+        self._action_noise_reset(mask)
+        return out
+
+    def _episode_start(self, mask, deltas=None):
+        """What the wrappers' reset() methods do once the env below them has been reset, for the envs in `mask`."""
         if self.randomize:
-            self._randomize_after_reset(mask)
+            self._randomize_after_reset(mask, deltas)
         self._steps.masked_fill_(mask, 0); self._drops_so_far.masked_fill_(mask, 0); self._first_drop.masked_fill_(mask, 0)
         self._previous_action.masked_fill_(mask[:, None], 0.0)
         self._ema_value.masked_fill_(mask[:, None], 0.0); self._ema_t.masked_fill_(mask, 0)
         self._noise_reset(mask)
-        out = self._observation(obs, torch.zeros((B, self.nu), device=dev), torch.zeros((B, 2), device=dev), at_reset=mask)
+
+    def _action_noise_reset(self, mask):
         if self.randomize:                       # ActionNoiseWrapper.reset (randomizations.py:756-770)
             mult = 1.0 + self.draws.randn((self.nu,)) * 0.03
             add = self.draws.randn((self.nu,)) * 0.03
             self._an_mult = torch.where(mask[:, None], mult.to(self._an_mult.dtype), self._an_mult)
             self._an_add = torch.where(mask[:, None], add.to(self._an_add.dtype), self._an_add)
-        return out
 
     def step(self, action: torch.Tensor):
         """action: int64 [B, nu] bin indices in [0, n_action_bins).  Returns (obs dict, reward [B, 4] = env, goal, success, drop,
@@ -477,10 +499,18 @@ class BatchedDactylCubeWrappers:
             a = self._backlash(a)
         a = a.clamp(-1.0, 1.0)                                                           # ClipActionWrapper
         obs, rew, done, info = self.env.step(a)
+        started = resetting = None
+        if self.auto_reset:
+            started, resetting = info["episode_started"].bool(), info["resetting"].bool()
+            self._episode_start(started, list(self._next_delta.items()) if self.randomize and self._next_delta else None)
+            a_ema = torch.where(started[:, None], torch.zeros_like(a_ema), a_ema)
         if self.randomize:
             self._after_env_step()
         # StopOnFallWrapper.step (cube.py:125-151)
         fallen = self._is_fallen(obs)
+        if self.auto_reset:
+            fallen = fallen & ~self._in_recipe & ~started      # envs that spent this step inside the reset recipe are between episodes
+            self._in_recipe = resetting.clone()                # (the flag buffer is rewritten in place by the next step; `resetting` already includes the envs whose episode ended on this very step)
         done = done | fallen
         first = fallen & (self._first_drop == 0)
         self._drops_so_far += fallen.to(torch.int32)
@@ -491,5 +521,12 @@ class BatchedDactylCubeWrappers:
         reward = torch.cat([rew, drop_rew[:, None]], dim=1).clamp(-self.clip, self.clip)   # ... + ClipRewardWrapper
         info = dict(info)
         info.update({"fell_down": fallen, "drops_so_far": self._drops_so_far.clone(), "first_drop": self._first_drop.clone()})
-        self._steps += 1
-        return self._observation(obs, a_ema, reward[:, 1:3]), reward, done, info
+        self._steps += 1 if started is None else (~started).to(torch.int32)      # (the step that returns a new episode's first observation is its reset())
+        out = self._observation(obs, a_ema, reward[:, 1:3], at_reset=started, mixed=self.auto_reset)
+        if self.auto_reset:
+            self._action_noise_reset(started)
+            if self.randomize:
+                self._randomize_before_reset(done)        # the episode is over: its env restarts on the next step, with the new parameters
+                for key, val in self._pending_delta:      # (their observation entries switch when the new episode starts)
+                    self._next_delta[key] = val if key not in self._next_delta else torch.where(_bmask(done, val), val, self._next_delta[key].to(val.dtype))
+        return out, reward, done, info
