@@ -181,3 +181,66 @@ def test_batched_randomizers_follow_the_reference_formulas(locked_model, emul_li
     f0 = P["geom_friction"].clone()
     GenericSimRandomizer("geom_margin_like", "geom_friction", "variance_additive", param=0.05, positive_only=True).randomize(sim, gen)
     assert (P["geom_friction"] >= 0).all() and not torch.equal(P["geom_friction"], f0)
+
+
+@pytest.mark.gpu
+def test_per_env_parameters_at_full_batch_gpu(locked_model, oracle_lib):
+    """Row addressing of the parameter buffer at the BASELINE batch: the four parameter sets above sit in four random rows of
+    a B = 8192 batch whose other rows keep the model's values; one env.step; each of the four rows against the oracle built
+    from ITS model, a default row against the default oracle, and all default rows bit-identical to each other."""
+    from oracle.env_oracle import OracleLockedEnvPhysics
+    from robogym_amd.envs.dactyl.locked import LockedSimulation
+    from robogym_amd.mujoco import setconst
+    from robogym_amd.randomization.sim import refresh_constants
+
+    B = 8192
+    sim = LockedSimulation(locked_model, B, device="cuda:0")
+    variants, xf, cube_body = _variants(locked_model)
+    rows = [int(r) for r in np.random.RandomState(3).choice(B, 4, replace=False)]
+    P = sim.params
+    oras = []
+    for e, (row, ov) in enumerate(zip(rows, variants)):
+        me = locked_model.copy_with(**ov)
+        if "body_mass" in ov or "dof_armature" in ov:
+            setconst.set_constants(me)
+        o = OracleLockedEnvPhysics(me)
+        for k, val in ov.items():
+            if k == "geom_rbound":
+                continue
+            if k == "geom_size":
+                cg = locked_model.name2id("geom", "cube:middle")
+                P["geom_scale"][row] = float(val[cg, 0] / locked_model.arrays["geom_size"][cg, 0])
+                continue
+            t = torch.as_tensor(np.asarray(val, dtype=np.float32), device=sim.device)
+            P[PARAM_OF[k]][row] = t.reshape(P[PARAM_OF[k]][row].shape)
+        if e == 3:
+            o.sim.xfrc_applied[:] = xf.ravel()
+            P["xfrc_applied"][row] = torch.as_tensor(xf.astype(np.float32), device=sim.device)
+        oras.append(o)
+    refresh_constants(sim, rows=[rows[2]])
+    default = OracleLockedEnvPhysics(locked_model)
+    for e, o in enumerate(oras + [default]):
+        o.sim.reset()
+        if e == 3:
+            o.sim.xfrc_applied[:] = xf.ravel()      # (mj_resetData clears it)
+        o.settle(40)
+    sts = [o.get_state_f32() for o in oras]
+    for o, st in zip(oras, sts):
+        o.set_state_f32(st)
+    dst = default.get_state_f32(); default.set_state_f32(dst)
+    _put_rows(sim, np.arange(B), {k: np.repeat(dst[k][None], B, 0) for k in STATE_FIELDS})
+    _put_rows(sim, np.array(rows), {k: np.stack([st[k] for st in sts]) for k in STATE_FIELDS})
+    a = np.random.RandomState(4).uniform(-1, 1, 20).astype(np.float32)
+    sim.env_step(action=torch.as_tensor(np.repeat(a[None], B, 0), device=sim.device), nforward_ticks=3)
+    q = sim.qpos.cpu().numpy().astype(np.float64)
+    errs = []
+    for row, o in zip(rows, oras):
+        o.env_step(a)
+        errs.append(np.abs(q[row] - o.sim.qpos)[NON_TARGET_QPOS].max())
+    print("rows", rows, "qpos errors vs their own oracles", ["%.2e" % e for e in errs])
+    assert max(errs) < 5e-3 and np.median(errs) < 5e-5, errs      # (as the 4-env test: an impact step may reach 1e-3)
+    default.env_step(a)
+    others = np.setdiff1d(np.arange(B), rows)
+    assert np.abs(q[others[0]] - default.sim.qpos)[NON_TARGET_QPOS].max() < 5e-4
+    assert (q[others] == q[others[0]]).all() and int(sim.status.max().item()) == 0
+    assert np.abs(q[rows[0]] - q[rows[1]])[NON_TARGET_QPOS].max() > 1e-5      # the rows do differ
