@@ -121,6 +121,9 @@ int rg_batch_copy_rows(rg_batch* b, int field, const void* src_dev, const int* m
  *                      point on the final portal TRIANGLE (the default, = MuJoCo 2.0's mjc_Convex).  The two agree whenever
  *                      the origin projects inside the triangle; the plane variant does not depend on the rounding-level
  *                      tie breaks that pick the triangle on flat contacts.
+ *                bit5: evaluate data.sensordata (touch sensors, mj_sensorAcc) into the xdata row: the last of the state-less
+ *                      forwards then runs in full (collision and constraint solve at the final state, as mj_forward does),
+ *                      about one more substep of work.  Needs xdata_dev and nforward_ticks >= 1.
  *   stream       hipStream_t (NULL = default stream).  Asynchronous. */
 int rg_batch_step(rg_batch* b, const float* action_dev, const float* goal_quat_dev, float* obs_dev, float* goal_dist_dev,
                   const int* active_dev, int nsubsteps, int nforward_ticks, int flags, void* stream);
@@ -151,7 +154,8 @@ typedef struct rg_step_args {
    * site_xpos of the final state (mujoco_shadow_hand.py:18-61, observation providers), actuator_force of the last
    * state-less forward, ncon and contact[i].{geom1, geom2, dist} of the last mj_step (simulation/base.py:562-635,
    * utils/sensor_utils.py:18-38).  rg_xdata_layout: out = row length, offsets of xpos, xquat, site_xpos, actuator_force,
-   * ncon, contact triples, number of contact slots. */
+   * ncon, contact triples, number of contact slots, sensordata (touch sensors; filled by launches with flags bit 5), number of
+   * sensor slots. */
   float* xdata_dev;
 } rg_step_args;
 int rg_xdata_layout(int* out, int n);

@@ -53,8 +53,8 @@ typedef struct {
   const int *geom_type, *geom_bodyid, *geom_dataid, *geom_contype, *geom_conaffinity, *geom_condim;
   const double *geom_size, *geom_rbound, *geom_pos, *geom_quat, *geom_friction, *geom_margin, *geom_gap, *geom_solmix,
       *geom_solref, *geom_solimp;
-  const int *site_bodyid;
-  const double *site_pos, *site_quat;
+  const int *site_bodyid, *site_type, *sensor_type, *sensor_objid;
+  const double *site_pos, *site_quat, *site_size;
   const int *mesh_vertadr, *mesh_vertnum;
   const float *mesh_vert;
   const int *exclude_signature;
@@ -93,6 +93,7 @@ typedef struct {
   /* velocity / force stage */
   double *ten_velocity, *actuator_velocity, *cvel, *cdof_dot, *qfrc_passive, *qfrc_bias, *actuator_force,
       *qfrc_actuator, *qfrc_smooth, *qacc_smooth, *qfrc_constraint, *qacc;
+  double* sensordata; /* [nsensor] */
   /* diagnostics */
   int solver_iter, warn_contact_full, warn_efc_full, warn_bad;
   long stat_ncon, stat_nefc, stat_iter, stat_steps, stat_mpr_calls, stat_mpr_iter;
@@ -210,7 +211,7 @@ ro_model* ro_model_load(const void* blob_in, size_t nbytes) {
   I32(geom_type); I32(geom_bodyid); I32(geom_dataid); I32(geom_contype); I32(geom_conaffinity); I32(geom_condim);
   F64(geom_size); F64(geom_rbound); F64(geom_pos); F64(geom_quat); F64(geom_friction); F64(geom_margin); F64(geom_gap);
   F64(geom_solmix); F64(geom_solref); F64(geom_solimp);
-  I32(site_bodyid); F64(site_pos); F64(site_quat);
+  I32(site_bodyid); F64(site_pos); F64(site_quat); I32(site_type); F64(site_size); I32(sensor_type); I32(sensor_objid);
   I32(mesh_vertadr); I32(mesh_vertnum);
   m->mesh_vert = (const float*)blob_find(m->blob, "mesh_vert", NULL, 1);
   I32(exclude_signature);
@@ -251,6 +252,7 @@ ro_data* ro_data_new(const ro_model* m) {
   d->cdof_dot = dalloc(6 * nv); d->qfrc_passive = dalloc(nv); d->qfrc_bias = dalloc(nv);
   d->actuator_force = dalloc(m->nu); d->qfrc_actuator = dalloc(nv); d->qfrc_smooth = dalloc(nv);
   d->qacc_smooth = dalloc(nv); d->qfrc_constraint = dalloc(nv); d->qacc = dalloc(nv);
+  d->sensordata = dalloc(m->nsensor > 0 ? m->nsensor : 1);
   memcpy(d->qpos, m->qpos0, m->nq * sizeof(double));
   return d;
 }
@@ -1394,6 +1396,82 @@ static void ro_solve(const ro_model* m, ro_data* d) {
 }
 
 /* ------------------------------------------------------------------------------------------ forward / step */
+/* engine_sensor.c: mj_sensorAcc, mjSENS_TOUCH.  A touch sensor sums the NORMAL forces of the contacts that involve the
+ * body of its site and whose contact point "sees" the site's volume along the contact normal (mju_rayGeom(site, contact
+ * position, +-normal) >= 0: only the sign of the ray test matters, i.e. "does the ray from the contact point along the
+ * normal meet the site's shape").  The normal force of a pyramidal contact is the sum of its pyramid edge forces
+ * (mju_decodePyramid).  The ray test is stated geometrically (exact for sphere, capsule = cylinder segment + two spheres,
+ * ellipsoid, cylinder, box), not as MuJoCo's root bookkeeping. */
+static int ray_hits_sphere(const double* c, double r, const double* p, const double* v) {
+  double w[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]}, vv = dot3(v, v);
+  double t = vv > 0 ? -dot3(w, v) / vv : 0; if (t < 0) t = 0;
+  double q[3] = {w[0] + t * v[0], w[1] + t * v[1], w[2] + t * v[2]};
+  return dot3(q, q) <= r * r;
+}
+/* the part of the ray (t >= 0) inside the infinite cylinder x^2 + y^2 <= r^2: [t0, t1]; returns 0 if empty */
+static int ray_in_cylinder(double r, const double* p, const double* v, double* t0, double* t1) {
+  double a = v[0] * v[0] + v[1] * v[1], b = p[0] * v[0] + p[1] * v[1], c = p[0] * p[0] + p[1] * p[1] - r * r;
+  if (a < 1e-30) { if (c > 0) return 0; *t0 = 0; *t1 = 1e300; return 1; }
+  double det = b * b - a * c; if (det < 0) return 0;
+  double sq = sqrt(det); *t0 = (-b - sq) / a; *t1 = (-b + sq) / a;
+  if (*t1 < 0) return 0;
+  if (*t0 < 0) *t0 = 0;
+  return 1;
+}
+static int ray_hits_site(int type, const double* size, const double* p, const double* v) {   /* p, v in the site frame */
+  const double zero[3] = {0, 0, 0};
+  if (type == GEOM_SPHERE) return ray_hits_sphere(zero, size[0], p, v);
+  if (type == GEOM_CAPSULE || type == GEOM_CYLINDER) {
+    double r = size[0], h = size[1], t0, t1;
+    if (ray_in_cylinder(r, p, v, &t0, &t1)) {   /* somewhere on [t0, t1] the height must be within +-h */
+      double z0 = p[2] + t0 * v[2], z1 = t1 > 1e299 ? (v[2] > 0 ? 1e300 : (v[2] < 0 ? -1e300 : p[2])) : p[2] + t1 * v[2];
+      double lo = z0 < z1 ? z0 : z1, hi = z0 < z1 ? z1 : z0;
+      if (lo <= h && hi >= -h) return 1;
+    }
+    if (type == GEOM_CYLINDER) return 0;        /* (flat ends: entering through an end disk also puts a ray point inside the side test above) */
+    double ct[3] = {0, 0, h}, cb[3] = {0, 0, -h};
+    return ray_hits_sphere(ct, r, p, v) || ray_hits_sphere(cb, r, p, v);
+  }
+  if (type == GEOM_ELLIPSOID) {
+    double ps[3] = {p[0] / size[0], p[1] / size[1], p[2] / size[2]}, vs[3] = {v[0] / size[0], v[1] / size[1], v[2] / size[2]};
+    return ray_hits_sphere(zero, 1.0, ps, vs);
+  }
+  if (type == GEOM_BOX) {
+    double t0 = 0, t1 = 1e300;
+    for (int k = 0; k < 3; k++) {
+      if (fabs(v[k]) < 1e-30) { if (fabs(p[k]) > size[k]) return 0; continue; }
+      double a = (-size[k] - p[k]) / v[k], b = (size[k] - p[k]) / v[k];
+      if (a > b) { double t = a; a = b; b = t; }
+      if (a > t0) t0 = a;
+      if (b < t1) t1 = b;
+    }
+    return t0 <= t1;
+  }
+  return 0;
+}
+void ro_sensor(const ro_model* m, ro_data* d) {
+  for (int k = 0; k < m->nsensor; k++) {
+    d->sensordata[k] = 0;
+    if (m->sensor_type[k] != 0) continue;   /* mjSENS_TOUCH */
+    int site = m->sensor_objid[k], body = m->site_bodyid[site];
+    for (int i = 0; i < d->ncon; i++) {
+      const ro_contact* c = d->contact + i;
+      if (c->efc_address < 0) continue;
+      int b1 = m->geom_bodyid[c->geom1], b2 = m->geom_bodyid[c->geom2];
+      if (b1 != body && b2 != body) continue;
+      double nf = 0;
+      if (c->dim == 1) nf = d->efc_force[c->efc_address];
+      else for (int q = 0; q < 2 * (c->dim - 1); q++) nf += d->efc_force[c->efc_address + q];
+      if (nf <= 0) continue;
+      double sgn = body == b2 ? -1.0 : 1.0, ray[3] = {sgn * c->frame[0], sgn * c->frame[1], sgn * c->frame[2]};
+      double rel[3], lp[3], lv[3]; const double* R = d->site_xmat + 9 * site;
+      sub3(rel, c->pos, d->site_xpos + 3 * site);
+      for (int a = 0; a < 3; a++) { lp[a] = R[a] * rel[0] + R[3 + a] * rel[1] + R[6 + a] * rel[2]; lv[a] = R[a] * ray[0] + R[3 + a] * ray[1] + R[6 + a] * ray[2]; }
+      if (ray_hits_site(m->site_type[site], m->site_size + 3 * site, lp, lv)) d->sensordata[k] += nf;
+    }
+  }
+}
+
 void ro_fwd_position(const ro_model* m, ro_data* d) {
   ro_kinematics(m, d); ro_com_pos(m, d); ro_tendon(m, d); ro_transmission(m, d); ro_crb(m, d);
   ro_collision(m, d); ro_make_constraint(m, d);
@@ -1405,6 +1483,7 @@ void ro_forward(const ro_model* m, ro_data* d) {
   ro_fwd_actuation(m, d);
   ro_fwd_acceleration(m, d);
   ro_solve(m, d);
+  ro_sensor(m, d);
 }
 static int bad(const double* x, int n) { for (int i = 0; i < n; i++) if (!(fabs(x[i]) < 1e10)) return 1; return 0; }
 
@@ -1464,7 +1543,7 @@ double* ro_field(const ro_model* m, ro_data* d, const char* field, int* n) {
   FIELD(efc_vel, d->nefc) FIELD(efc_frictionloss, d->nefc) FIELD(efc_diagApprox, d->nefc)
   FIELD(ten_velocity, m->ntendon) FIELD(actuator_velocity, m->nu) FIELD(cvel, 6 * nb) FIELD(cdof_dot, 6 * nv)
   FIELD(qfrc_passive, nv) FIELD(qfrc_bias, nv) FIELD(actuator_force, m->nu) FIELD(qfrc_actuator, nv) FIELD(qfrc_smooth, nv)
-  FIELD(qacc_smooth, nv) FIELD(qfrc_constraint, nv) FIELD(qacc, nv)
+  FIELD(qacc_smooth, nv) FIELD(qfrc_constraint, nv) FIELD(qacc, nv) FIELD(sensordata, m->nsensor)
   *n = 0;
   return NULL;
 }

@@ -28,6 +28,19 @@ typedef rg_post_args RgPostArgs;
 #undef RG_CPOOL
 #undef RG_MAXCAND
 #undef RG_MAXCAND2
+// the large capacities once more, with data.sensordata evaluation compiled in (launches with flags bit 5)
+#define RG_NS rgx
+#define RG_MAXCON 64
+#define RG_CPOOL 3072
+#define RG_MAXCAND 256
+#define RG_MAXCAND2 128
+#define RG_SENSORS 1
+#include "rg_kernel.h"
+#undef RG_NS
+#undef RG_MAXCON
+#undef RG_CPOOL
+#undef RG_MAXCAND
+#undef RG_MAXCAND2
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -239,6 +252,18 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
   UPI(geom_type, "geom_type"); UPI(geom_bodyid, "geom_bodyid"); UPI(geom_dataid, "geom_dataid"); UPI(body_geomadr, "body_geomadr"); UPI(body_geomnum, "body_geomnum");
   UPF(geom_size, "geom_size"); UPF(geom_rbound, "geom_rbound"); UPF(geom_pos, "geom_pos"); UPF(geom_quat, "geom_quat"); UPF(geom_aabb, "k_geom_aabb");
   UPI(site_bodyid, "site_bodyid"); UPF(site_pos, "site_pos");
+  UPI(site_type, "site_type"); UPF(site_size, "site_size"); UPF(site_quat, "site_quat");
+  { std::vector<int> st, so, sty;
+    if (!get_i(B, "sensor_type", st, e) || !get_i(B, "sensor_objid", so, e) || !get_i(B, "site_type", sty, e)) return bail(e, m);
+    if (st.size() > RG_MAXSENSOR) return bail("more than RG_MAXSENSOR sensors", m);
+    for (size_t k = 0; k < st.size(); k++) {
+      if (st[k] != 0) return bail("only touch sensors are implemented", m);
+      int t = sty[so[k]];
+      if (t != RG_GEOM_SPHERE && t != RG_GEOM_CAPSULE && t != RG_GEOM_ELLIPSOID && t != RG_GEOM_CYLINDER && t != RG_GEOM_BOX) return bail("touch sensor on a site of unsupported shape", m);
+    }
+    d.nsensor = (int)st.size();
+    if (so.empty()) so.push_back(0);
+    if (!upload<int>(m, so, &d.sensor_site)) return bail("hipMalloc failed", m); }
   UPI(mesh_vertadr, "mesh_vertadr"); UPI(mesh_vertnum, "mesh_vertnum");
   { GF("mesh_vert"); std::vector<float> v4(fv.size() / 3 * 4, 0.f);  // 16-byte vertex records: one dwordx4 load per vertex
     for (size_t i = 0; i < fv.size() / 3; i++) { v4[4 * i] = fv[3 * i]; v4[4 * i + 1] = fv[3 * i + 1]; v4[4 * i + 2] = fv[3 * i + 2]; }
@@ -421,7 +446,7 @@ int rg_batch_enable_env_params(rg_batch* b) {
   return 0;
 }
 int rg_xdata_layout(int* out, int n) {
-  const int lay[] = {RG_XDATA, RG_XD_XPOS, RG_XD_XQUAT, RG_XD_SITE_XPOS, RG_XD_ACT_FORCE, RG_XD_NCON, RG_XD_CONTACT, RG_DBG_MAXCON};
+  const int lay[] = {RG_XDATA, RG_XD_XPOS, RG_XD_XQUAT, RG_XD_SITE_XPOS, RG_XD_ACT_FORCE, RG_XD_NCON, RG_XD_CONTACT, RG_DBG_MAXCON, RG_XD_SENSOR, RG_MAXSENSOR};
   const int k = (int)(sizeof lay / sizeof lay[0]);
   for (int i = 0; i < k && i < n; i++) out[i] = lay[i];
   return k;
@@ -538,6 +563,7 @@ int rg_batch_copy_rows(rg_batch* b, int field, const void* src_dev, const int* m
 struct EmulArgs { const RgModelDev* m; RgLaunch launch; };
 static void emul_entry(void* a) { EmulArgs* p = (EmulArgs*)a; rgs::rg_step_kernel(p->m, p->launch); }
 static void emul_entry_large(void* a) { EmulArgs* p = (EmulArgs*)a; rgl::rg_step_kernel(p->m, p->launch); }
+static void emul_entry_sensors(void* a) { EmulArgs* p = (EmulArgs*)a; rgx::rg_step_kernel(p->m, p->launch); }
 #endif
 
 int rg_batch_step_ex(rg_batch* b, const rg_step_args* a) {
@@ -548,18 +574,21 @@ int rg_batch_step_ex(rg_batch* b, const rg_step_args* a) {
   RgBatchDev bt = b->dev;
   bt.action = a->action_dev; bt.goal_quat = a->goal_quat_dev; bt.obs = a->obs_dev; bt.goal_dist = a->goal_dist_dev; bt.active = a->active_dev;
   bt.hold = a->hold_dev; bt.nticks = a->nticks_dev; bt.order = a->order_dev;
-  const bool large = a->config == RG_CFG_LARGE, prof = (a->flags & 2) != 0;
+  // flags bit 5 (sensordata): the sensor-evaluating instantiation, which has the large capacities (no redo hand-off needed)
+  const bool sens = (a->flags & 32) != 0 && a->xdata_dev && b->model->dev.nsensor > 0;
+  const bool large = a->config == RG_CFG_LARGE || sens, prof = (a->flags & 2) != 0;
   if (a->config != RG_CFG_LARGE && a->config != RG_CFG_ROLLOUT) return fail("rg_batch_step: unknown kernel configuration");
   bt.redo = large ? nullptr : a->redo_dev;
   bt.preticks = a->preticks_dev;
   bt.xdata = a->xdata_dev;
   RgLaunch launch{b->model->aux, b->env, bt, a->nsubsteps, a->nforward_ticks, a->flags};
-  const size_t lds = large ? rgl::rg_lds_launch_bytes(prof) : rgs::rg_lds_launch_bytes(prof);
+  const size_t lds = sens ? rgx::rg_lds_launch_bytes(prof) : (large ? rgl::rg_lds_launch_bytes(prof) : rgs::rg_lds_launch_bytes(prof));
 #ifdef RG_EMUL
   EmulArgs args{b->model->dev_copy, launch};
-  emul_launch(bt.B, lds, large ? emul_entry_large : emul_entry, &args);
+  emul_launch(bt.B, lds, sens ? emul_entry_sensors : (large ? emul_entry_large : emul_entry), &args);
 #else
-  if (large) hipLaunchKernelGGL(rgl::rg_step_kernel, dim3(bt.B), dim3(RG_WAVE), lds, (hipStream_t)a->stream, b->model->dev_copy, launch);
+  if (sens) hipLaunchKernelGGL(rgx::rg_step_kernel, dim3(bt.B), dim3(RG_WAVE), lds, (hipStream_t)a->stream, b->model->dev_copy, launch);
+  else if (large) hipLaunchKernelGGL(rgl::rg_step_kernel, dim3(bt.B), dim3(RG_WAVE), lds, (hipStream_t)a->stream, b->model->dev_copy, launch);
   else hipLaunchKernelGGL(rgs::rg_step_kernel, dim3(bt.B), dim3(RG_WAVE), lds, (hipStream_t)a->stream, b->model->dev_copy, launch);
   HIPCHK(hipGetLastError());
 #endif

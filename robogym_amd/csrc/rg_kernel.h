@@ -258,6 +258,9 @@ __device__ __forceinline__ void cross_force(float* r, const float* vel, const fl
 #if !defined(RG_NS) || !defined(RG_MAXCON) || !defined(RG_CPOOL) || !defined(RG_MAXCAND) || !defined(RG_MAXCAND2)
 #error "define RG_NS, RG_MAXCON, RG_CPOOL, RG_MAXCAND, RG_MAXCAND2 before including rg_kernel.h"
 #endif
+#ifndef RG_SENSORS
+#define RG_SENSORS 0   /* 1: this configuration evaluates data.sensordata (launch flag bit 5); its own instantiation so that the hot configurations carry none of it */
+#endif
 namespace RG_NS {
 #define RG_MAXPYR (RG_MAXCON * 6)
 #define RG_PSLOTS ((RG_MAXPYR + RG_WAVE - 1) / RG_WAVE)   // pyramid rows a lane owns during a line search
@@ -287,6 +290,9 @@ struct RgLds {
   float c_D[RG_MAXCON], c_mu[RG_MAXCON * 2];   // friction coefficient of the two sliding directions | of the spin direction
   short c_pair[RG_MAXCON], c_off[RG_MAXCON];
   unsigned char c_dim[RG_MAXCON], c_nnz[RG_MAXCON];
+#if RG_SENSORS
+  unsigned char c_touch[RG_MAXCON];   // bit k: touch sensor k sees this contact (sensor pass only)
+#endif
   unsigned char c_idx[RG_MAXCON * RG_W];
   float c_pool[RG_CPOOL];  // basis Jacobian rows (normal, tangent1, tangent2, spin) x nnz, packed per contact
   float p_aref[RG_MAXPYR];
@@ -1773,7 +1779,7 @@ __device__ __forceinline__ LsPt rg_ls_eval(const LsRows& L, float alpha, float q
 
 // Newton solver on the primal problem (see oracle ro_solve), in the compact space of constrained dofs
 // (trees no constraint row can touch keep qacc = qacc_smooth).  Result: s.qacc, s.qfrc_con (full space).
-__device__ __forceinline__ int rg_solve(RgM m, RgLds& s, const float* P, int& nefc_out, int flags) {
+template <bool SENSORS> __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, const float* P, int& nefc_out, int flags) {
   long long t0 = rg_clock(), t1;
 #define PROFS(k) do { if (flags & 2) { t1 = rg_clock(); if (LANE == 0) s.prof[k] += (float)(t1 - t0); t0 = t1; } } while (0)
   int nv = m.nv, nvc = m.nvc, hs = m.hs, ns = nsrow(m), ncon = s.ncon;
@@ -1954,6 +1960,16 @@ __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, const float* P, int& ne
   { bool chg; rg_constraint_update(m, s, RR, chg); }
   rg_JT_force(m, s, RR, s.jtf);
 #endif
+  if (SENSORS) {   // sensor pass (its own instantiation: the hot path's solver carries none of this): normal force of every contact = sum of its pyramid edge forces (mju_decodePyramid), f = -D jar where jar < 0
+    PFOR(c, ncon) s.c_bfrc[c] = 0.f;
+    SYNC();
+#pragma unroll
+    for (int k = 0; k < RG_PSLOTS; k++) {
+      int w = LANE + RG_WAVE * k;
+      if (w < ncon * 6) { int cc = w / 6; if ((w - 6 * cc) < npyr(s.c_dim[cc]) && RR.pjar[k] < 0) atomicAdd(s.c_bfrc + cc, -s.c_D[cc] * RR.pjar[k]); }
+    }
+    SYNC();
+  }
   PFOR(d, nv) { int i = m.d2c[d]; s.qacc[d] = i >= 0 ? s.a[i] : s.qacc_smooth[d]; s.qfrc_con[d] = i >= 0 ? s.jtf[i] : 0.f; }
   SYNC();
   return iters;
@@ -2004,6 +2020,79 @@ __device__ __forceinline__ void rg_dump_slv(RgM m, RgLds& s, float* dbg, int nef
 }
 
 // ------------------------------------------------------------------------------------------------- stage calls (definitions of RgLaunch / RgCtx / RG_STAGE: top of the file)
+// ------------------------------------------------------------------------------------------------- touch sensors
+// mj_sensorAcc, mjSENS_TOUCH (oracle: ro_sensor): the sum of the normal forces of the contacts on the site's body whose contact
+// point sees the site's volume along the contact normal.  The geometric half runs while the position stage is alive
+// (c_touch masks), the force half after the solve.
+__device__ __forceinline__ bool ray_hits_sphere(v3 c, float r, v3 p, v3 v) {
+  v3 w = p - c; float vv = dot(v, v);
+  float t = vv > 0 ? -dot(w, v) / vv : 0.f; t = t < 0 ? 0.f : t;
+  v3 q = w + v * t;
+  return dot(q, q) <= r * r;
+}
+__device__ __forceinline__ bool ray_hits_site(int type, v3 size, v3 p, v3 v) {   // p, v in the site frame
+  if (type == RG_GEOM_SPHERE) return ray_hits_sphere(mk3(0, 0, 0), size.x, p, v);
+  if (type == RG_GEOM_CAPSULE || type == RG_GEOM_CYLINDER) {
+    float r = size.x, h = size.y;
+    float a = v.x * v.x + v.y * v.y, b = p.x * v.x + p.y * v.y, cc = p.x * p.x + p.y * p.y - r * r;
+    bool in = false; float t0 = 0, t1 = 3.0e38f;
+    if (a < 1e-30f) in = !(cc > 0);
+    else { float det = b * b - a * cc; if (det >= 0) { float sq = sqrtf(det); t0 = (-b - sq) / a; t1 = (-b + sq) / a; in = t1 >= 0; t0 = t0 < 0 ? 0.f : t0; } }
+    if (in) {
+      float z0 = p.z + t0 * v.z, z1 = t1 > 1e37f ? (v.z > 0 ? 3.0e38f : (v.z < 0 ? -3.0e38f : p.z)) : p.z + t1 * v.z;
+      float lo = fminf(z0, z1), hi = fmaxf(z0, z1);
+      if (lo <= h && hi >= -h) return true;
+    }
+    if (type == RG_GEOM_CYLINDER) return false;
+    return ray_hits_sphere(mk3(0, 0, h), r, p, v) || ray_hits_sphere(mk3(0, 0, -h), r, p, v);
+  }
+  if (type == RG_GEOM_ELLIPSOID) return ray_hits_sphere(mk3(0, 0, 0), 1.f, mk3(p.x / size.x, p.y / size.y, p.z / size.z), mk3(v.x / size.x, v.y / size.y, v.z / size.z));
+  if (type == RG_GEOM_BOX) {
+    float t0 = 0, t1 = 3.0e38f; float pp[3] = {p.x, p.y, p.z}, vv[3] = {v.x, v.y, v.z}, ss[3] = {size.x, size.y, size.z};
+    for (int k = 0; k < 3; k++) {
+      if (fabsf(vv[k]) < 1e-30f) { if (fabsf(pp[k]) > ss[k]) return false; continue; }
+      float a = (-ss[k] - pp[k]) / vv[k], b = (ss[k] - pp[k]) / vv[k];
+      t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b));
+    }
+    return t0 <= t1;
+  }
+  return false;
+}
+#if RG_SENSORS
+__device__ __forceinline__ void rg_touch_geom(RgM m, RgLds& s, const float* P) {
+  PFOR(c, s.ncon) {
+    const float* R = m.pair_rec + RG_PAIRREC * s.c_pair[c];
+    int hdr = __builtin_bit_cast(int, R[0]), bb = __builtin_bit_cast(int, R[19]), b1 = bb & 255, b2 = bb >> 8;
+    v3 pos = ld3(s.c_pos + 3 * c), n = ld3(s.c_normal + 3 * c);
+    int mask = 0;
+    for (int k = 0; k < m.nsensor; k++) {
+      int site = m.sensor_site[k], body = m.site_bodyid[site];
+      if (body != b1 && body != b2) continue;
+      // the body frames of the position stage are gone by now (their LDS was reused); the frame of the contact's own geom on
+      // that body is still there: body = geom frame o inverse(geom's local frame)
+      int g = body == b1 ? (hdr & 255) : ((hdr >> 8) & 255);
+      q4 gl = ldq(m.geom_quat + 4 * g); gl.x = -gl.x; gl.y = -gl.y; gl.z = -gl.z;
+      q4 bq = qmul(ldq(s.gquat + 4 * g), gl);
+      v3 bp = ld3(s.gpos + 3 * g) - qrot(bq, ld3(m.geom_pos + 3 * g));
+      q4 q = qmul(bq, ldq(m.site_quat + 4 * site));
+      v3 lp = qrotT(q, pos - (bp + qrot(bq, ld3(P + RG_PRM_SITE_POS + 3 * site)))), lv = qrotT(q, body == b2 ? n * -1.0f : n);
+      if (ray_hits_site(m.site_type[site], ld3(m.site_size + 3 * site), lp, lv)) mask |= 1 << k;
+    }
+    s.c_touch[c] = (unsigned char)mask;
+  }
+  SYNC();
+}
+// after the solve: s.c_bfrc[c] holds the normal force of contact c (rg_solve, sensor pass)
+__device__ __forceinline__ void rg_touch_write(RgM m, RgLds& s, float* xd) {
+  PFOR(k, m.nsensor) {
+    float f = 0;
+    for (int c = 0; c < s.ncon; c++) { float nf = s.c_bfrc[c]; if (((s.c_touch[c] >> k) & 1) && nf > 0) f += nf; }
+    xd[RG_XD_SENSOR + k] = f;
+  }
+  SYNC();
+}
+#endif
+
 RG_STAGE void st_kinematics(RgCtx c) { RgM m = RG_M(c); RgLRef L = RG_L(c); rg_kinematics(m, RG_S(), rg_prm(m, L)); }
 RG_STAGE void st_com_pos(RgCtx c) { RgM m = RG_M(c); rg_com_pos(m, RG_S(), rg_prm(m, RG_L(c))); }
 RG_STAGE void st_tendon(RgCtx c) { rg_tendon(RG_M(c), RG_S()); }
@@ -2019,7 +2108,14 @@ RG_STAGE void st_make_constraint(RgCtx c) { RgM m = RG_M(c); rg_make_constraint(
 RG_STAGE void st_pid(RgCtx c) { RgM m = RG_M(c); rg_pid(m, RG_S(), rg_prm(m, RG_L(c))); }
 RG_STAGE void st_smooth(RgCtx c) { RgM m = RG_M(c); rg_smooth(m, RG_S(), rg_prm(m, RG_L(c))); }
 RG_STAGE void st_factor_smooth(RgCtx c) { RgLds& s = RG_S(); rg_ltdl_factor_solve(RG_M(c), s, (const float*)0, 0.f, s.qacc_smooth); }
-RG_STAGE_BIG int st_solve(RgCtx c) { RgM m = RG_M(c); int nefc = 0; int it = rg_solve(m, RG_S(), rg_prm(m, RG_L(c)), nefc, RG_L(c).flags); return it | (nefc << 8); }
+RG_STAGE_BIG int st_solve(RgCtx c) { RgM m = RG_M(c); int nefc = 0; int it = rg_solve<false>(m, RG_S(), rg_prm(m, RG_L(c)), nefc, RG_L(c).flags); return it | (nefc << 8); }
+#if RG_SENSORS
+RG_STAGE_BIG int st_solve_sensors(RgCtx c) { RgM m = RG_M(c); int nefc = 0; int it = rg_solve<true>(m, RG_S(), rg_prm(m, RG_L(c)), nefc, RG_L(c).flags); return it | (nefc << 8); }
+#endif
+#if RG_SENSORS
+RG_STAGE void st_touch_geom(RgCtx c) { RgM m = RG_M(c); rg_touch_geom(m, RG_S(), rg_prm(m, RG_L(c))); }
+RG_STAGE void st_touch_write(RgCtx c) { RgM m = RG_M(c); RgLRef L = RG_L(c); rg_touch_write(m, RG_S(), L.bt.xdata + (size_t)rg_env(L) * RG_XDATA); }
+#endif
 RG_STAGE void st_euler(RgCtx c) { RgM m = RG_M(c); rg_euler(m, RG_S(), rg_prm(m, RG_L(c))); }
 RG_STAGE void st_build_row_desc(RgCtx c) { rg_build_row_desc(RG_M(c), RG_S()); }
 RG_STAGE void st_dump(RgCtx c, int which, int nefc, int iters) {
@@ -2152,7 +2248,29 @@ __global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_kernel(con
       if (nsubsteps == 0 && LANE == 0) xd[RG_XD_NCON] = 0.f;
     }
     st_com_pos(c); st_tendon(c);
-    for (int k = 0; k < nticks; k++) st_pid(c);
+#if RG_SENSORS
+    const bool sensors = (flags & 32) && L.bt.xdata && m.nsensor > 0 && nticks > 0;
+#else
+    const bool sensors = false;
+#endif
+    for (int k = 0; k < nticks - (sensors ? 1 : 0); k++) st_pid(c);
+#if RG_SENSORS
+    if (sensors) {
+      // data.sensordata: the LAST state-less forward of the reference in full — contacts and their forces at the final state
+      // (mj_sensorAcc reads efc_force); its actuation stage is the last controller tick
+      st_crb(c); st_velocity(c); st_collision(c); st_make_constraint(c);
+      if (L.bt.redo && (s.status & ~status0 & (RG_STATUS_CON_FULL | RG_STATUS_CAND_FULL))) {
+        if (L.bt.pairlb) { float* lb = L.bt.pairlb + (size_t)e * m.npair; PFOR(i, m.npair) lb[i] = 0.f; }
+        if (LANE == 0) L.bt.redo[e] = 1;
+        return;
+      }
+      st_touch_geom(c);
+      st_pid(c); st_smooth(c);
+      st_factor_smooth(c);
+      st_solve_sensors(c);
+      st_touch_write(c);
+    }
+#endif
     if (L.bt.xdata) PFOR(u, m.nu) L.bt.xdata[(size_t)e * RG_XDATA + RG_XD_ACT_FORCE + u] = s.actfrc[u];
   }
   // ---- write back
@@ -2232,6 +2350,7 @@ __global__ void rg_copy_rows_kernel(float* dst, const float* src, const int* mas
 }
 }  // namespace RG_NS
 #undef RG_MAXPYR
+#undef RG_SENSORS
 #undef RG_PSLOTS
 #undef RG_RSLOTS
 #undef RG_MSLOTS

@@ -23,6 +23,7 @@
 #define RG_LTDL_TRI_ROUNDS 12   // caps on the descriptor rounds of the L'DL passes (registers per lane)
 #define RG_LTDL_PAIR_ROUNDS 8
 #define RG_KINREC 20    // words per kinematics record
+#define RG_MAXSENSOR 8
 #define RG_PAIRREC 28   // words per pair record
 #define RG_PAIR_SCALED1 (1 << 28)   // pair record header: geom 1 / geom 2 takes the env's RG_PRM_GEOM_SCALE
 #define RG_PAIR_SCALED2 (1 << 29)
@@ -66,7 +67,8 @@ enum {
   RG_XD_ACT_FORCE = RG_XD_SITE_XPOS + 3 * RG_MAXSITE,   // nu    data.actuator_force (of the last state-less forward)
   RG_XD_NCON = RG_XD_ACT_FORCE + RG_MAXU,           // 1         data.ncon of the last mj_step
   RG_XD_CONTACT = RG_XD_NCON + 1,                   // RG_DBG_MAXCON x (geom1, geom2, dist)
-  RG_XDATA = RG_XD_CONTACT + 3 * 32
+  RG_XD_SENSOR = RG_XD_CONTACT + 3 * 32,            // RG_MAXSENSOR  data.sensordata (touch sensors; launches with flags bit 5)
+  RG_XDATA = RG_XD_SENSOR + 8
 };
 
 // per-env sticky status bits (replace MuJoCo's warning callback, warning_buffer.py:27-83)
@@ -116,6 +118,9 @@ struct RgModelDev {
   const float *geom_size, *geom_rbound, *geom_pos, *geom_quat, *geom_aabb;
   const int* site_bodyid;
   const float *site_pos;
+  int nsensor;                  // touch sensors (mjSENS_TOUCH): site ids, and the shape of every site
+  const int *sensor_site, *site_type;
+  const float *site_size, *site_quat;
   const int *mesh_vertadr, *mesh_vertnum;
   const float* mesh_vert;
   // hull vertices that can be the support point for a direction in the cell (ascending vertex index):

@@ -57,6 +57,7 @@ class BatchedSimulationInterface:
         self._params = None
         self._xdata = None
         self._data = None
+        self.sensors = False      # data.sensordata requested (see BatchedData.sensordata)
 
     def __del__(self):
         try:
@@ -191,8 +192,8 @@ class BatchedSimulationInterface:
         refreshed by every step / forward launch from now on, body_xpos, body_xquat, site_xpos, actuator_force, ncon and the
         contact list (geom1, geom2, dist).  First access switches the readout on (one more row written per env per launch)."""
         if self._data is None:
-            lay = (ctypes.c_int * 8)()
-            self._L.rg_xdata_layout(lay, 8)
+            lay = (ctypes.c_int * 10)()
+            assert self._L.rg_xdata_layout(lay, 10) == 10, "rg_xdata_layout and simulation_interface.py disagree"
             self._xdata = torch.zeros((self.batch_size, int(lay[0])), dtype=torch.float32, device=self.device)
             self._data = BatchedData(self, [int(v) for v in lay])
             self.forward(ticks=0)   # fill it for the current state
@@ -260,7 +261,7 @@ class BatchedSimulationInterface:
         a.hold_dev, a.nticks_dev, a.order_dev, a.preticks_dev = (None if t is None else t.data_ptr() for t in (hold, nticks, order, preticks))
         a.xdata_dev = None if self._xdata is None else self._xdata.data_ptr()
         a.nsubsteps = self.n_substeps if nsubsteps is None else int(nsubsteps)
-        a.nforward_ticks, a.flags = int(nforward_ticks), int(flags) | (_native.RG_FLAG_MPR_PLANE_DEPTH if MPR_PLANE_DEPTH else 0)
+        a.nforward_ticks, a.flags = int(nforward_ticks), int(flags) | (_native.RG_FLAG_MPR_PLANE_DEPTH if MPR_PLANE_DEPTH else 0) | (_native.RG_FLAG_SENSORS if self.sensors else 0)
         self._keep.append((action, goal_quat, obs, goal_dist, active, hold, nticks, order, large_mask))
         del self._keep[:-16]
 
@@ -346,7 +347,7 @@ class BatchedData:
 
     def __init__(self, sim: BatchedSimulationInterface, lay):
         self._sim = sim
-        row, o_xpos, o_xquat, o_site, o_act, o_ncon, o_con, ncon_slots = lay
+        row, o_xpos, o_xquat, o_site, o_act, o_ncon, o_con, ncon_slots, o_sensor, sensor_slots = lay
         d = sim.model.dims
         nb, ns, nu = int(d[3]), int(d[6]), int(d[2])
         x, B = sim._xdata, sim.batch_size
@@ -358,12 +359,25 @@ class BatchedData:
         self.actuator_force = x[:, o_act:o_act + nu]
         self._ncon = x[:, o_ncon]
         self._contact = x[:, o_con:o_con + 3 * ncon_slots].view(B, ncon_slots, 3)
+        nsens = len(sim.model.names.get("sensor", []))
+        assert nsens <= sensor_slots
+        self._sensordata = x[:, o_sensor:o_sensor + nsens]
 
     qpos = property(lambda self: self._sim.view(_native.RG_F_QPOS))
     qvel = property(lambda self: self._sim.view(_native.RG_F_QVEL))
     ctrl = property(lambda self: self._sim.view(_native.RG_F_CTRL))
     time = property(lambda self: self._sim.view(_native.RG_F_TIME)[:, 0])
     ncon = property(lambda self: self._ncon.to(torch.int32))
+
+    @property
+    def sensordata(self) -> torch.Tensor:
+        """data.sensordata (touch sensors), `[B, nsensor]`: the contact normal forces each sensor's site sees, evaluated at the final
+        state by the last state-less forward of the step.  That forward then runs in full (collision + solve: about one more
+        substep of work), so it is opt-in: first access switches it on (`sim.sensors = True`, rg_step_args.flags bit 5) and the
+        values are valid from the next step on."""
+        if not self._sim.sensors:
+            self._sim.sensors = True
+        return self._sensordata
 
     @property
     def contact(self):

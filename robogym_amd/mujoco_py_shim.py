@@ -113,6 +113,7 @@ class PyMjData:
         self.site_xpos, self.body_xpos, self.body_xquat = np.zeros((m.nsite, 3)), np.zeros((m.nbody, 3)), np.zeros((m.nbody, 4))
         self.xpos, self.xquat = self.body_xpos, self.body_xquat
         self.time, self.ncon, self.contact = 0.0, 0, []
+        self.sensordata = np.zeros(len(m.sensor_names))   # touch sensors (mj_sensorAcc): evaluated by forward()
 
     def get_site_xpos(self, name):
         return self.site_xpos[self._model.site_name2id(name)]
@@ -149,6 +150,9 @@ class MjSim:
         kw = dict(lib=lib) if lib is not None else dict(device=device)
         self._sim = BatchedSimulationInterface(model._compiled, 1, n_substeps=self.nsubsteps, **kw)
         self._sim.data           # readout row on
+        self._sensors = len(model.sensor_names) > 0
+        if self._sensors:
+            self._sim.data.sensordata   # sensor pass on
         self._P = self._sim.params
         self.data = PyMjData(model)
         self.reset()
@@ -180,6 +184,8 @@ class MjSim:
         d.time = float(s.view(_native.RG_F_TIME)[0, 0])
         d.site_xpos[:] = x.site_xpos[0].cpu().numpy(); d.body_xpos[:] = x.body_xpos[0].cpu().numpy(); d.body_xquat[:] = x.body_xquat[0].cpu().numpy()
         d.actuator_force[:] = x.actuator_force[0].cpu().numpy()
+        if self._sensors:
+            d.sensordata[:] = x.sensordata[0].cpu().numpy()
         g1, g2, dist = x.contact
         d.ncon = int(x.ncon[0])
         d.contact = [_Contact(g1[0, i], g2[0, i], dist[0, i]) for i in range(d.ncon)]
@@ -192,7 +198,7 @@ class MjSim:
         """nsubsteps x mj_step (mujoco_py's MjSim.step does not add a forward; SimulationInterface.step does, :176-189)."""
         self._upload()
         self._sim.env_step(nsubsteps=self.nsubsteps, nforward_ticks=0)
-        self._download()
+        self._download()      # (data.sensordata keeps the values of the last forward(): mj_step's own sensor pass describes the state BEFORE its integration step and is not reproduced)
 
     def forward(self):
         self._upload()

@@ -153,3 +153,42 @@ def test_product_library_loads_and_exports_the_header():
     assert set(_native.EXPORTS) == set(declared)
     assert L.rg_post_args_size() == ctypes.sizeof(_native.PostArgs)
     assert L.rg_lds_bytes_cfg(0) <= 11 * 1280 and 160 * 1024 // (-(-L.rg_lds_bytes_cfg(1) // 1280) * 1280) >= 5
+
+
+def _check_touch_sensors(sim, ora, model, nsteps):
+    """Fingers closing on the cube: data.sensordata (mj_sensorAcc, touch) of the step's last forward against the oracle's, each
+    step from the oracle's state."""
+    d = sim.data
+    d.sensordata                                   # switches the sensor pass on
+    ora.sim.reset(); ora.settle(40)
+    a = np.zeros(20, dtype=np.float32)
+    for i, n in enumerate(model.names["actuator"]):
+        if n.endswith(("FJ2", "FJ1", "THJ1", "THJ0", "THJ4")):
+            a[i] = 1.0
+    B, seen = sim.batch_size, 0.0
+    for t in range(nsteps):
+        st = ora.get_state_f32(); ora.set_state_f32(st)
+        _put_rows(sim, np.arange(B), {k: np.repeat(st[k][None], B, 0) for k in STATE_FIELDS})
+        sim.env_step(action=torch.as_tensor(np.repeat(a[None], B, 0), device=sim.device), nforward_ticks=3)
+        ora.env_step(a)
+        got, want = d.sensordata[0].cpu().numpy().astype(np.float64), ora.sim.sensordata.copy()
+        np.testing.assert_allclose(got, want, atol=0.02 + 0.02 * np.abs(want).max(), err_msg="step %d" % t)
+        seen = max(seen, float(want.max()))
+        np.testing.assert_allclose(sim.view(3)[0].cpu().numpy(), ora.sim.pid, atol=1e-2)     # the full forward is still exactly ONE controller tick (filtered derivatives under contact: 1e-2)
+    return seen
+
+
+def test_touch_sensors_match_oracle_emul(locked_model, emul_lib, oracle_lib):
+    from oracle.env_oracle import OracleLockedEnvPhysics
+    from robogym_amd.envs.dactyl.locked import LockedSimulation
+
+    _check_touch_sensors(LockedSimulation(locked_model, 1, lib=emul_lib, n_substeps=10), OracleLockedEnvPhysics(locked_model), locked_model, 2)
+
+
+@pytest.mark.gpu
+def test_touch_sensors_match_oracle_gpu(locked_model, oracle_lib):
+    from oracle.env_oracle import OracleLockedEnvPhysics
+    from robogym_amd.envs.dactyl.locked import LockedSimulation
+
+    seen = _check_touch_sensors(LockedSimulation(locked_model, 2, device="cuda:0"), OracleLockedEnvPhysics(locked_model), locked_model, 20)
+    assert seen > 1.0       # the fingertips did press on the cube (several newtons)

@@ -76,6 +76,8 @@ def test_model_surface_and_step_against_oracle(locked_model, emul_lib, oracle_li
     for _ in range(8):
         sim.step()
     assert z_up > sim.data.get_joint_qpos("cube:cube_tz") + 1e-3
+    sim.forward()
+    assert sim.data.sensordata.shape == (5,) and (sim.data.sensordata >= 0).all()
     sim.reset()
     np.testing.assert_allclose(sim.data.qpos, locked_model.qpos0, atol=1e-7)
     assert sim.data.time == 0.0 and not sim.data.qvel.any()
