@@ -196,6 +196,19 @@ def load_stl(path):
     return np.frombuffer(raw, dtype=rec, count=n, offset=84)["v"].astype(float)
 
 
+def load_msh(path):
+    """MuJoCo's legacy binary mesh (.msh): int32 nvertex, nnormal, ntexcoord, nface, then float32 vertices [nvertex, 3], normals
+    [nnormal, 3], texcoords [ntexcoord, 2], int32 faces [nface, 3]  ->  (nfaces, 3, 3) triangle soup."""
+    with open(path, "rb") as f:
+        raw = f.read()
+    nv, nn, nt, nf = struct.unpack("<4i", raw[:16])
+    if 16 + 4 * (3 * nv + 3 * nn + 2 * nt + 3 * nf) != len(raw):
+        raise ValueError("%s: not a MuJoCo .msh file" % path)
+    vert = np.frombuffer(raw, dtype="<f4", count=3 * nv, offset=16).reshape(nv, 3).astype(float)
+    face = np.frombuffer(raw, dtype="<i4", count=3 * nf, offset=16 + 4 * (3 * nv + 3 * nn + 2 * nt)).reshape(nf, 3)
+    return vert[face]
+
+
 def _legacy_mesh_frame(tris):
     """Centre of mass and principal frame of a triangle mesh, MuJoCo-2.0 style:
     pyramids from the area-weighted face centroid with unsigned volumes."""
@@ -226,7 +239,7 @@ def _legacy_mesh_frame(tris):
 def process_mesh(path, scale):
     from scipy.spatial import ConvexHull
 
-    tris = load_stl(path) * np.asarray(scale, dtype=float)
+    tris = (load_msh(path) if path.lower().endswith(".msh") else load_stl(path)) * np.asarray(scale, dtype=float)
     com, R, volume = _legacy_mesh_frame(tris)
     pts = np.unique(tris.reshape(-1, 3), axis=0)
     hull = ConvexHull(pts)

@@ -150,6 +150,14 @@ class MujocoXML:
                         parent.remove(child)
         return self
 
+    def remove_objects_by_prefix(self, prefix: str, tag: str = "*") -> "MujocoXML":
+        """mujoco_xml.py:351-358: drop every named `tag` element whose name starts with `prefix`."""
+        for parent in self.root_element.findall(".//%s[@name]/.." % tag):
+            for child in list(parent):
+                if (tag == "*" or child.tag == tag) and (child.get("name") or "").startswith(prefix):
+                    parent.remove(child)
+        return self
+
     def remove_objects_by_tag(self, tag: str) -> "MujocoXML":
         for parent in self.root_element.findall(".//%s/.." % tag):
             for child in list(parent):
