@@ -292,3 +292,32 @@ def test_auto_reset_around_the_pipelined_env_emul(locked_model, emul_lib):
     assert bool(done[1]) and float(reward[1, 3]) == -20.0 and bool(info["fell_down"][1]) and float(reward[0, 3]) == 0.0
     obs, reward, done, info = env.step(a)
     assert bool(info["resetting"][1]) and float(reward[1, 3]) == 0.0 and not bool(info["fell_down"][1])
+
+
+@pytest.mark.gpu
+def test_auto_reset_rollout_gpu(locked_model):
+    """The default randomized env with in-step resets on the MI355X: 200 steps at B = 512 with goals timing out after 25
+    steps — episodes end and restart without any reset() call, every restart redraws that env's physics, the drop penalty is
+    paid at most once per episode, nothing non-finite, no status bit."""
+    from robogym_amd.envs.dactyl.locked import make_env
+
+    B = 512
+    env = make_env(constants={"max_timesteps_per_goal": 25}, batch_size=B, model=locked_model, starting_seed=11, pipelined_reset=True)
+    obs = env.reset()
+    P = env.unwrapped.mujoco_simulation.params
+    g0 = P["gravity"].clone()
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(2)
+    ends = torch.zeros(B, dtype=torch.int32, device="cuda:0"); starts = ends.clone(); drops = ends.clone(); bad = 0
+    since_start_drops = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+    for t in range(200):
+        obs, reward, done, info = env.step(torch.randint(0, 11, (B, 20), generator=gen, device="cuda:0"))
+        ends += done.to(torch.int32); starts += info["episode_started"].to(torch.int32)
+        d = (reward[:, 3] < 0).to(torch.int32)
+        since_start_drops = torch.where(info["episode_started"].bool(), torch.zeros_like(d), since_start_drops + d)
+        drops += d
+        assert int(since_start_drops.max()) <= 1
+        bad += int(sum((~torch.isfinite(v.float())).sum() for v in obs.values()))
+    assert bad == 0 and int(env.unwrapped.sim_status().max()) == 0
+    assert int(ends.sum()) > B and int(starts.sum()) > B // 2 and int(drops.sum()) > 0
+    changed = (P["gravity"] != g0).any(dim=1)
+    assert bool((changed | (ends == 0)).all())          # every env whose episode ended got new physics
