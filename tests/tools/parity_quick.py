@@ -2,7 +2,7 @@
 200 random-action env-steps, plus the mean Newton iterations: the A/B companion of tools/gpu_ab.sh (RGSTEP_LIB)."""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import rg_oracle
 from oracle.env_oracle import OracleLockedEnvPhysics

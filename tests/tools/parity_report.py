@@ -2,7 +2,7 @@
 CPU oracle at env-steps 1, 10, 100, 1000 and the first step beyond 1e-4, plus the re-synchronised one-env-step
 errors over the same action stream.  Oracle = test infrastructure (oracle/): this tool is a checker, not product.
 
-    python tools/parity_report.py [n_streams] [n_steps]  > profiles/rNN_parity.txt
+    python tests/tools/parity_report.py [n_streams] [n_steps]  > profiles/rNN_parity.txt
 """
 import os
 import sys
@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle.env_oracle import OracleLockedEnvPhysics  # noqa: E402
 from robogym_amd.envs.dactyl.locked import LockedSimulation, load_locked_model  # noqa: E402

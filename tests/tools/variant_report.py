@@ -5,14 +5,14 @@ mode, from identical fp64 states along random-action rollouts.  Per state: the c
 geom pair), their depth and normal deltas, and the non-target qpos / qvel delta after ONE mj_step and after one env.step.
 CPU only (oracle = test infrastructure).
 
-    python tools/variant_report.py [n_streams] [n_steps]  >> profiles/rNN_parity.txt
+    python tests/tools/variant_report.py [n_streams] [n_steps]  >> profiles/rNN_parity.txt
 """
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import rg_oracle  # noqa: E402
 from oracle.env_oracle import OracleLockedEnvPhysics  # noqa: E402

@@ -16,5 +16,5 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_write_$R -o write --
 python tools/stage_profile.py 8192 > gpurun_out/stage_$R.txt 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM -d gpurun_out/pmc1 -o pmc1 --output-format csv -- python tools/stage_profile.py 8192 > gpurun_out/pmc1.log 2>&1
 rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_MISSES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_WAVES -d gpurun_out/pmc2 -o pmc2 --output-format csv -- python tools/stage_profile.py 8192 > gpurun_out/pmc2.log 2>&1
-python tools/parity_report.py 4 1000 > gpurun_out/parity_$R.txt 2>&1
+python tests/tools/parity_report.py 4 1000 > gpurun_out/parity_$R.txt 2>&1
 ls gpurun_out/prof_$R gpurun_out/pmc_fetch_$R gpurun_out/pmc_write_$R | head -20
