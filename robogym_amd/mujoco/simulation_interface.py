@@ -99,7 +99,9 @@ class BatchedSimulationInterface:
                 raise _native.NativeError("rg_batch_field_ptr: " + self._L.rg_last_error().decode())
             shape = (self.batch_size, int(n.value))
             is_int = field == _native.RG_F_STATUS
-            if self._emul:
+            if shape[1] == 0:      # a model without actuators: nothing to alias
+                t = torch.zeros(shape, dtype=torch.int32 if is_int else torch.float32, device=self.device)
+            elif self._emul:
                 ctype = ctypes.c_int32 if is_int else ctypes.c_float
                 arr = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctype)), shape=shape)
                 t = torch.from_numpy(arr)

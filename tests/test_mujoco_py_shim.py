@@ -131,3 +131,79 @@ def test_move_hand_through_the_shim_gpu():
             sim.step()
         observed = P @ sim.data.qpos[hand_q]
         assert np.rad2deg(np.abs(observed - control)).max() < 7.5, (name, np.rad2deg(np.abs(observed - control)))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the KERNEL against closed forms (no oracle in the loop): Coulomb's law on a slope, the period of a compound pendulum
+SLOPE = """
+<mujoco>
+  <compiler angle="radian"/>
+  <option timestep="0.002" gravity="{gx} 0 {gz}"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="2 2 1" condim="3" friction="{mu} 0.005 0.0001"/>
+    <body name="box" pos="0 0 0.0195">
+      <joint name="free" type="free"/>
+      <geom name="box" type="box" size="0.05 0.05 0.02" density="600" condim="3" friction="{mu} 0.005 0.0001"/>
+    </body>
+  </worldbody>
+</mujoco>
+"""
+PENDULUM = """
+<mujoco>
+  <compiler angle="radian"/>
+  <option timestep="0.0005" gravity="0 0 -9.81"/>
+  <worldbody>
+    <body name="rod" pos="0 0 1">
+      <joint name="hinge" type="hinge" axis="0 1 0"/>
+      <geom name="rod" type="box" size="0.01 0.02 0.15" pos="0 0 -0.15" density="1000"/>
+    </body>
+  </worldbody>
+</mujoco>
+"""
+
+
+def _slope(mujoco_py, kw, mu, tan_theta, T):
+    g, th = 9.81, np.arctan(tan_theta)
+    sim = mujoco_py.MjSim(mujoco_py.load_model_from_xml(SLOPE.format(gx=g * np.sin(th), gz=-g * np.cos(th), mu=mu)), nsubsteps=int(round(T / 0.002)), **kw)
+    sim.step()
+    return float(sim.data.qvel[0]), g * (np.sin(th) - mu * np.cos(th)) * T, g * np.sin(th) * T
+
+
+def _pendulum_period(mujoco_py, kw):
+    sim = mujoco_py.MjSim(mujoco_py.load_model_from_xml(PENDULUM), nsubsteps=1, **kw)
+    sim.data.qpos[0] = 0.02
+    crossings, prev, t = [], 0.02, 0.0
+    while len(crossings) < 2 and t < 3.0:
+        sim.step(); t += 0.0005
+        q = float(sim.data.qpos[0])
+        if prev > 0 >= q:
+            crossings.append(t - 0.0005 * (0 - q) / (prev - q))
+        prev = q
+    a, b, c, l = 0.01, 0.02, 0.15, 0.15
+    mass = 1000 * 8 * a * b * c
+    return crossings[1] - crossings[0], 2 * np.pi * np.sqrt((mass * ((2 * a) ** 2 + (2 * c) ** 2) / 12 + mass * l * l) / (mass * 9.81 * l))
+
+
+def test_kernel_obeys_coulomb_friction_emul(emul_lib):
+    from robogym_amd import mujoco_py_shim as mujoco_py
+
+    vx, sliding, free = _slope(mujoco_py, dict(lib=emul_lib), 0.3, 1.4 * 0.3, 0.2)
+    assert abs(vx - sliding) < 0.06 * sliding
+    vx, _, free = _slope(mujoco_py, dict(lib=emul_lib), 0.3, 0.7 * 0.3, 0.2)
+    assert abs(vx) < 0.01 * free
+
+
+@pytest.mark.gpu
+def test_kernel_obeys_closed_forms_gpu():
+    """The HIP kernel itself (fp32, MI355X) against physics closed forms, no oracle involved: a = g (sin theta - mu cos theta)
+    above the friction angle and rest below it, for two friction coefficients; T = 2 pi sqrt(I / (m g l)) of a compound pendulum
+    to 0.2 %."""
+    from robogym_amd import mujoco_py_shim as mujoco_py
+
+    for mu in (0.3, 0.8):
+        vx, sliding, free = _slope(mujoco_py, {}, mu, 1.4 * mu, 0.6)
+        assert abs(vx - sliding) < 0.06 * sliding, (mu, vx, sliding)
+        vx, _, free = _slope(mujoco_py, {}, mu, 0.7 * mu, 0.6)
+        assert abs(vx) < 0.01 * free, (mu, vx)
+    got, want = _pendulum_period(mujoco_py, {})
+    assert abs(got - want) < 2e-3 * want, (got, want)

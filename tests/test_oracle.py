@@ -254,3 +254,71 @@ def test_mpr_plane_variant_equals_libccd_variant_when_projection_is_interior(loc
             np.testing.assert_allclose(a[3], b[3], atol=1e-12)  # the contact position is the same
             same += abs(a[1] - b[1]) < 1e-9
     assert same >= 2
+
+
+SLOPE = """
+<mujoco>
+  <compiler angle="radian"/>
+  <option timestep="0.002" gravity="{gx} 0 {gz}"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="2 2 1" condim="3" friction="{mu} 0.005 0.0001"/>
+    <body name="box" pos="0 0 0.0195">
+      <joint type="free"/>
+      <geom type="box" size="0.05 0.05 0.02" density="600" condim="3" friction="{mu} 0.005 0.0001"/>
+    </body>
+  </worldbody>
+</mujoco>
+"""
+
+
+@pytest.mark.parametrize("mu", [0.3, 0.8])
+def test_coulomb_friction_on_a_slope(mu):
+    """Physics, not MuJoCo lore: a box on a plane tilted by theta (gravity rotated about y: the slope runs along a pyramid axis,
+    where the pyramidal cone is exact; a flat box, so it slides before it tips) stays put while tan(theta) < mu and slides with a = g (sin theta - mu cos theta) when
+    tan(theta) > mu.  Soft constraints allow a slow creep below the threshold (MuJoCo's documented behaviour): it must stay
+    two orders of magnitude under the sliding speed."""
+    g, T = 9.81, 0.6
+    for tan_theta, slides in ((0.7 * mu, False), (1.4 * mu, True)):
+        th = np.arctan(tan_theta)
+        m, s = _sim(SLOPE.format(gx=g * np.sin(th), gz=-g * np.cos(th), mu=mu))
+        n = int(T / 0.002)
+        for _ in range(n):
+            s.step()
+        vx = s.qvel[0]
+        expected = g * (np.sin(th) - mu * np.cos(th)) * T
+        if slides:
+            assert abs(vx - expected) < 0.06 * expected, (mu, vx, expected)
+        else:
+            assert abs(vx) < 0.01 * g * np.sin(th) * T, (mu, vx)
+        assert abs(s.qvel[1]) < 1e-3 and s.warn_bad == 0
+
+
+def test_small_oscillation_period_of_a_compound_pendulum():
+    """T = 2 pi sqrt(I_pivot / (m g l)): pins gravity, the rigid-body inertia about the hinge and the time integration (no
+    contact, no actuator, no damping) against the closed form, through the same model compiler."""
+    xml = """
+<mujoco>
+  <compiler angle="radian"/>
+  <option timestep="0.0005" gravity="0 0 -9.81"/>
+  <worldbody>
+    <body name="rod" pos="0 0 1">
+      <joint name="hinge" type="hinge" axis="0 1 0"/>
+      <geom type="box" size="0.01 0.02 0.15" pos="0 0 -0.15" density="1000"/>
+    </body>
+  </worldbody>
+</mujoco>
+"""
+    m, s = _sim(xml)
+    a, b, c, l = 0.01, 0.02, 0.15, 0.15                      # half sizes; the com sits l below the pivot
+    mass = 1000 * 8 * a * b * c
+    I_pivot = mass * ((2 * a) ** 2 + (2 * c) ** 2) / 12 + mass * l * l      # about the hinge's y axis
+    T = 2 * np.pi * np.sqrt(I_pivot / (mass * 9.81 * l))
+    s.qpos[0] = 0.02                                           # small amplitude: the linearisation error is ~ theta^2 / 16 = 2.5e-5
+    crossings, prev, t = [], s.qpos[0], 0.0
+    for k in range(int(2.6 * T / 0.0005)):
+        s.step(); t += 0.0005
+        if prev > 0 >= s.qpos[0]:                              # downward zero crossing, linearly interpolated
+            crossings.append(t - 0.0005 * (0 - s.qpos[0]) / (prev - s.qpos[0]))
+        prev = s.qpos[0]
+    assert len(crossings) >= 2
+    assert abs((crossings[1] - crossings[0]) - T) < 2e-3 * T, (crossings, T)
