@@ -207,3 +207,42 @@ def test_kernel_obeys_closed_forms_gpu():
         assert abs(vx) < 0.01 * free, (mu, vx)
     got, want = _pendulum_period(mujoco_py, {})
     assert abs(got - want) < 2e-3 * want, (got, want)
+
+
+@pytest.mark.gpu
+def test_kernel_resting_depth_matches_the_documented_soft_constraint_law_gpu():
+    """The HIP kernel against the closed form of MuJoCo's documented soft-constraint law (tests/test_oracle.py:
+    rest_depth_closed_form): a frictionless sphere at rest on a plane, three (solref, solimp) settings."""
+    from robogym_amd import mujoco_py_shim as mujoco_py
+    from tests.test_oracle import REST, REST_CASES, rest_depth_closed_form
+
+    for case in REST_CASES:
+        sim = mujoco_py.MjSim(mujoco_py.load_model_from_xml(REST.format(tc=case[0], dr=case[1], d0=case[2], d1=case[3], w=case[4])), nsubsteps=4000)
+        sim.step()
+        assert abs(sim.data.qvel[2]) < 1e-5
+        np.testing.assert_allclose(sim.data.qpos[2] - 0.05, rest_depth_closed_form(*case), rtol=2e-3)
+
+
+def _damped_wheel(mujoco_py, kw, n):
+    from tests.test_oracle import DAMPED, damped_wheel_closed_form
+
+    sim = mujoco_py.MjSim(mujoco_py.load_model_from_xml(DAMPED), nsubsteps=n, **kw)
+    sim.data.qvel[0] = 3.0
+    sim.step()
+    return float(sim.data.qvel[0]), damped_wheel_closed_form(n)
+
+
+def test_kernel_implicit_damping_emul(emul_lib):
+    from robogym_amd import mujoco_py_shim as mujoco_py
+
+    got, want = _damped_wheel(mujoco_py, dict(lib=emul_lib), 50)
+    assert abs(got - want) < 2e-5 * want
+
+
+@pytest.mark.gpu
+def test_kernel_implicit_damping_gpu():
+    """w' = w I / (I + h b) per step (mj_Euler's implicit joint damping), 250 steps, on the MI355X."""
+    from robogym_amd import mujoco_py_shim as mujoco_py
+
+    got, want = _damped_wheel(mujoco_py, {}, 250)
+    assert abs(got - want) < 1e-4 * want, (got, want)

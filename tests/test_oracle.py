@@ -322,3 +322,74 @@ def test_small_oscillation_period_of_a_compound_pendulum():
         prev = s.qpos[0]
     assert len(crossings) >= 2
     assert abs((crossings[1] - crossings[0]) - T) < 2e-3 * T, (crossings, T)
+
+
+REST = """
+<mujoco>
+  <compiler angle="radian"/>
+  <option timestep="0.001" gravity="0 0 -9.81"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="1 1 1" condim="1" solref="{tc} {dr}" solimp="{d0} {d1} {w}"/>
+    <body name="ball" pos="0 0 0.05">
+      <joint name="free" type="free"/>
+      <geom name="ball" type="sphere" size="0.05" density="1000" condim="1" solref="{tc} {dr}" solimp="{d0} {d1} {w}"/>
+    </body>
+  </worldbody>
+</mujoco>
+"""
+REST_CASES = ((0.02, 1.0, 0.9, 0.95, 0.001), (0.01, 1.0, 0.8, 0.8, 0.001), (0.05, 0.7, 0.9, 0.99, 0.01))
+
+
+def rest_depth_closed_form(tc, dr, d0, d1, w, g=9.81):
+    """MuJoCo documentation, "Solver parameters": a scalar constraint obeys a1 = (1 - d) a0 + d aref with aref = -b v - k d r,
+    k = 1 / (dmax^2 timeconst^2 dampratio^2).  A body at rest on it has a1 = 0, v = 0, a0 = -g, hence
+    r = -(1 - d) g dmax^2 timeconst^2 dampratio^2 / d^2, where d = d(|r|) rises from d0 to d1 over `width` along MuJoCo 2.0's
+    default power curve (midpoint 0.5, power 2): a fixed point in r."""
+    r = 0.0
+    for _ in range(200):
+        x = min(abs(r) / w, 1.0)
+        y = 2 * x * x if x < 0.5 else 1 - 2 * (1 - x) ** 2
+        d = d0 + (d1 - d0) * y
+        r = -(1 - d) * g * d1 * d1 * tc * tc * dr * dr / (d * d)
+    return r
+
+
+@pytest.mark.parametrize("case", REST_CASES)
+def test_resting_depth_matches_the_documented_soft_constraint_law(case):
+    """A frictionless sphere at rest on a plane sinks in by exactly what MuJoCo's documented constraint model says: pins the
+    reference acceleration, the impedance curve and the regulariser of the oracle against a closed form (constant impedance:
+    exact; position-dependent impedance: the fixed point above)."""
+    m, s = _sim(REST.format(tc=case[0], dr=case[1], d0=case[2], d1=case[3], w=case[4]))
+    for _ in range(4000):
+        s.step()
+    assert abs(s.qvel[2]) < 1e-9
+    np.testing.assert_allclose(s.qpos[2] - 0.05, rest_depth_closed_form(*case), rtol=1e-4)
+
+
+DAMPED = """
+<mujoco>
+  <compiler angle="radian"/>
+  <option timestep="0.004" gravity="0 0 0"/>
+  <worldbody>
+    <body name="wheel" pos="0 0 1">
+      <joint name="spin" type="hinge" axis="0 0 1" damping="0.05" armature="0.002"/>
+      <geom name="wheel" type="cylinder" size="0.1 0.02" density="900"/>
+    </body>
+  </worldbody>
+</mujoco>
+"""
+
+
+def damped_wheel_closed_form(n, h=0.004, b=0.05, arm=0.002, w0=3.0):
+    """mj_Euler treats joint damping implicitly: (I + h b) (w' - w) = h (-b w)  =>  w' = w I / (I + h b), exactly, every step."""
+    mass = 900 * np.pi * 0.1 ** 2 * 0.04
+    inertia = 0.5 * mass * 0.1 ** 2 + arm
+    return w0 * (inertia / (inertia + h * b)) ** n
+
+
+def test_implicit_damping_of_the_euler_integrator():
+    m, s = _sim(DAMPED)
+    s.qvel[0] = 3.0
+    for _ in range(250):
+        s.step()
+    np.testing.assert_allclose(s.qvel[0], damped_wheel_closed_form(250), rtol=1e-9)
