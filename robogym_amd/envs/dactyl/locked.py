@@ -370,12 +370,14 @@ class BatchedLockedEnv:
         moves ("rewards/dones ride in the same buffer").  Written by the env kernel of the last `step`."""
         return self._packed
 
+    _sort_every = int(os.environ.get("RG_SORT_EVERY", "1"))
+
     def _dispatch_order(self):
         """Longest-expected-first dispatch (rg_step_args.order_dev): the envs sorted by the cycles their previous
-        env.step took, so the launch's tail is made of short envs.  Re-sorted every fourth step (costs stay correlated)."""
+        env.step took, so the launch's tail is made of short envs.  Re-sorted every step (every 4th: -1.3 %; RG_SORT_EVERY overrides)."""
         if not self.sort_dispatch:
             return None
-        if self._order is None or self._order_age >= 4:
+        if self._order is None or self._order_age >= self._sort_every:
             self._order = torch.argsort(self.mujoco_simulation.view(_native.RG_F_COST)[:, 0], descending=True).to(torch.int32)
             self._order_age = 0
         self._order_age += 1
