@@ -193,7 +193,7 @@ def main():
                        "cube_on_palm_fraction": {"start_of_timed_region": on_palm_start, "end_of_timed_region": on_palm_end},
                        "pipelined_reset": bool(args.pipelined_reset), "sort_dispatch": bool(args.sort_dispatch),
                        "gathered_row": "obs 166 + reward 3 + done 1 = %d floats per env" % env.packed_dim},
-            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
+            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_unit": "GB per launch (PMC)", "algorithmic_gb_per_launch": b_step * B / 1e9,
                          "kernel": "rg_step_kernel", "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": b_step, "algorithmic_bytes_per_substep": b_sub,
                          "note": "algorithmic bytes = SURVEY 8(d) stage-boundary model with measured ncon/nefc/iters; the fused kernel keeps stage arrays in LDS, so real HBM traffic is far below the algorithmic figure" + tnote},
         }
