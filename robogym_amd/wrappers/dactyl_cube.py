@@ -17,7 +17,7 @@ through a `draws` object (`TorchDraws`: a torch generator, one independent draw 
 of the REAL reference stack and must then reproduce its observations, actions and model writes (tests/test_wrappers.py,
 tools/gen_golden_wrappers.py).  Writes into `sim.model` / `sim.data` become writes into the env's row of the per-env
 parameter buffer (`sim.params`, include/rgstep.h RG_F_ENVPRM).  `ObservationDelayWrapper` has no delay groups in any dactyl
-env (locked.py:244-262 comments them out) and is the identity.  Not built: `FixedWristWrapper` (refused when asked for).
+env (locked.py:244-262 comments them out) and is the identity.  `FixedWristWrapper` (constants.fixed_wrist) is there as well.
 Quirks of the reference that are part of the observable behaviour and reproduced here: the "friction" observation is the
 snapshot CubeFriction takes BEFORE RobotFriction draws in the same reset; RandomizedTimestep leaves the last step's
 timestep in place across a reset; Wind's hit probability is computed from whatever timestep is current at reset;
@@ -31,7 +31,7 @@ import torch
 
 from robogym_amd.utils import rotation
 
-NOT_BUILT = ["FixedWristWrapper"]
+NOT_BUILT: list = []
 
 DEFAULT_OBSERVATION_NOISE_LEVELS = {   # locked.py:232-237
     "fingertip_pos": {"uncorrelated": 0.002, "additive": 0.001},
@@ -91,14 +91,14 @@ class BatchedDactylCubeWrappers:
     def __init__(self, env, randomize: bool = False, n_action_bins: Optional[int] = None, relative_goal_wrapper: bool = True, drop_reward: float = -20.0,
                  min_episode_length: int = -1, noise_levels: Optional[dict] = None, smooth_alpha: float = 0.0, clip: float = 100.0, fixed_wrist: bool = False,
                  draws=None, auto_reset: bool = False):
-        if fixed_wrist:
-            raise NotImplementedError("FixedWristWrapper is not built (wrappers/dactyl.py:173-189)")
+        self.fixed_wrist = bool(fixed_wrist)
         self.env = env
         self.unwrapped = env
         self.randomize = bool(randomize)
         # auto_reset: around an env with `pipelined_reset=True` — a finished episode restarts by itself inside the following steps, and
         # the wrappers redraw that env's randomizations when its episode ends and reset their per-episode state when the new one starts
         self.auto_reset = bool(auto_reset)
+        self._wrist = None
         self._next_delta: Dict[str, torch.Tensor] = {}
         self._in_recipe = torch.zeros(env.batch_size, dtype=torch.bool, device=env.device)
         if self.auto_reset and not getattr(env, "pipelined_reset", False):
@@ -497,6 +497,16 @@ class BatchedDactylCubeWrappers:
             self._action_history = torch.stack([a.to(self._action_history.dtype)] * 2, dim=1)
             a = torch.gather(self._action_history, 1, self._action_delay[:, None, :])[:, 0]
             a = self._backlash(a)
+        if self.fixed_wrist:                                                             # FixedWristWrapper.step (dactyl.py:173-187): inside the clipping
+            sim = self.env.mujoco_simulation
+            if self._wrist is None:
+                m = sim.model
+                u = m.names["actuator"].index("robot0:A_WRJ0")
+                self._wrist = (u, int(m.arrays["jnt_qposadr"][m.names["joint"].index("robot0:WRJ0")]))
+            u, qadr = self._wrist
+            rng = (sim.params["actuator_ctrlrange"][:, u] if self.randomize else torch.as_tensor(sim.model.arrays["actuator_ctrlrange"][u], dtype=a.dtype, device=self.device)[None])
+            a = a.clone()
+            a[:, u] = (0.0 - sim.qpos[:, qadr].to(a.dtype)) / ((rng[:, 1] - rng[:, 0]) / 2.0).to(a.dtype)
         a = a.clamp(-1.0, 1.0)                                                           # ClipActionWrapper
         obs, rew, done, info = self.env.step(a)
         started = resetting = None

@@ -79,8 +79,7 @@ def test_make_env_signature_and_constants(locked_model, emul_lib):
     wrapped = make_env(batch_size=2, model=locked_model, lib=emul_lib)          # the reference's defaults: apply_wrappers=True, randomize=True
     assert wrapped.action_space["nvec"] == [11] * 20 and wrapped.unwrapped.stop_on_fall and wrapped.randomize
     assert not make_env(constants={"randomize": False}, batch_size=1, model=locked_model, lib=emul_lib).randomize
-    with pytest.raises(NotImplementedError):
-        make_env(constants={"fixed_wrist": True}, batch_size=1, model=locked_model, lib=emul_lib)
+    assert make_env(constants={"fixed_wrist": True}, batch_size=1, model=locked_model, lib=emul_lib).fixed_wrist
     with pytest.raises(NotImplementedError):
         make_env(wrapper_params={"delete": ["StopOnFallWrapper"]}, batch_size=1, model=locked_model, lib=emul_lib)
 

@@ -321,3 +321,22 @@ def test_auto_reset_rollout_gpu(locked_model):
     assert int(ends.sum()) > B and int(starts.sum()) > B // 2 and int(drops.sum()) > 0
     changed = (P["gravity"] != g0).any(dim=1)
     assert bool((changed | (ends == 0)).all())          # every env whose episode ended got new physics
+
+
+def test_fixed_wrist_matches_the_reference_wrapper(locked_model):
+    """constants.fixed_wrist: the reference's FixedWristWrapper, innermost in its stack, against the vectorised stack: the
+    actions that reach the env (tests/golden/wrappers_fixed_wrist.npz, tools/gen_golden_wrappers.py)."""
+    from robogym_amd.wrappers.dactyl_cube import BatchedDactylCubeWrappers
+
+    g = dict(np.load(os.path.join(G, "wrappers_fixed_wrist.npz")))
+    T = len(g["actions"])
+    g["script_contacts"] = np.zeros((0, 4)); g["pos_to_ctrl"] = np.zeros((20, 24))
+    inner = RandomizedScriptedBatchedEnv(g, locked_model)
+    env = BatchedDactylCubeWrappers(inner, randomize=False, fixed_wrist=True)
+    inner.t = 0
+    env.reset()
+    for t in range(T):
+        env.step(torch.as_tensor(np.repeat(g["actions"][t][None], inner.batch_size, 0)))
+    np.testing.assert_allclose(np.stack(inner.received), g["received_actions"], atol=2e-6)
+    u = locked_model.names["actuator"].index("robot0:A_WRJ0")
+    assert np.abs(g["received_actions"][:, u] - np.linspace(-1, 1, 11)[g["actions"][:, u]]).max() > 0.1     # the wrapper did override the policy
