@@ -19,7 +19,7 @@ typedef rg_post_args RgPostArgs;
 #undef RG_MAXCAND2
 #define RG_NS rgl
 #define RG_MAXCON 64
-#define RG_CPOOL 2080
+#define RG_CPOOL 2048
 #define RG_MAXCAND 256
 #define RG_MAXCAND2 128
 #include "rg_kernel.h"
@@ -31,7 +31,7 @@ typedef rg_post_args RgPostArgs;
 // the large capacities once more, with data.sensordata evaluation compiled in (launches with flags bit 5)
 #define RG_NS rgx
 #define RG_MAXCON 64
-#define RG_CPOOL 2080
+#define RG_CPOOL 2048
 #define RG_MAXCAND 256
 #define RG_MAXCAND2 128
 #define RG_SENSORS 1

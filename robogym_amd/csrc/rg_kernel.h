@@ -258,6 +258,8 @@ __device__ __forceinline__ void cross_force(float* r, const float* vel, const fl
 #if !defined(RG_NS) || !defined(RG_MAXCON) || !defined(RG_CPOOL) || !defined(RG_MAXCAND) || !defined(RG_MAXCAND2)
 #error "define RG_NS, RG_MAXCON, RG_CPOOL, RG_MAXCAND, RG_MAXCAND2 before including rg_kernel.h"
 #endif
+#undef RG_HCOEF_LDS
+#define RG_HCOEF_LDS (RG_MAXCON <= 32)   /* rollout configuration: its position side is the larger one anyway */
 #ifndef RG_SENSORS
 #define RG_SENSORS 0   /* 1: this configuration evaluates data.sensordata (launch flag bit 5); its own instantiation so that the hot configurations carry none of it */
 #endif
@@ -277,7 +279,7 @@ namespace RG_NS {
 // models) and is expanded into H's block layout where a factorisation needs it.
 struct RgLds {
   // state
-  alignas(16) float qpos[RG_MAXNQ], qvel[RG_MAXNV], ctrl[RG_MAXU], pid[3 * RG_MAXU], warm[RG_MAXNV];
+  alignas(16) float qpos[RG_MAXNQ], qvel[RG_MAXNV], ctrl[RG_MAXU];   // (the PID controller state of actuator u and qacc_warmstart[d] live in lane u's / lane d's registers)
   // persistent through the substep
   float org[4 * 3];   // com-frame origin per kinematic tree (slot via b2org)
   float Msp[RG_MAXNM];  // M[i][j] for the model's (i, j = i or an ancestor of i) list (M_i, M_j)
@@ -295,13 +297,13 @@ struct RgLds {
 #endif
   unsigned char c_idx[RG_MAXCON * RG_W];
   float c_pool[RG_CPOOL];  // basis Jacobian rows (normal, tangent1, tangent2, spin) x nnz, packed per contact
-  float p_aref[RG_MAXPYR];
+  float c_aref0[RG_MAXCON], c_kb[RG_MAXCON];   // reference acceleration of the contact's pyramid rows = aref0 - kb * (row velocity); the rows' lanes hold the result (RowRegs::paref)
   unsigned int status;
   int has_xfrc;   // any non-zero entry in the env's xfrc_applied row (checked once per launch)
   union {
     struct {  // ---- pos
       union {  // slot A
-        struct { alignas(16) float xquat[RG_MAXBODY * 4]; float xpos[RG_MAXBODY * 3], xipos[RG_MAXBODY * 3], xanchor[RG_MAXJNT * 3], xaxis[RG_MAXJNT * 3], spos[RG_MAXSITE * 3]; };
+        struct { alignas(16) float xquat[RG_MAXBODY * 4]; float xpos[RG_MAXBODY * 3], xanchor[RG_MAXJNT * 3], xaxis[RG_MAXJNT * 3], spos[RG_MAXSITE * 3]; };
         struct { float crb[RG_MAXBODY * 10]; };
         struct { float cdofdot[RG_MAXNV * 6], cacc[RG_MAXBODY * 6], tenfrc[RG_MAXTEN], tenvel[RG_MAXTEN], qfrc_passive[RG_MAXNV], qfrc_bias[RG_MAXNV], qfrc_act[RG_MAXNV]; };   // (cacc: per-body forces, then their subtree sums in place)
       };
@@ -310,14 +312,30 @@ struct RgLds {
       float gspeed[RG_MAXGEOM];  // bound on the speed of any point of the geom (velocity stage -> broadphase)
       union {  // slot C
         float cinert[RG_MAXBODY * 10];   // com_pos .. velocity stage
-        struct { short cand[RG_MAXCAND], cand2[RG_MAXCAND2], tlist[RG_TLIST]; float c_dist[RG_MAXCON], c_pos[RG_MAXCON * 3], c_normal[RG_MAXCON * 3]; };   // collision .. constraint rows
+        struct {   // collision .. constraint rows
+          short cand[RG_MAXCAND], cand2[RG_MAXCAND2];
+          union {
+            short tlist[RG_TLIST];   // broadphase only
+            struct { float c_dist[RG_MAXCON], c_pos[RG_MAXCON * 3], c_normal[RG_MAXCON * 3]; };   // narrowphase .. constraint rows
+          };
+        };
       };
     };
     struct {  // ---- slv
       alignas(16) float H[RG_HWORDS];
-      float a[RG_MAXNVC], as[RG_MAXNVC], fs[RG_MAXNVC], jtf[RG_MAXNVC], Ma[RG_MAXNVC], search[RG_MAXNVC], Mv[RG_MAXNVC], dinv[RG_MAXNV], tmpv[RG_MAXNV], qfrc_con[RG_MAXNV], qacc[RG_MAXNV];
+      float a[RG_MAXNVC], jtf[RG_MAXNVC], Ma[RG_MAXNVC];
+      union { struct { float as[RG_MAXNVC], fs[RG_MAXNVC]; }; float qfrc_con[RG_MAXNV]; };   // (qfrc_con / qacc: the solver's results in dof order, written when its
+      union { struct { float search[RG_MAXNVC], Mv[RG_MAXNVC]; }; float qacc[RG_MAXNV]; };   //  compact-space vectors are dead; read by the integrator)
+      float dinv[RG_MAXNV], tmpv[RG_MAXNV];
       unsigned char p_quad[RG_MAXPYR];
+      // per contact basis (normal, t1, t2, spin): J x on the way to the rows | the rows' forces on the way to J' f (never both at
+      // once).  RG_HCOEF_LDS (configurations whose solver side has the room): the H assembly's per-contact coefficients are
+      // staged through both (8 words per contact); otherwise the two share storage and the coefficients go lane to lane.
+#if RG_HCOEF_LDS
       float c_bdot[RG_MAXCON * 4], c_bfrc[RG_MAXCON * 4];
+#else
+      union { float c_bdot[RG_MAXCON * 4], c_bfrc[RG_MAXCON * 4]; };
+#endif   // per contact basis (normal, t1, t2, spin): J x on the way to the rows | the rows' forces on the way to J' f (never both at once)
     };
   };
   float prof[RG_NPROF];   // LAST: launches without the profiling flag do not allocate it (rg_lds_launch_bytes)
@@ -326,12 +344,13 @@ struct RgLds {
 static inline size_t rg_lds_launch_bytes(bool profiling) { return profiling ? sizeof(RgLds) : offsetof(RgLds, prof); }
 
 // ------------------------------------------------------------------------------------------------- position stage
+// data.xipos of body b (com of the body in the world): not stored, its three readers derive it from the body frame
+__device__ __forceinline__ v3 rg_xipos(RgM m, const RgLds& s, int b) { return ld3(s.xpos + 3 * b) + qrot(ldq(s.xquat + 4 * b), ld3(m.body_ipos + 3 * b)); }
 __device__ __forceinline__ void rg_kinematics(RgM m, RgLds& s, const float* P) {
   PFOR(i, m.nstatic) {
     int b = m.static_body[i];
     st3(s.xpos + 3 * b, ld3(m.static_xpos + 3 * b));
     q4 q = ldq(m.static_xquat + 4 * b); stq(s.xquat + 4 * b, q);
-    st3(s.xipos + 3 * b, ld3(m.static_xpos + 3 * b) + qrot(q, ld3(m.body_ipos + 3 * b)));
   }
   SYNC();
   for (int L = 0; L < m.nlevel; L++) {
@@ -342,7 +361,6 @@ __device__ __forceinline__ void rg_kinematics(RgM m, RgLds& s, const float* P) {
       rgf4 r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3], r4 = R[4];
       int w0 = __builtin_bit_cast(int, r0.x), w1 = __builtin_bit_cast(int, r0.y);
       int b = w0 & 255, p = (w0 >> 8) & 255, jn = (w0 >> 16) & 15, ja = w1 & 0xFFFF;
-      v3 bipos = mk3(r2.y, r2.z, r2.w);
       q4 pq = ldq(s.xquat + 4 * p);
       v3 pos = ld3(s.xpos + 3 * p) + qrot(pq, mk3(r0.z, r0.w, r1.x));
       q4 bq; bq.w = r1.y; bq.x = r1.z; bq.y = r1.w; bq.z = r2.x;
@@ -368,7 +386,6 @@ __device__ __forceinline__ void rg_kinematics(RgM m, RgLds& s, const float* P) {
       }
       quat = qnormalize(quat);
       st3(s.xpos + 3 * b, pos); stq(s.xquat + 4 * b, quat);
-      st3(s.xipos + 3 * b, pos + qrot(quat, bipos));
     }
     SYNC();
   }
@@ -384,7 +401,7 @@ __device__ __forceinline__ void rg_kinematics(RgM m, RgLds& s, const float* P) {
   }
   PFOR(b, m.nbody) {
     int r = m.body_rootid[b], ob = m.root_origin_body[r];
-    st3(s.org + 3 * s.b2org[b], ob >= 0 ? ld3(s.xipos + 3 * ob) : ld3(m.root_origin_const + 3 * r));
+    st3(s.org + 3 * s.b2org[b], ob >= 0 ? rg_xipos(m, s, ob) : ld3(m.root_origin_const + 3 * r));
   }
   SYNC();
 }
@@ -399,7 +416,7 @@ __device__ __forceinline__ void rg_com_pos(RgM m, RgLds& s, const float* P) {
     q2mat(R, qmul(ldq(s.xquat + 4 * b), ldq(m.body_iquat + 4 * b)));   // orientation of the inertial frame: body frame x iquat
     const float* in = P + RG_PRM_BODY_INERTIA + 3 * b;
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) I[3 * i + j] = R[3 * i] * in[0] * R[3 * j] + R[3 * i + 1] * in[1] * R[3 * j + 1] + R[3 * i + 2] * in[2] * R[3 * j + 2];
-    v3 d = ld3(s.xipos + 3 * b) - ld3(s.org + 3 * s.b2org[b]);
+    v3 d = rg_xipos(m, s, b) - ld3(s.org + 3 * s.b2org[b]);
     float mass = P[RG_PRM_BODY_MASS + b], d2 = dot(d, d);
     float* ci = s.cinert + 10 * b;
     ci[0] = I[0] + mass * (d2 - d.x * d.x); ci[1] = I[4] + mass * (d2 - d.y * d.y); ci[2] = I[8] + mass * (d2 - d.z * d.z);
@@ -432,7 +449,7 @@ __device__ __forceinline__ void rg_com_pos(RgM m, RgLds& s, const float* P) {
       for (int b = 1; b < m.nbody; b++) {
         if (!in_chain(m, b, d)) continue;
         const float* w = P + RG_PRM_XFRC + 6 * b;
-        v3 off = ld3(s.xipos + 3 * b) - ld3(s.org + 3 * s.b2org[b]);
+        v3 off = rg_xipos(m, s, b) - ld3(s.org + 3 * s.b2org[b]);
         xf += dot(ld3(w), jac_col(s, d, off)) + dot(ld3(w + 3), ld3(s.cdof + 6 * d));
       }
       s.qfrc_smooth[d] = xf;
@@ -1210,7 +1227,8 @@ __device__ __forceinline__ void rg_velocity(RgM m, RgLds& s, const float* P, con
 }
 
 // PID actuators (mjpid.pyx semantics, see oracle ro_fwd_actuation); updates controller state
-__device__ __forceinline__ void rg_pid(RgM m, RgLds& s, const float* P) {
+static_assert(RG_MAXU <= RG_WAVE && RG_MAXNV <= RG_WAVE, "controller state / warm start: one lane per actuator / dof");
+__device__ __forceinline__ void rg_pid(RgM m, RgLds& s, const float* P, float* st /* this lane's actuator: integral, previous error, filtered derivative */) {
   float dt = P[RG_PRM_TIMESTEP];
   PFOR(u, m.nu) {
     const float* gp = P + RG_PRM_ACT_GAINPRM + 10 * u;
@@ -1219,7 +1237,6 @@ __device__ __forceinline__ void rg_pid(RgM m, RgLds& s, const float* P) {
     if (m.actuator_biastype[u] == 2) {
       float err = s.ctrl[u] - s.actlen[u];
       if (fabsf(err) < gp[5]) err = 0;
-      float* st = s.pid + 3 * u;
       float integ = clampf(st[0] + err * dt, -gp[2], gp[2]);
       float deriv = (1 - gp[4]) * st[2] + gp[4] * (err - st[1]) * rg_rcp(dt);
       force = gp[0] * (err + (gp[1] != 0 ? integ * rg_rcp(gp[1]) : 0.f) + gp[3] * deriv);
@@ -1374,12 +1391,8 @@ __device__ __forceinline__ void rg_make_constraint(RgM m, RgLds& s, const float*
     s.c_D[c] = rg_rcp(R);
     // friction coefficient of tangent direction k (k = 0,1 sliding; 2 spin)
     s.c_mu[2 * c] = fr_slide; s.c_mu[2 * c + 1] = fr_spin;
-    const float* Bc = s.c_pool + s.c_off[c]; int nnz = s.c_nnz[c], nb = nbasis(dim);
-    float vb[4] = {0, 0, 0, 0};
-    for (int sl = 0; sl < nnz; sl++) { float q = s.qvel[s.c2d[s.c_idx[c * RG_W + sl]]]; for (int k = 0; k < nb; k++) vb[k] += Bc[k * nnz + sl] * q; }
-    float base = -K * imp * (dist - includemargin);
-    if (dim == 1) s.p_aref[6 * c] = base - B * vb[0];
-    else for (int k = 0; k < dim - 1; k++) { float mu = s.c_mu[2 * c + (k >> 1)]; s.p_aref[6 * c + 2 * k] = base - B * (vb[0] + mu * vb[k + 1]); s.p_aref[6 * c + 2 * k + 1] = base - B * (vb[0] - mu * vb[k + 1]); }
+    // aref of pyramid row q = -K imp (dist - margin) - B (J_q qvel): the velocity term is evaluated by the row's lane at the start of the solve
+    s.c_aref0[c] = -K * imp * (dist - includemargin); s.c_kb[c] = B;
   }
   SYNC();
 }
@@ -1387,7 +1400,7 @@ __device__ __forceinline__ void rg_make_constraint(RgM m, RgLds& s, const float*
 // Residuals of the static rows (friction loss, limits) live in the registers of the lane that owns the row (row
 // LANE + 64 k): only that lane ever touches them, so they need no LDS (1.2 kB per env that the occupancy wants back).
 #define RG_RSLOTS ((RG_MAXSROW + RG_WAVE - 1) / RG_WAVE)
-struct RowRegs { int desc[RG_RSLOTS]; float D[RG_RSLOTS], aref[RG_RSLOTS], floss[RG_RSLOTS], jar[RG_RSLOTS], jv[RG_RSLOTS]; int quad[RG_RSLOTS]; float pjar[RG_PSLOTS], pjv[RG_PSLOTS]; };   // (row forces are functions of jar: recomputed where needed, not kept)
+struct RowRegs { int desc[RG_RSLOTS]; float D[RG_RSLOTS], aref[RG_RSLOTS], floss[RG_RSLOTS], jar[RG_RSLOTS], jv[RG_RSLOTS]; int quad[RG_RSLOTS]; float pjar[RG_PSLOTS], pjv[RG_PSLOTS], paref[RG_PSLOTS]; };   // (row forces are functions of jar: recomputed where needed, not kept)
 // force of a friction-loss / limit row from its residual (mj_constraintUpdate's three cases)
 __device__ __forceinline__ float srow_force(float D, float f, float x) {
   if (!(D > 0)) return 0.f;
@@ -1432,10 +1445,10 @@ __device__ __forceinline__ void rg_static_rows(RgM m, const RgLds& s, const floa
   }
 }
 // jar = J x - aref (or jv = J x) for every active row; x lives in the compact dof space
-__device__ __forceinline__ void rg_J_mul(RgM m, RgLds& s, RowRegs& R, const float* x, bool to_jv) {
+template <bool SROWS = true> __device__ __forceinline__ void rg_J_mul(RgM m, RgLds& s, RowRegs& R, const float* x, bool to_jv) {
   int ns = nsrow(m), ncon = s.ncon;
 #pragma unroll
-  for (int k = 0; k < RG_RSLOTS; k++) {
+  for (int k = 0; k < (SROWS ? RG_RSLOTS : 0); k++) {
     int r = LANE + RG_WAVE * k;
     if (r < ns && R.D[k] > 0) { float v = srow_dot<false>(s, R.desc[k], x); if (to_jv) R.jv[k] = v; else R.jar[k] = v - R.aref[k]; }
   }
@@ -1454,7 +1467,7 @@ __device__ __forceinline__ void rg_J_mul(RgM m, RgLds& s, RowRegs& R, const floa
     float v;
     if (dim == 1) v = s.c_bdot[4 * c];
     else { int k = q >> 1; float mu = s.c_mu[2 * c + (k >> 1)]; v = s.c_bdot[4 * c] + ((q & 1) ? -mu : mu) * s.c_bdot[4 * c + k + 1]; }
-    if (to_jv) R.pjv[kk] = v; else R.pjar[kk] = v - s.p_aref[w];
+    if (to_jv) R.pjv[kk] = v; else R.pjar[kk] = v - R.paref[kk];
   }
   SYNC();
 }
@@ -1779,7 +1792,7 @@ __device__ __forceinline__ LsPt rg_ls_eval(const LsRows& L, float alpha, float q
 
 // Newton solver on the primal problem (see oracle ro_solve), in the compact space of constrained dofs
 // (trees no constraint row can touch keep qacc = qacc_smooth).  Result: s.qacc, s.qfrc_con (full space).
-template <bool SENSORS> __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, const float* P, int& nefc_out, int flags) {
+template <bool SENSORS> __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, const float* P, int& nefc_out, int flags, float warm /* qacc_warmstart[LANE] */) {
   long long t0 = rg_clock(), t1;
 #define PROFS(k) do { if (flags & 2) { t1 = rg_clock(); if (LANE == 0) s.prof[k] += (float)(t1 - t0); t0 = t1; } } while (0)
   int nv = m.nv, nvc = m.nvc, hs = m.hs, ns = nsrow(m), ncon = s.ncon;
@@ -1797,7 +1810,8 @@ template <bool SENSORS> __device__ __forceinline__ int rg_solve(RgM m, RgLds& s,
                                 identical re-synchronised errors vs the fp64 oracle at its 1e-8 (profiles/r02_ab.txt, tools/parity_quick.py) */
 #endif
   float tol = fmaxf(m.tolerance, RG_TOL_FLOOR);
-  PFOR(i, nvc) { int d = s.c2d[i]; s.as[i] = s.qacc_smooth[d]; s.fs[i] = s.qfrc_smooth[d]; s.a[i] = s.warm[d]; }
+  { const int d = LANE < nvc ? s.c2d[LANE] : 0; const float w = __shfl(warm, d);
+    if (LANE < nvc) { s.as[LANE] = s.qacc_smooth[d]; s.fs[LANE] = s.qfrc_smooth[d]; s.a[LANE] = w; } }
   SYNC();
   // When every contact couples the dofs of ONE chain only (a body against a static geom, or against one of its own
   // ancestors), J'DJ has the pattern of M and the Hessian is factorised tree-sparsely like M instead of densely.
@@ -1819,6 +1833,15 @@ template <bool SENSORS> __device__ __forceinline__ int rg_solve(RgM m, RgLds& s,
   for (int k = 0; k < RG_RSLOTS; k++) { RR.jar[k] = RR.jv[k] = 0.f; RR.quad[k] = 0; }
 #pragma unroll
   for (int k = 0; k < RG_PSLOTS; k++) RR.pjar[k] = RR.pjv[k] = 0.f;
+  // reference accelerations of the pyramid rows (mj_referenceConstraint): aref = aref0(contact) - kb(contact) * (J_row qvel)
+  PFOR(i, nvc) s.search[i] = s.qvel[s.c2d[i]];
+  SYNC();
+  rg_J_mul<false>(m, s, RR, s.search, true);
+#pragma unroll
+  for (int k = 0; k < RG_PSLOTS; k++) {
+    int w = LANE + RG_WAVE * k, cc = w / 6;
+    RR.paref[k] = w < ncon * 6 ? s.c_aref0[cc] - s.c_kb[cc] * RR.pjv[k] : 0.f; RR.pjv[k] = 0.f;
+  }
   // (the tree-pattern descriptors are fetched where they are used — 32 registers that would otherwise stay live, or be
   //  spilled, through the whole dense path as well)
   int cblk_own = LANE < nvc ? s.cblk[LANE] : 0, akk_own = (cblk_own & 0xFFFF) + LANE - ((cblk_own >> 16) & 255);
@@ -1881,23 +1904,32 @@ template <bool SENSORS> __device__ __forceinline__ int rg_solve(RgM m, RgLds& s,
     for (int k = 0; k < RG_RSLOTS; k++) { int r = LANE + RG_WAVE * k; if (r < ns && RR.D[k] > 0 && RR.quad[k]) srow_hess(m, s, RR.desc[k], RR.D[k]); }
     }
     // per contact, C = P' D_act P in the basis (normal, t1, t2, spin) has only its first row/column and its diagonal
-    // non-zero: cn, ck[3], cd[3].  One lane per contact computes them (c_bdot/c_bfrc are free between J products).
-    float* cf = s.c_bdot;
-    PFOR(c, ncon) {
-      int dim = s.c_dim[c]; float D = s.c_D[c], cn = 0, ck[3] = {0, 0, 0}, cd[3] = {0, 0, 0};
-      if (dim == 1) cn = s.p_quad[6 * c] ? D : 0.f;
+    // non-zero: cn, ck[3], cd[3].  Lane c computes them for contact c; the block loop below reads them lane to lane.
+    static_assert(RG_MAXCON <= RG_WAVE, "one lane per contact");
+    float cn_own = 0, ck_own[3] = {0, 0, 0}, cd_own[3] = {0, 0, 0};
+    if (LANE < ncon) {
+      const int c = LANE, dim = s.c_dim[c]; const float D = s.c_D[c];
+      if (dim == 1) cn_own = s.p_quad[6 * c] ? D : 0.f;
       else for (int k = 0; k < dim - 1; k++) {
         float mu = s.c_mu[2 * c + (k >> 1)]; int qp = s.p_quad[6 * c + 2 * k], qm = s.p_quad[6 * c + 2 * k + 1];
-        cn += D * (qp + qm); ck[k] = D * mu * (qp - qm); cd[k] = D * mu * mu * (qp + qm);
+        cn_own += D * (qp + qm); ck_own[k] = D * mu * (qp - qm); cd_own[k] = D * mu * mu * (qp + qm);
       }
-      float* o = cf + 8 * c; o[0] = cn; o[1] = ck[0]; o[2] = ck[1]; o[3] = ck[2]; o[4] = cd[0]; o[5] = cd[1]; o[6] = cd[2];
     }
+#if RG_HCOEF_LDS
+    if (LANE < ncon) { float* o = s.c_bdot + 8 * LANE; o[0] = cn_own; o[1] = ck_own[0]; o[2] = ck_own[1]; o[3] = ck_own[2]; o[4] = cd_own[0]; o[5] = cd_own[1]; o[6] = cd_own[2]; }
     SYNC();
+#endif
     for (int c = 0; c < ncon; c++) {
-      int nnz = s.c_nnz[c], nb = nbasis(s.c_dim[c]);
-      const float* o = cf + 8 * c;
-      float cn = o[0], ck[3] = {o[1], o[2], o[3]}, cd[3] = {o[4], o[5], o[6]};
+#if RG_HCOEF_LDS
+      const float* o = s.c_bdot + 8 * c;
+      const float cn = o[0], ck[3] = {o[1], o[2], o[3]}, cd[3] = {o[4], o[5], o[6]};
       if (cn == 0) continue;
+#else
+      const float cn = lane_bcast(cn_own, c);
+      if (cn == 0) continue;
+      const float ck[3] = {lane_bcast(ck_own[0], c), lane_bcast(ck_own[1], c), lane_bcast(ck_own[2], c)}, cd[3] = {lane_bcast(cd_own[0], c), lane_bcast(cd_own[1], c), lane_bcast(cd_own[2], c)};
+#endif
+      const int nnz = s.c_nnz[c], nb = nbasis(s.c_dim[c]);
       const float* Bc = s.c_pool + s.c_off[c];
       for (int a = LANE >> 4, b = LANE & 15; a < nnz; a += 4) {   // nnz <= RG_W < 16: 4 rows of the block per pass
         if (b >= nnz) continue;
@@ -1970,18 +2002,19 @@ template <bool SENSORS> __device__ __forceinline__ int rg_solve(RgM m, RgLds& s,
     }
     SYNC();
   }
+  SYNC();   // (qacc / qfrc_con overlay as, fs, search, Mv)
   PFOR(d, nv) { int i = m.d2c[d]; s.qacc[d] = i >= 0 ? s.a[i] : s.qacc_smooth[d]; s.qfrc_con[d] = i >= 0 ? s.jtf[i] : 0.f; }
   SYNC();
   return iters;
 }
 
 // ------------------------------------------------------------------------------------------------- integration
-__device__ __forceinline__ void rg_euler(RgM m, RgLds& s, const float* P) {
+__device__ __forceinline__ void rg_euler(RgM m, RgLds& s, const float* P, float& warm) {
   float h = P[RG_PRM_TIMESTEP];
   PFOR(i, m.nv) s.tmpv[i] = s.qfrc_smooth[i] + s.qfrc_con[i];
   SYNC();
   rg_ltdl_factor_solve(m, s, P + RG_PRM_DOF_DAMPING, h, s.tmpv);
-  PFOR(i, m.nv) { s.qvel[i] += h * s.tmpv[i]; s.warm[i] = s.qacc[i]; }
+  if (LANE < m.nv) { s.qvel[LANE] += h * s.tmpv[LANE]; warm = s.qacc[LANE]; }
   SYNC();
   PFOR(j, m.njnt) {
     int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j], t = m.jnt_type[j];
@@ -2105,18 +2138,18 @@ RG_STAGE_BIG void st_collision(RgCtx c) {
                (L.bt.pairlb && !(flags & 4)) ? L.bt.pairlb + (size_t)e * m.npair : (float*)0, !(flags & 8));
 }
 RG_STAGE void st_make_constraint(RgCtx c) { RgM m = RG_M(c); rg_make_constraint(m, RG_S(), rg_prm(m, RG_L(c))); }
-RG_STAGE void st_pid(RgCtx c) { RgM m = RG_M(c); rg_pid(m, RG_S(), rg_prm(m, RG_L(c))); }
+RG_STAGE void st_pid(RgCtx c, float* pid) { RgM m = RG_M(c); rg_pid(m, RG_S(), rg_prm(m, RG_L(c)), pid); }
 RG_STAGE void st_smooth(RgCtx c) { RgM m = RG_M(c); rg_smooth(m, RG_S(), rg_prm(m, RG_L(c))); }
 RG_STAGE void st_factor_smooth(RgCtx c) { RgLds& s = RG_S(); rg_ltdl_factor_solve(RG_M(c), s, (const float*)0, 0.f, s.qacc_smooth); }
-RG_STAGE_BIG int st_solve(RgCtx c) { RgM m = RG_M(c); int nefc = 0; int it = rg_solve<false>(m, RG_S(), rg_prm(m, RG_L(c)), nefc, RG_L(c).flags); return it | (nefc << 8); }
+RG_STAGE_BIG int st_solve(RgCtx c, float warm) { RgM m = RG_M(c); int nefc = 0; int it = rg_solve<false>(m, RG_S(), rg_prm(m, RG_L(c)), nefc, RG_L(c).flags, warm); return it | (nefc << 8); }
 #if RG_SENSORS
-RG_STAGE_BIG int st_solve_sensors(RgCtx c) { RgM m = RG_M(c); int nefc = 0; int it = rg_solve<true>(m, RG_S(), rg_prm(m, RG_L(c)), nefc, RG_L(c).flags); return it | (nefc << 8); }
+RG_STAGE_BIG int st_solve_sensors(RgCtx c, float warm) { RgM m = RG_M(c); int nefc = 0; int it = rg_solve<true>(m, RG_S(), rg_prm(m, RG_L(c)), nefc, RG_L(c).flags, warm); return it | (nefc << 8); }
 #endif
 #if RG_SENSORS
 RG_STAGE void st_touch_geom(RgCtx c) { RgM m = RG_M(c); rg_touch_geom(m, RG_S(), rg_prm(m, RG_L(c))); }
 RG_STAGE void st_touch_write(RgCtx c) { RgM m = RG_M(c); RgLRef L = RG_L(c); rg_touch_write(m, RG_S(), L.bt.xdata + (size_t)rg_env(L) * RG_XDATA); }
 #endif
-RG_STAGE void st_euler(RgCtx c) { RgM m = RG_M(c); rg_euler(m, RG_S(), rg_prm(m, RG_L(c))); }
+RG_STAGE float st_euler(RgCtx c, float warm) { RgM m = RG_M(c); rg_euler(m, RG_S(), rg_prm(m, RG_L(c)), warm); return warm; }
 RG_STAGE void st_build_row_desc(RgCtx c) { rg_build_row_desc(RG_M(c), RG_S()); }
 RG_STAGE void st_dump(RgCtx c, int which, int nefc, int iters) {
   RgM m = RG_M(c); RgLRef L = RG_L(c); RgLds& s = RG_S();
@@ -2148,8 +2181,9 @@ __global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_kernel(con
   long long tk0 = rg_clock();
   // ---- load the env's state row
   PFOR(i, m.nq) s.qpos[i] = L.bt.qpos[(size_t)e * m.nq + i];
-  PFOR(i, m.nv) { s.qvel[i] = L.bt.qvel[(size_t)e * m.nv + i]; s.warm[i] = L.bt.qacc_warmstart[(size_t)e * m.nv + i]; }
-  PFOR(i, 3 * m.nu) s.pid[i] = L.bt.pid[(size_t)e * 3 * m.nu + i];
+  float warmr = 0.f, pidr[3] = {0.f, 0.f, 0.f};
+  if (LANE < m.nv) { s.qvel[LANE] = L.bt.qvel[(size_t)e * m.nv + LANE]; warmr = L.bt.qacc_warmstart[(size_t)e * m.nv + LANE]; }
+  if (LANE < m.nu) for (int k = 0; k < 3; k++) pidr[k] = L.bt.pid[(size_t)e * 3 * m.nu + 3 * LANE + k];
   const float* P = rg_prm(m, L);
   { float nz = 0; PFOR(i, 6 * m.nbody) nz += P[RG_PRM_XFRC + i] != 0.f ? 1.f : 0.f; nz = wave_sum(nz); if (LANE == 0) s.has_xfrc = nz > 0; }
   const unsigned status0 = L.bt.status[e];
@@ -2165,7 +2199,7 @@ __global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_kernel(con
       PFOR(u, m.nu) s.ctrl[u] = L.bt.ctrl[(size_t)e * m.nu + u];
       SYNC();
       st_kinematics(c); st_com_pos(c); st_tendon(c);
-      for (int k = 0; k < pre; k++) st_pid(c);
+      for (int k = 0; k < pre; k++) st_pid(c, pidr);
       if (LANE == 0) L.bt.preticks[e] = 0;
     }
   }
@@ -2219,7 +2253,7 @@ __global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_kernel(con
       if (LANE == 0) L.bt.redo[e] = 1;
       return;
     }
-    st_pid(c);
+    st_pid(c, pidr);
     st_smooth(c); PROF(9);
     if (sub == 0 && (flags & 1) && L.bt.dbg) st_dump(c, 1, 0, 0);
     // ---- the position-stage scratch is dead from here on; the solver scratch takes its place
@@ -2227,12 +2261,12 @@ __global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_kernel(con
     { unsigned int* u = (unsigned int*)s.H; int nw = (int)((sizeof(RgLds) - ((char*)s.H - (char*)&s)) / 4); for (int w = LANE; w < nw; w += RG_WAVE) u[w] = 0x7fc00000u; SYNC(); }
 #endif
     st_factor_smooth(c); PROF(4);
-    int packed = st_solve(c), iters = packed & 255, nefc = packed >> 8; t0 = rg_clock();
+    int packed = st_solve(c, warmr), iters = packed & 255, nefc = packed >> 8; t0 = rg_clock();
     st_ncon += s.ncon; st_nefc += nefc; st_iter += iters;
     if (sub == 0 && (flags & 1) && L.bt.dbg) st_dump(c, 2, nefc, iters);
     bd = 0; PFOR(i, m.nv) bd += (fabsf(s.qacc[i]) < 1e10f) ? 0.f : 1.f;
     if (wave_sum(bd) > 0) { bad = true; break; }
-    st_euler(c); PROF(11);
+    warmr = st_euler(c, warmr); PROF(11);
   }
   if (bad && LANE == 0) s.status |= RG_STATUS_BAD_STATE;
   // ---- state-less forward() calls of the reference (simulation_interface.py:185, robot_env.py:677,
@@ -2253,7 +2287,7 @@ __global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_kernel(con
 #else
     const bool sensors = false;
 #endif
-    for (int k = 0; k < nticks - (sensors ? 1 : 0); k++) st_pid(c);
+    for (int k = 0; k < nticks - (sensors ? 1 : 0); k++) st_pid(c, pidr);
 #if RG_SENSORS
     if (sensors) {
       // data.sensordata: the LAST state-less forward of the reference in full — contacts and their forces at the final state
@@ -2265,9 +2299,9 @@ __global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_kernel(con
         return;
       }
       st_touch_geom(c);
-      st_pid(c); st_smooth(c);
+      st_pid(c, pidr); st_smooth(c);
       st_factor_smooth(c);
-      st_solve_sensors(c);
+      st_solve_sensors(c, warmr);
       st_touch_write(c);
     }
 #endif
@@ -2275,8 +2309,8 @@ __global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_kernel(con
   }
   // ---- write back
   PFOR(i, m.nq) L.bt.qpos[(size_t)e * m.nq + i] = s.qpos[i];
-  PFOR(i, m.nv) { L.bt.qvel[(size_t)e * m.nv + i] = s.qvel[i]; L.bt.qacc_warmstart[(size_t)e * m.nv + i] = s.warm[i]; }
-  PFOR(i, 3 * m.nu) L.bt.pid[(size_t)e * 3 * m.nu + i] = s.pid[i];
+  if (LANE < m.nv) { L.bt.qvel[(size_t)e * m.nv + LANE] = s.qvel[LANE]; L.bt.qacc_warmstart[(size_t)e * m.nv + LANE] = warmr; }
+  if (LANE < m.nu) for (int k = 0; k < 3; k++) L.bt.pid[(size_t)e * 3 * m.nu + 3 * LANE + k] = pidr[k];
   PFOR(u, m.nu) L.bt.ctrl[(size_t)e * m.nu + u] = s.ctrl[u];
   if (LANE == 0) {
     L.bt.status[e] = s.status; L.bt.time[e] += nsubsteps * P[RG_PRM_TIMESTEP];

@@ -133,8 +133,8 @@ def test_data_fields_match_oracle_gpu(locked_model, oracle_lib):
 def test_product_library_loads_and_exports_the_header():
     """The gfx950 build of the C ABI (robogym_amd/csrc/librgstep.so) loads without a GPU and exports every function that
     include/rgstep.h declares (no compute calls here); the binding's list and struct size agree with it; and the LDS
-    footprint of the rollout configuration still fits 11 allocation granules of 1280 B (11 envs per CU: what the measured
-    throughput rests on), the large configuration 7 per CU."""
+    footprint of the rollout configuration still fits 10 allocation granules of 1280 B (12 envs per CU, which is also what
+    the 168-VGPR budget allows: what the measured throughput rests on), the large configuration 16 granules (8 per CU)."""
     import ctypes
     import os
     import re
@@ -151,7 +151,8 @@ def test_product_library_loads_and_exports_the_header():
         assert hasattr(L, name), name
     assert set(_native.EXPORTS) == set(declared)
     assert L.rg_post_args_size() == ctypes.sizeof(_native.PostArgs)
-    assert L.rg_lds_bytes_cfg(0) <= 11 * 1280 and 160 * 1024 // (-(-L.rg_lds_bytes_cfg(1) // 1280) * 1280) >= 7
+    assert L.rg_lds_bytes_cfg(0) <= 10 * 1280 and 160 * 1024 // (10 * 1280) == 12
+    assert L.rg_lds_bytes_cfg(1) <= 16 * 1280 and 160 * 1024 // (16 * 1280) == 8
 
 
 def _check_touch_sensors(sim, ora, model, nsteps):
