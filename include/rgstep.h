@@ -141,7 +141,7 @@ typedef struct rg_step_args {
   int nsubsteps, nforward_ticks, flags;
   void* stream;
   /* Kernel configuration: RG_CFG_ROLLOUT holds 24 contacts / 768 Jacobian words per env in LDS (rollouts: mean 3.5
-   * contacts, P(> 21) < 2e-6 per mj_step; 11 envs in flight per CU), RG_CFG_LARGE 64 / 2080 (7 per CU; the reset recipe, where the
+   * contacts, P(> 21) < 2e-6 per mj_step; 12 envs in flight per CU), RG_CFG_LARGE 64 / 2048 (8 per CU; the reset recipe, where the
    * hand closes around a freshly dropped cube; MuJoCo's nconmax for these models is 100).
    * redo_dev int [B] (RG_CFG_ROLLOUT only, may be NULL): an env that exceeds the rollout capacities is left untouched
    * and gets redo_dev[e] = 1 instead of dropping contacts; pass the array as active_dev of an RG_CFG_LARGE launch. */
