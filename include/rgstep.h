@@ -120,7 +120,9 @@ int rg_batch_copy_rows(rg_batch* b, int field, const void* src_dev, const int* m
  *                bit4: contact depth / normal of convex pairs from the final MPR portal's PLANE instead of libccd's closest
  *                      point on the final portal TRIANGLE (the default, = MuJoCo 2.0's mjc_Convex).  The two agree whenever
  *                      the origin projects inside the triangle; the plane variant does not depend on the rounding-level
- *                      tie breaks that pick the triangle on flat contacts.
+ *                      tie breaks that pick the triangle on flat contacts.  The flag selects round 1's contact generation as a
+ *                      whole: pairs of two boxes then go through MPR too (one contact) instead of the multi-point box-box
+ *                      routine (the default, = mjc_BoxBox: face clipping, up to 8 contacts per pair).
  *                bit5: evaluate data.sensordata (touch sensors, mj_sensorAcc) into the xdata row: the last of the state-less
  *                      forwards then runs in full (collision and constraint solve at the final state, as mj_forward does),
  *                      about one more substep of work.  Needs xdata_dev and nforward_ticks >= 1.

@@ -947,6 +947,158 @@ __device__ __forceinline__ void rg_mpr_geoms(RgM m, const RgLds& s, int p, float
   A.mesh = __builtin_bit_cast(int, r0.z); A.vertadr = __builtin_bit_cast(int, r3.x); A.nvert = __builtin_bit_cast(int, r1.w);
   B.mesh = __builtin_bit_cast(int, r0.w); B.vertadr = __builtin_bit_cast(int, r3.y); B.nvert = __builtin_bit_cast(int, r2.w);
 }
+// ------------------------------------------------------------------------------------------------- box - box
+// engine_collision_box.c: mjc_BoxBox (oracle: collide_box_box) — multi-point contacts of two boxes: separating-axis search
+// over the 15 candidate axes; edge-edge: one contact at the closest points of the two edges; face: the incident face clipped
+// against the reference face, one contact per vertex of the clipped polygon that lies within the margin.
+// Two pairs per pass, 32 lanes each.  The axis search is scalar per pair (every lane of the group runs it); the clipped
+// polygon's vertices are enumerated one candidate per lane — 4 incident corners inside the reference rectangle, 4 reference
+// corners inside the incident parallelogram, 16 edge crossings — which is the point set Sutherland-Hodgman produces,
+// without its serial polygon lists.  Launch flag bit 4 (round-1 contact variant) sends these pairs through MPR instead.
+__device__ __forceinline__ v3 pick3(v3 a0, v3 a1, v3 a2, int k) { return k == 0 ? a0 : (k == 1 ? a1 : a2); }
+__device__ __forceinline__ float pick3(float a0, float a1, float a2, int k) { return k == 0 ? a0 : (k == 1 ? a1 : a2); }
+__device__ __forceinline__ bool rg_box_box_lane(RgM m, const RgLds& s, int p, float gscale, int l, float& dist, v3& pos, v3& n, int& dim) {
+  const rgf4* Rc = (const rgf4*)m.pair_rec + (RG_PAIRREC / 4) * p;
+  rgf4 r0 = Rc[0], r1 = Rc[1], r2 = Rc[2];
+  const int hdr = __builtin_bit_cast(int, r0.x), g1 = hdr & 255, g2 = (hdr >> 8) & 255;
+  dim = (hdr >> 16) & 15;
+  const float margin = r0.y;
+  const float sc1 = (hdr & RG_PAIR_SCALED1) ? gscale : 1.f, sc2 = (hdr & RG_PAIR_SCALED2) ? gscale : 1.f;
+  const float A[3] = {r1.x * sc1, r1.y * sc1, r1.z * sc1}, B[3] = {r2.x * sc2, r2.y * sc2, r2.z * sc2};
+  float R1[9], R2[9]; q2mat(R1, ldq(s.gquat + 4 * g1)); q2mat(R2, ldq(s.gquat + 4 * g2));
+  const v3 P1 = ld3(s.gpos + 3 * g1), t = ld3(s.gpos + 3 * g2) - P1;   // pair-local coordinates: origin at box 1's centre
+  v3 ax1[3], ax2[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) { ax1[k] = mk3(R1[k], R1[3 + k], R1[6 + k]); ax2[k] = mk3(R2[k], R2[3 + k], R2[6 + k]); }
+  float ta[3], tb[3], Q[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) { ta[i] = dot(t, ax1[i]); tb[i] = dot(t, ax2[i]);
+#pragma unroll
+    for (int j = 0; j < 3; j++) Q[i][j] = fabsf(dot(ax1[i], ax2[j])); }
+  float best = -3.0e38f; int code = 0; bool sep = false; n = mk3(0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 3; i++) {   // face normals of box 1
+    float sv = fabsf(ta[i]) - (A[i] + B[0] * Q[i][0] + B[1] * Q[i][1] + B[2] * Q[i][2]);
+    sep = sep || sv > margin;
+    if (sv > best) { best = sv; code = 1 + i; n = ax1[i] * (ta[i] < 0 ? -1.f : 1.f); }
+  }
+#pragma unroll
+  for (int j = 0; j < 3; j++) {   // face normals of box 2
+    float sv = fabsf(tb[j]) - (B[j] + A[0] * Q[0][j] + A[1] * Q[1][j] + A[2] * Q[2][j]);
+    sep = sep || sv > margin;
+    if (sv > best) { best = sv; code = 4 + j; n = ax2[j] * (tb[j] < 0 ? -1.f : 1.f); }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) {   // edge x edge
+      v3 cv = cross(ax1[i], ax2[j]);
+      float ln = norm(cv);
+      if (ln < 1e-4f) continue;   // parallel edges: covered by the face axes (fp32: below this the direction is rounding noise)
+      cv = cv * rg_rcp(ln);
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      float ra = A[i1] * fabsf(dot(cv, ax1[i1])) + A[i2] * fabsf(dot(cv, ax1[i2]));
+      float rb = B[j1] * fabsf(dot(cv, ax2[j1])) + B[j2] * fabsf(dot(cv, ax2[j2]));
+      float tc = dot(t, cv), sv = fabsf(tc) - (ra + rb);
+      sep = sep || sv > margin;
+      // a face axis is preferred unless the edge axis is clearly better (5 % hysteresis)
+      if (sv > best + 0.05f * fabsf(best) + 1e-12f && sv > best) { best = sv; code = 7 + 3 * i + j; n = cv * (tc < 0 ? -1.f : 1.f); }
+    }
+  }
+  if (sep) return false;
+  if (code >= 7) {   // edge - edge: one contact midway between the closest points of the two edges
+    const int i = (code - 7) / 3, j = (code - 7) - 3 * i;
+    v3 pa = mk3(0, 0, 0), pb = t;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      if (k != i) pa = pa + ax1[k] * ((dot(n, ax1[k]) > 0 ? 1.f : -1.f) * A[k]);
+      if (k != j) pb = pb + ax2[k] * ((dot(n, ax2[k]) > 0 ? -1.f : 1.f) * B[k]);
+    }
+    const v3 ui = pick3(ax1[0], ax1[1], ax1[2], i), uj = pick3(ax2[0], ax2[1], ax2[2], j), w = pb - pa;
+    const float uaub = dot(ui, uj), q1 = dot(ui, w), q2 = -dot(uj, w), den = 1.f - uaub * uaub;
+    float alpha = den > 1e-6f ? (q1 + uaub * q2) / den : 0.f, beta = den > 1e-6f ? (uaub * q1 + q2) / den : 0.f;
+    const float Ai = pick3(A[0], A[1], A[2], i), Bj = pick3(B[0], B[1], B[2], j);
+    alpha = clampf(alpha, -Ai, Ai); beta = clampf(beta, -Bj, Bj);
+    pa = pa + ui * alpha; pb = pb + uj * beta;
+    dist = best; pos = (pa + pb) * 0.5f + P1;
+    return l == 0;
+  }
+  // face contact: the reference box owns the axis; nr = its outward normal towards the other box
+  const bool ref1 = code <= 3; const int ia = ref1 ? code - 1 : code - 4;
+  v3 rax[3], iax[3]; float rs[3], is[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) { rax[k] = ref1 ? ax1[k] : ax2[k]; iax[k] = ref1 ? ax2[k] : ax1[k]; rs[k] = ref1 ? A[k] : B[k]; is[k] = ref1 ? B[k] : A[k]; }
+  const v3 rp = ref1 ? mk3(0, 0, 0) : t, ip = ref1 ? t : mk3(0, 0, 0), nr = n * (ref1 ? 1.f : -1.f);
+  int ib = 0; float bd = 3.0e38f;   // incident face: the one facing the reference face most directly
+#pragma unroll
+  for (int k = 0; k < 3; k++) { float dk = -fabsf(dot(nr, iax[k])); if (dk < bd) { bd = dk; ib = k; } }
+  const v3 iab = pick3(iax[0], iax[1], iax[2], ib);
+  const float isgn = dot(nr, iab) > 0 ? -1.f : 1.f;
+  const v3 ic = ip + iab * (isgn * pick3(is[0], is[1], is[2], ib));
+  const int u = (ia + 1) % 3, v = (ia + 2) % 3, iu = (ib + 1) % 3, iv = (ib + 2) % 3;
+  const v3 ru = pick3(rax[0], rax[1], rax[2], u), rv = pick3(rax[0], rax[1], rax[2], v);
+  const float lu = pick3(rs[0], rs[1], rs[2], u), lv = pick3(rs[0], rs[1], rs[2], v), la = pick3(rs[0], rs[1], rs[2], ia);
+  const v3 eu = pick3(iax[0], iax[1], iax[2], iu) * pick3(is[0], is[1], is[2], iu), ev = pick3(iax[0], iax[1], iax[2], iv) * pick3(is[0], is[1], is[2], iv);
+  // the reference face's plane coordinates: incident parallelogram = c2 + a e1 + b e2, |a|, |b| <= 1; reference rectangle |x| <= lu, |y| <= lv
+  const v3 rel = ic - rp;
+  const float c2x = dot(rel, ru), c2y = dot(rel, rv), e1x = dot(eu, ru), e1y = dot(eu, rv), e2x = dot(ev, ru), e2y = dot(ev, rv);
+  float x = 0, y = 0; bool ok = false;
+  if (l < 4) {          // incident corner l (order (+,+), (-,+), (-,-), (+,-)) inside the rectangle
+    const float su = (l == 0 || l == 3) ? 1.f : -1.f, sv = l < 2 ? 1.f : -1.f;
+    x = c2x + su * e1x + sv * e2x; y = c2y + su * e1y + sv * e2y;
+    ok = fabsf(x) <= lu && fabsf(y) <= lv;
+  } else if (l < 8) {   // reference corner inside the parallelogram
+    x = (l & 1) ? lu : -lu; y = (l & 2) ? lv : -lv;
+    const float det = e1x * e2y - e1y * e2x, dx = x - c2x, dy = y - c2y;
+    if (fabsf(det) > 1e-12f) { const float a = (dx * e2y - dy * e2x) / det, b = (e1x * dy - e1y * dx) / det; ok = fabsf(a) < 1.f && fabsf(b) < 1.f; }
+  } else if (l < 24) {  // incident edge (l-8)/4 crossing reference edge line (l-8)%4, within that edge's extent
+    const int ea = (l - 8) >> 2, eb = (l - 8) & 3, k0 = ea, k1 = (ea + 1) & 3;
+    const float su0 = (k0 == 0 || k0 == 3) ? 1.f : -1.f, sv0 = k0 < 2 ? 1.f : -1.f, su1 = (k1 == 0 || k1 == 3) ? 1.f : -1.f, sv1 = k1 < 2 ? 1.f : -1.f;
+    const float ax_ = c2x + su0 * e1x + sv0 * e2x, ay_ = c2y + su0 * e1y + sv0 * e2y, bx_ = c2x + su1 * e1x + sv1 * e2x, by_ = c2y + su1 * e1y + sv1 * e2y;
+    const bool xedge = eb < 2; const float sg = (eb & 1) ? -1.f : 1.f, lim = xedge ? lu : lv, olim = xedge ? lv : lu;
+    const float da = sg * (xedge ? ax_ : ay_) - lim, db = sg * (xedge ? bx_ : by_) - lim;
+    if ((da < 0 && db > 0) || (da > 0 && db < 0)) {
+      const float tt = da / (da - db);
+      x = ax_ + tt * (bx_ - ax_); y = ay_ + tt * (by_ - ay_);
+      ok = fabsf(xedge ? y : x) <= olim;
+    }
+  }
+  if (!ok) return false;
+  // lift onto the incident face's plane: X = rp + x ru + y rv + h nr with (X - ic) . inorm = 0
+  const v3 base = rp + ru * x + rv * y, inorm = iab * isgn;
+  const float dn = dot(nr, inorm), hh = fabsf(dn) > 1e-12f ? dot(ic - base, inorm) / dn : dot(ic - base, nr);
+  dist = hh - la;   // signed distance of the incident-face point from the reference face
+  if (dist > margin) return false;
+  pos = base + nr * (la + 0.5f * dist) + P1;
+  return true;
+}
+RG_STAGE void rg_narrow_boxbox(RgCtx c, int ncand) {
+  RgM m = RG_M(c); RgLRef L = RG_L(c); RgLds& s = RG_S();
+  const float gscale = rg_prm(m, L)[RG_PRM_GEOM_SCALE];
+  const int l = LANE & 31, grp = LANE >> 5;
+  for (int cbase = 0; cbase < ncand; cbase += RG_WAVE) {
+    bool is_bb = false;
+    if (cbase + LANE < ncand) { const int hdr = __builtin_bit_cast(int, m.pair_rec[RG_PAIRREC * s.cand[cbase + LANE]]); is_bb = ((hdr >> 20) & 15) == RG_GEOM_BOX && ((hdr >> 24) & 15) == RG_GEOM_BOX; }
+    unsigned long long bits = __ballot(is_bb);
+    while (bits) {
+      const int ci0 = cbase + __builtin_ctzll(bits); bits &= bits - 1;
+      int ci1 = -1; if (bits) { ci1 = cbase + __builtin_ctzll(bits); bits &= bits - 1; }
+      const int ci = grp == 0 ? ci0 : ci1;
+      bool hit = false; float dist = 0; v3 pos = mk3(0, 0, 0), nrm = mk3(0, 0, 1); int p = 0, dim = 3;
+      if (ci >= 0) { p = s.cand[ci]; hit = rg_box_box_lane(m, s, p, gscale, l, dist, pos, nrm, dim); }
+      unsigned long long bal = __ballot(hit);
+      int cb = s.ncon;
+      SYNC();
+      if (hit) {
+        int cc = cb + __popcll(bal & ((1ull << LANE) - 1ull));
+        if (cc < RG_MAXCON) { s.c_dist[cc] = dist; st3(s.c_pos + 3 * cc, pos); st3(s.c_normal + 3 * cc, normalized(nrm)); s.c_pair[cc] = p; s.c_dim[cc] = dim; }
+        else s.status |= RG_STATUS_CON_FULL;
+      }
+      if (LANE == 0) { int nn = cb + __popcll(bal); s.ncon = nn < RG_MAXCON ? nn : RG_MAXCON; }
+      SYNC();
+    }
+  }
+}
 template <int G> RG_STAGE void rg_narrow_phase1(RgCtx c, int ncand) {
   RgM m = RG_M(c); RgLRef L = RG_L(c); RgLds& s = RG_S();
   bool cells = !(L.flags & 8);
@@ -954,6 +1106,7 @@ template <int G> RG_STAGE void rg_narrow_phase1(RgCtx c, int ncand) {
   float* pairlb = (L.bt.pairlb && !(L.flags & 4)) ? L.bt.pairlb + (size_t)rg_env(L) * m.npair : (float*)0;
   const float gscale = rg_prm(m, L)[RG_PRM_GEOM_SCALE];
   MprEnv E = rg_mpr_env(m, (float*)0, cells);
+  const bool boxbox = !(L.flags & 16);   // box-box pairs have their own routine (rg_narrow_boxbox)
   for (int base = 0; base < ncand; base += RG_WAVE / G) {
     int ci = base + LANE / G;
     bool keep = false; int p = 0;
@@ -961,7 +1114,7 @@ template <int G> RG_STAGE void rg_narrow_phase1(RgCtx c, int ncand) {
       p = s.cand[ci];
       MprGeom A, B; int dim; float margin;
       rg_mpr_geoms(m, s, p, gscale, A, B, dim, margin);
-      if (A.type != RG_GEOM_PLANE) {
+      if (A.type != RG_GEOM_PLANE && !(boxbox && A.type == RG_GEOM_BOX && B.type == RG_GEOM_BOX)) {
         v3 c0 = A.pos - B.pos;
         if (mz(c0.x) && mz(c0.y) && mz(c0.z)) c0.x += 1e-6f;
         v3 dir = normalized(c0 * -1.0f);
@@ -1038,7 +1191,7 @@ __device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, const flo
   // then oriented boxes; both conservative, both refresh the bound when they separate the pair.
   int nround = (m.npair + RG_WAVE - 1) / RG_WAVE;
   float hb = 1.5f * P[RG_PRM_TIMESTEP];
-  int nt = 0;
+  int nt = 0; bool bbany = false;   // (bbany: this lane queued a pair of two boxes — those have their own narrowphase routine)
   for (int r0 = 0; r0 < nround; r0 += 4) {   // four rounds per trip: eight independent loads in flight per lane
     int gg[4]; float lbv[4];
 #pragma unroll
@@ -1064,7 +1217,7 @@ __device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, const flo
     SYNC();
     for (int i0 = 0; i0 < nt; i0 += RG_WAVE) {
       int i = i0 + LANE, q = 0;
-      bool hit = false;
+      bool hit = false, isbb = false;
       if (i < nt) {
         q = s.tlist[i];
         const rgf4* R = (const rgf4*)m.pair_rec + (RG_PAIRREC / 4) * q;
@@ -1074,6 +1227,7 @@ __device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, const flo
         const float sc1 = (hdr & RG_PAIR_SCALED1) ? gscale : 1.f, sc2 = (hdr & RG_PAIR_SCALED2) ? gscale : 1.f;
         r3.z *= sc1; r3.w *= sc2;
         v3 p1 = ld3(s.gpos + 3 * g1), p2 = ld3(s.gpos + 3 * g2), dif = p2 - p1;
+        isbb = ((hdr >> 20) & 255) == (RG_GEOM_BOX | (RG_GEOM_BOX << 4));
         if (((hdr >> 20) & 15) == RG_GEOM_PLANE) {
           float d = dot(dif, qrot(ldq(s.gquat + 4 * g1), mk3(0, 0, 1))) - (r3.w + margin);
           hit = d <= 0; newlb = fmaxf(d, 0.f);
@@ -1090,6 +1244,7 @@ __device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, const flo
         if (pairlb) pairlb[q] = fmaxf(newlb - 1e-6f, 0.f);
       }
       unsigned long long bal = __ballot(hit);
+      bbany = bbany || (hit && isbb);
       int base = s.ncand;
       SYNC();
       if (hit) {
@@ -1118,6 +1273,7 @@ __device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, const flo
   if (prof && LANE == 0) { prof[16] += (float)(rg_clock() - tb0); prof[17] += ncand; prof[18] += ncand2; }
   if (ncand2 > 4) rg_narrow_phase2<8>(c, ncand2); else rg_narrow_phase2<16>(c, ncand2);
   if (prof && LANE == 0) prof[19] += (float)(rg_clock() - tb0);
+  if (!(RG_L(c).flags & 16) && __ballot(bbany) != 0) rg_narrow_boxbox(c, ncand);
   // plane pairs (rare: something near the floor), whole wave cooperating, one pair at a time.  Which candidates are plane
   // pairs is found lane-parallel from the pair headers (a serial scan of ~25 candidates cost two dependent loads each).
   for (int cbase = 0; cbase < ncand; cbase += RG_WAVE) {

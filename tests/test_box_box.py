@@ -1,0 +1,146 @@
+"""Box-box contacts (engine_collision_box.c: mjc_BoxBox; oracle: collide_box_box; kernel: rg_narrow_boxbox): the kernel's
+lane-parallel multi-point routine against the oracle's serial one on a free box dropped onto a fixed box — flat (four face
+contacts), tilted (a corner, then an edge, then the face) and edge across edge — contact count, contact distances and the
+state after the landing; the launch flag's round-1 variant (one MPR contact per pair) stays available."""
+import numpy as np
+import pytest
+
+TWO_BOXES = """
+<mujoco>
+  <compiler angle="radian" coordinate="local"/>
+  <option timestep="0.004"/>
+  <worldbody>
+    <geom name="table" type="box" size="0.2 0.15 0.05" pos="0 0 0.05" condim="3" friction="0.8 0.005 0.0001"/>
+    <body name="brick" pos="{pos}" quat="{quat}">
+      <joint name="free" type="free"/>
+      <geom name="brick" type="box" size="0.04 0.03 0.02" density="700" condim="3" friction="0.8 0.005 0.0001"/>
+    </body>
+  </worldbody>
+</mujoco>
+"""
+
+CASES = {
+    # name: (pos, quat w x y z, substeps before the comparison)
+    "flat": ("0.01 0.02 0.125", "1 0 0 0", 60),
+    "tilted": ("0.0 0.0 0.14", "0.9689 0.1730 0.1211 0.1298", 120),
+    "overhang": ("0.19 0.0 0.125", "0.9239 0 0 0.3827", 60),           # partly over the table's edge, yawed 45 degrees
+    "edge_on_edge": ("0.2 0.0 0.135", "0.6533 0.2706 0.6533 -0.2706", 40),   # brick on its long edge across the table's edge
+}
+
+
+def _oracle(compiled):
+    from oracle.rg_oracle import OracleSim
+    from robogym_amd.mujoco.model_blob import pack_model
+
+    return OracleSim(pack_model(compiled))
+
+
+def _run(case, lib=None, device=None, flags_variant=False):
+    from robogym_amd import mujoco_py_shim as mujoco_py
+    from robogym_amd.mujoco import simulation_interface
+
+    pos, quat, nsteps = CASES[case]
+    model = mujoco_py.load_model_from_xml(TWO_BOXES.format(pos=pos, quat=quat))
+    kw = dict(lib=lib) if lib is not None else dict(device=device)
+    old = simulation_interface.MPR_PLANE_DEPTH
+    simulation_interface.MPR_PLANE_DEPTH = flags_variant
+    try:
+        sim = mujoco_py.MjSim(model, nsubsteps=1, **kw)
+    finally:
+        simulation_interface.MPR_PLANE_DEPTH = old
+    return model, sim, nsteps
+
+
+def _compare(case, oracle_lib, lib=None, device=None):
+    oracle_lib.set_kernel_variant(False)
+    model, sim, nsteps = _run(case, lib=lib, device=device)
+    ora = _oracle(model._compiled)
+    seen = 0
+    worst = 0.0
+    for k in range(nsteps):
+        # re-synchronised comparison: both sides step from the oracle's state
+        sim.data.qpos[:] = ora.qpos
+        sim.data.qvel[:] = ora.qvel
+        sim.step()
+        ora.step()
+        oc = ora.contacts()
+        assert sim.data.ncon == len(oc), (case, k, sim.data.ncon, len(oc))
+        if oc:
+            seen = max(seen, len(oc))
+            kd = sorted(c.dist for c in sim.data.contact[: sim.data.ncon])
+            od = sorted(c["dist"] for c in oc)
+            np.testing.assert_allclose(kd, od, atol=2e-6, err_msg="%s step %d" % (case, k))
+        worst = max(worst, float(np.abs(sim.data.qpos - ora.qpos).max()))
+    return seen, worst
+
+
+@pytest.mark.parametrize("case,min_contacts", [("flat", 4), ("tilted", 4), ("overhang", 3), ("edge_on_edge", 1)])
+def test_box_box_contacts_match_oracle_emul(case, min_contacts, emul_lib, oracle_lib):
+    seen, worst = _compare(case, oracle_lib, lib=emul_lib)
+    assert seen >= min_contacts, (case, seen)
+    assert worst < 2e-5, (case, worst)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,min_contacts", [("flat", 4), ("tilted", 4), ("overhang", 3), ("edge_on_edge", 1)])
+def test_box_box_contacts_match_oracle_gpu(case, min_contacts, oracle_lib):
+    seen, worst = _compare(case, oracle_lib, device="cuda:0")
+    assert seen >= min_contacts, (case, seen)
+    assert worst < 2e-5, (case, worst)
+
+
+def test_round1_variant_keeps_one_contact_per_pair_emul(emul_lib, oracle_lib):
+    """Launch flag bit 4: box-box pairs through MPR (one contact), the oracle's kernel variant likewise."""
+    from robogym_amd.mujoco import simulation_interface
+
+    oracle_lib.set_kernel_variant(True)
+    old = simulation_interface.MPR_PLANE_DEPTH
+    simulation_interface.MPR_PLANE_DEPTH = True
+    try:
+        model, sim, nsteps = _run("flat", lib=emul_lib, flags_variant=True)
+        ora = _oracle(model._compiled)
+        for _ in range(nsteps):
+            sim.step()
+            ora.step()
+        assert sim.data.ncon == 1 and len(ora.contacts()) == 1
+    finally:
+        simulation_interface.MPR_PLANE_DEPTH = old
+        oracle_lib.set_kernel_variant(False)
+
+
+def _random_poses(oracle_lib, n, lib=None, device=None):
+    """Random orientations (every third one nearly aligned with the table) and positions around the table's top, edges and
+    corners: the contacts of ONE collision pass from that pose, kernel vs oracle — count and sorted distances."""
+    oracle_lib.set_kernel_variant(False)
+    model, sim, _ = _run("flat", lib=lib, device=device)
+    ora = _oracle(model._compiled)
+    rng = np.random.RandomState(5)
+    counts, worst = {}, 0.0
+    for k in range(n):
+        q = rng.randn(4)
+        if k % 3 == 0:
+            q = np.array([1.0, 0, 0, 0]) + 0.02 * rng.randn(4)
+        q /= np.linalg.norm(q)
+        qpos = np.concatenate([[rng.uniform(-0.26, 0.26), rng.uniform(-0.2, 0.2), rng.uniform(0.09, 0.16)], q])
+        ora.reset(); ora.qpos[:] = qpos; ora.qvel[:] = 0
+        sim.reset(); sim.data.qpos[:] = qpos; sim.data.qvel[:] = 0
+        sim.step(); ora.step()          # (the contacts of a step are those of the state it started from)
+        oc = ora.contacts()
+        assert sim.data.ncon == len(oc), (k, qpos, sim.data.ncon, len(oc))
+        counts[len(oc)] = counts.get(len(oc), 0) + 1
+        if oc:
+            kd = np.array(sorted(c.dist for c in sim.data.contact[: len(oc)]))
+            od = np.array(sorted(c["dist"] for c in oc))
+            worst = max(worst, float(np.abs(kd - od).max()))
+    return counts, worst
+
+
+def test_box_box_random_poses_match_oracle_emul(emul_lib, oracle_lib):
+    counts, worst = _random_poses(oracle_lib, 150, lib=emul_lib)
+    assert worst < 1e-6 and all(counts.get(c, 0) > 0 for c in (1, 2, 3, 4)), (counts, worst)
+
+
+@pytest.mark.gpu
+def test_box_box_random_poses_match_oracle_gpu(oracle_lib):
+    counts, worst = _random_poses(oracle_lib, 600, device="cuda:0")
+    assert worst < 1e-6 and all(counts.get(c, 0) > 0 for c in (1, 2, 3, 4, 5)), (counts, worst)

@@ -27,7 +27,7 @@ for kernel_variant in (True, False):
     simulation_interface.MPR_PLANE_DEPTH = kernel_variant
     print("=" * 110)
     print("ORACLE = %s" % ("PORTAL-PLANE contact depth on both sides (kernel flags bit 4; oracle: set_kernel_variant, box-box through MPR): does the kernel compute what it says, at fp32 tolerance"
-                           if kernel_variant else "DEFAULT on both sides (product: libccd contact depth, box-box through MPR; oracle: libccd depth, multi-point box-box): distance of the product to the MuJoCo restatement"))
+                           if kernel_variant else "DEFAULT on both sides (libccd contact depth, multi-point box-box): distance of the product to the MuJoCo restatement"))
     marks = [1, 10, 100, 1000]
     print("free-running drift, kernel (fp32, MI355X) vs oracle (fp64, CPU), dactyl/locked, iid U(-1,1) relative actions, same bytes at step 0")
     print("stream  " + "  ".join("Linf@%-5d" % m for m in marks) + "  first step with Linf > 1e-4   contacts/substep")

@@ -1,5 +1,5 @@
-"""How far the HIP kernel's two documented collision deviations (portal-plane MPR depth instead of libccd's closest point
-on the final portal triangle; box-box through MPR instead of MuJoCo's multi-point mjc_BoxBox) move the physics, measured
+"""How far the HIP kernel's optional round-1 contact generation (launch flag bit 4: portal-plane MPR depth instead of libccd's
+closest point on the final portal triangle; box-box through MPR instead of the multi-point mjc_BoxBox) moves the physics, measured
 inside the oracle alone: the DEFAULT oracle (closest available statement of MuJoCo 2.0) against the oracle in kernel-variant
 mode, from identical fp64 states along random-action rollouts.  Per state: the contact lists of both variants (matched by
 geom pair), their depth and normal deltas, and the non-target qpos / qvel delta after ONE mj_step and after one env.step.
@@ -87,7 +87,7 @@ for sidx in range(n_streams):
 
 depth, angle, sub_q, sub_v, env_q, env_v = map(np.asarray, (depth, angle, sub_q, sub_v, env_q, env_v))
 print()
-print("documented collision deviations, measured inside the oracle: DEFAULT (libccd triangle-distance MPR depth + multi-point box-box)")
+print("the optional round-1 contact generation (flag bit 4), measured inside the oracle: DEFAULT (libccd triangle-distance MPR depth + multi-point box-box)")
 print("vs KERNEL VARIANT (portal-plane depth, box-box through MPR); %d states along %d random-action rollouts of dactyl/locked, fp64" % (len(sub_q), n_streams))
 print("  contacts per state (default oracle): mean %.2f, max %d; states where the contact COUNT differs: %d (a box-box pair in contact in %d)" % (np.mean(ncons), max(ncons), int(np.sum(np.asarray(extra) > 0)), boxbox_states))
 print("  matched contacts: %d" % len(depth))
