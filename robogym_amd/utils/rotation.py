@@ -20,7 +20,7 @@ def quat_mul(q0: torch.Tensor, q1: torch.Tensor) -> torch.Tensor:
 
 
 def quat_conjugate(q: torch.Tensor) -> torch.Tensor:
-    return q * q.new_tensor([1.0, -1.0, -1.0, -1.0])
+    return torch.cat([q[..., :1], -q[..., 1:]], dim=-1)   # (no host-built constant: a tensor made from a Python list is a blocking copy behind the queued kernels)
 
 
 def quat_normalize(q: torch.Tensor) -> torch.Tensor:

@@ -56,6 +56,7 @@ class TorchDraws:
 
     def __init__(self, generator: torch.Generator, batch_size: int, device):
         self.gen, self.B, self.device = generator, batch_size, device
+        self._choice_tables = {}
 
     def _u(self, shape):
         return torch.rand((self.B,) + tuple(shape), generator=self.gen, device=self.device)
@@ -79,7 +80,10 @@ class TorchDraws:
         return torch.randint(low, high, (self.B,) + tuple(shape), generator=self.gen, device=self.device)
 
     def choice(self, values):
-        v = torch.as_tensor(values, device=self.device)
+        key = tuple(values)   # (the value table is built on the device once: a host-made tensor per call is a blocking copy behind the queued kernels)
+        v = self._choice_tables.get(key)
+        if v is None:
+            v = self._choice_tables[key] = torch.as_tensor(values, device=self.device)
         return v[torch.randint(0, len(values), (self.B,), generator=self.gen, device=self.device)]
 
 
@@ -99,6 +103,8 @@ class BatchedDactylCubeWrappers:
         # the wrappers redraw that env's randomizations when its episode ends and reset their per-episode state when the new one starts
         self.auto_reset = bool(auto_reset)
         self._wrist = None
+        self._wrist_rng = None
+        self._backlash_logs = None
         self._next_delta: Dict[str, torch.Tensor] = {}
         self._in_recipe = torch.zeros(env.batch_size, dtype=torch.bool, device=env.device)
         if self.auto_reset and not getattr(env, "pipelined_reset", False):
@@ -154,6 +160,7 @@ class BatchedDactylCubeWrappers:
             marker_sites=t([N["site"].index("robot0:" + s) for s in FINGERTIP_SITES + REFERENCE_SITES], torch.long),
             occlusion=t([N["geom"].index(n) for n in OCCLUSION_MARKERS], torch.long) if all(n in N["geom"] for n in OCCLUSION_MARKERS) else None,
         )
+        self._marker_site_list = [N["site"].index("robot0:" + s) for s in FINGERTIP_SITES + REFERENCE_SITES]   # (host copy: `.tolist()` of the device index per reset would synchronise)
         self._marker_noise = [0.003] * 5 + [0.001] * 3                    # RandomizedPhasespaceFingersWrapper(fingertips_noise, reference_noise)
         self._cube_body = N["body"].index("cube:middle")
         self._cube_size0 = t(A["geom_size"][N["geom"].index("cube:middle")])
@@ -237,7 +244,7 @@ class BatchedDactylCubeWrappers:
         damp = O["dof_damping"][I["robot_dofs"]][None] * torch.exp(D.uniform(np.log(1 / 1.5), np.log(1.5), (len(I["robot_dofs"]),)))
         self._put("dof_damping", mask, damp, I["robot_dofs"])
         # RandomizedPhasespaceFingersWrapper (dactyl.py:14-50): one uniform(-noise, noise, 3) per marker site, in list order
-        sp = torch.stack([O["site_pos"][s][None] + D.uniform(-n, n, (3,)) for s, n in zip(I["marker_sites"].tolist(), self._marker_noise)], dim=1)
+        sp = torch.stack([O["site_pos"][s][None] + D.uniform(-n, n, (3,)) for s, n in zip(self._marker_site_list, self._marker_noise)], dim=1)
         self._put("site_pos", mask, sp, I["marker_sites"])
         # RandomizedGravityWrapper (randomizations.py:176-191)
         grav = O["gravity"][None] + 0.4 * D.randn((3,))
@@ -271,11 +278,12 @@ class BatchedDactylCubeWrappers:
 
     def _randomize_after_reset(self, mask, deltas=None):
         D, dev = self.draws, self.device
-        t = lambda a: torch.as_tensor(a, dtype=torch.float32, device=dev)
+        if self._backlash_logs is None:   # device copies of the two constant rows, made once
+            self._backlash_logs = tuple(torch.as_tensor(a, dtype=torch.float32, device=dev) for a in (BACKLASH_COEF_DOWN_LOG, BACKLASH_COEF_UP_LOG))
         # BacklashWrapper.reset (randomizations.py:856-874)
         self._slack = torch.where(mask[:, None], torch.zeros_like(self._slack), self._slack)
-        down = torch.clamp(torch.exp(t(BACKLASH_COEF_DOWN_LOG)[None] * (1.0 + D.randn((self.nu,)) * 0.1)), min=2.0)
-        up = torch.clamp(torch.exp(t(BACKLASH_COEF_UP_LOG)[None] * (1.0 + D.randn((self.nu,)) * 0.1)), min=2.0)
+        down = torch.clamp(torch.exp(self._backlash_logs[0][None] * (1.0 + D.randn((self.nu,)) * 0.1)), min=2.0)
+        up = torch.clamp(torch.exp(self._backlash_logs[1][None] * (1.0 + D.randn((self.nu,)) * 0.1)), min=2.0)
         self._coef_down = torch.where(mask[:, None], down.to(self._coef_down.dtype), self._coef_down)
         self._coef_up = torch.where(mask[:, None], up.to(self._coef_up.dtype), self._coef_up)
         # RandomizedActionLatency.reset (:534-543), max_delay = 1
@@ -504,7 +512,12 @@ class BatchedDactylCubeWrappers:
                 u = m.names["actuator"].index("robot0:A_WRJ0")
                 self._wrist = (u, int(m.arrays["jnt_qposadr"][m.names["joint"].index("robot0:WRJ0")]))
             u, qadr = self._wrist
-            rng = (sim.params["actuator_ctrlrange"][:, u] if self.randomize else torch.as_tensor(sim.model.arrays["actuator_ctrlrange"][u], dtype=a.dtype, device=self.device)[None])
+            if self.randomize:
+                rng = sim.params["actuator_ctrlrange"][:, u]
+            else:
+                if self._wrist_rng is None:   # (built once: a host-made tensor per step would be a blocking copy behind the queued kernels)
+                    self._wrist_rng = torch.as_tensor(sim.model.arrays["actuator_ctrlrange"][u], dtype=a.dtype, device=self.device)[None]
+                rng = self._wrist_rng
             a = a.clone()
             a[:, u] = (0.0 - sim.qpos[:, qadr].to(a.dtype)) / ((rng[:, 1] - rng[:, 0]) / 2.0).to(a.dtype)
         a = a.clamp(-1.0, 1.0)                                                           # ClipActionWrapper
