@@ -222,7 +222,11 @@ __device__ __forceinline__ void wave_argmax(float& v, int& i) {
 #ifdef RG_EMUL
 static inline long long rg_clock() { return 0; }
 #else
+#ifdef RG_CLOCK_REALTIME   /* analysis builds (tools/tail_analysis.py): the constant-rate counter instead of the shader clock */
+__device__ __forceinline__ long long rg_clock() { return (long long)__builtin_amdgcn_s_memrealtime(); }
+#else
 __device__ __forceinline__ long long rg_clock() { return (long long)__builtin_readcyclecounter(); }
+#endif
 #endif
 #define LANE ((int)threadIdx.x)
 #define SYNC() __syncthreads()
@@ -2470,6 +2474,9 @@ __global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_kernel(con
   PFOR(u, m.nu) L.bt.ctrl[(size_t)e * m.nu + u] = s.ctrl[u];
   if (LANE == 0) {
     L.bt.status[e] = s.status; L.bt.time[e] += nsubsteps * P[RG_PRM_TIMESTEP];
+#if defined(RG_CLOCK_REALTIME) && RG_CLOCK_REALTIME == 2
+    L.bt.time[e] = (float)(tk0 & 0xFFFFFF);   // analysis build only: when the env's wave started (low 24 bits of the 100 MHz counter) instead of the simulation time
+#endif
     if (L.bt.cost) L.bt.cost[e] = (float)(rg_clock() - tk0);
     if (L.bt.stats) { float* st = L.bt.stats + 4 * (size_t)e; st[0] += st_ncon; st[1] += st_nefc; st[2] += st_iter; st[3] += nsubsteps; }
   }
