@@ -204,7 +204,7 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
   GI("k_ltdl_pair_c"); d.n_pair_rounds_c = (int)(iv.size() / 64); if (!upload<int>(m, iv, &d.ltdl_pair_c)) return bail("hipMalloc failed", m);
   GI("k_tree_newton_ok"); d.tree_newton_ok = iv.empty() ? 0 : iv[0];
   if (d.n_tri_rounds_c > RG_LTDL_TRI_ROUNDS || d.n_pair_rounds_c > RG_LTDL_PAIR_ROUNDS) d.tree_newton_ok = 0;
-  if (d.n_tri_rounds > RG_LTDL_TRI_ROUNDS || d.n_pair_rounds > RG_LTDL_PAIR_ROUNDS) return bail("dof tree too large for the L'DL descriptor caps", m); UPI(lvl_body, "k_lvl_body"); UPI(lvl_body_adr, "k_lvl_body_adr"); UPI(static_body, "k_static_body");
+  if (d.n_tri_rounds > RG_LTDL_TRI_ROUNDS || d.n_pair_rounds > RG_LTDL_PAIR_ROUNDS) return bail("dof tree too large for the L'DL descriptor caps", m);
   UPF(static_xpos, "k_static_xpos"); UPF(static_xquat, "k_static_xquat");
   UPI(root_origin_body, "k_root_origin_body"); UPI(body_orgslot, "k_body_orgslot"); UPF(root_origin_const, "k_root_origin_const");
   { GI("k_body_dofmask"); std::vector<uint32_t> u(iv.begin(), iv.end()); for (size_t i = 0; i < iv.size(); i++) u[i] = (uint32_t)iv[i]; if (!upload<uint32_t>(m, u, &d.body_dofmask)) return bail("hipMalloc failed", m); }
@@ -215,7 +215,7 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
   UPF(dof_armature, "dof_armature"); UPF(dof_damping, "dof_damping"); UPF(dof_frictionloss, "dof_frictionloss");
   UPF(dof_solref, "dof_solref"); UPF(dof_solimp, "dof_solimp"); UPF(dof_invweight0, "dof_invweight0");
   UPF(qpos0, "qpos0"); m->qpos0 = fv; UPF(qpos_spring, "qpos_spring");
-  {  // kinematics records, one per level slot: w0 body | parent<<8 | njnt<<16 | type(first joint)<<20, w1 first joint | its qposadr<<16,
+  {  // kinematics records (host side: one per level slot, copied per body below): w0 body | parent<<8 | njnt<<16 | type(first joint)<<20, w1 first joint | its qposadr<<16,
      // w2-4 body_pos, w5-8 body_quat, w9-11 body_ipos, w12-14 jnt_pos, w15-17 jnt_axis, w18 qpos0 of the joint
     std::vector<int> lb, par, jn, ja, jt, jq; std::vector<float> bp, bq, bi, jp, jx, q0;
     if (!get_i(B, "k_lvl_body", lb, e) || !get_i(B, "body_parentid", par, e) || !get_i(B, "body_jntnum", jn, e) || !get_i(B, "body_jntadr", ja, e) ||
@@ -231,7 +231,42 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
       for (int c = 0; c < 4; c++) r[5 + c] = bq[4 * b + c];
       r[18] = jn[b] > 0 ? q0[qa] : 0.f;
     }
-    if (!upload<float>(m, rec, &d.kin_rec)) return bail("hipMalloc failed", m);
+    // per moving body: its own record once more (indexed by body), and its chain of moving ancestors (root first, the body
+    // last; one byte each) — rg_kinematics composes the bodies' relative frames down that chain, one lane per body
+    {
+      static_assert(RG_MAXDEPTH <= 8 && RG_MAXBODY <= 256, "body chain: 8 bytes per body");
+      std::vector<int> slot(d.nbody, -1), depth(d.nbody, 0), chainw((size_t)(d.nbody ? d.nbody : 1) * 2, 0);
+      for (size_t k = 0; k < lb.size(); k++) if (lb[k] >= 0 && lb[k] < d.nbody) slot[lb[k]] = (int)k;
+      std::vector<float> brec((size_t)(d.nbody ? d.nbody : 1) * RG_KINREC, 0.f);
+      for (int b0 = 0; b0 < d.nbody; b0++) {
+        if (slot[b0] < 0) continue;
+        memcpy(brec.data() + (size_t)b0 * RG_KINREC, rec.data() + (size_t)slot[b0] * RG_KINREC, RG_KINREC * 4);
+        int chain[RG_MAXDEPTH + 1], n = 0, a0 = b0;
+        for (; a0 > 0 && slot[a0] >= 0; a0 = par[a0]) { if (n >= RG_MAXDEPTH) return bail("kinematic chain deeper than RG_MAXDEPTH", m); chain[n++] = a0; }
+        unsigned long long cw = 0; int absmask = 0;
+        for (int i = 0; i < n; i++) {
+          int a = chain[n - 1 - i];
+          cw |= (unsigned long long)(a & 255) << (8 * i);
+          for (int jj = 0; jj < jn[a]; jj++) if (jt[ja[a] + jj] == RG_JNT_FREE) absmask |= 1 << i;
+        }
+        depth[b0] = n | (absmask << 8) | ((a0 & 255) << 16);
+        chainw[2 * b0] = (int)(unsigned)(cw & 0xFFFFFFFFull); chainw[2 * b0 + 1] = (int)(unsigned)(cw >> 32);
+      }
+      if (!upload<float>(m, brec, &d.body_rec) || !upload<int>(m, depth, &d.body_depth) || !upload<int>(m, chainw, &d.body_chain)) return bail("hipMalloc failed", m);
+    }
+    {  // com-frame origin slots (the kernel's `org`): one record per slot instead of body -> root -> origin body -> ipos
+      std::vector<int> os, rid, rob; std::vector<float> roc;
+      if (!get_i(B, "k_body_orgslot", os, e) || !get_i(B, "body_rootid", rid, e) || !get_i(B, "k_root_origin_body", rob, e) || !get_f(B, "k_root_origin_const", roc, e)) return bail(e, m);
+      std::vector<float> orec(16, 0.f);
+      for (int sl = 0; sl < 4; sl++) { int unused = -2; memcpy(&orec[4 * sl], &unused, 4); }
+      for (int b0 = 0; b0 < d.nbody; b0++) {
+        int sl = os[b0], r = rid[b0], ob = rob[r];
+        if (sl < 0 || sl > 3) return bail("com-frame slot out of range", m);
+        memcpy(&orec[4 * sl], &ob, 4);
+        for (int c = 0; c < 3; c++) orec[4 * sl + 1 + c] = ob >= 0 ? bi[3 * ob + c] : roc[3 * r + c];
+      }
+      if (!upload<float>(m, orec, &d.org_rec)) return bail("hipMalloc failed", m);
+    }
   }
   UPI(lvl_dof, "k_lvl_dof"); UPI(lvl_dof_adr, "k_lvl_dof_adr"); UPI(M_i, "k_M_i"); UPI(M_j, "k_M_j"); UPI(M_lvl_adr, "k_M_lvl_adr");
   UPI(desc_adr, "k_desc_adr"); UPI(desc, "k_desc");

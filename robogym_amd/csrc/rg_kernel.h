@@ -351,61 +351,83 @@ static inline size_t rg_lds_launch_bytes(bool profiling) { return profiling ? si
 // data.xipos of body b (com of the body in the world): not stored, its three readers derive it from the body frame
 __device__ __forceinline__ v3 rg_xipos(RgM m, const RgLds& s, int b) { return ld3(s.xpos + 3 * b) + qrot(ldq(s.xquat + 4 * b), ld3(m.body_ipos + 3 * b)); }
 __device__ __forceinline__ void rg_kinematics(RgM m, RgLds& s, const float* P) {
-  PFOR(i, m.nstatic) {
-    int b = m.static_body[i];
-    st3(s.xpos + 3 * b, ld3(m.static_xpos + 3 * b));
-    q4 q = ldq(m.static_xquat + 4 * b); stq(s.xquat + 4 * b, q);
+  // Pass A, one lane per moving body, all at once: the body's frame RELATIVE TO ITS PARENT (body offset, then its joints in
+  // turn: engine_core_smooth.c mj_kinematics with the parent at the origin) and its joints' anchors / axes in that frame.
+  // Pass B, one lane per moving body: compose the relative frames down the body's own chain of moving ancestors (a lane
+  // recomputes its ancestors' world frames with the arithmetic their own lanes use, so parent and child agree to the bit):
+  // 7 x (rotate + quaternion product) per lane instead of 7 level barriers with the joint trigonometry inside each.
+  // (relative frames wait in the geom-frame area, which is written only at the end of this stage)
+  float* lp = s.gpos; float* lq = s.gquat;
+  PFOR(b, m.nbody) {
+    if ((m.body_depth[b] & 255) == 0) {   // static body (the world included): its constant frame
+      st3(s.xpos + 3 * b, ld3(m.static_xpos + 3 * b)); stq(s.xquat + 4 * b, ldq(m.static_xquat + 4 * b));
+      continue;
+    }
+    // everything static about this body in one 80-byte record (one load latency, not a chain of four)
+    const rgf4* R = (const rgf4*)m.body_rec + (RG_KINREC / 4) * b;
+    rgf4 r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3], r4 = R[4];
+    int w0 = __builtin_bit_cast(int, r0.x), w1 = __builtin_bit_cast(int, r0.y);
+    int jn = (w0 >> 16) & 15, ja = w1 & 0xFFFF;
+    v3 pos = mk3(r0.z, r0.w, r1.x);
+    q4 quat; quat.w = r1.y; quat.x = r1.z; quat.y = r1.w; quat.z = r2.x;
+    for (int jj = 0; jj < jn; jj++) {
+      int j = ja + jj, t, qa; v3 jpos, jaxis; float q0;
+      if (jj == 0) { t = (w0 >> 20) & 15; qa = (w1 >> 16) & 0xFFFF; jpos = mk3(r3.x, r3.y, r3.z); jaxis = mk3(r3.w, r4.x, r4.y); q0 = r4.z; }
+      else { t = m.jnt_type[j]; qa = m.jnt_qposadr[j]; jpos = ld3(m.jnt_pos + 3 * j); jaxis = ld3(m.jnt_axis + 3 * j); q0 = m.qpos0[qa]; }
+      if (t == RG_JNT_FREE) {   // a free joint states the world frame itself (body_depth flags the chain element as absolute)
+        pos = ld3(s.qpos + qa); quat = qnormalize(ldq(s.qpos + qa + 3));
+        st3(s.xanchor + 3 * j, pos); st3(s.xaxis + 3 * j, mk3(0, 0, 1));
+        continue;
+      }
+      v3 anchor = pos + qrot(quat, jpos);
+      v3 axis = qrot(quat, jaxis);
+      st3(s.xanchor + 3 * j, anchor); st3(s.xaxis + 3 * j, axis);
+      if (t == RG_JNT_SLIDE) pos = pos + axis * (s.qpos[qa] - q0);
+      else {
+        q4 ql = (t == RG_JNT_BALL) ? qnormalize(ldq(s.qpos + qa)) : axisangle(jaxis, s.qpos[qa] - q0);
+        quat = qmul(quat, ql);
+        pos = anchor - qrot(quat, jpos);
+      }
+    }
+    st3(lp + 3 * b, pos); stq(lq + 4 * b, quat);
   }
   SYNC();
-  for (int L = 0; L < m.nlevel; L++) {
-    int a0 = m.lvl_body_adr[L], a1 = m.lvl_body_adr[L + 1];
-    for (int k = a0 + LANE; k < a1; k += RG_WAVE) {
-      // everything static about this level slot in one 80-byte record (one load latency, not a chain of four)
-      const rgf4* R = (const rgf4*)m.kin_rec + (RG_KINREC / 4) * k;
-      rgf4 r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3], r4 = R[4];
-      int w0 = __builtin_bit_cast(int, r0.x), w1 = __builtin_bit_cast(int, r0.y);
-      int b = w0 & 255, p = (w0 >> 8) & 255, jn = (w0 >> 16) & 15, ja = w1 & 0xFFFF;
-      q4 pq = ldq(s.xquat + 4 * p);
-      v3 pos = ld3(s.xpos + 3 * p) + qrot(pq, mk3(r0.z, r0.w, r1.x));
-      q4 bq; bq.w = r1.y; bq.x = r1.z; bq.y = r1.w; bq.z = r2.x;
-      q4 quat = qmul(pq, bq);
-      for (int jj = 0; jj < jn; jj++) {
-        int j = ja + jj, t, qa; v3 jpos, jaxis; float q0;
-        if (jj == 0) { t = (w0 >> 20) & 15; qa = (w1 >> 16) & 0xFFFF; jpos = mk3(r3.x, r3.y, r3.z); jaxis = mk3(r3.w, r4.x, r4.y); q0 = r4.z; }
-        else { t = m.jnt_type[j]; qa = m.jnt_qposadr[j]; jpos = ld3(m.jnt_pos + 3 * j); jaxis = ld3(m.jnt_axis + 3 * j); q0 = m.qpos0[qa]; }
-        if (t == RG_JNT_FREE) {
-          pos = ld3(s.qpos + qa); quat = qnormalize(ldq(s.qpos + qa + 3));
-          st3(s.xanchor + 3 * j, pos); st3(s.xaxis + 3 * j, mk3(0, 0, 1));
-          continue;
-        }
-        v3 anchor = pos + qrot(quat, jpos);
-        v3 axis = qrot(quat, jaxis);
-        st3(s.xanchor + 3 * j, anchor); st3(s.xaxis + 3 * j, axis);
-        if (t == RG_JNT_SLIDE) pos = pos + axis * (s.qpos[qa] - q0);
-        else {
-          q4 ql = (t == RG_JNT_BALL) ? qnormalize(ldq(s.qpos + qa)) : axisangle(jaxis, s.qpos[qa] - q0);
-          quat = qmul(quat, ql);
-          pos = anchor - qrot(quat, jpos);
-        }
-      }
-      quat = qnormalize(quat);
-      st3(s.xpos + 3 * b, pos); stq(s.xquat + 4 * b, quat);
+  for (int b = 1 + LANE; b < m.nbody; b += RG_WAVE) {
+    const int dw = m.body_depth[b], depth = dw & 255, absmask = (dw >> 8) & 255, p0 = (dw >> 16) & 255;
+    if (depth == 0) continue;
+    const unsigned c0 = (unsigned)m.body_chain[2 * b], c1 = (unsigned)m.body_chain[2 * b + 1];
+    const int w0 = __builtin_bit_cast(int, m.body_rec[RG_KINREC * b]), w1 = __builtin_bit_cast(int, m.body_rec[RG_KINREC * b + 1]);
+    v3 pos = ld3(m.static_xpos + 3 * p0), ppos = pos; q4 quat = ldq(m.static_xquat + 4 * p0), pq = quat;   // the chain hangs off the world or a static body
+    for (int i = 0; i < depth; i++) {
+      const int a = (i < 4 ? c0 >> (8 * i) : c1 >> (8 * (i - 4))) & 255;
+      ppos = pos; pq = quat;
+      if ((absmask >> i) & 1) { pos = ld3(lp + 3 * a); quat = ldq(lq + 4 * a); }
+      else { pos = ppos + qrot(pq, ld3(lp + 3 * a)); quat = qnormalize(qmul(pq, ldq(lq + 4 * a))); }
     }
-    SYNC();
+    const bool absolute = (absmask >> (depth - 1)) & 1;
+    const int jn = (w0 >> 16) & 15, ja = w1 & 0xFFFF;
+    if (!absolute) for (int jj = 0; jj < jn; jj++) {   // the body's joints: parent frame -> world
+      const int j = ja + jj;
+      st3(s.xanchor + 3 * j, ppos + qrot(pq, ld3(s.xanchor + 3 * j))); st3(s.xaxis + 3 * j, qrot(pq, ld3(s.xaxis + 3 * j)));
+    }
+    st3(s.xpos + 3 * b, pos); stq(s.xquat + 4 * b, quat);
   }
-  PFOR(g, m.ngeom) {
-    int b = m.geom_bodyid[g];
-    q4 xq = ldq(s.xquat + 4 * b);
-    st3(s.gpos + 3 * g, ld3(s.xpos + 3 * b) + qrot(xq, ld3(m.geom_pos + 3 * g)));
-    stq(s.gquat + 4 * g, qmul(xq, ldq(m.geom_quat + 4 * g)));
+  SYNC();
+  for (int g0 = 0; g0 < m.ngeom; g0 += 2 * RG_WAVE) {   // two geoms per lane and trip, their constants requested together (65 geoms: one trip)
+    const int gA = g0 + LANE, gB = gA + RG_WAVE, last = m.ngeom - 1, iA = gA < last ? gA : last, iB = gB < last ? gB : last;
+    const int bA = m.geom_bodyid[iA], bB = m.geom_bodyid[iB];
+    const v3 pA = ld3(m.geom_pos + 3 * iA), pB = ld3(m.geom_pos + 3 * iB); const q4 qA = ldq(m.geom_quat + 4 * iA), qB = ldq(m.geom_quat + 4 * iB);
+    if (gA < m.ngeom) { q4 xq = ldq(s.xquat + 4 * bA); st3(s.gpos + 3 * gA, ld3(s.xpos + 3 * bA) + qrot(xq, pA)); stq(s.gquat + 4 * gA, qmul(xq, qA)); }
+    if (gB < m.ngeom) { q4 xq = ldq(s.xquat + 4 * bB); st3(s.gpos + 3 * gB, ld3(s.xpos + 3 * bB) + qrot(xq, pB)); stq(s.gquat + 4 * gB, qmul(xq, qB)); }
   }
   PFOR(i, m.nsite) {
     int b = m.site_bodyid[i];
     st3(s.spos + 3 * i, ld3(s.xpos + 3 * b) + qrot(ldq(s.xquat + 4 * b), ld3(P + RG_PRM_SITE_POS + 3 * i)));
   }
-  PFOR(b, m.nbody) {
-    int r = m.body_rootid[b], ob = m.root_origin_body[r];
-    st3(s.org + 3 * s.b2org[b], ob >= 0 ? rg_xipos(m, s, ob) : ld3(m.root_origin_const + 3 * r));
+  if (LANE < 4) {   // com-frame origin of every kinematic tree: the com of its origin body, or a constant (one record per slot, rg_api.hip)
+    const rgf4 o = ((const rgf4*)m.org_rec)[LANE];
+    const int ob = __builtin_bit_cast(int, o.x);
+    if (ob != -2) st3(s.org + 3 * LANE, ob >= 0 ? ld3(s.xpos + 3 * ob) + qrot(ldq(s.xquat + 4 * ob), mk3(o.y, o.z, o.w)) : mk3(o.y, o.z, o.w));
   }
   SYNC();
 }

@@ -23,6 +23,7 @@
 #define RG_LTDL_TRI_ROUNDS 12   // caps on the descriptor rounds of the L'DL passes (registers per lane)
 #define RG_LTDL_PAIR_ROUNDS 8
 #define RG_KINREC 20    // words per kinematics record
+#define RG_MAXDEPTH 8   // moving bodies on a root-to-leaf chain
 #define RG_MAXSENSOR 8
 #define RG_PAIRREC 28   // words per pair record
 #define RG_PAIR_SCALED1 (1 << 28)   // pair record header: geom 1 / geom 2 takes the env's RG_PRM_GEOM_SCALE
@@ -93,16 +94,18 @@ struct RgModelDev {
   // bodies
   const int *body_parentid, *body_rootid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum, *body_lastdof;
   const float *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_invweight0;
-  const int *lvl_body, *lvl_body_adr, *static_body;
   const int *ltdl_tri, *ltdl_pair;   // tree-sparse L'DL passes of M: rounds of 64 descriptors (kernel_tables.py)
   int n_tri_rounds, n_pair_rounds;
   const int *ltdl_tri_c, *ltdl_pair_c;   // the same for the constrained trees, vectors indexed by compact dof (Newton Hessian with tree pattern)
   int n_tri_rounds_c, n_pair_rounds_c, tree_newton_ok;
   const int* subtree_mask;      // [nbody] bit c: body c belongs to the subtree rooted at the body (self included)
-  const float* kin_rec;         // [len(lvl_body)][RG_KINREC] per level slot: body, parent, first joint and their constants (rg_api.hip)
+  const float* body_rec;        // [nbody][RG_KINREC] per moving body: body, parent, first joint and their constants (rg_api.hip)
+  const int* body_depth;        // [nbody] moving bodies on the chain from the root to this body, itself included (0: static body) | bit i of the next byte: chain element i has a free joint (its frame is absolute) << 8 | the body the chain hangs off (world / static) << 16
+  const int* body_chain;        // [nbody][2] that chain, root first, one byte per body
   const float *static_xpos, *static_xquat;
   const int *root_origin_body, *body_orgslot;
   const float* root_origin_const;
+  const float* org_rec;         // [4][4] per com-frame slot: origin body (int; -1: constant, -2: slot unused), then that body's ipos or the constant (rg_api.hip)
   const uint32_t* body_dofmask;  // [nbody][2]
   // joints / dofs
   const int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid;
