@@ -1218,12 +1218,16 @@ __device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, const flo
   int nround = (m.npair + RG_WAVE - 1) / RG_WAVE;
   float hb = 1.5f * P[RG_PRM_TIMESTEP];
   int nt = 0; bool bbany = false;   // (bbany: this lane queued a pair of two boxes — those have their own narrowphase routine)
-  for (int r0 = 0; r0 < nround; r0 += 4) {   // four rounds per trip: eight independent loads in flight per lane
+  int gg_next[4]; float lb_next[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) { int p = k * RG_WAVE + LANE, pc = p < m.npair ? p : m.npair - 1; gg_next[k] = m.pair_gg[pc]; lb_next[k] = pairlb ? pairlb[pc] : 0.f; }
+  for (int r0 = 0; r0 < nround; r0 += 4) {   // four rounds per trip: eight independent loads in flight per lane, requested one trip ahead (a trip only writes the bounds of its own pairs)
     int gg[4]; float lbv[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      int p = (r0 + k) * RG_WAVE + LANE, pc = p < m.npair ? p : m.npair - 1;
-      gg[k] = m.pair_gg[pc]; lbv[k] = pairlb ? pairlb[pc] : 0.f;
+    for (int k = 0; k < 4; k++) { gg[k] = gg_next[k]; lbv[k] = lb_next[k]; }
+    if (r0 + 4 < nround) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) { int p = (r0 + 4 + k) * RG_WAVE + LANE, pc = p < m.npair ? p : m.npair - 1; gg_next[k] = m.pair_gg[pc]; lb_next[k] = pairlb ? pairlb[pc] : 0.f; }
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
