@@ -268,7 +268,7 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
       if (!upload<float>(m, orec, &d.org_rec)) return bail("hipMalloc failed", m);
     }
   }
-  UPI(lvl_dof, "k_lvl_dof"); UPI(lvl_dof_adr, "k_lvl_dof_adr"); UPI(M_i, "k_M_i"); UPI(M_j, "k_M_j"); UPI(M_lvl_adr, "k_M_lvl_adr");
+  UPI(lvl_dof, "k_lvl_dof"); UPI(lvl_dof_adr, "k_lvl_dof_adr"); UPI(M_i, "k_M_i"); UPI(M_j, "k_M_j"); { std::vector<int> mi0, mj0, db0; if (!get_i(B, "k_M_i", mi0, e) || !get_i(B, "k_M_j", mj0, e) || !get_i(B, "dof_bodyid", db0, e)) return bail(e, m); std::vector<int> w(mi0.size() ? mi0.size() : 1, 0); for (size_t q = 0; q < mi0.size(); q++) w[q] = mi0[q] | (mj0[q] << 8) | (db0[mi0[q]] << 16); if (!upload<int>(m, w, &d.M_ijb)) return bail("hipMalloc failed", m); }   /* M entry: dof i | dof j << 8 | body of i << 16 */ UPI(M_lvl_adr, "k_M_lvl_adr");
   UPI(desc_adr, "k_desc_adr"); UPI(desc, "k_desc");
   {  // per tree-sparse entry of M: its two words in the per-tree block layout and its place in the compact Newton space
     std::vector<int> mi, mj, blk, d2c;
@@ -363,6 +363,23 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
   UPF(tendon_solref_lim, "tendon_solref_lim"); UPF(tendon_solimp_lim, "tendon_solimp_lim"); UPF(tendon_solref_fri, "tendon_solref_fri");
   UPF(tendon_solimp_fri, "tendon_solimp_fri"); UPF(tendon_invweight0, "tendon_invweight0");
   UPI(dof_ten_adr, "k_dof_ten_adr"); UPI(dof_ten, "k_dof_ten"); UPI(dof_act_adr, "k_dof_act_adr"); UPI(dof_act, "k_dof_act");
+  {  // per-dof record for the velocity / actuation stages (one load instead of dof -> joint -> stiffness / qposadr -> spring chains):
+     // w0 body | tendon entries begin << 8 | end << 16, w1 actuator entries begin | end << 8, w2 joint stiffness (0 unless hinge / slide), w3 qposadr, w4 qpos_spring, w5-7 unused
+    std::vector<int> db, dj, jt, jq, ta, aa; std::vector<float> js, qs;
+    if (!get_i(B, "dof_bodyid", db, e) || !get_i(B, "dof_jntid", dj, e) || !get_i(B, "jnt_type", jt, e) || !get_i(B, "jnt_qposadr", jq, e) ||
+        !get_i(B, "k_dof_ten_adr", ta, e) || !get_i(B, "k_dof_act_adr", aa, e) || !get_f(B, "jnt_stiffness", js, e) || !get_f(B, "qpos_spring", qs, e)) return bail(e, m);
+    std::vector<float> drec((size_t)(d.nv ? d.nv : 1) * 8, 0.f);
+    for (int i = 0; i < d.nv; i++) {
+      int j = dj[i], t = jt[j], qa = jq[j];
+      if (ta[i + 1] > 255 || aa[i + 1] > 255 || db[i] > 255) return bail("dof record: table index out of range", m);
+      int w0 = db[i] | (ta[i] << 8) | (ta[i + 1] << 16), w1 = aa[i] | (aa[i + 1] << 8);
+      float* r = drec.data() + 8 * (size_t)i;
+      memcpy(r, &w0, 4); memcpy(r + 1, &w1, 4);
+      r[2] = (t == RG_JNT_HINGE || t == RG_JNT_SLIDE) ? js[j] : 0.f;
+      memcpy(r + 3, &qa, 4); r[4] = qs[qa];
+    }
+    if (!upload<float>(m, drec, &d.dof_rec)) return bail("hipMalloc failed", m);
+  }
   UPI(actuator_trntype, "actuator_trntype"); UPI(actuator_trnid, "actuator_trnid"); UPI(actuator_ctrllimited, "actuator_ctrllimited");
   UPI(actuator_forcelimited, "actuator_forcelimited"); UPI(actuator_biastype, "actuator_biastype");
   UPF(actuator_gear, "actuator_gear"); UPF(actuator_ctrlrange, "actuator_ctrlrange"); UPF(actuator_forcerange, "actuator_forcerange");
@@ -372,6 +389,30 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
   GI("k_lim_jnt"); d.nlim_jnt = (int)iv.size(); if (!upload<int>(m, iv, &d.lim_jnt)) return bail("hipMalloc failed", m);
   GI("k_lim_ten"); d.nlim_ten = (int)iv.size(); if (!upload<int>(m, iv, &d.lim_ten)) return bail("hipMalloc failed", m);
   if (d.nfric_dof + d.nfric_ten + 2 * d.nlim_jnt + 2 * d.nlim_ten > RG_MAXSROW || d.nfric_dof + d.nfric_ten > RG_MAXFRIC) return bail("too many friction/limit rows for RG_MAXSROW / RG_MAXFRIC", m);
+  {  // static constraint rows (friction loss of dofs / tendons, joint / tendon limits), one 16-word record per row in row order:
+     // w0 Jacobian descriptor (compact dof | tendon << 6 | sign << 11) | kind << 16, w1 qposadr / tendon whose position the limit reads,
+     // w2 parameter-row offset of the row's diagApprox, w3 of its friction loss (-1: none or constant), w4 constant friction loss,
+     // w5 parameter-row offset of the limit, w6 margin, w7-8 solref, w9-13 solimp
+    std::vector<int> fd, ft, lj, lt, d2c, jq, jd; std::vector<float> tfl, jm, tm, dsr, dsi, tsrf, tsif, jsr, jsi, tsrl, tsil;
+    if (!get_i(B, "k_fric_dof", fd, e) || !get_i(B, "k_fric_ten", ft, e) || !get_i(B, "k_lim_jnt", lj, e) || !get_i(B, "k_lim_ten", lt, e) || !get_i(B, "k_d2c", d2c, e) ||
+        !get_i(B, "jnt_qposadr", jq, e) || !get_i(B, "jnt_dofadr", jd, e) || !get_f(B, "tendon_frictionloss", tfl, e) || !get_f(B, "jnt_margin", jm, e) || !get_f(B, "tendon_margin", tm, e) ||
+        !get_f(B, "dof_solref", dsr, e) || !get_f(B, "dof_solimp", dsi, e) || !get_f(B, "tendon_solref_fri", tsrf, e) || !get_f(B, "tendon_solimp_fri", tsif, e) ||
+        !get_f(B, "jnt_solref", jsr, e) || !get_f(B, "jnt_solimp", jsi, e) || !get_f(B, "tendon_solref_lim", tsrl, e) || !get_f(B, "tendon_solimp_lim", tsil, e)) return bail(e, m);
+    const int ns = d.nfric_dof + d.nfric_ten + 2 * d.nlim_jnt + 2 * d.nlim_ten;
+    std::vector<float> srec((size_t)(ns ? ns : 1) * 16, 0.f);
+    for (int r = 0; r < ns; r++) {
+      float* o = srec.data() + 16 * (size_t)r;
+      int rr = r, kind, dof = 0, ten = 31, neg = 0, src = 0, odiag, ofl = -1, olim = 0; float cfl = 0.f, margin = 0.f; const float *sr, *si;
+      if (rr < d.nfric_dof) { int q = fd[rr]; kind = 0; dof = d2c[q]; ofl = RG_PRM_DOF_FRICTIONLOSS + q; odiag = RG_PRM_DOF_INVWEIGHT0 + q; sr = &dsr[2 * q]; si = &dsi[5 * q]; }
+      else if ((rr -= d.nfric_dof) < d.nfric_ten) { int t = ft[rr]; kind = 1; ten = t; cfl = tfl[t]; odiag = RG_PRM_TENDON_INVWEIGHT0 + t; sr = &tsrf[2 * t]; si = &tsif[5 * t]; }
+      else if ((rr -= d.nfric_ten) < 2 * d.nlim_jnt) { int j = lj[rr >> 1]; kind = 2; dof = d2c[jd[j]]; neg = rr & 1; src = jq[j]; olim = RG_PRM_JNT_RANGE + 2 * j + (rr & 1); margin = jm[j]; odiag = RG_PRM_DOF_INVWEIGHT0 + jd[j]; sr = &jsr[2 * j]; si = &jsi[5 * j]; }
+      else { rr -= 2 * d.nlim_jnt; int t = lt[rr >> 1]; kind = 3; ten = t; neg = rr & 1; src = t; olim = RG_PRM_TENDON_RANGE + 2 * t + (rr & 1); margin = tm[t]; odiag = RG_PRM_TENDON_INVWEIGHT0 + t; sr = &tsrl[2 * t]; si = &tsil[5 * t]; }
+      int w0 = (dof & 63) | (ten << 6) | (neg << 11) | (kind << 16);
+      memcpy(o, &w0, 4); memcpy(o + 1, &src, 4); memcpy(o + 2, &odiag, 4); memcpy(o + 3, &ofl, 4); o[4] = cfl; memcpy(o + 5, &olim, 4); o[6] = margin;
+      o[7] = sr[0]; o[8] = sr[1]; for (int c = 0; c < 5; c++) o[9 + c] = si[c];
+    }
+    if (!upload<float>(m, srec, &d.srow_rec)) return bail("hipMalloc failed", m);
+  }
   { GI("k_pair_geom"); for (size_t i = 2; i < iv.size(); i += 3) if (iv[i] > 4) return bail("condim 6 (rolling friction) contacts are not implemented", m); }
   GI("k_subtree_adr"); if (!upload<int>(m, iv, &m->aux.subtree_adr)) return bail("hipMalloc failed", m);
   GI("k_subtree"); if (!upload<int>(m, iv, &m->aux.subtree)) return bail("hipMalloc failed", m);

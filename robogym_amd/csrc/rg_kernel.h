@@ -627,9 +627,9 @@ __device__ __forceinline__ void rg_crb(RgM m, RgLds& s, const float* P, const in
   }
   SYNC();
   PFOR(e, m.nM) {
-    int i = m.M_i[e], j = m.M_j[e];
+    const int ijb = m.M_ijb[e], i = ijb & 255, j = (ijb >> 8) & 255;
     float buf[6];
-    mul_inert_vec(buf, s.crb + 10 * m.dof_bodyid[i], s.cdof + 6 * i);
+    mul_inert_vec(buf, s.crb + 10 * (ijb >> 16), s.cdof + 6 * i);
     const float* c = s.cdof + 6 * j;
     float v = c[0] * buf[0] + c[1] * buf[1] + c[2] * buf[2] + c[3] * buf[3] + c[4] * buf[4] + c[5] * buf[5];
     if (i == j) v += P[RG_PRM_DOF_ARMATURE + i];
@@ -1401,12 +1401,13 @@ __device__ __forceinline__ void rg_velocity(RgM m, RgLds& s, const float* P, con
   }
   SYNC();
   PFOR(d, m.nv) {
-    const float *c = s.cdof + 6 * d, *f = s.cacc + 6 * m.dof_bodyid[d];
+    const rgf4 dr0 = ((const rgf4*)m.dof_rec)[2 * d]; const float spring_ref = m.dof_rec[8 * d + 4];   // body, tendon entries, joint stiffness, qposadr | spring reference
+    const int w0 = __builtin_bit_cast(int, dr0.x);
+    const float *c = s.cdof + 6 * d, *f = s.cacc + 6 * (w0 & 255);
     s.qfrc_bias[d] = c[0] * f[0] + c[1] * f[1] + c[2] * f[2] + c[3] * f[3] + c[4] * f[4] + c[5] * f[5];
-    int j = m.dof_jntid[d], t = m.jnt_type[j];
     float pas = -P[RG_PRM_DOF_DAMPING + d] * s.qvel[d];
-    if ((t == RG_JNT_HINGE || t == RG_JNT_SLIDE) && m.jnt_stiffness[j] != 0) { int qa = m.jnt_qposadr[j]; pas -= m.jnt_stiffness[j] * (s.qpos[qa] - m.qpos_spring[qa]); }
-    for (int q = m.dof_ten_adr[d]; q < m.dof_ten_adr[d + 1]; q++) { int tt = m.dof_ten[2 * q], sl = m.dof_ten[2 * q + 1]; pas += s.tenJ[4 * tt + sl] * s.tenfrc[tt]; }
+    if (dr0.z != 0) pas -= dr0.z * (s.qpos[__builtin_bit_cast(int, dr0.w)] - spring_ref);
+    for (int q = (w0 >> 8) & 255; q < ((w0 >> 16) & 255); q++) { int tt = m.dof_ten[2 * q], sl = m.dof_ten[2 * q + 1]; pas += s.tenJ[4 * tt + sl] * s.tenfrc[tt]; }
     s.qfrc_passive[d] = pas;
   }
   SYNC();
@@ -1441,7 +1442,8 @@ __device__ __forceinline__ void rg_pid(RgM m, RgLds& s, const float* P, float* s
 __device__ __forceinline__ void rg_smooth(RgM m, RgLds& s, const float* P) {
   PFOR(d, m.nv) {
     float f = 0;
-    for (int q = m.dof_act_adr[d]; q < m.dof_act_adr[d + 1]; q++) {
+    const int aw = __builtin_bit_cast(int, m.dof_rec[8 * d + 1]);
+    for (int q = aw & 255; q < ((aw >> 8) & 255); q++) {
       int u = m.dof_act[2 * q], sl = m.dof_act[2 * q + 1];
       f += m.actuator_gear[u] * (sl < 0 ? 1.0f : s.tenJ[4 * m.actuator_trnid[u] + sl]) * s.actfrc[u];
     }
@@ -1601,22 +1603,20 @@ __device__ __forceinline__ void rg_static_rows(RgM m, const RgLds& s, const floa
   for (int k = 0; k < RG_RSLOTS; k++) {
     int r = LANE + RG_WAVE * k;
     if (r >= ns) { R.D[k] = 0.f; R.aref[k] = 0.f; R.floss[k] = 0.f; R.desc[k] = 0; continue; }
-    int rr = r; float pos = 0, margin = 0, diag, floss = 0; const float *solref, *solimp; bool active = true, fric = false;
-    int dsc_dof = 0, dsc_ten = 31, dsc_neg = 0;
-    if (rr < m.nfric_dof) { int d = m.fric_dof[rr]; dsc_dof = m.d2c[d]; floss = P[RG_PRM_DOF_FRICTIONLOSS + d]; diag = P[RG_PRM_DOF_INVWEIGHT0 + d]; solref = m.dof_solref + 2 * d; solimp = m.dof_solimp + 5 * d; fric = true; }
-    else if ((rr -= m.nfric_dof) < m.nfric_ten) { int t = m.fric_ten[rr]; dsc_ten = t; floss = m.tendon_frictionloss[t]; diag = P[RG_PRM_TENDON_INVWEIGHT0 + t]; solref = m.tendon_solref_fri + 2 * t; solimp = m.tendon_solimp_fri + 5 * t; fric = true; }
-    else if ((rr -= m.nfric_ten) < 2 * m.nlim_jnt) {
-      int j = m.lim_jnt[rr >> 1]; float q = s.qpos[m.jnt_qposadr[j]];
-      dsc_dof = m.d2c[m.jnt_dofadr[j]]; dsc_neg = rr & 1;   // lower: J = +1, upper: J = -1
-      pos = (rr & 1) ? (P[RG_PRM_JNT_RANGE + 2 * j + 1] - q) : (q - P[RG_PRM_JNT_RANGE + 2 * j]);
-      margin = m.jnt_margin[j]; active = pos < margin; diag = P[RG_PRM_DOF_INVWEIGHT0 + m.jnt_dofadr[j]]; solref = m.jnt_solref + 2 * j; solimp = m.jnt_solimp + 5 * j;
-    } else {
-      rr -= 2 * m.nlim_jnt; int t = m.lim_ten[rr >> 1]; float L = s.tenlen[t];
-      dsc_ten = t; dsc_neg = rr & 1;
-      pos = (rr & 1) ? (P[RG_PRM_TENDON_RANGE + 2 * t + 1] - L) : (L - P[RG_PRM_TENDON_RANGE + 2 * t]);
-      margin = m.tendon_margin[t]; active = pos < margin; diag = P[RG_PRM_TENDON_INVWEIGHT0 + t]; solref = m.tendon_solref_lim + 2 * t; solimp = m.tendon_solimp_lim + 5 * t;
+    // everything static about the row in one 64-byte record (rg_api.hip: srow_rec)
+    const rgf4* S = (const rgf4*)m.srow_rec + 4 * r;
+    const rgf4 sa = S[0], sb = S[1], sc = S[2], sd = S[3];
+    const int w0 = __builtin_bit_cast(int, sa.x), kind = w0 >> 16, desc = w0 & 0xFFFF, src = __builtin_bit_cast(int, sa.y), ofl = __builtin_bit_cast(int, sa.w);
+    const bool fric = kind < 2;
+    const float diag = P[__builtin_bit_cast(int, sa.z)];
+    const float floss = kind == 0 ? P[ofl] : sb.x;
+    const float solref[2] = {sb.w, sc.x}, solimp[5] = {sc.y, sc.z, sc.w, sd.x, sd.y};
+    float pos = 0, margin = 0; bool active = true;
+    if (!fric) {
+      const float x = kind == 2 ? s.qpos[src] : s.tenlen[src], bound = P[__builtin_bit_cast(int, sb.y)];
+      pos = (desc >> 11) & 1 ? bound - x : x - bound;   // lower limit: J = +1, upper: J = -1
+      margin = sb.z; active = pos < margin;
     }
-    const int desc = (dsc_dof & 63) | (dsc_ten << 6) | (dsc_neg << 11);
     R.desc[k] = desc;
     float D = 0, aref = 0;
     if (active) {

@@ -141,6 +141,9 @@ struct RgModelDev {
   const float *wrap_prm, *tendon_range, *tendon_margin, *tendon_stiffness, *tendon_damping, *tendon_frictionloss,
       *tendon_lengthspring, *tendon_solref_lim, *tendon_solimp_lim, *tendon_solref_fri, *tendon_solimp_fri, *tendon_invweight0;
   const int *dof_ten_adr, *dof_ten, *dof_act_adr, *dof_act;
+  const float* srow_rec;        // [static rows][16] friction-loss / limit rows: Jacobian descriptor, what they read and their solver parameters (rg_api.hip)
+  const float* dof_rec;         // [nv][8] per dof: body, tendon / actuator entry ranges, joint stiffness, qposadr, spring reference (rg_api.hip)
+  const int* M_ijb;             // [nM] dof i | dof j << 8 | body of dof i << 16
   // actuators
   const int *actuator_trntype, *actuator_trnid, *actuator_ctrllimited, *actuator_forcelimited, *actuator_biastype;
   const float *actuator_gear, *actuator_ctrlrange, *actuator_forcerange, *actuator_gainprm, *actuator_biasprm;
