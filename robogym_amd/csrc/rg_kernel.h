@@ -2117,13 +2117,19 @@ template <bool SENSORS> __device__ __forceinline__ int rg_solve(RgM m, RgLds& s,
 #endif
       const int nnz = s.c_nnz[c], nb = nbasis(s.c_dim[c]);
       const float* Bc = s.c_pool + s.c_off[c];
-      for (int a = LANE >> 4, b = LANE & 15; a < nnz; a += 4) {   // nnz <= RG_W < 16: 4 rows of the block per pass
-        if (b >= nnz) continue;
+      // the block's lower triangle, one (a >= b) pair per lane: nnz (nnz + 1) / 2 <= 105 entries, i.e. one or two trips per
+      // contact (both factorisations read the lower triangle only)
+      const int np = (nnz * (nnz + 1)) >> 1;
+      for (int q = LANE; q < np; q += RG_WAVE) {
+        int a = (int)((sqrtf(8.f * (float)q + 1.f) - 1.f) * 0.5f);
+        if ((((a + 1) * (a + 2)) >> 1) <= q) a++;
+        if (((a * (a + 1)) >> 1) > q) a--;
+        const int b = q - ((a * (a + 1)) >> 1);
         float na = Bc[a], nbv = Bc[b], v = cn * na * nbv;
         for (int k = 0; k + 1 < nb; k++) { float ta = Bc[(k + 1) * nnz + a], tb = Bc[(k + 1) * nnz + b]; v += ck[k] * (na * tb + ta * nbv) + cd[k] * ta * tb; }
-        int ia = s.c_idx[c * RG_W + a], ib = s.c_idx[c * RG_W + b];
-        if (!tree) atomicAdd(s.H + ia * hs + ib, v);
-        else if (ia >= ib) { int blk = s.cblk[ia]; atomicAdd(s.H + (blk & 0xFFFF) + ib - ((blk >> 16) & 255), v); }
+        const int ia = s.c_idx[c * RG_W + a], ib = s.c_idx[c * RG_W + b], hi = ia > ib ? ia : ib, lo = ia > ib ? ib : ia;
+        if (!tree) atomicAdd(s.H + hi * hs + lo, v);
+        else { int blk = s.cblk[hi]; atomicAdd(s.H + (blk & 0xFFFF) + lo - ((blk >> 16) & 255), v); }
       }
     }
     SYNC();
