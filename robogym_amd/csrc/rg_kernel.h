@@ -1301,7 +1301,7 @@ __device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, const flo
   if (ncand > 8) rg_narrow_phase1<4>(c, ncand); else if (ncand > 4) rg_narrow_phase1<8>(c, ncand); else rg_narrow_phase1<16>(c, ncand);
   int ncand2 = s.ncand2;
   if (prof && LANE == 0) { prof[16] += (float)(rg_clock() - tb0); prof[17] += ncand; prof[18] += ncand2; }
-  if (ncand2 > 4) rg_narrow_phase2<8>(c, ncand2); else rg_narrow_phase2<16>(c, ncand2);
+  rg_narrow_phase2<4>(c, ncand2);   // quads whatever the queue length: a support's first four candidates are one load round, 16 queries per trip (measured against 8- and 16-lane groups for short queues: quads win everywhere, profiles/r02_ab.txt)   // (quads: a support's first four candidates are one load round, and a crowded queue gets through in half the trips)
   if (prof && LANE == 0) prof[19] += (float)(rg_clock() - tb0);
   if (!(RG_L(c).flags & 16) && __ballot(bbany) != 0) rg_narrow_boxbox(c, ncand);
   // plane pairs (rare: something near the floor), whole wave cooperating, one pair at a time.  Which candidates are plane
@@ -1508,7 +1508,7 @@ __device__ __forceinline__ void srow_hess(RgM m, RgLds& s, int desc, float D) {
   int t = (desc >> 6) & 31;
   if (t == 31) { int d = desc & 63; atomicAdd(s.H + d * m.hs + d, D); return; }
   for (int a = 0; a < 4; a++) { int da = s.ten_cdof[4 * t + a]; if (da == 255) continue;
-    for (int b = 0; b < 4; b++) { int db = s.ten_cdof[4 * t + b]; if (db == 255) continue; atomicAdd(s.H + da * m.hs + db, D * s.tenJ[4 * t + a] * s.tenJ[4 * t + b]); } }
+    for (int b = 0; b < 4; b++) { int db = s.ten_cdof[4 * t + b]; if (db == 255 || db > da) continue; atomicAdd(s.H + da * m.hs + db, D * s.tenJ[4 * t + a] * s.tenJ[4 * t + b]); } }   // (lower triangle: what the factorisation reads)
 }
 // the same in the per-tree block layout, lower triangle only (Hessian with the pattern of M)
 __device__ __forceinline__ void srow_hess_tree(RgLds& s, int desc, float D) {
@@ -2075,14 +2075,14 @@ template <bool SENSORS> __device__ __forceinline__ int rg_solve(RgM m, RgLds& s,
       for (int k = 0; k < RG_RSLOTS; k++) { int r = LANE + RG_WAVE * k; if (r < ns && RR.D[k] > 0 && RR.quad[k]) srow_hess_tree(s, RR.desc[k], RR.D[k]); }
     } else {
     // H = M + J' D J over the quadratic rows (LDS atomics from one wave: in-order, deterministic)
-    {  // H <- M: zero the compact nvc x hs matrix, then scatter the tree-sparse entries (both triangles)
+    {  // H <- M: zero the compact nvc x hs matrix, then scatter the tree-sparse entries (lower triangle: what the factorisation reads)
       rgf4 z; z.x = z.y = z.z = z.w = 0.f; rgf4* H4 = (rgf4*)s.H;
       for (int w = LANE; w < nvc * (hs >> 2); w += RG_WAVE) H4[w] = z;
       SYNC();
 #pragma unroll
       for (int k = 0; k < RG_MSLOTS; k++) {
         int w = ME.w[k];
-        if (w >> 16) { int ci = w & 255, cj = (w >> 8) & 255; float mv = s.Msp[LANE + RG_WAVE * k]; s.H[ci * hs + cj] = mv; s.H[cj * hs + ci] = mv; }
+        if (w >> 16) { int ci = w & 255, cj = (w >> 8) & 255; s.H[(ci > cj ? ci : cj) * hs + (ci > cj ? cj : ci)] = s.Msp[LANE + RG_WAVE * k]; }
       }
     }
     SYNC();
