@@ -204,12 +204,12 @@ template <int G> __device__ __forceinline__ int grp_min_i(int v) { for (int o = 
 #else
 template <int G> __device__ __forceinline__ float grp_max(float v) {
   if (G == 16) { v = fmaxf(v, dpp_f<0x128, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x124, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x122, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x121, 0xf>(v, v)); }
-  else { v = fmaxf(v, dpp_f<0xB1, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x4E, 0xf>(v, v)); if (G == 8) v = fmaxf(v, dpp_f<0x141, 0xf>(v, v)); }
+  else { v = fmaxf(v, dpp_f<0xB1, 0xf>(v, v)); if (G >= 4) v = fmaxf(v, dpp_f<0x4E, 0xf>(v, v)); if (G == 8) v = fmaxf(v, dpp_f<0x141, 0xf>(v, v)); }
   return v;
 }
 template <int G> __device__ __forceinline__ int grp_min_i(int v) {
   if (G == 16) { v = imin(v, dpp_i<0x128, 0xf>(v, v)); v = imin(v, dpp_i<0x124, 0xf>(v, v)); v = imin(v, dpp_i<0x122, 0xf>(v, v)); v = imin(v, dpp_i<0x121, 0xf>(v, v)); }
-  else { v = imin(v, dpp_i<0xB1, 0xf>(v, v)); v = imin(v, dpp_i<0x4E, 0xf>(v, v)); if (G == 8) v = imin(v, dpp_i<0x141, 0xf>(v, v)); }
+  else { v = imin(v, dpp_i<0xB1, 0xf>(v, v)); if (G >= 4) v = imin(v, dpp_i<0x4E, 0xf>(v, v)); if (G == 8) v = imin(v, dpp_i<0x141, 0xf>(v, v)); }
   return v;
 }
 #endif
@@ -687,9 +687,17 @@ __device__ __forceinline__ int dir_cell(v3 ld) {
 template <int G> __device__ __forceinline__ void scan_cell(const int* celladr, const rgf4* cellblk, const rgf4* cellovf, v3 ld, float& bv, int& bi, v3& bp) {
   int cell = dir_cell(ld), l = LANE & (G - 1);
   int e = celladr[cell];
-  rgf4 a = cellblk[4 * cell + (l & 3)];   // the cell's first four candidates sit at a computable address: one load latency
-  float da = vdot(ld, a);
-  if (da > bv) { bv = da; bi = __builtin_bit_cast(int, a.w); bp = mk3(a.x, a.y, a.z); }
+  if (G >= 4) {
+    rgf4 a = cellblk[4 * cell + (l & 3)];   // the cell's first four candidates sit at a computable address: one load latency
+    float da = vdot(ld, a);
+    if (da > bv) { bv = da; bi = __builtin_bit_cast(int, a.w); bp = mk3(a.x, a.y, a.z); }
+  } else {   // pairs of lanes: two of the four each
+    rgf4 a = cellblk[4 * cell + 2 * (l & 1)], a2 = cellblk[4 * cell + 2 * (l & 1) + 1];
+    float da = vdot(ld, a), da2 = vdot(ld, a2);
+    if (da > bv) { bv = da; bi = __builtin_bit_cast(int, a.w); bp = mk3(a.x, a.y, a.z); }
+    int i2 = __builtin_bit_cast(int, a2.w);
+    if (da2 > bv || (da2 == bv && i2 < bi)) { bv = da2; bi = i2; bp = mk3(a2.x, a2.y, a2.z); }
+  }
   int cnt = (e & 255) - 4, last = cnt - 1;
   if (cnt > 0) {
     const rgf4* rec = cellovf + (e >> 8);
@@ -1217,7 +1225,7 @@ __device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, const flo
   // then oriented boxes; both conservative, both refresh the bound when they separate the pair.
   int nround = (m.npair + RG_WAVE - 1) / RG_WAVE;
   float hb = 1.5f * P[RG_PRM_TIMESTEP];
-  int nt = 0; bool bbany = false;   // (bbany: this lane queued a pair of two boxes — those have their own narrowphase routine)
+  int nt = 0; bool bbany = false, plany = false;   // (bbany: this lane queued a pair of two boxes — those have their own narrowphase routine)
   int gg_next[4]; float lb_next[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) { int p = k * RG_WAVE + LANE, pc = p < m.npair ? p : m.npair - 1; gg_next[k] = m.pair_gg[pc]; lb_next[k] = pairlb ? pairlb[pc] : 0.f; }
@@ -1247,7 +1255,7 @@ __device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, const flo
     SYNC();
     for (int i0 = 0; i0 < nt; i0 += RG_WAVE) {
       int i = i0 + LANE, q = 0;
-      bool hit = false, isbb = false;
+      bool hit = false, isbb = false, ispl = false;
       if (i < nt) {
         q = s.tlist[i];
         const rgf4* R = (const rgf4*)m.pair_rec + (RG_PAIRREC / 4) * q;
@@ -1257,7 +1265,7 @@ __device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, const flo
         const float sc1 = (hdr & RG_PAIR_SCALED1) ? gscale : 1.f, sc2 = (hdr & RG_PAIR_SCALED2) ? gscale : 1.f;
         r3.z *= sc1; r3.w *= sc2;
         v3 p1 = ld3(s.gpos + 3 * g1), p2 = ld3(s.gpos + 3 * g2), dif = p2 - p1;
-        isbb = ((hdr >> 20) & 255) == (RG_GEOM_BOX | (RG_GEOM_BOX << 4));
+        isbb = ((hdr >> 20) & 255) == (RG_GEOM_BOX | (RG_GEOM_BOX << 4)); ispl = ((hdr >> 20) & 15) == RG_GEOM_PLANE;
         if (((hdr >> 20) & 15) == RG_GEOM_PLANE) {
           float d = dot(dif, qrot(ldq(s.gquat + 4 * g1), mk3(0, 0, 1))) - (r3.w + margin);
           hit = d <= 0; newlb = fmaxf(d, 0.f);
@@ -1274,7 +1282,7 @@ __device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, const flo
         if (pairlb) pairlb[q] = fmaxf(newlb - 1e-6f, 0.f);
       }
       unsigned long long bal = __ballot(hit);
-      bbany = bbany || (hit && isbb);
+      bbany = bbany || (hit && isbb); plany = plany || (hit && ispl);
       int base = s.ncand;
       SYNC();
       if (hit) {
@@ -1298,7 +1306,7 @@ __device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, const flo
   int ncand = s.ncand;
   if (LANE == 0) s.ncand2 = 0;
   SYNC();
-  if (ncand > 8) rg_narrow_phase1<4>(c, ncand); else if (ncand > 4) rg_narrow_phase1<8>(c, ncand); else rg_narrow_phase1<16>(c, ncand);
+  if (ncand > 16) rg_narrow_phase1<2>(c, ncand); else rg_narrow_phase1<4>(c, ncand);   // pairs of lanes once the queue is long: 32 one-support tests per trip
   int ncand2 = s.ncand2;
   if (prof && LANE == 0) { prof[16] += (float)(rg_clock() - tb0); prof[17] += ncand; prof[18] += ncand2; }
   rg_narrow_phase2<4>(c, ncand2);   // quads whatever the queue length: a support's first four candidates are one load round, 16 queries per trip (measured against 8- and 16-lane groups for short queues: quads win everywhere, profiles/r02_ab.txt)   // (quads: a support's first four candidates are one load round, and a crowded queue gets through in half the trips)
@@ -1306,6 +1314,7 @@ __device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, const flo
   if (!(RG_L(c).flags & 16) && __ballot(bbany) != 0) rg_narrow_boxbox(c, ncand);
   // plane pairs (rare: something near the floor), whole wave cooperating, one pair at a time.  Which candidates are plane
   // pairs is found lane-parallel from the pair headers (a serial scan of ~25 candidates cost two dependent loads each).
+  if (__ballot(plany) != 0)   // (no plane pair among the candidates: nothing to look for)
   for (int cbase = 0; cbase < ncand; cbase += RG_WAVE) {
   bool is_plane = false;
   if (cbase + LANE < ncand) is_plane = ((__builtin_bit_cast(int, m.pair_rec[RG_PAIRREC * s.cand[cbase + LANE]]) >> 20) & 15) == RG_GEOM_PLANE;

@@ -22,15 +22,15 @@ void* emul_lds() { return g_lds; }
 
 void emul_yield() { swapcontext(&g_fiber[g_cur], &g_sched); }
 
-// barrier state per group size (quads: 16 groups, 8-lane half rows: 8, 16-lane rows: 4, wave: 1)
-static int g_arrived[4][16], g_gen[4][16];
+// barrier state per group size (quads: 16 groups, 8-lane half rows: 8, 16-lane rows: 4, wave: 1, lane pairs: 32)
+static int g_arrived[5][32], g_gen[5][32];
 static int g_wsize[64];
 static void* g_hist[64][16]; static long g_nwave[64];   // last wave-wide collectives of each lane + how many it has executed
 static void* g_where[64];  // call site of the collective each lane waits in (deadlock report)
 static bool g_restart;  // a wave barrier was released: resume the sweep at lane 0 (hardware executes a wave's lanes in lane order)
 static int live_in_group(int gsize, int grp) { int n = 0; for (int l = grp * gsize; l < (grp + 1) * gsize; l++) n += !g_done[l]; return n; }
 void emul_barrier(int gsize) {
-  int k = gsize == 64 ? 3 : (gsize == 16 ? 2 : (gsize == 8 ? 1 : 0)), gs = gsize == 64 ? 64 : (gsize == 16 ? 16 : (gsize == 8 ? 8 : 4)), grp = g_cur / gs;
+  int k = gsize == 64 ? 3 : (gsize == 16 ? 2 : (gsize == 8 ? 1 : (gsize == 2 ? 4 : 0))), gs = gsize == 64 ? 64 : (gsize == 16 ? 16 : (gsize == 8 ? 8 : (gsize == 2 ? 2 : 4))), grp = g_cur / gs;
   int gen = g_gen[k][grp];
   g_where[g_cur] = __builtin_return_address(0); g_wsize[g_cur] = gs;
   if (gs == 64) { g_hist[g_cur][g_nwave[g_cur] & 15] = g_where[g_cur]; g_nwave[g_cur]++; }
@@ -66,7 +66,7 @@ void emul_launch(int nblocks, size_t lds_bytes, emul_kernel_fn fn, void* arg) {
       makecontext(&g_fiber[l], fiber_main, 0);
       g_done[l] = 0;
     }
-    for (int k = 0; k < 4; k++) for (int g = 0; g < 16; g++) g_arrived[k][g] = 0;
+    for (int k = 0; k < 5; k++) for (int g = 0; g < 32; g++) g_arrived[k][g] = 0;
     for (int l = 0; l < 64; l++) g_nwave[l] = 0;
     int alive = 64;
     long idle_sweeps = 0;

@@ -37,8 +37,8 @@ template <class T> static inline T emul_exchange(T v, int src, int gsize) {
   emul_barrier(gsize);
   return r;
 }
-// xor shuffles with a mask below 16 (8, 4) stay inside a 16-lane row (8-lane half row, quad): only that group has to be convergent
-template <class T> static inline T __shfl_xor(T v, int mask) { return emul_exchange(v, (int)threadIdx.x ^ mask, mask < 4 ? 4 : (mask < 8 ? 8 : (mask < 16 ? 16 : 64))); }
+// xor shuffles with a mask below 16 (8, 4, 2) stay inside a 16-lane row (8-lane half row, quad, lane pair): only that group has to be convergent
+template <class T> static inline T __shfl_xor(T v, int mask) { return emul_exchange(v, (int)threadIdx.x ^ mask, mask < 2 ? 2 : (mask < 4 ? 4 : (mask < 8 ? 8 : (mask < 16 ? 16 : 64)))); }
 template <class T> static inline T __shfl(T v, int src) { return emul_exchange(v, src, 64); }
 static inline unsigned long long __ballot(int pred) {
   emul_xchg[threadIdx.x] = pred ? 1 : 0;
