@@ -1761,7 +1761,9 @@ __device__ __forceinline__ void rg_M_mul(RgM m, RgLds& s, const RgMEnt& E, const
 // (pivot rows are broadcast reads), the 4x4 diagonal block is factored redundantly in every lane from ten
 // v_readlane values, and each lane solves its four new entries against it.  n/4 LDS round trips, not n.
 __device__ __forceinline__ float dot4(rgf4 a, rgf4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
-__device__ __forceinline__ void rg_chol(RgM m, RgLds& s) {
+// RHS: row n of the work matrix holds a right-hand side g (columns n.. zero); lane n carries it through the same steps as the
+// matrix rows, which is the forward substitution L y = g: y is left in row n (rg_chol_solve_bwd finishes the solve)
+template <bool RHS> __device__ __forceinline__ void rg_chol(RgM m, RgLds& s) {
   int n = m.nvc, hs4 = m.hs >> 2, i = LANE;
   rgf4* H4 = (rgf4*)s.H;
   bool bad = false;
@@ -1769,7 +1771,7 @@ __device__ __forceinline__ void rg_chol(RgM m, RgLds& s) {
     int jb = j0 >> 2, nb = n - j0;  // nb >= 4: full block
     int r1 = j0 + 1 < n ? j0 + 1 : n - 1, r2 = j0 + 2 < n ? j0 + 2 : n - 1, r3 = j0 + 3 < n ? j0 + 3 : n - 1;
     float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    bool mine = i >= j0 && i < n;
+    bool mine = i >= j0 && (RHS ? i <= n : i < n);
     if (mine) {
       rgf4 own = H4[i * hs4 + jb];
       a0 = own.x; a1 = own.y; a2 = own.z; a3 = own.w;
@@ -1798,6 +1800,7 @@ __device__ __forceinline__ void rg_chol(RgM m, RgLds& s) {
     if (mine) {
       int r = i - j0;
       float x0 = a0 * i00, x1 = (a1 - x0 * l10) * i11, x2 = (a2 - x0 * l20 - x1 * l21) * i22, x3 = (a3 - x0 * l30 - x1 * l31 - x2 * l32) * i33;
+      if (RHS && i == n) r = 4;   // (the right-hand-side row is never a pivot row)
       if (r == 0) { x0 = l00; x1 = 0; x2 = 0; x3 = 0; }
       else if (r == 1) { x1 = l11; x2 = 0; x3 = 0; }
       else if (r == 2) { x2 = l22; x3 = 0; }
@@ -1859,6 +1862,23 @@ __device__ __forceinline__ void rg_chol_solve(RgM m, RgLds& s, float* x) {
     if (j0 + 8 < n) tri_fetch(s, n, hs, j0 + 8, i, false, A);
     tri_fwd(B, n, j0 + 4, i, xi);
   }
+  int jl = ((n - 1) >> 2) << 2;
+  tri_fetch(s, n, hs, jl, i, true, A);
+  for (int j0 = jl; j0 >= 0; j0 -= 8) {  // backward: L' x = y
+    if (j0 >= 4) tri_fetch(s, n, hs, j0 - 4, i, true, B);
+    tri_bwd(A, n, j0, i, xi);
+    if (j0 < 4) break;
+    if (j0 >= 8) tri_fetch(s, n, hs, j0 - 8, i, true, A);
+    tri_bwd(B, n, j0 - 4, i, xi);
+  }
+  if (i < n) x[i] = xi;
+  SYNC();
+}
+// the second half alone: y = L^-1 g was produced by rg_chol<true> in row n of the work matrix
+__device__ __forceinline__ void rg_chol_solve_bwd(RgM m, RgLds& s, float* x) {
+  int n = m.nvc, hs = m.hs, i = LANE;
+  float xi = i < n ? s.H[n * hs + i] : 0.f;
+  TriOps A, B;
   int jl = ((n - 1) >> 2) << 2;
   tri_fetch(s, n, hs, jl, i, true, A);
   for (int j0 = jl; j0 >= 0; j0 -= 8) {  // backward: L' x = y
@@ -2060,6 +2080,7 @@ template <bool SENSORS> __device__ __forceinline__ int rg_solve(RgM m, RgLds& s,
   // advanced by alpha * (M s, J s) after the line search instead of being recomputed).
   // The factor of H is kept while the set of quadratic rows stays the same (H depends on nothing else).
   float cost = 0, oldcost = 0; int iters = 0; bool have_factor = false;
+  bool fresh_rhs = false; const bool rhs_row = (nvc + 1) * hs <= RG_HWORDS;   // (room for the right-hand-side row under the work matrix)
   for (int iter = 0;; iter++) {
     float gauss = 0; PFOR(i, nvc) gauss += 0.5f * (s.Ma[i] - s.fs[i]) * (s.a[i] - s.as[i]);
     gauss = wave_sum(gauss);
@@ -2141,12 +2162,16 @@ template <bool SENSORS> __device__ __forceinline__ int rg_solve(RgM m, RgLds& s,
         else { int blk = s.cblk[hi]; atomicAdd(s.H + (blk & 0xFFFF) + lo - ((blk >> 16) & 255), v); }
       }
     }
+    // dense path: the gradient rides through the factorisation as one more row (row nvc), so the forward substitution costs nothing
+    if (!tree && rhs_row) { if (LANE < hs) s.H[nvc * hs + LANE] = LANE < nvc ? s.search[LANE] : 0.f; fresh_rhs = true; }
     SYNC();
     PROFS(13);
-    if (tree) { LtdlDesc LT; rg_ltdl_load(m.ltdl_tri_c, m.ltdl_pair_c, m.n_tri_rounds_c, m.n_pair_rounds_c, LT); rg_ltdl_factor(s, LT); } else rg_chol(m, s);
+    if (tree) { LtdlDesc LT; rg_ltdl_load(m.ltdl_tri_c, m.ltdl_pair_c, m.n_tri_rounds_c, m.n_pair_rounds_c, LT); rg_ltdl_factor(s, LT); } else if (rhs_row) rg_chol<true>(m, s); else rg_chol<false>(m, s);
     }
     PROFS(14);
-    if (tree) { LtdlDesc LT; rg_ltdl_load((const int*)0, m.ltdl_pair_c, 0, m.n_pair_rounds_c, LT); rg_ltdl_solve(s, LT, s.search, LANE, LANE < nvc, akk_own); } else rg_chol_solve(m, s, s.search);
+    if (tree) { LtdlDesc LT; rg_ltdl_load((const int*)0, m.ltdl_pair_c, 0, m.n_pair_rounds_c, LT); rg_ltdl_solve(s, LT, s.search, LANE, LANE < nvc, akk_own); }
+    else if (fresh_rhs) rg_chol_solve_bwd(m, s, s.search); else rg_chol_solve(m, s, s.search);
+    fresh_rhs = false;
     PROFS(15);
     // exact line search along `search`
     rg_M_mul(m, s, ME, s.search, s.Mv);

@@ -16,7 +16,7 @@
 #define RG_MAXFRIC 32   // friction-loss rows (dofs + tendons)
 #define RG_MAXSROW 96   // static row slots: friction rows + 2 per limited joint / tendon
 #define RG_MAXNVC 32    // dofs in constrained kinematic trees (the Newton space)
-#define RG_HWORDS 1088  // solver work matrix: max(per-tree inertia blocks, nvc x hs)
+#define RG_HWORDS 1124  // solver work matrix: max(per-tree inertia blocks, (nvc + 1) x hs: the extra row carries the right-hand side through the dense factorisation)
 #define RG_MAXNM 160    // non-zeros of the tree-sparse inertia matrix: (dof, ancestor) pairs
 #define RG_CELLN 8      // direction cells: cube map, RG_CELLN x RG_CELLN per face (kernel_tables.py CELL_N)
 #define RG_NCELL (6 * RG_CELLN * RG_CELLN)
