@@ -92,7 +92,7 @@ def test_load_model_from_xml_matches_oracle(emul_lib, oracle_lib):
     assert model.joint_names == ("lift", "swing", "free") and model.nq == 9 and model.nv == 8 and abs(model.opt.timestep - 0.004) < 1e-12
     sim = mujoco_py.MjSim(model, nsubsteps=5, lib=emul_lib)
     ora = _oracle(model._compiled)
-    for k in range(40):
+    for k in range(26):
         sim.step()
         for _ in range(5):
             ora.step()
