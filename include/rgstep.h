@@ -126,6 +126,8 @@ int rg_batch_copy_rows(rg_batch* b, int field, const void* src_dev, const int* m
  *                bit5: evaluate data.sensordata (touch sensors, mj_sensorAcc) into the xdata row: the last of the state-less
  *                      forwards then runs in full (collision and constraint solve at the final state, as mj_forward does),
  *                      about one more substep of work.  Needs xdata_dev and nforward_ticks >= 1.
+ *                bit6: dense Newton step with the forward substitution as its own pass instead of inside the
+ *                      factorisation (same result to rounding; test hook)
  *   stream       hipStream_t (NULL = default stream).  Asynchronous. */
 int rg_batch_step(rg_batch* b, const float* action_dev, const float* goal_quat_dev, float* obs_dev, float* goal_dist_dev,
                   const int* active_dev, int nsubsteps, int nforward_ticks, int flags, void* stream);

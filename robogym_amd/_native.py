@@ -120,6 +120,7 @@ def check(L, rc, what):
 
 RG_FLAG_MPR_PLANE_DEPTH = 16   # rg_step_args.flags bit 4 (include/rgstep.h)
 RG_FLAG_SENSORS = 32           # bit 5: evaluate data.sensordata (the last state-less forward runs in full)
+RG_FLAG_SEPARATE_FORWARD_SUBSTITUTION = 64   # bit 6: test hook (include/rgstep.h)
 
 PRM_NAMES = ["row", "gravity", "timestep", "dof_damping", "dof_armature", "dof_frictionloss", "dof_invweight0", "body_mass", "body_inertia", "body_invweight0",
              "jnt_range", "tendon_range", "tendon_invweight0", "actuator_gainprm", "actuator_ctrlrange", "actuator_forcerange", "geom_friction", "xfrc_applied", "site_pos", "geom_scale"]

@@ -2080,7 +2080,7 @@ template <bool SENSORS> __device__ __forceinline__ int rg_solve(RgM m, RgLds& s,
   // advanced by alpha * (M s, J s) after the line search instead of being recomputed).
   // The factor of H is kept while the set of quadratic rows stays the same (H depends on nothing else).
   float cost = 0, oldcost = 0; int iters = 0; bool have_factor = false;
-  bool fresh_rhs = false; const bool rhs_row = (nvc + 1) * hs <= RG_HWORDS;   // (room for the right-hand-side row under the work matrix)
+  bool fresh_rhs = false; const bool rhs_row = (nvc + 1) * hs <= RG_HWORDS && !(flags & 64);   // (room for the right-hand-side row under the work matrix; flag bit 6: test hook, the separate forward substitution)
   for (int iter = 0;; iter++) {
     float gauss = 0; PFOR(i, nvc) gauss += 0.5f * (s.Ma[i] - s.fs[i]) * (s.a[i] - s.as[i]);
     gauss = wave_sum(gauss);

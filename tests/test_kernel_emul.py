@@ -104,6 +104,30 @@ def test_pair_distance_cache_is_exact(locked_model, emul_lib):
     assert int(sims[0].status.max()) == 0
 
 
+def _forward_substitution_paths(make):
+    """The dense Newton step carries the gradient through the Cholesky factorisation as one more row (the forward substitution
+    for free); flag bit 6 runs the substitution as its own pass instead: same solution to rounding."""
+    sims = [make() for _ in range(2)]
+    rng = np.random.RandomState(13)
+    worst = 0.0
+    for k in range(8):
+        a = torch.tensor(rng.uniform(-1, 1, (sims[0].batch_size, 20)), dtype=torch.float32, device=sims[0].qpos.device)
+        for sim, fl in zip(sims, (0, 64)):
+            sim.env_step(action=a, nforward_ticks=3, flags=fl)
+        worst = max(worst, float((sims[0].qpos - sims[1].qpos).abs().max()))
+        sims[1].view(0)[:] = sims[0].view(0); sims[1].view(1)[:] = sims[0].view(1); sims[1].touch_qpos()     # (keep the two on one trajectory: the comparison is per step)
+    assert worst < 5e-6 and int(sims[0].status.max()) == 0 and int(sims[1].status.max()) == 0, worst
+
+
+def test_forward_substitution_inside_the_factorisation_emul(locked_model, emul_lib):
+    _forward_substitution_paths(lambda: LockedSimulation(locked_model, 1, lib=emul_lib, n_substeps=3))
+
+
+@pytest.mark.gpu
+def test_forward_substitution_inside_the_factorisation_gpu(locked_model):
+    _forward_substitution_paths(lambda: LockedSimulation(locked_model, 64, device="cuda:0"))
+
+
 def test_pipelined_reset_state_machine(locked_model, emul_lib):
     """finished episodes are re-initialised inside the following step launches.  Short
     recipe (2 zero-action steps, perturbation, 1 random-action step), goals time out after 3 steps:
