@@ -2,6 +2,7 @@
 
     python bench.py --gpus 1 --steps K --warmup W          (single GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N ...                           (no launcher: re-executes itself under torch.distributed.run with N ranks)
 
 Workload: BASELINE.json configs[1] — dactyl/locked (Shadow hand + locked cube, nv=36), batch 8192 per
 GPU (weak scaling), synthetic iid U(-1,1)^20 relative actions, 1 env-step = action map + 10 mj_step
@@ -41,12 +42,29 @@ def algorithmic_bytes_per_env_step(m, ncon, nefc, iters, nsub, obs_dim):
     return nsub * b_sub + 4.0 * (nu + obs_dim), b_sub
 
 
-def cpu_baseline(seconds=12.0):
-    """The CPU oracle (double-precision C restatement) stepping the same env on EVERY host core, one env per
-    process; kind 'port'.  oracle/cpu_baseline.py."""
+def cpu_baseline(seconds=3.0):
+    """The CPU oracle (double-precision C restatement, -O3 -march=native) stepping the same env, one env per C thread:
+    1-thread rate, a ladder of thread counts up to the host's affinity, the best aggregate; kind 'port'.
+    Also the oracle's own mean Newton iterations on the bench's action distribution.  oracle/cpu_baseline.py."""
     from oracle import cpu_baseline as cb
 
-    return cb.run(seconds)
+    out = cb.run(seconds)
+    out["oracle_counters"] = cb.oracle_newton_iterations()
+    return out
+
+
+def relaunch_with_ranks(n):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start N ranks of this very command under
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) and return its exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def kernel_source_hash():
@@ -72,9 +90,13 @@ def main():
     ap.add_argument("--sort-dispatch", type=int, default=1, help="dispatch the envs longest-expected-first (previous step's cycles)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_with_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, world))
     # RG_BENCH_FORCE_DIST=1: take the distributed branch (process group, barriers, all-gather, max-reduce) even with one rank, so the
     # RCCL code path can be executed on a 1-GPU box: torchrun --nproc-per-node 1 bench.py --gpus 1
     distributed = world > 1 or os.environ.get("RG_BENCH_FORCE_DIST") == "1"
@@ -95,6 +117,7 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     from robogym_amd.envs.dactyl.locked import LockedEnvConstants, make_simple_env
 
@@ -191,6 +214,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "dactyl/locked (Shadow hand + locked cube, nv=36), batch %d per GPU, iid U(-1,1) relative actions, 10 substeps x 0.008 s" % B,
                        "batch_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d (envs sharded, RCCL all-gather of obs rows)" % world,
+                       "ranks": (dist.get_world_size() if distributed else 1), "collective_backend": (dist.get_backend() if distributed else None),
                        "mean_ncon": float(ncon), "mean_nefc": float(nefc), "mean_newton_iters": float(iters), "status_bits": status, "status_bits_before_timed_region": status_before,
                        "cube_on_palm_fraction": {"start_of_timed_region": on_palm_start, "end_of_timed_region": on_palm_end},
                        "pipelined_reset": bool(args.pipelined_reset), "sort_dispatch": bool(args.sort_dispatch),

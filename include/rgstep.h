@@ -219,6 +219,13 @@ typedef struct rg_post_args {
 } rg_post_args;
 int rg_env_post_step(rg_batch* b, const rg_post_args* args, void* stream);
 int rg_post_args_size(void);   /* sizeof(rg_post_args) as compiled: a binding checks its own struct against it */
+/* mj_setConst for the envs of `mask_dev` (int [B] device pointer, NULL: all) -- replaces `MjSim.set_constants()` =
+ * `mujoco_simulation.set_constants()`, which the reference calls in every `_reset` after the randomizers have written
+ * the model (/root/reference/robogym/envs/dactyl/common/cube_env.py:346-349,
+ * /root/reference/robogym/mujoco/simulation_interface.py:199-201): recomputes dof_invweight0 / body_invweight0 /
+ * tendon_invweight0 in each env's parameter row (RG_F_ENVPRM) from that row's body_mass / body_inertia / dof_armature /
+ * site_pos at qpos0.  Asynchronous on `stream`; needs rg_batch_enable_env_params. */
+int rg_batch_set_constants(rg_batch* b, const int* mask_dev, void* stream);
 /* Collision unit-test hook (no reference counterpart; mjc_Convex is internal to MuJoCo): runs the
  * kinematics of every env's stored qpos and one MPR penetration query between geoms g1, g2 inflated
  * by margin/2 each.  out_dev float [B][8] = hit, depth, direction3 (g1 -> g2), position3. */

@@ -1,13 +1,19 @@
-"""cpu_baseline leg of bench.py: the CPU oracle (double-precision C restatement of mj_step, one env per process) stepping
-dactyl/locked env.steps on every host core.  TEST INFRASTRUCTURE (oracle/): timed beside the HIP path, never part of it.
+"""cpu_baseline leg of bench.py: the CPU oracle (double-precision C restatement of mj_step) stepping dactyl/locked
+env.steps on the host cores.  TEST INFRASTRUCTURE (oracle/): timed beside the HIP path, never part of it.
 
-SURVEY.md §8(d): "one env per thread, N = all host cores, state N"; kind "port" (a CPU restatement, not mujoco-py: the
-reference's own physics is a closed binary that is absent here).
+SURVEY.md §8(d) / BASELINE.md §3: "one env per thread, -O3 -march=native, N = all host cores, state N"; kind "port"
+(a CPU restatement, not mujoco-py: the reference's own physics is a closed binary that is absent here).
 
-    python -m oracle.cpu_baseline --worker SECONDS SEED      (one core; prints "<env-steps> <seconds>")
+The envs run on plain C threads inside one process (`ro_bench_locked`, oracle/rg_oracle.c), so nothing but the physics is
+timed.  Round 2 started one Python interpreter per core and measured 18 env-steps/s per "core" on a 256-thread box whose
+single-core rate is ~300-600: what it measured was the box's CPU allotment and 256 interpreters starting.  This leg now
+reports the 1-thread rate, the aggregate over a ladder of thread counts, the count where the aggregate stops growing,
+and what the OS says the process may use (affinity, cgroup quota).
+
+    python -m oracle.cpu_baseline [SECONDS_PER_RUNG]
 """
+import ctypes
 import os
-import subprocess
 import sys
 import time
 
@@ -16,51 +22,91 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(seconds, seed):
+def cpu_allotment():
+    """What this process may use: affinity mask size, online CPUs, cgroup quota (cpu.max, v2; cfs quota, v1)."""
+    out = {"affinity": len(os.sched_getaffinity(0)), "online": os.cpu_count()}
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        out["cgroup_cpu_max"] = "max" if q == "max" else round(float(q) / float(p), 2)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            out["cgroup_cpu_max"] = "max" if q < 0 else round(q / p, 2)
+        except (OSError, ValueError):
+            out["cgroup_cpu_max"] = "unknown"
+    try:
+        names = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")]
+        out["cpu_model"] = names[0] if names else "unknown"
+    except OSError:
+        out["cpu_model"] = "unknown"
+    return out
+
+
+def _bench(ora, nthreads, seconds, seed):
+    from oracle import rg_oracle
+
+    L = rg_oracle.lib()
+    P = np.ascontiguousarray(ora.P, dtype=np.float64)
+    hq = np.ascontiguousarray(ora.hand_q, dtype=np.int32)
+    lo, hi = np.ascontiguousarray(ora.lo, dtype=np.float64), np.ascontiguousarray(ora.hi, dtype=np.float64)
+    steps, secs = (ctypes.c_long * nthreads)(), (ctypes.c_double * nthreads)()
+    dp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    t0 = time.perf_counter()
+    n = L.ro_bench_locked(ora.sim.m, nthreads, float(seconds), dp(P), hq.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), len(hq), dp(lo), dp(hi),
+                          ora.n_substeps, int(ora.cube_pos_q[2]), seed, steps, secs)
+    wall = time.perf_counter() - t0
+    total = sum(steps[i] for i in range(n))
+    rate = sum(steps[i] / secs[i] for i in range(n) if secs[i] > 0)
+    return n, total, rate, wall
+
+
+def oracle_newton_iterations(nsteps=40, seed=20200901 + 1):
+    """Mean Newton iterations / contacts / rows per mj_step of the ORACLE (fp64, tolerance 1e-8) on the bench's action
+    distribution, printed next to the kernel's own counters so the algorithmic byte model cannot grow by iterating more."""
     from oracle.env_oracle import OracleLockedEnvPhysics
     from robogym_amd.envs.dactyl.locked import load_locked_model
 
     ora = OracleLockedEnvPhysics(load_locked_model())
     ora.settle(30)
     rng = np.random.RandomState(seed)
-    n = 0
-    t0 = time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        for _ in range(20):
-            ora.env_step(rng.uniform(-1, 1, 20))
-            n += 1
-            if ora.sim.qpos[2] < -0.1:  # dropped: start over from a settled pose
-                ora.sim.reset(); ora.settle(30); ora.prev_dist = None
-    return n, time.perf_counter() - t0
+    ora.sim.stats_reset()
+    for _ in range(nsteps):
+        ora.env_step(rng.uniform(-1, 1, 20))
+    s = ora.sim.stats()
+    return {"mean_newton_iters": s["iters"], "mean_ncon": s["ncon"], "mean_nefc": s["nefc"], "mj_steps": int(s["steps"])}
 
 
-def run(seconds=12.0, cores=None):
-    """One worker process per host core (separate interpreters: the caller holds a HIP context that must not be forked)."""
-    cores = cores or len(os.sched_getaffinity(0))
-    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS="1")
-    t0 = time.perf_counter()
-    procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_baseline", "--worker", str(seconds), str(20200901 + 1 + 7919 * i)],
-                              stdout=subprocess.PIPE, cwd=ROOT, env=env) for i in range(cores)]
-    res = []
-    for p in procs:
-        try:
-            out, _ = p.communicate(timeout=seconds + 120)
-            n, dt = out.decode().strip().split("\n")[-1].split()
-            res.append((int(n), float(dt)))
-        except Exception:   # a worker that failed to start is simply not counted (cores reports the ones that ran)
-            p.kill()
-    wall = time.perf_counter() - t0
-    if not res:
-        raise RuntimeError("no cpu_baseline worker finished")
-    total, rate = sum(n for n, _ in res), sum(n / dt for n, dt in res)
-    return {"value": rate, "unit": "env-steps/s", "cores": len(res), "kind": "port",
-            "sample": "%d env-steps of dactyl/locked (10 substeps + 3 forwards each, same action distribution), one oracle env per process on %d host cores for %.0f s each "
-                      "(%.1f env-steps/s per core; %.0f s wall incl. process start-up); CPU restatement of MuJoCo, not mujoco-py" % (total, len(res), seconds, rate / len(res), wall)}
+def run(seconds=3.0, max_threads=None):
+    from oracle.env_oracle import OracleLockedEnvPhysics
+    from robogym_amd.envs.dactyl.locked import load_locked_model
+
+    ora = OracleLockedEnvPhysics(load_locked_model())
+    allot = cpu_allotment()
+    cap = max_threads or allot["affinity"]
+    _, n1, r1, _ = _bench(ora, 1, seconds, 20200901 + 1)
+    ladder = [(1, r1)]
+    best = (1, r1, n1)
+    total_steps = n1
+    rungs = sorted({min(cap, k) for k in (8, 32, 128, cap)} - {1})
+    for k in rungs:
+        n, tot, rate, _ = _bench(ora, k, seconds, 20200901 + 1 + k)
+        ladder.append((n, rate))
+        total_steps += tot
+        if rate > best[1]:
+            best = (n, rate, tot)
+        elif rate < 1.05 * best[1] and n > 4 * best[0]:
+            break       # the aggregate stopped growing: more threads only add contention
+    return {"value": best[1], "unit": "env-steps/s", "cores": best[0], "kind": "port",
+            "one_core": r1, "ladder": [{"threads": n, "env_steps_per_s": r} for n, r in ladder], "cpu_allotment": allot,
+            "sample": "%d env-steps of dactyl/locked (10 mj_step + 3 mj_forward each, iid U(-1,1) relative actions as the GPU run), one oracle env per C thread, %.0f s per rung; "
+                      "1 thread %.0f env-steps/s; best aggregate %.0f at %d threads (%.0f per thread); the process may use %s CPUs (affinity) / cgroup quota %s on '%s'; "
+                      "oracle built -O3 -march=native -ffp-contract=off; CPU restatement of MuJoCo, not mujoco-py" % (
+                          total_steps, seconds, r1, best[1], best[0], best[1] / best[0], allot["affinity"], allot["cgroup_cpu_max"], allot["cpu_model"])}
 
 
 if __name__ == "__main__":
-    if len(sys.argv) == 4 and sys.argv[1] == "--worker":
-        n, dt = _worker(float(sys.argv[2]), int(sys.argv[3]))
-        print(n, dt)
-    else:
-        print(run(float(sys.argv[1]) if len(sys.argv) > 1 else 12.0))
+    sys.path.insert(0, ROOT)
+    import json
+
+    print(json.dumps(run(float(sys.argv[1]) if len(sys.argv) > 1 else 3.0)))

@@ -50,7 +50,7 @@ EXPORTS = [
     "rg_model_create", "rg_model_free", "rg_model_dims", "rg_batch_create", "rg_batch_free", "rg_batch_set_env",
     "rg_batch_copy", "rg_batch_reset", "rg_batch_step", "rg_obs_dim", "rg_debug_size", "rg_lds_bytes", "rg_sync",
     "rg_last_error", "rg_batch_mpr_pair", "rg_batch_copy_rows", "rg_batch_step_ex", "rg_batch_field_ptr", "rg_model_create_on", "rg_model_npair",
-    "rg_lds_bytes_cfg", "rg_env_post_step", "rg_post_args_size", "rg_batch_enable_env_params", "rg_prm_layout", "rg_xdata_layout",
+    "rg_lds_bytes_cfg", "rg_env_post_step", "rg_post_args_size", "rg_batch_enable_env_params", "rg_prm_layout", "rg_xdata_layout", "rg_batch_set_constants",
 ]
 
 
@@ -98,6 +98,7 @@ def bind(path):
     L.rg_post_args_size.restype = ci
     if L.rg_post_args_size() != ctypes.sizeof(PostArgs):
         raise NativeError("rg_post_args layout mismatch between include/rgstep.h and robogym_amd/_native.py")
+    L.rg_batch_set_constants.argtypes = [vp, vp, vp]
     L.rg_sync.argtypes = [vp]
     L.rg_last_error.restype = ctypes.c_char_p
     return L

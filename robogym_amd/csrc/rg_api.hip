@@ -18,6 +18,7 @@ typedef rg_post_args RgPostArgs;
 #undef RG_MAXCAND
 #undef RG_MAXCAND2
 #define RG_NS rgl
+#define RG_SETCONST 1
 #define RG_MAXCON 64
 #define RG_CPOOL 2048
 #define RG_MAXCAND 256
@@ -720,6 +721,28 @@ int rg_env_post_step(rg_batch* b, const rg_post_args* args, void* stream) {
   emul_launch(b->dev.B, 256, emul_post_entry, &ea);
 #else
   hipLaunchKernelGGL(rg_post_step_kernel, dim3(b->dev.B), dim3(RG_WAVE), 0, (hipStream_t)stream, b->dev, a, d.nq, d.nv, d.nu, d.npair);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+
+#ifdef RG_EMUL
+struct EmulSetconstArgs { const RgModelDev* m; RgLaunch launch; float* envprm; };
+static void emul_setconst_entry(void* a) { EmulSetconstArgs* p = (EmulSetconstArgs*)a; rgl::rg_setconst_kernel(p->m, p->launch, p->envprm); }
+#endif
+int rg_batch_set_constants(rg_batch* b, const int* mask_dev, void* stream) {
+  if (!b) return fail("null batch");
+  if (!b->dev.envprm) return fail("rg_batch_set_constants: the batch has no per-env parameter rows (rg_batch_enable_env_params); the model's own constants are already consistent");
+  DeviceGuard g(b->device);
+  RgBatchDev bt = b->dev;
+  bt.active = mask_dev; bt.order = nullptr;
+  RgLaunch launch{b->model->aux, b->env, bt, 0, 0, 0};
+  const size_t lds = rgl::rg_lds_setconst_bytes();
+#ifdef RG_EMUL
+  EmulSetconstArgs args{b->model->dev_copy, launch, (float*)b->dev.envprm};
+  emul_launch(bt.B, lds, emul_setconst_entry, &args);
+#else
+  hipLaunchKernelGGL(rgl::rg_setconst_kernel, dim3(bt.B), dim3(RG_WAVE), lds, (hipStream_t)stream, b->model->dev_copy, launch, (float*)b->dev.envprm);
   HIPCHK(hipGetLastError());
 #endif
   return 0;

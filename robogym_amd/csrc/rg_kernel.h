@@ -264,6 +264,9 @@ __device__ __forceinline__ void cross_force(float* r, const float* vel, const fl
 #endif
 #undef RG_HCOEF_LDS
 #define RG_HCOEF_LDS (RG_MAXCON <= 32)   /* rollout configuration: its position side is the larger one anyway */
+#ifndef RG_SETCONST
+#define RG_SETCONST 0  /* 1: this configuration also carries rg_setconst_kernel (one instantiation is enough) */
+#endif
 #ifndef RG_SENSORS
 #define RG_SENSORS 0   /* 1: this configuration evaluates data.sensordata (launch flag bit 5); its own instantiation so that the hot configurations carry none of it */
 #endif
@@ -2426,7 +2429,8 @@ __global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_kernel(con
       SYNC();
       st_kinematics(c); st_com_pos(c); st_tendon(c);
       for (int k = 0; k < pre; k++) st_pid(c, pidr);
-      if (LANE == 0) L.bt.preticks[e] = 0;
+      // (cleared in the write-back section: an env that is handed to the large configuration through `redo` returns
+      //  without writing its PID row, so the ticks must still be owed when that launch picks it up)
     }
   }
   // envs on `hold` (scripted reset recipe) and envs whose action row holds a non-finite entry keep their stored ctrl row
@@ -2539,6 +2543,7 @@ __global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_kernel(con
   if (LANE < m.nu) for (int k = 0; k < 3; k++) L.bt.pid[(size_t)e * 3 * m.nu + 3 * LANE + k] = pidr[k];
   PFOR(u, m.nu) L.bt.ctrl[(size_t)e * m.nu + u] = s.ctrl[u];
   if (LANE == 0) {
+    if (L.bt.preticks) L.bt.preticks[e] = 0;
     L.bt.status[e] = s.status; L.bt.time[e] += nsubsteps * P[RG_PRM_TIMESTEP];
 #if defined(RG_CLOCK_REALTIME) && RG_CLOCK_REALTIME == 2
     L.bt.time[e] = (float)(tk0 & 0xFFFFFF);   // analysis build only: when the env's wave started (low 24 bits of the 100 MHz counter) instead of the simulation time
@@ -2604,6 +2609,96 @@ __global__ void __launch_bounds__(RG_WAVE) rg_mpr_pair_kernel(const RgModelDev* 
   }
 }
 
+#if RG_SETCONST
+// mj_setConst on the device (reference: mujoco_simulation.set_constants() in every _reset, cube_env.py:346-349,
+// simulation_interface.py:199-201): for every env of the mask, recompute the quantities MuJoCo derives from the model at
+// qpos0 and the kernel reads through the env's parameter row -- dof_invweight0 (diagonal of inv(M), averaged over the
+// components of a ball / free joint), body_invweight0 (mean diagonal of J inv(M) J' for the translational and the rotational
+// Jacobian of the body's com) and tendon_invweight0 (J inv(M) J') -- from the row's CURRENT body_mass / body_inertia /
+// dof_armature (and site_pos, for the tendon paths).  They scale the regulariser R of every constraint row
+// (rg_make_constraint), so a mass / inertia randomisation without this pass steps with the wrong softness.
+// One wave per env: the position stages of the step kernel at qpos0, the tree-sparse L'DL of M, then one substitution per
+// needed row of inv(M) J' (nv + 6 per moving body + 1 per tendon: ~230 for the hand models, about one mj_step of work).
+// Scratch that has to survive the factorisation (which overlays the position-stage arrays) sits behind the RgLds image.
+struct RgSetconstX { float cdof[6 * RG_MAXNV], off[3 * RG_MAXBODY], x[RG_MAXNV], y[RG_MAXNV], dg[RG_MAXNV]; };
+static inline size_t rg_lds_setconst_bytes() { return sizeof(RgLds) + sizeof(RgSetconstX); }
+__global__ void __launch_bounds__(RG_WAVE) rg_setconst_kernel(const RgModelDev* mp, RgLaunch launch, float* envprm) {
+  RG_MAKE_CTX();
+  RgM m = RG_M(c);
+  RgLRef L = RG_L(c);
+  RgLds& s = RG_S();
+  RgSetconstX& X = *(RgSetconstX*)((char*)&s + sizeof(RgLds));
+  const int e = blockIdx.x;
+  if (e >= L.bt.B) return;
+  if (L.bt.active && !L.bt.active[e]) return;
+  PFOR(i, m.nq) s.qpos[i] = m.qpos0[i];
+  if (LANE == 0) { s.has_xfrc = 0; s.status = 0; }
+  st_build_row_desc(c);
+  SYNC();
+  st_kinematics(c); st_com_pos(c); st_tendon(c);
+  PFOR(i, 6 * m.nv) X.cdof[i] = s.cdof[i];
+  for (int b = 1 + LANE; b < m.nbody; b += RG_WAVE) st3(X.off + 3 * b, rg_xipos(m, s, b) - ld3(s.org + 3 * s.b2org[b]));
+  SYNC();
+  st_crb(c);
+  LtdlDesc D;
+  rg_ltdl_load(m.ltdl_tri, m.ltdl_pair, m.n_tri_rounds, m.n_pair_rounds, D);
+  rg_M_to_blocks(m, s);
+  const int d = LANE; const bool on = d < m.nv;
+  const int blk = on ? m.dof_blk[d] : 0, akk = (blk & 0xFFFF) + d - ((blk >> 16) & 255);
+  rg_ltdl_factor(s, D);
+  float* P = envprm + (size_t)e * RG_NPRM;
+  // ---- dof_invweight0
+  for (int i = 0; i < m.nv; i++) {
+    if (on) X.x[d] = d == i ? 1.f : 0.f;
+    SYNC();
+    rg_ltdl_solve(s, D, X.x, d, on, akk);
+    if (LANE == 0) X.dg[i] = X.x[i];
+    SYNC();
+  }
+  PFOR(j, m.njnt) {
+    const int da = m.jnt_dofadr[j], t = m.jnt_type[j];
+    if (t == RG_JNT_FREE || t == RG_JNT_BALL) {
+      for (int h = 0; h < (t == RG_JNT_FREE ? 2 : 1); h++) {
+        const float a = (X.dg[da + 3 * h] + X.dg[da + 3 * h + 1] + X.dg[da + 3 * h + 2]) * (1.f / 3.f);
+        for (int k = 0; k < 3; k++) P[RG_PRM_DOF_INVWEIGHT0 + da + 3 * h + k] = a;
+      }
+    } else P[RG_PRM_DOF_INVWEIGHT0 + da] = X.dg[da];
+  }
+  // ---- body_invweight0
+  for (int b = 1; b < m.nbody; b++) {
+    if ((m.body_depth[b] & 255) == 0) { if (LANE == 0) { P[RG_PRM_BODY_INVWEIGHT0 + 2 * b] = 0.f; P[RG_PRM_BODY_INVWEIGHT0 + 2 * b + 1] = 0.f; } continue; }
+    float tr[2] = {0.f, 0.f};
+    const v3 off = ld3(X.off + 3 * b);
+    for (int k = 0; k < 6; k++) {
+      float v = 0.f;
+      if (on && in_chain(m, b, d)) {
+        const v3 ang = ld3(X.cdof + 6 * d), jc = k < 3 ? ld3(X.cdof + 6 * d + 3) + cross(ang, off) : ang;
+        const int kk = k < 3 ? k : k - 3;
+        v = kk == 0 ? jc.x : (kk == 1 ? jc.y : jc.z);
+      }
+      if (on) { X.x[d] = v; X.y[d] = v; }
+      SYNC();
+      rg_ltdl_solve(s, D, X.x, d, on, akk);
+      tr[k < 3 ? 0 : 1] += wave_sum(on ? X.x[d] * X.y[d] : 0.f);
+      SYNC();
+    }
+    if (LANE == 0) { P[RG_PRM_BODY_INVWEIGHT0 + 2 * b] = fmaxf(1e-15f, tr[0] * (1.f / 3.f)); P[RG_PRM_BODY_INVWEIGHT0 + 2 * b + 1] = fmaxf(1e-15f, tr[1] * (1.f / 3.f)); }
+  }
+  // ---- tendon_invweight0
+  for (int t = 0; t < m.ntendon; t++) {
+    float v = 0.f;
+    if (on) for (int q = 0; q < 4; q++) if (m.ten_dofs[4 * t + q] == d) v += s.tenJ[4 * t + q];
+    if (on) { X.x[d] = v; X.y[d] = v; }
+    SYNC();
+    rg_ltdl_solve(s, D, X.x, d, on, akk);
+    const float w = wave_sum(on ? X.x[d] * X.y[d] : 0.f);
+    SYNC();
+    if (LANE == 0) P[RG_PRM_TENDON_INVWEIGHT0 + t] = fmaxf(1e-15f, w);
+  }
+  if (LANE == 0 && s.status) L.bt.status[e] |= s.status;
+}
+#endif
+
 // masked row copy (rg_batch_copy_rows): one workgroup per env
 __global__ void rg_copy_rows_kernel(float* dst, const float* src, const int* mask, int n, int col0, int ncols, float* pairlb, int npair) {
   int e = blockIdx.x;
@@ -2614,6 +2709,7 @@ __global__ void rg_copy_rows_kernel(float* dst, const float* src, const int* mas
 }  // namespace RG_NS
 #undef RG_MAXPYR
 #undef RG_SENSORS
+#undef RG_SETCONST
 #undef RG_PSLOTS
 #undef RG_RSLOTS
 #undef RG_MSLOTS

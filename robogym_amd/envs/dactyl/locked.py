@@ -114,6 +114,9 @@ class LockedSimulation(BatchedSimulationInterface):
     def denormalize_position_control(self, action: torch.Tensor, relative_action: bool = False) -> torch.Tensor:
         """robot_interface.py:247-278 for the whole batch (host-side use: resets)."""
         lo, hi = self.ctrl_lo, self.ctrl_hi
+        if self._params is not None:    # the envs' own ranges (RandomizedJointLimitWrapper rewrites them per episode; the
+            cr = self._params["actuator_ctrlrange"]   # reference reads sim.model.actuator_ctrlrange, mujoco_shadow_hand.py:105-113)
+            lo, hi = cr[..., 0], cr[..., 1]
         if relative_action:
             p2c = torch.tensor(self.pos_to_ctrl, dtype=torch.float32, device=self.device)
             centre = self.get_qpos("hand_angle") @ p2c.T
@@ -290,6 +293,7 @@ class BatchedLockedEnv:
         for _ in range(c.max_pose_resets):
             active = need.to(torch.int32).contiguous()
             self._masked_sim_reset(need)
+            sim.set_constants(active)   # cube_env.py:346-349: parameters are in the model by now (the wrappers write them before env.reset) -> mj_setConst
             zero = torch.zeros((B, self.num_actions), dtype=torch.float32, device=self.device)
             self._set_ctrl_masked(sim.denormalize_position_control(zero), need)
             for _ in range(c.reset_initial_steps):

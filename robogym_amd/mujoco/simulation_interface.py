@@ -156,9 +156,10 @@ class BatchedSimulationInterface:
         return self.get_field(_native.RG_F_QVEL)
 
     def _group_idx(self, table, group):
-        key = (id(table), group)
+        idx = table[group]
+        key = (table is self.qpos_idxs, group, np.asarray(idx).tobytes())   # keyed by CONTENT: a reassigned group gets a fresh tensor
         if key not in self._idx_cache:
-            self._idx_cache[key] = torch.as_tensor(table[group], device=self.device)
+            self._idx_cache[key] = torch.as_tensor(idx, device=self.device)
         return self._idx_cache[key]
 
     def get_qpos(self, group: str) -> torch.Tensor:
@@ -212,6 +213,20 @@ class BatchedSimulationInterface:
         if self._params is None:
             self._params = EnvParams(self)
         return self._params
+
+    def set_constants(self, mask: Optional[torch.Tensor] = None):
+        """`SimulationInterface.set_constants` (simulation_interface.py:199-201 -> MjSim.set_constants -> mj_setConst), which the
+        reference calls in every `_reset` after the randomizers have written the model (cube_env.py:346-349): recompute
+        dof / body / tendon `_invweight0` of the masked envs (None: all) from each env's own mass / inertia / armature /
+        site_pos row, on the device (`rg_setconst_kernel`), asynchronously on the current stream.  A batch without
+        parameter rows has nothing to refresh (the model's own constants are consistent)."""
+        if self._params is None:
+            return
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=torch.int32).contiguous()
+            assert mask.shape == (self.batch_size,)
+        _native.check(self._L, self._L.rg_batch_set_constants(self._bh, self._ptr(mask), self._stream_ptr()), "rg_batch_set_constants")
+        self._keep_alive = mask   # (the launch is asynchronous: the mask must outlive it)
 
     # ------------------------------------------------------------------ state (simulation_interface.py:154-172)
     def get_state(self) -> dict:

@@ -137,23 +137,11 @@ class _RowSubset:   # (placeholder type for _field(); GenericSimRandomizer.rando
 
 def refresh_constants(sim, rows: Optional[Sequence[int]] = None):
     """mj_setConst for the envs whose mass / inertia / armature rows were changed (the reference calls
-    `mujoco_simulation.set_constants()` in `_reset`, cube_env.py:349): recompute dof / body / tendon `_invweight0` on the
-    host from each row's values (robogym_amd/mujoco/setconst.py, double precision) and write them back.  Host cost is per
-    distinct env row; identical rows are computed once."""
-    from robogym_amd.mujoco import setconst
-
-    P = sim.params
-    mass, inertia, arm = P["body_mass"].cpu().numpy(), P["body_inertia"].cpu().numpy(), P["dof_armature"].cpu().numpy()
-    rows = range(sim.batch_size) if rows is None else rows
-    cache = {}
-    out_d, out_b, out_t = P["dof_invweight0"], P["body_invweight0"], P["tendon_invweight0"]
-    for e in rows:
-        key = (mass[e].tobytes(), inertia[e].tobytes(), arm[e].tobytes())
-        if key not in cache:
-            m = sim.model.copy_with(body_mass=mass[e].astype(np.float64), body_inertia=inertia[e].astype(np.float64), dof_armature=arm[e].astype(np.float64))
-            setconst.set_constants(m)
-            cache[key] = (m.arrays["dof_invweight0"], m.arrays["body_invweight0"], m.arrays["tendon_invweight0"])
-        d, b, t = cache[key]
-        out_d[e] = torch.as_tensor(d, dtype=torch.float32, device=out_d.device)
-        out_b[e] = torch.as_tensor(b.reshape(-1, 2), dtype=torch.float32, device=out_b.device)
-        out_t[e] = torch.as_tensor(t, dtype=torch.float32, device=out_t.device)
+    `mujoco_simulation.set_constants()` in `_reset`, cube_env.py:349): dof / body / tendon `_invweight0` recomputed ON THE
+    DEVICE from each env's own row (`sim.set_constants`, rg_setconst_kernel); no host loop, no synchronisation."""
+    if rows is None:
+        sim.set_constants()
+        return
+    mask = torch.zeros(sim.batch_size, dtype=torch.int32, device=sim.device)
+    mask[torch.as_tensor(list(rows), dtype=torch.long, device=sim.device)] = 1
+    sim.set_constants(mask)

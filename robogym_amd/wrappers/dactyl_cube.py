@@ -29,6 +29,8 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 
+from robogym_amd import _native
+
 from robogym_amd.utils import rotation
 
 NOT_BUILT: list = []
@@ -109,6 +111,9 @@ class BatchedDactylCubeWrappers:
         self._in_recipe = torch.zeros(env.batch_size, dtype=torch.bool, device=env.device)
         if self.auto_reset and not getattr(env, "pipelined_reset", False):
             raise ValueError("auto_reset needs an env built with pipelined_reset=True")
+        if self.auto_reset and int(min_episode_length) > 0:
+            # the env kernel restarts a fallen env by itself (stop_on_fall) while this wrapper would suppress its `done`
+            raise ValueError("min_episode_length > 0 cannot be combined with auto_reset")
         self.B, self.device, self.nu = env.batch_size, env.device, env.num_actions
         self.batch_size = self.B
         nb = 11 if n_action_bins is None else int(n_action_bins)          # DiscretizeActionWrapper.DEFAULT_BINS
@@ -136,6 +141,8 @@ class BatchedDactylCubeWrappers:
         sim = env.mujoco_simulation
         self._cube_center_z0 = sim.cube_body_z
         self._step_s0 = sim.n_substeps * float(sim.model.opt_timestep[0])   # step length with the model's own timestep (wrapper construction time)
+        self._nsub = int(sim.n_substeps)
+        self._ema_alpha = torch.full((env.batch_size,), float(np.power(self.smooth_alpha, self._step_s0 / 0.08)) if self.smooth_alpha > 0 else 0.0, dtype=torch.float32, device=env.device)
         if randomize:
             self._build_randomizations()
         self.action_space = {"nvec": [nb] * self.nu, "dtype": "int64"}   # gym.spaces.MultiDiscrete([n_action_bins] * nu)
@@ -324,7 +331,7 @@ class BatchedDactylCubeWrappers:
         self._slack = (self._slack + incr).clamp(-1.0, 1.0).to(self._slack.dtype)
         return (ctrl - centre) / (0.5 * (hi - lo))                                                             # _ctrl2action
 
-    def _after_env_step(self):
+    def _after_env_step(self, live=None, started=None):
         """What the randomization wrappers do after the env below them has stepped, innermost first: RandomizedTimestepWrapper.step
         (randomizations.py:267-304), then RandomizedWindWrapper.step (cube.py:75-85)."""
         D, P, ts = self.draws, self._P, self._ts
@@ -337,12 +344,16 @@ class BatchedDactylCubeWrappers:
         neg = ts["side"] < 0
         frac = noise / h0
         noise = torch.where(neg, (h0 * (frac / (1 + frac))).clamp(0.0, h0 / 2), noise)
-        P["timestep"][:, 0] = (h0 + ts["side"] * noise).to(P["timestep"].dtype)
+        new_ts = (h0 + ts["side"] * noise).to(P["timestep"].dtype)
+        P["timestep"][:, 0] = new_ts if live is None else torch.where(live, new_ts, P["timestep"][:, 0])
         x = P["xfrc_applied"][:, self._cube_body, :3]
-        x *= 0.99
         hit = D.random_sample() < self._wind_hit_prob
         force = D.randn_where(hit, (3,)) * P["body_mass"][:, self._cube_body, None] * 1.0
-        P["xfrc_applied"][:, self._cube_body, :3] = torch.where(hit[:, None], force.to(x.dtype), x)
+        new_x = torch.where(hit[:, None], force.to(x.dtype), x * 0.99)
+        if live is not None:
+            new_x = torch.where(live[:, None], new_x, x)
+            new_x = torch.where(started[:, None], torch.zeros_like(new_x), new_x)
+        P["xfrc_applied"][:, self._cube_body, :3] = new_x
 
     def _post_noise_obs(self, o, at_reset, mixed=False):
         """FingersOccludedPhasespaceMarkers -> FingersFreezingPhasespaceMarkers -> CubeFreezingPhasespaceBody (dactyl.py:53-107,
@@ -476,6 +487,9 @@ class BatchedDactylCubeWrappers:
         self._steps.masked_fill_(mask, 0); self._drops_so_far.masked_fill_(mask, 0); self._first_drop.masked_fill_(mask, 0)
         self._previous_action.masked_fill_(mask[:, None], 0.0)
         self._ema_value.masked_fill_(mask[:, None], 0.0); self._ema_t.masked_fill_(mask, 0)
+        if self.smooth_alpha > 0 and self.randomize:
+            step_s = self._P["timestep"][:, 0].to(self._ema_alpha.dtype) * self._nsub
+            self._ema_alpha = torch.where(mask, torch.pow(torch.full_like(step_s, self.smooth_alpha), step_s / 0.08), self._ema_alpha)
         self._noise_reset(mask)
 
     def _action_noise_reset(self, mask):
@@ -493,10 +507,13 @@ class BatchedDactylCubeWrappers:
         if self.randomize:                                                               # ActionNoiseWrapper.action (randomizations.py:772-778)
             a = a * self._an_mult + self._an_add + self.draws.randn((self.nu,)) * 0.1
         # SmoothActionWrapper.step: IncrementalExpAvg with alpha adjusted to the step length (util.py:142-219)
-        alpha = float(np.power(self.smooth_alpha, self._step_s0 / 0.08)) if self.smooth_alpha > 0 else 0.0
+        if self.smooth_alpha > 0 and self.randomize:   # reset() recomputes alpha from the CURRENT (randomized) opt.timestep (util.py:204-210)
+            alpha = self._ema_alpha[:, None]
+        else:
+            alpha = torch.full((self.B, 1), float(np.power(self.smooth_alpha, self._step_s0 / 0.08)) if self.smooth_alpha > 0 else 0.0, dtype=a.dtype, device=self.device)
         self._ema_value = self._ema_value * alpha + (1 - alpha) * a
         self._ema_t += 1
-        a = self._ema_value / (1 - torch.pow(torch.full_like(self._ema_value, alpha), self._ema_t[:, None].to(a.dtype)))
+        a = self._ema_value / (1 - torch.pow(alpha.expand_as(self._ema_value), self._ema_t[:, None].to(a.dtype)))
         a_ema = a
         if self.randomize:
             # RandomizedActionLatency.step (randomizations.py:545-556): per coordinate, the action `action_delay` steps back.  The
@@ -528,7 +545,9 @@ class BatchedDactylCubeWrappers:
             self._episode_start(started, list(self._next_delta.items()) if self.randomize and self._next_delta else None)
             a_ema = torch.where(started[:, None], torch.zeros_like(a_ema), a_ema)
         if self.randomize:
-            self._after_env_step()
+            # (auto_reset: envs inside the reset recipe are between episodes -- in the reference the recipe runs inside reset() with a
+            #  constant timestep and xfrc_applied = 0, and an episode starts with zero wind)
+            self._after_env_step(live=None if not self.auto_reset else ~(resetting | started), started=started)
         # StopOnFallWrapper.step (cube.py:125-151)
         fallen = self._is_fallen(obs)
         if self.auto_reset:
@@ -550,6 +569,12 @@ class BatchedDactylCubeWrappers:
             self._action_noise_reset(started)
             if self.randomize:
                 self._randomize_before_reset(done)        # the episode is over: its env restarts on the next step, with the new parameters
+                sim = self.env.mujoco_simulation
+                restarted = done & info["resetting"].bool()
+                sim.set_constants(restarted)              # cube_env.py:346-349: mj_setConst after the model was written, before the recipe runs
+                # the env kernel wrote the recipe's first ctrl (zero action = mid-range) from the OLD episode's ctrl range: rewrite it
+                cr = sim.params["actuator_ctrlrange"]
+                sim.copy_rows(_native.RG_F_CTRL, (0.5 * (cr[..., 0] + cr[..., 1])).contiguous(), restarted)
                 for key, val in self._pending_delta:      # (their observation entries switch when the new episode starts)
                     self._next_delta[key] = val if key not in self._next_delta else torch.where(_bmask(done, val), val, self._next_delta[key].to(val.dtype))
         return out, reward, done, info

@@ -26,10 +26,11 @@ def sync_state_from_oracle(sim, env_oracle, rows=None):
     sim.set_state({k: full[k] for k in st})
 
 
-def resync_errors(sim, env_oracle, actions, substep_level=False):
+def resync_errors(sim, env_oracle, actions, substep_level=False, detail=False):
     """Re-synchronised errors: the kernel is restarted from the oracle's (fp32-rounded) state before
     every env.step (10 substeps + 3 forward ticks) or, with `substep_level`, before every mj_step.
-    Returns rows of (qpos Linf over non-target joints, qvel Linf, pid Linf)."""
+    Returns rows of (qpos Linf over non-target joints, qvel Linf, pid Linf); `detail` appends (largest contact count of the
+    env.step's substeps, deepest penetration) for the tail characterisation."""
     out = []
     for a in actions:
         if substep_level:
@@ -48,9 +49,24 @@ def resync_errors(sim, env_oracle, actions, substep_level=False):
         sync_state_from_oracle(sim, env_oracle)
         at = torch.tensor(np.repeat(a[None].astype(np.float32), sim.batch_size, 0), device=sim.device)
         sim.env_step(action=at, nforward_ticks=3)
-        env_oracle.env_step(a)
+        extra = ()
+        if detail:   # the oracle substep by substep (same arithmetic as env_step), recording what the step went through
+            o = env_oracle
+            o.sim.ctrl[:] = o.denormalize(np.clip(np.asarray(a, dtype=np.float64), -1, 1), o.relative_action)
+            ncon_max, depth = 0, 0.0
+            for _ in range(o.n_substeps):
+                o.sim.step()
+                ncon_max = max(ncon_max, o.sim.ncon)
+                for c in o.sim.contacts():
+                    depth = max(depth, -c["dist"])
+            o.sim.forward(); o.sim.forward()
+            dist = o.goal_distance(); o.prev_dist = dist
+            o.sim.forward()
+            extra = (ncon_max, depth)
+        else:
+            env_oracle.env_step(a)
         q = sim.qpos.cpu().numpy()[0].astype(np.float64)
         v = sim.qvel.cpu().numpy()[0].astype(np.float64)
         p = sim.get_field(3).cpu().numpy()[0].astype(np.float64)
-        out.append((np.abs(q - env_oracle.sim.qpos)[NON_TARGET_QPOS].max(), np.abs(v - env_oracle.sim.qvel).max(), np.abs(p - env_oracle.sim.pid).max()))
+        out.append((np.abs(q - env_oracle.sim.qpos)[NON_TARGET_QPOS].max(), np.abs(v - env_oracle.sim.qvel).max(), np.abs(p - env_oracle.sim.pid).max()) + extra)
     return np.array(out)

@@ -67,3 +67,31 @@ def test_bench_distributed_path_under_gloo(emul_lib):
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["steps"] == 2 and r["value"] > 0 and r["scaling"] == "weak"
     assert r["config"]["global_batch"] == 4 and "170 floats" in r["config"]["gathered_row"]
+
+
+def test_bench_spawns_its_own_ranks(emul_lib):
+    """`python bench.py --gpus 2` WITHOUT a launcher (--gpus was parsed and ignored): the script
+    re-executes itself under torch.distributed.run with 2 ranks, asserts the world size equals --gpus and prints
+    n_gpus 2 with the rank count of the process group."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["RG_BENCH_EMUL_LIB"] = os.path.join(ROOT, "tests", "emul", "librgstep_emul.so")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.split("\n") if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["ranks"] == 2 and r["config"]["collective_backend"] == "gloo"
+    assert r["config"]["global_batch"] == 4
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus(emul_lib):
+    import subprocess
+
+    env = dict(os.environ, RG_BENCH_EMUL_LIB=os.path.join(ROOT, "tests", "emul", "librgstep_emul.so"), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "--gpus 2" in out.stderr

@@ -56,7 +56,17 @@ for kernel_variant in (True, False):
     ora.sim.reset(); ora.settle(30)
     sim = LockedSimulation(model, 1, device="cuda:0")
     rng = np.random.RandomState(20200901 + 1)
-    errs = resync_errors(sim, ora, rng.uniform(-1, 1, (200, 20)))
+    errs = resync_errors(sim, ora, rng.uniform(-1, 1, (200, 20)), detail=True)
     for name, col in (("qpos", 0), ("qvel", 1), ("pid state", 2)):
         v = errs[:, col]
-        print("  %-9s median %.2e   p90 %.2e   max %.2e   (200 env-steps)" % (name, np.median(v), np.percentile(v, 90), v.max()))
+        print("  %-9s median %.2e   p90 %.2e   p99 %.2e   max %.2e   (200 env-steps)" % (name, np.median(v), np.percentile(v, 90), np.percentile(v, 99), v.max()))
+    print("  qpos error by the largest contact count the env.step went through (tail characterisation; compare profiles/r03_precision.txt:")
+    print("  the same table between an fp32 and an fp64 build of the ORACLE):")
+    for lo, hi in ((0, 0), (1, 2), (3, 4), (5, 6), (7, 9), (10, 99)):
+        sel = (errs[:, 3] >= lo) & (errs[:, 3] <= hi)
+        if sel.any():
+            v = errs[sel, 0]
+            print("    ncon %2d-%-2d  n %-4d median %.2e  p90 %.2e  max %.2e   deepest penetration (median) %.2e m" % (lo, hi, sel.sum(), np.median(v), np.percentile(v, 90), v.max(), np.median(errs[sel, 4])))
+    big = errs[errs[:, 0] > 2e-3]
+    print("  env-steps beyond 2e-3: %d of %d%s" % (len(big), len(errs), "" if not len(big) else "; their contact counts %s, deepest penetrations %s" % (
+        [int(x) for x in big[:, 3]], ["%.1e" % x for x in big[:, 4]])))
