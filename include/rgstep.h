@@ -128,6 +128,15 @@ int rg_batch_copy_rows(rg_batch* b, int field, const void* src_dev, const int* m
  *                      about one more substep of work.  Needs xdata_dev and nforward_ticks >= 1.
  *                bit6: dense Newton step with the forward substitution as its own pass instead of inside the
  *                      factorisation (same result to rounding; test hook)
+ *                bit7: substep-granular dispatch (RG_CFG_ROLLOUT, nsubsteps >= 2, no bit 0 / 1 / 5): the launch is a grid of
+ *                      persistent workgroups that draw (env, substep) work items in substep-major order instead of one workgroup
+ *                      per env.step, so the device stays full to the end of the launch; bit-identical results.  An env that
+ *                      exceeds the rollout capacities in substep s gets redo_dev[e] = s + 1.  Ignored where the device probe
+ *                      at rg_batch_create found it unavailable (rg_batch_items_info).
+ *                bit9: test hook for the hand-over: a rollout-configuration substep with more than 5 contacts counts as exceeding the
+ *                      capacities (the env goes to redo_dev although it would fit)
+ *                bit8: active_dev is the redo_dev array of a rollout launch: entry - 1 is the first substep still to do
+ *                      (the env.step is resumed there; entry 1 = from the start)
  *   stream       hipStream_t (NULL = default stream).  Asynchronous. */
 int rg_batch_step(rg_batch* b, const float* action_dev, const float* goal_quat_dev, float* obs_dev, float* goal_dist_dev,
                   const int* active_dev, int nsubsteps, int nforward_ticks, int flags, void* stream);
@@ -230,6 +239,8 @@ int rg_batch_set_constants(rg_batch* b, const int* mask_dev, void* stream);
  * kinematics of every env's stored qpos and one MPR penetration query between geoms g1, g2 inflated
  * by margin/2 each.  out_dev float [B][8] = hit, depth, direction3 (g1 -> g2), position3. */
 int rg_batch_mpr_pair(rg_batch* b, int g1, int g2, float margin, float* out_dev, void* stream);
+/* substep-granular dispatch (flags bit 7): persistent workgroups per launch (0: unavailable on this device) and work queues (XCDs) */
+int rg_batch_items_info(const rg_batch* b, int* slots, int* queues);
 int rg_obs_dim(const rg_batch* b);
 int rg_debug_size(void);
 /* bytes of LDS one env occupies in the rollout configuration (diagnostic); rg_lds_bytes_cfg: any configuration */

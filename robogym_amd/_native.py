@@ -50,7 +50,7 @@ EXPORTS = [
     "rg_model_create", "rg_model_free", "rg_model_dims", "rg_batch_create", "rg_batch_free", "rg_batch_set_env",
     "rg_batch_copy", "rg_batch_reset", "rg_batch_step", "rg_obs_dim", "rg_debug_size", "rg_lds_bytes", "rg_sync",
     "rg_last_error", "rg_batch_mpr_pair", "rg_batch_copy_rows", "rg_batch_step_ex", "rg_batch_field_ptr", "rg_model_create_on", "rg_model_npair",
-    "rg_lds_bytes_cfg", "rg_env_post_step", "rg_post_args_size", "rg_batch_enable_env_params", "rg_prm_layout", "rg_xdata_layout", "rg_batch_set_constants",
+    "rg_lds_bytes_cfg", "rg_env_post_step", "rg_post_args_size", "rg_batch_enable_env_params", "rg_prm_layout", "rg_xdata_layout", "rg_batch_set_constants", "rg_batch_items_info",
 ]
 
 
@@ -99,6 +99,7 @@ def bind(path):
     if L.rg_post_args_size() != ctypes.sizeof(PostArgs):
         raise NativeError("rg_post_args layout mismatch between include/rgstep.h and robogym_amd/_native.py")
     L.rg_batch_set_constants.argtypes = [vp, vp, vp]
+    L.rg_batch_items_info.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci)]
     L.rg_sync.argtypes = [vp]
     L.rg_last_error.restype = ctypes.c_char_p
     return L
@@ -122,6 +123,9 @@ def check(L, rc, what):
 RG_FLAG_MPR_PLANE_DEPTH = 16   # rg_step_args.flags bit 4 (include/rgstep.h)
 RG_FLAG_SENSORS = 32           # bit 5: evaluate data.sensordata (the last state-less forward runs in full)
 RG_FLAG_SEPARATE_FORWARD_SUBSTITUTION = 64   # bit 6: test hook (include/rgstep.h)
+RG_FLAG_SUBSTEP_ITEMS = 128    # bit 7: substep-granular dispatch of a rollout launch (rg_step_items_kernel)
+RG_FLAG_CAPACITY_TEST_HOOK = 512   # bit 9: test hook (include/rgstep.h)
+RG_FLAG_RESUME = 256           # bit 8: active_dev is a redo array: entry - 1 = first substep still to do
 
 PRM_NAMES = ["row", "gravity", "timestep", "dof_damping", "dof_armature", "dof_frictionloss", "dof_invweight0", "body_mass", "body_inertia", "body_invweight0",
              "jnt_range", "tendon_range", "tendon_invweight0", "actuator_gainprm", "actuator_ctrlrange", "actuator_forcerange", "geom_friction", "xfrc_applied", "site_pos", "geom_scale"]

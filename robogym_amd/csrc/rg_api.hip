@@ -43,6 +43,21 @@ typedef rg_post_args RgPostArgs;
 #undef RG_MAXCAND
 #undef RG_MAXCAND2
 
+// the rollout capacities once more as the substep-granular configuration (rg_step_items_kernel: persistent workgroups drawing
+// (env, substep) work items; rows written by a previous item are read past the L1)
+#define RG_NS rgi
+#define RG_ITEMS 1
+#define RG_MAXCON 24
+#define RG_CPOOL 768
+#define RG_MAXCAND 128
+#define RG_MAXCAND2 64
+#include "rg_kernel.h"
+#undef RG_NS
+#undef RG_MAXCON
+#undef RG_CPOOL
+#undef RG_MAXCAND
+#undef RG_MAXCAND2
+
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -67,6 +82,9 @@ static const char* hipGetErrorString(hipError_t) { return "emul"; }
 #endif
 
 #include "rg_env_kernel.h"
+#define RG_WAVES_PER_SIMD_HOST 3   /* = RG_WAVES_PER_SIMD of rg_kernel.h (its default) */
+struct rg_batch;
+extern "C" { static void rg_items_probe(rg_batch* b); }
 
 static thread_local std::string g_err;
 #ifdef RG_EMUL
@@ -99,6 +117,8 @@ struct rg_batch {
   RgEnvDev env;
   int device;
   int has_env = 0;
+  int items_slots = 0;   // substep-granular dispatch: persistent workgroups per launch (wave slots of the device), 0 = not available
+  int items_queues = 1;  // work queues (XCDs)
   std::vector<void*> allocs;
 };
 
@@ -484,6 +504,9 @@ rg_batch* rg_batch_create(const rg_model* m, int B, int device) {
   s.cost = (float*)balloc(b, (size_t)B * 4);
   s.sepdir = (float*)balloc(b, (size_t)B * (d.npair > 0 ? d.npair : 1) * 16);
   s.pairlb = (float*)balloc(b, (size_t)B * (d.npair > 0 ? d.npair : 1) * 4);
+  s.sched = (int*)balloc(b, ((size_t)RG_SCHED_PROG + B) * 4);
+  if (!s.sched) { fail("hipMalloc failed"); rg_batch_free(b); return nullptr; }
+  rg_items_probe(b);
   if (!s.qpos || !s.qvel || !s.ctrl || !s.pid || !s.qacc_warmstart || !s.time || !s.status || !s.stats || !s.dbg || !s.sepdir || !s.pairlb || !s.cost) { fail("hipMalloc failed"); rg_batch_free(b); return nullptr; }
   if (rg_batch_reset(b) != 0) { rg_batch_free(b); return nullptr; }
   return b;
@@ -636,11 +659,52 @@ int rg_batch_copy_rows(rg_batch* b, int field, const void* src_dev, const int* m
   return 0;
 }
 
+// ---- substep-granular dispatch: is it available on this device?  One queue per XCD, served only by workgroups of that XCD:
+// every XCD must receive workgroups of a slots-sized grid.  Probed once per batch with a tiny kernel that counts workgroups
+// per XCC id; if any XCD stays empty (or the ids are not 0..7) the batch keeps the one-workgroup-per-env kernel.
+#ifndef RG_EMUL
+__global__ void rg_xcc_probe_kernel(int* counts) { if (threadIdx.x == 0) atomicAdd(counts + (rg_xcc_id() & 15), 1); }
+#endif
+static void rg_items_probe(rg_batch* b) {
+#ifdef RG_EMUL
+  b->items_slots = 2; b->items_queues = 1;   // (workgroups run one after the other: the first drains the queue, the second finds it empty)
+#else
+  b->items_slots = 0; b->items_queues = 1;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, b->device) != hipSuccess) return;
+  const int cus = prop.multiProcessorCount;
+  // wave slots: LDS granules (1280 B) per CU / per workgroup, capped by the 3 waves per SIMD the kernel is compiled for
+  const int per_cu_lds = (160 * 1024) / (int)(((rgi::rg_lds_launch_bytes(false) + 1279) / 1280) * 1280);
+  const int per_cu = per_cu_lds < 4 * RG_WAVES_PER_SIMD_HOST ? per_cu_lds : 4 * RG_WAVES_PER_SIMD_HOST;
+  int* counts = nullptr;
+  if (hipMalloc((void**)&counts, 16 * 4) != hipSuccess) return;
+  (void)hipMemset(counts, 0, 16 * 4);
+  const int grid = cus * per_cu;
+  hipLaunchKernelGGL(rg_xcc_probe_kernel, dim3(grid), dim3(RG_WAVE), 0, 0, counts);
+  int h[16];
+  if (hipMemcpy(h, counts, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+    int nq = 0; bool ok = true;
+    for (int x = 0; x < 16; x++) if (h[x] > 0) nq = x + 1;
+    for (int x = 0; x < nq; x++) if (h[x] <= 0) ok = false;
+    if (ok && nq >= 1 && nq <= 8) { b->items_slots = grid; b->items_queues = nq; }
+  }
+  (void)hipFree(counts);
+#endif
+}
+int rg_batch_items_info(const rg_batch* b, int* slots, int* queues) {
+  if (!b) return fail("null batch");
+  if (slots) *slots = b->items_slots;
+  if (queues) *queues = b->items_queues;
+  return 0;
+}
+
 #ifdef RG_EMUL
 struct EmulArgs { const RgModelDev* m; RgLaunch launch; };
+static void emul_entry_items(void* a);
 static void emul_entry(void* a) { EmulArgs* p = (EmulArgs*)a; rgs::rg_step_kernel(p->m, p->launch); }
 static void emul_entry_large(void* a) { EmulArgs* p = (EmulArgs*)a; rgl::rg_step_kernel(p->m, p->launch); }
 static void emul_entry_sensors(void* a) { EmulArgs* p = (EmulArgs*)a; rgx::rg_step_kernel(p->m, p->launch); }
+static void emul_entry_items(void* a) { EmulArgs* p = (EmulArgs*)a; rgi::rg_step_items_kernel(p->m, p->launch); }
 #endif
 
 int rg_batch_step_ex(rg_batch* b, const rg_step_args* a) {
@@ -658,7 +722,24 @@ int rg_batch_step_ex(rg_batch* b, const rg_step_args* a) {
   bt.redo = large ? nullptr : a->redo_dev;
   bt.preticks = a->preticks_dev;
   bt.xdata = a->xdata_dev;
-  RgLaunch launch{b->model->aux, b->env, bt, a->nsubsteps, a->nforward_ticks, a->flags};
+  // flags bit 7: substep-granular dispatch (rollout configuration, >= 2 substeps, no debug / profiling / sensor pass): see rg_step_items_kernel
+  const bool items = (a->flags & 128) && !large && !(a->flags & (1 | 2 | 256)) && a->nsubsteps >= 2 && b->items_slots > 0;
+  RgLaunch launch{b->model->aux, b->env, bt, a->nsubsteps, a->nforward_ticks, a->flags, items ? b->items_queues : 1};
+  if (items) {
+    const long long nitems = (long long)bt.B * a->nsubsteps;
+    const int grid = (int)(nitems < b->items_slots ? nitems : b->items_slots);
+    const size_t ldsi = rgi::rg_lds_launch_bytes(false);
+#ifdef RG_EMUL
+    memset(bt.sched, 0, ((size_t)RG_SCHED_PROG + bt.B) * 4);
+    EmulArgs args{b->model->dev_copy, launch};
+    emul_launch(grid, ldsi, emul_entry_items, &args);
+#else
+    HIPCHK(hipMemsetAsync(bt.sched, 0, ((size_t)RG_SCHED_PROG + bt.B) * 4, (hipStream_t)a->stream));
+    hipLaunchKernelGGL(rgi::rg_step_items_kernel, dim3(grid), dim3(RG_WAVE), ldsi, (hipStream_t)a->stream, b->model->dev_copy, launch);
+    HIPCHK(hipGetLastError());
+#endif
+    return 0;
+  }
   const size_t lds = sens ? rgx::rg_lds_launch_bytes(prof) : (large ? rgl::rg_lds_launch_bytes(prof) : rgs::rg_lds_launch_bytes(prof));
 #ifdef RG_EMUL
   EmulArgs args{b->model->dev_copy, launch};
@@ -689,7 +770,7 @@ int rg_batch_mpr_pair(rg_batch* b, int g1, int g2, float margin, float* out_dev,
   const RgModelDev& d = b->model->dev;
   if (g1 < 0 || g2 < 0 || g1 >= d.ngeom || g2 >= d.ngeom) return fail("geom id out of range");
   DeviceGuard g(b->device);
-  RgLaunch launch{b->model->aux, b->env, b->dev, 0, 0, 0};
+  RgLaunch launch{b->model->aux, b->env, b->dev, 0, 0, 0, 1};
 #ifdef RG_EMUL
   EmulMprArgs args{b->model->dev_copy, launch, g1, g2, margin, out_dev};
   emul_launch(b->dev.B, sizeof(rgs::RgLds), emul_mpr_entry, &args);
@@ -736,7 +817,7 @@ int rg_batch_set_constants(rg_batch* b, const int* mask_dev, void* stream) {
   DeviceGuard g(b->device);
   RgBatchDev bt = b->dev;
   bt.active = mask_dev; bt.order = nullptr;
-  RgLaunch launch{b->model->aux, b->env, bt, 0, 0, 0};
+  RgLaunch launch{b->model->aux, b->env, bt, 0, 0, 0, 1};
   const size_t lds = rgl::rg_lds_setconst_bytes();
 #ifdef RG_EMUL
   EmulSetconstArgs args{b->model->dev_copy, launch, (float*)b->dev.envprm};

@@ -41,7 +41,7 @@ struct RgAux {  // extra static tables (kept out of RgModelDev to keep the kerna
 // Everything a launch passes besides the model, as ONE by-value kernel argument that is read through the
 // constant address space (the kernarg segment), so that its ~100 scalars are loaded where they are used
 // instead of living in (or being spilled from) SGPRs for the whole kernel.
-struct RgLaunch { RgAux x; RgEnvDev env; RgBatchDev bt; int nsubsteps, nforward_ticks, flags; };
+struct RgLaunch { RgAux x; RgEnvDev env; RgBatchDev bt; int nsubsteps, nforward_ticks, flags, nqueues; };
 
 // The substep is a sequence of REAL function calls (not inlined): each stage gets its own register
 // allocation, so loop invariants of one stage are not kept alive (or spilled) through all the others.
@@ -82,16 +82,11 @@ typedef const RG_AS4 RgLaunch& RgLRef;
 #endif
 // env handled by this workgroup: the launch may carry a permutation (longest-expected-first dispatch order)
 #ifdef RG_EMUL
-static inline int rg_env(RgLRef L) { return L.bt.order ? L.bt.order[blockIdx.x] : (int)blockIdx.x; }
+static inline int rg_env_blk(RgLRef L) { return L.bt.order ? L.bt.order[blockIdx.x] : (int)blockIdx.x; }
 #else
-__device__ __forceinline__ int rg_env(RgLRef L) { return L.bt.order ? __builtin_amdgcn_readfirstlane(L.bt.order[blockIdx.x]) : (int)blockIdx.x; }
+__device__ __forceinline__ int rg_env_blk(RgLRef L) { return L.bt.order ? __builtin_amdgcn_readfirstlane(L.bt.order[blockIdx.x]) : (int)blockIdx.x; }
 #endif
-// the env's row of model parameters (RG_PRM_* layout): its own if the batch carries per-env overrides, else the model's
-#ifdef RG_EMUL
-static inline const float* rg_prm(const RgModelDev& m, RgLRef L) { return L.bt.envprm ? L.bt.envprm + (size_t)rg_env(L) * RG_NPRM : m.prm_default; }
-#else
-__device__ __forceinline__ const float* rg_prm(const RG_AS4 RgModelDev& m, RgLRef L) { return L.bt.envprm ? L.bt.envprm + (size_t)rg_env(L) * RG_NPRM : m.prm_default; }
-#endif
+// (rg_env / rg_prm, the env of this workgroup and its row of model parameters, are defined per kernel configuration below)
 // ------------------------------------------------------------------------------------------------- small math
 struct alignas(16) rgf4 { float x, y, z, w; };
 struct v3 { float x, y, z; };
@@ -228,6 +223,31 @@ __device__ __forceinline__ long long rg_clock() { return (long long)__builtin_am
 __device__ __forceinline__ long long rg_clock() { return (long long)__builtin_readcyclecounter(); }
 #endif
 #endif
+// ---- cross-workgroup plumbing of the substep-granular dispatch (rg_step_items_kernel).  All work items of an env run on ONE
+// XCD (queue = XCC id), so the XCD's L2 is the point of coherence: the producer's plain stores are in L2 once its vmcnt
+// has drained (the vector L1 is write-through), the consumer reads everything a previous item wrote with sc1 loads (agent-scope
+// relaxed atomics: they bypass the CU's L1, which is never refreshed by another CU's stores).  No cache-wide fence anywhere.
+#ifdef RG_EMUL
+static inline int rg_xcc_id() { return 0; }
+static inline int rg_ld_sc1(const int* p) { return *p; }
+static inline float rg_ld_sc1(const float* p) { return *p; }
+static inline unsigned rg_ld_sc1(const unsigned* p) { return *p; }
+static inline void rg_st_sc1(int* p, int v) { *p = v; }
+static inline int rg_ticket(int* p) { int o = *p; *p = o + 1; return o; }
+static inline void rg_drain_stores() {}
+static inline void rg_pause() {}
+static inline int rg_first(int v) { return __shfl(v, 0); }
+#else
+__device__ __forceinline__ int rg_xcc_id() { return (int)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15); }   // hwreg(HW_REG_XCC_ID, 0, 4)
+__device__ __forceinline__ int rg_ld_sc1(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned rg_ld_sc1(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float rg_ld_sc1(const float* p) { return __builtin_bit_cast(float, __hip_atomic_load((const int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+__device__ __forceinline__ void rg_st_sc1(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int rg_ticket(int* p) { return __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void rg_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void rg_pause() { __builtin_amdgcn_s_sleep(16); }
+__device__ __forceinline__ int rg_first(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#endif
 #define LANE ((int)threadIdx.x)
 #define SYNC() __syncthreads()
 #define PFOR(i, n) for (int i = LANE; i < (n); i += RG_WAVE)
@@ -264,6 +284,16 @@ __device__ __forceinline__ void cross_force(float* r, const float* vel, const fl
 #endif
 #undef RG_HCOEF_LDS
 #define RG_HCOEF_LDS (RG_MAXCON <= 32)   /* rollout configuration: its position side is the larger one anyway */
+#ifndef RG_ITEMS
+#define RG_ITEMS 0     /* 1: this configuration is the substep-granular one: rg_step_items_kernel instead of rg_step_kernel, rows that a previous
+                          work item of the env may have written are read with L1-bypassing loads, the env comes from the work item */
+#endif
+#undef RG_ROW_LD
+#if RG_ITEMS
+#define RG_ROW_LD(p) rg_ld_sc1(p)
+#else
+#define RG_ROW_LD(p) (*(p))
+#endif
 #ifndef RG_SETCONST
 #define RG_SETCONST 0  /* 1: this configuration also carries rg_setconst_kernel (one instantiation is enough) */
 #endif
@@ -307,6 +337,9 @@ struct RgLds {
   float c_aref0[RG_MAXCON], c_kb[RG_MAXCON];   // reference acceleration of the contact's pyramid rows = aref0 - kb * (row velocity); the rows' lanes hold the result (RowRegs::paref)
   unsigned int status;
   int has_xfrc;   // any non-zero entry in the env's xfrc_applied row (checked once per launch)
+#if RG_ITEMS
+  int cur_env;    // the env of the work item this workgroup is on
+#endif
   union {
     struct {  // ---- pos
       union {  // slot A
@@ -350,6 +383,24 @@ struct RgLds {
 // dynamic LDS bytes of a launch
 static inline size_t rg_lds_launch_bytes(bool profiling) { return profiling ? sizeof(RgLds) : offsetof(RgLds, prof); }
 
+// the env this workgroup works on: from the block index (through the dispatch permutation), or -- substep-granular
+// configuration -- from the work item it holds; and the env's row of model parameters (RG_PRM_* layout): its own if the
+// batch carries per-env overrides, else the model's
+#ifdef RG_EMUL
+#if RG_ITEMS
+static inline int rg_env(RgLRef L) { return RG_S().cur_env; }
+#else
+static inline int rg_env(RgLRef L) { return rg_env_blk(L); }
+#endif
+static inline const float* rg_prm(const RgModelDev& m, RgLRef L) { return L.bt.envprm ? L.bt.envprm + (size_t)rg_env(L) * RG_NPRM : m.prm_default; }
+#else
+#if RG_ITEMS
+__device__ __forceinline__ int rg_env(RgLRef L) { return __builtin_amdgcn_readfirstlane(RG_S().cur_env); }
+#else
+__device__ __forceinline__ int rg_env(RgLRef L) { return rg_env_blk(L); }
+#endif
+__device__ __forceinline__ const float* rg_prm(const RG_AS4 RgModelDev& m, RgLRef L) { return L.bt.envprm ? L.bt.envprm + (size_t)rg_env(L) * RG_NPRM : m.prm_default; }
+#endif
 // ------------------------------------------------------------------------------------------------- position stage
 // data.xipos of body b (com of the body in the world): not stored, its three readers derive it from the body frame
 __device__ __forceinline__ v3 rg_xipos(RgM m, const RgLds& s, int b) { return ld3(s.xpos + 3 * b) + qrot(ldq(s.xquat + 4 * b), ld3(m.body_ipos + 3 * b)); }
@@ -1155,7 +1206,7 @@ template <int G> RG_STAGE void rg_narrow_phase1(RgCtx c, int ncand) {
         v3 c0 = A.pos - B.pos;
         if (mz(c0.x) && mz(c0.y) && mz(c0.z)) c0.x += 1e-6f;
         v3 dir = normalized(c0 * -1.0f);
-        if (sepdir) { rgf4 cd = sepdir[p]; if (cd.x * cd.x + cd.y * cd.y + cd.z * cd.z > 0.5f) dir = mk3(cd.x, cd.y, cd.z); }  // last substep's separating direction first
+        if (sepdir) { rgf4 cd; const float* sp_ = (const float*)(sepdir + p); cd.x = RG_ROW_LD(sp_); cd.y = RG_ROW_LD(sp_ + 1); cd.z = RG_ROW_LD(sp_ + 2); cd.w = 0.f; if (cd.x * cd.x + cd.y * cd.y + cd.z * cd.z > 0.5f) dir = mk3(cd.x, cd.y, cd.z); }  // last substep's separating direction first
         SupPt p1; mpr_support<G>(E, A, B, dir, p1);
         float d = dot(p1.v, dir);
         keep = d > 0;
@@ -1231,14 +1282,14 @@ __device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, const flo
   int nt = 0; bool bbany = false, plany = false;   // (bbany: this lane queued a pair of two boxes — those have their own narrowphase routine)
   int gg_next[4]; float lb_next[4];
 #pragma unroll
-  for (int k = 0; k < 4; k++) { int p = k * RG_WAVE + LANE, pc = p < m.npair ? p : m.npair - 1; gg_next[k] = m.pair_gg[pc]; lb_next[k] = pairlb ? pairlb[pc] : 0.f; }
+  for (int k = 0; k < 4; k++) { int p = k * RG_WAVE + LANE, pc = p < m.npair ? p : m.npair - 1; gg_next[k] = m.pair_gg[pc]; lb_next[k] = pairlb ? RG_ROW_LD(pairlb + pc) : 0.f; }
   for (int r0 = 0; r0 < nround; r0 += 4) {   // four rounds per trip: eight independent loads in flight per lane, requested one trip ahead (a trip only writes the bounds of its own pairs)
     int gg[4]; float lbv[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) { gg[k] = gg_next[k]; lbv[k] = lb_next[k]; }
     if (r0 + 4 < nround) {
 #pragma unroll
-      for (int k = 0; k < 4; k++) { int p = (r0 + 4 + k) * RG_WAVE + LANE, pc = p < m.npair ? p : m.npair - 1; gg_next[k] = m.pair_gg[pc]; lb_next[k] = pairlb ? pairlb[pc] : 0.f; }
+      for (int k = 0; k < 4; k++) { int p = (r0 + 4 + k) * RG_WAVE + LANE, pc = p < m.npair ? p : m.npair - 1; gg_next[k] = m.pair_gg[pc]; lb_next[k] = pairlb ? RG_ROW_LD(pairlb + pc) : 0.f; }
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -2398,6 +2449,7 @@ RG_STAGE void st_dump(RgCtx c, int which, int nefc, int iters) {
 #ifndef RG_WAVES_PER_SIMD
 #define RG_WAVES_PER_SIMD 3
 #endif
+#if !RG_ITEMS
 __global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_kernel(const RgModelDev* mp, RgLaunch launch) {
   RG_MAKE_CTX();
   RgM m = RG_M(c);
@@ -2407,6 +2459,9 @@ __global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_kernel(con
   if ((int)blockIdx.x >= L.bt.B) return;
   int e = rg_env(L);
   if (L.bt.active && !L.bt.active[e]) return;
+  // flags bit 8: `active` is the redo array of a rollout launch, whose entries say where to resume: entry - 1 = the first substep
+  // that is still to do (the substep-granular rollout kernel hands an env over in the middle of its env.step)
+  const int sub0 = ((flags & 256) && L.bt.active) ? L.bt.active[e] - 1 : 0;
   long long tk0 = rg_clock();
   // ---- load the env's state row
   PFOR(i, m.nq) s.qpos[i] = L.bt.qpos[(size_t)e * m.nq + i];
@@ -2420,7 +2475,7 @@ __global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_kernel(con
   if ((L.flags & 2) && LANE < RG_NPROF) s.prof[LANE] = 0;
   st_build_row_desc(c);
   // ---- action -> ctrl (robot_interface.py:247-278 with the hand's position->control matrix)
-  if (L.bt.preticks) {
+  if (L.bt.preticks && sub0 == 0) {
     // reset_goal's two state-less forwards (robot_env.py:893-909 -> _observe_sync), booked by rg_env_post_step: same state,
     // same stored ctrl as when they were owed, so running them here is the same arithmetic
     const int pre = L.bt.preticks[e];
@@ -2434,7 +2489,7 @@ __global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_kernel(con
     }
   }
   // envs on `hold` (scripted reset recipe) and envs whose action row holds a non-finite entry keep their stored ctrl row
-  bool use_action = L.bt.action && !(L.bt.hold && L.bt.hold[e]);
+  bool use_action = L.bt.action && !(L.bt.hold && L.bt.hold[e]) && sub0 == 0;   // (a resumed env.step: the action went into the stored ctrl row at its first substep)
   if (use_action) {
     float nf = 0; PFOR(u, m.nu) nf += (fabsf(L.bt.action[(size_t)e * m.nu + u]) <= 3.0e38f) ? 0.f : 1.f;
     if (wave_sum(nf) > 0) { use_action = false; if (LANE == 0) s.status |= RG_STATUS_BAD_ACTION; }
@@ -2451,7 +2506,7 @@ __global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_kernel(con
   SYNC();
   float st_ncon = 0, st_nefc = 0, st_iter = 0;
   bool bad = false;
-  for (int sub = 0; sub < nsubsteps; sub++) {
+  for (int sub = sub0; sub < nsubsteps; sub++) {
     // mj_checkPos / mj_checkVel
     float bd = 0; PFOR(i, m.nq) bd += (fabsf(s.qpos[i]) < 1e10f) ? 0.f : 1.f; PFOR(i, m.nv) bd += (fabsf(s.qvel[i]) < 1e10f) ? 0.f : 1.f;
     if (wave_sum(bd) > 0) { bad = true; break; }
@@ -2475,7 +2530,7 @@ __global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_kernel(con
       if (LANE == 0) xd[RG_XD_NCON] = (float)s.ncon;
       PFOR(ci, nc) { int gg = m.pair_gg[s.c_pair[ci]]; float* o = xd + RG_XD_CONTACT + 3 * ci; o[0] = (float)(gg & 255); o[1] = (float)(gg >> 8); o[2] = s.c_dist[ci]; }
     }
-    if (L.bt.redo && (s.status & ~status0 & (RG_STATUS_CON_FULL | RG_STATUS_CAND_FULL))) {
+    if (L.bt.redo && ((s.status & ~status0 & (RG_STATUS_CON_FULL | RG_STATUS_CAND_FULL)) || ((RG_L(c).flags & 512) && s.ncon > 5))) {   // (flags bit 9: test hook, "more than 5 contacts do not fit")
       // more contacts / candidates than this configuration holds: leave the env exactly as it was (state rows are
       // written at the end; the distance-bound cache was advanced by the substeps done so far, so it is voided) and
       // hand it to the large configuration
@@ -2523,7 +2578,7 @@ __global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_kernel(con
       // data.sensordata: the LAST state-less forward of the reference in full — contacts and their forces at the final state
       // (mj_sensorAcc reads efc_force); its actuation stage is the last controller tick
       st_crb(c); st_velocity(c); st_collision(c); st_make_constraint(c);
-      if (L.bt.redo && (s.status & ~status0 & (RG_STATUS_CON_FULL | RG_STATUS_CAND_FULL))) {
+      if (L.bt.redo && ((s.status & ~status0 & (RG_STATUS_CON_FULL | RG_STATUS_CAND_FULL)) || ((RG_L(c).flags & 512) && s.ncon > 5))) {   // (flags bit 9: test hook, "more than 5 contacts do not fit")
         if (L.bt.pairlb) { float* lb = L.bt.pairlb + (size_t)e * m.npair; PFOR(i, m.npair) lb[i] = 0.f; }
         if (LANE == 0) L.bt.redo[e] = 1;
         return;
@@ -2549,7 +2604,7 @@ __global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_kernel(con
     L.bt.time[e] = (float)(tk0 & 0xFFFFFF);   // analysis build only: when the env's wave started (low 24 bits of the 100 MHz counter) instead of the simulation time
 #endif
     if (L.bt.cost) L.bt.cost[e] = (float)(rg_clock() - tk0);
-    if (L.bt.stats) { float* st = L.bt.stats + 4 * (size_t)e; st[0] += st_ncon; st[1] += st_nefc; st[2] += st_iter; st[3] += nsubsteps; }
+    if (L.bt.stats) { float* st = L.bt.stats + 4 * (size_t)e; st[0] += st_ncon; st[1] += st_nefc; st[2] += st_iter; st[3] += nsubsteps - sub0; }
   }
   if ((flags & 2) && L.bt.dbg && LANE < RG_NPROF) L.bt.dbg[(size_t)e * RG_DBG_SIZE + RG_DBG_CON + LANE] = s.prof[LANE];  // stage cycle counters (overlays the contact dump)
   // ---- observation row (robot_env.py:714-743; keys/order: DESIGN.md "observation layout")
@@ -2581,6 +2636,204 @@ __global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_kernel(con
   }
 }
 
+#endif   // !RG_ITEMS
+
+#if RG_ITEMS
+// The env.step of the rollout configuration as B x nsubsteps WORK ITEMS instead of B jobs (VERDICT r02 item 6 i).
+// With one workgroup per env.step a launch of 8192 envs on 3072 wave slots is 2.67 jobs per slot whose lengths vary
+// 3.5 x: the last third of the launch is ramp-down (slots 81 % utilised, profiles/r02_residency.txt).  Here a launch is a
+// grid of PERSISTENT workgroups (one per wave slot) that draw (env, substep) items from a queue in substep-major order --
+// substep 0 of every env (longest-expected env first), then substep 1 of every env, ... -- so all envs advance together
+// and the slots stay full until the last row: the tail is one mj_step long instead of one env.step.
+//   * item (e, s) needs item (e, s - 1): it waits on the env's progress word.  Its predecessor was drawn earlier from the
+//     same queue by a workgroup that is therefore running (or done): no order of dispatch can deadlock, and with ~1000 other
+//     items between the two the wait is almost never entered.
+//   * the env's state travels through its HBM rows (qpos, qvel, ctrl, PID state, warm start: 760 B) and its collision caches;
+//     nothing else crosses a substep boundary in the one-workgroup kernel either (registers: PID state, warm start).
+//   * one queue per XCD (the L2s of different XCDs are not coherent): queue x holds the envs at positions k = x (mod nqueues)
+//     of the dispatch order and is served only by workgroups whose XCC id is x, so an env never leaves its XCD during a
+//     launch, that XCD's L2 is the point of coherence, and the hand-off needs no cache-wide fence: plain stores, a vmcnt
+//     drain, then the progress word; the consumer polls it and reads the rows with L1-bypassing loads (RG_ROW_LD).
+//   * an env that exceeds the rollout capacities in substep s raises redo[e] = s + 1: its later items skip, and the large
+//     configuration resumes it at substep s (rg_step_kernel, flags bit 8).
+// Results are bit-identical to rg_step_kernel (same stages on the same bytes; tested).
+__device__ __forceinline__ void rg_item_publish(int* prog, int e, int value) {
+  rg_drain_stores();   // this wave's row stores have reached L2 (gfx9: stores count on vmcnt; the vector L1 is write-through)
+  SYNC();
+  if (LANE == 0) rg_st_sc1(prog + e, value);
+}
+__global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_items_kernel(const RgModelDev* mp, RgLaunch launch) {
+  RG_MAKE_CTX();
+  RgM m = RG_M(c);
+  RgLRef L = RG_L(c);
+  RgLds& s = RG_S();
+  const int nsub = L.nsubsteps, B = L.bt.B, nforward_ticks = L.nforward_ticks, nq_ = L.nqueues;
+  int* sched = L.bt.sched;
+  int* prog = sched + RG_SCHED_PROG;
+  const int xq = rg_xcc_id() % nq_;
+  const int nx = (B - xq + nq_ - 1) / nq_;   // envs at positions k = nq_ * j + xq < B
+  const int nitems = nx * nsub;
+  for (;;) {
+    SYNC();   // (the previous item's LDS image is dead only when every lane is here)
+    int t = 0;
+    if (LANE == 0) t = rg_ticket(sched + 16 * xq);
+    t = rg_first(t);
+    if (t >= nitems) break;
+    const int sub = t / nx, k = nq_ * (t - sub * nx) + xq;
+    const int e = L.bt.order ? rg_first(L.bt.order[k]) : k;
+    if (L.bt.active && !L.bt.active[e]) continue;   // (every item of an inactive env skips: nothing to publish)
+    if (LANE == 0) s.cur_env = e;
+    int pv = 0;
+    if (sub > 0) {
+      if (LANE == 0) { while (((pv = rg_ld_sc1(prog + e)) & 0xFFFF) < sub) rg_pause(); }
+      pv = rg_first(pv);
+    }
+    SYNC();
+    const bool last = sub == nsub - 1;
+    const bool handed_over = sub > 0 && L.bt.redo && rg_first(rg_ld_sc1(L.bt.redo + e)) != 0;
+    if (handed_over) { rg_item_publish(prog, e, (sub + 1) | (pv & RG_SCHED_BAD)); continue; }
+    const long long tk0 = rg_clock();
+    // ---- the env's state row
+    PFOR(i, m.nq) s.qpos[i] = RG_ROW_LD(L.bt.qpos + (size_t)e * m.nq + i);
+    float warmr = 0.f, pidr[3] = {0.f, 0.f, 0.f};
+    if (LANE < m.nv) { s.qvel[LANE] = RG_ROW_LD(L.bt.qvel + (size_t)e * m.nv + LANE); warmr = RG_ROW_LD(L.bt.qacc_warmstart + (size_t)e * m.nv + LANE); }
+    if (LANE < m.nu) for (int q = 0; q < 3; q++) pidr[q] = RG_ROW_LD(L.bt.pid + (size_t)e * 3 * m.nu + 3 * LANE + q);
+    const float* P = rg_prm(m, L);
+    { float nz = 0; PFOR(i, 6 * m.nbody) nz += P[RG_PRM_XFRC + i] != 0.f ? 1.f : 0.f; nz = wave_sum(nz); if (LANE == 0) s.has_xfrc = nz > 0; }
+    const unsigned status0 = RG_ROW_LD(L.bt.status + e);
+    if (LANE == 0) s.status = status0;
+    st_build_row_desc(c);
+    bool cleared_preticks = false;
+    if (sub == 0) {
+      if (L.bt.preticks) {   // reset_goal's two state-less forwards, owed from the previous step (see rg_step_kernel)
+        const int pre = L.bt.preticks[e];
+        if (pre > 0) {
+          PFOR(u, m.nu) s.ctrl[u] = L.bt.ctrl[(size_t)e * m.nu + u];
+          SYNC();
+          st_kinematics(c); st_com_pos(c); st_tendon(c);
+          for (int q = 0; q < pre; q++) st_pid(c, pidr);
+        }
+        cleared_preticks = true;
+      }
+      bool use_action = L.bt.action && !(L.bt.hold && L.bt.hold[e]);
+      if (use_action) {
+        float nf = 0; PFOR(u, m.nu) nf += (fabsf(L.bt.action[(size_t)e * m.nu + u]) <= 3.0e38f) ? 0.f : 1.f;
+        if (wave_sum(nf) > 0) { use_action = false; if (LANE == 0) s.status |= RG_STATUS_BAD_ACTION; }
+      }
+      if (use_action) {
+        PFOR(u, m.nu) {
+          float lo = P[RG_PRM_ACT_CTRLRANGE + 2 * u], hi = P[RG_PRM_ACT_CTRLRANGE + 2 * u + 1], centre;
+          if (L.env.relative_action) { centre = 0; for (int j = 0; j < L.env.n_hand_jnt; j++) centre += L.env.pos_to_ctrl[u * L.env.n_hand_jnt + j] * s.qpos[L.env.hand_qposadr + j]; }
+          else centre = 0.5f * (hi + lo);
+          float a = clampf(L.bt.action[(size_t)e * m.nu + u], -1.f, 1.f);
+          s.ctrl[u] = clampf(centre + a * 0.5f * (hi - lo), lo, hi);
+        }
+      } else { PFOR(u, m.nu) s.ctrl[u] = L.bt.ctrl[(size_t)e * m.nu + u]; }
+    } else { PFOR(u, m.nu) s.ctrl[u] = RG_ROW_LD(L.bt.ctrl + (size_t)e * m.nu + u); }
+    SYNC();
+    // ---- one mj_step (skipped once a substep of this env.step has failed its checks: rg_step_kernel breaks out of its loop)
+    bool bad = (pv & RG_SCHED_BAD) != 0, newly_bad = false;
+    float st_ncon = 0, st_nefc = 0, st_iter = 0;
+    if (!bad) {
+      float bd = 0; PFOR(i, m.nq) bd += (fabsf(s.qpos[i]) < 1e10f) ? 0.f : 1.f; PFOR(i, m.nv) bd += (fabsf(s.qvel[i]) < 1e10f) ? 0.f : 1.f;
+      if (wave_sum(bd) > 0) bad = newly_bad = true;
+    }
+    if (!bad) {
+      st_kinematics(c); st_com_pos(c); st_tendon(c);
+      st_crb(c); st_velocity(c);
+      st_collision(c);
+      st_make_constraint(c);
+      if (L.bt.xdata && last) {   // data.ncon / data.contact[i].{geom1, geom2, dist} of the last mj_step
+        float* xd = L.bt.xdata + (size_t)e * RG_XDATA;
+        const int nc = s.ncon < RG_DBG_MAXCON ? s.ncon : RG_DBG_MAXCON;
+        if (LANE == 0) xd[RG_XD_NCON] = (float)s.ncon;
+        PFOR(ci, nc) { int gg = m.pair_gg[s.c_pair[ci]]; float* o = xd + RG_XD_CONTACT + 3 * ci; o[0] = (float)(gg & 255); o[1] = (float)(gg >> 8); o[2] = s.c_dist[ci]; }
+      }
+      if (L.bt.redo && ((s.status & ~status0 & (RG_STATUS_CON_FULL | RG_STATUS_CAND_FULL)) || ((RG_L(c).flags & 512) && s.ncon > 5))) {   // (flags bit 9: test hook, "more than 5 contacts do not fit")
+        // more contacts / candidates than this configuration holds: the env's rows stay as this item found them (in substep 0:
+        // as the launch found them, owed ticks and action included) and the large configuration takes over at this substep
+        if (L.bt.pairlb) { float* lb = L.bt.pairlb + (size_t)e * m.npair; PFOR(i, m.npair) lb[i] = 0.f; }
+        if (LANE == 0) L.bt.redo[e] = sub + 1;
+        rg_item_publish(prog, e, sub + 1);
+        continue;
+      }
+      st_pid(c, pidr);
+      st_smooth(c);
+      st_factor_smooth(c);
+      const int packed = st_solve(c, warmr), iters = packed & 255, nefc = packed >> 8;
+      st_ncon = (float)s.ncon; st_nefc = (float)nefc; st_iter = (float)iters;
+      float bd = 0; PFOR(i, m.nv) bd += (fabsf(s.qacc[i]) < 1e10f) ? 0.f : 1.f;
+      if (wave_sum(bd) > 0) bad = newly_bad = true;
+      else warmr = st_euler(c, warmr);
+    }
+    if (newly_bad && LANE == 0) s.status |= RG_STATUS_BAD_STATE;
+    // ---- last item: the state-less forward() calls of the reference and the readout (see rg_step_kernel)
+    if (last) {
+      const int nticks = L.bt.nticks ? L.bt.nticks[e] : nforward_ticks;
+      if (nticks > 0 || L.bt.obs || L.bt.xdata) {
+        st_kinematics(c);
+        if (L.bt.xdata) {
+          float* xd = L.bt.xdata + (size_t)e * RG_XDATA;
+          PFOR(i, 3 * m.nbody) xd[RG_XD_XPOS + i] = s.xpos[i];
+          PFOR(i, 4 * m.nbody) xd[RG_XD_XQUAT + i] = s.xquat[i];
+          PFOR(i, 3 * m.nsite) xd[RG_XD_SITE_XPOS + i] = s.spos[i];
+        }
+        st_com_pos(c); st_tendon(c);
+        for (int q = 0; q < nticks; q++) st_pid(c, pidr);
+        if (L.bt.xdata) PFOR(u, m.nu) L.bt.xdata[(size_t)e * RG_XDATA + RG_XD_ACT_FORCE + u] = s.actfrc[u];
+      }
+    }
+    // ---- write back
+    PFOR(i, m.nq) L.bt.qpos[(size_t)e * m.nq + i] = s.qpos[i];
+    if (LANE < m.nv) { L.bt.qvel[(size_t)e * m.nv + LANE] = s.qvel[LANE]; L.bt.qacc_warmstart[(size_t)e * m.nv + LANE] = warmr; }
+    if (LANE < m.nu) for (int q = 0; q < 3; q++) L.bt.pid[(size_t)e * 3 * m.nu + 3 * LANE + q] = pidr[q];
+    if (sub == 0) PFOR(u, m.nu) L.bt.ctrl[(size_t)e * m.nu + u] = s.ctrl[u];
+    if (LANE == 0) {
+      if (cleared_preticks) L.bt.preticks[e] = 0;
+      if (s.status != status0) L.bt.status[e] = s.status;
+      if (last) L.bt.time[e] += nsub * P[RG_PRM_TIMESTEP];
+      if (L.bt.cost) { const float cy = (float)(rg_clock() - tk0); L.bt.cost[e] = sub == 0 ? cy : RG_ROW_LD(L.bt.cost + e) + cy; }
+      if (L.bt.stats) { float* st = L.bt.stats + 4 * (size_t)e; st[0] = RG_ROW_LD(st) + st_ncon; st[1] = RG_ROW_LD(st + 1) + st_nefc; st[2] = RG_ROW_LD(st + 2) + st_iter; st[3] = RG_ROW_LD(st + 3) + 1.f; }
+    }
+    // ---- observation row of the final state (robot_env.py:714-743; see rg_step_kernel)
+    if (last && L.bt.obs) {
+      int od = 3 + 4 + m.nq + m.nv + L.env.n_hand_jnt + 15;
+      float* o = L.bt.obs + (size_t)e * od;
+      PFOR(i, 3) o[i] = s.qpos[L.env.cube_pos_qposadr + i];
+      { float sg = s.qpos[L.env.cube_quat_qposadr] < 0 ? -1.f : 1.f; PFOR(i, 4) o[3 + i] = sg * s.qpos[L.env.cube_quat_qposadr + i]; }
+      PFOR(i, m.nq) o[7 + i] = (i >= L.env.target_qposadr && i < L.env.target_qposadr + L.env.target_nq) ? 0.f : s.qpos[i];
+      PFOR(i, m.nv) o[7 + m.nq + i] = (i >= L.env.target_dofadr && i < L.env.target_dofadr + L.env.target_nv) ? 0.f : s.qvel[i];
+      PFOR(i, L.env.n_hand_jnt) o[7 + m.nq + m.nv + i] = s.qpos[L.env.hand_qposadr + i];
+      PFOR(i, 5) {
+        v3 r0 = ld3(s.spos + 3 * L.env.ref_site[0]), r1 = ld3(s.spos + 3 * L.env.ref_site[1]), r2 = ld3(s.spos + 3 * L.env.ref_site[2]);
+        v3 a = normalized(r0 - r1), cc = normalized(r2 - r1), b = cross(a, cc);
+        v3 tt = ld3(s.spos + 3 * L.env.tip_site[i]) - r1;
+        float* ot = o + 7 + m.nq + m.nv + L.env.n_hand_jnt + 3 * i;
+        ot[0] = dot(tt, a); ot[1] = dot(tt, b); ot[2] = dot(tt, cc);
+      }
+      if (L.bt.goal_quat && L.bt.goal_dist && LANE == 0) {
+        q4 g = ldq(L.bt.goal_quat + 4 * (size_t)e), cq = ldq(s.qpos + L.env.cube_quat_qposadr);
+        cq.x = -cq.x; cq.y = -cq.y; cq.z = -cq.z;
+        q4 dq = qmul(g, cq);
+        L.bt.goal_dist[e] = 2.0f * acosf(clampf(fabsf(dq.w), -1.f, 1.f));
+      }
+    }
+    rg_item_publish(prog, e, (sub + 1) | (bad ? RG_SCHED_BAD : 0));
+  }
+  // ---- the last workgroup to leave checks that every queue was drained (a queue whose XCD received no workgroup would be left
+  //      standing: the host probes the dispatch once before it enables this kernel, this is the run-time net under that)
+  if (LANE == 0) {
+    const int g = rg_ticket(sched + RG_SCHED_FIN);
+    if (g == (int)gridDim.x - 1) {
+      bool ok = true;
+      for (int x = 0; x < nq_; x++) { const int n = (B - x + nq_ - 1) / nq_ * nsub; if (rg_ld_sc1(sched + 16 * x) < n) ok = false; }
+      if (!ok) L.bt.status[0] |= RG_STATUS_SCHED;
+    }
+  }
+}
+#endif   // RG_ITEMS
+
+#if !RG_ITEMS
 // Collision unit-test hook: kinematics of each env's stored qpos, then one MPR query between two geoms.
 // out[e][8] = hit, depth, dir3, pos3 (world)
 __global__ void __launch_bounds__(RG_WAVE) rg_mpr_pair_kernel(const RgModelDev* mp, RgLaunch launch, int g1, int g2, float margin, float* out) {
@@ -2706,10 +2959,12 @@ __global__ void rg_copy_rows_kernel(float* dst, const float* src, const int* mas
   for (int i = LANE; i < ncols; i += RG_WAVE) dst[(size_t)e * n + col0 + i] = src[(size_t)e * ncols + i];
   if (pairlb) for (int i = LANE; i < npair; i += RG_WAVE) pairlb[(size_t)e * npair + i] = 0.f;
 }
+#endif   // !RG_ITEMS (hooks and helper kernels exist once, in the classic configurations)
 }  // namespace RG_NS
 #undef RG_MAXPYR
 #undef RG_SENSORS
 #undef RG_SETCONST
+#undef RG_ITEMS
 #undef RG_PSLOTS
 #undef RG_RSLOTS
 #undef RG_MSLOTS

@@ -79,6 +79,7 @@ enum {
 #define RG_STATUS_ROW_FULL 8u    // more friction/limit rows than RG_MAXROW
 #define RG_STATUS_BAD_FACTOR 16u // Cholesky pivot <= 0
 #define RG_STATUS_BAD_ACTION 32u // non-finite entry in the env's action row (the row is ignored: ctrl keeps its value)
+#define RG_STATUS_SCHED 64u      // substep-granular dispatch: a launch ended with work items left in a queue (raised on env 0; never observed)
 
 enum { RG_JNT_FREE = 0, RG_JNT_BALL = 1, RG_JNT_SLIDE = 2, RG_JNT_HINGE = 3 };
 enum { RG_GEOM_PLANE = 0, RG_GEOM_SPHERE = 2, RG_GEOM_CAPSULE = 3, RG_GEOM_ELLIPSOID = 4, RG_GEOM_CYLINDER = 5, RG_GEOM_BOX = 6, RG_GEOM_MESH = 7 };
@@ -192,7 +193,12 @@ struct RgBatchDev {
   float* goal_dist;     // [B]
   float* stats;         // [B][4]: sum ncon, sum nefc, sum newton iters, substeps
   float* dbg;           // optional [B][RG_DBG_SIZE] stage dump of the first forward pass
+  int* sched;           // [RG_SCHED_PROG + B] substep-granular dispatch (rg_step_items_kernel): queue heads (one per XCD, 64 B apart), exit counter,
+                        // then per env the number of substeps of the current launch that are complete (| RG_SCHED_BAD)
 };
+#define RG_SCHED_FIN 128
+#define RG_SCHED_PROG 192
+#define RG_SCHED_BAD (1 << 16)
 
 // debug-dump layout (floats)
 #define RG_DBG_XPOS 0                                   // nbody*3

@@ -19,6 +19,10 @@ from robogym_amd.mujoco.model_blob import pack_model
 #: final triangle, and free of libccd's rounding-level tie breaks on flat contacts; the tight-tolerance parity tests use it on both sides.
 #: The flag is round 1's contact generation as a whole: with it box-box pairs go through MPR (one contact) instead of the multi-point routine.
 MPR_PLANE_DEPTH = os.environ.get("RG_MPR_PLANE", "0") == "1"
+# Substep-granular dispatch of the rollout launches (rg_step_args.flags bit 7, rg_step_items_kernel): persistent workgroups draw
+# (env, substep) work items, so the wave slots stay full to the end of a launch.  Bit-identical results; RG_SUBSTEP_ITEMS=0
+# (or this switch) keeps one workgroup per env.step.
+SUBSTEP_ITEMS = os.environ.get("RG_SUBSTEP_ITEMS", "1") == "1"
 
 
 class BatchedSimulationInterface:
@@ -313,8 +317,13 @@ class BatchedSimulationInterface:
                     self._side = torch.cuda.Stream(device=self.device)
                 self._side.wait_stream(cur)
                 launch(_native.RG_CFG_LARGE, big.contiguous(), None, self._side)
+        base_flags = a.flags
+        if SUBSTEP_ITEMS:
+            a.flags = base_flags | _native.RG_FLAG_SUBSTEP_ITEMS
         launch(_native.RG_CFG_ROLLOUT, act0, self._redo, cur)
+        a.flags = base_flags | _native.RG_FLAG_RESUME      # redo[e] - 1 = the substep at which the env was handed over
         launch(_native.RG_CFG_LARGE, self._redo, None, cur)
+        a.flags = base_flags
         if large_mask is not None and not self._emul:
             cur.wait_stream(self._side)
 

@@ -32,7 +32,9 @@ def test_native_library_is_the_hip_build():
         assert "librgstep.so" in f.read()
 
 
-def test_stage_dump_matches_oracle_gpu(gpu_pair):
+def test_stage_dump_matches_oracle_gpu(gpu_pair, kernel_variant):
+    """One mj_step from a settled state (cube flat on the palm, 4 contacts), stage by stage.  Contact normals: plane 2e-4;
+    default 2e-2 (flat contact: the final portal triangle of libccd hangs on a tie break; distance and position still 1e-6)."""
     from tests.helpers import sync_state_from_oracle
 
     sim, ora = gpu_pair
@@ -60,12 +62,14 @@ def test_stage_dump_matches_oracle_gpu(gpu_pair):
         k = dbg[off + 4 + 8 * c: off + 12 + 8 * c]
         assert abs(k[0] - oc["dist"]) < 1e-6
         np.testing.assert_allclose(k[1:4], oc["pos"], atol=1e-6)
-        np.testing.assert_allclose(k[4:7], oc["frame"][0], atol=2e-4)
+        np.testing.assert_allclose(k[4:7], oc["frame"][0], atol=kernel_variant.tol(2e-4, 2e-2))
 
 
-def test_resync_substep_errors_gpu(gpu_pair):
+def test_resync_substep_errors_gpu(gpu_pair, kernel_variant):
     """fp32 tolerance per mj_step, kernel restarted from the oracle state every substep:
-    qpos <= 2e-6 (+ h * qvel tolerance), qvel median <= 2e-4, worst multi-contact impact <= 5e-2."""
+    qpos <= 2e-6 (+ h * qvel tolerance), qvel median <= 2e-4, worst multi-contact impact <= 5e-2 (plane) / 5e-1 (default: one
+    contact normal on the other side of a libccd tie break is a different impulse: the fp32 build of the oracle shows qvel
+    max 5e-1 against the fp64 build, profiles/r03_precision.txt)."""
     from tests.helpers import resync_errors
 
     sim, ora = gpu_pair
@@ -73,8 +77,9 @@ def test_resync_substep_errors_gpu(gpu_pair):
     rng = np.random.RandomState(3)
     errs = resync_errors(sim, ora, rng.uniform(-1, 1, (6, 20)), substep_level=True)
     print("substep resync errors: qpos max %.2e | qvel median %.2e p90 %.2e max %.2e" % (errs[:, 0].max(), np.median(errs[:, 1]), np.percentile(errs[:, 1], 90), errs[:, 1].max()))
-    assert errs[:, 0].max() < 2e-6 + 0.008 * 5e-2
-    assert np.median(errs[:, 1]) < 2e-4 and np.percentile(errs[:, 1], 90) < 2e-3 and errs[:, 1].max() < 5e-2
+    vmax = kernel_variant.tol(5e-2, 5e-1)
+    assert errs[:, 0].max() < 2e-6 + 0.008 * vmax
+    assert np.median(errs[:, 1]) < 2e-4 and np.percentile(errs[:, 1], 90) < 2e-3 and errs[:, 1].max() < vmax
     assert int(sim.status.max()) == 0
 
 

@@ -107,7 +107,7 @@ def test_reach_batch_rollout_gpu(reach_model):
 
 # ---------------------------------------------------------------------------------------------------------------------------
 # the env proper: FingertipPosGoal's second simulation, RobotEnv bookkeeping, the B = 1 1000-step run
-def _reach_env_run(env, ora, nsteps, seed, resync):
+def _reach_env_run(env, ora, nsteps, seed, resync, flag_band=0.0):
     """Both envs get the same goal draws and actions; with `resync` the kernel's hand state is re-written from the oracle's
     before every step (the goal simulations are never re-synchronised: they see two steps per goal only)."""
     from tests.test_env_parity import STATE_FIELDS, _put_rows
@@ -148,7 +148,10 @@ def _reach_env_run(env, ora, nsteps, seed, resync):
         if resync:
             assert bool(done[0]) == bool(d) and float(reward[0, 2]) == r[2], t
             assert int(info["successes_so_far"][0]) == inf["successes_so_far"] and int(info["goals_so_far"][0]) == inf["goals_so_far"], t
-            assert int(obs["is_goal_achieved"][0, 0]) == int(inf["is_goal_achieved"]), t
+            # (the flag of the observation is `distance to the CURRENT goal < threshold` after a possible goal reset; within
+            #  `flag_band` of the threshold the two precisions may decide differently -- it feeds no counter)
+            if abs(ora.goal_distance() - ora.SUCCESS_THRESHOLD) >= flag_band:
+                assert int(obs["is_goal_achieved"][0, 0]) == int(inf["is_goal_achieved"]), t
         if new_goal:
             stats["goal_err"].append(np.abs(obs["goal_fingertip_pos"][0].cpu().numpy() - ora.goal_tips).max())
         if d:
@@ -174,7 +177,7 @@ def test_reach_env_emul(reach_model, emul_lib, oracle_lib):
 
 
 @pytest.mark.gpu
-def test_reach_env_1000_steps_gpu(reach_model, oracle_lib):
+def test_reach_env_1000_steps_gpu(reach_model, oracle_lib, kernel_variant):
     """BASELINE configs[0]: dactyl/reach, 1000 env.steps (B = 2 identical rows so that row handling is in the picture), every
     step re-synchronised from the oracle env: fingertip observation, goal-distance reward, success flag, tracker counters,
     timeouts (150 steps) and every goal the second simulation produces."""
@@ -183,9 +186,10 @@ def test_reach_env_1000_steps_gpu(reach_model, oracle_lib):
 
     env = BatchedReachEnv(2, device="cuda:0", model=reach_model)
     ora = OracleReachEnv(reach_model, goal_simulation_model(reach_model))
-    st = _reach_env_run(env, ora, 1000, 1, resync=True)
+    st = _reach_env_run(env, ora, 1000, 1, resync=True, flag_band=kernel_variant.tol(0.0, 5e-4))
     print("reach env, 1000 re-synchronised steps: fingertip obs max err %.2e | goal reward max err %.2e | %d goals reached, %d timeouts | goal fingertip (second sim) max err %.2e"
           % (max(st["tip_err"]), max(st["rew_err"]), st["goals"], st["timeouts"], max(st["goal_err"]) if st["goal_err"] else float("nan")))
-    assert max(st["tip_err"]) < 2e-4 and np.median(st["tip_err"]) < 2e-6 and max(st["rew_err"]) < 5e-4
-    assert st["goals"] >= 3 and st["timeouts"] >= 2 and max(st["goal_err"]) < 5e-4
+    t = kernel_variant.tol   # (default: finger-finger mesh contacts through libccd's depth; tails as in profiles/r03_precision.txt)
+    assert max(st["tip_err"]) < t(2e-4, 1e-3) and np.median(st["tip_err"]) < 2e-6 and max(st["rew_err"]) < t(5e-4, 1e-3)
+    assert st["goals"] >= 3 and st["timeouts"] >= 2 and max(st["goal_err"]) < t(5e-4, 1e-3)
     assert int(env.sim.status.max()) == 0 and int(env.goal_simulation.status.max()) == 0
