@@ -33,6 +33,7 @@ def algorithmic_bytes_per_env_step(m, ncon, nefc, iters, nsub, obs_dim):
     d = m.dims
     nq, nv, nu, nb, nj, ng, ns, nt = (int(d[i]) for i in (0, 1, 2, 3, 4, 5, 6, 7))
     nM = int(m.k_dims[2]) if "k_dims" in m.arrays else 149
+    nM = nM or 149
     S = 5 * nu
     staged = (2 * (nq + 2 * nv + S + nu) + 2 * (28 * nb + 12 * ng + 12 * ns + 6 * nj) + 2 * (13 * nb + 6 * nv)
               + 2 * (nt + nt * nv + nu + nu * nv) + 2 * (10 * nb + 2 * nM + nv) + 2 * 29 * ncon + 2 * (nefc * nv + 8 * nefc)
@@ -77,8 +78,64 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def bench_full_perpendicular(args):
+    """BASELINE.json configs[2]: dactyl/full_perpendicular (Shadow hand + full Rubik's cube, nv 168, condim-6 contacts), batch 4096
+    on one MI355X, on the large-model stepper (rb_step_kernel).  Physics env.step only (action map, 10 mj_step, 3 PID ticks):
+    the full-cube env layer (face-angle goals) is not built.  One JSON line with its own roofline; single GPU."""
+    from robogym_amd.envs.dactyl.full_perpendicular import load_full_perpendicular_model
+    from robogym_amd.mujoco.large_simulation import LargeModelSimulation
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    B = args.batch if args.batch != 8192 else 4096
+    model = load_full_perpendicular_model()
+    sim = LargeModelSimulation(model, B, device=dev)
+    zero = torch.zeros((B, 20), device=dev)
+    for _ in range(6):                       # the cube lands on the palm (outside the timed region)
+        sim.env_step(action=zero, nforward_ticks=3)
+    gen = torch.Generator(device=dev); gen.manual_seed(20200901 + 2)
+    step = lambda: sim.env_step(action=torch.rand((B, 20), generator=gen, device=dev) * 2 - 1, nforward_ticks=3)
+    for _ in range(args.warmup):
+        step()
+    sim.stats.zero_()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for s_, e_ in ev:
+        s_.record(); step(); e_.record()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    st = sim.stats.sum(0).cpu().numpy()
+    nsub = max(st[3], 1.0)
+    ncon, nefc, iters = float(st[0] / nsub), float(st[1] / nsub), float(st[2] / nsub)
+
+    class _M:   # the byte model reads dims / k_dims
+        dims = model.dims
+        arrays = {"k_dims": None}
+        k_dims = [0, 0, sim.info["nM"]]
+    b_step, b_sub = algorithmic_bytes_per_env_step(_M, ncon, nefc, iters, sim.n_substeps, sim.nq + sim.nv)
+    achieved = B * b_step / (kern_ms * 1e-3)
+    out = {
+        "metric": "env-steps/sec dactyl/full_perpendicular batch 4096 (BASELINE.json configs[2]); physics env.step, parity vs the in-repo CPU oracle (unpinned)",
+        "value": B * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "dactyl/full_perpendicular (Shadow hand + full Rubik's cube, nv=168, 135 bodies, condim-6 contacts), batch %d, iid U(-1,1) relative actions, 10 substeps x 0.008 s; physics only" % B,
+                   "batch_per_gpu": B, "mean_ncon": ncon, "mean_nefc": nefc, "mean_newton_iters": iters, "status_bits": int(sim.status.max().item()), "lds_bytes_per_workgroup": sim.info["lds_bytes"]},
+        "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None, "kernel": "rb_step_kernel", "kernel_ms": kern_ms,
+                     "algorithmic_bytes_per_env_step": b_step, "algorithmic_bytes_per_substep": b_sub,
+                     "note": "SURVEY 8(d) byte model with this model's dimensions (nM 1193) and the run's measured ncon / nefc / iterations; first, clarity-first version of the kernel"},
+    }
+    if not args.no_cpu_baseline:
+        from oracle import cpu_baseline as cb
+
+        out["cpu_baseline"] = cb.run_full_perpendicular(2.0)
+    print(json.dumps(out, default=float))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="locked", choices=["locked", "full_perpendicular"], help="locked = BASELINE.json configs[1] (the headline); full_perpendicular = configs[2]")
     ap.add_argument("--gpus", type=int, default=1)
     # default window: the 20 steps right after the reset, where the cubes are still in the hands (iid random actions throw them off
     # over time and the workload gets cheaper: 100 steps after 10 warm-up steps measure ~10 % more; the line reports the on-palm fraction)
@@ -90,6 +147,8 @@ def main():
     ap.add_argument("--sort-dispatch", type=int, default=1, help="dispatch the envs longest-expected-first (previous step's cycles)")
     args = ap.parse_args()
 
+    if args.workload == "full_perpendicular":
+        return bench_full_perpendicular(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch_with_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))

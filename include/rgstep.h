@@ -246,6 +246,32 @@ int rg_debug_size(void);
 /* bytes of LDS one env occupies in the rollout configuration (diagnostic); rg_lds_bytes_cfg: any configuration */
 int rg_lds_bytes(void);
 int rg_lds_bytes_cfg(int config);
+/* ---- Large-model path (rb_kernel.h): models beyond the compile-time layout of the Shadow-hand kernel -- BASELINE.json
+ * configs[2], dactyl/full_perpendicular (/root/reference/robogym/envs/dactyl/full_perpendicular.py:92-136: nv 168, 135 bodies,
+ * condim-6 mesh hulls, njmax 2000 / nconmax 200 from cube_env.py:239-242).  Same blob format (plus the b_* tables of
+ * robogym_amd/mujoco/big_tables.py), same ownership / error / stream conventions as the rg_* entry points they mirror:
+ *   rb_model_create / rb_model_free        mujoco_py.load_model_from_xml (mujoco_xml.py:259)
+ *   rb_batch_create / _free / _reset       B x MjSim, MjSim.reset (mujoco_xml.py:260, simulation_interface.py:191-197)
+ *   rb_batch_field_ptr(field)              device address of a state field (RG_F_QPOS ... RG_F_STATS; RG_F_DEBUG = the env's
+ *                                          scratch row of stage arrays under their mjData names, offsets from rb_scratch_offset)
+ *   rb_batch_set_env                       hand joint block + position -> control matrix of the action map (robot_interface.py:247-278)
+ *   rb_batch_step                          RobotEnv._set_action + SimulationInterface.step + the PID ticks of the state-less forwards
+ *                                          (robot_env.py:497-504,677, simulation_interface.py:176-189); flags bit 0: stage dump, bit 4:
+ *                                          portal-plane contact depth (as rg_batch_step)
+ *   rb_model_info: out = nq, nv, nu, nbody, njnt, ngeom, nsite, ntendon, nM, npair, ngroup, gmax, maxcon, maxrow, scratch words,
+ *                  contact record words, row record words, contact dof width, tendon dof width, LDS bytes per workgroup */
+typedef struct rb_model rb_model;
+typedef struct rb_batch rb_batch;
+rb_model* rb_model_create(const void* blob, size_t nbytes, char* err, int errlen);
+void rb_model_free(rb_model* m);
+int rb_model_info(const rb_model* m, int* out, int n);
+int rb_scratch_offset(const rb_model* m, int which);
+rb_batch* rb_batch_create(const rb_model* m, int B);
+void rb_batch_free(rb_batch* b);
+int rb_batch_reset(rb_batch* b);
+int rb_batch_set_env(rb_batch* b, int hand_qposadr, int n_hand_jnt, int relative_action, const float* pos_to_ctrl);
+void* rb_batch_field_ptr(rb_batch* b, int field, int* row_words);
+int rb_batch_step(rb_batch* b, const float* action_dev, const int* active_dev, int nsubsteps, int nforward_ticks, int flags, void* stream);
 int rg_sync(void* stream);
 const char* rg_last_error(void);
 

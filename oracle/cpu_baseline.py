@@ -77,6 +77,43 @@ def oracle_newton_iterations(nsteps=40, seed=20200901 + 1):
     return {"mean_newton_iters": s["iters"], "mean_ncon": s["ncon"], "mean_nefc": s["nefc"], "mj_steps": int(s["steps"])}
 
 
+def run_full_perpendicular(seconds=2.0):
+    """configs[2] beside its GPU line: the oracle stepping dactyl/full_perpendicular env.steps on C threads (1 thread, then as many
+    as the cgroup quota allows)."""
+    from robogym_amd.envs.dactyl.full_perpendicular import load_full_perpendicular_model
+    from robogym_amd.mujoco import setconst
+    from robogym_amd.mujoco.model_blob import pack_model
+    from oracle import rg_oracle
+
+    m = load_full_perpendicular_model(); setconst.set_constants(m)
+    A, names = m.arrays, m.names["joint"]
+    hand_j = [j for j, n in enumerate(names) if n.startswith("robot0:")]
+
+    class _Ora:   # the arguments _bench reads
+        sim = rg_oracle.OracleSim(pack_model(m))
+        hand_q = np.array([A["jnt_qposadr"][j] for j in hand_j])
+        lo, hi = A["actuator_ctrlrange"][:, 0].copy(), A["actuator_ctrlrange"][:, 1].copy()
+        n_substeps = 10
+        cube_pos_q = [0, 0, int(A["jnt_qposadr"][names.index("cube:cube:tz")])]
+        P = np.zeros((20, len(hand_j)))
+    for u in range(20):
+        if A["actuator_trntype"][u] == 0:
+            _Ora.P[u, hand_j.index(int(A["actuator_trnid"][u]))] = 1
+        else:
+            t = int(A["actuator_trnid"][u])
+            for w in range(A["tendon_adr"][t], A["tendon_adr"][t] + A["tendon_num"][t]):
+                _Ora.P[u, hand_j.index(int(A["wrap_objid"][w]))] = 1
+    allot = cpu_allotment()
+    _, n1, r1, _ = _bench(_Ora, 1, seconds, 20200901 + 2)
+    q = allot["cgroup_cpu_max"]
+    k = int(min(allot["affinity"], q if isinstance(q, (int, float)) else allot["affinity"]))
+    nk, totk, rk, _ = _bench(_Ora, max(k, 1), seconds, 20200901 + 3)
+    best = (nk, rk) if rk > r1 else (1, r1)
+    return {"value": best[1], "unit": "env-steps/s", "cores": best[0], "kind": "port", "one_core": r1, "cpu_allotment": allot,
+            "sample": "%d env-steps of dactyl/full_perpendicular (10 mj_step + 3 mj_forward each) on the CPU oracle, %.0f s per rung: 1 thread %.1f env-steps/s, %d threads %.1f; CPU restatement of MuJoCo, not mujoco-py" % (
+                n1 + totk, seconds, r1, nk, rk)}
+
+
 def run(seconds=3.0, max_threads=None):
     from oracle.env_oracle import OracleLockedEnvPhysics
     from robogym_amd.envs.dactyl.locked import load_locked_model

@@ -37,8 +37,8 @@ typedef double real;
 #include <time.h>
 
 #define MINVAL 1e-15
-#define MAXCON 128
-#define MAXEFC 600
+#define MAXCON 200   /* the largest nconmax / njmax the reference sets on this path: cube_env.py:239-242 (full cube) */
+#define MAXEFC 2000
 #define MAXCONPAIR 8
 #define PI 3.14159265358979323846
 
@@ -215,8 +215,8 @@ ro_model* ro_model_load(const void* blob_in, size_t nbytes) {
   const int* oi = (const int*)blob_find(m->blob, "opt_int", NULL, 1);
   m->iterations = oi[0]; m->cone = oi[1]; m->ls_iterations = oi[2]; m->mpr_iterations = oi[3];
   const int* si = (const int*)blob_find(m->blob, "size_int", NULL, 1);
-  m->njmax = si[0] > 0 && si[0] < MAXEFC ? si[0] : MAXEFC;
-  m->nconmax = si[1] > 0 && si[1] < MAXCON ? si[1] : MAXCON;
+  m->njmax = si[0] > 0 && si[0] <= MAXEFC ? si[0] : MAXEFC;
+  m->nconmax = si[1] > 0 && si[1] <= MAXCON ? si[1] : MAXCON;
   I32(body_parentid); I32(body_rootid); I32(body_weldid); I32(body_jntadr); I32(body_jntnum); I32(body_dofadr);
   I32(body_dofnum); I32(body_geomadr); I32(body_geomnum);
   F64(body_pos); F64(body_quat); F64(body_ipos); F64(body_iquat); F64(body_mass); F64(body_inertia);

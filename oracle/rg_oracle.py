@@ -141,7 +141,7 @@ class OracleSim:
         return self._L.ro_time(self.d)
 
     def efc_types(self):
-        return np.ctypeslib.as_array(self._L.ro_efc_type(self.d), shape=(600,))[: self.nefc].copy()
+        return np.ctypeslib.as_array(self._L.ro_efc_type(self.d), shape=(2000,))[: self.nefc].copy()
 
     def reset(self):
         self._L.ro_reset(self.m, self.d)

@@ -51,6 +51,8 @@ EXPORTS = [
     "rg_batch_copy", "rg_batch_reset", "rg_batch_step", "rg_obs_dim", "rg_debug_size", "rg_lds_bytes", "rg_sync",
     "rg_last_error", "rg_batch_mpr_pair", "rg_batch_copy_rows", "rg_batch_step_ex", "rg_batch_field_ptr", "rg_model_create_on", "rg_model_npair",
     "rg_lds_bytes_cfg", "rg_env_post_step", "rg_post_args_size", "rg_batch_enable_env_params", "rg_prm_layout", "rg_xdata_layout", "rg_batch_set_constants", "rg_batch_items_info",
+    "rb_model_create", "rb_model_free", "rb_model_info", "rb_scratch_offset", "rb_batch_create", "rb_batch_free", "rb_batch_reset", "rb_batch_set_env",
+    "rb_batch_field_ptr", "rb_batch_step",
 ]
 
 
@@ -100,6 +102,19 @@ def bind(path):
         raise NativeError("rg_post_args layout mismatch between include/rgstep.h and robogym_amd/_native.py")
     L.rg_batch_set_constants.argtypes = [vp, vp, vp]
     L.rg_batch_items_info.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci)]
+    L.rb_model_create.restype = vp
+    L.rb_model_create.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ci]
+    L.rb_model_free.argtypes = [vp]
+    L.rb_model_info.argtypes = [vp, ctypes.POINTER(ci), ci]
+    L.rb_scratch_offset.argtypes = [vp, ci]
+    L.rb_batch_create.restype = vp
+    L.rb_batch_create.argtypes = [vp, ci]
+    L.rb_batch_free.argtypes = [vp]
+    L.rb_batch_reset.argtypes = [vp]
+    L.rb_batch_set_env.argtypes = [vp, ci, ci, ci, ctypes.POINTER(cf)]
+    L.rb_batch_field_ptr.restype = vp
+    L.rb_batch_field_ptr.argtypes = [vp, ci, ctypes.POINTER(ci)]
+    L.rb_batch_step.argtypes = [vp, vp, vp, ci, ci, ci, vp]
     L.rg_sync.argtypes = [vp]
     L.rg_last_error.restype = ctypes.c_char_p
     return L

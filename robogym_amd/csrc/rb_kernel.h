@@ -1,0 +1,994 @@
+// rb_kernel.h — the LARGE-MODEL stepper for gfx950: env.step (action -> ctrl, nsubsteps x mj_step, the PID ticks of the
+// reference's state-less forwards) for models beyond the compile-time layout of rg_kernel.h — dactyl/full_perpendicular
+// (BASELINE.json configs[2]: Shadow hand + Rubik's cube, nv 168, 135 bodies, 26 condim-6 mesh hulls;
+// /root/reference/robogym/envs/dactyl/full_perpendicular.py:92-136, cube_env.py:239-242, simulation_interface.py:176-189).
+//
+// Execution plan: ONE 256-thread workgroup (4 waves) per env, every size a run-time number of the model.  Stage arrays
+// (body / geom frames, spatial inertias, motion axes, M in MuJoCo's tree-sparse form, contacts, contact Jacobians,
+// constraint rows) live in the env's HBM scratch row under their mjData names and stay L2-resident for the launch; the
+// vectors of the solver and ONE dense block (the Newton Hessian / M + h B of the largest constraint-coupled group of trees:
+// 96 x 96 for hand + cube) live in LDS.  Tree recursions are level sweeps, reductions DPP + a 4-entry LDS exchange, all
+// appends are ballot-prefix compactions in index order and all scatters are owner-computes loops: a launch is run-to-run
+// deterministic.  Collision: static pair list -> bounding spheres -> libccd-style MPR in quads (rg_kernel.h's routine,
+// 64 queries per trip).  Constraints: friction loss, joint / tendon limits, pyramidal contacts of condim 1 / 3 / 4 / 6 as
+// six basis Jacobians per contact on the union of the two bodies' dof chains.  Solver: primal Newton with exact line
+// search (mj_solNewton), dense Cholesky per group.  Arithmetic follows oracle/rg_oracle.c stage by stage; this first
+// version is written for clarity and parity, not yet for speed.
+#pragma once
+#include "rb_types.h"
+
+namespace rgb {
+using namespace rgl;   // small math, wave collectives and the MPR / support routines of rg_kernel.h
+
+#ifdef RG_EMUL
+typedef const RbModelDev& RbM;
+typedef const RbLaunch& RbLRef;
+#define RB_S() (*(RbLds*)emul_lds())
+#else
+typedef const RG_AS4 RbModelDev& RbM;
+typedef const RG_AS4 RbLaunch& RbLRef;
+#define RB_S() (*(RbLds*)rg_lds_raw)
+#endif
+#define TID ((int)threadIdx.x)
+#define WID (TID >> 6)
+#define WL (TID & 63)
+#define BFOR(i, n) for (int i = TID; i < (n); i += RB_T)
+#define BSYNC() __syncthreads()
+#define RB_MINVAL 1e-15f
+
+struct RbLds {
+  alignas(16) float A[RB_MAXGROUP * RB_MAXGROUP];   // the dense block of the moment
+  float qpos[RB_MAXNQ], qvel[RB_MAXNV], warm[RB_MAXNV], ctrl[32], pid[96], actlen[32], actfrc[32];
+  float qfrc_passive[RB_MAXNV], qfrc_bias[RB_MAXNV], qfrc_act[RB_MAXNV], qfrc_smooth[RB_MAXNV], qacc_smooth[RB_MAXNV];
+  float qa[RB_MAXNV], Ma[RB_MAXNV], grad[RB_MAXNV], search[RB_MAXNV], Mv[RB_MAXNV], qfrc_con[RB_MAXNV], x[RB_MAXNV];
+  float red[16];
+  int wcnt[4];
+  int ncand, ncon, nefc, nlim, stop;
+  unsigned status;
+};
+
+// ------------------------------------------------------------------------------------------------- block collectives
+__device__ __forceinline__ float rb_sum(RbLds& s, float v) {
+  float w = wave_sum(v);
+  BSYNC();
+  if (WL == 0) s.red[WID] = w;
+  BSYNC();
+  return (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]);
+}
+__device__ __forceinline__ void rb_sum3(RbLds& s, float& a, float& b, float& c) {
+  float wa = wave_sum(a), wb = wave_sum(b), wc = wave_sum(c);
+  BSYNC();
+  if (WL == 0) { s.red[WID] = wa; s.red[4 + WID] = wb; s.red[8 + WID] = wc; }
+  BSYNC();
+  a = (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]); b = (s.red[4] + s.red[5]) + (s.red[6] + s.red[7]); c = (s.red[8] + s.red[9]) + (s.red[10] + s.red[11]);
+}
+// slot of this thread's item in a list that grows in thread order (all threads call; -1: no item, or the list is full)
+__device__ __forceinline__ int rb_slot(RbLds& s, bool pred, int* cnt, int cap, unsigned full_bit) {
+  unsigned long long bal = __ballot(pred);
+  BSYNC();
+  if (WL == 0) s.wcnt[WID] = __popcll(bal);
+  BSYNC();
+  int base = *cnt;
+  for (int k = 0; k < WID; k++) base += s.wcnt[k];
+  int slot = base + __popcll(bal & ((1ull << WL) - 1ull));
+  if (pred && slot >= cap) { s.status |= full_bit; }
+  BSYNC();
+  if (TID == 0) { int n = *cnt + s.wcnt[0] + s.wcnt[1] + s.wcnt[2] + s.wcnt[3]; *cnt = n < cap ? n : cap; }
+  BSYNC();
+  return (pred && slot < cap) ? slot : -1;
+}
+#define SC(name) (S + m.off[RB_O_##name])
+
+// ------------------------------------------------------------------------------------------------- position stage
+// engine_core_smooth.c mj_kinematics: body frames top-down (level sweep), joint anchors / axes, geoms, sites
+__device__ __forceinline__ void rb_kinematics(RbM m, RbLds& s, float* S) {
+  float *xpos = SC(XPOS), *xquat = SC(XQUAT), *xipos = SC(XIPOS), *xiquat = SC(XIQUAT), *xanchor = SC(XANCHOR), *xaxis = SC(XAXIS);
+  if (TID == 0) {
+    st3(xpos, mk3(0, 0, 0)); st3(xipos, mk3(0, 0, 0));
+    q4 id; id.w = 1; id.x = id.y = id.z = 0; stq(xquat, id); stq(xiquat, id);
+  }
+  BSYNC();
+  for (int L = 0; L < m.nlevel; L++) {
+    for (int q = m.b_lvl_adr[L] + TID; q < m.b_lvl_adr[L + 1]; q += RB_T) {
+      const int b = m.b_lvl_body[q], p = m.body_parentid[b];
+      const q4 pq = ldq(xquat + 4 * p);
+      v3 pos = ld3(xpos + 3 * p) + qrot(pq, ld3(m.body_pos + 3 * b));
+      q4 quat = qmul(pq, ldq(m.body_quat + 4 * b));
+      for (int k = 0; k < m.body_jntnum[b]; k++) {
+        const int j = m.body_jntadr[b] + k, qa = m.jnt_qposadr[j], t = m.jnt_type[j];
+        if (t == RG_JNT_FREE) {
+          pos = ld3(s.qpos + qa); quat = qnormalize(ldq(s.qpos + qa + 3));
+          st3(xanchor + 3 * j, pos); st3(xaxis + 3 * j, mk3(0, 0, 1));
+          continue;
+        }
+        const v3 jpos = ld3(m.jnt_pos + 3 * j), jaxis = ld3(m.jnt_axis + 3 * j);
+        const v3 anchor = pos + qrot(quat, jpos), axis = qrot(quat, jaxis);
+        st3(xanchor + 3 * j, anchor); st3(xaxis + 3 * j, axis);
+        if (t == RG_JNT_SLIDE) pos = pos + axis * (s.qpos[qa] - m.qpos0[qa]);
+        else {
+          const q4 ql = (t == RG_JNT_BALL) ? qnormalize(ldq(s.qpos + qa)) : axisangle(jaxis, s.qpos[qa] - m.qpos0[qa]);
+          quat = qmul(quat, ql);
+          pos = anchor - qrot(quat, jpos);   // the anchor stays where it is
+        }
+      }
+      quat = qnormalize(quat);
+      st3(xpos + 3 * b, pos); stq(xquat + 4 * b, quat);
+      st3(xipos + 3 * b, pos + qrot(quat, ld3(m.body_ipos + 3 * b)));
+      stq(xiquat + 4 * b, qmul(quat, ldq(m.body_iquat + 4 * b)));
+    }
+    BSYNC();
+  }
+  BFOR(g, m.ngeom) {
+    const int b = m.geom_bodyid[g]; const q4 xq = ldq(xquat + 4 * b);
+    st3(SC(GPOS) + 3 * g, ld3(xpos + 3 * b) + qrot(xq, ld3(m.geom_pos + 3 * g)));
+    stq(SC(GQUAT) + 4 * g, qmul(xq, ldq(m.geom_quat + 4 * g)));
+  }
+  BFOR(i, m.nsite) {
+    const int b = m.site_bodyid[i];
+    st3(SC(SPOS) + 3 * i, ld3(xpos + 3 * b) + qrot(ldq(xquat + 4 * b), ld3(m.site_pos + 3 * i)));
+  }
+  BSYNC();
+}
+
+// mj_comPos: subtree com of every tree root, body inertias (cinert) and motion axes (cdof) in the com-based frame of the tree
+__device__ __forceinline__ void rb_com_pos(RbM m, RbLds& s, float* S) {
+  float *xipos = SC(XIPOS), *rootcom = SC(ROOTCOM), *cinert = SC(CINERT), *cdof = SC(CDOF);
+  BFOR(r, m.nroot) {
+    const int root = m.b_root_list[r];
+    v3 acc = mk3(0, 0, 0);
+    for (int q = m.b_subtree_adr[root]; q < m.b_subtree_adr[root + 1]; q++) { const int b = m.b_subtree[q]; acc = acc + ld3(xipos + 3 * b) * m.body_mass[b]; }
+    const float sm = m.body_subtreemass[root];
+    st3(rootcom + 3 * root, sm < RB_MINVAL ? ld3(xipos + 3 * root) : acc * (1.0f / sm));
+  }
+  BSYNC();
+  if (TID < 10) cinert[TID] = 0.f;
+  for (int b = 1 + TID; b < m.nbody; b += RB_T) {
+    float R[9], I[9];
+    q2mat(R, ldq(SC(XIQUAT) + 4 * b));
+    const float* in = m.body_inertia + 3 * b;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) I[3 * i + j] = R[3 * i] * in[0] * R[3 * j] + R[3 * i + 1] * in[1] * R[3 * j + 1] + R[3 * i + 2] * in[2] * R[3 * j + 2];
+    const v3 d = ld3(xipos + 3 * b) - ld3(rootcom + 3 * m.body_rootid[b]);
+    const float mass = m.body_mass[b], d2 = dot(d, d);
+    float* ci = cinert + 10 * b;
+    ci[0] = I[0] + mass * (d2 - d.x * d.x); ci[1] = I[4] + mass * (d2 - d.y * d.y); ci[2] = I[8] + mass * (d2 - d.z * d.z);
+    ci[3] = I[1] - mass * d.x * d.y; ci[4] = I[2] - mass * d.x * d.z; ci[5] = I[5] - mass * d.y * d.z;
+    ci[6] = mass * d.x; ci[7] = mass * d.y; ci[8] = mass * d.z; ci[9] = mass;
+  }
+  BFOR(j, m.njnt) {
+    const int b = m.jnt_bodyid[j], t = m.jnt_type[j]; int da = m.jnt_dofadr[j];
+    const v3 off = ld3(rootcom + 3 * m.body_rootid[b]) - ld3(SC(XANCHOR) + 3 * j);
+    if (t == RG_JNT_FREE || t == RG_JNT_BALL) {
+      float R[9]; q2mat(R, ldq(SC(XQUAT) + 4 * b));
+      if (t == RG_JNT_FREE) {
+        for (int k = 0; k < 3; k++) { float* c = cdof + 6 * (da + k); for (int e = 0; e < 6; e++) c[e] = 0; c[3 + k] = 1; }
+        da += 3;
+      }
+      for (int k = 0; k < 3; k++) { const v3 ax = mk3(R[k], R[3 + k], R[6 + k]); st3(cdof + 6 * (da + k), ax); st3(cdof + 6 * (da + k) + 3, cross(ax, off)); }
+    } else if (t == RG_JNT_SLIDE) {
+      st3(cdof + 6 * da, mk3(0, 0, 0)); st3(cdof + 6 * da + 3, ld3(SC(XAXIS) + 3 * j));
+    } else {
+      const v3 ax = ld3(SC(XAXIS) + 3 * j); st3(cdof + 6 * da, ax); st3(cdof + 6 * da + 3, cross(ax, off));
+    }
+  }
+  BSYNC();
+}
+
+// translational Jacobian column of dof i for a point at offset `off` from its tree's com (mj_jac with cdof)
+__device__ __forceinline__ v3 rb_jacp(const float* cdof, int i, v3 off) { return ld3(cdof + 6 * i + 3) + cross(ld3(cdof + 6 * i), off); }
+
+// mj_tendon: lengths and Jacobians on the static dof supports (b_ten_dofs); actuator lengths (mj_transmission)
+__device__ __forceinline__ void rb_tendon(RbM m, RbLds& s, float* S) {
+  const float *spos = SC(SPOS), *cdof = SC(CDOF), *rootcom = SC(ROOTCOM);
+  BFOR(t, m.ntendon) {
+    const int adr = m.tendon_adr[t], num = m.tendon_num[t];
+    const int* td = m.b_ten_dofs + RB_TENW * t;
+    float J[RB_TENW], L = 0;
+    for (int e = 0; e < RB_TENW; e++) J[e] = 0;
+    if (m.wrap_type[adr] == RG_WRAP_JOINT) {
+      for (int w = adr; w < adr + num; w++) {
+        const int j = m.wrap_objid[w], d = m.jnt_dofadr[j];
+        L += m.wrap_prm[w] * s.qpos[m.jnt_qposadr[j]];
+        for (int e = 0; e < RB_TENW; e++) if (td[e] == d) J[e] = m.wrap_prm[w];
+      }
+    } else {
+      float divisor = 1.f;
+      int w = adr;
+      while (w < adr + num - 1) {
+        const int t0 = m.wrap_type[w], t1 = m.wrap_type[w + 1];
+        if (t0 == RG_WRAP_PULLEY || t1 == RG_WRAP_PULLEY) { if (t0 == RG_WRAP_PULLEY) divisor = m.wrap_prm[w]; w++; continue; }
+        v3 pnt[4]; int body[4], cnt;
+        const int s0 = m.wrap_objid[w];
+        pnt[0] = ld3(spos + 3 * s0); body[0] = m.site_bodyid[s0];
+        float wlen = -1.f;
+        if (t1 == RG_WRAP_SPHERE || t1 == RG_WRAP_CYLINDER) {
+          const int g = m.wrap_objid[w + 1], s1 = m.wrap_objid[w + 2], sid = (int)lrintf(m.wrap_prm[w + 1]);
+          float gm[9]; q2mat(gm, ldq(SC(GQUAT) + 4 * g));
+          v3 w0 = mk3(0, 0, 0), w1 = mk3(0, 0, 0);
+          const v3 x1 = ld3(spos + 3 * s1);
+          wlen = rg_wrap(w0, w1, pnt[0], x1, ld3(SC(GPOS) + 3 * g), gm, m.geom_size[3 * g], t1, sid >= 0, sid >= 0 ? ld3(spos + 3 * sid) : mk3(0, 0, 0));
+          if (wlen < 0) { pnt[1] = x1; body[1] = m.site_bodyid[s1]; cnt = 2; }
+          else { pnt[1] = w0; pnt[2] = w1; pnt[3] = x1; body[1] = body[2] = m.geom_bodyid[g]; body[3] = m.site_bodyid[s1]; cnt = 4; }
+          w += 2;
+        } else {
+          const int s1 = m.wrap_objid[w + 1];
+          pnt[1] = ld3(spos + 3 * s1); body[1] = m.site_bodyid[s1]; cnt = 2;
+          w += 1;
+        }
+        const float idiv = 1.0f / divisor;
+        if (wlen >= 0) L += wlen * idiv;
+        for (int k = 0; k < cnt - 1; k++) {
+          if (cnt == 4 && k == 1) continue;   // the arc lies on the wrapping geom
+          v3 dif = pnt[k + 1] - pnt[k];
+          const float dist = sqrtf(dot(dif, dif));
+          L += dist * idiv;
+          if (body[k] != body[k + 1] && dist > RB_MINVAL) {
+            dif = dif * (1.0f / dist);
+            for (int side = 0; side < 2; side++) {
+              const int bb = body[k + side]; const float sg = side ? idiv : -idiv;
+              const v3 off = pnt[k + side] - ld3(rootcom + 3 * m.body_rootid[bb]);
+              for (int i = m.b_body_lastdof[bb]; i >= 0; i = m.dof_parentid[i]) {
+                const float v = sg * dot(dif, rb_jacp(cdof, i, off));
+                for (int e = 0; e < RB_TENW; e++) if (td[e] == i) J[e] += v;
+              }
+            }
+          }
+        }
+      }
+    }
+    SC(TENLEN)[t] = L;
+    for (int e = 0; e < RB_TENW; e++) SC(TENJ)[RB_TENW * t + e] = J[e];
+  }
+  BSYNC();
+  BFOR(u, m.nu) {
+    const int id = m.actuator_trnid[u];
+    s.actlen[u] = m.actuator_gear[u] * (m.actuator_trntype[u] == 0 ? s.qpos[m.jnt_qposadr[id]] : SC(TENLEN)[id]);
+  }
+  BSYNC();
+}
+
+// mj_crb: composite inertias (subtree sums, owner computes), M in tree-sparse form: entry e = (i, j = i or an ancestor of i)
+__device__ __forceinline__ void rb_crb(RbM m, RbLds& s, float* S) {
+  const float* cinert = SC(CINERT); float* crb = SC(CRB);
+  BFOR(w, 10 * m.nbody) {
+    const int b = w / 10, k = w - 10 * b;
+    float acc = 0;
+    for (int q = m.b_subtree_adr[b]; q < m.b_subtree_adr[b + 1]; q++) acc += cinert[10 * m.b_subtree[q] + k];
+    crb[w] = acc;
+  }
+  BSYNC();
+  BFOR(e, m.nM) {
+    const int i = m.b_M_i[e], j = m.b_M_j[e];
+    float buf[6];
+    mul_inert_vec(buf, crb + 10 * m.dof_bodyid[i], SC(CDOF) + 6 * i);
+    const float* c = SC(CDOF) + 6 * j;
+    float v = c[0] * buf[0] + c[1] * buf[1] + c[2] * buf[2] + c[3] * buf[3] + c[4] * buf[4] + c[5] * buf[5];
+    if (i == j) v += m.dof_armature[i];
+    SC(MSP)[e] = v;
+  }
+  BSYNC();
+}
+// y = M x (all dofs): row i = its own entries (ancestors) + the entries of its descendants that name i
+__device__ __forceinline__ void rb_M_mul(RbM m, const float* Msp, const float* x, float* y) {
+  BFOR(i, m.nv) {
+    float acc = 0;
+    for (int e = m.b_M_adr[i]; e < m.b_M_adr[i + 1]; e++) acc += Msp[e] * x[m.b_M_j[e]];
+    // descendants: dofs k > i whose chain passes through i; their entry for ancestor i sits at depth distance from k
+    for (int k = i + 1; k < m.nv; k++) {
+      // (dofs are numbered depth-first: the subtree of i is a contiguous range that ends at the first k whose parent chain misses i)
+      int a = m.dof_parentid[k];
+      while (a > i) a = m.dof_parentid[a];
+      if (a != i) break;
+      // entry (k, i): walk k's entry list
+      for (int e = m.b_M_adr[k]; e < m.b_M_adr[k + 1]; e++) if (m.b_M_j[e] == i) { acc += Msp[e] * x[k]; break; }
+    }
+    y[i] = acc;
+  }
+  BSYNC();
+}
+// s.A <- the dense block of group g of M (+ diag), lower and upper triangle, row stride n
+__device__ __forceinline__ void rb_M_block(RbM m, RbLds& s, const float* Msp, int g, const float* diag, float dscale) {
+  const int g0 = m.b_group_adr[g], n = m.b_group_adr[g + 1] - g0;
+  BFOR(w, n * n) s.A[w] = 0.f;
+  BSYNC();
+  BFOR(e, m.nM) {
+    const int i = m.b_M_i[e], j = m.b_M_j[e];
+    if (m.b_dof_group[i] != g) continue;
+    const int li = m.b_dof_local[i], lj = m.b_dof_local[j];
+    float v = Msp[e];
+    if (i == j && diag) v += dscale * diag[i];
+    s.A[li * n + lj] = v; s.A[lj * n + li] = v;
+  }
+  BSYNC();
+}
+// in-place Cholesky of the n x n block in s.A (lower triangle, row stride n); returns false on a non-positive pivot
+__device__ __forceinline__ bool rb_chol(RbLds& s, int n) {
+  bool ok = true;
+  for (int k = 0; k < n; k++) {
+    const float pkk = s.A[k * n + k];
+    if (!(pkk > RB_MINVAL)) ok = false;
+    const float d = sqrtf(fmaxf(pkk, RB_MINVAL)), id = 1.0f / d;
+    BSYNC();
+    for (int i = k + TID; i < n; i += RB_T) s.A[i * n + k] = i == k ? d : s.A[i * n + k] * id;
+    BSYNC();
+    const int r = n - k - 1;   // trailing rows k+1..n-1: entries (i, j <= i)
+    for (int w = TID; w < r * r; w += RB_T) {
+      const int a = w / r, b2 = w - a * r;
+      if (b2 <= a) { const int i = k + 1 + a, j = k + 1 + b2; s.A[i * n + j] -= s.A[i * n + k] * s.A[j * n + k]; }
+    }
+    BSYNC();
+  }
+  return ok;
+}
+// x <- inv(L L') x for the group's local vector x[0..n)
+__device__ __forceinline__ void rb_chol_solve(RbLds& s, int n, float* x) {
+  for (int k = 0; k < n; k++) {          // forward: column sweeps
+    if (TID == 0) x[k] /= s.A[k * n + k];
+    BSYNC();
+    const float xk = x[k];
+    for (int i = k + 1 + TID; i < n; i += RB_T) x[i] -= s.A[i * n + k] * xk;
+    BSYNC();
+  }
+  for (int k = n - 1; k >= 0; k--) {     // backward
+    if (TID == 0) x[k] /= s.A[k * n + k];
+    BSYNC();
+    const float xk = x[k];
+    for (int i = TID; i < k; i += RB_T) x[i] -= s.A[k * n + i] * xk;
+    BSYNC();
+  }
+}
+// dst[dofs of group g] = inv(block in s.A factored) applied to src[dofs of group g], through the local vector s.x
+__device__ __forceinline__ void rb_group_solve(RbM m, RbLds& s, int g, const float* src, float* dst, float scale) {
+  const int g0 = m.b_group_adr[g], n = m.b_group_adr[g + 1] - g0;
+  BFOR(l, n) s.x[l] = src[m.b_group_dofs[g0 + l]];
+  BSYNC();
+  rb_chol_solve(s, n, s.x);
+  BFOR(l, n) dst[m.b_group_dofs[g0 + l]] = scale * s.x[l];
+  BSYNC();
+}
+
+// ------------------------------------------------------------------------------------------------- velocity stage
+// mj_comVel, mj_passive, mj_rne (zero acceleration: Coriolis, centrifugal, gravity)
+__device__ __forceinline__ void rb_velocity(RbM m, RbLds& s, float* S) {
+  const float* cdof = SC(CDOF); float *cdofdot = SC(CDOFDOT), *cvel = SC(CVEL), *cacc = SC(CACC), *cfrc = SC(CFRC);
+  if (TID < 6) { cvel[TID] = 0.f; cacc[TID] = TID < 3 ? 0.f : -m.gravity[TID - 3]; cfrc[TID] = 0.f; }
+  BSYNC();
+  for (int L = 0; L < m.nlevel; L++) {
+    for (int q = m.b_lvl_adr[L] + TID; q < m.b_lvl_adr[L + 1]; q += RB_T) {
+      const int b = m.b_lvl_body[q], p = m.body_parentid[b];
+      float cv[6], ca[6];
+      for (int c = 0; c < 6; c++) { cv[c] = cvel[6 * p + c]; ca[c] = cacc[6 * p + c]; }
+      for (int k = 0; k < m.body_jntnum[b]; k++) {
+        const int j = m.body_jntadr[b] + k, t = m.jnt_type[j]; int da = m.jnt_dofadr[j];
+        if (t == RG_JNT_FREE) {
+          for (int i = 0; i < 3; i++) { for (int c = 0; c < 6; c++) { cdofdot[6 * (da + i) + c] = 0.f; cv[c] += cdof[6 * (da + i) + c] * s.qvel[da + i]; } }
+          da += 3;
+        }
+        if (t == RG_JNT_FREE || t == RG_JNT_BALL) {
+          for (int i = 0; i < 3; i++) cross_motion(cdofdot + 6 * (da + i), cv, cdof + 6 * (da + i));
+          for (int i = 0; i < 3; i++) for (int c = 0; c < 6; c++) cv[c] += cdof[6 * (da + i) + c] * s.qvel[da + i];
+        } else {
+          cross_motion(cdofdot + 6 * da, cv, cdof + 6 * da);
+          for (int c = 0; c < 6; c++) cv[c] += cdof[6 * da + c] * s.qvel[da];
+        }
+      }
+      for (int k = 0; k < m.body_dofnum[b]; k++) { const int i = m.body_dofadr[b] + k; for (int c = 0; c < 6; c++) ca[c] += cdofdot[6 * i + c] * s.qvel[i]; }
+      float t1[6], t2[6], t3[6];
+      mul_inert_vec(t1, SC(CINERT) + 10 * b, ca);
+      mul_inert_vec(t2, SC(CINERT) + 10 * b, cv);
+      cross_force(t3, cv, t2);
+      for (int c = 0; c < 6; c++) { cvel[6 * b + c] = cv[c]; cacc[6 * b + c] = ca[c]; cfrc[6 * b + c] = t1[c] + t3[c]; }
+    }
+    BSYNC();
+  }
+  BFOR(t, m.ntendon) {
+    float v = 0;
+    for (int e = 0; e < RB_TENW; e++) { const int d = m.b_ten_dofs[RB_TENW * t + e]; if (d >= 0) v += SC(TENJ)[RB_TENW * t + e] * s.qvel[d]; }
+    SC(TENVEL)[t] = v;
+  }
+  BSYNC();
+  BFOR(i, m.nv) {
+    // passive: joint spring, dof damping, tendon spring-dampers
+    const int j = m.dof_jntid[i], jt = m.jnt_type[j];
+    float f = -m.dof_damping[i] * s.qvel[i];
+    if ((jt == RG_JNT_HINGE || jt == RG_JNT_SLIDE) && m.jnt_stiffness[j] != 0.f) { const int qa = m.jnt_qposadr[j]; f -= m.jnt_stiffness[j] * (s.qpos[qa] - m.qpos_spring[qa]); }
+    for (int t = 0; t < m.ntendon; t++) {
+      const float tf = m.tendon_stiffness[t] * (m.tendon_lengthspring[t] - SC(TENLEN)[t]) - m.tendon_damping[t] * SC(TENVEL)[t];
+      if (tf != 0.f) for (int e = 0; e < RB_TENW; e++) if (m.b_ten_dofs[RB_TENW * t + e] == i) f += SC(TENJ)[RB_TENW * t + e] * tf;
+    }
+    s.qfrc_passive[i] = f;
+    // bias: cdof_i . (sum of cfrc over the subtree of the dof's body)
+    const int b = m.dof_bodyid[i];
+    float acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int q = m.b_subtree_adr[b]; q < m.b_subtree_adr[b + 1]; q++) { const float* cf = cfrc + 6 * m.b_subtree[q]; for (int c = 0; c < 6; c++) acc[c] += cf[c]; }
+    const float* c = cdof + 6 * i;
+    s.qfrc_bias[i] = c[0] * acc[0] + c[1] * acc[1] + c[2] * acc[2] + c[3] * acc[3] + c[4] * acc[4] + c[5] * acc[5];
+  }
+  BSYNC();
+}
+
+// ------------------------------------------------------------------------------------------------- actuation
+// mujoco-py's PID callback (mjpid.pyx semantics as restated by oracle ro_fwd_actuation); `apply`: also qfrc_actuator
+__device__ __forceinline__ void rb_pid(RbM m, RbLds& s, float* S, bool apply) {
+  const float dt = m.timestep;
+  BFOR(u, m.nu) {
+    const float* gp = m.actuator_gainprm + 10 * u;
+    const float kp = gp[0], ti = gp[1], iclamp = gp[2], td = gp[3], smooth = gp[4], deadband = gp[5];
+    float err = s.ctrl[u] - s.actlen[u];
+    if (fabsf(err) < deadband) err = 0.f;
+    float* st = s.pid + 3 * u;
+    const float integ = clampf(st[0] + err * dt, -iclamp, iclamp);
+    const float deriv = (1.f - smooth) * st[2] + smooth * (err - st[1]) / dt;
+    float force = kp * (err + (ti != 0.f ? integ / ti : 0.f) + td * deriv);
+    st[0] = integ; st[1] = err; st[2] = deriv;
+    const float lo = m.actuator_forcerange[2 * u], hi = m.actuator_forcerange[2 * u + 1];
+    if (lo != 0.f || hi != 0.f) force = clampf(force, lo, hi);
+    if (m.actuator_forcelimited[u]) force = clampf(force, lo, hi);
+    s.actfrc[u] = force;
+  }
+  BSYNC();
+  if (!apply) return;
+  BFOR(i, m.nv) {
+    float f = 0;
+    for (int u = 0; u < m.nu; u++) {
+      const int id = m.actuator_trnid[u]; const float g = m.actuator_gear[u];
+      if (m.actuator_trntype[u] == 0) { if (m.jnt_dofadr[id] == i) f += g * s.actfrc[u]; }
+      else for (int e = 0; e < RB_TENW; e++) if (m.b_ten_dofs[RB_TENW * id + e] == i) f += g * SC(TENJ)[RB_TENW * id + e] * s.actfrc[u];
+    }
+    s.qfrc_act[i] = f;
+    s.qfrc_smooth[i] = s.qfrc_passive[i] - s.qfrc_bias[i] + f;
+  }
+  BSYNC();
+}
+
+// ------------------------------------------------------------------------------------------------- collision
+__device__ __forceinline__ void rb_geom(RbM m, const float* S, int g, MprGeom& G) {
+  G.type = m.geom_type[g]; G.quat = SC(GQUAT) + 4 * g; G.size = ld3(m.geom_size + 3 * g); G.mesh = -1; G.vertadr = 0; G.nvert = 0;
+  if (G.type == RG_GEOM_MESH) { G.mesh = m.geom_dataid[g]; G.vertadr = m.mesh_vertadr[G.mesh]; G.nvert = m.mesh_vertnum[G.mesh]; }
+}
+__device__ __forceinline__ void rb_make_frame(float* f) {   // mju_makeFrame: f[0..2] given, tangents completed (as oracle make_frame)
+  make_frame(f);
+}
+__device__ __forceinline__ void rb_collision(RbM m, RbLds& s, float* S, int flags) {
+  int* cand = (int*)SC(CAND);
+  const float *gpos = SC(GPOS), *gquat = SC(GQUAT);
+  if (TID == 0) { s.ncand = 0; s.ncon = 0; }
+  BSYNC();
+  // broadphase: the static pair list against bounding spheres (planes: distance of the sphere to the plane)
+  for (int base = 0; base < m.npair; base += RB_T) {
+    const int p = base + TID;
+    bool keep = false;
+    if (p < m.npair) {
+      const int g1 = m.b_pair_geom[3 * p], g2 = m.b_pair_geom[3 * p + 1];
+      const float margin = m.b_pair_prm[12 * p];
+      const v3 dif = ld3(gpos + 3 * g2) - ld3(gpos + 3 * g1);
+      if (m.geom_type[g1] == RG_GEOM_PLANE) keep = dot(dif, qrot(ldq(gquat + 4 * g1), mk3(0, 0, 1))) <= m.geom_rbound[g2] + margin;
+      else { const float bound = m.geom_rbound[g1] + m.geom_rbound[g2] + margin; keep = dot(dif, dif) <= bound * bound; }
+    }
+    const int slot = rb_slot(s, keep, &s.ncand, m.maxcand, RG_STATUS_CAND_FULL);
+    if (slot >= 0) cand[slot] = p;
+  }
+  // narrowphase: one quad per candidate, 64 candidates per trip
+  MprEnv E; E.mesh_vert = m.b_mesh_rec; E.cell_adr = 0; E.cell_blk = 0; E.cell_ovf = 0; E.prof = 0; E.cells = false; E.plane_depth = (flags & 16) != 0;
+  const int ncand = s.ncand;
+  float* con = SC(CON);
+  for (int base = 0; base < ncand; base += RB_T / 4) {
+    const int ci = base + (TID >> 2);
+    const bool active = ci < ncand;
+    bool hit = false; float dist = 0; v3 pos = mk3(0, 0, 0), nrm = mk3(0, 0, 1); int p = 0;
+    MprGeom A, B; A.type = RG_GEOM_SPHERE; B.type = RG_GEOM_SPHERE; A.quat = B.quat = gquat; A.size = B.size = mk3(0, 0, 0); A.pos = B.pos = mk3(0, 0, 0);
+    A.margin = B.margin = 0; A.mesh = B.mesh = -1; A.vertadr = B.vertadr = 0; A.nvert = B.nvert = 0;
+    float margin = 0;
+    v3 p1 = mk3(0, 0, 0);
+    bool plane = false;
+    if (active) {
+      p = cand[ci];
+      const int g1 = m.b_pair_geom[3 * p], g2 = m.b_pair_geom[3 * p + 1];
+      margin = m.b_pair_prm[12 * p];
+      rb_geom(m, S, g1, A); rb_geom(m, S, g2, B);
+      p1 = ld3(gpos + 3 * g1);
+      A.pos = mk3(0, 0, 0); B.pos = ld3(gpos + 3 * g2) - p1;
+      plane = A.type == RG_GEOM_PLANE;
+      A.margin = B.margin = plane ? 0.f : 0.5f * margin;
+    }
+    v3 sep, dir = mk3(0, 0, 0); float depth = 0;
+    // (the quads of a wave take the two branches with their own lanes: the group collectives inside only need the quad)
+    const bool mh = rg_mpr<4>(E, A, B, m.mpr_iterations, m.mpr_tolerance, depth, dir, pos, sep, active && !plane);
+    if (active && !plane) {
+      hit = mh && dot(dir, dir) > 0.25f;
+      dist = margin - depth; nrm = normalized(dir); pos = pos + p1;
+    }
+    const v3 pn = qrot(ldq(A.quat), mk3(0, 0, 1));
+    MprGeom Bs = B;   // plane - convex: the deepest point of the convex geom (quads on other pairs scan nothing)
+    if (!(active && plane)) { Bs.type = RG_GEOM_SPHERE; Bs.mesh = -1; Bs.size = mk3(0, 0, 0); }
+    const v3 sp = rg_support<4>(E, Bs, (active && plane) ? pn * -1.0f : mk3(0, 0, 1));
+    if (active && plane) {
+      dist = dot(sp, pn);
+      hit = dist <= margin;
+      pos = sp + p1 - pn * (0.5f * dist); nrm = pn;
+    }
+    const int slot = rb_slot(s, hit && (TID & 3) == 0, &s.ncon, m.maxcon, RG_STATUS_CON_FULL);
+    if (slot >= 0) {
+      float* c = con + RB_CONREC * slot;
+      const float* pr = m.b_pair_prm + 12 * p;
+      c[RB_CR_DIST] = dist; st3(c + RB_CR_POS, pos);
+      float fr[9]; fr[0] = nrm.x; fr[1] = nrm.y; fr[2] = nrm.z; rb_make_frame(fr);
+      for (int k = 0; k < 9; k++) c[RB_CR_FRAME + k] = fr[k];
+      c[RB_CR_INCL] = pr[0] - pr[1];
+      c[RB_CR_FRIC] = pr[2]; c[RB_CR_FRIC + 1] = pr[2]; c[RB_CR_FRIC + 2] = pr[3]; c[RB_CR_FRIC + 3] = pr[4]; c[RB_CR_FRIC + 4] = pr[4];
+      c[RB_CR_SOLREF] = pr[5]; c[RB_CR_SOLREF + 1] = pr[6];
+      for (int k = 0; k < 5; k++) c[RB_CR_SOLIMP + k] = pr[7 + k];
+      c[RB_CR_DIM] = (float)m.b_pair_geom[3 * p + 2]; c[RB_CR_G1] = (float)m.b_pair_geom[3 * p]; c[RB_CR_G2] = (float)m.b_pair_geom[3 * p + 1];
+      c[RB_CR_ADR] = -1.f; c[RB_CR_NNZ] = 0.f;
+    }
+  }
+  BSYNC();
+}
+
+// ------------------------------------------------------------------------------------------------- constraints
+__device__ __forceinline__ float rb_impedance(const float* si, float pos, float margin) { return impedance(si, pos, margin); }
+__device__ __forceinline__ void rb_KB(float timestep, const float* solref, const float* solimp, float& K, float& B) {
+  const float dmax = clampf(solimp[1], 1e-4f, 0.9999f);
+  if (solref[0] > 0) {
+    const float tc = fmaxf(solref[0], 2.f * timestep), dr = solref[1];
+    K = 1.f / fmaxf(RB_MINVAL, dmax * dmax * tc * tc * dr * dr); B = 2.f / fmaxf(RB_MINVAL, dmax * tc);
+  } else { K = -solref[0] / fmaxf(RB_MINVAL, dmax * dmax); B = -solref[1] / fmaxf(RB_MINVAL, dmax); }
+}
+__device__ __forceinline__ int rb_npyr(int dim) { return dim == 1 ? 1 : 2 * (dim - 1); }
+// J_row . x for a static row
+__device__ __forceinline__ float rb_srow_dot(RbM m, const float* S, int type, int id, float aux, const float* x) {
+  if (type == 0) return x[id];
+  if (type == 2) return aux * x[m.jnt_dofadr[id]];
+  float v = 0;
+  for (int e = 0; e < RB_TENW; e++) { const int d = m.b_ten_dofs[RB_TENW * id + e]; if (d >= 0) v += SC(TENJ)[RB_TENW * id + e] * x[d]; }
+  return type == 1 ? v : aux * v;
+}
+// mj_makeConstraint + mj_makeImpedance: rows in MuJoCo's order (friction dofs, friction tendons, joint limits, tendon limits,
+// contacts); per contact the six basis Jacobian rows (3 translational, 3 rotational, contact frame) on the union of the dof chains
+__device__ __forceinline__ void rb_make_constraint(RbM m, RbLds& s, float* S) {
+  float* row = SC(ROW); float* con = SC(CON);
+  const int nf = m.nfric_dof + m.nfric_ten;
+  // friction-loss rows
+  BFOR(r, nf) {
+    float* R = row + RB_ROWREC * r;
+    const bool ten = r >= m.nfric_dof;
+    const int id = ten ? m.b_fric_ten[r - m.nfric_dof] : m.b_fric_dof[r];
+    const float* solref = ten ? m.tendon_solref_fri + 2 * id : m.dof_solref + 2 * id;
+    const float* solimp = ten ? m.tendon_solimp_fri + 5 * id : m.dof_solimp + 5 * id;
+    const float diag = ten ? m.tendon_invweight0[id] : m.dof_invweight0[id], floss = ten ? m.tendon_frictionloss[id] : m.dof_frictionloss[id];
+    const float imp = rb_impedance(solimp, 0.f, 0.f);
+    const float Rr = fmaxf(RB_MINVAL, (1.f - imp) * diag / imp);
+    float K, B; rb_KB(m.timestep, solref, solimp, K, B);
+    R[RB_RR_TYPE] = ten ? 1.f : 0.f; R[RB_RR_ID] = (float)id; R[RB_RR_AUX] = 1.f; R[RB_RR_FLOSS] = floss; R[RB_RR_D] = 1.f / Rr;
+    R[RB_RR_AREF] = -B * rb_srow_dot(m, S, ten ? 1 : 0, id, 1.f, s.qvel);
+  }
+  // limits: joints then tendons, compacted in order by one thread (at most 2 x (limited joints + limited tendons) candidates)
+  if (TID == 0) {
+    int n = nf;
+    for (int q = 0; q < m.nlim_jnt + m.nlim_ten; q++) {
+      const bool ten = q >= m.nlim_jnt;
+      const int id = ten ? m.b_lim_ten[q - m.nlim_jnt] : m.b_lim_jnt[q];
+      const float value = ten ? SC(TENLEN)[id] : s.qpos[m.jnt_qposadr[id]];
+      const float* range = ten ? m.tendon_range + 2 * id : m.jnt_range + 2 * id;
+      const float margin = ten ? m.tendon_margin[id] : m.jnt_margin[id];
+      for (int side = -1; side <= 1; side += 2) {
+        const float dist = side * (range[(side + 1) / 2] - value);
+        if (dist < margin && n < m.maxrow) {
+          float* R = row + RB_ROWREC * n;
+          const float* solref = ten ? m.tendon_solref_lim + 2 * id : m.jnt_solref + 2 * id;
+          const float* solimp = ten ? m.tendon_solimp_lim + 5 * id : m.jnt_solimp + 5 * id;
+          const float diag = ten ? m.tendon_invweight0[id] : m.dof_invweight0[m.jnt_dofadr[id]];
+          const float imp = rb_impedance(solimp, dist, margin);
+          const float Rr = fmaxf(RB_MINVAL, (1.f - imp) * diag / imp);
+          float K, B; rb_KB(m.timestep, solref, solimp, K, B);
+          R[RB_RR_TYPE] = ten ? 3.f : 2.f; R[RB_RR_ID] = (float)id; R[RB_RR_AUX] = (float)(-side); R[RB_RR_FLOSS] = 0.f; R[RB_RR_D] = 1.f / Rr;
+          R[RB_RR_AREF] = -B * rb_srow_dot(m, S, ten ? 3 : 2, id, (float)(-side), s.qvel) - K * imp * (dist - margin);
+          n++;
+        }
+      }
+    }
+    s.nlim = n - nf;
+    // contacts: row addresses
+    for (int c = 0; c < s.ncon; c++) {
+      const int np = rb_npyr((int)con[RB_CONREC * c + RB_CR_DIM]);
+      if (n + np <= m.maxrow) { con[RB_CONREC * c + RB_CR_ADR] = (float)n; n += np; }
+      else { con[RB_CONREC * c + RB_CR_ADR] = -1.f; s.status |= RG_STATUS_ROW_FULL; }
+    }
+    s.nefc = n;
+  }
+  BSYNC();
+  // contact Jacobians: one thread per contact builds the dof list and the six basis rows
+  float* cj = SC(CONJ); int* cidx = (int*)SC(CONIDX);
+  const float *cdof = SC(CDOF), *rootcom = SC(ROOTCOM);
+  BFOR(c, s.ncon) {
+    float* C = con + RB_CONREC * c;
+    const int b1 = m.geom_bodyid[(int)C[RB_CR_G1]], b2 = m.geom_bodyid[(int)C[RB_CR_G2]];
+    const v3 pos = ld3(C + RB_CR_POS);
+    int* idx = cidx + RB_CONW * c; float* J = cj + 6 * RB_CONW * c;
+    int nnz = 0;
+    for (int side = 0; side < 2; side++) {
+      const int bb = side ? b1 : b2; const float sg = side ? -1.f : 1.f;   // difference body2 - body1
+      const v3 off = pos - ld3(rootcom + 3 * m.body_rootid[bb]);
+      for (int i = (bb > 0 ? m.b_body_lastdof[bb] : -1); i >= 0; i = m.dof_parentid[i]) {
+        int e = 0;
+        while (e < nnz && idx[e] != i) e++;
+        if (e == nnz) { if (nnz >= RB_CONW) continue; idx[nnz] = i; for (int r = 0; r < 6; r++) J[r * RB_CONW + nnz] = 0.f; nnz++; }
+        const v3 jp = rb_jacp(cdof, i, off), jr = ld3(cdof + 6 * i);
+        for (int r = 0; r < 3; r++) {
+          const v3 fr = ld3(C + RB_CR_FRAME + 3 * r);
+          J[r * RB_CONW + e] += sg * dot(fr, jp);
+          J[(3 + r) * RB_CONW + e] += sg * dot(fr, jr);
+        }
+      }
+    }
+    C[RB_CR_NNZ] = (float)nnz;
+    // rows of this contact
+    const int adr = (int)C[RB_CR_ADR];
+    if (adr < 0) continue;
+    const int dim = (int)C[RB_CR_DIM], np = rb_npyr(dim);
+    const float tran = m.body_invweight0[2 * b1] + m.body_invweight0[2 * b2], rot = m.body_invweight0[2 * b1 + 1] + m.body_invweight0[2 * b2 + 1];
+    const float dist = C[RB_CR_DIST], incl = C[RB_CR_INCL];
+    const float imp = rb_impedance(C + RB_CR_SOLIMP, dist, incl);
+    float K, B; rb_KB(m.timestep, C + RB_CR_SOLREF, C + RB_CR_SOLIMP, K, B);
+    float bd[6];
+    for (int r = 0; r < 6; r++) { float v = 0; for (int e = 0; e < nnz; e++) v += J[r * RB_CONW + e] * s.qvel[idx[e]]; bd[r] = v; }
+    if (dim == 1) {
+      float* R = row + RB_ROWREC * adr;
+      R[RB_RR_TYPE] = 4.f; R[RB_RR_ID] = (float)c; R[RB_RR_AUX] = 0.f; R[RB_RR_FLOSS] = 0.f;
+      R[RB_RR_D] = 1.f / fmaxf(RB_MINVAL, (1.f - imp) * tran / imp);
+      R[RB_RR_AREF] = -B * bd[0] - K * imp * (dist - incl);
+    } else {
+      // all pyramid rows share R = 2 mu^2 R_first, R_first from the first edge's diagApprox
+      const float fri0 = C[RB_CR_FRIC], diag0 = tran + fri0 * fri0 * tran;
+      const float Rfirst = fmaxf(RB_MINVAL, (1.f - imp) * diag0 / imp);
+      const float mu = fri0 * sqrtf(1.f / m.impratio);
+      const float Rpy = 2.f * mu * mu * Rfirst;
+      for (int q = 0; q < np; q++) {
+        const int k = q >> 1; const float sgn = (q & 1) ? -1.f : 1.f, fri = C[RB_CR_FRIC + k];
+        float* R = row + RB_ROWREC * (adr + q);
+        R[RB_RR_TYPE] = 4.f; R[RB_RR_ID] = (float)c; R[RB_RR_AUX] = sgn * (float)(k + 1); R[RB_RR_FLOSS] = 0.f;
+        R[RB_RR_D] = 1.f / Rpy;
+        R[RB_RR_AREF] = -B * (bd[0] + sgn * fri * bd[k + 1]) - K * imp * (dist - incl);
+      }
+    }
+  }
+  BSYNC();
+}
+
+// jar (to_jv = false: J x - aref) or jv (to_jv = true: J x) of every row
+__device__ __forceinline__ void rb_J_mul(RbM m, RbLds& s, float* S, const float* x, bool to_jv) {
+  float* row = SC(ROW); const float* con = SC(CON); const float* cj = SC(CONJ); const int* cidx = (const int*)SC(CONIDX);
+  BFOR(r, s.nefc) {
+    float* R = row + RB_ROWREC * r;
+    const int type = (int)R[RB_RR_TYPE], id = (int)R[RB_RR_ID];
+    float v;
+    if (type < 4) v = rb_srow_dot(m, S, type, id, R[RB_RR_AUX], x);
+    else {
+      const float* C = con + RB_CONREC * id; const float* J = cj + 6 * RB_CONW * id; const int* idx = cidx + RB_CONW * id;
+      const int nnz = (int)C[RB_CR_NNZ], a = (int)fabsf(R[RB_RR_AUX]);
+      float b0 = 0, bk = 0;
+      for (int e = 0; e < nnz; e++) { const float xe = x[idx[e]]; b0 += J[e] * xe; if (a) bk += J[a * RB_CONW + e] * xe; }
+      v = b0 + (a ? (R[RB_RR_AUX] < 0 ? -1.f : 1.f) * C[RB_CR_FRIC + a - 1] * bk : 0.f);
+    }
+    if (to_jv) R[RB_RR_JV] = v; else R[RB_RR_JAR] = v - R[RB_RR_AREF];
+  }
+  BSYNC();
+}
+// force of a row from its jar; `quad`: the row is in its quadratic zone (contributes D J'J to the Hessian)
+__device__ __forceinline__ float rb_row_force(const float* R, bool& quad, float& cost) {
+  const float D = R[RB_RR_D], x = R[RB_RR_JAR];
+  if ((int)R[RB_RR_TYPE] < 2) {
+    const float f = R[RB_RR_FLOSS], Rr = 1.f / D;
+    if (x <= -Rr * f) { quad = false; cost = f * (-0.5f * Rr * f - x); return f; }
+    if (x >= Rr * f) { quad = false; cost = f * (-0.5f * Rr * f + x); return -f; }
+    quad = true; cost = 0.5f * D * x * x; return -D * x;
+  }
+  if (x >= 0) { quad = false; cost = 0.f; return 0.f; }
+  quad = true; cost = 0.5f * D * x * x; return -D * x;
+}
+// dst[i] = sum over rows of J[r][i] * force[r]  (owner computes: every dof collects its rows in row order)
+__device__ __forceinline__ void rb_JT_force(RbM m, RbLds& s, float* S, float* dst) {
+  const float* row = SC(ROW); const float* con = SC(CON); const float* cj = SC(CONJ); const int* cidx = (const int*)SC(CONIDX);
+  const int nstat = m.nfric_dof + m.nfric_ten + s.nlim;
+  BFOR(i, m.nv) {
+    float acc = 0;
+    for (int r = 0; r < nstat; r++) {
+      const float* R = row + RB_ROWREC * r;
+      const int type = (int)R[RB_RR_TYPE], id = (int)R[RB_RR_ID];
+      bool q; float c; const float f = rb_row_force(R, q, c);
+      if (f == 0.f) continue;
+      if (type == 0) { if (id == i) acc += f; }
+      else if (type == 2) { if (m.jnt_dofadr[id] == i) acc += R[RB_RR_AUX] * f; }
+      else for (int e = 0; e < RB_TENW; e++) if (m.b_ten_dofs[RB_TENW * id + e] == i) acc += (type == 1 ? 1.f : R[RB_RR_AUX]) * SC(TENJ)[RB_TENW * id + e] * f;
+    }
+    for (int c = 0; c < s.ncon; c++) {
+      const float* C = con + RB_CONREC * c;
+      const int nnz = (int)C[RB_CR_NNZ], adr = (int)C[RB_CR_ADR];
+      if (adr < 0) continue;
+      const int* idx = cidx + RB_CONW * c;
+      int e = 0;
+      while (e < nnz && idx[e] != i) e++;
+      if (e == nnz) continue;
+      const float* J = cj + 6 * RB_CONW * c;
+      const int np = rb_npyr((int)C[RB_CR_DIM]);
+      for (int q = 0; q < np; q++) {
+        const float* R = row + RB_ROWREC * (adr + q);
+        bool qd; float cst; const float f = rb_row_force(R, qd, cst);
+        if (f == 0.f) continue;
+        const int a = (int)fabsf(R[RB_RR_AUX]);
+        acc += f * (J[e] + (a ? (R[RB_RR_AUX] < 0 ? -1.f : 1.f) * C[RB_CR_FRIC + a - 1] * J[a * RB_CONW + e] : 0.f));
+      }
+    }
+    dst[i] = acc;
+  }
+  BSYNC();
+}
+// s.A (holding the group's block of M) += J' diag(D, quadratic rows) J restricted to group g
+__device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g) {
+  const float* row = SC(ROW); const float* con = SC(CON); const float* cj = SC(CONJ); const int* cidx = (const int*)SC(CONIDX);
+  const int n = m.b_group_adr[g + 1] - m.b_group_adr[g];
+  const int nstat = m.nfric_dof + m.nfric_ten + s.nlim;
+  // static rows: dof rows add to the diagonal (friction rows first, then the limit rows: a dof has one friction row and at most
+  // one active limit side, so neither pass has two writers of an entry), tendon rows as small outer products one row at a time
+  for (int pass = 0; pass < 2; pass++) {
+    BFOR(r, nstat) {
+      const float* R = row + RB_ROWREC * r;
+      const int type = (int)R[RB_RR_TYPE], id = (int)R[RB_RR_ID];
+      if (type != (pass == 0 ? 0 : 2)) continue;
+      const int d = type == 0 ? id : m.jnt_dofadr[id];
+      if (m.b_dof_group[d] != g) continue;
+      bool q; float c; rb_row_force(R, q, c);
+      if (q) { const int l = m.b_dof_local[d]; s.A[l * n + l] += R[RB_RR_D]; }
+    }
+    BSYNC();
+  }
+  for (int r = 0; r < nstat; r++) {
+    const float* R = row + RB_ROWREC * r;
+    const int type = (int)R[RB_RR_TYPE], id = (int)R[RB_RR_ID];
+    if (type != 1 && type != 3) continue;
+    bool q; float c; rb_row_force(R, q, c);
+    if (!q) continue;
+    if (TID < RB_TENW * RB_TENW) {
+      const int ea = TID / RB_TENW, eb = TID % RB_TENW;
+      const int da = m.b_ten_dofs[RB_TENW * id + ea], db = m.b_ten_dofs[RB_TENW * id + eb];
+      if (da >= 0 && db >= 0 && m.b_dof_group[da] == g) s.A[m.b_dof_local[da] * n + m.b_dof_local[db]] += R[RB_RR_D] * SC(TENJ)[RB_TENW * id + ea] * SC(TENJ)[RB_TENW * id + eb];
+    }
+    BSYNC();
+  }
+  // contacts, one at a time: A += Jc' W Jc with the 6 x 6 weight W of the contact's quadratic pyramid edges
+  for (int c = 0; c < s.ncon; c++) {
+    const float* C = con + RB_CONREC * c;
+    const int adr = (int)C[RB_CR_ADR], nnz = (int)C[RB_CR_NNZ];
+    if (adr < 0) continue;
+    const int* idx = cidx + RB_CONW * c;
+    if (m.b_dof_group[idx[0]] != g) continue;
+    const float* J = cj + 6 * RB_CONW * c;
+    const int dim = (int)C[RB_CR_DIM], np = rb_npyr(dim);
+    // W: w_row = e0 +- mu_k e_(k+1)
+    float W00 = 0, W0k[5] = {0, 0, 0, 0, 0}, Wkk[5] = {0, 0, 0, 0, 0};
+    for (int q = 0; q < np; q++) {
+      const float* R = row + RB_ROWREC * (adr + q);
+      bool qd; float cst; rb_row_force(R, qd, cst);
+      if (!qd) continue;
+      const float D = R[RB_RR_D]; const int a = (int)fabsf(R[RB_RR_AUX]);
+      W00 += D;
+      if (a) { const float mu = (R[RB_RR_AUX] < 0 ? -1.f : 1.f) * C[RB_CR_FRIC + a - 1]; W0k[a - 1] += D * mu; Wkk[a - 1] += D * mu * mu; }
+    }
+    if (W00 != 0.f) {
+      for (int w = TID; w < nnz * nnz; w += RB_T) {
+        const int ea = w / nnz, eb = w - ea * nnz;
+        float v = W00 * J[ea] * J[eb];
+        for (int k = 0; k < dim - 1; k++) {
+          const float ja = J[(k + 1) * RB_CONW + ea], jb = J[(k + 1) * RB_CONW + eb];
+          v += W0k[k] * (J[ea] * jb + ja * J[eb]) + Wkk[k] * ja * jb;
+        }
+        s.A[m.b_dof_local[idx[ea]] * n + m.b_dof_local[idx[eb]]] += v;
+      }
+    }
+    BSYNC();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- solver
+struct RbLs { float cost, grad, hess; };
+__device__ __forceinline__ RbLs rb_ls_eval(RbLds& s, const float* row, int nefc, float alpha, float q0, float q1, float q2) {
+  float cst = 0, grd = 0, hss = 0;
+  BFOR(r, nefc) {
+    const float* R = row + RB_ROWREC * r;
+    const float D = R[RB_RR_D], jv = R[RB_RR_JV], x = R[RB_RR_JAR] + alpha * jv;
+    if ((int)R[RB_RR_TYPE] < 2) {
+      const float f = R[RB_RR_FLOSS], Rr = 1.f / D;
+      if (x <= -Rr * f) { cst += f * (-0.5f * Rr * f - x); grd += -f * jv; }
+      else if (x >= Rr * f) { cst += f * (-0.5f * Rr * f + x); grd += f * jv; }
+      else { cst += 0.5f * D * x * x; grd += D * x * jv; hss += D * jv * jv; }
+    } else if (x < 0) { cst += 0.5f * D * x * x; grd += D * x * jv; hss += D * jv * jv; }
+  }
+  rb_sum3(s, cst, grd, hss);
+  RbLs p; p.cost = alpha * alpha * q2 + alpha * q1 + q0 + cst; p.grad = 2.f * alpha * q2 + q1 + grd; p.hess = 2.f * q2 + hss;
+  return p;
+}
+// exact minimiser of the convex piecewise-quadratic 1-D restriction (oracle line_search: safeguarded Newton on the derivative)
+__device__ __forceinline__ float rb_line_search(RbLds& s, const float* row, int nefc, float q0, float q1, float q2, float gtol, int maxit) {
+  const RbLs p0 = rb_ls_eval(s, row, nefc, 0.f, q0, q1, q2);
+  if (p0.grad >= 0 || p0.hess <= 0) return 0.f;
+  float lo = 0, hi = -1, glo = p0.grad, hlo = p0.hess, ghi = 0, hhi = 0;
+  float a = -p0.grad / p0.hess;
+  for (int it = 0; it < maxit; it++) {
+    const RbLs p = rb_ls_eval(s, row, nefc, a, q0, q1, q2);
+    if (fabsf(p.grad) < gtol) return a;
+    if (p.grad < 0) { lo = a; glo = p.grad; hlo = p.hess; } else { hi = a; ghi = p.grad; hhi = p.hess; }
+    float cand = lo - glo / hlo;
+    if (hi >= 0 && !(cand > lo && cand < hi)) {
+      cand = hi - ghi / hhi;
+      if (!(cand > lo && cand < hi)) cand = 0.5f * (lo + hi);
+    }
+    if (cand == a) return a;
+    a = cand;
+  }
+  return a;
+}
+// mj_solNewton (oracle ro_solve): s.qa <- qacc, s.qfrc_con <- J' f; returns the iteration count
+__device__ __forceinline__ int rb_solve(RbM m, RbLds& s, float* S) {
+  const int nv = m.nv, ne = s.nefc;
+  float* row = SC(ROW); const float* Msp = SC(MSP);
+  if (ne == 0) { BFOR(i, nv) { s.qa[i] = s.qacc_smooth[i]; s.qfrc_con[i] = 0.f; } BSYNC(); return 0; }
+  const float scale = 1.f / (m.meaninertia * (nv > 1 ? nv : 1));
+  // warm start: the better of qacc_warmstart and qacc_smooth
+  float cost2[2];
+  for (int pass = 0; pass < 2; pass++) {
+    const float* a = pass == 0 ? s.warm : s.qacc_smooth;
+    rb_M_mul(m, Msp, a, s.Ma);
+    rb_J_mul(m, s, S, a, false);
+    float g = 0, c = 0;
+    BFOR(i, nv) g += 0.5f * (s.Ma[i] - s.qfrc_smooth[i]) * (a[i] - s.qacc_smooth[i]);
+    BFOR(r, ne) { bool q; float cc; rb_row_force(row + RB_ROWREC * r, q, cc); c += cc; }
+    cost2[pass] = rb_sum(s, g + c);
+  }
+  { const float* a = cost2[0] < cost2[1] ? s.warm : s.qacc_smooth; BFOR(i, nv) s.qa[i] = a[i]; }
+  BSYNC();
+  // fp32 cannot resolve (scaled) cost improvements below ~3e-7 (rg_kernel.h RG_TOL_FLOOR): MuJoCo's 1e-8 is an fp64 number
+  const float tol = fmaxf(m.tolerance, 3e-7f);
+  float cost = 0, oldcost = 0;
+  int iters = 0;
+  for (int iter = 0;; iter++) {
+    rb_M_mul(m, Msp, s.qa, s.Ma);
+    rb_J_mul(m, s, S, s.qa, false);
+    float g = 0, c = 0;
+    BFOR(i, nv) g += 0.5f * (s.Ma[i] - s.qfrc_smooth[i]) * (s.qa[i] - s.qacc_smooth[i]);
+    BFOR(r, ne) { bool q; float cc; rb_row_force(row + RB_ROWREC * r, q, cc); c += cc; }
+    const float gauss = rb_sum(s, g);
+    const float ccost = rb_sum(s, c);
+    oldcost = cost; cost = gauss + ccost;
+    rb_JT_force(m, s, S, s.qfrc_con);
+    float gn = 0;
+    BFOR(i, nv) { const float gi = s.Ma[i] - s.qfrc_smooth[i] - s.qfrc_con[i]; s.grad[i] = gi; gn += gi * gi; }
+    gn = sqrtf(rb_sum(s, gn)) * scale;
+    if (iter > 0 && scale * (oldcost - cost) < tol) break;
+    if (gn < tol || iter >= m.iterations) break;
+    iters = iter + 1;
+    // search = - inv(H) grad, group by group
+    bool okf = true;
+    for (int grp = 0; grp < m.ngroup; grp++) {
+      rb_M_block(m, s, Msp, grp, (const float*)0, 0.f);
+      rb_hessian_add(m, s, S, grp);
+      okf = rb_chol(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]) && okf;
+      rb_group_solve(m, s, grp, s.grad, s.search, -1.f);
+    }
+    if (!okf && TID == 0) s.status |= RG_STATUS_BAD_FACTOR;
+    rb_M_mul(m, Msp, s.search, s.Mv);
+    rb_J_mul(m, s, S, s.search, true);
+    float q1 = 0, q2 = 0, sn = 0;
+    BFOR(i, nv) { q1 += s.search[i] * (s.Ma[i] - s.qfrc_smooth[i]); q2 += 0.5f * s.search[i] * s.Mv[i]; sn += s.search[i] * s.search[i]; }
+    rb_sum3(s, q1, q2, sn);
+    sn = sqrtf(sn);
+    if (sn < RB_MINVAL) break;
+    const float gtol = tol * 0.01f * sn / scale * 1e-3f;   // (tolerance x ls_tolerance x |search| / scale x 1e-3: oracle's "exact" line search)
+    const float alpha = rb_line_search(s, row, ne, gauss, q1, q2, gtol, 40);
+    if (alpha == 0.f) break;
+    BFOR(i, nv) s.qa[i] += alpha * s.search[i];
+    BSYNC();
+  }
+  // forces at the solution (the loop's last gradient evaluation holds them: qfrc_con = J' f(qa))
+  return iters;
+}
+
+// ------------------------------------------------------------------------------------------------- integration
+// mj_Euler: implicit in joint damping, quaternion integration
+__device__ __forceinline__ void rb_euler(RbM m, RbLds& s, float* S) {
+  const float h = m.timestep;
+  BFOR(i, m.nv) s.grad[i] = s.qfrc_smooth[i] + s.qfrc_con[i];
+  BSYNC();
+  for (int grp = 0; grp < m.ngroup; grp++) {
+    rb_M_block(m, s, SC(MSP), grp, m.dof_damping, h);
+    if (!rb_chol(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]) && TID == 0) s.status |= RG_STATUS_BAD_FACTOR;
+    rb_group_solve(m, s, grp, s.grad, s.search, 1.f);   // s.search <- qacc of the damped system
+  }
+  BFOR(i, m.nv) s.qvel[i] += h * s.search[i];
+  BSYNC();
+  BFOR(j, m.njnt) {
+    int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j]; const int t = m.jnt_type[j];
+    if (t == RG_JNT_FREE) { for (int k = 0; k < 3; k++) s.qpos[qa + k] += h * s.qvel[da + k]; qa += 3; da += 3; }
+    if (t == RG_JNT_FREE || t == RG_JNT_BALL) {
+      v3 w = mk3(s.qvel[da], s.qvel[da + 1], s.qvel[da + 2]);
+      const float ang = norm(w) * h;
+      if (ang > 0) { const q4 qn = qnormalize(qmul(ldq(s.qpos + qa), axisangle(normalized(w), ang))); stq(s.qpos + qa, qn); }
+    } else s.qpos[qa] += h * s.qvel[da];
+  }
+  BSYNC();
+}
+
+#ifdef RG_EMUL
+#define RB_MAKE_CTX() const RbModelDev& m = *mp; const RbLaunch& L = launch
+#else
+#define RB_MAKE_CTX() RbM m = *(const RG_AS4 RbModelDev*)rg_uniform(mp); RbLRef L = *(const RG_AS4 RbLaunch*)((const RG_AS4 char*)__builtin_amdgcn_kernarg_segment_ptr() + 8)
+#endif
+__global__ void __launch_bounds__(RB_T) rb_step_kernel(const RbModelDev* mp, RbLaunch launch) {
+  RB_MAKE_CTX();
+  RbLds& s = RB_S();
+  const int e = blockIdx.x;
+  if (e >= L.bt.B) return;
+  if (L.bt.active && !L.bt.active[e]) return;
+  float* S = L.bt.scratch + (size_t)e * m.scratch_words;
+  const int nv = m.nv, nq = m.nq, nu = m.nu, flags = L.flags;
+  BFOR(i, nq) s.qpos[i] = L.bt.qpos[(size_t)e * nq + i];
+  BFOR(i, nv) { s.qvel[i] = L.bt.qvel[(size_t)e * nv + i]; s.warm[i] = L.bt.qacc_warmstart[(size_t)e * nv + i]; }
+  BFOR(i, 3 * nu) s.pid[i] = L.bt.pid[(size_t)e * 3 * nu + i];
+  if (TID == 0) { s.status = L.bt.status[e]; s.stop = 0; }
+  BSYNC();
+  // ---- action -> ctrl (robot_interface.py:247-278 with the hand's position -> control matrix)
+  bool use_action = L.bt.action != 0;
+  if (use_action) {
+    float nf = 0; BFOR(u, nu) nf += (fabsf(L.bt.action[(size_t)e * nu + u]) <= 3.0e38f) ? 0.f : 1.f;
+    if (rb_sum(s, nf) > 0) { use_action = false; if (TID == 0) s.status |= RG_STATUS_BAD_ACTION; }
+  }
+  BFOR(u, nu) {
+    if (use_action) {
+      const float lo = m.actuator_ctrlrange[2 * u], hi = m.actuator_ctrlrange[2 * u + 1];
+      float centre;
+      if (L.env.relative_action) { centre = 0; for (int j = 0; j < L.env.n_hand_jnt; j++) centre += L.env.pos_to_ctrl[u * L.env.n_hand_jnt + j] * s.qpos[L.env.hand_qposadr + j]; }
+      else centre = 0.5f * (hi + lo);
+      s.ctrl[u] = clampf(centre + clampf(L.bt.action[(size_t)e * nu + u], -1.f, 1.f) * 0.5f * (hi - lo), lo, hi);
+    } else s.ctrl[u] = L.bt.ctrl[(size_t)e * nu + u];
+  }
+  BSYNC();
+  float st_ncon = 0, st_nefc = 0, st_iter = 0; int nsub_done = 0;
+  for (int sub = 0; sub < L.nsubsteps; sub++) {
+    float bd = 0; BFOR(i, nq) bd += (fabsf(s.qpos[i]) < 1e10f) ? 0.f : 1.f; BFOR(i, nv) bd += (fabsf(s.qvel[i]) < 1e10f) ? 0.f : 1.f;
+    if (rb_sum(s, bd) > 0) { if (TID == 0) s.status |= RG_STATUS_BAD_STATE; break; }
+    rb_kinematics(m, s, S); rb_com_pos(m, s, S); rb_tendon(m, s, S); rb_crb(m, s, S);
+    rb_velocity(m, s, S);
+    rb_collision(m, s, S, flags);
+    rb_make_constraint(m, s, S);
+    rb_pid(m, s, S, true);
+    // qacc_smooth = inv(M) qfrc_smooth
+    for (int grp = 0; grp < m.ngroup; grp++) {
+      rb_M_block(m, s, SC(MSP), grp, (const float*)0, 0.f);
+      if (!rb_chol(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]) && TID == 0) s.status |= RG_STATUS_BAD_FACTOR;
+      rb_group_solve(m, s, grp, s.qfrc_smooth, s.qacc_smooth, 1.f);
+    }
+    if ((flags & 1) && sub == 0) {   // stage dump of the first mj_step: ncon, nefc (the arrays themselves are read from the scratch row)
+      if (TID == 0) { SC(DBG)[0] = (float)s.ncon; SC(DBG)[1] = (float)s.nefc; }
+      BFOR(i, nv) { SC(DBG)[8 + i] = s.qfrc_bias[i]; SC(DBG)[8 + nv + i] = s.qfrc_passive[i]; SC(DBG)[8 + 2 * nv + i] = s.qfrc_act[i]; SC(DBG)[8 + 3 * nv + i] = s.qacc_smooth[i]; }
+    }
+    const int iters = rb_solve(m, s, S);
+    if ((flags & 1) && sub == 0) { if (TID == 0) SC(DBG)[2] = (float)iters; BFOR(i, nv) SC(DBG)[8 + 4 * nv + i] = s.qa[i]; }
+    st_ncon += s.ncon; st_nefc += s.nefc; st_iter += iters; nsub_done++;
+    bd = 0; BFOR(i, nv) bd += (fabsf(s.qa[i]) < 1e10f) ? 0.f : 1.f;
+    if (rb_sum(s, bd) > 0) { if (TID == 0) s.status |= RG_STATUS_BAD_STATE; break; }
+    BFOR(i, nv) s.warm[i] = s.qa[i];
+    rb_euler(m, s, S);
+  }
+  // ---- the state-less forward() calls of the reference: only their PID side effect touches the state
+  if (L.nforward_ticks > 0) {
+    rb_kinematics(m, s, S); rb_com_pos(m, s, S); rb_tendon(m, s, S);
+    for (int k = 0; k < L.nforward_ticks; k++) rb_pid(m, s, S, false);
+  }
+  BFOR(i, nq) L.bt.qpos[(size_t)e * nq + i] = s.qpos[i];
+  BFOR(i, nv) { L.bt.qvel[(size_t)e * nv + i] = s.qvel[i]; L.bt.qacc_warmstart[(size_t)e * nv + i] = s.warm[i]; }
+  BFOR(i, 3 * nu) L.bt.pid[(size_t)e * 3 * nu + i] = s.pid[i];
+  BFOR(u, nu) L.bt.ctrl[(size_t)e * nu + u] = s.ctrl[u];
+  if (TID == 0) {
+    L.bt.status[e] = s.status; L.bt.time[e] += nsub_done * m.timestep;
+    float* st = L.bt.stats + 4 * (size_t)e; st[0] += st_ncon; st[1] += st_nefc; st[2] += st_iter; st[3] += nsub_done;
+  }
+}
+}  // namespace rgb

@@ -1,0 +1,104 @@
+// rb_types.h — descriptors of the LARGE-MODEL stepper (rb_kernel.h): models beyond the compile-time layout of the
+// Shadow-hand kernel (rg_kernel.h), e.g. dactyl/full_perpendicular (BASELINE.json configs[2]: nv 168, 135 bodies,
+// condim-6 contacts; /root/reference/robogym/envs/dactyl/full_perpendicular.py:92-136, cube_env.py:239-242).
+// One 256-thread workgroup per env, every size a run-time number of the model, per-env stage arrays in an HBM scratch row
+// (names as MuJoCo's mjData), the dense blocks of the solver in LDS.
+#pragma once
+#include <stdint.h>
+
+#define RB_T 256          // threads per workgroup (4 waves)
+#define RB_TENW 8         // dofs a tendon can depend on (big_tables.py TEN_W)
+#define RB_CONW 24        // dofs a contact can depend on (big_tables.py CON_W)
+#define RB_MAXGROUP 96    // dofs of the largest constraint-coupled group of trees: its dense block lives in LDS
+#define RB_MAXNV 192      // LDS vectors
+#define RB_MAXNQ 192
+
+// arrays of the model blob that are uploaded as they are (field name = blob name)
+#define RB_INT_ARRAYS(X) \
+  X(body_parentid) X(body_rootid) X(body_weldid) X(body_jntadr) X(body_jntnum) X(body_dofadr) X(body_dofnum) \
+  X(jnt_type) X(jnt_qposadr) X(jnt_dofadr) X(jnt_bodyid) \
+  X(dof_bodyid) X(dof_jntid) X(dof_parentid) \
+  X(geom_type) X(geom_bodyid) X(geom_dataid) X(site_bodyid) \
+  X(mesh_vertadr) X(mesh_vertnum) \
+  X(tendon_adr) X(tendon_num) X(wrap_type) X(wrap_objid) \
+  X(actuator_trntype) X(actuator_trnid) X(actuator_forcelimited) X(actuator_biastype) \
+  X(b_lvl_body) X(b_lvl_adr) X(b_body_lastdof) X(b_subtree_adr) X(b_subtree) X(b_root_list) X(b_M_i) X(b_M_j) X(b_M_adr) \
+  X(b_group_adr) X(b_group_dofs) X(b_dof_group) X(b_dof_local) X(b_pair_geom) X(b_ten_dofs) X(b_fric_dof) X(b_fric_ten) X(b_lim_jnt) X(b_lim_ten)
+#define RB_FLT_ARRAYS(X) \
+  X(body_pos) X(body_quat) X(body_ipos) X(body_iquat) X(body_mass) X(body_inertia) X(body_subtreemass) X(body_invweight0) \
+  X(jnt_pos) X(jnt_axis) X(jnt_stiffness) X(jnt_range) X(jnt_margin) X(jnt_solref) X(jnt_solimp) \
+  X(dof_armature) X(dof_damping) X(dof_frictionloss) X(dof_solref) X(dof_solimp) X(dof_invweight0) \
+  X(qpos0) X(qpos_spring) \
+  X(geom_size) X(geom_rbound) X(geom_pos) X(geom_quat) X(site_pos) \
+  X(wrap_prm) X(tendon_range) X(tendon_margin) X(tendon_stiffness) X(tendon_damping) X(tendon_frictionloss) X(tendon_lengthspring) \
+  X(tendon_solref_lim) X(tendon_solimp_lim) X(tendon_solref_fri) X(tendon_solimp_fri) X(tendon_invweight0) \
+  X(actuator_gear) X(actuator_ctrlrange) X(actuator_forcerange) X(actuator_gainprm) \
+  X(b_pair_prm) X(b_mesh_rec)
+
+// per-env scratch row: offsets (in 4-byte words) of the stage arrays
+enum {
+  RB_O_XPOS, RB_O_XQUAT, RB_O_XIPOS, RB_O_XIQUAT, RB_O_XANCHOR, RB_O_XAXIS, RB_O_GPOS, RB_O_GQUAT, RB_O_SPOS, RB_O_ROOTCOM,
+  RB_O_CINERT, RB_O_CRB, RB_O_CDOF, RB_O_CDOFDOT, RB_O_CVEL, RB_O_CACC, RB_O_CFRC,
+  RB_O_TENLEN, RB_O_TENJ, RB_O_TENVEL, RB_O_MSP,
+  RB_O_CAND, RB_O_CON, RB_O_CONJ, RB_O_CONIDX, RB_O_ROW,
+  RB_O_DBG, RB_NOFF
+};
+// per contact record (floats): dist, pos3, frame9, includemargin, friction5, solref2, solimp5, dim, geom1, geom2, efc_address, nnz, R
+#define RB_CONREC 32
+#define RB_CR_DIST 0
+#define RB_CR_POS 1
+#define RB_CR_FRAME 4
+#define RB_CR_INCL 13
+#define RB_CR_FRIC 14
+#define RB_CR_SOLREF 19
+#define RB_CR_SOLIMP 21
+#define RB_CR_DIM 26
+#define RB_CR_G1 27
+#define RB_CR_G2 28
+#define RB_CR_ADR 29
+#define RB_CR_NNZ 30
+// per constraint row (floats): D, aref, jar, jv, floss, type (0 friction dof, 1 friction tendon, 2 joint limit, 3 tendon limit, 4 pyramid edge), id, aux (side | pyramid edge k, sign)
+#define RB_ROWREC 8
+#define RB_RR_D 0
+#define RB_RR_AREF 1
+#define RB_RR_JAR 2
+#define RB_RR_JV 3
+#define RB_RR_FLOSS 4
+#define RB_RR_TYPE 5
+#define RB_RR_ID 6
+#define RB_RR_AUX 7
+
+struct RbModelDev {
+  int nq, nv, nu, nbody, njnt, ngeom, nsite, ntendon, nmesh;
+  int nlevel, nM, npair, ngroup, gmax, nroot, conw;
+  int nfric_dof, nfric_ten, nlim_jnt, nlim_ten;
+  int maxcon, maxrow, maxcand;       // capacities of the scratch row (nconmax, njmax of the model)
+  int iterations, mpr_iterations, ls_iterations;
+  float timestep, gravity[3], tolerance, impratio, mpr_tolerance, meaninertia;
+  int off[RB_NOFF];
+  int scratch_words;                 // row length
+#define X(n) const int* n;
+  RB_INT_ARRAYS(X)
+#undef X
+#define X(n) const float* n;
+  RB_FLT_ARRAYS(X)
+#undef X
+};
+
+// env-level description: hand joint block and position -> control matrix of the action map (robot_interface.py:247-278)
+struct RbEnvDev {
+  int hand_qposadr, n_hand_jnt, relative_action;
+  const float* pos_to_ctrl;   // [nu][n_hand_jnt]
+};
+
+struct RbBatchDev {
+  int B;
+  float *qpos, *qvel, *ctrl, *pid, *qacc_warmstart, *time;
+  uint32_t* status;
+  float* stats;          // [B][4] accumulated ncon, nefc, Newton iterations, substeps
+  float* scratch;        // [B][scratch_words]
+  const float* action;   // [B][nu] or null
+  const int* active;     // [B] or null
+};
+
+struct RbLaunch { RbEnvDev env; RbBatchDev bt; int nsubsteps, nforward_ticks, flags; };

@@ -82,6 +82,7 @@ static const char* hipGetErrorString(hipError_t) { return "emul"; }
 #endif
 
 #include "rg_env_kernel.h"
+#include "rb_kernel.h"
 #define RG_WAVES_PER_SIMD_HOST 3   /* = RG_WAVES_PER_SIMD of rg_kernel.h (its default) */
 struct rg_batch;
 extern "C" { static void rg_items_probe(rg_batch* b); }
@@ -824,6 +825,208 @@ int rg_batch_set_constants(rg_batch* b, const int* mask_dev, void* stream) {
   emul_launch(bt.B, lds, emul_setconst_entry, &args);
 #else
   hipLaunchKernelGGL(rgl::rg_setconst_kernel, dim3(bt.B), dim3(RG_WAVE), lds, (hipStream_t)stream, b->model->dev_copy, launch, (float*)b->dev.envprm);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+
+// =====================================================================================================================
+// Large-model path (rb_kernel.h): models beyond the compile-time layout of the Shadow-hand kernel.  Same blob, same
+// ownership and error conventions; entry points rb_* (include/rgstep.h).
+// =====================================================================================================================
+struct rb_model {
+  int device = 0;
+  RbModelDev dev;
+  const RbModelDev* dev_copy = nullptr;
+  std::vector<void*> allocs;
+  std::vector<float> qpos0;
+};
+struct rb_batch {
+  const rb_model* model;
+  RbBatchDev dev;
+  RbEnvDev env;
+  int device;
+  int has_env = 0;
+  std::vector<void*> allocs;
+};
+static bool rb_upload_bytes(rb_model* m, const void* host, size_t bytes, const void** dst) {
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes ? bytes : 4) != hipSuccess) return false;
+  m->allocs.push_back(p);
+  if (bytes && hipMemcpy(p, host, bytes, hipMemcpyHostToDevice) != hipSuccess) return false;
+  *dst = p;
+  return true;
+}
+void rb_model_free(rb_model* m) {
+  if (!m) return;
+  { DeviceGuard g(m->device); for (void* p : m->allocs) hipFree(p); }
+  delete m;
+}
+rb_model* rb_model_create(const void* blob, size_t nbytes, char* err, int errlen) {
+  auto bail = [&](const std::string& msg, rb_model* m) -> rb_model* {
+    g_err = msg;
+    if (err && errlen > 0) { strncpy(err, msg.c_str(), errlen - 1); err[errlen - 1] = 0; }
+    if (m) rb_model_free(m);
+    return nullptr;
+  };
+  if (!blob || nbytes < 16 || memcmp(blob, "RGMODEL1", 8) != 0) return bail("not an RGMODEL1 blob", nullptr);
+  Blob B{(const char*)blob, nbytes};
+  rb_model* m = new rb_model();
+#ifndef RG_EMUL
+  if (hipGetDevice(&m->device) != hipSuccess) return bail("hipGetDevice failed", m);
+#endif
+  RbModelDev& d = m->dev;
+  memset(&d, 0, sizeof d);
+  std::string e;
+  std::vector<int> iv; std::vector<float> fv;
+  if (!get_i(B, "dims", iv, e)) return bail(e, m);
+  d.nq = iv[0]; d.nv = iv[1]; d.nu = iv[2]; d.nbody = iv[3]; d.njnt = iv[4]; d.ngeom = iv[5]; d.nsite = iv[6]; d.ntendon = iv[7]; d.nmesh = iv[9];
+  if (!get_i(B, "b_dims", iv, e)) return bail(e + " (derive_big_tables was not run on the model)", m);
+  d.nlevel = iv[0]; d.nM = iv[1]; d.npair = iv[2]; d.ngroup = iv[3]; d.gmax = iv[4]; d.nroot = iv[5]; d.conw = iv[6];
+  if (d.gmax > RB_MAXGROUP) return bail("a constraint-coupled group of trees has more dofs than RB_MAXGROUP", m);
+  if (d.nv > RB_MAXNV || d.nq > RB_MAXNQ || d.nu > 32 || d.conw > RB_CONW) return bail("model exceeds the LDS vector capacities of rb_kernel.h", m);
+#define X(n) if (!get_i(B, #n, iv, e)) return bail(e, m); if (!rb_upload_bytes(m, iv.data(), iv.size() * 4, (const void**)&d.n)) return bail("hipMalloc failed", m);
+  RB_INT_ARRAYS(X)
+#undef X
+#define X(n) if (!get_f(B, #n, fv, e)) return bail(e, m); if (!rb_upload_bytes(m, fv.data(), fv.size() * 4, (const void**)&d.n)) return bail("hipMalloc failed", m);
+  RB_FLT_ARRAYS(X)
+#undef X
+  if (!get_i(B, "b_fric_dof", iv, e)) return bail(e, m); d.nfric_dof = (int)iv.size();
+  if (!get_i(B, "b_fric_ten", iv, e)) return bail(e, m); d.nfric_ten = (int)iv.size();
+  if (!get_i(B, "b_lim_jnt", iv, e)) return bail(e, m); d.nlim_jnt = (int)iv.size();
+  if (!get_i(B, "b_lim_ten", iv, e)) return bail(e, m); d.nlim_ten = (int)iv.size();
+  if (!get_i(B, "actuator_biastype", iv, e)) return bail(e, m);
+  for (int v : iv) if (v != 2) return bail("rb_model_create: only mujoco-py PID actuators (biastype user) are implemented", m);
+  if (!get_i(B, "opt_int", iv, e)) return bail(e, m);
+  d.iterations = iv[0]; d.ls_iterations = iv[2]; d.mpr_iterations = iv[3];
+  if (iv[1] != 0) return bail("rb_model_create: elliptic cones are not implemented", m);
+  if (!get_i(B, "size_int", iv, e)) return bail(e, m);
+  d.maxrow = iv[0] > 0 ? iv[0] : 2000; d.maxcon = iv[1] > 0 ? iv[1] : 200;   // njmax / nconmax of the model
+  d.maxcand = 4 * d.maxcon + 256;
+  if (!get_f(B, "opt_timestep", fv, e)) return bail(e, m); d.timestep = fv[0];
+  if (!get_f(B, "opt_gravity", fv, e)) return bail(e, m); for (int k = 0; k < 3; k++) d.gravity[k] = fv[k];
+  if (!get_f(B, "opt_tolerance", fv, e)) return bail(e, m); d.tolerance = fv[0];
+  if (!get_f(B, "opt_impratio", fv, e)) return bail(e, m); d.impratio = fv[0];
+  if (!get_f(B, "opt_mpr_tolerance", fv, e)) return bail(e, m); d.mpr_tolerance = fv[0];
+  if (!get_f(B, "stat_meaninertia", fv, e)) return bail(e, m); d.meaninertia = fv[0];
+  if (!get_f(B, "qpos0", m->qpos0, e)) return bail(e, m);
+  // scratch row layout
+  int o = 0;
+  auto take = [&](int which, int words) { d.off[which] = o; o += (words + 3) & ~3; };
+  take(RB_O_XPOS, 3 * d.nbody); take(RB_O_XQUAT, 4 * d.nbody); take(RB_O_XIPOS, 3 * d.nbody); take(RB_O_XIQUAT, 4 * d.nbody);
+  take(RB_O_XANCHOR, 3 * d.njnt); take(RB_O_XAXIS, 3 * d.njnt); take(RB_O_GPOS, 3 * d.ngeom); take(RB_O_GQUAT, 4 * d.ngeom); take(RB_O_SPOS, 3 * d.nsite);
+  take(RB_O_ROOTCOM, 3 * d.nbody); take(RB_O_CINERT, 10 * d.nbody); take(RB_O_CRB, 10 * d.nbody); take(RB_O_CDOF, 6 * d.nv); take(RB_O_CDOFDOT, 6 * d.nv);
+  take(RB_O_CVEL, 6 * d.nbody); take(RB_O_CACC, 6 * d.nbody); take(RB_O_CFRC, 6 * d.nbody);
+  take(RB_O_TENLEN, d.ntendon); take(RB_O_TENJ, RB_TENW * d.ntendon); take(RB_O_TENVEL, d.ntendon); take(RB_O_MSP, d.nM);
+  take(RB_O_CAND, d.maxcand); take(RB_O_CON, RB_CONREC * d.maxcon); take(RB_O_CONJ, 6 * RB_CONW * d.maxcon); take(RB_O_CONIDX, RB_CONW * d.maxcon);
+  take(RB_O_ROW, RB_ROWREC * d.maxrow); take(RB_O_DBG, 8 + 5 * d.nv);
+  d.scratch_words = o;
+  void* p = nullptr;
+  if (hipMalloc(&p, sizeof(RbModelDev)) != hipSuccess) return bail("hipMalloc failed", m);
+  m->allocs.push_back(p);
+  if (hipMemcpy(p, &d, sizeof(RbModelDev), hipMemcpyHostToDevice) != hipSuccess) return bail("hipMemcpy failed", m);
+  m->dev_copy = (const RbModelDev*)p;
+  return m;
+}
+int rb_model_info(const rb_model* m, int* out, int n) {
+  if (!m) return fail("null model");
+  const RbModelDev& d = m->dev;
+  const int v[] = {d.nq, d.nv, d.nu, d.nbody, d.njnt, d.ngeom, d.nsite, d.ntendon, d.nM, d.npair, d.ngroup, d.gmax, d.maxcon, d.maxrow, d.scratch_words, RB_CONREC, RB_ROWREC, RB_CONW, RB_TENW,
+                   (int)sizeof(rgb::RbLds)};
+  const int k = (int)(sizeof v / sizeof v[0]);
+  for (int i = 0; i < k && i < n; i++) out[i] = v[i];
+  return k;
+}
+int rb_scratch_offset(const rb_model* m, int which) { return (m && which >= 0 && which < RB_NOFF) ? m->dev.off[which] : -1; }
+static void* rb_balloc(rb_batch* b, size_t n) {
+  void* p = nullptr;
+  if (hipMalloc(&p, n ? n : 1) != hipSuccess) return nullptr;
+  hipMemset(p, 0, n ? n : 1);
+  b->allocs.push_back(p);
+  return p;
+}
+void rb_batch_free(rb_batch* b) {
+  if (!b) return;
+  { DeviceGuard g(b->device); for (void* p : b->allocs) hipFree(p); }
+  delete b;
+}
+int rb_batch_reset(rb_batch* b) {
+  if (!b) return fail("null batch");
+  DeviceGuard g(b->device);
+  const RbModelDev& d = b->model->dev; RbBatchDev& s = b->dev;
+  HIPCHK(hipDeviceSynchronize());
+  std::vector<float> q((size_t)s.B * d.nq);
+  for (int e = 0; e < s.B; e++) memcpy(q.data() + (size_t)e * d.nq, b->model->qpos0.data(), d.nq * 4);
+  HIPCHK(hipMemcpy(s.qpos, q.data(), q.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(s.qvel, 0, (size_t)s.B * d.nv * 4)); HIPCHK(hipMemset(s.ctrl, 0, (size_t)s.B * d.nu * 4));
+  HIPCHK(hipMemset(s.pid, 0, (size_t)s.B * 3 * d.nu * 4)); HIPCHK(hipMemset(s.qacc_warmstart, 0, (size_t)s.B * d.nv * 4));
+  HIPCHK(hipMemset(s.time, 0, (size_t)s.B * 4)); HIPCHK(hipMemset(s.status, 0, (size_t)s.B * 4)); HIPCHK(hipMemset(s.stats, 0, (size_t)s.B * 16));
+  return 0;
+}
+rb_batch* rb_batch_create(const rb_model* m, int B) {
+  if (!m || B <= 0) { fail("bad arguments to rb_batch_create"); return nullptr; }
+  DeviceGuard g(m->device);
+  rb_batch* b = new rb_batch();
+  b->model = m; b->device = m->device;
+  memset(&b->dev, 0, sizeof b->dev); memset(&b->env, 0, sizeof b->env);
+  const RbModelDev& d = m->dev; RbBatchDev& s = b->dev;
+  s.B = B;
+  s.qpos = (float*)rb_balloc(b, (size_t)B * d.nq * 4); s.qvel = (float*)rb_balloc(b, (size_t)B * d.nv * 4);
+  s.ctrl = (float*)rb_balloc(b, (size_t)B * d.nu * 4); s.pid = (float*)rb_balloc(b, (size_t)B * 3 * d.nu * 4);
+  s.qacc_warmstart = (float*)rb_balloc(b, (size_t)B * d.nv * 4); s.time = (float*)rb_balloc(b, (size_t)B * 4);
+  s.status = (uint32_t*)rb_balloc(b, (size_t)B * 4); s.stats = (float*)rb_balloc(b, (size_t)B * 16);
+  s.scratch = (float*)rb_balloc(b, (size_t)B * d.scratch_words * 4);
+  if (!s.qpos || !s.qvel || !s.ctrl || !s.pid || !s.qacc_warmstart || !s.time || !s.status || !s.stats || !s.scratch) { fail("hipMalloc failed"); rb_batch_free(b); return nullptr; }
+  if (rb_batch_reset(b) != 0) { rb_batch_free(b); return nullptr; }
+  return b;
+}
+int rb_batch_set_env(rb_batch* b, int hand_qposadr, int n_hand_jnt, int relative_action, const float* p2c) {
+  if (!b || !p2c) return fail("rb_batch_set_env: null argument");
+  DeviceGuard g(b->device);
+  const size_t n = (size_t)b->model->dev.nu * n_hand_jnt;
+  float* dp = (float*)rb_balloc(b, n * 4);
+  if (!dp) return fail("hipMalloc failed");
+  HIPCHK(hipMemcpy(dp, p2c, n * 4, hipMemcpyHostToDevice));
+  b->env.hand_qposadr = hand_qposadr; b->env.n_hand_jnt = n_hand_jnt; b->env.relative_action = relative_action; b->env.pos_to_ctrl = dp;
+  b->has_env = 1;
+  return 0;
+}
+void* rb_batch_field_ptr(rb_batch* b, int field, int* row_words) {
+  if (!b) { fail("null batch"); return nullptr; }
+  const RbModelDev& d = b->model->dev; RbBatchDev& s = b->dev;
+  void* p = nullptr; int n = 0;
+  switch (field) {
+    case RG_F_QPOS: p = s.qpos; n = d.nq; break;
+    case RG_F_QVEL: p = s.qvel; n = d.nv; break;
+    case RG_F_CTRL: p = s.ctrl; n = d.nu; break;
+    case RG_F_PID: p = s.pid; n = 3 * d.nu; break;
+    case RG_F_WARMSTART: p = s.qacc_warmstart; n = d.nv; break;
+    case RG_F_TIME: p = s.time; n = 1; break;
+    case RG_F_STATUS: p = s.status; n = 1; break;
+    case RG_F_STATS: p = s.stats; n = 4; break;
+    case RG_F_DEBUG: p = s.scratch; n = d.scratch_words; break;   // the whole scratch row (stage arrays, rb_scratch_offset)
+    default: fail("rb_batch_field_ptr: unknown field"); return nullptr;
+  }
+  if (row_words) *row_words = n;
+  return p;
+}
+#ifdef RG_EMUL
+struct EmulRbArgs { const RbModelDev* m; RbLaunch launch; };
+static void emul_rb_entry(void* a) { EmulRbArgs* p = (EmulRbArgs*)a; rgb::rb_step_kernel(p->m, p->launch); }
+#endif
+int rb_batch_step(rb_batch* b, const float* action_dev, const int* active_dev, int nsubsteps, int nforward_ticks, int flags, void* stream) {
+  if (!b) return fail("null batch");
+  if (action_dev && !b->has_env) return fail("rb_batch_set_env must be called before stepping with actions");
+  if (nsubsteps < 0 || nforward_ticks < 0) return fail("rb_batch_step: negative step counts");
+  DeviceGuard g(b->device);
+  RbBatchDev bt = b->dev;
+  bt.action = action_dev; bt.active = active_dev;
+  RbLaunch launch{b->env, bt, nsubsteps, nforward_ticks, flags};
+#ifdef RG_EMUL
+  EmulRbArgs args{b->model->dev_copy, launch};
+  emul_launch_n(bt.B, RB_T, sizeof(rgb::RbLds), emul_rb_entry, &args);
+#else
+  hipLaunchKernelGGL(rgb::rb_step_kernel, dim3(bt.B), dim3(RB_T), sizeof(rgb::RbLds), (hipStream_t)stream, b->model->dev_copy, launch);
   HIPCHK(hipGetLastError());
 #endif
   return 0;

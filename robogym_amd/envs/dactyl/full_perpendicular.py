@@ -41,6 +41,7 @@ def build_full_perpendicular_xml(cube_xml_path: str = "rubik/rubik_perpendicular
     xml.append(
         MujocoXML.parse("robot/shadowhand/main.xml")
         .add_name_prefix("robot0:")
+        .set_objects_attr(tag="size", njmax=2000, nconmax=200, nuserdata=100, nuser_actuator=20)     # cube_env.py:239-242, applied at :199
         .set_named_objects_attr("robot0:hand_mount", tag="body", pos=[1.0, 1.25, 0.15], euler=[np.pi / 2, 0, np.pi])
         .remove_objects_by_name("robot0:annotation:outer_bound")
         .remove_objects_by_name("robot0:hand_base")

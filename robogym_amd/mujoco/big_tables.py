@@ -1,0 +1,159 @@
+"""Static execution tables of the LARGE-MODEL stepper (`rb_step_kernel`, robogym_amd/csrc/rb_kernel.h), derived once on the
+host from a compiled model: what `kernel_tables.py` is to the Shadow-hand kernel, for models beyond its compile-time layout
+(dactyl/full_perpendicular: nv 168, 135 bodies, condim-6 contacts; reference
+/root/reference/robogym/envs/dactyl/full_perpendicular.py:92-136, cube_env.py:239-242).
+
+Everything here is a re-arrangement of `mjModel` index arrays (no physics):
+
+* body levels (tree depth) for the top-down / bottom-up sweeps, subtree lists, the last dof of every body's chain
+* the tree-sparse entry list of the joint-space inertia matrix M: (i, j) for every dof i and every ancestor dof j
+* dof GROUPS: kinematic trees that a constraint can couple (static collision pairs, tendons) are merged; the Newton Hessian
+  and M are factored group by group as dense blocks over the group's dofs
+* the static collision pair list with mixed contact parameters (shared with kernel_tables: `collision_pairs`)
+* static dof supports of the tendons, the constraint-row sources (friction-loss dofs / tendons, limited joints / tendons)
+"""
+import numpy as np
+
+from robogym_amd.mujoco import mjcf_compiler as C
+from robogym_amd.mujoco.kernel_tables import collision_pairs
+
+TEN_W = 8        # dofs a tendon can depend on (RB_TENW)
+CON_W = 24       # dofs a contact can depend on (RB_CONW)
+
+
+def _i32(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.int32))
+
+
+def derive_big_tables(model):
+    A = model.arrays
+    nb, nv, ng = len(A["body_parentid"]), len(A["dof_bodyid"]), len(A["geom_type"])
+    parent, dpar = A["body_parentid"], A["dof_parentid"]
+
+    # ---- body levels (world = 0)
+    depth = np.zeros(nb, dtype=int)
+    for b in range(1, nb):
+        depth[b] = depth[parent[b]] + 1
+    lvl, adr = [], [0]
+    for L in range(1, depth.max() + 1):
+        lvl += [b for b in range(1, nb) if depth[b] == L]
+        adr.append(len(lvl))
+    A["b_lvl_body"], A["b_lvl_adr"] = _i32(lvl), _i32(adr)
+    # ---- last dof of the chain a body hangs on (-1: none), dof chain lists root-first
+    lastdof = np.full(nb, -1, dtype=np.int32)
+    for b in range(1, nb):
+        lastdof[b] = A["body_dofadr"][b] + A["body_dofnum"][b] - 1 if A["body_dofnum"][b] > 0 else lastdof[parent[b]]
+    A["b_body_lastdof"] = lastdof
+    chains = []
+    for b in range(nb):
+        c, i = [], int(lastdof[b])
+        while i >= 0:
+            c.append(i)
+            i = int(dpar[i])
+        chains.append(sorted(c))
+    # ---- subtree lists (self included)
+    sub = [[b] for b in range(nb)]
+    for b in range(nb - 1, 0, -1):
+        sub[parent[b]] += sub[b]
+    sadr = [0]
+    for b in range(nb):
+        sadr.append(sadr[-1] + len(sub[b]))
+    A["b_subtree_adr"], A["b_subtree"] = _i32(sadr), _i32([x for s in sub for x in sorted(s)])
+    # ---- roots of the kinematic trees (MuJoCo's com-based frames use the subtree com of body_rootid)
+    A["b_root_list"] = _i32(sorted(set(int(A["body_rootid"][b]) for b in range(1, nb))))
+    # ---- M entries: (i, j) with j = i, parent(i), ...; Madr[i] = first entry of dof i
+    Mi, Mj, Madr = [], [], []
+    for i in range(nv):
+        Madr.append(len(Mi))
+        j = i
+        while j >= 0:
+            Mi.append(i); Mj.append(j)
+            j = int(dpar[j])
+    Madr.append(len(Mi))
+    A["b_M_i"], A["b_M_j"], A["b_M_adr"] = _i32(Mi), _i32(Mj), _i32(Madr)
+    # ---- trees and dof groups
+    tree_of_dof = np.array([int(A["body_rootid"][A["dof_bodyid"][i]]) for i in range(nv)])
+    trees = sorted(set(tree_of_dof.tolist()), key=lambda r: np.where(tree_of_dof == r)[0][0])
+    for r in trees:   # a tree's dofs are contiguous (MuJoCo numbers dofs depth-first)
+        idx = np.where(tree_of_dof == r)[0]
+        assert (np.diff(idx) == 1).all()
+    pairs, prm = collision_pairs(model)
+    link = {r: r for r in trees}
+
+    def find(r):
+        while link[r] != r:
+            r = link[r]
+        return r
+
+    def union(bodies):
+        rs = [find(int(A["body_rootid"][b])) for b in bodies if A["body_weldid"][b] != 0 and lastdof[b] >= 0]
+        for r in rs[1:]:
+            link[find(r)] = find(rs[0])
+
+    for a, b, _ in pairs:
+        union([int(A["geom_bodyid"][a]), int(A["geom_bodyid"][b])])
+    # tendon supports
+    nt = len(A["tendon_adr"])
+    ten_dofs = np.full((nt, TEN_W), -1, dtype=np.int32)
+    for t in range(nt):
+        adr_, num = int(A["tendon_adr"][t]), int(A["tendon_num"][t])
+        dofs = set()
+        if A["wrap_type"][adr_] == C.WRAP_JOINT:
+            dofs = {int(A["jnt_dofadr"][A["wrap_objid"][w]]) for w in range(adr_, adr_ + num)}
+            bodies = [int(A["jnt_bodyid"][A["wrap_objid"][w]]) for w in range(adr_, adr_ + num)]
+        else:
+            bodies = []
+            for w in range(adr_, adr_ + num):
+                ty = int(A["wrap_type"][w])
+                if ty == C.WRAP_SITE:
+                    bodies.append(int(A["site_bodyid"][A["wrap_objid"][w]]))
+                elif ty in (C.WRAP_SPHERE, C.WRAP_CYLINDER):
+                    bodies.append(int(A["geom_bodyid"][A["wrap_objid"][w]]))
+            for x in bodies:   # any two bodies of the path: the dofs between them (symmetric difference of their chains)
+                for y in bodies:
+                    dofs |= set(chains[x]) ^ set(chains[y])
+        if len(dofs) > TEN_W:
+            raise NotImplementedError("tendon %d depends on %d dofs > %d" % (t, len(dofs), TEN_W))
+        ten_dofs[t, :len(dofs)] = sorted(dofs)
+        union(bodies)
+    A["b_ten_dofs"] = ten_dofs
+    groups = {}
+    for r in trees:
+        groups.setdefault(find(r), []).append(r)
+    # a group = the dofs of its trees in ascending order (not necessarily one contiguous range: the target cube's tree sits between
+    # the cube's and the hand's); b_dof_local = position of a dof inside its group = its row in the group's dense blocks
+    gadr, gdofs, dof_group, dof_local = [0], [], np.zeros(nv, dtype=np.int32), np.zeros(nv, dtype=np.int32)
+    order = sorted(groups.values(), key=lambda rs: min(np.where(tree_of_dof == r)[0][0] for r in rs))
+    for gi, rs in enumerate(order):
+        idx = np.sort(np.concatenate([np.where(tree_of_dof == r)[0] for r in rs]))
+        dof_group[idx] = gi
+        dof_local[idx] = np.arange(len(idx))
+        gdofs += idx.tolist()
+        gadr.append(len(gdofs))
+    A["b_group_adr"], A["b_group_dofs"], A["b_dof_group"], A["b_dof_local"] = _i32(gadr), _i32(gdofs), dof_group, dof_local
+    # ---- collision pairs
+    A["b_pair_geom"] = _i32(pairs).reshape(-1, 3)
+    A["b_pair_prm"] = np.asarray(prm, dtype=np.float64).reshape(-1, 12)
+    wmax = 0
+    for a, b, _ in pairs:
+        wmax = max(wmax, len(set(chains[A["geom_bodyid"][a]]) | set(chains[A["geom_bodyid"][b]])))
+    if wmax > CON_W:
+        raise NotImplementedError("a contact depends on %d dofs > %d" % (wmax, CON_W))
+    # ---- constraint-row sources
+    A["b_fric_dof"] = _i32([i for i in range(nv) if A["dof_frictionloss"][i] > 0])
+    A["b_fric_ten"] = _i32([t for t in range(nt) if A["tendon_frictionloss"][t] > 0])
+    A["b_lim_jnt"] = _i32([j for j in range(len(A["jnt_type"])) if A["jnt_limited"][j] and A["jnt_type"][j] in (C.JNT_HINGE, C.JNT_SLIDE)])
+    A["b_lim_ten"] = _i32([t for t in range(nt) if A["tendon_limited"][t]])
+    for j in range(len(A["jnt_type"])):
+        if A["jnt_stiffness"][j] != 0 and A["jnt_type"][j] not in (C.JNT_HINGE, C.JNT_SLIDE):
+            raise NotImplementedError("ball / free joint springs")
+    # mesh vertices as 16-byte records (x, y, z, vertex index): what the hull scans of the collision code read
+    mv = np.asarray(A["mesh_vert"], dtype=np.float32).reshape(-1, 3)
+    rec = np.zeros((len(mv), 4), dtype=np.float32)
+    rec[:, :3] = mv
+    for mesh in range(len(A["mesh_vertadr"])):
+        a0, n = int(A["mesh_vertadr"][mesh]), int(A["mesh_vertnum"][mesh])
+        rec[a0:a0 + n, 3] = np.arange(n, dtype=np.int32).view(np.float32)
+    A["b_mesh_rec"] = rec.reshape(-1)
+    A["b_dims"] = _i32([len(adr) - 1, len(Mi), len(pairs), len(gadr) - 1, max(np.diff(gadr)), len(A["b_root_list"]), wmax])
+    return model

@@ -23,6 +23,59 @@ def _i32(x):
     return np.asarray(x, dtype=np.int32)
 
 
+def collision_pairs(model):
+    """The static candidate list of the collision driver (engine_collision_driver.c filters: same weld group, parent-child,
+    explicit excludes, contype / conaffinity) with each pair's mixed contact parameters (mj_contactParam: margin / gap max,
+    friction element-wise max, solref / solimp by solmix, condim max).  Returns ([(g1, g2, condim)], [12 floats per pair:
+    margin, gap, friction3, solref2, solimp5]); g1 has the smaller geom type (planes first)."""
+    A = model.arrays
+    nbody, ngeom = len(A["body_parentid"]), len(A["geom_type"])
+    parent = A["body_parentid"]
+    gtype, gbody = A["geom_type"], A["geom_bodyid"]
+    weld = A["body_weldid"]
+    excl = set(int(s) for s in A["exclude_signature"])
+    geoms_of = [[g for g in range(ngeom) if gbody[g] == b] for b in range(nbody)]
+    pairs, prm = [], []
+    for b1 in range(nbody):
+        if not geoms_of[b1]:
+            continue
+        for b2 in range(b1 + 1, nbody):
+            if not geoms_of[b2]:
+                continue
+            w1, w2 = weld[b1], weld[b2]
+            if w1 == w2:
+                continue
+            pw1, pw2 = weld[parent[w1]], weld[parent[w2]]
+            if w1 != 0 and w2 != 0 and (w1 == pw2 or w2 == pw1):
+                continue
+            if ((b1 << 16) + b2) in excl:
+                continue
+            for g1 in geoms_of[b1]:
+                for g2 in geoms_of[b2]:
+                    a, b = (g1, g2) if gtype[g1] <= gtype[g2] else (g2, g1)
+                    if not ((A["geom_contype"][a] & A["geom_conaffinity"][b]) or (A["geom_contype"][b] & A["geom_conaffinity"][a])):
+                        continue
+                    if gtype[a] == C.GEOM_PLANE and gtype[b] == C.GEOM_PLANE:
+                        continue
+                    margin = max(A["geom_margin"][a], A["geom_margin"][b])
+                    gap = max(A["geom_gap"][a], A["geom_gap"][b])
+                    fr = np.maximum(A["geom_friction"][a], A["geom_friction"][b])
+                    m1, m2 = A["geom_solmix"][a], A["geom_solmix"][b]
+                    if m1 >= 1e-15 and m2 >= 1e-15:
+                        mix = m1 / (m1 + m2)
+                    elif m1 < 1e-15 and m2 < 1e-15:
+                        mix = 0.5
+                    else:
+                        mix = 0.0 if m1 < 1e-15 else 1.0
+                    r1, r2 = A["geom_solref"][a], A["geom_solref"][b]
+                    solref = mix * r1 + (1 - mix) * r2 if (r1[0] > 0 and r2[0] > 0) else np.minimum(r1, r2)
+                    solimp = mix * A["geom_solimp"][a] + (1 - mix) * A["geom_solimp"][b]
+                    condim = max(A["geom_condim"][a], A["geom_condim"][b])
+                    pairs.append((a, b, condim))
+                    prm.append(np.concatenate([[margin, gap], fr, solref, solimp]))  # 12 floats
+    return pairs, prm
+
+
 def derive_kernel_tables(model, max_row_nnz=16):
     A = model.arrays
     nbody, nv, ngeom = len(A["body_parentid"]), len(A["dof_bodyid"]), len(A["geom_type"])
@@ -163,49 +216,8 @@ def derive_kernel_tables(model, max_row_nnz=16):
 
     # ---------------------------------------------------------------- collision pair list
     gtype, gbody = A["geom_type"], A["geom_bodyid"]
-    weld = A["body_weldid"]
-    excl = set(int(s) for s in A["exclude_signature"])
-    pairs, prm = [], []
-    max_nnz = 0
-    for b1 in range(nbody):
-        for b2 in range(b1 + 1, nbody):
-            w1, w2 = weld[b1], weld[b2]
-            if w1 == w2:
-                continue
-            pw1, pw2 = weld[parent[w1]], weld[parent[w2]]
-            if w1 != 0 and w2 != 0 and (w1 == pw2 or w2 == pw1):
-                continue
-            if ((b1 << 16) + b2) in excl:
-                continue
-            for g1 in range(ngeom):
-                if gbody[g1] != b1:
-                    continue
-                for g2 in range(ngeom):
-                    if gbody[g2] != b2:
-                        continue
-                    a, b = (g1, g2) if gtype[g1] <= gtype[g2] else (g2, g1)
-                    if not ((A["geom_contype"][a] & A["geom_conaffinity"][b]) or (A["geom_contype"][b] & A["geom_conaffinity"][a])):
-                        continue
-                    if gtype[a] == C.GEOM_PLANE and gtype[b] == C.GEOM_PLANE:
-                        continue
-                    margin = max(A["geom_margin"][a], A["geom_margin"][b])
-                    gap = max(A["geom_gap"][a], A["geom_gap"][b])
-                    fr = np.maximum(A["geom_friction"][a], A["geom_friction"][b])
-                    m1, m2 = A["geom_solmix"][a], A["geom_solmix"][b]
-                    if m1 >= 1e-15 and m2 >= 1e-15:
-                        mix = m1 / (m1 + m2)
-                    elif m1 < 1e-15 and m2 < 1e-15:
-                        mix = 0.5
-                    else:
-                        mix = 0.0 if m1 < 1e-15 else 1.0
-                    r1, r2 = A["geom_solref"][a], A["geom_solref"][b]
-                    solref = mix * r1 + (1 - mix) * r2 if (r1[0] > 0 and r2[0] > 0) else np.minimum(r1, r2)
-                    solimp = mix * A["geom_solimp"][a] + (1 - mix) * A["geom_solimp"][b]
-                    condim = max(A["geom_condim"][a], A["geom_condim"][b])
-                    pairs.append((a, b, condim))
-                    prm.append(np.concatenate([[margin, gap], fr, solref, solimp]))  # 12 floats
-                    nnz = bin(int(mask[gbody[a]] | mask[gbody[b]])).count("1")
-                    max_nnz = max(max_nnz, nnz)
+    pairs, prm = collision_pairs(model)
+    max_nnz = max([bin(int(mask[gbody[a]] | mask[gbody[b]])).count("1") for a, b, _ in pairs], default=0)
     if max_nnz > max_row_nnz:
         raise NotImplementedError("contact row needs %d nonzeros > %d" % (max_nnz, max_row_nnz))
     A["k_pair_geom"] = _i32(pairs).reshape(-1, 3)

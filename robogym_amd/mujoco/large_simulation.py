@@ -1,0 +1,131 @@
+"""Batched simulation of models beyond the Shadow-hand kernel's compile-time layout (`rb_step_kernel`,
+robogym_amd/csrc/rb_kernel.h): BASELINE.json configs[2], dactyl/full_perpendicular.  Mirrors the part of
+`SimulationInterface` (/root/reference/robogym/mujoco/simulation_interface.py:92-250) the physics path needs:
+state fields as zero-copy `[B, n]` tensor views, `reset`, `step` / `env_step`, joint groups.  No CPU fallback: the gfx950
+library and a GPU are required (tests may pass `lib=` = the kernel source on the emulation harness, as for the other kernels)."""
+import ctypes
+from typing import Dict
+
+import numpy as np
+import torch
+
+from robogym_amd import _native
+from robogym_amd.mujoco.big_tables import derive_big_tables
+from robogym_amd.mujoco.model_blob import pack_model
+from robogym_amd.mujoco import simulation_interface
+
+SCRATCH = ["xpos", "xquat", "xipos", "xiquat", "xanchor", "xaxis", "geom_xpos", "geom_xquat", "site_xpos", "rootcom", "cinert", "crb", "cdof", "cdof_dot", "cvel",
+           "cacc", "cfrc", "ten_length", "ten_J", "ten_velocity", "Msp", "cand", "contact", "contact_J", "contact_idx", "row", "dbg"]
+INFO = ["nq", "nv", "nu", "nbody", "njnt", "ngeom", "nsite", "ntendon", "nM", "npair", "ngroup", "gmax", "maxcon", "maxrow", "scratch_words", "conrec", "rowrec", "conw", "tenw", "lds_bytes"]
+
+
+class LargeModelSimulation:
+    def __init__(self, model, batch_size: int, device="cuda:0", n_substeps: int = 10, relative_action: bool = True, lib=None):
+        self._emul = lib is not None
+        self._L = L = lib if lib is not None else _native.lib()
+        self.device = torch.device("cpu") if self._emul else torch.device(device)
+        if not self._emul and not torch.cuda.is_available():
+            raise _native.NativeError("LargeModelSimulation needs an MI355X (no CPU fallback)")
+        if "b_dims" not in model.arrays:
+            derive_big_tables(model)
+        self.model, self.batch_size, self.n_substeps = model, int(batch_size), int(n_substeps)
+        blob = pack_model(model)
+        err = ctypes.create_string_buffer(512)
+        if not self._emul:
+            torch.cuda.set_device(self.device)
+        self._mh = L.rb_model_create(blob, len(blob), err, 512)
+        if not self._mh:
+            raise _native.NativeError("rb_model_create: " + err.value.decode())
+        buf = (ctypes.c_int * 32)()
+        n = L.rb_model_info(self._mh, buf, 32)
+        assert n == len(INFO)
+        self.info = {k: int(buf[i]) for i, k in enumerate(INFO)}
+        self._bh = L.rb_batch_create(self._mh, self.batch_size)
+        if not self._bh:
+            raise _native.NativeError("rb_batch_create: " + L.rg_last_error().decode())
+        self.nq, self.nv, self.nu = self.info["nq"], self.info["nv"], self.info["nu"]
+        names = model.names["joint"]
+        A = model.arrays
+        self.qpos_idxs: Dict[str, np.ndarray] = {}
+        self.qvel_idxs: Dict[str, np.ndarray] = {}
+        self.register_joint_group("hand_angle", "robot0:")
+        hand_j = [j for j, nm in enumerate(names) if nm.startswith("robot0:")]
+        P = np.zeros((self.nu, len(hand_j)), dtype=np.float32)
+        for u in range(self.nu):
+            if A["actuator_trntype"][u] == 0:
+                P[u, hand_j.index(int(A["actuator_trnid"][u]))] = 1
+            else:
+                t = int(A["actuator_trnid"][u])
+                for w in range(A["tendon_adr"][t], A["tendon_adr"][t] + A["tendon_num"][t]):
+                    P[u, hand_j.index(int(A["wrap_objid"][w]))] = 1
+        self.pos_to_ctrl = P
+        hq = self.qpos_idxs["hand_angle"]
+        assert (np.diff(hq) == 1).all()
+        _native.check(L, L.rb_batch_set_env(self._bh, int(hq[0]), len(hq), 1 if relative_action else 0, P.ctypes.data_as(ctypes.POINTER(ctypes.c_float))), "rb_batch_set_env")
+        self._views = {}
+        self._keep = []
+
+    def __del__(self):
+        try:
+            self._L.rb_batch_free(self._bh)
+            self._L.rb_model_free(self._mh)
+        except Exception:
+            pass
+
+    def register_joint_group(self, name, prefix):
+        A, names = self.model.arrays, self.model.names["joint"]
+        q, v = [], []
+        for j, nm in enumerate(names):
+            if nm.startswith(prefix):
+                nq, nv = {0: (7, 6), 1: (4, 3), 2: (1, 1), 3: (1, 1)}[int(A["jnt_type"][j])]
+                q += list(range(A["jnt_qposadr"][j], A["jnt_qposadr"][j] + nq))
+                v += list(range(A["jnt_dofadr"][j], A["jnt_dofadr"][j] + nv))
+        self.qpos_idxs[name], self.qvel_idxs[name] = np.array(q), np.array(v)
+
+    def view(self, field: int) -> torch.Tensor:
+        if field not in self._views:
+            n = ctypes.c_int(0)
+            p = self._L.rb_batch_field_ptr(self._bh, field, ctypes.byref(n))
+            if not p:
+                raise _native.NativeError(self._L.rg_last_error().decode())
+            dt = torch.int32 if field == _native.RG_F_STATUS else torch.float32
+            self._views[field] = simulation_interface.device_tensor(p, (self.batch_size, n.value), dt, self.device)
+        return self._views[field]
+
+    qpos = property(lambda self: self.view(_native.RG_F_QPOS))
+    qvel = property(lambda self: self.view(_native.RG_F_QVEL))
+    ctrl = property(lambda self: self.view(_native.RG_F_CTRL))
+    pid = property(lambda self: self.view(_native.RG_F_PID))
+    qacc_warmstart = property(lambda self: self.view(_native.RG_F_WARMSTART))
+    status = property(lambda self: self.view(_native.RG_F_STATUS)[:, 0])
+    stats = property(lambda self: self.view(_native.RG_F_STATS))
+
+    def scratch(self, name: str) -> torch.Tensor:
+        """A stage array of the last launch, `[B, words]` (debugging / stage parity tests)."""
+        k = SCRATCH.index(name)
+        o0 = self._L.rb_scratch_offset(self._mh, k)
+        o1 = self._L.rb_scratch_offset(self._mh, k + 1) if k + 1 < len(SCRATCH) else self.info["scratch_words"]
+        return self.view(_native.RG_F_DEBUG)[:, o0:o1]
+
+    def reset(self):
+        self.sync()
+        _native.check(self._L, self._L.rb_batch_reset(self._bh), "rb_batch_reset")
+
+    def env_step(self, action=None, active=None, nsubsteps=None, nforward_ticks=3, flags=0):
+        for t in (action,):
+            assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.device == self.device and t.shape == (self.batch_size, self.nu))
+        assert active is None or (active.dtype == torch.int32 and active.is_contiguous())
+        flags = int(flags) | (_native.RG_FLAG_MPR_PLANE_DEPTH if simulation_interface.MPR_PLANE_DEPTH else 0)
+        stream = None if self._emul else ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        self._keep = [action, active]
+        ptr = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+        _native.check(self._L, self._L.rb_batch_step(self._bh, ptr(action), ptr(active), self.n_substeps if nsubsteps is None else int(nsubsteps), int(nforward_ticks), flags, stream),
+                      "rb_batch_step")
+
+    def step(self, active=None):
+        """SimulationInterface.step: nsubsteps x mj_step, then mj_forward (its PID tick)."""
+        self.env_step(nforward_ticks=1, active=active)
+
+    def sync(self):
+        if not self._emul:
+            torch.cuda.synchronize(self.device)

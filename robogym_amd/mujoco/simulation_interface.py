@@ -25,6 +25,22 @@ MPR_PLANE_DEPTH = os.environ.get("RG_MPR_PLANE", "0") == "1"
 SUBSTEP_ITEMS = os.environ.get("RG_SUBSTEP_ITEMS", "1") == "1"
 
 
+def device_tensor(ptr, shape, dtype, device) -> torch.Tensor:
+    """Zero-copy tensor over a buffer the native library owns (`__cuda_array_interface__`; host memory under the emulation harness)."""
+    is_int = dtype == torch.int32
+    if shape[1] == 0:      # e.g. a model without actuators: nothing to alias
+        return torch.zeros(shape, dtype=dtype, device=device)
+    if torch.device(device).type == "cpu":
+        ctype = ctypes.c_int32 if is_int else ctypes.c_float
+        return torch.from_numpy(np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctype)), shape=shape))
+    holder = type("_DevArray", (), {})()
+    holder.__cuda_array_interface__ = {"shape": shape, "typestr": "<i4" if is_int else "<f4", "data": (int(ptr), False), "version": 2, "strides": None}
+    with torch.cuda.device(device):
+        t = torch.as_tensor(holder, device=device)
+    assert t.data_ptr() == int(ptr) and t.device == torch.device(device)
+    return t
+
+
 class BatchedSimulationInterface:
     def __init__(self, model, batch_size: int, device="cuda:0", n_substeps: int = 10, lib=None):
         self.model = model
@@ -102,20 +118,7 @@ class BatchedSimulationInterface:
             ptr = self._L.rg_batch_field_ptr(self._bh, field, ctypes.byref(n))
             if not ptr:
                 raise _native.NativeError("rg_batch_field_ptr: " + self._L.rg_last_error().decode())
-            shape = (self.batch_size, int(n.value))
-            is_int = field == _native.RG_F_STATUS
-            if shape[1] == 0:      # a model without actuators: nothing to alias
-                t = torch.zeros(shape, dtype=torch.int32 if is_int else torch.float32, device=self.device)
-            elif self._emul:
-                ctype = ctypes.c_int32 if is_int else ctypes.c_float
-                arr = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctype)), shape=shape)
-                t = torch.from_numpy(arr)
-            else:
-                holder = type("_DevArray", (), {})()
-                holder.__cuda_array_interface__ = {"shape": shape, "typestr": "<i4" if is_int else "<f4", "data": (int(ptr), False), "version": 2, "strides": None}
-                with torch.cuda.device(self.device):
-                    t = torch.as_tensor(holder, device=self.device)
-                assert t.data_ptr() == int(ptr) and t.device == self.device
+            t = device_tensor(ptr, (self.batch_size, int(n.value)), torch.int32 if field == _native.RG_F_STATUS else torch.float32, self.device)
             self._views[field] = t
         return t
 

@@ -24,27 +24,28 @@ void emul_yield();
 void* emul_lds();
 // arrival-counting barrier over the `gsize`-lane group that contains the calling lane (64 = the wave)
 void emul_barrier(int gsize);
-extern uint64_t emul_xchg[64];
+#define EMUL_MAXT 256
+extern uint64_t emul_xchg[EMUL_MAXT];
 
-static inline void __syncthreads() { emul_barrier(64); }
+static inline void __syncthreads() { emul_barrier((int)blockDim.x); }   // (a 64-thread workgroup is one wave; larger ones use the workgroup-wide barrier)
 
 template <class T> static inline T emul_exchange(T v, int src, int gsize) {
   static_assert(sizeof(T) <= 8, "shuffle payload");
   uint64_t raw = 0; memcpy(&raw, &v, sizeof(T));
   emul_xchg[threadIdx.x] = raw;
   emul_barrier(gsize);
-  T r; memcpy(&r, &emul_xchg[src & 63], sizeof(T));
+  T r; memcpy(&r, &emul_xchg[(threadIdx.x & ~63u) | (src & 63)], sizeof(T));   // (src: lane of the calling lane's wave)
   emul_barrier(gsize);
   return r;
 }
 // xor shuffles with a mask below 16 (8, 4, 2) stay inside a 16-lane row (8-lane half row, quad, lane pair): only that group has to be convergent
-template <class T> static inline T __shfl_xor(T v, int mask) { return emul_exchange(v, (int)threadIdx.x ^ mask, mask < 2 ? 2 : (mask < 4 ? 4 : (mask < 8 ? 8 : (mask < 16 ? 16 : 64)))); }
+template <class T> static inline T __shfl_xor(T v, int mask) { return emul_exchange(v, (int)(threadIdx.x & 63) ^ mask, mask < 2 ? 2 : (mask < 4 ? 4 : (mask < 8 ? 8 : (mask < 16 ? 16 : 64)))); }
 template <class T> static inline T __shfl(T v, int src) { return emul_exchange(v, src, 64); }
 static inline unsigned long long __ballot(int pred) {
   emul_xchg[threadIdx.x] = pred ? 1 : 0;
   emul_barrier(64);
   unsigned long long r = 0;
-  for (int i = 0; i < 64; i++) if (emul_xchg[i]) r |= 1ull << i;
+  for (int i = 0; i < 64; i++) if (emul_xchg[(threadIdx.x & ~63u) + i]) r |= 1ull << i;
   emul_barrier(64);
   return r;
 }
@@ -55,3 +56,4 @@ static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; ret
 // launch: run `nblocks` workgroups of 64 fibers each; `fn(arg)` is the kernel body closure
 typedef void (*emul_kernel_fn)(void* arg);
 void emul_launch(int nblocks, size_t lds_bytes, emul_kernel_fn fn, void* arg);
+void emul_launch_n(int nblocks, int nthreads, size_t lds_bytes, emul_kernel_fn fn, void* arg);   // workgroups of `nthreads` (a multiple of 64, <= EMUL_MAXT)
