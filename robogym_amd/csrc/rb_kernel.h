@@ -35,13 +35,20 @@ typedef const RG_AS4 RbLaunch& RbLRef;
 #define BFOR(i, n) for (int i = TID; i < (n); i += RB_T)
 #define BSYNC() __syncthreads()
 #define RB_MINVAL 1e-15f
+#ifndef RB_COST_EPS
+#define RB_COST_EPS 1e-7f   /* relative rounding noise of the fp32 cost sum: improvements below it are not resolvable */
+#endif
 
 struct RbLds {
-  alignas(16) float A[RB_MAXGROUP * RB_MAXGROUP];   // the dense block of the moment
+  alignas(16) float A[RB_MAXGROUP * (RB_MAXGROUP + 1)];   // the dense block of the moment, row stride n + 1 (odd: a column walk touches every LDS bank)
+  float Dinv[RB_MAXGROUP * 8];   // inverses of the 8 x 8 diagonal blocks of the factor
+  float prow[8];
+  float sc[RB_MAXGROUP];
   float qpos[RB_MAXNQ], qvel[RB_MAXNV], warm[RB_MAXNV], ctrl[32], pid[96], actlen[32], actfrc[32];
   float qfrc_passive[RB_MAXNV], qfrc_bias[RB_MAXNV], qfrc_act[RB_MAXNV], qfrc_smooth[RB_MAXNV], qacc_smooth[RB_MAXNV];
   float qa[RB_MAXNV], Ma[RB_MAXNV], grad[RB_MAXNV], search[RB_MAXNV], Mv[RB_MAXNV], qfrc_con[RB_MAXNV], x[RB_MAXNV];
   float red[16];
+  float prof[16];
   int wcnt[4];
   int ncand, ncon, nefc, nlim, stop;
   unsigned status;
@@ -272,23 +279,16 @@ __device__ __forceinline__ void rb_M_mul(RbM m, const float* Msp, const float* x
   BFOR(i, m.nv) {
     float acc = 0;
     for (int e = m.b_M_adr[i]; e < m.b_M_adr[i + 1]; e++) acc += Msp[e] * x[m.b_M_j[e]];
-    // descendants: dofs k > i whose chain passes through i; their entry for ancestor i sits at depth distance from k
-    for (int k = i + 1; k < m.nv; k++) {
-      // (dofs are numbered depth-first: the subtree of i is a contiguous range that ends at the first k whose parent chain misses i)
-      int a = m.dof_parentid[k];
-      while (a > i) a = m.dof_parentid[a];
-      if (a != i) break;
-      // entry (k, i): walk k's entry list
-      for (int e = m.b_M_adr[k]; e < m.b_M_adr[k + 1]; e++) if (m.b_M_j[e] == i) { acc += Msp[e] * x[k]; break; }
-    }
+    for (int q = m.b_Mdesc_adr[i]; q < m.b_Mdesc_adr[i + 1]; q++) acc += Msp[m.b_Mdesc_ent[q]] * x[m.b_Mdesc_dof[q]];   // descendants' entries that name i
     y[i] = acc;
   }
   BSYNC();
 }
-// s.A <- the dense block of group g of M (+ diag), lower and upper triangle, row stride n
+// s.A <- the dense block of group g of M (+ diag), lower and upper triangle, row stride n + 1
+#define RB_LD(n) ((n) + 1)
 __device__ __forceinline__ void rb_M_block(RbM m, RbLds& s, const float* Msp, int g, const float* diag, float dscale) {
-  const int g0 = m.b_group_adr[g], n = m.b_group_adr[g + 1] - g0;
-  BFOR(w, n * n) s.A[w] = 0.f;
+  const int g0 = m.b_group_adr[g], n = m.b_group_adr[g + 1] - g0, ld = RB_LD(n);
+  BFOR(w, n * ld) s.A[w] = 0.f;
   BSYNC();
   BFOR(e, m.nM) {
     const int i = m.b_M_i[e], j = m.b_M_j[e];
@@ -296,53 +296,158 @@ __device__ __forceinline__ void rb_M_block(RbM m, RbLds& s, const float* Msp, in
     const int li = m.b_dof_local[i], lj = m.b_dof_local[j];
     float v = Msp[e];
     if (i == j && diag) v += dscale * diag[i];
-    s.A[li * n + lj] = v; s.A[lj * n + li] = v;
+    s.A[li * ld + lj] = v; s.A[lj * ld + li] = v;
   }
   BSYNC();
 }
-// in-place Cholesky of the n x n block in s.A (lower triangle, row stride n); returns false on a non-positive pivot
+// In-place Cholesky of the n x n block in s.A (lower triangle, row stride n + 1), blocked by RB_NB columns; false on a
+// non-positive pivot.  Per block: (a) the panel (rows kb.., RB_NB columns), one row per thread IN REGISTERS, column by column with
+// one barrier each (the pivot row travels through LDS); (b) the RB_NB x RB_NB diagonal block is inverted (one column per
+// thread, registers) into s.Dinv so that the substitutions multiply instead of dividing serially; (c) the trailing block,
+// a 16 x 16 thread tile with its operands loaded into registers before any store (an LDS load behind a possibly aliasing LDS
+// store does not overlap), rank-RB_NB update per pass.  Columns beyond n are padded with the identity.
+#define RB_NB 8
 __device__ __forceinline__ bool rb_chol(RbLds& s, int n) {
+  const int ld = RB_LD(n), ty = TID >> 4, tx = TID & 15;
   bool ok = true;
-  for (int k = 0; k < n; k++) {
-    const float pkk = s.A[k * n + k];
-    if (!(pkk > RB_MINVAL)) ok = false;
-    const float d = sqrtf(fmaxf(pkk, RB_MINVAL)), id = 1.0f / d;
+  for (int kb = 0; kb < n; kb += RB_NB) {
+    const int nb = n - kb < RB_NB ? n - kb : RB_NB;
+    // (a) panel
+    const int i = kb + TID;
+    float p[RB_NB];
+#pragma unroll
+    for (int c = 0; c < RB_NB; c++) p[c] = (i < n && c < nb) ? s.A[i * ld + kb + c] : 0.f;
+#pragma unroll
+    for (int c = 0; c < RB_NB; c++) {
+      if (c < nb) {
+        if (TID == c) {   // the pivot row finishes itself and publishes its entries
+          float d = p[c];
+#pragma unroll
+          for (int q = 0; q < RB_NB; q++) if (q < c) d -= p[q] * p[q];
+          if (!(d > RB_MINVAL)) s.stop = 1;
+          p[c] = rg_sqrt(fmaxf(d, RB_MINVAL));
+#pragma unroll
+          for (int q = 0; q < RB_NB; q++) if (q <= c) s.prow[q] = p[q];
+        }
+        BSYNC();
+        if (i < n && TID > c) {
+          float v = p[c];
+#pragma unroll
+          for (int q = 0; q < RB_NB; q++) if (q < c) v -= p[q] * s.prow[q];
+          p[c] = v * rg_rcp(s.prow[c]);
+        }
+        BSYNC();
+      }
+    }
+    if (i < n) {
+#pragma unroll
+      for (int c = 0; c < RB_NB; c++) if (c < nb && (TID >= c)) s.A[i * ld + kb + c] = p[c];
+    }
     BSYNC();
-    for (int i = k + TID; i < n; i += RB_T) s.A[i * n + k] = i == k ? d : s.A[i * n + k] * id;
-    BSYNC();
-    const int r = n - k - 1;   // trailing rows k+1..n-1: entries (i, j <= i)
-    for (int w = TID; w < r * r; w += RB_T) {
-      const int a = w / r, b2 = w - a * r;
-      if (b2 <= a) { const int i = k + 1 + a, j = k + 1 + b2; s.A[i * n + j] -= s.A[i * n + k] * s.A[j * n + k]; }
+    // (b) inverse of the diagonal block: thread c < nb solves L y = e_c
+    if (TID < nb) {
+      float y[RB_NB];
+#pragma unroll
+      for (int r = 0; r < RB_NB; r++) {
+        float v = r == TID ? 1.f : 0.f;
+        if (r < nb && r >= TID) {
+#pragma unroll
+          for (int q = 0; q < RB_NB; q++) if (q < r && q >= TID) v -= s.A[(kb + r) * ld + kb + q] * y[q];
+          v *= rg_rcp(s.A[(kb + r) * ld + kb + r]);
+        } else v = 0.f;
+        y[r] = v;
+      }
+#pragma unroll
+      for (int r = 0; r < RB_NB; r++) s.Dinv[(kb / RB_NB) * RB_NB * RB_NB + r * RB_NB + TID] = y[r];   // Dinv[r][c]
+    }
+    // (c) trailing update: A[i][j] -= sum_c L[i][kb + c] L[j][kb + c], i, j >= kb + RB_NB
+    const int t0 = kb + RB_NB;
+    if (t0 < n) {
+      constexpr int NT = RB_MAXGROUP / 16;
+      float acc[NT][NT];
+#pragma unroll
+      for (int qa = 0; qa < NT; qa++)
+#pragma unroll
+        for (int qb = 0; qb < NT; qb++) acc[qa][qb] = 0.f;
+#pragma unroll
+      for (int half = 0; half < 2; half++) {
+        float li[NT][RB_NB / 2], lj[NT][RB_NB / 2];
+#pragma unroll
+        for (int q = 0; q < NT; q++) {
+          const int ii = t0 + ty + 16 * q, jj = t0 + tx + 16 * q;
+#pragma unroll
+          for (int c = 0; c < RB_NB / 2; c++) {
+            li[q][c] = ii < n ? s.A[ii * ld + kb + half * (RB_NB / 2) + c] : 0.f;
+            lj[q][c] = jj < n ? s.A[jj * ld + kb + half * (RB_NB / 2) + c] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int qa = 0; qa < NT; qa++)
+#pragma unroll
+          for (int qb = 0; qb < NT; qb++)
+#pragma unroll
+            for (int c = 0; c < RB_NB / 2; c++) acc[qa][qb] += li[qa][c] * lj[qb][c];
+      }
+      // (the operands sit in columns kb .. kb + RB_NB - 1, the stores go to columns >= t0: no barrier in between)
+#pragma unroll
+      for (int qa = 0; qa < NT; qa++)
+#pragma unroll
+        for (int qb = 0; qb < NT; qb++) {
+          const int ii = t0 + ty + 16 * qa, jj = t0 + tx + 16 * qb;
+          if (ii < n && jj <= ii) s.A[ii * ld + jj] -= acc[qa][qb];
+        }
     }
     BSYNC();
   }
+  if (s.stop) ok = false;
   return ok;
 }
-// x <- inv(L L') x for the group's local vector x[0..n)
+// x <- inv(L L') x for the group's local vector x[0..n), block by block: the diagonal block through its inverse (RB_NB threads, one
+// dot product each), the rest of the column panel by everybody
 __device__ __forceinline__ void rb_chol_solve(RbLds& s, int n, float* x) {
-  for (int k = 0; k < n; k++) {          // forward: column sweeps
-    if (TID == 0) x[k] /= s.A[k * n + k];
+  const int ld = RB_LD(n);
+  for (int kb = 0; kb < n; kb += RB_NB) {          // forward: L y = x
+    const int nb = n - kb < RB_NB ? n - kb : RB_NB;
+    float v = 0.f;
+    if (TID < nb) { const float* D = s.Dinv + (kb / RB_NB) * RB_NB * RB_NB + TID * RB_NB; for (int c = 0; c <= TID; c++) v += D[c] * x[kb + c]; }
     BSYNC();
-    const float xk = x[k];
-    for (int i = k + 1 + TID; i < n; i += RB_T) x[i] -= s.A[i * n + k] * xk;
+    if (TID < nb) x[kb + TID] = v;
+    BSYNC();
+    const int i = kb + nb + TID;
+    if (i < n) { float a = x[i]; for (int c = 0; c < nb; c++) a -= s.A[i * ld + kb + c] * x[kb + c]; x[i] = a; }
     BSYNC();
   }
-  for (int k = n - 1; k >= 0; k--) {     // backward
-    if (TID == 0) x[k] /= s.A[k * n + k];
+  const int last = ((n - 1) / RB_NB) * RB_NB;
+  for (int kb = last; kb >= 0; kb -= RB_NB) {      // backward: L' z = y
+    const int nb = n - kb < RB_NB ? n - kb : RB_NB;
+    float v = 0.f;
+    if (TID < nb) { const float* D = s.Dinv + (kb / RB_NB) * RB_NB * RB_NB; for (int c = TID; c < nb; c++) v += D[c * RB_NB + TID] * x[kb + c]; }   // inv(L')[r][c] = Dinv[c][r]
     BSYNC();
-    const float xk = x[k];
-    for (int i = TID; i < k; i += RB_T) x[i] -= s.A[k * n + i] * xk;
+    if (TID < nb) x[kb + TID] = v;
+    BSYNC();
+    const int i = TID;
+    if (i < kb) { float a = x[i]; for (int c = 0; c < nb; c++) a -= s.A[(kb + c) * ld + i] * x[kb + c]; x[i] = a; }
     BSYNC();
   }
 }
-// dst[dofs of group g] = inv(block in s.A factored) applied to src[dofs of group g], through the local vector s.x
+// Symmetric diagonal scaling of the block in s.A before it is factored: A <- S A S with S = diag(1 / sqrt(A_ii)) (s.sc).  The
+// blocks mix hand links with 5-gram cubelets and constraint weights D ~ 1e6: in fp32 the unscaled factor is accurate to a few
+// digits only and the Newton directions it gives converge linearly (20 iterations instead of 6); scaled, the condition number is
+// within a small factor of the best diagonal scaling can do (van der Sluis).
+__device__ __forceinline__ void rb_scale_block(RbLds& s, int n) {
+  const int ld = RB_LD(n);
+  BFOR(l, n) s.sc[l] = rg_rsqrt(fmaxf(s.A[l * ld + l], RB_MINVAL));
+  BSYNC();
+  for (int w = TID; w < n * n; w += RB_T) { const int i = w / n, j = w - i * n; s.A[i * ld + j] *= s.sc[i] * s.sc[j]; }
+  BSYNC();
+}
+// dst[dofs of group g] = inv(block) applied to src[dofs of group g] (block scaled by rb_scale_block, then factored), through s.x
 __device__ __forceinline__ void rb_group_solve(RbM m, RbLds& s, int g, const float* src, float* dst, float scale) {
   const int g0 = m.b_group_adr[g], n = m.b_group_adr[g + 1] - g0;
-  BFOR(l, n) s.x[l] = src[m.b_group_dofs[g0 + l]];
+  BFOR(l, n) s.x[l] = s.sc[l] * src[m.b_group_dofs[g0 + l]];
   BSYNC();
   rb_chol_solve(s, n, s.x);
-  BFOR(l, n) dst[m.b_group_dofs[g0 + l]] = scale * s.x[l];
+  BFOR(l, n) dst[m.b_group_dofs[g0 + l]] = scale * s.sc[l] * s.x[l];
   BSYNC();
 }
 
@@ -468,7 +573,7 @@ __device__ __forceinline__ void rb_collision(RbM m, RbLds& s, float* S, int flag
     if (slot >= 0) cand[slot] = p;
   }
   // narrowphase: one quad per candidate, 64 candidates per trip
-  MprEnv E; E.mesh_vert = m.b_mesh_rec; E.cell_adr = 0; E.cell_blk = 0; E.cell_ovf = 0; E.prof = 0; E.cells = false; E.plane_depth = (flags & 16) != 0;
+  MprEnv E; E.mesh_vert = m.b_mesh_rec; E.cell_adr = m.b_cell_adr; E.cell_blk = (const rgf4*)m.b_cell_blk; E.cell_ovf = (const rgf4*)m.b_cell_ovf; E.prof = 0; E.cells = !(flags & 8); E.plane_depth = (flags & 16) != 0;
   const int ncand = s.ncand;
   float* con = SC(CON);
   for (int base = 0; base < ncand; base += RB_T / 4) {
@@ -621,6 +726,7 @@ __device__ __forceinline__ void rb_make_constraint(RbM m, RbLds& s, float* S) {
       }
     }
     C[RB_CR_NNZ] = (float)nnz;
+    for (int e = nnz; e < RB_CONW; e++) idx[e] = -1;
     // rows of this contact
     const int adr = (int)C[RB_CR_ADR];
     if (adr < 0) continue;
@@ -654,6 +760,24 @@ __device__ __forceinline__ void rb_make_constraint(RbM m, RbLds& s, float* S) {
   BSYNC();
 }
 
+// every dof's contact entries (contact c, slot e with idx[c][e] == dof), in contact order: the owner-computes form of J' f
+__device__ __forceinline__ void rb_dof_contact_lists(RbM m, RbLds& s, float* S) {
+  const int* cidx = (const int*)SC(CONIDX); int* adr = (int*)SC(DOFCON_ADR); int* lst = (int*)SC(DOFCON);
+  const float* con = SC(CON);
+  BFOR(i, m.nv) {   // counts
+    int n = 0;
+    for (int c = 0; c < s.ncon; c++) { if (con[RB_CONREC * c + RB_CR_ADR] < 0) continue; for (int e = 0; e < RB_CONW; e++) if (cidx[RB_CONW * c + e] == i) n++; }
+    adr[i + 1] = n;
+  }
+  BSYNC();
+  if (TID == 0) { adr[0] = 0; for (int i = 0; i < m.nv; i++) adr[i + 1] += adr[i]; }
+  BSYNC();
+  BFOR(i, m.nv) {
+    int n = adr[i];
+    for (int c = 0; c < s.ncon; c++) { if (con[RB_CONREC * c + RB_CR_ADR] < 0) continue; for (int e = 0; e < RB_CONW; e++) if (cidx[RB_CONW * c + e] == i) lst[n++] = c * RB_CONW + e; }
+  }
+  BSYNC();
+}
 // jar (to_jv = false: J x - aref) or jv (to_jv = true: J x) of every row
 __device__ __forceinline__ void rb_J_mul(RbM m, RbLds& s, float* S, const float* x, bool to_jv) {
   float* row = SC(ROW); const float* con = SC(CON); const float* cj = SC(CONJ); const int* cidx = (const int*)SC(CONIDX);
@@ -685,38 +809,44 @@ __device__ __forceinline__ float rb_row_force(const float* R, bool& quad, float&
   if (x >= 0) { quad = false; cost = 0.f; return 0.f; }
   quad = true; cost = 0.5f * D * x * x; return -D * x;
 }
-// dst[i] = sum over rows of J[r][i] * force[r]  (owner computes: every dof collects its rows in row order)
+// dst[i] = sum over rows of J[r][i] * force[r]: the contacts' basis forces first (one (contact, basis row) per thread), then every
+// dof collects its own friction row, the few limit rows and its contact entries (owner computes, fixed order)
 __device__ __forceinline__ void rb_JT_force(RbM m, RbLds& s, float* S, float* dst) {
-  const float* row = SC(ROW); const float* con = SC(CON); const float* cj = SC(CONJ); const int* cidx = (const int*)SC(CONIDX);
-  const int nstat = m.nfric_dof + m.nfric_ten + s.nlim;
+  const float* row = SC(ROW); const float* con = SC(CON); const float* cj = SC(CONJ);
+  float* Fb = SC(CONF);
+  BFOR(w, 6 * s.ncon) {
+    const int c = w / 6, b = w - 6 * c;
+    const float* C = con + RB_CONREC * c;
+    const int adr = (int)C[RB_CR_ADR], np = rb_npyr((int)C[RB_CR_DIM]);
+    float acc = 0;
+    if (adr >= 0) for (int q = 0; q < np; q++) {
+      const float* R = row + RB_ROWREC * (adr + q);
+      const int a = (int)fabsf(R[RB_RR_AUX]);
+      if (b != 0 && a != b) continue;
+      bool qd; float cst; const float f = rb_row_force(R, qd, cst);
+      acc += b == 0 ? f : (R[RB_RR_AUX] < 0 ? -1.f : 1.f) * C[RB_CR_FRIC + a - 1] * f;
+    }
+    Fb[w] = acc;
+  }
+  BSYNC();
+  const int nf = m.nfric_dof + m.nfric_ten;
+  const int* adr = (const int*)SC(DOFCON_ADR); const int* lst = (const int*)SC(DOFCON);
   BFOR(i, m.nv) {
     float acc = 0;
-    for (int r = 0; r < nstat; r++) {
+    const int fr = m.b_dof_fricrow[i];
+    if (fr >= 0) { bool q; float c; acc += rb_row_force(row + RB_ROWREC * fr, q, c); }
+    for (int r = m.nfric_dof; r < nf + s.nlim; r++) {   // friction tendons, limits
       const float* R = row + RB_ROWREC * r;
       const int type = (int)R[RB_RR_TYPE], id = (int)R[RB_RR_ID];
       bool q; float c; const float f = rb_row_force(R, q, c);
       if (f == 0.f) continue;
-      if (type == 0) { if (id == i) acc += f; }
-      else if (type == 2) { if (m.jnt_dofadr[id] == i) acc += R[RB_RR_AUX] * f; }
+      if (type == 2) { if (m.jnt_dofadr[id] == i) acc += R[RB_RR_AUX] * f; }
       else for (int e = 0; e < RB_TENW; e++) if (m.b_ten_dofs[RB_TENW * id + e] == i) acc += (type == 1 ? 1.f : R[RB_RR_AUX]) * SC(TENJ)[RB_TENW * id + e] * f;
     }
-    for (int c = 0; c < s.ncon; c++) {
-      const float* C = con + RB_CONREC * c;
-      const int nnz = (int)C[RB_CR_NNZ], adr = (int)C[RB_CR_ADR];
-      if (adr < 0) continue;
-      const int* idx = cidx + RB_CONW * c;
-      int e = 0;
-      while (e < nnz && idx[e] != i) e++;
-      if (e == nnz) continue;
-      const float* J = cj + 6 * RB_CONW * c;
-      const int np = rb_npyr((int)C[RB_CR_DIM]);
-      for (int q = 0; q < np; q++) {
-        const float* R = row + RB_ROWREC * (adr + q);
-        bool qd; float cst; const float f = rb_row_force(R, qd, cst);
-        if (f == 0.f) continue;
-        const int a = (int)fabsf(R[RB_RR_AUX]);
-        acc += f * (J[e] + (a ? (R[RB_RR_AUX] < 0 ? -1.f : 1.f) * C[RB_CR_FRIC + a - 1] * J[a * RB_CONW + e] : 0.f));
-      }
+    for (int q = adr[i]; q < adr[i + 1]; q++) {
+      const int ce = lst[q], c = ce / RB_CONW, e = ce - c * RB_CONW;
+      const float* J = cj + 6 * RB_CONW * c; const float* F = Fb + 6 * c;
+      acc += (J[e] * F[0] + J[RB_CONW + e] * F[1] + J[2 * RB_CONW + e] * F[2]) + (J[3 * RB_CONW + e] * F[3] + J[4 * RB_CONW + e] * F[4] + J[5 * RB_CONW + e] * F[5]);
     }
     dst[i] = acc;
   }
@@ -725,7 +855,7 @@ __device__ __forceinline__ void rb_JT_force(RbM m, RbLds& s, float* S, float* ds
 // s.A (holding the group's block of M) += J' diag(D, quadratic rows) J restricted to group g
 __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g) {
   const float* row = SC(ROW); const float* con = SC(CON); const float* cj = SC(CONJ); const int* cidx = (const int*)SC(CONIDX);
-  const int n = m.b_group_adr[g + 1] - m.b_group_adr[g];
+  const int ld = RB_LD(m.b_group_adr[g + 1] - m.b_group_adr[g]);
   const int nstat = m.nfric_dof + m.nfric_ten + s.nlim;
   // static rows: dof rows add to the diagonal (friction rows first, then the limit rows: a dof has one friction row and at most
   // one active limit side, so neither pass has two writers of an entry), tendon rows as small outer products one row at a time
@@ -737,11 +867,11 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
       const int d = type == 0 ? id : m.jnt_dofadr[id];
       if (m.b_dof_group[d] != g) continue;
       bool q; float c; rb_row_force(R, q, c);
-      if (q) { const int l = m.b_dof_local[d]; s.A[l * n + l] += R[RB_RR_D]; }
+      if (q) { const int l = m.b_dof_local[d]; s.A[l * ld + l] += R[RB_RR_D]; }
     }
     BSYNC();
   }
-  for (int r = 0; r < nstat; r++) {
+  for (int r = m.nfric_dof; r < nstat; r++) {   // (the friction-dof rows, the bulk of the static rows, were handled above)
     const float* R = row + RB_ROWREC * r;
     const int type = (int)R[RB_RR_TYPE], id = (int)R[RB_RR_ID];
     if (type != 1 && type != 3) continue;
@@ -750,39 +880,53 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
     if (TID < RB_TENW * RB_TENW) {
       const int ea = TID / RB_TENW, eb = TID % RB_TENW;
       const int da = m.b_ten_dofs[RB_TENW * id + ea], db = m.b_ten_dofs[RB_TENW * id + eb];
-      if (da >= 0 && db >= 0 && m.b_dof_group[da] == g) s.A[m.b_dof_local[da] * n + m.b_dof_local[db]] += R[RB_RR_D] * SC(TENJ)[RB_TENW * id + ea] * SC(TENJ)[RB_TENW * id + eb];
+      if (da >= 0 && db >= 0 && m.b_dof_group[da] == g) s.A[m.b_dof_local[da] * ld + m.b_dof_local[db]] += R[RB_RR_D] * SC(TENJ)[RB_TENW * id + ea] * SC(TENJ)[RB_TENW * id + eb];
     }
     BSYNC();
   }
-  // contacts, one at a time: A += Jc' W Jc with the 6 x 6 weight W of the contact's quadratic pyramid edges
-  for (int c = 0; c < s.ncon; c++) {
+  // contacts: A += Jc' W Jc with the 6 x 6 weight W of the contact's quadratic pyramid edges (w_row = e0 +- mu_k e_(k+1)):
+  // the weights of all contacts first (one contact per thread), then the contacts one at a time, one (a, b) entry per thread
+  float* Wc = SC(CONF);   // 12 words per contact: W00, W0k[5], Wkk[5]
+  if (TID == 0) s.wcnt[0] = 0;
+  BSYNC();
+  BFOR(c, s.ncon) {
     const float* C = con + RB_CONREC * c;
-    const int adr = (int)C[RB_CR_ADR], nnz = (int)C[RB_CR_NNZ];
-    if (adr < 0) continue;
-    const int* idx = cidx + RB_CONW * c;
-    if (m.b_dof_group[idx[0]] != g) continue;
-    const float* J = cj + 6 * RB_CONW * c;
-    const int dim = (int)C[RB_CR_DIM], np = rb_npyr(dim);
-    // W: w_row = e0 +- mu_k e_(k+1)
+    const int adr = (int)C[RB_CR_ADR];
     float W00 = 0, W0k[5] = {0, 0, 0, 0, 0}, Wkk[5] = {0, 0, 0, 0, 0};
-    for (int q = 0; q < np; q++) {
-      const float* R = row + RB_ROWREC * (adr + q);
-      bool qd; float cst; rb_row_force(R, qd, cst);
-      if (!qd) continue;
-      const float D = R[RB_RR_D]; const int a = (int)fabsf(R[RB_RR_AUX]);
-      W00 += D;
-      if (a) { const float mu = (R[RB_RR_AUX] < 0 ? -1.f : 1.f) * C[RB_CR_FRIC + a - 1]; W0k[a - 1] += D * mu; Wkk[a - 1] += D * mu * mu; }
-    }
-    if (W00 != 0.f) {
-      for (int w = TID; w < nnz * nnz; w += RB_T) {
-        const int ea = w / nnz, eb = w - ea * nnz;
-        float v = W00 * J[ea] * J[eb];
-        for (int k = 0; k < dim - 1; k++) {
-          const float ja = J[(k + 1) * RB_CONW + ea], jb = J[(k + 1) * RB_CONW + eb];
-          v += W0k[k] * (J[ea] * jb + ja * J[eb]) + Wkk[k] * ja * jb;
-        }
-        s.A[m.b_dof_local[idx[ea]] * n + m.b_dof_local[idx[eb]]] += v;
+    if (adr >= 0 && m.b_dof_group[cidx[RB_CONW * c]] == g) {
+      const int np = rb_npyr((int)C[RB_CR_DIM]);
+      for (int q = 0; q < np; q++) {
+        const float* R = row + RB_ROWREC * (adr + q);
+        bool qd; float cst; rb_row_force(R, qd, cst);
+        if (!qd) continue;
+        const float D = R[RB_RR_D]; const int a = (int)fabsf(R[RB_RR_AUX]);
+        W00 += D;
+        if (a) { const float mu = (R[RB_RR_AUX] < 0 ? -1.f : 1.f) * C[RB_CR_FRIC + a - 1]; W0k[a - 1] += D * mu; Wkk[a - 1] += D * mu * mu; }
       }
+    }
+    float* W = Wc + 12 * c;
+    W[0] = W00; for (int k = 0; k < 5; k++) { W[1 + k] = W0k[k]; W[6 + k] = Wkk[k]; }
+    if (W00 != 0.f) s.wcnt[0] = 1;   // (benign race: every writer stores the same value)
+  }
+  BSYNC();
+  const bool any = s.wcnt[0] != 0;
+  BSYNC();
+  if (TID == 0) s.wcnt[0] = 0;
+  if (any) for (int c = 0; c < s.ncon; c++) {
+    const float* W = Wc + 12 * c;
+    if (W[0] == 0.f) continue;   // (uniform: every thread reads the same word)
+    const float* C = con + RB_CONREC * c;
+    const int nnz = (int)C[RB_CR_NNZ], dim = (int)C[RB_CR_DIM];
+    const int* idx = cidx + RB_CONW * c;
+    const float* J = cj + 6 * RB_CONW * c;
+    for (int w = TID; w < nnz * nnz; w += RB_T) {
+      const int ea = w / nnz, eb = w - ea * nnz;
+      float v = W[0] * J[ea] * J[eb];
+      for (int k = 0; k < dim - 1; k++) {
+        const float ja = J[(k + 1) * RB_CONW + ea], jb = J[(k + 1) * RB_CONW + eb];
+        v += W[1 + k] * (J[ea] * jb + ja * J[eb]) + W[6 + k] * ja * jb;
+      }
+      s.A[m.b_dof_local[idx[ea]] * ld + m.b_dof_local[idx[eb]]] += v;
     }
     BSYNC();
   }
@@ -827,7 +971,9 @@ __device__ __forceinline__ float rb_line_search(RbLds& s, const float* row, int 
   return a;
 }
 // mj_solNewton (oracle ro_solve): s.qa <- qacc, s.qfrc_con <- J' f; returns the iteration count
-__device__ __forceinline__ int rb_solve(RbM m, RbLds& s, float* S) {
+__device__ __forceinline__ int rb_solve(RbM m, RbLds& s, float* S, int flags) {
+  long long tq0 = rg_clock(), tq1;
+#define RB_PROFS(k) do { if (flags & 2) { BSYNC(); tq1 = rg_clock(); if (TID == 0) s.prof[k] += (float)(tq1 - tq0); tq0 = tq1; } } while (0)
   const int nv = m.nv, ne = s.nefc;
   float* row = SC(ROW); const float* Msp = SC(MSP);
   if (ne == 0) { BFOR(i, nv) { s.qa[i] = s.qacc_smooth[i]; s.qfrc_con[i] = 0.f; } BSYNC(); return 0; }
@@ -858,20 +1004,27 @@ __device__ __forceinline__ int rb_solve(RbM m, RbLds& s, float* S) {
     const float gauss = rb_sum(s, g);
     const float ccost = rb_sum(s, c);
     oldcost = cost; cost = gauss + ccost;
+    RB_PROFS(8);
     rb_JT_force(m, s, S, s.qfrc_con);
     float gn = 0;
     BFOR(i, nv) { const float gi = s.Ma[i] - s.qfrc_smooth[i] - s.qfrc_con[i]; s.grad[i] = gi; gn += gi * gi; }
     gn = sqrtf(rb_sum(s, gn)) * scale;
-    if (iter > 0 && scale * (oldcost - cost) < tol) break;
+    // (fp32: the cost itself carries ~1e-6 of relative rounding noise, with ~450 rows far more than the absolute floor)
+#if defined(RG_EMUL) && defined(RB_TRACE)
+    if (TID == 0) printf("iter %d cost %.9g improvement*scale %.3e gn %.3e scale %.3e\n", iter, (double)cost, (double)(scale * (oldcost - cost)), (double)gn, (double)scale);
+#endif
+    if (iter > 0 && scale * (oldcost - cost) < fmaxf(tol, RB_COST_EPS * scale * fabsf(cost))) break;
     if (gn < tol || iter >= m.iterations) break;
     iters = iter + 1;
+    RB_PROFS(9);
     // search = - inv(H) grad, group by group
     bool okf = true;
     for (int grp = 0; grp < m.ngroup; grp++) {
       rb_M_block(m, s, Msp, grp, (const float*)0, 0.f);
-      rb_hessian_add(m, s, S, grp);
-      okf = rb_chol(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]) && okf;
-      rb_group_solve(m, s, grp, s.grad, s.search, -1.f);
+      rb_hessian_add(m, s, S, grp); RB_PROFS(10);
+      rb_scale_block(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]);
+      okf = rb_chol(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]) && okf; RB_PROFS(11);
+      rb_group_solve(m, s, grp, s.grad, s.search, -1.f); RB_PROFS(12);
     }
     if (!okf && TID == 0) s.status |= RG_STATUS_BAD_FACTOR;
     rb_M_mul(m, Msp, s.search, s.Mv);
@@ -882,7 +1035,8 @@ __device__ __forceinline__ int rb_solve(RbM m, RbLds& s, float* S) {
     sn = sqrtf(sn);
     if (sn < RB_MINVAL) break;
     const float gtol = tol * 0.01f * sn / scale * 1e-3f;   // (tolerance x ls_tolerance x |search| / scale x 1e-3: oracle's "exact" line search)
-    const float alpha = rb_line_search(s, row, ne, gauss, q1, q2, gtol, 40);
+    RB_PROFS(13);
+    const float alpha = rb_line_search(s, row, ne, gauss, q1, q2, gtol, 40); RB_PROFS(14);
     if (alpha == 0.f) break;
     BFOR(i, nv) s.qa[i] += alpha * s.search[i];
     BSYNC();
@@ -899,6 +1053,7 @@ __device__ __forceinline__ void rb_euler(RbM m, RbLds& s, float* S) {
   BSYNC();
   for (int grp = 0; grp < m.ngroup; grp++) {
     rb_M_block(m, s, SC(MSP), grp, m.dof_damping, h);
+    rb_scale_block(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]);
     if (!rb_chol(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]) && TID == 0) s.status |= RG_STATUS_BAD_FACTOR;
     rb_group_solve(m, s, grp, s.grad, s.search, 1.f);   // s.search <- qacc of the damped system
   }
@@ -921,7 +1076,7 @@ __device__ __forceinline__ void rb_euler(RbM m, RbLds& s, float* S) {
 #else
 #define RB_MAKE_CTX() RbM m = *(const RG_AS4 RbModelDev*)rg_uniform(mp); RbLRef L = *(const RG_AS4 RbLaunch*)((const RG_AS4 char*)__builtin_amdgcn_kernarg_segment_ptr() + 8)
 #endif
-__global__ void __launch_bounds__(RB_T) rb_step_kernel(const RbModelDev* mp, RbLaunch launch) {
+__global__ void __launch_bounds__(RB_T, 2) rb_step_kernel(const RbModelDev* mp, RbLaunch launch) {
   RB_MAKE_CTX();
   RbLds& s = RB_S();
   const int e = blockIdx.x;
@@ -933,6 +1088,7 @@ __global__ void __launch_bounds__(RB_T) rb_step_kernel(const RbModelDev* mp, RbL
   BFOR(i, nv) { s.qvel[i] = L.bt.qvel[(size_t)e * nv + i]; s.warm[i] = L.bt.qacc_warmstart[(size_t)e * nv + i]; }
   BFOR(i, 3 * nu) s.pid[i] = L.bt.pid[(size_t)e * 3 * nu + i];
   if (TID == 0) { s.status = L.bt.status[e]; s.stop = 0; }
+  if (TID < 16) s.prof[TID] = 0.f;
   BSYNC();
   // ---- action -> ctrl (robot_interface.py:247-278 with the hand's position -> control matrix)
   bool use_action = L.bt.action != 0;
@@ -954,14 +1110,19 @@ __global__ void __launch_bounds__(RB_T) rb_step_kernel(const RbModelDev* mp, RbL
   for (int sub = 0; sub < L.nsubsteps; sub++) {
     float bd = 0; BFOR(i, nq) bd += (fabsf(s.qpos[i]) < 1e10f) ? 0.f : 1.f; BFOR(i, nv) bd += (fabsf(s.qvel[i]) < 1e10f) ? 0.f : 1.f;
     if (rb_sum(s, bd) > 0) { if (TID == 0) s.status |= RG_STATUS_BAD_STATE; break; }
-    rb_kinematics(m, s, S); rb_com_pos(m, s, S); rb_tendon(m, s, S); rb_crb(m, s, S);
-    rb_velocity(m, s, S);
-    rb_collision(m, s, S, flags);
-    rb_make_constraint(m, s, S);
+    long long tp0 = rg_clock(), tp1;
+#define RB_PROF(k) do { if (flags & 2) { BSYNC(); tp1 = rg_clock(); if (TID == 0) s.prof[k] += (float)(tp1 - tp0); tp0 = tp1; } } while (0)
+    rb_kinematics(m, s, S); rb_com_pos(m, s, S); RB_PROF(0);
+    rb_tendon(m, s, S); rb_crb(m, s, S); RB_PROF(1);
+    rb_velocity(m, s, S); RB_PROF(2);
+    rb_collision(m, s, S, flags); RB_PROF(3);
+    rb_make_constraint(m, s, S); RB_PROF(4);
+    rb_dof_contact_lists(m, s, S);
     rb_pid(m, s, S, true);
     // qacc_smooth = inv(M) qfrc_smooth
     for (int grp = 0; grp < m.ngroup; grp++) {
       rb_M_block(m, s, SC(MSP), grp, (const float*)0, 0.f);
+      rb_scale_block(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]);
       if (!rb_chol(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]) && TID == 0) s.status |= RG_STATUS_BAD_FACTOR;
       rb_group_solve(m, s, grp, s.qfrc_smooth, s.qacc_smooth, 1.f);
     }
@@ -969,14 +1130,16 @@ __global__ void __launch_bounds__(RB_T) rb_step_kernel(const RbModelDev* mp, RbL
       if (TID == 0) { SC(DBG)[0] = (float)s.ncon; SC(DBG)[1] = (float)s.nefc; }
       BFOR(i, nv) { SC(DBG)[8 + i] = s.qfrc_bias[i]; SC(DBG)[8 + nv + i] = s.qfrc_passive[i]; SC(DBG)[8 + 2 * nv + i] = s.qfrc_act[i]; SC(DBG)[8 + 3 * nv + i] = s.qacc_smooth[i]; }
     }
-    const int iters = rb_solve(m, s, S);
+    RB_PROF(5);
+    const int iters = rb_solve(m, s, S, flags); RB_PROF(6);
     if ((flags & 1) && sub == 0) { if (TID == 0) SC(DBG)[2] = (float)iters; BFOR(i, nv) SC(DBG)[8 + 4 * nv + i] = s.qa[i]; }
     st_ncon += s.ncon; st_nefc += s.nefc; st_iter += iters; nsub_done++;
     bd = 0; BFOR(i, nv) bd += (fabsf(s.qa[i]) < 1e10f) ? 0.f : 1.f;
     if (rb_sum(s, bd) > 0) { if (TID == 0) s.status |= RG_STATUS_BAD_STATE; break; }
     BFOR(i, nv) s.warm[i] = s.qa[i];
-    rb_euler(m, s, S);
+    rb_euler(m, s, S); RB_PROF(7);
   }
+  if ((flags & 2) && TID < 16) SC(DBG)[8 + 5 * nv + TID] = s.prof[TID];   // stage cycle counters: frames+com, tendon+crb, velocity, collision, rows, smooth, Newton, Euler
   // ---- the state-less forward() calls of the reference: only their PID side effect touches the state
   if (L.nforward_ticks > 0) {
     rb_kinematics(m, s, S); rb_com_pos(m, s, S); rb_tendon(m, s, S);

@@ -23,7 +23,7 @@
   X(tendon_adr) X(tendon_num) X(wrap_type) X(wrap_objid) \
   X(actuator_trntype) X(actuator_trnid) X(actuator_forcelimited) X(actuator_biastype) \
   X(b_lvl_body) X(b_lvl_adr) X(b_body_lastdof) X(b_subtree_adr) X(b_subtree) X(b_root_list) X(b_M_i) X(b_M_j) X(b_M_adr) \
-  X(b_group_adr) X(b_group_dofs) X(b_dof_group) X(b_dof_local) X(b_pair_geom) X(b_ten_dofs) X(b_fric_dof) X(b_fric_ten) X(b_lim_jnt) X(b_lim_ten)
+  X(b_group_adr) X(b_group_dofs) X(b_dof_group) X(b_dof_local) X(b_pair_geom) X(b_ten_dofs) X(b_fric_dof) X(b_fric_ten) X(b_lim_jnt) X(b_lim_ten) X(b_cell_adr) X(b_Mdesc_adr) X(b_Mdesc_ent) X(b_Mdesc_dof) X(b_dof_fricrow)
 #define RB_FLT_ARRAYS(X) \
   X(body_pos) X(body_quat) X(body_ipos) X(body_iquat) X(body_mass) X(body_inertia) X(body_subtreemass) X(body_invweight0) \
   X(jnt_pos) X(jnt_axis) X(jnt_stiffness) X(jnt_range) X(jnt_margin) X(jnt_solref) X(jnt_solimp) \
@@ -33,14 +33,14 @@
   X(wrap_prm) X(tendon_range) X(tendon_margin) X(tendon_stiffness) X(tendon_damping) X(tendon_frictionloss) X(tendon_lengthspring) \
   X(tendon_solref_lim) X(tendon_solimp_lim) X(tendon_solref_fri) X(tendon_solimp_fri) X(tendon_invweight0) \
   X(actuator_gear) X(actuator_ctrlrange) X(actuator_forcerange) X(actuator_gainprm) \
-  X(b_pair_prm) X(b_mesh_rec)
+  X(b_pair_prm) X(b_mesh_rec) X(b_cell_blk) X(b_cell_ovf)
 
 // per-env scratch row: offsets (in 4-byte words) of the stage arrays
 enum {
   RB_O_XPOS, RB_O_XQUAT, RB_O_XIPOS, RB_O_XIQUAT, RB_O_XANCHOR, RB_O_XAXIS, RB_O_GPOS, RB_O_GQUAT, RB_O_SPOS, RB_O_ROOTCOM,
   RB_O_CINERT, RB_O_CRB, RB_O_CDOF, RB_O_CDOFDOT, RB_O_CVEL, RB_O_CACC, RB_O_CFRC,
   RB_O_TENLEN, RB_O_TENJ, RB_O_TENVEL, RB_O_MSP,
-  RB_O_CAND, RB_O_CON, RB_O_CONJ, RB_O_CONIDX, RB_O_ROW,
+  RB_O_CAND, RB_O_CON, RB_O_CONJ, RB_O_CONIDX, RB_O_ROW, RB_O_DOFCON_ADR, RB_O_DOFCON, RB_O_CONF,
   RB_O_DBG, RB_NOFF
 };
 // per contact record (floats): dist, pos3, frame9, includemargin, friction5, solref2, solimp5, dim, geom1, geom2, efc_address, nnz, R

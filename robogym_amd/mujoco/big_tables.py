@@ -155,5 +155,44 @@ def derive_big_tables(model):
         a0, n = int(A["mesh_vertadr"][mesh]), int(A["mesh_vertnum"][mesh])
         rec[a0:a0 + n, 3] = np.arange(n, dtype=np.int32).view(np.float32)
     A["b_mesh_rec"] = rec.reshape(-1)
+    # support cells of the hulls (kernel_tables.mesh_support_cells: per direction cell the vertices that can be the support point),
+    # laid out as the hull scans read them: the first four records of a cell at a computable address, the rest in an overflow run
+    from robogym_amd.mujoco.kernel_tables import CELL_N, mesh_support_cells
+
+    cadr, vidx = mesh_support_cells(A["mesh_vertadr"], A["mesh_vertnum"], A["mesh_vert"])
+    ncell = 6 * CELL_N * CELL_N
+    nmesh = len(A["mesh_vertadr"])
+    blk = np.zeros((nmesh * ncell, 4, 4), dtype=np.float32)
+    ovf = [np.zeros(4, dtype=np.float32)]
+    new_adr = np.zeros(nmesh * ncell, dtype=np.int32)
+    for mi in range(nmesh):
+        a0 = int(A["mesh_vertadr"][mi])
+        for c in range(ncell):
+            ce = mi * ncell + c
+            e = int(cadr[ce]); start, cnt = e >> 8, e & 255
+            new_adr[ce] = (len(ovf) << 8) | cnt
+            for k in range(max(cnt, 4)):
+                vi = int(vidx[start + min(k, cnt - 1)])
+                r = np.zeros(4, dtype=np.float32)
+                r[:3] = mv[a0 + vi]
+                r[3] = np.array([vi], dtype=np.int32).view(np.float32)[0]
+                if k < 4:
+                    blk[ce, k] = r
+                else:
+                    ovf.append(r)
+    A["b_cell_adr"], A["b_cell_blk"], A["b_cell_ovf"] = new_adr, blk.reshape(-1), np.concatenate(ovf)
+    # every dof's entries of M below it: (entry index, descendant dof) pairs, for the owner-computes product M x
+    dadr, dent, ddof = [0], [], []
+    for i in range(nv):
+        for e in range(len(Mi)):
+            if Mj[e] == i and Mi[e] != i:
+                dent.append(e); ddof.append(Mi[e])
+        dadr.append(len(dent))
+    A["b_Mdesc_adr"], A["b_Mdesc_ent"], A["b_Mdesc_dof"] = _i32(dadr), _i32(dent), _i32(ddof)
+    # friction-loss row of every dof (-1: none)
+    fr = np.full(nv, -1, dtype=np.int32)
+    for r, i in enumerate(A["b_fric_dof"]):
+        fr[i] = r
+    A["b_dof_fricrow"] = fr
     A["b_dims"] = _i32([len(adr) - 1, len(Mi), len(pairs), len(gadr) - 1, max(np.diff(gadr)), len(A["b_root_list"]), wmax])
     return model

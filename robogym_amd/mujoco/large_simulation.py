@@ -15,7 +15,7 @@ from robogym_amd.mujoco.model_blob import pack_model
 from robogym_amd.mujoco import simulation_interface
 
 SCRATCH = ["xpos", "xquat", "xipos", "xiquat", "xanchor", "xaxis", "geom_xpos", "geom_xquat", "site_xpos", "rootcom", "cinert", "crb", "cdof", "cdof_dot", "cvel",
-           "cacc", "cfrc", "ten_length", "ten_J", "ten_velocity", "Msp", "cand", "contact", "contact_J", "contact_idx", "row", "dbg"]
+           "cacc", "cfrc", "ten_length", "ten_J", "ten_velocity", "Msp", "cand", "contact", "contact_J", "contact_idx", "row", "dofcon_adr", "dofcon", "contact_f", "dbg"]
 INFO = ["nq", "nv", "nu", "nbody", "njnt", "ngeom", "nsite", "ntendon", "nM", "npair", "ngroup", "gmax", "maxcon", "maxrow", "scratch_words", "conrec", "rowrec", "conw", "tenw", "lds_bytes"]
 
 
