@@ -73,7 +73,7 @@ def kernel_source_hash():
     import hashlib
 
     h = hashlib.sha256()
-    for f in ("rg_kernel.h", "rg_env_kernel.h", "rg_api.hip", "rg_types.h", "Makefile"):
+    for f in ("rg_kernel.h", "rg_env_kernel.h", "rg_api.hip", "rg_types.h", "rb_kernel.h", "rb_types.h", "Makefile"):
         h.update(open(os.path.join(ROOT, "robogym_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -251,6 +251,8 @@ def main():
     status = int(sim.status.max().item())
 
     if rank == 0:
+        from robogym_amd.mujoco import simulation_interface as _si
+        kernel_name = "rg_step_items_kernel (substep-granular dispatch) + masked rg_step_kernel (large configuration)" if (_si.SUBSTEP_ITEMS and not emul_path) else "rg_step_kernel"
         value = world * B * args.steps / elapsed
         b_step, b_sub = algorithmic_bytes_per_env_step(env.model, ncon, nefc, iters, sim.n_substeps, 166)
         achieved = B * b_step / (kern_ms * 1e-3)
@@ -276,10 +278,10 @@ def main():
                        "ranks": (dist.get_world_size() if distributed else 1), "collective_backend": (dist.get_backend() if distributed else None),
                        "mean_ncon": float(ncon), "mean_nefc": float(nefc), "mean_newton_iters": float(iters), "status_bits": status, "status_bits_before_timed_region": status_before,
                        "cube_on_palm_fraction": {"start_of_timed_region": on_palm_start, "end_of_timed_region": on_palm_end},
-                       "pipelined_reset": bool(args.pipelined_reset), "sort_dispatch": bool(args.sort_dispatch),
+                       "pipelined_reset": bool(args.pipelined_reset), "sort_dispatch": bool(args.sort_dispatch), "substep_items": bool(_si.SUBSTEP_ITEMS),
                        "gathered_row": "obs 166 + reward 3 + done 1 = %d floats per env" % env.packed_dim},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_unit": "GB per launch (PMC)", "algorithmic_gb_per_launch": b_step * B / 1e9,
-                         "kernel": "rg_step_kernel", "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": b_step, "algorithmic_bytes_per_substep": b_sub,
+                         "kernel": kernel_name, "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": b_step, "algorithmic_bytes_per_substep": b_sub,
                          "note": "algorithmic bytes = SURVEY 8(d) stage-boundary model with measured ncon/nefc/iters; the fused kernel keeps stage arrays in LDS, so real HBM traffic is far below the algorithmic figure" + tnote},
         }
         if not args.no_cpu_baseline and world == 1:

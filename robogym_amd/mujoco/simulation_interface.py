@@ -321,7 +321,10 @@ class BatchedSimulationInterface:
                 self._side.wait_stream(cur)
                 launch(_native.RG_CFG_LARGE, big.contiguous(), None, self._side)
         base_flags = a.flags
-        if SUBSTEP_ITEMS:
+        # (not next to a concurrent large-configuration launch on the side stream -- envs inside the pipelined reset recipe: the
+        #  persistent workgroups hold every wave slot until the last work item, so that launch would run AFTER instead of beside
+        #  this one; measured with a third of the envs in the recipe: 890 k vs 928 k env-steps/s, profiles/r03_ab.txt)
+        if SUBSTEP_ITEMS and large_mask is None:
             a.flags = base_flags | _native.RG_FLAG_SUBSTEP_ITEMS
         launch(_native.RG_CFG_ROLLOUT, act0, self._redo, cur)
         a.flags = base_flags | _native.RG_FLAG_RESUME      # redo[e] - 1 = the substep at which the env was handed over

@@ -11,6 +11,7 @@ import pytest
 import torch
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DEV = [torch.device("cpu")]     # the golden replays run on this device (the `_gpu` variants switch it to cuda:0)
 OBS_KEYS = ["cube_pos", "cube_quat", "qpos", "qvel", "hand_angle", "fingertip_pos", "goal_pos", "goal_quat", "qpos_goal", "is_goal_achieved"]
 
 
@@ -18,13 +19,13 @@ class ScriptedBatchedEnv:
     """Batched stand-in for BatchedLockedEnv replaying the golden script in every row."""
 
     def __init__(self, g, B=3):
-        self.g, self.batch_size, self.device, self.num_actions, self._seed, self.t = g, B, torch.device("cpu"), 20, 0, 0
+        self.g, self.batch_size, self.device, self.num_actions, self._seed, self.t = g, B, DEV[0], 20, 0, 0
         self.mujoco_simulation = types.SimpleNamespace(cube_body_z=0.2, n_substeps=10, model=types.SimpleNamespace(opt_timestep=np.array([0.008])))
         self.received = []
         self.stop_on_fall = True
 
     def _emit(self):
-        rep = lambda a: torch.as_tensor(np.repeat(a[None], self.batch_size, 0), dtype=torch.float64)
+        rep = lambda a: torch.as_tensor(np.repeat(a[None], self.batch_size, 0), dtype=torch.float64, device=self.device)
         obs = {k: rep(self.g["script_obs_" + k][self.t]) for k in OBS_KEYS}
         self._goal_quat = obs["goal_quat"]
         return obs
@@ -34,14 +35,28 @@ class ScriptedBatchedEnv:
         return self._emit()
 
     def step(self, a):
-        self.received.append(a[0].numpy().copy())
+        self.received.append(a[0].cpu().numpy().copy())
         self.t += 1
-        rep = lambda a: torch.as_tensor(np.repeat(np.asarray(a)[None], self.batch_size, 0))
+        rep = lambda a: torch.as_tensor(np.repeat(np.asarray(a)[None], self.batch_size, 0), device=self.device)
         info = {"successes_so_far": rep(int(self.g["script_successes_so_far"][self.t])).to(torch.int32)}
         return self._emit(), rep(self.g["script_reward"][self.t]).double(), rep(bool(self.g["script_done"][self.t])), info
 
 
 def test_default_wrapper_stack_matches_reference_stack():
+    _default_golden_replay()
+
+
+@pytest.mark.gpu
+def test_default_wrapper_stack_matches_reference_stack_gpu():
+    """The same golden replay with every tensor of the stack on the MI355X (the goldens ran on CPU tensors only)."""
+    DEV[0] = torch.device("cuda:0")
+    try:
+        _default_golden_replay()
+    finally:
+        DEV[0] = torch.device("cpu")
+
+
+def _default_golden_replay():
     from robogym_amd.wrappers.dactyl_cube import BatchedDactylCubeWrappers
 
     g = np.load(os.path.join(G, "wrappers.npz"))
@@ -52,15 +67,15 @@ def test_default_wrapper_stack_matches_reference_stack():
     T = len(g["actions"])
     for t in range(T + 1):
         if t > 0:
-            obs, reward, done, info = env.step(torch.as_tensor(np.repeat(g["actions"][t - 1][None], inner.batch_size, 0)))
-            np.testing.assert_allclose(reward[0].numpy(), g["wreward"][t - 1], atol=1e-6, err_msg="reward at step %d" % t)
+            obs, reward, done, info = env.step(torch.as_tensor(np.repeat(g["actions"][t - 1][None], inner.batch_size, 0), device=DEV[0]))
+            np.testing.assert_allclose(reward[0].cpu().numpy(), g["wreward"][t - 1], atol=1e-6, err_msg="reward at step %d" % t)
             assert bool(done[0]) == bool(g["wdone"][t - 1]), t
             for k in ("fell_down", "drops_so_far", "first_drop"):
                 assert int(info[k][0]) == int(g["winfo_" + k][t - 1]), (k, t)
             assert (reward == reward[0]).all() and (done == done[0]).all()     # every row of the batch alike
         assert list(obs.keys()) == keys, (list(obs.keys()), keys)
         for k in keys:
-            np.testing.assert_allclose(obs[k][0].double().numpy().ravel(), g["wobs_" + k][t], atol=1e-6, err_msg="%s at step %d" % (k, t))
+            np.testing.assert_allclose(obs[k][0].double().cpu().numpy().ravel(), g["wobs_" + k][t], atol=1e-6, err_msg="%s at step %d" % (k, t))
     np.testing.assert_allclose(np.stack(inner.received), g["received_actions"], atol=1e-6)   # what reaches the env: binned, smoothed, clipped
     assert env.action_space["nvec"] == [11] * 20
 
@@ -106,7 +121,7 @@ class ReplayDraws:
         v = self.val[self.off[self.i]:self.off[self.i + 1]]
         assert len(v) == max(int(np.prod(shape)), 1), "draw %d (%s): %d values recorded, %s requested" % (self.i, name, len(v), tuple(shape))
         self.i += 1
-        return torch.as_tensor(v, dtype=torch.float64).reshape(tuple(shape))[None].repeat((self.B,) + (1,) * len(shape))
+        return torch.as_tensor(v, dtype=torch.float64, device=DEV[0]).reshape(tuple(shape))[None].repeat((self.B,) + (1,) * len(shape))
 
     def uniform(self, low, high, shape=()):
         return self._next("uniform", shape)
@@ -115,7 +130,7 @@ class ReplayDraws:
         return self._next("randn", shape)
 
     def randn_where(self, cond, shape):
-        return self._next("randn", shape) if bool(cond[0]) else torch.zeros((self.B,) + tuple(shape), dtype=torch.float64)
+        return self._next("randn", shape) if bool(cond[0]) else torch.zeros((self.B,) + tuple(shape), dtype=torch.float64, device=DEV[0])
 
     def random_sample(self, shape=()):
         return self._next("random_sample", shape)
@@ -136,11 +151,11 @@ class RandomizedScriptedBatchedEnv(ScriptedBatchedEnv):
     def __init__(self, g, model, B=2):
         super().__init__(g, B)
         A = model.arrays
-        rows = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64))[None].repeat((B,) + (1,) * np.asarray(a).ndim)
+        rows = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64), device=DEV[0])[None].repeat((B,) + (1,) * np.asarray(a).ndim)
         self.params = {"gravity": rows(A["opt_gravity"]), "timestep": rows(A["opt_timestep"]), "dof_damping": rows(A["dof_damping"]), "body_inertia": rows(A["body_inertia"]),
                        "body_mass": rows(A["body_mass"]), "geom_friction": rows(A["geom_friction"]), "actuator_gainprm": rows(A["actuator_gainprm"][:, :10]),
                        "jnt_range": rows(A["jnt_range"]), "tendon_range": rows(A["tendon_range"]), "actuator_ctrlrange": rows(A["actuator_ctrlrange"]),
-                       "site_pos": rows(A["site_pos"]), "geom_scale": torch.ones((B, 1), dtype=torch.float64), "xfrc_applied": torch.zeros((B, len(A["body_mass"]), 6), dtype=torch.float64)}
+                       "site_pos": rows(A["site_pos"]), "geom_scale": torch.ones((B, 1), dtype=torch.float64, device=DEV[0]), "xfrc_applied": torch.zeros((B, len(A["body_mass"]), 6), dtype=torch.float64, device=DEV[0])}
         hand_q = np.array([int(A["jnt_qposadr"][j]) for j, n in enumerate(model.names["joint"]) if n.startswith("robot0:")])
         self.constants = types.SimpleNamespace(relative_action=True)
         con = g["script_contacts"]
@@ -155,8 +170,8 @@ class RandomizedScriptedBatchedEnv(ScriptedBatchedEnv):
         sim.qpos = obs["qpos"]
         c = self._contacts[self.t]
         pad = np.zeros((8, 3)); pad[:len(c)] = c
-        rep = lambda a, dt: torch.as_tensor(np.repeat(a[None], B, 0), dtype=dt)
-        sim.data.ncon = torch.full((B,), len(c), dtype=torch.int32)
+        rep = lambda a, dt: torch.as_tensor(np.repeat(a[None], B, 0), dtype=dt, device=self.device)
+        sim.data.ncon = torch.full((B,), len(c), dtype=torch.int32, device=self.device)
         sim.data.contact = (rep(pad[:, 0], torch.int32), rep(pad[:, 1], torch.int32), rep(pad[:, 2], torch.float64))
         return obs
 
@@ -164,11 +179,25 @@ class RandomizedScriptedBatchedEnv(ScriptedBatchedEnv):
         return self._emit()
 
     def step(self, a):
-        self.step_timestep.append(float(self.params["timestep"][0, 0])); self.step_xfrc.append(self.params["xfrc_applied"][0].numpy().copy())
+        self.step_timestep.append(float(self.params["timestep"][0, 0])); self.step_xfrc.append(self.params["xfrc_applied"][0].cpu().numpy().copy())
         return super().step(a)
 
 
 def test_randomized_wrapper_stack_replays_the_reference_stack(locked_model):
+    _randomized_golden_replay(locked_model)
+
+
+@pytest.mark.gpu
+def test_randomized_wrapper_stack_replays_the_reference_stack_gpu(locked_model):
+    """The randomize=True golden replay (612 reference draws, 44 observation keys, model rows at both resets) on cuda:0."""
+    DEV[0] = torch.device("cuda:0")
+    try:
+        _randomized_golden_replay(locked_model)
+    finally:
+        DEV[0] = torch.device("cpu")
+
+
+def _randomized_golden_replay(locked_model):
     """randomize=True (the reference's default): BacklashWrapper, the thirteen pre-noise randomizations of LockedEnv, observation
     noise, occluded / freezing phasespace markers, action noise.  On the reference's own draws the vectorised stack must
     (a) ask for the same draws in the same order, (b) write the same values into the model rows at both resets, (c) return the
@@ -189,7 +218,7 @@ def test_randomized_wrapper_stack_replays_the_reference_stack(locked_model):
         nonlocal row
         assert list(obs.keys()) == keys, (list(obs.keys()), keys)
         for k in keys:
-            np.testing.assert_allclose(obs[k][0].double().numpy().ravel(), g["wobs_" + k][row], atol=2e-6, rtol=2e-6, err_msg="%s at %s" % (k, what))
+            np.testing.assert_allclose(obs[k][0].double().cpu().numpy().ravel(), g["wobs_" + k][row], atol=2e-6, rtol=2e-6, err_msg="%s at %s" % (k, what))
             assert (obs[k] == obs[k][0]).all()
         row += 1
 
@@ -201,10 +230,10 @@ def test_randomized_wrapper_stack_replays_the_reference_stack(locked_model):
             cube = N["geom"].index("cube:middle")
             for name, got in (("body_inertia", P["body_inertia"][0]), ("geom_friction", P["geom_friction"][0]), ("gravity", P["gravity"][0]), ("dof_damping", P["dof_damping"][0]),
                               ("actuator_kp", P["actuator_gainprm"][0, :, 0]), ("jnt_range", P["jnt_range"][0]), ("actuator_ctrlrange", P["actuator_ctrlrange"][0]),
-                              ("tendon_range", P["tendon_range"][0]), ("site_pos", P["site_pos"][0]), ("cube_size", P["geom_scale"][0] * torch.as_tensor(A["geom_size"][cube]))):
-                np.testing.assert_allclose(got.numpy(), g["model%d_%s" % (r, name)], rtol=1e-9, atol=1e-12, err_msg="model field %s after reset %d" % (name, r))
-        obs, reward, done, info = env.step(torch.as_tensor(np.repeat(g["actions"][t][None], inner.batch_size, 0)))
-        np.testing.assert_allclose(reward[0].numpy(), g["wreward"][t], atol=1e-6, err_msg="reward at step %d" % t)
+                              ("tendon_range", P["tendon_range"][0]), ("site_pos", P["site_pos"][0]), ("cube_size", P["geom_scale"][0] * torch.as_tensor(A["geom_size"][cube], device=DEV[0]))):
+                np.testing.assert_allclose(got.cpu().numpy(), g["model%d_%s" % (r, name)], rtol=1e-9, atol=1e-12, err_msg="model field %s after reset %d" % (name, r))
+        obs, reward, done, info = env.step(torch.as_tensor(np.repeat(g["actions"][t][None], inner.batch_size, 0), device=DEV[0]))
+        np.testing.assert_allclose(reward[0].cpu().numpy(), g["wreward"][t], atol=1e-6, err_msg="reward at step %d" % t)
         assert bool(done[0]) == bool(g["wdone"][t]), t
         for k in ("fell_down", "drops_so_far", "first_drop"):
             assert int(info[k][0]) == int(g["winfo_" + k][t]), (k, t)
