@@ -145,8 +145,8 @@ def test_product_library_loads_and_exports_the_header():
     path = os.path.join(root, "robogym_amd", "csrc", "librgstep.so")
     assert os.path.exists(path), "build it: python -c 'import __graft_entry__ as g; g.build()'"
     L = ctypes.CDLL(path)
-    declared = sorted(set(re.findall(r"\b(rg_[a-z_0-9]+)\s*\(", open(os.path.join(root, "include", "rgstep.h")).read())))
-    assert len(declared) >= 26
+    declared = sorted(set(re.findall(r"\b(r[gb]_[a-z_0-9]+)\s*\(", open(os.path.join(root, "include", "rgstep.h")).read())))
+    assert len(declared) >= 38 and sum(n.startswith("rb_") for n in declared) == 10      # (rb_*: the large-model path)
     for name in declared:
         assert hasattr(L, name), name
     assert set(_native.EXPORTS) == set(declared)
