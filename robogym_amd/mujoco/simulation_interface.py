@@ -324,6 +324,8 @@ class BatchedSimulationInterface:
         # (not next to a concurrent large-configuration launch on the side stream -- envs inside the pipelined reset recipe: the
         #  persistent workgroups hold every wave slot until the last work item, so that launch would run AFTER instead of beside
         #  this one; measured with a third of the envs in the recipe: 890 k vs 928 k env-steps/s, profiles/r03_ab.txt)
+        #  A rule that follows the share of envs in the recipe (a count sent to pinned host memory behind each step) was tried:
+        #  no better than "never beside a recipe launch" in any episode-length mix, profiles/r03_ab.txt.
         if SUBSTEP_ITEMS and large_mask is None:
             a.flags = base_flags | _native.RG_FLAG_SUBSTEP_ITEMS
         launch(_native.RG_CFG_ROLLOUT, act0, self._redo, cur)

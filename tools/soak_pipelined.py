@@ -8,7 +8,7 @@ from robogym_amd.envs.dactyl.locked import BatchedLockedEnv, LockedEnvConstants 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 dev = torch.device("cuda:0")
-env = BatchedLockedEnv(B, device=dev, constants=LockedEnvConstants(max_timesteps_per_goal=60), starting_seed=5, pipelined_reset=True)
+env = BatchedLockedEnv(B, device=dev, constants=LockedEnvConstants(max_timesteps_per_goal=int(sys.argv[3]) if len(sys.argv) > 3 else 60), starting_seed=5, pipelined_reset=True)
 env.reset()
 env.mujoco_simulation.set_field(6, torch.zeros((B, 1), dtype=torch.int32, device=dev))
 gen = torch.Generator(device=dev); gen.manual_seed(9)
