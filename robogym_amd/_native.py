@@ -143,7 +143,7 @@ RG_FLAG_CAPACITY_TEST_HOOK = 512   # bit 9: test hook (include/rgstep.h)
 RG_FLAG_RESUME = 256           # bit 8: active_dev is a redo array: entry - 1 = first substep still to do
 
 PRM_NAMES = ["row", "gravity", "timestep", "dof_damping", "dof_armature", "dof_frictionloss", "dof_invweight0", "body_mass", "body_inertia", "body_invweight0",
-             "jnt_range", "tendon_range", "tendon_invweight0", "actuator_gainprm", "actuator_ctrlrange", "actuator_forcerange", "geom_friction", "xfrc_applied", "site_pos", "geom_scale"]
+             "jnt_range", "tendon_range", "tendon_invweight0", "actuator_gainprm", "actuator_ctrlrange", "actuator_forcerange", "geom_friction", "xfrc_applied", "site_pos", "geom_scale", "jnt_margin", "geom_solref", "geom_solimp"]
 
 
 def prm_layout(L):

@@ -343,7 +343,7 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
       }
     }
     if (!upload<int>(m, cadr, &d.mesh_cell_adr) || !upload<float>(m, blk, &d.mesh_cell_blk) || !upload<float>(m, ovf, &d.mesh_cell_ovf)) return bail("hipMalloc failed", m); }
-  UPI(pair_geom, "k_pair_geom"); UPF(pair_prm, "k_pair_prm");
+  UPI(pair_geom, "k_pair_geom"); UPF(pair_prm, "k_pair_prm"); UPF(pair_mix, "k_pair_mix");
   {  // pair records: w0 g1 | g2<<8 | condim<<16 | type1<<20 | type2<<24, w1 margin, w2/w3 mesh ids (-1: none),
      // w4-6 size1, w7 nvert1, w8-10 size2, w11 nvert2, w12/w13 first vertex of the meshes, w14/w15 bounding radii,
      // w16-18 / w20-22 box half extents of the geoms (geom frame), w19 body1 | body2 << 8, w23 / w24 union of the two bodies' dof masks
@@ -424,13 +424,13 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
     std::vector<float> srec((size_t)(ns ? ns : 1) * 16, 0.f);
     for (int r = 0; r < ns; r++) {
       float* o = srec.data() + 16 * (size_t)r;
-      int rr = r, kind, dof = 0, ten = 31, neg = 0, src = 0, odiag, ofl = -1, olim = 0; float cfl = 0.f, margin = 0.f; const float *sr, *si;
+      int rr = r, kind, dof = 0, ten = 31, neg = 0, src = 0, odiag, ofl = -1, olim = 0, omargin = -1; float cfl = 0.f, margin = 0.f; const float *sr, *si;
       if (rr < d.nfric_dof) { int q = fd[rr]; kind = 0; dof = d2c[q]; ofl = RG_PRM_DOF_FRICTIONLOSS + q; odiag = RG_PRM_DOF_INVWEIGHT0 + q; sr = &dsr[2 * q]; si = &dsi[5 * q]; }
       else if ((rr -= d.nfric_dof) < d.nfric_ten) { int t = ft[rr]; kind = 1; ten = t; cfl = tfl[t]; odiag = RG_PRM_TENDON_INVWEIGHT0 + t; sr = &tsrf[2 * t]; si = &tsif[5 * t]; }
-      else if ((rr -= d.nfric_ten) < 2 * d.nlim_jnt) { int j = lj[rr >> 1]; kind = 2; dof = d2c[jd[j]]; neg = rr & 1; src = jq[j]; olim = RG_PRM_JNT_RANGE + 2 * j + (rr & 1); margin = jm[j]; odiag = RG_PRM_DOF_INVWEIGHT0 + jd[j]; sr = &jsr[2 * j]; si = &jsi[5 * j]; }
+      else if ((rr -= d.nfric_ten) < 2 * d.nlim_jnt) { int j = lj[rr >> 1]; kind = 2; dof = d2c[jd[j]]; neg = rr & 1; src = jq[j]; olim = RG_PRM_JNT_RANGE + 2 * j + (rr & 1); margin = 0.f; omargin = RG_PRM_JNT_MARGIN + j; (void)jm; odiag = RG_PRM_DOF_INVWEIGHT0 + jd[j]; sr = &jsr[2 * j]; si = &jsi[5 * j]; }
       else { rr -= 2 * d.nlim_jnt; int t = lt[rr >> 1]; kind = 3; ten = t; neg = rr & 1; src = t; olim = RG_PRM_TENDON_RANGE + 2 * t + (rr & 1); margin = tm[t]; odiag = RG_PRM_TENDON_INVWEIGHT0 + t; sr = &tsrl[2 * t]; si = &tsil[5 * t]; }
       int w0 = (dof & 63) | (ten << 6) | (neg << 11) | (kind << 16);
-      memcpy(o, &w0, 4); memcpy(o + 1, &src, 4); memcpy(o + 2, &odiag, 4); memcpy(o + 3, &ofl, 4); o[4] = cfl; memcpy(o + 5, &olim, 4); o[6] = margin;
+      memcpy(o, &w0, 4); memcpy(o + 1, &src, 4); memcpy(o + 2, &odiag, 4); memcpy(o + 3, &ofl, 4); o[4] = cfl; memcpy(o + 5, &olim, 4); o[6] = margin; if (omargin >= 0) memcpy(o + 6, &omargin, 4);   // (w6: joint limits carry the parameter-row offset of their margin)
       o[7] = sr[0]; o[8] = sr[1]; for (int c = 0; c < 5; c++) o[9 + c] = si[c];
     }
     if (!upload<float>(m, srec, &d.srow_rec)) return bail("hipMalloc failed", m);
@@ -453,7 +453,8 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
         !put("jnt_range", RG_PRM_JNT_RANGE, 2 * RG_MAXJNT) || !put("tendon_range", RG_PRM_TENDON_RANGE, 2 * RG_MAXTEN) || !put("tendon_invweight0", RG_PRM_TENDON_INVWEIGHT0, RG_MAXTEN) ||
         !put("actuator_gainprm", RG_PRM_ACT_GAINPRM, 10 * RG_MAXU) || !put("actuator_ctrlrange", RG_PRM_ACT_CTRLRANGE, 2 * RG_MAXU) ||
         !put("actuator_forcerange", RG_PRM_ACT_FORCERANGE, 2 * RG_MAXU) || !put("geom_friction", RG_PRM_GEOM_FRICTION, 3 * RG_MAXGEOM) ||
-        !put("site_pos", RG_PRM_SITE_POS, 3 * RG_MAXSITE)) return bail(e, m);
+        !put("site_pos", RG_PRM_SITE_POS, 3 * RG_MAXSITE) || !put("jnt_margin", RG_PRM_JNT_MARGIN, RG_MAXJNT) || !put("geom_solref", RG_PRM_GEOM_SOLREF, 2 * RG_MAXGEOM) ||
+        !put("geom_solimp", RG_PRM_GEOM_SOLIMP, 5 * RG_MAXGEOM)) return bail(e, m);
     prm[RG_PRM_GEOM_SCALE] = 1.f;
     m->prm_default = prm;
     if (!upload<float>(m, prm, &d.prm_default)) return bail("hipMalloc failed", m);
@@ -555,7 +556,7 @@ int rg_xdata_layout(int* out, int n) {
 int rg_prm_layout(int* out, int n) {
   const int lay[] = {RG_NPRM, RG_PRM_GRAVITY, RG_PRM_TIMESTEP, RG_PRM_DOF_DAMPING, RG_PRM_DOF_ARMATURE, RG_PRM_DOF_FRICTIONLOSS, RG_PRM_DOF_INVWEIGHT0, RG_PRM_BODY_MASS,
                      RG_PRM_BODY_INERTIA, RG_PRM_BODY_INVWEIGHT0, RG_PRM_JNT_RANGE, RG_PRM_TENDON_RANGE, RG_PRM_TENDON_INVWEIGHT0, RG_PRM_ACT_GAINPRM, RG_PRM_ACT_CTRLRANGE,
-                     RG_PRM_ACT_FORCERANGE, RG_PRM_GEOM_FRICTION, RG_PRM_XFRC, RG_PRM_SITE_POS, RG_PRM_GEOM_SCALE};
+                     RG_PRM_ACT_FORCERANGE, RG_PRM_GEOM_FRICTION, RG_PRM_XFRC, RG_PRM_SITE_POS, RG_PRM_GEOM_SCALE, RG_PRM_JNT_MARGIN, RG_PRM_GEOM_SOLREF, RG_PRM_GEOM_SOLIMP};
   const int k = (int)(sizeof lay / sizeof lay[0]);
   for (int i = 0; i < k && i < n; i++) out[i] = lay[i];
   return k;

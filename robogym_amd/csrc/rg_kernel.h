@@ -1629,10 +1629,18 @@ __device__ __forceinline__ void rg_make_constraint(RgM m, RgLds& s, const float*
     const int hdr = __builtin_bit_cast(int, m.pair_rec[RG_PAIRREC * p]), bb = __builtin_bit_cast(int, m.pair_rec[RG_PAIRREC * p + 19]), b1 = bb & 255, b2 = bb >> 8;
     float tran = P[RG_PRM_BODY_INVWEIGHT0 + 2 * b1] + P[RG_PRM_BODY_INVWEIGHT0 + 2 * b2];
     float includemargin = prm[0] - prm[1], dist = s.c_dist[c];
-    float imp = impedance(prm + 7, dist, includemargin), K, B;
-    kb(P[RG_PRM_TIMESTEP], prm + 5, prm + 7, K, B);
-    // friction of the pair: element-wise max of its geoms' (engine_collision_driver: mj_contactParam)
+    // solref / solimp of the pair from its geoms' (the env's own rows: GeomSolrefRandomizer / GeomSolimpRandomizer), mixed by solmix;
+    // friction: element-wise max of its geoms' (engine_collision_driver: mj_contactParam)
     const int pg1 = hdr & 255, pg2 = (hdr >> 8) & 255;
+    const float mix = m.pair_mix[p];
+    const float* r1 = P + RG_PRM_GEOM_SOLREF + 2 * pg1; const float* r2 = P + RG_PRM_GEOM_SOLREF + 2 * pg2;
+    const float* i1 = P + RG_PRM_GEOM_SOLIMP + 5 * pg1; const float* i2 = P + RG_PRM_GEOM_SOLIMP + 5 * pg2;
+    float solref[2], solimp[5];
+    if (r1[0] > 0 && r2[0] > 0) { solref[0] = mix * r1[0] + (1.f - mix) * r2[0]; solref[1] = mix * r1[1] + (1.f - mix) * r2[1]; }
+    else { solref[0] = fminf(r1[0], r2[0]); solref[1] = fminf(r1[1], r2[1]); }
+    for (int q = 0; q < 5; q++) solimp[q] = mix * i1[q] + (1.f - mix) * i2[q];
+    float imp = impedance(solimp, dist, includemargin), K, B;
+    kb(P[RG_PRM_TIMESTEP], solref, solimp, K, B);
     const float fr_slide = fmaxf(P[RG_PRM_GEOM_FRICTION + 3 * pg1], P[RG_PRM_GEOM_FRICTION + 3 * pg2]), fr_spin = fmaxf(P[RG_PRM_GEOM_FRICTION + 3 * pg1 + 1], P[RG_PRM_GEOM_FRICTION + 3 * pg2 + 1]);
     float mu0 = fr_slide;  // friction[0]
     // first pyramid row: diagApprox = tran + mu0^2 * tran ; all rows get R = 2 mu^2 R_first, mu = friction[0]/sqrt(impratio)
@@ -1678,7 +1686,7 @@ __device__ __forceinline__ void rg_static_rows(RgM m, const RgLds& s, const floa
     if (!fric) {
       const float x = kind == 2 ? s.qpos[src] : s.tenlen[src], bound = P[__builtin_bit_cast(int, sb.y)];
       pos = (desc >> 11) & 1 ? bound - x : x - bound;   // lower limit: J = +1, upper: J = -1
-      margin = sb.z; active = pos < margin;
+      margin = kind == 2 ? P[__builtin_bit_cast(int, sb.z)] : sb.z; active = pos < margin;   // (joint margins: the env's own, RG_PRM_JNT_MARGIN)
     }
     R.desc[k] = desc;
     float D = 0, aref = 0;

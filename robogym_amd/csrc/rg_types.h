@@ -56,7 +56,10 @@ enum {
   RG_PRM_XFRC = RG_PRM_GEOM_FRICTION + 3 * RG_MAXGEOM,     // 6 nbody: data.xfrc_applied (force, torque in world coordinates at the body's com)
   RG_PRM_SITE_POS = RG_PRM_XFRC + 6 * RG_MAXBODY,          // 3 nsite: model.site_pos (marker placement, wrappers/dactyl.py:14-50)
   RG_PRM_GEOM_SCALE = RG_PRM_SITE_POS + 3 * RG_MAXSITE,    // 1   size factor of the geoms flagged in k_geom_scaled (the cube: wrappers/cube.py:12-53)
-  RG_NPRM = RG_PRM_GEOM_SCALE + 1
+  RG_PRM_JNT_MARGIN = RG_PRM_GEOM_SCALE + 1,               // njnt     model.jnt_margin (JointMarginRandomizer, randomization/sim.py:163-180)
+  RG_PRM_GEOM_SOLREF = RG_PRM_JNT_MARGIN + RG_MAXJNT,      // 2 ngeom  model.geom_solref (GeomSolrefRandomizer, :271-315): a contact mixes its two geoms' by solmix
+  RG_PRM_GEOM_SOLIMP = RG_PRM_GEOM_SOLREF + 2 * RG_MAXGEOM, // 5 ngeom  model.geom_solimp (GeomSolimpRandomizer, :183-268)
+  RG_NPRM = RG_PRM_GEOM_SOLIMP + 5 * RG_MAXGEOM
 };
 
 // `sim.data` readout row (mujoco_shadow_hand.py:18-61 reads site_xpos / actuator_force, simulation/base.py and
@@ -136,6 +139,7 @@ struct RgModelDev {
   const float* pair_rec;        // [npair][RG_PAIRREC] see rg_api.hip build_pair_records
   const int* pair_geom;   // [npair][3] g1, g2, condim
   const float* pair_prm;  // [npair][12] margin, gap, friction3, solref2, solimp5
+  const float* pair_mix;  // [npair] solmix weight of geom 1 in the pair's solref / solimp (mj_contactParam)
   // tendons
   const int *tendon_adr, *tendon_num, *wrap_type, *wrap_objid, *ten_dofs;
   const int *ten_path, *ten_path_adr;   // per tendon: 8-word path records (kernel_tables.py k_ten_path), [ntendon + 1] offsets

@@ -133,7 +133,7 @@ def derive_big_tables(model):
     A["b_group_adr"], A["b_group_dofs"], A["b_dof_group"], A["b_dof_local"] = _i32(gadr), _i32(gdofs), dof_group, dof_local
     # ---- collision pairs
     A["b_pair_geom"] = _i32(pairs).reshape(-1, 3)
-    A["b_pair_prm"] = np.asarray(prm, dtype=np.float64).reshape(-1, 12)
+    A["b_pair_prm"] = np.ascontiguousarray(np.asarray(prm, dtype=np.float64).reshape(-1, 13)[:, :12])
     wmax = 0
     for a, b, _ in pairs:
         wmax = max(wmax, len(set(chains[A["geom_bodyid"][a]]) | set(chains[A["geom_bodyid"][b]])))

@@ -72,7 +72,7 @@ def collision_pairs(model):
                     solimp = mix * A["geom_solimp"][a] + (1 - mix) * A["geom_solimp"][b]
                     condim = max(A["geom_condim"][a], A["geom_condim"][b])
                     pairs.append((a, b, condim))
-                    prm.append(np.concatenate([[margin, gap], fr, solref, solimp]))  # 12 floats
+                    prm.append(np.concatenate([[margin, gap], fr, solref, solimp, [mix]]))  # 12 floats + the solmix weight of geom a
     return pairs, prm
 
 
@@ -224,7 +224,9 @@ def derive_kernel_tables(model, max_row_nnz=16):
     # geoms whose size follows the env's `geom_scale` parameter: what RandomizedCubeSizeWrapper rescales (wrappers/cube.py:12-53)
     gnames = model.names["geom"]
     A["k_geom_scaled"] = _i32([1 if (n in ("cube:middle", "cube:top", "cube:bottom") and int(A["geom_type"][g]) == 6) else 0 for g, n in enumerate(gnames)])
-    A["k_pair_prm"] = np.asarray(prm, dtype=np.float64).reshape(-1, 12)
+    prm = np.asarray(prm, dtype=np.float64).reshape(-1, 13)
+    A["k_pair_prm"] = np.ascontiguousarray(prm[:, :12])
+    A["k_pair_mix"] = np.ascontiguousarray(prm[:, 12])
     # oriented bounding boxes in the geom frame (conservative pre-filter before MPR)
     aabb = np.zeros((ngeom, 3))
     for g in range(ngeom):

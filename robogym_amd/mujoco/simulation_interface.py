@@ -362,7 +362,7 @@ class EnvParams:
         nv, nu, nb, nj, ng, ns, nt = int(d[1]), int(d[2]), int(d[3]), int(d[4]), int(d[5]), int(d[6]), int(d[7])
         shapes = dict(gravity=(3,), timestep=(1,), dof_damping=(nv,), dof_armature=(nv,), dof_frictionloss=(nv,), dof_invweight0=(nv,), body_mass=(nb,),
                       body_inertia=(nb, 3), body_invweight0=(nb, 2), jnt_range=(nj, 2), tendon_range=(nt, 2), tendon_invweight0=(nt,),
-                      actuator_gainprm=(nu, 10), actuator_ctrlrange=(nu, 2), actuator_forcerange=(nu, 2), geom_friction=(ng, 3), xfrc_applied=(nb, 6), site_pos=(ns, 3), geom_scale=(1,))
+                      actuator_gainprm=(nu, 10), actuator_ctrlrange=(nu, 2), actuator_forcerange=(nu, 2), geom_friction=(ng, 3), xfrc_applied=(nb, 6), site_pos=(ns, 3), geom_scale=(1,), jnt_margin=(nj,), geom_solref=(ng, 2), geom_solimp=(ng, 5))
         self._views: Dict[str, torch.Tensor] = {}
         B = sim.batch_size
         for name, shape in shapes.items():

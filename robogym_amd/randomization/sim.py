@@ -1,5 +1,6 @@
 """Batched simulation randomizers: the reference's `robogym/randomization/sim.py` (GravityRandomizer :115-133,
-PidRandomizer :136-160, GenericSimRandomizer :317-589) and the dactyl physics wrappers
+PidRandomizer :136-160, JointMarginRandomizer :163-180, GeomSolimpRandomizer :183-268, GeomSolrefRandomizer :271-315,
+GenericSimRandomizer :317-589) and the dactyl physics wrappers
 (`wrappers/randomizations.py`: RandomizedBodyInertiaWrapper :72-92, RandomizedFrictionBaseWrapper :95-173,
 RandomizedGravityWrapper :176-191, RandomizedDampingWrapper :562-590, RandomizedKpWrapper :720-746) acting on the
 per-env model parameter rows of the HIP stepper instead of on one `sim.model`.
@@ -128,6 +129,65 @@ class GenericSimRandomizer(SimulationRandomizer):
         if m == "max_additive":
             return init + u() * float(np.exp(abs(p[0])) - 1.0)
         raise ValueError("Invalid mode: {}".format(m))
+
+
+class JointMarginRandomizer(SimulationRandomizer):
+    """sim.py:163-180: jnt_margin + U(0, 1) * (exp(p) - 1) * 0.15 per joint."""
+
+    def __init__(self, param: float = 0.0):
+        super().__init__("jnt_margin")
+        self.param = param
+
+    def _field(self, sim):
+        return sim.params["jnt_margin"]
+
+    def _sample(self, init, gen):
+        return init + torch.rand(init.shape, generator=gen, device=init.device) * float(np.exp(self.param) - 1.0) * 0.15
+
+
+class GeomSolimpRandomizer(SimulationRandomizer):
+    """sim.py:183-268: (dmin, dmax, width) of every geom.  dmax = 1 - (1 - dmax0) exp(N(dmax_mean, dmax_std)) clipped to `drange`;
+    dmin = clip(dmax - (dmax0 - dmin0) exp(N(delta_mean, delta_std))); width = width0 exp(N(width_mean, width_std)).
+    `param` = [dmax_mean, dmax_std, delta_mean, delta_std, width_mean, width_std]."""
+
+    def __init__(self, param=(0.0, 0.0, 0.0, 0.0, 0.0, 0.0), drange=(0.5, 0.99)):
+        super().__init__("geom_solimp")
+        self.param, self.drange = [float(v) for v in param], (float(drange[0]), float(drange[1]))
+        assert len(self.param) == 6 and self.param[1] >= 0 and self.param[3] >= 0 and self.param[5] >= 0
+
+    def _field(self, sim):
+        return sim.params["geom_solimp"]
+
+    def _sample(self, init, gen):
+        p, (lo, hi) = self.param, self.drange
+        n = lambda: torch.randn(init.shape[:-1], generator=gen, device=init.device)
+        dmax = (1.0 - (1.0 - init[..., 1]) * torch.exp(p[0] + p[1] * n())).clamp(lo, hi)
+        delta = (init[..., 1] - init[..., 0]) * torch.exp(p[2] + p[3] * n())
+        dmin = (dmax - delta).clamp(lo, hi)
+        width = init[..., 2] * torch.exp(p[4] + p[5] * n())
+        out = init.clone()
+        out[..., 0], out[..., 1], out[..., 2] = dmin, dmax, width
+        return out
+
+
+class GeomSolrefRandomizer(SimulationRandomizer):
+    """sim.py:271-315: timeconst * exp(N(timeconst_mean, timeconst_std)), dampratio * exp(N(dampratio_mean, dampratio_std)) per geom."""
+
+    def __init__(self, param=(0.0, 0.0, 0.0, 0.0)):
+        super().__init__("geom_solref")
+        self.param = [float(v) for v in param]
+        assert len(self.param) == 4 and self.param[1] >= 0 and self.param[3] >= 0
+
+    def _field(self, sim):
+        return sim.params["geom_solref"]
+
+    def _sample(self, init, gen):
+        p = self.param
+        n = lambda: torch.randn(init.shape[:-1], generator=gen, device=init.device)
+        out = init.clone()
+        out[..., 0] = init[..., 0] * torch.exp(p[0] + p[1] * n())
+        out[..., 1] = init[..., 1] * torch.exp(p[2] + p[3] * n())
+        return out
 
 
 class _RowSubset:   # (placeholder type for _field(); GenericSimRandomizer.randomize handles subsets itself)

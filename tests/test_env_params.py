@@ -45,13 +45,21 @@ def _variants(model):
     tr = A["tendon_range"].copy(); tr[:, 1] = tr[:, 0] + 0.8 * (tr[:, 1] - tr[:, 0]); v[3]["tendon_range"] = tr
     fr = A["actuator_forcerange"].copy(); fr *= 0.5; v[3]["actuator_forcerange"] = fr
     cr = A["actuator_ctrlrange"].copy(); mid = cr.mean(1, keepdims=True); cr = mid + 0.7 * (cr - mid); v[3]["actuator_ctrlrange"] = cr
+    # ... and its own joint margins and contact softness (JointMarginRandomizer, GeomSolrefRandomizer, GeomSolimpRandomizer: randomization/sim.py:163-315)
+    rs = np.random.RandomState(4)
+    v[3]["jnt_margin"] = A["jnt_margin"] + rs.uniform(size=A["jnt_margin"].shape) * 0.15 * (np.exp(0.3) - 1.0)
+    gsr = A["geom_solref"].copy(); gsr[:, 0] *= np.exp(rs.normal(0.1, 0.2, len(gsr))); gsr[:, 1] *= np.exp(rs.normal(0.0, 0.1, len(gsr))); v[3]["geom_solref"] = gsr
+    gsi = A["geom_solimp"].copy()
+    dmax = np.clip(1.0 - (1.0 - gsi[:, 1]) * np.exp(rs.normal(0.2, 0.3, len(gsi))), 0.5, 0.99)
+    gsi[:, 0] = np.clip(dmax - (A["geom_solimp"][:, 1] - A["geom_solimp"][:, 0]) * np.exp(rs.normal(0.0, 0.3, len(gsi))), 0.5, 0.99); gsi[:, 1] = dmax
+    gsi[:, 2] *= np.exp(rs.normal(0.0, 0.3, len(gsi))); v[3]["geom_solimp"] = gsi
     xf = np.zeros((len(A["body_mass"]), 6)); xf[cube_body] = [0.05, -0.03, 0.3, 0.002, -0.001, 0.003]
     return v, xf, cube_body
 
 
 PARAM_OF = dict(opt_gravity="gravity", opt_timestep="timestep", dof_damping="dof_damping", dof_armature="dof_armature", dof_frictionloss="dof_frictionloss",
                 body_mass="body_mass", body_inertia="body_inertia", geom_friction="geom_friction", jnt_range="jnt_range", tendon_range="tendon_range",
-                actuator_gainprm="actuator_gainprm", actuator_forcerange="actuator_forcerange", actuator_ctrlrange="actuator_ctrlrange", site_pos="site_pos")
+                actuator_gainprm="actuator_gainprm", actuator_forcerange="actuator_forcerange", actuator_ctrlrange="actuator_ctrlrange", site_pos="site_pos", jnt_margin="jnt_margin", geom_solref="geom_solref", geom_solimp="geom_solimp")
 
 
 def _run(sim, model, nsteps, seed):
@@ -251,3 +259,31 @@ def test_per_env_parameters_at_full_batch_gpu(locked_model, oracle_lib):
     assert np.abs(q[others[0]] - default.sim.qpos)[NON_TARGET_QPOS].max() < 5e-4
     assert (q[others] == q[others[0]]).all() and int(sim.status.max().item()) == 0
     assert np.abs(q[rows[0]] - q[rows[1]])[NON_TARGET_QPOS].max() > 1e-5      # the rows do differ
+
+
+def test_joint_margin_and_geom_softness_randomizers_emul(locked_model, emul_lib):
+    """JointMarginRandomizer, GeomSolimpRandomizer, GeomSolrefRandomizer (randomization/sim.py:163-315) on the per-env rows:
+    the reference's formulas (margins only grow, by at most 0.15 (exp(p) - 1); dmin <= dmax inside drange; zero parameters leave
+    solref untouched), masked to the envs being reset, and the kernel steps with the rows (no status bit, finite state)."""
+    from robogym_amd.envs.dactyl.locked import LockedSimulation
+    from robogym_amd.randomization.sim import GeomSolimpRandomizer, GeomSolrefRandomizer, JointMarginRandomizer
+
+    sim = LockedSimulation(locked_model, 3, lib=emul_lib, n_substeps=2)
+    A = locked_model.arrays
+    gen = torch.Generator(); gen.manual_seed(0)
+    mask = torch.tensor([True, False, True])
+    P = sim.params
+    JointMarginRandomizer(0.4).randomize(sim, gen, mask)
+    GeomSolimpRandomizer((0.1, 0.3, 0.0, 0.3, 0.0, 0.2)).randomize(sim, gen, mask)
+    GeomSolrefRandomizer((0.0, 0.0, 0.0, 0.0)).randomize(sim, gen, mask)
+    jm, jm0 = P["jnt_margin"].numpy(), A["jnt_margin"].astype(np.float32)
+    assert (jm[1] == jm0).all() and (jm[0] >= jm0).all() and (jm[0] - jm0).max() <= 0.15 * (np.exp(0.4) - 1) + 1e-7 and (jm[0] != jm[2]).any()
+    si = P["geom_solimp"].numpy()
+    assert (si[1] == A["geom_solimp"].astype(np.float32)).all()
+    assert (si[0][:, 0] <= si[0][:, 1]).all() and si[0][:, :2].min() >= 0.5 - 1e-6 and si[0][:, :2].max() <= 0.99 + 1e-6 and (si[0][:, 3:] == si[1][:, 3:]).all()
+    np.testing.assert_allclose(P["geom_solref"].numpy()[0], A["geom_solref"], rtol=1e-6)      # exp(N(0, 0)) = 1
+    GeomSolrefRandomizer((0.2, 0.1, 0.0, 0.1)).randomize(sim, gen, mask)
+    assert (P["geom_solref"][0, :, 0] != P["geom_solref"][1, :, 0]).all()
+    for _ in range(3):
+        sim.env_step(action=torch.zeros((3, 20)), nforward_ticks=1)
+    assert torch.isfinite(sim.qpos).all() and int(sim.status.max()) == 0
