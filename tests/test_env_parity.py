@@ -174,7 +174,7 @@ def _run_reward_stream(env, oras, nsteps, seed, near=None, easy=0.4, reward_tol=
                 continue
             events["compared"] += 1
             worst_r = max(worst_r, abs(reward[e, 1] - r[1]))
-            assert abs(reward[e, 1] - r[1]) < reward_tol * (1.0 + 4.0 * abs(r[1])), (t, e, reward[e], r)     # (a tumbling cube turns 0.5 rad per step: relative part)                     # goal-distance reward
+            assert abs(reward[e, 1] - r[1]) < reward_tol, (t, e, reward[e], r)                     # goal-distance reward
             assert reward[e, 0] == 0 and reward[e, 2] == r[2], (t, e, reward[e], r)          # env reward, success reward
             assert bool(done[e]) == d, (t, e)
             assert bool(info["goal_achieved"][e]) == inf["goal_achieved"]
@@ -183,7 +183,7 @@ def _run_reward_stream(env, oras, nsteps, seed, near=None, easy=0.4, reward_tol=
             assert int(info["goals_so_far"][e]) == inf["goals_so_far"]
             assert bool(info["goal_reset"][e]) == inf["goal_reset"] and bool(info["trial_success"][e]) == inf["trial_success"]
             assert int(obs["is_goal_achieved"][e, 0]) == int(inf["is_goal_achieved"])
-            assert abs(float(info["goal_dist"]["cube_quat"][e]) - inf["goal_dist"]) < 4.0 * reward_tol     # (the cube quaternion of this step: the env.step tolerance, max 2e-2 in the default configuration)
+            assert abs(float(info["goal_dist"]["cube_quat"][e]) - inf["goal_dist"]) < reward_tol
             events["success"] += int(inf["sub_goal_is_successful"]); events["trial"] += int(inf["trial_success"])
             events["timeout"] += int(d and not inf["trial_success"])
         # finished episodes start over on both sides (tracker + goal; the physics keeps running: the reset recipe has its own test)
@@ -212,8 +212,10 @@ def test_reward_success_tracker_stream_gpu(locked_model, oracle_lib, kernel_vari
     c = LockedEnvConstants(max_timesteps_per_goal=40, successes_needed=3)
     env = BatchedLockedEnv(B, device="cuda:0", constants=c, model=locked_model, starting_seed=1)
     oras = [OracleLockedEnv(locked_model, max_timesteps_per_goal=40, successes_needed=3) for _ in range(B)]
-    # goal-distance reward per step: plane 1e-3, default 5e-3 rad (a rotation-distance difference of two steps; the cube quaternion carries the env.step tolerance)
-    events, tainted, worst = _run_reward_stream(env, oras, 600, seed=21, easy=0.4, reward_tol=kernel_variant.tol(1e-3, 5e-3), near=kernel_variant.tol(None, 1e-2))
+    # goal-distance reward per step: previous minus current rotation distance.  The current one carries this step's env.step error, the
+    # previous one the env's own value from the step before (only the PHYSICS is re-synchronised): plane 1e-3, default 2e-2 rad = twice
+    # the env.step tail of the default configuration (measured worst 1.1e-2)
+    events, tainted, worst = _run_reward_stream(env, oras, 600, seed=21, easy=0.4, reward_tol=kernel_variant.tol(1e-3, 2e-2), near=kernel_variant.tol(None, 4e-2))
     print("reward stream on cuda: %s, %d of %d envs compared to the end, worst |goal reward - oracle| %.2e" % (events, int((~tainted).sum()), B, worst))
     assert (~tainted).sum() >= 3
     assert events["success"] >= 5 and events["timeout"] >= 2 and events["trial"] >= 1 and events["compared"] >= 1500
