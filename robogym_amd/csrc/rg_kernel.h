@@ -2681,6 +2681,9 @@ __global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_items_kern
   const int xq = rg_xcc_id() % nq_;
   const int nx = (B - xq + nq_ - 1) / nq_;   // envs at positions k = nq_ * j + xq < B
   const int nitems = nx * nsub;
+  st_build_row_desc(c);   // (static index tables in the persistent part of the LDS image: once per workgroup, not per item)
+  int xfrc_default = -1;  // batches without per-env parameter rows: "any external wrench?" is a property of the model's default row
+  if (!L.bt.envprm) { const float* P0 = m.prm_default; float nz = 0; PFOR(i, 6 * m.nbody) nz += P0[RG_PRM_XFRC + i] != 0.f ? 1.f : 0.f; xfrc_default = wave_sum(nz) > 0 ? 1 : 0; }
   for (;;) {
     SYNC();   // (the previous item's LDS image is dead only when every lane is here)
     int t = 0;
@@ -2707,10 +2710,10 @@ __global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_items_kern
     if (LANE < m.nv) { s.qvel[LANE] = RG_ROW_LD(L.bt.qvel + (size_t)e * m.nv + LANE); warmr = RG_ROW_LD(L.bt.qacc_warmstart + (size_t)e * m.nv + LANE); }
     if (LANE < m.nu) for (int q = 0; q < 3; q++) pidr[q] = RG_ROW_LD(L.bt.pid + (size_t)e * 3 * m.nu + 3 * LANE + q);
     const float* P = rg_prm(m, L);
-    { float nz = 0; PFOR(i, 6 * m.nbody) nz += P[RG_PRM_XFRC + i] != 0.f ? 1.f : 0.f; nz = wave_sum(nz); if (LANE == 0) s.has_xfrc = nz > 0; }
+    if (xfrc_default >= 0) { if (LANE == 0) s.has_xfrc = xfrc_default; }
+    else { float nz = 0; PFOR(i, 6 * m.nbody) nz += P[RG_PRM_XFRC + i] != 0.f ? 1.f : 0.f; nz = wave_sum(nz); if (LANE == 0) s.has_xfrc = nz > 0; }
     const unsigned status0 = RG_ROW_LD(L.bt.status + e);
     if (LANE == 0) s.status = status0;
-    st_build_row_desc(c);
     bool cleared_preticks = false;
     if (sub == 0) {
       if (L.bt.preticks) {   // reset_goal's two state-less forwards, owed from the previous step (see rg_step_kernel)

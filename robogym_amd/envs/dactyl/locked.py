@@ -379,6 +379,9 @@ class BatchedLockedEnv:
     def _dispatch_order(self):
         """Longest-expected-first dispatch (rg_step_args.order_dev): the envs sorted by the cycles their previous
         env.step took, so the launch's tail is made of short envs.  Re-sorted every step (every 4th: -1.3 %; RG_SORT_EVERY overrides)."""
+        from robogym_amd.mujoco import simulation_interface as _si
+        if _si.SUBSTEP_ITEMS and not self.pipelined_reset and not self.mujoco_simulation._emul:
+            return None      # (the substep-granular dispatch keeps the slots full whatever the order: sorting measured +-0, profiles/r03_ab.txt)
         if not self.sort_dispatch:
             return None
         if self._order is None or self._order_age >= self._sort_every:
