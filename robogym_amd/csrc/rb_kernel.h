@@ -301,66 +301,80 @@ __device__ __forceinline__ void rb_M_block(RbM m, RbLds& s, const float* Msp, in
   BSYNC();
 }
 // In-place Cholesky of the n x n block in s.A (lower triangle, row stride n + 1), blocked by RB_NB columns; false on a
-// non-positive pivot.  Per block: (a) the panel (rows kb.., RB_NB columns), one row per thread IN REGISTERS, column by column with
-// one barrier each (the pivot row travels through LDS); (b) the RB_NB x RB_NB diagonal block is inverted (one column per
-// thread, registers) into s.Dinv so that the substitutions multiply instead of dividing serially; (c) the trailing block,
-// a 16 x 16 thread tile with its operands loaded into registers before any store (an LDS load behind a possibly aliasing LDS
-// store does not overlap), rank-RB_NB update per pass.  Columns beyond n are padded with the identity.
+// non-positive pivot.  Per block THREE workgroup barriers: (a) every thread loads the RB_NB x RB_NB diagonal block and factors it
+// REDUNDANTLY in registers (as rg_chol does with its 4 x 4 blocks: 36 broadcast LDS reads and ~150 flops instead of a pivot row
+// travelling through LDS with two barriers per column), solves its own row's RB_NB entries against it and writes them back;
+// threads < RB_NB also leave the inverse of the diagonal block in s.Dinv so that the substitutions multiply instead of dividing
+// serially; (b) the trailing block, a 16 x 16 thread tile with its operands loaded into registers before any store, rank-RB_NB
+// update per pass.
 #define RB_NB 8
 __device__ __forceinline__ bool rb_chol(RbLds& s, int n) {
   const int ld = RB_LD(n), ty = TID >> 4, tx = TID & 15;
   bool ok = true;
   for (int kb = 0; kb < n; kb += RB_NB) {
     const int nb = n - kb < RB_NB ? n - kb : RB_NB;
-    // (a) panel
-    const int i = kb + TID;
-    float p[RB_NB];
+    // (a) the diagonal block, redundantly: L (lower triangle) with the reciprocals of its diagonal in id[]
+    float Lb[RB_NB][RB_NB], id[RB_NB];
 #pragma unroll
-    for (int c = 0; c < RB_NB; c++) p[c] = (i < n && c < nb) ? s.A[i * ld + kb + c] : 0.f;
+    for (int r = 0; r < RB_NB; r++)
+#pragma unroll
+      for (int q = 0; q < RB_NB; q++) if (q <= r) Lb[r][q] = (r < nb) ? s.A[(kb + r) * ld + kb + q] : (r == q ? 1.f : 0.f);
+    BSYNC();   // (every thread holds the unfactored block before its rows are overwritten with the factor)
 #pragma unroll
     for (int c = 0; c < RB_NB; c++) {
-      if (c < nb) {
-        if (TID == c) {   // the pivot row finishes itself and publishes its entries
-          float d = p[c];
+      float d = Lb[c][c];
 #pragma unroll
-          for (int q = 0; q < RB_NB; q++) if (q < c) d -= p[q] * p[q];
-          if (!(d > RB_MINVAL)) s.stop = 1;
-          p[c] = rg_sqrt(fmaxf(d, RB_MINVAL));
+      for (int q = 0; q < RB_NB; q++) if (q < c) d -= Lb[c][q] * Lb[c][q];
+      if (!(d > RB_MINVAL)) ok = false;
+      id[c] = rg_rsqrt(fmaxf(d, RB_MINVAL));
+      Lb[c][c] = fmaxf(d, RB_MINVAL) * id[c];
 #pragma unroll
-          for (int q = 0; q < RB_NB; q++) if (q <= c) s.prow[q] = p[q];
-        }
-        BSYNC();
-        if (i < n && TID > c) {
-          float v = p[c];
+      for (int r = 0; r < RB_NB; r++) if (r > c) {
+        float v = Lb[r][c];
 #pragma unroll
-          for (int q = 0; q < RB_NB; q++) if (q < c) v -= p[q] * s.prow[q];
-          p[c] = v * rg_rcp(s.prow[c]);
-        }
-        BSYNC();
+        for (int q = 0; q < RB_NB; q++) if (q < c) v -= Lb[r][q] * Lb[c][q];
+        Lb[r][c] = v * id[c];
       }
     }
+    // the thread's own row below / inside the block
+    const int i = kb + TID;
     if (i < n) {
+      if (TID < nb) {   // a row of the diagonal block: its finished entries
 #pragma unroll
-      for (int c = 0; c < RB_NB; c++) if (c < nb && (TID >= c)) s.A[i * ld + kb + c] = p[c];
+        for (int r = 0; r < RB_NB; r++) if (r == TID) {
+#pragma unroll
+          for (int q = 0; q < RB_NB; q++) if (q <= r) s.A[i * ld + kb + q] = Lb[r][q];
+        }
+      } else {
+        float p[RB_NB];
+#pragma unroll
+        for (int c = 0; c < RB_NB; c++) p[c] = c < nb ? s.A[i * ld + kb + c] : 0.f;
+#pragma unroll
+        for (int c = 0; c < RB_NB; c++) {
+          float v = p[c];
+#pragma unroll
+          for (int q = 0; q < RB_NB; q++) if (q < c) v -= p[q] * Lb[c][q];
+          p[c] = v * id[c];
+        }
+#pragma unroll
+        for (int c = 0; c < RB_NB; c++) if (c < nb) s.A[i * ld + kb + c] = p[c];
+      }
     }
-    BSYNC();
-    // (b) inverse of the diagonal block: thread c < nb solves L y = e_c
+    // inverse of the diagonal block: thread c < nb solves L y = e_c in registers
     if (TID < nb) {
       float y[RB_NB];
 #pragma unroll
       for (int r = 0; r < RB_NB; r++) {
         float v = r == TID ? 1.f : 0.f;
-        if (r < nb && r >= TID) {
 #pragma unroll
-          for (int q = 0; q < RB_NB; q++) if (q < r && q >= TID) v -= s.A[(kb + r) * ld + kb + q] * y[q];
-          v *= rg_rcp(s.A[(kb + r) * ld + kb + r]);
-        } else v = 0.f;
-        y[r] = v;
+        for (int q = 0; q < RB_NB; q++) if (q < r) v -= Lb[r][q] * ((q >= TID) ? y[q] : 0.f);
+        y[r] = (r >= TID && r < nb) ? v * id[r] : 0.f;
       }
 #pragma unroll
       for (int r = 0; r < RB_NB; r++) s.Dinv[(kb / RB_NB) * RB_NB * RB_NB + r * RB_NB + TID] = y[r];   // Dinv[r][c]
     }
-    // (c) trailing update: A[i][j] -= sum_c L[i][kb + c] L[j][kb + c], i, j >= kb + RB_NB
+    BSYNC();
+    // (b) trailing update: A[i][j] -= sum_c L[i][kb + c] L[j][kb + c], i, j >= kb + RB_NB
     const int t0 = kb + RB_NB;
     if (t0 < n) {
       constexpr int NT = RB_MAXGROUP / 16;
@@ -399,11 +413,11 @@ __device__ __forceinline__ bool rb_chol(RbLds& s, int n) {
     }
     BSYNC();
   }
-  if (s.stop) ok = false;
   return ok;
 }
 // x <- inv(L L') x for the group's local vector x[0..n), block by block: the diagonal block through its inverse (RB_NB threads, one
-// dot product each), the rest of the column panel by everybody
+// dot product each), the rest of the column panel by everybody.  (Every thread doing the 8 x 8 product redundantly, which saves a
+// barrier per block, measured 3 x slower: profiles/r03_ab.txt.)
 __device__ __forceinline__ void rb_chol_solve(RbLds& s, int n, float* x) {
   const int ld = RB_LD(n);
   for (int kb = 0; kb < n; kb += RB_NB) {          // forward: L y = x
