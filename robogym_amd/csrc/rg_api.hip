@@ -689,6 +689,7 @@ static void rg_items_probe(rg_batch* b) {
     for (int x = 0; x < 16; x++) if (h[x] > 0) nq = x + 1;
     for (int x = 0; x < nq; x++) if (h[x] <= 0) ok = false;
     if (ok && nq >= 1 && nq <= 8) { b->items_slots = grid; b->items_queues = nq; }
+    if (const char* ov = getenv("RG_ITEMS_SLOTS")) { const int v = atoi(ov); if (v > 0 && b->items_slots > 0) b->items_slots = v; }   // (experiments: persistent workgroups per launch)
   }
   (void)hipFree(counts);
 #endif
