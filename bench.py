@@ -73,39 +73,42 @@ def kernel_source_hash():
     import hashlib
 
     h = hashlib.sha256()
-    for f in ("rg_kernel.h", "rg_env_kernel.h", "rg_api.hip", "rg_types.h", "rb_kernel.h", "rb_types.h", "Makefile"):
+    for f in ("rg_kernel.h", "rg_env_kernel.h", "rg_api.hip", "rg_types.h", "rb_kernel.h", "rb_env_kernel.h", "rb_types.h", "Makefile"):
         h.update(open(os.path.join(ROOT, "robogym_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
 
 def bench_full_perpendicular(args):
     """BASELINE.json configs[2]: dactyl/full_perpendicular (Shadow hand + full Rubik's cube, nv 168, condim-6 contacts), batch 4096
-    on one MI355X, on the large-model stepper (rb_step_kernel).  Physics env.step only (action map, 10 mj_step, 3 PID ticks):
-    the full-cube env layer (face-angle goals) is not built.  One JSON line with its own roofline; single GPU."""
-    from robogym_amd.envs.dactyl.full_perpendicular import load_full_perpendicular_model
-    from robogym_amd.mujoco.large_simulation import LargeModelSimulation
+    on one MI355X: `BatchedFullPerpendicularEnv.step` = the large-model stepper (rb_step_kernel: action map, 10 mj_step, 3 PID ticks)
+    + the env kernel (rb_post_step_kernel: FaceFreeGoal distances, reward, success, tracker, goal generation, observation row), after
+    the reference's reset recipe (scrambled cubes).  One JSON line with its own roofline (the physics launch); single GPU."""
+    from robogym_amd.envs.dactyl.full_perpendicular import BatchedFullPerpendicularEnv
 
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     B = args.batch if args.batch != 8192 else 4096
-    model = load_full_perpendicular_model()
-    sim = LargeModelSimulation(model, B, device=dev)
-    zero = torch.zeros((B, 20), device=dev)
-    for _ in range(6):                       # the cube lands on the palm (outside the timed region)
-        sim.env_step(action=zero, nforward_ticks=3)
+    env = BatchedFullPerpendicularEnv(B, device=dev, starting_seed=20200901 + 2)
+    sim, model = env.sim, env.model
+    env.constants.max_pose_resets = 6        # (bounded set-up time: envs whose cube is still off the palm after 6 passes of the recipe are stepped as they are)
+    env.reset()
+    on_palm0 = float((sim.scratch("site_xpos")[:, 3 * sim.center_site + 2] > 0.04).float().mean().item())
     gen = torch.Generator(device=dev); gen.manual_seed(20200901 + 2)
-    step = lambda: sim.env_step(action=torch.rand((B, 20), generator=gen, device=dev) * 2 - 1, nforward_ticks=3)
+    step = lambda: env.step(torch.rand((B, 20), generator=gen, device=dev) * 2 - 1)
     for _ in range(args.warmup):
         step()
     sim.stats.zero_()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for s_, e_ in ev:
-        s_.record(); step(); e_.record()
+    for pair in ev:
+        env._physics_events = pair
+        step()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    env._physics_events = None
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    on_palm = float((sim.scratch("site_xpos")[:, 3 * sim.center_site + 2] > 0.04).float().mean().item())
     st = sim.stats.sum(0).cpu().numpy()
     nsub = max(st[3], 1.0)
     ncon, nefc, iters = float(st[0] / nsub), float(st[1] / nsub), float(st[2] / nsub)
@@ -117,11 +120,11 @@ def bench_full_perpendicular(args):
     b_step, b_sub = algorithmic_bytes_per_env_step(_M, ncon, nefc, iters, sim.n_substeps, sim.nq + sim.nv)
     achieved = B * b_step / (kern_ms * 1e-3)
     out = {
-        "metric": "env-steps/sec dactyl/full_perpendicular batch 4096 (BASELINE.json configs[2]); physics env.step, parity vs the in-repo CPU oracle (unpinned)",
+        "metric": "env-steps/sec dactyl/full_perpendicular batch 4096 (BASELINE.json configs[2]); unwrapped env.step, parity vs the in-repo CPU oracle (unpinned)",
         "value": B * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "dactyl/full_perpendicular (Shadow hand + full Rubik's cube, nv=168, 135 bodies, condim-6 contacts), batch %d, iid U(-1,1) relative actions, 10 substeps x 0.008 s; physics only" % B,
-                   "batch_per_gpu": B, "mean_ncon": ncon, "mean_nefc": nefc, "mean_newton_iters": iters, "status_bits": int(sim.status.max().item()), "lds_bytes_per_workgroup": sim.info["lds_bytes"]},
+        "config": {"workload": "dactyl/full_perpendicular (Shadow hand + full Rubik's cube, nv=168, 135 bodies, condim-6 contacts), batch %d, iid U(-1,1) relative actions, 10 substeps x 0.008 s; env.step = physics + env kernel (face_free goals), after the reset recipe with scrambled cubes" % B,
+                   "batch_per_gpu": B, "cube_on_palm_fraction_after_reset": on_palm0, "cube_on_palm_fraction_at_end": on_palm, "goals_so_far_mean": float(env.multi_goal_tracker.goals_so_far.float().mean().item()), "mean_ncon": ncon, "mean_nefc": nefc, "mean_newton_iters": iters, "status_bits": int(sim.status.max().item()), "lds_bytes_per_workgroup": sim.info["lds_bytes"]},
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None, "kernel": "rb_step_kernel", "kernel_ms": kern_ms,
                      "algorithmic_bytes_per_env_step": b_step, "algorithmic_bytes_per_substep": b_sub,
                      "note": "SURVEY 8(d) byte model with this model's dimensions (nM 1193) and the run's measured ncon / nefc / iterations; first, clarity-first version of the kernel"},

@@ -273,6 +273,49 @@ int rb_batch_reset(rb_batch* b);
 int rb_batch_set_env(rb_batch* b, int hand_qposadr, int n_hand_jnt, int relative_action, const float* pos_to_ctrl);
 void* rb_batch_field_ptr(rb_batch* b, int field, int* row_words);
 int rb_batch_step(rb_batch* b, const float* action_dev, const int* active_dev, int nsubsteps, int nforward_ticks, int flags, void* stream);
+/* ---- the env-level half of RobotEnv.step for the full cube (dactyl/full_perpendicular), one launch after rb_batch_step:
+ * FaceFreeGoal.goal_distance / relative_goal / next_goal (/root/reference/robogym/envs/dactyl/goals/face_free.py:61-189, with
+ * cube_utils.py:26-181), the target cube's joint manipulation that next_goal entails (full_perpendicular.py:138-155 ->
+ * cube_manipulator.py:148-187, 377-409: clone, soft_align_faces, rotate_face), reward / success of robot_env.py:550-625 (sum over
+ * the keys cube_quat and cube_face_angle), MultiGoalTracker.process (utils/multi_goal_tracker.py:157-241), reset_goal
+ * (robot_env.py:893-909; its two state-less forwards are executed as PID ticks inside this launch) and the observation row of
+ * full_perpendicular.py:177-192.  Arrays are device pointers owned by the caller, int32 / float32, [B] unless noted.
+ * goal row (RB_GOAL_WORDS floats): cube_quat[4] (w >= 0), cube_face_angle[6], goal_type (1 rotation, 0 flip), axis_nr, axis_sign, pad.
+ * observation row: cube_pos 3 | cube_quat 4 | cube_face_angle 6 | hand_angle n_hand | fingertip_pos 15 | goal_pos 3 | goal_quat 4 |
+ * goal_face_angle 6.  Randomness: `draws` ([B][RB_POST_NDRAW] = u_reorient, u_round, k_direction (index; the fraction of the range
+ * when round_target_face < 1), k_face (index), z angle in [-pi, pi)) or, when NULL, a counter-based generator keyed by (seed, step, env).
+ * force_new_goal ([B] or NULL): when given, ONLY reset_goal runs, for the flagged envs (the tail of RobotEnv.reset, robot_env.py:787-792). */
+#define RB_POST_NDRAW 5
+#define RB_GOAL_WORDS 16
+typedef struct rb_post_args {
+  float* obs; int obs_dim;
+  int *t, *steps, *steps_since_last_goal, *successes_so_far, *goals_so_far, *consecutive;   /* env clock, MultiGoalTracker */
+  float* prev_dist;            /* [B][2] previous distances (cube_quat, cube_face_angle) */
+  int *prev_valid, *is_successful;
+  float* goal;                 /* [B][RB_GOAL_WORDS] */
+  float* reward;               /* [B][3] */
+  float* goal_dist;            /* [B][2] distances to the goal the env had during the step */
+  unsigned char *done, *goal_reset, *trial_success, *sub_goal_ok, *env_crash;   /* 0 / 1 bytes (torch.bool storage) */
+  int* info_ssl;
+  const int* force_new_goal;
+  const float* draws;
+  unsigned seed, step;
+  const int* cube_tab;         /* [20][6]: per cubelet the offsets of its rotx / roty / rotz joint in the 66-joint block, its coordinates in {-1,0,1}^3 */
+  const float* face_up_quats;  /* [6][4]: per face the axis-aligned orientation that puts it up (cube_utils.face_up_quats) */
+  int face_geom[6];            /* geom ids of cube:cubelet:neg_x ... pos_z */
+  int tip_site[5], ref_site[3], center_site;
+  int cube_pos_col, cube_quat_col, cube_block_col, target_block_col, hand_col, n_hand;   /* qpos columns; *_block_col: first of the 66 cubelet joints (6 drivers, 20 x 3 hinges) */
+  float quat_threshold, face_threshold, success_reward, p_face_flip, round_target_face;
+  int directions;              /* bit 0 "cw", bit 1 "ccw" (goal_directions) */
+  int max_timesteps_per_goal, successes_needed, use_goal_distance_reward, stop_on_fall;
+} rb_post_args;
+int rb_env_post_step(rb_batch* b, const rb_post_args* args, void* stream);
+int rb_post_args_size(void);
+/* CubeManipulator operations on one of the two cubes of every env in `active_dev` (NULL: all): ops_dev float [B][nops][4] =
+ * {axis, side, angle, code}; code 0 rotate_face (cube_manipulator.py:148-187), 1 the same without the driver joint, 2 soft_align_faces
+ * (:377-409), negative: nothing.  block_col = the qpos column of the cube's first cubelet joint.  Used by the reset recipe
+ * (full_perpendicular.py:318-332: randomize_face_angles) and by the parity tests. */
+int rb_cube_ops(rb_batch* b, int block_col, const int* cube_tab_dev, const float* ops_dev, int nops, const int* active_dev, void* stream);
 int rg_sync(void* stream);
 const char* rg_last_error(void);
 

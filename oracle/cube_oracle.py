@@ -1,0 +1,246 @@
+"""Goal layer of dactyl/full_perpendicular on the CPU, one env at a time, double precision, numpy.
+TEST INFRASTRUCTURE ONLY (oracle/): the checker of `rb_post_step_kernel` / `rb_cube_ops_kernel`
+(robogym_amd/csrc/rb_env_kernel.h), never part of the product path.
+
+Restates, from /root/reference/robogym:
+  utils/rotation.py:86-107 euler2mat, :129-148 mat2euler, :202-225 quat2mat, :372-384 normalize_angles /
+      round_to_straight_angles, :461-486 any_orthogonal / vectors2quat, :518-538 rot_xyz_aligned
+  envs/dactyl/common/cube_manipulator.py:148-187 rotate_face, :377-409 soft_align_faces (CubeManipulator)
+  envs/dactyl/common/cube_utils.py:26-38 uniform_z_aligned_quat / face_up, :99-181 rotated_face_with_angle, align_quat_up,
+      up_axis_with_sign, distance_quat_from_being_up
+  envs/dactyl/goals/face_free.py:61-189 FaceFreeGoal.next_goal / relative_goal / goal_distance
+  envs/dactyl/full_perpendicular.py:138-155 clone_target_from_cube / align_target_faces / rotate_target_face
+PINNED against the real reference classes (imported with `pycuber` stubbed; they are pure numpy otherwise) by
+tests/golden/full_cube.npz (tools/gen_golden_cube.py).  The scramble (`from_pycuber`, cube_manipulator.py:189-289) needs pycuber
+itself, which is absent here: `scramble_matrices` restates pycuber 0.2.2's face turns (L, R, F, B, D, U clockwise as seen from
+outside that face, primes counter-clockwise) as signed permutation matrices — that piece is UNPINNED and says so.
+
+Random numbers are arguments (`draws`), in the order the reference consumes its RandomState, so that the product can be fed the same.
+"""
+import numpy as np
+
+EPS4 = np.finfo(np.float64).eps * 4.0
+
+
+def euler2mat(e):
+    a, b, c = -e[2], -e[1], -e[0]
+    sa, sb, sc = np.sin(a), np.sin(b), np.sin(c)
+    ca, cb, cc = np.cos(a), np.cos(b), np.cos(c)
+    return np.array([[cb * ca, cb * sa, -sb],
+                     [sb * ca * sc - sa * cc, sb * sa * sc + ca * cc, cb * sc],
+                     [sb * ca * cc + sa * sc, sb * sa * cc - ca * sc, cb * cc]])
+
+
+def mat2euler(m):
+    cy = np.sqrt(m[2, 2] * m[2, 2] + m[1, 2] * m[1, 2])
+    y = -np.arctan2(-m[0, 2], cy)
+    if cy > EPS4:
+        return np.array([-np.arctan2(m[1, 2], m[2, 2]), y, -np.arctan2(m[0, 1], m[0, 0])])
+    return np.array([0.0, y, -np.arctan2(-m[1, 0], m[1, 1])])
+
+
+def quat2mat(q):
+    w, x, y, z = q
+    n = np.dot(q, q)
+    if n <= np.finfo(np.float64).eps:
+        return np.eye(3)
+    s = 2.0 / n
+    return np.array([[1 - s * (y * y + z * z), s * (x * y - w * z), s * (x * z + w * y)],
+                     [s * (x * y + w * z), 1 - s * (x * x + z * z), s * (y * z - w * x)],
+                     [s * (x * z - w * y), s * (y * z + w * x), 1 - s * (x * x + y * y)]])
+
+
+def quat_mul(p, q):
+    return np.array([p[0] * q[0] - p[1] * q[1] - p[2] * q[2] - p[3] * q[3], p[0] * q[1] + p[1] * q[0] + p[2] * q[3] - p[3] * q[2],
+                     p[0] * q[2] + p[2] * q[0] + p[3] * q[1] - p[1] * q[3], p[0] * q[3] + p[3] * q[0] + p[1] * q[2] - p[2] * q[1]])
+
+
+def quat_sign(q):
+    """rotation.quat_normalize: the representative with w >= 0"""
+    return -q if q[0] < 0 else q.copy()
+
+
+def quat_difference(q, p):
+    return quat_sign(quat_mul(q, p * np.array([1.0, -1, -1, -1])))
+
+
+def quat_magnitude(q):
+    return 2 * np.arccos(np.clip(q[0], -1.0, 1.0))
+
+
+def normalize_angles(a):
+    return np.mod(np.asarray(a, dtype=np.float64) + np.pi, 2 * np.pi) - np.pi
+
+
+def round_to_straight_angles(a):
+    return normalize_angles(np.round(np.asarray(a, dtype=np.float64) / (np.pi / 2)) * (np.pi / 2))
+
+
+def any_orthogonal(v):
+    b = np.zeros(3)
+    b[int(np.argmin(np.abs(v)))] = 1.0
+    o = np.cross(v, b)
+    return o / np.linalg.norm(o)
+
+
+def vectors2quat(a, b):
+    q = np.concatenate([[np.sqrt(np.dot(a, a) * np.dot(b, b)) + np.dot(a, b)], np.cross(a, b)])
+    if np.linalg.norm(q) < 1e-6:   # opposite vectors: half a turn about anything orthogonal
+        q = np.concatenate([[0.0], any_orthogonal(a)])
+    return quat_sign(q / np.linalg.norm(q))
+
+
+def up_axis_with_sign(cube_quat):
+    m = quat2mat(cube_quat)
+    k = int(np.argmax(np.abs(m[2, :])))
+    return k, float(np.sign(m[2, k]))
+
+
+def distance_quat_from_being_up(cube_quat, axis_nr, sign):
+    return vectors2quat(quat2mat(cube_quat)[:, axis_nr] * sign, np.array([0.0, 0.0, 1.0]))
+
+
+def rot_xyz_aligned(cube_quat, threshold):
+    k, s = up_axis_with_sign(cube_quat)
+    return quat_magnitude(distance_quat_from_being_up(cube_quat, k, s)) < threshold
+
+
+def align_quat_up(cube_quat):
+    k, s = up_axis_with_sign(cube_quat)
+    return quat_sign(quat_mul(distance_quat_from_being_up(cube_quat, k, s), cube_quat))
+
+
+def z_quat(angle):
+    return quat_sign(np.array([np.cos(0.5 * angle), 0.0, 0.0, np.sin(0.5 * angle)]))
+
+
+class CubeModel:
+    """CubeManipulator: the joint tables of one 3x3x3 cube (`prefix` "cube:" or "target:") of a compiled model and the two
+    operations on a qpos vector."""
+
+    AXES = "xyz"
+
+    def __init__(self, model, prefix):
+        names, A = model.names["joint"], model.arrays
+        adr = lambda n: int(A["jnt_qposadr"][names.index(prefix + n)])
+        self.driver_q = np.array([adr("cubelet:driver:%s_%s" % (s, a)) for a in self.AXES for s in ("neg", "pos")])
+        coords, eq = [], []
+        for x in (-1, 0, 1):
+            for y in (-1, 0, 1):
+                for z in (-1, 0, 1):
+                    c = (x, y, z)
+                    if sum(abs(v) for v in c) < 2:
+                        continue
+                    nm = "_".join("%s_%s" % ("neg" if v < 0 else "pos", a) for a, v in zip(self.AXES, c) if v)
+                    coords.append(c)
+                    eq.append([adr("cubelet:rot%s:%s" % (a, nm)) for a in self.AXES])
+        self.coords, self.euler_q = np.array(coords, dtype=np.float64), np.array(eq)
+        self.all_q = np.array(sorted(adr(n[len(prefix):]) for n in names if n.startswith(prefix + "cubelet:")))
+
+    def matrices(self, qpos):
+        return np.array([euler2mat(qpos[q]) for q in self.euler_q])
+
+    def rotate_face(self, qpos, axis, side, angle, drivers=True):
+        angle = float(normalize_angles(angle))
+        if abs(angle) < 1e-4:
+            return
+        sgn = 2 * side - 1
+        e = np.zeros(3); e[axis] = angle
+        turn = euler2mat(e)
+        for c, q in zip(self.coords, self.euler_q):
+            m = euler2mat(qpos[q])
+            if (m @ c)[axis] * sgn > 0.5:
+                qpos[q] = mat2euler(turn @ m)
+        if drivers:
+            qpos[self.driver_q[2 * axis + side]] += angle
+
+    def soft_align_faces(self, qpos):
+        cur = qpos[self.driver_q]
+        diff = normalize_angles(round_to_straight_angles(cur) - cur)
+        for k in sorted(range(6), key=lambda i: (abs(diff[i]), i), reverse=True):
+            self.rotate_face(qpos, k // 2, k % 2, diff[k])
+        for q in self.euler_q:
+            qpos[q] = mat2euler(np.round(euler2mat(qpos[q])))
+
+
+# ------------------------------------------------------------------------------------------------ scramble (UNPINNED, see header)
+#: face letter -> (axis, side) of cube_manipulator.py:8-15; a clockwise quarter turn seen from outside is -90 degrees about the outward normal
+PYCUBER_FACES = {"L": (0, 0), "R": (0, 1), "F": (1, 0), "B": (1, 1), "D": (2, 0), "U": (2, 1)}
+PYCUBER_ACTIONS = ["L", "L'", "R", "R'", "F", "F'", "B", "B'", "D", "D'", "U", "U'"]
+
+
+def scramble_matrices(cm: CubeModel, actions):
+    """Orientation matrix of every cubelet after the face turns `actions` from the solved cube (what `from_pycuber` writes as
+    Euler angles; the drivers stay at zero, cube_manipulator.py:208-209)."""
+    mats = [np.eye(3, dtype=np.int64) for _ in cm.coords]
+    for a in actions:
+        axis, side = PYCUBER_FACES[a[0]]
+        sgn = 2 * side - 1
+        quarter = -sgn * (-1 if a.endswith("'") else 1)        # +1: +90 degrees about +axis
+        i, j = (axis + 1) % 3, (axis + 2) % 3
+        T = np.eye(3, dtype=np.int64); T[i, i] = T[j, j] = 0; T[j, i] = quarter; T[i, j] = -quarter
+        for k, c in enumerate(cm.coords):
+            if (mats[k] @ c.astype(np.int64))[axis] * sgn > 0:
+                mats[k] = T @ mats[k]
+    return mats
+
+
+# ------------------------------------------------------------------------------------------------ FaceFreeGoal
+class FaceFreeGoalOracle:
+    def __init__(self, model, face_up_quats, quat_threshold=0.4, face_threshold=0.2, p_face_flip=0.5, round_target_face=True, directions=("cw", "ccw")):
+        self.cube, self.target = CubeModel(model, "cube:"), CubeModel(model, "target:")
+        jn, A = model.names["joint"], model.arrays
+        j = jn.index("cube:cube:rot")
+        self.quat_q = np.arange(A["jnt_qposadr"][j], A["jnt_qposadr"][j] + 4)
+        self.face_up_quats = np.asarray(face_up_quats, dtype=np.float64)
+        self.quat_threshold, self.face_threshold, self.p_face_flip = quat_threshold, face_threshold, p_face_flip
+        self.round_target_face, self.directions = float(round_target_face), list(directions)
+
+    def current_state(self, qpos):
+        return {"cube_quat": qpos[self.quat_q].copy(), "cube_face_angle": qpos[self.cube.driver_q].copy()}
+
+    def next_goal(self, qpos, face_geom_z, draws):
+        """`draws` = [u_reorient, u_round, k_direction, k_face, u_z]: uniform(), uniform(), randint(len(directions)), randint(6),
+        uniform(-pi, pi) as the reference would draw them (only the ones of the branch taken are consumed there).  Writes the
+        target cube's joints in `qpos` and returns the goal dict."""
+        st = self.current_state(qpos)
+        quat, face = st["cube_quat"], st["cube_face_angle"]
+        qpos[self.target.all_q] = qpos[self.cube.all_q]                      # clone_target_from_cube
+        self.target.soft_align_faces(qpos)                                   # align_target_faces
+        rounded = round_to_straight_angles(face)
+        face_aligned = np.linalg.norm(normalize_angles(face - rounded)) < self.face_threshold
+        z_aligned = rot_xyz_aligned(quat, self.quat_threshold)
+        axis_nr, axis_sign = up_axis_with_sign(quat)
+        reorient = draws[0] < self.p_face_flip
+        rotate = bool(face_aligned and z_aligned and not reorient)
+        if rotate:
+            f = int(np.argmax(face_geom_z))
+            cw = (-1.0) ** f
+            dirs = [np.pi / 2 * {"cw": cw, "ccw": -cw}[d] for d in self.directions]
+            goal_face = face.copy()
+            if draws[1] < self.round_target_face:
+                delta = dirs[int(draws[2])]
+                goal_face[f] += delta
+                goal_face = round_to_straight_angles(normalize_angles(goal_face))
+            else:
+                lo, hi = min(dirs + [0.0]), max(dirs + [0.0])
+                delta = lo + (hi - lo) * draws[2]
+                goal_face[f] += delta
+                goal_face = normalize_angles(goal_face)
+            self.target.rotate_face(qpos, f // 2, f % 2, delta)
+            goal_quat = align_quat_up(quat)
+        else:
+            goal_face = rounded
+            goal_quat = quat_mul(z_quat(draws[4]), self.face_up_quats[int(draws[3])])
+        return {"cube_quat": quat_sign(goal_quat), "cube_face_angle": goal_face, "goal_type": "rotation" if rotate else "flip", "axis_nr": axis_nr, "axis_sign": axis_sign}
+
+    def relative_goal(self, goal, st):
+        if goal["goal_type"] == "rotation":
+            dq = distance_quat_from_being_up(st["cube_quat"], goal["axis_nr"], goal["axis_sign"])
+        else:
+            dq = quat_difference(goal["cube_quat"], st["cube_quat"])
+        return {"cube_quat": dq, "cube_face_angle": normalize_angles(goal["cube_face_angle"] - st["cube_face_angle"])}
+
+    def goal_distance(self, goal, st):
+        r = self.relative_goal(goal, st)
+        return {"cube_quat": quat_magnitude(r["cube_quat"]), "cube_face_angle": float(np.linalg.norm(r["cube_face_angle"]))}

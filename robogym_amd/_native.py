@@ -46,13 +46,30 @@ class PostArgs(ctypes.Structure):
     _fields_ = _post_fields()
 
 
+RB_POST_NDRAW, RB_GOAL_WORDS = 5, 16
+
+
+class RbPostArgs(ctypes.Structure):
+    """`rb_post_args` of include/rgstep.h (field order and types must match; bind() checks the size)."""
+
+    _fields_ = ([("obs", ctypes.c_void_p), ("obs_dim", ctypes.c_int)]
+                + [(n, ctypes.c_void_p) for n in ("t", "steps", "steps_since_last_goal", "successes_so_far", "goals_so_far", "consecutive", "prev_dist", "prev_valid",
+                                                  "is_successful", "goal", "reward", "goal_dist", "done", "goal_reset", "trial_success", "sub_goal_ok", "env_crash",
+                                                  "info_ssl", "force_new_goal", "draws")]
+                + [("seed", ctypes.c_uint), ("step", ctypes.c_uint), ("cube_tab", ctypes.c_void_p), ("face_up_quats", ctypes.c_void_p),
+                   ("face_geom", ctypes.c_int * 6), ("tip_site", ctypes.c_int * 5), ("ref_site", ctypes.c_int * 3), ("center_site", ctypes.c_int)]
+                + [(n, ctypes.c_int) for n in ("cube_pos_col", "cube_quat_col", "cube_block_col", "target_block_col", "hand_col", "n_hand")]
+                + [(n, ctypes.c_float) for n in ("quat_threshold", "face_threshold", "success_reward", "p_face_flip", "round_target_face")]
+                + [(n, ctypes.c_int) for n in ("directions", "max_timesteps_per_goal", "successes_needed", "use_goal_distance_reward", "stop_on_fall")])
+
+
 EXPORTS = [
     "rg_model_create", "rg_model_free", "rg_model_dims", "rg_batch_create", "rg_batch_free", "rg_batch_set_env",
     "rg_batch_copy", "rg_batch_reset", "rg_batch_step", "rg_obs_dim", "rg_debug_size", "rg_lds_bytes", "rg_sync",
     "rg_last_error", "rg_batch_mpr_pair", "rg_batch_copy_rows", "rg_batch_step_ex", "rg_batch_field_ptr", "rg_model_create_on", "rg_model_npair",
     "rg_lds_bytes_cfg", "rg_env_post_step", "rg_post_args_size", "rg_batch_enable_env_params", "rg_prm_layout", "rg_xdata_layout", "rg_batch_set_constants", "rg_batch_items_info",
     "rb_model_create", "rb_model_free", "rb_model_info", "rb_scratch_offset", "rb_batch_create", "rb_batch_free", "rb_batch_reset", "rb_batch_set_env",
-    "rb_batch_field_ptr", "rb_batch_step",
+    "rb_batch_field_ptr", "rb_batch_step", "rb_env_post_step", "rb_post_args_size", "rb_cube_ops",
 ]
 
 
@@ -115,6 +132,11 @@ def bind(path):
     L.rb_batch_field_ptr.restype = vp
     L.rb_batch_field_ptr.argtypes = [vp, ci, ctypes.POINTER(ci)]
     L.rb_batch_step.argtypes = [vp, vp, vp, ci, ci, ci, vp]
+    L.rb_env_post_step.argtypes = [vp, ctypes.POINTER(RbPostArgs), vp]
+    L.rb_post_args_size.restype = ci
+    if L.rb_post_args_size() != ctypes.sizeof(RbPostArgs):
+        raise NativeError("rb_post_args layout mismatch between include/rgstep.h and robogym_amd/_native.py")
+    L.rb_cube_ops.argtypes = [vp, ci, vp, vp, ci, vp, vp]
     L.rg_sync.argtypes = [vp]
     L.rg_last_error.restype = ctypes.c_char_p
     return L

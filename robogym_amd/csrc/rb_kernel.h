@@ -527,23 +527,25 @@ __device__ __forceinline__ void rb_velocity(RbM m, RbLds& s, float* S) {
 
 // ------------------------------------------------------------------------------------------------- actuation
 // mujoco-py's PID callback (mjpid.pyx semantics as restated by oracle ro_fwd_actuation); `apply`: also qfrc_actuator
-__device__ __forceinline__ void rb_pid(RbM m, RbLds& s, float* S, bool apply) {
+// one tick of one actuator's controller: st = {integral, previous error, smoothed derivative}; returns the clamped force
+template <class Model>
+__device__ __forceinline__ float rb_pid_tick(const Model& m, int u, float ctrl, float length, float* st) {
   const float dt = m.timestep;
-  BFOR(u, m.nu) {
-    const float* gp = m.actuator_gainprm + 10 * u;
-    const float kp = gp[0], ti = gp[1], iclamp = gp[2], td = gp[3], smooth = gp[4], deadband = gp[5];
-    float err = s.ctrl[u] - s.actlen[u];
-    if (fabsf(err) < deadband) err = 0.f;
-    float* st = s.pid + 3 * u;
-    const float integ = clampf(st[0] + err * dt, -iclamp, iclamp);
-    const float deriv = (1.f - smooth) * st[2] + smooth * (err - st[1]) / dt;
-    float force = kp * (err + (ti != 0.f ? integ / ti : 0.f) + td * deriv);
-    st[0] = integ; st[1] = err; st[2] = deriv;
-    const float lo = m.actuator_forcerange[2 * u], hi = m.actuator_forcerange[2 * u + 1];
-    if (lo != 0.f || hi != 0.f) force = clampf(force, lo, hi);
-    if (m.actuator_forcelimited[u]) force = clampf(force, lo, hi);
-    s.actfrc[u] = force;
-  }
+  const float* gp = m.actuator_gainprm + 10 * u;
+  const float kp = gp[0], ti = gp[1], iclamp = gp[2], td = gp[3], smooth = gp[4], deadband = gp[5];
+  float err = ctrl - length;
+  if (fabsf(err) < deadband) err = 0.f;
+  const float integ = clampf(st[0] + err * dt, -iclamp, iclamp);
+  const float deriv = (1.f - smooth) * st[2] + smooth * (err - st[1]) / dt;
+  float force = kp * (err + (ti != 0.f ? integ / ti : 0.f) + td * deriv);
+  st[0] = integ; st[1] = err; st[2] = deriv;
+  const float lo = m.actuator_forcerange[2 * u], hi = m.actuator_forcerange[2 * u + 1];
+  if (lo != 0.f || hi != 0.f) force = clampf(force, lo, hi);
+  if (m.actuator_forcelimited[u]) force = clampf(force, lo, hi);
+  return force;
+}
+__device__ __forceinline__ void rb_pid(RbM m, RbLds& s, float* S, bool apply) {
+  BFOR(u, m.nu) s.actfrc[u] = rb_pid_tick(m, u, s.ctrl[u], s.actlen[u], s.pid + 3 * u);
   BSYNC();
   if (!apply) return;
   BFOR(i, m.nv) {

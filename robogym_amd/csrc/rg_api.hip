@@ -6,6 +6,7 @@
 // bounds the envs in flight per CU, so the hot path runs with capacities sized for rollouts and the reset recipe
 // (2-3 x more contacts) with larger ones
 typedef rg_post_args RgPostArgs;
+typedef rb_post_args RbPostArgs;
 #define RG_NS rgs
 #define RG_MAXCON 24
 #define RG_CPOOL 768
@@ -83,6 +84,7 @@ static const char* hipGetErrorString(hipError_t) { return "emul"; }
 
 #include "rg_env_kernel.h"
 #include "rb_kernel.h"
+#include "rb_env_kernel.h"
 #define RG_WAVES_PER_SIMD_HOST 3   /* = RG_WAVES_PER_SIMD of rg_kernel.h (its default) */
 struct rg_batch;
 extern "C" { static void rg_items_probe(rg_batch* b); }
@@ -1029,6 +1031,54 @@ int rb_batch_step(rb_batch* b, const float* action_dev, const int* active_dev, i
   emul_launch_n(bt.B, RB_T, sizeof(rgb::RbLds), emul_rb_entry, &args);
 #else
   hipLaunchKernelGGL(rgb::rb_step_kernel, dim3(bt.B), dim3(RB_T), sizeof(rgb::RbLds), (hipStream_t)stream, b->model->dev_copy, launch);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+
+#ifdef RG_EMUL
+struct EmulRbPostArgs { const RbModelDev* m; RbBatchDev bt; RbPostArgs a; };
+static void emul_rb_post_entry(void* p_) { EmulRbPostArgs* p = (EmulRbPostArgs*)p_; rgb::rb_post_step_kernel(p->m, p->bt, p->a); }
+struct EmulRbCubeArgs { RbBatchDev bt; int nq, col; const int* tab; const float* ops; int nops; };
+static void emul_rb_cube_entry(void* p_) { EmulRbCubeArgs* p = (EmulRbCubeArgs*)p_; rgb::rb_cube_ops_kernel(p->bt, p->nq, p->col, p->tab, p->ops, p->nops); }
+#endif
+int rb_post_args_size(void) { return (int)sizeof(rb_post_args); }
+int rb_env_post_step(rb_batch* b, const rb_post_args* args, void* stream) {
+  if (!b || !args) return fail("null argument");
+  const rb_post_args& a = *args;
+  const RbModelDev& d = b->model->dev;
+  if (!a.obs || !a.t || !a.steps || !a.steps_since_last_goal || !a.successes_so_far || !a.goals_so_far || !a.consecutive || !a.prev_dist || !a.prev_valid ||
+      !a.is_successful || !a.goal || !a.reward || !a.goal_dist || !a.done || !a.goal_reset || !a.trial_success || !a.sub_goal_ok || !a.env_crash || !a.info_ssl ||
+      !a.cube_tab || !a.face_up_quats) return fail("rb_env_post_step: a required array is NULL");
+  if (a.obs_dim != 13 + a.n_hand + 15 + 13) return fail("rb_env_post_step: obs_dim does not match the row layout");
+  if (d.nu > 64) return fail("rb_env_post_step: nu exceeds the workgroup");
+  for (int k = 0; k < 6; k++) if (a.face_geom[k] < 0 || a.face_geom[k] >= d.ngeom) return fail("rb_env_post_step: face geom id out of range");
+  for (int k = 0; k < 5; k++) if (a.tip_site[k] < 0 || a.tip_site[k] >= d.nsite) return fail("rb_env_post_step: site id out of range");
+  for (int k = 0; k < 3; k++) if (a.ref_site[k] < 0 || a.ref_site[k] >= d.nsite) return fail("rb_env_post_step: site id out of range");
+  if (a.center_site < 0 || a.center_site >= d.nsite) return fail("rb_env_post_step: site id out of range");
+  if (a.cube_block_col < 0 || a.cube_block_col + 66 > d.nq || a.target_block_col < 0 || a.target_block_col + 66 > d.nq || a.cube_quat_col < 0 || a.cube_quat_col + 4 > d.nq ||
+      a.cube_pos_col < 0 || a.cube_pos_col + 3 > d.nq || a.hand_col < 0 || a.hand_col + a.n_hand > d.nq) return fail("rb_env_post_step: qpos column out of range");
+  DeviceGuard g(b->device);
+#ifdef RG_EMUL
+  EmulRbPostArgs ea{b->model->dev_copy, b->dev, a};
+  emul_launch(b->dev.B, 1024, emul_rb_post_entry, &ea);
+#else
+  hipLaunchKernelGGL(rgb::rb_post_step_kernel, dim3(b->dev.B), dim3(64), 0, (hipStream_t)stream, b->model->dev_copy, b->dev, a);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+int rb_cube_ops(rb_batch* b, int block_col, const int* cube_tab_dev, const float* ops_dev, int nops, const int* active_dev, void* stream) {
+  if (!b || !cube_tab_dev || !ops_dev || nops < 0) return fail("rb_cube_ops: bad argument");
+  const RbModelDev& d = b->model->dev;
+  if (block_col < 0 || block_col + 66 > d.nq) return fail("rb_cube_ops: block column out of range");
+  DeviceGuard g(b->device);
+  RbBatchDev bt = b->dev; bt.active = active_dev;
+#ifdef RG_EMUL
+  EmulRbCubeArgs ea{bt, d.nq, block_col, cube_tab_dev, ops_dev, nops};
+  emul_launch(bt.B, 1024, emul_rb_cube_entry, &ea);
+#else
+  hipLaunchKernelGGL(rgb::rb_cube_ops_kernel, dim3(bt.B), dim3(64), 0, (hipStream_t)stream, bt, d.nq, block_col, cube_tab_dev, ops_dev, nops);
   HIPCHK(hipGetLastError());
 #endif
   return 0;

@@ -1,0 +1,334 @@
+"""The env layer of dactyl/full_perpendicular (BASELINE.json configs[2]): FaceFreeGoal, the CubeManipulator operations on the two
+cubes, reward / success / tracker and the observation row (robogym_amd/csrc/rb_env_kernel.h, robogym_amd/envs/dactyl/full_perpendicular.py).
+
+Chain of evidence:
+  reference classes (CubeManipulator, FaceFreeGoal, cube_utils; imported with pycuber stubbed)  ->  tests/golden/full_cube.npz (tools/gen_golden_cube.py)
+  golden  ->  oracle/cube_oracle.py (double, exact)                               [test_cube_oracle_matches_reference_*]
+  golden + oracle  ->  the HIP kernels, on the emulation harness (CPU) and on the MI355X (`-m gpu`), fp32 tolerances stated per test.
+Euler triples are compared as rotation matrices (a triple is not unique at gimbal lock, which quarter turns about y produce all the time).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cube_oracle as co
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_cube.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+@pytest.fixture(scope="module")
+def full_model():
+    from robogym_amd.envs.dactyl.full_perpendicular import load_full_perpendicular_model
+    from robogym_amd.mujoco import setconst
+    from robogym_amd.mujoco.big_tables import derive_big_tables
+
+    m = load_full_perpendicular_model()
+    setconst.set_constants(m)
+    derive_big_tables(m)
+    return m
+
+
+def _same_quat(a, b, tol):
+    return min(np.abs(a - b).max(), np.abs(a + b).max()) < tol
+
+
+# ------------------------------------------------------------------------------------------------ oracle vs the reference's own classes
+def test_cube_oracle_matches_reference_cube_manipulator(gold, full_model):
+    cm = co.CubeModel(full_model, "cube:")
+    for q0, ops, q1 in zip(gold["rf_qpos0"], gold["rf_ops"], gold["rf_qpos1"]):
+        q = q0.copy()
+        for axis, side, ang in ops:
+            cm.rotate_face(q, int(axis), int(side), ang)
+        np.testing.assert_allclose(q, q1, atol=1e-12)
+    for q0, q1 in zip(gold["sa_qpos0"], gold["sa_qpos1"]):
+        q = q0.copy()
+        cm.soft_align_faces(q)
+        np.testing.assert_allclose(q, q1, atol=1e-12)
+
+
+def test_cube_oracle_matches_reference_face_free_goal(gold, full_model):
+    gg = co.FaceFreeGoalOracle(full_model, gold["ng_face_up_quats"])
+    kinds = set()
+    for i in range(len(gold["ng_qpos0"])):
+        q = gold["ng_qpos0"][i].copy()
+        g = gg.next_goal(q, gold["ng_geom_z"][i], gold["ng_draws"][i])
+        kinds.add(g["goal_type"])
+        assert (g["goal_type"] == "rotation") == bool(gold["ng_goal_type"][i])
+        assert g["axis_nr"] == gold["ng_axis_nr"][i] and g["axis_sign"] == gold["ng_axis_sign"][i][0]
+        np.testing.assert_allclose(q, gold["ng_qpos1"][i], atol=1e-12)                      # the target cube's joints
+        assert _same_quat(g["cube_quat"], gold["ng_goal_quat"][i], 1e-12)
+        np.testing.assert_allclose(g["cube_face_angle"], gold["ng_goal_face"][i], atol=1e-12)
+        g["cube_quat"], g["cube_face_angle"] = gold["ng_goal_quat"][i], gold["ng_goal_face"][i]
+        st = {"cube_quat": gold["ng_probe_quat"][i], "cube_face_angle": gold["ng_probe_face"][i]}
+        r, d = gg.relative_goal(g, st), gg.goal_distance(g, st)
+        assert _same_quat(r["cube_quat"], gold["ng_rel_quat"][i], 1e-12)
+        np.testing.assert_allclose(r["cube_face_angle"], gold["ng_rel_face"][i], atol=1e-12)
+        np.testing.assert_allclose([d["cube_quat"], d["cube_face_angle"]], gold["ng_dist"][i], atol=1e-12)
+    assert kinds == {"rotation", "flip"}
+
+
+# ------------------------------------------------------------------------------------------------ host tables
+def test_scramble_matches_oracle_turns_and_is_a_valid_cube(full_model):
+    from robogym_amd.envs.dactyl.full_perpendicular import PYCUBER_ACTIONS, cube_tables, scramble_euler
+
+    col, tab = cube_tables(full_model, "cube:")
+    cm = co.CubeModel(full_model, "cube:")
+    assert col == cm.driver_q[0] and np.array_equal(tab[:, :3] + col, cm.euler_q) and np.array_equal(tab[:, 3:], cm.coords)
+    rng = np.random.RandomState(5)
+    acts = rng.randint(12, size=(6, 50))
+    eul = scramble_euler(tab, acts)
+    for b in range(6):
+        mats = co.scramble_matrices(cm, [PYCUBER_ACTIONS[k] for k in acts[b]])
+        where = set()
+        for k in range(20):
+            m = co.euler2mat(eul[b, tab[k, :3] - 6])
+            np.testing.assert_allclose(m, mats[k], atol=1e-12)
+            where.add(tuple(np.round(m @ tab[k, 3:]).astype(int)))
+        assert len(where) == 20                                          # every cubelet in its own place
+    # one face turn moves exactly the 8 edge / corner cubelets of that face, four quarter turns are the identity
+    one = scramble_euler(tab, np.array([[PYCUBER_ACTIONS.index("U")]]))
+    assert sum(np.abs(one[0, tab[k, :3] - 6]).max() > 0 for k in range(20)) == 8
+    np.testing.assert_allclose(scramble_euler(tab, np.array([[10, 10, 10, 10]])), 0, atol=1e-12)
+    # U then U' is the identity; U is -90 degrees about +z: the cubelet at (+x, +y, +z) goes to (+x, -y, +z)
+    np.testing.assert_allclose(scramble_euler(tab, np.array([[10, 11]])), 0, atol=1e-12)
+    k = [i for i in range(20) if tuple(tab[i, 3:]) == (1, 1, 1)][0]
+    np.testing.assert_allclose(co.euler2mat(one[0, tab[k, :3] - 6]) @ np.array([1.0, 1, 1]), [1, -1, 1], atol=1e-12)
+
+
+def test_face_up_quats_lift_their_face(full_model):
+    """cube_utils.face_up_quats: with the cube's ball joint at table[i], face geom i is the highest of the six (oracle kinematics)."""
+    from oracle.rg_oracle import OracleSim
+    from robogym_amd.envs.dactyl.full_perpendicular import FACE_GEOM_NAMES, face_up_quats
+    from robogym_amd.mujoco.model_blob import pack_model
+    from robogym_amd.utils.rotation import parallel_quats_np
+
+    table = face_up_quats(full_model, parallel_quats_np())
+    sim = OracleSim(pack_model(full_model))
+    jn = full_model.names["joint"]
+    qa = int(full_model.arrays["jnt_qposadr"][jn.index("cube:cube:rot")])
+    gids = [full_model.names["geom"].index(n) for n in FACE_GEOM_NAMES]
+    for i in range(6):
+        sim.qpos[qa:qa + 4] = table[i]
+        sim.fwd_position()
+        z = sim.geom_xpos.reshape(-1, 3)[gids, 2]
+        assert np.argmax(z) == i and z[i] - np.sort(z)[-2] > 0.01
+
+
+# ------------------------------------------------------------------------------------------------ kernels: emulation harness (CPU) and MI355X
+def _make_env(full_model, B, lib):
+    from robogym_amd.envs.dactyl.full_perpendicular import BatchedFullPerpendicularEnv
+
+    return BatchedFullPerpendicularEnv(B, model=full_model, lib=lib) if lib is not None else BatchedFullPerpendicularEnv(B, model=full_model, device="cuda:0")
+
+
+def _mats(cm, q):
+    return np.array([co.euler2mat(q[e]) for e in cm.euler_q])
+
+
+def _check_cube_ops(full_model, gold, lib):
+    cm = co.CubeModel(full_model, "cube:")
+    n = len(gold["rf_qpos0"])
+    env = _make_env(full_model, n, lib)
+    sim = env.sim
+    # rotate_face sequences
+    sim.qpos[:] = torch.as_tensor(gold["rf_qpos0"], dtype=torch.float32, device=sim.device)
+    ops = np.concatenate([gold["rf_ops"], np.zeros(gold["rf_ops"].shape[:2] + (1,))], axis=2)
+    sim.cube_ops("cube", torch.as_tensor(ops, dtype=torch.float32))
+    sim.sync()
+    got = sim.qpos.cpu().numpy().astype(np.float64)
+    for b in range(n):
+        np.testing.assert_allclose(_mats(cm, got[b]), _mats(cm, gold["rf_qpos1"][b]), atol=3e-6)
+        np.testing.assert_allclose(got[b][cm.driver_q], gold["rf_qpos1"][b][cm.driver_q], atol=3e-6)
+        other = np.setdiff1d(np.arange(got.shape[1]), cm.all_q)
+        np.testing.assert_array_equal(got[b][other], gold["rf_qpos0"][b][other].astype(np.float32))
+    # soft_align_faces; the mask leaves the other envs alone
+    sim.qpos[:] = torch.as_tensor(gold["sa_qpos0"], dtype=torch.float32, device=sim.device)
+    active = torch.ones(n, dtype=torch.int32, device=sim.device); active[3] = 0
+    ops = torch.zeros((n, 1, 4)); ops[:, 0, 3] = 2
+    sim.cube_ops("cube", ops, active)
+    sim.sync()
+    got = sim.qpos.cpu().numpy().astype(np.float64)
+    for b in range(n):
+        want = gold["sa_qpos0"][b] if b == 3 else gold["sa_qpos1"][b]
+        np.testing.assert_allclose(_mats(cm, got[b]), _mats(cm, want), atol=3e-6)
+        np.testing.assert_allclose(got[b][cm.driver_q], want[cm.driver_q], atol=3e-6)
+        if b != 3:
+            assert np.abs(_mats(cm, got[b]) - np.round(_mats(cm, got[b]))).max() < 1e-6     # aligned means: signed permutation matrices
+
+
+def _check_next_goal_and_distances(full_model, gold, lib):
+    n = len(gold["ng_qpos0"])
+    env = _make_env(full_model, n, lib)
+    sim = env.sim
+    cm_t = co.CubeModel(full_model, "target:")
+    env._face_up_quats.copy_(torch.as_tensor(gold["ng_face_up_quats"], dtype=torch.float32))
+    sim.qpos[:] = torch.as_tensor(gold["ng_qpos0"], dtype=torch.float32, device=sim.device)
+    sim.ctrl[:] = 0.1                                                              # (a control error, so that the controllers have something to integrate)
+    sim.forward()                                                                  # fills the scratch row (site / geom frames, tendon lengths)
+    gz = sim.scratch("geom_xpos")
+    for k, g in enumerate(sim.face_geoms):                                         # the goldens' face heights are synthetic numbers: plant them
+        gz[:, 3 * g + 2] = torch.as_tensor(gold["ng_geom_z"][:, k], dtype=torch.float32, device=sim.device)
+    env.set_draws(gold["ng_draws"])
+    pid0 = sim.pid.clone()
+    env._post(force=torch.ones(n, dtype=torch.int32, device=sim.device))
+    sim.sync()
+    goal = env._goal.cpu().numpy().astype(np.float64)
+    got = sim.qpos.cpu().numpy().astype(np.float64)
+    tr = env.multi_goal_tracker
+    assert (tr.goals_so_far.cpu().numpy() == 1).all() and (tr.steps_since_last_goal.cpu().numpy() == 0).all()
+    assert not torch.equal(sim.pid, pid0)                                          # the two re-observation forwards ticked the controllers
+    gg = co.FaceFreeGoalOracle(full_model, gold["ng_face_up_quats"])
+    for b in range(n):
+        assert bool(goal[b, 10]) == bool(gold["ng_goal_type"][b]), b
+        assert int(goal[b, 11]) == gold["ng_axis_nr"][b] and goal[b, 12] == gold["ng_axis_sign"][b][0]
+        assert _same_quat(goal[b, :4], gold["ng_goal_quat"][b], 2e-6), (b, goal[b, :4], gold["ng_goal_quat"][b])
+        np.testing.assert_allclose(np.cos(goal[b, 4:10]), np.cos(gold["ng_goal_face"][b]), atol=2e-6)      # (-pi and pi are the same face angle)
+        np.testing.assert_allclose(np.sin(goal[b, 4:10]), np.sin(gold["ng_goal_face"][b]), atol=2e-6)
+        np.testing.assert_allclose(_mats(cm_t, got[b]), _mats(cm_t, gold["ng_qpos1"][b]), atol=3e-6)
+        np.testing.assert_allclose(np.cos(got[b][cm_t.driver_q]), np.cos(gold["ng_qpos1"][b][cm_t.driver_q]), atol=3e-6)
+        np.testing.assert_allclose(np.sin(got[b][cm_t.driver_q]), np.sin(gold["ng_qpos1"][b][cm_t.driver_q]), atol=3e-6)
+        # prev_dist = distance of the current state to the new goal (re-observation)
+        st = gg.current_state(gold["ng_qpos0"][b])
+        g = {"cube_quat": gold["ng_goal_quat"][b], "cube_face_angle": gold["ng_goal_face"][b], "goal_type": "rotation" if gold["ng_goal_type"][b] else "flip",
+             "axis_nr": int(gold["ng_axis_nr"][b]), "axis_sign": float(gold["ng_axis_sign"][b][0])}
+        d = gg.goal_distance(g, st)
+        np.testing.assert_allclose(env._prev_dist[b].cpu().numpy(), [d["cube_quat"], d["cube_face_angle"]], atol=5e-6)
+    # ---- distances / reward / success of a step: the probe states against the goldens' goals
+    q = gold["ng_qpos0"].copy()
+    cq = np.arange(4) + int(sim.qpos_idxs["cube_rotation"][0])
+    q[:, cq] = gold["ng_probe_quat"]; q[:, co.CubeModel(full_model, "cube:").driver_q] = gold["ng_probe_face"]
+    sim.qpos[:] = torch.as_tensor(q, dtype=torch.float32, device=sim.device)
+    grow = np.zeros((n, 16)); grow[:, :4] = gold["ng_goal_quat"]; grow[:, 4:10] = gold["ng_goal_face"]; grow[:, 10] = gold["ng_goal_type"]
+    grow[:, 11] = gold["ng_axis_nr"]; grow[:, 12] = gold["ng_axis_sign"][:, 0]
+    env._goal.copy_(torch.as_tensor(grow, dtype=torch.float32))
+    prev = env._prev_dist.cpu().numpy().copy()
+    env.set_draws(np.zeros((n, 5)))
+    env._post()
+    sim.sync()
+    dist = env._goal_dist.cpu().numpy()
+    np.testing.assert_allclose(dist[:, 0], gold["ng_dist"][:, 0], atol=5e-6)
+    np.testing.assert_allclose(dist[:, 1], gold["ng_dist"][:, 1], atol=2e-5)
+    rew = env._reward.cpu().numpy()
+    np.testing.assert_allclose(rew[:, 1], (prev - dist).sum(1), atol=1e-6)
+    succ = (gold["ng_dist"][:, 0] < 0.4) & (gold["ng_dist"][:, 1] < 0.2)
+    margin = np.minimum(np.abs(gold["ng_dist"][:, 0] - 0.4), np.abs(gold["ng_dist"][:, 1] - 0.2)) > 1e-3
+    got_succ = env._flags["sub_goal_ok"].cpu().numpy()
+    assert (got_succ == succ)[margin].all() and succ.any() and not succ.all()
+    np.testing.assert_array_equal(rew[:, 2], np.where(got_succ, 5.0, 0.0).astype(np.float32))
+    assert (env._flags["goal_reset"].cpu().numpy() == got_succ).all()             # one success -> a new goal (successes_needed 50 is far)
+    # observation row
+    obs = env.observe()
+    np.testing.assert_allclose(obs["cube_quat"].cpu().numpy(), np.where(q[:, cq][:, :1] < 0, -q[:, cq], q[:, cq]), atol=1e-6)
+    face = obs["cube_face_angle"].cpu().numpy()
+    np.testing.assert_allclose(np.sin(face), np.sin(gold["ng_probe_face"]), atol=2e-6)
+    assert (face >= -np.pi - 1e-6).all() and (face <= np.pi + 1e-6).all()
+    assert obs["qpos"].shape == (n, 170) and obs["fingertip_pos"].shape == (n, 15) and obs["goal_face_angle"].shape == (n, 6)
+    keep = ~got_succ
+    np.testing.assert_allclose(obs["goal_quat"].cpu().numpy()[keep], grow[keep, :4], atol=1e-6)
+
+
+def test_cube_ops_kernel_matches_reference_emul(full_model, gold, emul_lib):
+    _check_cube_ops(full_model, gold, emul_lib)
+
+
+def test_goal_kernel_matches_reference_emul(full_model, gold, emul_lib):
+    _check_next_goal_and_distances(full_model, gold, emul_lib)
+
+
+@pytest.mark.gpu
+def test_cube_ops_kernel_matches_reference_gpu(full_model, gold):
+    _check_cube_ops(full_model, gold, None)
+
+
+@pytest.mark.gpu
+def test_goal_kernel_matches_reference_gpu(full_model, gold):
+    _check_next_goal_and_distances(full_model, gold, None)
+
+
+@pytest.mark.gpu
+def test_full_cube_env_reset_and_steps_match_oracle_gpu(full_model):
+    """`reset()` (the recipe with scramble and face-angle randomisation, free-running for 30 env.steps) and then env.steps with the
+    oracle's state copied in before each (resync protocol of tests/test_large_model.py), same draws on both sides."""
+    from oracle.env_oracle import OracleFullPerpendicularEnv
+
+    B = 3
+    env = _make_env(full_model, B, None)
+    sim = env.sim
+    rng = np.random.RandomState(11)
+    d = {"wiggle": rng.randn(B, 3), "quat": rng.randn(B, 4), "scramble": rng.randint(12, size=(B, 50)), "face_k": rng.randint(-2, 3, size=(B, 6)).astype(np.float64),
+         "face_angle": rng.uniform(-np.pi / 4, np.pi / 4, size=(B, 2)), "face_axis": rng.randint(3, size=B).astype(np.float64), "action": rng.uniform(-1, 1, size=(B, 20))}
+    gd = np.stack([rng.uniform(0, 1, B), rng.uniform(0, 1, B), rng.randint(2, size=B), rng.randint(6, size=B), rng.uniform(-np.pi, np.pi, B)], axis=1)
+    env.set_reset_draws(d)
+    env.set_draws(gd)
+    env.reset()
+    sim.sync()
+    assert int(sim.status.max().item()) == 0
+    oras = [OracleFullPerpendicularEnv(full_model, env.face_up_quats_np) for _ in range(B)]
+    cm = co.CubeModel(full_model, "cube:")
+    got = sim.qpos.cpu().numpy().astype(np.float64)
+    worst = np.zeros(3)
+    for b, o in enumerate(oras):
+        on_palm = o.reset_recipe(d["wiggle"][b], d["quat"][b], d["scramble"][b], d["face_k"][b], d["face_angle"][b], d["face_axis"][b], d["action"][b])
+        q = o.sim.qpos
+        # 30 env.steps free-running in fp32 vs fp64 with ~30 contacts: the cubes agree to millimetres / hundredths of a radian, the discrete
+        # outcome (which cubelet sits where) exactly
+        worst = np.maximum(worst, [np.abs(got[b][o.pos_q] - q[o.pos_q]).max(), np.abs(got[b][o.hand_q] - q[o.hand_q]).max(), np.abs(_mats(cm, got[b]) - _mats(cm, q)).max()])
+        assert np.array_equal(np.round(_mats(cm, got[b]) @ cm.coords[:, :, None])[..., 0], np.round(_mats(cm, q) @ cm.coords[:, :, None])[..., 0])
+        assert bool(sim.scratch("site_xpos")[b, 3 * sim.center_site + 2] > 0.04) == bool(on_palm)
+    print("reset recipe, device vs oracle after 30 free-running env.steps: cube pos %.2e m, hand joints %.2e rad, cubelet matrices %.2e" % tuple(worst))
+    assert worst[0] < 1e-2 and worst[1] < 5e-2 and worst[2] < 1e-1
+    # ---- first goal + steps, resynchronised
+    def put(b, o):
+        s = o.sim
+        for name, view in (("qpos", sim.qpos), ("qvel", sim.qvel), ("pid", sim.pid), ("qacc_warmstart", sim.qacc_warmstart), ("ctrl", sim.ctrl)):
+            a = getattr(s, name).astype(np.float32)
+            getattr(s, name)[:] = a
+            view[b] = torch.as_tensor(a, device=sim.device)
+    for b, o in enumerate(oras):
+        put(b, o)
+        o.sim.forward()
+    sim.forward()
+    for b, o in enumerate(oras):                                    # (the forward above ticked the controllers on both sides: same state again)
+        put(b, o)
+    env.multi_goal_tracker.reset(torch.ones(B, dtype=torch.bool, device=sim.device))
+    env._post(force=torch.ones(B, dtype=torch.int32, device=sim.device))
+    sim.sync()
+    for b, o in enumerate(oras):
+        o.start_episode(gd[b])
+        g = env._goal[b].cpu().numpy().astype(np.float64)
+        assert bool(g[10]) == (o.goal["goal_type"] == "rotation") and int(g[11]) == o.goal["axis_nr"]
+        assert _same_quat(g[:4], o.goal["cube_quat"], 1e-5)
+        np.testing.assert_allclose(np.sin(g[4:10]), np.sin(o.goal["cube_face_angle"]), atol=1e-5)
+        np.testing.assert_allclose(env._prev_dist[b].cpu().numpy(), [o.prev["cube_quat"], o.prev["cube_face_angle"]], atol=2e-5)
+        np.testing.assert_allclose(sim.pid[b].cpu().numpy(), o.sim.pid, atol=1e-4, rtol=1e-4)
+    err = {k: [] for k in ("reward", "dist", "cube_pos", "hand", "tips", "face")}
+    for step in range(6):
+        for b, o in enumerate(oras):
+            put(b, o)
+            env._prev_dist[b] = torch.as_tensor([o.prev["cube_quat"], o.prev["cube_face_angle"]], dtype=torch.float32)
+        act = rng.uniform(-1, 1, size=(B, 20))
+        obs, rew, done, info = env.step(torch.as_tensor(act, dtype=torch.float32))
+        sim.sync()
+        for b, o in enumerate(oras):
+            r, dn, inf = o.step(act[b], gd[b])
+            oo = o.obs()
+            err["reward"].append(abs(rew[b, 1].item() - r[1]))
+            err["dist"].append(max(abs(info["goal_dist"]["cube_quat"][b].item() - inf["goal_dist"]["cube_quat"]), abs(info["goal_dist"]["cube_face_angle"][b].item() - inf["goal_dist"]["cube_face_angle"])))
+            err["cube_pos"].append(np.abs(obs["cube_pos"][b].cpu().numpy() - oo["cube_pos"]).max())
+            err["hand"].append(np.abs(obs["hand_angle"][b].cpu().numpy() - oo["hand_angle"]).max())
+            err["tips"].append(np.abs(obs["fingertip_pos"][b].cpu().numpy() - oo["fingertip_pos"]).max())
+            err["face"].append(np.abs(np.sin(obs["cube_face_angle"][b].cpu().numpy()) - np.sin(oo["cube_face_angle"])).max())
+            assert bool(done[b]) == dn and rew[b, 2].item() == r[2]
+            assert _same_quat(obs["goal_quat"][b].cpu().numpy().astype(np.float64), oo["goal_quat"], 1e-5)
+    rep = {k: (float(np.median(v)), float(np.max(v))) for k, v in err.items()}
+    print("full-cube env.step vs oracle (resync), median / max:", {k: "%.1e / %.1e" % v for k, v in rep.items()})
+    # one env.step of the full cube in fp32 vs fp64 (tests/test_large_model.py: state error median ~5e-4 with the cubelet contacts deciding)
+    assert rep["hand"][1] < 2e-3 and rep["tips"][1] < 1e-3 and rep["cube_pos"][1] < 2e-3
+    assert rep["dist"][0] < 2e-3 and rep["dist"][1] < 3e-2 and rep["reward"][0] < 3e-3 and rep["reward"][1] < 5e-2
