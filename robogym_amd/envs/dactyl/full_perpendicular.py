@@ -290,6 +290,7 @@ class BatchedFullPerpendicularEnv:
         self._reset_draws = None
         self._step_count = 0
         self._needs_reset = True
+        self._trace = None            # test hook: a list that receives qpos after the recipe's settling steps and after its state writes
         self._physics_events = None   # bench hook: a (start, end) pair of torch.cuda.Event recorded around the physics launch of `step`
         self.seed(starting_seed)
         self.action_space = {"low": -1.0, "high": 1.0, "shape": (self.num_actions,), "dtype": "float32"}
@@ -344,6 +345,8 @@ class BatchedFullPerpendicularEnv:
             sim.ctrl.copy_(torch.where(need[:, None], denorm(torch.zeros((B, self.num_actions), device=self.device)), sim.ctrl))
             for _ in range(c.reset_initial_steps):
                 sim.env_step(active=active, nforward_ticks=1)
+            if self._trace is not None:
+                self._trace.append(sim.qpos.clone())
             d = self._draw_reset()
             sim.set_qpos("cube_position", sim.get_qpos("cube_position") + d["wiggle"] * c.cube_position_wiggle_std, need)
             q = d["quat"] / d["quat"].norm(dim=-1, keepdim=True)                      # rotation.uniform_quat: normalised, w >= 0
@@ -357,6 +360,8 @@ class BatchedFullPerpendicularEnv:
                 ops = torch.zeros((B, 2, 4), dtype=torch.float32, device=self.device)
                 ops[:, :, 0] = d["face_axis"][:, None]; ops[:, 1, 1] = 1; ops[:, :, 2] = d["face_angle"]
                 sim.cube_ops("cube", ops, active)
+            if self._trace is not None:
+                self._trace.append(sim.qpos.clone())
             sim.forward(active=active)
             sim.ctrl.copy_(torch.where(need[:, None], denorm(d["action"]), sim.ctrl))
             for _ in range(c.n_random_initial_steps):
