@@ -43,6 +43,7 @@ struct RbLds {
   alignas(16) float A[RB_MAXGROUP * (RB_MAXGROUP + 1)];   // the dense block of the moment, row stride n + 1 (odd: a column walk touches every LDS bank)
   float Dinv[RB_MAXGROUP * 8];   // inverses of the 8 x 8 diagonal blocks of the factor
   float prow[8];
+  float yb[2 * 8];   // rb_chol_solve: the current block's solution, double-buffered
   float sc[RB_MAXGROUP];
   float qpos[RB_MAXNQ], qvel[RB_MAXNV], warm[RB_MAXNV], ctrl[32], pid[96], actlen[32], actfrc[32];
   float qfrc_passive[RB_MAXNV], qfrc_bias[RB_MAXNV], qfrc_act[RB_MAXNV], qfrc_smooth[RB_MAXNV], qacc_smooth[RB_MAXNV];
@@ -387,7 +388,7 @@ __device__ __forceinline__ bool rb_chol(RbLds& s, int n) {
       for (int half = 0; half < 2; half++) {
         float li[NT][RB_NB / 2], lj[NT][RB_NB / 2];
 #pragma unroll
-        for (int q = 0; q < NT; q++) {
+        for (int q = 0; q < NT; q++) if (t0 + 16 * q < n) {   // (uniform: tile rows / columns beyond the block hold nothing)
           const int ii = t0 + ty + 16 * q, jj = t0 + tx + 16 * q;
 #pragma unroll
           for (int c = 0; c < RB_NB / 2; c++) {
@@ -396,17 +397,17 @@ __device__ __forceinline__ bool rb_chol(RbLds& s, int n) {
           }
         }
 #pragma unroll
-        for (int qa = 0; qa < NT; qa++)
+        for (int qa = 0; qa < NT; qa++) if (t0 + 16 * qa < n)
 #pragma unroll
-          for (int qb = 0; qb < NT; qb++)
+          for (int qb = 0; qb < NT; qb++) if (qb <= qa)       // lower triangle of tiles only
 #pragma unroll
             for (int c = 0; c < RB_NB / 2; c++) acc[qa][qb] += li[qa][c] * lj[qb][c];
       }
       // (the operands sit in columns kb .. kb + RB_NB - 1, the stores go to columns >= t0: no barrier in between)
 #pragma unroll
-      for (int qa = 0; qa < NT; qa++)
+      for (int qa = 0; qa < NT; qa++) if (t0 + 16 * qa < n)
 #pragma unroll
-        for (int qb = 0; qb < NT; qb++) {
+        for (int qb = 0; qb < NT; qb++) if (qb <= qa) {
           const int ii = t0 + ty + 16 * qa, jj = t0 + tx + 16 * qb;
           if (ii < n && jj <= ii) s.A[ii * ld + jj] -= acc[qa][qb];
         }
@@ -420,27 +421,28 @@ __device__ __forceinline__ bool rb_chol(RbLds& s, int n) {
 // barrier per block, measured 3 x slower: profiles/r03_ab.txt.)
 __device__ __forceinline__ void rb_chol_solve(RbLds& s, int n, float* x) {
   const int ld = RB_LD(n);
-  for (int kb = 0; kb < n; kb += RB_NB) {          // forward: L y = x
+  // the block's solution travels through s.yb (two buffers, alternating: a block's readers may still be at it while the next block's
+  // writers are done), which makes it TWO barriers per block
+  int par = 0;
+  for (int kb = 0; kb < n; kb += RB_NB, par ^= 1) {          // forward: L y = x
     const int nb = n - kb < RB_NB ? n - kb : RB_NB;
-    float v = 0.f;
-    if (TID < nb) { const float* D = s.Dinv + (kb / RB_NB) * RB_NB * RB_NB + TID * RB_NB; for (int c = 0; c <= TID; c++) v += D[c] * x[kb + c]; }
+    float* yb = s.yb + RB_NB * par;
+    if (TID < nb) { const float* D = s.Dinv + (kb / RB_NB) * RB_NB * RB_NB + TID * RB_NB; float v = 0.f; for (int c = 0; c <= TID; c++) v += D[c] * x[kb + c]; yb[TID] = v; }
     BSYNC();
-    if (TID < nb) x[kb + TID] = v;
-    BSYNC();
+    if (TID < nb) x[kb + TID] = yb[TID];
     const int i = kb + nb + TID;
-    if (i < n) { float a = x[i]; for (int c = 0; c < nb; c++) a -= s.A[i * ld + kb + c] * x[kb + c]; x[i] = a; }
+    if (i < n) { float a = x[i]; for (int c = 0; c < nb; c++) a -= s.A[i * ld + kb + c] * yb[c]; x[i] = a; }
     BSYNC();
   }
   const int last = ((n - 1) / RB_NB) * RB_NB;
-  for (int kb = last; kb >= 0; kb -= RB_NB) {      // backward: L' z = y
+  for (int kb = last; kb >= 0; kb -= RB_NB, par ^= 1) {      // backward: L' z = y
     const int nb = n - kb < RB_NB ? n - kb : RB_NB;
-    float v = 0.f;
-    if (TID < nb) { const float* D = s.Dinv + (kb / RB_NB) * RB_NB * RB_NB; for (int c = TID; c < nb; c++) v += D[c * RB_NB + TID] * x[kb + c]; }   // inv(L')[r][c] = Dinv[c][r]
+    float* yb = s.yb + RB_NB * par;
+    if (TID < nb) { const float* D = s.Dinv + (kb / RB_NB) * RB_NB * RB_NB; float v = 0.f; for (int c = TID; c < nb; c++) v += D[c * RB_NB + TID] * x[kb + c]; yb[TID] = v; }   // inv(L')[r][c] = Dinv[c][r]
     BSYNC();
-    if (TID < nb) x[kb + TID] = v;
-    BSYNC();
+    if (TID < nb) x[kb + TID] = yb[TID];
     const int i = TID;
-    if (i < kb) { float a = x[i]; for (int c = 0; c < nb; c++) a -= s.A[(kb + c) * ld + i] * x[kb + c]; x[i] = a; }
+    if (i < kb) { float a = x[i]; for (int c = 0; c < nb; c++) a -= s.A[(kb + c) * ld + i] * yb[c]; x[i] = a; }
     BSYNC();
   }
 }
@@ -465,6 +467,120 @@ __device__ __forceinline__ void rb_group_solve(RbM m, RbLds& s, int g, const flo
   BSYNC();
 }
 
+// "Star" groups (big_tables.py b_star_*: one tree, a root body's <= 6 dofs with hinge chains of <= 3 dofs hanging off them, no contact
+// pair, no tendon -- the target cube): every matrix the step needs to invert on such a group (M, M + h B, the Newton Hessian M + a
+// diagonal) has M's tree sparsity, [[R, C'], [C, blockdiag(B_k)]] in (root | chains) order.  Block elimination instead of a dense
+// factorisation: thread k factors its chain's B_k = L L' (<= 3 x 3, registers), forms Z_k = inv(L) C_k and u_k = inv(L) y_k and leaves its
+// contribution Z_k' Z_k, Z_k' u_k in LDS; the contributions are summed in chain order (deterministic), every thread then solves the
+// <= 6 x 6 Schur system (R - sum Z'Z) x_r = y_r - sum Z'u redundantly in registers and back-substitutes its own chain.
+// dst[dofs of g] = scale * inv(M_g + dscale * diag(diag)) src[dofs of g]; a non-positive pivot sets RG_STATUS_BAD_FACTOR.
+__device__ __forceinline__ bool rb_star_solve(RbM m, RbLds& s, const float* Msp, int g, const float* diag, float dscale, const float* src, float* dst, float scale) {
+  const int r0 = m.b_star_grp[4 * g + 1], nr = m.b_star_grp[4 * g + 2];
+  const int k0 = m.b_star_adr[g], T = m.b_star_adr[g + 1] - k0;
+  float* W = s.A;                     // [T][28]: lower triangle of Z'Z (21), Z'u (6)
+  float* red = s.A + 28 * RB_T;       // the 27 sums
+  bool ok = true;
+  float l00 = 1, l10 = 0, l11 = 1, l20 = 0, l21 = 0, l22 = 1, Z[3][6], uu[3] = {0, 0, 0};
+  int f = 0, b = 0;
+#pragma unroll
+  for (int q = 0; q < 3; q++)
+#pragma unroll
+    for (int a = 0; a < 6; a++) Z[q][a] = 0.f;
+  if (TID < T) {
+    f = m.b_star_branch[2 * (k0 + TID)]; b = m.b_star_branch[2 * (k0 + TID) + 1];
+    float B[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+#pragma unroll
+    for (int q = 0; q < 3; q++) if (q < b) {
+      const int i = f + q, e0 = m.b_M_adr[i];   // entries (i, i), (i, i - 1), ..., (i, chain top), then (i, last root dof) ... (i, first root dof)
+#pragma unroll
+      for (int t = 0; t < 3; t++) if (t <= q) B[q][q - t] = Msp[e0 + t];
+      if (diag) B[q][q] += dscale * diag[i];
+#pragma unroll
+      for (int a = 0; a < 6; a++) if (a < nr) Z[q][nr - 1 - a] = Msp[e0 + q + 1 + a];
+      uu[q] = src[i];
+    }
+    float d = B[0][0]; ok = ok && d > RB_MINVAL; float r = rg_rsqrt(fmaxf(d, RB_MINVAL)); l00 = fmaxf(d, RB_MINVAL) * r; const float i00 = r;
+    l10 = B[1][0] * i00; l20 = B[2][0] * i00;
+    d = B[1][1] - l10 * l10; ok = ok && d > RB_MINVAL; r = rg_rsqrt(fmaxf(d, RB_MINVAL)); l11 = fmaxf(d, RB_MINVAL) * r; const float i11 = r;
+    l21 = (B[2][1] - l20 * l10) * i11;
+    d = B[2][2] - l20 * l20 - l21 * l21; ok = ok && d > RB_MINVAL; r = rg_rsqrt(fmaxf(d, RB_MINVAL)); l22 = fmaxf(d, RB_MINVAL) * r; const float i22 = r;
+#pragma unroll
+    for (int a = 0; a < 6; a++) { Z[0][a] *= i00; Z[1][a] = (Z[1][a] - l10 * Z[0][a]) * i11; Z[2][a] = (Z[2][a] - l20 * Z[0][a] - l21 * Z[1][a]) * i22; }
+    uu[0] *= i00; uu[1] = (uu[1] - l10 * uu[0]) * i11; uu[2] = (uu[2] - l20 * uu[0] - l21 * uu[1]) * i22;
+    float* w = W + 28 * TID;
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+#pragma unroll
+      for (int c = 0; c < 6; c++) if (c <= a) w[a * (a + 1) / 2 + c] = Z[0][a] * Z[0][c] + Z[1][a] * Z[1][c] + Z[2][a] * Z[2][c];
+      w[21 + a] = Z[0][a] * uu[0] + Z[1][a] * uu[1] + Z[2][a] * uu[2];
+    }
+  }
+  BSYNC();
+  if (TID < 27) { float acc = 0.f; for (int k = 0; k < T; k++) acc += W[28 * k + TID]; red[TID] = acc; }
+  BSYNC();
+  // the Schur system, redundantly
+  float Sm[6][6], xr[6];
+#pragma unroll
+  for (int p = 0; p < 6; p++) {
+#pragma unroll
+    for (int c = 0; c < 6; c++) if (c <= p) Sm[p][c] = (p == c) ? 1.f : 0.f;
+    xr[p] = 0.f;
+    if (p < nr) {
+      const int i = r0 + p, e0 = m.b_M_adr[i];
+#pragma unroll
+      for (int t = 0; t < 6; t++) if (t <= p) Sm[p][p - t] = Msp[e0 + t] - red[p * (p + 1) / 2 + p - t];
+      if (diag) Sm[p][p] += dscale * diag[i];
+      xr[p] = src[i] - red[21 + p];
+    }
+  }
+  float idg[6];
+#pragma unroll
+  for (int c = 0; c < 6; c++) {
+    float d = Sm[c][c];
+#pragma unroll
+    for (int q = 0; q < 6; q++) if (q < c) d -= Sm[c][q] * Sm[c][q];
+    ok = ok && d > RB_MINVAL;
+    idg[c] = rg_rsqrt(fmaxf(d, RB_MINVAL));
+    Sm[c][c] = fmaxf(d, RB_MINVAL) * idg[c];
+#pragma unroll
+    for (int p = 0; p < 6; p++) if (p > c) {
+      float v = Sm[p][c];
+#pragma unroll
+      for (int q = 0; q < 6; q++) if (q < c) v -= Sm[p][q] * Sm[c][q];
+      Sm[p][c] = v * idg[c];
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 6; p++) {   // L y = t
+    float v = xr[p];
+#pragma unroll
+    for (int q = 0; q < 6; q++) if (q < p) v -= Sm[p][q] * xr[q];
+    xr[p] = v * idg[p];
+  }
+#pragma unroll
+  for (int p = 5; p >= 0; p--) {  // L' x = y
+    float v = xr[p];
+#pragma unroll
+    for (int q = 0; q < 6; q++) if (q > p) v -= Sm[q][p] * xr[q];
+    xr[p] = v * idg[p];
+  }
+  if (TID < T) {
+    float w0 = uu[0], w1 = uu[1], w2 = uu[2];
+#pragma unroll
+    for (int a = 0; a < 6; a++) { w0 -= Z[0][a] * xr[a]; w1 -= Z[1][a] * xr[a]; w2 -= Z[2][a] * xr[a]; }
+    const float x2 = w2 / l22, x1 = (w1 - l21 * x2) / l11, x0 = (w0 - l10 * x1 - l20 * x2) / l00;
+    if (b > 0) dst[f] = scale * x0;
+    if (b > 1) dst[f + 1] = scale * x1;
+    if (b > 2) dst[f + 2] = scale * x2;
+  }
+  if (TID == 0) {
+#pragma unroll
+    for (int p = 0; p < 6; p++) if (p < nr) dst[r0 + p] = scale * xr[p];
+  }
+  if (!ok) s.status |= RG_STATUS_BAD_FACTOR;   // (every writer ORs the same bit into the same word; nobody else writes it in this phase)
+  BSYNC();
+  return true;
+}
 // ------------------------------------------------------------------------------------------------- velocity stage
 // mj_comVel, mj_passive, mj_rne (zero acceleration: Coriolis, centrifugal, gravity)
 __device__ __forceinline__ void rb_velocity(RbM m, RbLds& s, float* S) {
@@ -868,6 +984,28 @@ __device__ __forceinline__ void rb_JT_force(RbM m, RbLds& s, float* S, float* ds
   }
   BSYNC();
 }
+// out[d] = sum of D over the quadratic friction-loss row and the active limit row of dof d, for the dofs of group g (the diagonal a
+// star group's Newton Hessian adds to M)
+__device__ __forceinline__ void rb_row_diag(RbM m, RbLds& s, float* S, int g, float* out) {
+  const float* row = SC(ROW);
+  const int nstat = m.nfric_dof + m.nfric_ten + s.nlim;
+  const int g0 = m.b_group_adr[g], n = m.b_group_adr[g + 1] - g0;
+  BFOR(l, n) out[m.b_group_dofs[g0 + l]] = 0.f;
+  BSYNC();
+  for (int pass = 0; pass < 2; pass++) {
+    BFOR(r, nstat) {
+      const float* R = row + RB_ROWREC * r;
+      const int type = (int)R[RB_RR_TYPE], id = (int)R[RB_RR_ID];
+      if (type != (pass == 0 ? 0 : 2)) continue;
+      const int d = type == 0 ? id : m.jnt_dofadr[id];
+      if (m.b_dof_group[d] != g) continue;
+      bool q; float c; rb_row_force(R, q, c);
+      if (q) out[d] += R[RB_RR_D];
+    }
+    BSYNC();
+  }
+}
+
 // s.A (holding the group's block of M) += J' diag(D, quadratic rows) J restricted to group g
 __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g) {
   const float* row = SC(ROW); const float* con = SC(CON); const float* cj = SC(CONJ); const int* cidx = (const int*)SC(CONIDX);
@@ -1036,6 +1174,11 @@ __device__ __forceinline__ int rb_solve(RbM m, RbLds& s, float* S, int flags) {
     // search = - inv(H) grad, group by group
     bool okf = true;
     for (int grp = 0; grp < m.ngroup; grp++) {
+      if (m.b_star_grp[4 * grp] && !(flags & 4)) {   // H = M + diagonal on this group: block elimination along the tree
+        rb_row_diag(m, s, S, grp, s.Mv); RB_PROFS(10);
+        rb_star_solve(m, s, Msp, grp, s.Mv, 1.f, s.grad, s.search, -1.f); RB_PROFS(11);
+        continue;
+      }
       rb_M_block(m, s, Msp, grp, (const float*)0, 0.f);
       rb_hessian_add(m, s, S, grp); RB_PROFS(10);
       rb_scale_block(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]);
@@ -1063,11 +1206,12 @@ __device__ __forceinline__ int rb_solve(RbM m, RbLds& s, float* S, int flags) {
 
 // ------------------------------------------------------------------------------------------------- integration
 // mj_Euler: implicit in joint damping, quaternion integration
-__device__ __forceinline__ void rb_euler(RbM m, RbLds& s, float* S) {
+__device__ __forceinline__ void rb_euler(RbM m, RbLds& s, float* S, int flags) {
   const float h = m.timestep;
   BFOR(i, m.nv) s.grad[i] = s.qfrc_smooth[i] + s.qfrc_con[i];
   BSYNC();
   for (int grp = 0; grp < m.ngroup; grp++) {
+    if (m.b_star_grp[4 * grp] && !(flags & 4)) { rb_star_solve(m, s, SC(MSP), grp, m.dof_damping, h, s.grad, s.search, 1.f); continue; }
     rb_M_block(m, s, SC(MSP), grp, m.dof_damping, h);
     rb_scale_block(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]);
     if (!rb_chol(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]) && TID == 0) s.status |= RG_STATUS_BAD_FACTOR;
@@ -1137,6 +1281,7 @@ __global__ void __launch_bounds__(RB_T, 2) rb_step_kernel(const RbModelDev* mp, 
     rb_pid(m, s, S, true);
     // qacc_smooth = inv(M) qfrc_smooth
     for (int grp = 0; grp < m.ngroup; grp++) {
+      if (m.b_star_grp[4 * grp] && !(flags & 4)) { rb_star_solve(m, s, SC(MSP), grp, (const float*)0, 0.f, s.qfrc_smooth, s.qacc_smooth, 1.f); continue; }   // (flags bit 2: dense path everywhere, test hook)
       rb_M_block(m, s, SC(MSP), grp, (const float*)0, 0.f);
       rb_scale_block(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]);
       if (!rb_chol(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]) && TID == 0) s.status |= RG_STATUS_BAD_FACTOR;
@@ -1153,7 +1298,7 @@ __global__ void __launch_bounds__(RB_T, 2) rb_step_kernel(const RbModelDev* mp, 
     bd = 0; BFOR(i, nv) bd += (fabsf(s.qa[i]) < 1e10f) ? 0.f : 1.f;
     if (rb_sum(s, bd) > 0) { if (TID == 0) s.status |= RG_STATUS_BAD_STATE; break; }
     BFOR(i, nv) s.warm[i] = s.qa[i];
-    rb_euler(m, s, S); RB_PROF(7);
+    rb_euler(m, s, S, flags); RB_PROF(7);
   }
   if ((flags & 2) && TID < 16) SC(DBG)[8 + 5 * nv + TID] = s.prof[TID];   // stage cycle counters: frames+com, tendon+crb, velocity, collision, rows, smooth, Newton, Euler
   // ---- the state-less forward() calls of the reference: only their PID side effect touches the state

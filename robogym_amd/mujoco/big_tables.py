@@ -194,5 +194,40 @@ def derive_big_tables(model):
     for r, i in enumerate(A["b_fric_dof"]):
         fr[i] = r
     A["b_dof_fricrow"] = fr
+    # ---- "star" groups: one tree, a root body's dofs with short hinge chains hanging off them, no contact pair and no tendon on it
+    # (the target cube).  The blocks such a group gives the solver (M, M + h B, the Newton Hessian M + diagonal) keep M's tree sparsity:
+    # rb_star_solve eliminates the chains one thread each and the root block last instead of a dense factorisation.
+    # b_star_grp[g] = (is star, first root dof, root dofs, -); b_star_branch = (first dof, dofs) per chain, b_star_adr per group
+    touched = set()
+    for a, b, _ in pairs:
+        touched |= set(chains[A["geom_bodyid"][a]]) | set(chains[A["geom_bodyid"][b]])
+    touched |= set(int(d) for d in ten_dofs.reshape(-1) if d >= 0)
+    sgrp, sadr2, sbr = [], [0], []
+    for gi in range(len(gadr) - 1):
+        dofs = gdofs[gadr[gi]:gadr[gi + 1]]
+        star, br = False, []
+        if len(set(tree_of_dof[dofs].tolist())) == 1 and not (touched & set(dofs)) and dofs == list(range(dofs[0], dofs[-1] + 1)):
+            rb_ = int(A["dof_bodyid"][dofs[0]])
+            nroot = int(A["body_dofnum"][rb_])
+            root_last = dofs[0] + nroot - 1
+            star = 1 <= nroot <= 6 and all(int(dpar[dofs[0] + q]) == (dofs[0] + q - 1 if q else -1) for q in range(nroot))
+            i = root_last + 1
+            while star and i <= dofs[-1]:
+                if int(dpar[i]) != root_last:
+                    star = False
+                    break
+                n_ = 1
+                while i + n_ <= dofs[-1] and int(dpar[i + n_]) == i + n_ - 1:
+                    n_ += 1
+                if n_ > 3:
+                    star = False
+                br.append((i, n_))
+                i += n_
+            star = star and len(br) <= 256
+        sgrp.append([1 if star else 0, dofs[0] if star else 0, nroot if star else 0, 0])
+        if star:
+            sbr += br
+        sadr2.append(len(sbr))
+    A["b_star_grp"], A["b_star_adr"], A["b_star_branch"] = _i32(sgrp).reshape(-1), _i32(sadr2), _i32(sbr if sbr else [(0, 0)]).reshape(-1)
     A["b_dims"] = _i32([len(adr) - 1, len(Mi), len(pairs), len(gadr) - 1, max(np.diff(gadr)), len(A["b_root_list"]), wmax])
     return model

@@ -117,6 +117,23 @@ def test_large_model_stages_match_oracle_emul(full_model, emul_lib, oracle_lib):
     print("one mj_step with the cube on the palm: contacts %d (oracle %d), qpos err %.2e, qvel err %.2e" % (nk, no, eq, ev))
     assert eq < 5e-4 and ev < 5e-2      # (one or two of the touching-cubelet contacts exist on one side only: their damping acts on the hinge chains)
     assert int(sim.status[0]) == 0
+    # the target cube's group (no contacts, no tendons) goes through the tree-structured block elimination (rb_star_solve); launch flag
+    # bit 2 sends it through the dense factorisation like the hand + cube group: same step, same answer
+    assert full_model.arrays["b_star_grp"].reshape(-1, 4)[:, 0].tolist() == [0, 1]
+    tq, tv = sim.qpos_idxs, None
+    sim.register_joint_group("target", "target:")
+    st = ora.state_f32()
+    st["qvel"][sim.qvel_idxs["target"]] += np.linspace(-0.3, 0.3, len(sim.qvel_idxs["target"])).astype(np.float32)   # (so that the friction-loss rows of its hinges are not all in one zone)
+    out = []
+    for flg in (0, 4):
+        _put(sim, st)
+        sim.env_step(nsubsteps=2, nforward_ticks=0, flags=flg)
+        out.append((sim.qpos[0].cpu().numpy().copy(), sim.qvel[0].cpu().numpy().copy(), sim.qacc_warmstart[0].cpu().numpy().copy()))
+    tvi = sim.qvel_idxs["target"]
+    np.testing.assert_allclose(out[0][1][tvi], out[1][1][tvi], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(out[0][2][tvi], out[1][2][tvi], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(out[0][0], out[1][0], atol=2e-6)
+    assert np.abs(out[0][2][tvi]).max() > 1.0 and int(sim.status[0]) == 0
 
 
 @pytest.mark.gpu
