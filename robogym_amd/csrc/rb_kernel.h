@@ -35,12 +35,15 @@ typedef const RG_AS4 RbLaunch& RbLRef;
 #define BFOR(i, n) for (int i = TID; i < (n); i += RB_T)
 #define BSYNC() __syncthreads()
 #define RB_MINVAL 1e-15f
+#ifndef RB_WG_PER_CU
+#define RB_WG_PER_CU 4   /* resident workgroups per CU the kernel is compiled for (register budget 512 / RB_WG_PER_CU per lane) */
+#endif
 #ifndef RB_COST_EPS
 #define RB_COST_EPS 1e-7f   /* relative rounding noise of the fp32 cost sum: improvements below it are not resolvable */
 #endif
 
 struct RbLds {
-  alignas(16) float A[RB_MAXGROUP * (RB_MAXGROUP + 1)];   // the dense block of the moment, row stride n + 1 (odd: a column walk touches every LDS bank)
+  alignas(16) float A[RB_MAXGROUP * (RB_MAXGROUP + 1) / 2 + 8];   // the dense block of the moment: LOWER triangle, packed by rows (entry (i, j <= i) at i (i + 1) / 2 + j)
   float Dinv[RB_MAXGROUP * 8];   // inverses of the 8 x 8 diagonal blocks of the factor
   float prow[8];
   float yb[2 * 8];   // rb_chol_solve: the current block's solution, double-buffered
@@ -285,23 +288,23 @@ __device__ __forceinline__ void rb_M_mul(RbM m, const float* Msp, const float* x
   }
   BSYNC();
 }
-// s.A <- the dense block of group g of M (+ diag), lower and upper triangle, row stride n + 1
-#define RB_LD(n) ((n) + 1)
+// s.A <- the block of group g of M (+ diag): lower triangle, packed by rows
+#define RB_TRI(i, j) ((((i) * ((i) + 1)) >> 1) + (j))   /* i >= j */
 __device__ __forceinline__ void rb_M_block(RbM m, RbLds& s, const float* Msp, int g, const float* diag, float dscale) {
-  const int g0 = m.b_group_adr[g], n = m.b_group_adr[g + 1] - g0, ld = RB_LD(n);
-  BFOR(w, n * ld) s.A[w] = 0.f;
+  const int g0 = m.b_group_adr[g], n = m.b_group_adr[g + 1] - g0;
+  BFOR(w, RB_TRI(n, 0)) s.A[w] = 0.f;
   BSYNC();
   BFOR(e, m.nM) {
     const int i = m.b_M_i[e], j = m.b_M_j[e];
     if (m.b_dof_group[i] != g) continue;
-    const int li = m.b_dof_local[i], lj = m.b_dof_local[j];
+    const int li = m.b_dof_local[i], lj = m.b_dof_local[j];   // (j = i or an ancestor of i: lj <= li)
     float v = Msp[e];
     if (i == j && diag) v += dscale * diag[i];
-    s.A[li * ld + lj] = v; s.A[lj * ld + li] = v;
+    s.A[RB_TRI(li, lj)] = v;
   }
   BSYNC();
 }
-// In-place Cholesky of the n x n block in s.A (lower triangle, row stride n + 1), blocked by RB_NB columns; false on a
+// In-place Cholesky of the n x n block in s.A (lower triangle, packed rows), blocked by RB_NB columns; false on a
 // non-positive pivot.  Per block THREE workgroup barriers: (a) every thread loads the RB_NB x RB_NB diagonal block and factors it
 // REDUNDANTLY in registers (as rg_chol does with its 4 x 4 blocks: 36 broadcast LDS reads and ~150 flops instead of a pivot row
 // travelling through LDS with two barriers per column), solves its own row's RB_NB entries against it and writes them back;
@@ -310,7 +313,7 @@ __device__ __forceinline__ void rb_M_block(RbM m, RbLds& s, const float* Msp, in
 // update per pass.
 #define RB_NB 8
 __device__ __forceinline__ bool rb_chol(RbLds& s, int n) {
-  const int ld = RB_LD(n), ty = TID >> 4, tx = TID & 15;
+  const int ty = TID >> 4, tx = TID & 15;
   bool ok = true;
   for (int kb = 0; kb < n; kb += RB_NB) {
     const int nb = n - kb < RB_NB ? n - kb : RB_NB;
@@ -319,7 +322,7 @@ __device__ __forceinline__ bool rb_chol(RbLds& s, int n) {
 #pragma unroll
     for (int r = 0; r < RB_NB; r++)
 #pragma unroll
-      for (int q = 0; q < RB_NB; q++) if (q <= r) Lb[r][q] = (r < nb) ? s.A[(kb + r) * ld + kb + q] : (r == q ? 1.f : 0.f);
+      for (int q = 0; q < RB_NB; q++) if (q <= r) Lb[r][q] = (r < nb) ? s.A[RB_TRI(kb + r, kb + q)] : (r == q ? 1.f : 0.f);
     BSYNC();   // (every thread holds the unfactored block before its rows are overwritten with the factor)
 #pragma unroll
     for (int c = 0; c < RB_NB; c++) {
@@ -344,12 +347,12 @@ __device__ __forceinline__ bool rb_chol(RbLds& s, int n) {
 #pragma unroll
         for (int r = 0; r < RB_NB; r++) if (r == TID) {
 #pragma unroll
-          for (int q = 0; q < RB_NB; q++) if (q <= r) s.A[i * ld + kb + q] = Lb[r][q];
+          for (int q = 0; q < RB_NB; q++) if (q <= r) s.A[RB_TRI(i, kb + q)] = Lb[r][q];
         }
       } else {
         float p[RB_NB];
 #pragma unroll
-        for (int c = 0; c < RB_NB; c++) p[c] = c < nb ? s.A[i * ld + kb + c] : 0.f;
+        for (int c = 0; c < RB_NB; c++) p[c] = c < nb ? s.A[RB_TRI(i, kb + c)] : 0.f;
 #pragma unroll
         for (int c = 0; c < RB_NB; c++) {
           float v = p[c];
@@ -358,7 +361,7 @@ __device__ __forceinline__ bool rb_chol(RbLds& s, int n) {
           p[c] = v * id[c];
         }
 #pragma unroll
-        for (int c = 0; c < RB_NB; c++) if (c < nb) s.A[i * ld + kb + c] = p[c];
+        for (int c = 0; c < RB_NB; c++) if (c < nb) s.A[RB_TRI(i, kb + c)] = p[c];
       }
     }
     // inverse of the diagonal block: thread c < nb solves L y = e_c in registers
@@ -392,8 +395,8 @@ __device__ __forceinline__ bool rb_chol(RbLds& s, int n) {
           const int ii = t0 + ty + 16 * q, jj = t0 + tx + 16 * q;
 #pragma unroll
           for (int c = 0; c < RB_NB / 2; c++) {
-            li[q][c] = ii < n ? s.A[ii * ld + kb + half * (RB_NB / 2) + c] : 0.f;
-            lj[q][c] = jj < n ? s.A[jj * ld + kb + half * (RB_NB / 2) + c] : 0.f;
+            li[q][c] = ii < n ? s.A[RB_TRI(ii, kb + half * (RB_NB / 2) + c)] : 0.f;
+            lj[q][c] = jj < n ? s.A[RB_TRI(jj, kb + half * (RB_NB / 2) + c)] : 0.f;
           }
         }
 #pragma unroll
@@ -409,7 +412,7 @@ __device__ __forceinline__ bool rb_chol(RbLds& s, int n) {
 #pragma unroll
         for (int qb = 0; qb < NT; qb++) if (qb <= qa) {
           const int ii = t0 + ty + 16 * qa, jj = t0 + tx + 16 * qb;
-          if (ii < n && jj <= ii) s.A[ii * ld + jj] -= acc[qa][qb];
+          if (ii < n && jj <= ii) s.A[RB_TRI(ii, jj)] -= acc[qa][qb];
         }
     }
     BSYNC();
@@ -420,7 +423,6 @@ __device__ __forceinline__ bool rb_chol(RbLds& s, int n) {
 // dot product each), the rest of the column panel by everybody.  (Every thread doing the 8 x 8 product redundantly, which saves a
 // barrier per block, measured 3 x slower: profiles/r03_ab.txt.)
 __device__ __forceinline__ void rb_chol_solve(RbLds& s, int n, float* x) {
-  const int ld = RB_LD(n);
   // the block's solution travels through s.yb (two buffers, alternating: a block's readers may still be at it while the next block's
   // writers are done), which makes it TWO barriers per block
   int par = 0;
@@ -431,7 +433,7 @@ __device__ __forceinline__ void rb_chol_solve(RbLds& s, int n, float* x) {
     BSYNC();
     if (TID < nb) x[kb + TID] = yb[TID];
     const int i = kb + nb + TID;
-    if (i < n) { float a = x[i]; for (int c = 0; c < nb; c++) a -= s.A[i * ld + kb + c] * yb[c]; x[i] = a; }
+    if (i < n) { float a = x[i]; for (int c = 0; c < nb; c++) a -= s.A[RB_TRI(i, kb + c)] * yb[c]; x[i] = a; }
     BSYNC();
   }
   const int last = ((n - 1) / RB_NB) * RB_NB;
@@ -442,7 +444,7 @@ __device__ __forceinline__ void rb_chol_solve(RbLds& s, int n, float* x) {
     BSYNC();
     if (TID < nb) x[kb + TID] = yb[TID];
     const int i = TID;
-    if (i < kb) { float a = x[i]; for (int c = 0; c < nb; c++) a -= s.A[(kb + c) * ld + i] * yb[c]; x[i] = a; }
+    if (i < kb) { float a = x[i]; for (int c = 0; c < nb; c++) a -= s.A[RB_TRI(kb + c, i)] * yb[c]; x[i] = a; }
     BSYNC();
   }
 }
@@ -451,10 +453,9 @@ __device__ __forceinline__ void rb_chol_solve(RbLds& s, int n, float* x) {
 // digits only and the Newton directions it gives converge linearly (20 iterations instead of 6); scaled, the condition number is
 // within a small factor of the best diagonal scaling can do (van der Sluis).
 __device__ __forceinline__ void rb_scale_block(RbLds& s, int n) {
-  const int ld = RB_LD(n);
-  BFOR(l, n) s.sc[l] = rg_rsqrt(fmaxf(s.A[l * ld + l], RB_MINVAL));
+  BFOR(l, n) s.sc[l] = rg_rsqrt(fmaxf(s.A[RB_TRI(l, l)], RB_MINVAL));
   BSYNC();
-  for (int w = TID; w < n * n; w += RB_T) { const int i = w / n, j = w - i * n; s.A[i * ld + j] *= s.sc[i] * s.sc[j]; }
+  for (int w = TID; w < n * n; w += RB_T) { const int i = w / n, j = w - i * n; if (j <= i) s.A[RB_TRI(i, j)] *= s.sc[i] * s.sc[j]; }
   BSYNC();
 }
 // dst[dofs of group g] = inv(block) applied to src[dofs of group g] (block scaled by rb_scale_block, then factored), through s.x
@@ -478,7 +479,7 @@ __device__ __forceinline__ bool rb_star_solve(RbM m, RbLds& s, const float* Msp,
   const int r0 = m.b_star_grp[4 * g + 1], nr = m.b_star_grp[4 * g + 2];
   const int k0 = m.b_star_adr[g], T = m.b_star_adr[g + 1] - k0;
   float* W = s.A;                     // [T][28]: lower triangle of Z'Z (21), Z'u (6)
-  float* red = s.A + 28 * RB_T;       // the 27 sums
+  float* red = s.A + 28 * T;          // the 27 sums (big_tables.py: T <= 128)
   bool ok = true;
   float l00 = 1, l10 = 0, l11 = 1, l20 = 0, l21 = 0, l22 = 1, Z[3][6], uu[3] = {0, 0, 0};
   int f = 0, b = 0;
@@ -1009,7 +1010,6 @@ __device__ __forceinline__ void rb_row_diag(RbM m, RbLds& s, float* S, int g, fl
 // s.A (holding the group's block of M) += J' diag(D, quadratic rows) J restricted to group g
 __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g) {
   const float* row = SC(ROW); const float* con = SC(CON); const float* cj = SC(CONJ); const int* cidx = (const int*)SC(CONIDX);
-  const int ld = RB_LD(m.b_group_adr[g + 1] - m.b_group_adr[g]);
   const int nstat = m.nfric_dof + m.nfric_ten + s.nlim;
   // static rows: dof rows add to the diagonal (friction rows first, then the limit rows: a dof has one friction row and at most
   // one active limit side, so neither pass has two writers of an entry), tendon rows as small outer products one row at a time
@@ -1021,7 +1021,7 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
       const int d = type == 0 ? id : m.jnt_dofadr[id];
       if (m.b_dof_group[d] != g) continue;
       bool q; float c; rb_row_force(R, q, c);
-      if (q) { const int l = m.b_dof_local[d]; s.A[l * ld + l] += R[RB_RR_D]; }
+      if (q) { const int l = m.b_dof_local[d]; s.A[RB_TRI(l, l)] += R[RB_RR_D]; }
     }
     BSYNC();
   }
@@ -1034,7 +1034,7 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
     if (TID < RB_TENW * RB_TENW) {
       const int ea = TID / RB_TENW, eb = TID % RB_TENW;
       const int da = m.b_ten_dofs[RB_TENW * id + ea], db = m.b_ten_dofs[RB_TENW * id + eb];
-      if (da >= 0 && db >= 0 && m.b_dof_group[da] == g) s.A[m.b_dof_local[da] * ld + m.b_dof_local[db]] += R[RB_RR_D] * SC(TENJ)[RB_TENW * id + ea] * SC(TENJ)[RB_TENW * id + eb];
+      if (da >= 0 && db >= 0 && db <= da && m.b_dof_group[da] == g) s.A[RB_TRI(m.b_dof_local[da], m.b_dof_local[db])] += R[RB_RR_D] * SC(TENJ)[RB_TENW * id + ea] * SC(TENJ)[RB_TENW * id + eb];
     }
     BSYNC();
   }
@@ -1075,12 +1075,14 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
     const float* J = cj + 6 * RB_CONW * c;
     for (int w = TID; w < nnz * nnz; w += RB_T) {
       const int ea = w / nnz, eb = w - ea * nnz;
+      const int la = m.b_dof_local[idx[ea]], lb = m.b_dof_local[idx[eb]];
+      if (lb > la) continue;   // (the lower triangle only)
       float v = W[0] * J[ea] * J[eb];
       for (int k = 0; k < dim - 1; k++) {
         const float ja = J[(k + 1) * RB_CONW + ea], jb = J[(k + 1) * RB_CONW + eb];
         v += W[1 + k] * (J[ea] * jb + ja * J[eb]) + W[6 + k] * ja * jb;
       }
-      s.A[m.b_dof_local[idx[ea]] * ld + m.b_dof_local[idx[eb]]] += v;
+      s.A[RB_TRI(la, lb)] += v;
     }
     BSYNC();
   }
@@ -1236,7 +1238,7 @@ __device__ __forceinline__ void rb_euler(RbM m, RbLds& s, float* S, int flags) {
 #else
 #define RB_MAKE_CTX() RbM m = *(const RG_AS4 RbModelDev*)rg_uniform(mp); RbLRef L = *(const RG_AS4 RbLaunch*)((const RG_AS4 char*)__builtin_amdgcn_kernarg_segment_ptr() + 8)
 #endif
-__global__ void __launch_bounds__(RB_T, 2) rb_step_kernel(const RbModelDev* mp, RbLaunch launch) {
+__global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbModelDev* mp, RbLaunch launch) {
   RB_MAKE_CTX();
   RbLds& s = RB_S();
   const int e = blockIdx.x;

@@ -223,7 +223,7 @@ def derive_big_tables(model):
                     star = False
                 br.append((i, n_))
                 i += n_
-            star = star and len(br) <= 256
+            star = star and len(br) <= 128
         sgrp.append([1 if star else 0, dofs[0] if star else 0, nroot if star else 0, 0])
         if star:
             sbr += br
