@@ -38,6 +38,7 @@ typedef const RG_AS4 RbLaunch& RbLRef;
 #ifndef RB_WG_PER_CU
 #define RB_WG_PER_CU 4   /* resident workgroups per CU the kernel is compiled for (register budget 512 / RB_WG_PER_CU per lane) */
 #endif
+#define RB_CST (7 * RB_CONW + 12 + 2)
 #ifndef RB_COST_EPS
 #define RB_COST_EPS 1e-7f   /* relative rounding noise of the fp32 cost sum: improvements below it are not resolvable */
 #endif
@@ -47,6 +48,7 @@ struct RbLds {
   float Dinv[RB_MAXGROUP * 8];   // inverses of the 8 x 8 diagonal blocks of the factor
   float prow[8];
   float yb[2 * 8];   // rb_chol_solve: the current block's solution, double-buffered
+  float cst[2 * RB_CST];   // rb_hessian_add: the contact being added and the next one (basis Jacobians, block rows, weights, nnz, dim)
   float sc[RB_MAXGROUP];
   float qpos[RB_MAXNQ], qvel[RB_MAXNV], warm[RB_MAXNV], ctrl[32], pid[96], actlen[32], actfrc[32];
   float qfrc_passive[RB_MAXNV], qfrc_bias[RB_MAXNV], qfrc_act[RB_MAXNV], qfrc_smooth[RB_MAXNV], qacc_smooth[RB_MAXNV];
@@ -305,79 +307,77 @@ __device__ __forceinline__ void rb_M_block(RbM m, RbLds& s, const float* Msp, in
   BSYNC();
 }
 // In-place Cholesky of the n x n block in s.A (lower triangle, packed rows), blocked by RB_NB columns; false on a
-// non-positive pivot.  Per block THREE workgroup barriers: (a) every thread loads the RB_NB x RB_NB diagonal block and factors it
-// REDUNDANTLY in registers (as rg_chol does with its 4 x 4 blocks: 36 broadcast LDS reads and ~150 flops instead of a pivot row
-// travelling through LDS with two barriers per column), solves its own row's RB_NB entries against it and writes them back;
-// threads < RB_NB also leave the inverse of the diagonal block in s.Dinv so that the substitutions multiply instead of dividing
-// serially; (b) the trailing block, a 16 x 16 thread tile with its operands loaded into registers before any store, rank-RB_NB
-// update per pass.
+// non-positive pivot.  Per block three workgroup barriers: (a1) wave 0 factors the RB_NB x RB_NB diagonal block with one row per lane
+// in registers, pivots and multipliers by v_readlane, and leaves the block's inverse in s.Dinv (the substitutions and (a2) multiply by
+// it instead of dividing serially); (a2) every row below multiplies its RB_NB entries by inv(L)': independent dot products; (b) the
+// trailing block, a 16 x 16 thread tile over the tiles that still hold entries of the lower triangle, rank-RB_NB update per pass.
+// (The first version factored the diagonal block redundantly in every thread, 36 words of a register array per thread: with the
+// register budget of four resident workgroups that array lived in scratch and the step cost 6.9 k cycles per block.)
 #define RB_NB 8
 __device__ __forceinline__ bool rb_chol(RbLds& s, int n) {
   const int ty = TID >> 4, tx = TID & 15;
   bool ok = true;
   for (int kb = 0; kb < n; kb += RB_NB) {
     const int nb = n - kb < RB_NB ? n - kb : RB_NB;
-    // (a) the diagonal block, redundantly: L (lower triangle) with the reciprocals of its diagonal in id[]
-    float Lb[RB_NB][RB_NB], id[RB_NB];
+#ifdef RB_CHOL_PROBE
+    const long long tprobe = rg_clock();
+#endif
+    // (a1) the diagonal block, by wave 0 alone: lane r < 8 holds row r in registers, pivots and multipliers travel by v_readlane
+    // (no LDS round trip, no barrier inside); lane c then builds column c of inv(L) the same way
+    if (WID == 0) {
+      const int r = WL;
+      float Lr[RB_NB], y[RB_NB], idg[RB_NB];
 #pragma unroll
-    for (int r = 0; r < RB_NB; r++)
+      for (int q = 0; q < RB_NB; q++) Lr[q] = (r < nb && q <= r) ? s.A[RB_TRI(kb + r, kb + q)] : ((r < RB_NB && q == r) ? 1.f : 0.f);
 #pragma unroll
-      for (int q = 0; q < RB_NB; q++) if (q <= r) Lb[r][q] = (r < nb) ? s.A[RB_TRI(kb + r, kb + q)] : (r == q ? 1.f : 0.f);
-    BSYNC();   // (every thread holds the unfactored block before its rows are overwritten with the factor)
+      for (int c = 0; c < RB_NB; c++) {
+        const float d = lane_bcast(Lr[c], c);
+        if (!(d > RB_MINVAL)) ok = false;
+        idg[c] = rg_rsqrt(fmaxf(d, RB_MINVAL));
+        Lr[c] = (r == c) ? fmaxf(d, RB_MINVAL) * idg[c] : Lr[c] * idg[c];
 #pragma unroll
-    for (int c = 0; c < RB_NB; c++) {
-      float d = Lb[c][c];
-#pragma unroll
-      for (int q = 0; q < RB_NB; q++) if (q < c) d -= Lb[c][q] * Lb[c][q];
-      if (!(d > RB_MINVAL)) ok = false;
-      id[c] = rg_rsqrt(fmaxf(d, RB_MINVAL));
-      Lb[c][c] = fmaxf(d, RB_MINVAL) * id[c];
-#pragma unroll
-      for (int r = 0; r < RB_NB; r++) if (r > c) {
-        float v = Lb[r][c];
-#pragma unroll
-        for (int q = 0; q < RB_NB; q++) if (q < c) v -= Lb[r][q] * Lb[c][q];
-        Lb[r][c] = v * id[c];
-      }
-    }
-    // the thread's own row below / inside the block
-    const int i = kb + TID;
-    if (i < n) {
-      if (TID < nb) {   // a row of the diagonal block: its finished entries
-#pragma unroll
-        for (int r = 0; r < RB_NB; r++) if (r == TID) {
-#pragma unroll
-          for (int q = 0; q < RB_NB; q++) if (q <= r) s.A[RB_TRI(i, kb + q)] = Lb[r][q];
-        }
-      } else {
-        float p[RB_NB];
-#pragma unroll
-        for (int c = 0; c < RB_NB; c++) p[c] = c < nb ? s.A[RB_TRI(i, kb + c)] : 0.f;
-#pragma unroll
-        for (int c = 0; c < RB_NB; c++) {
-          float v = p[c];
-#pragma unroll
-          for (int q = 0; q < RB_NB; q++) if (q < c) v -= p[q] * Lb[c][q];
-          p[c] = v * id[c];
-        }
-#pragma unroll
-        for (int c = 0; c < RB_NB; c++) if (c < nb) s.A[RB_TRI(i, kb + c)] = p[c];
-      }
-    }
-    // inverse of the diagonal block: thread c < nb solves L y = e_c in registers
-    if (TID < nb) {
-      float y[RB_NB];
-#pragma unroll
-      for (int r = 0; r < RB_NB; r++) {
-        float v = r == TID ? 1.f : 0.f;
-#pragma unroll
-        for (int q = 0; q < RB_NB; q++) if (q < r) v -= Lb[r][q] * ((q >= TID) ? y[q] : 0.f);
-        y[r] = (r >= TID && r < nb) ? v * id[r] : 0.f;
+        for (int q = 0; q < RB_NB; q++) if (q > c) { const float lqc = lane_bcast(Lr[c], q); Lr[q] -= Lr[c] * lqc; }
       }
 #pragma unroll
-      for (int r = 0; r < RB_NB; r++) s.Dinv[(kb / RB_NB) * RB_NB * RB_NB + r * RB_NB + TID] = y[r];   // Dinv[r][c]
+      for (int rr = 0; rr < RB_NB; rr++) {          // y[rr] of lane c = inv(L)[rr][c]
+        float acc = (rr == r) ? 1.f : 0.f;
+#pragma unroll
+        for (int q = 0; q < RB_NB; q++) if (q < rr) acc -= lane_bcast(Lr[q], rr) * y[q];
+        y[rr] = acc * idg[rr];
+      }
+      if (r < nb) {
+#pragma unroll
+        for (int q = 0; q < RB_NB; q++) if (q <= r) s.A[RB_TRI(kb + r, kb + q)] = Lr[q];
+      }
+      if (r < RB_NB) {
+#pragma unroll
+        for (int rr = 0; rr < RB_NB; rr++) s.Dinv[(kb / RB_NB) * RB_NB * RB_NB + rr * RB_NB + r] = (rr >= r && rr < nb && r < nb) ? y[rr] : 0.f;   // Dinv[rr][c]
+      }
     }
     BSYNC();
+    // (a2) every row below the block: its RB_NB entries times inv(L)' (independent dot products)
+    {
+      const int i = kb + nb + TID;
+      if (i < n) {
+        float p[RB_NB], o[RB_NB];
+#pragma unroll
+        for (int c = 0; c < RB_NB; c++) p[c] = c < nb ? s.A[RB_TRI(i, kb + c)] : 0.f;
+        const float* D = s.Dinv + (kb / RB_NB) * RB_NB * RB_NB;
+#pragma unroll
+        for (int c = 0; c < RB_NB; c++) {
+          float v = 0.f;
+#pragma unroll
+          for (int q = 0; q < RB_NB; q++) if (q <= c) v += p[q] * D[c * RB_NB + q];
+          o[c] = v;
+        }
+#pragma unroll
+        for (int c = 0; c < RB_NB; c++) if (c < nb) s.A[RB_TRI(i, kb + c)] = o[c];
+      }
+    }
+    BSYNC();
+#ifdef RB_CHOL_PROBE
+    if (TID == 0) s.prof[15] += (float)(rg_clock() - tprobe);
+#endif
     // (b) trailing update: A[i][j] -= sum_c L[i][kb + c] L[j][kb + c], i, j >= kb + RB_NB
     const int t0 = kb + RB_NB;
     if (t0 < n) {
@@ -1066,23 +1066,42 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
   const bool any = s.wcnt[0] != 0;
   BSYNC();
   if (TID == 0) s.wcnt[0] = 0;
-  if (any) for (int c = 0; c < s.ncon; c++) {
-    const float* W = Wc + 12 * c;
-    if (W[0] == 0.f) continue;   // (uniform: every thread reads the same word)
-    const float* C = con + RB_CONREC * c;
-    const int nnz = (int)C[RB_CR_NNZ], dim = (int)C[RB_CR_DIM];
-    const int* idx = cidx + RB_CONW * c;
-    const float* J = cj + 6 * RB_CONW * c;
-    for (int w = TID; w < nnz * nnz; w += RB_T) {
-      const int ea = w / nnz, eb = w - ea * nnz;
-      const int la = m.b_dof_local[idx[ea]], lb = m.b_dof_local[idx[eb]];
-      if (lb > la) continue;   // (the lower triangle only)
-      float v = W[0] * J[ea] * J[eb];
-      for (int k = 0; k < dim - 1; k++) {
-        const float ja = J[(k + 1) * RB_CONW + ea], jb = J[(k + 1) * RB_CONW + eb];
-        v += W[1 + k] * (J[ea] * jb + ja * J[eb]) + W[6 + k] * ja * jb;
+  if (!any) return;
+  // One contact at a time (two contacts may share entries; the order of the sums is fixed), but its data -- six basis Jacobian rows,
+  // the dofs' rows in the block, the weights -- is staged through LDS by one load per thread while the previous contact is being
+  // added: a thread adding an entry then reads LDS only.  (Reading them from the scratch row cost ~30 global loads per thread and
+  // contact: 40 % of the kernel's vector memory instructions.)
+  auto stage = [&](int c, float* dst) {
+    for (int t = TID; t < RB_CST; t += RB_T) {
+      float v;
+      if (t < 6 * RB_CONW) v = cj[6 * RB_CONW * c + t];
+      else if (t < 7 * RB_CONW) { const int d = cidx[RB_CONW * c + t - 6 * RB_CONW]; v = (float)((d >= 0 && d < m.nv) ? m.b_dof_local[d] : 0); }
+      else if (t < 7 * RB_CONW + 12) v = Wc[12 * c + t - 7 * RB_CONW];
+      else v = con[RB_CONREC * c + (t == 7 * RB_CONW + 12 ? RB_CR_NNZ : RB_CR_DIM)];
+      dst[t] = v;
+    }
+  };
+  int buf = 0;
+  stage(0, s.cst);
+  BSYNC();
+  for (int c = 0; c < s.ncon; c++, buf ^= 1) {
+    if (c + 1 < s.ncon) stage(c + 1, s.cst + RB_CST * (buf ^ 1));
+    const float* K = s.cst + RB_CST * buf;
+    const float* W = K + 7 * RB_CONW;
+    if (W[0] != 0.f) {
+      const int nnz = (int)K[7 * RB_CONW + 12], dim = (int)K[7 * RB_CONW + 13];
+      for (int w = TID; w < nnz * (nnz + 1) / 2; w += RB_T) {
+        int ea = (int)((sqrtf(8.f * (float)w + 1.f) - 1.f) * 0.5f);
+        if (ea * (ea + 1) / 2 > w) ea--; else if ((ea + 1) * (ea + 2) / 2 <= w) ea++;
+        const int eb = w - ea * (ea + 1) / 2;                    // every unordered pair of the contact's dofs once (eb <= ea)
+        float v = W[0] * K[ea] * K[eb];
+        for (int k = 0; k < dim - 1; k++) {
+          const float ja = K[(k + 1) * RB_CONW + ea], jb = K[(k + 1) * RB_CONW + eb];
+          v += W[1 + k] * (K[ea] * jb + ja * K[eb]) + W[6 + k] * ja * jb;
+        }
+        const int la = (int)K[6 * RB_CONW + ea], lb = (int)K[6 * RB_CONW + eb];
+        s.A[la >= lb ? RB_TRI(la, lb) : RB_TRI(lb, la)] += v;
       }
-      s.A[RB_TRI(la, lb)] += v;
     }
     BSYNC();
   }
