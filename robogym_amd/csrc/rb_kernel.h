@@ -280,13 +280,24 @@ __device__ __forceinline__ void rb_crb(RbM m, RbLds& s, float* S) {
   }
   BSYNC();
 }
-// y = M x (all dofs): row i = its own entries (ancestors) + the entries of its descendants that name i
+// y = M x (all dofs): row i = its own entries (ancestors) + the entries of its descendants that name i.  The descendant lists of
+// tree roots are long (the cube's root dofs: ~70 entries): those are summed by a whole wave each (b_Mlong), the others by the row's thread
 __device__ __forceinline__ void rb_M_mul(RbM m, const float* Msp, const float* x, float* y) {
   BFOR(i, m.nv) {
     float acc = 0;
     for (int e = m.b_M_adr[i]; e < m.b_M_adr[i + 1]; e++) acc += Msp[e] * x[m.b_M_j[e]];
-    for (int q = m.b_Mdesc_adr[i]; q < m.b_Mdesc_adr[i + 1]; q++) acc += Msp[m.b_Mdesc_ent[q]] * x[m.b_Mdesc_dof[q]];   // descendants' entries that name i
+    const int q0 = m.b_Mdesc_adr[i], q1 = m.b_Mdesc_adr[i + 1];
+    if (q1 - q0 <= RB_MLONG) for (int q = q0; q < q1; q++) acc += Msp[m.b_Mdesc_ent[q]] * x[m.b_Mdesc_dof[q]];   // descendants' entries that name i
     y[i] = acc;
+  }
+  BSYNC();
+  const int nlong = m.b_Mlong[0];
+  for (int k = WID; k < nlong; k += RB_T / 64) {
+    const int i = m.b_Mlong[1 + k];
+    float acc = 0;
+    for (int q = m.b_Mdesc_adr[i] + WL; q < m.b_Mdesc_adr[i + 1]; q += 64) acc += Msp[m.b_Mdesc_ent[q]] * x[m.b_Mdesc_dof[q]];
+    acc = wave_sum(acc);
+    if (WL == 0) y[i] += acc;
   }
   BSYNC();
 }
@@ -914,23 +925,32 @@ __device__ __forceinline__ void rb_dof_contact_lists(RbM m, RbLds& s, float* S) 
 // jar (to_jv = false: J x - aref) or jv (to_jv = true: J x) of every row
 __device__ __forceinline__ void rb_J_mul(RbM m, RbLds& s, float* S, const float* x, bool to_jv) {
   float* row = SC(ROW); const float* con = SC(CON); const float* cj = SC(CONJ); const int* cidx = (const int*)SC(CONIDX);
+  // the six basis products of every contact first (its pyramid rows combine them: up to ten rows share them)
+  float* bd = SC(CONF);
+  BFOR(w, 6 * s.ncon) {
+    const int c = w / 6, k = w - 6 * c;
+    const float* J = cj + 6 * RB_CONW * c + k * RB_CONW; const int* idx = cidx + RB_CONW * c;
+    const int nnz = (int)con[RB_CONREC * c + RB_CR_NNZ];
+    float v = 0;
+    for (int e = 0; e < nnz; e++) v += J[e] * x[idx[e]];
+    bd[w] = v;
+  }
+  BSYNC();
   BFOR(r, s.nefc) {
     float* R = row + RB_ROWREC * r;
     const int type = (int)R[RB_RR_TYPE], id = (int)R[RB_RR_ID];
+    const float aux = R[RB_RR_AUX];
     float v;
-    if (type < 4) v = rb_srow_dot(m, S, type, id, R[RB_RR_AUX], x);
+    if (type < 4) v = rb_srow_dot(m, S, type, id, aux, x);
     else {
-      const float* C = con + RB_CONREC * id; const float* J = cj + 6 * RB_CONW * id; const int* idx = cidx + RB_CONW * id;
-      const int nnz = (int)C[RB_CR_NNZ], a = (int)fabsf(R[RB_RR_AUX]);
-      float b0 = 0, bk = 0;
-      for (int e = 0; e < nnz; e++) { const float xe = x[idx[e]]; b0 += J[e] * xe; if (a) bk += J[a * RB_CONW + e] * xe; }
-      v = b0 + (a ? (R[RB_RR_AUX] < 0 ? -1.f : 1.f) * C[RB_CR_FRIC + a - 1] * bk : 0.f);
+      const int a = (int)fabsf(aux);
+      v = bd[6 * id] + (a ? (aux < 0 ? -1.f : 1.f) * con[RB_CONREC * id + RB_CR_FRIC + a - 1] * bd[6 * id + a] : 0.f);
     }
     if (to_jv) R[RB_RR_JV] = v; else R[RB_RR_JAR] = v - R[RB_RR_AREF];
   }
   BSYNC();
 }
-// force of a row from its jar; `quad`: the row is in its quadratic zone (contributes D J'J to the Hessian)
+// force of one constraint row at its current residual (R[JAR]), whether it is in its quadratic zone, and its cost
 __device__ __forceinline__ float rb_row_force(const float* R, bool& quad, float& cost) {
   const float D = R[RB_RR_D], x = R[RB_RR_JAR];
   if ((int)R[RB_RR_TYPE] < 2) {
@@ -964,24 +984,46 @@ __device__ __forceinline__ void rb_JT_force(RbM m, RbLds& s, float* S, float* ds
   BSYNC();
   const int nf = m.nfric_dof + m.nfric_ten;
   const int* adr = (const int*)SC(DOFCON_ADR); const int* lst = (const int*)SC(DOFCON);
+  // friction tendons and limits: one thread per row leaves (force, kind, dof or tendon, coefficient) in LDS; the dofs then scan LDS
+  // (kind 0: nothing, 1: one dof, 2: a tendon's dofs)
+  const int nst = nf + s.nlim - m.nfric_dof, cap = 2 * RB_CST / 4;
   BFOR(i, m.nv) {
     float acc = 0;
     const int fr = m.b_dof_fricrow[i];
     if (fr >= 0) { bool q; float c; acc += rb_row_force(row + RB_ROWREC * fr, q, c); }
-    for (int r = m.nfric_dof; r < nf + s.nlim; r++) {   // friction tendons, limits
-      const float* R = row + RB_ROWREC * r;
+    dst[i] = acc;
+  }
+  for (int r0 = 0; r0 < nst; r0 += cap) {
+    const int nr = nst - r0 < cap ? nst - r0 : cap;
+    BSYNC();
+    BFOR(k, nr) {
+      const float* R = row + RB_ROWREC * (m.nfric_dof + r0 + k);
       const int type = (int)R[RB_RR_TYPE], id = (int)R[RB_RR_ID];
       bool q; float c; const float f = rb_row_force(R, q, c);
-      if (f == 0.f) continue;
-      if (type == 2) { if (m.jnt_dofadr[id] == i) acc += R[RB_RR_AUX] * f; }
-      else for (int e = 0; e < RB_TENW; e++) if (m.b_ten_dofs[RB_TENW * id + e] == i) acc += (type == 1 ? 1.f : R[RB_RR_AUX]) * SC(TENJ)[RB_TENW * id + e] * f;
+      float* o = s.cst + 4 * k;
+      o[0] = f; o[1] = f == 0.f ? 0.f : (type == 2 ? 1.f : 2.f); o[2] = (float)(type == 2 ? m.jnt_dofadr[id] : id); o[3] = type == 1 ? 1.f : R[RB_RR_AUX];
     }
+    BSYNC();
+    BFOR(i, m.nv) {
+      float acc = 0;
+      for (int k = 0; k < nr; k++) {
+        const float* o = s.cst + 4 * k;
+        if (o[1] == 0.f) continue;
+        if (o[1] == 1.f) { if ((int)o[2] == i) acc += o[3] * o[0]; }
+        else { const int id = (int)o[2]; for (int e = 0; e < RB_TENW; e++) if (m.b_ten_dofs[RB_TENW * id + e] == i) acc += o[3] * SC(TENJ)[RB_TENW * id + e] * o[0]; }
+      }
+      dst[i] += acc;
+    }
+  }
+  BSYNC();
+  BFOR(i, m.nv) {
+    float acc = 0;
     for (int q = adr[i]; q < adr[i + 1]; q++) {
       const int ce = lst[q], c = ce / RB_CONW, e = ce - c * RB_CONW;
       const float* J = cj + 6 * RB_CONW * c; const float* F = Fb + 6 * c;
       acc += (J[e] * F[0] + J[RB_CONW + e] * F[1] + J[2 * RB_CONW + e] * F[2]) + (J[3 * RB_CONW + e] * F[3] + J[4 * RB_CONW + e] * F[4] + J[5 * RB_CONW + e] * F[5]);
     }
-    dst[i] = acc;
+    dst[i] += acc;
   }
   BSYNC();
 }
@@ -1109,17 +1151,24 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
 
 // ------------------------------------------------------------------------------------------------- solver
 struct RbLs { float cost, grad, hess; };
-__device__ __forceinline__ RbLs rb_ls_eval(RbLds& s, const float* row, int nefc, float alpha, float q0, float q1, float q2) {
+// the rows a thread owns in the line search (r = TID and TID + RB_T; rows beyond 2 RB_T are read from the scratch row each time): loaded once
+struct RbLsRows { float D[2], jar[2], jv[2], fl[2]; int fric[2]; };
+__device__ __forceinline__ void rb_ls_acc(float D, float jar, float jv, float fl, bool fric, float alpha, float& cst, float& grd, float& hss) {
+  const float x = jar + alpha * jv;
+  if (fric) {
+    const float Rr = 1.f / D;
+    if (x <= -Rr * fl) { cst += fl * (-0.5f * Rr * fl - x); grd += -fl * jv; }
+    else if (x >= Rr * fl) { cst += fl * (-0.5f * Rr * fl + x); grd += fl * jv; }
+    else { cst += 0.5f * D * x * x; grd += D * x * jv; hss += D * jv * jv; }
+  } else if (x < 0) { cst += 0.5f * D * x * x; grd += D * x * jv; hss += D * jv * jv; }
+}
+__device__ __forceinline__ RbLs rb_ls_eval(RbLds& s, const float* row, const RbLsRows& own, int nefc, float alpha, float q0, float q1, float q2) {
   float cst = 0, grd = 0, hss = 0;
-  BFOR(r, nefc) {
+#pragma unroll
+  for (int k = 0; k < 2; k++) if (TID + k * RB_T < nefc) rb_ls_acc(own.D[k], own.jar[k], own.jv[k], own.fl[k], own.fric[k] != 0, alpha, cst, grd, hss);
+  for (int r = TID + 2 * RB_T; r < nefc; r += RB_T) {
     const float* R = row + RB_ROWREC * r;
-    const float D = R[RB_RR_D], jv = R[RB_RR_JV], x = R[RB_RR_JAR] + alpha * jv;
-    if ((int)R[RB_RR_TYPE] < 2) {
-      const float f = R[RB_RR_FLOSS], Rr = 1.f / D;
-      if (x <= -Rr * f) { cst += f * (-0.5f * Rr * f - x); grd += -f * jv; }
-      else if (x >= Rr * f) { cst += f * (-0.5f * Rr * f + x); grd += f * jv; }
-      else { cst += 0.5f * D * x * x; grd += D * x * jv; hss += D * jv * jv; }
-    } else if (x < 0) { cst += 0.5f * D * x * x; grd += D * x * jv; hss += D * jv * jv; }
+    rb_ls_acc(R[RB_RR_D], R[RB_RR_JAR], R[RB_RR_JV], R[RB_RR_FLOSS], (int)R[RB_RR_TYPE] < 2, alpha, cst, grd, hss);
   }
   rb_sum3(s, cst, grd, hss);
   RbLs p; p.cost = alpha * alpha * q2 + alpha * q1 + q0 + cst; p.grad = 2.f * alpha * q2 + q1 + grd; p.hess = 2.f * q2 + hss;
@@ -1127,12 +1176,19 @@ __device__ __forceinline__ RbLs rb_ls_eval(RbLds& s, const float* row, int nefc,
 }
 // exact minimiser of the convex piecewise-quadratic 1-D restriction (oracle line_search: safeguarded Newton on the derivative)
 __device__ __forceinline__ float rb_line_search(RbLds& s, const float* row, int nefc, float q0, float q1, float q2, float gtol, int maxit) {
-  const RbLs p0 = rb_ls_eval(s, row, nefc, 0.f, q0, q1, q2);
+  RbLsRows own;
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int r = TID + k * RB_T;
+    const float* R = row + RB_ROWREC * (r < nefc ? r : 0);
+    own.D[k] = R[RB_RR_D]; own.jar[k] = R[RB_RR_JAR]; own.jv[k] = R[RB_RR_JV]; own.fl[k] = R[RB_RR_FLOSS]; own.fric[k] = (int)R[RB_RR_TYPE] < 2;
+  }
+  const RbLs p0 = rb_ls_eval(s, row, own, nefc, 0.f, q0, q1, q2);
   if (p0.grad >= 0 || p0.hess <= 0) return 0.f;
   float lo = 0, hi = -1, glo = p0.grad, hlo = p0.hess, ghi = 0, hhi = 0;
   float a = -p0.grad / p0.hess;
   for (int it = 0; it < maxit; it++) {
-    const RbLs p = rb_ls_eval(s, row, nefc, a, q0, q1, q2);
+    const RbLs p = rb_ls_eval(s, row, own, nefc, a, q0, q1, q2);
     if (fabsf(p.grad) < gtol) return a;
     if (p.grad < 0) { lo = a; glo = p.grad; hlo = p.hess; } else { hi = a; ghi = p.grad; hhi = p.hess; }
     float cand = lo - glo / hlo;

@@ -19,6 +19,7 @@ from robogym_amd.mujoco.kernel_tables import collision_pairs
 
 TEN_W = 8        # dofs a tendon can depend on (RB_TENW)
 CON_W = 24       # dofs a contact can depend on (RB_CONW)
+MLONG = 8        # descendant lists longer than this are summed by a wave (RB_MLONG)
 
 
 def _i32(x):
@@ -189,6 +190,9 @@ def derive_big_tables(model):
                 dent.append(e); ddof.append(Mi[e])
         dadr.append(len(dent))
     A["b_Mdesc_adr"], A["b_Mdesc_ent"], A["b_Mdesc_dof"] = _i32(dadr), _i32(dent), _i32(ddof)
+    # dofs whose descendant list is long (tree roots): rb_M_mul sums those lists with a whole wave; [count, dof, dof, ...]
+    long_ = [i for i in range(nv) if dadr[i + 1] - dadr[i] > MLONG]
+    A["b_Mlong"] = _i32([len(long_)] + long_)
     # friction-loss row of every dof (-1: none)
     fr = np.full(nv, -1, dtype=np.int32)
     for r, i in enumerate(A["b_fric_dof"]):
