@@ -147,6 +147,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8192, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipelined-reset", action="store_true", help="finished episodes run the reset recipe inside the step launches")
+    ap.add_argument("--launch-flags", type=int, default=0, help="diagnostic: extra rg_step_args.flags of the step launches (4: no per-pair collision cache)")
     ap.add_argument("--sort-dispatch", type=int, default=1, help="dispatch the envs longest-expected-first (previous step's cycles)")
     args = ap.parse_args()
 
@@ -188,6 +189,7 @@ def main():
     env = make_simple_env(batch_size=B, device=dev, starting_seed=20200901 + 1 + rank, pipelined_reset=args.pipelined_reset,
                           sort_dispatch=bool(args.sort_dispatch) and not emul_path, **kw)
     env.reset()
+    env.launch_flags = int(args.launch_flags)
     sim = env.mujoco_simulation
     gen = torch.Generator(device=dev)
     gen.manual_seed(20200901 + 1 + 1000 * rank)

@@ -38,7 +38,7 @@ typedef const RG_AS4 RbLaunch& RbLRef;
 #ifndef RB_WG_PER_CU
 #define RB_WG_PER_CU 4   /* resident workgroups per CU the kernel is compiled for (register budget 512 / RB_WG_PER_CU per lane) */
 #endif
-#define RB_CST (7 * RB_CONW + 12 + 2)
+#define RB_CST (7 * RB_CONW + 12 + 2)   /* words of a staged contact; <= RB_T */
 #ifndef RB_COST_EPS
 #define RB_COST_EPS 1e-7f   /* relative rounding noise of the fp32 cost sum: improvements below it are not resolvable */
 #endif
@@ -1113,21 +1113,21 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
   // the dofs' rows in the block, the weights -- is staged through LDS by one load per thread while the previous contact is being
   // added: a thread adding an entry then reads LDS only.  (Reading them from the scratch row cost ~30 global loads per thread and
   // contact: 40 % of the kernel's vector memory instructions.)
-  auto stage = [&](int c, float* dst) {
-    for (int t = TID; t < RB_CST; t += RB_T) {
-      float v;
-      if (t < 6 * RB_CONW) v = cj[6 * RB_CONW * c + t];
-      else if (t < 7 * RB_CONW) { const int d = cidx[RB_CONW * c + t - 6 * RB_CONW]; v = (float)((d >= 0 && d < m.nv) ? m.b_dof_local[d] : 0); }
-      else if (t < 7 * RB_CONW + 12) v = Wc[12 * c + t - 7 * RB_CONW];
-      else v = con[RB_CONREC * c + (t == 7 * RB_CONW + 12 ? RB_CR_NNZ : RB_CR_DIM)];
-      dst[t] = v;
-    }
+  // (RB_CST <= RB_T: one word per thread; the load is issued before the current contact is added, the LDS store after it, so that the
+  //  load's latency is covered by the adding instead of being waited for in front of it)
+  auto stage_load = [&](int c) -> float {
+    const int t = TID;
+    if (t >= RB_CST) return 0.f;
+    if (t < 6 * RB_CONW) return cj[6 * RB_CONW * c + t];
+    if (t < 7 * RB_CONW) { const int d = cidx[RB_CONW * c + t - 6 * RB_CONW]; return (float)((d >= 0 && d < m.nv) ? m.b_dof_local[d] : 0); }
+    if (t < 7 * RB_CONW + 12) return Wc[12 * c + t - 7 * RB_CONW];
+    return con[RB_CONREC * c + (t == 7 * RB_CONW + 12 ? RB_CR_NNZ : RB_CR_DIM)];
   };
   int buf = 0;
-  stage(0, s.cst);
+  { const float v = stage_load(0); if (TID < RB_CST) s.cst[TID] = v; }
   BSYNC();
   for (int c = 0; c < s.ncon; c++, buf ^= 1) {
-    if (c + 1 < s.ncon) stage(c + 1, s.cst + RB_CST * (buf ^ 1));
+    const float next = c + 1 < s.ncon ? stage_load(c + 1) : 0.f;
     const float* K = s.cst + RB_CST * buf;
     const float* W = K + 7 * RB_CONW;
     if (W[0] != 0.f) {
@@ -1145,6 +1145,7 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
         s.A[la >= lb ? RB_TRI(la, lb) : RB_TRI(lb, la)] += v;
       }
     }
+    if (TID < RB_CST) s.cst[RB_CST * (buf ^ 1) + TID] = next;
     BSYNC();
   }
 }

@@ -222,6 +222,7 @@ class BatchedLockedEnv:
         self._zero_ctrl_rows = (0.5 * (sim.ctrl_lo + sim.ctrl_hi)).repeat(B, 1)   # denormalize_position_control(zero action), absolute
         self.sort_dispatch = bool(sort_dispatch)
         self.stop_on_fall = False    # set by the wrapper stack (StopOnFallWrapper): a dropped cube ends the episode
+        self.launch_flags = 0        # diagnostic: extra rg_step_args.flags of the step launches (e.g. 4: without the per-pair collision cache)
         self._order, self._order_age = None, 0
         self._draws = None           # test hook: [B, RG_POST_NDRAW] draws instead of the counter-based generator
         self._goal_override = None   # test hook / scripted goals: [B, 4]
@@ -433,7 +434,7 @@ class BatchedLockedEnv:
         sim = self.mujoco_simulation
         action = torch.as_tensor(action, dtype=torch.float32, device=self.device).reshape(self.batch_size, self.num_actions).contiguous()
         pipe = self.pipelined_reset
-        sim.env_step(action=action, goal_quat=self._goal_quat, obs=self._obs_buf, goal_dist=self._goal_dist, nforward_ticks=3,
+        sim.env_step(action=action, goal_quat=self._goal_quat, obs=self._obs_buf, goal_dist=self._goal_dist, nforward_ticks=3, flags=self.launch_flags,
                      hold=self._reset_mask if pipe else None, nticks=self._nticks if pipe else None, order=self._dispatch_order(),
                      large_mask=self._reset_mask if pipe else None, small_mask=self._live_mask if pipe else None, preticks=self._preticks)
         a = self._post_args()

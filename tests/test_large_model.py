@@ -127,7 +127,7 @@ def test_large_model_stages_match_oracle_emul(full_model, emul_lib, oracle_lib):
     out = []
     for flg in (0, 4):
         _put(sim, st)
-        sim.env_step(nsubsteps=2, nforward_ticks=0, flags=flg)
+        sim.env_step(nsubsteps=1, nforward_ticks=0, flags=flg)
         out.append((sim.qpos[0].cpu().numpy().copy(), sim.qvel[0].cpu().numpy().copy(), sim.qacc_warmstart[0].cpu().numpy().copy()))
     tvi = sim.qvel_idxs["target"]
     np.testing.assert_allclose(out[0][1][tvi], out[1][1][tvi], rtol=2e-5, atol=2e-6)

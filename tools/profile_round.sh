@@ -16,6 +16,9 @@ python bench.py --steps 20 --warmup 5 --no-cpu-baseline --sort-dispatch 0 > gpur
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$R -o $R --output-format csv -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_prof_$R.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_fetch_$R -o fetch --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/pmc_fetch_$R.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_write_$R -o write --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/pmc_write_$R.log 2>&1
+# the same two PMC passes without the per-pair collision cache (launch flag bit 2): what is left is state rows + register spills
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_fetch_nocache_$R -o fetch --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --launch-flags 4 > gpurun_out/pmc_fetch_nocache_$R.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_write_nocache_$R -o write --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --launch-flags 4 > gpurun_out/pmc_write_nocache_$R.log 2>&1
 python tools/stage_profile.py 8192 > gpurun_out/stage_$R.txt 2>&1
 python tests/tools/parity_report.py 4 1000 > gpurun_out/parity_$R.txt 2>&1
 python bench.py --workload full_perpendicular --steps 5 --warmup 1 > gpurun_out/bench_full_$R.json 2> gpurun_out/bench_full_$R.err
@@ -23,4 +26,5 @@ tail -1 gpurun_out/bench_full_$R.json | cut -c1-300
 python tools/large_stage_profile.py 512 > gpurun_out/large_stage_$R.txt 2>&1
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_full_$R -o full_$R --output-format csv -- python bench.py --workload full_perpendicular --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_full_prof_$R.log 2>&1
 python tools/bench_wrapped.py > gpurun_out/wrapped_$R.txt 2>&1
+bash tools/prof_pmc_large.sh > gpurun_out/pmc_large_$R.txt 2>&1
 ls gpurun_out/prof_$R gpurun_out/pmc_fetch_$R gpurun_out/pmc_write_$R | head -20
