@@ -238,16 +238,17 @@ def test_substep_items_dispatch_is_bit_identical_emul(locked_model, emul_lib):
     rg_step_kernel (one workgroup per env.step, state in LDS / registers): same stages on the same bytes -> same bits."""
     from robogym_amd.envs.dactyl.locked import LockedSimulation
 
-    out, _ = _rollout_both_dispatch_modes(lambda: LockedSimulation(locked_model, 3, device="cpu", lib=emul_lib, n_substeps=3), 8, 0)
+    out, _ = _rollout_both_dispatch_modes(lambda: LockedSimulation(locked_model, 2, device="cpu", lib=emul_lib, n_substeps=3), 7, 0)
     for a, b in zip(*out):
         assert torch.equal(a, b)
-    assert float(out[0][4][:, 3].min()) == 24.0       # 8 env.steps x 3 substeps counted in both modes
+    assert float(out[0][4][:, 3].min()) == 21.0       # 7 env.steps x 3 substeps counted in both modes
     # hand-over in the middle of an env.step (test hook: more than 5 contacts "do not fit"): resumed by the large configuration
     # at the substep where the rollout configuration stopped; same bits as the rollout that was never handed over
     from robogym_amd import _native
-    out2, redone = _rollout_both_dispatch_modes(lambda: LockedSimulation(locked_model, 3, device="cpu", lib=emul_lib, n_substeps=3), 8, 0, flags=_native.RG_FLAG_CAPACITY_TEST_HOOK)
+    out2, redone = _rollout_both_dispatch_modes(lambda: LockedSimulation(locked_model, 2, device="cpu", lib=emul_lib, n_substeps=3), 7, 0, flags=_native.RG_FLAG_CAPACITY_TEST_HOOK)
     for a, b, r in zip(out2[0], out2[1], out[0]):
         assert torch.equal(a, b) and torch.equal(a, r)
+    assert min(redone) > 0                            # (the hook did hand env.steps over)
 
 
 @pytest.mark.gpu
