@@ -346,3 +346,65 @@ def test_full_cube_env_reset_and_steps_match_oracle_gpu(full_model):
     # one env.step of the full cube in fp32 vs fp64 (tests/test_large_model.py: state error median ~5e-4 with the cubelet contacts deciding)
     assert rep["hand"][1] < 2e-3 and rep["tips"][1] < 1e-3 and rep["cube_pos"][1] < 2e-3
     assert rep["dist"][0] < 2e-3 and rep["dist"][1] < 3e-2 and rep["reward"][0] < 3e-3 and rep["reward"][1] < 5e-2
+
+
+def _check_cube_op_properties(full_model, lib, B):
+    """Size-independent properties of the CubeManipulator kernels on B differently scrambled cubes: a face turn and its inverse cancel,
+    four quarter turns are the identity, soft_align_faces is idempotent and leaves signed permutation matrices, a scramble keeps every
+    cubelet in a place of its own -- and nothing outside the cube's 66 joints is touched."""
+    from robogym_amd.envs.dactyl.full_perpendicular import scramble_euler
+
+    env = _make_env(full_model, B, lib)
+    sim = env.sim
+    cm = co.CubeModel(full_model, "cube:")
+    rng = np.random.RandomState(7)
+    block = np.zeros((B, 66))
+    block[:, 6:] = scramble_euler(sim.cube_tab_np, rng.randint(12, size=(B, 30)))
+    block[:, :6] = rng.randint(-2, 3, size=(B, 6)) * (np.pi / 2)
+    q0 = sim.qpos.clone()
+    q0[:, sim.cube_col:sim.cube_col + 66] = torch.as_tensor(block, dtype=torch.float32)
+    sim.qpos.copy_(q0)
+    T = torch.as_tensor
+    eul = lambda q: q[:, sim.cube_col + 6:sim.cube_col + 66].reshape(B, 20, 3)
+
+    def mats(q):
+        e = eul(q).double().cpu().numpy()                                       # (block order = joint order = cm.euler_q sorted by address)
+        return np.array([[co.euler2mat(x) for x in row] for row in e[: min(B, 64)]])
+    m0 = mats(sim.qpos)
+    axis, side, ang = rng.randint(3, size=B), rng.randint(2, size=B), rng.uniform(-0.7, 0.7, size=B)
+    ops = np.zeros((B, 2, 4)); ops[:, :, 0] = axis[:, None]; ops[:, :, 1] = side[:, None]; ops[:, 0, 2] = ang; ops[:, 1, 2] = -ang
+    sim.cube_ops("cube", T(ops, dtype=torch.float32))
+    sim.sync()
+    np.testing.assert_allclose(mats(sim.qpos), m0, atol=5e-6)                   # turn, then the inverse turn
+    np.testing.assert_allclose(sim.qpos[:, sim.cube_col:sim.cube_col + 6].cpu().numpy(), block[:, :6], atol=5e-6)
+    ops = np.zeros((B, 4, 4)); ops[:, :, 0] = axis[:, None]; ops[:, :, 1] = side[:, None]; ops[:, :, 2] = np.pi / 2
+    sim.cube_ops("cube", T(ops, dtype=torch.float32))
+    sim.sync()
+    np.testing.assert_allclose(mats(sim.qpos), m0, atol=1e-5)                   # four quarter turns
+    align = torch.zeros((B, 1, 4)); align[:, 0, 3] = 2
+    ops = np.zeros((B, 1, 4)); ops[:, 0, 0] = axis; ops[:, 0, 1] = side; ops[:, 0, 2] = rng.uniform(-0.6, 0.6, size=B)
+    sim.cube_ops("cube", T(ops, dtype=torch.float32))                           # a face off by < 45 degrees ...
+    sim.cube_ops("cube", align)                                                 # ... aligned ...
+    sim.sync()
+    q1 = sim.qpos.clone()
+    np.testing.assert_allclose(mats(q1), m0, atol=1e-5)                         # ... is back where it was
+    sim.cube_ops("cube", align)
+    sim.sync()
+    np.testing.assert_allclose(mats(sim.qpos), mats(q1), atol=1e-6)             # idempotent (as rotations: +pi and -pi are the same hinge angle, fp32 pi / 2 is 4e-8 off)
+    np.testing.assert_allclose(sim.qpos[:, sim.cube_col:sim.cube_col + 6].cpu().numpy(), q1[:, sim.cube_col:sim.cube_col + 6].cpu().numpy(), atol=1e-6)
+    e = eul(sim.qpos).double().cpu().numpy()
+    c, s_ = np.cos(e), np.sin(e)
+    assert np.abs(np.minimum(np.abs(c), np.abs(s_))).max() < 1e-6              # every hinge at a multiple of 90 degrees
+    other = torch.ones(sim.nq, dtype=torch.bool); other[sim.cube_col:sim.cube_col + 66] = False
+    assert torch.equal(sim.qpos[:, other].cpu(), q0[:, other].cpu())
+    where = np.round(np.einsum("bkij,kj->bki", mats(sim.qpos), cm.coords[np.argsort(cm.euler_q[:, 0])])).astype(int)
+    assert all(len({tuple(x) for x in w}) == 20 for w in where)
+
+
+def test_cube_op_properties_emul(full_model, emul_lib):
+    _check_cube_op_properties(full_model, emul_lib, 6)
+
+
+@pytest.mark.gpu
+def test_cube_op_properties_full_batch_gpu(full_model):
+    _check_cube_op_properties(full_model, None, 4096)
