@@ -173,6 +173,13 @@ class LockedEnvConstants:
     cube_position_wiggle_std: float = 0.005
 
 
+# With pipelined resets the envs inside the reset recipe go through the substep-granular dispatch like everybody else (rollout capacities, scripted ctrl by
+# `hold`, per-env forward ticks; an env.step that exceeds the capacities -- the cube landing in the closing hand -- is handed over MID-STEP to the large
+# configuration, flags bit 8).  RG_PIPE_ITEMS=0 restores round 2's routing: the recipe's envs in a large-configuration launch on a side stream beside a
+# classic rollout launch (1.35 M vs 1.59 M env-steps/s over bench.py --pipelined-reset --steps 60 --warmup 40).
+_PIPE_ITEMS = os.environ.get("RG_PIPE_ITEMS", "1") == "1"
+
+
 class BatchedLockedEnv:
     """B independent dactyl/locked envs stepped in lock-step on one GPU.
 
@@ -381,7 +388,7 @@ class BatchedLockedEnv:
         """Longest-expected-first dispatch (rg_step_args.order_dev): the envs sorted by the cycles their previous
         env.step took, so the launch's tail is made of short envs.  Re-sorted every step (every 4th: -1.3 %; RG_SORT_EVERY overrides)."""
         from robogym_amd.mujoco import simulation_interface as _si
-        if _si.SUBSTEP_ITEMS and not self.pipelined_reset and not self.mujoco_simulation._emul:
+        if _si.SUBSTEP_ITEMS and (not self.pipelined_reset or _PIPE_ITEMS) and not self.mujoco_simulation._emul:
             return None      # (the substep-granular dispatch keeps the slots full whatever the order: sorting measured +-0, profiles/r03_ab.txt)
         if not self.sort_dispatch:
             return None
@@ -436,7 +443,7 @@ class BatchedLockedEnv:
         pipe = self.pipelined_reset
         sim.env_step(action=action, goal_quat=self._goal_quat, obs=self._obs_buf, goal_dist=self._goal_dist, nforward_ticks=3, flags=self.launch_flags,
                      hold=self._reset_mask if pipe else None, nticks=self._nticks if pipe else None, order=self._dispatch_order(),
-                     large_mask=self._reset_mask if pipe else None, small_mask=self._live_mask if pipe else None, preticks=self._preticks)
+                     large_mask=self._reset_mask if (pipe and not _PIPE_ITEMS) else None, small_mask=self._live_mask if (pipe and not _PIPE_ITEMS) else None, preticks=self._preticks)
         a = self._post_args()
         stream = None if sim._emul else ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         _native.check(sim._L, sim._L.rg_env_post_step(sim._bh, ctypes.byref(a), stream), "rg_env_post_step")
