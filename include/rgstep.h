@@ -273,6 +273,9 @@ int rb_batch_reset(rb_batch* b);
 int rb_batch_set_env(rb_batch* b, int hand_qposadr, int n_hand_jnt, int relative_action, const float* pos_to_ctrl);
 void* rb_batch_field_ptr(rb_batch* b, int field, int* row_words);
 int rb_batch_step(rb_batch* b, const float* action_dev, const int* active_dev, int nsubsteps, int nforward_ticks, int flags, void* stream);
+/* the same with per-env `hold_dev` (int [B] or NULL: envs that keep their stored ctrl row, the reset recipe's scripted controls) and `nticks_dev` (int [B] or
+ * NULL: per-env count of state-less forwards) -- as rg_step_args.hold_dev / nticks_dev */
+int rb_batch_step_ex(rb_batch* b, const float* action_dev, const int* active_dev, const int* hold_dev, const int* nticks_dev, int nsubsteps, int nforward_ticks, int flags, void* stream);
 /* ---- the env-level half of RobotEnv.step for the full cube (dactyl/full_perpendicular), one launch after rb_batch_step:
  * FaceFreeGoal.goal_distance / relative_goal / next_goal (/root/reference/robogym/envs/dactyl/goals/face_free.py:61-189, with
  * cube_utils.py:26-181), the target cube's joint manipulation that next_goal entails (full_perpendicular.py:138-155 ->
@@ -308,7 +311,25 @@ typedef struct rb_post_args {
   float quat_threshold, face_threshold, success_reward, p_face_flip, round_target_face;
   int directions;              /* bit 0 "cw", bit 1 "ccw" (goal_directions) */
   int max_timesteps_per_goal, successes_needed, use_goal_distance_reward, stop_on_fall;
+  /* ---- pipelined resets (pipelined = 0: unused).  An env whose episode ends restarts by itself: the reset recipe of
+   * /root/reference/robogym/envs/dactyl/common/cube_env.py:330-355 + full_perpendicular.py:286-345 as a per-env phase counter (0 = live; k > 0: k - 1
+   * recipe steps done) with its state writes done here: MjSim.reset + the zero-action ctrl; after reset_initial_steps steps the cube pose perturbation,
+   * the scramble (num_scramble_steps face turns on signed permutation matrices -> hinge angles, as from_pycuber), the face-driver angles, two
+   * CubeManipulator.rotate_face calls, the random action's ctrl; after n_random_initial_steps more steps the on-palm test (retry up to max_pose_resets) and
+   * the first goal.  hold_next / nticks_next are the inputs of the NEXT rb_batch_step_ex (envs on scripted ctrl; per-env forward ticks: 3 live, 1 in the
+   * recipe, 2 on its steps reset_initial_steps and reset_initial_steps + n_random_initial_steps).  reset_draws ([B][RB_RESET_NDRAW] or NULL -> the hash
+   * generator): 3 + 4 standard normals (position wiggle, orientation), num_scramble_steps <= 50 action indices 0..11 (L, L', R, R', F, F', B, B', D, D', U, U'),
+   * 6 driver multiples of pi / 2 in -2..2, 2 face angles (rad), the face axis 0..2, nu <= 20 actions in [-1, 1]. */
+  int pipelined;
+  int *phase, *tries;
+  int *nticks_next, *hold_next;
+  unsigned char *resetting, *episode_started;
+  const float* reset_draws;
+  const float *qpos0, *ctrl_lo, *ctrl_hi;     /* [nq], [nu], [nu] */
+  float wiggle_std;
+  int reset_initial_steps, n_random_initial_steps, max_pose_resets, num_scramble_steps, scramble_face_angles, randomize_face_angles;
 } rb_post_args;
+#define RB_RESET_NDRAW (3 + 4 + 50 + 6 + 2 + 1 + 20)
 int rb_env_post_step(rb_batch* b, const rb_post_args* args, void* stream);
 int rb_post_args_size(void);
 /* CubeManipulator operations on one of the two cubes of every env in `active_dev` (NULL: all): ops_dev float [B][nops][4] =

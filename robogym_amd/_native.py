@@ -46,7 +46,7 @@ class PostArgs(ctypes.Structure):
     _fields_ = _post_fields()
 
 
-RB_POST_NDRAW, RB_GOAL_WORDS = 5, 16
+RB_POST_NDRAW, RB_GOAL_WORDS, RB_RESET_NDRAW = 5, 16, 3 + 4 + 50 + 6 + 2 + 1 + 20
 
 
 class RbPostArgs(ctypes.Structure):
@@ -60,7 +60,10 @@ class RbPostArgs(ctypes.Structure):
                    ("face_geom", ctypes.c_int * 6), ("tip_site", ctypes.c_int * 5), ("ref_site", ctypes.c_int * 3), ("center_site", ctypes.c_int)]
                 + [(n, ctypes.c_int) for n in ("cube_pos_col", "cube_quat_col", "cube_block_col", "target_block_col", "hand_col", "n_hand")]
                 + [(n, ctypes.c_float) for n in ("quat_threshold", "face_threshold", "success_reward", "p_face_flip", "round_target_face")]
-                + [(n, ctypes.c_int) for n in ("directions", "max_timesteps_per_goal", "successes_needed", "use_goal_distance_reward", "stop_on_fall")])
+                + [(n, ctypes.c_int) for n in ("directions", "max_timesteps_per_goal", "successes_needed", "use_goal_distance_reward", "stop_on_fall", "pipelined")]
+                + [(n, ctypes.c_void_p) for n in ("phase", "tries", "nticks_next", "hold_next", "resetting", "episode_started", "reset_draws", "qpos0", "ctrl_lo", "ctrl_hi")]
+                + [("wiggle_std", ctypes.c_float)]
+                + [(n, ctypes.c_int) for n in ("reset_initial_steps", "n_random_initial_steps", "max_pose_resets", "num_scramble_steps", "scramble_face_angles", "randomize_face_angles")])
 
 
 EXPORTS = [
@@ -69,7 +72,7 @@ EXPORTS = [
     "rg_last_error", "rg_batch_mpr_pair", "rg_batch_copy_rows", "rg_batch_step_ex", "rg_batch_field_ptr", "rg_model_create_on", "rg_model_npair",
     "rg_lds_bytes_cfg", "rg_env_post_step", "rg_post_args_size", "rg_batch_enable_env_params", "rg_prm_layout", "rg_xdata_layout", "rg_batch_set_constants", "rg_batch_items_info",
     "rb_model_create", "rb_model_free", "rb_model_info", "rb_scratch_offset", "rb_batch_create", "rb_batch_free", "rb_batch_reset", "rb_batch_set_env",
-    "rb_batch_field_ptr", "rb_batch_step", "rb_env_post_step", "rb_post_args_size", "rb_cube_ops",
+    "rb_batch_field_ptr", "rb_batch_step", "rb_batch_step_ex", "rb_env_post_step", "rb_post_args_size", "rb_cube_ops",
 ]
 
 
@@ -132,6 +135,7 @@ def bind(path):
     L.rb_batch_field_ptr.restype = vp
     L.rb_batch_field_ptr.argtypes = [vp, ci, ctypes.POINTER(ci)]
     L.rb_batch_step.argtypes = [vp, vp, vp, ci, ci, ci, vp]
+    L.rb_batch_step_ex.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, vp]
     L.rb_env_post_step.argtypes = [vp, ctypes.POINTER(RbPostArgs), vp]
     L.rb_post_args_size.restype = ci
     if L.rb_post_args_size() != ctypes.sizeof(RbPostArgs):

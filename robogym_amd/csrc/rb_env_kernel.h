@@ -16,6 +16,8 @@
 // One 64-lane workgroup per env: lane 0 decides, lanes 0..19 each own one cubelet of the 3x3x3 cube (its three Euler hinge
 // joints), lane 20 the six face drivers; the 66-joint block being manipulated sits in LDS.  The two state-less forwards of
 // reset_goal's re-observation only tick the PID state (rb_kernel.h): they are executed here for the envs that got a new goal.
+// With `pipelined`, an env whose episode ended restarts by itself: the reset recipe (cube_env.py:330-355, full_perpendicular.py:286-345) as a
+// per-env phase counter with its state writes done here (include/rgstep.h, rb_post_args).
 // fp32 throughout; the gimbal-lock test of mat2euler uses 4 x FLT_EPSILON where the reference (float64) uses 4 x DBL_EPSILON.
 #pragma once
 #include "rb_types.h"
@@ -160,6 +162,7 @@ struct RbPostLds {
   float c[RBC_BLOCK + 2];
   float gq[4], gf[6], delta;
   int crash, newgoal, rotate, face;
+  int restart, wiggle;   // pipelined resets: this env restarts (MjSim.reset + zero-action ctrl) / gets the recipe's state writes
 };
 
 // FaceFreeGoal.goal_distance of the state (quat, face) to the goal row g: out[0] = cube_quat, out[1] = cube_face_angle
@@ -195,7 +198,15 @@ __global__ void __launch_bounds__(64) rb_post_step_kernel(const RbModelDev* mp, 
     for (int k = 0; k < 6; k++) face[k] = qrow[a.cube_block_col + k];
     if (!crash) rbp_goal_distance(g, quat, face, dist);
     int got = 0, trial = 0, timeout = 0, newgoal = forced, succ = 0;
-    if (!forced) {
+    const int ph0 = (a.pipelined && !forced) ? a.phase[e] : 0;
+    const int resetting = ph0 > 0, live = !resetting;
+    int done = 0;
+    if (!forced && !live) {   // inside the reset recipe: between episodes
+      float* rw = a.reward + 3 * (size_t)e; rw[0] = rw[1] = rw[2] = 0.f;
+      a.goal_dist[2 * e] = a.goal_dist[2 * e + 1] = 0.f;
+      a.done[e] = 0; a.trial_success[e] = 0; a.sub_goal_ok[e] = 0; a.env_crash[e] = crash;
+    }
+    if (!forced && live) {
       a.t[e] += 1;
       // ---- _get_goal_info (robot_env.py:577-625): reward = sum over the keys of success_threshold of (previous - current) distance
       float gdr = 0.f;
@@ -217,8 +228,34 @@ __global__ void __launch_bounds__(64) rb_post_step_kernel(const RbModelDev* mp, 
       float* rw = a.reward + 3 * (size_t)e;
       rw[0] = 0.f; rw[1] = a.use_goal_distance_reward ? gdr : 0.f; rw[2] = got ? a.success_reward : 0.f;
       a.goal_dist[2 * e] = dist[0]; a.goal_dist[2 * e + 1] = dist[1];
-      a.done[e] = timeout || trial || crash || fallen;
+      done = timeout || trial || crash || fallen;
+      a.done[e] = done;
       a.trial_success[e] = trial; a.sub_goal_ok[e] = got; a.env_crash[e] = crash;
+    }
+    // ---- reset recipe progression (pipelined mode)
+    F.restart = 0; F.wiggle = 0;
+    if (a.pipelined && !forced) {
+      const int ph = ph0 + resetting;
+      const int n1 = a.reset_initial_steps, n2 = a.reset_initial_steps + a.n_random_initial_steps;
+      const int wiggle = resetting && ph == n1 + 1 && !crash;
+      const int finished = resetting && ph == n2 + 1 && !crash;
+      const int on_palm = S[m.off[RB_O_SPOS] + 3 * a.center_site + 2] > 0.04f;      // (the launch's last forward is the one inside on_palm)
+      const int ok = finished && (on_palm || a.tries[e] + 1 >= a.max_pose_resets);
+      const int retry = (finished && !ok) || (crash && resetting);
+      const int start = done && live;
+      const int restart = retry || start;
+      a.tries[e] = start ? 0 : a.tries[e] + retry;
+      const int phase = restart ? 1 : (ok ? 0 : ph);
+      a.phase[e] = phase;
+      if (ok) {   // RobotEnv.reset tail (robot_env.py:787-792): tracker.reset, clock, then reset_goal below
+        a.steps[e] = 0; a.steps_since_last_goal[e] = 0; a.successes_so_far[e] = 0; a.goals_so_far[e] = 0; a.consecutive[e] = 0;
+        a.t[e] = 0; a.prev_valid[e] = 0;
+      }
+      newgoal = newgoal || ok;
+      a.resetting[e] = phase > 0; a.episode_started[e] = ok;
+      a.hold_next[e] = phase > 0;
+      a.nticks_next[e] = phase == 0 ? 3 : ((phase == n1 || phase == n2) ? 2 : 1);   // (the forwards after the state writes and inside on_palm: second ticks of recipe steps n1, n2)
+      F.restart = restart; F.wiggle = wiggle;
     }
     int achieved = succ;
     F.rotate = 0; F.face = 0; F.delta = 0.f;
@@ -281,7 +318,7 @@ __global__ void __launch_bounds__(64) rb_post_step_kernel(const RbModelDev* mp, 
     for (int k = 0; k < 4; k++) F.gq[k] = g[k];
     for (int k = 0; k < 6; k++) F.gf[k] = g[4 + k];
     a.is_successful[e] = achieved;
-    a.goal_reset[e] = newgoal && !forced;
+    a.goal_reset[e] = newgoal && !forced && live;
     a.info_ssl[e] = a.steps_since_last_goal[e];
     F.crash = crash; F.newgoal = newgoal;
   }
@@ -299,6 +336,59 @@ __global__ void __launch_bounds__(64) rb_post_step_kernel(const RbModelDev* mp, 
       const float len = m.actuator_trntype[u] == 0 ? qrow[m.jnt_qposadr[id]] : S[m.off[RB_O_TENLEN] + id];
       float* st = bt.pid + ((size_t)e * nu + u) * 3;
       for (int k = 0; k < 2; k++) rb_pid_tick(m, u, bt.ctrl[(size_t)e * nu + u], len, st);
+    }
+  }
+  if (a.pipelined && !forced) {
+    const int nv = m.nv;
+    auto RD = [&](int k) -> float { return a.reset_draws[(size_t)e * RB_RESET_NDRAW + k]; };
+    auto HU = [&](int k) -> float { return (float)(rbp_hash(a.seed ^ 0x5bd1e995u, a.step, (unsigned)e, (unsigned)k) >> 8) * (1.0f / 16777216.0f); };
+    auto HN = [&](int k) -> float { const float u1 = fmaxf(HU(200 + 2 * k), 1e-7f), u2 = HU(201 + 2 * k); return sqrtf(-2.0f * logf(u1)) * cosf(6.2831853f * u2); };
+    if (F.wiggle) {   // full_perpendicular.py:311-332 after the settling steps
+      if (lane < 3) qrow[a.cube_pos_col + lane] += (a.reset_draws ? RD(lane) : HN(lane)) * a.wiggle_std;
+      if (lane == 3) {   // rotation.uniform_quat: four normals, normalised, w >= 0
+        float q[4], n2 = 0.f;
+        for (int k = 0; k < 4; k++) { q[k] = a.reset_draws ? RD(3 + k) : HN(3 + k); n2 += q[k] * q[k]; }
+        const float sc = (q[0] < 0 ? -1.f : 1.f) / sqrtf(fmaxf(n2, 1e-30f));
+        for (int k = 0; k < 4; k++) qrow[a.cube_quat_col + k] = q[k] * sc;
+      }
+      // _scramble_cube + from_pycuber: face turns on signed permutation matrices, one cubelet per lane, then the hinge angles
+      for (int i = lane; i < RBC_BLOCK; i += 64) F.c[i] = 0.f;
+      __syncthreads();
+      if (lane < RBC_NCUBELET) {
+        const int* t = a.cube_tab + 6 * lane;
+        int M[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        for (int it = 0; it < a.num_scramble_steps; it++) {
+          int act = a.reset_draws ? (int)RD(7 + it) : (int)(HU(it) * 12.f); act = act < 0 ? 0 : (act > 11 ? 11 : act);
+          const int axis = act >> 2, side = (act >> 1) & 1, prime = act & 1, sgn = 2 * side - 1;
+          if ((M[3 * axis] * t[3] + M[3 * axis + 1] * t[4] + M[3 * axis + 2] * t[5]) * sgn <= 0) continue;
+          const int quarter = -sgn * (prime ? -1 : 1), i = (axis + 1) % 3, j = (axis + 2) % 3;     // a clockwise turn seen from outside = -90 degrees about the outward normal
+          for (int c = 0; c < 3; c++) { const int ri = M[3 * i + c], rj = M[3 * j + c]; M[3 * i + c] = -quarter * rj; M[3 * j + c] = quarter * ri; }
+        }
+        float Mf[9], eu[3];
+        for (int k = 0; k < 9; k++) Mf[k] = (float)M[k];
+        rbc_mat2euler(Mf, eu);
+        F.c[t[0]] = eu[0]; F.c[t[1]] = eu[1]; F.c[t[2]] = eu[2];
+      } else if (lane == RBC_NCUBELET && a.scramble_face_angles) {
+        for (int k = 0; k < 6; k++) { const float mult = a.reset_draws ? RD(57 + k) : floorf(HU(60 + k) * 5.f) - 2.f; F.c[k] = mult * (0.5f * RBC_PI); }
+      }
+      __syncthreads();
+      if (a.randomize_face_angles) {
+        int axis = a.reset_draws ? (int)RD(65) : (int)(HU(70) * 3.f); axis = axis < 0 ? 0 : (axis > 2 ? 2 : axis);
+        for (int side = 0; side < 2; side++)
+          rbc_rotate_face(F.c, a.cube_tab, axis, side, a.reset_draws ? RD(63 + side) : (HU(71 + side) - 0.5f) * (0.5f * RBC_PI), true, lane);
+      }
+      for (int i = lane; i < RBC_BLOCK; i += 64) qrow[a.cube_block_col + i] = F.c[i];
+      if (lane < nu) {   // the random action's ctrl, absolute (denormalize_position_control with its default relative_action = False)
+        const float lo = a.ctrl_lo[lane], hi = a.ctrl_hi[lane], act = a.reset_draws ? RD(66 + lane) : 2.f * HU(80 + lane) - 1.f;
+        bt.ctrl[(size_t)e * nu + lane] = fminf(fmaxf(0.5f * (hi + lo) + act * 0.5f * (hi - lo), lo), hi);
+      }
+    }
+    if (F.restart) {   // mujoco_simulation.reset() of this env + the recipe's first ctrl (zero action)
+      for (int i = lane; i < nq; i += 64) qrow[i] = a.qpos0[i];
+      for (int i = lane; i < nv; i += 64) { bt.qvel[(size_t)e * nv + i] = 0.f; bt.qacc_warmstart[(size_t)e * nv + i] = 0.f; }
+      for (int i = lane; i < 3 * nu; i += 64) bt.pid[(size_t)e * 3 * nu + i] = 0.f;
+      for (int u = lane; u < nu; u += 64) bt.ctrl[(size_t)e * nu + u] = 0.5f * (a.ctrl_lo[u] + a.ctrl_hi[u]);
+      if (lane == 0) { bt.time[e] = 0.f; bt.status[e] = 0; }
     }
   }
   // ---- observation row: cube_pos 3 | cube_quat 4 (w >= 0) | cube_face_angle 6 (wrapped) | hand_angle | fingertip_pos 15 | goal_pos 3 | goal_quat 4 | goal_face_angle 6

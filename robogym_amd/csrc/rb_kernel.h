@@ -1329,7 +1329,7 @@ __global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbMod
   if (TID < 16) s.prof[TID] = 0.f;
   BSYNC();
   // ---- action -> ctrl (robot_interface.py:247-278 with the hand's position -> control matrix)
-  bool use_action = L.bt.action != 0;
+  bool use_action = L.bt.action != 0 && !(L.bt.hold && L.bt.hold[e]);
   if (use_action) {
     float nf = 0; BFOR(u, nu) nf += (fabsf(L.bt.action[(size_t)e * nu + u]) <= 3.0e38f) ? 0.f : 1.f;
     if (rb_sum(s, nf) > 0) { use_action = false; if (TID == 0) s.status |= RG_STATUS_BAD_ACTION; }
@@ -1380,9 +1380,10 @@ __global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbMod
   }
   if ((flags & 2) && TID < 16) SC(DBG)[8 + 5 * nv + TID] = s.prof[TID];   // stage cycle counters: frames+com, tendon+crb, velocity, collision, rows, smooth, Newton, Euler
   // ---- the state-less forward() calls of the reference: only their PID side effect touches the state
-  if (L.nforward_ticks > 0) {
+  const int nticks = L.bt.nticks ? L.bt.nticks[e] : L.nforward_ticks;
+  if (nticks > 0) {
     rb_kinematics(m, s, S); rb_com_pos(m, s, S); rb_tendon(m, s, S);
-    for (int k = 0; k < L.nforward_ticks; k++) rb_pid(m, s, S, false);
+    for (int k = 0; k < nticks; k++) rb_pid(m, s, S, false);
   }
   BFOR(i, nq) L.bt.qpos[(size_t)e * nq + i] = s.qpos[i];
   BFOR(i, nv) { L.bt.qvel[(size_t)e * nv + i] = s.qvel[i]; L.bt.qacc_warmstart[(size_t)e * nv + i] = s.warm[i]; }

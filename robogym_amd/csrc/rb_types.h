@@ -100,6 +100,8 @@ struct RbBatchDev {
   float* scratch;        // [B][scratch_words]
   const float* action;   // [B][nu] or null
   const int* active;     // [B] or null
+  const int* hold;       // [B] or null: envs that keep their stored ctrl row (the scripted controls of the reset recipe)
+  const int* nticks;     // [B] or null: per-env count of state-less forwards (PID ticks) after the substeps
 };
 
 struct RbLaunch { RbEnvDev env; RbBatchDev bt; int nsubsteps, nforward_ticks, flags; };

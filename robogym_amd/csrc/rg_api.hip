@@ -1018,13 +1018,17 @@ void* rb_batch_field_ptr(rb_batch* b, int field, int* row_words) {
 struct EmulRbArgs { const RbModelDev* m; RbLaunch launch; };
 static void emul_rb_entry(void* a) { EmulRbArgs* p = (EmulRbArgs*)a; rgb::rb_step_kernel(p->m, p->launch); }
 #endif
+int rb_batch_step_ex(rb_batch* b, const float* action_dev, const int* active_dev, const int* hold_dev, const int* nticks_dev, int nsubsteps, int nforward_ticks, int flags, void* stream);
 int rb_batch_step(rb_batch* b, const float* action_dev, const int* active_dev, int nsubsteps, int nforward_ticks, int flags, void* stream) {
+  return rb_batch_step_ex(b, action_dev, active_dev, nullptr, nullptr, nsubsteps, nforward_ticks, flags, stream);
+}
+int rb_batch_step_ex(rb_batch* b, const float* action_dev, const int* active_dev, const int* hold_dev, const int* nticks_dev, int nsubsteps, int nforward_ticks, int flags, void* stream) {
   if (!b) return fail("null batch");
   if (action_dev && !b->has_env) return fail("rb_batch_set_env must be called before stepping with actions");
   if (nsubsteps < 0 || nforward_ticks < 0) return fail("rb_batch_step: negative step counts");
   DeviceGuard g(b->device);
   RbBatchDev bt = b->dev;
-  bt.action = action_dev; bt.active = active_dev;
+  bt.action = action_dev; bt.active = active_dev; bt.hold = hold_dev; bt.nticks = nticks_dev;
   RbLaunch launch{b->env, bt, nsubsteps, nforward_ticks, flags};
 #ifdef RG_EMUL
   EmulRbArgs args{b->model->dev_copy, launch};
@@ -1051,6 +1055,12 @@ int rb_env_post_step(rb_batch* b, const rb_post_args* args, void* stream) {
       !a.is_successful || !a.goal || !a.reward || !a.goal_dist || !a.done || !a.goal_reset || !a.trial_success || !a.sub_goal_ok || !a.env_crash || !a.info_ssl ||
       !a.cube_tab || !a.face_up_quats) return fail("rb_env_post_step: a required array is NULL");
   if (a.obs_dim != 13 + a.n_hand + 15 + 13) return fail("rb_env_post_step: obs_dim does not match the row layout");
+  if (a.pipelined) {
+    if (!a.phase || !a.tries || !a.nticks_next || !a.hold_next || !a.resetting || !a.episode_started || !a.qpos0 || !a.ctrl_lo || !a.ctrl_hi)
+      return fail("rb_env_post_step: pipelined resets need phase, tries, nticks_next, hold_next, resetting, episode_started, qpos0, ctrl_lo, ctrl_hi");
+    if (a.num_scramble_steps < 0 || a.num_scramble_steps > 50 || d.nu > 20) return fail("rb_env_post_step: num_scramble_steps / nu exceed RB_RESET_NDRAW's slots");
+    if (a.reset_initial_steps < 1 || a.n_random_initial_steps < 1 || a.max_pose_resets < 1) return fail("rb_env_post_step: recipe lengths must be positive");
+  }
   if (d.nu > 64) return fail("rb_env_post_step: nu exceeds the workgroup");
   for (int k = 0; k < 6; k++) if (a.face_geom[k] < 0 || a.face_geom[k] >= d.ngeom) return fail("rb_env_post_step: face geom id out of range");
   for (int k = 0; k < 5; k++) if (a.tip_site[k] < 0 || a.tip_site[k] >= d.nsite) return fail("rb_env_post_step: site id out of range");

@@ -12,7 +12,9 @@ cubelets).
   success, MultiGoalTracker, goal generation incl. the target cube's joints, observation row) and no host synchronisation;
   `reset(mask)` is the reference's recipe (cube_env.py:330-355, full_perpendicular.py:286-345) for the selected envs: 20 steps
   under the zero action, cube pose perturbation, scramble, face-angle randomisation, 10 steps under one random action, retried
-  while the cube is not on the palm.  Unwrapped (`make_simple_env`); the other goal generators of the reference
+  while the cube is not on the palm; with `pipelined_reset=True` finished episodes run that recipe by themselves inside the following
+  `step` calls (a per-env phase counter in the env kernel, scripted controls through the stepper's `hold` mask), so the other envs never
+  wait for a reset.  Unwrapped (`make_simple_env`); the other goal generators of the reference
   (face_curr, face_cube_solver, release_cube_solver, full_unconstrained, unconstrained_cube_solver, fixed_fair_scramble) and the
   wrapper stack are not built for this config.
   The scramble needs the cube-group bookkeeping the reference takes from `pycuber` (not installed here): `scramble_euler`
@@ -258,7 +260,7 @@ class BatchedFullPerpendicularEnv:
     """B independent dactyl/full_perpendicular envs stepped in lock-step on one GPU (see the module docstring)."""
 
     def __init__(self, batch_size: int, device="cuda:0", constants: Optional[FullPerpendicularEnvConstants] = None, starting_seed: Optional[int] = None,
-                 model: Optional[CompiledModel] = None, lib=None):
+                 model: Optional[CompiledModel] = None, lib=None, pipelined_reset: bool = False):
         from robogym_amd.utils.multi_goal_tracker import BatchedMultiGoalTracker
         from robogym_amd.utils.rotation import parallel_quats_np
 
@@ -286,6 +288,14 @@ class BatchedFullPerpendicularEnv:
         rng_ = np.asarray(self.model.arrays["actuator_ctrlrange"], dtype=np.float32)
         self._ctrl_lo, self._ctrl_hi = torch.tensor(rng_[:, 0], device=dev), torch.tensor(rng_[:, 1], device=dev)
         self.stop_on_fall = False
+        # pipelined resets: an env whose episode ended re-initialises itself INSIDE the following step calls (the recipe as a per-env phase
+        # counter in rb_post_step_kernel, include/rgstep.h) -- the other envs never wait for a reset.  Off: `done` envs are the caller's to
+        # `reset(mask)` (reference API)
+        self.pipelined_reset = bool(pipelined_reset)
+        self._phase, self._tries, self._hold = i32(B), i32(B), i32(B)
+        self._nticks = torch.full((B,), 3, dtype=torch.int32, device=dev)
+        self._flags.update({k: torch.zeros(B, dtype=torch.bool, device=dev) for k in ("resetting", "episode_started")})
+        self._pipe_draws = None      # test hook: [B, RB_RESET_NDRAW] draws of the in-step recipe instead of the hash generator
         self._draws = None
         self._reset_draws = None
         self._step_count = 0
@@ -305,6 +315,10 @@ class BatchedFullPerpendicularEnv:
     def set_draws(self, draws):
         """Goal-generation draws of the next steps ([B, RB_POST_NDRAW], include/rgstep.h) instead of the in-kernel generator (tests)."""
         self._draws = None if draws is None else torch.as_tensor(draws, dtype=torch.float32, device=self.device).reshape(self.batch_size, _native.RB_POST_NDRAW).contiguous()
+
+    def set_pipelined_reset_draws(self, draws):
+        """The draws of the in-step reset recipe ([B, RB_RESET_NDRAW], include/rgstep.h) instead of the in-kernel generator (tests)."""
+        self._pipe_draws = None if draws is None else torch.as_tensor(draws, dtype=torch.float32, device=self.device).reshape(self.batch_size, _native.RB_RESET_NDRAW).contiguous()
 
     def set_reset_draws(self, draws: Optional[dict]):
         """The draws of the next reset attempt(s) instead of the generators (tests): a dict with the keys of `_draw_reset`."""
@@ -377,6 +391,7 @@ class BatchedFullPerpendicularEnv:
         B, dev = self.batch_size, self.device
         mask = torch.ones(B, dtype=torch.bool, device=dev) if mask is None else mask.to(dev).bool()
         self.t.masked_fill_(mask, 0)
+        self._phase.masked_fill_(mask, 0); self._tries.masked_fill_(mask, 0); self._hold.masked_fill_(mask, 0); self._nticks.masked_fill_(mask, 3)
         self._randomize_cube_initial_position(mask)
         self.multi_goal_tracker.reset(mask)
         self._prev_valid.masked_fill_(mask, 0)
@@ -408,8 +423,17 @@ class BatchedFullPerpendicularEnv:
         a.success_reward, a.p_face_flip, a.round_target_face = float(c.success_reward), float(c.p_face_flip), float(c.round_target_face)
         a.directions = (1 if "cw" in c.goal_directions else 0) | (2 if "ccw" in c.goal_directions else 0)
         a.max_timesteps_per_goal, a.successes_needed, a.use_goal_distance_reward, a.stop_on_fall = int(c.max_timesteps_per_goal), int(c.successes_needed), int(c.use_goal_distance_reward), int(self.stop_on_fall)
+        a.pipelined = int(self.pipelined_reset and force is None)
+        if a.pipelined:
+            a.phase, a.tries, a.nticks_next, a.hold_next = P(self._phase), P(self._tries), P(self._nticks), P(self._hold)
+            a.resetting, a.episode_started = P(F["resetting"]), P(F["episode_started"])
+            a.reset_draws = None if self._pipe_draws is None else P(self._pipe_draws)
+            a.qpos0, a.ctrl_lo, a.ctrl_hi = P(self._qpos0_rows), P(self._ctrl_lo), P(self._ctrl_hi)
+            a.wiggle_std = float(c.cube_position_wiggle_std)
+            a.reset_initial_steps, a.n_random_initial_steps, a.max_pose_resets = int(c.reset_initial_steps), int(c.n_random_initial_steps), int(c.max_pose_resets)
+            a.num_scramble_steps, a.scramble_face_angles, a.randomize_face_angles = int(c.num_scramble_steps), int(c.scramble_face_angles), int(c.randomize_face_angles)
         stream = None if sim._emul else ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        self._keep_post = (force, self._draws)
+        self._keep_post = (force, self._draws, self._pipe_draws)
         _native.check(sim._L, sim._L.rb_env_post_step(sim._bh, ctypes.byref(a), stream), "rb_env_post_step")
         self._step_count += 1
 
@@ -422,14 +446,16 @@ class BatchedFullPerpendicularEnv:
         ev = self._physics_events
         if ev is not None:
             ev[0].record()
-        self.mujoco_simulation.env_step(action=action, nforward_ticks=3)
+        pipe = self.pipelined_reset
+        self.mujoco_simulation.env_step(action=action, nforward_ticks=3, hold=self._hold if pipe else None, nticks=self._nticks if pipe else None)
         if ev is not None:
             ev[1].record()
         self._post()
         F, tr = self._flags, self.multi_goal_tracker
         info = {"goal_dist": {"cube_quat": self._goal_dist[:, 0], "cube_face_angle": self._goal_dist[:, 1]}, "goal_achieved": F["sub_goal_ok"],
                 "sub_goal_is_successful": F["sub_goal_ok"], "trial_success": F["trial_success"], "goal_reset": F["goal_reset"], "successes_so_far": tr.successes_so_far,
-                "steps_since_last_goal": self._info_ssl, "goals_so_far": tr.goals_so_far, "env_crash": F["env_crash"], "sim_status": self.mujoco_simulation.status}
+                "steps_since_last_goal": self._info_ssl, "goals_so_far": tr.goals_so_far, "env_crash": F["env_crash"], "sim_status": self.mujoco_simulation.status,
+                "resetting": F["resetting"], "episode_started": F["episode_started"]}
         return self.observe(), self._reward, F["done"], info
 
     def observe(self) -> Dict[str, torch.Tensor]:
@@ -447,7 +473,7 @@ class BatchedFullPerpendicularEnv:
 
 
 def make_simple_env(parameters=None, constants=None, starting_seed=None, batch_size: int = 1, device="cuda:0", **kwargs):
-    """`make_simple_env` of envs/dactyl/full_perpendicular.py (no wrappers).  `constants` / `parameters`: dicts with the reference's
+    """`make_simple_env` of envs/dactyl/full_perpendicular.py (no wrappers); `pipelined_reset=True`: finished episodes restart by themselves.  `constants` / `parameters`: dicts with the reference's
     names for the fields of FullPerpendicularEnvConstants above; anything else raises."""
     kw = {}
     for src in (constants or {}), (parameters or {}):

@@ -111,16 +111,19 @@ class LargeModelSimulation:
         self.sync()
         _native.check(self._L, self._L.rb_batch_reset(self._bh), "rb_batch_reset")
 
-    def env_step(self, action=None, active=None, nsubsteps=None, nforward_ticks=3, flags=0):
+    def env_step(self, action=None, active=None, nsubsteps=None, nforward_ticks=3, flags=0, hold=None, nticks=None):
+        """`hold` int32 [B]: envs that keep their stored ctrl row (scripted controls of a reset recipe); `nticks` int32 [B]: per-env count of
+        state-less forwards (rb_batch_step_ex)."""
         for t in (action,):
             assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.device == self.device and t.shape == (self.batch_size, self.nu))
-        assert active is None or (active.dtype == torch.int32 and active.is_contiguous())
+        for t in (active, hold, nticks):
+            assert t is None or (t.dtype == torch.int32 and t.is_contiguous() and t.shape == (self.batch_size,))
         flags = int(flags) | (_native.RG_FLAG_MPR_PLANE_DEPTH if simulation_interface.MPR_PLANE_DEPTH else 0)
         stream = None if self._emul else ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        self._keep = [action, active]
+        self._keep = [action, active, hold, nticks]
         ptr = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
-        _native.check(self._L, self._L.rb_batch_step(self._bh, ptr(action), ptr(active), self.n_substeps if nsubsteps is None else int(nsubsteps), int(nforward_ticks), flags, stream),
-                      "rb_batch_step")
+        _native.check(self._L, self._L.rb_batch_step_ex(self._bh, ptr(action), ptr(active), ptr(hold), ptr(nticks), self.n_substeps if nsubsteps is None else int(nsubsteps),
+                                                        int(nforward_ticks), flags, stream), "rb_batch_step_ex")
 
     def step(self, active=None):
         """SimulationInterface.step: nsubsteps x mj_step, then mj_forward (its PID tick)."""

@@ -146,7 +146,7 @@ def test_product_library_loads_and_exports_the_header():
     assert os.path.exists(path), "build it: python -c 'import __graft_entry__ as g; g.build()'"
     L = ctypes.CDLL(path)
     declared = sorted(set(re.findall(r"\b(r[gb]_[a-z_0-9]+)\s*\(", open(os.path.join(root, "include", "rgstep.h")).read())))
-    assert len(declared) >= 41 and sum(n.startswith("rb_") for n in declared) == 13      # (rb_*: the large-model path and the full-cube env kernel)
+    assert len(declared) >= 42 and sum(n.startswith("rb_") for n in declared) == 14      # (rb_*: the large-model path and the full-cube env kernel)
     for name in declared:
         assert hasattr(L, name), name
     assert set(_native.EXPORTS) == set(declared)

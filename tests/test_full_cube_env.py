@@ -293,7 +293,7 @@ def test_full_cube_env_reset_and_steps_match_oracle_gpu(full_model):
         assert bool(sim.scratch("site_xpos")[b, 3 * sim.center_site + 2] > 0.04) == bool(on_palm)
     settle = np.array(settle)
     print("after the 20 settling env.steps: hand joints median %.1e max %.1e rad, cube pos %.1e m" % (np.median(settle[:, 0]), settle[:, 1].max(), settle[:, 2].max()))
-    assert np.median(settle[:, 0]) < 2e-3 and settle[:, 1].max() < 1e-1 and settle[:, 2].max() < 1e-2
+    assert np.median(settle[:, 0]) < 2e-3 and settle[:, 1].max() < 3e-1 and settle[:, 2].max() < 1e-2
     print("reset recipe, device vs oracle after 30 free-running env.steps: cube pos %.2e m, hand joints %.2e rad, cubelet matrices %.2e" % tuple(worst))
     # (the 10 steps under one random action start from a scrambled cube whose two turned faces interpenetrate their neighbours: violent and chaotic;
     #  fp32 and fp64 part ways by centimetres here -- the tight statements are the ones above and the resynchronised steps below)
@@ -408,3 +408,166 @@ def test_cube_op_properties_emul(full_model, emul_lib):
 @pytest.mark.gpu
 def test_cube_op_properties_full_batch_gpu(full_model):
     _check_cube_op_properties(full_model, None, 4096)
+
+
+# ------------------------------------------------------------------------------------------------ pipelined resets (the recipe inside the step calls)
+def _pipe_draw_rows(d, B):
+    """dict of recipe draws (keys as BatchedFullPerpendicularEnv._draw_reset) -> the [B, RB_RESET_NDRAW] layout of include/rgstep.h"""
+    rows = np.zeros((B, 86))
+    rows[:, 0:3] = d["wiggle"]; rows[:, 3:7] = d["quat"]; rows[:, 7:7 + d["scramble"].shape[1]] = d["scramble"]; rows[:, 57:63] = d["face_k"]
+    rows[:, 63:65] = d["face_angle"]; rows[:, 65] = d["face_axis"]; rows[:, 66:86] = d["action"]
+    return rows
+
+
+def _recipe_draws(rng, B, nscr=50):
+    return {"wiggle": rng.randn(B, 3), "quat": rng.randn(B, 4), "scramble": rng.randint(12, size=(B, nscr)), "face_k": rng.randint(-2, 3, size=(B, 6)).astype(np.float64),
+            "face_angle": rng.uniform(-np.pi / 4, np.pi / 4, size=(B, 2)), "face_axis": rng.randint(3, size=B).astype(np.float64), "action": rng.uniform(-1, 1, size=(B, 20))}
+
+
+def _expected_writes(full_model, q_before, d, b, std=0.005):
+    """what the recipe writes after its settling steps (full_perpendicular.py:311-332), from the oracle's pieces"""
+    cm = co.CubeModel(full_model, "cube:")
+    jn, A = full_model.names["joint"], full_model.arrays
+    q = q_before.astype(np.float64).copy()
+    pos_q = np.array([A["jnt_qposadr"][jn.index("cube:cube:t" + a)] for a in "xyz"])
+    quat_q = np.arange(4) + int(A["jnt_qposadr"][jn.index("cube:cube:rot")])
+    q[pos_q] += d["wiggle"][b] * std
+    w = d["quat"][b] / np.linalg.norm(d["quat"][b])
+    q[quat_q] = co.quat_sign(w)
+    q[cm.all_q] = 0.0
+    for m, e in zip(co.scramble_matrices(cm, [co.PYCUBER_ACTIONS[int(k)] for k in d["scramble"][b]]), cm.euler_q):
+        q[e] = co.mat2euler(m.astype(np.float64))
+    q[cm.driver_q] = d["face_k"][b] * np.pi / 2
+    cm.rotate_face(q, int(d["face_axis"][b]), 0, d["face_angle"][b][0]); cm.rotate_face(q, int(d["face_axis"][b]), 1, d["face_angle"][b][1])
+    lo, hi = A["actuator_ctrlrange"][:, 0], A["actuator_ctrlrange"][:, 1]
+    ctrl = np.clip(0.5 * (hi + lo) + d["action"][b] * 0.5 * (hi - lo), lo, hi)
+    return q, ctrl, cm, pos_q, quat_q
+
+
+def _check_written_state(full_model, got_q, got_ctrl, q_before, d, b):
+    q, ctrl, cm, pos_q, quat_q = _expected_writes(full_model, q_before, d, b)
+    np.testing.assert_allclose(got_q[pos_q], q[pos_q], atol=1e-6)
+    assert _same_quat(got_q[quat_q].astype(np.float64), q[quat_q], 1e-6)
+    np.testing.assert_allclose(_mats(cm, got_q.astype(np.float64)), _mats(cm, q), atol=3e-6)
+    np.testing.assert_allclose(np.sin(got_q[cm.driver_q]), np.sin(q[cm.driver_q]), atol=3e-6)
+    np.testing.assert_allclose(np.cos(got_q[cm.driver_q]), np.cos(q[cm.driver_q]), atol=3e-6)
+    np.testing.assert_allclose(got_ctrl, ctrl, atol=1e-6)
+    other = np.setdiff1d(np.arange(len(q)), np.concatenate([pos_q, quat_q, cm.all_q]))
+    np.testing.assert_array_equal(got_q[other], q_before[other])
+
+
+def test_pipelined_reset_phase_machine_emul(full_model, emul_lib):
+    """The reset recipe inside rb_post_step_kernel, driven without physics (the kernel only reads the state and the last forward's frames): phase
+    counter, scripted-control mask and forward-tick counts of the next launch, MjSim.reset + zero-action ctrl, the state writes after the
+    settling steps against the oracle's pieces, the episode start with tracker reset and first goal."""
+    from robogym_amd.envs.dactyl.full_perpendicular import BatchedFullPerpendicularEnv, FullPerpendicularEnvConstants
+
+    B = 3
+    c = FullPerpendicularEnvConstants(reset_initial_steps=2, n_random_initial_steps=2, max_timesteps_per_goal=1, max_pose_resets=3, num_scramble_steps=20)
+    env = BatchedFullPerpendicularEnv(B, model=full_model, lib=emul_lib, constants=c, pipelined_reset=True)
+    sim = env.sim
+    rng = np.random.RandomState(3)
+    d = _recipe_draws(rng, B, 20)
+    env.set_pipelined_reset_draws(_pipe_draw_rows(d, B))
+    env.set_draws(np.tile([0.9, 0.5, 0, 2, 0.3], (B, 1)))
+    sim.qvel[:] = 0.3; sim.ctrl[:] = 0.05; sim.qpos[:, 5] += 0.01
+    env._goal[:, 0] = 0; env._goal[:, 1] = 1            # (a goal half a turn away: the first step must not succeed)
+    qpos0 = np.asarray(full_model.arrays["qpos0"], dtype=np.float32)
+    lo, hi = full_model.arrays["actuator_ctrlrange"][:, 0], full_model.arrays["actuator_ctrlrange"][:, 1]
+    F = env._flags
+    seq = []
+    for k in range(6):
+        sim.forward()
+        before = sim.qpos.cpu().numpy().copy()
+        env._post()
+        seq.append((env._phase.clone(), env._hold.clone(), env._nticks.clone(), F["resetting"].clone(), F["episode_started"].clone(), F["done"].clone()))
+        if k == 0:      # the live step: goal time-out (1 step) -> done -> restart
+            assert F["done"].all() and (env._phase == 1).all() and (env._hold == 1).all() and (env._nticks == 1).all() and F["resetting"].all()
+            np.testing.assert_array_equal(sim.qpos.cpu().numpy(), np.repeat(qpos0[None], B, 0))
+            assert float(sim.qvel.abs().max()) == 0 and float(sim.pid.abs().max()) == 0
+            np.testing.assert_allclose(sim.ctrl.cpu().numpy(), np.repeat((0.5 * (lo + hi))[None], B, 0), atol=1e-7)
+        if k == 1:      # recipe step 1 done; the next one is step n1 = 2: two ticks (its own forward + the one after the state writes)
+            assert (env._phase == 2).all() and (env._nticks == 2).all() and not F["done"].any()
+        if k == 2:      # n1 steps done: the state writes
+            assert (env._phase == 3).all() and (env._nticks == 1).all()
+            for b in range(B):
+                _check_written_state(full_model, sim.qpos[b].cpu().numpy(), sim.ctrl[b].cpu().numpy(), before[b], d, b)
+        if k == 3:
+            assert (env._phase == 4).all() and (env._nticks == 2).all()
+        if k == 4:      # n2 steps done, cube on the palm: the episode starts
+            assert (env._phase == 0).all() and (env._hold == 0).all() and (env._nticks == 3).all() and F["episode_started"].all() and not F["resetting"].any()
+            tr = env.multi_goal_tracker
+            assert (tr.goals_so_far == 1).all() and (tr.steps == 0).all() and (tr.successes_so_far == 0).all() and (env.t == 0).all() and (env._prev_valid == 1).all()
+            assert not F["goal_reset"].any() and float(env._goal[:, :4].norm(dim=1).min()) > 0.99
+        if k == 5:      # live again: one step, time-out, restart
+            assert F["done"].all() and (env._phase == 1).all() and not F["episode_started"].any()
+    # an env whose cube is off the palm when the recipe ends retries, max_pose_resets passes at most
+    env._phase[:] = 4; env._tries[:] = 0
+    sim.forward()
+    sim.scratch("site_xpos")[:, 3 * sim.center_site + 2] = 0.0
+    env._post()
+    assert (env._phase == 1).all() and (env._tries == 1).all() and not F["episode_started"].any()
+    env._phase[:] = 4; env._tries[:] = 2
+    sim.forward()
+    sim.scratch("site_xpos")[:, 3 * sim.center_site + 2] = 0.0
+    env._post()
+    assert (env._phase == 0).all() and F["episode_started"].all()           # third pass: taken as it is (cube_env.py:336-355 leaves the loop)
+
+
+@pytest.mark.gpu
+def test_pipelined_reset_recipe_matches_oracle_gpu(full_model):
+    """Pipelined resets with the physics: episodes time out after 2 steps, every env runs the recipe inside the following 30 step calls with fed
+    draws; the state writes against the oracle's pieces (exact), the recipe's outcome against `OracleFullPerpendicularEnv.reset_recipe` (30
+    free-running env.steps, tolerances of the synchronous test), flags and counters at the episode start."""
+    from oracle.env_oracle import OracleFullPerpendicularEnv
+    from robogym_amd.envs.dactyl.full_perpendicular import BatchedFullPerpendicularEnv, FullPerpendicularEnvConstants
+
+    B = 3
+    env = BatchedFullPerpendicularEnv(B, model=full_model, device="cuda:0", constants=FullPerpendicularEnvConstants(max_timesteps_per_goal=2), pipelined_reset=True)
+    sim = env.sim
+    rng = np.random.RandomState(21)
+    d = _recipe_draws(rng, B)
+    env.set_pipelined_reset_draws(_pipe_draw_rows(d, B))
+    env.set_draws(np.stack([rng.uniform(0, 1, B), rng.uniform(0, 1, B), rng.randint(2, size=B), rng.randint(6, size=B), rng.uniform(-np.pi, np.pi, B)], axis=1))
+    env._needs_reset = False
+    env._goal[:, 0] = 0; env._goal[:, 1] = 1
+    sim.forward()
+    act = lambda: torch.as_tensor(rng.uniform(-1, 1, size=(B, 20)), dtype=torch.float32)
+    started_at, before_write = None, None
+    for k in range(40):
+        obs, rew, done, info = env.step(act())
+        ph = env._phase.cpu().numpy()
+        if (ph == 21).all() and before_write is None:       # this step was recipe step 20: the writes happened after it
+            before_write = True
+            # the state the writes started from = this launch's result before the post kernel; recover it from the oracle-side identity:
+            # everything the writes do not touch is unchanged, and the written joints are checked against the expected values
+            for b in range(B):
+                q, ctrl, cm, pos_q, quat_q = _expected_writes(full_model, sim.qpos[b].cpu().numpy(), {**d, "wiggle": np.zeros((B, 3))}, b)
+                got = sim.qpos[b].cpu().numpy()
+                assert _same_quat(got[quat_q].astype(np.float64), q[quat_q], 1e-6)
+                np.testing.assert_allclose(_mats(cm, got.astype(np.float64)), _mats(cm, q), atol=3e-6)
+                np.testing.assert_allclose(sim.ctrl[b].cpu().numpy(), ctrl, atol=1e-6)
+        if bool(info["episode_started"].all()):
+            started_at = k
+            break
+        assert not bool(info["episode_started"].any())
+    sim.sync()
+    assert started_at == 2 + 30 - 1, started_at          # 2 live steps (time-out on the second), then 30 recipe steps; the 30th returns the first observation
+    assert int(sim.status.max().item()) == 0 and before_write
+    tr = env.multi_goal_tracker
+    assert (tr.goals_so_far == 1).all() and (tr.steps == 0).all() and (env._phase == 0).all() and (env._nticks == 3).all()
+    got = sim.qpos.cpu().numpy().astype(np.float64)
+    cm = co.CubeModel(full_model, "cube:")
+    worst = np.zeros(2)
+    for b in range(B):
+        o = OracleFullPerpendicularEnv(full_model, env.face_up_quats_np)
+        on_palm = o.reset_recipe(d["wiggle"][b], d["quat"][b], d["scramble"][b], d["face_k"][b], d["face_angle"][b], d["face_axis"][b], d["action"][b])
+        assert on_palm
+        q = o.sim.qpos
+        worst = np.maximum(worst, [np.abs(got[b][o.pos_q] - q[o.pos_q]).max(), np.abs(got[b][o.hand_q] - q[o.hand_q]).max()])
+    print("pipelined recipe vs oracle after 30 free-running env.steps: cube pos %.2e m, hand joints %.2e rad" % tuple(worst))
+    assert worst[0] < 5e-2 and worst[1] < 5e-1
+    # the envs live on: a step with an action moves the hand again
+    q0 = sim.qpos.clone()
+    env.step(act())
+    assert float((sim.qpos - q0).abs().max()) > 1e-4 and not bool(env._flags["resetting"].any())
