@@ -88,7 +88,8 @@ def bench_full_perpendicular(args):
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     B = args.batch if args.batch != 8192 else 4096
-    env = BatchedFullPerpendicularEnv(B, device=dev, starting_seed=20200901 + 2)
+    env = BatchedFullPerpendicularEnv(B, device=dev, starting_seed=20200901 + 2, pipelined_reset=args.pipelined_reset)
+    env.stop_on_fall = bool(args.pipelined_reset)      # (with in-step resets a dropped cube ends the episode, as under the reference's StopOnFallWrapper)
     sim, model = env.sim, env.model
     env.constants.max_pose_resets = 6        # (bounded set-up time: envs whose cube is still off the palm after 6 passes of the recipe are stepped as they are)
     env.reset()
@@ -124,7 +125,7 @@ def bench_full_perpendicular(args):
         "value": B * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "dactyl/full_perpendicular (Shadow hand + full Rubik's cube, nv=168, 135 bodies, condim-6 contacts), batch %d, iid U(-1,1) relative actions, 10 substeps x 0.008 s; env.step = physics + env kernel (face_free goals), after the reset recipe with scrambled cubes" % B,
-                   "batch_per_gpu": B, "cube_on_palm_fraction_after_reset": on_palm0, "cube_on_palm_fraction_at_end": on_palm, "goals_so_far_mean": float(env.multi_goal_tracker.goals_so_far.float().mean().item()), "mean_ncon": ncon, "mean_nefc": nefc, "mean_newton_iters": iters, "status_bits": int(sim.status.max().item()), "lds_bytes_per_workgroup": sim.info["lds_bytes"]},
+                   "batch_per_gpu": B, "pipelined_reset": bool(args.pipelined_reset), "cube_on_palm_fraction_after_reset": on_palm0, "cube_on_palm_fraction_at_end": on_palm, "goals_so_far_mean": float(env.multi_goal_tracker.goals_so_far.float().mean().item()), "mean_ncon": ncon, "mean_nefc": nefc, "mean_newton_iters": iters, "status_bits": int(sim.status.max().item()), "lds_bytes_per_workgroup": sim.info["lds_bytes"]},
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None, "kernel": "rb_step_kernel", "kernel_ms": kern_ms,
                      "algorithmic_bytes_per_env_step": b_step, "algorithmic_bytes_per_substep": b_sub,
                      "note": "SURVEY 8(d) byte model with this model's dimensions (nM 1193) and the run's measured ncon / nefc / iterations; first, clarity-first version of the kernel"},
