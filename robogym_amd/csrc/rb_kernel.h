@@ -479,52 +479,78 @@ __device__ __forceinline__ void rb_group_solve(RbM m, RbLds& s, int g, const flo
   BSYNC();
 }
 
-// "Star" groups (big_tables.py b_star_*: one tree, a root body's <= 6 dofs with hinge chains of <= 3 dofs hanging off them, no contact
-// pair, no tendon -- the target cube): every matrix the step needs to invert on such a group (M, M + h B, the Newton Hessian M + a
-// diagonal) has M's tree sparsity, [[R, C'], [C, blockdiag(B_k)]] in (root | chains) order.  Block elimination instead of a dense
-// factorisation: thread k factors its chain's B_k = L L' (<= 3 x 3, registers), forms Z_k = inv(L) C_k and u_k = inv(L) y_k and leaves its
-// contribution Z_k' Z_k, Z_k' u_k in LDS; the contributions are summed in chain order (deterministic), every thread then solves the
-// <= 6 x 6 Schur system (R - sum Z'Z) x_r = y_r - sum Z'u redundantly in registers and back-substitutes its own chain.
-// dst[dofs of g] = scale * inv(M_g + dscale * diag(diag)) src[dofs of g]; a non-positive pivot sets RG_STATUS_BAD_FACTOR.
-__device__ __forceinline__ bool rb_star_solve(RbM m, RbLds& s, const float* Msp, int g, const float* diag, float dscale, const float* src, float* dst, float scale) {
-  const int r0 = m.b_star_grp[4 * g + 1], nr = m.b_star_grp[4 * g + 2];
-  const int k0 = m.b_star_adr[g], T = m.b_star_adr[g + 1] - k0;
+// "Star" trees (big_tables.py b_tree_*: a chain of <= 6 root dofs with simple chains of <= RB_STARB dofs hanging off its last dof -- the cubes, the
+// hand): M and M + h B of such a tree, and the Newton Hessian M + a diagonal of a tree no contact or tendon touches (the target cube), have the
+// tree's sparsity, [[R, C'], [C, blockdiag(B_k)]] in (root | chains) order.  Block elimination instead of a dense factorisation: thread k
+// factors its chain's B_k = L L' (<= 5 x 5, registers), forms Z_k = inv(L) C_k and u_k = inv(L) y_k and leaves its contribution Z_k' Z_k,
+// Z_k' u_k in LDS; the contributions are summed in chain order (deterministic), every thread then solves the <= 6 x 6 Schur system
+// (R - sum Z'Z) x_r = y_r - sum Z'u redundantly in registers and back-substitutes its own chain.
+// dst[dofs of tree t] = scale * inv(M_t + dscale * diag(diag)) src[dofs of tree t]; a non-positive pivot sets RG_STATUS_BAD_FACTOR.
+__device__ __forceinline__ void rb_star_solve(RbM m, RbLds& s, const float* Msp, int t, const float* diag, float dscale, const float* src, float* dst, float scale) {
+  const int r0 = m.b_tree_desc[4 * t + 1], nr = m.b_tree_desc[4 * t + 2];
+  const int k0 = m.b_tree_desc[4 * t + 3], T = m.b_tree_brn_end[t] - k0;
   float* W = s.A;                     // [T][28]: lower triangle of Z'Z (21), Z'u (6)
   float* red = s.A + 28 * T;          // the 27 sums (big_tables.py: T <= 128)
   bool ok = true;
-  float l00 = 1, l10 = 0, l11 = 1, l20 = 0, l21 = 0, l22 = 1, Z[3][6], uu[3] = {0, 0, 0};
+  float L[RB_STARB][RB_STARB], idg[RB_STARB], Z[RB_STARB][6], uu[RB_STARB];
   int f = 0, b = 0;
 #pragma unroll
-  for (int q = 0; q < 3; q++)
+  for (int q = 0; q < RB_STARB; q++) {
+    uu[q] = 0.f; idg[q] = 1.f;
 #pragma unroll
     for (int a = 0; a < 6; a++) Z[q][a] = 0.f;
-  if (TID < T) {
-    f = m.b_star_branch[2 * (k0 + TID)]; b = m.b_star_branch[2 * (k0 + TID) + 1];
-    float B[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
 #pragma unroll
-    for (int q = 0; q < 3; q++) if (q < b) {
+    for (int c = 0; c < RB_STARB; c++) L[q][c] = q == c ? 1.f : 0.f;
+  }
+  if (TID < T) {
+    f = m.b_tree_branch[2 * (k0 + TID)]; b = m.b_tree_branch[2 * (k0 + TID) + 1];
+#pragma unroll
+    for (int q = 0; q < RB_STARB; q++) if (q < b) {
       const int i = f + q, e0 = m.b_M_adr[i];   // entries (i, i), (i, i - 1), ..., (i, chain top), then (i, last root dof) ... (i, first root dof)
 #pragma unroll
-      for (int t = 0; t < 3; t++) if (t <= q) B[q][q - t] = Msp[e0 + t];
-      if (diag) B[q][q] += dscale * diag[i];
+      for (int c = 0; c < RB_STARB; c++) if (c <= q) L[q][q - c] = Msp[e0 + c];
+      if (diag) L[q][q] += dscale * diag[i];
 #pragma unroll
       for (int a = 0; a < 6; a++) if (a < nr) Z[q][nr - 1 - a] = Msp[e0 + q + 1 + a];
       uu[q] = src[i];
     }
-    float d = B[0][0]; ok = ok && d > RB_MINVAL; float r = rg_rsqrt(fmaxf(d, RB_MINVAL)); l00 = fmaxf(d, RB_MINVAL) * r; const float i00 = r;
-    l10 = B[1][0] * i00; l20 = B[2][0] * i00;
-    d = B[1][1] - l10 * l10; ok = ok && d > RB_MINVAL; r = rg_rsqrt(fmaxf(d, RB_MINVAL)); l11 = fmaxf(d, RB_MINVAL) * r; const float i11 = r;
-    l21 = (B[2][1] - l20 * l10) * i11;
-    d = B[2][2] - l20 * l20 - l21 * l21; ok = ok && d > RB_MINVAL; r = rg_rsqrt(fmaxf(d, RB_MINVAL)); l22 = fmaxf(d, RB_MINVAL) * r; const float i22 = r;
 #pragma unroll
-    for (int a = 0; a < 6; a++) { Z[0][a] *= i00; Z[1][a] = (Z[1][a] - l10 * Z[0][a]) * i11; Z[2][a] = (Z[2][a] - l20 * Z[0][a] - l21 * Z[1][a]) * i22; }
-    uu[0] *= i00; uu[1] = (uu[1] - l10 * uu[0]) * i11; uu[2] = (uu[2] - l20 * uu[0] - l21 * uu[1]) * i22;
+    for (int c = 0; c < RB_STARB; c++) {           // Cholesky of the chain's block (rows beyond the chain: identity)
+      float d = L[c][c];
+#pragma unroll
+      for (int q = 0; q < RB_STARB; q++) if (q < c) d -= L[c][q] * L[c][q];
+      ok = ok && d > RB_MINVAL;
+      idg[c] = rg_rsqrt(fmaxf(d, RB_MINVAL));
+      L[c][c] = fmaxf(d, RB_MINVAL) * idg[c];
+#pragma unroll
+      for (int r = 0; r < RB_STARB; r++) if (r > c) {
+        float v = L[r][c];
+#pragma unroll
+        for (int q = 0; q < RB_STARB; q++) if (q < c) v -= L[r][q] * L[c][q];
+        L[r][c] = v * idg[c];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RB_STARB; r++) {           // Z <- inv(L) Z, u <- inv(L) u
+#pragma unroll
+      for (int q = 0; q < RB_STARB; q++) if (q < r) {
+#pragma unroll
+        for (int a = 0; a < 6; a++) Z[r][a] -= L[r][q] * Z[q][a];
+        uu[r] -= L[r][q] * uu[q];
+      }
+#pragma unroll
+      for (int a = 0; a < 6; a++) Z[r][a] *= idg[r];
+      uu[r] *= idg[r];
+    }
     float* w = W + 28 * TID;
 #pragma unroll
     for (int a = 0; a < 6; a++) {
 #pragma unroll
-      for (int c = 0; c < 6; c++) if (c <= a) w[a * (a + 1) / 2 + c] = Z[0][a] * Z[0][c] + Z[1][a] * Z[1][c] + Z[2][a] * Z[2][c];
-      w[21 + a] = Z[0][a] * uu[0] + Z[1][a] * uu[1] + Z[2][a] * uu[2];
+      for (int c = 0; c < 6; c++) if (c <= a) { float v = 0.f; for (int r = 0; r < RB_STARB; r++) v += Z[r][a] * Z[r][c]; w[a * (a + 1) / 2 + c] = v; }
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < RB_STARB; r++) v += Z[r][a] * uu[r];
+      w[21 + a] = v;
     }
   }
   BSYNC();
@@ -540,26 +566,26 @@ __device__ __forceinline__ bool rb_star_solve(RbM m, RbLds& s, const float* Msp,
     if (p < nr) {
       const int i = r0 + p, e0 = m.b_M_adr[i];
 #pragma unroll
-      for (int t = 0; t < 6; t++) if (t <= p) Sm[p][p - t] = Msp[e0 + t] - red[p * (p + 1) / 2 + p - t];
+      for (int c = 0; c < 6; c++) if (c <= p) Sm[p][p - c] = Msp[e0 + c] - red[p * (p + 1) / 2 + p - c];
       if (diag) Sm[p][p] += dscale * diag[i];
       xr[p] = src[i] - red[21 + p];
     }
   }
-  float idg[6];
+  float sdg[6];
 #pragma unroll
   for (int c = 0; c < 6; c++) {
     float d = Sm[c][c];
 #pragma unroll
     for (int q = 0; q < 6; q++) if (q < c) d -= Sm[c][q] * Sm[c][q];
     ok = ok && d > RB_MINVAL;
-    idg[c] = rg_rsqrt(fmaxf(d, RB_MINVAL));
-    Sm[c][c] = fmaxf(d, RB_MINVAL) * idg[c];
+    sdg[c] = rg_rsqrt(fmaxf(d, RB_MINVAL));
+    Sm[c][c] = fmaxf(d, RB_MINVAL) * sdg[c];
 #pragma unroll
     for (int p = 0; p < 6; p++) if (p > c) {
       float v = Sm[p][c];
 #pragma unroll
       for (int q = 0; q < 6; q++) if (q < c) v -= Sm[p][q] * Sm[c][q];
-      Sm[p][c] = v * idg[c];
+      Sm[p][c] = v * sdg[c];
     }
   }
 #pragma unroll
@@ -567,23 +593,28 @@ __device__ __forceinline__ bool rb_star_solve(RbM m, RbLds& s, const float* Msp,
     float v = xr[p];
 #pragma unroll
     for (int q = 0; q < 6; q++) if (q < p) v -= Sm[p][q] * xr[q];
-    xr[p] = v * idg[p];
+    xr[p] = v * sdg[p];
   }
 #pragma unroll
   for (int p = 5; p >= 0; p--) {  // L' x = y
     float v = xr[p];
 #pragma unroll
     for (int q = 0; q < 6; q++) if (q > p) v -= Sm[q][p] * xr[q];
-    xr[p] = v * idg[p];
+    xr[p] = v * sdg[p];
   }
   if (TID < T) {
-    float w0 = uu[0], w1 = uu[1], w2 = uu[2];
+    float x[RB_STARB];
 #pragma unroll
-    for (int a = 0; a < 6; a++) { w0 -= Z[0][a] * xr[a]; w1 -= Z[1][a] * xr[a]; w2 -= Z[2][a] * xr[a]; }
-    const float x2 = w2 / l22, x1 = (w1 - l21 * x2) / l11, x0 = (w0 - l10 * x1 - l20 * x2) / l00;
-    if (b > 0) dst[f] = scale * x0;
-    if (b > 1) dst[f + 1] = scale * x1;
-    if (b > 2) dst[f + 2] = scale * x2;
+    for (int r = 0; r < RB_STARB; r++) { float v = uu[r]; for (int a = 0; a < 6; a++) v -= Z[r][a] * xr[a]; x[r] = v; }
+#pragma unroll
+    for (int r = RB_STARB - 1; r >= 0; r--) {    // L' x = w
+      float v = x[r];
+#pragma unroll
+      for (int q = 0; q < RB_STARB; q++) if (q > r) v -= L[q][r] * x[q];
+      x[r] = v * idg[r];
+    }
+#pragma unroll
+    for (int r = 0; r < RB_STARB; r++) if (r < b) dst[f + r] = scale * x[r];
   }
   if (TID == 0) {
 #pragma unroll
@@ -591,8 +622,12 @@ __device__ __forceinline__ bool rb_star_solve(RbM m, RbLds& s, const float* Msp,
   }
   if (!ok) s.status |= RG_STATUS_BAD_FACTOR;   // (every writer ORs the same bit into the same word; nobody else writes it in this phase)
   BSYNC();
-  return true;
 }
+// every tree of group g through rb_star_solve (groups whose trees are all stars: b_star_grp[4 g + 3])
+__device__ __forceinline__ void rb_star_group_solve(RbM m, RbLds& s, const float* Msp, int g, const float* diag, float dscale, const float* src, float* dst, float scale) {
+  for (int t = m.b_tree_adr[g]; t < m.b_tree_adr[g + 1]; t++) rb_star_solve(m, s, Msp, t, diag, dscale, src, dst, scale);
+}
+
 // ------------------------------------------------------------------------------------------------- velocity stage
 // mj_comVel, mj_passive, mj_rne (zero acceleration: Coriolis, centrifugal, gravity)
 __device__ __forceinline__ void rb_velocity(RbM m, RbLds& s, float* S) {
@@ -1254,7 +1289,7 @@ __device__ __forceinline__ int rb_solve(RbM m, RbLds& s, float* S, int flags) {
     for (int grp = 0; grp < m.ngroup; grp++) {
       if (m.b_star_grp[4 * grp] && !(flags & 4)) {   // H = M + diagonal on this group: block elimination along the tree
         rb_row_diag(m, s, S, grp, s.Mv); RB_PROFS(10);
-        rb_star_solve(m, s, Msp, grp, s.Mv, 1.f, s.grad, s.search, -1.f); RB_PROFS(11);
+        rb_star_group_solve(m, s, Msp, grp, s.Mv, 1.f, s.grad, s.search, -1.f); RB_PROFS(11);
         continue;
       }
       rb_M_block(m, s, Msp, grp, (const float*)0, 0.f);
@@ -1289,7 +1324,7 @@ __device__ __forceinline__ void rb_euler(RbM m, RbLds& s, float* S, int flags) {
   BFOR(i, m.nv) s.grad[i] = s.qfrc_smooth[i] + s.qfrc_con[i];
   BSYNC();
   for (int grp = 0; grp < m.ngroup; grp++) {
-    if (m.b_star_grp[4 * grp] && !(flags & 4)) { rb_star_solve(m, s, SC(MSP), grp, m.dof_damping, h, s.grad, s.search, 1.f); continue; }
+    if (m.b_star_grp[4 * grp + 3] && !(flags & 4)) { rb_star_group_solve(m, s, SC(MSP), grp, m.dof_damping, h, s.grad, s.search, 1.f); continue; }
     rb_M_block(m, s, SC(MSP), grp, m.dof_damping, h);
     rb_scale_block(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]);
     if (!rb_chol(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]) && TID == 0) s.status |= RG_STATUS_BAD_FACTOR;
@@ -1359,7 +1394,7 @@ __global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbMod
     rb_pid(m, s, S, true);
     // qacc_smooth = inv(M) qfrc_smooth
     for (int grp = 0; grp < m.ngroup; grp++) {
-      if (m.b_star_grp[4 * grp] && !(flags & 4)) { rb_star_solve(m, s, SC(MSP), grp, (const float*)0, 0.f, s.qfrc_smooth, s.qacc_smooth, 1.f); continue; }   // (flags bit 2: dense path everywhere, test hook)
+      if (m.b_star_grp[4 * grp + 3] && !(flags & 4)) { rb_star_group_solve(m, s, SC(MSP), grp, (const float*)0, 0.f, s.qfrc_smooth, s.qacc_smooth, 1.f); continue; }   // (flags bit 2: dense path everywhere, test hook)
       rb_M_block(m, s, SC(MSP), grp, (const float*)0, 0.f);
       rb_scale_block(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]);
       if (!rb_chol(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]) && TID == 0) s.status |= RG_STATUS_BAD_FACTOR;

@@ -10,6 +10,7 @@
 #define RB_TENW 8         // dofs a tendon can depend on (big_tables.py TEN_W)
 #define RB_CONW 24        // dofs a contact can depend on (big_tables.py CON_W)
 #define RB_MAXGROUP 96    // dofs of the largest constraint-coupled group of trees: its dense block lives in LDS
+#define RB_STARB 5        // longest chain of a star tree (big_tables.py STAR_B)
 #define RB_MLONG 8        // descendant lists of M longer than this are summed by a wave (big_tables.py MLONG)
 #define RB_MAXNV 192      // LDS vectors
 #define RB_MAXNQ 192
@@ -24,7 +25,7 @@
   X(tendon_adr) X(tendon_num) X(wrap_type) X(wrap_objid) \
   X(actuator_trntype) X(actuator_trnid) X(actuator_forcelimited) X(actuator_biastype) \
   X(b_lvl_body) X(b_lvl_adr) X(b_body_lastdof) X(b_subtree_adr) X(b_subtree) X(b_root_list) X(b_M_i) X(b_M_j) X(b_M_adr) \
-  X(b_group_adr) X(b_group_dofs) X(b_dof_group) X(b_dof_local) X(b_pair_geom) X(b_ten_dofs) X(b_fric_dof) X(b_fric_ten) X(b_lim_jnt) X(b_lim_ten) X(b_cell_adr) X(b_Mdesc_adr) X(b_Mdesc_ent) X(b_Mdesc_dof) X(b_dof_fricrow) X(b_star_grp) X(b_star_adr) X(b_star_branch) X(b_Mlong)
+  X(b_group_adr) X(b_group_dofs) X(b_dof_group) X(b_dof_local) X(b_pair_geom) X(b_ten_dofs) X(b_fric_dof) X(b_fric_ten) X(b_lim_jnt) X(b_lim_ten) X(b_cell_adr) X(b_Mdesc_adr) X(b_Mdesc_ent) X(b_Mdesc_dof) X(b_dof_fricrow) X(b_star_grp) X(b_tree_adr) X(b_tree_desc) X(b_tree_branch) X(b_tree_brn_end) X(b_Mlong)
 #define RB_FLT_ARRAYS(X) \
   X(body_pos) X(body_quat) X(body_ipos) X(body_iquat) X(body_mass) X(body_inertia) X(body_subtreemass) X(body_invweight0) \
   X(jnt_pos) X(jnt_axis) X(jnt_stiffness) X(jnt_range) X(jnt_margin) X(jnt_solref) X(jnt_solimp) \
