@@ -943,17 +943,35 @@ __device__ __forceinline__ void rb_make_constraint(RbM m, RbLds& s, float* S) {
 __device__ __forceinline__ void rb_dof_contact_lists(RbM m, RbLds& s, float* S) {
   const int* cidx = (const int*)SC(CONIDX); int* adr = (int*)SC(DOFCON_ADR); int* lst = (int*)SC(DOFCON);
   const float* con = SC(CON);
-  BFOR(i, m.nv) {   // counts
-    int n = 0;
-    for (int c = 0; c < s.ncon; c++) { if (con[RB_CONREC * c + RB_CR_ADR] < 0) continue; for (int e = 0; e < RB_CONW; e++) if (cidx[RB_CONW * c + e] == i) n++; }
-    adr[i + 1] = n;
+  // a bit mask of its dofs per contact first (6 words: nv <= 192), so that a dof looks at one word per contact instead of its whole dof list
+  unsigned* mask = (unsigned*)SC(CONF);   // (the per-contact solver scratch is free until the solver starts)
+  BFOR(c, s.ncon) {
+    unsigned w[6] = {0, 0, 0, 0, 0, 0};
+    if (!(con[RB_CONREC * c + RB_CR_ADR] < 0)) {
+      const int nnz = (int)con[RB_CONREC * c + RB_CR_NNZ];
+      for (int e = 0; e < nnz; e++) { const int d = cidx[RB_CONW * c + e]; if (d >= 0 && d < RB_MAXNV) w[d >> 5] |= 1u << (d & 31); }
+    }
+    for (int k = 0; k < 6; k++) mask[6 * c + k] = w[k];
   }
   BSYNC();
-  if (TID == 0) { adr[0] = 0; for (int i = 0; i < m.nv; i++) adr[i + 1] += adr[i]; }
+  int* cnt = (int*)s.x;
+  BFOR(i, m.nv) {   // counts
+    int n = 0;
+    for (int c = 0; c < s.ncon; c++) n += (mask[6 * c + (i >> 5)] >> (i & 31)) & 1u;
+    cnt[i] = n;
+  }
   BSYNC();
-  BFOR(i, m.nv) {
-    int n = adr[i];
-    for (int c = 0; c < s.ncon; c++) { if (con[RB_CONREC * c + RB_CR_ADR] < 0) continue; for (int e = 0; e < RB_CONW; e++) if (cidx[RB_CONW * c + e] == i) lst[n++] = c * RB_CONW + e; }
+  BFOR(i, m.nv) {   // exclusive prefix (every dof sums the counts before it: LDS reads, no serial pass through the scratch row)
+    int a0 = 0;
+    for (int k = 0; k < i; k++) a0 += cnt[k];
+    adr[i] = a0;
+    if (i == m.nv - 1) adr[m.nv] = a0 + cnt[i];
+    int n = a0;
+    for (int c = 0; c < s.ncon; c++) {
+      if (!((mask[6 * c + (i >> 5)] >> (i & 31)) & 1u)) continue;
+      const int nnz = (int)con[RB_CONREC * c + RB_CR_NNZ];
+      for (int e = 0; e < nnz; e++) if (cidx[RB_CONW * c + e] == i) { lst[n++] = c * RB_CONW + e; break; }
+    }
   }
   BSYNC();
 }
