@@ -1177,10 +1177,14 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
     return con[RB_CONREC * c + (t == 7 * RB_CONW + 12 ? RB_CR_NNZ : RB_CR_DIM)];
   };
   int buf = 0;
+#ifdef RB_HESS_PROBE
+  const long long tprobe = rg_clock();
+#endif
   { const float v = stage_load(0); if (TID < RB_CST) s.cst[TID] = v; }
+  float next = s.ncon > 1 ? stage_load(1) : 0.f;   // two contacts in flight: the word stored at the end of a pass was requested a whole pass earlier
   BSYNC();
   for (int c = 0; c < s.ncon; c++, buf ^= 1) {
-    const float next = c + 1 < s.ncon ? stage_load(c + 1) : 0.f;
+    const float after = c + 2 < s.ncon ? stage_load(c + 2) : 0.f;
     const float* K = s.cst + RB_CST * buf;
     const float* W = K + 7 * RB_CONW;
     if (W[0] != 0.f) {
@@ -1199,8 +1203,12 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
       }
     }
     if (TID < RB_CST) s.cst[RB_CST * (buf ^ 1) + TID] = next;
+    next = after;
     BSYNC();
   }
+#ifdef RB_HESS_PROBE
+  if (TID == 0) s.prof[15] += (float)(rg_clock() - tprobe);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------- solver
