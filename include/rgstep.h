@@ -311,6 +311,8 @@ typedef struct rb_post_args {
   float quat_threshold, face_threshold, success_reward, p_face_flip, round_target_face;
   int directions;              /* bit 0 "cw", bit 1 "ccw" (goal_directions) */
   int max_timesteps_per_goal, successes_needed, use_goal_distance_reward, stop_on_fall;
+  int goal_mode;               /* 0: FaceFreeGoal (goals/face_free.py); 1: FullUnconstrainedGoal (goals/full_unconstrained.py:55-117: any face gets a turn --
+                                  draws k_face, u_round, k_direction -- the goal quaternion is zero and its distance 0) */
   /* ---- pipelined resets (pipelined = 0: unused).  An env whose episode ends restarts by itself: the reset recipe of
    * /root/reference/robogym/envs/dactyl/common/cube_env.py:330-355 + full_perpendicular.py:286-345 as a per-env phase counter (0 = live; k > 0: k - 1
    * recipe steps done) with its state writes done here: MjSim.reset + the zero-action ctrl; after reset_initial_steps steps the cube pose perturbation,

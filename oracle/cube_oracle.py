@@ -244,3 +244,34 @@ class FaceFreeGoalOracle:
     def goal_distance(self, goal, st):
         r = self.relative_goal(goal, st)
         return {"cube_quat": quat_magnitude(r["cube_quat"]), "cube_face_angle": float(np.linalg.norm(r["cube_face_angle"]))}
+
+
+class FullUnconstrainedGoalOracle(FaceFreeGoalOracle):
+    """goals/full_unconstrained.py:55-117: any face gets a turn, no orientation objective (the goal quaternion is zero, its distance 0).
+    `draws` as FaceFreeGoalOracle.next_goal; consumed: k_face, u_round, k_direction."""
+
+    def next_goal(self, qpos, face_geom_z, draws):
+        face = qpos[self.cube.driver_q].copy()
+        qpos[self.target.all_q] = qpos[self.cube.all_q]
+        self.target.soft_align_faces(qpos)
+        f = int(draws[3])
+        cw = (-1.0) ** f
+        dirs = [np.pi / 2 * {"cw": cw, "ccw": -cw}[d] for d in self.directions]
+        goal_face = face.copy()
+        if draws[1] < self.round_target_face:
+            delta = dirs[int(draws[2])]
+            goal_face[f] += delta
+            goal_face = round_to_straight_angles(normalize_angles(goal_face))
+        else:
+            lo, hi = min(dirs + [0.0]), max(dirs + [0.0])
+            delta = lo + (hi - lo) * draws[2]
+            goal_face[f] += delta
+            goal_face = normalize_angles(goal_face)
+        self.target.rotate_face(qpos, f // 2, f % 2, delta)
+        return {"cube_quat": np.zeros(4), "cube_face_angle": goal_face, "goal_type": "rotation", "axis_nr": 0, "axis_sign": 0.0}
+
+    def relative_goal(self, goal, st):
+        return {"cube_quat": np.zeros(4), "cube_face_angle": normalize_angles(goal["cube_face_angle"] - st["cube_face_angle"])}
+
+    def goal_distance(self, goal, st):
+        return {"cube_quat": 0.0, "cube_face_angle": float(np.linalg.norm(self.relative_goal(goal, st)["cube_face_angle"]))}

@@ -60,7 +60,7 @@ class RbPostArgs(ctypes.Structure):
                    ("face_geom", ctypes.c_int * 6), ("tip_site", ctypes.c_int * 5), ("ref_site", ctypes.c_int * 3), ("center_site", ctypes.c_int)]
                 + [(n, ctypes.c_int) for n in ("cube_pos_col", "cube_quat_col", "cube_block_col", "target_block_col", "hand_col", "n_hand")]
                 + [(n, ctypes.c_float) for n in ("quat_threshold", "face_threshold", "success_reward", "p_face_flip", "round_target_face")]
-                + [(n, ctypes.c_int) for n in ("directions", "max_timesteps_per_goal", "successes_needed", "use_goal_distance_reward", "stop_on_fall", "pipelined")]
+                + [(n, ctypes.c_int) for n in ("directions", "max_timesteps_per_goal", "successes_needed", "use_goal_distance_reward", "stop_on_fall", "goal_mode", "pipelined")]
                 + [(n, ctypes.c_void_p) for n in ("phase", "tries", "nticks_next", "hold_next", "resetting", "episode_started", "reset_draws", "qpos0", "ctrl_lo", "ctrl_hi")]
                 + [("wiggle_std", ctypes.c_float)]
                 + [(n, ctypes.c_int) for n in ("reset_initial_steps", "n_random_initial_steps", "max_pose_resets", "num_scramble_steps", "scramble_face_angles", "randomize_face_angles")])

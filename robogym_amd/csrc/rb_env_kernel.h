@@ -166,9 +166,10 @@ struct RbPostLds {
 };
 
 // FaceFreeGoal.goal_distance of the state (quat, face) to the goal row g: out[0] = cube_quat, out[1] = cube_face_angle
-__device__ __forceinline__ void rbp_goal_distance(const float* g, const float* quat, const float* face, float* out) {
-  float M[9], dq[4];
-  if (g[10] > 0.5f) { rbc_quat2mat(quat, M); rbc_dist_up(M, (int)g[11], g[12], dq); }
+__device__ __forceinline__ void rbp_goal_distance(const float* g, const float* quat, const float* face, float* out, int goal_mode) {
+  float M[9], dq[4] = {1.f, 0.f, 0.f, 0.f};
+  if (goal_mode == 1) {}                                        // FullUnconstrainedGoal: no orientation objective
+  else if (g[10] > 0.5f) { rbc_quat2mat(quat, M); rbc_dist_up(M, (int)g[11], g[12], dq); }
   else { float cj[4] = {quat[0], -quat[1], -quat[2], -quat[3]}; rbc_qmul(g, cj, dq); rbc_qsign(dq); }
   out[0] = rbc_qmag(dq);
   float s2 = 0; for (int k = 0; k < 6; k++) { const float d = rbc_wrap(g[4 + k] - face[k]); s2 += d * d; }
@@ -196,7 +197,7 @@ __global__ void __launch_bounds__(64) rb_post_step_kernel(const RbModelDev* mp, 
     float quat[4], face[6], dist[2] = {0.f, 0.f};
     for (int k = 0; k < 4; k++) quat[k] = qrow[a.cube_quat_col + k];
     for (int k = 0; k < 6; k++) face[k] = qrow[a.cube_block_col + k];
-    if (!crash) rbp_goal_distance(g, quat, face, dist);
+    if (!crash) rbp_goal_distance(g, quat, face, dist, a.goal_mode);
     int got = 0, trial = 0, timeout = 0, newgoal = forced, succ = 0;
     const int ph0 = (a.pipelined && !forced) ? a.phase[e] : 0;
     const int resetting = ph0 > 0, live = !resetting;
@@ -269,12 +270,13 @@ __global__ void __launch_bounds__(64) rb_post_step_kernel(const RbModelDev* mp, 
       rbc_up_axis(M, axis, asgn);
       rbc_dist_up(M, axis, asgn, dq);
       const bool z_aligned = rbc_qmag(dq) < a.quat_threshold;                 // rotation.rot_xyz_aligned
-      const bool reorient = U(0) < a.p_face_flip;
-      const bool rotate = face_aligned && z_aligned && !reorient;
+      const bool reorient = a.goal_mode == 1 ? false : U(0) < a.p_face_flip;
+      const bool rotate = a.goal_mode == 1 || (face_aligned && z_aligned && !reorient);
       float gq[4], gf[6];
       if (rotate) {
         int f = 0; float zb = S[m.off[RB_O_GPOS] + 3 * a.face_geom[0] + 2];                // cube_utils.face_up: the face geom highest in z
         for (int k = 1; k < 6; k++) { const float z = S[m.off[RB_O_GPOS] + 3 * a.face_geom[k] + 2]; if (z > zb) { zb = z; f = k; } }
+        if (a.goal_mode == 1) { f = a.draws ? (int)U(3) : (int)(U(3) * 6.f); f = f < 0 ? 0 : (f > 5 ? 5 : f); }   // FullUnconstrainedGoal: any face (full_unconstrained.py:62)
         const float cw = (f & 1) ? -1.f : 1.f;
         float dirs[2]; int nd = 0;
         if (a.directions & 1) dirs[nd++] = 0.5f * RBC_PI * cw;
@@ -294,6 +296,7 @@ __global__ void __launch_bounds__(64) rb_post_step_kernel(const RbModelDev* mp, 
           for (int i = 0; i < 6; i++) gf[i] = rbc_wrap(gf[i]);
         }
         rbc_qmul(dq, quat, gq);                                              // cube_utils.align_quat_up
+        if (a.goal_mode == 1) gq[0] = gq[1] = gq[2] = gq[3] = 0.f;           // (no orientation goal: np.zeros(4))
         F.face = f; F.delta = delta;
       } else {
         for (int k = 0; k < 6; k++) gf[k] = rounded[k];
@@ -311,7 +314,7 @@ __global__ void __launch_bounds__(64) rb_post_step_kernel(const RbModelDev* mp, 
       // ---- reset_goal (robot_env.py:893-909): goal counters, _previous_goal_distance = None -> the re-observation sets it to the current distance
       a.goals_so_far[e] += 1; a.steps_since_last_goal[e] = 0; a.consecutive[e] = 0;
       float nd2[2] = {0.f, 0.f};
-      if (!crash) rbp_goal_distance(g, quat, face, nd2);
+      if (!crash) rbp_goal_distance(g, quat, face, nd2, a.goal_mode);
       a.prev_dist[2 * e] = nd2[0]; a.prev_dist[2 * e + 1] = nd2[1]; a.prev_valid[e] = 1;
       achieved = !crash && nd2[0] < a.quat_threshold && nd2[1] < a.face_threshold;
     }

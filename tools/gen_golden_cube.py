@@ -175,6 +175,34 @@ def main():
         rec["dist"].append([dist["cube_quat"], dist["cube_face_angle"]])
     out.update({"ng_" + k: np.array(v) for k, v in rec.items()})
     out["ng_face_up_quats"] = table
+    # ---- FullUnconstrainedGoal (goals/full_unconstrained.py): any face turned, no orientation objective
+    from robogym.envs.dactyl.goals.full_unconstrained import FullUnconstrainedGoal
+
+    msim.target_model = target
+    fu = FullUnconstrainedGoal.__new__(FullUnconstrainedGoal)
+    fu.mujoco_simulation, fu.success_threshold, fu.face_geom_names = msim, {"cube_quat": 0.4, "cube_face_angle": 0.2}, FACES
+    fu.goal_directions, fu.round_target_face, fu.goal_candidates = ["cw", "ccw"], True, list(range(6))
+    rec2 = {k: [] for k in ("qpos0", "qpos1", "draws", "goal_face", "probe_face", "dist")}
+    for case in range(48):
+        scrambled(rng.randint(0, 10))
+        axis = rng.randint(3)
+        for side in range(2):
+            cube.rotate_face(axis, side, rng.uniform(-0.6, 0.6))
+        sim.data.qpos[quat_q] = (lambda q: q / np.linalg.norm(q))(rng.randn(4))
+        sim.data.qpos[tq] = rng.uniform(-1, 1, size=len(tq))
+        rec2["qpos0"].append(sim.data.qpos.copy())
+        rr = RecordingRandom(5000 + case)
+        state = {"cube_quat": sim.data.qpos[quat_q].copy(), "cube_face_angle": sim.data.qpos[[cube.joints_qpos_map[d] for d in cube.drivers]].copy()}
+        goal = fu.next_goal(rr, state)
+        assert rr.log[0][:2] == ("choice", 6) and rr.log[1][0] == "uniform" and rr.log[2][:2] == ("choice", 2)
+        rec2["draws"].append([0.0, rr.log[1][3], rr.log[2][2], rr.log[0][2], 0.0])
+        rec2["qpos1"].append(sim.data.qpos.copy()); rec2["goal_face"].append(goal["cube_face_angle"])
+        assert goal["goal_type"] == "rotation" and not np.any(goal["cube_quat"])
+        pf = goal["cube_face_angle"] + (rng.uniform(-0.15, 0.15, size=6) if case % 3 == 0 else rng.uniform(-4, 4, size=6))
+        dist = fu.goal_distance(goal, {"cube_quat": rng.randn(4), "cube_face_angle": pf, "cube_pos": np.zeros(3)})
+        assert dist["cube_quat"] == 0.0
+        rec2["probe_face"].append(pf); rec2["dist"].append(dist["cube_face_angle"])
+    out.update({"fu_" + k: np.array(v) for k, v in rec2.items()})
     print("next_goal cases: %d rotation, %d flip" % (sum(rec["goal_type"]), N - sum(rec["goal_type"])))
     np.savez_compressed(os.path.join(OUT, "full_cube.npz"), **out)
     print("wrote", os.path.join(OUT, "full_cube.npz"), {k: v.shape for k, v in out.items()})
