@@ -312,7 +312,9 @@ typedef struct rb_post_args {
   int directions;              /* bit 0 "cw", bit 1 "ccw" (goal_directions) */
   int max_timesteps_per_goal, successes_needed, use_goal_distance_reward, stop_on_fall;
   int goal_mode;               /* 0: FaceFreeGoal (goals/face_free.py); 1: FullUnconstrainedGoal (goals/full_unconstrained.py:55-117: any face gets a turn --
-                                  draws k_face, u_round, k_direction -- the goal quaternion is zero and its distance 0) */
+                                  draws k_face, u_round, k_direction -- the goal quaternion is zero and its distance 0); 2: FaceCurriculumGoal
+                                  (goals/face_curriculum.py:57-170: as 0, but a turn's orientation goal is round_to_straight_quat(cube_quat) and the orientation
+                                  distance is always the plain quaternion difference) */
   /* ---- pipelined resets (pipelined = 0: unused).  An env whose episode ends restarts by itself: the reset recipe of
    * /root/reference/robogym/envs/dactyl/common/cube_env.py:330-355 + full_perpendicular.py:286-345 as a per-env phase counter (0 = live; k > 0: k - 1
    * recipe steps done) with its state writes done here: MjSim.reset + the zero-action ctrl; after reset_initial_steps steps the cube pose perturbation,

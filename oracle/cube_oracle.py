@@ -275,3 +275,30 @@ class FullUnconstrainedGoalOracle(FaceFreeGoalOracle):
 
     def goal_distance(self, goal, st):
         return {"cube_quat": 0.0, "cube_face_angle": float(np.linalg.norm(self.relative_goal(goal, st)["cube_face_angle"]))}
+
+
+def euler2quat(e):
+    """rotation.py:110-126"""
+    ai, aj, ak = e[2] / 2, -e[1] / 2, e[0] / 2
+    si, sj, sk, ci, cj, ck = np.sin(ai), np.sin(aj), np.sin(ak), np.cos(ai), np.cos(aj), np.cos(ak)
+    return np.array([cj * ci * ck + sj * si * sk, cj * ci * sk - sj * si * ck, -(cj * si * sk + sj * ci * ck), cj * si * ck - sj * ci * sk])
+
+
+def round_to_straight_quat(q):
+    """rotation.py:387-390: the orientation with its Euler angles rounded to multiples of 90 degrees"""
+    return euler2quat(round_to_straight_angles(mat2euler(quat2mat(q))))
+
+
+class FaceCurriculumGoalOracle(FaceFreeGoalOracle):
+    """goals/face_curriculum.py:57-170: FaceFreeGoal's choice between a face turn and a flip, but a turn's orientation goal is the cube's own
+    orientation rounded to straight Euler angles, and the orientation distance is always the plain quaternion difference."""
+
+    def next_goal(self, qpos, face_geom_z, draws):
+        quat = qpos[self.quat_q].copy()
+        g = super().next_goal(qpos, face_geom_z, draws)
+        if g["goal_type"] == "rotation":
+            g["cube_quat"] = quat_sign(round_to_straight_quat(quat))
+        return g
+
+    def relative_goal(self, goal, st):
+        return {"cube_quat": quat_difference(goal["cube_quat"], st["cube_quat"]), "cube_face_angle": normalize_angles(goal["cube_face_angle"] - st["cube_face_angle"])}

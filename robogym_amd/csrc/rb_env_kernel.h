@@ -169,7 +169,7 @@ struct RbPostLds {
 __device__ __forceinline__ void rbp_goal_distance(const float* g, const float* quat, const float* face, float* out, int goal_mode) {
   float M[9], dq[4] = {1.f, 0.f, 0.f, 0.f};
   if (goal_mode == 1) {}                                        // FullUnconstrainedGoal: no orientation objective
-  else if (g[10] > 0.5f) { rbc_quat2mat(quat, M); rbc_dist_up(M, (int)g[11], g[12], dq); }
+  else if (g[10] > 0.5f && goal_mode != 2) { rbc_quat2mat(quat, M); rbc_dist_up(M, (int)g[11], g[12], dq); }   // (goal_mode 2, FaceCurriculumGoal: always the plain difference)
   else { float cj[4] = {quat[0], -quat[1], -quat[2], -quat[3]}; rbc_qmul(g, cj, dq); rbc_qsign(dq); }
   out[0] = rbc_qmag(dq);
   float s2 = 0; for (int k = 0; k < 6; k++) { const float d = rbc_wrap(g[4 + k] - face[k]); s2 += d * d; }
@@ -297,6 +297,13 @@ __global__ void __launch_bounds__(64) rb_post_step_kernel(const RbModelDev* mp, 
         }
         rbc_qmul(dq, quat, gq);                                              // cube_utils.align_quat_up
         if (a.goal_mode == 1) gq[0] = gq[1] = gq[2] = gq[3] = 0.f;           // (no orientation goal: np.zeros(4))
+        if (a.goal_mode == 2) {                                              // FaceCurriculumGoal: rotation.round_to_straight_quat(cube_quat)
+          float eu[3];
+          rbc_mat2euler(M, eu);
+          const float ai = 0.5f * rbc_straight(eu[2]), aj = -0.5f * rbc_straight(eu[1]), ak = 0.5f * rbc_straight(eu[0]);
+          const float si = sinf(ai), sj = sinf(aj), sk = sinf(ak), ci = cosf(ai), cj = cosf(aj), ck = cosf(ak);
+          gq[0] = cj * ci * ck + sj * si * sk; gq[1] = cj * ci * sk - sj * si * ck; gq[2] = -(cj * si * sk + sj * ci * ck); gq[3] = cj * si * ck - sj * ci * sk;
+        }
         F.face = f; F.delta = delta;
       } else {
         for (int k = 0; k < 6; k++) gf[k] = rounded[k];

@@ -14,9 +14,9 @@ cubelets).
   under the zero action, cube pose perturbation, scramble, face-angle randomisation, 10 steps under one random action, retried
   while the cube is not on the palm; with `pipelined_reset=True` finished episodes run that recipe by themselves inside the following
   `step` calls (a per-env phase counter in the env kernel, scripted controls through the stepper's `hold` mask), so the other envs never
-  wait for a reset.  Goal generation: `face_free` (the default) and `full_unconstrained` (goals/full_unconstrained.py).  Unwrapped
-  (`make_simple_env`); the other goal generators of the reference (face_curr, and the four that need pycuber's solver: face_cube_solver,
-  release_cube_solver, unconstrained_cube_solver, fixed_fair_scramble) and the wrapper stack are not built for this config.
+  wait for a reset.  Goal generation: `face_free` (the default), `full_unconstrained` and `face_curr` (goals/face_free.py, full_unconstrained.py,
+  face_curriculum.py).  Unwrapped (`make_simple_env`); the other goal generators of the reference (the four that need pycuber's solver:
+  face_cube_solver, release_cube_solver, unconstrained_cube_solver, fixed_fair_scramble) and the wrapper stack are not built for this config.
   The scramble needs the cube-group bookkeeping the reference takes from `pycuber` (not installed here): `scramble_euler`
   applies the same 12 face turns (L, L', R, ... clockwise seen from outside the face) to signed permutation matrices.
 """
@@ -256,6 +256,10 @@ class FullPerpendicularEnvConstants:
     max_pose_resets: int = 50
 
 
+#: FullPerpendicularEnv.build_goal_generation (full_perpendicular.py:194-259): the generators the env kernel implements (rb_post_args.goal_mode)
+_GOAL_MODES = {"face_free": 0, "full_unconstrained": 1, "face_curr": 2}
+
+
 class BatchedFullPerpendicularEnv:
     """B independent dactyl/full_perpendicular envs stepped in lock-step on one GPU (see the module docstring)."""
 
@@ -265,8 +269,8 @@ class BatchedFullPerpendicularEnv:
         from robogym_amd.utils.rotation import parallel_quats_np
 
         self.constants = c = constants or FullPerpendicularEnvConstants()
-        if c.goal_generation not in ("face_free", "full_unconstrained"):
-            raise NotImplementedError("goal_generation=%r: 'face_free' (the default) and 'full_unconstrained' are built for dactyl/full_perpendicular" % c.goal_generation)
+        if c.goal_generation not in _GOAL_MODES:
+            raise NotImplementedError("goal_generation=%r: %s are built for dactyl/full_perpendicular" % (c.goal_generation, sorted(_GOAL_MODES)))
         self.model = model or load_full_perpendicular_model()
         kw = dict(lib=lib) if lib is not None else dict(device=device)
         self.mujoco_simulation = sim = FullPerpendicularSimulation(self.model, batch_size, n_substeps=c.mujoco_substeps, relative_action=c.relative_action, **kw)
@@ -422,7 +426,7 @@ class BatchedFullPerpendicularEnv:
         a.quat_threshold, a.face_threshold = float(c.success_threshold["cube_quat"]), float(c.success_threshold["cube_face_angle"])
         a.success_reward, a.p_face_flip, a.round_target_face = float(c.success_reward), float(c.p_face_flip), float(c.round_target_face)
         a.directions = (1 if "cw" in c.goal_directions else 0) | (2 if "ccw" in c.goal_directions else 0)
-        a.goal_mode = 1 if c.goal_generation == "full_unconstrained" else 0
+        a.goal_mode = _GOAL_MODES[c.goal_generation]
         a.max_timesteps_per_goal, a.successes_needed, a.use_goal_distance_reward, a.stop_on_fall = int(c.max_timesteps_per_goal), int(c.successes_needed), int(c.use_goal_distance_reward), int(self.stop_on_fall)
         a.pipelined = int(self.pipelined_reset and force is None)
         if a.pipelined:

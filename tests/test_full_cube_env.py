@@ -628,3 +628,64 @@ def test_full_unconstrained_goal_kernel_emul(full_model, gold, emul_lib):
 @pytest.mark.gpu
 def test_full_unconstrained_goal_kernel_gpu(full_model, gold):
     _check_full_unconstrained(full_model, gold, None)
+
+
+# ------------------------------------------------------------------------------------------------ goal_generation = "face_curr"
+def test_cube_oracle_matches_reference_face_curriculum_goal(gold, full_model):
+    gg = co.FaceCurriculumGoalOracle(full_model, gold["ng_face_up_quats"], p_face_flip=0.25)
+    for i in range(len(gold["fc_qpos0"])):
+        q = gold["fc_qpos0"][i].copy()
+        g = gg.next_goal(q, gold["fc_geom_z"][i], gold["fc_draws"][i])
+        assert (g["goal_type"] == "rotation") == bool(gold["fc_goal_type"][i])
+        np.testing.assert_allclose(q, gold["fc_qpos1"][i], atol=1e-12)
+        assert _same_quat(g["cube_quat"], gold["fc_goal_quat"][i], 1e-12)
+        np.testing.assert_allclose(g["cube_face_angle"], gold["fc_goal_face"][i], atol=1e-12)
+        d = gg.goal_distance({"cube_quat": gold["fc_goal_quat"][i], "cube_face_angle": gold["fc_goal_face"][i], "goal_type": g["goal_type"]},
+                             {"cube_quat": gold["fc_probe_quat"][i], "cube_face_angle": gold["fc_probe_face"][i]})
+        np.testing.assert_allclose([d["cube_quat"], d["cube_face_angle"]], gold["fc_dist"][i], atol=1e-12)
+
+
+def _check_face_curriculum(full_model, gold, lib):
+    from robogym_amd.envs.dactyl.full_perpendicular import BatchedFullPerpendicularEnv, FullPerpendicularEnvConstants
+
+    n = len(gold["fc_qpos0"])
+    c = FullPerpendicularEnvConstants(goal_generation="face_curr", p_face_flip=0.25)
+    env = BatchedFullPerpendicularEnv(n, model=full_model, lib=lib, constants=c) if lib is not None else BatchedFullPerpendicularEnv(n, model=full_model, device="cuda:0", constants=c)
+    sim = env.sim
+    cm_t = co.CubeModel(full_model, "target:")
+    env._face_up_quats.copy_(torch.as_tensor(gold["ng_face_up_quats"], dtype=torch.float32))
+    sim.qpos[:] = torch.as_tensor(gold["fc_qpos0"], dtype=torch.float32, device=sim.device)
+    sim.forward()
+    gz = sim.scratch("geom_xpos")
+    for k, g_ in enumerate(sim.face_geoms):
+        gz[:, 3 * g_ + 2] = torch.as_tensor(gold["fc_geom_z"][:, k], dtype=torch.float32, device=sim.device)
+    env.set_draws(gold["fc_draws"])
+    env._post(force=torch.ones(n, dtype=torch.int32, device=sim.device))
+    sim.sync()
+    goal, got = env._goal.cpu().numpy().astype(np.float64), sim.qpos.cpu().numpy().astype(np.float64)
+    for b in range(n):
+        assert bool(goal[b, 10]) == bool(gold["fc_goal_type"][b]), b
+        assert _same_quat(goal[b, :4], gold["fc_goal_quat"][b], 3e-6), (b, goal[b, :4], gold["fc_goal_quat"][b])
+        np.testing.assert_allclose(np.sin(goal[b, 4:10]), np.sin(gold["fc_goal_face"][b]), atol=2e-6)
+        np.testing.assert_allclose(_mats(cm_t, got[b]), _mats(cm_t, gold["fc_qpos1"][b]), atol=3e-6)
+    q = gold["fc_qpos0"].copy()
+    cq = np.arange(4) + int(sim.qpos_idxs["cube_rotation"][0])
+    q[:, cq] = gold["fc_probe_quat"]; q[:, co.CubeModel(full_model, "cube:").driver_q] = gold["fc_probe_face"]
+    sim.qpos[:] = torch.as_tensor(q, dtype=torch.float32, device=sim.device)
+    grow = np.zeros((n, 16)); grow[:, :4] = gold["fc_goal_quat"]; grow[:, 4:10] = gold["fc_goal_face"]; grow[:, 10] = gold["fc_goal_type"]
+    env._goal.copy_(torch.as_tensor(grow, dtype=torch.float32))
+    env.set_draws(np.zeros((n, 5)))
+    env._post()
+    sim.sync()
+    dist = env._goal_dist.cpu().numpy()
+    np.testing.assert_allclose(dist[:, 0], gold["fc_dist"][:, 0], atol=5e-6)
+    np.testing.assert_allclose(dist[:, 1], gold["fc_dist"][:, 1], atol=2e-5)
+
+
+def test_face_curriculum_goal_kernel_emul(full_model, gold, emul_lib):
+    _check_face_curriculum(full_model, gold, emul_lib)
+
+
+@pytest.mark.gpu
+def test_face_curriculum_goal_kernel_gpu(full_model, gold):
+    _check_face_curriculum(full_model, gold, None)

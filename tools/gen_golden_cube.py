@@ -203,6 +203,43 @@ def main():
         assert dist["cube_quat"] == 0.0
         rec2["probe_face"].append(pf); rec2["dist"].append(dist["cube_face_angle"])
     out.update({"fu_" + k: np.array(v) for k, v in rec2.items()})
+    # ---- FaceCurriculumGoal (goals/face_curriculum.py): as face_free, but a turn keeps the cube's orientation rounded to straight Euler angles
+    # and every distance is the plain quaternion difference
+    from robogym.envs.dactyl.goals.face_curriculum import FaceCurriculumGoal
+
+    fc = FaceCurriculumGoal.__new__(FaceCurriculumGoal)
+    fc.mujoco_simulation, fc.success_threshold, fc.face_geom_names = msim, {"cube_quat": 0.4, "cube_face_angle": 0.2}, FACES
+    fc.goal_directions, fc.round_target_face, fc.p_face_flip = ["cw", "ccw"], True, 0.25
+    fc.goal_quat_for_face = {i: table[i] for i in range(6)}
+    rec3 = {k: [] for k in ("qpos0", "qpos1", "geom_z", "draws", "goal_quat", "goal_face", "goal_type", "probe_quat", "probe_face", "dist")}
+    for case in range(64):
+        scrambled(rng.randint(0, 10))
+        axis = rng.randint(3)
+        for side in range(2):
+            cube.rotate_face(axis, side, rng.uniform(-0.1, 0.1) if case % 4 else rng.uniform(-0.6, 0.6))
+        base = np.array([rotation.quat_normalize(rotation.euler2quat(r)) for r in rotation.get_parallel_rotations()])[rng.randint(24)]
+        tilt = rotation.quat_from_angle_and_axis(np.array([rng.uniform(0, 0.3)]), rng.randn(3))
+        sim.data.qpos[quat_q] = rotation.quat_mul(rotation.quat_mul(rotation.quat_from_angle_and_axis(np.array([rng.uniform(-np.pi, np.pi)]), np.array([0.0, 0.0, 1.0])), tilt), base)
+        sim.data.qpos[tq] = rng.uniform(-1, 1, size=len(tq))
+        z = rng.uniform(0, 1, size=6)
+        sim.geom_z = dict(zip(FACES, z))
+        rec3["qpos0"].append(sim.data.qpos.copy()); rec3["geom_z"].append(z)
+        rr = RecordingRandom(7000 + case)
+        state = {"cube_pos": np.zeros(3), "cube_quat": sim.data.qpos[quat_q].copy(), "cube_face_angle": sim.data.qpos[[cube.joints_qpos_map[d] for d in cube.drivers]].copy()}
+        goal = fc.next_goal(rr, state)
+        d = np.zeros(5); d[0] = rr.log[0][3]
+        if goal["goal_type"] == "rotation":
+            d[1], d[2] = rr.log[1][3], rr.log[2][2]
+        else:
+            d[3], d[4] = rr.log[1][2], rr.log[2][3]
+        rec3["draws"].append(d); rec3["qpos1"].append(sim.data.qpos.copy())
+        rec3["goal_quat"].append(goal["cube_quat"]); rec3["goal_face"].append(goal["cube_face_angle"]); rec3["goal_type"].append(1 if goal["goal_type"] == "rotation" else 0)
+        pq = rotation.quat_mul(rotation.quat_from_angle_and_axis(np.array([rng.uniform(0, 0.6)]), rng.randn(3)), goal["cube_quat"]) if case % 2 else (lambda q: q / np.linalg.norm(q))(rng.randn(4))
+        pf = goal["cube_face_angle"] + (rng.uniform(-0.15, 0.15, size=6) if case % 2 else rng.uniform(-4, 4, size=6))
+        dist = fc.goal_distance(goal, {"cube_quat": pq, "cube_face_angle": pf, "cube_pos": np.zeros(3)})
+        rec3["probe_quat"].append(pq); rec3["probe_face"].append(pf); rec3["dist"].append([dist["cube_quat"], dist["cube_face_angle"]])
+    out.update({"fc_" + k: np.array(v) for k, v in rec3.items()})
+    print("face_curr cases: %d rotation" % sum(rec3["goal_type"]))
     print("next_goal cases: %d rotation, %d flip" % (sum(rec["goal_type"]), N - sum(rec["goal_type"])))
     np.savez_compressed(os.path.join(OUT, "full_cube.npz"), **out)
     print("wrote", os.path.join(OUT, "full_cube.npz"), {k: v.shape for k, v in out.items()})
