@@ -689,3 +689,35 @@ def test_face_curriculum_goal_kernel_emul(full_model, gold, emul_lib):
 @pytest.mark.gpu
 def test_face_curriculum_goal_kernel_gpu(full_model, gold):
     _check_face_curriculum(full_model, gold, None)
+
+
+@pytest.mark.gpu
+def test_full_cube_env_is_deterministic_at_full_batch_gpu(full_model):
+    """BASELINE.json configs[2]'s batch (4096): two envs built from the same seed -- reset recipe with scramble, then env.steps with the same
+    actions and in-step resets -- end in the same bits (state, goals, rewards, counters): no atomics, no unordered sums anywhere on the path.
+    And the batch is not 4096 copies of one trajectory."""
+    from robogym_amd.envs.dactyl.full_perpendicular import BatchedFullPerpendicularEnv, FullPerpendicularEnvConstants
+
+    B = 4096
+    runs = []
+    for rep in range(2):
+        env = BatchedFullPerpendicularEnv(B, model=full_model, device="cuda:0", starting_seed=17, pipelined_reset=True,
+                                          constants=FullPerpendicularEnvConstants(max_pose_resets=2, max_timesteps_per_goal=3))
+        env.stop_on_fall = True
+        env.reset()
+        q_reset = env.sim.qpos.clone()
+        gen = torch.Generator(device="cuda:0"); gen.manual_seed(5)
+        rsum = torch.zeros(B, 3, device="cuda:0")
+        for k in range(6):
+            obs, rew, done, info = env.step(torch.rand((B, 20), generator=gen, device="cuda:0") * 2 - 1)
+            rsum += rew
+        env.sim.sync()
+        runs.append((env.sim.qpos.clone(), env.sim.qvel.clone(), env.sim.pid.clone(), env._goal.clone(), rsum, env._phase.clone(), env.multi_goal_tracker.goals_so_far.clone(),
+                     env._obs_buf.clone(), env.sim.status.clone(), q_reset))
+        del env
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+    status, phase, q_reset = runs[0][8], runs[0][5], runs[0][9]
+    assert int(status.max()) == 0
+    assert int((phase > 0).sum()) > B // 2                      # 3-step goals: most envs are inside the in-step recipe by now (all on the same settling trajectory)
+    assert len(torch.unique(q_reset[:, :3].double().sum(1))) > B // 2      # after reset(): every env its own scramble, pose and random action
