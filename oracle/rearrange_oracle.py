@@ -1,0 +1,411 @@
+"""Env-level CPU oracle for the rearrange hot path (UR16e + 2f-85 gripper, `tcp+roll+yaw` control through the `mocap_ik`
+dual simulation): a one-env, double-precision numpy restatement of `RearrangeEnv.step` around the C physics oracle
+(oracle/rg_oracle.c).  TEST INFRASTRUCTURE ONLY (tests/, smoke(), bench.py's cpu_baseline leg).
+
+PARITY UNPINNED vs MuJoCo for the physics (see oracle/rg_oracle.c); what pins the pieces restated HERE:
+  * rotation helpers: tests/golden/rearrange_rotation.npz, generated from the reference's own `robogym.utils.rotation`
+    (tools/gen_golden_rearrange.py);
+  * the controller chain as a whole: the reference's own property tests re-expressed on this oracle
+    (/root/reference/robogym/envs/rearrange/tests/test_rearrange_sim.py:96-230: gripper sync, mocap-IK impulse response;
+    tests/test_rearrange_robots.py:45-78,194-243: action scaling tables) in tests/test_rearrange_oracle.py.
+
+Follows, one env at a time:
+  action -> controls   robot_env.py:497-504, robot/composite/composite_robot.py:72-107,
+                       robot/ur16e/mujoco/free_dof_tcp_arm.py:161-206 (FreeRollYawTcpArm), robot/robot_interface.py:220-278 (gripper)
+  dual simulation      robot/ur16e/mujoco/joint_controlled_tcp_arm.py:89-129, robot/control/tcp/mocap_solver.py:33-57,
+                       gym.envs.robotics.utils.{mocap_set_action, reset_mocap_welds, reset_mocap2body_xpos} (gym==0.15.3, not in
+                       the tree: restated from SURVEY.md appendix B)
+  physics              mujoco/simulation_interface.py:176-189 (nsubsteps x mj_step + mj_forward), robot_env.py:672-688 (+1 mj_forward)
+  observation          envs/rearrange/common/base.py:376-421, envs/rearrange/simulation/base.py:420-640,
+                       robot/ur16e/mujoco/joint_controlled_arm.py:20-85
+  goal / reward        envs/rearrange/goals/object_state.py:492-599, envs/rearrange/common/base.py:768-795,824-848
+"""
+import numpy as np
+
+from oracle.rg_oracle import OracleSim
+from robogym_amd.mujoco.model_blob import pack_model
+
+EQ_WELD = 1
+TABLETOP_EXPERIMENT_INITIAL_POS = np.deg2rad(np.array([135.0, -90, 135, -100, -240, 135]))   # robot/ur16e/arm_interface.py:27
+SAFETY_STOP_FORCE_THRESHOLD = 150.0                                                          # arm_interface.py:46
+JOINT_DRIFT_THRESHOLD = np.deg2rad(1)                                                        # free_dof_tcp_arm.py:26-28
+SPEED_ROLL, SPEED_PITCH = np.deg2rad(200), np.deg2rad(600)                                   # free_dof_tcp_arm.py:13-17
+
+
+# ----------------------------------------------------------------------------------------- rotation helpers (utils/rotation.py)
+def quat_mul(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    w0, x0, y0, z0 = a[..., 0], a[..., 1], a[..., 2], a[..., 3]
+    w1, x1, y1, z1 = b[..., 0], b[..., 1], b[..., 2], b[..., 3]
+    return np.stack([w0 * w1 - x0 * x1 - y0 * y1 - z0 * z1, w0 * x1 + x0 * w1 + y0 * z1 - z0 * y1,
+                     w0 * y1 - x0 * z1 + y0 * w1 + z0 * x1, w0 * z1 + x0 * y1 - y0 * x1 + z0 * w1], axis=-1)
+
+
+def quat_conjugate(q):
+    q = np.asarray(q, dtype=float)
+    return q * np.array([1.0, -1, -1, -1])
+
+
+def quat_normalize(q):
+    """sign normalisation to w >= 0 (rotation.py:281-286)"""
+    q = np.asarray(q, dtype=float)
+    return q * np.where(q[..., :1] < 0, -1.0, 1.0)
+
+
+def quat_magnitude(q):
+    return 2 * np.arccos(np.clip(np.asarray(q)[..., 0], -1.0, 1.0))
+
+
+def euler2quat(e):
+    """Euler angles -> quaternion in the convention of rotation.py:110-126: q = qx(e0) * qy(e1) * qz(e2)"""
+    e = np.asarray(e, dtype=float)
+    hx, hy, hz = 0.5 * e[..., 0], 0.5 * e[..., 1], 0.5 * e[..., 2]
+    cx, sx, cy, sy, cz, sz = np.cos(hx), np.sin(hx), np.cos(hy), np.sin(hy), np.cos(hz), np.sin(hz)
+    return np.stack([cx * cy * cz - sx * sy * sz, sx * cy * cz + cx * sy * sz, cx * sy * cz - sx * cy * sz, cx * cy * sz + sx * sy * cz], axis=-1)
+
+
+def quat2mat(q):
+    q = np.asarray(q, dtype=float)
+    w, x, y, z = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    n = w * w + x * x + y * y + z * z
+    s = np.where(n > np.finfo(float).eps, 2.0 / np.where(n > 0, n, 1.0), 0.0)
+    m = np.empty(q.shape[:-1] + (3, 3))
+    m[..., 0, 0] = 1 - s * (y * y + z * z); m[..., 0, 1] = s * (x * y - w * z); m[..., 0, 2] = s * (x * z + w * y)
+    m[..., 1, 0] = s * (x * y + w * z); m[..., 1, 1] = 1 - s * (x * x + z * z); m[..., 1, 2] = s * (y * z - w * x)
+    m[..., 2, 0] = s * (x * z - w * y); m[..., 2, 1] = s * (y * z + w * x); m[..., 2, 2] = 1 - s * (x * x + y * y)
+    bad = ~(n > np.finfo(float).eps)
+    if np.any(bad):
+        m[bad] = np.eye(3)
+    return m
+
+
+def mat2euler(m):
+    """rotation.py:129-148 (gimbal branch when cos(pitch) vanishes)"""
+    m = np.asarray(m, dtype=float)
+    cy = np.sqrt(m[..., 2, 2] ** 2 + m[..., 1, 2] ** 2)
+    ok = cy > np.finfo(float).eps * 4
+    e = np.empty(m.shape[:-2] + (3,))
+    e[..., 2] = np.where(ok, -np.arctan2(m[..., 0, 1], m[..., 0, 0]), -np.arctan2(-m[..., 1, 0], m[..., 1, 1]))
+    e[..., 1] = -np.arctan2(-m[..., 0, 2], cy)
+    e[..., 0] = np.where(ok, -np.arctan2(m[..., 1, 2], m[..., 2, 2]), 0.0)
+    return e
+
+
+def quat2euler(q):
+    return mat2euler(quat2mat(q))
+
+
+def mat2quat(m):
+    """largest-eigenvector construction of rotation.py:151-185 (symmetric 4x4 K matrix), batched over the leading axes"""
+    m = np.asarray(m, dtype=float)
+    xx, yx, zx = m[..., 0, 0], m[..., 0, 1], m[..., 0, 2]
+    xy, yy, zy = m[..., 1, 0], m[..., 1, 1], m[..., 1, 2]
+    xz, yz, zz = m[..., 2, 0], m[..., 2, 1], m[..., 2, 2]
+    K = np.zeros(m.shape[:-2] + (4, 4))
+    K[..., 0, 0] = xx - yy - zz; K[..., 1, 0] = yx + xy; K[..., 1, 1] = yy - xx - zz
+    K[..., 2, 0] = zx + xz; K[..., 2, 1] = zy + yz; K[..., 2, 2] = zz - xx - yy
+    K[..., 3, 0] = yz - zy; K[..., 3, 1] = zx - xz; K[..., 3, 2] = xy - yx; K[..., 3, 3] = xx + yy + zz
+    K /= 3.0
+    q = np.empty(K.shape[:-2] + (4,))
+    it = np.nditer(q[..., 0], flags=["multi_index"])
+    while not it.finished:
+        vals, vecs = np.linalg.eigh(K[it.multi_index])
+        v = vecs[[3, 0, 1, 2], np.argmax(vals)]
+        q[it.multi_index] = -v if v[0] < 0 else v
+        it.iternext()
+    return q
+
+
+def subtract_euler(e1, e2):
+    return quat2euler(quat_mul(euler2quat(e1), quat_conjugate(euler2quat(e2))))
+
+
+def normalize_angles(a, low=-np.pi, high=np.pi):
+    a = np.asarray(a, dtype=float)
+    return np.mod(a - low, high - low) + low if a.size else a.copy()
+
+
+# ----------------------------------------------------------------------------------------- one simulation with name lookups
+class OracleArmSim:
+    """An `OracleSim` of one of the two rearrange worlds plus the handful of id lookups the robot code does by name."""
+
+    def __init__(self, model, n_substeps=40):
+        self.model, self.n_substeps = model, n_substeps
+        self.sim = OracleSim(pack_model(model))
+        A, jn = model.arrays, model.names["joint"]
+        self.arm_q = np.array([A["jnt_qposadr"][jn.index("robot0:J%d" % k)] for k in range(1, 7)])
+        self.arm_v = np.array([A["jnt_dofadr"][jn.index("robot0:J%d" % k)] for k in range(1, 7)])
+        self.grip_q = int(A["jnt_qposadr"][jn.index("robot0:r_gripper_RJ0_outer")])
+        self.grip_v = int(A["jnt_dofadr"][jn.index("robot0:r_gripper_RJ0_outer")])
+        self.grip_act = model.names["actuator"].index("robot0:r_gripper_finger_joint")
+        self.tcp_body = model.name2id("body", "robot0:gripper_tcp")
+        self.nv = int(model.dims[1])
+
+    # mujoco-py MjSim.step / SimulationInterface.step
+    def mj_sim_step(self):
+        for _ in range(self.n_substeps):
+            self.sim.step()
+
+    def step(self):
+        self.mj_sim_step()
+        self.sim.forward()
+
+    def body_xpos(self, b):
+        return self.sim.xpos[3 * b:3 * b + 3].copy()
+
+    def body_xquat(self, b):
+        return self.sim.xquat[4 * b:4 * b + 4].copy()
+
+    def body_xmat(self, b):
+        return self.sim.xmat[9 * b:9 * b + 9].reshape(3, 3).copy()
+
+    def body_xvel(self, b):
+        """mujoco-py `body_xvelp / body_xvelr`: Jacobian of the body frame's origin times qvel (world frame)."""
+        A = self.model.arrays
+        s = self.sim
+        cdof = s.cdof.reshape(-1, 6)
+        bb = b
+        while bb > 0 and A["body_dofnum"][bb] == 0:
+            bb = int(A["body_parentid"][bb])
+        vp, vr = np.zeros(3), np.zeros(3)
+        if bb <= 0:
+            return vp, vr
+        root = int(A["body_rootid"][b])
+        off = s.xpos[3 * b:3 * b + 3] - s.subtree_com[3 * root:3 * root + 3]
+        i = int(A["body_dofadr"][bb] + A["body_dofnum"][bb] - 1)
+        while i >= 0:
+            vr += cdof[i, :3] * s.qvel[i]
+            vp += (cdof[i, 3:] + np.cross(cdof[i, :3], off)) * s.qvel[i]
+            i = int(A["dof_parentid"][i])
+        return vp, vr
+
+
+# gym.envs.robotics.utils (gym==0.15.3), SURVEY appendix B
+def reset_mocap_welds(o: OracleArmSim):
+    A = o.model.arrays
+    if o.sim.nmocap > 0 and o.sim.neq > 0:
+        ed = o.sim.eq_data.reshape(-1, 7)
+        for e in range(o.sim.neq):
+            if A["eq_type"][e] == EQ_WELD:
+                ed[e] = [0, 0, 0, 1, 0, 0, 0]
+    o.sim.forward()
+
+
+def reset_mocap2body_xpos(o: OracleArmSim):
+    A = o.model.arrays
+    for e in range(o.sim.neq):
+        if A["eq_type"][e] != EQ_WELD:
+            continue
+        b1, b2 = int(A["eq_obj1id"][e]), int(A["eq_obj2id"][e])
+        mid = int(A["body_mocapid"][b1])
+        body = b2
+        if mid == -1:
+            mid, body = int(A["body_mocapid"][b2]), b1
+        assert mid != -1
+        o.sim.mocap_pos[3 * mid:3 * mid + 3] = o.sim.xpos[3 * body:3 * body + 3]
+        o.sim.mocap_quat[4 * mid:4 * mid + 4] = o.sim.xquat[4 * body:4 * body + 4]
+
+
+def mocap_set_action(o: OracleArmSim, action):
+    if o.sim.nmocap > 0:
+        a = np.asarray(action, dtype=float)[:7 * o.sim.nmocap].reshape(-1, 7)
+        reset_mocap2body_xpos(o)
+        o.sim.mocap_pos[:] = o.sim.mocap_pos + a[:, :3].reshape(-1)
+        o.sim.mocap_quat[:] = o.sim.mocap_quat + a[:, 3:].reshape(-1)
+
+
+# ----------------------------------------------------------------------------------------- the env
+class OracleRearrangeEnv:
+    """`BlockRearrangeEnv` (envs/rearrange/blocks.py) with its default robot: MujocoURTcpJointGripperCompositeRobot =
+    JointControlledTcpArm (FreeRollYawTcpArm controller in the solver simulation) + MujocoRobotiqGripper."""
+
+    def __init__(self, main_model, solver_model, num_objects, n_substeps=40, max_position_change=0.1, arm_reset_controller_error=True,
+                 success_threshold=None, goal_reward_per_object=1.0, penalty=None):
+        self.main, self.solver = OracleArmSim(main_model, n_substeps), OracleArmSim(solver_model, n_substeps)
+        self.num_objects = num_objects
+        self.mpc, self.reset_controller_error = max_position_change, arm_reset_controller_error
+        self.success_threshold = dict(success_threshold or {"obj_pos": 0.04, "obj_rot": 0.2})
+        self.goal_reward_per_object = goal_reward_per_object
+        self.penalty = dict(penalty or dict(table_collision=0.0, objects_off_table=1.0, wrist_collision=0.0))
+        m, A = main_model, main_model.arrays
+        jn = m.names["joint"]
+        self.obj_q = [int(A["jnt_qposadr"][jn.index("object%d:joint" % i)]) for i in range(num_objects)]
+        self.obj_body = [m.name2id("body", "object%d" % i) for i in range(num_objects)]
+        self.target_body = [m.name2id("body", "target:object%d" % i) for i in range(num_objects)]
+        gn = m.names["geom"]
+        self.finger_geoms = [gn.index("robot0:left_contact_v"), gn.index("robot0:right_contact_v")]
+        self.table_plane_geom = gn.index("table_collision_plane")
+        self.gripper_geoms = [g for b in ("robot0:gripper_base", "left_gripper", "left_inner_follower", "left_outer_driver", "right_gripper",
+                                          "right_inner_follower", "right_outer_driver")
+                              for g in range(len(gn)) if A["geom_bodyid"][g] == m.name2id("body", b)]
+        tb, tg = m.name2id("body", "table"), gn.index("table")
+        self.table_pos, self.table_size = A["body_pos"][tb].copy(), A["geom_size"][tg].copy()
+        self.table_height = self.table_pos[2] + self.table_size[2]          # simulation/base.py compute_table_dimension
+        sn = m.names["sensor"]
+        self.force_adr, self.torque_adr = int(A["sensor_adr"][sn.index("toolhead_force")]), int(A["sensor_adr"][sn.index("toolhead_torque")])
+        self.goal = None
+        self.prev_dist = None
+        self.reset_robot()
+
+    # ------------------------------------------------------------------ reset pieces
+    def reset_robot(self):
+        """`JointControlledArm.__init__ / reset`, `JointControlledTcpArm.__init__`, `MujocoRobotiqGripper.__init__`,
+        `RearrangeEnv._initialize_sim_state` (joint actuated: no weld in the main world) + `robot.reset()`."""
+        s = self.main.sim
+        s.qpos[self.main.arm_q] = TABLETOP_EXPERIMENT_INITIAL_POS
+        s.ctrl[:6] = TABLETOP_EXPERIMENT_INITIAL_POS
+        s.ctrl[self.main.grip_act] = s.qpos[self.main.grip_q]
+        c = self.solver.sim
+        c.qpos[self.solver.arm_q] = s.qpos[self.main.arm_q]
+        c.forward()
+        c.ctrl[self.solver.grip_act] = c.qpos[self.solver.grip_q]
+        reset_mocap_welds(self.solver)
+        reset_mocap2body_xpos(self.solver)
+
+    def set_object_poses(self, pos, quat):
+        for i, qa in enumerate(self.obj_q):
+            self.main.sim.qpos[qa:qa + 3] = pos[i]
+            self.main.sim.qpos[qa + 3:qa + 7] = quat[i]
+
+    def set_goal(self, goal_pos, goal_rot_euler):
+        self.goal = {"obj_pos": np.asarray(goal_pos, dtype=float).copy(), "obj_rot": np.asarray(goal_rot_euler, dtype=float).copy()}
+        self.prev_dist = None
+
+    # ------------------------------------------------------------------ action path
+    def denormalize(self, action):
+        """CompositeRobot.denormalize_position_control (relative actions): 5 arm numbers + 1 gripper number."""
+        a = np.clip(np.asarray(action, dtype=float), -1, 1)
+        arm = np.concatenate([a[:3] * self.mpc, a[3:5] * np.array([SPEED_ROLL, SPEED_PITCH]) * self.mpc])
+        A = self.main.model.arrays
+        lo, hi = A["actuator_ctrlrange"][self.main.grip_act]
+        grip = np.clip(self.main.sim.ctrl[self.main.grip_act] + a[5] * 0.5 * (hi - lo), lo, hi)
+        return arm, grip
+
+    def set_action(self, action):
+        arm, grip = self.denormalize(action)
+        m, c = self.main, self.solver
+        # JointControlledTcpArm.set_position_control
+        if self.reset_controller_error:
+            c.sim.qpos[c.arm_q] = m.sim.qpos[m.arm_q]
+            c.sim.forward()
+        pos, angle = arm[:3], arm[3:].copy()
+        # FreeDOFTcpArm.constrain_quat_ctrl: the PITCH dimension is the wrist joint (index 5), kept inside its range
+        A = c.model.arrays
+        j6 = c.model.names["joint"].index("robot0:J6")
+        lo, hi = A["jnt_range"][j6]
+        q6 = c.sim.qpos[c.arm_q[5]]
+        angle[1] = np.clip(angle[1], lo + JOINT_DRIFT_THRESHOLD - q6, hi - JOINT_DRIFT_THRESHOLD - q6)
+        # MocapSolver.get_tcp_quat: dof dims (ROLL -> euler[0], PITCH -> euler[2]), a quaternion DIFFERENCE
+        euler = np.zeros(3); euler[0], euler[2] = angle[0], angle[1]
+        gq = c.body_xquat(c.tcp_body)
+        dq = quat_mul(gq, euler2quat(euler)) - gq
+        mocap_set_action(c, np.concatenate([pos, dq]))
+        c.mj_sim_step()                                             # controller_autostep: MjSim.step, no trailing forward
+        m.sim.ctrl[:6] = c.sim.qpos[c.arm_q]                        # JointControlledArm.set_position_control
+        m.sim.ctrl[m.grip_act] = grip                               # MujocoRobotiqGripper.set_position_control
+
+    def observe_sync(self):
+        """RobotEnv._observe_sync: one more mj_forward, goal info, observation, robots notified (gripper state -> solver world)."""
+        self.main.sim.forward()
+        obs = self.observe()
+        c = self.solver
+        c.sim.qpos[c.grip_q] = obs["gripper_qpos"][0]
+        c.sim.ctrl[c.grip_act] = obs["gripper_controls"][0]
+        return obs
+
+    def env_step(self, action):
+        self.set_action(action)
+        self.main.step()
+        obs = self.observe_sync()
+        info = self.simulation_info(obs)
+        reward, done = self.simulation_reward_with_done(obs, info)
+        goal_reward = 0.0
+        if self.goal is not None:
+            dist = self.goal_distance()
+            goal_reward = 0.0 if self.prev_dist is None else self.num_success(dist) - self.num_success(self.prev_dist)
+            self.prev_dist = dist
+        return obs, reward, goal_reward, done, info
+
+    # ------------------------------------------------------------------ observation (common/base.py:376-421)
+    def object_state(self):
+        m = self.main
+        pos = np.array([m.body_xpos(b) for b in self.obj_body])
+        mats = np.array([m.body_xmat(b) for b in self.obj_body])
+        return pos, normalize_angles(mat2euler(mats)), mats
+
+    def observe(self):
+        m, s = self.main, self.main.sim
+        pos, rot, mats = self.object_state()
+        tcp_pos = m.body_xpos(m.tcp_body)
+        tcp_velp, _ = m.body_xvel(m.tcp_body)
+        vel = [m.body_xvel(b) for b in self.obj_body]
+        force = s.sensordata[self.force_adr:self.force_adr + 3].copy()
+        obs = {
+            "obj_pos": pos, "obj_rel_pos": pos - tcp_pos, "obj_vel_pos": np.array([v[0] - tcp_velp for v in vel]), "obj_rot": rot,
+            "obj_vel_rot": np.array([v[1] for v in vel]), "robot_joint_pos": s.qpos[m.arm_q].copy(), "gripper_pos": tcp_pos, "gripper_velp": tcp_velp,
+            "gripper_controls": s.ctrl[m.grip_act:m.grip_act + 1].copy(), "gripper_qpos": s.qpos[m.grip_q:m.grip_q + 1].copy(),
+            "gripper_vel": s.qvel[m.grip_v:m.grip_v + 1].copy(), "qpos": s.qpos.copy(), "obj_gripper_contact": self.object_gripper_contact(),
+            "safety_stop": np.array([np.linalg.norm(force) > SAFETY_STOP_FORCE_THRESHOLD]), "tcp_force": force,
+            "tcp_torque": s.sensordata[self.torque_adr:self.torque_adr + 3].copy(),
+        }
+        if self.goal is not None:
+            rel = self.relative_goal(pos, rot)
+            obs.update(goal_obj_pos=self.goal["obj_pos"].copy(), goal_obj_rot=self.goal["obj_rot"].copy(), rel_goal_obj_pos=rel[0], rel_goal_obj_rot=rel[1])
+        return obs
+
+    def object_gripper_contact(self, dist_cutoff=1.0e-5):
+        """simulation/base.py:592-635: per object and finger pad, any contact between them"""
+        A = self.main.model.arrays
+        out = np.zeros((self.num_objects, 2))
+        for c in self.main.sim.contacts():
+            if not c["dist"] < dist_cutoff:
+                continue
+            for k, fg in enumerate(self.finger_geoms):
+                other = c["geom2"] if c["geom1"] == fg else (c["geom1"] if c["geom2"] == fg else -1)
+                if other >= 0:
+                    b = int(A["geom_bodyid"][other])
+                    if b in self.obj_body:
+                        out[self.obj_body.index(b), k] = 1.0
+        return out
+
+    def gripper_table_contact(self):
+        """robot/ur16e/mujoco/simulation/base.py:142-167"""
+        for c in self.main.sim.contacts():
+            other = c["geom2"] if c["geom1"] in self.gripper_geoms else (c["geom1"] if c["geom2"] in self.gripper_geoms else -1)
+            if other == self.table_plane_geom:
+                return True
+        return False
+
+    def objects_off_table(self, pos):
+        """simulation/base.py:805-832"""
+        lo, hi = self.table_pos - self.table_size, self.table_pos + self.table_size
+        return (pos[:, 2] < self.table_height * 0.75) | (pos[:, 0] < lo[0]) | (pos[:, 0] > hi[0]) | (pos[:, 1] < lo[1]) | (pos[:, 1] > hi[1])
+
+    def simulation_info(self, obs):
+        return {"objects_off_table": self.objects_off_table(obs["obj_pos"])}
+
+    def simulation_reward_with_done(self, obs, info):
+        """common/base.py:768-795"""
+        reward, done = 0.0, False
+        if self.gripper_table_contact():
+            reward -= self.penalty.get("table_collision", 0.0)
+        if info["objects_off_table"].any():
+            done = True
+            reward -= self.penalty.get("objects_off_table", 0.0)
+        if obs["safety_stop"].any():
+            reward -= self.penalty.get("safety_stop", 0.0)
+        return reward, done
+
+    # ------------------------------------------------------------------ goal (goals/object_state.py:492-599, rot_dist_type "full")
+    def relative_goal(self, pos, rot):
+        return self.goal["obj_pos"] - pos, normalize_angles(subtract_euler(self.goal["obj_rot"], rot))
+
+    def goal_distance(self):
+        pos, rot, _ = self.object_state()
+        rel_pos, rel_rot = self.relative_goal(pos, rot)
+        return {"obj_pos": np.maximum(np.linalg.norm(rel_pos, axis=-1), 0), "obj_rot": quat_magnitude(quat_normalize(euler2quat(rel_rot)))}
+
+    def num_success(self, dist):
+        """common/base.py:824-842"""
+        ok = np.all(np.stack([dist[k] < self.success_threshold[k] for k in self.success_threshold], axis=0), axis=0)
+        return float(np.sum(ok) * self.goal_reward_per_object)

@@ -46,10 +46,15 @@ enum { JNT_FREE = 0, JNT_BALL, JNT_SLIDE, JNT_HINGE };
 enum { GEOM_PLANE = 0, GEOM_HFIELD, GEOM_SPHERE, GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_CYLINDER, GEOM_BOX, GEOM_MESH };
 enum { WRAP_JOINT = 1, WRAP_PULLEY, WRAP_SITE, WRAP_SPHERE, WRAP_CYLINDER };
 enum { TRN_JOINT = 0, TRN_TENDON = 3 };
-enum { EFC_FRICTION_DOF = 1, EFC_FRICTION_TENDON, EFC_LIMIT_JOINT, EFC_LIMIT_TENDON, EFC_CONTACT_PYRAMIDAL };
+enum { EFC_EQUALITY = 0, EFC_FRICTION_DOF = 1, EFC_FRICTION_TENDON, EFC_LIMIT_JOINT, EFC_LIMIT_TENDON, EFC_CONTACT_PYRAMIDAL, EFC_CONTACT_ELLIPTIC = 7 };
+enum { EQ_WELD = 1, EQ_JOINT = 2 };                               /* mjtEq */
+enum { SENS_TOUCH = 0, SENS_FORCE = 4, SENS_TORQUE = 5, SENS_JOINTPOS = 8 };   /* mjtSensor (MuJoCo 2.0) */
 
 typedef struct {
   int nq, nv, nu, nbody, njnt, ngeom, nsite, ntendon, nwrap, nmesh, nmeshvert, nexclude, nsensor;
+  int neq, nmocap, nsensordata;   /* rearrange models (ur16e/base.xml:52-54, gripper_actuators.xml:3); 0 for the dactyl models */
+  const int *eq_type, *eq_obj1id, *eq_obj2id, *eq_active0, *body_mocapid, *sensor_adr, *sensor_dim;
+  const real *eq_solref, *eq_solimp, *eq_data0;
   real timestep, gravity[3], tolerance, impratio, ls_tolerance, mpr_tolerance, meaninertia;
   int iterations, cone, ls_iterations, mpr_iterations;
   int nconmax, njmax;
@@ -89,9 +94,13 @@ typedef struct {
   int dim, geom1, geom2, efc_address;
 } ro_contact;
 
-typedef struct {
+typedef struct ro_data_s {
   /* state */
   real *qpos, *qvel, *ctrl, *pid, *qacc_warmstart, time;
+  real *mocap_pos, *mocap_quat;   /* [nmocap][3], [nmocap][4]: mjData.mocap_pos / mocap_quat */
+  real* eq_data; int* eq_active;  /* [neq][7], [neq]: run-time copies (gym's reset_mocap_welds writes eq_data; the envs toggle eq_active) */
+  int ne;                         /* equality rows (they come first, as in mj_makeConstraint) */
+  real *cacc, *cfrc_int, *cfrc_ext;   /* [nbody][6]: mj_rnePostConstraint, for the force / torque sensors */
   real* xfrc_applied; /* [nbody][6] force, torque in world coordinates, applied at the body's com (mjData.xfrc_applied) */
   /* position stage */
   real *xpos, *xquat, *xmat, *xipos, *ximat, *xanchor, *xaxis, *geom_xpos, *geom_xmat, *site_xpos, *site_xmat;
@@ -242,11 +251,29 @@ ro_model* ro_model_load(const void* blob_in, size_t nbytes) {
   I32(actuator_gaintype); I32(actuator_biastype);
   F64(actuator_gear); F64(actuator_ctrlrange); F64(actuator_forcerange); F64(actuator_gainprm); F64(actuator_biasprm);
   F64(actuator_user);
+  /* optional sections (absent from model files compiled before the rearrange features existed) */
+  { uint32_t n = 0;
+    m->eq_type = (const int*)blob_find(m->blob, "eq_type", &n, 0); m->neq = m->eq_type ? (int)n : 0;
+    if (m->neq) { I32(eq_obj1id); I32(eq_obj2id); m->eq_active0 = (const int*)blob_find(m->blob, "eq_active", NULL, 1); F64(eq_solref); F64(eq_solimp);
+#ifdef RO_F32
+      m->eq_data0 = blob_f64_as_real(m, "eq_data");
+#else
+      m->eq_data0 = (const real*)blob_find(m->blob, "eq_data", NULL, 1);
+#endif
+    }
+    m->body_mocapid = (const int*)blob_find(m->blob, "body_mocapid", NULL, 0);
+    const int* nm = (const int*)blob_find(m->blob, "nmocap", NULL, 0); m->nmocap = (nm && m->body_mocapid) ? nm[0] : 0;
+    m->sensor_adr = (const int*)blob_find(m->blob, "sensor_adr", NULL, 0); m->sensor_dim = (const int*)blob_find(m->blob, "sensor_dim", NULL, 0);
+    m->nsensordata = m->nsensor;
+    if (m->sensor_adr && m->sensor_dim && m->nsensor > 0) m->nsensordata = m->sensor_adr[m->nsensor - 1] + m->sensor_dim[m->nsensor - 1];
+  }
   return m;
 }
 void ro_model_free(ro_model* m) { if (m) { for (int i = 0; i < m->nconv; i++) free(m->conv[i]); free(m->blob); free(m); } }
 
 static real* dalloc(size_t n) { return (real*)calloc(n ? n : 1, sizeof(real)); }
+/* the parts of mjData / mjModel that mj_resetData and a fresh model restore: mocap pose <- body pose, equality data and flags */
+static void ro_reset_model_state(const ro_model* m, ro_data* d);
 
 ro_data* ro_data_new(const ro_model* m) {
   ro_data* d = (ro_data*)calloc(1, sizeof(ro_data));
@@ -270,8 +297,12 @@ ro_data* ro_data_new(const ro_model* m) {
   d->cdof_dot = dalloc(6 * nv); d->qfrc_passive = dalloc(nv); d->qfrc_bias = dalloc(nv);
   d->actuator_force = dalloc(m->nu); d->qfrc_actuator = dalloc(nv); d->qfrc_smooth = dalloc(nv);
   d->qacc_smooth = dalloc(nv); d->qfrc_constraint = dalloc(nv); d->qacc = dalloc(nv);
-  d->sensordata = dalloc(m->nsensor > 0 ? m->nsensor : 1);
+  d->sensordata = dalloc(m->nsensordata > 0 ? m->nsensordata : 1);
+  d->mocap_pos = dalloc(3 * m->nmocap); d->mocap_quat = dalloc(4 * m->nmocap);
+  d->eq_data = dalloc(7 * m->neq); d->eq_active = (int*)calloc(m->neq ? m->neq : 1, sizeof(int));
+  d->cacc = dalloc(6 * nb); d->cfrc_int = dalloc(6 * nb); d->cfrc_ext = dalloc(6 * nb);
   memcpy(d->qpos, m->qpos0, m->nq * sizeof(real));
+  ro_reset_model_state(m, d);
   return d;
 }
 void ro_data_free(ro_data* d) {
@@ -282,9 +313,18 @@ void ro_data_free(ro_data* d) {
                   &d->actuator_moment, &d->qM, &d->qL, &d->efc_J, &d->efc_pos, &d->efc_margin, &d->efc_frictionloss,
                   &d->efc_diagApprox, &d->efc_R, &d->efc_D, &d->efc_KBIP, &d->efc_vel, &d->efc_aref, &d->efc_force,
                   &d->ten_velocity, &d->actuator_velocity, &d->cvel, &d->cdof_dot, &d->qfrc_passive, &d->qfrc_bias,
-                  &d->actuator_force, &d->qfrc_actuator, &d->qfrc_smooth, &d->qacc_smooth, &d->qfrc_constraint, &d->qacc};
+                  &d->actuator_force, &d->qfrc_actuator, &d->qfrc_smooth, &d->qacc_smooth, &d->qfrc_constraint, &d->qacc,
+                  &d->mocap_pos, &d->mocap_quat, &d->eq_data, &d->cacc, &d->cfrc_int, &d->cfrc_ext, &d->sensordata};
   for (size_t i = 0; i < sizeof(p) / sizeof(p[0]); i++) free(*p[i]);
-  free(d->efc_type); free(d->efc_id); free(d);
+  free(d->efc_type); free(d->efc_id); free(d->eq_active); free(d);
+}
+static void ro_reset_model_state(const ro_model* m, ro_data* d) {
+  for (int b = 0; b < m->nbody && m->nmocap; b++) {
+    int k = m->body_mocapid[b];
+    if (k < 0) continue;
+    copy3(d->mocap_pos + 3 * k, m->body_pos + 3 * b); memcpy(d->mocap_quat + 4 * k, m->body_quat + 4 * b, 4 * sizeof(real));
+  }
+  for (int e = 0; e < m->neq; e++) { d->eq_active[e] = m->eq_active0[e]; memcpy(d->eq_data + 7 * e, m->eq_data0 + 7 * e, 7 * sizeof(real)); }
 }
 
 /* mj_resetData: qpos <- qpos0, everything else zero (mujoco-py MjSim.reset) */
@@ -294,6 +334,11 @@ void ro_reset(const ro_model* m, ro_data* d) {
   memset(d->pid, 0, 3 * m->nu * sizeof(real)); memset(d->qacc_warmstart, 0, m->nv * sizeof(real));
   memset(d->xfrc_applied, 0, 6 * m->nbody * sizeof(real));
   d->time = 0; d->warn_bad = d->warn_contact_full = d->warn_efc_full = 0;
+  /* mj_resetData restores the mocap pose; eq_data / eq_active are model fields and survive a reset */
+  for (int b = 0; b < m->nbody && m->nmocap; b++) {
+    int k = m->body_mocapid[b];
+    if (k >= 0) { copy3(d->mocap_pos + 3 * k, m->body_pos + 3 * b); memcpy(d->mocap_quat + 4 * k, m->body_quat + 4 * b, 4 * sizeof(real)); }
+  }
 }
 
 /* ------------------------------------------------------------------------------------------ kinematics
@@ -307,6 +352,9 @@ static void ro_kinematics(const ro_model* m, ro_data* d) {
     mulmat3(tmp, d->xmat + 9 * p, m->body_pos + 3 * b);
     add3(pos, d->xpos + 3 * p, tmp);
     mulquat(quat, d->xquat + 4 * p, m->body_quat + 4 * b);
+    if (m->nmocap && m->body_mocapid[b] >= 0) {   /* mj_kinematics: a mocap body takes its pose from mjData.mocap_pos / mocap_quat (normalised) */
+      copy3(pos, d->mocap_pos + 3 * m->body_mocapid[b]); memcpy(quat, d->mocap_quat + 4 * m->body_mocapid[b], 4 * sizeof(real));
+    }
     for (int k = 0; k < m->body_jntnum[b]; k++) {
       int j = m->body_jntadr[b] + k, qa = m->jnt_qposadr[j], t = m->jnt_type[j];
       if (t == JNT_FREE) {
@@ -1052,7 +1100,57 @@ static int add_row(const ro_model* m, ro_data* d, int type, int id, real pos, re
 }
 static void ro_make_constraint(const ro_model* m, ro_data* d) {
   int nv = m->nv;
-  d->nefc = d->nf = d->nl = 0;
+  d->nefc = d->nf = d->nl = d->ne = 0;
+  /* equality constraints (mj_instantiateEquality), MuJoCo 2.0 semantics:
+   *   weld  (ur16e/base.xml:52-54, the mocap weld of the TCP solver simulation): eq_data = pose of body2 in the frame of body1
+   *         (3 position + 4 quaternion numbers); residual position = (xpos1 + R1 relpos) - xpos2, residual rotation = vector part
+   *         of conj(q2) q1 relquat; Jacobian = J(body1, point 1) - J(body2, point 2), rotational rows through the half-quaternion
+   *         product ("0.5 * neg(q1) * (jac0 - jac1) * q0 * relpose").
+   *   joint (gripper_actuators.xml:3, the two-finger coupling): q1 - q1_0 - poly(q2 - q2_0), J = [1, -poly'].
+   * Rows are always active (two-sided, quadratic); margin 0.  PROVENANCE: MuJoCo documentation ("Computation: Equality") and the
+   * later open-sourced engine_core_constraint.c, recalled. */
+  for (int e = 0; e < m->neq; e++) {
+    if (!d->eq_active[e]) continue;
+    const real* data = d->eq_data + 7 * e;
+    if (m->eq_type[e] == EQ_WELD) {
+      int b1 = m->eq_obj1id[e], b2 = m->eq_obj2id[e];
+      real p1[3], cpos[6], q[4], qn[4], q2[4], tmp[3];
+      mulmat3(tmp, d->xmat + 9 * b1, data); add3(p1, d->xpos + 3 * b1, tmp);
+      const real* p2 = d->xpos + 3 * b2;
+      sub3(cpos, p1, p2);
+      mulquat(q, d->xquat + 4 * b1, data + 3);                                   /* q = q1 * relquat */
+      qn[0] = d->xquat[4 * b2]; qn[1] = -d->xquat[4 * b2 + 1]; qn[2] = -d->xquat[4 * b2 + 2]; qn[3] = -d->xquat[4 * b2 + 3];
+      mulquat(q2, qn, q);                                                        /* conj(q2) * q1 * relquat */
+      cpos[3] = q2[1]; cpos[4] = q2[2]; cpos[5] = q2[3];
+      real* jb = (real*)malloc(12 * nv * sizeof(real));
+      real *jp1 = jb, *jr1 = jb + 3 * nv, *jp2 = jb + 6 * nv, *jr2 = jb + 9 * nv;
+      ro_jac(m, d, jp1, jr1, p1, b1); ro_jac(m, d, jp2, jr2, p2, b2);
+      real tran = m->body_invweight0[2 * b1] + m->body_invweight0[2 * b2], rot = m->body_invweight0[2 * b1 + 1] + m->body_invweight0[2 * b2 + 1];
+      int rows[6];
+      for (int k = 0; k < 6; k++) rows[k] = add_row(m, d, EFC_EQUALITY, e, cpos[k], 0, 0, k < 3 ? tran : rot);
+      for (int i = 0; i < nv; i++) {
+        for (int k = 0; k < 3; k++) if (rows[k] >= 0) d->efc_J[(size_t)rows[k] * nv + i] = jp1[k * nv + i] - jp2[k * nv + i];
+        real ax[4] = {0, jr1[i] - jr2[i], jr1[nv + i] - jr2[nv + i], jr1[2 * nv + i] - jr2[2 * nv + i]}, t1[4], t2[4];
+        mulquat(t1, qn, ax); mulquat(t2, t1, q);
+        for (int k = 0; k < 3; k++) if (rows[3 + k] >= 0) d->efc_J[(size_t)rows[3 + k] * nv + i] = 0.5 * t2[1 + k];
+      }
+      free(jb);
+    } else if (m->eq_type[e] == EQ_JOINT) {
+      int j1 = m->eq_obj1id[e], j2 = m->eq_obj2id[e];
+      int q1a = m->jnt_qposadr[j1], d1 = m->jnt_dofadr[j1];
+      real pos = d->qpos[q1a] - m->qpos0[q1a] - data[0], deriv = 0, diag = m->dof_invweight0[d1];
+      if (j2 >= 0) {
+        int q2a = m->jnt_qposadr[j2];
+        real dif = d->qpos[q2a] - m->qpos0[q2a];
+        pos -= data[1] * dif + data[2] * dif * dif + data[3] * dif * dif * dif + data[4] * dif * dif * dif * dif;
+        deriv = data[1] + 2 * data[2] * dif + 3 * data[3] * dif * dif + 4 * data[4] * dif * dif * dif;
+        diag += m->dof_invweight0[m->jnt_dofadr[j2]];
+      }
+      int r = add_row(m, d, EFC_EQUALITY, e, pos, 0, 0, diag);
+      if (r >= 0) { d->efc_J[(size_t)r * nv + d1] = 1; if (j2 >= 0) d->efc_J[(size_t)r * nv + m->jnt_dofadr[j2]] = -deriv; }
+    } else { fprintf(stderr, "rg_oracle: equality type %d not implemented\n", m->eq_type[e]); abort(); }
+  }
+  d->ne = d->nefc;
   /* friction loss: dofs, then tendons */
   for (int i = 0; i < nv; i++)
     if (m->dof_frictionloss[i] > 0) {
@@ -1064,7 +1162,7 @@ static void ro_make_constraint(const ro_model* m, ro_data* d) {
       int r = add_row(m, d, EFC_FRICTION_TENDON, t, 0, 0, m->tendon_frictionloss[t], m->tendon_invweight0[t]);
       if (r >= 0) memcpy(d->efc_J + (size_t)r * nv, d->ten_J + (size_t)t * nv, nv * sizeof(real));
     }
-  d->nf = d->nefc;
+  d->nf = d->nefc - d->ne;
   /* limits: joints (hinge/slide), then tendons */
   for (int j = 0; j < m->njnt; j++) {
     if (!m->jnt_limited[j]) continue;
@@ -1089,14 +1187,13 @@ static void ro_make_constraint(const ro_model* m, ro_data* d) {
       }
     }
   }
-  d->nl = d->nefc - d->nf;
-  /* contacts (pyramidal cones) */
+  d->nl = d->nefc - d->nf - d->ne;
+  /* contacts (pyramidal or elliptic cones) */
   real* jbuf = (real*)malloc(12 * nv * sizeof(real));
   real *jp1 = jbuf, *jr1 = jbuf + 3 * nv, *jp2 = jbuf + 6 * nv, *jr2 = jbuf + 9 * nv;
   for (int ci = 0; ci < d->ncon; ci++) {
     ro_contact* c = &d->contact[ci];
     c->efc_address = -1;
-    if (m->cone != 0) { fprintf(stderr, "rg_oracle: elliptic cones not implemented\n"); abort(); }
     int b1 = m->geom_bodyid[c->geom1], b2 = m->geom_bodyid[c->geom2];
     ro_jac(m, d, jp1, jr1, c->pos, b1); ro_jac(m, d, jp2, jr2, c->pos, b2);
     /* contact-frame Jacobian rows: 3 translational then 3 rotational, difference body2 - body1 */
@@ -1111,6 +1208,15 @@ static void ro_make_constraint(const ro_model* m, ro_data* d) {
     if (c->dim == 1) {
       int r = add_row(m, d, EFC_CONTACT_PYRAMIDAL, ci, c->dist, c->includemargin, 0, tran);
       if (r >= 0) { memcpy(d->efc_J + (size_t)r * nv, Jc, nv * sizeof(real)); c->efc_address = r; }
+    } else if (m->cone == 1) {
+      /* elliptic cone (ur16e/base.xml:3 cone="elliptic"): one row per contact dimension, the rows of the contact-frame Jacobian
+       * themselves (normal, two tangents, torsion, two rolling axes); only the normal row carries the distance */
+      if (d->nefc + c->dim > m->njmax) { d->warn_efc_full = 1; free(Jc); continue; }
+      for (int k = 0; k < c->dim; k++) {
+        int r = add_row(m, d, EFC_CONTACT_ELLIPTIC, ci, k == 0 ? c->dist : 0, k == 0 ? c->includemargin : 0, 0, k < 3 ? tran : rot);
+        if (k == 0) c->efc_address = r;
+        memcpy(d->efc_J + (size_t)r * nv, Jc + (size_t)k * nv, nv * sizeof(real));
+      }
     } else {
       for (int k = 0; k < c->dim - 1; k++) {
         real fri = c->friction[k], diag = tran + fri * fri * (k < 2 ? tran : rot);
@@ -1137,6 +1243,7 @@ static void ro_make_impedance(const ro_model* m, ro_data* d) {
       case EFC_FRICTION_TENDON: solref = m->tendon_solref_fri + 2 * id; solimp = m->tendon_solimp_fri + 5 * id; break;
       case EFC_LIMIT_JOINT: solref = m->jnt_solref + 2 * id; solimp = m->jnt_solimp + 5 * id; break;
       case EFC_LIMIT_TENDON: solref = m->tendon_solref_lim + 2 * id; solimp = m->tendon_solimp_lim + 5 * id; break;
+      case EFC_EQUALITY: solref = m->eq_solref + 2 * id; solimp = m->eq_solimp + 5 * id; break;
       default: solref = d->contact[id].solref; solimp = d->contact[id].solimp; break;
     }
     real imp = get_impedance(solimp, d->efc_pos[r], d->efc_margin[r]);
@@ -1153,6 +1260,15 @@ static void ro_make_impedance(const ro_model* m, ro_data* d) {
   for (int ci = 0; ci < d->ncon; ci++) {
     ro_contact* c = &d->contact[ci];
     if (c->efc_address < 0 || c->dim == 1) continue;
+    if (m->cone == 1) {
+      /* mj_makeImpedance, elliptic: R[1] = R[0] / impratio, mu of the regularised cone = friction[0] sqrt(R[1] / R[0]),
+       * R[j] mu_j^2 = R[1] mu_1^2 for the remaining friction dimensions */
+      int a = c->efc_address;
+      d->efc_R[a + 1] = d->efc_R[a] / fmax(MINVAL, m->impratio);
+      c->mu = c->friction[0] * sqrt(d->efc_R[a + 1] / d->efc_R[a]);
+      for (int j = 2; j < c->dim; j++) d->efc_R[a + j] = d->efc_R[a + 1] * c->friction[0] * c->friction[0] / (c->friction[j - 1] * c->friction[j - 1]);
+      continue;
+    }
     c->mu = c->friction[0] * sqrt(1 / m->impratio);
     real Rpy = 2 * c->mu * c->mu * d->efc_R[c->efc_address];
     for (int k = 0; k < 2 * (c->dim - 1) && c->efc_address + k < d->nefc; k++) d->efc_R[c->efc_address + k] = Rpy;
@@ -1245,7 +1361,32 @@ static void ro_fwd_actuation(const ro_model* m, ro_data* d) {
   for (int i = 0; i < m->nu; i++) {
     const real* gp = m->actuator_gainprm + 10 * i;
     real force;
-    if (m->actuator_biastype[i] == 2) {
+    if (m->actuator_biastype[i] == 2 && m->actuator_user[i] == 1) {
+      /* mujoco-py mjpid.pyx, cascaded PI controller (actuator user[0] == 1; ur16e/jointspec/calibrations/cascaded_pi/
+       * joint_actuations.xml:4-10): gainprm = [kp, ti, iclamp, td, dsmooth | kp_v, ti_v, iclamp_v, ema_smooth, max_vel].
+       * The position set-point is EMA-smoothed (warm-started with ctrl at time 0), an outer P(ID) loop on position produces a
+       * velocity set-point clamped to +-max_vel, an inner PI loop on actuator_velocity produces the force, clamped to forcerange.
+       * State per actuator: {position integral, velocity integral, smoothed set-point}.  PROVENANCE: recalled from mujoco-py
+       * 2.0.2.13; pinned only through the reference's impulse-response / gripper-sync property tests (tests/test_rearrange_*). */
+      real* st = d->pid + 3 * i;
+      real ema = gp[8], max_vel = gp[9];
+      real setp = d->time == 0 ? d->ctrl[i] : ema * st[2] + (1 - ema) * d->ctrl[i];
+      st[2] = setp;
+      real des_vel;
+      if (gp[0] != 0) {
+        real err = setp - d->actuator_length[i];
+        real integ = clampd(st[0] + err * dt, -gp[2], gp[2]);
+        des_vel = gp[0] * (err + (gp[1] != 0 ? integ / gp[1] : 0));   /* (td = dsmooth = 0 in the calibration: no derivative term is carried) */
+        st[0] = integ;
+      } else des_vel = d->ctrl[i];
+      des_vel = clampd(des_vel, -max_vel, max_vel);
+      real errv = des_vel - d->actuator_velocity[i];
+      real integv = clampd(st[1] + errv * dt, -gp[7], gp[7]);
+      force = gp[5] * (errv + (gp[6] != 0 ? integv / gp[6] : 0));
+      st[1] = integv;
+      real lo = m->actuator_forcerange[2 * i], hi = m->actuator_forcerange[2 * i + 1];
+      if (lo != 0 || hi != 0) force = clampd(force, lo, hi);
+    } else if (m->actuator_biastype[i] == 2) {
       real kp = gp[0], ti = gp[1], iclamp = gp[2], td = gp[3], smooth = gp[4], deadband = gp[5];
       real err = d->ctrl[i] - d->actuator_length[i];
       if (fabs(err) < deadband) err = 0;
@@ -1293,11 +1434,51 @@ static void ro_fwd_acceleration(const ro_model* m, ro_data* d) {
  * iteration gives the same iterates.) */
 typedef struct { real cost, grad, hess; } ls_pt;
 
+/* Elliptic cone, one contact (engine_core_constraint.c mj_constraintUpdate, "elliptic" branch).  In the scaled variables
+ * U0 = mu jar_0, Uj = friction_(j-1) jar_j, N = U0, T = |U_1..|:  top zone (N >= mu T): no force;  bottom zone (mu N + T <= 0): every
+ * row quadratic with its own D;  middle zone: cost = 1/2 Dm (N - mu T)^2 with Dm = D_0 / (mu^2 (1 + mu^2)).
+ * zone: 0 top, 1 bottom, 2 middle.  `hess` (dim x dim, may be NULL) is the cone's Hessian with respect to jar in the middle zone. */
+static int cone_eval(const ro_data* d, const ro_contact* c, const real* jar, real* force, real* cost, real* hess) {
+  int a = c->efc_address, dim = c->dim;
+  real mu = c->mu, U[6], N, T = 0;
+  U[0] = jar[a] * mu;
+  for (int j = 1; j < dim; j++) { U[j] = jar[a + j] * c->friction[j - 1]; T += U[j] * U[j]; }
+  N = U[0]; T = sqrt(T);
+  if (N >= mu * T || (T <= 0 && N >= 0)) { if (force) for (int j = 0; j < dim; j++) force[a + j] = 0; *cost = 0; return 0; }
+  if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
+    real cc = 0;
+    for (int j = 0; j < dim; j++) { real D = d->efc_D[a + j]; if (force) force[a + j] = -D * jar[a + j]; cc += 0.5 * D * jar[a + j] * jar[a + j]; }
+    *cost = cc; return 1;
+  }
+  real Dm = d->efc_D[a] / (mu * mu * (1 + mu * mu)), NT = N - mu * T;
+  *cost = 0.5 * Dm * NT * NT;
+  if (force) {
+    force[a] = -Dm * NT * mu;
+    for (int j = 1; j < dim; j++) force[a + j] = -force[a] / T * U[j] * c->friction[j - 1];
+  }
+  if (hess) {
+    /* second derivatives of 1/2 Dm (N - mu T)^2 in U, then the chain rule through U = diag(mu, friction) jar */
+    real H[36], sc[6];
+    sc[0] = mu; for (int j = 1; j < dim; j++) sc[j] = c->friction[j - 1];
+    H[0] = 1;
+    for (int j = 1; j < dim; j++) H[j] = H[j * dim] = -mu * U[j] / T;
+    for (int j = 1; j < dim; j++) for (int k = 1; k < dim; k++) H[j * dim + k] = mu * N / (T * T * T) * U[j] * U[k] + (j == k ? mu * mu - mu * N / T : 0);
+    for (int j = 0; j < dim; j++) for (int k = 0; k < dim; k++) hess[j * dim + k] = Dm * sc[j] * sc[k] * H[j * dim + k];
+  }
+  return 2;
+}
 static void constraint_update(const ro_model* m, const ro_data* d, const real* jar, real* force, int* active, real* cost) {
   real c = 0;
   for (int r = 0; r < d->nefc; r++) {
     real D = d->efc_D[r], R = d->efc_R[r], x = jar[r];
     int type = d->efc_type[r];
+    if (type == EFC_EQUALITY) { force[r] = -D * x; active[r] = 1; c += 0.5 * D * x * x; continue; }
+    if (type == EFC_CONTACT_ELLIPTIC) {
+      const ro_contact* con = d->contact + d->efc_id[r];
+      real cc; int zone = cone_eval(d, con, jar, force, &cc, NULL);
+      for (int j = 0; j < con->dim; j++) active[r + j] = zone == 1 ? 1 : (zone == 2 ? 2 : 0);   /* 2: coupled through the cone Hessian */
+      c += cc; r += con->dim - 1; continue;
+    }
     if (type == EFC_FRICTION_DOF || type == EFC_FRICTION_TENDON) {
       real f = d->efc_frictionloss[r];
       if (x <= -R * f) { force[r] = f; active[r] = 0; c += f * (-0.5 * R * f - x); }
@@ -1315,6 +1496,27 @@ static ls_pt ls_eval(const ro_data* d, real alpha, const real* jar, const real* 
   for (int r = 0; r < d->nefc; r++) {
     real D = d->efc_D[r], R = d->efc_R[r], x = jar[r] + alpha * jv[r];
     int type = d->efc_type[r];
+    if (type == EFC_EQUALITY) { p.cost += 0.5 * D * x * x; p.grad += D * x * jv[r]; p.hess += D * jv[r] * jv[r]; continue; }
+    if (type == EFC_CONTACT_ELLIPTIC) {
+      /* the cone's cost along the search direction and its first two derivatives in alpha */
+      const ro_contact* con = d->contact + d->efc_id[r];
+      int dim = con->dim; real mu = con->mu, U[6], V[6], N, T = 0, UV = 0, VV = 0;
+      U[0] = (jar[r] + alpha * jv[r]) * mu; V[0] = jv[r] * mu;
+      for (int j = 1; j < dim; j++) {
+        U[j] = (jar[r + j] + alpha * jv[r + j]) * con->friction[j - 1]; V[j] = jv[r + j] * con->friction[j - 1];
+        T += U[j] * U[j]; UV += U[j] * V[j]; VV += V[j] * V[j];
+      }
+      N = U[0]; T = sqrt(T);
+      if (N >= mu * T || (T <= 0 && N >= 0)) { /* top zone: nothing */ }
+      else if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
+        for (int j = 0; j < dim; j++) { real Dj = d->efc_D[r + j], xj = jar[r + j] + alpha * jv[r + j]; p.cost += 0.5 * Dj * xj * xj; p.grad += Dj * xj * jv[r + j]; p.hess += Dj * jv[r + j] * jv[r + j]; }
+      } else {
+        real Dm = d->efc_D[r] / (mu * mu * (1 + mu * mu)), NT = N - mu * T;
+        real N1 = V[0], T1 = UV / T, T2 = (VV - T1 * T1) / T;
+        p.cost += 0.5 * Dm * NT * NT; p.grad += Dm * NT * (N1 - mu * T1); p.hess += Dm * ((N1 - mu * T1) * (N1 - mu * T1) - NT * mu * T2);
+      }
+      r += dim - 1; continue;
+    }
     if (type == EFC_FRICTION_DOF || type == EFC_FRICTION_TENDON) {
       real f = d->efc_frictionloss[r];
       if (x <= -R * f) { p.cost += f * (-0.5 * R * f - x); p.grad += -f * jv[r]; }
@@ -1384,9 +1586,21 @@ static void ro_solve(const ro_model* m, ro_data* d) {
     /* Hessian H = M + J' diag(D_active) J */
     memcpy(H, d->qM, (size_t)nv * nv * sizeof(real));
     for (int r = 0; r < ne; r++) {
-      if (!active[r]) continue;
+      if (active[r] != 1) continue;
       const real* J = d->efc_J + (size_t)r * nv; real D = d->efc_D[r];
       for (int i = 0; i < nv; i++) { if (J[i] == 0) continue; real di = D * J[i]; for (int k = 0; k < nv; k++) H[i * nv + k] += di * J[k]; }
+    }
+    for (int ci = 0; ci < d->ncon; ci++) {   /* middle-zone elliptic contacts: J_c' H_cone J_c (engine_solver.c HessianCone) */
+      const ro_contact* con = d->contact + ci;
+      if (m->cone != 1 || con->dim == 1 || con->efc_address < 0 || active[con->efc_address] != 2) continue;
+      real hc[36], cc; int dim = con->dim;
+      cone_eval(d, con, jar, NULL, &cc, hc);
+      const real* Jc = d->efc_J + (size_t)con->efc_address * nv;
+      for (int a = 0; a < dim; a++) for (int b = 0; b < dim; b++) {
+        real h = hc[a * dim + b];
+        if (h == 0) continue;
+        for (int i = 0; i < nv; i++) { real ja = Jc[(size_t)a * nv + i]; if (ja == 0) continue; real t = h * ja; for (int k = 0; k < nv; k++) H[i * nv + k] += t * Jc[(size_t)b * nv + k]; }
+      }
     }
     if (cholesky(Lh, H, nv) != 0) { d->warn_bad |= 2; break; }
     for (int i = 0; i < nv; i++) search[i] = -grad[i];
@@ -1467,10 +1681,70 @@ static int ray_hits_site(int type, const real* size, const real* p, const real* 
   }
   return 0;
 }
+/* engine_core_smooth.c: mj_rnePostConstraint — body accelerations with the final qacc, external forces (xfrc_applied + contacts)
+ * and the interaction force of every body with its parent, all in the com-based frame (rotational part first). */
+static void contact_force_world(const ro_model* m, const ro_data* d, const ro_contact* c, real* f, real* t) {
+  real cf[6] = {0, 0, 0, 0, 0, 0};
+  int a = c->efc_address;
+  if (c->dim == 1) cf[0] = d->efc_force[a];
+  else if (m->cone == 1) for (int j = 0; j < c->dim; j++) cf[j] = d->efc_force[a + j];
+  else for (int j = 0; j < c->dim - 1; j++) {   /* mju_decodePyramid */
+    real fp = d->efc_force[a + 2 * j], fn = d->efc_force[a + 2 * j + 1];
+    cf[0] += fp + fn; cf[1 + j] = (fp - fn) * c->friction[j];
+  }
+  for (int k = 0; k < 3; k++) { f[k] = c->frame[k] * cf[0] + c->frame[3 + k] * cf[1] + c->frame[6 + k] * cf[2]; t[k] = c->frame[k] * cf[3] + c->frame[3 + k] * cf[4] + c->frame[6 + k] * cf[5]; }
+}
+static void ro_rne_post_constraint(const ro_model* m, ro_data* d) {
+  int nb = m->nbody;
+  memset(d->cfrc_ext, 0, 6 * nb * sizeof(real));
+  for (int b = 1; b < nb; b++) {   /* xfrc_applied: force / torque at the body's com, moved to the com-frame origin of its tree */
+    const real* w = d->xfrc_applied + 6 * b;
+    real off[3], tq[3];
+    sub3(off, d->xipos + 3 * b, d->subtree_com + 3 * m->body_rootid[b]); cross3(tq, off, w);
+    for (int k = 0; k < 3; k++) { d->cfrc_ext[6 * b + k] += w[3 + k] + tq[k]; d->cfrc_ext[6 * b + 3 + k] += w[k]; }
+  }
+  for (int i = 0; i < d->ncon; i++) {
+    const ro_contact* c = d->contact + i;
+    if (c->efc_address < 0) continue;
+    real f[3], t[3]; contact_force_world(m, d, c, f, t);   /* force body1 exerts on body2 is +f along the frame (geom1 -> geom2) */
+    for (int side = 0; side < 2; side++) {
+      int b = m->geom_bodyid[side ? c->geom2 : c->geom1]; real sg = side ? 1.0 : -1.0;
+      if (b == 0) continue;
+      real off[3], tq[3]; sub3(off, c->pos, d->subtree_com + 3 * m->body_rootid[b]); cross3(tq, off, f);
+      for (int k = 0; k < 3; k++) { d->cfrc_ext[6 * b + k] += sg * (t[k] + tq[k]); d->cfrc_ext[6 * b + 3 + k] += sg * f[k]; }
+    }
+  }
+  memset(d->cacc, 0, 6 * sizeof(real)); d->cacc[3] = -m->gravity[0]; d->cacc[4] = -m->gravity[1]; d->cacc[5] = -m->gravity[2];
+  memset(d->cfrc_int, 0, 6 * sizeof(real));
+  for (int b = 1; b < nb; b++) {
+    real* a = d->cacc + 6 * b; memcpy(a, d->cacc + 6 * m->body_parentid[b], 6 * sizeof(real));
+    for (int k = 0; k < m->body_dofnum[b]; k++) { int i = m->body_dofadr[b] + k; for (int c = 0; c < 6; c++) a[c] += d->cdof_dot[6 * i + c] * d->qvel[i] + d->cdof[6 * i + c] * d->qacc[i]; }
+    real t1[6], t2[6], t3[6];
+    mul_inert_vec(t1, d->cinert + 10 * b, a); mul_inert_vec(t2, d->cinert + 10 * b, d->cvel + 6 * b); cross_force(t3, d->cvel + 6 * b, t2);
+    for (int c = 0; c < 6; c++) d->cfrc_int[6 * b + c] = t1[c] + t3[c] - d->cfrc_ext[6 * b + c];
+  }
+  for (int b = nb - 1; b > 0; b--) { int p = m->body_parentid[b]; if (p > 0) for (int c = 0; c < 6; c++) d->cfrc_int[6 * p + c] += d->cfrc_int[6 * b + c]; }
+}
 void ro_sensor(const ro_model* m, ro_data* d) {
+  int need_rne = 0;
+  for (int k = 0; k < m->nsensor; k++) if (m->sensor_type[k] == SENS_FORCE || m->sensor_type[k] == SENS_TORQUE) need_rne = 1;
+  if (need_rne) ro_rne_post_constraint(m, d);
   for (int k = 0; k < m->nsensor; k++) {
-    d->sensordata[k] = 0;
-    if (m->sensor_type[k] != 0) continue;   /* mjSENS_TOUCH */
+    int adr = m->sensor_adr ? m->sensor_adr[k] : k;
+    if (m->sensor_type[k] == SENS_JOINTPOS) { d->sensordata[adr] = d->qpos[m->jnt_qposadr[m->sensor_objid[k]]]; continue; }
+    if (m->sensor_type[k] == SENS_FORCE || m->sensor_type[k] == SENS_TORQUE) {
+      /* engine_sensor.c: cfrc_int of the site's body, moved from the com-frame origin to the site and rotated into the site frame */
+      int site = m->sensor_objid[k], body = m->site_bodyid[site];
+      const real* cf = d->cfrc_int + 6 * body; const real* R = d->site_xmat + 9 * site;
+      real off[3], tq[3], v[3];
+      sub3(off, d->site_xpos + 3 * site, d->subtree_com + 3 * m->body_rootid[body]);
+      cross3(tq, off, cf + 3);
+      if (m->sensor_type[k] == SENS_FORCE) copy3(v, cf + 3); else sub3(v, cf, tq);
+      mulmatT3(d->sensordata + adr, R, v);
+      continue;
+    }
+    d->sensordata[adr] = 0;
+    if (m->sensor_type[k] != SENS_TOUCH) continue;
     int site = m->sensor_objid[k], body = m->site_bodyid[site];
     for (int i = 0; i < d->ncon; i++) {
       const ro_contact* c = d->contact + i;
@@ -1478,14 +1752,14 @@ void ro_sensor(const ro_model* m, ro_data* d) {
       int b1 = m->geom_bodyid[c->geom1], b2 = m->geom_bodyid[c->geom2];
       if (b1 != body && b2 != body) continue;
       real nf = 0;
-      if (c->dim == 1) nf = d->efc_force[c->efc_address];
+      if (c->dim == 1 || m->cone == 1) nf = d->efc_force[c->efc_address];
       else for (int q = 0; q < 2 * (c->dim - 1); q++) nf += d->efc_force[c->efc_address + q];
       if (nf <= 0) continue;
       real sgn = body == b2 ? -1.0 : 1.0, ray[3] = {sgn * c->frame[0], sgn * c->frame[1], sgn * c->frame[2]};
       real rel[3], lp[3], lv[3]; const real* R = d->site_xmat + 9 * site;
       sub3(rel, c->pos, d->site_xpos + 3 * site);
       for (int a = 0; a < 3; a++) { lp[a] = R[a] * rel[0] + R[3 + a] * rel[1] + R[6 + a] * rel[2]; lv[a] = R[a] * ray[0] + R[3 + a] * ray[1] + R[6 + a] * ray[2]; }
-      if (ray_hits_site(m->site_type[site], m->site_size + 3 * site, lp, lv)) d->sensordata[k] += nf;
+      if (ray_hits_site(m->site_type[site], m->site_size + 3 * site, lp, lv)) d->sensordata[adr] += nf;
     }
   }
 }
@@ -1564,16 +1838,19 @@ real* ro_field(const ro_model* m, ro_data* d, const char* field, int* n) {
   FIELD(efc_vel, d->nefc) FIELD(efc_frictionloss, d->nefc) FIELD(efc_diagApprox, d->nefc)
   FIELD(ten_velocity, m->ntendon) FIELD(actuator_velocity, m->nu) FIELD(cvel, 6 * nb) FIELD(cdof_dot, 6 * nv)
   FIELD(qfrc_passive, nv) FIELD(qfrc_bias, nv) FIELD(actuator_force, m->nu) FIELD(qfrc_actuator, nv) FIELD(qfrc_smooth, nv)
-  FIELD(qacc_smooth, nv) FIELD(qfrc_constraint, nv) FIELD(qacc, nv) FIELD(sensordata, m->nsensor)
+  FIELD(qacc_smooth, nv) FIELD(qfrc_constraint, nv) FIELD(qacc, nv) FIELD(sensordata, m->nsensordata) FIELD(mocap_pos, 3 * m->nmocap) FIELD(mocap_quat, 4 * m->nmocap) FIELD(eq_data, 7 * m->neq)
+  FIELD(cfrc_int, 6 * nb) FIELD(cfrc_ext, 6 * nb) FIELD(cacc, 6 * nb)
   *n = 0;
   return NULL;
 }
 int ro_int(const ro_model* m, const ro_data* d, const char* field) {
-  (void)m;
   if (!strcmp(field, "ncon")) return d->ncon;
   if (!strcmp(field, "nefc")) return d->nefc;
   if (!strcmp(field, "nf")) return d->nf;
   if (!strcmp(field, "nl")) return d->nl;
+  if (!strcmp(field, "ne")) return d->ne;
+  if (!strcmp(field, "neq")) return m->neq;
+  if (!strcmp(field, "nmocap")) return m->nmocap;
   if (!strcmp(field, "solver_iter")) return d->solver_iter;
   if (!strcmp(field, "warn_bad")) return d->warn_bad;
   if (!strcmp(field, "warn_contact_full")) return d->warn_contact_full;
@@ -1581,6 +1858,8 @@ int ro_int(const ro_model* m, const ro_data* d, const char* field) {
   return -1;
 }
 int* ro_efc_type(ro_data* d) { return d->efc_type; }
+int* ro_eq_active(ro_data* d) { return d->eq_active; }
+int* ro_efc_id(ro_data* d) { return d->efc_id; }
 int ro_real_size(void) { return (int)sizeof(real); }
 double ro_time(const ro_data* d) { return d->time; }
 void ro_set_time(ro_data* d, double t) { d->time = t; }

@@ -57,6 +57,8 @@ def lib(f32=False):
         L.ro_int.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p]
         L.ro_efc_type.restype = ctypes.POINTER(ctypes.c_int)
         L.ro_efc_type.argtypes = [ctypes.c_void_p]
+        L.ro_eq_active.restype = ctypes.POINTER(ctypes.c_int)
+        L.ro_eq_active.argtypes = [ctypes.c_void_p]
         L.ro_time.restype = ctypes.c_double
         L.ro_time.argtypes = [ctypes.c_void_p]
         L.ro_set_time.argtypes = [ctypes.c_void_p, ctypes.c_double]
@@ -142,6 +144,11 @@ class OracleSim:
 
     def efc_types(self):
         return np.ctypeslib.as_array(self._L.ro_efc_type(self.d), shape=(2000,))[: self.nefc].copy()
+
+    def eq_active(self):
+        """mjModel.eq_active as a writable int view (run-time copy: the envs toggle it)."""
+        n = self.neq
+        return np.ctypeslib.as_array(self._L.ro_eq_active(self.d), shape=(max(n, 1),))[:n]
 
     def reset(self):
         self._L.ro_reset(self.m, self.d)
