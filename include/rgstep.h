@@ -276,6 +276,35 @@ int rb_batch_step(rb_batch* b, const float* action_dev, const int* active_dev, i
 /* the same with per-env `hold_dev` (int [B] or NULL: envs that keep their stored ctrl row, the reset recipe's scripted controls) and `nticks_dev` (int [B] or
  * NULL: per-env count of state-less forwards) -- as rg_step_args.hold_dev / nticks_dev */
 int rb_batch_step_ex(rb_batch* b, const float* action_dev, const int* active_dev, const int* hold_dev, const int* nticks_dev, int nsubsteps, int nforward_ticks, int flags, void* stream);
+/* ---- rearrange (UR16e + 2f-85 gripper; BASELINE.json configs[3]).  The large-model stepper also runs the rearrange worlds: elliptic friction
+ * cones with impratio (assets/xmls/robot/ur16e/base.xml:3), weld-to-mocap and joint-coupling equality constraints (base.xml:52-54,
+ * gripper_actuators.xml:3), mujoco-py's cascaded-PI actuators (jointspec/calibrations/cascaded_pi/joint_actuations.xml:4-10), jointpos / force /
+ * torque sensors (base.xml:38-49).  Extra per-env rows, through rb_batch_field_ptr: */
+enum {
+  RB_F_MOCAP = 12,      /* float [B][7 nmocap]  data.mocap_pos | mocap_quat per mocap body (gym.envs.robotics.utils.mocap_set_action writes them) */
+  RB_F_EQ_DATA = 13,    /* float [B][7 neq]     model.eq_data (reset_mocap_welds writes it; joint coupling: polycoef[5])                    */
+  RB_F_EQ_ACTIVE = 14,  /* int32 [B][neq]       model.eq_active (envs/rearrange/common/base.py:452-455)                                     */
+  RB_F_SENSORDATA = 15  /* float [B][nsensordata] data.sensordata of the last full forward (step flags bit 5)                               */
+};
+/* step flags bit 5 (32): the LAST state-less forward of the call runs in full (mj_forward: collision, constraint solve) and the sensors are
+ * evaluated from it (mj_sensorPos / mj_sensorAcc with mj_rnePostConstraint); the stage arrays of the scratch row (body frames, velocities,
+ * contact list) then describe the final state, which is what the rearrange observation reads (envs/rearrange/common/base.py:376-421).
+ *
+ * rb_batch_step_tcp: `JointControlledTcpArm.set_position_control` (robot/ur16e/mujoco/joint_controlled_tcp_arm.py:89-97) as ONE launch of the TCP
+ * solver's own simulation (`solver`: arm + gripper world with the mocap weld, build_solver_sim, robot/composite/ur_gripper_arm.py:143-160):
+ *   controller_arm.sync_to(main joint positions) + mj_forward          free_dof_tcp_arm.py:214-225        (reset_controller_error)
+ *   FreeDOFTcpArm.denormalize / constrain_quat_ctrl / set_position_control   free_dof_tcp_arm.py:161-206   action[B][6] = xyz, roll, wrist, gripper
+ *   MocapSolver.get_tcp_quat + gym mocap_set_action                      robot/control/tcp/mocap_solver.py:33-57
+ *   solver simulation: nsubsteps x mj_step                                (controller autostep)
+ *   main ctrl[:6] <- solver joint angles                                  joint_controlled_arm.py:180-184
+ *   main ctrl[gripper] <- clip(ctrl + a * range / 2)                      robot_interface.py:247-278 around the current ctrl (mujoco_robotiq_gripper.py:139-172)
+ * `main` is stepped afterwards by rb_batch_step_ex with a NULL action (its ctrl row is the input). */
+typedef struct rb_tcp_args {
+  int arm_qposadr[6], main_arm_qposadr[6];   /* qpos addresses of robot0:J1..J6 in the solver / main model */
+  int main_gripper_actuator, tcp_body, wrist_joint, reset_controller_error;
+  float max_position_change, speed_roll, speed_pitch, joint_drift_threshold, gripper_ctrl_lo, gripper_ctrl_hi;
+} rb_tcp_args;
+int rb_batch_step_tcp(rb_batch* solver, rb_batch* main, const float* action_dev, const rb_tcp_args* args, int nsubsteps, int flags, void* stream);
 /* ---- the env-level half of RobotEnv.step for the full cube (dactyl/full_perpendicular), one launch after rb_batch_step:
  * FaceFreeGoal.goal_distance / relative_goal / next_goal (/root/reference/robogym/envs/dactyl/goals/face_free.py:61-189, with
  * cube_utils.py:26-181), the target cube's joint manipulation that next_goal entails (full_perpendicular.py:138-155 ->

@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RGSTEP_LIB") or os.path.join(_HERE, "csrc", "librgstep.so")   # (RGSTEP_LIB: A/B builds of the same ABI, tools/ only)
 
 RG_F_QPOS, RG_F_QVEL, RG_F_CTRL, RG_F_PID, RG_F_WARMSTART, RG_F_TIME, RG_F_STATUS, RG_F_STATS, RG_F_DEBUG, RG_F_COST, RG_F_PAIRLB, RG_F_ENVPRM = range(12)
+RB_F_MOCAP, RB_F_EQ_DATA, RB_F_EQ_ACTIVE, RB_F_SENSORDATA = 12, 13, 14, 15
 RG_STATUS_BAD_STATE, RG_STATUS_CON_FULL, RG_STATUS_CAND_FULL, RG_STATUS_ROW_FULL, RG_STATUS_BAD_FACTOR, RG_STATUS_BAD_ACTION = 1, 2, 4, 8, 16, 32
 
 
@@ -66,13 +67,21 @@ class RbPostArgs(ctypes.Structure):
                 + [(n, ctypes.c_int) for n in ("reset_initial_steps", "n_random_initial_steps", "max_pose_resets", "num_scramble_steps", "scramble_face_angles", "randomize_face_angles")])
 
 
+class RbTcpArgs(ctypes.Structure):
+    """`rb_tcp_args` of include/rgstep.h."""
+
+    _fields_ = [("arm_qposadr", ctypes.c_int * 6), ("main_arm_qposadr", ctypes.c_int * 6), ("main_gripper_actuator", ctypes.c_int), ("tcp_body", ctypes.c_int),
+                ("wrist_joint", ctypes.c_int), ("reset_controller_error", ctypes.c_int), ("max_position_change", ctypes.c_float), ("speed_roll", ctypes.c_float),
+                ("speed_pitch", ctypes.c_float), ("joint_drift_threshold", ctypes.c_float), ("gripper_ctrl_lo", ctypes.c_float), ("gripper_ctrl_hi", ctypes.c_float)]
+
+
 EXPORTS = [
     "rg_model_create", "rg_model_free", "rg_model_dims", "rg_batch_create", "rg_batch_free", "rg_batch_set_env",
     "rg_batch_copy", "rg_batch_reset", "rg_batch_step", "rg_obs_dim", "rg_debug_size", "rg_lds_bytes", "rg_sync",
     "rg_last_error", "rg_batch_mpr_pair", "rg_batch_copy_rows", "rg_batch_step_ex", "rg_batch_field_ptr", "rg_model_create_on", "rg_model_npair",
     "rg_lds_bytes_cfg", "rg_env_post_step", "rg_post_args_size", "rg_batch_enable_env_params", "rg_prm_layout", "rg_xdata_layout", "rg_batch_set_constants", "rg_batch_items_info",
     "rb_model_create", "rb_model_free", "rb_model_info", "rb_scratch_offset", "rb_batch_create", "rb_batch_free", "rb_batch_reset", "rb_batch_set_env",
-    "rb_batch_field_ptr", "rb_batch_step", "rb_batch_step_ex", "rb_env_post_step", "rb_post_args_size", "rb_cube_ops",
+    "rb_batch_field_ptr", "rb_batch_step", "rb_batch_step_ex", "rb_env_post_step", "rb_post_args_size", "rb_cube_ops", "rb_batch_step_tcp",
 ]
 
 
@@ -136,6 +145,7 @@ def bind(path):
     L.rb_batch_field_ptr.argtypes = [vp, ci, ctypes.POINTER(ci)]
     L.rb_batch_step.argtypes = [vp, vp, vp, ci, ci, ci, vp]
     L.rb_batch_step_ex.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, vp]
+    L.rb_batch_step_tcp.argtypes = [vp, vp, vp, ctypes.POINTER(RbTcpArgs), ci, ci, vp]
     L.rb_env_post_step.argtypes = [vp, ctypes.POINTER(RbPostArgs), vp]
     L.rb_post_args_size.restype = ci
     if L.rb_post_args_size() != ctypes.sizeof(RbPostArgs):

@@ -38,7 +38,7 @@ typedef const RG_AS4 RbLaunch& RbLRef;
 #ifndef RB_WG_PER_CU
 #define RB_WG_PER_CU 4   /* resident workgroups per CU the kernel is compiled for (register budget 512 / RB_WG_PER_CU per lane) */
 #endif
-#define RB_CST (7 * RB_CONW + 12 + 2)   /* words of a staged contact; <= RB_T */
+#define RB_CST (7 * RB_CONW + RB_NW + 2)   /* words of a staged contact; <= RB_T */
 #ifndef RB_COST_EPS
 #define RB_COST_EPS 1e-7f   /* relative rounding noise of the fp32 cost sum: improvements below it are not resolvable */
 #endif
@@ -57,6 +57,9 @@ struct RbLds {
   float prof[16];
   int wcnt[4];
   int ncand, ncon, nefc, nlim, stop;
+  int neqcon;            // equality constraints of this mj_step: they are the first records of the contact list
+  float mocap[14];       // pose of the mocap bodies (mjData.mocap_pos / mocap_quat), at most two
+  float time;            // mjData.time (the cascaded-PI controller warm-starts its smoothed set-point at time 0)
   unsigned status;
 };
 
@@ -107,6 +110,7 @@ __device__ __forceinline__ void rb_kinematics(RbM m, RbLds& s, float* S) {
       const q4 pq = ldq(xquat + 4 * p);
       v3 pos = ld3(xpos + 3 * p) + qrot(pq, ld3(m.body_pos + 3 * b));
       q4 quat = qmul(pq, ldq(m.body_quat + 4 * b));
+      if (m.nmocap > 0 && m.body_mocapid[b] >= 0) { const float* mc = s.mocap + 7 * m.body_mocapid[b]; pos = ld3(mc); quat = ldq(mc + 3); }   // mj_kinematics: mocap pose (normalised below)
       for (int k = 0; k < m.body_jntnum[b]; k++) {
         const int j = m.body_jntadr[b] + k, qa = m.jnt_qposadr[j], t = m.jnt_type[j];
         if (t == RG_JNT_FREE) {
@@ -707,8 +711,41 @@ __device__ __forceinline__ float rb_pid_tick(const Model& m, int u, float ctrl, 
   if (m.actuator_forcelimited[u]) force = clampf(force, lo, hi);
   return force;
 }
+// mujoco-py's cascaded PI controller (actuator user[0] == 1; ur16e/jointspec/calibrations/cascaded_pi/joint_actuations.xml:4-10), as restated by
+// oracle ro_fwd_actuation: gainprm = [kp, ti, iclamp, td, dsmooth | kp_v, ti_v, iclamp_v, ema, max_vel]; st = {position integral, velocity
+// integral, smoothed set-point}.  EMA-smoothed position set-point (warm start at time 0) -> P(I) on position -> velocity set-point clamped to
+// +- max_vel -> PI on actuator_velocity -> force clamped to forcerange.
+template <class Model>
+__device__ __forceinline__ float rb_cascade_tick(const Model& m, int u, float ctrl, float length, float velocity, bool time0, float* st) {
+  const float dt = m.timestep;
+  const float* gp = m.actuator_gainprm + 10 * u;
+  const float setp = time0 ? ctrl : gp[8] * st[2] + (1.f - gp[8]) * ctrl;
+  st[2] = setp;
+  float des_vel;
+  if (gp[0] != 0.f) {
+    const float err = setp - length;
+    const float integ = clampf(st[0] + err * dt, -gp[2], gp[2]);
+    des_vel = gp[0] * (err + (gp[1] != 0.f ? integ / gp[1] : 0.f));
+    st[0] = integ;
+  } else des_vel = ctrl;
+  des_vel = clampf(des_vel, -gp[9], gp[9]);
+  const float errv = des_vel - velocity;
+  const float integv = clampf(st[1] + errv * dt, -gp[7], gp[7]);
+  float force = gp[5] * (errv + (gp[6] != 0.f ? integv / gp[6] : 0.f));
+  st[1] = integv;
+  const float lo = m.actuator_forcerange[2 * u], hi = m.actuator_forcerange[2 * u + 1];
+  if (lo != 0.f || hi != 0.f) force = clampf(force, lo, hi);
+  if (m.actuator_forcelimited[u]) force = clampf(force, lo, hi);
+  return force;
+}
 __device__ __forceinline__ void rb_pid(RbM m, RbLds& s, float* S, bool apply) {
-  BFOR(u, m.nu) s.actfrc[u] = rb_pid_tick(m, u, s.ctrl[u], s.actlen[u], s.pid + 3 * u);
+  BFOR(u, m.nu) {
+    if (m.actuator_user[u] == 1.f) {
+      const int id = m.actuator_trnid[u];
+      const float vel = m.actuator_gear[u] * (m.actuator_trntype[u] == 0 ? s.qvel[m.jnt_dofadr[id]] : SC(TENVEL)[id]);   // mj_transmission: moment . qvel
+      s.actfrc[u] = rb_cascade_tick(m, u, s.ctrl[u], s.actlen[u], vel, s.time == 0.f, s.pid + 3 * u);
+    } else s.actfrc[u] = rb_pid_tick(m, u, s.ctrl[u], s.actlen[u], s.pid + 3 * u);
+  }
   BSYNC();
   if (!apply) return;
   BFOR(i, m.nv) {
@@ -732,11 +769,65 @@ __device__ __forceinline__ void rb_geom(RbM m, const float* S, int g, MprGeom& G
 __device__ __forceinline__ void rb_make_frame(float* f) {   // mju_makeFrame: f[0..2] given, tangents completed (as oracle make_frame)
   make_frame(f);
 }
+// mj_instantiateEquality (oracle ro_make_constraint, equality block): every active equality becomes one record at the head of the contact
+// list — weld (6 rows: position residual (xpos1 + R1 relpos) - xpos2, rotation residual = vector part of conj(q2) q1 relquat) or joint
+// coupling (1 row: q1 - q1_0 - poly(q2 - q2_0)).  Residuals in frame[0..5], diagApprox (translational, rotational) in friction[0..1].
+__device__ __forceinline__ void rb_equality(RbM m, RbLds& s, float* S, const float* eq_data, const int* eq_active) {
+  float* con = SC(CON);
+  if (TID == 0) {
+    int n = 0;
+    for (int e = 0; e < m.neq; e++) {
+      if (!eq_active[e] || n >= m.maxcon) continue;
+      float* C = con + RB_CONREC * n;
+      const float* data = eq_data + 7 * e;
+      for (int k = 0; k < RB_CONREC; k++) C[k] = 0.f;
+      C[RB_CR_KIND] = (float)RB_KIND_EQUALITY; C[RB_CR_G1] = (float)e; C[RB_CR_G2] = 0.f; C[RB_CR_ADR] = -1.f;
+      C[RB_CR_SOLREF] = m.eq_solref[2 * e]; C[RB_CR_SOLREF + 1] = m.eq_solref[2 * e + 1];
+      for (int k = 0; k < 5; k++) C[RB_CR_SOLIMP + k] = m.eq_solimp[5 * e + k];
+      const int o1 = m.eq_obj1id[e], o2 = m.eq_obj2id[e];
+      if (m.eq_type[e] == 1) {          // mjEQ_WELD
+        const q4 q1 = ldq(SC(XQUAT) + 4 * o1), q2 = ldq(SC(XQUAT) + 4 * o2);
+        const v3 p1 = ld3(SC(XPOS) + 3 * o1) + qrot(q1, ld3(data));
+        st3(C + RB_CR_POS, p1);
+        st3(C + RB_CR_FRAME, p1 - ld3(SC(XPOS) + 3 * o2));
+        q4 qc; qc.w = q2.w; qc.x = -q2.x; qc.y = -q2.y; qc.z = -q2.z;
+        const q4 r = qmul(qc, qmul(q1, ldq(data + 3)));
+        C[RB_CR_FRAME + 3] = r.x; C[RB_CR_FRAME + 4] = r.y; C[RB_CR_FRAME + 5] = r.z;
+        C[RB_CR_FRIC] = m.body_invweight0[2 * o1] + m.body_invweight0[2 * o2]; C[RB_CR_FRIC + 1] = m.body_invweight0[2 * o1 + 1] + m.body_invweight0[2 * o2 + 1];
+        C[RB_CR_DIM] = 6.f;
+      } else {                          // mjEQ_JOINT
+        const int qa1 = m.jnt_qposadr[o1];
+        float pos = s.qpos[qa1] - m.qpos0[qa1] - data[0], deriv = 0.f, diag = m.dof_invweight0[m.jnt_dofadr[o1]];
+        if (o2 >= 0) {
+          const int qa2 = m.jnt_qposadr[o2]; const float dif = s.qpos[qa2] - m.qpos0[qa2];
+          pos -= data[1] * dif + data[2] * dif * dif + data[3] * dif * dif * dif + data[4] * dif * dif * dif * dif;
+          deriv = data[1] + 2.f * data[2] * dif + 3.f * data[3] * dif * dif + 4.f * data[4] * dif * dif * dif;
+          diag += m.dof_invweight0[m.jnt_dofadr[o2]];
+        }
+        C[RB_CR_FRAME] = pos; C[RB_CR_FRAME + 1] = deriv; C[RB_CR_FRIC] = diag; C[RB_CR_DIM] = 1.f;
+      }
+      n++;
+    }
+    s.neqcon = n;
+  }
+  BSYNC();
+}
+// mjc_PlaneBox (oracle collide_pair, plane - box): corner l of the box (l < 8) against the plane through the origin of the pair-local frame with
+// normal pn; the box centre is at bp
+__device__ __forceinline__ bool rb_plane_box_lane(v3 pn, v3 bp, q4 bq, v3 sz, float margin, int l, float& dist, v3& pos) {
+  if (l >= 8) return false;
+  const v3 lc = mk3((l & 1) ? sz.x : -sz.x, (l & 2) ? sz.y : -sz.y, (l & 4) ? sz.z : -sz.z);
+  const v3 c = bp + qrot(bq, lc);
+  dist = dot(c, pn);
+  pos = c - pn * (0.5f * dist);
+  return dist <= margin;
+}
 __device__ __forceinline__ void rb_collision(RbM m, RbLds& s, float* S, int flags) {
   int* cand = (int*)SC(CAND);
   const float *gpos = SC(GPOS), *gquat = SC(GQUAT);
-  if (TID == 0) { s.ncand = 0; s.ncon = 0; }
+  if (TID == 0) { s.ncand = 0; s.ncon = s.neqcon; }
   BSYNC();
+  const bool multipoint = !(flags & 16);   // box - box and plane - box pairs have their own multi-point routines (bit 4: everything through MPR / the support map)
   // broadphase: the static pair list against bounding spheres (planes: distance of the sphere to the plane)
   for (int base = 0; base < m.npair; base += RB_T) {
     const int p = base + TID;
@@ -751,6 +842,7 @@ __device__ __forceinline__ void rb_collision(RbM m, RbLds& s, float* S, int flag
     const int slot = rb_slot(s, keep, &s.ncand, m.maxcand, RG_STATUS_CAND_FULL);
     if (slot >= 0) cand[slot] = p;
   }
+  BSYNC();   // (the last trip's candidates are written after rb_slot's barrier: the narrowphase below reads them from other waves)
   // narrowphase: one quad per candidate, 64 candidates per trip
   MprEnv E; E.mesh_vert = m.b_mesh_rec; E.cell_adr = m.b_cell_adr; E.cell_blk = (const rgf4*)m.b_cell_blk; E.cell_ovf = (const rgf4*)m.b_cell_ovf; E.prof = 0; E.cells = !(flags & 8); E.plane_depth = (flags & 16) != 0;
   const int ncand = s.ncand;
@@ -763,7 +855,7 @@ __device__ __forceinline__ void rb_collision(RbM m, RbLds& s, float* S, int flag
     A.margin = B.margin = 0; A.mesh = B.mesh = -1; A.vertadr = B.vertadr = 0; A.nvert = B.nvert = 0;
     float margin = 0;
     v3 p1 = mk3(0, 0, 0);
-    bool plane = false;
+    bool plane = false, special = false;
     if (active) {
       p = cand[ci];
       const int g1 = m.b_pair_geom[3 * p], g2 = m.b_pair_geom[3 * p + 1];
@@ -773,19 +865,20 @@ __device__ __forceinline__ void rb_collision(RbM m, RbLds& s, float* S, int flag
       A.pos = mk3(0, 0, 0); B.pos = ld3(gpos + 3 * g2) - p1;
       plane = A.type == RG_GEOM_PLANE;
       A.margin = B.margin = plane ? 0.f : 0.5f * margin;
+      special = multipoint && B.type == RG_GEOM_BOX && (A.type == RG_GEOM_BOX || plane);
     }
     v3 sep, dir = mk3(0, 0, 0); float depth = 0;
     // (the quads of a wave take the two branches with their own lanes: the group collectives inside only need the quad)
-    const bool mh = rg_mpr<4>(E, A, B, m.mpr_iterations, m.mpr_tolerance, depth, dir, pos, sep, active && !plane);
-    if (active && !plane) {
+    const bool mh = rg_mpr<4>(E, A, B, m.mpr_iterations, m.mpr_tolerance, depth, dir, pos, sep, active && !plane && !special);
+    if (active && !plane && !special) {
       hit = mh && dot(dir, dir) > 0.25f;
       dist = margin - depth; nrm = normalized(dir); pos = pos + p1;
     }
     const v3 pn = qrot(ldq(A.quat), mk3(0, 0, 1));
     MprGeom Bs = B;   // plane - convex: the deepest point of the convex geom (quads on other pairs scan nothing)
-    if (!(active && plane)) { Bs.type = RG_GEOM_SPHERE; Bs.mesh = -1; Bs.size = mk3(0, 0, 0); }
-    const v3 sp = rg_support<4>(E, Bs, (active && plane) ? pn * -1.0f : mk3(0, 0, 1));
-    if (active && plane) {
+    if (!(active && plane && !special)) { Bs.type = RG_GEOM_SPHERE; Bs.mesh = -1; Bs.size = mk3(0, 0, 0); }
+    const v3 sp = rg_support<4>(E, Bs, (active && plane && !special) ? pn * -1.0f : mk3(0, 0, 1));
+    if (active && plane && !special) {
       dist = dot(sp, pn);
       hit = dist <= margin;
       pos = sp + p1 - pn * (0.5f * dist); nrm = pn;
@@ -802,7 +895,48 @@ __device__ __forceinline__ void rb_collision(RbM m, RbLds& s, float* S, int flag
       c[RB_CR_SOLREF] = pr[5]; c[RB_CR_SOLREF + 1] = pr[6];
       for (int k = 0; k < 5; k++) c[RB_CR_SOLIMP + k] = pr[7 + k];
       c[RB_CR_DIM] = (float)m.b_pair_geom[3 * p + 2]; c[RB_CR_G1] = (float)m.b_pair_geom[3 * p]; c[RB_CR_G2] = (float)m.b_pair_geom[3 * p + 1];
-      c[RB_CR_ADR] = -1.f; c[RB_CR_NNZ] = 0.f;
+      c[RB_CR_ADR] = -1.f; c[RB_CR_NNZ] = 0.f; c[RB_CR_KIND] = (float)((m.cone == 1 && m.b_pair_geom[3 * p + 2] > 1) ? RB_KIND_ELLIPTIC : RB_KIND_PYRAMID);
+    }
+  }
+  // box - box (mjc_BoxBox, up to 8 contacts) and plane - box (up to 4 corners): 32 lanes per pair, 8 pairs per trip
+  if (multipoint) {
+    for (int base = 0; base < ncand; base += RB_T / 32) {
+      const int ci = base + (TID >> 5), l = TID & 31;
+      bool hit = false, planebox = false; float dist = 0; v3 pos = mk3(0, 0, 0), nrm = mk3(0, 0, 1); int p = 0;
+      if (ci < ncand) {
+        p = cand[ci];
+        const int g1 = m.b_pair_geom[3 * p], g2 = m.b_pair_geom[3 * p + 1], t1 = m.geom_type[g1];
+        if (m.geom_type[g2] == RG_GEOM_BOX && (t1 == RG_GEOM_BOX || t1 == RG_GEOM_PLANE)) {
+          const float margin = m.b_pair_prm[12 * p];
+          const v3 P1 = ld3(gpos + 3 * g1), t = ld3(gpos + 3 * g2) - P1;
+          if (t1 == RG_GEOM_BOX) {
+            const float A[3] = {m.geom_size[3 * g1], m.geom_size[3 * g1 + 1], m.geom_size[3 * g1 + 2]}, B[3] = {m.geom_size[3 * g2], m.geom_size[3 * g2 + 1], m.geom_size[3 * g2 + 2]};
+            hit = box_box_lane(A, B, ldq(gquat + 4 * g1), ldq(gquat + 4 * g2), P1, t, margin, l, dist, pos, nrm);
+          } else {
+            nrm = qrot(ldq(gquat + 4 * g1), mk3(0, 0, 1));
+            hit = rb_plane_box_lane(nrm, t, ldq(gquat + 4 * g2), ld3(m.geom_size + 3 * g2), margin, l, dist, pos);
+            pos = pos + P1; planebox = true;
+          }
+        }
+      }
+      // plane - box: the first four corners (in corner order) within the margin, as the reference routine's early exit does
+      const unsigned long long balpb = __ballot(hit && planebox);
+      if (hit && planebox && __popc((unsigned)((balpb >> (TID & 32)) & 0xffull) & ((1u << l) - 1u)) >= 4) hit = false;
+      const int slot = rb_slot(s, hit, &s.ncon, m.maxcon, RG_STATUS_CON_FULL);
+      if (slot >= 0) {
+        float* c = con + RB_CONREC * slot;
+        const float* pr = m.b_pair_prm + 12 * p;
+        c[RB_CR_DIST] = dist; st3(c + RB_CR_POS, pos);
+        const v3 nn = normalized(nrm);
+        float fr[9]; fr[0] = nn.x; fr[1] = nn.y; fr[2] = nn.z; rb_make_frame(fr);
+        for (int k = 0; k < 9; k++) c[RB_CR_FRAME + k] = fr[k];
+        c[RB_CR_INCL] = pr[0] - pr[1];
+        c[RB_CR_FRIC] = pr[2]; c[RB_CR_FRIC + 1] = pr[2]; c[RB_CR_FRIC + 2] = pr[3]; c[RB_CR_FRIC + 3] = pr[4]; c[RB_CR_FRIC + 4] = pr[4];
+        c[RB_CR_SOLREF] = pr[5]; c[RB_CR_SOLREF + 1] = pr[6];
+        for (int k = 0; k < 5; k++) c[RB_CR_SOLIMP + k] = pr[7 + k];
+        c[RB_CR_DIM] = (float)m.b_pair_geom[3 * p + 2]; c[RB_CR_G1] = (float)m.b_pair_geom[3 * p]; c[RB_CR_G2] = (float)m.b_pair_geom[3 * p + 1];
+        c[RB_CR_ADR] = -1.f; c[RB_CR_NNZ] = 0.f; c[RB_CR_KIND] = (float)((m.cone == 1 && m.b_pair_geom[3 * p + 2] > 1) ? RB_KIND_ELLIPTIC : RB_KIND_PYRAMID);
+      }
     }
   }
   BSYNC();
@@ -818,6 +952,7 @@ __device__ __forceinline__ void rb_KB(float timestep, const float* solref, const
   } else { K = -solref[0] / fmaxf(RB_MINVAL, dmax * dmax); B = -solref[1] / fmaxf(RB_MINVAL, dmax); }
 }
 __device__ __forceinline__ int rb_npyr(int dim) { return dim == 1 ? 1 : 2 * (dim - 1); }
+__device__ __forceinline__ int rb_nrows(int kind, int dim) { return kind == RB_KIND_PYRAMID ? rb_npyr(dim) : dim; }   // elliptic contacts and equalities: one row per dimension
 // J_row . x for a static row
 __device__ __forceinline__ float rb_srow_dot(RbM m, const float* S, int type, int id, float aux, const float* x) {
   if (type == 0) return x[id];
@@ -828,7 +963,7 @@ __device__ __forceinline__ float rb_srow_dot(RbM m, const float* S, int type, in
 }
 // mj_makeConstraint + mj_makeImpedance: rows in MuJoCo's order (friction dofs, friction tendons, joint limits, tendon limits,
 // contacts); per contact the six basis Jacobian rows (3 translational, 3 rotational, contact frame) on the union of the dof chains
-__device__ __forceinline__ void rb_make_constraint(RbM m, RbLds& s, float* S) {
+__device__ __forceinline__ void rb_make_constraint(RbM m, RbLds& s, float* S, const float* L_eq_data) {
   float* row = SC(ROW); float* con = SC(CON);
   const int nf = m.nfric_dof + m.nfric_ten;
   // friction-loss rows
@@ -873,7 +1008,7 @@ __device__ __forceinline__ void rb_make_constraint(RbM m, RbLds& s, float* S) {
     s.nlim = n - nf;
     // contacts: row addresses
     for (int c = 0; c < s.ncon; c++) {
-      const int np = rb_npyr((int)con[RB_CONREC * c + RB_CR_DIM]);
+      const int np = rb_nrows((int)con[RB_CONREC * c + RB_CR_KIND], (int)con[RB_CONREC * c + RB_CR_DIM]);
       if (n + np <= m.maxrow) { con[RB_CONREC * c + RB_CR_ADR] = (float)n; n += np; }
       else { con[RB_CONREC * c + RB_CR_ADR] = -1.f; s.status |= RG_STATUS_ROW_FULL; }
     }
@@ -885,9 +1020,53 @@ __device__ __forceinline__ void rb_make_constraint(RbM m, RbLds& s, float* S) {
   const float *cdof = SC(CDOF), *rootcom = SC(ROOTCOM);
   BFOR(c, s.ncon) {
     float* C = con + RB_CONREC * c;
+    int* idx = cidx + RB_CONW * c; float* J = cj + 6 * RB_CONW * c;
+    if ((int)C[RB_CR_KIND] == RB_KIND_EQUALITY) {
+      // equality rows: the basis Jacobian rows ARE the constraint rows (oracle ro_make_constraint, equality block)
+      const int e = (int)C[RB_CR_G1], dim = (int)C[RB_CR_DIM], o1 = m.eq_obj1id[e], o2 = m.eq_obj2id[e];
+      int nnz = 0;
+      if (dim == 1) {
+        idx[0] = m.jnt_dofadr[o1]; J[0] = 1.f; nnz = 1;
+        if (o2 >= 0) { idx[1] = m.jnt_dofadr[o2]; J[1] = -C[RB_CR_FRAME + 1]; nnz = 2; }
+      } else {
+        const q4 q1 = ldq(SC(XQUAT) + 4 * o1), q2 = ldq(SC(XQUAT) + 4 * o2);
+        q4 qc; qc.w = q2.w; qc.x = -q2.x; qc.y = -q2.y; qc.z = -q2.z;
+        const q4 qr = qmul(q1, ldq(L_eq_data + 7 * e + 3));
+        for (int side = 0; side < 2; side++) {
+          const int bb = side ? o2 : o1; const float sg = side ? -1.f : 1.f;   // body1 - body2 ("opposite of contact")
+          if (bb <= 0 || m.body_weldid[bb] == 0) continue;
+          const v3 pnt = side ? ld3(SC(XPOS) + 3 * o2) : ld3(C + RB_CR_POS);
+          const v3 off = pnt - ld3(rootcom + 3 * m.body_rootid[bb]);
+          for (int i = m.b_body_lastdof[bb]; i >= 0; i = m.dof_parentid[i]) {
+            int q = 0;
+            while (q < nnz && idx[q] != i) q++;
+            if (q == nnz) { if (nnz >= RB_CONW) continue; idx[nnz] = i; for (int r = 0; r < 6; r++) J[r * RB_CONW + nnz] = 0.f; nnz++; }
+            const v3 jp = rb_jacp(cdof, i, off), jr = ld3(cdof + 6 * i);
+            J[q] += sg * jp.x; J[RB_CONW + q] += sg * jp.y; J[2 * RB_CONW + q] += sg * jp.z;
+            q4 ax; ax.w = 0.f; ax.x = sg * jr.x; ax.y = sg * jr.y; ax.z = sg * jr.z;
+            const q4 t2 = qmul(qmul(qc, ax), qr);                                  // 0.5 conj(q2) (jac1 - jac2) q1 relquat
+            J[3 * RB_CONW + q] += 0.5f * t2.x; J[4 * RB_CONW + q] += 0.5f * t2.y; J[5 * RB_CONW + q] += 0.5f * t2.z;
+          }
+        }
+      }
+      C[RB_CR_NNZ] = (float)nnz;
+      for (int q = nnz; q < RB_CONW; q++) idx[q] = -1;
+      const int adr = (int)C[RB_CR_ADR];
+      if (adr < 0) continue;
+      float K, B; rb_KB(m.timestep, C + RB_CR_SOLREF, C + RB_CR_SOLIMP, K, B);
+      for (int k = 0; k < dim; k++) {
+        const float pos = C[RB_CR_FRAME + (dim == 1 ? 0 : k)];
+        const float imp = rb_impedance(C + RB_CR_SOLIMP, pos, 0.f);
+        float vel = 0.f; for (int q = 0; q < nnz; q++) vel += J[k * RB_CONW + q] * s.qvel[idx[q]];
+        float* R = row + RB_ROWREC * (adr + k);
+        R[RB_RR_TYPE] = 5.f; R[RB_RR_ID] = (float)c; R[RB_RR_AUX] = (float)k; R[RB_RR_FLOSS] = 0.f; R[RB_RR_ZONE] = 3.f;
+        R[RB_RR_D] = 1.f / fmaxf(RB_MINVAL, (1.f - imp) * C[RB_CR_FRIC + (k < 3 ? 0 : 1)] / imp);
+        R[RB_RR_AREF] = -B * vel - K * imp * pos;
+      }
+      continue;
+    }
     const int b1 = m.geom_bodyid[(int)C[RB_CR_G1]], b2 = m.geom_bodyid[(int)C[RB_CR_G2]];
     const v3 pos = ld3(C + RB_CR_POS);
-    int* idx = cidx + RB_CONW * c; float* J = cj + 6 * RB_CONW * c;
     int nnz = 0;
     for (int side = 0; side < 2; side++) {
       const int bb = side ? b1 : b2; const float sg = side ? -1.f : 1.f;   // difference body2 - body1
@@ -921,6 +1100,19 @@ __device__ __forceinline__ void rb_make_constraint(RbM m, RbLds& s, float* S) {
       R[RB_RR_TYPE] = 4.f; R[RB_RR_ID] = (float)c; R[RB_RR_AUX] = 0.f; R[RB_RR_FLOSS] = 0.f;
       R[RB_RR_D] = 1.f / fmaxf(RB_MINVAL, (1.f - imp) * tran / imp);
       R[RB_RR_AREF] = -B * bd[0] - K * imp * (dist - incl);
+    } else if ((int)C[RB_CR_KIND] == RB_KIND_ELLIPTIC) {
+      // mj_makeImpedance, elliptic: R_1 = R_0 / impratio, mu = friction_0 sqrt(R_1 / R_0), R_j mu_j^2 = R_1 mu_1^2; only the normal row
+      // carries the distance.  mu is kept in the record's solref slot (its last reader was rb_KB above)
+      const float R0 = fmaxf(RB_MINVAL, (1.f - imp) * tran / imp), R1 = R0 / fmaxf(RB_MINVAL, m.impratio), fri0 = C[RB_CR_FRIC];
+      C[RB_CR_SOLREF] = fri0 * sqrtf(R1 / R0);
+      for (int k = 0; k < dim; k++) {
+        float* R = row + RB_ROWREC * (adr + k);
+        const float fk = k ? C[RB_CR_FRIC + k - 1] : 1.f;
+        const float Rk = k == 0 ? R0 : (k == 1 ? R1 : R1 * fri0 * fri0 / (fk * fk));
+        R[RB_RR_TYPE] = 5.f; R[RB_RR_ID] = (float)c; R[RB_RR_AUX] = (float)k; R[RB_RR_FLOSS] = 0.f; R[RB_RR_ZONE] = 0.f;
+        R[RB_RR_D] = 1.f / Rk;
+        R[RB_RR_AREF] = -B * bd[k] - (k == 0 ? K * imp * (dist - incl) : 0.f);
+      }
     } else {
       // all pyramid rows share R = 2 mu^2 R_first, R_first from the first edge's diagApprox
       const float fri0 = C[RB_CR_FRIC], diag0 = tran + fri0 * fri0 * tran;
@@ -975,6 +1167,35 @@ __device__ __forceinline__ void rb_dof_contact_lists(RbM m, RbLds& s, float* S) 
   }
   BSYNC();
 }
+// Elliptic cones (engine_core_constraint.c mj_constraintUpdate, oracle cone_eval): one thread per contact evaluates its zone from the rows'
+// residuals and leaves force / zone / cost in the row records (the whole contact's cost on its first row).  In the scaled variables
+// U0 = mu jar_0, Uj = friction_(j-1) jar_j, N = U0, T = |U_1..|: top zone (N >= mu T) no force; bottom zone (mu N + T <= 0) every row
+// quadratic with its own D; middle zone cost = 1/2 Dm (N - mu T)^2, Dm = D_0 / (mu^2 (1 + mu^2)).
+__device__ __forceinline__ void rb_cone_update(RbM m, RbLds& s, float* S) {
+  float* row = SC(ROW); const float* con = SC(CON);
+  BFOR(c, s.ncon) {
+    const float* C = con + RB_CONREC * c;
+    const int adr = (int)C[RB_CR_ADR], dim = (int)C[RB_CR_DIM];
+    if ((int)C[RB_CR_KIND] != RB_KIND_ELLIPTIC || adr < 0 || dim < 2) continue;
+    float* R0 = row + RB_ROWREC * adr;
+    const float mu = C[RB_CR_SOLREF];
+    float U[6], T = 0.f;
+    U[0] = R0[RB_RR_JAR] * mu;
+    for (int j = 1; j < dim; j++) { U[j] = R0[RB_ROWREC * j + RB_RR_JAR] * C[RB_CR_FRIC + j - 1]; T += U[j] * U[j]; }
+    const float N = U[0]; T = sqrtf(T);
+    if (N >= mu * T || (T <= 0.f && N >= 0.f)) {
+      for (int j = 0; j < dim; j++) { float* R = R0 + RB_ROWREC * j; R[RB_RR_FORCE] = 0.f; R[RB_RR_ZONE] = 0.f; R[RB_RR_COST] = 0.f; }
+    } else if (mu * N + T <= 0.f || (T <= 0.f && N < 0.f)) {
+      for (int j = 0; j < dim; j++) { float* R = R0 + RB_ROWREC * j; const float x = R[RB_RR_JAR], D = R[RB_RR_D]; R[RB_RR_FORCE] = -D * x; R[RB_RR_ZONE] = 1.f; R[RB_RR_COST] = 0.5f * D * x * x; }
+    } else {
+      const float Dm = R0[RB_RR_D] / (mu * mu * (1.f + mu * mu)), NT = N - mu * T;
+      const float f0 = -Dm * NT * mu;
+      R0[RB_RR_FORCE] = f0; R0[RB_RR_ZONE] = 2.f; R0[RB_RR_COST] = 0.5f * Dm * NT * NT;
+      for (int j = 1; j < dim; j++) { float* R = R0 + RB_ROWREC * j; R[RB_RR_FORCE] = -f0 / T * U[j] * C[RB_CR_FRIC + j - 1]; R[RB_RR_ZONE] = 2.f; R[RB_RR_COST] = 0.f; }
+    }
+  }
+  BSYNC();
+}
 // jar (to_jv = false: J x - aref) or jv (to_jv = true: J x) of every row
 __device__ __forceinline__ void rb_J_mul(RbM m, RbLds& s, float* S, const float* x, bool to_jv) {
   float* row = SC(ROW); const float* con = SC(CON); const float* cj = SC(CONJ); const int* cidx = (const int*)SC(CONIDX);
@@ -995,6 +1216,7 @@ __device__ __forceinline__ void rb_J_mul(RbM m, RbLds& s, float* S, const float*
     const float aux = R[RB_RR_AUX];
     float v;
     if (type < 4) v = rb_srow_dot(m, S, type, id, aux, x);
+    else if (type == 5) v = bd[6 * id + (int)aux];
     else {
       const int a = (int)fabsf(aux);
       v = bd[6 * id] + (a ? (aux < 0 ? -1.f : 1.f) * con[RB_CONREC * id + RB_CR_FRIC + a - 1] * bd[6 * id + a] : 0.f);
@@ -1002,10 +1224,15 @@ __device__ __forceinline__ void rb_J_mul(RbM m, RbLds& s, float* S, const float*
     if (to_jv) R[RB_RR_JV] = v; else R[RB_RR_JAR] = v - R[RB_RR_AREF];
   }
   BSYNC();
+  if (!to_jv && m.cone == 1) rb_cone_update(m, s, S);
 }
 // force of one constraint row at its current residual (R[JAR]), whether it is in its quadratic zone, and its cost
 __device__ __forceinline__ float rb_row_force(const float* R, bool& quad, float& cost) {
   const float D = R[RB_RR_D], x = R[RB_RR_JAR];
+  if ((int)R[RB_RR_TYPE] == 5) {
+    if (R[RB_RR_ZONE] == 3.f) { quad = true; cost = 0.5f * D * x * x; return -D * x; }   // equality row: always active, two-sided
+    quad = R[RB_RR_ZONE] == 1.f; cost = R[RB_RR_COST]; return R[RB_RR_FORCE];              // elliptic contact row: what rb_cone_update left
+  }
   if ((int)R[RB_RR_TYPE] < 2) {
     const float f = R[RB_RR_FLOSS], Rr = 1.f / D;
     if (x <= -Rr * f) { quad = false; cost = f * (-0.5f * Rr * f - x); return f; }
@@ -1025,7 +1252,9 @@ __device__ __forceinline__ void rb_JT_force(RbM m, RbLds& s, float* S, float* ds
     const float* C = con + RB_CONREC * c;
     const int adr = (int)C[RB_CR_ADR], np = rb_npyr((int)C[RB_CR_DIM]);
     float acc = 0;
-    if (adr >= 0) for (int q = 0; q < np; q++) {
+    if ((int)C[RB_CR_KIND] != RB_KIND_PYRAMID) {   // rows = basis rows: the basis force is the row's force
+      if (adr >= 0 && b < (int)C[RB_CR_DIM]) { bool qd; float cst; acc = rb_row_force(row + RB_ROWREC * (adr + b), qd, cst); }
+    } else if (adr >= 0) for (int q = 0; q < np; q++) {
       const float* R = row + RB_ROWREC * (adr + q);
       const int a = (int)fabsf(R[RB_RR_AUX]);
       if (b != 0 && a != b) continue;
@@ -1135,15 +1364,19 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
   }
   // contacts: A += Jc' W Jc with the 6 x 6 weight W of the contact's quadratic pyramid edges (w_row = e0 +- mu_k e_(k+1)):
   // the weights of all contacts first (one contact per thread), then the contacts one at a time, one (a, b) entry per thread
-  float* Wc = SC(CONF);   // 12 words per contact: W00, W0k[5], Wkk[5]
+  float* Wc = SC(CONF);   // RB_NW words per contact.  Pyramidal: W00, W0k[5], Wkk[5] (mode 1).  Elliptic / equality: the lower triangle of the 6 x 6 weight
+                          // of the basis rows (mode 2): diag(D) of the quadratic rows, or the cone's Hessian in its middle zone (engine_solver.c HessianCone)
   if (TID == 0) s.wcnt[0] = 0;
   BSYNC();
   BFOR(c, s.ncon) {
     const float* C = con + RB_CONREC * c;
-    const int adr = (int)C[RB_CR_ADR];
-    float W00 = 0, W0k[5] = {0, 0, 0, 0, 0}, Wkk[5] = {0, 0, 0, 0, 0};
-    if (adr >= 0 && m.b_dof_group[cidx[RB_CONW * c]] == g) {
-      const int np = rb_npyr((int)C[RB_CR_DIM]);
+    const int adr = (int)C[RB_CR_ADR], kind = (int)C[RB_CR_KIND], dim = (int)C[RB_CR_DIM];
+    float* W = Wc + RB_NW * c;
+    for (int k = 0; k < RB_NW; k++) W[k] = 0.f;
+    if (!(adr >= 0 && m.b_dof_group[cidx[RB_CONW * c]] == g)) continue;
+    if (kind == RB_KIND_PYRAMID) {
+      float W00 = 0, W0k[5] = {0, 0, 0, 0, 0}, Wkk[5] = {0, 0, 0, 0, 0};
+      const int np = rb_npyr(dim);
       for (int q = 0; q < np; q++) {
         const float* R = row + RB_ROWREC * (adr + q);
         bool qd; float cst; rb_row_force(R, qd, cst);
@@ -1152,10 +1385,32 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
         W00 += D;
         if (a) { const float mu = (R[RB_RR_AUX] < 0 ? -1.f : 1.f) * C[RB_CR_FRIC + a - 1]; W0k[a - 1] += D * mu; Wkk[a - 1] += D * mu * mu; }
       }
+      W[0] = W00; for (int k = 0; k < 5; k++) { W[1 + k] = W0k[k]; W[6 + k] = Wkk[k]; }
+      if (W00 != 0.f) { W[RB_NW - 1] = 1.f; s.wcnt[0] = 1; }   // (benign race: every writer stores the same value)
+    } else {
+      const float* R0 = row + RB_ROWREC * adr;
+      const float zone = R0[RB_RR_ZONE];
+      bool any = false;
+      if (zone == 2.f) {   // middle zone of the cone: second derivatives of 1/2 Dm (N - mu T)^2 through U = diag(mu, friction) jar
+        const float mu = C[RB_CR_SOLREF];
+        float U[6], sc[6], T = 0.f;
+        sc[0] = mu; U[0] = R0[RB_RR_JAR] * mu;
+        for (int j = 1; j < dim; j++) { sc[j] = C[RB_CR_FRIC + j - 1]; U[j] = R0[RB_ROWREC * j + RB_RR_JAR] * sc[j]; T += U[j] * U[j]; }
+        T = sqrtf(T);
+        const float N = U[0], Dm = R0[RB_RR_D] / (mu * mu * (1.f + mu * mu)), iT = 1.f / T;
+        for (int j = 0; j < dim; j++) for (int k = 0; k <= j; k++) {
+          float h;
+          if (j == 0) h = 1.f;
+          else if (k == 0) h = -mu * U[j] * iT;
+          else h = mu * N * iT * iT * iT * U[j] * U[k] + (j == k ? mu * mu - mu * N * iT : 0.f);
+          W[j * (j + 1) / 2 + k] = Dm * sc[j] * sc[k] * h;
+        }
+        any = true;
+      } else {
+        for (int j = 0; j < dim; j++) { const float* R = R0 + RB_ROWREC * j; bool qd; float cst; rb_row_force(R, qd, cst); if (qd) { W[j * (j + 1) / 2 + j] = R[RB_RR_D]; any = true; } }
+      }
+      if (any) { W[RB_NW - 1] = 2.f; s.wcnt[0] = 1; }
     }
-    float* W = Wc + 12 * c;
-    W[0] = W00; for (int k = 0; k < 5; k++) { W[1 + k] = W0k[k]; W[6 + k] = Wkk[k]; }
-    if (W00 != 0.f) s.wcnt[0] = 1;   // (benign race: every writer stores the same value)
   }
   BSYNC();
   const bool any = s.wcnt[0] != 0;
@@ -1173,8 +1428,8 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
     if (t >= RB_CST) return 0.f;
     if (t < 6 * RB_CONW) return cj[6 * RB_CONW * c + t];
     if (t < 7 * RB_CONW) { const int d = cidx[RB_CONW * c + t - 6 * RB_CONW]; return (float)((d >= 0 && d < m.nv) ? m.b_dof_local[d] : 0); }
-    if (t < 7 * RB_CONW + 12) return Wc[12 * c + t - 7 * RB_CONW];
-    return con[RB_CONREC * c + (t == 7 * RB_CONW + 12 ? RB_CR_NNZ : RB_CR_DIM)];
+    if (t < 7 * RB_CONW + RB_NW) return Wc[RB_NW * c + t - 7 * RB_CONW];
+    return con[RB_CONREC * c + (t == 7 * RB_CONW + RB_NW ? RB_CR_NNZ : RB_CR_DIM)];
   };
   int buf = 0;
 #ifdef RB_HESS_PROBE
@@ -1187,16 +1442,27 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
     const float after = c + 2 < s.ncon ? stage_load(c + 2) : 0.f;
     const float* K = s.cst + RB_CST * buf;
     const float* W = K + 7 * RB_CONW;
-    if (W[0] != 0.f) {
-      const int nnz = (int)K[7 * RB_CONW + 12], dim = (int)K[7 * RB_CONW + 13];
+    const float mode = W[RB_NW - 1];
+    if (mode != 0.f) {
+      const int nnz = (int)K[7 * RB_CONW + RB_NW], dim = (int)K[7 * RB_CONW + RB_NW + 1];
       for (int w = TID; w < nnz * (nnz + 1) / 2; w += RB_T) {
         int ea = (int)((sqrtf(8.f * (float)w + 1.f) - 1.f) * 0.5f);
         if (ea * (ea + 1) / 2 > w) ea--; else if ((ea + 1) * (ea + 2) / 2 <= w) ea++;
         const int eb = w - ea * (ea + 1) / 2;                    // every unordered pair of the contact's dofs once (eb <= ea)
-        float v = W[0] * K[ea] * K[eb];
-        for (int k = 0; k < dim - 1; k++) {
-          const float ja = K[(k + 1) * RB_CONW + ea], jb = K[(k + 1) * RB_CONW + eb];
-          v += W[1 + k] * (K[ea] * jb + ja * K[eb]) + W[6 + k] * ja * jb;
+        float v;
+        if (mode == 1.f) {
+          v = W[0] * K[ea] * K[eb];
+          for (int k = 0; k < dim - 1; k++) {
+            const float ja = K[(k + 1) * RB_CONW + ea], jb = K[(k + 1) * RB_CONW + eb];
+            v += W[1 + k] * (K[ea] * jb + ja * K[eb]) + W[6 + k] * ja * jb;
+          }
+        } else {   // general symmetric weight of the basis rows
+          v = 0.f;
+          for (int j = 0; j < dim; j++) {
+            const float ja = K[j * RB_CONW + ea], jb = K[j * RB_CONW + eb];
+            v += W[j * (j + 1) / 2 + j] * ja * jb;
+            for (int k = 0; k < j; k++) { const float wk = W[j * (j + 1) / 2 + k]; if (wk != 0.f) v += wk * (ja * K[k * RB_CONW + eb] + K[k * RB_CONW + ea] * jb); }
+          }
         }
         const int la = (int)K[6 * RB_CONW + ea], lb = (int)K[6 * RB_CONW + eb];
         s.A[la >= lb ? RB_TRI(la, lb) : RB_TRI(lb, la)] += v;
@@ -1215,42 +1481,76 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
 struct RbLs { float cost, grad, hess; };
 // the rows a thread owns in the line search (r = TID and TID + RB_T; rows beyond 2 RB_T are read from the scratch row each time): loaded once
 struct RbLsRows { float D[2], jar[2], jv[2], fl[2]; int fric[2]; };
-__device__ __forceinline__ void rb_ls_acc(float D, float jar, float jv, float fl, bool fric, float alpha, float& cst, float& grd, float& hss) {
+// row classes of the line search: 0 one-sided (limits, pyramid edges), 1 friction loss, 2 always quadratic (equality), 3 row of an elliptic contact
+// (skipped here: rb_ls_cones evaluates the contact as a whole)
+__device__ __forceinline__ int rb_ls_class(const float* R) {
+  const int type = (int)R[RB_RR_TYPE];
+  return type < 2 ? 1 : (type == 5 ? (R[RB_RR_ZONE] == 3.f ? 2 : 3) : 0);
+}
+__device__ __forceinline__ void rb_ls_acc(float D, float jar, float jv, float fl, int cls, float alpha, float& cst, float& grd, float& hss) {
   const float x = jar + alpha * jv;
-  if (fric) {
+  if (cls == 3) return;
+  if (cls == 2) { cst += 0.5f * D * x * x; grd += D * x * jv; hss += D * jv * jv; return; }
+  if (cls == 1) {
     const float Rr = 1.f / D;
     if (x <= -Rr * fl) { cst += fl * (-0.5f * Rr * fl - x); grd += -fl * jv; }
     else if (x >= Rr * fl) { cst += fl * (-0.5f * Rr * fl + x); grd += fl * jv; }
     else { cst += 0.5f * D * x * x; grd += D * x * jv; hss += D * jv * jv; }
   } else if (x < 0) { cst += 0.5f * D * x * x; grd += D * x * jv; hss += D * jv * jv; }
 }
-__device__ __forceinline__ RbLs rb_ls_eval(RbLds& s, const float* row, const RbLsRows& own, int nefc, float alpha, float q0, float q1, float q2) {
+// the elliptic contacts' cost along the search direction and its first two derivatives in alpha (oracle ls_eval, elliptic branch): one thread per contact
+__device__ __forceinline__ void rb_ls_cones(const float* row, const float* con, int ncon, float alpha, float& cst, float& grd, float& hss) {
+  for (int c = TID; c < ncon; c += RB_T) {
+    const float* C = con + RB_CONREC * c;
+    const int adr = (int)C[RB_CR_ADR], dim = (int)C[RB_CR_DIM];
+    if ((int)C[RB_CR_KIND] != RB_KIND_ELLIPTIC || adr < 0 || dim < 2) continue;
+    const float* R0 = row + RB_ROWREC * adr;
+    const float mu = C[RB_CR_SOLREF];
+    float T = 0.f, UV = 0.f, VV = 0.f;
+    const float N = (R0[RB_RR_JAR] + alpha * R0[RB_RR_JV]) * mu, N1 = R0[RB_RR_JV] * mu;
+    for (int j = 1; j < dim; j++) {
+      const float* R = R0 + RB_ROWREC * j; const float f = C[RB_CR_FRIC + j - 1];
+      const float u = (R[RB_RR_JAR] + alpha * R[RB_RR_JV]) * f, v = R[RB_RR_JV] * f;
+      T += u * u; UV += u * v; VV += v * v;
+    }
+    T = sqrtf(T);
+    if (N >= mu * T || (T <= 0.f && N >= 0.f)) continue;
+    if (mu * N + T <= 0.f || (T <= 0.f && N < 0.f)) {
+      for (int j = 0; j < dim; j++) { const float* R = R0 + RB_ROWREC * j; const float D = R[RB_RR_D], jv = R[RB_RR_JV], x = R[RB_RR_JAR] + alpha * jv; cst += 0.5f * D * x * x; grd += D * x * jv; hss += D * jv * jv; }
+    } else {
+      const float Dm = R0[RB_RR_D] / (mu * mu * (1.f + mu * mu)), NT = N - mu * T, T1 = UV / T, T2 = (VV - T1 * T1) / T, dN = N1 - mu * T1;
+      cst += 0.5f * Dm * NT * NT; grd += Dm * NT * dN; hss += Dm * (dN * dN - NT * mu * T2);
+    }
+  }
+}
+__device__ __forceinline__ RbLs rb_ls_eval(RbLds& s, const float* row, const float* con, int ncone, const RbLsRows& own, int nefc, float alpha, float q0, float q1, float q2) {
   float cst = 0, grd = 0, hss = 0;
 #pragma unroll
-  for (int k = 0; k < 2; k++) if (TID + k * RB_T < nefc) rb_ls_acc(own.D[k], own.jar[k], own.jv[k], own.fl[k], own.fric[k] != 0, alpha, cst, grd, hss);
+  for (int k = 0; k < 2; k++) if (TID + k * RB_T < nefc) rb_ls_acc(own.D[k], own.jar[k], own.jv[k], own.fl[k], own.fric[k], alpha, cst, grd, hss);
   for (int r = TID + 2 * RB_T; r < nefc; r += RB_T) {
     const float* R = row + RB_ROWREC * r;
-    rb_ls_acc(R[RB_RR_D], R[RB_RR_JAR], R[RB_RR_JV], R[RB_RR_FLOSS], (int)R[RB_RR_TYPE] < 2, alpha, cst, grd, hss);
+    rb_ls_acc(R[RB_RR_D], R[RB_RR_JAR], R[RB_RR_JV], R[RB_RR_FLOSS], rb_ls_class(R), alpha, cst, grd, hss);
   }
+  if (ncone > 0) rb_ls_cones(row, con, ncone, alpha, cst, grd, hss);
   rb_sum3(s, cst, grd, hss);
   RbLs p; p.cost = alpha * alpha * q2 + alpha * q1 + q0 + cst; p.grad = 2.f * alpha * q2 + q1 + grd; p.hess = 2.f * q2 + hss;
   return p;
 }
 // exact minimiser of the convex piecewise-quadratic 1-D restriction (oracle line_search: safeguarded Newton on the derivative)
-__device__ __forceinline__ float rb_line_search(RbLds& s, const float* row, int nefc, float q0, float q1, float q2, float gtol, int maxit) {
+__device__ __forceinline__ float rb_line_search(RbLds& s, const float* row, const float* con, int ncone, int nefc, float q0, float q1, float q2, float gtol, int maxit) {
   RbLsRows own;
 #pragma unroll
   for (int k = 0; k < 2; k++) {
     const int r = TID + k * RB_T;
     const float* R = row + RB_ROWREC * (r < nefc ? r : 0);
-    own.D[k] = R[RB_RR_D]; own.jar[k] = R[RB_RR_JAR]; own.jv[k] = R[RB_RR_JV]; own.fl[k] = R[RB_RR_FLOSS]; own.fric[k] = (int)R[RB_RR_TYPE] < 2;
+    own.D[k] = R[RB_RR_D]; own.jar[k] = R[RB_RR_JAR]; own.jv[k] = R[RB_RR_JV]; own.fl[k] = R[RB_RR_FLOSS]; own.fric[k] = rb_ls_class(R);
   }
-  const RbLs p0 = rb_ls_eval(s, row, own, nefc, 0.f, q0, q1, q2);
+  const RbLs p0 = rb_ls_eval(s, row, con, ncone, own, nefc, 0.f, q0, q1, q2);
   if (p0.grad >= 0 || p0.hess <= 0) return 0.f;
   float lo = 0, hi = -1, glo = p0.grad, hlo = p0.hess, ghi = 0, hhi = 0;
   float a = -p0.grad / p0.hess;
   for (int it = 0; it < maxit; it++) {
-    const RbLs p = rb_ls_eval(s, row, own, nefc, a, q0, q1, q2);
+    const RbLs p = rb_ls_eval(s, row, con, ncone, own, nefc, a, q0, q1, q2);
     if (fabsf(p.grad) < gtol) return a;
     if (p.grad < 0) { lo = a; glo = p.grad; hlo = p.hess; } else { hi = a; ghi = p.grad; hhi = p.hess; }
     float cand = lo - glo / hlo;
@@ -1334,7 +1634,7 @@ __device__ __forceinline__ int rb_solve(RbM m, RbLds& s, float* S, int flags) {
     if (sn < RB_MINVAL) break;
     const float gtol = tol * 0.01f * sn / scale * 1e-3f;   // (tolerance x ls_tolerance x |search| / scale x 1e-3: oracle's "exact" line search)
     RB_PROFS(13);
-    const float alpha = rb_line_search(s, row, ne, gauss, q1, q2, gtol, 40); RB_PROFS(14);
+    const float alpha = rb_line_search(s, row, SC(CON), m.cone == 1 ? s.ncon : 0, ne, gauss, q1, q2, gtol, 40); RB_PROFS(14);
     if (alpha == 0.f) break;
     BFOR(i, nv) s.qa[i] += alpha * s.search[i];
     BSYNC();
@@ -1370,6 +1670,70 @@ __device__ __forceinline__ void rb_euler(RbM m, RbLds& s, float* S, int flags) {
   BSYNC();
 }
 
+// ------------------------------------------------------------------------------------------------- sensors
+// mj_sensorPos (jointpos) and mj_sensorAcc (force, torque) after a full forward pass at the final state: mj_rnePostConstraint — body
+// accelerations with the solver's qacc, contact forces as external forces, the interaction force of the sensor site's body with its
+// parent = the sum over its subtree — moved to the site and rotated into the site frame (oracle ro_rne_post_constraint / ro_sensor).
+__device__ __forceinline__ void rb_sensors(RbM m, RbLds& s, float* S, float* out) {
+  const float *cdof = SC(CDOF), *cdofdot = SC(CDOFDOT), *cvel = SC(CVEL), *rootcom = SC(ROOTCOM), *con = SC(CON), *row = SC(ROW);
+  float *cacc = SC(CACC), *cfrc = SC(CFRC), *cext = SC(CFRCEXT);
+  if (TID < 6) { cacc[TID] = TID < 3 ? 0.f : -m.gravity[TID - 3]; cfrc[TID] = 0.f; }
+  BFOR(b, m.nbody) {
+    float acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int c = 0; c < s.ncon; c++) {
+      const float* C = con + RB_CONREC * c;
+      const int adr = (int)C[RB_CR_ADR], kind = (int)C[RB_CR_KIND];
+      if (adr < 0 || kind == RB_KIND_EQUALITY) continue;
+      const int b1 = m.geom_bodyid[(int)C[RB_CR_G1]], b2 = m.geom_bodyid[(int)C[RB_CR_G2]];
+      if (b == 0 || (b != b1 && b != b2)) continue;
+      const int dim = (int)C[RB_CR_DIM];
+      float cf[6] = {0, 0, 0, 0, 0, 0};
+      if (kind == RB_KIND_ELLIPTIC) { for (int j = 0; j < dim; j++) cf[j] = row[RB_ROWREC * (adr + j) + RB_RR_FORCE]; }
+      else if (dim == 1) { bool q; float cc; cf[0] = rb_row_force(row + RB_ROWREC * adr, q, cc); }
+      else for (int j = 0; j < dim - 1; j++) {
+        bool q; float cc;
+        const float fp = rb_row_force(row + RB_ROWREC * (adr + 2 * j), q, cc), fn = rb_row_force(row + RB_ROWREC * (adr + 2 * j + 1), q, cc);
+        cf[0] += fp + fn; cf[1 + j] = (fp - fn) * C[RB_CR_FRIC + j];
+      }
+      const v3 f0 = ld3(C + RB_CR_FRAME), f1 = ld3(C + RB_CR_FRAME + 3), f2 = ld3(C + RB_CR_FRAME + 6);
+      const v3 f = f0 * cf[0] + f1 * cf[1] + f2 * cf[2], t = f0 * cf[3] + f1 * cf[4] + f2 * cf[5];
+      const v3 off = ld3(C + RB_CR_POS) - ld3(rootcom + 3 * m.body_rootid[b]);
+      const v3 tq = t + cross(off, f);
+      const float sg = (b == b2 ? 1.f : 0.f) - (b == b1 ? 1.f : 0.f);
+      acc[0] += sg * tq.x; acc[1] += sg * tq.y; acc[2] += sg * tq.z; acc[3] += sg * f.x; acc[4] += sg * f.y; acc[5] += sg * f.z;
+    }
+    for (int k = 0; k < 6; k++) cext[6 * b + k] = acc[k];
+  }
+  BSYNC();
+  for (int L = 0; L < m.nlevel; L++) {
+    for (int q = m.b_lvl_adr[L] + TID; q < m.b_lvl_adr[L + 1]; q += RB_T) {
+      const int b = m.b_lvl_body[q], p = m.body_parentid[b];
+      float ca[6], cv[6];
+      for (int c = 0; c < 6; c++) { ca[c] = cacc[6 * p + c]; cv[c] = cvel[6 * b + c]; }
+      for (int k = 0; k < m.body_dofnum[b]; k++) { const int i = m.body_dofadr[b] + k; for (int c = 0; c < 6; c++) ca[c] += cdofdot[6 * i + c] * s.qvel[i] + cdof[6 * i + c] * s.qa[i]; }
+      float t1[6], t2[6], t3[6];
+      mul_inert_vec(t1, SC(CINERT) + 10 * b, ca);
+      mul_inert_vec(t2, SC(CINERT) + 10 * b, cv);
+      cross_force(t3, cv, t2);
+      for (int c = 0; c < 6; c++) { cacc[6 * b + c] = ca[c]; cfrc[6 * b + c] = t1[c] + t3[c] - cext[6 * b + c]; }
+    }
+    BSYNC();
+  }
+  BFOR(k, m.nsensor) {
+    const int type = m.sensor_type[k], obj = m.sensor_objid[k], adr = m.sensor_adr[k];
+    if (type == 8) { out[adr] = s.qpos[m.jnt_qposadr[obj]]; continue; }   // mjSENS_JOINTPOS
+    if (type != 4 && type != 5) { out[adr] = 0.f; continue; }              // (touch sensors: rg_kernel.h's sensor instantiation; not needed by this path)
+    const int body = m.site_bodyid[obj];
+    float cf[6] = {0, 0, 0, 0, 0, 0};
+    for (int q = m.b_subtree_adr[body]; q < m.b_subtree_adr[body + 1]; q++) { const float* f = cfrc + 6 * m.b_subtree[q]; for (int c = 0; c < 6; c++) cf[c] += f[c]; }
+    const v3 frc = mk3(cf[3], cf[4], cf[5]), off = ld3(SC(SPOS) + 3 * obj) - ld3(rootcom + 3 * m.body_rootid[body]);
+    const v3 v = type == 4 ? frc : mk3(cf[0], cf[1], cf[2]) - cross(off, frc);
+    q4 sq = qmul(ldq(SC(XQUAT) + 4 * body), ldq(m.site_quat + 4 * obj)); sq.x = -sq.x; sq.y = -sq.y; sq.z = -sq.z;
+    st3(out + adr, qrot(sq, v));
+  }
+  BSYNC();
+}
+
 #ifdef RG_EMUL
 #define RB_MAKE_CTX() const RbModelDev& m = *mp; const RbLaunch& L = launch
 #else
@@ -1386,8 +1750,11 @@ __global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbMod
   BFOR(i, nq) s.qpos[i] = L.bt.qpos[(size_t)e * nq + i];
   BFOR(i, nv) { s.qvel[i] = L.bt.qvel[(size_t)e * nv + i]; s.warm[i] = L.bt.qacc_warmstart[(size_t)e * nv + i]; }
   BFOR(i, 3 * nu) s.pid[i] = L.bt.pid[(size_t)e * 3 * nu + i];
-  if (TID == 0) { s.status = L.bt.status[e]; s.stop = 0; }
+  if (TID == 0) { s.status = L.bt.status[e]; s.stop = 0; s.neqcon = 0; s.time = L.bt.time[e]; }
   if (TID < 16) s.prof[TID] = 0.f;
+  if (TID < 7 * m.nmocap && TID < 14) s.mocap[TID] = L.bt.mocap[(size_t)e * 7 * m.nmocap + TID];
+  const float* eqd = m.neq > 0 ? L.bt.eq_data + (size_t)e * 7 * m.neq : (const float*)0;
+  const int* eqa = m.neq > 0 ? L.bt.eq_active + (size_t)e * m.neq : (const int*)0;
   BSYNC();
   // ---- action -> ctrl (robot_interface.py:247-278 with the hand's position -> control matrix)
   bool use_action = L.bt.action != 0 && !(L.bt.hold && L.bt.hold[e]);
@@ -1405,6 +1772,31 @@ __global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbMod
     } else s.ctrl[u] = L.bt.ctrl[(size_t)e * nu + u];
   }
   BSYNC();
+  // ---- the TCP solver hook (RbTcpHook): arm joints <- main simulation, forward(), mocap target <- TCP pose + denormalised action
+  if (L.tcp.enabled) {
+    if (L.tcp.sync) { if (TID < 6) s.qpos[L.tcp.arm_q[TID]] = L.tcp.main_qpos[(size_t)e * L.tcp.main_nq + L.tcp.main_arm_q[TID]]; }
+    BSYNC();
+    rb_kinematics(m, s, S); rb_com_pos(m, s, S); rb_tendon(m, s, S);
+    if (L.tcp.sync) rb_pid(m, s, S, false);   // the controller tick of sync_to's mj_forward (free_dof_tcp_arm.py:214-225)
+    if (TID == 0) {
+      const float* a = L.tcp.action + (size_t)e * 6;
+      const float mpc = L.tcp.max_position_change;
+      const float a0 = clampf(a[0], -1.f, 1.f), a1 = clampf(a[1], -1.f, 1.f), a2 = clampf(a[2], -1.f, 1.f), a3 = clampf(a[3], -1.f, 1.f), a4 = clampf(a[4], -1.f, 1.f);
+      const float roll = a3 * L.tcp.speed[0] * mpc;
+      const float q6 = s.qpos[L.tcp.arm_q[5]], lo = m.jnt_range[2 * L.tcp.wrist_jnt], hi = m.jnt_range[2 * L.tcp.wrist_jnt + 1];
+      const float pitch = clampf(a4 * L.tcp.speed[1] * mpc, lo + L.tcp.drift_threshold - q6, hi - L.tcp.drift_threshold - q6);   // FreeDOFTcpArm.constrain_quat_ctrl
+      // MocapSolver.get_tcp_quat: euler = (roll, 0, pitch dimension) -> qx(roll) * qz(.), applied on the right of the TCP's orientation; mocap_set_action
+      // adds the DIFFERENCE to the mocap quaternion, which reset_mocap2body_xpos has just set to the TCP's own pose
+      const float cr = cosf(0.5f * roll), sr = sinf(0.5f * roll), cp = cosf(0.5f * pitch), sp = sinf(0.5f * pitch);
+      q4 eq; eq.w = cr * cp; eq.x = sr * cp; eq.y = -sr * sp; eq.z = cr * sp;
+      const q4 gq = ldq(SC(XQUAT) + 4 * L.tcp.tcp_body);
+      const q4 tq = qmul(gq, eq);
+      const v3 tp = ld3(SC(XPOS) + 3 * L.tcp.tcp_body);
+      s.mocap[0] = tp.x + a0 * mpc; s.mocap[1] = tp.y + a1 * mpc; s.mocap[2] = tp.z + a2 * mpc;
+      s.mocap[3] = gq.w + (tq.w - gq.w); s.mocap[4] = gq.x + (tq.x - gq.x); s.mocap[5] = gq.y + (tq.y - gq.y); s.mocap[6] = gq.z + (tq.z - gq.z);
+    }
+    BSYNC();
+  }
   float st_ncon = 0, st_nefc = 0, st_iter = 0; int nsub_done = 0;
   for (int sub = 0; sub < L.nsubsteps; sub++) {
     float bd = 0; BFOR(i, nq) bd += (fabsf(s.qpos[i]) < 1e10f) ? 0.f : 1.f; BFOR(i, nv) bd += (fabsf(s.qvel[i]) < 1e10f) ? 0.f : 1.f;
@@ -1414,8 +1806,9 @@ __global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbMod
     rb_kinematics(m, s, S); rb_com_pos(m, s, S); RB_PROF(0);
     rb_tendon(m, s, S); rb_crb(m, s, S); RB_PROF(1);
     rb_velocity(m, s, S); RB_PROF(2);
+    rb_equality(m, s, S, eqd, eqa);
     rb_collision(m, s, S, flags); RB_PROF(3);
-    rb_make_constraint(m, s, S); RB_PROF(4);
+    rb_make_constraint(m, s, S, eqd); RB_PROF(4);
     rb_dof_contact_lists(m, s, S);
     rb_pid(m, s, S, true);
     // qacc_smooth = inv(M) qfrc_smooth
@@ -1438,14 +1831,44 @@ __global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbMod
     if (rb_sum(s, bd) > 0) { if (TID == 0) s.status |= RG_STATUS_BAD_STATE; break; }
     BFOR(i, nv) s.warm[i] = s.qa[i];
     rb_euler(m, s, S, flags); RB_PROF(7);
+    if (TID == 0) s.time += m.timestep;
+    BSYNC();
   }
   if ((flags & 2) && TID < 16) SC(DBG)[8 + 5 * nv + TID] = s.prof[TID];   // stage cycle counters: frames+com, tendon+crb, velocity, collision, rows, smooth, Newton, Euler
   // ---- the state-less forward() calls of the reference: only their PID side effect touches the state
   const int nticks = L.bt.nticks ? L.bt.nticks[e] : L.nforward_ticks;
+  const bool full_forward = (flags & 32) && nticks > 0;   // bit 5: the last state-less forward runs in full (mj_forward) and the sensors are read from it
   if (nticks > 0) {
     rb_kinematics(m, s, S); rb_com_pos(m, s, S); rb_tendon(m, s, S);
-    for (int k = 0; k < nticks; k++) rb_pid(m, s, S, false);
+    for (int k = 0; k < nticks - (full_forward ? 1 : 0); k++) rb_pid(m, s, S, false);
   }
+  if (full_forward) {
+    rb_crb(m, s, S); rb_velocity(m, s, S);
+    rb_equality(m, s, S, eqd, eqa);
+    rb_collision(m, s, S, flags);
+    rb_make_constraint(m, s, S, eqd);
+    rb_dof_contact_lists(m, s, S);
+    rb_pid(m, s, S, true);
+    for (int grp = 0; grp < m.ngroup; grp++) {
+      if (m.b_star_grp[4 * grp + 3] && !(flags & 4)) { rb_star_group_solve(m, s, SC(MSP), grp, (const float*)0, 0.f, s.qfrc_smooth, s.qacc_smooth, 1.f); continue; }
+      rb_M_block(m, s, SC(MSP), grp, (const float*)0, 0.f);
+      rb_scale_block(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]);
+      if (!rb_chol(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]) && TID == 0) s.status |= RG_STATUS_BAD_FACTOR;
+      rb_group_solve(m, s, grp, s.qfrc_smooth, s.qacc_smooth, 1.f);
+    }
+    rb_solve(m, s, S, flags);
+    if (m.nsensor > 0 && L.bt.sensordata) rb_sensors(m, s, S, L.bt.sensordata + (size_t)e * m.nsensordata);
+    if (TID == 0) { SC(DBG)[3] = (float)s.ncon; SC(DBG)[4] = (float)s.nefc; SC(DBG)[5] = (float)s.neqcon; }   // what the env kernel's contact scans read
+  }
+  if (L.tcp.enabled) {
+    // JointControlledArm.set_position_control: main ctrl[:6] <- the solver's joint angles; MujocoRobotiqGripper: a relative target around its current ctrl
+    if (TID < 6) L.tcp.main_ctrl[(size_t)e * L.tcp.main_nu + TID] = s.qpos[L.tcp.arm_q[TID]];
+    if (TID == 6) {
+      float* gc = L.tcp.main_ctrl + (size_t)e * L.tcp.main_nu + L.tcp.main_grip_act;
+      *gc = clampf(*gc + clampf(L.tcp.action[(size_t)e * 6 + 5], -1.f, 1.f) * 0.5f * (L.tcp.grip_hi - L.tcp.grip_lo), L.tcp.grip_lo, L.tcp.grip_hi);
+    }
+  }
+  if (TID < 7 * m.nmocap && TID < 14) L.bt.mocap[(size_t)e * 7 * m.nmocap + TID] = s.mocap[TID];
   BFOR(i, nq) L.bt.qpos[(size_t)e * nq + i] = s.qpos[i];
   BFOR(i, nv) { L.bt.qvel[(size_t)e * nv + i] = s.qvel[i]; L.bt.qacc_warmstart[(size_t)e * nv + i] = s.warm[i]; }
   BFOR(i, 3 * nu) L.bt.pid[(size_t)e * 3 * nu + i] = s.pid[i];

@@ -14,6 +14,7 @@
 #define RB_MLONG 8        // descendant lists of M longer than this are summed by a wave (big_tables.py MLONG)
 #define RB_MAXNV 192      // LDS vectors
 #define RB_MAXNQ 192
+#define RB_NW 22         // weight words of a contact in the Hessian assembly: 21 (lower triangle of a 6 x 6) + the mode
 
 // arrays of the model blob that are uploaded as they are (field name = blob name)
 #define RB_INT_ARRAYS(X) \
@@ -24,6 +25,7 @@
   X(mesh_vertadr) X(mesh_vertnum) \
   X(tendon_adr) X(tendon_num) X(wrap_type) X(wrap_objid) \
   X(actuator_trntype) X(actuator_trnid) X(actuator_forcelimited) X(actuator_biastype) \
+  X(body_mocapid) X(eq_type) X(eq_obj1id) X(eq_obj2id) X(sensor_type) X(sensor_objid) X(sensor_adr) \
   X(b_lvl_body) X(b_lvl_adr) X(b_body_lastdof) X(b_subtree_adr) X(b_subtree) X(b_root_list) X(b_M_i) X(b_M_j) X(b_M_adr) \
   X(b_group_adr) X(b_group_dofs) X(b_dof_group) X(b_dof_local) X(b_pair_geom) X(b_ten_dofs) X(b_fric_dof) X(b_fric_ten) X(b_lim_jnt) X(b_lim_ten) X(b_cell_adr) X(b_Mdesc_adr) X(b_Mdesc_ent) X(b_Mdesc_dof) X(b_dof_fricrow) X(b_star_grp) X(b_tree_adr) X(b_tree_desc) X(b_tree_branch) X(b_tree_brn_end) X(b_Mlong)
 #define RB_FLT_ARRAYS(X) \
@@ -34,7 +36,8 @@
   X(geom_size) X(geom_rbound) X(geom_pos) X(geom_quat) X(site_pos) \
   X(wrap_prm) X(tendon_range) X(tendon_margin) X(tendon_stiffness) X(tendon_damping) X(tendon_frictionloss) X(tendon_lengthspring) \
   X(tendon_solref_lim) X(tendon_solimp_lim) X(tendon_solref_fri) X(tendon_solimp_fri) X(tendon_invweight0) \
-  X(actuator_gear) X(actuator_ctrlrange) X(actuator_forcerange) X(actuator_gainprm) \
+  X(actuator_gear) X(actuator_ctrlrange) X(actuator_forcerange) X(actuator_gainprm) X(actuator_user) \
+  X(eq_solref) X(eq_solimp) X(site_quat) \
   X(b_pair_prm) X(b_mesh_rec) X(b_cell_blk) X(b_cell_ovf)
 
 // per-env scratch row: offsets (in 4-byte words) of the stage arrays
@@ -43,10 +46,18 @@ enum {
   RB_O_CINERT, RB_O_CRB, RB_O_CDOF, RB_O_CDOFDOT, RB_O_CVEL, RB_O_CACC, RB_O_CFRC,
   RB_O_TENLEN, RB_O_TENJ, RB_O_TENVEL, RB_O_MSP,
   RB_O_CAND, RB_O_CON, RB_O_CONJ, RB_O_CONIDX, RB_O_ROW, RB_O_DOFCON_ADR, RB_O_DOFCON, RB_O_CONF,
-  RB_O_DBG, RB_NOFF
+  RB_O_DBG, RB_O_CFRCEXT, RB_NOFF
 };
-// per contact record (floats): dist, pos3, frame9, includemargin, friction5, solref2, solimp5, dim, geom1, geom2, efc_address, nnz, R
+// per contact record (floats): dist, pos3, frame9, includemargin, friction5, solref2, solimp5, dim, geom1, geom2, efc_address, nnz, kind
+// kind: 0 pyramidal contact, 1 elliptic contact (ur16e/base.xml:3), 2 equality constraint (weld: dim 6, joint coupling: dim 1) — an
+// equality is a "contact" whose rows are its basis Jacobian rows themselves: it shares the Jacobian / J'f / Hessian machinery.
+// Equality records hold their residuals in frame[0..5], their diagApprox in friction[0..1] (translational, rotational) and the
+// equality's index in geom1.
 #define RB_CONREC 32
+#define RB_CR_KIND 31
+#define RB_KIND_PYRAMID 0
+#define RB_KIND_ELLIPTIC 1
+#define RB_KIND_EQUALITY 2
 #define RB_CR_DIST 0
 #define RB_CR_POS 1
 #define RB_CR_FRAME 4
@@ -59,8 +70,13 @@ enum {
 #define RB_CR_G2 28
 #define RB_CR_ADR 29
 #define RB_CR_NNZ 30
-// per constraint row (floats): D, aref, jar, jv, floss, type (0 friction dof, 1 friction tendon, 2 joint limit, 3 tendon limit, 4 pyramid edge), id, aux (side | pyramid edge k, sign)
-#define RB_ROWREC 8
+// per constraint row (floats): D, aref, jar, jv, floss, type (0 friction dof, 1 friction tendon, 2 joint limit, 3 tendon limit, 4 pyramid edge,
+// 5 basis row of an elliptic contact or of an equality), id, aux (side | pyramid edge k, sign | basis row k), then for type 5 the
+// state the per-contact cone pass leaves: force, zone (0 none, 1 quadratic, 2 cone), cost (whole contact's on its first row)
+#define RB_ROWREC 12
+#define RB_RR_FORCE 8
+#define RB_RR_ZONE 9
+#define RB_RR_COST 10
 #define RB_RR_D 0
 #define RB_RR_AREF 1
 #define RB_RR_JAR 2
@@ -76,6 +92,7 @@ struct RbModelDev {
   int nfric_dof, nfric_ten, nlim_jnt, nlim_ten;
   int maxcon, maxrow, maxcand;       // capacities of the scratch row (nconmax, njmax of the model)
   int iterations, mpr_iterations, ls_iterations;
+  int cone, neq, nmocap, nsensor, nsensordata;   // rearrange models: elliptic cones, equality constraints, mocap bodies, sensors
   float timestep, gravity[3], tolerance, impratio, mpr_tolerance, meaninertia;
   int off[RB_NOFF];
   int scratch_words;                 // row length
@@ -96,6 +113,8 @@ struct RbEnvDev {
 struct RbBatchDev {
   int B;
   float *qpos, *qvel, *ctrl, *pid, *qacc_warmstart, *time;
+  float *mocap, *eq_data, *sensordata;   // [B][7 nmocap] (pos3 quat4 per mocap body), [B][7 neq], [B][nsensordata]
+  int* eq_active;                        // [B][neq]
   uint32_t* status;
   float* stats;          // [B][4] accumulated ncon, nefc, Newton iterations, substeps
   float* scratch;        // [B][scratch_words]
@@ -105,4 +124,17 @@ struct RbBatchDev {
   const int* nticks;     // [B] or null: per-env count of state-less forwards (PID ticks) after the substeps
 };
 
-struct RbLaunch { RbEnvDev env; RbBatchDev bt; int nsubsteps, nforward_ticks, flags; };
+// The TCP solver hook (rearrange, tcp+roll+yaw through the mocap_ik dual simulation): what JointControlledTcpArm.set_position_control
+// (/root/reference/robogym/robot/ur16e/mujoco/joint_controlled_tcp_arm.py:89-97) does around the solver simulation's step, run INSIDE that
+// simulation's launch: arm joints <- main simulation (sync_to + forward), mocap target <- TCP pose + the denormalised action
+// (free_dof_tcp_arm.py:161-206, mocap_solver.py:33-57, gym's mocap_set_action), 40 x mj_step, then main ctrl <- the solver's joint angles and
+// the gripper's own position target (robot_interface.py:247-278 around the current ctrl).
+struct RbTcpHook {
+  int enabled, sync;                 // sync = arm_reset_controller_error
+  const float* action;               // [B][6] normalised: xyz, roll, pitch(wrist), gripper
+  const float* main_qpos;            // [B][main_nq]
+  float* main_ctrl;                  // [B][main_nu]
+  int main_nq, main_nu, main_arm_q[6], arm_q[6], main_grip_act, tcp_body, wrist_jnt;
+  float max_position_change, speed[2], drift_threshold, grip_lo, grip_hi;
+};
+struct RbLaunch { RbEnvDev env; RbBatchDev bt; int nsubsteps, nforward_ticks, flags; RbTcpHook tcp; };

@@ -843,7 +843,8 @@ struct rb_model {
   RbModelDev dev;
   const RbModelDev* dev_copy = nullptr;
   std::vector<void*> allocs;
-  std::vector<float> qpos0;
+  std::vector<float> qpos0, mocap0, eq_data0;
+  std::vector<int> eq_active0;
 };
 struct rb_batch {
   const rb_model* model;
@@ -903,7 +904,13 @@ rb_model* rb_model_create(const void* blob, size_t nbytes, char* err, int errlen
   for (int v : iv) if (v != 2) return bail("rb_model_create: only mujoco-py PID actuators (biastype user) are implemented", m);
   if (!get_i(B, "opt_int", iv, e)) return bail(e, m);
   d.iterations = iv[0]; d.ls_iterations = iv[2]; d.mpr_iterations = iv[3];
-  if (iv[1] != 0) return bail("rb_model_create: elliptic cones are not implemented", m);
+  d.cone = iv[1];   // 0 pyramidal, 1 elliptic (ur16e/base.xml:3)
+  if (!get_i(B, "eq_type", iv, e)) return bail(e, m); d.neq = (int)iv.size();
+  if (!get_i(B, "nmocap", iv, e)) return bail(e, m); d.nmocap = iv[0];
+  if (d.nmocap > 2) return bail("rb_model_create: at most two mocap bodies", m);
+  if (!get_i(B, "sensor_type", iv, e)) return bail(e, m); d.nsensor = (int)iv.size();
+  { std::vector<int> sa, sd; if (!get_i(B, "sensor_adr", sa, e) || !get_i(B, "sensor_dim", sd, e)) return bail(e, m); d.nsensordata = d.nsensor ? sa.back() + sd.back() : 0; }
+  for (int k = 0; k < d.nsensor; k++) if (iv[k] != 0 && iv[k] != 4 && iv[k] != 5 && iv[k] != 8) return bail("rb_model_create: sensor type not implemented", m);
   if (!get_i(B, "size_int", iv, e)) return bail(e, m);
   d.maxrow = iv[0] > 0 ? iv[0] : 2000; d.maxcon = iv[1] > 0 ? iv[1] : 200;   // njmax / nconmax of the model
   d.maxcand = 4 * d.maxcon + 256;
@@ -914,6 +921,13 @@ rb_model* rb_model_create(const void* blob, size_t nbytes, char* err, int errlen
   if (!get_f(B, "opt_mpr_tolerance", fv, e)) return bail(e, m); d.mpr_tolerance = fv[0];
   if (!get_f(B, "stat_meaninertia", fv, e)) return bail(e, m); d.meaninertia = fv[0];
   if (!get_f(B, "qpos0", m->qpos0, e)) return bail(e, m);
+  if (!get_f(B, "eq_data", m->eq_data0, e) || !get_i(B, "eq_active", m->eq_active0, e)) return bail(e, m);
+  {
+    std::vector<int> mid; std::vector<float> bp, bq;
+    if (!get_i(B, "body_mocapid", mid, e) || !get_f(B, "body_pos", bp, e) || !get_f(B, "body_quat", bq, e)) return bail(e, m);
+    m->mocap0.assign(7 * d.nmocap, 0.f);
+    for (int bb = 0; bb < d.nbody; bb++) if (mid[bb] >= 0 && mid[bb] < d.nmocap) { for (int k = 0; k < 3; k++) m->mocap0[7 * mid[bb] + k] = bp[3 * bb + k]; for (int k = 0; k < 4; k++) m->mocap0[7 * mid[bb] + 3 + k] = bq[4 * bb + k]; }
+  }
   // scratch row layout
   int o = 0;
   auto take = [&](int which, int words) { d.off[which] = o; o += (words + 3) & ~3; };
@@ -923,7 +937,7 @@ rb_model* rb_model_create(const void* blob, size_t nbytes, char* err, int errlen
   take(RB_O_CVEL, 6 * d.nbody); take(RB_O_CACC, 6 * d.nbody); take(RB_O_CFRC, 6 * d.nbody);
   take(RB_O_TENLEN, d.ntendon); take(RB_O_TENJ, RB_TENW * d.ntendon); take(RB_O_TENVEL, d.ntendon); take(RB_O_MSP, d.nM);
   take(RB_O_CAND, d.maxcand); take(RB_O_CON, RB_CONREC * d.maxcon); take(RB_O_CONJ, 6 * RB_CONW * d.maxcon); take(RB_O_CONIDX, RB_CONW * d.maxcon);
-  take(RB_O_ROW, RB_ROWREC * d.maxrow); take(RB_O_DOFCON_ADR, d.nv + 1); take(RB_O_DOFCON, RB_CONW * d.maxcon); take(RB_O_CONF, 12 * d.maxcon); take(RB_O_DBG, 8 + 5 * d.nv + 16);
+  take(RB_O_ROW, RB_ROWREC * d.maxrow); take(RB_O_DOFCON_ADR, d.nv + 1); take(RB_O_DOFCON, RB_CONW * d.maxcon); take(RB_O_CONF, RB_NW * d.maxcon); take(RB_O_DBG, 8 + 5 * d.nv + 16); take(RB_O_CFRCEXT, 6 * d.nbody);
   d.scratch_words = o;
   void* p = nullptr;
   if (hipMalloc(&p, sizeof(RbModelDev)) != hipSuccess) return bail("hipMalloc failed", m);
@@ -965,6 +979,12 @@ int rb_batch_reset(rb_batch* b) {
   HIPCHK(hipMemset(s.qvel, 0, (size_t)s.B * d.nv * 4)); HIPCHK(hipMemset(s.ctrl, 0, (size_t)s.B * d.nu * 4));
   HIPCHK(hipMemset(s.pid, 0, (size_t)s.B * 3 * d.nu * 4)); HIPCHK(hipMemset(s.qacc_warmstart, 0, (size_t)s.B * d.nv * 4));
   HIPCHK(hipMemset(s.time, 0, (size_t)s.B * 4)); HIPCHK(hipMemset(s.status, 0, (size_t)s.B * 4)); HIPCHK(hipMemset(s.stats, 0, (size_t)s.B * 16));
+  if (d.nmocap) {   // mj_resetData: mocap pose <- the mocap bodies' model pose
+    std::vector<float> mc((size_t)s.B * 7 * d.nmocap);
+    for (int e = 0; e < s.B; e++) memcpy(mc.data() + (size_t)e * 7 * d.nmocap, b->model->mocap0.data(), 7 * d.nmocap * 4);
+    HIPCHK(hipMemcpy(s.mocap, mc.data(), mc.size() * 4, hipMemcpyHostToDevice));
+  }
+  if (d.nsensordata) HIPCHK(hipMemset(s.sensordata, 0, (size_t)s.B * d.nsensordata * 4));
   return 0;
 }
 rb_batch* rb_batch_create(const rb_model* m, int B) {
@@ -980,6 +1000,14 @@ rb_batch* rb_batch_create(const rb_model* m, int B) {
   s.qacc_warmstart = (float*)rb_balloc(b, (size_t)B * d.nv * 4); s.time = (float*)rb_balloc(b, (size_t)B * 4);
   s.status = (uint32_t*)rb_balloc(b, (size_t)B * 4); s.stats = (float*)rb_balloc(b, (size_t)B * 16);
   s.scratch = (float*)rb_balloc(b, (size_t)B * d.scratch_words * 4);
+  s.mocap = (float*)rb_balloc(b, (size_t)B * 7 * d.nmocap * 4); s.eq_data = (float*)rb_balloc(b, (size_t)B * 7 * d.neq * 4);
+  s.eq_active = (int*)rb_balloc(b, (size_t)B * d.neq * 4); s.sensordata = (float*)rb_balloc(b, (size_t)B * d.nsensordata * 4);
+  if (!s.mocap || !s.eq_data || !s.eq_active || !s.sensordata) { fail("hipMalloc failed"); rb_batch_free(b); return nullptr; }
+  {  // equality data and flags are MODEL fields in MuJoCo: they start at the model's values and survive MjSim.reset (the envs write them)
+    std::vector<float> ed((size_t)B * 7 * d.neq); std::vector<int> ea((size_t)B * d.neq);
+    for (int e = 0; e < B; e++) { for (int k = 0; k < 7 * d.neq; k++) ed[(size_t)e * 7 * d.neq + k] = m->eq_data0[k]; for (int k = 0; k < d.neq; k++) ea[(size_t)e * d.neq + k] = m->eq_active0[k]; }
+    if (d.neq && (hipMemcpy(s.eq_data, ed.data(), ed.size() * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(s.eq_active, ea.data(), ea.size() * 4, hipMemcpyHostToDevice) != hipSuccess)) { fail("hipMemcpy failed"); rb_batch_free(b); return nullptr; }
+  }
   if (!s.qpos || !s.qvel || !s.ctrl || !s.pid || !s.qacc_warmstart || !s.time || !s.status || !s.stats || !s.scratch) { fail("hipMalloc failed"); rb_batch_free(b); return nullptr; }
   if (rb_batch_reset(b) != 0) { rb_batch_free(b); return nullptr; }
   return b;
@@ -1009,6 +1037,10 @@ void* rb_batch_field_ptr(rb_batch* b, int field, int* row_words) {
     case RG_F_STATUS: p = s.status; n = 1; break;
     case RG_F_STATS: p = s.stats; n = 4; break;
     case RG_F_DEBUG: p = s.scratch; n = d.scratch_words; break;   // the whole scratch row (stage arrays, rb_scratch_offset)
+    case RB_F_MOCAP: p = s.mocap; n = 7 * d.nmocap; break;
+    case RB_F_EQ_DATA: p = s.eq_data; n = 7 * d.neq; break;
+    case RB_F_EQ_ACTIVE: p = s.eq_active; n = d.neq; break;
+    case RB_F_SENSORDATA: p = s.sensordata; n = d.nsensordata; break;
     default: fail("rb_batch_field_ptr: unknown field"); return nullptr;
   }
   if (row_words) *row_words = n;
@@ -1019,6 +1051,27 @@ struct EmulRbArgs { const RbModelDev* m; RbLaunch launch; };
 static void emul_rb_entry(void* a) { EmulRbArgs* p = (EmulRbArgs*)a; rgb::rb_step_kernel(p->m, p->launch); }
 #endif
 int rb_batch_step_ex(rb_batch* b, const float* action_dev, const int* active_dev, const int* hold_dev, const int* nticks_dev, int nsubsteps, int nforward_ticks, int flags, void* stream);
+static thread_local const RbTcpHook* g_tcp_hook = nullptr;   // set by rb_batch_step_tcp around its launch
+// JointControlledTcpArm.set_position_control as ONE launch of the solver simulation (RbTcpHook, rb_types.h)
+int rb_batch_step_tcp(rb_batch* solver, rb_batch* main_batch, const float* action_dev, const rb_tcp_args* a, int nsubsteps, int flags, void* stream) {
+  if (!solver || !main_batch || !action_dev || !a) return fail("rb_batch_step_tcp: null argument");
+  if (solver->dev.B != main_batch->dev.B || solver->device != main_batch->device) return fail("rb_batch_step_tcp: the two batches must have the same size and device");
+  const RbModelDev& ds = solver->model->dev; const RbModelDev& dm = main_batch->model->dev;
+  if (ds.nmocap != 1) return fail("rb_batch_step_tcp: the solver model needs exactly one mocap body");
+  for (int k = 0; k < 6; k++) if (a->arm_qposadr[k] < 0 || a->arm_qposadr[k] >= ds.nq || a->main_arm_qposadr[k] < 0 || a->main_arm_qposadr[k] >= dm.nq) return fail("rb_batch_step_tcp: joint address out of range");
+  if (a->main_gripper_actuator < 0 || a->main_gripper_actuator >= dm.nu || a->tcp_body <= 0 || a->tcp_body >= ds.nbody || a->wrist_joint < 0 || a->wrist_joint >= ds.njnt) return fail("rb_batch_step_tcp: id out of range");
+  RbTcpHook h; memset(&h, 0, sizeof h);
+  h.enabled = 1; h.sync = a->reset_controller_error; h.action = action_dev; h.main_qpos = main_batch->dev.qpos; h.main_ctrl = main_batch->dev.ctrl;
+  h.main_nq = dm.nq; h.main_nu = dm.nu;
+  for (int k = 0; k < 6; k++) { h.main_arm_q[k] = a->main_arm_qposadr[k]; h.arm_q[k] = a->arm_qposadr[k]; }
+  h.main_grip_act = a->main_gripper_actuator; h.tcp_body = a->tcp_body; h.wrist_jnt = a->wrist_joint;
+  h.max_position_change = a->max_position_change; h.speed[0] = a->speed_roll; h.speed[1] = a->speed_pitch; h.drift_threshold = a->joint_drift_threshold;
+  h.grip_lo = a->gripper_ctrl_lo; h.grip_hi = a->gripper_ctrl_hi;
+  g_tcp_hook = &h;
+  const int rc = rb_batch_step_ex(solver, nullptr, nullptr, nullptr, nullptr, nsubsteps, 0, flags, stream);
+  g_tcp_hook = nullptr;
+  return rc;
+}
 int rb_batch_step(rb_batch* b, const float* action_dev, const int* active_dev, int nsubsteps, int nforward_ticks, int flags, void* stream) {
   return rb_batch_step_ex(b, action_dev, active_dev, nullptr, nullptr, nsubsteps, nforward_ticks, flags, stream);
 }
@@ -1029,7 +1082,8 @@ int rb_batch_step_ex(rb_batch* b, const float* action_dev, const int* active_dev
   DeviceGuard g(b->device);
   RbBatchDev bt = b->dev;
   bt.action = action_dev; bt.active = active_dev; bt.hold = hold_dev; bt.nticks = nticks_dev;
-  RbLaunch launch{b->env, bt, nsubsteps, nforward_ticks, flags};
+  RbLaunch launch{b->env, bt, nsubsteps, nforward_ticks, flags, RbTcpHook{}};
+  if (g_tcp_hook) { launch.tcp = *g_tcp_hook; }
 #ifdef RG_EMUL
   EmulRbArgs args{b->model->dev_copy, launch};
   emul_launch_n(bt.B, RB_T, sizeof(rgb::RbLds), emul_rb_entry, &args);

@@ -1045,16 +1045,9 @@ __device__ __forceinline__ void rg_mpr_geoms(RgM m, const RgLds& s, int p, float
 // without its serial polygon lists.  Launch flag bit 4 (round-1 contact variant) sends these pairs through MPR instead.
 __device__ __forceinline__ v3 pick3(v3 a0, v3 a1, v3 a2, int k) { return k == 0 ? a0 : (k == 1 ? a1 : a2); }
 __device__ __forceinline__ float pick3(float a0, float a1, float a2, int k) { return k == 0 ? a0 : (k == 1 ? a1 : a2); }
-__device__ __forceinline__ bool rg_box_box_lane(RgM m, const RgLds& s, int p, float gscale, int l, float& dist, v3& pos, v3& n, int& dim) {
-  const rgf4* Rc = (const rgf4*)m.pair_rec + (RG_PAIRREC / 4) * p;
-  rgf4 r0 = Rc[0], r1 = Rc[1], r2 = Rc[2];
-  const int hdr = __builtin_bit_cast(int, r0.x), g1 = hdr & 255, g2 = (hdr >> 8) & 255;
-  dim = (hdr >> 16) & 15;
-  const float margin = r0.y;
-  const float sc1 = (hdr & RG_PAIR_SCALED1) ? gscale : 1.f, sc2 = (hdr & RG_PAIR_SCALED2) ? gscale : 1.f;
-  const float A[3] = {r1.x * sc1, r1.y * sc1, r1.z * sc1}, B[3] = {r2.x * sc2, r2.y * sc2, r2.z * sc2};
-  float R1[9], R2[9]; q2mat(R1, ldq(s.gquat + 4 * g1)); q2mat(R2, ldq(s.gquat + 4 * g2));
-  const v3 P1 = ld3(s.gpos + 3 * g1), t = ld3(s.gpos + 3 * g2) - P1;   // pair-local coordinates: origin at box 1's centre
+// lane l of the group's work on one pair of boxes: half sizes A, B, orientations q1, q2, centre P1 of box 1 and t = centre of box 2 - P1
+__device__ __forceinline__ bool box_box_lane(const float* A, const float* B, q4 q1, q4 q2, v3 P1, v3 t, float margin, int l, float& dist, v3& pos, v3& n) {
+  float R1[9], R2[9]; q2mat(R1, q1); q2mat(R2, q2);
   v3 ax1[3], ax2[3];
 #pragma unroll
   for (int k = 0; k < 3; k++) { ax1[k] = mk3(R1[k], R1[3 + k], R1[6 + k]); ax2[k] = mk3(R2[k], R2[3 + k], R2[6 + k]); }
@@ -1159,6 +1152,17 @@ __device__ __forceinline__ bool rg_box_box_lane(RgM m, const RgLds& s, int p, fl
   if (dist > margin) return false;
   pos = base + nr * (la + 0.5f * dist) + P1;
   return true;
+}
+__device__ __forceinline__ bool rg_box_box_lane(RgM m, const RgLds& s, int p, float gscale, int l, float& dist, v3& pos, v3& n, int& dim) {
+  const rgf4* Rc = (const rgf4*)m.pair_rec + (RG_PAIRREC / 4) * p;
+  rgf4 r0 = Rc[0], r1 = Rc[1], r2 = Rc[2];
+  const int hdr = __builtin_bit_cast(int, r0.x), g1 = hdr & 255, g2 = (hdr >> 8) & 255;
+  dim = (hdr >> 16) & 15;
+  const float margin = r0.y;
+  const float sc1 = (hdr & RG_PAIR_SCALED1) ? gscale : 1.f, sc2 = (hdr & RG_PAIR_SCALED2) ? gscale : 1.f;
+  const float A[3] = {r1.x * sc1, r1.y * sc1, r1.z * sc1}, B[3] = {r2.x * sc2, r2.y * sc2, r2.z * sc2};
+  const v3 P1 = ld3(s.gpos + 3 * g1), t = ld3(s.gpos + 3 * g2) - P1;   // pair-local coordinates: origin at box 1's centre
+  return box_box_lane(A, B, ldq(s.gquat + 4 * g1), ldq(s.gquat + 4 * g2), P1, t, margin, l, dist, pos, n);
 }
 RG_STAGE void rg_narrow_boxbox(RgCtx c, int ncand) {
   RgM m = RG_M(c); RgLRef L = RG_L(c); RgLds& s = RG_S();

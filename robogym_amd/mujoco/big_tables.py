@@ -119,6 +119,20 @@ def derive_big_tables(model):
         ten_dofs[t, :len(dofs)] = sorted(dofs)
         union(bodies)
     A["b_ten_dofs"] = ten_dofs
+    # equality constraints couple trees too (weld: the two bodies; joint coupling: the two joints' bodies)
+    eq_dofs = set()
+    for e in range(len(A.get("eq_type", []))):
+        o1, o2 = int(A["eq_obj1id"][e]), int(A["eq_obj2id"][e])
+        if int(A["eq_type"][e]) == C.EQ_WELD:
+            bodies = [o1, o2]
+        else:
+            bodies = [int(A["jnt_bodyid"][o1])] + ([int(A["jnt_bodyid"][o2])] if o2 >= 0 else [])
+        union(bodies)
+        for x in bodies:
+            eq_dofs |= set(chains[x])
+        w_eq = len(set().union(*[set(chains[x]) for x in bodies]))
+        if w_eq > CON_W:
+            raise NotImplementedError("an equality constraint depends on %d dofs > %d" % (w_eq, CON_W))
     groups = {}
     for r in trees:
         groups.setdefault(find(r), []).append(r)
@@ -209,6 +223,7 @@ def derive_big_tables(model):
     for a, b, _ in pairs:
         touched |= set(chains[A["geom_bodyid"][a]]) | set(chains[A["geom_bodyid"][b]])
     touched |= set(int(d) for d in ten_dofs.reshape(-1) if d >= 0)
+    touched |= eq_dofs
     kids = [[] for _ in range(nv)]
     for i in range(nv):
         if dpar[i] >= 0:

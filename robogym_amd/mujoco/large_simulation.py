@@ -15,12 +15,14 @@ from robogym_amd.mujoco.model_blob import pack_model
 from robogym_amd.mujoco import simulation_interface
 
 SCRATCH = ["xpos", "xquat", "xipos", "xiquat", "xanchor", "xaxis", "geom_xpos", "geom_xquat", "site_xpos", "rootcom", "cinert", "crb", "cdof", "cdof_dot", "cvel",
-           "cacc", "cfrc", "ten_length", "ten_J", "ten_velocity", "Msp", "cand", "contact", "contact_J", "contact_idx", "row", "dofcon_adr", "dofcon", "contact_f", "dbg"]
+           "cacc", "cfrc", "ten_length", "ten_J", "ten_velocity", "Msp", "cand", "contact", "contact_J", "contact_idx", "row", "dofcon_adr", "dofcon", "contact_f", "dbg", "cfrc_ext"]
 INFO = ["nq", "nv", "nu", "nbody", "njnt", "ngeom", "nsite", "ntendon", "nM", "npair", "ngroup", "gmax", "maxcon", "maxrow", "scratch_words", "conrec", "rowrec", "conw", "tenw", "lds_bytes"]
 
 
 class LargeModelSimulation:
-    def __init__(self, model, batch_size: int, device="cuda:0", n_substeps: int = 10, relative_action: bool = True, lib=None):
+    def __init__(self, model, batch_size: int, device="cuda:0", n_substeps: int = 10, relative_action: bool = True, lib=None, hand: bool = True):
+        """`hand`: the model is a Shadow-hand world (joint group `robot0:` = the hand, in-kernel action map through the position -> control matrix);
+        False for the rearrange worlds, whose action path is the TCP solver hook (`step_tcp`)."""
         self._emul = lib is not None
         self._L = L = lib if lib is not None else _native.lib()
         self.device = torch.device("cpu") if self._emul else torch.device(device)
@@ -48,6 +50,10 @@ class LargeModelSimulation:
         A = model.arrays
         self.qpos_idxs: Dict[str, np.ndarray] = {}
         self.qvel_idxs: Dict[str, np.ndarray] = {}
+        self._views = {}
+        self._keep = []
+        if not hand:
+            return
         self.register_joint_group("hand_angle", "robot0:")
         hand_j = [j for j, nm in enumerate(names) if nm.startswith("robot0:")]
         P = np.zeros((self.nu, len(hand_j)), dtype=np.float32)
@@ -88,7 +94,7 @@ class LargeModelSimulation:
             p = self._L.rb_batch_field_ptr(self._bh, field, ctypes.byref(n))
             if not p:
                 raise _native.NativeError(self._L.rg_last_error().decode())
-            dt = torch.int32 if field == _native.RG_F_STATUS else torch.float32
+            dt = torch.int32 if field in (_native.RG_F_STATUS, _native.RB_F_EQ_ACTIVE) else torch.float32
             self._views[field] = simulation_interface.device_tensor(p, (self.batch_size, n.value), dt, self.device)
         return self._views[field]
 
@@ -99,6 +105,11 @@ class LargeModelSimulation:
     qacc_warmstart = property(lambda self: self.view(_native.RG_F_WARMSTART))
     status = property(lambda self: self.view(_native.RG_F_STATUS)[:, 0])
     stats = property(lambda self: self.view(_native.RG_F_STATS))
+    time = property(lambda self: self.view(_native.RG_F_TIME)[:, 0])
+    mocap = property(lambda self: self.view(_native.RB_F_MOCAP))            # [B, 7 nmocap]: mocap_pos | mocap_quat per mocap body
+    eq_data = property(lambda self: self.view(_native.RB_F_EQ_DATA))        # [B, 7 neq]
+    eq_active = property(lambda self: self.view(_native.RB_F_EQ_ACTIVE))    # [B, neq] int32
+    sensordata = property(lambda self: self.view(_native.RB_F_SENSORDATA))  # [B, nsensordata], of the last full forward (flags bit 5)
 
     def scratch(self, name: str) -> torch.Tensor:
         """A stage array of the last launch, `[B, words]` (debugging / stage parity tests)."""
@@ -124,6 +135,14 @@ class LargeModelSimulation:
         ptr = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
         _native.check(self._L, self._L.rb_batch_step_ex(self._bh, ptr(action), ptr(active), ptr(hold), ptr(nticks), self.n_substeps if nsubsteps is None else int(nsubsteps),
                                                         int(nforward_ticks), flags, stream), "rb_batch_step_ex")
+
+    def step_tcp(self, main: "LargeModelSimulation", action: torch.Tensor, args: "_native.RbTcpArgs", flags=0):
+        """`JointControlledTcpArm.set_position_control` as one launch of THIS (the TCP solver's) simulation: rb_batch_step_tcp (include/rgstep.h)."""
+        assert action.dtype == torch.float32 and action.is_contiguous() and action.device == self.device and action.shape == (self.batch_size, 6)
+        flags = int(flags) | (_native.RG_FLAG_MPR_PLANE_DEPTH if simulation_interface.MPR_PLANE_DEPTH else 0)
+        stream = None if self._emul else ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        self._keep = [action, args]
+        _native.check(self._L, self._L.rb_batch_step_tcp(self._bh, main._bh, ctypes.c_void_p(action.data_ptr()), ctypes.byref(args), self.n_substeps, flags, stream), "rb_batch_step_tcp")
 
     def step(self, active=None):
         """SimulationInterface.step: nsubsteps x mj_step, then mj_forward (its PID tick)."""
