@@ -1,0 +1,176 @@
+"""The rearrange worlds on the large-model stepper (`rb_step_kernel`) against the CPU oracle: BASELINE.json configs[3] (rearrange/blocks,
+num_objects = 5: UR16e + 2f-85 gripper + table, elliptic cones, equality rows, cascaded-PI actuators, F/T sensors) and the TCP solver's own
+world (mocap weld), through the C ABI (`rb_batch_step_ex`, `rb_batch_step_tcp`).  The same checks run on the CPU against the kernel SOURCE
+(fiber-emulation harness) and, under `-m gpu`, on the MI355X.
+
+Protocol (as for the dactyl models): re-synchronised errors — before every compared step both sides start from the oracle's
+state rounded to fp32 — because contact-rich trajectories diverge chaotically in any precision."""
+import numpy as np
+import pytest
+import torch
+
+from robogym_amd import _native
+from robogym_amd.envs.rearrange.xml import load_blocks_model, load_solver_model
+from robogym_amd.mujoco.large_simulation import LargeModelSimulation
+
+NV = 38
+
+
+@pytest.fixture(scope="module")
+def models():
+    return load_blocks_model(5), load_solver_model()
+
+
+def _oracle_env(models, n_substeps, settle=3, seed=0):
+    from oracle import rearrange_oracle as RO
+
+    main, solver = models
+    env = RO.OracleRearrangeEnv(main, solver, 5, n_substeps=n_substeps)
+    rng = np.random.RandomState(seed)
+    ztop = 0.453 + 0.03324 + 0.0254
+    pos = [[1.2 + 0.11 * i + 0.01 * rng.rand(), 0.55 + 0.1 * i, ztop] for i in range(5)]
+    yaw = rng.uniform(0, 2 * np.pi, 5)
+    env.set_object_poses(pos, [[np.cos(a / 2), 0, 0, np.sin(a / 2)] for a in yaw])
+    env.main.sim.forward()
+    for _ in range(settle):
+        env.main.step()
+    return env
+
+
+def sync_from_oracle(sim, o, row=0):
+    """kernel rows <- oracle state rounded to fp32; oracle <- the same rounded values"""
+    for name, f in (("qpos", sim.qpos), ("qvel", sim.qvel), ("ctrl", sim.ctrl), ("pid", sim.pid), ("qacc_warmstart", sim.qacc_warmstart)):
+        v = getattr(o, name).astype(np.float32)
+        f[row] = torch.tensor(v, device=sim.device)
+        getattr(o, name)[:] = v.astype(np.float64)
+    sim.view(_native.RG_F_TIME)[row, 0] = float(o.time)
+    if o.nmocap:
+        mc = np.concatenate([o.mocap_pos, o.mocap_quat]).astype(np.float32)
+        sim.mocap[row] = torch.tensor(mc, device=sim.device)
+        o.mocap_pos[:] = mc[:3]; o.mocap_quat[:] = mc[3:]
+    if o.neq:
+        ed = o.eq_data.astype(np.float32)
+        sim.eq_data[row] = torch.tensor(ed, device=sim.device)
+        o.eq_data[:] = ed
+        sim.eq_active[row] = torch.tensor(o.eq_active().astype(np.int32), device=sim.device)
+
+
+def tcp_args(env, mpc=0.1, rce=True):
+    from oracle import rearrange_oracle as RO
+
+    Am, solver = env.main.model.arrays, env.solver.model
+    a = _native.RbTcpArgs()
+    for k in range(6):
+        a.arm_qposadr[k] = int(env.solver.arm_q[k]); a.main_arm_qposadr[k] = int(env.main.arm_q[k])
+    a.main_gripper_actuator = env.main.grip_act; a.tcp_body = env.solver.tcp_body; a.wrist_joint = solver.names["joint"].index("robot0:J6")
+    a.reset_controller_error = 1 if rce else 0
+    a.max_position_change = mpc; a.speed_roll = float(RO.SPEED_ROLL); a.speed_pitch = float(RO.SPEED_PITCH); a.joint_drift_threshold = float(RO.JOINT_DRIFT_THRESHOLD)
+    a.gripper_ctrl_lo = float(Am["actuator_ctrlrange"][6, 0]); a.gripper_ctrl_hi = float(Am["actuator_ctrlrange"][6, 1])
+    return a
+
+
+def _stage_dump(models, lib, device):
+    """One mj_step of the main world with ~25 contacts: contact list, row count, generalized forces, qacc_smooth, qacc, the new state."""
+    env = _oracle_env(models, 1, settle=40)
+    o = env.main.sim
+    sim = LargeModelSimulation(models[0], 1, device=device, n_substeps=1, lib=lib, hand=False)
+    sync_from_oracle(sim, o)
+    sim.env_step(nsubsteps=1, nforward_ticks=0, flags=1)
+    sim.sync()
+    o.step()
+    dbg = sim.scratch("dbg")[0].cpu().numpy()
+    assert int(sim.status[0]) == 0
+    ncon_k, nefc_k = int(dbg[0]), int(dbg[1])
+    assert ncon_k == o.ncon + o.neq and nefc_k == o.nefc and o.ncon >= 20          # (the kernel's list carries the equality as its first record)
+    # contacts: same geom pairs, distances, positions, normals (order may differ: pair list vs body loop)
+    con = sim.scratch("contact")[0].cpu().numpy().reshape(-1, 32)[:ncon_k]
+    assert int(con[0, 31]) == 2 and int(con[0, 26]) == 1                              # the finger coupling (joint equality, one row)
+    kc = sorted([(int(c[27]), int(c[28]), float(c[0]), c[1:4].copy(), c[4:7].copy()) for c in con[1:]], key=lambda t: (t[0], t[1], round(t[3][0], 4), round(t[3][1], 4)))
+    oc = sorted([(c["geom1"], c["geom2"], c["dist"], c["pos"], c["frame"][0]) for c in o.contacts()], key=lambda t: (t[0], t[1], round(t[3][0], 4), round(t[3][1], 4)))
+    for a, b in zip(kc, oc):
+        assert a[0] == b[0] and a[1] == b[1]
+        assert abs(a[2] - b[2]) < 2e-6 and np.abs(a[3] - b[3]).max() < 5e-6 and np.abs(a[4] - b[4]).max() < 2e-4
+    assert np.abs(dbg[8:8 + NV] - o.qfrc_bias).max() < 1e-4 * max(1.0, np.abs(o.qfrc_bias).max())
+    assert np.abs(dbg[8 + 2 * NV:8 + 3 * NV] - o.qfrc_actuator).max() < 1e-4 * max(1.0, np.abs(o.qfrc_actuator).max())
+    assert np.abs(dbg[8 + 3 * NV:8 + 4 * NV] - o.qacc_smooth).max() < 1e-4 * np.abs(o.qacc_smooth).max()
+    assert np.abs(dbg[8 + 4 * NV:8 + 5 * NV] - o.qacc).max() < 2e-3 * np.abs(o.qacc).max()
+    assert np.abs(sim.qpos[0].cpu().numpy() - o.qpos).max() < 2e-6 and np.abs(sim.qvel[0].cpu().numpy() - o.qvel).max() < 2e-5
+    assert np.abs(sim.pid[0].cpu().numpy() - o.pid).max() < 1e-5
+
+
+def _resync_env_steps(models, lib, device, n_substeps, nsteps, seed=1):
+    """Re-synchronised env.steps of the dual simulation: `rb_batch_step_tcp` (sync, forward, mocap target, solver mj_steps, main ctrl) then the
+    main world's mj_steps + two state-less forwards, the last in full (sensors) — against OracleRearrangeEnv.env_step."""
+    env = _oracle_env(models, n_substeps, settle=10, seed=seed)
+    om, oc = env.main.sim, env.solver.sim
+    sm = LargeModelSimulation(models[0], 1, device=device, n_substeps=n_substeps, lib=lib, hand=False)
+    sc = LargeModelSimulation(models[1], 1, device=device, n_substeps=n_substeps, lib=lib, hand=False)
+    args = tcp_args(env)
+    rng = np.random.RandomState(seed)
+    errs = []
+    for step in range(nsteps):
+        a = rng.uniform(-1, 1, 6)
+        if step % 3 == 2:
+            a[2] = -1.0          # push down towards the blocks / table from time to time
+        sync_from_oracle(sm, om); sync_from_oracle(sc, oc)
+        sc.step_tcp(sm, torch.tensor(a[None].astype(np.float32), device=sm.device), args)
+        sm.env_step(nforward_ticks=2, flags=32)
+        sm.sync()
+        env.env_step(a)
+        e = lambda x, y: float(np.abs(x.cpu().numpy().astype(np.float64) - y).max())
+        errs.append((e(sc.qpos[0], oc.qpos), e(sc.mocap[0], np.concatenate([oc.mocap_pos, oc.mocap_quat])), e(sm.ctrl[0], om.ctrl), e(sm.qpos[0], om.qpos),
+                     e(sm.qvel[0], om.qvel), e(sm.pid[0], om.pid), e(sm.sensordata[0], om.sensordata) / max(1.0, np.abs(om.sensordata).max())))
+        assert int(sm.status[0]) == 0 and int(sc.status[0]) == 0
+    return np.array(errs)
+
+
+def _assert_resync(errs):
+    names = ["solver qpos", "mocap", "main ctrl", "main qpos", "main qvel", "main pid", "sensordata (rel)"]
+    med = dict(zip(names, np.median(errs, axis=0))); mx = dict(zip(names, errs.max(axis=0)))
+    # (main ctrl = the solver's six arm angles: tight.  The solver's whole qpos includes its gripper slides, which sit ON their upper limit
+    #  (q = 0, range [-0.04473, 0]): whether the limit row is active is a rounding-level decision, worth ~1e-5 m on a joint with armature 100)
+    assert mx["solver qpos"] < 1e-4 and mx["mocap"] < 2e-6 and mx["main ctrl"] < 5e-6, (med, mx)
+    assert med["main qpos"] < 2e-6 and mx["main qpos"] < 2e-4, (med, mx)          # (box-box contacts of the blocks on the table: flat contacts, as dactyl's cube on the palm)
+    assert med["main qvel"] < 1e-4 and mx["main qvel"] < 2e-2, (med, mx)
+    assert mx["main pid"] < 1e-4 and med["sensordata (rel)"] < 1e-3, (med, mx)
+
+
+# ------------------------------------------------------------------------------------------------ CPU: the kernel source on the emulation harness
+def test_rearrange_stage_dump_matches_oracle_emul(models, emul_lib, oracle_lib):
+    _stage_dump(models, emul_lib, "cpu")
+
+
+def test_rearrange_resync_env_steps_emul(models, emul_lib, oracle_lib):
+    _assert_resync(_resync_env_steps(models, emul_lib, "cpu", n_substeps=3, nsteps=4))
+
+
+# ------------------------------------------------------------------------------------------------ MI355X
+@pytest.mark.gpu
+def test_rearrange_stage_dump_matches_oracle_gpu(models, oracle_lib):
+    _stage_dump(models, None, "cuda:0")
+
+
+@pytest.mark.gpu
+def test_rearrange_resync_env_steps_gpu(models, oracle_lib):
+    """the full 40 + 40 mj_steps per env.step"""
+    _assert_resync(_resync_env_steps(models, None, "cuda:0", n_substeps=40, nsteps=25))
+
+
+@pytest.mark.gpu
+def test_rearrange_batch_is_deterministic_and_rows_are_independent_gpu(models, oracle_lib):
+    """B = 512 identical rows give bit-identical results, run to run and row to row."""
+    env = _oracle_env(models, 40, settle=10)
+    sims = []
+    for rep in range(2):
+        sm = LargeModelSimulation(models[0], 512, n_substeps=40, hand=False)
+        for r in (0,):
+            sync_from_oracle(sm, env.main.sim, row=r)
+        for f in (sm.qpos, sm.qvel, sm.ctrl, sm.pid, sm.qacc_warmstart, sm.eq_data):
+            f[1:] = f[0:1]
+        sm.eq_active[1:] = sm.eq_active[0:1]
+        sm.env_step(nforward_ticks=2, flags=32)
+        sm.sync()
+        sims.append(sm)
+    a, b = sims
+    assert torch.equal(a.qpos, b.qpos) and torch.equal(a.qvel, b.qvel) and torch.equal(a.sensordata, b.sensordata)
+    assert torch.equal(a.qpos[1:], a.qpos[:1].expand(511, -1)) and int(a.status.max()) == 0
