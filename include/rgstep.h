@@ -304,7 +304,40 @@ typedef struct rb_tcp_args {
   int main_gripper_actuator, tcp_body, wrist_joint, reset_controller_error;
   float max_position_change, speed_roll, speed_pitch, joint_drift_threshold, gripper_ctrl_lo, gripper_ctrl_hi;
 } rb_tcp_args;
-int rb_batch_step_tcp(rb_batch* solver, rb_batch* main, const float* action_dev, const rb_tcp_args* args, int nsubsteps, int flags, void* stream);
+int rb_batch_step_tcp(rb_batch* solver, rb_batch* main, const float* action_dev, const int* active_dev /* [B] or NULL */, const rb_tcp_args* args, int nsubsteps, int flags, void* stream);
+/* ---- the env-level half of RearrangeEnv.step (one launch after the two physics launches; robogym_amd/csrc/ra_env_kernel.h lists the
+ * reference call sites): the 24-key observation of envs/rearrange/common/base.py:376-421 as one packed row per env — obj_pos 3N | obj_rel_pos 3N |
+ * obj_vel_pos 3N | obj_rot 3N | obj_vel_rot 3N | robot_joint_pos 6 | gripper_pos 3 | gripper_velp 3 | gripper_controls 1 | gripper_qpos 1 |
+ * gripper_vel 1 | qpos nq | qpos_goal nq | goal_obj_pos 3N | goal_obj_rot 3N | is_goal_achieved 1 | rel_goal_obj_pos 3N | rel_goal_obj_rot 3N |
+ * obj_gripper_contact 2N | obj_bbox_size 3N | obj_colors 4N | safety_stop 1 | tcp_force 3 | tcp_torque 3 (= 36 N + 23 + 2 nq scalars; 289 for blocks
+ * with 5 objects) followed by reward[3] and done — plus reward / done (common/base.py:768-795, 824-848), ObjectStateGoal's distances
+ * (goals/object_state.py:492-599), MultiGoalTracker.process and the gripper hand-over to the solver world (joint_controlled_tcp_arm.py:114-129).
+ * The main batch must have been stepped with flags bit 5 (the row is read from the final forward's stage arrays).  goal_reset[e] = 1 asks the
+ * host for a new goal (ObjectStateGoal.next_goal is placement sampling: host work). */
+#define RA_MAXOBJ 16
+typedef struct ra_post_args {
+  float* obs; int obs_dim;                       /* [B][obs_dim + 4] */
+  int num_objects;
+  int *t, *steps, *steps_since_last_goal, *successes_so_far, *consecutive;
+  float* prev_nsucc; int* prev_valid;            /* previous count of objects within both thresholds (x goal_reward_per_object) */
+  const float* goal;                             /* [B][N][7]: goal position, goal orientation as a quaternion (euler2quat of goal_obj_rot) */
+  const float* goal_rot;                         /* [B][N][3]: goal_obj_rot (Euler angles, as observed) */
+  const float* qpos_goal;                        /* [B][nq] */
+  const float* static_obs;                       /* [B][N][7]: obj_bbox_size 3, obj_colors 4 */
+  float* reward;                                 /* [B][3] env, goal, success */
+  float* goal_dist;                              /* [B][2] sums over the objects of obj_pos / obj_rot distances */
+  unsigned char *done, *goal_reset, *trial_success, *sub_goal_ok, *env_crash, *objects_off_table;
+  int* info_ssl;
+  int obj_body[RA_MAXOBJ], tcp_body, arm_qposadr[6], grip_qposadr, grip_dofadr, grip_act, finger_geom[2], table_plane_geom, force_adr, torque_adr;
+  unsigned long long gripper_geom_mask;          /* geoms of the gripper's bodies (ur16e/mujoco/simulation/base.py:40-52); needs ngeom <= 64 */
+  float table_min[2], table_max[2], table_height, pos_threshold, rot_threshold, goal_pos_offset, goal_rot_weight, goal_reward_per_object, success_reward,
+      penalty_table_collision, penalty_objects_off_table, penalty_safety_stop, safety_stop_force;
+  int max_timesteps_per_goal, successes_needed, use_goal_distance_reward;
+  float *solver_qpos, *solver_ctrl;              /* rows of the solver batch (filled by ra_env_post_step), NULL: no hand-over */
+  int solver_nq, solver_nu, solver_grip_qposadr, solver_grip_act;
+} ra_post_args;
+int ra_env_post_step(rb_batch* main, rb_batch* solver, const ra_post_args* args, void* stream);
+int ra_post_args_size(void);
 /* ---- the env-level half of RobotEnv.step for the full cube (dactyl/full_perpendicular), one launch after rb_batch_step:
  * FaceFreeGoal.goal_distance / relative_goal / next_goal (/root/reference/robogym/envs/dactyl/goals/face_free.py:61-189, with
  * cube_utils.py:26-181), the target cube's joint manipulation that next_goal entails (full_perpendicular.py:138-155 ->

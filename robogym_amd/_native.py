@@ -75,13 +75,35 @@ class RbTcpArgs(ctypes.Structure):
                 ("speed_pitch", ctypes.c_float), ("joint_drift_threshold", ctypes.c_float), ("gripper_ctrl_lo", ctypes.c_float), ("gripper_ctrl_hi", ctypes.c_float)]
 
 
+RA_MAXOBJ = 16
+
+
+def _ra_post_fields():
+    _p, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+    return ([("obs", _p), ("obs_dim", _i), ("num_objects", _i)]
+            + [(n, _p) for n in ("t", "steps", "steps_since_last_goal", "successes_so_far", "consecutive", "prev_nsucc", "prev_valid", "goal", "goal_rot", "qpos_goal", "static_obs",
+                                 "reward", "goal_dist", "done", "goal_reset", "trial_success", "sub_goal_ok", "env_crash", "objects_off_table", "info_ssl")]
+            + [("obj_body", _i * RA_MAXOBJ), ("tcp_body", _i), ("arm_qposadr", _i * 6), ("grip_qposadr", _i), ("grip_dofadr", _i), ("grip_act", _i), ("finger_geom", _i * 2),
+               ("table_plane_geom", _i), ("force_adr", _i), ("torque_adr", _i), ("gripper_geom_mask", ctypes.c_ulonglong), ("table_min", _f * 2), ("table_max", _f * 2)]
+            + [(n, _f) for n in ("table_height", "pos_threshold", "rot_threshold", "goal_pos_offset", "goal_rot_weight", "goal_reward_per_object", "success_reward",
+                                 "penalty_table_collision", "penalty_objects_off_table", "penalty_safety_stop", "safety_stop_force")]
+            + [(n, _i) for n in ("max_timesteps_per_goal", "successes_needed", "use_goal_distance_reward")]
+            + [("solver_qpos", _p), ("solver_ctrl", _p), ("solver_nq", _i), ("solver_nu", _i), ("solver_grip_qposadr", _i), ("solver_grip_act", _i)])
+
+
+class RaPostArgs(ctypes.Structure):
+    """`ra_post_args` of include/rgstep.h (field order and types must match; bind() checks the size)."""
+
+    _fields_ = _ra_post_fields()
+
+
 EXPORTS = [
     "rg_model_create", "rg_model_free", "rg_model_dims", "rg_batch_create", "rg_batch_free", "rg_batch_set_env",
     "rg_batch_copy", "rg_batch_reset", "rg_batch_step", "rg_obs_dim", "rg_debug_size", "rg_lds_bytes", "rg_sync",
     "rg_last_error", "rg_batch_mpr_pair", "rg_batch_copy_rows", "rg_batch_step_ex", "rg_batch_field_ptr", "rg_model_create_on", "rg_model_npair",
     "rg_lds_bytes_cfg", "rg_env_post_step", "rg_post_args_size", "rg_batch_enable_env_params", "rg_prm_layout", "rg_xdata_layout", "rg_batch_set_constants", "rg_batch_items_info",
     "rb_model_create", "rb_model_free", "rb_model_info", "rb_scratch_offset", "rb_batch_create", "rb_batch_free", "rb_batch_reset", "rb_batch_set_env",
-    "rb_batch_field_ptr", "rb_batch_step", "rb_batch_step_ex", "rb_env_post_step", "rb_post_args_size", "rb_cube_ops", "rb_batch_step_tcp",
+    "rb_batch_field_ptr", "rb_batch_step", "rb_batch_step_ex", "rb_env_post_step", "rb_post_args_size", "rb_cube_ops", "rb_batch_step_tcp", "ra_env_post_step", "ra_post_args_size",
 ]
 
 
@@ -145,7 +167,11 @@ def bind(path):
     L.rb_batch_field_ptr.argtypes = [vp, ci, ctypes.POINTER(ci)]
     L.rb_batch_step.argtypes = [vp, vp, vp, ci, ci, ci, vp]
     L.rb_batch_step_ex.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, vp]
-    L.rb_batch_step_tcp.argtypes = [vp, vp, vp, ctypes.POINTER(RbTcpArgs), ci, ci, vp]
+    L.rb_batch_step_tcp.argtypes = [vp, vp, vp, vp, ctypes.POINTER(RbTcpArgs), ci, ci, vp]
+    L.ra_env_post_step.argtypes = [vp, vp, ctypes.POINTER(RaPostArgs), vp]
+    L.ra_post_args_size.restype = ci
+    if L.ra_post_args_size() != ctypes.sizeof(RaPostArgs):
+        raise NativeError("ra_post_args layout mismatch between include/rgstep.h and robogym_amd/_native.py")
     L.rb_env_post_step.argtypes = [vp, ctypes.POINTER(RbPostArgs), vp]
     L.rb_post_args_size.restype = ci
     if L.rb_post_args_size() != ctypes.sizeof(RbPostArgs):

@@ -7,6 +7,7 @@
 // (2-3 x more contacts) with larger ones
 typedef rg_post_args RgPostArgs;
 typedef rb_post_args RbPostArgs;
+typedef ra_post_args RaPostArgs;
 #define RG_NS rgs
 #define RG_MAXCON 24
 #define RG_CPOOL 768
@@ -85,6 +86,7 @@ static const char* hipGetErrorString(hipError_t) { return "emul"; }
 #include "rg_env_kernel.h"
 #include "rb_kernel.h"
 #include "rb_env_kernel.h"
+#include "ra_env_kernel.h"
 #define RG_WAVES_PER_SIMD_HOST 3   /* = RG_WAVES_PER_SIMD of rg_kernel.h (its default) */
 struct rg_batch;
 extern "C" { static void rg_items_probe(rg_batch* b); }
@@ -1053,7 +1055,7 @@ static void emul_rb_entry(void* a) { EmulRbArgs* p = (EmulRbArgs*)a; rgb::rb_ste
 int rb_batch_step_ex(rb_batch* b, const float* action_dev, const int* active_dev, const int* hold_dev, const int* nticks_dev, int nsubsteps, int nforward_ticks, int flags, void* stream);
 static thread_local const RbTcpHook* g_tcp_hook = nullptr;   // set by rb_batch_step_tcp around its launch
 // JointControlledTcpArm.set_position_control as ONE launch of the solver simulation (RbTcpHook, rb_types.h)
-int rb_batch_step_tcp(rb_batch* solver, rb_batch* main_batch, const float* action_dev, const rb_tcp_args* a, int nsubsteps, int flags, void* stream) {
+int rb_batch_step_tcp(rb_batch* solver, rb_batch* main_batch, const float* action_dev, const int* active_dev, const rb_tcp_args* a, int nsubsteps, int flags, void* stream) {
   if (!solver || !main_batch || !action_dev || !a) return fail("rb_batch_step_tcp: null argument");
   if (solver->dev.B != main_batch->dev.B || solver->device != main_batch->device) return fail("rb_batch_step_tcp: the two batches must have the same size and device");
   const RbModelDev& ds = solver->model->dev; const RbModelDev& dm = main_batch->model->dev;
@@ -1068,7 +1070,7 @@ int rb_batch_step_tcp(rb_batch* solver, rb_batch* main_batch, const float* actio
   h.max_position_change = a->max_position_change; h.speed[0] = a->speed_roll; h.speed[1] = a->speed_pitch; h.drift_threshold = a->joint_drift_threshold;
   h.grip_lo = a->gripper_ctrl_lo; h.grip_hi = a->gripper_ctrl_hi;
   g_tcp_hook = &h;
-  const int rc = rb_batch_step_ex(solver, nullptr, nullptr, nullptr, nullptr, nsubsteps, 0, flags, stream);
+  const int rc = rb_batch_step_ex(solver, nullptr, active_dev, nullptr, nullptr, nsubsteps, 0, flags, stream);
   g_tcp_hook = nullptr;
   return rc;
 }
@@ -1128,6 +1130,42 @@ int rb_env_post_step(rb_batch* b, const rb_post_args* args, void* stream) {
   emul_launch(b->dev.B, 1024, emul_rb_post_entry, &ea);
 #else
   hipLaunchKernelGGL(rgb::rb_post_step_kernel, dim3(b->dev.B), dim3(64), 0, (hipStream_t)stream, b->model->dev_copy, b->dev, a);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+#ifdef RG_EMUL
+struct EmulRaPostArgs { const RbModelDev* m; RbBatchDev bt; RaPostArgs a; };
+static void emul_ra_post_entry(void* p_) { EmulRaPostArgs* p = (EmulRaPostArgs*)p_; rgb::ra_post_step_kernel(p->m, p->bt, p->a); }
+#endif
+int ra_post_args_size(void) { return (int)sizeof(ra_post_args); }
+int ra_env_post_step(rb_batch* b, rb_batch* solver, const ra_post_args* args, void* stream) {
+  if (!b || !args) return fail("null argument");
+  ra_post_args a = *args;
+  const RbModelDev& d = b->model->dev;
+  if (!a.obs || !a.t || !a.steps || !a.steps_since_last_goal || !a.successes_so_far || !a.consecutive || !a.prev_nsucc || !a.prev_valid || !a.goal || !a.goal_rot || !a.qpos_goal ||
+      !a.static_obs || !a.reward || !a.goal_dist || !a.done || !a.goal_reset || !a.trial_success || !a.sub_goal_ok || !a.env_crash || !a.objects_off_table || !a.info_ssl)
+    return fail("ra_env_post_step: a required array is NULL");
+  if (a.num_objects < 1 || a.num_objects > RA_MAXOBJ) return fail("ra_env_post_step: num_objects out of range");
+  if (a.obs_dim != 36 * a.num_objects + 23 + 2 * d.nq) return fail("ra_env_post_step: obs_dim does not match the row layout");
+  if (d.ngeom > 64) return fail("ra_env_post_step: the gripper geom mask needs ngeom <= 64");
+  if (d.nsensordata < 1 || a.force_adr < 0 || a.force_adr + 3 > d.nsensordata || a.torque_adr < 0 || a.torque_adr + 3 > d.nsensordata) return fail("ra_env_post_step: sensor address out of range");
+  for (int k = 0; k < a.num_objects; k++) if (a.obj_body[k] <= 0 || a.obj_body[k] >= d.nbody) return fail("ra_env_post_step: object body id out of range");
+  if (a.tcp_body <= 0 || a.tcp_body >= d.nbody || a.grip_act < 0 || a.grip_act >= d.nu || a.grip_qposadr < 0 || a.grip_qposadr >= d.nq || a.grip_dofadr < 0 || a.grip_dofadr >= d.nv)
+    return fail("ra_env_post_step: robot id out of range");
+  for (int k = 0; k < 6; k++) if (a.arm_qposadr[k] < 0 || a.arm_qposadr[k] >= d.nq) return fail("ra_env_post_step: arm joint address out of range");
+  if (solver) {
+    if (solver->dev.B != b->dev.B || solver->device != b->device) return fail("ra_env_post_step: the two batches must have the same size and device");
+    const RbModelDev& ds = solver->model->dev;
+    if (a.solver_grip_qposadr < 0 || a.solver_grip_qposadr >= ds.nq || a.solver_grip_act < 0 || a.solver_grip_act >= ds.nu) return fail("ra_env_post_step: solver gripper id out of range");
+    a.solver_qpos = solver->dev.qpos; a.solver_ctrl = solver->dev.ctrl; a.solver_nq = ds.nq; a.solver_nu = ds.nu;
+  } else { a.solver_qpos = nullptr; a.solver_ctrl = nullptr; }
+  DeviceGuard g(b->device);
+#ifdef RG_EMUL
+  EmulRaPostArgs ea{b->model->dev_copy, b->dev, a};
+  emul_launch(b->dev.B, 1024, emul_ra_post_entry, &ea);
+#else
+  hipLaunchKernelGGL(rgb::ra_post_step_kernel, dim3(b->dev.B), dim3(64), 0, (hipStream_t)stream, b->model->dev_copy, b->dev, a);
   HIPCHK(hipGetLastError());
 #endif
   return 0;

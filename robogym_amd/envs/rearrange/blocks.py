@@ -1,0 +1,311 @@
+"""rearrange/blocks on the MI355X (BASELINE.json configs[3]: UR16e + 2f-85 gripper, table contacts, num_objects = 5, batch 4096).
+
+Host-side mirror of the reference's `BlockRearrangeEnv` (/root/reference/robogym/envs/rearrange/blocks.py:23-40 over
+envs/rearrange/common/base.py `RearrangeEnv`), batched: `make_env` / `make_simple_env`, `step(actions[B, 6])`, `reset(mask)`, `observe()`.
+
+`step` = THREE launches, no host synchronisation:
+  1. `rb_batch_step_tcp`   the TCP solver's own world: sync to the main arm, forward, mocap target from the action, 40 x mj_step, main ctrl
+                           (JointControlledTcpArm.set_position_control, robot/ur16e/mujoco/joint_controlled_tcp_arm.py:89-97)
+  2. `rb_batch_step_ex`    the main world: 40 x mj_step + two state-less forwards, the last in full (sensors, final-state stage arrays)
+                           (SimulationInterface.step + RobotEnv._observe_sync, simulation_interface.py:176-189, robot_env.py:672-688)
+  3. `ra_env_post_step`    observation row, reward, done, goal distances, MultiGoalTracker, gripper hand-over to the solver world
+                           (robogym_amd/csrc/ra_env_kernel.h)
+
+Host work (numpy, outside the per-step path): the reset recipe's placement sampling (`place_objects_in_grid`, common/utils.py:719-829: a grid of
+cells over the placement area, distinct random cells; restated for boxes, distribution-equivalent, not draw-for-draw) and goal sampling
+(`ObjectStateGoal.next_goal`, goals/object_state.py:355-418: targets keep the objects' initial yaw, new grid placement).  The per-episode
+"re-creation" of the simulation (common/base.py:850-856) is the same model with new object poses here: blocks have no per-episode shape
+parameters at the default `object_scale_low/high = 0`, material `default`.
+
+Not built for this env: the wrapper stack (SmoothActionWrapper / ClipRewardWrapper / DiscretizeActionWrapper, common/base.py:986-996), vision,
+`teleport_to_goal`, masks of the placement area, duplicated-object groups.
+"""
+import ctypes
+from typing import Optional
+
+import numpy as np
+import torch
+
+from robogym_amd import _native
+from robogym_amd.envs.rearrange.xml import load_blocks_model, load_solver_model
+from robogym_amd.mujoco.large_simulation import LargeModelSimulation
+
+TABLETOP_EXPERIMENT_INITIAL_POS = np.deg2rad(np.array([135.0, -90, 135, -100, -240, 135]))   # robot/ur16e/arm_interface.py:27
+SPEED_ROLL, SPEED_PITCH = float(np.deg2rad(200)), float(np.deg2rad(600))                      # free_dof_tcp_arm.py:13-17
+JOINT_DRIFT_THRESHOLD = float(np.deg2rad(1))
+FLAG_FULL_FORWARD = 32
+
+OBS_KEYS = [("obj_pos", "N3"), ("obj_rel_pos", "N3"), ("obj_vel_pos", "N3"), ("obj_rot", "N3"), ("obj_vel_rot", "N3"), ("robot_joint_pos", 6), ("gripper_pos", 3),
+            ("gripper_velp", 3), ("gripper_controls", 1), ("gripper_qpos", 1), ("gripper_vel", 1), ("qpos", "nq"), ("qpos_goal", "nq"), ("goal_obj_pos", "N3"),
+            ("goal_obj_rot", "N3"), ("is_goal_achieved", 1), ("rel_goal_obj_pos", "N3"), ("rel_goal_obj_rot", "N3"), ("obj_gripper_contact", "N2"), ("obj_bbox_size", "N3"),
+            ("obj_colors", "N4"), ("safety_stop", 1), ("tcp_force", 3), ("tcp_torque", 3)]
+
+
+def euler2quat(e):
+    """robogym/utils/rotation.py:110-126 convention: q = qx(e0) qy(e1) qz(e2) (pinned by tests/golden/rearrange_rotation.npz)"""
+    e = np.asarray(e, dtype=np.float64)
+    hx, hy, hz = 0.5 * e[..., 0], 0.5 * e[..., 1], 0.5 * e[..., 2]
+    cx, sx, cy, sy, cz, sz = np.cos(hx), np.sin(hx), np.cos(hy), np.sin(hy), np.cos(hz), np.sin(hz)
+    return np.stack([cx * cy * cz - sx * sy * sz, sx * cy * cz + cx * sy * sz, cx * sy * cz - sx * cy * sz, cx * cy * sz + sx * sy * cz], axis=-1)
+
+
+class BatchedBlockRearrangeEnv:
+    def __init__(self, batch_size: int, device="cuda:0", num_objects: int = 5, starting_seed: int = 0, max_position_change: float = 0.1,
+                 arm_reset_controller_error: bool = True, n_random_initial_steps: int = 10, stabilize_steps: int = 100, settle_steps: int = 100,
+                 success_threshold=None, penalty=None, max_timesteps_per_goal_per_obj: int = 200, successes_needed: int = 5, success_reward: float = 5.0,
+                 use_goal_distance_reward: bool = True, goal_reward_per_object: float = 1.0, used_table_portion: float = 1.0, lib=None, n_substeps: int = 40):
+        self.B, self.N = int(batch_size), int(num_objects)
+        self._L = lib if lib is not None else _native.lib()
+        main, solver = load_blocks_model(self.N), load_solver_model()
+        self.sim = LargeModelSimulation(main, self.B, device=device, n_substeps=n_substeps, lib=lib, hand=False)
+        self.solver_sim = LargeModelSimulation(solver, self.B, device=device, n_substeps=n_substeps, lib=lib, hand=False)
+        self.device = self.sim.device
+        self.model, self.solver_model = main, solver
+        self.n_random_initial_steps, self.stabilize_steps, self.settle_steps = n_random_initial_steps, stabilize_steps, settle_steps
+        self.used_table_portion = used_table_portion
+        self._rng = np.random.RandomState(starting_seed)
+        A, As = main.arrays, solver.arrays
+        jn, sj = main.names["joint"], solver.names["joint"]
+        self.arm_q = [int(A["jnt_qposadr"][jn.index("robot0:J%d" % k)]) for k in range(1, 7)]
+        self.obj_q = [int(A["jnt_qposadr"][jn.index("object%d:joint" % i)]) for i in range(self.N)]
+        self.obj_v = [int(A["jnt_dofadr"][jn.index("object%d:joint" % i)]) for i in range(self.N)]
+        self.grip_q = int(A["jnt_qposadr"][jn.index("robot0:r_gripper_RJ0_outer")])
+        self.grip_act = main.names["actuator"].index("robot0:r_gripper_finger_joint")
+        self.nq, self.nu = self.sim.nq, self.sim.nu
+        self.obs_dim = 36 * self.N + 23 + 2 * self.nq
+        gn = main.names["geom"]
+        tb, tg = main.name2id("body", "table"), gn.index("table")
+        self.table_pos, self.table_size = A["body_pos"][tb].copy(), A["geom_size"][tg].copy()
+        self.table_height = float(self.table_pos[2] + self.table_size[2])
+        self.object_size = A["geom_size"][[g for g in range(len(gn)) if A["geom_bodyid"][g] == main.name2id("body", "object0")][0]].copy()
+        # ---- TCP hook arguments
+        t = self.tcp = _native.RbTcpArgs()
+        for k in range(6):
+            t.arm_qposadr[k] = int(As["jnt_qposadr"][sj.index("robot0:J%d" % (k + 1))]); t.main_arm_qposadr[k] = self.arm_q[k]
+        t.main_gripper_actuator = self.grip_act; t.tcp_body = solver.name2id("body", "robot0:gripper_tcp"); t.wrist_joint = sj.index("robot0:J6")
+        t.reset_controller_error = 1 if arm_reset_controller_error else 0
+        t.max_position_change = max_position_change; t.speed_roll = SPEED_ROLL; t.speed_pitch = SPEED_PITCH; t.joint_drift_threshold = JOINT_DRIFT_THRESHOLD
+        t.gripper_ctrl_lo, t.gripper_ctrl_hi = float(A["actuator_ctrlrange"][self.grip_act, 0]), float(A["actuator_ctrlrange"][self.grip_act, 1])
+        self.solver_arm_q = [int(t.arm_qposadr[k]) for k in range(6)]
+        self.solver_grip_q = int(As["jnt_qposadr"][sj.index("robot0:r_gripper_RJ0_outer")])
+        self.solver_grip_act = solver.names["actuator"].index("robot0:r_gripper_finger_joint")
+        # ---- env-level state (device) and the post kernel's arguments
+        dev, B, N = self.device, self.B, self.N
+        z = lambda *shape, dt=torch.float32: torch.zeros(*shape, dtype=dt, device=dev)
+        self.packed = z(B, self.obs_dim + 4)
+        self.t, self.steps, self.ssl, self.successes, self.consecutive = (z(B, dt=torch.int32) for _ in range(5))
+        self.prev_nsucc, self.prev_valid = z(B), z(B, dt=torch.int32)
+        self.goal, self.goal_rot, self.qpos_goal, self.static_obs = z(B, N, 7), z(B, N, 3), z(B, self.nq), z(B, N, 7)
+        self.reward, self.goal_dist = z(B, 3), z(B, 2)
+        self.done, self.goal_reset, self.trial_success, self.sub_goal_ok, self.env_crash, self.objects_off_table = (z(B, dt=torch.bool) for _ in range(6))
+        self.info_ssl = z(B, dt=torch.int32)
+        self.goal[:, :, 3] = 1.0
+        st = dict(success_threshold or {"obj_pos": 0.04, "obj_rot": 0.2})
+        pen = dict(penalty or dict(table_collision=0.0, objects_off_table=1.0, wrist_collision=0.0))
+        a = self.post = _native.RaPostArgs()
+        P = lambda x: ctypes.c_void_p(x.data_ptr())
+        a.obs, a.obs_dim, a.num_objects = P(self.packed), self.obs_dim, N
+        for name, ten in (("t", self.t), ("steps", self.steps), ("steps_since_last_goal", self.ssl), ("successes_so_far", self.successes), ("consecutive", self.consecutive),
+                          ("prev_nsucc", self.prev_nsucc), ("prev_valid", self.prev_valid), ("goal", self.goal), ("goal_rot", self.goal_rot), ("qpos_goal", self.qpos_goal),
+                          ("static_obs", self.static_obs), ("reward", self.reward), ("goal_dist", self.goal_dist), ("done", self.done), ("goal_reset", self.goal_reset),
+                          ("trial_success", self.trial_success), ("sub_goal_ok", self.sub_goal_ok), ("env_crash", self.env_crash), ("objects_off_table", self.objects_off_table),
+                          ("info_ssl", self.info_ssl)):
+            setattr(a, name, P(ten))
+        for i in range(N):
+            a.obj_body[i] = main.name2id("body", "object%d" % i)
+        a.tcp_body = main.name2id("body", "robot0:gripper_tcp")
+        for k in range(6):
+            a.arm_qposadr[k] = self.arm_q[k]
+        a.grip_qposadr, a.grip_dofadr, a.grip_act = self.grip_q, int(A["jnt_dofadr"][jn.index("robot0:r_gripper_RJ0_outer")]), self.grip_act
+        a.finger_geom[0], a.finger_geom[1] = gn.index("robot0:left_contact_v"), gn.index("robot0:right_contact_v")
+        a.table_plane_geom = gn.index("table_collision_plane")
+        sn = main.names["sensor"]
+        a.force_adr, a.torque_adr = int(A["sensor_adr"][sn.index("toolhead_force")]), int(A["sensor_adr"][sn.index("toolhead_torque")])
+        mask = 0
+        for bname in ("robot0:gripper_base", "left_gripper", "left_inner_follower", "left_outer_driver", "right_gripper", "right_inner_follower", "right_outer_driver"):
+            bid = main.name2id("body", bname)
+            for g in range(len(gn)):
+                if A["geom_bodyid"][g] == bid:
+                    mask |= 1 << g
+        a.gripper_geom_mask = mask
+        lo, hi = self.table_pos - self.table_size, self.table_pos + self.table_size
+        a.table_min[0], a.table_min[1], a.table_max[0], a.table_max[1], a.table_height = float(lo[0]), float(lo[1]), float(hi[0]), float(hi[1]), self.table_height
+        a.pos_threshold, a.rot_threshold, a.goal_pos_offset, a.goal_rot_weight = st["obj_pos"], st["obj_rot"], 0.0, 1.0
+        a.goal_reward_per_object, a.success_reward = goal_reward_per_object, success_reward
+        a.penalty_table_collision, a.penalty_objects_off_table, a.penalty_safety_stop = pen.get("table_collision", 0.0), pen.get("objects_off_table", 0.0), pen.get("safety_stop", 0.0)
+        a.safety_stop_force = 150.0                                      # robot/ur16e/arm_interface.py:46
+        a.max_timesteps_per_goal, a.successes_needed, a.use_goal_distance_reward = max_timesteps_per_goal_per_obj * N, successes_needed, int(use_goal_distance_reward)
+        a.solver_grip_qposadr, a.solver_grip_act = self.solver_grip_q, self.solver_grip_act
+        self.action_shape = (self.B, 6)
+        self._zero_action = z(B, 6)
+
+    # ------------------------------------------------------------------ launches
+    def _stream(self):
+        return None if self.sim._emul else ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _post(self):
+        _native.check(self._L, self._L.ra_env_post_step(self.sim._bh, self.solver_sim._bh, ctypes.byref(self.post), self._stream()), "ra_env_post_step")
+
+    def _physics(self, actions, active=None):
+        self.solver_sim.step_tcp(self.sim, actions, self.tcp, active=active)
+        self.sim.env_step(nforward_ticks=2, flags=FLAG_FULL_FORWARD, active=active)
+
+    def step(self, actions: torch.Tensor):
+        """RobotEnv.step (robot_env.py:804-844): returns (obs dict of [B, ...] views, reward [B, 3], done [B], info dict of tensors)."""
+        assert actions.shape == self.action_shape and actions.dtype == torch.float32 and actions.is_contiguous() and actions.device == self.device
+        self._physics(actions)
+        self._post()
+        return self.observe(), self.reward, self.done, self.info()
+
+    def info(self):
+        return {"goal_dist_obj_pos": self.goal_dist[:, 0], "goal_dist_obj_rot": self.goal_dist[:, 1], "goal_reset": self.goal_reset, "trial_success": self.trial_success,
+                "sub_goal_is_successful": self.sub_goal_ok, "env_crash": self.env_crash, "objects_off_table": self.objects_off_table, "successes_so_far": self.successes,
+                "steps_since_last_goal": self.info_ssl}
+
+    def observe(self):
+        """Views into the packed row, keys / shapes of `RearrangeEnv._observe_simple` (common/base.py:376-421)."""
+        out, o, N = {}, 0, self.N
+        for k, w in OBS_KEYS:
+            if isinstance(w, str):
+                n = self.nq if w == "nq" else N * int(w[1])
+                v = self.packed[:, o:o + n]
+                out[k] = v if w == "nq" else v.view(self.B, N, int(w[1]))
+            else:
+                n = w
+                out[k] = self.packed[:, o:o + n]
+            o += n
+        assert o == self.obs_dim
+        return out
+
+    # ------------------------------------------------------------------ reset (host work + physics launches)
+    def _grid_placement(self, yaw, rows):
+        """place_objects_in_grid (common/utils.py:719-829) for boxes: AABB of each yawed block, a grid of cells sized by the largest block over the
+        placement area (simulation/base.py:992-1010), distinct random cells."""
+        B, N = len(rows), self.N
+        sx, sy, sz = self.object_size
+        half = np.stack([np.abs(np.cos(yaw)) * sx + np.abs(np.sin(yaw)) * sy, np.abs(np.sin(yaw)) * sx + np.abs(np.cos(yaw)) * sy, np.full_like(yaw, sz)], -1)   # rotate_bounding_box
+        tsx, tsy = 2 * self.table_size[0], 2 * self.table_size[1]
+        portion = float(np.clip(self.used_table_portion, N * 0.1, 1.0))
+        width, height = 0.5 * tsx * portion, 0.38 * tsy * portion
+        off_x, off_y = 0.5 * tsx - width / 2.0, 0.44 * tsy - height / 2.0
+        out = np.zeros((B, N, 3))
+        for r in range(B):
+            ncol, nrow = int(width // (2 * half[r, :, 0].max())), int(height // (2 * half[r, :, 1].max()))
+            cw, ch = width / ncol, height / nrow
+            cells = self._rng.permutation(ncol * nrow)[:N]
+            row_i, col_i = cells // ncol, cells % ncol
+            p = np.stack([cw * col_i + half[r, :, 0], ch * row_i + half[r, :, 1], half[r, :, 2] + 2 * self.table_size[2]], -1)
+            out[r] = p + [off_x, off_y, 0.0] - self.table_size + self.table_pos
+        return out
+
+    def _write_goal(self, rows, goal_pos, yaw):
+        dev = self.device
+        idx = torch.as_tensor(rows, device=dev, dtype=torch.long)
+        eul = np.zeros(goal_pos.shape); eul[..., 2] = np.mod(yaw + np.pi, 2 * np.pi) - np.pi        # mat2euler of a z-rotation, normalised as get_target_rot + normalize_angles give it
+        quat = euler2quat(eul)
+        g = np.concatenate([goal_pos, quat], -1).astype(np.float32)
+        self.goal[idx] = torch.tensor(g, device=dev)
+        self.goal_rot[idx] = torch.tensor(eul.astype(np.float32), device=dev)
+        qg = self.sim.qpos[idx].clone()                                   # qpos_goal: the current qpos with the objects at their goals (object_state.py:381-389)
+        for i, qa in enumerate(self.obj_q):
+            qg[:, qa:qa + 7] = torch.tensor(g[:, i], device=dev)
+        self.qpos_goal[idx] = qg
+        self.prev_valid[idx] = 0
+
+    def reset(self, mask: Optional[torch.Tensor] = None):
+        """RobotEnv.reset -> RearrangeEnv._reset (common/base.py:897-932): robot start pose, object rotations + grid placement, stabilisation
+        (100 simulation steps), n_random_initial_steps of one random action then 100 zero-action steps, tracker reset, first goal."""
+        rows = np.arange(self.B) if mask is None else np.nonzero(mask.cpu().numpy())[0]
+        if len(rows) == 0:
+            return self.observe()
+        dev, N = self.device, self.N
+        idx = torch.as_tensor(rows, device=dev, dtype=torch.long)
+        active = torch.zeros(self.B, dtype=torch.int32, device=dev); active[idx] = 1
+        A, As = self.model.arrays, self.solver_model.arrays
+        # MjSim of a fresh model: qpos0, zero velocities / controller state / time; robot.reset()
+        for sim, model in ((self.sim, A), (self.solver_sim, As)):
+            sim.qpos[idx] = torch.tensor(model["qpos0"].astype(np.float32), device=dev)
+            for f in (sim.qvel, sim.ctrl, sim.pid, sim.qacc_warmstart):
+                f[idx] = 0
+            sim.view(_native.RG_F_TIME)[idx] = 0
+            sim.view(_native.RG_F_STATUS)[idx] = 0
+        arm0 = torch.tensor(TABLETOP_EXPERIMENT_INITIAL_POS.astype(np.float32), device=dev)
+        self.sim.qpos[idx[:, None], torch.tensor(self.arm_q, device=dev)] = arm0
+        self.sim.ctrl[idx, :6] = arm0
+        self.solver_sim.qpos[idx[:, None], torch.tensor(self.solver_arm_q, device=dev)] = arm0
+        self.solver_sim.eq_data[idx, :7] = torch.tensor([0, 0, 0, 1, 0, 0, 0], dtype=torch.float32, device=dev)     # reset_mocap_welds
+        # object rotations about z and grid placement (common/base.py:613-640, 797-822)
+        yaw = self._rng.uniform(0.0, 2 * np.pi, (len(rows), N))
+        pos = self._grid_placement(yaw, rows)
+        quat = np.stack([np.cos(yaw / 2), 0 * yaw, 0 * yaw, np.sin(yaw / 2)], -1)
+        for i, qa in enumerate(self.obj_q):
+            self.sim.qpos[idx, qa:qa + 7] = torch.tensor(np.concatenate([pos[:, i], quat[:, i]], -1).astype(np.float32), device=dev)
+        colors = self._rng.random_sample((len(rows), N, 4)); colors[..., 3] = 1.0
+        so = np.concatenate([np.broadcast_to(self._aabb_half(yaw), (len(rows), N, 3)), colors], -1)
+        self.static_obs[idx] = torch.tensor(so.astype(np.float32), device=dev)
+        # stabilize_objects (common/utils.py:76-92; its temporary damping change is not reproduced: blocks at rest on the table need none)
+        for _ in range(self.stabilize_steps):
+            self.sim.env_step(nforward_ticks=1, active=active)
+        # _randomize_robot_initial_position (common/base.py:498-510)
+        if self.n_random_initial_steps >= 1:
+            act = torch.zeros(self.B, 6, device=dev)
+            act[idx] = torch.tensor(self._rng.uniform(-1, 1, (len(rows), 6)).astype(np.float32), device=dev)
+            for _ in range(self.n_random_initial_steps):
+                self._physics(act, active)
+                self._sync_solver_gripper(idx)
+            for _ in range(self.settle_steps):
+                self._physics(self._zero_action, active)
+                self._sync_solver_gripper(idx)
+        # tracker reset and the first goal (robot_env.py:780-792; ObjectStateGoal.next_goal with randomize_goal_rot = False)
+        for f in (self.t, self.steps, self.ssl, self.successes, self.consecutive):
+            f[idx] = 0
+        self._write_goal(rows, self._grid_placement(yaw, rows), yaw)
+        self.sim.env_step(nsubsteps=0, nforward_ticks=1, flags=FLAG_FULL_FORWARD, active=active)       # the forward of _observe_sync
+        self._observe_only()
+        return self.observe()
+
+    def _aabb_half(self, yaw):
+        sx, sy, sz = self.object_size
+        return np.stack([np.abs(np.cos(yaw)) * sx + np.abs(np.sin(yaw)) * sy, np.abs(np.sin(yaw)) * sx + np.abs(np.cos(yaw)) * sy, np.full_like(yaw, sz)], -1)
+
+    def _sync_solver_gripper(self, idx):
+        self.solver_sim.qpos[idx, self.solver_grip_q] = self.sim.qpos[idx, self.grip_q]
+        self.solver_sim.ctrl[idx, self.solver_grip_act] = self.sim.ctrl[idx, self.grip_act]
+
+    def _observe_only(self):
+        """The observation row without a step: the post kernel on saved tracker state (its counters are restored)."""
+        saved = [x.clone() for x in (self.t, self.steps, self.ssl, self.successes, self.consecutive, self.prev_nsucc, self.prev_valid)]
+        self._post()
+        for dst, src in zip((self.t, self.steps, self.ssl, self.successes, self.consecutive, self.prev_nsucc, self.prev_valid), saved):
+            dst.copy_(src)
+
+    def reset_goals(self):
+        """`reset_goal` for the envs the tracker flagged (robot_env.py:893-909): a new ObjectStateGoal placement; host sampling."""
+        rows = np.nonzero(self.goal_reset.cpu().numpy())[0]
+        if len(rows) == 0:
+            return
+        yaw = self.goal_rot[torch.as_tensor(rows, device=self.device, dtype=torch.long), :, 2].cpu().numpy().astype(np.float64)
+        self._write_goal(rows, self._grid_placement(yaw, rows), yaw)
+
+    def sync(self):
+        self.sim.sync()
+
+
+def make_env(batch_size: int = 4096, device="cuda:0", parameters=None, constants=None, starting_seed: int = 0, apply_wrappers: bool = False, **kw):
+    """`BlockRearrangeEnv.build` surface (robot_env.py:1081-1089) for the batched env.  `parameters` / `constants` accept the subset this env
+    implements: parameters.simulation_params.num_objects, parameters.robot_control_params.{max_position_change, arm_reset_controller_error},
+    parameters.n_random_initial_steps, constants.{success_threshold, successes_needed, success_reward, max_timesteps_per_goal_per_obj}."""
+    if apply_wrappers:
+        raise NotImplementedError("the rearrange wrapper stack (common/base.py:986-996) is not built")
+    parameters, constants = dict(parameters or {}), dict(constants or {})
+    sp, rc = dict(parameters.get("simulation_params", {})), dict(parameters.get("robot_control_params", {}))
+    args = dict(num_objects=sp.get("num_objects", 5), max_position_change=rc.get("max_position_change", 0.1), arm_reset_controller_error=rc.get("arm_reset_controller_error", True),
+                n_random_initial_steps=parameters.get("n_random_initial_steps", 10), starting_seed=starting_seed)
+    for k in ("success_threshold", "successes_needed", "success_reward", "max_timesteps_per_goal_per_obj"):
+        if k in constants:
+            args[k] = constants[k]
+    args.update(kw)
+    return BatchedBlockRearrangeEnv(batch_size, device=device, **args)
+
+
+make_simple_env = make_env

@@ -1,0 +1,121 @@
+"""`BatchedBlockRearrangeEnv.step` (three launches: TCP solver world, main world, env kernel) against `OracleRearrangeEnv.env_step`
+started from the SAME state: observation row (24 keys of envs/rearrange/common/base.py:376-421), rewards, done flags, goal distances, the
+tracker's counters and the gripper hand-over to the solver world.  CPU: kernel source on the emulation harness; `-m gpu`: the MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from robogym_amd import _native
+from robogym_amd.envs.rearrange.blocks import BatchedBlockRearrangeEnv
+
+
+def _oracle_from_kernel(env, row, n_substeps):
+    """An OracleRearrangeEnv holding env `row`'s state (both worlds), goal and previous success count."""
+    from oracle import rearrange_oracle as RO
+
+    o = RO.OracleRearrangeEnv(env.model, env.solver_model, env.N, n_substeps=n_substeps, max_position_change=env.tcp.max_position_change)
+    for sim, os_ in ((env.sim, o.main.sim), (env.solver_sim, o.solver.sim)):
+        for name, f in (("qpos", sim.qpos), ("qvel", sim.qvel), ("ctrl", sim.ctrl), ("pid", sim.pid), ("qacc_warmstart", sim.qacc_warmstart)):
+            getattr(os_, name)[:] = f[row].cpu().numpy().astype(np.float64)
+        os_._L.ro_set_time(os_.d, float(sim.time[row]))
+        if os_.nmocap:
+            mc = sim.mocap[row].cpu().numpy().astype(np.float64); os_.mocap_pos[:] = mc[:3]; os_.mocap_quat[:] = mc[3:]
+        if os_.neq:
+            os_.eq_data[:] = sim.eq_data[row].cpu().numpy().astype(np.float64)
+    o.set_goal(env.goal[row, :, :3].cpu().numpy().astype(np.float64), env.goal_rot[row].cpu().numpy().astype(np.float64))
+    return o
+
+
+def _check_steps(lib, device, B, n_substeps, nsteps, tol_scale=1.0):
+    env = BatchedBlockRearrangeEnv(B, device=device, lib=lib, n_substeps=n_substeps, stabilize_steps=1 if lib is not None else 20, n_random_initial_steps=0 if lib is not None else 1, settle_steps=0 if lib is not None else 10, starting_seed=3)
+    obs = env.reset()
+    assert set(obs) == {k for k, _ in __import__("robogym_amd.envs.rearrange.blocks", fromlist=["OBS_KEYS"]).OBS_KEYS} and env.obs_dim == 289
+    assert obs["obj_pos"].shape == (B, 5, 3) and obs["qpos"].shape == (B, 43) and obs["obj_colors"].shape == (B, 5, 4)
+    # after reset: blocks on the table inside the placement area, targets elsewhere, nothing flagged
+    z = obs["obj_pos"][..., 2].cpu().numpy()
+    assert np.all(np.abs(z - (env.table_height + 0.0254)) < 2e-3) and int(env.sim.status.max()) == 0
+    rng = np.random.RandomState(5)
+    worst = {}
+    for step in range(nsteps):
+        a = rng.uniform(-1, 1, (B, 6)).astype(np.float32)
+        a[:, 2] = -np.abs(a[:, 2])            # downwards: towards the blocks
+        oracles = [_oracle_from_kernel(env, r, n_substeps) for r in range(B)]
+        prev_valid = env.prev_valid.cpu().numpy().copy(); prev_ns = env.prev_nsucc.cpu().numpy().copy()
+        t0 = env.t.cpu().numpy().copy()
+        obs, rew, done, info = env.step(torch.tensor(a, device=env.device))
+        env.sync()
+        for r in range(B):
+            o = oracles[r]
+            if prev_valid[r]:
+                o.prev_dist = None   # (the oracle recomputes its own previous count below)
+            before = o.num_success(o.goal_distance()) if prev_valid[r] else None
+            oobs, orew, ogoal_rew, odone, oinfo = o.env_step(a[r].astype(np.float64))
+            if before is not None:
+                ogoal_rew = o.num_success(o.goal_distance()) - before
+                assert abs(before - prev_ns[r]) < 1e-6
+            tol = dict(obj_pos=2e-5, obj_rel_pos=2e-5, obj_vel_pos=3e-3, obj_rot=2e-4, obj_vel_rot=3e-2, robot_joint_pos=5e-6, gripper_pos=1e-5, gripper_velp=2e-3,
+                       gripper_controls=1e-6, gripper_qpos=5e-5, gripper_vel=2e-3, qpos=2e-5, goal_obj_pos=1e-6, goal_obj_rot=1e-6, rel_goal_obj_pos=2e-5, rel_goal_obj_rot=2e-4,
+                       obj_gripper_contact=0, tcp_force=3e-2, tcp_torque=3e-3)
+            for k, tl in tol.items():
+                got = obs[k][r].cpu().numpy().astype(np.float64).reshape(np.asarray(oobs[k]).shape)
+                err = float(np.abs(got - oobs[k]).max())
+                worst[k] = max(worst.get(k, 0.0), err)
+                assert err <= tl * tol_scale + 0, (step, r, k, err)
+            assert bool(obs["safety_stop"][r, 0]) == bool(oobs["safety_stop"][0])
+            assert abs(float(rew[r, 0]) - orew) < 1e-6 and abs(float(rew[r, 1]) - ogoal_rew) < 1e-6 and bool(done[r]) == bool(odone)
+            d = o.goal_distance()
+            assert abs(float(env.goal_dist[r, 0]) - d["obj_pos"].sum()) < 1e-4 and abs(float(env.goal_dist[r, 1]) - d["obj_rot"].sum()) < 2e-3
+            assert int(env.t[r]) == t0[r] + 1
+            # gripper hand-over to the solver world
+            assert float(env.solver_sim.qpos[r, env.solver_grip_q]) == float(env.sim.qpos[r, env.grip_q]) and float(env.solver_sim.ctrl[r, env.solver_grip_act]) == float(env.sim.ctrl[r, env.grip_act])
+        assert int(env.sim.status.max()) == 0 and int(env.solver_sim.status.max()) == 0
+    return env
+
+
+def _goal_and_tracker_checks(env):
+    """Teleport the blocks onto their goals: every object within both thresholds -> goal reward = +N on the step it happens, success reward,
+    `goal_reset` raised, a new goal drawn by `reset_goals`, the tracker's counters as MultiGoalTracker.process leaves them; then a block pushed
+    off the table ends the episode with the penalty."""
+    B = env.B
+    z = torch.zeros(B, 6, device=env.device)
+    env.step(z)                                                 # establishes the previous success count (0)
+    ssl0 = int(env.ssl[1])
+    assert float(env.reward[:, 1].abs().max()) == 0 and not bool(env.goal_reset.any())
+    for i, qa in enumerate(env.obj_q):                          # env 0: all blocks at their goals
+        env.sim.qpos[0, qa:qa + 7] = env.goal[0, i]
+    env.step(z)
+    assert float(env.reward[0, 1]) == 5.0 and float(env.reward[0, 2]) == 5.0 and float(env.reward[1, 1]) == 0.0
+    assert bool(env.goal_reset[0]) and not bool(env.goal_reset[1]) and int(env.successes[0]) == 1 and int(env.ssl[0]) == 0 and int(env.ssl[1]) == ssl0 + 1
+    assert float(env.observe()["is_goal_achieved"][0, 0]) == 1.0
+    old = env.goal[0].clone()
+    env.reset_goals()
+    assert not torch.equal(old[:, :3], env.goal[0, :, :3]) and torch.allclose(env.goal[0, :, 3:], old[:, 3:], atol=1e-6) and int(env.prev_valid[0]) == 0
+    env.sim.qpos[1, env.obj_q[2]] = 3.0
+    env.step(z)
+    assert bool(env.done[1]) and bool(env.objects_off_table[1]) and float(env.reward[1, 0]) == -1.0 and not bool(env.done[0])
+
+
+def test_rearrange_env_step_matches_oracle_emul(emul_lib, oracle_lib):
+    """(the emulation harness runs about one mj_step of these worlds per 4 s: one short env.step here, the full 40 + 40 on the GPU)"""
+    env = _check_steps(emul_lib, "cpu", B=2, n_substeps=1, nsteps=1)
+    _goal_and_tracker_checks(env)
+
+
+@pytest.mark.gpu
+def test_rearrange_env_step_matches_oracle_gpu(oracle_lib):
+    """the full 40 + 40 mj_steps per env.step, four envs, 12 steps with the arm pressing down"""
+    env = _check_steps(None, "cuda:0", B=4, n_substeps=40, nsteps=12, tol_scale=3.0)
+    _goal_and_tracker_checks(env)
+
+
+@pytest.mark.gpu
+def test_rearrange_env_batch_4096_runs_clean_gpu():
+    """BASELINE.json configs[3] at its batch size: reset + 8 random-action steps, no status bits, finite rows, blocks stay on the table."""
+    env = BatchedBlockRearrangeEnv(4096, stabilize_steps=20, n_random_initial_steps=2, settle_steps=10)
+    env.reset()
+    g = torch.Generator(device="cpu").manual_seed(0)
+    for _ in range(8):
+        obs, rew, done, info = env.step((torch.rand(4096, 6, generator=g) * 2 - 1).to(env.device))
+    env.sync()
+    assert int(env.sim.status.max()) == 0 and int(env.solver_sim.status.max()) == 0 and bool(torch.isfinite(env.packed).all())
+    assert float(done.float().mean()) < 0.02
