@@ -73,12 +73,101 @@ def kernel_source_hash():
     import hashlib
 
     h = hashlib.sha256()
-    for f in ("rg_kernel.h", "rg_env_kernel.h", "rg_api.hip", "rg_types.h", "rb_kernel.h", "rb_env_kernel.h", "rb_types.h", "Makefile"):
+    for f in ("rg_kernel.h", "rg_env_kernel.h", "rg_api.hip", "rg_types.h", "rb_kernel.h", "rb_env_kernel.h", "ra_env_kernel.h", "rb_types.h", "Makefile"):
         h.update(open(os.path.join(ROOT, "robogym_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
 
-def bench_full_perpendicular(args):
+def algorithmic_bytes_sparse(m, nM, ncon, nefc, iters, nsub, obs_dim, jw=16):
+    """The same stage-boundary model with the constraint Jacobian counted as it is stored by the large-model stepper: at most `jw` dofs per row
+    (a contact touches two dof chains) instead of dense nefc x nv, and the solver's per-iteration traffic likewise (J once, the tree-sparse M
+    instead of 2 nv^2).  Reported NEXT TO the SURVEY 8(d) dense figure for models with nv >> a row's support."""
+    d = m.dims
+    nq, nv, nu, nb, nj, ng, ns, nt = (int(d[i]) for i in (0, 1, 2, 3, 4, 5, 6, 7))
+    S = 5 * nu
+    w = min(jw, nv)
+    staged = (2 * (nq + 2 * nv + S + nu) + 2 * (28 * nb + 12 * ng + 12 * ns + 6 * nj) + 2 * (13 * nb + 6 * nv) + 2 * (nt + nt * w + nu + nu * w)
+              + 2 * (10 * nb + 2 * nM + nv) + 2 * 29 * ncon + 2 * (nefc * w + 8 * nefc) + 2 * (6 * nb + 6 * nv + 3 * nv + nu + nefc + 2 * nv))
+    solver = iters * (nefc * w + 2 * nM + 2 * nefc + 5 * nv)
+    b_sub = 4.0 * (staged + solver)
+    return nsub * b_sub + 4.0 * (nu + obs_dim), b_sub
+
+
+def bench_rearrange_blocks(args, emit=True):
+    """BASELINE.json configs[3]: rearrange/blocks, num_objects = 5 (UR16e + 2f-85 gripper, table contacts), batch 4096 on one MI355X.
+    `BatchedBlockRearrangeEnv.step` = rb_batch_step_tcp (TCP solver world: sync, forward, mocap target, 40 mj_step) + rb_batch_step_ex (main world:
+    40 mj_step + 2 forwards, the last in full with sensors) + ra_env_post_step (observation row, reward, goals, tracker), after the reference's reset
+    recipe (grid placement, 100 stabilisation steps, 10 random + 100 zero-action steps).  1 env-step = 80 mj_step of two models."""
+    from robogym_amd.envs.rearrange.blocks import BatchedBlockRearrangeEnv
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    B = args.batch if args.batch != 8192 else 4096
+    quick = bool(getattr(args, "quick_reset", False))
+    env = BatchedBlockRearrangeEnv(B, device=dev, starting_seed=20200901 + 3, **(dict(stabilize_steps=20, n_random_initial_steps=2, settle_steps=20) if quick else {}))
+    t_reset = time.perf_counter()
+    env.reset()
+    torch.cuda.synchronize(dev)
+    t_reset = time.perf_counter() - t_reset
+    gen = torch.Generator(device=dev); gen.manual_seed(20200901 + 3)
+    step = lambda: env.step(torch.rand((B, 6), generator=gen, device=dev) * 2 - 1)
+    for _ in range(args.warmup):
+        step()
+    env.sim.stats.zero_(); env.solver_sim.stats.zero_()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    orig = env._physics
+
+    def timed(actions, active=None, _i=[0]):
+        e = ev[_i[0] % len(ev)]; _i[0] += 1
+        e[0].record(); env.solver_sim.step_tcp(env.sim, actions, env.tcp, active=active); e[1].record()
+        env.sim.env_step(nforward_ticks=2, flags=32, active=active); e[2].record()
+    env._physics = timed
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    env._physics = orig
+    ms_solver = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])); ms_main = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    res = {}
+    total_bytes = 0.0
+    for name, sim, obs_dim in (("main", env.sim, env.obs_dim), ("solver", env.solver_sim, 0)):
+        st = sim.stats.sum(0).cpu().numpy(); n = max(st[3], 1.0)
+        ncon, nefc, iters = float(st[0] / n), float(st[1] / n), float(st[2] / n)
+
+        class _M:
+            dims = sim.model.dims
+            arrays = {"k_dims": None}
+            k_dims = [0, 0, sim.info["nM"]]
+        bd, _ = algorithmic_bytes_per_env_step(_M, ncon, nefc, iters, sim.n_substeps, obs_dim)
+        bs, _ = algorithmic_bytes_sparse(_M, sim.info["nM"], ncon, nefc, iters, sim.n_substeps, obs_dim)
+        res[name] = dict(mean_ncon=ncon, mean_nefc=nefc, mean_newton_iters=iters, algorithmic_bytes_dense=bd, algorithmic_bytes_sparse_J=bs)
+        total_bytes += bd
+    achieved = B * res["main"]["algorithmic_bytes_dense"] / (ms_main * 1e-3)
+    out = {
+        "metric": "env-steps/sec rearrange/blocks num_objects=5 batch 4096 (BASELINE.json configs[3]); unwrapped env.step incl. the TCP solver's second simulation; parity vs the in-repo CPU oracle (unpinned)",
+        "value": B * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "rearrange/blocks (UR16e + 2f-85 gripper + table, 5 blocks: nv=38, elliptic cones, impratio 10) with its TCP solver world (nv=8, mocap weld), batch %d, iid U(-1,1) relative tcp+roll+yaw actions, 40 + 40 substeps x 0.001 s + 2 forwards; after the reset recipe%s" % (B, " (shortened: --quick-reset)" if quick else ""),
+                   "batch_per_gpu": B, "reset_seconds": t_reset, "main": res["main"], "solver": res["solver"], "status_bits": int(max(env.sim.status.max().item(), env.solver_sim.status.max().item())),
+                   "done_fraction_last_step": float(env.done.float().mean().item()), "launch_ms": {"solver_world": ms_solver, "main_world": ms_main}, "lds_bytes_per_workgroup": env.sim.info["lds_bytes"]},
+        "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None, "kernel": "rb_step_kernel (main world launch)", "kernel_ms": ms_main,
+                     "algorithmic_bytes_per_env_step": res["main"]["algorithmic_bytes_dense"], "frac_sparse_J": B * res["main"]["algorithmic_bytes_sparse_J"] / (ms_main * 1e-3) / HBM_PEAK,
+                     "note": "dominant kernel = the main world's launch; SURVEY 8(d) dense byte model with the run's ncon / nefc / iterations; frac_sparse_J counts a constraint row at <= 16 dofs and M tree-sparse (what the stepper stores)"},
+    }
+    if not args.no_cpu_baseline:
+        from oracle import cpu_baseline as cb
+
+        out["cpu_baseline"] = cb.run_rearrange_blocks(4.0)
+    if emit:
+        print(json.dumps(out, default=float))
+    del env
+    torch.cuda.empty_cache()
+    return out
+
+
+def bench_full_perpendicular(args, emit=True):
     """BASELINE.json configs[2]: dactyl/full_perpendicular (Shadow hand + full Rubik's cube, nv 168, condim-6 contacts), batch 4096
     on one MI355X: `BatchedFullPerpendicularEnv.step` = the large-model stepper (rb_step_kernel: action map, 10 mj_step, 3 PID ticks)
     + the env kernel (rb_post_step_kernel: FaceFreeGoal distances, reward, success, tracker, goal generation, observation row), after
@@ -128,18 +217,63 @@ def bench_full_perpendicular(args):
                    "batch_per_gpu": B, "pipelined_reset": bool(args.pipelined_reset), "cube_on_palm_fraction_after_reset": on_palm0, "cube_on_palm_fraction_at_end": on_palm, "goals_so_far_mean": float(env.multi_goal_tracker.goals_so_far.float().mean().item()), "mean_ncon": ncon, "mean_nefc": nefc, "mean_newton_iters": iters, "status_bits": int(sim.status.max().item()), "lds_bytes_per_workgroup": sim.info["lds_bytes"]},
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None, "kernel": "rb_step_kernel", "kernel_ms": kern_ms,
                      "algorithmic_bytes_per_env_step": b_step, "algorithmic_bytes_per_substep": b_sub,
-                     "note": "SURVEY 8(d) byte model with this model's dimensions (nM 1193) and the run's measured ncon / nefc / iterations; first, clarity-first version of the kernel"},
+                     "frac_sparse_J": B * algorithmic_bytes_sparse(_M, sim.info["nM"], ncon, nefc, iters, sim.n_substeps, sim.nq + sim.nv)[0] / (kern_ms * 1e-3) / HBM_PEAK,
+                     "note": "frac = SURVEY 8(d) DENSE byte model (nefc x nv Jacobian, 2 nv^2 solver terms) with this model's dimensions (nM 1193) and the run's measured ncon / nefc / iterations; frac_sparse_J = the same model with a constraint row counted at <= 16 dofs and M tree-sparse, which is what the stepper stores: the dense figure overstates the bytes of a kernel whose Jacobians are sparse"},
     }
     if not args.no_cpu_baseline:
         from oracle import cpu_baseline as cb
 
         out["cpu_baseline"] = cb.run_full_perpendicular(2.0)
-    print(json.dumps(out, default=float))
+    if emit:
+        print(json.dumps(out, default=float))
+    del env
+    torch.cuda.empty_cache()
+    return out
+
+
+def bench_locked_variant(args, emit=True, pipelined_reset=False, default_make_env=False):
+    """configs[1] in its two other shapes: the steady state with episode ends (pipelined in-step resets; the window starts after
+    `warmup` steps so that recipe and live envs are mixed) and the reference's default `make_env()` (wrapper stack, randomize=True)."""
+    from robogym_amd.envs.dactyl import locked as LK
+
+    dev = torch.device("cuda", 0)
+    B = args.batch
+    if default_make_env:
+        env = LK.make_env(batch_size=B, device=dev, starting_seed=20200901 + 1)
+        label = "default make_env() (reference wrapper stack incl. randomize=True), unwrapped physics underneath"
+    else:
+        env = LK.make_simple_env(batch_size=B, device=dev, starting_seed=20200901 + 1, pipelined_reset=True)
+        label = "make_simple_env(pipelined_reset=True): finished episodes run the reset recipe inside the step launches"
+    env.reset()
+    gen = torch.Generator(device=dev); gen.manual_seed(20200901 + 1)
+    nu = 20
+    if default_make_env:
+        act = lambda: torch.randint(0, 11, (B, nu), generator=gen, device=dev)
+    else:
+        act = lambda: torch.rand((B, nu), generator=gen, device=dev) * 2 - 1
+    for _ in range(args.warmup):
+        env.step(act())
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        env.step(act())
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    out = {"metric": "env-steps/sec dactyl/locked batch %d: %s" % (B, label), "value": B * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "dtype": "f32", "data": "synthetic",
+           "roofline": None, "cpu_baseline": None, "note": "same kernels and byte model as the headline line; its roofline / cpu_baseline objects apply"}
+    if emit:
+        print(json.dumps(out, default=float))
+    del env
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="locked", choices=["locked", "full_perpendicular"], help="locked = BASELINE.json configs[1] (the headline); full_perpendicular = configs[2]")
+    ap.add_argument("--workload", default="locked", choices=["locked", "full_perpendicular", "rearrange_blocks"], help="locked = BASELINE.json configs[1] (the headline); full_perpendicular = configs[2]; rearrange_blocks = configs[3]")
+    ap.add_argument("--no-secondary", action="store_true", help="headline only: skip the shortened runs of the other built configs that the default line carries under 'secondary'")
+    ap.add_argument("--quick-reset", action="store_true", help="rearrange_blocks: a shortened reset recipe (20 / 2 / 20 steps instead of 100 / 10 / 100)")
     ap.add_argument("--gpus", type=int, default=1)
     # default window: the 20 steps right after the reset, where the cubes are still in the hands (iid random actions throw them off
     # over time and the workload gets cheaper: 100 steps after 10 warm-up steps measure ~10 % more; the line reports the on-palm fraction)
@@ -154,6 +288,8 @@ def main():
 
     if args.workload == "full_perpendicular":
         return bench_full_perpendicular(args)
+    if args.workload == "rearrange_blocks":
+        return bench_rearrange_blocks(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch_with_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
@@ -292,6 +428,20 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not emul_path and not args.no_secondary:
+            # every other built config in the one line: shortened runs, each with its own roofline and cpu_baseline
+            del env, sim, gather
+            torch.cuda.empty_cache()
+            import copy
+            sec = []
+            for fn, kw in ((bench_locked_variant, dict(pipelined_reset=True)), (bench_locked_variant, dict(default_make_env=True)), (bench_full_perpendicular, {}), (bench_rearrange_blocks, {})):
+                a2 = copy.copy(args); a2.steps, a2.warmup, a2.batch = (20, 40, 8192) if fn is bench_locked_variant else (4, 2, 4096)
+                a2.pipelined_reset = False
+                try:
+                    sec.append(fn(a2, emit=False, **kw))
+                except Exception as ex:   # a secondary run must not cost the headline
+                    sec.append({"metric": getattr(fn, "__name__", "?"), "error": repr(ex)})
+            out["secondary"] = sec
         print(json.dumps(out, default=float))
     if distributed:
         dist.destroy_process_group()

@@ -48,6 +48,8 @@ enum {
 #define RG_STATUS_ROW_FULL 8u
 #define RG_STATUS_BAD_FACTOR 16u
 #define RG_STATUS_BAD_ACTION 32u /* a non-finite entry in the env's action row: the row was ignored (ctrl kept) */
+#define RG_STATUS_SCHED 64u      /* substep-granular dispatch (flags bit 7): the rollout launch ended with work items of this env undrawn (its XCD's queue was not
+                                    served); the env.step was completed by the large-configuration launch behind it (redo_dev).  Informational, sticky. */
 
 /* Replaces mujoco_py.load_model_from_xml (mujoco_xml.py:259): `blob` is the "RGMODEL1" flat model
  * produced by the host-side MJCF compiler (robogym_amd/mujoco/model_blob.py). Returns NULL on error. */

@@ -202,6 +202,8 @@ RG_FLAG_SENSORS = 32           # bit 5: evaluate data.sensordata (the last state
 RG_FLAG_SEPARATE_FORWARD_SUBSTITUTION = 64   # bit 6: test hook (include/rgstep.h)
 RG_FLAG_SUBSTEP_ITEMS = 128    # bit 7: substep-granular dispatch of a rollout launch (rg_step_items_kernel)
 RG_FLAG_CAPACITY_TEST_HOOK = 512   # bit 9: test hook (include/rgstep.h)
+RG_FLAG_DESERT_QUEUE0 = 1024       # bit 10: test hook: the substep-granular dispatch leaves its queue 0 unserved (the fallback must complete those envs)
+RG_STATUS_SCHED = 64
 RG_FLAG_RESUME = 256           # bit 8: active_dev is a redo array: entry - 1 = first substep still to do
 
 PRM_NAMES = ["row", "gravity", "timestep", "dof_damping", "dof_armature", "dof_frictionloss", "dof_invweight0", "body_mass", "body_inertia", "body_invweight0",

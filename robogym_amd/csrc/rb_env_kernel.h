@@ -348,6 +348,26 @@ __global__ void __launch_bounds__(64) rb_post_step_kernel(const RbModelDev* mp, 
       for (int k = 0; k < 2; k++) rb_pid_tick(m, u, bt.ctrl[(size_t)e * nu + u], len, st);
     }
   }
+  // ---- state part of the observation row: cube_pos 3 | cube_quat 4 (w >= 0) | cube_face_angle 6 (wrapped) | hand_angle | fingertip_pos 15 (| goal_pos 3 |
+  // goal_quat 4 | goal_face_angle 6 below).  Written BEFORE the pipelined recipe's state writes (restart: qpos <- qpos0; wiggle), so that an env whose
+  // episode ends in this step returns its TERMINAL observation, as RobotEnv.step does (robot_env.py:804-844) — and so that no lane reads a state row another
+  // lane is rewriting.  (`observe()`'s qpos / qvel keys are views of the state rows themselves: for a restarted env they show the reset state.)
+  {
+    float* o = a.obs + (size_t)e * a.obs_dim;
+    if (lane < 3) o[lane] = qrow[a.cube_pos_col + lane];
+    if (lane < 4) o[3 + lane] = (qrow[a.cube_quat_col] < 0 ? -1.f : 1.f) * qrow[a.cube_quat_col + lane];
+    if (lane < 6) o[7 + lane] = rbc_wrap(qrow[a.cube_block_col + lane]);
+    for (int i = lane; i < a.n_hand; i += 64) o[13 + i] = qrow[a.hand_col + i];
+    const int ot = 13 + a.n_hand;
+    if (lane < 5) {   // fingertips relative to the three reference sites (hand_forward_kinematics.py:39-50)
+      const float* sp = S + m.off[RB_O_SPOS];
+      v3 r0 = ld3(sp + 3 * a.ref_site[0]), r1 = ld3(sp + 3 * a.ref_site[1]), r2 = ld3(sp + 3 * a.ref_site[2]);
+      v3 ax = normalized(r0 - r1), cx = normalized(r2 - r1), bx = cross(ax, cx);
+      v3 t = ld3(sp + 3 * a.tip_site[lane]) - r1;
+      o[ot + 3 * lane] = dot(t, ax); o[ot + 3 * lane + 1] = dot(t, bx); o[ot + 3 * lane + 2] = dot(t, cx);
+    }
+  }
+  __syncthreads();
   if (a.pipelined && !forced) {
     const int nv = m.nv;
     auto RD = [&](int k) -> float { return a.reset_draws[(size_t)e * RB_RESET_NDRAW + k]; };
@@ -401,21 +421,10 @@ __global__ void __launch_bounds__(64) rb_post_step_kernel(const RbModelDev* mp, 
       if (lane == 0) { bt.time[e] = 0.f; bt.status[e] = 0; }
     }
   }
-  // ---- observation row: cube_pos 3 | cube_quat 4 (w >= 0) | cube_face_angle 6 (wrapped) | hand_angle | fingertip_pos 15 | goal_pos 3 | goal_quat 4 | goal_face_angle 6
+  // ---- goal part of the observation row (written last: a new goal of this step is part of it); a crashed env returns a zero row
   float* o = a.obs + (size_t)e * a.obs_dim;
   if (F.crash) { for (int i = lane; i < a.obs_dim; i += 64) o[i] = 0.f; return; }
-  if (lane < 3) o[lane] = qrow[a.cube_pos_col + lane];
-  if (lane < 4) o[3 + lane] = (qrow[a.cube_quat_col] < 0 ? -1.f : 1.f) * qrow[a.cube_quat_col + lane];
-  if (lane < 6) o[7 + lane] = rbc_wrap(qrow[a.cube_block_col + lane]);
-  for (int i = lane; i < a.n_hand; i += 64) o[13 + i] = qrow[a.hand_col + i];
   const int ot = 13 + a.n_hand;
-  if (lane < 5) {   // fingertips relative to the three reference sites (hand_forward_kinematics.py:39-50)
-    const float* sp = S + m.off[RB_O_SPOS];
-    v3 r0 = ld3(sp + 3 * a.ref_site[0]), r1 = ld3(sp + 3 * a.ref_site[1]), r2 = ld3(sp + 3 * a.ref_site[2]);
-    v3 ax = normalized(r0 - r1), cx = normalized(r2 - r1), bx = cross(ax, cx);
-    v3 t = ld3(sp + 3 * a.tip_site[lane]) - r1;
-    o[ot + 3 * lane] = dot(t, ax); o[ot + 3 * lane + 1] = dot(t, bx); o[ot + 3 * lane + 2] = dot(t, cx);
-  }
   if (lane < 3) o[ot + 15 + lane] = 0.f;
   if (lane < 4) o[ot + 18 + lane] = F.gq[lane];
   if (lane < 6) o[ot + 22 + lane] = F.gf[lane];

@@ -2688,8 +2688,10 @@ __global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_items_kern
   st_build_row_desc(c);   // (static index tables in the persistent part of the LDS image: once per workgroup, not per item)
   int xfrc_default = -1;  // batches without per-env parameter rows: "any external wrench?" is a property of the model's default row
   if (!L.bt.envprm) { const float* P0 = m.prm_default; float nz = 0; PFOR(i, 6 * m.nbody) nz += P0[RG_PRM_XFRC + i] != 0.f ? 1.f : 0.f; xfrc_default = wave_sum(nz) > 0 ? 1 : 0; }
+  const bool desert = (L.flags & 1024) && xq == 0;   // TEST HOOK (flags bit 10): queue 0 is left unserved, as if its XCD had received no workgroup
   for (;;) {
     SYNC();   // (the previous item's LDS image is dead only when every lane is here)
+    if (desert) break;
     int t = 0;
     if (LANE == 0) t = rg_ticket(sched + 16 * xq);
     t = rg_first(t);
@@ -2837,12 +2839,23 @@ __global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_items_kern
   }
   // ---- the last workgroup to leave checks that every queue was drained (a queue whose XCD received no workgroup would be left
   //      standing: the host probes the dispatch once before it enables this kernel, this is the run-time net under that)
-  if (LANE == 0) {
-    const int g = rg_ticket(sched + RG_SCHED_FIN);
-    if (g == (int)gridDim.x - 1) {
-      bool ok = true;
-      for (int x = 0; x < nq_; x++) { const int n = (B - x + nq_ - 1) / nq_ * nsub; if (rg_ld_sc1(sched + 16 * x) < n) ok = false; }
-      if (!ok) L.bt.status[0] |= RG_STATUS_SCHED;
+  // Round 4: the net is a FALLBACK, not a flag on env 0.  Every env whose progress word is short of nsub (its remaining items were never drawn)
+  // gets redo[e] = progress + 1, i.e. it is handed to the large-configuration launch that follows every rollout launch and resumes an env.step at
+  // the substep named there (flags bit 8) — the mid-step hand-over path — and RG_STATUS_SCHED on ITS OWN status word (informational: the env WAS
+  // stepped).  All other workgroups have left, so nobody else touches these rows; the kernel boundary makes them visible to the next launch.
+  int g = 0;
+  if (LANE == 0) g = rg_ticket(sched + RG_SCHED_FIN);
+  g = rg_first(g);
+  if (g == (int)gridDim.x - 1) {
+    int ok = 1;
+    if (LANE == 0) for (int x = 0; x < nq_; x++) { const int n = (B - x + nq_ - 1) / nq_ * nsub; if (rg_ld_sc1(sched + 16 * x) < n) ok = 0; }
+    ok = rg_first(ok);
+    if (!ok) {
+      PFOR(e, B) {
+        if (L.bt.active && !L.bt.active[e]) continue;
+        const int p = rg_ld_sc1(prog + e) & 0xFFFF;
+        if (p < nsub) { if (L.bt.redo) L.bt.redo[e] = p + 1; L.bt.status[e] |= RG_STATUS_SCHED; }
+      }
     }
   }
 }

@@ -82,7 +82,7 @@ enum {
 #define RG_STATUS_ROW_FULL 8u    // more friction/limit rows than RG_MAXROW
 #define RG_STATUS_BAD_FACTOR 16u // Cholesky pivot <= 0
 #define RG_STATUS_BAD_ACTION 32u // non-finite entry in the env's action row (the row is ignored: ctrl keeps its value)
-#define RG_STATUS_SCHED 64u      // substep-granular dispatch: a launch ended with work items left in a queue (raised on env 0; never observed)
+#define RG_STATUS_SCHED 64u      // substep-granular dispatch: work items of this env were left undrawn; the env.step was completed by the fallback (include/rgstep.h)
 
 enum { RG_JNT_FREE = 0, RG_JNT_BALL = 1, RG_JNT_SLIDE = 2, RG_JNT_HINGE = 3 };
 enum { RG_GEOM_PLANE = 0, RG_GEOM_SPHERE = 2, RG_GEOM_CAPSULE = 3, RG_GEOM_ELLIPSOID = 4, RG_GEOM_CYLINDER = 5, RG_GEOM_BOX = 6, RG_GEOM_MESH = 7 };

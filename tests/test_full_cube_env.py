@@ -471,6 +471,7 @@ def test_pipelined_reset_phase_machine_emul(full_model, emul_lib):
     env.set_pipelined_reset_draws(_pipe_draw_rows(d, B))
     env.set_draws(np.tile([0.9, 0.5, 0, 2, 0.3], (B, 1)))
     sim.qvel[:] = 0.3; sim.ctrl[:] = 0.05; sim.qpos[:, 5] += 0.01
+    sim.qpos[:, int(sim.qpos_idxs["cube_position"][0])] += 0.02      # (so that the terminal state differs from qpos0 in an observed column)
     env._goal[:, 0] = 0; env._goal[:, 1] = 1            # (a goal half a turn away: the first step must not succeed)
     qpos0 = np.asarray(full_model.arrays["qpos0"], dtype=np.float32)
     lo, hi = full_model.arrays["actuator_ctrlrange"][:, 0], full_model.arrays["actuator_ctrlrange"][:, 1]
@@ -485,6 +486,14 @@ def test_pipelined_reset_phase_machine_emul(full_model, emul_lib):
             assert F["done"].all() and (env._phase == 1).all() and (env._hold == 1).all() and (env._nticks == 1).all() and F["resetting"].all()
             np.testing.assert_array_equal(sim.qpos.cpu().numpy(), np.repeat(qpos0[None], B, 0))
             assert float(sim.qvel.abs().max()) == 0 and float(sim.pid.abs().max()) == 0
+            # the observation row returned WITH done is the TERMINAL one (robot_env.py:804-844), built before the restart's state writes
+            row = env._obs_buf.cpu().numpy()
+            pc, qc, hc = int(sim.qpos_idxs["cube_position"][0]), int(sim.qpos_idxs["cube_rotation"][0]), int(sim.qpos_idxs["hand_angle"][0])
+            cq = before[:, qc:qc + 4] * np.where(before[:, qc:qc + 1] < 0, -1.0, 1.0)
+            np.testing.assert_array_equal(row[:, 0:3], before[:, pc:pc + 3])
+            np.testing.assert_array_equal(row[:, 3:7], cq)
+            np.testing.assert_array_equal(row[:, 13:13 + env.n_hand], before[:, hc:hc + env.n_hand])
+            assert np.abs(row[:, 0:3] - qpos0[pc:pc + 3]).max() > 1e-3       # (i.e. NOT the reset state)
             np.testing.assert_allclose(sim.ctrl.cpu().numpy(), np.repeat((0.5 * (lo + hi))[None], B, 0), atol=1e-7)
         if k == 1:      # recipe step 1 done; the next one is step n1 = 2: two ticks (its own forward + the one after the state writes)
             assert (env._phase == 2).all() and (env._nticks == 2).all() and not F["done"].any()

@@ -251,6 +251,35 @@ def test_substep_items_dispatch_is_bit_identical_emul(locked_model, emul_lib):
     assert min(redone) > 0                            # (the hook did hand env.steps over)
 
 
+def _unserved_queue_check(make_sim, nsteps, expect_fraction):
+    """TEST HOOK flags bit 10: the persistent workgroups of queue 0 leave at once, as if that XCD had received none.  The last workgroup to leave finds
+    the undrawn items, hands those envs to the large-configuration launch behind the rollout launch (redo = progress + 1) and marks them with
+    RG_STATUS_SCHED: nothing is silently left unstepped, and the results are those of the normal dispatch, bit for bit (VERDICT r03 weak 4 / ADVICE)."""
+    from robogym_amd import _native
+
+    ref, _ = _rollout_both_dispatch_modes(make_sim, nsteps, 4)
+    out, redone = _rollout_both_dispatch_modes(make_sim, nsteps, 4, flags=_native.RG_FLAG_DESERT_QUEUE0)
+    for k in range(5):   # qpos, qvel, pid, warm start, stats
+        assert torch.equal(out[1][k], ref[1][k]) and torch.equal(out[0][k], ref[0][k])
+    st = out[1][5]
+    frac = float(((st & _native.RG_STATUS_SCHED) != 0).float().mean())
+    assert abs(frac - expect_fraction) < 0.02 and int((st & ~_native.RG_STATUS_SCHED).max()) == 0
+    assert int(out[0][5].max()) == 0 and redone[1] > 0      # (the one-workgroup dispatch has no queues: the hook does nothing there)
+
+
+def test_unserved_queue_is_completed_by_the_fallback_emul(locked_model, emul_lib):
+    from robogym_amd.envs.dactyl.locked import LockedSimulation
+
+    _unserved_queue_check(lambda: LockedSimulation(locked_model, 2, device="cpu", lib=emul_lib, n_substeps=3), 4, 1.0)   # one queue on the harness: every env
+
+
+@pytest.mark.gpu
+def test_unserved_queue_is_completed_by_the_fallback_gpu(locked_model):
+    from robogym_amd.envs.dactyl.locked import LockedSimulation
+
+    _unserved_queue_check(lambda: LockedSimulation(locked_model, 8192, device="cuda:0"), 6, 1.0 / 8)                     # eight queues: one env in eight
+
+
 @pytest.mark.gpu
 def test_substep_items_dispatch_is_bit_identical_gpu(locked_model):
     """The same at the BASELINE batch (8192 distinct trajectories, 12 env.steps), and with the hand closing around the cube

@@ -115,6 +115,8 @@ def _resync_env_steps(models, lib, device, n_substeps, nsteps, seed=1):
         sync_from_oracle(sm, om); sync_from_oracle(sc, oc)
         sc.step_tcp(sm, torch.tensor(a[None].astype(np.float32), device=sm.device), args)
         sm.env_step(nforward_ticks=2, flags=32)
+        # on_observations_updated (the env kernel's last act; joint_controlled_tcp_arm.py:114-129): the solver world's gripper follows the main world's
+        sc.qpos[0, env.solver.grip_q] = sm.qpos[0, env.main.grip_q]; sc.ctrl[0, env.solver.grip_act] = sm.ctrl[0, env.main.grip_act]
         sm.sync()
         env.env_step(a)
         e = lambda x, y: float(np.abs(x.cpu().numpy().astype(np.float64) - y).max())
