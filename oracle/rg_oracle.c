@@ -1627,6 +1627,52 @@ static void ro_solve(const ro_model* m, ro_data* d) {
   free(jar); free(jv); free(force); free(Ma); free(grad); free(search); free(Mv); free(H); free(Lh); free(qa); free(active);
 }
 
+/* ------------------------------------------------------------------------------------------ independent cross-check solver
+ * engine_solver.c: mj_solPGS — projected Gauss-Seidel on the DUAL of the same convex problem (VERDICT r03 item 6 iii):
+ *     minimise 1/2 f' (A + R) f + f' (J qacc_smooth - aref),  A = J M^-1 J',  subject to the rows' force bounds
+ *     (equality: free; friction loss: |f| <= frictionloss; limits and pyramidal contact edges: f >= 0),
+ * then qacc = qacc_smooth + M^-1 J' f.  It shares NOTHING with the Newton path but the constraint rows: no Hessian, no line search, no warm
+ * start.  At the optimum the two coincide (strong duality), which is what tests/test_oracle.py asserts.  Elliptic cones (a per-contact cone
+ * projection of a coupled block) are not covered.  Uses the rows of the last ro_forward; returns the number of sweeps, -1 for elliptic models. */
+int ro_solve_pgs(const ro_model* m, ro_data* d, int max_sweeps, double tol, double* qacc_out) {
+  int nv = m->nv, ne = d->nefc;
+  for (int r = 0; r < ne; r++) if (d->efc_type[r] == EFC_CONTACT_ELLIPTIC) return -1;
+  if (ne < 0 || ne > MAXEFC || nv <= 0) return -2;
+  const size_t un = (size_t)(ne > 0 ? ne : 1);
+  real* MinvJt = dalloc((size_t)nv * un);   /* column r = M^-1 J_r' */
+  real* A = dalloc(un * un);
+  real *b = dalloc(un), *f = dalloc(un), *col = dalloc((size_t)nv);
+  for (int r = 0; r < ne; r++) {
+    memcpy(col, d->efc_J + (size_t)r * nv, nv * sizeof(real));
+    chol_solve(d->qL, col, nv);
+    for (int i = 0; i < nv; i++) MinvJt[(size_t)i * ne + r] = col[i];
+  }
+  for (int r = 0; r < ne; r++) {
+    const real* J = d->efc_J + (size_t)r * nv;
+    for (int c = 0; c < ne; c++) { real s = 0; for (int i = 0; i < nv; i++) s += J[i] * MinvJt[(size_t)i * ne + c]; A[(size_t)r * ne + c] = s; }
+    real s = 0; for (int i = 0; i < nv; i++) s += J[i] * d->qacc_smooth[i];
+    b[r] = s - d->efc_aref[r];
+  }
+  int sweep = 0;
+  for (; sweep < max_sweeps; sweep++) {
+    real change = 0;
+    for (int r = 0; r < ne; r++) {
+      real g = b[r] + d->efc_R[r] * f[r];
+      for (int c = 0; c < ne; c++) g += A[(size_t)r * ne + c] * f[c];
+      real fn = f[r] - g / (A[(size_t)r * ne + r] + d->efc_R[r]);
+      int type = d->efc_type[r];
+      if (type == EFC_FRICTION_DOF || type == EFC_FRICTION_TENDON) fn = clampd(fn, -d->efc_frictionloss[r], d->efc_frictionloss[r]);
+      else if (type != EFC_EQUALITY && fn < 0) fn = 0;
+      change = fmax(change, fabs(fn - f[r]) * (A[(size_t)r * ne + r] + d->efc_R[r]));
+      f[r] = fn;
+    }
+    if (change < tol) { sweep++; break; }
+  }
+  for (int i = 0; i < nv; i++) { real s = d->qacc_smooth[i]; for (int r = 0; r < ne; r++) s += MinvJt[(size_t)i * ne + r] * f[r]; qacc_out[i] = (double)s; }
+  free(MinvJt); free(A); free(b); free(f); free(col);
+  return sweep;
+}
+
 /* ------------------------------------------------------------------------------------------ forward / step */
 /* engine_sensor.c: mj_sensorAcc, mjSENS_TOUCH.  A touch sensor sums the NORMAL forces of the contacts that involve the
  * body of its site and whose contact point "sees" the site's volume along the contact normal (mju_rayGeom(site, contact

@@ -57,6 +57,8 @@ def lib(f32=False):
         L.ro_int.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p]
         L.ro_efc_type.restype = ctypes.POINTER(ctypes.c_int)
         L.ro_efc_type.argtypes = [ctypes.c_void_p]
+        L.ro_solve_pgs.restype = ctypes.c_int
+        L.ro_solve_pgs.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
         L.ro_eq_active.restype = ctypes.POINTER(ctypes.c_int)
         L.ro_eq_active.argtypes = [ctypes.c_void_p]
         L.ro_time.restype = ctypes.c_double
@@ -144,6 +146,12 @@ class OracleSim:
 
     def efc_types(self):
         return np.ctypeslib.as_array(self._L.ro_efc_type(self.d), shape=(2000,))[: self.nefc].copy()
+
+    def solve_pgs(self, max_sweeps=200000, tol=1e-13):
+        """The dual projected Gauss-Seidel solver on the rows of the last forward(): (qacc, sweeps).  Independent cross-check of the Newton solver."""
+        out = (ctypes.c_double * self.field("qacc").shape[0])()
+        n = self._L.ro_solve_pgs(self.m, self.d, int(max_sweeps), float(tol), out)
+        return np.array(out[:]), n
 
     def eq_active(self):
         """mjModel.eq_active as a writable int view (run-time copy: the envs toggle it)."""

@@ -393,3 +393,26 @@ def test_implicit_damping_of_the_euler_integrator():
     for _ in range(250):
         s.step()
     np.testing.assert_allclose(s.qvel[0], damped_wheel_closed_form(250), rtol=1e-9)
+
+
+def test_pgs_dual_solver_agrees_with_newton(locked_model):
+    """SURVEY section 7 step 2 / VERDICT r03 item 6 iii: an independent solver on the same constraint rows.  `ro_solve_pgs` is projected Gauss-Seidel on the
+    DUAL problem (forces, box bounds; no Hessian, no line search, no warm start); the Newton solver works on the PRIMAL (accelerations).  On the bench's
+    action stream (contacts, active limits, friction loss in both zones) the two fixed points agree to 1e-9 of the acceleration scale."""
+    from oracle.env_oracle import OracleLockedEnvPhysics
+
+    ora = OracleLockedEnvPhysics(locked_model)
+    ora.settle(30)
+    rng = np.random.RandomState(20200901 + 1)
+    worst, seen_contacts = 0.0, 0
+    for k in range(25):
+        ora.env_step(rng.uniform(-1, 1, 20))
+        s = ora.sim
+        for _ in range(2):                      # mid-step states too: one more mj_step, then the forward whose rows are compared
+            s.step()
+        s.forward()
+        q, sweeps = s.solve_pgs(max_sweeps=400000, tol=1e-11)
+        assert sweeps > 0
+        worst = max(worst, float(np.abs(q - s.qacc).max() / max(1.0, np.abs(s.qacc).max())))
+        seen_contacts += s.ncon
+    assert worst < 1e-9 and seen_contacts > 40

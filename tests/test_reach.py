@@ -193,3 +193,35 @@ def test_reach_env_1000_steps_gpu(reach_model, oracle_lib, kernel_variant):
     assert max(st["tip_err"]) < t(2e-4, 1e-3) and np.median(st["tip_err"]) < 2e-6 and max(st["rew_err"]) < t(5e-4, 1e-3)
     assert st["goals"] >= 3 and st["timeouts"] >= 2 and max(st["goal_err"]) < t(5e-4, 1e-3)
     assert int(env.sim.status.max()) == 0 and int(env.goal_simulation.status.max()) == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# FREE-RUNNING parity on a contact-light protocol (north_star: "qpos drift <= 1e-4 vs reference over 1000 steps"; SURVEY section 7 hard part 3;
+# VERDICT r03 "missing" 7 / item 6 i): no re-synchronisation — both sides start from the same bytes and run 1000 env.steps on their own.
+def _smooth_actions(nsteps, nu, amp, seed):
+    """a slowly varying action stream: per actuator a sum of two sinusoids (periods 60 - 400 env.steps), amplitude `amp`"""
+    rng = np.random.RandomState(seed)
+    t = np.arange(nsteps)[:, None]
+    p1, p2 = rng.uniform(60, 200, nu), rng.uniform(200, 400, nu)
+    ph1, ph2 = rng.uniform(0, 2 * np.pi, nu), rng.uniform(0, 2 * np.pi, nu)
+    return amp * (0.6 * np.sin(2 * np.pi * t / p1 + ph1) + 0.4 * np.sin(2 * np.pi * t / p2 + ph2))
+
+
+@pytest.mark.gpu
+def test_reach_free_running_1000_steps_gpu(reach_model, oracle_lib):
+    """dactyl/reach (configs[0], the hand alone), 1000 env.steps = 10 000 mj_steps under a smooth relative-action stream, product default on
+    the kernel side, oracle default on the other, NO re-synchronisation: qpos L-infinity <= 1e-4 at every step."""
+    sim = ReachSimulation(reach_model, 2, device="cuda:0")
+    ora = OracleReachPhysics(reach_model)
+    ora.zero_control_settle(20)
+    _sync(sim, ora)
+    acts = _smooth_actions(1000, 20, 0.08, 11)
+    err = np.zeros(1000)
+    for k in range(1000):
+        sim.env_step(action=torch.tensor(np.repeat(acts[k][None].astype(np.float32), 2, 0), device=sim.device), nforward_ticks=3)
+        ora.env_step(acts[k].astype(np.float32).astype(np.float64))
+        err[k] = np.abs(sim.qpos[0].cpu().numpy().astype(np.float64) - ora.sim.qpos).max()
+    moved = np.abs(ora.sim.qpos - reach_model.arrays["qpos0"]).max()
+    print("reach free-running: qpos Linf at steps 1 / 10 / 100 / 1000 = %.1e / %.1e / %.1e / %.1e, max over the run %.1e (joints moved up to %.2f rad)"
+          % (err[0], err[9], err[99], err[999], err.max(), moved))
+    assert err.max() <= 1e-4 and moved > 0.2 and int(sim.status.max()) == 0
