@@ -10,6 +10,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # with worker processes (tests/_parallel_cpu.py) the two test-harness libraries are built ONCE, by the controller, before the workers start
+    if not hasattr(config, "workerinput") and getattr(config.option, "numprocesses", None):
+        import subprocess
+
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "emul"), "-s"])
+        from oracle import rg_oracle
+
+        rg_oracle.build(); rg_oracle.build(f32=True)
 
 
 @pytest.fixture(scope="session")
