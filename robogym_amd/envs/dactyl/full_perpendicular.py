@@ -393,6 +393,8 @@ class BatchedFullPerpendicularEnv:
     def reset(self, mask: Optional[torch.Tensor] = None):
         """RobotEnv.reset (robot_env.py:757-792) for the envs selected by `mask` (default: all)."""
         B, dev = self.batch_size, self.device
+        if mask is not None and not bool(mask.any()):      # `reset(mask=done)` on a step where nothing ended: one sync instead of the ~35-launch recipe
+            return self.observe()
         mask = torch.ones(B, dtype=torch.bool, device=dev) if mask is None else mask.to(dev).bool()
         self.t.masked_fill_(mask, 0)
         self._phase.masked_fill_(mask, 0); self._tries.masked_fill_(mask, 0); self._hold.masked_fill_(mask, 0); self._nticks.masked_fill_(mask, 3)

@@ -568,13 +568,13 @@ class BatchedDactylCubeWrappers:
         if self.auto_reset:
             self._action_noise_reset(started)
             if self.randomize:
-                self._randomize_before_reset(done)        # the episode is over: its env restarts on the next step, with the new parameters
                 sim = self.env.mujoco_simulation
-                restarted = done & info["resetting"].bool()
+                restarted = done & info["resetting"].bool()     # the envs the env kernel really restarts: parameters, constants and ctrl change for exactly these
+                self._randomize_before_reset(restarted)   # the episode is over: its env restarts on the next step, with the new parameters
                 sim.set_constants(restarted)              # cube_env.py:346-349: mj_setConst after the model was written, before the recipe runs
                 # the env kernel wrote the recipe's first ctrl (zero action = mid-range) from the OLD episode's ctrl range: rewrite it
                 cr = sim.params["actuator_ctrlrange"]
                 sim.copy_rows(_native.RG_F_CTRL, (0.5 * (cr[..., 0] + cr[..., 1])).contiguous(), restarted)
                 for key, val in self._pending_delta:      # (their observation entries switch when the new episode starts)
-                    self._next_delta[key] = val if key not in self._next_delta else torch.where(_bmask(done, val), val, self._next_delta[key].to(val.dtype))
+                    self._next_delta[key] = val if key not in self._next_delta else torch.where(_bmask(restarted, val), val, self._next_delta[key].to(val.dtype))
         return out, reward, done, info
