@@ -262,7 +262,9 @@ int rg_lds_bytes_cfg(int config);
  *                                          (robot_env.py:497-504,677, simulation_interface.py:176-189); flags bit 0: stage dump, bit 4:
  *                                          portal-plane contact depth (as rg_batch_step)
  *   rb_model_info: out = nq, nv, nu, nbody, njnt, ngeom, nsite, ntendon, nM, npair, ngroup, gmax, maxcon, maxrow, scratch words,
- *                  contact record words, row record words, contact dof width, tendon dof width, LDS bytes per workgroup */
+ *                  contact record words, row record words, contact dof width, tendon dof width, LDS bytes per workgroup, threads per
+ *                  workgroup (the kernel configuration the model runs on: 256 = large, 64 = small / one wave per env; the small one is used
+ *                  when the model fits it, RB_CONFIG=large in the environment forces the large one) */
 typedef struct rb_model rb_model;
 typedef struct rb_batch rb_batch;
 rb_model* rb_model_create(const void* blob, size_t nbytes, char* err, int errlen);

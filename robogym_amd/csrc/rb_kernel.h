@@ -14,10 +14,14 @@
 // six basis Jacobians per contact on the union of the two bodies' dof chains.  Solver: primal Newton with exact line
 // search (mj_solNewton), dense Cholesky per group.  Arithmetic follows oracle/rg_oracle.c stage by stage; this first
 // version is written for clarity and parity, not yet for speed.
-#pragma once
+// The file is included once per CONFIGURATION (rg_api.hip): RB_NS = namespace, RB_T = threads per workgroup (a multiple of 64),
+// RB_MAXGROUP / RB_MAXNV / RB_MAXNQ = LDS capacities, RB_WG_PER_CU = waves per SIMD the registers are budgeted for.
 #include "rb_types.h"
+#if !defined(RB_NS) || !defined(RB_T) || !defined(RB_MAXGROUP) || !defined(RB_MAXNV) || !defined(RB_MAXNQ)
+#error "rb_kernel.h: define RB_NS, RB_T, RB_MAXGROUP, RB_MAXNV, RB_MAXNQ before including"
+#endif
 
-namespace rgb {
+namespace RB_NS {
 using namespace rgl;   // small math, wave collectives and the MPR / support routines of rg_kernel.h
 
 #ifdef RG_EMUL
@@ -34,6 +38,8 @@ typedef const RG_AS4 RbLaunch& RbLRef;
 #define WL (TID & 63)
 #define BFOR(i, n) for (int i = TID; i < (n); i += RB_T)
 #define BSYNC() __syncthreads()
+#define RB_NWAVE (RB_T / 64)
+#define RB_TS (RB_T >= 256 ? 16 : 8)   /* side of the thread tile in the trailing update of the Cholesky (RB_TS^2 <= RB_T) */
 #define RB_MINVAL 1e-15f
 #ifndef RB_WG_PER_CU
 #define RB_WG_PER_CU 4   /* resident workgroups per CU the kernel is compiled for (register budget 512 / RB_WG_PER_CU per lane) */
@@ -55,8 +61,8 @@ struct RbLds {
   float qa[RB_MAXNV], Ma[RB_MAXNV], grad[RB_MAXNV], search[RB_MAXNV], Mv[RB_MAXNV], qfrc_con[RB_MAXNV], x[RB_MAXNV];
   float red[16];
   float prof[16];
-  int wcnt[4];
-  int ncand, ncon, nefc, nlim, stop;
+  int wcnt[RB_NWAVE < 4 ? 4 : RB_NWAVE];
+  int ncand, ncand2, ncon, nefc, nlim, stop;   // (ncand2: box - box / plane - box candidates, listed from the END of the candidate array)
   int neqcon;            // equality constraints of this mj_step: they are the first records of the contact list
   float mocap[14];       // pose of the mocap bodies (mjData.mocap_pos / mocap_quat), at most two
   float time;            // mjData.time (the cascaded-PI controller warm-starts its smoothed set-point at time 0)
@@ -66,17 +72,23 @@ struct RbLds {
 // ------------------------------------------------------------------------------------------------- block collectives
 __device__ __forceinline__ float rb_sum(RbLds& s, float v) {
   float w = wave_sum(v);
+  if (RB_NWAVE == 1) { BSYNC(); return w; }   // (one wave: the barrier is only the memory fence callers count on)
   BSYNC();
   if (WL == 0) s.red[WID] = w;
   BSYNC();
-  return (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]);
+  if (RB_NWAVE == 4) return (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]);
+  float t = 0.f; for (int k = 0; k < RB_NWAVE; k++) t += s.red[k];
+  return t;
 }
 __device__ __forceinline__ void rb_sum3(RbLds& s, float& a, float& b, float& c) {
   float wa = wave_sum(a), wb = wave_sum(b), wc = wave_sum(c);
+  if (RB_NWAVE == 1) { BSYNC(); a = wa; b = wb; c = wc; return; }
   BSYNC();
   if (WL == 0) { s.red[WID] = wa; s.red[4 + WID] = wb; s.red[8 + WID] = wc; }
   BSYNC();
-  a = (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]); b = (s.red[4] + s.red[5]) + (s.red[6] + s.red[7]); c = (s.red[8] + s.red[9]) + (s.red[10] + s.red[11]);
+  if (RB_NWAVE == 4) { a = (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]); b = (s.red[4] + s.red[5]) + (s.red[6] + s.red[7]); c = (s.red[8] + s.red[9]) + (s.red[10] + s.red[11]); return; }
+  a = b = c = 0.f;
+  for (int k = 0; k < RB_NWAVE; k++) { a += s.red[k]; b += s.red[4 + k]; c += s.red[8 + k]; }
 }
 // slot of this thread's item in a list that grows in thread order (all threads call; -1: no item, or the list is full)
 __device__ __forceinline__ int rb_slot(RbLds& s, bool pred, int* cnt, int cap, unsigned full_bit) {
@@ -89,7 +101,7 @@ __device__ __forceinline__ int rb_slot(RbLds& s, bool pred, int* cnt, int cap, u
   int slot = base + __popcll(bal & ((1ull << WL) - 1ull));
   if (pred && slot >= cap) { s.status |= full_bit; }
   BSYNC();
-  if (TID == 0) { int n = *cnt + s.wcnt[0] + s.wcnt[1] + s.wcnt[2] + s.wcnt[3]; *cnt = n < cap ? n : cap; }
+  if (TID == 0) { int n = *cnt; for (int k = 0; k < RB_NWAVE; k++) n += s.wcnt[k]; *cnt = n < cap ? n : cap; }
   BSYNC();
   return (pred && slot < cap) ? slot : -1;
 }
@@ -330,7 +342,7 @@ __device__ __forceinline__ void rb_M_block(RbM m, RbLds& s, const float* Msp, in
 // register budget of four resident workgroups that array lived in scratch and the step cost 6.9 k cycles per block.)
 #define RB_NB 8
 __device__ __forceinline__ bool rb_chol(RbLds& s, int n) {
-  const int ty = TID >> 4, tx = TID & 15;
+  const int ty = TID / RB_TS, tx = TID % RB_TS;   // (threads beyond RB_TS^2 do not exist: RB_T = 256 / 16 or 64 / 8)
   bool ok = true;
   for (int kb = 0; kb < n; kb += RB_NB) {
     const int nb = n - kb < RB_NB ? n - kb : RB_NB;
@@ -396,7 +408,7 @@ __device__ __forceinline__ bool rb_chol(RbLds& s, int n) {
     // (b) trailing update: A[i][j] -= sum_c L[i][kb + c] L[j][kb + c], i, j >= kb + RB_NB
     const int t0 = kb + RB_NB;
     if (t0 < n) {
-      constexpr int NT = RB_MAXGROUP / 16;
+      constexpr int NT = (RB_MAXGROUP + RB_TS - 1) / RB_TS;
       float acc[NT][NT];
 #pragma unroll
       for (int qa = 0; qa < NT; qa++)
@@ -406,8 +418,8 @@ __device__ __forceinline__ bool rb_chol(RbLds& s, int n) {
       for (int half = 0; half < 2; half++) {
         float li[NT][RB_NB / 2], lj[NT][RB_NB / 2];
 #pragma unroll
-        for (int q = 0; q < NT; q++) if (t0 + 16 * q < n) {   // (uniform: tile rows / columns beyond the block hold nothing)
-          const int ii = t0 + ty + 16 * q, jj = t0 + tx + 16 * q;
+        for (int q = 0; q < NT; q++) if (t0 + RB_TS * q < n) {   // (uniform: tile rows / columns beyond the block hold nothing)
+          const int ii = t0 + ty + RB_TS * q, jj = t0 + tx + RB_TS * q;
 #pragma unroll
           for (int c = 0; c < RB_NB / 2; c++) {
             li[q][c] = ii < n ? s.A[RB_TRI(ii, kb + half * (RB_NB / 2) + c)] : 0.f;
@@ -415,7 +427,7 @@ __device__ __forceinline__ bool rb_chol(RbLds& s, int n) {
           }
         }
 #pragma unroll
-        for (int qa = 0; qa < NT; qa++) if (t0 + 16 * qa < n)
+        for (int qa = 0; qa < NT; qa++) if (t0 + RB_TS * qa < n)
 #pragma unroll
           for (int qb = 0; qb < NT; qb++) if (qb <= qa)       // lower triangle of tiles only
 #pragma unroll
@@ -423,10 +435,10 @@ __device__ __forceinline__ bool rb_chol(RbLds& s, int n) {
       }
       // (the operands sit in columns kb .. kb + RB_NB - 1, the stores go to columns >= t0: no barrier in between)
 #pragma unroll
-      for (int qa = 0; qa < NT; qa++) if (t0 + 16 * qa < n)
+      for (int qa = 0; qa < NT; qa++) if (t0 + RB_TS * qa < n)
 #pragma unroll
         for (int qb = 0; qb < NT; qb++) if (qb <= qa) {
-          const int ii = t0 + ty + 16 * qa, jj = t0 + tx + 16 * qb;
+          const int ii = t0 + ty + RB_TS * qa, jj = t0 + tx + RB_TS * qb;
           if (ii < n && jj <= ii) s.A[RB_TRI(ii, jj)] -= acc[qa][qb];
         }
     }
@@ -632,6 +644,65 @@ __device__ __forceinline__ void rb_star_group_solve(RbM m, RbLds& s, const float
   for (int t = m.b_tree_adr[g]; t < m.b_tree_adr[g + 1]; t++) rb_star_solve(m, s, Msp, t, diag, dscale, src, dst, scale);
 }
 
+// Models whose trees all have <= 8 dofs in one contiguous range (b_tree8 = [count, (first dof, dofs) ...]: the rearrange worlds -- one arm +
+// gripper tree, one free body per object): groups of 8 lanes factor one tree each, all trees at once.  Lane r of a group holds row r of the
+// tree's block of M (+ dscale diag) in registers; pivots and multipliers travel by lane exchange inside the group (no barrier, no LDS), the factor
+// is parked in LDS only for the transposed reads of the backward substitution.  dst[tree dofs] = scale * inv(M_t + dscale diag) src[tree dofs].
+// (rb_star_solve, one tree after the other with a redundant 6 x 6 Schur system per thread, was 11 % of the rearrange step.)
+// value of lane `src` (a per-lane index: ds_bpermute; lane_bcast = v_readlane needs a wave-uniform one)
+__device__ __forceinline__ float grp8_get(float v, int src) { return __shfl(v, src); }
+__device__ __forceinline__ void rb_trees8_solve(RbM m, RbLds& s, const float* Msp, const float* diag, float dscale, const float* src, float* dst, float scale) {
+  const int nt = m.b_tree8[0];
+  bool ok = true;
+  for (int base = 0; base < nt; base += RB_T / 8) {
+    const int t = base + (TID >> 3), r = TID & 7, g0 = WL & ~7;
+    const bool on = t < nt;
+    const int first = on ? m.b_tree8[1 + 2 * t] : 0, n = on ? m.b_tree8[2 + 2 * t] : 0;
+    float Lr[8], idg[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) Lr[q] = (q == r && r >= n) ? 1.f : 0.f;   // (identity padding beyond the tree's dofs)
+    if (r < n) {
+      // row i of M in tree-sparse storage: (i, i), (i, parent), (i, grandparent), ... -- the columns between them are structural zeros
+      const int i = first + r;
+      int e = m.b_M_adr[i], j = i;
+#pragma unroll
+      for (int q = 7; q >= 0; q--) if (j == first + q) {
+        float v = Msp[e];
+        if (j == i && diag) v += dscale * diag[i];
+        Lr[q] = v; e++; j = m.dof_parentid[j];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const float d = grp8_get(Lr[c], g0 + c);
+      if (c < n && !(d > RB_MINVAL)) ok = false;
+      idg[c] = rg_rsqrt(fmaxf(d, RB_MINVAL));
+      Lr[c] = (r == c) ? fmaxf(d, RB_MINVAL) * idg[c] : Lr[c] * idg[c];
+#pragma unroll
+      for (int q = 0; q < 8; q++) if (q > c) { const float lqc = grp8_get(Lr[c], g0 + q); Lr[q] -= Lr[c] * lqc; }
+    }
+    float x = r < n ? src[first + r] : 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {          // L y = b
+      const float yc = grp8_get(x, g0 + c) * idg[c];
+      if (r == c) x = yc; else if (r > c) x -= Lr[c] * yc;
+    }
+    float* Lt = s.A + 64 * (TID >> 3);
+    BSYNC();                               // (s.A may still be read as the previous trip's factor)
+#pragma unroll
+    for (int q = 0; q < 8; q++) Lt[8 * r + q] = q <= r ? Lr[q] : 0.f;
+    BSYNC();
+#pragma unroll
+    for (int c = 7; c >= 0; c--) {         // L' z = y
+      const float zc = grp8_get(x, g0 + c) * idg[c];
+      if (r == c) x = zc; else if (r < c) x -= Lt[8 * c + r] * zc;
+    }
+    if (r < n) dst[first + r] = scale * x;
+  }
+  if (__ballot(!ok) != 0ull && WL == 0) s.status |= RG_STATUS_BAD_FACTOR;
+  BSYNC();
+}
+
 // ------------------------------------------------------------------------------------------------- velocity stage
 // mj_comVel, mj_passive, mj_rne (zero acceleration: Coriolis, centrifugal, gravity)
 __device__ __forceinline__ void rb_velocity(RbM m, RbLds& s, float* S) {
@@ -822,25 +893,76 @@ __device__ __forceinline__ bool rb_plane_box_lane(v3 pn, v3 bp, q4 bq, v3 sz, fl
   pos = c - pn * (0.5f * dist);
   return dist <= margin;
 }
+// Oriented boxes (b_geom_aabb: centre and half extents in the geom's frame, the hull's for a mesh) further apart than `margin`: the
+// separating-axis test on the 15 axes (faces of A, faces of B, edge x edge).  Conservative -- eps keeps near-parallel edge pairs from
+// producing a false separation, the slack absorbs the rounding of the frames --, so a pruned pair cannot hold a contact.
+__device__ __forceinline__ bool rb_obb_apart(v3 ca, q4 qa, v3 ha, v3 cb, q4 qb, v3 hb, float margin) {
+  const v3 ax[3] = {qrot(qa, mk3(1, 0, 0)), qrot(qa, mk3(0, 1, 0)), qrot(qa, mk3(0, 0, 1))};
+  const v3 bx[3] = {qrot(qb, mk3(1, 0, 0)), qrot(qb, mk3(0, 1, 0)), qrot(qb, mk3(0, 0, 1))};
+  const v3 d = cb - ca;
+  const float t[3] = {dot(d, ax[0]), dot(d, ax[1]), dot(d, ax[2])};
+  const float a[3] = {ha.x, ha.y, ha.z}, b[3] = {hb.x, hb.y, hb.z};
+  float R[3][3], Q[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) { R[i][j] = dot(ax[i], bx[j]); Q[i][j] = fabsf(R[i][j]) + 1e-6f; }
+  const float mg = margin + 1e-5f;
+  bool apart = false;
+#pragma unroll
+  for (int i = 0; i < 3; i++) apart = apart || fabsf(t[i]) > a[i] + b[0] * Q[i][0] + b[1] * Q[i][1] + b[2] * Q[i][2] + mg;
+#pragma unroll
+  for (int j = 0; j < 3; j++) apart = apart || fabsf(t[0] * R[0][j] + t[1] * R[1][j] + t[2] * R[2][j]) > a[0] * Q[0][j] + a[1] * Q[1][j] + a[2] * Q[2][j] + b[j] + mg;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      apart = apart || fabsf(t[i2] * R[i1][j] - t[i1] * R[i2][j]) > a[i1] * Q[i2][j] + a[i2] * Q[i1][j] + b[j1] * Q[i][j2] + b[j2] * Q[i][j1] + mg;
+    }
+  return apart;
+}
 __device__ __forceinline__ void rb_collision(RbM m, RbLds& s, float* S, int flags) {
   int* cand = (int*)SC(CAND);
   const float *gpos = SC(GPOS), *gquat = SC(GQUAT);
-  if (TID == 0) { s.ncand = 0; s.ncon = s.neqcon; }
+  if (TID == 0) { s.ncand = 0; s.ncand2 = 0; s.ncon = s.neqcon; }
   BSYNC();
   const bool multipoint = !(flags & 16);   // box - box and plane - box pairs have their own multi-point routines (bit 4: everything through MPR / the support map)
-  // broadphase: the static pair list against bounding spheres (planes: distance of the sphere to the plane)
+  const bool obb = !(flags & 2048);        // (bit 11: bounding spheres only, the test switch of the oriented-box prune)
+  const int halfcand = m.maxcand >> 1;
+  // broadphase: the static pair list against bounding spheres (planes: distance of the sphere to the plane), then the geoms' oriented boxes.
+  // Two lists: pairs for the support-map routines from the front of the candidate array, box - box / plane - box pairs from its end
   for (int base = 0; base < m.npair; base += RB_T) {
     const int p = base + TID;
-    bool keep = false;
+    bool keep = false, special = false;
     if (p < m.npair) {
-      const int g1 = m.b_pair_geom[3 * p], g2 = m.b_pair_geom[3 * p + 1];
+      const int g1 = m.b_pair_geom[3 * p], g2 = m.b_pair_geom[3 * p + 1], t1 = m.geom_type[g1];
       const float margin = m.b_pair_prm[12 * p];
-      const v3 dif = ld3(gpos + 3 * g2) - ld3(gpos + 3 * g1);
-      if (m.geom_type[g1] == RG_GEOM_PLANE) keep = dot(dif, qrot(ldq(gquat + 4 * g1), mk3(0, 0, 1))) <= m.geom_rbound[g2] + margin;
-      else { const float bound = m.geom_rbound[g1] + m.geom_rbound[g2] + margin; keep = dot(dif, dif) <= bound * bound; }
+      const v3 P1 = ld3(gpos + 3 * g1), P2 = ld3(gpos + 3 * g2), dif = P2 - P1;
+      const float* bb = m.b_geom_aabb + 6 * g2;
+      if (t1 == RG_GEOM_PLANE) {
+        const v3 pn = qrot(ldq(gquat + 4 * g1), mk3(0, 0, 1));
+        keep = dot(dif, pn) <= m.geom_rbound[g2] + margin;
+        if (keep && obb) {
+          const q4 q2 = ldq(gquat + 4 * g2);
+          const v3 c2 = dif + qrot(q2, ld3(bb)), nl = qrotT(q2, pn);
+          keep = dot(c2, pn) - (bb[3] * fabsf(nl.x) + bb[4] * fabsf(nl.y) + bb[5] * fabsf(nl.z)) <= margin + 1e-5f;
+        }
+      } else {
+        const float bound = m.geom_rbound[g1] + m.geom_rbound[g2] + margin;
+        keep = dot(dif, dif) <= bound * bound;
+        if (keep && obb) {
+          const float* ba = m.b_geom_aabb + 6 * g1;
+          const q4 q1 = ldq(gquat + 4 * g1), q2 = ldq(gquat + 4 * g2);
+          keep = !rb_obb_apart(qrot(q1, ld3(ba)), q1, ld3(ba + 3), dif + qrot(q2, ld3(bb)), q2, ld3(bb + 3), margin);
+        }
+      }
+      special = multipoint && m.geom_type[g2] == RG_GEOM_BOX && (t1 == RG_GEOM_BOX || t1 == RG_GEOM_PLANE);
     }
-    const int slot = rb_slot(s, keep, &s.ncand, m.maxcand, RG_STATUS_CAND_FULL);
+    const int slot = rb_slot(s, keep && !special, &s.ncand, halfcand, RG_STATUS_CAND_FULL);
     if (slot >= 0) cand[slot] = p;
+    const int slot2 = rb_slot(s, keep && special, &s.ncand2, halfcand, RG_STATUS_CAND_FULL);
+    if (slot2 >= 0) cand[m.maxcand - 1 - slot2] = p;
   }
   BSYNC();   // (the last trip's candidates are written after rb_slot's barrier: the narrowphase below reads them from other waves)
   // narrowphase: one quad per candidate, 64 candidates per trip
@@ -855,7 +977,7 @@ __device__ __forceinline__ void rb_collision(RbM m, RbLds& s, float* S, int flag
     A.margin = B.margin = 0; A.mesh = B.mesh = -1; A.vertadr = B.vertadr = 0; A.nvert = B.nvert = 0;
     float margin = 0;
     v3 p1 = mk3(0, 0, 0);
-    bool plane = false, special = false;
+    bool plane = false; const bool special = false;   // (box pairs are on the second list)
     if (active) {
       p = cand[ci];
       const int g1 = m.b_pair_geom[3 * p], g2 = m.b_pair_geom[3 * p + 1];
@@ -865,7 +987,6 @@ __device__ __forceinline__ void rb_collision(RbM m, RbLds& s, float* S, int flag
       A.pos = mk3(0, 0, 0); B.pos = ld3(gpos + 3 * g2) - p1;
       plane = A.type == RG_GEOM_PLANE;
       A.margin = B.margin = plane ? 0.f : 0.5f * margin;
-      special = multipoint && B.type == RG_GEOM_BOX && (A.type == RG_GEOM_BOX || plane);
     }
     v3 sep, dir = mk3(0, 0, 0); float depth = 0;
     // (the quads of a wave take the two branches with their own lanes: the group collectives inside only need the quad)
@@ -900,11 +1021,12 @@ __device__ __forceinline__ void rb_collision(RbM m, RbLds& s, float* S, int flag
   }
   // box - box (mjc_BoxBox, up to 8 contacts) and plane - box (up to 4 corners): 32 lanes per pair, 8 pairs per trip
   if (multipoint) {
-    for (int base = 0; base < ncand; base += RB_T / 32) {
+    const int ncand2 = s.ncand2;
+    for (int base = 0; base < ncand2; base += RB_T / 32) {
       const int ci = base + (TID >> 5), l = TID & 31;
       bool hit = false, planebox = false; float dist = 0; v3 pos = mk3(0, 0, 0), nrm = mk3(0, 0, 1); int p = 0;
-      if (ci < ncand) {
-        p = cand[ci];
+      if (ci < ncand2) {
+        p = cand[m.maxcand - 1 - ci];
         const int g1 = m.b_pair_geom[3 * p], g2 = m.b_pair_geom[3 * p + 1], t1 = m.geom_type[g1];
         if (m.geom_type[g2] == RG_GEOM_BOX && (t1 == RG_GEOM_BOX || t1 == RG_GEOM_PLANE)) {
           const float margin = m.b_pair_prm[12 * p];
@@ -1421,25 +1543,38 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
   // the dofs' rows in the block, the weights -- is staged through LDS by one load per thread while the previous contact is being
   // added: a thread adding an entry then reads LDS only.  (Reading them from the scratch row cost ~30 global loads per thread and
   // contact: 40 % of the kernel's vector memory instructions.)
-  // (RB_CST <= RB_T: one word per thread; the load is issued before the current contact is added, the LDS store after it, so that the
+  // (one word per thread at 256 threads, three at 64; the load is issued before the current contact is added, the LDS store after it, so that the
   //  load's latency is covered by the adding instead of being waited for in front of it)
-  auto stage_load = [&](int c) -> float {
-    const int t = TID;
-    if (t >= RB_CST) return 0.f;
-    if (t < 6 * RB_CONW) return cj[6 * RB_CONW * c + t];
-    if (t < 7 * RB_CONW) { const int d = cidx[RB_CONW * c + t - 6 * RB_CONW]; return (float)((d >= 0 && d < m.nv) ? m.b_dof_local[d] : 0); }
-    if (t < 7 * RB_CONW + RB_NW) return Wc[RB_NW * c + t - 7 * RB_CONW];
-    return con[RB_CONREC * c + (t == 7 * RB_CONW + RB_NW ? RB_CR_NNZ : RB_CR_DIM)];
+  constexpr int NST = (RB_CST + RB_T - 1) / RB_T;   // words per thread (1 at 256 threads)
+  struct Staged { float v[NST]; };
+  auto stage_load = [&](int c) -> Staged {
+    Staged r;
+#pragma unroll
+    for (int k = 0; k < NST; k++) {
+      const int t = TID + k * RB_T;
+      float v = 0.f;
+      if (t < 6 * RB_CONW) v = cj[6 * RB_CONW * c + t];
+      else if (t < 7 * RB_CONW) { const int d = cidx[RB_CONW * c + t - 6 * RB_CONW]; v = (float)((d >= 0 && d < m.nv) ? m.b_dof_local[d] : 0); }
+      else if (t < 7 * RB_CONW + RB_NW) v = Wc[RB_NW * c + t - 7 * RB_CONW];
+      else if (t < RB_CST) v = con[RB_CONREC * c + (t == 7 * RB_CONW + RB_NW ? RB_CR_NNZ : RB_CR_DIM)];
+      r.v[k] = v;
+    }
+    return r;
   };
+  auto stage_store = [&](int b, const Staged& r) {
+#pragma unroll
+    for (int k = 0; k < NST; k++) { const int t = TID + k * RB_T; if (t < RB_CST) s.cst[RB_CST * b + t] = r.v[k]; }
+  };
+  const Staged zero = {};
   int buf = 0;
 #ifdef RB_HESS_PROBE
   const long long tprobe = rg_clock();
 #endif
-  { const float v = stage_load(0); if (TID < RB_CST) s.cst[TID] = v; }
-  float next = s.ncon > 1 ? stage_load(1) : 0.f;   // two contacts in flight: the word stored at the end of a pass was requested a whole pass earlier
+  stage_store(0, stage_load(0));
+  Staged next = s.ncon > 1 ? stage_load(1) : zero;   // two contacts in flight: the word stored at the end of a pass was requested a whole pass earlier
   BSYNC();
   for (int c = 0; c < s.ncon; c++, buf ^= 1) {
-    const float after = c + 2 < s.ncon ? stage_load(c + 2) : 0.f;
+    const Staged after = c + 2 < s.ncon ? stage_load(c + 2) : zero;
     const float* K = s.cst + RB_CST * buf;
     const float* W = K + 7 * RB_CONW;
     const float mode = W[RB_NW - 1];
@@ -1468,7 +1603,7 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
         s.A[la >= lb ? RB_TRI(la, lb) : RB_TRI(lb, la)] += v;
       }
     }
-    if (TID < RB_CST) s.cst[RB_CST * (buf ^ 1) + TID] = next;
+    stage_store(buf ^ 1, next);
     next = after;
     BSYNC();
   }
@@ -1649,7 +1784,8 @@ __device__ __forceinline__ void rb_euler(RbM m, RbLds& s, float* S, int flags) {
   const float h = m.timestep;
   BFOR(i, m.nv) s.grad[i] = s.qfrc_smooth[i] + s.qfrc_con[i];
   BSYNC();
-  for (int grp = 0; grp < m.ngroup; grp++) {
+  if (m.b_tree8[0] > 0 && !(flags & 4)) rb_trees8_solve(m, s, SC(MSP), m.dof_damping, h, s.grad, s.search, 1.f);
+  else for (int grp = 0; grp < m.ngroup; grp++) {
     if (m.b_star_grp[4 * grp + 3] && !(flags & 4)) { rb_star_group_solve(m, s, SC(MSP), grp, m.dof_damping, h, s.grad, s.search, 1.f); continue; }
     rb_M_block(m, s, SC(MSP), grp, m.dof_damping, h);
     rb_scale_block(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]);
@@ -1812,7 +1948,8 @@ __global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbMod
     rb_dof_contact_lists(m, s, S);
     rb_pid(m, s, S, true);
     // qacc_smooth = inv(M) qfrc_smooth
-    for (int grp = 0; grp < m.ngroup; grp++) {
+    if (m.b_tree8[0] > 0 && !(flags & 4)) rb_trees8_solve(m, s, SC(MSP), (const float*)0, 0.f, s.qfrc_smooth, s.qacc_smooth, 1.f);
+    else for (int grp = 0; grp < m.ngroup; grp++) {
       if (m.b_star_grp[4 * grp + 3] && !(flags & 4)) { rb_star_group_solve(m, s, SC(MSP), grp, (const float*)0, 0.f, s.qfrc_smooth, s.qacc_smooth, 1.f); continue; }   // (flags bit 2: dense path everywhere, test hook)
       rb_M_block(m, s, SC(MSP), grp, (const float*)0, 0.f);
       rb_scale_block(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]);
@@ -1849,7 +1986,8 @@ __global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbMod
     rb_make_constraint(m, s, S, eqd);
     rb_dof_contact_lists(m, s, S);
     rb_pid(m, s, S, true);
-    for (int grp = 0; grp < m.ngroup; grp++) {
+    if (m.b_tree8[0] > 0 && !(flags & 4)) rb_trees8_solve(m, s, SC(MSP), (const float*)0, 0.f, s.qfrc_smooth, s.qacc_smooth, 1.f);
+    else for (int grp = 0; grp < m.ngroup; grp++) {
       if (m.b_star_grp[4 * grp + 3] && !(flags & 4)) { rb_star_group_solve(m, s, SC(MSP), grp, (const float*)0, 0.f, s.qfrc_smooth, s.qacc_smooth, 1.f); continue; }
       rb_M_block(m, s, SC(MSP), grp, (const float*)0, 0.f);
       rb_scale_block(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]);

@@ -6,14 +6,20 @@
 #pragma once
 #include <stdint.h>
 
-#define RB_T 256          // threads per workgroup (4 waves)
+// Two configurations of rb_kernel.h are compiled (rg_api.hip); a model runs on the smallest one that holds it (rb_model_create):
+//   large: 256 threads (4 waves) per env, 4 workgroups per CU    small: 64 threads (1 wave) per env, 16 workgroups per CU
+#define RB_T_LARGE 256
+#define RB_MAXGROUP_LARGE 96    // dofs of the largest constraint-coupled group of trees: its dense block lives in LDS
+#define RB_MAXNV_LARGE 192      // LDS vectors
+#define RB_MAXNQ_LARGE 192
+#define RB_T_SMALL 64
+#define RB_MAXGROUP_SMALL 40
+#define RB_MAXNV_SMALL 40
+#define RB_MAXNQ_SMALL 48
 #define RB_TENW 8         // dofs a tendon can depend on (big_tables.py TEN_W)
 #define RB_CONW 24        // dofs a contact can depend on (big_tables.py CON_W)
-#define RB_MAXGROUP 96    // dofs of the largest constraint-coupled group of trees: its dense block lives in LDS
 #define RB_STARB 5        // longest chain of a star tree (big_tables.py STAR_B)
 #define RB_MLONG 8        // descendant lists of M longer than this are summed by a wave (big_tables.py MLONG)
-#define RB_MAXNV 192      // LDS vectors
-#define RB_MAXNQ 192
 #define RB_NW 22         // weight words of a contact in the Hessian assembly: 21 (lower triangle of a 6 x 6) + the mode
 
 // arrays of the model blob that are uploaded as they are (field name = blob name)
@@ -27,7 +33,7 @@
   X(actuator_trntype) X(actuator_trnid) X(actuator_forcelimited) X(actuator_biastype) \
   X(body_mocapid) X(eq_type) X(eq_obj1id) X(eq_obj2id) X(sensor_type) X(sensor_objid) X(sensor_adr) \
   X(b_lvl_body) X(b_lvl_adr) X(b_body_lastdof) X(b_subtree_adr) X(b_subtree) X(b_root_list) X(b_M_i) X(b_M_j) X(b_M_adr) \
-  X(b_group_adr) X(b_group_dofs) X(b_dof_group) X(b_dof_local) X(b_pair_geom) X(b_ten_dofs) X(b_fric_dof) X(b_fric_ten) X(b_lim_jnt) X(b_lim_ten) X(b_cell_adr) X(b_Mdesc_adr) X(b_Mdesc_ent) X(b_Mdesc_dof) X(b_dof_fricrow) X(b_star_grp) X(b_tree_adr) X(b_tree_desc) X(b_tree_branch) X(b_tree_brn_end) X(b_Mlong)
+  X(b_group_adr) X(b_group_dofs) X(b_dof_group) X(b_dof_local) X(b_pair_geom) X(b_ten_dofs) X(b_fric_dof) X(b_fric_ten) X(b_lim_jnt) X(b_lim_ten) X(b_cell_adr) X(b_Mdesc_adr) X(b_Mdesc_ent) X(b_Mdesc_dof) X(b_dof_fricrow) X(b_star_grp) X(b_tree_adr) X(b_tree_desc) X(b_tree_branch) X(b_tree_brn_end) X(b_Mlong) X(b_tree8)
 #define RB_FLT_ARRAYS(X) \
   X(body_pos) X(body_quat) X(body_ipos) X(body_iquat) X(body_mass) X(body_inertia) X(body_subtreemass) X(body_invweight0) \
   X(jnt_pos) X(jnt_axis) X(jnt_stiffness) X(jnt_range) X(jnt_margin) X(jnt_solref) X(jnt_solimp) \
@@ -38,7 +44,7 @@
   X(tendon_solref_lim) X(tendon_solimp_lim) X(tendon_solref_fri) X(tendon_solimp_fri) X(tendon_invweight0) \
   X(actuator_gear) X(actuator_ctrlrange) X(actuator_forcerange) X(actuator_gainprm) X(actuator_user) \
   X(eq_solref) X(eq_solimp) X(site_quat) \
-  X(b_pair_prm) X(b_mesh_rec) X(b_cell_blk) X(b_cell_ovf)
+  X(b_pair_prm) X(b_geom_aabb) X(b_mesh_rec) X(b_cell_blk) X(b_cell_ovf)
 
 // per-env scratch row: offsets (in 4-byte words) of the stage arrays
 enum {

@@ -84,7 +84,35 @@ static const char* hipGetErrorString(hipError_t) { return "emul"; }
 #endif
 
 #include "rg_env_kernel.h"
+#define RB_NS rgb            /* large configuration: 4 waves per env (dactyl/full_perpendicular) */
+#define RB_T RB_T_LARGE
+#define RB_MAXGROUP RB_MAXGROUP_LARGE
+#define RB_MAXNV RB_MAXNV_LARGE
+#define RB_MAXNQ RB_MAXNQ_LARGE
+#define RB_WG_PER_CU 4
 #include "rb_kernel.h"
+#undef RB_NS
+#undef RB_T
+#undef RB_MAXGROUP
+#undef RB_MAXNV
+#undef RB_MAXNQ
+#undef RB_WG_PER_CU
+#define RB_NS rgbs           /* small configuration: one wave per env, 16 envs per CU (the rearrange worlds) */
+#define RB_T RB_T_SMALL
+#define RB_MAXGROUP RB_MAXGROUP_SMALL
+#define RB_MAXNV RB_MAXNV_SMALL
+#define RB_MAXNQ RB_MAXNQ_SMALL
+#ifndef RB_SMALL_WAVES
+#define RB_SMALL_WAVES 4     /* waves per SIMD the small configuration's registers are budgeted for (4: 128 VGPRs, 16 envs per CU) */
+#endif
+#define RB_WG_PER_CU RB_SMALL_WAVES
+#include "rb_kernel.h"
+#undef RB_NS
+#undef RB_T
+#undef RB_MAXGROUP
+#undef RB_MAXNV
+#undef RB_MAXNQ
+#undef RB_WG_PER_CU
 #include "rb_env_kernel.h"
 #include "ra_env_kernel.h"
 #define RG_WAVES_PER_SIMD_HOST 3   /* = RG_WAVES_PER_SIMD of rg_kernel.h (its default) */
@@ -847,6 +875,7 @@ struct rb_model {
   std::vector<void*> allocs;
   std::vector<float> qpos0, mocap0, eq_data0;
   std::vector<int> eq_active0;
+  int config = 0;   // 0: large configuration of rb_kernel.h, 1: small
 };
 struct rb_batch {
   const rb_model* model;
@@ -890,8 +919,20 @@ rb_model* rb_model_create(const void* blob, size_t nbytes, char* err, int errlen
   d.nq = iv[0]; d.nv = iv[1]; d.nu = iv[2]; d.nbody = iv[3]; d.njnt = iv[4]; d.ngeom = iv[5]; d.nsite = iv[6]; d.ntendon = iv[7]; d.nmesh = iv[9];
   if (!get_i(B, "b_dims", iv, e)) return bail(e + " (derive_big_tables was not run on the model)", m);
   d.nlevel = iv[0]; d.nM = iv[1]; d.npair = iv[2]; d.ngroup = iv[3]; d.gmax = iv[4]; d.nroot = iv[5]; d.conw = iv[6];
-  if (d.gmax > RB_MAXGROUP) return bail("a constraint-coupled group of trees has more dofs than RB_MAXGROUP", m);
-  if (d.nv > RB_MAXNV || d.nq > RB_MAXNQ || d.nu > 32 || d.conw > RB_CONW) return bail("model exceeds the LDS vector capacities of rb_kernel.h", m);
+  if (d.gmax > RB_MAXGROUP_LARGE) return bail("a constraint-coupled group of trees has more dofs than RB_MAXGROUP", m);
+  if (d.nv > RB_MAXNV_LARGE || d.nq > RB_MAXNQ_LARGE || d.nu > 32 || d.conw > RB_CONW) return bail("model exceeds the LDS vector capacities of rb_kernel.h", m);
+  {
+    // the small configuration (one wave per env) when the model fits it: LDS vectors, the dense block, and the star trees' branch lists
+    // (one thread per branch, 28 words of the block's storage per branch + 27)
+    std::vector<int> td, te;
+    if (!get_i(B, "b_tree_desc", td, e) || !get_i(B, "b_tree_brn_end", te, e)) return bail(e, m);
+    int tmax = 0;
+    for (size_t t = 0; t < te.size() && 4 * t + 3 < td.size(); t++) tmax = std::max(tmax, te[t] - td[4 * t + 3]);
+    const char* force = getenv("RB_CONFIG");
+    const bool fits = d.gmax <= RB_MAXGROUP_SMALL && d.nv <= RB_MAXNV_SMALL && d.nq <= RB_MAXNQ_SMALL && tmax <= RB_T_SMALL &&
+                      28 * tmax + 27 <= RB_MAXGROUP_SMALL * (RB_MAXGROUP_SMALL + 1) / 2 + 8;
+    m->config = (fits && !(force && !strcmp(force, "large"))) ? 1 : 0;
+  }
 #define X(n) if (!get_i(B, #n, iv, e)) return bail(e, m); if (!rb_upload_bytes(m, iv.data(), iv.size() * 4, (const void**)&d.n)) return bail("hipMalloc failed", m);
   RB_INT_ARRAYS(X)
 #undef X
@@ -952,7 +993,7 @@ int rb_model_info(const rb_model* m, int* out, int n) {
   if (!m) return fail("null model");
   const RbModelDev& d = m->dev;
   const int v[] = {d.nq, d.nv, d.nu, d.nbody, d.njnt, d.ngeom, d.nsite, d.ntendon, d.nM, d.npair, d.ngroup, d.gmax, d.maxcon, d.maxrow, d.scratch_words, RB_CONREC, RB_ROWREC, RB_CONW, RB_TENW,
-                   (int)sizeof(rgb::RbLds)};
+                   m->config ? (int)sizeof(rgbs::RbLds) : (int)sizeof(rgb::RbLds), m->config ? RB_T_SMALL : RB_T_LARGE};
   const int k = (int)(sizeof v / sizeof v[0]);
   for (int i = 0; i < k && i < n; i++) out[i] = v[i];
   return k;
@@ -1051,6 +1092,7 @@ void* rb_batch_field_ptr(rb_batch* b, int field, int* row_words) {
 #ifdef RG_EMUL
 struct EmulRbArgs { const RbModelDev* m; RbLaunch launch; };
 static void emul_rb_entry(void* a) { EmulRbArgs* p = (EmulRbArgs*)a; rgb::rb_step_kernel(p->m, p->launch); }
+static void emul_rbs_entry(void* a) { EmulRbArgs* p = (EmulRbArgs*)a; rgbs::rb_step_kernel(p->m, p->launch); }
 #endif
 int rb_batch_step_ex(rb_batch* b, const float* action_dev, const int* active_dev, const int* hold_dev, const int* nticks_dev, int nsubsteps, int nforward_ticks, int flags, void* stream);
 static thread_local const RbTcpHook* g_tcp_hook = nullptr;   // set by rb_batch_step_tcp around its launch
@@ -1088,9 +1130,11 @@ int rb_batch_step_ex(rb_batch* b, const float* action_dev, const int* active_dev
   if (g_tcp_hook) { launch.tcp = *g_tcp_hook; }
 #ifdef RG_EMUL
   EmulRbArgs args{b->model->dev_copy, launch};
-  emul_launch_n(bt.B, RB_T, sizeof(rgb::RbLds), emul_rb_entry, &args);
+  if (b->model->config) emul_launch_n(bt.B, RB_T_SMALL, sizeof(rgbs::RbLds), emul_rbs_entry, &args);
+  else emul_launch_n(bt.B, RB_T_LARGE, sizeof(rgb::RbLds), emul_rb_entry, &args);
 #else
-  hipLaunchKernelGGL(rgb::rb_step_kernel, dim3(bt.B), dim3(RB_T), sizeof(rgb::RbLds), (hipStream_t)stream, b->model->dev_copy, launch);
+  if (b->model->config) hipLaunchKernelGGL(rgbs::rb_step_kernel, dim3(bt.B), dim3(RB_T_SMALL), sizeof(rgbs::RbLds), (hipStream_t)stream, b->model->dev_copy, launch);
+  else hipLaunchKernelGGL(rgb::rb_step_kernel, dim3(bt.B), dim3(RB_T_LARGE), sizeof(rgb::RbLds), (hipStream_t)stream, b->model->dev_copy, launch);
   HIPCHK(hipGetLastError());
 #endif
   return 0;

@@ -163,6 +163,28 @@ def derive_big_tables(model):
     for j in range(len(A["jnt_type"])):
         if A["jnt_stiffness"][j] != 0 and A["jnt_type"][j] not in (C.JNT_HINGE, C.JNT_SLIDE):
             raise NotImplementedError("ball / free joint springs")
+    # oriented bounding box of every geom in its own frame (centre, half extents): the broadphase's second test after the bounding spheres
+    gt, gs = A["geom_type"], np.asarray(A["geom_size"], dtype=np.float64).reshape(-1, 3)
+    mv_all = np.asarray(A["mesh_vert"], dtype=np.float64).reshape(-1, 3)
+    aabb = np.zeros((len(gt), 6), dtype=np.float32)
+    for g in range(len(gt)):
+        t = int(gt[g])
+        if t == C.GEOM_SPHERE:
+            aabb[g, 3:] = gs[g, 0]
+        elif t in (C.GEOM_CAPSULE, C.GEOM_CYLINDER):
+            aabb[g, 3:] = (gs[g, 0], gs[g, 0], gs[g, 1] + (gs[g, 0] if t == C.GEOM_CAPSULE else 0.0))
+        elif t in (C.GEOM_ELLIPSOID, C.GEOM_BOX):
+            aabb[g, 3:] = gs[g]
+        elif t == C.GEOM_MESH:
+            mid = int(A["geom_dataid"][g])
+            v = mv_all[int(A["mesh_vertadr"][mid]):int(A["mesh_vertadr"][mid]) + int(A["mesh_vertnum"][mid])]
+            lo, hi = v.min(axis=0), v.max(axis=0)
+            aabb[g, :3], aabb[g, 3:] = 0.5 * (lo + hi), 0.5 * (hi - lo)
+        elif t == C.GEOM_PLANE:
+            aabb[g, 3:] = 0.0
+        else:
+            raise NotImplementedError("geom type %d" % t)
+    A["b_geom_aabb"] = aabb.reshape(-1)
     # mesh vertices as 16-byte records (x, y, z, vertex index): what the hull scans of the collision code read
     mv = np.asarray(A["mesh_vert"], dtype=np.float32).reshape(-1, 3)
     rec = np.zeros((len(mv), 4), dtype=np.float32)
@@ -264,5 +286,15 @@ def derive_big_tables(model):
     A["b_star_grp"], A["b_tree_adr"], A["b_tree_desc"] = _i32(sgrp).reshape(-1), _i32(tadr), _i32(tdesc).reshape(-1)
     A["b_tree_branch"] = _i32(tbr + [(0, 0)]).reshape(-1)
     A["b_tree_brn_end"] = _i32([d_[3] for d_ in tdesc[1:]] + [len(tbr)])
+    # trees of <= 8 dofs in one contiguous range, all of them (the rearrange worlds): rb_trees8_solve factors them side by side, eight lanes each.
+    # [count, (first dof, dofs) ...]; count 0 = some tree does not qualify and the group-wise solves are used
+    t8 = []
+    for r in trees:
+        td = np.where(tree_of_dof == r)[0].tolist()
+        if len(td) > 8 or td != list(range(td[0], td[-1] + 1)):
+            t8 = None
+            break
+        t8.append((td[0], len(td)))
+    A["b_tree8"] = _i32([len(t8)] + [x for p_ in t8 for x in p_]) if t8 else _i32([0])
     A["b_dims"] = _i32([len(adr) - 1, len(Mi), len(pairs), len(gadr) - 1, max(np.diff(gadr)), len(A["b_root_list"]), wmax])
     return model

@@ -16,7 +16,7 @@ from robogym_amd.mujoco import simulation_interface
 
 SCRATCH = ["xpos", "xquat", "xipos", "xiquat", "xanchor", "xaxis", "geom_xpos", "geom_xquat", "site_xpos", "rootcom", "cinert", "crb", "cdof", "cdof_dot", "cvel",
            "cacc", "cfrc", "ten_length", "ten_J", "ten_velocity", "Msp", "cand", "contact", "contact_J", "contact_idx", "row", "dofcon_adr", "dofcon", "contact_f", "dbg", "cfrc_ext"]
-INFO = ["nq", "nv", "nu", "nbody", "njnt", "ngeom", "nsite", "ntendon", "nM", "npair", "ngroup", "gmax", "maxcon", "maxrow", "scratch_words", "conrec", "rowrec", "conw", "tenw", "lds_bytes"]
+INFO = ["nq", "nv", "nu", "nbody", "njnt", "ngeom", "nsite", "ntendon", "nM", "npair", "ngroup", "gmax", "maxcon", "maxrow", "scratch_words", "conrec", "rowrec", "conw", "tenw", "lds_bytes", "threads"]
 
 
 class LargeModelSimulation:
@@ -28,7 +28,7 @@ class LargeModelSimulation:
         self.device = torch.device("cpu") if self._emul else torch.device(device)
         if not self._emul and not torch.cuda.is_available():
             raise _native.NativeError("LargeModelSimulation needs an MI355X (no CPU fallback)")
-        if "b_dims" not in model.arrays or "b_tree_desc" not in model.arrays or "b_Mlong" not in model.arrays:
+        if "b_dims" not in model.arrays or "b_tree_desc" not in model.arrays or "b_Mlong" not in model.arrays or "b_tree8" not in model.arrays or "b_geom_aabb" not in model.arrays:
             derive_big_tables(model)
         self.model, self.batch_size, self.n_substeps = model, int(batch_size), int(n_substeps)
         blob = pack_model(model)

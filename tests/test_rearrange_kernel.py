@@ -98,6 +98,25 @@ def _stage_dump(models, lib, device):
     assert np.abs(sim.pid[0].cpu().numpy() - o.pid).max() < 1e-5
 
 
+def _obb_prune_is_exact(models, lib, device):
+    """The broadphase's oriented-box test (after the bounding spheres) only removes pairs that cannot hold a contact: with the test switched
+    off (flags bit 11) the contact list and the step are bit-identical, in both worlds."""
+    env = _oracle_env(models, 1, settle=40)
+    for model, o in ((models[0], env.main.sim), (models[1], env.solver.sim)):
+        out = []
+        for flags in (1, 1 | 2048):
+            sim = LargeModelSimulation(model, 1, device=device, n_substeps=1, lib=lib, hand=False)
+            sync_from_oracle(sim, o)
+            sim.env_step(nsubsteps=1, nforward_ticks=0, flags=flags)
+            sim.sync()
+            dbg = sim.scratch("dbg")[0].cpu().numpy()
+            ncon = int(dbg[0])
+            out.append((ncon, sim.scratch("contact")[0].cpu().numpy().reshape(-1, 32)[:ncon].copy(), sim.qpos[0].cpu().numpy().copy(), sim.qvel[0].cpu().numpy().copy()))
+            assert int(sim.status[0]) == 0
+        a, b = out
+        assert a[0] == b[0] and a[0] >= 1 and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+
+
 def _resync_env_steps(models, lib, device, n_substeps, nsteps, seed=1):
     """Re-synchronised env.steps of the dual simulation: `rb_batch_step_tcp` (sync, forward, mocap target, solver mj_steps, main ctrl) then the
     main world's mj_steps + two state-less forwards, the last in full (sensors) — against OracleRearrangeEnv.env_step."""
@@ -142,6 +161,10 @@ def test_rearrange_stage_dump_matches_oracle_emul(models, emul_lib, oracle_lib):
     _stage_dump(models, emul_lib, "cpu")
 
 
+def test_oriented_box_prune_is_exact_emul(models, emul_lib, oracle_lib):
+    _obb_prune_is_exact(models, emul_lib, "cpu")
+
+
 def test_rearrange_resync_env_steps_emul(models, emul_lib, oracle_lib):
     _assert_resync(_resync_env_steps(models, emul_lib, "cpu", n_substeps=3, nsteps=4))
 
@@ -150,6 +173,11 @@ def test_rearrange_resync_env_steps_emul(models, emul_lib, oracle_lib):
 @pytest.mark.gpu
 def test_rearrange_stage_dump_matches_oracle_gpu(models, oracle_lib):
     _stage_dump(models, None, "cuda:0")
+
+
+@pytest.mark.gpu
+def test_oriented_box_prune_is_exact_gpu(models, oracle_lib):
+    _obb_prune_is_exact(models, None, "cuda:0")
 
 
 @pytest.mark.gpu
