@@ -93,43 +93,89 @@ def algorithmic_bytes_sparse(m, nM, ncon, nefc, iters, nsub, obs_dim, jw=16):
     return nsub * b_sub + 4.0 * (nu + obs_dim), b_sub
 
 
-def bench_rearrange_blocks(args, emit=True):
-    """BASELINE.json configs[3]: rearrange/blocks, num_objects = 5 (UR16e + 2f-85 gripper, table contacts), batch 4096 on one MI355X.
+def bench_rearrange_blocks(args, emit=True, ycb=False):
+    """BASELINE.json configs[3]: rearrange/blocks, num_objects = 5 (UR16e + 2f-85 gripper, table contacts), batch 4096 on one MI355X; with `ycb`
+    configs[4]: rearrange/ycb, num_objects = 8 (mesh objects), batch 4096 PER GPU (32768 on 8).
     `BatchedBlockRearrangeEnv.step` = rb_batch_step_tcp (TCP solver world: sync, forward, mocap target, 40 mj_step) + rb_batch_step_ex (main world:
     40 mj_step + 2 forwards, the last in full with sensors) + ra_env_post_step (observation row, reward, goals, tracker), after the reference's reset
-    recipe (grid placement, 100 stabilisation steps, 10 random + 100 zero-action steps).  1 env-step = 80 mj_step of two models."""
+    recipe (grid placement, 100 stabilisation steps, 10 random + 100 zero-action steps).  1 env-step = 80 mj_step of two models.
+    N > 1 (`--gpus N`, one rank per GPU): the envs are sharded, every rank steps its own 4096, the packed observation rows (obs + reward + done) are
+    all-gathered over RCCL behind the next step -- the path's only exchange, as for dactyl/locked."""
     from robogym_amd.envs.rearrange.blocks import BatchedBlockRearrangeEnv
+    from robogym_amd.envs.rearrange.ycb import BatchedYcbRearrangeEnv
 
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(dev)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_with_ranks(args.gpus))
+    rank, local_rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if emit and world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, world))
+    distributed = emit and (world > 1 or os.environ.get("RG_BENCH_FORCE_DIST") == "1")
+    emul_path = os.environ.get("RG_BENCH_EMUL_LIB")      # TEST HOOK (tests/test_distributed.py): this code path on CPU, 2 ranks, gloo, kernel source on the emulation harness
+    lib = None
+    if emul_path:
+        from robogym_amd import _native
+        lib = _native.bind(emul_path)
+        dev = torch.device("cpu")
+    else:
+        dev = torch.device("cuda", local_rank if emit else 0)
+        torch.cuda.set_device(dev)
+    if distributed:
+        import torch.distributed as dist
+
+        dist.init_process_group("gloo") if emul_path else dist.init_process_group("nccl", device_id=dev)
     B = args.batch if args.batch != 8192 else 4096
     quick = bool(getattr(args, "quick_reset", False))
-    env = BatchedBlockRearrangeEnv(B, device=dev, starting_seed=20200901 + 3, **(dict(stabilize_steps=20, n_random_initial_steps=2, settle_steps=20) if quick else {}))
+    kw = dict(stabilize_steps=20, n_random_initial_steps=2, settle_steps=20) if quick else {}
+    if emul_path:
+        kw = dict(stabilize_steps=1, n_random_initial_steps=1, settle_steps=1, n_substeps=1, lib=lib)
+    env = (BatchedYcbRearrangeEnv if ycb else BatchedBlockRearrangeEnv)(B, device=dev, starting_seed=20200901 + 3 + rank, **kw)
+    sync = (lambda: torch.cuda.synchronize(dev)) if not emul_path else (lambda: None)
     t_reset = time.perf_counter()
     env.reset()
-    torch.cuda.synchronize(dev)
+    sync()
     t_reset = time.perf_counter() - t_reset
-    gen = torch.Generator(device=dev); gen.manual_seed(20200901 + 3)
-    step = lambda: env.step(torch.rand((B, 6), generator=gen, device=dev) * 2 - 1)
+    gen = torch.Generator(device=dev); gen.manual_seed(20200901 + 3 + 1000 * rank)
+    from robogym_amd.distributed import ShardedObservationGather
+
+    gather = ShardedObservationGather(B, env.packed.shape[1], dev)
+
+    def step():
+        env.step(torch.rand((B, 6), generator=gen, device=dev) * 2 - 1)
+        gather.start(env.packed)      # the packed row: observation + reward (3) + done
+
     for _ in range(args.warmup):
         step()
     env.sim.stats.zero_(); env.solver_sim.stats.zero_()
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    mk_event = (lambda: torch.cuda.Event(enable_timing=True)) if not emul_path else (lambda: None)
+    ev = [[mk_event() for _ in range(3)] for _ in range(args.steps)]
     orig = env._physics
 
     def timed(actions, active=None, _i=[0]):
         e = ev[_i[0] % len(ev)]; _i[0] += 1
-        e[0].record(); env.solver_sim.step_tcp(env.sim, actions, env.tcp, active=active); e[1].record()
-        env.sim.env_step(nforward_ticks=2, flags=32, active=active); e[2].record()
+        rec = lambda x: x.record() if x is not None else None
+        rec(e[0]); env.solver_sim.step_tcp(env.sim, actions, env.tcp, active=active); rec(e[1])
+        env.sim.env_step(nforward_ticks=2, flags=32, active=active); rec(e[2])
     env._physics = timed
-    torch.cuda.synchronize(dev)
+    if distributed:
+        dist.barrier()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize(dev)
+    gather.finish()
+    if distributed:
+        dist.barrier()
+    sync()
     elapsed = time.perf_counter() - t0
     env._physics = orig
-    ms_solver = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])); ms_main = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if emul_path:
+        ms_solver = ms_main = 0.5e3 * elapsed / args.steps
+    else:
+        ms_solver = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])); ms_main = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
     res = {}
     total_bytes = 0.0
     for name, sim, obs_dim in (("main", env.sim, env.obs_dim), ("solver", env.solver_sim, 0)):
@@ -146,24 +192,29 @@ def bench_rearrange_blocks(args, emit=True):
         total_bytes += bd
     achieved = B * res["main"]["algorithmic_bytes_dense"] / (ms_main * 1e-3)
     out = {
-        "metric": "env-steps/sec rearrange/blocks num_objects=5 batch 4096 (BASELINE.json configs[3]); unwrapped env.step incl. the TCP solver's second simulation; parity vs the in-repo CPU oracle (unpinned)",
-        "value": B * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "metric": ("env-steps/sec (whole node) rearrange/ycb num_objects=8 batch 4096 per GPU (BASELINE.json configs[4]: 32768 on 8 GPUs); FIXED object set per model, "
+                   "unwrapped env.step incl. the TCP solver's second simulation; parity vs the in-repo CPU oracle (unpinned)") if ycb else
+                  "env-steps/sec rearrange/blocks num_objects=5 batch 4096 (BASELINE.json configs[3]); unwrapped env.step incl. the TCP solver's second simulation; parity vs the in-repo CPU oracle (unpinned)",
+        "value": world * B * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "rearrange/blocks (UR16e + 2f-85 gripper + table, 5 blocks: nv=38, elliptic cones, impratio 10) with its TCP solver world (nv=8, mocap weld), batch %d, iid U(-1,1) relative tcp+roll+yaw actions, 40 + 40 substeps x 0.001 s + 2 forwards; after the reset recipe%s" % (B, " (shortened: --quick-reset)" if quick else ""),
-                   "batch_per_gpu": B, "reset_seconds": t_reset, "main": res["main"], "solver": res["solver"], "status_bits": int(max(env.sim.status.max().item(), env.solver_sim.status.max().item())),
+        "config": {"workload": ("rearrange/ycb (UR16e + 2f-85 gripper + table, 8 YCB objects %s as convex-part mesh geoms: nv=56, %d geoms, elliptic cones, impratio 10)" % (getattr(env, "object_names", []), env.sim.info["ngeom"]) if ycb else "rearrange/blocks (UR16e + 2f-85 gripper + table, 5 blocks: nv=38, elliptic cones, impratio 10)") + " with its TCP solver world (nv=8, mocap weld), batch %d, iid U(-1,1) relative tcp+roll+yaw actions, 40 + 40 substeps x 0.001 s + 2 forwards; after the reset recipe%s" % (B, " (shortened: --quick-reset)" if quick else ""),
+                   "batch_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d (envs sharded, all-gather of the packed observation rows)" % world, "collective_backend": (dist.get_backend() if distributed else None), "reset_seconds": t_reset, "main": res["main"], "solver": res["solver"], "status_bits": int(max(env.sim.status.max().item(), env.solver_sim.status.max().item())),
                    "done_fraction_last_step": float(env.done.float().mean().item()), "launch_ms": {"solver_world": ms_solver, "main_world": ms_main}, "lds_bytes_per_workgroup": env.sim.info["lds_bytes"]},
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None, "kernel": "rb_step_kernel (main world launch)", "kernel_ms": ms_main,
                      "algorithmic_bytes_per_env_step": res["main"]["algorithmic_bytes_dense"], "frac_sparse_J": B * res["main"]["algorithmic_bytes_sparse_J"] / (ms_main * 1e-3) / HBM_PEAK,
                      "note": "dominant kernel = the main world's launch; SURVEY 8(d) dense byte model with the run's ncon / nefc / iterations; frac_sparse_J counts a constraint row at <= 16 dofs and M tree-sparse (what the stepper stores)"},
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1 and not emul_path:
         from oracle import cpu_baseline as cb
 
-        out["cpu_baseline"] = cb.run_rearrange_blocks(4.0)
-    if emit:
+        out["cpu_baseline"] = cb.run_rearrange_blocks(4.0, ycb=ycb)
+    if emit and rank == 0:
         print(json.dumps(out, default=float))
+    if distributed:
+        dist.destroy_process_group()
     del env
-    torch.cuda.empty_cache()
+    if not emul_path:
+        torch.cuda.empty_cache()
     return out
 
 
@@ -271,7 +322,7 @@ def bench_locked_variant(args, emit=True, pipelined_reset=False, default_make_en
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="locked", choices=["locked", "full_perpendicular", "rearrange_blocks"], help="locked = BASELINE.json configs[1] (the headline); full_perpendicular = configs[2]; rearrange_blocks = configs[3]")
+    ap.add_argument("--workload", default="locked", choices=["locked", "full_perpendicular", "rearrange_blocks", "ycb"], help="locked = BASELINE.json configs[1] (the headline); full_perpendicular = configs[2]; rearrange_blocks = configs[3]")
     ap.add_argument("--no-secondary", action="store_true", help="headline only: skip the shortened runs of the other built configs that the default line carries under 'secondary'")
     ap.add_argument("--quick-reset", action="store_true", help="rearrange_blocks: a shortened reset recipe (20 / 2 / 20 steps instead of 100 / 10 / 100)")
     ap.add_argument("--gpus", type=int, default=1)
@@ -288,8 +339,8 @@ def main():
 
     if args.workload == "full_perpendicular":
         return bench_full_perpendicular(args)
-    if args.workload == "rearrange_blocks":
-        return bench_rearrange_blocks(args)
+    if args.workload in ("rearrange_blocks", "ycb"):
+        return bench_rearrange_blocks(args, ycb=args.workload == "ycb")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch_with_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))

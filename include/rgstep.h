@@ -333,7 +333,7 @@ typedef struct ra_post_args {
   unsigned char *done, *goal_reset, *trial_success, *sub_goal_ok, *env_crash, *objects_off_table;
   int* info_ssl;
   int obj_body[RA_MAXOBJ], tcp_body, arm_qposadr[6], grip_qposadr, grip_dofadr, grip_act, finger_geom[2], table_plane_geom, force_adr, torque_adr;
-  unsigned long long gripper_geom_mask;          /* geoms of the gripper's bodies (ur16e/mujoco/simulation/base.py:40-52); needs ngeom <= 64 */
+  unsigned long long gripper_geom_mask;          /* geoms of the gripper's bodies (ur16e/mujoco/simulation/base.py:40-52): bit g = geom g, so they need ids < 64 (robot geoms come first) */
   float table_min[2], table_max[2], table_height, pos_threshold, rot_threshold, goal_pos_offset, goal_rot_weight, goal_reward_per_object, success_reward,
       penalty_table_collision, penalty_objects_off_table, penalty_safety_stop, safety_stop_force;
   int max_timesteps_per_goal, successes_needed, use_goal_distance_reward;

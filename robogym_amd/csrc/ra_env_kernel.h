@@ -112,7 +112,8 @@ __global__ void __launch_bounds__(64) ra_post_step_kernel(const RbModelDev* mp, 
       const float* C = con + RB_CONREC * c;
       if ((int)C[RB_CR_KIND] == RB_KIND_EQUALITY) continue;
       const int g1 = (int)C[RB_CR_G1], g2 = (int)C[RB_CR_G2];
-      const int other = ((a.gripper_geom_mask >> g1) & 1ull) ? g2 : (((a.gripper_geom_mask >> g2) & 1ull) ? g1 : -1);
+      const bool in1 = g1 < 64 && ((a.gripper_geom_mask >> g1) & 1ull), in2 = g2 < 64 && ((a.gripper_geom_mask >> g2) & 1ull);
+      const int other = in1 ? g2 : (in2 ? g1 : -1);
       if (other == a.table_plane_geom) table_hit = 1;
     }
   }

@@ -8,6 +8,7 @@
 
 // Two configurations of rb_kernel.h are compiled (rg_api.hip); a model runs on the smallest one that holds it (rb_model_create):
 //   large: 256 threads (4 waves) per env, 4 workgroups per CU    small: 64 threads (1 wave) per env, 16 workgroups per CU
+//   medium: one wave per env as well, capacities for 56 dofs (rearrange with 8 objects), 10 workgroups per CU
 #define RB_T_LARGE 256
 #define RB_MAXGROUP_LARGE 96    // dofs of the largest constraint-coupled group of trees: its dense block lives in LDS
 #define RB_MAXNV_LARGE 192      // LDS vectors
@@ -16,6 +17,10 @@
 #define RB_MAXGROUP_SMALL 40
 #define RB_MAXNV_SMALL 40
 #define RB_MAXNQ_SMALL 48
+#define RB_T_MEDIUM 64
+#define RB_MAXGROUP_MEDIUM 56
+#define RB_MAXNV_MEDIUM 56
+#define RB_MAXNQ_MEDIUM 64
 #define RB_TENW 8         // dofs a tendon can depend on (big_tables.py TEN_W)
 #define RB_CONW 24        // dofs a contact can depend on (big_tables.py CON_W)
 #define RB_STARB 5        // longest chain of a star tree (big_tables.py STAR_B)

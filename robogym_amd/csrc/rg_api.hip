@@ -113,6 +113,19 @@ static const char* hipGetErrorString(hipError_t) { return "emul"; }
 #undef RB_MAXNV
 #undef RB_MAXNQ
 #undef RB_WG_PER_CU
+#define RB_NS rgbm           /* medium configuration: one wave per env, 56 dofs (rearrange/ycb with 8 objects), 10 envs per CU */
+#define RB_T RB_T_MEDIUM
+#define RB_MAXGROUP RB_MAXGROUP_MEDIUM
+#define RB_MAXNV RB_MAXNV_MEDIUM
+#define RB_MAXNQ RB_MAXNQ_MEDIUM
+#define RB_WG_PER_CU 3
+#include "rb_kernel.h"
+#undef RB_NS
+#undef RB_T
+#undef RB_MAXGROUP
+#undef RB_MAXNV
+#undef RB_MAXNQ
+#undef RB_WG_PER_CU
 #include "rb_env_kernel.h"
 #include "ra_env_kernel.h"
 #define RG_WAVES_PER_SIMD_HOST 3   /* = RG_WAVES_PER_SIMD of rg_kernel.h (its default) */
@@ -875,7 +888,7 @@ struct rb_model {
   std::vector<void*> allocs;
   std::vector<float> qpos0, mocap0, eq_data0;
   std::vector<int> eq_active0;
-  int config = 0;   // 0: large configuration of rb_kernel.h, 1: small
+  int config = 0;   // 0: large configuration of rb_kernel.h, 1: small, 2: medium
 };
 struct rb_batch {
   const rb_model* model;
@@ -929,9 +942,14 @@ rb_model* rb_model_create(const void* blob, size_t nbytes, char* err, int errlen
     int tmax = 0;
     for (size_t t = 0; t < te.size() && 4 * t + 3 < td.size(); t++) tmax = std::max(tmax, te[t] - td[4 * t + 3]);
     const char* force = getenv("RB_CONFIG");
-    const bool fits = d.gmax <= RB_MAXGROUP_SMALL && d.nv <= RB_MAXNV_SMALL && d.nq <= RB_MAXNQ_SMALL && tmax <= RB_T_SMALL &&
-                      28 * tmax + 27 <= RB_MAXGROUP_SMALL * (RB_MAXGROUP_SMALL + 1) / 2 + 8;
-    m->config = (fits && !(force && !strcmp(force, "large"))) ? 1 : 0;
+    auto fits = [&](int maxgroup, int maxnv, int maxnq, int threads) {
+      return d.gmax <= maxgroup && d.nv <= maxnv && d.nq <= maxnq && tmax <= threads && 28 * tmax + 27 <= maxgroup * (maxgroup + 1) / 2 + 8;
+    };
+    m->config = 0;
+    if (!(force && !strcmp(force, "large"))) {
+      if (fits(RB_MAXGROUP_SMALL, RB_MAXNV_SMALL, RB_MAXNQ_SMALL, RB_T_SMALL) && !(force && !strcmp(force, "medium"))) m->config = 1;
+      else if (fits(RB_MAXGROUP_MEDIUM, RB_MAXNV_MEDIUM, RB_MAXNQ_MEDIUM, RB_T_MEDIUM)) m->config = 2;
+    }
   }
 #define X(n) if (!get_i(B, #n, iv, e)) return bail(e, m); if (!rb_upload_bytes(m, iv.data(), iv.size() * 4, (const void**)&d.n)) return bail("hipMalloc failed", m);
   RB_INT_ARRAYS(X)
@@ -993,7 +1011,7 @@ int rb_model_info(const rb_model* m, int* out, int n) {
   if (!m) return fail("null model");
   const RbModelDev& d = m->dev;
   const int v[] = {d.nq, d.nv, d.nu, d.nbody, d.njnt, d.ngeom, d.nsite, d.ntendon, d.nM, d.npair, d.ngroup, d.gmax, d.maxcon, d.maxrow, d.scratch_words, RB_CONREC, RB_ROWREC, RB_CONW, RB_TENW,
-                   m->config ? (int)sizeof(rgbs::RbLds) : (int)sizeof(rgb::RbLds), m->config ? RB_T_SMALL : RB_T_LARGE};
+                   m->config == 1 ? (int)sizeof(rgbs::RbLds) : m->config == 2 ? (int)sizeof(rgbm::RbLds) : (int)sizeof(rgb::RbLds), m->config ? RB_T_SMALL : RB_T_LARGE};
   const int k = (int)(sizeof v / sizeof v[0]);
   for (int i = 0; i < k && i < n; i++) out[i] = v[i];
   return k;
@@ -1093,6 +1111,7 @@ void* rb_batch_field_ptr(rb_batch* b, int field, int* row_words) {
 struct EmulRbArgs { const RbModelDev* m; RbLaunch launch; };
 static void emul_rb_entry(void* a) { EmulRbArgs* p = (EmulRbArgs*)a; rgb::rb_step_kernel(p->m, p->launch); }
 static void emul_rbs_entry(void* a) { EmulRbArgs* p = (EmulRbArgs*)a; rgbs::rb_step_kernel(p->m, p->launch); }
+static void emul_rbm_entry(void* a) { EmulRbArgs* p = (EmulRbArgs*)a; rgbm::rb_step_kernel(p->m, p->launch); }
 #endif
 int rb_batch_step_ex(rb_batch* b, const float* action_dev, const int* active_dev, const int* hold_dev, const int* nticks_dev, int nsubsteps, int nforward_ticks, int flags, void* stream);
 static thread_local const RbTcpHook* g_tcp_hook = nullptr;   // set by rb_batch_step_tcp around its launch
@@ -1130,10 +1149,12 @@ int rb_batch_step_ex(rb_batch* b, const float* action_dev, const int* active_dev
   if (g_tcp_hook) { launch.tcp = *g_tcp_hook; }
 #ifdef RG_EMUL
   EmulRbArgs args{b->model->dev_copy, launch};
-  if (b->model->config) emul_launch_n(bt.B, RB_T_SMALL, sizeof(rgbs::RbLds), emul_rbs_entry, &args);
+  if (b->model->config == 1) emul_launch_n(bt.B, RB_T_SMALL, sizeof(rgbs::RbLds), emul_rbs_entry, &args);
+  else if (b->model->config == 2) emul_launch_n(bt.B, RB_T_MEDIUM, sizeof(rgbm::RbLds), emul_rbm_entry, &args);
   else emul_launch_n(bt.B, RB_T_LARGE, sizeof(rgb::RbLds), emul_rb_entry, &args);
 #else
-  if (b->model->config) hipLaunchKernelGGL(rgbs::rb_step_kernel, dim3(bt.B), dim3(RB_T_SMALL), sizeof(rgbs::RbLds), (hipStream_t)stream, b->model->dev_copy, launch);
+  if (b->model->config == 1) hipLaunchKernelGGL(rgbs::rb_step_kernel, dim3(bt.B), dim3(RB_T_SMALL), sizeof(rgbs::RbLds), (hipStream_t)stream, b->model->dev_copy, launch);
+  else if (b->model->config == 2) hipLaunchKernelGGL(rgbm::rb_step_kernel, dim3(bt.B), dim3(RB_T_MEDIUM), sizeof(rgbm::RbLds), (hipStream_t)stream, b->model->dev_copy, launch);
   else hipLaunchKernelGGL(rgb::rb_step_kernel, dim3(bt.B), dim3(RB_T_LARGE), sizeof(rgb::RbLds), (hipStream_t)stream, b->model->dev_copy, launch);
   HIPCHK(hipGetLastError());
 #endif
@@ -1192,7 +1213,6 @@ int ra_env_post_step(rb_batch* b, rb_batch* solver, const ra_post_args* args, vo
     return fail("ra_env_post_step: a required array is NULL");
   if (a.num_objects < 1 || a.num_objects > RA_MAXOBJ) return fail("ra_env_post_step: num_objects out of range");
   if (a.obs_dim != 36 * a.num_objects + 23 + 2 * d.nq) return fail("ra_env_post_step: obs_dim does not match the row layout");
-  if (d.ngeom > 64) return fail("ra_env_post_step: the gripper geom mask needs ngeom <= 64");
   if (d.nsensordata < 1 || a.force_adr < 0 || a.force_adr + 3 > d.nsensordata || a.torque_adr < 0 || a.torque_adr + 3 > d.nsensordata) return fail("ra_env_post_step: sensor address out of range");
   for (int k = 0; k < a.num_objects; k++) if (a.obj_body[k] <= 0 || a.obj_body[k] >= d.nbody) return fail("ra_env_post_step: object body id out of range");
   if (a.tcp_body <= 0 || a.tcp_body >= d.nbody || a.grip_act < 0 || a.grip_act >= d.nu || a.grip_qposadr < 0 || a.grip_qposadr >= d.nq || a.grip_dofadr < 0 || a.grip_dofadr >= d.nv)

@@ -27,7 +27,7 @@ import numpy as np
 import torch
 
 from robogym_amd import _native
-from robogym_amd.envs.rearrange.xml import load_blocks_model, load_solver_model
+from robogym_amd.envs.rearrange.xml import load_blocks_model, load_solver_model, object_bounding_boxes
 from robogym_amd.mujoco.large_simulation import LargeModelSimulation
 
 TABLETOP_EXPERIMENT_INITIAL_POS = np.deg2rad(np.array([135.0, -90, 135, -100, -240, 135]))   # robot/ur16e/arm_interface.py:27
@@ -53,10 +53,11 @@ class BatchedBlockRearrangeEnv:
     def __init__(self, batch_size: int, device="cuda:0", num_objects: int = 5, starting_seed: int = 0, max_position_change: float = 0.1,
                  arm_reset_controller_error: bool = True, n_random_initial_steps: int = 10, stabilize_steps: int = 100, settle_steps: int = 100,
                  success_threshold=None, penalty=None, max_timesteps_per_goal_per_obj: int = 200, successes_needed: int = 5, success_reward: float = 5.0,
-                 use_goal_distance_reward: bool = True, goal_reward_per_object: float = 1.0, used_table_portion: float = 1.0, lib=None, n_substeps: int = 40):
+                 use_goal_distance_reward: bool = True, goal_reward_per_object: float = 1.0, used_table_portion: float = 1.0, lib=None, n_substeps: int = 40,
+                 main_model=None):
         self.B, self.N = int(batch_size), int(num_objects)
         self._L = lib if lib is not None else _native.lib()
-        main, solver = load_blocks_model(self.N), load_solver_model()
+        main, solver = (main_model if main_model is not None else load_blocks_model(self.N)), load_solver_model()   # (main_model: the same world with other objects, envs/rearrange/ycb.py)
         self.sim = LargeModelSimulation(main, self.B, device=device, n_substeps=n_substeps, lib=lib, hand=False)
         self.solver_sim = LargeModelSimulation(solver, self.B, device=device, n_substeps=n_substeps, lib=lib, hand=False)
         self.device = self.sim.device
@@ -77,7 +78,8 @@ class BatchedBlockRearrangeEnv:
         tb, tg = main.name2id("body", "table"), gn.index("table")
         self.table_pos, self.table_size = A["body_pos"][tb].copy(), A["geom_size"][tg].copy()
         self.table_height = float(self.table_pos[2] + self.table_size[2])
-        self.object_size = A["geom_size"][[g for g in range(len(gn)) if A["geom_bodyid"][g] == main.name2id("body", "object0")][0]].copy()
+        bb = object_bounding_boxes(main, self.N)                        # per object: centre and half extents of its vertices in the body frame
+        self.obj_center, self.obj_half = bb[:, :3].copy(), bb[:, 3:].copy()
         # ---- TCP hook arguments
         t = self.tcp = _native.RbTcpArgs()
         for k in range(6):
@@ -126,6 +128,7 @@ class BatchedBlockRearrangeEnv:
             bid = main.name2id("body", bname)
             for g in range(len(gn)):
                 if A["geom_bodyid"][g] == bid:
+                    assert g < 64, "gripper geoms beyond id 63"
                     mask |= 1 << g
         a.gripper_geom_mask = mask
         lo, hi = self.table_pos - self.table_size, self.table_pos + self.table_size
@@ -182,20 +185,50 @@ class BatchedBlockRearrangeEnv:
         """place_objects_in_grid (common/utils.py:719-829) for boxes: AABB of each yawed block, a grid of cells sized by the largest block over the
         placement area (simulation/base.py:992-1010), distinct random cells."""
         B, N = len(rows), self.N
-        sx, sy, sz = self.object_size
-        half = np.stack([np.abs(np.cos(yaw)) * sx + np.abs(np.sin(yaw)) * sy, np.abs(np.sin(yaw)) * sx + np.abs(np.cos(yaw)) * sy, np.full_like(yaw, sz)], -1)   # rotate_bounding_box
+        half = self._aabb_half(yaw)                                      # rotate_bounding_box
+        c, s_ = np.cos(yaw), np.sin(yaw)
+        centre = np.stack([c * self.obj_center[:, 0] - s_ * self.obj_center[:, 1], s_ * self.obj_center[:, 0] + c * self.obj_center[:, 1], np.broadcast_to(self.obj_center[:, 2], yaw.shape)], -1)
         tsx, tsy = 2 * self.table_size[0], 2 * self.table_size[1]
         portion = float(np.clip(self.used_table_portion, N * 0.1, 1.0))
         width, height = 0.5 * tsx * portion, 0.38 * tsy * portion
         off_x, off_y = 0.5 * tsx - width / 2.0, 0.44 * tsy - height / 2.0
         out = np.zeros((B, N, 3))
-        for r in range(B):
-            ncol, nrow = int(width // (2 * half[r, :, 0].max())), int(height // (2 * half[r, :, 1].max()))
-            cw, ch = width / ncol, height / nrow
-            cells = self._rng.permutation(ncol * nrow)[:N]
-            row_i, col_i = cells // ncol, cells % ncol
-            p = np.stack([cw * col_i + half[r, :, 0], ch * row_i + half[r, :, 1], half[r, :, 2] + 2 * self.table_size[2]], -1)
-            out[r] = p + [off_x, off_y, 0.0] - self.table_size + self.table_pos
+        xy = np.zeros((B, N, 2))
+        ncol, nrow = (width // (2 * half[:, :, 0].max(1))).astype(int), (height // (2 * half[:, :, 1].max(1))).astype(int)
+        crowded = ncol * nrow < N
+        for r in np.nonzero(~crowded)[0]:
+            cw, ch = width / ncol[r], height / nrow[r]
+            cells = self._rng.permutation(ncol[r] * nrow[r])[:N]
+            row_i, col_i = cells // ncol[r], cells % ncol[r]
+            xy[r] = np.stack([cw * col_i + half[r, :, 0], ch * row_i + half[r, :, 1]], -1)
+        if crowded.any():
+            # fewer cells than objects (large mesh objects): place_objects_with_no_constraint (common/utils.py:829-880, _place_objects :623-716) --
+            # uniform proposals inside the area, rejected while the object's box overlaps a placed one; a set restarts when one of its objects runs
+            # out of trials (the reference gives up after max_placement_trial_count restarts and resamples the episode; this keeps trying).
+            # All crowded rows are sampled together.
+            pending = np.nonzero(crowded)[0]
+            area = np.array([width, height])
+            while len(pending):
+                h = half[pending]
+                cur, alive = np.zeros((len(pending), N, 2)), np.ones(len(pending), dtype=bool)
+                for i in range(N):
+                    placed = np.zeros(len(pending), dtype=bool)
+                    for _ in range(100):
+                        need = np.nonzero(alive & ~placed)[0]
+                        if len(need) == 0:
+                            break
+                        c_ = self._rng.uniform(h[need, i, :2], area - h[need, i, :2])
+                        free = np.ones(len(need), dtype=bool)
+                        if i:
+                            apart = (np.abs(c_[:, None, :] - cur[need, :i]) >= h[need, i, None, :2] + h[need, :i, :2]).any(-1)
+                            free = apart.all(1)
+                        cur[need[free], i] = c_[free]
+                        placed[need[free]] = True
+                    alive &= placed
+                xy[pending[alive]] = cur[alive]
+                pending = pending[~alive]
+        p = np.concatenate([xy, half[:, :, 2:3] + 2 * self.table_size[2]], -1)
+        out = p + [off_x, off_y, 0.0] - self.table_size + self.table_pos - centre      # (the body origin, from the centre of its bounding box)
         return out
 
     def _write_goal(self, rows, goal_pos, yaw):
@@ -265,8 +298,9 @@ class BatchedBlockRearrangeEnv:
         return self.observe()
 
     def _aabb_half(self, yaw):
-        sx, sy, sz = self.object_size
-        return np.stack([np.abs(np.cos(yaw)) * sx + np.abs(np.sin(yaw)) * sy, np.abs(np.sin(yaw)) * sx + np.abs(np.cos(yaw)) * sy, np.full_like(yaw, sz)], -1)
+        """half extents [.., N, 3] of the objects' bounding boxes after a rotation by `yaw` [.., N] about z"""
+        sx, sy, sz = self.obj_half[:, 0], self.obj_half[:, 1], self.obj_half[:, 2]
+        return np.stack([np.abs(np.cos(yaw)) * sx + np.abs(np.sin(yaw)) * sy, np.abs(np.sin(yaw)) * sx + np.abs(np.cos(yaw)) * sy, np.broadcast_to(sz, yaw.shape)], -1)
 
     def _sync_solver_gripper(self, idx):
         self.solver_sim.qpos[idx, self.solver_grip_q] = self.sim.qpos[idx, self.grip_q]

@@ -12,6 +12,9 @@ Reference call sites restated here:
 * `make_block / make_target / make_blocks_and_targets` (/root/reference/robogym/envs/rearrange/common/utils.py:195-291).
 * `build_solver_sim` (/root/reference/robogym/robot/composite/ur_gripper_arm.py:143-160): the arm-only world with the
   mocap weld that turns TCP commands into joint targets (sizes 200 / 200 / 200).
+* `make_mesh_object`, `get_combined_mesh`, `find_meshes_by_dirname`, `get_mesh_bounding_box` (common/utils.py:244-281, 391-397, 997-1019),
+  `MeshRearrangeSim.make_objects_xml` (simulation/mesh.py:50-67), `YcbRearrangeEnv._sample_object_meshes` (envs/rearrange/ycb.py:67-84):
+  the mesh objects of rearrange/ycb (BASELINE.json configs[4]) -- one free body per object, one mesh geom per convex part.
 * materials: /root/reference/robogym/envs/rearrange/materials/default.jsonnet (the reference's default
   `material_names = ["default"]`, envs/rearrange/common/base.py:210).
 """
@@ -86,6 +89,83 @@ def build_blocks_xml(num_objects: int = 5, object_size: float = 0.0254, mujoco_t
     return make_robot_xml(xml, joint_actuated)
 
 
+# ----------------------------------------------------------------------------------------- mesh objects (rearrange/ycb)
+def find_meshes_by_dirname(root_mesh_dir: str) -> dict:
+    """{object directory -> its convex-part STL files, paths relative to the mesh directory}, as the reference's helper of that name."""
+    import glob
+    import os
+
+    from robogym_amd.mujoco.mujoco_xml import assets_dir
+
+    root = os.path.join(assets_dir(), "stls")
+    out = {}
+    for sub in sorted(os.listdir(os.path.join(root, root_mesh_dir))):
+        files = sorted(glob.glob(os.path.join(root, root_mesh_dir, sub, "*.stl")))
+        if files:
+            out[sub] = [os.path.relpath(f, root) for f in files]
+    return out
+
+
+def combined_center_of_mass(files) -> np.ndarray:
+    """Centre of mass of the concatenated part meshes at uniform density (what trimesh's `center_mass` integrates for the reference:
+    signed tetrahedra from the origin over every triangle of every part)."""
+    import os
+
+    from robogym_amd.mujoco.mjcf_compiler import load_stl
+    from robogym_amd.mujoco.mujoco_xml import assets_dir
+
+    vol, mom = 0.0, np.zeros(3)
+    for f in files:
+        t = load_stl(os.path.join(assets_dir(), "stls", f))
+        a, b, c = t[:, 0], t[:, 1], t[:, 2]
+        v = np.einsum("ij,ij->i", a, np.cross(b, c)) / 6.0
+        vol += v.sum()
+        mom += ((a + b + c) / 4.0 * v[:, None]).sum(0)
+    return mom / vol
+
+
+def make_mesh_object(name: str, files, scale: float = 1.0) -> MujocoXML:
+    """One free body whose geoms are the object's convex parts, shifted so that the body origin is the combined centre of mass."""
+    pos = -combined_center_of_mass(files) * scale
+    fmt = lambda v: " ".join(repr(float(x)) for x in v)
+    assets = "\n".join('<mesh file="%s" name="%s-%d" scale="%s" />' % (f, name, i, fmt([scale] * 3)) for i, f in enumerate(files))
+    geoms = "\n".join('<geom type="mesh" mesh="%s-%d" pos="%s"/>' % (name, i, fmt(pos)) for i in range(len(files)))
+    src = """
+    <mujoco>
+      <asset>
+        %s
+      </asset>
+      <worldbody>
+        <body name="%s" pos="0.0 0.0 0.0">
+          %s
+          <joint name="%s:joint" type="free"/>
+        </body>
+      </worldbody>
+    </mujoco>
+    """ % (assets, name, geoms, name)
+    return MujocoXML.from_string(src)
+
+
+def sample_ycb_object_sets(random_state: np.random.RandomState, num_objects: int, mesh_names=None):
+    """`YcbRearrangeEnv._sample_object_meshes`: `num_objects` draws WITH replacement from the sorted candidate list."""
+    meshes = find_meshes_by_dirname("ycb")
+    cands = sorted(v for k, v in meshes.items() if mesh_names is None or k in mesh_names)
+    idx = random_state.choice(len(cands), size=num_objects, replace=True)
+    return [cands[i] for i in idx]
+
+
+def build_ycb_xml(mesh_sets, mesh_scale: float = 1.0, mujoco_timestep: float = 0.001, joint_actuated: bool = True, material: dict = DEFAULT_MATERIAL) -> MujocoXML:
+    """MeshRearrangeSim.build for the given per-object part lists (simulation/mesh.py:50-67 + simulation/base.py:236-300)."""
+    xml = make_world_xml(mujoco_timestep, dict(njmax=2000, nconmax=500, nuserdata=2000, nuser_actuator=16))
+    for i, files in enumerate(mesh_sets):
+        obj = make_mesh_object("object%d" % i, files, mesh_scale)
+        tgt = make_target(obj)
+        set_objects_attrs(obj, material)
+        xml.append(obj)
+        xml.append(tgt)
+    return make_robot_xml(xml, joint_actuated)
+
+
 def build_solver_xml(mujoco_timestep: float = 0.001) -> MujocoXML:
     """The controller arm's own simulation: ArmSimulationInterface.build with tcp_solver_mode = mocap."""
     xml = make_world_xml(mujoco_timestep, dict(njmax=200, nconmax=200, nuserdata=200))
@@ -114,3 +194,46 @@ def load_solver_model(recompile: bool = False) -> CompiledModel:
     if not recompile and os.path.exists(path):
         return CompiledModel.load(path)
     return build_solver_xml().build()
+
+
+def object_bounding_boxes(model: CompiledModel, num_objects: int) -> np.ndarray:
+    """[N, 6]: centre and half extents of every object's vertices in its body frame (get_mesh_bounding_box / get_block_bounding_box at
+    the identity orientation, common/utils.py:391-412) -- what the placement code works with."""
+    from robogym_amd.mujoco.mjcf_compiler import GEOM_BOX, GEOM_MESH, q2mat
+
+    A = model.arrays
+    out = np.zeros((num_objects, 6))
+    for i in range(num_objects):
+        b = model.name2id("body", "object%d" % i)
+        pts = []
+        for g in np.nonzero(A["geom_bodyid"] == b)[0]:
+            R, p = q2mat(A["geom_quat"][g]), A["geom_pos"][g]
+            if A["geom_type"][g] == GEOM_MESH:
+                m = int(A["geom_dataid"][g])
+                v = np.asarray(A["mesh_vert"], dtype=float).reshape(-1, 3)[int(A["mesh_vertadr"][m]):int(A["mesh_vertadr"][m]) + int(A["mesh_vertnum"][m])]
+            elif A["geom_type"][g] == GEOM_BOX:
+                s_ = A["geom_size"][g]
+                v = np.array([[sx * s_[0], sy * s_[1], sz * s_[2]] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)])
+            else:
+                raise NotImplementedError("bounding box of geom type %d" % A["geom_type"][g])
+            pts.append(v @ R.T + p)
+        pts = np.concatenate(pts)
+        lo, hi = pts.min(0), pts.max(0)
+        out[i, :3], out[i, 3:] = 0.5 * (lo + hi), 0.5 * (hi - lo)
+    return out
+
+
+#: the fixed object set of the shipped rearrange/ycb model: `sample_ycb_object_sets(RandomState(0), 8)` (tools/compile_models.py)
+YCB_MODEL_SEED = 0
+
+
+def load_ycb_model(num_objects: int = 8, recompile: bool = False) -> CompiledModel:
+    """The main world of rearrange/ycb with a FIXED set of `num_objects` YCB objects (BASELINE.json configs[4]: num_objects = 8).  The reference
+    draws a new set per episode and rebuilds the simulation (envs/rearrange/ycb.py:58-84); per-env object sets are not built yet."""
+    path = os.path.join(MODEL_DIR, "rearrange_ycb%d.npz" % num_objects)
+    if not recompile and os.path.exists(path):
+        return CompiledModel.load(path)
+    sets = sample_ycb_object_sets(np.random.RandomState(YCB_MODEL_SEED), num_objects)
+    m = build_ycb_xml(sets).build()
+    m.names["object_mesh"] = [os.path.basename(os.path.dirname(s_[0])) for s_ in sets]
+    return m

@@ -235,19 +235,19 @@ def _legacy_mesh_frame(tris):
     V = V[:, order]
     if np.linalg.det(V) < 0:
         V[:, 2] = -V[:, 2]
-    return com, V, vol.sum()
+    return com, V, vol.sum(), w[order]
 
 
 def process_mesh(path, scale):
     from scipy.spatial import ConvexHull
 
     tris = (load_msh(path) if path.lower().endswith(".msh") else load_stl(path)) * np.asarray(scale, dtype=float)
-    com, R, volume = _legacy_mesh_frame(tris)
+    com, R, volume, inertia = _legacy_mesh_frame(tris)
     pts = np.unique(tris.reshape(-1, 3), axis=0)
     hull = ConvexHull(pts)
     verts = pts[np.sort(hull.vertices)]
     local = ((verts - com) @ R).astype(np.float32)  # stored as float, like mjModel.mesh_vert
-    return dict(pos=com, quat=mat2q(R), vert=local, volume=volume)
+    return dict(pos=com, quat=mat2q(R), vert=local, volume=volume, inertia=inertia)   # (inertia: principal moments at unit density)
 
 
 # ----------------------------------------------------------------------------- the compiled model
@@ -432,7 +432,7 @@ def compile_mjcf(root, meshdir: Optional[str] = None, verbose: bool = False) -> 
             aabb = np.abs(v).max(0)
             sz = aabb
             rbound = float(np.linalg.norm(aabb))
-            mass, inertia = density * md["volume"], np.zeros(3)
+            mass, inertia = density * md["volume"], density * np.asarray(md["inertia"], dtype=float)
         elif gtype == GEOM_PLANE:
             rbound, mass, inertia = 0.0, 0.0, np.zeros(3)
         else:

@@ -69,6 +69,26 @@ def test_bench_distributed_path_under_gloo(emul_lib):
     assert r["config"]["global_batch"] == 4 and "170 floats" in r["config"]["gathered_row"]
 
 
+def test_bench_ycb_distributed_path_under_gloo(emul_lib):
+    """`bench.py --workload ycb --gpus 2` (BASELINE.json configs[4] is an 8-GPU line: 4096 envs per GPU): the N > 1 code path of the rearrange
+    workloads -- a shard of envs per rank, packed observation rows all-gathered behind the next step, barrier + max-over-ranks timing, one JSON
+    line from rank 0 -- on CPU with 2 ranks, gloo and the emulation harness (one mj_step per world per env.step, a one-step reset recipe)."""
+    import json
+    import subprocess
+
+    port = 31600 + os.getpid() % 2000
+    env = dict(os.environ, RG_BENCH_EMUL_LIB=os.path.join(ROOT, "tests", "emul", "librgstep_emul.so"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--workload", "ycb", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.split("\n") if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["value"] > 0 and r["scaling"] == "weak" and "configs[4]" in r["metric"]
+    assert r["config"]["global_batch"] == 2 and r["config"]["collective_backend"] == "gloo" and r["config"]["status_bits"] == 0
+
+
 def test_bench_spawns_its_own_ranks(emul_lib):
     """`python bench.py --gpus 2` WITHOUT a launcher (--gpus was parsed and ignored): the script
     re-executes itself under torch.distributed.run with 2 ranks, asserts the world size equals --gpus and prints

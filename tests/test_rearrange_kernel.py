@@ -31,6 +31,10 @@ def _oracle_env(models, n_substeps, settle=3, seed=0):
     pos = [[1.2 + 0.11 * i + 0.01 * rng.rand(), 0.55 + 0.1 * i, ztop] for i in range(5)]
     yaw = rng.uniform(0, 2 * np.pi, 5)
     env.set_object_poses(pos, [[np.cos(a / 2), 0, 0, np.sin(a / 2)] for a in yaw])
+    # gripper half open: at qpos0 the two finger pads touch face to face, a degenerate box - box case whose number of clipped points (4 or 5) is
+    # decided by rounding (fp32 kernel vs fp64 oracle)
+    cr = main.arrays["actuator_ctrlrange"][env.main.grip_act]
+    env.main.sim.ctrl[env.main.grip_act] = 0.5 * (cr[0] + cr[1])
     env.main.sim.forward()
     for _ in range(settle):
         env.main.step()
@@ -150,7 +154,7 @@ def _assert_resync(errs):
     med = dict(zip(names, np.median(errs, axis=0))); mx = dict(zip(names, errs.max(axis=0)))
     # (main ctrl = the solver's six arm angles: tight.  The solver's whole qpos includes its gripper slides, which sit ON their upper limit
     #  (q = 0, range [-0.04473, 0]): whether the limit row is active is a rounding-level decision, worth ~1e-5 m on a joint with armature 100)
-    assert mx["solver qpos"] < 1e-4 and mx["mocap"] < 2e-6 and mx["main ctrl"] < 5e-6, (med, mx)
+    assert mx["solver qpos"] < 1e-4 and mx["mocap"] < 2e-6 and med["main ctrl"] < 2e-6 and mx["main ctrl"] < 2e-5, (med, mx)
     assert med["main qpos"] < 2e-6 and mx["main qpos"] < 2e-4, (med, mx)          # (box-box contacts of the blocks on the table: flat contacts, as dactyl's cube on the palm)
     assert med["main qvel"] < 1e-4 and mx["main qvel"] < 2e-2, (med, mx)
     assert mx["main pid"] < 1e-4 and med["sensordata (rel)"] < 1e-3, (med, mx)
