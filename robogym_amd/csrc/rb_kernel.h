@@ -1512,7 +1512,7 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
     } else {
       const float* R0 = row + RB_ROWREC * adr;
       const float zone = R0[RB_RR_ZONE];
-      bool any = false;
+      bool any = false, diag = false;
       if (zone == 2.f) {   // middle zone of the cone: second derivatives of 1/2 Dm (N - mu T)^2 through U = diag(mu, friction) jar
         const float mu = C[RB_CR_SOLREF];
         float U[6], sc[6], T = 0.f;
@@ -1530,8 +1530,9 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
         any = true;
       } else {
         for (int j = 0; j < dim; j++) { const float* R = R0 + RB_ROWREC * j; bool qd; float cst; rb_row_force(R, qd, cst); if (qd) { W[j * (j + 1) / 2 + j] = R[RB_RR_D]; any = true; } }
+        diag = true;
       }
-      if (any) { W[RB_NW - 1] = 2.f; s.wcnt[0] = 1; }
+      if (any) { W[RB_NW - 1] = diag ? 3.f : 2.f; s.wcnt[0] = 1; }   // (mode 3: a diagonal weight -- equality rows, cone contacts outside the middle zone: the common case of objects at rest)
     }
   }
   BSYNC();
@@ -1591,6 +1592,9 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
             const float ja = K[(k + 1) * RB_CONW + ea], jb = K[(k + 1) * RB_CONW + eb];
             v += W[1 + k] * (K[ea] * jb + ja * K[eb]) + W[6 + k] * ja * jb;
           }
+        } else if (mode == 3.f) {   // diagonal weight (the same sums as the general form with its zero terms left out)
+          v = 0.f;
+          for (int j = 0; j < dim; j++) v += W[j * (j + 1) / 2 + j] * K[j * RB_CONW + ea] * K[j * RB_CONW + eb];
         } else {   // general symmetric weight of the basis rows
           v = 0.f;
           for (int j = 0; j < dim; j++) {

@@ -1,12 +1,14 @@
 """Stage cycle counters of rb_step_kernel on the two rearrange worlds (flags bit 1): mean cycles per mj_step per workgroup.
-    python tools/rearrange_stage_profile.py [B]"""
+    python tools/rearrange_stage_profile.py [B] [ycb]"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from robogym_amd.envs.rearrange.blocks import BatchedBlockRearrangeEnv  # noqa: E402
 
+from robogym_amd.envs.rearrange.ycb import BatchedYcbRearrangeEnv  # noqa: E402
+
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-env = BatchedBlockRearrangeEnv(B, stabilize_steps=20, n_random_initial_steps=2, settle_steps=10)
+env = (BatchedYcbRearrangeEnv if "ycb" in sys.argv[2:] else BatchedBlockRearrangeEnv)(B, stabilize_steps=20, n_random_initial_steps=2, settle_steps=10)
 env.reset()
 gen = torch.Generator(device="cuda:0"); gen.manual_seed(0)
 act = lambda: torch.rand((B, 6), generator=gen, device="cuda:0") * 2 - 1
