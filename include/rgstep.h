@@ -307,6 +307,12 @@ typedef struct rb_tcp_args {
   int arm_qposadr[6], main_arm_qposadr[6];   /* qpos addresses of robot0:J1..J6 in the solver / main model */
   int main_gripper_actuator, tcp_body, wrist_joint, reset_controller_error;
   float max_position_change, speed_roll, speed_pitch, joint_drift_threshold, gripper_ctrl_lo, gripper_ctrl_hi;
+  /* the rearrange env's default wrapper stack on the action side (RearrangeEnv.apply_wrappers, envs/rearrange/common/base.py:986-996), all optional:
+   * DiscretizeActionWrapper (wrappers/util.py:36-70): action_index[B][6] bin indices into bins[6][nbins] replace `action_dev` (which may then be NULL);
+   * SmoothActionWrapper (util.py:192-218): ema_value[B][6] / ema_t[B] = IncrementalExpAvg state (zero at reset), ema_alpha = alpha ^ (timestep nsubsteps / 0.08);
+   * action_out[B][6] receives the action that reached the env (the wrapper's "action_ema" observation).  device pointers; NULL = not used */
+  const int* action_index; const float* bins; int nbins; float ema_alpha;
+  float* ema_value; int* ema_t; float* action_out;
 } rb_tcp_args;
 int rb_batch_step_tcp(rb_batch* solver, rb_batch* main, const float* action_dev, const int* active_dev /* [B] or NULL */, const rb_tcp_args* args, int nsubsteps, int flags, void* stream);
 /* ---- the env-level half of RearrangeEnv.step (one launch after the two physics launches; robogym_amd/csrc/ra_env_kernel.h lists the
@@ -339,6 +345,7 @@ typedef struct ra_post_args {
   int max_timesteps_per_goal, successes_needed, use_goal_distance_reward;
   float *solver_qpos, *solver_ctrl;              /* rows of the solver batch (filled by ra_env_post_step), NULL: no hand-over */
   int solver_nq, solver_nu, solver_grip_qposadr, solver_grip_act;
+  float reward_clip;                             /* ClipRewardWrapper (wrappers/util.py:115-126; 100 in RearrangeEnv.apply_wrappers): every reward entry clipped to +- this; 0 = off */
 } ra_post_args;
 int ra_env_post_step(rb_batch* main, rb_batch* solver, const ra_post_args* args, void* stream);
 int ra_post_args_size(void);

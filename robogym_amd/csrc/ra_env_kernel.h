@@ -147,6 +147,7 @@ __global__ void __launch_bounds__(64) ra_post_step_kernel(const RbModelDev* mp, 
     a.steps_since_last_goal[e] = ssl; a.consecutive[e] = cons;
     float* rw = a.reward + 3 * (size_t)e;
     rw[0] = env_reward; rw[1] = a.use_goal_distance_reward ? gdr : 0.f; rw[2] = got ? a.success_reward : 0.f;
+    if (a.reward_clip > 0.f) for (int k = 0; k < 3; k++) rw[k] = fminf(fmaxf(rw[k], -a.reward_clip), a.reward_clip);   // ClipRewardWrapper
     a.goal_dist[2 * e] = sp; a.goal_dist[2 * e + 1] = sr;
     done = done || timeout || trial || crash;
     a.done[e] = done; a.goal_reset[e] = newgoal; a.trial_success[e] = trial; a.sub_goal_ok[e] = got; a.env_crash[e] = crash;

@@ -1913,13 +1913,36 @@ __global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbMod
   }
   BSYNC();
   // ---- the TCP solver hook (RbTcpHook): arm joints <- main simulation, forward(), mocap target <- TCP pose + denormalised action
+  float tcp_grip_action = 0.f;
   if (L.tcp.enabled) {
     if (L.tcp.sync) { if (TID < 6) s.qpos[L.tcp.arm_q[TID]] = L.tcp.main_qpos[(size_t)e * L.tcp.main_nq + L.tcp.main_arm_q[TID]]; }
     BSYNC();
     rb_kinematics(m, s, S); rb_com_pos(m, s, S); rb_tendon(m, s, S);
     if (L.tcp.sync) rb_pid(m, s, S, false);   // the controller tick of sync_to's mj_forward (free_dof_tcp_arm.py:214-225)
+    // the action that reaches the env: as given, or bin index -> value (DiscretizeActionWrapper.action, wrappers/util.py:66-70) -> exponential
+    // moving average with bias correction (SmoothActionWrapper.step / IncrementalExpAvg, util.py:142-160, 213-218)
+    if (TID < 6) {
+      float a = L.tcp.action ? L.tcp.action[(size_t)e * 6 + TID] : 0.f;
+      if (L.tcp.action_index) {
+        int ix = L.tcp.action_index[(size_t)e * 6 + TID];
+        ix = ix < 0 ? 0 : (ix >= L.tcp.nbins ? L.tcp.nbins - 1 : ix);
+        a = L.tcp.bins[TID * L.tcp.nbins + ix];
+      }
+      if (L.tcp.ema_value) {
+        const float al = L.tcp.ema_alpha;
+        const float v = L.tcp.ema_value[(size_t)e * 6 + TID] * al + (1.f - al) * a;
+        const int t = L.tcp.ema_t[e] + 1;
+        L.tcp.ema_value[(size_t)e * 6 + TID] = v;
+        a = v / (1.f - powf(al, (float)t));
+      }
+      if (L.tcp.action_out) L.tcp.action_out[(size_t)e * 6 + TID] = a;
+      s.prow[TID] = a;
+    }
+    BSYNC();
+    tcp_grip_action = s.prow[5];
+    if (TID == 0 && L.tcp.ema_value) L.tcp.ema_t[e] += 1;
     if (TID == 0) {
-      const float* a = L.tcp.action + (size_t)e * 6;
+      const float* a = s.prow;
       const float mpc = L.tcp.max_position_change;
       const float a0 = clampf(a[0], -1.f, 1.f), a1 = clampf(a[1], -1.f, 1.f), a2 = clampf(a[2], -1.f, 1.f), a3 = clampf(a[3], -1.f, 1.f), a4 = clampf(a[4], -1.f, 1.f);
       const float roll = a3 * L.tcp.speed[0] * mpc;
@@ -2007,7 +2030,7 @@ __global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbMod
     if (TID < 6) L.tcp.main_ctrl[(size_t)e * L.tcp.main_nu + TID] = s.qpos[L.tcp.arm_q[TID]];
     if (TID == 6) {
       float* gc = L.tcp.main_ctrl + (size_t)e * L.tcp.main_nu + L.tcp.main_grip_act;
-      *gc = clampf(*gc + clampf(L.tcp.action[(size_t)e * 6 + 5], -1.f, 1.f) * 0.5f * (L.tcp.grip_hi - L.tcp.grip_lo), L.tcp.grip_lo, L.tcp.grip_hi);
+      *gc = clampf(*gc + clampf(tcp_grip_action, -1.f, 1.f) * 0.5f * (L.tcp.grip_hi - L.tcp.grip_lo), L.tcp.grip_lo, L.tcp.grip_hi);
     }
   }
   if (TID < 7 * m.nmocap && TID < 14) L.bt.mocap[(size_t)e * 7 * m.nmocap + TID] = s.mocap[TID];

@@ -147,5 +147,12 @@ struct RbTcpHook {
   float* main_ctrl;                  // [B][main_nu]
   int main_nq, main_nu, main_arm_q[6], arm_q[6], main_grip_act, tcp_body, wrist_jnt;
   float max_position_change, speed[2], drift_threshold, grip_lo, grip_hi;
+  // the rearrange wrapper stack's action path (envs/rearrange/common/base.py:986-996), optional
+  const int* action_index;           // [B][6] bin indices (DiscretizeActionWrapper); null: `action` holds the continuous action
+  const float* bins;                 // [6][nbins]
+  int nbins;
+  float ema_alpha;                   // SmoothActionWrapper's step-adjusted alpha
+  float* ema_value; int* ema_t;      // IncrementalExpAvg state [B][6], [B]; null: no smoothing
+  float* action_out;                 // [B][6] the action that reached the env (= obs["action_ema"]); may be null
 };
 struct RbLaunch { RbEnvDev env; RbBatchDev bt; int nsubsteps, nforward_ticks, flags; RbTcpHook tcp; };

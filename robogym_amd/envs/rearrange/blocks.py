@@ -54,7 +54,7 @@ class BatchedBlockRearrangeEnv:
                  arm_reset_controller_error: bool = True, n_random_initial_steps: int = 10, stabilize_steps: int = 100, settle_steps: int = 100,
                  success_threshold=None, penalty=None, max_timesteps_per_goal_per_obj: int = 200, successes_needed: int = 5, success_reward: float = 5.0,
                  use_goal_distance_reward: bool = True, goal_reward_per_object: float = 1.0, used_table_portion: float = 1.0, lib=None, n_substeps: int = 40,
-                 main_model=None):
+                 main_model=None, wrappers: bool = False, n_action_bins: int = 11, smooth_alpha: float = 0.3, reward_clip: float = 100.0):
         self.B, self.N = int(batch_size), int(num_objects)
         self._L = lib if lib is not None else _native.lib()
         main, solver = (main_model if main_model is not None else load_blocks_model(self.N)), load_solver_model()   # (main_model: the same world with other objects, envs/rearrange/ycb.py)
@@ -141,6 +141,19 @@ class BatchedBlockRearrangeEnv:
         a.solver_grip_qposadr, a.solver_grip_act = self.solver_grip_q, self.solver_grip_act
         self.action_shape = (self.B, 6)
         self._zero_action = z(B, 6)
+        # ---- RearrangeEnv.apply_wrappers (common/base.py:986-996): SmoothActionWrapper(alpha = 0.3) -> ClipRewardWrapper -> DiscretizeActionWrapper, all inside
+        # the launches: the solver world's launch maps bin indices to actions and smooths them (rb_tcp_args), the post kernel clips the reward
+        self.wrapped = bool(wrappers)
+        self.n_action_bins = int(n_action_bins)
+        self.ema_value, self.ema_t, self.action_ema = z(B, 6), z(B, dt=torch.int32), z(B, 6)
+        self.bins = torch.tensor(np.tile(np.linspace(-1.0, 1.0, self.n_action_bins), (6, 1)).astype(np.float32), device=dev).contiguous()   # BinSpacing.LINEAR over Box(-1, 1)
+        tw = self.tcp_wrapped = _native.RbTcpArgs()
+        ctypes.memmove(ctypes.byref(tw), ctypes.byref(t), ctypes.sizeof(t))
+        tw.bins, tw.nbins = self.bins.data_ptr(), self.n_action_bins
+        tw.ema_alpha = float(np.power(smooth_alpha, float(np.asarray(A["opt_timestep"]).reshape(-1)[0]) * n_substeps / 0.08))       # SmoothActionWrapper.reset (wrappers/util.py:203-211)
+        tw.ema_value, tw.ema_t, tw.action_out = self.ema_value.data_ptr(), self.ema_t.data_ptr(), self.action_ema.data_ptr()
+        if self.wrapped:
+            a.reward_clip = float(reward_clip)
 
     # ------------------------------------------------------------------ launches
     def _stream(self):
@@ -149,13 +162,25 @@ class BatchedBlockRearrangeEnv:
     def _post(self):
         _native.check(self._L, self._L.ra_env_post_step(self.sim._bh, self.solver_sim._bh, ctypes.byref(self.post), self._stream()), "ra_env_post_step")
 
-    def _physics(self, actions, active=None):
-        self.solver_sim.step_tcp(self.sim, actions, self.tcp, active=active)
+    def _physics(self, actions, active=None, wrapped=False):
+        if wrapped:       # `actions`: int32 bin indices through the wrapper stack's action path
+            self.tcp_wrapped.action_index = actions.data_ptr()
+            self._keep_idx = actions
+            self.solver_sim.step_tcp(self.sim, None, self.tcp_wrapped, active=active)
+        else:
+            self.solver_sim.step_tcp(self.sim, actions, self.tcp, active=active)
         self.sim.env_step(nforward_ticks=2, flags=FLAG_FULL_FORWARD, active=active)
 
     def step(self, actions: torch.Tensor):
-        """RobotEnv.step (robot_env.py:804-844): returns (obs dict of [B, ...] views, reward [B, 3], done [B], info dict of tensors)."""
-        assert actions.shape == self.action_shape and actions.dtype == torch.float32 and actions.is_contiguous() and actions.device == self.device
+        """RobotEnv.step (robot_env.py:804-844): returns (obs dict of [B, ...] views, reward [B, 3], done [B], info dict of tensors).
+        Unwrapped: `actions` float32 [B, 6] in [-1, 1].  With the wrapper stack (`make_env`'s default): integer bin indices [B, 6] in [0, n_action_bins)."""
+        assert actions.shape == self.action_shape and actions.device == self.device
+        if self.wrapped:
+            assert not actions.dtype.is_floating_point, "the wrapped env takes MultiDiscrete actions (bin indices)"
+            self._physics(actions.to(torch.int32).contiguous(), wrapped=True)
+            self._post()
+            return self.observe(), self.reward, self.done, self.info()
+        assert actions.dtype == torch.float32 and actions.is_contiguous()
         self._physics(actions)
         self._post()
         return self.observe(), self.reward, self.done, self.info()
@@ -178,6 +203,8 @@ class BatchedBlockRearrangeEnv:
                 out[k] = self.packed[:, o:o + n]
             o += n
         assert o == self.obs_dim
+        if self.wrapped:
+            out["action_ema"] = self.action_ema      # SmoothActionWrapper's observation: the smoothed action of the last step (zeros after reset)
         return out
 
     # ------------------------------------------------------------------ reset (host work + physics launches)
@@ -290,8 +317,9 @@ class BatchedBlockRearrangeEnv:
                 self._physics(self._zero_action, active)
                 self._sync_solver_gripper(idx)
         # tracker reset and the first goal (robot_env.py:780-792; ObjectStateGoal.next_goal with randomize_goal_rot = False)
-        for f in (self.t, self.steps, self.ssl, self.successes, self.consecutive):
+        for f in (self.t, self.steps, self.ssl, self.successes, self.consecutive, self.ema_t):
             f[idx] = 0
+        self.ema_value[idx] = 0; self.action_ema[idx] = 0          # SmoothActionWrapper.reset: a fresh filter, action_ema = 0
         self._write_goal(rows, self._grid_placement(yaw, rows), yaw)
         self.sim.env_step(nsubsteps=0, nforward_ticks=1, flags=FLAG_FULL_FORWARD, active=active)       # the forward of _observe_sync
         self._observe_only()
@@ -325,16 +353,18 @@ class BatchedBlockRearrangeEnv:
         self.sim.sync()
 
 
-def make_env(batch_size: int = 4096, device="cuda:0", parameters=None, constants=None, starting_seed: int = 0, apply_wrappers: bool = False, **kw):
-    """`BlockRearrangeEnv.build` surface (robot_env.py:1081-1089) for the batched env.  `parameters` / `constants` accept the subset this env
+def make_env(batch_size: int = 4096, device="cuda:0", parameters=None, constants=None, starting_seed: int = 0, apply_wrappers: bool = True, **kw):
+    """`BlockRearrangeEnv.build` surface (robot_env.py:1081-1089) for the batched env; `apply_wrappers` (default True, as in the reference) = the rearrange
+    wrapper stack of common/base.py:986-996 (MultiDiscrete actions of `constants.n_action_bins` = 11 bins, action smoothing, reward clipping).  `parameters` / `constants` accept the subset this env
     implements: parameters.simulation_params.num_objects, parameters.robot_control_params.{max_position_change, arm_reset_controller_error},
     parameters.n_random_initial_steps, constants.{success_threshold, successes_needed, success_reward, max_timesteps_per_goal_per_obj}."""
-    if apply_wrappers:
-        raise NotImplementedError("the rearrange wrapper stack (common/base.py:986-996) is not built")
     parameters, constants = dict(parameters or {}), dict(constants or {})
     sp, rc = dict(parameters.get("simulation_params", {})), dict(parameters.get("robot_control_params", {}))
     args = dict(num_objects=sp.get("num_objects", 5), max_position_change=rc.get("max_position_change", 0.1), arm_reset_controller_error=rc.get("arm_reset_controller_error", True),
-                n_random_initial_steps=parameters.get("n_random_initial_steps", 10), starting_seed=starting_seed)
+                n_random_initial_steps=parameters.get("n_random_initial_steps", 10), starting_seed=starting_seed, wrappers=bool(apply_wrappers),
+                n_action_bins=constants.get("n_action_bins", 11))
+    if constants.get("action_spacing", "linear") not in ("linear", "LINEAR"):
+        raise NotImplementedError("action_spacing other than linear")
     for k in ("success_threshold", "successes_needed", "success_reward", "max_timesteps_per_goal_per_obj"):
         if k in constants:
             args[k] = constants[k]
@@ -342,4 +372,7 @@ def make_env(batch_size: int = 4096, device="cuda:0", parameters=None, constants
     return BatchedBlockRearrangeEnv(batch_size, device=device, **args)
 
 
-make_simple_env = make_env
+def make_simple_env(*a, **kw):
+    """make_env(apply_wrappers=False) (robot_env.py:1137-1139)"""
+    kw["apply_wrappers"] = False
+    return make_env(*a, **kw)

@@ -25,16 +25,15 @@ class BatchedYcbRearrangeEnv(BatchedBlockRearrangeEnv):
         return out
 
 
-def make_env(batch_size: int = 4096, device="cuda:0", parameters=None, constants=None, starting_seed: int = 0, apply_wrappers: bool = False, **kw):
+def make_env(batch_size: int = 4096, device="cuda:0", parameters=None, constants=None, starting_seed: int = 0, apply_wrappers: bool = True, **kw):
     """`YcbRearrangeEnv.build` surface (ycb.py:96) for the batched env; accepts what envs/rearrange/blocks.py `make_env` accepts."""
-    if apply_wrappers:
-        raise NotImplementedError("the rearrange wrapper stack (common/base.py:986-996) is not built")
     parameters, constants = dict(parameters or {}), dict(constants or {})
     sp, rc = dict(parameters.get("simulation_params", {})), dict(parameters.get("robot_control_params", {}))
     if parameters.get("mesh_names") is not None or constants.get("normalize_mesh"):
         raise NotImplementedError("mesh_names / normalize_mesh: the shipped model holds one fixed object set")
     args = dict(num_objects=sp.get("num_objects", 8), max_position_change=rc.get("max_position_change", 0.1), arm_reset_controller_error=rc.get("arm_reset_controller_error", True),
-                n_random_initial_steps=parameters.get("n_random_initial_steps", 10), starting_seed=starting_seed)
+                n_random_initial_steps=parameters.get("n_random_initial_steps", 10), starting_seed=starting_seed, wrappers=bool(apply_wrappers),
+                n_action_bins=constants.get("n_action_bins", 11))
     for k in ("success_threshold", "successes_needed", "success_reward", "max_timesteps_per_goal_per_obj"):
         if k in constants:
             args[k] = constants[k]
@@ -42,4 +41,6 @@ def make_env(batch_size: int = 4096, device="cuda:0", parameters=None, constants
     return BatchedYcbRearrangeEnv(batch_size, device=device, **args)
 
 
-make_simple_env = make_env
+def make_simple_env(*a, **kw):
+    kw["apply_wrappers"] = False
+    return make_env(*a, **kw)

@@ -138,12 +138,12 @@ class LargeModelSimulation:
 
     def step_tcp(self, main: "LargeModelSimulation", action: torch.Tensor, args: "_native.RbTcpArgs", flags=0, active=None):
         """`JointControlledTcpArm.set_position_control` as one launch of THIS (the TCP solver's) simulation: rb_batch_step_tcp (include/rgstep.h)."""
-        assert action.dtype == torch.float32 and action.is_contiguous() and action.device == self.device and action.shape == (self.batch_size, 6)
+        assert action is None or (action.dtype == torch.float32 and action.is_contiguous() and action.device == self.device and action.shape == (self.batch_size, 6))
         flags = int(flags) | (_native.RG_FLAG_MPR_PLANE_DEPTH if simulation_interface.MPR_PLANE_DEPTH else 0)
         stream = None if self._emul else ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         self._keep = [action, args, active]
         assert active is None or (active.dtype == torch.int32 and active.is_contiguous() and active.shape == (self.batch_size,))
-        _native.check(self._L, self._L.rb_batch_step_tcp(self._bh, main._bh, ctypes.c_void_p(action.data_ptr()), None if active is None else ctypes.c_void_p(active.data_ptr()), ctypes.byref(args), self.n_substeps, flags, stream), "rb_batch_step_tcp")
+        _native.check(self._L, self._L.rb_batch_step_tcp(self._bh, main._bh, None if action is None else ctypes.c_void_p(action.data_ptr()), None if active is None else ctypes.c_void_p(active.data_ptr()), ctypes.byref(args), self.n_substeps, flags, stream), "rb_batch_step_tcp")
 
     def step(self, active=None):
         """SimulationInterface.step: nsubsteps x mj_step, then mj_forward (its PID tick)."""

@@ -123,3 +123,48 @@ def test_rearrange_env_batch_4096_runs_clean_gpu():
     env.sync()
     assert int(env.sim.status.max()) == 0 and int(env.solver_sim.status.max()) == 0 and bool(torch.isfinite(env.packed).all())
     assert float(done.float().mean()) < 0.02
+
+
+# ------------------------------------------------------------------------------------------------ the rearrange wrapper stack (RearrangeEnv.apply_wrappers)
+def _wrapper_stack_replay(lib, device, n_substeps):
+    """`make_env()`'s default stack -- DiscretizeActionWrapper(11 bins) -> ClipRewardWrapper -> SmoothActionWrapper(0.3) -- runs inside the launches
+    (rb_tcp_args.action_index / bins / ema_*, ra_post_args.reward_clip).  Replay of tests/golden/rearrange_wrappers.npz, recorded from the reference's own
+    classes (tools/gen_golden_rearrange_wrappers.py): the action that reaches the env and the `action_ema` observation step by step, a reset in between."""
+    import os
+
+    from robogym_amd.envs.rearrange.blocks import make_env
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "rearrange_wrappers.npz"))
+    # (emulation harness: ONE mj_step per env.step; smooth_alpha is chosen so that the step-adjusted alpha is the reference's 0.3 ^ (0.04 / 0.08) all the same)
+    kw = dict(lib=lib, n_substeps=n_substeps, stabilize_steps=1, n_random_initial_steps=0, settle_steps=0, smooth_alpha=0.3 ** (40 / n_substeps)) if lib is not None else dict(stabilize_steps=5, n_random_initial_steps=1, settle_steps=2)
+    env = make_env(batch_size=2, device=device, starting_seed=3, penalty=dict(table_collision=0.0, objects_off_table=250.0, wrist_collision=0.0), **kw)
+    assert env.wrapped and env.n_action_bins == 11 and abs(env.tcp_wrapped.ema_alpha - 0.3 ** 0.5) < 1e-6        # alpha ^ (0.001 x 40 / 0.08)
+    obs = env.reset()
+    assert np.array_equal(obs["action_ema"].cpu().numpy(), np.zeros((2, 6))) and np.array_equal(g["action_ema_at_reset"], np.zeros(6))
+    T = len(g["idx"]) if lib is None else 8
+    with pytest.raises(AssertionError):
+        env.step(torch.zeros((2, 6), dtype=torch.float32, device=env.device))                                      # MultiDiscrete actions only
+    for t in range(T):
+        if t == int(g["reset_at"][0]):
+            env.reset()
+        idx = torch.tensor(np.stack([g["idx"][t], g["idx"][(t + 3) % len(g["idx"])]]), device=env.device)       # row 1: another stream (rows are independent)
+        obs, rew, done, info = env.step(idx)
+        env.sync()
+        got = obs["action_ema"][0].cpu().numpy().astype(np.float64)
+        assert np.abs(got - g["action_to_env"][t]).max() < 2e-6 and np.abs(got - g["action_ema"][t]).max() < 2e-6, (t, got, g["action_to_env"][t])
+        assert float(rew.abs().max()) <= 100.0
+    # ClipRewardWrapper: an object pushed off the table costs 250 in this configuration and arrives as -100
+    env.sim.qpos[0, env.obj_q[0]:env.obj_q[0] + 3] = torch.tensor([3.0, 3.0, 0.5], device=env.device)
+    obs, rew, done, info = env.step(torch.full((2, 6), 5, dtype=torch.int64, device=env.device))
+    env.sync()
+    assert bool(info["objects_off_table"][0]) and float(rew[0, 0]) == -100.0 and bool(done[0]) and not bool(info["objects_off_table"][1])
+    return env
+
+
+def test_rearrange_wrapper_stack_matches_reference_classes_emul(emul_lib):
+    _wrapper_stack_replay(emul_lib, "cpu", n_substeps=1)
+
+
+@pytest.mark.gpu
+def test_rearrange_wrapper_stack_matches_reference_classes_gpu():
+    _wrapper_stack_replay(None, "cuda:0", n_substeps=40)

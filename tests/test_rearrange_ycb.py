@@ -153,14 +153,14 @@ def test_ycb_env_runs_clean_gpu(oracle_lib):
     bit, finite observation rows of the documented width, every object on the table, rows of different envs differ."""
     from robogym_amd.envs.rearrange.ycb import make_env
 
-    env = make_env(batch_size=256, starting_seed=7, stabilize_steps=30, n_random_initial_steps=2, settle_steps=30)
+    env = make_env(batch_size=256, starting_seed=7, stabilize_steps=30, n_random_initial_steps=2, settle_steps=30)      # (the default: with the wrapper stack)
     obs = env.reset()
     assert env.obs_dim == 36 * N + 23 + 2 * 64 and obs["obj_pos"].shape == (256, N, 3)
     gen = torch.Generator(device=env.device); gen.manual_seed(1)
     for _ in range(6):
-        obs, reward, done, info = env.step(torch.rand((256, 6), generator=gen, device=env.device) * 2 - 1)
+        obs, reward, done, info = env.step(torch.randint(0, 11, (256, 6), generator=gen, device=env.device))
     env.sync()
-    assert int(env.sim.status.max()) == 0 and int(env.solver_sim.status.max()) == 0
+    assert int(env.sim.status.max()) == 0 and int(env.solver_sim.status.max()) == 0 and obs["action_ema"].shape == (256, 6) and float(obs["action_ema"].abs().max()) <= 1.0
     assert bool(torch.isfinite(env.packed).all())
     z = obs["obj_pos"][:, :, 2]
     assert float(z.min()) > env.table_height - 0.01 and float((z < env.table_height + 0.2).float().mean()) > 0.99
