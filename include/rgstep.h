@@ -53,6 +53,19 @@ enum {
 
 /* Replaces mujoco_py.load_model_from_xml (mujoco_xml.py:259): `blob` is the "RGMODEL1" flat model
  * produced by the host-side MJCF compiler (robogym_amd/mujoco/model_blob.py). Returns NULL on error. */
+/* ---- The model blob (format "RGMODEL1"; what mujoco_py.load_model_from_xml's result is to the reference, mujoco/mujoco_xml.py:249-260).
+ * MJCF compilation is host-side (robogym_amd/mujoco/mjcf_compiler.py + setconst.py + kernel_tables.py / big_tables.py; SURVEY 8b's
+ * `rg_compile_mjcf` is NOT behind this ABI) and its product is this self-describing container, which any language can assemble:
+ *   bytes 0..7   "RGMODEL1"        bytes 8..11  uint32 entry count n        bytes 12..15  reserved (0)
+ *   then n directory entries of 56 bytes: char name[40] (NUL padded) | uint32 dtype (0 = float64, 1 = int32, 2 = float32) | uint32 element count |
+ *   uint64 byte offset of the data from the start of the blob (8-byte aligned); the arrays follow, little endian, C order.
+ * Arrays carry mjModel's names and layouts (body_pos [nbody][3], jnt_range [njnt][2], ...; `dims` = nq, nv, nu, nbody, njnt, ngeom, nsite, ntendon,
+ * nwrap, nmesh, nmeshvert, nexclude, nsensor) plus the derived execution tables k_* (rg_model_create) / b_* (rb_model_create).  The exact key set a model
+ * kind needs is reported by the reader itself: rg_model_blob_keys / rb_model_blob_keys return the comma-separated names the create call asked for
+ * (return value: bytes needed incl. NUL); a missing or mistyped key fails the create with an error that names it.  rg_blob_entry enumerates a blob's
+ * directory (index < 0: only the entry count is returned) with the same bounds checks the creates apply. */
+int rg_blob_entry(const void* blob, size_t nbytes, int index, char* name40, int* dtype, unsigned* count);
+int rg_model_blob_keys(const rg_model* m, char* out, int outlen);
 rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen);
 /* The same with the HIP device ordinal that shall hold the model tables (rg_model_create uses the calling
  * thread's current device).  A batch must be created on the device of its model. */
@@ -268,6 +281,7 @@ int rg_lds_bytes_cfg(int config);
 typedef struct rb_model rb_model;
 typedef struct rb_batch rb_batch;
 rb_model* rb_model_create(const void* blob, size_t nbytes, char* err, int errlen);
+int rb_model_blob_keys(const rb_model* m, char* out, int outlen);   /* the blob arrays rb_model_create read (see rg_blob_entry) */
 void rb_model_free(rb_model* m);
 int rb_model_info(const rb_model* m, int* out, int n);
 int rb_scratch_offset(const rb_model* m, int which);

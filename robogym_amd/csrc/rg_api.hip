@@ -64,6 +64,7 @@ typedef ra_post_args RaPostArgs;
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -155,6 +156,7 @@ struct rg_model {
   RgAux aux;
   std::vector<void*> allocs;
   std::vector<float> qpos0, prm_default;
+  std::vector<std::string> blob_keys;
   int ok = 0;
 };
 struct rg_batch {
@@ -193,7 +195,11 @@ template <class T> bool upload(rg_model* m, const std::vector<T>& host, const T*
   *dst = (const T*)p;
   return true;
 }
+// the arrays a model create asked the blob for, in order (rg_model_blob_keys / rb_model_blob_keys: the schema of that model kind, stated by the reader itself)
+thread_local std::vector<std::string>* g_key_log = nullptr;
+void log_key(const char* name) { if (g_key_log && std::find(g_key_log->begin(), g_key_log->end(), name) == g_key_log->end()) g_key_log->push_back(name); }
 bool get_f(const Blob& b, const char* name, std::vector<float>& out, std::string& err) {
+  log_key(name);
   const blob_entry* e = b.find(name);
   if (!e) { err = std::string("model blob lacks '") + name + "' (or its directory entry is out of bounds)"; return false; }
   out.resize(e->count);
@@ -203,6 +209,7 @@ bool get_f(const Blob& b, const char* name, std::vector<float>& out, std::string
   return true;
 }
 bool get_i(const Blob& b, const char* name, std::vector<int>& out, std::string& err) {
+  log_key(name);
   const blob_entry* e = b.find(name);
   if (!e) { err = std::string("model blob lacks '") + name + "' (or its directory entry is out of bounds)"; return false; }
   if (e->dtype != 1) { err = std::string("'") + name + "' is not int32"; return false; }
@@ -220,6 +227,7 @@ int rg_lds_bytes_cfg(int config) { return (int)(config == RG_CFG_LARGE ? rgl::rg
 
 rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen) {
   auto bail = [&](const std::string& msg, rg_model* m) -> rg_model* {
+    g_key_log = nullptr;
     g_err = msg;
     if (err && errlen > 0) { strncpy(err, msg.c_str(), errlen - 1); err[errlen - 1] = 0; }
     if (m) rg_model_free(m);
@@ -228,6 +236,7 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
   if (!blob || nbytes < 16 || memcmp(blob, "RGMODEL1", 8) != 0) return bail("not an RGMODEL1 blob", nullptr);
   Blob B{(const char*)blob, nbytes};
   rg_model* m = new rg_model();
+  g_key_log = &m->blob_keys;
 #ifndef RG_EMUL
   if (hipGetDevice(&m->device) != hipSuccess) return bail("hipGetDevice failed", m);
 #endif
@@ -506,6 +515,7 @@ rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen
   }
   { std::vector<RgModelDev> one(1, d); if (!upload<RgModelDev>(m, one, &m->dev_copy)) return bail("hipMalloc failed", m); }
   m->ok = 1;
+  g_key_log = nullptr;
   return m;
 }
 
@@ -889,6 +899,7 @@ struct rb_model {
   std::vector<float> qpos0, mocap0, eq_data0;
   std::vector<int> eq_active0;
   int config = 0;   // 0: large configuration of rb_kernel.h, 1: small, 2: medium
+  std::vector<std::string> blob_keys;
 };
 struct rb_batch {
   const rb_model* model;
@@ -913,6 +924,7 @@ void rb_model_free(rb_model* m) {
 }
 rb_model* rb_model_create(const void* blob, size_t nbytes, char* err, int errlen) {
   auto bail = [&](const std::string& msg, rb_model* m) -> rb_model* {
+    g_key_log = nullptr;
     g_err = msg;
     if (err && errlen > 0) { strncpy(err, msg.c_str(), errlen - 1); err[errlen - 1] = 0; }
     if (m) rb_model_free(m);
@@ -921,6 +933,7 @@ rb_model* rb_model_create(const void* blob, size_t nbytes, char* err, int errlen
   if (!blob || nbytes < 16 || memcmp(blob, "RGMODEL1", 8) != 0) return bail("not an RGMODEL1 blob", nullptr);
   Blob B{(const char*)blob, nbytes};
   rb_model* m = new rb_model();
+  g_key_log = &m->blob_keys;
 #ifndef RG_EMUL
   if (hipGetDevice(&m->device) != hipSuccess) return bail("hipGetDevice failed", m);
 #endif
@@ -1005,7 +1018,31 @@ rb_model* rb_model_create(const void* blob, size_t nbytes, char* err, int errlen
   m->allocs.push_back(p);
   if (hipMemcpy(p, &d, sizeof(RbModelDev), hipMemcpyHostToDevice) != hipSuccess) return bail("hipMemcpy failed", m);
   m->dev_copy = (const RbModelDev*)p;
+  g_key_log = nullptr;
   return m;
+}
+// ---- the model blob as an interface of its own (SURVEY 8b lists `rg_compile_mjcf`: compilation stays host-side, the blob is what crosses the ABI)
+static int join_keys(const std::vector<std::string>& keys, char* out, int outlen) {
+  std::string j;
+  for (size_t i = 0; i < keys.size(); i++) { if (i) j += ","; j += keys[i]; }
+  if (out && outlen > 0) { strncpy(out, j.c_str(), outlen - 1); out[outlen - 1] = 0; }
+  return (int)j.size() + 1;
+}
+int rg_model_blob_keys(const rg_model* m, char* out, int outlen) { return m ? join_keys(m->blob_keys, out, outlen) : fail("null model"); }
+int rb_model_blob_keys(const rb_model* m, char* out, int outlen) { return m ? join_keys(m->blob_keys, out, outlen) : fail("null model"); }
+int rg_blob_entry(const void* blob, size_t nbytes, int index, char* name40, int* dtype, unsigned* count) {
+  if (!blob || nbytes < 16 || memcmp(blob, "RGMODEL1", 8) != 0) return fail("not an RGMODEL1 blob");
+  const uint32_t n = *(const uint32_t*)((const char*)blob + 8);
+  if (16 + (uint64_t)n * sizeof(blob_entry) > nbytes) return fail("blob directory out of bounds");
+  if (index < 0) return (int)n;
+  if ((uint32_t)index >= n) return fail("blob entry index out of range");
+  const blob_entry& e = ((const blob_entry*)((const char*)blob + 16))[index];
+  const uint64_t esz = e.dtype == 0 ? 8 : 4;
+  if (e.dtype > 2 || e.offset > nbytes || (uint64_t)e.count * esz > nbytes - e.offset) return fail("blob entry out of bounds");
+  if (name40) { memcpy(name40, e.name, 40); }
+  if (dtype) *dtype = (int)e.dtype;
+  if (count) *count = e.count;
+  return (int)n;
 }
 int rb_model_info(const rb_model* m, int* out, int n) {
   if (!m) return fail("null model");

@@ -147,7 +147,7 @@ def test_product_library_loads_and_exports_the_header():
     L = ctypes.CDLL(path)
     declared = sorted(set(re.findall(r"\b(r[gba]_[a-z_0-9]+)\s*\(", open(os.path.join(root, "include", "rgstep.h")).read())))
     # (rb_*: the large-model path, the full-cube env kernel and the rearrange TCP hook; ra_*: the rearrange env kernel)
-    assert len(declared) >= 45 and sum(n.startswith("rb_") for n in declared) == 15 and sum(n.startswith("ra_") for n in declared) == 2
+    assert len(declared) >= 45 and sum(n.startswith("rb_") for n in declared) == 16 and sum(n.startswith("ra_") for n in declared) == 2
     assert L.ra_post_args_size() == ctypes.sizeof(_native.RaPostArgs) and L.rb_post_args_size() == ctypes.sizeof(_native.RbPostArgs)
     for name in declared:
         assert hasattr(L, name), name
@@ -197,3 +197,46 @@ def test_touch_sensors_match_oracle_gpu(locked_model, oracle_lib, kernel_variant
     seen = _check_touch_sensors(LockedSimulation(locked_model, 2, device="cuda:0"), OracleLockedEnvPhysics(locked_model), locked_model, 20,
                                 atol=kernel_variant.tol((0.02, 0.02), (0.2, 0.05)), pid_atol=kernel_variant.tol(1e-2, 3e-1))
     assert seen > 1.0       # the fingertips did press on the cube (several newtons)
+
+
+def test_model_blob_is_a_documented_interface(locked_model, emul_lib):
+    """SURVEY 8(b) lists `rg_compile_mjcf`; compilation stays host-side here and the RGMODEL1 blob is the interface (include/rgstep.h): its
+    directory is enumerable through the ABI, the library reports which arrays each model kind reads, every one of them is in the blob the
+    Python compiler packs, and a blob that lacks one is refused with an error naming it."""
+    import ctypes
+
+    from robogym_amd.envs.rearrange.xml import load_solver_model
+    from robogym_amd.mujoco.big_tables import derive_big_tables
+    from robogym_amd.mujoco.model_blob import pack_model
+
+    L = emul_lib
+    solver = load_solver_model(); derive_big_tables(solver)
+    for model, create, free, keys_fn in ((locked_model, L.rg_model_create, L.rg_model_free, L.rg_model_blob_keys), (solver, L.rb_model_create, L.rb_model_free, L.rb_model_blob_keys)):
+        blob = pack_model(model)
+        n = L.rg_blob_entry(blob, len(blob), -1, None, None, None)
+        assert n == len(model.arrays)
+        seen = {}
+        for i in range(n):
+            name, dt, cnt = ctypes.create_string_buffer(41), ctypes.c_int(), ctypes.c_uint()
+            assert L.rg_blob_entry(blob, len(blob), i, name, ctypes.byref(dt), ctypes.byref(cnt)) == n
+            seen[name.value.decode()] = (dt.value, cnt.value)
+        assert set(seen) == set(model.arrays)
+        for k, (dt, cnt) in seen.items():
+            a = np.asarray(model.arrays[k])
+            assert cnt == a.size and dt == (0 if a.dtype == np.float64 else 2 if a.dtype == np.float32 else 1 if np.issubdtype(a.dtype, np.integer) else 0), k
+        err = ctypes.create_string_buffer(512)
+        create.restype = ctypes.c_void_p
+        h = create(blob, len(blob), err, 512)
+        assert h, err.value
+        buf = ctypes.create_string_buffer(1 << 14)
+        need = keys_fn(ctypes.c_void_p(h), buf, len(buf))
+        keys = buf.value.decode().split(",")
+        assert 0 < need <= len(buf) and len(keys) > 40 and set(keys) <= set(model.arrays) and "dims" in keys and "qpos0" in keys
+        free(ctypes.c_void_p(h))
+        victim = keys[len(keys) // 2]
+        m2 = model.copy_with(); del m2.arrays[victim]
+        blob2 = pack_model(m2)
+        assert not create(blob2, len(blob2), err, 512) and victim in err.value.decode()
+    assert L.rg_blob_entry(b"NOTABLOB" + bytes(8), 16, -1, None, None, None) < 0
+    trunc = pack_model(solver)[:4096]      # the directory points past the end: refused, not read
+    assert L.rg_blob_entry(trunc, len(trunc), L.rg_blob_entry(trunc, len(trunc), -1, None, None, None) - 1, None, None, None) < 0
