@@ -1256,6 +1256,9 @@ __device__ __forceinline__ void rb_make_constraint(RbM m, RbLds& s, float* S, co
 // every dof's contact entries (contact c, slot e with idx[c][e] == dof), in contact order: the owner-computes form of J' f
 __device__ __forceinline__ void rb_dof_contact_lists(RbM m, RbLds& s, float* S) {
   const int* cidx = (const int*)SC(CONIDX); int* adr = (int*)SC(DOFCON_ADR); int* lst = (int*)SC(DOFCON);
+  // every contact dof's row in its group's dense block, once per mj_step (the Hessian assembly stages it with the Jacobian rows: one load, not a
+  // dependent pair of them per contact and Newton iteration)
+  { float* loc = SC(CONLOC); BFOR(w, RB_CONW * s.ncon) { const int d = cidx[w]; loc[w] = (float)((d >= 0 && d < m.nv) ? m.b_dof_local[d] : 0); } }
   const float* con = SC(CON);
   // a bit mask of its dofs per contact first (6 words: nv <= 192), so that a dof looks at one word per contact instead of its whole dof list
   unsigned* mask = (unsigned*)SC(CONF);   // (the per-contact solver scratch is free until the solver starts)
@@ -1546,6 +1549,7 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
   // contact: 40 % of the kernel's vector memory instructions.)
   // (one word per thread at 256 threads, three at 64; the load is issued before the current contact is added, the LDS store after it, so that the
   //  load's latency is covered by the adding instead of being waited for in front of it)
+  const float* cloc = SC(CONLOC);
   constexpr int NST = (RB_CST + RB_T - 1) / RB_T;   // words per thread (1 at 256 threads)
   struct Staged { float v[NST]; };
   auto stage_load = [&](int c) -> Staged {
@@ -1555,7 +1559,7 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
       const int t = TID + k * RB_T;
       float v = 0.f;
       if (t < 6 * RB_CONW) v = cj[6 * RB_CONW * c + t];
-      else if (t < 7 * RB_CONW) { const int d = cidx[RB_CONW * c + t - 6 * RB_CONW]; v = (float)((d >= 0 && d < m.nv) ? m.b_dof_local[d] : 0); }
+      else if (t < 7 * RB_CONW) v = cloc[RB_CONW * c + t - 6 * RB_CONW];
       else if (t < 7 * RB_CONW + RB_NW) v = Wc[RB_NW * c + t - 7 * RB_CONW];
       else if (t < RB_CST) v = con[RB_CONREC * c + (t == 7 * RB_CONW + RB_NW ? RB_CR_NNZ : RB_CR_DIM)];
       r.v[k] = v;
@@ -1572,10 +1576,11 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
   const long long tprobe = rg_clock();
 #endif
   stage_store(0, stage_load(0));
-  Staged next = s.ncon > 1 ? stage_load(1) : zero;   // two contacts in flight: the word stored at the end of a pass was requested a whole pass earlier
+  Staged next = s.ncon > 1 ? stage_load(1) : zero;   // three contacts in flight: the words stored at the end of a pass were requested two passes earlier
+  Staged next2 = s.ncon > 2 ? stage_load(2) : zero;
   BSYNC();
   for (int c = 0; c < s.ncon; c++, buf ^= 1) {
-    const Staged after = c + 2 < s.ncon ? stage_load(c + 2) : zero;
+    const Staged after = c + 3 < s.ncon ? stage_load(c + 3) : zero;
     const float* K = s.cst + RB_CST * buf;
     const float* W = K + 7 * RB_CONW;
     const float mode = W[RB_NW - 1];
@@ -1608,7 +1613,7 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
       }
     }
     stage_store(buf ^ 1, next);
-    next = after;
+    next = next2; next2 = after;
     BSYNC();
   }
 #ifdef RB_HESS_PROBE

@@ -57,7 +57,7 @@ enum {
   RB_O_CINERT, RB_O_CRB, RB_O_CDOF, RB_O_CDOFDOT, RB_O_CVEL, RB_O_CACC, RB_O_CFRC,
   RB_O_TENLEN, RB_O_TENJ, RB_O_TENVEL, RB_O_MSP,
   RB_O_CAND, RB_O_CON, RB_O_CONJ, RB_O_CONIDX, RB_O_ROW, RB_O_DOFCON_ADR, RB_O_DOFCON, RB_O_CONF,
-  RB_O_DBG, RB_O_CFRCEXT, RB_NOFF
+  RB_O_DBG, RB_O_CFRCEXT, RB_O_CONLOC, RB_NOFF
 };
 // per contact record (floats): dist, pos3, frame9, includemargin, friction5, solref2, solimp5, dim, geom1, geom2, efc_address, nnz, kind
 // kind: 0 pyramidal contact, 1 elliptic contact (ur16e/base.xml:3), 2 equality constraint (weld: dim 6, joint coupling: dim 1) — an

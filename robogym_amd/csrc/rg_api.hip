@@ -1011,7 +1011,7 @@ rb_model* rb_model_create(const void* blob, size_t nbytes, char* err, int errlen
   take(RB_O_CVEL, 6 * d.nbody); take(RB_O_CACC, 6 * d.nbody); take(RB_O_CFRC, 6 * d.nbody);
   take(RB_O_TENLEN, d.ntendon); take(RB_O_TENJ, RB_TENW * d.ntendon); take(RB_O_TENVEL, d.ntendon); take(RB_O_MSP, d.nM);
   take(RB_O_CAND, d.maxcand); take(RB_O_CON, RB_CONREC * d.maxcon); take(RB_O_CONJ, 6 * RB_CONW * d.maxcon); take(RB_O_CONIDX, RB_CONW * d.maxcon);
-  take(RB_O_ROW, RB_ROWREC * d.maxrow); take(RB_O_DOFCON_ADR, d.nv + 1); take(RB_O_DOFCON, RB_CONW * d.maxcon); take(RB_O_CONF, RB_NW * d.maxcon); take(RB_O_DBG, 8 + 5 * d.nv + 16); take(RB_O_CFRCEXT, 6 * d.nbody);
+  take(RB_O_ROW, RB_ROWREC * d.maxrow); take(RB_O_DOFCON_ADR, d.nv + 1); take(RB_O_DOFCON, RB_CONW * d.maxcon); take(RB_O_CONF, RB_NW * d.maxcon); take(RB_O_DBG, 8 + 5 * d.nv + 16); take(RB_O_CFRCEXT, 6 * d.nbody); take(RB_O_CONLOC, RB_CONW * d.maxcon);
   d.scratch_words = o;
   void* p = nullptr;
   if (hipMalloc(&p, sizeof(RbModelDev)) != hipSuccess) return bail("hipMalloc failed", m);
