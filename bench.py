@@ -485,7 +485,7 @@ def main():
             torch.cuda.empty_cache()
             import copy
             sec = []
-            for fn, kw in ((bench_locked_variant, dict(pipelined_reset=True)), (bench_locked_variant, dict(default_make_env=True)), (bench_full_perpendicular, {}), (bench_rearrange_blocks, {})):
+            for fn, kw in ((bench_locked_variant, dict(pipelined_reset=True)), (bench_locked_variant, dict(default_make_env=True)), (bench_full_perpendicular, {}), (bench_rearrange_blocks, {}), (bench_rearrange_blocks, dict(ycb=True))):
                 a2 = copy.copy(args); a2.steps, a2.warmup, a2.batch = (20, 40, 8192) if fn is bench_locked_variant else (4, 2, 4096)
                 a2.pipelined_reset = False
                 try:

@@ -232,13 +232,16 @@ class BatchedBlockRearrangeEnv:
             # fewer cells than objects (large mesh objects): place_objects_with_no_constraint (common/utils.py:829-880, _place_objects :623-716) --
             # uniform proposals inside the area, rejected while the object's box overlaps a placed one; a set restarts when one of its objects runs
             # out of trials (the reference gives up after max_placement_trial_count restarts and resamples the episode; this keeps trying).
-            # All crowded rows are sampled together.
+            # All crowded rows are sampled together; the objects of a row are placed largest first (the reference goes in object order: with a table this
+            # full that mostly runs out of trials on the last large object and starts over).
             pending = np.nonzero(crowded)[0]
             area = np.array([width, height])
+            order = np.argsort(-(self.obj_half[:, 0] * self.obj_half[:, 1]), kind="stable")
             while len(pending):
                 h = half[pending]
                 cur, alive = np.zeros((len(pending), N, 2)), np.ones(len(pending), dtype=bool)
-                for i in range(N):
+                done_objs = []
+                for i in order:
                     placed = np.zeros(len(pending), dtype=bool)
                     for _ in range(100):
                         need = np.nonzero(alive & ~placed)[0]
@@ -246,12 +249,13 @@ class BatchedBlockRearrangeEnv:
                             break
                         c_ = self._rng.uniform(h[need, i, :2], area - h[need, i, :2])
                         free = np.ones(len(need), dtype=bool)
-                        if i:
-                            apart = (np.abs(c_[:, None, :] - cur[need, :i]) >= h[need, i, None, :2] + h[need, :i, :2]).any(-1)
+                        if done_objs:
+                            apart = (np.abs(c_[:, None, :] - cur[need][:, done_objs]) >= h[need, i, None, :2] + h[need][:, done_objs, :2]).any(-1)
                             free = apart.all(1)
                         cur[need[free], i] = c_[free]
                         placed[need[free]] = True
                     alive &= placed
+                    done_objs.append(i)
                 xy[pending[alive]] = cur[alive]
                 pending = pending[~alive]
         p = np.concatenate([xy, half[:, :, 2:3] + 2 * self.table_size[2]], -1)

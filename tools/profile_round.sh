@@ -31,5 +31,10 @@ bash tools/prof_pmc_large.sh > gpurun_out/pmc_large_$R.txt 2>&1
 python bench.py --workload rearrange_blocks --steps 10 --warmup 3 > gpurun_out/bench_rearrange_$R.json 2> gpurun_out/bench_rearrange_$R.err
 tail -1 gpurun_out/bench_rearrange_$R.json | cut -c1-300
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_rearrange_$R -o rearrange_$R --output-format csv -- python bench.py --workload rearrange_blocks --quick-reset --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_rearrange_prof_$R.log 2>&1
-python tools/rearrange_stage_profile.py 1024 > gpurun_out/rearrange_stage_$R.txt 2>&1
+python tools/rearrange_stage_profile.py 4096 > gpurun_out/rearrange_stage_$R.txt 2>&1
+bash tools/prof_pmc_rearrange.sh > gpurun_out/pmc_rearrange_$R.txt 2>&1
+# configs[4] rearrange/ycb (fixed object set), one GPU's share of the 8-GPU line
+python bench.py --workload ycb --steps 10 --warmup 3 > gpurun_out/bench_ycb_$R.json 2> gpurun_out/bench_ycb_$R.err
+tail -1 gpurun_out/bench_ycb_$R.json | cut -c1-300
+python tools/rearrange_stage_profile.py 4096 ycb > gpurun_out/ycb_stage_$R.txt 2>&1
 ls gpurun_out/prof_$R gpurun_out/pmc_fetch_$R gpurun_out/pmc_write_$R gpurun_out/prof_rearrange_$R | head -30
