@@ -327,6 +327,9 @@ typedef struct rb_tcp_args {
    * action_out[B][6] receives the action that reached the env (the wrapper's "action_ema" observation).  device pointers; NULL = not used */
   const int* action_index; const float* bins; int nbins; float ema_alpha;
   float* ema_value; int* ema_t; float* action_out;
+  /* scripted actions (pipelined resets: the recipe's random-action and settle steps, RearrangeEnv._randomize_robot_initial_position, common/base.py:498-510):
+   * hold[B] != 0 -> that env takes scripted[B][6] (continuous, unwrapped) instead of its action, its smoothing filter is left alone; NULL = not used */
+  const int* hold; const float* scripted;
 } rb_tcp_args;
 int rb_batch_step_tcp(rb_batch* solver, rb_batch* main, const float* action_dev, const int* active_dev /* [B] or NULL */, const rb_tcp_args* args, int nsubsteps, int flags, void* stream);
 /* ---- the env-level half of RearrangeEnv.step (one launch after the two physics launches; robogym_amd/csrc/ra_env_kernel.h lists the
@@ -359,6 +362,9 @@ typedef struct ra_post_args {
   int max_timesteps_per_goal, successes_needed, use_goal_distance_reward;
   float *solver_qpos, *solver_ctrl;              /* rows of the solver batch (filled by ra_env_post_step), NULL: no hand-over */
   int solver_nq, solver_nu, solver_grip_qposadr, solver_grip_act;
+  const unsigned char* frozen;                   /* [B] or NULL.  1: an env inside its reset recipe (pipelined resets) or being re-observed after a goal change — observation
+                                                    row and gripper hand-over only: no reward, no tracker step, done = 0.  2: the env is skipped altogether.  3: the observation entries only (a live env
+                                                    whose goal was just replaced): reward / done / flags / counters of the step stay */
   float reward_clip;                             /* ClipRewardWrapper (wrappers/util.py:115-126; 100 in RearrangeEnv.apply_wrappers): every reward entry clipped to +- this; 0 = off */
 } ra_post_args;
 int ra_env_post_step(rb_batch* main, rb_batch* solver, const ra_post_args* args, void* stream);

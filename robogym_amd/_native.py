@@ -74,7 +74,7 @@ class RbTcpArgs(ctypes.Structure):
                 ("wrist_joint", ctypes.c_int), ("reset_controller_error", ctypes.c_int), ("max_position_change", ctypes.c_float), ("speed_roll", ctypes.c_float),
                 ("speed_pitch", ctypes.c_float), ("joint_drift_threshold", ctypes.c_float), ("gripper_ctrl_lo", ctypes.c_float), ("gripper_ctrl_hi", ctypes.c_float),
                 ("action_index", ctypes.c_void_p), ("bins", ctypes.c_void_p), ("nbins", ctypes.c_int), ("ema_alpha", ctypes.c_float),
-                ("ema_value", ctypes.c_void_p), ("ema_t", ctypes.c_void_p), ("action_out", ctypes.c_void_p)]
+                ("ema_value", ctypes.c_void_p), ("ema_t", ctypes.c_void_p), ("action_out", ctypes.c_void_p), ("hold", ctypes.c_void_p), ("scripted", ctypes.c_void_p)]
 
 
 RA_MAXOBJ = 16
@@ -90,7 +90,7 @@ def _ra_post_fields():
             + [(n, _f) for n in ("table_height", "pos_threshold", "rot_threshold", "goal_pos_offset", "goal_rot_weight", "goal_reward_per_object", "success_reward",
                                  "penalty_table_collision", "penalty_objects_off_table", "penalty_safety_stop", "safety_stop_force")]
             + [(n, _i) for n in ("max_timesteps_per_goal", "successes_needed", "use_goal_distance_reward")]
-            + [("solver_qpos", _p), ("solver_ctrl", _p), ("solver_nq", _i), ("solver_nu", _i), ("solver_grip_qposadr", _i), ("solver_grip_act", _i), ("reward_clip", _f)])
+            + [("solver_qpos", _p), ("solver_ctrl", _p), ("solver_nq", _i), ("solver_nu", _i), ("solver_grip_qposadr", _i), ("solver_grip_act", _i), ("frozen", _p), ("reward_clip", _f)])
 
 
 class RaPostArgs(ctypes.Structure):

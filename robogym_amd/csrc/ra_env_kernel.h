@@ -21,6 +21,7 @@ __global__ void __launch_bounds__(64) ra_post_step_kernel(const RbModelDev* mp, 
   const RbModelDev& m = *mp;
   const int e = blockIdx.x, lane = threadIdx.x;
   if (e >= bt.B) return;
+  if (a.frozen && a.frozen[e] == 2) return;      // not this env's turn (re-observation of selected envs only)
   const int nq = m.nq, N = a.num_objects;
   const float* qrow = bt.qpos + (size_t)e * nq;
   const float* vrow = bt.qvel + (size_t)e * m.nv;
@@ -120,7 +121,32 @@ __global__ void __launch_bounds__(64) ra_post_step_kernel(const RbModelDev* mp, 
   const int table_contact = __ballot(table_hit) != 0;
   const float fx = sens[a.force_adr], fy = sens[a.force_adr + 1], fz = sens[a.force_adr + 2];
   const int safety = sqrtf(fx * fx + fy * fy + fz * fz) > a.safety_stop_force;
-  if (lane == 0) {
+  const int frozen = a.frozen ? a.frozen[e] : 0;   // 1: an env inside its reset recipe (pipelined resets): observation row and gripper hand-over only, outputs zeroed
+  if (lane == 0 && frozen == 3) {                  // 3: observation entries only (a live env whose goal was just replaced): reward / done / flags / counters untouched
+    const int g0 = 15 * N + 15 + 2 * nq;
+    row[g0 + 6 * N] = (float)(!crash && nsucc == N);
+    float* o = row + g0 + 21 * N + 1;
+    o[0] = (float)safety;
+    for (int k = 0; k < 3; k++) { o[1 + k] = sens[a.force_adr + k]; o[4 + k] = sens[a.torque_adr + k]; }
+  }
+  if (lane == 0 && frozen == 1) {
+    float* rw = a.reward + 3 * (size_t)e;
+    rw[0] = rw[1] = rw[2] = 0.f;
+    a.goal_dist[2 * e] = sp; a.goal_dist[2 * e + 1] = sr;
+    a.done[e] = 0; a.goal_reset[e] = 0; a.trial_success[e] = 0; a.sub_goal_ok[e] = 0; a.env_crash[e] = crash; a.objects_off_table[e] = any_off;
+    const int g0 = 15 * N + 15 + 2 * nq;
+    row[g0 + 6 * N] = 0.f;
+    float* o = row + g0 + 21 * N + 1;
+    o[0] = (float)safety;
+    for (int k = 0; k < 3; k++) { o[1 + k] = sens[a.force_adr + k]; o[4 + k] = sens[a.torque_adr + k]; }
+    float* tail = row + a.obs_dim;
+    tail[0] = tail[1] = tail[2] = tail[3] = 0.f;
+    if (a.solver_qpos) {
+      a.solver_qpos[(size_t)e * a.solver_nq + a.solver_grip_qposadr] = qrow[a.grip_qposadr];
+      a.solver_ctrl[(size_t)e * a.solver_nu + a.solver_grip_act] = crow[a.grip_act];
+    }
+  }
+  if (lane == 0 && frozen == 0) {
     // ---- reward / done of the simulation (common/base.py:768-795)
     float env_reward = 0.f;
     int done = 0;

@@ -116,7 +116,47 @@ __device__ __forceinline__ void rb_kinematics(RbM m, RbLds& s, float* S) {
     q4 id; id.w = 1; id.x = id.y = id.z = 0; stq(xquat, id); stq(xiquat, id);
   }
   BSYNC();
-  for (int L = 0; L < m.nlevel; L++) {
+  // One wave per env and at most 64 bodies: body b lives in lane b, a level's bodies take their parent's frame from the parent's lane (lane exchange)
+  // instead of from the scratch row, so the sweep has no memory round trip between levels; the arithmetic is the level loop's below, word for word.
+  const bool wave_sweep = RB_NWAVE == 1 && m.nbody <= 64;
+  if (wave_sweep) {
+    const int b = TID; const bool on = b > 0 && b < m.nbody;
+    const int p = on ? m.body_parentid[b] : 0, lvl = on ? m.b_body_level[b] : -1;
+    v3 pos = mk3(0, 0, 0); q4 quat; quat.w = 1; quat.x = quat.y = quat.z = 0;
+    for (int L = 0; L < m.nlevel; L++) {
+      q4 pq; pq.w = __shfl(quat.w, p); pq.x = __shfl(quat.x, p); pq.y = __shfl(quat.y, p); pq.z = __shfl(quat.z, p);
+      const v3 pp = mk3(__shfl(pos.x, p), __shfl(pos.y, p), __shfl(pos.z, p));
+      if (lvl != L) continue;
+      pos = pp + qrot(pq, ld3(m.body_pos + 3 * b));
+      quat = qmul(pq, ldq(m.body_quat + 4 * b));
+      if (m.nmocap > 0 && m.body_mocapid[b] >= 0) { const float* mc = s.mocap + 7 * m.body_mocapid[b]; pos = ld3(mc); quat = ldq(mc + 3); }
+      for (int k = 0; k < m.body_jntnum[b]; k++) {
+        const int j = m.body_jntadr[b] + k, qa = m.jnt_qposadr[j], t = m.jnt_type[j];
+        if (t == RG_JNT_FREE) {
+          pos = ld3(s.qpos + qa); quat = qnormalize(ldq(s.qpos + qa + 3));
+          st3(xanchor + 3 * j, pos); st3(xaxis + 3 * j, mk3(0, 0, 1));
+          continue;
+        }
+        const v3 jpos = ld3(m.jnt_pos + 3 * j), jaxis = ld3(m.jnt_axis + 3 * j);
+        const v3 anchor = pos + qrot(quat, jpos), axis = qrot(quat, jaxis);
+        st3(xanchor + 3 * j, anchor); st3(xaxis + 3 * j, axis);
+        if (t == RG_JNT_SLIDE) pos = pos + axis * (s.qpos[qa] - m.qpos0[qa]);
+        else {
+          const q4 ql = (t == RG_JNT_BALL) ? qnormalize(ldq(s.qpos + qa)) : axisangle(jaxis, s.qpos[qa] - m.qpos0[qa]);
+          quat = qmul(quat, ql);
+          pos = anchor - qrot(quat, jpos);
+        }
+      }
+      quat = qnormalize(quat);
+    }
+    if (on) {
+      st3(xpos + 3 * b, pos); stq(xquat + 4 * b, quat);
+      st3(xipos + 3 * b, pos + qrot(quat, ld3(m.body_ipos + 3 * b)));
+      stq(xiquat + 4 * b, qmul(quat, ldq(m.body_iquat + 4 * b)));
+    }
+    BSYNC();
+  }
+  for (int L = 0; L < (wave_sweep ? 0 : m.nlevel); L++) {
     for (int q = m.b_lvl_adr[L] + TID; q < m.b_lvl_adr[L + 1]; q += RB_T) {
       const int b = m.b_lvl_body[q], p = m.body_parentid[b];
       const q4 pq = ldq(xquat + 4 * p);
@@ -709,7 +749,46 @@ __device__ __forceinline__ void rb_velocity(RbM m, RbLds& s, float* S) {
   const float* cdof = SC(CDOF); float *cdofdot = SC(CDOFDOT), *cvel = SC(CVEL), *cacc = SC(CACC), *cfrc = SC(CFRC);
   if (TID < 6) { cvel[TID] = 0.f; cacc[TID] = TID < 3 ? 0.f : -m.gravity[TID - 3]; cfrc[TID] = 0.f; }
   BSYNC();
-  for (int L = 0; L < m.nlevel; L++) {
+  const bool wave_sweep = RB_NWAVE == 1 && m.nbody <= 64;   // (as in rb_kinematics: body b in lane b, the parent's cvel / cacc by lane exchange)
+  if (wave_sweep) {
+    const int b = TID; const bool on = b > 0 && b < m.nbody;
+    const int p = on ? m.body_parentid[b] : 0, lvl = on ? m.b_body_level[b] : -1;
+    float cv[6], ca[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) { cv[c] = 0.f; ca[c] = (b == 0 && c >= 3) ? -m.gravity[c - 3] : 0.f; }
+    for (int L = 0; L < m.nlevel; L++) {
+      float pv[6], pa[6];
+#pragma unroll
+      for (int c = 0; c < 6; c++) { pv[c] = __shfl(cv[c], p); pa[c] = __shfl(ca[c], p); }
+      if (lvl != L) continue;
+#pragma unroll
+      for (int c = 0; c < 6; c++) { cv[c] = pv[c]; ca[c] = pa[c]; }
+      for (int k = 0; k < m.body_jntnum[b]; k++) {
+        const int j = m.body_jntadr[b] + k, t = m.jnt_type[j]; int da = m.jnt_dofadr[j];
+        if (t == RG_JNT_FREE) {
+          for (int i = 0; i < 3; i++) { for (int c = 0; c < 6; c++) { cdofdot[6 * (da + i) + c] = 0.f; cv[c] += cdof[6 * (da + i) + c] * s.qvel[da + i]; } }
+          da += 3;
+        }
+        if (t == RG_JNT_FREE || t == RG_JNT_BALL) {
+          for (int i = 0; i < 3; i++) cross_motion(cdofdot + 6 * (da + i), cv, cdof + 6 * (da + i));
+          for (int i = 0; i < 3; i++) for (int c = 0; c < 6; c++) cv[c] += cdof[6 * (da + i) + c] * s.qvel[da + i];
+        } else {
+          cross_motion(cdofdot + 6 * da, cv, cdof + 6 * da);
+          for (int c = 0; c < 6; c++) cv[c] += cdof[6 * da + c] * s.qvel[da];
+        }
+      }
+      for (int k = 0; k < m.body_dofnum[b]; k++) { const int i = m.body_dofadr[b] + k; for (int c = 0; c < 6; c++) ca[c] += cdofdot[6 * i + c] * s.qvel[i]; }
+    }
+    if (on) {
+      float t1[6], t2[6], t3[6];
+      mul_inert_vec(t1, SC(CINERT) + 10 * b, ca);
+      mul_inert_vec(t2, SC(CINERT) + 10 * b, cv);
+      cross_force(t3, cv, t2);
+      for (int c = 0; c < 6; c++) { cvel[6 * b + c] = cv[c]; cacc[6 * b + c] = ca[c]; cfrc[6 * b + c] = t1[c] + t3[c]; }
+    }
+    BSYNC();
+  }
+  for (int L = 0; L < (wave_sweep ? 0 : m.nlevel); L++) {
     for (int q = m.b_lvl_adr[L] + TID; q < m.b_lvl_adr[L + 1]; q += RB_T) {
       const int b = m.b_lvl_body[q], p = m.body_parentid[b];
       float cv[6], ca[6];
@@ -1926,7 +2005,13 @@ __global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbMod
     if (L.tcp.sync) rb_pid(m, s, S, false);   // the controller tick of sync_to's mj_forward (free_dof_tcp_arm.py:214-225)
     // the action that reaches the env: as given, or bin index -> value (DiscretizeActionWrapper.action, wrappers/util.py:66-70) -> exponential
     // moving average with bias correction (SmoothActionWrapper.step / IncrementalExpAvg, util.py:142-160, 213-218)
-    if (TID < 6) {
+    const bool scripted = L.tcp.hold && L.tcp.hold[e] != 0;
+    if (TID < 6 && scripted) {
+      const float a = L.tcp.scripted[(size_t)e * 6 + TID];
+      if (L.tcp.action_out) L.tcp.action_out[(size_t)e * 6 + TID] = a;
+      s.prow[TID] = a;
+    }
+    if (TID < 6 && !scripted) {
       float a = L.tcp.action ? L.tcp.action[(size_t)e * 6 + TID] : 0.f;
       if (L.tcp.action_index) {
         int ix = L.tcp.action_index[(size_t)e * 6 + TID];
@@ -1945,7 +2030,7 @@ __global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbMod
     }
     BSYNC();
     tcp_grip_action = s.prow[5];
-    if (TID == 0 && L.tcp.ema_value) L.tcp.ema_t[e] += 1;
+    if (TID == 0 && L.tcp.ema_value && !scripted) L.tcp.ema_t[e] += 1;
     if (TID == 0) {
       const float* a = s.prow;
       const float mpc = L.tcp.max_position_change;

@@ -37,7 +37,7 @@
   X(tendon_adr) X(tendon_num) X(wrap_type) X(wrap_objid) \
   X(actuator_trntype) X(actuator_trnid) X(actuator_forcelimited) X(actuator_biastype) \
   X(body_mocapid) X(eq_type) X(eq_obj1id) X(eq_obj2id) X(sensor_type) X(sensor_objid) X(sensor_adr) \
-  X(b_lvl_body) X(b_lvl_adr) X(b_body_lastdof) X(b_subtree_adr) X(b_subtree) X(b_root_list) X(b_M_i) X(b_M_j) X(b_M_adr) \
+  X(b_lvl_body) X(b_lvl_adr) X(b_body_level) X(b_body_lastdof) X(b_subtree_adr) X(b_subtree) X(b_root_list) X(b_M_i) X(b_M_j) X(b_M_adr) \
   X(b_group_adr) X(b_group_dofs) X(b_dof_group) X(b_dof_local) X(b_pair_geom) X(b_ten_dofs) X(b_fric_dof) X(b_fric_ten) X(b_lim_jnt) X(b_lim_ten) X(b_cell_adr) X(b_Mdesc_adr) X(b_Mdesc_ent) X(b_Mdesc_dof) X(b_dof_fricrow) X(b_star_grp) X(b_tree_adr) X(b_tree_desc) X(b_tree_branch) X(b_tree_brn_end) X(b_Mlong) X(b_tree8)
 #define RB_FLT_ARRAYS(X) \
   X(body_pos) X(body_quat) X(body_ipos) X(body_iquat) X(body_mass) X(body_inertia) X(body_subtreemass) X(body_invweight0) \
@@ -154,5 +154,6 @@ struct RbTcpHook {
   float ema_alpha;                   // SmoothActionWrapper's step-adjusted alpha
   float* ema_value; int* ema_t;      // IncrementalExpAvg state [B][6], [B]; null: no smoothing
   float* action_out;                 // [B][6] the action that reached the env (= obs["action_ema"]); may be null
+  const int* hold; const float* scripted;   // [B], [B][6]: envs inside their reset recipe take a scripted continuous action (and leave the filter alone); may be null
 };
 struct RbLaunch { RbEnvDev env; RbBatchDev bt; int nsubsteps, nforward_ticks, flags; RbTcpHook tcp; };

@@ -1155,6 +1155,7 @@ static thread_local const RbTcpHook* g_tcp_hook = nullptr;   // set by rb_batch_
 // JointControlledTcpArm.set_position_control as ONE launch of the solver simulation (RbTcpHook, rb_types.h)
 int rb_batch_step_tcp(rb_batch* solver, rb_batch* main_batch, const float* action_dev, const int* active_dev, const rb_tcp_args* a, int nsubsteps, int flags, void* stream) {
   if (!solver || !main_batch || !a || (!action_dev && !a->action_index)) return fail("rb_batch_step_tcp: null argument");
+  if ((a->hold != nullptr) != (a->scripted != nullptr)) return fail("rb_batch_step_tcp: hold and scripted go together");
   if (a->action_index && (!a->bins || a->nbins < 1)) return fail("rb_batch_step_tcp: action_index needs bins");
   if ((a->ema_value != nullptr) != (a->ema_t != nullptr)) return fail("rb_batch_step_tcp: ema_value and ema_t go together");
   if (solver->dev.B != main_batch->dev.B || solver->device != main_batch->device) return fail("rb_batch_step_tcp: the two batches must have the same size and device");
@@ -1169,7 +1170,7 @@ int rb_batch_step_tcp(rb_batch* solver, rb_batch* main_batch, const float* actio
   h.main_grip_act = a->main_gripper_actuator; h.tcp_body = a->tcp_body; h.wrist_jnt = a->wrist_joint;
   h.max_position_change = a->max_position_change; h.speed[0] = a->speed_roll; h.speed[1] = a->speed_pitch; h.drift_threshold = a->joint_drift_threshold;
   h.grip_lo = a->gripper_ctrl_lo; h.grip_hi = a->gripper_ctrl_hi;
-  h.action_index = a->action_index; h.bins = a->bins; h.nbins = a->nbins; h.ema_alpha = a->ema_alpha; h.ema_value = a->ema_value; h.ema_t = a->ema_t; h.action_out = a->action_out;
+  h.action_index = a->action_index; h.bins = a->bins; h.nbins = a->nbins; h.ema_alpha = a->ema_alpha; h.ema_value = a->ema_value; h.ema_t = a->ema_t; h.action_out = a->action_out; h.hold = a->hold; h.scripted = a->scripted;
   g_tcp_hook = &h;
   const int rc = rb_batch_step_ex(solver, nullptr, active_dev, nullptr, nullptr, nsubsteps, 0, flags, stream);
   g_tcp_hook = nullptr;

@@ -54,7 +54,8 @@ class BatchedBlockRearrangeEnv:
                  arm_reset_controller_error: bool = True, n_random_initial_steps: int = 10, stabilize_steps: int = 100, settle_steps: int = 100,
                  success_threshold=None, penalty=None, max_timesteps_per_goal_per_obj: int = 200, successes_needed: int = 5, success_reward: float = 5.0,
                  use_goal_distance_reward: bool = True, goal_reward_per_object: float = 1.0, used_table_portion: float = 1.0, lib=None, n_substeps: int = 40,
-                 main_model=None, wrappers: bool = False, n_action_bins: int = 11, smooth_alpha: float = 0.3, reward_clip: float = 100.0):
+                 main_model=None, wrappers: bool = False, n_action_bins: int = 11, smooth_alpha: float = 0.3, reward_clip: float = 100.0,
+                 pipelined_reset: bool = False):
         self.B, self.N = int(batch_size), int(num_objects)
         self._L = lib if lib is not None else _native.lib()
         main, solver = (main_model if main_model is not None else load_blocks_model(self.N)), load_solver_model()   # (main_model: the same world with other objects, envs/rearrange/ycb.py)
@@ -154,6 +155,19 @@ class BatchedBlockRearrangeEnv:
         tw.ema_value, tw.ema_t, tw.action_out = self.ema_value.data_ptr(), self.ema_t.data_ptr(), self.action_ema.data_ptr()
         if self.wrapped:
             a.reward_clip = float(reward_clip)
+        # ---- pipelined resets: an env whose episode ended runs the reset recipe INSIDE the following step calls (the stepper's launches take everybody
+        # along; a synchronous reset of a few envs costs ~210 launch pairs at the latency of a full batch).  The recipe's bookkeeping is host numpy (one
+        # readback of the flags per step -- a step is 70 ms of GPU work), its physics goes through the same three launches as the live envs': `hold` /
+        # `scripted` feed the recipe's actions to the solver world's launch, `frozen` keeps the env kernel from scoring those envs.
+        self.pipelined = bool(pipelined_reset)
+        self._stage, self._left = np.zeros(B, dtype=np.int8), np.zeros(B, dtype=np.int32)      # 0 live, 1 stabilise, 2 random action, 3 settle
+        self._yaw = np.zeros((B, N))
+        self.hold, self.scripted, self.frozen, self.solver_active = z(B, dt=torch.int32), z(B, 6), z(B, dt=torch.uint8), torch.ones(B, dtype=torch.int32, device=dev)
+        self.resetting, self.episode_started = z(B, dt=torch.bool), z(B, dt=torch.bool)
+        if self.pipelined:
+            for args_ in (t, tw):
+                args_.hold, args_.scripted = self.hold.data_ptr(), self.scripted.data_ptr()
+            a.frozen = self.frozen.data_ptr()
 
     # ------------------------------------------------------------------ launches
     def _stream(self):
@@ -162,33 +176,41 @@ class BatchedBlockRearrangeEnv:
     def _post(self):
         _native.check(self._L, self._L.ra_env_post_step(self.sim._bh, self.solver_sim._bh, ctypes.byref(self.post), self._stream()), "ra_env_post_step")
 
-    def _physics(self, actions, active=None, wrapped=False):
+    def _physics(self, actions, active=None, wrapped=False, solver_active=None):
+        sa = active if solver_active is None else solver_active      # (pipelined resets: envs that are settling their objects skip the solver world)
         if wrapped:       # `actions`: int32 bin indices through the wrapper stack's action path
             self.tcp_wrapped.action_index = actions.data_ptr()
             self._keep_idx = actions
-            self.solver_sim.step_tcp(self.sim, None, self.tcp_wrapped, active=active)
+            self.solver_sim.step_tcp(self.sim, None, self.tcp_wrapped, active=sa)
         else:
-            self.solver_sim.step_tcp(self.sim, actions, self.tcp, active=active)
+            self.solver_sim.step_tcp(self.sim, actions, self.tcp, active=sa)
         self.sim.env_step(nforward_ticks=2, flags=FLAG_FULL_FORWARD, active=active)
 
     def step(self, actions: torch.Tensor):
         """RobotEnv.step (robot_env.py:804-844): returns (obs dict of [B, ...] views, reward [B, 3], done [B], info dict of tensors).
         Unwrapped: `actions` float32 [B, 6] in [-1, 1].  With the wrapper stack (`make_env`'s default): integer bin indices [B, 6] in [0, n_action_bins)."""
         assert actions.shape == self.action_shape and actions.device == self.device
+        sa = self.solver_active if self.pipelined else None
         if self.wrapped:
             assert not actions.dtype.is_floating_point, "the wrapped env takes MultiDiscrete actions (bin indices)"
-            self._physics(actions.to(torch.int32).contiguous(), wrapped=True)
+            self._physics(actions.to(torch.int32).contiguous(), wrapped=True, solver_active=sa)
+        else:
+            assert actions.dtype == torch.float32 and actions.is_contiguous()
+            self._physics(actions, solver_active=sa)
+        if self.pipelined:
+            self._post()
+            self._advance_recipes()
+            return self.observe(), self.reward, self.done, self.info()
+        if self.wrapped:
             self._post()
             return self.observe(), self.reward, self.done, self.info()
-        assert actions.dtype == torch.float32 and actions.is_contiguous()
-        self._physics(actions)
         self._post()
         return self.observe(), self.reward, self.done, self.info()
 
     def info(self):
         return {"goal_dist_obj_pos": self.goal_dist[:, 0], "goal_dist_obj_rot": self.goal_dist[:, 1], "goal_reset": self.goal_reset, "trial_success": self.trial_success,
                 "sub_goal_is_successful": self.sub_goal_ok, "env_crash": self.env_crash, "objects_off_table": self.objects_off_table, "successes_so_far": self.successes,
-                "steps_since_last_goal": self.info_ssl}
+                "steps_since_last_goal": self.info_ssl, "resetting": self.resetting, "episode_started": self.episode_started}
 
     def observe(self):
         """Views into the packed row, keys / shapes of `RearrangeEnv._observe_simple` (common/base.py:376-421)."""
@@ -276,15 +298,10 @@ class BatchedBlockRearrangeEnv:
         self.qpos_goal[idx] = qg
         self.prev_valid[idx] = 0
 
-    def reset(self, mask: Optional[torch.Tensor] = None):
-        """RobotEnv.reset -> RearrangeEnv._reset (common/base.py:897-932): robot start pose, object rotations + grid placement, stabilisation
-        (100 simulation steps), n_random_initial_steps of one random action then 100 zero-action steps, tracker reset, first goal."""
-        rows = np.arange(self.B) if mask is None else np.nonzero(mask.cpu().numpy())[0]
-        if len(rows) == 0:
-            return self.observe()
+    def _begin_episode_state(self, rows, idx):
+        """What RearrangeEnv._reset writes before anything is simulated (common/base.py:897-932): both worlds as freshly made, the arm's start pose, object
+        rotations about z and their placement, bounding boxes / colours of the static observation.  Returns the drawn yaw angles [len(rows), N]."""
         dev, N = self.device, self.N
-        idx = torch.as_tensor(rows, device=dev, dtype=torch.long)
-        active = torch.zeros(self.B, dtype=torch.int32, device=dev); active[idx] = 1
         A, As = self.model.arrays, self.solver_model.arrays
         # MjSim of a fresh model: qpos0, zero velocities / controller state / time; robot.reset()
         for sim, model in ((self.sim, A), (self.solver_sim, As)):
@@ -307,6 +324,21 @@ class BatchedBlockRearrangeEnv:
         colors = self._rng.random_sample((len(rows), N, 4)); colors[..., 3] = 1.0
         so = np.concatenate([np.broadcast_to(self._aabb_half(yaw), (len(rows), N, 3)), colors], -1)
         self.static_obs[idx] = torch.tensor(so.astype(np.float32), device=dev)
+        return yaw
+
+    def reset(self, mask: Optional[torch.Tensor] = None):
+        """RobotEnv.reset -> RearrangeEnv._reset (common/base.py:897-932): robot start pose, object rotations + grid placement, stabilisation
+        (100 simulation steps), n_random_initial_steps of one random action then 100 zero-action steps, tracker reset, first goal."""
+        rows = np.arange(self.B) if mask is None else np.nonzero(mask.cpu().numpy())[0]
+        if len(rows) == 0:
+            return self.observe()
+        dev, N = self.device, self.N
+        idx = torch.as_tensor(rows, device=dev, dtype=torch.long)
+        active = torch.zeros(self.B, dtype=torch.int32, device=dev); active[idx] = 1
+        if self.pipelined:       # a synchronous reset ends whatever recipe those envs were in
+            self._stage[rows] = 0; self._left[rows] = 0
+            self.hold[idx] = 0; self.frozen[idx] = 0; self.solver_active[idx] = 1; self.resetting[idx] = False; self.episode_started[idx] = False
+        yaw = self._begin_episode_state(rows, idx)
         # stabilize_objects (common/utils.py:76-92; its temporary damping change is not reproduced: blocks at rest on the table need none)
         for _ in range(self.stabilize_steps):
             self.sim.env_step(nforward_ticks=1, active=active)
@@ -328,6 +360,78 @@ class BatchedBlockRearrangeEnv:
         self.sim.env_step(nsubsteps=0, nforward_ticks=1, flags=FLAG_FULL_FORWARD, active=active)       # the forward of _observe_sync
         self._observe_only()
         return self.observe()
+
+    # ------------------------------------------------------------------ pipelined resets
+    def _reobserve(self, started, regoaled):
+        """The observation rows of these envs again, after their goal changed, every other env skipped by the env kernel: `started` (first observation of a new
+        episode: reward 0, done 0) and `regoaled` (live envs with a new goal: the observation entries only, this step's reward / done / flags stay)."""
+        if len(started) + len(regoaled) == 0:
+            return
+        saved = self.frozen.clone()
+        self.frozen.fill_(2)
+        self.frozen[torch.as_tensor(started, device=self.device, dtype=torch.long)] = 1
+        self.frozen[torch.as_tensor(regoaled, device=self.device, dtype=torch.long)] = 3
+        had = self.post.frozen
+        self.post.frozen = self.frozen.data_ptr()
+        self._post()
+        self.post.frozen = had
+        self.frozen.copy_(saved)
+
+    def _advance_recipes(self):
+        """After the step's three launches: start the reset recipe of the envs whose episode ended, move the envs inside it one step on (stabilise ->
+        random action -> settle -> episode start: tracker reset, first goal, first observation), give the live envs that reached their goal a new one."""
+        dev = self.device
+        done = self.done.cpu().numpy()                       # (the one host synchronisation of a step)
+        newgoal = self.goal_reset.cpu().numpy()
+        self.episode_started.zero_()
+        st, left = self._stage, self._left
+        # ---- envs inside the recipe: this step counted
+        inside = st > 0
+        left[inside] -= 1
+        nxt = np.nonzero(inside & (left <= 0))[0]
+        started = []
+        was = st[nxt].copy()
+        for stage in (1, 2, 3):
+            rows = nxt[was == stage]
+            if len(rows) == 0:
+                continue
+            idx = torch.as_tensor(rows, device=dev, dtype=torch.long)
+            if stage == 1 and self.n_random_initial_steps >= 1:         # -> one random action for n_random_initial_steps steps
+                st[rows], left[rows] = 2, self.n_random_initial_steps
+                self.scripted[idx] = torch.tensor(self._rng.uniform(-1, 1, (len(rows), 6)).astype(np.float32), device=dev)
+                self.solver_active[idx] = 1
+            elif stage == 2:                                            # -> zero action while everything settles
+                st[rows], left[rows] = 3, self.settle_steps
+                self.scripted[idx] = 0
+            else:                                                       # -> the episode starts
+                started.append(rows)
+        if started:
+            rows = np.concatenate(started)
+            idx = torch.as_tensor(rows, device=dev, dtype=torch.long)
+            st[rows], left[rows] = 0, 0
+            for f in (self.t, self.steps, self.ssl, self.successes, self.consecutive, self.ema_t, self.hold):
+                f[idx] = 0
+            self.ema_value[idx] = 0; self.action_ema[idx] = 0; self.scripted[idx] = 0
+            self.frozen[idx] = 0; self.solver_active[idx] = 1
+            self.resetting[idx] = False; self.episode_started[idx] = True
+            yaw = self._yaw[rows]
+            self._write_goal(rows, self._grid_placement(yaw, rows), yaw)
+        # ---- live envs with a reached goal: ObjectStateGoal.next_goal (what reset_goals() does on request)
+        grows = np.nonzero(newgoal.astype(bool) & (st == 0))[0]
+        if len(grows):
+            yaw = self.goal_rot[torch.as_tensor(grows, device=dev, dtype=torch.long), :, 2].cpu().numpy().astype(np.float64)
+            self._write_goal(grows, self._grid_placement(yaw, grows), yaw)
+        self._reobserve(np.concatenate(started) if started else np.zeros(0, dtype=np.int64), grows)
+        # ---- episodes that ended on this step: their recipe begins (the returned observation / reward / done are the terminal ones)
+        rows = np.nonzero(done.astype(bool) & (st == 0))[0]
+        if len(rows):
+            idx = torch.as_tensor(rows, device=dev, dtype=torch.long)
+            self._yaw[rows] = self._begin_episode_state(rows, idx)
+            st[rows], left[rows] = 1, self.stabilize_steps
+            self.hold[idx] = 1; self.scripted[idx] = 0; self.frozen[idx] = 1; self.solver_active[idx] = 0
+            self.resetting[idx] = True
+            if self.stabilize_steps <= 0:        # (degenerate configuration: straight to the next stage on the following step)
+                left[rows] = 1
 
     def _aabb_half(self, yaw):
         """half extents [.., N, 3] of the objects' bounding boxes after a rotation by `yaw` [.., N] about z"""
@@ -366,7 +470,7 @@ def make_env(batch_size: int = 4096, device="cuda:0", parameters=None, constants
     sp, rc = dict(parameters.get("simulation_params", {})), dict(parameters.get("robot_control_params", {}))
     args = dict(num_objects=sp.get("num_objects", 5), max_position_change=rc.get("max_position_change", 0.1), arm_reset_controller_error=rc.get("arm_reset_controller_error", True),
                 n_random_initial_steps=parameters.get("n_random_initial_steps", 10), starting_seed=starting_seed, wrappers=bool(apply_wrappers),
-                n_action_bins=constants.get("n_action_bins", 11))
+                n_action_bins=constants.get("n_action_bins", 11))      # (+ pipelined_reset=True through **kw: episodes restart inside the step calls)
     if constants.get("action_spacing", "linear") not in ("linear", "LINEAR"):
         raise NotImplementedError("action_spacing other than linear")
     for k in ("success_threshold", "successes_needed", "success_reward", "max_timesteps_per_goal_per_obj"):

@@ -41,6 +41,7 @@ def derive_big_tables(model):
         lvl += [b for b in range(1, nb) if depth[b] == L]
         adr.append(len(lvl))
     A["b_lvl_body"], A["b_lvl_adr"] = _i32(lvl), _i32(adr)
+    A["b_body_level"] = _i32(depth - 1)      # index of a body's level in the lists above (world: -1): the one-wave sweeps keep body b in lane b
     # ---- last dof of the chain a body hangs on (-1: none), dof chain lists root-first
     lastdof = np.full(nb, -1, dtype=np.int32)
     for b in range(1, nb):

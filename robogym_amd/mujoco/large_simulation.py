@@ -28,7 +28,7 @@ class LargeModelSimulation:
         self.device = torch.device("cpu") if self._emul else torch.device(device)
         if not self._emul and not torch.cuda.is_available():
             raise _native.NativeError("LargeModelSimulation needs an MI355X (no CPU fallback)")
-        if "b_dims" not in model.arrays or "b_tree_desc" not in model.arrays or "b_Mlong" not in model.arrays or "b_tree8" not in model.arrays or "b_geom_aabb" not in model.arrays:
+        if "b_dims" not in model.arrays or "b_tree_desc" not in model.arrays or "b_Mlong" not in model.arrays or "b_tree8" not in model.arrays or "b_geom_aabb" not in model.arrays or "b_body_level" not in model.arrays:
             derive_big_tables(model)
         self.model, self.batch_size, self.n_substeps = model, int(batch_size), int(n_substeps)
         blob = pack_model(model)

@@ -168,3 +168,47 @@ def test_rearrange_wrapper_stack_matches_reference_classes_emul(emul_lib):
 @pytest.mark.gpu
 def test_rearrange_wrapper_stack_matches_reference_classes_gpu():
     _wrapper_stack_replay(None, "cuda:0", n_substeps=40)
+
+
+# ------------------------------------------------------------------------------------------------ pipelined resets
+def _pipelined_reset_sequence(lib, device, n_substeps, B):
+    """Episodes that end (goal time-out after 5 steps here) restart INSIDE the following step calls: recipe stages of 2 + 1 + 2 steps (stabilise, one random
+    action, settle), during which the env reports `resetting`, zero reward and done = False, then `episode_started` with fresh counters, objects placed on the
+    table, a new goal and an observation row that already carries it."""
+    kw = dict(lib=lib) if lib is not None else {}
+    env = BatchedBlockRearrangeEnv(B, device=device, n_substeps=n_substeps, stabilize_steps=2, n_random_initial_steps=1, settle_steps=2, max_timesteps_per_goal_per_obj=1,
+                                   pipelined_reset=True, starting_seed=11, **kw)
+    env.reset()
+    goal0 = env.goal.clone()
+    act = lambda: torch.zeros((B, 6), dtype=torch.float32, device=env.device)
+    seen = []
+    for k in range(1, 12):
+        obs, rew, done, info = env.step(act())
+        env.sync()
+        seen.append((bool(done.all()), bool(info["resetting"].all()), bool(info["episode_started"].all()), float(rew.abs().max())))
+        assert int(env.sim.status.max()) == 0 and int(env.solver_sim.status.max()) == 0 and bool(torch.isfinite(env.packed).all())
+        if k == 5:
+            assert bool(done.all()) and bool(info["resetting"].all())                      # the time-out step: terminal observation, recipe scheduled
+            z = obs["obj_pos"][..., 2]                                                     # (the observation is still the old episode's)
+        if 6 <= k <= 9:
+            assert not bool(done.any()) and bool(info["resetting"].all()) and float(rew.abs().max()) == 0.0 and int(env.steps.max()) == 5
+        if k == 10:
+            assert bool(info["episode_started"].all()) and not bool(info["resetting"].any()) and not bool(done.any())
+            assert int(env.steps.max()) == 0 and int(env.t.max()) == 0 and int(env.ssl.max()) == 0
+            assert not torch.equal(env.goal, goal0)                                          # a new goal ...
+            assert torch.allclose(obs["goal_obj_pos"], env.goal[:, :, :3]) and float(rew.abs().max()) == 0.0   # ... which the returned observation already carries
+            zz = obs["obj_pos"][..., 2].cpu().numpy()
+            assert np.all(np.abs(zz - (env.table_height + 0.0254)) < 5e-3)               # blocks on the table where the new episode placed them
+        if k == 11:
+            assert int(env.steps.max()) == 1 and not bool(info["episode_started"].any())   # the new episode is live
+    assert [s[0] for s in seen] == [False] * 4 + [True] + [False] * 6
+    return env
+
+
+def test_rearrange_pipelined_reset_sequence_emul(emul_lib):
+    _pipelined_reset_sequence(emul_lib, "cpu", n_substeps=1, B=2)
+
+
+@pytest.mark.gpu
+def test_rearrange_pipelined_reset_sequence_gpu():
+    _pipelined_reset_sequence(None, "cuda:0", n_substeps=40, B=64)
