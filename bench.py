@@ -150,7 +150,7 @@ def bench_rearrange_blocks(args, emit=True, ycb=False):
     ev = [[mk_event() for _ in range(3)] for _ in range(args.steps)]
     orig = env._physics
 
-    def timed(actions, active=None, _i=[0]):
+    def timed(actions, active=None, wrapped=False, solver_active=None, _i=[0]):
         e = ev[_i[0] % len(ev)]; _i[0] += 1
         rec = lambda x: x.record() if x is not None else None
         rec(e[0]); env.solver_sim.step_tcp(env.sim, actions, env.tcp, active=active); rec(e[1])
