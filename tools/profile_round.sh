@@ -37,4 +37,7 @@ bash tools/prof_pmc_rearrange.sh > gpurun_out/pmc_rearrange_$R.txt 2>&1
 python bench.py --workload ycb --steps 10 --warmup 3 > gpurun_out/bench_ycb_$R.json 2> gpurun_out/bench_ycb_$R.err
 tail -1 gpurun_out/bench_ycb_$R.json | cut -c1-300
 python tools/rearrange_stage_profile.py 4096 ycb > gpurun_out/ycb_stage_$R.txt 2>&1
+# steady state with episode ends (pipelined resets)
+python tools/soak_rearrange.py 4096 500 blocks 20 > gpurun_out/soak_rearrange_$R.txt 2>&1
+python tools/soak_rearrange.py 4096 300 ycb 10 >> gpurun_out/soak_rearrange_$R.txt 2>&1
 ls gpurun_out/prof_$R gpurun_out/pmc_fetch_$R gpurun_out/pmc_write_$R gpurun_out/prof_rearrange_$R | head -30
