@@ -261,7 +261,8 @@ def bench_full_perpendicular(args, emit=True):
     b_step, b_sub = algorithmic_bytes_per_env_step(_M, ncon, nefc, iters, sim.n_substeps, sim.nq + sim.nv)
     achieved = B * b_step / (kern_ms * 1e-3)
     out = {
-        "metric": "env-steps/sec dactyl/full_perpendicular batch 4096 (BASELINE.json configs[2]); unwrapped env.step, parity vs the in-repo CPU oracle (unpinned)",
+        "metric": "env-steps/sec dactyl/full_perpendicular batch 4096 (BASELINE.json configs[2]); unwrapped env.step, parity vs the in-repo CPU oracle (unpinned; also unpinned: the reset "
+                  "recipe's scramble restates pycuber's turn convention from memory, the PID clamp / smoothing order is restated from mujoco-py's documented semantics)",
         "value": B * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "dactyl/full_perpendicular (Shadow hand + full Rubik's cube, nv=168, 135 bodies, condim-6 contacts), batch %d, iid U(-1,1) relative actions, 10 substeps x 0.008 s; env.step = physics + env kernel (face_free goals), after the reset recipe with scrambled cubes" % B,

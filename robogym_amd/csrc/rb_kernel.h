@@ -1001,7 +1001,8 @@ __device__ __forceinline__ bool rb_obb_apart(v3 ca, q4 qa, v3 ha, v3 cb, q4 qb, 
     }
   return apart;
 }
-__device__ __forceinline__ void rb_collision(RbM m, RbLds& s, float* S, int flags) {
+// mj_collision in three parts (each a stage call of its own, RB_STAGE wrappers below): broadphase, the support-map narrowphase, the multi-point box routines
+__device__ __forceinline__ void rb_broadphase(RbM m, RbLds& s, float* S, int flags) {
   int* cand = (int*)SC(CAND);
   const float *gpos = SC(GPOS), *gquat = SC(GQUAT);
   if (TID == 0) { s.ncand = 0; s.ncand2 = 0; s.ncon = s.neqcon; }
@@ -1044,6 +1045,12 @@ __device__ __forceinline__ void rb_collision(RbM m, RbLds& s, float* S, int flag
     if (slot2 >= 0) cand[m.maxcand - 1 - slot2] = p;
   }
   BSYNC();   // (the last trip's candidates are written after rb_slot's barrier: the narrowphase below reads them from other waves)
+}
+__device__ __forceinline__ void rb_narrow_convex(RbM m, RbLds& s, float* S, int flags) {
+  const int* cand = (const int*)SC(CAND);
+  const float *gpos = SC(GPOS), *gquat = SC(GQUAT);
+  const bool multipoint = !(flags & 16);
+  (void)multipoint;
   // narrowphase: one quad per candidate, 64 candidates per trip
   MprEnv E; E.mesh_vert = m.b_mesh_rec; E.cell_adr = m.b_cell_adr; E.cell_blk = (const rgf4*)m.b_cell_blk; E.cell_ovf = (const rgf4*)m.b_cell_ovf; E.prof = 0; E.cells = !(flags & 8); E.plane_depth = (flags & 16) != 0;
   const int ncand = s.ncand;
@@ -1098,6 +1105,13 @@ __device__ __forceinline__ void rb_collision(RbM m, RbLds& s, float* S, int flag
       c[RB_CR_ADR] = -1.f; c[RB_CR_NNZ] = 0.f; c[RB_CR_KIND] = (float)((m.cone == 1 && m.b_pair_geom[3 * p + 2] > 1) ? RB_KIND_ELLIPTIC : RB_KIND_PYRAMID);
     }
   }
+  BSYNC();
+}
+__device__ __forceinline__ void rb_narrow_box(RbM m, RbLds& s, float* S, int flags) {
+  const int* cand = (const int*)SC(CAND);
+  const float *gpos = SC(GPOS), *gquat = SC(GQUAT);
+  float* con = SC(CON);
+  const bool multipoint = !(flags & 16);
   // box - box (mjc_BoxBox, up to 8 contacts) and plane - box (up to 4 corners): 32 lanes per pair, 8 pairs per trip
   if (multipoint) {
     const int ncand2 = s.ncand2;
@@ -1407,10 +1421,21 @@ __device__ __forceinline__ void rb_J_mul(RbM m, RbLds& s, float* S, const float*
   float* bd = SC(CONF);
   BFOR(w, 6 * s.ncon) {
     const int c = w / 6, k = w - 6 * c;
-    const float* J = cj + 6 * RB_CONW * c + k * RB_CONW; const int* idx = cidx + RB_CONW * c;
     const int nnz = (int)con[RB_CONREC * c + RB_CR_NNZ];
+    // the whole padded row and its dof list in 16-byte loads issued together (a loop over nnz waits for every element's round trip in turn); the sum
+    // itself runs over the first nnz entries in order, as before
+    const rgf4* J4 = (const rgf4*)(cj + 6 * RB_CONW * c + k * RB_CONW); const rgf4* I4 = (const rgf4*)(cidx + RB_CONW * c);
+    rgf4 jv[RB_CONW / 4], iv[RB_CONW / 4];
+#pragma unroll
+    for (int q = 0; q < RB_CONW / 4; q++) { jv[q] = J4[q]; iv[q] = I4[q]; }
     float v = 0;
-    for (int e = 0; e < nnz; e++) v += J[e] * x[idx[e]];
+#pragma unroll
+    for (int q = 0; q < RB_CONW / 4; q++) {
+      if (4 * q + 0 < nnz) v += jv[q].x * x[__builtin_bit_cast(int, iv[q].x)];
+      if (4 * q + 1 < nnz) v += jv[q].y * x[__builtin_bit_cast(int, iv[q].y)];
+      if (4 * q + 2 < nnz) v += jv[q].z * x[__builtin_bit_cast(int, iv[q].z)];
+      if (4 * q + 3 < nnz) v += jv[q].w * x[__builtin_bit_cast(int, iv[q].w)];
+    }
     bd[w] = v;
   }
   BSYNC();
@@ -1700,6 +1725,23 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------- stage calls
+// The stages are real function calls (as rg_kernel.h's): each gets its own register allocation, and the substep loop, the TCP hook's forward and the final
+// full forward share ONE copy of every stage (inlined, the kernel was 445 kB of code with every stage three times over).  A stage finds the model, the launch
+// descriptor and the env's scratch row through wave-uniform addresses (read back into SGPRs: everything loaded through them is a scalar load again).
+struct RbCtx { const void* km; const void* kl; float* S; };
+#ifdef RG_EMUL
+#define RB_M(c) (*(const RbModelDev*)(c).km)
+#define RB_L(c) (*(const RbLaunch*)(c).kl)
+#define RB_SP(c) ((c).S)
+#define RB_STAGE static inline
+#else
+#define RB_M(c) (*(const RG_AS4 RbModelDev*)rg_uniform((c).km))
+#define RB_L(c) (*(const RG_AS4 RbLaunch*)rg_uniform((c).kl))
+#define RB_SP(c) ((float*)rg_uniform((c).S))
+#define RB_STAGE __device__ __attribute__((noinline))
+#endif
+#define RB_STAGE_ENTER() RbM m = RB_M(c); RbLds& s = RB_S(); float* S = RB_SP(c); (void)m; (void)s; (void)S
 // ------------------------------------------------------------------------------------------------- solver
 struct RbLs { float cost, grad, hess; };
 // the rows a thread owns in the line search (r = TID and TID + RB_T; rows beyond 2 RB_T are read from the scratch row each time): loaded once
@@ -1787,7 +1829,41 @@ __device__ __forceinline__ float rb_line_search(RbLds& s, const float* row, cons
   return a;
 }
 // mj_solNewton (oracle ro_solve): s.qa <- qacc, s.qfrc_con <- J' f; returns the iteration count
-__device__ __forceinline__ int rb_solve(RbM m, RbLds& s, float* S, int flags) {
+// the solver's sub-stages as calls of their own: one copy each of the products M x / J x (three call sites), J' f, the Hessian assembly, the factorisation and the line search
+__device__ __forceinline__ const float* rb_vec_src(RbLds& s, int which) { return which == 0 ? s.warm : which == 1 ? s.qacc_smooth : which == 2 ? s.qa : s.search; }
+RB_STAGE void sv_MJ_mul(RbCtx c, int which) {   // which: 0 warm start, 1 qacc_smooth, 2 qa (-> Ma, jar); 3 search (-> Mv, jv)
+  RB_STAGE_ENTER();
+  const float* a = rb_vec_src(s, which);
+  rb_M_mul(m, SC(MSP), a, which == 3 ? s.Mv : s.Ma);
+  rb_J_mul(m, s, S, a, which == 3);
+}
+RB_STAGE void sv_JT_force(RbCtx c) { RB_STAGE_ENTER(); rb_JT_force(m, s, S, s.qfrc_con); }
+RB_STAGE void sv_hessian(RbCtx c, int grp) { RB_STAGE_ENTER(); rb_M_block(m, s, SC(MSP), grp, (const float*)0, 0.f); rb_hessian_add(m, s, S, grp); }
+RB_STAGE int sv_factor(RbCtx c, int grp) { RB_STAGE_ENTER(); const int n = m.b_group_adr[grp + 1] - m.b_group_adr[grp]; rb_scale_block(s, n); return rb_chol(s, n) ? 1 : 0; }
+RB_STAGE void sv_direction(RbCtx c, int grp) { RB_STAGE_ENTER(); rb_group_solve(m, s, grp, s.grad, s.search, -1.f); }
+RB_STAGE void sv_star_direction(RbCtx c, int grp, int part) {
+  RB_STAGE_ENTER();
+  if (part == 0) rb_row_diag(m, s, S, grp, s.Mv); else rb_star_group_solve(m, s, SC(MSP), grp, s.Mv, 1.f, s.grad, s.search, -1.f);
+}
+RB_STAGE float sv_line_search(RbCtx c, float gauss, float q1, float q2, float gtol) {
+  RB_STAGE_ENTER();
+  return rb_line_search(s, SC(ROW), SC(CON), m.cone == 1 ? s.ncon : 0, s.nefc, gauss, q1, q2, gtol, 40);
+}
+// dst = inv(M + h B) src of every group: mode 0 qacc_smooth = inv(M) qfrc_smooth (h = 0), mode 1 search = inv(M + h B) grad (the Euler step)
+RB_STAGE void sv_M_solve(RbCtx c, int mode, int flags) {
+  RB_STAGE_ENTER();
+  const float* diag = mode ? m.dof_damping : (const float*)0; const float h = mode ? m.timestep : 0.f;
+  const float* src = mode ? s.grad : s.qfrc_smooth; float* dst = mode ? s.search : s.qacc_smooth;
+  if (m.b_tree8[0] > 0 && !(flags & 4)) { rb_trees8_solve(m, s, SC(MSP), diag, h, src, dst, 1.f); return; }
+  for (int grp = 0; grp < m.ngroup; grp++) {
+    if (m.b_star_grp[4 * grp + 3] && !(flags & 4)) { rb_star_group_solve(m, s, SC(MSP), grp, diag, h, src, dst, 1.f); continue; }   // (flags bit 2: dense path everywhere, test hook)
+    rb_M_block(m, s, SC(MSP), grp, diag, h);
+    rb_scale_block(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]);
+    if (!rb_chol(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]) && TID == 0) s.status |= RG_STATUS_BAD_FACTOR;
+    rb_group_solve(m, s, grp, src, dst, 1.f);
+  }
+}
+__device__ __forceinline__ int rb_solve(RbCtx cx, RbM m, RbLds& s, float* S, int flags) {
   long long tq0 = rg_clock(), tq1;
 #define RB_PROFS(k) do { if (flags & 2) { BSYNC(); tq1 = rg_clock(); if (TID == 0) s.prof[k] += (float)(tq1 - tq0); tq0 = tq1; } } while (0)
   const int nv = m.nv, ne = s.nefc;
@@ -1798,8 +1874,7 @@ __device__ __forceinline__ int rb_solve(RbM m, RbLds& s, float* S, int flags) {
   float cost2[2];
   for (int pass = 0; pass < 2; pass++) {
     const float* a = pass == 0 ? s.warm : s.qacc_smooth;
-    rb_M_mul(m, Msp, a, s.Ma);
-    rb_J_mul(m, s, S, a, false);
+    sv_MJ_mul(cx, pass);
     float g = 0, c = 0;
     BFOR(i, nv) g += 0.5f * (s.Ma[i] - s.qfrc_smooth[i]) * (a[i] - s.qacc_smooth[i]);
     BFOR(r, ne) { bool q; float cc; rb_row_force(row + RB_ROWREC * r, q, cc); c += cc; }
@@ -1812,8 +1887,7 @@ __device__ __forceinline__ int rb_solve(RbM m, RbLds& s, float* S, int flags) {
   float cost = 0, oldcost = 0;
   int iters = 0;
   for (int iter = 0;; iter++) {
-    rb_M_mul(m, Msp, s.qa, s.Ma);
-    rb_J_mul(m, s, S, s.qa, false);
+    sv_MJ_mul(cx, 2);
     float g = 0, c = 0;
     BFOR(i, nv) g += 0.5f * (s.Ma[i] - s.qfrc_smooth[i]) * (s.qa[i] - s.qacc_smooth[i]);
     BFOR(r, ne) { bool q; float cc; rb_row_force(row + RB_ROWREC * r, q, cc); c += cc; }
@@ -1821,7 +1895,7 @@ __device__ __forceinline__ int rb_solve(RbM m, RbLds& s, float* S, int flags) {
     const float ccost = rb_sum(s, c);
     oldcost = cost; cost = gauss + ccost;
     RB_PROFS(8);
-    rb_JT_force(m, s, S, s.qfrc_con);
+    sv_JT_force(cx);
     float gn = 0;
     BFOR(i, nv) { const float gi = s.Ma[i] - s.qfrc_smooth[i] - s.qfrc_con[i]; s.grad[i] = gi; gn += gi * gi; }
     gn = sqrtf(rb_sum(s, gn)) * scale;
@@ -1837,19 +1911,16 @@ __device__ __forceinline__ int rb_solve(RbM m, RbLds& s, float* S, int flags) {
     bool okf = true;
     for (int grp = 0; grp < m.ngroup; grp++) {
       if (m.b_star_grp[4 * grp] && !(flags & 4)) {   // H = M + diagonal on this group: block elimination along the tree
-        rb_row_diag(m, s, S, grp, s.Mv); RB_PROFS(10);
-        rb_star_group_solve(m, s, Msp, grp, s.Mv, 1.f, s.grad, s.search, -1.f); RB_PROFS(11);
+        sv_star_direction(cx, grp, 0); RB_PROFS(10);
+        sv_star_direction(cx, grp, 1); RB_PROFS(11);
         continue;
       }
-      rb_M_block(m, s, Msp, grp, (const float*)0, 0.f);
-      rb_hessian_add(m, s, S, grp); RB_PROFS(10);
-      rb_scale_block(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]);
-      okf = rb_chol(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]) && okf; RB_PROFS(11);
-      rb_group_solve(m, s, grp, s.grad, s.search, -1.f); RB_PROFS(12);
+      sv_hessian(cx, grp); RB_PROFS(10);
+      okf = (sv_factor(cx, grp) != 0) && okf; RB_PROFS(11);
+      sv_direction(cx, grp); RB_PROFS(12);
     }
     if (!okf && TID == 0) s.status |= RG_STATUS_BAD_FACTOR;
-    rb_M_mul(m, Msp, s.search, s.Mv);
-    rb_J_mul(m, s, S, s.search, true);
+    sv_MJ_mul(cx, 3);
     float q1 = 0, q2 = 0, sn = 0;
     BFOR(i, nv) { q1 += s.search[i] * (s.Ma[i] - s.qfrc_smooth[i]); q2 += 0.5f * s.search[i] * s.Mv[i]; sn += s.search[i] * s.search[i]; }
     rb_sum3(s, q1, q2, sn);
@@ -1857,7 +1928,7 @@ __device__ __forceinline__ int rb_solve(RbM m, RbLds& s, float* S, int flags) {
     if (sn < RB_MINVAL) break;
     const float gtol = tol * 0.01f * sn / scale * 1e-3f;   // (tolerance x ls_tolerance x |search| / scale x 1e-3: oracle's "exact" line search)
     RB_PROFS(13);
-    const float alpha = rb_line_search(s, row, SC(CON), m.cone == 1 ? s.ncon : 0, ne, gauss, q1, q2, gtol, 40); RB_PROFS(14);
+    const float alpha = sv_line_search(cx, gauss, q1, q2, gtol); RB_PROFS(14);
     if (alpha == 0.f) break;
     BFOR(i, nv) s.qa[i] += alpha * s.search[i];
     BSYNC();
@@ -1868,18 +1939,11 @@ __device__ __forceinline__ int rb_solve(RbM m, RbLds& s, float* S, int flags) {
 
 // ------------------------------------------------------------------------------------------------- integration
 // mj_Euler: implicit in joint damping, quaternion integration
-__device__ __forceinline__ void rb_euler(RbM m, RbLds& s, float* S, int flags) {
+__device__ __forceinline__ void rb_euler(RbCtx cx, RbM m, RbLds& s, float* S, int flags) {
   const float h = m.timestep;
   BFOR(i, m.nv) s.grad[i] = s.qfrc_smooth[i] + s.qfrc_con[i];
   BSYNC();
-  if (m.b_tree8[0] > 0 && !(flags & 4)) rb_trees8_solve(m, s, SC(MSP), m.dof_damping, h, s.grad, s.search, 1.f);
-  else for (int grp = 0; grp < m.ngroup; grp++) {
-    if (m.b_star_grp[4 * grp + 3] && !(flags & 4)) { rb_star_group_solve(m, s, SC(MSP), grp, m.dof_damping, h, s.grad, s.search, 1.f); continue; }
-    rb_M_block(m, s, SC(MSP), grp, m.dof_damping, h);
-    rb_scale_block(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]);
-    if (!rb_chol(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]) && TID == 0) s.status |= RG_STATUS_BAD_FACTOR;
-    rb_group_solve(m, s, grp, s.grad, s.search, 1.f);   // s.search <- qacc of the damped system
-  }
+  sv_M_solve(cx, 1, flags);
   BFOR(i, m.nv) s.qvel[i] += h * s.search[i];
   BSYNC();
   BFOR(j, m.njnt) {
@@ -1958,6 +2022,31 @@ __device__ __forceinline__ void rb_sensors(RbM m, RbLds& s, float* S, float* out
   BSYNC();
 }
 
+RB_STAGE void sb_position(RbCtx c) { RB_STAGE_ENTER(); rb_kinematics(m, s, S); rb_com_pos(m, s, S); }
+RB_STAGE void sb_tendon(RbCtx c) { RB_STAGE_ENTER(); rb_tendon(m, s, S); }
+RB_STAGE void sb_crb(RbCtx c) { RB_STAGE_ENTER(); rb_crb(m, s, S); }
+RB_STAGE void sb_velocity(RbCtx c) { RB_STAGE_ENTER(); rb_velocity(m, s, S); }
+RB_STAGE void sb_collision(RbCtx c, int flags) {   // equality pseudo-contacts + broadphase
+  RB_STAGE_ENTER(); RbLRef L = RB_L(c);
+  const int e = blockIdx.x;
+  const float* eqd = m.neq > 0 ? L.bt.eq_data + (size_t)e * 7 * m.neq : (const float*)0;
+  const int* eqa = m.neq > 0 ? L.bt.eq_active + (size_t)e * m.neq : (const int*)0;
+  rb_equality(m, s, S, eqd, eqa);
+  rb_broadphase(m, s, S, flags);
+}
+RB_STAGE void sb_narrow_convex(RbCtx c, int flags) { RB_STAGE_ENTER(); rb_narrow_convex(m, s, S, flags); }
+RB_STAGE void sb_narrow_box(RbCtx c, int flags) { RB_STAGE_ENTER(); rb_narrow_box(m, s, S, flags); }
+RB_STAGE void sb_rows(RbCtx c) {
+  RB_STAGE_ENTER(); RbLRef L = RB_L(c);
+  const float* eqd = m.neq > 0 ? L.bt.eq_data + (size_t)blockIdx.x * 7 * m.neq : (const float*)0;
+  rb_make_constraint(m, s, S, eqd);
+}
+RB_STAGE void sb_pid(RbCtx c, int apply) { RB_STAGE_ENTER(); rb_pid(m, s, S, apply != 0); }
+RB_STAGE void sb_smooth(RbCtx c, int flags) { RB_STAGE_ENTER(); rb_dof_contact_lists(m, s, S); rb_pid(m, s, S, true); sv_M_solve(c, 0, flags); }
+RB_STAGE int sb_solve(RbCtx c, int flags) { RB_STAGE_ENTER(); return rb_solve(c, m, s, S, flags); }
+RB_STAGE void sb_euler(RbCtx c, int flags) { RB_STAGE_ENTER(); rb_euler(c, m, s, S, flags); }
+RB_STAGE void sb_sensors(RbCtx c) { RB_STAGE_ENTER(); RbLRef L = RB_L(c); rb_sensors(m, s, S, L.bt.sensordata + (size_t)blockIdx.x * m.nsensordata); }
+
 #ifdef RG_EMUL
 #define RB_MAKE_CTX() const RbModelDev& m = *mp; const RbLaunch& L = launch
 #else
@@ -1970,6 +2059,11 @@ __global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbMod
   if (e >= L.bt.B) return;
   if (L.bt.active && !L.bt.active[e]) return;
   float* S = L.bt.scratch + (size_t)e * m.scratch_words;
+#ifdef RG_EMUL
+  const RbCtx c{(const void*)mp, (const void*)&launch, S};
+#else
+  const RbCtx c{(const void*)mp, (const void*)((const RG_AS4 char*)__builtin_amdgcn_kernarg_segment_ptr() + 8), S};
+#endif
   const int nv = m.nv, nq = m.nq, nu = m.nu, flags = L.flags;
   BFOR(i, nq) s.qpos[i] = L.bt.qpos[(size_t)e * nq + i];
   BFOR(i, nv) { s.qvel[i] = L.bt.qvel[(size_t)e * nv + i]; s.warm[i] = L.bt.qacc_warmstart[(size_t)e * nv + i]; }
@@ -2001,8 +2095,8 @@ __global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbMod
   if (L.tcp.enabled) {
     if (L.tcp.sync) { if (TID < 6) s.qpos[L.tcp.arm_q[TID]] = L.tcp.main_qpos[(size_t)e * L.tcp.main_nq + L.tcp.main_arm_q[TID]]; }
     BSYNC();
-    rb_kinematics(m, s, S); rb_com_pos(m, s, S); rb_tendon(m, s, S);
-    if (L.tcp.sync) rb_pid(m, s, S, false);   // the controller tick of sync_to's mj_forward (free_dof_tcp_arm.py:214-225)
+    sb_position(c); sb_tendon(c);
+    if (L.tcp.sync) sb_pid(c, 0);   // the controller tick of sync_to's mj_forward (free_dof_tcp_arm.py:214-225)
     // the action that reaches the env: as given, or bin index -> value (DiscretizeActionWrapper.action, wrappers/util.py:66-70) -> exponential
     // moving average with bias correction (SmoothActionWrapper.step / IncrementalExpAvg, util.py:142-160, 213-218)
     const bool scripted = L.tcp.hold && L.tcp.hold[e] != 0;
@@ -2056,35 +2150,24 @@ __global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbMod
     if (rb_sum(s, bd) > 0) { if (TID == 0) s.status |= RG_STATUS_BAD_STATE; break; }
     long long tp0 = rg_clock(), tp1;
 #define RB_PROF(k) do { if (flags & 2) { BSYNC(); tp1 = rg_clock(); if (TID == 0) s.prof[k] += (float)(tp1 - tp0); tp0 = tp1; } } while (0)
-    rb_kinematics(m, s, S); rb_com_pos(m, s, S); RB_PROF(0);
-    rb_tendon(m, s, S); rb_crb(m, s, S); RB_PROF(1);
-    rb_velocity(m, s, S); RB_PROF(2);
-    rb_equality(m, s, S, eqd, eqa);
-    rb_collision(m, s, S, flags); RB_PROF(3);
-    rb_make_constraint(m, s, S, eqd); RB_PROF(4);
-    rb_dof_contact_lists(m, s, S);
-    rb_pid(m, s, S, true);
-    // qacc_smooth = inv(M) qfrc_smooth
-    if (m.b_tree8[0] > 0 && !(flags & 4)) rb_trees8_solve(m, s, SC(MSP), (const float*)0, 0.f, s.qfrc_smooth, s.qacc_smooth, 1.f);
-    else for (int grp = 0; grp < m.ngroup; grp++) {
-      if (m.b_star_grp[4 * grp + 3] && !(flags & 4)) { rb_star_group_solve(m, s, SC(MSP), grp, (const float*)0, 0.f, s.qfrc_smooth, s.qacc_smooth, 1.f); continue; }   // (flags bit 2: dense path everywhere, test hook)
-      rb_M_block(m, s, SC(MSP), grp, (const float*)0, 0.f);
-      rb_scale_block(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]);
-      if (!rb_chol(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]) && TID == 0) s.status |= RG_STATUS_BAD_FACTOR;
-      rb_group_solve(m, s, grp, s.qfrc_smooth, s.qacc_smooth, 1.f);
-    }
+    sb_position(c); RB_PROF(0);
+    sb_tendon(c); sb_crb(c); RB_PROF(1);
+    sb_velocity(c); RB_PROF(2);
+    sb_collision(c, flags); sb_narrow_convex(c, flags); sb_narrow_box(c, flags); RB_PROF(3);
+    sb_rows(c); RB_PROF(4);
+    sb_smooth(c, flags);
     if ((flags & 1) && sub == 0) {   // stage dump of the first mj_step: ncon, nefc (the arrays themselves are read from the scratch row)
       if (TID == 0) { SC(DBG)[0] = (float)s.ncon; SC(DBG)[1] = (float)s.nefc; }
       BFOR(i, nv) { SC(DBG)[8 + i] = s.qfrc_bias[i]; SC(DBG)[8 + nv + i] = s.qfrc_passive[i]; SC(DBG)[8 + 2 * nv + i] = s.qfrc_act[i]; SC(DBG)[8 + 3 * nv + i] = s.qacc_smooth[i]; }
     }
     RB_PROF(5);
-    const int iters = rb_solve(m, s, S, flags); RB_PROF(6);
+    const int iters = sb_solve(c, flags); RB_PROF(6);
     if ((flags & 1) && sub == 0) { if (TID == 0) SC(DBG)[2] = (float)iters; BFOR(i, nv) SC(DBG)[8 + 4 * nv + i] = s.qa[i]; }
     st_ncon += s.ncon; st_nefc += s.nefc; st_iter += iters; nsub_done++;
     bd = 0; BFOR(i, nv) bd += (fabsf(s.qa[i]) < 1e10f) ? 0.f : 1.f;
     if (rb_sum(s, bd) > 0) { if (TID == 0) s.status |= RG_STATUS_BAD_STATE; break; }
     BFOR(i, nv) s.warm[i] = s.qa[i];
-    rb_euler(m, s, S, flags); RB_PROF(7);
+    sb_euler(c, flags); RB_PROF(7);
     if (TID == 0) s.time += m.timestep;
     BSYNC();
   }
@@ -2093,26 +2176,16 @@ __global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbMod
   const int nticks = L.bt.nticks ? L.bt.nticks[e] : L.nforward_ticks;
   const bool full_forward = (flags & 32) && nticks > 0;   // bit 5: the last state-less forward runs in full (mj_forward) and the sensors are read from it
   if (nticks > 0) {
-    rb_kinematics(m, s, S); rb_com_pos(m, s, S); rb_tendon(m, s, S);
-    for (int k = 0; k < nticks - (full_forward ? 1 : 0); k++) rb_pid(m, s, S, false);
+    sb_position(c); sb_tendon(c);
+    for (int k = 0; k < nticks - (full_forward ? 1 : 0); k++) sb_pid(c, 0);
   }
   if (full_forward) {
-    rb_crb(m, s, S); rb_velocity(m, s, S);
-    rb_equality(m, s, S, eqd, eqa);
-    rb_collision(m, s, S, flags);
-    rb_make_constraint(m, s, S, eqd);
-    rb_dof_contact_lists(m, s, S);
-    rb_pid(m, s, S, true);
-    if (m.b_tree8[0] > 0 && !(flags & 4)) rb_trees8_solve(m, s, SC(MSP), (const float*)0, 0.f, s.qfrc_smooth, s.qacc_smooth, 1.f);
-    else for (int grp = 0; grp < m.ngroup; grp++) {
-      if (m.b_star_grp[4 * grp + 3] && !(flags & 4)) { rb_star_group_solve(m, s, SC(MSP), grp, (const float*)0, 0.f, s.qfrc_smooth, s.qacc_smooth, 1.f); continue; }
-      rb_M_block(m, s, SC(MSP), grp, (const float*)0, 0.f);
-      rb_scale_block(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]);
-      if (!rb_chol(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]) && TID == 0) s.status |= RG_STATUS_BAD_FACTOR;
-      rb_group_solve(m, s, grp, s.qfrc_smooth, s.qacc_smooth, 1.f);
-    }
-    rb_solve(m, s, S, flags);
-    if (m.nsensor > 0 && L.bt.sensordata) rb_sensors(m, s, S, L.bt.sensordata + (size_t)e * m.nsensordata);
+    sb_crb(c); sb_velocity(c);
+    sb_collision(c, flags); sb_narrow_convex(c, flags); sb_narrow_box(c, flags);
+    sb_rows(c);
+    sb_smooth(c, flags);
+    sb_solve(c, flags);
+    if (m.nsensor > 0 && L.bt.sensordata) sb_sensors(c);
     if (TID == 0) { SC(DBG)[3] = (float)s.ncon; SC(DBG)[4] = (float)s.nefc; SC(DBG)[5] = (float)s.neqcon; }   // what the env kernel's contact scans read
   }
   if (L.tcp.enabled) {

@@ -78,7 +78,11 @@ typedef const RG_AS4 RgLaunch& RgLRef;
 #ifdef RG_EMUL
 #define RG_STAGE_BIG static inline
 #else
+#ifdef RG_BIG_STAGES_AS_CALLS
+#define RG_STAGE_BIG __device__ __attribute__((noinline))
+#else
 #define RG_STAGE_BIG __device__ __forceinline__   /* the register-hungriest stages stay in the kernel body: a call would save/restore ~30 callee-saved VGPRs through scratch */
+#endif
 #endif
 // env handled by this workgroup: the launch may carry a permutation (longest-expected-first dispatch order)
 #ifdef RG_EMUL
