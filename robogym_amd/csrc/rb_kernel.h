@@ -1353,6 +1353,53 @@ __device__ __forceinline__ void rb_dof_contact_lists(RbM m, RbLds& s, float* S) 
   // dependent pair of them per contact and Newton iteration)
   { float* loc = SC(CONLOC); BFOR(w, RB_CONW * s.ncon) { const int d = cidx[w]; loc[w] = (float)((d >= 0 && d < m.nv) ? m.b_dof_local[d] : 0); } }
   const float* con = SC(CON);
+  const int nvw = (m.nv + 31) >> 5, estride = (m.nv + 3) & ~3;
+  // LDS that is free between the solver calls: the dense block and everything up to the contact staging area
+  unsigned char* area = (unsigned char*)s.A;
+  const int cap = (int)((unsigned char*)(s.cst + 2 * RB_CST) - area);
+  if (s.ncon * (4 * nvw + estride) <= cap) {
+    // Per contact (one thread each): a bit mask of its dofs and a byte map dof -> entry, both in LDS, from ONE pass over its dof list (16-byte loads).
+    // Per dof: count, prefix, fill -- LDS reads only; the list keeps contact order, as the scan of the dof lists below produced it.
+    unsigned* mask = (unsigned*)area; unsigned char* emap = area + 4 * nvw * s.ncon;
+    BFOR(w, (nvw * s.ncon)) mask[w] = 0u;
+    BSYNC();
+    BFOR(c, s.ncon) {
+      if (con[RB_CONREC * c + RB_CR_ADR] < 0) continue;
+      const int nnz = (int)con[RB_CONREC * c + RB_CR_NNZ];
+      const rgf4* I4 = (const rgf4*)(cidx + RB_CONW * c);
+      rgf4 iv[RB_CONW / 4];
+#pragma unroll
+      for (int q = 0; q < RB_CONW / 4; q++) iv[q] = I4[q];
+#pragma unroll
+      for (int q = 0; q < RB_CONW / 4; q++) {
+        const int d4[4] = {__builtin_bit_cast(int, iv[q].x), __builtin_bit_cast(int, iv[q].y), __builtin_bit_cast(int, iv[q].z), __builtin_bit_cast(int, iv[q].w)};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int e = 4 * q + k, d = d4[k];
+          if (e < nnz && d >= 0 && d < m.nv) { mask[nvw * c + (d >> 5)] |= 1u << (d & 31); emap[estride * c + d] = (unsigned char)e; }
+        }
+      }
+    }
+    BSYNC();
+    int* cnt = (int*)s.x;
+    BFOR(i, m.nv) {
+      int n = 0;
+      for (int c = 0; c < s.ncon; c++) n += (mask[nvw * c + (i >> 5)] >> (i & 31)) & 1u;
+      cnt[i] = n;
+    }
+    BSYNC();
+    BFOR(i, m.nv) {
+      int a0 = 0;
+      for (int k = 0; k < i; k++) a0 += cnt[k];
+      adr[i] = a0;
+      if (i == m.nv - 1) adr[m.nv] = a0 + cnt[i];
+      int n = a0;
+      for (int c = 0; c < s.ncon; c++) if ((mask[nvw * c + (i >> 5)] >> (i & 31)) & 1u) lst[n++] = c * RB_CONW + (int)emap[estride * c + i];
+    }
+    BSYNC();
+    return;
+  }
+  // (more contacts than the free LDS holds: the same lists from masks in the scratch row and a scan of the dof lists)
   // a bit mask of its dofs per contact first (6 words: nv <= 192), so that a dof looks at one word per contact instead of its whole dof list
   unsigned* mask = (unsigned*)SC(CONF);   // (the per-contact solver scratch is free until the solver starts)
   BFOR(c, s.ncon) {
