@@ -35,4 +35,5 @@ torch.cuda.synchronize()
 el = time.time() - t0
 print("rearrange/%s, %d envs x %d steps with pipelined resets (goal time-out %d steps): %.1f s = %.0f env-steps/s (recipe steps included; %.1f %% of the env-steps were inside the recipe)"
       % ("ycb" if ycb else "blocks", B, T, per_obj * env.N, el, B * T / el, 100 * inside / T))
-print("episodes ended %d, started %d; envs with a status bit ever %d; non-finite observation rows %d" % (ended, started, int((seen != 0).sum()), bad))
+bits = {int(b): int(((seen & b) != 0).sum()) for b in (1, 2, 4, 8, 16, 32, 64) if int(((seen & b) != 0).sum())}
+print("episodes ended %d, started %d; envs with a status bit ever %d %s; non-finite observation rows %d" % (ended, started, int((seen != 0).sum()), bits, bad))
