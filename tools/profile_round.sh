@@ -41,3 +41,13 @@ python tools/rearrange_stage_profile.py 4096 ycb > gpurun_out/ycb_stage_$R.txt 2
 python tools/soak_rearrange.py 4096 500 blocks 20 > gpurun_out/soak_rearrange_$R.txt 2>&1
 python tools/soak_rearrange.py 4096 300 ycb 10 >> gpurun_out/soak_rearrange_$R.txt 2>&1
 ls gpurun_out/prof_$R gpurun_out/pmc_fetch_$R gpurun_out/pmc_write_$R gpurun_out/prof_rearrange_$R | head -30
+# HBM traffic of rb_step_kernel on configs[2] / [3] / [4] (separate FETCH_SIZE / WRITE_SIZE passes, as for the headline): the dominant launch of each
+for W in full_perpendicular rearrange_blocks ycb; do
+  X="--quick-reset"; [ $W = full_perpendicular ] && X=""
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_fetch_${W}_$R -o fetch --output-format csv -- python bench.py --workload $W $X --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > gpurun_out/pmc_fetch_${W}_$R.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_write_${W}_$R -o write --output-format csv -- python bench.py --workload $W $X --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > gpurun_out/pmc_write_${W}_$R.log 2>&1
+done
+# the N > 1 code path of the ycb workload over RCCL with one rank (process group, barriers, all-gather of the packed rows, max-reduce) on this 1-GPU box
+RG_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29712 bench.py --workload ycb --quick-reset --gpus 1 --steps 4 --warmup 1 --no-cpu-baseline > gpurun_out/bench_ycb_rccl1_$R.json 2> gpurun_out/bench_ycb_rccl1_$R.err
+tail -1 gpurun_out/bench_ycb_rccl1_$R.json | cut -c1-200
+
