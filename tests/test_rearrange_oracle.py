@@ -313,3 +313,37 @@ def test_mocap_ik_impulse_response(models, rce, mpc, expected, rise):
         assert abs(P[2 + rise, dim]) > 0.9 * total                       # (i) as the reference states it
         assert abs(total - expected) < 0.20 * expected, (dim, total)     # (ii) NOT the reference's 1e-3: see the docstring
         assert total < expected                                          # the deviation has one sign everywhere (pinned so that a change is noticed)
+
+
+def test_crowded_table_placement_keeps_objects_apart():
+    """`BatchedBlockRearrangeEnv._grid_placement` on the ycb object set, where the grid has fewer cells than objects (8 large meshes on the 0.61 x 0.58 m area):
+    the fallback (place_objects_with_no_constraint, common/utils.py:829-880, vectorised over envs, largest object first) leaves no two bounding boxes overlapping
+    and every box inside the placement area; the blocks set still takes the grid branch."""
+    from robogym_amd.envs.rearrange import blocks as Bk
+    from robogym_amd.envs.rearrange.xml import load_blocks_model, load_ycb_model, object_bounding_boxes
+
+    for model, N, crowded in ((load_ycb_model(8), 8, True), (load_blocks_model(5), 5, False)):
+        class Stub:
+            pass
+        e = Stub(); e.N = N
+        bb = object_bounding_boxes(model, N); e.obj_center, e.obj_half = bb[:, :3], bb[:, 3:]
+        A, gn = model.arrays, model.names["geom"]
+        tb, tg = model.name2id("body", "table"), gn.index("table")
+        e.table_pos, e.table_size, e.used_table_portion, e._rng = A["body_pos"][tb].copy(), A["geom_size"][tg].copy(), 1.0, np.random.RandomState(3)
+        e._aabb_half = lambda yaw, e=e: Bk.BatchedBlockRearrangeEnv._aabb_half(e, yaw)
+        B = 256
+        yaw = e._rng.uniform(0, 2 * np.pi, (B, N))
+        half = e._aabb_half(yaw)
+        tsx, tsy = 2 * e.table_size[0], 2 * e.table_size[1]
+        width, height = 0.5 * tsx, 0.38 * tsy
+        ncells = (width // (2 * half[:, :, 0].max(1))).astype(int) * (height // (2 * half[:, :, 1].max(1))).astype(int)
+        assert bool((ncells < N).any()) == crowded
+        out = Bk.BatchedBlockRearrangeEnv._grid_placement(e, yaw, np.arange(B))
+        c, s_ = np.cos(yaw), np.sin(yaw)
+        ctr = out[:, :, :2] + np.stack([c * e.obj_center[:, 0] - s_ * e.obj_center[:, 1], s_ * e.obj_center[:, 0] + c * e.obj_center[:, 1]], -1)
+        for i in range(N):
+            for j in range(i):
+                assert not ((np.abs(ctr[:, i] - ctr[:, j]) < half[:, i, :2] + half[:, j, :2] - 1e-9).all(-1)).any()
+        lo = e.table_pos[:2] - e.table_size[:2] + [0.5 * tsx - width / 2, 0.44 * tsy - height / 2]
+        assert (ctr - half[:, :, :2] >= lo - 1e-9).all() and (ctr + half[:, :, :2] <= lo + [width, height] + 1e-9).all()
+        assert np.allclose(out[:, :, 2] + e.obj_center[:, 2] - half[:, :, 2], e.table_pos[2] + e.table_size[2])      # every box stands on the table top
