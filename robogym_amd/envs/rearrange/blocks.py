@@ -189,6 +189,11 @@ class BatchedBlockRearrangeEnv:
     def step(self, actions: torch.Tensor):
         """RobotEnv.step (robot_env.py:804-844): returns (obs dict of [B, ...] views, reward [B, 3], done [B], info dict of tensors).
         Unwrapped: `actions` float32 [B, 6] in [-1, 1].  With the wrapper stack (`make_env`'s default): integer bin indices [B, 6] in [0, n_action_bins)."""
+        self._step_launch(actions)
+        return self._step_finish()
+
+    def _step_launch(self, actions):
+        """The step's three launches, nothing that waits for them (envs/rearrange/ycb.py GroupedYcbRearrangeEnv enqueues several groups before it finishes any)."""
         assert actions.shape == self.action_shape and actions.device == self.device
         sa = self.solver_active if self.pipelined else None
         if self.wrapped:
@@ -197,14 +202,11 @@ class BatchedBlockRearrangeEnv:
         else:
             assert actions.dtype == torch.float32 and actions.is_contiguous()
             self._physics(actions, solver_active=sa)
-        if self.pipelined:
-            self._post()
-            self._advance_recipes()
-            return self.observe(), self.reward, self.done, self.info()
-        if self.wrapped:
-            self._post()
-            return self.observe(), self.reward, self.done, self.info()
         self._post()
+
+    def _step_finish(self):
+        if self.pipelined:
+            self._advance_recipes()
         return self.observe(), self.reward, self.done, self.info()
 
     def info(self):
@@ -259,7 +261,12 @@ class BatchedBlockRearrangeEnv:
             pending = np.nonzero(crowded)[0]
             area = np.array([width, height])
             order = np.argsort(-(self.obj_half[:, 0] * self.obj_half[:, 1]), kind="stable")
+            rounds = 0
             while len(pending):
+                rounds += 1
+                if rounds > 200:      # (the reference gives up after max_placement_trial_count restarts as well, common/utils.py:623-716)
+                    raise RuntimeError("no collision-free placement for %d envs: the objects' bounding boxes cover %.0f %% of the placement area" % (
+                        len(pending), 100 * float((4 * self.obj_half[:, 0] * self.obj_half[:, 1]).sum()) / (width * height)))
                 h = half[pending]
                 cur, alive = np.zeros((len(pending), N, 2)), np.ones(len(pending), dtype=bool)
                 done_objs = []

@@ -227,13 +227,19 @@ def object_bounding_boxes(model: CompiledModel, num_objects: int) -> np.ndarray:
 YCB_MODEL_SEED = 0
 
 
-def load_ycb_model(num_objects: int = 8, recompile: bool = False) -> CompiledModel:
+def load_ycb_model(num_objects: int = 8, recompile: bool = False, set_index: int = 0) -> CompiledModel:
     """The main world of rearrange/ycb with a FIXED set of `num_objects` YCB objects (BASELINE.json configs[4]: num_objects = 8).  The reference
-    draws a new set per episode and rebuilds the simulation (envs/rearrange/ycb.py:58-84); per-env object sets are not built yet."""
-    path = os.path.join(MODEL_DIR, "rearrange_ycb%d.npz" % num_objects)
+    draws a new set per episode and rebuilds the simulation (envs/rearrange/ycb.py:58-84); here a compiled model holds one set, `set_index` selects
+    among the shipped ones (`_sample_object_meshes` with seed YCB_MODEL_SEED + set_index; envs/rearrange/ycb.py GroupedYcbRearrangeEnv runs several
+    side by side).  Per-episode sets are not built."""
+    path = os.path.join(MODEL_DIR, "rearrange_ycb%d%s.npz" % (num_objects, "" if set_index == 0 else "_s%d" % set_index))
     if not recompile and os.path.exists(path):
         return CompiledModel.load(path)
-    sets = sample_ycb_object_sets(np.random.RandomState(YCB_MODEL_SEED), num_objects)
+    sets = sample_ycb_object_sets(np.random.RandomState(YCB_MODEL_SEED + set_index), num_objects)
     m = build_ycb_xml(sets).build()
     m.names["object_mesh"] = [os.path.basename(os.path.dirname(s_[0])) for s_ in sets]
     return m
+
+
+#: object sets shipped as compiled models (tools/compile_models.py; seeds whose eight objects fit the placement area)
+YCB_SHIPPED_SETS = (0, 1, 2, 3, 4, 5)

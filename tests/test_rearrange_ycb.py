@@ -165,3 +165,35 @@ def test_ycb_env_runs_clean_gpu(oracle_lib):
     z = obs["obj_pos"][:, :, 2]
     assert float(z.min()) > env.table_height - 0.01 and float((z < env.table_height + 0.2).float().mean()) > 0.99
     assert not torch.equal(obs["obj_pos"][0], obs["obj_pos"][1]) and info["object_names"][0] == "055_baseball"
+
+
+def _grouped_env_checks(lib, device, B, sets, n_substeps, steps):
+    """Different object sets across the batch (GroupedYcbRearrangeEnv): one compiled model per group of envs, one API for the whole batch."""
+    from robogym_amd.envs.rearrange.ycb import GroupedYcbRearrangeEnv, make_env
+
+    kw = dict(lib=lib, n_substeps=n_substeps, stabilize_steps=1, n_random_initial_steps=0, settle_steps=0) if lib is not None else dict(stabilize_steps=20, n_random_initial_steps=2, settle_steps=20)
+    env = make_env(batch_size=B, device=device, starting_seed=4, object_sets=sets, pipelined_reset=True, **kw)
+    assert isinstance(env, GroupedYcbRearrangeEnv) and env.K == len(sets) and env.b == B // len(sets)
+    assert env.object_names[0][0] == "055_baseball" and env.object_names[1][0] == "044_flat_screwdriver" and env.object_names[0] != env.object_names[1]
+    obs = env.reset()
+    assert obs["obj_pos"].shape == (B, N, 3) and obs["qpos"].shape == (B, 64)
+    half0 = obs["obj_bbox_size"][0].cpu().numpy(); half1 = obs["obj_bbox_size"][env.b].cpu().numpy()
+    assert not np.allclose(np.sort(half0.max(1)), np.sort(half1.max(1)))                    # the two groups really hold different objects
+    gen = torch.Generator(device=env.device); gen.manual_seed(2)
+    for _ in range(steps):
+        obs, reward, done, info = env.step(torch.randint(0, 11, (B, 6), generator=gen, device=env.device))
+    env.sync()
+    assert reward.shape == (B, 3) and done.shape == (B,) and info["resetting"].shape == (B,) and len(info["object_names"]) == B
+    assert int(env.status().max()) == 0 and all(bool(torch.isfinite(g.packed).all()) for g in env.groups)
+    z = obs["obj_pos"][:, :, 2]
+    assert float(z.min()) > env.groups[0].table_height - 0.01
+    return env
+
+
+def test_ycb_object_sets_across_the_batch_emul(emul_lib):
+    _grouped_env_checks(emul_lib, "cpu", B=2, sets=(0, 1), n_substeps=1, steps=2)
+
+
+@pytest.mark.gpu
+def test_ycb_object_sets_across_the_batch_gpu():
+    _grouped_env_checks(None, "cuda:0", B=256, sets=(0, 1, 2, 4), n_substeps=40, steps=5)
