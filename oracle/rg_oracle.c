@@ -1526,25 +1526,39 @@ static ls_pt ls_eval(const ro_data* d, real alpha, const real* jar, const real* 
   }
   return p;
 }
+static int ro_trace = 0;   /* diagnostics of the Newton iterations (ro_set_trace) */
+void ro_set_trace(int on) { ro_trace = on; }
 /* exact minimiser of the convex piecewise-quadratic 1-D restriction: safeguarded Newton on its derivative */
 static real line_search(const ro_data* d, const real* jar, const real* jv, const real* quadGauss, real gtol, int maxit) {
   ls_pt p0 = ls_eval(d, 0, jar, jv, quadGauss);
   if (p0.grad >= 0 || p0.hess <= 0) return 0;
   real lo = 0, hi = -1, glo = p0.grad, hlo = p0.hess, ghi = 0, hhi = 0;
   real a = -p0.grad / p0.hess;
+  real best_a = 0, best_cost = p0.cost;     /* the best point seen: what is returned when the iteration limit ends the search */
+  real wprev = -1; int since = 0;
   for (int it = 0; it < maxit; it++) {
     ls_pt p = ls_eval(d, a, jar, jv, quadGauss);
+    if (ro_trace) fprintf(stderr, "      ls it %d a %.9g grad %.4g hess %.4g lo %.9g hi %.9g gtol %.3g\n", it, (double)a, (double)p.grad, (double)p.hess, (double)lo, (double)hi, (double)gtol);
+    if (p.cost < best_cost) { best_cost = p.cost; best_a = a; }
     if (fabs(p.grad) < gtol) return a;
     if (p.grad < 0) { lo = a; glo = p.grad; hlo = p.hess; } else { hi = a; ghi = p.grad; hhi = p.hess; }
-    real cand = lo - glo / hlo;               /* Newton step from the left end (derivative is convex-monotone) */
-    if (hi >= 0 && !(cand > lo && cand < hi)) { /* fall back: Newton from the right end, then bisection */
-      cand = hi - ghi / hhi;
-      if (!(cand > lo && cand < hi)) cand = 0.5 * (lo + hi);
+    real cand = lo - glo / hlo;               /* Newton step from the left end */
+    if (hi >= 0) {
+      if (!(cand > lo && cand < hi)) {        /* fall back: Newton from the right end, then bisection */
+        cand = hi - ghi / hhi;
+        if (!(cand > lo && cand < hi)) cand = 0.5 * (lo + hi);
+      }
+      /* The derivative is increasing but only piecewise smooth: at a kink where a stiff row switches on, the Newton steps from the two ends can
+       * alternate between two points on either side of it for ever (seen with the gripper driven into a joint limit: slope ratio 10 at the kink).
+       * Safeguard: the bracket has to halve at least every two evaluations, else bisect. */
+      real w = hi - lo;
+      if (wprev < 0) { wprev = w; since = 0; }
+      else if (++since >= 2) { if (w > 0.5 * wprev) cand = 0.5 * (lo + hi); wprev = w; since = 0; }
     }
     if (cand == a) return a;
     a = cand;
   }
-  return a;
+  return best_a;
 }
 
 static void ro_solve(const ro_model* m, ro_data* d) {
@@ -1580,6 +1594,7 @@ static void ro_solve(const ro_model* m, ro_data* d) {
     for (int i = 0; i < nv; i++) { real s = Ma[i] - d->qfrc_smooth[i]; for (int r = 0; r < ne; r++) s -= d->efc_J[(size_t)r * nv + i] * force[r]; grad[i] = s; }
     real gn = 0; for (int i = 0; i < nv; i++) gn += grad[i] * grad[i];
     gn = sqrt(gn) * scale;
+    if (ro_trace) fprintf(stderr, "newton iter %d cost %.12g improvement*scale %.3e gn %.3e nefc %d\n", iter, (double)cost, iter ? (double)(scale * (oldcost - cost)) : 0.0, (double)gn, ne);
     if (iter > 0) { real improvement = scale * (oldcost - cost); if (improvement < m->tolerance) break; }
     if (gn < m->tolerance || iter >= m->iterations) break;
     d->solver_iter = iter + 1;
@@ -1615,6 +1630,11 @@ static void ro_solve(const ro_model* m, ro_data* d) {
     if (snorm < MINVAL) break;
     real gtol = m->tolerance * m->ls_tolerance * snorm / scale * 1e-3; /* much tighter than MuJoCo's: "exact" */
     real alpha = line_search(d, jar, jv, quadGauss, gtol, 60);
+    if (ro_trace) {
+      ls_pt pa = ls_eval(d, alpha, jar, jv, quadGauss), pz = ls_eval(d, 0, jar, jv, quadGauss);
+      fprintf(stderr, "   alpha %.6g |search| %.3e  model cost(0) %.12g grad(0) %.4g hess(0) %.4g  model cost(alpha) %.12g grad %.4g\n", (double)alpha, (double)snorm, (double)pz.cost, (double)pz.grad, (double)pz.hess, (double)pa.cost, (double)pa.grad);
+      for (real t = 0.1; t < 1.25; t += 0.1) { ls_pt q = ls_eval(d, t, jar, jv, quadGauss); fprintf(stderr, "      t %.1f cost %.10g grad %.4g\n", (double)t, (double)q.cost, (double)q.grad); }
+    }
     if (alpha == 0) break;
     for (int i = 0; i < nv; i++) qa[i] += alpha * search[i];
   }

@@ -1861,19 +1861,29 @@ __device__ __forceinline__ float rb_line_search(RbLds& s, const float* row, cons
   if (p0.grad >= 0 || p0.hess <= 0) return 0.f;
   float lo = 0, hi = -1, glo = p0.grad, hlo = p0.hess, ghi = 0, hhi = 0;
   float a = -p0.grad / p0.hess;
+  float best_a = 0.f, best_cost = p0.cost;   // the best point seen: what is returned when the iteration limit ends the search
+  float wprev = -1.f; int since = 0;
   for (int it = 0; it < maxit; it++) {
     const RbLs p = rb_ls_eval(s, row, con, ncone, own, nefc, a, q0, q1, q2);
+    if (p.cost < best_cost) { best_cost = p.cost; best_a = a; }
     if (fabsf(p.grad) < gtol) return a;
     if (p.grad < 0) { lo = a; glo = p.grad; hlo = p.hess; } else { hi = a; ghi = p.grad; hhi = p.hess; }
     float cand = lo - glo / hlo;
-    if (hi >= 0 && !(cand > lo && cand < hi)) {
-      cand = hi - ghi / hhi;
-      if (!(cand > lo && cand < hi)) cand = 0.5f * (lo + hi);
+    if (hi >= 0) {
+      if (!(cand > lo && cand < hi)) {
+        cand = hi - ghi / hhi;
+        if (!(cand > lo && cand < hi)) cand = 0.5f * (lo + hi);
+      }
+      // at a kink of the derivative (a stiff row switching on) the Newton steps from the two ends can alternate between two points on either side of it
+      // for ever: the bracket has to halve at least every two evaluations, else bisect (oracle line_search)
+      const float w = hi - lo;
+      if (wprev < 0.f) { wprev = w; since = 0; }
+      else if (++since >= 2) { if (w > 0.5f * wprev) cand = 0.5f * (lo + hi); wprev = w; since = 0; }
     }
     if (cand == a) return a;
     a = cand;
   }
-  return a;
+  return best_a;
 }
 // mj_solNewton (oracle ro_solve): s.qa <- qacc, s.qfrc_con <- J' f; returns the iteration count
 // the solver's sub-stages as calls of their own: one copy each of the products M x / J x (three call sites), J' f, the Hessian assembly, the factorisation and the line search
