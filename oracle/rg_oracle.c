@@ -1535,7 +1535,7 @@ static real line_search(const ro_data* d, const real* jar, const real* jv, const
   real lo = 0, hi = -1, glo = p0.grad, hlo = p0.hess, ghi = 0, hhi = 0;
   real a = -p0.grad / p0.hess;
   real best_a = 0, best_cost = p0.cost;     /* the best point seen: what is returned when the iteration limit ends the search */
-  real wprev = -1; int since = 0;
+  real wprev = 1e300; int since = 0;
   for (int it = 0; it < maxit; it++) {
     ls_pt p = ls_eval(d, a, jar, jv, quadGauss);
     if (ro_trace) fprintf(stderr, "      ls it %d a %.9g grad %.4g hess %.4g lo %.9g hi %.9g gtol %.3g\n", it, (double)a, (double)p.grad, (double)p.hess, (double)lo, (double)hi, (double)gtol);
@@ -1550,10 +1550,11 @@ static real line_search(const ro_data* d, const real* jar, const real* jv, const
       }
       /* The derivative is increasing but only piecewise smooth: at a kink where a stiff row switches on, the Newton steps from the two ends can
        * alternate between two points on either side of it for ever (seen with the gripper driven into a joint limit: slope ratio 10 at the kink).
-       * Safeguard: the bracket has to halve at least every two evaluations, else bisect. */
-      real w = hi - lo;
-      if (wprev < 0) { wprev = w; since = 0; }
-      else if (++since >= 2) { if (w > 0.5 * wprev) cand = 0.5 * (lo + hi); wprev = w; since = 0; }
+       * Safeguard: three steps in a row that are not at least halving (a converging Newton iteration shrinks them much faster) -> bisect. */
+      real step = fabs(cand - a);
+      if (step > 0.5 * wprev) since++; else since = 0;      /* (wprev: the previous step's length) */
+      if (since >= 3) { cand = 0.5 * (lo + hi); since = 0; step = fabs(cand - a); }
+      wprev = step;
     }
     if (cand == a) return a;
     a = cand;

@@ -1862,7 +1862,7 @@ __device__ __forceinline__ float rb_line_search(RbLds& s, const float* row, cons
   float lo = 0, hi = -1, glo = p0.grad, hlo = p0.hess, ghi = 0, hhi = 0;
   float a = -p0.grad / p0.hess;
   float best_a = 0.f, best_cost = p0.cost;   // the best point seen: what is returned when the iteration limit ends the search
-  float wprev = -1.f; int since = 0;
+  float wprev = 3.0e38f; int since = 0;
   for (int it = 0; it < maxit; it++) {
     const RbLs p = rb_ls_eval(s, row, con, ncone, own, nefc, a, q0, q1, q2);
     if (p.cost < best_cost) { best_cost = p.cost; best_a = a; }
@@ -1875,10 +1875,11 @@ __device__ __forceinline__ float rb_line_search(RbLds& s, const float* row, cons
         if (!(cand > lo && cand < hi)) cand = 0.5f * (lo + hi);
       }
       // at a kink of the derivative (a stiff row switching on) the Newton steps from the two ends can alternate between two points on either side of it
-      // for ever: the bracket has to halve at least every two evaluations, else bisect (oracle line_search)
-      const float w = hi - lo;
-      if (wprev < 0.f) { wprev = w; since = 0; }
-      else if (++since >= 2) { if (w > 0.5f * wprev) cand = 0.5f * (lo + hi); wprev = w; since = 0; }
+      // for ever: three steps in a row that are not at least halving (a converging Newton iteration shrinks them much faster) -> bisect (oracle line_search)
+      float step = fabsf(cand - a);
+      if (step > 0.5f * wprev) since++; else since = 0;     // (wprev: the previous step's length)
+      if (since >= 3) { cand = 0.5f * (lo + hi); since = 0; step = fabsf(cand - a); }
+      wprev = step;
     }
     if (cand == a) return a;
     a = cand;
