@@ -212,3 +212,68 @@ def test_rearrange_pipelined_reset_sequence_emul(emul_lib):
 @pytest.mark.gpu
 def test_rearrange_pipelined_reset_sequence_gpu():
     _pipelined_reset_sequence(None, "cuda:0", n_substeps=40, B=64)
+
+
+# ------------------------------------------------------------------------------------------------ the goal layer against the reference's own code
+def _goal_golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "rearrange_goal.npz"))
+
+
+def test_oracle_goal_distance_matches_reference_code():
+    """oracle/rearrange_oracle.py's relative_goal / goal_distance against tests/golden/rearrange_goal.npz = `ObjectStateGoal.relative_goal / goal_distance`
+    (goals/object_state.py:492-599), whose source tools/gen_golden_rearrange_goal.py executes as it stands: 64 random object / goal states."""
+    from oracle import rearrange_oracle as RO
+
+    g = _goal_golden()
+    for t in range(len(g["cur_pos"])):
+        rel_pos = g["goal_pos"][t] - g["cur_pos"][t]
+        rel_rot = RO.normalize_angles(RO.subtract_euler(g["goal_rot"][t], g["cur_rot"][t]))
+        assert np.abs(rel_pos - g["rel_pos"][t]).max() < 1e-12 and np.abs(rel_rot - g["rel_rot"][t]).max() < 1e-9
+        d_rot = RO.quat_magnitude(RO.quat_normalize(RO.euler2quat(rel_rot)))
+        assert np.abs(np.linalg.norm(rel_pos, axis=-1) - g["dist_pos"][t]).max() < 1e-12 and np.abs(d_rot - g["dist_rot"][t]).max() < 1e-9
+
+
+def _env_kernel_goal_layer(lib, device, B):
+    """The env kernel's goal entries (rel_goal_obj_pos, rel_goal_obj_rot, the summed distances in info, is_goal_achieved) for object poses and goals taken
+    from the golden: the objects are put at (cur_pos, euler2quat(cur_rot)), one forward, then the observation row."""
+    from oracle import rearrange_oracle as RO
+
+    g = _goal_golden()
+    kw = dict(lib=lib, n_substeps=1) if lib is not None else {}
+    env = BatchedBlockRearrangeEnv(B, device=device, stabilize_steps=1, n_random_initial_steps=0, settle_steps=0, **kw)
+    env.reset()
+    T = B * 2 if lib is not None else len(g["cur_pos"]) // B * B
+    worst = np.zeros(4)
+    for t0 in range(0, T, B):
+        sl = slice(t0, t0 + B)
+        pos = g["cur_pos"][sl] + np.array([1.45, 0.77, 0.9])                      # (somewhere above the table: nothing touches)
+        quat = RO.euler2quat(g["cur_rot"][sl])
+        for i, qa in enumerate(env.obj_q):
+            env.sim.qpos[:, qa:qa + 7] = torch.tensor(np.concatenate([pos[:, i], quat[:, i]], -1).astype(np.float32), device=env.device)
+        gq = RO.euler2quat(g["goal_rot"][sl])
+        env.goal[:] = torch.tensor(np.concatenate([g["goal_pos"][sl] + np.array([1.45, 0.77, 0.9]), gq], -1).astype(np.float32), device=env.device)
+        env.goal_rot[:] = torch.tensor(g["goal_rot"][sl].astype(np.float32), device=env.device)
+        env.sim.env_step(nsubsteps=0, nforward_ticks=1, flags=32)
+        env._observe_only()
+        env.sync()
+        obs = env.observe()
+        rp, rr = obs["rel_goal_obj_pos"].cpu().numpy(), obs["rel_goal_obj_rot"].cpu().numpy()
+        e_rr = np.abs(RO.normalize_angles(rr - g["rel_rot"][sl]))                  # (angles compare modulo 2 pi)
+        # Euler triples are not unique at the gimbal lock (|pitch| ~ pi / 2): the rotation they stand for is what has to agree there
+        q_k, q_g = RO.euler2quat(rr.astype(np.float64)), RO.euler2quat(g["rel_rot"][sl])
+        e_q = np.minimum(np.abs(q_k - q_g).max(-1), np.abs(q_k + q_g).max(-1))
+        lock = np.abs(np.abs(g["rel_rot"][sl][..., 1]) - np.pi / 2) < 0.05
+        worst = np.maximum(worst, [np.abs(rp - g["rel_pos"][sl]).max(), e_rr[~lock].max() if (~lock).any() else 0.0, e_q.max(),
+                                   np.abs(env.goal_dist[:, 0].cpu().numpy() - g["dist_pos"][sl].sum(-1)).max() + np.abs(env.goal_dist[:, 1].cpu().numpy() - g["dist_rot"][sl].sum(-1)).max()])
+    print("env kernel goal layer vs the reference's code: rel pos %.1e, rel rot (Euler, away from gimbal lock) %.1e, rel rot as a quaternion %.1e, summed distances %.1e" % tuple(worst))
+    assert worst[0] < 2e-6 and worst[1] < 2e-5 and worst[2] < 2e-6 and worst[3] < 5e-5
+
+
+def test_env_kernel_goal_layer_matches_reference_code_emul(emul_lib):
+    _env_kernel_goal_layer(emul_lib, "cpu", B=4)
+
+
+@pytest.mark.gpu
+def test_env_kernel_goal_layer_matches_reference_code_gpu():
+    _env_kernel_goal_layer(None, "cuda:0", B=16)
