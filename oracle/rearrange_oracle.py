@@ -215,6 +215,18 @@ def mocap_set_action(o: OracleArmSim, action):
 
 
 # ----------------------------------------------------------------------------------------- the env
+def tcp_quat_control(arm_control, wrist_qpos, wrist_lo, wrist_hi, gripper_quat):
+    """FreeDOFTcpArm.set_position_control up to the solver call (robot/ur16e/mujoco/free_dof_tcp_arm.py:182-206): the denormalised control (xyz, roll, pitch)
+    -> position part and the quaternion DIFFERENCE handed to the mocap solver.  `constrain_quat_ctrl` (:131-155): the PITCH dimension is mapped to joint 5
+    (MocapSolver.JOINT_MAPPING, control/tcp/mocap_solver.py:17-19) and kept inside that joint's range less JOINT_DRIFT_THRESHOLD; `get_tcp_quat`
+    (mocap_solver.py:33-49, no alignment axis for the roll + yaw arm): dof dims ROLL -> euler[0], PITCH -> euler[2]."""
+    pos, angle = np.asarray(arm_control[:3], dtype=float), np.asarray(arm_control[3:], dtype=float).copy()
+    angle[1] = np.clip(angle[1], wrist_lo + JOINT_DRIFT_THRESHOLD - wrist_qpos, wrist_hi - JOINT_DRIFT_THRESHOLD - wrist_qpos)
+    euler = np.zeros(3); euler[0], euler[2] = angle[0], angle[1]
+    gq = np.asarray(gripper_quat, dtype=float)
+    return pos, quat_mul(gq, euler2quat(euler)) - gq
+
+
 class OracleRearrangeEnv:
     """`BlockRearrangeEnv` (envs/rearrange/blocks.py) with its default robot: MujocoURTcpJointGripperCompositeRobot =
     JointControlledTcpArm (FreeRollYawTcpArm controller in the solver simulation) + MujocoRobotiqGripper."""
@@ -288,17 +300,10 @@ class OracleRearrangeEnv:
         if self.reset_controller_error:
             c.sim.qpos[c.arm_q] = m.sim.qpos[m.arm_q]
             c.sim.forward()
-        pos, angle = arm[:3], arm[3:].copy()
-        # FreeDOFTcpArm.constrain_quat_ctrl: the PITCH dimension is the wrist joint (index 5), kept inside its range
         A = c.model.arrays
         j6 = c.model.names["joint"].index("robot0:J6")
         lo, hi = A["jnt_range"][j6]
-        q6 = c.sim.qpos[c.arm_q[5]]
-        angle[1] = np.clip(angle[1], lo + JOINT_DRIFT_THRESHOLD - q6, hi - JOINT_DRIFT_THRESHOLD - q6)
-        # MocapSolver.get_tcp_quat: dof dims (ROLL -> euler[0], PITCH -> euler[2]), a quaternion DIFFERENCE
-        euler = np.zeros(3); euler[0], euler[2] = angle[0], angle[1]
-        gq = c.body_xquat(c.tcp_body)
-        dq = quat_mul(gq, euler2quat(euler)) - gq
+        pos, dq = tcp_quat_control(arm, c.sim.qpos[c.arm_q[5]], lo, hi, c.body_xquat(c.tcp_body))
         mocap_set_action(c, np.concatenate([pos, dq]))
         c.mj_sim_step()                                             # controller_autostep: MjSim.step, no trailing forward
         m.sim.ctrl[:6] = c.sim.qpos[c.arm_q]                        # JointControlledArm.set_position_control

@@ -347,3 +347,20 @@ def test_crowded_table_placement_keeps_objects_apart():
         lo = e.table_pos[:2] - e.table_size[:2] + [0.5 * tsx - width / 2, 0.44 * tsy - height / 2]
         assert (ctr - half[:, :, :2] >= lo - 1e-9).all() and (ctr + half[:, :, :2] <= lo + [width, height] + 1e-9).all()
         assert np.allclose(out[:, :, 2] + e.obj_center[:, 2] - half[:, :, 2], e.table_pos[2] + e.table_size[2])      # every box stands on the table top
+
+
+def test_tcp_action_path_matches_reference_code():
+    """Normalised action -> denormalised control -> wrist-constrained angles -> the quaternion difference handed to the mocap solver: the oracle's
+    `denormalize` scaling and `tcp_quat_control` against tests/golden/rearrange_tcp.npz, i.e. the reference's own `FreeDOFTcpArm.denormalize_position_control /
+    constrain_quat_ctrl` and `MocapSolver.get_tcp_quat` source run by tools/gen_golden_rearrange_tcp.py (96 samples, the wrist constraint binding in 18)."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "rearrange_tcp.npz"))
+    lo, hi = g["wrist_range"]
+    for t in range(len(g["action"])):
+        a, mpc = g["action"][t], float(g["mpc"][t])
+        den = np.concatenate([a[:3] * mpc, a[3:5] * np.array([RO.SPEED_ROLL, RO.SPEED_PITCH]) * mpc])          # OracleRearrangeEnv.denormalize, the arm's five numbers
+        assert np.abs(den - g["denorm"][t]).max() < 1e-15
+        pos, dq = RO.tcp_quat_control(den, g["q"][t][5], lo, hi, g["gripper_quat"][t])
+        assert np.abs(pos - g["denorm"][t][:3]).max() == 0 and np.abs(dq - g["dquat"][t]).max() < 1e-14
+    assert abs(RO.JOINT_DRIFT_THRESHOLD - np.deg2rad(1)) < 1e-15
