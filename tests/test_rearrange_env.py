@@ -232,6 +232,11 @@ def test_oracle_goal_distance_matches_reference_code():
         assert np.abs(rel_pos - g["rel_pos"][t]).max() < 1e-12 and np.abs(rel_rot - g["rel_rot"][t]).max() < 1e-9
         d_rot = RO.quat_magnitude(RO.quat_normalize(RO.euler2quat(rel_rot)))
         assert np.abs(np.linalg.norm(rel_pos, axis=-1) - g["dist_pos"][t]).max() < 1e-12 and np.abs(d_rot - g["dist_rot"][t]).max() < 1e-9
+    # _calculate_num_success / _calculate_goal_distance_reward (common/base.py:824-848): the count of objects inside both thresholds, and its change
+    env = RO.OracleRearrangeEnv.__new__(RO.OracleRearrangeEnv)
+    env.success_threshold, env.goal_reward_per_object = {"obj_pos": 0.04, "obj_rot": 0.2}, 1.0
+    ns = np.array([env.num_success({"obj_pos": g["thr_dist_pos"][t], "obj_rot": g["thr_dist_rot"][t]}) for t in range(len(g["num_success"]))])
+    assert np.array_equal(ns, g["num_success"]) and np.array_equal(ns[1:] - ns[:-1], g["goal_reward"]) and 0 < ns.min() + 1 and ns.max() >= 3
 
 
 def _env_kernel_goal_layer(lib, device, B):

@@ -55,9 +55,28 @@ def main():
     for t in range(T):
         out = g.goal_distance({"obj_pos": goal_pos[t], "obj_rot": goal_rot[t]}, {"obj_pos": cur_pos[t], "obj_rot": cur_rot[t]})
         rel_pos.append(out["relative_goal"]["obj_pos"]); rel_rot.append(out["relative_goal"]["obj_rot"]); d_pos.append(out["obj_pos"]); d_rot.append(out["obj_rot"])
+    # RearrangeEnv._calculate_num_success / _calculate_goal_distance_reward (envs/rearrange/common/base.py:824-848), same treatment: their source on a stub env
+    BASE = "/root/reference/robogym/envs/rearrange/common/base.py"
+    tree2 = ast.parse(open(BASE).read())
+    env_cls = [n for n in tree2.body if isinstance(n, ast.ClassDef) and n.name == "RearrangeEnv"][0]
+    meths = [n for n in env_cls.body if isinstance(n, ast.FunctionDef) and n.name in ("_calculate_num_success", "_calculate_goal_distance_reward")]
+    assert len(meths) == 2
+    for n in meths:
+        n.returns = None
+    m2 = ast.Module(body=[ast.ClassDef(name="RearrangeEnv", bases=[], keywords=[], body=meths, decorator_list=[])], type_ignores=[])
+    ast.fix_missing_locations(m2)
+    ns2 = {"np": np}
+    exec(compile(m2, BASE, "exec"), ns2)
+    env = types.SimpleNamespace(constants=types.SimpleNamespace(success_threshold={"obj_pos": 0.04, "obj_rot": 0.2}, goal_reward_per_object=1.0))
+    env._calculate_num_success = types.MethodType(ns2["RearrangeEnv"]._calculate_num_success, env)
+    dp, dr = np.array(d_pos), np.array(d_rot)
+    near = rng.rand(T, N) < 0.5                                            # some objects inside the thresholds
+    dp = np.where(near, dp * 0.05, dp); dr = np.where(near, dr * 0.05, dr)
+    nsucc = np.array([env._calculate_num_success({"obj_pos": dp[t], "obj_rot": dr[t]}) for t in range(T)])
+    greward = np.array([ns2["RearrangeEnv"]._calculate_goal_distance_reward(env, {"obj_pos": dp[t - 1], "obj_rot": dr[t - 1]}, {"obj_pos": dp[t], "obj_rot": dr[t]}) for t in range(1, T)])
     out = os.path.join(HERE, "..", "tests", "golden", "rearrange_goal.npz")
     np.savez_compressed(out, cur_pos=cur_pos, cur_rot=cur_rot, goal_pos=goal_pos, goal_rot=goal_rot, rel_pos=np.array(rel_pos), rel_rot=np.array(rel_rot),
-                        dist_pos=np.array(d_pos), dist_rot=np.array(d_rot))
+                        dist_pos=np.array(d_pos), dist_rot=np.array(d_rot), thr_dist_pos=dp, thr_dist_rot=dr, num_success=nsucc, goal_reward=greward)
     print("wrote", out, "dist_rot[0]", np.array(d_rot)[0])
 
 
