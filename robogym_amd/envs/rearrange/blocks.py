@@ -463,6 +463,7 @@ class BatchedBlockRearrangeEnv:
             return
         yaw = self.goal_rot[torch.as_tensor(rows, device=self.device, dtype=torch.long), :, 2].cpu().numpy().astype(np.float64)
         self._write_goal(rows, self._grid_placement(yaw, rows), yaw)
+        self._reobserve(np.zeros(0, dtype=np.int64), rows)      # robot_env.py:893-909: the observation returned after a goal reset carries the new goal
 
     def sync(self):
         self.sim.sync()

@@ -92,8 +92,12 @@ def _goal_and_tracker_checks(env):
     assert bool(env.goal_reset[0]) and not bool(env.goal_reset[1]) and int(env.successes[0]) == 1 and int(env.ssl[0]) == 0 and int(env.ssl[1]) == ssl0 + 1
     assert float(env.observe()["is_goal_achieved"][0, 0]) == 1.0
     old = env.goal[0].clone()
+    rew_before = env.reward.clone()
     env.reset_goals()
     assert not torch.equal(old[:, :3], env.goal[0, :, :3]) and torch.allclose(env.goal[0, :, 3:], old[:, 3:], atol=1e-6) and int(env.prev_valid[0]) == 0
+    o = env.observe()      # the observation carries the NEW goal (re-observed for that env only), the step's reward / counters are untouched
+    assert torch.allclose(o["goal_obj_pos"][0], env.goal[0, :, :3]) and float(o["is_goal_achieved"][0, 0]) == 0.0 and torch.equal(env.reward, rew_before) and int(env.successes[0]) == 1
+    assert torch.allclose(o["rel_goal_obj_pos"][0], env.goal[0, :, :3] - o["obj_pos"][0], atol=1e-6)
     env.sim.qpos[1, env.obj_q[2]] = 3.0
     env.step(z)
     assert bool(env.done[1]) and bool(env.objects_off_table[1]) and float(env.reward[1, 0]) == -1.0 and not bool(env.done[0])
