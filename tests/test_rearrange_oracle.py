@@ -364,3 +364,21 @@ def test_tcp_action_path_matches_reference_code():
         pos, dq = RO.tcp_quat_control(den, g["q"][t][5], lo, hi, g["gripper_quat"][t])
         assert np.abs(pos - g["denorm"][t][:3]).max() == 0 and np.abs(dq - g["dquat"][t]).max() < 1e-14
     assert abs(RO.JOINT_DRIFT_THRESHOLD - np.deg2rad(1)) < 1e-15
+
+
+def test_observation_keys_and_order_are_the_reference_methods():
+    """The packed observation row of the batched env (robogym_amd/envs/rearrange/blocks.py OBS_KEYS, written by ra_post_step_kernel) and the oracle env's
+    observation have the keys of `RearrangeEnv._observe_simple` in its order: tests/golden/rearrange_obs_keys.json is what executing that method's own source on a
+    recording stub returns (tools/gen_golden_rearrange_obs_keys.py)."""
+    import json
+    import os
+
+    from robogym_amd.envs.rearrange.blocks import OBS_KEYS
+
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "rearrange_obs_keys.json")))
+    assert [k for k, _ in OBS_KEYS] == [k for k, _ in ref] and len(ref) == 24
+    src = dict(ref)
+    assert src["qpos"] == "sim.qpos" and src["gripper_pos"].endswith("tcp_xyz()") and src["rel_goal_obj_rot"] == "goal[rel_goal_obj_rot]"
+    widths = dict(OBS_KEYS)      # per-object keys are per-object in the row too
+    assert all(str(widths[k]).startswith("N") for k in ("obj_pos", "obj_rel_pos", "obj_vel_pos", "obj_rot", "obj_vel_rot", "goal_obj_pos", "goal_obj_rot", "rel_goal_obj_pos",
+                                                         "rel_goal_obj_rot", "obj_gripper_contact", "obj_bbox_size", "obj_colors"))
