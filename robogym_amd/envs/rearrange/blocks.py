@@ -162,6 +162,7 @@ class BatchedBlockRearrangeEnv:
         self.pipelined = bool(pipelined_reset)
         self._stage, self._left = np.zeros(B, dtype=np.int8), np.zeros(B, dtype=np.int32)      # 0 live, 1 stabilise, 2 random action, 3 settle
         self._yaw = np.zeros((B, N))
+        self.ended_rows = np.zeros(0, dtype=np.int64)          # rows whose episode ended on the last step (pipelined resets)
         self.hold, self.scripted, self.frozen, self.solver_active = z(B, dt=torch.int32), z(B, 6), z(B, dt=torch.uint8), torch.ones(B, dtype=torch.int32, device=dev)
         self.resetting, self.episode_started = z(B, dt=torch.bool), z(B, dt=torch.bool)
         if self.pipelined:
@@ -214,21 +215,23 @@ class BatchedBlockRearrangeEnv:
                 "sub_goal_is_successful": self.sub_goal_ok, "env_crash": self.env_crash, "objects_off_table": self.objects_off_table, "successes_so_far": self.successes,
                 "steps_since_last_goal": self.info_ssl, "resetting": self.resetting, "episode_started": self.episode_started}
 
-    def observe(self):
-        """Views into the packed row, keys / shapes of `RearrangeEnv._observe_simple` (common/base.py:376-421)."""
+    def observe(self, packed=None, action_ema=None):
+        """Views into the packed row, keys / shapes of `RearrangeEnv._observe_simple` (common/base.py:376-421).  (`packed` / `action_ema`: rows of several envs
+        put together by the caller, envs/rearrange/ycb.py.)"""
         out, o, N = {}, 0, self.N
+        packed = self.packed if packed is None else packed
         for k, w in OBS_KEYS:
             if isinstance(w, str):
                 n = self.nq if w == "nq" else N * int(w[1])
-                v = self.packed[:, o:o + n]
-                out[k] = v if w == "nq" else v.view(self.B, N, int(w[1]))
+                v = packed[:, o:o + n]
+                out[k] = v if w == "nq" else v.view(packed.shape[0], N, int(w[1]))
             else:
                 n = w
-                out[k] = self.packed[:, o:o + n]
+                out[k] = packed[:, o:o + n]
             o += n
         assert o == self.obs_dim
         if self.wrapped:
-            out["action_ema"] = self.action_ema      # SmoothActionWrapper's observation: the smoothed action of the last step (zeros after reset)
+            out["action_ema"] = self.action_ema if action_ema is None else action_ema      # SmoothActionWrapper's observation: the smoothed action of the last step (zeros after reset)
         return out
 
     # ------------------------------------------------------------------ reset (host work + physics launches)
@@ -431,6 +434,7 @@ class BatchedBlockRearrangeEnv:
         self._reobserve(np.concatenate(started) if started else np.zeros(0, dtype=np.int64), grows)
         # ---- episodes that ended on this step: their recipe begins (the returned observation / reward / done are the terminal ones)
         rows = np.nonzero(done.astype(bool) & (st == 0))[0]
+        self.ended_rows = rows                              # (envs/rearrange/ycb.py hands these slots out again, to other envs of the batch)
         if len(rows):
             idx = torch.as_tensor(rows, device=dev, dtype=torch.long)
             self._yaw[rows] = self._begin_episode_state(rows, idx)

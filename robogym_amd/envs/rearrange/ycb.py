@@ -6,9 +6,10 @@ around the objects -- TCP-controlled UR16e with its solver simulation, the 40 + 
 tracker, contact scans, safety stop -- is the same code here as there, so this env IS `BatchedBlockRearrangeEnv` on another compiled model;
 the stepper runs it on `rb_step_kernel`'s medium configuration (one wave per env, 56 dofs, 10 envs per CU).
 
-Built: the world with a FIXED set of objects per compiled model (`load_ycb_model`: the reference's `_sample_object_meshes` draw with seed 0).
-Not built: a new object set per episode and env (the reference re-creates the simulation at every reset,
-common/base.py:850-856); `normalize_mesh`, object-scale randomisation, the mesh envs' damping change while objects settle."""
+Built: the world with a FIXED set of objects per compiled model (`load_ycb_model`: the reference's `_sample_object_meshes` draw with seed 0 + set index); a new
+object set per episode out of the shipped sets by moving envs between the groups' slots (`GroupedYcbRearrangeEnv`).
+Not built: a set sampled from the whole YCB catalogue per episode (the reference re-creates the simulation at every reset, common/base.py:850-856:
+needs per-env geometry rows in the stepper); `normalize_mesh`, object-scale randomisation, the mesh envs' damping change while objects settle."""
 from robogym_amd.envs.rearrange.blocks import BatchedBlockRearrangeEnv
 from robogym_amd.envs.rearrange.xml import load_ycb_model
 
@@ -26,25 +27,69 @@ class BatchedYcbRearrangeEnv(BatchedBlockRearrangeEnv):
 
 
 class GroupedYcbRearrangeEnv:
-    """rearrange/ycb with DIFFERENT object sets across the batch: the envs are split into equal groups, every group runs its own compiled model (one of the
-    shipped object sets, `xml.YCB_SHIPPED_SETS`) as a `BatchedYcbRearrangeEnv` on a stream of its own, so the groups' launches overlap on the GPU; `step` / `reset` /
-    `observe` speak for the whole batch (rows in group order).  This is per-ENV variety with a fixed set per env slot -- the reference draws a new set per EPISODE and
-    rebuilds the simulation (envs/rearrange/ycb.py:58-84, common/base.py:850-856), which needs per-env geometry rows in the stepper."""
+    """rearrange/ycb with DIFFERENT object sets across the batch and a NEW set per episode.  The batch is split into equal groups, every group runs its own
+    compiled model (one of the shipped object sets, `xml.YCB_SHIPPED_SETS`) as a `BatchedYcbRearrangeEnv` on a stream of its own, so the groups' launches
+    overlap on the GPU; `step` / `reset` / `observe` speak for the whole batch.
 
-    def __init__(self, batch_size: int, device="cuda:0", object_sets=(0, 1, 2, 3), starting_seed: int = 0, **kw):
+    The reference draws a new object set at every reset and rebuilds the simulation (envs/rearrange/ycb.py:58-84, common/base.py:850-856).  Here the compiled
+    models stay where they are and the ENVS move: env i of the batch is served by a physics slot `slot[i]` (a row of one group), and the slots whose episodes end
+    on the same step -- all of them are about to run the reset recipe from a freshly made world, nothing of the old episode survives in them -- are handed out
+    again among the envs that ended, by a random permutation.  The next episode of env i therefore runs on the object set of whatever group its new slot belongs
+    to.  Limits, stated: the pool is the K shipped sets (the reference samples `num_objects` meshes from the whole YCB catalogue), and an env can only receive a set
+    that some env of the batch released on the same step (with thousands of envs and episodes of a few hundred steps that is tens of slots per step; an env that
+    ends alone keeps its slot).  `resample_object_sets=False` pins env i to slot i."""
+
+    def __init__(self, batch_size: int, device="cuda:0", object_sets=(0, 1, 2, 3), starting_seed: int = 0, resample_object_sets: bool = True, **kw):
+        import numpy as np
         import torch
 
         K = len(object_sets)
         assert batch_size % K == 0, "batch_size must be a multiple of the number of object sets"
         self.B, self.K, self.b = int(batch_size), K, int(batch_size) // K
-        self.groups = [BatchedYcbRearrangeEnv(self.b, device=device, main_model=load_ycb_model(kw.get("num_objects", 8), set_index=int(k)), starting_seed=starting_seed + 1000 * i, **kw)
-                       for i, k in enumerate(object_sets)]
+        self.object_sets = tuple(int(k) for k in object_sets)
+        self.groups = [BatchedYcbRearrangeEnv(self.b, device=device, main_model=load_ycb_model(kw.get("num_objects", 8), set_index=k), starting_seed=starting_seed + 1000 * i, **kw)
+                       for i, k in enumerate(self.object_sets)]
         g0 = self.groups[0]
         self.device, self.N, self.obs_dim, self.wrapped, self.action_shape = g0.device, g0.N, g0.obs_dim, g0.wrapped, (self.B, 6)
         self._cuda = self.device.type == "cuda"
         self.streams = [torch.cuda.Stream(self.device) for _ in self.groups] if self._cuda else [None] * K
         self.object_names = [g.object_names for g in self.groups]
+        self.resample = bool(resample_object_sets)
+        self._rng = np.random.RandomState(starting_seed + 77)
+        self._slot = np.arange(self.B)                               # env -> physics slot (group * b + row)
+        self._slot_dev = torch.arange(self.B, device=self.device)
+        self._env_of_slot_dev = torch.arange(self.B, device=self.device)
+        self.episodes_moved = 0                                      # episodes that started on another group's object set than the previous one of that env
 
+    # ------------------------------------------------------------------ env <-> slot
+    def _reassign(self, envs):
+        """The slots of `envs` (all of them at the start of a reset) handed out again among these envs."""
+        import numpy as np
+        import torch
+
+        if not self.resample or len(envs) < 2:
+            return
+        old = self._slot[envs]
+        new = old[self._rng.permutation(len(envs))]
+        self.episodes_moved += int((old // self.b != new // self.b).sum())
+        self._slot[envs] = new
+        self._slot_dev = torch.as_tensor(self._slot, device=self.device)
+        inv = np.empty(self.B, dtype=np.int64); inv[self._slot] = np.arange(self.B)
+        self._env_of_slot_dev = torch.as_tensor(inv, device=self.device)
+
+    def object_set_of_env(self):
+        """index into `object_sets` of the set every env of the batch currently has on its table"""
+        return self._slot // self.b
+
+    def _to_slots(self, x):
+        """a per-env tensor in slot order"""
+        return x if not self.resample else x[self._env_of_slot_dev]
+
+    def _to_envs(self, x):
+        """a per-slot tensor in env order"""
+        return x if not self.resample else x[self._slot_dev]
+
+    # ------------------------------------------------------------------ the groups
     def _each(self, fn):
         """fn(group index, group) for every group, on the group's stream; the caller's stream waits for all of them afterwards"""
         import torch
@@ -63,29 +108,47 @@ class GroupedYcbRearrangeEnv:
                 cur.wait_stream(st)
         return out
 
-    def _cat(self, outs):
+    def _observation(self):
         import torch
 
-        obs = {k: torch.cat([o[0][k] for o in outs]) for k in outs[0][0]}
-        info = {k: (torch.cat([o[3][k] for o in outs]) if torch.is_tensor(outs[0][3][k]) else [x for o in outs for x in [o[3][k]] * self.b]) for k in outs[0][3]}
-        return obs, torch.cat([o[1] for o in outs]), torch.cat([o[2] for o in outs]), info
+        packed = self._to_envs(torch.cat([g.packed for g in self.groups]))
+        ema = self._to_envs(torch.cat([g.action_ema for g in self.groups])) if self.wrapped else None
+        return self.groups[0].observe(packed, ema)
+
+    def _names(self):
+        return [self.object_names[s // self.b] for s in self._slot]
 
     def reset(self, mask=None):
-        import torch
+        import numpy as np
 
-        outs = self._each(lambda i, g: g.reset(None if mask is None else mask[i * self.b:(i + 1) * self.b]))
-        return {k: torch.cat([o[k] for o in outs]) for k in outs[0]}
+        envs = np.arange(self.B) if mask is None else np.nonzero(mask.cpu().numpy())[0]
+        self._reassign(envs)                                          # a reset is a new episode: a new object set with it
+        smask = None if mask is None else self._to_slots(mask)
+        self._each(lambda i, g: g.reset(None if smask is None else smask[i * self.b:(i + 1) * self.b]))
+        return self._observation()
 
     def step(self, actions):
-        b = self.b
-        self._each(lambda i, g: g._step_launch(actions[i * b:(i + 1) * b].contiguous()))       # every group's three launches are queued ...
-        return self._cat(self._each(lambda i, g: g._step_finish()))                             # ... before any group's flags are read back
-
-    def observe(self):
+        import numpy as np
         import torch
 
-        outs = [g.observe() for g in self.groups]
-        return {k: torch.cat([o[k] for o in outs]) for k in outs[0]}
+        b = self.b
+        sact = self._to_slots(actions)
+        self._each(lambda i, g: g._step_launch(sact[i * b:(i + 1) * b].contiguous()))           # every group's three launches are queued ...
+        outs = self._each(lambda i, g: g._step_finish())                                        # ... before any group's flags are read back
+        obs = self._observation()
+        reward, done = self._to_envs(torch.cat([o[1] for o in outs])), self._to_envs(torch.cat([o[2] for o in outs]))
+        info = {k: self._to_envs(torch.cat([o[3][k] for o in outs])) for k in outs[0][3] if torch.is_tensor(outs[0][3][k])}
+        info["object_names"] = self._names()            # (of the episode this step belonged to: the terminal step still names the set that just ended)
+        self._slot_of_step = self._slot.copy()
+        if self.resample and self.groups[0].pipelined:
+            ended = np.concatenate([i * b + np.asarray(g.ended_rows, dtype=np.int64) for i, g in enumerate(self.groups)])
+            if len(ended) > 1:
+                inv = np.empty(self.B, dtype=np.int64); inv[self._slot] = np.arange(self.B)
+                self._reassign(inv[ended])
+        return obs, reward, done, info
+
+    def observe(self):
+        return self._observation()
 
     def sync(self):
         for g in self.groups:
@@ -94,7 +157,7 @@ class GroupedYcbRearrangeEnv:
     def status(self):
         import torch
 
-        return torch.cat([torch.maximum(g.sim.status.reshape(-1), g.solver_sim.status.reshape(-1)) for g in self.groups])
+        return self._to_envs(torch.cat([torch.maximum(g.sim.status.reshape(-1), g.solver_sim.status.reshape(-1)) for g in self.groups]))
 
 
 def make_env(batch_size: int = 4096, device="cuda:0", parameters=None, constants=None, starting_seed: int = 0, apply_wrappers: bool = True, **kw):

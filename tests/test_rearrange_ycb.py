@@ -177,7 +177,9 @@ def _grouped_env_checks(lib, device, B, sets, n_substeps, steps):
     assert env.object_names[0][0] == "055_baseball" and env.object_names[1][0] == "044_flat_screwdriver" and env.object_names[0] != env.object_names[1]
     obs = env.reset()
     assert obs["obj_pos"].shape == (B, N, 3) and obs["qpos"].shape == (B, 64)
-    half0 = obs["obj_bbox_size"][0].cpu().numpy(); half1 = obs["obj_bbox_size"][env.b].cpu().numpy()
+    which = env.object_set_of_env()                                                          # (a reset is a new episode: the envs were dealt their sets at random)
+    assert sorted(np.bincount(which, minlength=len(sets))) == [env.b] * len(sets)
+    half0 = obs["obj_bbox_size"][int(np.nonzero(which == 0)[0][0])].cpu().numpy(); half1 = obs["obj_bbox_size"][int(np.nonzero(which == 1)[0][0])].cpu().numpy()
     assert not np.allclose(np.sort(half0.max(1)), np.sort(half1.max(1)))                    # the two groups really hold different objects
     gen = torch.Generator(device=env.device); gen.manual_seed(2)
     for _ in range(steps):
@@ -192,6 +194,60 @@ def _grouped_env_checks(lib, device, B, sets, n_substeps, steps):
 
 def test_ycb_object_sets_across_the_batch_emul(emul_lib):
     _grouped_env_checks(emul_lib, "cpu", B=2, sets=(0, 1), n_substeps=1, steps=2)
+
+
+def _per_episode_checks(lib, device, B, steps, seed, **recipe):
+    """A new object set per episode (the reference rebuilds the simulation at every reset, envs/rearrange/ycb.py:58-84, common/base.py:850-856) = the envs of the batch
+    trade physics slots when their episodes end.  Checked against a twin with env i pinned to slot i that is fed the same actions in slot order: every output of the
+    trading env is the twin's, read through the env -> slot table, bit for bit, through a reset, episode ends (goal time-out: 8 objects x 1 step per object), the reset
+    recipe and the first steps of the next episodes; and the table really changed."""
+    from robogym_amd.envs.rearrange.ycb import make_env
+
+    kw = dict(pipelined_reset=True, max_timesteps_per_goal_per_obj=1, starting_seed=seed, object_sets=(0, 1), **recipe)
+    if lib is not None:
+        kw["lib"] = lib
+    env, twin = make_env(batch_size=B, device=device, **kw), make_env(batch_size=B, device=device, resample_object_sets=False, **kw)
+    assert twin.object_set_of_env().tolist() == [0] * (B // 2) + [1] * (B // 2)
+
+    def same(a, b, slot):
+        for k in a:
+            if torch.is_tensor(a[k]):
+                assert torch.equal(a[k], b[k][slot]), k
+
+    obs, ref = env.reset(), twin.reset()
+    tables = [env._slot.copy()]
+    same(obs, ref, torch.as_tensor(env._slot, device=env.device))
+    gen = torch.Generator(device=env.device); gen.manual_seed(2)
+    ended = started = 0
+    for k in range(steps):
+        a = torch.randint(0, 11, (B, 6), generator=gen, device=env.device)
+        slot = torch.as_tensor(env._slot.copy(), device=env.device)             # the table this step runs on (it changes AFTER the terminal step's outputs are taken)
+        inv = torch.empty(B, dtype=torch.long, device=env.device); inv[slot] = torch.arange(B, device=env.device)
+        out, tw = env.step(a), twin.step(a[inv].contiguous())
+        same(out[0], tw[0], slot); same(out[3], tw[3], slot)
+        assert torch.equal(out[1], tw[1][slot]) and torch.equal(out[2], tw[2][slot])
+        assert out[3]["object_names"] == [tw[3]["object_names"][int(s)] for s in env._slot_of_step]
+        ended += int(out[2].sum()); started += int(out[3]["episode_started"].sum())
+        tables.append(env._slot.copy())
+    env.sync(); twin.sync()
+    assert bool(torch.isfinite(out[0]["obj_pos"]).all()) and (lib is None or int(env.status().max()) == 0)
+    assert sorted(env._slot.tolist()) == list(range(B)) and twin.episodes_moved == 0
+    assert sorted(np.bincount(env.object_set_of_env(), minlength=2)) == [B // 2, B // 2]
+    return env, ended, started, tables
+
+
+def test_ycb_new_object_set_per_episode_emul(emul_lib):
+    env, ended, started, tables = _per_episode_checks(emul_lib, "cpu", B=2, steps=10, seed=8, n_substeps=1, stabilize_steps=1, n_random_initial_steps=0, settle_steps=0)
+    assert ended == 2 and started == 2                   # the goal times out on step 8, the next episode starts on step 9
+    assert len({tuple(t) for t in tables}) >= 2 and env.episodes_moved == 4, tables      # (seed 8: both draws -- at reset, at the episode end -- swap the two slots)
+
+
+@pytest.mark.gpu
+def test_ycb_new_object_set_per_episode_gpu():
+    B = 64
+    env, ended, started, tables = _per_episode_checks(None, "cuda:0", B=B, steps=22, seed=3, stabilize_steps=4, n_random_initial_steps=1, settle_steps=4)
+    assert ended >= B and started >= B                   # every env timed out at least once (8 steps) and came back (4 + 1 + 4 recipe steps)
+    assert env.episodes_moved > B // 4 and len({tuple(t) for t in tables}) >= 3
 
 
 @pytest.mark.gpu
