@@ -299,27 +299,44 @@ def test_mocap_ik_impulse_response(models, rce, mpc, expected, rise):
     The env the reference test steps is `make_env(...).env`: the DiscretizeActionWrapper is taken off, the SmoothActionWrapper (alpha 0.3, i.e. 0.3 ^ 0.5 per
     step, with bias correction) and the reward clip stay ON (common/base.py:986-996) -- the "impulse" reaches the robot as 0.54, 0.27, 0.14, ... (sum 1.11).
     With that filter in the loop, as here, (i) holds as stated and (ii) holds at the reference's own 1e-3 for the two cases without controller-error reset
-    (measured: 0.0365 / 0.0367 / 0.0365 for 0.0363; 0.0219 / 0.0220 / 0.0218 for 0.022); with the reset x comes out 1.4-1.6e-3 high and y as much low, their mean
-    and z within 1e-3 (0.0374 / 0.0346 / 0.0366 for 0.036; 0.0236 / 0.0204 / 0.0221 for 0.022): asserted at 2e-3 per axis, 1e-3 for the mean of x and y and for z.
+    (measured: 0.0365 / 0.0367 / 0.0365 for 0.0363; 0.0219 / 0.0220 / 0.0218 for 0.022).  With the reset the raw numbers are 0.0374 / 0.0346 / 0.0366 for 0.036
+    and 0.0236 / 0.0204 / 0.0221 for 0.022: x 1.4-1.6e-3 high, y as much low.  That asymmetry is not the impulse's: the same env stepped with ZERO actions moves its
+    TCP by +2.1e-3 / -1.5e-3 / -0.1e-3 over the 42 steps, because joint J5 creeps by -2.2e-4 rad per env.step -- its cascaded controller has a P-only velocity loop
+    (gainprm kp_v 20, ti_v 0: joint_actuations.xml:9), the off-axis wrist camera (0.42 kg, 6 cm) loads it with ~0.1 N m of gravity torque, and with the
+    controller-error reset every step's joint target is the position the arm has crept to.  The response to the impulse itself (run with impulse minus run
+    without) is 0.0353 / 0.0361 / 0.0366 and 0.0215 / 0.0219 / 0.0222: asserted at the reference's 1e-3 on every axis; the raw numbers at 2e-3.  Whether MuJoCo +
+    mjpid.pyx creep as much cannot be decided here (the reference's tolerance admits about half of it).
     (Rounds 3-4 fed the raw impulse and read the missing factor 1.11 as a 10 % deviation of the weld model.)"""
     alpha = 0.3 ** (0.001 * 40 / 0.08)                                   # SmoothActionWrapper.reset (wrappers/util.py:203-211)
-    total = []
-    for dim in range(3):
+
+    def trajectory(dim):
         env = _env(models, mpc, rce)
-        z = np.zeros(6); imp = z.copy(); imp[dim] = 1
+        z = np.zeros(6); imp = z.copy()
+        if dim is not None:
+            imp[dim] = 1
+        q0 = env.main.sim.qpos[env.main.arm_q].copy()
         P, ema = [], np.zeros(6)
         for k in range(43):
             ema = ema * alpha + (1 - alpha) * (imp if k == 2 else z)     # IncrementalExpAvg.update / get (util.py:142-160)
             env.env_step(ema / (1 - alpha ** (k + 1)))
             P.append(env.main.body_xpos(env.main.tcp_body))
-        P = np.array(P) - P[0]
+        return np.array(P) - P[0], env.main.sim.qpos[env.main.arm_q] - q0
+
+    total = []
+    for dim in range(3):
+        P, _ = trajectory(dim)
         total.append(P[-1, dim])
         assert abs(P[2 + rise, dim]) > 0.9 * total[-1]                   # (i) as the reference states it
     total = np.array(total)
     if not rce:
         assert np.abs(total - expected).max() < 1e-3, total              # (ii) as the reference states it
     else:
-        assert np.abs(total - expected).max() < 2e-3 and abs(0.5 * (total[0] + total[1]) - expected) < 1e-3 and abs(total[2] - expected) < 1e-3, total
+        P0, dq = trajectory(None)                                        # the same 43 steps without the impulse
+        creep = P0[-1]
+        assert 1e-3 < np.abs(creep[:2]).max() < 3e-3 and abs(creep[2]) < 3e-4, creep
+        assert np.argmax(np.abs(dq)) == 4 and abs(dq[4]) > 5 * np.abs(np.delete(dq, 4)).max(), dq      # it is J5 that creeps
+        assert np.abs(total - creep - expected).max() < 1e-3, (total, creep)       # (ii) at the reference's tolerance for the response to the impulse
+        assert np.abs(total - expected).max() < 2e-3, total
 
 
 def test_crowded_table_placement_keeps_objects_apart():
