@@ -68,13 +68,18 @@ def relaunch_with_ranks(n):
     return subprocess.call(cmd)
 
 
-def kernel_source_hash():
-    """Identifies the kernel build a committed PMC figure belongs to (profiles/hbm_traffic.json carries it)."""
+RG_KERNEL_SOURCES = ("rg_kernel.h", "rg_env_kernel.h", "rg_api.hip", "rg_types.h", "Makefile")                       # what rg_step_items_kernel / rg_step_kernel compile from
+RB_KERNEL_SOURCES = RG_KERNEL_SOURCES + ("rb_kernel.h", "rb_env_kernel.h", "ra_env_kernel.h", "rb_types.h")           # rb_step_kernel shares the narrow-phase code of rg_kernel.h
+
+
+def kernel_source_hash(which="rg"):
+    """Identifies the kernel build a committed PMC figure belongs to (profiles/hbm_traffic.json carries one stamp for the hand's stepper, "rg", and one for the
+    general stepper, "rb": an edit of rb_kernel.h leaves the rg kernels' machine code as it was -- tools/kernel_isa_hash.py shows that per kernel)."""
     import hashlib
 
     h = hashlib.sha256()
-    for f in ("rg_kernel.h", "rg_env_kernel.h", "rg_api.hip", "rg_types.h", "rb_kernel.h", "rb_env_kernel.h", "ra_env_kernel.h", "rb_types.h", "Makefile"):
-        h.update(open(os.path.join(ROOT, "robogym_amd", "csrc", f), "rb").read())
+    for f in sorted(RG_KERNEL_SOURCES if which == "rg" else RB_KERNEL_SOURCES):
+        h.update(f.encode()); h.update(open(os.path.join(ROOT, "robogym_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -83,7 +88,7 @@ def rb_traffic(workload, B):
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
         e = t.get("rb_step_kernel", {}).get(workload)
-        if e and int(e["batch_per_gpu"]) == B and t.get("kernel_source_hash") == kernel_source_hash():
+        if e and int(e["batch_per_gpu"]) == B and t.get("rb_source_hash") == kernel_source_hash("rb"):
             return float(e["bytes_per_launch"]) / 1e9
     except (OSError, ValueError, KeyError):
         pass

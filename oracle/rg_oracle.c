@@ -1354,6 +1354,13 @@ static void ro_fwd_velocity(const ro_model* m, ro_data* d) {
  * robot/shadow_hand/mujoco/parameter_manager.py:23-47).  Controller state per actuator:
  * {integral error, last error, last smoothed derivative}.  The callback runs in EVERY mj_forward,
  * including the three state-less forward() calls the reference makes per env step. */
+/* The cascaded-PI controller's bias feed-forward (gravity + Coriolis compensation: the force of the velocity loop plus qfrc_bias of the actuated dof).  mjpid.pyx
+ * is not in the tree; the term is inferred from the reference's own pins (envs/rearrange/tests/test_rearrange_sim.py:135-230): with it all four impulse-response
+ * cases hold at the stated 1e-3 (0.0362 / 0.0364 / 0.0365 for 0.036, 0.02197 / 0.02209 / 0.02206 for 0.022, ...), without it the wrist joints J5 / J6 -- P-only
+ * velocity loops, gainprm ti_v = 0 -- creep under the wrist camera's weight and two cases miss by 1.4-1.6e-3 (tests/test_rearrange_oracle.py keeps both runs).
+ * ro_set_cascade_bias_ff(0) switches it off for that comparison. */
+static int ro_cascade_bias_ff = 1;
+void ro_set_cascade_bias_ff(int on) { ro_cascade_bias_ff = on; }
 static void ro_fwd_actuation(const ro_model* m, ro_data* d) {
   int nv = m->nv;
   real dt = m->timestep;
@@ -1365,7 +1372,8 @@ static void ro_fwd_actuation(const ro_model* m, ro_data* d) {
       /* mujoco-py mjpid.pyx, cascaded PI controller (actuator user[0] == 1; ur16e/jointspec/calibrations/cascaded_pi/
        * joint_actuations.xml:4-10): gainprm = [kp, ti, iclamp, td, dsmooth | kp_v, ti_v, iclamp_v, ema_smooth, max_vel].
        * The position set-point is EMA-smoothed (warm-started with ctrl at time 0), an outer P(ID) loop on position produces a
-       * velocity set-point clamped to +-max_vel, an inner PI loop on actuator_velocity produces the force, clamped to forcerange.
+       * velocity set-point clamped to +-max_vel, an inner PI loop on actuator_velocity produces the force, the dof's bias force is added (see
+       * ro_cascade_bias_ff above), the sum is clamped to forcerange.
        * State per actuator: {position integral, velocity integral, smoothed set-point}.  PROVENANCE: recalled from mujoco-py
        * 2.0.2.13; pinned only through the reference's impulse-response / gripper-sync property tests (tests/test_rearrange_*). */
       real* st = d->pid + 3 * i;
@@ -1384,6 +1392,10 @@ static void ro_fwd_actuation(const ro_model* m, ro_data* d) {
       real integv = clampd(st[1] + errv * dt, -gp[7], gp[7]);
       force = gp[5] * (errv + (gp[6] != 0 ? integv / gp[6] : 0));
       st[1] = integv;
+      if (ro_cascade_bias_ff && m->actuator_trntype[i] == TRN_JOINT) {   /* joint transmission: the moment row has the single entry `gear` at the joint's dof */
+        int k = m->jnt_dofadr[m->actuator_trnid[i]];
+        force += d->qfrc_bias[k] / d->actuator_moment[(size_t)i * nv + k];
+      }
       real lo = m->actuator_forcerange[2 * i], hi = m->actuator_forcerange[2 * i + 1];
       if (lo != 0 || hi != 0) force = clampd(force, lo, hi);
     } else if (m->actuator_biastype[i] == 2) {

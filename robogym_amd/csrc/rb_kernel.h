@@ -864,9 +864,10 @@ __device__ __forceinline__ float rb_pid_tick(const Model& m, int u, float ctrl, 
 // mujoco-py's cascaded PI controller (actuator user[0] == 1; ur16e/jointspec/calibrations/cascaded_pi/joint_actuations.xml:4-10), as restated by
 // oracle ro_fwd_actuation: gainprm = [kp, ti, iclamp, td, dsmooth | kp_v, ti_v, iclamp_v, ema, max_vel]; st = {position integral, velocity
 // integral, smoothed set-point}.  EMA-smoothed position set-point (warm start at time 0) -> P(I) on position -> velocity set-point clamped to
-// +- max_vel -> PI on actuator_velocity -> force clamped to forcerange.
+// +- max_vel -> PI on actuator_velocity -> plus `bias_ff`, the bias force (gravity + Coriolis) of the actuated dof over the gear -> clamped to forcerange.
+// (The feed-forward is inferred from the reference's impulse-response pins, oracle/rg_oracle.c ro_cascade_bias_ff: the wrist joints' velocity loops are P-only.)
 template <class Model>
-__device__ __forceinline__ float rb_cascade_tick(const Model& m, int u, float ctrl, float length, float velocity, bool time0, float* st) {
+__device__ __forceinline__ float rb_cascade_tick(const Model& m, int u, float ctrl, float length, float velocity, float bias_ff, bool time0, float* st) {
   const float dt = m.timestep;
   const float* gp = m.actuator_gainprm + 10 * u;
   const float setp = time0 ? ctrl : gp[8] * st[2] + (1.f - gp[8]) * ctrl;
@@ -881,7 +882,7 @@ __device__ __forceinline__ float rb_cascade_tick(const Model& m, int u, float ct
   des_vel = clampf(des_vel, -gp[9], gp[9]);
   const float errv = des_vel - velocity;
   const float integv = clampf(st[1] + errv * dt, -gp[7], gp[7]);
-  float force = gp[5] * (errv + (gp[6] != 0.f ? integv / gp[6] : 0.f));
+  float force = gp[5] * (errv + (gp[6] != 0.f ? integv / gp[6] : 0.f)) + bias_ff;
   st[1] = integv;
   const float lo = m.actuator_forcerange[2 * u], hi = m.actuator_forcerange[2 * u + 1];
   if (lo != 0.f || hi != 0.f) force = clampf(force, lo, hi);
@@ -892,8 +893,10 @@ __device__ __forceinline__ void rb_pid(RbM m, RbLds& s, float* S, bool apply) {
   BFOR(u, m.nu) {
     if (m.actuator_user[u] == 1.f) {
       const int id = m.actuator_trnid[u];
-      const float vel = m.actuator_gear[u] * (m.actuator_trntype[u] == 0 ? s.qvel[m.jnt_dofadr[id]] : SC(TENVEL)[id]);   // mj_transmission: moment . qvel
-      s.actfrc[u] = rb_cascade_tick(m, u, s.ctrl[u], s.actlen[u], vel, s.time == 0.f, s.pid + 3 * u);
+      const bool joint = m.actuator_trntype[u] == 0;
+      const float vel = m.actuator_gear[u] * (joint ? s.qvel[m.jnt_dofadr[id]] : SC(TENVEL)[id]);   // mj_transmission: moment . qvel
+      const float ff = joint ? s.qfrc_bias[m.jnt_dofadr[id]] / m.actuator_gear[u] : 0.f;
+      s.actfrc[u] = rb_cascade_tick(m, u, s.ctrl[u], s.actlen[u], vel, ff, s.time == 0.f, s.pid + 3 * u);
     } else s.actfrc[u] = rb_pid_tick(m, u, s.ctrl[u], s.actlen[u], s.pid + 3 * u);
   }
   BSYNC();

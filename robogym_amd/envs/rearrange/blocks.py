@@ -242,10 +242,7 @@ class BatchedBlockRearrangeEnv:
         half = self._aabb_half(yaw)                                      # rotate_bounding_box
         c, s_ = np.cos(yaw), np.sin(yaw)
         centre = np.stack([c * self.obj_center[:, 0] - s_ * self.obj_center[:, 1], s_ * self.obj_center[:, 0] + c * self.obj_center[:, 1], np.broadcast_to(self.obj_center[:, 2], yaw.shape)], -1)
-        tsx, tsy = 2 * self.table_size[0], 2 * self.table_size[1]
-        portion = float(np.clip(self.used_table_portion, N * 0.1, 1.0))
-        width, height = 0.5 * tsx * portion, 0.38 * tsy * portion
-        off_x, off_y = 0.5 * tsx - width / 2.0, 0.44 * tsy - height / 2.0
+        (off_x, off_y, _), (width, height, _) = self.placement_area()
         out = np.zeros((B, N, 3))
         xy = np.zeros((B, N, 2))
         ncol, nrow = (width // (2 * half[:, :, 0].max(1))).astype(int), (height // (2 * half[:, :, 1].max(1))).astype(int)
@@ -293,6 +290,14 @@ class BatchedBlockRearrangeEnv:
         p = np.concatenate([xy, half[:, :, 2:3] + 2 * self.table_size[2]], -1)
         out = p + [off_x, off_y, 0.0] - self.table_size + self.table_pos - centre      # (the body origin, from the centre of its bounding box)
         return out
+
+    def placement_area(self):
+        """RearrangeSimulationInterface.get_placement_area / get_table_setting (simulation/base.py:980-1010): (offset, size) of the box objects and goals are placed
+        in, offset measured from the table's low corner; `used_table_portion` is clipped to at least a tenth per object."""
+        tsx, tsy = 2 * self.table_size[0], 2 * self.table_size[1]
+        portion = float(np.clip(self.used_table_portion, self.N * 0.1, 1.0))
+        width, height = 0.5 * tsx * portion, 0.38 * tsy * portion
+        return (0.5 * tsx - width / 2.0, 0.44 * tsy - height / 2.0, 2 * self.table_size[2]), (width, height, 0.26)
 
     def _write_goal(self, rows, goal_pos, yaw):
         dev = self.device
