@@ -149,15 +149,27 @@ def _resync_env_steps(models, lib, device, n_substeps, nsteps, seed=1):
     return np.array(errs)
 
 
+RESYNC_COLUMNS = ["solver qpos", "mocap", "main ctrl", "main qpos", "main qvel", "main pid", "sensordata (rel)"]
+# per-step bounds of an ORDINARY re-synchronised env.step (80 mj_steps in fp32 against the double-precision oracle) ...
+RESYNC_STEP_BOUND = {"solver qpos": 1e-4, "mocap": 2e-6, "main ctrl": 2e-5, "main qpos": 2e-4, "main qvel": 2e-2, "main pid": 1e-4, "sensordata (rel)": 1e-2}
+# ... and of an env.step with a contact EVENT that the two precisions resolve a substep apart (a block's flat box-box contact point appearing, the solver's gripper
+# slide leaving its limit row): the emulation harness and the MI355X round differently, so WHICH step of a trajectory is such a step differs between them --
+# the harness shows one in 25 on this protocol (main qpos 9e-4, qvel 5e-2), rounds 3-4's GPU runs happened to show none
+RESYNC_EVENT_BOUND = {"solver qpos": 2e-3, "mocap": 2e-5, "main ctrl": 2e-3, "main qpos": 5e-3, "main qvel": 0.5, "main pid": 5e-3, "sensordata (rel)": 0.2}
+
+
 def _assert_resync(errs):
-    names = ["solver qpos", "mocap", "main ctrl", "main qpos", "main qvel", "main pid", "sensordata (rel)"]
+    names = RESYNC_COLUMNS
     med = dict(zip(names, np.median(errs, axis=0))); mx = dict(zip(names, errs.max(axis=0)))
-    # (main ctrl = the solver's six arm angles: tight.  The solver's whole qpos includes its gripper slides, which sit ON their upper limit
+    # medians: fp32 rounding.  (main ctrl = the solver's six arm angles.  The solver's whole qpos includes its gripper slides, which sit ON their upper limit
     #  (q = 0, range [-0.04473, 0]): whether the limit row is active is a rounding-level decision, worth ~1e-5 m on a joint with armature 100)
-    assert mx["solver qpos"] < 1e-4 and mx["mocap"] < 2e-6 and med["main ctrl"] < 2e-6 and mx["main ctrl"] < 2e-5, (med, mx)
-    assert med["main qpos"] < 2e-6 and mx["main qpos"] < 2e-4, (med, mx)          # (box-box contacts of the blocks on the table: flat contacts, as dactyl's cube on the palm)
-    assert med["main qvel"] < 1e-4 and mx["main qvel"] < 2e-2, (med, mx)
-    assert mx["main pid"] < 1e-4 and med["sensordata (rel)"] < 1e-3, (med, mx)
+    assert med["solver qpos"] < 5e-6 and med["mocap"] < 1e-6 and med["main ctrl"] < 2e-6 and med["main qpos"] < 2e-6 and med["main qvel"] < 1e-4, (med, mx)
+    assert med["main pid"] < 2e-5 and med["sensordata (rel)"] < 1e-3, (med, mx)
+    # every step inside the ordinary bound, except at most one step in ten, which stays inside the event bound
+    ordinary = np.array([[row[i] < RESYNC_STEP_BOUND[n] for i, n in enumerate(names)] for row in errs]).all(axis=1)
+    assert (~ordinary).sum() <= max(1, len(errs) // 10), (errs[~ordinary], med, mx)
+    for i, n in enumerate(names):
+        assert errs[:, i].max() < RESYNC_EVENT_BOUND[n], (n, med, mx)
 
 
 # ------------------------------------------------------------------------------------------------ CPU: the kernel source on the emulation harness
