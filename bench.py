@@ -210,8 +210,8 @@ def bench_rearrange_blocks(args, emit=True, ycb=False):
     achieved = B * res["main"]["algorithmic_bytes_dense"] / (ms_main * 1e-3)
     out = {
         "metric": ("env-steps/sec (whole node) rearrange/ycb num_objects=8 batch 4096 per GPU (BASELINE.json configs[4]: 32768 on 8 GPUs); FIXED object set per model, "
-                   "unwrapped env.step incl. the TCP solver's second simulation; parity vs the in-repo CPU oracle (unpinned)") if ycb else
-                  "env-steps/sec rearrange/blocks num_objects=5 batch 4096 (BASELINE.json configs[3]); unwrapped env.step incl. the TCP solver's second simulation; parity vs the in-repo CPU oracle (unpinned)",
+                   "unwrapped env.step incl. the TCP solver's second simulation; parity vs the in-repo CPU oracle (physics unpinned vs MuJoCo; the controller chain holds the reference's own rearrange tests at their tolerances)") if ycb else
+                  "env-steps/sec rearrange/blocks num_objects=5 batch 4096 (BASELINE.json configs[3]); unwrapped env.step incl. the TCP solver's second simulation; parity vs the in-repo CPU oracle (physics unpinned vs MuJoCo; the controller chain holds the reference's own rearrange tests at their tolerances)",
         "value": world * B * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("rearrange/ycb (UR16e + 2f-85 gripper + table, 8 YCB objects %s as convex-part mesh geoms: nv=56, %d geoms, elliptic cones, impratio 10)" % (getattr(env, "object_names", []), env.sim.info["ngeom"]) if ycb else "rearrange/blocks (UR16e + 2f-85 gripper + table, 5 blocks: nv=38, elliptic cones, impratio 10)") + " with its TCP solver world (nv=8, mocap weld), batch %d, iid U(-1,1) relative tcp+roll+yaw actions, 40 + 40 substeps x 0.001 s + 2 forwards; after the reset recipe%s" % (B, " (shortened: --quick-reset)" if quick else ""),

@@ -5,9 +5,14 @@ dual simulation): a one-env, double-precision numpy restatement of `RearrangeEnv
 PARITY UNPINNED vs MuJoCo for the physics (see oracle/rg_oracle.c); what pins the pieces restated HERE:
   * rotation helpers: tests/golden/rearrange_rotation.npz, generated from the reference's own `robogym.utils.rotation`
     (tools/gen_golden_rearrange.py);
-  * the controller chain as a whole: the reference's own property tests re-expressed on this oracle
-    (/root/reference/robogym/envs/rearrange/tests/test_rearrange_sim.py:96-230: gripper sync, mocap-IK impulse response;
-    tests/test_rearrange_robots.py:45-78,194-243: action scaling tables) in tests/test_rearrange_oracle.py.
+  * the controller chain as a whole: the reference's own physics tests re-expressed on this oracle, at THEIR tolerances
+    (/root/reference/robogym/envs/rearrange/tests/test_rearrange_sim.py:96-132 gripper sync, joint limit -0.04473 +- 1e-4; :135-230 mocap-IK impulse
+    response, four cases x three axes, +- 1e-3 -- which is also what decided the cascaded-PI controller's bias feed-forward, oracle/rg_oracle.c
+    ro_cascade_bias_ff; tests/test_rearrange_robots.py:45-78,194-243 action scaling tables, exact; tests/test_rearrange_envs.py:140-176 gripper-table
+    proximity, :296-320 rest after the reset recipe, :323-399 table-collision penalty; tests/test_placement.py:7-47 placement-area table) in
+    tests/test_rearrange_oracle.py;
+  * the action path, goal layer, observation keys and wrapper stack: fixtures recorded from the reference's own source (tests/golden/rearrange_*.npz / .json,
+    tools/gen_golden_rearrange_*.py).
 
 Follows, one env at a time:
   action -> controls   robot_env.py:497-504, robot/composite/composite_robot.py:72-107,

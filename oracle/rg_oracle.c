@@ -1375,7 +1375,8 @@ static void ro_fwd_actuation(const ro_model* m, ro_data* d) {
        * velocity set-point clamped to +-max_vel, an inner PI loop on actuator_velocity produces the force, the dof's bias force is added (see
        * ro_cascade_bias_ff above), the sum is clamped to forcerange.
        * State per actuator: {position integral, velocity integral, smoothed set-point}.  PROVENANCE: recalled from mujoco-py
-       * 2.0.2.13; pinned only through the reference's impulse-response / gripper-sync property tests (tests/test_rearrange_*). */
+       * 2.0.2.13 except for the bias feed-forward, which is inferred; pinned through the reference's impulse-response / gripper-sync / rest tests
+       * re-expressed on this oracle at their own tolerances (tests/test_rearrange_oracle.py). */
       real* st = d->pid + 3 * i;
       real ema = gp[8], max_vel = gp[9];
       real setp = d->time == 0 ? d->ctrl[i] : ema * st[2] + (1 - ema) * d->ctrl[i];
