@@ -9,7 +9,8 @@ PARITY UNPINNED vs MuJoCo for the physics (see oracle/rg_oracle.c); what pins th
     (/root/reference/robogym/envs/rearrange/tests/test_rearrange_sim.py:96-132 gripper sync, joint limit -0.04473 +- 1e-4; :135-230 mocap-IK impulse
     response, four cases x three axes, +- 1e-3 -- which is also what decided the cascaded-PI controller's bias feed-forward, oracle/rg_oracle.c
     ro_cascade_bias_ff; tests/test_rearrange_robots.py:45-78,194-243 action scaling tables, exact; tests/test_rearrange_envs.py:140-176 gripper-table
-    proximity, :296-320 rest after the reset recipe, :323-399 table-collision penalty; tests/test_placement.py:7-47 placement-area table) in
+    proximity, :296-320 rest after the reset recipe, :323-399 table-collision penalty; tests/test_rearrange_robots.py:142-190 wrist reach, :306-378 wrist
+    isolation; tests/test_placement.py:7-47 placement-area table) in
     tests/test_rearrange_oracle.py;
   * the action path, goal layer, observation keys and wrapper stack: fixtures recorded from the reference's own source (tests/golden/rearrange_*.npz / .json,
     tools/gen_golden_rearrange_*.py).
@@ -299,7 +300,10 @@ class OracleRearrangeEnv:
         return arm, grip
 
     def set_action(self, action):
-        arm, grip = self.denormalize(action)
+        self.set_control(*self.denormalize(action))
+
+    def set_control(self, arm, grip):
+        """CompositeRobot.set_position_control with DENORMALISED controls: arm = (dx, dy, dz, roll, pitch/yaw -> J6), grip = the gripper's control target"""
         m, c = self.main, self.solver
         # JointControlledTcpArm.set_position_control
         if self.reset_controller_error:

@@ -1357,7 +1357,8 @@ static void ro_fwd_velocity(const ro_model* m, ro_data* d) {
 /* The cascaded-PI controller's bias feed-forward (gravity + Coriolis compensation: the force of the velocity loop plus qfrc_bias of the actuated dof).  mjpid.pyx
  * is not in the tree; the term is inferred from the reference's own pins (envs/rearrange/tests/test_rearrange_sim.py:135-230): with it all four impulse-response
  * cases hold at the stated 1e-3 (0.0362 / 0.0364 / 0.0365 for 0.036, 0.02197 / 0.02209 / 0.02206 for 0.022, ...), without it the wrist joints J5 / J6 -- P-only
- * velocity loops, gainprm ti_v = 0 -- creep under the wrist camera's weight and two cases miss by 1.4-1.6e-3 (tests/test_rearrange_oracle.py keeps both runs).
+ * velocity loops, gainprm ti_v = 0 -- creep under the wrist camera's weight and two cases miss by 1.4-1.6e-3; test_rearrange_robots.py:306-378 (wrist isolation:
+ * J1 .. J5 within 0.7 deg over 100 wrist-only steps) likewise holds with it and fails without (tests/test_rearrange_oracle.py keeps both runs of each).
  * ro_set_cascade_bias_ff(0) switches it off for that comparison. */
 static int ro_cascade_bias_ff = 1;
 void ro_set_cascade_bias_ff(int on) { ro_cascade_bias_ff = on; }

@@ -401,6 +401,70 @@ def test_randomized_initial_robot_position_comes_to_rest(models):
     assert min(np.linalg.norm(ends[i] - ends[j]) for i in range(6) for j in range(i)) > 1e-2
 
 
+def _wrist_only(models, value, steps=100):
+    """test_rearrange_robots.py:306-378's protocol on the default env (TCP_ROLL_YAW, MOCAP_IK, max_position_change 0.1, no random initial steps): `steps` steps of the
+    wrapped env with every action bin at 5 (zero) except the wrist's (index -2) at 7 or 3, i.e. +-0.4 through the smoothing wrapper.  Returns the arm's joint
+    displacement over the run."""
+    env = _env(models, 0.1, True)
+    m = env.main
+    q0 = m.sim.qpos[m.arm_q].copy()
+    alpha, ema = 0.3 ** (0.001 * 40 / 0.08), np.zeros(6)
+    a = np.zeros(6); a[-2] = value
+    for k in range(steps):
+        ema = ema * alpha + (1 - alpha) * a
+        env.env_step(ema / (1 - alpha ** (k + 1)))
+    return m.sim.qpos[m.arm_q] - q0
+
+
+def test_wrist_isolation(models, oracle_lib):
+    """test_rearrange_robots.py:306-378, as stated: 100 steps of a pure wrist action, clockwise and counter-clockwise, leave J1 .. J5 within 0.7 deg of where they
+    started while J6 turns (to its range's end less JOINT_DRIFT_THRESHOLD, where `constrain_quat_ctrl` holds it).  This is the reference's second statement that
+    needs the cascaded-PI controller's bias feed-forward: without it J5 alone creeps by more than a degree in those 100 steps (checked below)."""
+    tol = np.deg2rad(0.7)
+    for value in (0.4, -0.4):
+        dq = _wrist_only(models, value)
+        assert np.abs(dq[:5]).max() < tol and abs(dq[5]) > 0.5, np.rad2deg(dq)
+    try:
+        oracle_lib.lib().ro_set_cascade_bias_ff(0)
+        dq = _wrist_only(models, 0.4)
+    finally:
+        oracle_lib.lib().ro_set_cascade_bias_ff(1)
+    assert np.abs(dq[:5]).max() > tol and np.argmax(np.abs(dq[:5])) == 4, np.rad2deg(dq)
+
+
+def test_free_wrist_reach(models):
+    """test_rearrange_robots.py:142-190 (TCP_ROLL_YAW, MOCAP_IK, max_position_change 0.1, controller-error reset) with robot/utils/reach_helper.py:731-762: a
+    proportional controller on the wrist dimension of the DENORMALISED control -- Kp x clip(error, +-30 deg) per step, the arm auto-stepping -- brings J6 to each of 12
+    angles between its control range's ends less 5 deg within 200 steps (tolerance 1e-2 rad, Kp = 2); the angles 5 deg OUTSIDE the range are not reached (Kp = 1,
+    100 steps): `constrain_quat_ctrl` keeps the wrist JOINT_DRIFT_THRESHOLD = 1 deg inside.  (The reference resets with 10 random initial steps; here every reach
+    starts from the tabletop start pose.)"""
+    def reach(target, Kp=1, max_steps=100, speed_limit=np.deg2rad(30), atol=1e-2):
+        env = _env(models, 0.1, True, stabilize=20)
+        m = env.main
+        j6 = lambda: m.sim.qpos[m.arm_q[5]]
+        step, error = 0, target - j6()
+        while step < max_steps and not abs(error) < atol:
+            ctrl = np.zeros(5); ctrl[-1] = Kp * np.clip(error, -speed_limit, speed_limit)
+            env.set_control(ctrl, m.sim.ctrl[m.grip_act])
+            m.step(); env.observe_sync()                                  # autostep + the observation that syncs the solver world's gripper
+            error, step = target - j6(), step + 1
+        return abs(error) < atol, step, j6()
+
+    A = models[0].arrays
+    lo, hi = A["actuator_ctrlrange"][5]
+    assert np.allclose([lo, hi], [0.872665, 5.49778714])                 # joint_actuations.xml:10
+    buf = np.deg2rad(5)
+    steps = []
+    for target in np.linspace(lo + buf, hi - buf, 12):
+        ok, n, got = reach(target, Kp=2, max_steps=200)
+        assert ok, (np.rad2deg(target), np.rad2deg(got))
+        steps.append(n)
+    assert max(steps) <= 60, steps                                        # (measured: at most a few tens of steps; the reference allows 200)
+    for target in (lo - buf, hi + buf):
+        ok, n, got = reach(target)
+        assert not ok and abs(got - np.clip(target, lo + np.deg2rad(1), hi - np.deg2rad(1))) < np.deg2rad(1.5), (np.rad2deg(target), np.rad2deg(got))
+
+
 def test_crowded_table_placement_keeps_objects_apart():
     """`BatchedBlockRearrangeEnv._grid_placement` on the ycb object set, where the grid has fewer cells than objects (8 large meshes on the 0.61 x 0.58 m area):
     the fallback (place_objects_with_no_constraint, common/utils.py:829-880, vectorised over envs, largest object first) leaves no two bounding boxes overlapping
