@@ -218,6 +218,43 @@ def test_rearrange_pipelined_reset_sequence_gpu():
     _pipelined_reset_sequence(None, "cuda:0", n_substeps=40, B=64)
 
 
+# ------------------------------------------------------------------------------------------------ the reference's impulse-response pin on the batched env itself
+def _impulse_response_on_the_kernel(lib, device, stabilize_steps, cases=((True, 0.165, 0.036, 5), (False, 0.05, 0.0363, 12))):
+    """envs/rearrange/tests/test_rearrange_sim.py:135-230 stepped on the PRODUCT (BatchedBlockRearrangeEnv, no oracle in the loop): three envs per case, env i gets the
+    impulse on TCP axis i after two zero steps, then 40 zero steps, the actions passed through the smoothing wrapper's filter as the reference's
+    `make_env(...).env` does (tests/test_rearrange_oracle.py::_impulse_trajectory is the same protocol on the oracle).  Asserted as the reference states it:
+    steady-state displacement within 1e-3 of the expected value and 90 % of it within `rise` steps, on every axis."""
+    kw = dict(lib=lib) if lib is not None else {}
+    alpha = 0.3 ** (0.001 * 40 / 0.08)
+    out = []
+    for rce, mpc, expected, rise in cases:
+        env = BatchedBlockRearrangeEnv(3, device=device, max_position_change=mpc, arm_reset_controller_error=rce, n_random_initial_steps=0, stabilize_steps=stabilize_steps,
+                                       settle_steps=0, starting_seed=0, **kw)
+        env.reset()
+        P, ema = [], np.zeros((3, 6))
+        for k in range(43):
+            imp = np.zeros((3, 6))
+            if k == 2:
+                imp[np.arange(3), np.arange(3)] = 1.0
+            ema = ema * alpha + (1 - alpha) * imp
+            obs = env.step(torch.tensor((ema / (1 - alpha ** (k + 1))).astype(np.float32), device=env.device))[0]
+            P.append(obs["gripper_pos"].cpu().numpy().astype(np.float64).copy())
+        env.sync()
+        assert int(env.sim.status.max()) == 0 and int(env.solver_sim.status.max()) == 0
+        P = np.array(P) - P[0]
+        total = P[-1][np.arange(3), np.arange(3)]
+        out.append(total)
+        assert np.abs(total - expected).max() < 1e-3, (rce, mpc, total)
+        assert (np.abs(P[2 + rise][np.arange(3), np.arange(3)]) > 0.9 * total).all(), (rce, mpc, P[2 + rise], total)
+    return out
+
+
+@pytest.mark.gpu
+def test_mocap_ik_impulse_response_on_the_kernel_gpu():
+    """(written after round 4's last GPU call; the same function was run once on the emulation harness with a shortened stabilisation: profiles/r04_impulse_response_emul.txt)"""
+    _impulse_response_on_the_kernel(None, "cuda:0", stabilize_steps=100)
+
+
 # ------------------------------------------------------------------------------------------------ the goal layer against the reference's own code
 def _goal_golden():
     import os
