@@ -83,6 +83,19 @@ def kernel_source_hash(which="rg"):
     return h.hexdigest()[:16]
 
 
+def rb_traffic_note(workload, B):
+    """Why `traffic` is null, with the last measured figure, or where the figure comes from."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+        e = t["rb_step_kernel"][workload]
+        gb = float(e["bytes_per_launch"]) / 1e9
+        if rb_traffic(workload, B) is not None:
+            return "PMC FETCH_SIZE x2 + WRITE_SIZE of the dominant launch, profiles/hbm_traffic.json (round %s)" % t.get("round")
+        return "null: the committed figure (%.1f GB per launch at batch %d, round %s) was measured on another build of rb_step_kernel or batch size" % (gb, int(e["batch_per_gpu"]), t.get("round"))
+    except (OSError, ValueError, KeyError):
+        return "null: no PMC figure committed for this workload"
+
+
 def rb_traffic(workload, B):
     """HBM GB per dominant rb_step_kernel launch from the round's PMC passes (profiles/hbm_traffic.json), if measured on this kernel build and batch; else None."""
     try:
@@ -217,7 +230,7 @@ def bench_rearrange_blocks(args, emit=True, ycb=False):
         "config": {"workload": ("rearrange/ycb (UR16e + 2f-85 gripper + table, 8 YCB objects %s as convex-part mesh geoms: nv=56, %d geoms, elliptic cones, impratio 10)" % (getattr(env, "object_names", []), env.sim.info["ngeom"]) if ycb else "rearrange/blocks (UR16e + 2f-85 gripper + table, 5 blocks: nv=38, elliptic cones, impratio 10)") + " with its TCP solver world (nv=8, mocap weld), batch %d, iid U(-1,1) relative tcp+roll+yaw actions, 40 + 40 substeps x 0.001 s + 2 forwards; after the reset recipe%s" % (B, " (shortened: --quick-reset)" if quick else ""),
                    "batch_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d (envs sharded, all-gather of the packed observation rows)" % world, "collective_backend": (dist.get_backend() if distributed else None), "reset_seconds": t_reset, "main": res["main"], "solver": res["solver"], "status_bits": int(max(env.sim.status.max().item(), env.solver_sim.status.max().item())),
                    "done_fraction_last_step": float(env.done.float().mean().item()), "launch_ms": {"solver_world": ms_solver, "main_world": ms_main}, "lds_bytes_per_workgroup": env.sim.info["lds_bytes"]},
-        "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": rb_traffic("ycb" if ycb else "rearrange_blocks", B), "traffic_unit": "GB per launch (PMC, profiles/hbm_traffic.json)", "kernel": "rb_step_kernel (main world launch)", "kernel_ms": ms_main,
+        "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": rb_traffic("ycb" if ycb else "rearrange_blocks", B), "traffic_unit": "GB per launch (PMC, profiles/hbm_traffic.json)", "traffic_note": rb_traffic_note("ycb" if ycb else "rearrange_blocks", B), "kernel": "rb_step_kernel (main world launch)", "kernel_ms": ms_main,
                      "algorithmic_bytes_per_env_step": res["main"]["algorithmic_bytes_dense"], "frac_sparse_J": B * res["main"]["algorithmic_bytes_sparse_J"] / (ms_main * 1e-3) / HBM_PEAK,
                      "note": "dominant kernel = the main world's launch; SURVEY 8(d) dense byte model with the run's ncon / nefc / iterations; frac_sparse_J counts a constraint row at <= 16 dofs and M tree-sparse (what the stepper stores)"},
     }
@@ -284,7 +297,7 @@ def bench_full_perpendicular(args, emit=True):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "dactyl/full_perpendicular (Shadow hand + full Rubik's cube, nv=168, 135 bodies, condim-6 contacts), batch %d, iid U(-1,1) relative actions, 10 substeps x 0.008 s; env.step = physics + env kernel (face_free goals), after the reset recipe with scrambled cubes" % B,
                    "batch_per_gpu": B, "pipelined_reset": bool(args.pipelined_reset), "cube_on_palm_fraction_after_reset": on_palm0, "cube_on_palm_fraction_at_end": on_palm, "goals_so_far_mean": float(env.multi_goal_tracker.goals_so_far.float().mean().item()), "mean_ncon": ncon, "mean_nefc": nefc, "mean_newton_iters": iters, "status_bits": int(sim.status.max().item()), "lds_bytes_per_workgroup": sim.info["lds_bytes"]},
-        "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": rb_traffic("full_perpendicular", B), "traffic_unit": "GB per launch (PMC, profiles/hbm_traffic.json)", "kernel": "rb_step_kernel", "kernel_ms": kern_ms,
+        "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": rb_traffic("full_perpendicular", B), "traffic_unit": "GB per launch (PMC, profiles/hbm_traffic.json)", "traffic_note": rb_traffic_note("full_perpendicular", B), "kernel": "rb_step_kernel", "kernel_ms": kern_ms,
                      "algorithmic_bytes_per_env_step": b_step, "algorithmic_bytes_per_substep": b_sub,
                      "frac_sparse_J": B * algorithmic_bytes_sparse(_M, sim.info["nM"], ncon, nefc, iters, sim.n_substeps, sim.nq + sim.nv)[0] / (kern_ms * 1e-3) / HBM_PEAK,
                      "note": "frac = SURVEY 8(d) DENSE byte model (nefc x nv Jacobian, 2 nv^2 solver terms) with this model's dimensions (nM 1193) and the run's measured ncon / nefc / iterations; frac_sparse_J = the same model with a constraint row counted at <= 16 dofs and M tree-sparse, which is what the stepper stores: the dense figure overstates the bytes of a kernel whose Jacobians are sparse"},
