@@ -478,21 +478,45 @@ class BatchedBlockRearrangeEnv:
         self.sim.sync()
 
 
+SUPPORTED_PARAMETERS = {"simulation_params", "robot_control_params", "n_random_initial_steps"}
+SUPPORTED_SIMULATION_PARAMS = {"num_objects", "penalty", "used_table_portion"}
+SUPPORTED_ROBOT_CONTROL_PARAMS = {"max_position_change", "arm_reset_controller_error", "control_mode", "tcp_solver_mode"}
+SUPPORTED_CONSTANTS = {"success_threshold", "successes_needed", "success_reward", "max_timesteps_per_goal_per_obj", "n_action_bins", "action_spacing", "use_goal_distance_reward",
+                       "goal_reward_per_object", "normalize_mesh"}
+
+
+def _check_supported(parameters, sp, rc, constants):
+    """A parameter or constant of the reference's env that this env does not implement is an error, not a silently ignored key (the reference's attrs classes reject
+    unknown names the same way; the supported subset keeps the reference's names and meaning)."""
+    for got, known, where in ((parameters, SUPPORTED_PARAMETERS, "parameters"), (sp, SUPPORTED_SIMULATION_PARAMS, "parameters.simulation_params"),
+                              (rc, SUPPORTED_ROBOT_CONTROL_PARAMS, "parameters.robot_control_params"), (constants, SUPPORTED_CONSTANTS, "constants")):
+        unknown = sorted(set(got) - known)
+        if unknown:
+            raise NotImplementedError("%s: %s not implemented by the batched rearrange env (supported: %s)" % (where, ", ".join(unknown), ", ".join(sorted(known))))
+    if str(rc.get("control_mode", "tcp+roll+yaw")).lower().split(".")[-1] not in ("tcp+roll+yaw", "tcp_roll_yaw"):
+        raise NotImplementedError("control_mode other than tcp+roll+yaw (the reference's default, robot_interface.py:43-47)")
+    if str(rc.get("tcp_solver_mode", "mocap_ik")).lower().split(".")[-1] != "mocap_ik":
+        raise NotImplementedError("tcp_solver_mode other than mocap_ik (the reference's default, robot_interface.py:54-58)")
+
+
 def make_env(batch_size: int = 4096, device="cuda:0", parameters=None, constants=None, starting_seed: int = 0, apply_wrappers: bool = True, **kw):
     """`BlockRearrangeEnv.build` surface (robot_env.py:1081-1089) for the batched env; `apply_wrappers` (default True, as in the reference) = the rearrange
     wrapper stack of common/base.py:986-996 (MultiDiscrete actions of `constants.n_action_bins` = 11 bins, action smoothing, reward clipping).  `parameters` / `constants` accept the subset this env
-    implements: parameters.simulation_params.num_objects, parameters.robot_control_params.{max_position_change, arm_reset_controller_error},
-    parameters.n_random_initial_steps, constants.{success_threshold, successes_needed, success_reward, max_timesteps_per_goal_per_obj}."""
+    implements (`SUPPORTED_*` below); any other name raises NotImplementedError."""
     parameters, constants = dict(parameters or {}), dict(constants or {})
     sp, rc = dict(parameters.get("simulation_params", {})), dict(parameters.get("robot_control_params", {}))
+    _check_supported(parameters, sp, rc, constants)
     args = dict(num_objects=sp.get("num_objects", 5), max_position_change=rc.get("max_position_change", 0.1), arm_reset_controller_error=rc.get("arm_reset_controller_error", True),
                 n_random_initial_steps=parameters.get("n_random_initial_steps", 10), starting_seed=starting_seed, wrappers=bool(apply_wrappers),
                 n_action_bins=constants.get("n_action_bins", 11))      # (+ pipelined_reset=True through **kw: episodes restart inside the step calls)
     if constants.get("action_spacing", "linear") not in ("linear", "LINEAR"):
         raise NotImplementedError("action_spacing other than linear")
-    for k in ("success_threshold", "successes_needed", "success_reward", "max_timesteps_per_goal_per_obj"):
+    for k in ("success_threshold", "successes_needed", "success_reward", "max_timesteps_per_goal_per_obj", "use_goal_distance_reward", "goal_reward_per_object"):
         if k in constants:
             args[k] = constants[k]
+    for k in ("penalty", "used_table_portion"):      # (a given penalty dict replaces the default one as a whole, as the reference's attrs field does)
+        if k in sp:
+            args[k] = sp[k]
     args.update(kw)
     return BatchedBlockRearrangeEnv(batch_size, device=device, **args)
 

@@ -162,16 +162,22 @@ class GroupedYcbRearrangeEnv:
 
 def make_env(batch_size: int = 4096, device="cuda:0", parameters=None, constants=None, starting_seed: int = 0, apply_wrappers: bool = True, **kw):
     """`YcbRearrangeEnv.build` surface (ycb.py:96) for the batched env; accepts what envs/rearrange/blocks.py `make_env` accepts."""
+    from robogym_amd.envs.rearrange.blocks import _check_supported
+
     parameters, constants = dict(parameters or {}), dict(constants or {})
     sp, rc = dict(parameters.get("simulation_params", {})), dict(parameters.get("robot_control_params", {}))
     if parameters.get("mesh_names") is not None or constants.get("normalize_mesh"):
-        raise NotImplementedError("mesh_names / normalize_mesh: the shipped model holds one fixed object set")
+        raise NotImplementedError("mesh_names / normalize_mesh: the shipped models hold fixed object sets")
+    _check_supported({k: v for k, v in parameters.items() if k != "mesh_names"}, sp, rc, constants)
     args = dict(num_objects=sp.get("num_objects", 8), max_position_change=rc.get("max_position_change", 0.1), arm_reset_controller_error=rc.get("arm_reset_controller_error", True),
                 n_random_initial_steps=parameters.get("n_random_initial_steps", 10), starting_seed=starting_seed, wrappers=bool(apply_wrappers),
                 n_action_bins=constants.get("n_action_bins", 11))
-    for k in ("success_threshold", "successes_needed", "success_reward", "max_timesteps_per_goal_per_obj"):
+    for k in ("success_threshold", "successes_needed", "success_reward", "max_timesteps_per_goal_per_obj", "use_goal_distance_reward", "goal_reward_per_object"):
         if k in constants:
             args[k] = constants[k]
+    for k in ("penalty", "used_table_portion"):
+        if k in sp:
+            args[k] = sp[k]
     args.update(kw)
     object_sets = args.pop("object_sets", None)      # e.g. (0, 1, 2, 3): different object sets across the batch (GroupedYcbRearrangeEnv)
     if object_sets is not None and len(object_sets) > 1:

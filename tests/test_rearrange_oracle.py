@@ -465,6 +465,20 @@ def test_free_wrist_reach(models):
         assert not ok and abs(got - np.clip(target, lo + np.deg2rad(1), hi - np.deg2rad(1))) < np.deg2rad(1.5), (np.rad2deg(target), np.rad2deg(got))
 
 
+def test_make_env_rejects_what_it_does_not_implement():
+    """`make_env(parameters=..., constants=...)` of the batched rearrange envs: a name of the reference's parameter / constant classes that is not implemented raises
+    (the reference's attrs classes raise on unknown names; silently ignoring e.g. `success_pause_range_s` would change the task without a word), and so does a
+    control or solver mode other than the default pair."""
+    from robogym_amd.envs.rearrange import blocks as Bk, ycb as Yc
+
+    for mk in (Bk.make_env, Yc.make_env):
+        for bad in (dict(constants={"success_pause_range_s": (1.0, 1.0)}), dict(parameters={"simulation_params": {"object_groups": []}}),
+                    dict(parameters={"robot_control_params": {"control_mode": "tcp+wrist"}}), dict(parameters={"robot_control_params": {"tcp_solver_mode": "mocap"}}),
+                    dict(parameters={"object_scale_high": 0.5})):
+            with pytest.raises(NotImplementedError):
+                mk(batch_size=1, device="cpu", **bad)
+
+
 def test_crowded_table_placement_keeps_objects_apart():
     """`BatchedBlockRearrangeEnv._grid_placement` on the ycb object set, where the grid has fewer cells than objects (8 large meshes on the 0.61 x 0.58 m area):
     the fallback (place_objects_with_no_constraint, common/utils.py:829-880, vectorised over envs, largest object first) leaves no two bounding boxes overlapping
