@@ -55,7 +55,7 @@ class BatchedBlockRearrangeEnv:
                  success_threshold=None, penalty=None, max_timesteps_per_goal_per_obj: int = 200, successes_needed: int = 5, success_reward: float = 5.0,
                  use_goal_distance_reward: bool = True, goal_reward_per_object: float = 1.0, used_table_portion: float = 1.0, lib=None, n_substeps: int = 40,
                  main_model=None, wrappers: bool = False, n_action_bins: int = 11, smooth_alpha: float = 0.3, reward_clip: float = 100.0,
-                 pipelined_reset: bool = False):
+                 pipelined_reset: bool = False, action_spacing: str = "linear"):
         self.B, self.N = int(batch_size), int(num_objects)
         self._L = lib if lib is not None else _native.lib()
         main, solver = (main_model if main_model is not None else load_blocks_model(self.N)), load_solver_model()   # (main_model: the same world with other objects, envs/rearrange/ycb.py)
@@ -147,7 +147,7 @@ class BatchedBlockRearrangeEnv:
         self.wrapped = bool(wrappers)
         self.n_action_bins = int(n_action_bins)
         self.ema_value, self.ema_t, self.action_ema = z(B, 6), z(B, dt=torch.int32), z(B, 6)
-        self.bins = torch.tensor(np.tile(np.linspace(-1.0, 1.0, self.n_action_bins), (6, 1)).astype(np.float32), device=dev).contiguous()   # BinSpacing.LINEAR over Box(-1, 1)
+        self.bins = torch.tensor(np.tile(action_bin_array(-1.0, 1.0, self.n_action_bins, action_spacing), (6, 1)).astype(np.float32), device=dev).contiguous()   # over Box(-1, 1)
         tw = self.tcp_wrapped = _native.RbTcpArgs()
         ctypes.memmove(ctypes.byref(tw), ctypes.byref(t), ctypes.sizeof(t))
         tw.bins, tw.nbins = self.bins.data_ptr(), self.n_action_bins
@@ -478,6 +478,19 @@ class BatchedBlockRearrangeEnv:
         self.sim.sync()
 
 
+def action_bin_array(lower_bound, upper_bound, n_bins, spacing="linear"):
+    """BinSpacing.get_bin_array (wrappers/util.py:17-33): the table DiscretizeActionWrapper maps a bin index through.  "linear": n_bins evenly spaced values;
+    "exponential" (symmetric range, odd n_bins): -1, -1/2, -1/4, ... 0 ... 1/4, 1/2, 1 times the bound."""
+    spacing = str(spacing).lower().split(".")[-1]
+    if spacing == "linear":
+        return np.linspace(lower_bound, upper_bound, n_bins)
+    if spacing != "exponential":
+        raise NotImplementedError("action_spacing %r" % spacing)
+    assert lower_bound == -upper_bound and n_bins % 2 == 1, "Exponential binning is only supported on symmetric action space with an odd number of bins"
+    half = np.array([2.0 ** (-n) for n in range(n_bins // 2)]) * lower_bound
+    return np.concatenate([half, [0.0], -half[::-1]])
+
+
 SUPPORTED_PARAMETERS = {"simulation_params", "robot_control_params", "n_random_initial_steps"}
 SUPPORTED_SIMULATION_PARAMS = {"num_objects", "penalty", "used_table_portion"}
 SUPPORTED_ROBOT_CONTROL_PARAMS = {"max_position_change", "arm_reset_controller_error", "control_mode", "tcp_solver_mode"}
@@ -509,8 +522,8 @@ def make_env(batch_size: int = 4096, device="cuda:0", parameters=None, constants
     args = dict(num_objects=sp.get("num_objects", 5), max_position_change=rc.get("max_position_change", 0.1), arm_reset_controller_error=rc.get("arm_reset_controller_error", True),
                 n_random_initial_steps=parameters.get("n_random_initial_steps", 10), starting_seed=starting_seed, wrappers=bool(apply_wrappers),
                 n_action_bins=constants.get("n_action_bins", 11))      # (+ pipelined_reset=True through **kw: episodes restart inside the step calls)
-    if constants.get("action_spacing", "linear") not in ("linear", "LINEAR"):
-        raise NotImplementedError("action_spacing other than linear")
+    if "action_spacing" in constants:
+        args["action_spacing"] = constants["action_spacing"]
     for k in ("success_threshold", "successes_needed", "success_reward", "max_timesteps_per_goal_per_obj", "use_goal_distance_reward", "goal_reward_per_object"):
         if k in constants:
             args[k] = constants[k]

@@ -172,6 +172,8 @@ def make_env(batch_size: int = 4096, device="cuda:0", parameters=None, constants
     args = dict(num_objects=sp.get("num_objects", 8), max_position_change=rc.get("max_position_change", 0.1), arm_reset_controller_error=rc.get("arm_reset_controller_error", True),
                 n_random_initial_steps=parameters.get("n_random_initial_steps", 10), starting_seed=starting_seed, wrappers=bool(apply_wrappers),
                 n_action_bins=constants.get("n_action_bins", 11))
+    if "action_spacing" in constants:
+        args["action_spacing"] = constants["action_spacing"]
     for k in ("success_threshold", "successes_needed", "success_reward", "max_timesteps_per_goal_per_obj", "use_goal_distance_reward", "goal_reward_per_object"):
         if k in constants:
             args[k] = constants[k]

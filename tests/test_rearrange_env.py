@@ -174,6 +174,20 @@ def test_rearrange_wrapper_stack_matches_reference_classes_gpu():
     _wrapper_stack_replay(None, "cuda:0", n_substeps=40)
 
 
+def test_exponential_action_bins_reach_the_launch_emul(emul_lib):
+    """`constants.action_spacing = "exponential"` (BinSpacing.EXPONENTIAL, wrappers/util.py:17-33): the env's device table is the reference's exponential array and
+    the launch maps bin indices through it -- after the first step of an episode the smoothing wrapper's output is the mapped action itself."""
+    from robogym_amd.envs.rearrange.blocks import make_env
+
+    env = make_env(batch_size=1, device="cpu", lib=emul_lib, constants={"action_spacing": "exponential"}, n_substeps=1, stabilize_steps=1, n_random_initial_steps=0, settle_steps=0)
+    table = [-1.0, -0.5, -0.25, -0.125, -0.0625, 0.0, 0.0625, 0.125, 0.25, 0.5, 1.0]
+    assert env.bins.shape == (6, 11) and all(env.bins[d].tolist() == table for d in range(6))
+    env.reset()
+    idx = torch.tensor([[3, 9, 5, 0, 10, 6]])
+    obs = env.step(idx)[0]
+    assert np.allclose(obs["action_ema"][0].numpy(), [table[i] for i in idx[0].tolist()], atol=1e-7)
+
+
 # ------------------------------------------------------------------------------------------------ pipelined resets
 def _pipelined_reset_sequence(lib, device, n_substeps, B):
     """Episodes that end (goal time-out after 5 steps here) restart INSIDE the following step calls: recipe stages of 2 + 1 + 2 steps (stabilise, one random

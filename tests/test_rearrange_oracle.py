@@ -465,6 +465,19 @@ def test_free_wrist_reach(models):
         assert not ok and abs(got - np.clip(target, lo + np.deg2rad(1), hi - np.deg2rad(1))) < np.deg2rad(1.5), (np.rad2deg(target), np.rad2deg(got))
 
 
+def test_discretize_action_tables():
+    """wrappers/tests/test_action_wrappers.py:7-31, the reference's own numbers: 11 linear bins = linspace(-1, 1, 11), 11 exponential bins =
+    -1, -0.5, -0.25, -0.125, -0.0625, 0, ... 1; and the env's device table is that array for each of the six action dimensions."""
+    from robogym_amd.envs.rearrange.blocks import action_bin_array
+
+    assert np.array_equal(action_bin_array(-1.0, 1.0, 11, "linear"), np.linspace(-1, 1, 11))
+    assert np.array_equal(action_bin_array(-1.0, 1.0, 11, "exponential"), [-1.0, -0.5, -0.25, -0.125, -0.0625, 0.0, 0.0625, 0.125, 0.25, 0.5, 1.0])
+    with pytest.raises(AssertionError):
+        action_bin_array(-1.0, 1.0, 10, "exponential")
+    with pytest.raises(NotImplementedError):
+        action_bin_array(-1.0, 1.0, 11, "log")
+
+
 def test_make_env_rejects_what_it_does_not_implement():
     """`make_env(parameters=..., constants=...)` of the batched rearrange envs: a name of the reference's parameter / constant classes that is not implemented raises
     (the reference's attrs classes raise on unknown names; silently ignoring e.g. `success_pause_range_s` would change the task without a word), and so does a
