@@ -35,9 +35,10 @@ class GroupedYcbRearrangeEnv:
     models stay where they are and the ENVS move: env i of the batch is served by a physics slot `slot[i]` (a row of one group), and the slots whose episodes end
     on the same step -- all of them are about to run the reset recipe from a freshly made world, nothing of the old episode survives in them -- are handed out
     again among the envs that ended, by a random permutation.  The next episode of env i therefore runs on the object set of whatever group its new slot belongs
-    to.  Limits, stated: the pool is the K shipped sets (the reference samples `num_objects` meshes from the whole YCB catalogue), and an env can only receive a set
-    that some env of the batch released on the same step (with thousands of envs and episodes of a few hundred steps that is tens of slots per step; an env that
-    ends alone keeps its slot).  `resample_object_sets=False` pins env i to slot i."""
+    to.  With pipelined resets the slots that ended on EARLIER steps and are still inside the reset recipe take part in the deal as well (they are as ownerless as
+    the ones that just ended), so an env that ends draws its next slot from everything that is resetting at that moment -- recipe length x episode ends per step,
+    hundreds of slots at B = 4096.  Limits, stated: the pool of object sets is the K shipped ones (the reference samples `num_objects` meshes from the whole YCB
+    catalogue); an env that ends while nothing else is resetting keeps its slot.  `resample_object_sets=False` pins env i to slot i."""
 
     def __init__(self, batch_size: int, device="cuda:0", object_sets=(0, 1, 2, 3), starting_seed: int = 0, resample_object_sets: bool = True, **kw):
         import numpy as np
@@ -140,12 +141,20 @@ class GroupedYcbRearrangeEnv:
         info = {k: self._to_envs(torch.cat([o[3][k] for o in outs])) for k in outs[0][3] if torch.is_tensor(outs[0][3][k])}
         info["object_names"] = self._names()            # (of the episode this step belonged to: the terminal step still names the set that just ended)
         self._slot_of_step = self._slot.copy()
-        if self.resample and self.groups[0].pipelined:
-            ended = np.concatenate([i * b + np.asarray(g.ended_rows, dtype=np.int64) for i, g in enumerate(self.groups)])
-            if len(ended) > 1:
-                inv = np.empty(self.B, dtype=np.int64); inv[self._slot] = np.arange(self.B)
-                self._reassign(inv[ended])
+        self._trade_slots()
         return obs, reward, done, info
+
+    def _trade_slots(self):
+        """After a step with pipelined resets: if episodes ended on it, every slot that is INSIDE the reset recipe now -- the ones that just ended and the ones that
+        ended on earlier steps and are still stabilising / settling -- is dealt out again among the envs that hold those slots.  (Nothing an env owns lives in a
+        slot during the recipe: its outputs are flagged `resetting` until the slot it holds at that moment reports `episode_started`, which every slot does once.)"""
+        import numpy as np
+
+        if not (self.resample and self.groups[0].pipelined) or sum(len(g.ended_rows) for g in self.groups) == 0:
+            return
+        pool = np.concatenate([i * self.b + np.nonzero(np.asarray(g._stage) > 0)[0] for i, g in enumerate(self.groups)])
+        inv = np.empty(self.B, dtype=np.int64); inv[self._slot] = np.arange(self.B)
+        self._reassign(inv[pool])
 
     def observe(self):
         return self._observation()

@@ -240,6 +240,33 @@ def _per_episode_checks(lib, device, B, steps, seed, **recipe):
     return env, ended, started, tables
 
 
+def test_slot_trading_pool_is_everything_inside_the_reset_recipe():
+    """GroupedYcbRearrangeEnv._trade_slots on stub groups (no physics): on a step with episode ends, the envs holding slots inside the reset recipe -- just ended or
+    ended earlier -- get those same slots back in a new order; live slots and their envs are untouched; a step without ends deals nothing."""
+    import types
+    from robogym_amd.envs.rearrange.ycb import GroupedYcbRearrangeEnv
+
+    env = object.__new__(GroupedYcbRearrangeEnv)
+    env.B, env.b, env.K, env.resample, env.device, env.episodes_moved = 8, 4, 2, True, torch.device("cpu"), 0
+    env._rng = np.random.RandomState(0)
+    env._slot = np.array([3, 0, 6, 1, 7, 2, 5, 4])                       # env -> slot, some earlier deal
+    stage = [np.array([0, 2, 0, 1]), np.array([3, 0, 0, 1])]               # slots 1, 3 (group 0) and 4, 7 (group 1) are inside the recipe
+    env.groups = [types.SimpleNamespace(_stage=stage[0], ended_rows=np.array([3]), pipelined=True), types.SimpleNamespace(_stage=stage[1], ended_rows=np.array([3]), pipelined=True)]
+    before = env._slot.copy()
+    env._trade_slots()
+    pool_slots = {1, 3, 4, 7}
+    holders = [e for e in range(8) if before[e] in pool_slots]
+    assert sorted(env._slot[holders]) == sorted(pool_slots) and sorted(env._slot.tolist()) == list(range(8))
+    assert all(env._slot[e] == before[e] for e in range(8) if before[e] not in pool_slots)
+    assert not np.array_equal(env._slot, before) and torch.equal(env._slot_dev, torch.as_tensor(env._slot))
+    assert torch.equal(env._env_of_slot_dev[env._slot_dev], torch.arange(8))
+    for g in env.groups:
+        g.ended_rows = np.zeros(0, dtype=np.int64)
+    again = env._slot.copy()
+    env._trade_slots()
+    assert np.array_equal(env._slot, again)
+
+
 def test_ycb_new_object_set_per_episode_emul(emul_lib):
     env, ended, started, tables = _per_episode_checks(emul_lib, "cpu", B=2, steps=10, seed=8, n_substeps=1, stabilize_steps=1, n_random_initial_steps=0, settle_steps=0)
     assert ended == 2 and started == 2                   # the goal times out on step 8, the next episode starts on step 9
