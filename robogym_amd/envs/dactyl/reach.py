@@ -12,6 +12,9 @@ is moved to a sampled joint pose and stepped twice so that contacts push the fin
 fingertip positions), `RobotEnv.step` / `reset` bookkeeping (robot_env.py:757-844) with the golden-pinned tracker, and the
 observation keys of `ReachEnv._default_observation_map`.  This config is the reference's plumbing case (B = 1, 1000 steps);
 its bookkeeping runs as `[B]` tensor ops around the physics launch, not in the fused env kernel of dactyl/locked.
+(`ReachEnv._reset` writes `constants.success_pause_range_s = (0.0, 0.5)` (reach.py:208-211); the tracker was built in `RobotEnv.__init__` from the constants as
+they were then, (0, 0), and keeps its own copy (robot_env.py:405-412, multi_goal_tracker.py:63,83-93), so the write never reaches it: one successful step is a
+success here as there.)
 """
 import os
 
