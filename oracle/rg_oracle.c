@@ -1665,13 +1665,27 @@ static void ro_solve(const ro_model* m, ro_data* d) {
 /* ------------------------------------------------------------------------------------------ independent cross-check solver
  * engine_solver.c: mj_solPGS — projected Gauss-Seidel on the DUAL of the same convex problem (VERDICT r03 item 6 iii):
  *     minimise 1/2 f' (A + R) f + f' (J qacc_smooth - aref),  A = J M^-1 J',  subject to the rows' force bounds
- *     (equality: free; friction loss: |f| <= frictionloss; limits and pyramidal contact edges: f >= 0),
+ *     (equality: free; friction loss: |f| <= frictionloss; limits and pyramidal contact edges: f >= 0;
+ *      an elliptic contact's rows jointly: f_0 >= 0, sum_j (f_j / friction_(j-1))^2 <= f_0^2),
  * then qacc = qacc_smooth + M^-1 J' f.  It shares NOTHING with the Newton path but the constraint rows: no Hessian, no line search, no warm
- * start.  At the optimum the two coincide (strong duality), which is what tests/test_oracle.py asserts.  Elliptic cones (a per-contact cone
- * projection of a coupled block) are not covered.  Uses the rows of the last ro_forward; returns the number of sweeps, -1 for elliptic models. */
+ * start, no zone formulas -- the Newton solver's three-zone cone cost (cone_eval) is the closed form of exactly this cone-constrained problem in
+ * the metric R (with R_j friction_(j-1)^2 equal for all friction rows the cone is circular in the variables f_j sqrt(R_j), slope `mu`), so at the
+ * optimum the two coincide (strong duality), which is what tests/test_oracle.py and tests/test_rearrange_oracle.py assert.  An elliptic contact is
+ * one Gauss-Seidel block: its dim x dim subproblem is minimised over the cone by projected gradient in the variables y_0 = f_0,
+ * y_j = f_j / friction_(j-1), where the cone is the second-order cone |y_1..| <= y_0 and the Euclidean projection is closed form.
+ * Uses the rows of the last ro_forward; returns the number of sweeps. */
+static void soc_project(real* y, int dim) {
+  real t = y[0], n = 0;
+  for (int j = 1; j < dim; j++) n += y[j] * y[j];
+  n = sqrt(n);
+  if (n <= t) return;
+  if (n <= -t) { for (int j = 0; j < dim; j++) y[j] = 0; return; }
+  real beta = 0.5 * (t + n);
+  y[0] = beta;
+  for (int j = 1; j < dim; j++) y[j] *= beta / n;
+}
 int ro_solve_pgs(const ro_model* m, ro_data* d, int max_sweeps, double tol, double* qacc_out) {
   int nv = m->nv, ne = d->nefc;
-  for (int r = 0; r < ne; r++) if (d->efc_type[r] == EFC_CONTACT_ELLIPTIC) return -1;
   if (ne < 0 || ne > MAXEFC || nv <= 0) return -2;
   const size_t un = (size_t)(ne > 0 ? ne : 1);
   real* MinvJt = dalloc((size_t)nv * un);   /* column r = M^-1 J_r' */
@@ -1692,10 +1706,36 @@ int ro_solve_pgs(const ro_model* m, ro_data* d, int max_sweeps, double tol, doub
   for (; sweep < max_sweeps; sweep++) {
     real change = 0;
     for (int r = 0; r < ne; r++) {
+      int type = d->efc_type[r];
+      if (type == EFC_CONTACT_ELLIPTIC) {
+        const ro_contact* con = d->contact + d->efc_id[r];
+        int dim = con->dim;
+        real H[36], c[6], y[6], y0[6], sc[6], tr = 0;
+        sc[0] = 1; for (int j = 1; j < dim; j++) sc[j] = con->friction[j - 1];
+        for (int j = 0; j < dim; j++) {
+          real g = b[r + j];
+          for (int k = 0; k < ne; k++) if (k < r || k >= r + dim) g += A[(size_t)(r + j) * ne + k] * f[k];
+          c[j] = g * sc[j];                                                   /* linear term, in y */
+          for (int k = 0; k < dim; k++) H[j * dim + k] = (A[(size_t)(r + j) * ne + r + k] + (j == k ? d->efc_R[r + j] : 0)) * sc[j] * sc[k];
+          tr += H[j * dim + j];
+          y[j] = y0[j] = f[r + j] / sc[j];
+        }
+        for (int it = 0; it < 2000; it++) {                                   /* projected gradient, step 1 / trace(H) <= 1 / lambda_max */
+          real g[6], step = 0;
+          for (int j = 0; j < dim; j++) { g[j] = c[j]; for (int k = 0; k < dim; k++) g[j] += H[j * dim + k] * y[k]; }
+          real yn[6] = {0};
+          for (int j = 0; j < dim; j++) yn[j] = y[j] - g[j] / tr;
+          soc_project(yn, dim);
+          for (int j = 0; j < dim; j++) { step = fmax(step, fabs(yn[j] - y[j]) * tr); y[j] = yn[j]; }
+          if (step < 0.01 * tol) break;
+        }
+        for (int j = 0; j < dim; j++) { change = fmax(change, fabs(y[j] - y0[j]) * H[j * dim + j]); f[r + j] = y[j] * sc[j]; }
+        r += dim - 1;
+        continue;
+      }
       real g = b[r] + d->efc_R[r] * f[r];
       for (int c = 0; c < ne; c++) g += A[(size_t)r * ne + c] * f[c];
       real fn = f[r] - g / (A[(size_t)r * ne + r] + d->efc_R[r]);
-      int type = d->efc_type[r];
       if (type == EFC_FRICTION_DOF || type == EFC_FRICTION_TENDON) fn = clampd(fn, -d->efc_frictionloss[r], d->efc_frictionloss[r]);
       else if (type != EFC_EQUALITY && fn < 0) fn = 0;
       change = fmax(change, fabs(fn - f[r]) * (A[(size_t)r * ne + r] + d->efc_R[r]));

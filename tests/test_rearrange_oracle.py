@@ -343,6 +343,34 @@ def test_cascaded_pi_bias_feed_forward_is_what_the_reference_pins_ask_for(models
     assert np.abs(drift1[-1]).max() < 2e-4 and np.abs(dq1).max() < 1e-3, (drift1[-1], dq1)      # ... and the arm holds still with it
 
 
+def test_elliptic_dual_solver_agrees_with_newton(models):
+    """The independent cross-check of tests/test_oracle.py::test_pgs_dual_solver_agrees_with_newton for the rearrange worlds, i.e. for ELLIPTIC cones with
+    impratio 10, weld / joint equalities with negative solref, friction loss and limits: `ro_solve_pgs` minimises the DUAL problem -- forces, each elliptic
+    contact's rows confined to the friction cone f_0 >= 0, sum (f_j / friction_j)^2 <= f_0^2 by a second-order-cone projection -- and shares nothing with the
+    Newton solver but the constraint rows (no three-zone cone cost, no Hessian, no line search).  States: the gripper closing on a block and pushing it into the table
+    (main world: ~20 contacts, ~125 rows; solver world: the gripper on the table plane).  The two accelerations agree to 1e-10 in the median, 1e-6 at worst (the
+    Newton solver's own tolerance shows in one state, 6e-8)."""
+    env = _env(models, 0.1, True, stabilize=20)
+    rng = np.random.RandomState(0)
+    tcp = env.main.body_xpos(env.main.tcp_body)
+    ztop = 0.453 + 0.03324 + 0.0254
+    env.set_object_poses([[tcp[0], tcp[1], ztop]] + [[1.25 + 0.1 * i, 0.9 + 0.08 * i, ztop] for i in range(1, 5)], [[1, 0, 0, 0]] * 5)
+    env.main.sim.forward()
+    errs, contacts = [], 0
+    for k in range(22):
+        a = rng.uniform(-1, 1, 6); a[2] = -0.6; a[5] = 1.0 if k > 8 else -1.0
+        env.env_step(a)
+        if k % 3 != 0 and k < 18:
+            continue
+        for s in (env.main.sim, env.solver.sim):
+            s.forward()
+            q, sweeps = s.solve_pgs(max_sweeps=400000, tol=1e-11)
+            assert 0 < sweeps < 400000
+            errs.append(float(np.abs(q - s.qacc).max() / max(1.0, np.abs(s.qacc).max())))
+            contacts += s.ncon
+    assert np.median(errs) < 1e-10 and max(errs) < 1e-6 and contacts > 100, (errs, contacts)
+
+
 @pytest.mark.parametrize("z_action", [1, -1])
 def test_table_collision_penalty(models, z_action):
     """envs/rearrange/tests/test_rearrange_envs.py:323-399 (blocks, MOCAP_IK, max_position_change = the solver mode's default 0.1, no random initial steps): 20 steps of
