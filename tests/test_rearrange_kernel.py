@@ -98,6 +98,11 @@ def _stage_dump(models, lib, device):
     assert np.abs(dbg[8 + 2 * NV:8 + 3 * NV] - o.qfrc_actuator).max() < 1e-4 * max(1.0, np.abs(o.qfrc_actuator).max())
     assert np.abs(dbg[8 + 3 * NV:8 + 4 * NV] - o.qacc_smooth).max() < 1e-4 * np.abs(o.qacc_smooth).max()
     assert np.abs(dbg[8 + 4 * NV:8 + 5 * NV] - o.qacc).max() < 2e-3 * np.abs(o.qacc).max()
+    # ... and against the oracle's INDEPENDENT solver on the same rows (dual problem, cone projection per elliptic contact: oracle/rg_oracle.c ro_solve_pgs), which
+    # shares no code with either Newton implementation
+    q_dual, sweeps = o.solve_pgs(max_sweeps=400000, tol=1e-11)
+    assert sweeps > 0 and np.abs(q_dual - o.qacc).max() < 1e-7 * np.abs(o.qacc).max()
+    assert np.abs(dbg[8 + 4 * NV:8 + 5 * NV] - q_dual).max() < 2e-3 * np.abs(q_dual).max()
     assert np.abs(sim.qpos[0].cpu().numpy() - o.qpos).max() < 2e-6 and np.abs(sim.qvel[0].cpu().numpy() - o.qvel).max() < 2e-5
     assert np.abs(sim.pid[0].cpu().numpy() - o.pid).max() < 1e-5
 
