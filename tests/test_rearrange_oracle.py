@@ -343,6 +343,38 @@ def test_cascaded_pi_bias_feed_forward_is_what_the_reference_pins_ask_for(models
     assert np.abs(drift1[-1]).max() < 2e-4 and np.abs(dq1).max() < 1e-3, (drift1[-1], dq1)      # ... and the arm holds still with it
 
 
+def test_bias_force_at_rest_is_the_gradient_of_the_potential_energy(models):
+    """What the cascaded-PI controller feeds forward: at zero velocity `qfrc_bias` (mj_rne: gravity + Coriolis) is the gradient of the potential energy
+    V(q) = - sum_b m_b g . xipos_b with respect to the joint angles -- checked by central differences over forward kinematics alone, for the six arm joints and the
+    gripper's, in five random arm poses (1e-6 of the largest gravity torque, ~70 N m at the shoulder)."""
+    env = _env(models, 0.1, True, stabilize=0)
+    m, s = env.main, env.main.sim
+    A = m.model.arrays
+    mass, g = A["body_mass"], np.asarray(A["opt_gravity"], dtype=float).reshape(3)
+    rng = np.random.RandomState(2)
+    qadr = list(m.arm_q) + [m.grip_q]
+    dofs = [int(A["jnt_dofadr"][list(A["jnt_qposadr"]).index(q)]) for q in qadr]
+
+    def potential():
+        s.forward()
+        return -float((mass[:, None] * s.field("xipos").reshape(-1, 3) @ g).sum())
+
+    for _ in range(5):
+        s.qvel[:] = 0
+        s.qpos[m.arm_q] = RO.TABLETOP_EXPERIMENT_INITIAL_POS + rng.uniform(-0.4, 0.4, 6)
+        s.forward()
+        bias = s.qfrc_bias.copy()
+        grad = []
+        for q in qadr:
+            q0, eps = s.qpos[q], 1e-5
+            s.qpos[q] = q0 + eps; vp = potential()
+            s.qpos[q] = q0 - eps; vm = potential()
+            s.qpos[q] = q0
+            grad.append((vp - vm) / (2 * eps))
+        s.forward()
+        assert np.abs(bias[dofs]).max() > 20 and np.abs(bias[dofs] - grad).max() < 1e-6 * np.abs(bias[dofs]).max() + 1e-7, (bias[dofs], grad)
+
+
 def test_elliptic_dual_solver_agrees_with_newton(models):
     """The independent cross-check of tests/test_oracle.py::test_pgs_dual_solver_agrees_with_newton for the rearrange worlds, i.e. for ELLIPTIC cones with
     impratio 10, weld / joint equalities with negative solref, friction loss and limits: `ro_solve_pgs` minimises the DUAL problem -- forces, each elliptic
