@@ -44,6 +44,23 @@ def _oracle_env(models, n_substeps, settle, seed=0):
     return env
 
 
+def test_elliptic_dual_solver_agrees_with_newton_on_mesh_contacts(models, oracle_lib):
+    """tests/test_rearrange_oracle.py::test_elliptic_dual_solver_agrees_with_newton on the ycb world: eight mesh objects settling on the table (convex parts against the
+    table box through MPR, ~19 contacts, ~115 rows, elliptic cones): the oracle's independent dual solver and its Newton solver give the same accelerations."""
+    env = _oracle_env(models, 1, settle=40)
+    s = env.main.sim
+    errs, contacts = [], 0
+    for _ in range(3):
+        for _ in range(40):
+            env.main.step()
+        s.forward()
+        q, sweeps = s.solve_pgs(max_sweeps=400000, tol=1e-11)
+        assert 0 < sweeps < 400000
+        errs.append(float(np.abs(q - s.qacc).max() / max(1.0, np.abs(s.qacc).max())))
+        contacts += s.ncon
+    assert max(errs) < 1e-7 and contacts >= 30, (errs, contacts)
+
+
 def test_model_and_object_set(models):
     main, _ = models
     A = main.arrays
