@@ -727,7 +727,12 @@ def compile_mjcf(root, meshdir: Optional[str] = None, verbose: bool = False) -> 
     for asec in root.findall("actuator"):
         for ae in asec:
             at = defaults.resolve(ae, None)
-            if ae.tag != "general":
+            if ae.tag == "motor":        # MJCF shortcuts (MuJoCo XML reference, actuator/motor and actuator/position): a <general> with these settings
+                at = dict(at, gaintype="fixed", biastype="none", gainprm="1")
+            elif ae.tag == "position":
+                kp = float(_floats(at.get("kp"), 1, [1])[0])
+                at = dict(at, gaintype="fixed", biastype="affine", gainprm=repr(kp), biasprm="0 %r 0" % (-kp))
+            elif ae.tag != "general":
                 raise NotImplementedError("actuator shortcut <%s>" % ae.tag)
             U["name"].append(at.get("name", ""))
             if at.get("joint") is not None:

@@ -66,6 +66,33 @@ def test_fingertip_observation_matches_reference_fk(locked_model):
     assert worst < 1e-6, worst
 
 
+def test_pendulum_forward_kinematics_matches_reference_fk(oracle_lib):
+    """A second model through MJCF compiler -> oracle kinematics, against the reference's own numpy forward kinematics on its double-pendulum test model
+    (tests/golden/pendulum_fk.npz from tools/gen_golden_pendulum_fk.py; the reference pins that FK to MuJoCo's site_xpos at 1e-6 on this very model,
+    mujoco/test/test_mujoco_utils.py:148-179): site positions and the hinge2 joint anchor for 64 joint configurations, 1e-9.  (The XML's `integrator="RK4"` is
+    taken out before compiling -- this stepper is Euler only, as every robogym world is -- which kinematics do not see.)"""
+    from oracle.rg_oracle import OracleSim
+    from robogym_amd.mujoco.model_blob import pack_model
+    from robogym_amd.mujoco.mujoco_xml import MujocoXML
+
+    x = MujocoXML.parse("test/inverted_pendulum/inverted_double_pendulum.xml").add_name_prefix("ivp:").add_default_compiler_directive()
+    for opt in x.root_element.iter("option"):
+        opt.attrib.pop("integrator", None)
+    m = x.build()
+    assert m.names["joint"] == ["ivp:hinge", "ivp:hinge2"] and int(m.arrays["dims"][0]) == 2
+    s = OracleSim(pack_model(m))
+    g = np.load(os.path.join(G, "pendulum_fk.npz"))
+    sites = [m.names["site"].index(n) for n in g["site_names"]]
+    j2 = m.names["joint"].index("ivp:hinge2")
+    worst = 0.0
+    for q, pos in zip(g["joint_angles"], g["positions"]):
+        s.qpos[:] = q
+        s.fwd_position()
+        sx = s.field("site_xpos").reshape(-1, 3)
+        worst = max(worst, np.abs(sx[sites] - pos[:2]).max(), np.abs(s.field("xanchor").reshape(-1, 3)[j2] - pos[-1]).max())
+    assert worst < 1e-9, worst
+
+
 def test_cube_mass_and_model_dims(locked_model):
     m = locked_model
     assert tuple(int(x) for x in m.dims[:3]) == (38, 36, 20)            # test_locked.py joint list: nq 38, nv 36, nu 20
