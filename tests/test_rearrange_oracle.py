@@ -42,6 +42,13 @@ def _env(models, mpc=0.1, rce=True, stabilize=100):
 
 
 # ------------------------------------------------------------------------------------------------ model
+def test_arm_actuation_range_table(models):
+    """robot/test/test_robot_interface.py:25-48, the reference's own numbers: the arm's actuation range (half the control range of its six actuators; what a JOINT
+    arm reports for absolute actions and, without max_position_change, for relative ones) is 6.1959, 6.1959, 2.8, 6.1959, 6.1959, 2.312561."""
+    cr = models[0].arrays["actuator_ctrlrange"][:6]
+    assert np.allclose(0.5 * (cr[:, 1] - cr[:, 0]), [6.1959, 6.1959, 2.8, 6.1959, 6.1959, 2.312561], atol=1e-6)
+
+
 def test_model_sizes_match_the_reference(models):
     """test_rearrange_sim.py:10-55 and SURVEY §8's dimension table (43 / 38 / 7 / 37 / 55 / 3; solver 8 / 8 / 1 / 27 / 45 / 3)."""
     main, solver = models
