@@ -64,6 +64,15 @@ class KernelVariant:
         return self.name
 
 
+def pytest_collection_modifyitems(config, items):
+    """Order of the run: the dactyl workloads, then the rearrange family, then tests/test_zz_* (GPU tests that have not had a GPU run yet).  The driver runs the
+    suites with `-x`: a failure in a newer workload must not hide the tests of the headline path.  (Stable sort: the order inside each group is unchanged.)"""
+    def rank(item):
+        name = item.fspath.basename
+        return 2 if name.startswith("test_zz") else (1 if "rearrange" in name else 0)
+    items.sort(key=rank)
+
+
 def pytest_generate_tests(metafunc):
     """Every `-m gpu` parity test that uses `kernel_variant` runs TWICE: `plane` (portal-plane depth on both sides) and
     `default` (the product default = the benchmarked kernel, flags 0, against the oracle's default = the MuJoCo restatement:

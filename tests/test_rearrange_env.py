@@ -266,12 +266,6 @@ def _impulse_response_on_the_kernel(lib, device, stabilize_steps, cases=((True, 
     return out
 
 
-@pytest.mark.gpu
-def test_mocap_ik_impulse_response_on_the_kernel_gpu():
-    """(written after round 4's last GPU call; the same function was run once on the emulation harness with a shortened stabilisation: profiles/r04_emul_gpu_protocols.txt)"""
-    _impulse_response_on_the_kernel(None, "cuda:0", stabilize_steps=100)
-
-
 # ------------------------------------------------------------------------------------------------ the goal layer against the reference's own code
 def _goal_golden():
     import os
