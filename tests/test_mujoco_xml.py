@@ -5,31 +5,14 @@ import numpy as np
 
 from robogym_amd.mujoco.mujoco_xml import MujocoXML
 
-XML_BALL = """
-<mujoco>
-  <worldbody>
-    <body name="ball">
-      <freejoint name="ball_joint"/>
-      <geom  name="sphere"    pos="0.00 0.00 0.00"  type="sphere" size="0.1 0.1 0.1"/>
-    </body>
-  </worldbody>
-</mujoco>
-"""
+def _doc(*bodies):
+    return "<mujoco><worldbody>%s</worldbody></mujoco>" % "".join(bodies)
 
-XML_ARM = """
-<mujoco>
-  <worldbody>
-    <body name="arm">
-      <joint type="hinge" name="hinge_joint" axis="0 0 1"/>
-      <geom  name="sphere"    pos="0.00 0.00 0.00"  type="sphere" size="0.1 0.1 0.1"/>
-      <body name="forearm" pos="1 0 0">
-        <joint type="slide" axis="1 0 0" name="slide_joint"/>
-        <geom  name="box"   pos="0.00 0.00 0.00"  type="box" size="0.1 0.1 0.1"/>
-      </body>
-    </body>
-  </worldbody>
-</mujoco>
-"""
+
+# the reference tests' two little worlds: a free ball; a hinge arm with a sliding forearm one unit along x
+XML_BALL = _doc('<body name="ball"><freejoint name="ball_joint"/><geom name="sphere" type="sphere" size="0.1 0.1 0.1" pos="0.00 0.00 0.00"/></body>')
+XML_ARM = _doc('<body name="arm"><joint name="hinge_joint" type="hinge" axis="0 0 1"/><geom name="sphere" type="sphere" size="0.1 0.1 0.1" pos="0.00 0.00 0.00"/>'
+               '<body name="forearm" pos="1 0 0"><joint name="slide_joint" type="slide" axis="1 0 0"/><geom name="box" type="box" size="0.1 0.1 0.1" pos="0.00 0.00 0.00"/></body></body>')
 
 
 def _group(model, prefix):
@@ -79,15 +62,7 @@ def test_set_attributes_mixed_precision():
 def test_remove_elem():
     """:182-197: removal by tag, and the serialised document"""
     ball = MujocoXML.from_string(XML_BALL).remove_objects_by_tag("freejoint")
-    ref = """
-<mujoco>
-  <worldbody>
-    <body name="ball">
-      <geom name="sphere" pos="0.00 0.00 0.00" size="0.1 0.1 0.1" type="sphere" />
-    </body>
-  </worldbody>
-</mujoco>
-"""
+    ref = _doc('<body name="ball"><geom name="sphere" pos="0.00 0.00 0.00" size="0.1 0.1 0.1" type="sphere"/></body>')
     import xml.etree.ElementTree as et
 
     # (the reference compares strings, which holds on the Python it pins -- ElementTree sorted attributes alphabetically up to 3.7; the canonical forms are compared here)
