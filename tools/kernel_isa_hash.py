@@ -2,7 +2,8 @@
 kernel symbol out of its .text): tells whether an edit of one kernel's source changed another kernel's code.
 
     python tools/kernel_isa_hash.py [robogym_amd/csrc/librgstep.so] [substring of the kernel names to print]
-    python tools/kernel_isa_hash.py --compare before.so after.so [substring]"""
+    python tools/kernel_isa_hash.py --compare before.so after.so [substring]
+    python tools/kernel_isa_hash.py --mix [substring]        static instruction mix per function (spill loads / stores, LDS, memory, waits)"""
 import hashlib
 import os
 import struct
@@ -81,7 +82,35 @@ def compare(a_path, b_path, sub=""):
     return rows
 
 
+def static_mix(so_path, sub=""):
+    """Per function: instruction counts by class from the disassembly (static, not executed counts): VALU, SALU, LDS (ds_*), global / buffer memory, scratch
+    (spill) loads and stores, waits, branches, calls (s_swappc)."""
+    names = [n for n in sorted(kernel_hashes(so_path)) if sub in n]
+    rows = []
+    for n, lines in disassembly(so_path, names).items():
+        c = dict(valu=0, salu=0, lds=0, vmem=0, scratch_ld=0, scratch_st=0, wait=0, branch=0, call=0)
+        for l in lines:
+            op = l.split()[0] if l.split() else ""
+            if op.startswith("scratch_load"): c["scratch_ld"] += 1
+            elif op.startswith("scratch_store"): c["scratch_st"] += 1
+            elif op.startswith("ds_"): c["lds"] += 1
+            elif op.startswith(("global_", "buffer_", "flat_")): c["vmem"] += 1
+            elif op.startswith("s_waitcnt"): c["wait"] += 1
+            elif op.startswith("s_swappc"): c["call"] += 1
+            elif op.startswith(("s_cbranch", "s_branch")): c["branch"] += 1
+            elif op.startswith("v_"): c["valu"] += 1
+            elif op.startswith("s_"): c["salu"] += 1
+        rows.append((n, len(lines), c))
+    return rows
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--mix":
+        so = os.path.join(ROOT, "robogym_amd", "csrc", "librgstep.so")
+        print("%-58s %7s %6s %6s %5s %5s %6s %6s %5s %6s %4s" % ("function", "instr", "valu", "salu", "lds", "vmem", "spl_ld", "spl_st", "wait", "branch", "call"))
+        for n, total, c in static_mix(so, sys.argv[2] if len(sys.argv) > 2 else ""):
+            print("%-58s %7d %6d %6d %5d %5d %6d %6d %5d %6d %4d" % (n[:58], total, c["valu"], c["salu"], c["lds"], c["vmem"], c["scratch_ld"], c["scratch_st"], c["wait"], c["branch"], c["call"]))
+        sys.exit(0)
     if len(sys.argv) > 3 and sys.argv[1] == "--compare":
         for n, verdict in compare(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else ""):
             print("%-60s %s" % (verdict, n))
