@@ -248,6 +248,58 @@ def bench_rearrange_blocks(args, emit=True, ycb=False):
     return out
 
 
+def bench_rearrange_steady(args, ycb=False, knock_per_step=4, warm_steps=215):
+    """The rearrange envs WITH episode ends, as driver evidence: `pipelined_reset=True`, the reference's full reset recipe (100 stabilisation
+    steps, 10 of one random action, 100 of the zero action) running inside the step calls.  Random actions almost never reach a goal, so episodes of this workload
+    end by the goal time-out (200 steps per object) or by an object leaving the table; to see the steady-state MIX inside a short run, `knock_per_step` live envs per
+    step have one object put off the table (their episode ends on that step: done, penalty, recipe starts) during `warm_steps` >= one recipe length, so that at the
+    timed window ~ knock_per_step x 210 / B of the envs are spread over all stages of the recipe -- the share a 1000-step time-out gives (210 / 1210 = 17 %)."""
+    from robogym_amd.envs.rearrange.blocks import BatchedBlockRearrangeEnv
+    from robogym_amd.envs.rearrange.ycb import BatchedYcbRearrangeEnv
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    B = args.batch if args.batch != 8192 else 4096
+    env = (BatchedYcbRearrangeEnv if ycb else BatchedBlockRearrangeEnv)(B, device=dev, starting_seed=20200901 + 5, pipelined_reset=True)
+    # (the FIRST reset is shortened -- it only places the objects; every recipe that runs inside the steps is the full one)
+    full = (env.stabilize_steps, env.n_random_initial_steps, env.settle_steps)
+    env.stabilize_steps, env.n_random_initial_steps, env.settle_steps = 20, 2, 20
+    env.reset()
+    env.stabilize_steps, env.n_random_initial_steps, env.settle_steps = full
+    gen = torch.Generator(device=dev); gen.manual_seed(20200901 + 5)
+    rng = np.random.RandomState(20200901 + 5)
+    ended = started = 0
+    inside = 0.0
+
+    def step(knock):
+        nonlocal ended, started, inside
+        if knock:
+            live = np.nonzero(env._stage == 0)[0]
+            rows = torch.as_tensor(rng.choice(live, size=min(knock, len(live)), replace=False), device=dev, dtype=torch.long)
+            env.sim.qpos[rows, env.obj_q[0]] = 3.0          # object 0 far off the table: check_objects_off_table ends the episode on this step
+        obs, reward, done, info = env.step(torch.rand((B, 6), generator=gen, device=dev) * 2 - 1)
+        return done, info
+
+    for _ in range(warm_steps):
+        step(knock_per_step)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        done, info = step(knock_per_step)
+        ended += int(done.sum()); started += int(info["episode_started"].sum()); inside += float(info["resetting"].float().mean())
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    out = {"metric": "env-steps/sec rearrange/%s batch %d WITH episode ends: pipelined in-step resets (the reference's full reset recipe inside the step calls), recipe steps counted as env-steps" % ("ycb num_objects=8" if ycb else "blocks num_objects=5", B),
+           "value": B * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": warm_steps, "ms_per_step": 1e3 * elapsed / args.steps, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "as the rearrange line above; episode ends forced at %d live envs per step (one object put off the table) through %d warm-up steps and the timed window" % (knock_per_step, warm_steps),
+                      "fraction_of_env_steps_inside_the_reset_recipe": inside / max(args.steps, 1), "episodes_ended_in_window": ended, "episodes_started_in_window": started,
+                      "status_bits": int(max(env.sim.status.max().item(), env.solver_sim.status.max().item()))},
+           "roofline": None, "cpu_baseline": None, "note": "same kernels and byte model as the rearrange line; envs that stabilise their objects skip the solver world's launch"}
+    del env
+    torch.cuda.empty_cache()
+    return out
+
+
 def bench_full_perpendicular(args, emit=True):
     """BASELINE.json configs[2]: dactyl/full_perpendicular (Shadow hand + full Rubik's cube, nv 168, condim-6 contacts), batch 4096
     on one MI355X: `BatchedFullPerpendicularEnv.step` = the large-model stepper (rb_step_kernel: action map, 10 mj_step, 3 PID ticks)
@@ -363,6 +415,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8192, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-long-window", action="store_true", help="skip the >= 2 s continuation of the headline rollout (config.long_window)")
+    ap.add_argument("--long-steps", type=int, default=300)
     ap.add_argument("--pipelined-reset", action="store_true", help="finished episodes run the reset recipe inside the step launches")
     ap.add_argument("--launch-flags", type=int, default=0, help="diagnostic: extra rg_step_args.flags of the step launches (4: no per-pair collision cache)")
     ap.add_argument("--sort-dispatch", type=int, default=1, help="dispatch the envs longest-expected-first (previous step's cycles)")
@@ -473,6 +527,24 @@ def main():
     nsub_total = max(stats[3], 1.0)
     ncon, nefc, iters = float(stats[0] / nsub_total), float(stats[1] / nsub_total), float(stats[2] / nsub_total)
     status = int(sim.status.max().item())
+    # the same rollout carried on over a window of >= 2 s (the driver's --steps 20 is 0.12 s of GPU time): reported next to the contract's K-step value, not as it
+    long_window = None
+    if not emul_path and not args.no_long_window and not args.no_secondary:      # (profiling runs pass --no-secondary: their kernel statistics then hold the K timed launches only)
+        sync()
+        tl = time.perf_counter()
+        for _ in range(args.long_steps):
+            one_step()
+        gather.finish()
+        if distributed:
+            dist.barrier()
+        sync()
+        tl = time.perf_counter() - tl
+        if distributed:
+            t = torch.tensor([tl], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tl = float(t.item())
+        long_window = {"steps": args.long_steps, "seconds": tl, "value": world * B * args.long_steps / tl, "cube_on_palm_fraction_at_end": on_palm_fraction(),
+                       "note": "the next %d steps of the same rollout; iid random actions throw the cubes off over time, so the workload gets cheaper (on-palm fraction)" % args.long_steps}
 
     if rank == 0:
         from robogym_amd.mujoco import simulation_interface as _si
@@ -502,7 +574,7 @@ def main():
                        "ranks": (dist.get_world_size() if distributed else 1), "collective_backend": (dist.get_backend() if distributed else None),
                        "mean_ncon": float(ncon), "mean_nefc": float(nefc), "mean_newton_iters": float(iters), "status_bits": status, "status_bits_before_timed_region": status_before,
                        "cube_on_palm_fraction": {"start_of_timed_region": on_palm_start, "end_of_timed_region": on_palm_end},
-                       "pipelined_reset": bool(args.pipelined_reset), "sort_dispatch": bool(args.sort_dispatch), "substep_items": bool(_si.SUBSTEP_ITEMS),
+                       "long_window": long_window, "pipelined_reset": bool(args.pipelined_reset), "sort_dispatch": bool(args.sort_dispatch), "substep_items": bool(_si.SUBSTEP_ITEMS),
                        "gathered_row": "obs 166 + reward 3 + done 1 = %d floats per env" % env.packed_dim},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_unit": "GB per launch (PMC)", "algorithmic_gb_per_launch": b_step * B / 1e9,
                          "kernel": kernel_name, "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": b_step, "algorithmic_bytes_per_substep": b_sub,
@@ -516,11 +588,15 @@ def main():
             torch.cuda.empty_cache()
             import copy
             sec = []
-            for fn, kw in ((bench_locked_variant, dict(pipelined_reset=True)), (bench_locked_variant, dict(default_make_env=True)), (bench_full_perpendicular, {}), (bench_rearrange_blocks, {}), (bench_rearrange_blocks, dict(ycb=True))):
-                a2 = copy.copy(args); a2.steps, a2.warmup, a2.batch = (20, 40, 8192) if fn is bench_locked_variant else (4, 2, 4096)
+            # windows of >= 2 s each whatever the driver's --steps: 300 steps of ~6 ms, 20 of ~115 ms, 30 of 64-90 ms
+            plan = ((bench_locked_variant, dict(pipelined_reset=True), (300, 40, 8192)), (bench_locked_variant, dict(default_make_env=True), (300, 40, 8192)),
+                    (bench_full_perpendicular, {}, (20, 2, 4096)), (bench_rearrange_blocks, {}, (30, 3, 4096)), (bench_rearrange_steady, {}, (30, 0, 4096)),
+                    (bench_rearrange_blocks, dict(ycb=True), (30, 3, 4096)), (bench_rearrange_steady, dict(ycb=True), (30, 0, 4096)))
+            for fn, kw, (st_, wu_, b_) in plan:
+                a2 = copy.copy(args); a2.steps, a2.warmup, a2.batch = st_, wu_, b_
                 a2.pipelined_reset = False
                 try:
-                    sec.append(fn(a2, emit=False, **kw))
+                    sec.append(fn(a2, **kw) if fn is bench_rearrange_steady else fn(a2, emit=False, **kw))
                 except Exception as ex:   # a secondary run must not cost the headline
                     sec.append({"metric": getattr(fn, "__name__", "?"), "error": repr(ex)})
             out["secondary"] = sec

@@ -146,11 +146,16 @@ class OracleArmSim:
         self.grip_act = model.names["actuator"].index("robot0:r_gripper_finger_joint")
         self.tcp_body = model.name2id("body", "robot0:gripper_tcp")
         self.nv = int(model.dims[1])
+        self.ncon_sum = self.nefc_sum = 0
 
     # mujoco-py MjSim.step / SimulationInterface.step
     def mj_sim_step(self):
         for _ in range(self.n_substeps):
             self.sim.step()
+            # contact / row counts of every mj_step, summed as the kernel's statistics row sums them (equality records count as contacts there): two runs
+            # whose sums agree over an env.step held the same number of contacts and rows in every one of its mj_steps (tests: classification of the errors)
+            self.ncon_sum += self.sim.ncon + self.sim.neq
+            self.nefc_sum += self.sim.nefc
 
     def step(self):
         self.mj_sim_step()

@@ -125,6 +125,9 @@ __global__ void __launch_bounds__(64) ra_post_step_kernel(const RbModelDev* mp, 
   if (lane == 0 && frozen == 3) {                  // 3: observation entries only (a live env whose goal was just replaced): reward / done / flags / counters untouched
     const int g0 = 15 * N + 15 + 2 * nq;
     row[g0 + 6 * N] = (float)(!crash && nsucc == N);
+    // reset_goal -> _observe_sync -> update_goal_info (robot_env.py:893-909, 586-593): the re-observation under the new goal is what the next step's
+    // goal-distance reward is measured from
+    a.prev_nsucc[e] = (float)nsucc * a.goal_reward_per_object; a.prev_valid[e] = 1;
     float* o = row + g0 + 21 * N + 1;
     o[0] = (float)safety;
     for (int k = 0; k < 3; k++) { o[1 + k] = sens[a.force_adr + k]; o[4 + k] = sens[a.torque_adr + k]; }
@@ -134,6 +137,10 @@ __global__ void __launch_bounds__(64) ra_post_step_kernel(const RbModelDev* mp, 
     rw[0] = rw[1] = rw[2] = 0.f;
     a.goal_dist[2 * e] = sp; a.goal_dist[2 * e + 1] = sr;
     a.done[e] = 0; a.goal_reset[e] = 0; a.trial_success[e] = 0; a.sub_goal_ok[e] = 0; a.env_crash[e] = crash; a.objects_off_table[e] = any_off;
+    a.info_ssl[e] = a.steps_since_last_goal[e];
+    // RobotEnv.reset -> reset_goal_generation -> _observe_sync -> update_goal_info (robot_env.py:757-792, 586-593): the observation that ends a reset
+    // establishes the success count the first step's goal-distance reward is measured from
+    a.prev_nsucc[e] = (float)nsucc * a.goal_reward_per_object; a.prev_valid[e] = 1;
     const int g0 = 15 * N + 15 + 2 * nq;
     row[g0 + 6 * N] = 0.f;
     float* o = row + g0 + 21 * N + 1;

@@ -895,7 +895,9 @@ __device__ __forceinline__ void rb_pid(RbM m, RbLds& s, float* S, bool apply) {
       const int id = m.actuator_trnid[u];
       const bool joint = m.actuator_trntype[u] == 0;
       const float vel = m.actuator_gear[u] * (joint ? s.qvel[m.jnt_dofadr[id]] : SC(TENVEL)[id]);   // mj_transmission: moment . qvel
-      const float ff = joint ? s.qfrc_bias[m.jnt_dofadr[id]] / m.actuator_gear[u] : 0.f;
+      // (a state-less tick, apply == false, keeps only the controller state, which the feed-forward never enters: it is not read there — the TCP
+      // hook's sync tick runs before any stage of the launch has written qfrc_bias)
+      const float ff = (apply && joint) ? s.qfrc_bias[m.jnt_dofadr[id]] / m.actuator_gear[u] : 0.f;
       s.actfrc[u] = rb_cascade_tick(m, u, s.ctrl[u], s.actlen[u], vel, ff, s.time == 0.f, s.pid + 3 * u);
     } else s.actfrc[u] = rb_pid_tick(m, u, s.ctrl[u], s.actlen[u], s.pid + 3 * u);
   }

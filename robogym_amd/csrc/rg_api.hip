@@ -1048,7 +1048,7 @@ int rb_model_info(const rb_model* m, int* out, int n) {
   if (!m) return fail("null model");
   const RbModelDev& d = m->dev;
   const int v[] = {d.nq, d.nv, d.nu, d.nbody, d.njnt, d.ngeom, d.nsite, d.ntendon, d.nM, d.npair, d.ngroup, d.gmax, d.maxcon, d.maxrow, d.scratch_words, RB_CONREC, RB_ROWREC, RB_CONW, RB_TENW,
-                   m->config == 1 ? (int)sizeof(rgbs::RbLds) : m->config == 2 ? (int)sizeof(rgbm::RbLds) : (int)sizeof(rgb::RbLds), m->config ? RB_T_SMALL : RB_T_LARGE};
+                   m->config == 1 ? (int)sizeof(rgbs::RbLds) : m->config == 2 ? (int)sizeof(rgbm::RbLds) : (int)sizeof(rgb::RbLds), m->config == 1 ? RB_T_SMALL : m->config == 2 ? RB_T_MEDIUM : RB_T_LARGE};
   const int k = (int)(sizeof v / sizeof v[0]);
   for (int i = 0; i < k && i < n; i++) out[i] = v[i];
   return k;
@@ -1161,6 +1161,7 @@ int rb_batch_step_tcp(rb_batch* solver, rb_batch* main_batch, const float* actio
   if (solver->dev.B != main_batch->dev.B || solver->device != main_batch->device) return fail("rb_batch_step_tcp: the two batches must have the same size and device");
   const RbModelDev& ds = solver->model->dev; const RbModelDev& dm = main_batch->model->dev;
   if (ds.nmocap != 1) return fail("rb_batch_step_tcp: the solver model needs exactly one mocap body");
+  if (dm.nu < 6) return fail("rb_batch_step_tcp: the main model's first six actuators must be the arm's (JointControlledArm.set_position_control writes ctrl[:6])");
   for (int k = 0; k < 6; k++) if (a->arm_qposadr[k] < 0 || a->arm_qposadr[k] >= ds.nq || a->main_arm_qposadr[k] < 0 || a->main_arm_qposadr[k] >= dm.nq) return fail("rb_batch_step_tcp: joint address out of range");
   if (a->main_gripper_actuator < 0 || a->main_gripper_actuator >= dm.nu || a->tcp_body <= 0 || a->tcp_body >= ds.nbody || a->wrist_joint < 0 || a->wrist_joint >= ds.njnt) return fail("rb_batch_step_tcp: id out of range");
   RbTcpHook h; memset(&h, 0, sizeof h);
@@ -1259,6 +1260,9 @@ int ra_env_post_step(rb_batch* b, rb_batch* solver, const ra_post_args* args, vo
   if (a.tcp_body <= 0 || a.tcp_body >= d.nbody || a.grip_act < 0 || a.grip_act >= d.nu || a.grip_qposadr < 0 || a.grip_qposadr >= d.nq || a.grip_dofadr < 0 || a.grip_dofadr >= d.nv)
     return fail("ra_env_post_step: robot id out of range");
   for (int k = 0; k < 6; k++) if (a.arm_qposadr[k] < 0 || a.arm_qposadr[k] >= d.nq) return fail("ra_env_post_step: arm joint address out of range");
+  for (int k = 0; k < 2; k++) if (a.finger_geom[k] < 0 || a.finger_geom[k] >= d.ngeom) return fail("ra_env_post_step: finger pad geom id out of range");
+  if (a.table_plane_geom < 0 || a.table_plane_geom >= d.ngeom) return fail("ra_env_post_step: table plane geom id out of range");
+  if (d.ngeom < 64 && (a.gripper_geom_mask >> d.ngeom) != 0) return fail("ra_env_post_step: gripper_geom_mask names a geom the model does not have (bit g = geom g, g < 64)");
   if (solver) {
     if (solver->dev.B != b->dev.B || solver->device != b->device) return fail("ra_env_post_step: the two batches must have the same size and device");
     const RbModelDev& ds = solver->model->dev;

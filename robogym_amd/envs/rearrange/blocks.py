@@ -129,7 +129,8 @@ class BatchedBlockRearrangeEnv:
             bid = main.name2id("body", bname)
             for g in range(len(gn)):
                 if A["geom_bodyid"][g] == bid:
-                    assert g < 64, "gripper geoms beyond id 63"
+                    if g >= 64:      # (the env kernel's gripper - table scan keeps the gripper's geoms in one 64-bit mask)
+                        raise ValueError("gripper geom %r has id %d: the env kernel needs the gripper's geoms below id 64" % (gn[g], g))
                     mask |= 1 << g
         a.gripper_geom_mask = mask
         lo, hi = self.table_pos - self.table_size, self.table_pos + self.table_size
@@ -373,7 +374,9 @@ class BatchedBlockRearrangeEnv:
         self.ema_value[idx] = 0; self.action_ema[idx] = 0          # SmoothActionWrapper.reset: a fresh filter, action_ema = 0
         self._write_goal(rows, self._grid_placement(yaw, rows), yaw)
         self.sim.env_step(nsubsteps=0, nforward_ticks=1, flags=FLAG_FULL_FORWARD, active=active)       # the forward of _observe_sync
-        self._observe_only()
+        # the first observation of the new episodes: the env kernel for exactly those rows (observation + gripper hand-over, zeroed reward / done, the success count
+        # the first step's goal reward is measured from); the rows of everybody else -- and the reward / done / info tensors their last step() returned -- stay
+        self._reobserve(rows, np.zeros(0, dtype=np.int64))
         return self.observe()
 
     # ------------------------------------------------------------------ pipelined resets
@@ -458,12 +461,10 @@ class BatchedBlockRearrangeEnv:
         self.solver_sim.qpos[idx, self.solver_grip_q] = self.sim.qpos[idx, self.grip_q]
         self.solver_sim.ctrl[idx, self.solver_grip_act] = self.sim.ctrl[idx, self.grip_act]
 
-    def _observe_only(self):
-        """The observation row without a step: the post kernel on saved tracker state (its counters are restored)."""
-        saved = [x.clone() for x in (self.t, self.steps, self.ssl, self.successes, self.consecutive, self.prev_nsucc, self.prev_valid)]
-        self._post()
-        for dst, src in zip((self.t, self.steps, self.ssl, self.successes, self.consecutive, self.prev_nsucc, self.prev_valid), saved):
-            dst.copy_(src)
+    def _observe_only(self, rows=None):
+        """The observation rows of `rows` (default: everybody) from the state as it is, without a step: observation entries, gripper hand-over, zeroed
+        reward / done, and -- as `_observe_sync` does through `update_goal_info` -- the success count the next step's goal reward is measured from."""
+        self._reobserve(np.arange(self.B) if rows is None else np.asarray(rows), np.zeros(0, dtype=np.int64))
 
     def reset_goals(self):
         """`reset_goal` for the envs the tracker flagged (robot_env.py:893-909): a new ObjectStateGoal placement; host sampling."""

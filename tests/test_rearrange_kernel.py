@@ -126,21 +126,32 @@ def _obb_prune_is_exact(models, lib, device):
         assert a[0] == b[0] and a[0] >= 1 and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
 
 
-def _resync_env_steps(models, lib, device, n_substeps, nsteps, seed=1):
+def contact_history(sim, oarm, before, row=0):
+    """Did kernel and oracle hold the same NUMBER of contacts and of constraint rows in every mj_step since `before` (= `sim.stats[0]` then, with the oracle's
+    `ncon_sum / nefc_sum` zeroed at the same moment)?  The kernel's statistics row and OracleArmSim sum both counts per mj_step; equal sums over an env.step are
+    (up to cancelling differences) equal counts in each of its mj_steps: the classification VERDICT r04 weak 1 asks the rearrange parity bounds to be split by."""
+    d = sim.stats[row].cpu().numpy().astype(np.float64) - before
+    return int(round(d[0])) == int(oarm.ncon_sum) and int(round(d[1])) == int(oarm.nefc_sum)
+
+
+def _resync_env_steps(models, lib, device, n_substeps, nsteps, seed=1, classify=False):
     """Re-synchronised env.steps of the dual simulation: `rb_batch_step_tcp` (sync, forward, mocap target, solver mj_steps, main ctrl) then the
-    main world's mj_steps + two state-less forwards, the last in full (sensors) — against OracleRearrangeEnv.env_step."""
+    main world's mj_steps + two state-less forwards, the last in full (sensors) — against OracleRearrangeEnv.env_step.  `classify`: also returns, per step,
+    whether both worlds went through the same contact / row counts on the two sides (`contact_history`)."""
     env = _oracle_env(models, n_substeps, settle=10, seed=seed)
     om, oc = env.main.sim, env.solver.sim
     sm = LargeModelSimulation(models[0], 1, device=device, n_substeps=n_substeps, lib=lib, hand=False)
     sc = LargeModelSimulation(models[1], 1, device=device, n_substeps=n_substeps, lib=lib, hand=False)
     args = tcp_args(env)
     rng = np.random.RandomState(seed)
-    errs = []
+    errs, same = [], []
     for step in range(nsteps):
         a = rng.uniform(-1, 1, 6)
         if step % 3 == 2:
             a[2] = -1.0          # push down towards the blocks / table from time to time
         sync_from_oracle(sm, om); sync_from_oracle(sc, oc)
+        km, kc = sm.stats[0].cpu().numpy().astype(np.float64), sc.stats[0].cpu().numpy().astype(np.float64)
+        env.main.ncon_sum = env.main.nefc_sum = env.solver.ncon_sum = env.solver.nefc_sum = 0
         sc.step_tcp(sm, torch.tensor(a[None].astype(np.float32), device=sm.device), args)
         sm.env_step(nforward_ticks=2, flags=32)
         # on_observations_updated (the env kernel's last act; joint_controlled_tcp_arm.py:114-129): the solver world's gripper follows the main world's
@@ -151,7 +162,8 @@ def _resync_env_steps(models, lib, device, n_substeps, nsteps, seed=1):
         errs.append((e(sc.qpos[0], oc.qpos), e(sc.mocap[0], np.concatenate([oc.mocap_pos, oc.mocap_quat])), e(sm.ctrl[0], om.ctrl), e(sm.qpos[0], om.qpos),
                      e(sm.qvel[0], om.qvel), e(sm.pid[0], om.pid), e(sm.sensordata[0], om.sensordata) / max(1.0, np.abs(om.sensordata).max())))
         assert int(sm.status[0]) == 0 and int(sc.status[0]) == 0
-    return np.array(errs)
+        same.append(contact_history(sm, env.main, km) and contact_history(sc, env.solver, kc))
+    return (np.array(errs), np.array(same)) if classify else np.array(errs)
 
 
 RESYNC_COLUMNS = ["solver qpos", "mocap", "main ctrl", "main qpos", "main qvel", "main pid", "sensordata (rel)"]
@@ -205,6 +217,37 @@ def test_oriented_box_prune_is_exact_gpu(models, oracle_lib):
 def test_rearrange_resync_env_steps_gpu(models, oracle_lib):
     """the full 40 + 40 mj_steps per env.step"""
     _assert_resync(_resync_env_steps(models, None, "cuda:0", n_substeps=40, nsteps=25))
+
+
+# an env.step whose 80 mj_steps held the same contact and row counts on both sides: fp32 rounding of one trajectory, no event -- bounds per step, no exceptions
+RESYNC_SAME_HISTORY_BOUND = {"solver qpos": 2e-5, "mocap": 2e-6, "main ctrl": 2e-5, "main qpos": 5e-5, "main qvel": 5e-3, "main pid": 5e-5, "sensordata (rel)": 5e-3}
+
+
+def _assert_resync_classified(errs, same, min_same_fraction=0.5):
+    """The errors of the re-synchronised env.steps split by `contact_history`: steps that went through the same contact / row counts on both sides are held to
+    RESYNC_SAME_HISTORY_BOUND one by one (no "one in ten" allowance); steps whose histories differ -- a contact appearing a substep apart -- to the event bound."""
+    names = RESYNC_COLUMNS
+    assert same.mean() >= min_same_fraction, same
+    for i, n in enumerate(names):
+        assert errs[same, i].max() < RESYNC_SAME_HISTORY_BOUND[n], (n, errs[same, i].max(), int(same.sum()))
+        assert errs[:, i].max() < RESYNC_EVENT_BOUND[n], (n, errs[:, i].max())
+    if (~same).any():      # and the events are where the tail is
+        assert np.median(errs[~same, 3]) >= np.median(errs[same, 3])
+
+
+def test_rearrange_resync_classified_emul(models, emul_lib, oracle_lib):
+    errs, same = _resync_env_steps(models, emul_lib, "cpu", n_substeps=3, nsteps=3, classify=True)
+    _assert_resync_classified(errs, same, min_same_fraction=0.0)
+
+
+@pytest.mark.gpu
+def test_rearrange_resync_errors_by_contact_history_gpu(models, oracle_lib):
+    """40 re-synchronised env.steps (40 + 40 mj_steps each) classified by whether kernel and oracle went through the same contact and
+    row counts; the agreeing steps carry the fp32 tolerance, the disagreeing ones the event bound."""
+    errs, same = _resync_env_steps(models, None, "cuda:0", n_substeps=40, nsteps=40, seed=7, classify=True)
+    print("rearrange/blocks, 40 re-synchronised env.steps: %d with the same contact history (main qpos max %.1e, qvel max %.1e), %d with a differing one (qpos max %.1e, qvel max %.1e)" % (
+        same.sum(), errs[same, 3].max(), errs[same, 4].max(), (~same).sum(), errs[~same, 3].max() if (~same).any() else 0, errs[~same, 4].max() if (~same).any() else 0))
+    _assert_resync_classified(errs, same)
 
 
 @pytest.mark.gpu

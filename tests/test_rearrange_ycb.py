@@ -18,7 +18,7 @@ def models():
     return load_ycb_model(N), load_solver_model()
 
 
-def _oracle_env(models, n_substeps, settle, seed=0):
+def _oracle_env(models, n_substeps, settle, seed=0, spread=False):
     from oracle import rearrange_oracle as RO
 
     main, solver = models
@@ -32,6 +32,8 @@ def _oracle_env(models, n_substeps, settle, seed=0):
         c, s = np.cos(yaw), np.sin(yaw)
         centre = np.array([c * bb[i, 0] - s * bb[i, 1], s * bb[i, 0] + c * bb[i, 1], bb[i, 2]])
         box = np.array([1.25 + 0.15 * (i % 4), 0.52 + 0.3 * (i // 4), table_top + bb[i, 5] + 0.002])     # inside the reference's placement area (simulation/base.py:992-1010)
+        if spread:      # (the other shipped sets hold objects up to 40 cm long: a wider grid over the table so that nothing starts interpenetrating)
+            box[:2] = [1.02 + 0.27 * (i % 4), 0.40 + 0.52 * (i // 4)]
         pos.append(box - centre); quat.append([np.cos(yaw / 2), 0, 0, np.sin(yaw / 2)])
     env.set_object_poses(pos, quat)
     # gripper half open: at qpos0 the two finger pads touch face to face, a degenerate box - box case whose number of clipped points (4 or 5)
@@ -91,8 +93,8 @@ def test_objects_come_to_rest_on_the_table_oracle(models, oracle_lib):
     assert np.abs(o.qvel[va:va + 6 * N]).max() < 0.5 and o.ncon >= N + 4       # (one contact per touching convex part; balls may still roll slowly)
 
 
-def _stage_dump(models, lib, device):
-    env = _oracle_env(models, 1, settle=60)
+def _stage_dump(models, lib, device, spread=False, min_contacts=12, normal_tol=1e-3):
+    env = _oracle_env(models, 1, settle=60, spread=spread)
     o = env.main.sim
     sim = LargeModelSimulation(models[0], 1, device=device, n_substeps=1, lib=lib, hand=False)
     assert sim.info["threads"] == 64 and sim.info["lds_bytes"] <= 15360            # the medium configuration: one wave per env, 10 envs per CU
@@ -103,7 +105,7 @@ def _stage_dump(models, lib, device):
     dbg = sim.scratch("dbg")[0].cpu().numpy()
     assert int(sim.status[0]) == 0
     ncon_k, nefc_k = int(dbg[0]), int(dbg[1])
-    assert ncon_k == o.ncon + o.neq and nefc_k == o.nefc and o.ncon >= 12, (ncon_k, o.ncon, nefc_k, o.nefc)
+    assert ncon_k == o.ncon + o.neq and nefc_k == o.nefc and o.ncon >= min_contacts, (ncon_k, o.ncon, nefc_k, o.nefc)
     con = sim.scratch("contact")[0].cpu().numpy().reshape(-1, 32)[:ncon_k]
     key = lambda t: (t[0], t[1], round(float(t[3][0]), 4), round(float(t[3][1]), 4))
     kc = sorted([(int(c[27]), int(c[28]), float(c[0]), c[1:4].copy(), c[4:7].copy()) for c in con[1:]], key=key)
@@ -116,7 +118,9 @@ def _stage_dump(models, lib, device):
     perr = []
     for a, b in zip(kc, oc):
         assert a[0] == b[0] and a[1] == b[1]
-        assert abs(a[2] - b[2]) < 5e-6 and np.abs(a[4] - b[4]).max() < 1e-3
+        # (the normal of an MPR contact is its last portal's: the portal may tilt by mpr_tolerance / its own size, 1e-6 m over a millimetre -- the fp64 oracle lands
+        #  on the table's face normal exactly, the fp32 kernel within that tilt)
+        assert abs(a[2] - b[2]) < 5e-6 and np.abs(a[4] - b[4]).max() < normal_tol, (a, b)
         perr.append(np.abs(a[3] - b[3]).max())
     assert np.median(perr) < 2e-5 and max(perr) < 0.03, perr
     assert np.abs(dbg[8:8 + NV] - o.qfrc_bias).max() < 1e-4 * max(1.0, np.abs(o.qfrc_bias).max())
@@ -124,17 +128,21 @@ def _stage_dump(models, lib, device):
     assert np.abs(sim.qpos[0].cpu().numpy() - o.qpos).max() < 5e-6 and np.abs(sim.qvel[0].cpu().numpy() - o.qvel).max() < 2e-3
 
 
-def _resync(models, lib, device, n_substeps, nsteps):
-    env = _oracle_env(models, n_substeps, settle=30, seed=1)
+def _resync(models, lib, device, n_substeps, nsteps, spread=False, classify=False):
+    from tests.test_rearrange_kernel import contact_history
+
+    env = _oracle_env(models, n_substeps, settle=30, seed=1, spread=spread)
     om, oc = env.main.sim, env.solver.sim
     sm = LargeModelSimulation(models[0], 1, device=device, n_substeps=n_substeps, lib=lib, hand=False)
     sc = LargeModelSimulation(models[1], 1, device=device, n_substeps=n_substeps, lib=lib, hand=False)
     args = tcp_args(env)
     rng = np.random.RandomState(3)
-    errs = []
+    errs, same = [], []
     for step in range(nsteps):
         a = rng.uniform(-1, 1, 6)
         sync_from_oracle(sm, om); sync_from_oracle(sc, oc)
+        km, kc = sm.stats[0].cpu().numpy().astype(np.float64), sc.stats[0].cpu().numpy().astype(np.float64)
+        env.main.ncon_sum = env.main.nefc_sum = env.solver.ncon_sum = env.solver.nefc_sum = 0
         sc.step_tcp(sm, torch.tensor(a[None].astype(np.float32), device=sm.device), args)
         sm.env_step(nforward_ticks=2, flags=32)
         sm.sync()
@@ -142,7 +150,8 @@ def _resync(models, lib, device, n_substeps, nsteps):
         e = lambda x, y: float(np.abs(x.cpu().numpy().astype(np.float64) - y).max())
         errs.append((e(sm.ctrl[0], om.ctrl), e(sm.qpos[0], om.qpos), e(sm.qvel[0], om.qvel)))
         assert int(sm.status[0]) == 0 and int(sc.status[0]) == 0
-    return np.array(errs)
+        same.append(contact_history(sm, env.main, km) and contact_history(sc, env.solver, kc))
+    return (np.array(errs), np.array(same)) if classify else np.array(errs)
 
 
 def test_ycb_stage_dump_matches_oracle_emul(models, emul_lib, oracle_lib):
@@ -166,6 +175,26 @@ def test_ycb_resync_env_steps_gpu(models, oracle_lib):
     # step that is depends on the rounding: tests/test_rearrange_kernel.py RESYNC_EVENT_BOUND) -- which stays inside (2e-3, 5e-3, 0.5)
     ordinary = (errs < np.array([5e-6, 5e-4, 0.1])).all(axis=1)
     assert (~ordinary).sum() <= 1 and (errs < np.array([2e-3, 5e-3, 0.5])).all(), (errs, med, mx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("set_index", [1, 2, 3, 4, 5])
+def test_ycb_other_object_sets_match_oracle_gpu(set_index, oracle_lib):
+    """the shipped object sets 1-5 (objects of 20-33 convex parts, 177-305 geoms, up to 10 k static pairs) had no oracle comparison.  Stage
+    dump of one mj_step with the objects lying on the table (contact list pair by pair, generalized forces, the new state) and 4 re-synchronised env.steps of
+    40 + 40 mj_steps each, bounds of set 0's tests."""
+    models = (load_ycb_model(N, set_index=set_index), load_solver_model())
+    _stage_dump(models, None, "cuda:0", spread=True, min_contacts=8, normal_tol=2e-3)
+    errs, same = _resync(models, None, "cuda:0", 40, 4, spread=True, classify=True)
+    print("ycb object set %d: ctrl / qpos / qvel max %s; same contact history in %d of 4 steps" % (set_index, errs.max(axis=0), same.sum()))
+    assert (errs < np.array([2e-3, 5e-3, 0.5])).all(), errs
+    assert (errs[same] < np.array([5e-6, 5e-4, 0.1])).all(), (errs, same)
+
+
+def test_ycb_other_object_set_stage_dump_emul(emul_lib, oracle_lib):
+    """(one of the other sets on the emulation harness: the same stage dump as the GPU test's)"""
+    models = (load_ycb_model(N, set_index=1), load_solver_model())
+    _stage_dump(models, emul_lib, "cpu", spread=True, min_contacts=8)
 
 
 @pytest.mark.gpu
