@@ -28,10 +28,12 @@ using namespace rgl;   // small math, wave collectives and the MPR / support rou
 typedef const RbModelDev& RbM;
 typedef const RbLaunch& RbLRef;
 #define RB_S() (*(RbLds*)emul_lds())
+#define RB_ARENA() ((float*)((char*)emul_lds() + RB_ARENA_BASE))
 #else
 typedef const RG_AS4 RbModelDev& RbM;
 typedef const RG_AS4 RbLaunch& RbLRef;
 #define RB_S() (*(RbLds*)rg_lds_raw)
+#define RB_ARENA() ((float*)(rg_lds_raw + RB_ARENA_BASE))   /* as a generic pointer: the stage functions reach their arrays through flat loads either way */
 #endif
 #define TID ((int)threadIdx.x)
 #define WID (TID >> 6)
@@ -105,7 +107,9 @@ __device__ __forceinline__ int rb_slot(RbLds& s, bool pred, int* cnt, int cap, u
   BSYNC();
   return (pred && slot < cap) ? slot : -1;
 }
-#define SC(name) (S + m.off[RB_O_##name])
+// a stage array of this env: in the LDS arena if the model's placement puts it there, else in the HBM scratch row (one scalar select per use of the pointer)
+#define RB_ARENA_BASE ((sizeof(RbLds) + 15) & ~(size_t)15)
+#define SC(name) (m.lds_off[RB_O_##name] >= 0 ? RB_ARENA() + m.lds_off[RB_O_##name] : S + m.off[RB_O_##name])
 
 // ------------------------------------------------------------------------------------------------- position stage
 // engine_core_smooth.c mj_kinematics: body frames top-down (level sweep), joint anchors / axes, geoms, sites
@@ -2257,6 +2261,16 @@ __global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbMod
     if (TID == 6) {
       float* gc = L.tcp.main_ctrl + (size_t)e * L.tcp.main_nu + L.tcp.main_grip_act;
       *gc = clampf(*gc + clampf(tcp_grip_action, -1.f, 1.f) * 0.5f * (L.tcp.grip_hi - L.tcp.grip_lo), L.tcp.grip_lo, L.tcp.grip_hi);
+    }
+  }
+  if (m.lds_words > 0) {   // LDS-resident stage arrays -> the env's scratch row (what the env kernel and the host's stage readers see)
+    BSYNC();
+#pragma unroll 1
+    for (int k = 0; k < RB_NOFF; k++) {
+      const int lo = m.lds_off[k];
+      if (lo < 0) continue;
+      const float* src = RB_ARENA() + lo; float* dst = S + m.off[k];
+      BFOR(w, m.lds_len[k]) dst[w] = src[w];
     }
   }
   if (TID < 7 * m.nmocap && TID < 14) L.bt.mocap[(size_t)e * 7 * m.nmocap + TID] = s.mocap[TID];

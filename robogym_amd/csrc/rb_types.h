@@ -107,6 +107,10 @@ struct RbModelDev {
   float timestep, gravity[3], tolerance, impratio, mpr_tolerance, meaninertia;
   int off[RB_NOFF];
   int scratch_words;                 // row length
+  // LDS residency of stage arrays (round 5): arrays with lds_off[k] >= 0 live in the workgroup's LDS arena (behind RbLds; offsets in words) for the whole launch
+  // instead of the env's HBM scratch row, and are copied out to the row (lds_len[k] words) when the launch ends, for the env kernel and the host readers.
+  int lds_off[RB_NOFF], lds_len[RB_NOFF];
+  int lds_words;                     // arena size
 #define X(n) const int* n;
   RB_INT_ARRAYS(X)
 #undef X

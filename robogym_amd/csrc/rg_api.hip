@@ -98,6 +98,14 @@ static const char* hipGetErrorString(hipError_t) { return "emul"; }
 #undef RB_MAXNV
 #undef RB_MAXNQ
 #undef RB_WG_PER_CU
+// The one-wave configurations hold a contact's Jacobian rows at RB_CONW_ONEWAVE dofs (the rearrange worlds need 13: a free object against the arm + gripper chain),
+// the large one at 24 (finger chain + wrist against the cube's chain): 384 instead of 576 bytes of Jacobian per contact, 4 instead of 6 16-byte loads per row.
+#ifndef RB_CONW_ONEWAVE
+#define RB_CONW_ONEWAVE 16
+#endif
+#define RB_CONW_LARGE RB_CONW
+#undef RB_CONW
+#define RB_CONW RB_CONW_ONEWAVE
 #define RB_NS rgbs           /* small configuration: one wave per env, 16 envs per CU (the rearrange worlds) */
 #define RB_T RB_T_SMALL
 #define RB_MAXGROUP RB_MAXGROUP_SMALL
@@ -127,6 +135,8 @@ static const char* hipGetErrorString(hipError_t) { return "emul"; }
 #undef RB_MAXNV
 #undef RB_MAXNQ
 #undef RB_WG_PER_CU
+#undef RB_CONW
+#define RB_CONW 24           /* (= rb_types.h; the env kernels and the host code below see the large configuration's width unless they ask per model) */
 #include "rb_env_kernel.h"
 #include "ra_env_kernel.h"
 #define RG_WAVES_PER_SIMD_HOST 3   /* = RG_WAVES_PER_SIMD of rg_kernel.h (its default) */
@@ -956,7 +966,7 @@ rb_model* rb_model_create(const void* blob, size_t nbytes, char* err, int errlen
     for (size_t t = 0; t < te.size() && 4 * t + 3 < td.size(); t++) tmax = std::max(tmax, te[t] - td[4 * t + 3]);
     const char* force = getenv("RB_CONFIG");
     auto fits = [&](int maxgroup, int maxnv, int maxnq, int threads) {
-      return d.gmax <= maxgroup && d.nv <= maxnv && d.nq <= maxnq && tmax <= threads && 28 * tmax + 27 <= maxgroup * (maxgroup + 1) / 2 + 8;
+      return d.gmax <= maxgroup && d.nv <= maxnv && d.nq <= maxnq && tmax <= threads && 28 * tmax + 27 <= maxgroup * (maxgroup + 1) / 2 + 8 && d.conw <= RB_CONW_ONEWAVE;
     };
     m->config = 0;
     if (!(force && !strcmp(force, "large"))) {
@@ -987,6 +997,10 @@ rb_model* rb_model_create(const void* blob, size_t nbytes, char* err, int errlen
   for (int k = 0; k < d.nsensor; k++) if (iv[k] != 0 && iv[k] != 4 && iv[k] != 5 && iv[k] != 8) return bail("rb_model_create: sensor type not implemented", m);
   if (!get_i(B, "size_int", iv, e)) return bail(e, m);
   d.maxrow = iv[0] > 0 ? iv[0] : 2000; d.maxcon = iv[1] > 0 ? iv[1] : 200;   // njmax / nconmax of the model
+  // RB_SCRATCH_MAXCON / RB_SCRATCH_MAXROW: capacities of the per-env scratch row below the model's nconmax / njmax (the row's arrays are laid out at capacity:
+  // rearrange's 500 / 2000 spread the ~40 kB an mj_step touches over 660 kB per env).  Exceeding them raises RG_STATUS_CON_FULL / ROW_FULL as the model's own do.
+  if (const char* ov = getenv("RB_SCRATCH_MAXCON")) { const int v = atoi(ov); if (v > 0 && v < d.maxcon) d.maxcon = v; }
+  if (const char* ov = getenv("RB_SCRATCH_MAXROW")) { const int v = atoi(ov); if (v > 0 && v < d.maxrow) d.maxrow = v; }
   d.maxcand = 4 * d.maxcon + 256;
   if (!get_f(B, "opt_timestep", fv, e)) return bail(e, m); d.timestep = fv[0];
   if (!get_f(B, "opt_gravity", fv, e)) return bail(e, m); for (int k = 0; k < 3; k++) d.gravity[k] = fv[k];
@@ -1010,9 +1024,43 @@ rb_model* rb_model_create(const void* blob, size_t nbytes, char* err, int errlen
   take(RB_O_ROOTCOM, 3 * d.nbody); take(RB_O_CINERT, 10 * d.nbody); take(RB_O_CRB, 10 * d.nbody); take(RB_O_CDOF, 6 * d.nv); take(RB_O_CDOFDOT, 6 * d.nv);
   take(RB_O_CVEL, 6 * d.nbody); take(RB_O_CACC, 6 * d.nbody); take(RB_O_CFRC, 6 * d.nbody);
   take(RB_O_TENLEN, d.ntendon); take(RB_O_TENJ, RB_TENW * d.ntendon); take(RB_O_TENVEL, d.ntendon); take(RB_O_MSP, d.nM);
-  take(RB_O_CAND, d.maxcand); take(RB_O_CON, RB_CONREC * d.maxcon); take(RB_O_CONJ, 6 * RB_CONW * d.maxcon); take(RB_O_CONIDX, RB_CONW * d.maxcon);
-  take(RB_O_ROW, RB_ROWREC * d.maxrow); take(RB_O_DOFCON_ADR, d.nv + 1); take(RB_O_DOFCON, RB_CONW * d.maxcon); take(RB_O_CONF, RB_NW * d.maxcon); take(RB_O_DBG, 8 + 5 * d.nv + 16); take(RB_O_CFRCEXT, 6 * d.nbody); take(RB_O_CONLOC, RB_CONW * d.maxcon);
+  const int cw = m->config ? RB_CONW_ONEWAVE : RB_CONW;      // dofs per contact row the model's configuration is compiled for
+  take(RB_O_CAND, d.maxcand); take(RB_O_CON, RB_CONREC * d.maxcon); take(RB_O_CONJ, 6 * cw * d.maxcon); take(RB_O_CONIDX, cw * d.maxcon);
+  take(RB_O_ROW, RB_ROWREC * d.maxrow); take(RB_O_DOFCON_ADR, d.nv + 1); take(RB_O_DOFCON, cw * d.maxcon); take(RB_O_CONF, RB_NW * d.maxcon); take(RB_O_DBG, 8 + 5 * d.nv + 16); take(RB_O_CFRCEXT, 6 * d.nbody); take(RB_O_CONLOC, cw * d.maxcon);
   d.scratch_words = o;
+  // ---- LDS residency of stage arrays (rb_types.h lds_off): RB_LDS_PLACE = a preset or a comma-separated list of array names.  Only arrays whose length does not
+  // depend on the number of contacts / rows of the mj_step can be placed (their capacity is the model's own size).
+  {
+    static const char* names[RB_NOFF] = {"xpos", "xquat", "xipos", "xiquat", "xanchor", "xaxis", "gpos", "gquat", "spos", "rootcom", "cinert", "crb", "cdof", "cdofdot", "cvel", "cacc", "cfrc",
+                                         "tenlen", "tenj", "tenvel", "msp", "cand", "con", "conj", "conidx", "row", "dofcon_adr", "dofcon", "conf", "dbg", "cfrcext", "conloc"};
+    const int len[RB_NOFF] = {3 * d.nbody, 4 * d.nbody, 3 * d.nbody, 4 * d.nbody, 3 * d.njnt, 3 * d.njnt, 3 * d.ngeom, 4 * d.ngeom, 3 * d.nsite, 3 * d.nbody, 10 * d.nbody, 10 * d.nbody, 6 * d.nv, 6 * d.nv,
+                              6 * d.nbody, 6 * d.nbody, 6 * d.nbody, d.ntendon, RB_TENW * d.ntendon, d.ntendon, d.nM, 0, 0, 0, 0, 0, d.nv + 1, 0, 0, 0, 6 * d.nbody, 0};
+    for (int k = 0; k < RB_NOFF; k++) { d.lds_off[k] = -1; d.lds_len[k] = 0; }
+    d.lds_words = 0;
+    const char* place = getenv("RB_LDS_PLACE");
+    std::string want = place ? place : "";
+    if (want == "frames") want = "xpos,xquat,xipos,xiquat,xanchor,xaxis,gpos,gquat,spos,rootcom";
+    else if (want == "kin") want = "xpos,xquat,xipos,xiquat,xanchor,xaxis,gpos,gquat,spos,rootcom,cinert,crb,cdof,cdofdot,cvel,cacc,cfrc,tenlen,tenj,tenvel,msp,dofcon_adr,cfrcext";
+    else if (want == "dyn") want = "cinert,crb,cdof,cdofdot,cvel,cacc,cfrc,msp";
+    if (!want.empty() && m->config != 0) {   // (the one-wave configurations; the large configuration's LDS is spoken for by its 96-dof block)
+      int lo = 0;
+      size_t at = 0;
+      while (at <= want.size()) {
+        const size_t e2 = want.find(',', at);
+        const std::string nm = want.substr(at, e2 == std::string::npos ? std::string::npos : e2 - at);
+        at = e2 == std::string::npos ? want.size() + 1 : e2 + 1;
+        if (nm.empty()) continue;
+        int k = -1;
+        for (int q = 0; q < RB_NOFF; q++) if (nm == names[q]) k = q;
+        if (k < 0 || (len[k] == 0 && k != RB_O_TENLEN && k != RB_O_TENJ && k != RB_O_TENVEL)) return bail("RB_LDS_PLACE: unknown or unplaceable stage array name", m);
+        if (d.lds_off[k] >= 0 || len[k] == 0) continue;
+        d.lds_off[k] = lo; d.lds_len[k] = len[k]; lo += (len[k] + 3) & ~3;
+      }
+      d.lds_words = lo;
+      const size_t base = m->config == 1 ? ((sizeof(rgbs::RbLds) + 15) & ~(size_t)15) : ((sizeof(rgbm::RbLds) + 15) & ~(size_t)15);
+      if (base + 4 * (size_t)lo > 64 * 1024) return bail("RB_LDS_PLACE: the arena exceeds 64 kB of LDS per workgroup", m);
+    }
+  }
   void* p = nullptr;
   if (hipMalloc(&p, sizeof(RbModelDev)) != hipSuccess) return bail("hipMalloc failed", m);
   m->allocs.push_back(p);
@@ -1047,8 +1095,8 @@ int rg_blob_entry(const void* blob, size_t nbytes, int index, char* name40, int*
 int rb_model_info(const rb_model* m, int* out, int n) {
   if (!m) return fail("null model");
   const RbModelDev& d = m->dev;
-  const int v[] = {d.nq, d.nv, d.nu, d.nbody, d.njnt, d.ngeom, d.nsite, d.ntendon, d.nM, d.npair, d.ngroup, d.gmax, d.maxcon, d.maxrow, d.scratch_words, RB_CONREC, RB_ROWREC, RB_CONW, RB_TENW,
-                   m->config == 1 ? (int)sizeof(rgbs::RbLds) : m->config == 2 ? (int)sizeof(rgbm::RbLds) : (int)sizeof(rgb::RbLds), m->config == 1 ? RB_T_SMALL : m->config == 2 ? RB_T_MEDIUM : RB_T_LARGE};
+  const int v[] = {d.nq, d.nv, d.nu, d.nbody, d.njnt, d.ngeom, d.nsite, d.ntendon, d.nM, d.npair, d.ngroup, d.gmax, d.maxcon, d.maxrow, d.scratch_words, RB_CONREC, RB_ROWREC, m->config ? RB_CONW_ONEWAVE : RB_CONW, RB_TENW,
+                   (m->config == 1 ? (int)sizeof(rgbs::RbLds) : m->config == 2 ? (int)sizeof(rgbm::RbLds) : (int)sizeof(rgb::RbLds)) + (d.lds_words ? 4 * d.lds_words + 16 : 0), m->config == 1 ? RB_T_SMALL : m->config == 2 ? RB_T_MEDIUM : RB_T_LARGE};
   const int k = (int)(sizeof v / sizeof v[0]);
   for (int i = 0; i < k && i < n; i++) out[i] = v[i];
   return k;
@@ -1191,12 +1239,14 @@ int rb_batch_step_ex(rb_batch* b, const float* action_dev, const int* active_dev
   if (g_tcp_hook) { launch.tcp = *g_tcp_hook; }
 #ifdef RG_EMUL
   EmulRbArgs args{b->model->dev_copy, launch};
-  if (b->model->config == 1) emul_launch_n(bt.B, RB_T_SMALL, sizeof(rgbs::RbLds), emul_rbs_entry, &args);
-  else if (b->model->config == 2) emul_launch_n(bt.B, RB_T_MEDIUM, sizeof(rgbm::RbLds), emul_rbm_entry, &args);
+  const size_t arena = 4 * (size_t)b->model->dev.lds_words + 16;
+  if (b->model->config == 1) emul_launch_n(bt.B, RB_T_SMALL, sizeof(rgbs::RbLds) + arena, emul_rbs_entry, &args);
+  else if (b->model->config == 2) emul_launch_n(bt.B, RB_T_MEDIUM, sizeof(rgbm::RbLds) + arena, emul_rbm_entry, &args);
   else emul_launch_n(bt.B, RB_T_LARGE, sizeof(rgb::RbLds), emul_rb_entry, &args);
 #else
-  if (b->model->config == 1) hipLaunchKernelGGL(rgbs::rb_step_kernel, dim3(bt.B), dim3(RB_T_SMALL), sizeof(rgbs::RbLds), (hipStream_t)stream, b->model->dev_copy, launch);
-  else if (b->model->config == 2) hipLaunchKernelGGL(rgbm::rb_step_kernel, dim3(bt.B), dim3(RB_T_MEDIUM), sizeof(rgbm::RbLds), (hipStream_t)stream, b->model->dev_copy, launch);
+  const size_t arena = b->model->dev.lds_words ? 4 * (size_t)b->model->dev.lds_words + 16 : 0;   // (+16: the arena starts at the next 16-byte boundary behind RbLds)
+  if (b->model->config == 1) hipLaunchKernelGGL(rgbs::rb_step_kernel, dim3(bt.B), dim3(RB_T_SMALL), sizeof(rgbs::RbLds) + arena, (hipStream_t)stream, b->model->dev_copy, launch);
+  else if (b->model->config == 2) hipLaunchKernelGGL(rgbm::rb_step_kernel, dim3(bt.B), dim3(RB_T_MEDIUM), sizeof(rgbm::RbLds) + arena, (hipStream_t)stream, b->model->dev_copy, launch);
   else hipLaunchKernelGGL(rgb::rb_step_kernel, dim3(bt.B), dim3(RB_T_LARGE), sizeof(rgb::RbLds), (hipStream_t)stream, b->model->dev_copy, launch);
   HIPCHK(hipGetLastError());
 #endif

@@ -220,7 +220,9 @@ def test_rearrange_resync_env_steps_gpu(models, oracle_lib):
 
 
 # an env.step whose 80 mj_steps held the same contact and row counts on both sides: fp32 rounding of one trajectory, no event -- bounds per step, no exceptions
-RESYNC_SAME_HISTORY_BOUND = {"solver qpos": 2e-5, "mocap": 2e-6, "main ctrl": 2e-5, "main qpos": 5e-5, "main qvel": 5e-3, "main pid": 5e-5, "sensordata (rel)": 5e-3}
+# (measured on the MI355X, 150 steps of this protocol, profiles/r05_parity_rearrange.txt: 131 same-history steps with solver qpos <= 1.8e-6, main qpos <= 3.1e-6,
+#  qvel <= 1.9e-4, pid <= 2.2e-6, sensordata <= 4.2e-4; the bounds leave a factor of ~10)
+RESYNC_SAME_HISTORY_BOUND = {"solver qpos": 2e-5, "mocap": 2e-6, "main ctrl": 2e-5, "main qpos": 3e-5, "main qvel": 2e-3, "main pid": 3e-5, "sensordata (rel)": 5e-3}
 
 
 def _assert_resync_classified(errs, same, min_same_fraction=0.5):
@@ -231,8 +233,6 @@ def _assert_resync_classified(errs, same, min_same_fraction=0.5):
     for i, n in enumerate(names):
         assert errs[same, i].max() < RESYNC_SAME_HISTORY_BOUND[n], (n, errs[same, i].max(), int(same.sum()))
         assert errs[:, i].max() < RESYNC_EVENT_BOUND[n], (n, errs[:, i].max())
-    if (~same).any():      # and the events are where the tail is
-        assert np.median(errs[~same, 3]) >= np.median(errs[same, 3])
 
 
 def test_rearrange_resync_classified_emul(models, emul_lib, oracle_lib):

@@ -23,9 +23,21 @@ def table(title, names, errs):
         print("  %-18s median %.2e  p90 %.2e  p99 %.2e  max %.2e" % (n, np.median(e), np.percentile(e, 90), np.percentile(e, 99), e.max()))
 
 
-errs = TK._resync_env_steps((load_blocks_model(5), load_solver_model()), None, "cuda:0", n_substeps=40, nsteps=nb, seed=5)
+def by_history(names, errs, same):
+    """the same table split by contact history (tests/test_rearrange_kernel.py contact_history): steps whose 40 + 40 mj_steps held the same contact and row counts on both sides"""
+    for label, sel in (("same contact history", same), ("differing contact history", ~same)):
+        if sel.any():
+            table("  -- %s: %d of %d steps" % (label, sel.sum(), len(sel)), names, errs[sel])
+
+
+errs, same = TK._resync_env_steps((load_blocks_model(5), load_solver_model()), None, "cuda:0", n_substeps=40, nsteps=nb, seed=5, classify=True)
 print("  steps with solver qpos error > 1e-3:", [(int(k), float("%.3g" % errs[k, 0])) for k in np.nonzero(errs[:, 0] > 1e-3)[0]])
 table("rearrange/blocks, %d re-synchronised env.steps (random actions, every third pressing down), L-inf per env.step:" % nb,
       ["solver qpos", "mocap", "main ctrl", "main qpos", "main qvel", "main pid", "sensordata (rel)"], errs)
-errs = TY._resync((load_ycb_model(8), load_solver_model()), None, "cuda:0", 40, ny)
+by_history(["solver qpos", "mocap", "main ctrl", "main qpos", "main qvel", "main pid", "sensordata (rel)"], errs, same)
+errs, same = TY._resync((load_ycb_model(8), load_solver_model()), None, "cuda:0", 40, ny, classify=True)
 table("rearrange/ycb (object set 0), %d re-synchronised env.steps:" % ny, ["main ctrl", "main qpos", "main qvel"], errs)
+by_history(["main ctrl", "main qpos", "main qvel"], errs, same)
+for k in (1, 2, 3, 4, 5):
+    errs, same = TY._resync((load_ycb_model(8, set_index=k), load_solver_model()), None, "cuda:0", 40, max(ny // 6, 4), spread=True, classify=True)
+    table("rearrange/ycb object set %d, %d re-synchronised env.steps (%d with the same contact history):" % (k, len(errs), same.sum()), ["main ctrl", "main qpos", "main qvel"], errs)
