@@ -54,8 +54,8 @@ enum {
 /* Replaces mujoco_py.load_model_from_xml (mujoco_xml.py:259): `blob` is the "RGMODEL1" flat model
  * produced by the host-side MJCF compiler (robogym_amd/mujoco/model_blob.py). Returns NULL on error. */
 /* ---- The model blob (format "RGMODEL1"; what mujoco_py.load_model_from_xml's result is to the reference, mujoco/mujoco_xml.py:249-260).
- * MJCF compilation is host-side (robogym_amd/mujoco/mjcf_compiler.py + setconst.py + kernel_tables.py / big_tables.py; SURVEY 8b's
- * `rg_compile_mjcf` is NOT behind this ABI) and its product is this self-describing container, which any language can assemble:
+ * MJCF compilation is host-side (robogym_amd/mujoco/mjcf_compiler.py + setconst.py + kernel_tables.py / big_tables.py; reachable through this ABI as
+ * rg_compile_mjcf / rb_compile_mjcf below, which run it as a helper process) and its product is this self-describing container, which any language can assemble:
  *   bytes 0..7   "RGMODEL1"        bytes 8..11  uint32 entry count n        bytes 12..15  reserved (0)
  *   then n directory entries of 56 bytes: char name[40] (NUL padded) | uint32 dtype (0 = float64, 1 = int32, 2 = float32) | uint32 element count |
  *   uint64 byte offset of the data from the start of the blob (8-byte aligned); the arrays follow, little endian, C order.
@@ -65,6 +65,20 @@ enum {
  * (return value: bytes needed incl. NUL); a missing or mistyped key fails the create with an error that names it.  rg_blob_entry enumerates a blob's
  * directory (index < 0: only the entry count is returned) with the same bounds checks the creates apply. */
 int rg_blob_entry(const void* blob, size_t nbytes, int index, char* name40, int* dtype, unsigned* count);
+/* ---- MJCF across the boundary (SURVEY 8b `rg_compile_mjcf`).  Replaces MujocoXML.build -> mujoco_py.load_model_from_xml(xml_string)
+ * (/root/reference/robogym/mujoco/mujoco_xml.py:249-260): `xml` is the merged MJCF document as a NUL-terminated string, `meshdir` the directory mesh file
+ * names are relative to (NULL or "": the document's <compiler meshdir>).  The MJCF compiler is the package's Python module: the library runs it as a helper
+ * process -- `$RGSTEP_PYTHON` (default "python3") `-m robogym_amd.mujoco.compile_cli`, with the package root (three directories above the library file, or
+ * `$RGSTEP_PYTHONPATH`) prepended to PYTHONPATH -- which writes the RGMODEL1 blob to a private temporary directory; the library reads it back, removes the
+ * directory and creates the model from it.  Blocking, host only (no GPU work before the create), seconds for a Shadow-hand document (mesh hulls).
+ * Errors (compiler unavailable, a feature outside the supported MJCF subset, a missing mesh) return NULL with the compiler's message in `err`.
+ *   rg_compile_mjcf       -> a model of the Shadow-hand layout (as rg_model_create)
+ *   rb_compile_mjcf       -> a model of the large-model stepper (as rb_model_create)
+ *   rg_compile_mjcf_blob  -> only the blob (kind 0: with the k_* tables rg_model_create reads; 1: with the b_* tables of rb_model_create), malloc'ed,
+ *                            released with rg_blob_free: compile once, create on several devices (rg_model_create_on). */
+rg_model* rg_compile_mjcf(const char* xml, const char* meshdir, char* err, int errlen);
+int rg_compile_mjcf_blob(const char* xml, const char* meshdir, int kind, void** blob_out, size_t* nbytes_out, char* err, int errlen);
+void rg_blob_free(void* blob);
 int rg_model_blob_keys(const rg_model* m, char* out, int outlen);
 rg_model* rg_model_create(const void* blob, size_t nbytes, char* err, int errlen);
 /* The same with the HIP device ordinal that shall hold the model tables (rg_model_create uses the calling
@@ -281,6 +295,7 @@ int rg_lds_bytes_cfg(int config);
 typedef struct rb_model rb_model;
 typedef struct rb_batch rb_batch;
 rb_model* rb_model_create(const void* blob, size_t nbytes, char* err, int errlen);
+rb_model* rb_compile_mjcf(const char* xml, const char* meshdir, char* err, int errlen);   /* MJCF string -> model (see rg_compile_mjcf) */
 int rb_model_blob_keys(const rb_model* m, char* out, int outlen);   /* the blob arrays rb_model_create read (see rg_blob_entry) */
 void rb_model_free(rb_model* m);
 int rb_model_info(const rb_model* m, int* out, int n);

@@ -106,7 +106,7 @@ EXPORTS = [
     "rg_lds_bytes_cfg", "rg_env_post_step", "rg_post_args_size", "rg_batch_enable_env_params", "rg_prm_layout", "rg_xdata_layout", "rg_batch_set_constants", "rg_batch_items_info",
     "rb_model_create", "rb_model_free", "rb_model_info", "rb_scratch_offset", "rb_batch_create", "rb_batch_free", "rb_batch_reset", "rb_batch_set_env",
     "rb_batch_field_ptr", "rb_batch_step", "rb_batch_step_ex", "rb_env_post_step", "rb_post_args_size", "rb_cube_ops", "rb_batch_step_tcp", "ra_env_post_step", "ra_post_args_size",
-    "rg_blob_entry", "rg_model_blob_keys", "rb_model_blob_keys",
+    "rg_blob_entry", "rg_model_blob_keys", "rb_model_blob_keys", "rg_compile_mjcf", "rb_compile_mjcf", "rg_compile_mjcf_blob", "rg_blob_free",
 ]
 
 
@@ -163,6 +163,12 @@ def bind(path):
     L.rg_blob_entry.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ci, ctypes.c_char_p, ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_uint)]
     L.rg_model_blob_keys.argtypes = [vp, ctypes.c_char_p, ci]
     L.rb_model_blob_keys.argtypes = [vp, ctypes.c_char_p, ci]
+    L.rg_compile_mjcf.restype = vp
+    L.rg_compile_mjcf.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ci]
+    L.rb_compile_mjcf.restype = vp
+    L.rb_compile_mjcf.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ci]
+    L.rg_compile_mjcf_blob.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ci, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t), ctypes.c_char_p, ci]
+    L.rg_blob_free.argtypes = [vp]
     L.rb_scratch_offset.argtypes = [vp, ci]
     L.rb_batch_create.restype = vp
     L.rb_batch_create.argtypes = [vp, ci]

@@ -107,9 +107,16 @@ __device__ __forceinline__ int rb_slot(RbLds& s, bool pred, int* cnt, int cap, u
   BSYNC();
   return (pred && slot < cap) ? slot : -1;
 }
-// a stage array of this env: in the LDS arena if the model's placement puts it there, else in the HBM scratch row (one scalar select per use of the pointer)
+// a stage array of this env.  Default build: in the HBM scratch row.  With -DRB_LDS_ARENA (an experiment of round 5, kept as a build option: tools/gpu_call_r05b.sh,
+// DESIGN.md section 3.4c): in the workgroup's LDS arena if the model's placement (RB_LDS_PLACE) puts it there -- one scalar select per use of the pointer; the stage
+// functions reach their arrays through generic pointers (flat loads) either way, so nothing else changes.  Measured: per-workgroup latency falls by 1.7x, occupancy
+// by 2.3x (LDS), throughput by 17-27 %: what binds these kernels at 4 waves per SIMD is not the scratch row's latency alone.
 #define RB_ARENA_BASE ((sizeof(RbLds) + 15) & ~(size_t)15)
+#ifdef RB_LDS_ARENA
 #define SC(name) (m.lds_off[RB_O_##name] >= 0 ? RB_ARENA() + m.lds_off[RB_O_##name] : S + m.off[RB_O_##name])
+#else
+#define SC(name) (S + m.off[RB_O_##name])
+#endif
 
 // ------------------------------------------------------------------------------------------------- position stage
 // engine_core_smooth.c mj_kinematics: body frames top-down (level sweep), joint anchors / axes, geoms, sites
@@ -2263,6 +2270,7 @@ __global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbMod
       *gc = clampf(*gc + clampf(tcp_grip_action, -1.f, 1.f) * 0.5f * (L.tcp.grip_hi - L.tcp.grip_lo), L.tcp.grip_lo, L.tcp.grip_hi);
     }
   }
+#ifdef RB_LDS_ARENA
   if (m.lds_words > 0) {   // LDS-resident stage arrays -> the env's scratch row (what the env kernel and the host's stage readers see)
     BSYNC();
 #pragma unroll 1
@@ -2273,6 +2281,7 @@ __global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbMod
       BFOR(w, m.lds_len[k]) dst[w] = src[w];
     }
   }
+#endif
   if (TID < 7 * m.nmocap && TID < 14) L.bt.mocap[(size_t)e * 7 * m.nmocap + TID] = s.mocap[TID];
   BFOR(i, nq) L.bt.qpos[(size_t)e * nq + i] = s.qpos[i];
   BFOR(i, nv) { L.bt.qvel[(size_t)e * nv + i] = s.qvel[i]; L.bt.qacc_warmstart[(size_t)e * nv + i] = s.warm[i]; }

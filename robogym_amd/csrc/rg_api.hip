@@ -63,6 +63,11 @@ typedef ra_post_args RaPostArgs;
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <dlfcn.h>
+#include <unistd.h>
+#include <sys/wait.h>
 
 #include <algorithm>
 #include <string>
@@ -1042,6 +1047,9 @@ rb_model* rb_model_create(const void* blob, size_t nbytes, char* err, int errlen
     if (want == "frames") want = "xpos,xquat,xipos,xiquat,xanchor,xaxis,gpos,gquat,spos,rootcom";
     else if (want == "kin") want = "xpos,xquat,xipos,xiquat,xanchor,xaxis,gpos,gquat,spos,rootcom,cinert,crb,cdof,cdofdot,cvel,cacc,cfrc,tenlen,tenj,tenvel,msp,dofcon_adr,cfrcext";
     else if (want == "dyn") want = "cinert,crb,cdof,cdofdot,cvel,cacc,cfrc,msp";
+#ifndef RB_LDS_ARENA
+    if (!want.empty()) return bail("RB_LDS_PLACE: this library was built without -DRB_LDS_ARENA (rb_kernel.h)", m);
+#endif
     if (!want.empty() && m->config != 0) {   // (the one-wave configurations; the large configuration's LDS is spoken for by its 96-dof block)
       int lo = 0;
       size_t at = 0;
@@ -1075,6 +1083,86 @@ static int join_keys(const std::vector<std::string>& keys, char* out, int outlen
   for (size_t i = 0; i < keys.size(); i++) { if (i) j += ","; j += keys[i]; }
   if (out && outlen > 0) { strncpy(out, j.c_str(), outlen - 1); out[outlen - 1] = 0; }
   return (int)j.size() + 1;
+}
+// ---- MJCF across the boundary (SURVEY 8b `rg_compile_mjcf`; the reference's seam: MujocoXML.build -> mujoco_py.load_model_from_xml(xml_string), mujoco_xml.py:249-260).
+// The compiler is the package's Python module; the library runs it as a HELPER PROCESS (robogym_amd/mujoco/compile_cli.py: document -> RGMODEL1 blob file) and
+// creates the model from the blob it wrote, so that a host in any language hands over an XML string as the reference hands one to MuJoCo.
+static std::string lib_root() {
+  if (const char* ov = getenv("RGSTEP_PYTHONPATH")) return ov;
+  Dl_info info;
+  if (!dladdr((const void*)&rg_last_error, &info) || !info.dli_fname) return ".";
+  std::string p = info.dli_fname;                       // <root>/robogym_amd/csrc/librgstep.so (or <root>/tests/emul/librgstep_emul.so): three levels up
+  for (int k = 0; k < 3; k++) { const size_t at = p.find_last_of('/'); if (at == std::string::npos) return "."; p.erase(at); }
+  return p.empty() ? "/" : p;
+}
+static bool read_file(const std::string& path, std::vector<char>& out) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  fseek(f, 0, SEEK_END); const long n = ftell(f); fseek(f, 0, SEEK_SET);
+  out.resize(n > 0 ? (size_t)n : 0);
+  const bool ok = n <= 0 || fread(out.data(), 1, (size_t)n, f) == (size_t)n;
+  fclose(f);
+  return ok;
+}
+static bool compile_mjcf_to_blob(const char* xml, const char* meshdir, int kind, std::vector<char>& blob, std::string& err) {
+  if (!xml || !*xml) { err = "rg_compile_mjcf: empty MJCF document"; return false; }
+  if (kind != 0 && kind != 1) { err = "rg_compile_mjcf: kind must be 0 (rg_model) or 1 (rb_model)"; return false; }
+  char dir[] = "/tmp/rgstep_mjcf_XXXXXX";
+  if (!mkdtemp(dir)) { err = "rg_compile_mjcf: mkdtemp failed"; return false; }
+  const std::string d = dir, fx = d + "/model.xml", fb = d + "/model.blob", fe = d + "/stderr.txt";
+  auto cleanup = [&]() { unlink(fx.c_str()); unlink(fb.c_str()); unlink(fe.c_str()); rmdir(dir); };
+  { FILE* f = fopen(fx.c_str(), "wb"); if (!f || fwrite(xml, 1, strlen(xml), f) != strlen(xml)) { if (f) fclose(f); cleanup(); err = "rg_compile_mjcf: cannot write the document to " + fx; return false; } fclose(f); }
+  const char* py = getenv("RGSTEP_PYTHON");
+  const std::string python = py && *py ? py : "python3", root = lib_root();
+  const pid_t pid = fork();
+  if (pid < 0) { cleanup(); err = "rg_compile_mjcf: fork failed"; return false; }
+  if (pid == 0) {
+    const char* old = getenv("PYTHONPATH");
+    const std::string pp = old && *old ? root + ":" + old : root;
+    setenv("PYTHONPATH", pp.c_str(), 1);
+    const int efd = open(fe.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
+    if (efd >= 0) { dup2(efd, 2); dup2(efd, 1); close(efd); }
+    std::vector<const char*> av = {python.c_str(), "-m", "robogym_amd.mujoco.compile_cli", "--kind", kind == 0 ? "rg" : "rb", "--xml", fx.c_str(), "--out", fb.c_str()};
+    if (meshdir && *meshdir) { av.push_back("--meshdir"); av.push_back(meshdir); }
+    av.push_back(nullptr);
+    execvp(python.c_str(), (char* const*)av.data());
+    _exit(127);
+  }
+  int status = 0;
+  while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {}
+  const bool ok = WIFEXITED(status) && WEXITSTATUS(status) == 0 && read_file(fb, blob) && blob.size() >= 16;
+  if (!ok) {
+    std::vector<char> msg; read_file(fe, msg);
+    std::string tail(msg.begin(), msg.end());
+    while (!tail.empty() && (tail.back() == '\n' || tail.back() == ' ')) tail.pop_back();
+    if (tail.size() > 400) tail = tail.substr(tail.size() - 400);
+    err = "rg_compile_mjcf: the MJCF compiler (" + python + " -m robogym_amd.mujoco.compile_cli, PYTHONPATH " + root + ") " +
+          (WIFEXITED(status) && WEXITSTATUS(status) == 127 ? "could not be started" : "failed") + (tail.empty() ? "" : ": " + tail);
+  }
+  cleanup();
+  return ok;
+}
+static void put_err(const std::string& e, char* err, int errlen) { g_err = e; if (err && errlen > 0) { strncpy(err, e.c_str(), errlen - 1); err[errlen - 1] = 0; } }
+int rg_compile_mjcf_blob(const char* xml, const char* meshdir, int kind, void** blob_out, size_t* nbytes_out, char* err, int errlen) {
+  if (!blob_out || !nbytes_out) { put_err("rg_compile_mjcf_blob: null output pointer", err, errlen); return -1; }
+  std::vector<char> blob; std::string e;
+  if (!compile_mjcf_to_blob(xml, meshdir, kind, blob, e)) { put_err(e, err, errlen); return -1; }
+  void* p = malloc(blob.size());
+  if (!p) { put_err("rg_compile_mjcf_blob: out of memory", err, errlen); return -1; }
+  memcpy(p, blob.data(), blob.size());
+  *blob_out = p; *nbytes_out = blob.size();
+  return 0;
+}
+void rg_blob_free(void* blob) { free(blob); }
+rg_model* rg_compile_mjcf(const char* xml, const char* meshdir, char* err, int errlen) {
+  std::vector<char> blob; std::string e;
+  if (!compile_mjcf_to_blob(xml, meshdir, 0, blob, e)) { put_err(e, err, errlen); return nullptr; }
+  return rg_model_create(blob.data(), blob.size(), err, errlen);
+}
+rb_model* rb_compile_mjcf(const char* xml, const char* meshdir, char* err, int errlen) {
+  std::vector<char> blob; std::string e;
+  if (!compile_mjcf_to_blob(xml, meshdir, 1, blob, e)) { put_err(e, err, errlen); return nullptr; }
+  return rb_model_create(blob.data(), blob.size(), err, errlen);
 }
 int rg_model_blob_keys(const rg_model* m, char* out, int outlen) { return m ? join_keys(m->blob_keys, out, outlen) : fail("null model"); }
 int rb_model_blob_keys(const rb_model* m, char* out, int outlen) { return m ? join_keys(m->blob_keys, out, outlen) : fail("null model"); }

@@ -68,6 +68,7 @@ def _check_steps(lib, device, B, n_substeps, nsteps, tol_scale=1.0, make=None, t
             o = oracles[r]
             if prev_valid[r]:
                 o.prev_dist = None   # (the oracle recomputes its own previous count below)
+                o.main.sim.fwd_position()      # (body frames of the copied state: the count is read from xpos / xquat; no controller tick)
             before = o.num_success(o.goal_distance()) if prev_valid[r] else None
             oobs, orew, ogoal_rew, odone, oinfo = o.env_step(a[r].astype(np.float64))
             if before is not None:

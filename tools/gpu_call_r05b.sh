@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round 5, second GPU call: A/B of rb_step_kernel placements / capacities on rearrange blocks + ycb (one build, env-var variants; plus two builds under ab_libs/)
+# Round 5, second GPU call: A/B of rb_step_kernel placements / capacities on rearrange blocks + ycb (env-var variants of one build + two builds under ab_libs/).
+# (The RB_LDS_PLACE variants need a library built with -DRB_LDS_ARENA: at the time of the call that was the default build; results: profiles/r05_ab_rb_placement.txt)
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
