@@ -296,6 +296,16 @@ typedef struct rb_model rb_model;
 typedef struct rb_batch rb_batch;
 rb_model* rb_model_create(const void* blob, size_t nbytes, char* err, int errlen);
 rb_model* rb_compile_mjcf(const char* xml, const char* meshdir, char* err, int errlen);   /* MJCF string -> model (see rg_compile_mjcf) */
+/* Per-env model parameters on the large-model stepper (what the reference's simulation randomizers write into `sim.model` per episode,
+ * /root/reference/robogym/envs/rearrange/common/base.py:1008-1092, randomization/sim.py:115-589).  rb_model_enable_env_params switches the MODEL (before its first
+ * rb_batch_create): every batch then carries one parameter block per env inside the env's scratch row (RG_F_DEBUG through rb_batch_field_ptr), initialised with the
+ * model's values, which rb_step_kernel reads instead of the model's arrays: opt.gravity, dof_damping / armature / frictionloss / invweight0, jnt_stiffness / margin /
+ * range, body_pos / mass / inertia / invweight0, actuator_gainprm / forcerange / ctrlrange, geom_pos / margin / gap / friction / solref / solimp (a contact mixes its
+ * two geoms' values as mj_contactParam does), tendon_range / invweight0.  The *_invweight0 rows are mj_setConst outputs: the reference's rearrange envs never call
+ * set_constants after randomizing (only dactyl's cube_env.py:349 does), so they stay at the compiled model's values unless the host writes them.
+ * rb_prm_layout: out[0] = 1 if enabled, out[1] = words per block, then per field (order above) its word offset in the scratch row and its length. */
+int rb_model_enable_env_params(rb_model* m);
+int rb_prm_layout(const rb_model* m, int* out, int n);
 int rb_model_blob_keys(const rb_model* m, char* out, int outlen);   /* the blob arrays rb_model_create read (see rg_blob_entry) */
 void rb_model_free(rb_model* m);
 int rb_model_info(const rb_model* m, int* out, int n);

@@ -107,6 +107,7 @@ EXPORTS = [
     "rb_model_create", "rb_model_free", "rb_model_info", "rb_scratch_offset", "rb_batch_create", "rb_batch_free", "rb_batch_reset", "rb_batch_set_env",
     "rb_batch_field_ptr", "rb_batch_step", "rb_batch_step_ex", "rb_env_post_step", "rb_post_args_size", "rb_cube_ops", "rb_batch_step_tcp", "ra_env_post_step", "ra_post_args_size",
     "rg_blob_entry", "rg_model_blob_keys", "rb_model_blob_keys", "rg_compile_mjcf", "rb_compile_mjcf", "rg_compile_mjcf_blob", "rg_blob_free",
+    "rb_model_enable_env_params", "rb_prm_layout",
 ]
 
 
@@ -169,6 +170,8 @@ def bind(path):
     L.rb_compile_mjcf.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ci]
     L.rg_compile_mjcf_blob.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ci, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t), ctypes.c_char_p, ci]
     L.rg_blob_free.argtypes = [vp]
+    L.rb_model_enable_env_params.argtypes = [vp]
+    L.rb_prm_layout.argtypes = [vp, ctypes.POINTER(ci), ci]
     L.rb_scratch_offset.argtypes = [vp, ci]
     L.rb_batch_create.restype = vp
     L.rb_batch_create.argtypes = [vp, ci]
@@ -218,6 +221,9 @@ RG_FLAG_DESERT_QUEUE0 = 1024       # bit 10: test hook: the substep-granular dis
 RG_STATUS_SCHED = 64
 RG_FLAG_RESUME = 256           # bit 8: active_dev is a redo array: entry - 1 = first substep still to do
 
+RB_PRM_NAMES = ["gravity", "dof_damping", "dof_armature", "dof_frictionloss", "dof_invweight0", "jnt_stiffness", "jnt_margin", "jnt_range", "body_pos", "body_mass", "body_inertia",
+                "body_invweight0", "actuator_gainprm", "actuator_forcerange", "actuator_ctrlrange", "geom_pos", "geom_margin", "geom_gap", "geom_friction", "geom_solref", "geom_solimp",
+                "tendon_range", "tendon_invweight0"]      # rb_types.h RB_P_* order (rb_prm_layout)
 PRM_NAMES = ["row", "gravity", "timestep", "dof_damping", "dof_armature", "dof_frictionloss", "dof_invweight0", "body_mass", "body_inertia", "body_invweight0",
              "jnt_range", "tendon_range", "tendon_invweight0", "actuator_gainprm", "actuator_ctrlrange", "actuator_forcerange", "geom_friction", "xfrc_applied", "site_pos", "geom_scale", "jnt_margin", "geom_solref", "geom_solimp"]
 

@@ -121,7 +121,10 @@ __global__ void __launch_bounds__(64) ra_post_step_kernel(const RbModelDev* mp, 
   const int table_contact = __ballot(table_hit) != 0;
   const float fx = sens[a.force_adr], fy = sens[a.force_adr + 1], fz = sens[a.force_adr + 2];
   const int safety = sqrtf(fx * fx + fy * fy + fz * fz) > a.safety_stop_force;
-  const int frozen = a.frozen ? a.frozen[e] : 0;   // 1: an env inside its reset recipe (pipelined resets): observation row and gripper hand-over only, outputs zeroed
+  // frozen: 1 = the first observation of a new episode (reset's _observe_sync): observation row, gripper hand-over, zeroed outputs, the success count the next step's
+  // reward is measured from; 4 = an env INSIDE its reset recipe (pipelined resets): the recipe's steps are `_set_action + mujoco_simulation.step()`
+  // (common/base.py:484-496), no _observe_sync -- observation row and zeroed outputs only, no hand-over, no goal bookkeeping
+  const int frozen = a.frozen ? a.frozen[e] : 0;
   if (lane == 0 && frozen == 3) {                  // 3: observation entries only (a live env whose goal was just replaced): reward / done / flags / counters untouched
     const int g0 = 15 * N + 15 + 2 * nq;
     row[g0 + 6 * N] = (float)(!crash && nsucc == N);
@@ -132,7 +135,7 @@ __global__ void __launch_bounds__(64) ra_post_step_kernel(const RbModelDev* mp, 
     o[0] = (float)safety;
     for (int k = 0; k < 3; k++) { o[1 + k] = sens[a.force_adr + k]; o[4 + k] = sens[a.torque_adr + k]; }
   }
-  if (lane == 0 && frozen == 1) {
+  if (lane == 0 && (frozen == 1 || frozen == 4)) {
     float* rw = a.reward + 3 * (size_t)e;
     rw[0] = rw[1] = rw[2] = 0.f;
     a.goal_dist[2 * e] = sp; a.goal_dist[2 * e + 1] = sr;
@@ -140,7 +143,7 @@ __global__ void __launch_bounds__(64) ra_post_step_kernel(const RbModelDev* mp, 
     a.info_ssl[e] = a.steps_since_last_goal[e];
     // RobotEnv.reset -> reset_goal_generation -> _observe_sync -> update_goal_info (robot_env.py:757-792, 586-593): the observation that ends a reset
     // establishes the success count the first step's goal-distance reward is measured from
-    a.prev_nsucc[e] = (float)nsucc * a.goal_reward_per_object; a.prev_valid[e] = 1;
+    if (frozen == 1) { a.prev_nsucc[e] = (float)nsucc * a.goal_reward_per_object; a.prev_valid[e] = 1; }
     const int g0 = 15 * N + 15 + 2 * nq;
     row[g0 + 6 * N] = 0.f;
     float* o = row + g0 + 21 * N + 1;
@@ -148,7 +151,7 @@ __global__ void __launch_bounds__(64) ra_post_step_kernel(const RbModelDev* mp, 
     for (int k = 0; k < 3; k++) { o[1 + k] = sens[a.force_adr + k]; o[4 + k] = sens[a.torque_adr + k]; }
     float* tail = row + a.obs_dim;
     tail[0] = tail[1] = tail[2] = tail[3] = 0.f;
-    if (a.solver_qpos) {
+    if (a.solver_qpos && frozen == 1) {
       a.solver_qpos[(size_t)e * a.solver_nq + a.solver_grip_qposadr] = qrow[a.grip_qposadr];
       a.solver_ctrl[(size_t)e * a.solver_nu + a.solver_grip_act] = crow[a.grip_act];
     }

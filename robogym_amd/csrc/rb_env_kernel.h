@@ -345,7 +345,10 @@ __global__ void __launch_bounds__(64) rb_post_step_kernel(const RbModelDev* mp, 
       const int u = lane, id = m.actuator_trnid[u];
       const float len = m.actuator_trntype[u] == 0 ? qrow[m.jnt_qposadr[id]] : S[m.off[RB_O_TENLEN] + id];
       float* st = bt.pid + ((size_t)e * nu + u) * 3;
-      for (int k = 0; k < 2; k++) rb_pid_tick(m, u, bt.ctrl[(size_t)e * nu + u], len, st);
+      // (the env's own gains when the model carries per-env parameter rows, rb_types.h RB_P_*)
+      const float* gainprm = m.prm_on ? S + m.prm_off[RB_P_ACT_GAINPRM] : m.actuator_gainprm;
+      const float* forcerange = m.prm_on ? S + m.prm_off[RB_P_ACT_FORCERANGE] : m.actuator_forcerange;
+      for (int k = 0; k < 2; k++) rb_pid_tick(m, gainprm, forcerange, u, bt.ctrl[(size_t)e * nu + u], len, st);
     }
   }
   // ---- state part of the observation row: cube_pos 3 | cube_quat 4 (w >= 0) | cube_face_angle 6 (wrapped) | hand_angle | fingertip_pos 15 (| goal_pos 3 |

@@ -20,6 +20,9 @@
 #if !defined(RB_NS) || !defined(RB_T) || !defined(RB_MAXGROUP) || !defined(RB_MAXNV) || !defined(RB_MAXNQ)
 #error "rb_kernel.h: define RB_NS, RB_T, RB_MAXGROUP, RB_MAXNV, RB_MAXNQ before including"
 #endif
+#ifndef RB_MAXNU
+#define RB_MAXNU 32      /* actuators (LDS rows ctrl, controller state, lengths, forces) */
+#endif
 
 namespace RB_NS {
 using namespace rgl;   // small math, wave collectives and the MPR / support routines of rg_kernel.h
@@ -58,9 +61,14 @@ struct RbLds {
   float yb[2 * 8];   // rb_chol_solve: the current block's solution, double-buffered
   float cst[2 * RB_CST];   // rb_hessian_add: the contact being added and the next one (basis Jacobians, block rows, weights, nnz, dim)
   float sc[RB_MAXGROUP];
-  float qpos[RB_MAXNQ], qvel[RB_MAXNV], warm[RB_MAXNV], ctrl[32], pid[96], actlen[32], actfrc[32];
-  float qfrc_passive[RB_MAXNV], qfrc_bias[RB_MAXNV], qfrc_act[RB_MAXNV], qfrc_smooth[RB_MAXNV], qacc_smooth[RB_MAXNV];
-  float qa[RB_MAXNV], Ma[RB_MAXNV], grad[RB_MAXNV], search[RB_MAXNV], Mv[RB_MAXNV], qfrc_con[RB_MAXNV], x[RB_MAXNV];
+  float qpos[RB_MAXNQ], qvel[RB_MAXNV], warm[RB_MAXNV], ctrl[RB_MAXNU], pid[3 * RB_MAXNU], actlen[RB_MAXNU], actfrc[RB_MAXNU];
+  // the force terms of the smooth dynamics are dead once qfrc_smooth is formed (sb_smooth; their stage dump sits right behind it), the solver's work vectors
+  // are born in sb_solve: they share storage (round 5: the small configuration fits 8 kB of LDS, the medium one 13 kB)
+  union { float qfrc_passive[RB_MAXNV]; float grad[RB_MAXNV]; };
+  union { float qfrc_bias[RB_MAXNV]; float search[RB_MAXNV]; };
+  union { float qfrc_act[RB_MAXNV]; float Mv[RB_MAXNV]; };
+  float qfrc_smooth[RB_MAXNV], qacc_smooth[RB_MAXNV];
+  float qa[RB_MAXNV], Ma[RB_MAXNV], qfrc_con[RB_MAXNV], x[RB_MAXNV];
   float red[16];
   float prof[16];
   int wcnt[RB_NWAVE < 4 ? 4 : RB_NWAVE];
@@ -111,6 +119,8 @@ __device__ __forceinline__ int rb_slot(RbLds& s, bool pred, int* cnt, int cap, u
 // DESIGN.md section 3.4c): in the workgroup's LDS arena if the model's placement (RB_LDS_PLACE) puts it there -- one scalar select per use of the pointer; the stage
 // functions reach their arrays through generic pointers (flat loads) either way, so nothing else changes.  Measured: per-workgroup latency falls by 1.7x, occupancy
 // by 2.3x (LDS), throughput by 17-27 %: what binds these kernels at 4 waves per SIMD is not the scratch row's latency alone.
+// a randomisable model field of this env: from the env's parameter block when the model carries per-env rows (rb_types.h RB_P_*), else the model's own array
+#define PRM(field, K) (m.prm_on ? (const float*)(S + m.prm_off[K]) : m.field)
 #define RB_ARENA_BASE ((sizeof(RbLds) + 15) & ~(size_t)15)
 #ifdef RB_LDS_ARENA
 #define SC(name) (m.lds_off[RB_O_##name] >= 0 ? RB_ARENA() + m.lds_off[RB_O_##name] : S + m.off[RB_O_##name])
@@ -138,7 +148,7 @@ __device__ __forceinline__ void rb_kinematics(RbM m, RbLds& s, float* S) {
       q4 pq; pq.w = __shfl(quat.w, p); pq.x = __shfl(quat.x, p); pq.y = __shfl(quat.y, p); pq.z = __shfl(quat.z, p);
       const v3 pp = mk3(__shfl(pos.x, p), __shfl(pos.y, p), __shfl(pos.z, p));
       if (lvl != L) continue;
-      pos = pp + qrot(pq, ld3(m.body_pos + 3 * b));
+      pos = pp + qrot(pq, ld3(PRM(body_pos, RB_P_BODY_POS) + 3 * b));
       quat = qmul(pq, ldq(m.body_quat + 4 * b));
       if (m.nmocap > 0 && m.body_mocapid[b] >= 0) { const float* mc = s.mocap + 7 * m.body_mocapid[b]; pos = ld3(mc); quat = ldq(mc + 3); }
       for (int k = 0; k < m.body_jntnum[b]; k++) {
@@ -171,7 +181,7 @@ __device__ __forceinline__ void rb_kinematics(RbM m, RbLds& s, float* S) {
     for (int q = m.b_lvl_adr[L] + TID; q < m.b_lvl_adr[L + 1]; q += RB_T) {
       const int b = m.b_lvl_body[q], p = m.body_parentid[b];
       const q4 pq = ldq(xquat + 4 * p);
-      v3 pos = ld3(xpos + 3 * p) + qrot(pq, ld3(m.body_pos + 3 * b));
+      v3 pos = ld3(xpos + 3 * p) + qrot(pq, ld3(PRM(body_pos, RB_P_BODY_POS) + 3 * b));
       q4 quat = qmul(pq, ldq(m.body_quat + 4 * b));
       if (m.nmocap > 0 && m.body_mocapid[b] >= 0) { const float* mc = s.mocap + 7 * m.body_mocapid[b]; pos = ld3(mc); quat = ldq(mc + 3); }   // mj_kinematics: mocap pose (normalised below)
       for (int k = 0; k < m.body_jntnum[b]; k++) {
@@ -200,7 +210,7 @@ __device__ __forceinline__ void rb_kinematics(RbM m, RbLds& s, float* S) {
   }
   BFOR(g, m.ngeom) {
     const int b = m.geom_bodyid[g]; const q4 xq = ldq(xquat + 4 * b);
-    st3(SC(GPOS) + 3 * g, ld3(xpos + 3 * b) + qrot(xq, ld3(m.geom_pos + 3 * g)));
+    st3(SC(GPOS) + 3 * g, ld3(xpos + 3 * b) + qrot(xq, ld3(PRM(geom_pos, RB_P_GEOM_POS) + 3 * g)));
     stq(SC(GQUAT) + 4 * g, qmul(xq, ldq(m.geom_quat + 4 * g)));
   }
   BFOR(i, m.nsite) {
@@ -213,11 +223,13 @@ __device__ __forceinline__ void rb_kinematics(RbM m, RbLds& s, float* S) {
 // mj_comPos: subtree com of every tree root, body inertias (cinert) and motion axes (cdof) in the com-based frame of the tree
 __device__ __forceinline__ void rb_com_pos(RbM m, RbLds& s, float* S) {
   float *xipos = SC(XIPOS), *rootcom = SC(ROOTCOM), *cinert = SC(CINERT), *cdof = SC(CDOF);
+  const float *body_mass = PRM(body_mass, RB_P_BODY_MASS), *body_inertia = PRM(body_inertia, RB_P_BODY_INERTIA);
   BFOR(r, m.nroot) {
     const int root = m.b_root_list[r];
     v3 acc = mk3(0, 0, 0);
-    for (int q = m.b_subtree_adr[root]; q < m.b_subtree_adr[root + 1]; q++) { const int b = m.b_subtree[q]; acc = acc + ld3(xipos + 3 * b) * m.body_mass[b]; }
-    const float sm = m.body_subtreemass[root];
+    float msum = 0.f;      // (per-env masses: the subtree's mass is summed here, in the list's order; the model's own body_subtreemass otherwise)
+    for (int q = m.b_subtree_adr[root]; q < m.b_subtree_adr[root + 1]; q++) { const int b = m.b_subtree[q]; const float mb = body_mass[b]; acc = acc + ld3(xipos + 3 * b) * mb; msum += mb; }
+    const float sm = m.prm_on ? msum : m.body_subtreemass[root];
     st3(rootcom + 3 * root, sm < RB_MINVAL ? ld3(xipos + 3 * root) : acc * (1.0f / sm));
   }
   BSYNC();
@@ -225,10 +237,10 @@ __device__ __forceinline__ void rb_com_pos(RbM m, RbLds& s, float* S) {
   for (int b = 1 + TID; b < m.nbody; b += RB_T) {
     float R[9], I[9];
     q2mat(R, ldq(SC(XIQUAT) + 4 * b));
-    const float* in = m.body_inertia + 3 * b;
+    const float* in = body_inertia + 3 * b;
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) I[3 * i + j] = R[3 * i] * in[0] * R[3 * j] + R[3 * i + 1] * in[1] * R[3 * j + 1] + R[3 * i + 2] * in[2] * R[3 * j + 2];
     const v3 d = ld3(xipos + 3 * b) - ld3(rootcom + 3 * m.body_rootid[b]);
-    const float mass = m.body_mass[b], d2 = dot(d, d);
+    const float mass = body_mass[b], d2 = dot(d, d);
     float* ci = cinert + 10 * b;
     ci[0] = I[0] + mass * (d2 - d.x * d.x); ci[1] = I[4] + mass * (d2 - d.y * d.y); ci[2] = I[8] + mass * (d2 - d.z * d.z);
     ci[3] = I[1] - mass * d.x * d.y; ci[4] = I[2] - mass * d.x * d.z; ci[5] = I[5] - mass * d.y * d.z;
@@ -329,6 +341,7 @@ __device__ __forceinline__ void rb_tendon(RbM m, RbLds& s, float* S) {
 // mj_crb: composite inertias (subtree sums, owner computes), M in tree-sparse form: entry e = (i, j = i or an ancestor of i)
 __device__ __forceinline__ void rb_crb(RbM m, RbLds& s, float* S) {
   const float* cinert = SC(CINERT); float* crb = SC(CRB);
+  const float* dof_armature = PRM(dof_armature, RB_P_DOF_ARMATURE);
   BFOR(w, 10 * m.nbody) {
     const int b = w / 10, k = w - 10 * b;
     float acc = 0;
@@ -342,7 +355,7 @@ __device__ __forceinline__ void rb_crb(RbM m, RbLds& s, float* S) {
     mul_inert_vec(buf, crb + 10 * m.dof_bodyid[i], SC(CDOF) + 6 * i);
     const float* c = SC(CDOF) + 6 * j;
     float v = c[0] * buf[0] + c[1] * buf[1] + c[2] * buf[2] + c[3] * buf[3] + c[4] * buf[4] + c[5] * buf[5];
-    if (i == j) v += m.dof_armature[i];
+    if (i == j) v += dof_armature[i];
     SC(MSP)[e] = v;
   }
   BSYNC();
@@ -758,7 +771,7 @@ __device__ __forceinline__ void rb_trees8_solve(RbM m, RbLds& s, const float* Ms
 // mj_comVel, mj_passive, mj_rne (zero acceleration: Coriolis, centrifugal, gravity)
 __device__ __forceinline__ void rb_velocity(RbM m, RbLds& s, float* S) {
   const float* cdof = SC(CDOF); float *cdofdot = SC(CDOFDOT), *cvel = SC(CVEL), *cacc = SC(CACC), *cfrc = SC(CFRC);
-  if (TID < 6) { cvel[TID] = 0.f; cacc[TID] = TID < 3 ? 0.f : -m.gravity[TID - 3]; cfrc[TID] = 0.f; }
+  if (TID < 6) { cvel[TID] = 0.f; cacc[TID] = TID < 3 ? 0.f : -PRM(opt_gravity, RB_P_GRAVITY)[TID - 3]; cfrc[TID] = 0.f; }
   BSYNC();
   const bool wave_sweep = RB_NWAVE == 1 && m.nbody <= 64;   // (as in rb_kinematics: body b in lane b, the parent's cvel / cacc by lane exchange)
   if (wave_sweep) {
@@ -766,7 +779,7 @@ __device__ __forceinline__ void rb_velocity(RbM m, RbLds& s, float* S) {
     const int p = on ? m.body_parentid[b] : 0, lvl = on ? m.b_body_level[b] : -1;
     float cv[6], ca[6];
 #pragma unroll
-    for (int c = 0; c < 6; c++) { cv[c] = 0.f; ca[c] = (b == 0 && c >= 3) ? -m.gravity[c - 3] : 0.f; }
+    for (int c = 0; c < 6; c++) { cv[c] = 0.f; ca[c] = (b == 0 && c >= 3) ? -PRM(opt_gravity, RB_P_GRAVITY)[c - 3] : 0.f; }
     for (int L = 0; L < m.nlevel; L++) {
       float pv[6], pa[6];
 #pragma unroll
@@ -833,11 +846,12 @@ __device__ __forceinline__ void rb_velocity(RbM m, RbLds& s, float* S) {
     SC(TENVEL)[t] = v;
   }
   BSYNC();
+  const float* jnt_stiffness = PRM(jnt_stiffness, RB_P_JNT_STIFFNESS);
   BFOR(i, m.nv) {
     // passive: joint spring, dof damping, tendon spring-dampers
     const int j = m.dof_jntid[i], jt = m.jnt_type[j];
-    float f = -m.dof_damping[i] * s.qvel[i];
-    if ((jt == RG_JNT_HINGE || jt == RG_JNT_SLIDE) && m.jnt_stiffness[j] != 0.f) { const int qa = m.jnt_qposadr[j]; f -= m.jnt_stiffness[j] * (s.qpos[qa] - m.qpos_spring[qa]); }
+    float f = -PRM(dof_damping, RB_P_DOF_DAMPING)[i] * s.qvel[i];
+    if ((jt == RG_JNT_HINGE || jt == RG_JNT_SLIDE) && jnt_stiffness[j] != 0.f) { const int qa = m.jnt_qposadr[j]; f -= jnt_stiffness[j] * (s.qpos[qa] - m.qpos_spring[qa]); }
     for (int t = 0; t < m.ntendon; t++) {
       const float tf = m.tendon_stiffness[t] * (m.tendon_lengthspring[t] - SC(TENLEN)[t]) - m.tendon_damping[t] * SC(TENVEL)[t];
       if (tf != 0.f) for (int e = 0; e < RB_TENW; e++) if (m.b_ten_dofs[RB_TENW * t + e] == i) f += SC(TENJ)[RB_TENW * t + e] * tf;
@@ -856,10 +870,11 @@ __device__ __forceinline__ void rb_velocity(RbM m, RbLds& s, float* S) {
 // ------------------------------------------------------------------------------------------------- actuation
 // mujoco-py's PID callback (mjpid.pyx semantics as restated by oracle ro_fwd_actuation); `apply`: also qfrc_actuator
 // one tick of one actuator's controller: st = {integral, previous error, smoothed derivative}; returns the clamped force
+// (gainprm / forcerange: the model's arrays or the env's own rows)
 template <class Model>
-__device__ __forceinline__ float rb_pid_tick(const Model& m, int u, float ctrl, float length, float* st) {
+__device__ __forceinline__ float rb_pid_tick(const Model& m, const float* gainprm, const float* forcerange, int u, float ctrl, float length, float* st) {
   const float dt = m.timestep;
-  const float* gp = m.actuator_gainprm + 10 * u;
+  const float* gp = gainprm + 10 * u;
   const float kp = gp[0], ti = gp[1], iclamp = gp[2], td = gp[3], smooth = gp[4], deadband = gp[5];
   float err = ctrl - length;
   if (fabsf(err) < deadband) err = 0.f;
@@ -867,7 +882,7 @@ __device__ __forceinline__ float rb_pid_tick(const Model& m, int u, float ctrl, 
   const float deriv = (1.f - smooth) * st[2] + smooth * (err - st[1]) / dt;
   float force = kp * (err + (ti != 0.f ? integ / ti : 0.f) + td * deriv);
   st[0] = integ; st[1] = err; st[2] = deriv;
-  const float lo = m.actuator_forcerange[2 * u], hi = m.actuator_forcerange[2 * u + 1];
+  const float lo = forcerange[2 * u], hi = forcerange[2 * u + 1];
   if (lo != 0.f || hi != 0.f) force = clampf(force, lo, hi);
   if (m.actuator_forcelimited[u]) force = clampf(force, lo, hi);
   return force;
@@ -878,9 +893,9 @@ __device__ __forceinline__ float rb_pid_tick(const Model& m, int u, float ctrl, 
 // +- max_vel -> PI on actuator_velocity -> plus `bias_ff`, the bias force (gravity + Coriolis) of the actuated dof over the gear -> clamped to forcerange.
 // (The feed-forward is inferred from the reference's impulse-response pins, oracle/rg_oracle.c ro_cascade_bias_ff: the wrist joints' velocity loops are P-only.)
 template <class Model>
-__device__ __forceinline__ float rb_cascade_tick(const Model& m, int u, float ctrl, float length, float velocity, float bias_ff, bool time0, float* st) {
+__device__ __forceinline__ float rb_cascade_tick(const Model& m, const float* gainprm, const float* forcerange, int u, float ctrl, float length, float velocity, float bias_ff, bool time0, float* st) {
   const float dt = m.timestep;
-  const float* gp = m.actuator_gainprm + 10 * u;
+  const float* gp = gainprm + 10 * u;
   const float setp = time0 ? ctrl : gp[8] * st[2] + (1.f - gp[8]) * ctrl;
   st[2] = setp;
   float des_vel;
@@ -895,12 +910,13 @@ __device__ __forceinline__ float rb_cascade_tick(const Model& m, int u, float ct
   const float integv = clampf(st[1] + errv * dt, -gp[7], gp[7]);
   float force = gp[5] * (errv + (gp[6] != 0.f ? integv / gp[6] : 0.f)) + bias_ff;
   st[1] = integv;
-  const float lo = m.actuator_forcerange[2 * u], hi = m.actuator_forcerange[2 * u + 1];
+  const float lo = forcerange[2 * u], hi = forcerange[2 * u + 1];
   if (lo != 0.f || hi != 0.f) force = clampf(force, lo, hi);
   if (m.actuator_forcelimited[u]) force = clampf(force, lo, hi);
   return force;
 }
 __device__ __forceinline__ void rb_pid(RbM m, RbLds& s, float* S, bool apply) {
+  const float *gainprm = PRM(actuator_gainprm, RB_P_ACT_GAINPRM), *forcerange = PRM(actuator_forcerange, RB_P_ACT_FORCERANGE);
   BFOR(u, m.nu) {
     if (m.actuator_user[u] == 1.f) {
       const int id = m.actuator_trnid[u];
@@ -909,8 +925,8 @@ __device__ __forceinline__ void rb_pid(RbM m, RbLds& s, float* S, bool apply) {
       // (a state-less tick, apply == false, keeps only the controller state, which the feed-forward never enters: it is not read there — the TCP
       // hook's sync tick runs before any stage of the launch has written qfrc_bias)
       const float ff = (apply && joint) ? s.qfrc_bias[m.jnt_dofadr[id]] / m.actuator_gear[u] : 0.f;
-      s.actfrc[u] = rb_cascade_tick(m, u, s.ctrl[u], s.actlen[u], vel, ff, s.time == 0.f, s.pid + 3 * u);
-    } else s.actfrc[u] = rb_pid_tick(m, u, s.ctrl[u], s.actlen[u], s.pid + 3 * u);
+      s.actfrc[u] = rb_cascade_tick(m, gainprm, forcerange, u, s.ctrl[u], s.actlen[u], vel, ff, s.time == 0.f, s.pid + 3 * u);
+    } else s.actfrc[u] = rb_pid_tick(m, gainprm, forcerange, u, s.ctrl[u], s.actlen[u], s.pid + 3 * u);
   }
   BSYNC();
   if (!apply) return;
@@ -940,6 +956,7 @@ __device__ __forceinline__ void rb_make_frame(float* f) {   // mju_makeFrame: f[
 // coupling (1 row: q1 - q1_0 - poly(q2 - q2_0)).  Residuals in frame[0..5], diagApprox (translational, rotational) in friction[0..1].
 __device__ __forceinline__ void rb_equality(RbM m, RbLds& s, float* S, const float* eq_data, const int* eq_active) {
   float* con = SC(CON);
+  const float *biw = PRM(body_invweight0, RB_P_BODY_INVWEIGHT0), *diw = PRM(dof_invweight0, RB_P_DOF_INVWEIGHT0);
   if (TID == 0) {
     int n = 0;
     for (int e = 0; e < m.neq; e++) {
@@ -959,16 +976,16 @@ __device__ __forceinline__ void rb_equality(RbM m, RbLds& s, float* S, const flo
         q4 qc; qc.w = q2.w; qc.x = -q2.x; qc.y = -q2.y; qc.z = -q2.z;
         const q4 r = qmul(qc, qmul(q1, ldq(data + 3)));
         C[RB_CR_FRAME + 3] = r.x; C[RB_CR_FRAME + 4] = r.y; C[RB_CR_FRAME + 5] = r.z;
-        C[RB_CR_FRIC] = m.body_invweight0[2 * o1] + m.body_invweight0[2 * o2]; C[RB_CR_FRIC + 1] = m.body_invweight0[2 * o1 + 1] + m.body_invweight0[2 * o2 + 1];
+        C[RB_CR_FRIC] = biw[2 * o1] + biw[2 * o2]; C[RB_CR_FRIC + 1] = biw[2 * o1 + 1] + biw[2 * o2 + 1];
         C[RB_CR_DIM] = 6.f;
       } else {                          // mjEQ_JOINT
         const int qa1 = m.jnt_qposadr[o1];
-        float pos = s.qpos[qa1] - m.qpos0[qa1] - data[0], deriv = 0.f, diag = m.dof_invweight0[m.jnt_dofadr[o1]];
+        float pos = s.qpos[qa1] - m.qpos0[qa1] - data[0], deriv = 0.f, diag = diw[m.jnt_dofadr[o1]];
         if (o2 >= 0) {
           const int qa2 = m.jnt_qposadr[o2]; const float dif = s.qpos[qa2] - m.qpos0[qa2];
           pos -= data[1] * dif + data[2] * dif * dif + data[3] * dif * dif * dif + data[4] * dif * dif * dif * dif;
           deriv = data[1] + 2.f * data[2] * dif + 3.f * data[3] * dif * dif + 4.f * data[4] * dif * dif * dif;
-          diag += m.dof_invweight0[m.jnt_dofadr[o2]];
+          diag += diw[m.jnt_dofadr[o2]];
         }
         C[RB_CR_FRAME] = pos; C[RB_CR_FRAME + 1] = deriv; C[RB_CR_FRIC] = diag; C[RB_CR_DIM] = 1.f;
       }
@@ -1018,6 +1035,26 @@ __device__ __forceinline__ bool rb_obb_apart(v3 ca, q4 qa, v3 ha, v3 cb, q4 qb, 
   return apart;
 }
 // mj_collision in three parts (each a stage call of its own, RB_STAGE wrappers below): broadphase, the support-map narrowphase, the multi-point box routines
+// mixed contact parameters of static pair p (mj_contactParam; kernel_tables.py collision_pairs is the host statement): out = margin, gap, friction 3, solref 2,
+// solimp 5.  The model's precomputed table, or -- per-env geom rows -- the same mixing on the env's own geom_margin / gap / friction / solref / solimp.
+__device__ __forceinline__ float rb_pair_margin(RbM m, const float* S, int p) {
+  if (!m.prm_on) return m.b_pair_prm[12 * p];
+  const float* gm = S + m.prm_off[RB_P_GEOM_MARGIN];
+  return fmaxf(gm[m.b_pair_geom[3 * p]], gm[m.b_pair_geom[3 * p + 1]]);
+}
+__device__ __forceinline__ void rb_pair_prm(RbM m, const float* S, int p, float* out) {
+  if (!m.prm_on) { for (int k = 0; k < 12; k++) out[k] = m.b_pair_prm[12 * p + k]; return; }
+  const int a = m.b_pair_geom[3 * p], b = m.b_pair_geom[3 * p + 1];
+  const float *gm = S + m.prm_off[RB_P_GEOM_MARGIN], *gg = S + m.prm_off[RB_P_GEOM_GAP], *gf = S + m.prm_off[RB_P_GEOM_FRICTION];
+  const float *gr = S + m.prm_off[RB_P_GEOM_SOLREF], *gi = S + m.prm_off[RB_P_GEOM_SOLIMP];
+  out[0] = fmaxf(gm[a], gm[b]); out[1] = fmaxf(gg[a], gg[b]);
+  for (int k = 0; k < 3; k++) out[2 + k] = fmaxf(gf[3 * a + k], gf[3 * b + k]);
+  const float m1 = m.geom_solmix[a], m2 = m.geom_solmix[b];
+  const float mix = (m1 >= 1e-15f && m2 >= 1e-15f) ? m1 / (m1 + m2) : ((m1 < 1e-15f && m2 < 1e-15f) ? 0.5f : (m1 < 1e-15f ? 0.f : 1.f));
+  if (gr[2 * a] > 0.f && gr[2 * b] > 0.f) { out[5] = mix * gr[2 * a] + (1.f - mix) * gr[2 * b]; out[6] = mix * gr[2 * a + 1] + (1.f - mix) * gr[2 * b + 1]; }
+  else { out[5] = fminf(gr[2 * a], gr[2 * b]); out[6] = fminf(gr[2 * a + 1], gr[2 * b + 1]); }
+  for (int k = 0; k < 5; k++) out[7 + k] = mix * gi[5 * a + k] + (1.f - mix) * gi[5 * b + k];
+}
 __device__ __forceinline__ void rb_broadphase(RbM m, RbLds& s, float* S, int flags) {
   int* cand = (int*)SC(CAND);
   const float *gpos = SC(GPOS), *gquat = SC(GQUAT);
@@ -1033,7 +1070,7 @@ __device__ __forceinline__ void rb_broadphase(RbM m, RbLds& s, float* S, int fla
     bool keep = false, special = false;
     if (p < m.npair) {
       const int g1 = m.b_pair_geom[3 * p], g2 = m.b_pair_geom[3 * p + 1], t1 = m.geom_type[g1];
-      const float margin = m.b_pair_prm[12 * p];
+      const float margin = rb_pair_margin(m, S, p);
       const v3 P1 = ld3(gpos + 3 * g1), P2 = ld3(gpos + 3 * g2), dif = P2 - P1;
       const float* bb = m.b_geom_aabb + 6 * g2;
       if (t1 == RG_GEOM_PLANE) {
@@ -1083,7 +1120,7 @@ __device__ __forceinline__ void rb_narrow_convex(RbM m, RbLds& s, float* S, int 
     if (active) {
       p = cand[ci];
       const int g1 = m.b_pair_geom[3 * p], g2 = m.b_pair_geom[3 * p + 1];
-      margin = m.b_pair_prm[12 * p];
+      margin = rb_pair_margin(m, S, p);
       rb_geom(m, S, g1, A); rb_geom(m, S, g2, B);
       p1 = ld3(gpos + 3 * g1);
       A.pos = mk3(0, 0, 0); B.pos = ld3(gpos + 3 * g2) - p1;
@@ -1109,7 +1146,7 @@ __device__ __forceinline__ void rb_narrow_convex(RbM m, RbLds& s, float* S, int 
     const int slot = rb_slot(s, hit && (TID & 3) == 0, &s.ncon, m.maxcon, RG_STATUS_CON_FULL);
     if (slot >= 0) {
       float* c = con + RB_CONREC * slot;
-      const float* pr = m.b_pair_prm + 12 * p;
+      float pr[12]; rb_pair_prm(m, S, p, pr);
       c[RB_CR_DIST] = dist; st3(c + RB_CR_POS, pos);
       float fr[9]; fr[0] = nrm.x; fr[1] = nrm.y; fr[2] = nrm.z; rb_make_frame(fr);
       for (int k = 0; k < 9; k++) c[RB_CR_FRAME + k] = fr[k];
@@ -1138,7 +1175,7 @@ __device__ __forceinline__ void rb_narrow_box(RbM m, RbLds& s, float* S, int fla
         p = cand[m.maxcand - 1 - ci];
         const int g1 = m.b_pair_geom[3 * p], g2 = m.b_pair_geom[3 * p + 1], t1 = m.geom_type[g1];
         if (m.geom_type[g2] == RG_GEOM_BOX && (t1 == RG_GEOM_BOX || t1 == RG_GEOM_PLANE)) {
-          const float margin = m.b_pair_prm[12 * p];
+          const float margin = rb_pair_margin(m, S, p);
           const v3 P1 = ld3(gpos + 3 * g1), t = ld3(gpos + 3 * g2) - P1;
           if (t1 == RG_GEOM_BOX) {
             const float A[3] = {m.geom_size[3 * g1], m.geom_size[3 * g1 + 1], m.geom_size[3 * g1 + 2]}, B[3] = {m.geom_size[3 * g2], m.geom_size[3 * g2 + 1], m.geom_size[3 * g2 + 2]};
@@ -1156,7 +1193,7 @@ __device__ __forceinline__ void rb_narrow_box(RbM m, RbLds& s, float* S, int fla
       const int slot = rb_slot(s, hit, &s.ncon, m.maxcon, RG_STATUS_CON_FULL);
       if (slot >= 0) {
         float* c = con + RB_CONREC * slot;
-        const float* pr = m.b_pair_prm + 12 * p;
+        float pr[12]; rb_pair_prm(m, S, p, pr);
         c[RB_CR_DIST] = dist; st3(c + RB_CR_POS, pos);
         const v3 nn = normalized(nrm);
         float fr[9]; fr[0] = nn.x; fr[1] = nn.y; fr[2] = nn.z; rb_make_frame(fr);
@@ -1196,6 +1233,7 @@ __device__ __forceinline__ float rb_srow_dot(RbM m, const float* S, int type, in
 // contacts); per contact the six basis Jacobian rows (3 translational, 3 rotational, contact frame) on the union of the dof chains
 __device__ __forceinline__ void rb_make_constraint(RbM m, RbLds& s, float* S, const float* L_eq_data) {
   float* row = SC(ROW); float* con = SC(CON);
+  const float *biw = PRM(body_invweight0, RB_P_BODY_INVWEIGHT0), *diw = PRM(dof_invweight0, RB_P_DOF_INVWEIGHT0), *tiw = PRM(tendon_invweight0, RB_P_TENDON_INVWEIGHT0);
   const int nf = m.nfric_dof + m.nfric_ten;
   // friction-loss rows
   BFOR(r, nf) {
@@ -1204,7 +1242,7 @@ __device__ __forceinline__ void rb_make_constraint(RbM m, RbLds& s, float* S, co
     const int id = ten ? m.b_fric_ten[r - m.nfric_dof] : m.b_fric_dof[r];
     const float* solref = ten ? m.tendon_solref_fri + 2 * id : m.dof_solref + 2 * id;
     const float* solimp = ten ? m.tendon_solimp_fri + 5 * id : m.dof_solimp + 5 * id;
-    const float diag = ten ? m.tendon_invweight0[id] : m.dof_invweight0[id], floss = ten ? m.tendon_frictionloss[id] : m.dof_frictionloss[id];
+    const float diag = ten ? tiw[id] : diw[id], floss = ten ? m.tendon_frictionloss[id] : PRM(dof_frictionloss, RB_P_DOF_FRICTIONLOSS)[id];
     const float imp = rb_impedance(solimp, 0.f, 0.f);
     const float Rr = fmaxf(RB_MINVAL, (1.f - imp) * diag / imp);
     float K, B; rb_KB(m.timestep, solref, solimp, K, B);
@@ -1218,15 +1256,15 @@ __device__ __forceinline__ void rb_make_constraint(RbM m, RbLds& s, float* S, co
       const bool ten = q >= m.nlim_jnt;
       const int id = ten ? m.b_lim_ten[q - m.nlim_jnt] : m.b_lim_jnt[q];
       const float value = ten ? SC(TENLEN)[id] : s.qpos[m.jnt_qposadr[id]];
-      const float* range = ten ? m.tendon_range + 2 * id : m.jnt_range + 2 * id;
-      const float margin = ten ? m.tendon_margin[id] : m.jnt_margin[id];
+      const float* range = ten ? PRM(tendon_range, RB_P_TENDON_RANGE) + 2 * id : PRM(jnt_range, RB_P_JNT_RANGE) + 2 * id;
+      const float margin = ten ? m.tendon_margin[id] : PRM(jnt_margin, RB_P_JNT_MARGIN)[id];
       for (int side = -1; side <= 1; side += 2) {
         const float dist = side * (range[(side + 1) / 2] - value);
         if (dist < margin && n < m.maxrow) {
           float* R = row + RB_ROWREC * n;
           const float* solref = ten ? m.tendon_solref_lim + 2 * id : m.jnt_solref + 2 * id;
           const float* solimp = ten ? m.tendon_solimp_lim + 5 * id : m.jnt_solimp + 5 * id;
-          const float diag = ten ? m.tendon_invweight0[id] : m.dof_invweight0[m.jnt_dofadr[id]];
+          const float diag = ten ? tiw[id] : diw[m.jnt_dofadr[id]];
           const float imp = rb_impedance(solimp, dist, margin);
           const float Rr = fmaxf(RB_MINVAL, (1.f - imp) * diag / imp);
           float K, B; rb_KB(m.timestep, solref, solimp, K, B);
@@ -1320,7 +1358,7 @@ __device__ __forceinline__ void rb_make_constraint(RbM m, RbLds& s, float* S, co
     const int adr = (int)C[RB_CR_ADR];
     if (adr < 0) continue;
     const int dim = (int)C[RB_CR_DIM], np = rb_npyr(dim);
-    const float tran = m.body_invweight0[2 * b1] + m.body_invweight0[2 * b2], rot = m.body_invweight0[2 * b1 + 1] + m.body_invweight0[2 * b2 + 1];
+    const float tran = biw[2 * b1] + biw[2 * b2], rot = biw[2 * b1 + 1] + biw[2 * b2 + 1];
     const float dist = C[RB_CR_DIST], incl = C[RB_CR_INCL];
     const float imp = rb_impedance(C + RB_CR_SOLIMP, dist, incl);
     float K, B; rb_KB(m.timestep, C + RB_CR_SOLREF, C + RB_CR_SOLIMP, K, B);
@@ -1926,7 +1964,7 @@ RB_STAGE float sv_line_search(RbCtx c, float gauss, float q1, float q2, float gt
 // dst = inv(M + h B) src of every group: mode 0 qacc_smooth = inv(M) qfrc_smooth (h = 0), mode 1 search = inv(M + h B) grad (the Euler step)
 RB_STAGE void sv_M_solve(RbCtx c, int mode, int flags) {
   RB_STAGE_ENTER();
-  const float* diag = mode ? m.dof_damping : (const float*)0; const float h = mode ? m.timestep : 0.f;
+  const float* diag = mode ? PRM(dof_damping, RB_P_DOF_DAMPING) : (const float*)0; const float h = mode ? m.timestep : 0.f;
   const float* src = mode ? s.grad : s.qfrc_smooth; float* dst = mode ? s.search : s.qacc_smooth;
   if (m.b_tree8[0] > 0 && !(flags & 4)) { rb_trees8_solve(m, s, SC(MSP), diag, h, src, dst, 1.f); return; }
   for (int grp = 0; grp < m.ngroup; grp++) {
@@ -2039,7 +2077,7 @@ __device__ __forceinline__ void rb_euler(RbCtx cx, RbM m, RbLds& s, float* S, in
 __device__ __forceinline__ void rb_sensors(RbM m, RbLds& s, float* S, float* out) {
   const float *cdof = SC(CDOF), *cdofdot = SC(CDOFDOT), *cvel = SC(CVEL), *rootcom = SC(ROOTCOM), *con = SC(CON), *row = SC(ROW);
   float *cacc = SC(CACC), *cfrc = SC(CFRC), *cext = SC(CFRCEXT);
-  if (TID < 6) { cacc[TID] = TID < 3 ? 0.f : -m.gravity[TID - 3]; cfrc[TID] = 0.f; }
+  if (TID < 6) { cacc[TID] = TID < 3 ? 0.f : -PRM(opt_gravity, RB_P_GRAVITY)[TID - 3]; cfrc[TID] = 0.f; }
   BFOR(b, m.nbody) {
     float acc[6] = {0, 0, 0, 0, 0, 0};
     for (int c = 0; c < s.ncon; c++) {
@@ -2156,7 +2194,7 @@ __global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbMod
   }
   BFOR(u, nu) {
     if (use_action) {
-      const float lo = m.actuator_ctrlrange[2 * u], hi = m.actuator_ctrlrange[2 * u + 1];
+      const float lo = PRM(actuator_ctrlrange, RB_P_ACT_CTRLRANGE)[2 * u], hi = PRM(actuator_ctrlrange, RB_P_ACT_CTRLRANGE)[2 * u + 1];
       float centre;
       if (L.env.relative_action) { centre = 0; for (int j = 0; j < L.env.n_hand_jnt; j++) centre += L.env.pos_to_ctrl[u * L.env.n_hand_jnt + j] * s.qpos[L.env.hand_qposadr + j]; }
       else centre = 0.5f * (hi + lo);
@@ -2204,7 +2242,7 @@ __global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbMod
       const float mpc = L.tcp.max_position_change;
       const float a0 = clampf(a[0], -1.f, 1.f), a1 = clampf(a[1], -1.f, 1.f), a2 = clampf(a[2], -1.f, 1.f), a3 = clampf(a[3], -1.f, 1.f), a4 = clampf(a[4], -1.f, 1.f);
       const float roll = a3 * L.tcp.speed[0] * mpc;
-      const float q6 = s.qpos[L.tcp.arm_q[5]], lo = m.jnt_range[2 * L.tcp.wrist_jnt], hi = m.jnt_range[2 * L.tcp.wrist_jnt + 1];
+      const float q6 = s.qpos[L.tcp.arm_q[5]], lo = PRM(jnt_range, RB_P_JNT_RANGE)[2 * L.tcp.wrist_jnt], hi = PRM(jnt_range, RB_P_JNT_RANGE)[2 * L.tcp.wrist_jnt + 1];
       const float pitch = clampf(a4 * L.tcp.speed[1] * mpc, lo + L.tcp.drift_threshold - q6, hi - L.tcp.drift_threshold - q6);   // FreeDOFTcpArm.constrain_quat_ctrl
       // MocapSolver.get_tcp_quat: euler = (roll, 0, pitch dimension) -> qx(roll) * qz(.), applied on the right of the TCP's orientation; mocap_set_action
       // adds the DIFFERENCE to the mocap quaternion, which reset_mocap2body_xpos has just set to the TCP's own pose

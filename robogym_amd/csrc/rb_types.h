@@ -49,6 +49,7 @@
   X(tendon_solref_lim) X(tendon_solimp_lim) X(tendon_solref_fri) X(tendon_solimp_fri) X(tendon_invweight0) \
   X(actuator_gear) X(actuator_ctrlrange) X(actuator_forcerange) X(actuator_gainprm) X(actuator_user) \
   X(eq_solref) X(eq_solimp) X(site_quat) \
+  X(geom_margin) X(geom_gap) X(geom_friction) X(geom_solref) X(geom_solimp) X(geom_solmix) X(opt_gravity) \
   X(b_pair_prm) X(b_geom_aabb) X(b_mesh_rec) X(b_cell_blk) X(b_cell_ovf)
 
 // per-env scratch row: offsets (in 4-byte words) of the stage arrays
@@ -57,7 +58,16 @@ enum {
   RB_O_CINERT, RB_O_CRB, RB_O_CDOF, RB_O_CDOFDOT, RB_O_CVEL, RB_O_CACC, RB_O_CFRC,
   RB_O_TENLEN, RB_O_TENJ, RB_O_TENVEL, RB_O_MSP,
   RB_O_CAND, RB_O_CON, RB_O_CONJ, RB_O_CONIDX, RB_O_ROW, RB_O_DOFCON_ADR, RB_O_DOFCON, RB_O_CONF,
-  RB_O_DBG, RB_O_CFRCEXT, RB_O_CONLOC, RB_NOFF
+  RB_O_DBG, RB_O_CFRCEXT, RB_O_CONLOC, RB_O_PRM, RB_NOFF
+};
+// Per-env model parameters (SURVEY 8f rank 2 on this stepper; what `sim.model.<field>` writes of the reference's randomizers reach:
+// /root/reference/robogym/envs/rearrange/common/base.py:1008-1092, randomization/sim.py:115-589).  A model switched on by rb_model_enable_env_params gives every
+// env a block RB_O_PRM of its scratch row that holds these fields (initialised with the model's values, written by the host through rb_batch_field_ptr);
+// the kernel then reads them from the block instead of from the model's arrays.  Offsets of the fields inside the block: RbModelDev.prm_off.
+enum {
+  RB_P_GRAVITY, RB_P_DOF_DAMPING, RB_P_DOF_ARMATURE, RB_P_DOF_FRICTIONLOSS, RB_P_DOF_INVWEIGHT0, RB_P_JNT_STIFFNESS, RB_P_JNT_MARGIN, RB_P_JNT_RANGE,
+  RB_P_BODY_POS, RB_P_BODY_MASS, RB_P_BODY_INERTIA, RB_P_BODY_INVWEIGHT0, RB_P_ACT_GAINPRM, RB_P_ACT_FORCERANGE, RB_P_ACT_CTRLRANGE,
+  RB_P_GEOM_POS, RB_P_GEOM_MARGIN, RB_P_GEOM_GAP, RB_P_GEOM_FRICTION, RB_P_GEOM_SOLREF, RB_P_GEOM_SOLIMP, RB_P_TENDON_RANGE, RB_P_TENDON_INVWEIGHT0, RB_NPRMF
 };
 // per contact record (floats): dist, pos3, frame9, includemargin, friction5, solref2, solimp5, dim, geom1, geom2, efc_address, nnz, kind
 // kind: 0 pyramidal contact, 1 elliptic contact (ur16e/base.xml:3), 2 equality constraint (weld: dim 6, joint coupling: dim 1) — an
@@ -111,6 +121,9 @@ struct RbModelDev {
   // instead of the env's HBM scratch row, and are copied out to the row (lds_len[k] words) when the launch ends, for the env kernel and the host readers.
   int lds_off[RB_NOFF], lds_len[RB_NOFF];
   int lds_words;                     // arena size
+  int prm_on;                        // per-env parameter blocks in the scratch rows (rb_model_enable_env_params)
+  int prm_off[RB_NPRMF];             // word offset of each field from the start of the scratch row
+  int prm_words;
 #define X(n) const int* n;
   RB_INT_ARRAYS(X)
 #undef X

@@ -111,6 +111,9 @@ static const char* hipGetErrorString(hipError_t) { return "emul"; }
 #define RB_CONW_LARGE RB_CONW
 #undef RB_CONW
 #define RB_CONW RB_CONW_ONEWAVE
+#define RB_MAXNU_ONEWAVE 8   /* the rearrange worlds have 7 and 1 actuators; a model with more runs on the large configuration */
+#undef RB_MAXNU
+#define RB_MAXNU RB_MAXNU_ONEWAVE
 #define RB_NS rgbs           /* small configuration: one wave per env, 16 envs per CU (the rearrange worlds) */
 #define RB_T RB_T_SMALL
 #define RB_MAXGROUP RB_MAXGROUP_SMALL
@@ -140,6 +143,7 @@ static const char* hipGetErrorString(hipError_t) { return "emul"; }
 #undef RB_MAXNV
 #undef RB_MAXNQ
 #undef RB_WG_PER_CU
+#undef RB_MAXNU
 #undef RB_CONW
 #define RB_CONW 24           /* (= rb_types.h; the env kernels and the host code below see the large configuration's width unless they ask per model) */
 #include "rb_env_kernel.h"
@@ -915,6 +919,9 @@ struct rb_model {
   std::vector<int> eq_active0;
   int config = 0;   // 0: large configuration of rb_kernel.h, 1: small, 2: medium
   std::vector<std::string> blob_keys;
+  std::vector<float> prm_default;   // the model's own values in the layout of an env's parameter block (RB_P_* order)
+  int prm_len[RB_NPRMF] = {0};      // words of each field
+  int nbatches = 0;                 // batches created from this model (the per-env parameter switch must precede them)
 };
 struct rb_batch {
   const rb_model* model;
@@ -936,6 +943,29 @@ void rb_model_free(rb_model* m) {
   if (!m) return;
   { DeviceGuard g(m->device); for (void* p : m->allocs) hipFree(p); }
   delete m;
+}
+// the per-env scratch row: stage arrays at the model's capacities, then (models switched to per-env parameters) the env's parameter block
+static void rb_layout(rb_model* m) {
+  RbModelDev& d = m->dev;
+  int o = 0;
+  auto take = [&](int which, int words) { d.off[which] = o; o += (words + 3) & ~3; };
+  take(RB_O_XPOS, 3 * d.nbody); take(RB_O_XQUAT, 4 * d.nbody); take(RB_O_XIPOS, 3 * d.nbody); take(RB_O_XIQUAT, 4 * d.nbody);
+  take(RB_O_XANCHOR, 3 * d.njnt); take(RB_O_XAXIS, 3 * d.njnt); take(RB_O_GPOS, 3 * d.ngeom); take(RB_O_GQUAT, 4 * d.ngeom); take(RB_O_SPOS, 3 * d.nsite);
+  take(RB_O_ROOTCOM, 3 * d.nbody); take(RB_O_CINERT, 10 * d.nbody); take(RB_O_CRB, 10 * d.nbody); take(RB_O_CDOF, 6 * d.nv); take(RB_O_CDOFDOT, 6 * d.nv);
+  take(RB_O_CVEL, 6 * d.nbody); take(RB_O_CACC, 6 * d.nbody); take(RB_O_CFRC, 6 * d.nbody);
+  take(RB_O_TENLEN, d.ntendon); take(RB_O_TENJ, RB_TENW * d.ntendon); take(RB_O_TENVEL, d.ntendon); take(RB_O_MSP, d.nM);
+  const int cw = m->config ? RB_CONW_ONEWAVE : RB_CONW;      // dofs per contact row the model's configuration is compiled for
+  take(RB_O_CAND, d.maxcand); take(RB_O_CON, RB_CONREC * d.maxcon); take(RB_O_CONJ, 6 * cw * d.maxcon); take(RB_O_CONIDX, cw * d.maxcon);
+  take(RB_O_ROW, RB_ROWREC * d.maxrow); take(RB_O_DOFCON_ADR, d.nv + 1); take(RB_O_DOFCON, cw * d.maxcon); take(RB_O_CONF, RB_NW * d.maxcon); take(RB_O_DBG, 8 + 5 * d.nv + 16); take(RB_O_CFRCEXT, 6 * d.nbody); take(RB_O_CONLOC, cw * d.maxcon);
+  d.prm_words = 0;
+  for (int k = 0; k < RB_NPRMF; k++) d.prm_off[k] = 0;
+  d.off[RB_O_PRM] = o;
+  if (d.prm_on) {
+    int w = 0;
+    for (int k = 0; k < RB_NPRMF; k++) { d.prm_off[k] = o + w; w += (m->prm_len[k] + 3) & ~3; }
+    d.prm_words = w; o += w;
+  }
+  d.scratch_words = o;
 }
 rb_model* rb_model_create(const void* blob, size_t nbytes, char* err, int errlen) {
   auto bail = [&](const std::string& msg, rb_model* m) -> rb_model* {
@@ -971,7 +1001,7 @@ rb_model* rb_model_create(const void* blob, size_t nbytes, char* err, int errlen
     for (size_t t = 0; t < te.size() && 4 * t + 3 < td.size(); t++) tmax = std::max(tmax, te[t] - td[4 * t + 3]);
     const char* force = getenv("RB_CONFIG");
     auto fits = [&](int maxgroup, int maxnv, int maxnq, int threads) {
-      return d.gmax <= maxgroup && d.nv <= maxnv && d.nq <= maxnq && tmax <= threads && 28 * tmax + 27 <= maxgroup * (maxgroup + 1) / 2 + 8 && d.conw <= RB_CONW_ONEWAVE;
+      return d.gmax <= maxgroup && d.nv <= maxnv && d.nq <= maxnq && tmax <= threads && 28 * tmax + 27 <= maxgroup * (maxgroup + 1) / 2 + 8 && d.conw <= RB_CONW_ONEWAVE && d.nu <= RB_MAXNU_ONEWAVE;
     };
     m->config = 0;
     if (!(force && !strcmp(force, "large"))) {
@@ -1021,18 +1051,16 @@ rb_model* rb_model_create(const void* blob, size_t nbytes, char* err, int errlen
     m->mocap0.assign(7 * d.nmocap, 0.f);
     for (int bb = 0; bb < d.nbody; bb++) if (mid[bb] >= 0 && mid[bb] < d.nmocap) { for (int k = 0; k < 3; k++) m->mocap0[7 * mid[bb] + k] = bp[3 * bb + k]; for (int k = 0; k < 4; k++) m->mocap0[7 * mid[bb] + 3 + k] = bq[4 * bb + k]; }
   }
-  // scratch row layout
-  int o = 0;
-  auto take = [&](int which, int words) { d.off[which] = o; o += (words + 3) & ~3; };
-  take(RB_O_XPOS, 3 * d.nbody); take(RB_O_XQUAT, 4 * d.nbody); take(RB_O_XIPOS, 3 * d.nbody); take(RB_O_XIQUAT, 4 * d.nbody);
-  take(RB_O_XANCHOR, 3 * d.njnt); take(RB_O_XAXIS, 3 * d.njnt); take(RB_O_GPOS, 3 * d.ngeom); take(RB_O_GQUAT, 4 * d.ngeom); take(RB_O_SPOS, 3 * d.nsite);
-  take(RB_O_ROOTCOM, 3 * d.nbody); take(RB_O_CINERT, 10 * d.nbody); take(RB_O_CRB, 10 * d.nbody); take(RB_O_CDOF, 6 * d.nv); take(RB_O_CDOFDOT, 6 * d.nv);
-  take(RB_O_CVEL, 6 * d.nbody); take(RB_O_CACC, 6 * d.nbody); take(RB_O_CFRC, 6 * d.nbody);
-  take(RB_O_TENLEN, d.ntendon); take(RB_O_TENJ, RB_TENW * d.ntendon); take(RB_O_TENVEL, d.ntendon); take(RB_O_MSP, d.nM);
-  const int cw = m->config ? RB_CONW_ONEWAVE : RB_CONW;      // dofs per contact row the model's configuration is compiled for
-  take(RB_O_CAND, d.maxcand); take(RB_O_CON, RB_CONREC * d.maxcon); take(RB_O_CONJ, 6 * cw * d.maxcon); take(RB_O_CONIDX, cw * d.maxcon);
-  take(RB_O_ROW, RB_ROWREC * d.maxrow); take(RB_O_DOFCON_ADR, d.nv + 1); take(RB_O_DOFCON, cw * d.maxcon); take(RB_O_CONF, RB_NW * d.maxcon); take(RB_O_DBG, 8 + 5 * d.nv + 16); take(RB_O_CFRCEXT, 6 * d.nbody); take(RB_O_CONLOC, cw * d.maxcon);
-  d.scratch_words = o;
+  {  // the model's own values of the per-env parameter fields, in block order (rb_types.h RB_P_*)
+    static const char* fields[RB_NPRMF] = {"opt_gravity", "dof_damping", "dof_armature", "dof_frictionloss", "dof_invweight0", "jnt_stiffness", "jnt_margin", "jnt_range",
+                                           "body_pos", "body_mass", "body_inertia", "body_invweight0", "actuator_gainprm", "actuator_forcerange", "actuator_ctrlrange",
+                                           "geom_pos", "geom_margin", "geom_gap", "geom_friction", "geom_solref", "geom_solimp", "tendon_range", "tendon_invweight0"};
+    std::vector<std::vector<float>> vals(RB_NPRMF);
+    for (int k = 0; k < RB_NPRMF; k++) { if (!get_f(B, fields[k], vals[k], e)) return bail(e, m); m->prm_len[k] = (int)vals[k].size(); }
+    m->prm_default.clear();
+    for (int k = 0; k < RB_NPRMF; k++) { m->prm_default.insert(m->prm_default.end(), vals[k].begin(), vals[k].end()); m->prm_default.resize((m->prm_default.size() + 3) & ~(size_t)3, 0.f); }
+  }
+  rb_layout(m);
   // ---- LDS residency of stage arrays (rb_types.h lds_off): RB_LDS_PLACE = a preset or a comma-separated list of array names.  Only arrays whose length does not
   // depend on the number of contacts / rows of the mj_step can be placed (their capacity is the model's own size).
   {
@@ -1189,6 +1217,29 @@ int rb_model_info(const rb_model* m, int* out, int n) {
   for (int i = 0; i < k && i < n; i++) out[i] = v[i];
   return k;
 }
+// Per-env model parameters on this stepper (base.py:1008-1092's randomizers write these fields of `sim.model`): switches the MODEL so that every
+// batch created from it afterwards carries a parameter block per env (rb_types.h RB_P_*, initialised with the model's values) which the kernel reads instead of
+// the model's arrays.  Must precede rb_batch_create for this model.
+int rb_model_enable_env_params(rb_model* m) {
+  if (!m) return fail("null model");
+  if (m->dev.prm_on) return 0;
+  if (m->nbatches > 0) return fail("rb_model_enable_env_params: call it before the model's first rb_batch_create");
+  DeviceGuard g(m->device);
+  m->dev.prm_on = 1;
+  rb_layout(m);
+  HIPCHK(hipMemcpy((void*)m->dev_copy, &m->dev, sizeof(RbModelDev), hipMemcpyHostToDevice));
+  return 0;
+}
+// out[0] = 1 if the model carries per-env blocks, out[1] = words of a block, then per field (RB_P_* order) its word offset in the scratch row and its length
+int rb_prm_layout(const rb_model* m, int* out, int n) {
+  if (!m || !out) return fail("rb_prm_layout: null argument");
+  const int k = 2 + 2 * RB_NPRMF;
+  std::vector<int> v(k);
+  v[0] = m->dev.prm_on; v[1] = m->dev.prm_words;
+  for (int f = 0; f < RB_NPRMF; f++) { v[2 + 2 * f] = m->dev.prm_off[f]; v[3 + 2 * f] = m->prm_len[f]; }
+  for (int i = 0; i < k && i < n; i++) out[i] = v[i];
+  return k;
+}
 int rb_scratch_offset(const rb_model* m, int which) { return (m && which >= 0 && which < RB_NOFF) ? m->dev.off[which] : -1; }
 static void* rb_balloc(rb_batch* b, size_t n) {
   void* p = nullptr;
@@ -1243,6 +1294,15 @@ rb_batch* rb_batch_create(const rb_model* m, int B) {
     if (d.neq && (hipMemcpy(s.eq_data, ed.data(), ed.size() * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(s.eq_active, ea.data(), ea.size() * 4, hipMemcpyHostToDevice) != hipSuccess)) { fail("hipMemcpy failed"); rb_batch_free(b); return nullptr; }
   }
   if (!s.qpos || !s.qvel || !s.ctrl || !s.pid || !s.qacc_warmstart || !s.time || !s.status || !s.stats || !s.scratch) { fail("hipMalloc failed"); rb_batch_free(b); return nullptr; }
+  if (d.prm_on) {   // every env's parameter block starts as the model's own values
+    std::vector<float> rows((size_t)B * d.prm_words);
+    for (int e = 0; e < B; e++) memcpy(rows.data() + (size_t)e * d.prm_words, m->prm_default.data(), (size_t)d.prm_words * 4);
+    bool ok = true;   // (one strided copy per env block: set-up time only)
+    for (int e = 0; e < B && ok; e++)
+      ok = hipMemcpy(s.scratch + (size_t)e * d.scratch_words + d.off[RB_O_PRM], rows.data() + (size_t)e * d.prm_words, (size_t)d.prm_words * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { fail("hipMemcpy failed"); rb_batch_free(b); return nullptr; }
+  }
+  const_cast<rb_model*>(m)->nbatches++;
   if (rb_batch_reset(b) != 0) { rb_batch_free(b); return nullptr; }
   return b;
 }

@@ -55,11 +55,18 @@ class BatchedBlockRearrangeEnv:
                  success_threshold=None, penalty=None, max_timesteps_per_goal_per_obj: int = 200, successes_needed: int = 5, success_reward: float = 5.0,
                  use_goal_distance_reward: bool = True, goal_reward_per_object: float = 1.0, used_table_portion: float = 1.0, lib=None, n_substeps: int = 40,
                  main_model=None, wrappers: bool = False, n_action_bins: int = 11, smooth_alpha: float = 0.3, reward_clip: float = 100.0,
-                 pipelined_reset: bool = False, action_spacing: str = "linear"):
+                 pipelined_reset: bool = False, action_spacing: str = "linear", per_env_parameters: Optional[bool] = None, randomizer_params: Optional[dict] = None,
+                 stabilize_object_damping: float = 1.0e-3):
+        """`per_env_parameters`: every env carries its own copy of the randomisable model fields (`self.sim.params`, LargeModelSimulation(env_params=True)) -- what
+        the reference's simulation randomizers and `stabilize_objects` write into `sim.model`.  None (default): on iff a randomizer parameter is non-zero.
+        `randomizer_params`: name -> parameter of `build_simulation_randomizers` (the reference's ADR-controlled values; all zero by default = identity)."""
         self.B, self.N = int(batch_size), int(num_objects)
         self._L = lib if lib is not None else _native.lib()
         main, solver = (main_model if main_model is not None else load_blocks_model(self.N)), load_solver_model()   # (main_model: the same world with other objects, envs/rearrange/ycb.py)
-        self.sim = LargeModelSimulation(main, self.B, device=device, n_substeps=n_substeps, lib=lib, hand=False)
+        self.randomizer_params = dict(randomizer_params or {})
+        nonzero = any(np.any(np.asarray(v, dtype=np.float64) != 0) for v in self.randomizer_params.values())
+        self.per_env_parameters = bool(nonzero if per_env_parameters is None else per_env_parameters)
+        self.sim = LargeModelSimulation(main, self.B, device=device, n_substeps=n_substeps, lib=lib, hand=False, env_params=self.per_env_parameters)
         self.solver_sim = LargeModelSimulation(solver, self.B, device=device, n_substeps=n_substeps, lib=lib, hand=False)
         self.device = self.sim.device
         self.model, self.solver_model = main, solver
@@ -143,6 +150,13 @@ class BatchedBlockRearrangeEnv:
         a.solver_grip_qposadr, a.solver_grip_act = self.solver_grip_q, self.solver_grip_act
         self.action_shape = (self.B, 6)
         self._zero_action = z(B, 6)
+        # ---- per-env model parameters: the reference's simulation randomizers (applied after _reset, robot_env.py:779-783) and stabilize_objects' damping change
+        self.stabilize_object_damping = float(stabilize_object_damping)
+        self.obj_dofs = torch.tensor([d for v in self.obj_v for d in range(v, v + 6)], device=dev, dtype=torch.long)
+        self.randomizers = build_simulation_randomizers(main, self.randomizer_params) if self.per_env_parameters else []
+        self._rand_gen = torch.Generator(device=dev); self._rand_gen.manual_seed(int(starting_seed) + 90001)
+        if self.per_env_parameters:
+            self._param_defaults = {k: self.sim.params[k][0].clone() for k in self.sim.params.keys()}
         # ---- RearrangeEnv.apply_wrappers (common/base.py:986-996): SmoothActionWrapper(alpha = 0.3) -> ClipRewardWrapper -> DiscretizeActionWrapper, all inside
         # the launches: the solver world's launch maps bin indices to actions and smooths them (rb_tcp_args), the post kernel clips the reward
         self.wrapped = bool(wrappers)
@@ -166,6 +180,7 @@ class BatchedBlockRearrangeEnv:
         self.ended_rows = np.zeros(0, dtype=np.int64)          # rows whose episode ended on the last step (pipelined resets)
         self.hold, self.scripted, self.frozen, self.solver_active = z(B, dt=torch.int32), z(B, 6), z(B, dt=torch.uint8), torch.ones(B, dtype=torch.int32, device=dev)
         self.resetting, self.episode_started = z(B, dt=torch.bool), z(B, dt=torch.bool)
+        self.nticks = torch.full((B,), 2, dtype=torch.int32, device=dev)       # state-less forwards (controller ticks) per env of the main world's launch
         if self.pipelined:
             for args_ in (t, tw):
                 args_.hold, args_.scripted = self.hold.data_ptr(), self.scripted.data_ptr()
@@ -186,7 +201,15 @@ class BatchedBlockRearrangeEnv:
             self.solver_sim.step_tcp(self.sim, None, self.tcp_wrapped, active=sa)
         else:
             self.solver_sim.step_tcp(self.sim, actions, self.tcp, active=sa)
-        self.sim.env_step(nforward_ticks=2, flags=FLAG_FULL_FORWARD, active=active)
+        # live envs: sim.step's forward + _observe_sync's forward = two controller ticks, the last forward in full; envs inside their reset recipe (pipelined
+        # resets): `mujoco_simulation.step()` only = one tick, `self.nticks` (the recipe's last step gets the second tick: the _observe_sync that ends a reset)
+        self.sim.env_step(nforward_ticks=2, flags=FLAG_FULL_FORWARD, active=active, nticks=self.nticks if self.pipelined else None)
+
+    def _recipe_physics(self, actions, active):
+        """One step of the reset recipe's robot moves, `self._set_action(action); self.mujoco_simulation.step()` (common/base.py:484-496): the TCP solver world's
+        launch, the main world's mj_steps with ONE state-less forward (MjSim.step), no _observe_sync: no second forward, no gripper hand-over to the solver world."""
+        self.solver_sim.step_tcp(self.sim, actions, self.tcp, active=active)
+        self.sim.env_step(nforward_ticks=1, active=active)
 
     def step(self, actions: torch.Tensor):
         """RobotEnv.step (robot_env.py:804-844): returns (obs dict of [B, ...] views, reward [B, 3], done [B], info dict of tensors).
@@ -319,6 +342,9 @@ class BatchedBlockRearrangeEnv:
         rotations about z and their placement, bounding boxes / colours of the static observation.  Returns the drawn yaw angles [len(rows), N]."""
         dev, N = self.device, self.N
         A, As = self.model.arrays, self.solver_model.arrays
+        if self.per_env_parameters:      # _recreate_sim (common/base.py:850-856): a fresh model -- the previous episode's randomised values are gone
+            for k, v in self._param_defaults.items():
+                self.sim.params[k][idx] = v
         # MjSim of a fresh model: qpos0, zero velocities / controller state / time; robot.reset()
         for sim, model in ((self.sim, A), (self.solver_sim, As)):
             sim.qpos[idx] = torch.tensor(model["qpos0"].astype(np.float32), device=dev)
@@ -354,24 +380,27 @@ class BatchedBlockRearrangeEnv:
         if self.pipelined:       # a synchronous reset ends whatever recipe those envs were in
             self._stage[rows] = 0; self._left[rows] = 0
             self.hold[idx] = 0; self.frozen[idx] = 0; self.solver_active[idx] = 1; self.resetting[idx] = False; self.episode_started[idx] = False
+            self.nticks[idx] = 2; self._nticks_host = None
         yaw = self._begin_episode_state(rows, idx)
-        # stabilize_objects (common/utils.py:76-92; its temporary damping change is not reproduced: blocks at rest on the table need none)
+        # stabilize_objects (common/utils.py:76-92): the objects' dof damping is lowered to 1e-3 while they settle and restored afterwards -- with per-env parameter
+        # rows; without them the model's own damping (0.01) stays (blocks at rest on the table need no help; mesh objects settle a little slower)
+        self._set_object_damping(idx, self.stabilize_object_damping)
         for _ in range(self.stabilize_steps):
             self.sim.env_step(nforward_ticks=1, active=active)
+        self._set_object_damping(idx, None)
         # _randomize_robot_initial_position (common/base.py:498-510)
         if self.n_random_initial_steps >= 1:
             act = torch.zeros(self.B, 6, device=dev)
             act[idx] = torch.tensor(self._rng.uniform(-1, 1, (len(rows), 6)).astype(np.float32), device=dev)
             for _ in range(self.n_random_initial_steps):
-                self._physics(act, active)
-                self._sync_solver_gripper(idx)
+                self._recipe_physics(act, active)
             for _ in range(self.settle_steps):
-                self._physics(self._zero_action, active)
-                self._sync_solver_gripper(idx)
+                self._recipe_physics(self._zero_action, active)
         # tracker reset and the first goal (robot_env.py:780-792; ObjectStateGoal.next_goal with randomize_goal_rot = False)
         for f in (self.t, self.steps, self.ssl, self.successes, self.consecutive, self.ema_t):
             f[idx] = 0
         self.ema_value[idx] = 0; self.action_ema[idx] = 0          # SmoothActionWrapper.reset: a fresh filter, action_ema = 0
+        self._randomize_simulation(idx)                               # simulation_randomizer.randomize AFTER _reset (robot_env.py:779-783)
         self._write_goal(rows, self._grid_placement(yaw, rows), yaw)
         self.sim.env_step(nsubsteps=0, nforward_ticks=1, flags=FLAG_FULL_FORWARD, active=active)       # the forward of _observe_sync
         # the first observation of the new episodes: the env kernel for exactly those rows (observation + gripper hand-over, zeroed reward / done, the success count
@@ -414,6 +443,8 @@ class BatchedBlockRearrangeEnv:
             if len(rows) == 0:
                 continue
             idx = torch.as_tensor(rows, device=dev, dtype=torch.long)
+            if stage == 1:
+                self._set_object_damping(idx, None)                     # stabilize_objects restores the objects' damping
             if stage == 1 and self.n_random_initial_steps >= 1:         # -> one random action for n_random_initial_steps steps
                 st[rows], left[rows] = 2, self.n_random_initial_steps
                 self.scripted[idx] = torch.tensor(self._rng.uniform(-1, 1, (len(rows), 6)).astype(np.float32), device=dev)
@@ -432,6 +463,7 @@ class BatchedBlockRearrangeEnv:
             self.ema_value[idx] = 0; self.action_ema[idx] = 0; self.scripted[idx] = 0
             self.frozen[idx] = 0; self.solver_active[idx] = 1
             self.resetting[idx] = False; self.episode_started[idx] = True
+            self._randomize_simulation(idx)
             yaw = self._yaw[rows]
             self._write_goal(rows, self._grid_placement(yaw, rows), yaw)
         # ---- live envs with a reached goal: ObjectStateGoal.next_goal (what reset_goals() does on request)
@@ -446,20 +478,40 @@ class BatchedBlockRearrangeEnv:
         if len(rows):
             idx = torch.as_tensor(rows, device=dev, dtype=torch.long)
             self._yaw[rows] = self._begin_episode_state(rows, idx)
+            self._set_object_damping(idx, self.stabilize_object_damping)
             st[rows], left[rows] = 1, self.stabilize_steps
-            self.hold[idx] = 1; self.scripted[idx] = 0; self.frozen[idx] = 1; self.solver_active[idx] = 0
+            self.hold[idx] = 1; self.scripted[idx] = 0; self.frozen[idx] = 4; self.solver_active[idx] = 0
             self.resetting[idx] = True
             if self.stabilize_steps <= 0:        # (degenerate configuration: straight to the next stage on the following step)
                 left[rows] = 1
+        # controller ticks of the NEXT step's main-world launch: two for live envs, one inside the recipe, two on the recipe's last step (see _physics)
+        last_stage = 3 if self.n_random_initial_steps >= 1 else 1
+        want = np.where(st > 0, np.where((st == last_stage) & (left <= 1), 2, 1), 2).astype(np.int32)
+        if not np.array_equal(want, getattr(self, "_nticks_host", None)):
+            self._nticks_host = want
+            self.nticks.copy_(torch.as_tensor(want, device=dev))
+
+    def _set_object_damping(self, idx, value):
+        """RearrangeSimulationInterface.set_object_damping for the envs `idx` (simulation/base.py:753-770): `value` on the objects' six dofs, None = the model's own."""
+        if not self.per_env_parameters:
+            return
+        d = self.sim.params["dof_damping"]
+        cols = self.obj_dofs
+        d[idx[:, None], cols[None, :]] = self._param_defaults["dof_damping"][cols] if value is None else float(value)
+
+    def _randomize_simulation(self, idx):
+        """`randomization.simulation_randomizer.randomize(mj_sim, random_state)` for the envs `idx` (robot_env.py:779-783): every randomizer draws new values of its
+        model field from the model's own (the block was restored at the start of the reset), on the device."""
+        if not self.randomizers:
+            return
+        mask = torch.zeros(self.B, dtype=torch.bool, device=self.device); mask[idx] = True
+        for r in self.randomizers:
+            r.randomize(self.sim, self._rand_gen, mask)
 
     def _aabb_half(self, yaw):
         """half extents [.., N, 3] of the objects' bounding boxes after a rotation by `yaw` [.., N] about z"""
         sx, sy, sz = self.obj_half[:, 0], self.obj_half[:, 1], self.obj_half[:, 2]
         return np.stack([np.abs(np.cos(yaw)) * sx + np.abs(np.sin(yaw)) * sy, np.abs(np.sin(yaw)) * sx + np.abs(np.cos(yaw)) * sy, np.broadcast_to(sz, yaw.shape)], -1)
-
-    def _sync_solver_gripper(self, idx):
-        self.solver_sim.qpos[idx, self.solver_grip_q] = self.sim.qpos[idx, self.grip_q]
-        self.solver_sim.ctrl[idx, self.solver_grip_act] = self.sim.ctrl[idx, self.grip_act]
 
     def _observe_only(self, rows=None):
         """The observation rows of `rows` (default: everybody) from the state as it is, without a step: observation entries, gripper hand-over, zeroed
@@ -479,6 +531,47 @@ class BatchedBlockRearrangeEnv:
         self.sim.sync()
 
 
+def build_simulation_randomizers(model, params: Optional[dict] = None):
+    """`RearrangeEnv.build_simulation_randomizers` (common/base.py:1008-1092) on the batched randomizers of robogym_amd/randomization/sim.py: the same list, names,
+    fields, prefixes, apply modes and coefficients; `params[name]` is the randomizer's parameter (what ADR controls in the reference; 0 = identity)."""
+    from robogym_amd.randomization.sim import GenericSimRandomizer, GeomSolimpRandomizer, GeomSolrefRandomizer, GravityRandomizer, JointMarginRandomizer, PidRandomizer
+
+    P = dict(params or {})
+    A, names = model.arrays, model.names
+    robot_jnt = [j for j, n in enumerate(names["joint"]) if n.startswith("robot0:")]
+    robot_dof = [d for d in range(len(A["dof_jntid"])) if int(A["dof_jntid"][d]) in set(robot_jnt)]
+    robot_body = [b for b, n in enumerate(names["body"]) if n.startswith("robot0:")]
+    g = lambda name, default=(0.0, 0.0): P.get(name, default)
+    G = GenericSimRandomizer
+    out = [
+        GravityRandomizer(param=float(np.atleast_1d(g("gravity", 0.0))[0])),
+        JointMarginRandomizer(param=float(np.atleast_1d(g("jnt_margin", 0.0))[0])),
+        G("dof_frictionloss_robot", "dof_frictionloss", "uncoupled_mean_variance", param=g("dof_frictionloss_robot"), ids=robot_dof),
+        G("dof_damping_robot", "dof_damping", "uncoupled_mean_variance", param=g("dof_damping_robot"), ids=robot_dof),
+        G("dof_armature_robot", "dof_armature", "uncoupled_mean_variance", param=g("dof_armature_robot"), ids=robot_dof),
+        G("jnt_stiffness_robot", "jnt_stiffness", "variance_mean_additive", param=g("jnt_stiffness_robot"), coef=0.005, ids=robot_jnt, positive_only=True),
+        G("body_pos_robot", "body_pos", "variance_additive", param=g("body_pos_robot", (0.0,)), coef=0.02, ids=robot_body),
+    ]
+    for name in ("pid_kp", "pid_ti", "pid_td", "pid_imax_clamp", "pid_error_deadband"):
+        mean, std = (list(np.atleast_1d(g(name))) + [0.0, 0.0])[:2]
+        out.append(PidRandomizer(name, mean=float(mean), std=float(std)))
+    out += [
+        G("actuator_forcerange", "actuator_forcerange", "uncoupled_mean_variance", param=g("actuator_forcerange")),
+        GeomSolimpRandomizer(param=g("geom_solimp", (0.0,) * 6)),
+        GeomSolrefRandomizer(param=g("geom_solref", (0.0,) * 4)),
+        G("geom_margin", "geom_margin", "variance_additive", param=g("geom_margin", (0.0,)), coef=0.0005),
+        G("geom_pos", "geom_pos", "variance_additive", param=g("geom_pos", (0.0,)), coef=0.002),
+        G("geom_gap", "geom_gap", "max_additive", param=g("geom_gap", (0.0,)), coef=0.01),
+        G("geom_friction", "geom_friction", "uncoupled_mean_variance", param=g("geom_friction")),
+        G("body_mass", "body_mass", "uncoupled_mean_variance", param=g("body_mass")),
+        G("body_inertia", "body_inertia", "variance_additive", param=g("body_inertia", (0.0,))),
+    ]
+    unknown = sorted(set(P) - {r.name for r in out})
+    if unknown:
+        raise KeyError("randomizer_params: no simulation randomizer named %s (known: %s)" % (", ".join(unknown), ", ".join(r.name for r in out)))
+    return out
+
+
 def action_bin_array(lower_bound, upper_bound, n_bins, spacing="linear"):
     """BinSpacing.get_bin_array (wrappers/util.py:17-33): the table DiscretizeActionWrapper maps a bin index through.  "linear": n_bins evenly spaced values;
     "exponential" (symmetric range, odd n_bins): -1, -1/2, -1/4, ... 0 ... 1/4, 1/2, 1 times the bound."""
@@ -496,7 +589,7 @@ SUPPORTED_PARAMETERS = {"simulation_params", "robot_control_params", "n_random_i
 SUPPORTED_SIMULATION_PARAMS = {"num_objects", "penalty", "used_table_portion"}
 SUPPORTED_ROBOT_CONTROL_PARAMS = {"max_position_change", "arm_reset_controller_error", "control_mode", "tcp_solver_mode"}
 SUPPORTED_CONSTANTS = {"success_threshold", "successes_needed", "success_reward", "max_timesteps_per_goal_per_obj", "n_action_bins", "action_spacing", "use_goal_distance_reward",
-                       "goal_reward_per_object", "normalize_mesh"}
+                       "goal_reward_per_object", "normalize_mesh", "randomize"}
 
 
 def _check_supported(parameters, sp, rc, constants):
@@ -531,6 +624,8 @@ def make_env(batch_size: int = 4096, device="cuda:0", parameters=None, constants
     for k in ("penalty", "used_table_portion"):      # (a given penalty dict replaces the default one as a whole, as the reference's attrs field does)
         if k in sp:
             args[k] = sp[k]
+    if constants.get("randomize", True) is False:    # RobotEnvConstants.randomize (robot_env.py:155): no simulation randomizers at all
+        kw = dict(kw); kw.pop("randomizer_params", None); args["per_env_parameters"] = kw.pop("per_env_parameters", False)
     args.update(kw)
     return BatchedBlockRearrangeEnv(batch_size, device=device, **args)
 

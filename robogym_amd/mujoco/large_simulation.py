@@ -20,7 +20,7 @@ INFO = ["nq", "nv", "nu", "nbody", "njnt", "ngeom", "nsite", "ntendon", "nM", "n
 
 
 class LargeModelSimulation:
-    def __init__(self, model, batch_size: int, device="cuda:0", n_substeps: int = 10, relative_action: bool = True, lib=None, hand: bool = True):
+    def __init__(self, model, batch_size: int, device="cuda:0", n_substeps: int = 10, relative_action: bool = True, lib=None, hand: bool = True, env_params: bool = False):
         """`hand`: the model is a Shadow-hand world (joint group `robot0:` = the hand, in-kernel action map through the position -> control matrix);
         False for the rearrange worlds, whose action path is the TCP solver hook (`step_tcp`)."""
         self._emul = lib is not None
@@ -38,6 +38,11 @@ class LargeModelSimulation:
         self._mh = L.rb_model_create(blob, len(blob), err, 512)
         if not self._mh:
             raise _native.NativeError("rb_model_create: " + err.value.decode())
+        # per-env model parameters: every env gets its own block of the randomisable model fields, read by the kernel instead of the model's arrays
+        self._env_params = bool(env_params)
+        if self._env_params:
+            _native.check(L, L.rb_model_enable_env_params(self._mh), "rb_model_enable_env_params")
+        self._params = None
         buf = (ctypes.c_int * 32)()
         n = L.rb_model_info(self._mh, buf, 32)
         assert n == len(INFO)
@@ -111,6 +116,18 @@ class LargeModelSimulation:
     eq_active = property(lambda self: self.view(_native.RB_F_EQ_ACTIVE))    # [B, neq] int32
     sensordata = property(lambda self: self.view(_native.RB_F_SENSORDATA))  # [B, nsensordata], of the last full forward (flags bit 5)
 
+    @property
+    def params(self) -> "LargeEnvParams":
+        """`sim.model.<field>` of the reference for a batch on this stepper: `[B, ...]` tensor views into the envs' parameter blocks (include/rgstep.h
+        rb_model_enable_env_params): gravity, dof_damping / armature / frictionloss / invweight0, jnt_stiffness / margin / range, body_pos / mass / inertia /
+        invweight0, actuator_gainprm / forcerange / ctrlrange, geom_pos / margin / gap / friction / solref / solimp, tendon_range / invweight0.  The simulation
+        must have been created with `env_params=True`."""
+        if not self._env_params:
+            raise _native.NativeError("this simulation was created without per-env parameter rows (LargeModelSimulation(..., env_params=True))")
+        if self._params is None:
+            self._params = LargeEnvParams(self)
+        return self._params
+
     def scratch(self, name: str) -> torch.Tensor:
         """A stage array of the last launch, `[B, words]` (debugging / stage parity tests)."""
         k = SCRATCH.index(name)
@@ -152,3 +169,28 @@ class LargeModelSimulation:
     def sync(self):
         if not self._emul:
             torch.cuda.synchronize(self.device)
+
+
+class LargeEnvParams:
+    """Named `[B, ...]` views into the per-env parameter blocks of the scratch rows (rb_prm_layout); same interface as simulation_interface.EnvParams, so the
+    randomizers of robogym_amd/randomization/sim.py act on either stepper."""
+
+    def __init__(self, sim: LargeModelSimulation):
+        buf = (ctypes.c_int * (2 + 2 * len(_native.RB_PRM_NAMES)))()
+        n = sim._L.rb_prm_layout(sim._mh, buf, len(buf))
+        assert n == len(buf) and buf[0] == 1, "rb_prm_layout and robogym_amd/_native.py disagree"
+        rows = sim.view(_native.RG_F_DEBUG)          # the whole scratch row [B, scratch_words]
+        shape_of = dict(gravity=(3,), jnt_range=(-1, 2), body_pos=(-1, 3), body_inertia=(-1, 3), body_invweight0=(-1, 2), actuator_gainprm=(-1, 10), actuator_forcerange=(-1, 2),
+                        actuator_ctrlrange=(-1, 2), geom_pos=(-1, 3), geom_friction=(-1, 3), geom_solref=(-1, 2), geom_solimp=(-1, 5), tendon_range=(-1, 2))
+        self._views: Dict[str, torch.Tensor] = {}
+        B = sim.batch_size
+        for k, name in enumerate(_native.RB_PRM_NAMES):
+            off, length = int(buf[2 + 2 * k]), int(buf[3 + 2 * k])
+            v = rows[:, off:off + length]
+            self._views[name] = v.unflatten(1, shape_of[name]) if (name in shape_of and length) else v
+
+    def __getitem__(self, name: str) -> torch.Tensor:
+        return self._views[name]
+
+    def keys(self):
+        return self._views.keys()
