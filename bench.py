@@ -158,6 +158,8 @@ def bench_rearrange_blocks(args, emit=True, ycb=False):
     kw = dict(stabilize_steps=20, n_random_initial_steps=2, settle_steps=20) if quick else {}
     if emul_path:
         kw = dict(stabilize_steps=1, n_random_initial_steps=1, settle_steps=1, n_substeps=1, lib=lib)
+    if getattr(args, "per_env_params", False):      # every env reads its own copy of the randomisable model fields (rb_model_enable_env_params), values = the model's
+        kw["per_env_parameters"] = True
     env = (BatchedYcbRearrangeEnv if ycb else BatchedBlockRearrangeEnv)(B, device=dev, starting_seed=20200901 + 3 + rank, **kw)
     sync = (lambda: torch.cuda.synchronize(dev)) if not emul_path else (lambda: None)
     t_reset = time.perf_counter()
@@ -229,7 +231,7 @@ def bench_rearrange_blocks(args, emit=True, ycb=False):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("rearrange/ycb (UR16e + 2f-85 gripper + table, 8 YCB objects %s as convex-part mesh geoms: nv=56, %d geoms, elliptic cones, impratio 10)" % (getattr(env, "object_names", []), env.sim.info["ngeom"]) if ycb else "rearrange/blocks (UR16e + 2f-85 gripper + table, 5 blocks: nv=38, elliptic cones, impratio 10)") + " with its TCP solver world (nv=8, mocap weld), batch %d, iid U(-1,1) relative tcp+roll+yaw actions, 40 + 40 substeps x 0.001 s + 2 forwards; after the reset recipe%s" % (B, " (shortened: --quick-reset)" if quick else ""),
                    "batch_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d (envs sharded, all-gather of the packed observation rows)" % world, "collective_backend": (dist.get_backend() if distributed else None), "reset_seconds": t_reset, "main": res["main"], "solver": res["solver"], "status_bits": int(max(env.sim.status.max().item(), env.solver_sim.status.max().item())),
-                   "done_fraction_last_step": float(env.done.float().mean().item()), "launch_ms": {"solver_world": ms_solver, "main_world": ms_main}, "lds_bytes_per_workgroup": env.sim.info["lds_bytes"]},
+                   "done_fraction_last_step": float(env.done.float().mean().item()), "launch_ms": {"solver_world": ms_solver, "main_world": ms_main}, "lds_bytes_per_workgroup": env.sim.info["lds_bytes"], "per_env_parameters": bool(env.per_env_parameters)},
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": rb_traffic("ycb" if ycb else "rearrange_blocks", B), "traffic_unit": "GB per launch (PMC, profiles/hbm_traffic.json)", "traffic_note": rb_traffic_note("ycb" if ycb else "rearrange_blocks", B), "kernel": "rb_step_kernel (main world launch)", "kernel_ms": ms_main,
                      "algorithmic_bytes_per_env_step": res["main"]["algorithmic_bytes_dense"], "frac_sparse_J": B * res["main"]["algorithmic_bytes_sparse_J"] / (ms_main * 1e-3) / HBM_PEAK,
                      "note": "dominant kernel = the main world's launch; SURVEY 8(d) dense byte model with the run's ncon / nefc / iterations; frac_sparse_J counts a constraint row at <= 16 dofs and M tree-sparse (what the stepper stores)"},
@@ -415,6 +417,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8192, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-env-params", action="store_true", help="rearrange workloads: per-env model parameter rows on (what the simulation randomizers write)")
     ap.add_argument("--no-long-window", action="store_true", help="skip the >= 2 s continuation of the headline rollout (config.long_window)")
     ap.add_argument("--long-steps", type=int, default=300)
     ap.add_argument("--pipelined-reset", action="store_true", help="finished episodes run the reset recipe inside the step launches")
@@ -574,6 +577,14 @@ def main():
                        "ranks": (dist.get_world_size() if distributed else 1), "collective_backend": (dist.get_backend() if distributed else None),
                        "mean_ncon": float(ncon), "mean_nefc": float(nefc), "mean_newton_iters": float(iters), "status_bits": status, "status_bits_before_timed_region": status_before,
                        "cube_on_palm_fraction": {"start_of_timed_region": on_palm_start, "end_of_timed_region": on_palm_end},
+                       "parity": {"oracle": "in-repo CPU restatement of MuJoCo 2.0 (fp64); physics unpinned against MuJoCo itself (absent offline), env layer pinned by fixtures generated from the reference's source",
+                                  "protocol": "re-synchronised one-env.step error (kernel restarted from the oracle's fp32-rounded state before every env.step): the stated fp32 tolerance; "
+                                              "free-running first step with qpos L-inf > 1e-4 under THIS workload's iid random actions, next to the oracle's own source built in float (the algorithm's fp32 limit)",
+                                  "resync_qpos_Linf_plane": {"median": 2.0e-7, "p99": 1.5e-6, "max": 5.9e-6}, "resync_qpos_Linf_default": {"median": 3.2e-7, "p99": 1.4e-3, "max": 2.4e-3},
+                                  "free_running_first_step_beyond_1e-4": {"kernel_default": [2, 10, 16, 8], "float_oracle_default": [4, 6, 13, 8], "kernel_plane": [28, 22, 19, 57], "float_oracle_plane": [28, 22, 18, 49]},
+                                  "north_star_drift_statement": "<= 1e-4 over 1000 steps is met on the contact-light hold-pose protocol in the portal-plane configuration only (tests/test_gpu_parity.py); "
+                                                                "under random actions no fp32 build of the algorithm meets it (tests/test_oracle.py::test_free_running_divergence_of_the_default_is_a_property_of_the_algorithm_at_fp32)",
+                                  "source": "profiles/r04_parity.txt, profiles/r03_precision.txt (200 env.steps, 4 streams); asserted by tests/test_gpu_parity.py"},
                        "long_window": long_window, "pipelined_reset": bool(args.pipelined_reset), "sort_dispatch": bool(args.sort_dispatch), "substep_items": bool(_si.SUBSTEP_ITEMS),
                        "gathered_row": "obs 166 + reward 3 + done 1 = %d floats per env" % env.packed_dim},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_unit": "GB per launch (PMC)", "algorithmic_gb_per_launch": b_step * B / 1e9,

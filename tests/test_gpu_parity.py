@@ -305,3 +305,39 @@ def test_locked_free_running_hold_pose_1000_steps_gpu(gpu_pair):
         # product default (libccd's triangle-distance depth on both sides): the flat cube-palm contacts hang on rounding-level tie breaks, the cube
         # slides differently and the runs part ways — NOT asserted beyond the first ten steps; the curve is printed (measured: 5e-7 at step 10, 6e-2 at step 100)
         assert err[:10].max() <= 1e-5
+
+
+def test_free_running_default_parts_ways_no_earlier_than_the_float_oracle_gpu(locked_model, oracle_lib, kernel_variant):
+    """north_star's drift statement on the BENCHMARKED configuration: under the bench's iid U(-1, 1) relative actions the product
+    default leaves 1e-4 of the fp64 oracle after 2-16 env.steps -- and so does the oracle's OWN source compiled in float (4-13 steps,
+    tests/test_oracle.py::test_free_running_divergence_of_the_default_is_a_property_of_the_algorithm_at_fp32): the divergence time is a property of the restated
+    algorithm at fp32 (libccd's contact depth on flat contacts), not of the kernel.  Asserted here, on the same four action streams: the kernel's first-exceed steps
+    are not earlier than the float oracle's in distribution (median within a factor of two, no stream gone at step 1), in either configuration; the protocol the
+    north star's number can honestly be held to is the re-synchronised one (test_resync_*) and the portal-plane free run (first-exceed >= 15 steps)."""
+    from oracle.env_oracle import OracleLockedEnvPhysics
+    from robogym_amd.envs.dactyl.locked import LockedSimulation
+    from tests.helpers import NON_TARGET_QPOS, sync_state_from_oracle
+    from tests.test_oracle import _first_exceed_steps, float_oracle_pair_stepper
+
+    nsteps = 60
+    oracle_float = _first_exceed_steps(lambda s: float_oracle_pair_stepper(locked_model, s), 4, nsteps)
+
+    def kernel_stepper(sidx):
+        sim = LockedSimulation(locked_model, 1, device="cuda:0")
+        ora = OracleLockedEnvPhysics(locked_model)
+        ora.sim.reset(); ora.settle(30)
+        sync_state_from_oracle(sim, ora)
+        rng = np.random.RandomState(20200901 + 1 + sidx)
+
+        def step():
+            a = rng.uniform(-1, 1, 20)
+            sim.env_step(action=torch.tensor(a[None].astype(np.float32), device=sim.device), nforward_ticks=3)
+            ora.env_step(a.astype(np.float32).astype(np.float64))
+            return float(np.abs(sim.qpos[0].cpu().numpy().astype(np.float64) - ora.sim.qpos)[NON_TARGET_QPOS].max())
+        return step
+
+    kernel = _first_exceed_steps(kernel_stepper, 4, nsteps)
+    print("free-running first step beyond 1e-4 (%s): kernel vs fp64 oracle %s | oracle built in float vs fp64 oracle %s" % (kernel_variant.name, kernel, oracle_float))
+    assert min(kernel) >= 2 and np.median(kernel) >= 0.5 * np.median(oracle_float), (kernel, oracle_float)
+    if kernel_variant.plane:
+        assert min(kernel) >= 15, kernel
