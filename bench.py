@@ -158,8 +158,8 @@ def bench_rearrange_blocks(args, emit=True, ycb=False):
     kw = dict(stabilize_steps=20, n_random_initial_steps=2, settle_steps=20) if quick else {}
     if emul_path:
         kw = dict(stabilize_steps=1, n_random_initial_steps=1, settle_steps=1, n_substeps=1, lib=lib)
-    if getattr(args, "per_env_params", False):      # every env reads its own copy of the randomisable model fields (rb_model_enable_env_params), values = the model's
-        kw["per_env_parameters"] = True
+    if getattr(args, "no_per_env_params", False):   # (A/B: the model's shared arrays instead of every env's own parameter block)
+        kw["per_env_parameters"] = False
     env = (BatchedYcbRearrangeEnv if ycb else BatchedBlockRearrangeEnv)(B, device=dev, starting_seed=20200901 + 3 + rank, **kw)
     sync = (lambda: torch.cuda.synchronize(dev)) if not emul_path else (lambda: None)
     t_reset = time.perf_counter()
@@ -417,7 +417,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8192, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--per-env-params", action="store_true", help="rearrange workloads: per-env model parameter rows on (what the simulation randomizers write)")
+    ap.add_argument("--no-per-env-params", action="store_true", help="rearrange workloads: without the per-env model parameter rows (what the simulation randomizers and stabilize_objects write); default: with")
     ap.add_argument("--no-long-window", action="store_true", help="skip the >= 2 s continuation of the headline rollout (config.long_window)")
     ap.add_argument("--long-steps", type=int, default=300)
     ap.add_argument("--pipelined-reset", action="store_true", help="finished episodes run the reset recipe inside the step launches")

@@ -163,5 +163,7 @@ def test_env_applies_the_reference_randomizer_list_at_reset_emul(emul_lib):
     env.reset(mask)
     assert torch.equal(P["body_mass"][0], m_before[0]) and torch.equal(P["body_mass"][2], m_before[2]) and not torch.equal(P["body_mass"][1], m_before[1])
     assert int(env.sim.status.max()) == 0 and bool(torch.isfinite(env.packed).all())
-    plain = BatchedBlockRearrangeEnv(1, device="cpu", lib=emul_lib, n_substeps=1, stabilize_steps=1, n_random_initial_steps=0, settle_steps=0)
+    plain = BatchedBlockRearrangeEnv(1, device="cpu", lib=emul_lib, n_substeps=1, stabilize_steps=1, n_random_initial_steps=0, settle_steps=0, per_env_parameters=False)
     assert not plain.per_env_parameters and plain.randomizers == []
+    with pytest.raises(ValueError):
+        BatchedBlockRearrangeEnv(1, device="cpu", lib=emul_lib, n_substeps=1, per_env_parameters=False, randomizer_params={"gravity": 0.1})
