@@ -228,7 +228,17 @@ __device__ __forceinline__ void rb_com_pos(RbM m, RbLds& s, float* S) {
     const int root = m.b_root_list[r];
     v3 acc = mk3(0, 0, 0);
     float msum = 0.f;      // (per-env masses: the subtree's mass is summed here, in the list's order; the model's own body_subtreemass otherwise)
-    for (int q = m.b_subtree_adr[root]; q < m.b_subtree_adr[root + 1]; q++) { const int b = m.b_subtree[q]; const float mb = body_mass[b]; acc = acc + ld3(xipos + 3 * b) * mb; msum += mb; }
+    // (four bodies' loads in flight at a time, the sums in list order as before: a one-at-a-time loop waits for every body's round trip in turn)
+    const int q1 = m.b_subtree_adr[root + 1];
+    for (int q = m.b_subtree_adr[root]; q < q1; q += 4) {
+      int bb[4]; float mm[4]; v3 xx[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) bb[u] = m.b_subtree[q + u < q1 ? q + u : q1 - 1];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { mm[u] = body_mass[bb[u]]; xx[u] = ld3(xipos + 3 * bb[u]); }
+#pragma unroll
+      for (int u = 0; u < 4; u++) if (q + u < q1) { acc = acc + xx[u] * mm[u]; msum += mm[u]; }
+    }
     const float sm = m.prm_on ? msum : m.body_subtreemass[root];
     st3(rootcom + 3 * root, sm < RB_MINVAL ? ld3(xipos + 3 * root) : acc * (1.0f / sm));
   }
@@ -345,7 +355,18 @@ __device__ __forceinline__ void rb_crb(RbM m, RbLds& s, float* S) {
   BFOR(w, 10 * m.nbody) {
     const int b = w / 10, k = w - 10 * b;
     float acc = 0;
-    for (int q = m.b_subtree_adr[b]; q < m.b_subtree_adr[b + 1]; q++) acc += cinert[10 * m.b_subtree[q] + k];
+    // (the world body's composite inertia is never read -- M's entries take their dof's body --: its subtree, every body of the model, is not summed;
+    //  four loads in flight at a time, the sums in list order as before)
+    const int q1 = b == 0 ? m.b_subtree_adr[0] : m.b_subtree_adr[b + 1];
+    for (int q = m.b_subtree_adr[b]; q < q1; q += 4) {
+      int bb[4]; float vv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) bb[u] = m.b_subtree[q + u < q1 ? q + u : q1 - 1];
+#pragma unroll
+      for (int u = 0; u < 4; u++) vv[u] = cinert[10 * bb[u] + k];
+#pragma unroll
+      for (int u = 0; u < 4; u++) if (q + u < q1) acc += vv[u];
+    }
     crb[w] = acc;
   }
   BSYNC();
@@ -1337,6 +1358,40 @@ __device__ __forceinline__ void rb_make_constraint(RbM m, RbLds& s, float* S, co
     const int b1 = m.geom_bodyid[(int)C[RB_CR_G1]], b2 = m.geom_bodyid[(int)C[RB_CR_G2]];
     const v3 pos = ld3(C + RB_CR_POS);
     int nnz = 0;
+    float bd[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bool bd_done = false;
+#ifndef RB_ROWS_LEGACY
+    if (RB_NWAVE == 1) {
+      // One wave per env (round 5): the dof list is built in LDS first (the block's storage is free until the smooth stage: RB_CONW words per lane, dof | sides << 16),
+      // then every column of the six basis rows is formed in registers and stored ONCE -- instead of searching the list in the scratch row and six
+      // read-modify-write round trips per dof and side.  Same sums in the same order (side 0 = body 2 first), so the rows are unchanged.
+      static_assert(sizeof(s.A) + sizeof(s.Dinv) >= sizeof(int) * RB_CONW * RB_T || RB_NWAVE != 1, "rb_make_constraint: the dof lists do not fit the block's storage");
+      int* li = (int*)s.A + RB_CONW * TID;
+      for (int side = 0; side < 2; side++) {
+        const int bb = side ? b1 : b2;
+        for (int i = (bb > 0 ? m.b_body_lastdof[bb] : -1); i >= 0; i = m.dof_parentid[i]) {
+          int e = 0;
+          while (e < nnz && (li[e] & 0xffff) != i) e++;
+          if (e == nnz) { if (nnz >= RB_CONW) continue; li[nnz++] = i | (1 << (16 + side)); }
+          else li[e] |= 1 << (16 + side);
+        }
+      }
+      const v3 fr0 = ld3(C + RB_CR_FRAME), fr1 = ld3(C + RB_CR_FRAME + 3), fr2 = ld3(C + RB_CR_FRAME + 6);
+      const v3 off2 = pos - ld3(rootcom + 3 * m.body_rootid[b2]), off1 = pos - ld3(rootcom + 3 * m.body_rootid[b1]);
+      for (int e = 0; e < nnz; e++) {
+        const int i = li[e] & 0xffff, sides = li[e] >> 16;
+        const v3 jr = ld3(cdof + 6 * i);
+        float col[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (sides & 1) { const v3 jp = rb_jacp(cdof, i, off2); col[0] += dot(fr0, jp); col[3] += dot(fr0, jr); col[1] += dot(fr1, jp); col[4] += dot(fr1, jr); col[2] += dot(fr2, jp); col[5] += dot(fr2, jr); }
+        if (sides & 2) { const v3 jp = rb_jacp(cdof, i, off1); col[0] += -1.f * dot(fr0, jp); col[3] += -1.f * dot(fr0, jr); col[1] += -1.f * dot(fr1, jp); col[4] += -1.f * dot(fr1, jr); col[2] += -1.f * dot(fr2, jp); col[5] += -1.f * dot(fr2, jr); }
+        const float qv = s.qvel[i];
+        idx[e] = i;
+#pragma unroll
+        for (int r = 0; r < 6; r++) { J[r * RB_CONW + e] = col[r]; bd[r] += col[r] * qv; }
+      }
+      bd_done = true;
+    } else
+#endif
     for (int side = 0; side < 2; side++) {
       const int bb = side ? b1 : b2; const float sg = side ? -1.f : 1.f;   // difference body2 - body1
       const v3 off = pos - ld3(rootcom + 3 * m.body_rootid[bb]);
@@ -1362,8 +1417,7 @@ __device__ __forceinline__ void rb_make_constraint(RbM m, RbLds& s, float* S, co
     const float dist = C[RB_CR_DIST], incl = C[RB_CR_INCL];
     const float imp = rb_impedance(C + RB_CR_SOLIMP, dist, incl);
     float K, B; rb_KB(m.timestep, C + RB_CR_SOLREF, C + RB_CR_SOLIMP, K, B);
-    float bd[6];
-    for (int r = 0; r < 6; r++) { float v = 0; for (int e = 0; e < nnz; e++) v += J[r * RB_CONW + e] * s.qvel[idx[e]]; bd[r] = v; }
+    if (!bd_done) for (int r = 0; r < 6; r++) { float v = 0; for (int e = 0; e < nnz; e++) v += J[r * RB_CONW + e] * s.qvel[idx[e]]; bd[r] = v; }
     if (dim == 1) {
       float* R = row + RB_ROWREC * adr;
       R[RB_RR_TYPE] = 4.f; R[RB_RR_ID] = (float)c; R[RB_RR_AUX] = 0.f; R[RB_RR_FLOSS] = 0.f;
@@ -1755,6 +1809,59 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
   // (one word per thread at 256 threads, three at 64; the load is issued before the current contact is added, the LDS store after it, so that the
   //  load's latency is covered by the adding instead of being waited for in front of it)
   const float* cloc = SC(CONLOC);
+#ifndef RB_HESS_SERIAL
+  if (RB_NWAVE == 1) {
+    // One wave per env (round 5): ALL contacts' entries at once.  The (contact, dof pair) items of up to 64 contacts are numbered through a prefix sum of
+    // nnz (nnz + 1) / 2; a lane takes items w = lane, lane + 64, ..., fetches its two Jacobian columns, the weight and the block rows straight from the scratch row
+    // (independent loads, all in flight together) and adds its product into the block with an LDS atomic.  A single wave issues its LDS atomics in program order
+    // and resolves same-address lanes in lane order, so the sums are run-to-run identical (rg_kernel.h relies on the same property); what is gone is one barrier,
+    // one staging round trip and 40+ idle lanes per contact.  (Several waves would interleave their atomics: the large configuration keeps the loop below.)
+    int* offs = (int*)s.cst;   // 65 words: item offsets of this chunk's contacts
+    for (int c0 = 0; c0 < s.ncon; c0 += 64) {
+      const int c = c0 + TID;
+      int cnt = 0;
+      if (c < s.ncon && Wc[RB_NW * c + RB_NW - 1] != 0.f) { const int nnz = (int)con[RB_CONREC * c + RB_CR_NNZ]; cnt = nnz * (nnz + 1) / 2; }
+      int incl = cnt;
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl(incl, TID >= o ? TID - o : TID); if (TID >= o) incl += t; }
+      offs[TID + 1] = incl;
+      if (TID == 0) offs[0] = 0;
+      BSYNC();
+      const int total = offs[64];
+      for (int w = TID; w < total; w += 64) {
+        int lo = 0, hi = 64;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= w) lo = mid; else hi = mid; }
+        const int cc = c0 + lo, wl = w - offs[lo];
+        int ea = (int)((sqrtf(8.f * (float)wl + 1.f) - 1.f) * 0.5f);
+        if (ea * (ea + 1) / 2 > wl) ea--; else if ((ea + 1) * (ea + 2) / 2 <= wl) ea++;
+        const int eb = wl - ea * (ea + 1) / 2;
+        const float* K = cj + 6 * RB_CONW * cc; const float* W = Wc + RB_NW * cc;
+        const float mode = W[RB_NW - 1];
+        const int dim = (int)con[RB_CONREC * cc + RB_CR_DIM];
+        float ja[6], jb[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) { ja[j] = j < dim ? K[j * RB_CONW + ea] : 0.f; jb[j] = j < dim ? K[j * RB_CONW + eb] : 0.f; }
+        float v;
+        if (mode == 1.f) {
+          v = W[0] * ja[0] * jb[0];
+          for (int k = 0; k < dim - 1; k++) v += W[1 + k] * (ja[0] * jb[k + 1] + ja[k + 1] * jb[0]) + W[6 + k] * ja[k + 1] * jb[k + 1];
+        } else if (mode == 3.f) {
+          v = 0.f;
+          for (int j = 0; j < dim; j++) v += W[j * (j + 1) / 2 + j] * ja[j] * jb[j];
+        } else {
+          v = 0.f;
+          for (int j = 0; j < dim; j++) {
+            v += W[j * (j + 1) / 2 + j] * ja[j] * jb[j];
+            for (int k = 0; k < j; k++) { const float wk = W[j * (j + 1) / 2 + k]; if (wk != 0.f) v += wk * (ja[j] * jb[k] + ja[k] * jb[j]); }
+          }
+        }
+        const int la = (int)cloc[RB_CONW * cc + ea], lb = (int)cloc[RB_CONW * cc + eb];
+        atomicAdd(&s.A[la >= lb ? RB_TRI(la, lb) : RB_TRI(lb, la)], v);
+      }
+      BSYNC();
+    }
+    return;
+  }
+#endif
   constexpr int NST = (RB_CST + RB_T - 1) / RB_T;   // words per thread (1 at 256 threads)
   struct Staged { float v[NST]; };
   auto stage_load = [&](int c) -> Staged {

@@ -13,7 +13,13 @@ def _oracle_from_kernel(env, row, n_substeps):
     """An OracleRearrangeEnv holding env `row`'s state (both worlds), goal and previous success count."""
     from oracle import rearrange_oracle as RO
 
-    o = RO.OracleRearrangeEnv(env.model, env.solver_model, env.N, n_substeps=n_substeps, max_position_change=env.tcp.max_position_change)
+    model = env.model
+    if getattr(env, "per_env_parameters", False):
+        # the env's own model: its parameter block as the kernel reads it (the reference's randomizers have written it at reset -- GeomSolimpRandomizer clips dmin / dmax
+        # into [0.5, 0.99] even at parameter 0, randomization/sim.py:183-268 -- and so has stabilize_objects' damping change)
+        P = env.sim.params
+        model = env.model.copy_with(**{("opt_gravity" if k == "gravity" else k): P[k][row].cpu().numpy().astype(np.float64) for k in P.keys() if P[k].shape[1] > 0})
+    o = RO.OracleRearrangeEnv(model, env.solver_model, env.N, n_substeps=n_substeps, max_position_change=env.tcp.max_position_change)
     for sim, os_ in ((env.sim, o.main.sim), (env.solver_sim, o.solver.sim)):
         for name, f in (("qpos", sim.qpos), ("qvel", sim.qvel), ("ctrl", sim.ctrl), ("pid", sim.pid), ("qacc_warmstart", sim.qacc_warmstart)):
             getattr(os_, name)[:] = f[row].cpu().numpy().astype(np.float64)
@@ -100,7 +106,8 @@ def _check_steps(lib, device, B, n_substeps, nsteps, tol_scale=1.0, make=None, t
         e = np.array(worst[k])
         if same.any():
             assert np.median(e[same]) <= tl and e[same].max() <= max(SAME_HISTORY_TAIL * tl, 1e-6), (k, np.median(e[same]), e[same].max(), int(same.sum()))
-        assert e.max() <= max(EVENT_TAIL * tl * tol_scale, 1e-6), (k, np.median(e), e.max())
+        if tl > 0:      # (a 0 / 1 contact flag can differ on a step whose contact history differs: that is what the classification says)
+            assert e.max() <= max(EVENT_TAIL * tl * tol_scale, 1e-6), (k, np.median(e), e.max())
     return env
 
 
