@@ -144,26 +144,36 @@ __device__ __forceinline__ void rb_kinematics(RbM m, RbLds& s, float* S) {
     const int b = TID; const bool on = b > 0 && b < m.nbody;
     const int p = on ? m.body_parentid[b] : 0, lvl = on ? m.b_body_level[b] : -1;
     v3 pos = mk3(0, 0, 0); q4 quat; quat.w = 1; quat.x = quat.y = quat.z = 0;
+    // the body's own constants and its first joint's are fetched BEFORE the level sweep (round 5): a level's iteration is then arithmetic and lane exchange only,
+    // instead of a chain of model loads per level (the arm is ten levels deep); further joints of a body are read in the sweep as before
+    const int bb = on ? b : 0;
+    const v3 bpos = ld3(PRM(body_pos, RB_P_BODY_POS) + 3 * bb); const q4 bquat = ldq(m.body_quat + 4 * bb);
+    const int mocapid = m.nmocap > 0 ? m.body_mocapid[bb] : -1, jn = on ? m.body_jntnum[bb] : 0, j0 = m.body_jntadr[bb];
+    const int jj = jn > 0 ? j0 : 0;
+    const int t0 = m.jnt_type[jj], qa0 = m.jnt_qposadr[jj];
+    const v3 jpos0 = ld3(m.jnt_pos + 3 * jj), jaxis0 = ld3(m.jnt_axis + 3 * jj);
+    const float q00 = m.qpos0[qa0];
     for (int L = 0; L < m.nlevel; L++) {
       q4 pq; pq.w = __shfl(quat.w, p); pq.x = __shfl(quat.x, p); pq.y = __shfl(quat.y, p); pq.z = __shfl(quat.z, p);
       const v3 pp = mk3(__shfl(pos.x, p), __shfl(pos.y, p), __shfl(pos.z, p));
       if (lvl != L) continue;
-      pos = pp + qrot(pq, ld3(PRM(body_pos, RB_P_BODY_POS) + 3 * b));
-      quat = qmul(pq, ldq(m.body_quat + 4 * b));
-      if (m.nmocap > 0 && m.body_mocapid[b] >= 0) { const float* mc = s.mocap + 7 * m.body_mocapid[b]; pos = ld3(mc); quat = ldq(mc + 3); }
-      for (int k = 0; k < m.body_jntnum[b]; k++) {
-        const int j = m.body_jntadr[b] + k, qa = m.jnt_qposadr[j], t = m.jnt_type[j];
+      pos = pp + qrot(pq, bpos);
+      quat = qmul(pq, bquat);
+      if (mocapid >= 0) { const float* mc = s.mocap + 7 * mocapid; pos = ld3(mc); quat = ldq(mc + 3); }
+      for (int k = 0; k < jn; k++) {
+        const int j = j0 + k, qa = k == 0 ? qa0 : m.jnt_qposadr[j], t = k == 0 ? t0 : m.jnt_type[j];
         if (t == RG_JNT_FREE) {
           pos = ld3(s.qpos + qa); quat = qnormalize(ldq(s.qpos + qa + 3));
           st3(xanchor + 3 * j, pos); st3(xaxis + 3 * j, mk3(0, 0, 1));
           continue;
         }
-        const v3 jpos = ld3(m.jnt_pos + 3 * j), jaxis = ld3(m.jnt_axis + 3 * j);
+        const v3 jpos = k == 0 ? jpos0 : ld3(m.jnt_pos + 3 * j), jaxis = k == 0 ? jaxis0 : ld3(m.jnt_axis + 3 * j);
         const v3 anchor = pos + qrot(quat, jpos), axis = qrot(quat, jaxis);
         st3(xanchor + 3 * j, anchor); st3(xaxis + 3 * j, axis);
-        if (t == RG_JNT_SLIDE) pos = pos + axis * (s.qpos[qa] - m.qpos0[qa]);
+        const float q0 = k == 0 ? q00 : m.qpos0[qa];
+        if (t == RG_JNT_SLIDE) pos = pos + axis * (s.qpos[qa] - q0);
         else {
-          const q4 ql = (t == RG_JNT_BALL) ? qnormalize(ldq(s.qpos + qa)) : axisangle(jaxis, s.qpos[qa] - m.qpos0[qa]);
+          const q4 ql = (t == RG_JNT_BALL) ? qnormalize(ldq(s.qpos + qa)) : axisangle(jaxis, s.qpos[qa] - q0);
           quat = qmul(quat, ql);
           pos = anchor - qrot(quat, jpos);
         }
@@ -801,6 +811,15 @@ __device__ __forceinline__ void rb_velocity(RbM m, RbLds& s, float* S) {
     float cv[6], ca[6];
 #pragma unroll
     for (int c = 0; c < 6; c++) { cv[c] = 0.f; ca[c] = (b == 0 && c >= 3) ? -PRM(opt_gravity, RB_P_GRAVITY)[c - 3] : 0.f; }
+    // (as in rb_kinematics: a body with ONE hinge or slide joint -- every link of the arm's ten-level chain -- has its joint's motion axis and velocity fetched before
+    //  the sweep and keeps the axis' time derivative in registers: no memory round trip inside a level for it; the arithmetic is unchanged)
+    const int bb = on ? b : 0;
+    const int jn = on ? m.body_jntnum[bb] : 0, j0 = m.body_jntadr[bb], dn = on ? m.body_dofnum[bb] : 0, d0 = m.body_dofadr[bb];
+    const int t0 = m.jnt_type[jn > 0 ? j0 : 0], da0 = m.jnt_dofadr[jn > 0 ? j0 : 0];
+    const bool single = jn == 1 && dn == 1 && (t0 == RG_JNT_HINGE || t0 == RG_JNT_SLIDE);
+    float cd0[6]; const float qv0 = s.qvel[single ? da0 : 0];
+#pragma unroll
+    for (int c = 0; c < 6; c++) cd0[c] = cdof[6 * (single ? da0 : 0) + c];
     for (int L = 0; L < m.nlevel; L++) {
       float pv[6], pa[6];
 #pragma unroll
@@ -808,8 +827,17 @@ __device__ __forceinline__ void rb_velocity(RbM m, RbLds& s, float* S) {
       if (lvl != L) continue;
 #pragma unroll
       for (int c = 0; c < 6; c++) { cv[c] = pv[c]; ca[c] = pa[c]; }
-      for (int k = 0; k < m.body_jntnum[b]; k++) {
-        const int j = m.body_jntadr[b] + k, t = m.jnt_type[j]; int da = m.jnt_dofadr[j];
+      if (single) {
+        float dd[6];
+        cross_motion(dd, cv, cd0);
+#pragma unroll
+        for (int c = 0; c < 6; c++) { cdofdot[6 * da0 + c] = dd[c]; cv[c] += cd0[c] * qv0; }
+#pragma unroll
+        for (int c = 0; c < 6; c++) ca[c] += dd[c] * qv0;
+        continue;
+      }
+      for (int k = 0; k < jn; k++) {
+        const int j = j0 + k, t = m.jnt_type[j]; int da = m.jnt_dofadr[j];
         if (t == RG_JNT_FREE) {
           for (int i = 0; i < 3; i++) { for (int c = 0; c < 6; c++) { cdofdot[6 * (da + i) + c] = 0.f; cv[c] += cdof[6 * (da + i) + c] * s.qvel[da + i]; } }
           da += 3;
@@ -822,7 +850,7 @@ __device__ __forceinline__ void rb_velocity(RbM m, RbLds& s, float* S) {
           for (int c = 0; c < 6; c++) cv[c] += cdof[6 * da + c] * s.qvel[da];
         }
       }
-      for (int k = 0; k < m.body_dofnum[b]; k++) { const int i = m.body_dofadr[b] + k; for (int c = 0; c < 6; c++) ca[c] += cdofdot[6 * i + c] * s.qvel[i]; }
+      for (int k = 0; k < dn; k++) { const int i = d0 + k; for (int c = 0; c < 6; c++) ca[c] += cdofdot[6 * i + c] * s.qvel[i]; }
     }
     if (on) {
       float t1[6], t2[6], t3[6];
@@ -1270,10 +1298,45 @@ __device__ __forceinline__ void rb_make_constraint(RbM m, RbLds& s, float* S, co
     R[RB_RR_TYPE] = ten ? 1.f : 0.f; R[RB_RR_ID] = (float)id; R[RB_RR_AUX] = 1.f; R[RB_RR_FLOSS] = floss; R[RB_RR_D] = 1.f / Rr;
     R[RB_RR_AREF] = -B * rb_srow_dot(m, S, ten ? 1 : 0, id, 1.f, s.qvel);
   }
-  // limits: joints then tendons, compacted in order by one thread (at most 2 x (limited joints + limited tendons) candidates)
+  // limits: joints then tendons, compacted in order.  One wave per env (round 5): a lane per (joint or tendon, side) candidate, the active ones numbered by a ballot
+  // prefix -- the same rows in the same order as the serial loop below, without its chain of dependent loads per candidate
+  int nlim_par = -1;
+  if (RB_NWAVE == 1) {
+    int n = nf;
+    const int ncand = 2 * (m.nlim_jnt + m.nlim_ten);
+    for (int k0 = 0; k0 < ncand; k0 += 64) {
+      const int k = k0 + TID, q = k >> 1, side = (k & 1) ? 1 : -1;
+      bool act = false; float dist = 0.f, margin = 0.f; int id = 0; bool ten = false;
+      if (k < ncand) {
+        ten = q >= m.nlim_jnt;
+        id = ten ? m.b_lim_ten[q - m.nlim_jnt] : m.b_lim_jnt[q];
+        const float value = ten ? SC(TENLEN)[id] : s.qpos[m.jnt_qposadr[id]];
+        const float* range = ten ? PRM(tendon_range, RB_P_TENDON_RANGE) + 2 * id : PRM(jnt_range, RB_P_JNT_RANGE) + 2 * id;
+        margin = ten ? m.tendon_margin[id] : PRM(jnt_margin, RB_P_JNT_MARGIN)[id];
+        dist = side * (range[(side + 1) / 2] - value);
+        act = dist < margin;
+      }
+      const unsigned long long bal = __ballot(act);
+      const int slot = n + __popcll(bal & ((1ull << TID) - 1ull));
+      if (act && slot < m.maxrow) {
+        float* R = row + RB_ROWREC * slot;
+        const float* solref = ten ? m.tendon_solref_lim + 2 * id : m.jnt_solref + 2 * id;
+        const float* solimp = ten ? m.tendon_solimp_lim + 5 * id : m.jnt_solimp + 5 * id;
+        const float diag = ten ? tiw[id] : diw[m.jnt_dofadr[id]];
+        const float imp = rb_impedance(solimp, dist, margin);
+        const float Rr = fmaxf(RB_MINVAL, (1.f - imp) * diag / imp);
+        float K, B; rb_KB(m.timestep, solref, solimp, K, B);
+        R[RB_RR_TYPE] = ten ? 3.f : 2.f; R[RB_RR_ID] = (float)id; R[RB_RR_AUX] = (float)(-side); R[RB_RR_FLOSS] = 0.f; R[RB_RR_D] = 1.f / Rr;
+        R[RB_RR_AREF] = -B * rb_srow_dot(m, S, ten ? 3 : 2, id, (float)(-side), s.qvel) - K * imp * (dist - margin);
+      }
+      n += __popcll(bal);
+      if (n > m.maxrow) n = m.maxrow;
+    }
+    nlim_par = n - nf;
+  }
   if (TID == 0) {
     int n = nf;
-    for (int q = 0; q < m.nlim_jnt + m.nlim_ten; q++) {
+    for (int q = 0; q < (nlim_par >= 0 ? 0 : m.nlim_jnt + m.nlim_ten); q++) {
       const bool ten = q >= m.nlim_jnt;
       const int id = ten ? m.b_lim_ten[q - m.nlim_jnt] : m.b_lim_jnt[q];
       const float value = ten ? SC(TENLEN)[id] : s.qpos[m.jnt_qposadr[id]];
@@ -1295,14 +1358,39 @@ __device__ __forceinline__ void rb_make_constraint(RbM m, RbLds& s, float* S, co
         }
       }
     }
+    if (nlim_par >= 0) n = nf + nlim_par;
     s.nlim = n - nf;
-    // contacts: row addresses
-    for (int c = 0; c < s.ncon; c++) {
-      const int np = rb_nrows((int)con[RB_CONREC * c + RB_CR_KIND], (int)con[RB_CONREC * c + RB_CR_DIM]);
-      if (n + np <= m.maxrow) { con[RB_CONREC * c + RB_CR_ADR] = (float)n; n += np; }
-      else { con[RB_CONREC * c + RB_CR_ADR] = -1.f; s.status |= RG_STATUS_ROW_FULL; }
+    s.nefc = n;      // (the contacts' rows follow: below)
+  }
+  BSYNC();
+  // contacts: row addresses = running sum of the contacts' row counts.  One wave: a lane per contact and a wave prefix sum when everything fits (the usual case);
+  // else -- and with several waves -- the serial walk with its skip-on-overflow rule
+  {
+    int n = s.nefc;
+    bool done = false;
+    if (RB_NWAVE == 1 && s.ncon <= 64) {
+      const int np = TID < s.ncon ? rb_nrows((int)con[RB_CONREC * TID + RB_CR_KIND], (int)con[RB_CONREC * TID + RB_CR_DIM]) : 0;
+      int incl = np;
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl(incl, TID >= o ? TID - o : TID); if (TID >= o) incl += t; }
+      const int total = __shfl(incl, 63);
+      if (n + total <= m.maxrow) {
+        if (TID < s.ncon) con[RB_CONREC * TID + RB_CR_ADR] = (float)(n + incl - np);
+        BSYNC();
+        if (TID == 0) s.nefc = n + total;
+        done = true;
+      }
     }
-    s.nefc = n;
+    if (!done) {
+      BSYNC();
+      if (TID == 0) {
+        for (int c = 0; c < s.ncon; c++) {
+          const int np = rb_nrows((int)con[RB_CONREC * c + RB_CR_KIND], (int)con[RB_CONREC * c + RB_CR_DIM]);
+          if (n + np <= m.maxrow) { con[RB_CONREC * c + RB_CR_ADR] = (float)n; n += np; }
+          else { con[RB_CONREC * c + RB_CR_ADR] = -1.f; s.status |= RG_STATUS_ROW_FULL; }
+        }
+        s.nefc = n;
+      }
+    }
   }
   BSYNC();
   // contact Jacobians: one thread per contact builds the dof list and the six basis rows
@@ -1973,7 +2061,7 @@ __device__ __forceinline__ void rb_ls_acc(float D, float jar, float jv, float fl
 }
 // the elliptic contacts' cost along the search direction and its first two derivatives in alpha (oracle ls_eval, elliptic branch): one thread per contact
 __device__ __forceinline__ void rb_ls_cones(const float* row, const float* con, int ncon, float alpha, float& cst, float& grd, float& hss) {
-  for (int c = TID; c < ncon; c += RB_T) {
+  for (int c = TID + RB_T; c < ncon; c += RB_T) {      // (contact TID itself: rb_ls_cone_eval on the thread's cached copy)
     const float* C = con + RB_CONREC * c;
     const int adr = (int)C[RB_CR_ADR], dim = (int)C[RB_CR_DIM];
     if ((int)C[RB_CR_KIND] != RB_KIND_ELLIPTIC || adr < 0 || dim < 2) continue;
@@ -1996,7 +2084,47 @@ __device__ __forceinline__ void rb_ls_cones(const float* row, const float* con, 
     }
   }
 }
-__device__ __forceinline__ RbLs rb_ls_eval(RbLds& s, const float* row, const float* con, int ncone, const RbLsRows& own, int nefc, float alpha, float q0, float q1, float q2) {
+// the elliptic contact a thread owns in the line search (contact TID; contacts beyond RB_T go through rb_ls_cones each time): its rows' D / jar / jv and its friction
+// coefficients, loaded ONCE per line search instead of once per evaluation (the same arithmetic on the same numbers as rb_ls_cones)
+struct RbLsCone { int dim; float mu, fr[5], D[6], jar[6], jv[6]; };
+__device__ __forceinline__ void rb_ls_cone_load(const float* row, const float* con, int ncon, RbLsCone& k) {
+  k.dim = 0;
+  if (TID >= ncon) return;
+  const float* C = con + RB_CONREC * TID;
+  const int adr = (int)C[RB_CR_ADR], dim = (int)C[RB_CR_DIM];
+  if ((int)C[RB_CR_KIND] != RB_KIND_ELLIPTIC || adr < 0 || dim < 2) return;
+  k.dim = dim; k.mu = C[RB_CR_SOLREF];
+  const float* R0 = row + RB_ROWREC * adr;
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    const float* R = R0 + RB_ROWREC * (j < dim ? j : 0);
+    k.D[j] = R[RB_RR_D]; k.jar[j] = R[RB_RR_JAR]; k.jv[j] = R[RB_RR_JV];
+    if (j >= 1) k.fr[j - 1] = C[RB_CR_FRIC + (j < dim ? j - 1 : 0)];
+  }
+}
+__device__ __forceinline__ void rb_ls_cone_eval(const RbLsCone& k, float alpha, float& cst, float& grd, float& hss) {
+  const int dim = k.dim;
+  if (dim < 2) return;
+  const float mu = k.mu;
+  float T = 0.f, UV = 0.f, VV = 0.f;
+  const float N = (k.jar[0] + alpha * k.jv[0]) * mu, N1 = k.jv[0] * mu;
+#pragma unroll
+  for (int j = 1; j < 6; j++) if (j < dim) {
+    const float f = k.fr[j - 1];
+    const float u = (k.jar[j] + alpha * k.jv[j]) * f, v = k.jv[j] * f;
+    T += u * u; UV += u * v; VV += v * v;
+  }
+  T = sqrtf(T);
+  if (N >= mu * T || (T <= 0.f && N >= 0.f)) return;
+  if (mu * N + T <= 0.f || (T <= 0.f && N < 0.f)) {
+#pragma unroll
+    for (int j = 0; j < 6; j++) if (j < dim) { const float D = k.D[j], jv = k.jv[j], x = k.jar[j] + alpha * jv; cst += 0.5f * D * x * x; grd += D * x * jv; hss += D * jv * jv; }
+  } else {
+    const float Dm = k.D[0] / (mu * mu * (1.f + mu * mu)), NT = N - mu * T, T1 = UV / T, T2 = (VV - T1 * T1) / T, dN = N1 - mu * T1;
+    cst += 0.5f * Dm * NT * NT; grd += Dm * NT * dN; hss += Dm * (dN * dN - NT * mu * T2);
+  }
+}
+__device__ __forceinline__ RbLs rb_ls_eval(RbLds& s, const float* row, const float* con, int ncone, const RbLsRows& own, const RbLsCone& cone, int nefc, float alpha, float q0, float q1, float q2) {
   float cst = 0, grd = 0, hss = 0;
 #pragma unroll
   for (int k = 0; k < 2; k++) if (TID + k * RB_T < nefc) rb_ls_acc(own.D[k], own.jar[k], own.jv[k], own.fl[k], own.fric[k], alpha, cst, grd, hss);
@@ -2004,7 +2132,10 @@ __device__ __forceinline__ RbLs rb_ls_eval(RbLds& s, const float* row, const flo
     const float* R = row + RB_ROWREC * r;
     rb_ls_acc(R[RB_RR_D], R[RB_RR_JAR], R[RB_RR_JV], R[RB_RR_FLOSS], rb_ls_class(R), alpha, cst, grd, hss);
   }
-  if (ncone > 0) rb_ls_cones(row, con, ncone, alpha, cst, grd, hss);
+  if (ncone > 0) {
+    rb_ls_cone_eval(cone, alpha, cst, grd, hss);
+    if (ncone > RB_T) rb_ls_cones(row, con, ncone, alpha, cst, grd, hss);
+  }
   rb_sum3(s, cst, grd, hss);
   RbLs p; p.cost = alpha * alpha * q2 + alpha * q1 + q0 + cst; p.grad = 2.f * alpha * q2 + q1 + grd; p.hess = 2.f * q2 + hss;
   return p;
@@ -2018,14 +2149,16 @@ __device__ __forceinline__ float rb_line_search(RbLds& s, const float* row, cons
     const float* R = row + RB_ROWREC * (r < nefc ? r : 0);
     own.D[k] = R[RB_RR_D]; own.jar[k] = R[RB_RR_JAR]; own.jv[k] = R[RB_RR_JV]; own.fl[k] = R[RB_RR_FLOSS]; own.fric[k] = rb_ls_class(R);
   }
-  const RbLs p0 = rb_ls_eval(s, row, con, ncone, own, nefc, 0.f, q0, q1, q2);
+  RbLsCone cone;
+  rb_ls_cone_load(row, con, ncone, cone);
+  const RbLs p0 = rb_ls_eval(s, row, con, ncone, own, cone, nefc, 0.f, q0, q1, q2);
   if (p0.grad >= 0 || p0.hess <= 0) return 0.f;
   float lo = 0, hi = -1, glo = p0.grad, hlo = p0.hess, ghi = 0, hhi = 0;
   float a = -p0.grad / p0.hess;
   float best_a = 0.f, best_cost = p0.cost;   // the best point seen: what is returned when the iteration limit ends the search
   float wprev = 3.0e38f; int since = 0;
   for (int it = 0; it < maxit; it++) {
-    const RbLs p = rb_ls_eval(s, row, con, ncone, own, nefc, a, q0, q1, q2);
+    const RbLs p = rb_ls_eval(s, row, con, ncone, own, cone, nefc, a, q0, q1, q2);
     if (p.cost < best_cost) { best_cost = p.cost; best_a = a; }
     if (fabsf(p.grad) < gtol) return a;
     if (p.grad < 0) { lo = a; glo = p.grad; hlo = p.hess; } else { hi = a; ghi = p.grad; hhi = p.hess; }
