@@ -1804,8 +1804,17 @@ __device__ __forceinline__ void rb_row_diag(RbM m, RbLds& s, float* S, int g, fl
 }
 
 // s.A (holding the group's block of M) += J' diag(D, quadratic rows) J restricted to group g
+// (-DRB_HESS_PROBE=k: cycles of section k of the assembly -- 1 static rows, 2 contact weights, 3 the contacts' entries -- accumulate in prof[15]; a profiling build)
+#ifdef RB_HESS_PROBE
+#define RB_HPROBE_BEGIN(k) long long tprobe##k = 0; if (RB_HESS_PROBE == k) { BSYNC(); tprobe##k = rg_clock(); }
+#define RB_HPROBE_END(k) if (RB_HESS_PROBE == k) { BSYNC(); if (TID == 0) s.prof[15] += (float)(rg_clock() - tprobe##k); }
+#else
+#define RB_HPROBE_BEGIN(k)
+#define RB_HPROBE_END(k)
+#endif
 __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g) {
   const float* row = SC(ROW); const float* con = SC(CON); const float* cj = SC(CONJ); const int* cidx = (const int*)SC(CONIDX);
+  RB_HPROBE_BEGIN(1)
   const int nstat = m.nfric_dof + m.nfric_ten + s.nlim;
   // static rows: dof rows add to the diagonal (friction rows first, then the limit rows: a dof has one friction row and at most
   // one active limit side, so neither pass has two writers of an entry), tendon rows as small outer products one row at a time
@@ -1836,6 +1845,8 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
   }
   // contacts: A += Jc' W Jc with the 6 x 6 weight W of the contact's quadratic pyramid edges (w_row = e0 +- mu_k e_(k+1)):
   // the weights of all contacts first (one contact per thread), then the contacts one at a time, one (a, b) entry per thread
+  RB_HPROBE_END(1)
+  RB_HPROBE_BEGIN(2)
   float* Wc = SC(CONF);   // RB_NW words per contact.  Pyramidal: W00, W0k[5], Wkk[5] (mode 1).  Elliptic / equality: the lower triangle of the 6 x 6 weight
                           // of the basis rows (mode 2): diag(D) of the quadratic rows, or the cone's Hessian in its middle zone (engine_solver.c HessianCone)
   if (TID == 0) s.wcnt[0] = 0;
@@ -1889,6 +1900,7 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
   const bool any = s.wcnt[0] != 0;
   BSYNC();
   if (TID == 0) s.wcnt[0] = 0;
+  RB_HPROBE_END(2)
   if (!any) return;
   // One contact at a time (two contacts may share entries; the order of the sums is fixed), but its data -- six basis Jacobian rows,
   // the dofs' rows in the block, the weights -- is staged through LDS by one load per thread while the previous contact is being
@@ -1899,54 +1911,81 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
   const float* cloc = SC(CONLOC);
 #ifndef RB_HESS_SERIAL
   if (RB_NWAVE == 1) {
-    // One wave per env (round 5): ALL contacts' entries at once.  The (contact, dof pair) items of up to 64 contacts are numbered through a prefix sum of
-    // nnz (nnz + 1) / 2; a lane takes items w = lane, lane + 64, ..., fetches its two Jacobian columns, the weight and the block rows straight from the scratch row
-    // (independent loads, all in flight together) and adds its product into the block with an LDS atomic.  A single wave issues its LDS atomics in program order
-    // and resolves same-address lanes in lane order, so the sums are run-to-run identical (rg_kernel.h relies on the same property); what is gone is one barrier,
-    // one staging round trip and 40+ idle lanes per contact.  (Several waves would interleave their atomics: the large configuration keeps the loop below.)
-    int* offs = (int*)s.cst;   // 65 words: item offsets of this chunk's contacts
+    RB_HPROBE_BEGIN(3)
+    // One wave per env (round 5): a lane per (contact, Jacobian column).  The columns of up to 64 contacts are numbered through a prefix sum of nnz; a round takes as
+    // many whole contacts as fit 64 lanes.  A lane fetches ITS column of the six basis rows, its block row and the contact's weight once (one round of independent
+    // loads), then walks the contact's columns k = 0 .. nnz - 1: the partner column comes by lane exchange from the lane that holds it, and the pair (e, k <= e) is
+    // added into the block with an LDS atomic.  A single wave issues its LDS atomics in program order and resolves same-address lanes in lane order, so the sums
+    // are run-to-run identical (rg_kernel.h relies on the same property).  Against the staged loop below: no barrier and no staging round trip per contact, no idle
+    // lanes; against one entry per lane: a sixth of the loads.  (Several waves would interleave their atomics: the large configuration keeps the loop below.)
+    int* offs = (int*)s.cst;           // 65 words: column offsets of this chunk's contacts
+    int* cmeta = (int*)s.cst + 65;     // 64 words: dim | mode << 8 of this chunk's contacts
     for (int c0 = 0; c0 < s.ncon; c0 += 64) {
       const int c = c0 + TID;
-      int cnt = 0;
-      if (c < s.ncon && Wc[RB_NW * c + RB_NW - 1] != 0.f) { const int nnz = (int)con[RB_CONREC * c + RB_CR_NNZ]; cnt = nnz * (nnz + 1) / 2; }
+      int cnt = 0, meta = 0;
+      if (c < s.ncon) { const int mode = (int)Wc[RB_NW * c + RB_NW - 1]; if (mode != 0) { cnt = (int)con[RB_CONREC * c + RB_CR_NNZ]; meta = (int)con[RB_CONREC * c + RB_CR_DIM] | (mode << 8); } }
       int incl = cnt;
       for (int o = 1; o < 64; o <<= 1) { const int t = __shfl(incl, TID >= o ? TID - o : TID); if (TID >= o) incl += t; }
-      offs[TID + 1] = incl;
+      BSYNC();
+      offs[TID + 1] = incl; cmeta[TID] = meta;
       if (TID == 0) offs[0] = 0;
       BSYNC();
-      const int total = offs[64];
-      for (int w = TID; w < total; w += 64) {
-        int lo = 0, hi = 64;
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= w) lo = mid; else hi = mid; }
-        const int cc = c0 + lo, wl = w - offs[lo];
-        int ea = (int)((sqrtf(8.f * (float)wl + 1.f) - 1.f) * 0.5f);
-        if (ea * (ea + 1) / 2 > wl) ea--; else if ((ea + 1) * (ea + 2) / 2 <= wl) ea++;
-        const int eb = wl - ea * (ea + 1) / 2;
+      int cs = 0;                       // first contact (chunk-local) of the round
+      while (cs < 64 && offs[cs] < offs[64]) {
+        // the round's contacts: cs .. ce - 1, the longest run whose columns fit the wave (a single contact has at most RB_CONW <= 64 columns)
+        const unsigned long long fit = __ballot(TID >= cs && offs[TID + 1] - offs[cs] <= 64);
+        const int ce = cs + __popcll(fit);
+        const int t = offs[cs] + TID;
+        const bool on = t < offs[ce];
+        int lo = cs, hi = ce;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= t) lo = mid; else hi = mid; }
+        const int cl = on ? lo : cs, cc = c0 + cl, e = on ? t - offs[cl] : 0;
+        const int base = offs[cl] - offs[cs], nnz = offs[cl + 1] - offs[cl], dim = cmeta[cl] & 255, mode = cmeta[cl] >> 8;
         const float* K = cj + 6 * RB_CONW * cc; const float* W = Wc + RB_NW * cc;
-        const float mode = W[RB_NW - 1];
-        const int dim = (int)con[RB_CONREC * cc + RB_CR_DIM];
-        float ja[6], jb[6];
+        float ja[6], w[21];
 #pragma unroll
-        for (int j = 0; j < 6; j++) { ja[j] = j < dim ? K[j * RB_CONW + ea] : 0.f; jb[j] = j < dim ? K[j * RB_CONW + eb] : 0.f; }
-        float v;
-        if (mode == 1.f) {
-          v = W[0] * ja[0] * jb[0];
-          for (int k = 0; k < dim - 1; k++) v += W[1 + k] * (ja[0] * jb[k + 1] + ja[k + 1] * jb[0]) + W[6 + k] * ja[k + 1] * jb[k + 1];
-        } else if (mode == 3.f) {
-          v = 0.f;
-          for (int j = 0; j < dim; j++) v += W[j * (j + 1) / 2 + j] * ja[j] * jb[j];
-        } else {
-          v = 0.f;
-          for (int j = 0; j < dim; j++) {
-            v += W[j * (j + 1) / 2 + j] * ja[j] * jb[j];
-            for (int k = 0; k < j; k++) { const float wk = W[j * (j + 1) / 2 + k]; if (wk != 0.f) v += wk * (ja[j] * jb[k] + ja[k] * jb[j]); }
+        for (int q = 0; q < 6; q++) ja[q] = (on && q < dim) ? K[q * RB_CONW + e] : 0.f;
+        const int la = on ? (int)cloc[RB_CONW * cc + e] : 0;
+        // the weight: pyramid (mode 1) W00, W0k[5], Wkk[5]; diagonal (mode 3) the six diagonal entries; general (mode 2) the lower triangle of the 6 x 6
+#pragma unroll
+        for (int q = 0; q < 21; q++) w[q] = 0.f;
+        if (on && mode == 1) { for (int q = 0; q < 11; q++) w[q] = W[q]; }
+        else if (on && mode == 3) { for (int q = 0; q < 6; q++) if (q < dim) w[q] = W[q * (q + 1) / 2 + q]; }
+        else if (on) { for (int q = 0; q < 21; q++) w[q] = W[q]; }
+        int kmax = on ? nnz : 0;
+        for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(kmax, o); kmax = other > kmax ? other : kmax; }
+        for (int k = 0; k < kmax; k++) {
+          const int src = (base + (k < nnz ? k : 0)) & 63;
+          float jb[6];
+#pragma unroll
+          for (int q = 0; q < 6; q++) jb[q] = __shfl(ja[q], src);
+          const int lb = __shfl(la, src);
+          if (!(on && k <= e)) continue;
+          float v;
+          if (mode == 1) {
+            v = w[0] * ja[0] * jb[0];
+#pragma unroll
+            for (int q = 0; q < 5; q++) if (q < dim - 1) v += w[1 + q] * (ja[0] * jb[q + 1] + ja[q + 1] * jb[0]) + w[6 + q] * ja[q + 1] * jb[q + 1];
+          } else if (mode == 3) {
+            v = 0.f;
+#pragma unroll
+            for (int q = 0; q < 6; q++) if (q < dim) v += w[q] * ja[q] * jb[q];
+          } else {
+            v = 0.f;
+#pragma unroll
+            for (int q = 0; q < 6; q++) if (q < dim) {
+              v += w[q * (q + 1) / 2 + q] * ja[q] * jb[q];
+#pragma unroll
+              for (int r = 0; r < 5; r++) if (r < q) { const float wk = w[q * (q + 1) / 2 + r]; if (wk != 0.f) v += wk * (ja[q] * jb[r] + ja[r] * jb[q]); }
+            }
           }
+          atomicAdd(&s.A[la >= lb ? RB_TRI(la, lb) : RB_TRI(lb, la)], v);
         }
-        const int la = (int)cloc[RB_CONW * cc + ea], lb = (int)cloc[RB_CONW * cc + eb];
-        atomicAdd(&s.A[la >= lb ? RB_TRI(la, lb) : RB_TRI(lb, la)], v);
+        cs = ce;
       }
       BSYNC();
     }
+    RB_HPROBE_END(3)
     return;
   }
 #endif
@@ -1972,9 +2011,6 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
   };
   const Staged zero = {};
   int buf = 0;
-#ifdef RB_HESS_PROBE
-  const long long tprobe = rg_clock();
-#endif
   stage_store(0, stage_load(0));
   Staged next = s.ncon > 1 ? stage_load(1) : zero;   // three contacts in flight: the words stored at the end of a pass were requested two passes earlier
   Staged next2 = s.ncon > 2 ? stage_load(2) : zero;
@@ -2016,9 +2052,6 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
     next = next2; next2 = after;
     BSYNC();
   }
-#ifdef RB_HESS_PROBE
-  if (TID == 0) s.prof[15] += (float)(rg_clock() - tprobe);
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------- stage calls

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 5, seventh GPU call: line search with the cones in registers, limit rows and contact row addresses by ballot / prefix sum, kinematics and velocity sweeps with their
+# Round 5, A/B of the working tree against HEAD (generic; see the commit it was run for)
 # model loads hoisted (all bit-identical): head (the 88 k build) against the working tree, twice; then the rearrange GPU tests
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
