@@ -1410,6 +1410,41 @@ __device__ __forceinline__ void rb_make_constraint(RbM m, RbLds& s, float* S, co
         const q4 q1 = ldq(SC(XQUAT) + 4 * o1), q2 = ldq(SC(XQUAT) + 4 * o2);
         q4 qc; qc.w = q2.w; qc.x = -q2.x; qc.y = -q2.y; qc.z = -q2.z;
         const q4 qr = qmul(q1, ldq(L_eq_data + 7 * e + 3));
+#ifndef RB_ROWS_LEGACY
+        if (RB_NWAVE == 1) {
+          // (as for the contacts below: the dof list in LDS first, then every column formed in registers -- side 0 = body 1, then body 2 -- and stored once)
+          int* li = (int*)s.A + RB_CONW * TID;
+          for (int side = 0; side < 2; side++) {
+            const int bb = side ? o2 : o1;
+            if (bb <= 0 || m.body_weldid[bb] == 0) continue;
+            for (int i = m.b_body_lastdof[bb]; i >= 0; i = m.dof_parentid[i]) {
+              int q = 0;
+              while (q < nnz && (li[q] & 0xffff) != i) q++;
+              if (q == nnz) { if (nnz >= RB_CONW) continue; li[nnz++] = i | (1 << (16 + side)); }
+              else li[q] |= 1 << (16 + side);
+            }
+          }
+          const v3 offA = ld3(C + RB_CR_POS) - ld3(rootcom + 3 * m.body_rootid[o1 > 0 ? o1 : 0]), offB = ld3(SC(XPOS) + 3 * o2) - ld3(rootcom + 3 * m.body_rootid[o2 > 0 ? o2 : 0]);
+          for (int q = 0; q < nnz; q++) {
+            const int i = li[q] & 0xffff, sides = li[q] >> 16;
+            const v3 jr = ld3(cdof + 6 * i);
+            float col[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int side = 0; side < 2; side++) {
+              if (!((sides >> side) & 1)) continue;
+              const float sg = side ? -1.f : 1.f;
+              const v3 jp = rb_jacp(cdof, i, side ? offB : offA);
+              col[0] += sg * jp.x; col[1] += sg * jp.y; col[2] += sg * jp.z;
+              q4 ax; ax.w = 0.f; ax.x = sg * jr.x; ax.y = sg * jr.y; ax.z = sg * jr.z;
+              const q4 t2 = qmul(qmul(qc, ax), qr);
+              col[3] += 0.5f * t2.x; col[4] += 0.5f * t2.y; col[5] += 0.5f * t2.z;
+            }
+            idx[q] = i;
+#pragma unroll
+            for (int r = 0; r < 6; r++) J[r * RB_CONW + q] = col[r];
+          }
+        } else
+#endif
         for (int side = 0; side < 2; side++) {
           const int bb = side ? o2 : o1; const float sg = side ? -1.f : 1.f;   // body1 - body2 ("opposite of contact")
           if (bb <= 0 || m.body_weldid[bb] == 0) continue;
@@ -1855,7 +1890,8 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
     const float* C = con + RB_CONREC * c;
     const int adr = (int)C[RB_CR_ADR], kind = (int)C[RB_CR_KIND], dim = (int)C[RB_CR_DIM];
     float* W = Wc + RB_NW * c;
-    for (int k = 0; k < RB_NW; k++) W[k] = 0.f;
+    if (RB_NWAVE == 1) W[RB_NW - 1] = 0.f;      // (one wave: the consumer reads exactly the entries its mode defines, each of which is assigned below; no blanket zeroing)
+    else for (int k = 0; k < RB_NW; k++) W[k] = 0.f;
     if (!(adr >= 0 && m.b_dof_group[cidx[RB_CONW * c]] == g)) continue;
     if (kind == RB_KIND_PYRAMID) {
       float W00 = 0, W0k[5] = {0, 0, 0, 0, 0}, Wkk[5] = {0, 0, 0, 0, 0};
@@ -1890,7 +1926,7 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
         }
         any = true;
       } else {
-        for (int j = 0; j < dim; j++) { const float* R = R0 + RB_ROWREC * j; bool qd; float cst; rb_row_force(R, qd, cst); if (qd) { W[j * (j + 1) / 2 + j] = R[RB_RR_D]; any = true; } }
+        for (int j = 0; j < dim; j++) { const float* R = R0 + RB_ROWREC * j; bool qd; float cst; rb_row_force(R, qd, cst); if (qd) { W[j * (j + 1) / 2 + j] = R[RB_RR_D]; any = true; } else if (RB_NWAVE == 1) W[j * (j + 1) / 2 + j] = 0.f; }
         diag = true;
       }
       if (any) { W[RB_NW - 1] = diag ? 3.f : 2.f; s.wcnt[0] = 1; }   // (mode 3: a diagonal weight -- equality rows, cone contacts outside the middle zone: the common case of objects at rest)
