@@ -14,7 +14,7 @@ for tag in ("pmcR1", "pmcR2"):
     acc = {}
     for r in csv.DictReader(open(f[0])):
         d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-        if "rb_step_kernel" in r["Kernel_Name"] and d > 30e6:      # the main world's full launches (the solver world's are ~20 ms)
+        if "rb_step_kernel" in r["Kernel_Name"] and d > 20e6:      # the main world's full launches (round 5: ~26 ms; the solver world's are ~13 ms)
             acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     print(tag, {k: "%.3g" % (sum(v) / len(v)) for k, v in sorted(acc.items())}, "launches", len(next(iter(acc.values()), [])))
 PY
