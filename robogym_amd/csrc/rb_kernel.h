@@ -1301,11 +1301,11 @@ __device__ __forceinline__ void rb_make_constraint(RbM m, RbLds& s, float* S, co
   // limits: joints then tendons, compacted in order.  One wave per env (round 5): a lane per (joint or tendon, side) candidate, the active ones numbered by a ballot
   // prefix -- the same rows in the same order as the serial loop below, without its chain of dependent loads per candidate
   int nlim_par = -1;
-  if (RB_NWAVE == 1) {
+  if (WID == 0) {      // (several waves: wave 0 does this while the others wait at the barrier below, as they did for the serial walk)
     int n = nf;
     const int ncand = 2 * (m.nlim_jnt + m.nlim_ten);
     for (int k0 = 0; k0 < ncand; k0 += 64) {
-      const int k = k0 + TID, q = k >> 1, side = (k & 1) ? 1 : -1;
+      const int k = k0 + WL, q = k >> 1, side = (k & 1) ? 1 : -1;
       bool act = false; float dist = 0.f, margin = 0.f; int id = 0; bool ten = false;
       if (k < ncand) {
         ten = q >= m.nlim_jnt;
@@ -1317,7 +1317,7 @@ __device__ __forceinline__ void rb_make_constraint(RbM m, RbLds& s, float* S, co
         act = dist < margin;
       }
       const unsigned long long bal = __ballot(act);
-      const int slot = n + __popcll(bal & ((1ull << TID) - 1ull));
+      const int slot = n + __popcll(bal & ((1ull << WL) - 1ull));
       if (act && slot < m.maxrow) {
         float* R = row + RB_ROWREC * slot;
         const float* solref = ten ? m.tendon_solref_lim + 2 * id : m.jnt_solref + 2 * id;
@@ -1368,13 +1368,13 @@ __device__ __forceinline__ void rb_make_constraint(RbM m, RbLds& s, float* S, co
   {
     int n = s.nefc;
     bool done = false;
-    if (RB_NWAVE == 1 && s.ncon <= 64) {
-      const int np = TID < s.ncon ? rb_nrows((int)con[RB_CONREC * TID + RB_CR_KIND], (int)con[RB_CONREC * TID + RB_CR_DIM]) : 0;
+    if (s.ncon <= 64) {      // (several waves: each computes the same prefix from its own 64 lanes, wave 0 writes)
+      const int np = WL < s.ncon ? rb_nrows((int)con[RB_CONREC * WL + RB_CR_KIND], (int)con[RB_CONREC * WL + RB_CR_DIM]) : 0;
       int incl = np;
-      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl(incl, TID >= o ? TID - o : TID); if (TID >= o) incl += t; }
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl(incl, WL >= o ? WL - o : WL); if (WL >= o) incl += t; }
       const int total = __shfl(incl, 63);
       if (n + total <= m.maxrow) {
-        if (TID < s.ncon) con[RB_CONREC * TID + RB_CR_ADR] = (float)(n + incl - np);
+        if (WID == 0 && WL < s.ncon) con[RB_CONREC * WL + RB_CR_ADR] = (float)(n + incl - np);
         BSYNC();
         if (TID == 0) s.nefc = n + total;
         done = true;
@@ -1761,12 +1761,17 @@ __device__ __forceinline__ void rb_JT_force(RbM m, RbLds& s, float* S, float* ds
     float acc = 0;
     if ((int)C[RB_CR_KIND] != RB_KIND_PYRAMID) {   // rows = basis rows: the basis force is the row's force
       if (adr >= 0 && b < (int)C[RB_CR_DIM]) { bool qd; float cst; acc = rb_row_force(row + RB_ROWREC * (adr + b), qd, cst); }
-    } else if (adr >= 0) for (int q = 0; q < np; q++) {
-      const float* R = row + RB_ROWREC * (adr + q);
-      const int a = (int)fabsf(R[RB_RR_AUX]);
-      if (b != 0 && a != b) continue;
-      bool qd; float cst; const float f = rb_row_force(R, qd, cst);
-      acc += b == 0 ? f : (R[RB_RR_AUX] < 0 ? -1.f : 1.f) * C[RB_CR_FRIC + a - 1] * f;
+    } else if (adr >= 0) {
+      // (the pyramid rows of a contact are laid out normal-plus / normal-minus per friction axis k: rows 2 (k - 1) and 2 (k - 1) + 1 carry |aux| = k; basis row 0 sums
+      //  every row, basis row b >= 1 exactly its two -- read directly instead of scanning all rows for them; a condim-1 contact has one row with aux 0)
+      const int q0 = b == 0 ? 0 : 2 * (b - 1), q1 = b == 0 ? np : (2 * b <= np ? 2 * b : q0);
+      for (int q = q0; q < q1; q++) {
+        const float* R = row + RB_ROWREC * (adr + q);
+        const int a = (int)fabsf(R[RB_RR_AUX]);
+        if (b != 0 && a != b) continue;
+        bool qd; float cst; const float f = rb_row_force(R, qd, cst);
+        acc += b == 0 ? f : (R[RB_RR_AUX] < 0 ? -1.f : 1.f) * C[RB_CR_FRIC + a - 1] * f;
+      }
     }
     Fb[w] = acc;
   }
@@ -1839,6 +1844,9 @@ __device__ __forceinline__ void rb_row_diag(RbM m, RbLds& s, float* S, int g, fl
 }
 
 // s.A (holding the group's block of M) += J' diag(D, quadratic rows) J restricted to group g
+#ifndef RB_HESS_MULTIWAVE_OFF
+#define RB_HESS_MULTIWAVE_OFF 0      /* 1: configurations with several waves keep the staged one-contact-per-barrier assembly (A/B switch) */
+#endif
 // (-DRB_HESS_PROBE=k: cycles of section k of the assembly -- 1 static rows, 2 contact weights, 3 the contacts' entries -- accumulate in prof[15]; a profiling build)
 #ifdef RB_HESS_PROBE
 #define RB_HPROBE_BEGIN(k) long long tprobe##k = 0; if (RB_HESS_PROBE == k) { BSYNC(); tprobe##k = rg_clock(); }
@@ -1946,32 +1954,35 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
   //  load's latency is covered by the adding instead of being waited for in front of it)
   const float* cloc = SC(CONLOC);
 #ifndef RB_HESS_SERIAL
-  if (RB_NWAVE == 1) {
+  if (RB_NWAVE == 1 || !(RB_HESS_MULTIWAVE_OFF)) {
     RB_HPROBE_BEGIN(3)
     // One wave per env (round 5): a lane per (contact, Jacobian column).  The columns of up to 64 contacts are numbered through a prefix sum of nnz; a round takes as
     // many whole contacts as fit 64 lanes.  A lane fetches ITS column of the six basis rows, its block row and the contact's weight once (one round of independent
     // loads), then walks the contact's columns k = 0 .. nnz - 1: the partner column comes by lane exchange from the lane that holds it, and the pair (e, k <= e) is
     // added into the block with an LDS atomic.  A single wave issues its LDS atomics in program order and resolves same-address lanes in lane order, so the sums
     // are run-to-run identical (rg_kernel.h relies on the same property).  Against the staged loop below: no barrier and no staging round trip per contact, no idle
-    // lanes; against one entry per lane: a sixth of the loads.  (Several waves would interleave their atomics: the large configuration keeps the loop below.)
+    // lanes; against one entry per lane: a sixth of the loads.
+    // Several waves (the large configuration): EVERY wave walks all columns, and a lane adds its entry only if the entry's block row belongs to its wave
+    // (row mod RB_NWAVE): waves never touch the same address, each wave's own atomics are ordered as above -- still run-to-run identical, four waves' worth of
+    // lanes on the pairs, at the price of every wave loading every column.
     int* offs = (int*)s.cst;           // 65 words: column offsets of this chunk's contacts
     int* cmeta = (int*)s.cst + 65;     // 64 words: dim | mode << 8 of this chunk's contacts
     for (int c0 = 0; c0 < s.ncon; c0 += 64) {
-      const int c = c0 + TID;
+      const int c = c0 + WL;
       int cnt = 0, meta = 0;
       if (c < s.ncon) { const int mode = (int)Wc[RB_NW * c + RB_NW - 1]; if (mode != 0) { cnt = (int)con[RB_CONREC * c + RB_CR_NNZ]; meta = (int)con[RB_CONREC * c + RB_CR_DIM] | (mode << 8); } }
       int incl = cnt;
-      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl(incl, TID >= o ? TID - o : TID); if (TID >= o) incl += t; }
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl(incl, WL >= o ? WL - o : WL); if (WL >= o) incl += t; }
       BSYNC();
-      offs[TID + 1] = incl; cmeta[TID] = meta;
+      if (WID == 0) { offs[WL + 1] = incl; cmeta[WL] = meta; }      // (every wave computed the same numbers: one writes)
       if (TID == 0) offs[0] = 0;
       BSYNC();
       int cs = 0;                       // first contact (chunk-local) of the round
       while (cs < 64 && offs[cs] < offs[64]) {
         // the round's contacts: cs .. ce - 1, the longest run whose columns fit the wave (a single contact has at most RB_CONW <= 64 columns)
-        const unsigned long long fit = __ballot(TID >= cs && offs[TID + 1] - offs[cs] <= 64);
+        const unsigned long long fit = __ballot(WL >= cs && offs[WL + 1] - offs[cs] <= 64);
         const int ce = cs + __popcll(fit);
-        const int t = offs[cs] + TID;
+        const int t = offs[cs] + WL;
         const bool on = t < offs[ce];
         int lo = cs, hi = ce;
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= t) lo = mid; else hi = mid; }
@@ -2015,7 +2026,8 @@ __device__ __forceinline__ void rb_hessian_add(RbM m, RbLds& s, float* S, int g)
               for (int r = 0; r < 5; r++) if (r < q) { const float wk = w[q * (q + 1) / 2 + r]; if (wk != 0.f) v += wk * (ja[q] * jb[r] + ja[r] * jb[q]); }
             }
           }
-          atomicAdd(&s.A[la >= lb ? RB_TRI(la, lb) : RB_TRI(lb, la)], v);
+          const int rmax = la >= lb ? la : lb, rmin = la >= lb ? lb : la;
+          if (RB_NWAVE == 1 || (rmax & (RB_NWAVE - 1)) == WID) atomicAdd(&s.A[RB_TRI(rmax, rmin)], v);
         }
         cs = ce;
       }

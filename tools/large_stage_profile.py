@@ -30,6 +30,6 @@ print("B %d: launch %.1f ms; per mj_step per workgroup (cycles): total %.0f" % (
 for n, p in zip(names, prof):
     print("  %-14s %10.0f  %5.1f %%" % (n, p, 100 * p / prof.sum()))
 print("means: ncon %.1f nefc %.0f Newton iterations %.2f" % (st[0] / st[3], st[1] / st[3], st[2] / st[3]))
-print("inside Newton (cycles per mj_step): " + ", ".join("%s %.0f" % (n, v) for n, v in zip(["M x, J x, cost", "J' f, gradient", "H assembly", "Cholesky", "substitution", "M v, J v", "line search"], allp[8:15])))
+print("inside Newton (cycles per mj_step): " + ", ".join("%s %.0f" % (n, v) for n, v in zip(["M x, J x, cost", "J' f, gradient", "H assembly", "Cholesky", "substitution", "M v, J v", "line search"], allp[8:15])) + ("; probe (a -DRB_HESS_PROBE build) %.0f" % allp[15] if allp[15] else ""))
 if allp[15] > 0:
     print("probe slot (builds with -DRB_CHOL_PROBE: diagonal block + row solve + inverse of the blocked Cholesky; -DRB_HESS_PROBE: the per-contact loop of the Hessian assembly): %.0f cycles per mj_step" % allp[15])
