@@ -746,6 +746,15 @@ static void rg_items_probe(rg_batch* b) {
   b->items_slots = 2; b->items_queues = 1;   // (workgroups run one after the other: the first drains the queue, the second finds it empty)
 #else
   b->items_slots = 0; b->items_queues = 1;
+  // the probe's answer is a property of the device: measured once per device and process (it used to allocate, launch and synchronise in every
+  // rg_batch_create), and a failed probe launch is reported through rg_last_error instead of being swallowed -- the mode then stays off, which is always correct
+  static int cached_slots[64], cached_queues[64]; static bool cached[64];
+  const bool cacheable = b->device >= 0 && b->device < 64;
+  if (cacheable && cached[b->device]) {
+    b->items_slots = cached_slots[b->device]; b->items_queues = cached_queues[b->device];
+    if (const char* ov = getenv("RG_ITEMS_SLOTS")) { const int v = atoi(ov); if (v > 0 && b->items_slots > 0) b->items_slots = v; }
+    return;
+  }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, b->device) != hipSuccess) return;
   const int cus = prop.multiProcessorCount;
@@ -757,12 +766,15 @@ static void rg_items_probe(rg_batch* b) {
   (void)hipMemset(counts, 0, 16 * 4);
   const int grid = cus * per_cu;
   hipLaunchKernelGGL(rg_xcc_probe_kernel, dim3(grid), dim3(RG_WAVE), 0, 0, counts);
+  const hipError_t launch_err = hipGetLastError();
   int h[16];
-  if (hipMemcpy(h, counts, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+  if (launch_err != hipSuccess) (void)fail(std::string("rg_items_probe: probe launch failed (substep-granular dispatch stays off): ") + hipGetErrorString(launch_err));
+  else if (hipMemcpy(h, counts, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
     int nq = 0; bool ok = true;
     for (int x = 0; x < 16; x++) if (h[x] > 0) nq = x + 1;
     for (int x = 0; x < nq; x++) if (h[x] <= 0) ok = false;
     if (ok && nq >= 1 && nq <= 8) { b->items_slots = grid; b->items_queues = nq; }
+    if (cacheable) { cached_slots[b->device] = b->items_slots; cached_queues[b->device] = b->items_queues; cached[b->device] = true; }
     if (const char* ov = getenv("RG_ITEMS_SLOTS")) { const int v = atoi(ov); if (v > 0 && b->items_slots > 0) b->items_slots = v; }   // (experiments: persistent workgroups per launch)
   }
   (void)hipFree(counts);
