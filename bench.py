@@ -123,14 +123,15 @@ def algorithmic_bytes_sparse(m, nM, ncon, nefc, iters, nsub, obs_dim, jw=16):
     return nsub * b_sub + 4.0 * (nu + obs_dim), b_sub
 
 
-def bench_rearrange_blocks(args, emit=True, ycb=False):
+def bench_rearrange_blocks(args, emit=True, ycb=False, joint=False):
     """BASELINE.json configs[3]: rearrange/blocks, num_objects = 5 (UR16e + 2f-85 gripper, table contacts), batch 4096 on one MI355X; with `ycb`
     configs[4]: rearrange/ycb, num_objects = 8 (mesh objects), batch 4096 PER GPU (32768 on 8).
     `BatchedBlockRearrangeEnv.step` = rb_batch_step_tcp (TCP solver world: sync, forward, mocap target, 40 mj_step) + rb_batch_step_ex (main world:
     40 mj_step + 2 forwards, the last in full with sensors) + ra_env_post_step (observation row, reward, goals, tracker), after the reference's reset
     recipe (grid placement, 100 stabilisation steps, 10 random + 100 zero-action steps).  1 env-step = 80 mj_step of two models.
     N > 1 (`--gpus N`, one rank per GPU): the envs are sharded, every rank steps its own 4096, the packed observation rows (obs + reward + done) are
-    all-gathered over RCCL behind the next step -- the path's only exchange, as for dactyl/locked."""
+    all-gathered over RCCL behind the next step -- the path's only exchange, as for dactyl/locked.
+    `joint`: robot_control_params.control_mode = "joint" (robot_interface.py:9-20): [B, 7] actions, no TCP solver world, two launches per step."""
     from robogym_amd.envs.rearrange.blocks import BatchedBlockRearrangeEnv
     from robogym_amd.envs.rearrange.ycb import BatchedYcbRearrangeEnv
 
@@ -160,6 +161,8 @@ def bench_rearrange_blocks(args, emit=True, ycb=False):
         kw = dict(stabilize_steps=1, n_random_initial_steps=1, settle_steps=1, n_substeps=1, lib=lib)
     if getattr(args, "no_per_env_params", False):   # (A/B: the model's shared arrays instead of every env's own parameter block)
         kw["per_env_parameters"] = False
+    if joint:
+        kw["control_mode"] = "joint"
     env = (BatchedYcbRearrangeEnv if ycb else BatchedBlockRearrangeEnv)(B, device=dev, starting_seed=20200901 + 3 + rank, **kw)
     sync = (lambda: torch.cuda.synchronize(dev)) if not emul_path else (lambda: None)
     t_reset = time.perf_counter()
@@ -172,12 +175,14 @@ def bench_rearrange_blocks(args, emit=True, ycb=False):
     gather = ShardedObservationGather(B, env.packed.shape[1], dev)
 
     def step():
-        env.step(torch.rand((B, 6), generator=gen, device=dev) * 2 - 1)
+        env.step(torch.rand((B, env.action_dim), generator=gen, device=dev) * 2 - 1)
         gather.start(env.packed)      # the packed row: observation + reward (3) + done
 
     for _ in range(args.warmup):
         step()
-    env.sim.stats.zero_(); env.solver_sim.stats.zero_()
+    env.sim.stats.zero_()
+    if env.solver_sim is not None:
+        env.solver_sim.stats.zero_()
     mk_event = (lambda: torch.cuda.Event(enable_timing=True)) if not emul_path else (lambda: None)
     ev = [[mk_event() for _ in range(3)] for _ in range(args.steps)]
     orig = env._physics
@@ -185,6 +190,10 @@ def bench_rearrange_blocks(args, emit=True, ycb=False):
     def timed(actions, active=None, wrapped=False, solver_active=None, _i=[0]):
         e = ev[_i[0] % len(ev)]; _i[0] += 1
         rec = lambda x: x.record() if x is not None else None
+        if joint:
+            rec(e[0]); rec(e[1]); env._keep_act = env._joint_action(actions, wrapped)
+            env.sim.env_step(action=env._keep_act, nforward_ticks=2, flags=32, active=active); rec(e[2])
+            return
         rec(e[0]); env.solver_sim.step_tcp(env.sim, actions, env.tcp, active=active); rec(e[1])
         env.sim.env_step(nforward_ticks=2, flags=32, active=active); rec(e[2])
     env._physics = timed
@@ -210,7 +219,7 @@ def bench_rearrange_blocks(args, emit=True, ycb=False):
         ms_solver = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])); ms_main = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
     res = {}
     total_bytes = 0.0
-    for name, sim, obs_dim in (("main", env.sim, env.obs_dim), ("solver", env.solver_sim, 0)):
+    for name, sim, obs_dim in [("main", env.sim, env.obs_dim)] + ([] if env.solver_sim is None else [("solver", env.solver_sim, 0)]):
         st = sim.stats.sum(0).cpu().numpy(); n = max(st[3], 1.0)
         ncon, nefc, iters = float(st[0] / n), float(st[1] / n), float(st[2] / n)
 
@@ -230,7 +239,7 @@ def bench_rearrange_blocks(args, emit=True, ycb=False):
         "value": world * B * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("rearrange/ycb (UR16e + 2f-85 gripper + table, 8 YCB objects %s as convex-part mesh geoms: nv=56, %d geoms, elliptic cones, impratio 10)" % (getattr(env, "object_names", []), env.sim.info["ngeom"]) if ycb else "rearrange/blocks (UR16e + 2f-85 gripper + table, 5 blocks: nv=38, elliptic cones, impratio 10)") + " with its TCP solver world (nv=8, mocap weld), batch %d, iid U(-1,1) relative tcp+roll+yaw actions, 40 + 40 substeps x 0.001 s + 2 forwards; after the reset recipe%s" % (B, " (shortened: --quick-reset)" if quick else ""),
-                   "batch_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d (envs sharded, all-gather of the packed observation rows)" % world, "collective_backend": (dist.get_backend() if distributed else None), "reset_seconds": t_reset, "main": res["main"], "solver": res["solver"], "status_bits": int(max(env.sim.status.max().item(), env.solver_sim.status.max().item())),
+                   "batch_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d (envs sharded, all-gather of the packed observation rows)" % world, "collective_backend": (dist.get_backend() if distributed else None), "reset_seconds": t_reset, "main": res["main"], "solver": res.get("solver"), "status_bits": int(max(env.sim.status.max().item(), 0 if env.solver_sim is None else env.solver_sim.status.max().item())),
                    "done_fraction_last_step": float(env.done.float().mean().item()), "launch_ms": {"solver_world": ms_solver, "main_world": ms_main}, "lds_bytes_per_workgroup": env.sim.info["lds_bytes"], "per_env_parameters": bool(env.per_env_parameters)},
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": rb_traffic("ycb" if ycb else "rearrange_blocks", B), "traffic_unit": "GB per launch (PMC, profiles/hbm_traffic.json)", "traffic_note": rb_traffic_note("ycb" if ycb else "rearrange_blocks", B), "kernel": "rb_step_kernel (main world launch)", "kernel_ms": ms_main,
                      "algorithmic_bytes_per_env_step": res["main"]["algorithmic_bytes_dense"], "frac_sparse_J": B * res["main"]["algorithmic_bytes_sparse_J"] / (ms_main * 1e-3) / HBM_PEAK,
@@ -239,7 +248,10 @@ def bench_rearrange_blocks(args, emit=True, ycb=False):
     if not args.no_cpu_baseline and world == 1 and not emul_path:
         from oracle import cpu_baseline as cb
 
-        out["cpu_baseline"] = cb.run_rearrange_blocks(4.0, ycb=ycb)
+        out["cpu_baseline"] = cb.run_rearrange_blocks(4.0, ycb=ycb, joint=joint)
+    if joint:
+        out["metric"] = out["metric"].replace("unwrapped env.step incl. the TCP solver's second simulation", "control_mode joint (7 action numbers, no TCP solver world): unwrapped env.step = the main world's launch + the env kernel")
+        out["config"]["control_mode"] = "joint"
     if emit and rank == 0:
         print(json.dumps(out, default=float))
     if distributed:
@@ -409,6 +421,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="locked", choices=["locked", "full_perpendicular", "rearrange_blocks", "ycb"], help="locked = BASELINE.json configs[1] (the headline); full_perpendicular = configs[2]; rearrange_blocks = configs[3]")
     ap.add_argument("--no-secondary", action="store_true", help="headline only: skip the shortened runs of the other built configs that the default line carries under 'secondary'")
+    ap.add_argument("--control-mode", default="tcp+roll+yaw", choices=["tcp+roll+yaw", "joint"], help="rearrange workloads: robot_control_params.control_mode")
     ap.add_argument("--quick-reset", action="store_true", help="rearrange_blocks: a shortened reset recipe (20 / 2 / 20 steps instead of 100 / 10 / 100)")
     ap.add_argument("--gpus", type=int, default=1)
     # default window: the 20 steps right after the reset, where the cubes are still in the hands (iid random actions throw them off
@@ -428,7 +441,7 @@ def main():
     if args.workload == "full_perpendicular":
         return bench_full_perpendicular(args)
     if args.workload in ("rearrange_blocks", "ycb"):
-        return bench_rearrange_blocks(args, ycb=args.workload == "ycb")
+        return bench_rearrange_blocks(args, ycb=args.workload == "ycb", joint=args.control_mode == "joint")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch_with_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
@@ -602,7 +615,8 @@ def main():
             # windows of >= 2 s each whatever the driver's --steps: 300 steps of ~6 ms, 20 of ~115 ms, 30 of 64-90 ms
             plan = ((bench_locked_variant, dict(pipelined_reset=True), (300, 40, 8192)), (bench_locked_variant, dict(default_make_env=True), (300, 40, 8192)),
                     (bench_full_perpendicular, {}, (20, 2, 4096)), (bench_rearrange_blocks, {}, (30, 3, 4096)), (bench_rearrange_steady, {}, (30, 0, 4096)),
-                    (bench_rearrange_blocks, dict(ycb=True), (30, 3, 4096)), (bench_rearrange_steady, dict(ycb=True), (30, 0, 4096)))
+                    (bench_rearrange_blocks, dict(ycb=True), (30, 3, 4096)), (bench_rearrange_steady, dict(ycb=True), (30, 0, 4096)),
+                    (bench_rearrange_blocks, dict(joint=True), (30, 3, 4096)))
             for fn, kw, (st_, wu_, b_) in plan:
                 a2 = copy.copy(args); a2.steps, a2.warmup, a2.batch = st_, wu_, b_
                 a2.pipelined_reset = False

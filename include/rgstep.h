@@ -314,6 +314,11 @@ rb_batch* rb_batch_create(const rb_model* m, int B);
 void rb_batch_free(rb_batch* b);
 int rb_batch_reset(rb_batch* b);
 int rb_batch_set_env(rb_batch* b, int hand_qposadr, int n_hand_jnt, int relative_action, const float* pos_to_ctrl);
+/* relative actions of a composite robot (/root/reference/robogym/robot/robot_interface.py:220-231 Robot.actuation_range, robot/composite/composite_robot.py): the
+ * per-step actuation range of the actuators that centre on a joint position is min((hi - lo) / 2, max_position_change) (0 = not capped); the actuators named by
+ * `ctrl_centre_mask` (bit u) centre on their stored control and keep the full range (the gripper of the UR16e + Robotiq robot, joint control mode:
+ * robot/ur16e/mujoco/joint_controlled_arm.py:89-200, robot/gripper/mujoco/mujoco_robotiq_gripper.py:142-172).  After rb_batch_set_env. */
+int rb_batch_set_action_limits(rb_batch* b, float max_position_change, unsigned ctrl_centre_mask);
 void* rb_batch_field_ptr(rb_batch* b, int field, int* row_words);
 int rb_batch_step(rb_batch* b, const float* action_dev, const int* active_dev, int nsubsteps, int nforward_ticks, int flags, void* stream);
 /* the same with per-env `hold_dev` (int [B] or NULL: envs that keep their stored ctrl row, the reset recipe's scripted controls) and `nticks_dev` (int [B] or

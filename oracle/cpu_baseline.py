@@ -115,7 +115,7 @@ def run_full_perpendicular(seconds=2.0):
 
 
 def _rearrange_worker(args):
-    seconds, seed, ycb = args
+    seconds, seed, ycb, joint = (tuple(args) + (False,))[:4]
     from oracle import rearrange_oracle as RO
     from robogym_amd.envs.rearrange.xml import load_blocks_model, load_solver_model, load_ycb_model, object_bounding_boxes
 
@@ -123,40 +123,40 @@ def _rearrange_worker(args):
     table_top = 0.453 + 0.03324
     if ycb:
         main = load_ycb_model(8)
-        env = RO.OracleRearrangeEnv(main, load_solver_model(), 8)
+        env = RO.OracleRearrangeEnv(main, None if joint else load_solver_model(), 8)
         bb = object_bounding_boxes(main, 8)
         env.set_object_poses([[1.25 + 0.15 * (i % 4) - bb[i, 0], 0.52 + 0.3 * (i // 4) - bb[i, 1], table_top + bb[i, 5] - bb[i, 2] + 0.002] for i in range(8)], [[1, 0, 0, 0]] * 8)
     else:
-        env = RO.OracleRearrangeEnv(load_blocks_model(5), load_solver_model(), 5)
+        env = RO.OracleRearrangeEnv(load_blocks_model(5), None if joint else load_solver_model(), 5)
         env.set_object_poses([[1.2 + 0.11 * i, 0.55 + 0.1 * i, table_top + 0.0254] for i in range(5)], [[1, 0, 0, 0]] * 5)
     env.main.sim.forward()
     for _ in range(5):
         env.main.step()
     n, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < seconds:
-        env.env_step(rng.uniform(-1, 1, 6))
+        env.env_step(rng.uniform(-1, 1, 7 if joint else 6))
         n += 1
     return n, time.perf_counter() - t0
 
 
-def run_rearrange_blocks(seconds=4.0, ycb=False):
+def run_rearrange_blocks(seconds=4.0, ycb=False, joint=False):
     """configs[3] beside its GPU line: `OracleRearrangeEnv.env_step` (40 + 40 mj_step of the two worlds + 3 mj_forward, the numpy env layer around the
     C oracle) in one process, then in as many processes as the cgroup quota allows.  kind "port"."""
     import multiprocessing as mp
 
     allot = cpu_allotment()
-    n1, s1 = _rearrange_worker((seconds, 20200901 + 3, ycb))
+    n1, s1 = _rearrange_worker((seconds, 20200901 + 3, ycb, joint))
     r1 = n1 / s1
     q = allot["cgroup_cpu_max"]
     k = int(max(1, min(allot["affinity"], q if isinstance(q, (int, float)) else allot["affinity"], 32)))
     rk, totk = r1, n1
     if k > 1:
         with mp.get_context("fork").Pool(k) as pool:
-            res = pool.map(_rearrange_worker, [(seconds, 20200901 + 3 + 7 * i, ycb) for i in range(k)])
+            res = pool.map(_rearrange_worker, [(seconds, 20200901 + 3 + 7 * i, ycb, joint) for i in range(k)])
         rk, totk = sum(n / s for n, s in res), sum(n for n, _ in res)
     best = (k, rk) if rk > r1 else (1, r1)
     return {"value": best[1], "unit": "env-steps/s", "cores": best[0], "kind": "port", "one_core": r1, "cpu_allotment": allot,
-            "sample": ("%d env-steps of rearrange/" + ("ycb" if ycb else "blocks") + " (80 mj_step of two worlds + 3 mj_forward each) on the CPU oracle, %.0f s per rung: 1 process %.1f env-steps/s, %d processes %.1f; "
+            "sample": ("%d env-steps of rearrange/" + ("ycb" if ycb else "blocks") + " (" + ("40 mj_step of the main world + 2 mj_forward, control_mode joint" if joint else "80 mj_step of two worlds + 3 mj_forward each") + ") on the CPU oracle, %.0f s per rung: 1 process %.1f env-steps/s, %d processes %.1f; "
                        "CPU restatement of MuJoCo, not mujoco-py") % (n1 + totk, seconds, r1, k, rk)}
 
 

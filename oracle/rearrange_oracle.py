@@ -240,11 +240,14 @@ def tcp_quat_control(arm_control, wrist_qpos, wrist_lo, wrist_hi, gripper_quat):
 
 class OracleRearrangeEnv:
     """`BlockRearrangeEnv` (envs/rearrange/blocks.py) with its default robot: MujocoURTcpJointGripperCompositeRobot =
-    JointControlledTcpArm (FreeRollYawTcpArm controller in the solver simulation) + MujocoRobotiqGripper."""
+    JointControlledTcpArm (FreeRollYawTcpArm controller in the solver simulation) + MujocoRobotiqGripper.
+    `solver_model = None`: control_mode "joint", MujocoURJointGripperCompositeRobot = JointControlledArm + MujocoRobotiqGripper (robot/composite/ur_gripper_arm.py,
+    robot/ur16e/mujoco/joint_controlled_arm.py:89-200), no TCP solver world (RobotControlParameters.requires_solver_sim, robot_interface.py:83-91); 7 action numbers."""
 
     def __init__(self, main_model, solver_model, num_objects, n_substeps=40, max_position_change=0.1, arm_reset_controller_error=True,
                  success_threshold=None, goal_reward_per_object=1.0, penalty=None):
-        self.main, self.solver = OracleArmSim(main_model, n_substeps), OracleArmSim(solver_model, n_substeps)
+        self.main, self.solver = OracleArmSim(main_model, n_substeps), (None if solver_model is None else OracleArmSim(solver_model, n_substeps))
+        self.joint_control = solver_model is None
         self.num_objects = num_objects
         self.mpc, self.reset_controller_error = max_position_change, arm_reset_controller_error
         self.success_threshold = dict(success_threshold or {"obj_pos": 0.04, "obj_rot": 0.2})
@@ -278,6 +281,8 @@ class OracleRearrangeEnv:
         s.qpos[self.main.arm_q] = TABLETOP_EXPERIMENT_INITIAL_POS
         s.ctrl[:6] = TABLETOP_EXPERIMENT_INITIAL_POS
         s.ctrl[self.main.grip_act] = s.qpos[self.main.grip_q]
+        if self.joint_control:
+            return
         c = self.solver.sim
         c.qpos[self.solver.arm_q] = s.qpos[self.main.arm_q]
         c.forward()
@@ -298,6 +303,17 @@ class OracleRearrangeEnv:
     def denormalize(self, action):
         """CompositeRobot.denormalize_position_control (relative actions): 5 arm numbers + 1 gripper number."""
         a = np.clip(np.asarray(action, dtype=float), -1, 1)
+        if self.joint_control:
+            # Robot.denormalize_position_control with relative actions (robot_interface.py:247-278): centre = the joint positions, range = min((hi - lo) / 2,
+            # max_position_change) (actuation_range, :220-231), clipped to the model's control range (joint_controlled_arm.py:166-174)
+            A, m = self.main.model.arrays, self.main
+            lo, hi = A["actuator_ctrlrange"][:6, 0], A["actuator_ctrlrange"][:6, 1]
+            rng = 0.5 * (hi - lo)
+            if self.mpc:
+                rng = np.minimum(rng, self.mpc)
+            arm = np.clip(m.sim.qpos[m.arm_q] + a[:6] * rng, lo, hi)
+            glo, ghi = A["actuator_ctrlrange"][m.grip_act]
+            return arm, np.clip(m.sim.ctrl[m.grip_act] + a[6] * 0.5 * (ghi - glo), glo, ghi)
         arm = np.concatenate([a[:3] * self.mpc, a[3:5] * np.array([SPEED_ROLL, SPEED_PITCH]) * self.mpc])
         A = self.main.model.arrays
         lo, hi = A["actuator_ctrlrange"][self.main.grip_act]
@@ -310,6 +326,10 @@ class OracleRearrangeEnv:
     def set_control(self, arm, grip):
         """CompositeRobot.set_position_control with DENORMALISED controls: arm = (dx, dy, dz, roll, pitch/yaw -> J6), grip = the gripper's control target"""
         m, c = self.main, self.solver
+        if self.joint_control:
+            m.sim.ctrl[:6] = arm                                    # JointControlledArm.set_position_control (joint_controlled_arm.py:186-190)
+            m.sim.ctrl[m.grip_act] = grip
+            return
         # JointControlledTcpArm.set_position_control
         if self.reset_controller_error:
             c.sim.qpos[c.arm_q] = m.sim.qpos[m.arm_q]
@@ -327,6 +347,8 @@ class OracleRearrangeEnv:
         """RobotEnv._observe_sync: one more mj_forward, goal info, observation, robots notified (gripper state -> solver world)."""
         self.main.sim.forward()
         obs = self.observe()
+        if self.joint_control:
+            return obs
         c = self.solver
         c.sim.qpos[c.grip_q] = obs["gripper_qpos"][0]
         c.sim.ctrl[c.grip_act] = obs["gripper_controls"][0]

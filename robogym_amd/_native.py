@@ -107,7 +107,7 @@ EXPORTS = [
     "rb_model_create", "rb_model_free", "rb_model_info", "rb_scratch_offset", "rb_batch_create", "rb_batch_free", "rb_batch_reset", "rb_batch_set_env",
     "rb_batch_field_ptr", "rb_batch_step", "rb_batch_step_ex", "rb_env_post_step", "rb_post_args_size", "rb_cube_ops", "rb_batch_step_tcp", "ra_env_post_step", "ra_post_args_size",
     "rg_blob_entry", "rg_model_blob_keys", "rb_model_blob_keys", "rg_compile_mjcf", "rb_compile_mjcf", "rg_compile_mjcf_blob", "rg_blob_free",
-    "rb_model_enable_env_params", "rb_prm_layout",
+    "rb_model_enable_env_params", "rb_prm_layout", "rb_batch_set_action_limits",
 ]
 
 
@@ -178,6 +178,7 @@ def bind(path):
     L.rb_batch_free.argtypes = [vp]
     L.rb_batch_reset.argtypes = [vp]
     L.rb_batch_set_env.argtypes = [vp, ci, ci, ci, ctypes.POINTER(cf)]
+    L.rb_batch_set_action_limits.argtypes = [vp, cf, ctypes.c_uint]
     L.rb_batch_field_ptr.restype = vp
     L.rb_batch_field_ptr.argtypes = [vp, ci, ctypes.POINTER(ci)]
     L.rb_batch_step.argtypes = [vp, vp, vp, ci, ci, ci, vp]

@@ -2529,10 +2529,16 @@ __global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbMod
   BFOR(u, nu) {
     if (use_action) {
       const float lo = PRM(actuator_ctrlrange, RB_P_ACT_CTRLRANGE)[2 * u], hi = PRM(actuator_ctrlrange, RB_P_ACT_CTRLRANGE)[2 * u + 1];
-      float centre;
-      if (L.env.relative_action) { centre = 0; for (int j = 0; j < L.env.n_hand_jnt; j++) centre += L.env.pos_to_ctrl[u * L.env.n_hand_jnt + j] * s.qpos[L.env.hand_qposadr + j]; }
-      else centre = 0.5f * (hi + lo);
-      s.ctrl[u] = clampf(centre + clampf(L.bt.action[(size_t)e * nu + u], -1.f, 1.f) * 0.5f * (hi - lo), lo, hi);
+      float centre, half = 0.5f * (hi - lo);
+      const bool from_ctrl = (L.env.ctrl_centre_mask >> u) & 1u;
+      if (L.env.relative_action) {
+        if (from_ctrl) centre = L.bt.ctrl[(size_t)e * nu + u];
+        else {
+          centre = 0; for (int j = 0; j < L.env.n_hand_jnt; j++) centre += L.env.pos_to_ctrl[u * L.env.n_hand_jnt + j] * s.qpos[L.env.hand_qposadr + j];
+          if (L.env.max_position_change > 0.f) half = fminf(half, L.env.max_position_change);   // Robot.actuation_range (robot_interface.py:220-231)
+        }
+      } else centre = 0.5f * (hi + lo);
+      s.ctrl[u] = clampf(centre + clampf(L.bt.action[(size_t)e * nu + u], -1.f, 1.f) * half, lo, hi);
     } else s.ctrl[u] = L.bt.ctrl[(size_t)e * nu + u];
   }
   BSYNC();

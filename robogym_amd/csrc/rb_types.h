@@ -136,6 +136,10 @@ struct RbModelDev {
 struct RbEnvDev {
   int hand_qposadr, n_hand_jnt, relative_action;
   const float* pos_to_ctrl;   // [nu][n_hand_jnt]
+  // relative actions of a composite robot (robot_interface.py:220-231, composite_robot.py): actuation range capped by max_position_change (> 0), and the
+  // actuators whose centre is their stored control instead of a joint position (bit u: the gripper, whose range is not capped)
+  float max_position_change;
+  unsigned ctrl_centre_mask;
 };
 
 struct RbBatchDev {

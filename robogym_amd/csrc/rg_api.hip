@@ -1329,6 +1329,14 @@ int rb_batch_set_env(rb_batch* b, int hand_qposadr, int n_hand_jnt, int relative
   b->has_env = 1;
   return 0;
 }
+int rb_batch_set_action_limits(rb_batch* b, float max_position_change, unsigned ctrl_centre_mask) {
+  if (!b) return fail("rb_batch_set_action_limits: null batch");
+  if (!b->has_env) return fail("rb_batch_set_action_limits: rb_batch_set_env first");
+  if (!(max_position_change >= 0.f)) return fail("rb_batch_set_action_limits: max_position_change must be >= 0 (0 = not capped)");
+  if (b->model->dev.nu < 32 && (ctrl_centre_mask >> b->model->dev.nu) != 0) return fail("rb_batch_set_action_limits: ctrl_centre_mask names an actuator the model does not have");
+  b->env.max_position_change = max_position_change; b->env.ctrl_centre_mask = ctrl_centre_mask;
+  return 0;
+}
 void* rb_batch_field_ptr(rb_batch* b, int field, int* row_words) {
   if (!b) { fail("null batch"); return nullptr; }
   const RbModelDev& d = b->model->dev; RbBatchDev& s = b->dev;

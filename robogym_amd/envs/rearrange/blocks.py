@@ -17,8 +17,11 @@ cells over the placement area, distinct random cells; restated for boxes, distri
 "re-creation" of the simulation (common/base.py:850-856) is the same model with new object poses here: blocks have no per-episode shape
 parameters at the default `object_scale_low/high = 0`, material `default`.
 
-Not built for this env: the wrapper stack (SmoothActionWrapper / ClipRewardWrapper / DiscretizeActionWrapper, common/base.py:986-996), vision,
-`teleport_to_goal`, masks of the placement area, duplicated-object groups.
+`control_mode = "joint"` (robot_interface.py:9-20, MujocoURJointGripperCompositeRobot = JointControlledArm + MujocoRobotiqGripper, composite/ur_gripper_arm.py): no TCP
+solver world; `step(actions[B, 7])`, the action map (six arm joints relative to their positions, capped by max_position_change; the gripper relative to its control)
+runs at the head of the main world's launch (rb_batch_set_action_limits) -- TWO launches per step.
+
+Not built for this env: vision, `teleport_to_goal`, masks of the placement area, duplicated-object groups, control_mode tcp+wrist, tcp_solver_mode mocap.
 """
 import ctypes
 from typing import Optional
@@ -56,27 +59,32 @@ class BatchedBlockRearrangeEnv:
                  use_goal_distance_reward: bool = True, goal_reward_per_object: float = 1.0, used_table_portion: float = 1.0, lib=None, n_substeps: int = 40,
                  main_model=None, wrappers: bool = False, n_action_bins: int = 11, smooth_alpha: float = 0.3, reward_clip: float = 100.0,
                  pipelined_reset: bool = False, action_spacing: str = "linear", per_env_parameters: bool = True, randomizer_params: Optional[dict] = None,
-                 stabilize_object_damping: float = 1.0e-3):
+                 stabilize_object_damping: float = 1.0e-3, control_mode: str = "tcp+roll+yaw"):
         """`per_env_parameters`: every env carries its own copy of the randomisable model fields (`self.sim.params`, LargeModelSimulation(env_params=True)) -- what
         the reference's simulation randomizers and `stabilize_objects` write into `sim.model`.  On by default (measured cost: 0.7 % of the step,
         profiles/r05_ab_rb_env_params.txt); off: the model's own arrays, no randomizers, no damping change while the objects stabilise.
         `randomizer_params`: name -> parameter of `build_simulation_randomizers` (the reference's ADR-controlled values; all zero by default = identity)."""
         self.B, self.N = int(batch_size), int(num_objects)
         self._L = lib if lib is not None else _native.lib()
-        main, solver = (main_model if main_model is not None else load_blocks_model(self.N)), load_solver_model()   # (main_model: the same world with other objects, envs/rearrange/ycb.py)
+        self.control_mode = _control_mode_name(control_mode)
+        self.joint_control = self.control_mode == "joint"      # ControlMode.JOINT: no TCP solver world (RobotControlParameters.requires_solver_sim, robot_interface.py:83-91)
+        AD = self.action_dim = 7 if self.joint_control else 6
+        self.max_position_change = float(max_position_change)
+        main = main_model if main_model is not None else load_blocks_model(self.N)   # (main_model: the same world with other objects, envs/rearrange/ycb.py)
+        solver = None if self.joint_control else load_solver_model()
         self.randomizer_params = dict(randomizer_params or {})
         self.per_env_parameters = bool(per_env_parameters)
         if self.randomizer_params and not self.per_env_parameters:
             raise ValueError("randomizer_params need per_env_parameters=True")
         self.sim = LargeModelSimulation(main, self.B, device=device, n_substeps=n_substeps, lib=lib, hand=False, env_params=self.per_env_parameters)
-        self.solver_sim = LargeModelSimulation(solver, self.B, device=device, n_substeps=n_substeps, lib=lib, hand=False)
+        self.solver_sim = None if self.joint_control else LargeModelSimulation(solver, self.B, device=device, n_substeps=n_substeps, lib=lib, hand=False)
         self.device = self.sim.device
         self.model, self.solver_model = main, solver
         self.n_random_initial_steps, self.stabilize_steps, self.settle_steps = n_random_initial_steps, stabilize_steps, settle_steps
         self.used_table_portion = used_table_portion
         self._rng = np.random.RandomState(starting_seed)
-        A, As = main.arrays, solver.arrays
-        jn, sj = main.names["joint"], solver.names["joint"]
+        A, As = main.arrays, (None if solver is None else solver.arrays)
+        jn, sj = main.names["joint"], (None if solver is None else solver.names["joint"])
         self.arm_q = [int(A["jnt_qposadr"][jn.index("robot0:J%d" % k)]) for k in range(1, 7)]
         self.obj_q = [int(A["jnt_qposadr"][jn.index("object%d:joint" % i)]) for i in range(self.N)]
         self.obj_v = [int(A["jnt_dofadr"][jn.index("object%d:joint" % i)]) for i in range(self.N)]
@@ -92,15 +100,24 @@ class BatchedBlockRearrangeEnv:
         self.obj_center, self.obj_half = bb[:, :3].copy(), bb[:, 3:].copy()
         # ---- TCP hook arguments
         t = self.tcp = _native.RbTcpArgs()
-        for k in range(6):
-            t.arm_qposadr[k] = int(As["jnt_qposadr"][sj.index("robot0:J%d" % (k + 1))]); t.main_arm_qposadr[k] = self.arm_q[k]
-        t.main_gripper_actuator = self.grip_act; t.tcp_body = solver.name2id("body", "robot0:gripper_tcp"); t.wrist_joint = sj.index("robot0:J6")
-        t.reset_controller_error = 1 if arm_reset_controller_error else 0
-        t.max_position_change = max_position_change; t.speed_roll = SPEED_ROLL; t.speed_pitch = SPEED_PITCH; t.joint_drift_threshold = JOINT_DRIFT_THRESHOLD
-        t.gripper_ctrl_lo, t.gripper_ctrl_hi = float(A["actuator_ctrlrange"][self.grip_act, 0]), float(A["actuator_ctrlrange"][self.grip_act, 1])
-        self.solver_arm_q = [int(t.arm_qposadr[k]) for k in range(6)]
-        self.solver_grip_q = int(As["jnt_qposadr"][sj.index("robot0:r_gripper_RJ0_outer")])
-        self.solver_grip_act = solver.names["actuator"].index("robot0:r_gripper_finger_joint")
+        if self.joint_control:
+            # JointControlledArm drives ctrl[:6] from the six arm joints (joint_controlled_arm.py:186-190), MujocoRobotiqGripper its own actuator; relative actions:
+            # arm joint k around its position, +- min(ctrl range / 2, max_position_change); the gripper around its control, +- ctrl range / 2
+            assert self.grip_act == 6 and self.nu == 7 and list(np.diff(self.arm_q)) == [1] * 5, "joint control: ctrl[:6] = the arm's joints, ctrl[6] = the gripper"
+            assert [int(np.ravel(A["actuator_trnid"][u])[0]) for u in range(6)] == [jn.index("robot0:J%d" % k) for k in range(1, 7)], main.names["actuator"]
+            P = np.zeros((7, 6), dtype=np.float32); P[:6] = np.eye(6)
+            self.sim.set_action_map(self.arm_q[0], P, relative_action=True, max_position_change=float(max_position_change), ctrl_centre_mask=1 << self.grip_act)
+            self.solver_arm_q, self.solver_grip_q, self.solver_grip_act = [], -1, -1
+        else:
+            for k in range(6):
+                t.arm_qposadr[k] = int(As["jnt_qposadr"][sj.index("robot0:J%d" % (k + 1))]); t.main_arm_qposadr[k] = self.arm_q[k]
+            t.main_gripper_actuator = self.grip_act; t.tcp_body = solver.name2id("body", "robot0:gripper_tcp"); t.wrist_joint = sj.index("robot0:J6")
+            t.reset_controller_error = 1 if arm_reset_controller_error else 0
+            t.max_position_change = max_position_change; t.speed_roll = SPEED_ROLL; t.speed_pitch = SPEED_PITCH; t.joint_drift_threshold = JOINT_DRIFT_THRESHOLD
+            t.gripper_ctrl_lo, t.gripper_ctrl_hi = float(A["actuator_ctrlrange"][self.grip_act, 0]), float(A["actuator_ctrlrange"][self.grip_act, 1])
+            self.solver_arm_q = [int(t.arm_qposadr[k]) for k in range(6)]
+            self.solver_grip_q = int(As["jnt_qposadr"][sj.index("robot0:r_gripper_RJ0_outer")])
+            self.solver_grip_act = solver.names["actuator"].index("robot0:r_gripper_finger_joint")
         # ---- env-level state (device) and the post kernel's arguments
         dev, B, N = self.device, self.B, self.N
         z = lambda *shape, dt=torch.float32: torch.zeros(*shape, dtype=dt, device=dev)
@@ -150,8 +167,8 @@ class BatchedBlockRearrangeEnv:
         a.safety_stop_force = 150.0                                      # robot/ur16e/arm_interface.py:46
         a.max_timesteps_per_goal, a.successes_needed, a.use_goal_distance_reward = max_timesteps_per_goal_per_obj * N, successes_needed, int(use_goal_distance_reward)
         a.solver_grip_qposadr, a.solver_grip_act = self.solver_grip_q, self.solver_grip_act
-        self.action_shape = (self.B, 6)
-        self._zero_action = z(B, 6)
+        self.action_shape = (self.B, AD)
+        self._zero_action = z(B, AD)
         # ---- per-env model parameters: the reference's simulation randomizers (applied after _reset, robot_env.py:779-783) and stabilize_objects' damping change
         self.stabilize_object_damping = float(stabilize_object_damping)
         self.obj_dofs = torch.tensor([d for v in self.obj_v for d in range(v, v + 6)], device=dev, dtype=torch.long)
@@ -163,12 +180,12 @@ class BatchedBlockRearrangeEnv:
         # the launches: the solver world's launch maps bin indices to actions and smooths them (rb_tcp_args), the post kernel clips the reward
         self.wrapped = bool(wrappers)
         self.n_action_bins = int(n_action_bins)
-        self.ema_value, self.ema_t, self.action_ema = z(B, 6), z(B, dt=torch.int32), z(B, 6)
-        self.bins = torch.tensor(np.tile(action_bin_array(-1.0, 1.0, self.n_action_bins, action_spacing), (6, 1)).astype(np.float32), device=dev).contiguous()   # over Box(-1, 1)
+        self.ema_value, self.ema_t, self.action_ema = z(B, AD), z(B, dt=torch.int32), z(B, AD)
+        self.bins = torch.tensor(np.tile(action_bin_array(-1.0, 1.0, self.n_action_bins, action_spacing), (AD, 1)).astype(np.float32), device=dev).contiguous()   # over Box(-1, 1)
         tw = self.tcp_wrapped = _native.RbTcpArgs()
         ctypes.memmove(ctypes.byref(tw), ctypes.byref(t), ctypes.sizeof(t))
         tw.bins, tw.nbins = self.bins.data_ptr(), self.n_action_bins
-        tw.ema_alpha = float(np.power(smooth_alpha, float(np.asarray(A["opt_timestep"]).reshape(-1)[0]) * n_substeps / 0.08))       # SmoothActionWrapper.reset (wrappers/util.py:203-211)
+        self.ema_alpha = tw.ema_alpha = float(np.power(smooth_alpha, float(np.asarray(A["opt_timestep"]).reshape(-1)[0]) * n_substeps / 0.08))       # SmoothActionWrapper.reset (wrappers/util.py:203-211)
         tw.ema_value, tw.ema_t, tw.action_out = self.ema_value.data_ptr(), self.ema_t.data_ptr(), self.action_ema.data_ptr()
         if self.wrapped:
             a.reward_clip = float(reward_clip)
@@ -180,7 +197,8 @@ class BatchedBlockRearrangeEnv:
         self._stage, self._left = np.zeros(B, dtype=np.int8), np.zeros(B, dtype=np.int32)      # 0 live, 1 stabilise, 2 random action, 3 settle
         self._yaw = np.zeros((B, N))
         self.ended_rows = np.zeros(0, dtype=np.int64)          # rows whose episode ended on the last step (pipelined resets)
-        self.hold, self.scripted, self.frozen, self.solver_active = z(B, dt=torch.int32), z(B, 6), z(B, dt=torch.uint8), torch.ones(B, dtype=torch.int32, device=dev)
+        self.hold, self.scripted, self.frozen, self.solver_active = z(B, dt=torch.int32), z(B, AD), z(B, dt=torch.uint8), torch.ones(B, dtype=torch.int32, device=dev)
+        self.hold_ctrl = z(B, dt=torch.int32)      # joint control, pipelined resets: envs whose objects stabilise keep their stored controls (no action reaches the robot)
         self.resetting, self.episode_started = z(B, dt=torch.bool), z(B, dt=torch.bool)
         self.nticks = torch.full((B,), 2, dtype=torch.int32, device=dev)       # state-less forwards (controller ticks) per env of the main world's launch
         if self.pipelined:
@@ -193,9 +211,32 @@ class BatchedBlockRearrangeEnv:
         return None if self.sim._emul else ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _post(self):
-        _native.check(self._L, self._L.ra_env_post_step(self.sim._bh, self.solver_sim._bh, ctypes.byref(self.post), self._stream()), "ra_env_post_step")
+        _native.check(self._L, self._L.ra_env_post_step(self.sim._bh, None if self.solver_sim is None else self.solver_sim._bh, ctypes.byref(self.post), self._stream()), "ra_env_post_step")
+
+    def _joint_action(self, actions, wrapped):
+        """Joint control: the [B, 7] action that reaches `RobotEnv._set_action`.  With the wrapper stack: bin index -> value (DiscretizeActionWrapper.action,
+        wrappers/util.py:66-70) -> exponential moving average with bias correction (SmoothActionWrapper.step / IncrementalExpAvg, util.py:142-160, 213-218) -- a few
+        elementwise device ops here (in TCP mode the solver world's launch does them).  Pipelined resets: envs inside their recipe take its scripted action."""
+        if wrapped:
+            x = self.bins[torch.arange(self.action_dim, device=self.device)[None, :], actions.long()]
+            live = (self.hold == 0) if self.pipelined else torch.ones(self.B, dtype=torch.bool, device=self.device)
+            al = self.ema_alpha
+            v = torch.where(live[:, None], self.ema_value * al + (1.0 - al) * x, self.ema_value)
+            self.ema_value.copy_(v)
+            self.ema_t += live.to(torch.int32)
+            out = v / (1.0 - torch.pow(torch.full_like(v[:, :1], al), self.ema_t[:, None].to(torch.float32))).clamp_min(1.0e-30)
+            self.action_ema.copy_(torch.where(live[:, None], out, self.action_ema))
+            actions = self.action_ema
+        if self.pipelined:
+            actions = torch.where(self.hold[:, None] != 0, self.scripted, actions)
+        return actions.contiguous()
 
     def _physics(self, actions, active=None, wrapped=False, solver_active=None):
+        if self.joint_control:     # CompositeRobot.set_position_control at the head of the main world's launch; no solver world
+            self._keep_act = self._joint_action(actions, wrapped)
+            self.sim.env_step(action=self._keep_act, nforward_ticks=2, flags=FLAG_FULL_FORWARD, active=active, nticks=self.nticks if self.pipelined else None,
+                              hold=self.hold_ctrl if self.pipelined else None)
+            return
         sa = active if solver_active is None else solver_active      # (pipelined resets: envs that are settling their objects skip the solver world)
         if wrapped:       # `actions`: int32 bin indices through the wrapper stack's action path
             self.tcp_wrapped.action_index = actions.data_ptr()
@@ -210,6 +251,9 @@ class BatchedBlockRearrangeEnv:
     def _recipe_physics(self, actions, active):
         """One step of the reset recipe's robot moves, `self._set_action(action); self.mujoco_simulation.step()` (common/base.py:484-496): the TCP solver world's
         launch, the main world's mj_steps with ONE state-less forward (MjSim.step), no _observe_sync: no second forward, no gripper hand-over to the solver world."""
+        if self.joint_control:
+            self.sim.env_step(action=actions, nforward_ticks=1, active=active)
+            return
         self.solver_sim.step_tcp(self.sim, actions, self.tcp, active=active)
         self.sim.env_step(nforward_ticks=1, active=active)
 
@@ -343,12 +387,13 @@ class BatchedBlockRearrangeEnv:
         """What RearrangeEnv._reset writes before anything is simulated (common/base.py:897-932): both worlds as freshly made, the arm's start pose, object
         rotations about z and their placement, bounding boxes / colours of the static observation.  Returns the drawn yaw angles [len(rows), N]."""
         dev, N = self.device, self.N
-        A, As = self.model.arrays, self.solver_model.arrays
+        A = self.model.arrays
+        worlds = [(self.sim, A)] + ([] if self.solver_sim is None else [(self.solver_sim, self.solver_model.arrays)])
         if self.per_env_parameters:      # _recreate_sim (common/base.py:850-856): a fresh model -- the previous episode's randomised values are gone
             for k, v in self._param_defaults.items():
                 self.sim.params[k][idx] = v
         # MjSim of a fresh model: qpos0, zero velocities / controller state / time; robot.reset()
-        for sim, model in ((self.sim, A), (self.solver_sim, As)):
+        for sim, model in worlds:
             sim.qpos[idx] = torch.tensor(model["qpos0"].astype(np.float32), device=dev)
             for f in (sim.qvel, sim.ctrl, sim.pid, sim.qacc_warmstart):
                 f[idx] = 0
@@ -357,8 +402,9 @@ class BatchedBlockRearrangeEnv:
         arm0 = torch.tensor(TABLETOP_EXPERIMENT_INITIAL_POS.astype(np.float32), device=dev)
         self.sim.qpos[idx[:, None], torch.tensor(self.arm_q, device=dev)] = arm0
         self.sim.ctrl[idx, :6] = arm0
-        self.solver_sim.qpos[idx[:, None], torch.tensor(self.solver_arm_q, device=dev)] = arm0
-        self.solver_sim.eq_data[idx, :7] = torch.tensor([0, 0, 0, 1, 0, 0, 0], dtype=torch.float32, device=dev)     # reset_mocap_welds
+        if self.solver_sim is not None:
+            self.solver_sim.qpos[idx[:, None], torch.tensor(self.solver_arm_q, device=dev)] = arm0
+            self.solver_sim.eq_data[idx, :7] = torch.tensor([0, 0, 0, 1, 0, 0, 0], dtype=torch.float32, device=dev)     # reset_mocap_welds
         # object rotations about z and grid placement (common/base.py:613-640, 797-822)
         yaw = self._rng.uniform(0.0, 2 * np.pi, (len(rows), N))
         pos = self._grid_placement(yaw, rows)
@@ -381,7 +427,7 @@ class BatchedBlockRearrangeEnv:
         active = torch.zeros(self.B, dtype=torch.int32, device=dev); active[idx] = 1
         if self.pipelined:       # a synchronous reset ends whatever recipe those envs were in
             self._stage[rows] = 0; self._left[rows] = 0
-            self.hold[idx] = 0; self.frozen[idx] = 0; self.solver_active[idx] = 1; self.resetting[idx] = False; self.episode_started[idx] = False
+            self.hold[idx] = 0; self.hold_ctrl[idx] = 0; self.frozen[idx] = 0; self.solver_active[idx] = 1; self.resetting[idx] = False; self.episode_started[idx] = False
             self.nticks[idx] = 2; self._nticks_host = None
         yaw = self._begin_episode_state(rows, idx)
         # stabilize_objects (common/utils.py:76-92): the objects' dof damping is lowered to 1e-3 while they settle and restored afterwards -- with per-env parameter
@@ -392,8 +438,8 @@ class BatchedBlockRearrangeEnv:
         self._set_object_damping(idx, None)
         # _randomize_robot_initial_position (common/base.py:498-510)
         if self.n_random_initial_steps >= 1:
-            act = torch.zeros(self.B, 6, device=dev)
-            act[idx] = torch.tensor(self._rng.uniform(-1, 1, (len(rows), 6)).astype(np.float32), device=dev)
+            act = torch.zeros(self.B, self.action_dim, device=dev)
+            act[idx] = torch.tensor(self._rng.uniform(-1, 1, (len(rows), self.action_dim)).astype(np.float32), device=dev)
             for _ in range(self.n_random_initial_steps):
                 self._recipe_physics(act, active)
             for _ in range(self.settle_steps):
@@ -449,8 +495,8 @@ class BatchedBlockRearrangeEnv:
                 self._set_object_damping(idx, None)                     # stabilize_objects restores the objects' damping
             if stage == 1 and self.n_random_initial_steps >= 1:         # -> one random action for n_random_initial_steps steps
                 st[rows], left[rows] = 2, self.n_random_initial_steps
-                self.scripted[idx] = torch.tensor(self._rng.uniform(-1, 1, (len(rows), 6)).astype(np.float32), device=dev)
-                self.solver_active[idx] = 1
+                self.scripted[idx] = torch.tensor(self._rng.uniform(-1, 1, (len(rows), self.action_dim)).astype(np.float32), device=dev)
+                self.solver_active[idx] = 1; self.hold_ctrl[idx] = 0
             elif stage == 2:                                            # -> zero action while everything settles
                 st[rows], left[rows] = 3, self.settle_steps
                 self.scripted[idx] = 0
@@ -463,7 +509,7 @@ class BatchedBlockRearrangeEnv:
             for f in (self.t, self.steps, self.ssl, self.successes, self.consecutive, self.ema_t, self.hold):
                 f[idx] = 0
             self.ema_value[idx] = 0; self.action_ema[idx] = 0; self.scripted[idx] = 0
-            self.frozen[idx] = 0; self.solver_active[idx] = 1
+            self.frozen[idx] = 0; self.solver_active[idx] = 1; self.hold_ctrl[idx] = 0
             self.resetting[idx] = False; self.episode_started[idx] = True
             self._randomize_simulation(idx)
             yaw = self._yaw[rows]
@@ -482,7 +528,7 @@ class BatchedBlockRearrangeEnv:
             self._yaw[rows] = self._begin_episode_state(rows, idx)
             self._set_object_damping(idx, self.stabilize_object_damping)
             st[rows], left[rows] = 1, self.stabilize_steps
-            self.hold[idx] = 1; self.scripted[idx] = 0; self.frozen[idx] = 4; self.solver_active[idx] = 0
+            self.hold[idx] = 1; self.scripted[idx] = 0; self.frozen[idx] = 4; self.solver_active[idx] = 0; self.hold_ctrl[idx] = 1
             self.resetting[idx] = True
             if self.stabilize_steps <= 0:        # (degenerate configuration: straight to the next stage on the following step)
                 left[rows] = 1
@@ -594,6 +640,16 @@ SUPPORTED_CONSTANTS = {"success_threshold", "successes_needed", "success_reward"
                        "goal_reward_per_object", "normalize_mesh", "randomize"}
 
 
+def _control_mode_name(mode) -> str:
+    """`ControlMode` value or name (robot_interface.py:9-20) -> "tcp+roll+yaw" | "joint"; tcp+wrist is not built."""
+    name = str(getattr(mode, "value", mode)).lower().split(".")[-1]
+    if name in ("tcp+roll+yaw", "tcp_roll_yaw"):
+        return "tcp+roll+yaw"
+    if name == "joint":
+        return "joint"
+    raise NotImplementedError("control_mode %r: tcp+roll+yaw (the reference's default, robot_interface.py:43-47) and joint are implemented" % (mode,))
+
+
 def _check_supported(parameters, sp, rc, constants):
     """A parameter or constant of the reference's env that this env does not implement is an error, not a silently ignored key (the reference's attrs classes reject
     unknown names the same way; the supported subset keeps the reference's names and meaning)."""
@@ -602,8 +658,7 @@ def _check_supported(parameters, sp, rc, constants):
         unknown = sorted(set(got) - known)
         if unknown:
             raise NotImplementedError("%s: %s not implemented by the batched rearrange env (supported: %s)" % (where, ", ".join(unknown), ", ".join(sorted(known))))
-    if str(rc.get("control_mode", "tcp+roll+yaw")).lower().split(".")[-1] not in ("tcp+roll+yaw", "tcp_roll_yaw"):
-        raise NotImplementedError("control_mode other than tcp+roll+yaw (the reference's default, robot_interface.py:43-47)")
+    _control_mode_name(rc.get("control_mode", "tcp+roll+yaw"))
     if str(rc.get("tcp_solver_mode", "mocap_ik")).lower().split(".")[-1] != "mocap_ik":
         raise NotImplementedError("tcp_solver_mode other than mocap_ik (the reference's default, robot_interface.py:54-58)")
 
@@ -617,7 +672,7 @@ def make_env(batch_size: int = 4096, device="cuda:0", parameters=None, constants
     _check_supported(parameters, sp, rc, constants)
     args = dict(num_objects=sp.get("num_objects", 5), max_position_change=rc.get("max_position_change", 0.1), arm_reset_controller_error=rc.get("arm_reset_controller_error", True),
                 n_random_initial_steps=parameters.get("n_random_initial_steps", 10), starting_seed=starting_seed, wrappers=bool(apply_wrappers),
-                n_action_bins=constants.get("n_action_bins", 11))      # (+ pipelined_reset=True through **kw: episodes restart inside the step calls)
+                n_action_bins=constants.get("n_action_bins", 11), control_mode=rc.get("control_mode", "tcp+roll+yaw"))      # (+ pipelined_reset=True through **kw: episodes restart inside the step calls)
     if "action_spacing" in constants:
         args["action_spacing"] = constants["action_spacing"]
     for k in ("success_threshold", "successes_needed", "success_reward", "max_timesteps_per_goal_per_obj", "use_goal_distance_reward", "goal_reward_per_object"):

@@ -83,6 +83,16 @@ class LargeModelSimulation:
         except Exception:
             pass
 
+    def set_action_map(self, first_qposadr: int, pos_to_ctrl: np.ndarray, relative_action: bool = True, max_position_change: float = 0.0, ctrl_centre_mask: int = 0):
+        """The action map of `env_step(action=...)` for a robot that is not the hand (rb_batch_set_env + rb_batch_set_action_limits, include/rgstep.h):
+        `pos_to_ctrl` [nu, n] over the n joint positions from `first_qposadr` on."""
+        P = np.ascontiguousarray(pos_to_ctrl, dtype=np.float32)
+        assert P.ndim == 2 and P.shape[0] == self.nu
+        L = self._L
+        _native.check(L, L.rb_batch_set_env(self._bh, int(first_qposadr), P.shape[1], 1 if relative_action else 0, P.ctypes.data_as(ctypes.POINTER(ctypes.c_float))), "rb_batch_set_env")
+        _native.check(L, L.rb_batch_set_action_limits(self._bh, float(max_position_change), int(ctrl_centre_mask)), "rb_batch_set_action_limits")
+        self.pos_to_ctrl = P
+
     def register_joint_group(self, name, prefix):
         A, names = self.model.arrays, self.model.names["joint"]
         q, v = [], []

@@ -19,8 +19,8 @@ def _oracle_from_kernel(env, row, n_substeps):
         # into [0.5, 0.99] even at parameter 0, randomization/sim.py:183-268 -- and so has stabilize_objects' damping change)
         P = env.sim.params
         model = env.model.copy_with(**{("opt_gravity" if k == "gravity" else k): P[k][row].cpu().numpy().astype(np.float64) for k in P.keys() if P[k].shape[1] > 0})
-    o = RO.OracleRearrangeEnv(model, env.solver_model, env.N, n_substeps=n_substeps, max_position_change=env.tcp.max_position_change)
-    for sim, os_ in ((env.sim, o.main.sim), (env.solver_sim, o.solver.sim)):
+    o = RO.OracleRearrangeEnv(model, None if env.joint_control else env.solver_model, env.N, n_substeps=n_substeps, max_position_change=env.max_position_change)
+    for sim, os_ in [(env.sim, o.main.sim)] + ([] if env.joint_control else [(env.solver_sim, o.solver.sim)]):
         for name, f in (("qpos", sim.qpos), ("qvel", sim.qvel), ("ctrl", sim.ctrl), ("pid", sim.pid), ("qacc_warmstart", sim.qacc_warmstart)):
             getattr(os_, name)[:] = f[row].cpu().numpy().astype(np.float64)
         os_._L.ro_set_time(os_.d, float(sim.time[row]))
@@ -62,12 +62,14 @@ def _check_steps(lib, device, B, n_substeps, nsteps, tol_scale=1.0, make=None, t
     rng = np.random.RandomState(5)
     worst, same = {}, []
     for step in range(nsteps):
-        a = rng.uniform(-1, 1, (B, 6)).astype(np.float32)
-        a[:, 2] = -np.abs(a[:, 2])            # downwards: towards the blocks
+        a = rng.uniform(-1, 1, (B, env.action_dim)).astype(np.float32)
+        if not env.joint_control:
+            a[:, 2] = -np.abs(a[:, 2])            # downwards: towards the blocks
         oracles = [_oracle_from_kernel(env, r, n_substeps) for r in range(B)]
         prev_valid = env.prev_valid.cpu().numpy().copy(); prev_ns = env.prev_nsucc.cpu().numpy().copy()
         t0 = env.t.cpu().numpy().copy()
-        km, kc = env.sim.stats.cpu().numpy().astype(np.float64), env.solver_sim.stats.cpu().numpy().astype(np.float64)
+        km = env.sim.stats.cpu().numpy().astype(np.float64)
+        kc = None if env.joint_control else env.solver_sim.stats.cpu().numpy().astype(np.float64)
         obs, rew, done, info = env.step(torch.tensor(a, device=env.device))
         env.sync()
         for r in range(B):
@@ -80,7 +82,7 @@ def _check_steps(lib, device, B, n_substeps, nsteps, tol_scale=1.0, make=None, t
             if before is not None:
                 ogoal_rew = o.num_success(o.goal_distance()) - before
                 assert abs(before - prev_ns[r]) < 1e-6
-            same.append(contact_history(env.sim, o.main, km[r], row=r) and contact_history(env.solver_sim, o.solver, kc[r], row=r))
+            same.append(contact_history(env.sim, o.main, km[r], row=r) and (env.joint_control or contact_history(env.solver_sim, o.solver, kc[r], row=r)))
             for k, tl in tol.items():
                 got = obs[k][r].cpu().numpy().astype(np.float64).reshape(np.asarray(oobs[k]).shape)
                 err = float(np.abs(got - oobs[k]).max())
@@ -93,8 +95,8 @@ def _check_steps(lib, device, B, n_substeps, nsteps, tol_scale=1.0, make=None, t
             assert abs(float(env.goal_dist[r, 0]) - d["obj_pos"].sum()) < gd[0] and abs(float(env.goal_dist[r, 1]) - d["obj_rot"].sum()) < gd[1], (gd, bool(same[-1]))
             assert int(env.t[r]) == t0[r] + 1
             # gripper hand-over to the solver world
-            assert float(env.solver_sim.qpos[r, env.solver_grip_q]) == float(env.sim.qpos[r, env.grip_q]) and float(env.solver_sim.ctrl[r, env.solver_grip_act]) == float(env.sim.ctrl[r, env.grip_act])
-        assert int(env.sim.status.max()) == 0 and int(env.solver_sim.status.max()) == 0
+            assert env.joint_control or float(env.solver_sim.qpos[r, env.solver_grip_q]) == float(env.sim.qpos[r, env.grip_q]) and float(env.solver_sim.ctrl[r, env.solver_grip_act]) == float(env.sim.ctrl[r, env.grip_act])
+        assert int(env.sim.status.max()) == 0 and (env.joint_control or int(env.solver_sim.status.max()) == 0)
     # Re-synchronised env.steps with the gripper pushing objects, classified by contact history: the (step, env) pairs whose 80 mj_steps held
     # the same contact / row counts on both sides carry the stated fp32 tolerance -- median <= tol, each <= SAME_HISTORY_TAIL x tol, no `tol_scale` --; a pair
     # with a differing history is an env.step with a contact event resolved a substep apart and is bounded loosely.
@@ -116,7 +118,7 @@ def _goal_and_tracker_checks(env):
     `goal_reset` raised, a new goal drawn by `reset_goals`, the tracker's counters as MultiGoalTracker.process leaves them; then a block pushed
     off the table ends the episode with the penalty."""
     B = env.B
-    z = torch.zeros(B, 6, device=env.device)
+    z = torch.zeros(B, env.action_dim, device=env.device)
     ssl0 = int(env.ssl[1])
     assert int(env.prev_valid.min()) == 1      # (the observation that ended the reset / the last step established the success count the next reward is measured from)
     for i, qa in enumerate(env.obj_q):                          # env 0: all blocks at their goals
@@ -147,6 +149,26 @@ def test_rearrange_env_step_matches_oracle_emul(emul_lib, oracle_lib):
 def test_rearrange_env_step_matches_oracle_gpu(oracle_lib):
     """the full 40 + 40 mj_steps per env.step, four envs, 12 steps with the arm pressing down"""
     env = _check_steps(None, "cuda:0", B=4, n_substeps=40, nsteps=12, min_same_fraction=0.4)
+    _goal_and_tracker_checks(env)
+
+
+def _joint_env(lib, device, B, n_substeps, **kw):
+    return lambda: BatchedBlockRearrangeEnv(B, device=device, lib=lib, n_substeps=n_substeps, control_mode="joint", **kw)
+
+
+def test_rearrange_joint_control_env_step_matches_oracle_emul(emul_lib, oracle_lib):
+    """control_mode "joint" (robot_interface.py:9-20; JointControlledArm + MujocoRobotiqGripper, no TCP solver world): the action map at the head of the main world's
+    launch, env kernel without a solver world -- one short env.step here, the full 40 mj_steps on the GPU"""
+    env = _check_steps(emul_lib, "cpu", B=2, n_substeps=1, nsteps=2, make=_joint_env(emul_lib, "cpu", 2, 1, stabilize_steps=1, n_random_initial_steps=1, settle_steps=1))
+    assert env.solver_sim is None and env.action_shape == (2, 7)
+    _goal_and_tracker_checks(env)
+
+
+@pytest.mark.gpu
+def test_rearrange_joint_control_env_step_matches_oracle_gpu(oracle_lib):
+    """the arm's joints commanded directly, +- max_position_change = 0.1 rad per step, gripper opening / closing: 12 steps of four envs after the full reset recipe"""
+    env = _check_steps(None, "cuda:0", B=4, n_substeps=40, nsteps=12, make=_joint_env(None, "cuda:0", 4, 40, stabilize_steps=20, n_random_initial_steps=2, settle_steps=10),
+                       min_same_fraction=0.4)
     _goal_and_tracker_checks(env)
 
 
@@ -287,6 +309,62 @@ def test_rearrange_pipelined_reset_sequence_emul(emul_lib):
 @pytest.mark.gpu
 def test_rearrange_pipelined_reset_sequence_gpu():
     _pipelined_reset_sequence(None, "cuda:0", n_substeps=40, B=64)
+
+
+def _joint_control_wrapped_pipelined(lib, device, n_substeps, B):
+    """control_mode "joint" through `make_env` with the wrapper stack and pipelined resets: MultiDiscrete [B, 7] actions, the smoothing filter's output (the reference's
+    IncrementalExpAvg, wrappers/util.py:142-160, recomputed here in float64) is the action that reaches the robot -- checked on the control row the main world's launch
+    wrote: ctrl[:6] = clip(q + a * min(range / 2, 0.1)), the gripper around its previous control --, and an episode that times out restarts inside the step calls with
+    the controls held while the objects stabilise."""
+    from robogym_amd.envs.rearrange.blocks import make_env
+
+    kw = dict(lib=lib) if lib is not None else {}
+    env = make_env(batch_size=B, device=device, starting_seed=4, parameters={"robot_control_params": {"control_mode": "joint", "max_position_change": 0.1}},
+                   constants={"max_timesteps_per_goal_per_obj": 1}, n_substeps=n_substeps, stabilize_steps=2, n_random_initial_steps=1, settle_steps=2, pipelined_reset=True,
+                   smooth_alpha=0.3 ** (40 / n_substeps), **kw)
+    assert env.joint_control and env.wrapped and env.solver_sim is None and env.bins.shape == (7, 11)
+    obs = env.reset()
+    assert obs["action_ema"].shape == (B, 7) and float(obs["action_ema"].abs().max()) == 0.0
+    A = env.model.arrays
+    lo, hi = A["actuator_ctrlrange"][:, 0].astype(np.float64), A["actuator_ctrlrange"][:, 1].astype(np.float64)
+    rng = np.random.RandomState(2)
+    al, value, t = 0.3 ** 0.5, np.zeros((B, 7)), 0
+    for k in range(1, 12):
+        idx = rng.randint(0, 11, (B, 7))
+        q = env.sim.qpos[:, env.arm_q[0]:env.arm_q[0] + 6].cpu().numpy().astype(np.float64)
+        g0 = env.sim.ctrl[:, env.grip_act].cpu().numpy().astype(np.float64)
+        c0 = env.sim.ctrl.cpu().numpy().copy()
+        live = not bool(env.resetting.any())
+        obs, rew, done, info = env.step(torch.tensor(idx, device=env.device))
+        env.sync()
+        assert int(env.sim.status.max()) == 0 and bool(torch.isfinite(env.packed).all())
+        ctrl = env.sim.ctrl.cpu().numpy().astype(np.float64)
+        if live:
+            value = value * al + (1 - al) * (idx / 5.0 - 1.0); t += 1
+            a = value / (1 - al ** t)
+            assert np.abs(obs["action_ema"].cpu().numpy() - a).max() < 2e-6
+        if live and not bool(done.any()):      # (an episode that ended on this step already carries the next episode's start state)
+            assert np.abs(ctrl[:, :6] - np.clip(q + a[:, :6] * np.minimum(0.5 * (hi - lo)[:6], 0.1), lo[:6], hi[:6])).max() < 2e-6
+            assert np.abs(ctrl[:, 6] - np.clip(g0 + a[:, 6] * 0.5 * (hi - lo)[6], lo[6], hi[6])).max() < 2e-6
+        assert bool(done.all()) == (k == 5)     # the goal's time-out: 5 objects x 1 step; the recipe's 2 + 1 + 2 steps follow
+        if k in (6, 7):     # stabilise: the stored controls stay
+            assert bool(info["resetting"].all()) and np.array_equal(ctrl, c0)
+        if k == 8:          # the recipe's one random action moved the arm's targets
+            assert bool(info["resetting"].all()) and not np.array_equal(ctrl[:, :6], c0[:, :6])
+        if k == 10:
+            assert bool(info["episode_started"].all()) and float(obs["action_ema"].abs().max()) == 0.0
+            value, t = np.zeros((B, 7)), 0
+    assert int(env.steps.max()) == 1
+    return env
+
+
+def test_rearrange_joint_control_wrapped_pipelined_emul(emul_lib):
+    _joint_control_wrapped_pipelined(emul_lib, "cpu", n_substeps=1, B=2)
+
+
+@pytest.mark.gpu
+def test_rearrange_joint_control_wrapped_pipelined_gpu():
+    _joint_control_wrapped_pipelined(None, "cuda:0", n_substeps=40, B=16)
 
 
 # ------------------------------------------------------------------------------------------------ the reference's impulse-response pin on the batched env itself
