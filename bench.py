@@ -252,6 +252,8 @@ def bench_rearrange_blocks(args, emit=True, ycb=False, joint=False):
     if joint:
         out["metric"] = out["metric"].replace("unwrapped env.step incl. the TCP solver's second simulation", "control_mode joint (7 action numbers, no TCP solver world): unwrapped env.step = the main world's launch + the env kernel")
         out["config"]["control_mode"] = "joint"
+        out["config"]["workload"] = out["config"]["workload"].replace(" with its TCP solver world (nv=8, mocap weld)", ", control_mode joint: no TCP solver world").replace(
+            "relative tcp+roll+yaw actions, 40 + 40 substeps", "relative joint actions (7 numbers), 40 substeps")
     if emit and rank == 0:
         print(json.dumps(out, default=float))
     if distributed:
@@ -262,19 +264,21 @@ def bench_rearrange_blocks(args, emit=True, ycb=False, joint=False):
     return out
 
 
-def bench_rearrange_steady(args, ycb=False, knock_per_step=4, warm_steps=215):
+def bench_rearrange_steady(args, ycb=False, knock_per_step=4, warm_steps=215, device_reset=True):
     """The rearrange envs WITH episode ends, as driver evidence: `pipelined_reset=True`, the reference's full reset recipe (100 stabilisation
     steps, 10 of one random action, 100 of the zero action) running inside the step calls.  Random actions almost never reach a goal, so episodes of this workload
     end by the goal time-out (200 steps per object) or by an object leaving the table; to see the steady-state MIX inside a short run, `knock_per_step` live envs per
     step have one object put off the table (their episode ends on that step: done, penalty, recipe starts) during `warm_steps` >= one recipe length, so that at the
-    timed window ~ knock_per_step x 210 / B of the envs are spread over all stages of the recipe -- the share a 1000-step time-out gives (210 / 1210 = 17 %)."""
+    timed window ~ knock_per_step x 210 / B of the envs are spread over all stages of the recipe -- the share a 1000-step time-out gives (210 / 1210 = 17 %).
+    `device_reset` (default): the recipe's stage machine and the placement / goal sampling in ra_recipe_kernel, no readback inside a step call -- the knocked envs are
+    drawn on the device too and the counters are read after the window; False: the host recipe behind one readback of the flags per step."""
     from robogym_amd.envs.rearrange.blocks import BatchedBlockRearrangeEnv
     from robogym_amd.envs.rearrange.ycb import BatchedYcbRearrangeEnv
 
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     B = args.batch if args.batch != 8192 else 4096
-    env = (BatchedYcbRearrangeEnv if ycb else BatchedBlockRearrangeEnv)(B, device=dev, starting_seed=20200901 + 5, pipelined_reset=True)
+    env = (BatchedYcbRearrangeEnv if ycb else BatchedBlockRearrangeEnv)(B, device=dev, starting_seed=20200901 + 5, pipelined_reset=True, device_reset=bool(device_reset))
     # (the FIRST reset is shortened -- it only places the objects; every recipe that runs inside the steps is the full one)
     full = (env.stabilize_steps, env.n_random_initial_steps, env.settle_steps)
     env.stabilize_steps, env.n_random_initial_steps, env.settle_steps = 20, 2, 20
@@ -284,10 +288,15 @@ def bench_rearrange_steady(args, ycb=False, knock_per_step=4, warm_steps=215):
     rng = np.random.RandomState(20200901 + 5)
     ended = started = 0
     inside = 0.0
+    if device_reset:
+        ended, started, inside = torch.zeros((), device=dev), torch.zeros((), device=dev), torch.zeros((), device=dev)
 
     def step(knock):
         nonlocal ended, started, inside
-        if knock:
+        if knock and device_reset:
+            rows = torch.multinomial((env.stage == 0).float() + 1.0e-9, knock, generator=gen)      # (live envs, drawn without a readback)
+            env.sim.qpos[rows, env.obj_q[0]] = 3.0
+        elif knock:
             live = np.nonzero(env._stage == 0)[0]
             rows = torch.as_tensor(rng.choice(live, size=min(knock, len(live)), replace=False), device=dev, dtype=torch.long)
             env.sim.qpos[rows, env.obj_q[0]] = 3.0          # object 0 far off the table: check_objects_off_table ends the episode on this step
@@ -300,13 +309,18 @@ def bench_rearrange_steady(args, ycb=False, knock_per_step=4, warm_steps=215):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         done, info = step(knock_per_step)
-        ended += int(done.sum()); started += int(info["episode_started"].sum()); inside += float(info["resetting"].float().mean())
+        if device_reset:
+            ended += done.sum(); started += info["episode_started"].sum(); inside += info["resetting"].float().mean()
+        else:
+            ended += int(done.sum()); started += int(info["episode_started"].sum()); inside += float(info["resetting"].float().mean())
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    ended, started, inside = int(ended), int(started), float(inside)
     out = {"metric": "env-steps/sec rearrange/%s batch %d WITH episode ends: pipelined in-step resets (the reference's full reset recipe inside the step calls), recipe steps counted as env-steps" % ("ycb num_objects=8" if ycb else "blocks num_objects=5", B),
            "value": B * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": warm_steps, "ms_per_step": 1e3 * elapsed / args.steps, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "as the rearrange line above; episode ends forced at %d live envs per step (one object put off the table) through %d warm-up steps and the timed window" % (knock_per_step, warm_steps),
-                      "fraction_of_env_steps_inside_the_reset_recipe": inside / max(args.steps, 1), "episodes_ended_in_window": ended, "episodes_started_in_window": started,
+                      "fraction_of_env_steps_inside_the_reset_recipe": inside / max(args.steps, 1), "episodes_ended_in_window": ended, "episodes_started_in_window": started, "device_reset": bool(device_reset),
+                      "placements_out_of_trials": int(env.placement_failed.sum()) if device_reset else None,
                       "status_bits": int(max(env.sim.status.max().item(), env.solver_sim.status.max().item()))},
            "roofline": None, "cpu_baseline": None, "note": "same kernels and byte model as the rearrange line; envs that stabilise their objects skip the solver world's launch"}
     del env

@@ -399,6 +399,38 @@ typedef struct ra_post_args {
 } ra_post_args;
 int ra_env_post_step(rb_batch* main, rb_batch* solver, const ra_post_args* args, void* stream);
 int ra_post_args_size(void);
+/* ---- the reset recipe and the goal sampling of the rearrange envs on the device (pipelined resets: an ended episode restarts INSIDE the following step calls),
+ * one launch after ra_env_post_step; no host readback.  Per env: the recipe's stage machine — stabilise (stabilize_steps, the stored controls held) -> one random
+ * action for n_random_initial_steps (RearrangeEnv._randomize_robot_initial_position, /root/reference/robogym/envs/rearrange/common/base.py:498-510) -> settle_steps
+ * of the zero action -> the episode starts: tracker / wrapper state zeroed, first goal —; for an episode that ended on this step the state RearrangeEnv._reset writes
+ * before anything is simulated (common/base.py:897-932: both worlds as freshly made, the arm's start pose, object rotations about z, `place_objects_in_grid`,
+ * common/utils.py:719-829, with `place_objects_with_no_constraint`'s rejection sampling, :829-880, when the grid has fewer cells than objects; bounding boxes and colours
+ * of the static observation); for a live env whose goal was reached `ObjectStateGoal.next_goal` (goals/object_state.py:355-418: a new placement, the goal keeps the
+ * objects' initial yaw).  Draws come from a counter-based generator (seed, step, env, k).  Outputs for the NEXT step's launches: hold / hold_ctrl / scripted /
+ * frozen / solver_active / nticks; `reobserve` is the `frozen` array of a second ra_env_post_step launch (1 = first observation of a new episode, 3 = a live env with
+ * a new goal, 2 = skip); `ended` / `stabilised` / `episode_started` are masks for the host's tensor ops on the per-env parameter rows (stabilize_objects' damping,
+ * the simulation randomizers).  solver may be NULL (control_mode joint). */
+typedef struct ra_recipe_args {
+  int num_objects, action_dim;
+  int *stage, *left;                             /* [B]: 0 live, 1 stabilise, 2 random action, 3 settle; steps left in the stage */
+  float* yaw;                                    /* [B][N] the episode's object rotations about z */
+  const unsigned char *done, *goal_reset;        /* [B] as ra_env_post_step left them */
+  int *hold, *hold_ctrl, *solver_active, *nticks;
+  float* scripted;                               /* [B][action_dim] */
+  unsigned char *frozen, *resetting, *episode_started, *reobserve, *ended, *stabilised;
+  int* placement_failed;                         /* [B] += 1 when the rejection sampling ran out of restarts (the last proposal is used) */
+  int *t, *steps, *steps_since_last_goal, *successes_so_far, *consecutive, *prev_valid, *ema_t;
+  float *ema_value, *action_ema;                 /* [B][action_dim] */
+  float *goal, *goal_rot, *qpos_goal, *static_obs;   /* as ra_post_args */
+  int obj_qposadr[RA_MAXOBJ], arm_qposadr[6], solver_arm_qposadr[6];
+  float arm_start[6];                            /* TABLETOP_EXPERIMENT_INITIAL_POS (robot/ur16e/arm_interface.py:27) */
+  float obj_center[RA_MAXOBJ][3], obj_half[RA_MAXOBJ][3];   /* bounding box of each object's vertices in its body frame */
+  float area_offset[2], area_size[2], table_pos[3], table_size[3];   /* get_placement_area (simulation/base.py:980-1010), offset from the table's low corner */
+  int stabilize_steps, n_random_initial_steps, settle_steps;
+  unsigned seed, step;
+} ra_recipe_args;
+int ra_env_recipe_step(rb_batch* main, rb_batch* solver, const ra_recipe_args* args, void* stream);
+int ra_recipe_args_size(void);
 /* ---- the env-level half of RobotEnv.step for the full cube (dactyl/full_perpendicular), one launch after rb_batch_step:
  * FaceFreeGoal.goal_distance / relative_goal / next_goal (/root/reference/robogym/envs/dactyl/goals/face_free.py:61-189, with
  * cube_utils.py:26-181), the target cube's joint manipulation that next_goal entails (full_perpendicular.py:138-155 ->

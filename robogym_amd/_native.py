@@ -99,6 +99,23 @@ class RaPostArgs(ctypes.Structure):
     _fields_ = _ra_post_fields()
 
 
+def _ra_recipe_fields():
+    _p, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+    return ([("num_objects", _i), ("action_dim", _i)]
+            + [(n, _p) for n in ("stage", "left", "yaw", "done", "goal_reset", "hold", "hold_ctrl", "solver_active", "nticks", "scripted", "frozen", "resetting", "episode_started",
+                                 "reobserve", "ended", "stabilised", "placement_failed", "t", "steps", "steps_since_last_goal", "successes_so_far", "consecutive", "prev_valid",
+                                 "ema_t", "ema_value", "action_ema", "goal", "goal_rot", "qpos_goal", "static_obs")]
+            + [("obj_qposadr", _i * RA_MAXOBJ), ("arm_qposadr", _i * 6), ("solver_arm_qposadr", _i * 6), ("arm_start", _f * 6), ("obj_center", (_f * 3) * RA_MAXOBJ),
+               ("obj_half", (_f * 3) * RA_MAXOBJ), ("area_offset", _f * 2), ("area_size", _f * 2), ("table_pos", _f * 3), ("table_size", _f * 3), ("stabilize_steps", _i),
+               ("n_random_initial_steps", _i), ("settle_steps", _i), ("seed", ctypes.c_uint), ("step", ctypes.c_uint)])
+
+
+class RaRecipeArgs(ctypes.Structure):
+    """`ra_recipe_args` of include/rgstep.h (field order and types must match; bind() checks the size)."""
+
+    _fields_ = _ra_recipe_fields()
+
+
 EXPORTS = [
     "rg_model_create", "rg_model_free", "rg_model_dims", "rg_batch_create", "rg_batch_free", "rg_batch_set_env",
     "rg_batch_copy", "rg_batch_reset", "rg_batch_step", "rg_obs_dim", "rg_debug_size", "rg_lds_bytes", "rg_sync",
@@ -107,7 +124,7 @@ EXPORTS = [
     "rb_model_create", "rb_model_free", "rb_model_info", "rb_scratch_offset", "rb_batch_create", "rb_batch_free", "rb_batch_reset", "rb_batch_set_env",
     "rb_batch_field_ptr", "rb_batch_step", "rb_batch_step_ex", "rb_env_post_step", "rb_post_args_size", "rb_cube_ops", "rb_batch_step_tcp", "ra_env_post_step", "ra_post_args_size",
     "rg_blob_entry", "rg_model_blob_keys", "rb_model_blob_keys", "rg_compile_mjcf", "rb_compile_mjcf", "rg_compile_mjcf_blob", "rg_blob_free",
-    "rb_model_enable_env_params", "rb_prm_layout", "rb_batch_set_action_limits",
+    "rb_model_enable_env_params", "rb_prm_layout", "rb_batch_set_action_limits", "ra_env_recipe_step", "ra_recipe_args_size",
 ]
 
 
@@ -188,6 +205,10 @@ def bind(path):
     L.ra_post_args_size.restype = ci
     if L.ra_post_args_size() != ctypes.sizeof(RaPostArgs):
         raise NativeError("ra_post_args layout mismatch between include/rgstep.h and robogym_amd/_native.py")
+    L.ra_env_recipe_step.argtypes = [vp, vp, ctypes.POINTER(RaRecipeArgs), vp]
+    L.ra_recipe_args_size.restype = ci
+    if L.ra_recipe_args_size() != ctypes.sizeof(RaRecipeArgs):
+        raise NativeError("ra_recipe_args layout mismatch between include/rgstep.h and robogym_amd/_native.py")
     L.rb_env_post_step.argtypes = [vp, ctypes.POINTER(RbPostArgs), vp]
     L.rb_post_args_size.restype = ci
     if L.rb_post_args_size() != ctypes.sizeof(RbPostArgs):

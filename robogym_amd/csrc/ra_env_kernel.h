@@ -203,4 +203,209 @@ __global__ void __launch_bounds__(64) ra_post_step_kernel(const RbModelDev* mp, 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------------------
+// The reset recipe and the goal sampling on the device (ra_recipe_args, include/rgstep.h): what BatchedBlockRearrangeEnv._advance_recipes does on the host
+// (robogym_amd/envs/rearrange/blocks.py) without its readback of the done / goal_reset flags.  Reference call sites:
+//   RearrangeEnv._reset, _randomize_robot_initial_position        envs/rearrange/common/base.py:897-932, 498-510
+//   place_objects_in_grid / place_objects_with_no_constraint       envs/rearrange/common/utils.py:719-829 / 829-880 (_place_objects :623-716)
+//   get_placement_area                                             envs/rearrange/simulation/base.py:980-1010
+//   ObjectStateGoal.next_goal                                      envs/rearrange/goals/object_state.py:355-418
+struct RaRecipeLds { int started, ended, regoal; float pos[RA_MAXOBJ][3], gpos[RA_MAXOBJ][3], gyaw[RA_MAXOBJ]; };
+
+// One placement of the N objects (rotated about z by yaw[i]) inside the placement area: body origins in world coordinates.  Returns false when the rejection
+// sampling ran out of restarts (out = its last proposal).  `k`: this env's running draw index.
+__device__ inline bool ra_place(const RaRecipeArgs& a, const float* yaw, int ystride, unsigned seed, unsigned step, unsigned e, unsigned& k, float (*out)[3]) {
+  const int N = a.num_objects;
+  auto U = [&]() -> float { return (float)(rbp_hash(seed, step, e, k++) >> 8) * (1.0f / 16777216.0f); };
+  float hx[RA_MAXOBJ], hy[RA_MAXOBJ], xy[RA_MAXOBJ][2];
+  float mx = 0.f, my = 0.f;
+  for (int i = 0; i < N; i++) {      // rotate_bounding_box
+    const float c = fabsf(cosf(yaw[i * ystride])), s_ = fabsf(sinf(yaw[i * ystride]));
+    hx[i] = c * a.obj_half[i][0] + s_ * a.obj_half[i][1]; hy[i] = s_ * a.obj_half[i][0] + c * a.obj_half[i][1];
+    mx = fmaxf(mx, hx[i]); my = fmaxf(my, hy[i]);
+  }
+  const float width = a.area_size[0], height = a.area_size[1];
+  const int ncol = (int)floorf(width / (2.f * mx)), nrow = (int)floorf(height / (2.f * my));
+  const int M = ncol * nrow;
+  bool ok = true;
+  if (M >= N) {
+    // N distinct cells in random order = the first N of a random permutation of the M cells: a uniform random subset (Floyd), then shuffled
+    int cell[RA_MAXOBJ];
+    for (int idx = 0, j = M - N; j < M; j++, idx++) {
+      int t = (int)(U() * (float)(j + 1)); t = t > j ? j : t;
+      bool seen = false;
+      for (int q = 0; q < idx; q++) seen = seen || cell[q] == t;
+      cell[idx] = seen ? j : t;
+    }
+    for (int i = N - 1; i > 0; i--) { int j = (int)(U() * (float)(i + 1)); j = j > i ? i : j; const int tmp = cell[i]; cell[i] = cell[j]; cell[j] = tmp; }
+    const float cw = width / (float)ncol, ch = height / (float)nrow;
+    for (int i = 0; i < N; i++) { xy[i][0] = cw * (float)(cell[i] % ncol) + hx[i]; xy[i][1] = ch * (float)(cell[i] / ncol) + hy[i]; }
+  } else {
+    // fewer cells than objects (large mesh objects): uniform proposals, rejected while the object's box overlaps a placed one; largest objects first; a set
+    // restarts when one of its objects runs out of trials
+    int order[RA_MAXOBJ];
+    for (int i = 0; i < N; i++) order[i] = i;
+    for (int i = 1; i < N; i++) {      // stable insertion sort, area descending
+      const int v = order[i]; const float av = a.obj_half[v][0] * a.obj_half[v][1];
+      int j = i - 1;
+      while (j >= 0 && a.obj_half[order[j]][0] * a.obj_half[order[j]][1] < av) { order[j + 1] = order[j]; j--; }
+      order[j + 1] = v;
+    }
+    ok = false;
+    for (int round = 0; round < 200 && !ok; round++) {
+      ok = true;
+      for (int oi = 0; oi < N && ok; oi++) {
+        const int i = order[oi];
+        bool placed = false;
+        for (int trial = 0; trial < 100 && !placed; trial++) {
+          const float cx = hx[i] + U() * (width - 2.f * hx[i]), cy = hy[i] + U() * (height - 2.f * hy[i]);
+          bool free_ = true;
+          for (int od = 0; od < oi; od++) { const int d = order[od]; free_ = free_ && (fabsf(cx - xy[d][0]) >= hx[i] + hx[d] || fabsf(cy - xy[d][1]) >= hy[i] + hy[d]); }
+          xy[i][0] = cx; xy[i][1] = cy;
+          placed = free_;
+        }
+        ok = placed;
+      }
+    }
+  }
+  for (int i = 0; i < N; i++) {      // the body origin, from the centre of its bounding box
+    const float c = cosf(yaw[i * ystride]), s_ = sinf(yaw[i * ystride]);
+    const float ccx = c * a.obj_center[i][0] - s_ * a.obj_center[i][1], ccy = s_ * a.obj_center[i][0] + c * a.obj_center[i][1];
+    out[i][0] = xy[i][0] + a.area_offset[0] - a.table_size[0] + a.table_pos[0] - ccx;
+    out[i][1] = xy[i][1] + a.area_offset[1] - a.table_size[1] + a.table_pos[1] - ccy;
+    out[i][2] = a.obj_half[i][2] + 2.f * a.table_size[2] - a.table_size[2] + a.table_pos[2] - a.obj_center[i][2];
+  }
+  return ok;
+}
+
+__global__ void __launch_bounds__(64) ra_recipe_kernel(const RbModelDev* mp, RbBatchDev bt, const RbModelDev* sp, RbBatchDev sb, RaRecipeArgs a) {
+#ifdef RG_EMUL
+  RaRecipeLds& F = *(RaRecipeLds*)emul_lds();
+#else
+  __shared__ RaRecipeLds Fs; RaRecipeLds& F = Fs;
+#endif
+  const RbModelDev& m = *mp;
+  const int e = blockIdx.x, lane = threadIdx.x;
+  if (e >= bt.B) return;
+  const int N = a.num_objects, AD = a.action_dim, nq = m.nq;
+  if (lane == 0) {
+    int st = a.stage[e], lf = a.left[e];
+    int started = 0, ended = 0, regoal = 0, stabilised = 0;
+    unsigned k = 0;
+    auto U = [&]() -> float { return (float)(rbp_hash(a.seed, a.step, (unsigned)e, k++) >> 8) * (1.0f / 16777216.0f); };
+    a.episode_started[e] = 0;
+    // ---- an env inside the recipe: this step counted
+    if (st > 0) {
+      lf -= 1;
+      if (lf <= 0) {
+        if (st == 1) {
+          stabilised = 1;                                              // stabilize_objects restores the objects' damping (host tensor op on this mask)
+          if (a.n_random_initial_steps >= 1) {                         // -> one random action for n_random_initial_steps steps
+            st = 2; lf = a.n_random_initial_steps;
+            for (int d = 0; d < AD; d++) a.scripted[(size_t)e * AD + d] = 2.f * U() - 1.f;
+            a.solver_active[e] = 1; a.hold_ctrl[e] = 0;
+          } else started = 1;
+        } else if (st == 2) {                                          // -> zero action while everything settles
+          st = 3; lf = a.settle_steps;
+          for (int d = 0; d < AD; d++) a.scripted[(size_t)e * AD + d] = 0.f;
+        } else started = 1;
+      }
+    }
+    const float* gy = 0; int gstride = 1;
+    if (started) {                                                     // -> the episode starts: tracker reset, a fresh smoothing filter, the first goal
+      st = 0; lf = 0;
+      a.t[e] = 0; a.steps[e] = 0; a.steps_since_last_goal[e] = 0; a.successes_so_far[e] = 0; a.consecutive[e] = 0; a.ema_t[e] = 0;
+      a.hold[e] = 0; a.hold_ctrl[e] = 0; a.frozen[e] = 0; a.solver_active[e] = 1; a.resetting[e] = 0; a.episode_started[e] = 1;
+      for (int d = 0; d < AD; d++) { a.scripted[(size_t)e * AD + d] = 0.f; a.ema_value[(size_t)e * AD + d] = 0.f; a.action_ema[(size_t)e * AD + d] = 0.f; }
+      gy = a.yaw + (size_t)e * N; gstride = 1;
+    } else if (st == 0 && a.goal_reset[e]) {                           // a live env that reached its goal: ObjectStateGoal.next_goal keeps the goal's yaw
+      regoal = 1;
+      gy = a.goal_rot + (size_t)e * N * 3 + 2; gstride = 3;
+    }
+    if (gy) {
+      k = 100000u;
+      if (!ra_place(a, gy, gstride, a.seed, a.step, (unsigned)e, k, F.gpos)) a.placement_failed[e] += 1;
+      for (int i = 0; i < N; i++) F.gyaw[i] = gy[i * gstride];
+    }
+    // ---- an episode that ended on this step: its recipe begins (the returned observation / reward / done are the terminal ones)
+    if (!started && st == 0 && a.done[e]) {
+      ended = 1;
+      k = 1000u;
+      float* yw = a.yaw + (size_t)e * N;
+      for (int i = 0; i < N; i++) yw[i] = 2.f * RBC_PI * U();
+      if (!ra_place(a, yw, 1, a.seed, a.step, (unsigned)e, k, F.pos)) a.placement_failed[e] += 1;
+      st = 1; lf = a.stabilize_steps > 0 ? a.stabilize_steps : 1;
+      a.hold[e] = 1; a.hold_ctrl[e] = 1; a.frozen[e] = 4; a.solver_active[e] = 0; a.resetting[e] = 1;
+      for (int d = 0; d < AD; d++) a.scripted[(size_t)e * AD + d] = 0.f;
+    }
+    // controller ticks of the NEXT step's main-world launch: two for live envs, one inside the recipe, two on the recipe's last step
+    const int last_stage = a.n_random_initial_steps >= 1 ? 3 : 1;
+    a.nticks[e] = st > 0 ? ((st == last_stage && lf <= 1) ? 2 : 1) : 2;
+    a.stage[e] = st; a.left[e] = lf;
+    a.reobserve[e] = started ? 1 : (regoal ? 3 : 2);
+    a.ended[e] = (unsigned char)ended; a.stabilised[e] = (unsigned char)stabilised;
+    F.started = started; F.ended = ended; F.regoal = regoal;
+  }
+  __syncthreads();
+  // ---- goal rows (goals/object_state.py:381-418): position, orientation (a z rotation, as Euler angles and as a quaternion), qpos_goal = the current qpos with
+  // the objects at their goals; the previous success count is void
+  if (F.started || F.regoal) {
+    if (lane < N) {
+      const float ez = rbc_wrap(F.gyaw[lane]);        // mat2euler of a z rotation, normalised
+      float* g = a.goal + ((size_t)e * N + lane) * 7;
+      g[0] = F.gpos[lane][0]; g[1] = F.gpos[lane][1]; g[2] = F.gpos[lane][2];
+      g[3] = cosf(0.5f * ez); g[4] = 0.f; g[5] = 0.f; g[6] = sinf(0.5f * ez);
+      float* gr = a.goal_rot + ((size_t)e * N + lane) * 3;
+      gr[0] = 0.f; gr[1] = 0.f; gr[2] = ez;
+    }
+    for (int i = lane; i < nq; i += 64) {
+      float v = bt.qpos[(size_t)e * nq + i];
+      for (int o = 0; o < N; o++) {
+        const int d = i - a.obj_qposadr[o];
+        if (d >= 0 && d < 7) { const float ez = rbc_wrap(F.gyaw[o]); v = d < 3 ? F.gpos[o][d] : (d == 3 ? cosf(0.5f * ez) : (d == 6 ? sinf(0.5f * ez) : 0.f)); }
+      }
+      a.qpos_goal[(size_t)e * nq + i] = v;
+    }
+    if (lane == 0) a.prev_valid[e] = 0;
+  }
+  __syncthreads();
+  // ---- what RearrangeEnv._reset writes before anything is simulated: both worlds as freshly made, the arm's start pose, the objects placed
+  if (F.ended) {
+    const float* yw = a.yaw + (size_t)e * N;
+    for (int i = lane; i < nq; i += 64) {
+      float v = m.qpos0[i];
+      for (int j = 0; j < 6; j++) if (i == a.arm_qposadr[j]) v = a.arm_start[j];
+      for (int o = 0; o < N; o++) {
+        const int d = i - a.obj_qposadr[o];
+        if (d >= 0 && d < 7) v = d < 3 ? F.pos[o][d] : (d == 3 ? cosf(0.5f * yw[o]) : (d == 6 ? sinf(0.5f * yw[o]) : 0.f));
+      }
+      bt.qpos[(size_t)e * nq + i] = v;
+    }
+    for (int i = lane; i < m.nv; i += 64) { bt.qvel[(size_t)e * m.nv + i] = 0.f; bt.qacc_warmstart[(size_t)e * m.nv + i] = 0.f; }
+    for (int i = lane; i < m.nu; i += 64) bt.ctrl[(size_t)e * m.nu + i] = i < 6 ? a.arm_start[i] : 0.f;
+    for (int i = lane; i < 3 * m.nu; i += 64) bt.pid[(size_t)e * 3 * m.nu + i] = 0.f;
+    if (lane == 0) { bt.time[e] = 0.f; bt.status[e] = 0; }
+    if (sp) {
+      const RbModelDev& ms = *sp;
+      for (int i = lane; i < ms.nq; i += 64) {
+        float v = ms.qpos0[i];
+        for (int j = 0; j < 6; j++) if (i == a.solver_arm_qposadr[j]) v = a.arm_start[j];
+        sb.qpos[(size_t)e * ms.nq + i] = v;
+      }
+      for (int i = lane; i < ms.nv; i += 64) { sb.qvel[(size_t)e * ms.nv + i] = 0.f; sb.qacc_warmstart[(size_t)e * ms.nv + i] = 0.f; }
+      for (int i = lane; i < ms.nu; i += 64) sb.ctrl[(size_t)e * ms.nu + i] = 0.f;
+      for (int i = lane; i < 3 * ms.nu; i += 64) sb.pid[(size_t)e * 3 * ms.nu + i] = 0.f;
+      if (lane == 0) { sb.time[e] = 0.f; sb.status[e] = 0; }
+      if (ms.neq > 0 && lane < 7) sb.eq_data[(size_t)e * 7 * ms.neq + lane] = lane == 3 ? 1.f : 0.f;      // reset_mocap_welds
+    }
+    if (lane < N) {      // the static observation: bounding box of the yawed object, a random colour
+      const float c = fabsf(cosf(yw[lane])), s_ = fabsf(sinf(yw[lane]));
+      float* so = a.static_obs + ((size_t)e * N + lane) * 7;
+      so[0] = c * a.obj_half[lane][0] + s_ * a.obj_half[lane][1]; so[1] = s_ * a.obj_half[lane][0] + c * a.obj_half[lane][1]; so[2] = a.obj_half[lane][2];
+      for (int q = 0; q < 3; q++) so[3 + q] = (float)(rbp_hash(a.seed, a.step, (unsigned)e, 500u + 3u * lane + q) >> 8) * (1.0f / 16777216.0f);
+      so[6] = 1.f;
+    }
+  }
+}
+
 }  // namespace rgb

@@ -8,6 +8,7 @@
 typedef rg_post_args RgPostArgs;
 typedef rb_post_args RbPostArgs;
 typedef ra_post_args RaPostArgs;
+typedef ra_recipe_args RaRecipeArgs;
 #define RG_NS rgs
 #define RG_MAXCON 24
 #define RG_CPOOL 768
@@ -1493,6 +1494,46 @@ int ra_env_post_step(rb_batch* b, rb_batch* solver, const ra_post_args* args, vo
   emul_launch(b->dev.B, 1024, emul_ra_post_entry, &ea);
 #else
   hipLaunchKernelGGL(rgb::ra_post_step_kernel, dim3(b->dev.B), dim3(64), 0, (hipStream_t)stream, b->model->dev_copy, b->dev, a);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+#ifdef RG_EMUL
+struct EmulRaRecipeArgs { const RbModelDev* m; RbBatchDev bt; const RbModelDev* ms; RbBatchDev sb; RaRecipeArgs a; };
+static void emul_ra_recipe_entry(void* p_) { EmulRaRecipeArgs* p = (EmulRaRecipeArgs*)p_; rgb::ra_recipe_kernel(p->m, p->bt, p->ms, p->sb, p->a); }
+#endif
+int ra_recipe_args_size(void) { return (int)sizeof(ra_recipe_args); }
+int ra_env_recipe_step(rb_batch* b, rb_batch* solver, const ra_recipe_args* args, void* stream) {
+  if (!b || !args) return fail("null argument");
+  const ra_recipe_args& a = *args;
+  const RbModelDev& d = b->model->dev;
+  if (!a.stage || !a.left || !a.yaw || !a.done || !a.goal_reset || !a.hold || !a.hold_ctrl || !a.solver_active || !a.nticks || !a.scripted || !a.frozen || !a.resetting ||
+      !a.episode_started || !a.reobserve || !a.ended || !a.stabilised || !a.placement_failed || !a.t || !a.steps || !a.steps_since_last_goal || !a.successes_so_far ||
+      !a.consecutive || !a.prev_valid || !a.ema_t || !a.ema_value || !a.action_ema || !a.goal || !a.goal_rot || !a.qpos_goal || !a.static_obs)
+    return fail("ra_env_recipe_step: a required array is NULL");
+  if (a.num_objects < 1 || a.num_objects > RA_MAXOBJ) return fail("ra_env_recipe_step: num_objects out of range");
+  if (a.action_dim < 1 || a.action_dim > 16) return fail("ra_env_recipe_step: action_dim out of range");
+  if (d.nu < 6) return fail("ra_env_recipe_step: the model has fewer than the arm's six actuators");
+  for (int k = 0; k < a.num_objects; k++) {
+    if (a.obj_qposadr[k] < 0 || a.obj_qposadr[k] + 7 > d.nq) return fail("ra_env_recipe_step: object joint address out of range");
+    if (!(a.obj_half[k][0] > 0.f) || !(a.obj_half[k][1] > 0.f)) return fail("ra_env_recipe_step: an object's bounding box is empty");
+  }
+  for (int k = 0; k < 6; k++) if (a.arm_qposadr[k] < 0 || a.arm_qposadr[k] >= d.nq) return fail("ra_env_recipe_step: arm joint address out of range");
+  if (!(a.area_size[0] > 0.f) || !(a.area_size[1] > 0.f)) return fail("ra_env_recipe_step: empty placement area");
+  if (a.stabilize_steps < 0 || a.n_random_initial_steps < 0 || a.settle_steps < 0) return fail("ra_env_recipe_step: negative step count");
+  RbBatchDev sb; memset(&sb, 0, sizeof sb);
+  const RbModelDev* ms = nullptr;
+  if (solver) {
+    if (solver->dev.B != b->dev.B || solver->device != b->device) return fail("ra_env_recipe_step: the two batches must have the same size and device");
+    for (int k = 0; k < 6; k++) if (a.solver_arm_qposadr[k] < 0 || a.solver_arm_qposadr[k] >= solver->model->dev.nq) return fail("ra_env_recipe_step: solver arm joint address out of range");
+    sb = solver->dev; ms = solver->model->dev_copy;
+  }
+  DeviceGuard g(b->device);
+#ifdef RG_EMUL
+  EmulRaRecipeArgs ea{b->model->dev_copy, b->dev, ms, sb, a};
+  emul_launch(b->dev.B, 1024, emul_ra_recipe_entry, &ea);
+#else
+  hipLaunchKernelGGL(rgb::ra_recipe_kernel, dim3(b->dev.B), dim3(64), 0, (hipStream_t)stream, b->model->dev_copy, b->dev, ms, sb, a);
   HIPCHK(hipGetLastError());
 #endif
   return 0;

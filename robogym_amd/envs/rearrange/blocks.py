@@ -59,10 +59,12 @@ class BatchedBlockRearrangeEnv:
                  use_goal_distance_reward: bool = True, goal_reward_per_object: float = 1.0, used_table_portion: float = 1.0, lib=None, n_substeps: int = 40,
                  main_model=None, wrappers: bool = False, n_action_bins: int = 11, smooth_alpha: float = 0.3, reward_clip: float = 100.0,
                  pipelined_reset: bool = False, action_spacing: str = "linear", per_env_parameters: bool = True, randomizer_params: Optional[dict] = None,
-                 stabilize_object_damping: float = 1.0e-3, control_mode: str = "tcp+roll+yaw"):
+                 stabilize_object_damping: float = 1.0e-3, control_mode: str = "tcp+roll+yaw", device_reset: bool = False):
         """`per_env_parameters`: every env carries its own copy of the randomisable model fields (`self.sim.params`, LargeModelSimulation(env_params=True)) -- what
         the reference's simulation randomizers and `stabilize_objects` write into `sim.model`.  On by default (measured cost: 0.7 % of the step,
         profiles/r05_ab_rb_env_params.txt); off: the model's own arrays, no randomizers, no damping change while the objects stabilise.
+        `device_reset` (with `pipelined_reset`): the recipe's stage machine, the begin-of-episode state and the placement / goal sampling run in ONE more launch after the
+        env kernel (ra_env_recipe_step, include/rgstep.h) instead of host numpy behind a readback of the done / goal flags: a step call never waits for the GPU.
         `randomizer_params`: name -> parameter of `build_simulation_randomizers` (the reference's ADR-controlled values; all zero by default = identity)."""
         self.B, self.N = int(batch_size), int(num_objects)
         self._L = lib if lib is not None else _native.lib()
@@ -176,6 +178,7 @@ class BatchedBlockRearrangeEnv:
         self._rand_gen = torch.Generator(device=dev); self._rand_gen.manual_seed(int(starting_seed) + 90001)
         if self.per_env_parameters:
             self._param_defaults = {k: self.sim.params[k][0].clone() for k in self.sim.params.keys()}
+            self._param_block_default = self.sim.params.block[0].clone()
         # ---- RearrangeEnv.apply_wrappers (common/base.py:986-996): SmoothActionWrapper(alpha = 0.3) -> ClipRewardWrapper -> DiscretizeActionWrapper, all inside
         # the launches: the solver world's launch maps bin indices to actions and smooths them (rb_tcp_args), the post kernel clips the reward
         self.wrapped = bool(wrappers)
@@ -205,6 +208,35 @@ class BatchedBlockRearrangeEnv:
             for args_ in (t, tw):
                 args_.hold, args_.scripted = self.hold.data_ptr(), self.scripted.data_ptr()
             a.frozen = self.frozen.data_ptr()
+        self.device_reset = bool(device_reset)
+        if self.device_reset:
+            if not self.pipelined:
+                raise ValueError("device_reset needs pipelined_reset=True (the synchronous reset() keeps its host recipe)")
+            self.stage, self.left, self.yaw, self.placement_failed = z(B, dt=torch.int32), z(B, dt=torch.int32), z(B, N), z(B, dt=torch.int32)
+            self.reobserve, self.ended, self.stabilised = torch.full((B,), 2, dtype=torch.uint8, device=dev), z(B, dt=torch.bool), z(B, dt=torch.bool)
+            r = self.recipe = _native.RaRecipeArgs()
+            r.num_objects, r.action_dim = N, AD
+            for name, ten in (("stage", self.stage), ("left", self.left), ("yaw", self.yaw), ("done", self.done), ("goal_reset", self.goal_reset), ("hold", self.hold),
+                              ("hold_ctrl", self.hold_ctrl), ("solver_active", self.solver_active), ("nticks", self.nticks), ("scripted", self.scripted), ("frozen", self.frozen),
+                              ("resetting", self.resetting), ("episode_started", self.episode_started), ("reobserve", self.reobserve), ("ended", self.ended),
+                              ("stabilised", self.stabilised), ("placement_failed", self.placement_failed), ("t", self.t), ("steps", self.steps), ("steps_since_last_goal", self.ssl),
+                              ("successes_so_far", self.successes), ("consecutive", self.consecutive), ("prev_valid", self.prev_valid), ("ema_t", self.ema_t),
+                              ("ema_value", self.ema_value), ("action_ema", self.action_ema), ("goal", self.goal), ("goal_rot", self.goal_rot), ("qpos_goal", self.qpos_goal),
+                              ("static_obs", self.static_obs)):
+                setattr(r, name, P(ten))
+            for i in range(N):
+                r.obj_qposadr[i] = self.obj_q[i]
+                for k in range(3):
+                    r.obj_center[i][k], r.obj_half[i][k] = float(self.obj_center[i, k]), float(self.obj_half[i, k])
+            for k in range(6):
+                r.arm_qposadr[k], r.arm_start[k] = self.arm_q[k], float(TABLETOP_EXPERIMENT_INITIAL_POS[k])
+                r.solver_arm_qposadr[k] = self.solver_arm_q[k] if self.solver_arm_q else 0
+            (off_x, off_y, _), (width, height, _) = self.placement_area()
+            r.area_offset[0], r.area_offset[1], r.area_size[0], r.area_size[1] = float(off_x), float(off_y), float(width), float(height)
+            for k in range(3):
+                r.table_pos[k], r.table_size[k] = float(self.table_pos[k]), float(self.table_size[k])
+            r.stabilize_steps, r.n_random_initial_steps, r.settle_steps = int(stabilize_steps), int(n_random_initial_steps), int(settle_steps)
+            r.seed, r.step = (int(starting_seed) * 2654435761 + 40503) & 0xFFFFFFFF, 0
 
     # ------------------------------------------------------------------ launches
     def _stream(self):
@@ -276,7 +308,9 @@ class BatchedBlockRearrangeEnv:
         self._post()
 
     def _step_finish(self):
-        if self.pipelined:
+        if self.pipelined and self.device_reset:
+            self._advance_recipes_device()
+        elif self.pipelined:
             self._advance_recipes()
         return self.observe(), self.reward, self.done, self.info()
 
@@ -427,6 +461,8 @@ class BatchedBlockRearrangeEnv:
         active = torch.zeros(self.B, dtype=torch.int32, device=dev); active[idx] = 1
         if self.pipelined:       # a synchronous reset ends whatever recipe those envs were in
             self._stage[rows] = 0; self._left[rows] = 0
+            if self.device_reset:
+                self.stage[idx] = 0; self.left[idx] = 0
             self.hold[idx] = 0; self.hold_ctrl[idx] = 0; self.frozen[idx] = 0; self.solver_active[idx] = 1; self.resetting[idx] = False; self.episode_started[idx] = False
             self.nticks[idx] = 2; self._nticks_host = None
         yaw = self._begin_episode_state(rows, idx)
@@ -538,6 +574,28 @@ class BatchedBlockRearrangeEnv:
         if not np.array_equal(want, getattr(self, "_nticks_host", None)):
             self._nticks_host = want
             self.nticks.copy_(torch.as_tensor(want, device=dev))
+
+    def _advance_recipes_device(self):
+        """`_advance_recipes` without the host: the recipe kernel (stage machine, begin-of-episode state, placement and goal sampling), tensor ops on its masks for the
+        per-env parameter rows (the block restored for an episode that ended = `_recreate_sim`'s fresh model; stabilize_objects' damping change; the simulation randomizers
+        for the envs whose episode starts), and the env kernel once more over the `reobserve` codes (first observation of a new episode / the new goal's entries)."""
+        r = self.recipe
+        r.step = (int(r.step) + 1) & 0xFFFFFFFF
+        _native.check(self._L, self._L.ra_env_recipe_step(self.sim._bh, None if self.solver_sim is None else self.solver_sim._bh, ctypes.byref(r), self._stream()), "ra_env_recipe_step")
+        if self.per_env_parameters:
+            P = self.sim.params
+            P.block.copy_(torch.where(self.ended[:, None], self._param_block_default[None, :], P.block))
+            d, cols = P["dof_damping"], self.obj_dofs
+            cur = d[:, cols]
+            d[:, cols] = torch.where(self.ended[:, None], torch.full_like(cur, self.stabilize_object_damping),
+                                     torch.where(self.stabilised[:, None], self._param_defaults["dof_damping"][cols][None, :].expand_as(cur), cur))
+            for rz in self.randomizers:
+                rz.randomize(self.sim, self._rand_gen, self.episode_started)
+        had = self.post.frozen
+        self.post.frozen = self.reobserve.data_ptr()
+        self._post()
+        self.post.frozen = had
+        self.ended_rows = np.zeros(0, dtype=np.int64)
 
     def _set_object_damping(self, idx, value):
         """RearrangeSimulationInterface.set_object_damping for the envs `idx` (simulation/base.py:753-770): `value` on the objects' six dofs, None = the model's own."""

@@ -45,6 +45,8 @@ class GroupedYcbRearrangeEnv:
         import torch
 
         K = len(object_sets)
+        if kw.get("device_reset") and resample_object_sets:
+            raise NotImplementedError("device_reset with resample_object_sets: trading slots between the groups reads the ended episodes on the host")
         assert batch_size % K == 0, "batch_size must be a multiple of the number of object sets"
         self.B, self.K, self.b = int(batch_size), K, int(batch_size) // K
         self.object_sets = tuple(int(k) for k in object_sets)

@@ -194,8 +194,11 @@ class LargeEnvParams:
                         actuator_ctrlrange=(-1, 2), geom_pos=(-1, 3), geom_friction=(-1, 3), geom_solref=(-1, 2), geom_solimp=(-1, 5), tendon_range=(-1, 2))
         self._views: Dict[str, torch.Tensor] = {}
         B = sim.batch_size
+        lo = min(int(buf[2 + 2 * k]) for k in range(len(_native.RB_PRM_NAMES)))
+        self.block = rows[:, lo:lo + int(buf[1])]        # every field of an env's block as one [B, words] view (a masked restore of the whole block is one tensor op)
         for k, name in enumerate(_native.RB_PRM_NAMES):
             off, length = int(buf[2 + 2 * k]), int(buf[3 + 2 * k])
+            assert lo <= off and off + length <= lo + int(buf[1])
             v = rows[:, off:off + length]
             self._views[name] = v.unflatten(1, shape_of[name]) if (name in shape_of and length) else v
 

@@ -268,22 +268,22 @@ def test_exponential_action_bins_reach_the_launch_emul(emul_lib):
 
 
 # ------------------------------------------------------------------------------------------------ pipelined resets
-def _pipelined_reset_sequence(lib, device, n_substeps, B):
+def _pipelined_reset_sequence(lib, device, n_substeps, B, **extra):
     """Episodes that end (goal time-out after 5 steps here) restart INSIDE the following step calls: recipe stages of 2 + 1 + 2 steps (stabilise, one random
     action, settle), during which the env reports `resetting`, zero reward and done = False, then `episode_started` with fresh counters, objects placed on the
     table, a new goal and an observation row that already carries it."""
     kw = dict(lib=lib) if lib is not None else {}
     env = BatchedBlockRearrangeEnv(B, device=device, n_substeps=n_substeps, stabilize_steps=2, n_random_initial_steps=1, settle_steps=2, max_timesteps_per_goal_per_obj=1,
-                                   pipelined_reset=True, starting_seed=11, **kw)
+                                   pipelined_reset=True, starting_seed=11, **kw, **extra)
     env.reset()
     goal0 = env.goal.clone()
-    act = lambda: torch.zeros((B, 6), dtype=torch.float32, device=env.device)
+    act = lambda: torch.zeros((B, env.action_dim), dtype=torch.float32, device=env.device)
     seen = []
     for k in range(1, 12):
         obs, rew, done, info = env.step(act())
         env.sync()
         seen.append((bool(done.all()), bool(info["resetting"].all()), bool(info["episode_started"].all()), float(rew.abs().max())))
-        assert int(env.sim.status.max()) == 0 and int(env.solver_sim.status.max()) == 0 and bool(torch.isfinite(env.packed).all())
+        assert int(env.sim.status.max()) == 0 and (env.solver_sim is None or int(env.solver_sim.status.max()) == 0) and bool(torch.isfinite(env.packed).all())
         if k == 5:
             assert bool(done.all()) and bool(info["resetting"].all())                      # the time-out step: terminal observation, recipe scheduled
             z = obs["obj_pos"][..., 2]                                                     # (the observation is still the old episode's)
@@ -306,9 +306,101 @@ def test_rearrange_pipelined_reset_sequence_emul(emul_lib):
     _pipelined_reset_sequence(emul_lib, "cpu", n_substeps=1, B=2)
 
 
+def _device_recipe_checks(env):
+    """After `_pipelined_reset_sequence(device_reset=True)`: nothing of the recipe lives on the host, no placement ran out of trials, the per-env parameter rows are back
+    at the model's values (stabilize_objects' damping restored, zero-parameter randomizers)."""
+    assert env.device_reset and int(env.placement_failed.max()) == 0 and int(env.stage.max()) == 0
+    if env.per_env_parameters:
+        d = env.sim.params["dof_damping"]
+        assert torch.equal(d[:, env.obj_dofs], env._param_defaults["dof_damping"][env.obj_dofs][None, :].expand(env.B, -1))
+
+
+def test_rearrange_device_reset_sequence_emul(emul_lib):
+    """the same protocol with the recipe's stage machine, begin-of-episode state and placement / goal sampling in ra_recipe_kernel (no flag readback)"""
+    _device_recipe_checks(_pipelined_reset_sequence(emul_lib, "cpu", n_substeps=1, B=2, device_reset=True))
+    _device_recipe_checks(_pipelined_reset_sequence(emul_lib, "cpu", n_substeps=1, B=2, device_reset=True, control_mode="joint"))
+
+
+def _device_placement_statistics(lib, device, B, rounds):
+    """ra_recipe_kernel's `place_objects_in_grid` (common/utils.py:719-829) on its own: every env is told its episode ended, `rounds` times.  Each placement: the
+    blocks' yawed bounding boxes inside the placement area and pairwise disjoint (distinct grid cells), resting on the table, the start pose everywhere else, a fresh
+    goal drawn the same way when the episode starts; over all draws the cell of object 0 is uniform over the grid (chi-square against the uniform law)."""
+    kw = dict(lib=lib) if lib is not None else {}
+    env = BatchedBlockRearrangeEnv(B, device=device, n_substeps=1, stabilize_steps=0, n_random_initial_steps=0, settle_steps=0, pipelined_reset=True, device_reset=True,
+                                   starting_seed=5, **kw)
+    (off_x, off_y, _), (width, height, _) = env.placement_area()
+    lo = np.array([off_x, off_y]) - env.table_size[:2] + env.table_pos[:2]
+    half0 = env.obj_half[:, :2]
+    cells = []
+    qpos0 = torch.tensor(env.model.arrays["qpos0"].astype(np.float32), device=env.device)
+    for _ in range(rounds):
+        env.stage.zero_(); env.done.fill_(True); env.goal_reset.fill_(False)
+        env._advance_recipes_device()
+        env.sync()
+        assert bool(env.ended.all()) and bool(env.resetting.all()) and int(env.stage.min()) == 1 and int(env.placement_failed.max()) == 0
+        q = env.sim.qpos.cpu().numpy().astype(np.float64)
+        yaw = env.yaw.cpu().numpy().astype(np.float64)
+        assert yaw.min() >= 0 and yaw.max() <= 2 * np.pi + 1e-5
+        half = env._aabb_half(yaw)[..., :2]
+        xy = np.stack([q[:, qa:qa + 2] for qa in env.obj_q], 1)                          # (blocks: the body origin is the box centre)
+        quat = np.stack([q[:, qa + 3:qa + 7] for qa in env.obj_q], 1)
+        assert np.abs(quat[..., 0] - np.cos(yaw / 2)).max() < 1e-6 and np.abs(quat[..., 3] - np.sin(yaw / 2)).max() < 1e-6 and np.abs(quat[..., 1:3]).max() == 0
+        assert np.all(xy - half >= lo - 1e-5) and np.all(xy + half <= lo + [width, height] + 1e-5)
+        z = np.stack([q[:, qa + 2] for qa in env.obj_q], 1)
+        assert np.abs(z - (env.table_height + 0.0254)).max() < 1e-5
+        for i in range(env.N):
+            for j in range(i + 1, env.N):
+                apart = np.abs(xy[:, i] - xy[:, j]) >= half[:, i] + half[:, j] - 1e-6
+                assert apart.any(-1).all()
+        assert np.abs(q[:, env.arm_q] - np.asarray(__import__("robogym_amd.envs.rearrange.blocks", fromlist=["x"]).TABLETOP_EXPERIMENT_INITIAL_POS)).max() < 1e-6
+        assert float(env.sim.qvel.abs().max()) == 0 and float(env.sim.time.abs().max()) == 0
+        so = env.static_obs.cpu().numpy()
+        assert np.abs(so[..., :2] - half).max() < 1e-6 and so[..., 3:6].min() >= 0 and so[..., 3:6].max() < 1 and np.all(so[..., 6] == 1)
+        ncol, nrow = (width // (2 * half[..., 0].max(1))).astype(int), (height // (2 * half[..., 1].max(1))).astype(int)
+        col = np.floor((xy[:, 0, 0] - half[:, 0, 0] - lo[0]) / (width / ncol) + 0.5).astype(int); row = np.floor((xy[:, 0, 1] - half[:, 0, 1] - lo[1]) / (height / nrow) + 0.5).astype(int)
+        assert col.min() >= 0 and (col < ncol).all() and row.min() >= 0 and (row < nrow).all()
+        cells.append(np.stack([col / ncol, row / nrow], -1))                             # (grids differ with the yaw draw: compare the cell's relative position)
+        # the episode starts on the next call (all three stage lengths are zero): first goal = another placement with the same yaw
+        env.done.fill_(False)
+        env._advance_recipes_device()
+        env.sync()
+        assert bool(env.episode_started.all()) and int(env.stage.max()) == 0 and int(env.prev_valid.max()) == 1     # (re-observed: the first step's reward has its reference)
+        g = env.goal.cpu().numpy().astype(np.float64)
+        assert np.all(g[..., :2] - half >= lo - 1e-5) and np.all(g[..., :2] + half <= lo + [width, height] + 1e-5) and np.abs(g[..., :2] - xy).max() > 1e-3
+        ez = np.mod(yaw + np.pi, 2 * np.pi) - np.pi
+        assert np.abs(env.goal_rot[..., 2].cpu().numpy() - ez).max() < 1e-5 and np.abs(np.abs(g[..., 3]) - np.abs(np.cos(ez / 2))).max() < 1e-5
+        qg = env.qpos_goal.cpu().numpy()
+        assert np.abs(qg[:, env.obj_q[1]:env.obj_q[1] + 7] - g[:, 1]).max() < 1e-6 and np.abs(qg[:, env.arm_q] - q[:, env.arm_q]).max() < 1e-6
+    c = np.concatenate(cells)
+    # uniformity of object 0's cell: quadrants of the placement area equally likely (4 bins, chi-square with 3 dof: 16.3 = p 0.001)
+    quad = (c[:, 0] >= 0.5).astype(int) * 2 + (c[:, 1] >= 0.5).astype(int)
+    counts = np.bincount(quad, minlength=4)
+    return env, counts
+
+
+def test_device_placement_is_valid_emul(emul_lib):
+    env, counts = _device_placement_statistics(emul_lib, "cpu", B=64, rounds=2)
+    assert counts.sum() == 128 and counts.min() > 0
+
+
+@pytest.mark.gpu
+def test_device_placement_is_valid_and_uniform_gpu():
+    env, counts = _device_placement_statistics(None, "cuda:0", B=4096, rounds=4)
+    n = counts.sum()
+    # (grids with an odd number of columns / rows put the middle column on the upper side of the split: compare with the expectation of the observed grids instead
+    # of 1/4 each -- loosely: every quadrant between 15 % and 35 %)
+    assert n == 4 * 4096 and counts.min() > 0.15 * n and counts.max() < 0.35 * n, counts
+
+
 @pytest.mark.gpu
 def test_rearrange_pipelined_reset_sequence_gpu():
     _pipelined_reset_sequence(None, "cuda:0", n_substeps=40, B=64)
+
+
+@pytest.mark.gpu
+def test_rearrange_device_reset_sequence_gpu():
+    _device_recipe_checks(_pipelined_reset_sequence(None, "cuda:0", n_substeps=40, B=64, device_reset=True))
+    _device_recipe_checks(_pipelined_reset_sequence(None, "cuda:0", n_substeps=40, B=64, device_reset=True, control_mode="joint"))
 
 
 def _joint_control_wrapped_pipelined(lib, device, n_substeps, B):
