@@ -360,6 +360,10 @@ typedef struct rb_tcp_args {
   /* scripted actions (pipelined resets: the recipe's random-action and settle steps, RearrangeEnv._randomize_robot_initial_position, common/base.py:498-510):
    * hold[B] != 0 -> that env takes scripted[B][6] (continuous, unwrapped) instead of its action, its smoothing filter is left alone; NULL = not used */
   const int* hold; const float* scripted;
+  /* control_mode tcp+wrist (robot_interface.py:9-20; FreeWristTcpArm, robot/ur16e/mujoco/free_dof_tcp_arm.py:238-246): the roll number (index 3 of the six) is ignored
+   * = 0, and the commanded TCP orientation is rotated back onto the vertical before the difference goes to the mocap body (MocapSolver.align_axis with ALIGN_AXIS =
+   * PITCH, robot/control/tcp/mocap_solver.py:41-74).  0: tcp+roll+yaw (FreeRollYawTcpArm) */
+  int wrist_only;
 } rb_tcp_args;
 int rb_batch_step_tcp(rb_batch* solver, rb_batch* main, const float* action_dev, const int* active_dev /* [B] or NULL */, const rb_tcp_args* args, int nsubsteps, int flags, void* stream);
 /* ---- the env-level half of RearrangeEnv.step (one launch after the two physics launches; robogym_amd/csrc/ra_env_kernel.h lists the

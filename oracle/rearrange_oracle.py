@@ -232,10 +232,34 @@ def tcp_quat_control(arm_control, wrist_qpos, wrist_lo, wrist_hi, gripper_quat):
     (MocapSolver.JOINT_MAPPING, control/tcp/mocap_solver.py:17-19) and kept inside that joint's range less JOINT_DRIFT_THRESHOLD; `get_tcp_quat`
     (mocap_solver.py:33-49, no alignment axis for the roll + yaw arm): dof dims ROLL -> euler[0], PITCH -> euler[2]."""
     pos, angle = np.asarray(arm_control[:3], dtype=float), np.asarray(arm_control[3:], dtype=float).copy()
+    gq = np.asarray(gripper_quat, dtype=float)
+    if len(angle) == 1:
+        # control_mode tcp+wrist, FreeWristTcpArm (free_dof_tcp_arm.py:238-246): DOF_DIMS = [PITCH] -> euler[2], ALIGN_AXIS = PITCH: the commanded orientation is put
+        # back onto the vertical before the difference is taken (MocapSolver.get_tcp_quat :41-48, align_axis :58-74)
+        angle[0] = np.clip(angle[0], wrist_lo + JOINT_DRIFT_THRESHOLD - wrist_qpos, wrist_hi - JOINT_DRIFT_THRESHOLD - wrist_qpos)
+        return pos, align_axis(quat_mul(gq, euler2quat(np.array([0.0, 0.0, angle[0]]))), 2) - gq
     angle[1] = np.clip(angle[1], wrist_lo + JOINT_DRIFT_THRESHOLD - wrist_qpos, wrist_hi - JOINT_DRIFT_THRESHOLD - wrist_qpos)
     euler = np.zeros(3); euler[0], euler[2] = angle[0], angle[1]
-    gq = np.asarray(gripper_quat, dtype=float)
     return pos, quat_mul(gq, euler2quat(euler)) - gq
+
+
+def vectors2quat(v_from, v_to):
+    """rotation.vectors2quat (utils/rotation.py:469-486): the rotation along the shortest arc from v_from to v_to (the antiparallel case, :478-484, cannot occur for
+    align_axis: its two vectors have a positive dot product)"""
+    q = np.zeros(4)
+    q[0] = np.sqrt(np.dot(v_from, v_from) * np.dot(v_to, v_to)) + np.dot(v_from, v_to)
+    q[1:] = np.cross(v_from, v_to)
+    assert np.linalg.norm(q) >= 1e-6
+    return quat_normalize(q / np.linalg.norm(q))
+
+
+def align_axis(cmd_quat, axis):
+    """MocapSolver.align_axis (robot/control/tcp/mocap_solver.py:58-74): of the commanded frame's three axes the one closest to world axis `axis` is rotated onto it"""
+    alignment = np.zeros(3); alignment[axis] = 1
+    mtx = quat2mat(cmd_quat)
+    k = int(np.abs(alignment @ mtx).argmax())
+    ax = mtx[:, k] * np.sign(mtx[:, k] @ alignment)
+    return quat_mul(vectors2quat(ax, alignment), cmd_quat)
 
 
 class OracleRearrangeEnv:
@@ -245,9 +269,10 @@ class OracleRearrangeEnv:
     robot/ur16e/mujoco/joint_controlled_arm.py:89-200), no TCP solver world (RobotControlParameters.requires_solver_sim, robot_interface.py:83-91); 7 action numbers."""
 
     def __init__(self, main_model, solver_model, num_objects, n_substeps=40, max_position_change=0.1, arm_reset_controller_error=True,
-                 success_threshold=None, goal_reward_per_object=1.0, penalty=None):
+                 success_threshold=None, goal_reward_per_object=1.0, penalty=None, wrist_only=False):
         self.main, self.solver = OracleArmSim(main_model, n_substeps), (None if solver_model is None else OracleArmSim(solver_model, n_substeps))
         self.joint_control = solver_model is None
+        self.wrist_only = bool(wrist_only)      # control_mode tcp+wrist: FreeWristTcpArm as the solver world's controller, 4 + 1 action numbers
         self.num_objects = num_objects
         self.mpc, self.reset_controller_error = max_position_change, arm_reset_controller_error
         self.success_threshold = dict(success_threshold or {"obj_pos": 0.04, "obj_rot": 0.2})
@@ -314,6 +339,10 @@ class OracleRearrangeEnv:
             arm = np.clip(m.sim.qpos[m.arm_q] + a[:6] * rng, lo, hi)
             glo, ghi = A["actuator_ctrlrange"][m.grip_act]
             return arm, np.clip(m.sim.ctrl[m.grip_act] + a[6] * 0.5 * (ghi - glo), glo, ghi)
+        if self.wrist_only:
+            arm = np.concatenate([a[:3] * self.mpc, a[3:4] * SPEED_PITCH * self.mpc])
+            lo, hi = self.main.model.arrays["actuator_ctrlrange"][self.main.grip_act]
+            return arm, np.clip(self.main.sim.ctrl[self.main.grip_act] + a[4] * 0.5 * (hi - lo), lo, hi)
         arm = np.concatenate([a[:3] * self.mpc, a[3:5] * np.array([SPEED_ROLL, SPEED_PITCH]) * self.mpc])
         A = self.main.model.arrays
         lo, hi = A["actuator_ctrlrange"][self.main.grip_act]

@@ -74,7 +74,7 @@ class RbTcpArgs(ctypes.Structure):
                 ("wrist_joint", ctypes.c_int), ("reset_controller_error", ctypes.c_int), ("max_position_change", ctypes.c_float), ("speed_roll", ctypes.c_float),
                 ("speed_pitch", ctypes.c_float), ("joint_drift_threshold", ctypes.c_float), ("gripper_ctrl_lo", ctypes.c_float), ("gripper_ctrl_hi", ctypes.c_float),
                 ("action_index", ctypes.c_void_p), ("bins", ctypes.c_void_p), ("nbins", ctypes.c_int), ("ema_alpha", ctypes.c_float),
-                ("ema_value", ctypes.c_void_p), ("ema_t", ctypes.c_void_p), ("action_out", ctypes.c_void_p), ("hold", ctypes.c_void_p), ("scripted", ctypes.c_void_p)]
+                ("ema_value", ctypes.c_void_p), ("ema_t", ctypes.c_void_p), ("action_out", ctypes.c_void_p), ("hold", ctypes.c_void_p), ("scripted", ctypes.c_void_p), ("wrist_only", ctypes.c_int)]
 
 
 RA_MAXOBJ = 16

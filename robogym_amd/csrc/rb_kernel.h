@@ -2581,7 +2581,7 @@ __global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbMod
       const float* a = s.prow;
       const float mpc = L.tcp.max_position_change;
       const float a0 = clampf(a[0], -1.f, 1.f), a1 = clampf(a[1], -1.f, 1.f), a2 = clampf(a[2], -1.f, 1.f), a3 = clampf(a[3], -1.f, 1.f), a4 = clampf(a[4], -1.f, 1.f);
-      const float roll = a3 * L.tcp.speed[0] * mpc;
+      const float roll = L.tcp.wrist_only ? 0.f : a3 * L.tcp.speed[0] * mpc;
       const float q6 = s.qpos[L.tcp.arm_q[5]], lo = PRM(jnt_range, RB_P_JNT_RANGE)[2 * L.tcp.wrist_jnt], hi = PRM(jnt_range, RB_P_JNT_RANGE)[2 * L.tcp.wrist_jnt + 1];
       const float pitch = clampf(a4 * L.tcp.speed[1] * mpc, lo + L.tcp.drift_threshold - q6, hi - L.tcp.drift_threshold - q6);   // FreeDOFTcpArm.constrain_quat_ctrl
       // MocapSolver.get_tcp_quat: euler = (roll, 0, pitch dimension) -> qx(roll) * qz(.), applied on the right of the TCP's orientation; mocap_set_action
@@ -2589,7 +2589,22 @@ __global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbMod
       const float cr = cosf(0.5f * roll), sr = sinf(0.5f * roll), cp = cosf(0.5f * pitch), sp = sinf(0.5f * pitch);
       q4 eq; eq.w = cr * cp; eq.x = sr * cp; eq.y = -sr * sp; eq.z = cr * sp;
       const q4 gq = ldq(SC(XQUAT) + 4 * L.tcp.tcp_body);
-      const q4 tq = qmul(gq, eq);
+      q4 tq = qmul(gq, eq);
+      if (L.tcp.wrist_only) {
+        // MocapSolver.align_axis(cmd, PITCH = world z) (mocap_solver.py:58-74): of the commanded frame's axes the one closest to z (by |dot|), made to point up,
+        // is rotated onto z along the shortest arc (rotation.vectors2quat; its antiparallel branch cannot occur: the dot product is >= 1 / sqrt 3)
+        float R[9]; q2mat(R, tq);
+        int k = 0; if (fabsf(R[7]) > fabsf(R[6 + k])) k = 1; if (fabsf(R[8]) > fabsf(R[6 + k])) k = 2;      // argmax |row 2| (first maximum, as numpy)
+        const float sg = R[6 + k] > 0.f ? 1.f : (R[6 + k] < 0.f ? -1.f : 0.f);
+        const float ax = sg * R[k], ay = sg * R[3 + k], az = sg * R[6 + k];
+        // vectors2quat(axis, ez): w = |axis| |ez| + axis . ez, xyz = axis x ez = (ay, -ax, 0)
+        float w = sqrtf(ax * ax + ay * ay + az * az) + az, x = ay, y = -ax;
+        const float n = sqrtf(w * w + x * x + y * y);
+        w /= n; x /= n; y /= n;
+        if (w < 0.f) { w = -w; x = -x; y = -y; }       // quat_normalize
+        q4 d; d.w = w; d.x = x; d.y = y; d.z = 0.f;
+        tq = qmul(d, tq);
+      }
       const v3 tp = ld3(SC(XPOS) + 3 * L.tcp.tcp_body);
       s.mocap[0] = tp.x + a0 * mpc; s.mocap[1] = tp.y + a1 * mpc; s.mocap[2] = tp.z + a2 * mpc;
       s.mocap[3] = gq.w + (tq.w - gq.w); s.mocap[4] = gq.x + (tq.x - gq.x); s.mocap[5] = gq.y + (tq.y - gq.y); s.mocap[6] = gq.z + (tq.z - gq.z);

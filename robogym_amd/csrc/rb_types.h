@@ -176,5 +176,6 @@ struct RbTcpHook {
   float* ema_value; int* ema_t;      // IncrementalExpAvg state [B][6], [B]; null: no smoothing
   float* action_out;                 // [B][6] the action that reached the env (= obs["action_ema"]); may be null
   const int* hold; const float* scripted;   // [B], [B][6]: envs inside their reset recipe take a scripted continuous action (and leave the filter alone); may be null
+  int wrist_only;                    // control_mode tcp+wrist: no roll, the commanded orientation aligned with the vertical (MocapSolver.align_axis)
 };
 struct RbLaunch { RbEnvDev env; RbBatchDev bt; int nsubsteps, nforward_ticks, flags; RbTcpHook tcp; };

@@ -1389,6 +1389,7 @@ int rb_batch_step_tcp(rb_batch* solver, rb_batch* main_batch, const float* actio
   h.max_position_change = a->max_position_change; h.speed[0] = a->speed_roll; h.speed[1] = a->speed_pitch; h.drift_threshold = a->joint_drift_threshold;
   h.grip_lo = a->gripper_ctrl_lo; h.grip_hi = a->gripper_ctrl_hi;
   h.action_index = a->action_index; h.bins = a->bins; h.nbins = a->nbins; h.ema_alpha = a->ema_alpha; h.ema_value = a->ema_value; h.ema_t = a->ema_t; h.action_out = a->action_out; h.hold = a->hold; h.scripted = a->scripted;
+  h.wrist_only = a->wrist_only != 0;
   g_tcp_hook = &h;
   const int rc = rb_batch_step_ex(solver, nullptr, active_dev, nullptr, nullptr, nsubsteps, 0, flags, stream);
   g_tcp_hook = nullptr;

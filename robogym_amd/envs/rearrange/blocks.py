@@ -21,7 +21,10 @@ parameters at the default `object_scale_low/high = 0`, material `default`.
 solver world; `step(actions[B, 7])`, the action map (six arm joints relative to their positions, capped by max_position_change; the gripper relative to its control)
 runs at the head of the main world's launch (rb_batch_set_action_limits) -- TWO launches per step.
 
-Not built for this env: vision, `teleport_to_goal`, masks of the placement area, duplicated-object groups, control_mode tcp+wrist, tcp_solver_mode mocap.
+`control_mode = "tcp+wrist"` (FreeWristTcpArm, free_dof_tcp_arm.py:238-246): `step(actions[B, 5])` = xyz, wrist, gripper; the solver world's launch ignores the roll number
+and aligns the commanded orientation with the vertical (rb_tcp_args.wrist_only).
+
+Not built for this env: vision, `teleport_to_goal`, masks of the placement area, duplicated-object groups, tcp_solver_mode mocap.
 """
 import ctypes
 from typing import Optional
@@ -70,7 +73,11 @@ class BatchedBlockRearrangeEnv:
         self._L = lib if lib is not None else _native.lib()
         self.control_mode = _control_mode_name(control_mode)
         self.joint_control = self.control_mode == "joint"      # ControlMode.JOINT: no TCP solver world (RobotControlParameters.requires_solver_sim, robot_interface.py:83-91)
-        AD = self.action_dim = 7 if self.joint_control else 6
+        self.wrist_only = self.control_mode == "tcp+wrist"      # ControlMode.TCP_WRIST: FreeWristTcpArm in the solver world, 4 arm numbers + the gripper's
+        AD = 7 if self.joint_control else 6                     # the launches' action width (tcp+wrist: the six of tcp+roll+yaw with the roll number ignored)
+        self.action_dim = 5 if self.wrist_only else AD          # the env's action width
+        self.launch_action_dim = AD
+        self._ext_cols = torch.tensor([0, 1, 2, 4, 5]) if self.wrist_only else None
         self.max_position_change = float(max_position_change)
         main = main_model if main_model is not None else load_blocks_model(self.N)   # (main_model: the same world with other objects, envs/rearrange/ycb.py)
         solver = None if self.joint_control else load_solver_model()
@@ -115,6 +122,7 @@ class BatchedBlockRearrangeEnv:
                 t.arm_qposadr[k] = int(As["jnt_qposadr"][sj.index("robot0:J%d" % (k + 1))]); t.main_arm_qposadr[k] = self.arm_q[k]
             t.main_gripper_actuator = self.grip_act; t.tcp_body = solver.name2id("body", "robot0:gripper_tcp"); t.wrist_joint = sj.index("robot0:J6")
             t.reset_controller_error = 1 if arm_reset_controller_error else 0
+            t.wrist_only = 1 if self.wrist_only else 0
             t.max_position_change = max_position_change; t.speed_roll = SPEED_ROLL; t.speed_pitch = SPEED_PITCH; t.joint_drift_threshold = JOINT_DRIFT_THRESHOLD
             t.gripper_ctrl_lo, t.gripper_ctrl_hi = float(A["actuator_ctrlrange"][self.grip_act, 0]), float(A["actuator_ctrlrange"][self.grip_act, 1])
             self.solver_arm_q = [int(t.arm_qposadr[k]) for k in range(6)]
@@ -169,7 +177,7 @@ class BatchedBlockRearrangeEnv:
         a.safety_stop_force = 150.0                                      # robot/ur16e/arm_interface.py:46
         a.max_timesteps_per_goal, a.successes_needed, a.use_goal_distance_reward = max_timesteps_per_goal_per_obj * N, successes_needed, int(use_goal_distance_reward)
         a.solver_grip_qposadr, a.solver_grip_act = self.solver_grip_q, self.solver_grip_act
-        self.action_shape = (self.B, AD)
+        self.action_shape = (self.B, self.action_dim)
         self._zero_action = z(B, AD)
         # ---- per-env model parameters: the reference's simulation randomizers (applied after _reset, robot_env.py:779-783) and stabilize_objects' damping change
         self.stabilize_object_damping = float(stabilize_object_damping)
@@ -298,6 +306,8 @@ class BatchedBlockRearrangeEnv:
     def _step_launch(self, actions):
         """The step's three launches, nothing that waits for them (envs/rearrange/ycb.py GroupedYcbRearrangeEnv enqueues several groups before it finishes any)."""
         assert actions.shape == self.action_shape and actions.device == self.device
+        if self.wrist_only:      # [x, y, z, wrist, gripper] -> the launch's six columns (the roll column is ignored by the hook)
+            actions = torch.cat([actions[:, :3], torch.zeros_like(actions[:, :1]), actions[:, 3:]], 1)
         sa = self.solver_active if self.pipelined else None
         if self.wrapped:
             assert not actions.dtype.is_floating_point, "the wrapped env takes MultiDiscrete actions (bin indices)"
@@ -335,7 +345,8 @@ class BatchedBlockRearrangeEnv:
             o += n
         assert o == self.obs_dim
         if self.wrapped:
-            out["action_ema"] = self.action_ema if action_ema is None else action_ema      # SmoothActionWrapper's observation: the smoothed action of the last step (zeros after reset)
+            ema = self.action_ema if action_ema is None else action_ema
+            out["action_ema"] = ema[:, self._ext_cols.to(ema.device)] if self.wrist_only else ema      # SmoothActionWrapper's observation: the smoothed action of the last step (zeros after reset)
         return out
 
     # ------------------------------------------------------------------ reset (host work + physics launches)
@@ -474,8 +485,8 @@ class BatchedBlockRearrangeEnv:
         self._set_object_damping(idx, None)
         # _randomize_robot_initial_position (common/base.py:498-510)
         if self.n_random_initial_steps >= 1:
-            act = torch.zeros(self.B, self.action_dim, device=dev)
-            act[idx] = torch.tensor(self._rng.uniform(-1, 1, (len(rows), self.action_dim)).astype(np.float32), device=dev)
+            act = torch.zeros(self.B, self.launch_action_dim, device=dev)
+            act[idx] = torch.tensor(self._rng.uniform(-1, 1, (len(rows), self.launch_action_dim)).astype(np.float32), device=dev)
             for _ in range(self.n_random_initial_steps):
                 self._recipe_physics(act, active)
             for _ in range(self.settle_steps):
@@ -531,7 +542,7 @@ class BatchedBlockRearrangeEnv:
                 self._set_object_damping(idx, None)                     # stabilize_objects restores the objects' damping
             if stage == 1 and self.n_random_initial_steps >= 1:         # -> one random action for n_random_initial_steps steps
                 st[rows], left[rows] = 2, self.n_random_initial_steps
-                self.scripted[idx] = torch.tensor(self._rng.uniform(-1, 1, (len(rows), self.action_dim)).astype(np.float32), device=dev)
+                self.scripted[idx] = torch.tensor(self._rng.uniform(-1, 1, (len(rows), self.launch_action_dim)).astype(np.float32), device=dev)
                 self.solver_active[idx] = 1; self.hold_ctrl[idx] = 0
             elif stage == 2:                                            # -> zero action while everything settles
                 st[rows], left[rows] = 3, self.settle_steps
@@ -699,13 +710,15 @@ SUPPORTED_CONSTANTS = {"success_threshold", "successes_needed", "success_reward"
 
 
 def _control_mode_name(mode) -> str:
-    """`ControlMode` value or name (robot_interface.py:9-20) -> "tcp+roll+yaw" | "joint"; tcp+wrist is not built."""
+    """`ControlMode` value or name (robot_interface.py:9-20) -> "tcp+roll+yaw" | "tcp+wrist" | "joint"."""
     name = str(getattr(mode, "value", mode)).lower().split(".")[-1]
     if name in ("tcp+roll+yaw", "tcp_roll_yaw"):
         return "tcp+roll+yaw"
+    if name in ("tcp+wrist", "tcp_wrist"):
+        return "tcp+wrist"
     if name == "joint":
         return "joint"
-    raise NotImplementedError("control_mode %r: tcp+roll+yaw (the reference's default, robot_interface.py:43-47) and joint are implemented" % (mode,))
+    raise ValueError("control_mode %r is not one of the reference's ControlMode values (joint, tcp+roll+yaw, tcp+wrist; robot_interface.py:9-20)" % (mode,))
 
 
 def _check_supported(parameters, sp, rc, constants):

@@ -548,15 +548,17 @@ def test_discretize_action_tables():
 def test_make_env_rejects_what_it_does_not_implement():
     """`make_env(parameters=..., constants=...)` of the batched rearrange envs: a name of the reference's parameter / constant classes that is not implemented raises
     (the reference's attrs classes raise on unknown names; silently ignoring e.g. `success_pause_range_s` would change the task without a word), and so does a
-    control or solver mode other than the default pair."""
+    solver mode other than mocap_ik; a control mode that is none of the reference's three ControlMode values is a ValueError (all three are built)."""
     from robogym_amd.envs.rearrange import blocks as Bk, ycb as Yc
 
     for mk in (Bk.make_env, Yc.make_env):
         for bad in (dict(constants={"success_pause_range_s": (1.0, 1.0)}), dict(parameters={"simulation_params": {"object_groups": []}}),
-                    dict(parameters={"robot_control_params": {"control_mode": "tcp+wrist"}}), dict(parameters={"robot_control_params": {"tcp_solver_mode": "mocap"}}),
-                    dict(parameters={"object_scale_high": 0.5})):
+                    dict(parameters={"robot_control_params": {"tcp_solver_mode": "mocap"}}), dict(parameters={"object_scale_high": 0.5})):
             with pytest.raises(NotImplementedError):
                 mk(batch_size=1, device="cpu", **bad)
+        with pytest.raises(ValueError):
+            mk(batch_size=1, device="cpu", parameters={"robot_control_params": {"control_mode": "tcp+pitch"}})
+    assert [Bk._control_mode_name(x) for x in ("joint", "tcp+roll+yaw", "tcp+wrist", "ControlMode.TCP_WRIST")] == ["joint", "tcp+roll+yaw", "tcp+wrist", "tcp+wrist"]
 
 
 def test_crowded_table_placement_keeps_objects_apart():
@@ -630,6 +632,14 @@ def test_tcp_action_path_matches_reference_code():
         pos, dq = RO.tcp_quat_control(den, g["q"][t][5], lo, hi, g["gripper_quat"][t])
         assert np.abs(pos - g["denorm"][t][:3]).max() == 0 and np.abs(dq - g["dquat"][t]).max() < 1e-14
     assert abs(RO.JOINT_DRIFT_THRESHOLD - np.deg2rad(1)) < 1e-15
+    # control_mode tcp+wrist: FreeWristTcpArm's class attributes through the same source, with MocapSolver.align_axis (tests/golden/rearrange_tcp_wrist.npz)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "rearrange_tcp_wrist.npz"))
+    for t in range(len(g["action"])):
+        a, mpc = g["action"][t], float(g["mpc"][t])
+        den = np.concatenate([a[:3] * mpc, a[3:4] * RO.SPEED_PITCH * mpc])
+        assert np.abs(den - g["denorm"][t]).max() < 1e-15
+        pos, dq = RO.tcp_quat_control(den, g["q"][t][5], lo, hi, g["gripper_quat"][t])
+        assert np.abs(pos - g["denorm"][t][:3]).max() == 0 and np.abs(dq - g["dquat"][t]).max() < 1e-13, (t, dq, g["dquat"][t])
 
 
 def test_observation_keys_and_order_are_the_reference_methods():

@@ -25,4 +25,8 @@ python tools/rearrange_stage_profile.py 4096 > gpurun_out/rearrange_stage_$R.txt
 python tools/rearrange_stage_profile.py 4096 ycb > gpurun_out/ycb_stage_$R.txt 2>&1
 python tools/large_stage_profile.py 512 > gpurun_out/large_stage_$R.txt 2>&1
 bash tools/prof_pmc_rearrange.sh > gpurun_out/pmc_rearrange_$R.txt 2>&1
+# steady state with episode ends, the recipe on the device (ra_recipe_kernel): 2 M env-steps of blocks, 1.2 M of ycb; heterogeneous ycb batches
+python tools/soak_rearrange.py 4096 500 blocks 30 device > gpurun_out/soak_rearrange_$R.txt 2>&1
+python tools/soak_rearrange.py 4096 300 ycb 30 device >> gpurun_out/soak_rearrange_$R.txt 2>&1
+python tools/bench_ycb_sets.py > gpurun_out/ycb_object_sets_$R.txt 2>&1
 du -sh gpurun_out

@@ -54,10 +54,11 @@ def main():
         m_ = ast.Module(body=body, type_ignores=[]); ast.fix_missing_locations(m_)
         exec(compile(m_, path, "exec"), ns)
     exec(extract(ROBOT + "/control/tcp/solver.py", "Solver", {"get_joint_mapping"}), ns)
-    exec(extract(ROBOT + "/control/tcp/mocap_solver.py", "MocapSolver", {"JOINT_MAPPING", "get_tcp_quat"}), ns)
+    exec(extract(ROBOT + "/control/tcp/mocap_solver.py", "MocapSolver", {"JOINT_MAPPING", "get_tcp_quat", "align_axis"}), ns)
     exec(extract(ROBOT + "/ur16e/mujoco/free_dof_tcp_arm.py", "FreeDOFTcpArm", {"JOINT_DRIFT_THRESHOLD", "denormalize_position_control", "constrain_quat_ctrl"}), ns)
     exec(extract(ROBOT + "/ur16e/mujoco/free_dof_tcp_arm.py", "FreeRollYawTcpArm", {"DOF_DIMS"}), ns)
-    PA, Solver, Mocap, Arm, RollYaw = ns["PrincipalAxis"], ns["Solver"], ns["MocapSolver"], ns["FreeDOFTcpArm"], ns["FreeRollYawTcpArm"]
+    exec(extract(ROBOT + "/ur16e/mujoco/free_dof_tcp_arm.py", "FreeWristTcpArm", {"DOF_DIMS", "ALIGN_AXIS"}), ns)
+    PA, Solver, Mocap, Arm, RollYaw, Wrist = ns["PrincipalAxis"], ns["Solver"], ns["MocapSolver"], ns["FreeDOFTcpArm"], ns["FreeRollYawTcpArm"], ns["FreeWristTcpArm"]
 
     sys.path.insert(0, os.path.join(HERE, ".."))
     from robogym_amd.envs.rearrange.xml import load_solver_model
@@ -94,6 +95,38 @@ def main():
     np.savez_compressed(path, wrist_range=np.array([rng_lo[5], rng_hi[5]]), **{k: np.array(v) for k, v in out.items()})
     bind = np.sum(np.abs(np.array(out["angles"])[:, 1] - np.array(out["denorm"])[:, 4]) > 1e-12)
     print("wrote", path, "; the wrist constraint binds in %d of %d samples" % (bind, T))
+
+    # ---- control_mode tcp+wrist: FreeWristTcpArm (DOF_DIMS = [PITCH], ALIGN_AXIS = PITCH; free_dof_tcp_arm.py:238-246) -- 4 arm numbers, the commanded orientation
+    # forced back onto the vertical by MocapSolver.align_axis (mocap_solver.py:58-74)
+    out = {k: [] for k in ("action", "mpc", "q", "gripper_quat", "denorm", "angles", "dquat")}
+    for t in range(T):
+        mpc = [0.1, 0.05, 0.165, 0.03][t % 4]
+        q = rng.uniform(rng_lo, rng_hi)
+        if t % 3 == 0:
+            q[5] = (rng_hi[5] - rng.uniform(0, 0.05)) if t % 2 else (rng_lo[5] + rng.uniform(0, 0.05))
+        if t % 2:      # a gripper pointing (almost) straight down, as the arm holds it, tilted by a few degrees
+            tilt = rng.uniform(-0.15, 0.15, 3)
+            gq = rotation.quat_mul(rotation.euler2quat(np.array([np.pi, 0.0, rng.uniform(-np.pi, np.pi)])), rotation.euler2quat(tilt))
+        else:
+            gq = rng.randn(4); gq /= np.linalg.norm(gq)
+        a = rng.uniform(-1, 1, 4)
+        solver = types.SimpleNamespace(dof_dims=Wrist.DOF_DIMS, dof_dims_axes=[ax.value for ax in Wrist.DOF_DIMS], alignment_axis=Wrist.ALIGN_AXIS, JOINT_MAPPING=Mocap.JOINT_MAPPING,
+                                       body_name="tcp", align_axis=Mocap.align_axis, mj_sim=types.SimpleNamespace(data=types.SimpleNamespace(get_body_xquat=lambda name, gq=gq: gq.copy())))
+        solver.get_joint_mapping = types.MethodType(Solver.get_joint_mapping, solver)
+        solver.get_tcp_quat = types.MethodType(Mocap.get_tcp_quat, solver)
+        arm = types.SimpleNamespace(is_in_joint_control_mode=False, max_position_change=mpc, solver=solver, JOINT_DRIFT_THRESHOLD=Arm.JOINT_DRIFT_THRESHOLD,
+                                    speed_per_dof_dim=[ns["DOF_DIM_SPEED_SCALE"][ax] * mpc for ax in Wrist.DOF_DIMS],
+                                    observe=lambda q=q: types.SimpleNamespace(joint_positions=lambda: q.copy()),
+                                    actuator_ctrl_range_lower_bound=lambda: rng_lo.copy(), actuator_ctrl_range_upper_bound=lambda: rng_hi.copy())
+        den = Arm.denormalize_position_control(arm, a.copy(), relative_action=True)
+        pos, angle = np.split(den, (3,))
+        angle = Arm.constrain_quat_ctrl(arm, angle.copy())
+        dq = solver.get_tcp_quat(angle)
+        for k, v in (("action", a), ("mpc", mpc), ("q", q), ("gripper_quat", gq), ("denorm", den), ("angles", angle), ("dquat", dq)):
+            out[k].append(np.asarray(v, dtype=np.float64))
+    path = os.path.join(HERE, "..", "tests", "golden", "rearrange_tcp_wrist.npz")
+    np.savez_compressed(path, wrist_range=np.array([rng_lo[5], rng_hi[5]]), **{k: np.array(v) for k, v in out.items()})
+    print("wrote", path)
 
 
 if __name__ == "__main__":
