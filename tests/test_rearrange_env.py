@@ -348,13 +348,16 @@ def test_rearrange_device_reset_sequence_emul(emul_lib):
     _device_recipe_checks(_pipelined_reset_sequence(emul_lib, "cpu", n_substeps=1, B=2, device_reset=True, control_mode="joint"))
 
 
-def _device_placement_statistics(lib, device, B, rounds):
+def _device_placement_statistics(lib, device, B, rounds, ycb=False):
     """ra_recipe_kernel's `place_objects_in_grid` (common/utils.py:719-829) on its own: every env is told its episode ended, `rounds` times.  Each placement: the
     blocks' yawed bounding boxes inside the placement area and pairwise disjoint (distinct grid cells), resting on the table, the start pose everywhere else, a fresh
     goal drawn the same way when the episode starts; over all draws the cell of object 0 is uniform over the grid (chi-square against the uniform law)."""
     kw = dict(lib=lib) if lib is not None else {}
-    env = BatchedBlockRearrangeEnv(B, device=device, n_substeps=1, stabilize_steps=0, n_random_initial_steps=0, settle_steps=0, pipelined_reset=True, device_reset=True,
-                                   starting_seed=5, **kw)
+    if ycb:      # 8 mesh objects: the grid has fewer cells than objects -> the kernel's rejection sampling (place_objects_with_no_constraint)
+        from robogym_amd.envs.rearrange.ycb import BatchedYcbRearrangeEnv as cls
+    else:
+        cls = BatchedBlockRearrangeEnv
+    env = cls(B, device=device, n_substeps=1, stabilize_steps=0, n_random_initial_steps=0, settle_steps=0, pipelined_reset=True, device_reset=True, starting_seed=5, **kw)
     (off_x, off_y, _), (width, height, _) = env.placement_area()
     lo = np.array([off_x, off_y]) - env.table_size[:2] + env.table_pos[:2]
     half0 = env.obj_half[:, :2]
@@ -369,12 +372,13 @@ def _device_placement_statistics(lib, device, B, rounds):
         yaw = env.yaw.cpu().numpy().astype(np.float64)
         assert yaw.min() >= 0 and yaw.max() <= 2 * np.pi + 1e-5
         half = env._aabb_half(yaw)[..., :2]
-        xy = np.stack([q[:, qa:qa + 2] for qa in env.obj_q], 1)                          # (blocks: the body origin is the box centre)
+        cen = np.stack([np.cos(yaw) * env.obj_center[:, 0] - np.sin(yaw) * env.obj_center[:, 1], np.sin(yaw) * env.obj_center[:, 0] + np.cos(yaw) * env.obj_center[:, 1]], -1)
+        xy = np.stack([q[:, qa:qa + 2] for qa in env.obj_q], 1) + cen                    # centre of the yawed bounding box (blocks: the body origin itself)
         quat = np.stack([q[:, qa + 3:qa + 7] for qa in env.obj_q], 1)
         assert np.abs(quat[..., 0] - np.cos(yaw / 2)).max() < 1e-6 and np.abs(quat[..., 3] - np.sin(yaw / 2)).max() < 1e-6 and np.abs(quat[..., 1:3]).max() == 0
         assert np.all(xy - half >= lo - 1e-5) and np.all(xy + half <= lo + [width, height] + 1e-5)
         z = np.stack([q[:, qa + 2] for qa in env.obj_q], 1)
-        assert np.abs(z - (env.table_height + 0.0254)).max() < 1e-5
+        assert np.abs(z + env.obj_center[:, 2] - env.obj_half[:, 2] - env.table_height).max() < 1e-5       # the bounding box rests on the table top
         for i in range(env.N):
             for j in range(i + 1, env.N):
                 apart = np.abs(xy[:, i] - xy[:, j]) >= half[:, i] + half[:, j] - 1e-6
@@ -384,8 +388,11 @@ def _device_placement_statistics(lib, device, B, rounds):
         so = env.static_obs.cpu().numpy()
         assert np.abs(so[..., :2] - half).max() < 1e-6 and so[..., 3:6].min() >= 0 and so[..., 3:6].max() < 1 and np.all(so[..., 6] == 1)
         ncol, nrow = (width // (2 * half[..., 0].max(1))).astype(int), (height // (2 * half[..., 1].max(1))).astype(int)
+        if ycb:
+            assert (ncol * nrow < env.N).mean() > 0.5        # (most yaw draws leave fewer cells than objects)
+            ncol, nrow = np.maximum(ncol, 1), np.maximum(nrow, 1)
         col = np.floor((xy[:, 0, 0] - half[:, 0, 0] - lo[0]) / (width / ncol) + 0.5).astype(int); row = np.floor((xy[:, 0, 1] - half[:, 0, 1] - lo[1]) / (height / nrow) + 0.5).astype(int)
-        assert col.min() >= 0 and (col < ncol).all() and row.min() >= 0 and (row < nrow).all()
+        assert ycb or (col.min() >= 0 and (col < ncol).all() and row.min() >= 0 and (row < nrow).all())
         cells.append(np.stack([col / ncol, row / nrow], -1))                             # (grids differ with the yaw draw: compare the cell's relative position)
         # the episode starts on the next call (all three stage lengths are zero): first goal = another placement with the same yaw
         env.done.fill_(False)
@@ -393,7 +400,7 @@ def _device_placement_statistics(lib, device, B, rounds):
         env.sync()
         assert bool(env.episode_started.all()) and int(env.stage.max()) == 0 and int(env.prev_valid.max()) == 1     # (re-observed: the first step's reward has its reference)
         g = env.goal.cpu().numpy().astype(np.float64)
-        assert np.all(g[..., :2] - half >= lo - 1e-5) and np.all(g[..., :2] + half <= lo + [width, height] + 1e-5) and np.abs(g[..., :2] - xy).max() > 1e-3
+        assert np.all(g[..., :2] + cen - half >= lo - 1e-5) and np.all(g[..., :2] + cen + half <= lo + [width, height] + 1e-5) and np.abs(g[..., :2] + cen - xy).max() > 1e-3
         ez = np.mod(yaw + np.pi, 2 * np.pi) - np.pi
         assert np.abs(env.goal_rot[..., 2].cpu().numpy() - ez).max() < 1e-5 and np.abs(np.abs(g[..., 3]) - np.abs(np.cos(ez / 2))).max() < 1e-5
         qg = env.qpos_goal.cpu().numpy()
@@ -408,6 +415,7 @@ def _device_placement_statistics(lib, device, B, rounds):
 def test_device_placement_is_valid_emul(emul_lib):
     env, counts = _device_placement_statistics(emul_lib, "cpu", B=64, rounds=2)
     assert counts.sum() == 128 and counts.min() > 0
+    _device_placement_statistics(emul_lib, "cpu", B=32, rounds=1, ycb=True)
 
 
 @pytest.mark.gpu
@@ -417,6 +425,7 @@ def test_device_placement_is_valid_and_uniform_gpu():
     # (grids with an odd number of columns / rows put the middle column on the upper side of the split: compare with the expectation of the observed grids instead
     # of 1/4 each -- loosely: every quadrant between 15 % and 35 %)
     assert n == 4 * 4096 and counts.min() > 0.15 * n and counts.max() < 0.35 * n, counts
+    _device_placement_statistics(None, "cuda:0", B=4096, rounds=2, ycb=True)
 
 
 @pytest.mark.gpu
