@@ -58,3 +58,38 @@ def parallel_quats_np() -> np.ndarray:
     out = np.array(sorted(quats), dtype=np.float64)
     assert out.shape == (24, 4)
     return out
+
+
+def quat2mat(q: torch.Tensor) -> torch.Tensor:
+    """rotation.quat2mat (utils/rotation.py:202-225) for quaternions [..., 4] -> [..., 3, 3] (identity where the quaternion is ~0)."""
+    w, x, y, z = q.unbind(-1)
+    nq = (q * q).sum(-1)
+    s = torch.where(nq > 2.220446049250313e-16, 2.0 / nq.clamp_min(1.0e-30), torch.zeros_like(nq))
+    X, Y, Z = x * s, y * s, z * s
+    wX, wY, wZ, xX, xY, xZ, yY, yZ, zZ = w * X, w * Y, w * Z, x * X, x * Y, x * Z, y * Y, y * Z, z * Z
+    m = torch.stack([1.0 - (yY + zZ), xY - wZ, xZ + wY, xY + wZ, 1.0 - (xX + zZ), yZ - wX, xZ - wY, yZ + wX, 1.0 - (xX + yY)], -1).reshape(q.shape[:-1] + (3, 3))
+    eye = torch.eye(3, dtype=q.dtype, device=q.device).expand_as(m)
+    return torch.where((nq > 2.220446049250313e-16)[..., None, None], m, eye)
+
+
+def vectors2quat_to_z(v: torch.Tensor) -> torch.Tensor:
+    """rotation.vectors2quat(v, ez) (utils/rotation.py:469-486), batched over the leading dimensions: the shortest-arc rotation of v onto the world's z;
+    v = -|v| ez: half a turn about any_orthogonal(v) (:461-466)."""
+    n = v.norm(dim=-1)
+    w = n + v[..., 2]
+    q = torch.stack([w, v[..., 1], -v[..., 0], torch.zeros_like(w)], -1)            # cross(v, ez) = (vy, -vx, 0)
+    qn = q.norm(dim=-1, keepdim=True)
+    # the antiparallel case: promising axis = the unit vector of v's smallest component (np.abs(vec).argmin()), orthogonal = cross(v, axis), normalised
+    k = v.abs().argmin(dim=-1)
+    axis = torch.nn.functional.one_hot(k, 3).to(v.dtype)
+    orth = torch.cross(v, axis, dim=-1)
+    orth = orth / orth.norm(dim=-1, keepdim=True).clamp_min(1.0e-30)
+    flip = torch.cat([torch.zeros_like(w)[..., None], orth], -1)
+    small = qn < 1.0e-6
+    q = torch.where(small, flip, q)
+    return quat_normalize(q / q.norm(dim=-1, keepdim=True).clamp_min(1.0e-30))
+
+
+def normalize_angles(a: torch.Tensor) -> torch.Tensor:
+    """rotation.normalize_angles (utils/rotation.py:372-378): into [-pi, pi)."""
+    return (a + np.pi) % (2 * np.pi) - np.pi

@@ -42,6 +42,7 @@ DEFAULT_OBSERVATION_NOISE_LEVELS = {   # locked.py:232-237
     "cube_quat": {"additive": 0.1, "uncorrelated": 0.09},
 }
 NO_NOISE_LEVELS = {"fingertip_pos": {}, "hand_angle": {}, "cube_pos": {}, "cube_quat": {}}   # locked.py:239-244
+NO_NOISE_LEVELS_FULL = dict(NO_NOISE_LEVELS, cube_face_angle={})                              # full_perpendicular.py:390-396
 QUAT_NOISE_CORRECTION = 1.96   # wrappers/randomizations.py:309-311
 FINGERTIP_SITES = ["S_fftip", "S_mftip", "S_rftip", "S_lftip", "S_thtip"]          # hand_forward_kinematics.py FINGERTIP_SITE_NAMES
 REFERENCE_SITES = ["phasespace_ref0", "phasespace_ref1", "phasespace_ref2"]        # ... REFERENCE_SITE_NAMES
@@ -121,7 +122,12 @@ class BatchedDactylCubeWrappers:
         self._bins = torch.linspace(-1.0, 1.0, nb, device=self.device)     # BinSpacing.LINEAR over Box(-1, 1)
         self.relative_goal_wrapper = relative_goal_wrapper
         self.drop_reward, self.min_episode_length, self.clip = float(drop_reward), int(min_episode_length), float(clip)
-        self.levels = noise_levels if noise_levels is not None else (DEFAULT_OBSERVATION_NOISE_LEVELS if randomize else NO_NOISE_LEVELS)
+        # the full cube (FullPerpendicularEnv): face angles among the observations, FaceFreeGoal.relative_goal -- the env supplies the goal-space differences
+        self.full_cube = hasattr(env, "relative_goal")
+        if self.full_cube and randomize:
+            raise NotImplementedError("randomize=True around the full cube: RandomizedPerpendicularCubeSizeWrapper / Timestep / Wind need per-env mesh scale, timestep and "
+                                      "applied forces on rb_step_kernel (DESIGN.md section 9); constants={'randomize': False} gives the reference's stack without them")
+        self.levels = noise_levels if noise_levels is not None else (DEFAULT_OBSERVATION_NOISE_LEVELS if randomize else (NO_NOISE_LEVELS_FULL if self.full_cube else NO_NOISE_LEVELS))
         self.smooth_alpha = float(smooth_alpha)
         if draws is None:
             gen = torch.Generator(device=self.device)
@@ -137,7 +143,7 @@ class BatchedDactylCubeWrappers:
         self._ema_value, self._ema_t = z(B, self.nu), torch.zeros(B, dtype=torch.int32, device=dev)
         self._additive_bias: Dict[str, torch.Tensor] = {}
         self._multiplicative_bias: Dict[str, torch.Tensor] = {}
-        self._key_len = {"fingertip_pos": 15, "hand_angle": 24, "cube_pos": 3, "cube_quat": 1}   # key_length(): quaternions get ONE angle
+        self._key_len = {"fingertip_pos": 15, "hand_angle": 24, "cube_pos": 3, "cube_quat": 1, "cube_face_angle": 6}   # key_length(): quaternions get ONE angle
         sim = env.mujoco_simulation
         self._cube_center_z0 = sim.cube_body_z
         self._step_s0 = sim.n_substeps * float(sim.model.opt_timestep[0])   # step length with the model's own timestep (wrapper construction time)
@@ -441,10 +447,13 @@ class BatchedDactylCubeWrappers:
         o.update(self._noisy(obs))                                                       # (ObservationDelayWrapper: no groups) + RandomizeObservationWrapper
         o["action_ema"] = action_ema                                                     # SmoothActionWrapper
         if self.relative_goal_wrapper:                                                   # RelativeGoalWrapper(obs_prefix="cube_") with LockedParallelGoal.relative_goal
-            gq = self.env._goal_quat
             zero3 = torch.zeros((self.B, 3), device=self.device, dtype=o["cube_pos"].dtype)
-            rel = {"pos": lambda cur: zero3, "quat": lambda cur: rotation.quat_difference(gq.to(cur.dtype), cur)}
-            for name in ("pos", "quat"):      # the reference's key order: per goal part, achieved / relative / noisy achieved / noisy relative
+            if self.full_cube:                # FaceFreeGoal.relative_goal (goals/face_free.py:147-173), evaluated by the env on its goal rows
+                rel = {"pos": lambda cur: zero3, "quat": lambda cur: self.env.relative_goal("cube_quat", cur), "face_angle": lambda cur: self.env.relative_goal("cube_face_angle", cur)}
+            else:
+                gq = self.env._goal_quat
+                rel = {"pos": lambda cur: zero3, "quat": lambda cur: rotation.quat_difference(gq.to(cur.dtype), cur)}
+            for name in (("pos", "quat", "face_angle") if self.full_cube else ("pos", "quat")):      # the reference's key order: per goal part, achieved / relative / noisy achieved / noisy relative
                 o["achieved_goal_" + name] = o["cube_" + name].clone()
                 o["relative_goal_" + name] = rel[name](o["cube_" + name])
                 o["noisy_achieved_goal_" + name] = o["noisy_cube_" + name].clone()

@@ -80,6 +80,100 @@ def _default_golden_replay():
     assert env.action_space["nvec"] == [11] * 20
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# the same stack around the FULL cube's observation set, with FaceFreeGoal.relative_goal (tests/golden/wrappers_full.npz: the reference's wrapper classes and the goal
+# class's own relative_goal source, tools/gen_golden_wrappers.py main_full)
+FULL_OBS_KEYS = ["cube_pos", "cube_quat", "cube_face_angle", "qpos", "qvel", "perp_qpos", "perp_qvel", "hand_angle", "fingertip_pos", "goal_pos", "goal_quat", "goal_face_angle"]
+
+
+class FullScriptedBatchedEnv(ScriptedBatchedEnv):
+    """Batched stand-in for BatchedFullPerpendicularEnv: the script's observations and goal rows in the env's own layout (quat 4, face angles 6, goal_type, axis_nr,
+    axis_sign), `relative_goal` = the real env's method."""
+
+    def _emit(self):
+        from robogym_amd import _native
+
+        rep = lambda a: torch.as_tensor(np.repeat(np.asarray(a)[None], self.batch_size, 0), dtype=torch.float64, device=self.device)
+        obs = {k: rep(self.g["script_obs_" + k][self.t]) for k in FULL_OBS_KEYS}
+        goal = torch.zeros((self.batch_size, _native.RB_GOAL_WORDS), dtype=torch.float64, device=self.device)
+        goal[:, 0:4], goal[:, 4:10] = obs["goal_quat"], obs["goal_face_angle"]
+        goal[:, 10], goal[:, 11], goal[:, 12] = float(self.g["script_goal_rotation"][self.t]), float(self.g["script_axis_nr"][self.t]), float(self.g["script_axis_sign"][self.t])
+        self._goal = goal
+        return obs
+
+    def relative_goal(self, key, current):
+        from robogym_amd.envs.dactyl.full_perpendicular import BatchedFullPerpendicularEnv
+
+        return BatchedFullPerpendicularEnv.relative_goal(self, key, current)
+
+
+def _full_golden_replay():
+    from robogym_amd.wrappers.dactyl_cube import BatchedDactylCubeWrappers
+
+    g = np.load(os.path.join(G, "wrappers_full.npz"))
+    inner = FullScriptedBatchedEnv(g)
+    env = BatchedDactylCubeWrappers(inner, randomize=False)
+    assert env.full_cube and sorted(env.levels) == ["cube_face_angle", "cube_pos", "cube_quat", "fingertip_pos", "hand_angle"]
+    keys = [str(k) for k in g["obs_keys"]]
+    obs = env.reset()
+    T = len(g["actions"])
+    kinds = set()
+    for t in range(T + 1):
+        if t > 0:
+            obs, reward, done, info = env.step(torch.as_tensor(np.repeat(g["actions"][t - 1][None], inner.batch_size, 0), device=DEV[0]))
+            np.testing.assert_allclose(reward[0].cpu().numpy(), g["wreward"][t - 1], atol=1e-6, err_msg="reward at step %d" % t)
+            assert bool(done[0]) == bool(g["wdone"][t - 1]), t
+            for k in ("fell_down", "drops_so_far", "first_drop"):
+                assert int(info[k][0]) == int(g["winfo_" + k][t - 1]), (k, t)
+        assert list(obs.keys()) == keys, (list(obs.keys()), keys)
+        for k in keys:
+            np.testing.assert_allclose(obs[k][0].double().cpu().numpy().ravel(), g["wobs_" + k][t], atol=1e-6, err_msg="%s at step %d" % (k, t))
+        kinds.add(bool(g["script_goal_rotation"][t]))
+    assert kinds == {True, False}                      # both goal types of FaceFreeGoal.relative_goal went through
+    np.testing.assert_allclose(np.stack(inner.received), g["received_actions"], atol=1e-6)
+    assert obs["relative_goal"].shape == (inner.batch_size, 3 + 4 + 12) and obs["goal"].shape == (inner.batch_size, 19)
+    with pytest.raises(NotImplementedError):
+        BatchedDactylCubeWrappers(FullScriptedBatchedEnv(g), randomize=True)
+
+
+def test_full_cube_wrapper_stack_matches_reference_stack():
+    _full_golden_replay()
+
+
+@pytest.mark.gpu
+def test_full_cube_wrapper_stack_matches_reference_stack_gpu():
+    DEV[0] = torch.device("cuda:0")
+    try:
+        _full_golden_replay()
+    finally:
+        DEV[0] = torch.device("cpu")
+
+
+@pytest.mark.gpu
+def test_full_cube_make_env_with_wrappers_gpu():
+    """`full_perpendicular.make_env(constants={"randomize": False})` around the real batched env on the MI355X: the wrapped keys and widths, MultiDiscrete actions
+    through the launch, the relative goal consistent with the env kernel's own goal distance (|relative face angles| = cube_face_angle distance), drop penalty."""
+    from robogym_amd.envs.dactyl.full_perpendicular import make_env
+
+    with pytest.raises(NotImplementedError):
+        make_env(batch_size=2)                                                            # the reference's default is randomize=True: not silently narrowed
+    env = make_env(constants={"randomize": False}, batch_size=8, starting_seed=3)
+    obs = env.reset()
+    g = np.load(os.path.join(G, "wrappers_full.npz"))
+    assert list(obs.keys()) == [str(k) for k in g["obs_keys"]]
+    assert obs["relative_goal"].shape == (8, 19) and obs["noisy_cube_face_angle"].shape == (8, 12) and obs["cube_face_angle"].shape == (8, 12) and obs["reward"].shape == (8, 2)
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    for _ in range(5):
+        obs, reward, done, info = env.step(torch.randint(0, 11, (8, 20), generator=gen).to(env.device))
+    assert reward.shape == (8, 4) and bool(torch.isfinite(obs["relative_goal"]).all()) and int(env.unwrapped.mujoco_simulation.status.max()) == 0
+    raw = env.unwrapped
+    rel = raw.relative_goal("cube_face_angle", raw.observe()["cube_face_angle"])
+    assert torch.allclose(rel.norm(dim=1), info["goal_dist"]["cube_face_angle"], atol=1e-4)
+    relq = raw.relative_goal("cube_quat", raw.observe()["cube_quat"])
+    from robogym_amd.utils import rotation
+    assert torch.allclose(rotation.quat_magnitude(relq), info["goal_dist"]["cube_quat"], atol=1e-4)
+
+
 def test_wrapper_stack_on_the_kernel_emul(locked_model, emul_lib):
     """make_env() default (apply_wrappers=True) around the real batched env: shapes, drop penalty and done when the cube is
     thrown off, noise statistics with randomize=True, per-env physics rows actually written."""

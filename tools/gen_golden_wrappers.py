@@ -446,7 +446,99 @@ def main_fixed_wrist():
     print("fixed wrist: received wrist actions", np.round(out["received_actions"][:4, u], 4))
 
 
+# ------------------------------------------------------------------------------------------------------------------------
+# The same stack around the FULL cube's observation set (FullPerpendicularEnv._default_observation_map, full_perpendicular.py:177-192; its default_no_noise_levels
+# :390-396 add cube_face_angle) with FaceFreeGoal.relative_goal (goals/face_free.py:147-173) -- the method's own source, lifted out of its class with ast (the module
+# imports robot_env.py, which needs mujoco_py.cymj) and run on the reference's cube_utils / rotation: tests/golden/wrappers_full.npz.
+# (qpos / qvel and their perp_ duplicates only pass through the clip: 12 / 11 numbers instead of the model's 173 / 168 keep the fixture small)
+FULL_OBS_SHAPES = OrderedDict([("cube_pos", 3), ("cube_quat", 4), ("cube_face_angle", 6), ("qpos", 12), ("qvel", 11), ("perp_qpos", 12), ("perp_qvel", 11), ("hand_angle", 24),
+                               ("fingertip_pos", 15), ("goal_pos", 3), ("goal_quat", 4), ("goal_face_angle", 6)])
+
+
+def _face_free_relative_goal():
+    import ast
+
+    path = "/root/reference/robogym/envs/dactyl/goals/face_free.py"
+    tree = ast.parse(open(path).read())
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "FaceFreeGoal"][0]
+    fn = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "relative_goal"][0]
+    m_ = ast.Module(body=[fn], type_ignores=[]); ast.fix_missing_locations(m_)
+    mod("robogym.mujoco.helpers", joint_qpos_ids_from_prefix=None)      # (cube_utils imports one helper it does not need here)
+    from robogym.envs.dactyl.common import cube_utils
+
+    ns = {"np": np, "rotation": rotation, "cube_utils": cube_utils}
+    exec(compile(m_, path, "exec"), ns)
+    return ns["relative_goal"]
+
+
+class FullScriptedEnv(ScriptedEnv):
+    def __init__(self, script):
+        super().__init__(script)
+        self.observation_space = Dict({k: Box(-np.inf, np.inf, (n,), np.float32) for k, n in FULL_OBS_SHAPES.items()})
+        rel = _face_free_relative_goal()
+        self.goal_generation = types.SimpleNamespace(relative_goal=lambda goal_state, current_state: rel(None, goal_state, current_state))
+
+    def _emit(self):
+        o = OrderedDict((k, self.script["obs_" + k][self.t].copy()) for k in FULL_OBS_SHAPES)
+        self._goal = {"cube_quat": o["goal_quat"].copy(), "cube_pos": o["goal_pos"].copy(), "cube_face_angle": o["goal_face_angle"].copy(),
+                      "goal_type": "rotation" if self.script["goal_rotation"][self.t] else "flip", "axis_nr": int(self.script["axis_nr"][self.t]),
+                      "axis_sign": int(self.script["axis_sign"][self.t])}
+        self.sim.data.site_xpos[0] = [1.0, 0.87, 0.2 + o["cube_pos"][2]]
+        return o
+
+
+def main_full():
+    rng = np.random.RandomState(20200907)
+    T = 40
+    script = {}
+    for k, n in FULL_OBS_SHAPES.items():
+        script["obs_" + k] = rng.randn(T + 1, n) * (150.0 if k in ("qvel", "perp_qvel") else 1.0)
+    for k in ("cube_quat", "goal_quat"):
+        q = script["obs_" + k]; q /= np.linalg.norm(q, axis=1, keepdims=True)
+    script["obs_cube_face_angle"] *= 2.0; script["obs_goal_face_angle"] = np.round(script["obs_goal_face_angle"] * 2.0) * (np.pi / 2)      # (differences beyond +-pi: normalize_angles at work)
+    script["obs_cube_pos"] *= 0.05
+    script["obs_cube_pos"][25:, 2] = -0.19
+    script["goal_rotation"] = rng.rand(T + 1) < 0.5
+    script["axis_nr"] = rng.randint(0, 3, T + 1); script["axis_sign"] = rng.choice([-1, 1], T + 1)
+    script["reward"] = np.stack([np.zeros(T + 1), rng.randn(T + 1) * 0.2, (rng.rand(T + 1) < 0.1) * 5.0], axis=1)
+    script["done"] = np.zeros(T + 1, bool); script["done"][33] = True
+    script["successes_so_far"] = np.cumsum(script["reward"][:, 2] > 0)
+    actions = rng.randint(0, 11, size=(T, 20))
+    inner = FullScriptedEnv(script)
+    default_wrappers = {"default_no_noise_levels": {"fingertip_pos": {}, "hand_angle": {}, "cube_pos": {}, "cube_quat": {}, "cube_face_angle": {}},
+                        "default_no_observation_delay_levels": {"interpolators": {}, "groups": {}}}
+    env = apply_wrappers(inner, randomize=False, n_action_bins=None, fixed_wrist=False, relative_goal_wrapper=True, drop_reward=-20.0,
+                         default_wrappers=default_wrappers, min_episode_length=-1)
+    out = {("script_" + k): np.asarray(v) for k, v in script.items()}
+    out["actions"] = actions
+    obs = env.reset()
+    keys = list(obs.keys())
+    rec = {k: [np.asarray(obs[k], dtype=np.float64).ravel()] for k in keys}
+    rewards, dones, infos = [], [], {"fell_down": [], "drops_so_far": [], "first_drop": []}
+    for t in range(T):
+        obs, rew, done, info = env.step(actions[t])
+        assert list(obs.keys()) == keys
+        for k in keys:
+            rec[k].append(np.asarray(obs[k], dtype=np.float64).ravel())
+        rewards.append(np.asarray(rew, dtype=np.float64)); dones.append(done)
+        for k in infos:
+            infos[k].append(int(info[k]))
+    for k in keys:
+        out["wobs_" + k] = np.stack(rec[k])
+    out["obs_keys"] = np.array(keys)
+    out["wreward"] = np.stack(rewards); out["wdone"] = np.array(dones)
+    for k, v in infos.items():
+        out["winfo_" + k] = np.array(v)
+    out["received_actions"] = np.stack(inner.received)
+    np.savez_compressed(os.path.join(OUT, "wrappers_full.npz"), **out)
+    print("full cube: wrapped observation keys:", keys)
+
+
 if __name__ == "__main__":
+    if "--full-only" in sys.argv:
+        main_full()
+        sys.exit(0)
     main()
     main_randomized()
     main_fixed_wrist()
+    main_full()
