@@ -77,7 +77,6 @@ class BatchedBlockRearrangeEnv:
         AD = 7 if self.joint_control else 6                     # the launches' action width (tcp+wrist: the six of tcp+roll+yaw with the roll number ignored)
         self.action_dim = 5 if self.wrist_only else AD          # the env's action width
         self.launch_action_dim = AD
-        self._ext_cols = torch.tensor([0, 1, 2, 4, 5]) if self.wrist_only else None
         self.max_position_change = float(max_position_change)
         main = main_model if main_model is not None else load_blocks_model(self.N)   # (main_model: the same world with other objects, envs/rearrange/ycb.py)
         solver = None if self.joint_control else load_solver_model()
@@ -88,6 +87,7 @@ class BatchedBlockRearrangeEnv:
         self.sim = LargeModelSimulation(main, self.B, device=device, n_substeps=n_substeps, lib=lib, hand=False, env_params=self.per_env_parameters)
         self.solver_sim = None if self.joint_control else LargeModelSimulation(solver, self.B, device=device, n_substeps=n_substeps, lib=lib, hand=False)
         self.device = self.sim.device
+        self._ext_cols = torch.tensor([0, 1, 2, 4, 5], device=self.device) if self.wrist_only else None      # tcp+wrist: the launch's columns without the roll
         self.model, self.solver_model = main, solver
         self.n_random_initial_steps, self.stabilize_steps, self.settle_steps = n_random_initial_steps, stabilize_steps, settle_steps
         self.used_table_portion = used_table_portion
@@ -346,7 +346,7 @@ class BatchedBlockRearrangeEnv:
         assert o == self.obs_dim
         if self.wrapped:
             ema = self.action_ema if action_ema is None else action_ema
-            out["action_ema"] = ema[:, self._ext_cols.to(ema.device)] if self.wrist_only else ema      # SmoothActionWrapper's observation: the smoothed action of the last step (zeros after reset)
+            out["action_ema"] = ema[:, self._ext_cols] if self.wrist_only else ema      # SmoothActionWrapper's observation: the smoothed action of the last step (zeros after reset)
         return out
 
     # ------------------------------------------------------------------ reset (host work + physics launches)
