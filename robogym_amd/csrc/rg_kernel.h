@@ -237,6 +237,8 @@ static inline int rg_ld_sc1(const int* p) { return *p; }
 static inline float rg_ld_sc1(const float* p) { return *p; }
 static inline unsigned rg_ld_sc1(const unsigned* p) { return *p; }
 static inline void rg_st_sc1(int* p, int v) { *p = v; }
+static inline void rg_st_sc1(unsigned* p, unsigned v) { *p = v; }
+static inline void rg_st_sc1(float* p, float v) { *p = v; }
 static inline int rg_ticket(int* p) { int o = *p; *p = o + 1; return o; }
 static inline void rg_drain_stores() {}
 static inline void rg_pause() {}
@@ -247,6 +249,8 @@ __device__ __forceinline__ int rg_ld_sc1(const int* p) { return __hip_atomic_loa
 __device__ __forceinline__ unsigned rg_ld_sc1(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float rg_ld_sc1(const float* p) { return __builtin_bit_cast(float, __hip_atomic_load((const int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
 __device__ __forceinline__ void rg_st_sc1(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void rg_st_sc1(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void rg_st_sc1(float* p, float v) { __hip_atomic_store((int*)p, __builtin_bit_cast(int, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int rg_ticket(int* p) { return __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void rg_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void rg_pause() { __builtin_amdgcn_s_sleep(16); }
@@ -293,10 +297,21 @@ __device__ __forceinline__ void cross_force(float* r, const float* vel, const fl
                           work item of the env may have written are read with L1-bypassing loads, the env comes from the work item */
 #endif
 #undef RG_ROW_LD
+#undef RG_ROW_ST
 #if RG_ITEMS
 #define RG_ROW_LD(p) rg_ld_sc1(p)
 #else
 #define RG_ROW_LD(p) (*(p))
+#endif
+// stores of the rows a later work item of the env reads.  Default: plain stores (made visible in the XCD's L2 by rg_item_publish's vmcnt drain: the vector L1 is
+// write-through).  -DRG_ROW_ST_SC1: agent-scope relaxed atomic stores, the formal counterpart of RG_ROW_LD (A/B: profiles/r05_ab_items_sc1_stores.txt).
+#undef RG_SEPDIR_ST
+#if RG_ITEMS && defined(RG_ROW_ST_SC1)
+#define RG_ROW_ST(p, v) rg_st_sc1((p), (v))
+#define RG_SEPDIR_ST(p, cd) do { float* sp__ = (float*)(p); rg_st_sc1(sp__, (cd).x); rg_st_sc1(sp__ + 1, (cd).y); rg_st_sc1(sp__ + 2, (cd).z); } while (0)
+#else
+#define RG_ROW_ST(p, v) (*(p) = (v))
+#define RG_SEPDIR_ST(p, cd) (*(p) = (cd))
 #endif
 #ifndef RG_SETCONST
 #define RG_SETCONST 0  /* 1: this configuration also carries rg_setconst_kernel (one instantiation is enough) */
@@ -1219,7 +1234,7 @@ template <int G> RG_STAGE void rg_narrow_phase1(RgCtx c, int ncand) {
         float d = dot(p1.v, dir);
         keep = d > 0;
         // separated by -d along dir: a lower bound on the distance of the inflated shapes
-        if (!keep && pairlb && (LANE & (G - 1)) == 0) pairlb[p] = fmaxf(-d - 1e-6f, 0.f);
+        if (!keep && pairlb && (LANE & (G - 1)) == 0) RG_ROW_ST(pairlb + p, fmaxf(-d - 1e-6f, 0.f));
       }
     }
     bool lead = keep && (LANE & (G - 1)) == 0;
@@ -1255,7 +1270,7 @@ template <int G> RG_STAGE_BIG void rg_narrow_phase2(RgCtx c, int ncand2) {
     v3 sep;
     hit = rg_mpr<G>(E, A, B, m.mpr_iterations, m.mpr_tolerance, depth, dir, pos, sep, active);
     if (active) {
-      if (sepdir && (LANE & (G - 1)) == 0) { rgf4 cd; cd.x = hit ? 0.f : sep.x; cd.y = hit ? 0.f : sep.y; cd.z = hit ? 0.f : sep.z; cd.w = 0.f; sepdir[p] = cd; }
+      if (sepdir && (LANE & (G - 1)) == 0) { rgf4 cd; cd.x = hit ? 0.f : sep.x; cd.y = hit ? 0.f : sep.y; cd.z = hit ? 0.f : sep.z; cd.w = 0.f; RG_SEPDIR_ST(sepdir + p, cd); }
       hit = hit && dot(dir, dir) > 0.25f;
       pos = pos + ld3(s.gpos + 3 * (m.pair_gg[p] & 255));
     }
@@ -1307,7 +1322,7 @@ __device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, const flo
         int g1 = gg[k] & 255, g2 = gg[k] >> 8;
         float lb = lbv[k] - (hb * (s.gspeed[g1] + s.gspeed[g2]) + 1e-7f);
         need = !(lb > 0.f);
-        if (!need) pairlb[p] = lb;
+        if (!need) RG_ROW_ST(pairlb + p, lb);
       }
       unsigned long long nb = __ballot(need);
       if (need) s.tlist[nt + __popcll(nb & ((1ull << LANE) - 1ull))] = (short)p;
@@ -1341,7 +1356,7 @@ __device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, const flo
             hit = og < 0; newlb = fmaxf(og, 0.f);
           } else newlb = d;
         }
-        if (pairlb) pairlb[q] = fmaxf(newlb - 1e-6f, 0.f);
+        if (pairlb) RG_ROW_ST(pairlb + q, fmaxf(newlb - 1e-6f, 0.f));
       }
       unsigned long long bal = __ballot(hit);
       bbany = bbany || (hit && isbb); plany = plany || (hit && ispl);
@@ -2805,16 +2820,16 @@ __global__ void __launch_bounds__(RG_WAVE, RG_WAVES_PER_SIMD) rg_step_items_kern
       }
     }
     // ---- write back
-    PFOR(i, m.nq) L.bt.qpos[(size_t)e * m.nq + i] = s.qpos[i];
-    if (LANE < m.nv) { L.bt.qvel[(size_t)e * m.nv + LANE] = s.qvel[LANE]; L.bt.qacc_warmstart[(size_t)e * m.nv + LANE] = warmr; }
-    if (LANE < m.nu) for (int q = 0; q < 3; q++) L.bt.pid[(size_t)e * 3 * m.nu + 3 * LANE + q] = pidr[q];
-    if (sub == 0) PFOR(u, m.nu) L.bt.ctrl[(size_t)e * m.nu + u] = s.ctrl[u];
+    PFOR(i, m.nq) RG_ROW_ST(L.bt.qpos + (size_t)e * m.nq + i, s.qpos[i]);
+    if (LANE < m.nv) { RG_ROW_ST(L.bt.qvel + (size_t)e * m.nv + LANE, s.qvel[LANE]); RG_ROW_ST(L.bt.qacc_warmstart + (size_t)e * m.nv + LANE, warmr); }
+    if (LANE < m.nu) for (int q = 0; q < 3; q++) RG_ROW_ST(L.bt.pid + (size_t)e * 3 * m.nu + 3 * LANE + q, pidr[q]);
+    if (sub == 0) PFOR(u, m.nu) RG_ROW_ST(L.bt.ctrl + (size_t)e * m.nu + u, s.ctrl[u]);
     if (LANE == 0) {
       if (cleared_preticks) L.bt.preticks[e] = 0;
-      if (s.status != status0) L.bt.status[e] = s.status;
+      if (s.status != status0) RG_ROW_ST(L.bt.status + e, s.status);
       if (last) L.bt.time[e] += nsub * P[RG_PRM_TIMESTEP];
-      if (L.bt.cost) { const float cy = (float)(rg_clock() - tk0); L.bt.cost[e] = sub == 0 ? cy : RG_ROW_LD(L.bt.cost + e) + cy; }
-      if (L.bt.stats) { float* st = L.bt.stats + 4 * (size_t)e; st[0] = RG_ROW_LD(st) + st_ncon; st[1] = RG_ROW_LD(st + 1) + st_nefc; st[2] = RG_ROW_LD(st + 2) + st_iter; st[3] = RG_ROW_LD(st + 3) + 1.f; }
+      if (L.bt.cost) { const float cy = (float)(rg_clock() - tk0); RG_ROW_ST(L.bt.cost + e, sub == 0 ? cy : RG_ROW_LD(L.bt.cost + e) + cy); }
+      if (L.bt.stats) { float* st = L.bt.stats + 4 * (size_t)e; RG_ROW_ST(st, RG_ROW_LD(st) + st_ncon); RG_ROW_ST(st + 1, RG_ROW_LD(st + 1) + st_nefc); RG_ROW_ST(st + 2, RG_ROW_LD(st + 2) + st_iter); RG_ROW_ST(st + 3, RG_ROW_LD(st + 3) + 1.f); }
     }
     // ---- observation row of the final state (robot_env.py:714-743; see rg_step_kernel)
     if (last && L.bt.obs) {
