@@ -53,7 +53,7 @@ class GroupedYcbRearrangeEnv:
         self.groups = [BatchedYcbRearrangeEnv(self.b, device=device, main_model=load_ycb_model(kw.get("num_objects", 8), set_index=k), starting_seed=starting_seed + 1000 * i, **kw)
                        for i, k in enumerate(self.object_sets)]
         g0 = self.groups[0]
-        self.device, self.N, self.obs_dim, self.wrapped, self.action_shape = g0.device, g0.N, g0.obs_dim, g0.wrapped, (self.B, 6)
+        self.device, self.N, self.obs_dim, self.wrapped, self.action_shape = g0.device, g0.N, g0.obs_dim, g0.wrapped, (self.B, g0.action_dim)
         self._cuda = self.device.type == "cuda"
         self.streams = [torch.cuda.Stream(self.device) for _ in self.groups] if self._cuda else [None] * K
         self.object_names = [g.object_names for g in self.groups]
