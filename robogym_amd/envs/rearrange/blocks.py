@@ -762,3 +762,40 @@ def make_simple_env(*a, **kw):
     """make_env(apply_wrappers=False) (robot_env.py:1137-1139)"""
     kw["apply_wrappers"] = False
     return make_env(*a, **kw)
+
+
+class SingleEnvView:
+    """B = 1 view of a batched rearrange env with the reference's types (robot_env.py:757-844): observations as numpy arrays without the batch dimension, the reward as a
+    LIST of three floats (env, goal, success), a Python bool `done`, an info dict of Python scalars / arrays -- what a caller of `BlockRearrangeEnv` sees.  For porting
+    single-env code and tests; not the fast path.  `step` takes the action of the env's mode: floats in [-1, 1] (`make_simple_env`) or bin indices (`make_env`)."""
+
+    def __init__(self, env: BatchedBlockRearrangeEnv):
+        assert env.B == 1
+        self.env = env
+        self.unwrapped = self
+        self.mujoco_simulation = self.sim = env.sim
+        self.action_shape = env.action_shape[1:]
+
+    @staticmethod
+    def _np(t):
+        a = t[0].detach().cpu().numpy()
+        return a.astype(np.float32) if a.dtype.kind == "f" else a
+
+    def _obs(self, obs):
+        return {k: self._np(v) for k, v in obs.items()}
+
+    def reset(self):
+        return self._obs(self.env.reset())
+
+    def observe(self):
+        return self._obs(self.env.observe())
+
+    def reset_goals(self):
+        self.env.reset_goals()
+        return self.observe()
+
+    def step(self, action):
+        a = np.asarray(action)
+        t = torch.as_tensor((a.astype(np.int64) if self.env.wrapped else a.astype(np.float32))[None], device=self.env.device)
+        obs, reward, done, info = self.env.step(t.contiguous())
+        return self._obs(obs), [float(x) for x in reward[0]], bool(done[0]), {k: (v[0].item() if v[0].dim() == 0 else self._np(v)) for k, v in info.items()}

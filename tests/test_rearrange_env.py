@@ -235,6 +235,19 @@ def test_rearrange_env_batch_4096_runs_clean_gpu():
     assert float(done.float().mean()) < 0.02
 
 
+def test_single_env_view_has_the_reference_types_emul(emul_lib):
+    """`SingleEnvView(make_simple_env(batch_size=1))`: numpy observations without the batch dimension, reward list of three floats, bool done, scalar info values"""
+    from robogym_amd.envs.rearrange.blocks import SingleEnvView, make_simple_env
+
+    env = SingleEnvView(make_simple_env(batch_size=1, device="cpu", lib=emul_lib, n_substeps=1, stabilize_steps=1, n_random_initial_steps=0, settle_steps=0))
+    obs = env.reset()
+    assert isinstance(obs["obj_pos"], np.ndarray) and obs["obj_pos"].shape == (5, 3) and obs["obj_pos"].dtype == np.float32 and obs["qpos"].shape == (env.env.nq,)
+    obs, reward, done, info = env.step(np.zeros(6))
+    assert isinstance(reward, list) and len(reward) == 3 and all(isinstance(x, float) for x in reward) and isinstance(done, bool) and not done
+    assert isinstance(info["goal_dist_obj_pos"], float) and isinstance(info["successes_so_far"], int) and isinstance(info["goal_reset"], bool)
+    assert np.allclose(obs["rel_goal_obj_pos"], obs["goal_obj_pos"] - obs["obj_pos"], atol=1e-6)
+
+
 # ------------------------------------------------------------------------------------------------ the rearrange wrapper stack (RearrangeEnv.apply_wrappers)
 def _wrapper_stack_replay(lib, device, n_substeps):
     """`make_env()`'s default stack -- DiscretizeActionWrapper(11 bins) -> ClipRewardWrapper -> SmoothActionWrapper(0.3) -- runs inside the launches
