@@ -323,8 +323,8 @@ __global__ void __launch_bounds__(64) ra_recipe_kernel(const RbModelDev* mp, RbB
       gy = a.goal_rot + (size_t)e * N * 3 + 2; gstride = 3;
     }
     if (gy) {
-      k = 100000u;
-      if (!ra_place(a, gy, gstride, a.seed, a.step, (unsigned)e, k, F.gpos)) a.placement_failed[e] += 1;
+      k = 0u;     // (the goal's placement draws from its own stream: an env can get a new goal and end its episode on the same step)
+      if (!ra_place(a, gy, gstride, a.seed ^ 0x9E3779B9u, a.step, (unsigned)e, k, F.gpos)) a.placement_failed[e] += 1;
       for (int i = 0; i < N; i++) F.gyaw[i] = gy[i * gstride];
     }
     // ---- an episode that ended on this step: its recipe begins (the returned observation / reward / done are the terminal ones)
