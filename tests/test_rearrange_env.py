@@ -215,6 +215,16 @@ def test_ycb_env_step_observation_row_matches_oracle_gpu(oracle_lib):
                  make=lambda: BatchedYcbRearrangeEnv(3, n_substeps=40, stabilize_steps=30, n_random_initial_steps=1, settle_steps=10, starting_seed=3))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["joint", "tcp+wrist"])
+def test_ycb_env_step_other_control_modes_match_oracle_gpu(oracle_lib, mode):
+    """the same protocol on the ycb world in the two other control modes (7 joint numbers, no solver world; xyz + wrist with the vertical alignment)"""
+    from robogym_amd.envs.rearrange.ycb import BatchedYcbRearrangeEnv
+
+    _check_steps(None, "cuda:0", B=3, n_substeps=40, nsteps=5, tol=YCB_STEP_TOL,
+                 make=lambda: BatchedYcbRearrangeEnv(3, n_substeps=40, stabilize_steps=30, n_random_initial_steps=1, settle_steps=10, starting_seed=3, control_mode=mode))
+
+
 def test_ycb_env_step_observation_row_matches_oracle_emul(emul_lib, oracle_lib):
     from robogym_amd.envs.rearrange.ycb import BatchedYcbRearrangeEnv
 
