@@ -642,6 +642,53 @@ def test_tcp_action_path_matches_reference_code():
         assert np.abs(pos - g["denorm"][t][:3]).max() == 0 and np.abs(dq - g["dquat"][t]).max() < 1e-13, (t, dq, g["dquat"][t])
 
 
+def test_solver_quaternion_response_holds_the_references_own_test():
+    """robot/control/tcp/test/test_solver.py (test_zero_control, test_wrist_rotations, test_quat_second_dof_rotation) re-expressed on the oracle: at the arm's start
+    pose, for rotations of +-30 ... 180 degrees in every controlled dimension of both TCP control modes, the quaternion difference handed to the mocap solver must give
+    the rotation the test derives independently -- current orientation times the control, then, for tcp+wrist, the shortest rotation that puts the frame's
+    most-vertical axis back onto the vertical (`calculate_quat_adjustment_due_to_axis_alignment`, :46-71) -- to the test's own 1e-5 on the Euler angles of the
+    difference."""
+    from robogym_amd.envs.rearrange.xml import load_solver_model
+
+    ora = RO.OracleArmSim(load_solver_model(), 40)
+    ora.sim.qpos[ora.arm_q] = RO.TABLETOP_EXPERIMENT_INITIAL_POS
+    ora.sim.forward()
+    cur = np.array(ora.body_xquat(ora.tcp_body), dtype=float)
+    cur = RO.euler2quat(RO.quat2euler(cur))                    # (the test goes through tcp_rot(): Euler angles of the TCP)
+
+    def rot_vec(q, v):
+        return RO.quat_mul(q, RO.quat_mul(np.array([0.0, *v]), RO.quat_conjugate(q)))[1:]
+
+    def adjustment(from_quat, axis):
+        t = np.zeros(3); t[axis] = 1.0
+        c = rot_vec(from_quat, t)
+        d = float(np.dot(c, t))
+        t = t * np.sign(d)
+        ang, ax = np.arccos(abs(d)), np.cross(c, t)
+        if np.linalg.norm(ax) < 1e-12:
+            return np.array([1.0, 0, 0, 0])
+        ax = ax / np.linalg.norm(ax)
+        return np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * ax])
+
+    n = 0
+    for dims, align in (((2,), 2), ((0, 2), None)):            # FreeWristTcpArm: DOF_DIMS = [PITCH (value 2)], ALIGN_AXIS = PITCH; FreeRollYawTcpArm: [ROLL, PITCH]
+        for which in range(len(dims)):
+            for deg in (0, 30, 60, 90, 160, 180):
+                for sign in (1.0, -1.0):
+                    ctrl = np.zeros(len(dims)); ctrl[which] = sign * np.deg2rad(deg)
+                    eul = np.zeros(3)
+                    for k, d in enumerate(dims):
+                        eul[d] = ctrl[k]
+                    target = RO.quat_mul(cur, RO.euler2quat(eul))
+                    if align is not None:
+                        target = RO.quat_mul(adjustment(target, align), target)
+                    _, dq = RO.tcp_quat_control(np.concatenate([np.zeros(3), ctrl]), 0.0, -1e9, 1e9, cur)      # (wide joint range: get_tcp_quat alone, as the test calls it)
+                    diff = RO.quat2euler(RO.quat_normalize(RO.quat_mul(cur + (target - cur), RO.quat_conjugate(cur + dq))))      # rotation.quat_difference
+                    assert np.allclose(diff, 0.0, atol=1e-5), (dims, which, deg, sign, diff)
+                    n += 1
+    assert n == 36
+
+
 def test_observation_keys_and_order_are_the_reference_methods():
     """The packed observation row of the batched env (robogym_amd/envs/rearrange/blocks.py OBS_KEYS, written by ra_post_step_kernel) and the oracle env's
     observation have the keys of `RearrangeEnv._observe_simple` in its order: tests/golden/rearrange_obs_keys.json is what executing that method's own source on a
