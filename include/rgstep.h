@@ -364,8 +364,17 @@ typedef struct rb_tcp_args {
    * = 0, and the commanded TCP orientation is rotated back onto the vertical before the difference goes to the mocap body (MocapSolver.align_axis with ALIGN_AXIS =
    * PITCH, robot/control/tcp/mocap_solver.py:41-74).  0: tcp+roll+yaw (FreeRollYawTcpArm) */
   int wrist_only;
+  /* tcp_solver_mode = mocap (robot_interface.py:22-29, 54-58): the arm of the MAIN world hangs on the mocap weld itself (MujocoIdealURGripperCompositeRobot =
+   * IdealJointControlledTcpArm + MujocoRobotiqGripper with solver_simulation = simulation, robot/composite/ur_gripper_arm.py:126-128; robot/ur16e/mujoco/
+   * ideal_joint_controlled_tcp_arm.py:67-76): `solver` IS the env's world, `main` is ignored (may be NULL).  No arm synchronisation and no hand-over; the gripper's
+   * relative target goes into this world's own ctrl[main_gripper_actuator] BEFORE the mj_steps; the launch then continues like rb_batch_step_ex with `nforward_ticks`
+   * state-less forwards (flags bit 5: the last in full) or the per-env `nticks`.  skip[B] (or NULL): envs whose robot gets no command this step (their mocap target and
+   * ctrl stay: the objects' stabilisation steps of the reset recipe). */
+  int self_world, nforward_ticks;
+  const int* nticks; const int* skip;
 } rb_tcp_args;
 int rb_batch_step_tcp(rb_batch* solver, rb_batch* main, const float* action_dev, const int* active_dev /* [B] or NULL */, const rb_tcp_args* args, int nsubsteps, int flags, void* stream);
+int rb_tcp_args_size(void);   /* sizeof(rb_tcp_args): a binding checks its own layout against it */
 /* ---- the env-level half of RearrangeEnv.step (one launch after the two physics launches; robogym_amd/csrc/ra_env_kernel.h lists the
  * reference call sites): the 24-key observation of envs/rearrange/common/base.py:376-421 as one packed row per env — obj_pos 3N | obj_rel_pos 3N |
  * obj_vel_pos 3N | obj_rot 3N | obj_vel_rot 3N | robot_joint_pos 6 | gripper_pos 3 | gripper_velp 3 | gripper_controls 1 | gripper_qpos 1 |

@@ -269,9 +269,13 @@ class OracleRearrangeEnv:
     robot/ur16e/mujoco/joint_controlled_arm.py:89-200), no TCP solver world (RobotControlParameters.requires_solver_sim, robot_interface.py:83-91); 7 action numbers."""
 
     def __init__(self, main_model, solver_model, num_objects, n_substeps=40, max_position_change=0.1, arm_reset_controller_error=True,
-                 success_threshold=None, goal_reward_per_object=1.0, penalty=None, wrist_only=False):
+                 success_threshold=None, goal_reward_per_object=1.0, penalty=None, wrist_only=False, ideal_arm=False):
         self.main, self.solver = OracleArmSim(main_model, n_substeps), (None if solver_model is None else OracleArmSim(solver_model, n_substeps))
-        self.joint_control = solver_model is None
+        # tcp_solver_mode mocap: MujocoIdealURGripperCompositeRobot = IdealJointControlledTcpArm + MujocoRobotiqGripper with solver_simulation = simulation
+        # (robot/composite/ur_gripper_arm.py:126-128, robot/ur16e/mujoco/ideal_joint_controlled_tcp_arm.py): the main world's arm hangs on the mocap weld, one world
+        self.ideal_arm = bool(ideal_arm)
+        assert not (self.ideal_arm and solver_model is not None)
+        self.joint_control = solver_model is None and not self.ideal_arm
         self.wrist_only = bool(wrist_only)      # control_mode tcp+wrist: FreeWristTcpArm as the solver world's controller, 4 + 1 action numbers
         self.num_objects = num_objects
         self.mpc, self.reset_controller_error = max_position_change, arm_reset_controller_error
@@ -304,6 +308,11 @@ class OracleRearrangeEnv:
         `RearrangeEnv._initialize_sim_state` (joint actuated: no weld in the main world) + `robot.reset()`."""
         s = self.main.sim
         s.qpos[self.main.arm_q] = TABLETOP_EXPERIMENT_INITIAL_POS
+        if self.ideal_arm:      # IdealJointControlledTcpArm.reset (:132-134): joint positions, then the controller arm's solver.reset() on the same simulation
+            s.ctrl[self.main.grip_act] = s.qpos[self.main.grip_q]
+            reset_mocap_welds(self.main)
+            reset_mocap2body_xpos(self.main)
+            return
         s.ctrl[:6] = TABLETOP_EXPERIMENT_INITIAL_POS
         s.ctrl[self.main.grip_act] = s.qpos[self.main.grip_q]
         if self.joint_control:
@@ -355,6 +364,16 @@ class OracleRearrangeEnv:
     def set_control(self, arm, grip):
         """CompositeRobot.set_position_control with DENORMALISED controls: arm = (dx, dy, dz, roll, pitch/yaw -> J6), grip = the gripper's control target"""
         m, c = self.main, self.solver
+        if self.ideal_arm:
+            # IdealJointControlledTcpArm.set_position_control -> FreeDOFTcpArm.set_position_control on the main simulation, no autostep (:67-76); the TCP's frame is
+            # the one of the last forward (= the kinematics of the current qpos: nothing has moved since)
+            m.sim.fwd_position()
+            j6 = m.model.names["joint"].index("robot0:J6")
+            lo, hi = m.model.arrays["jnt_range"][j6]
+            pos, dq = tcp_quat_control(arm, m.sim.qpos[m.arm_q[5]], lo, hi, m.body_xquat(m.tcp_body))
+            mocap_set_action(m, np.concatenate([pos, dq]))
+            m.sim.ctrl[m.grip_act] = grip
+            return
         if self.joint_control:
             m.sim.ctrl[:6] = arm                                    # JointControlledArm.set_position_control (joint_controlled_arm.py:186-190)
             m.sim.ctrl[m.grip_act] = grip
@@ -376,7 +395,7 @@ class OracleRearrangeEnv:
         """RobotEnv._observe_sync: one more mj_forward, goal info, observation, robots notified (gripper state -> solver world)."""
         self.main.sim.forward()
         obs = self.observe()
-        if self.joint_control:
+        if self.joint_control or self.ideal_arm:
             return obs
         c = self.solver
         c.sim.qpos[c.grip_q] = obs["gripper_qpos"][0]

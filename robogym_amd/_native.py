@@ -74,7 +74,8 @@ class RbTcpArgs(ctypes.Structure):
                 ("wrist_joint", ctypes.c_int), ("reset_controller_error", ctypes.c_int), ("max_position_change", ctypes.c_float), ("speed_roll", ctypes.c_float),
                 ("speed_pitch", ctypes.c_float), ("joint_drift_threshold", ctypes.c_float), ("gripper_ctrl_lo", ctypes.c_float), ("gripper_ctrl_hi", ctypes.c_float),
                 ("action_index", ctypes.c_void_p), ("bins", ctypes.c_void_p), ("nbins", ctypes.c_int), ("ema_alpha", ctypes.c_float),
-                ("ema_value", ctypes.c_void_p), ("ema_t", ctypes.c_void_p), ("action_out", ctypes.c_void_p), ("hold", ctypes.c_void_p), ("scripted", ctypes.c_void_p), ("wrist_only", ctypes.c_int)]
+                ("ema_value", ctypes.c_void_p), ("ema_t", ctypes.c_void_p), ("action_out", ctypes.c_void_p), ("hold", ctypes.c_void_p), ("scripted", ctypes.c_void_p), ("wrist_only", ctypes.c_int), ("self_world", ctypes.c_int), ("nforward_ticks", ctypes.c_int),
+                ("nticks", ctypes.c_void_p), ("skip", ctypes.c_void_p)]
 
 
 RA_MAXOBJ = 16
@@ -124,7 +125,7 @@ EXPORTS = [
     "rb_model_create", "rb_model_free", "rb_model_info", "rb_scratch_offset", "rb_batch_create", "rb_batch_free", "rb_batch_reset", "rb_batch_set_env",
     "rb_batch_field_ptr", "rb_batch_step", "rb_batch_step_ex", "rb_env_post_step", "rb_post_args_size", "rb_cube_ops", "rb_batch_step_tcp", "ra_env_post_step", "ra_post_args_size",
     "rg_blob_entry", "rg_model_blob_keys", "rb_model_blob_keys", "rg_compile_mjcf", "rb_compile_mjcf", "rg_compile_mjcf_blob", "rg_blob_free",
-    "rb_model_enable_env_params", "rb_prm_layout", "rb_batch_set_action_limits", "ra_env_recipe_step", "ra_recipe_args_size",
+    "rb_model_enable_env_params", "rb_prm_layout", "rb_batch_set_action_limits", "ra_env_recipe_step", "ra_recipe_args_size", "rb_tcp_args_size",
 ]
 
 
@@ -201,6 +202,9 @@ def bind(path):
     L.rb_batch_step.argtypes = [vp, vp, vp, ci, ci, ci, vp]
     L.rb_batch_step_ex.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, vp]
     L.rb_batch_step_tcp.argtypes = [vp, vp, vp, vp, ctypes.POINTER(RbTcpArgs), ci, ci, vp]
+    L.rb_tcp_args_size.restype = ci
+    if L.rb_tcp_args_size() != ctypes.sizeof(RbTcpArgs):
+        raise NativeError("rb_tcp_args layout mismatch between include/rgstep.h and robogym_amd/_native.py")
     L.ra_env_post_step.argtypes = [vp, vp, ctypes.POINTER(RaPostArgs), vp]
     L.ra_post_args_size.restype = ci
     if L.ra_post_args_size() != ctypes.sizeof(RaPostArgs):

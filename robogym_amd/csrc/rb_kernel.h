@@ -2544,7 +2544,8 @@ __global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbMod
   BSYNC();
   // ---- the TCP solver hook (RbTcpHook): arm joints <- main simulation, forward(), mocap target <- TCP pose + denormalised action
   float tcp_grip_action = 0.f;
-  if (L.tcp.enabled) {
+  const bool tcp_on = L.tcp.enabled && !(L.tcp.skip && L.tcp.skip[e] != 0);
+  if (tcp_on) {
     if (L.tcp.sync) { if (TID < 6) s.qpos[L.tcp.arm_q[TID]] = L.tcp.main_qpos[(size_t)e * L.tcp.main_nq + L.tcp.main_arm_q[TID]]; }
     BSYNC();
     sb_position(c); sb_tendon(c);
@@ -2608,6 +2609,10 @@ __global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbMod
       const v3 tp = ld3(SC(XPOS) + 3 * L.tcp.tcp_body);
       s.mocap[0] = tp.x + a0 * mpc; s.mocap[1] = tp.y + a1 * mpc; s.mocap[2] = tp.z + a2 * mpc;
       s.mocap[3] = gq.w + (tq.w - gq.w); s.mocap[4] = gq.x + (tq.x - gq.x); s.mocap[5] = gq.y + (tq.y - gq.y); s.mocap[6] = gq.z + (tq.z - gq.z);
+      if (L.tcp.self_world) {   // MujocoRobotiqGripper.set_position_control on THIS world, before its mj_steps (CompositeRobot.set_position_control, then mujoco_simulation.step())
+        float* gc = s.ctrl + L.tcp.main_grip_act;
+        *gc = clampf(*gc + clampf(tcp_grip_action, -1.f, 1.f) * 0.5f * (L.tcp.grip_hi - L.tcp.grip_lo), L.tcp.grip_lo, L.tcp.grip_hi);
+      }
     }
     BSYNC();
   }
@@ -2655,7 +2660,7 @@ __global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbMod
     if (m.nsensor > 0 && L.bt.sensordata) sb_sensors(c);
     if (TID == 0) { SC(DBG)[3] = (float)s.ncon; SC(DBG)[4] = (float)s.nefc; SC(DBG)[5] = (float)s.neqcon; }   // what the env kernel's contact scans read
   }
-  if (L.tcp.enabled) {
+  if (tcp_on && !L.tcp.self_world) {
     // JointControlledArm.set_position_control: main ctrl[:6] <- the solver's joint angles; MujocoRobotiqGripper: a relative target around its current ctrl
     if (TID < 6) L.tcp.main_ctrl[(size_t)e * L.tcp.main_nu + TID] = s.qpos[L.tcp.arm_q[TID]];
     if (TID == 6) {

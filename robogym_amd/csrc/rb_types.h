@@ -177,5 +177,7 @@ struct RbTcpHook {
   float* action_out;                 // [B][6] the action that reached the env (= obs["action_ema"]); may be null
   const int* hold; const float* scripted;   // [B], [B][6]: envs inside their reset recipe take a scripted continuous action (and leave the filter alone); may be null
   int wrist_only;                    // control_mode tcp+wrist: no roll, the commanded orientation aligned with the vertical (MocapSolver.align_axis)
+  int self_world;                    // tcp_solver_mode mocap: this world IS the env's world (no sync, no hand-over; the gripper target goes into its own ctrl before the steps)
+  const int* skip;                   // [B] or null: envs whose robot gets no command in this launch
 };
 struct RbLaunch { RbEnvDev env; RbBatchDev bt; int nsubsteps, nforward_ticks, flags; RbTcpHook tcp; };

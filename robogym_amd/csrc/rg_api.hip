@@ -1368,9 +1368,11 @@ static void emul_rbs_entry(void* a) { EmulRbArgs* p = (EmulRbArgs*)a; rgbs::rb_s
 static void emul_rbm_entry(void* a) { EmulRbArgs* p = (EmulRbArgs*)a; rgbm::rb_step_kernel(p->m, p->launch); }
 #endif
 int rb_batch_step_ex(rb_batch* b, const float* action_dev, const int* active_dev, const int* hold_dev, const int* nticks_dev, int nsubsteps, int nforward_ticks, int flags, void* stream);
+int rb_tcp_args_size(void) { return (int)sizeof(rb_tcp_args); }
 static thread_local const RbTcpHook* g_tcp_hook = nullptr;   // set by rb_batch_step_tcp around its launch
 // JointControlledTcpArm.set_position_control as ONE launch of the solver simulation (RbTcpHook, rb_types.h)
 int rb_batch_step_tcp(rb_batch* solver, rb_batch* main_batch, const float* action_dev, const int* active_dev, const rb_tcp_args* a, int nsubsteps, int flags, void* stream) {
+  if (a && a->self_world) main_batch = solver;      // tcp_solver_mode mocap: one world
   if (!solver || !main_batch || !a || (!action_dev && !a->action_index)) return fail("rb_batch_step_tcp: null argument");
   if ((a->hold != nullptr) != (a->scripted != nullptr)) return fail("rb_batch_step_tcp: hold and scripted go together");
   if (a->action_index && (!a->bins || a->nbins < 1)) return fail("rb_batch_step_tcp: action_index needs bins");
@@ -1378,7 +1380,10 @@ int rb_batch_step_tcp(rb_batch* solver, rb_batch* main_batch, const float* actio
   if (solver->dev.B != main_batch->dev.B || solver->device != main_batch->device) return fail("rb_batch_step_tcp: the two batches must have the same size and device");
   const RbModelDev& ds = solver->model->dev; const RbModelDev& dm = main_batch->model->dev;
   if (ds.nmocap != 1) return fail("rb_batch_step_tcp: the solver model needs exactly one mocap body");
-  if (dm.nu < 6) return fail("rb_batch_step_tcp: the main model's first six actuators must be the arm's (JointControlledArm.set_position_control writes ctrl[:6])");
+  if (!a->self_world && dm.nu < 6) return fail("rb_batch_step_tcp: the main model's first six actuators must be the arm's (JointControlledArm.set_position_control writes ctrl[:6])");
+  if (a->self_world && a->reset_controller_error) return fail("rb_batch_step_tcp: self_world has no second arm to synchronise (reset_controller_error must be 0)");
+  if (!a->self_world && (a->nforward_ticks != 0 || a->nticks)) return fail("rb_batch_step_tcp: nforward_ticks / nticks belong to self_world (the solver's own world takes no state-less forwards)");
+  if (a->nforward_ticks < 0) return fail("rb_batch_step_tcp: negative nforward_ticks");
   for (int k = 0; k < 6; k++) if (a->arm_qposadr[k] < 0 || a->arm_qposadr[k] >= ds.nq || a->main_arm_qposadr[k] < 0 || a->main_arm_qposadr[k] >= dm.nq) return fail("rb_batch_step_tcp: joint address out of range");
   if (a->main_gripper_actuator < 0 || a->main_gripper_actuator >= dm.nu || a->tcp_body <= 0 || a->tcp_body >= ds.nbody || a->wrist_joint < 0 || a->wrist_joint >= ds.njnt) return fail("rb_batch_step_tcp: id out of range");
   RbTcpHook h; memset(&h, 0, sizeof h);
@@ -1389,9 +1394,9 @@ int rb_batch_step_tcp(rb_batch* solver, rb_batch* main_batch, const float* actio
   h.max_position_change = a->max_position_change; h.speed[0] = a->speed_roll; h.speed[1] = a->speed_pitch; h.drift_threshold = a->joint_drift_threshold;
   h.grip_lo = a->gripper_ctrl_lo; h.grip_hi = a->gripper_ctrl_hi;
   h.action_index = a->action_index; h.bins = a->bins; h.nbins = a->nbins; h.ema_alpha = a->ema_alpha; h.ema_value = a->ema_value; h.ema_t = a->ema_t; h.action_out = a->action_out; h.hold = a->hold; h.scripted = a->scripted;
-  h.wrist_only = a->wrist_only != 0;
+  h.wrist_only = a->wrist_only != 0; h.self_world = a->self_world != 0; h.skip = a->skip;
   g_tcp_hook = &h;
-  const int rc = rb_batch_step_ex(solver, nullptr, active_dev, nullptr, nullptr, nsubsteps, 0, flags, stream);
+  const int rc = rb_batch_step_ex(solver, nullptr, active_dev, nullptr, a->self_world ? a->nticks : nullptr, nsubsteps, a->self_world ? a->nforward_ticks : 0, flags, stream);
   g_tcp_hook = nullptr;
   return rc;
 }

@@ -24,7 +24,10 @@ runs at the head of the main world's launch (rb_batch_set_action_limits) -- TWO 
 `control_mode = "tcp+wrist"` (FreeWristTcpArm, free_dof_tcp_arm.py:238-246): `step(actions[B, 5])` = xyz, wrist, gripper; the solver world's launch ignores the roll number
 and aligns the commanded orientation with the vertical (rb_tcp_args.wrist_only).
 
-Not built for this env: vision, `teleport_to_goal`, masks of the placement area, duplicated-object groups, tcp_solver_mode mocap.
+`tcp_solver_mode = "mocap"` (MujocoIdealURGripperCompositeRobot, composite/ur_gripper_arm.py:126-128): the main world's arm on the mocap weld, no joint actuators, no solver
+world; the hook runs on the env's own world (rb_tcp_args.self_world) -- ONE physics launch per step.  Blocks, synchronous reset.
+
+Not built for this env: vision, `teleport_to_goal`, masks of the placement area, duplicated-object groups.
 """
 import ctypes
 from typing import Optional
@@ -62,7 +65,7 @@ class BatchedBlockRearrangeEnv:
                  use_goal_distance_reward: bool = True, goal_reward_per_object: float = 1.0, used_table_portion: float = 1.0, lib=None, n_substeps: int = 40,
                  main_model=None, wrappers: bool = False, n_action_bins: int = 11, smooth_alpha: float = 0.3, reward_clip: float = 100.0,
                  pipelined_reset: bool = False, action_spacing: str = "linear", per_env_parameters: bool = True, randomizer_params: Optional[dict] = None,
-                 stabilize_object_damping: float = 1.0e-3, control_mode: str = "tcp+roll+yaw", device_reset: bool = False):
+                 stabilize_object_damping: float = 1.0e-3, control_mode: str = "tcp+roll+yaw", device_reset: bool = False, tcp_solver_mode: str = "mocap_ik"):
         """`per_env_parameters`: every env carries its own copy of the randomisable model fields (`self.sim.params`, LargeModelSimulation(env_params=True)) -- what
         the reference's simulation randomizers and `stabilize_objects` write into `sim.model`.  On by default (measured cost: 0.7 % of the step,
         profiles/r05_ab_rb_env_params.txt); off: the model's own arrays, no randomizers, no damping change while the objects stabilise.
@@ -79,13 +82,22 @@ class BatchedBlockRearrangeEnv:
         self.launch_action_dim = AD
         self.max_position_change = float(max_position_change)
         main = main_model if main_model is not None else load_blocks_model(self.N)   # (main_model: the same world with other objects, envs/rearrange/ycb.py)
-        solver = None if self.joint_control else load_solver_model()
+        # TcpSolverMode.MOCAP (robot_interface.py:22-29): the MAIN world's arm hangs on the mocap weld itself -- MujocoIdealURGripperCompositeRobot, one world, no joint actuators
+        self.tcp_solver_mode = _solver_mode_name(tcp_solver_mode)
+        self.ideal_arm = self.tcp_solver_mode == "mocap" and not self.joint_control
+        if self.ideal_arm:
+            if main_model is not None:
+                raise NotImplementedError("tcp_solver_mode mocap is built for the blocks world (its mocap-arm model is shipped; the ycb sets are compiled with joint actuators)")
+            if pipelined_reset or device_reset:
+                raise NotImplementedError("tcp_solver_mode mocap with pipelined resets: the synchronous reset() only (the reference's sim initialisation steps the world before the recipe)")
+            main = load_blocks_model(self.N, mocap_arm=True)
+        solver = None if (self.joint_control or self.ideal_arm) else load_solver_model()
         self.randomizer_params = dict(randomizer_params or {})
         self.per_env_parameters = bool(per_env_parameters)
         if self.randomizer_params and not self.per_env_parameters:
             raise ValueError("randomizer_params need per_env_parameters=True")
         self.sim = LargeModelSimulation(main, self.B, device=device, n_substeps=n_substeps, lib=lib, hand=False, env_params=self.per_env_parameters)
-        self.solver_sim = None if self.joint_control else LargeModelSimulation(solver, self.B, device=device, n_substeps=n_substeps, lib=lib, hand=False)
+        self.solver_sim = None if solver is None else LargeModelSimulation(solver, self.B, device=device, n_substeps=n_substeps, lib=lib, hand=False)
         self.device = self.sim.device
         self._ext_cols = torch.tensor([0, 1, 2, 4, 5], device=self.device) if self.wrist_only else None      # tcp+wrist: the launch's columns without the roll
         self.model, self.solver_model = main, solver
@@ -117,6 +129,17 @@ class BatchedBlockRearrangeEnv:
             P = np.zeros((7, 6), dtype=np.float32); P[:6] = np.eye(6)
             self.sim.set_action_map(self.arm_q[0], P, relative_action=True, max_position_change=float(max_position_change), ctrl_centre_mask=1 << self.grip_act)
             self.solver_arm_q, self.solver_grip_q, self.solver_grip_act = [], -1, -1
+        elif self.ideal_arm:
+            # the hook on the env's own world (rb_tcp_args.self_world): TCP pose + denormalised action -> mocap target, gripper target into this world's ctrl, then its mj_steps
+            assert self.nu == 1 and self.grip_act == 0 and int(A["body_mocapid"][main.name2id("body", "robot0:mocap")]) == 0
+            for k in range(6):
+                t.arm_qposadr[k] = t.main_arm_qposadr[k] = self.arm_q[k]
+            t.main_gripper_actuator = self.grip_act; t.tcp_body = main.name2id("body", "robot0:gripper_tcp"); t.wrist_joint = jn.index("robot0:J6")
+            t.reset_controller_error = 0; t.self_world = 1; t.wrist_only = 1 if self.wrist_only else 0
+            t.max_position_change = max_position_change; t.speed_roll = SPEED_ROLL; t.speed_pitch = SPEED_PITCH; t.joint_drift_threshold = JOINT_DRIFT_THRESHOLD
+            t.gripper_ctrl_lo, t.gripper_ctrl_hi = float(A["actuator_ctrlrange"][self.grip_act, 0]), float(A["actuator_ctrlrange"][self.grip_act, 1])
+            self.solver_arm_q, self.solver_grip_q, self.solver_grip_act = [], -1, -1
+            self._tcp_body, self._gripper_base_body = int(t.tcp_body), main.name2id("body", "robot0:gripper_base")
         else:
             for k in range(6):
                 t.arm_qposadr[k] = int(As["jnt_qposadr"][sj.index("robot0:J%d" % (k + 1))]); t.main_arm_qposadr[k] = self.arm_q[k]
@@ -277,6 +300,13 @@ class BatchedBlockRearrangeEnv:
             self.sim.env_step(action=self._keep_act, nforward_ticks=2, flags=FLAG_FULL_FORWARD, active=active, nticks=self.nticks if self.pipelined else None,
                               hold=self.hold_ctrl if self.pipelined else None)
             return
+        if self.ideal_arm:         # one launch: the hook on this world, its mj_steps, the two state-less forwards (the last in full)
+            args = self.tcp_wrapped if wrapped else self.tcp
+            if wrapped:
+                args.action_index = actions.data_ptr(); self._keep_idx = actions
+            args.nforward_ticks = 2
+            self.sim.step_tcp(self.sim, None if wrapped else actions, args, flags=FLAG_FULL_FORWARD, active=active)
+            return
         sa = active if solver_active is None else solver_active      # (pipelined resets: envs that are settling their objects skip the solver world)
         if wrapped:       # `actions`: int32 bin indices through the wrapper stack's action path
             self.tcp_wrapped.action_index = actions.data_ptr()
@@ -293,6 +323,10 @@ class BatchedBlockRearrangeEnv:
         launch, the main world's mj_steps with ONE state-less forward (MjSim.step), no _observe_sync: no second forward, no gripper hand-over to the solver world."""
         if self.joint_control:
             self.sim.env_step(action=actions, nforward_ticks=1, active=active)
+            return
+        if self.ideal_arm:
+            self.tcp.nforward_ticks = 1
+            self.sim.step_tcp(self.sim, actions, self.tcp, active=active)
             return
         self.solver_sim.step_tcp(self.sim, actions, self.tcp, active=active)
         self.sim.env_step(nforward_ticks=1, active=active)
@@ -445,8 +479,13 @@ class BatchedBlockRearrangeEnv:
             sim.view(_native.RG_F_TIME)[idx] = 0
             sim.view(_native.RG_F_STATUS)[idx] = 0
         arm0 = torch.tensor(TABLETOP_EXPERIMENT_INITIAL_POS.astype(np.float32), device=dev)
+        if self.ideal_arm:
+            self._initialize_mocap_world(idx)
         self.sim.qpos[idx[:, None], torch.tensor(self.arm_q, device=dev)] = arm0
-        self.sim.ctrl[idx, :6] = arm0
+        if self.ideal_arm:       # IdealJointControlledTcpArm.reset: joint positions, then solver.reset() = reset_mocap_welds (with its forward) + reset_mocap2body_xpos
+            self._mocap_to_body(idx, self._tcp_body)
+        else:
+            self.sim.ctrl[idx, :6] = arm0
         if self.solver_sim is not None:
             self.solver_sim.qpos[idx[:, None], torch.tensor(self.solver_arm_q, device=dev)] = arm0
             self.solver_sim.eq_data[idx, :7] = torch.tensor([0, 0, 0, 1, 0, 0, 0], dtype=torch.float32, device=dev)     # reset_mocap_welds
@@ -460,6 +499,23 @@ class BatchedBlockRearrangeEnv:
         so = np.concatenate([np.broadcast_to(self._aabb_half(yaw), (len(rows), N, 3)), colors], -1)
         self.static_obs[idx] = torch.tensor(so.astype(np.float32), device=dev)
         return yaw
+
+    def _mocap_to_body(self, idx, body):
+        """reset_mocap_welds + "mocap pose <- that body's pose" for the envs `idx`: the weld's relative pose back to identity, one forward (kinematics + the controller
+        tick of mj_forward), the mocap row from the body's frame (gym.envs.robotics.utils.reset_mocap_welds / reset_mocap2body_xpos)."""
+        active = torch.zeros(self.B, dtype=torch.int32, device=self.device); active[idx] = 1
+        self.sim.eq_data[idx, :7] = torch.tensor([0, 0, 0, 1, 0, 0, 0], dtype=torch.float32, device=self.device)
+        self.sim.env_step(nsubsteps=0, nforward_ticks=1, active=active)
+        xp, xq = self.sim.scratch("xpos"), self.sim.scratch("xquat")
+        self.sim.mocap[idx] = torch.cat([xp[idx, 3 * body:3 * body + 3], xq[idx, 4 * body:4 * body + 4]], 1)
+
+    def _initialize_mocap_world(self, idx):
+        """RearrangeEnv._initialize_sim_state for a mocap-actuated arm (common/base.py:448-465): welds reset, forward, the mocap body put at the pose of
+        robot0:gripper_base, ten simulation steps (the weld pulls the TCP there)."""
+        active = torch.zeros(self.B, dtype=torch.int32, device=self.device); active[idx] = 1
+        self._mocap_to_body(idx, self._gripper_base_body)
+        for _ in range(10):
+            self.sim.env_step(nforward_ticks=1, active=active)
 
     def reset(self, mask: Optional[torch.Tensor] = None):
         """RobotEnv.reset -> RearrangeEnv._reset (common/base.py:897-932): robot start pose, object rotations + grid placement, stabilisation
@@ -721,6 +777,14 @@ def _control_mode_name(mode) -> str:
     raise ValueError("control_mode %r is not one of the reference's ControlMode values (joint, tcp+roll+yaw, tcp+wrist; robot_interface.py:9-20)" % (mode,))
 
 
+def _solver_mode_name(mode) -> str:
+    """`TcpSolverMode` value or name (robot_interface.py:22-29) -> "mocap_ik" | "mocap"."""
+    name = str(getattr(mode, "value", mode)).lower().split(".")[-1]
+    if name in ("mocap_ik", "mocap"):
+        return name
+    raise ValueError("tcp_solver_mode %r is not one of the reference's TcpSolverMode values (mocap, mocap_ik)" % (mode,))
+
+
 def _check_supported(parameters, sp, rc, constants):
     """A parameter or constant of the reference's env that this env does not implement is an error, not a silently ignored key (the reference's attrs classes reject
     unknown names the same way; the supported subset keeps the reference's names and meaning)."""
@@ -730,8 +794,7 @@ def _check_supported(parameters, sp, rc, constants):
         if unknown:
             raise NotImplementedError("%s: %s not implemented by the batched rearrange env (supported: %s)" % (where, ", ".join(unknown), ", ".join(sorted(known))))
     _control_mode_name(rc.get("control_mode", "tcp+roll+yaw"))
-    if str(rc.get("tcp_solver_mode", "mocap_ik")).lower().split(".")[-1] != "mocap_ik":
-        raise NotImplementedError("tcp_solver_mode other than mocap_ik (the reference's default, robot_interface.py:54-58)")
+    _solver_mode_name(rc.get("tcp_solver_mode", "mocap_ik"))
 
 
 def make_env(batch_size: int = 4096, device="cuda:0", parameters=None, constants=None, starting_seed: int = 0, apply_wrappers: bool = True, **kw):
@@ -743,7 +806,7 @@ def make_env(batch_size: int = 4096, device="cuda:0", parameters=None, constants
     _check_supported(parameters, sp, rc, constants)
     args = dict(num_objects=sp.get("num_objects", 5), max_position_change=rc.get("max_position_change", 0.1), arm_reset_controller_error=rc.get("arm_reset_controller_error", True),
                 n_random_initial_steps=parameters.get("n_random_initial_steps", 10), starting_seed=starting_seed, wrappers=bool(apply_wrappers),
-                n_action_bins=constants.get("n_action_bins", 11), control_mode=rc.get("control_mode", "tcp+roll+yaw"))      # (+ pipelined_reset=True through **kw: episodes restart inside the step calls)
+                n_action_bins=constants.get("n_action_bins", 11), control_mode=rc.get("control_mode", "tcp+roll+yaw"), tcp_solver_mode=rc.get("tcp_solver_mode", "mocap_ik"))      # (+ pipelined_reset=True through **kw: episodes restart inside the step calls)
     if "action_spacing" in constants:
         args["action_spacing"] = constants["action_spacing"]
     for k in ("success_threshold", "successes_needed", "success_reward", "max_timesteps_per_goal_per_obj", "use_goal_distance_reward", "goal_reward_per_object"):

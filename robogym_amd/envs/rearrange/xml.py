@@ -180,12 +180,14 @@ from robogym_amd.mujoco.mjcf_compiler import CompiledModel  # noqa: E402
 MODEL_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "models")
 
 
-def load_blocks_model(num_objects: int = 5, recompile: bool = False) -> CompiledModel:
-    """The main world of rearrange/blocks with `num_objects` blocks (BASELINE.json configs[3]: num_objects = 5)."""
-    path = os.path.join(MODEL_DIR, "rearrange_blocks%d.npz" % num_objects)
+def load_blocks_model(num_objects: int = 5, recompile: bool = False, mocap_arm: bool = False) -> CompiledModel:
+    """The main world of rearrange/blocks with `num_objects` blocks (BASELINE.json configs[3]: num_objects = 5).  `mocap_arm`: tcp_solver_mode = mocap
+    (ArmSimulationInterface.make_robot_xml's other branch, robot/ur16e/mujoco/simulation/base.py:89-114: the mocap weld stays, no joint actuators, the mocap
+    joint class) -- the arm of MujocoIdealURGripperCompositeRobot."""
+    path = os.path.join(MODEL_DIR, "rearrange_blocks%d%s.npz" % (num_objects, "_mocap" if mocap_arm else ""))
     if not recompile and os.path.exists(path):
         return CompiledModel.load(path)
-    return build_blocks_xml(num_objects).build()
+    return build_blocks_xml(num_objects, joint_actuated=not mocap_arm).build()
 
 
 def load_solver_model(recompile: bool = False) -> CompiledModel:

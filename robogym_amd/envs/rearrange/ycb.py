@@ -182,7 +182,7 @@ def make_env(batch_size: int = 4096, device="cuda:0", parameters=None, constants
     _check_supported({k: v for k, v in parameters.items() if k != "mesh_names"}, sp, rc, constants)
     args = dict(num_objects=sp.get("num_objects", 8), max_position_change=rc.get("max_position_change", 0.1), arm_reset_controller_error=rc.get("arm_reset_controller_error", True),
                 n_random_initial_steps=parameters.get("n_random_initial_steps", 10), starting_seed=starting_seed, wrappers=bool(apply_wrappers),
-                n_action_bins=constants.get("n_action_bins", 11))
+                n_action_bins=constants.get("n_action_bins", 11), control_mode=rc.get("control_mode", "tcp+roll+yaw"), tcp_solver_mode=rc.get("tcp_solver_mode", "mocap_ik"))
     if "action_spacing" in constants:
         args["action_spacing"] = constants["action_spacing"]
     for k in ("success_threshold", "successes_needed", "success_reward", "max_timesteps_per_goal_per_obj", "use_goal_distance_reward", "goal_reward_per_object"):

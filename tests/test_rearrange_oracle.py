@@ -553,9 +553,16 @@ def test_make_env_rejects_what_it_does_not_implement():
 
     for mk in (Bk.make_env, Yc.make_env):
         for bad in (dict(constants={"success_pause_range_s": (1.0, 1.0)}), dict(parameters={"simulation_params": {"object_groups": []}}),
-                    dict(parameters={"robot_control_params": {"tcp_solver_mode": "mocap"}}), dict(parameters={"object_scale_high": 0.5})):
+                    dict(parameters={"object_scale_high": 0.5})):
             with pytest.raises(NotImplementedError):
                 mk(batch_size=1, device="cpu", **bad)
+        with pytest.raises(ValueError):
+            mk(batch_size=1, device="cpu", parameters={"robot_control_params": {"tcp_solver_mode": "ik"}})
+    # tcp_solver_mode mocap: built for the blocks world with the synchronous reset; the ycb sets and pipelined resets say so
+    with pytest.raises(NotImplementedError):
+        Yc.make_env(batch_size=1, device="cpu", parameters={"robot_control_params": {"tcp_solver_mode": "mocap"}})
+    with pytest.raises(NotImplementedError):
+        Bk.make_env(batch_size=1, device="cpu", parameters={"robot_control_params": {"tcp_solver_mode": "mocap"}}, pipelined_reset=True)
         with pytest.raises(ValueError):
             mk(batch_size=1, device="cpu", parameters={"robot_control_params": {"control_mode": "tcp+pitch"}})
     assert [Bk._control_mode_name(x) for x in ("joint", "tcp+roll+yaw", "tcp+wrist", "ControlMode.TCP_WRIST")] == ["joint", "tcp+roll+yaw", "tcp+wrist", "tcp+wrist"]

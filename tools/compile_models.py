@@ -21,7 +21,7 @@ from robogym_amd.envs.rearrange.xml import YCB_SHIPPED_SETS, build_blocks_xml, b
 def main():
     os.makedirs(MODEL_DIR, exist_ok=True)
     for name, build in (("dactyl_locked", build_locked_xml), ("dactyl_reach", build_reach_xml), ("dactyl_full_perpendicular", build_full_perpendicular_xml),
-                        ("rearrange_blocks5", lambda: build_blocks_xml(5)), ("ur16e_solver", build_solver_xml),
+                        ("rearrange_blocks5", lambda: build_blocks_xml(5)), ("rearrange_blocks5_mocap", lambda: build_blocks_xml(5, joint_actuated=False)), ("ur16e_solver", build_solver_xml),
                         ("rearrange_ycb8", lambda: load_ycb_model(8, recompile=True)),    # (a fixed object set: envs/rearrange/xml.py YCB_MODEL_SEED)
                         ) + tuple(("rearrange_ycb8_s%d" % k, (lambda k=k: load_ycb_model(8, recompile=True, set_index=k))) for k in YCB_SHIPPED_SETS[1:]):
         model = build()
