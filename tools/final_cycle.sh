@@ -8,8 +8,6 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider > gpurun_out/gpu_tests_$R.txt 2>&1
 tail -4 gpurun_out/gpu_tests_$R.txt
-( time python bench.py --steps 20 --warmup 5 ) > gpurun_out/bench_$R.json 2> gpurun_out/bench_$R.err
-tail -3 gpurun_out/bench_$R.err; tail -1 gpurun_out/bench_$R.json | cut -c1-200
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$R -o $R --output-format csv -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > gpurun_out/bench_prof_$R.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_fetch_$R -o fetch --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > gpurun_out/pmc_fetch_$R.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_write_$R -o write --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > gpurun_out/pmc_write_$R.log 2>&1
@@ -19,6 +17,11 @@ for W in full_perpendicular rearrange_blocks ycb; do
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_fetch_${W}_$R -o fetch --output-format csv -- python bench.py --workload $W $X --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > gpurun_out/pmc_fetch_${W}_$R.log 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_write_${W}_$R -o write --output-format csv -- python bench.py --workload $W $X --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > gpurun_out/pmc_write_${W}_$R.log 2>&1
 done
+# the PMC figures of THIS build are stamped (profiles/hbm_traffic.json, on this box's copy) before the bench line runs, so that the line carries them (`roofline.traffic`)
+python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > gpurun_out/bench_$R.json 2> /dev/null      # (a short line for the summariser to read the batch size from)
+python tools/summarize_profile.py $R > /dev/null 2>&1
+( time python bench.py --steps 20 --warmup 5 ) > gpurun_out/bench_$R.json 2> gpurun_out/bench_$R.err
+tail -3 gpurun_out/bench_$R.err; tail -1 gpurun_out/bench_$R.json | cut -c1-200
 python tests/tools/rearrange_parity_report.py 150 60 > gpurun_out/parity_rearrange_$R.txt 2>&1
 python tools/stage_profile.py 8192 > gpurun_out/stage_$R.txt 2>&1
 python tools/rearrange_stage_profile.py 4096 > gpurun_out/rearrange_stage_$R.txt 2>&1
