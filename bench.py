@@ -187,7 +187,7 @@ def bench_rearrange_blocks(args, emit=True, ycb=False, joint=False):
     ev = [[mk_event() for _ in range(3)] for _ in range(args.steps)]
     orig = env._physics
 
-    def timed(actions, active=None, wrapped=False, solver_active=None, _i=[0]):
+    def timed(actions, active=None, wrapped=False, solver_active=None, phase=None, _i=[0]):
         e = ev[_i[0] % len(ev)]; _i[0] += 1
         rec = lambda x: x.record() if x is not None else None
         if joint:

@@ -375,6 +375,12 @@ typedef struct rb_tcp_args {
 } rb_tcp_args;
 int rb_batch_step_tcp(rb_batch* solver, rb_batch* main, const float* action_dev, const int* active_dev /* [B] or NULL */, const rb_tcp_args* args, int nsubsteps, int flags, void* stream);
 int rb_tcp_args_size(void);   /* sizeof(rb_tcp_args): a binding checks its own layout against it */
+/* Several batches in ONE launch (heterogeneous object sets side by side: /root/reference/robogym/envs/rearrange/ycb.py:58-84 rebuilds the simulation with new objects per
+ * episode -- here a batch per compiled object set).  Between rb_multi_begin and rb_multi_launch the rb_batch_step / _step_ex / _step_tcp calls of the calling thread
+ * validate their arguments and RECORD the launch; rb_multi_launch issues ONE kernel over all recorded batches (same batch size, same one-wave kernel configuration;
+ * at most 8), or one launch each, in order, when they do not match.  Results are those of the separate launches, bit for bit. */
+int rb_multi_begin(void);
+int rb_multi_launch(void* stream);
 /* ---- the env-level half of RearrangeEnv.step (one launch after the two physics launches; robogym_amd/csrc/ra_env_kernel.h lists the
  * reference call sites): the 24-key observation of envs/rearrange/common/base.py:376-421 as one packed row per env — obj_pos 3N | obj_rel_pos 3N |
  * obj_vel_pos 3N | obj_rot 3N | obj_vel_rot 3N | robot_joint_pos 6 | gripper_pos 3 | gripper_velp 3 | gripper_controls 1 | gripper_qpos 1 |

@@ -125,7 +125,7 @@ EXPORTS = [
     "rb_model_create", "rb_model_free", "rb_model_info", "rb_scratch_offset", "rb_batch_create", "rb_batch_free", "rb_batch_reset", "rb_batch_set_env",
     "rb_batch_field_ptr", "rb_batch_step", "rb_batch_step_ex", "rb_env_post_step", "rb_post_args_size", "rb_cube_ops", "rb_batch_step_tcp", "ra_env_post_step", "ra_post_args_size",
     "rg_blob_entry", "rg_model_blob_keys", "rb_model_blob_keys", "rg_compile_mjcf", "rb_compile_mjcf", "rg_compile_mjcf_blob", "rg_blob_free",
-    "rb_model_enable_env_params", "rb_prm_layout", "rb_batch_set_action_limits", "ra_env_recipe_step", "ra_recipe_args_size", "rb_tcp_args_size",
+    "rb_model_enable_env_params", "rb_prm_layout", "rb_batch_set_action_limits", "ra_env_recipe_step", "ra_recipe_args_size", "rb_tcp_args_size", "rb_multi_begin", "rb_multi_launch",
 ]
 
 
@@ -202,6 +202,7 @@ def bind(path):
     L.rb_batch_step.argtypes = [vp, vp, vp, ci, ci, ci, vp]
     L.rb_batch_step_ex.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, vp]
     L.rb_batch_step_tcp.argtypes = [vp, vp, vp, vp, ctypes.POINTER(RbTcpArgs), ci, ci, vp]
+    L.rb_multi_launch.argtypes = [vp]
     L.rb_tcp_args_size.restype = ci
     if L.rb_tcp_args_size() != ctypes.sizeof(RbTcpArgs):
         raise NativeError("rb_tcp_args layout mismatch between include/rgstep.h and robogym_amd/_native.py")

@@ -74,6 +74,7 @@ struct RbLds {
   int wcnt[RB_NWAVE < 4 ? 4 : RB_NWAVE];
   int ncand, ncand2, ncon, nefc, nlim, stop;   // (ncand2: box - box / plane - box candidates, listed from the END of the candidate array)
   int neqcon;            // equality constraints of this mj_step: they are the first records of the contact list
+  int env;               // this workgroup's env in its batch (= blockIdx.x in a one-batch launch; a multi-batch launch, rb_step_multi_kernel, splits blockIdx.x into batch and env)
   float mocap[14];       // pose of the mocap bodies (mjData.mocap_pos / mocap_quat), at most two
   float time;            // mjData.time (the cascaded-PI controller warm-starts its smoothed set-point at time 0)
   unsigned status;
@@ -2474,7 +2475,7 @@ RB_STAGE void sb_crb(RbCtx c) { RB_STAGE_ENTER(); rb_crb(m, s, S); }
 RB_STAGE void sb_velocity(RbCtx c) { RB_STAGE_ENTER(); rb_velocity(m, s, S); }
 RB_STAGE void sb_collision(RbCtx c, int flags) {   // equality pseudo-contacts + broadphase
   RB_STAGE_ENTER(); RbLRef L = RB_L(c);
-  const int e = blockIdx.x;
+  const int e = s.env;
   const float* eqd = m.neq > 0 ? L.bt.eq_data + (size_t)e * 7 * m.neq : (const float*)0;
   const int* eqa = m.neq > 0 ? L.bt.eq_active + (size_t)e * m.neq : (const int*)0;
   rb_equality(m, s, S, eqd, eqa);
@@ -2484,37 +2485,37 @@ RB_STAGE void sb_narrow_convex(RbCtx c, int flags) { RB_STAGE_ENTER(); rb_narrow
 RB_STAGE void sb_narrow_box(RbCtx c, int flags) { RB_STAGE_ENTER(); rb_narrow_box(m, s, S, flags); }
 RB_STAGE void sb_rows(RbCtx c) {
   RB_STAGE_ENTER(); RbLRef L = RB_L(c);
-  const float* eqd = m.neq > 0 ? L.bt.eq_data + (size_t)blockIdx.x * 7 * m.neq : (const float*)0;
+  const float* eqd = m.neq > 0 ? L.bt.eq_data + (size_t)s.env * 7 * m.neq : (const float*)0;
   rb_make_constraint(m, s, S, eqd);
 }
 RB_STAGE void sb_pid(RbCtx c, int apply) { RB_STAGE_ENTER(); rb_pid(m, s, S, apply != 0); }
 RB_STAGE void sb_smooth(RbCtx c, int flags) { RB_STAGE_ENTER(); rb_dof_contact_lists(m, s, S); rb_pid(m, s, S, true); sv_M_solve(c, 0, flags); }
 RB_STAGE int sb_solve(RbCtx c, int flags) { RB_STAGE_ENTER(); return rb_solve(c, m, s, S, flags); }
 RB_STAGE void sb_euler(RbCtx c, int flags) { RB_STAGE_ENTER(); rb_euler(c, m, s, S, flags); }
-RB_STAGE void sb_sensors(RbCtx c) { RB_STAGE_ENTER(); RbLRef L = RB_L(c); rb_sensors(m, s, S, L.bt.sensordata + (size_t)blockIdx.x * m.nsensordata); }
+RB_STAGE void sb_sensors(RbCtx c) { RB_STAGE_ENTER(); RbLRef L = RB_L(c); rb_sensors(m, s, S, L.bt.sensordata + (size_t)s.env * m.nsensordata); }
 
+// The kernel's body for env `e` of the batch described by the launch record at `klp` (in the kernel argument segment) and the model `mp`: one batch per launch
+// (rb_step_kernel) or several batches of several models in ONE launch (rb_step_multi_kernel: heterogeneous object sets side by side at full occupancy instead of one
+// launch chain per set on its own stream, which the GPU runs mostly one after the other -- profiles/r05_ycb_object_sets.txt).
 #ifdef RG_EMUL
-#define RB_MAKE_CTX() const RbModelDev& m = *mp; const RbLaunch& L = launch
+typedef const RbLaunch* RbKlp;
+#define RB_MAKE_CTX() const RbModelDev& m = *mp; const RbLaunch& L = *klp
 #else
-#define RB_MAKE_CTX() RbM m = *(const RG_AS4 RbModelDev*)rg_uniform(mp); RbLRef L = *(const RG_AS4 RbLaunch*)((const RG_AS4 char*)__builtin_amdgcn_kernarg_segment_ptr() + 8)
+typedef const RG_AS4 char* RbKlp;
+#define RB_MAKE_CTX() RbM m = *(const RG_AS4 RbModelDev*)rg_uniform(mp); RbLRef L = *(const RG_AS4 RbLaunch*)klp
 #endif
-__global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbModelDev* mp, RbLaunch launch) {
+__device__ __forceinline__ void rb_step_body(const RbModelDev* mp, RbKlp klp, const int e) {
   RB_MAKE_CTX();
   RbLds& s = RB_S();
-  const int e = blockIdx.x;
   if (e >= L.bt.B) return;
   if (L.bt.active && !L.bt.active[e]) return;
   float* S = L.bt.scratch + (size_t)e * m.scratch_words;
-#ifdef RG_EMUL
-  const RbCtx c{(const void*)mp, (const void*)&launch, S};
-#else
-  const RbCtx c{(const void*)mp, (const void*)((const RG_AS4 char*)__builtin_amdgcn_kernarg_segment_ptr() + 8), S};
-#endif
+  const RbCtx c{(const void*)mp, (const void*)klp, S};
   const int nv = m.nv, nq = m.nq, nu = m.nu, flags = L.flags;
   BFOR(i, nq) s.qpos[i] = L.bt.qpos[(size_t)e * nq + i];
   BFOR(i, nv) { s.qvel[i] = L.bt.qvel[(size_t)e * nv + i]; s.warm[i] = L.bt.qacc_warmstart[(size_t)e * nv + i]; }
   BFOR(i, 3 * nu) s.pid[i] = L.bt.pid[(size_t)e * 3 * nu + i];
-  if (TID == 0) { s.status = L.bt.status[e]; s.stop = 0; s.neqcon = 0; s.time = L.bt.time[e]; }
+  if (TID == 0) { s.status = L.bt.status[e]; s.stop = 0; s.neqcon = 0; s.time = L.bt.time[e]; s.env = e; }
   if (TID < 16) s.prof[TID] = 0.f;
   if (TID < 7 * m.nmocap && TID < 14) s.mocap[TID] = L.bt.mocap[(size_t)e * 7 * m.nmocap + TID];
   const float* eqd = m.neq > 0 ? L.bt.eq_data + (size_t)e * 7 * m.neq : (const float*)0;
@@ -2690,4 +2691,27 @@ __global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbMod
     float* st = L.bt.stats + 4 * (size_t)e; st[0] += st_ncon; st[1] += st_nefc; st[2] += st_iter; st[3] += nsub_done;
   }
 }
+__global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_kernel(const RbModelDev* mp, RbLaunch launch) {
+#ifdef RG_EMUL
+  rb_step_body(mp, &launch, (int)blockIdx.x);
+#else
+  rb_step_body(mp, (const RG_AS4 char*)__builtin_amdgcn_kernarg_segment_ptr() + 8, (int)blockIdx.x);
+#endif
+}
+#if RB_NWAVE == 1
+// several batches (same size, same kernel configuration, each with its own model) in one launch: workgroup k steps env k % group_size of batch k / group_size
+__global__ void __launch_bounds__(RB_T, RB_WG_PER_CU) rb_step_multi_kernel(RbMultiLaunch ml) {
+#ifdef RG_EMUL
+  const int g = (int)blockIdx.x / ml.group_size, e = (int)blockIdx.x - g * ml.group_size;
+  if (g >= ml.n) return;
+  rb_step_body(ml.m[g], &ml.L[g], e);
+#else
+  const RG_AS4 char* ka = (const RG_AS4 char*)__builtin_amdgcn_kernarg_segment_ptr();
+  const RG_AS4 RbMultiLaunch& K = *(const RG_AS4 RbMultiLaunch*)ka;
+  const int g = (int)blockIdx.x / K.group_size, e = (int)blockIdx.x - g * K.group_size;
+  if (g >= K.n) return;
+  rb_step_body(K.m[g], ka + offsetof(RbMultiLaunch, L) + (size_t)g * sizeof(RbLaunch), e);
+#endif
+}
+#endif
 }  // namespace rgb

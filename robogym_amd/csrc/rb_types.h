@@ -181,3 +181,7 @@ struct RbTcpHook {
   const int* skip;                   // [B] or null: envs whose robot gets no command in this launch
 };
 struct RbLaunch { RbEnvDev env; RbBatchDev bt; int nsubsteps, nforward_ticks, flags; RbTcpHook tcp; };
+// several batches of several models stepped by ONE launch (rb_step_multi_kernel; one-wave configurations): the whole record travels in the kernel argument segment
+#define RB_MAXMULTI 8
+struct RbMultiLaunch { int n, group_size; const RbModelDev* m[RB_MAXMULTI]; RbLaunch L[RB_MAXMULTI]; };
+static_assert(sizeof(RbMultiLaunch) <= 4096, "RbMultiLaunch must fit the kernel argument segment");

@@ -1369,7 +1369,51 @@ static void emul_rbm_entry(void* a) { EmulRbArgs* p = (EmulRbArgs*)a; rgbm::rb_s
 #endif
 int rb_batch_step_ex(rb_batch* b, const float* action_dev, const int* active_dev, const int* hold_dev, const int* nticks_dev, int nsubsteps, int nforward_ticks, int flags, void* stream);
 int rb_tcp_args_size(void) { return (int)sizeof(rb_tcp_args); }
-static thread_local const RbTcpHook* g_tcp_hook = nullptr;   // set by rb_batch_step_tcp around its launch
+static thread_local const RbTcpHook* g_tcp_hook = nullptr;
+// ---- several batches in ONE launch (rb_multi_begin / rb_multi_launch): between the two calls the rb_batch_step* entry points of this thread validate and record
+// their launch instead of issuing it
+struct RbCollected { const rb_batch* b; RbLaunch launch; };
+static thread_local std::vector<RbCollected>* g_multi = nullptr;
+#ifdef RG_EMUL
+static void emul_rbs_multi_entry(void* a) { rgbs::rb_step_multi_kernel(*(RbMultiLaunch*)a); }
+static void emul_rbm_multi_entry(void* a) { rgbm::rb_step_multi_kernel(*(RbMultiLaunch*)a); }
+#endif
+static int rb_issue(const rb_batch* b, const RbLaunch& launch, void* stream);
+int rb_multi_begin(void) {
+  if (g_multi) return fail("rb_multi_begin: already collecting");
+  g_multi = new std::vector<RbCollected>();
+  return 0;
+}
+int rb_multi_launch(void* stream) {
+  if (!g_multi) return fail("rb_multi_launch without rb_multi_begin");
+  std::vector<RbCollected> v; v.swap(*g_multi);
+  delete g_multi; g_multi = nullptr;
+  if (v.empty()) return 0;
+  bool same = v.size() <= RB_MAXMULTI;
+  for (const RbCollected& c : v)
+    same = same && c.b->dev.B == v[0].b->dev.B && c.b->device == v[0].b->device && c.b->model->config == v[0].b->model->config && (c.b->model->config == 1 || c.b->model->config == 2) &&
+           c.b->model->dev.lds_words == v[0].b->model->dev.lds_words;
+  if (!same || v.size() == 1) {      // different sizes / configurations (or a single batch): one launch each, in order
+    for (const RbCollected& c : v) { const int rc = rb_issue(c.b, c.launch, stream); if (rc) return rc; }
+    return 0;
+  }
+  DeviceGuard g(v[0].b->device);
+  RbMultiLaunch ml; memset(&ml, 0, sizeof ml);
+  ml.n = (int)v.size(); ml.group_size = v[0].b->dev.B;
+  for (size_t k = 0; k < v.size(); k++) { ml.m[k] = v[k].b->model->dev_copy; ml.L[k] = v[k].launch; }
+  const int total = ml.n * ml.group_size, cfg = v[0].b->model->config;
+#ifdef RG_EMUL
+  const size_t arena = 4 * (size_t)v[0].b->model->dev.lds_words + 16;
+  if (cfg == 1) emul_launch_n(total, RB_T_SMALL, sizeof(rgbs::RbLds) + arena, emul_rbs_multi_entry, &ml);
+  else emul_launch_n(total, RB_T_MEDIUM, sizeof(rgbm::RbLds) + arena, emul_rbm_multi_entry, &ml);
+#else
+  const size_t arena = v[0].b->model->dev.lds_words ? 4 * (size_t)v[0].b->model->dev.lds_words + 16 : 0;
+  if (cfg == 1) hipLaunchKernelGGL(rgbs::rb_step_multi_kernel, dim3(total), dim3(RB_T_SMALL), sizeof(rgbs::RbLds) + arena, (hipStream_t)stream, ml);
+  else hipLaunchKernelGGL(rgbm::rb_step_multi_kernel, dim3(total), dim3(RB_T_MEDIUM), sizeof(rgbm::RbLds) + arena, (hipStream_t)stream, ml);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}   // set by rb_batch_step_tcp around its launch
 // JointControlledTcpArm.set_position_control as ONE launch of the solver simulation (RbTcpHook, rb_types.h)
 int rb_batch_step_tcp(rb_batch* solver, rb_batch* main_batch, const float* action_dev, const int* active_dev, const rb_tcp_args* a, int nsubsteps, int flags, void* stream) {
   if (a && a->self_world) main_batch = solver;      // tcp_solver_mode mocap: one world
@@ -1412,6 +1456,12 @@ int rb_batch_step_ex(rb_batch* b, const float* action_dev, const int* active_dev
   bt.action = action_dev; bt.active = active_dev; bt.hold = hold_dev; bt.nticks = nticks_dev;
   RbLaunch launch{b->env, bt, nsubsteps, nforward_ticks, flags, RbTcpHook{}};
   if (g_tcp_hook) { launch.tcp = *g_tcp_hook; }
+  if (g_multi) { g_multi->push_back(RbCollected{b, launch}); return 0; }
+  return rb_issue(b, launch, stream);
+}
+static int rb_issue(const rb_batch* b, const RbLaunch& launch, void* stream) {
+  const RbBatchDev& bt = launch.bt;
+  DeviceGuard g(b->device);
 #ifdef RG_EMUL
   EmulRbArgs args{b->model->dev_copy, launch};
   const size_t arena = 4 * (size_t)b->model->dev.lds_words + 16;

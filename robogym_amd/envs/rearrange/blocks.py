@@ -294,7 +294,11 @@ class BatchedBlockRearrangeEnv:
             actions = torch.where(self.hold[:, None] != 0, self.scripted, actions)
         return actions.contiguous()
 
-    def _physics(self, actions, active=None, wrapped=False, solver_active=None):
+    def _physics(self, actions, active=None, wrapped=False, solver_active=None, phase=None):
+        """`phase`: None = both physics launches; "solver" / "main" = one of them (envs/rearrange/ycb.py GroupedYcbRearrangeEnv records the same phase of every group and
+        issues it as ONE launch, rb_multi_begin / rb_multi_launch)."""
+        if phase == "solver" and (self.joint_control or self.ideal_arm):
+            return                        # one-world robots have no solver phase
         if self.joint_control:     # CompositeRobot.set_position_control at the head of the main world's launch; no solver world
             self._keep_act = self._joint_action(actions, wrapped)
             self.sim.env_step(action=self._keep_act, nforward_ticks=2, flags=FLAG_FULL_FORWARD, active=active, nticks=self.nticks if self.pipelined else None,
@@ -308,12 +312,17 @@ class BatchedBlockRearrangeEnv:
             self.sim.step_tcp(self.sim, None if wrapped else actions, args, flags=FLAG_FULL_FORWARD, active=active)
             return
         sa = active if solver_active is None else solver_active      # (pipelined resets: envs that are settling their objects skip the solver world)
-        if wrapped:       # `actions`: int32 bin indices through the wrapper stack's action path
+        if phase == "main":
+            pass
+        elif wrapped:       # `actions`: int32 bin indices through the wrapper stack's action path
             self.tcp_wrapped.action_index = actions.data_ptr()
             self._keep_idx = actions
             self.solver_sim.step_tcp(self.sim, None, self.tcp_wrapped, active=sa)
         else:
+            self._keep_actions = actions
             self.solver_sim.step_tcp(self.sim, actions, self.tcp, active=sa)
+        if phase == "solver":
+            return
         # live envs: sim.step's forward + _observe_sync's forward = two controller ticks, the last forward in full; envs inside their reset recipe (pipelined
         # resets): `mujoco_simulation.step()` only = one tick, `self.nticks` (the recipe's last step gets the second tick: the _observe_sync that ends a reset)
         self.sim.env_step(nforward_ticks=2, flags=FLAG_FULL_FORWARD, active=active, nticks=self.nticks if self.pipelined else None)
@@ -337,19 +346,25 @@ class BatchedBlockRearrangeEnv:
         self._step_launch(actions)
         return self._step_finish()
 
-    def _step_launch(self, actions):
-        """The step's three launches, nothing that waits for them (envs/rearrange/ycb.py GroupedYcbRearrangeEnv enqueues several groups before it finishes any)."""
-        assert actions.shape == self.action_shape and actions.device == self.device
-        if self.wrist_only:      # [x, y, z, wrist, gripper] -> the launch's six columns (the roll column is ignored by the hook)
-            actions = torch.cat([actions[:, :3], torch.zeros_like(actions[:, :1]), actions[:, 3:]], 1)
+    def _step_launch(self, actions, phase=None):
+        """The step's three launches, nothing that waits for them (envs/rearrange/ycb.py GroupedYcbRearrangeEnv enqueues several groups before it finishes any; with
+        `phase` = "solver" / "main" / "post" one of the three, the action prepared by the first)."""
+        if phase in (None, "solver"):
+            assert actions.shape == self.action_shape and actions.device == self.device
+            if self.wrist_only:      # [x, y, z, wrist, gripper] -> the launch's six columns (the roll column is ignored by the hook)
+                actions = torch.cat([actions[:, :3], torch.zeros_like(actions[:, :1]), actions[:, 3:]], 1)
+            if self.wrapped:
+                assert not actions.dtype.is_floating_point, "the wrapped env takes MultiDiscrete actions (bin indices)"
+                actions = actions.to(torch.int32).contiguous()
+            else:
+                assert actions.dtype == torch.float32 and actions.is_contiguous()
+            self._phase_actions = actions
+        if phase == "post":
+            return self._post()
         sa = self.solver_active if self.pipelined else None
-        if self.wrapped:
-            assert not actions.dtype.is_floating_point, "the wrapped env takes MultiDiscrete actions (bin indices)"
-            self._physics(actions.to(torch.int32).contiguous(), wrapped=True, solver_active=sa)
-        else:
-            assert actions.dtype == torch.float32 and actions.is_contiguous()
-            self._physics(actions, solver_active=sa)
-        self._post()
+        self._physics(self._phase_actions, wrapped=self.wrapped, solver_active=sa, phase=phase)
+        if phase is None:
+            self._post()
 
     def _step_finish(self):
         if self.pipelined and self.device_reset:

@@ -147,7 +147,7 @@ def test_product_library_loads_and_exports_the_header():
     L = ctypes.CDLL(path)
     declared = sorted(set(re.findall(r"\b(r[gba]_[a-z_0-9]+)\s*\(", open(os.path.join(root, "include", "rgstep.h")).read())))
     # (rb_*: the large-model path, the full-cube env kernel and the rearrange TCP hook; ra_*: the rearrange env kernel)
-    assert len(declared) >= 53 and sum(n.startswith("rb_") for n in declared) == 21 and sum(n.startswith("ra_") for n in declared) == 4
+    assert len(declared) >= 55 and sum(n.startswith("rb_") for n in declared) == 23 and sum(n.startswith("ra_") for n in declared) == 4
     assert L.ra_post_args_size() == ctypes.sizeof(_native.RaPostArgs) and L.rb_post_args_size() == ctypes.sizeof(_native.RbPostArgs)
     for name in declared:
         assert hasattr(L, name), name

@@ -291,6 +291,27 @@ def test_make_env_robot_polymorphism_emul(emul_lib):
     assert env.joint_control and env.action_shape == (1, 7) and env.N == 8
 
 
+def test_grouped_ycb_multi_launch_is_bit_identical_emul(emul_lib):
+    """GroupedYcbRearrangeEnv: the groups' physics phases as ONE launch each (rb_multi_begin / rb_multi_launch -> rb_step_multi_kernel: workgroup k steps env k % b of
+    batch k / b, each batch with its own model) against one launch chain per group -- the same bytes in every observation row, reward and state vector."""
+    from robogym_amd.envs.rearrange.ycb import GroupedYcbRearrangeEnv
+
+    outs = []
+    for multi in (True, False):
+        env = GroupedYcbRearrangeEnv(2, device="cpu", lib=emul_lib, object_sets=(0, 1), starting_seed=4, n_substeps=1, stabilize_steps=1, n_random_initial_steps=1, settle_steps=1,
+                                     resample_object_sets=False, multi_launch=multi)
+        assert env.multi_launch == multi
+        env.reset()
+        g = torch.Generator().manual_seed(1)
+        for _ in range(2):
+            obs, rew, done, info = env.step(torch.rand((2, 6), generator=g) * 2 - 1)
+        outs.append((torch.cat([gr.packed for gr in env.groups]).clone(), rew.clone(), torch.cat([gr.sim.qpos for gr in env.groups]).clone(),
+                     torch.cat([gr.solver_sim.qpos for gr in env.groups]).clone(), torch.cat([gr.sim.ctrl for gr in env.groups]).clone()))
+        assert int(max(gr.sim.status.max() for gr in env.groups)) == 0
+    for a, b_ in zip(*outs):
+        assert torch.equal(a, b_)
+
+
 def test_single_env_view_has_the_reference_types_emul(emul_lib):
     """`SingleEnvView(make_simple_env(batch_size=1))`: numpy observations without the batch dimension, reward list of three floats, bool done, scalar info values"""
     from robogym_amd.envs.rearrange.blocks import SingleEnvView, make_simple_env

@@ -1,5 +1,6 @@
 """rearrange/ycb with K different object sets across the batch (GroupedYcbRearrangeEnv: one compiled model per group, groups on their own streams) next to the
-single-set env: env-steps/s at B envs after a shortened reset recipe.      python tools/bench_ycb_sets.py [B] [steps]"""
+single-set env: env-steps/s at B envs after a shortened reset recipe.      python tools/bench_ycb_sets.py [B] [steps] [multi|streams]
+multi (default): the groups' physics phases as ONE launch each (rb_multi_launch); streams: one launch chain per group on its own stream."""
 import os
 import sys
 import time
@@ -11,10 +12,17 @@ from robogym_amd.envs.rearrange.ycb import make_simple_env      # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-for sets in ((0,), (0, 1), (0, 1, 2, 4), (0, 1, 2, 3, 4, 5)):
+MULTI = not (len(sys.argv) > 3 and sys.argv[3] == "streams")
+print("groups' launches: %s" % ("one launch per phase over all groups (rb_multi_launch)" if MULTI else "one chain per group on its own stream"))
+SINGLES = len(sys.argv) > 4 and sys.argv[4] == "singles"      # also every set of the mixed batches on its own: a mixed batch's step is as long as its slowest set's
+for sets in ((0,), (0, 1), (0, 1, 2, 4), (0, 1, 2, 3, 4, 5)) + (((1,), (2,), (4,)) if SINGLES else ()):
     if B % len(sets):
         continue
-    env = make_simple_env(batch_size=B, starting_seed=3, object_sets=sets, stabilize_steps=20, n_random_initial_steps=2, settle_steps=20)
+    kw = dict(multi_launch=MULTI) if len(sets) > 1 else {}
+    if len(sets) == 1 and sets[0] != 0:
+        from robogym_amd.envs.rearrange.xml import load_ycb_model
+        kw["main_model"] = load_ycb_model(8, set_index=sets[0])
+    env = make_simple_env(batch_size=B, starting_seed=3, object_sets=sets if len(sets) > 1 else None, stabilize_steps=20, n_random_initial_steps=2, settle_steps=20, **kw)
     env.reset()
     dev = env.device
     gen = torch.Generator(device=dev); gen.manual_seed(1)

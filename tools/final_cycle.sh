@@ -31,5 +31,6 @@ bash tools/prof_pmc_rearrange.sh > gpurun_out/pmc_rearrange_$R.txt 2>&1
 # steady state with episode ends, the recipe on the device (ra_recipe_kernel): 2 M env-steps of blocks, 1.2 M of ycb; heterogeneous ycb batches
 python tools/soak_rearrange.py 4096 500 blocks 30 device > gpurun_out/soak_rearrange_$R.txt 2>&1
 python tools/soak_rearrange.py 4096 300 ycb 30 device >> gpurun_out/soak_rearrange_$R.txt 2>&1
-python tools/bench_ycb_sets.py > gpurun_out/ycb_object_sets_$R.txt 2>&1
+python tools/bench_ycb_sets.py 4096 8 multi singles > gpurun_out/ycb_object_sets_$R.txt 2>&1
+python tools/bench_ycb_sets.py 4096 8 streams 2>&1 | grep -v "object sets (0,)" >> gpurun_out/ycb_object_sets_$R.txt
 du -sh gpurun_out
