@@ -436,6 +436,27 @@ def test_rearrange_device_reset_sequence_emul(emul_lib):
     """the same protocol with the recipe's stage machine, begin-of-episode state and placement / goal sampling in ra_recipe_kernel (no flag readback)"""
     _device_recipe_checks(_pipelined_reset_sequence(emul_lib, "cpu", n_substeps=1, B=2, device_reset=True))
     _device_recipe_checks(_pipelined_reset_sequence(emul_lib, "cpu", n_substeps=1, B=2, device_reset=True, control_mode="joint"))
+    _device_recipe_checks(_pipelined_reset_sequence(emul_lib, "cpu", n_substeps=1, B=2, device_reset=True, control_mode="tcp+wrist"))
+
+
+def test_mocap_solver_mode_with_the_wrapper_stack_emul(emul_lib):
+    """`make_env` with tcp_solver_mode mocap and the default wrapper stack: MultiDiscrete actions through the hook on the env's own world (bin lookup and smoothing inside
+    the launch), the smoothed action as observed, the mocap target moving by action x max_position_change from the TCP's pose."""
+    from robogym_amd.envs.rearrange.blocks import make_env
+
+    env = make_env(batch_size=2, device="cpu", lib=emul_lib, parameters={"robot_control_params": {"tcp_solver_mode": "mocap", "max_position_change": 0.05}}, n_substeps=1,
+                   stabilize_steps=1, n_random_initial_steps=0, settle_steps=0, smooth_alpha=0.3 ** 40)
+    assert env.ideal_arm and env.wrapped and env.solver_sim is None
+    obs = env.reset()
+    assert float(obs["action_ema"].abs().max()) == 0.0
+    tcp0 = obs["gripper_pos"].clone()
+    idx = torch.tensor([[10, 5, 5, 5, 5, 5], [5, 0, 5, 5, 5, 5]])
+    obs = env.step(idx)[0]
+    a = obs["action_ema"].numpy()
+    assert np.allclose(a[0], [1, 0, 0, 0, 0, 0], atol=1e-6) and np.allclose(a[1], [0, -1, 0, 0, 0, 0], atol=1e-6)      # (first step of the filter: the action itself)
+    mc = env.sim.mocap.numpy()
+    assert np.allclose(mc[0, :3] - tcp0[0].numpy(), [0.05, 0, 0], atol=2e-5) and np.allclose(mc[1, :3] - tcp0[1].numpy(), [0, -0.05, 0], atol=2e-5)
+    assert int(env.sim.status.max()) == 0
 
 
 def _device_placement_statistics(lib, device, B, rounds, ycb=False):
