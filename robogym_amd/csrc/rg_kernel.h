@@ -31,7 +31,11 @@ typedef const RgModelDev& RgM;
 // compiler may re-issue next to its use instead of keeping ~240 SGPRs of pointers alive
 typedef const __attribute__((address_space(4))) RgModelDev& RgM;
 #endif
+#ifdef RG_FINE_PROF
+#define RG_NPROF 48   /* analysis build (-DRG_FINE_PROF): sub-stage counters inside the Newton loop, slots 24.. (tools/stage_profile.py prints them) */
+#else
 #define RG_NPROF 24
+#endif
 struct RgAux {  // extra static tables (kept out of RgModelDev to keep the kernarg small)
   const int *subtree_adr, *subtree;
   const uint32_t* dof_velmask;
@@ -212,6 +216,43 @@ template <int G> __device__ __forceinline__ int grp_min_i(int v) {
   return v;
 }
 #endif
+// sum over a group of 16 lanes (one DPP row); every lane of the group ends up with the total of all 16 (on the device each lane adds them
+// in its own rotation order: read the result from ONE designated lane where bit-identical copies matter)
+#ifdef RG_EMUL
+__device__ __forceinline__ float grp_sum16(float v) { for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
+#else
+__device__ __forceinline__ float grp_sum16(float v) { v += dpp_f<0x128, 0xf>(v, v); v += dpp_f<0x124, 0xf>(v, v); v += dpp_f<0x122, 0xf>(v, v); v += dpp_f<0x121, 0xf>(v, v); return v; }
+#endif
+// ---- the matrix pipe, used by the dense Newton step (rg_chol_mfma_n).  One 32 x 32 f32 accumulator tile = 16 registers per lane: lane l holds
+// column l % 32, register r holds row 8 (r / 4) + 4 (l / 32) + r % 4.  rg_mfma32: acc += A B with A = 32 x 2 (lane l: A[l % 32][l / 32]) and
+// B = 2 x 32 (lane l: B[l / 32][l % 32]) -- v_mfma_f32_32x32x2_f32, exact f32 (a chain of fused multiply-adds over k).
+// rg_halves<H>(a, b): lanes 0..31 get half H of a, lanes 32..63 get half H of b (H = 0: lanes 0..31, H = 1: lanes 32..63): v_permlane32_swap.
+#ifdef RG_EMUL
+typedef float rgacc __attribute__((vector_size(64)));
+static inline void rg_mfma32(float a, float b, rgacc& acc) {
+  const int l = (int)(threadIdx.x & 63), col = l & 31, hi = l >> 5; const unsigned w0 = threadIdx.x & ~63u;
+  float ab[2] = {a, b}; uint64_t raw; memcpy(&raw, ab, 8);
+  emul_xchg[threadIdx.x] = raw;          // one exchange per instruction: every lane publishes (a, b), then reads what it needs
+  emul_barrier(64);
+  float av[32][2], bv[2];
+  for (int k = 0; k < 2; k++) { float t[2]; memcpy(t, &emul_xchg[w0 + col + 32 * k], 8); bv[k] = t[1]; }
+  for (int i = 0; i < 32; i++) for (int k = 0; k < 2; k++) { float t[2]; memcpy(t, &emul_xchg[w0 + i + 32 * k], 8); av[i][k] = t[0]; }
+  emul_barrier(64);
+  for (int r = 0; r < 16; r++) { const int i = 8 * (r >> 2) + 4 * hi + (r & 3); acc[r] = fmaf(av[i][1], bv[1], fmaf(av[i][0], bv[0], acc[r])); }
+}
+template <int H> static inline float rg_halves(float a, float b) {
+  const int l = (int)(threadIdx.x & 63);
+  const float ax = __shfl(a, (l & 31) + 32 * H), bx = __shfl(b, (l & 31) + 32 * H);
+  return l < 32 ? ax : bx;
+}
+#else
+typedef float rgacc __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void rg_mfma32(float a, float b, rgacc& acc) { acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0); }
+template <int H> __device__ __forceinline__ float rg_halves(float a, float b) {
+  auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+  return __builtin_bit_cast(float, H ? r[1] : r[0]);
+}
+#endif
 // arg-max with smallest-index tie break (matches a first-max serial scan)
 __device__ __forceinline__ void wave_argmax(float& v, int& i) {
   float vm = wave_max(v);
@@ -290,8 +331,6 @@ __device__ __forceinline__ void cross_force(float* r, const float* vel, const fl
 #if !defined(RG_NS) || !defined(RG_MAXCON) || !defined(RG_CPOOL) || !defined(RG_MAXCAND) || !defined(RG_MAXCAND2)
 #error "define RG_NS, RG_MAXCON, RG_CPOOL, RG_MAXCAND, RG_MAXCAND2 before including rg_kernel.h"
 #endif
-#undef RG_HCOEF_LDS
-#define RG_HCOEF_LDS (RG_MAXCON <= 32)   /* rollout configuration: its position side is the larger one anyway */
 #ifndef RG_ITEMS
 #define RG_ITEMS 0     /* 1: this configuration is the substep-granular one: rg_step_items_kernel instead of rg_step_kernel, rows that a previous
                           work item of the env may have written are read with L1-bypassing loads, the env comes from the work item */
@@ -387,14 +426,8 @@ struct RgLds {
       union { struct { float search[RG_MAXNVC], Mv[RG_MAXNVC]; }; float qacc[RG_MAXNV]; };   //  compact-space vectors are dead; read by the integrator)
       float dinv[RG_MAXNV], tmpv[RG_MAXNV];
       unsigned char p_quad[RG_MAXPYR];
-      // per contact basis (normal, t1, t2, spin): J x on the way to the rows | the rows' forces on the way to J' f (never both at
-      // once).  RG_HCOEF_LDS (configurations whose solver side has the room): the H assembly's per-contact coefficients are
-      // staged through both (8 words per contact); otherwise the two share storage and the coefficients go lane to lane.
-#if RG_HCOEF_LDS
-      float c_bdot[RG_MAXCON * 4], c_bfrc[RG_MAXCON * 4];
-#else
-      union { float c_bdot[RG_MAXCON * 4], c_bfrc[RG_MAXCON * 4]; };
-#endif   // per contact basis (normal, t1, t2, spin): J x on the way to the rows | the rows' forces on the way to J' f (never both at once)
+      // per contact basis (normal, t1, t2, spin): J x on the way to the pyramid rows | the rows' forces 0..3 on their way to J' f (rows 4, 5: c_aref0 / c_kb)
+      float c_bdot[RG_MAXCON * 4];
     };
   };
   float prof[RG_NPROF];   // LAST: launches without the profiling flag do not allocate it (rg_lds_launch_bytes)
@@ -1732,10 +1765,19 @@ template <bool SROWS = true> __device__ __forceinline__ void rg_J_mul(RgM m, RgL
     int r = LANE + RG_WAVE * k;
     if (r < ns && R.D[k] > 0) { float v = srow_dot<false>(s, R.desc[k], x); if (to_jv) R.jv[k] = v; else R.jar[k] = v - R.aref[k]; }
   }
-  for (int w = LANE; w < ncon * 4; w += RG_WAVE) {
-    int c = w >> 2, k = w & 3, nnz = s.c_nnz[c]; float v = 0;
-    if (k < nbasis(s.c_dim[c])) { const float* Bc = s.c_pool + s.c_off[c] + k * nnz; for (int sl = 0; sl < nnz; sl++) v += Bc[sl] * x[s.c_idx[c * RG_W + sl]]; }
-    s.c_bdot[w] = v;
+  // basis products of the contacts: a 16-lane group per contact (four per trip), lane (c, sl) multiplies x[dof of slot sl] into the slot's
+  // <= 4 basis entries, a DPP row sum adds the slots up.  (Before: a lane per (contact, basis vector) walking the <= 14 slots one after the
+  // other, two dependent LDS reads each.)
+  for (int c0 = 0; c0 < ncon; c0 += 4) {
+    const int c = c0 + (LANE >> 4), sl = LANE & 15, cc = c < ncon ? c : c0;
+    const int nnz = s.c_nnz[cc], nb = nbasis(s.c_dim[cc]);
+    const bool on = c < ncon && sl < nnz;
+    const int slc = on ? sl : 0;
+    const float* Bc = s.c_pool + s.c_off[cc] + slc;
+    const float xv = on ? x[s.c_idx[cc * RG_W + slc]] : 0.f;
+    float p0 = Bc[0] * xv, p1 = nb > 1 ? Bc[nnz] * xv : 0.f, p2 = nb > 2 ? Bc[2 * nnz] * xv : 0.f, p3 = nb > 3 ? Bc[3 * nnz] * xv : 0.f;
+    p0 = grp_sum16(p0); p1 = grp_sum16(p1); p2 = grp_sum16(p2); p3 = grp_sum16(p3);
+    if (c < ncon && sl < 4) s.c_bdot[4 * c + sl] = sl == 0 ? p0 : (sl == 1 ? p1 : (sl == 2 ? p2 : p3));
   }
   SYNC();
 #pragma unroll
@@ -1756,6 +1798,9 @@ template <bool SROWS = true> __device__ __forceinline__ void rg_J_mul(RgM m, RgL
 // M + J' D J depends on the state only through these flags)
 __device__ __forceinline__ float rg_constraint_update(RgM m, RgLds& s, RowRegs& R, bool& changed) {
   int ns = nsrow(m), ncon = s.ncon; float cost = 0; bool chg = false;
+#ifdef RG_FINE_PROF
+  float nchg_f = 0.f;
+#endif
 #pragma unroll
   for (int k = 0; k < RG_RSLOTS; k++) {
     int r = LANE + RG_WAVE * k;
@@ -1771,6 +1816,9 @@ __device__ __forceinline__ float rg_constraint_update(RgM m, RgLds& s, RowRegs& 
       } else if (x < 0) { q = 1; cost += 0.5f * D * x * x; }
     }
     R.quad[k] = q; chg |= q != old;
+#ifdef RG_FINE_PROF
+    nchg_f += q != old ? 1.f : 0.f;
+#endif
   }
 #pragma unroll
   for (int kk = 0; kk < RG_PSLOTS; kk++) {
@@ -1782,9 +1830,17 @@ __device__ __forceinline__ float rg_constraint_update(RgM m, RgLds& s, RowRegs& 
         if (x < 0) { q = 1; cost += 0.5f * D * x * x; }
       }
       s.p_quad[w] = q; chg |= q != old;
+#ifdef RG_FINE_PROF
+      nchg_f += q != old ? 1.f : 0.f;
+#endif
     }
   }
   changed = __ballot(chg) != 0;
+#ifdef RG_FINE_PROF
+  s.prof[47] = 0.f;   // (analysis build: the number of rows that changed their zone, for the refactorisation statistics in rg_solve)
+  SYNC();
+  { float n = wave_sum(nchg_f); if (LANE == 0) s.prof[47] = n; }
+#endif
   SYNC();
   return wave_sum(cost);
 }
@@ -1792,29 +1848,37 @@ __device__ __forceinline__ float rg_constraint_update(RgM m, RgLds& s, RowRegs& 
 __device__ __forceinline__ void rg_JT_force(RgM m, RgLds& s, const RowRegs& R, float* dst) {
   int ns = nsrow(m), ncon = s.ncon;
   PFOR(d, m.nvc) dst[d] = 0;
-  // basis forces (normal, tangent 1, tangent 2, spin) of every contact: P' f, accumulated from the pyramid rows' owner lanes
-  for (int w = LANE; w < ncon * 4; w += RG_WAVE) s.c_bfrc[w] = 0.f;
-  SYNC();
+  // Round 6: the pyramid rows' forces are staged in LDS -- rows 0..3 of contact c in c_bdot[4 c ..] (free here: J x has been consumed), rows 4 and 5
+  // in c_aref0[c] / c_kb[c] (dead since the rows took their reference accelerations at the start of the solve) -- and a 16-lane group per
+  // contact then forms the contact's four basis forces itself and scatters slot sl's column: one LDS phase less than summing the basis forces
+  // with atomics first, and no serial walk.
+  static_assert(RG_W <= 16, "one 16-lane group per contact");
 #pragma unroll
   for (int kk = 0; kk < RG_PSLOTS; kk++) {
     int w = LANE + RG_WAVE * kk;
-    if (w < ncon * 6 && s.p_quad[w]) {   // (a pyramid row carries force exactly when it is quadratic: x < 0)
-      int c = w / 6, q = w - 6 * c; float f = -s.c_D[c] * R.pjar[kk];
-      atomicAdd(s.c_bfrc + 4 * c, f);
-      if (s.c_dim[c] > 1) { int k = q >> 1; float mu = s.c_mu[2 * c + (k >> 1)]; atomicAdd(s.c_bfrc + 4 * c + 1 + k, (q & 1) ? -mu * f : mu * f); }
+    if (w < ncon * 6) {
+      const int c = w / 6, q = w - 6 * c;
+      const float f = s.p_quad[w] ? -s.c_D[c] * R.pjar[kk] : 0.f;   // (a pyramid row carries force exactly when it is quadratic: x < 0)
+      float* o = q < 4 ? s.c_bdot + 4 * c + q : (q == 4 ? s.c_aref0 + c : s.c_kb + c);
+      *o = f;
     }
   }
   SYNC();
 #pragma unroll
   for (int k = 0; k < RG_RSLOTS; k++) { int r = LANE + RG_WAVE * k; float f = r < ns ? srow_force(R.D[k], R.floss[k], R.jar[k]) : 0.f; if (f != 0) srow_scatter(s, R.desc[k], f, dst); }
-  for (int w = LANE; w < ncon * RG_W; w += RG_WAVE) {
-    int c = w / RG_W, sl = w - c * RG_W, nnz = s.c_nnz[c];
-    if (sl >= nnz) continue;
-    const float* Bc = s.c_pool + s.c_off[c]; const float* bf = s.c_bfrc + 4 * c; int nb = nbasis(s.c_dim[c]);
-    float v = Bc[sl] * bf[0];
-    if (nb >= 3) v += Bc[nnz + sl] * bf[1] + Bc[2 * nnz + sl] * bf[2];
-    if (nb >= 4) v += Bc[3 * nnz + sl] * bf[3];
-    atomicAdd(dst + s.c_idx[c * RG_W + sl], v);
+  for (int c0 = 0; c0 < ncon; c0 += 4) {
+    const int c = c0 + (LANE >> 4), sl = LANE & 15, cc = c < ncon ? c : c0;
+    const int nnz = s.c_nnz[cc], nb = nbasis(s.c_dim[cc]);
+    const float mu0 = s.c_mu[2 * cc], mu1 = s.c_mu[2 * cc + 1];
+    const float* fq = s.c_bdot + 4 * cc;
+    const float f0 = fq[0], f1 = fq[1], f2 = fq[2], f3 = fq[3], f4 = s.c_aref0[cc], f5 = s.c_kb[cc];
+    if (c < ncon && sl < nnz) {
+      const float* Bc = s.c_pool + s.c_off[cc] + sl;
+      float v = Bc[0] * (((((f0 + f1) + f2) + f3) + f4) + f5);
+      if (nb >= 3) v += Bc[nnz] * (mu0 * (f0 - f1)) + Bc[2 * nnz] * (mu0 * (f2 - f3));
+      if (nb >= 4) v += Bc[3 * nnz] * (mu1 * (f4 - f5));
+      atomicAdd(dst + s.c_idx[cc * RG_W + sl], v);
+    }
   }
   SYNC();
 }
@@ -1976,6 +2040,186 @@ __device__ __forceinline__ void rg_chol_solve_bwd(RgM m, RgLds& s, float* x) {
   if (i < n) x[i] = xi;
   SYNC();
 }
+// ---- The dense Newton step in REGISTERS (round 6).  The left-looking factorisation above makes n/4 LDS round trips with a serial 4x4
+// block in each (25 k cycles for n = 30), and the substitutions another 2 n/4.  Here lane i <= n loads row i of the work matrix (row n =
+// the right-hand side g) into 32 registers and the wave runs the RIGHT-looking elimination on them: column j's pivot and multipliers
+// travel by v_readlane (wave-uniform, no LDS), every lane updates its own row.  The lanes the matrix leaves idle carry the IDENTITY as
+// n more rows (lane n + 1 + m starts as e_m): what the elimination does to a row b is b <- b inv(L'), so those lanes end up holding the
+// rows of inv(L') (= the columns of inv(L)) while lane n ends up holding y = inv(L) g -- and the solution is one dot product per lane,
+// x_m = (row m of inv(L')) . y: no backward substitution at all.  W = inv(L') is left in the work matrix (row m, upper triangular) for
+// the iterations that reuse the factor (rg_cholinv_apply: x = W (W' g), two passes of broadcast products, no LDS writes).
+// Needs 2 n + 1 <= 64 lanes; launch flag bit 6 keeps the path above.
+// The size is a template parameter (every loop static, no branch inside the elimination; the wave's code is straight-line): instantiated for
+// the Newton spaces of the hand models (dactyl/locked 30, dactyl/reach 24); other sizes keep the path above.
+__device__ __forceinline__ bool rg_cholreg_ok(int n) { return n == 30 || n == 24; }
+template <int N> __device__ __forceinline__ void rg_chol_inv_solve_n(RgM m, RgLds& s, float* x) {
+  static_assert(2 * N + 1 <= RG_WAVE && N <= RG_MAXNVC, "matrix rows + right-hand side + identity rows: one lane each");
+  constexpr int NC = (N + 3) / 4;
+  const int hs4 = m.hs >> 2, i = LANE;
+  int zr = i - (N + 1);                // identity row carried by this lane (lanes > N)
+#ifndef RG_EMUL
+  asm volatile("" : "+v"(zr));         // (opaque: otherwise the 32 identity-row constants are hoisted out of the Newton loop and live in scratch)
+#endif
+  const bool isrow = i <= N;
+  float a[4 * NC];
+  {
+    const rgf4* src = (const rgf4*)s.H + (isrow ? i : 0) * hs4;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+      const rgf4 v = src[c];
+      a[4 * c + 0] = isrow ? v.x : (zr == 4 * c + 0 ? 1.f : 0.f);
+      a[4 * c + 1] = isrow ? v.y : (zr == 4 * c + 1 ? 1.f : 0.f);
+      a[4 * c + 2] = isrow ? v.z : (zr == 4 * c + 2 ? 1.f : 0.f);
+      a[4 * c + 3] = isrow ? v.w : (zr == 4 * c + 3 ? 1.f : 0.f);
+    }
+  }
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    float p = lane_bcast(a[j], j);
+    if (!(p > 1e-30f)) bad = true;
+    const float inv = rg_rsqrt(fmaxf(p, 1e-30f));
+    a[j] *= inv;                       // lanes > j: L[i][j]; lane j: the pivot's root; lanes < j: never read
+    const float naj = -a[j];
+#pragma unroll
+    for (int k = j + 1; k < N; k += 4) {   // multipliers four at a time: the readlane -> fma latency of one hides behind the others
+      const float l0 = lane_bcast(a[j], k), l1 = k + 1 < N ? lane_bcast(a[j], k + 1) : 0.f, l2 = k + 2 < N ? lane_bcast(a[j], k + 2) : 0.f, l3 = k + 3 < N ? lane_bcast(a[j], k + 3) : 0.f;
+      a[k] = __builtin_fmaf(naj, l0, a[k]);
+      if (k + 1 < N) a[k + 1] = __builtin_fmaf(naj, l1, a[k + 1]);
+      if (k + 2 < N) a[k + 2] = __builtin_fmaf(naj, l2, a[k + 2]);
+      if (k + 3 < N) a[k + 3] = __builtin_fmaf(naj, l3, a[k + 3]);
+    }
+  }
+  // x_m = sum_k W[m][k] y_k in lane N + 1 + m
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+#pragma unroll
+  for (int k = 0; k < N; k += 4) {
+    acc0 = __builtin_fmaf(a[k], lane_bcast(a[k], N), acc0);
+    if (k + 1 < N) acc1 = __builtin_fmaf(a[k + 1], lane_bcast(a[k + 1], N), acc1);
+    if (k + 2 < N) acc2 = __builtin_fmaf(a[k + 2], lane_bcast(a[k + 2], N), acc2);
+    if (k + 3 < N) acc3 = __builtin_fmaf(a[k + 3], lane_bcast(a[k + 3], N), acc3);
+  }
+  if (zr >= 0 && zr < N) {
+    x[zr] = (acc0 + acc1) + (acc2 + acc3);
+    rgf4* dst = (rgf4*)s.H + zr * hs4;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+      rgf4 o; o.x = a[4 * c]; o.y = 4 * c + 1 < N ? a[4 * c + 1] : 0.f; o.z = 4 * c + 2 < N ? a[4 * c + 2] : 0.f; o.w = 4 * c + 3 < N ? a[4 * c + 3] : 0.f;
+      dst[c] = o;
+    }
+  }
+  if (bad && i == 0) s.status |= RG_STATUS_BAD_FACTOR;
+  SYNC();
+}
+// ---- The same step on the MATRIX PIPE (round 6, an OPTION: -DRG_CHOL_MFMA; measured and not the default, see the end of this comment).  The elimination above is ~1230 VALU
+// instructions per factorisation in a kernel whose waves share a VALU that is ~45 % busy: alone it takes 5.3 k cycles, between two other waves
+// 15 k.  Here the same right-looking elimination is two 32 x 32 f32 accumulator tiles and one rank-2 v_mfma_f32_32x32x2_f32 per tile and PAIR of
+// columns (~30 VALU instructions per pair; the matrix pipe is otherwise idle in this kernel):
+//   S  = [H g] in symmetric storage (column N = the right-hand side; its row is never a pivot),
+//   T' = the transpose of the N rows that start as the identity (T'[c][i] = row i, column c): it ends up as inv(L), and its row N as -x.
+// A pivot row j of either tile is ONE register across 32 lanes (the half l / 32 = (j / 4) % 2), so step (j, j + 1) is: pivots and the
+// multiplier by v_readlane, w = row / root on the VALU (row j + 1 takes step j's correction there too), the two k-slots of the operands
+// assembled with one v_permlane32_swap each, rows <= j + 1 masked out of the A operand (they are final), S -= w w', T' -= w z'.
+// By symmetry column j of S is row j of S, and the transposed storage makes "column j of the identity rows" a row as well: no transposes.
+// Measured (profiles/r06_ab_newton.txt): alone 5.5 k cycles per factorisation against 5.3 k for the VALU elimination (tools/ubench), but inside the kernel the two
+// 16-register accumulator tuples cost more in spills around the solve than the ~800 VALU instructions they save: 1.46 M against 1.62 M env-steps/s.
+template <int N> __device__ __forceinline__ void rg_chol_mfma_n(RgM m, RgLds& s, float* x) {
+  static_assert(N % 2 == 0 && N <= 30, "pairs of columns; column N = right-hand side, row / column 31 stay zero");
+  const int hs = m.hs, hs4 = hs >> 2, l = LANE, col = l & 31, hi = l >> 5;
+  const rgf4* H4 = (const rgf4*)s.H;
+  rgacc S, T;
+  {
+    const int cc = col < N + 1 ? col : N;   // (column 31: clamped here, zeroed below)
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const int i0 = 8 * g + 4 * hi;
+      const rgf4 rowf = H4[cc * hs4 + 2 * g + hi];   // H[c][i0 .. i0 + 3]: the stored (lower) triangle where i <= c
+      const float v[4] = {rowf.x, rowf.y, rowf.z, rowf.w};
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int i = i0 + q, ic = i < N + 1 ? i : N;
+        const float colf = s.H[ic * hs + cc];       // H[i][c]: stored where c <= i
+        float val = i < cc ? v[q] : colf;
+        if (i > N || col > N) val = 0.f;
+        S[4 * g + q] = val;
+        T[4 * g + q] = (i == col && col < N) ? 1.f : 0.f;
+      }
+    }
+  }
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < N; j += 2) {
+    constexpr int dummy = 0; (void)dummy;
+    const int rj = 4 * (j >> 3) + (j & 3), hj = (j >> 2) & 1, lj = 32 * hj + j;
+    const float s0 = S[rj], s1 = S[rj + 1], t0 = T[rj], t1 = T[rj + 1];
+    const float p = lane_bcast(s0, lj);
+    if (!(p > 1e-30f)) bad = true;
+    const float inv = rg_rsqrt(fmaxf(p, 1e-30f));
+    const float w0 = s0 * inv, z0 = t0 * inv;
+    const float mlt = lane_bcast(w0, lj + 1);
+    const float s1c = __builtin_fmaf(-mlt, w0, s1), t1c = __builtin_fmaf(-mlt, z0, t1);
+    const float p2 = lane_bcast(s1c, lj + 1);
+    if (!(p2 > 1e-30f)) bad = true;
+    const float inv2 = rg_rsqrt(fmaxf(p2, 1e-30f));
+    const float w1 = s1c * inv2, z1 = t1c * inv2;
+    const bool mine = hi == hj;
+    T[rj] = mine ? z0 : t0; T[rj + 1] = mine ? z1 : t1;
+    float WW, ZZ;
+    if (hj == 0) { WW = rg_halves<0>(w0, w1); ZZ = rg_halves<0>(z0, z1); } else { WW = rg_halves<1>(w0, w1); ZZ = rg_halves<1>(z0, z1); }
+    const float WWn = col > j + 1 ? -WW : 0.f;   // rows <= j + 1 are final (row j + 1 took its correction on the VALU)
+    rg_mfma32(WWn, WW, S);
+    rg_mfma32(WWn, ZZ, T);
+  }
+  // x_i = -T'[N][i]
+  constexpr int rN = 4 * (N >> 3) + (N & 3), hN = (N >> 2) & 1;
+  if (hi == hN && col < N) x[col] = -T[rN];
+  // W[m][k] = T'[k][m] for the iterations that reuse the factor (rg_cholinv_apply)
+  if (col < N) {
+    rgf4* dst = (rgf4*)s.H + col * hs4;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const int k0 = 8 * g + 4 * hi;
+      if (k0 < ((N + 3) & ~3)) {
+        rgf4 o; o.x = k0 < N ? T[4 * g] : 0.f; o.y = k0 + 1 < N ? T[4 * g + 1] : 0.f; o.z = k0 + 2 < N ? T[4 * g + 2] : 0.f; o.w = k0 + 3 < N ? T[4 * g + 3] : 0.f;
+        dst[2 * g + hi] = o;
+      }
+    }
+  }
+  if (bad && l == 0) s.status |= RG_STATUS_BAD_FACTOR;
+  SYNC();
+}
+// x <- inv(H) x from W = inv(L') left by rg_chol_inv_solve: y = W' x (lane k: column k of W), then x = W y (lane m: row m of W)
+template <int N> __device__ __forceinline__ void rg_cholinv_apply_n(RgM m, RgLds& s, float* x) {
+  constexpr int NC = (N + 3) / 4;
+  const int hs = m.hs, hs4 = hs >> 2, i = LANE, ic = i < N ? i : 0;
+  const float g = i < N ? x[i] : 0.f;
+  float y0 = 0.f, y1 = 0.f;
+  const float* col = s.H + ic;
+#pragma unroll
+  for (int mm = 0; mm < N; mm += 2) {
+    y0 = __builtin_fmaf(col[mm * hs], lane_bcast(g, mm), y0);
+    if (mm + 1 < N) y1 = __builtin_fmaf(col[(mm + 1) * hs], lane_bcast(g, mm + 1), y1);
+  }
+  const float y = i < N ? y0 + y1 : 0.f;
+  const rgf4* row = (const rgf4*)s.H + ic * hs4;
+  float xa = 0.f, xb = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    const rgf4 w = row[c];
+    xa = __builtin_fmaf(w.x, lane_bcast(y, 4 * c), xa);
+    if (4 * c + 1 < N) xb = __builtin_fmaf(w.y, lane_bcast(y, 4 * c + 1), xb);
+    if (4 * c + 2 < N) xa = __builtin_fmaf(w.z, lane_bcast(y, 4 * c + 2), xa);
+    if (4 * c + 3 < N) xb = __builtin_fmaf(w.w, lane_bcast(y, 4 * c + 3), xb);
+  }
+  if (i < N) x[i] = xa + xb;
+  SYNC();
+}
+#ifdef RG_CHOL_MFMA
+__device__ __forceinline__ void rg_chol_inv_solve(RgM m, RgLds& s, float* x) { if (m.nvc == 30) rg_chol_mfma_n<30>(m, s, x); else rg_chol_mfma_n<24>(m, s, x); }
+#else
+__device__ __forceinline__ void rg_chol_inv_solve(RgM m, RgLds& s, float* x) { if (m.nvc == 30) rg_chol_inv_solve_n<30>(m, s, x); else rg_chol_inv_solve_n<24>(m, s, x); }
+#endif
+__device__ __forceinline__ void rg_cholinv_apply(RgM m, RgLds& s, float* x) { if (m.nvc == 30) rg_cholinv_apply_n<30>(m, s, x); else rg_cholinv_apply_n<24>(m, s, x); }
 // Tree-sparse factorisation A = L' D L in the per-tree block storage (work copy in s.H) and its substitutions
 // (mj_factorM / mj_solveM).  Only (dof, ancestor) entries exist and dofs of equal depth are independent, so the
 // factorisation is one lane-parallel pass per depth (deepest first), every lane taking one (k, i, j) update
@@ -2095,6 +2339,12 @@ __device__ __forceinline__ LsPt rg_ls_eval(const LsRows& L, float alpha, float q
 template <bool SENSORS> __device__ __forceinline__ int rg_solve(RgM m, RgLds& s, const float* P, int& nefc_out, int flags, float warm /* qacc_warmstart[LANE] */) {
   long long t0 = rg_clock(), t1;
 #define PROFS(k) do { if (flags & 2) { t1 = rg_clock(); if (LANE == 0) s.prof[k] += (float)(t1 - t0); t0 = t1; } } while (0)
+#ifdef RG_FINE_PROF
+  long long tf0 = rg_clock(), tf1;
+#define PROFF(k) do { if (flags & 2) { tf1 = rg_clock(); if (LANE == 0) s.prof[k] += (float)(tf1 - tf0); tf0 = tf1; } } while (0)
+#else
+#define PROFF(k) do { } while (0)
+#endif
   int nv = m.nv, nvc = m.nvc, hs = m.hs, ns = nsrow(m), ncon = s.ncon;
   // count active rows (diagnostic only)
   RgMEnt ME; rg_M_ent_load(m, ME);
@@ -2164,14 +2414,22 @@ template <bool SENSORS> __device__ __forceinline__ int rg_solve(RgM m, RgLds& s,
   // Invariant at the top of every iteration: Ma = M a and jar = J a - aref (both linear in a, so they are
   // advanced by alpha * (M s, J s) after the line search instead of being recomputed).
   // The factor of H is kept while the set of quadratic rows stays the same (H depends on nothing else).
+  PROFF(24);
   float cost = 0, oldcost = 0; int iters = 0; bool have_factor = false;
   bool fresh_rhs = false; const bool rhs_row = (nvc + 1) * hs <= RG_HWORDS && !(flags & 64);   // (room for the right-hand-side row under the work matrix; flag bit 6: test hook, the separate forward substitution)
+  const bool regchol = rhs_row && rg_cholreg_ok(nvc);   // the dense step in registers (rg_chol_inv_solve); flag bit 6 therefore also selects the LDS factorisation
   for (int iter = 0;; iter++) {
     float gauss = 0; PFOR(i, nvc) gauss += 0.5f * (s.Ma[i] - s.fs[i]) * (s.a[i] - s.as[i]);
     gauss = wave_sum(gauss);
     bool flags_changed; float cc = rg_constraint_update(m, s, RR, flags_changed);
     oldcost = cost; cost = gauss + cc;
+#ifdef RG_FINE_PROF
+    if ((flags & 2) && iter > 0 && flags_changed && LANE == 0) { const float k = s.prof[47]; s.prof[36] += 1.f; s.prof[37] += k; s.prof[38] += k <= 2.f ? 1.f : 0.f; s.prof[39] += k <= 4.f ? 1.f : 0.f; s.prof[40] += k <= 8.f ? 1.f : 0.f; }
+    if ((flags & 2) && iter > 0 && !flags_changed && LANE == 0) s.prof[41] += 1.f;
+#endif
+    PROFF(25);
     rg_JT_force(m, s, RR, s.jtf);
+    PROFF(26);
     float gn = 0; PFOR(i, nvc) { float gi = s.Ma[i] - s.fs[i] - s.jtf[i]; s.search[i] = -gi; gn += gi * gi; }
     gn = sqrtf(wave_sum(gn)) * scale;
 #ifdef RG_EMUL_TRACE
@@ -2180,7 +2438,7 @@ template <bool SENSORS> __device__ __forceinline__ int rg_solve(RgM m, RgLds& s,
     if (iter > 0 && scale * (oldcost - cost) < tol) break;
     if (gn < tol || iter >= m.iterations) break;
     iters = iter + 1;
-    PROFS(12);
+    PROFS(12); PROFF(27);
     if (!have_factor || flags_changed) {
     have_factor = true;
     if (tree) {
@@ -2207,60 +2465,68 @@ template <bool SENSORS> __device__ __forceinline__ int rg_solve(RgM m, RgLds& s,
     // per contact, C = P' D_act P in the basis (normal, t1, t2, spin) has only its first row/column and its diagonal
     // non-zero: cn, ck[3], cd[3].  Lane c computes them for contact c; the block loop below reads them lane to lane.
     static_assert(RG_MAXCON <= RG_WAVE, "one lane per contact");
-    float cn_own = 0, ck_own[3] = {0, 0, 0}, cd_own[3] = {0, 0, 0};
-    if (LANE < ncon) {
-      const int c = LANE, dim = s.c_dim[c]; const float D = s.c_D[c];
-      if (dim == 1) cn_own = s.p_quad[6 * c] ? D : 0.f;
-      else for (int k = 0; k < dim - 1; k++) {
-        float mu = s.c_mu[2 * c + (k >> 1)]; int qp = s.p_quad[6 * c + 2 * k], qm = s.p_quad[6 * c + 2 * k + 1];
-        cn_own += D * (qp + qm); ck_own[k] = D * mu * (qp - qm); cd_own[k] = D * mu * mu * (qp + qm);
+    PROFF(28);
+    // Round 6: a lane per (contact, block row).  Four contacts per trip, one 16-lane group each (a row of a contact has <= RG_W = 14 non-zeros);
+    // lane (c, a) forms the contact's coefficients itself (one round of independent LDS reads, no staging), folds them with its own row's basis
+    // entries -- v(a, b) = n_b w0 + sum_k t_kb w_k -- and walks b = 0..a, two entries in flight.  (Before: one contact after the other, a
+    // lane per (a, b) pair with the coefficients staged through LDS: 3.7 k cycles per contact, all of it LDS latency.)
+    static_assert(RG_W <= 16, "one 16-lane group per contact");
+    for (int c0 = 0; c0 < ncon; c0 += 4) {
+      const int c = c0 + (LANE >> 4), a = LANE & 15, cc = c < ncon ? c : c0;
+      const int dim = s.c_dim[cc], nnz = s.c_nnz[cc], nb = nbasis(dim);
+      const float D = s.c_D[cc], mu0 = s.c_mu[2 * cc], mu1 = s.c_mu[2 * cc + 1];
+      const unsigned char* pq = s.p_quad + 6 * cc;
+      const int q0 = pq[0], q1 = pq[1], q2 = pq[2], q3 = pq[3], q4 = pq[4], q5 = pq[5];
+      float cn, ck0 = 0.f, ck1 = 0.f, ck2 = 0.f, cd0 = 0.f, cd1 = 0.f, cd2 = 0.f;
+      if (dim == 1) cn = q0 ? D : 0.f;
+      else {
+        cn = D * (float)(q0 + q1); ck0 = D * mu0 * (float)(q0 - q1); cd0 = D * mu0 * mu0 * (float)(q0 + q1);
+        if (dim > 2) { cn += D * (float)(q2 + q3); ck1 = D * mu0 * (float)(q2 - q3); cd1 = D * mu0 * mu0 * (float)(q2 + q3); }
+        if (dim > 3) { cn += D * (float)(q4 + q5); ck2 = D * mu1 * (float)(q4 - q5); cd2 = D * mu1 * mu1 * (float)(q4 + q5); }
       }
-    }
-#if RG_HCOEF_LDS
-    if (LANE < ncon) { float* o = s.c_bdot + 8 * LANE; o[0] = cn_own; o[1] = ck_own[0]; o[2] = ck_own[1]; o[3] = ck_own[2]; o[4] = cd_own[0]; o[5] = cd_own[1]; o[6] = cd_own[2]; }
-    SYNC();
-#endif
-    for (int c = 0; c < ncon; c++) {
-#if RG_HCOEF_LDS
-      const float* o = s.c_bdot + 8 * c;
-      const float cn = o[0], ck[3] = {o[1], o[2], o[3]}, cd[3] = {o[4], o[5], o[6]};
-      if (cn == 0) continue;
-#else
-      const float cn = lane_bcast(cn_own, c);
-      if (cn == 0) continue;
-      const float ck[3] = {lane_bcast(ck_own[0], c), lane_bcast(ck_own[1], c), lane_bcast(ck_own[2], c)}, cd[3] = {lane_bcast(cd_own[0], c), lane_bcast(cd_own[1], c), lane_bcast(cd_own[2], c)};
-#endif
-      const int nnz = s.c_nnz[c], nb = nbasis(s.c_dim[c]);
-      const float* Bc = s.c_pool + s.c_off[c];
-      // the block's lower triangle, one (a >= b) pair per lane: nnz (nnz + 1) / 2 <= 105 entries, i.e. one or two trips per
-      // contact (both factorisations read the lower triangle only)
-      const int np = (nnz * (nnz + 1)) >> 1;
-      for (int q = LANE; q < np; q += RG_WAVE) {
-        int a = (int)((sqrtf(8.f * (float)q + 1.f) - 1.f) * 0.5f);
-        if ((((a + 1) * (a + 2)) >> 1) <= q) a++;
-        if (((a * (a + 1)) >> 1) > q) a--;
-        const int b = q - ((a * (a + 1)) >> 1);
-        float na = Bc[a], nbv = Bc[b], v = cn * na * nbv;
-        for (int k = 0; k + 1 < nb; k++) { float ta = Bc[(k + 1) * nnz + a], tb = Bc[(k + 1) * nnz + b]; v += ck[k] * (na * tb + ta * nbv) + cd[k] * ta * tb; }
-        const int ia = s.c_idx[c * RG_W + a], ib = s.c_idx[c * RG_W + b], hi = ia > ib ? ia : ib, lo = ia > ib ? ib : ia;
-        if (!tree) atomicAdd(s.H + hi * hs + lo, v);
-        else { int blk = s.cblk[hi]; atomicAdd(s.H + (blk & 0xFFFF) + lo - ((blk >> 16) & 255), v); }
+      if (c < ncon && a < nnz && cn != 0.f) {
+        const float* Bc = s.c_pool + s.c_off[cc];
+        const unsigned char* ix = s.c_idx + cc * RG_W;
+        const float na = Bc[a], ta0 = nb > 1 ? Bc[nnz + a] : 0.f, ta1 = nb > 2 ? Bc[2 * nnz + a] : 0.f, ta2 = nb > 3 ? Bc[3 * nnz + a] : 0.f;
+        const int ia = ix[a];
+        const float w0 = cn * na + ck0 * ta0 + ck1 * ta1 + ck2 * ta2, w1 = ck0 * na + cd0 * ta0, w2 = ck1 * na + cd1 * ta1, w3 = ck2 * na + cd2 * ta2;
+        for (int b = 0; b <= a; b += 2) {
+          const bool two = b + 1 <= a; const int b1 = two ? b + 1 : b;
+          const float n0 = Bc[b], n1 = Bc[b1];
+          const float s0 = nb > 1 ? Bc[nnz + b] : 0.f, s1 = nb > 1 ? Bc[nnz + b1] : 0.f;
+          const float u0 = nb > 2 ? Bc[2 * nnz + b] : 0.f, u1 = nb > 2 ? Bc[2 * nnz + b1] : 0.f;
+          const float r0 = nb > 3 ? Bc[3 * nnz + b] : 0.f, r1 = nb > 3 ? Bc[3 * nnz + b1] : 0.f;
+          const int i0 = ix[b], i1 = ix[b1];
+          const float v0 = n0 * w0 + s0 * w1 + u0 * w2 + r0 * w3, v1 = n1 * w0 + s1 * w1 + u1 * w2 + r1 * w3;
+          const int h0 = ia > i0 ? ia : i0, l0 = ia > i0 ? i0 : ia, h1 = ia > i1 ? ia : i1, l1 = ia > i1 ? i1 : ia;
+          if (!tree) { atomicAdd(s.H + h0 * hs + l0, v0); if (two) atomicAdd(s.H + h1 * hs + l1, v1); }
+          else {
+            const int k0 = s.cblk[h0], k1 = s.cblk[h1];
+            atomicAdd(s.H + (k0 & 0xFFFF) + l0 - ((k0 >> 16) & 255), v0);
+            if (two) atomicAdd(s.H + (k1 & 0xFFFF) + l1 - ((k1 >> 16) & 255), v1);
+          }
+        }
       }
     }
     // dense path: the gradient rides through the factorisation as one more row (row nvc), so the forward substitution costs nothing
     if (!tree && rhs_row) { if (LANE < hs) s.H[nvc * hs + LANE] = LANE < nvc ? s.search[LANE] : 0.f; fresh_rhs = true; }
     SYNC();
-    PROFS(13);
-    if (tree) { LtdlDesc LT; rg_ltdl_load(m.ltdl_tri_c, m.ltdl_pair_c, m.n_tri_rounds_c, m.n_pair_rounds_c, LT); rg_ltdl_factor(s, LT); } else if (rhs_row) rg_chol<true>(m, s); else rg_chol<false>(m, s);
+    PROFS(13); PROFF(29);
+    if (tree) { LtdlDesc LT; rg_ltdl_load(m.ltdl_tri_c, m.ltdl_pair_c, m.n_tri_rounds_c, m.n_pair_rounds_c, LT); rg_ltdl_factor(s, LT); }
+    else if (regchol) rg_chol_inv_solve(m, s, s.search);   // factorisation AND solution (the right-hand side rode along)
+    else if (rhs_row) rg_chol<true>(m, s); else rg_chol<false>(m, s);
     }
     PROFS(14);
     if (tree) { LtdlDesc LT; rg_ltdl_load((const int*)0, m.ltdl_pair_c, 0, m.n_pair_rounds_c, LT); rg_ltdl_solve(s, LT, s.search, LANE, LANE < nvc, akk_own); }
+    else if (regchol) { if (!fresh_rhs) rg_cholinv_apply(m, s, s.search); }
     else if (fresh_rhs) rg_chol_solve_bwd(m, s, s.search); else rg_chol_solve(m, s, s.search);
     fresh_rhs = false;
-    PROFS(15);
+    PROFS(15); PROFF(30);
     // exact line search along `search`
     rg_M_mul(m, s, ME, s.search, s.Mv);
+    PROFF(31);
     rg_J_mul(m, s, RR, s.search, true);
+    PROFF(32);
     float q1 = 0, q2 = 0, sn = 0;
     PFOR(i, nvc) { q1 += s.search[i] * (s.Ma[i] - s.fs[i]); q2 += 0.5f * s.search[i] * s.Mv[i]; sn += s.search[i] * s.search[i]; }
     q1 = wave_sum(q1); q2 = wave_sum(q2); sn = sqrtf(wave_sum(sn));
@@ -2285,6 +2551,7 @@ template <bool SENSORS> __device__ __forceinline__ int rg_solve(RgM m, RgLds& s,
 #ifdef RG_EMUL_TRACE
     if (LANE == 0) printf("     alpha %.6e p0.grad %.3e p0.hess %.3e gtol %.3e\n", alpha, p0.grad, p0.hess, gtol);
 #endif
+    PROFF(33);
     if (alpha == 0) break;
     PFOR(i, nvc) { s.a[i] += alpha * s.search[i]; s.Ma[i] += alpha * s.Mv[i]; }
 #pragma unroll
@@ -2292,8 +2559,9 @@ template <bool SENSORS> __device__ __forceinline__ int rg_solve(RgM m, RgLds& s,
 #pragma unroll
     for (int k = 0; k < RG_PSLOTS; k++) RR.pjar[k] += alpha * RR.pjv[k];
     SYNC();
-    PROFS(10);
+    PROFS(10); PROFF(34);
   }
+  PROFF(35);
   // Every exit of the loop leaves s.jtf = J' f(a) for the final a (the gradient evaluation at the top of the pass that
   // broke out, or the pass whose step length came out zero), so the forces at the solution are already there; only the
   // expansion to the full dof space remains.  (RG_SOLVE_RECOMPUTE: evaluate them once more from J a - aref computed from
@@ -2304,12 +2572,12 @@ template <bool SENSORS> __device__ __forceinline__ int rg_solve(RgM m, RgLds& s,
   rg_JT_force(m, s, RR, s.jtf);
 #endif
   if (SENSORS) {   // sensor pass (its own instantiation: the hot path's solver carries none of this): normal force of every contact = sum of its pyramid edge forces (mju_decodePyramid), f = -D jar where jar < 0
-    PFOR(c, ncon) s.c_bfrc[c] = 0.f;
+    PFOR(c, ncon) s.c_bdot[c] = 0.f;
     SYNC();
 #pragma unroll
     for (int k = 0; k < RG_PSLOTS; k++) {
       int w = LANE + RG_WAVE * k;
-      if (w < ncon * 6) { int cc = w / 6; if ((w - 6 * cc) < npyr(s.c_dim[cc]) && RR.pjar[k] < 0) atomicAdd(s.c_bfrc + cc, -s.c_D[cc] * RR.pjar[k]); }
+      if (w < ncon * 6) { int cc = w / 6; if ((w - 6 * cc) < npyr(s.c_dim[cc]) && RR.pjar[k] < 0) atomicAdd(s.c_bdot + cc, -s.c_D[cc] * RR.pjar[k]); }
     }
     SYNC();
   }
@@ -2426,11 +2694,11 @@ __device__ __forceinline__ void rg_touch_geom(RgM m, RgLds& s, const float* P) {
   }
   SYNC();
 }
-// after the solve: s.c_bfrc[c] holds the normal force of contact c (rg_solve, sensor pass)
+// after the solve: s.c_bdot[c] holds the normal force of contact c (rg_solve, sensor pass; the array is free by then)
 __device__ __forceinline__ void rg_touch_write(RgM m, RgLds& s, float* xd) {
   PFOR(k, m.nsensor) {
     float f = 0;
-    for (int c = 0; c < s.ncon; c++) { float nf = s.c_bfrc[c]; if (((s.c_touch[c] >> k) & 1) && nf > 0) f += nf; }
+    for (int c = 0; c < s.ncon; c++) { float nf = s.c_bdot[c]; if (((s.c_touch[c] >> k) & 1) && nf > 0) f += nf; }
     xd[RG_XD_SENSOR + k] = f;
   }
   SYNC();

@@ -17,7 +17,7 @@ s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True
 s.record(); sim.env_step(action=a, nforward_ticks=3, flags=2); e.record(); torch.cuda.synchronize()
 dbg = sim.get_field(8)
 off = dbg.shape[1] - 32 * 8
-prof = dbg[:, off:off + 24].double().mean(0).cpu().numpy() / 10.0
+prof = dbg[:, off:off + 48].double().mean(0).cpu().numpy() / 10.0
 names = ["kinematics", "com_pos", "tendon", "crb+M", "factor M", "broadphase", "narrowphase(+broad)", "velocity/RNE", "constraint rows", "pid+smooth", "newton linesearch+update", "euler", "newton grad/cost eval", "newton H assembly", "newton cholesky", "newton tri-solve"]
 tot = sum(prof[i] for i in range(16) if i != 5)
 print("kernel ms %.2f for B=%d ; cycles per substep per wave (mean over envs):" % (s.elapsed_time(e), B))
@@ -25,3 +25,9 @@ for i, n in enumerate(names):
     print("  %-22s %10.0f  %5.1f%%" % (n, prof[i], 100 * prof[i] / tot))
 print("  total %.0f cycles/substep" % tot)
 print("  collision: after broadphase %.0f, after phase1 %.0f, after phase2 %.0f cycles; ncand %.1f -> survivors %.1f; phase2 lane0-row supports %.1f, scan cycles %.0f, pick+xform cycles %.0f" % (prof[5], prof[16], prof[19], prof[17], prof[18], prof[20], prof[21], prof[22]))
+fine = ["solve setup (rows, warm-start pick)", "gauss + constraint update", "J' f", "gradient norm, search", "H: zero, M, static rows", "H: contact blocks", "factor + solve", "M s", "J s", "line search (dots, evaluations)", "update", "exit pass"]
+if prof[24:36].sum() > 0 and prof[24:36].sum() < 1e7:   # analysis build (-DRG_FINE_PROF); otherwise these words are the contact dump's
+    print("  Newton sub-stages (RG_FINE_PROF):")
+    for i, n in enumerate(fine):
+        print("    %-38s %9.0f" % (n, prof[24 + i]))
+    print("    refactorisations after the first, per substep: %.3f ; rows that changed zone per refactorisation: mean %.2f ; with <= 2 rows %.3f, <= 4 %.3f, <= 8 %.3f per substep ; iterations that reused the factor %.3f per substep" % (prof[36], prof[37] / max(prof[36], 1e-9), prof[38], prof[39], prof[40], prof[41]))
