@@ -378,7 +378,10 @@ int rb_tcp_args_size(void);   /* sizeof(rb_tcp_args): a binding checks its own l
 /* Several batches in ONE launch (heterogeneous object sets side by side: /root/reference/robogym/envs/rearrange/ycb.py:58-84 rebuilds the simulation with new objects per
  * episode -- here a batch per compiled object set).  Between rb_multi_begin and rb_multi_launch the rb_batch_step / _step_ex / _step_tcp calls of the calling thread
  * validate their arguments and RECORD the launch; rb_multi_launch issues ONE kernel over all recorded batches (same batch size, same one-wave kernel configuration;
- * at most 8), or one launch each, in order, when they do not match.  Results are those of the separate launches, bit for bit. */
+ * at most 8), or one launch each, in order, when they do not match.  Results are those of the separate launches, bit for bit.
+ * While recording: the `stream` argument of the recorded calls is IGNORED (rb_multi_launch's stream is the one); a batch may be recorded once only
+ * (rb_multi_launch refuses a duplicate: two workgroups would step the same rows); the entry points that are not recordable -- rb_env_post_step, ra_env_post_step,
+ * ra_env_recipe_step, rb_cube_ops -- fail instead of running ahead of the recorded physics. */
 int rb_multi_begin(void);
 int rb_multi_launch(void* stream);
 /* ---- the env-level half of RearrangeEnv.step (one launch after the two physics launches; robogym_amd/csrc/ra_env_kernel.h lists the

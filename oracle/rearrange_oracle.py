@@ -135,9 +135,11 @@ def normalize_angles(a, low=-np.pi, high=np.pi):
 class OracleArmSim:
     """An `OracleSim` of one of the two rearrange worlds plus the handful of id lookups the robot code does by name."""
 
-    def __init__(self, model, n_substeps=40):
+    def __init__(self, model, n_substeps=40, f32=False):
+        # f32: the oracle's own source built in single precision (oracle/librg_oracle_f32.so) -- the precision twin the parity tests measure
+        # "what fp32 arithmetic alone does to this protocol" with; never the reference for anything
         self.model, self.n_substeps = model, n_substeps
-        self.sim = OracleSim(pack_model(model))
+        self.sim = OracleSim(pack_model(model), f32=f32)
         A, jn = model.arrays, model.names["joint"]
         self.arm_q = np.array([A["jnt_qposadr"][jn.index("robot0:J%d" % k)] for k in range(1, 7)])
         self.arm_v = np.array([A["jnt_dofadr"][jn.index("robot0:J%d" % k)] for k in range(1, 7)])
@@ -269,8 +271,8 @@ class OracleRearrangeEnv:
     robot/ur16e/mujoco/joint_controlled_arm.py:89-200), no TCP solver world (RobotControlParameters.requires_solver_sim, robot_interface.py:83-91); 7 action numbers."""
 
     def __init__(self, main_model, solver_model, num_objects, n_substeps=40, max_position_change=0.1, arm_reset_controller_error=True,
-                 success_threshold=None, goal_reward_per_object=1.0, penalty=None, wrist_only=False, ideal_arm=False):
-        self.main, self.solver = OracleArmSim(main_model, n_substeps), (None if solver_model is None else OracleArmSim(solver_model, n_substeps))
+                 success_threshold=None, goal_reward_per_object=1.0, penalty=None, wrist_only=False, ideal_arm=False, f32=False):
+        self.main, self.solver = OracleArmSim(main_model, n_substeps, f32=f32), (None if solver_model is None else OracleArmSim(solver_model, n_substeps, f32=f32))
         # tcp_solver_mode mocap: MujocoIdealURGripperCompositeRobot = IdealJointControlledTcpArm + MujocoRobotiqGripper with solver_simulation = simulation
         # (robot/composite/ur_gripper_arm.py:126-128, robot/ur16e/mujoco/ideal_joint_controlled_tcp_arm.py): the main world's arm hangs on the mocap weld, one world
         self.ideal_arm = bool(ideal_arm)

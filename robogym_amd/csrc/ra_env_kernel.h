@@ -318,7 +318,9 @@ __global__ void __launch_bounds__(64) ra_recipe_kernel(const RbModelDev* mp, RbB
       a.hold[e] = 0; a.hold_ctrl[e] = 0; a.frozen[e] = 0; a.solver_active[e] = 1; a.resetting[e] = 0; a.episode_started[e] = 1;
       for (int d = 0; d < AD; d++) { a.scripted[(size_t)e * AD + d] = 0.f; a.ema_value[(size_t)e * AD + d] = 0.f; a.action_ema[(size_t)e * AD + d] = 0.f; }
       gy = a.yaw + (size_t)e * N; gstride = 1;
-    } else if (st == 0 && a.goal_reset[e]) {                           // a live env that reached its goal: ObjectStateGoal.next_goal keeps the goal's yaw
+    } else if (st == 0 && a.goal_reset[e] && !a.done[e]) {             // a live env that reached its goal: ObjectStateGoal.next_goal keeps the goal's yaw
+      // (not when the episode ends on the same step -- objects off the table while every object sits within its thresholds --: the begin-of-episode state written
+      //  below would be what the goal's re-observation reads; the terminal observation keeps the reached goal's entries, on this path and on the host path alike)
       regoal = 1;
       gy = a.goal_rot + (size_t)e * N * 3 + 2; gstride = 3;
     }

@@ -591,6 +591,79 @@ __device__ __forceinline__ void rb_group_solve(RbM m, RbLds& s, int g, const flo
   BSYNC();
 }
 
+#if RB_T == 64
+// ---- Round 6, one-wave configurations: the group's Newton step x = inv(S A S) (S grad) in REGISTERS (the construction of rg_kernel.h's rg_chol_inv_solve_n).
+// rb_chol + rb_chol_solve above are built for 256 threads: per 8 columns three workgroup barriers, the diagonal block through LDS, the substitutions two barriers per
+// block -- 43 k + 22 k cycles for the rearrange main world's 38-dof group on ONE wave that waits 72 % of its cycles.  Here lane i < n loads row i of the packed block
+// (scaled by the diagonal, as rb_scale_block does) into NP registers, lane NP holds the right-hand side as one more row, lanes n .. NP - 1 pad with the identity, and
+// the wave runs the right-looking elimination with pivots and multipliers by v_readlane: no LDS, no barrier.  The right-hand side row comes out as y = inv(L) g;
+// the backward substitution runs four columns per step: four independent wave sums of L[k][c] x_k over the lanes k that are done, then the 4 x 4 triangle on
+// wave-uniform numbers.  NP = the padded size (template: straight-line code).
+template <int NP> __device__ __forceinline__ bool rb_reg_solve_n(RbM m, RbLds& s, int g0, int n, const float* src, float* dst, float scale) {
+  static_assert(NP % 4 == 0 && NP < 64, "row NP = the right-hand side");
+  const int i = LANE;
+  const float sci = i < n ? s.sc[i] : 1.f;
+  float a[NP];
+  {
+    const bool isrow = i < n, isrhs = i == NP;
+    const int rbase = isrow ? RB_TRI(i, 0) : 0;
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+      const float sck = lane_bcast(sci, k);
+      float v = (k == i) ? 1.f : 0.f;                                        // padding rows: identity
+      if (isrow) v = k <= i ? s.A[rbase + k] * sci * sck : 0.f;              // (entries right of the diagonal are never read)
+      if (isrhs) v = k < n ? sck * src[m.b_group_dofs[g0 + (k < n ? k : 0)]] : 0.f;
+      a[k] = v;
+    }
+  }
+  bool ok = true;
+  float dv = 1.f;   // lane j: 1 / L[j][j]
+#pragma unroll
+  for (int j = 0; j < NP; j++) {
+    const float p = lane_bcast(a[j], j);
+    if (!(p > RB_MINVAL)) ok = false;
+    const float inv = rg_rsqrt(fmaxf(p, RB_MINVAL));
+    a[j] *= inv;
+    if (i == j) dv = inv;
+    const float naj = -a[j];
+#pragma unroll
+    for (int k = j + 1; k < NP; k++) a[k] = __builtin_fmaf(naj, lane_bcast(a[j], k), a[k]);
+  }
+  // backward substitution L' x = y, four columns per step (lane k holds x_k once it is known)
+  float xk = 0.f;
+#pragma unroll
+  for (int c0 = NP - 4; c0 >= 0; c0 -= 4) {
+    const bool below = i > c0 + 3 && i < NP;
+    float p0 = below ? a[c0] * xk : 0.f, p1 = below ? a[c0 + 1] * xk : 0.f, p2 = below ? a[c0 + 2] * xk : 0.f, p3 = below ? a[c0 + 3] * xk : 0.f;
+    p0 = wave_sum(p0); p1 = wave_sum(p1); p2 = wave_sum(p2); p3 = wave_sum(p3);
+    const float i0 = lane_bcast(dv, c0), i1 = lane_bcast(dv, c0 + 1), i2 = lane_bcast(dv, c0 + 2), i3 = lane_bcast(dv, c0 + 3);
+    const float x3 = (lane_bcast(a[c0 + 3], NP) - p3) * i3;
+    const float x2 = (lane_bcast(a[c0 + 2], NP) - p2 - lane_bcast(a[c0 + 2], c0 + 3) * x3) * i2;
+    const float x1 = (lane_bcast(a[c0 + 1], NP) - p1 - lane_bcast(a[c0 + 1], c0 + 3) * x3 - lane_bcast(a[c0 + 1], c0 + 2) * x2) * i1;
+    const float x0 = (lane_bcast(a[c0], NP) - p0 - lane_bcast(a[c0], c0 + 3) * x3 - lane_bcast(a[c0], c0 + 2) * x2 - lane_bcast(a[c0], c0 + 1) * x1) * i0;
+    if (i == c0) xk = x0; else if (i == c0 + 1) xk = x1; else if (i == c0 + 2) xk = x2; else if (i == c0 + 3) xk = x3;
+  }
+  if (i < n) dst[m.b_group_dofs[g0 + i]] = scale * sci * xk;
+  BSYNC();
+  return ok;
+}
+// dst[dofs of group g] = scale * inv(block in s.A) src[dofs of group g]; false on a non-positive pivot
+__device__ __forceinline__ bool rb_reg_solve(RbM m, RbLds& s, int g, const float* src, float* dst, float scale) {
+  const int g0 = m.b_group_adr[g], n = m.b_group_adr[g + 1] - g0;
+  BFOR(l, n) s.sc[l] = rg_rsqrt(fmaxf(s.A[RB_TRI(l, l)], RB_MINVAL));
+  BSYNC();
+  if (n <= 8) return rb_reg_solve_n<8>(m, s, g0, n, src, dst, scale);
+  if (n <= 16) return rb_reg_solve_n<16>(m, s, g0, n, src, dst, scale);
+  if (n <= 24) return rb_reg_solve_n<24>(m, s, g0, n, src, dst, scale);
+#if RB_MAXGROUP <= 40
+  return rb_reg_solve_n<40>(m, s, g0, n, src, dst, scale);
+#else
+  if (n <= 40) return rb_reg_solve_n<40>(m, s, g0, n, src, dst, scale);
+  return rb_reg_solve_n<RB_MAXGROUP>(m, s, g0, n, src, dst, scale);
+#endif
+}
+#endif
+
 // "Star" trees (big_tables.py b_tree_*: a chain of <= 6 root dofs with simple chains of <= RB_STARB dofs hanging off its last dof -- the cubes, the
 // hand): M and M + h B of such a tree, and the Newton Hessian M + a diagonal of a tree no contact or tendon touches (the target cube), have the
 // tree's sparsity, [[R, C'], [C, blockdiag(B_k)]] in (root | chains) order.  Block elimination instead of a dense factorisation: thread k
@@ -2285,6 +2358,9 @@ RB_STAGE void sv_JT_force(RbCtx c) { RB_STAGE_ENTER(); rb_JT_force(m, s, S, s.qf
 RB_STAGE void sv_hessian(RbCtx c, int grp) { RB_STAGE_ENTER(); rb_M_block(m, s, SC(MSP), grp, (const float*)0, 0.f); rb_hessian_add(m, s, S, grp); }
 RB_STAGE int sv_factor(RbCtx c, int grp) { RB_STAGE_ENTER(); const int n = m.b_group_adr[grp + 1] - m.b_group_adr[grp]; rb_scale_block(s, n); return rb_chol(s, n) ? 1 : 0; }
 RB_STAGE void sv_direction(RbCtx c, int grp) { RB_STAGE_ENTER(); rb_group_solve(m, s, grp, s.grad, s.search, -1.f); }
+#if RB_T == 64
+RB_STAGE int sv_factor_direction(RbCtx c, int grp) { RB_STAGE_ENTER(); return rb_reg_solve(m, s, grp, s.grad, s.search, -1.f) ? 1 : 0; }   // one wave: factorisation and both substitutions in registers
+#endif
 RB_STAGE void sv_star_direction(RbCtx c, int grp, int part) {
   RB_STAGE_ENTER();
   if (part == 0) rb_row_diag(m, s, S, grp, s.Mv); else rb_star_group_solve(m, s, SC(MSP), grp, s.Mv, 1.f, s.grad, s.search, -1.f);
@@ -2302,9 +2378,13 @@ RB_STAGE void sv_M_solve(RbCtx c, int mode, int flags) {
   for (int grp = 0; grp < m.ngroup; grp++) {
     if (m.b_star_grp[4 * grp + 3] && !(flags & 4)) { rb_star_group_solve(m, s, SC(MSP), grp, diag, h, src, dst, 1.f); continue; }   // (flags bit 2: dense path everywhere, test hook)
     rb_M_block(m, s, SC(MSP), grp, diag, h);
+#if RB_T == 64 && !defined(RB_LDS_CHOL)
+    if (!rb_reg_solve(m, s, grp, src, dst, 1.f) && TID == 0) s.status |= RG_STATUS_BAD_FACTOR;
+#else
     rb_scale_block(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]);
     if (!rb_chol(s, m.b_group_adr[grp + 1] - m.b_group_adr[grp]) && TID == 0) s.status |= RG_STATUS_BAD_FACTOR;
     rb_group_solve(m, s, grp, src, dst, 1.f);
+#endif
   }
 }
 __device__ __forceinline__ int rb_solve(RbCtx cx, RbM m, RbLds& s, float* S, int flags) {
@@ -2362,8 +2442,12 @@ __device__ __forceinline__ int rb_solve(RbCtx cx, RbM m, RbLds& s, float* S, int
         continue;
       }
       sv_hessian(cx, grp); RB_PROFS(10);
+#if RB_T == 64 && !defined(RB_LDS_CHOL)
+      okf = (sv_factor_direction(cx, grp) != 0) && okf; RB_PROFS(11);
+#else
       okf = (sv_factor(cx, grp) != 0) && okf; RB_PROFS(11);
       sv_direction(cx, grp); RB_PROFS(12);
+#endif
     }
     if (!okf && TID == 0) s.status |= RG_STATUS_BAD_FACTOR;
     sv_MJ_mul(cx, 3);

@@ -69,6 +69,11 @@ typedef ra_recipe_args RaRecipeArgs;
 #include <dlfcn.h>
 #include <unistd.h>
 #include <sys/wait.h>
+#include <spawn.h>
+#include <signal.h>
+#include <time.h>
+#include <mutex>
+extern char** environ;
 
 #include <algorithm>
 #include <string>
@@ -749,7 +754,11 @@ static void rg_items_probe(rg_batch* b) {
   b->items_slots = 0; b->items_queues = 1;
   // the probe's answer is a property of the device: measured once per device and process (it used to allocate, launch and synchronise in every
   // rg_batch_create), and a failed probe launch is reported through rg_last_error instead of being swallowed -- the mode then stays off, which is always correct
+  // (the cache is shared by every thread that creates batches -- one per device is a normal host layout -- so it sits behind a mutex, and a probe whose
+  //  launch FAILED is cached too, as "off", instead of allocating and launching again in every rg_batch_create)
   static int cached_slots[64], cached_queues[64]; static bool cached[64];
+  static std::mutex probe_mutex;
+  std::lock_guard<std::mutex> probe_lock(probe_mutex);
   const bool cacheable = b->device >= 0 && b->device < 64;
   if (cacheable && cached[b->device]) {
     b->items_slots = cached_slots[b->device]; b->items_queues = cached_queues[b->device];
@@ -769,8 +778,10 @@ static void rg_items_probe(rg_batch* b) {
   hipLaunchKernelGGL(rg_xcc_probe_kernel, dim3(grid), dim3(RG_WAVE), 0, 0, counts);
   const hipError_t launch_err = hipGetLastError();
   int h[16];
-  if (launch_err != hipSuccess) (void)fail(std::string("rg_items_probe: probe launch failed (substep-granular dispatch stays off): ") + hipGetErrorString(launch_err));
-  else if (hipMemcpy(h, counts, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+  if (launch_err != hipSuccess) {
+    (void)fail(std::string("rg_items_probe: probe launch failed (substep-granular dispatch stays off): ") + hipGetErrorString(launch_err));
+    if (cacheable) { cached_slots[b->device] = 0; cached_queues[b->device] = 1; cached[b->device] = true; }
+  } else if (hipMemcpy(h, counts, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
     int nq = 0; bool ok = true;
     for (int x = 0; x < 16; x++) if (h[x] > 0) nq = x + 1;
     for (int x = 0; x < nq; x++) if (h[x] <= 0) ok = false;
@@ -1148,29 +1159,52 @@ static bool read_file(const std::string& path, std::vector<char>& out) {
 static bool compile_mjcf_to_blob(const char* xml, const char* meshdir, int kind, std::vector<char>& blob, std::string& err) {
   if (!xml || !*xml) { err = "rg_compile_mjcf: empty MJCF document"; return false; }
   if (kind != 0 && kind != 1) { err = "rg_compile_mjcf: kind must be 0 (rg_model) or 1 (rb_model)"; return false; }
-  char dir[] = "/tmp/rgstep_mjcf_XXXXXX";
-  if (!mkdtemp(dir)) { err = "rg_compile_mjcf: mkdtemp failed"; return false; }
+  const char* tmp = getenv("TMPDIR");
+  std::string dirs = std::string(tmp && *tmp ? tmp : "/tmp") + "/rgstep_mjcf_XXXXXX";
+  std::vector<char> dirbuf(dirs.begin(), dirs.end()); dirbuf.push_back(0);
+  char* dir = dirbuf.data();
+  if (!mkdtemp(dir)) { err = "rg_compile_mjcf: mkdtemp failed under " + dirs; return false; }
   const std::string d = dir, fx = d + "/model.xml", fb = d + "/model.blob", fe = d + "/stderr.txt";
   auto cleanup = [&]() { unlink(fx.c_str()); unlink(fb.c_str()); unlink(fe.c_str()); rmdir(dir); };
   { FILE* f = fopen(fx.c_str(), "wb"); if (!f || fwrite(xml, 1, strlen(xml), f) != strlen(xml)) { if (f) fclose(f); cleanup(); err = "rg_compile_mjcf: cannot write the document to " + fx; return false; } fclose(f); }
   const char* py = getenv("RGSTEP_PYTHON");
   const std::string python = py && *py ? py : "python3", root = lib_root();
-  const pid_t pid = fork();
-  if (pid < 0) { cleanup(); err = "rg_compile_mjcf: fork failed"; return false; }
-  if (pid == 0) {
-    const char* old = getenv("PYTHONPATH");
-    const std::string pp = old && *old ? root + ":" + old : root;
-    setenv("PYTHONPATH", pp.c_str(), 1);
-    const int efd = open(fe.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
-    if (efd >= 0) { dup2(efd, 2); dup2(efd, 1); close(efd); }
-    std::vector<const char*> av = {python.c_str(), "-m", "robogym_amd.mujoco.compile_cli", "--kind", kind == 0 ? "rg" : "rb", "--xml", fx.c_str(), "--out", fb.c_str()};
-    if (meshdir && *meshdir) { av.push_back("--meshdir"); av.push_back(meshdir); }
-    av.push_back(nullptr);
-    execvp(python.c_str(), (char* const*)av.data());
-    _exit(127);
+  // The helper is started with posix_spawnp from argv / envp / file actions that are complete BEFORE the call (the process holds HIP runtime threads,
+  // so nothing that allocates or takes a lock may run between fork and exec); stdout / stderr go to a file of the scratch directory, stdin to /dev/null.
+  // (Descriptors the runtime opened without O_CLOEXEC -- the GPU device nodes -- are inherited by the helper, which never touches them and exits.)
+  std::vector<std::string> envs;
+  bool have_pp = false;
+  for (char** e = environ; e && *e; e++) {
+    if (strncmp(*e, "PYTHONPATH=", 11) == 0) { envs.push_back(std::string("PYTHONPATH=") + root + ((*e)[11] ? std::string(":") + (*e + 11) : std::string())); have_pp = true; }
+    else envs.push_back(*e);
   }
-  int status = 0;
-  while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {}
+  if (!have_pp) envs.push_back("PYTHONPATH=" + root);
+  std::vector<char*> envp; for (auto& e : envs) envp.push_back((char*)e.c_str()); envp.push_back(nullptr);
+  std::vector<std::string> args = {python, "-m", "robogym_amd.mujoco.compile_cli", "--kind", kind == 0 ? "rg" : "rb", "--xml", fx, "--out", fb};
+  if (meshdir && *meshdir) { args.push_back("--meshdir"); args.push_back(meshdir); }
+  std::vector<char*> av; for (auto& a : args) av.push_back((char*)a.c_str()); av.push_back(nullptr);
+  posix_spawn_file_actions_t fa; posix_spawn_file_actions_init(&fa);
+  posix_spawn_file_actions_addopen(&fa, 0, "/dev/null", O_RDONLY, 0);
+  posix_spawn_file_actions_addopen(&fa, 1, fe.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
+  posix_spawn_file_actions_adddup2(&fa, 1, 2);
+  pid_t pid = -1;
+  const int rc = posix_spawnp(&pid, python.c_str(), &fa, nullptr, av.data(), envp.data());
+  posix_spawn_file_actions_destroy(&fa);
+  if (rc != 0) { cleanup(); err = "rg_compile_mjcf: the MJCF compiler (" + python + ") could not be started: " + strerror(rc); return false; }
+  // bounded wait: RGSTEP_COMPILE_TIMEOUT seconds (default 600; the largest shipped document compiles in under a minute), then the helper is killed
+  double limit = 600.0;
+  if (const char* t = getenv("RGSTEP_COMPILE_TIMEOUT")) { const double v = atof(t); if (v > 0) limit = v; }
+  int status = 0; bool timed_out = false;
+  { struct timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (;;) {
+      const pid_t w = waitpid(pid, &status, WNOHANG);
+      if (w == pid) break;
+      if (w < 0 && errno != EINTR) { status = 0x7f00; break; }
+      struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+      if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > limit) { kill(pid, SIGKILL); while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {} timed_out = true; break; }
+      struct timespec nap = {0, 20 * 1000 * 1000}; nanosleep(&nap, nullptr);
+    } }
+  if (timed_out) { cleanup(); err = "rg_compile_mjcf: the MJCF compiler did not finish within RGSTEP_COMPILE_TIMEOUT = " + std::to_string((int)limit) + " s and was killed"; return false; }
   const bool ok = WIFEXITED(status) && WEXITSTATUS(status) == 0 && read_file(fb, blob) && blob.size() >= 16;
   if (!ok) {
     std::vector<char> msg; read_file(fe, msg);
@@ -1389,6 +1423,8 @@ int rb_multi_launch(void* stream) {
   std::vector<RbCollected> v; v.swap(*g_multi);
   delete g_multi; g_multi = nullptr;
   if (v.empty()) return 0;
+  // (a batch recorded twice would put two workgroups on the same rows of one launch)
+  for (size_t a = 0; a < v.size(); a++) for (size_t c = a + 1; c < v.size(); c++) if (v[a].b == v[c].b) return fail("rb_multi_launch: the same batch was recorded twice between rb_multi_begin and rb_multi_launch");
   bool same = v.size() <= RB_MAXMULTI;
   for (const RbCollected& c : v)
     same = same && c.b->dev.B == v[0].b->dev.B && c.b->device == v[0].b->device && c.b->model->config == v[0].b->model->config && (c.b->model->config == 1 || c.b->model->config == 2) &&
@@ -1486,6 +1522,7 @@ static void emul_rb_cube_entry(void* p_) { EmulRbCubeArgs* p = (EmulRbCubeArgs*)
 #endif
 int rb_post_args_size(void) { return (int)sizeof(rb_post_args); }
 int rb_env_post_step(rb_batch* b, const rb_post_args* args, void* stream) {
+  if (g_multi) return fail("rb_env_post_step: not recordable -- called between rb_multi_begin and rb_multi_launch it would run AHEAD of the recorded physics launches; issue it after rb_multi_launch");
   if (!b || !args) return fail("null argument");
   const rb_post_args& a = *args;
   const RbModelDev& d = b->model->dev;
@@ -1522,6 +1559,7 @@ static void emul_ra_post_entry(void* p_) { EmulRaPostArgs* p = (EmulRaPostArgs*)
 #endif
 int ra_post_args_size(void) { return (int)sizeof(ra_post_args); }
 int ra_env_post_step(rb_batch* b, rb_batch* solver, const ra_post_args* args, void* stream) {
+  if (g_multi) return fail("ra_env_post_step: not recordable -- called between rb_multi_begin and rb_multi_launch it would run AHEAD of the recorded physics launches; issue it after rb_multi_launch");
   if (!b || !args) return fail("null argument");
   ra_post_args a = *args;
   const RbModelDev& d = b->model->dev;
@@ -1560,6 +1598,7 @@ static void emul_ra_recipe_entry(void* p_) { EmulRaRecipeArgs* p = (EmulRaRecipe
 #endif
 int ra_recipe_args_size(void) { return (int)sizeof(ra_recipe_args); }
 int ra_env_recipe_step(rb_batch* b, rb_batch* solver, const ra_recipe_args* args, void* stream) {
+  if (g_multi) return fail("ra_env_recipe_step: not recordable -- called between rb_multi_begin and rb_multi_launch it would run AHEAD of the recorded physics launches; issue it after rb_multi_launch");
   if (!b || !args) return fail("null argument");
   const ra_recipe_args& a = *args;
   const RbModelDev& d = b->model->dev;
@@ -1595,6 +1634,7 @@ int ra_env_recipe_step(rb_batch* b, rb_batch* solver, const ra_recipe_args* args
   return 0;
 }
 int rb_cube_ops(rb_batch* b, int block_col, const int* cube_tab_dev, const float* ops_dev, int nops, const int* active_dev, void* stream) {
+  if (g_multi) return fail("rb_cube_ops: not recordable -- called between rb_multi_begin and rb_multi_launch it would run AHEAD of the recorded physics launches; issue it after rb_multi_launch");
   if (!b || !cube_tab_dev || !ops_dev || nops < 0) return fail("rb_cube_ops: bad argument");
   const RbModelDev& d = b->model->dev;
   if (block_col < 0 || block_col + 66 > d.nq) return fail("rb_cube_ops: block column out of range");
@@ -1616,3 +1656,8 @@ int rg_sync(void* stream) {
 }
 
 }  // extern "C"
+
+#if defined(RG_WOODBURY_CHECK) && defined(RG_EMUL)
+// test harness only (tests/test_kernel_emul.py): the statistics of the Woodbury self check since the last call, then reset
+extern "C" void rg_emul_woodbury_check(float* max_rel, int* solves, int* rows) { *max_rel = rg_wchk_max; *solves = rg_wchk_n; *rows = rg_wchk_rows; rg_wchk_max = 0.f; rg_wchk_n = 0; rg_wchk_rows = 0; }
+#endif

@@ -319,6 +319,9 @@ __device__ __forceinline__ void cross_force(float* r, const float* vel, const fl
   st3(r, cross(w, a) + cross(vt, b)); st3(r + 3, cross(w, b));
 }
 
+#if defined(RG_WOODBURY_CHECK) && defined(RG_EMUL)
+static float rg_wchk_max = 0.f; static int rg_wchk_n = 0, rg_wchk_rows = 0;   // emulation-harness self check of rg_cholinv_woodbury (see rg_solve)
+#endif
 #endif  // RG_KERNEL_COMMON_H
 
 // =================================================================================================================
@@ -1796,44 +1799,51 @@ template <bool SROWS = true> __device__ __forceinline__ void rg_J_mul(RgM m, RgL
 // forces / quadratic flags from jar; returns the wave-summed constraint cost
 // `changed`: whether any row's quadratic flag differs from what the arrays held before (the Hessian
 // M + J' D J depends on the state only through these flags)
-__device__ __forceinline__ float rg_constraint_update(RgM m, RgLds& s, RowRegs& R, bool& changed) {
-  int ns = nsrow(m), ncon = s.ncon; float cost = 0; bool chg = false;
+// Flag words (RowRegs::quad, RgLds::p_quad): bit 0 = the row is in its quadratic zone NOW, bit 1 = it was when the factor held in s.H was built
+// (rg_solve sets it at every factorisation).  `nset`: the number of rows whose two bits differ = the rank of H(now) - H(factor).
+__device__ __forceinline__ float rg_constraint_update(RgM m, RgLds& s, RowRegs& R, bool& changed, int& nset) {
+  int ns = nsrow(m), ncon = s.ncon; float cost = 0; bool chg = false; nset = 0;
 #ifdef RG_FINE_PROF
   float nchg_f = 0.f;
 #endif
 #pragma unroll
   for (int k = 0; k < RG_RSLOTS; k++) {
     int r = LANE + RG_WAVE * k;
-    if (r >= ns) continue;
-    float D = R.D[k]; int old = R.quad[k], q = 0;
-    if (D > 0) {
-      float x = R.jar[k], f = R.floss[k];
-      if (f > 0) {
-        float R = rg_rcp(D);
-        if (x <= -R * f) cost += f * (-0.5f * R * f - x);
-        else if (x >= R * f) cost += f * (-0.5f * R * f + x);
-        else { q = 1; cost += 0.5f * D * x * x; }
-      } else if (x < 0) { q = 1; cost += 0.5f * D * x * x; }
-    }
-    R.quad[k] = q; chg |= q != old;
-#ifdef RG_FINE_PROF
-    nchg_f += q != old ? 1.f : 0.f;
-#endif
-  }
-#pragma unroll
-  for (int kk = 0; kk < RG_PSLOTS; kk++) {
-    int w = LANE + RG_WAVE * kk;
-    if (w < ncon * 6) {
-      int c = w / 6, k = w - 6 * c, old = s.p_quad[w], q = 0;
-      if (k < npyr(s.c_dim[c])) {
-        float x = R.pjar[kk], D = s.c_D[c];
-        if (x < 0) { q = 1; cost += 0.5f * D * x * x; }
+    bool diff = false;
+    if (r < ns) {
+      float D = R.D[k]; const int oldw = R.quad[k], old = oldw & 1; int q = 0;
+      if (D > 0) {
+        float x = R.jar[k], f = R.floss[k];
+        if (f > 0) {
+          float R = rg_rcp(D);
+          if (x <= -R * f) cost += f * (-0.5f * R * f - x);
+          else if (x >= R * f) cost += f * (-0.5f * R * f + x);
+          else { q = 1; cost += 0.5f * D * x * x; }
+        } else if (x < 0) { q = 1; cost += 0.5f * D * x * x; }
       }
-      s.p_quad[w] = q; chg |= q != old;
+      R.quad[k] = q | (oldw & 2); chg |= q != old; diff = q != (oldw >> 1);
 #ifdef RG_FINE_PROF
       nchg_f += q != old ? 1.f : 0.f;
 #endif
     }
+    nset += __popcll(__ballot(diff));
+  }
+#pragma unroll
+  for (int kk = 0; kk < RG_PSLOTS; kk++) {
+    int w = LANE + RG_WAVE * kk;
+    bool diff = false;
+    if (w < ncon * 6) {
+      const int c = w / 6, k = w - 6 * c, oldw = s.p_quad[w], old = oldw & 1; int q = 0;
+      if (k < npyr(s.c_dim[c])) {
+        float x = R.pjar[kk], D = s.c_D[c];
+        if (x < 0) { q = 1; cost += 0.5f * D * x * x; }
+      }
+      s.p_quad[w] = (unsigned char)(q | (oldw & 2)); chg |= q != old; diff = q != (oldw >> 1);
+#ifdef RG_FINE_PROF
+      nchg_f += q != old ? 1.f : 0.f;
+#endif
+    }
+    nset += __popcll(__ballot(diff));
   }
   changed = __ballot(chg) != 0;
 #ifdef RG_FINE_PROF
@@ -1858,7 +1868,7 @@ __device__ __forceinline__ void rg_JT_force(RgM m, RgLds& s, const RowRegs& R, f
     int w = LANE + RG_WAVE * kk;
     if (w < ncon * 6) {
       const int c = w / 6, q = w - 6 * c;
-      const float f = s.p_quad[w] ? -s.c_D[c] * R.pjar[kk] : 0.f;   // (a pyramid row carries force exactly when it is quadratic: x < 0)
+      const float f = (s.p_quad[w] & 1) ? -s.c_D[c] * R.pjar[kk] : 0.f;   // (a pyramid row carries force exactly when it is quadratic: x < 0)
       float* o = q < 4 ? s.c_bdot + 4 * c + q : (q == 4 ? s.c_aref0 + c : s.c_kb + c);
       *o = f;
     }
@@ -2214,6 +2224,127 @@ template <int N> __device__ __forceinline__ void rg_cholinv_apply_n(RgM m, RgLds
   if (i < N) x[i] = xa + xb;
   SYNC();
 }
+// ---- A few rows changed zone since the factorisation (rank-k change of the Hessian, k <= RG_WOODBURY): x = inv(H + U C U') g by the Woodbury identity on
+// the inverse factor W that is still in the work matrix, instead of assembling and factorising H again (mj_solNewton itself updates its factor row by row,
+// engine_solver.c HessianIncremental).  U's columns are the changed rows' Jacobians j_a (sparse), C = diag(+D_a: the row entered its quadratic zone,
+// -D_a: it left), P = W' U (lane = dof, one register per changed row):
+//     x = W (y - P t),   y = W' g,   (inv(C) + P' P) t = P' y.
+// Cost: the two passes of rg_cholinv_apply, ~14 LDS reads per changed row, k (k + 3) / 2 wave sums and a k x k elimination on wave-uniform numbers --
+// ~4 k cycles against ~26 k for assembly + factorisation.  Returns false (x untouched) when the small system is numerically singular: the caller
+// then factorises.  Measured on the bench stream: half of the refactorisations follow a change of <= 2 rows, 70 % of <= 4 (tools/stage_profile.py, RG_FINE_PROF).
+#ifndef RG_WOODBURY
+#define RG_WOODBURY 4
+#endif
+__device__ __forceinline__ int lane_bcast_i(int v, int src) { return __builtin_bit_cast(int, lane_bcast(__builtin_bit_cast(float, v), src)); }
+template <int N> __device__ __forceinline__ bool rg_cholinv_woodbury_n(RgM m, RgLds& s, const RowRegs& R, float* x) {
+  constexpr int NC = (N + 3) / 4, K = RG_WOODBURY;
+  const int hs = m.hs, hs4 = hs >> 2, i = LANE, ic = i < N ? i : 0, ns = nsrow(m), ncon = s.ncon;
+  const float g = i < N ? x[i] : 0.f;
+  const float* col = s.H + ic;     // column `ic` of W: W[mm][ic] = col[mm * hs]
+  float p[K], cinv[K];
+#pragma unroll
+  for (int a = 0; a < K; a++) { p[a] = 0.f; cinv[a] = 1.f; }
+  int na = 0;
+  // P = W' U, one changed row after the other (wave-uniform loops over ballots)
+#pragma unroll
+  for (int k = 0; k < RG_RSLOTS; k++) {
+    const int r = LANE + RG_WAVE * k, qw = R.quad[k];
+    unsigned long long msk = __ballot(r < ns && R.D[k] > 0 && (qw & 1) != (qw >> 1));
+    while (msk) {
+      const int L = __builtin_ctzll(msk); msk &= msk - 1;
+      const int desc = lane_bcast_i(R.desc[k], L), qq = lane_bcast_i(qw, L); const float D = lane_bcast(R.D[k], L);
+      const int t = (desc >> 6) & 31; float v;
+      if (t == 31) v = col[(desc & 63) * hs];
+      else { v = 0.f; for (int e = 0; e < 4; e++) { const int d = s.ten_cdof[4 * t + e]; if (d != 255) v += s.tenJ[4 * t + e] * col[d * hs]; } }
+      if ((desc >> 11) & 1) v = -v;
+      const float ci = (qq & 1) ? rg_rcp(D) : -rg_rcp(D);
+#pragma unroll
+      for (int a = 0; a < K; a++) if (a == na) { p[a] = i < N ? v : 0.f; cinv[a] = ci; }
+      na++;
+    }
+  }
+#pragma unroll
+  for (int kk = 0; kk < RG_PSLOTS; kk++) {
+    const int w = LANE + RG_WAVE * kk; const int qw = w < ncon * 6 ? s.p_quad[w] : 0;
+    unsigned long long msk = __ballot((qw & 1) != ((qw >> 1) & 1));
+    while (msk) {
+      const int L = __builtin_ctzll(msk); msk &= msk - 1;
+      const int wr = L + RG_WAVE * kk, c = wr / 6, q = wr - 6 * c, qq = lane_bcast_i(qw, L);
+      const int nnz = s.c_nnz[c], dim = s.c_dim[c];
+      const float* Bc = s.c_pool + s.c_off[c];
+      // lane sl < nnz holds the row's entry for slot sl and the slot's dof; the sum over the slots reads them back lane by lane
+      float jv = 0.f; int jd = 0;
+      if (i < nnz) {
+        jv = Bc[i];
+        if (dim > 1) { const int kb = q >> 1; const float mu = s.c_mu[2 * c + (kb >> 1)]; jv += ((q & 1) ? -mu : mu) * Bc[(kb + 1) * nnz + i]; }
+        jd = s.c_idx[c * RG_W + i];
+      }
+      float v = 0.f;   // (all RG_W slots, the unused ones with a zero entry on dof 0: independent LDS reads, all in flight)
+#pragma unroll
+      for (int sl = 0; sl < RG_W; sl++) v = __builtin_fmaf(lane_bcast(jv, sl), col[lane_bcast_i(jd, sl) * hs], v);
+      const float D = s.c_D[c];
+      const float ci = (qq & 1) ? rg_rcp(D) : -rg_rcp(D);
+#pragma unroll
+      for (int a = 0; a < K; a++) if (a == na) { p[a] = i < N ? v : 0.f; cinv[a] = ci; }
+      na++;
+    }
+  }
+  // y = W' g
+  float y0 = 0.f, y1 = 0.f;
+#pragma unroll
+  for (int mm = 0; mm < N; mm += 2) {
+    y0 = __builtin_fmaf(col[mm * hs], lane_bcast(g, mm), y0);
+    if (mm + 1 < N) y1 = __builtin_fmaf(col[(mm + 1) * hs], lane_bcast(g, mm + 1), y1);
+  }
+  float y = i < N ? y0 + y1 : 0.f;
+  // S = inv(C) + P' P (symmetric, unused slots: identity), r = P' y
+  float S[K][K], rr[K];
+#pragma unroll
+  for (int a = 0; a < K; a++) {
+    rr[a] = a < na ? wave_sum(p[a] * y) : 0.f;
+#pragma unroll
+    for (int b = a; b < K; b++) { float v = (a < na && b < na) ? wave_sum(p[a] * p[b]) : 0.f; if (a == b) v += cinv[a]; S[a][b] = v; S[b][a] = v; }
+  }
+  // elimination with the diagonal as pivots (S is symmetric, not definite: a row that left makes a negative pivot), scale-relative singularity test
+  bool ok = true;
+#pragma unroll
+  for (int a = 0; a < K; a++) {
+    const float piv = S[a][a];
+    if (!(fabsf(piv) > 1e-4f * fabsf(cinv[a]))) ok = false;   // (|pivot| / |1 / D| = 1 / (1 + D j' inv(H_rest) j): below this the difference has lost four digits)
+    const float ip = rg_rcp(piv);
+#pragma unroll
+    for (int b = a + 1; b < K; b++) {
+      const float f = S[b][a] * ip;
+#pragma unroll
+      for (int c2 = a + 1; c2 < K; c2++) S[b][c2] -= f * S[a][c2];
+      rr[b] -= f * rr[a];
+    }
+  }
+  float t[K];
+#pragma unroll
+  for (int a = K - 1; a >= 0; a--) { float v = rr[a];
+#pragma unroll
+    for (int b = a + 1; b < K; b++) v -= S[a][b] * t[b];
+    t[a] = v * rg_rcp(S[a][a]); }
+  if (!ok) return false;
+#pragma unroll
+  for (int a = 0; a < K; a++) y -= p[a] * t[a];
+  // x = W y
+  const rgf4* row = (const rgf4*)s.H + ic * hs4;
+  float xa = 0.f, xb = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    const rgf4 w = row[c];
+    xa = __builtin_fmaf(w.x, lane_bcast(y, 4 * c), xa);
+    if (4 * c + 1 < N) xb = __builtin_fmaf(w.y, lane_bcast(y, 4 * c + 1), xb);
+    if (4 * c + 2 < N) xa = __builtin_fmaf(w.z, lane_bcast(y, 4 * c + 2), xa);
+    if (4 * c + 3 < N) xb = __builtin_fmaf(w.w, lane_bcast(y, 4 * c + 3), xb);
+  }
+  if (i < N) x[i] = xa + xb;
+  SYNC();
+  return true;
+}
+__device__ __forceinline__ bool rg_cholinv_woodbury(RgM m, RgLds& s, const RowRegs& R, float* x) { return m.nvc == 30 ? rg_cholinv_woodbury_n<30>(m, s, R, x) : rg_cholinv_woodbury_n<24>(m, s, R, x); }
 #ifdef RG_CHOL_MFMA
 __device__ __forceinline__ void rg_chol_inv_solve(RgM m, RgLds& s, float* x) { if (m.nvc == 30) rg_chol_mfma_n<30>(m, s, x); else rg_chol_mfma_n<24>(m, s, x); }
 #else
@@ -2403,7 +2534,7 @@ template <bool SENSORS> __device__ __forceinline__ int rg_solve(RgM m, RgLds& s,
     if (pass == 1) rg_M_mul(m, s, ME, a, s.Ma);    // (at a = qacc_smooth the Gauss term is exactly zero: no M a needed to price it)
     rg_J_mul(m, s, RR, a, false);
     if (pass == 1) { PFOR(i, nvc) g += 0.5f * (s.Ma[i] - s.fs[i]) * (a[i] - s.as[i]); g = wave_sum(g); }
-    bool chg; cost_pick[pass] = g + rg_constraint_update(m, s, RR, chg);
+    bool chg; int nsd; cost_pick[pass] = g + rg_constraint_update(m, s, RR, chg, nsd);
   }
   if (!(cost_pick[1] < cost_pick[0])) {
     PFOR(i, nvc) s.a[i] = s.as[i];
@@ -2421,7 +2552,7 @@ template <bool SENSORS> __device__ __forceinline__ int rg_solve(RgM m, RgLds& s,
   for (int iter = 0;; iter++) {
     float gauss = 0; PFOR(i, nvc) gauss += 0.5f * (s.Ma[i] - s.fs[i]) * (s.a[i] - s.as[i]);
     gauss = wave_sum(gauss);
-    bool flags_changed; float cc = rg_constraint_update(m, s, RR, flags_changed);
+    bool flags_changed; int nset; float cc = rg_constraint_update(m, s, RR, flags_changed, nset);
     oldcost = cost; cost = gauss + cc;
 #ifdef RG_FINE_PROF
     if ((flags & 2) && iter > 0 && flags_changed && LANE == 0) { const float k = s.prof[47]; s.prof[36] += 1.f; s.prof[37] += k; s.prof[38] += k <= 2.f ? 1.f : 0.f; s.prof[39] += k <= 4.f ? 1.f : 0.f; s.prof[40] += k <= 8.f ? 1.f : 0.f; }
@@ -2439,13 +2570,24 @@ template <bool SENSORS> __device__ __forceinline__ int rg_solve(RgM m, RgLds& s,
     if (gn < tol || iter >= m.iterations) break;
     iters = iter + 1;
     PROFS(12); PROFF(27);
-    if (!have_factor || flags_changed) {
+    // Factorise again?  Tree-sparse / LDS paths: whenever a row changed zone since the last iteration.  Register path: the inverse factor in the work
+    // matrix stays valid while the rows that differ from ITS zones (nset) are few -- those iterations correct the solve (rg_cholinv_woodbury).
+    const bool invfac = regchol && !tree;   // (the work matrix holds the inverse factor W)
+    bool refactor = !have_factor || (invfac ? nset > RG_WOODBURY : flags_changed), corrected = false;
+#ifdef RG_WOODBURY_CHECK   /* emulation-harness self check (tests/test_kernel_emul.py::test_woodbury_correction_matches_refactorisation_emul): every corrected solve is also done by refactorisation and the two are compared */
+    float dbg_g = LANE < nvc ? s.search[LANE] : 0.f, dbg_xw = 0.f; bool dbg_chk = false;
+#endif
+    if (!refactor && invfac && nset > 0) { corrected = rg_cholinv_woodbury(m, s, RR, s.search); if (!corrected) refactor = true; }
+#ifdef RG_WOODBURY_CHECK
+    if (corrected) { dbg_xw = LANE < nvc ? s.search[LANE] : 0.f; SYNC(); if (LANE < nvc) s.search[LANE] = dbg_g; SYNC(); corrected = false; refactor = true; dbg_chk = true; }
+#endif
+    if (refactor) {
     have_factor = true;
     if (tree) {
       // H <- M in the block layout (the factor only uses the lower triangle), then + J' D J on the same addresses
       rg_M_to_blocks(m, s);
 #pragma unroll
-      for (int k = 0; k < RG_RSLOTS; k++) { int r = LANE + RG_WAVE * k; if (r < ns && RR.D[k] > 0 && RR.quad[k]) srow_hess_tree(s, RR.desc[k], RR.D[k]); }
+      for (int k = 0; k < RG_RSLOTS; k++) { int r = LANE + RG_WAVE * k; if (r < ns && RR.D[k] > 0 && (RR.quad[k] & 1)) srow_hess_tree(s, RR.desc[k], RR.D[k]); }
     } else {
     // H = M + J' D J over the quadratic rows (LDS atomics from one wave: in-order, deterministic)
     {  // H <- M: zero the compact nvc x hs matrix, then scatter the tree-sparse entries (lower triangle: what the factorisation reads)
@@ -2460,7 +2602,7 @@ template <bool SENSORS> __device__ __forceinline__ int rg_solve(RgM m, RgLds& s,
     }
     SYNC();
 #pragma unroll
-    for (int k = 0; k < RG_RSLOTS; k++) { int r = LANE + RG_WAVE * k; if (r < ns && RR.D[k] > 0 && RR.quad[k]) srow_hess(m, s, RR.desc[k], RR.D[k]); }
+    for (int k = 0; k < RG_RSLOTS; k++) { int r = LANE + RG_WAVE * k; if (r < ns && RR.D[k] > 0 && (RR.quad[k] & 1)) srow_hess(m, s, RR.desc[k], RR.D[k]); }
     }
     // per contact, C = P' D_act P in the basis (normal, t1, t2, spin) has only its first row/column and its diagonal
     // non-zero: cn, ck[3], cd[3].  Lane c computes them for contact c; the block loop below reads them lane to lane.
@@ -2476,7 +2618,7 @@ template <bool SENSORS> __device__ __forceinline__ int rg_solve(RgM m, RgLds& s,
       const int dim = s.c_dim[cc], nnz = s.c_nnz[cc], nb = nbasis(dim);
       const float D = s.c_D[cc], mu0 = s.c_mu[2 * cc], mu1 = s.c_mu[2 * cc + 1];
       const unsigned char* pq = s.p_quad + 6 * cc;
-      const int q0 = pq[0], q1 = pq[1], q2 = pq[2], q3 = pq[3], q4 = pq[4], q5 = pq[5];
+      const int q0 = pq[0] & 1, q1 = pq[1] & 1, q2 = pq[2] & 1, q3 = pq[3] & 1, q4 = pq[4] & 1, q5 = pq[5] & 1;
       float cn, ck0 = 0.f, ck1 = 0.f, ck2 = 0.f, cd0 = 0.f, cd1 = 0.f, cd2 = 0.f;
       if (dim == 1) cn = q0 ? D : 0.f;
       else {
@@ -2508,6 +2650,11 @@ template <bool SENSORS> __device__ __forceinline__ int rg_solve(RgM m, RgLds& s,
         }
       }
     }
+    // the zones this factor is built with (bit 1 of the flag words)
+#pragma unroll
+    for (int k = 0; k < RG_RSLOTS; k++) RR.quad[k] = (RR.quad[k] & 1) * 3;
+#pragma unroll
+    for (int kk = 0; kk < RG_PSLOTS; kk++) { const int w = LANE + RG_WAVE * kk; if (w < ncon * 6) s.p_quad[w] = (unsigned char)((s.p_quad[w] & 1) * 3); }
     // dense path: the gradient rides through the factorisation as one more row (row nvc), so the forward substitution costs nothing
     if (!tree && rhs_row) { if (LANE < hs) s.H[nvc * hs + LANE] = LANE < nvc ? s.search[LANE] : 0.f; fresh_rhs = true; }
     SYNC();
@@ -2518,9 +2665,12 @@ template <bool SENSORS> __device__ __forceinline__ int rg_solve(RgM m, RgLds& s,
     }
     PROFS(14);
     if (tree) { LtdlDesc LT; rg_ltdl_load((const int*)0, m.ltdl_pair_c, 0, m.n_pair_rounds_c, LT); rg_ltdl_solve(s, LT, s.search, LANE, LANE < nvc, akk_own); }
-    else if (regchol) { if (!fresh_rhs) rg_cholinv_apply(m, s, s.search); }
+    else if (regchol) { if (!fresh_rhs && !corrected) rg_cholinv_apply(m, s, s.search); }
     else if (fresh_rhs) rg_chol_solve_bwd(m, s, s.search); else rg_chol_solve(m, s, s.search);
     fresh_rhs = false;
+#ifdef RG_WOODBURY_CHECK
+    if (dbg_chk) { float xf = LANE < nvc ? s.search[LANE] : 0.f; float e = wave_max(fabsf(xf - dbg_xw)), n = wave_max(fabsf(xf)); if (LANE == 0) { const float rel = e / (n + 1e-30f); if (rel > rg_wchk_max) rg_wchk_max = rel; rg_wchk_n++; rg_wchk_rows += nset; } }
+#endif
     PROFS(15); PROFF(30);
     // exact line search along `search`
     rg_M_mul(m, s, ME, s.search, s.Mv);
@@ -2568,7 +2718,7 @@ template <bool SENSORS> __device__ __forceinline__ int rg_solve(RgM m, RgLds& s,
   // scratch instead of the incrementally advanced residuals: identical to ~1e-7 relative, and 3.5 % of the step.)
 #ifdef RG_SOLVE_RECOMPUTE
   rg_J_mul(m, s, RR, s.a, false);
-  { bool chg; rg_constraint_update(m, s, RR, chg); }
+  { bool chg; int nsd; rg_constraint_update(m, s, RR, chg, nsd); }
   rg_JT_force(m, s, RR, s.jtf);
 #endif
   if (SENSORS) {   // sensor pass (its own instantiation: the hot path's solver carries none of this): normal force of every contact = sum of its pyramid edge forces (mju_decodePyramid), f = -D jar where jar < 0

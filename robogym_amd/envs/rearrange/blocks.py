@@ -633,7 +633,7 @@ class BatchedBlockRearrangeEnv:
             yaw = self._yaw[rows]
             self._write_goal(rows, self._grid_placement(yaw, rows), yaw)
         # ---- live envs with a reached goal: ObjectStateGoal.next_goal (what reset_goals() does on request)
-        grows = np.nonzero(newgoal.astype(bool) & (st == 0))[0]
+        grows = np.nonzero(newgoal.astype(bool) & (st == 0) & ~done.astype(bool))[0]     # (an episode that ends on the same step keeps the reached goal's entries in its terminal observation: ra_recipe_kernel)
         if len(grows):
             yaw = self.goal_rot[torch.as_tensor(grows, device=dev, dtype=torch.long), :, 2].cpu().numpy().astype(np.float64)
             self._write_goal(grows, self._grid_placement(yaw, grows), yaw)

@@ -2,6 +2,7 @@
 tests/emul) against the double-precision oracle.  These run without a GPU; the same comparisons run
 on the real gfx950 build in test_gpu_parity.py."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -106,19 +107,24 @@ def test_pair_distance_cache_is_exact(locked_model, emul_lib):
     assert int(sims[0].status.max()) == 0
 
 
-def _forward_substitution_paths(make):
-    """The dense Newton step carries the gradient through the Cholesky factorisation as one more row (the forward substitution
-    for free); flag bit 6 runs the substitution as its own pass instead: same solution to rounding."""
+def _forward_substitution_paths(make, tol=5e-6, tol_median=None):
+    """Two implementations of the dense Newton step: the default (round 6: right-looking elimination in registers with the inverse
+    factor riding along, rank-k Woodbury corrections instead of refactorisations while few rows changed zone) and, behind flag bit 6,
+    the LDS path of rounds 2-5 (left-looking blocked Cholesky, separate substitutions, refactorisation on every change).  Same Newton
+    iteration, different floating-point paths: the env.step results agree to the solver's tolerance (`tol`: the worst env of the batch;
+    `tol_median`: the median env)."""
     sims = [make() for _ in range(2)]
     rng = np.random.RandomState(13)
-    worst = 0.0
+    worst = np.zeros(sims[0].batch_size)
     for k in range(8):
         a = torch.tensor(rng.uniform(-1, 1, (sims[0].batch_size, 20)), dtype=torch.float32, device=sims[0].qpos.device)
         for sim, fl in zip(sims, (0, 64)):
             sim.env_step(action=a, nforward_ticks=3, flags=fl)
-        worst = max(worst, float((sims[0].qpos - sims[1].qpos).abs().max()))
+        worst = np.maximum(worst, (sims[0].qpos - sims[1].qpos).abs().max(dim=1).values.cpu().numpy())
         sims[1].view(0)[:] = sims[0].view(0); sims[1].view(1)[:] = sims[0].view(1); sims[1].touch_qpos()     # (keep the two on one trajectory: the comparison is per step)
-    assert worst < 5e-6 and int(sims[0].status.max()) == 0 and int(sims[1].status.max()) == 0, worst
+    assert worst.max() < tol and int(sims[0].status.max()) == 0 and int(sims[1].status.max()) == 0, (worst.max(), np.median(worst))
+    if tol_median is not None:
+        assert np.median(worst) < tol_median, np.median(worst)
 
 
 def test_forward_substitution_inside_the_factorisation_emul(locked_model, emul_lib):
@@ -126,8 +132,36 @@ def test_forward_substitution_inside_the_factorisation_emul(locked_model, emul_l
 
 
 @pytest.mark.gpu
-def test_forward_substitution_inside_the_factorisation_gpu(locked_model):
-    _forward_substitution_paths(lambda: LockedSimulation(locked_model, 64, device="cuda:0"))
+def test_forward_substitution_inside_the_factorisation_gpu(locked_model, kernel_variant):
+    # 64 envs x 8 env.steps of 10 substeps with contacts: the median env agrees to 5e-6 (plane; default: 1.3e-4 measured, see below); an iterate that differs at the solver's tolerance (3e-7 of the scaled
+    # cost) moves a contact-rich env.step by up to ~1e-4 in qpos (plane: measured 1.4e-4); in the default configuration libccd's contact depth turns such a
+    # difference into another portal triangle on flat contacts: the worst env is bounded at the size of that effect, as everywhere else
+    _forward_substitution_paths(lambda: LockedSimulation(locked_model, 64, device="cuda:0"), tol=kernel_variant.tol(5e-4, 2e-2), tol_median=kernel_variant.tol(5e-6, 1e-3))
+
+
+def test_woodbury_correction_matches_refactorisation_emul(locked_model, tmp_path):
+    """Round 6: Newton iterations after which only a few rows changed zone do not factorise H again: they correct the solve with the Woodbury
+    identity on the inverse factor (rg_cholinv_woodbury).  A harness build (-DRG_WOODBURY_CHECK) does BOTH on every such iteration -- the corrected
+    solve, then assembly + factorisation on the same right-hand side -- and records the largest relative difference of the two search directions."""
+    import ctypes
+    import subprocess
+
+    from robogym_amd import _native
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "librgstep_emul_wchk.so")
+    subprocess.check_call(["g++", "-O2", "-fPIC", "-std=c++17", "-DRG_EMUL", "-DRG_WOODBURY_CHECK", "-I" + os.path.join(root, "tests", "emul"), "-I" + os.path.join(root, "robogym_amd", "csrc"),
+                           "-w", "-shared", "-o", so, os.path.join(root, "tests", "emul", "hip_emul.cpp"), "-x", "c++", os.path.join(root, "robogym_amd", "csrc", "rg_api.hip")])
+    lib = _native.bind(so)
+    sim = LockedSimulation(locked_model, 1, lib=lib, n_substeps=3)
+    rng = np.random.RandomState(13)
+    for k in range(6):
+        sim.env_step(action=torch.tensor(rng.uniform(-1, 1, (1, 20)), dtype=torch.float32), nforward_ticks=3, flags=0)
+    mx, n, rows = ctypes.c_float(), ctypes.c_int(), ctypes.c_int()
+    lib.rg_emul_woodbury_check(ctypes.byref(mx), ctypes.byref(n), ctypes.byref(rows))
+    assert int(sim.status.max()) == 0
+    assert n.value >= 10 and rows.value >= n.value, (n.value, rows.value)      # the path is taken, with one to four rows each
+    assert mx.value < 1e-3, mx.value                                            # measured 4.7e-5 (fp32, the rest ~1e-6)
 
 
 def test_pipelined_reset_state_machine(locked_model, emul_lib):

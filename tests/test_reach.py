@@ -211,28 +211,41 @@ def _smooth_actions(nsteps, nu, amp, seed):
 def test_reach_free_running_1000_steps_gpu(reach_model, oracle_lib):
     """dactyl/reach (configs[0], the hand alone), 1000 env.steps = 10 000 mj_steps, NO re-synchronisation: both sides start from the same bytes and
     run on their own under a smooth ABSOLUTE action stream around the range centres (the fingers breathe by a fifth of their ranges; no finger
-    rams another, no joint reaches its limit: the contact-light protocol SURVEY section 7 hard-part 3 asks for).  Asserted: qpos L-infinity <= 1e-4 at step 1000,
-    median over the run <= 3e-5, at most 15 % of the steps beyond 1e-4 (a finger-finger contact that opens a substep apart on the two sides leaves a transient of
-    ~1e-3 whose tail decays slowly: 10.3 % of the steps in the default variant, measured), never beyond 5e-3.  This is NOT "<= 1e-4 at every step": the hand is an
-    attractor and returns, but the transient is there and the bound says so.  (Under relative actions the targets random-walk into finger-finger collisions, and the run leaves 1e-4 at the first impact that the
-    two precisions resolve a substep apart: measured 4e-3 — that is what the re-synchronised protocol is for.)"""
-    sim = ReachSimulation(reach_model, 2, device="cuda:0", relative_action=False)
-    ora = OracleReachPhysics(reach_model, relative_action=False)
-    ora.zero_control_settle(20)
-    _sync(sim, ora)
-    acts = _smooth_actions(1000, 20, 0.2, 11)
-    err, ncon = np.zeros(1000), 0
-    for k in range(1000):
-        sim.env_step(action=torch.tensor(np.repeat(acts[k][None].astype(np.float32), 2, 0), device=sim.device), nforward_ticks=3)
-        ora.env_step(acts[k].astype(np.float32).astype(np.float64))
-        err[k] = np.abs(sim.qpos[0].cpu().numpy().astype(np.float64) - ora.sim.qpos).max()
-        ncon = max(ncon, ora.sim.ncon)
-    span = np.ptp(np.array([ora.sim.qpos]), axis=0).max()
-    print("reach free-running (absolute smooth actions): qpos Linf at steps 1 / 10 / 100 / 1000 = %.1e / %.1e / %.1e / %.1e, max over the run %.1e; most contacts in a step %d"
-          % (err[0], err[9], err[99], err[999], err.max(), ncon))
-    beyond = float(np.mean(err > 1e-4))
-    print("   steps beyond 1e-4: %.1f %%" % (100 * beyond))
-    # measured (MI355X): 1e-7 ... 1e-6 throughout and 4e-7 / 1.4e-5 at step 1000 (plane / default) — the position-controlled hand is an attractor —, with
-    # a transient of 4e-4 / 1.1e-3 for a few steps where a finger-finger contact (up to 4 contacts exist even in this pose) opens a substep apart on the two sides
-    # (default variant: median 1.2e-5, 10.3 % of the steps beyond 1e-4 -- the tail of that transient decays slowly)
-    assert err[-1] <= 1e-4 and np.median(err) <= 3e-5 and beyond <= 0.15 and err.max() <= 5e-3 and int(sim.status.max()) == 0
+    rams another, no joint reaches its limit: the contact-light protocol SURVEY section 7 hard-part 3 asks for).  The position-controlled hand is an attractor:
+    the run stays at 1e-7 ... 1e-6 and returns there, but a finger-finger contact that opens a substep apart on the two sides leaves a transient of ~1e-3
+    whose tail decays over hundreds of steps -- and WHETHER a stream has such an event is decided by rounding.  Round 6: the bound is therefore anchored on
+    what fp32 alone does to this protocol -- the oracle's own source built in float, run beside the kernel on the same three action streams (the float build
+    itself leaves 1e-4 on 7 / 10 / 12 % of the steps in the portal-plane configuration and on 12 / 29 / 38 % in the default one; rounds 4-5 asserted
+    "<= 15 %" from ONE stream on which the kernel happened to show 10 %).  Asserted: the kernel's fraction of steps beyond 1e-4, its largest excursion and its
+    run median are within small factors of the float build's, it ends where it started (<= 3e-4), and no status bit.
+    (Under relative actions the targets random-walk into finger-finger collisions, and the run leaves 1e-4 at the first impact that the
+    two precisions resolve a substep apart: measured 4e-3 -- that is what the re-synchronised protocol is for.)"""
+    from oracle import rg_oracle
+    from robogym_amd.mujoco.model_blob import pack_model
+
+    stats_k, stats_f = [], []
+    for seed in (11, 12, 13):
+        sim = ReachSimulation(reach_model, 2, device="cuda:0", relative_action=False)
+        ora = OracleReachPhysics(reach_model, relative_action=False)
+        ora.zero_control_settle(20)
+        _sync(sim, ora)
+        twin = OracleReachPhysics(reach_model, relative_action=False)
+        twin.sim = rg_oracle.OracleSim(pack_model(reach_model), f32=True)
+        for name in ("qpos", "qvel", "ctrl", "pid", "qacc_warmstart"):
+            getattr(twin.sim, name)[:] = getattr(ora.sim, name)
+        acts = _smooth_actions(1000, 20, 0.2, seed)
+        err, e32 = np.zeros(1000), np.zeros(1000)
+        for k in range(1000):
+            sim.env_step(action=torch.tensor(np.repeat(acts[k][None].astype(np.float32), 2, 0), device=sim.device), nforward_ticks=3)
+            a = acts[k].astype(np.float32).astype(np.float64)
+            ora.env_step(a); twin.env_step(a)
+            err[k] = np.abs(sim.qpos[0].cpu().numpy().astype(np.float64) - ora.sim.qpos).max()
+            e32[k] = np.abs(twin.sim.qpos.astype(np.float64) - ora.sim.qpos).max()
+        assert int(sim.status.max()) == 0
+        stats_k.append((err[-1], np.median(err), np.mean(err > 1e-4), err.max())); stats_f.append((e32[-1], np.median(e32), np.mean(e32 > 1e-4), e32.max()))
+        print("reach free-running seed %d: kernel end %.1e median %.1e beyond %.3f max %.1e | float oracle end %.1e median %.1e beyond %.3f max %.1e" % ((seed,) + stats_k[-1] + stats_f[-1]))
+    K, F = np.array(stats_k), np.array(stats_f)
+    assert K[:, 2].mean() <= 1.5 * F[:, 2].mean() + 0.05, (K[:, 2], F[:, 2])          # steps beyond 1e-4
+    assert K[:, 3].max() <= 3.0 * F[:, 3].max(), (K[:, 3], F[:, 3])                   # the largest excursion
+    assert np.median(K[:, 1]) <= 3.0 * np.median(F[:, 1]) + 1e-6, (K[:, 1], F[:, 1])  # run medians
+    assert K[:, 0].max() <= 3e-4                                                      # and back at the attractor at the end
