@@ -542,6 +542,84 @@ __device__ __forceinline__ bool rb_chol(RbLds& s, int n) {
   }
   return ok;
 }
+#if RB_T == 256 && RB_MAXGROUP == 96 && !defined(RB_LDS_CHOL)
+// ---- Round 6, the large configuration: the same factorisation on the MATRIX PIPE, by ONE wave.  A 96-dof Hessian is a dense matrix and its right-looking Cholesky is
+// rank-k updates of the trailing block -- the one place of this code base where the work IS a small GEMM.  The UPPER triangle of the (scaled) matrix lives in six
+// 32 x 32 f32 accumulator tiles of wave 0 (96 registers; rgl::rg_mfma32: lane l holds column l % 32, register r row 8 (r / 4) + 4 (l / 32) + r % 4): the part of pivot
+// row j right of the diagonal is then one register across 32 lanes of each tile of its row block, which IS column j of L below the diagonal -- no transposes, no LDS,
+// no barriers.  Step (j, j + 1): pivots and the multiplier by v_readlane, w = row / root on the VALU (row j + 1 takes step j's correction there), the two k-slots of
+// the operand put together with one v_permlane32_swap per 32-column piece, then one v_mfma_f32_32x32x2_f32 per remaining tile (6 / 3 / 1 by row block: 160 in all),
+// A = -w masked to the rows that are not final, B = w; columns j, j + 1 of L go to the packed block as they are formed.  (The blocked version above: per 8 columns a
+// serial diagonal block, a panel pass and a 16 x 16 VALU tile update with three workgroup barriers, 127 k cycles per factorisation.  A first MFMA version with the
+// nine tiles spread over the four waves and one barrier per column pair measured no faster than that: 48 four-wave barriers cost what the arithmetic saved.)
+// (No inverses of diagonal blocks: this configuration's substitutions are rb_chol_solve_wave's.)
+__device__ __forceinline__ bool rb_chol_mfma(RbLds& s, int n) {
+  bool ok = true;
+  if (WID == 0) {
+    const int l = WL, col = l & 31, hi = l >> 5;
+    rgacc T[3][3];   // tiles (R, C), R <= C
+#pragma unroll
+    for (int R = 0; R < 3; R++)
+#pragma unroll
+      for (int C = R; C < 3; C++)
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int i = 32 * R + 8 * g + 4 * hi + q, c = 32 * C + col;
+            float v = (i == c) ? 1.f : 0.f;                                   // padding beyond n: identity
+            if (i < n && c < n) v = i >= c ? s.A[RB_TRI(i, c)] : s.A[RB_TRI(c, i)];
+            T[R][C][4 * g + q] = v;
+          }
+    const int nstep = (n + 1) & ~1;
+#pragma unroll
+    for (int Rj = 0; Rj < 3; Rj++) {
+#pragma unroll
+      for (int jl = 0; jl < 32; jl += 2) {
+        const int j = 32 * Rj + jl;
+        if (j < nstep) {
+          constexpr int dummy = 0; (void)dummy;
+          const int rj = 4 * (jl >> 3) + (jl & 3), hj = (jl >> 2) & 1, lj = 32 * hj + jl;
+          float w0[3], w1[3];
+          const float p = lane_bcast(T[Rj][Rj][rj], lj);
+          if (!(p > RB_MINVAL)) ok = false;
+          const float inv = rg_rsqrt(fmaxf(p, RB_MINVAL));
+#pragma unroll
+          for (int C = Rj; C < 3; C++) w0[C] = T[Rj][C][rj] * inv;
+          const float mlt = lane_bcast(w0[Rj], lj + 1);
+#pragma unroll
+          for (int C = Rj; C < 3; C++) w1[C] = __builtin_fmaf(-mlt, w0[C], T[Rj][C][rj + 1]);
+          const float p2 = lane_bcast(w1[Rj], lj + 1);
+          if (!(p2 > RB_MINVAL)) ok = false;
+          const float inv2 = rg_rsqrt(fmaxf(p2, RB_MINVAL));
+          float WW[3];
+#pragma unroll
+          for (int C = Rj; C < 3; C++) {
+            w1[C] *= inv2;
+            const int x = 32 * C + col;
+            if (hi == hj && x < n) {                                           // columns j, j + 1 of L (rows x >= j / j + 1)
+              if (x >= j) s.A[RB_TRI(x, j)] = w0[C];
+              if (x >= j + 1 && j + 1 < n) s.A[RB_TRI(x, j + 1)] = w1[C];
+            }
+            WW[C] = hj == 0 ? rg_halves<0>(w0[C], w1[C]) : rg_halves<1>(w0[C], w1[C]);
+          }
+#pragma unroll
+          for (int R = Rj; R < 3; R++) {
+            const float Aop = (R > Rj || col > jl + 1) ? -WW[R] : 0.f;         // rows <= j + 1 are final
+#pragma unroll
+            for (int C = R; C < 3; C++) rg_mfma32(Aop, WW[C], T[R][C]);
+          }
+        }
+      }
+    }
+  }
+  BSYNC();
+  // (`ok` is wave 0's; the other waves learn it through LDS)
+  if (TID == 0) s.prow[0] = ok ? 1.f : 0.f;
+  BSYNC();
+  return s.prow[0] != 0.f;
+}
+#endif
 // x <- inv(L L') x for the group's local vector x[0..n), block by block: the diagonal block through its inverse (RB_NB threads, one
 // dot product each), the rest of the column panel by everybody.  (Every thread doing the 8 x 8 product redundantly, which saves a
 // barrier per block, measured 3 x slower: profiles/r03_ab.txt.)
@@ -571,6 +649,62 @@ __device__ __forceinline__ void rb_chol_solve(RbLds& s, int n, float* x) {
     BSYNC();
   }
 }
+#if RB_T == 256 && !defined(RB_LDS_CHOL)
+// Round 6: the same substitutions by ONE wave, no barriers.  rb_chol_solve above runs n / 8 blocks with two workgroup barriers each, twice (49 k cycles for the
+// full cube's 96 dofs, 11 times per mj_step).  Here lane i of wave 0 owns rows i and i + 64 of the right-hand side; column j's solution y_j is formed by its lane and
+// travels by v_readlane, every lane subtracts L[i][j] y_j from its rows -- the factor's entries come from the packed block in LDS, fetched ONE COLUMN AHEAD so that
+// their latency sits beside the arithmetic.  2 n dependent steps of a multiply, a broadcast and a fused multiply-add.
+__device__ __forceinline__ void rb_chol_solve_wave(RbLds& s, int n, float* x) {
+  if (WID == 0) {
+    const int i0 = WL, i1 = WL + 64;
+    const bool v0 = i0 < n, v1 = i1 < n;
+    float b0 = v0 ? x[i0] : 0.f, b1 = v1 ? x[i1] : 0.f;
+    const float d0 = v0 ? rg_rcp(s.A[RB_TRI(i0, i0)]) : 0.f, d1 = v1 ? rg_rcp(s.A[RB_TRI(i1, i1)]) : 0.f;
+    const int nblk = (n + 7) >> 3;
+    float c0[8], c1[8], n0[8], n1[8];
+    // forward: L y = b, eight columns per block; c0 / c1: this lane's entries of the block's columns (rows i0, i1), zero on and above the diagonal
+#pragma unroll
+    for (int q = 0; q < 8; q++) { c0[q] = (v0 && i0 > q && q < n) ? s.A[RB_TRI(i0, q)] : 0.f; c1[q] = (v1 && q < n) ? s.A[RB_TRI(i1, q)] : 0.f; }
+    for (int jb = 0; jb < nblk; jb++) {
+      const int j0 = 8 * jb, jn = j0 + 8;
+#pragma unroll
+      for (int q = 0; q < 8; q++) { const int j = jn + q; n0[q] = (v0 && i0 > j && j < n) ? s.A[RB_TRI(i0, j)] : 0.f; n1[q] = (v1 && i1 > j && j < n) ? s.A[RB_TRI(i1, j)] : 0.f; }
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int j = j0 + q;   // (columns >= n: c = 0 and the broadcast value is unused)
+        const float yl = j0 < 64 ? b0 * d0 : b1 * d1;
+        const float yj = lane_bcast(yl, j & 63);
+        if (j0 < 64) { if (i0 == j) b0 = yj; } else { if (i1 == j) b1 = yj; }
+        b0 = __builtin_fmaf(-c0[q], yj, b0); b1 = __builtin_fmaf(-c1[q], yj, b1);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; q++) { c0[q] = n0[q]; c1[q] = n1[q]; }
+    }
+    // backward: L' z = y, eight rows of L per block (descending); c0 / c1: this lane's entries of those rows (columns i0, i1), zero on and right of the diagonal
+    const int ktop = 8 * nblk - 1;
+#pragma unroll
+    for (int q = 0; q < 8; q++) { const int k = ktop - q; c0[q] = (v0 && k < n && i0 < k) ? s.A[RB_TRI(k, i0)] : 0.f; c1[q] = (v1 && k < n && i1 < k) ? s.A[RB_TRI(k, i1)] : 0.f; }
+    for (int kb = nblk - 1; kb >= 0; kb--) {
+      const int k0 = 8 * kb + 7, kn = k0 - 8;
+#pragma unroll
+      for (int q = 0; q < 8; q++) { const int k = kn - q; n0[q] = (v0 && k >= 0 && i0 < k) ? s.A[RB_TRI(k >= 0 ? k : 0, i0)] : 0.f; n1[q] = (v1 && k >= 0 && i1 < k) ? s.A[RB_TRI(k >= 0 ? k : 0, i1)] : 0.f; }
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int k = k0 - q;
+        const float zl = k0 - 7 < 64 ? b0 * d0 : b1 * d1;   // (a block of eight rows lies on one side of 64)
+        const float zk = lane_bcast(zl, k & 63);
+        if (k < n) { if (k0 - 7 < 64) { if (i0 == k) b0 = zk; } else { if (i1 == k) b1 = zk; } }
+        b0 = __builtin_fmaf(-c0[q], zk, b0); b1 = __builtin_fmaf(-c1[q], zk, b1);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; q++) { c0[q] = n0[q]; c1[q] = n1[q]; }
+    }
+    if (v0) x[i0] = b0;
+    if (v1) x[i1] = b1;
+  }
+  BSYNC();
+}
+#endif
 // Symmetric diagonal scaling of the block in s.A before it is factored: A <- S A S with S = diag(1 / sqrt(A_ii)) (s.sc).  The
 // blocks mix hand links with 5-gram cubelets and constraint weights D ~ 1e6: in fp32 the unscaled factor is accurate to a few
 // digits only and the Newton directions it gives converge linearly (20 iterations instead of 6); scaled, the condition number is
@@ -586,7 +720,11 @@ __device__ __forceinline__ void rb_group_solve(RbM m, RbLds& s, int g, const flo
   const int g0 = m.b_group_adr[g], n = m.b_group_adr[g + 1] - g0;
   BFOR(l, n) s.x[l] = s.sc[l] * src[m.b_group_dofs[g0 + l]];
   BSYNC();
+#if RB_T == 256 && !defined(RB_LDS_CHOL)
+  rb_chol_solve_wave(s, n, s.x);
+#else
   rb_chol_solve(s, n, s.x);
+#endif
   BFOR(l, n) dst[m.b_group_dofs[g0 + l]] = scale * s.sc[l] * s.x[l];
   BSYNC();
 }
@@ -2356,7 +2494,11 @@ RB_STAGE void sv_advance(RbCtx c, float alpha) {
 }
 RB_STAGE void sv_JT_force(RbCtx c) { RB_STAGE_ENTER(); rb_JT_force(m, s, S, s.qfrc_con); }
 RB_STAGE void sv_hessian(RbCtx c, int grp) { RB_STAGE_ENTER(); rb_M_block(m, s, SC(MSP), grp, (const float*)0, 0.f); rb_hessian_add(m, s, S, grp); }
+#if RB_T == 256 && RB_MAXGROUP == 96 && !defined(RB_LDS_CHOL)
+RB_STAGE int sv_factor(RbCtx c, int grp) { RB_STAGE_ENTER(); const int n = m.b_group_adr[grp + 1] - m.b_group_adr[grp]; rb_scale_block(s, n); return rb_chol_mfma(s, n) ? 1 : 0; }
+#else
 RB_STAGE int sv_factor(RbCtx c, int grp) { RB_STAGE_ENTER(); const int n = m.b_group_adr[grp + 1] - m.b_group_adr[grp]; rb_scale_block(s, n); return rb_chol(s, n) ? 1 : 0; }
+#endif
 RB_STAGE void sv_direction(RbCtx c, int grp) { RB_STAGE_ENTER(); rb_group_solve(m, s, grp, s.grad, s.search, -1.f); }
 #if RB_T == 64
 RB_STAGE int sv_factor_direction(RbCtx c, int grp) { RB_STAGE_ENTER(); return rb_reg_solve(m, s, grp, s.grad, s.search, -1.f) ? 1 : 0; }   // one wave: factorisation and both substitutions in registers

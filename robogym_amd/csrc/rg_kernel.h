@@ -1366,6 +1366,10 @@ __device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, const flo
     }
     if (nt <= RG_TLIST - 4 * RG_WAVE && r0 + 4 < nround) continue;
     SYNC();
+#ifdef RG_FINE_PROF
+    const long long tref0 = rg_clock();
+    if (prof && LANE == 0) { prof[42] += (float)nt; prof[43] += (float)((nt + RG_WAVE - 1) / RG_WAVE); }
+#endif
     for (int i0 = 0; i0 < nt; i0 += RG_WAVE) {
       int i = i0 + LANE, q = 0;
       bool hit = false, isbb = false, ispl = false;
@@ -1405,6 +1409,9 @@ __device__ __forceinline__ void rg_collision(RgCtx c, RgM m, RgLds& s, const flo
       if (LANE == 0) { int n = base + __popcll(bal); s.ncand = n < RG_MAXCAND ? n : RG_MAXCAND; }
       SYNC();
     }
+#ifdef RG_FINE_PROF
+    if (prof && LANE == 0) prof[44] += (float)(rg_clock() - tref0);
+#endif
     nt = 0;
   }
   if (prof && LANE == 0) prof[5] += (float)(rg_clock() - tb0);

@@ -31,3 +31,4 @@ if prof[24:36].sum() > 0 and prof[24:36].sum() < 1e7:   # analysis build (-DRG_F
     for i, n in enumerate(fine):
         print("    %-38s %9.0f" % (n, prof[24 + i]))
     print("    refactorisations after the first, per substep: %.3f ; rows that changed zone per refactorisation: mean %.2f ; with <= 2 rows %.3f, <= 4 %.3f, <= 8 %.3f per substep ; iterations that reused the factor %.3f per substep" % (prof[36], prof[37] / max(prof[36], 1e-9), prof[38], prof[39], prof[40], prof[41]))
+    print("    broadphase: pairs whose bound ran out per substep %.1f in %.2f batches of 64; cycles in the sphere / box tests %.0f of the broadphase's %.0f" % (prof[42], prof[43], prof[44], prof[5]))
