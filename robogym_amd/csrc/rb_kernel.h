@@ -741,16 +741,18 @@ template <int NP> __device__ __forceinline__ bool rb_reg_solve_n(RbM m, RbLds& s
   static_assert(NP % 4 == 0 && NP < 64, "row NP = the right-hand side");
   const int i = LANE;
   const float sci = i < n ? s.sc[i] : 1.f;
+  const int dof_own = i < n ? m.b_group_dofs[g0 + i] : 0;                    // (one vector load; the right-hand side reaches its row's registers lane by lane)
+  const float rhs_own = i < n ? sci * src[dof_own] : 0.f;
   float a[NP];
   {
     const bool isrow = i < n, isrhs = i == NP;
     const int rbase = isrow ? RB_TRI(i, 0) : 0;
 #pragma unroll
     for (int k = 0; k < NP; k++) {
-      const float sck = lane_bcast(sci, k);
+      const float sck = lane_bcast(sci, k), rk = lane_bcast(rhs_own, k);
       float v = (k == i) ? 1.f : 0.f;                                        // padding rows: identity
       if (isrow) v = k <= i ? s.A[rbase + k] * sci * sck : 0.f;              // (entries right of the diagonal are never read)
-      if (isrhs) v = k < n ? sck * src[m.b_group_dofs[g0 + (k < n ? k : 0)]] : 0.f;
+      if (isrhs) v = rk;
       a[k] = v;
     }
   }
@@ -781,7 +783,7 @@ template <int NP> __device__ __forceinline__ bool rb_reg_solve_n(RbM m, RbLds& s
     const float x0 = (lane_bcast(a[c0], NP) - p0 - lane_bcast(a[c0], c0 + 3) * x3 - lane_bcast(a[c0], c0 + 2) * x2 - lane_bcast(a[c0], c0 + 1) * x1) * i0;
     if (i == c0) xk = x0; else if (i == c0 + 1) xk = x1; else if (i == c0 + 2) xk = x2; else if (i == c0 + 3) xk = x3;
   }
-  if (i < n) dst[m.b_group_dofs[g0 + i]] = scale * sci * xk;
+  if (i < n) dst[dof_own] = scale * sci * xk;
   BSYNC();
   return ok;
 }
