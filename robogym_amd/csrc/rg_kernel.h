@@ -32,7 +32,7 @@ typedef const RgModelDev& RgM;
 typedef const __attribute__((address_space(4))) RgModelDev& RgM;
 #endif
 #ifdef RG_FINE_PROF
-#define RG_NPROF 48   /* analysis build (-DRG_FINE_PROF): sub-stage counters inside the Newton loop, slots 24.. (tools/stage_profile.py prints them) */
+#define RG_NPROF 56   /* analysis build (-DRG_FINE_PROF): sub-stage counters inside the Newton loop, slots 24.. (tools/stage_profile.py prints them) */
 #else
 #define RG_NPROF 24
 #endif
@@ -2584,7 +2584,14 @@ template <bool SENSORS> __device__ __forceinline__ int rg_solve(RgM m, RgLds& s,
 #ifdef RG_WOODBURY_CHECK   /* emulation-harness self check (tests/test_kernel_emul.py::test_woodbury_correction_matches_refactorisation_emul): every corrected solve is also done by refactorisation and the two are compared */
     float dbg_g = LANE < nvc ? s.search[LANE] : 0.f, dbg_xw = 0.f; bool dbg_chk = false;
 #endif
+#ifdef RG_FINE_PROF
+    const long long twb0 = rg_clock();
+#endif
     if (!refactor && invfac && nset > 0) { corrected = rg_cholinv_woodbury(m, s, RR, s.search); if (!corrected) refactor = true; }
+#ifdef RG_FINE_PROF
+    if ((flags & 2) && LANE == 0 && !(!have_factor) && invfac && nset > 0 && nset <= RG_WOODBURY) { s.prof[45] += 1.f; s.prof[46] += (float)(rg_clock() - twb0); if (!corrected) s.prof[49] += 1.f; }
+    if ((flags & 2) && LANE == 0 && refactor) s.prof[48] += 1.f;
+#endif
 #ifdef RG_WOODBURY_CHECK
     if (corrected) { dbg_xw = LANE < nvc ? s.search[LANE] : 0.f; SYNC(); if (LANE < nvc) s.search[LANE] = dbg_g; SYNC(); corrected = false; refactor = true; dbg_chk = true; }
 #endif

@@ -27,6 +27,30 @@ class BatchedYcbRearrangeEnv(BatchedBlockRearrangeEnv):
         return out
 
 
+class _LazyNames:
+    """info["object_names"] of a step with device-side slot trading: the per-env list of object names, resolved (one readback) when it is looked at"""
+
+    def __init__(self, names_of_group, slot_dev, b):
+        self._g, self._s, self._b, self._v = names_of_group, slot_dev, b, None
+
+    def _list(self):
+        if self._v is None:
+            self._v = [self._g[int(x) // self._b] for x in self._s.cpu().numpy()]
+        return self._v
+
+    def __len__(self):
+        return int(self._s.shape[0])
+
+    def __getitem__(self, i):
+        return self._list()[i]
+
+    def __iter__(self):
+        return iter(self._list())
+
+    def __eq__(self, other):
+        return list(self) == list(other)
+
+
 class GroupedYcbRearrangeEnv:
     """rearrange/ycb with DIFFERENT object sets across the batch and a NEW set per episode.  The batch is split into equal groups, every group runs its own
     compiled model (one of the shipped object sets, `xml.YCB_SHIPPED_SETS`) as a `BatchedYcbRearrangeEnv` on a stream of its own, so the groups' launches
@@ -46,8 +70,8 @@ class GroupedYcbRearrangeEnv:
         import torch
 
         K = len(object_sets)
-        if kw.get("device_reset") and resample_object_sets:
-            raise NotImplementedError("device_reset with resample_object_sets: trading slots between the groups reads the ended episodes on the host")
+        # device_reset (the recipe kernel): the slot trading runs on the device too (round 6, _trade_slots_device): no readback of the ended episodes in a step call
+        self._device_trade = bool(kw.get("device_reset")) and bool(resample_object_sets)
         assert batch_size % K == 0, "batch_size must be a multiple of the number of object sets"
         self.B, self.K, self.b = int(batch_size), K, int(batch_size) // K
         self.object_sets = tuple(int(k) for k in object_sets)
@@ -62,10 +86,25 @@ class GroupedYcbRearrangeEnv:
         self.object_names = [g.object_names for g in self.groups]
         self.resample = bool(resample_object_sets)
         self._rng = np.random.RandomState(starting_seed + 77)
-        self._slot = np.arange(self.B)                               # env -> physics slot (group * b + row)
+        self._slot_host = np.arange(self.B)                          # env -> physics slot (group * b + row); with device trading the device table is the authority
         self._slot_dev = torch.arange(self.B, device=self.device)
         self._env_of_slot_dev = torch.arange(self.B, device=self.device)
         self.episodes_moved = 0                                      # episodes that started on another group's object set than the previous one of that env
+        if self._device_trade:
+            self._gen = torch.Generator(device=self.device); self._gen.manual_seed(starting_seed + 77)
+            self._moved_dev = torch.zeros((), dtype=torch.int64, device=self.device)
+            self._arange = torch.arange(self.B, device=self.device)
+
+    @property
+    def _slot(self):
+        """env -> slot as a host array (with device trading: read back from the device table -- tests and reset() only, never inside step())"""
+        if getattr(self, "_device_trade", False):
+            self._slot_host = self._slot_dev.cpu().numpy()
+        return self._slot_host
+
+    @_slot.setter
+    def _slot(self, v):
+        self._slot_host = v
 
     # ------------------------------------------------------------------ env <-> slot
     def _reassign(self, envs):
@@ -75,16 +114,20 @@ class GroupedYcbRearrangeEnv:
 
         if not self.resample or len(envs) < 2:
             return
-        old = self._slot[envs]
+        table = self._slot.copy()
+        old = table[envs]
         new = old[self._rng.permutation(len(envs))]
         self.episodes_moved += int((old // self.b != new // self.b).sum())
-        self._slot[envs] = new
-        self._slot_dev = torch.as_tensor(self._slot, device=self.device)
-        inv = np.empty(self.B, dtype=np.int64); inv[self._slot] = np.arange(self.B)
+        table[envs] = new
+        self._slot_host = table
+        self._slot_dev = torch.as_tensor(table, device=self.device)
+        inv = np.empty(self.B, dtype=np.int64); inv[table] = np.arange(self.B)
         self._env_of_slot_dev = torch.as_tensor(inv, device=self.device)
 
     def object_set_of_env(self):
         """index into `object_sets` of the set every env of the batch currently has on its table"""
+        if self._device_trade:
+            self.episodes_moved = int(self._moved_dev)          # (a readback: this is a host query)
         return self._slot // self.b
 
     def _to_slots(self, x):
@@ -159,10 +202,50 @@ class GroupedYcbRearrangeEnv:
         obs = self._observation()
         reward, done = self._to_envs(torch.cat([o[1] for o in outs])), self._to_envs(torch.cat([o[2] for o in outs]))
         info = {k: self._to_envs(torch.cat([o[3][k] for o in outs])) for k in outs[0][3] if torch.is_tensor(outs[0][3][k])}
-        info["object_names"] = self._names()            # (of the episode this step belonged to: the terminal step still names the set that just ended)
-        self._slot_of_step = self._slot.copy()
-        self._trade_slots()
+        if self._device_trade:
+            # the names and the table of THIS step are resolved on request (a readback); nothing in a step call waits for the GPU
+            snap = self._slot_dev.clone()
+            info["object_names"] = _LazyNames(self.object_names, snap, self.b)
+            self._slot_of_step_dev = snap
+            self._trade_slots_device()
+        else:
+            info["object_names"] = self._names()            # (of the episode this step belonged to: the terminal step still names the set that just ended)
+            self._slot_of_step = self._slot.copy()
+            self._trade_slots()
         return obs, reward, done, info
+
+    def _trade_slots_device(self):
+        """`_trade_slots` without the host (device_reset): the pool -- every slot whose recipe stage is > 0 after this step's recipe launch -- is dealt out again among
+        the envs that hold those slots by a random permutation, if any episode ended on this step; fixed-shape tensor ops, no readback.  Sorting the slots by
+        (in the pool ? 0 : 1, index) and by (in the pool ? random key : 2 + index) lists the pool first in both orders -- in index order and in random order -- and the
+        other slots identically behind it, so "the k-th env of the first order gets the k-th slot of the second" is the identity outside the pool."""
+        import torch
+
+        if not self.groups[0].pipelined:
+            return
+        stage = torch.cat([g.stage.reshape(-1) for g in self.groups]).to(torch.int64)
+        ended = torch.cat([g.ended.reshape(-1) for g in self.groups])
+        pool = stage > 0
+        idx = self._arange.to(torch.float64) / float(self.B)
+        by_index = torch.argsort(torch.where(pool, idx, 2.0 + idx))
+        by_key = torch.argsort(torch.where(pool, torch.rand(self.B, generator=self._gen, device=self.device, dtype=torch.float64), 2.0 + idx))
+        envs = self._env_of_slot_dev[by_index]
+        new_slot = self._slot_dev.clone()
+        new_slot[envs] = by_key
+        new_slot = torch.where(ended.any(), new_slot, self._slot_dev)
+        self._moved_dev += ((new_slot // self.b) != (self._slot_dev // self.b)).sum()
+        inv = torch.empty_like(new_slot); inv[new_slot] = self._arange
+        self._slot_dev, self._env_of_slot_dev = new_slot, inv
+
+    @property
+    def _slot_of_step(self):
+        if getattr(self, "_device_trade", False):
+            return self._slot_of_step_dev.cpu().numpy()
+        return self._slot_of_step_host
+
+    @_slot_of_step.setter
+    def _slot_of_step(self, v):
+        self._slot_of_step_host = v
 
     def _trade_slots(self):
         """After a step with pipelined resets: if episodes ended on it, every slot that is INSIDE the reset recipe now -- the ones that just ended and the ones that

@@ -17,7 +17,7 @@ s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True
 s.record(); sim.env_step(action=a, nforward_ticks=3, flags=2); e.record(); torch.cuda.synchronize()
 dbg = sim.get_field(8)
 off = dbg.shape[1] - 32 * 8
-prof = dbg[:, off:off + 48].double().mean(0).cpu().numpy() / 10.0
+prof = dbg[:, off:off + 56].double().mean(0).cpu().numpy() / 10.0
 names = ["kinematics", "com_pos", "tendon", "crb+M", "factor M", "broadphase", "narrowphase(+broad)", "velocity/RNE", "constraint rows", "pid+smooth", "newton linesearch+update", "euler", "newton grad/cost eval", "newton H assembly", "newton cholesky", "newton tri-solve"]
 tot = sum(prof[i] for i in range(16) if i != 5)
 print("kernel ms %.2f for B=%d ; cycles per substep per wave (mean over envs):" % (s.elapsed_time(e), B))
@@ -32,3 +32,5 @@ if prof[24:36].sum() > 0 and prof[24:36].sum() < 1e7:   # analysis build (-DRG_F
         print("    %-38s %9.0f" % (n, prof[24 + i]))
     print("    refactorisations after the first, per substep: %.3f ; rows that changed zone per refactorisation: mean %.2f ; with <= 2 rows %.3f, <= 4 %.3f, <= 8 %.3f per substep ; iterations that reused the factor %.3f per substep" % (prof[36], prof[37] / max(prof[36], 1e-9), prof[38], prof[39], prof[40], prof[41]))
     print("    broadphase: pairs whose bound ran out per substep %.1f in %.2f batches of 64; cycles in the sphere / box tests %.0f of the broadphase's %.0f" % (prof[42], prof[43], prof[44], prof[5]))
+    print("    Woodbury-corrected solves per substep %.3f, %.0f cycles each; factorisations per substep %.3f; corrections that fell back to a factorisation %.4f" % (
+        prof[45], prof[46] / max(prof[45], 1e-9), prof[48], prof[49]))
