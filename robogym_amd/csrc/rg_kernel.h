@@ -922,6 +922,29 @@ __device__ __forceinline__ float origin_tri_dist2(v3 a, v3 b, v3 c, v3& w) {
   w = a + ab * (vb * den) + ac * (vc * den);
   return dot(w, w);
 }
+// depth, direction and position of a penetration from the final portal (the tail of libccd's __ccdMPRFindPenetr / ccdMPRPenetration)
+__device__ __forceinline__ void mpr_result(bool plane_depth, const SupPt& p0, const SupPt& p1, const SupPt& p2, const SupPt& p3, v3 dir, float& depth, v3& dir_out, v3& pos) {
+  // depth / direction from the portal PLANE (not libccd's closest point on the final portal triangle,
+  // whose choice among the triangles of a flat supporting plane is rounding noise; see DESIGN.md "MPR")
+  if (plane_depth) {
+    depth = fmaxf((dot(p1.v, dir) + dot(p2.v, dir) + dot(p3.v, dir)) * (1.0f / 3.0f), 0.f);
+    dir_out = dir;
+  } else {   // libccd verbatim (what MuJoCo 2.0's mjc_Convex runs): the closest point of the final portal triangle to the origin
+    v3 w; depth = sqrtf(origin_tri_dist2(p1.v, p2.v, p3.v, w));
+    dir_out = mz(depth) ? mk3(0, 0, 0) : w * (1.0f / depth);
+  }
+  // contact position from the barycentric coordinates of the origin in the portal tetrahedron
+  float b0 = dot(cross(p1.v, p2.v), p3.v), b1 = dot(cross(p3.v, p2.v), p0.v);
+  float b2 = dot(cross(p0.v, p1.v), p3.v), b3 = dot(cross(p2.v, p1.v), p0.v);
+  float sum = b0 + b1 + b2 + b3;
+  if (sum <= 0) {
+    v3 dd = portal_dir(p1, p2, p3);
+    b0 = 0; b1 = dot(cross(p2.v, p3.v), dd); b2 = dot(cross(p3.v, p1.v), dd); b3 = dot(cross(p1.v, p2.v), dd);
+    sum = b1 + b2 + b3;
+  }
+  float inv = 0.5f * rg_rcp(sum);
+  pos = p0.s * (b0 * inv) + p1.s * (b1 * inv) + p2.s * (b2 * inv) + p3.s * (b3 * inv);
+}
 // MPR penetration query (libccd ccdMPRPenetration) of one pair per group of G lanes.  Returns true on contact.
 // `sep`: on a "no contact" exit that PROVES separation (support of the Minkowski difference along `sep` is <= 0)
 // the unit direction that proves it, else zero — cached per pair and tried first on the next substep.
@@ -937,7 +960,7 @@ template <int G> __device__ __forceinline__ bool rg_mpr(const MprEnv& E, const M
   SupPt p0, p1, p2, p3;
   p0.v = p0.s = p1.v = p1.s = p2.v = p2.s = p3.v = p3.s = mk3(0, 0, 0);
   int state = active ? MPR_FIRST : MPR_DONE, guard = 0;
-  bool result = false;
+  bool result = false, finish = false;
   v3 dir = mk3(1, 0, 0);
   sep = mk3(0, 0, 0);
   if (active) {
@@ -991,27 +1014,9 @@ template <int G> __device__ __forceinline__ bool rg_mpr(const MprEnv& E, const M
         else if (reach) state = MPR_DONE;
         else expand = true;
       } else if (reach || guard > max_iter) {
-        // depth / direction from the portal PLANE (not libccd's closest point on the final portal triangle,
-        // whose choice among the triangles of a flat supporting plane is rounding noise; see DESIGN.md "MPR")
-        if (E.plane_depth) {
-          depth = fmaxf((dot(p1.v, dir) + dot(p2.v, dir) + dot(p3.v, dir)) * (1.0f / 3.0f), 0.f);
-          dir_out = dir;
-        } else {   // libccd verbatim (what MuJoCo 2.0's mjc_Convex runs): the closest point of the final portal triangle to the origin
-          v3 w; depth = sqrtf(origin_tri_dist2(p1.v, p2.v, p3.v, w));
-          dir_out = mz(depth) ? mk3(0, 0, 0) : w * (1.0f / depth);
-        }
-        // contact position from the barycentric coordinates of the origin in the portal tetrahedron
-        float b0 = dot(cross(p1.v, p2.v), p3.v), b1 = dot(cross(p3.v, p2.v), p0.v);
-        float b2 = dot(cross(p0.v, p1.v), p3.v), b3 = dot(cross(p2.v, p1.v), p0.v);
-        float sum = b0 + b1 + b2 + b3;
-        if (sum <= 0) {
-          v3 dd = portal_dir(p1, p2, p3);
-          b0 = 0; b1 = dot(cross(p2.v, p3.v), dd); b2 = dot(cross(p3.v, p1.v), dd); b3 = dot(cross(p1.v, p2.v), dd);
-          sum = b1 + b2 + b3;
-        }
-        float inv = 0.5f * rg_rcp(sum);
-        pos = p0.s * (b0 * inv) + p1.s * (b1 * inv) + p2.s * (b2 * inv) + p3.s * (b3 * inv);
-        result = true; state = MPR_DONE;
+        // the penetration is found: its depth / direction / position are formed ONCE after the loop from the portal this group keeps (round 6: inside the loop the
+        // block ran once per iteration in which some group finished -- the groups finish at different iterations --, ~250 instructions each time for the whole wave)
+        finish = true; state = MPR_DONE;
       } else expand = true;
       if (expand) {
         expand_portal(p0, p1, p2, p3, q);
@@ -1025,6 +1030,7 @@ template <int G> __device__ __forceinline__ bool rg_mpr(const MprEnv& E, const M
       if (state != MPR_PENETR) { if (dot(dir, p1.v) >= 0) { state = MPR_PENETR; guard = 0; } else state = MPR_REFINE; }
     }
   }
+  if (finish) { mpr_result(E.plane_depth, p0, p1, p2, p3, dir, depth, dir_out, pos); result = true; }
   return result;
 }
 

@@ -202,6 +202,53 @@ def test_rearrange_resync_env_steps_emul(models, emul_lib, oracle_lib):
     _assert_resync(_resync_env_steps(models, emul_lib, "cpu", n_substeps=3, nsteps=4))
 
 
+def test_register_and_matrix_pipe_solves_match_the_lds_cholesky_emul(models, emul_lib, oracle_lib, tmp_path):
+    """Round 6 replaced rb_step_kernel's blocked LDS Cholesky + substitutions (rb_chol / rb_chol_solve, still in the source behind -DRB_LDS_CHOL) by a factor + solve in
+    registers on the one-wave configurations (rb_reg_solve_n) and by a matrix-pipe factorisation with single-wave substitutions on the large one (rb_chol_mfma,
+    rb_chol_solve_wave).  Same linear systems, different floating-point paths: one mj_step of the rearrange main world (38-dof group, ~25 contacts) and of the full cube
+    (96-dof group, ~28 contacts) from the same state on a harness build of either kind."""
+    import os
+    import subprocess
+
+    from robogym_amd import _native
+    from robogym_amd.envs.dactyl.full_perpendicular import load_full_perpendicular_model
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "librgstep_emul_ldschol.so")
+    subprocess.check_call(["g++", "-O2", "-fPIC", "-std=c++17", "-DRG_EMUL", "-DRB_LDS_CHOL", "-I" + os.path.join(root, "tests", "emul"), "-I" + os.path.join(root, "robogym_amd", "csrc"),
+                           "-w", "-shared", "-o", so, os.path.join(root, "tests", "emul", "hip_emul.cpp"), "-x", "c++", os.path.join(root, "robogym_amd", "csrc", "rg_api.hip")])
+    lds_lib = _native.bind(so)
+    # rearrange main world: the oracle provides a contact-rich state
+    env = _oracle_env(models, 1, settle=40)
+    o = env.main.sim
+    out = []
+    for lib in (emul_lib, lds_lib):
+        sim = LargeModelSimulation(models[0], 1, device="cpu", n_substeps=1, lib=lib, hand=False)
+        sync_from_oracle(sim, o)
+        sim.env_step(nsubsteps=1, nforward_ticks=0, flags=1)
+        dbg = sim.scratch("dbg")[0].cpu().numpy()
+        assert int(sim.status[0]) == 0 and int(dbg[0]) >= 20
+        out.append((dbg[8 + 4 * NV:8 + 5 * NV].copy(), sim.qpos[0].cpu().numpy().copy(), sim.qvel[0].cpu().numpy().copy()))
+    assert np.abs(out[0][0] - out[1][0]).max() < 2e-4 * np.abs(out[1][0]).max()          # qacc of the constrained solve
+    assert np.abs(out[0][1] - out[1][1]).max() < 1e-6 and np.abs(out[0][2] - out[1][2]).max() < 2e-5
+    # the full cube on the palm: the 96-dof group through the matrix-pipe factorisation
+    from tests.test_large_model import OracleFullCube, _put
+    full = load_full_perpendicular_model()
+    sims = [LargeModelSimulation(full, 1, lib=lib, n_substeps=1) for lib in (emul_lib, lds_lib)]
+    ora = OracleFullCube(full, sims[0].pos_to_ctrl, sims[0].qpos_idxs["hand_angle"])
+    ora.hold_pose()
+    for _ in range(60):
+        ora.sim.step()
+    st = ora.state_f32()
+    res = []
+    for sim in sims:
+        _put(sim, st)
+        sim.env_step(nsubsteps=1, nforward_ticks=0, flags=0)
+        assert int(sim.status[0]) == 0
+        res.append((sim.qpos[0].cpu().numpy().copy(), sim.qvel[0].cpu().numpy().copy()))
+    assert np.abs(res[0][0] - res[1][0]).max() < 2e-6 and np.abs(res[0][1] - res[1][1]).max() < 5e-4, (np.abs(res[0][0] - res[1][0]).max(), np.abs(res[0][1] - res[1][1]).max())
+
+
 # ------------------------------------------------------------------------------------------------ MI355X
 @pytest.mark.gpu
 def test_rearrange_stage_dump_matches_oracle_gpu(models, oracle_lib):
