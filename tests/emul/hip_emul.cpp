@@ -5,9 +5,12 @@
 #include <stdlib.h>
 #include <dlfcn.h>
 #include <ucontext.h>
+#include <setjmp.h>
 
 emul_dim3 threadIdx, blockIdx, blockDim = {64, 1, 1}, gridDim;
 uint64_t emul_xchg[EMUL_MAXT];
+uint64_t emul_xchg2[2][EMUL_MAXT];
+unsigned emul_wave_calls[EMUL_MAXT];
 
 static const size_t kStack = 512 * 1024;
 static ucontext_t g_sched, g_fiber[EMUL_MAXT];
@@ -21,7 +24,12 @@ static void* g_arg;
 
 void* emul_lds() { return g_lds; }
 
-void emul_yield() { swapcontext(&g_fiber[g_cur], &g_sched); }
+// Fiber switches go through _setjmp / _longjmp (no signal-mask system call; swapcontext makes two per switch, which had become a third of the CPU suite's time once
+// the register Newton step raised the number of wave collectives); ucontext only STARTS a fiber on its own stack.  (Built with -U_FORTIFY_SOURCE: the fortified
+// longjmp refuses jumps between stacks.)
+static jmp_buf g_sched_jb, g_fiber_jb[EMUL_MAXT];
+static bool g_started[EMUL_MAXT];
+void emul_yield() { if (_setjmp(g_fiber_jb[g_cur]) == 0) _longjmp(g_sched_jb, 1); }
 
 // barrier state per group size (quads: 16 groups, 8-lane half rows: 8, 16-lane rows: 4, wave: 1, lane pairs: 32)
 static int g_arrived[6][128], g_gen[6][128];
@@ -48,7 +56,7 @@ void emul_barrier(int gsize) {
 static void fiber_main() {
   g_fn(g_arg);
   g_done[g_cur] = 1;
-  swapcontext(&g_fiber[g_cur], &g_sched);
+  _longjmp(g_sched_jb, 1);
 }
 
 void emul_launch(int nblocks, size_t lds_bytes, emul_kernel_fn fn, void* arg) { emul_launch_n(nblocks, 64, lds_bytes, fn, arg); }
@@ -68,12 +76,12 @@ void emul_launch_n(int nblocks, int nthreads, size_t lds_bytes, emul_kernel_fn f
       g_fiber[l].uc_stack.ss_size = kStack;
       g_fiber[l].uc_link = &g_sched;
       makecontext(&g_fiber[l], fiber_main, 0);
-      g_done[l] = 0;
+      g_done[l] = 0; g_started[l] = false;
     }
     for (int k = 0; k < 6; k++) for (int g = 0; g < 128; g++) g_arrived[k][g] = 0;
-    for (int l = 0; l < nthreads; l++) g_nwave[l] = 0;
-    int alive = nthreads;
-    long idle_sweeps = 0;
+    for (int l = 0; l < nthreads; l++) { g_nwave[l] = 0; emul_wave_calls[l] = 0; }
+    volatile int alive = nthreads;
+    volatile long idle_sweeps = 0;
     while (alive > 0) {
       alive = 0;
       // a sweep over all lanes that releases no barrier makes no progress: lanes wait in DIFFERENT collectives (control flow
@@ -93,10 +101,13 @@ void emul_launch_n(int nblocks, int nthreads, size_t lds_bytes, emul_kernel_fn f
         }
         abort();
       }
-      for (int l = 0; l < nthreads; l++) {
+      for (volatile int l = 0; l < nthreads; l++) {
         if (g_done[l]) continue;
         g_cur = l; threadIdx.x = l; threadIdx.y = threadIdx.z = 0;
-        swapcontext(&g_sched, &g_fiber[l]);
+        if (_setjmp(g_sched_jb) == 0) {
+          if (!g_started[l]) { g_started[l] = true; setcontext(&g_fiber[l]); }
+          else _longjmp(g_fiber_jb[l], 1);
+        }
         if (!g_done[l]) alive++;
         if (g_restart) { g_restart = false; alive = nthreads; l = -1; idle_sweeps = 0; }
       }

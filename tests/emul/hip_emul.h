@@ -26,12 +26,24 @@ void* emul_lds();
 void emul_barrier(int gsize);
 #define EMUL_MAXT 256
 extern uint64_t emul_xchg[EMUL_MAXT];
+// wave-wide exchanges alternate between two buffers (emul_xchg2[parity of the lane's wave-collective count]): a lane can be at most one wave collective ahead of the
+// slowest lane of its wave (it cannot pass the next one's barrier alone), so the buffer of exchange k is free again when exchange k + 2 writes it -- ONE barrier per
+// shuffle / ballot instead of two (round 6: the register Newton step is ~900 broadcasts per factorisation)
+extern uint64_t emul_xchg2[2][EMUL_MAXT];
+extern unsigned emul_wave_calls[EMUL_MAXT];
 
 static inline void __syncthreads() { emul_barrier((int)blockDim.x); }   // (a 64-thread workgroup is one wave; larger ones use the workgroup-wide barrier)
 
 template <class T> static inline T emul_exchange(T v, int src, int gsize) {
   static_assert(sizeof(T) <= 8, "shuffle payload");
   uint64_t raw = 0; memcpy(&raw, &v, sizeof(T));
+  if (gsize == 64) {
+    uint64_t* buf = emul_xchg2[emul_wave_calls[threadIdx.x]++ & 1];
+    buf[threadIdx.x] = raw;
+    emul_barrier(64);
+    T r; memcpy(&r, &buf[(threadIdx.x & ~63u) | (src & 63)], sizeof(T));
+    return r;
+  }
   emul_xchg[threadIdx.x] = raw;
   emul_barrier(gsize);
   T r; memcpy(&r, &emul_xchg[(threadIdx.x & ~63u) | (src & 63)], sizeof(T));   // (src: lane of the calling lane's wave)
@@ -42,11 +54,11 @@ template <class T> static inline T emul_exchange(T v, int src, int gsize) {
 template <class T> static inline T __shfl_xor(T v, int mask) { return emul_exchange(v, (int)(threadIdx.x & 63) ^ mask, mask < 2 ? 2 : (mask < 4 ? 4 : (mask < 8 ? 8 : (mask < 16 ? 16 : 64)))); }
 template <class T> static inline T __shfl(T v, int src) { return emul_exchange(v, src, 64); }
 static inline unsigned long long __ballot(int pred) {
-  emul_xchg[threadIdx.x] = pred ? 1 : 0;
+  uint64_t* buf = emul_xchg2[emul_wave_calls[threadIdx.x]++ & 1];
+  buf[threadIdx.x] = pred ? 1 : 0;
   emul_barrier(64);
   unsigned long long r = 0;
-  for (int i = 0; i < 64; i++) if (emul_xchg[(threadIdx.x & ~63u) + i]) r |= 1ull << i;
-  emul_barrier(64);
+  for (int i = 0; i < 64; i++) if (buf[(threadIdx.x & ~63u) + i]) r |= 1ull << i;
   return r;
 }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }

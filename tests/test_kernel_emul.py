@@ -150,7 +150,7 @@ def test_woodbury_correction_matches_refactorisation_emul(locked_model, tmp_path
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     so = str(tmp_path / "librgstep_emul_wchk.so")
-    subprocess.check_call(["g++", "-O2", "-fPIC", "-std=c++17", "-DRG_EMUL", "-DRG_WOODBURY_CHECK", "-I" + os.path.join(root, "tests", "emul"), "-I" + os.path.join(root, "robogym_amd", "csrc"),
+    subprocess.check_call(["g++", "-O2", "-fPIC", "-std=c++17", "-U_FORTIFY_SOURCE", "-DRG_EMUL", "-DRG_WOODBURY_CHECK", "-I" + os.path.join(root, "tests", "emul"), "-I" + os.path.join(root, "robogym_amd", "csrc"),
                            "-w", "-shared", "-o", so, os.path.join(root, "tests", "emul", "hip_emul.cpp"), "-x", "c++", os.path.join(root, "robogym_amd", "csrc", "rg_api.hip")])
     lib = _native.bind(so)
     sim = LockedSimulation(locked_model, 1, lib=lib, n_substeps=3)

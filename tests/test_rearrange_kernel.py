@@ -215,7 +215,7 @@ def test_register_and_matrix_pipe_solves_match_the_lds_cholesky_emul(models, emu
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     so = str(tmp_path / "librgstep_emul_ldschol.so")
-    subprocess.check_call(["g++", "-O2", "-fPIC", "-std=c++17", "-DRG_EMUL", "-DRB_LDS_CHOL", "-I" + os.path.join(root, "tests", "emul"), "-I" + os.path.join(root, "robogym_amd", "csrc"),
+    subprocess.check_call(["g++", "-O2", "-fPIC", "-std=c++17", "-U_FORTIFY_SOURCE", "-DRG_EMUL", "-DRB_LDS_CHOL", "-I" + os.path.join(root, "tests", "emul"), "-I" + os.path.join(root, "robogym_amd", "csrc"),
                            "-w", "-shared", "-o", so, os.path.join(root, "tests", "emul", "hip_emul.cpp"), "-x", "c++", os.path.join(root, "robogym_amd", "csrc", "rg_api.hip")])
     lds_lib = _native.bind(so)
     # rearrange main world: the oracle provides a contact-rich state
