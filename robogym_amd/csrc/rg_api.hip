@@ -1089,9 +1089,10 @@ rb_model* rb_model_create(const void* blob, size_t nbytes, char* err, int errlen
   // depend on the number of contacts / rows of the mj_step can be placed (their capacity is the model's own size).
   {
     static const char* names[RB_NOFF] = {"xpos", "xquat", "xipos", "xiquat", "xanchor", "xaxis", "gpos", "gquat", "spos", "rootcom", "cinert", "crb", "cdof", "cdofdot", "cvel", "cacc", "cfrc",
-                                         "tenlen", "tenj", "tenvel", "msp", "cand", "con", "conj", "conidx", "row", "dofcon_adr", "dofcon", "conf", "dbg", "cfrcext", "conloc"};
+                                         "tenlen", "tenj", "tenvel", "msp", "cand", "con", "conj", "conidx", "row", "dofcon_adr", "dofcon", "conf", "dbg", "cfrcext", "conloc", "prm"};
+    const int cwl = m->config ? RB_CONW_ONEWAVE : RB_CONW;
     const int len[RB_NOFF] = {3 * d.nbody, 4 * d.nbody, 3 * d.nbody, 4 * d.nbody, 3 * d.njnt, 3 * d.njnt, 3 * d.ngeom, 4 * d.ngeom, 3 * d.nsite, 3 * d.nbody, 10 * d.nbody, 10 * d.nbody, 6 * d.nv, 6 * d.nv,
-                              6 * d.nbody, 6 * d.nbody, 6 * d.nbody, d.ntendon, RB_TENW * d.ntendon, d.ntendon, d.nM, 0, 0, 0, 0, 0, d.nv + 1, 0, 0, 0, 6 * d.nbody, 0};
+                              6 * d.nbody, 6 * d.nbody, 6 * d.nbody, d.ntendon, RB_TENW * d.ntendon, d.ntendon, d.nM, d.maxcand, RB_CONREC * d.maxcon, 6 * cwl * d.maxcon, cwl * d.maxcon, RB_ROWREC * d.maxrow, d.nv + 1, cwl * d.maxcon, RB_NW * d.maxcon, 0, 6 * d.nbody, cwl * d.maxcon, 0};
     for (int k = 0; k < RB_NOFF; k++) { d.lds_off[k] = -1; d.lds_len[k] = 0; }
     d.lds_words = 0;
     const char* place = getenv("RB_LDS_PLACE");

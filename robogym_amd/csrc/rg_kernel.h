@@ -2251,6 +2251,9 @@ template <int N> __device__ __forceinline__ void rg_cholinv_apply_n(RgM m, RgLds
 __device__ __forceinline__ int lane_bcast_i(int v, int src) { return __builtin_bit_cast(int, lane_bcast(__builtin_bit_cast(float, v), src)); }
 template <int N> __device__ __forceinline__ bool rg_cholinv_woodbury_n(RgM m, RgLds& s, const RowRegs& R, float* x) {
   constexpr int NC = (N + 3) / 4, K = RG_WOODBURY;
+#ifdef RG_FINE_PROF
+  const long long tw_entry = rg_clock();
+#endif
   const int hs = m.hs, hs4 = hs >> 2, i = LANE, ic = i < N ? i : 0, ns = nsrow(m), ncon = s.ncon;
   const float g = i < N ? x[i] : 0.f;
   const float* col = s.H + ic;     // column `ic` of W: W[mm][ic] = col[mm * hs]
@@ -2302,6 +2305,13 @@ template <int N> __device__ __forceinline__ bool rg_cholinv_woodbury_n(RgM m, Rg
       na++;
     }
   }
+#ifdef RG_FINE_PROF
+  long long tw0 = tw_entry, tw1;
+#define WPROF(k) do { tw1 = rg_clock(); if (LANE == 0) s.prof[k] += (float)(tw1 - tw0); tw0 = tw1; } while (0)
+  WPROF(50);   // (50: since function entry -- the rows' P columns; the caller's stamp covers the whole call)
+#else
+#define WPROF(k) do { } while (0)
+#endif
   // y = W' g
   float y0 = 0.f, y1 = 0.f;
 #pragma unroll
@@ -2310,6 +2320,7 @@ template <int N> __device__ __forceinline__ bool rg_cholinv_woodbury_n(RgM m, Rg
     if (mm + 1 < N) y1 = __builtin_fmaf(col[(mm + 1) * hs], lane_bcast(g, mm + 1), y1);
   }
   float y = i < N ? y0 + y1 : 0.f;
+  WPROF(51);
   // S = inv(C) + P' P (symmetric, unused slots: identity), r = P' y
   float S[K][K], rr[K];
 #pragma unroll
@@ -2339,6 +2350,7 @@ template <int N> __device__ __forceinline__ bool rg_cholinv_woodbury_n(RgM m, Rg
 #pragma unroll
     for (int b = a + 1; b < K; b++) v -= S[a][b] * t[b];
     t[a] = v * rg_rcp(S[a][a]); }
+  WPROF(52);
   if (!ok) return false;
 #pragma unroll
   for (int a = 0; a < K; a++) y -= p[a] * t[a];
@@ -2355,8 +2367,10 @@ template <int N> __device__ __forceinline__ bool rg_cholinv_woodbury_n(RgM m, Rg
   }
   if (i < N) x[i] = xa + xb;
   SYNC();
+  WPROF(53);
   return true;
 }
+#undef WPROF
 __device__ __forceinline__ bool rg_cholinv_woodbury(RgM m, RgLds& s, const RowRegs& R, float* x) { return m.nvc == 30 ? rg_cholinv_woodbury_n<30>(m, s, R, x) : rg_cholinv_woodbury_n<24>(m, s, R, x); }
 #ifdef RG_CHOL_MFMA
 __device__ __forceinline__ void rg_chol_inv_solve(RgM m, RgLds& s, float* x) { if (m.nvc == 30) rg_chol_mfma_n<30>(m, s, x); else rg_chol_mfma_n<24>(m, s, x); }

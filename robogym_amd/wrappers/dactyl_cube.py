@@ -315,8 +315,21 @@ class BatchedDactylCubeWrappers:
     def _randomization_obs(self, o):
         o["action_history"] = self._action_history[:, :-1].reshape(self.B, -1).clone()      # RandomizedActionLatency: history[:-1]
         o["action_delay"] = self._action_delay.to(torch.float32)
+        # the RandomizedBodyWrapper family's entries: fresh copies of the [B, n] state rows -- ONE concatenation per dtype, handed out as column slices,
+        # instead of a clone kernel per key (11 keys)
+        by_dtype = OrderedDict()
         for key, val in self._obs_delta.items():
-            o[key] = val.clone()
+            by_dtype.setdefault(val.dtype, []).append(key)
+        fresh = {}
+        for keys in by_dtype.values():
+            flat = torch.cat([self._obs_delta[k] for k in keys], dim=1)
+            at = 0
+            for k in keys:
+                n = self._obs_delta[k].shape[1]
+                fresh[k] = flat[:, at:at + n]
+                at += n
+        for key in self._obs_delta:      # (the reference's key order)
+            o[key] = fresh[key]
 
     def _backlash(self, action):
         """BacklashWrapper.step (randomizations.py:876-903): the action is turned into the control it would produce, the part of
@@ -387,10 +400,10 @@ class BatchedDactylCubeWrappers:
             occluded = (live[..., None] & ((g1[..., None].to(torch.long) == occ) | (g2[..., None].to(torch.long) == occ))).any(dim=1)      # [B, 5]
             vis = (~occluded).repeat_interleave(3, dim=1)
             self._occl_buf = torch.where(vis, o[key], self._occl_buf.to(o[key].dtype))
-            o[key] = self._occl_buf.clone()
+            o[key] = self._occl_buf      # (no copy: the buffers are replaced, never written in place, and ClipObservationWrapper below hands out fresh tensors)
         upd = (self._ff_left <= 0).repeat_interleave(3, dim=1)
         self._ff_buf = torch.where(upd, o[key], self._ff_buf.to(o[key].dtype))
-        o[key] = self._ff_buf.clone()
+        o[key] = self._ff_buf
         self._ff_left = (self._ff_left - 1).clamp(min=0)
         does = D.random_sample((5,)) < self._ff_p
         new_len = torch.round(D.exponential(self._freeze_scale, (5,)))
@@ -403,7 +416,7 @@ class BatchedDactylCubeWrappers:
         new_len = torch.round(D.exponential(self._freeze_scale))
         self._cf_left = torch.where(does, new_len.to(self._cf_left.dtype), self._cf_left)
         for k in cube_keys:
-            o[k] = self._cf_buf[k].clone()
+            o[k] = self._cf_buf[k]
         if at_reset is not None:        # auto-reset: the envs whose episode starts on this step see their first observation unfrozen
             restart(at_reset)
             for k in fresh:
@@ -425,10 +438,10 @@ class BatchedDactylCubeWrappers:
         out = {}
         for key in sorted(self.levels):
             lv, n = self.levels[key], self._key_len[key]
-            add = self._additive_bias[key] + self.draws.randn((n,)) * lv.get("uncorrelated", 0.0)
-            v = obs[key].clone()
+            add = torch.add(self._additive_bias[key], self.draws.randn((n,)), alpha=lv.get("uncorrelated", 0.0))      # bias + uncorrelated * draw in one kernel
+            v = obs[key]
             if not key.endswith("_quat"):
-                v = v * self._multiplicative_bias[key].to(v.dtype) + add.to(v.dtype)
+                v = torch.addcmul(add.to(v.dtype), v, self._multiplicative_bias[key].to(v.dtype))                    # obs * multiplicative + additive in one kernel
             else:
                 axis = self.draws.uniform(-1.0, 1.0, (3,)).to(v.dtype)
                 axis = axis / axis.norm(dim=-1, keepdim=True)                           # quat_from_angle_and_axis normalises the axis
@@ -470,9 +483,19 @@ class BatchedDactylCubeWrappers:
                 parts = [o[pre + goal_key + "_" + p] for p in ("pos", "quat", "face_angle") if pre + goal_key + "_" + p in o]
                 if parts:
                     o[pre + goal_key] = torch.cat(parts, dim=-1)
-        for key in o:                                                                    # ClipObservationWrapper
-            if o[key].dtype.is_floating_point:
-                o[key] = o[key].clamp(-self.clip, self.clip)
+        # ClipObservationWrapper: the dense float entries of one dtype in two multi-tensor launches (a list of mixed dtypes or strided views makes the
+        # multi-tensor ops fall back to one kernel per tensor and call), the others by a clamp each -- instead of a clamp kernel per key (~45 keys)
+        groups = OrderedDict()
+        for key in o:
+            v = o[key]
+            if v.dtype.is_floating_point:
+                if v.is_contiguous():
+                    groups.setdefault(v.dtype, []).append(key)
+                else:
+                    o[key] = v.clamp(-self.clip, self.clip)
+        for keys in groups.values():
+            for key, val in zip(keys, torch._foreach_clamp_max(torch._foreach_clamp_min([o[key] for key in keys], -self.clip), self.clip)):
+                o[key] = val
         o["previous_action"] = self._previous_action.clone()                             # PreviousActionObservationWrapper
         o["reward"] = reward                                                             # RewardObservationWrapper(reward_inds=[1, 2])
         return o

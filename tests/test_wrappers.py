@@ -528,3 +528,40 @@ def test_default_make_env_recomputes_invweight0_at_reset_gpu(locked_model):
     assert len(idx) >= 2
     _check_rows_went_through_setconst(env, locked_model, idx)
     assert int(env.unwrapped.sim_status().max()) == 0
+
+
+# ------------------------------------------------------------------------------------------------ the quaternion helpers the stack leans on
+def _quat_helpers_match_the_component_formulas(device):
+    """`rotation.quat_mul` forms the Hamilton product from one outer product, one gather and three sums (six tensor kernels instead of 29: the wrapper stack is
+    launch latency).  The products and the order of the sums are those of the reference's component formula (utils/rotation.py:234-257 `quat_mul`), so it is
+    BIT-identical to it -- also with the conjugate folded into its sign table (`quat_difference`, rotation.py:271) and for signed zeros in `quat_normalize`
+    (rotation.py:281-286)."""
+    from robogym_amd.utils import rotation
+
+    def formula(q0, q1):
+        w0, x0, y0, z0 = q0.unbind(-1); w1, x1, y1, z1 = q1.unbind(-1)
+        return torch.stack([w0 * w1 - x0 * x1 - y0 * y1 - z0 * z1, w0 * x1 + x0 * w1 + y0 * z1 - z0 * y1,
+                            w0 * y1 + y0 * w1 + z0 * x1 - x0 * z1, w0 * z1 + z0 * w1 + x0 * y1 - y0 * x1], dim=-1)
+
+    def normalize(q):
+        return q * torch.where(q[..., :1] < 0, -torch.ones_like(q[..., :1]), torch.ones_like(q[..., :1]))
+
+    gen = torch.Generator(device=device); gen.manual_seed(3)
+    for dtype, bits in ((torch.float32, torch.int32), (torch.float64, torch.int64)):
+        a = torch.randn((4096, 4), generator=gen, device=device, dtype=dtype)
+        b = torch.randn((4096, 4), generator=gen, device=device, dtype=dtype)
+        a[:8, 0] = 0.0; a[4:8, 0] = -0.0
+        same = lambda x, y: torch.equal(x.contiguous().view(bits), y.contiguous().view(bits))
+        assert same(rotation.quat_mul(a, b), formula(a, b))
+        assert same(rotation.quat_mul(a[:3, None], b[None, :5]), formula(*torch.broadcast_tensors(a[:3, None], b[None, :5])))
+        assert same(rotation.quat_difference(a, b), normalize(formula(a, rotation.quat_conjugate(b))))
+        assert same(rotation.quat_normalize(a), normalize(a))
+
+
+def test_quat_helpers_match_the_component_formulas():
+    _quat_helpers_match_the_component_formulas("cpu")
+
+
+@pytest.mark.gpu
+def test_quat_helpers_match_the_component_formulas_gpu():
+    _quat_helpers_match_the_component_formulas("cuda:0")

@@ -34,3 +34,4 @@ if prof[24:36].sum() > 0 and prof[24:36].sum() < 1e7:   # analysis build (-DRG_F
     print("    broadphase: pairs whose bound ran out per substep %.1f in %.2f batches of 64; cycles in the sphere / box tests %.0f of the broadphase's %.0f" % (prof[42], prof[43], prof[44], prof[5]))
     print("    Woodbury-corrected solves per substep %.3f, %.0f cycles each; factorisations per substep %.3f; corrections that fell back to a factorisation %.4f" % (
         prof[45], prof[46] / max(prof[45], 1e-9), prof[48], prof[49]))
+    print("    inside a corrected solve (cycles per substep): the changed rows' columns P = W'U %.0f, y = W'g %.0f, k x k system (wave sums + elimination) %.0f, x = W y %.0f" % (prof[50], prof[51], prof[52], prof[53]))
