@@ -57,18 +57,42 @@ CUBE_FREEZE_KEYS = ["noisy_relative_goal_pos", "noisy_relative_goal_quat", "nois
 class TorchDraws:
     """The env's `_random_state` for a batch: every method returns one independent draw per env, `[B, *shape]`."""
 
+    # A step of the wrapper stack takes ~8 uniform and ~6 normal draws of a few numbers per env each: `begin_step` draws one [B, 32] uniform and one [B, 128]
+    # normal block, and the step's draws are column slices of them (independent numbers either way; two generator kernels per step instead of ~14).  Draws
+    # that do not fit what is left of a block, and everything outside a step (the reset path), are drawn on their own.
+    U_POOL, N_POOL = 32, 128
+
     def __init__(self, generator: torch.Generator, batch_size: int, device):
         self.gen, self.B, self.device = generator, batch_size, device
         self._choice_tables = {}
+        self._pool = {}
+
+    def begin_step(self):
+        self._pool = {"u": [torch.rand((self.B, self.U_POOL), generator=self.gen, device=self.device), 0],
+                      "n": [torch.randn((self.B, self.N_POOL), generator=self.gen, device=self.device), 0]}
+
+    def end_step(self):
+        self._pool = {}
+
+    def _take(self, kind, shape):
+        p = self._pool.get(kind)
+        n = int(np.prod(shape)) if len(shape) else 1
+        if p is None or p[1] + n > p[0].shape[1]:
+            return None
+        v = p[0][:, p[1]:p[1] + n].reshape((self.B,) + tuple(shape))
+        p[1] += n
+        return v
 
     def _u(self, shape):
-        return torch.rand((self.B,) + tuple(shape), generator=self.gen, device=self.device)
+        v = self._take("u", tuple(shape))
+        return v if v is not None else torch.rand((self.B,) + tuple(shape), generator=self.gen, device=self.device)
 
     def uniform(self, low, high, shape=()):
         return low + (high - low) * self._u(shape)
 
     def randn(self, shape):
-        return torch.randn((self.B,) + tuple(shape), generator=self.gen, device=self.device)
+        v = self._take("n", tuple(shape))
+        return v if v is not None else torch.randn((self.B,) + tuple(shape), generator=self.gen, device=self.device)
 
     def randn_where(self, cond, shape):      # the reference draws only when `cond`; per-env streams are independent, so drawing for all is equivalent
         return self.randn(shape)
@@ -77,7 +101,7 @@ class TorchDraws:
         return self._u(shape)
 
     def exponential(self, scale, shape=()):
-        return -scale * torch.log1p(-self._u(shape))
+        return torch.log1p(-self._u(shape)) * (-scale)
 
     def randint(self, low, high, shape):
         return torch.randint(low, high, (self.B,) + tuple(shape), generator=self.gen, device=self.device)
@@ -340,15 +364,18 @@ class BatchedDactylCubeWrappers:
         qpos_as_ctrl = sim.qpos[:, self._hand_q].to(action.dtype) @ self._pos_to_ctrl.to(action.dtype).T      # _qpos2ctrl: joint (+ coupled J0)
         relative = bool(self.env.constants.relative_action)
         centre = qpos_as_ctrl if relative else 0.5 * (hi + lo)
-        ctrl = torch.minimum(torch.maximum(centre + action.clamp(-1.0, 1.0) * 0.5 * (hi - lo), lo), hi)        # RobotEnv._set_action
+        # (written for few tensor kernels -- every one of them is launch latency on [B, 20]: fused multiply-add, clamp with tensor bounds, lerp; 26 -> 17)
+        half = 0.5 * (hi - lo)
+        ctrl = torch.clamp(torch.addcmul(centre, action.clamp(-1.0, 1.0), half), lo, hi)                       # RobotEnv._set_action
         dt = P["timestep"][:, :1] * sim.n_substeps
         diff = ctrl - qpos_as_ctrl
         eps = 1e-5
-        incr = (diff < -eps) * diff * self._coef_down * dt + (diff > eps) * diff * self._coef_up * dt
+        # incr = [diff < -eps] diff coef_down dt + [diff > eps] diff coef_up dt: the side's coefficient, zero inside the dead band
+        incr = (diff * torch.where(diff < 0, self._coef_down, self._coef_up) * dt) * (diff.abs() > eps)
         alpha = ((torch.sign(diff) - self._slack).abs() / (incr.abs() + 1e-12)).clamp(0.0, 1.0)
-        ctrl = alpha * qpos_as_ctrl + (1.0 - alpha) * ctrl
+        ctrl = torch.lerp(ctrl, qpos_as_ctrl.to(ctrl.dtype), alpha.to(ctrl.dtype))                            # alpha qpos_as_ctrl + (1 - alpha) ctrl
         self._slack = (self._slack + incr).clamp(-1.0, 1.0).to(self._slack.dtype)
-        return (ctrl - centre) / (0.5 * (hi - lo))                                                             # _ctrl2action
+        return (ctrl - centre) / half                                                                          # _ctrl2action
 
     def _after_env_step(self, live=None, started=None):
         """What the randomization wrappers do after the env below them has stepped, innermost first: RandomizedTimestepWrapper.step
@@ -464,12 +491,15 @@ class BatchedDactylCubeWrappers:
             if self.full_cube:                # FaceFreeGoal.relative_goal (goals/face_free.py:147-173), evaluated by the env on its goal rows
                 rel = {"pos": lambda cur: zero3, "quat": lambda cur: self.env.relative_goal("cube_quat", cur), "face_angle": lambda cur: self.env.relative_goal("cube_face_angle", cur)}
             else:
-                gq = self.env._goal_quat
-                rel = {"pos": lambda cur: zero3, "quat": lambda cur: rotation.quat_difference(gq.to(cur.dtype), cur)}
+                # LockedParallelGoal.relative_goal of the true and of the noisy reading in ONE batched quaternion difference ([2, B, 4]: half the kernels)
+                cq, nq = o["cube_quat"], o["noisy_cube_quat"].to(o["cube_quat"].dtype)
+                both = rotation.quat_difference(self.env._goal_quat.to(cq.dtype)[None], torch.stack([cq, nq]))
+                relq = {id(o["cube_quat"]): both[0], id(o["noisy_cube_quat"]): both[1]}
+                rel = {"pos": lambda cur: zero3, "quat": lambda cur: relq[id(cur)]}
             for name in (("pos", "quat", "face_angle") if self.full_cube else ("pos", "quat")):      # the reference's key order: per goal part, achieved / relative / noisy achieved / noisy relative
-                o["achieved_goal_" + name] = o["cube_" + name].clone()
+                o["achieved_goal_" + name] = o["cube_" + name]                # (no copies: nothing below writes an entry in place, and ClipObservationWrapper hands out fresh tensors)
                 o["relative_goal_" + name] = rel[name](o["cube_" + name])
-                o["noisy_achieved_goal_" + name] = o["noisy_cube_" + name].clone()
+                o["noisy_achieved_goal_" + name] = o["noisy_cube_" + name]
                 o["noisy_relative_goal_" + name] = rel[name](o["noisy_cube_" + name])
         if self.randomize:
             self._post_noise_obs(o, at_reset, mixed)
@@ -485,17 +515,23 @@ class BatchedDactylCubeWrappers:
                     o[pre + goal_key] = torch.cat(parts, dim=-1)
         # ClipObservationWrapper: the dense float entries of one dtype in two multi-tensor launches (a list of mixed dtypes or strided views makes the
         # multi-tensor ops fall back to one kernel per tensor and call), the others by a clamp each -- instead of a clamp kernel per key (~45 keys)
-        groups = OrderedDict()
+        # (the strided ones -- column slices of the env's observation row and of the randomization entries' buffer, 16 keys -- are gathered into one buffer per
+        #  dtype, clamped there and handed out as its column slices: two kernels per dtype)
+        groups, strided = OrderedDict(), OrderedDict()
         for key in o:
             v = o[key]
             if v.dtype.is_floating_point:
-                if v.is_contiguous():
-                    groups.setdefault(v.dtype, []).append(key)
-                else:
-                    o[key] = v.clamp(-self.clip, self.clip)
+                (groups if v.is_contiguous() else strided).setdefault(v.dtype, []).append(key)
         for keys in groups.values():
             for key, val in zip(keys, torch._foreach_clamp_max(torch._foreach_clamp_min([o[key] for key in keys], -self.clip), self.clip)):
                 o[key] = val
+        for keys in strided.values():
+            flat = torch.cat([o[key].reshape(self.B, -1) for key in keys], dim=1).clamp(-self.clip, self.clip)
+            at = 0
+            for key in keys:
+                n = o[key].numel() // self.B
+                o[key] = flat[:, at:at + n].reshape(o[key].shape)
+                at += n
         o["previous_action"] = self._previous_action.clone()                             # PreviousActionObservationWrapper
         o["reward"] = reward                                                             # RewardObservationWrapper(reward_inds=[1, 2])
         return o
@@ -534,6 +570,8 @@ class BatchedDactylCubeWrappers:
     def step(self, action: torch.Tensor):
         """action: int64 [B, nu] bin indices in [0, n_action_bins).  Returns (obs dict, reward [B, 4] = env, goal, success, drop,
         done [B], info)."""
+        if hasattr(self.draws, "begin_step"):
+            self.draws.begin_step()
         a = self._bins[torch.as_tensor(action, device=self.device).long()]              # DiscretizeActionWrapper.action
         self._previous_action = a.clone()                                                # PreviousActionObservationWrapper.step
         if self.randomize:                                                               # ActionNoiseWrapper.action (randomizations.py:772-778)
@@ -609,4 +647,6 @@ class BatchedDactylCubeWrappers:
                 sim.copy_rows(_native.RG_F_CTRL, (0.5 * (cr[..., 0] + cr[..., 1])).contiguous(), restarted)
                 for key, val in self._pending_delta:      # (their observation entries switch when the new episode starts)
                     self._next_delta[key] = val if key not in self._next_delta else torch.where(_bmask(restarted, val), val, self._next_delta[key].to(val.dtype))
+        if hasattr(self.draws, "end_step"):
+            self.draws.end_step()
         return out, reward, done, info
