@@ -68,7 +68,9 @@ class TorchDraws:
         self._pool = {}
 
     def begin_step(self):
-        self._pool = {"u": [torch.rand((self.B, self.U_POOL), generator=self.gen, device=self.device), 0],
+        u = torch.rand((self.B, self.U_POOL), generator=self.gen, device=self.device)
+        # ("e": -log(1 - u) of the same block, for `exponential` -- a draw takes ITS columns of one of the two, so no number is used twice)
+        self._pool = {"u": [u, 0], "e": [torch.log1p(-u).neg_(), 0],
                       "n": [torch.randn((self.B, self.N_POOL), generator=self.gen, device=self.device), 0]}
 
     def end_step(self):
@@ -81,6 +83,8 @@ class TorchDraws:
             return None
         v = p[0][:, p[1]:p[1] + n].reshape((self.B,) + tuple(shape))
         p[1] += n
+        if kind in ("u", "e"):      # the uniform block and its exponential image share their column cursor
+            self._pool["u"][1] = self._pool["e"][1] = p[1]
         return v
 
     def _u(self, shape):
@@ -101,7 +105,8 @@ class TorchDraws:
         return self._u(shape)
 
     def exponential(self, scale, shape=()):
-        return torch.log1p(-self._u(shape)) * (-scale)
+        e = self._take("e", tuple(shape))
+        return e * scale if e is not None else torch.log1p(-self._u(shape)) * (-scale)
 
     def randint(self, low, high, shape):
         return torch.randint(low, high, (self.B,) + tuple(shape), generator=self.gen, device=self.device)
