@@ -92,6 +92,8 @@ class TorchDraws:
         return v if v is not None else torch.rand((self.B,) + tuple(shape), generator=self.gen, device=self.device)
 
     def uniform(self, low, high, shape=()):
+        if isinstance(low, float) and isinstance(high, float) and low == 0.0 and high == 1.0:
+            return self._u(shape)
         return low + (high - low) * self._u(shape)
 
     def randn(self, shape):
@@ -387,7 +389,7 @@ class BatchedDactylCubeWrappers:
         (randomizations.py:267-304), then RandomizedWindWrapper.step (cube.py:75-85)."""
         D, P, ts = self.draws, self._P, self._ts
         u = D.uniform(0.0, 1.0)
-        flip = torch.where(ts["side"] > 0, u > ts["p_flip_pos"], u > ts["p_flip_neg"])
+        flip = u > torch.where(ts["side"] > 0, ts["p_flip_pos"], ts["p_flip_neg"])
         ts["side"] = torch.where(flip, -ts["side"], ts["side"])
         lam = torch.where(ts["side"] > 0, ts["pos_lambda"], ts["neg_lambda"])
         noise = D.exponential(1.0 / lam)
@@ -399,7 +401,7 @@ class BatchedDactylCubeWrappers:
         P["timestep"][:, 0] = new_ts if live is None else torch.where(live, new_ts, P["timestep"][:, 0])
         x = P["xfrc_applied"][:, self._cube_body, :3]
         hit = D.random_sample() < self._wind_hit_prob
-        force = D.randn_where(hit, (3,)) * P["body_mass"][:, self._cube_body, None] * 1.0
+        force = D.randn_where(hit, (3,)) * P["body_mass"][:, self._cube_body, None]      # (cube.py:81: ... * 1.0)
         new_x = torch.where(hit[:, None], force.to(x.dtype), x * 0.99)
         if live is not None:
             new_x = torch.where(live[:, None], new_x, x)

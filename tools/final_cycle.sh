@@ -28,6 +28,7 @@ python tools/stage_profile.py 8192 > gpurun_out/stage_$R.txt 2>&1
 # (round 6) the parity block of the bench line, measured on this build; the Newton sub-stage profile of the analysis build (-DRG_FINE_PROF, ab_libs/librgstep_fine.so); the FETCH / WRITE calibration
 [ -f ab_libs/librgstep_fine.so ] && RGSTEP_LIB=$GRAFT_REPO_ROOT/ab_libs/librgstep_fine.so python tools/stage_profile.py 8192 > gpurun_out/stage_fine_$R.txt 2>&1
 bash tools/gpu_call_fetch_calib.sh > /dev/null 2>&1
+timeout 500 python tools/wrapped_breakdown.py 8192 20 2>&1 | grep -v amdgpu.ids > gpurun_out/wrapped_breakdown_$R.txt      # the default make_env(): physics launches vs the wrapper stack's tensor kernels
 RG_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29712 bench.py --workload ycb --quick-reset --gpus 1 --steps 4 --warmup 1 --no-cpu-baseline > gpurun_out/bench_ycb_rccl1_$R.json 2> gpurun_out/bench_ycb_rccl1_$R.err
 python tools/rearrange_stage_profile.py 4096 > gpurun_out/rearrange_stage_$R.txt 2>&1
 python tools/rearrange_stage_profile.py 4096 ycb > gpurun_out/ycb_stage_$R.txt 2>&1
