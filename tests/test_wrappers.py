@@ -565,3 +565,58 @@ def test_quat_helpers_match_the_component_formulas():
 @pytest.mark.gpu
 def test_quat_helpers_match_the_component_formulas_gpu():
     _quat_helpers_match_the_component_formulas("cuda:0")
+
+
+# ------------------------------------------------------------------------------------------------ the stack's launch count and its draw blocks
+_VIEW_OPS = {"view", "select", "slice", "unsqueeze", "squeeze", "expand", "reshape", "_unsafe_view", "as_strided", "t", "transpose", "permute", "unbind", "alias",
+             "detach", "_reshape_alias", "split", "split_with_sizes", "unfold"}
+
+
+def test_default_wrapper_step_stays_under_its_kernel_budget_emul(locked_model, emul_lib):
+    """On the GPU every tensor op of the wrapper stack is a ~4 us kernel queued behind the physics launch (profiles/r06_wrapped_breakdown.txt): round 6 brought the
+    default make_env() step from ~370 to ~200 of them.  The count is a property of the Python code, so it is held here (aten ops that are not views, counted by a
+    dispatch mode around one step on the CPU): a change that brings per-key loops back shows up as a failure, not as a slower bench line a round later."""
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from robogym_amd.envs.dactyl.locked import make_env
+
+    counts = {}
+
+    class Count(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            name = func.__name__.split(".")[0]
+            if name not in _VIEW_OPS:
+                counts[name] = counts.get(name, 0) + 1
+            return func(*args, **(kwargs or {}))
+
+    quick = dict(mujoco_substeps=1, reset_initial_steps=1, n_random_initial_steps=1, max_pose_resets=1)      # (the physics is not what is counted)
+    for kw, budget in ((dict(constants=dict(quick)), 215), (dict(constants=dict(quick, randomize=False)), 110)):
+        env = make_env(batch_size=2, device="cpu", model=locked_model, starting_seed=1, lib=emul_lib, **kw)
+        env.reset()
+        gen = torch.Generator(); gen.manual_seed(0)
+        env.step(torch.randint(0, 11, (2, 20), generator=gen))
+        counts.clear()
+        with Count():
+            env.step(torch.randint(0, 11, (2, 20), generator=gen))
+        total = sum(counts.values())
+        print("tensor kernels per wrapped step (randomize %s): %d" % (kw["constants"].get("randomize", True), total), sorted(counts.items(), key=lambda kv: -kv[1])[:8])
+        assert total <= budget, (total, counts)
+
+
+def test_torch_draws_blocks():
+    """TorchDraws inside a step: the small draws are disjoint column slices of one uniform and one normal block (exponentials: of the uniform block's image, on the
+    same cursor, so no number is used twice); what does not fit, and everything outside a step, is drawn on its own."""
+    from robogym_amd.wrappers.dactyl_cube import TorchDraws
+
+    gen = torch.Generator(); gen.manual_seed(4)
+    D = TorchDraws(gen, 6, "cpu")
+    outside = D.uniform(0.0, 1.0, (3,))
+    assert outside.shape == (6, 3) and outside.is_contiguous()
+    D.begin_step()
+    ublock, nblock = D._pool["u"][0], D._pool["n"][0]
+    a = D.random_sample((5,)); e = D.exponential(2.0, (4,)); b = D.uniform(-1.0, 1.0, (3,)); n1 = D.randn((20,)); n2 = D.randn((3,)); c = D.uniform(0.0, 1.0)
+    assert torch.equal(a, ublock[:, 0:5]) and torch.equal(e, -torch.log1p(-ublock[:, 5:9]) * 2.0) and torch.equal(b, -1.0 + 2.0 * ublock[:, 9:12]) and torch.equal(c, ublock[:, 12])
+    assert torch.equal(n1, nblock[:, :20]) and torch.equal(n2, nblock[:, 20:23]) and (e > 0).all() and c.shape == (6,)
+    big = D.randn((TorchDraws.N_POOL,))            # does not fit what is left of the block: drawn on its own, the cursor stays
+    assert big.shape == (6, TorchDraws.N_POOL) and D._pool["n"][1] == 23
+    D.end_step()
+    assert D.randn((2,)).shape == (6, 2) and not D._pool
