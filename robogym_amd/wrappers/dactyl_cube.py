@@ -141,6 +141,7 @@ class BatchedDactylCubeWrappers:
         self._backlash_logs = None
         self._next_delta: Dict[str, torch.Tensor] = {}
         self._in_recipe = torch.zeros(env.batch_size, dtype=torch.bool, device=env.device)
+        self._occ_cache = None
         if self.auto_reset and not getattr(env, "pipelined_reset", False):
             raise ValueError("auto_reset needs an env built with pipelined_reset=True")
         if self.auto_reset and int(min_episode_length) > 0:
@@ -428,10 +429,16 @@ class BatchedDactylCubeWrappers:
             return
         if self._idx["occlusion"] is not None:      # check_occlusion (utils/sensor_utils.py:25-44): a penetrating contact on the finger's occlusion geom
             data = self.env.mujoco_simulation.data
-            g1, g2, dist = data.contact
-            live = (torch.arange(g1.shape[1], device=self.device)[None] < data.ncon[:, None].to(torch.long)) & (dist < OCCLUSION_DIST_CUTOFF)
-            occ = self._idx["occlusion"][None, None, :]
-            occluded = (live[..., None] & ((g1[..., None].to(torch.long) == occ) | (g2[..., None].to(torch.long) == occ))).any(dim=1)      # [B, 5]
+            c = getattr(data, "_contact", None)
+            if c is not None:              # the stepper's raw record, geom ids as the floats the kernel wrote (`data.contact` / `data.ncon` convert [B, K] columns per call)
+                g1, g2, dist, ncon = c[:, :, 0], c[:, :, 1], c[:, :, 2], data._ncon
+            else:
+                (g1, g2, dist), ncon = data.contact, data.ncon
+            if self._occ_cache is None or self._occ_cache[0].shape[1] != g1.shape[1] or self._occ_cache[1].dtype != g1.dtype:      # (slot numbers and the geom ids in the contact columns' own dtype, once)
+                self._occ_cache = (torch.arange(g1.shape[1], device=self.device)[None], self._idx["occlusion"].to(g1.dtype)[None, None, :])
+            slots, occ = self._occ_cache
+            live = (slots < ncon[:, None]) & (dist < OCCLUSION_DIST_CUTOFF)
+            occluded = (live[..., None] & ((g1[..., None] == occ) | (g2[..., None] == occ))).any(dim=1)      # [B, 5]
             vis = (~occluded).repeat_interleave(3, dim=1)
             self._occl_buf = torch.where(vis, o[key], self._occl_buf.to(o[key].dtype))
             o[key] = self._occl_buf      # (no copy: the buffers are replaced, never written in place, and ClipObservationWrapper below hands out fresh tensors)
