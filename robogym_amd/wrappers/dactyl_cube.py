@@ -589,13 +589,13 @@ class BatchedDactylCubeWrappers:
         a = self._bins[torch.as_tensor(action, device=self.device).long()]              # DiscretizeActionWrapper.action
         self._previous_action = a.clone()                                                # PreviousActionObservationWrapper.step
         if self.randomize:                                                               # ActionNoiseWrapper.action (randomizations.py:772-778)
-            a = a * self._an_mult + self._an_add + self.draws.randn((self.nu,)) * 0.1
+            a = torch.add(torch.addcmul(self._an_add.to(a.dtype), a, self._an_mult.to(a.dtype)), self.draws.randn((self.nu,)).to(a.dtype), alpha=0.1)      # a * mult + add + 0.1 * draw
         # SmoothActionWrapper.step: IncrementalExpAvg with alpha adjusted to the step length (util.py:142-219)
         if self.smooth_alpha > 0 and self.randomize:   # reset() recomputes alpha from the CURRENT (randomized) opt.timestep (util.py:204-210)
             alpha = self._ema_alpha[:, None]
         else:
             alpha = torch.full((self.B, 1), float(np.power(self.smooth_alpha, self._step_s0 / 0.08)) if self.smooth_alpha > 0 else 0.0, dtype=a.dtype, device=self.device)
-        self._ema_value = self._ema_value * alpha + (1 - alpha) * a
+        self._ema_value = torch.lerp(a, self._ema_value.to(a.dtype), alpha.to(a.dtype).expand_as(a))      # ema * alpha + (1 - alpha) * a
         self._ema_t += 1
         a = self._ema_value / (1 - torch.pow(alpha.expand_as(self._ema_value), self._ema_t[:, None].to(a.dtype)))
         a_ema = a
