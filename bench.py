@@ -442,9 +442,42 @@ def bench_locked_variant(args, emit=True, pipelined_reset=False, default_make_en
     return out
 
 
+def compact_secondary(e):
+    """A secondary entry without its prose: the numbers, the workload's short name, what bounds it.  (The full entries made the one JSON line 19 kB; the text is in
+    DESIGN.md section 6 and, with --verbose-secondary, in profiles/rNN_bench.json.)"""
+    if "error" in e:
+        return e
+    r = lambda v, n: round(v, n) if isinstance(v, float) else v
+    out = {"metric": e["metric"].split(";")[0].split(" (BASELINE")[0][:120], "value": r(e["value"], 1), "unit": e.get("unit"), "steps": e.get("steps"), "warmup": e.get("warmup"),
+           "ms_per_step": r(e.get("ms_per_step"), 3), "dtype": e.get("dtype")}
+    c = e.get("config")
+    if isinstance(c, dict):
+        cc = {"workload": str(c.get("workload", "")).split(" (")[0][:60]}
+        for k in ("batch_per_gpu", "status_bits"):
+            if k in c:
+                cc[k] = c[k]
+        if isinstance(c.get("launch_ms"), dict):
+            cc["launch_ms"] = {k: r(v, 2) for k, v in c["launch_ms"].items()}
+        for k in ("mean_ncon", "mean_nefc", "mean_newton_iters"):
+            src = c.get("main", c)
+            if isinstance(src, dict) and k in src:
+                cc[k] = r(src[k], 2)
+        out["config"] = cc
+    elif c is not None:
+        out["config"] = {"workload": str(c)[:60]}
+    rf = e.get("roofline")
+    if isinstance(rf, dict):
+        out["roofline"] = {k: (r(rf[k], 4) if k in ("frac", "frac_sparse_J") else r(rf[k], 2)) for k in ("bound", "achieved", "peak", "unit", "frac", "frac_sparse_J", "traffic", "kernel_ms") if k in rf}
+    cb = e.get("cpu_baseline")
+    if isinstance(cb, dict):
+        out["cpu_baseline"] = {k: r(cb[k], 1) for k in ("value", "unit", "cores", "kind") if k in cb}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="locked", choices=["locked", "full_perpendicular", "rearrange_blocks", "ycb"], help="locked = BASELINE.json configs[1] (the headline); full_perpendicular = configs[2]; rearrange_blocks = configs[3]")
+    ap.add_argument("--verbose-secondary", action="store_true", help="keep every field of the secondary entries (the default line carries their numbers only: it stays under ~10 kB; tools/final_cycle.sh passes this for profiles/)")
     ap.add_argument("--no-secondary", action="store_true", help="headline only: skip the shortened runs of the other built configs that the default line carries under 'secondary'")
     ap.add_argument("--control-mode", default="tcp+roll+yaw", choices=["tcp+roll+yaw", "joint"], help="rearrange workloads: robot_control_params.control_mode")
     ap.add_argument("--quick-reset", action="store_true", help="rearrange_blocks: a shortened reset recipe (20 / 2 / 20 steps instead of 100 / 10 / 100)")
@@ -648,7 +681,11 @@ def main():
                     sec.append(fn(a2, **kw) if fn is bench_rearrange_steady else fn(a2, emit=False, **kw))
                 except Exception as ex:   # a secondary run must not cost the headline
                     sec.append({"metric": getattr(fn, "__name__", "?"), "error": repr(ex)})
-            out["secondary"] = sec
+            names = ("locked_pipelined_resets", "locked_default_make_env", "full_perpendicular", "rearrange_blocks", "rearrange_blocks_episode_ends", "ycb", "ycb_episode_ends", "rearrange_blocks_joint")
+            out["secondary"] = sec if args.verbose_secondary else [compact_secondary(e) for e in sec]
+            # every number of the line once more, at its very END: a reader who keeps only the tail of the run's stdout (the driver's log did) still sees all of them
+            out["summary"] = dict([("headline_env_steps_per_s", round(out["value"])), ("roofline_frac", round(out["roofline"]["frac"], 4))] +
+                                  [(n, round(e["value"]) if "value" in e else None) for n, e in zip(names, sec)])
         print(json.dumps(out, default=float))
     if distributed:
         dist.destroy_process_group()

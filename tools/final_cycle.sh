@@ -21,7 +21,7 @@ done
 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > gpurun_out/bench_$R.json 2> /dev/null      # (a short line for the summariser to read the batch size from)
 python tools/summarize_profile.py $R > /dev/null 2>&1
 python tests/tools/parity_json.py $R > gpurun_out/parity_json_$R.log 2>&1; cp profiles/parity.json gpurun_out/parity.json
-( time python bench.py --steps 20 --warmup 5 ) > gpurun_out/bench_$R.json 2> gpurun_out/bench_$R.err
+( time python bench.py --steps 20 --warmup 5 --verbose-secondary ) > gpurun_out/bench_$R.json 2> gpurun_out/bench_$R.err      # (profiles/ keeps the secondary entries' text; the default line carries their numbers only)
 tail -3 gpurun_out/bench_$R.err; tail -1 gpurun_out/bench_$R.json | cut -c1-200
 python tests/tools/rearrange_parity_report.py 150 60 > gpurun_out/parity_rearrange_$R.txt 2>&1
 python tools/stage_profile.py 8192 > gpurun_out/stage_$R.txt 2>&1
