@@ -26,6 +26,7 @@ from tests.helpers import NON_TARGET_QPOS, resync_errors, sync_state_from_oracle
 
 model = load_locked_model()
 N_STREAMS, N_FREE, N_RESYNC = 4, 120, 200
+N_LONG, CHECKPOINTS = 1000, (1, 10, 100, 1000)      # free-running qpos L-inf at steps 1, 10, 100, 1000 (the first stream runs on to step 1000)
 
 
 def first_beyond(step_pair, n):
@@ -37,7 +38,7 @@ def first_beyond(step_pair, n):
 
 def main():
     out = {"round": sys.argv[1] if len(sys.argv) > 1 else "r06", "kernel_source_hash": bench.kernel_source_hash("rg"), "device": torch.cuda.get_device_name(0),
-           "protocol": "tests/tools/parity_json.py: %d re-synchronised env.steps; first free-running env.step with qpos L-inf > 1e-4 on %d streams (up to %d steps)" % (N_RESYNC, N_STREAMS, N_FREE)}
+           "protocol": "tests/tools/parity_json.py: %d re-synchronised env.steps; first free-running env.step with qpos L-inf > 1e-4 on %d streams (up to %d steps); free-running L-inf at steps 1 / 10 / 100 / 1000 of the first stream, kernel and float oracle against the fp64 oracle" % (N_RESYNC, N_STREAMS, N_FREE)}
     for variant, tag in ((True, "plane"), (False, "default")):
         rg_oracle.set_kernel_variant(variant)
         simulation_interface.MPR_PLANE_DEPTH = variant
@@ -49,14 +50,16 @@ def main():
         kern, flt = [], []
         for sidx in range(N_STREAMS):
             rng = np.random.RandomState(20200901 + 1 + sidx)
-            acts = rng.uniform(-1, 1, (N_FREE, 20))
+            nsteps = N_LONG if sidx == 0 else N_FREE
+            acts = rng.uniform(-1, 1, (nsteps, 20))      # (row-major draws: the first N_FREE rows are those of a (N_FREE, 20) draw)
+            at_k, at_f = {}, {}
             ora = OracleLockedEnvPhysics(model); ora.sim.reset(); ora.settle(30)
             sim = LockedSimulation(model, 1, device="cuda:0")
             sync_state_from_oracle(sim, ora)
             o32 = OracleLockedEnvPhysics(model); o32.sim = rg_oracle.OracleSim(pack_model(model), f32=True)
             st = ora.get_state_f32(); o32.set_state_f32(st); o32.prev_dist = ora.prev_dist
             fk = ff = None
-            for t in range(1, N_FREE + 1):
+            for t in range(1, nsteps + 1):
                 a = acts[t - 1]
                 sim.env_step(action=torch.tensor(a[None].astype(np.float32), device="cuda:0"), nforward_ticks=3)
                 ora.env_step(a); o32.env_step(a)
@@ -66,9 +69,13 @@ def main():
                     fk = t
                 if ff is None and ef > 1e-4:
                     ff = t
-                if fk is not None and ff is not None:
+                if sidx == 0 and t in CHECKPOINTS:
+                    at_k[str(t)], at_f[str(t)] = float(ek), float(ef)
+                if sidx != 0 and fk is not None and ff is not None:
                     break
             kern.append(fk); flt.append(ff)
+            if sidx == 0:
+                out["free_running_qpos_Linf_at_steps_kernel_" + tag], out["free_running_qpos_Linf_at_steps_float_oracle_" + tag] = at_k, at_f
         out["free_running_first_step_beyond_1e-4_kernel_" + tag] = kern
         out["free_running_first_step_beyond_1e-4_float_oracle_" + tag] = flt
     rg_oracle.set_kernel_variant(False); simulation_interface.MPR_PLANE_DEPTH = False
