@@ -2904,9 +2904,18 @@ RG_STAGE void st_make_constraint(RgCtx c) { RgM m = RG_M(c); rg_make_constraint(
 RG_STAGE void st_pid(RgCtx c, float* pid) { RgM m = RG_M(c); rg_pid(m, RG_S(), rg_prm(m, RG_L(c)), pid); }
 RG_STAGE void st_smooth(RgCtx c) { RgM m = RG_M(c); rg_smooth(m, RG_S(), rg_prm(m, RG_L(c))); }
 RG_STAGE void st_factor_smooth(RgCtx c) { RgLds& s = RG_S(); rg_ltdl_factor_solve(RG_M(c), s, (const float*)0, 0.f, s.qacc_smooth); }
-RG_STAGE_BIG int st_solve(RgCtx c, float warm) { RgM m = RG_M(c); int nefc = 0; int it = rg_solve<false>(m, RG_S(), rg_prm(m, RG_L(c)), nefc, RG_L(c).flags, warm); return it | (nefc << 8); }
+// The Newton stage runs at raised wave priority (s_setprio): it is the kernel's longest dependent instruction chain (the register elimination alone takes 5.3 k cycles
+// for a wave by itself and 15 k between two others), while the waves it shares its SIMD with are mostly in stages with independent work in flight -- the arbiter
+// then serves the chain first.  Measured +0.4 ... +0.6 % on the bench line (profiles/r06_ab_newton.txt); level 3, or raising the collision stage / the tree sweeps as
+// well, measured no better.  -DRG_NO_PRIO builds without it.
+#if !defined(RG_EMUL) && !defined(RG_NO_PRIO)
+#define RG_SOLVE_PRIO(level) __builtin_amdgcn_s_setprio(level)
+#else
+#define RG_SOLVE_PRIO(level) do { } while (0)
+#endif
+RG_STAGE_BIG int st_solve(RgCtx c, float warm) { RgM m = RG_M(c); int nefc = 0; RG_SOLVE_PRIO(2); int it = rg_solve<false>(m, RG_S(), rg_prm(m, RG_L(c)), nefc, RG_L(c).flags, warm); RG_SOLVE_PRIO(0); return it | (nefc << 8); }
 #if RG_SENSORS
-RG_STAGE_BIG int st_solve_sensors(RgCtx c, float warm) { RgM m = RG_M(c); int nefc = 0; int it = rg_solve<true>(m, RG_S(), rg_prm(m, RG_L(c)), nefc, RG_L(c).flags, warm); return it | (nefc << 8); }
+RG_STAGE_BIG int st_solve_sensors(RgCtx c, float warm) { RgM m = RG_M(c); int nefc = 0; RG_SOLVE_PRIO(2); int it = rg_solve<true>(m, RG_S(), rg_prm(m, RG_L(c)), nefc, RG_L(c).flags, warm); RG_SOLVE_PRIO(0); return it | (nefc << 8); }
 #endif
 #if RG_SENSORS
 RG_STAGE void st_touch_geom(RgCtx c) { RgM m = RG_M(c); rg_touch_geom(m, RG_S(), rg_prm(m, RG_L(c))); }
